@@ -1,0 +1,245 @@
+/*
+ * rdf_mi355x.h — C ABI of librdf_mi355x.so, the MI355X (gfx950) engine for rust-dataframe's
+ * Arrow compute hot path.
+ *
+ * The reference (nevi-me/rust-dataframe, Rust) has no FFI of its own; the seams this ABI replaces are
+ * the Rust signatures named next to each entry point (paths relative to the reference root).  A Rust
+ * shim binds these with `extern "C"` and passes raw Arrow buffer pointers
+ * (`array.data().buffers()[0].raw_data()`, `null_buffer()`, `offset()`, `len()`, `null_count()`);
+ * see INTEGRATION.md.
+ *
+ * Conventions (mirroring the reference):
+ *   - inputs are borrowed and never written; outputs are caller-allocated and owned by the caller;
+ *   - a column is a list of `nchunks` arrays (ChunkedArray, src/table.rs:13-18); chunk i of every
+ *     column of a frame is RecordBatch i (src/dataframe.rs:128-163);
+ *   - errors are values (rdf_status mirrors DataFrameError, src/error.rs:6-15); nothing aborts;
+ *   - every entry point is re-entrant; state (stream, arena, last error) is per calling thread;
+ *   - `mem` says where the buffers live: RDF_MEM_HOST (Arrow buffers in host RAM: staged to HBM,
+ *     computed there, results copied back) or RDF_MEM_DEVICE (already resident in HBM: kernels run
+ *     in place, nothing crosses PCIe).  All arrays of one call must share one `mem`.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute entry point returns
+ *     RDF_DEVICE_ERROR.
+ *
+ * Buffer rules (Arrow columnar format): values little-endian natives, element `offset` is the first
+ * logical element; validity is LSB-first, 1 = valid, NULL = all valid, and shares `offset`.
+ * RDF_BOOL arrays are bit-packed in `values` like a validity bitmap.  Bitmap buffers must be
+ * readable up to the next 8-byte boundary (Arrow allocates in 64-byte multiples).  Output buffers
+ * with mem == RDF_MEM_DEVICE must have room for `capacity` elements rounded up to a multiple of 64
+ * (values and bitmap alike).
+ */
+#ifndef RDF_MI355X_H
+#define RDF_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* DataFrameError (src/error.rs:6-15) / ArrowError as raised on the path. */
+typedef enum {
+    RDF_OK = 0,
+    RDF_COMPUTE_ERROR = 1,    /* ArrowError::ComputeError / DataFrameError::ComputeError */
+    RDF_DIVIDE_BY_ZERO = 2,   /* ArrowError::DivideByZero / DataFrameError::DivideByZero */
+    RDF_INVALID_ARGUMENT = 3, /* ArrowError::InvalidArgumentError, the reference's panic!("Unsupported operation") arms */
+    RDF_MEMORY_ERROR = 4,     /* DataFrameError::MemoryError */
+    RDF_DEVICE_ERROR = 5      /* no counterpart: HIP runtime failure / no gfx950 device */
+} rdf_status;
+
+/* arrow::datatypes::DataType subset that reaches the path (src/evaluation.rs:107-293). */
+typedef enum {
+    RDF_I8 = 0, RDF_I16 = 1, RDF_I32 = 2, RDF_I64 = 3,
+    RDF_U8 = 4, RDF_U16 = 5, RDF_U32 = 6, RDF_U64 = 7,
+    RDF_F32 = 8, RDF_F64 = 9, RDF_BOOL = 10,
+    RDF_NULLTYPE = 11 /* only as the dtype of a Scalar::Null literal (src/expression.rs:719) */
+} rdf_dtype;
+
+typedef enum { RDF_MEM_HOST = 0, RDF_MEM_DEVICE = 1 } rdf_mem;
+
+/* One Arrow array (chunk), borrowed and read-only: PrimitiveArray<T> / BooleanArray. */
+typedef struct {
+    const void*    values;
+    const uint8_t* validity;   /* NULL = no nulls */
+    int64_t        offset;     /* in elements (and bits) */
+    int64_t        length;
+    int64_t        null_count; /* -1 = unknown */
+    int32_t        dtype;      /* rdf_dtype */
+    int32_t        mem;        /* rdf_mem */
+} rdf_array;
+
+/* One output chunk.  Caller allocates `values` (capacity elements) and, when nulls can result,
+ * `validity`; callee fills them and sets length / null_count.  Output offset is always 0. */
+typedef struct {
+    void*    values;
+    uint8_t* validity;   /* may be NULL when no input carries a validity bitmap */
+    int64_t  capacity;   /* in elements */
+    int64_t  length;     /* set by callee */
+    int64_t  null_count; /* set by callee */
+    int32_t  dtype;
+    int32_t  mem;
+} rdf_out;
+
+typedef enum {
+    /* arrow::compute::{add,subtract,multiply,divide} via ScalarFunctions (src/functions/scalar.rs:16-103) */
+    RDF_OP_ADD = 1, RDF_OP_SUB = 2, RDF_OP_MUL = 3, RDF_OP_DIV = 4,
+    /* math_op users (src/functions/scalar.rs:148,274,291): atan2(a,b), hypot(a,b), log of a in base b */
+    RDF_OP_ATAN2 = 5, RDF_OP_HYPOT = 6, RDF_OP_LOG = 7,
+    /* scalar_op users (src/functions/scalar.rs:106-452) */
+    RDF_OP_ABS = 8, RDF_OP_ACOS = 9, RDF_OP_ASIN = 10, RDF_OP_ATAN = 11, RDF_OP_CBRT = 12,
+    RDF_OP_CEIL = 13, RDF_OP_COS = 14, RDF_OP_COSH = 15, RDF_OP_DEGREES = 16, RDF_OP_EXP = 17,
+    RDF_OP_EXPM1 = 18, RDF_OP_FLOOR = 19, RDF_OP_LOG10 = 20, RDF_OP_LOG2 = 21, RDF_OP_RADIANS = 22,
+    RDF_OP_ROUND = 23, RDF_OP_SIN = 24, RDF_OP_SINH = 25, RDF_OP_SQRT = 26, RDF_OP_TAN = 27,
+    RDF_OP_TANH = 28,
+    /* arrow::compute::cast (src/evaluation.rs:296-315) */
+    RDF_OP_CAST = 29,
+    /* BooleanFilter (src/expression.rs:752-763): comparisons are evaluated in f64 (:844-845) */
+    RDF_OP_GT = 30, RDF_OP_GE = 31, RDF_OP_EQ = 32, RDF_OP_NE = 33, RDF_OP_LT = 34, RDF_OP_LE = 35,
+    RDF_OP_NOT = 36, RDF_OP_AND = 37, RDF_OP_OR = 38
+} rdf_op;
+
+/* ------------------------------------------------------------------ library / device plumbing */
+
+const char* rdf_version(void);
+/* Thread-local message of the last failing call -> DataFrameError::ComputeError(String). */
+const char* rdf_last_error(void);
+rdf_status  rdf_device_count(int32_t* count);
+rdf_status  rdf_set_device(int32_t device);
+/* Use the caller's hipStream_t for this thread (NULL = the library's own stream). */
+rdf_status  rdf_set_stream(void* hip_stream);
+rdf_status  rdf_synchronize(void);
+rdf_status  rdf_dev_alloc(void** ptr, int64_t bytes);
+rdf_status  rdf_dev_free(void* ptr);
+rdf_status  rdf_copy_h2d(void* dst_dev, const void* src_host, int64_t bytes);
+rdf_status  rdf_copy_d2h(void* dst_host, const void* src_dev, int64_t bytes);
+
+/* ------------------------------------------------------------------ scalar kernels */
+
+/* ScalarFunctions::{add,subtract,multiply,divide,par_multiply} (src/functions/scalar.rs:16-103) and
+ * ::{atan2,hypot,log} (:148,:274,:291).  a[i] op b[i] per chunk pair; validity = AND; chunk length
+ * mismatch -> RDF_COMPUTE_ERROR; DIV with a zero divisor at a valid slot -> RDF_DIVIDE_BY_ZERO;
+ * integers wrap.  a, b, out: nchunks entries each, one dtype. */
+rdf_status rdf_binary(int32_t op, const rdf_array* a, const rdf_array* b, int64_t nchunks, rdf_out* out);
+
+/* ScalarFunctions::{abs,acos,...,tanh} through scalar_op (src/functions/scalar.rs:525-540):
+ * out[i] = f(a[i]) where valid, null elsewhere. */
+rdf_status rdf_unary(int32_t op, const rdf_array* a, int64_t nchunks, rdf_out* out);
+
+/* Function::Cast arm (src/evaluation.rs:296-315): arrow::compute::cast per chunk to out[i].dtype
+ * (numeric `as` conversions; numeric<->bool), validity carried. */
+rdf_status rdf_cast(const rdf_array* a, int64_t nchunks, rdf_out* out);
+
+/* ------------------------------------------------------------------ aggregate kernels */
+
+/* AggregateFunctions::sum (src/functions/aggregate.rs:82-93): nulls skipped, empty/all-null -> 0,
+ * always Some.  out_scalar has the array's native type (integers wrap). */
+rdf_status rdf_sum(const rdf_array* a, int64_t nchunks, void* out_scalar, int32_t* out_is_some);
+/* AggregateFunctions::min / max (:12-31) with the evident intent (min is min; floats accepted;
+ * None when every slot is null or there are no chunks).  See DESIGN.md "divergences". */
+rdf_status rdf_min(const rdf_array* a, int64_t nchunks, void* out_scalar, int32_t* out_is_some);
+rdf_status rdf_max(const rdf_array* a, int64_t nchunks, void* out_scalar, int32_t* out_is_some);
+/* AggregateFunctions::count (:70-80): sum(len - null_count) as i64; counts validity bits when
+ * null_count is unknown (-1). */
+rdf_status rdf_count(const rdf_array* a, int64_t nchunks, int64_t* out_count, int32_t* out_is_some);
+/* AggregateFunctions::avg (:32-65): mean of the valid values as f64, None when there are none. */
+rdf_status rdf_avg(const rdf_array* a, int64_t nchunks, double* out_mean, int32_t* out_is_some);
+
+/* ------------------------------------------------------------------ expressions */
+
+typedef enum { RDF_NODE_COLUMN = 0, RDF_NODE_SCALAR = 1, RDF_NODE_OP = 2 } rdf_node_kind;
+
+/* One node of an expression tree stored as an array, children before parents.  It restates
+ * BooleanFilter / BooleanInput / Scalar (src/expression.rs:718-763) and, for value expressions,
+ * a run of Calculation steps (src/expression.rs:410-500) folded into one tree. */
+typedef struct {
+    int32_t kind;    /* rdf_node_kind */
+    int32_t op;      /* rdf_op when kind == RDF_NODE_OP */
+    int32_t dtype;   /* SCALAR: literal type (RDF_NULLTYPE for Scalar::Null); OP CAST: target type */
+    int32_t lhs;     /* child node index or -1 */
+    int32_t rhs;     /* child node index or -1 */
+    int32_t column;  /* COLUMN: index into the cols argument */
+    double  f64;     /* SCALAR of RDF_F32 / RDF_F64 */
+    int64_t i64;     /* SCALAR of integer / RDF_BOOL type */
+} rdf_expr_node;
+
+/* BooleanFilter::eval_to_array for every RecordBatch (src/expression.rs:766-861 as driven by
+ * DataFrame::evaluate_boolean_filter, src/dataframe.rs:612-624).  cols is laid out
+ * cols[c * nchunks + i] = chunk i of column c.  mask: nchunks RDF_BOOL outputs (values + validity
+ * bitmaps); the value bit of a null slot is 0.  The root must be boolean-typed. */
+rdf_status rdf_predicate(const rdf_expr_node* nodes, int32_t nnodes, int32_t root,
+                         const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_out* mask);
+
+/* ------------------------------------------------------------------ filter / take */
+
+/* Rows Column::filter would keep per chunk (two-phase filter: size the outputs with this). */
+rdf_status rdf_filter_count(const rdf_array* mask, int64_t nchunks, int64_t* counts);
+/* Column::filter -> ChunkedArray::filter -> arrow::compute::filter per chunk pair
+ * (src/table.rs:97-107,213-215): keeps rows whose mask bit is set (and valid), order and chunk
+ * boundaries preserved, validity carried.  mask[i].length must equal col[i].length. */
+rdf_status rdf_filter(const rdf_array* col, const rdf_array* mask, int64_t nchunks, rdf_out* out);
+/* DataFrame::filter's per-column loop (src/dataframe.rs:183-187) as ONE pass: ranks are computed
+ * once per tile and every column is compacted with them.  cols/outs laid out [c * nchunks + i]. */
+rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_array* mask,
+                              int64_t nchunks, rdf_out* outs);
+/* Column::take (src/table.rs:218-241): gather over the virtual concatenation of the chunks
+ * (Column::to_array, :180-182, without the concat copy).  indices: ONE RDF_U32 (drop-in) or RDF_U64
+ * array; null index -> null; out of range -> RDF_COMPUTE_ERROR.  out: ONE chunk (B4 in SURVEY.md). */
+rdf_status rdf_take(const rdf_array* chunks, int64_t nchunks, const rdf_array* indices, rdf_out* out);
+
+/* ------------------------------------------------------------------ fused batch loop */
+
+typedef enum {
+    RDF_SINK_STORE = 0, /* materialise every value expression as a new column (Evaluate::calculate) */
+    RDF_SINK_AGG = 1    /* fold every value expression into {sum,min,max,count} (AggregateFunctions) */
+} rdf_sink;
+
+#define RDF_MAX_VALUES 4
+
+/* A maximal run of Calculate / Filter / aggregate steps of Evaluate::evaluate
+ * (src/evaluation.rs:66-96) fused into one pass per batch. */
+typedef struct {
+    const rdf_expr_node* nodes;
+    int32_t nnodes;
+    int32_t filter_root;                 /* BooleanFilter root or -1: rows where it is false/null are dropped */
+    int32_t nvalues;                     /* 1..RDF_MAX_VALUES */
+    int32_t value_roots[RDF_MAX_VALUES];
+    int32_t sink;                        /* rdf_sink */
+} rdf_program;
+
+/* AggregateFunctions results for one value expression.  sum/min/max are returned in the value's
+ * class: f64 for F32/F64 values, i64 bit pattern (wrapped to the value's width) otherwise. */
+typedef struct {
+    double  sum_f64, min_f64, max_f64;
+    int64_t sum_i64, min_i64, max_i64;
+    int64_t count;    /* valid rows that passed the filter */
+    int32_t is_some;  /* count > 0 */
+    int32_t dtype;    /* value dtype */
+} rdf_agg_result;
+
+/* cols[c * nchunks + i].  SINK_STORE: outs[v * nchunks + i] receives value v of batch i
+ * (filter_root must be -1: filter then store is rdf_predicate + rdf_filter_columns).
+ * SINK_AGG: aggs[v] receives the aggregates, outs may be NULL. */
+rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks,
+                        rdf_out* outs, rdf_agg_result* aggs);
+
+/* ------------------------------------------------------------------ synthetic data (bench/tests) */
+
+/* x[row] = lo + (hi-lo) * u(seed, column_id, first_row + row), u in [0,1) from a counter-based
+ * SplitMix64 hash; identical on every rank/device and in the CPU oracle.  Device memory only. */
+rdf_status rdf_fill_uniform_f64(double* dev_ptr, int64_t n, uint64_t seed, uint64_t column_id,
+                                int64_t first_row, double lo, double hi);
+/* x[row] = lo + (hash mod span), span = hi - lo (> 0). */
+rdf_status rdf_fill_uniform_i64(int64_t* dev_ptr, int64_t n, uint64_t seed, uint64_t column_id,
+                                int64_t first_row, int64_t lo, int64_t hi);
+/* validity bit = (hash(seed, column_id, row) mod 2^32) >= null_fraction * 2^32; nbits bits written. */
+rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uint64_t column_id,
+                             int64_t first_row, double null_fraction);
+
+/* Average duration (ms) and launch count of the dominant kernel launched by this thread since the
+ * last reset, from hipEvents recorded on the stream the kernels run on (bench.py's roofline leg). */
+rdf_status rdf_kernel_timing_reset(int32_t enable);
+rdf_status rdf_kernel_timing_get(double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDF_MI355X_H */

@@ -1,0 +1,949 @@
+/*
+ * rdf_oracle.c — CPU oracle (see rdf_oracle.h).  TEST INFRASTRUCTURE ONLY, never shipped.
+ *
+ * Build: make -C oracle   (gcc -O3 -march=native -ffp-contract=off -shared -fPIC)
+ *
+ * The reference delegates its inner loops to the `arrow` crate (apache/arrow, branch
+ * rust-parquet-arrow-writer, un-pinned: Cargo.toml:9; API era ~ arrow-rs 2.0.0, Aug-Oct 2020).
+ * That crate is not under /root/reference, so its kernels are restated here from the Arrow
+ * columnar semantics listed in SURVEY.md §8c, anchored on the reference's own call sites.
+ */
+#include "rdf_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static __thread char g_err[256];
+const char* ora_last_error(void) { return g_err; }
+#define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
+
+/* ------------------------------------------------------------------ small helpers */
+
+static inline int bit_get(const uint8_t* b, int64_t i) { return (b[i >> 3] >> (i & 7)) & 1; }
+static inline void bit_set(uint8_t* b, int64_t i) { b[i >> 3] |= (uint8_t)(1u << (i & 7)); }
+static inline void bit_clr(uint8_t* b, int64_t i) { b[i >> 3] &= (uint8_t)~(1u << (i & 7)); }
+static inline void bit_put(uint8_t* b, int64_t i, int v) { if (v) bit_set(b, i); else bit_clr(b, i); }
+
+static int dtype_size(int32_t dt) {
+    switch (dt) {
+        case RDF_I8: case RDF_U8: return 1;
+        case RDF_I16: case RDF_U16: return 2;
+        case RDF_I32: case RDF_U32: case RDF_F32: return 4;
+        case RDF_I64: case RDF_U64: case RDF_F64: return 8;
+        default: return 0; /* BOOL is bit-packed */
+    }
+}
+static int is_float(int32_t dt) { return dt == RDF_F32 || dt == RDF_F64; }
+static int is_signed_int(int32_t dt) { return dt >= RDF_I8 && dt <= RDF_I64; }
+static int is_numeric(int32_t dt) { return dt >= RDF_I8 && dt <= RDF_F64; }
+
+/* PrimitiveArray::is_valid(i) (arrow array data: bitmap at offset + i). */
+static inline int arr_valid(const rdf_array* a, int64_t i) {
+    return a->validity == NULL || bit_get(a->validity, a->offset + i);
+}
+
+/* Typed element access; integers are widened to 64 bits (sign- or zero-extended). */
+static inline double arr_f64(const rdf_array* a, int64_t i) {
+    int64_t k = a->offset + i;
+    switch (a->dtype) {
+        case RDF_I8: return (double)((const int8_t*)a->values)[k];
+        case RDF_I16: return (double)((const int16_t*)a->values)[k];
+        case RDF_I32: return (double)((const int32_t*)a->values)[k];
+        case RDF_I64: return (double)((const int64_t*)a->values)[k];
+        case RDF_U8: return (double)((const uint8_t*)a->values)[k];
+        case RDF_U16: return (double)((const uint16_t*)a->values)[k];
+        case RDF_U32: return (double)((const uint32_t*)a->values)[k];
+        case RDF_U64: return (double)((const uint64_t*)a->values)[k];
+        case RDF_F32: return (double)((const float*)a->values)[k];
+        case RDF_F64: return ((const double*)a->values)[k];
+        case RDF_BOOL: return bit_get((const uint8_t*)a->values, k) ? 1.0 : 0.0;
+        default: return 0.0;
+    }
+}
+
+static void out_begin(rdf_out* o, int64_t len) {
+    o->length = len;
+    o->null_count = 0;
+    if (o->validity) memset(o->validity, 0xFF, (size_t)((len + 7) / 8));
+}
+static inline void out_null(rdf_out* o, int64_t i) {
+    bit_clr(o->validity, i);
+    o->null_count++;
+}
+
+/* ------------------------------------------------------------------ ScalarFunctions: binary
+ * src/functions/scalar.rs:16-103 -> arrow::compute::{add,subtract,multiply,divide}(chunk_a, chunk_b):
+ *   length mismatch -> ComputeError; validity = AND of inputs; integers wrap; divide raises
+ *   DivideByZero for a zero divisor at a valid slot (ints and floats).
+ * src/functions/scalar.rs:499-523 math_op (atan2 :148, hypot :274, log :291): same shape, op(l,r)
+ *   on valid slots via libm (num::Float = std f64/f32 methods = platform libm). */
+
+#define BIN_INT_CASE(DT, T, UT)                                                                   \
+    case DT: {                                                                                    \
+        const T* x = (const T*)a->values + a->offset;                                             \
+        const T* y = (const T*)b->values + b->offset;                                             \
+        T* z = (T*)o->values;                                                                     \
+        for (int64_t i = 0; i < n; i++) {                                                         \
+            int v = arr_valid(a, i) && arr_valid(b, i);                                           \
+            if (!v) { z[i] = 0; out_null(o, i); continue; }                                       \
+            switch (op) {                                                                         \
+                case RDF_OP_ADD: z[i] = (T)((UT)x[i] + (UT)y[i]); break;                          \
+                case RDF_OP_SUB: z[i] = (T)((UT)x[i] - (UT)y[i]); break;                          \
+                case RDF_OP_MUL: z[i] = (T)((UT)x[i] * (UT)y[i]); break;                          \
+                default: /* DIV */                                                                \
+                    if (y[i] == 0) FAIL(RDF_DIVIDE_BY_ZERO, "Divide by zero error");              \
+                    if ((T)-1 < 0 && y[i] == (T)-1) z[i] = (T)((UT)0 - (UT)x[i]); /* MIN/-1 wraps */ \
+                    else z[i] = (T)(x[i] / y[i]);                                                 \
+            }                                                                                     \
+        }                                                                                         \
+    } break;
+
+#define BIN_FLT_CASE(DT, T, ATAN2, HYPOT, LOG)                                                    \
+    case DT: {                                                                                    \
+        const T* x = (const T*)a->values + a->offset;                                             \
+        const T* y = (const T*)b->values + b->offset;                                             \
+        T* z = (T*)o->values;                                                                     \
+        for (int64_t i = 0; i < n; i++) {                                                         \
+            int v = arr_valid(a, i) && arr_valid(b, i);                                           \
+            if (!v) { z[i] = 0; out_null(o, i); continue; }                                       \
+            switch (op) {                                                                         \
+                case RDF_OP_ADD: z[i] = x[i] + y[i]; break;                                       \
+                case RDF_OP_SUB: z[i] = x[i] - y[i]; break;                                       \
+                case RDF_OP_MUL: z[i] = x[i] * y[i]; break;                                       \
+                case RDF_OP_DIV:                                                                  \
+                    if (y[i] == 0) FAIL(RDF_DIVIDE_BY_ZERO, "Divide by zero error");              \
+                    z[i] = x[i] / y[i]; break;                                                    \
+                case RDF_OP_ATAN2: z[i] = ATAN2(x[i], y[i]); break;                               \
+                case RDF_OP_HYPOT: z[i] = HYPOT(x[i], y[i]); break;                               \
+                default: /* LOG: self.ln() / base.ln() */ z[i] = LOG(x[i]) / LOG(y[i]);           \
+            }                                                                                     \
+        }                                                                                         \
+    } break;
+
+static rdf_status binary_chunk(int32_t op, const rdf_array* a, const rdf_array* b, rdf_out* o) {
+    if (a->length != b->length)
+        FAIL(RDF_COMPUTE_ERROR, "Cannot perform math operation on arrays of different length");
+    if (a->dtype != b->dtype || o->dtype != a->dtype) FAIL(RDF_INVALID_ARGUMENT, "binary op: dtype mismatch");
+    if (!is_numeric(a->dtype)) FAIL(RDF_INVALID_ARGUMENT, "binary op: numeric type required");
+    if (op >= RDF_OP_ATAN2 && !is_float(a->dtype)) FAIL(RDF_INVALID_ARGUMENT, "math_op: float type required");
+    int64_t n = a->length;
+    if (o->capacity < n) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
+    if ((a->validity || b->validity) && !o->validity) FAIL(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    out_begin(o, n);
+    switch (a->dtype) {
+        BIN_INT_CASE(RDF_I8, int8_t, uint8_t)
+        BIN_INT_CASE(RDF_I16, int16_t, uint16_t)
+        BIN_INT_CASE(RDF_I32, int32_t, uint32_t)
+        BIN_INT_CASE(RDF_I64, int64_t, uint64_t)
+        BIN_INT_CASE(RDF_U8, uint8_t, uint8_t)
+        BIN_INT_CASE(RDF_U16, uint16_t, uint16_t)
+        BIN_INT_CASE(RDF_U32, uint32_t, uint32_t)
+        BIN_INT_CASE(RDF_U64, uint64_t, uint64_t)
+        BIN_FLT_CASE(RDF_F32, float, atan2f, hypotf, logf)
+        BIN_FLT_CASE(RDF_F64, double, atan2, hypot, log)
+        default: break;
+    }
+    return RDF_OK;
+}
+
+rdf_status ora_binary(int32_t op, const rdf_array* a, const rdf_array* b, int64_t nchunks, rdf_out* out) {
+    if (op < RDF_OP_ADD || op > RDF_OP_LOG) FAIL(RDF_INVALID_ARGUMENT, "not a binary op: %d", op);
+    for (int64_t c = 0; c < nchunks; c++) { /* left.iter().zip(right.iter()).map(...) scalar.rs:28-31 */
+        rdf_status s = binary_chunk(op, &a[c], &b[c], &out[c]);
+        if (s != RDF_OK) return s;
+    }
+    return RDF_OK;
+}
+
+/* ------------------------------------------------------------------ ScalarFunctions: unary
+ * src/functions/scalar.rs:525-540 scalar_op: for i in 0..len { if null -> append_null else
+ * append_value(op(value(i))) } with op = num::Float::* (libm) or num::abs. */
+
+static double deg_f64(double x) { return x * (180.0 / 3.14159265358979323846264338327950288); }
+static double rad_f64(double x) { return x * (3.14159265358979323846264338327950288 / 180.0); }
+/* Rust core: f32::to_degrees multiplies by the literal 57.2957795130823208767981548141051703_f32. */
+static float deg_f32(float x) { return x * 57.2957795130823208767981548141051703f; }
+static float rad_f32(float x) { const float pi = 3.14159265358979323846264338327950288f; return x * (pi / 180.0f); }
+
+static double un_f64(int32_t op, double x) {
+    switch (op) {
+        case RDF_OP_ABS: return fabs(x);
+        case RDF_OP_ACOS: return acos(x);
+        case RDF_OP_ASIN: return asin(x);
+        case RDF_OP_ATAN: return atan(x);
+        case RDF_OP_CBRT: return cbrt(x);
+        case RDF_OP_CEIL: return ceil(x);
+        case RDF_OP_COS: return cos(x);
+        case RDF_OP_COSH: return cosh(x);
+        case RDF_OP_DEGREES: return deg_f64(x);
+        case RDF_OP_EXP: return exp(x);
+        case RDF_OP_EXPM1: return expm1(x);
+        case RDF_OP_FLOOR: return floor(x);
+        case RDF_OP_LOG10: return log10(x);
+        case RDF_OP_LOG2: return log2(x);
+        case RDF_OP_RADIANS: return rad_f64(x);
+        case RDF_OP_ROUND: return round(x); /* half away from zero, like f64::round */
+        case RDF_OP_SIN: return sin(x);
+        case RDF_OP_SINH: return sinh(x);
+        case RDF_OP_SQRT: return sqrt(x);
+        case RDF_OP_TAN: return tan(x);
+        default: return tanh(x);
+    }
+}
+static float un_f32(int32_t op, float x) {
+    switch (op) {
+        case RDF_OP_ABS: return fabsf(x);
+        case RDF_OP_ACOS: return acosf(x);
+        case RDF_OP_ASIN: return asinf(x);
+        case RDF_OP_ATAN: return atanf(x);
+        case RDF_OP_CBRT: return cbrtf(x);
+        case RDF_OP_CEIL: return ceilf(x);
+        case RDF_OP_COS: return cosf(x);
+        case RDF_OP_COSH: return coshf(x);
+        case RDF_OP_DEGREES: return deg_f32(x);
+        case RDF_OP_EXP: return expf(x);
+        case RDF_OP_EXPM1: return expm1f(x);
+        case RDF_OP_FLOOR: return floorf(x);
+        case RDF_OP_LOG10: return log10f(x);
+        case RDF_OP_LOG2: return log2f(x);
+        case RDF_OP_RADIANS: return rad_f32(x);
+        case RDF_OP_ROUND: return roundf(x);
+        case RDF_OP_SIN: return sinf(x);
+        case RDF_OP_SINH: return sinhf(x);
+        case RDF_OP_SQRT: return sqrtf(x);
+        case RDF_OP_TAN: return tanf(x);
+        default: return tanhf(x);
+    }
+}
+
+#define ABS_INT_CASE(DT, T, UT)                                                                   \
+    case DT: {                                                                                    \
+        const T* x = (const T*)a->values + a->offset;                                             \
+        T* z = (T*)o->values;                                                                     \
+        for (int64_t i = 0; i < n; i++) {                                                         \
+            if (!arr_valid(a, i)) { z[i] = 0; out_null(o, i); continue; }                         \
+            z[i] = x[i] < 0 ? (T)((UT)0 - (UT)x[i]) : x[i]; /* num::abs; MIN wraps */             \
+        }                                                                                         \
+    } break;
+
+static rdf_status unary_chunk(int32_t op, const rdf_array* a, rdf_out* o) {
+    if (o->dtype != a->dtype) FAIL(RDF_INVALID_ARGUMENT, "unary op: dtype mismatch");
+    if (op == RDF_OP_ABS) {
+        if (!(is_float(a->dtype) || is_signed_int(a->dtype)))
+            FAIL(RDF_INVALID_ARGUMENT, "abs: signed numeric type required"); /* T::Native: Signed, scalar.rs:109 */
+    } else if (!is_float(a->dtype)) {
+        FAIL(RDF_INVALID_ARGUMENT, "float type required"); /* T::Native: num_traits::Float */
+    }
+    int64_t n = a->length;
+    if (o->capacity < n) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
+    if (a->validity && !o->validity) FAIL(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    out_begin(o, n);
+    switch (a->dtype) {
+        ABS_INT_CASE(RDF_I8, int8_t, uint8_t)
+        ABS_INT_CASE(RDF_I16, int16_t, uint16_t)
+        ABS_INT_CASE(RDF_I32, int32_t, uint32_t)
+        ABS_INT_CASE(RDF_I64, int64_t, uint64_t)
+        case RDF_F32: {
+            const float* x = (const float*)a->values + a->offset;
+            float* z = (float*)o->values;
+            for (int64_t i = 0; i < n; i++) {
+                if (!arr_valid(a, i)) { z[i] = 0; out_null(o, i); continue; }
+                z[i] = un_f32(op, x[i]);
+            }
+        } break;
+        default: {
+            const double* x = (const double*)a->values + a->offset;
+            double* z = (double*)o->values;
+            for (int64_t i = 0; i < n; i++) {
+                if (!arr_valid(a, i)) { z[i] = 0; out_null(o, i); continue; }
+                z[i] = un_f64(op, x[i]);
+            }
+        }
+    }
+    return RDF_OK;
+}
+
+rdf_status ora_unary(int32_t op, const rdf_array* a, int64_t nchunks, rdf_out* out) {
+    if (op < RDF_OP_ABS || op > RDF_OP_TANH) FAIL(RDF_INVALID_ARGUMENT, "not a unary op: %d", op);
+    for (int64_t c = 0; c < nchunks; c++) { /* array.iter().map(|a| scalar_op(a, ..)) scalar.rs:111 */
+        rdf_status s = unary_chunk(op, &a[c], &out[c]);
+        if (s != RDF_OK) return s;
+    }
+    return RDF_OK;
+}
+
+/* ------------------------------------------------------------------ cast
+ * src/evaluation.rs:296-315 -> arrow::compute::cast per chunk: numeric `as` conversions
+ * (float->int saturating, NaN -> 0, like Rust `as`), numeric->bool = (x != 0), bool->numeric = 1/0. */
+
+static inline int64_t f64_to_i64_sat(double x) {
+    if (x != x) return 0;
+    if (x >= 9223372036854775808.0) return INT64_MAX;
+    if (x <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)x;
+}
+static inline uint64_t f64_to_u64_sat(double x) {
+    if (x != x || x <= 0.0) return 0;
+    if (x >= 18446744073709551616.0) return UINT64_MAX;
+    return (uint64_t)x;
+}
+/* Convert element i of `a` to dtype `to`, written at z[k]. */
+static void cast_elem(const rdf_array* a, int64_t i, int32_t to, void* zv, int64_t k) {
+    int64_t s = a->offset + i;
+    int from = a->dtype;
+    /* fetch as (i64 | u64 | f64) by class */
+    int64_t si = 0; uint64_t ui = 0; double f = 0; int cls; /* 0 signed, 1 unsigned, 2 float */
+    switch (from) {
+        case RDF_I8: si = ((const int8_t*)a->values)[s]; cls = 0; break;
+        case RDF_I16: si = ((const int16_t*)a->values)[s]; cls = 0; break;
+        case RDF_I32: si = ((const int32_t*)a->values)[s]; cls = 0; break;
+        case RDF_I64: si = ((const int64_t*)a->values)[s]; cls = 0; break;
+        case RDF_U8: ui = ((const uint8_t*)a->values)[s]; cls = 1; break;
+        case RDF_U16: ui = ((const uint16_t*)a->values)[s]; cls = 1; break;
+        case RDF_U32: ui = ((const uint32_t*)a->values)[s]; cls = 1; break;
+        case RDF_U64: ui = ((const uint64_t*)a->values)[s]; cls = 1; break;
+        case RDF_F32: f = ((const float*)a->values)[s]; cls = 2; break;
+        case RDF_F64: f = ((const double*)a->values)[s]; cls = 2; break;
+        default: ui = (uint64_t)bit_get((const uint8_t*)a->values, s); cls = 1; break; /* BOOL */
+    }
+    if (to == RDF_BOOL) {
+        int v = cls == 0 ? (si != 0) : cls == 1 ? (ui != 0) : (f != 0.0);
+        bit_put((uint8_t*)zv, k, v);
+        return;
+    }
+    if (to == RDF_F64 || to == RDF_F32) {
+        double d = cls == 0 ? (double)si : cls == 1 ? (double)ui : f;
+        if (to == RDF_F64) ((double*)zv)[k] = d;
+        else ((float*)zv)[k] = cls == 0 ? (float)si : cls == 1 ? (float)ui : (float)f;
+        return;
+    }
+    /* integer targets: int->int wraps (truncation), float->int saturates per target width */
+    if (cls == 2) {
+        switch (to) {
+            case RDF_I8: { double c = f != f ? 0 : f < -128.0 ? -128.0 : f > 127.0 ? 127.0 : f; ((int8_t*)zv)[k] = (int8_t)c; } break;
+            case RDF_I16: { double c = f != f ? 0 : f < -32768.0 ? -32768.0 : f > 32767.0 ? 32767.0 : f; ((int16_t*)zv)[k] = (int16_t)c; } break;
+            case RDF_I32: { double c = f != f ? 0 : f < -2147483648.0 ? -2147483648.0 : f > 2147483647.0 ? 2147483647.0 : f; ((int32_t*)zv)[k] = (int32_t)c; } break;
+            case RDF_I64: ((int64_t*)zv)[k] = f64_to_i64_sat(f); break;
+            case RDF_U8: { double c = f != f ? 0 : f < 0.0 ? 0.0 : f > 255.0 ? 255.0 : f; ((uint8_t*)zv)[k] = (uint8_t)c; } break;
+            case RDF_U16: { double c = f != f ? 0 : f < 0.0 ? 0.0 : f > 65535.0 ? 65535.0 : f; ((uint16_t*)zv)[k] = (uint16_t)c; } break;
+            case RDF_U32: { double c = f != f ? 0 : f < 0.0 ? 0.0 : f > 4294967295.0 ? 4294967295.0 : f; ((uint32_t*)zv)[k] = (uint32_t)c; } break;
+            default: ((uint64_t*)zv)[k] = f64_to_u64_sat(f); break;
+        }
+        return;
+    }
+    uint64_t bits = cls == 0 ? (uint64_t)si : ui;
+    switch (to) {
+        case RDF_I8: case RDF_U8: ((uint8_t*)zv)[k] = (uint8_t)bits; break;
+        case RDF_I16: case RDF_U16: ((uint16_t*)zv)[k] = (uint16_t)bits; break;
+        case RDF_I32: case RDF_U32: ((uint32_t*)zv)[k] = (uint32_t)bits; break;
+        default: ((uint64_t*)zv)[k] = bits; break;
+    }
+}
+
+static rdf_status cast_chunk(const rdf_array* a, rdf_out* o) {
+    int64_t n = a->length;
+    if (o->capacity < n) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
+    if (a->validity && !o->validity) FAIL(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    if (!(is_numeric(a->dtype) || a->dtype == RDF_BOOL) || !(is_numeric(o->dtype) || o->dtype == RDF_BOOL))
+        FAIL(RDF_INVALID_ARGUMENT, "cast: unsupported type");
+    out_begin(o, n);
+    if (o->dtype == RDF_BOOL) memset(o->values, 0, (size_t)((n + 7) / 8));
+    for (int64_t i = 0; i < n; i++) {
+        cast_elem(a, i, o->dtype, o->values, i);
+        if (!arr_valid(a, i)) out_null(o, i);
+    }
+    return RDF_OK;
+}
+
+rdf_status ora_cast(const rdf_array* a, int64_t nchunks, rdf_out* out) {
+    for (int64_t c = 0; c < nchunks; c++) {
+        rdf_status s = cast_chunk(&a[c], &out[c]);
+        if (s != RDF_OK) return s;
+    }
+    return RDF_OK;
+}
+
+/* ------------------------------------------------------------------ AggregateFunctions
+ * src/functions/aggregate.rs:12-93. */
+
+/* arrow::compute::sum(chunk): None iff len == null_count, else sequential left fold over valid
+ * slots.  aggregate.rs:82-93 adds `unwrap_or(default)` per chunk and returns Some(total). */
+#define SUM_CASE(DT, T, UT)                                                                       \
+    case DT: {                                                                                    \
+        UT tot = 0;                                                                               \
+        for (int64_t c = 0; c < nchunks; c++) {                                                   \
+            const T* x = (const T*)a[c].values + a[c].offset;                                     \
+            UT s = 0;                                                                             \
+            for (int64_t i = 0; i < a[c].length; i++)                                             \
+                if (arr_valid(&a[c], i)) s = (UT)(s + (UT)x[i]);                                  \
+            tot = (UT)(tot + s);                                                                  \
+        }                                                                                         \
+        *(T*)out_scalar = (T)tot;                                                                 \
+    } break;
+#define SUM_FLT_CASE(DT, T)                                                                       \
+    case DT: {                                                                                    \
+        T tot = 0;                                                                                \
+        for (int64_t c = 0; c < nchunks; c++) {                                                   \
+            const T* x = (const T*)a[c].values + a[c].offset;                                     \
+            T s = 0;                                                                              \
+            for (int64_t i = 0; i < a[c].length; i++)                                             \
+                if (arr_valid(&a[c], i)) s = s + x[i];                                            \
+            tot = tot + s;                                                                        \
+        }                                                                                         \
+        *(T*)out_scalar = tot;                                                                    \
+    } break;
+
+rdf_status ora_sum(const rdf_array* a, int64_t nchunks, void* out_scalar, int32_t* out_is_some) {
+    if (nchunks < 1) FAIL(RDF_INVALID_ARGUMENT, "sum: a column has at least one chunk"); /* table.rs:25 */
+    if (!is_numeric(a[0].dtype)) FAIL(RDF_INVALID_ARGUMENT, "sum: numeric type required");
+    int dt = a[0].dtype;
+    switch (dt) {
+        SUM_CASE(RDF_I8, int8_t, uint8_t)
+        SUM_CASE(RDF_I16, int16_t, uint16_t)
+        SUM_CASE(RDF_I32, int32_t, uint32_t)
+        SUM_CASE(RDF_I64, int64_t, uint64_t)
+        SUM_CASE(RDF_U8, uint8_t, uint8_t)
+        SUM_CASE(RDF_U16, uint16_t, uint16_t)
+        SUM_CASE(RDF_U32, uint32_t, uint32_t)
+        SUM_CASE(RDF_U64, uint64_t, uint64_t)
+        SUM_FLT_CASE(RDF_F32, float)
+        SUM_FLT_CASE(RDF_F64, double)
+        default: break;
+    }
+    *out_is_some = 1; /* Some(sum) always, aggregate.rs:92 */
+    return RDF_OK;
+}
+
+/* aggregate.rs:12-31 with the evident intent: a `<` / `>` fold over
+ * the valid slots of every chunk, all-null chunks skipped, None when nothing is valid.  Floats:
+ * NaN never wins unless every valid value is NaN (documented divergence: the reference bounds
+ * T::Native: Ord and cannot take floats at all). */
+#define MINMAX_INT_CASE(DT, T)                                                                    \
+    case DT: {                                                                                    \
+        T best = 0;                                                                               \
+        for (int64_t c = 0; c < nchunks; c++) {                                                   \
+            const T* x = (const T*)a[c].values + a[c].offset;                                     \
+            for (int64_t i = 0; i < a[c].length; i++) {                                           \
+                if (!arr_valid(&a[c], i)) continue;                                               \
+                if (!some || (want_max ? x[i] > best : x[i] < best)) { best = x[i]; some = 1; }   \
+            }                                                                                     \
+        }                                                                                         \
+        if (some) *(T*)out_scalar = best;                                                         \
+    } break;
+#define MINMAX_FLT_CASE(DT, T)                                                                    \
+    case DT: {                                                                                    \
+        T best = (T)NAN; int any = 0;                                                             \
+        for (int64_t c = 0; c < nchunks; c++) {                                                   \
+            const T* x = (const T*)a[c].values + a[c].offset;                                     \
+            for (int64_t i = 0; i < a[c].length; i++) {                                           \
+                if (!arr_valid(&a[c], i)) continue;                                               \
+                any = 1;                                                                          \
+                if (x[i] != x[i]) continue;                                                       \
+                if (best != best || (want_max ? x[i] > best : x[i] < best)) best = x[i];          \
+            }                                                                                     \
+        }                                                                                         \
+        some = any;                                                                               \
+        if (some) *(T*)out_scalar = best;                                                         \
+    } break;
+
+static rdf_status minmax(const rdf_array* a, int64_t nchunks, void* out_scalar, int32_t* out_is_some, int want_max) {
+    int some = 0;
+    if (nchunks < 1) FAIL(RDF_INVALID_ARGUMENT, "min/max: a column has at least one chunk");
+    if (!is_numeric(a[0].dtype)) FAIL(RDF_INVALID_ARGUMENT, "min/max: numeric type required");
+    int dt = a[0].dtype;
+    switch (dt) {
+        MINMAX_INT_CASE(RDF_I8, int8_t)
+        MINMAX_INT_CASE(RDF_I16, int16_t)
+        MINMAX_INT_CASE(RDF_I32, int32_t)
+        MINMAX_INT_CASE(RDF_I64, int64_t)
+        MINMAX_INT_CASE(RDF_U8, uint8_t)
+        MINMAX_INT_CASE(RDF_U16, uint16_t)
+        MINMAX_INT_CASE(RDF_U32, uint32_t)
+        MINMAX_INT_CASE(RDF_U64, uint64_t)
+        MINMAX_FLT_CASE(RDF_F32, float)
+        MINMAX_FLT_CASE(RDF_F64, double)
+        default: break;
+    }
+    *out_is_some = some;
+    return RDF_OK;
+}
+rdf_status ora_min(const rdf_array* a, int64_t n, void* o, int32_t* s) { return minmax(a, n, o, s, 0); }
+rdf_status ora_max(const rdf_array* a, int64_t n, void* o, int32_t* s) { return minmax(a, n, o, s, 1); }
+
+/* aggregate.rs:70-80: sum += (array.len() - array.null_count()) as i64; Some(sum). */
+static int64_t null_count_of(const rdf_array* a) {
+    if (a->validity == NULL) return 0;
+    if (a->null_count >= 0) return a->null_count;
+    int64_t nn = 0;
+    for (int64_t i = 0; i < a->length; i++) nn += !bit_get(a->validity, a->offset + i);
+    return nn;
+}
+rdf_status ora_count(const rdf_array* a, int64_t nchunks, int64_t* out_count, int32_t* out_is_some) {
+    int64_t sum = 0;
+    for (int64_t c = 0; c < nchunks; c++) sum += a[c].length - null_count_of(&a[c]);
+    *out_count = sum;
+    *out_is_some = 1;
+    return RDF_OK;
+}
+
+/* aggregate.rs:32-65: per-chunk running mean m += (v - m) / (i + 1 - nulls), then the
+ * count-weighted merge mean += (m - mean) * len / count; None if count == 0. */
+rdf_status ora_avg(const rdf_array* a, int64_t nchunks, double* out_mean, int32_t* out_is_some) {
+    double mean = 0.0;
+    int64_t count = 0;
+    for (int64_t c = 0; c < nchunks; c++) {
+        if (!is_numeric(a[c].dtype)) FAIL(RDF_INVALID_ARGUMENT, "avg: numeric type required");
+        double m = 0.0;
+        int64_t nulls = 0;
+        for (int64_t i = 0; i < a[c].length; i++) {
+            if (arr_valid(&a[c], i)) m = m + (arr_f64(&a[c], i) - m) / (double)(i + 1 - nulls);
+            else nulls++;
+        }
+        int64_t len = a[c].length - nulls;
+        count += len;
+        if (count > 0) mean = mean + ((m - mean) * (double)len) / (double)count;
+    }
+    *out_is_some = count != 0;
+    if (count != 0) *out_mean = mean;
+    return RDF_OK;
+}
+
+/* ------------------------------------------------------------------ temporaries for the unfused
+ * evaluators: every plan step materialises a whole array, as the reference does
+ * (src/evaluation.rs:70-92, src/expression.rs:777-859). */
+
+typedef struct {
+    int32_t dtype;
+    void* values;      /* offset 0 */
+    uint8_t* validity; /* NULL = all valid */
+    int64_t len;
+    int owns;
+} tmparr;
+
+static void tmp_free(tmparr* t) {
+    if (t->owns) { free(t->values); free(t->validity); }
+    t->values = NULL; t->validity = NULL; t->owns = 0;
+}
+static rdf_array tmp_view(const tmparr* t) {
+    rdf_array a = { t->values, t->validity, 0, t->len, -1, t->dtype, RDF_MEM_HOST };
+    return a;
+}
+static size_t values_bytes(int32_t dt, int64_t n) {
+    return dt == RDF_BOOL ? (size_t)((n + 63) / 64 * 8) : (size_t)(n > 0 ? n : 1) * (size_t)dtype_size(dt);
+}
+static int tmp_alloc(tmparr* t, int32_t dt, int64_t n, int with_validity) {
+    t->dtype = dt; t->len = n; t->owns = 1;
+    t->values = calloc(1, values_bytes(dt, n) + 8);
+    t->validity = with_validity ? calloc(1, (size_t)((n + 63) / 64 * 8) + 8) : NULL;
+    return t->values != NULL && (!with_validity || t->validity != NULL);
+}
+static rdf_out tmp_out(tmparr* t) {
+    rdf_out o = { t->values, t->validity, t->len, 0, 0, t->dtype, RDF_MEM_HOST };
+    return o;
+}
+/* Re-based copy of a (possibly offset) input chunk as a temporary: batch.column(i).clone(). */
+static int tmp_from_array(tmparr* t, const rdf_array* a) {
+    if (!tmp_alloc(t, a->dtype, a->length, a->validity != NULL)) return 0;
+    if (a->dtype == RDF_BOOL) {
+        for (int64_t i = 0; i < a->length; i++) bit_put((uint8_t*)t->values, i, bit_get((const uint8_t*)a->values, a->offset + i));
+    } else {
+        int es = dtype_size(a->dtype);
+        memcpy(t->values, (const char*)a->values + a->offset * es, (size_t)a->length * (size_t)es);
+    }
+    if (a->validity)
+        for (int64_t i = 0; i < a->length; i++) bit_put(t->validity, i, bit_get(a->validity, a->offset + i));
+    return 1;
+}
+
+/* Scalar -> constant array of batch length (src/expression.rs:777-803).  Scalar::Null becomes a
+ * BooleanArray of `false` (valid). */
+static int tmp_from_scalar(tmparr* t, const rdf_expr_node* nd, int64_t n) {
+    int32_t dt = nd->dtype == RDF_NULLTYPE ? RDF_BOOL : nd->dtype;
+    if (!tmp_alloc(t, dt, n, 0)) return 0;
+    for (int64_t i = 0; i < n; i++) {
+        switch (dt) {
+            case RDF_BOOL: bit_put((uint8_t*)t->values, i, nd->dtype == RDF_NULLTYPE ? 0 : nd->i64 != 0); break;
+            case RDF_F64: ((double*)t->values)[i] = nd->f64; break;
+            case RDF_F32: ((float*)t->values)[i] = (float)nd->f64; break;
+            case RDF_I8: case RDF_U8: ((uint8_t*)t->values)[i] = (uint8_t)nd->i64; break;
+            case RDF_I16: case RDF_U16: ((uint16_t*)t->values)[i] = (uint16_t)nd->i64; break;
+            case RDF_I32: case RDF_U32: ((uint32_t*)t->values)[i] = (uint32_t)nd->i64; break;
+            default: ((uint64_t*)t->values)[i] = (uint64_t)nd->i64; break;
+        }
+    }
+    return 1;
+}
+
+static rdf_status tmp_cast(const tmparr* in, int32_t to, tmparr* out) {
+    if (!tmp_alloc(out, to, in->len, in->validity != NULL)) FAIL(RDF_MEMORY_ERROR, "out of memory");
+    rdf_array a = tmp_view(in);
+    rdf_out o = tmp_out(out);
+    return cast_chunk(&a, &o);
+}
+
+/* Recursive, fully materialising evaluation of an expression node over ONE batch (chunk index c).
+ *   BooleanFilter::eval_to_array, src/expression.rs:766-861:
+ *     Input(Scalar) -> constant array; Input(Column) -> the batch's column;
+ *     Not -> cast to Boolean, compute::not; And/Or -> (intent) cast to Boolean, compute::and/or,
+ *     null if either side null; Gt..Le -> cast both sides to Float64, compare,
+ *     null if either side null.
+ *   Value expressions: each OP node is one Calculation step of Evaluate::calculate
+ *     (src/evaluation.rs:97-323): binary arithmetic, unary float ops, cast. */
+static rdf_status eval_node(const rdf_expr_node* nodes, int32_t nnodes, int32_t idx, const rdf_array* cols,
+                            int32_t ncols, int64_t nchunks, int64_t c, int64_t batch_len, tmparr* res) {
+    if (idx < 0 || idx >= nnodes) FAIL(RDF_INVALID_ARGUMENT, "bad node index %d", idx);
+    const rdf_expr_node* nd = &nodes[idx];
+    memset(res, 0, sizeof *res);
+    if (nd->kind == RDF_NODE_SCALAR) {
+        if (!tmp_from_scalar(res, nd, batch_len)) FAIL(RDF_MEMORY_ERROR, "out of memory");
+        return RDF_OK;
+    }
+    if (nd->kind == RDF_NODE_COLUMN) {
+        if (nd->column < 0 || nd->column >= ncols) FAIL(RDF_COMPUTE_ERROR, "Cannot find column %d", nd->column);
+        if (!tmp_from_array(res, &cols[(int64_t)nd->column * nchunks + c])) FAIL(RDF_MEMORY_ERROR, "out of memory");
+        return RDF_OK;
+    }
+    int op = nd->op;
+    tmparr l = {0}, r = {0}, lc = {0}, rc = {0};
+    rdf_status s = eval_node(nodes, nnodes, nd->lhs, cols, ncols, nchunks, c, batch_len, &l);
+    if (s != RDF_OK) return s;
+    int binary = (op >= RDF_OP_ADD && op <= RDF_OP_LOG) || (op >= RDF_OP_GT && op <= RDF_OP_LE) || op == RDF_OP_AND || op == RDF_OP_OR;
+    if (binary) {
+        s = eval_node(nodes, nnodes, nd->rhs, cols, ncols, nchunks, c, batch_len, &r);
+        if (s != RDF_OK) { tmp_free(&l); return s; }
+    }
+    if (op >= RDF_OP_ADD && op <= RDF_OP_LOG) {
+        if (!tmp_alloc(res, l.dtype, l.len, l.validity || r.validity)) s = RDF_MEMORY_ERROR;
+        else { rdf_array a = tmp_view(&l), b = tmp_view(&r); rdf_out o = tmp_out(res); s = binary_chunk(op, &a, &b, &o); }
+    } else if (op >= RDF_OP_ABS && op <= RDF_OP_TANH) {
+        if (!tmp_alloc(res, l.dtype, l.len, l.validity != NULL)) s = RDF_MEMORY_ERROR;
+        else { rdf_array a = tmp_view(&l); rdf_out o = tmp_out(res); s = unary_chunk(op, &a, &o); }
+    } else if (op == RDF_OP_CAST) {
+        s = tmp_cast(&l, nd->dtype, res);
+    } else if (op >= RDF_OP_GT && op <= RDF_OP_LE) {
+        s = tmp_cast(&l, RDF_F64, &lc);
+        if (s == RDF_OK) s = tmp_cast(&r, RDF_F64, &rc);
+        if (s == RDF_OK && !tmp_alloc(res, RDF_BOOL, l.len, lc.validity || rc.validity)) s = RDF_MEMORY_ERROR;
+        if (s == RDF_OK) {
+            const double* x = (const double*)lc.values; const double* y = (const double*)rc.values;
+            for (int64_t i = 0; i < l.len; i++) {
+                int v = (!lc.validity || bit_get(lc.validity, i)) && (!rc.validity || bit_get(rc.validity, i));
+                int b;
+                switch (op) {
+                    case RDF_OP_GT: b = x[i] > y[i]; break;
+                    case RDF_OP_GE: b = x[i] >= y[i]; break;
+                    case RDF_OP_EQ: b = x[i] == y[i]; break;
+                    case RDF_OP_NE: b = x[i] != y[i]; break;
+                    case RDF_OP_LT: b = x[i] < y[i]; break;
+                    default: b = x[i] <= y[i]; break;
+                }
+                bit_put((uint8_t*)res->values, i, b && v); /* value bit of a null slot is 0 */
+                if (res->validity) bit_put(res->validity, i, v);
+            }
+        }
+    } else if (op == RDF_OP_NOT) {
+        s = tmp_cast(&l, RDF_BOOL, &lc);
+        if (s == RDF_OK && !tmp_alloc(res, RDF_BOOL, l.len, lc.validity != NULL)) s = RDF_MEMORY_ERROR;
+        if (s == RDF_OK)
+            for (int64_t i = 0; i < l.len; i++) {
+                int v = !lc.validity || bit_get(lc.validity, i);
+                bit_put((uint8_t*)res->values, i, v && !bit_get((uint8_t*)lc.values, i));
+                if (res->validity) bit_put(res->validity, i, v);
+            }
+    } else if (op == RDF_OP_AND || op == RDF_OP_OR) {
+        s = tmp_cast(&l, RDF_BOOL, &lc);
+        if (s == RDF_OK) s = tmp_cast(&r, RDF_BOOL, &rc);
+        if (s == RDF_OK && !tmp_alloc(res, RDF_BOOL, l.len, lc.validity || rc.validity)) s = RDF_MEMORY_ERROR;
+        if (s == RDF_OK)
+            for (int64_t i = 0; i < l.len; i++) {
+                int v = (!lc.validity || bit_get(lc.validity, i)) && (!rc.validity || bit_get(rc.validity, i));
+                int x = bit_get((uint8_t*)lc.values, i), y = bit_get((uint8_t*)rc.values, i);
+                bit_put((uint8_t*)res->values, i, v && (op == RDF_OP_AND ? (x && y) : (x || y)));
+                if (res->validity) bit_put(res->validity, i, v);
+            }
+    } else {
+        snprintf(g_err, sizeof g_err, "unsupported op %d", op);
+        s = RDF_INVALID_ARGUMENT;
+    }
+    tmp_free(&l); tmp_free(&r); tmp_free(&lc); tmp_free(&rc);
+    if (s != RDF_OK) tmp_free(res);
+    if (s == RDF_MEMORY_ERROR) snprintf(g_err, sizeof g_err, "out of memory");
+    return s;
+}
+
+static int64_t batch_length(const rdf_array* cols, int32_t ncols, int64_t nchunks, int64_t c, rdf_status* st) {
+    *st = RDF_OK;
+    if (ncols <= 0) return 0;
+    int64_t n = cols[c].length;
+    for (int32_t k = 1; k < ncols; k++)
+        if (cols[(int64_t)k * nchunks + c].length != n) { *st = RDF_COMPUTE_ERROR; snprintf(g_err, sizeof g_err, "columns of a batch differ in length"); }
+    return n;
+}
+
+static rdf_status copy_tmp_to_out(const tmparr* t, rdf_out* o) {
+    if (o->capacity < t->len) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
+    if (o->dtype != t->dtype) FAIL(RDF_INVALID_ARGUMENT, "output dtype %d != expression dtype %d", o->dtype, t->dtype);
+    if (t->validity && !o->validity) FAIL(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    out_begin(o, t->len);
+    memcpy(o->values, t->values, t->dtype == RDF_BOOL ? (size_t)((t->len + 7) / 8) : (size_t)t->len * (size_t)dtype_size(t->dtype));
+    if (t->validity)
+        for (int64_t i = 0; i < t->len; i++) if (!bit_get(t->validity, i)) out_null(o, i);
+    return RDF_OK;
+}
+
+/* DataFrame::evaluate_boolean_filter, src/dataframe.rs:612-624: one mask array per RecordBatch. */
+rdf_status ora_predicate(const rdf_expr_node* nodes, int32_t nnodes, int32_t root, const rdf_array* cols,
+                         int32_t ncols, int64_t nchunks, rdf_out* mask) {
+    for (int64_t c = 0; c < nchunks; c++) {
+        rdf_status s;
+        int64_t n = batch_length(cols, ncols, nchunks, c, &s);
+        if (s != RDF_OK) return s;
+        tmparr t;
+        s = eval_node(nodes, nnodes, root, cols, ncols, nchunks, c, n, &t);
+        if (s != RDF_OK) return s;
+        if (t.dtype != RDF_BOOL) { tmp_free(&t); FAIL(RDF_INVALID_ARGUMENT, "predicate root must be boolean"); }
+        s = copy_tmp_to_out(&t, &mask[c]);
+        tmp_free(&t);
+        if (s != RDF_OK) return s;
+    }
+    return RDF_OK;
+}
+
+/* ------------------------------------------------------------------ filter
+ * src/table.rs:97-107: zip(chunks, mask chunks) -> arrow::compute::filter(chunk, mask): keep the
+ * rows whose mask bit is 1 (and valid), in order, carrying validity. */
+
+static inline int mask_keep(const rdf_array* m, int64_t i) {
+    return bit_get((const uint8_t*)m->values, m->offset + i) && (m->validity == NULL || bit_get(m->validity, m->offset + i));
+}
+
+rdf_status ora_filter_count(const rdf_array* mask, int64_t nchunks, int64_t* counts) {
+    for (int64_t c = 0; c < nchunks; c++) {
+        if (mask[c].dtype != RDF_BOOL) FAIL(RDF_INVALID_ARGUMENT, "filter mask must be boolean");
+        int64_t k = 0;
+        for (int64_t i = 0; i < mask[c].length; i++) k += mask_keep(&mask[c], i);
+        counts[c] = k;
+    }
+    return RDF_OK;
+}
+
+static rdf_status filter_chunk(const rdf_array* a, const rdf_array* m, rdf_out* o) {
+    if (m->dtype != RDF_BOOL) FAIL(RDF_INVALID_ARGUMENT, "filter mask must be boolean");
+    if (a->length != m->length) FAIL(RDF_COMPUTE_ERROR, "Filter array must have the same length as the data array");
+    if (!is_numeric(a->dtype) || o->dtype != a->dtype) FAIL(RDF_INVALID_ARGUMENT, "filter: unsupported or mismatched dtype");
+    if (a->validity && !o->validity) FAIL(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    int es = dtype_size(a->dtype);
+    int64_t k = 0;
+    for (int64_t i = 0; i < a->length; i++) k += mask_keep(m, i);
+    if (o->capacity < k) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
+    out_begin(o, k);
+    k = 0;
+    for (int64_t i = 0; i < a->length; i++) {
+        if (!mask_keep(m, i)) continue;
+        memcpy((char*)o->values + k * es, (const char*)a->values + (a->offset + i) * es, (size_t)es);
+        if (!arr_valid(a, i)) out_null(o, k);
+        k++;
+    }
+    return RDF_OK;
+}
+
+rdf_status ora_filter(const rdf_array* col, const rdf_array* mask, int64_t nchunks, rdf_out* out) {
+    for (int64_t c = 0; c < nchunks; c++) {
+        rdf_status s = filter_chunk(&col[c], &mask[c], &out[c]);
+        if (s != RDF_OK) return s;
+    }
+    return RDF_OK;
+}
+
+/* src/dataframe.rs:183-187: self.columns.map(|col| col.filter(&mask)). */
+rdf_status ora_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_array* mask, int64_t nchunks, rdf_out* outs) {
+    for (int32_t k = 0; k < ncols; k++) {
+        rdf_status s = ora_filter(cols + (int64_t)k * nchunks, mask, nchunks, outs + (int64_t)k * nchunks);
+        if (s != RDF_OK) return s;
+    }
+    return RDF_OK;
+}
+
+/* ------------------------------------------------------------------ take
+ * src/table.rs:218-241: values = concat(all chunks) (:221 -> :180-182); arrow::compute::take(values,
+ * indices, None): out[j] = values[idx[j]]; null index -> null; values' nulls carried; the result is
+ * ONE chunk whatever chunk_size says. */
+rdf_status ora_take(const rdf_array* chunks, int64_t nchunks, const rdf_array* indices, rdf_out* out) {
+    if (nchunks < 1) FAIL(RDF_INVALID_ARGUMENT, "take: a column has at least one chunk");
+    if (indices->dtype != RDF_U32 && indices->dtype != RDF_U64) FAIL(RDF_INVALID_ARGUMENT, "take: indices must be UInt32/UInt64");
+    int32_t dt = chunks[0].dtype;
+    if (!is_numeric(dt) || out->dtype != dt) FAIL(RDF_INVALID_ARGUMENT, "take: unsupported or mismatched dtype");
+    int es = dtype_size(dt);
+    int64_t total = 0;
+    int any_validity = indices->validity != NULL;
+    for (int64_t c = 0; c < nchunks; c++) {
+        if (chunks[c].dtype != dt) FAIL(RDF_INVALID_ARGUMENT, "take: chunks differ in dtype");
+        total += chunks[c].length;
+        any_validity |= chunks[c].validity != NULL;
+    }
+    /* Column::to_array: the concat copy */
+    char* values = (char*)malloc((size_t)(total > 0 ? total : 1) * (size_t)es);
+    uint8_t* valid = (uint8_t*)malloc((size_t)(total / 8 + 8));
+    if (!values || !valid) { free(values); free(valid); FAIL(RDF_MEMORY_ERROR, "out of memory"); }
+    memset(valid, 0xFF, (size_t)(total / 8 + 8));
+    int64_t pos = 0;
+    for (int64_t c = 0; c < nchunks; c++) {
+        memcpy(values + pos * es, (const char*)chunks[c].values + chunks[c].offset * es, (size_t)chunks[c].length * (size_t)es);
+        for (int64_t i = 0; i < chunks[c].length; i++) if (!arr_valid(&chunks[c], i)) bit_clr(valid, pos + i);
+        pos += chunks[c].length;
+    }
+    rdf_status st = RDF_OK;
+    int64_t n = indices->length;
+    if (out->capacity < n) { st = RDF_MEMORY_ERROR; snprintf(g_err, sizeof g_err, "output capacity too small"); }
+    else if (any_validity && !out->validity) { st = RDF_INVALID_ARGUMENT; snprintf(g_err, sizeof g_err, "output validity buffer required"); }
+    else {
+        out_begin(out, n);
+        for (int64_t j = 0; j < n; j++) {
+            if (!arr_valid(indices, j)) { memset((char*)out->values + j * es, 0, (size_t)es); out_null(out, j); continue; }
+            uint64_t ix = indices->dtype == RDF_U32 ? ((const uint32_t*)indices->values)[indices->offset + j]
+                                                    : ((const uint64_t*)indices->values)[indices->offset + j];
+            if (ix >= (uint64_t)total) { st = RDF_COMPUTE_ERROR; snprintf(g_err, sizeof g_err, "take index %llu out of bounds (len %lld)", (unsigned long long)ix, (long long)total); break; }
+            memcpy((char*)out->values + j * es, values + ix * es, (size_t)es);
+            if (!bit_get(valid, (int64_t)ix)) out_null(out, j);
+        }
+    }
+    free(values); free(valid);
+    return st;
+}
+
+/* ------------------------------------------------------------------ the batch loop, unfused
+ * Evaluate::evaluate, src/evaluation.rs:66-96: every step replaces the frame with freshly
+ * materialised columns; Filter -> DataFrame::filter (src/dataframe.rs:178-189); the aggregates
+ * are AggregateFunctions over the resulting chunk list. */
+
+static void agg_from_chunks(const rdf_array* chunks, int64_t nchunks, rdf_agg_result* r) {
+    int32_t dt = chunks[0].dtype, some = 0;
+    memset(r, 0, sizeof *r);
+    r->dtype = dt;
+    ora_count(chunks, nchunks, &r->count, &some);
+    /* count must look at the bitmap: temporaries carry null_count = -1 */
+    r->is_some = r->count > 0;
+    if (is_float(dt)) {
+        if (dt == RDF_F64) {
+            double v; int32_t s;
+            ora_sum(chunks, nchunks, &v, &s); r->sum_f64 = v;
+            ora_min(chunks, nchunks, &v, &s); if (s) r->min_f64 = v;
+            ora_max(chunks, nchunks, &v, &s); if (s) r->max_f64 = v;
+        } else {
+            float v; int32_t s;
+            ora_sum(chunks, nchunks, &v, &s); r->sum_f64 = v;
+            ora_min(chunks, nchunks, &v, &s); if (s) r->min_f64 = v;
+            ora_max(chunks, nchunks, &v, &s); if (s) r->max_f64 = v;
+        }
+    } else {
+        uint64_t raw; int32_t s; int es = dtype_size(dt);
+#define WIDEN(dst)                                                                                \
+        switch (dt) {                                                                             \
+            case RDF_I8: dst = (int64_t)(int8_t)raw; break;                                       \
+            case RDF_I16: dst = (int64_t)(int16_t)raw; break;                                     \
+            case RDF_I32: dst = (int64_t)(int32_t)raw; break;                                     \
+            case RDF_U8: dst = (int64_t)(uint8_t)raw; break;                                      \
+            case RDF_U16: dst = (int64_t)(uint16_t)raw; break;                                    \
+            case RDF_U32: dst = (int64_t)(uint32_t)raw; break;                                    \
+            default: dst = (int64_t)raw; break;                                                   \
+        }
+        (void)es;
+        raw = 0; ora_sum(chunks, nchunks, &raw, &s); WIDEN(r->sum_i64)
+        raw = 0; ora_min(chunks, nchunks, &raw, &s); if (s) { WIDEN(r->min_i64) }
+        raw = 0; ora_max(chunks, nchunks, &raw, &s); if (s) { WIDEN(r->max_i64) }
+#undef WIDEN
+    }
+}
+
+rdf_status ora_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks,
+                        rdf_out* outs, rdf_agg_result* aggs) {
+    if (prog->nvalues < 1 || prog->nvalues > RDF_MAX_VALUES) FAIL(RDF_INVALID_ARGUMENT, "nvalues out of range");
+    if (prog->sink == RDF_SINK_STORE && prog->filter_root >= 0)
+        FAIL(RDF_INVALID_ARGUMENT, "SINK_STORE with a filter: use rdf_predicate + rdf_filter_columns");
+    rdf_status st = RDF_OK;
+    /* materialise every value column for every batch */
+    tmparr* vals = (tmparr*)calloc((size_t)(prog->nvalues * (nchunks > 0 ? nchunks : 1)), sizeof(tmparr));
+    tmparr* masks = (tmparr*)calloc((size_t)(nchunks > 0 ? nchunks : 1), sizeof(tmparr));
+    if (!vals || !masks) { free(vals); free(masks); FAIL(RDF_MEMORY_ERROR, "out of memory"); }
+    for (int64_t c = 0; c < nchunks && st == RDF_OK; c++) {
+        int64_t n = batch_length(cols, ncols, nchunks, c, &st);
+        if (st != RDF_OK) break;
+        for (int32_t v = 0; v < prog->nvalues && st == RDF_OK; v++)
+            st = eval_node(prog->nodes, prog->nnodes, prog->value_roots[v], cols, ncols, nchunks, c, n, &vals[(int64_t)v * nchunks + c]);
+        if (st == RDF_OK && prog->filter_root >= 0) {
+            st = eval_node(prog->nodes, prog->nnodes, prog->filter_root, cols, ncols, nchunks, c, n, &masks[c]);
+            if (st == RDF_OK && masks[c].dtype != RDF_BOOL) { st = RDF_INVALID_ARGUMENT; snprintf(g_err, sizeof g_err, "predicate root must be boolean"); }
+        }
+    }
+    if (st == RDF_OK && prog->filter_root >= 0) {
+        /* DataFrame::filter: every column filtered by the mask column */
+        for (int32_t v = 0; v < prog->nvalues && st == RDF_OK; v++)
+            for (int64_t c = 0; c < nchunks && st == RDF_OK; c++) {
+                tmparr* t = &vals[(int64_t)v * nchunks + c];
+                tmparr f;
+                if (!tmp_alloc(&f, t->dtype, t->len, t->validity != NULL)) { st = RDF_MEMORY_ERROR; break; }
+                rdf_array a = tmp_view(t), m = tmp_view(&masks[c]);
+                rdf_out o = tmp_out(&f);
+                st = filter_chunk(&a, &m, &o);
+                f.len = o.length;
+                tmp_free(t);
+                *t = f;
+            }
+    }
+    if (st == RDF_OK && prog->sink == RDF_SINK_STORE) {
+        for (int32_t v = 0; v < prog->nvalues && st == RDF_OK; v++)
+            for (int64_t c = 0; c < nchunks && st == RDF_OK; c++)
+                st = copy_tmp_to_out(&vals[(int64_t)v * nchunks + c], &outs[(int64_t)v * nchunks + c]);
+    } else if (st == RDF_OK) {
+        rdf_array* views = (rdf_array*)calloc((size_t)(nchunks > 0 ? nchunks : 1), sizeof(rdf_array));
+        for (int32_t v = 0; v < prog->nvalues; v++) {
+            if (nchunks == 0) { memset(&aggs[v], 0, sizeof aggs[v]); continue; }
+            for (int64_t c = 0; c < nchunks; c++) views[c] = tmp_view(&vals[(int64_t)v * nchunks + c]);
+            if (!is_numeric(views[0].dtype)) { st = RDF_INVALID_ARGUMENT; snprintf(g_err, sizeof g_err, "aggregate of a non-numeric value"); break; }
+            agg_from_chunks(views, nchunks, &aggs[v]);
+        }
+        free(views);
+    }
+    for (int64_t i = 0; i < (int64_t)prog->nvalues * nchunks; i++) tmp_free(&vals[i]);
+    for (int64_t c = 0; c < nchunks; c++) tmp_free(&masks[c]);
+    free(vals); free(masks);
+    return st;
+}
+
+/* ------------------------------------------------------------------ synthetic data
+ * Counter-based generator shared (by restating the same few lines) with the device fill kernels:
+ * SplitMix64 finaliser over (seed, column_id, row). */
+static inline uint64_t rdf_hash64(uint64_t seed, uint64_t column_id, uint64_t row) {
+    uint64_t z = (seed ^ (column_id * 0xD6E8FEB86659FD93ULL)) + (row + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+rdf_status ora_fill_uniform_f64(double* p, int64_t n, uint64_t seed, uint64_t col, int64_t first_row, double lo, double hi) {
+    double span = hi - lo;
+    for (int64_t i = 0; i < n; i++) {
+        double u = (double)(rdf_hash64(seed, col, (uint64_t)(first_row + i)) >> 11) * (1.0 / 9007199254740992.0);
+        double t = span * u;
+        p[i] = lo + t;
+    }
+    return RDF_OK;
+}
+rdf_status ora_fill_uniform_i64(int64_t* p, int64_t n, uint64_t seed, uint64_t col, int64_t first_row, int64_t lo, int64_t hi) {
+    if (hi <= lo) FAIL(RDF_INVALID_ARGUMENT, "fill_uniform_i64: hi must exceed lo");
+    uint64_t span = (uint64_t)hi - (uint64_t)lo;
+    for (int64_t i = 0; i < n; i++)
+        p[i] = (int64_t)((uint64_t)lo + rdf_hash64(seed, col, (uint64_t)(first_row + i)) % span);
+    return RDF_OK;
+}
+rdf_status ora_fill_validity(uint8_t* p, int64_t nbits, uint64_t seed, uint64_t col, int64_t first_row, double null_fraction) {
+    double t = null_fraction * 4294967296.0;
+    uint64_t thr = t <= 0.0 ? 0 : t >= 4294967296.0 ? 4294967296ULL : (uint64_t)t;
+    memset(p, 0, (size_t)((nbits + 7) / 8));
+    for (int64_t i = 0; i < nbits; i++) {
+        uint64_t h = rdf_hash64(seed ^ 0xA5A5A5A5A5A5A5A5ULL, col, (uint64_t)(first_row + i)) >> 32;
+        if (h >= thr) bit_set(p, i);
+    }
+    return RDF_OK;
+}

@@ -1,0 +1,460 @@
+"""ctypes mirror of include/rdf_mi355x.h and a thin, symmetric call layer.
+
+`Api(lib, prefix)` wraps either the product library (prefix ``rdf_``, librdf_mi355x.so) or — in tests
+only — the CPU oracle (prefix ``ora_``): both export the same signatures over the same structs, so a
+parity test is the same call made twice.  Nothing in this module computes anything.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+# ---------------------------------------------------------------- enums (include/rdf_mi355x.h)
+RDF_OK, RDF_COMPUTE_ERROR, RDF_DIVIDE_BY_ZERO, RDF_INVALID_ARGUMENT, RDF_MEMORY_ERROR, RDF_DEVICE_ERROR = range(6)
+STATUS_NAMES = ["OK", "ComputeError", "DivideByZero", "InvalidArgument", "MemoryError", "DeviceError"]
+
+I8, I16, I32, I64, U8, U16, U32, U64, F32, F64, BOOL, NULLTYPE = range(12)
+MEM_HOST, MEM_DEVICE = 0, 1
+
+(OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_ATAN2, OP_HYPOT, OP_LOG, OP_ABS, OP_ACOS, OP_ASIN, OP_ATAN, OP_CBRT,
+ OP_CEIL, OP_COS, OP_COSH, OP_DEGREES, OP_EXP, OP_EXPM1, OP_FLOOR, OP_LOG10, OP_LOG2, OP_RADIANS, OP_ROUND,
+ OP_SIN, OP_SINH, OP_SQRT, OP_TAN, OP_TANH, OP_CAST, OP_GT, OP_GE, OP_EQ, OP_NE, OP_LT, OP_LE, OP_NOT,
+ OP_AND, OP_OR) = range(1, 39)
+
+OP_NAMES = {
+    "add": OP_ADD, "subtract": OP_SUB, "multiply": OP_MUL, "divide": OP_DIV, "atan2": OP_ATAN2,
+    "hypot": OP_HYPOT, "log": OP_LOG, "abs": OP_ABS, "acos": OP_ACOS, "asin": OP_ASIN, "atan": OP_ATAN,
+    "cbrt": OP_CBRT, "ceil": OP_CEIL, "cos": OP_COS, "cosh": OP_COSH, "degrees": OP_DEGREES, "exp": OP_EXP,
+    "expm1": OP_EXPM1, "floor": OP_FLOOR, "log10": OP_LOG10, "log2": OP_LOG2, "radians": OP_RADIANS,
+    "round": OP_ROUND, "sin": OP_SIN, "sinh": OP_SINH, "sqrt": OP_SQRT, "tan": OP_TAN, "tanh": OP_TANH,
+    "cast": OP_CAST, "gt": OP_GT, "ge": OP_GE, "eq": OP_EQ, "ne": OP_NE, "lt": OP_LT, "le": OP_LE,
+    "not": OP_NOT, "and": OP_AND, "or": OP_OR,
+}
+UNARY_OPS = [n for n, v in OP_NAMES.items() if OP_ABS <= v <= OP_TANH]
+
+NODE_COLUMN, NODE_SCALAR, NODE_OP = 0, 1, 2
+SINK_STORE, SINK_AGG = 0, 1
+MAX_VALUES = 4
+
+NP_OF = {I8: np.int8, I16: np.int16, I32: np.int32, I64: np.int64, U8: np.uint8, U16: np.uint16,
+         U32: np.uint32, U64: np.uint64, F32: np.float32, F64: np.float64}
+DT_OF = {np.dtype(v): k for k, v in NP_OF.items()}
+DT_OF[np.dtype(np.bool_)] = BOOL
+
+
+def dtype_code(np_dtype) -> int:
+    return DT_OF[np.dtype(np_dtype)]
+
+
+# ---------------------------------------------------------------- structs
+class rdf_array(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("validity", C.c_void_p), ("offset", C.c_int64), ("length", C.c_int64),
+                ("null_count", C.c_int64), ("dtype", C.c_int32), ("mem", C.c_int32)]
+
+
+class rdf_out(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("validity", C.c_void_p), ("capacity", C.c_int64), ("length", C.c_int64),
+                ("null_count", C.c_int64), ("dtype", C.c_int32), ("mem", C.c_int32)]
+
+
+class rdf_expr_node(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("op", C.c_int32), ("dtype", C.c_int32), ("lhs", C.c_int32), ("rhs", C.c_int32),
+                ("column", C.c_int32), ("f64", C.c_double), ("i64", C.c_int64)]
+
+
+class rdf_program(C.Structure):
+    _fields_ = [("nodes", C.POINTER(rdf_expr_node)), ("nnodes", C.c_int32), ("filter_root", C.c_int32),
+                ("nvalues", C.c_int32), ("value_roots", C.c_int32 * MAX_VALUES), ("sink", C.c_int32)]
+
+
+class rdf_agg_result(C.Structure):
+    _fields_ = [("sum_f64", C.c_double), ("min_f64", C.c_double), ("max_f64", C.c_double), ("sum_i64", C.c_int64),
+                ("min_i64", C.c_int64), ("max_i64", C.c_int64), ("count", C.c_int64), ("is_some", C.c_int32),
+                ("dtype", C.c_int32)]
+
+
+class RdfError(Exception):
+    """A non-OK rdf_status: DataFrameError / ArrowError as values (src/error.rs:6-15)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES[status] if 0 <= status < len(STATUS_NAMES) else status}: {message}")
+        self.status = status
+        self.message = message
+
+
+# ---------------------------------------------------------------- host arrays (numpy-backed Arrow arrays)
+def pack_bits(bits: np.ndarray, pad_words: bool = True) -> np.ndarray:
+    """LSB-first bitmap of a bool vector, padded to whole 8-byte words (Arrow pads to 64 bytes)."""
+    b = np.packbits(np.asarray(bits, dtype=np.uint8), bitorder="little")
+    n = len(b)
+    want = ((n + 7) // 8) * 8 + 8 if pad_words else n
+    out = np.zeros(want, dtype=np.uint8)
+    out[:n] = b
+    return out
+
+
+def unpack_bits(buf: np.ndarray, offset: int, length: int) -> np.ndarray:
+    if length == 0:
+        return np.zeros(0, dtype=bool)
+    bits = np.unpackbits(np.asarray(buf, dtype=np.uint8), bitorder="little")
+    return bits[offset:offset + length].astype(bool)
+
+
+@dataclass
+class HostArray:
+    """One Arrow array in host memory: values buffer (+ validity bitmap) with an element offset."""
+    values: np.ndarray               # primitive: typed vector incl. `offset` leading elements; BOOL: uint8 bitmap
+    validity: Optional[np.ndarray]   # uint8 bitmap or None
+    offset: int
+    length: int
+    dtype: int
+    null_count: int = -1
+
+    @staticmethod
+    def from_numpy(data, valid=None, offset: int = 0, dtype: Optional[int] = None, rng=None) -> "HostArray":
+        """Build an array whose logical content is `data` (`valid`: bool vector, True = valid).  With
+        offset > 0 the buffers get `offset` leading junk elements/bits, like a sliced Arrow array."""
+        data = np.asarray(data)
+        dt = dtype if dtype is not None else dtype_code(data.dtype)
+        n = len(data)
+        rng = rng or np.random.default_rng(1234)
+        if dt == BOOL:
+            junk = rng.integers(0, 2, size=offset).astype(bool)
+            vals = pack_bits(np.concatenate([junk, data.astype(bool)]))
+        else:
+            npdt = NP_OF[dt]
+            junk = rng.integers(0, 100, size=offset).astype(npdt)
+            vals = np.ascontiguousarray(np.concatenate([junk, data.astype(npdt)]))
+            if len(vals) == 0:
+                vals = np.zeros(1, dtype=npdt)
+        vbuf = None
+        nulls = 0
+        if valid is not None:
+            valid = np.asarray(valid, dtype=bool)
+            assert len(valid) == n
+            junkv = rng.integers(0, 2, size=offset).astype(bool)
+            vbuf = pack_bits(np.concatenate([junkv, valid]))
+            nulls = int(n - valid.sum())
+        return HostArray(vals, vbuf, offset, n, dt, nulls)
+
+    def valid_mask(self) -> np.ndarray:
+        if self.validity is None:
+            return np.ones(self.length, dtype=bool)
+        return unpack_bits(self.validity, self.offset, self.length)
+
+    def to_numpy(self) -> np.ndarray:
+        """Logical values (null slots included, whatever they hold)."""
+        if self.dtype == BOOL:
+            return unpack_bits(self.values, self.offset, self.length)
+        return self.values[self.offset:self.offset + self.length]
+
+    def to_pylist(self) -> list:
+        v, m = self.to_numpy(), self.valid_mask()
+        return [x.item() if ok else None for x, ok in zip(v, m)]
+
+    def slice(self, offset: int, length: int) -> "HostArray":
+        """Zero-copy slice (Array::slice, used by ChunkedArray::slice src/table.rs:77-95)."""
+        length = max(0, min(length, self.length - offset))
+        return HostArray(self.values, self.validity, self.offset + offset, length, self.dtype, -1)
+
+    def c_struct(self, unknown_null_count: bool = False) -> rdf_array:
+        return rdf_array(self.values.ctypes.data, self.validity.ctypes.data if self.validity is not None else None,
+                         self.offset, self.length, -1 if unknown_null_count else self.null_count, self.dtype, MEM_HOST)
+
+    @staticmethod
+    def empty_out(dtype: int, capacity: int, with_validity: bool) -> "HostArray":
+        if dtype == BOOL:
+            vals = np.zeros(((capacity + 63) // 64) * 8 + 8, dtype=np.uint8)
+        else:
+            vals = np.zeros(max(capacity, 1), dtype=NP_OF[dtype])
+        vbuf = np.zeros(((capacity + 63) // 64) * 8 + 8, dtype=np.uint8) if with_validity else None
+        return HostArray(vals, vbuf, 0, capacity, dtype, 0)
+
+    def out_struct(self) -> rdf_out:
+        return rdf_out(self.values.ctypes.data, self.validity.ctypes.data if self.validity is not None else None,
+                       self.length, 0, 0, self.dtype, MEM_HOST)
+
+
+@dataclass
+class DeviceArray:
+    """One Arrow array resident in HBM; `keep` holds whatever owns the memory (torch tensors)."""
+    values_ptr: int
+    validity_ptr: Optional[int]
+    offset: int
+    length: int
+    dtype: int
+    null_count: int = -1
+    keep: object = None
+
+    def c_struct(self, unknown_null_count: bool = False) -> rdf_array:
+        return rdf_array(self.values_ptr, self.validity_ptr, self.offset, self.length,
+                         -1 if unknown_null_count else self.null_count, self.dtype, MEM_DEVICE)
+
+    def out_struct(self) -> rdf_out:
+        return rdf_out(self.values_ptr, self.validity_ptr, self.length, 0, 0, self.dtype, MEM_DEVICE)
+
+
+# ---------------------------------------------------------------- expression trees
+class Expr:
+    """Builder for rdf_expr_node arrays; mirrors BooleanFilter / Scalar (src/expression.rs:718-763)."""
+
+    def __init__(self):
+        self.nodes: List[rdf_expr_node] = []
+
+    def _add(self, **kw) -> int:
+        n = rdf_expr_node(kind=kw.get("kind", 0), op=kw.get("op", 0), dtype=kw.get("dtype", 0), lhs=kw.get("lhs", -1),
+                          rhs=kw.get("rhs", -1), column=kw.get("column", 0), f64=kw.get("f64", 0.0), i64=kw.get("i64", 0))
+        self.nodes.append(n)
+        return len(self.nodes) - 1
+
+    def col(self, index: int) -> int:
+        return self._add(kind=NODE_COLUMN, column=index)
+
+    def scalar(self, value, dtype: Optional[int] = None) -> int:
+        if value is None:
+            return self._add(kind=NODE_SCALAR, dtype=NULLTYPE)
+        if dtype is None:
+            dtype = BOOL if isinstance(value, (bool, np.bool_)) else F64 if isinstance(value, (float, np.floating)) else I64
+        if dtype in (F32, F64):
+            return self._add(kind=NODE_SCALAR, dtype=dtype, f64=float(value))
+        iv = int(value)
+        if iv >= 2 ** 63:
+            iv -= 2 ** 64
+        return self._add(kind=NODE_SCALAR, dtype=dtype, i64=iv)
+
+    def op(self, name, lhs: int, rhs: int = -1, dtype: int = 0) -> int:
+        code = OP_NAMES[name] if isinstance(name, str) else int(name)
+        return self._add(kind=NODE_OP, op=code, lhs=lhs, rhs=rhs, dtype=dtype)
+
+    def cast(self, child: int, to: int) -> int:
+        return self.op("cast", child, -1, to)
+
+    def c_array(self):
+        arr = (rdf_expr_node * max(1, len(self.nodes)))()
+        for i, n in enumerate(self.nodes):
+            arr[i] = n
+        return arr
+
+
+@dataclass
+class AggResult:
+    sum: object
+    min: object
+    max: object
+    count: int
+    is_some: bool
+    dtype: int
+
+
+# ---------------------------------------------------------------- the call layer
+def _flat(cols: Sequence[Sequence], nchunks: int):
+    """cols[c][i] -> C array laid out [c * nchunks + i]."""
+    n = len(cols) * nchunks
+    arr = (rdf_array * max(1, n))()
+    for c, col in enumerate(cols):
+        assert len(col) == nchunks, "every column of a frame has the same chunking"
+        for i, a in enumerate(col):
+            arr[c * nchunks + i] = a.c_struct(getattr(a, "_unknown_nc", False))
+    return arr
+
+
+class Api:
+    """Symmetric wrapper over `<prefix>binary`, `<prefix>unary`, ... of one shared library."""
+
+    def __init__(self, lib: C.CDLL, prefix: str):
+        self.lib = lib
+        self.prefix = prefix
+        self._err = getattr(lib, prefix + "last_error")
+        self._err.restype = C.c_char_p
+        for name in ("binary", "unary", "cast", "sum", "min", "max", "count", "avg", "predicate", "filter_count",
+                     "filter", "filter_columns", "take", "pipeline", "fill_uniform_f64", "fill_uniform_i64",
+                     "fill_validity"):
+            fn = getattr(lib, prefix + name)
+            fn.restype = C.c_int
+        getattr(lib, prefix + "fill_uniform_f64").argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, C.c_double, C.c_double]
+        getattr(lib, prefix + "fill_uniform_i64").argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int64]
+        getattr(lib, prefix + "fill_validity").argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, C.c_double]
+
+    def _fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def _check(self, status: int):
+        if status != RDF_OK:
+            raise RdfError(status, (self._err() or b"").decode("utf-8", "replace"))
+
+    # ---- outputs
+    @staticmethod
+    def _mk_outs(dtype: int, lens: Sequence[int], with_validity: Sequence[bool], like=None):
+        outs = [HostArray.empty_out(dtype, n, wv) for n, wv in zip(lens, with_validity)]
+        carr = (rdf_out * max(1, len(outs)))()
+        for i, o in enumerate(outs):
+            carr[i] = o.out_struct()
+        return outs, carr
+
+    @staticmethod
+    def _finish(outs, carr):
+        for i, o in enumerate(outs):
+            o.length = carr[i].length
+            o.null_count = carr[i].null_count
+        return outs
+
+    # ---- scalar kernels (ScalarFunctions, src/functions/scalar.rs)
+    def binary(self, op, a: Sequence, b: Sequence, outs=None):
+        code = OP_NAMES[op] if isinstance(op, str) else op
+        n = len(a)
+        ca, cb = _flat([a], n), _flat([b], len(b)) if len(b) == n else None
+        if cb is None:
+            raise ValueError("chunk lists differ in length")
+        if outs is None:
+            outs, carr = self._mk_outs(a[0].dtype if n else F64, [x.length for x in a],
+                                       [x.validity is not None or y.validity is not None for x, y in zip(a, b)])
+        else:
+            carr = (rdf_out * max(1, n))(*[o.out_struct() for o in outs])
+        self._check(self._fn("binary")(C.c_int32(code), ca, cb, C.c_int64(n), carr))
+        return self._finish(outs, carr)
+
+    def unary(self, op, a: Sequence, outs=None):
+        code = OP_NAMES[op] if isinstance(op, str) else op
+        n = len(a)
+        ca = _flat([a], n)
+        if outs is None:
+            outs, carr = self._mk_outs(a[0].dtype if n else F64, [x.length for x in a], [x.validity is not None for x in a])
+        else:
+            carr = (rdf_out * max(1, n))(*[o.out_struct() for o in outs])
+        self._check(self._fn("unary")(C.c_int32(code), ca, C.c_int64(n), carr))
+        return self._finish(outs, carr)
+
+    def cast(self, a: Sequence, to: int, outs=None):
+        n = len(a)
+        ca = _flat([a], n)
+        if outs is None:
+            outs, carr = self._mk_outs(to, [x.length for x in a], [x.validity is not None for x in a])
+        else:
+            carr = (rdf_out * max(1, n))(*[o.out_struct() for o in outs])
+        self._check(self._fn("cast")(ca, C.c_int64(n), carr))
+        return self._finish(outs, carr)
+
+    # ---- aggregates (AggregateFunctions, src/functions/aggregate.rs)
+    def _agg(self, name: str, a: Sequence):
+        n = len(a)
+        ca = _flat([a], n)
+        buf = (C.c_uint8 * 16)()
+        some = C.c_int32(0)
+        self._check(self._fn(name)(ca, C.c_int64(n), buf, C.byref(some)))
+        if not some.value:
+            return None
+        dt = a[0].dtype
+        return np.frombuffer(bytes(buf), dtype=NP_OF[dt], count=1)[0].item()
+
+    def sum(self, a):
+        return self._agg("sum", a)
+
+    def min(self, a):
+        return self._agg("min", a)
+
+    def max(self, a):
+        return self._agg("max", a)
+
+    def count(self, a: Sequence):
+        ca = _flat([a], len(a))
+        out, some = C.c_int64(0), C.c_int32(0)
+        self._check(self._fn("count")(ca, C.c_int64(len(a)), C.byref(out), C.byref(some)))
+        return out.value if some.value else None
+
+    def avg(self, a: Sequence):
+        ca = _flat([a], len(a))
+        out, some = C.c_double(0), C.c_int32(0)
+        self._check(self._fn("avg")(ca, C.c_int64(len(a)), C.byref(out), C.byref(some)))
+        return out.value if some.value else None
+
+    # ---- expressions
+    def predicate(self, expr: Expr, root: int, cols: Sequence[Sequence], outs=None):
+        nchunks = len(cols[0]) if cols else 0
+        cc = _flat(cols, nchunks)
+        if outs is None:
+            lens = [cols[0][i].length for i in range(nchunks)]
+            nullable = [any(col[i].validity is not None for col in cols) for i in range(nchunks)]
+            outs, carr = self._mk_outs(BOOL, lens, nullable)
+        else:
+            carr = (rdf_out * max(1, nchunks))(*[o.out_struct() for o in outs])
+        nodes = expr.c_array()
+        self._check(self._fn("predicate")(nodes, C.c_int32(len(expr.nodes)), C.c_int32(root), cc, C.c_int32(len(cols)),
+                                          C.c_int64(nchunks), carr))
+        return self._finish(outs, carr)
+
+    # ---- filter / take
+    def filter_count(self, mask: Sequence) -> List[int]:
+        n = len(mask)
+        cm = _flat([mask], n)
+        counts = (C.c_int64 * max(1, n))()
+        self._check(self._fn("filter_count")(cm, C.c_int64(n), counts))
+        return [counts[i] for i in range(n)]
+
+    def filter_columns(self, cols: Sequence[Sequence], mask: Sequence, outs=None):
+        nchunks = len(mask)
+        if outs is None:
+            counts = self.filter_count(mask) if nchunks else []
+            outs_all, flat = [], []
+            for col in cols:
+                o, _ = self._mk_outs(col[0].dtype if nchunks else F64, counts, [x.validity is not None for x in col])
+                outs_all.append(o)
+                flat.extend(o)
+        else:
+            outs_all = outs
+            flat = [o for col in outs for o in col]
+        carr = (rdf_out * max(1, len(flat)))(*[o.out_struct() for o in flat])
+        cc = _flat(cols, nchunks)
+        cm = _flat([mask], nchunks)
+        self._check(self._fn("filter_columns")(cc, C.c_int32(len(cols)), cm, C.c_int64(nchunks), carr))
+        self._finish(flat, carr)
+        return outs_all
+
+    def filter(self, col: Sequence, mask: Sequence, outs=None):
+        nchunks = len(mask)
+        if outs is None:
+            counts = self.filter_count(mask) if nchunks else []
+            outs, carr = self._mk_outs(col[0].dtype if nchunks else F64, counts, [x.validity is not None for x in col])
+        else:
+            carr = (rdf_out * max(1, nchunks))(*[o.out_struct() for o in outs])
+        self._check(self._fn("filter")(_flat([col], nchunks), _flat([mask], nchunks), C.c_int64(nchunks), carr))
+        return self._finish(outs, carr)
+
+    def take(self, chunks: Sequence, indices, out=None):
+        n = len(chunks)
+        nullable = indices.validity is not None or any(c.validity is not None for c in chunks)
+        if out is None:
+            out = HostArray.empty_out(chunks[0].dtype, indices.length, nullable)
+        carr = (rdf_out * 1)(out.out_struct())
+        idx = (rdf_array * 1)(indices.c_struct())
+        self._check(self._fn("take")(_flat([chunks], n), C.c_int64(n), idx, carr))
+        return self._finish([out], carr)[0]
+
+    # ---- fused batch loop
+    def pipeline(self, expr: Expr, cols: Sequence[Sequence], value_roots: Sequence[int], filter_root: int = -1,
+                 sink: int = SINK_AGG, outs=None):
+        nchunks = len(cols[0]) if cols else 0
+        nodes = expr.c_array()
+        prog = rdf_program(C.cast(nodes, C.POINTER(rdf_expr_node)), len(expr.nodes), filter_root, len(value_roots),
+                           (C.c_int32 * MAX_VALUES)(*(list(value_roots) + [0] * (MAX_VALUES - len(value_roots)))), sink)
+        cc = _flat(cols, nchunks)
+        aggs = (rdf_agg_result * MAX_VALUES)()
+        if sink == SINK_STORE:
+            assert outs is not None, "SINK_STORE needs caller-allocated outputs: outs[v][chunk]"
+            flat = [o for v in outs for o in v]
+            carr = (rdf_out * max(1, len(flat)))(*[o.out_struct() for o in flat])
+            self._check(self._fn("pipeline")(C.byref(prog), cc, C.c_int32(len(cols)), C.c_int64(nchunks), carr, aggs))
+            self._finish(flat, carr)
+            return outs
+        self._check(self._fn("pipeline")(C.byref(prog), cc, C.c_int32(len(cols)), C.c_int64(nchunks), None, aggs))
+        res = []
+        for v in range(len(value_roots)):
+            r = aggs[v]
+            if r.dtype in (F32, F64):
+                res.append(AggResult(r.sum_f64, r.min_f64, r.max_f64, r.count, bool(r.is_some), r.dtype))
+            else:
+                fix = (lambda x: x + 2 ** 64 if x < 0 else x) if r.dtype == U64 else (lambda x: x)
+                res.append(AggResult(fix(r.sum_i64), fix(r.min_i64), fix(r.max_i64), r.count, bool(r.is_some), r.dtype))
+        return res

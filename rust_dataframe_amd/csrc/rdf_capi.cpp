@@ -1,0 +1,1439 @@
+// rdf_capi.cpp — host side of librdf_mi355x.so: the extern "C" boundary of include/rdf_mi355x.h.
+//
+// Per calling thread: one context (device, stream, HBM arena, pinned staging buffer, last error).
+// RDF_MEM_HOST arrays are staged into the arena (small chunks packed through one pinned buffer and
+// ONE H2D copy — the reference reads CSV/JSON/Parquet in 1024-row batches, src/dataframe.rs:352 —
+// large chunks DMA'd directly), computed by the kernels of rdf_kernels.hip, and copied back.
+// RDF_MEM_DEVICE arrays are used in place.  There is no CPU compute path in this file.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rdf_device.h"
+
+using namespace rdfk;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// context
+
+struct Arena {
+    char*  base = nullptr;
+    size_t cap = 0, used = 0, wanted = 0;
+    std::vector<void*> overflow;
+};
+
+struct Ctx {
+    bool        ready = false;
+    int         device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // own_stream or the caller's
+    Arena       arena;
+    char*       pinned = nullptr;
+    size_t      pinned_cap = 0;
+    std::string err;
+    // kernel timing (bench.py roofline leg)
+    bool   timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+};
+
+thread_local Ctx g_ctx;
+
+rdf_status fail(rdf_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_ctx.err = buf;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(RDF_DEVICE_ERROR, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+#define RDF_TRY(expr)                  \
+    do {                               \
+        rdf_status _s = (expr);        \
+        if (_s != RDF_OK) return _s;   \
+    } while (0)
+
+rdf_status ensure_ready() {
+    Ctx& c = g_ctx;
+    if (c.ready) return RDF_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RDF_DEVICE_ERROR, "no HIP device visible (%s); librdf_mi355x has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    HIP_TRY(hipGetDevice(&c.device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c.device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RDF_DEVICE_ERROR, "device %d is %s; this library carries gfx950 (MI355X) code only", c.device, prop.gcnArchName);
+    HIP_TRY(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    c.stream = c.own_stream;
+    c.ready = true;
+    return RDF_OK;
+}
+
+// ---- arena: bump allocator over one HBM block, regrown between calls ----
+void arena_begin() {
+    Arena& a = g_ctx.arena;
+    for (void* p : a.overflow) (void)hipFree(p);
+    a.overflow.clear();
+    if (a.wanted > a.cap) {
+        if (a.base) (void)hipFree(a.base);
+        a.base = nullptr;
+        a.cap = 0;
+        size_t want = a.wanted + a.wanted / 4 + (1u << 20);
+        void* p = nullptr;
+        if (hipMalloc(&p, want) == hipSuccess) { a.base = (char*)p; a.cap = want; }
+    }
+    a.used = 0;
+    a.wanted = 0;
+}
+rdf_status arena_alloc(size_t bytes, void** out) {
+    Arena& a = g_ctx.arena;
+    bytes = (bytes + 16 + 255) & ~(size_t)255;  // 16-byte tail pad for 8-byte bitmap window reads
+    a.wanted += bytes;
+    if (a.used + bytes <= a.cap) {
+        *out = a.base + a.used;
+        a.used += bytes;
+        return RDF_OK;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(RDF_MEMORY_ERROR, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    a.overflow.push_back(p);
+    *out = p;
+    return RDF_OK;
+}
+rdf_status pinned_reserve(size_t bytes) {
+    Ctx& c = g_ctx;
+    if (bytes <= c.pinned_cap) return RDF_OK;
+    // growing: copies still in flight may be reading the old buffer
+    if (c.pinned && c.stream) (void)hipStreamSynchronize(c.stream);
+    if (c.pinned) (void)hipHostFree(c.pinned);
+    c.pinned = nullptr;
+    c.pinned_cap = 0;
+    size_t want = bytes + bytes / 2 + 4096;
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(RDF_MEMORY_ERROR, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    c.pinned = (char*)p;
+    c.pinned_cap = want;
+    return RDF_OK;
+}
+
+// ---- kernel timing ----
+struct KernelTimer {
+    bool on;
+    size_t idx = 0;
+    explicit KernelTimer() : on(g_ctx.timing) {
+        if (!on) return;
+        Ctx& c = g_ctx;
+        if (c.events_used == c.events.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            c.events.emplace_back(a, b);
+        }
+        idx = c.events_used++;
+        (void)hipEventRecord(c.events[idx].first, c.stream);
+    }
+    void stop() {
+        if (on) (void)hipEventRecord(g_ctx.events[idx].second, g_ctx.stream);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// dtype helpers
+
+int dtype_size(int dt) {
+    switch (dt) {
+        case RDF_I8: case RDF_U8: return 1;
+        case RDF_I16: case RDF_U16: return 2;
+        case RDF_I32: case RDF_U32: case RDF_F32: return 4;
+        case RDF_I64: case RDF_U64: case RDF_F64: return 8;
+        default: return 0;
+    }
+}
+bool is_float(int dt) { return dt == RDF_F32 || dt == RDF_F64; }
+bool is_numeric(int dt) { return dt >= RDF_I8 && dt <= RDF_F64; }
+bool is_signed_int(int dt) { return dt >= RDF_I8 && dt <= RDF_I64; }
+bool is_unsigned_int(int dt) { return dt >= RDF_U8 && dt <= RDF_U64; }
+int value_class(int dt) { return is_float(dt) ? CLS_F64 : is_signed_int(dt) ? CLS_SIGNED : CLS_UNSIGNED; }
+
+uint64_t h_normalize_int(int dt, uint64_t x) {
+    switch (dt) {
+        case RDF_I8: return (uint64_t)(int64_t)(int8_t)x;
+        case RDF_I16: return (uint64_t)(int64_t)(int16_t)x;
+        case RDF_I32: return (uint64_t)(int64_t)(int32_t)x;
+        case RDF_U8: return x & 0xFFull;
+        case RDF_U16: return x & 0xFFFFull;
+        case RDF_U32: return x & 0xFFFFFFFFull;
+        default: return x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// staging of RDF_MEM_HOST buffers: small items are packed through the pinned buffer and moved with
+// ONE copy; large items are copied directly.
+
+constexpr size_t kSmallCopy = 256 * 1024;
+
+struct StageItem {
+    const void* src;   // host source (H2D) — or destination (D2H)
+    size_t bytes;
+    size_t off;        // offset inside the region
+    bool small;
+};
+
+struct Region {
+    std::vector<StageItem> items;
+    char* dev = nullptr;
+    size_t small_bytes = 0, total = 0;
+
+    int add(const void* host, size_t bytes) {
+        items.push_back(StageItem{host, bytes, 0, bytes < kSmallCopy});
+        return (int)items.size() - 1;
+    }
+    rdf_status layout() {
+        size_t off = 0;
+        for (auto& it : items) if (it.small) { it.off = off; off += (it.bytes + 16 + 63) & ~(size_t)63; }
+        small_bytes = off;
+        off = (off + 255) & ~(size_t)255;
+        for (auto& it : items) if (!it.small) { it.off = off; off += (it.bytes + 16 + 255) & ~(size_t)255; }
+        total = off;
+        void* p = nullptr;
+        RDF_TRY(arena_alloc(total ? total : 256, &p));
+        dev = (char*)p;
+        return RDF_OK;
+    }
+    char* ptr(int idx) const { return dev + items[(size_t)idx].off; }
+
+    rdf_status upload(size_t pinned_off, size_t* pinned_used) {
+        Ctx& c = g_ctx;
+        if (small_bytes) {
+            char* pin = c.pinned + pinned_off;
+            for (auto& it : items)
+                if (it.small && it.bytes) memcpy(pin + it.off, it.src, it.bytes);
+            HIP_TRY(hipMemcpyAsync(dev, pin, small_bytes, hipMemcpyHostToDevice, c.stream));
+        }
+        *pinned_used = small_bytes;
+        for (auto& it : items)
+            if (!it.small && it.bytes) HIP_TRY(hipMemcpyAsync(dev + it.off, it.src, it.bytes, hipMemcpyHostToDevice, c.stream));
+        return RDF_OK;
+    }
+    // D2H: `src` fields are the host destinations.  Ends with a stream sync.
+    rdf_status download(size_t pinned_off) {
+        Ctx& c = g_ctx;
+        if (small_bytes) HIP_TRY(hipMemcpyAsync(c.pinned + pinned_off, dev, small_bytes, hipMemcpyDeviceToHost, c.stream));
+        for (auto& it : items)
+            if (!it.small && it.bytes) HIP_TRY(hipMemcpyAsync((void*)it.src, dev + it.off, it.bytes, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        if (small_bytes) {
+            const char* pin = c.pinned + pinned_off;
+            for (auto& it : items)
+                if (it.small && it.bytes) memcpy((void*)it.src, pin + it.off, it.bytes);
+        }
+        return RDF_OK;
+    }
+};
+
+// Plan of one staged input array: which byte ranges to move and the resulting device view.
+struct InPlan {
+    int values_item = -1, validity_item = -1;
+    int64_t dev_offset = 0;
+};
+
+// Stage (or alias) a list of arrays.  After finish(), dev[i] is the HBM view of arrays[i].
+struct InputStager {
+    Region region;
+    std::vector<InPlan> plans;
+    std::vector<const rdf_array*> arrays;
+    std::vector<DevChunkCol> dev;
+    bool host = false;
+
+    void add(const rdf_array* a) {
+        arrays.push_back(a);
+        InPlan p;
+        if (a->mem == RDF_MEM_HOST) {
+            host = true;
+            const int64_t k = a->offset & 7;
+            const int64_t s0 = a->offset - k;
+            p.dev_offset = k;
+            if (a->length > 0) {
+                if (a->dtype == RDF_BOOL) {
+                    const size_t b0 = (size_t)(s0 >> 3), b1 = (size_t)((a->offset + a->length + 7) >> 3);
+                    p.values_item = region.add((const char*)a->values + b0, b1 - b0);
+                } else {
+                    const size_t es = (size_t)dtype_size(a->dtype);
+                    p.values_item = region.add((const char*)a->values + (size_t)s0 * es, (size_t)(a->length + k) * es);
+                }
+                if (a->validity) {
+                    const size_t b0 = (size_t)(s0 >> 3), b1 = (size_t)((a->offset + a->length + 7) >> 3);
+                    p.validity_item = region.add(a->validity + b0, b1 - b0);
+                }
+            }
+        }
+        plans.push_back(p);
+    }
+    rdf_status finish(size_t pinned_off, size_t* pinned_used) {
+        *pinned_used = 0;
+        dev.resize(arrays.size());
+        if (host) {
+            RDF_TRY(region.layout());
+            RDF_TRY(pinned_reserve(pinned_off + region.small_bytes));
+            RDF_TRY(region.upload(pinned_off, pinned_used));
+        }
+        for (size_t i = 0; i < arrays.size(); ++i) {
+            const rdf_array* a = arrays[i];
+            if (a->mem == RDF_MEM_DEVICE) dev[i] = DevChunkCol{a->values, a->validity, a->offset};
+            else {
+                const InPlan& p = plans[i];
+                dev[i].values = p.values_item >= 0 ? region.ptr(p.values_item) : region.dev;
+                dev[i].validity = p.validity_item >= 0 ? (const uint8_t*)region.ptr(p.validity_item) : nullptr;
+                dev[i].offset = p.dev_offset;
+            }
+        }
+        return RDF_OK;
+    }
+};
+
+// Small host tables (chunk descriptors, prefix arrays) uploaded in one copy.
+struct TableBuilder {
+    std::vector<char> host;
+    char* dev = nullptr;
+    size_t reserve(size_t bytes) {
+        size_t off = (host.size() + 15) & ~(size_t)15;
+        host.resize(off + bytes);
+        return off;
+    }
+    template <typename T> T* at(size_t off) { return (T*)(host.data() + off); }
+    template <typename T> T* dev_at(size_t off) const { return (T*)(dev + off); }
+    rdf_status alloc() {
+        void* p = nullptr;
+        RDF_TRY(arena_alloc(host.size() ? host.size() : 16, &p));
+        dev = (char*)p;
+        return RDF_OK;
+    }
+    rdf_status upload(size_t pinned_off) {
+        Ctx& c = g_ctx;
+        if (host.empty()) return RDF_OK;
+        RDF_TRY(pinned_reserve(pinned_off + host.size()));
+        memcpy(c.pinned + pinned_off, host.data(), host.size());
+        HIP_TRY(hipMemcpyAsync(dev, c.pinned + pinned_off, host.size(), hipMemcpyHostToDevice, c.stream));
+        return RDF_OK;
+    }
+};
+
+rdf_status check_mem(const rdf_array* arrs, int64_t n, int32_t* mem_io) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (arrs[i].mem != RDF_MEM_HOST && arrs[i].mem != RDF_MEM_DEVICE) return fail(RDF_INVALID_ARGUMENT, "bad mem tag %d", arrs[i].mem);
+        if (*mem_io < 0) *mem_io = arrs[i].mem;
+        else if (*mem_io != arrs[i].mem) return fail(RDF_INVALID_ARGUMENT, "all arrays of one call must share one memory space");
+        if (arrs[i].length < 0 || arrs[i].offset < 0) return fail(RDF_INVALID_ARGUMENT, "negative length/offset");
+        if (arrs[i].length > 0 && arrs[i].values == nullptr) return fail(RDF_INVALID_ARGUMENT, "null values pointer");
+    }
+    return RDF_OK;
+}
+rdf_status check_out_mem(const rdf_out* outs, int64_t n, int32_t mem) {
+    for (int64_t i = 0; i < n; ++i)
+        if (outs[i].mem != mem) return fail(RDF_INVALID_ARGUMENT, "outputs must live in the same memory space as the inputs");
+    return RDF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// expression compiler: rdf_expr_node tree -> accumulator-machine bytecode
+
+bool op_is_arith(int op) { return op >= RDF_OP_ADD && op <= RDF_OP_DIV; }
+bool op_is_fbinary(int op) { return op >= RDF_OP_ATAN2 && op <= RDF_OP_LOG; }
+bool op_is_unary_math(int op) { return op >= RDF_OP_ABS && op <= RDF_OP_TANH; }
+bool op_is_cmp(int op) { return op >= RDF_OP_GT && op <= RDF_OP_LE; }
+bool op_is_binary(int op) { return op_is_arith(op) || op_is_fbinary(op) || op_is_cmp(op) || op == RDF_OP_AND || op == RDF_OP_OR; }
+bool op_is_heavy(int op) {
+    if (op_is_fbinary(op)) return true;
+    if (!op_is_unary_math(op)) return false;
+    switch (op) {
+        case RDF_OP_ABS: case RDF_OP_CEIL: case RDF_OP_FLOOR: case RDF_OP_ROUND: case RDF_OP_SQRT:
+        case RDF_OP_DEGREES: case RDF_OP_RADIANS: return false;
+        default: return true;
+    }
+}
+
+struct Compiler {
+    const rdf_expr_node* nodes;
+    int nnodes;
+    const int* col_dtype;
+    int ncols;
+    std::vector<Instr> code;
+    std::vector<int> memo;
+    int tmp_used = 0, tmp_max = 0;
+    bool heavy = false;
+    rdf_status st = RDF_OK;
+
+    Compiler(const rdf_expr_node* n, int nn, const int* cd, int nc) : nodes(n), nnodes(nn), col_dtype(cd), ncols(nc), memo((size_t)(nn > 0 ? nn : 0), -2) {}
+
+    int bad(rdf_status s, const char* fmt, ...) {
+        if (st == RDF_OK) {
+            char buf[256];
+            va_list ap;
+            va_start(ap, fmt);
+            vsnprintf(buf, sizeof buf, fmt, ap);
+            va_end(ap);
+            st = fail(s, "%s", buf);
+        }
+        return -1;
+    }
+
+    // result dtype of node idx (or -1 on error)
+    int infer(int idx, int depth = 0) {
+        if (idx < 0 || idx >= nnodes) return bad(RDF_INVALID_ARGUMENT, "bad node index %d", idx);
+        if (depth > 64) return bad(RDF_INVALID_ARGUMENT, "expression too deep");
+        if (memo[(size_t)idx] != -2) return memo[(size_t)idx];
+        const rdf_expr_node& nd = nodes[idx];
+        int r = -1;
+        if (nd.kind == RDF_NODE_COLUMN) {
+            if (nd.column < 0 || nd.column >= ncols) r = bad(RDF_COMPUTE_ERROR, "Cannot find column %d", nd.column);
+            else r = col_dtype[nd.column];
+        } else if (nd.kind == RDF_NODE_SCALAR) {
+            if (nd.dtype == RDF_NULLTYPE) r = RDF_BOOL;
+            else if (is_numeric(nd.dtype) || nd.dtype == RDF_BOOL) r = nd.dtype;
+            else r = bad(RDF_INVALID_ARGUMENT, "unsupported scalar type %d", nd.dtype);
+        } else if (nd.kind == RDF_NODE_OP) {
+            const int op = nd.op;
+            const int l = infer(nd.lhs, depth + 1);
+            if (l < 0) return memo[(size_t)idx] = -1;
+            if (op_is_binary(op)) {
+                const int rr = infer(nd.rhs, depth + 1);
+                if (rr < 0) return memo[(size_t)idx] = -1;
+                if (op_is_arith(op) || op_is_fbinary(op)) {
+                    if (l != rr) r = bad(RDF_INVALID_ARGUMENT, "binary op %d: operand types differ (%d vs %d); insert a Cast", op, l, rr);
+                    else if (!is_numeric(l)) r = bad(RDF_INVALID_ARGUMENT, "binary op %d: numeric type required", op);
+                    else if (op_is_fbinary(op) && !is_float(l)) r = bad(RDF_INVALID_ARGUMENT, "math_op: float type required");
+                    else r = l;
+                } else r = RDF_BOOL;  // comparisons, and, or
+            } else if (op_is_unary_math(op)) {
+                if (op == RDF_OP_ABS) {
+                    if (!(is_float(l) || is_signed_int(l))) r = bad(RDF_INVALID_ARGUMENT, "abs: signed numeric type required");
+                    else r = l;
+                } else if (!is_float(l)) r = bad(RDF_INVALID_ARGUMENT, "float type required");
+                else r = l;
+            } else if (op == RDF_OP_CAST) {
+                if (!(is_numeric(nd.dtype) || nd.dtype == RDF_BOOL)) r = bad(RDF_INVALID_ARGUMENT, "cast: unsupported type");
+                else r = nd.dtype;
+            } else if (op == RDF_OP_NOT) r = RDF_BOOL;
+            else r = bad(RDF_INVALID_ARGUMENT, "unsupported op %d", op);
+        } else r = bad(RDF_INVALID_ARGUMENT, "bad node kind %d", nd.kind);
+        return memo[(size_t)idx] = r;
+    }
+
+    bool is_leaf(int idx) const { return nodes[idx].kind != RDF_NODE_OP; }
+
+    void push(Instr in) {
+        if ((int)code.size() >= kMaxCode) { bad(RDF_INVALID_ARGUMENT, "expression too long (more than %d steps)", kMaxCode); return; }
+        code.push_back(in);
+    }
+    static Instr mk(uint8_t bc) {
+        Instr in;
+        memset(&in, 0, sizeof in);
+        in.bc = bc;
+        return in;
+    }
+
+    // literal payload converted on the host into domain `dom`
+    uint64_t imm_for(const rdf_expr_node& nd, int dom) {
+        const int lt = nd.dtype == RDF_NULLTYPE ? RDF_BOOL : nd.dtype;
+        const bool flit = is_float(lt);
+        const double f = lt == RDF_F32 ? (double)(float)nd.f64 : nd.f64;
+        const uint64_t iv = nd.dtype == RDF_NULLTYPE ? 0 : (lt == RDF_BOOL ? (uint64_t)(nd.i64 != 0) : h_normalize_int(lt, (uint64_t)nd.i64));
+        if (dom == RDF_BOOL) return flit ? (uint64_t)(f != 0.0) : (uint64_t)(iv != 0);
+        if (dom == RDF_F64) {
+            double d = flit ? f : (is_signed_int(lt) ? (double)(int64_t)iv : (double)iv);
+            uint64_t u; memcpy(&u, &d, 8); return u;
+        }
+        if (dom == RDF_F32) {
+            float d = flit ? (float)f : (is_signed_int(lt) ? (float)(int64_t)iv : (float)iv);
+            uint32_t u; memcpy(&u, &d, 4); return u;
+        }
+        if (flit) {
+            if (f != f) return 0;
+            if (is_signed_int(dom)) {
+                double lo = dom == RDF_I8 ? -128.0 : dom == RDF_I16 ? -32768.0 : dom == RDF_I32 ? -2147483648.0 : -9223372036854775808.0;
+                double hi = dom == RDF_I8 ? 127.0 : dom == RDF_I16 ? 32767.0 : dom == RDF_I32 ? 2147483647.0 : 9223372036854775807.0;
+                if (f <= lo) return (uint64_t)(int64_t)lo;
+                if (f >= hi) return dom == RDF_I64 ? (uint64_t)INT64_MAX : (uint64_t)(int64_t)hi;
+                return (uint64_t)(int64_t)f;
+            }
+            double hi = dom == RDF_U8 ? 255.0 : dom == RDF_U16 ? 65535.0 : dom == RDF_U32 ? 4294967295.0 : 18446744073709551615.0;
+            if (f <= 0.0) return 0;
+            if (f >= hi) return dom == RDF_U64 ? ~0ull : (uint64_t)hi;
+            return (uint64_t)f;
+        }
+        return h_normalize_int(dom, iv);
+    }
+
+    void operand_fields(Instr& in, int leaf_idx, int dom) {
+        const rdf_expr_node& nd = nodes[leaf_idx];
+        if (nd.kind == RDF_NODE_COLUMN) {
+            in.src_kind = SRC_COL;
+            in.src = (uint16_t)nd.column;
+            in.src_dtype = (uint8_t)col_dtype[nd.column];
+        } else {
+            in.src_kind = SRC_IMM;
+            in.src_dtype = (uint8_t)dom;
+            in.imm = imm_for(nd, dom);
+        }
+        in.dtype = (uint8_t)dom;
+    }
+    void cast_acc(int from, int to) {
+        if (from == to) return;
+        Instr in = mk(BC_CAST);
+        in.src_dtype = (uint8_t)from;
+        in.dtype = (uint8_t)to;
+        push(in);
+    }
+
+    // generate code leaving node idx in the accumulator, in the domain of its inferred dtype
+    void gen(int idx) {
+        if (st != RDF_OK) return;
+        const int dt = infer(idx);
+        if (dt < 0) return;
+        const rdf_expr_node& nd = nodes[idx];
+        if (nd.kind != RDF_NODE_OP) {
+            Instr in = mk(BC_LOAD);
+            operand_fields(in, idx, dt);
+            push(in);
+            return;
+        }
+        const int op = nd.op;
+        if (op_is_heavy(op)) heavy = true;
+        if (!op_is_binary(op)) {
+            gen(nd.lhs);
+            const int l = infer(nd.lhs);
+            if (op == RDF_OP_CAST) { cast_acc(l, nd.dtype); return; }
+            Instr in = mk(BC_UN);
+            in.op = (uint8_t)op;
+            if (op == RDF_OP_NOT) { cast_acc(l, RDF_BOOL); in.dtype = RDF_BOOL; }
+            else in.dtype = (uint8_t)l;
+            push(in);
+            return;
+        }
+        const int l = infer(nd.lhs), r = infer(nd.rhs);
+        const int dom = op_is_cmp(op) ? RDF_F64 : (op == RDF_OP_AND || op == RDF_OP_OR) ? RDF_BOOL : l;
+        Instr in = mk(BC_BIN);
+        in.op = (uint8_t)op;
+        if (is_leaf(nd.rhs)) {
+            gen(nd.lhs);
+            cast_acc(l, dom);
+            operand_fields(in, nd.rhs, dom);
+        } else if (is_leaf(nd.lhs)) {
+            gen(nd.rhs);
+            cast_acc(r, dom);
+            operand_fields(in, nd.lhs, dom);
+            in.swapped = 1;
+        } else {
+            gen(nd.rhs);
+            cast_acc(r, dom);
+            if (tmp_used >= kMaxTmp) { bad(RDF_INVALID_ARGUMENT, "expression needs more than %d temporaries", kMaxTmp); return; }
+            const int slot = tmp_used++;
+            if (tmp_used > tmp_max) tmp_max = tmp_used;
+            Instr stt = mk(BC_STORE_TMP);
+            stt.src = (uint16_t)slot;
+            push(stt);
+            gen(nd.lhs);
+            cast_acc(l, dom);
+            in.src_kind = SRC_TMP;
+            in.src = (uint16_t)slot;
+            in.src_dtype = (uint8_t)dom;
+            in.dtype = (uint8_t)dom;
+            --tmp_used;
+        }
+        push(in);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the fused evaluator driver
+
+struct ProgramSpec {
+    const rdf_expr_node* nodes;
+    int nnodes;
+    int filter_root;
+    int nvalues;
+    int value_roots[kMaxValues];
+    int sink;
+};
+
+rdf_status launch_agg_pair(const EvalArgs* ea, const FilterAggF64Args* fa, int cmp, bool heavy, int grid, int nvalues,
+                           const int* cls, AggPartial* partials, AggPartial* result) {
+    Ctx& c = g_ctx;
+    KernelTimer kt;
+    if (fa) HIP_TRY(launch_filter_agg_f64(*fa, cmp, grid, c.stream));
+    else HIP_TRY(launch_eval(*ea, SINK_AGG, heavy, grid, c.stream));
+    kt.stop();
+    AggFinalArgs f;
+    memset(&f, 0, sizeof f);
+    f.partials = partials;
+    f.result = result;
+    f.nblocks = grid;
+    f.nvalues = nvalues;
+    for (int k = 0; k < nvalues; ++k) f.value_cls[k] = cls[k];
+    HIP_TRY(launch_agg_final(f, c.stream));
+    return RDF_OK;
+}
+
+void fill_agg_result(rdf_agg_result* r, int dt, const AggPartial& p) {
+    memset(r, 0, sizeof *r);
+    r->dtype = dt;
+    r->count = p.cnt;
+    r->is_some = p.cnt > 0;
+    if (is_float(dt)) {
+        double s, a, b;
+        memcpy(&s, &p.sum, 8); memcpy(&a, &p.mn, 8); memcpy(&b, &p.mx, 8);
+        r->sum_f64 = dt == RDF_F32 ? (double)(float)s : s;
+        if (p.cnt > 0) { r->min_f64 = a; r->max_f64 = b; }
+    } else {
+        r->sum_i64 = (int64_t)h_normalize_int(dt, p.sum);
+        if (p.cnt > 0) { r->min_i64 = (int64_t)p.mn; r->max_i64 = (int64_t)p.mx; }
+    }
+}
+
+rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, int64_t nchunks, rdf_out* outs,
+                       rdf_agg_result* aggs, const char* len_mismatch_msg) {
+    if (nchunks < 0) return fail(RDF_INVALID_ARGUMENT, "negative chunk count");
+    if (ncols < 0 || ncols > kMaxCols) return fail(RDF_INVALID_ARGUMENT, "a fused program reads at most %d columns", kMaxCols);
+    if (ps.nvalues < 1 || ps.nvalues > kMaxValues) return fail(RDF_INVALID_ARGUMENT, "nvalues out of range");
+    if (ps.sink == RDF_SINK_STORE && ps.filter_root >= 0)
+        return fail(RDF_INVALID_ARGUMENT, "SINK_STORE with a filter: use rdf_predicate + rdf_filter_columns");
+    int32_t mem = -1;
+    RDF_TRY(check_mem(cols, (int64_t)ncols * nchunks, &mem));
+    if (mem < 0) mem = ps.sink == RDF_SINK_STORE && outs && nchunks > 0 ? outs[0].mem : RDF_MEM_HOST;
+    if (ps.sink == RDF_SINK_STORE && nchunks > 0) {
+        if (!outs) return fail(RDF_INVALID_ARGUMENT, "outs is null");
+        RDF_TRY(check_out_mem(outs, (int64_t)ps.nvalues * nchunks, mem));
+    }
+    if (ps.sink == RDF_SINK_AGG && !aggs) return fail(RDF_INVALID_ARGUMENT, "aggs is null");
+
+    // column dtypes: chunk 0 decides, every chunk must agree (ChunkedArray::from_arrays, src/table.rs:24-40)
+    int col_dtype[kMaxCols];
+    for (int k = 0; k < ncols; ++k) {
+        col_dtype[k] = nchunks > 0 ? cols[(int64_t)k * nchunks].dtype : RDF_F64;
+        if (!(is_numeric(col_dtype[k]) || col_dtype[k] == RDF_BOOL)) return fail(RDF_INVALID_ARGUMENT, "column %d: unsupported dtype %d", k, col_dtype[k]);
+        for (int64_t c = 0; c < nchunks; ++c)
+            if (cols[(int64_t)k * nchunks + c].dtype != col_dtype[k]) return fail(RDF_INVALID_ARGUMENT, "column %d: chunks differ in dtype", k);
+    }
+    // batch lengths: all columns of RecordBatch c have one length
+    std::vector<int64_t> clen((size_t)nchunks, 0);
+    int64_t total_rows = 0;
+    for (int64_t c = 0; c < nchunks; ++c) {
+        clen[(size_t)c] = ncols > 0 ? cols[c].length : 0;
+        for (int k = 1; k < ncols; ++k)
+            if (cols[(int64_t)k * nchunks + c].length != clen[(size_t)c]) return fail(RDF_COMPUTE_ERROR, "%s", len_mismatch_msg);
+        total_rows += clen[(size_t)c];
+    }
+
+    // compile
+    Compiler cc(ps.nodes, ps.nnodes, col_dtype, ncols);
+    int value_dtype[kMaxValues];
+    if (ps.filter_root >= 0) {
+        const int ft = cc.infer(ps.filter_root);
+        if (cc.st != RDF_OK) return cc.st;
+        if (ft != RDF_BOOL) return fail(RDF_INVALID_ARGUMENT, "predicate root must be boolean");
+        cc.gen(ps.filter_root);
+        cc.push(Compiler::mk(BC_FILTER));
+    }
+    for (int v = 0; v < ps.nvalues; ++v) {
+        value_dtype[v] = cc.infer(ps.value_roots[v]);
+        if (cc.st != RDF_OK) return cc.st;
+        if (ps.sink == RDF_SINK_AGG && !(is_numeric(value_dtype[v]) || value_dtype[v] == RDF_BOOL))
+            return fail(RDF_INVALID_ARGUMENT, "aggregate of a non-numeric value");
+        cc.gen(ps.value_roots[v]);
+        Instr e = Compiler::mk(BC_EMIT);
+        e.src = (uint16_t)v;
+        e.dtype = (uint8_t)value_dtype[v];
+        cc.push(e);
+    }
+    if (cc.st != RDF_OK) return cc.st;
+
+    // output validation (SINK_STORE)
+    if (ps.sink == RDF_SINK_STORE) {
+        for (int v = 0; v < ps.nvalues; ++v)
+            for (int64_t c = 0; c < nchunks; ++c) {
+                rdf_out& o = outs[(int64_t)v * nchunks + c];
+                if (o.dtype != value_dtype[v]) return fail(RDF_INVALID_ARGUMENT, "output dtype %d != expression dtype %d", o.dtype, value_dtype[v]);
+                if (o.capacity < clen[(size_t)c]) return fail(RDF_MEMORY_ERROR, "output capacity too small");
+                bool nullable = false;
+                for (int k = 0; k < ncols; ++k) nullable |= cols[(int64_t)k * nchunks + c].validity != nullptr;
+                if (nullable && !o.validity) return fail(RDF_INVALID_ARGUMENT, "output validity buffer required");
+                if (clen[(size_t)c] > 0 && !o.values) return fail(RDF_INVALID_ARGUMENT, "null output values pointer");
+            }
+    }
+
+    // nothing to launch
+    if (total_rows == 0) {
+        if (ps.sink == RDF_SINK_STORE) {
+            for (int64_t i = 0; i < (int64_t)ps.nvalues * nchunks; ++i) { outs[i].length = 0; outs[i].null_count = 0; }
+        } else {
+            for (int v = 0; v < ps.nvalues; ++v) { memset(&aggs[v], 0, sizeof aggs[v]); aggs[v].dtype = value_dtype[v]; }
+        }
+        return RDF_OK;
+    }
+
+    RDF_TRY(ensure_ready());
+    Ctx& ctx = g_ctx;
+    arena_begin();
+    size_t pin_off = 0, pin_used = 0;
+
+    // inputs
+    InputStager in;
+    for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) in.add(&cols[i]);
+    RDF_TRY(in.finish(pin_off, &pin_used));
+    pin_off += (pin_used + 255) & ~(size_t)255;
+
+    // outputs (SINK_STORE)
+    Region outr;
+    std::vector<DevOutChunk> dev_outs;
+    std::vector<int> out_val_item, out_vld_item;
+    if (ps.sink == RDF_SINK_STORE) {
+        dev_outs.resize((size_t)ps.nvalues * nchunks);
+        if (mem == RDF_MEM_HOST) {
+            out_val_item.assign(dev_outs.size(), -1);
+            out_vld_item.assign(dev_outs.size(), -1);
+            for (int v = 0; v < ps.nvalues; ++v)
+                for (int64_t c = 0; c < nchunks; ++c) {
+                    const size_t i = (size_t)((int64_t)v * nchunks + c);
+                    const int64_t n = clen[(size_t)c];
+                    if (n == 0) continue;
+                    const size_t vb = value_dtype[v] == RDF_BOOL ? (size_t)((n + 7) / 8) : (size_t)n * (size_t)dtype_size(value_dtype[v]);
+                    out_val_item[i] = outr.add(outs[i].values, vb);
+                    if (outs[i].validity) out_vld_item[i] = outr.add(outs[i].validity, (size_t)((n + 7) / 8));
+                }
+            // word-granular bitmap stores need the items padded to 8 bytes: Region pads every item by >= 16
+            RDF_TRY(outr.layout());
+            for (size_t i = 0; i < dev_outs.size(); ++i) {
+                dev_outs[i].values = out_val_item[i] >= 0 ? outr.ptr(out_val_item[i]) : nullptr;
+                dev_outs[i].validity = out_vld_item[i] >= 0 ? (uint8_t*)outr.ptr(out_vld_item[i]) : nullptr;
+            }
+        } else {
+            for (size_t i = 0; i < dev_outs.size(); ++i) dev_outs[i] = DevOutChunk{outs[i].values, outs[i].validity};
+        }
+    }
+
+    // tiles
+    std::vector<int64_t> tile_start((size_t)nchunks + 1, 0);
+    for (int64_t c = 0; c < nchunks; ++c) tile_start[(size_t)c + 1] = tile_start[(size_t)c] + (clen[(size_t)c] + kEvalTile - 1) / kEvalTile;
+    const int64_t ntiles = tile_start[(size_t)nchunks];
+    int grid = (int)(ntiles < (int64_t)eval_grid_limit() ? ntiles : (int64_t)eval_grid_limit());
+
+    // device scratch: flags | null counts | partials | result
+    const size_t n_nc = ps.sink == RDF_SINK_STORE ? (size_t)ps.nvalues * (size_t)nchunks : 0;
+    const size_t scratch_bytes = 16 + n_nc * 8 + ((size_t)grid + 1) * (size_t)ps.nvalues * sizeof(AggPartial);
+    void* scratch = nullptr;
+    RDF_TRY(arena_alloc(scratch_bytes, &scratch));
+    uint32_t* d_flags = (uint32_t*)scratch;
+    int64_t* d_nullc = (int64_t*)((char*)scratch + 16);
+    AggPartial* d_partials = (AggPartial*)((char*)scratch + 16 + n_nc * 8);
+    AggPartial* d_result = d_partials + (size_t)grid * (size_t)ps.nvalues;
+    HIP_TRY(hipMemsetAsync(scratch, 0, 16 + n_nc * 8, ctx.stream));
+
+    EvalArgs ea;
+    memset(&ea, 0, sizeof ea);
+    ea.nchunks = nchunks;
+    ea.ntiles = ntiles;
+    ea.ncols = ncols;
+    ea.nvalues = ps.nvalues;
+    ea.ncode = (int)cc.code.size();
+    ea.ntmp = cc.tmp_max;
+    ea.flags = d_flags;
+    ea.out_null_counts = d_nullc;
+    ea.partials = d_partials;
+    for (int k = 0; k < ncols; ++k) ea.col_dtype[k] = col_dtype[k];
+    int cls[kMaxValues] = {0, 0, 0, 0};
+    for (int v = 0; v < ps.nvalues; ++v) { cls[v] = value_class(value_dtype[v]); ea.value_cls[v] = cls[v]; }
+    memcpy(ea.code, cc.code.data(), cc.code.size() * sizeof(Instr));
+
+    TableBuilder tb;
+    if (nchunks == 1) {
+        for (int k = 0; k < ncols; ++k) ea.inline_cols[k] = in.dev[(size_t)k];
+        for (int v = 0; v < ps.nvalues && ps.sink == RDF_SINK_STORE; ++v) ea.inline_outs[v] = dev_outs[(size_t)v];
+        ea.inline_len = clen[0];
+    } else {
+        const size_t o_cols = tb.reserve(sizeof(DevChunkCol) * in.dev.size());
+        const size_t o_ts = tb.reserve(sizeof(int64_t) * tile_start.size());
+        const size_t o_len = tb.reserve(sizeof(int64_t) * clen.size());
+        const size_t o_outs = tb.reserve(sizeof(DevOutChunk) * (dev_outs.size() + 1));
+        memcpy(tb.at<char>(o_cols), in.dev.data(), sizeof(DevChunkCol) * in.dev.size());
+        memcpy(tb.at<char>(o_ts), tile_start.data(), sizeof(int64_t) * tile_start.size());
+        memcpy(tb.at<char>(o_len), clen.data(), sizeof(int64_t) * clen.size());
+        if (!dev_outs.empty()) memcpy(tb.at<char>(o_outs), dev_outs.data(), sizeof(DevOutChunk) * dev_outs.size());
+        RDF_TRY(tb.alloc());
+        RDF_TRY(tb.upload(pin_off));
+        pin_off += (tb.host.size() + 255) & ~(size_t)255;
+        ea.cols = tb.dev_at<DevChunkCol>(o_cols);
+        ea.chunk_tile_start = tb.dev_at<int64_t>(o_ts);
+        ea.chunk_len = tb.dev_at<int64_t>(o_len);
+        ea.outs = tb.dev_at<DevOutChunk>(o_outs);
+    }
+
+    if (ps.sink == RDF_SINK_AGG) {
+        // fast path: filter(x CMP c) -> aggregates of y, both f64, one chunk, 16-byte-alignable
+        FilterAggF64Args fa;
+        bool fast = false;
+        int cmp = 0;
+        if (nchunks == 1 && ps.nvalues == 1 && ps.filter_root >= 0) {
+            const rdf_expr_node& fr = ps.nodes[ps.filter_root];
+            const rdf_expr_node& vr = ps.nodes[ps.value_roots[0]];
+            if (fr.kind == RDF_NODE_OP && op_is_cmp(fr.op) && vr.kind == RDF_NODE_COLUMN && col_dtype[vr.column] == RDF_F64) {
+                const rdf_expr_node& L = ps.nodes[fr.lhs];
+                const rdf_expr_node& R = ps.nodes[fr.rhs];
+                const rdf_expr_node* coln = nullptr;
+                const rdf_expr_node* sc = nullptr;
+                cmp = fr.op;
+                if (L.kind == RDF_NODE_COLUMN && R.kind == RDF_NODE_SCALAR) { coln = &L; sc = &R; }
+                else if (L.kind == RDF_NODE_SCALAR && R.kind == RDF_NODE_COLUMN) {
+                    coln = &R; sc = &L;  // c CMP x  ==  x CMP' c
+                    cmp = fr.op == RDF_OP_GT ? RDF_OP_LT : fr.op == RDF_OP_GE ? RDF_OP_LE : fr.op == RDF_OP_LT ? RDF_OP_GT : fr.op == RDF_OP_LE ? RDF_OP_GE : fr.op;
+                }
+                if (coln && col_dtype[coln->column] == RDF_F64 && sc->dtype != RDF_NULLTYPE && (is_numeric(sc->dtype) || sc->dtype == RDF_BOOL)) {
+                    const DevChunkCol& x = in.dev[(size_t)coln->column];
+                    const DevChunkCol& y = in.dev[(size_t)vr.column];
+                    const uintptr_t xa = (uintptr_t)((const double*)x.values + x.offset), ya = (uintptr_t)((const double*)y.values + y.offset);
+                    if ((xa & 7) == 0 && (ya & 7) == 0 && (xa & 15) == (ya & 15)) {
+                        memset(&fa, 0, sizeof fa);
+                        fa.x = (const double*)x.values; fa.x_validity = x.validity; fa.x_offset = x.offset;
+                        fa.y = (const double*)y.values; fa.y_validity = y.validity; fa.y_offset = y.offset;
+                        fa.n = clen[0];
+                        const uint64_t cu = cc.imm_for(*sc, RDF_F64);
+                        memcpy(&fa.c, &cu, 8);
+                        fa.partials = d_partials;
+                        fast = true;
+                    }
+                }
+            }
+        }
+        if (fast) {
+            const int64_t per_block = (int64_t)kBlock * 4 * 2;  // rows per block iteration
+            int64_t want = (clen[0] + per_block - 1) / per_block;
+            grid = (int)(want < (int64_t)eval_grid_limit() ? want : (int64_t)eval_grid_limit());
+            if (grid < 1) grid = 1;
+            // partials/result were sized for the eval grid (>= this grid, since its tiles are smaller)
+            d_result = d_partials + (size_t)grid * (size_t)ps.nvalues;
+            RDF_TRY(launch_agg_pair(nullptr, &fa, cmp, false, grid, 1, cls, d_partials, d_result));
+        } else {
+            RDF_TRY(launch_agg_pair(&ea, nullptr, 0, cc.heavy, grid, ps.nvalues, cls, d_partials, d_result));
+        }
+        // results: flags + aggregates in one D2H
+        RDF_TRY(pinned_reserve(pin_off + 64 + sizeof(AggPartial) * kMaxValues));
+        char* pin = ctx.pinned + pin_off;
+        HIP_TRY(hipMemcpyAsync(pin, d_flags, 16, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipMemcpyAsync(pin + 64, d_result, sizeof(AggPartial) * (size_t)ps.nvalues, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        uint32_t flags;
+        memcpy(&flags, pin, 4);
+        if (flags & 1u) return fail(RDF_DIVIDE_BY_ZERO, "Divide by zero error");
+        for (int v = 0; v < ps.nvalues; ++v) {
+            AggPartial p;
+            memcpy(&p, pin + 64 + sizeof(AggPartial) * (size_t)v, sizeof p);
+            fill_agg_result(&aggs[v], value_dtype[v], p);
+        }
+        return RDF_OK;
+    }
+
+    // SINK_STORE
+    {
+        KernelTimer kt;
+        HIP_TRY(launch_eval(ea, SINK_STORE, cc.heavy, grid, ctx.stream));
+        kt.stop();
+    }
+    RDF_TRY(pinned_reserve(pin_off + 64 + n_nc * 8 + outr.small_bytes + 256));
+    char* pin = ctx.pinned + pin_off;
+    HIP_TRY(hipMemcpyAsync(pin, scratch, 16 + n_nc * 8, hipMemcpyDeviceToHost, ctx.stream));
+    if (mem == RDF_MEM_HOST) RDF_TRY(outr.download(pin_off + ((16 + n_nc * 8 + 255) & ~(size_t)255)));
+    else HIP_TRY(hipStreamSynchronize(ctx.stream));
+    uint32_t flags;
+    memcpy(&flags, pin, 4);
+    if (flags & 1u) return fail(RDF_DIVIDE_BY_ZERO, "Divide by zero error");
+    for (int v = 0; v < ps.nvalues; ++v)
+        for (int64_t c = 0; c < nchunks; ++c) {
+            rdf_out& o = outs[(int64_t)v * nchunks + c];
+            o.length = clen[(size_t)c];
+            memcpy(&o.null_count, pin + 16 + 8 * (size_t)((int64_t)v * nchunks + c), 8);
+        }
+    return RDF_OK;
+}
+
+// one-node-per-op helper for the single-kernel entry points
+rdf_expr_node node_col(int c) { rdf_expr_node n; memset(&n, 0, sizeof n); n.kind = RDF_NODE_COLUMN; n.column = c; n.lhs = n.rhs = -1; return n; }
+rdf_expr_node node_op(int op, int l, int r, int dtype = 0) { rdf_expr_node n; memset(&n, 0, sizeof n); n.kind = RDF_NODE_OP; n.op = op; n.lhs = l; n.rhs = r; n.dtype = dtype; return n; }
+
+rdf_status agg_column(const rdf_array* a, int64_t nchunks, bool as_f64, rdf_agg_result* r) {
+    rdf_expr_node nodes[2] = {node_col(0), node_op(RDF_OP_CAST, 0, -1, RDF_F64)};
+    ProgramSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.nodes = nodes; ps.nnodes = 2; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = as_f64 ? 1 : 0; ps.sink = RDF_SINK_AGG;
+    return run_program(ps, a, 1, nchunks, nullptr, r, "chunk length mismatch");
+}
+
+void store_native(void* out, int dt, const rdf_agg_result& r, int which /*0 sum 1 min 2 max*/) {
+    if (is_float(dt)) {
+        const double v = which == 0 ? r.sum_f64 : which == 1 ? r.min_f64 : r.max_f64;
+        if (dt == RDF_F64) *(double*)out = v; else *(float*)out = (float)v;
+        return;
+    }
+    const int64_t v = which == 0 ? r.sum_i64 : which == 1 ? r.min_i64 : r.max_i64;
+    switch (dtype_size(dt)) {
+        case 1: *(uint8_t*)out = (uint8_t)v; break;
+        case 2: *(uint16_t*)out = (uint16_t)v; break;
+        case 4: *(uint32_t*)out = (uint32_t)v; break;
+        default: *(uint64_t*)out = (uint64_t)v; break;
+    }
+}
+
+rdf_status agg_entry(const rdf_array* a, int64_t nchunks, void* out_scalar, int32_t* out_is_some, int which, const char* name) {
+    if (!out_scalar || !out_is_some) return fail(RDF_INVALID_ARGUMENT, "%s: null output pointer", name);
+    // a column always has at least one chunk (ChunkedArray::from_arrays asserts, src/table.rs:25)
+    if (nchunks < 1 || !a) return fail(RDF_INVALID_ARGUMENT, "%s: a column has at least one chunk", name);
+    if (!is_numeric(a[0].dtype)) return fail(RDF_INVALID_ARGUMENT, "%s: numeric type required", name);
+    rdf_agg_result r;
+    RDF_TRY(agg_column(a, nchunks, false, &r));
+    if (which == 0) { store_native(out_scalar, a[0].dtype, r, 0); *out_is_some = 1; }
+    else { *out_is_some = r.is_some; if (r.is_some) store_native(out_scalar, a[0].dtype, r, which); }
+    return RDF_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// extern "C" boundary
+
+extern "C" {
+
+const char* rdf_version(void) { return "rdf_mi355x 0.1.0 (gfx950)"; }
+const char* rdf_last_error(void) { return g_ctx.err.c_str(); }
+
+rdf_status rdf_device_count(int32_t* count) {
+    if (!count) return fail(RDF_INVALID_ARGUMENT, "null pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = e == hipSuccess ? n : 0;
+    if (e != hipSuccess) return fail(RDF_DEVICE_ERROR, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return RDF_OK;
+}
+
+rdf_status rdf_set_device(int32_t device) {
+    Ctx& c = g_ctx;
+    if (c.ready && c.device == device) return RDF_OK;
+    if (c.ready) {  // drop everything tied to the old device
+        (void)hipStreamSynchronize(c.stream);
+        for (void* p : c.arena.overflow) (void)hipFree(p);
+        c.arena.overflow.clear();
+        if (c.arena.base) (void)hipFree(c.arena.base);
+        c.arena = Arena();
+        for (auto& ev : c.events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        c.events.clear();
+        c.events_used = 0;
+        if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
+        c.own_stream = c.stream = nullptr;
+        c.ready = false;
+    }
+    HIP_TRY(hipSetDevice(device));
+    return ensure_ready();
+}
+
+rdf_status rdf_set_stream(void* hip_stream) {
+    RDF_TRY(ensure_ready());
+    g_ctx.stream = hip_stream ? (hipStream_t)hip_stream : g_ctx.own_stream;
+    return RDF_OK;
+}
+
+rdf_status rdf_synchronize(void) {
+    RDF_TRY(ensure_ready());
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    return RDF_OK;
+}
+
+rdf_status rdf_dev_alloc(void** ptr, int64_t bytes) {
+    if (!ptr || bytes < 0) return fail(RDF_INVALID_ARGUMENT, "bad arguments");
+    RDF_TRY(ensure_ready());
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)bytes + 64);
+    if (e != hipSuccess) return fail(RDF_MEMORY_ERROR, "hipMalloc(%lld): %s", (long long)bytes, hipGetErrorString(e));
+    *ptr = p;
+    return RDF_OK;
+}
+rdf_status rdf_dev_free(void* ptr) {
+    if (!ptr) return RDF_OK;
+    RDF_TRY(ensure_ready());
+    HIP_TRY(hipFree(ptr));
+    return RDF_OK;
+}
+rdf_status rdf_copy_h2d(void* dst_dev, const void* src_host, int64_t bytes) {
+    RDF_TRY(ensure_ready());
+    if (bytes > 0) {
+        HIP_TRY(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    return RDF_OK;
+}
+rdf_status rdf_copy_d2h(void* dst_host, const void* src_dev, int64_t bytes) {
+    RDF_TRY(ensure_ready());
+    if (bytes > 0) {
+        HIP_TRY(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    return RDF_OK;
+}
+
+// ---------------------------------------------------------------- scalar kernels
+
+rdf_status rdf_binary(int32_t op, const rdf_array* a, const rdf_array* b, int64_t nchunks, rdf_out* out) {
+    if (!(op_is_arith(op) || op_is_fbinary(op))) return fail(RDF_INVALID_ARGUMENT, "not a binary op: %d", op);
+    if (nchunks < 0 || (nchunks > 0 && (!a || !b || !out))) return fail(RDF_INVALID_ARGUMENT, "bad chunk lists");
+    if (nchunks == 0) return RDF_OK;
+    for (int64_t c = 0; c < nchunks; ++c)  // compute::add(a, b): per-pair length check comes first
+        if (a[c].length != b[c].length) return fail(RDF_COMPUTE_ERROR, "Cannot perform math operation on arrays of different length");
+    std::vector<rdf_array> cols((size_t)(2 * nchunks));
+    for (int64_t c = 0; c < nchunks; ++c) { cols[(size_t)c] = a[c]; cols[(size_t)(nchunks + c)] = b[c]; }
+    rdf_expr_node nodes[3] = {node_col(0), node_col(1), node_op(op, 0, 1)};
+    ProgramSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.nodes = nodes; ps.nnodes = 3; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = 2; ps.sink = RDF_SINK_STORE;
+    return run_program(ps, cols.data(), 2, nchunks, out, nullptr, "Cannot perform math operation on arrays of different length");
+}
+
+rdf_status rdf_unary(int32_t op, const rdf_array* a, int64_t nchunks, rdf_out* out) {
+    if (!op_is_unary_math(op)) return fail(RDF_INVALID_ARGUMENT, "not a unary op: %d", op);
+    if (nchunks < 0 || (nchunks > 0 && (!a || !out))) return fail(RDF_INVALID_ARGUMENT, "bad chunk lists");
+    if (nchunks == 0) return RDF_OK;
+    rdf_expr_node nodes[2] = {node_col(0), node_op(op, 0, -1)};
+    ProgramSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.nodes = nodes; ps.nnodes = 2; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = 1; ps.sink = RDF_SINK_STORE;
+    return run_program(ps, a, 1, nchunks, out, nullptr, "chunk length mismatch");
+}
+
+rdf_status rdf_cast(const rdf_array* a, int64_t nchunks, rdf_out* out) {
+    if (nchunks < 0 || (nchunks > 0 && (!a || !out))) return fail(RDF_INVALID_ARGUMENT, "bad chunk lists");
+    if (nchunks == 0) return RDF_OK;
+    rdf_expr_node nodes[2] = {node_col(0), node_op(RDF_OP_CAST, 0, -1, out[0].dtype)};
+    ProgramSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.nodes = nodes; ps.nnodes = 2; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = 1; ps.sink = RDF_SINK_STORE;
+    return run_program(ps, a, 1, nchunks, out, nullptr, "chunk length mismatch");
+}
+
+// ---------------------------------------------------------------- aggregates
+
+rdf_status rdf_sum(const rdf_array* a, int64_t nchunks, void* out_scalar, int32_t* out_is_some) { return agg_entry(a, nchunks, out_scalar, out_is_some, 0, "sum"); }
+rdf_status rdf_min(const rdf_array* a, int64_t nchunks, void* out_scalar, int32_t* out_is_some) { return agg_entry(a, nchunks, out_scalar, out_is_some, 1, "min"); }
+rdf_status rdf_max(const rdf_array* a, int64_t nchunks, void* out_scalar, int32_t* out_is_some) { return agg_entry(a, nchunks, out_scalar, out_is_some, 2, "max"); }
+
+rdf_status rdf_count(const rdf_array* a, int64_t nchunks, int64_t* out_count, int32_t* out_is_some) {
+    if (!out_count || !out_is_some) return fail(RDF_INVALID_ARGUMENT, "count: null output pointer");
+    if (nchunks < 0 || (nchunks > 0 && !a)) return fail(RDF_INVALID_ARGUMENT, "count: bad chunk list");
+    *out_is_some = 1;  // Some(sum) always (aggregate.rs:79)
+    bool known = true;
+    int64_t sum = 0;
+    for (int64_t c = 0; c < nchunks; ++c) {
+        if (a[c].validity == nullptr) sum += a[c].length;
+        else if (a[c].null_count >= 0) sum += a[c].length - a[c].null_count;
+        else known = false;
+    }
+    if (known) { *out_count = sum; return RDF_OK; }  // O(#chunks), metadata only — like the reference
+    rdf_agg_result r;
+    RDF_TRY(agg_column(a, nchunks, false, &r));  // count the validity bits on the device
+    *out_count = r.count;
+    return RDF_OK;
+}
+
+rdf_status rdf_avg(const rdf_array* a, int64_t nchunks, double* out_mean, int32_t* out_is_some) {
+    if (!out_mean || !out_is_some) return fail(RDF_INVALID_ARGUMENT, "avg: null output pointer");
+    if (nchunks < 0 || (nchunks > 0 && !a)) return fail(RDF_INVALID_ARGUMENT, "avg: bad chunk list");
+    if (nchunks == 0) { *out_is_some = 0; return RDF_OK; }
+    if (!is_numeric(a[0].dtype)) return fail(RDF_INVALID_ARGUMENT, "avg: numeric type required");
+    rdf_agg_result r;
+    RDF_TRY(agg_column(a, nchunks, true, &r));  // f64::from(value) then mean, aggregate.rs:47
+    *out_is_some = r.is_some;
+    if (r.is_some) *out_mean = r.sum_f64 / (double)r.count;
+    return RDF_OK;
+}
+
+// ---------------------------------------------------------------- expressions
+
+rdf_status rdf_predicate(const rdf_expr_node* nodes, int32_t nnodes, int32_t root, const rdf_array* cols, int32_t ncols,
+                         int64_t nchunks, rdf_out* mask) {
+    if (!nodes || nnodes <= 0) return fail(RDF_INVALID_ARGUMENT, "empty expression");
+    if (nchunks < 0 || (nchunks > 0 && !mask)) return fail(RDF_INVALID_ARGUMENT, "bad chunk lists");
+    if (nchunks == 0) return RDF_OK;
+    ProgramSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.nodes = nodes; ps.nnodes = nnodes; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = root; ps.sink = RDF_SINK_STORE;
+    for (int64_t c = 0; c < nchunks; ++c)
+        if (mask[c].dtype != RDF_BOOL) return fail(RDF_INVALID_ARGUMENT, "predicate root must be boolean");
+    return run_program(ps, cols, ncols, nchunks, mask, nullptr, "columns of a batch differ in length");
+}
+
+rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_out* outs,
+                        rdf_agg_result* aggs) {
+    if (!prog || !prog->nodes || prog->nnodes <= 0) return fail(RDF_INVALID_ARGUMENT, "empty program");
+    if (prog->nvalues < 1 || prog->nvalues > RDF_MAX_VALUES) return fail(RDF_INVALID_ARGUMENT, "nvalues out of range");
+    ProgramSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.nodes = prog->nodes; ps.nnodes = prog->nnodes; ps.filter_root = prog->filter_root; ps.nvalues = prog->nvalues; ps.sink = prog->sink;
+    for (int v = 0; v < prog->nvalues; ++v) ps.value_roots[v] = prog->value_roots[v];
+    if (ps.sink != RDF_SINK_STORE && ps.sink != RDF_SINK_AGG) return fail(RDF_INVALID_ARGUMENT, "bad sink");
+    return run_program(ps, cols, ncols, nchunks, outs, aggs, "columns of a batch differ in length");
+}
+
+// ---------------------------------------------------------------- filter / take
+
+namespace {
+
+struct FilterPrep {
+    InputStager in;         // mask chunks first, then the columns
+    TableBuilder tb;
+    MaskTables mt;
+    std::vector<int64_t> clen, tile_start;
+    int64_t ntiles = 0;
+    int64_t* d_counts = nullptr;  // [ntiles]
+    int64_t* d_scan = nullptr;    // [ntiles + 1]
+    size_t o_cols = 0, o_outs = 0;
+    size_t pin_off = 0;
+};
+
+// Stage mask (+ columns), build the tile tables, run count + scan; leaves per-chunk keep totals in `totals`.
+rdf_status filter_prepare(FilterPrep& fp, const rdf_array* cols, int ncols, const rdf_array* mask, int64_t nchunks,
+                          std::vector<int64_t>& totals) {
+    Ctx& ctx = g_ctx;
+    for (int64_t c = 0; c < nchunks; ++c) fp.in.add(&mask[c]);
+    for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) fp.in.add(&cols[i]);
+    size_t used = 0;
+    RDF_TRY(fp.in.finish(fp.pin_off, &used));
+    fp.pin_off += (used + 255) & ~(size_t)255;
+
+    fp.clen.resize((size_t)nchunks);
+    fp.tile_start.assign((size_t)nchunks + 1, 0);
+    for (int64_t c = 0; c < nchunks; ++c) {
+        fp.clen[(size_t)c] = mask[c].length;
+        fp.tile_start[(size_t)c + 1] = fp.tile_start[(size_t)c] + (mask[c].length + kFilterTile - 1) / kFilterTile;
+    }
+    fp.ntiles = fp.tile_start[(size_t)nchunks];
+
+    const size_t o_mask = fp.tb.reserve(sizeof(DevChunkCol) * (size_t)nchunks);
+    const size_t o_ts = fp.tb.reserve(sizeof(int64_t) * fp.tile_start.size());
+    const size_t o_len = fp.tb.reserve(sizeof(int64_t) * fp.clen.size());
+    fp.o_cols = fp.tb.reserve(sizeof(DevChunkCol) * ((size_t)ncols * (size_t)nchunks + 1));
+    fp.o_outs = fp.tb.reserve(sizeof(DevOutChunk) * ((size_t)ncols * (size_t)nchunks + 1));
+    memcpy(fp.tb.at<char>(o_mask), fp.in.dev.data(), sizeof(DevChunkCol) * (size_t)nchunks);
+    memcpy(fp.tb.at<char>(o_ts), fp.tile_start.data(), sizeof(int64_t) * fp.tile_start.size());
+    memcpy(fp.tb.at<char>(o_len), fp.clen.data(), sizeof(int64_t) * fp.clen.size());
+    if (ncols > 0) memcpy(fp.tb.at<char>(fp.o_cols), fp.in.dev.data() + nchunks, sizeof(DevChunkCol) * (size_t)ncols * (size_t)nchunks);
+    RDF_TRY(fp.tb.alloc());
+    // the outs table is filled in later (after the counts are known): upload the front part now
+    RDF_TRY(fp.tb.upload(fp.pin_off));
+    fp.pin_off += (fp.tb.host.size() + 255) & ~(size_t)255;
+
+    fp.mt.mask = fp.tb.dev_at<DevChunkCol>(o_mask);
+    fp.mt.chunk_tile_start = fp.tb.dev_at<int64_t>(o_ts);
+    fp.mt.chunk_len = fp.tb.dev_at<int64_t>(o_len);
+    fp.mt.nchunks = nchunks;
+    fp.mt.ntiles = fp.ntiles;
+
+    void* p = nullptr;
+    RDF_TRY(arena_alloc(sizeof(int64_t) * (2 * (size_t)fp.ntiles + 2), &p));
+    fp.d_counts = (int64_t*)p;
+    fp.d_scan = fp.d_counts + fp.ntiles;
+    HIP_TRY(launch_mask_count(fp.mt, fp.d_counts, ctx.stream));
+    HIP_TRY(launch_scan(fp.d_counts, fp.d_scan, fp.ntiles, ctx.stream));
+
+    // per-chunk totals = scan[tile_start[c+1]] - scan[tile_start[c]]: fetch the nchunks+1 boundary values
+    totals.assign((size_t)nchunks, 0);
+    if (nchunks <= 64) {
+        RDF_TRY(pinned_reserve(fp.pin_off + 8 * ((size_t)nchunks + 1)));
+        int64_t* pin = (int64_t*)(ctx.pinned + fp.pin_off);
+        for (int64_t c = 0; c <= nchunks; ++c)
+            HIP_TRY(hipMemcpyAsync(pin + c, fp.d_scan + fp.tile_start[(size_t)c], 8, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        for (int64_t c = 0; c < nchunks; ++c) totals[(size_t)c] = pin[c + 1] - pin[c];
+    } else {
+        RDF_TRY(pinned_reserve(fp.pin_off + 8 * ((size_t)fp.ntiles + 1)));
+        int64_t* pin = (int64_t*)(ctx.pinned + fp.pin_off);
+        HIP_TRY(hipMemcpyAsync(pin, fp.d_scan, 8 * ((size_t)fp.ntiles + 1), hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        for (int64_t c = 0; c < nchunks; ++c) totals[(size_t)c] = pin[fp.tile_start[(size_t)c + 1]] - pin[fp.tile_start[(size_t)c]];
+    }
+    return RDF_OK;
+}
+
+rdf_status filter_validate(const rdf_array* cols, int ncols, const rdf_array* mask, int64_t nchunks, int32_t* mem) {
+    if (nchunks < 0 || (nchunks > 0 && !mask)) return fail(RDF_INVALID_ARGUMENT, "bad chunk lists");
+    RDF_TRY(check_mem(mask, nchunks, mem));
+    RDF_TRY(check_mem(cols, (int64_t)ncols * nchunks, mem));
+    for (int64_t c = 0; c < nchunks; ++c) {
+        if (mask[c].dtype != RDF_BOOL) return fail(RDF_INVALID_ARGUMENT, "filter mask must be boolean");
+        for (int k = 0; k < ncols; ++k) {
+            const rdf_array& a = cols[(int64_t)k * nchunks + c];
+            if (a.length != mask[c].length) return fail(RDF_COMPUTE_ERROR, "Filter array must have the same length as the data array");
+            if (!is_numeric(a.dtype)) return fail(RDF_INVALID_ARGUMENT, "filter: unsupported dtype %d", a.dtype);
+        }
+    }
+    return RDF_OK;
+}
+
+}  // namespace
+
+rdf_status rdf_filter_count(const rdf_array* mask, int64_t nchunks, int64_t* counts) {
+    int32_t mem = -1;
+    RDF_TRY(filter_validate(nullptr, 0, mask, nchunks, &mem));
+    if (nchunks == 0) return RDF_OK;
+    if (!counts) return fail(RDF_INVALID_ARGUMENT, "counts is null");
+    RDF_TRY(ensure_ready());
+    arena_begin();
+    FilterPrep fp;
+    std::vector<int64_t> totals;
+    RDF_TRY(filter_prepare(fp, nullptr, 0, mask, nchunks, totals));
+    for (int64_t c = 0; c < nchunks; ++c) counts[c] = totals[(size_t)c];
+    return RDF_OK;
+}
+
+rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_array* mask, int64_t nchunks, rdf_out* outs) {
+    if (ncols < 1 || ncols > kMaxFilterCols) return fail(RDF_INVALID_ARGUMENT, "filter: 1..%d columns per call", kMaxFilterCols);
+    int32_t mem = -1;
+    RDF_TRY(filter_validate(cols, ncols, mask, nchunks, &mem));
+    if (nchunks == 0) return RDF_OK;
+    if (!outs) return fail(RDF_INVALID_ARGUMENT, "outs is null");
+    RDF_TRY(check_out_mem(outs, (int64_t)ncols * nchunks, mem));
+    for (int k = 0; k < ncols; ++k)
+        for (int64_t c = 0; c < nchunks; ++c) {
+            const rdf_array& a = cols[(int64_t)k * nchunks + c];
+            const rdf_out& o = outs[(int64_t)k * nchunks + c];
+            if (o.dtype != a.dtype) return fail(RDF_INVALID_ARGUMENT, "filter: output dtype mismatch");
+            if (a.dtype != cols[(int64_t)k * nchunks].dtype) return fail(RDF_INVALID_ARGUMENT, "filter: chunks differ in dtype");
+            if (a.validity && !o.validity) return fail(RDF_INVALID_ARGUMENT, "output validity buffer required");
+        }
+    RDF_TRY(ensure_ready());
+    Ctx& ctx = g_ctx;
+    arena_begin();
+    FilterPrep fp;
+    std::vector<int64_t> totals;
+    RDF_TRY(filter_prepare(fp, cols, ncols, mask, nchunks, totals));
+    for (int k = 0; k < ncols; ++k)
+        for (int64_t c = 0; c < nchunks; ++c)
+            if (outs[(int64_t)k * nchunks + c].capacity < totals[(size_t)c]) return fail(RDF_MEMORY_ERROR, "output capacity too small");
+
+    // outputs
+    const size_t nout = (size_t)ncols * (size_t)nchunks;
+    std::vector<DevOutChunk> dev_outs(nout);
+    Region outr;
+    std::vector<int> vi(nout, -1), bi(nout, -1);
+    if (mem == RDF_MEM_HOST) {
+        for (int k = 0; k < ncols; ++k)
+            for (int64_t c = 0; c < nchunks; ++c) {
+                const size_t i = (size_t)((int64_t)k * nchunks + c);
+                const int64_t n = totals[(size_t)c];
+                if (n == 0) continue;
+                vi[i] = outr.add(outs[i].values, (size_t)n * (size_t)dtype_size(outs[i].dtype));
+                if (cols[i].validity) bi[i] = outr.add(outs[i].validity, (size_t)((n + 7) / 8));
+            }
+        RDF_TRY(outr.layout());
+        // validity bitmaps are OR-accumulated: zero the whole region once
+        HIP_TRY(hipMemsetAsync(outr.dev, 0, outr.total ? outr.total : 256, ctx.stream));
+        for (size_t i = 0; i < nout; ++i) {
+            dev_outs[i].values = vi[i] >= 0 ? outr.ptr(vi[i]) : nullptr;
+            dev_outs[i].validity = bi[i] >= 0 ? (uint8_t*)outr.ptr(bi[i]) : nullptr;
+        }
+    } else {
+        for (size_t i = 0; i < nout; ++i) {
+            dev_outs[i] = DevOutChunk{outs[i].values, cols[i].validity ? outs[i].validity : nullptr};
+            const int64_t n = totals[(size_t)(i % (size_t)nchunks)];
+            if (dev_outs[i].validity && n > 0) HIP_TRY(hipMemsetAsync(dev_outs[i].validity, 0, (size_t)((n + 63) / 64 * 8), ctx.stream));
+        }
+    }
+    // upload the outs table + null counters
+    void* p = nullptr;
+    RDF_TRY(arena_alloc(sizeof(int64_t) * nout, &p));
+    int64_t* d_nullc = (int64_t*)p;
+    HIP_TRY(hipMemsetAsync(d_nullc, 0, sizeof(int64_t) * nout, ctx.stream));
+    RDF_TRY(pinned_reserve(fp.pin_off + sizeof(DevOutChunk) * nout + 256));
+    memcpy(ctx.pinned + fp.pin_off, dev_outs.data(), sizeof(DevOutChunk) * nout);
+    HIP_TRY(hipMemcpyAsync(fp.tb.dev + fp.o_outs, ctx.pinned + fp.pin_off, sizeof(DevOutChunk) * nout, hipMemcpyHostToDevice, ctx.stream));
+    fp.pin_off += (sizeof(DevOutChunk) * nout + 255) & ~(size_t)255;
+
+    FilterArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.t = fp.mt;
+    fa.cols = fp.tb.dev_at<DevChunkCol>(fp.o_cols);
+    fa.outs = fp.tb.dev_at<DevOutChunk>(fp.o_outs);
+    fa.out_null_counts = d_nullc;
+    fa.tile_scan = fp.d_scan;
+    fa.ncols = ncols;
+    for (int k = 0; k < ncols; ++k) fa.esize[k] = dtype_size(cols[(int64_t)k * nchunks].dtype);
+    {
+        KernelTimer kt;
+        HIP_TRY(launch_compact(fa, ctx.stream));
+        kt.stop();
+    }
+    RDF_TRY(pinned_reserve(fp.pin_off + 8 * nout + 256 + outr.small_bytes + 256));
+    int64_t* pin_nc = (int64_t*)(ctx.pinned + fp.pin_off);
+    HIP_TRY(hipMemcpyAsync(pin_nc, d_nullc, 8 * nout, hipMemcpyDeviceToHost, ctx.stream));
+    if (mem == RDF_MEM_HOST) RDF_TRY(outr.download(fp.pin_off + ((8 * nout + 255) & ~(size_t)255)));
+    else HIP_TRY(hipStreamSynchronize(ctx.stream));
+    for (size_t i = 0; i < nout; ++i) {
+        const int64_t n = totals[i % (size_t)nchunks];
+        outs[i].length = n;
+        outs[i].null_count = cols[i].validity ? pin_nc[i] : 0;
+        if (!cols[i].validity && outs[i].validity && n > 0) {  // no input bitmap: everything kept is valid
+            if (mem == RDF_MEM_HOST) memset(outs[i].validity, 0xFF, (size_t)((n + 7) / 8));
+            else HIP_TRY(hipMemsetAsync(outs[i].validity, 0xFF, (size_t)((n + 7) / 8), ctx.stream));
+        }
+    }
+    if (mem == RDF_MEM_DEVICE) HIP_TRY(hipStreamSynchronize(ctx.stream));
+    return RDF_OK;
+}
+
+rdf_status rdf_filter(const rdf_array* col, const rdf_array* mask, int64_t nchunks, rdf_out* out) {
+    return rdf_filter_columns(col, 1, mask, nchunks, out);
+}
+
+rdf_status rdf_take(const rdf_array* chunks, int64_t nchunks, const rdf_array* indices, rdf_out* out) {
+    if (nchunks < 1 || !chunks) return fail(RDF_INVALID_ARGUMENT, "take: a column has at least one chunk");
+    if (!indices || !out) return fail(RDF_INVALID_ARGUMENT, "take: null argument");
+    if (indices->dtype != RDF_U32 && indices->dtype != RDF_U64) return fail(RDF_INVALID_ARGUMENT, "take: indices must be UInt32/UInt64");
+    int32_t mem = -1;
+    RDF_TRY(check_mem(chunks, nchunks, &mem));
+    RDF_TRY(check_mem(indices, 1, &mem));
+    RDF_TRY(check_out_mem(out, 1, mem));
+    const int dt = chunks[0].dtype;
+    if (!is_numeric(dt) || out->dtype != dt) return fail(RDF_INVALID_ARGUMENT, "take: unsupported or mismatched dtype");
+    bool any_validity = indices->validity != nullptr;
+    std::vector<int64_t> row_start((size_t)nchunks + 1, 0);
+    for (int64_t c = 0; c < nchunks; ++c) {
+        if (chunks[c].dtype != dt) return fail(RDF_INVALID_ARGUMENT, "take: chunks differ in dtype");
+        row_start[(size_t)c + 1] = row_start[(size_t)c] + chunks[c].length;
+        any_validity |= chunks[c].validity != nullptr;
+    }
+    const int64_t n = indices->length;
+    if (out->capacity < n) return fail(RDF_MEMORY_ERROR, "output capacity too small");
+    if (any_validity && !out->validity) return fail(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    if (n == 0) { out->length = 0; out->null_count = 0; return RDF_OK; }
+    RDF_TRY(ensure_ready());
+    Ctx& ctx = g_ctx;
+    arena_begin();
+    size_t pin_off = 0, used = 0;
+    InputStager in;
+    in.add(indices);
+    for (int64_t c = 0; c < nchunks; ++c) in.add(&chunks[c]);
+    RDF_TRY(in.finish(pin_off, &used));
+    pin_off += (used + 255) & ~(size_t)255;
+
+    TableBuilder tb;
+    const size_t o_ch = tb.reserve(sizeof(DevChunkCol) * (size_t)nchunks);
+    const size_t o_rs = tb.reserve(sizeof(int64_t) * row_start.size());
+    memcpy(tb.at<char>(o_ch), in.dev.data() + 1, sizeof(DevChunkCol) * (size_t)nchunks);
+    memcpy(tb.at<char>(o_rs), row_start.data(), sizeof(int64_t) * row_start.size());
+    RDF_TRY(tb.alloc());
+    RDF_TRY(tb.upload(pin_off));
+    pin_off += (tb.host.size() + 255) & ~(size_t)255;
+
+    const size_t es = (size_t)dtype_size(dt);
+    Region outr;
+    int vi = -1, bi = -1;
+    DevOutChunk doc;
+    if (mem == RDF_MEM_HOST) {
+        vi = outr.add(out->values, (size_t)n * es);
+        if (out->validity) bi = outr.add(out->validity, (size_t)((n + 7) / 8));
+        RDF_TRY(outr.layout());
+        doc.values = outr.ptr(vi);
+        doc.validity = bi >= 0 ? (uint8_t*)outr.ptr(bi) : nullptr;
+    } else doc = DevOutChunk{out->values, out->validity};
+
+    void* p = nullptr;
+    RDF_TRY(arena_alloc(32, &p));
+    HIP_TRY(hipMemsetAsync(p, 0, 32, ctx.stream));
+    TakeArgs ta;
+    memset(&ta, 0, sizeof ta);
+    ta.chunks = tb.dev_at<DevChunkCol>(o_ch);
+    ta.chunk_row_start = tb.dev_at<int64_t>(o_rs);
+    ta.nchunks = nchunks;
+    ta.total_rows = row_start[(size_t)nchunks];
+    ta.indices = in.dev[0];
+    ta.n = n;
+    ta.out = doc;
+    ta.flags = (uint32_t*)p;
+    ta.out_null_count = (int64_t*)((char*)p + 16);
+    ta.esize = (int)es;
+    ta.idx64 = indices->dtype == RDF_U64;
+    {
+        KernelTimer kt;
+        HIP_TRY(launch_take(ta, ctx.stream));
+        kt.stop();
+    }
+    RDF_TRY(pinned_reserve(pin_off + 256 + outr.small_bytes + 256));
+    char* pin = ctx.pinned + pin_off;
+    HIP_TRY(hipMemcpyAsync(pin, p, 32, hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    uint32_t flags;
+    memcpy(&flags, pin, 4);
+    if (flags & 2u) return fail(RDF_COMPUTE_ERROR, "take index out of bounds (len %lld)", (long long)ta.total_rows);
+    if (mem == RDF_MEM_HOST) RDF_TRY(outr.download(pin_off + 256));
+    out->length = n;
+    memcpy(&out->null_count, pin + 16, 8);
+    return RDF_OK;
+}
+
+// ---------------------------------------------------------------- synthetic data / timing
+
+rdf_status rdf_fill_uniform_f64(double* dev_ptr, int64_t n, uint64_t seed, uint64_t column_id, int64_t first_row, double lo, double hi) {
+    RDF_TRY(ensure_ready());
+    if (n > 0) HIP_TRY(launch_fill_f64(dev_ptr, n, seed, column_id, first_row, lo, hi, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    return RDF_OK;
+}
+rdf_status rdf_fill_uniform_i64(int64_t* dev_ptr, int64_t n, uint64_t seed, uint64_t column_id, int64_t first_row, int64_t lo, int64_t hi) {
+    if (hi <= lo) return fail(RDF_INVALID_ARGUMENT, "fill_uniform_i64: hi must exceed lo");
+    RDF_TRY(ensure_ready());
+    if (n > 0) HIP_TRY(launch_fill_i64(dev_ptr, n, seed, column_id, first_row, lo, hi, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    return RDF_OK;
+}
+rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uint64_t column_id, int64_t first_row, double null_fraction) {
+    RDF_TRY(ensure_ready());
+    if (nbits > 0) HIP_TRY(launch_fill_validity(dev_ptr, nbits, seed, column_id, first_row, null_fraction, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    return RDF_OK;
+}
+
+rdf_status rdf_kernel_timing_reset(int32_t enable) {
+    RDF_TRY(ensure_ready());
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    g_ctx.timing = enable != 0;
+    g_ctx.events_used = 0;
+    return RDF_OK;
+}
+rdf_status rdf_kernel_timing_get(double* total_ms, int64_t* launches) {
+    if (!total_ms || !launches) return fail(RDF_INVALID_ARGUMENT, "null pointer");
+    RDF_TRY(ensure_ready());
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < g_ctx.events_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g_ctx.events[i].first, g_ctx.events[i].second));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int64_t)g_ctx.events_used;
+    return RDF_OK;
+}
+
+}  // extern "C"

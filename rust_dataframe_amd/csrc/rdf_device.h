@@ -1,0 +1,134 @@
+// rdf_device.h — structures shared by the HIP kernels (rdf_kernels.hip) and the host side of the
+// C ABI (rdf_capi.cpp).  Not part of the public interface.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+#include "../../include/rdf_mi355x.h"
+
+namespace rdfk {
+
+constexpr int kBlock = 256;          // 4 wavefronts of 64
+constexpr int kVPT = 4;              // rows per thread per tile in the fused evaluator
+constexpr int kEvalTile = kBlock * kVPT;   // 1024 rows: one reference RecordBatch (src/dataframe.rs:352)
+constexpr int kFilterTile = 2048;    // rows per compaction tile (32 mask words)
+constexpr int kMaxCode = 56;         // accumulator-machine instructions per program
+constexpr int kMaxCols = 8;          // columns referenced by one program
+constexpr int kPreCols = 4;          // columns preloaded into registers per tile
+constexpr int kMaxTmp = 4;           // LDS spill slots for bushy expression trees
+constexpr int kMaxValues = RDF_MAX_VALUES;
+constexpr int kMaxFilterCols = 16;
+
+// One (column, chunk): an Arrow array resident in HBM.
+struct DevChunkCol {
+    const void*    values;
+    const uint8_t* validity;  // nullptr = all valid
+    int64_t        offset;    // elements / bits
+};
+struct DevOutChunk {
+    void*    values;
+    uint8_t* validity;        // nullptr = not requested
+};
+
+// Accumulator-machine bytecode.  The host compiles an rdf_expr_node tree (Sethi-Ullman order) into
+// this; the opcode stream is wave-uniform, so the interpreter's branches are scalar branches.
+enum : uint8_t { BC_LOAD = 0, BC_STORE_TMP = 1, BC_BIN = 2, BC_UN = 3, BC_CAST = 4, BC_EMIT = 5, BC_FILTER = 6 };
+enum : uint8_t { SRC_NONE = 0, SRC_COL = 1, SRC_IMM = 2, SRC_TMP = 3 };
+
+struct Instr {
+    uint8_t  bc;
+    uint8_t  op;         // rdf_op for BC_BIN / BC_UN
+    uint8_t  dtype;      // domain the op computes in / CAST target / EMIT value dtype
+    uint8_t  src_kind;
+    uint8_t  src_dtype;  // dtype of the operand as stored (converted to `dtype` on fetch); CAST: source dtype
+    uint8_t  swapped;    // BC_BIN: acc = operand OP acc
+    uint16_t src;        // column index / tmp slot / EMIT: value index
+    uint64_t imm;        // SRC_IMM payload already in the `dtype` domain
+};
+static_assert(sizeof(Instr) == 16, "Instr must stay 16 bytes");
+
+// Per-block partial aggregate of one value expression ({sum,min,max,count}, AggregateFunctions).
+struct AggPartial {
+    uint64_t sum, mn, mx;
+    int64_t  cnt;
+};
+enum : int32_t { CLS_F64 = 0, CLS_SIGNED = 1, CLS_UNSIGNED = 2 };
+
+enum : int32_t { SINK_STORE = 0, SINK_AGG = 1 };
+
+struct EvalArgs {
+    // chunk tables (device memory) — or the inline copies below when nchunks == 1
+    const DevChunkCol* cols;             // [ncols * nchunks]
+    const int64_t*     chunk_tile_start; // [nchunks + 1]
+    const int64_t*     chunk_len;        // [nchunks]
+    DevOutChunk*       outs;             // [nvalues * nchunks] (SINK_STORE)
+    int64_t*           out_null_counts;  // [nvalues * nchunks] (SINK_STORE)
+    AggPartial*        partials;         // [gridDim.x * nvalues] (SINK_AGG)
+    uint32_t*          flags;            // bit 0: divide by zero at a valid slot
+    int64_t            nchunks, ntiles;
+    DevChunkCol        inline_cols[kMaxCols];
+    DevOutChunk        inline_outs[kMaxValues];
+    int64_t            inline_len;
+    int32_t            ncols, nvalues, ncode, ntmp;
+    int32_t            col_dtype[kMaxCols];
+    int32_t            value_cls[kMaxValues];
+    Instr              code[kMaxCode];
+};
+
+struct AggFinalArgs {
+    const AggPartial* partials;  // [nblocks * nvalues]
+    AggPartial*       result;    // [nvalues]
+    int32_t           nblocks, nvalues;
+    int32_t           value_cls[kMaxValues];
+};
+
+// Specialised headline kernel: filter(x CMP c) -> {sum,min,max,count}(y), f64, one chunk.
+struct FilterAggF64Args {
+    const double*  x;   const uint8_t* x_validity;   int64_t x_offset;
+    const double*  y;   const uint8_t* y_validity;   int64_t y_offset;   // y == x when same column
+    int64_t        n;
+    double         c;
+    AggPartial*    partials;   // [gridDim.x]
+};
+
+struct MaskTables {
+    const DevChunkCol* mask;             // [nchunks]; values = bit-packed booleans
+    const int64_t*     chunk_tile_start; // [nchunks + 1], tiles of kFilterTile rows
+    const int64_t*     chunk_len;        // [nchunks]
+    int64_t            nchunks, ntiles;
+};
+struct FilterArgs {
+    MaskTables         t;
+    const DevChunkCol* cols;             // [ncols * nchunks]
+    DevOutChunk*       outs;             // [ncols * nchunks]
+    int64_t*           out_null_counts;  // [ncols * nchunks]
+    const int64_t*     tile_scan;        // [ntiles + 1] exclusive scan of per-tile keep counts
+    int32_t            ncols;
+    int32_t            esize[kMaxFilterCols];
+};
+
+struct TakeArgs {
+    const DevChunkCol* chunks;           // [nchunks]
+    const int64_t*     chunk_row_start;  // [nchunks + 1]
+    int64_t            nchunks, total_rows;
+    DevChunkCol        indices;          // u32 or u64
+    int64_t            n;
+    DevOutChunk        out;
+    int64_t*           out_null_count;
+    uint32_t*          flags;            // bit 1: index out of bounds
+    int32_t            esize, idx64;
+};
+
+// ---- launch wrappers (defined in rdf_kernels.hip) ----
+int  eval_grid_limit();   // persistent grid size for streaming kernels
+hipError_t launch_eval(const EvalArgs& a, int sink, bool heavy, int grid, hipStream_t s);
+hipError_t launch_agg_final(const AggFinalArgs& a, hipStream_t s);
+hipError_t launch_filter_agg_f64(const FilterAggF64Args& a, int cmp_op, int grid, hipStream_t s);
+hipError_t launch_mask_count(const MaskTables& t, int64_t* tile_counts, hipStream_t s);
+hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, hipStream_t s);
+hipError_t launch_compact(const FilterArgs& a, hipStream_t s);
+hipError_t launch_take(const TakeArgs& a, hipStream_t s);
+hipError_t launch_fill_f64(double* p, int64_t n, uint64_t seed, uint64_t col, int64_t first_row, double lo, double hi, hipStream_t s);
+hipError_t launch_fill_i64(int64_t* p, int64_t n, uint64_t seed, uint64_t col, int64_t first_row, int64_t lo, int64_t hi, hipStream_t s);
+hipError_t launch_fill_validity(uint8_t* p, int64_t nbits, uint64_t seed, uint64_t col, int64_t first_row, double null_fraction, hipStream_t s);
+
+}  // namespace rdfk

@@ -1,0 +1,104 @@
+"""Loader for librdf_mi355x.so — the product library (HIP kernels + C ABI).
+
+There is no Python or CPU fallback: if the shared library is missing this module raises, and every
+compute entry point of the library itself returns RDF_DEVICE_ERROR without a gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librdf_mi355x.so")
+
+# Every symbol include/rdf_mi355x.h declares (tests check the library exports all of them).
+EXPORTS = [
+    "rdf_version", "rdf_last_error", "rdf_device_count", "rdf_set_device", "rdf_set_stream", "rdf_synchronize",
+    "rdf_dev_alloc", "rdf_dev_free", "rdf_copy_h2d", "rdf_copy_d2h",
+    "rdf_binary", "rdf_unary", "rdf_cast", "rdf_sum", "rdf_min", "rdf_max", "rdf_count", "rdf_avg",
+    "rdf_predicate", "rdf_filter_count", "rdf_filter", "rdf_filter_columns", "rdf_take", "rdf_pipeline",
+    "rdf_fill_uniform_f64", "rdf_fill_uniform_i64", "rdf_fill_validity",
+    "rdf_kernel_timing_reset", "rdf_kernel_timing_get",
+]
+
+_lib = None
+_api = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C rust_dataframe_amd/csrc). There is no fallback path.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.rdf_version.restype = C.c_char_p
+        _lib.rdf_last_error.restype = C.c_char_p
+        _lib.rdf_dev_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_int64]
+        _lib.rdf_dev_free.argtypes = [C.c_void_p]
+        _lib.rdf_copy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        _lib.rdf_copy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        _lib.rdf_set_stream.argtypes = [C.c_void_p]
+        _lib.rdf_set_device.argtypes = [C.c_int32]
+        _lib.rdf_kernel_timing_reset.argtypes = [C.c_int32]
+    return _lib
+
+
+def api() -> _abi.Api:
+    """The product call layer (prefix rdf_)."""
+    global _api
+    if _api is None:
+        _api = _abi.Api(load(), "rdf_")
+    return _api
+
+
+def _check(status: int):
+    if status != _abi.RDF_OK:
+        raise _abi.RdfError(status, (load().rdf_last_error() or b"").decode("utf-8", "replace"))
+
+
+def version() -> str:
+    return load().rdf_version().decode()
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    st = load().rdf_device_count(C.byref(n))
+    return n.value if st == _abi.RDF_OK else 0
+
+
+def set_device(dev: int):
+    _check(load().rdf_set_device(dev))
+
+
+def set_stream(hip_stream_ptr):
+    _check(load().rdf_set_stream(C.c_void_p(hip_stream_ptr)))
+
+
+def synchronize():
+    _check(load().rdf_synchronize())
+
+
+def kernel_timing_reset(enable: bool):
+    _check(load().rdf_kernel_timing_reset(1 if enable else 0))
+
+
+def kernel_timing_get():
+    ms, n = C.c_double(0), C.c_int64(0)
+    _check(load().rdf_kernel_timing_get(C.byref(ms), C.byref(n)))
+    return ms.value, n.value
+
+
+def fill_uniform_f64(dev_ptr: int, n: int, seed: int, column_id: int, first_row: int, lo: float, hi: float):
+    _check(load().rdf_fill_uniform_f64(C.c_void_p(dev_ptr), n, seed, column_id, first_row, lo, hi))
+
+
+def fill_uniform_i64(dev_ptr: int, n: int, seed: int, column_id: int, first_row: int, lo: int, hi: int):
+    _check(load().rdf_fill_uniform_i64(C.c_void_p(dev_ptr), n, seed, column_id, first_row, lo, hi))
+
+
+def fill_validity(dev_ptr: int, nbits: int, seed: int, column_id: int, first_row: int, null_fraction: float):
+    _check(load().rdf_fill_validity(C.c_void_p(dev_ptr), nbits, seed, column_id, first_row, null_fraction))
