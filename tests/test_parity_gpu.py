@@ -35,3 +35,292 @@ def test_binary_arithmetic(gpu, ora, dtype, op):
         got = gpu.binary(op, a, b)
         # add/sub/mul/div are single IEEE operations: bit-exact even for floats
         assert_chunks_match(got, exp, exact=True, what=f"{op} dtype={dtype} lens={lens}")
+
+
+@pytest.mark.parametrize("dtype", [A.F32, A.F64])
+@pytest.mark.parametrize("op", ["atan2", "hypot", "log"])
+def test_binary_float_math(gpu, ora, dtype, op):
+    rng = np.random.default_rng(7)
+    for lens, nf, off in LAYOUTS[:5]:
+        a = make_chunks(rng, dtype, lens, nf, off, "pos")
+        b = make_chunks(rng, dtype, lens, nf, off, "pos")
+        assert_chunks_match(gpu.binary(op, a, b), ora.binary(op, a, b), exact=False, what=f"{op} {dtype}")
+
+
+UNARY_KIND = {"acos": "unit", "asin": "unit", "log10": "pos", "log2": "pos", "sqrt": "pos", "cosh": "unit", "sinh": "unit",
+              "exp": "unit", "expm1": "unit"}
+EXACT_UNARY = {"abs", "ceil", "floor", "round", "sqrt"}  # IEEE-exact operations
+
+
+@pytest.mark.parametrize("dtype", [A.F32, A.F64])
+@pytest.mark.parametrize("op", A.UNARY_OPS)
+def test_unary_float(gpu, ora, dtype, op):
+    rng = np.random.default_rng(11)
+    for lens, nf, off in LAYOUTS:
+        a = make_chunks(rng, dtype, lens, nf, off, UNARY_KIND.get(op, "plain"))
+        assert_chunks_match(gpu.unary(op, a), ora.unary(op, a), exact=op in EXACT_UNARY, what=f"{op} {dtype} {lens}")
+
+
+def test_unary_large_arguments_and_specials(gpu, ora):
+    """sin/cos/tan far outside [-pi, pi] (Payne-Hanek territory), NaN/inf/±0 inputs."""
+    v = np.array([1e6, -1e9, 1e15, 1e22, 3.0e300, -7.5e-310, 0.0, -0.0, np.nan, np.inf, -np.inf, 0.5, 1e-8, 710.0, -745.0])
+    a = [A.HostArray.from_numpy(v)]
+    for op in ["sin", "cos", "tan", "exp", "tanh", "atan", "cbrt", "floor", "round", "abs"]:
+        g, e = gpu.unary(op, a)[0], ora.unary(op, a)[0]
+        with np.errstate(all="ignore"):
+            np.testing.assert_allclose(g.to_numpy(), e.to_numpy(), rtol=1e-6, atol=0, equal_nan=True, err_msg=op)
+    # round is half away from zero (num::Float::round)
+    r = gpu.unary("round", [A.HostArray.from_numpy(np.array([0.5, 1.5, 2.5, -0.5, -1.5, -2.5]))])[0].to_numpy()
+    assert r.tolist() == [1.0, 2.0, 3.0, -1.0, -2.0, -3.0]
+
+
+@pytest.mark.parametrize("dtype", [A.I8, A.I16, A.I32, A.I64])
+def test_abs_signed_int(gpu, ora, dtype):
+    rng = np.random.default_rng(3)
+    for lens, nf, off in LAYOUTS:
+        a = make_chunks(rng, dtype, lens, nf, off, "extreme")
+        assert_chunks_match(gpu.unary("abs", a), ora.unary("abs", a), what=f"abs {dtype}")
+
+
+CAST_TYPES = NUMERIC + [A.BOOL]
+
+
+@pytest.mark.parametrize("src", CAST_TYPES)
+def test_cast_matrix(gpu, ora, src):
+    rng = np.random.default_rng(50 + src)
+    for dst in CAST_TYPES:
+        for lens, nf, off in [([1000], 0.0, 0), ([700, 0, 3000], 0.1, 13)]:
+            if src == A.BOOL:
+                a = [A.HostArray.from_numpy(rng.integers(0, 2, n).astype(bool), valid=(rng.uniform(size=n) >= nf) if nf else None,
+                                            offset=off, dtype=A.BOOL, rng=rng) for n in lens]
+            else:
+                a = make_chunks(rng, src, lens, nf, off, "special" if src in (A.F32, A.F64) else "extreme")
+                if src in (A.F32, A.F64):  # add magnitudes that saturate every integer width
+                    for ch in a:
+                        if ch.length >= 16:
+                            ch.values[ch.offset + 8:ch.offset + 16] = [300.7, -300.7, 7e4, -7e4, 5e9, -5e9, 3e19, -3e19]
+            assert_chunks_match(gpu.cast(a, dst), ora.cast(a, dst), exact=True, what=f"cast {src}->{dst}")
+
+
+@pytest.mark.parametrize("dtype", NUMERIC)
+def test_aggregates(gpu, ora, dtype):
+    rng = np.random.default_rng(200 + dtype)
+    for lens, nf, off in LAYOUTS + [([50_000, 70_001], 0.05, 3)]:
+        a = make_chunks(rng, dtype, lens, nf, off, "plain" if dtype in (A.F32, A.F64) else "extreme")
+        what = f"dtype={dtype} lens={lens} nf={nf}"
+        if dtype == A.F32:
+            # the reference sums f32 in f32 (sequential left fold, aggregate.rs:82-93); the device folds in f64
+            # and rounds once.  Both are within the f32 fold's own error bound n * 2^-24 * sum|x| of the exact sum.
+            mag = sum(float(np.abs(ch.to_numpy()[ch.valid_mask()].astype(np.float64)).sum()) for ch in a)
+            n = sum(ch.length for ch in a)
+            assert abs(gpu.sum(a) - ora.sum(a)) <= max(1e-6 * abs(ora.sum(a)), n * 2.0 ** -24 * mag), "sum " + what
+        else:
+            assert_scalar_close(gpu.sum(a), ora.sum(a), dtype, "sum " + what)
+        assert_scalar_close(gpu.min(a), ora.min(a), dtype, "min " + what)
+        assert_scalar_close(gpu.max(a), ora.max(a), dtype, "max " + what)
+        assert gpu.count(a) == ora.count(a), "count " + what
+        g, e = gpu.avg(a), ora.avg(a)
+        assert (g is None) == (e is None), what
+        if e is not None:
+            assert abs(g - e) <= 1e-6 * max(abs(e), 1e-12) + 1e-9, f"avg {what}: {g} vs {e}"
+        # unknown null_count: count must read the bitmap
+        for ch in a:
+            ch._unknown_nc = True
+        assert gpu.count(a) == ora.count(a), "count(bitmap) " + what
+
+
+def test_aggregates_nan_and_reference_known_answers(gpu, ora):
+    # NaN never wins min/max unless everything is NaN (documented divergence, DESIGN.md)
+    a = [A.HostArray.from_numpy(np.array([np.nan, 3.0, -2.0, np.nan]))]
+    assert gpu.min(a) == -2.0 and gpu.max(a) == 3.0
+    assert np.isnan(gpu.min([A.HostArray.from_numpy(np.array([np.nan, np.nan]))]))
+    # src/functions/aggregate.rs:123-146
+    assert gpu.count([A.HostArray.from_numpy(np.array([5, 6, 7, 8, 9], dtype=np.int32))]) == 5
+    a = A.HostArray.from_numpy(np.arange(0, 5, dtype=np.int32))
+    b = A.HostArray.from_numpy(np.arange(5, 10, dtype=np.int32))
+    assert gpu.avg([a, b]) == 4.5
+    d = A.HostArray.from_numpy(np.array([0, 0, 1, 0, 2, 3, 4], dtype=np.int32), valid=[1, 0, 1, 0, 1, 1, 1])
+    assert gpu.avg([d, b]) == 4.5
+
+
+def _pred_cases(e, ncols):
+    c0, c1 = e.col(0), e.col(1 % ncols)
+    gt = e.op("gt", c0, e.scalar(0.5))
+    le = e.op("le", c0, c1)
+    return {
+        "gt_scalar": gt,
+        "scalar_lt_col": e.op("lt", e.scalar(10, A.I64), c0),
+        "le_cols": le,
+        "eq": e.op("eq", c0, c1),
+        "ne": e.op("ne", c0, e.scalar(3.0)),
+        "ge": e.op("ge", c0, e.scalar(-7, A.I32)),
+        "not": e.op("not", gt),
+        "and": e.op("and", gt, le),
+        "or": e.op("or", e.op("not", le), e.op("lt", c0, e.scalar(-50.0))),
+        "not_numeric": e.op("not", c1),
+        "null_scalar": e.op("or", gt, e.scalar(None)),
+        "deep": e.op("and", e.op("or", e.op("gt", e.op("add", c0, c0), e.op("multiply", c1, c1)), gt),
+                     e.op("not", e.op("and", le, e.op("ne", c1, e.scalar(0.0))))),
+    }
+
+
+@pytest.mark.parametrize("dtypes", [(A.F64, A.F64), (A.I64, A.I64), (A.F32, A.F32), (A.I32, A.I32), (A.U8, A.U8)])
+def test_predicate_eval_to_array(gpu, ora, dtypes):
+    rng = np.random.default_rng(31)
+    for lens, nf, off in LAYOUTS:
+        cols = [make_chunks(rng, dt, lens, nf, off, "plain") for dt in dtypes]
+        e = A.Expr()
+        for name, root in _pred_cases(e, len(cols)).items():
+            exp = ora.predicate(e, root, cols)
+            got = gpu.predicate(e, root, cols)
+            assert_chunks_match(got, exp, what=f"predicate {name} {dtypes} {lens}")
+            for g in got:  # the value bit of a null slot is 0
+                assert not np.any(g.to_numpy() & ~g.valid_mask())
+
+
+def test_predicate_mixed_types_compare_in_f64(gpu, ora):
+    """Comparisons cast both sides to Float64 (src/expression.rs:844-845), so i64 beyond 2^53 compares lossy (B6)."""
+    big = np.array([2 ** 53, 2 ** 53 + 1, -(2 ** 53) - 1, 5], dtype=np.int64)
+    x = [A.HostArray.from_numpy(big)]
+    y = [A.HostArray.from_numpy(np.array([2.0 ** 53, 2.0 ** 53, -(2.0 ** 53), 5.5]))]
+    e = A.Expr()
+    for op in ["eq", "gt", "le"]:
+        root = e.op(op, e.col(0), e.col(1))
+        assert_chunks_match(gpu.predicate(e, root, [x, y]), ora.predicate(e, root, [x, y]), what=op)
+    got = gpu.predicate(e, e.op("eq", e.col(0), e.col(1)), [x, y])[0].to_numpy()
+    assert got.tolist() == [True, True, True, False]
+
+
+@pytest.mark.parametrize("dtype", NUMERIC)
+def test_filter(gpu, ora, dtype):
+    rng = np.random.default_rng(400 + dtype)
+    for lens, nf, off in LAYOUTS + [([2048], 0.0, 0), ([2049, 4095, 1], 0.2, 7), ([100_000], 0.1, 1)]:
+        for sel in (0.5, 0.02, 1.0, 0.0):
+            col = make_chunks(rng, dtype, lens, nf, off, "extreme" if dtype <= A.U64 else "special")
+            mask = [A.HostArray.from_numpy(rng.uniform(size=n) < sel, valid=(rng.uniform(size=n) > 0.1) if nf else None,
+                                           offset=(off * 3) % 11, dtype=A.BOOL, rng=rng) for n in lens]
+            assert gpu.filter_count(mask) == ora.filter_count(mask)
+            assert_chunks_match(gpu.filter(col, mask), ora.filter(col, mask), exact=True, what=f"filter {dtype} {lens} sel={sel}")
+
+
+def test_filter_columns_one_pass(gpu, ora):
+    """DataFrame::filter (src/dataframe.rs:178-189): every column compacted by one mask."""
+    rng = np.random.default_rng(9)
+    lens = [1024, 1024, 1024, 333]
+    cols = [make_chunks(rng, dt, lens, nf, off) for dt, nf, off in [(A.F64, 0.1, 0), (A.I64, 0.0, 5), (A.I32, 0.3, 2), (A.U8, 0.0, 0), (A.F32, 0.5, 9), (A.I16, 0.1, 1)]]
+    e = A.Expr()
+    root = e.op("gt", e.col(0), e.scalar(0.0))
+    mask = ora.predicate(e, root, cols)
+    assert_chunks_match(gpu.predicate(e, root, cols), mask, what="mask")
+    got, exp = gpu.filter_columns(cols, mask), ora.filter_columns(cols, mask)
+    for k in range(len(cols)):
+        assert_chunks_match(got[k], exp[k], exact=True, what=f"column {k}")
+
+
+@pytest.mark.parametrize("dtype", NUMERIC)
+@pytest.mark.parametrize("idx_dtype", [A.U32, A.U64])
+def test_take(gpu, ora, dtype, idx_dtype):
+    rng = np.random.default_rng(600 + dtype)
+    for lens, nf, off in LAYOUTS[:5] + [([1024] * 37 + [99], 0.1, 3)]:
+        col = make_chunks(rng, dtype, lens, nf, off, "extreme" if dtype <= A.U64 else "special")
+        total = sum(lens)
+        for n_idx, idx_nf, idx_off in [(1, 0.0, 0), (777, 0.0, 0), (5000, 0.2, 9)]:
+            idx = A.HostArray.from_numpy(rng.integers(0, total, n_idx).astype(A.NP_OF[idx_dtype]),
+                                         valid=(rng.uniform(size=n_idx) >= idx_nf) if idx_nf else None, offset=idx_off, rng=rng)
+            assert_arrays_match(gpu.take(col, idx), ora.take(col, idx), exact=True, what=f"take {dtype} {lens}")
+
+
+def test_take_reference_sort_case(gpu):
+    """test_sort (src/dataframe.rs:963-1003): lexsort indices [5,3,4,0,1,2] applied by Column::take."""
+    a = A.HostArray.from_numpy(np.array([1, 1, 0, 3, 3, 4], dtype=np.int32), valid=[1, 1, 0, 1, 1, 1])
+    b = A.HostArray.from_numpy(np.array([9, 5, 6, 7, 4, 8], dtype=np.uint8))
+    idx = A.HostArray.from_numpy(np.array([5, 4, 3, 1, 0, 2], dtype=np.uint32))
+    assert gpu.take([a], idx).to_pylist() == [4, 3, 3, 1, 1, None]
+    assert gpu.take([b], idx).to_pylist() == [8, 4, 7, 5, 9, 6]
+
+
+def _pipeline_programs(e):
+    a, b, c, k = e.col(0), e.col(1), e.col(2), e.col(3)
+    fma = e.op("add", e.op("multiply", a, b), c)
+    return {
+        "filter_sum": dict(values=[a], filt=e.op("gt", a, e.scalar(0.5))),
+        "filter_other": dict(values=[b, k], filt=e.op("le", a, e.scalar(0.25))),
+        "c3_fused": dict(values=[fma, k], filt=-1),
+        "c1_sin_add_scalar": dict(values=[e.op("sin", e.op("add", a, e.scalar(1.0)))], filt=-1),
+        "bushy": dict(values=[e.op("multiply", e.op("add", a, b), e.op("subtract", c, e.op("divide", a, e.op("add", e.op("abs", b), e.scalar(1.0)))))], filt=e.op("ne", k, e.scalar(0, A.I64))),
+        "casts": dict(values=[e.op("add", e.cast(k, A.F64), a), e.cast(e.op("multiply", a, e.scalar(100.0)), A.I32)], filt=e.op("and", e.op("gt", k, e.scalar(-100, A.I64)), e.op("lt", b, c))),
+        "four_values": dict(values=[a, b, c, k], filt=e.op("or", e.op("lt", a, e.scalar(-0.9)), e.op("gt", a, e.scalar(0.9)))),
+    }
+
+
+@pytest.mark.parametrize("layout", LAYOUTS + [([1024] * 50 + [576], 0.05, 0), ([300_000], 0.0, 2)])
+def test_pipeline_fused_vs_unfused_oracle(gpu, ora, layout):
+    """The fused batch loop against the oracle's step-by-step (materialising) evaluation."""
+    lens, nf, off = layout
+    rng = np.random.default_rng(77)
+    cols = [make_chunks(rng, A.F64, lens, nf, off, "unit") for _ in range(3)] + [make_chunks(rng, A.I64, lens, nf, off, "plain")]
+    e = A.Expr()
+    for name, p in _pipeline_programs(e).items():
+        exp = ora.pipeline(e, cols, p["values"], p["filt"])
+        got = gpu.pipeline(e, cols, p["values"], p["filt"])
+        for v, (g, x) in enumerate(zip(got, exp)):
+            what = f"{name} value {v} lens={lens[:3]} nf={nf}"
+            assert g.count == x.count and g.is_some == x.is_some and g.dtype == x.dtype, what
+            if not x.is_some:
+                continue
+            if g.dtype in (A.F32, A.F64):
+                assert abs(g.sum - x.sum) <= 1e-6 * max(abs(x.sum), 1e-9) + 1e-9, f"sum {what}: {g.sum} vs {x.sum}"
+                assert g.min == pytest.approx(x.min, rel=1e-6) and g.max == pytest.approx(x.max, rel=1e-6), what
+            else:
+                assert (g.sum, g.min, g.max) == (x.sum, x.min, x.max), what
+
+
+def test_pipeline_store_sink(gpu, ora):
+    rng = np.random.default_rng(5)
+    lens, nf, off = [1024, 1024, 100], 0.1, 3
+    cols = [make_chunks(rng, A.F64, lens, nf, off, "unit") for _ in range(3)] + [make_chunks(rng, A.I64, lens, nf, off)]
+    e = A.Expr()
+    progs = _pipeline_programs(e)
+    for name in ["c3_fused", "c1_sin_add_scalar", "casts"]:
+        vals = progs[name]["values"]
+        dts = {"c3_fused": [A.F64, A.I64], "c1_sin_add_scalar": [A.F64], "casts": [A.F64, A.I32]}[name]
+        mk = lambda: [[A.HostArray.empty_out(dt, n, True) for n in lens] for dt in dts]
+        got = gpu.pipeline(e, cols, vals, -1, A.SINK_STORE, mk())
+        exp = ora.pipeline(e, cols, vals, -1, A.SINK_STORE, mk())
+        for v in range(len(vals)):
+            assert_chunks_match(got[v], exp[v], exact=(name != "c1_sin_add_scalar"), what=f"{name} value {v}")
+
+
+def test_error_values_match_reference_semantics(gpu, ora):
+    a = [A.HostArray.from_numpy(np.array([1.0, 2.0, 3.0]))]
+    b = [A.HostArray.from_numpy(np.array([1.0, 0.0]))]
+    for api in (gpu, ora):
+        with pytest.raises(A.RdfError) as ei:  # compute::add length check -> ComputeError
+            api.binary("add", a, b)
+        assert ei.value.status == A.RDF_COMPUTE_ERROR
+        z = [A.HostArray.from_numpy(np.array([1.0, 0.0, 2.0]))]
+        with pytest.raises(A.RdfError) as ei:  # zero divisor at a valid slot -> DivideByZero (floats too)
+            api.binary("divide", a, z)
+        assert ei.value.status == A.RDF_DIVIDE_BY_ZERO
+        zn = [A.HostArray.from_numpy(np.array([1.0, 0.0, 2.0]), valid=[1, 0, 1])]
+        assert api.binary("divide", a, zn)[0].to_pylist() == [1.0, None, 1.5]  # ...but not at a null slot
+        zi = [A.HostArray.from_numpy(np.array([4, 0, 2], dtype=np.int32))]
+        with pytest.raises(A.RdfError) as ei:
+            api.binary("divide", zi, zi)
+        assert ei.value.status == A.RDF_DIVIDE_BY_ZERO
+        with pytest.raises(A.RdfError) as ei:  # sin on integers: T::Native: Float
+            api.unary("sin", zi)
+        assert ei.value.status == A.RDF_INVALID_ARGUMENT
+        with pytest.raises(A.RdfError) as ei:  # abs on unsigned: T::Native: Signed
+            api.unary("abs", [A.HostArray.from_numpy(np.array([1], dtype=np.uint32))])
+        assert ei.value.status == A.RDF_INVALID_ARGUMENT
+        with pytest.raises(A.RdfError) as ei:  # take out of bounds
+            api.take(a, A.HostArray.from_numpy(np.array([0, 3], dtype=np.uint32)))
+        assert ei.value.status == A.RDF_COMPUTE_ERROR
+        with pytest.raises(A.RdfError) as ei:  # filter length mismatch
+            api.filter(a, [A.HostArray.from_numpy(np.array([True, False]), dtype=A.BOOL)])
+        assert ei.value.status == A.RDF_COMPUTE_ERROR
+        e = A.Expr()
+        with pytest.raises(A.RdfError) as ei:  # add(f64, i32) without the Cast AddOperation inserts
+            api.pipeline(e, [a, zi], [e.op("add", e.col(0), e.col(1))])
+        assert ei.value.status == A.RDF_INVALID_ARGUMENT
