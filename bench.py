@@ -69,7 +69,7 @@ def main():
 
     import torch
     from rust_dataframe_amd import _abi as A
-    from rust_dataframe_amd import lib
+    from rust_dataframe_amd import lib, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -104,22 +104,10 @@ def main():
     e = A.Expr()
     c = e.col(0)
     pred = e.op("gt", c, e.scalar(THRESHOLD))
-    part = torch.zeros(2, dtype=torch.float64, device=dev)
-    gathered = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
-
     def step():
-        r = api.pipeline(e, [[col]], [c], pred)[0]      # fused filter -> {sum,min,max,count}, one pass over HBM
-        total_sum, total_cnt = r.sum, r.count
-        if world > 1:                                     # combine the per-rank partials, rank order
-            part[0], part[1] = r.sum, float(r.count)
-            dist.all_gather(gathered, part)
-            total_sum = 0.0
-            total_cnt = 0
-            for g in gathered:
-                s, n = g.tolist()
-                total_sum += s
-                total_cnt += int(n)
-        return total_sum, total_cnt
+        local = api.pipeline(e, [[col]], [c], pred)          # fused filter -> {sum,min,max,count}, one pass over HBM
+        tot = sharding.all_combine(local, device=dev)[0]      # N > 1: all_gather the partials (RCCL), fold in rank order
+        return tot.sum, tot.count
 
     def sync():
         torch.cuda.synchronize()

@@ -1,8 +1,9 @@
 """ctypes mirror of include/rdf_mi355x.h and a thin, symmetric call layer.
 
-`Api(lib, prefix)` wraps either the product library (prefix ``rdf_``, librdf_mi355x.so) or — in tests
-only — the CPU oracle (prefix ``ora_``): both export the same signatures over the same structs, so a
-parity test is the same call made twice.  Nothing in this module computes anything.
+`Api(lib, prefix)` wraps any shared library that exports `<prefix>binary`, `<prefix>unary`, ... with the
+signatures of the header over these structs.  The product is librdf_mi355x.so with prefix ``rdf_``
+(rust_dataframe_amd.lib); the tests bind their CPU checker through the same class, so a parity test is
+the same call made twice.  Nothing in this module computes anything.
 """
 from __future__ import annotations
 

@@ -1,0 +1,104 @@
+"""Multi-GPU layout of the hot path: one process per GPU, RecordBatches sharded by contiguous row
+ranges (every reference kernel is per-chunk independent: src/functions/scalar.rs:28-31,
+src/table.rs:98-105, src/functions/aggregate.rs:88-90), no data-path collective.  The only exchange is
+the combine of the per-rank {sum, min, max, count} partials, folded in rank order so the f64 result
+is deterministic.  Works over any torch.distributed backend ("nccl" = RCCL on the GPU box, "gloo" in
+the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+from ._abi import F32, F64, AggResult
+
+
+def shard_rows(total_rows: int, world: int, rank: int, align: int = 1024) -> Tuple[int, int]:
+    """Contiguous row range [begin, end) of `rank`; boundaries fall on `align`-row batch edges
+    (1024 = the reference readers' RecordBatch size, src/dataframe.rs:352)."""
+    nb = (total_rows + align - 1) // align
+    b0 = nb * rank // world
+    b1 = nb * (rank + 1) // world
+    return min(b0 * align, total_rows), min(b1 * align, total_rows)
+
+
+def shard_chunks(chunk_lens: Sequence[int], world: int) -> List[Tuple[int, int]]:
+    """Whole RecordBatches per rank: [first_chunk, last_chunk) per rank, balanced by rows, order kept
+    (chunk order = rank order preserves row order of sharded outputs)."""
+    total = sum(chunk_lens)
+    bounds, acc, c = [], 0, 0
+    for r in range(world):
+        first = c
+        target = total * (r + 1) / world
+        while c < len(chunk_lens) and (acc + chunk_lens[c] / 2.0 <= target or r == world - 1):
+            acc += chunk_lens[c]
+            c += 1
+        bounds.append((first, c))
+    return bounds
+
+
+def combine(parts: Sequence[AggResult]) -> AggResult:
+    """Fold per-rank partial aggregates in rank order (AggregateFunctions' own chunk fold,
+    src/functions/aggregate.rs:82-93, with ranks in place of chunks)."""
+    dt = parts[0].dtype
+    is_f = dt in (F32, F64)
+    tot = 0.0 if is_f else 0
+    mn = mx = None
+    cnt = 0
+    for p in parts:
+        tot = tot + p.sum
+        cnt += p.count
+        if p.is_some:
+            if is_f:
+                # NaN-ignoring like the device fold: a NaN partial never displaces a number
+                mn = p.min if mn is None or (p.min < mn) or (mn != mn) else mn
+                mx = p.max if mx is None or (p.max > mx) or (mx != mx) else mx
+            else:
+                mn = p.min if mn is None else min(mn, p.min)
+                mx = p.max if mx is None else max(mx, p.max)
+    if not is_f:
+        bits = {0: 8, 1: 16, 2: 32, 3: 64, 4: 8, 5: 16, 6: 32, 7: 64, 10: 64}[dt]
+        tot &= (1 << bits) - 1
+        if dt <= 3 and tot >= 1 << (bits - 1):
+            tot -= 1 << bits
+    return AggResult(tot, mn if mn is not None else 0, mx if mx is not None else 0, cnt, cnt > 0, dt)
+
+
+def all_combine(local: Sequence[AggResult], device=None) -> List[AggResult]:
+    """all_gather every rank's partials and fold them identically on every rank.  f64 partials travel
+    as f64; integer partials as two's-complement i64 (exact)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [combine([p]) for p in local]
+    world = dist.get_world_size()
+    nv = len(local)
+    f = torch.zeros(nv * 3, dtype=torch.float64)
+    i = torch.zeros(nv * 5, dtype=torch.int64)
+    for v, p in enumerate(local):
+        if p.dtype in (F32, F64):
+            f[3 * v], f[3 * v + 1], f[3 * v + 2] = float(p.sum), float(p.min), float(p.max)
+        else:
+            wrap = lambda x: x - (1 << 64) if x >= (1 << 63) else x
+            i[5 * v], i[5 * v + 1], i[5 * v + 2] = wrap(int(p.sum)), wrap(int(p.min)), wrap(int(p.max))
+        i[5 * v + 3], i[5 * v + 4] = int(p.count), int(p.is_some)
+    if device is not None:
+        f, i = f.to(device), i.to(device)
+    fs = [torch.zeros_like(f) for _ in range(world)]
+    is_ = [torch.zeros_like(i) for _ in range(world)]
+    dist.all_gather(fs, f)
+    dist.all_gather(is_, i)
+    fs = [t.tolist() for t in fs]
+    is_ = [t.tolist() for t in is_]
+    out = []
+    for v, p in enumerate(local):
+        parts = []
+        for r in range(world):
+            if p.dtype in (F32, F64):
+                s, a, b = fs[r][3 * v:3 * v + 3]
+            else:
+                s, a, b = is_[r][5 * v:5 * v + 3]
+                if p.dtype == 7:  # U64 travels as i64
+                    s, a, b = [x + (1 << 64) if x < 0 else x for x in (s, a, b)]
+            parts.append(AggResult(s, a, b, int(is_[r][5 * v + 3]), bool(is_[r][5 * v + 4]), p.dtype))
+        out.append(combine(parts))
+    return out

@@ -1,0 +1,119 @@
+"""The C-ABI boundary without a GPU: the library loads, exports every symbol include/rdf_mi355x.h declares,
+its structs match the ctypes mirror byte for byte, argument validation happens before any device work, and
+— with no device — every compute entry point fails loudly with RDF_DEVICE_ERROR (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from rust_dataframe_amd import _abi as A
+from rust_dataframe_amd import lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rdf_mi355x.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rdf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 25
+    so = lib.load()
+    for n in names:
+        assert hasattr(so, n), f"librdf_mi355x.so does not export {n}"
+    assert sorted(lib.EXPORTS) == names
+    assert "gfx950" in lib.version()
+
+
+def test_oracle_exports_the_mirror_symbols(ora):
+    for n in ["binary", "unary", "cast", "sum", "min", "max", "count", "avg", "predicate", "filter_count", "filter",
+              "filter_columns", "take", "pipeline", "fill_uniform_f64", "fill_uniform_i64", "fill_validity"]:
+        assert hasattr(ora.lib, "ora_" + n)
+
+
+def test_ctypes_structs_match_the_header():
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "rdf_mi355x.h"
+#define S(t) printf(#t " %zu\n", sizeof(t))
+#define O(t, f) printf(#t "." #f " %zu\n", offsetof(t, f))
+int main(void) {
+  S(rdf_array); O(rdf_array, validity); O(rdf_array, offset); O(rdf_array, null_count); O(rdf_array, dtype); O(rdf_array, mem);
+  S(rdf_out); O(rdf_out, capacity); O(rdf_out, length); O(rdf_out, null_count); O(rdf_out, dtype); O(rdf_out, mem);
+  S(rdf_expr_node); O(rdf_expr_node, column); O(rdf_expr_node, f64); O(rdf_expr_node, i64);
+  S(rdf_program); O(rdf_program, nnodes); O(rdf_program, filter_root); O(rdf_program, value_roots); O(rdf_program, sink);
+  S(rdf_agg_result); O(rdf_agg_result, sum_i64); O(rdf_agg_result, count); O(rdf_agg_result, is_some); O(rdf_agg_result, dtype);
+  printf("enum %d %d %d %d %d\n", RDF_OP_TANH, RDF_OP_CAST, RDF_OP_OR, RDF_BOOL, RDF_DEVICE_ERROR);
+  return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), src, "-o", exe])  # header is plain C
+        out = dict(line.rsplit(" ", 1) for line in subprocess.check_output([exe], text=True).splitlines() if not line.startswith("enum"))
+        enums = subprocess.check_output([exe], text=True).splitlines()[-1]
+    for cls in (A.rdf_array, A.rdf_out, A.rdf_expr_node, A.rdf_program, A.rdf_agg_result):
+        assert int(out[cls.__name__]) == C.sizeof(cls), cls.__name__
+        for key, val in out.items():
+            if key.startswith(cls.__name__ + "."):
+                assert getattr(cls, key.split(".")[1]).offset == int(val), key
+    assert enums == f"enum {A.OP_TANH} {A.OP_CAST} {A.OP_OR} {A.BOOL} {A.RDF_DEVICE_ERROR}"
+
+
+def test_argument_validation_needs_no_device():
+    """Errors that are values in the reference are reported before the device is touched."""
+    api = lib.api()
+    a = [A.HostArray.from_numpy(np.array([1.0, 2.0, 3.0]))]
+    b = [A.HostArray.from_numpy(np.array([1.0, 2.0]))]
+    with pytest.raises(A.RdfError) as ei:
+        api.binary("add", a, b)
+    assert ei.value.status == A.RDF_COMPUTE_ERROR and "different length" in ei.value.message
+    with pytest.raises(A.RdfError) as ei:
+        api.unary("sin", [A.HostArray.from_numpy(np.array([1, 2], dtype=np.int32))])
+    assert ei.value.status == A.RDF_INVALID_ARGUMENT
+    with pytest.raises(A.RdfError) as ei:
+        api.binary("add", a, [A.HostArray.from_numpy(np.array([1, 2, 3], dtype=np.int64))])
+    assert ei.value.status == A.RDF_INVALID_ARGUMENT
+    # metadata-only count needs no device either (O(#chunks), like aggregate.rs:70-80)
+    assert api.count([A.HostArray.from_numpy(np.arange(5.0), valid=[1, 0, 1, 1, 0])]) == 3
+    # empty inputs produce empty outputs
+    assert api.unary("sin", [A.HostArray.from_numpy(np.zeros(0))])[0].length == 0
+
+
+@pytest.mark.skipif(lib.device_count() > 0, reason="a GPU is visible")
+def test_no_gpu_means_loud_device_error_not_a_fallback():
+    api = lib.api()
+    a = [A.HostArray.from_numpy(np.array([1.0, 2.0, 3.0]))]
+    e = A.Expr()
+    calls = [lambda: api.binary("add", a, a), lambda: api.unary("sin", a), lambda: api.sum(a),
+             lambda: api.pipeline(e, [a], [e.col(0)]), lambda: api.filter(a, [A.HostArray.from_numpy(np.array([1, 0, 1], dtype=bool), dtype=A.BOOL)]),
+             lambda: api.take(a, A.HostArray.from_numpy(np.array([0], dtype=np.uint32)))]
+    for call in calls:
+        with pytest.raises(A.RdfError) as ei:
+            call()
+        assert ei.value.status == A.RDF_DEVICE_ERROR
+        assert "no CPU fallback" in ei.value.message
+
+
+def test_product_never_references_the_oracle():
+    """The shipped library and package must not link, import or call anything under oracle/."""
+    so = subprocess.check_output(["nm", "-D", lib.LIB_PATH], text=True)
+    assert "ora_" not in so
+    pkg = os.path.join(ROOT, "rust_dataframe_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f"{f} imports the oracle"
+                assert "librdf_oracle" not in text and "ora_" not in text and "rdf_oracle" not in text, f"{f} references the oracle"

@@ -1,0 +1,246 @@
+"""Pins the CPU oracle (test infrastructure) before anything trusts it:
+
+  1. the reference's own known answers (every #[test] that pins a hot-path result),
+  2. the reference's CSV fixture (test/data/uk_cities_with_headers.csv) and the constants derived from it,
+  3. pyarrow.compute — an independent implementation of the Arrow kernels the reference delegates to,
+  4. the committed golden vectors (tests/golden/vectors_v1.npz, made by tests/golden/make_golden.py).
+
+For filter, sum, min, max, divide, comparisons and sin/tan values the reference holds no test vector
+(parity unpinned by the reference): those rest on 3 and 4.
+"""
+import csv
+import os
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pytest
+
+from rust_dataframe_amd import _abi as A
+
+from util import make_chunks
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def H(x, valid=None, **kw):
+    return A.HostArray.from_numpy(np.asarray(x), valid, **kw)
+
+
+# ---------------------------------------------------------------- 1. reference known answers
+def test_ref_abs_f64_i32(ora):  # src/functions/scalar.rs:565-584
+    assert ora.unary("abs", [H([-5.2, -6.1, 7.3, -8.6, -0.0])])[0].to_numpy().tolist() == [5.2, 6.1, 7.3, 8.6, 0.0]
+    assert ora.unary("abs", [H(np.array([-5, -6, 7, -8, 0], dtype=np.int32))])[0].to_numpy().tolist() == [5, 6, 7, 8, 0]
+
+
+def test_ref_acos_cos_f64(ora):  # src/functions/scalar.rs:587-602 (two-sided, to the last printed digit)
+    a = [H([-0.2, 0.25, 0.75])]
+    assert ora.unary("acos", a)[0].to_numpy().tolist() == [1.7721542475852274, 1.318116071652818, 0.7227342478134157]
+    assert ora.unary("cos", a)[0].to_numpy().tolist() == [0.9800665778412416, 0.9689124217106447, 0.7316888688738209]
+
+
+def test_ref_aggregate_count_and_mean(ora):  # src/functions/aggregate.rs:123-146
+    assert ora.count([H(np.array([5, 6, 7, 8, 9], dtype=np.int32))]) == 5
+    a, b = H(np.arange(0, 5, dtype=np.int32)), H(np.arange(5, 10, dtype=np.int32))
+    assert ora.avg([a, b]) == 4.5
+    d = H(np.array([0, 0, 1, 0, 2, 3, 4], dtype=np.int32), valid=[1, 0, 1, 0, 1, 1, 1])
+    assert ora.avg([d, b]) == 4.5
+
+
+def test_ref_sort_take(ora):  # src/dataframe.rs:963-1003: a desc, b asc, nulls last -> indices [5,4,3,1,0,2]
+    a = H(np.array([1, 1, 0, 3, 3, 4], dtype=np.int32), valid=[1, 1, 0, 1, 1, 1])
+    b = H(np.array([9, 5, 6, 7, 4, 8], dtype=np.uint8))
+    idx = H(np.array([5, 4, 3, 1, 0, 2], dtype=np.uint32))
+    assert ora.take([a], idx).to_pylist() == [4, 3, 3, 1, 1, None]
+    assert ora.take([b], idx).to_pylist() == [8, 4, 7, 5, 9, 6]
+    # Column::take concatenates the chunks first (src/table.rs:221): same answer from a 2-chunk column
+    assert ora.take([a.slice(0, 2), a.slice(2, 4)], idx).to_pylist() == [4, 3, 3, 1, 1, None]
+
+
+def _cities():
+    with open(os.path.join(GOLDEN, "uk_cities_with_headers.csv")) as f:
+        rows = list(csv.DictReader(f))
+    return np.array([float(r["lat"]) for r in rows]), np.array([float(r["lng"]) for r in rows])
+
+
+def test_ref_csv_fixture_ops(ora):
+    lat, lng = _cities()
+    assert len(lat) == 37
+    la, ln = [H(lat)], [H(lng)]
+    add = ora.binary("add", la, ln)[0].to_numpy()
+    assert abs(add[0] - 54.31776) < 1e-4                      # test_dataframe_ops, src/dataframe.rs:782-808
+    assert add[0] == 57.653484 + -3.335724                   # test_with_columns, src/lazyframe.rs:366-408
+    assert ora.unary("abs", ln)[0].to_numpy()[0] == 3.335724  # src/dataframe.rs:809-836
+    # constants computed from the fixture in SURVEY.md §4 (libm, sequential left fold)
+    assert ora.sum(la) == 1948.1160980000002 and ora.sum(ln) == -69.700632
+    assert ora.min(la) == 50.376289 and ora.max(la) == 57.653484
+    assert ora.min(ln) == -7.318268 and ora.max(ln) == 0.573453
+    s = ora.unary("sin", la)
+    assert s[0].to_numpy()[0] == 0.8933816410476535 and ora.sum(s) == 17.719169676326633
+    assert ora.unary("sin", ln)[0].to_numpy()[0] == 0.1929142713855381
+    e = A.Expr()
+    c = e.col(0)
+    r = ora.pipeline(e, [la], [e.op("sin", e.op("add", c, e.scalar(1.0)))])[0]
+    assert r.sum == 11.238854156569243 and r.count == 37
+    r = ora.pipeline(e, [la], [c], e.op("gt", c, e.scalar(55.0)))[0]
+    assert r.count == 5 and r.sum == 282.746235
+    # test_lazy_pipeline / test_lazy_evaluation shapes (src/lazyframe.rs:324-363, src/evaluation.rs:359-434):
+    # 2 x Sine leaves 37 rows; limit(25) is a zero-copy slice -> 25 rows
+    assert ora.unary("sin", [H(lat).slice(0, 25)])[0].length == 25
+
+
+# ---------------------------------------------------------------- 3. pyarrow cross-check
+def to_pa(h):
+    return pa.array(h.to_numpy(), mask=~h.valid_mask())
+
+
+@pytest.mark.parametrize("dtype", [A.I32, A.I64, A.U16, A.F32, A.F64])
+def test_oracle_vs_pyarrow_arithmetic_nulls(ora, dtype):
+    rng = np.random.default_rng(dtype)
+    a = make_chunks(rng, dtype, [3000], 0.2, 5)[0]
+    b = make_chunks(rng, dtype, [3000], 0.2, 2, nonzero=True)[0]
+    for op, fn in [("add", pc.add), ("subtract", pc.subtract), ("multiply", pc.multiply), ("divide", pc.divide)]:
+        if dtype not in (A.F32, A.F64) and op != "divide":
+            continue  # pyarrow's unchecked integer kernels agree, but only wrapping (oracle) is the spec here
+        r = ora.binary(op, [a], [b])[0]
+        ref = fn(to_pa(a), to_pa(b))
+        m = r.valid_mask()
+        assert np.array_equal(m, ~np.asarray(ref.is_null()))
+        assert np.array_equal(r.to_numpy()[m], ref.fill_null(1).to_numpy(zero_copy_only=False)[m]), op
+
+
+def test_oracle_vs_pyarrow_filter_take_agg(ora):
+    rng = np.random.default_rng(3)
+    lens = [1024, 1024, 500]
+    col = make_chunks(rng, A.I64, lens, 0.15, 4, "extreme")
+    x = make_chunks(rng, A.F64, lens, 0.15, 1, "unit")
+    e = A.Expr()
+    for opname, fn in [("gt", pc.greater), ("ge", pc.greater_equal), ("eq", pc.equal), ("ne", pc.not_equal), ("lt", pc.less), ("le", pc.less_equal)]:
+        root = e.op(opname, e.col(0), e.scalar(0.1))
+        mask = ora.predicate(e, root, [x])
+        for i, n in enumerate(lens):
+            ref = fn(to_pa(x[i]), pa.scalar(0.1))
+            assert np.array_equal(mask[i].valid_mask(), ~np.asarray(ref.is_null()))
+            assert np.array_equal(mask[i].to_numpy(), np.asarray(ref.fill_null(False)))
+            f = ora.filter([col[i]], [mask[i]])[0]
+            reff = pc.filter(to_pa(col[i]), ref)
+            assert f.length == len(reff) and f.null_count == reff.null_count
+            assert f.to_pylist() == reff.to_pylist()
+    whole = pa.concat_arrays([to_pa(c) for c in col])
+    exact = sum(v for v in whole.to_pylist() if v is not None)           # python ints: no overflow
+    assert ora.sum(col) == (exact + 2 ** 63) % 2 ** 64 - 2 ** 63          # i64 sum wraps (release-mode Rust `+`)
+    assert ora.min(col) == pc.min(whole).as_py() and ora.max(col) == pc.max(whole).as_py()
+    assert ora.count(col) == pc.count(whole).as_py()
+    xw = pa.concat_arrays([to_pa(c) for c in x])
+    assert abs(ora.sum(x) - pc.sum(xw).as_py()) < 1e-9 and abs(ora.avg(x) - pc.mean(xw).as_py()) < 1e-12
+    idx = H(rng.integers(0, sum(lens), 700).astype(np.uint32), valid=rng.uniform(size=700) > 0.2)
+    assert ora.take(col, idx).to_pylist() == pc.take(whole, to_pa(idx)).to_pylist()
+
+
+def test_oracle_vs_pyarrow_cast_and_boolean(ora):
+    rng = np.random.default_rng(8)
+    k = make_chunks(rng, A.I64, [2000], 0.1, 3)[0]
+    assert ora.cast([k], A.F64)[0].to_pylist() == pc.cast(to_pa(k), pa.float64()).to_pylist()
+    assert ora.cast([k], A.BOOL)[0].to_pylist() == pc.cast(to_pa(k), pa.bool_()).to_pylist()
+    x = make_chunks(rng, A.F64, [2000], 0.1, 0, "unit")[0]
+    y = make_chunks(rng, A.F64, [2000], 0.1, 0, "unit")[0]
+    e = A.Expr()
+    p, q = e.op("gt", e.col(0), e.scalar(0.0)), e.op("lt", e.col(1), e.scalar(0.3))
+    P, Q = pc.greater(to_pa(x), pa.scalar(0.0)), pc.less(to_pa(y), pa.scalar(0.3))
+    for name, root, ref in [("and", e.op("and", p, q), pc.and_(P, Q)), ("or", e.op("or", p, q), pc.or_(P, Q)),
+                            ("not", e.op("not", p), pc.invert(P))]:
+        got = ora.predicate(e, root, [[x], [y]])[0]
+        assert got.to_pylist() == ref.to_pylist(), name   # non-Kleene: null if either side is null
+
+
+def test_oracle_errors(ora):
+    a, b = [H([1.0, 2.0, 3.0])], [H([1.0, 0.0])]
+    with pytest.raises(A.RdfError) as ei:
+        ora.binary("add", a, b)
+    assert ei.value.status == A.RDF_COMPUTE_ERROR
+    with pytest.raises(A.RdfError) as ei:
+        ora.binary("divide", a, [H([1.0, 0.0, 2.0])])
+    assert ei.value.status == A.RDF_DIVIDE_BY_ZERO
+    with pytest.raises(A.RdfError) as ei:
+        ora.take(a, H(np.array([3], dtype=np.uint32)))
+    assert ei.value.status == A.RDF_COMPUTE_ERROR
+
+
+# ---------------------------------------------------------------- 4. committed golden vectors
+def golden_cases(api, g):
+    """Re-computes every vector of vectors_v1.npz with `api`; yields (name, got, expected, exact)."""
+    a_, b_, c_, k_ = H(g["a"], g["valid_a"]), H(g["b"], g["valid_b"]), H(g["c"]), H(g["k"], g["valid_b"])
+    sp_ = H(g["sp"])
+    for op in ["add", "subtract", "multiply", "divide"]:
+        yield op, api.binary(op, [a_], [b_])[0], (g[op + "_values"], g[op + "_valid"]), True
+    yield "mul_i64_wrap", api.binary("multiply", [k_], [k_])[0], (g["mul_i64_wrap_values"], g["mul_i64_wrap_valid"]), True
+    for op in ["sin", "cos", "tan", "abs", "sqrt", "exp", "floor", "tanh"]:
+        src = a_ if op != "sqrt" else H(np.abs(g["a"]), g["valid_a"])
+        yield op, api.unary(op, [src])[0], (g[op + "_values"], g[op + "_valid"]), op in ("abs", "sqrt", "floor")
+    for op in ["sin", "cos", "tan"]:
+        yield op + "_special", api.unary(op, [sp_])[0], (g[op + "_special_values"], g[op + "_special_valid"]), False
+    yield "cast_k_f64", api.cast([k_], A.F64)[0], (g["cast_k_f64_values"], g["cast_k_f64_valid"]), True
+    yield "cast_f64_i32", api.cast([H(g["cast_src_f64"])], A.I32)[0], (g["cast_f64_i32_values"], g["cast_f64_i32_valid"]), True
+    e = A.Expr()
+    ca, cb = e.col(0), e.col(1)
+    pred = e.op("gt", ca, e.scalar(0.25))
+    pred2 = e.op("and", e.op("le", ca, cb), e.op("not", e.op("gt", cb, e.scalar(0.9))))
+    m = api.predicate(e, pred, [[a_], [b_]])[0]
+    yield "pred_gt", m, (g["pred_gt_values"], g["pred_gt_valid"]), True
+    yield "pred_and_not", api.predicate(e, pred2, [[a_], [b_]])[0], (g["pred_and_not_values"], g["pred_and_not_valid"]), True
+    yield "filter", api.filter([k_], [m])[0], (g["filter_k_by_pred_gt_values"], g["filter_k_by_pred_gt_valid"]), True
+    idx = H(g["idx"], g["idx_valid"])
+    yield "take", api.take([a_.slice(0, 1000), a_.slice(1000, 4096 - 1000)], idx), (g["take_a_values"], g["take_a_valid"]), True
+
+
+def golden_scalars(api, g):
+    a_, b_, c_, k_ = H(g["a"], g["valid_a"]), H(g["b"], g["valid_b"]), H(g["c"]), H(g["k"], g["valid_b"])
+    for name, h in [("a", a_), ("k", k_)]:
+        yield f"sum_{name}", api.sum([h]), g[f"sum_{name}"].item()
+        yield f"min_{name}", api.min([h]), g[f"min_{name}"].item()
+        yield f"max_{name}", api.max([h]), g[f"max_{name}"].item()
+        yield f"count_{name}", api.count([h]), g[f"count_{name}"].item()
+        yield f"avg_{name}", api.avg([h]), g[f"avg_{name}"].item()
+    e = A.Expr()
+    ca = e.col(0)
+    r = api.pipeline(e, [[a_], [b_]], [ca], e.op("gt", ca, e.scalar(0.25)))[0]
+    for i, v in enumerate([r.sum, r.min, r.max, r.count]):
+        yield f"pipe_filter_sum[{i}]", v, g["pipe_filter_sum"][i].item()
+    e2 = A.Expr()
+    fa, fb, fc, fk = e2.col(0), e2.col(1), e2.col(2), e2.col(3)
+    rr = api.pipeline(e2, [[a_], [b_], [c_], [k_]], [e2.op("add", e2.op("multiply", fa, fb), fc), fk])
+    for i, v in enumerate([rr[0].sum, rr[0].min, rr[0].max, rr[0].count]):
+        yield f"pipe_c3_y[{i}]", v, g["pipe_c3_y"][i].item()
+    for i, v in enumerate([rr[1].sum, rr[1].min, rr[1].max, rr[1].count]):
+        yield f"pipe_c3_k[{i}]", v, g["pipe_c3_k"][i].item()
+    e3 = A.Expr()
+    r3 = api.pipeline(e3, [[a_]], [e3.op("sin", e3.op("add", e3.col(0), e3.scalar(1.0)))])[0]
+    for i, v in enumerate([r3.sum, r3.min, r3.max, r3.count]):
+        yield f"pipe_c1_sin_add[{i}]", v, g["pipe_c1_sin_add"][i].item()
+
+
+def check_golden(api, exact_floats: bool):
+    g = np.load(os.path.join(GOLDEN, "vectors_v1.npz"))
+    for name, got, (ev, em), exact in golden_cases(api, g):
+        assert got.length == len(ev), name
+        assert np.array_equal(got.valid_mask(), em), name + ": validity"
+        gv, xv = got.to_numpy()[em], ev[em]
+        if exact or exact_floats or gv.dtype.kind != "f":
+            assert np.array_equal(gv, xv, equal_nan=gv.dtype.kind == "f"), name
+        else:
+            np.testing.assert_allclose(gv, xv, rtol=1e-6, atol=0, equal_nan=True, err_msg=name)
+    for name, got, exp in golden_scalars(api, g):
+        if isinstance(exp, float) and not exact_floats:
+            assert abs(got - exp) <= 1e-6 * abs(exp), f"{name}: {got} vs {exp}"
+        else:
+            assert got == exp, f"{name}: {got} vs {exp}"
+
+
+def test_oracle_reproduces_golden_vectors(ora):
+    check_golden(ora, exact_floats=True)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_vectors(gpu):
+    """The HIP path against the committed vectors (bit-exact ints/bitmaps/IEEE ops; 1e-6 rel for libm + sums)."""
+    check_golden(gpu, exact_floats=False)

@@ -1,0 +1,108 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes shard RecordBatches by row range, run the local
+hot path (the oracle stands in for the device engine here — test infrastructure), all_gather the partial
+aggregates and fold them in rank order; the result must equal the single-process answer."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rust_dataframe_amd import _abi as A
+from rust_dataframe_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LENS = [1024] * 9 + [576]
+SEED = 99
+
+
+def _columns():
+    rng = np.random.default_rng(SEED)
+    n = sum(LENS)
+    x = rng.uniform(0, 1, n)
+    k = rng.integers(-10 ** 12, 10 ** 12, n)
+    xv = rng.uniform(size=n) > 0.1
+    cols_x, cols_k, pos = [], [], 0
+    for ln in LENS:
+        cols_x.append(A.HostArray.from_numpy(x[pos:pos + ln], xv[pos:pos + ln]))
+        cols_k.append(A.HostArray.from_numpy(k[pos:pos + ln]))
+        pos += ln
+    return cols_x, cols_k
+
+
+def _program():
+    e = A.Expr()
+    cx, ck = e.col(0), e.col(1)
+    return e, [cx, ck, e.op("multiply", cx, cx)], e.op("gt", cx, e.scalar(0.5))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from oracle import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cx, ck = _columns()
+        first, last = sharding.shard_chunks(LENS, world)[rank]
+        e, values, filt = _program()
+        local = oracle.api().pipeline(e, [cx[first:last], ck[first:last]], values, filt)
+        combined = sharding.all_combine(local)
+        q.put((rank, [(r.sum, r.min, r.max, r.count, r.is_some) for r in combined]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_plans():
+    assert [sharding.shard_rows(10 ** 9, 8, r) for r in range(8)][0] == (0, 124999680)
+    ranges = [sharding.shard_rows(1_000_000, 3, r) for r in range(3)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == 1_000_000
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    assert all(b % 1024 == 0 for b, _ in ranges)
+    plan = sharding.shard_chunks(LENS, 4)
+    assert plan[0][0] == 0 and plan[-1][1] == len(LENS) and all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+
+
+def test_combine_matches_whole(ora):
+    cx, ck = _columns()
+    e, values, filt = _program()
+    whole = ora.pipeline(e, [cx, ck], values, filt)
+    for world in (2, 3, 5):
+        parts = []
+        for first, last in sharding.shard_chunks(LENS, world):
+            parts.append(ora.pipeline(e, [cx[first:last], ck[first:last]], values, filt) if last > first else None)
+        parts = [p for p in parts if p is not None]
+        for v in range(len(values)):
+            c = sharding.combine([p[v] for p in parts])
+            assert c.count == whole[v].count and c.min == whole[v].min and c.max == whole[v].max
+            if c.dtype == A.F64:
+                assert abs(c.sum - whole[v].sum) <= 1e-12 * abs(whole[v].sum)
+            else:
+                assert c.sum == whole[v].sum
+
+
+@pytest.mark.timeout(120)
+def test_world_size_2_gloo(ora):
+    world, port = 2, 29500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cx, ck = _columns()
+    e, values, filt = _program()
+    whole = ora.pipeline(e, [cx, ck], values, filt)
+    assert results[0] == results[1], "every rank folds the same partials in the same order"
+    for v, (s, mn, mx, cnt, some) in enumerate(results[0]):
+        w = whole[v]
+        assert cnt == w.count and mn == w.min and mx == w.max and some == w.is_some
+        if w.dtype == A.F64:
+            assert abs(s - w.sum) <= 1e-12 * abs(w.sum)
+        else:
+            assert s == w.sum
