@@ -234,6 +234,12 @@ rdf_status rdf_fill_uniform_i64(int64_t* dev_ptr, int64_t n, uint64_t seed, uint
 rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uint64_t column_id,
                              int64_t first_row, double null_fraction);
 
+/* Per-thread tunables, for tests and ablations: "spec" (1 = use the ahead-of-time specialised kernels
+ * when the program shape is in the catalog, default; 0 = always the general evaluator), "fast_filter". */
+rdf_status rdf_set_option(const char* name, int64_t value);
+/* Number of program shapes with a specialised kernel. */
+int32_t    rdf_spec_catalog_size(void);
+
 /* Average duration (ms) and launch count of the dominant kernel launched by this thread since the
  * last reset, from hipEvents recorded on the stream the kernels run on (bench.py's roofline leg). */
 rdf_status rdf_kernel_timing_reset(int32_t enable);

@@ -190,6 +190,10 @@ class DeviceArray:
     null_count: int = -1
     keep: object = None
 
+    @property
+    def validity(self):
+        return self.validity_ptr
+
     def c_struct(self, unknown_null_count: bool = False) -> rdf_array:
         return rdf_array(self.values_ptr, self.validity_ptr, self.offset, self.length,
                          -1 if unknown_null_count else self.null_count, self.dtype, MEM_DEVICE)

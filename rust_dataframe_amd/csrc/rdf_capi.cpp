@@ -38,6 +38,9 @@ struct Ctx {
     char*       pinned = nullptr;
     size_t      pinned_cap = 0;
     std::string err;
+    // tunables (rdf_set_option)
+    bool   opt_spec = true;        // specialised straight-line kernels (rdf_spec.hip)
+    bool   opt_fast_filter = true; // filter_agg_f64_kernel (handles 8-byte-misaligned columns)
     // kernel timing (bench.py roofline leg)
     bool   timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -379,8 +382,9 @@ struct Compiler {
     std::vector<Instr> code;
     std::vector<int> memo;
     int tmp_used = 0, tmp_max = 0;
-    bool heavy = false;
+    bool heavy = false, intdiv = false;
     rdf_status st = RDF_OK;
+    int feat() const { return heavy ? 2 : intdiv ? 1 : 0; }
 
     Compiler(const rdf_expr_node* n, int nn, const int* cd, int nc) : nodes(n), nnodes(nn), col_dtype(cd), ncols(nc), memo((size_t)(nn > 0 ? nn : 0), -2) {}
 
@@ -518,6 +522,7 @@ struct Compiler {
         }
         const int op = nd.op;
         if (op_is_heavy(op)) heavy = true;
+        if (op == RDF_OP_DIV && !is_float(dt)) intdiv = true;
         if (!op_is_binary(op)) {
             gen(nd.lhs);
             const int l = infer(nd.lhs);
@@ -564,6 +569,88 @@ struct Compiler {
 };
 
 // ------------------------------------------------------------------------------------------------
+// specialised-kernel lookup: canonical signature of a program (same grammar as rdf_spec.hip's sig())
+
+struct SpecPlan {
+    std::string sig;
+    int col_map[4];      // canonical column -> program column
+    int ncols = 0;
+    uint64_t imm[4];
+    int nimm = 0;
+    bool ok = true;
+};
+
+char spec_tag(int dt) { return dt == RDF_F64 ? 'd' : dt == RDF_I64 ? 'l' : dt == RDF_U64 ? 'u' : dt == RDF_BOOL ? 'b' : 0; }
+
+struct SpecSigBuilder {
+    Compiler& cc;
+    SpecPlan& sp;
+    SpecSigBuilder(Compiler& c, SpecPlan& s) : cc(c), sp(s) {}
+
+    std::string leaf(int idx, int dom) {
+        const rdf_expr_node& nd = cc.nodes[idx];
+        if (nd.kind == RDF_NODE_COLUMN) {
+            const int dt = cc.col_dtype[nd.column];
+            if (dt != RDF_F64 && dt != RDF_I64 && dt != RDF_U64) { sp.ok = false; return "?"; }
+            int id = -1;
+            for (int i = 0; i < sp.ncols; ++i) if (sp.col_map[i] == nd.column) id = i;
+            if (id < 0) {
+                if (sp.ncols >= 4) { sp.ok = false; return "?"; }
+                id = sp.ncols;
+                sp.col_map[sp.ncols++] = nd.column;
+            }
+            return std::string("c") + char('0' + id) + spec_tag(dt);
+        }
+        // scalar: payload converted to `dom`
+        if (dom != RDF_F64 && dom != RDF_I64 && dom != RDF_U64) { sp.ok = false; return "?"; }
+        if (nd.dtype == RDF_NULLTYPE || sp.nimm >= 4) { sp.ok = false; return "?"; }
+        const int id = sp.nimm;
+        sp.imm[sp.nimm++] = cc.imm_for(nd, dom);
+        return std::string("k") + char('0' + id) + spec_tag(dom);
+    }
+
+    std::string node(int idx, int dom_for_scalar) {
+        if (!sp.ok) return "?";
+        const rdf_expr_node& nd = cc.nodes[idx];
+        if (nd.kind != RDF_NODE_OP) return leaf(idx, dom_for_scalar);
+        const int op = nd.op;
+        if (op_is_binary(op)) {
+            int l = nd.lhs, r = nd.rhs, o = op;
+            const int lt = cc.infer(l), rt = cc.infer(r);
+            int dom = op_is_cmp(op) ? RDF_F64 : lt;
+            if (op_is_cmp(op) && cc.nodes[l].kind == RDF_NODE_SCALAR && cc.nodes[r].kind != RDF_NODE_SCALAR) {
+                std::swap(l, r);  // c CMP x  ==  x CMP' c
+                o = op == RDF_OP_GT ? RDF_OP_LT : op == RDF_OP_GE ? RDF_OP_LE : op == RDF_OP_LT ? RDF_OP_GT : op == RDF_OP_LE ? RDF_OP_GE : op;
+            }
+            (void)rt;
+            const std::string a = node(l, dom), b = node(r, dom);
+            return "(" + std::to_string(o) + " " + a + " " + b + ")";
+        }
+        if (op == RDF_OP_CAST) {
+            const int from = cc.infer(nd.lhs);
+            if (from == nd.dtype) return node(nd.lhs, dom_for_scalar);
+            if (!spec_tag(nd.dtype) || nd.dtype == RDF_BOOL) { sp.ok = false; return "?"; }
+            return "{" + std::to_string(nd.dtype) + " " + node(nd.lhs, from) + "}";
+        }
+        return "[" + std::to_string(op) + " " + node(nd.lhs, cc.infer(nd.lhs)) + "]";
+    }
+};
+
+// Builds the plan; returns true when a specialised kernel exists for this program.
+bool build_spec_plan(Compiler& cc, int filter_root, int nvalues, const int* value_roots, int sink, SpecPlan& sp) {
+    if (nvalues > 2 || (sink == RDF_SINK_STORE && nvalues != 1)) return false;
+    SpecSigBuilder b(cc, sp);
+    std::string s = "P:";
+    s += filter_root >= 0 ? b.node(filter_root, RDF_F64) : std::string("-");
+    s += ";V:" + b.node(value_roots[0], cc.infer(value_roots[0]));
+    s += ";" + (nvalues > 1 ? b.node(value_roots[1], cc.infer(value_roots[1])) : std::string("-"));
+    s += ";S:" + std::to_string(sink == RDF_SINK_AGG ? SINK_AGG : SINK_STORE);
+    if (!sp.ok) return false;
+    sp.sig = s;
+    return spec_available(s.c_str());
+}
+
+// ------------------------------------------------------------------------------------------------
 // the fused evaluator driver
 
 struct ProgramSpec {
@@ -575,12 +662,14 @@ struct ProgramSpec {
     int sink;
 };
 
-rdf_status launch_agg_pair(const EvalArgs* ea, const FilterAggF64Args* fa, int cmp, bool heavy, int grid, int nvalues,
-                           const int* cls, AggPartial* partials, AggPartial* result) {
+rdf_status launch_agg_pair(const EvalArgs* ea, const FilterAggF64Args* fa, int cmp, int feat, int grid, int nvalues,
+                           const int* cls, AggPartial* partials, AggPartial* result, const char* spec_sig = nullptr,
+                           const SpecArgs* sa = nullptr) {
     Ctx& c = g_ctx;
     KernelTimer kt;
-    if (fa) HIP_TRY(launch_filter_agg_f64(*fa, cmp, grid, c.stream));
-    else HIP_TRY(launch_eval(*ea, SINK_AGG, heavy, grid, c.stream));
+    if (sa) HIP_TRY(launch_spec(spec_sig, *sa, grid, c.stream));
+    else if (fa) HIP_TRY(launch_filter_agg_f64(*fa, cmp, grid, c.stream));
+    else HIP_TRY(launch_eval(*ea, SINK_AGG, feat, grid, c.stream));
     kt.stop();
     AggFinalArgs f;
     memset(&f, 0, sizeof f);
@@ -786,12 +875,41 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         ea.outs = tb.dev_at<DevOutChunk>(o_outs);
     }
 
+    // specialised straight-line kernel for this program shape? (one chunk, 8-byte columns, 16-byte aligned)
+    SpecPlan sp;
+    SpecArgs sa;
+    bool use_spec = false;
+    if (ctx.opt_spec && nchunks == 1 && build_spec_plan(cc, ps.filter_root, ps.nvalues, ps.value_roots, ps.sink, sp)) {
+        memset(&sa, 0, sizeof sa);
+        use_spec = true;
+        for (int k = 0; k < sp.ncols; ++k) {
+            sa.cols[k] = in.dev[(size_t)sp.col_map[k]];
+            if (((uintptr_t)((const uint64_t*)sa.cols[k].values + sa.cols[k].offset) & 15) != 0) use_spec = false;
+        }
+        for (int k = 0; k < sp.nimm; ++k) sa.imm[k] = sp.imm[k];
+        sa.n = clen[0];
+        sa.partials = d_partials;
+        sa.flags = d_flags;
+        if (ps.sink == RDF_SINK_STORE) {
+            sa.out = dev_outs[0];
+            sa.out_null_count = d_nullc;
+            if (((uintptr_t)sa.out.values & 15) != 0 || ((uintptr_t)sa.out.validity & 7) != 0) use_spec = false;
+        }
+    }
+    const int spec_rpb = use_spec ? spec_rows_per_block_iter(sp.sig.c_str()) : 0;
+    if (use_spec) {
+        const int64_t want = (clen[0] + spec_rpb - 1) / spec_rpb;
+        grid = (int)(want < (int64_t)eval_grid_limit() ? want : (int64_t)eval_grid_limit());
+        if (grid < 1) grid = 1;
+        d_result = d_partials + (size_t)grid * (size_t)ps.nvalues;
+    }
+
     if (ps.sink == RDF_SINK_AGG) {
         // fast path: filter(x CMP c) -> aggregates of y, both f64, one chunk, 16-byte-alignable
         FilterAggF64Args fa;
         bool fast = false;
         int cmp = 0;
-        if (nchunks == 1 && ps.nvalues == 1 && ps.filter_root >= 0) {
+        if (!use_spec && ctx.opt_fast_filter && nchunks == 1 && ps.nvalues == 1 && ps.filter_root >= 0) {
             const rdf_expr_node& fr = ps.nodes[ps.filter_root];
             const rdf_expr_node& vr = ps.nodes[ps.value_roots[0]];
             if (fr.kind == RDF_NODE_OP && op_is_cmp(fr.op) && vr.kind == RDF_NODE_COLUMN && col_dtype[vr.column] == RDF_F64) {
@@ -822,16 +940,18 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
                 }
             }
         }
-        if (fast) {
+        if (use_spec) {
+            RDF_TRY(launch_agg_pair(nullptr, nullptr, 0, 0, grid, ps.nvalues, cls, d_partials, d_result, sp.sig.c_str(), &sa));
+        } else if (fast) {
             const int64_t per_block = (int64_t)kBlock * 4 * 2;  // rows per block iteration
             int64_t want = (clen[0] + per_block - 1) / per_block;
             grid = (int)(want < (int64_t)eval_grid_limit() ? want : (int64_t)eval_grid_limit());
             if (grid < 1) grid = 1;
             // partials/result were sized for the eval grid (>= this grid, since its tiles are smaller)
             d_result = d_partials + (size_t)grid * (size_t)ps.nvalues;
-            RDF_TRY(launch_agg_pair(nullptr, &fa, cmp, false, grid, 1, cls, d_partials, d_result));
+            RDF_TRY(launch_agg_pair(nullptr, &fa, cmp, 0, grid, 1, cls, d_partials, d_result));
         } else {
-            RDF_TRY(launch_agg_pair(&ea, nullptr, 0, cc.heavy, grid, ps.nvalues, cls, d_partials, d_result));
+            RDF_TRY(launch_agg_pair(&ea, nullptr, 0, cc.feat(), grid, ps.nvalues, cls, d_partials, d_result));
         }
         // results: flags + aggregates in one D2H
         RDF_TRY(pinned_reserve(pin_off + 64 + sizeof(AggPartial) * kMaxValues));
@@ -853,7 +973,8 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     // SINK_STORE
     {
         KernelTimer kt;
-        HIP_TRY(launch_eval(ea, SINK_STORE, cc.heavy, grid, ctx.stream));
+        if (use_spec) HIP_TRY(launch_spec(sp.sig.c_str(), sa, grid, ctx.stream));
+        else HIP_TRY(launch_eval(ea, SINK_STORE, cc.feat(), grid, ctx.stream));
         kt.stop();
     }
     RDF_TRY(pinned_reserve(pin_off + 64 + n_nc * 8 + outr.small_bytes + 256));
@@ -1413,6 +1534,15 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     return RDF_OK;
 }
+
+rdf_status rdf_set_option(const char* name, int64_t value) {
+    if (!name) return fail(RDF_INVALID_ARGUMENT, "null option name");
+    if (strcmp(name, "spec") == 0) g_ctx.opt_spec = value != 0;
+    else if (strcmp(name, "fast_filter") == 0) g_ctx.opt_fast_filter = value != 0;
+    else return fail(RDF_INVALID_ARGUMENT, "unknown option %s", name);
+    return RDF_OK;
+}
+int32_t rdf_spec_catalog_size(void) { return spec_catalog_size(); }
 
 rdf_status rdf_kernel_timing_reset(int32_t enable) {
     RDF_TRY(ensure_ready());

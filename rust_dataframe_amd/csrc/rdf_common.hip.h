@@ -1,0 +1,136 @@
+// rdf_common.hip.h — device-side helpers shared by the kernel translation units.
+#pragma once
+#include "rdf_device.h"
+
+namespace rdfk {
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+// wave index inside the block as a scalar (the compiler cannot prove threadIdx.x >> 6 uniform)
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+__device__ __forceinline__ int clamp64(int64_t v) { return v <= 0 ? 0 : (v >= 64 ? 64 : (int)v); }
+
+// NW consecutive 64-bit windows of an LSB-first bitmap starting at bit `bitpos` (wave-uniform), rows
+// past `nbits` cleared.  All NW+1 aligned words are fetched with independent scalar loads (indices
+// clamped to the last word that holds a requested bit, so nothing outside the ABI's "readable to the
+// next 8-byte boundary" is touched) and funnel-shifted on the scalar unit: no branches between the
+// loads, no VALU work.
+template <int NW>
+__device__ __forceinline__ void load_windows(const uint8_t* base, int64_t bitpos, int64_t nbits, uint64_t (&win)[NW]) {
+    if (nbits <= 0) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) win[j] = 0;
+        return;
+    }
+    const uint64_t addr = uniform64((uint64_t)(uintptr_t)base + (uint64_t)(bitpos >> 3));
+    const uint64_t* w = (const uint64_t*)(uintptr_t)(addr & ~7ull);
+    const int sh = __builtin_amdgcn_readfirstlane((int)(addr & 7) * 8 + (int)(bitpos & 7));
+    const int64_t want = nbits < (int64_t)64 * NW ? nbits : (int64_t)64 * NW;
+    const int last = __builtin_amdgcn_readfirstlane((int)((sh + want - 1) >> 6));  // index of the last needed word
+    uint64_t word[NW + 1];
+#pragma unroll
+    for (int i = 0; i <= NW; ++i) word[i] = w[i < last ? i : last];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        uint64_t r = word[j] >> sh;
+        if (sh) r |= word[j + 1] << (64 - sh);
+        const int64_t left = nbits - (int64_t)64 * j;
+        if (left < 64) r = left <= 0 ? 0 : (r & ((1ull << left) - 1));
+        win[j] = r;
+    }
+}
+
+// single window (kept for call sites that need just one)
+__device__ __forceinline__ uint64_t load_bits64(const uint8_t* base, int64_t bitpos, int nbits) {
+    uint64_t w[1];
+    load_windows<1>(base, bitpos, nbits, w);
+    return w[0];
+}
+
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ double u2d(uint64_t v) { return __longlong_as_double((long long)v); }
+__device__ __forceinline__ uint64_t d2u(double v) { return (uint64_t)__double_as_longlong(v); }
+__device__ __forceinline__ float u2f(uint64_t v) { return __uint_as_float((uint32_t)v); }
+__device__ __forceinline__ uint64_t f2u(float v) { return (uint64_t)__float_as_uint(v); }
+
+// Integers live in the accumulator sign-/zero-extended to 64 bits.
+__device__ __forceinline__ uint64_t normalize_int(int dt, uint64_t x) {
+    switch (dt) {
+        case RDF_I8: return (uint64_t)(int64_t)(int8_t)x;
+        case RDF_I16: return (uint64_t)(int64_t)(int16_t)x;
+        case RDF_I32: return (uint64_t)(int64_t)(int32_t)x;
+        case RDF_U8: return x & 0xFFull;
+        case RDF_U16: return x & 0xFFFFull;
+        case RDF_U32: return x & 0xFFFFFFFFull;
+        default: return x;
+    }
+}
+__device__ __forceinline__ bool dt_is_signed(int dt) { return dt <= RDF_I64; }
+
+// ---- aggregate combine by class (F64: ieee add / NaN-ignoring min,max; ints: wrapping add) ----
+__device__ __forceinline__ void agg_init(int cls, uint64_t& sum, uint64_t& mn, uint64_t& mx, int64_t& cnt) {
+    cnt = 0;
+    if (cls == CLS_F64) { sum = d2u(0.0); mn = mx = 0x7FF8000000000000ull; }
+    else if (cls == CLS_SIGNED) { sum = 0; mn = (uint64_t)INT64_MAX; mx = (uint64_t)INT64_MIN; }
+    else { sum = 0; mn = ~0ull; mx = 0; }
+}
+__device__ __forceinline__ void agg_merge(int cls, uint64_t& sum, uint64_t& mn, uint64_t& mx, int64_t& cnt,
+                                          uint64_t s2, uint64_t mn2, uint64_t mx2, int64_t c2) {
+    cnt += c2;
+    if (cls == CLS_F64) {
+        sum = d2u(u2d(sum) + u2d(s2));
+        mn = d2u(fmin(u2d(mn), u2d(mn2)));
+        mx = d2u(fmax(u2d(mx), u2d(mx2)));
+    } else if (cls == CLS_SIGNED) {
+        sum += s2;
+        mn = (uint64_t)((int64_t)mn2 < (int64_t)mn ? (int64_t)mn2 : (int64_t)mn);
+        mx = (uint64_t)((int64_t)mx2 > (int64_t)mx ? (int64_t)mx2 : (int64_t)mx);
+    } else {
+        sum += s2;
+        mn = mn2 < mn ? mn2 : mn;
+        mx = mx2 > mx ? mx2 : mx;
+    }
+}
+
+// Block-wide reduction of one aggregate: wave butterfly (fixed order => deterministic), then the 4
+// wave results folded in wave order by thread 0.
+__device__ __forceinline__ void block_reduce_agg(int cls, uint64_t sum, uint64_t mn, uint64_t mx, int64_t cnt,
+                                                 AggPartial* lds4, AggPartial* out) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        uint64_t s2 = shfl_xor64(sum, m), mn2 = shfl_xor64(mn, m), mx2 = shfl_xor64(mx, m);
+        int64_t c2 = (int64_t)shfl_xor64((uint64_t)cnt, m);
+        agg_merge(cls, sum, mn, mx, cnt, s2, mn2, mx2, c2);
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { lds4[wave].sum = sum; lds4[wave].mn = mn; lds4[wave].mx = mx; lds4[wave].cnt = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t s = lds4[0].sum, a = lds4[0].mn, b = lds4[0].mx;
+        int64_t c = lds4[0].cnt;
+        for (int w = 1; w < kBlock / 64; ++w) agg_merge(cls, s, a, b, c, lds4[w].sum, lds4[w].mn, lds4[w].mx, lds4[w].cnt);
+        out->sum = s; out->mn = a; out->mx = b; out->cnt = c;
+    }
+}
+
+// largest c in [0, n) with start[c] <= t (start is a non-decreasing prefix table; scalar loads)
+__device__ __forceinline__ int64_t find_chunk(const int64_t* start, int64_t n, int64_t t) {
+    int64_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (start[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+}  // namespace rdfk

@@ -90,6 +90,17 @@ struct FilterAggF64Args {
     AggPartial*    partials;   // [gridDim.x]
 };
 
+// Specialised straight-line kernels (rdf_spec.hip): up to 4 eight-byte columns, one chunk.
+struct SpecArgs {
+    DevChunkCol cols[4];
+    int64_t     n;
+    uint64_t    imm[4];
+    DevOutChunk out;             // SINK_STORE
+    int64_t*    out_null_count;  // SINK_STORE
+    AggPartial* partials;        // SINK_AGG: [gridDim.x * nvalues]
+    uint32_t*   flags;
+};
+
 struct MaskTables {
     const DevChunkCol* mask;             // [nchunks]; values = bit-packed booleans
     const int64_t*     chunk_tile_start; // [nchunks + 1], tiles of kFilterTile rows
@@ -120,8 +131,12 @@ struct TakeArgs {
 
 // ---- launch wrappers (defined in rdf_kernels.hip) ----
 int  eval_grid_limit();   // persistent grid size for streaming kernels
-hipError_t launch_eval(const EvalArgs& a, int sink, bool heavy, int grid, hipStream_t s);
+hipError_t launch_eval(const EvalArgs& a, int sink, int feat, int grid, hipStream_t s);  // feat: 0 basic, 1 +int div, 2 +libm
 hipError_t launch_agg_final(const AggFinalArgs& a, hipStream_t s);
+bool spec_available(const char* sig);
+int  spec_rows_per_block_iter(const char* sig);
+int  spec_catalog_size();
+hipError_t launch_spec(const char* sig, const SpecArgs& a, int grid, hipStream_t s);
 hipError_t launch_filter_agg_f64(const FilterAggF64Args& a, int cmp_op, int grid, hipStream_t s);
 hipError_t launch_mask_count(const MaskTables& t, int64_t* tile_counts, hipStream_t s);
 hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, hipStream_t s);

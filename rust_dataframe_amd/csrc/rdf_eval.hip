@@ -1,0 +1,516 @@
+// rdf_eval.hip — the fused expression-tree evaluator (compiled once per feature level, -DRDF_FEAT=0|1|2).
+//
+//   eval_kernel<FEAT, SINK, NPRE, NVAL>
+//     [Evaluate::calculate src/evaluation.rs:97-323 + ScalarFunctions src/functions/scalar.rs:16-540 +
+//      BooleanFilter::eval_to_array src/expression.rs:766-861 + AggregateFunctions
+//      src/functions/aggregate.rs:12-93 — a maximal run of the batch loop's steps in ONE pass over HBM]
+//
+// One persistent block walks 1024-row tiles (= the reference's RecordBatch size).  Wave w owns rows
+// [256w, 256w+256) of the tile, lane l row 64j + l of it for j = 0..3, so every load instruction of a
+// wave covers 64 consecutive elements (512 B for 8-byte types) and the wave's validity bits are four
+// consecutive 64-bit windows fetched with a handful of independent scalar loads.  Per tile:
+//   (1) ALL loads of the NPRE preloaded columns are issued up front (memory-level parallelism),
+//   (2) the wave-uniform accumulator-machine bytecode runs over registers (scalar branches only),
+//   (3) the sink consumes: coalesced stores + ballot-built bitmaps (STORE), or running
+//       {sum,min,max,count} folded block-wide once at the end (AGG, two-stage reduction).
+// Template parameters exist to keep VGPRs (and with them occupancy) where a streaming kernel needs
+// them: FEAT 0 = arithmetic/compare/cast/boolean, 1 = + integer division, 2 = + libm functions;
+// NPRE = columns held in registers; NVAL = value expressions with live aggregate state.
+#include "rdf_common.hip.h"
+
+#ifndef RDF_FEAT
+#error "compile with -DRDF_FEAT=0|1|2"
+#endif
+
+namespace rdfk {
+
+// ------------------------------------------------------------------------------------------------
+// conversions (arrow::compute::cast: Rust `as` semantics — float->int saturates, NaN -> 0)
+
+__device__ __forceinline__ uint64_t cast_value(int from, int to, uint64_t x) {
+    if (from == to) return x;
+    double f = 0.0;
+    bool src_float = false;
+    if (from == RDF_F64) { f = u2d(x); src_float = true; }
+    else if (from == RDF_F32) { f = (double)u2f(x); src_float = true; }
+    if (to == RDF_BOOL) return src_float ? (uint64_t)(f != 0.0) : (uint64_t)(x != 0);
+    if (to == RDF_F64) {
+        if (src_float) return d2u(f);
+        return d2u(dt_is_signed(from) ? (double)(int64_t)x : (double)x);
+    }
+    if (to == RDF_F32) {
+        if (from == RDF_F64) return f2u((float)u2d(x));
+        return f2u(dt_is_signed(from) ? (float)(int64_t)x : (float)x);
+    }
+    if (src_float) {
+        if (f != f) return 0;
+        switch (to) {
+            case RDF_I8: return (uint64_t)(int64_t)(f < -128.0 ? -128.0 : f > 127.0 ? 127.0 : f);
+            case RDF_I16: return (uint64_t)(int64_t)(f < -32768.0 ? -32768.0 : f > 32767.0 ? 32767.0 : f);
+            case RDF_I32: return (uint64_t)(int64_t)(f < -2147483648.0 ? -2147483648.0 : f > 2147483647.0 ? 2147483647.0 : f);
+            case RDF_I64:
+                if (f >= 9223372036854775808.0) return (uint64_t)INT64_MAX;
+                if (f <= -9223372036854775808.0) return (uint64_t)INT64_MIN;
+                return (uint64_t)(int64_t)f;
+            case RDF_U8: return (uint64_t)(f < 0.0 ? 0.0 : f > 255.0 ? 255.0 : f);
+            case RDF_U16: return (uint64_t)(f < 0.0 ? 0.0 : f > 65535.0 ? 65535.0 : f);
+            case RDF_U32: return (uint64_t)(f < 0.0 ? 0.0 : f > 4294967295.0 ? 4294967295.0 : f);
+            default:
+                if (f <= 0.0) return 0;
+                if (f >= 18446744073709551616.0) return ~0ull;
+                return (uint64_t)f;
+        }
+    }
+    return normalize_int(to, x);  // int/bool -> int: truncate
+}
+
+// ------------------------------------------------------------------------------------------------
+// column loads: row(j) of this lane = r0 + 256*wave + 64*j + lane
+
+__device__ __forceinline__ void load_col(const DevChunkCol cc, int dt, int64_t rw, int64_t clen, uint32_t inr,
+                                         uint64_t (&v)[kVPT], uint32_t& valid) {
+    // rw = first row of this wave's 256-row span (wave-uniform)
+    const int lane = threadIdx.x & 63;
+    const int64_t e0 = cc.offset + rw + lane;
+    switch (dt) {
+        case RDF_I64: case RDF_U64: case RDF_F64: {
+            const uint64_t* p = (const uint64_t*)cc.values + e0;
+#pragma unroll
+            for (int j = 0; j < kVPT; ++j) v[j] = (inr >> j) & 1 ? __builtin_nontemporal_load(p + j * 64) : 0;
+        } break;
+        case RDF_I32: case RDF_U32: case RDF_F32: {
+            const uint32_t* p = (const uint32_t*)cc.values + e0;
+#pragma unroll
+            for (int j = 0; j < kVPT; ++j) {
+                uint32_t t = (inr >> j) & 1 ? __builtin_nontemporal_load(p + j * 64) : 0;
+                v[j] = dt == RDF_I32 ? (uint64_t)(int64_t)(int32_t)t : (uint64_t)t;
+            }
+        } break;
+        case RDF_I16: case RDF_U16: {
+            const uint16_t* p = (const uint16_t*)cc.values + e0;
+#pragma unroll
+            for (int j = 0; j < kVPT; ++j) {
+                uint16_t t = (inr >> j) & 1 ? p[j * 64] : (uint16_t)0;
+                v[j] = dt == RDF_I16 ? (uint64_t)(int64_t)(int16_t)t : (uint64_t)t;
+            }
+        } break;
+        case RDF_I8: case RDF_U8: {
+            const uint8_t* p = (const uint8_t*)cc.values + e0;
+#pragma unroll
+            for (int j = 0; j < kVPT; ++j) {
+                uint8_t t = (inr >> j) & 1 ? p[j * 64] : (uint8_t)0;
+                v[j] = dt == RDF_I8 ? (uint64_t)(int64_t)(int8_t)t : (uint64_t)t;
+            }
+        } break;
+        default: {  // RDF_BOOL: bit-packed values
+            uint64_t w[kVPT];
+            load_windows<kVPT>((const uint8_t*)cc.values, cc.offset + rw, clen - rw, w);
+#pragma unroll
+            for (int j = 0; j < kVPT; ++j) v[j] = (w[j] >> lane) & 1;
+        }
+    }
+    valid = (1u << kVPT) - 1;
+    if (cc.validity) {
+        uint64_t w[kVPT];
+        load_windows<kVPT>(cc.validity, cc.offset + rw, clen - rw, w);
+        valid = 0;
+#pragma unroll
+        for (int j = 0; j < kVPT; ++j) valid |= (uint32_t)((w[j] >> lane) & 1) << j;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// arithmetic
+
+template <int FEAT>
+__device__ __forceinline__ double unary_f64(int op, double x) {
+    switch (op) {
+        case RDF_OP_ABS: return fabs(x);
+        case RDF_OP_CEIL: return ceil(x);
+        case RDF_OP_FLOOR: return floor(x);
+        case RDF_OP_ROUND: return round(x);
+        case RDF_OP_SQRT: return sqrt(x);
+        case RDF_OP_DEGREES: return x * (180.0 / 3.14159265358979323846264338327950288);
+        case RDF_OP_RADIANS: return x * (3.14159265358979323846264338327950288 / 180.0);
+        default: break;
+    }
+    if constexpr (FEAT >= 2) {
+        switch (op) {
+            case RDF_OP_ACOS: return acos(x);
+            case RDF_OP_ASIN: return asin(x);
+            case RDF_OP_ATAN: return atan(x);
+            case RDF_OP_CBRT: return cbrt(x);
+            case RDF_OP_COS: return cos(x);
+            case RDF_OP_COSH: return cosh(x);
+            case RDF_OP_EXP: return exp(x);
+            case RDF_OP_EXPM1: return expm1(x);
+            case RDF_OP_LOG10: return log10(x);
+            case RDF_OP_LOG2: return log2(x);
+            case RDF_OP_SIN: return sin(x);
+            case RDF_OP_SINH: return sinh(x);
+            case RDF_OP_TAN: return tan(x);
+            case RDF_OP_TANH: return tanh(x);
+            default: break;
+        }
+    }
+    return x;
+}
+template <int FEAT>
+__device__ __forceinline__ float unary_f32(int op, float x) {
+    switch (op) {
+        case RDF_OP_ABS: return fabsf(x);
+        case RDF_OP_CEIL: return ceilf(x);
+        case RDF_OP_FLOOR: return floorf(x);
+        case RDF_OP_ROUND: return roundf(x);
+        case RDF_OP_SQRT: return sqrtf(x);
+        case RDF_OP_DEGREES: return x * 57.2957795130823208767981548141051703f;
+        case RDF_OP_RADIANS: return x * (3.14159265358979323846264338327950288f / 180.0f);
+        default: break;
+    }
+    if constexpr (FEAT >= 2) {
+        switch (op) {
+            case RDF_OP_ACOS: return acosf(x);
+            case RDF_OP_ASIN: return asinf(x);
+            case RDF_OP_ATAN: return atanf(x);
+            case RDF_OP_CBRT: return cbrtf(x);
+            case RDF_OP_COS: return cosf(x);
+            case RDF_OP_COSH: return coshf(x);
+            case RDF_OP_EXP: return expf(x);
+            case RDF_OP_EXPM1: return expm1f(x);
+            case RDF_OP_LOG10: return log10f(x);
+            case RDF_OP_LOG2: return log2f(x);
+            case RDF_OP_SIN: return sinf(x);
+            case RDF_OP_SINH: return sinhf(x);
+            case RDF_OP_TAN: return tanf(x);
+            case RDF_OP_TANH: return tanhf(x);
+            default: break;
+        }
+    }
+    return x;
+}
+
+#define RDF_ROWS _Pragma("unroll") for (int j = 0; j < kVPT; ++j)
+
+// acc = acc OP b.  `live` = rows where both sides are valid and in range (divide-by-zero is only an
+// error there, like arrow's math_divide).
+template <int FEAT>
+__device__ __forceinline__ void apply_binary(int op, int dt, uint64_t (&acc)[kVPT], const uint64_t (&b)[kVPT],
+                                             uint32_t live, uint32_t& err) {
+    if (op >= RDF_OP_GT && op <= RDF_OP_LE) {  // f64 comparisons (src/expression.rs:844-852)
+        switch (op) {
+            case RDF_OP_GT: RDF_ROWS acc[j] = u2d(acc[j]) > u2d(b[j]); break;
+            case RDF_OP_GE: RDF_ROWS acc[j] = u2d(acc[j]) >= u2d(b[j]); break;
+            case RDF_OP_EQ: RDF_ROWS acc[j] = u2d(acc[j]) == u2d(b[j]); break;
+            case RDF_OP_NE: RDF_ROWS acc[j] = u2d(acc[j]) != u2d(b[j]); break;
+            case RDF_OP_LT: RDF_ROWS acc[j] = u2d(acc[j]) < u2d(b[j]); break;
+            default: RDF_ROWS acc[j] = u2d(acc[j]) <= u2d(b[j]); break;
+        }
+        return;
+    }
+    if (op == RDF_OP_AND) { RDF_ROWS acc[j] = acc[j] & b[j]; return; }
+    if (op == RDF_OP_OR) { RDF_ROWS acc[j] = acc[j] | b[j]; return; }
+    if (dt == RDF_F64) {
+        switch (op) {
+            case RDF_OP_ADD: RDF_ROWS acc[j] = d2u(u2d(acc[j]) + u2d(b[j])); break;
+            case RDF_OP_SUB: RDF_ROWS acc[j] = d2u(u2d(acc[j]) - u2d(b[j])); break;
+            case RDF_OP_MUL: RDF_ROWS acc[j] = d2u(u2d(acc[j]) * u2d(b[j])); break;
+            case RDF_OP_DIV:
+                RDF_ROWS {
+                    bool z = u2d(b[j]) == 0.0;
+                    if (z && ((live >> j) & 1)) err |= 1u;
+                    acc[j] = z ? 0 : d2u(u2d(acc[j]) / u2d(b[j]));
+                }
+                break;
+            default:
+                if constexpr (FEAT >= 2) {
+                    if (op == RDF_OP_ATAN2) RDF_ROWS acc[j] = d2u(atan2(u2d(acc[j]), u2d(b[j])));
+                    else if (op == RDF_OP_HYPOT) RDF_ROWS acc[j] = d2u(hypot(u2d(acc[j]), u2d(b[j])));
+                    else RDF_ROWS acc[j] = d2u(log(u2d(acc[j])) / log(u2d(b[j])));
+                }
+        }
+        return;
+    }
+    if (dt == RDF_F32) {
+        switch (op) {
+            case RDF_OP_ADD: RDF_ROWS acc[j] = f2u(u2f(acc[j]) + u2f(b[j])); break;
+            case RDF_OP_SUB: RDF_ROWS acc[j] = f2u(u2f(acc[j]) - u2f(b[j])); break;
+            case RDF_OP_MUL: RDF_ROWS acc[j] = f2u(u2f(acc[j]) * u2f(b[j])); break;
+            case RDF_OP_DIV:
+                RDF_ROWS {
+                    bool z = u2f(b[j]) == 0.0f;
+                    if (z && ((live >> j) & 1)) err |= 1u;
+                    acc[j] = z ? 0 : f2u(u2f(acc[j]) / u2f(b[j]));
+                }
+                break;
+            default:
+                if constexpr (FEAT >= 2) {
+                    if (op == RDF_OP_ATAN2) RDF_ROWS acc[j] = f2u(atan2f(u2f(acc[j]), u2f(b[j])));
+                    else if (op == RDF_OP_HYPOT) RDF_ROWS acc[j] = f2u(hypotf(u2f(acc[j]), u2f(b[j])));
+                    else RDF_ROWS acc[j] = f2u(logf(u2f(acc[j])) / logf(u2f(b[j])));
+                }
+        }
+        return;
+    }
+    // integers: wrapping arithmetic in 64 bits, then re-normalised to the value's width
+    switch (op) {
+        case RDF_OP_ADD: RDF_ROWS acc[j] = normalize_int(dt, acc[j] + b[j]); break;
+        case RDF_OP_SUB: RDF_ROWS acc[j] = normalize_int(dt, acc[j] - b[j]); break;
+        case RDF_OP_MUL: RDF_ROWS acc[j] = normalize_int(dt, acc[j] * b[j]); break;
+        default:  // DIV
+            if constexpr (FEAT >= 1) {
+                RDF_ROWS {
+                    bool z = b[j] == 0;
+                    if (z && ((live >> j) & 1)) err |= 1u;
+                    uint64_t q;
+                    if (z) q = 0;
+                    else if (dt_is_signed(dt)) {
+                        int64_t x = (int64_t)acc[j], y = (int64_t)b[j];
+                        q = y == -1 ? (uint64_t)0 - (uint64_t)x : (uint64_t)(x / y);  // MIN / -1 wraps
+                    } else q = acc[j] / b[j];
+                    acc[j] = normalize_int(dt, q);
+                }
+            }
+    }
+}
+
+template <int FEAT>
+__device__ __forceinline__ void apply_unary(int op, int dt, uint64_t (&acc)[kVPT]) {
+    if (op == RDF_OP_NOT) { RDF_ROWS acc[j] = acc[j] ^ 1ull; return; }
+    if (dt == RDF_F64) { RDF_ROWS acc[j] = d2u(unary_f64<FEAT>(op, u2d(acc[j]))); return; }
+    if (dt == RDF_F32) { RDF_ROWS acc[j] = f2u(unary_f32<FEAT>(op, u2f(acc[j]))); return; }
+    // num::abs on signed integers; MIN wraps
+    RDF_ROWS { int64_t x = (int64_t)acc[j]; acc[j] = normalize_int(dt, x < 0 ? (uint64_t)0 - (uint64_t)x : (uint64_t)x); }
+}
+
+// ------------------------------------------------------------------------------------------------
+
+template <int FEAT, int SINK, int NPRE, int NVAL>
+__global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ AggPartial red_lds[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id();
+
+    uint64_t g_sum[NVAL], g_mn[NVAL], g_mx[NVAL];
+    int64_t g_cnt[NVAL];
+    if (SINK == SINK_AGG) {
+#pragma unroll
+        for (int k = 0; k < NVAL; ++k) agg_init(k < a.nvalues ? a.value_cls[k] : CLS_F64, g_sum[k], g_mn[k], g_mx[k], g_cnt[k]);
+    }
+    uint32_t err = 0;
+    // SINK_STORE: per-wave null counters, flushed with one atomic per (value, chunk) when the block
+    // moves on to another chunk — never one atomic per tile
+    uint32_t nullacc[NVAL];
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k) nullacc[k] = 0;
+    int64_t cur_chunk = -1;
+
+    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int64_t c = 0, r0, clen;
+        if (a.nchunks == 1) { r0 = tile * kEvalTile; clen = a.inline_len; }
+        else {
+            c = find_chunk(a.chunk_tile_start, a.nchunks, tile);
+            r0 = (tile - a.chunk_tile_start[c]) * kEvalTile;
+            clen = a.chunk_len[c];
+        }
+        if (SINK == SINK_STORE && c != cur_chunk) {
+            if (cur_chunk >= 0 && lane == 0) {
+#pragma unroll
+                for (int k = 0; k < NVAL; ++k)
+                    if (k < a.nvalues && nullacc[k]) {
+                        atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)k * a.nchunks + cur_chunk], (unsigned long long)nullacc[k]);
+                        nullacc[k] = 0;
+                    }
+            }
+            cur_chunk = c;
+        }
+        const int64_t rw = r0 + (int64_t)wave * (kVPT * 64);  // this wave's first row
+        uint32_t inr = 0;
+#pragma unroll
+        for (int j = 0; j < kVPT; ++j) inr |= (uint32_t)(rw + j * 64 + lane < clen) << j;
+
+        // (1) preload
+        uint64_t colv[NPRE][kVPT];
+        uint32_t colvalid[NPRE];
+#pragma unroll
+        for (int p = 0; p < NPRE; ++p) {
+            if (p < a.ncols) {
+                const DevChunkCol cc = a.nchunks == 1 ? a.inline_cols[p] : a.cols[(int64_t)p * a.nchunks + c];
+                load_col(cc, a.col_dtype[p], rw, clen, inr, colv[p], colvalid[p]);
+            } else {
+                colvalid[p] = 0;
+#pragma unroll
+                for (int j = 0; j < kVPT; ++j) colv[p][j] = 0;
+            }
+        }
+
+        // (2) interpret
+        uint64_t acc[kVPT];
+        uint32_t accv = 0, keep = inr;
+#pragma unroll
+        for (int j = 0; j < kVPT; ++j) acc[j] = 0;
+
+        for (int pc = 0; pc < a.ncode; ++pc) {
+            const Instr in = a.code[pc];
+            uint64_t opnd[kVPT];
+            uint32_t opv = (1u << kVPT) - 1;
+            if (in.bc == BC_LOAD || in.bc == BC_BIN) {
+                if (in.src_kind == SRC_COL) {
+                    const int ci = in.src;
+                    bool hit = false;
+#pragma unroll
+                    for (int p = 0; p < NPRE; ++p)
+                        if (p == ci) {
+                            hit = true;
+                            opv = colvalid[p];
+#pragma unroll
+                            for (int j = 0; j < kVPT; ++j) opnd[j] = colv[p][j];
+                        }
+                    if (!hit) {
+                        const DevChunkCol cc = a.nchunks == 1 ? a.inline_cols[ci & (kMaxCols - 1)] : a.cols[(int64_t)ci * a.nchunks + c];
+                        load_col(cc, a.col_dtype[ci & (kMaxCols - 1)], rw, clen, inr, opnd, opv);
+                    }
+                } else if (in.src_kind == SRC_IMM) {
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) opnd[j] = in.imm;
+                } else {  // SRC_TMP
+                    const uint64_t* tv = (const uint64_t*)smem + (size_t)in.src * kVPT * kBlock + tid;
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) opnd[j] = tv[j * kBlock];
+                    opv = ((const uint32_t*)(smem + (size_t)a.ntmp * kVPT * kBlock * 8))[in.src * kBlock + tid];
+                }
+                if (in.src_dtype != in.dtype) {
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) opnd[j] = cast_value(in.src_dtype, in.dtype, opnd[j]);
+                }
+            }
+            switch (in.bc) {
+                case BC_LOAD:
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) acc[j] = opnd[j];
+                    accv = opv;
+                    break;
+                case BC_STORE_TMP: {
+                    uint64_t* tv = (uint64_t*)smem + (size_t)in.src * kVPT * kBlock + tid;
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) tv[j * kBlock] = acc[j];
+                    ((uint32_t*)(smem + (size_t)a.ntmp * kVPT * kBlock * 8))[in.src * kBlock + tid] = accv;
+                } break;
+                case BC_BIN: {
+                    if (in.swapped) {
+#pragma unroll
+                        for (int j = 0; j < kVPT; ++j) { uint64_t t = acc[j]; acc[j] = opnd[j]; opnd[j] = t; }
+                    }
+                    accv &= opv;
+                    apply_binary<FEAT>(in.op, in.dtype, acc, opnd, accv & inr, err);
+                } break;
+                case BC_UN:
+                    apply_unary<FEAT>(in.op, in.dtype, acc);
+                    break;
+                case BC_CAST:
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) acc[j] = cast_value(in.src_dtype, in.dtype, acc[j]);
+                    break;
+                case BC_FILTER:  // DataFrame::filter: rows whose predicate is false or null are dropped
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) keep &= ~((uint32_t)(((acc[j] & 1) == 0) || (((accv >> j) & 1) == 0)) << j);
+                    break;
+                default: {  // BC_EMIT: acc is value expression `in.src`
+                    const int k = in.src;
+                    if (SINK == SINK_AGG) {
+                        const uint32_t live = keep & accv & inr;
+#pragma unroll
+                        for (int kk = 0; kk < NVAL; ++kk)
+                            if (kk == k) {
+                                const int cls = a.value_cls[kk];
+#pragma unroll
+                                for (int j = 0; j < kVPT; ++j)
+                                    if ((live >> j) & 1) {
+                                        uint64_t v = acc[j];
+                                        if (in.dtype == RDF_F32) v = d2u((double)u2f(v));
+                                        agg_merge(cls, g_sum[kk], g_mn[kk], g_mx[kk], g_cnt[kk], v, v, v, 1);
+                                    }
+                            }
+                    } else {
+                        const DevOutChunk oc = a.nchunks == 1 ? a.inline_outs[k & (kMaxValues - 1)] : a.outs[(int64_t)k * a.nchunks + c];
+                        const int dt = in.dtype;
+                        uint32_t nn = 0;
+#pragma unroll
+                        for (int j = 0; j < kVPT; ++j) {
+                            const int64_t row = rw + j * 64 + lane;
+                            const bool ok = (inr >> j) & 1;
+                            const bool valid = (accv >> j) & 1;
+                            const uint64_t v = valid ? acc[j] : 0;  // null slots hold 0
+                            const uint64_t ib = __ballot(ok);
+                            if (dt == RDF_BOOL) {
+                                const uint64_t bits = __ballot(ok && valid && (v & 1));
+                                if (lane == 0 && ib) ((uint64_t*)oc.values)[(rw + j * 64) >> 6] = bits;
+                            } else if (ok) {
+                                switch (dt) {
+                                    case RDF_I64: case RDF_U64: case RDF_F64: ((uint64_t*)oc.values)[row] = v; break;
+                                    case RDF_I32: case RDF_U32: case RDF_F32: ((uint32_t*)oc.values)[row] = (uint32_t)v; break;
+                                    case RDF_I16: case RDF_U16: ((uint16_t*)oc.values)[row] = (uint16_t)v; break;
+                                    default: ((uint8_t*)oc.values)[row] = (uint8_t)v; break;
+                                }
+                            }
+                            const uint64_t vb = __ballot(ok && valid);
+                            if (lane == 0 && ib) {
+                                if (oc.validity) ((uint64_t*)oc.validity)[(rw + j * 64) >> 6] = vb;
+                                nn += (uint32_t)__popcll(ib & ~vb);
+                            }
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < NVAL; ++kk)
+                            if (kk == k) nullacc[kk] += nn;
+                    }
+                }
+            }
+        }
+    }
+
+    if (SINK == SINK_STORE && cur_chunk >= 0 && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NVAL; ++k)
+            if (k < a.nvalues && nullacc[k])
+                atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)k * a.nchunks + cur_chunk], (unsigned long long)nullacc[k]);
+    }
+    if (err) atomicOr(a.flags, err);
+    if (SINK == SINK_AGG) {
+#pragma unroll
+        for (int k = 0; k < NVAL; ++k)
+            if (k < a.nvalues)
+                block_reduce_agg(a.value_cls[k], g_sum[k], g_mn[k], g_mx[k], g_cnt[k], red_lds,
+                                 &a.partials[(int64_t)blockIdx.x * a.nvalues + k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch: (NPRE, NVAL) in {(1,1),(2,1),(2,2),(4,1),(4,2),(4,4)}
+
+template <int SINK, int NPRE, int NVAL>
+static void launch_one(const EvalArgs& a, int grid, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((eval_kernel<RDF_FEAT, SINK, NPRE, NVAL>), dim3(grid), dim3(kBlock), lds, s, a);
+}
+template <int SINK>
+static void launch_shape(const EvalArgs& a, int npre, int nval, int grid, size_t lds, hipStream_t s) {
+    if (nval <= 1) {
+        if (npre <= 1) launch_one<SINK, 1, 1>(a, grid, lds, s);
+        else if (npre <= 2) launch_one<SINK, 2, 1>(a, grid, lds, s);
+        else launch_one<SINK, 4, 1>(a, grid, lds, s);
+    } else if (nval <= 2) {
+        if (npre <= 2) launch_one<SINK, 2, 2>(a, grid, lds, s);
+        else launch_one<SINK, 4, 2>(a, grid, lds, s);
+    } else launch_one<SINK, 4, 4>(a, grid, lds, s);
+}
+
+#define RDF_CAT2(a, b) a##b
+#define RDF_CAT(a, b) RDF_CAT2(a, b)
+hipError_t RDF_CAT(launch_eval_feat, RDF_FEAT)(const EvalArgs& a, int sink, int grid, hipStream_t s) {
+    const size_t lds = (size_t)a.ntmp * (kVPT * kBlock * 8 + kBlock * 4);
+    const int npre = a.ncols < kPreCols ? a.ncols : kPreCols;
+    if (sink == SINK_AGG) launch_shape<SINK_AGG>(a, npre, a.nvalues, grid, lds, s);
+    else launch_shape<SINK_STORE>(a, npre, a.nvalues, grid, lds, s);
+    return hipGetLastError();
+}
+
+}  // namespace rdfk

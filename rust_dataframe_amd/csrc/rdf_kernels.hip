@@ -6,7 +6,7 @@
 // fused expression tree, and persistent grids sized to the 256 CUs.
 //
 // Kernels (reference counterpart in brackets, paths relative to the reference root):
-//   eval_kernel<HEAVY,SINK>   fused expression-tree evaluator: an accumulator-machine interpreter
+//   eval_kernel (rdf_eval.hip) fused expression-tree evaluator: an accumulator-machine interpreter
 //                             whose opcode stream is wave-uniform
 //                             [Evaluate::calculate src/evaluation.rs:97-323 + ScalarFunctions
 //                              src/functions/scalar.rs:16-540 + BooleanFilter::eval_to_array
@@ -21,562 +21,9 @@
 //   take_kernel               gather over the virtual concatenation of a column's chunks
 //                             [Column::take src/table.rs:218-241]
 //   fill_*                    counter-based synthetic data (bench / tests)
-#include "rdf_device.h"
+#include "rdf_common.hip.h"
 
 namespace rdfk {
-
-// ------------------------------------------------------------------------------------------------
-// small device helpers
-
-__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
-    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// `nbits` (<= 64) consecutive bits of an LSB-first bitmap starting at bit `bitpos`, as the low bits
-// of a u64.  base/bitpos are wave-uniform, so these are scalar loads.  Reads only aligned 8-byte
-// words that contain requested bits (the ABI requires bitmaps readable to the next 8-byte boundary).
-__device__ __forceinline__ uint64_t load_bits64(const uint8_t* base, int64_t bitpos, int nbits) {
-    if (nbits <= 0) return 0;
-    uint64_t addr = uniform64((uint64_t)(uintptr_t)base + (uint64_t)(bitpos >> 3));
-    const uint64_t* w = (const uint64_t*)(uintptr_t)(addr & ~7ull);
-    int sh = (int)(addr & 7) * 8 + (int)(bitpos & 7);
-    uint64_t r = w[0] >> sh;
-    if (sh + nbits > 64) r |= w[1] << (64 - sh);
-    if (nbits < 64) r &= (1ull << nbits) - 1;
-    return r;
-}
-
-__device__ __forceinline__ int clamp64(int64_t v) { return v <= 0 ? 0 : (v >= 64 ? 64 : (int)v); }
-
-__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
-    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m);
-    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ double u2d(uint64_t v) { return __longlong_as_double((long long)v); }
-__device__ __forceinline__ uint64_t d2u(double v) { return (uint64_t)__double_as_longlong(v); }
-__device__ __forceinline__ float u2f(uint64_t v) { return __uint_as_float((uint32_t)v); }
-__device__ __forceinline__ uint64_t f2u(float v) { return (uint64_t)__float_as_uint(v); }
-
-// Integers live in the accumulator sign-/zero-extended to 64 bits.
-__device__ __forceinline__ uint64_t normalize_int(int dt, uint64_t x) {
-    switch (dt) {
-        case RDF_I8: return (uint64_t)(int64_t)(int8_t)x;
-        case RDF_I16: return (uint64_t)(int64_t)(int16_t)x;
-        case RDF_I32: return (uint64_t)(int64_t)(int32_t)x;
-        case RDF_U8: return x & 0xFFull;
-        case RDF_U16: return x & 0xFFFFull;
-        case RDF_U32: return x & 0xFFFFFFFFull;
-        default: return x;
-    }
-}
-__device__ __forceinline__ bool dt_is_signed(int dt) { return dt <= RDF_I64; }
-__device__ __forceinline__ bool dt_is_int(int dt) { return dt <= RDF_U64; }
-
-// ---- aggregate combine by class (F64: ieee add / NaN-ignoring min,max; ints: wrapping add) ----
-__device__ __forceinline__ void agg_init(int cls, uint64_t& sum, uint64_t& mn, uint64_t& mx, int64_t& cnt) {
-    cnt = 0;
-    if (cls == CLS_F64) { sum = d2u(0.0); mn = mx = 0x7FF8000000000000ull; }
-    else if (cls == CLS_SIGNED) { sum = 0; mn = (uint64_t)INT64_MAX; mx = (uint64_t)INT64_MIN; }
-    else { sum = 0; mn = ~0ull; mx = 0; }
-}
-__device__ __forceinline__ void agg_merge(int cls, uint64_t& sum, uint64_t& mn, uint64_t& mx, int64_t& cnt,
-                                          uint64_t s2, uint64_t mn2, uint64_t mx2, int64_t c2) {
-    cnt += c2;
-    if (cls == CLS_F64) {
-        sum = d2u(u2d(sum) + u2d(s2));
-        mn = d2u(fmin(u2d(mn), u2d(mn2)));
-        mx = d2u(fmax(u2d(mx), u2d(mx2)));
-    } else if (cls == CLS_SIGNED) {
-        sum += s2;
-        mn = (uint64_t)((int64_t)mn2 < (int64_t)mn ? (int64_t)mn2 : (int64_t)mn);
-        mx = (uint64_t)((int64_t)mx2 > (int64_t)mx ? (int64_t)mx2 : (int64_t)mx);
-    } else {
-        sum += s2;
-        mn = mn2 < mn ? mn2 : mn;
-        mx = mx2 > mx ? mx2 : mx;
-    }
-}
-
-// Block-wide reduction of one aggregate: wave butterfly (fixed order => deterministic), then the 4
-// wave results folded in wave order by thread 0.
-__device__ __forceinline__ void block_reduce_agg(int cls, uint64_t sum, uint64_t mn, uint64_t mx, int64_t cnt,
-                                                 AggPartial* lds4, AggPartial* out) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        uint64_t s2 = shfl_xor64(sum, m), mn2 = shfl_xor64(mn, m), mx2 = shfl_xor64(mx, m);
-        int64_t c2 = (int64_t)shfl_xor64((uint64_t)cnt, m);
-        agg_merge(cls, sum, mn, mx, cnt, s2, mn2, mx2, c2);
-    }
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { lds4[wave].sum = sum; lds4[wave].mn = mn; lds4[wave].mx = mx; lds4[wave].cnt = cnt; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t s = lds4[0].sum, a = lds4[0].mn, b = lds4[0].mx;
-        int64_t c = lds4[0].cnt;
-        for (int w = 1; w < kBlock / 64; ++w) agg_merge(cls, s, a, b, c, lds4[w].sum, lds4[w].mn, lds4[w].mx, lds4[w].cnt);
-        out->sum = s; out->mn = a; out->mx = b; out->cnt = c;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// conversions (arrow::compute::cast: Rust `as` semantics — float->int saturates, NaN -> 0)
-
-__device__ __forceinline__ uint64_t cast_value(int from, int to, uint64_t x) {
-    if (from == to) return x;
-    // classify the source
-    double f = 0.0;
-    bool src_float = false;
-    if (from == RDF_F64) { f = u2d(x); src_float = true; }
-    else if (from == RDF_F32) { f = (double)u2f(x); src_float = true; }
-    if (to == RDF_BOOL) return src_float ? (uint64_t)(f != 0.0) : (uint64_t)(x != 0);
-    if (to == RDF_F64) {
-        if (src_float) return d2u(f);
-        return d2u(dt_is_signed(from) ? (double)(int64_t)x : (double)x);
-    }
-    if (to == RDF_F32) {
-        if (from == RDF_F64) return f2u((float)u2d(x));
-        return f2u(dt_is_signed(from) ? (float)(int64_t)x : (float)x);
-    }
-    // integer targets
-    if (src_float) {
-        if (f != f) return 0;
-        switch (to) {
-            case RDF_I8: return (uint64_t)(int64_t)(f < -128.0 ? -128.0 : f > 127.0 ? 127.0 : f);
-            case RDF_I16: return (uint64_t)(int64_t)(f < -32768.0 ? -32768.0 : f > 32767.0 ? 32767.0 : f);
-            case RDF_I32: return (uint64_t)(int64_t)(f < -2147483648.0 ? -2147483648.0 : f > 2147483647.0 ? 2147483647.0 : f);
-            case RDF_I64:
-                if (f >= 9223372036854775808.0) return (uint64_t)INT64_MAX;
-                if (f <= -9223372036854775808.0) return (uint64_t)INT64_MIN;
-                return (uint64_t)(int64_t)f;
-            case RDF_U8: return (uint64_t)(f < 0.0 ? 0.0 : f > 255.0 ? 255.0 : f);
-            case RDF_U16: return (uint64_t)(f < 0.0 ? 0.0 : f > 65535.0 ? 65535.0 : f);
-            case RDF_U32: return (uint64_t)(f < 0.0 ? 0.0 : f > 4294967295.0 ? 4294967295.0 : f);
-            default:
-                if (f <= 0.0) return 0;
-                if (f >= 18446744073709551616.0) return ~0ull;
-                return (uint64_t)f;
-        }
-    }
-    return normalize_int(to, x);  // int/bool -> int: truncate
-}
-
-// ------------------------------------------------------------------------------------------------
-// column loads for the evaluator: kVPT rows per thread, row(j) = r0 + j*kBlock + tid, so every
-// wave-instruction touches 64 consecutive elements (512 B for 8-byte types).
-
-__device__ __forceinline__ void load_col(const DevChunkCol cc, int dt, int64_t r0, int64_t clen, uint32_t inr,
-                                         uint64_t (&v)[kVPT], uint32_t& valid) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t e0 = cc.offset + r0 + tid;
-    switch (dt) {
-        case RDF_I64: case RDF_U64: case RDF_F64: {
-            const uint64_t* p = (const uint64_t*)cc.values + e0;
-#pragma unroll
-            for (int j = 0; j < kVPT; ++j) v[j] = (inr >> j) & 1 ? __builtin_nontemporal_load(p + j * kBlock) : 0;
-        } break;
-        case RDF_I32: case RDF_U32: case RDF_F32: {
-            const uint32_t* p = (const uint32_t*)cc.values + e0;
-#pragma unroll
-            for (int j = 0; j < kVPT; ++j) {
-                uint32_t t = (inr >> j) & 1 ? __builtin_nontemporal_load(p + j * kBlock) : 0;
-                v[j] = dt == RDF_I32 ? (uint64_t)(int64_t)(int32_t)t : (uint64_t)t;
-            }
-        } break;
-        case RDF_I16: case RDF_U16: {
-            const uint16_t* p = (const uint16_t*)cc.values + e0;
-#pragma unroll
-            for (int j = 0; j < kVPT; ++j) {
-                uint16_t t = (inr >> j) & 1 ? p[j * kBlock] : (uint16_t)0;
-                v[j] = dt == RDF_I16 ? (uint64_t)(int64_t)(int16_t)t : (uint64_t)t;
-            }
-        } break;
-        case RDF_I8: case RDF_U8: {
-            const uint8_t* p = (const uint8_t*)cc.values + e0;
-#pragma unroll
-            for (int j = 0; j < kVPT; ++j) {
-                uint8_t t = (inr >> j) & 1 ? p[j * kBlock] : (uint8_t)0;
-                v[j] = dt == RDF_I8 ? (uint64_t)(int64_t)(int8_t)t : (uint64_t)t;
-            }
-        } break;
-        default: {  // RDF_BOOL: bit-packed values
-#pragma unroll
-            for (int j = 0; j < kVPT; ++j) {
-                int64_t rb = r0 + (int64_t)j * kBlock + wave * 64;
-                uint64_t w = load_bits64((const uint8_t*)cc.values, cc.offset + rb, clamp64(clen - rb));
-                v[j] = (w >> lane) & 1;
-            }
-        }
-    }
-    valid = (1u << kVPT) - 1;
-    if (cc.validity) {
-        valid = 0;
-#pragma unroll
-        for (int j = 0; j < kVPT; ++j) {
-            int64_t rb = r0 + (int64_t)j * kBlock + wave * 64;
-            uint64_t w = load_bits64(cc.validity, cc.offset + rb, clamp64(clen - rb));
-            valid |= (uint32_t)((w >> lane) & 1) << j;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// the interpreter's arithmetic.  `key`-style dispatch keeps the (uniform) switch outside the
-// per-row loop.
-
-template <bool HEAVY>
-__device__ __forceinline__ double unary_f64(int op, double x) {
-    switch (op) {
-        case RDF_OP_ABS: return fabs(x);
-        case RDF_OP_CEIL: return ceil(x);
-        case RDF_OP_FLOOR: return floor(x);
-        case RDF_OP_ROUND: return round(x);
-        case RDF_OP_SQRT: return sqrt(x);
-        case RDF_OP_DEGREES: return x * (180.0 / 3.14159265358979323846264338327950288);
-        case RDF_OP_RADIANS: return x * (3.14159265358979323846264338327950288 / 180.0);
-        default: break;
-    }
-    if constexpr (HEAVY) {
-        switch (op) {
-            case RDF_OP_ACOS: return acos(x);
-            case RDF_OP_ASIN: return asin(x);
-            case RDF_OP_ATAN: return atan(x);
-            case RDF_OP_CBRT: return cbrt(x);
-            case RDF_OP_COS: return cos(x);
-            case RDF_OP_COSH: return cosh(x);
-            case RDF_OP_EXP: return exp(x);
-            case RDF_OP_EXPM1: return expm1(x);
-            case RDF_OP_LOG10: return log10(x);
-            case RDF_OP_LOG2: return log2(x);
-            case RDF_OP_SIN: return sin(x);
-            case RDF_OP_SINH: return sinh(x);
-            case RDF_OP_TAN: return tan(x);
-            case RDF_OP_TANH: return tanh(x);
-            default: break;
-        }
-    }
-    return x;
-}
-template <bool HEAVY>
-__device__ __forceinline__ float unary_f32(int op, float x) {
-    switch (op) {
-        case RDF_OP_ABS: return fabsf(x);
-        case RDF_OP_CEIL: return ceilf(x);
-        case RDF_OP_FLOOR: return floorf(x);
-        case RDF_OP_ROUND: return roundf(x);
-        case RDF_OP_SQRT: return sqrtf(x);
-        case RDF_OP_DEGREES: return x * 57.2957795130823208767981548141051703f;
-        case RDF_OP_RADIANS: return x * (3.14159265358979323846264338327950288f / 180.0f);
-        default: break;
-    }
-    if constexpr (HEAVY) {
-        switch (op) {
-            case RDF_OP_ACOS: return acosf(x);
-            case RDF_OP_ASIN: return asinf(x);
-            case RDF_OP_ATAN: return atanf(x);
-            case RDF_OP_CBRT: return cbrtf(x);
-            case RDF_OP_COS: return cosf(x);
-            case RDF_OP_COSH: return coshf(x);
-            case RDF_OP_EXP: return expf(x);
-            case RDF_OP_EXPM1: return expm1f(x);
-            case RDF_OP_LOG10: return log10f(x);
-            case RDF_OP_LOG2: return log2f(x);
-            case RDF_OP_SIN: return sinf(x);
-            case RDF_OP_SINH: return sinhf(x);
-            case RDF_OP_TAN: return tanf(x);
-            case RDF_OP_TANH: return tanhf(x);
-            default: break;
-        }
-    }
-    return x;
-}
-
-#define RDF_ROWS _Pragma("unroll") for (int j = 0; j < kVPT; ++j)
-
-// acc = acc OP b.  `live` = rows where both sides are valid and in range (divide-by-zero is only an
-// error there, like arrow's math_divide).
-template <bool HEAVY>
-__device__ __forceinline__ void apply_binary(int op, int dt, uint64_t (&acc)[kVPT], const uint64_t (&b)[kVPT],
-                                             uint32_t live, uint32_t& err) {
-    if (op >= RDF_OP_GT && op <= RDF_OP_LE) {  // f64 comparisons (src/expression.rs:844-852)
-        switch (op) {
-            case RDF_OP_GT: RDF_ROWS acc[j] = u2d(acc[j]) > u2d(b[j]); break;
-            case RDF_OP_GE: RDF_ROWS acc[j] = u2d(acc[j]) >= u2d(b[j]); break;
-            case RDF_OP_EQ: RDF_ROWS acc[j] = u2d(acc[j]) == u2d(b[j]); break;
-            case RDF_OP_NE: RDF_ROWS acc[j] = u2d(acc[j]) != u2d(b[j]); break;
-            case RDF_OP_LT: RDF_ROWS acc[j] = u2d(acc[j]) < u2d(b[j]); break;
-            default: RDF_ROWS acc[j] = u2d(acc[j]) <= u2d(b[j]); break;
-        }
-        return;
-    }
-    if (op == RDF_OP_AND) { RDF_ROWS acc[j] = acc[j] & b[j]; return; }
-    if (op == RDF_OP_OR) { RDF_ROWS acc[j] = acc[j] | b[j]; return; }
-    if (dt == RDF_F64) {
-        switch (op) {
-            case RDF_OP_ADD: RDF_ROWS acc[j] = d2u(u2d(acc[j]) + u2d(b[j])); break;
-            case RDF_OP_SUB: RDF_ROWS acc[j] = d2u(u2d(acc[j]) - u2d(b[j])); break;
-            case RDF_OP_MUL: RDF_ROWS acc[j] = d2u(u2d(acc[j]) * u2d(b[j])); break;
-            case RDF_OP_DIV:
-                RDF_ROWS {
-                    bool z = u2d(b[j]) == 0.0;
-                    if (z && ((live >> j) & 1)) err |= 1u;
-                    acc[j] = z ? 0 : d2u(u2d(acc[j]) / u2d(b[j]));
-                }
-                break;
-            default:
-                if constexpr (HEAVY) {
-                    if (op == RDF_OP_ATAN2) RDF_ROWS acc[j] = d2u(atan2(u2d(acc[j]), u2d(b[j])));
-                    else if (op == RDF_OP_HYPOT) RDF_ROWS acc[j] = d2u(hypot(u2d(acc[j]), u2d(b[j])));
-                    else RDF_ROWS acc[j] = d2u(log(u2d(acc[j])) / log(u2d(b[j])));
-                }
-        }
-        return;
-    }
-    if (dt == RDF_F32) {
-        switch (op) {
-            case RDF_OP_ADD: RDF_ROWS acc[j] = f2u(u2f(acc[j]) + u2f(b[j])); break;
-            case RDF_OP_SUB: RDF_ROWS acc[j] = f2u(u2f(acc[j]) - u2f(b[j])); break;
-            case RDF_OP_MUL: RDF_ROWS acc[j] = f2u(u2f(acc[j]) * u2f(b[j])); break;
-            case RDF_OP_DIV:
-                RDF_ROWS {
-                    bool z = u2f(b[j]) == 0.0f;
-                    if (z && ((live >> j) & 1)) err |= 1u;
-                    acc[j] = z ? 0 : f2u(u2f(acc[j]) / u2f(b[j]));
-                }
-                break;
-            default:
-                if constexpr (HEAVY) {
-                    if (op == RDF_OP_ATAN2) RDF_ROWS acc[j] = f2u(atan2f(u2f(acc[j]), u2f(b[j])));
-                    else if (op == RDF_OP_HYPOT) RDF_ROWS acc[j] = f2u(hypotf(u2f(acc[j]), u2f(b[j])));
-                    else RDF_ROWS acc[j] = f2u(logf(u2f(acc[j])) / logf(u2f(b[j])));
-                }
-        }
-        return;
-    }
-    // integers: wrapping arithmetic in 64 bits, then re-normalised to the value's width
-    switch (op) {
-        case RDF_OP_ADD: RDF_ROWS acc[j] = normalize_int(dt, acc[j] + b[j]); break;
-        case RDF_OP_SUB: RDF_ROWS acc[j] = normalize_int(dt, acc[j] - b[j]); break;
-        case RDF_OP_MUL: RDF_ROWS acc[j] = normalize_int(dt, acc[j] * b[j]); break;
-        default:  // DIV
-            RDF_ROWS {
-                bool z = b[j] == 0;
-                if (z && ((live >> j) & 1)) err |= 1u;
-                uint64_t q;
-                if (z) q = 0;
-                else if (dt_is_signed(dt)) {
-                    int64_t x = (int64_t)acc[j], y = (int64_t)b[j];
-                    q = y == -1 ? (uint64_t)0 - (uint64_t)x : (uint64_t)(x / y);  // MIN / -1 wraps
-                } else q = acc[j] / b[j];
-                acc[j] = normalize_int(dt, q);
-            }
-    }
-}
-
-template <bool HEAVY>
-__device__ __forceinline__ void apply_unary(int op, int dt, uint64_t (&acc)[kVPT]) {
-    if (op == RDF_OP_NOT) { RDF_ROWS acc[j] = acc[j] ^ 1ull; return; }
-    if (dt == RDF_F64) { RDF_ROWS acc[j] = d2u(unary_f64<HEAVY>(op, u2d(acc[j]))); return; }
-    if (dt == RDF_F32) { RDF_ROWS acc[j] = f2u(unary_f32<HEAVY>(op, u2f(acc[j]))); return; }
-    // num::abs on signed integers; MIN wraps
-    RDF_ROWS { int64_t x = (int64_t)acc[j]; acc[j] = normalize_int(dt, x < 0 ? (uint64_t)0 - (uint64_t)x : (uint64_t)x); }
-}
-
-// ------------------------------------------------------------------------------------------------
-// eval_kernel: one persistent block walks 1024-row tiles (= the reference's RecordBatch size); per
-// tile it (1) issues ALL column loads for the tile up front (memory-level parallelism), (2) runs the
-// uniform bytecode over registers, (3) feeds the sink: coalesced stores + ballot-built bitmaps, or
-// running {sum,min,max,count} folded block-wide once at the end (two-stage reduction).
-
-template <bool HEAVY, int SINK>
-__global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ AggPartial red_lds[kBlock / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    uint64_t g_sum[kMaxValues], g_mn[kMaxValues], g_mx[kMaxValues];
-    int64_t g_cnt[kMaxValues];
-    if (SINK == SINK_AGG) {
-#pragma unroll
-        for (int k = 0; k < kMaxValues; ++k) agg_init(k < a.nvalues ? a.value_cls[k] : CLS_F64, g_sum[k], g_mn[k], g_mx[k], g_cnt[k]);
-    }
-    uint32_t err = 0;
-
-    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        int64_t c = 0, r0, clen;
-        if (a.nchunks == 1) { r0 = tile * kEvalTile; clen = a.inline_len; }
-        else {
-            int64_t lo = 0, hi = a.nchunks - 1;  // largest c with chunk_tile_start[c] <= tile
-            while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if (a.chunk_tile_start[mid] <= tile) lo = mid; else hi = mid - 1; }
-            c = lo;
-            r0 = (tile - a.chunk_tile_start[c]) * kEvalTile;
-            clen = a.chunk_len[c];
-        }
-        uint32_t inr = 0;
-#pragma unroll
-        for (int j = 0; j < kVPT; ++j) inr |= (uint32_t)(r0 + (int64_t)j * kBlock + tid < clen) << j;
-
-        // (1) preload
-        uint64_t colv[kPreCols][kVPT];
-        uint32_t colvalid[kPreCols];
-#pragma unroll
-        for (int p = 0; p < kPreCols; ++p) {
-            colvalid[p] = 0;
-#pragma unroll
-            for (int j = 0; j < kVPT; ++j) colv[p][j] = 0;
-            if (p < a.ncols) {
-                const DevChunkCol cc = a.nchunks == 1 ? a.inline_cols[p] : a.cols[(int64_t)p * a.nchunks + c];
-                load_col(cc, a.col_dtype[p], r0, clen, inr, colv[p], colvalid[p]);
-            }
-        }
-
-        // (2) interpret
-        uint64_t acc[kVPT];
-        uint32_t accv = 0, keep = inr;
-        uint32_t nullbits[kMaxValues];  // SINK_STORE: per-wave null counters (lane 0 only)
-#pragma unroll
-        for (int k = 0; k < kMaxValues; ++k) nullbits[k] = 0;
-#pragma unroll
-        for (int j = 0; j < kVPT; ++j) acc[j] = 0;
-
-        for (int pc = 0; pc < a.ncode; ++pc) {
-            const Instr in = a.code[pc];
-            // operand fetch (LOAD and BIN)
-            uint64_t opnd[kVPT];
-            uint32_t opv = (1u << kVPT) - 1;
-            if (in.bc == BC_LOAD || in.bc == BC_BIN) {
-                if (in.src_kind == SRC_COL) {
-                    const int ci = in.src;
-                    bool hit = false;
-#pragma unroll
-                    for (int p = 0; p < kPreCols; ++p)
-                        if (p == ci) {
-                            hit = true;
-                            opv = colvalid[p];
-#pragma unroll
-                            for (int j = 0; j < kVPT; ++j) opnd[j] = colv[p][j];
-                        }
-                    if (!hit) {
-                        const DevChunkCol cc = a.nchunks == 1 ? a.inline_cols[ci & (kMaxCols - 1)] : a.cols[(int64_t)ci * a.nchunks + c];
-                        load_col(cc, a.col_dtype[ci & (kMaxCols - 1)], r0, clen, inr, opnd, opv);
-                    }
-                } else if (in.src_kind == SRC_IMM) {
-#pragma unroll
-                    for (int j = 0; j < kVPT; ++j) opnd[j] = in.imm;
-                } else {  // SRC_TMP
-                    const uint64_t* tv = (const uint64_t*)smem + (size_t)in.src * kVPT * kBlock + tid;
-#pragma unroll
-                    for (int j = 0; j < kVPT; ++j) opnd[j] = tv[j * kBlock];
-                    opv = ((const uint32_t*)(smem + (size_t)a.ntmp * kVPT * kBlock * 8))[in.src * kBlock + tid];
-                }
-                if (in.src_dtype != in.dtype) {
-#pragma unroll
-                    for (int j = 0; j < kVPT; ++j) opnd[j] = cast_value(in.src_dtype, in.dtype, opnd[j]);
-                }
-            }
-            switch (in.bc) {
-                case BC_LOAD:
-#pragma unroll
-                    for (int j = 0; j < kVPT; ++j) acc[j] = opnd[j];
-                    accv = opv;
-                    break;
-                case BC_STORE_TMP: {
-                    uint64_t* tv = (uint64_t*)smem + (size_t)in.src * kVPT * kBlock + tid;
-#pragma unroll
-                    for (int j = 0; j < kVPT; ++j) tv[j * kBlock] = acc[j];
-                    ((uint32_t*)(smem + (size_t)a.ntmp * kVPT * kBlock * 8))[in.src * kBlock + tid] = accv;
-                } break;
-                case BC_BIN: {
-                    if (in.swapped) {
-#pragma unroll
-                        for (int j = 0; j < kVPT; ++j) { uint64_t t = acc[j]; acc[j] = opnd[j]; opnd[j] = t; }
-                    }
-                    accv &= opv;
-                    apply_binary<HEAVY>(in.op, in.dtype, acc, opnd, accv & inr, err);
-                } break;
-                case BC_UN:
-                    apply_unary<HEAVY>(in.op, in.dtype, acc);
-                    break;
-                case BC_CAST:
-#pragma unroll
-                    for (int j = 0; j < kVPT; ++j) acc[j] = cast_value(in.src_dtype, in.dtype, acc[j]);
-                    break;
-                case BC_FILTER:  // DataFrame::filter: rows whose predicate is false or null are dropped
-#pragma unroll
-                    for (int j = 0; j < kVPT; ++j) keep &= ~((uint32_t)(((acc[j] & 1) == 0) || (((accv >> j) & 1) == 0)) << j);
-                    break;
-                default: {  // BC_EMIT: acc is value expression `in.src`
-                    const int k = in.src;
-                    if (SINK == SINK_AGG) {
-                        const uint32_t live = keep & accv & inr;
-#pragma unroll
-                        for (int kk = 0; kk < kMaxValues; ++kk)
-                            if (kk == k) {
-                                const int cls = a.value_cls[kk];
-#pragma unroll
-                                for (int j = 0; j < kVPT; ++j)
-                                    if ((live >> j) & 1) {
-                                        uint64_t v = acc[j];
-                                        if (in.dtype == RDF_F32) v = d2u((double)u2f(v));
-                                        agg_merge(cls, g_sum[kk], g_mn[kk], g_mx[kk], g_cnt[kk], v, v, v, 1);
-                                    }
-                            }
-                    } else {
-                        const DevOutChunk oc = a.nchunks == 1 ? a.inline_outs[k & (kMaxValues - 1)] : a.outs[(int64_t)k * a.nchunks + c];
-                        const int dt = in.dtype;
-#pragma unroll
-                        for (int j = 0; j < kVPT; ++j) {
-                            const int64_t row = r0 + (int64_t)j * kBlock + tid;
-                            const bool ok = (inr >> j) & 1;
-                            const bool valid = (accv >> j) & 1;
-                            const uint64_t v = valid ? acc[j] : 0;  // null slots hold 0
-                            if (dt == RDF_BOOL) {
-                                const uint64_t bits = __ballot(ok && valid && (v & 1));
-                                if (lane == 0 && r0 + (int64_t)j * kBlock + wave * 64 < clen)
-                                    ((uint64_t*)oc.values)[(r0 + (int64_t)j * kBlock + wave * 64) >> 6] = bits;
-                            } else if (ok) {
-                                switch (dt) {
-                                    case RDF_I64: case RDF_U64: case RDF_F64: ((uint64_t*)oc.values)[row] = v; break;
-                                    case RDF_I32: case RDF_U32: case RDF_F32: ((uint32_t*)oc.values)[row] = (uint32_t)v; break;
-                                    case RDF_I16: case RDF_U16: ((uint16_t*)oc.values)[row] = (uint16_t)v; break;
-                                    default: ((uint8_t*)oc.values)[row] = (uint8_t)v; break;
-                                }
-                            }
-                            const uint64_t vb = __ballot(ok && valid);
-                            const uint64_t ib = __ballot(ok);
-                            if (lane == 0 && ib) {
-                                if (oc.validity) ((uint64_t*)oc.validity)[(r0 + (int64_t)j * kBlock + wave * 64) >> 6] = vb;
-#pragma unroll
-                                for (int kk = 0; kk < kMaxValues; ++kk)
-                                    if (kk == k) nullbits[kk] += (uint32_t)__popcll(ib & ~vb);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (SINK == SINK_STORE && lane == 0) {
-#pragma unroll
-            for (int kk = 0; kk < kMaxValues; ++kk)
-                if (kk < a.nvalues && nullbits[kk])
-                    atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)kk * a.nchunks + c], (unsigned long long)nullbits[kk]);
-        }
-        if (a.ntmp > 0) __syncthreads();  // tmp slots are thread-private, but keep tiles tidy across waves
-    }
-
-    if (err) atomicOr(a.flags, err);
-    if (SINK == SINK_AGG) {
-#pragma unroll
-        for (int k = 0; k < kMaxValues; ++k)
-            if (k < a.nvalues)
-                block_reduce_agg(a.value_cls[k], g_sum[k], g_mn[k], g_mx[k], g_cnt[k], red_lds,
-                                 &a.partials[(int64_t)blockIdx.x * a.nvalues + k]);
-    }
-}
 
 // Second stage: fold the per-block partials (fixed order => run-to-run deterministic f64 sums).
 __global__ __launch_bounds__(kBlock) void agg_final_kernel(const AggFinalArgs a) {
@@ -623,7 +70,8 @@ typedef double dvec2 __attribute__((ext_vector_type(2)));
 template <int CMP, bool SAME, bool HASV>
 __global__ __launch_bounds__(kBlock) void filter_agg_f64_kernel(const FilterAggF64Args a) {
     __shared__ AggPartial red_lds[kBlock / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id();
     const double* xb = a.x + a.x_offset;
     const double* yb = SAME ? xb : a.y + a.y_offset;
     F64Agg g;
@@ -649,13 +97,17 @@ __global__ __launch_bounds__(kBlock) void filter_agg_f64_kernel(const FilterAggF
     }
     const dvec2* xv = (const dvec2*)(xb + head);
     const dvec2* yv = (const dvec2*)(yb + head);  // only dereferenced when 16-byte aligned (host checks)
-    const int64_t per_iter = (int64_t)kBlock * kFU;     // vectors per block iteration
+    // Per block iteration: kBlock*kFU vectors = 2048 rows; wave w owns the 512 consecutive rows
+    // [256w, 256w+256) vectors of it, so one load instruction covers 64 consecutive 16-byte vectors
+    // (1 KiB) and the wave's validity bits are eight consecutive 64-bit windows (scalar loads).
+    const int64_t per_iter = (int64_t)kBlock * kFU;
+    const int64_t body_rows = 2 * nvec;  // rows covered by the vector body, starting at row `head`
     for (int64_t base = (int64_t)blockIdx.x * per_iter; base < nvec; base += (int64_t)gridDim.x * per_iter) {
+        const int64_t wbase = base + (int64_t)wave * (kFU * 64);  // first vector of this wave
         dvec2 vx[kFU], vy[kFU];
-        uint32_t vb[kFU];  // 2 validity bits per vector
 #pragma unroll
         for (int u = 0; u < kFU; ++u) {
-            const int64_t i = base + (int64_t)u * kBlock + tid;
+            const int64_t i = wbase + u * 64 + lane;
             if (i < nvec) {
                 vx[u] = __builtin_nontemporal_load(xv + i);
                 if (!SAME) vy[u] = __builtin_nontemporal_load(yv + i);
@@ -664,93 +116,70 @@ __global__ __launch_bounds__(kBlock) void filter_agg_f64_kernel(const FilterAggF
                 if (!SAME) vy[u] = (dvec2)(0.0);
             }
         }
-#pragma unroll
-        for (int u = 0; u < kFU; ++u) {
-            const int64_t i = base + (int64_t)u * kBlock + tid;
-            uint32_t bits = i < nvec ? 3u : 0u;
-            if (HASV) {
-                // the wave's 128 rows start at row head + 2*(base + u*kBlock + wave*64)
-                const int64_t rw = head + 2 * (base + (int64_t)u * kBlock + wave * 64);
-                const int64_t left = a.n - (tail ? 1 : 0) - rw;  // vector-body rows remaining from rw
-                if (a.x_validity) {
-                    const uint64_t w0 = load_bits64(a.x_validity, a.x_offset + rw, clamp64(left));
-                    const uint64_t w1 = load_bits64(a.x_validity, a.x_offset + rw + 64, clamp64(left - 64));
-                    const uint64_t w = lane < 32 ? w0 : w1;
-                    bits &= (uint32_t)(w >> ((2 * lane) & 63)) & 3u;
-                }
-                if (!SAME && a.y_validity) {
-                    const uint64_t w0 = load_bits64(a.y_validity, a.y_offset + rw, clamp64(left));
-                    const uint64_t w1 = load_bits64(a.y_validity, a.y_offset + rw + 64, clamp64(left - 64));
-                    const uint64_t w = lane < 32 ? w0 : w1;
-                    bits &= (uint32_t)(w >> ((2 * lane) & 63)) & 3u;
-                }
-            }
-            vb[u] = bits;
+        uint64_t wx[2 * kFU], wy[2 * kFU];
+        if (HASV) {
+            const int64_t rw = 2 * wbase;  // body-relative first row of this wave
+            if (a.x_validity) load_windows<2 * kFU>(a.x_validity, a.x_offset + head + rw, body_rows - rw, wx);
+            if (!SAME && a.y_validity) load_windows<2 * kFU>(a.y_validity, a.y_offset + head + rw, body_rows - rw, wy);
         }
 #pragma unroll
         for (int u = 0; u < kFU; ++u) {
+            const int64_t i = wbase + u * 64 + lane;
+            uint32_t bits = i < nvec ? 3u : 0u;
+            if (HASV) {
+                // lane l holds rows 128u + 2l, 2l+1 of the wave: window 2u (l < 32) or 2u+1, bits (2l)&63, +1
+                const int sh = (2 * lane) & 63;
+                if (a.x_validity) bits &= (uint32_t)((lane < 32 ? wx[2 * u] : wx[2 * u + 1]) >> sh) & 3u;
+                if (!SAME && a.y_validity) bits &= (uint32_t)((lane < 32 ? wy[2 * u] : wy[2 * u + 1]) >> sh) & 3u;
+            }
             const dvec2 yy = SAME ? vx[u] : vy[u];
-            if ((vb[u] & 1u) && cmp_f64<CMP>(vx[u].x, a.c)) g.add(yy.x);
-            if ((vb[u] & 2u) && cmp_f64<CMP>(vx[u].y, a.c)) g.add(yy.y);
+            if ((bits & 1u) && cmp_f64<CMP>(vx[u].x, a.c)) g.add(yy.x);
+            if ((bits & 2u) && cmp_f64<CMP>(vx[u].y, a.c)) g.add(yy.y);
         }
     }
     block_reduce_agg(CLS_F64, d2u(g.sum), d2u(g.mn), d2u(g.mx), g.cnt, red_lds, &a.partials[blockIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
-// stream compaction (Column::filter).  Tiles of kFilterTile = 2048 rows = 32 mask words.
+// stream compaction (Column::filter).  Tiles of kFilterTile = 2048 rows = 32 mask words; wave w owns
+// the 512 consecutive rows (8 mask words) [512w, 512w+512) of a tile.
 
 __device__ __forceinline__ void locate_tile(const MaskTables& t, int64_t tile, int64_t& c, int64_t& r0, int64_t& clen) {
-    int64_t lo = 0, hi = t.nchunks - 1;
-    while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if (t.chunk_tile_start[mid] <= tile) lo = mid; else hi = mid - 1; }
-    c = lo;
+    c = t.nchunks == 1 ? 0 : find_chunk(t.chunk_tile_start, t.nchunks, tile);
     r0 = (tile - t.chunk_tile_start[c]) * kFilterTile;
     clen = t.chunk_len[c];
 }
 
-// keep-word q of a tile: mask value bits AND mask validity bits, rows past the chunk end cleared.
-__device__ __forceinline__ uint64_t keep_word(const DevChunkCol& m, int64_t r0, int64_t clen, int q) {
-    const int64_t rb = r0 + (int64_t)q * 64;
-    const int nb = clamp64(clen - rb);
-    uint64_t w = load_bits64((const uint8_t*)m.values, m.offset + rb, nb);
-    if (m.validity) w &= load_bits64(m.validity, m.offset + rb, nb);
-    return w;
+constexpr int kWW = kFilterTile / 64 / (kBlock / 64);  // mask words per wave per tile (8)
+
+// keep-words of this wave's 512 rows: mask value bits AND mask validity bits, rows past the chunk end cleared
+__device__ __forceinline__ void keep_words(const DevChunkCol& m, int64_t rw, int64_t clen, uint64_t (&kw)[kWW]) {
+    load_windows<kWW>((const uint8_t*)m.values, m.offset + rw, clen - rw, kw);
+    if (m.validity) {
+        uint64_t vw[kWW];
+        load_windows<kWW>(m.validity, m.offset + rw, clen - rw, vw);
+#pragma unroll
+        for (int i = 0; i < kWW; ++i) kw[i] &= vw[i];
+    }
 }
 
-// One thread per mask word; 32-lane groups = tiles.  Reads 1 bit/row.
+// One wave per tile-quarter: counts the kept rows of 512 rows with scalar loads + s_bcnt1; reads 1 bit/row.
 __global__ __launch_bounds__(kBlock) void mask_count_kernel(const MaskTables t, int64_t* tile_counts) {
-    const int64_t tile = (int64_t)blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5);
-    const int q = threadIdx.x & 31;
-    int cnt = 0;
-    if (tile < t.ntiles) {
+    __shared__ int wave_cnt[kBlock / 64];
+    const int wave = wave_id();
+    for (int64_t tile = blockIdx.x; tile < t.ntiles; tile += gridDim.x) {
         int64_t c, r0, clen;
         locate_tile(t, tile, c, r0, clen);
-        // not wave-uniform here (two tiles per wave): plain byte-safe window load
-        const DevChunkCol m = t.mask[c];
-        const int64_t rb = r0 + (int64_t)q * 64;
-        const int nb = clamp64(clen - rb);
-        if (nb > 0) {
-            const int64_t bitpos = m.offset + rb;
-            uint64_t addr = (uint64_t)(uintptr_t)m.values + (uint64_t)(bitpos >> 3);
-            const uint64_t* w = (const uint64_t*)(uintptr_t)(addr & ~7ull);
-            int sh = (int)(addr & 7) * 8 + (int)(bitpos & 7);
-            uint64_t r = w[0] >> sh;
-            if (sh + nb > 64) r |= w[1] << (64 - sh);
-            if (m.validity) {
-                uint64_t addr2 = (uint64_t)(uintptr_t)m.validity + (uint64_t)(bitpos >> 3);
-                const uint64_t* w2 = (const uint64_t*)(uintptr_t)(addr2 & ~7ull);
-                int sh2 = (int)(addr2 & 7) * 8 + (int)(bitpos & 7);
-                uint64_t r2 = w2[0] >> sh2;
-                if (sh2 + nb > 64) r2 |= w2[1] << (64 - sh2);
-                r &= r2;
-            }
-            if (nb < 64) r &= (1ull << nb) - 1;
-            cnt = __popcll(r);
-        }
-    }
+        uint64_t kw[kWW];
+        keep_words(t.mask[c], r0 + (int64_t)wave * (kWW * 64), clen, kw);
+        int cnt = 0;
 #pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m);
-    if (q == 0 && tile < t.ntiles) tile_counts[tile] = cnt;
+        for (int i = 0; i < kWW; ++i) cnt += __popcll(kw[i]);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) wave_cnt[wave] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_counts[tile] = (int64_t)wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    }
 }
 
 // Exclusive scan of n int64 counts into scan[0..n] (scan[n] = total).  One block; each thread owns
@@ -763,7 +192,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const int64_t* count
     const int64_t b = (int64_t)tid * seg, e = b + seg < n ? b + seg : n;
     int64_t s = 0;
     for (int64_t i = b; i < e; ++i) s += counts[i];
-    // inclusive scan across the wave
     int64_t inc = s;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -784,49 +212,53 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const int64_t* count
     }
 }
 
-// Compaction of one column of one tile: ranks come from popcounts of the tile's keep words (no
-// shuffles, no atomics for the values); kept values are staged in LDS at their rank, then written
-// with coalesced stores at the tile's output offset.
+// Compaction of one column of one tile.  Ranks come from popcounts of the wave's keep words (scalar
+// prefix + v_mbcnt-style lane prefix): no shuffles, no atomics for the values.  Kept values are staged
+// in LDS at their rank, then written with coalesced stores at the tile's output offset.
 template <typename T>
-__device__ __forceinline__ void compact_column(const DevChunkCol col, const DevOutChunk oc, int64_t* null_count_out,
-                                               int64_t r0, int64_t clen, int64_t out_off, const uint64_t* keep_w,
-                                               const int* wbase, int total, unsigned char* stage_raw, uint8_t* vstage) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void compact_column(const DevChunkCol col, const DevOutChunk oc, int64_t rw, int64_t clen,
+                                               int64_t out_off, const uint64_t (&kw)[kWW], int wave_base, int total,
+                                               unsigned char* stage_raw, uint8_t* vstage, uint32_t& nulls) {
+    const int tid = threadIdx.x, lane = tid & 63;
     T* stage = (T*)stage_raw;
-    const T* src = (const T*)col.values + col.offset + r0;
+    const T* src = (const T*)col.values + col.offset + rw + lane;
+    uint64_t vw[kWW];
+    const bool hasv = col.validity != nullptr;
+    if (hasv) load_windows<kWW>(col.validity, col.offset + rw, clen - rw, vw);
+    T val[kWW];
 #pragma unroll
-    for (int s = 0; s < kFilterTile / kBlock; ++s) {
-        const int q = s * (kBlock / 64) + wave;
-        const uint64_t m = keep_w[q];
-        uint64_t vw = ~0ull;
-        if (col.validity && m) vw = load_bits64(col.validity, col.offset + r0 + (int64_t)q * 64, clamp64(clen - (r0 + (int64_t)q * 64)));
-        if ((m >> lane) & 1) {
-            const int rank = wbase[q] + __popcll(m & ((1ull << lane) - 1));
-            stage[rank] = __builtin_nontemporal_load(src + q * 64 + lane);
-            if (col.validity) vstage[rank] = (uint8_t)((vw >> lane) & 1);
+    for (int i = 0; i < kWW; ++i)
+        if ((kw[i] >> lane) & 1) val[i] = __builtin_nontemporal_load(src + i * 64);
+    int wb = wave_base;
+#pragma unroll
+    for (int i = 0; i < kWW; ++i) {
+        if ((kw[i] >> lane) & 1) {
+            const int rank = wb + __popcll(kw[i] & ((1ull << lane) - 1));
+            stage[rank] = val[i];
+            if (hasv) vstage[rank] = (uint8_t)((vw[i] >> lane) & 1);
         }
+        wb += __popcll(kw[i]);
     }
     __syncthreads();
     T* dst = (T*)oc.values + out_off;
     for (int i = tid; i < total; i += kBlock) dst[i] = stage[i];
-    if (col.validity && oc.validity) {
+    if (hasv && oc.validity) {
         // out bits [out_off, out_off+total): ballot 64 aligned positions at a time, OR into the
         // (pre-zeroed) bitmap; boundary words are shared with neighbouring tiles, hence atomics.
         const int64_t first = out_off & ~63ll;
         const int64_t end = out_off + total;
-        int nulls = 0;
-        for (int64_t wb = first + (int64_t)wave * 64; wb < end; wb += (kBlock / 64) * 64) {
-            const int64_t pos = wb + lane;
+        const int wave = wave_id();
+        for (int64_t wpos = first + (int64_t)wave * 64; wpos < end; wpos += (kBlock / 64) * 64) {
+            const int64_t pos = wpos + lane;
             const bool inside = pos >= out_off && pos < end;
             const bool bit = inside && vstage[pos - out_off];
             const uint64_t word = __ballot(bit);
             const uint64_t inw = __ballot(inside);
             if (lane == 0) {
-                if (word) atomicOr((unsigned long long*)oc.validity + (wb >> 6), (unsigned long long)word);
-                nulls += __popcll(inw & ~word);
+                if (word) atomicOr((unsigned long long*)oc.validity + (wpos >> 6), (unsigned long long)word);
+                nulls += (uint32_t)__popcll(inw & ~word);
             }
         }
-        if (lane == 0 && nulls) atomicAdd((unsigned long long*)null_count_out, (unsigned long long)nulls);
     }
     __syncthreads();
 }
@@ -834,44 +266,64 @@ __device__ __forceinline__ void compact_column(const DevChunkCol col, const DevO
 __global__ __launch_bounds__(kBlock) void compact_kernel(const FilterArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char stage[kFilterTile * 8];
     __shared__ uint8_t vstage[kFilterTile];
-    __shared__ uint64_t keep_w[kFilterTile / 64];
-    __shared__ int wbase[kFilterTile / 64];
-    __shared__ int total_s;
-    const int tid = threadIdx.x;
+    __shared__ int wave_cnt[kBlock / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id();
+    // per-wave null counters per column, flushed once per (column, chunk) — not once per tile
+    uint32_t nullacc[kMaxFilterCols];
+#pragma unroll
+    for (int k = 0; k < kMaxFilterCols; ++k) nullacc[k] = 0;
+    int64_t cur_chunk = -1;
     for (int64_t tile = blockIdx.x; tile < a.t.ntiles; tile += gridDim.x) {
         int64_t c, r0, clen;
         locate_tile(a.t, tile, c, r0, clen);
-        if (tid < 64) {  // wave 0: the 32 keep words and their exclusive popcount scan
-            const DevChunkCol m = a.t.mask[c];
-            uint64_t w = 0;
-            // load_bits64 wants wave-uniform addresses: loop the 32 words, lane q keeps word q
-            for (int q = 0; q < kFilterTile / 64; ++q) {
-                const uint64_t wq = keep_word(m, r0, clen, q);
-                if (tid == q) w = wq;
-            }
-            int cnt = __popcll(w), inc = cnt;
+        if (c != cur_chunk) {
+            if (cur_chunk >= 0 && lane == 0) {
 #pragma unroll
-            for (int d = 1; d < 32; d <<= 1) { int o = __shfl_up(inc, d); if (tid >= d) inc += o; }
-            if (tid < kFilterTile / 64) { keep_w[tid] = w; wbase[tid] = inc - cnt; }
-            if (tid == kFilterTile / 64 - 1) total_s = inc;
+                for (int k = 0; k < kMaxFilterCols; ++k)
+                    if (k < a.ncols && nullacc[k]) {
+                        atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)k * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[k]);
+                        nullacc[k] = 0;
+                    }
+            }
+            cur_chunk = c;
         }
+        const int64_t rw = r0 + (int64_t)wave * (kWW * 64);
+        uint64_t kw[kWW];
+        keep_words(a.t.mask[c], rw, clen, kw);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < kWW; ++i) cnt += __popcll(kw[i]);
+        __syncthreads();  // previous tile's readers of wave_cnt / stage are done
+        if (lane == 0) wave_cnt[wave] = cnt;
         __syncthreads();
-        const int total = total_s;
-        const int64_t out_off = a.tile_scan[tile] - a.tile_scan[a.t.chunk_tile_start[c]];
+        int wave_base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) wave_base += wave_cnt[w]; total += wave_cnt[w]; }
         if (total > 0) {
+            const int64_t out_off = a.tile_scan[tile] - a.tile_scan[a.t.chunk_tile_start[c]];
+#pragma unroll 1
             for (int k = 0; k < a.ncols; ++k) {
                 const DevChunkCol col = a.cols[(int64_t)k * a.t.nchunks + c];
                 const DevOutChunk oc = a.outs[(int64_t)k * a.t.nchunks + c];
-                int64_t* nc = &a.out_null_counts[(int64_t)k * a.t.nchunks + c];
+                uint32_t nn = 0;
                 switch (a.esize[k]) {
-                    case 8: compact_column<uint64_t>(col, oc, nc, r0, clen, out_off, keep_w, wbase, total, stage, vstage); break;
-                    case 4: compact_column<uint32_t>(col, oc, nc, r0, clen, out_off, keep_w, wbase, total, stage, vstage); break;
-                    case 2: compact_column<uint16_t>(col, oc, nc, r0, clen, out_off, keep_w, wbase, total, stage, vstage); break;
-                    default: compact_column<uint8_t>(col, oc, nc, r0, clen, out_off, keep_w, wbase, total, stage, vstage); break;
+                    case 8: compact_column<uint64_t>(col, oc, rw, clen, out_off, kw, wave_base, total, stage, vstage, nn); break;
+                    case 4: compact_column<uint32_t>(col, oc, rw, clen, out_off, kw, wave_base, total, stage, vstage, nn); break;
+                    case 2: compact_column<uint16_t>(col, oc, rw, clen, out_off, kw, wave_base, total, stage, vstage, nn); break;
+                    default: compact_column<uint8_t>(col, oc, rw, clen, out_off, kw, wave_base, total, stage, vstage, nn); break;
                 }
+#pragma unroll
+                for (int kk = 0; kk < kMaxFilterCols; ++kk)
+                    if (kk == k) nullacc[kk] += nn;
             }
         }
-        __syncthreads();
+    }
+    if (cur_chunk >= 0 && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < kMaxFilterCols; ++k)
+            if (k < a.ncols && nullacc[k])
+                atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)k * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[k]);
     }
 }
 
@@ -969,16 +421,13 @@ int eval_grid_limit() {
     return limit;
 }
 
-hipError_t launch_eval(const EvalArgs& a, int sink, bool heavy, int grid, hipStream_t s) {
-    const size_t lds = (size_t)a.ntmp * (kVPT * kBlock * 8 + kBlock * 4);
-    if (sink == SINK_AGG) {
-        if (heavy) hipLaunchKernelGGL((eval_kernel<true, SINK_AGG>), dim3(grid), dim3(kBlock), lds, s, a);
-        else hipLaunchKernelGGL((eval_kernel<false, SINK_AGG>), dim3(grid), dim3(kBlock), lds, s, a);
-    } else {
-        if (heavy) hipLaunchKernelGGL((eval_kernel<true, SINK_STORE>), dim3(grid), dim3(kBlock), lds, s, a);
-        else hipLaunchKernelGGL((eval_kernel<false, SINK_STORE>), dim3(grid), dim3(kBlock), lds, s, a);
-    }
-    return hipGetLastError();
+hipError_t launch_eval_feat0(const EvalArgs& a, int sink, int grid, hipStream_t s);
+hipError_t launch_eval_feat1(const EvalArgs& a, int sink, int grid, hipStream_t s);
+hipError_t launch_eval_feat2(const EvalArgs& a, int sink, int grid, hipStream_t s);
+hipError_t launch_eval(const EvalArgs& a, int sink, int feat, int grid, hipStream_t s) {
+    if (feat <= 0) return launch_eval_feat0(a, sink, grid, s);
+    if (feat == 1) return launch_eval_feat1(a, sink, grid, s);
+    return launch_eval_feat2(a, sink, grid, s);
 }
 
 hipError_t launch_agg_final(const AggFinalArgs& a, hipStream_t s) {
@@ -1011,8 +460,7 @@ hipError_t launch_filter_agg_f64(const FilterAggF64Args& a, int cmp_op, int grid
 }
 
 hipError_t launch_mask_count(const MaskTables& t, int64_t* tile_counts, hipStream_t s) {
-    const int64_t tiles_per_block = kBlock / 32;
-    const int64_t grid = (t.ntiles + tiles_per_block - 1) / tiles_per_block;
+    int64_t grid = t.ntiles < (int64_t)eval_grid_limit() ? t.ntiles : (int64_t)eval_grid_limit();
     if (grid > 0) hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, t, tile_counts);
     return hipGetLastError();
 }

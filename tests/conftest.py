@@ -19,11 +19,17 @@ def ora():
     return oracle.api()
 
 
-@pytest.fixture(scope="session")
-def gpu():
-    """The product: librdf_mi355x.so through its C ABI.  Fails loudly if the library is missing."""
+@pytest.fixture(params=["spec", "interp"])
+def gpu(request):
+    """The product: librdf_mi355x.so through its C ABI.  Fails loudly if the library is missing.
+    Every GPU test runs twice: with the ahead-of-time specialised kernels enabled (default) and with the
+    general evaluator forced, so both device paths are held to the same parity bar."""
     from rust_dataframe_amd import lib
     api = lib.api()  # raises ImportError when the .so is absent: no fallback
     if lib.device_count() < 1:
         pytest.fail("GPU test selected but no HIP device is visible")
-    return api
+    lib.set_option("spec", 1 if request.param == "spec" else 0)
+    lib.set_option("fast_filter", 1 if request.param == "spec" else 0)
+    yield api
+    lib.set_option("spec", 1)
+    lib.set_option("fast_filter", 1)

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks on HBM-resident columns (RDF_MEM_DEVICE): achieved algorithmic GB/s against the
+8 TB/s HBM peak for every kernel family of the path.  Not the driver's bench (that is bench.py); this is the
+tool the kernel tuning loop reads.  Usage: python tools/bench_kernels.py [--rows N] [--only name,name]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from rust_dataframe_amd import _abi as A  # noqa: E402
+from rust_dataframe_amd import lib  # noqa: E402
+
+PEAK = 8000.0
+
+
+def dev_f64(n, col, lo=0.0, hi=1.0, seed=42):
+    t = torch.empty(n, dtype=torch.float64, device="cuda")
+    lib.fill_uniform_f64(t.data_ptr(), n, seed, col, 0, lo, hi)
+    return t
+
+
+def dev_i64(n, col, lo=-2 ** 31, hi=2 ** 31, seed=42):
+    t = torch.empty(n, dtype=torch.int64, device="cuda")
+    lib.fill_uniform_i64(t.data_ptr(), n, seed, col, 0, lo, hi)
+    return t
+
+
+def dev_validity(n, col, frac, seed=42):
+    t = torch.zeros((n + 63) // 64 * 8 + 64, dtype=torch.uint8, device="cuda")
+    lib.fill_validity(t.data_ptr(), n, seed, col, 0, frac)
+    return t
+
+
+def arr(t, dtype, n, validity=None):
+    return A.DeviceArray(t.data_ptr(), validity.data_ptr() if validity is not None else None, 0, n, dtype, -1, keep=(t, validity))
+
+
+def out_like(dtype, n, with_validity=False):
+    es = {A.F64: 8, A.I64: 8, A.U32: 4, A.BOOL: 0}[dtype]
+    pad = (n + 63) // 64 * 64
+    v = torch.empty(pad * es if es else pad // 8 + 8, dtype=torch.uint8, device="cuda")
+    b = torch.empty(pad // 8 + 8, dtype=torch.uint8, device="cuda") if with_validity else None
+    return A.DeviceArray(v.data_ptr(), b.data_ptr() if b is not None else None, 0, n, dtype, 0, keep=(v, b))
+
+
+def timed(fn, steps, warmup=2):
+    for _ in range(warmup):
+        fn()
+    lib.synchronize()
+    lib.kernel_timing_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    lib.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    ms, n = lib.kernel_timing_get()
+    lib.kernel_timing_reset(False)
+    return wall, (ms / max(n, 1)) * 1e-3 * (n / steps if n else 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=100_000_000)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--no-spec", action="store_true", help="force the general evaluator")
+    args = ap.parse_args()
+    n = args.rows
+    only = set(filter(None, args.only.split(",")))
+    lib.set_device(0)
+    api = lib.api()
+    if args.no_spec:
+        lib.set_option("spec", 0)
+        lib.set_option("fast_filter", 0)
+    results = []
+
+    def report(name, alg_bytes, fn):
+        if only and name not in only:
+            return
+        wall, kern = timed(fn, args.steps)
+        gbs = alg_bytes / kern / 1e9 if kern > 0 else 0.0
+        r = {"kernel": name, "rows": n, "alg_bytes": alg_bytes, "wall_ms": wall * 1e3, "kernel_ms": kern * 1e3,
+             "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 3)}
+        results.append(r)
+        print(json.dumps(r), flush=True)
+
+    x, y, z = dev_f64(n, 0, -1, 1), dev_f64(n, 1, -1, 1), dev_f64(n, 2, -1, 1)
+    k = dev_i64(n, 3)
+    vx = dev_validity(n, 0, 0.1)
+    X, Y, Z, K = arr(x, A.F64, n), arr(y, A.F64, n), arr(z, A.F64, n), arr(k, A.I64, n)
+    XV = arr(x, A.F64, n, vx)
+
+    e = A.Expr()
+    cx, cy, cz, ck = e.col(0), e.col(1), e.col(2), e.col(3)
+    gt = e.op("gt", cx, e.scalar(0.0))
+    e_add0 = e.op("add", cx, e.scalar(0.0))   # same bytes as the fast path, but forces the interpreter
+    fma = e.op("add", e.op("multiply", cx, cy), cz)
+    sin1 = e.op("sin", e.op("add", cx, e.scalar(1.0)))
+
+    report("filter_sum_fast", 8.0 * n, lambda: api.pipeline(e, [[X]], [cx], gt))
+    report("filter_sum_fast_validity", 8.125 * n, lambda: api.pipeline(e, [[XV]], [cx], gt))
+    report("filter_sum_other_col_fast", 16.0 * n, lambda: api.pipeline(e, [[X], [Y]], [cy], gt))
+    report("filter_sum_interp", 8.0 * n, lambda: api.pipeline(e, [[X]], [e_add0], gt))
+    report("sum_interp", 8.0 * n, lambda: api.pipeline(e, [[X]], [cx]))
+    report("sum_interp_validity", 8.125 * n, lambda: api.pipeline(e, [[XV]], [cx]))
+    report("c3_fma_minmax_4col", 32.0 * n, lambda: api.pipeline(e, [[X], [Y], [Z], [K]], [fma, ck]))
+    report("c1_sin_add_scalar_sum", 8.0 * n, lambda: api.pipeline(e, [[X]], [sin1]))
+    o1 = out_like(A.F64, n)
+    report("add_store", 24.0 * n, lambda: api.binary("add", [X], [Y], [o1]))
+    report("fma_store", 32.0 * n, lambda: api.pipeline(e, [[X], [Y], [Z]], [fma], -1, A.SINK_STORE, [[o1]]))
+    report("sin_store", 16.0 * n, lambda: api.unary("sin", [X], [o1]))
+    ov = out_like(A.F64, n, True)
+    report("add_store_validity", 24.25 * n, lambda: api.binary("add", [XV], [Y], [ov]))
+    m = out_like(A.BOOL, n)
+    report("predicate_to_mask", 8.125 * n, lambda: api.predicate(e, gt, [[X]], [m]))
+    api.predicate(e, gt, [[X]], [m])
+    cnt = api.filter_count([m])[0]
+    sel = cnt / n
+    of, ok2 = out_like(A.F64, n), out_like(A.I64, n)
+    report("filter_count", n / 8.0, lambda: api.filter_count([m]))
+    report("filter_1col", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
+    report("filter_2col", (16 + 16 * sel + 0.25) * n, lambda: api.filter_columns([[X], [K]], [m], [[of], [ok2]]))
+    nidx = n // 4
+    idx = torch.randint(0, n, (nidx,), dtype=torch.int64, device="cuda").to(torch.uint32 if hasattr(torch, "uint32") else torch.int32)
+    I = A.DeviceArray(idx.data_ptr(), None, 0, nidx, A.U32, 0, keep=idx)
+    ot = out_like(A.F64, nidx)
+    report("take_random_u32", (4 + 8 + 8) * nidx, lambda: api.take([X], I, ot))
+    sidx = torch.arange(0, nidx, dtype=torch.int64, device="cuda").to(torch.uint32)
+    S = A.DeviceArray(sidx.data_ptr(), None, 0, nidx, A.U32, 0, keep=sidx)
+    report("take_sequential_u32", (4 + 8 + 8) * nidx, lambda: api.take([X], S, ot))
+    return results
+
+
+if __name__ == "__main__":
+    main()
