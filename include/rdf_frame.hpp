@@ -1,0 +1,1225 @@
+// rdf_frame.hpp — C++17 host-side mirror of rust-dataframe's interface for the hot path, header-only
+// over the C ABI of rdf_mi355x.h.  Columns live in HBM (RDF_MEM_DEVICE); every operation below is a
+// call into librdf_mi355x.so — there is no host compute path here.
+//
+// Mirrors (paths relative to the reference root):
+//   ChunkedArray / Column            src/table.rs:13-344        (from_arrays, slice, filter, take)
+//   DataFrame                        src/dataframe.rs:30-337    (with_column, with_column_renamed, limit,
+//                                                                filter, select, drop, to_record_batches)
+//   Scalar / BooleanFilter           src/expression.rs:718-870  (eval_to_array)
+//   Column / Calculation / Function / ScalarFunction / Transformation / Computation / Aggregation
+//                                    src/expression.rs:286-712
+//   Add/Subtract/Cast/Sin operations src/operation/scalar.rs:18-318 (plan builders: names, cast insertion)
+//   Evaluate::{evaluate, calculate}  src/evaluation.rs:54-323
+//   LazyFrame                        src/lazyframe.rs:15-315
+//   AggregateFunctions               src/functions/aggregate.rs:12-93
+// Where the reference materialises one DataFrame per plan step, Evaluate::evaluate here FUSES maximal
+// runs of Calculate / Filter / aggregate steps into single passes over HBM (rdf_pipeline).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <memory>
+#include <optional>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "rdf_mi355x.h"
+
+namespace rdf {
+
+// ------------------------------------------------------------------------------------------------
+// errors (src/error.rs:6-15)
+
+struct DataFrameError : std::runtime_error {
+    enum Kind { MemoryError, ParseError, ComputeError, DivideByZero, IoError, NoneError, ArrowError, SqlError, DeviceError } kind;
+    DataFrameError(Kind k, const std::string& m) : std::runtime_error(m), kind(k) {}
+};
+inline void check(rdf_status s) {
+    if (s == RDF_OK) return;
+    const std::string msg = rdf_last_error();
+    switch (s) {
+        case RDF_COMPUTE_ERROR: throw DataFrameError(DataFrameError::ComputeError, msg);
+        case RDF_DIVIDE_BY_ZERO: throw DataFrameError(DataFrameError::DivideByZero, msg);
+        case RDF_INVALID_ARGUMENT: throw DataFrameError(DataFrameError::ArrowError, msg);
+        case RDF_MEMORY_ERROR: throw DataFrameError(DataFrameError::MemoryError, msg);
+        default: throw DataFrameError(DataFrameError::DeviceError, msg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// data types
+
+enum class DataType : int32_t {
+    Int8 = RDF_I8, Int16 = RDF_I16, Int32 = RDF_I32, Int64 = RDF_I64, UInt8 = RDF_U8, UInt16 = RDF_U16,
+    UInt32 = RDF_U32, UInt64 = RDF_U64, Float32 = RDF_F32, Float64 = RDF_F64, Boolean = RDF_BOOL, Utf8 = 100
+};
+inline const char* type_name(DataType t) {
+    switch (t) {
+        case DataType::Int8: return "Int8"; case DataType::Int16: return "Int16"; case DataType::Int32: return "Int32";
+        case DataType::Int64: return "Int64"; case DataType::UInt8: return "UInt8"; case DataType::UInt16: return "UInt16";
+        case DataType::UInt32: return "UInt32"; case DataType::UInt64: return "UInt64"; case DataType::Float32: return "Float32";
+        case DataType::Float64: return "Float64"; case DataType::Boolean: return "Boolean"; default: return "Utf8";
+    }
+}
+inline int type_size(DataType t) {
+    switch (t) {
+        case DataType::Int8: case DataType::UInt8: return 1;
+        case DataType::Int16: case DataType::UInt16: return 2;
+        case DataType::Int32: case DataType::UInt32: case DataType::Float32: return 4;
+        case DataType::Int64: case DataType::UInt64: case DataType::Float64: return 8;
+        default: return 0;
+    }
+}
+inline bool is_integer(DataType t) { return (int)t <= RDF_U64; }
+inline bool is_float(DataType t) { return t == DataType::Float32 || t == DataType::Float64; }
+template <class T> struct TypeOf;
+template <> struct TypeOf<int8_t> { static constexpr DataType value = DataType::Int8; };
+template <> struct TypeOf<int16_t> { static constexpr DataType value = DataType::Int16; };
+template <> struct TypeOf<int32_t> { static constexpr DataType value = DataType::Int32; };
+template <> struct TypeOf<int64_t> { static constexpr DataType value = DataType::Int64; };
+template <> struct TypeOf<uint8_t> { static constexpr DataType value = DataType::UInt8; };
+template <> struct TypeOf<uint16_t> { static constexpr DataType value = DataType::UInt16; };
+template <> struct TypeOf<uint32_t> { static constexpr DataType value = DataType::UInt32; };
+template <> struct TypeOf<uint64_t> { static constexpr DataType value = DataType::UInt64; };
+template <> struct TypeOf<float> { static constexpr DataType value = DataType::Float32; };
+template <> struct TypeOf<double> { static constexpr DataType value = DataType::Float64; };
+
+struct Field {
+    std::string name;
+    DataType data_type;
+    bool nullable = true;
+};
+struct Schema {
+    std::vector<Field> fields;
+    std::optional<std::pair<size_t, Field>> column_with_name(const std::string& n) const {
+        for (size_t i = 0; i < fields.size(); ++i) if (fields[i].name == n) return std::make_pair(i, fields[i]);
+        return std::nullopt;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// device buffers and arrays (Arc<dyn Array> resident in HBM)
+
+class DeviceBuffer {
+  public:
+    explicit DeviceBuffer(int64_t bytes) : bytes_(bytes) { check(rdf_dev_alloc(&ptr_, bytes + 64)); }
+    ~DeviceBuffer() { if (ptr_) (void)rdf_dev_free(ptr_); }
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    void* data() const { return ptr_; }
+    int64_t bytes() const { return bytes_; }
+  private:
+    void* ptr_ = nullptr;
+    int64_t bytes_;
+};
+using BufferRef = std::shared_ptr<DeviceBuffer>;
+
+inline std::vector<uint8_t> pack_bits(const std::vector<bool>& bits) {
+    std::vector<uint8_t> out((bits.size() + 63) / 64 * 8 + 8, 0);
+    for (size_t i = 0; i < bits.size(); ++i) if (bits[i]) out[i >> 3] |= (uint8_t)(1u << (i & 7));
+    return out;
+}
+
+struct Array;
+using ArrayRef = std::shared_ptr<const Array>;
+
+struct Array {
+    BufferRef values, validity;  // validity null = no nulls
+    int64_t offset = 0, length = 0, null_count = 0;
+    DataType dtype = DataType::Float64;
+    std::shared_ptr<const std::vector<std::string>> strings;  // Utf8 columns are carried opaquely on the host
+
+    size_t len() const { return (size_t)length; }
+    DataType data_type() const { return dtype; }
+
+    rdf_array view() const {
+        if (dtype == DataType::Utf8) throw DataFrameError(DataFrameError::ComputeError, "Utf8 arrays are not on the compute path");
+        rdf_array a;
+        a.values = values ? values->data() : nullptr;
+        a.validity = validity ? (const uint8_t*)validity->data() : nullptr;
+        a.offset = offset; a.length = length; a.null_count = null_count; a.dtype = (int32_t)dtype; a.mem = RDF_MEM_DEVICE;
+        return a;
+    }
+    rdf_out out_view(int64_t capacity) const {
+        rdf_out o;
+        o.values = values ? values->data() : nullptr;
+        o.validity = validity ? (uint8_t*)validity->data() : nullptr;
+        o.capacity = capacity; o.length = 0; o.null_count = 0; o.dtype = (int32_t)dtype; o.mem = RDF_MEM_DEVICE;
+        return o;
+    }
+    // freshly allocated output array (capacity rounded up to 64 elements as the ABI asks)
+    static std::shared_ptr<Array> make_out(DataType t, int64_t capacity, bool with_validity) {
+        auto a = std::make_shared<Array>();
+        const int64_t cap = (capacity + 63) / 64 * 64;
+        a->dtype = t;
+        a->values = std::make_shared<DeviceBuffer>(t == DataType::Boolean ? cap / 8 + 8 : cap * type_size(t) + 8);
+        if (with_validity) a->validity = std::make_shared<DeviceBuffer>(cap / 8 + 8);
+        return a;
+    }
+    template <class T>
+    static ArrayRef from_vec(const std::vector<T>& v, const std::vector<bool>* valid = nullptr) {
+        auto a = std::make_shared<Array>();
+        a->dtype = TypeOf<T>::value;
+        a->length = (int64_t)v.size();
+        a->values = std::make_shared<DeviceBuffer>((int64_t)(v.size() * sizeof(T)) + 8);
+        if (!v.empty()) check(rdf_copy_h2d(a->values->data(), v.data(), (int64_t)(v.size() * sizeof(T))));
+        if (valid) {
+            const auto bits = pack_bits(*valid);
+            a->validity = std::make_shared<DeviceBuffer>((int64_t)bits.size());
+            check(rdf_copy_h2d(a->validity->data(), bits.data(), (int64_t)bits.size()));
+            for (bool b : *valid) a->null_count += !b;
+        }
+        return a;
+    }
+    static ArrayRef from_bools(const std::vector<bool>& v, const std::vector<bool>* valid = nullptr) {
+        auto a = std::make_shared<Array>();
+        a->dtype = DataType::Boolean;
+        a->length = (int64_t)v.size();
+        const auto bits = pack_bits(v);
+        a->values = std::make_shared<DeviceBuffer>((int64_t)bits.size());
+        check(rdf_copy_h2d(a->values->data(), bits.data(), (int64_t)bits.size()));
+        if (valid) {
+            const auto vb = pack_bits(*valid);
+            a->validity = std::make_shared<DeviceBuffer>((int64_t)vb.size());
+            check(rdf_copy_h2d(a->validity->data(), vb.data(), (int64_t)vb.size()));
+            for (bool b : *valid) a->null_count += !b;
+        }
+        return a;
+    }
+    static ArrayRef from_strings(std::vector<std::string> s) {
+        auto a = std::make_shared<Array>();
+        a->dtype = DataType::Utf8;
+        a->length = (int64_t)s.size();
+        a->strings = std::make_shared<const std::vector<std::string>>(std::move(s));
+        return a;
+    }
+    // Array::slice: zero-copy (src/table.rs:88)
+    ArrayRef slice(int64_t off, int64_t len) const {
+        auto a = std::make_shared<Array>(*this);
+        if (off > length) off = length;
+        if (len > length - off) len = length - off;
+        a->offset = offset + off;
+        a->length = len;
+        a->null_count = validity ? -1 : 0;
+        return a;
+    }
+    std::vector<bool> bits_to_host(const BufferRef& buf) const {
+        std::vector<bool> out((size_t)length, true);
+        if (!buf || length == 0) return out;
+        const int64_t b0 = offset >> 3, b1 = (offset + length + 7) >> 3;
+        std::vector<uint8_t> raw((size_t)(b1 - b0));
+        check(rdf_copy_d2h(raw.data(), (const uint8_t*)buf->data() + b0, b1 - b0));
+        for (int64_t i = 0; i < length; ++i) { const int64_t k = (offset & 7) + i; out[(size_t)i] = (raw[(size_t)(k >> 3)] >> (k & 7)) & 1; }
+        return out;
+    }
+    std::vector<bool> valid_to_host() const { return bits_to_host(validity); }
+    std::vector<bool> bools_to_host() const { return bits_to_host(values); }
+    template <class T>
+    std::vector<T> values_to_host() const {
+        if (TypeOf<T>::value != dtype) throw DataFrameError(DataFrameError::ComputeError, "values_to_host: type mismatch");
+        std::vector<T> out((size_t)length);
+        if (length) check(rdf_copy_d2h(out.data(), (const T*)values->data() + offset, length * (int64_t)sizeof(T)));
+        return out;
+    }
+    bool is_null(int64_t i) const { return validity && !valid_to_host()[(size_t)i]; }
+    template <class T> T value(int64_t i) const {
+        T v;
+        check(rdf_copy_d2h(&v, (const T*)values->data() + offset + i, (int64_t)sizeof(T)));
+        return v;
+    }
+    int64_t count_nulls() const {  // resolves an unknown null_count on the device
+        if (!validity) return 0;
+        if (null_count >= 0) return null_count;
+        rdf_array v = view();
+        int64_t c = 0; int32_t some = 0;
+        check(rdf_count(&v, 1, &c, &some));
+        return length - c;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// ChunkedArray (src/table.rs:13-112)
+
+class ChunkedArray {
+  public:
+    ChunkedArray() = default;
+    static ChunkedArray from_arrays(std::vector<ArrayRef> arrays) {
+        if (arrays.empty()) throw DataFrameError(DataFrameError::ComputeError, "ChunkedArray needs at least 1 array");  // assert!, :25
+        ChunkedArray c;
+        for (auto& a : arrays) {
+            if (a->dtype != arrays[0]->dtype) throw DataFrameError(DataFrameError::ComputeError, "arrays of a ChunkedArray share one data type");
+            c.num_rows_ += a->length;
+        }
+        c.chunks_ = std::move(arrays);
+        return c;
+    }
+    int64_t num_rows() const { return num_rows_; }
+    int64_t null_count() const { int64_t n = 0; for (auto& a : chunks_) n += a->count_nulls(); return n; }
+    size_t num_chunks() const { return chunks_.size(); }
+    const ArrayRef& chunk(size_t i) const { return chunks_[i]; }
+    const std::vector<ArrayRef>& chunks() const { return chunks_; }
+    DataType data_type() const { return chunks_[0]->dtype; }
+    std::vector<int64_t> chunk_counts() const { std::vector<int64_t> v; for (auto& a : chunks_) v.push_back(a->length); return v; }
+
+    // zero-copy slice, src/table.rs:77-95 (same chunk walk)
+    ChunkedArray slice(int64_t offset, std::optional<int64_t> length = std::nullopt) const {
+        int64_t len = std::min(length.value_or(INT64_MAX), num_rows_);
+        size_t cur = 0;
+        std::vector<ArrayRef> out;
+        while (cur < chunks_.size() && offset >= chunks_[cur]->length) { offset -= chunks_[cur]->length; ++cur; }
+        while (cur < chunks_.size() && len > 0) {
+            out.push_back(chunks_[cur]->slice(offset, len));
+            len -= std::min(len, chunks_[cur]->length - offset);
+            offset = 0;
+            ++cur;
+        }
+        if (out.empty()) out.push_back(chunks_[0]->slice(0, 0));
+        return from_arrays(std::move(out));
+    }
+
+    std::vector<rdf_array> views() const { std::vector<rdf_array> v; for (auto& a : chunks_) v.push_back(a->view()); return v; }
+
+    // src/table.rs:97-107: zip(chunks, condition chunks) -> arrow::compute::filter
+    ChunkedArray filter(const ChunkedArray& condition) const {
+        if (condition.num_chunks() != num_chunks()) throw DataFrameError(DataFrameError::ComputeError, "filter: chunk counts differ");
+        const auto cv = views(), mv = condition.views();
+        std::vector<int64_t> counts(cv.size());
+        check(rdf_filter_count(mv.data(), (int64_t)mv.size(), counts.data()));
+        std::vector<std::shared_ptr<Array>> outs;
+        std::vector<rdf_out> ov;
+        for (size_t i = 0; i < cv.size(); ++i) {
+            outs.push_back(Array::make_out(data_type(), counts[i], chunks_[i]->validity != nullptr));
+            ov.push_back(outs.back()->out_view(counts[i]));
+        }
+        check(rdf_filter(cv.data(), mv.data(), (int64_t)cv.size(), ov.data()));
+        std::vector<ArrayRef> res;
+        for (size_t i = 0; i < outs.size(); ++i) { outs[i]->length = ov[i].length; outs[i]->null_count = ov[i].null_count; res.push_back(outs[i]); }
+        return from_arrays(std::move(res));
+    }
+
+  private:
+    std::vector<ArrayRef> chunks_;
+    int64_t num_rows_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Column (src/table.rs:134-344)
+
+class Column {
+  public:
+    Column() = default;
+    Column(ChunkedArray data, Field field) : data_(std::move(data)), field_(std::move(field)) {}
+    static Column from_arrays(std::vector<ArrayRef> arrays, Field field) {
+        for (auto& a : arrays)
+            if (a->dtype != field.data_type) throw DataFrameError(DataFrameError::ComputeError, "array type differs from the field's");
+        return Column(ChunkedArray::from_arrays(std::move(arrays)), std::move(field));
+    }
+    const std::string& name() const { return field_.name; }
+    DataType data_type() const { return field_.data_type; }
+    const ChunkedArray& data() const { return data_; }
+    const Field& field() const { return field_; }
+    int64_t num_rows() const { return data_.num_rows(); }
+    int64_t null_count() const { return data_.null_count(); }
+    Column slice(int64_t offset, std::optional<int64_t> length = std::nullopt) const {
+        if (data_type() == DataType::Utf8) {  // opaque host column: slice the strings
+            std::vector<ArrayRef> out;
+            int64_t len = std::min(length.value_or(INT64_MAX), num_rows());
+            for (auto& c : data_.chunks()) {
+                if (offset >= c->length) { offset -= c->length; continue; }
+                if (len <= 0) break;
+                const int64_t n = std::min(len, c->length - offset);
+                out.push_back(Array::from_strings(std::vector<std::string>(c->strings->begin() + offset, c->strings->begin() + offset + n)));
+                len -= n; offset = 0;
+            }
+            if (out.empty()) out.push_back(Array::from_strings({}));
+            return Column(ChunkedArray::from_arrays(out), field_);
+        }
+        return Column(data_.slice(offset, length), field_);
+    }
+    Column filter(const Column& condition) const { return Column(data_.filter(condition.data()), field_); }  // :213-215
+    Column renamed(const std::string& n) const { Column c = *this; c.field_.name = n; return c; }
+
+    // src/table.rs:218-241: gather over the concatenation of the chunks; the result is ONE chunk whatever
+    // chunk_size says.  indices: UInt32 (drop-in) or UInt64.
+    Column take(const ArrayRef& indices, size_t /*chunk_size*/) const {
+        const auto cv = data_.views();
+        const rdf_array iv = indices->view();
+        bool nullable = indices->validity != nullptr;
+        for (auto& c : data_.chunks()) nullable |= c->validity != nullptr;
+        auto out = Array::make_out(data_type(), indices->length, nullable);
+        rdf_out ov = out->out_view(indices->length);
+        check(rdf_take(cv.data(), (int64_t)cv.size(), &iv, &ov));
+        out->length = ov.length;
+        out->null_count = ov.null_count;
+        return Column(ChunkedArray::from_arrays({out}), field_);
+    }
+  private:
+    ChunkedArray data_;
+    Field field_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Scalar / BooleanFilter (src/expression.rs:718-870)
+
+struct Scalar {
+    enum Kind { Null, Int32, Int64, Float32, Float64, Boolean } kind = Null;
+    double f = 0;
+    int64_t i = 0;
+    Scalar() = default;
+    Scalar(int32_t v) : kind(Int32), i(v) {}
+    Scalar(int64_t v) : kind(Int64), i(v) {}
+    Scalar(float v) : kind(Float32), f(v) {}
+    Scalar(double v) : kind(Float64), f(v) {}
+    Scalar(bool v) : kind(Boolean), i(v) {}
+    int32_t rdf_type() const {
+        switch (kind) { case Int32: return RDF_I32; case Int64: return RDF_I64; case Float32: return RDF_F32;
+                        case Float64: return RDF_F64; case Boolean: return RDF_BOOL; default: return RDF_NULLTYPE; }
+    }
+};
+
+struct BooleanFilter;
+using FilterRef = std::shared_ptr<const BooleanFilter>;
+struct BooleanFilter {
+    enum Kind { InputScalar, InputColumn, Not, And, Or, Gt, Ge, Eq, Ne, Lt, Le } kind;
+    Scalar scalar_v;
+    std::string column_name;
+    FilterRef l, r;
+    static FilterRef scalar(Scalar s) { auto f = std::make_shared<BooleanFilter>(); f->kind = InputScalar; f->scalar_v = s; return f; }
+    static FilterRef column(const std::string& name) { auto f = std::make_shared<BooleanFilter>(); f->kind = InputColumn; f->column_name = name; return f; }
+    static FilterRef make(Kind k, FilterRef a, FilterRef b = nullptr) { auto f = std::make_shared<BooleanFilter>(); f->kind = k; f->l = std::move(a); f->r = std::move(b); return f; }
+    static FilterRef gt(FilterRef a, FilterRef b) { return make(Gt, a, b); }
+    static FilterRef ge(FilterRef a, FilterRef b) { return make(Ge, a, b); }
+    static FilterRef eq(FilterRef a, FilterRef b) { return make(Eq, a, b); }
+    static FilterRef ne(FilterRef a, FilterRef b) { return make(Ne, a, b); }
+    static FilterRef lt(FilterRef a, FilterRef b) { return make(Lt, a, b); }
+    static FilterRef le(FilterRef a, FilterRef b) { return make(Le, a, b); }
+    static FilterRef and_(FilterRef a, FilterRef b) { return make(And, a, b); }
+    static FilterRef or_(FilterRef a, FilterRef b) { return make(Or, a, b); }
+    static FilterRef not_(FilterRef a) { return make(Not, a); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// expression trees over named columns, lowered to rdf_expr_node arrays
+
+struct Expr;
+using ExprRef = std::shared_ptr<const Expr>;
+struct Expr {
+    enum Kind { Col, Lit, Op } kind = Col;
+    std::string column;  // Col
+    Scalar lit;          // Lit
+    int32_t lit_type = RDF_F64;
+    int32_t op = 0;      // Op (rdf_op)
+    int32_t cast_to = 0;
+    ExprRef l, r;
+    static ExprRef col(const std::string& n) { auto e = std::make_shared<Expr>(); e->kind = Col; e->column = n; return e; }
+    static ExprRef literal(Scalar s, int32_t as_type) { auto e = std::make_shared<Expr>(); e->kind = Lit; e->lit = s; e->lit_type = as_type; return e; }
+    static ExprRef make(int32_t op, ExprRef a, ExprRef b = nullptr, int32_t cast_to = 0) {
+        auto e = std::make_shared<Expr>(); e->kind = Op; e->op = op; e->l = std::move(a); e->r = std::move(b); e->cast_to = cast_to; return e;
+    }
+    bool has_divide() const { return kind == Op && (op == RDF_OP_DIV || (l && l->has_divide()) || (r && r->has_divide())); }
+};
+
+inline ExprRef filter_to_expr(const FilterRef& f, const std::function<ExprRef(const std::string&)>& resolve) {
+    switch (f->kind) {
+        case BooleanFilter::InputScalar: return Expr::literal(f->scalar_v, f->scalar_v.rdf_type());
+        case BooleanFilter::InputColumn: return resolve(f->column_name);
+        case BooleanFilter::Not: return Expr::make(RDF_OP_NOT, filter_to_expr(f->l, resolve));
+        default: break;
+    }
+    static const std::map<int, int> ops = {{BooleanFilter::And, RDF_OP_AND}, {BooleanFilter::Or, RDF_OP_OR}, {BooleanFilter::Gt, RDF_OP_GT},
+                                            {BooleanFilter::Ge, RDF_OP_GE}, {BooleanFilter::Eq, RDF_OP_EQ}, {BooleanFilter::Ne, RDF_OP_NE},
+                                            {BooleanFilter::Lt, RDF_OP_LT}, {BooleanFilter::Le, RDF_OP_LE}};
+    return Expr::make(ops.at(f->kind), filter_to_expr(f->l, resolve), filter_to_expr(f->r, resolve));
+}
+
+// Lowered program: node array + the distinct columns it reads (in first-use order).
+struct Lowered {
+    std::vector<rdf_expr_node> nodes;
+    std::vector<std::string> columns;
+    int add(const ExprRef& e) {
+        rdf_expr_node n;
+        std::memset(&n, 0, sizeof n);
+        n.lhs = n.rhs = -1;
+        if (e->kind == Expr::Col) {
+            int idx = -1;
+            for (size_t i = 0; i < columns.size(); ++i) if (columns[i] == e->column) idx = (int)i;
+            if (idx < 0) { idx = (int)columns.size(); columns.push_back(e->column); }
+            n.kind = RDF_NODE_COLUMN; n.column = idx;
+        } else if (e->kind == Expr::Lit) {
+            n.kind = RDF_NODE_SCALAR; n.dtype = e->lit.kind == Scalar::Null ? RDF_NULLTYPE : e->lit_type;
+            const bool lit_is_float = e->lit.kind == Scalar::Float32 || e->lit.kind == Scalar::Float64;
+            n.f64 = lit_is_float ? e->lit.f : (double)e->lit.i;
+            n.i64 = lit_is_float ? (int64_t)e->lit.f : e->lit.i;
+        } else {
+            const int l = add(e->l);
+            const int r = e->r ? add(e->r) : -1;
+            n.kind = RDF_NODE_OP; n.op = e->op; n.lhs = l; n.rhs = r; n.dtype = e->cast_to;
+        }
+        nodes.push_back(n);
+        return (int)nodes.size() - 1;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// plan types (src/expression.rs:286-712) and operation builders (src/operation/scalar.rs)
+
+namespace plan {
+
+struct Column {  // expression::Column {name, column_type: Scalar(dtype)}
+    std::string name;
+    DataType data_type;
+    std::string debug() const { return "Column { name: \"" + name + "\", column_type: Scalar(" + type_name(data_type) + ") }"; }
+};
+struct Dataset {
+    std::string name;
+    std::vector<Column> columns;
+    std::optional<std::pair<size_t, Column>> get_column(const std::string& n) const {
+        for (size_t i = 0; i < columns.size(); ++i) if (columns[i].name == n) return std::make_pair(i, columns[i]);
+        return std::nullopt;
+    }
+    Dataset append_column(const Column& c) const {  // :95-112: replace in place or push
+        Dataset d = *this;
+        for (auto& e : d.columns) if (e.name == c.name) { e = c; return d; }
+        d.columns.push_back(c);
+        return d;
+    }
+};
+enum class ScalarFunction { Add, Subtract, Divide, Multiply, Abs, Sine, Cosine, Tangent, Cotangent, Secant, Cosecant };
+inline const char* scalar_function_name(ScalarFunction f) {
+    static const char* n[] = {"Add", "Subtract", "Divide", "Multiply", "Abs", "Sine", "Cosine", "Tangent", "Cotangent", "Secant", "Cosecant"};
+    return n[(int)f];
+}
+enum class AggregateFunction { Avg, Count, CountDistinct, First, Kurtosis, Last, Max, Min, Skewness, StdDev, Sum, SumDistinct, Variance };
+struct Function {
+    enum Kind { Scalar, Cast, Rename, Filter } kind = Scalar;
+    ScalarFunction scalar = ScalarFunction::Add;
+    FilterRef filter;
+    static Function Scalar_(ScalarFunction f) { Function x; x.kind = Scalar; x.scalar = f; return x; }
+    static Function Cast_() { Function x; x.kind = Cast; return x; }
+    static Function Rename_() { Function x; x.kind = Rename; return x; }
+    static Function Filter_(FilterRef f) { Function x; x.kind = Filter; x.filter = std::move(f); return x; }
+    std::string debug() const {
+        switch (kind) { case Cast: return "Cast"; case Rename: return "Rename"; case Filter: return "Filter(..)";
+                        default: return std::string("Scalar(") + scalar_function_name(scalar) + ")"; }
+    }
+};
+struct Calculation {
+    std::string name;
+    std::vector<Column> inputs;
+    Column output;
+    Function function;
+    std::string debug() const {  // mirrors #[derive(Debug)] so the reference's plan-text test can be restated
+        std::string s = "Calculation { name: \"" + name + "\", inputs: [";
+        for (size_t i = 0; i < inputs.size(); ++i) s += (i ? ", " : "") + inputs[i].debug();
+        return s + "], output: " + output.debug() + ", function: " + function.debug() + " }";
+    }
+};
+inline std::string debug(const std::vector<Calculation>& v) {
+    std::string s = "[";
+    for (size_t i = 0; i < v.size(); ++i) s += (i ? ", " : "") + v[i].debug();
+    return s + "]";
+}
+struct Aggregation { AggregateFunction function; std::vector<std::string> columns; };
+
+struct ArrowError : DataFrameError { using DataFrameError::DataFrameError; };
+
+// CastOperation (src/operation/scalar.rs:95-137)
+struct CastOperation {
+    static const char* name() { return "cast"; }
+    static std::vector<Calculation> transform(const std::vector<Column>& inputs, std::optional<std::string> out_name, std::optional<DataType> to_type) {
+        if (inputs.size() != 1) throw DataFrameError(DataFrameError::ComputeError, "Cast operation expects 1 input");
+        if (!to_type) throw DataFrameError(DataFrameError::ArrowError, "Cast requires a target output datatype");
+        const Column& a = inputs[0];
+        return {Calculation{name(), inputs, Column{out_name.value_or(std::string(name()) + "(" + a.name + " as datatype)"), *to_type}, Function::Cast_()}};
+    }
+};
+// AddOperation / SubtractOperation (:18-93, :139-214) + the same shape for multiply / divide
+template <ScalarFunction F>
+struct BinaryOperation {
+    static const char* name() {
+        return F == ScalarFunction::Add ? "add" : F == ScalarFunction::Subtract ? "subtract" : F == ScalarFunction::Multiply ? "multiply" : "divide";
+    }
+    static std::vector<Calculation> transform(const std::vector<Column>& inputs, std::optional<std::string> out_name, std::optional<DataType>) {
+        if (inputs.size() != 2) throw DataFrameError(DataFrameError::ComputeError, std::string(name()) + " operation expects 2 inputs");
+        const Column &a = inputs[0], &b = inputs[1];
+        const std::string oname = out_name.value_or(std::string(name()) + "(" + a.name + ", " + b.name + ")");
+        if (a.data_type != b.data_type) {
+            // cast b to a's type first (:47-72).  The reference's subtract emits Add here: not copied.
+            auto cast = CastOperation::transform({b}, b.name, a.data_type)[0];
+            return {cast, Calculation{name(), {a, cast.output}, Column{oname, a.data_type}, Function::Scalar_(F)}};
+        }
+        return {Calculation{name(), inputs, Column{oname, a.data_type}, Function::Scalar_(F)}};
+    }
+};
+using AddOperation = BinaryOperation<ScalarFunction::Add>;
+using SubtractOperation = BinaryOperation<ScalarFunction::Subtract>;
+using MultiplyOperation = BinaryOperation<ScalarFunction::Multiply>;
+using DivideOperation = BinaryOperation<ScalarFunction::Divide>;
+// SinOperation (:227-318) + the same shape for cosine / tangent: integers are cast to Float64 first
+template <ScalarFunction F>
+struct TrigOperation {
+    static const char* name() { return F == ScalarFunction::Sine ? "sin" : F == ScalarFunction::Cosine ? "cos" : "tan"; }
+    static std::vector<Calculation> transform(const std::vector<Column>& inputs, std::optional<std::string> out_name, std::optional<DataType>) {
+        if (inputs.size() != 1) throw DataFrameError(DataFrameError::ComputeError, "Sine operation expects 2 inputs");  // sic, :242
+        const Column& a = inputs[0];
+        const std::string oname = out_name.value_or(std::string(name()) + "(" + a.name + " as datatype)");
+        if (is_integer(a.data_type)) {
+            const Column cast_out{out_name.value_or(std::string(CastOperation::name()) + "(" + a.name + " as datatype)"), DataType::Float64};
+            return {Calculation{CastOperation::name(), inputs, cast_out, Function::Cast_()},
+                    Calculation{name(), {cast_out}, Column{oname, DataType::Float64}, Function::Scalar_(F)}};
+        }
+        if (is_float(a.data_type)) return {Calculation{name(), inputs, Column{oname, a.data_type}, Function::Scalar_(F)}};
+        throw DataFrameError(DataFrameError::ComputeError, std::string("Cannot perform ") + name() + " operation from " + type_name(a.data_type) + " data type");
+    }
+};
+using SinOperation = TrigOperation<ScalarFunction::Sine>;
+using CosOperation = TrigOperation<ScalarFunction::Cosine>;
+using TanOperation = TrigOperation<ScalarFunction::Tangent>;
+
+struct Transformation {
+    enum Kind { GroupAggregate, Calculate, Select, Drop, Limit, Filter, Sort, Join, Read } kind = Calculate;
+    Calculation calc;                       // Calculate
+    std::vector<std::string> names;         // Select / Drop / group columns
+    std::vector<Aggregation> aggregations;  // GroupAggregate
+    size_t limit = 0;
+    FilterRef filter;
+    static Transformation Calculate_(Calculation c) { Transformation t; t.kind = Calculate; t.calc = std::move(c); return t; }
+    static Transformation Filter_(FilterRef f) { Transformation t; t.kind = Filter; t.filter = std::move(f); return t; }
+    static Transformation Limit_(size_t n) { Transformation t; t.kind = Limit; t.limit = n; return t; }
+    static Transformation Select_(std::vector<std::string> n) { Transformation t; t.kind = Select; t.names = std::move(n); return t; }
+    static Transformation Drop_(std::vector<std::string> n) { Transformation t; t.kind = Drop; t.names = std::move(n); return t; }
+    static Transformation GroupAggregate_(std::vector<std::string> groups, std::vector<Aggregation> a) {
+        Transformation t; t.kind = GroupAggregate; t.names = std::move(groups); t.aggregations = std::move(a); return t;
+    }
+};
+struct Computation {
+    std::vector<Dataset> input;
+    std::vector<Transformation> transformations;
+    Dataset output;
+};
+
+// Calculation::calculate (src/expression.rs:433-499): name lookup + dispatch to the operation builders.
+inline std::vector<Transformation> calculate(const Dataset& ds, const std::vector<std::string>& in_col_names, const Function& function,
+                                             std::optional<std::string> out_col_name, std::optional<DataType> out_col_type) {
+    std::vector<Column> inputs;
+    for (auto& n : in_col_names) {
+        auto c = ds.get_column(n);
+        if (!c) throw DataFrameError(DataFrameError::ParseError, "Column " + n + " not found");
+        inputs.push_back(c->second);
+    }
+    std::vector<Calculation> ops;
+    switch (function.kind) {
+        case Function::Filter: return {Transformation::Filter_(function.filter)};
+        case Function::Cast: ops = CastOperation::transform(inputs, out_col_name, out_col_type); break;
+        case Function::Rename: throw DataFrameError(DataFrameError::ComputeError, "Please use rename function directly for now");
+        default:
+            switch (function.scalar) {
+                case ScalarFunction::Add: ops = AddOperation::transform(inputs, out_col_name, out_col_type); break;
+                case ScalarFunction::Subtract: ops = SubtractOperation::transform(inputs, out_col_name, out_col_type); break;
+                case ScalarFunction::Multiply: ops = MultiplyOperation::transform(inputs, out_col_name, out_col_type); break;
+                case ScalarFunction::Divide: ops = DivideOperation::transform(inputs, out_col_name, out_col_type); break;
+                case ScalarFunction::Sine: ops = SinOperation::transform(inputs, out_col_name, out_col_type); break;
+                case ScalarFunction::Cosine: ops = CosOperation::transform(inputs, out_col_name, out_col_type); break;
+                case ScalarFunction::Tangent: ops = TanOperation::transform(inputs, out_col_name, out_col_type); break;
+                default: throw DataFrameError(DataFrameError::ComputeError, std::string("Scalar Function ") + scalar_function_name(function.scalar) + " not supported");
+            }
+    }
+    std::vector<Transformation> out;
+    for (auto& c : ops) out.push_back(Transformation::Calculate_(c));
+    return out;
+}
+
+}  // namespace plan
+
+// ------------------------------------------------------------------------------------------------
+// DataFrame (src/dataframe.rs:30-337)
+
+struct RecordBatch {
+    Schema schema;
+    std::vector<ArrayRef> columns;
+    int64_t num_rows() const { return columns.empty() ? 0 : columns[0]->length; }
+};
+
+class DataFrame {
+  public:
+    DataFrame() = default;
+    DataFrame(Schema schema, std::vector<Column> columns) : schema_(std::move(schema)), columns_(std::move(columns)) {}
+    static DataFrame empty() { return DataFrame(); }
+    static DataFrame from_columns(std::vector<Column> cols) {
+        Schema s;
+        for (auto& c : cols) s.fields.push_back(c.field());
+        for (auto& c : cols)
+            if (c.num_rows() != cols[0].num_rows()) throw DataFrameError(DataFrameError::ComputeError, "columns differ in length");
+        return DataFrame(std::move(s), std::move(cols));
+    }
+    // Reads the numeric columns of a CSV with a header row into 1024-row batches (DataFrame::from_csv,
+    // src/dataframe.rs:349-389: batch_size 1024); quoted text columns are carried as opaque Utf8.
+    static DataFrame from_csv(const std::string& path, size_t batch_size = 1024) {
+        std::ifstream f(path);
+        if (!f) throw DataFrameError(DataFrameError::IoError, "cannot open " + path);
+        auto split = [](const std::string& line) {
+            std::vector<std::string> out; std::string cur; bool q = false;
+            for (char ch : line) { if (ch == '"') q = !q; else if (ch == ',' && !q) { out.push_back(cur); cur.clear(); } else if (ch != '\r') cur += ch; }
+            out.push_back(cur);
+            return out;
+        };
+        std::string line;
+        std::getline(f, line);
+        const auto header = split(line);
+        std::vector<std::vector<std::string>> cells(header.size());
+        while (std::getline(f, line)) {
+            if (line.empty()) continue;
+            auto v = split(line);
+            v.resize(header.size());
+            for (size_t i = 0; i < header.size(); ++i) cells[i].push_back(v[i]);
+        }
+        std::vector<Column> cols;
+        for (size_t i = 0; i < header.size(); ++i) {
+            bool numeric = !cells[i].empty();
+            for (auto& s : cells[i]) { char* e = nullptr; std::strtod(s.c_str(), &e); if (e == s.c_str() || *e) { numeric = false; break; } }
+            std::vector<ArrayRef> chunks;
+            const size_t n = cells[i].size();
+            for (size_t b = 0; b < n || chunks.empty(); b += batch_size) {
+                const size_t e = std::min(n, b + batch_size);
+                if (numeric) {
+                    std::vector<double> v;
+                    for (size_t k = b; k < e; ++k) v.push_back(std::strtod(cells[i][k].c_str(), nullptr));
+                    chunks.push_back(Array::from_vec(v));
+                } else chunks.push_back(Array::from_strings(std::vector<std::string>(cells[i].begin() + b, cells[i].begin() + e)));
+                if (n == 0) break;
+            }
+            cols.push_back(Column::from_arrays(chunks, Field{header[i], numeric ? DataType::Float64 : DataType::Utf8, true}));
+        }
+        return from_columns(std::move(cols));
+    }
+
+    const Schema& schema() const { return schema_; }
+    size_t num_columns() const { return columns_.size(); }
+    size_t num_chunks() const { return columns_.empty() ? 0 : columns_[0].data().num_chunks(); }
+    int64_t num_rows() const { return columns_.empty() ? 0 : columns_[0].num_rows(); }
+    const Column& column(size_t i) const { return columns_[i]; }
+    const std::vector<Column>& columns() const { return columns_; }
+    const Column& column_by_name(const std::string& name) const {
+        auto c = schema_.column_with_name(name);
+        if (!c) throw DataFrameError(DataFrameError::ComputeError, "Column not found by name: " + name);
+        return columns_[c->first];
+    }
+    bool has_column(const std::string& name) const { return schema_.column_with_name(name).has_value(); }
+
+    // :97-113 — an existing column of that name is dropped, the new one goes last
+    DataFrame with_column(const std::string& name, Column column) const {
+        DataFrame d = has_column(name) ? drop({name}) : *this;
+        column = column.renamed(name);
+        d.schema_.fields.push_back(column.field());
+        d.columns_.push_back(std::move(column));
+        return d;
+    }
+    DataFrame with_column_renamed(const std::string& old_name, const std::string& new_name) const {  // :116-124
+        DataFrame d = *this;
+        auto c = schema_.column_with_name(old_name);
+        if (!c) throw DataFrameError(DataFrameError::NoneError, "column " + old_name + " not found");
+        d.schema_.fields[c->first].name = new_name;
+        d.columns_[c->first] = d.columns_[c->first].renamed(new_name);
+        return d;
+    }
+    // :128-163 — chunk i of every column = RecordBatch i
+    std::vector<RecordBatch> to_record_batches() const {
+        std::vector<RecordBatch> out;
+        for (size_t i = 0; i < num_chunks(); ++i) {
+            RecordBatch b;
+            b.schema = schema_;
+            for (auto& c : columns_) b.columns.push_back(c.data().chunk(i));
+            out.push_back(std::move(b));
+        }
+        return out;
+    }
+    DataFrame limit(size_t count) const {  // :166-175, zero-copy slices
+        std::vector<Column> cols;
+        for (auto& c : columns_) cols.push_back(c.slice(0, (int64_t)count));
+        return DataFrame(schema_, std::move(cols));
+    }
+    DataFrame select(const std::vector<std::string>& names) const {  // :258-297 — unknown names are omitted
+        Schema s; std::vector<Column> cols;
+        for (size_t i = 0; i < columns_.size(); ++i)
+            for (auto& n : names) if (schema_.fields[i].name == n) { s.fields.push_back(schema_.fields[i]); cols.push_back(columns_[i]); break; }
+        return DataFrame(std::move(s), std::move(cols));
+    }
+    DataFrame drop(const std::vector<std::string>& names) const {  // :302-337
+        Schema s; std::vector<Column> cols;
+        for (size_t i = 0; i < columns_.size(); ++i) {
+            bool dropped = false;
+            for (auto& n : names) dropped |= schema_.fields[i].name == n;
+            if (!dropped) { s.fields.push_back(schema_.fields[i]); cols.push_back(columns_[i]); }
+        }
+        return DataFrame(std::move(s), std::move(cols));
+    }
+
+    // evaluate_boolean_filter (:612-624): one BooleanArray mask per RecordBatch, computed in ONE launch
+    Column evaluate_boolean_filter(const FilterRef& filter) const {
+        Lowered low;
+        const int root = low.add(filter_to_expr(filter, [this](const std::string& n) {
+            if (!has_column(n)) throw DataFrameError(DataFrameError::ComputeError, "Cannot find column " + n);  // expression.rs:812-815
+            return Expr::col(n);
+        }));
+        return run_predicate(low, root);
+    }
+    Column run_predicate(const Lowered& low, int root) const {
+        const size_t nch = num_chunks();
+        std::vector<rdf_array> cols;
+        bool nullable = false;
+        for (auto& n : low.columns)
+            for (auto& a : column_by_name(n).data().chunks()) { cols.push_back(a->view()); nullable |= a->validity != nullptr; }
+        std::vector<std::shared_ptr<Array>> outs;
+        std::vector<rdf_out> ov;
+        const auto counts = columns_[0].data().chunk_counts();
+        for (size_t i = 0; i < nch; ++i) { outs.push_back(Array::make_out(DataType::Boolean, counts[i], nullable)); ov.push_back(outs.back()->out_view(counts[i])); }
+        if (low.columns.empty()) {  // constant predicate: the batch length comes from column 0
+            for (auto& a : columns_[0].data().chunks()) cols.push_back(a->view());
+            check(rdf_predicate(low.nodes.data(), (int32_t)low.nodes.size(), root, cols.data(), 1, (int64_t)nch, ov.data()));
+        } else
+            check(rdf_predicate(low.nodes.data(), (int32_t)low.nodes.size(), root, cols.data(), (int32_t)low.columns.size(), (int64_t)nch, ov.data()));
+        std::vector<ArrayRef> res;
+        for (size_t i = 0; i < nch; ++i) { outs[i]->length = ov[i].length; outs[i]->null_count = ov[i].null_count; res.push_back(outs[i]); }
+        return Column::from_arrays(res, Field{"bool_filter", DataType::Boolean, true});
+    }
+    // DataFrame::filter (:178-189): the mask, then EVERY column compacted by it in one pass (rdf_filter_columns)
+    DataFrame filter(const FilterRef& condition) const { return filter_by_mask(evaluate_boolean_filter(condition)); }
+    DataFrame filter_by_mask(const Column& mask) const {
+        const size_t nch = num_chunks();
+        const auto mv = mask.data().views();
+        std::vector<int64_t> counts(nch);
+        check(rdf_filter_count(mv.data(), (int64_t)nch, counts.data()));
+        std::vector<Column> result(columns_.size());
+        for (size_t base = 0; base < columns_.size(); base += 16) {  // up to 16 columns per launch
+            const size_t n = std::min<size_t>(16, columns_.size() - base);
+            std::vector<rdf_array> cv;
+            std::vector<std::shared_ptr<Array>> outs;
+            std::vector<rdf_out> ov;
+            for (size_t k = 0; k < n; ++k) {
+                const Column& c = columns_[base + k];
+                if (c.data_type() == DataType::Utf8 || c.data_type() == DataType::Boolean)
+                    throw DataFrameError(DataFrameError::ComputeError, "filter of " + std::string(type_name(c.data_type())) + " columns is outside the accelerated path");
+                for (size_t i = 0; i < nch; ++i) {
+                    cv.push_back(c.data().chunk(i)->view());
+                    outs.push_back(Array::make_out(c.data_type(), counts[i], c.data().chunk(i)->validity != nullptr));
+                    ov.push_back(outs.back()->out_view(counts[i]));
+                }
+            }
+            check(rdf_filter_columns(cv.data(), (int32_t)n, mv.data(), (int64_t)nch, ov.data()));
+            for (size_t k = 0; k < n; ++k) {
+                std::vector<ArrayRef> chunks;
+                for (size_t i = 0; i < nch; ++i) { auto& o = outs[k * nch + i]; o->length = ov[k * nch + i].length; o->null_count = ov[k * nch + i].null_count; chunks.push_back(o); }
+                result[base + k] = Column::from_arrays(chunks, columns_[base + k].field());
+            }
+        }
+        return DataFrame(schema_, std::move(result));
+    }
+    // sort_by_indices (:216-222): Column::take of every column (chunk size 4096 as in the reference)
+    DataFrame take(const ArrayRef& indices) const {
+        std::vector<Column> cols;
+        for (auto& c : columns_) cols.push_back(c.take(indices, 4096));
+        return DataFrame(schema_, std::move(cols));
+    }
+
+  private:
+    Schema schema_;
+    std::vector<Column> columns_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// ScalarFunctions / AggregateFunctions over device columns (chunk list in, chunk list out)
+
+struct ScalarFunctions {
+    static std::vector<ArrayRef> binary(int32_t op, const std::vector<ArrayRef>& left, const std::vector<ArrayRef>& right) {
+        if (left.size() != right.size()) throw DataFrameError(DataFrameError::ComputeError, "chunk lists differ in length");
+        std::vector<rdf_array> a, b;
+        std::vector<std::shared_ptr<Array>> outs;
+        std::vector<rdf_out> ov;
+        for (size_t i = 0; i < left.size(); ++i) {
+            a.push_back(left[i]->view()); b.push_back(right[i]->view());
+            outs.push_back(Array::make_out(left[i]->dtype, left[i]->length, left[i]->validity || right[i]->validity));
+            ov.push_back(outs.back()->out_view(left[i]->length));
+        }
+        check(rdf_binary(op, a.data(), b.data(), (int64_t)a.size(), ov.data()));
+        return finish(outs, ov);
+    }
+    static std::vector<ArrayRef> unary(int32_t op, const std::vector<ArrayRef>& arr) {
+        std::vector<rdf_array> a;
+        std::vector<std::shared_ptr<Array>> outs;
+        std::vector<rdf_out> ov;
+        for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(x->dtype, x->length, x->validity != nullptr)); ov.push_back(outs.back()->out_view(x->length)); }
+        check(rdf_unary(op, a.data(), (int64_t)a.size(), ov.data()));
+        return finish(outs, ov);
+    }
+    static std::vector<ArrayRef> cast(const std::vector<ArrayRef>& arr, DataType to) {
+        std::vector<rdf_array> a;
+        std::vector<std::shared_ptr<Array>> outs;
+        std::vector<rdf_out> ov;
+        for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(to, x->length, x->validity != nullptr)); ov.push_back(outs.back()->out_view(x->length)); }
+        check(rdf_cast(a.data(), (int64_t)a.size(), ov.data()));
+        return finish(outs, ov);
+    }
+    // src/functions/scalar.rs:16-103
+    static std::vector<ArrayRef> add(const std::vector<ArrayRef>& l, const std::vector<ArrayRef>& r) { return binary(RDF_OP_ADD, l, r); }
+    static std::vector<ArrayRef> subtract(const std::vector<ArrayRef>& l, const std::vector<ArrayRef>& r) { return binary(RDF_OP_SUB, l, r); }
+    static std::vector<ArrayRef> multiply(const std::vector<ArrayRef>& l, const std::vector<ArrayRef>& r) { return binary(RDF_OP_MUL, l, r); }
+    static std::vector<ArrayRef> divide(const std::vector<ArrayRef>& l, const std::vector<ArrayRef>& r) { return binary(RDF_OP_DIV, l, r); }
+    // :106-452
+    static std::vector<ArrayRef> abs(const std::vector<ArrayRef>& a) { return unary(RDF_OP_ABS, a); }
+    static std::vector<ArrayRef> sin(const std::vector<ArrayRef>& a) { return unary(RDF_OP_SIN, a); }
+    static std::vector<ArrayRef> cos(const std::vector<ArrayRef>& a) { return unary(RDF_OP_COS, a); }
+    static std::vector<ArrayRef> tan(const std::vector<ArrayRef>& a) { return unary(RDF_OP_TAN, a); }
+    static std::vector<ArrayRef> acos(const std::vector<ArrayRef>& a) { return unary(RDF_OP_ACOS, a); }
+
+  private:
+    static std::vector<ArrayRef> finish(std::vector<std::shared_ptr<Array>>& outs, std::vector<rdf_out>& ov) {
+        std::vector<ArrayRef> res;
+        for (size_t i = 0; i < outs.size(); ++i) { outs[i]->length = ov[i].length; outs[i]->null_count = ov[i].null_count; res.push_back(outs[i]); }
+        return res;
+    }
+};
+
+struct AggregateFunctions {  // src/functions/aggregate.rs:12-93
+    template <class T> static std::optional<T> call(rdf_status (*fn)(const rdf_array*, int64_t, void*, int32_t*), const ChunkedArray& c) {
+        const auto v = c.views();
+        T out{}; int32_t some = 0;
+        check(fn(v.data(), (int64_t)v.size(), &out, &some));
+        return some ? std::optional<T>(out) : std::nullopt;
+    }
+    template <class T> static std::optional<T> sum(const ChunkedArray& c) { return call<T>(rdf_sum, c); }
+    template <class T> static std::optional<T> min(const ChunkedArray& c) { return call<T>(rdf_min, c); }
+    template <class T> static std::optional<T> max(const ChunkedArray& c) { return call<T>(rdf_max, c); }
+    static std::optional<int64_t> count(const ChunkedArray& c) {
+        const auto v = c.views(); int64_t out = 0; int32_t some = 0;
+        check(rdf_count(v.data(), (int64_t)v.size(), &out, &some));
+        return some ? std::optional<int64_t>(out) : std::nullopt;
+    }
+    static std::optional<double> avg(const ChunkedArray& c) {
+        const auto v = c.views(); double out = 0; int32_t some = 0;
+        check(rdf_avg(v.data(), (int64_t)v.size(), &out, &some));
+        return some ? std::optional<double>(out) : std::nullopt;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Evaluate (src/evaluation.rs:54-323), fusing
+
+inline int32_t scalar_function_op(plan::ScalarFunction f) {
+    using SF = plan::ScalarFunction;
+    switch (f) {
+        case SF::Add: return RDF_OP_ADD; case SF::Subtract: return RDF_OP_SUB; case SF::Multiply: return RDF_OP_MUL;
+        case SF::Divide: return RDF_OP_DIV; case SF::Abs: return RDF_OP_ABS; case SF::Sine: return RDF_OP_SIN;
+        case SF::Cosine: return RDF_OP_COS; case SF::Tangent: return RDF_OP_TAN;
+        default: throw DataFrameError(DataFrameError::ComputeError, std::string("Scalar Function ") + plan::scalar_function_name(f) + " not supported");
+    }
+}
+
+class Evaluate {
+  public:
+    // Evaluate::calculate, eager: ONE Calculation materialised as a new column (drop-in for :97-323)
+    static DataFrame calculate(const DataFrame& frame, const plan::Calculation& calc) {
+        Evaluate ev(frame);
+        ev.step_calculate(calc);
+        return ev.flush();
+    }
+    // Evaluate::evaluate (:66-96): computations newest-first (Expression::unroll order), each applied to
+    // the running frame.  Calculate / Filter / Select / Drop / Rename stay lazy and are flushed as fused
+    // passes; Limit and the end of the plan materialise; GroupAggregate with no groups is the fused
+    // filter -> aggregate pass.
+    static DataFrame evaluate(const DataFrame& frame, const std::vector<plan::Computation>& comps) {
+        Evaluate ev(frame);
+        for (auto c = comps.rbegin(); c != comps.rend(); ++c)
+            for (auto& t : c->transformations) ev.step(t);
+        return ev.flush();
+    }
+
+  private:
+    struct Lazy { std::string name; DataType dtype; ExprRef def; };  // def == nullptr: column `source` of base_
+    struct Entry { std::string name; DataType dtype; ExprRef def; std::string source; };
+
+    explicit Evaluate(const DataFrame& f) : base_(f) {
+        for (auto& fld : f.schema().fields) cols_.push_back(Entry{fld.name, fld.data_type, nullptr, fld.name});
+    }
+    Entry* find(const std::string& n) { for (auto& e : cols_) if (e.name == n) return &e; return nullptr; }
+    ExprRef ref(const std::string& n) {
+        Entry* e = find(n);
+        if (!e) throw DataFrameError(DataFrameError::ComputeError, "Column not found by name: " + n);
+        return e->def ? e->def : Expr::col(e->source);
+    }
+    void put(const std::string& name, DataType dt, ExprRef def) {  // with_column: replace-at-end semantics
+        for (size_t i = 0; i < cols_.size(); ++i) if (cols_[i].name == name) { cols_.erase(cols_.begin() + i); break; }
+        cols_.push_back(Entry{name, dt, std::move(def), ""});
+    }
+
+    void step(const plan::Transformation& t) {
+        using T = plan::Transformation;
+        switch (t.kind) {
+            case T::Calculate: step_calculate(t.calc); break;
+            case T::Filter: step_filter(t.filter); break;
+            case T::Limit: { DataFrame f = flush(); reset(f.limit(t.limit)); } break;
+            case T::Select: {
+                std::vector<Entry> keep;
+                for (auto& e : cols_) for (auto& n : t.names) if (e.name == n) { keep.push_back(e); break; }
+                cols_ = keep;
+            } break;
+            case T::Drop: {
+                std::vector<Entry> keep;
+                for (auto& e : cols_) { bool d = false; for (auto& n : t.names) d |= e.name == n; if (!d) keep.push_back(e); }
+                cols_ = keep;
+            } break;
+            case T::GroupAggregate: step_aggregate(t); break;
+            case T::Sort: throw DataFrameError(DataFrameError::ComputeError, "Sort is not on the accelerated path yet (SURVEY.md §8f)");
+            case T::Join: throw DataFrameError(DataFrameError::ComputeError, "Join is not on the accelerated path yet (SURVEY.md §8f)");
+            default: throw DataFrameError(DataFrameError::ComputeError, "Read inside evaluate: pass the frame in");
+        }
+    }
+
+    void step_calculate(const plan::Calculation& calc) {
+        using F = plan::Function;
+        std::vector<ExprRef> in;
+        for (auto& c : calc.inputs) in.push_back(ref(c.name));
+        switch (calc.function.kind) {
+            case F::Scalar: {
+                const DataType dt = calc.output.data_type;
+                const auto sf = calc.function.scalar;
+                const bool binary = sf == plan::ScalarFunction::Add || sf == plan::ScalarFunction::Subtract || sf == plan::ScalarFunction::Multiply || sf == plan::ScalarFunction::Divide;
+                if (binary) {
+                    if (dt == DataType::Int8 || dt == DataType::UInt8 || dt == DataType::Boolean || dt == DataType::Utf8)
+                        throw DataFrameError(DataFrameError::ComputeError, "Unsupported operation");  // evaluation.rs:239
+                    if (in.size() != 2) throw DataFrameError(DataFrameError::ComputeError, "binary scalar function expects 2 inputs");
+                    if (sf == plan::ScalarFunction::Divide && pending_) { DataFrame f = flush(); reset(f); in = {ref(calc.inputs[0].name), ref(calc.inputs[1].name)}; }
+                    put(calc.output.name, dt, Expr::make(scalar_function_op(sf), in[0], in[1]));
+                } else {
+                    if (!is_float(dt)) throw DataFrameError(DataFrameError::ComputeError, std::string("Expecting float datatype for operation, found ") + type_name(dt));  // :282-284
+                    put(calc.output.name, dt, Expr::make(scalar_function_op(sf), in[0]));
+                }
+            } break;
+            case F::Cast: put(calc.output.name, calc.output.data_type, Expr::make(RDF_OP_CAST, in[0], nullptr, (int32_t)calc.output.data_type)); break;
+            case F::Rename: {
+                Entry* e = find(calc.inputs[0].name);
+                if (!e) throw DataFrameError(DataFrameError::NoneError, "column " + calc.inputs[0].name + " not found");
+                e->name = calc.output.name;
+            } break;
+            case F::Filter: step_filter(calc.function.filter); break;
+        }
+    }
+    void step_filter(const FilterRef& f) {
+        ExprRef p = filter_to_expr(f, [this](const std::string& n) { return ref(n); });
+        pending_ = pending_ ? Expr::make(RDF_OP_AND, pending_, p) : p;
+    }
+
+    // fused filter -> aggregates (GroupAggregate with no grouping columns)
+    void step_aggregate(const plan::Transformation& t) {
+        if (!t.names.empty()) throw DataFrameError(DataFrameError::ComputeError, "aggregations not supported");  // evaluation.rs:73
+        struct Want { plan::AggregateFunction fn; std::string col; DataType dt; ExprRef e; };
+        std::vector<Want> wants;
+        for (auto& a : t.aggregations)
+            for (auto& c : a.columns) {
+                Entry* e = find(c);
+                if (!e) throw DataFrameError(DataFrameError::ComputeError, "Aggregating column \"" + c + "\" does not exist");
+                wants.push_back(Want{a.function, c, e->dtype, a.function == plan::AggregateFunction::Avg && !is_float(e->dtype)
+                                                                   ? Expr::make(RDF_OP_CAST, ref(c), nullptr, RDF_F64) : ref(c)});
+            }
+        std::vector<Column> out_cols;
+        for (size_t b = 0; b < wants.size(); b += RDF_MAX_VALUES) {
+            const size_t n = std::min<size_t>(RDF_MAX_VALUES, wants.size() - b);
+            Lowered low;
+            rdf_program prog;
+            std::memset(&prog, 0, sizeof prog);
+            prog.filter_root = pending_ ? low.add(pending_) : -1;
+            for (size_t k = 0; k < n; ++k) prog.value_roots[k] = low.add(wants[b + k].e);
+            prog.nvalues = (int32_t)n;
+            prog.sink = RDF_SINK_AGG;
+            prog.nodes = low.nodes.data();
+            prog.nnodes = (int32_t)low.nodes.size();
+            std::vector<rdf_array> cols;
+            for (auto& cn : low.columns) for (auto& a : base_.column_by_name(cn).data().chunks()) cols.push_back(a->view());
+            rdf_agg_result res[RDF_MAX_VALUES];
+            check(rdf_pipeline(&prog, cols.data(), (int32_t)low.columns.size(), (int64_t)base_.num_chunks(), nullptr, res));
+            for (size_t k = 0; k < n; ++k) out_cols.push_back(agg_column(wants[b + k].fn, wants[b + k].col, wants[b + k].dt, res[k]));
+        }
+        reset(DataFrame::from_columns(out_cols));
+    }
+    // output naming / typing of Dataset::try_aggregate (src/expression.rs:114-221)
+    static Column agg_column(plan::AggregateFunction fn, const std::string& col, DataType dt, const rdf_agg_result& r) {
+        using AF = plan::AggregateFunction;
+        const std::vector<bool> some{r.is_some != 0};
+        auto mk = [&](const std::string& name, DataType t, double f, int64_t i, bool always) -> Column {
+            const std::vector<bool>* valid = always ? nullptr : &some;
+            ArrayRef a;
+            switch (t) {
+                case DataType::Float64: a = Array::from_vec(std::vector<double>{f}, valid); break;
+                case DataType::Float32: a = Array::from_vec(std::vector<float>{(float)f}, valid); break;
+                case DataType::Int64: a = Array::from_vec(std::vector<int64_t>{i}, valid); break;
+                case DataType::UInt64: a = Array::from_vec(std::vector<uint64_t>{(uint64_t)i}, valid); break;
+                case DataType::Int32: a = Array::from_vec(std::vector<int32_t>{(int32_t)i}, valid); break;
+                case DataType::UInt32: a = Array::from_vec(std::vector<uint32_t>{(uint32_t)i}, valid); break;
+                case DataType::Int16: a = Array::from_vec(std::vector<int16_t>{(int16_t)i}, valid); break;
+                case DataType::UInt16: a = Array::from_vec(std::vector<uint16_t>{(uint16_t)i}, valid); break;
+                case DataType::Int8: a = Array::from_vec(std::vector<int8_t>{(int8_t)i}, valid); break;
+                default: a = Array::from_vec(std::vector<uint8_t>{(uint8_t)i}, valid); break;
+            }
+            return Column::from_arrays({a}, Field{name, t, true});
+        };
+        const bool fl = is_float(dt);
+        switch (fn) {
+            case AF::Sum: return mk("sum(" + col + ")", dt, r.sum_f64, r.sum_i64, true);
+            case AF::Min: return mk("min(" + col + ")", dt, r.min_f64, r.min_i64, false);
+            case AF::Max: return mk("max(" + col + ")", dt, r.max_f64, r.max_i64, false);
+            case AF::Count:
+                if (r.count > (int64_t)UINT32_MAX) throw DataFrameError(DataFrameError::ComputeError, "count does not fit the UInt32 the reference's schema declares");
+                return mk("count(" + col + ")", DataType::UInt32, 0, r.count, true);
+            case AF::Avg: return mk("avg(" + col + ")", DataType::Float64, r.count ? r.sum_f64 / (double)r.count : 0.0, 0, false);
+            default: (void)fl; throw DataFrameError(DataFrameError::ComputeError, "Aggregation not yet supported");
+        }
+    }
+
+    void reset(const DataFrame& f) {
+        base_ = f;
+        cols_.clear();
+        pending_ = nullptr;
+        for (auto& fld : f.schema().fields) cols_.push_back(Entry{fld.name, fld.data_type, nullptr, fld.name});
+    }
+
+    // materialise: every lazy column through fused SINK_STORE passes (<= RDF_MAX_VALUES values per pass), then
+    // the pending predicate as ONE mask + ONE compaction of all columns.
+    DataFrame flush() {
+        const size_t nch = base_.num_chunks();
+        std::vector<Column> out(cols_.size());
+        std::vector<size_t> lazy;
+        for (size_t i = 0; i < cols_.size(); ++i) {
+            if (cols_[i].def) lazy.push_back(i);
+            else out[i] = base_.column_by_name(cols_[i].source).renamed(cols_[i].name);
+        }
+        if (!lazy.empty() && base_.num_columns() == 0) throw DataFrameError(DataFrameError::ComputeError, "calculation on an empty frame");
+        const auto counts = base_.num_columns() ? base_.column(0).data().chunk_counts() : std::vector<int64_t>{};
+        for (size_t b = 0; b < lazy.size(); b += RDF_MAX_VALUES) {
+            const size_t n = std::min<size_t>(RDF_MAX_VALUES, lazy.size() - b);
+            Lowered low;
+            rdf_program prog;
+            std::memset(&prog, 0, sizeof prog);
+            prog.filter_root = -1;
+            for (size_t k = 0; k < n; ++k) prog.value_roots[k] = low.add(cols_[lazy[b + k]].def);
+            prog.nvalues = (int32_t)n;
+            prog.sink = RDF_SINK_STORE;
+            prog.nodes = low.nodes.data();
+            prog.nnodes = (int32_t)low.nodes.size();
+            std::vector<rdf_array> cv;
+            for (auto& cn : low.columns) for (auto& a : base_.column_by_name(cn).data().chunks()) cv.push_back(a->view());
+            std::vector<std::shared_ptr<Array>> outs;
+            std::vector<rdf_out> ov;
+            for (size_t k = 0; k < n; ++k)
+                for (size_t i = 0; i < nch; ++i) { outs.push_back(Array::make_out(cols_[lazy[b + k]].dtype, counts[i], true)); ov.push_back(outs.back()->out_view(counts[i])); }
+            check(rdf_pipeline(&prog, cv.data(), (int32_t)low.columns.size(), (int64_t)nch, ov.data(), nullptr));
+            for (size_t k = 0; k < n; ++k) {
+                std::vector<ArrayRef> chunks;
+                for (size_t i = 0; i < nch; ++i) {
+                    auto& o = outs[k * nch + i];
+                    o->length = ov[k * nch + i].length;
+                    o->null_count = ov[k * nch + i].null_count;
+                    if (o->null_count == 0) o->validity.reset();  // no nulls resulted: drop the bitmap like Arrow builders do
+                    chunks.push_back(o);
+                }
+                out[lazy[b + k]] = Column::from_arrays(chunks, Field{cols_[lazy[b + k]].name, cols_[lazy[b + k]].dtype, true});
+            }
+        }
+        DataFrame result = DataFrame::from_columns(out);
+        if (pending_) {
+            Lowered low;
+            const int root = low.add(pending_);
+            const Column mask = base_.run_predicate(low, root);
+            result = result.filter_by_mask(mask);
+        }
+        reset(result);
+        return result;
+    }
+
+    DataFrame base_;
+    std::vector<Entry> cols_;
+    ExprRef pending_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// LazyFrame (src/lazyframe.rs:15-315): a plan builder over an in-memory source frame
+
+class LazyFrame {
+  public:
+    static LazyFrame read(const DataFrame& source) {
+        LazyFrame f;
+        f.source_ = std::make_shared<DataFrame>(source);
+        f.output_.name = "source";
+        for (auto& fld : source.schema().fields) f.output_.columns.push_back(plan::Column{fld.name, fld.data_type});
+        return f;
+    }
+    std::optional<std::pair<size_t, plan::Column>> column(const std::string& name) const { return output_.get_column(name); }
+    const plan::Dataset& output() const { return output_; }
+
+    LazyFrame with_column(const std::string& col_name, const plan::Function& function, const std::vector<std::string>& input_col_names,
+                          std::optional<DataType> as_type = std::nullopt) const {  // :58-96
+        auto ops = plan::calculate(output_, input_col_names, function, col_name, as_type);
+        LazyFrame f = *this;
+        for (auto& t : ops) {
+            if (t.kind != plan::Transformation::Calculate) throw DataFrameError(DataFrameError::ComputeError, "can't create column from a non-calculation transformation");
+            f.output_ = f.output_.append_column(t.calc.output);
+        }
+        f.push(ops);
+        return f;
+    }
+    LazyFrame with_column_renamed(const std::string& old_name, const std::string& new_name) const {  // :98-131
+        auto c = output_.get_column(old_name);
+        if (!c) return *this;
+        LazyFrame f = *this;
+        f.output_.columns[c->first].name = new_name;
+        f.output_.name = "renamed_dataset";
+        f.push({plan::Transformation::Calculate_(plan::Calculation{"rename", {c->second}, plan::Column{new_name, c->second.data_type}, plan::Function::Rename_()})});
+        return f;
+    }
+    LazyFrame filter(const FilterRef& cond) const { LazyFrame f = *this; f.push({plan::Transformation::Filter_(cond)}); return f; }
+    LazyFrame limit(size_t n) const { LazyFrame f = *this; f.push({plan::Transformation::Limit_(n)}); return f; }
+    LazyFrame select(const std::vector<std::string>& names) const {
+        LazyFrame f = *this;
+        plan::Dataset d; d.name = output_.name;
+        for (auto& c : output_.columns) for (auto& n : names) if (c.name == n) { d.columns.push_back(c); break; }
+        f.output_ = d;
+        f.push({plan::Transformation::Select_(names)});
+        return f;
+    }
+    LazyFrame drop(const std::vector<std::string>& names) const {
+        LazyFrame f = *this;
+        plan::Dataset d; d.name = output_.name;
+        for (auto& c : output_.columns) { bool x = false; for (auto& n : names) x |= c.name == n; if (!x) d.columns.push_back(c); }
+        f.output_ = d;
+        f.push({plan::Transformation::Drop_(names)});
+        return f;
+    }
+    LazyFrame aggregate(const std::vector<std::string>& groups, const std::vector<plan::Aggregation>& aggr) const {
+        LazyFrame f = *this;
+        f.push({plan::Transformation::GroupAggregate_(groups, aggr)});
+        return f;
+    }
+    // LazyFrame::evaluate (:311-315): unroll (newest first) and hand to Evaluate
+    DataFrame evaluate() const {
+        std::vector<plan::Computation> unrolled(comps_.rbegin(), comps_.rend());
+        return Evaluate::evaluate(*source_, unrolled);
+    }
+
+  private:
+    void push(std::vector<plan::Transformation> t) {
+        plan::Computation c;
+        c.transformations = std::move(t);
+        c.output = output_;
+        comps_.push_back(std::move(c));
+    }
+    std::shared_ptr<DataFrame> source_;
+    plan::Dataset output_;
+    std::vector<plan::Computation> comps_;  // oldest first
+};
+
+}  // namespace rdf

@@ -1,0 +1,230 @@
+// C++ mirrors of the reference's in-file #[test] functions for the hot path, run on the device through
+// rdf_frame.hpp (-> librdf_mi355x.so), plus fused-vs-oracle parity of the batch loop.  The oracle
+// (librdf_oracle.so) is linked here as the checker only.
+#include <random>
+
+#include "mini_test.hpp"
+#include "rdf_frame.hpp"
+#include "rdf_oracle.h"
+
+using namespace rdf;
+namespace P = rdf::plan;
+
+static std::string g_csv = "tests/golden/uk_cities_with_headers.csv";
+
+template <class T> static std::vector<T> host(const ArrayRef& a) { return a->values_to_host<T>(); }
+
+// ---------------------------------------------------------------- src/functions/scalar.rs:565-602
+TEST(test_primitive_array_abs_f64) {
+    auto a = Array::from_vec<double>({-5.2, -6.1, 7.3, -8.6, -0.0});
+    auto c = host<double>(ScalarFunctions::abs({a})[0]);
+    CHECK_EQ(c, (std::vector<double>{5.2, 6.1, 7.3, 8.6, 0.0}));
+}
+TEST(test_primitive_array_abs_i32) {
+    auto a = Array::from_vec<int32_t>({-5, -6, 7, -8, 0});
+    CHECK_EQ(host<int32_t>(ScalarFunctions::abs({a})[0]), (std::vector<int32_t>{5, 6, 7, 8, 0}));
+}
+TEST(test_primitive_array_acos_f64) {
+    auto c = host<double>(ScalarFunctions::acos({Array::from_vec<double>({-0.2, 0.25, 0.75})})[0]);
+    CHECK_NEAR(c[0], 1.7721542475852274, 1e-15); CHECK_NEAR(c[1], 1.318116071652818, 1e-15); CHECK_NEAR(c[2], 0.7227342478134157, 1e-15);
+}
+TEST(test_primitive_array_cos_f64) {
+    auto c = host<double>(ScalarFunctions::cos({Array::from_vec<double>({-0.2, 0.25, 0.75})})[0]);
+    CHECK_NEAR(c[0], 0.9800665778412416, 1e-15); CHECK_NEAR(c[1], 0.9689124217106447, 1e-15); CHECK_NEAR(c[2], 0.7316888688738209, 1e-15);
+}
+
+// ---------------------------------------------------------------- src/functions/aggregate.rs:123-146
+TEST(test_aggregate_count) {
+    auto a = Array::from_vec<int32_t>({5, 6, 7, 8, 9});
+    CHECK_EQ(*AggregateFunctions::count(ChunkedArray::from_arrays({a})), 5);
+}
+TEST(test_aggregate_mean) {
+    auto a = Array::from_vec<int32_t>({0, 1, 2, 3, 4});
+    auto b = Array::from_vec<int32_t>({5, 6, 7, 8, 9});
+    CHECK_EQ(*AggregateFunctions::avg(ChunkedArray::from_arrays({a, b})), 4.5);
+    const std::vector<bool> valid{1, 0, 1, 0, 1, 1, 1};
+    auto d = Array::from_vec<int32_t>({0, 0, 1, 0, 2, 3, 4}, &valid);
+    CHECK_EQ(*AggregateFunctions::avg(ChunkedArray::from_arrays({d, b})), 4.5);
+}
+
+// ---------------------------------------------------------------- src/dataframe.rs:782-836
+TEST(test_dataframe_ops) {
+    DataFrame df = DataFrame::from_csv(g_csv);
+    CHECK_EQ(df.num_columns(), 3u);
+    CHECK_EQ(df.num_rows(), 37);
+    auto lat = df.column_by_name("lat").data().chunks(), lng = df.column_by_name("lng").data().chunks();
+    auto add = host<double>(ScalarFunctions::add(lat, lng)[0]);
+    CHECK(std::fabs(add[0] - 54.31776) < 1e-4);
+    CHECK_EQ(host<double>(ScalarFunctions::abs(lng)[0])[0], 3.335724);
+    // with_column appends (an existing name is dropped and re-added last, :97-113)
+    df = df.with_column("lat_lng", Column::from_arrays(ScalarFunctions::add(lat, lng), Field{"lat_lng", DataType::Float64, true}));
+    CHECK_EQ(df.num_columns(), 4u);
+    df = df.with_column("lat", df.column_by_name("lat_lng"));
+    CHECK_EQ(df.num_columns(), 4u);
+    CHECK_EQ(df.schema().fields.back().name, std::string("lat"));
+}
+
+// ---------------------------------------------------------------- src/lazyframe.rs:324-408, src/evaluation.rs:359-434
+TEST(test_lazy_pipeline) {
+    LazyFrame frame = LazyFrame::read(DataFrame::from_csv(g_csv));
+    frame = frame.with_column_renamed("city", "town");
+    frame = frame.with_column("sin_lat", P::Function::Scalar_(P::ScalarFunction::Sine), {"lat"});
+    frame = frame.with_column("sin_lng", P::Function::Scalar_(P::ScalarFunction::Sine), {"lng"});
+    DataFrame df = frame.evaluate();
+    CHECK_EQ(df.num_columns(), 5u);
+    CHECK_EQ(df.num_rows(), 37);
+    CHECK(df.has_column("town") && !df.has_column("city"));
+    CHECK_NEAR(df.column_by_name("sin_lat").data().chunk(0)->value<double>(0), 0.8933816410476535, 1e-12);
+    CHECK_NEAR(df.column_by_name("sin_lng").data().chunk(0)->value<double>(0), 0.1929142713855381, 1e-12);
+}
+TEST(test_with_columns) {
+    LazyFrame frame = LazyFrame::read(DataFrame::from_csv(g_csv));
+    frame = frame.with_column("sum", P::Function::Scalar_(P::ScalarFunction::Add), {"lat", "lng"});
+    DataFrame df = frame.evaluate();
+    CHECK_EQ(df.column_by_name("sum").data().chunk(0)->value<double>(0), 57.653484 - 3.335724);
+}
+TEST(test_lazy_evaluation) {
+    LazyFrame frame = LazyFrame::read(DataFrame::from_csv(g_csv));
+    frame = frame.with_column_renamed("city", "town");
+    frame = frame.with_column("sin_lat", P::Function::Scalar_(P::ScalarFunction::Sine), {"lat"});
+    frame = frame.with_column("sin_lng", P::Function::Scalar_(P::ScalarFunction::Sine), {"lng"});
+    frame = frame.limit(25);
+    DataFrame df = frame.evaluate();
+    CHECK_EQ(df.num_columns(), 5u);
+    CHECK_EQ(df.num_rows(), 25);
+    // ops after a limit see sliced (offset) arrays
+    DataFrame lim = DataFrame::from_csv(g_csv).limit(30).limit(10);
+    auto s = host<double>(ScalarFunctions::sin(lim.column_by_name("lat").data().chunks())[0]);
+    CHECK_EQ(s.size(), 10u);
+    CHECK_NEAR(s[0], 0.8933816410476535, 1e-12);
+}
+
+// ---------------------------------------------------------------- src/dataframe.rs:963-1003 (the take half of test_sort)
+TEST(test_sort_take) {
+    const std::vector<bool> valid{1, 1, 0, 1, 1, 1};
+    auto a = Array::from_vec<int32_t>({1, 1, 0, 3, 3, 4}, &valid);
+    auto b = Array::from_vec<uint8_t>({9, 5, 6, 7, 4, 8});
+    DataFrame frame = DataFrame::from_columns({Column::from_arrays({a}, Field{"a", DataType::Int32, true}), Column::from_arrays({b}, Field{"b", DataType::UInt8, false})});
+    // lexsort_to_indices(a desc, b asc, nulls last) = [5, 4, 3, 1, 0, 2]
+    DataFrame sorted = frame.take(Array::from_vec<uint32_t>({5, 4, 3, 1, 0, 2}));
+    auto ac = sorted.column(0).data().chunks();
+    CHECK_EQ(ac.size(), 1u);
+    CHECK_EQ(ac[0]->valid_to_host(), (std::vector<bool>{1, 1, 1, 1, 1, 0}));
+    auto av = host<int32_t>(ac[0]);
+    CHECK_EQ(std::vector<int32_t>(av.begin(), av.begin() + 5), (std::vector<int32_t>{4, 3, 3, 1, 1}));
+    CHECK_EQ(host<uint8_t>(sorted.column(1).data().chunk(0)), (std::vector<uint8_t>{8, 4, 7, 5, 9, 6}));
+}
+
+// ---------------------------------------------------------------- filter: DataFrame::filter + the fused filter -> aggregate
+TEST(test_filter_and_fused_aggregate) {
+    DataFrame df = DataFrame::from_csv(g_csv).drop({"city"});
+    auto cond = BooleanFilter::gt(BooleanFilter::column("lat"), BooleanFilter::scalar(Scalar(55.0)));
+    DataFrame f = df.filter(cond);
+    CHECK_EQ(f.num_rows(), 5);
+    CHECK_EQ(f.num_columns(), 2u);
+    CHECK_NEAR(*AggregateFunctions::sum<double>(f.column_by_name("lat").data()), 282.746235, 1e-12);
+    // same through the lazy, fused path: filter -> {sum, count, min, max, avg}(lat) in one pass
+    using AF = P::AggregateFunction;
+    DataFrame agg = LazyFrame::read(df).filter(cond).aggregate({}, {{AF::Sum, {"lat"}}, {AF::Count, {"lat"}}, {AF::Min, {"lat"}}, {AF::Max, {"lat"}}, {AF::Avg, {"lat"}}}).evaluate();
+    CHECK_EQ(agg.num_rows(), 1);
+    CHECK_EQ(agg.schema().fields[0].name, std::string("sum(lat)"));
+    CHECK_EQ(agg.schema().fields[1].name, std::string("count(lat)"));
+    CHECK(agg.schema().fields[1].data_type == DataType::UInt32);
+    CHECK_NEAR(agg.column(0).data().chunk(0)->value<double>(0), 282.746235, 1e-12);
+    CHECK_EQ(agg.column(1).data().chunk(0)->value<uint32_t>(0), 5u);
+    CHECK_EQ(agg.column(3).data().chunk(0)->value<double>(0), 57.653484);
+    CHECK_NEAR(agg.column(4).data().chunk(0)->value<double>(0), 282.746235 / 5, 1e-12);
+    // unknown column -> ComputeError("Cannot find column ..") like expression.rs:812-815
+    CHECK_THROWS(df.filter(BooleanFilter::gt(BooleanFilter::column("nope"), BooleanFilter::scalar(Scalar(1.0)))));
+    // GroupAggregate with grouping columns: "aggregations not supported" (evaluation.rs:73)
+    CHECK_THROWS(LazyFrame::read(df).aggregate({"lat"}, {{AF::Sum, {"lng"}}}).evaluate());
+}
+
+TEST(test_evaluate_type_rules) {
+    auto k = Array::from_vec<int64_t>({1, 2, 3, 4});
+    auto s = Array::from_vec<int8_t>({1, 2, 3, 4});
+    DataFrame df = DataFrame::from_columns({Column::from_arrays({k}, Field{"k", DataType::Int64, true}), Column::from_arrays({s}, Field{"s", DataType::Int8, true})});
+    // sin(Int64) inserts Cast -> Float64 (SinOperation)
+    DataFrame r = LazyFrame::read(df).with_column("sk", P::Function::Scalar_(P::ScalarFunction::Sine), {"k"}).evaluate();
+    CHECK(r.column_by_name("sk").data_type() == DataType::Float64);
+    CHECK_NEAR(r.column_by_name("sk").data().chunk(0)->value<double>(2), std::sin(3.0), 1e-12);
+    // Int8 arithmetic: panic!("Unsupported operation") in the reference (evaluation.rs:239) -> an error value here
+    CHECK_THROWS(LazyFrame::read(df).with_column("ss", P::Function::Scalar_(P::ScalarFunction::Add), {"s", "s"}).evaluate());
+    // add(Int64, Int8): the builder casts the right side to Int64 first
+    DataFrame m = LazyFrame::read(df).with_column("ks", P::Function::Scalar_(P::ScalarFunction::Add), {"k", "s"}).evaluate();
+    CHECK_EQ(host<int64_t>(m.column_by_name("ks").data().chunk(0)), (std::vector<int64_t>{2, 4, 6, 8}));
+}
+
+// ---------------------------------------------------------------- the fused batch loop vs the unfused oracle
+struct HostCol { std::vector<double> v; std::vector<bool> valid; std::vector<uint8_t> bits; };
+
+TEST(test_fused_pipeline_matches_unfused_oracle) {
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    const std::vector<size_t> lens{1024, 1024, 300};
+    std::vector<std::vector<HostCol>> cols(2);  // a, b per chunk
+    std::vector<Column> dev;
+    for (int c = 0; c < 2; ++c) {
+        std::vector<ArrayRef> chunks;
+        for (size_t n : lens) {
+            HostCol h;
+            for (size_t i = 0; i < n; ++i) { h.v.push_back(U(rng)); h.valid.push_back(U(rng) > -0.8); }
+            h.bits = pack_bits(h.valid);
+            chunks.push_back(Array::from_vec(h.v, &h.valid));
+            cols[c].push_back(std::move(h));
+        }
+        dev.push_back(Column::from_arrays(chunks, Field{c == 0 ? "a" : "b", DataType::Float64, true}));
+    }
+    DataFrame df = DataFrame::from_columns(dev);
+    using AF = P::AggregateFunction;
+    LazyFrame lf = LazyFrame::read(df)
+                       .with_column("s", P::Function::Scalar_(P::ScalarFunction::Add), {"a", "b"})
+                       .with_column("t", P::Function::Scalar_(P::ScalarFunction::Sine), {"s"})
+                       .filter(BooleanFilter::gt(BooleanFilter::column("s"), BooleanFilter::scalar(Scalar(0.2))));
+    DataFrame agg = lf.aggregate({}, {{AF::Sum, {"t"}}, {AF::Min, {"t"}}, {AF::Max, {"t"}}, {AF::Count, {"t"}}, {AF::Sum, {"s"}}}).evaluate();
+    DataFrame mat = lf.evaluate();  // materialised: a, b, s, t filtered
+
+    // oracle: sin(a + b) where a + b > 0.2, unfused
+    rdf_expr_node nodes[6];
+    std::memset(nodes, 0, sizeof nodes);
+    nodes[0].kind = RDF_NODE_COLUMN; nodes[0].column = 0; nodes[0].lhs = nodes[0].rhs = -1;
+    nodes[1].kind = RDF_NODE_COLUMN; nodes[1].column = 1; nodes[1].lhs = nodes[1].rhs = -1;
+    nodes[2].kind = RDF_NODE_OP; nodes[2].op = RDF_OP_ADD; nodes[2].lhs = 0; nodes[2].rhs = 1;
+    nodes[3].kind = RDF_NODE_OP; nodes[3].op = RDF_OP_SIN; nodes[3].lhs = 2; nodes[3].rhs = -1;
+    nodes[4].kind = RDF_NODE_SCALAR; nodes[4].dtype = RDF_F64; nodes[4].f64 = 0.2; nodes[4].lhs = nodes[4].rhs = -1;
+    nodes[5].kind = RDF_NODE_OP; nodes[5].op = RDF_OP_GT; nodes[5].lhs = 2; nodes[5].rhs = 4;
+    std::vector<rdf_array> hv;
+    for (int c = 0; c < 2; ++c)
+        for (size_t i = 0; i < lens.size(); ++i) {
+            rdf_array a; a.values = cols[c][i].v.data(); a.validity = cols[c][i].bits.data(); a.offset = 0; a.length = (int64_t)lens[i];
+            a.null_count = -1; a.dtype = RDF_F64; a.mem = RDF_MEM_HOST;
+            hv.push_back(a);
+        }
+    rdf_program prog;
+    std::memset(&prog, 0, sizeof prog);
+    prog.nodes = nodes; prog.nnodes = 6; prog.filter_root = 5; prog.nvalues = 2; prog.value_roots[0] = 3; prog.value_roots[1] = 2; prog.sink = RDF_SINK_AGG;
+    rdf_agg_result exp[RDF_MAX_VALUES];
+    CHECK_EQ(ora_pipeline(&prog, hv.data(), 2, (int64_t)lens.size(), nullptr, exp), RDF_OK);
+    CHECK_NEAR(agg.column(0).data().chunk(0)->value<double>(0), exp[0].sum_f64, 1e-9);
+    CHECK_NEAR(agg.column(1).data().chunk(0)->value<double>(0), exp[0].min_f64, 1e-9);
+    CHECK_NEAR(agg.column(2).data().chunk(0)->value<double>(0), exp[0].max_f64, 1e-9);
+    CHECK_EQ((int64_t)agg.column(3).data().chunk(0)->value<uint32_t>(0), exp[0].count);
+    CHECK_NEAR(agg.column(4).data().chunk(0)->value<double>(0), exp[1].sum_f64, 1e-9);
+    // the materialised frame agrees with the aggregates and keeps the chunking
+    CHECK_EQ(mat.num_columns(), 4u);
+    CHECK_EQ(mat.num_chunks(), lens.size());
+    CHECK_EQ(mat.num_rows() - mat.column_by_name("t").null_count(), exp[0].count);
+    CHECK_NEAR(*AggregateFunctions::sum<double>(mat.column_by_name("t").data()), exp[0].sum_f64, 1e-9);
+    // eager Evaluate::calculate of one step == the lazy result for that column
+    P::Calculation add = P::AddOperation::transform({P::Column{"a", DataType::Float64}, P::Column{"b", DataType::Float64}}, std::string("s"), std::nullopt)[0];
+    DataFrame eager = Evaluate::calculate(df, add);
+    CHECK_EQ(eager.num_columns(), 3u);
+    auto e0 = host<double>(eager.column_by_name("s").data().chunk(0));
+    for (size_t i = 0; i < 50; ++i)
+        if (cols[0][0].valid[i] && cols[1][0].valid[i]) CHECK_EQ(e0[i], cols[0][0].v[i] + cols[1][0].v[i]);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) g_csv = argv[1];
+    return run_all();
+}

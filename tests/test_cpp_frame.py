@@ -1,0 +1,42 @@
+"""Builds and runs the C++ host-side mirror's tests (tests/cpp/*.cpp over include/rdf_frame.hpp).
+
+test_plan: plan builders (src/operation/scalar.rs) — CPU only.
+test_frame: the reference's #[test]s for the hot path restated in C++ and run on the device, plus the fused
+            batch loop against the unfused oracle — GPU."""
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "rust_dataframe_amd")
+ORA = os.path.join(ROOT, "oracle")
+
+
+def build(name, with_oracle):
+    out = os.path.join(tempfile.gettempdir(), f"rdf_{name}_{os.getpid()}")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", ORA,
+           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", out, "-L", PKG, "-lrdf_mi355x", f"-Wl,-rpath,{PKG}"]
+    if with_oracle:
+        if not os.path.exists(os.path.join(ORA, "librdf_oracle.so")):
+            subprocess.check_call(["make", "-C", ORA, "-s"])
+        cmd += ["-L", ORA, "-lrdf_oracle", f"-Wl,-rpath,{ORA}"]
+    subprocess.check_call(cmd)
+    return out
+
+
+def run(exe, *args):
+    p = subprocess.run([exe, *args], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    print(p.stdout[-4000:], p.stderr[-2000:])
+    assert p.returncode == 0, p.stdout[-4000:]
+    assert " 0 failed" in p.stdout
+
+
+def test_plan_builders_cpp():
+    run(build("test_plan", False))
+
+
+@pytest.mark.gpu
+def test_frame_mirror_cpp():
+    run(build("test_frame", True), os.path.join(ROOT, "tests", "golden", "uk_cities_with_headers.csv"))
