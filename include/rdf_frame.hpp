@@ -797,8 +797,8 @@ class DataFrame {
         std::vector<int64_t> counts(nch);
         check(rdf_filter_count(mv.data(), (int64_t)nch, counts.data()));
         std::vector<Column> result(columns_.size());
-        for (size_t base = 0; base < columns_.size(); base += 16) {  // up to 16 columns per launch
-            const size_t n = std::min<size_t>(16, columns_.size() - base);
+        for (size_t base = 0; base < columns_.size(); base += 256) {  // rdf_filter_columns takes up to 256 columns per call
+            const size_t n = std::min<size_t>(256, columns_.size() - base);
             std::vector<rdf_array> cv;
             std::vector<std::shared_ptr<Array>> outs;
             std::vector<rdf_out> ov;

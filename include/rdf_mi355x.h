@@ -177,7 +177,8 @@ rdf_status rdf_filter_count(const rdf_array* mask, int64_t nchunks, int64_t* cou
  * boundaries preserved, validity carried.  mask[i].length must equal col[i].length. */
 rdf_status rdf_filter(const rdf_array* col, const rdf_array* mask, int64_t nchunks, rdf_out* out);
 /* DataFrame::filter's per-column loop (src/dataframe.rs:183-187) as ONE pass: ranks are computed
- * once per tile and every column is compacted with them.  cols/outs laid out [c * nchunks + i]. */
+ * once per tile and every column is compacted with them.  cols/outs laid out [c * nchunks + i];
+ * 1..256 columns per call. */
 rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_array* mask,
                               int64_t nchunks, rdf_out* outs);
 /* Column::take (src/table.rs:218-241): gather over the virtual concatenation of the chunks

@@ -1329,7 +1329,7 @@ rdf_status rdf_filter_count(const rdf_array* mask, int64_t nchunks, int64_t* cou
 }
 
 rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_array* mask, int64_t nchunks, rdf_out* outs) {
-    if (ncols < 1 || ncols > kMaxFilterCols) return fail(RDF_INVALID_ARGUMENT, "filter: 1..%d columns per call", kMaxFilterCols);
+    if (ncols < 1 || ncols > 256) return fail(RDF_INVALID_ARGUMENT, "filter: 1..256 columns per call");
     int32_t mem = -1;
     RDF_TRY(filter_validate(cols, ncols, mask, nchunks, &mem));
     if (nchunks == 0) return RDF_OK;
@@ -1391,18 +1391,20 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
     HIP_TRY(hipMemcpyAsync(fp.tb.dev + fp.o_outs, ctx.pinned + fp.pin_off, sizeof(DevOutChunk) * nout, hipMemcpyHostToDevice, ctx.stream));
     fp.pin_off += (sizeof(DevOutChunk) * nout + 255) & ~(size_t)255;
 
-    FilterArgs fa;
-    memset(&fa, 0, sizeof fa);
-    fa.t = fp.mt;
-    fa.cols = fp.tb.dev_at<DevChunkCol>(fp.o_cols);
-    fa.outs = fp.tb.dev_at<DevOutChunk>(fp.o_outs);
-    fa.out_null_counts = d_nullc;
-    fa.tile_scan = fp.d_scan;
-    fa.ncols = ncols;
-    for (int k = 0; k < ncols; ++k) fa.esize[k] = dtype_size(cols[(int64_t)k * nchunks].dtype);
     {
         KernelTimer kt;
-        HIP_TRY(launch_compact(fa, ctx.stream));
+        for (int g = 0; g < ncols; g += kMaxFilterCols) {  // ranks are recomputed per group of columns (1 bit/row)
+            FilterArgs fa;
+            memset(&fa, 0, sizeof fa);
+            fa.t = fp.mt;
+            fa.cols = fp.tb.dev_at<DevChunkCol>(fp.o_cols) + (size_t)g * (size_t)nchunks;
+            fa.outs = fp.tb.dev_at<DevOutChunk>(fp.o_outs) + (size_t)g * (size_t)nchunks;
+            fa.out_null_counts = d_nullc + (size_t)g * (size_t)nchunks;
+            fa.tile_scan = fp.d_scan;
+            fa.ncols = ncols - g < kMaxFilterCols ? ncols - g : kMaxFilterCols;
+            for (int k = 0; k < fa.ncols; ++k) fa.esize[k] = dtype_size(cols[(int64_t)(g + k) * nchunks].dtype);
+            HIP_TRY(launch_compact(fa, ctx.stream));
+        }
         kt.stop();
     }
     RDF_TRY(pinned_reserve(fp.pin_off + 8 * nout + 256 + outr.small_bytes + 256));

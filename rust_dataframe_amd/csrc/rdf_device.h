@@ -16,7 +16,7 @@ constexpr int kMaxCols = 8;          // columns referenced by one program
 constexpr int kPreCols = 4;          // columns preloaded into registers per tile
 constexpr int kMaxTmp = 4;           // LDS spill slots for bushy expression trees
 constexpr int kMaxValues = RDF_MAX_VALUES;
-constexpr int kMaxFilterCols = 16;
+constexpr int kMaxFilterCols = 8;    // columns per compaction launch
 
 // One (column, chunk): an Arrow array resident in HBM.
 struct DevChunkCol {

@@ -212,14 +212,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const int64_t* count
     }
 }
 
-// Compaction of one column of one tile.  Ranks come from popcounts of the wave's keep words (scalar
-// prefix + v_mbcnt-style lane prefix): no shuffles, no atomics for the values.  Kept values are staged
-// in LDS at their rank, then written with coalesced stores at the tile's output offset.
+// Compaction of one column of one wave's 512 rows.  Ranks come from popcounts of the wave's keep words
+// (scalar prefix + lane prefix): no shuffles, no atomics for the values.  Kept values are staged in the
+// wave's PRIVATE 4 KiB LDS region at their rank and written out as one contiguous, coalesced run at
+// the wave's output offset — waves never wait for each other inside a column.
 template <typename T>
-__device__ __forceinline__ void compact_column(const DevChunkCol col, const DevOutChunk oc, int64_t rw, int64_t clen,
-                                               int64_t out_off, const uint64_t (&kw)[kWW], int wave_base, int total,
-                                               unsigned char* stage_raw, uint8_t* vstage, uint32_t& nulls) {
-    const int tid = threadIdx.x, lane = tid & 63;
+__device__ __forceinline__ void compact_wave(const DevChunkCol col, const DevOutChunk oc, int64_t rw, int64_t clen,
+                                             int64_t wave_out, const uint64_t (&kw)[kWW], int wave_cnt,
+                                             unsigned char* stage_raw, uint8_t* vstage, uint32_t& nulls) {
+    const int lane = threadIdx.x & 63;
     T* stage = (T*)stage_raw;
     const T* src = (const T*)col.values + col.offset + rw + lane;
     uint64_t vw[kWW];
@@ -229,7 +230,7 @@ __device__ __forceinline__ void compact_column(const DevChunkCol col, const DevO
 #pragma unroll
     for (int i = 0; i < kWW; ++i)
         if ((kw[i] >> lane) & 1) val[i] = __builtin_nontemporal_load(src + i * 64);
-    int wb = wave_base;
+    int wb = 0;
 #pragma unroll
     for (int i = 0; i < kWW; ++i) {
         if ((kw[i] >> lane) & 1) {
@@ -239,19 +240,17 @@ __device__ __forceinline__ void compact_column(const DevChunkCol col, const DevO
         }
         wb += __popcll(kw[i]);
     }
-    __syncthreads();
-    T* dst = (T*)oc.values + out_off;
-    for (int i = tid; i < total; i += kBlock) dst[i] = stage[i];
+    __builtin_amdgcn_wave_barrier();  // same-wave LDS ops are executed in order; this only pins the compiler
+    T* dst = (T*)oc.values + wave_out;
+    for (int i = lane; i < wave_cnt; i += 64) dst[i] = stage[i];
     if (hasv && oc.validity) {
-        // out bits [out_off, out_off+total): ballot 64 aligned positions at a time, OR into the
-        // (pre-zeroed) bitmap; boundary words are shared with neighbouring tiles, hence atomics.
-        const int64_t first = out_off & ~63ll;
-        const int64_t end = out_off + total;
-        const int wave = wave_id();
-        for (int64_t wpos = first + (int64_t)wave * 64; wpos < end; wpos += (kBlock / 64) * 64) {
+        // out bits [wave_out, wave_out+wave_cnt): ballot 64 aligned positions at a time, OR into the
+        // (pre-zeroed) bitmap; boundary words are shared with neighbouring waves/tiles, hence atomics.
+        const int64_t end = wave_out + wave_cnt;
+        for (int64_t wpos = wave_out & ~63ll; wpos < end; wpos += 64) {
             const int64_t pos = wpos + lane;
-            const bool inside = pos >= out_off && pos < end;
-            const bool bit = inside && vstage[pos - out_off];
+            const bool inside = pos >= wave_out && pos < end;
+            const bool bit = inside && vstage[pos - wave_out];
             const uint64_t word = __ballot(bit);
             const uint64_t inw = __ballot(inside);
             if (lane == 0) {
@@ -260,27 +259,32 @@ __device__ __forceinline__ void compact_column(const DevChunkCol col, const DevO
             }
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 }
 
+constexpr int kCompactCols = 8;  // columns per launch (the host loops over wider frames)
+
+// ES = common element size of all columns of the launch (8/4/2/1) or 0 for mixed sizes.
+template <int ES>
 __global__ __launch_bounds__(kBlock) void compact_kernel(const FilterArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char stage[kFilterTile * 8];
-    __shared__ uint8_t vstage[kFilterTile];
-    __shared__ int wave_cnt[kBlock / 64];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[kBlock / 64][kWW * 64 * 8];  // 4 KiB per wave
+    __shared__ uint8_t vstage[kBlock / 64][kWW * 64];
+    __shared__ int wave_cnt[2][kBlock / 64];
     const int lane = threadIdx.x & 63;
     const int wave = wave_id();
     // per-wave null counters per column, flushed once per (column, chunk) — not once per tile
-    uint32_t nullacc[kMaxFilterCols];
+    uint32_t nullacc[kCompactCols];
 #pragma unroll
-    for (int k = 0; k < kMaxFilterCols; ++k) nullacc[k] = 0;
+    for (int k = 0; k < kCompactCols; ++k) nullacc[k] = 0;
     int64_t cur_chunk = -1;
-    for (int64_t tile = blockIdx.x; tile < a.t.ntiles; tile += gridDim.x) {
+    int parity = 0;
+    for (int64_t tile = blockIdx.x; tile < a.t.ntiles; tile += gridDim.x, parity ^= 1) {
         int64_t c, r0, clen;
         locate_tile(a.t, tile, c, r0, clen);
         if (c != cur_chunk) {
             if (cur_chunk >= 0 && lane == 0) {
 #pragma unroll
-                for (int k = 0; k < kMaxFilterCols; ++k)
+                for (int k = 0; k < kCompactCols; ++k)
                     if (k < a.ncols && nullacc[k]) {
                         atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)k * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[k]);
                         nullacc[k] = 0;
@@ -294,34 +298,32 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const FilterArgs a) {
         int cnt = 0;
 #pragma unroll
         for (int i = 0; i < kWW; ++i) cnt += __popcll(kw[i]);
-        __syncthreads();  // previous tile's readers of wave_cnt / stage are done
-        if (lane == 0) wave_cnt[wave] = cnt;
-        __syncthreads();
-        int wave_base = 0, total = 0;
+        if (lane == 0) wave_cnt[parity][wave] = cnt;
+        __syncthreads();  // the only block barrier per tile (wave_cnt is double-buffered by tile parity)
+        int wave_base = 0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) wave_base += wave_cnt[w]; total += wave_cnt[w]; }
-        if (total > 0) {
-            const int64_t out_off = a.tile_scan[tile] - a.tile_scan[a.t.chunk_tile_start[c]];
+        for (int w = 0; w < kBlock / 64; ++w) if (w < wave) wave_base += wave_cnt[parity][w];
+        if (cnt > 0) {
+            const int64_t wave_out = a.tile_scan[tile] - a.tile_scan[a.t.chunk_tile_start[c]] + wave_base;
 #pragma unroll 1
             for (int k = 0; k < a.ncols; ++k) {
                 const DevChunkCol col = a.cols[(int64_t)k * a.t.nchunks + c];
                 const DevOutChunk oc = a.outs[(int64_t)k * a.t.nchunks + c];
                 uint32_t nn = 0;
-                switch (a.esize[k]) {
-                    case 8: compact_column<uint64_t>(col, oc, rw, clen, out_off, kw, wave_base, total, stage, vstage, nn); break;
-                    case 4: compact_column<uint32_t>(col, oc, rw, clen, out_off, kw, wave_base, total, stage, vstage, nn); break;
-                    case 2: compact_column<uint16_t>(col, oc, rw, clen, out_off, kw, wave_base, total, stage, vstage, nn); break;
-                    default: compact_column<uint8_t>(col, oc, rw, clen, out_off, kw, wave_base, total, stage, vstage, nn); break;
-                }
+                const int es = ES ? ES : a.esize[k];
+                if (es == 8) compact_wave<uint64_t>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+                else if (es == 4) compact_wave<uint32_t>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+                else if (es == 2) compact_wave<uint16_t>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+                else compact_wave<uint8_t>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
 #pragma unroll
-                for (int kk = 0; kk < kMaxFilterCols; ++kk)
+                for (int kk = 0; kk < kCompactCols; ++kk)
                     if (kk == k) nullacc[kk] += nn;
             }
         }
     }
     if (cur_chunk >= 0 && lane == 0) {
 #pragma unroll
-        for (int k = 0; k < kMaxFilterCols; ++k)
+        for (int k = 0; k < kCompactCols; ++k)
             if (k < a.ncols && nullacc[k])
                 atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)k * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[k]);
     }
@@ -470,7 +472,16 @@ hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, hipStrea
 }
 hipError_t launch_compact(const FilterArgs& a, hipStream_t s) {
     int64_t grid = a.t.ntiles < (int64_t)eval_grid_limit() ? a.t.ntiles : (int64_t)eval_grid_limit();
-    if (grid > 0) hipLaunchKernelGGL(compact_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    if (grid <= 0) return hipSuccess;
+    int es = a.esize[0];
+    for (int k = 1; k < a.ncols; ++k) if (a.esize[k] != es) es = 0;
+    switch (es) {
+        case 8: hipLaunchKernelGGL((compact_kernel<8>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((compact_kernel<4>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((compact_kernel<2>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((compact_kernel<1>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
+        default: hipLaunchKernelGGL((compact_kernel<0>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
+    }
     return hipGetLastError();
 }
 

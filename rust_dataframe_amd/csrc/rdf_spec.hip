@@ -223,15 +223,13 @@ template <> struct AggT<RDF_U64> {
 };
 template <> struct AggT<RDF_BOOL> : AggT<RDF_U64> {};
 
-// spread the low 32 bits of x to the even bit positions of a u64
-__device__ __forceinline__ uint64_t spread32(uint64_t x) {
-    x &= 0xFFFFFFFFull;
-    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-    x = (x | (x << 2)) & 0x3333333333333333ull;
-    x = (x | (x << 1)) & 0x5555555555555555ull;
-    return x;
+// Lane l of a 16-byte-load wave holds rows 2l and 2l+1, so the two ballots b0 (even rows) and b1 (odd
+// rows) must be interleaved into Arrow's row-ordered bitmap words.  Every lane j picks the bit that
+// belongs at output position j and the wave ballots again: word `half` (rows 64*half .. +63) in ~5 VALU
+// instructions for the whole wave.
+__device__ __forceinline__ uint64_t interleave_word(uint64_t b0, uint64_t b1, int half, int lane) {
+    const uint64_t src = (lane & 1) ? b1 : b0;
+    return __ballot((src >> (32 * half + (lane >> 1))) & 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,31 +358,23 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
                 const uint32_t v2 = (vm >> (2 * u)) & 3u;
                 const uint64_t x0 = (v2 & 1u) ? out[2 * u] : 0, x1 = (v2 & 2u) ? out[2 * u + 1] : 0;  // null slots hold 0
                 const uint64_t in0 = __ballot(in2 & 1u), in1 = __ballot(in2 & 2u);
+                const bool upper = (in0 >> 32) != 0;  // the wave's second 64 rows exist
+                uint64_t* const ow = (uint64_t*)a.out.values + ((wbase + u * 64) >> 5);
                 if constexpr (V0::dt == RDF_BOOL) {
                     const uint64_t b0 = __ballot(x0 & 1), b1 = __ballot(x1 & 1);
-                    if (lane == 0 && in0) {
-                        uint64_t* ov = (uint64_t*)a.out.values + ((wbase + u * 64) >> 5);
-                        ov[0] = spread32(b0) | (spread32(b1) << 1);
-                        if (in0 >> 32) ov[1] = spread32(b0 >> 32) | (spread32(b1 >> 32) << 1);
-                    }
+                    const uint64_t w0 = interleave_word(b0, b1, 0, lane), w1 = interleave_word(b0, b1, 1, lane);
+                    if (lane == 0 && in0) { ow[0] = w0; if (upper) ow[1] = w1; }
                 } else {
                     if (in2 == 3u) { uvec2 t; t.x = x0; t.y = x1; ((uvec2*)a.out.values)[i] = t; }
                     else if (in2) ((uint64_t*)a.out.values)[2 * i] = x0;
                 }
                 const uint64_t vb0 = __ballot(v2 & 1u), vb1 = __ballot(v2 & 2u);
-                if (lane == 0 && in0) {
-                    const uint64_t w0 = spread32(vb0) | (spread32(vb1) << 1);
-                    const uint64_t i0 = spread32(in0) | (spread32(in1) << 1);
-                    nulls += (uint32_t)__popcll(i0 & ~w0);
-                    uint64_t* ob = a.out.validity ? (uint64_t*)a.out.validity + ((wbase + u * 64) >> 5) : nullptr;
-                    if (ob) ob[0] = w0;
-                    if (in0 >> 32) {
-                        const uint64_t w1 = spread32(vb0 >> 32) | (spread32(vb1 >> 32) << 1);
-                        const uint64_t i1 = spread32(in0 >> 32) | (spread32(in1 >> 32) << 1);
-                        nulls += (uint32_t)__popcll(i1 & ~w1);
-                        if (ob) ob[1] = w1;
-                    }
+                if (a.out.validity) {
+                    const uint64_t w0 = interleave_word(vb0, vb1, 0, lane), w1 = interleave_word(vb0, vb1, 1, lane);
+                    uint64_t* const ob = (uint64_t*)a.out.validity + ((wbase + u * 64) >> 5);
+                    if (lane == 0 && in0) { ob[0] = w0; if (upper) ob[1] = w1; }
                 }
+                if (lane == 0) nulls += (uint32_t)(__popcll(in0 & ~vb0) + __popcll(in1 & ~vb1));
             }
         }
     }
