@@ -186,6 +186,19 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
  * array; null index -> null; out of range -> RDF_COMPUTE_ERROR.  out: ONE chunk (B4 in SURVEY.md). */
 rdf_status rdf_take(const rdf_array* chunks, int64_t nchunks, const rdf_array* indices, rdf_out* out);
 
+/* ------------------------------------------------------------------ group-by */
+
+/* Transformation::GroupAggregate(groups, [Sum, Count]) for ONE integer key column — planned by
+ * Dataset::try_aggregate (src/expression.rs:114-221) but not executed by the reference
+ * (src/evaluation.rs:73 panics), so the semantics are SQL's: NULL keys form one group, NULL values
+ * are skipped, a group's count is its number of non-null values (of rows when values == NULL).
+ * Outputs are ONE chunk each, in unspecified group order: keys (key dtype), sums (Float64 for float
+ * values, wrapping Int64 otherwise), counts (Int64); capacity >= max_groups + 2.  More than
+ * max_groups distinct keys -> RDF_MEMORY_ERROR.  f64 sums are accumulated with hardware atomics:
+ * the rounding order is not deterministic (within 1e-6 relative of any sequential order). */
+rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,
+                           rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts);
+
 /* ------------------------------------------------------------------ fused batch loop */
 
 typedef enum {

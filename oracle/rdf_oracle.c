@@ -912,6 +912,85 @@ rdf_status ora_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t 
     return st;
 }
 
+/* ------------------------------------------------------------------ group-by
+ * Transformation::GroupAggregate has a schema (Dataset::try_aggregate, src/expression.rs:114-221) but no
+ * execution in the reference (src/evaluation.rs:73: panic!("aggregations not supported")): PARITY
+ * UNPINNED BY THE REFERENCE.  Restated from SQL semantics with a sequential scan and a chained hash
+ * map: NULL keys form one group, NULL values are skipped, groups are emitted in first-seen order. */
+static int64_t key_at(const rdf_array* a, int64_t i) {
+    int64_t k = a->offset + i;
+    switch (a->dtype) {
+        case RDF_I8: return ((const int8_t*)a->values)[k];
+        case RDF_I16: return ((const int16_t*)a->values)[k];
+        case RDF_I32: return ((const int32_t*)a->values)[k];
+        case RDF_U8: return ((const uint8_t*)a->values)[k];
+        case RDF_U16: return ((const uint16_t*)a->values)[k];
+        case RDF_U32: return ((const uint32_t*)a->values)[k];
+        default: return ((const int64_t*)a->values)[k];
+    }
+}
+rdf_status ora_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,
+                           rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts) {
+    if (nchunks < 1) FAIL(RDF_INVALID_ARGUMENT, "groupby: a column has at least one chunk");
+    int kdt = keys[0].dtype, vdt = values ? values[0].dtype : -1;
+    if (!(kdt >= RDF_I8 && kdt <= RDF_U64)) FAIL(RDF_INVALID_ARGUMENT, "groupby: integer key column required");
+    if (values && !is_numeric(vdt)) FAIL(RDF_INVALID_ARGUMENT, "groupby: numeric value column required");
+    int fsum = values && is_float(vdt);
+    int64_t cap = 1024;
+    while (cap < 4 * (max_groups + 2)) cap <<= 1;
+    int64_t* slot_of = (int64_t*)malloc(sizeof(int64_t) * (size_t)cap);   /* hash slot -> group index or -1 */
+    int64_t* gkey = (int64_t*)malloc(sizeof(int64_t) * (size_t)(max_groups + 2));
+    int* gnull = (int*)calloc((size_t)(max_groups + 2), sizeof(int));
+    double* gsumf = (double*)calloc((size_t)(max_groups + 2), sizeof(double));
+    uint64_t* gsumi = (uint64_t*)calloc((size_t)(max_groups + 2), sizeof(uint64_t));
+    int64_t* gcnt = (int64_t*)calloc((size_t)(max_groups + 2), sizeof(int64_t));
+    if (!slot_of || !gkey || !gnull || !gsumf || !gsumi || !gcnt) FAIL(RDF_MEMORY_ERROR, "out of memory");
+    for (int64_t i = 0; i < cap; i++) slot_of[i] = -1;
+    int64_t ng = 0, null_group = -1, distinct = 0;
+    rdf_status st = RDF_OK;
+    for (int64_t c = 0; c < nchunks && st == RDF_OK; c++) {
+        if (values && values[c].length != keys[c].length) { st = RDF_COMPUTE_ERROR; snprintf(g_err, sizeof g_err, "groupby: key and value chunks differ in length"); break; }
+        for (int64_t i = 0; i < keys[c].length; i++) {
+            int64_t g;
+            if (!arr_valid(&keys[c], i)) {
+                if (null_group < 0) { null_group = ng; gnull[ng] = 1; gkey[ng] = 0; ng++; }
+                g = null_group;
+            } else {
+                int64_t k = key_at(&keys[c], i);
+                uint64_t h = (uint64_t)k * 0x9E3779B97F4A7C15ULL;
+                int64_t s = (int64_t)((h ^ (h >> 29)) & (uint64_t)(cap - 1));
+                while (slot_of[s] >= 0 && gkey[slot_of[s]] != k) s = (s + 1) & (cap - 1);
+                if (slot_of[s] < 0) {
+                    if (++distinct > max_groups + 1) { st = RDF_MEMORY_ERROR; snprintf(g_err, sizeof g_err, "groupby: more than max_groups distinct keys"); break; }
+                    slot_of[s] = ng; gkey[ng] = k; ng++;
+                }
+                g = slot_of[s];
+            }
+            if (!values) { gcnt[g]++; continue; }
+            if (!arr_valid(&values[c], i)) continue;
+            if (fsum) gsumf[g] += arr_f64(&values[c], i);
+            else gsumi[g] += (uint64_t)key_at(&values[c], i);
+            gcnt[g]++;
+        }
+    }
+    if (st == RDF_OK && (out_keys->capacity < ng || out_sums->capacity < ng || out_counts->capacity < ng)) { st = RDF_MEMORY_ERROR; snprintf(g_err, sizeof g_err, "output capacity too small"); }
+    if (st == RDF_OK && null_group >= 0 && !out_keys->validity) { st = RDF_INVALID_ARGUMENT; snprintf(g_err, sizeof g_err, "output validity buffer required"); }
+    if (st == RDF_OK) {
+        out_begin(out_keys, ng); out_begin(out_sums, ng); out_begin(out_counts, ng);
+        int es = dtype_size(kdt);
+        for (int64_t g = 0; g < ng; g++) {
+            uint64_t kv = (uint64_t)gkey[g];
+            memcpy((char*)out_keys->values + g * es, &kv, (size_t)es);
+            if (gnull[g]) out_null(out_keys, g);
+            if (fsum) ((double*)out_sums->values)[g] = gsumf[g];
+            else ((int64_t*)out_sums->values)[g] = (int64_t)gsumi[g];
+            ((int64_t*)out_counts->values)[g] = gcnt[g];
+        }
+    }
+    free(slot_of); free(gkey); free(gnull); free(gsumf); free(gsumi); free(gcnt);
+    return st;
+}
+
 /* ------------------------------------------------------------------ synthetic data
  * Counter-based generator shared (by restating the same few lines) with the device fill kernels:
  * SplitMix64 finaliser over (seed, column_id, row). */

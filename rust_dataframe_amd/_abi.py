@@ -275,8 +275,8 @@ class Api:
         self._err = getattr(lib, prefix + "last_error")
         self._err.restype = C.c_char_p
         for name in ("binary", "unary", "cast", "sum", "min", "max", "count", "avg", "predicate", "filter_count",
-                     "filter", "filter_columns", "take", "pipeline", "fill_uniform_f64", "fill_uniform_i64",
-                     "fill_validity"):
+                     "filter", "filter_columns", "take", "pipeline", "groupby_sum", "fill_uniform_f64",
+                     "fill_uniform_i64", "fill_validity"):
             fn = getattr(lib, prefix + name)
             fn.restype = C.c_int
         getattr(lib, prefix + "fill_uniform_f64").argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, C.c_double, C.c_double]
@@ -436,6 +436,24 @@ class Api:
         idx = (rdf_array * 1)(indices.c_struct())
         self._check(self._fn("take")(_flat([chunks], n), C.c_int64(n), idx, carr))
         return self._finish([out], carr)[0]
+
+    # ---- group-by (Transformation::GroupAggregate with one integer key; SQL semantics)
+    def groupby_sum(self, keys: Sequence, values: Optional[Sequence], max_groups: int, outs=None):
+        """-> (keys, sums, counts) as three one-chunk arrays in unspecified group order."""
+        n = len(keys)
+        kdt = keys[0].dtype
+        sdt = F64 if values is not None and values[0].dtype in (F32, F64) else I64
+        if outs is None:
+            cap = max_groups + 2
+            outs = (HostArray.empty_out(kdt, cap, any(k.validity is not None for k in keys)),
+                    HostArray.empty_out(sdt, cap, False), HostArray.empty_out(I64, cap, False))
+        carr = [(rdf_out * 1)(o.out_struct()) for o in outs]
+        cv = _flat([values], n) if values is not None else None
+        self._check(self._fn("groupby_sum")(_flat([keys], n), cv, C.c_int64(n), C.c_int64(max_groups), carr[0], carr[1], carr[2]))
+        for o, cc in zip(outs, carr):
+            o.length = cc[0].length
+            o.null_count = cc[0].null_count
+        return outs
 
     # ---- fused batch loop
     def pipeline(self, expr: Expr, cols: Sequence[Sequence], value_roots: Sequence[int], filter_root: int = -1,

@@ -7,6 +7,7 @@
 // RDF_MEM_DEVICE arrays are used in place.  There is no CPU compute path in this file.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1512,6 +1513,152 @@ rdf_status rdf_take(const rdf_array* chunks, int64_t nchunks, const rdf_array* i
     if (mem == RDF_MEM_HOST) RDF_TRY(outr.download(pin_off + 256));
     out->length = n;
     memcpy(&out->null_count, pin + 16, 8);
+    return RDF_OK;
+}
+
+// ---------------------------------------------------------------- group-by
+
+rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,
+                           rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts) {
+    if (nchunks < 1 || !keys) return fail(RDF_INVALID_ARGUMENT, "groupby: a column has at least one chunk");
+    if (!out_keys || !out_sums || !out_counts) return fail(RDF_INVALID_ARGUMENT, "groupby: null output");
+    if (max_groups < 1) return fail(RDF_INVALID_ARGUMENT, "groupby: max_groups must be positive");
+    int32_t mem = -1;
+    RDF_TRY(check_mem(keys, nchunks, &mem));
+    if (values) RDF_TRY(check_mem(values, nchunks, &mem));
+    RDF_TRY(check_out_mem(out_keys, 1, mem));
+    RDF_TRY(check_out_mem(out_sums, 1, mem));
+    RDF_TRY(check_out_mem(out_counts, 1, mem));
+    const int kdt = keys[0].dtype;
+    if (!(kdt >= RDF_I8 && kdt <= RDF_U64)) return fail(RDF_INVALID_ARGUMENT, "groupby: integer key column required");
+    const int vdt = values ? values[0].dtype : -1;
+    if (values && !is_numeric(vdt)) return fail(RDF_INVALID_ARGUMENT, "groupby: numeric value column required");
+    const int sdt = values && is_float(vdt) ? RDF_F64 : RDF_I64;
+    if (out_keys->dtype != kdt || out_sums->dtype != sdt || out_counts->dtype != RDF_I64)
+        return fail(RDF_INVALID_ARGUMENT, "groupby: outputs must be (key dtype, %s, Int64)", sdt == RDF_F64 ? "Float64" : "Int64");
+    bool null_keys = false;
+    std::vector<int64_t> clen((size_t)nchunks), tile_start((size_t)nchunks + 1, 0);
+    for (int64_t c = 0; c < nchunks; ++c) {
+        if (keys[c].dtype != kdt || (values && values[c].dtype != vdt)) return fail(RDF_INVALID_ARGUMENT, "groupby: chunks differ in dtype");
+        if (values && values[c].length != keys[c].length) return fail(RDF_COMPUTE_ERROR, "groupby: key and value chunks differ in length");
+        null_keys |= keys[c].validity != nullptr;
+        clen[(size_t)c] = keys[c].length;
+        tile_start[(size_t)c + 1] = tile_start[(size_t)c] + (keys[c].length + kEvalTile - 1) / kEvalTile;
+    }
+    if (null_keys && !out_keys->validity) return fail(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    const int64_t cap_needed = std::min<int64_t>(max_groups + 2, tile_start[(size_t)nchunks] * kEvalTile + 2);
+    if (out_keys->capacity < cap_needed || out_sums->capacity < cap_needed || out_counts->capacity < cap_needed)
+        return fail(RDF_MEMORY_ERROR, "output capacity too small (need max_groups + 2)");
+    RDF_TRY(ensure_ready());
+    Ctx& ctx = g_ctx;
+    arena_begin();
+    size_t pin_off = 0, used = 0;
+    InputStager in;
+    for (int64_t c = 0; c < nchunks; ++c) in.add(&keys[c]);
+    if (values) for (int64_t c = 0; c < nchunks; ++c) in.add(&values[c]);
+    RDF_TRY(in.finish(pin_off, &used));
+    pin_off += (used + 255) & ~(size_t)255;
+    TableBuilder tb;
+    const size_t o_k = tb.reserve(sizeof(DevChunkCol) * (size_t)nchunks);
+    const size_t o_v = tb.reserve(sizeof(DevChunkCol) * (size_t)nchunks);
+    const size_t o_ts = tb.reserve(sizeof(int64_t) * tile_start.size());
+    const size_t o_len = tb.reserve(sizeof(int64_t) * clen.size());
+    memcpy(tb.at<char>(o_k), in.dev.data(), sizeof(DevChunkCol) * (size_t)nchunks);
+    if (values) memcpy(tb.at<char>(o_v), in.dev.data() + nchunks, sizeof(DevChunkCol) * (size_t)nchunks);
+    memcpy(tb.at<char>(o_ts), tile_start.data(), sizeof(int64_t) * tile_start.size());
+    memcpy(tb.at<char>(o_len), clen.data(), sizeof(int64_t) * clen.size());
+    RDF_TRY(tb.alloc());
+    RDF_TRY(tb.upload(pin_off));
+    pin_off += (tb.host.size() + 255) & ~(size_t)255;
+
+    int64_t capacity = 1024;
+    while (capacity < 2 * max_groups) capacity <<= 1;
+    void* p = nullptr;
+    const size_t tab_bytes = sizeof(uint64_t) * (size_t)(3 * capacity + 4) + 64;
+    RDF_TRY(arena_alloc(tab_bytes, &p));
+    GroupTable t;
+    t.keys = (unsigned long long*)p;
+    t.sums = t.keys + capacity;
+    t.counts = t.sums + capacity + 2;
+    t.special = (unsigned int*)(t.counts + capacity + 2);
+    t.ngroups = t.special + 2;
+    t.flags = (uint32_t*)(t.special + 4);
+    unsigned int* cursor = t.special + 6;
+    t.capacity = capacity;
+    // keys <- i64::MIN pattern (0x80 00 .. per 8 bytes): fill via a 64-bit pattern memset
+    // every slot key <- i64::MIN (the free marker): the fill kernel with a span of 1 writes the constant
+    HIP_TRY(launch_fill_i64((int64_t*)t.keys, capacity, 0, 0, 0, INT64_MIN, INT64_MIN + 1, ctx.stream));
+    HIP_TRY(hipMemsetAsync(t.sums, 0, sizeof(uint64_t) * (size_t)(2 * capacity + 4) + 64, ctx.stream));
+
+    GroupByArgs ga;
+    memset(&ga, 0, sizeof ga);
+    ga.keys = tb.dev_at<DevChunkCol>(o_k);
+    ga.values = tb.dev_at<DevChunkCol>(o_v);
+    ga.chunk_tile_start = tb.dev_at<int64_t>(o_ts);
+    ga.chunk_len = tb.dev_at<int64_t>(o_len);
+    ga.nchunks = nchunks;
+    ga.ntiles = tile_start[(size_t)nchunks];
+    ga.key_dtype = kdt;
+    ga.value_dtype = vdt;
+    ga.t = t;
+    ga.max_groups = max_groups;
+    {
+        KernelTimer kt;
+        HIP_TRY(launch_groupby_build(ga, ctx.stream));
+        kt.stop();
+    }
+    // group count + flags
+    RDF_TRY(pinned_reserve(pin_off + 64));
+    unsigned int* pin = (unsigned int*)(ctx.pinned + pin_off);
+    HIP_TRY(hipMemcpyAsync(pin, t.special, 32, hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    const int64_t ngroups = (int64_t)pin[2] + (pin[0] ? 1 : 0) + (pin[1] ? 1 : 0);
+    if ((pin[4] & 4u) || (int64_t)pin[2] > max_groups) return fail(RDF_MEMORY_ERROR, "groupby: more than max_groups (%lld) distinct keys", (long long)max_groups);
+    pin_off += 256;
+
+    // outputs
+    const size_t kes = (size_t)dtype_size(kdt);
+    Region outr;
+    int ik = -1, ikv = -1, is = -1, ic = -1;
+    GroupEmitArgs ea;
+    memset(&ea, 0, sizeof ea);
+    ea.t = t;
+    ea.cursor = cursor;
+    ea.key_dtype = kdt;
+    if (mem == RDF_MEM_HOST) {
+        ik = outr.add(out_keys->values, (size_t)ngroups * kes);
+        if (out_keys->validity) ikv = outr.add(out_keys->validity, (size_t)((ngroups + 7) / 8));
+        is = outr.add(out_sums->values, (size_t)ngroups * 8);
+        ic = outr.add(out_counts->values, (size_t)ngroups * 8);
+        RDF_TRY(outr.layout());
+        ea.out_keys = outr.ptr(ik);
+        ea.out_keys_validity = ikv >= 0 ? (uint8_t*)outr.ptr(ikv) : nullptr;
+        ea.out_sums = outr.ptr(is);
+        ea.out_counts = (int64_t*)outr.ptr(ic);
+    } else {
+        ea.out_keys = out_keys->values;
+        ea.out_keys_validity = out_keys->validity;
+        ea.out_sums = out_sums->values;
+        ea.out_counts = (int64_t*)out_counts->values;
+    }
+    if (ea.out_keys_validity) HIP_TRY(hipMemsetAsync(ea.out_keys_validity, 0, (size_t)((ngroups + 63) / 64 * 8), ctx.stream));
+    if (ngroups > 0) HIP_TRY(launch_groupby_emit(ea, ctx.stream));
+    if (mem == RDF_MEM_HOST) {
+        RDF_TRY(pinned_reserve(pin_off + outr.small_bytes + 256));
+        RDF_TRY(outr.download(pin_off));
+    } else HIP_TRY(hipStreamSynchronize(ctx.stream));
+    out_keys->length = out_sums->length = out_counts->length = ngroups;
+    out_keys->null_count = pin[1] ? 1 : 0;
+    out_sums->null_count = out_counts->null_count = 0;
+    if (out_sums->validity && ngroups > 0) {
+        if (mem == RDF_MEM_HOST) memset(out_sums->validity, 0xFF, (size_t)((ngroups + 7) / 8));
+        else HIP_TRY(hipMemsetAsync(out_sums->validity, 0xFF, (size_t)((ngroups + 7) / 8), ctx.stream));
+    }
+    if (out_counts->validity && ngroups > 0) {
+        if (mem == RDF_MEM_HOST) memset(out_counts->validity, 0xFF, (size_t)((ngroups + 7) / 8));
+        else HIP_TRY(hipMemsetAsync(out_counts->validity, 0xFF, (size_t)((ngroups + 7) / 8), ctx.stream));
+    }
+    if (mem == RDF_MEM_DEVICE) HIP_TRY(hipStreamSynchronize(ctx.stream));
     return RDF_OK;
 }
 

@@ -117,6 +117,35 @@ struct FilterArgs {
     int32_t            esize[kMaxFilterCols];
 };
 
+// Hash GROUP BY key -> {sum(value), count(value)}: open addressing, linear probing, 64-bit keys.
+struct GroupTable {
+    unsigned long long* keys;   // [capacity] slot keys, kGroupEmpty = free
+    unsigned long long* sums;   // [capacity + 2] f64 bits or wrapping i64; +0/+1 = the sentinel-key and null-key groups
+    unsigned long long* counts; // [capacity + 2]
+    unsigned int*       special;   // [2] 1 if the sentinel-key / null-key group exists
+    unsigned int*       ngroups;   // distinct keys inserted in the table proper
+    uint32_t*           flags;     // bit 2: table overflow
+    int64_t             capacity;  // power of two
+};
+constexpr unsigned long long kGroupEmpty = 0x8000000000000000ull;  // i64::MIN doubles as the free marker
+struct GroupByArgs {
+    const DevChunkCol* keys;             // [nchunks]
+    const DevChunkCol* values;           // [nchunks] (values pointer null = count rows only)
+    const int64_t*     chunk_tile_start; // [nchunks + 1], tiles of kEvalTile rows
+    const int64_t*     chunk_len;
+    int64_t            nchunks, ntiles;
+    int32_t            key_dtype, value_dtype;  // value_dtype < 0: no values
+    GroupTable         t;
+    int64_t            max_groups;
+};
+struct GroupEmitArgs {
+    GroupTable t;
+    void*      out_keys;  uint8_t* out_keys_validity;
+    void*      out_sums;  int64_t* out_counts;
+    unsigned int* cursor;   // running output index
+    int32_t    key_dtype;
+};
+
 struct TakeArgs {
     const DevChunkCol* chunks;           // [nchunks]
     const int64_t*     chunk_row_start;  // [nchunks + 1]
@@ -142,6 +171,8 @@ hipError_t launch_mask_count(const MaskTables& t, int64_t* tile_counts, hipStrea
 hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, hipStream_t s);
 hipError_t launch_compact(const FilterArgs& a, hipStream_t s);
 hipError_t launch_take(const TakeArgs& a, hipStream_t s);
+hipError_t launch_groupby_build(const GroupByArgs& a, hipStream_t s);
+hipError_t launch_groupby_emit(const GroupEmitArgs& a, hipStream_t s);
 hipError_t launch_fill_f64(double* p, int64_t n, uint64_t seed, uint64_t col, int64_t first_row, double lo, double hi, hipStream_t s);
 hipError_t launch_fill_i64(int64_t* p, int64_t n, uint64_t seed, uint64_t col, int64_t first_row, int64_t lo, int64_t hi, hipStream_t s);
 hipError_t launch_fill_validity(uint8_t* p, int64_t nbits, uint64_t seed, uint64_t col, int64_t first_row, double null_fraction, hipStream_t s);

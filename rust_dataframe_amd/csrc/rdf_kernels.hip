@@ -376,6 +376,107 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const TakeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// hash GROUP BY (Transformation::GroupAggregate, planned by Dataset::try_aggregate src/expression.rs:114-221,
+// never executed by the reference: src/evaluation.rs:73 panics).  SQL semantics: NULL keys form one
+// group, NULL values are skipped.  One global open-addressing table in HBM (it lives in L2/Infinity
+// Cache for the 1e6-group configuration), 64-bit CAS to claim a slot, hardware f64 / u64 atomic adds.
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ int64_t load_key(const DevChunkCol& k, int dt, int64_t row) {
+    const int64_t e = k.offset + row;
+    switch (dt) {
+        case RDF_I32: return ((const int32_t*)k.values)[e];
+        case RDF_U32: return (int64_t)((const uint32_t*)k.values)[e];
+        case RDF_I16: return ((const int16_t*)k.values)[e];
+        case RDF_U16: return (int64_t)((const uint16_t*)k.values)[e];
+        case RDF_I8: return ((const int8_t*)k.values)[e];
+        case RDF_U8: return (int64_t)((const uint8_t*)k.values)[e];
+        default: return ((const int64_t*)k.values)[e];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void groupby_build_kernel(const GroupByArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id();
+    const uint64_t mask = (uint64_t)a.t.capacity - 1;
+    uint32_t err = 0;
+    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int64_t c = a.nchunks == 1 ? 0 : find_chunk(a.chunk_tile_start, a.nchunks, tile);
+        const int64_t r0 = (tile - a.chunk_tile_start[c]) * kEvalTile;
+        const int64_t clen = a.chunk_len[c];
+        const DevChunkCol kc = a.keys[c];
+        const DevChunkCol vc = a.value_dtype >= 0 ? a.values[c] : DevChunkCol{nullptr, nullptr, 0};
+        const int64_t rw = r0 + (int64_t)wave * (kVPT * 64);
+        uint64_t kvw[kVPT], vvw[kVPT];
+        if (kc.validity) load_windows<kVPT>(kc.validity, kc.offset + rw, clen - rw, kvw);
+        if (vc.validity) load_windows<kVPT>(vc.validity, vc.offset + rw, clen - rw, vvw);
+#pragma unroll
+        for (int j = 0; j < kVPT; ++j) {
+            const int64_t row = rw + j * 64 + lane;
+            if (row >= clen) continue;
+            const bool kvalid = !kc.validity || ((kvw[j] >> lane) & 1);
+            const bool vvalid = a.value_dtype < 0 || !vc.validity || ((vvw[j] >> lane) & 1);
+            const uint64_t key = (uint64_t)load_key(kc, a.key_dtype, row);
+            int64_t slot;
+            if (!kvalid) { slot = a.t.capacity + 1; a.t.special[1] = 1; }
+            else if (key == kGroupEmpty) { slot = a.t.capacity; a.t.special[0] = 1; }
+            else {
+                uint64_t s = mix64(key) & mask;
+                int64_t probes = 0;
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&a.t.keys[s], kGroupEmpty, (unsigned long long)key);
+                    if (old == kGroupEmpty) { atomicAdd(a.t.ngroups, 1u); break; }
+                    if (old == key) break;
+                    s = (s + 1) & mask;
+                    if (++probes > a.t.capacity) { err |= 4u; break; }
+                }
+                slot = (int64_t)s;
+            }
+            if (err) break;
+            if (vvalid) {
+                if (a.value_dtype == RDF_F64) unsafeAtomicAdd((double*)&a.t.sums[slot], ((const double*)vc.values)[vc.offset + row]);
+                else if (a.value_dtype == RDF_F32) unsafeAtomicAdd((double*)&a.t.sums[slot], (double)((const float*)vc.values)[vc.offset + row]);
+                else if (a.value_dtype >= 0) atomicAdd(&a.t.sums[slot], (unsigned long long)load_key(vc, a.value_dtype, row));
+                atomicAdd(&a.t.counts[slot], 1ull);
+            }
+        }
+    }
+    if (err) atomicOr(a.t.flags, err);
+}
+
+__device__ __forceinline__ void store_key(void* out, int dt, unsigned idx, uint64_t key) {
+    switch (dt) {
+        case RDF_I32: case RDF_U32: ((uint32_t*)out)[idx] = (uint32_t)key; break;
+        case RDF_I16: case RDF_U16: ((uint16_t*)out)[idx] = (uint16_t)key; break;
+        case RDF_I8: case RDF_U8: ((uint8_t*)out)[idx] = (uint8_t)key; break;
+        default: ((uint64_t*)out)[idx] = key; break;
+    }
+}
+
+// Occupied slots -> dense outputs (order = claim order of the output cursor, i.e. unspecified).
+__global__ __launch_bounds__(kBlock) void groupby_emit_kernel(const GroupEmitArgs a) {
+    const int64_t n = a.t.capacity + 2;
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n; s += (int64_t)gridDim.x * kBlock) {
+        bool occ; uint64_t key = 0; bool knull = false;
+        if (s < a.t.capacity) { key = a.t.keys[s]; occ = key != kGroupEmpty; }
+        else if (s == a.t.capacity) { key = kGroupEmpty; occ = a.t.special[0] != 0; }
+        else { knull = true; occ = a.t.special[1] != 0; }
+        if (!occ) continue;
+        const unsigned idx = atomicAdd(a.cursor, 1u);
+        store_key(a.out_keys, a.key_dtype, idx, key);
+        if (a.out_keys_validity) {
+            if (!knull) atomicOr((unsigned int*)a.out_keys_validity + (idx >> 5), 1u << (idx & 31));
+        }
+        ((uint64_t*)a.out_sums)[idx] = a.t.sums[s];
+        a.out_counts[idx] = (int64_t)a.t.counts[s];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // synthetic data: SplitMix64 finaliser over (seed, column, row) — restated identically in the oracle.
 
 __device__ __forceinline__ uint64_t hash64(uint64_t seed, uint64_t col, uint64_t row) {
@@ -501,6 +602,18 @@ hipError_t launch_take(const TakeArgs& a, hipStream_t s) {
         case 2: launch_take_t<uint16_t>(a, (int)grid, s); break;
         default: launch_take_t<uint8_t>(a, (int)grid, s); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_groupby_build(const GroupByArgs& a, hipStream_t s) {
+    int64_t grid = a.ntiles < (int64_t)eval_grid_limit() ? a.ntiles : (int64_t)eval_grid_limit();
+    if (grid > 0) hipLaunchKernelGGL(groupby_build_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_groupby_emit(const GroupEmitArgs& a, hipStream_t s) {
+    int64_t grid = (a.t.capacity + 2 + kBlock - 1) / kBlock;
+    if (grid > eval_grid_limit()) grid = eval_grid_limit();
+    hipLaunchKernelGGL(groupby_emit_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

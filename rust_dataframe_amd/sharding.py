@@ -102,3 +102,63 @@ def all_combine(local: Sequence[AggResult], device=None) -> List[AggResult]:
             parts.append(AggResult(s, a, b, int(is_[r][5 * v + 3]), bool(is_[r][5 * v + 4]), p.dtype))
         out.append(combine(parts))
     return out
+
+
+# ---------------------------------------------------------------- group-by across ranks (the one real exchange)
+def group_owner(keys, world: int):
+    """Owning rank of each group key: a multiplicative hash of the key bits, mod world."""
+    import numpy as np
+    k = np.asarray(keys).astype(np.int64).view(np.uint64)
+    h = (k * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(33)
+    return (h % np.uint64(world)).astype(np.int64)
+
+
+def exchange_groups(keys, sums, counts, device=None):
+    """all-to-all(v) of locally pre-aggregated groups: every (key, sum, count) partial goes to
+    rank hash(key) % world, so each rank ends up with ALL partials of the keys it owns and merges them
+    locally (a second group-by).  Two collectives: the split sizes, then one packed payload.
+    Inputs / outputs: numpy arrays (keys int64, sums float64, counts int64)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return keys, sums, counts
+    world = dist.get_world_size()
+    owner = group_owner(keys, world)
+    order = np.argsort(owner, kind="stable")
+    send_counts = np.bincount(owner, minlength=world).astype(np.int64)
+    payload = np.stack([np.asarray(keys, dtype=np.int64)[order], np.asarray(sums, dtype=np.float64)[order].view(np.int64),
+                        np.asarray(counts, dtype=np.int64)[order]], axis=1)          # [n, 3] int64 words
+    t_send_counts = torch.from_numpy(send_counts)
+    t_recv_counts = torch.zeros(world, dtype=torch.int64)
+    if device is not None:
+        t_send_counts, t_recv_counts = t_send_counts.to(device), t_recv_counts.to(device)
+    dist.all_to_all_single(t_recv_counts, t_send_counts)
+    recv_counts = t_recv_counts.cpu().numpy()
+    t_send = torch.from_numpy(np.ascontiguousarray(payload))
+    t_recv = torch.zeros((int(recv_counts.sum()), 3), dtype=torch.int64)
+    if device is not None:
+        t_send, t_recv = t_send.to(device), t_recv.to(device)
+    dist.all_to_all_single(t_recv, t_send, output_split_sizes=[int(x) for x in recv_counts],
+                           input_split_sizes=[int(x) for x in send_counts])
+    r = t_recv.cpu().numpy()
+    return r[:, 0].copy(), r[:, 1].copy().view(np.float64), r[:, 2].copy()
+
+
+def distributed_groupby_sum(api, keys_chunks, value_chunks, max_groups: int, device=None):
+    """GROUP BY over row-sharded data: local hash aggregate -> exchange_groups -> local merge.
+    `api` is the engine (rust_dataframe_amd.lib.api() on a GPU).  Returns numpy (keys, sums, counts) of the
+    groups this rank owns; the union over ranks is the full result."""
+    import numpy as np
+    from ._abi import HostArray
+    k, s, c = api.groupby_sum(keys_chunks, value_chunks, max_groups)
+    if k.null_count:
+        raise ValueError("distributed group-by: NULL keys are not supported in the exchange")
+    rk, rs, rc = exchange_groups(k.to_numpy(), s.to_numpy(), c.to_numpy(), device)
+    if len(rk) == 0:
+        return rk, rs, rc
+    K = [HostArray.from_numpy(rk)]
+    mk, ms, _ = api.groupby_sum(K, [HostArray.from_numpy(rs)], max_groups)       # sum of partial sums
+    ck, cs, _ = api.groupby_sum(K, [HostArray.from_numpy(rc)], max_groups)       # sum of partial counts
+    o1, o2 = np.argsort(mk.to_numpy()), np.argsort(ck.to_numpy())
+    return mk.to_numpy()[o1], ms.to_numpy()[o1], cs.to_numpy()[o2]

@@ -324,3 +324,37 @@ def test_error_values_match_reference_semantics(gpu, ora):
         with pytest.raises(A.RdfError) as ei:  # add(f64, i32) without the Cast AddOperation inserts
             api.pipeline(e, [a, zi], [e.op("add", e.col(0), e.col(1))])
         assert ei.value.status == A.RDF_INVALID_ARGUMENT
+
+
+def _sorted_groups(k, s, c):
+    kv, km = k.to_numpy(), k.valid_mask()
+    order = np.lexsort((kv, ~km))  # valid keys ascending, the NULL-key group last
+    return kv[order], km[order], s.to_numpy()[order], c.to_numpy()[order]
+
+
+@pytest.mark.parametrize("key_dtype", [A.I64, A.I32, A.U32, A.U8])
+@pytest.mark.parametrize("val_dtype", [A.F64, A.I64, A.F32, None])
+def test_groupby_sum(gpu, ora, key_dtype, val_dtype):
+    """GROUP BY key -> sum, count: no reference execution exists (src/evaluation.rs:73), SQL semantics via the oracle."""
+    rng = np.random.default_rng(900 + key_dtype)
+    for lens, nf, off, ngroups in [([5], 0.0, 0, 3), ([1024, 1024, 576], 0.0, 0, 50), ([700, 0, 3000], 0.15, 13, 200), ([40_000], 0.05, 3, 5000)]:
+        hi = min(ngroups, np.iinfo(A.NP_OF[key_dtype]).max)
+        keys = []
+        for n in lens:
+            kv = rng.integers(0, hi, n).astype(A.NP_OF[key_dtype])
+            if key_dtype == A.I64 and n > 2:
+                kv[0], kv[1] = np.iinfo(np.int64).min, np.iinfo(np.int64).max  # the table's free marker is a legal key
+            keys.append(A.HostArray.from_numpy(kv, valid=(rng.uniform(size=n) >= nf) if nf else None, offset=off, rng=rng))
+        vals = make_chunks(rng, val_dtype, lens, nf, off) if val_dtype is not None else None
+        exp = _sorted_groups(*ora.groupby_sum(keys, vals, ngroups + 8))
+        got = _sorted_groups(*gpu.groupby_sum(keys, vals, ngroups + 8))
+        what = f"keys={key_dtype} vals={val_dtype} lens={lens}"
+        assert np.array_equal(got[1], exp[1]) and np.array_equal(got[0][exp[1]], exp[0][exp[1]]), "keys " + what
+        assert np.array_equal(got[3], exp[3]), "counts " + what
+        if val_dtype in (A.F64, A.F32):
+            np.testing.assert_allclose(got[2], exp[2], rtol=1e-6, atol=1e-9, err_msg="sums " + what)
+        else:
+            assert np.array_equal(got[2], exp[2]), "sums " + what
+    with pytest.raises(A.RdfError) as ei:  # more distinct keys than promised
+        gpu.groupby_sum([A.HostArray.from_numpy(np.arange(5000, dtype=np.int64))], None, 100)
+    assert ei.value.status == A.RDF_MEMORY_ERROR

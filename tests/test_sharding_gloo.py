@@ -106,3 +106,53 @@ def test_world_size_2_gloo(ora):
             assert abs(s - w.sum) <= 1e-12 * abs(w.sum)
         else:
             assert s == w.sum
+
+
+def _gb_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from oracle import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        keys, vals = _gb_data()
+        n = len(keys)
+        b, e = sharding.shard_rows(n, world, rank)
+        k, s, c = sharding.distributed_groupby_sum(oracle.api(), [A.HostArray.from_numpy(keys[b:e])], [A.HostArray.from_numpy(vals[b:e])], 1000)
+        q.put((rank, k.tolist(), s.tolist(), c.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _gb_data():
+    rng = np.random.default_rng(5)
+    n = 20_000
+    return rng.integers(-300, 300, n).astype(np.int64), rng.uniform(0, 1, n)
+
+
+@pytest.mark.timeout(120)
+def test_groupby_all_to_all_world_2_gloo(ora):
+    """Local pre-aggregation -> hash-partitioned all-to-all of partial groups -> local merge."""
+    world, port = 2, 31500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gb_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    keys, vals = _gb_data()
+    k, s, c = ora.groupby_sum([A.HostArray.from_numpy(keys)], [A.HostArray.from_numpy(vals)], 1000)
+    exp = {int(a): (float(b), int(d)) for a, b, d in zip(k.to_numpy(), s.to_numpy(), c.to_numpy())}
+    got = {}
+    for rank, gk, gs, gc in res:
+        owners = sharding.group_owner(np.array(gk, dtype=np.int64), world)
+        assert np.all(owners == rank), "every rank ends up with exactly the keys it owns"
+        for a, b, d in zip(gk, gs, gc):
+            assert a not in got
+            got[int(a)] = (b, d)
+    assert got.keys() == exp.keys()
+    for key, (sm, cnt) in exp.items():
+        assert got[key][1] == cnt and abs(got[key][0] - sm) <= 1e-9 * max(abs(sm), 1.0)
