@@ -189,6 +189,11 @@ class DeviceArray:
     dtype: int
     null_count: int = -1
     keep: object = None
+    capacity: int = -1     # for outputs: element capacity of the buffers (defaults to the initial length)
+
+    def __post_init__(self):
+        if self.capacity < 0:
+            self.capacity = self.length
 
     @property
     def validity(self):
@@ -199,7 +204,7 @@ class DeviceArray:
                          -1 if unknown_null_count else self.null_count, self.dtype, MEM_DEVICE)
 
     def out_struct(self) -> rdf_out:
-        return rdf_out(self.values_ptr, self.validity_ptr, self.length, 0, 0, self.dtype, MEM_DEVICE)
+        return rdf_out(self.values_ptr, self.validity_ptr, self.capacity, 0, 0, self.dtype, MEM_DEVICE)
 
 
 # ---------------------------------------------------------------- expression trees

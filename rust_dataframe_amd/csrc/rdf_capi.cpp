@@ -1609,9 +1609,10 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
     }
     // group count + flags
     RDF_TRY(pinned_reserve(pin_off + 64));
-    unsigned int* pin = (unsigned int*)(ctx.pinned + pin_off);
-    HIP_TRY(hipMemcpyAsync(pin, t.special, 32, hipMemcpyDeviceToHost, ctx.stream));
+    unsigned int pin[8];  // copied out: a later pinned_reserve may move the staging buffer
+    HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, t.special, 32, hipMemcpyDeviceToHost, ctx.stream));
     HIP_TRY(hipStreamSynchronize(ctx.stream));
+    memcpy(pin, ctx.pinned + pin_off, 32);
     const int64_t ngroups = (int64_t)pin[2] + (pin[0] ? 1 : 0) + (pin[1] ? 1 : 0);
     if ((pin[4] & 4u) || (int64_t)pin[2] > max_groups) return fail(RDF_MEMORY_ERROR, "groupby: more than max_groups (%lld) distinct keys", (long long)max_groups);
     pin_off += 256;

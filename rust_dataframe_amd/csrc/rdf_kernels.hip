@@ -448,6 +448,100 @@ __global__ __launch_bounds__(kBlock) void groupby_build_kernel(const GroupByArgs
     if (err) atomicOr(a.t.flags, err);
 }
 
+// Insert-or-find `key` in the global table and add (v, cnt) to its slot.  Returns false on overflow.
+__device__ __forceinline__ bool global_upsert(const GroupTable& t, uint64_t mask, uint64_t key, bool is_f64, uint64_t v, uint64_t cnt) {
+    uint64_t s = mix64(key) & mask;
+    int64_t probes = 0;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&t.keys[s], kGroupEmpty, (unsigned long long)key);
+        if (old == kGroupEmpty) { atomicAdd(t.ngroups, 1u); break; }
+        if (old == key) break;
+        s = (s + 1) & mask;
+        if (++probes > t.capacity) return false;
+    }
+    if (cnt) {
+        if (is_f64) unsafeAtomicAdd((double*)&t.sums[s], u2d(v)); else atomicAdd(&t.sums[s], (unsigned long long)v);
+        atomicAdd(&t.counts[s], (unsigned long long)cnt);
+    }
+    return true;
+}
+
+// Low-cardinality variant (max_groups <= kLdsGroups/2, e.g. TPC-H Q1's 4 groups): every block
+// pre-aggregates into an LDS-resident table (ds_cmpst / ds_add, no HBM atomics per row) and merges its
+// <= kLdsGroups partial groups into the global table once at the end.
+constexpr int kLdsGroups = 2048;
+__global__ __launch_bounds__(kBlock) void groupby_build_lds_kernel(const GroupByArgs a) {
+    __shared__ unsigned long long lkeys[kLdsGroups];
+    __shared__ unsigned long long lsums[kLdsGroups + 2];
+    __shared__ unsigned long long lcnts[kLdsGroups + 2];
+    __shared__ unsigned int lspecial[2];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id();
+    const uint64_t gmask = (uint64_t)a.t.capacity - 1;
+    const bool is_f64 = a.value_dtype == RDF_F64 || a.value_dtype == RDF_F32;
+    for (int i = threadIdx.x; i < kLdsGroups + 2; i += kBlock) {
+        if (i < kLdsGroups) lkeys[i] = kGroupEmpty;
+        lsums[i] = 0; lcnts[i] = 0;
+    }
+    if (threadIdx.x < 2) lspecial[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t err = 0;
+    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int64_t c = a.nchunks == 1 ? 0 : find_chunk(a.chunk_tile_start, a.nchunks, tile);
+        const int64_t r0 = (tile - a.chunk_tile_start[c]) * kEvalTile;
+        const int64_t clen = a.chunk_len[c];
+        const DevChunkCol kc = a.keys[c];
+        const DevChunkCol vc = a.value_dtype >= 0 ? a.values[c] : DevChunkCol{nullptr, nullptr, 0};
+        const int64_t rw = r0 + (int64_t)wave * (kVPT * 64);
+        uint64_t kvw[kVPT], vvw[kVPT];
+        if (kc.validity) load_windows<kVPT>(kc.validity, kc.offset + rw, clen - rw, kvw);
+        if (vc.validity) load_windows<kVPT>(vc.validity, vc.offset + rw, clen - rw, vvw);
+#pragma unroll
+        for (int j = 0; j < kVPT; ++j) {
+            const int64_t row = rw + j * 64 + lane;
+            if (row >= clen) continue;
+            const bool kvalid = !kc.validity || ((kvw[j] >> lane) & 1);
+            const bool vvalid = a.value_dtype < 0 || !vc.validity || ((vvw[j] >> lane) & 1);
+            const uint64_t key = (uint64_t)load_key(kc, a.key_dtype, row);
+            uint64_t v = 0;
+            if (a.value_dtype == RDF_F64) v = ((const uint64_t*)vc.values)[vc.offset + row];
+            else if (a.value_dtype == RDF_F32) v = d2u((double)((const float*)vc.values)[vc.offset + row]);
+            else if (a.value_dtype >= 0) v = (uint64_t)load_key(vc, a.value_dtype, row);
+            int slot = -1;
+            if (!kvalid) { slot = kLdsGroups + 1; lspecial[1] = 1; }
+            else if (key == kGroupEmpty) { slot = kLdsGroups; lspecial[0] = 1; }
+            else {
+                uint32_t s = (uint32_t)mix64(key) & (kLdsGroups - 1);
+                for (int probes = 0; probes < 64; ++probes) {
+                    const unsigned long long old = atomicCAS(&lkeys[s], kGroupEmpty, (unsigned long long)key);
+                    if (old == kGroupEmpty || old == key) { slot = (int)s; break; }
+                    s = (s + 1) & (kLdsGroups - 1);
+                }
+            }
+            if (slot >= 0) {
+                if (vvalid) {
+                    if (is_f64) unsafeAtomicAdd((double*)&lsums[slot], u2d(v)); else atomicAdd(&lsums[slot], (unsigned long long)v);
+                    atomicAdd(&lcnts[slot], 1ull);
+                }
+            } else if (!global_upsert(a.t, gmask, key, is_f64, v, vvalid ? 1 : 0)) err |= 4u;  // LDS table full: straight to HBM
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLdsGroups + 2; i += kBlock) {
+        if (i < kLdsGroups) {
+            if (lkeys[i] != kGroupEmpty && !global_upsert(a.t, gmask, lkeys[i], is_f64, lsums[i], lcnts[i])) err |= 4u;
+        } else if (lspecial[i - kLdsGroups]) {
+            const int64_t gs = a.t.capacity + (i - kLdsGroups);
+            a.t.special[i - kLdsGroups] = 1;
+            if (lcnts[i]) {
+                if (is_f64) unsafeAtomicAdd((double*)&a.t.sums[gs], u2d(lsums[i])); else atomicAdd(&a.t.sums[gs], lsums[i]);
+                atomicAdd(&a.t.counts[gs], lcnts[i]);
+            }
+        }
+    }
+    if (err) atomicOr(a.t.flags, err);
+}
+
 __device__ __forceinline__ void store_key(void* out, int dt, unsigned idx, uint64_t key) {
     switch (dt) {
         case RDF_I32: case RDF_U32: ((uint32_t*)out)[idx] = (uint32_t)key; break;
@@ -607,7 +701,9 @@ hipError_t launch_take(const TakeArgs& a, hipStream_t s) {
 
 hipError_t launch_groupby_build(const GroupByArgs& a, hipStream_t s) {
     int64_t grid = a.ntiles < (int64_t)eval_grid_limit() ? a.ntiles : (int64_t)eval_grid_limit();
-    if (grid > 0) hipLaunchKernelGGL(groupby_build_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    if (grid <= 0) return hipSuccess;
+    if (a.max_groups <= kLdsGroups / 2) hipLaunchKernelGGL(groupby_build_lds_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL(groupby_build_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_groupby_emit(const GroupEmitArgs& a, hipStream_t s) {

@@ -298,28 +298,43 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     for (int64_t base = (int64_t)blockIdx.x * per_iter; base < nvec; base += (int64_t)gridDim.x * per_iter) {
         const int64_t wbase = base + (int64_t)wave * (U * 64);
         const int64_t rw = 2 * wbase;  // first row of this wave
-        // rows in range
-        c.inr = 0;
+        // rows in range; `full` (wave-uniform) = every row of this wave's span exists: the common case
+        // runs without per-lane bounds checks or predicated loads
+        const bool full = rw + 128 * U <= n;
+        if (full) {
+            c.inr = (1u << R) - 1;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t row = 2 * (wbase + u * 64 + lane);
-            c.inr |= (uint32_t)(row < n) << (2 * u) | (uint32_t)(row + 1 < n) << (2 * u + 1);
-        }
-        // (1) all loads up front
+            for (int k = 0; k < NC; ++k) {
+                const uvec2* p = (const uvec2*)((const uint64_t*)a.cols[k].values + a.cols[k].offset) + wbase + lane;
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            const uint64_t* p = (const uint64_t*)a.cols[k].values + a.cols[k].offset;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t i = wbase + u * 64 + lane;
-                const uint32_t m = (c.inr >> (2 * u)) & 3u;
-                if (m == 3u) {
-                    const uvec2 t = __builtin_nontemporal_load((const uvec2*)p + i);
+                for (int u = 0; u < U; ++u) {
+                    const uvec2 t = __builtin_nontemporal_load(p + u * 64);
                     c.v[k][2 * u] = t.x;
                     c.v[k][2 * u + 1] = t.y;
-                } else {
-                    c.v[k][2 * u] = m ? p[2 * i] : 0;
-                    c.v[k][2 * u + 1] = 0;
+                }
+            }
+        } else {
+            c.inr = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t row = 2 * (wbase + u * 64 + lane);
+                c.inr |= (uint32_t)(row < n) << (2 * u) | (uint32_t)(row + 1 < n) << (2 * u + 1);
+            }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const uint64_t* p = (const uint64_t*)a.cols[k].values + a.cols[k].offset;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t i = wbase + u * 64 + lane;
+                    const uint32_t m = (c.inr >> (2 * u)) & 3u;
+                    if (m == 3u) {
+                        const uvec2 t = *((const uvec2*)p + i);
+                        c.v[k][2 * u] = t.x;
+                        c.v[k][2 * u + 1] = t.y;
+                    } else {
+                        c.v[k][2 * u] = m ? p[2 * i] : 0;
+                        c.v[k][2 * u + 1] = 0;
+                    }
                 }
             }
         }

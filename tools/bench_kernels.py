@@ -134,6 +134,19 @@ def main():
     sidx = torch.arange(0, nidx, dtype=torch.int64, device="cuda").to(torch.uint32)
     S = A.DeviceArray(sidx.data_ptr(), None, 0, nidx, A.U32, 0, keep=sidx)
     report("take_sequential_u32", (4 + 8 + 8) * nidx, lambda: api.take([X], S, ot))
+    # hash GROUP BY key -> sum(val): 1e6 groups (config C4's per-GPU leg) and 1e3 groups (contended)
+    for ng in (1_000_000, 1_000):
+        kk = dev_i64(n, 7, 0, ng)
+        KK = arr(kk, A.I64, n)
+        ok_, os_, oc_ = out_like(A.I64, ng + 2), out_like(A.F64, ng + 2), out_like(A.I64, ng + 2)
+        report(f"groupby_sum_{ng}_groups", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
+    # A/B in one process: the specialised template kernel vs the dedicated filter_agg_f64 kernel on the headline shape
+    for rep in range(3):
+        lib.set_option("spec", 1)
+        report(f"headline_spec_{rep}", 8.0 * n, lambda: api.pipeline(e, [[X]], [cx], gt))
+        lib.set_option("spec", 0)
+        report(f"headline_filter_agg_{rep}", 8.0 * n, lambda: api.pipeline(e, [[X]], [cx], gt))
+    lib.set_option("spec", 1)
     return results
 
 
