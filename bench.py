@@ -9,7 +9,7 @@ ranks is the job time; rank 0 prints ONE JSON line.
 
   value     = rows all ranks processed / job time            (whole-job rows/s, inputs resident in HBM)
   roofline  = algorithmic bytes per launch (8 B/row) / average duration of the dominant
-              kernel (filter_agg_f64_kernel), from hipEvents the library records on ITS stream around
+              kernel (the specialised filter->aggregate kernel, rdf_spec.hip), from hipEvents the library records on ITS stream around
               that launch, against the 8 TB/s HBM3E peak (MI355X_MICROARCH.md)
   cpu_baseline = the oracle's structurally faithful restatement of the reference CPU path (const-array
               materialisation -> f64 casts -> compare -> bitmap -> Column::filter -> sum, one thread,
@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU (f64, 8 B/row)")
     ap.add_argument("--cpu-sample", type=int, default=200_000_000, help="rows for the CPU baseline leg (0 = skip)")
     ap.add_argument("--null-fraction", type=float, default=0.0, help="attach a validity bitmap with this null rate")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for a smoke test)")
+    ap.add_argument("--share-gpu", action="store_true", help="smoke test only: every rank uses device 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -82,13 +84,19 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(local_rank)
     lib.set_device(local_rank)
     api = lib.api()
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if (world == 1 or args.backend == "nccl") else None   # gloo exchanges CPU tensors
 
     rows = args.rows
     first_row = rank * rows
@@ -106,7 +114,7 @@ def main():
     pred = e.op("gt", c, e.scalar(THRESHOLD))
     def step():
         local = api.pipeline(e, [[col]], [c], pred)          # fused filter -> {sum,min,max,count}, one pass over HBM
-        tot = sharding.all_combine(local, device=dev)[0]      # N > 1: all_gather the partials (RCCL), fold in rank order
+        tot = sharding.all_combine(local, device=comm_dev)[0]      # N > 1: all_gather the partials (RCCL), fold in rank order
         return tot.sum, tot.count
 
     def sync():
@@ -129,9 +137,10 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = lib.kernel_timing_get()
+    kernel_name = lib.last_kernel()
     lib.kernel_timing_reset(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
@@ -163,7 +172,7 @@ def main():
                        "result_sum": res[0], "result_count": res[1], "sharding": "row ranges per rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "filter_agg_f64_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": kern_n,
+                         "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3, "launches": kern_n,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and args.cpu_sample > 0:

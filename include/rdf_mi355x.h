@@ -253,6 +253,8 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
 rdf_status rdf_set_option(const char* name, int64_t value);
 /* Number of program shapes with a specialised kernel. */
 int32_t    rdf_spec_catalog_size(void);
+/* Name of the dominant kernel the last rdf_pipeline-family call of this thread launched. */
+const char* rdf_last_kernel(void);
 
 /* Average duration (ms) and launch count of the dominant kernel launched by this thread since the
  * last reset, from hipEvents recorded on the stream the kernels run on (bench.py's roofline leg). */

@@ -39,6 +39,7 @@ struct Ctx {
     char*       pinned = nullptr;
     size_t      pinned_cap = 0;
     std::string err;
+    std::string last_kernel;       // name of the dominant kernel of the last compute call
     // tunables (rdf_set_option)
     bool   opt_spec = true;        // specialised straight-line kernels (rdf_spec.hip)
     bool   opt_fast_filter = true; // filter_agg_f64_kernel (handles 8-byte-misaligned columns)
@@ -668,9 +669,9 @@ rdf_status launch_agg_pair(const EvalArgs* ea, const FilterAggF64Args* fa, int c
                            const SpecArgs* sa = nullptr) {
     Ctx& c = g_ctx;
     KernelTimer kt;
-    if (sa) HIP_TRY(launch_spec(spec_sig, *sa, grid, c.stream));
-    else if (fa) HIP_TRY(launch_filter_agg_f64(*fa, cmp, grid, c.stream));
-    else HIP_TRY(launch_eval(*ea, SINK_AGG, feat, grid, c.stream));
+    if (sa) { c.last_kernel = std::string("spec_kernel<") + spec_sig + ">"; HIP_TRY(launch_spec(spec_sig, *sa, grid, c.stream)); }
+    else if (fa) { c.last_kernel = "filter_agg_f64_kernel"; HIP_TRY(launch_filter_agg_f64(*fa, cmp, grid, c.stream)); }
+    else { c.last_kernel = "eval_kernel<AGG>"; HIP_TRY(launch_eval(*ea, SINK_AGG, feat, grid, c.stream)); }
     kt.stop();
     AggFinalArgs f;
     memset(&f, 0, sizeof f);
@@ -974,8 +975,8 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     // SINK_STORE
     {
         KernelTimer kt;
-        if (use_spec) HIP_TRY(launch_spec(sp.sig.c_str(), sa, grid, ctx.stream));
-        else HIP_TRY(launch_eval(ea, SINK_STORE, cc.feat(), grid, ctx.stream));
+        if (use_spec) { ctx.last_kernel = "spec_kernel<" + sp.sig + ">"; HIP_TRY(launch_spec(sp.sig.c_str(), sa, grid, ctx.stream)); }
+        else { ctx.last_kernel = "eval_kernel<STORE>"; HIP_TRY(launch_eval(ea, SINK_STORE, cc.feat(), grid, ctx.stream)); }
         kt.stop();
     }
     RDF_TRY(pinned_reserve(pin_off + 64 + n_nc * 8 + outr.small_bytes + 256));
@@ -1693,6 +1694,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     return RDF_OK;
 }
 int32_t rdf_spec_catalog_size(void) { return spec_catalog_size(); }
+const char* rdf_last_kernel(void) { return g_ctx.last_kernel.c_str(); }
 
 rdf_status rdf_kernel_timing_reset(int32_t enable) {
     RDF_TRY(ensure_ready());

@@ -20,7 +20,7 @@ EXPORTS = [
     "rdf_binary", "rdf_unary", "rdf_cast", "rdf_sum", "rdf_min", "rdf_max", "rdf_count", "rdf_avg",
     "rdf_predicate", "rdf_filter_count", "rdf_filter", "rdf_filter_columns", "rdf_take", "rdf_pipeline", "rdf_groupby_sum",
     "rdf_fill_uniform_f64", "rdf_fill_uniform_i64", "rdf_fill_validity",
-    "rdf_kernel_timing_reset", "rdf_kernel_timing_get", "rdf_set_option", "rdf_spec_catalog_size",
+    "rdf_kernel_timing_reset", "rdf_kernel_timing_get", "rdf_set_option", "rdf_spec_catalog_size", "rdf_last_kernel",
 ]
 
 _lib = None
@@ -85,6 +85,11 @@ def synchronize():
 def set_option(name: str, value: int):
     load().rdf_set_option.argtypes = [C.c_char_p, C.c_int64]
     _check(load().rdf_set_option(name.encode(), value))
+
+
+def last_kernel() -> str:
+    load().rdf_last_kernel.restype = C.c_char_p
+    return (load().rdf_last_kernel() or b"").decode()
 
 
 def spec_catalog_size() -> int:
