@@ -43,6 +43,7 @@ struct Ctx {
     // tunables (rdf_set_option)
     bool   opt_spec = true;        // specialised straight-line kernels (rdf_spec.hip)
     bool   opt_fast_filter = true; // filter_agg_f64_kernel (handles 8-byte-misaligned columns)
+    bool   opt_vec_bitmap = true;  // bitmap words via vector loads instead of scalar loads (spec kernels)
     // kernel timing (bench.py roofline leg)
     bool   timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -892,6 +893,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         sa.n = clen[0];
         sa.partials = d_partials;
         sa.flags = d_flags;
+        sa.vec_bitmap = ctx.opt_vec_bitmap ? 1 : 0;
         if (ps.sink == RDF_SINK_STORE) {
             sa.out = dev_outs[0];
             sa.out_null_count = d_nullc;
@@ -1690,6 +1692,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     if (!name) return fail(RDF_INVALID_ARGUMENT, "null option name");
     if (strcmp(name, "spec") == 0) g_ctx.opt_spec = value != 0;
     else if (strcmp(name, "fast_filter") == 0) g_ctx.opt_fast_filter = value != 0;
+    else if (strcmp(name, "vec_bitmap") == 0) g_ctx.opt_vec_bitmap = value != 0;
     else return fail(RDF_INVALID_ARGUMENT, "unknown option %s", name);
     return RDF_OK;
 }

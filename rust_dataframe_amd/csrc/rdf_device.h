@@ -99,6 +99,7 @@ struct SpecArgs {
     int64_t*    out_null_count;  // SINK_STORE
     AggPartial* partials;        // SINK_AGG: [gridDim.x * nvalues]
     uint32_t*   flags;
+    int32_t     vec_bitmap;      // 1: bitmap words through the vector memory path (A/B knob)
 };
 
 struct MaskTables {

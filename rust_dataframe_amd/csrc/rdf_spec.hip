@@ -344,7 +344,8 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             c.valid[k] = c.inr;
             if (a.cols[k].validity) {
                 uint64_t w[2 * U];
-                load_windows<2 * U>(a.cols[k].validity, a.cols[k].offset + rw, n - rw, w);
+                if (a.vec_bitmap) load_windows<2 * U>(a.cols[k].validity, a.cols[k].offset + rw, n - rw, w);
+                else load_windows_s<2 * U>(a.cols[k].validity, a.cols[k].offset + rw, n - rw, w);
                 uint32_t m = 0;
                 const int sh = (2 * lane) & 63;
 #pragma unroll

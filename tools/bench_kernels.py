@@ -147,6 +147,13 @@ def main():
         lib.set_option("spec", 0)
         report(f"headline_filter_agg_{rep}", 8.0 * n, lambda: api.pipeline(e, [[X]], [cx], gt))
     lib.set_option("spec", 1)
+    # A/B: bitmap words through scalar loads (0) vs vector loads + readlane (1)
+    for rep in range(2):
+        for vb in (0, 1):
+            lib.set_option("vec_bitmap", vb)
+            report(f"ab_filter_sum_validity_vecbitmap{vb}_{rep}", 8.125 * n, lambda: api.pipeline(e, [[XV]], [cx], gt))
+            report(f"ab_sum_validity_vecbitmap{vb}_{rep}", 8.125 * n, lambda: api.pipeline(e, [[XV]], [cx]))
+    lib.set_option("vec_bitmap", 0)
     return results
 
 
