@@ -878,32 +878,58 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         ea.outs = tb.dev_at<DevOutChunk>(o_outs);
     }
 
-    // specialised straight-line kernel for this program shape? (one chunk, 8-byte columns, 16-byte aligned)
+    // specialised straight-line kernel for this program shape? (8-byte columns, every chunk 16-byte aligned)
     SpecPlan sp;
     SpecArgs sa;
+    TableBuilder stb;
     bool use_spec = false;
-    if (ctx.opt_spec && nchunks == 1 && build_spec_plan(cc, ps.filter_root, ps.nvalues, ps.value_roots, ps.sink, sp)) {
+    int spec_rpb = 0;
+    if (ctx.opt_spec && build_spec_plan(cc, ps.filter_root, ps.nvalues, ps.value_roots, ps.sink, sp)) {
         memset(&sa, 0, sizeof sa);
         use_spec = true;
-        for (int k = 0; k < sp.ncols; ++k) {
-            sa.cols[k] = in.dev[(size_t)sp.col_map[k]];
-            if (((uintptr_t)((const uint64_t*)sa.cols[k].values + sa.cols[k].offset) & 15) != 0) use_spec = false;
-        }
+        spec_rpb = spec_rows_per_block_iter(sp.sig.c_str());
+        for (int k = 0; k < sp.ncols && use_spec; ++k)
+            for (int64_t c = 0; c < nchunks; ++c) {
+                const DevChunkCol& d = in.dev[(size_t)((int64_t)sp.col_map[k] * nchunks + c)];
+                if (clen[(size_t)c] > 0 && ((uintptr_t)((const uint64_t*)d.values + d.offset) & 15) != 0) { use_spec = false; break; }
+            }
+        if (ps.sink == RDF_SINK_STORE)
+            for (int64_t c = 0; c < nchunks && use_spec; ++c)
+                if (clen[(size_t)c] > 0 && (((uintptr_t)dev_outs[(size_t)c].values & 15) != 0 || ((uintptr_t)dev_outs[(size_t)c].validity & 7) != 0)) use_spec = false;
+    }
+    if (use_spec) {
         for (int k = 0; k < sp.nimm; ++k) sa.imm[k] = sp.imm[k];
-        sa.n = clen[0];
         sa.partials = d_partials;
         sa.flags = d_flags;
         sa.vec_bitmap = ctx.opt_vec_bitmap ? 1 : 0;
-        if (ps.sink == RDF_SINK_STORE) {
-            sa.out = dev_outs[0];
-            sa.out_null_count = d_nullc;
-            if (((uintptr_t)sa.out.values & 15) != 0 || ((uintptr_t)sa.out.validity & 7) != 0) use_spec = false;
+        sa.out_null_count = d_nullc;
+        sa.nchunks = nchunks;
+        std::vector<int64_t> sts((size_t)nchunks + 1, 0);
+        for (int64_t c = 0; c < nchunks; ++c) sts[(size_t)c + 1] = sts[(size_t)c] + (clen[(size_t)c] + spec_rpb - 1) / spec_rpb;
+        sa.ntiles = sts[(size_t)nchunks];
+        if (nchunks == 1) {
+            for (int k = 0; k < sp.ncols; ++k) sa.cols[k] = in.dev[(size_t)sp.col_map[k]];
+            sa.n = clen[0];
+            if (ps.sink == RDF_SINK_STORE) sa.out = dev_outs[0];
+        } else {
+            const size_t o_c = stb.reserve(sizeof(DevChunkCol) * (size_t)(sp.ncols > 0 ? sp.ncols : 1) * (size_t)nchunks);
+            const size_t o_t = stb.reserve(sizeof(int64_t) * sts.size());
+            const size_t o_l = stb.reserve(sizeof(int64_t) * clen.size());
+            const size_t o_o = stb.reserve(sizeof(DevOutChunk) * ((size_t)nchunks + 1));
+            for (int k = 0; k < sp.ncols; ++k)
+                memcpy(stb.at<DevChunkCol>(o_c) + (size_t)k * (size_t)nchunks, in.dev.data() + (size_t)sp.col_map[k] * (size_t)nchunks, sizeof(DevChunkCol) * (size_t)nchunks);
+            memcpy(stb.at<char>(o_t), sts.data(), sizeof(int64_t) * sts.size());
+            memcpy(stb.at<char>(o_l), clen.data(), sizeof(int64_t) * clen.size());
+            if (ps.sink == RDF_SINK_STORE) memcpy(stb.at<char>(o_o), dev_outs.data(), sizeof(DevOutChunk) * (size_t)nchunks);
+            RDF_TRY(stb.alloc());
+            RDF_TRY(stb.upload(pin_off));
+            pin_off += (stb.host.size() + 255) & ~(size_t)255;
+            sa.cols_tab = stb.dev_at<DevChunkCol>(o_c);
+            sa.chunk_tile_start = stb.dev_at<int64_t>(o_t);
+            sa.chunk_len = stb.dev_at<int64_t>(o_l);
+            sa.outs_tab = stb.dev_at<DevOutChunk>(o_o);
         }
-    }
-    const int spec_rpb = use_spec ? spec_rows_per_block_iter(sp.sig.c_str()) : 0;
-    if (use_spec) {
-        const int64_t want = (clen[0] + spec_rpb - 1) / spec_rpb;
-        grid = (int)(want < (int64_t)eval_grid_limit() ? want : (int64_t)eval_grid_limit());
+        grid = (int)(sa.ntiles < (int64_t)eval_grid_limit() ? sa.ntiles : (int64_t)eval_grid_limit());
         if (grid < 1) grid = 1;
         d_result = d_partials + (size_t)grid * (size_t)ps.nvalues;
     }

@@ -92,14 +92,19 @@ struct FilterAggF64Args {
 
 // Specialised straight-line kernels (rdf_spec.hip): up to 4 eight-byte columns, one chunk.
 struct SpecArgs {
-    DevChunkCol cols[4];
-    int64_t     n;
-    uint64_t    imm[4];
-    DevOutChunk out;             // SINK_STORE
-    int64_t*    out_null_count;  // SINK_STORE
-    AggPartial* partials;        // SINK_AGG: [gridDim.x * nvalues]
-    uint32_t*   flags;
-    int32_t     vec_bitmap;      // 1: bitmap words through the vector memory path (A/B knob)
+    DevChunkCol        cols[4];          // nchunks == 1: inline descriptors
+    DevOutChunk        out;              // nchunks == 1, SINK_STORE
+    const DevChunkCol* cols_tab;         // nchunks > 1: [NC * nchunks], canonical column order
+    const DevOutChunk* outs_tab;         // nchunks > 1, SINK_STORE: [nchunks]
+    const int64_t*     chunk_tile_start; // nchunks > 1: [nchunks + 1], tiles of rows_per_block_iter rows
+    const int64_t*     chunk_len;        // nchunks > 1: [nchunks]
+    int64_t            nchunks, ntiles;
+    int64_t            n;                // nchunks == 1: rows
+    uint64_t           imm[4];
+    int64_t*           out_null_count;   // SINK_STORE: [nchunks]
+    AggPartial*        partials;         // SINK_AGG: [gridDim.x * nvalues]
+    uint32_t*          flags;
+    int32_t            vec_bitmap;       // 1: bitmap words through the vector memory path (default); 0: scalar loads (A/B)
 };
 
 struct MaskTables {

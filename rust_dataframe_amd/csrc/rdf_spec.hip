@@ -291,11 +291,32 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     g0.init();
     g1.init();
     uint32_t nulls = 0;
+    int64_t cur_chunk = -1;
 
-    const int64_t n = a.n;
-    const int64_t nvec = (n + 1) >> 1;  // the last vector may hold one row
-    const int64_t per_iter = (int64_t)kBlock * U;
-    for (int64_t base = (int64_t)blockIdx.x * per_iter; base < nvec; base += (int64_t)gridDim.x * per_iter) {
+    // A "tile" is one block iteration: kBlock*U vectors = 2*kBlock*U rows of ONE chunk.
+    constexpr int64_t per_iter = (int64_t)kBlock * U;
+    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int64_t ch = 0, base, n;
+        DevChunkCol col[NC];
+        DevOutChunk out = a.out;
+        if (a.nchunks == 1) {
+            base = tile * per_iter;
+            n = a.n;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) col[k] = a.cols[k];
+        } else {
+            ch = find_chunk(a.chunk_tile_start, a.nchunks, tile);
+            base = (tile - a.chunk_tile_start[ch]) * per_iter;
+            n = a.chunk_len[ch];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) col[k] = a.cols_tab[(int64_t)k * a.nchunks + ch];
+            if (P::SINK == SINK_STORE) out = a.outs_tab[ch];
+        }
+        if (P::SINK == SINK_STORE && ch != cur_chunk) {  // one null-count atomic per (wave, chunk), not per tile
+            if (cur_chunk >= 0 && lane == 0 && nulls) atomicAdd((unsigned long long*)&a.out_null_count[cur_chunk], (unsigned long long)nulls);
+            nulls = 0;
+            cur_chunk = ch;
+        }
         const int64_t wbase = base + (int64_t)wave * (U * 64);
         const int64_t rw = 2 * wbase;  // first row of this wave
         // rows in range; `full` (wave-uniform) = every row of this wave's span exists: the common case
@@ -305,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             c.inr = (1u << R) - 1;
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                const uvec2* p = (const uvec2*)((const uint64_t*)a.cols[k].values + a.cols[k].offset) + wbase + lane;
+                const uvec2* p = (const uvec2*)((const uint64_t*)col[k].values + col[k].offset) + wbase + lane;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uvec2 t = __builtin_nontemporal_load(p + u * 64);
@@ -322,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             }
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                const uint64_t* p = (const uint64_t*)a.cols[k].values + a.cols[k].offset;
+                const uint64_t* p = (const uint64_t*)col[k].values + col[k].offset;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int64_t i = wbase + u * 64 + lane;
@@ -338,14 +359,14 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
                 }
             }
         }
-        // validity: 2U windows of 64 rows per column, scalar loads
+        // validity: 2U windows of 64 rows per column
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             c.valid[k] = c.inr;
-            if (a.cols[k].validity) {
+            if (col[k].validity) {
                 uint64_t w[2 * U];
-                if (a.vec_bitmap) load_windows<2 * U>(a.cols[k].validity, a.cols[k].offset + rw, n - rw, w);
-                else load_windows_s<2 * U>(a.cols[k].validity, a.cols[k].offset + rw, n - rw, w);
+                if (a.vec_bitmap) load_windows<2 * U>(col[k].validity, col[k].offset + rw, n - rw, w);
+                else load_windows_s<2 * U>(col[k].validity, col[k].offset + rw, n - rw, w);
                 uint32_t m = 0;
                 const int sh = (2 * lane) & 63;
 #pragma unroll
@@ -364,30 +385,30 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             agg_rows<V0, R, 0>(c, keep & V0::vmask(c), g0);
             if constexpr (has_v1) agg_rows<V1, R, 0>(c, keep & V1::vmask(c), g1);
         } else {
-            uint64_t out[R];
-            eval_rows<V0, R, 0>(c, out);
+            uint64_t outv[R];
+            eval_rows<V0, R, 0>(c, outv);
             const uint32_t vm = V0::vmask(c) & c.inr;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t i = wbase + u * 64 + lane;
                 const uint32_t in2 = (c.inr >> (2 * u)) & 3u;
                 const uint32_t v2 = (vm >> (2 * u)) & 3u;
-                const uint64_t x0 = (v2 & 1u) ? out[2 * u] : 0, x1 = (v2 & 2u) ? out[2 * u + 1] : 0;  // null slots hold 0
+                const uint64_t x0 = (v2 & 1u) ? outv[2 * u] : 0, x1 = (v2 & 2u) ? outv[2 * u + 1] : 0;  // null slots hold 0
                 const uint64_t in0 = __ballot(in2 & 1u), in1 = __ballot(in2 & 2u);
                 const bool upper = (in0 >> 32) != 0;  // the wave's second 64 rows exist
-                uint64_t* const ow = (uint64_t*)a.out.values + ((wbase + u * 64) >> 5);
+                uint64_t* const ow = (uint64_t*)out.values + ((wbase + u * 64) >> 5);
                 if constexpr (V0::dt == RDF_BOOL) {
                     const uint64_t b0 = __ballot(x0 & 1), b1 = __ballot(x1 & 1);
                     const uint64_t w0 = interleave_word(b0, b1, 0, lane), w1 = interleave_word(b0, b1, 1, lane);
                     if (lane == 0 && in0) { ow[0] = w0; if (upper) ow[1] = w1; }
                 } else {
-                    if (in2 == 3u) { uvec2 t; t.x = x0; t.y = x1; ((uvec2*)a.out.values)[i] = t; }
-                    else if (in2) ((uint64_t*)a.out.values)[2 * i] = x0;
+                    if (in2 == 3u) { uvec2 t; t.x = x0; t.y = x1; ((uvec2*)out.values)[i] = t; }
+                    else if (in2) ((uint64_t*)out.values)[2 * i] = x0;
                 }
                 const uint64_t vb0 = __ballot(v2 & 1u), vb1 = __ballot(v2 & 2u);
-                if (a.out.validity) {
+                if (out.validity) {
                     const uint64_t w0 = interleave_word(vb0, vb1, 0, lane), w1 = interleave_word(vb0, vb1, 1, lane);
-                    uint64_t* const ob = (uint64_t*)a.out.validity + ((wbase + u * 64) >> 5);
+                    uint64_t* const ob = (uint64_t*)out.validity + ((wbase + u * 64) >> 5);
                     if (lane == 0 && in0) { ob[0] = w0; if (upper) ob[1] = w1; }
                 }
                 if (lane == 0) nulls += (uint32_t)(__popcll(in0 & ~vb0) + __popcll(in1 & ~vb1));
@@ -400,7 +421,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
         block_reduce_agg(g0.cls, g0.s(), g0.a(), g0.b(), g0.cnt, red_lds, &a.partials[(int64_t)blockIdx.x * nv]);
         if constexpr (has_v1) block_reduce_agg(g1.cls, g1.s(), g1.a(), g1.b(), g1.cnt, red_lds, &a.partials[(int64_t)blockIdx.x * nv + 1]);
     } else {
-        if (lane == 0 && nulls) atomicAdd((unsigned long long*)a.out_null_count, (unsigned long long)nulls);
+        if (cur_chunk >= 0 && lane == 0 && nulls) atomicAdd((unsigned long long*)&a.out_null_count[cur_chunk], (unsigned long long)nulls);
     }
 }
 

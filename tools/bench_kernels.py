@@ -134,6 +134,14 @@ def main():
     sidx = torch.arange(0, nidx, dtype=torch.int64, device="cuda").to(torch.uint32)
     S = A.DeviceArray(sidx.data_ptr(), None, 0, nidx, A.U32, 0, keep=sidx)
     report("take_sequential_u32", (4 + 8 + 8) * nidx, lambda: api.take([X], S, ot))
+    # chunked device-resident columns (what a frame looks like after a filter): 1M-row chunks
+    def chunked(t, dtype, rows=1 << 20):
+        return [A.DeviceArray(t.data_ptr() + i * 8, None, 0, min(rows, n - i), dtype, 0, keep=t) for i in range(0, n, rows)]
+    XC, YC, ZC, KC = chunked(x, A.F64), chunked(y, A.F64), chunked(z, A.F64), chunked(k, A.I64)
+    report("filter_sum_chunked_1M", 8.0 * n, lambda: api.pipeline(e, [XC], [cx], gt))
+    report("c3_chunked_1M", 32.0 * n, lambda: api.pipeline(e, [XC, YC, ZC, KC], [fma, ck]))
+    oc1 = [out_like(A.F64, a_.length) for a_ in XC]
+    report("add_store_chunked_1M", 24.0 * n, lambda: api.binary("add", XC, YC, oc1))
     # hash GROUP BY key -> sum(val): 1e6 groups (config C4's per-GPU leg) and 1e3 groups (contended)
     for ng in (1_000_000, 1_000):
         kk = dev_i64(n, 7, 0, ng)
