@@ -580,10 +580,14 @@ struct SpecPlan {
     int ncols = 0;
     uint64_t imm[4];
     int nimm = 0;
+    int width = 0;       // common element width of the columns (8 or 4)
     bool ok = true;
 };
 
-char spec_tag(int dt) { return dt == RDF_F64 ? 'd' : dt == RDF_I64 ? 'l' : dt == RDF_U64 ? 'u' : dt == RDF_BOOL ? 'b' : 0; }
+char spec_tag(int dt) {
+    switch (dt) { case RDF_F64: return 'd'; case RDF_I64: return 'l'; case RDF_U64: return 'u'; case RDF_F32: return 'f';
+                  case RDF_I32: return 'i'; case RDF_U32: return 'j'; case RDF_BOOL: return 'b'; default: return 0; }
+}
 
 struct SpecSigBuilder {
     Compiler& cc;
@@ -594,7 +598,9 @@ struct SpecSigBuilder {
         const rdf_expr_node& nd = cc.nodes[idx];
         if (nd.kind == RDF_NODE_COLUMN) {
             const int dt = cc.col_dtype[nd.column];
-            if (dt != RDF_F64 && dt != RDF_I64 && dt != RDF_U64) { sp.ok = false; return "?"; }
+            if (!spec_tag(dt) || dt == RDF_BOOL) { sp.ok = false; return "?"; }
+            if (sp.width == 0) sp.width = dtype_size(dt);
+            else if (sp.width != dtype_size(dt)) { sp.ok = false; return "?"; }  // one width per program
             int id = -1;
             for (int i = 0; i < sp.ncols; ++i) if (sp.col_map[i] == nd.column) id = i;
             if (id < 0) {
@@ -605,7 +611,7 @@ struct SpecSigBuilder {
             return std::string("c") + char('0' + id) + spec_tag(dt);
         }
         // scalar: payload converted to `dom`
-        if (dom != RDF_F64 && dom != RDF_I64 && dom != RDF_U64) { sp.ok = false; return "?"; }
+        if (!spec_tag(dom) || dom == RDF_BOOL) { sp.ok = false; return "?"; }
         if (nd.dtype == RDF_NULLTYPE || sp.nimm >= 4) { sp.ok = false; return "?"; }
         const int id = sp.nimm;
         sp.imm[sp.nimm++] = cc.imm_for(nd, dom);
@@ -891,7 +897,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         for (int k = 0; k < sp.ncols && use_spec; ++k)
             for (int64_t c = 0; c < nchunks; ++c) {
                 const DevChunkCol& d = in.dev[(size_t)((int64_t)sp.col_map[k] * nchunks + c)];
-                if (clen[(size_t)c] > 0 && ((uintptr_t)((const uint64_t*)d.values + d.offset) & 15) != 0) { use_spec = false; break; }
+                if (clen[(size_t)c] > 0 && ((uintptr_t)((const char*)d.values + d.offset * sp.width) & 15) != 0) { use_spec = false; break; }
             }
         if (ps.sink == RDF_SINK_STORE)
             for (int64_t c = 0; c < nchunks && use_spec; ++c)

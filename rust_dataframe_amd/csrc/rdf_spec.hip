@@ -4,7 +4,8 @@
 // the program shapes that dominate the path — one ScalarFunctions op per call (src/functions/scalar.rs),
 // a comparison against a scalar (BooleanFilter, src/expression.rs:836-859), an aggregate of a column
 // or of a small fused expression (BASELINE configs C1-C3) — this file instantiates straight-line
-// kernels from C++ expression templates over 8-byte columns (f64 / i64 / u64):
+// kernels from C++ expression templates over 8-byte (f64 / i64 / u64) or 4-byte (f32 / i32 / u32) columns
+// (all columns of one program share one width, so a 16-byte vector holds the same rows of every column):
 //
 //   spec_kernel<Prog>: wave-contiguous rows, 16-byte global_load_dwordx4 (1 KiB per wave-instruction),
 //   U vectors in flight per lane per column, validity as bulk scalar bitmap windows, predicate and
@@ -21,21 +22,27 @@
 
 namespace rdfk {
 
-typedef double dvec2 __attribute__((ext_vector_type(2)));
-typedef uint64_t uvec2 __attribute__((ext_vector_type(2)));
+template <class S, int N> struct VecOf { typedef S type __attribute__((ext_vector_type(N))); };
 
 // ------------------------------------------------------------------------------------------------
 // expression templates
 
 template <int DT> struct CType;
-template <> struct CType<RDF_F64> { using T = double; static constexpr char tag = 'd'; };
-template <> struct CType<RDF_I64> { using T = int64_t; static constexpr char tag = 'l'; };
-template <> struct CType<RDF_U64> { using T = uint64_t; static constexpr char tag = 'u'; };
-template <> struct CType<RDF_BOOL> { using T = bool; static constexpr char tag = 'b'; };
+template <> struct CType<RDF_F64> { using T = double; static constexpr char tag = 'd'; static constexpr int width = 8; };
+template <> struct CType<RDF_I64> { using T = int64_t; static constexpr char tag = 'l'; static constexpr int width = 8; };
+template <> struct CType<RDF_U64> { using T = uint64_t; static constexpr char tag = 'u'; static constexpr int width = 8; };
+template <> struct CType<RDF_F32> { using T = float; static constexpr char tag = 'f'; static constexpr int width = 4; };
+template <> struct CType<RDF_I32> { using T = int32_t; static constexpr char tag = 'i'; static constexpr int width = 4; };
+template <> struct CType<RDF_U32> { using T = uint32_t; static constexpr char tag = 'j'; static constexpr int width = 4; };
+template <> struct CType<RDF_BOOL> { using T = bool; static constexpr char tag = 'b'; static constexpr int width = 0; };
 
-template <int NC, int R>
+constexpr int merge_width(int a, int b) { return a == 0 ? b : (b == 0 || b == a ? a : -1); }
+constexpr bool dt_float(int dt) { return dt == RDF_F64 || dt == RDF_F32; }
+constexpr bool dt_signed(int dt) { return dt == RDF_I64 || dt == RDF_I32; }
+
+template <int NC, int R, class S>
 struct Ctx {
-    uint64_t v[NC][R];   // raw 8-byte elements, row r of column c
+    S        v[NC][R];   // raw elements, row r of column c
     uint32_t valid[NC];  // bit r = row r of column c is valid
     uint64_t imm[4];
     uint32_t inr;        // bit r = row r exists
@@ -46,18 +53,25 @@ template <class T> __device__ __forceinline__ T from_bits(uint64_t x);
 template <> __device__ __forceinline__ double from_bits<double>(uint64_t x) { return u2d(x); }
 template <> __device__ __forceinline__ int64_t from_bits<int64_t>(uint64_t x) { return (int64_t)x; }
 template <> __device__ __forceinline__ uint64_t from_bits<uint64_t>(uint64_t x) { return x; }
+template <> __device__ __forceinline__ float from_bits<float>(uint64_t x) { return __uint_as_float((uint32_t)x); }
+template <> __device__ __forceinline__ int32_t from_bits<int32_t>(uint64_t x) { return (int32_t)(uint32_t)x; }
+template <> __device__ __forceinline__ uint32_t from_bits<uint32_t>(uint64_t x) { return (uint32_t)x; }
 template <> __device__ __forceinline__ bool from_bits<bool>(uint64_t x) { return x != 0; }
 __device__ __forceinline__ uint64_t to_bits(double x) { return d2u(x); }
 __device__ __forceinline__ uint64_t to_bits(int64_t x) { return (uint64_t)x; }
 __device__ __forceinline__ uint64_t to_bits(uint64_t x) { return x; }
+__device__ __forceinline__ uint64_t to_bits(float x) { return (uint64_t)__float_as_uint(x); }
+__device__ __forceinline__ uint64_t to_bits(int32_t x) { return (uint64_t)(uint32_t)x; }
+__device__ __forceinline__ uint64_t to_bits(uint32_t x) { return (uint64_t)x; }
 __device__ __forceinline__ uint64_t to_bits(bool x) { return (uint64_t)x; }
 
 template <int I, int DT>
 struct Col {
     static constexpr int dt = DT;
     static constexpr int ncols = I + 1;
+    static constexpr int width = CType<DT>::width;
     using T = typename CType<DT>::T;
-    template <int r, class C> static __device__ __forceinline__ T eval(C& c) { return from_bits<T>(c.v[I][r]); }
+    template <int r, class C> static __device__ __forceinline__ T eval(C& c) { return from_bits<T>((uint64_t)c.v[I][r]); }
     template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return c.valid[I]; }
     static std::string sig() { return std::string("c") + char('0' + I) + CType<DT>::tag; }
 };
@@ -65,6 +79,7 @@ template <int K, int DT>
 struct Imm {
     static constexpr int dt = DT;
     static constexpr int ncols = 0;
+    static constexpr int width = 0;
     using T = typename CType<DT>::T;
     template <int r, class C> static __device__ __forceinline__ T eval(C& c) { return from_bits<T>(c.imm[K]); }
     template <class C> static __device__ __forceinline__ uint32_t vmask(const C&) { return ~0u; }
@@ -81,6 +96,8 @@ struct Bin {
     static_assert(is_cmp(OP) || A::dt == B::dt, "arithmetic operands share one dtype");
     static constexpr int dt = (is_cmp(OP) || is_logic(OP)) ? RDF_BOOL : A::dt;
     static constexpr int ncols = A::ncols > B::ncols ? A::ncols : B::ncols;
+    static constexpr int width = merge_width(A::width, B::width);
+    static_assert(width >= 0, "columns of one program share one element width");
     using T = typename CType<dt>::T;
     template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c) & B::vmask(c); }
     template <int r, class C> static __device__ __forceinline__ T eval(C& c) {
@@ -96,19 +113,19 @@ struct Bin {
             else return a <= b;
         } else if constexpr (OP == RDF_OP_AND) return x && y;
         else if constexpr (OP == RDF_OP_OR) return x || y;
-        else if constexpr (A::dt == RDF_F64) {
+        else if constexpr (dt_float(A::dt)) {
             if constexpr (OP == RDF_OP_ADD) return x + y;
             else if constexpr (OP == RDF_OP_SUB) return x - y;
             else if constexpr (OP == RDF_OP_MUL) return x * y;
             else if constexpr (OP == RDF_OP_DIV) {
-                const bool z = y == 0.0;
+                const bool z = y == (T)0;
                 if (z && ((vmask(c) & c.inr) >> r & 1)) c.err |= 1u;
-                return z ? 0.0 : x / y;
+                return z ? (T)0 : x / y;
             } else if constexpr (OP == RDF_OP_ATAN2) return atan2(x, y);
             else if constexpr (OP == RDF_OP_HYPOT) return hypot(x, y);
             else return log(x) / log(y);
-        } else {  // i64 / u64: wrapping
-            using U = uint64_t;
+        } else {  // integers: wrapping
+            using U = typename std::make_unsigned<T>::type;
             if constexpr (OP == RDF_OP_ADD) return (T)((U)x + (U)y);
             else if constexpr (OP == RDF_OP_SUB) return (T)((U)x - (U)y);
             else if constexpr (OP == RDF_OP_MUL) return (T)((U)x * (U)y);
@@ -116,7 +133,7 @@ struct Bin {
                 const bool z = y == 0;
                 if (z && ((vmask(c) & c.inr) >> r & 1)) c.err |= 1u;
                 if (z) return (T)0;
-                if constexpr (A::dt == RDF_I64) return y == -1 ? (T)((U)0 - (U)x) : x / y;
+                if constexpr (dt_signed(A::dt)) return y == -1 ? (T)((U)0 - (U)x) : x / y;
                 else return x / y;
             }
         }
@@ -128,12 +145,15 @@ template <int OP, class A>
 struct Un {
     static constexpr int dt = OP == RDF_OP_NOT ? RDF_BOOL : A::dt;
     static constexpr int ncols = A::ncols;
+    static constexpr int width = A::width;
     using T = typename CType<dt>::T;
     template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c); }
     template <int r, class C> static __device__ __forceinline__ T eval(C& c) {
         const auto x = A::template eval<r>(c);
         if constexpr (OP == RDF_OP_NOT) return !x;
-        else if constexpr (A::dt == RDF_I64) return x < 0 ? (int64_t)((uint64_t)0 - (uint64_t)x) : x;  // abs, MIN wraps
+        else if constexpr (dt_signed(A::dt)) { using U = typename std::make_unsigned<T>::type; return x < 0 ? (T)((U)0 - (U)x) : x; }  // abs, MIN wraps
+        else if constexpr (A::dt == RDF_F32 && OP == RDF_OP_DEGREES) return x * 57.2957795130823208767981548141051703f;
+        else if constexpr (A::dt == RDF_F32 && OP == RDF_OP_RADIANS) return x * (3.14159265358979323846264338327950288f / 180.0f);
         else if constexpr (OP == RDF_OP_ABS) return fabs(x);
         else if constexpr (OP == RDF_OP_ACOS) return acos(x);
         else if constexpr (OP == RDF_OP_ASIN) return asin(x);
@@ -163,23 +183,27 @@ template <int TO, class A>
 struct Cast {
     static constexpr int dt = TO;
     static constexpr int ncols = A::ncols;
+    static constexpr int width = merge_width(A::width, CType<TO>::width);
+    static_assert(width >= 0, "specialised casts keep the element width (8->8 or 4->4 bytes)");
     using T = typename CType<TO>::T;
     template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c); }
     template <int r, class C> static __device__ __forceinline__ T eval(C& c) {
         const auto x = A::template eval<r>(c);
         if constexpr (TO == RDF_BOOL) return x != 0;
-        else if constexpr (TO == RDF_F64) return (double)x;
-        else if constexpr (A::dt == RDF_F64) {  // saturating `as`
-            if (x != x) return (T)0;
+        else if constexpr (dt_float(TO)) return (T)x;
+        else if constexpr (dt_float(A::dt)) {  // saturating `as`
+            const double f = (double)x;
+            if (f != f) return (T)0;
             if constexpr (TO == RDF_I64) {
-                if (x >= 9223372036854775808.0) return INT64_MAX;
-                if (x <= -9223372036854775808.0) return INT64_MIN;
-                return (int64_t)x;
-            } else {
-                if (x <= 0.0) return (T)0;
-                if (x >= 18446744073709551616.0) return ~0ull;
-                return (uint64_t)x;
-            }
+                if (f >= 9223372036854775808.0) return INT64_MAX;
+                if (f <= -9223372036854775808.0) return INT64_MIN;
+                return (int64_t)f;
+            } else if constexpr (TO == RDF_U64) {
+                if (f <= 0.0) return (T)0;
+                if (f >= 18446744073709551616.0) return ~0ull;
+                return (uint64_t)f;
+            } else if constexpr (TO == RDF_I32) return (int32_t)(f < -2147483648.0 ? -2147483648.0 : f > 2147483647.0 ? 2147483647.0 : f);
+            else return (uint32_t)(f < 0.0 ? 0.0 : f > 4294967295.0 ? 4294967295.0 : f);
         } else return (T)x;
     }
     static std::string sig() { return "{" + std::to_string(TO) + " " + A::sig() + "}"; }
@@ -187,6 +211,7 @@ struct Cast {
 
 struct None {
     static constexpr int ncols = 0;
+    static constexpr int width = 0;
     static std::string sig() { return "-"; }
 };
 
@@ -222,14 +247,26 @@ template <> struct AggT<RDF_U64> {
     __device__ __forceinline__ uint64_t b() const { return mx; }
 };
 template <> struct AggT<RDF_BOOL> : AggT<RDF_U64> {};
+template <> struct AggT<RDF_F32> : AggT<RDF_F64> {   // f32 values fold in f64 (rounded once at the end by the host)
+    __device__ __forceinline__ void add(float v) { AggT<RDF_F64>::add((double)v); }
+};
+template <> struct AggT<RDF_I32> : AggT<RDF_I64> {
+    __device__ __forceinline__ void add(int32_t v) { AggT<RDF_I64>::add((int64_t)v); }
+};
+template <> struct AggT<RDF_U32> : AggT<RDF_U64> {
+    __device__ __forceinline__ void add(uint32_t v) { AggT<RDF_U64>::add((uint64_t)v); }
+};
 
-// Lane l of a 16-byte-load wave holds rows 2l and 2l+1, so the two ballots b0 (even rows) and b1 (odd
-// rows) must be interleaved into Arrow's row-ordered bitmap words.  Every lane j picks the bit that
-// belongs at output position j and the wave ballots again: word `half` (rows 64*half .. +63) in ~5 VALU
-// instructions for the whole wave.
-__device__ __forceinline__ uint64_t interleave_word(uint64_t b0, uint64_t b1, int half, int lane) {
-    const uint64_t src = (lane & 1) ? b1 : b0;
-    return __ballot((src >> (32 * half + (lane >> 1))) & 1);
+// Lane l of a 16-byte-load wave holds RV consecutive rows (RV = 2 for 8-byte, 4 for 4-byte elements), so
+// the RV per-element ballots must be interleaved into Arrow's row-ordered bitmap words.  Every lane j picks
+// the bit that belongs at output position j of word h (rows 64h..64h+63 of the wave-load) and the wave
+// ballots again: a handful of VALU instructions per word for the whole wave.
+template <int RV>
+__device__ __forceinline__ uint64_t interleave_word(const uint64_t (&b)[RV], int h, int lane) {
+    uint64_t src = b[0];
+#pragma unroll
+    for (int e = 1; e < RV; ++e) if ((lane % RV) == e) src = b[e];
+    return __ballot((src >> ((64 / RV) * h + lane / RV)) & 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -242,7 +279,11 @@ struct Prog {
     static constexpr int NC_ = (PRED::ncols > V0::ncols ? PRED::ncols : V0::ncols) > V1::ncols
                                    ? (PRED::ncols > V0::ncols ? PRED::ncols : V0::ncols) : V1::ncols;
     static constexpr int NC = NC_ < 1 ? 1 : NC_;
-    static constexpr int U = NC <= 2 ? 4 : 2;  // 16-byte vectors per lane per column per iteration
+    static constexpr int W = merge_width(merge_width(PRED::width, V0::width), V1::width);  // element width of every column
+    static_assert(W == 8 || W == 4, "a program reads columns of one width (8 or 4 bytes)");
+    static constexpr int RV = 16 / W;                 // rows per 16-byte vector
+    static constexpr int R = NC <= 2 ? 8 : 4;         // rows per lane per iteration
+    static constexpr int U = R / RV;                  // 16-byte vectors per lane per column per iteration
     static std::string sig() { return "P:" + PRED::sig() + ";V:" + V0::sig() + ";" + V1::sig() + ";S:" + std::to_string(SINK_); }
 };
 
@@ -271,7 +312,9 @@ __device__ __forceinline__ void eval_rows(C& c, uint64_t (&out)[R]) {
 
 template <class P>
 __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
-    constexpr int NC = P::NC, U = P::U, R = 2 * U;
+    constexpr int NC = P::NC, U = P::U, R = P::R, RV = P::RV, W = P::W;
+    using S = typename std::conditional<W == 8, uint64_t, uint32_t>::type;
+    using VecS = typename VecOf<S, RV>::type;
     using Pred = typename P::Pred;
     using V0 = typename P::Val0;
     using V1 = typename P::Val1;
@@ -281,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = wave_id();
 
-    Ctx<NC, R> c;
+    Ctx<NC, R, S> c;
     c.err = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) c.imm[k] = a.imm[k];
@@ -293,7 +336,8 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     uint32_t nulls = 0;
     int64_t cur_chunk = -1;
 
-    // A "tile" is one block iteration: kBlock*U vectors = 2*kBlock*U rows of ONE chunk.
+    // A "tile" is one block iteration: kBlock*U vectors = kBlock*R rows of ONE chunk; wave w owns the
+    // 64*R consecutive rows [64*R*w, +64*R) of it.
     constexpr int64_t per_iter = (int64_t)kBlock * U;
     for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         int64_t ch = 0, base, n;
@@ -317,60 +361,57 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             nulls = 0;
             cur_chunk = ch;
         }
-        const int64_t wbase = base + (int64_t)wave * (U * 64);
-        const int64_t rw = 2 * wbase;  // first row of this wave
-        // rows in range; `full` (wave-uniform) = every row of this wave's span exists: the common case
-        // runs without per-lane bounds checks or predicated loads
-        const bool full = rw + 128 * U <= n;
+        const int64_t wbase = base + (int64_t)wave * (U * 64);  // first vector of this wave
+        const int64_t rw = (int64_t)RV * wbase;                 // first row of this wave
+        // `full` (wave-uniform) = every row of this wave's span exists: the common case runs without
+        // per-lane bounds checks or predicated loads
+        const bool full = rw + 64 * R <= n;
         if (full) {
             c.inr = (1u << R) - 1;
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                const uvec2* p = (const uvec2*)((const uint64_t*)col[k].values + col[k].offset) + wbase + lane;
+                const VecS* p = (const VecS*)((const S*)col[k].values + col[k].offset) + wbase + lane;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const uvec2 t = __builtin_nontemporal_load(p + u * 64);
-                    c.v[k][2 * u] = t.x;
-                    c.v[k][2 * u + 1] = t.y;
+                    const VecS t = __builtin_nontemporal_load(p + u * 64);
+#pragma unroll
+                    for (int e = 0; e < RV; ++e) c.v[k][RV * u + e] = t[e];
                 }
             }
         } else {
             c.inr = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t row = 2 * (wbase + u * 64 + lane);
-                c.inr |= (uint32_t)(row < n) << (2 * u) | (uint32_t)(row + 1 < n) << (2 * u + 1);
-            }
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int e = 0; e < RV; ++e) c.inr |= (uint32_t)((int64_t)RV * (wbase + u * 64 + lane) + e < n) << (RV * u + e);
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                const uint64_t* p = (const uint64_t*)col[k].values + col[k].offset;
+                const S* p = (const S*)col[k].values + col[k].offset;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int64_t i = wbase + u * 64 + lane;
-                    const uint32_t m = (c.inr >> (2 * u)) & 3u;
-                    if (m == 3u) {
-                        const uvec2 t = *((const uvec2*)p + i);
-                        c.v[k][2 * u] = t.x;
-                        c.v[k][2 * u + 1] = t.y;
-                    } else {
-                        c.v[k][2 * u] = m ? p[2 * i] : 0;
-                        c.v[k][2 * u + 1] = 0;
-                    }
-                }
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int e = 0; e < RV; ++e)
+                        c.v[k][RV * u + e] = ((c.inr >> (RV * u + e)) & 1) ? p[(int64_t)RV * (wbase + u * 64 + lane) + e] : (S)0;
             }
         }
-        // validity: 2U windows of 64 rows per column
+        // validity: R windows of 64 rows per column for this wave; lane l's RV bits of load u sit in window
+        // RV*u + (RV*l >> 6) at bit (RV*l) & 63
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             c.valid[k] = c.inr;
             if (col[k].validity) {
-                uint64_t w[2 * U];
-                if (a.vec_bitmap) load_windows<2 * U>(col[k].validity, col[k].offset + rw, n - rw, w);
-                else load_windows_s<2 * U>(col[k].validity, col[k].offset + rw, n - rw, w);
+                uint64_t w[R];
+                if (a.vec_bitmap) load_windows<R>(col[k].validity, col[k].offset + rw, n - rw, w);
+                else load_windows_s<R>(col[k].validity, col[k].offset + rw, n - rw, w);
                 uint32_t m = 0;
-                const int sh = (2 * lane) & 63;
+                const int sh = (RV * lane) & 63, wsel = (RV * lane) >> 6;
 #pragma unroll
-                for (int u = 0; u < U; ++u) m |= ((uint32_t)((lane < 32 ? w[2 * u] : w[2 * u + 1]) >> sh) & 3u) << (2 * u);
+                for (int u = 0; u < U; ++u) {
+                    uint64_t ww = w[RV * u];
+#pragma unroll
+                    for (int h = 1; h < RV; ++h) if (wsel == h) ww = w[RV * u + h];
+                    m |= ((uint32_t)(ww >> sh) & ((1u << RV) - 1)) << (RV * u);
+                }
                 c.valid[k] = m & c.inr;
             }
         }
@@ -391,27 +432,50 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t i = wbase + u * 64 + lane;
-                const uint32_t in2 = (c.inr >> (2 * u)) & 3u;
-                const uint32_t v2 = (vm >> (2 * u)) & 3u;
-                const uint64_t x0 = (v2 & 1u) ? outv[2 * u] : 0, x1 = (v2 & 2u) ? outv[2 * u + 1] : 0;  // null slots hold 0
-                const uint64_t in0 = __ballot(in2 & 1u), in1 = __ballot(in2 & 2u);
-                const bool upper = (in0 >> 32) != 0;  // the wave's second 64 rows exist
-                uint64_t* const ow = (uint64_t*)out.values + ((wbase + u * 64) >> 5);
+                const uint32_t inu = (c.inr >> (RV * u)) & ((1u << RV) - 1);
+                const uint32_t vu = (vm >> (RV * u)) & ((1u << RV) - 1);
+                uint64_t x[RV], inb[RV], vb[RV];
+#pragma unroll
+                for (int e = 0; e < RV; ++e) {
+                    x[e] = ((vu >> e) & 1) ? outv[RV * u + e] : 0;  // null slots hold 0
+                    inb[e] = __ballot((inu >> e) & 1);
+                    vb[e] = __ballot((vu >> e) & 1);
+                }
+                const int64_t row0 = rw + (int64_t)64 * RV * u;       // first row of this wave-load
+                const int64_t word0 = row0 >> 6;                      // its first bitmap word (row0 is a multiple of 64)
                 if constexpr (V0::dt == RDF_BOOL) {
-                    const uint64_t b0 = __ballot(x0 & 1), b1 = __ballot(x1 & 1);
-                    const uint64_t w0 = interleave_word(b0, b1, 0, lane), w1 = interleave_word(b0, b1, 1, lane);
-                    if (lane == 0 && in0) { ow[0] = w0; if (upper) ow[1] = w1; }
+                    uint64_t bb[RV];
+#pragma unroll
+                    for (int e = 0; e < RV; ++e) bb[e] = __ballot(x[e] & 1);
+#pragma unroll
+                    for (int h = 0; h < RV; ++h) {
+                        const uint64_t wv = interleave_word<RV>(bb, h, lane);
+                        if (lane == 0 && row0 + 64 * h < n) ((uint64_t*)out.values)[word0 + h] = wv;
+                    }
                 } else {
-                    if (in2 == 3u) { uvec2 t; t.x = x0; t.y = x1; ((uvec2*)out.values)[i] = t; }
-                    else if (in2) ((uint64_t*)out.values)[2 * i] = x0;
+                    using OT = typename CType<V0::dt>::T;
+                    static_assert(sizeof(OT) == W, "value width equals the column width");
+                    if (inu == (1u << RV) - 1) {
+                        VecS t;
+#pragma unroll
+                        for (int e = 0; e < RV; ++e) t[e] = (S)x[e];
+                        ((VecS*)out.values)[i] = t;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < RV; ++e) if ((inu >> e) & 1) ((S*)out.values)[(int64_t)RV * i + e] = (S)x[e];
+                    }
                 }
-                const uint64_t vb0 = __ballot(v2 & 1u), vb1 = __ballot(v2 & 2u);
                 if (out.validity) {
-                    const uint64_t w0 = interleave_word(vb0, vb1, 0, lane), w1 = interleave_word(vb0, vb1, 1, lane);
-                    uint64_t* const ob = (uint64_t*)out.validity + ((wbase + u * 64) >> 5);
-                    if (lane == 0 && in0) { ob[0] = w0; if (upper) ob[1] = w1; }
+#pragma unroll
+                    for (int h = 0; h < RV; ++h) {
+                        const uint64_t wv = interleave_word<RV>(vb, h, lane);
+                        if (lane == 0 && row0 + 64 * h < n) ((uint64_t*)out.validity)[word0 + h] = wv;
+                    }
                 }
-                if (lane == 0) nulls += (uint32_t)(__popcll(in0 & ~vb0) + __popcll(in1 & ~vb1));
+                if (lane == 0) {
+#pragma unroll
+                    for (int e = 0; e < RV; ++e) nulls += (uint32_t)__popcll(inb[e] & ~vb[e]);
+                }
             }
         }
     }
@@ -441,12 +505,15 @@ static std::map<std::string, SpecEntry>& registry() {
     return r;
 }
 template <class P>
-static void reg() { registry()[P::sig()] = SpecEntry{&launch_prog<P>, kBlock * P::U * 2}; }
+static void reg() { registry()[P::sig()] = SpecEntry{&launch_prog<P>, kBlock * P::R}; }
 
 using D0 = Col<0, RDF_F64>; using D1 = Col<1, RDF_F64>; using D2 = Col<2, RDF_F64>;
 using L0 = Col<0, RDF_I64>; using L1 = Col<1, RDF_I64>; using L3 = Col<3, RDF_I64>;
 using W0 = Col<0, RDF_U64>; using W1 = Col<1, RDF_U64>;
 using KD0 = Imm<0, RDF_F64>; using KL0 = Imm<0, RDF_I64>;
+using F0 = Col<0, RDF_F32>; using F1 = Col<1, RDF_F32>; using I0 = Col<0, RDF_I32>; using I1 = Col<1, RDF_I32>;
+using J0 = Col<0, RDF_U32>; using J1 = Col<1, RDF_U32>;
+using KF0 = Imm<0, RDF_F32>; using KI0 = Imm<0, RDF_I32>;
 
 template <int OP> static void reg_cmp_family() {
     // filter(x CMP c) -> aggregates of x / of another column (headline family, config C2)
@@ -459,6 +526,11 @@ template <int OP> static void reg_cmp_family() {
     reg<Prog<None, Bin<OP, L0, KD0>, None, SINK_STORE>>();
     reg<Prog<None, Bin<OP, D0, D1>, None, SINK_STORE>>();
     reg<Prog<None, Bin<OP, L0, L1>, None, SINK_STORE>>();
+    // 4-byte columns: comparisons still happen in f64 (the scalar arrives as an f64 immediate)
+    reg<Prog<Bin<OP, F0, KD0>, F0, None, SINK_AGG>>();
+    reg<Prog<Bin<OP, I0, KD0>, I0, None, SINK_AGG>>();
+    reg<Prog<None, Bin<OP, F0, KD0>, None, SINK_STORE>>();
+    reg<Prog<None, Bin<OP, I0, KD0>, None, SINK_STORE>>();
 }
 template <int OP> static void reg_arith_family() {
     reg<Prog<None, Bin<OP, D0, D1>, None, SINK_STORE>>();   // ScalarFunctions::add/... f64
@@ -466,11 +538,17 @@ template <int OP> static void reg_arith_family() {
     reg<Prog<None, Bin<OP, W0, W1>, None, SINK_STORE>>();   // u64
     reg<Prog<None, Bin<OP, D0, KD0>, None, SINK_STORE>>();  // column OP scalar ("add_scalar", config C1)
     reg<Prog<None, Bin<OP, L0, KL0>, None, SINK_STORE>>();
+    reg<Prog<None, Bin<OP, F0, F1>, None, SINK_STORE>>();   // f32 / i32 / u32 (the reference's type matrix, src/evaluation.rs:107-238)
+    reg<Prog<None, Bin<OP, I0, I1>, None, SINK_STORE>>();
+    reg<Prog<None, Bin<OP, J0, J1>, None, SINK_STORE>>();
+    reg<Prog<None, Bin<OP, F0, KF0>, None, SINK_STORE>>();
+    reg<Prog<None, Bin<OP, I0, KI0>, None, SINK_STORE>>();
 }
 template <int OP> static void reg_unary_f64() {
     reg<Prog<None, Un<OP, D0>, None, SINK_STORE>>();                      // ScalarFunctions::<op>
     reg<Prog<None, Un<OP, Bin<RDF_OP_ADD, D0, KD0>>, None, SINK_AGG>>();  // sum(op(x + c)) — config C1 shape
     reg<Prog<None, Un<OP, D0>, None, SINK_AGG>>();
+    reg<Prog<None, Un<OP, F0>, None, SINK_STORE>>();                      // f32
 }
 
 static void build_registry() {
@@ -480,6 +558,9 @@ static void build_registry() {
     reg<Prog<None, W0, None, SINK_AGG>>();
     reg<Prog<None, Cast<RDF_F64, L0>, None, SINK_AGG>>();  // avg of an i64 column
     reg<Prog<None, Cast<RDF_F64, W0>, None, SINK_AGG>>();
+    reg<Prog<None, F0, None, SINK_AGG>>();
+    reg<Prog<None, I0, None, SINK_AGG>>();
+    reg<Prog<None, J0, None, SINK_AGG>>();
     reg_cmp_family<RDF_OP_GT>(); reg_cmp_family<RDF_OP_GE>(); reg_cmp_family<RDF_OP_EQ>();
     reg_cmp_family<RDF_OP_NE>(); reg_cmp_family<RDF_OP_LT>(); reg_cmp_family<RDF_OP_LE>();
     reg_arith_family<RDF_OP_ADD>(); reg_arith_family<RDF_OP_SUB>(); reg_arith_family<RDF_OP_MUL>(); reg_arith_family<RDF_OP_DIV>();
@@ -493,11 +574,14 @@ static void build_registry() {
     reg_unary_f64<RDF_OP_SIN>(); reg_unary_f64<RDF_OP_SINH>(); reg_unary_f64<RDF_OP_SQRT>(); reg_unary_f64<RDF_OP_TAN>();
     reg_unary_f64<RDF_OP_TANH>();
     reg<Prog<None, Un<RDF_OP_ABS, L0>, None, SINK_STORE>>();
+    reg<Prog<None, Un<RDF_OP_ABS, I0>, None, SINK_STORE>>();
     // casts between the 8-byte types (Function::Cast, src/evaluation.rs:296-315)
     reg<Prog<None, Cast<RDF_F64, L0>, None, SINK_STORE>>();
     reg<Prog<None, Cast<RDF_I64, D0>, None, SINK_STORE>>();
     reg<Prog<None, Cast<RDF_F64, W0>, None, SINK_STORE>>();
     reg<Prog<None, Cast<RDF_U64, D0>, None, SINK_STORE>>();
+    reg<Prog<None, Cast<RDF_F32, I0>, None, SINK_STORE>>();
+    reg<Prog<None, Cast<RDF_I32, F0>, None, SINK_STORE>>();
     // config C3: fused a*b+c -> min/max/count, plus the i64 key column's min/max/count, one pass over 4 columns
     using FMA = Bin<RDF_OP_ADD, Bin<RDF_OP_MUL, D0, D1>, D2>;
     reg<Prog<None, FMA, L3, SINK_AGG>>();

@@ -358,3 +358,33 @@ def test_groupby_sum(gpu, ora, key_dtype, val_dtype):
     with pytest.raises(A.RdfError) as ei:  # more distinct keys than promised
         gpu.groupby_sum([A.HostArray.from_numpy(np.arange(5000, dtype=np.int64))], None, 100)
     assert ei.value.status == A.RDF_MEMORY_ERROR
+
+
+def test_specialised_kernels_are_the_ones_that_run(gpu, request):
+    """In 'spec' mode the catalog shapes must hit a specialised kernel (no silent fall-back to the interpreter);
+    in 'interp' mode the general evaluator must run.  One aligned chunk each."""
+    from rust_dataframe_amd import lib
+    spec_mode = request.node.callspec.params["gpu"] == "spec"
+    rng = np.random.default_rng(1)
+    n = 5000
+    e = A.Expr()
+    c0, c1 = e.col(0), e.col(1)
+    cases = []
+    for dt in (A.F64, A.I64, A.U64, A.F32, A.I32, A.U32):
+        a, b = make_chunks(rng, dt, [n], 0.1, 0, nonzero=True), make_chunks(rng, dt, [n], 0.0, 0, nonzero=True)
+        cases.append((f"add {dt}", lambda a=a, b=b: gpu.binary("add", a, b)))
+        cases.append((f"sum {dt}", lambda a=a: gpu.sum(a)))
+    for dt in (A.F64, A.F32):
+        a = make_chunks(rng, dt, [n], 0.1, 0, "unit")
+        cases.append((f"sin {dt}", lambda a=a: gpu.unary("sin", a)))
+        cases.append((f"mask {dt}", lambda a=a: gpu.predicate(e, e.op("gt", c0, e.scalar(0.25)), [a])))
+        cases.append((f"filter->sum {dt}", lambda a=a: gpu.pipeline(e, [a], [c0], e.op("le", c0, e.scalar(0.5)))))
+    x, y, z = (make_chunks(rng, A.F64, [n], 0.0, 0, "unit") for _ in range(3))
+    k = make_chunks(rng, A.I64, [n], 0.0, 0)
+    fma = e.op("add", e.op("multiply", c0, c1), e.col(2))
+    cases.append(("C3", lambda: gpu.pipeline(e, [x, y, z, k], [fma, e.col(3)])))
+    cases.append(("C1", lambda: gpu.pipeline(e, [x], [e.op("sin", e.op("add", c0, e.scalar(1.0)))])))
+    for name, call in cases:
+        call()
+        kern = lib.last_kernel()
+        assert kern.startswith("spec_kernel<" if spec_mode else "eval_kernel<"), f"{name}: ran {kern}"
