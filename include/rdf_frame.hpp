@@ -590,11 +590,15 @@ struct Transformation {
     std::vector<Aggregation> aggregations;  // GroupAggregate
     size_t limit = 0;
     FilterRef filter;
+    std::vector<bool> sort_descending;      // Sort: per criterion (names holds the columns)
     static Transformation Calculate_(Calculation c) { Transformation t; t.kind = Calculate; t.calc = std::move(c); return t; }
     static Transformation Filter_(FilterRef f) { Transformation t; t.kind = Filter; t.filter = std::move(f); return t; }
     static Transformation Limit_(size_t n) { Transformation t; t.kind = Limit; t.limit = n; return t; }
     static Transformation Select_(std::vector<std::string> n) { Transformation t; t.kind = Select; t.names = std::move(n); return t; }
     static Transformation Drop_(std::vector<std::string> n) { Transformation t; t.kind = Drop; t.names = std::move(n); return t; }
+    static Transformation Sort_(std::vector<std::string> cols, std::vector<bool> descending) {
+        Transformation t; t.kind = Sort; t.names = std::move(cols); t.sort_descending = std::move(descending); return t;
+    }
     static Transformation GroupAggregate_(std::vector<std::string> groups, std::vector<Aggregation> a) {
         Transformation t; t.kind = GroupAggregate; t.names = std::move(groups); t.aggregations = std::move(a); return t;
     }
@@ -821,6 +825,23 @@ class DataFrame {
         }
         return DataFrame(schema_, std::move(result));
     }
+    // DataFrame::sort (:194-214): lexsort_to_indices over the criteria columns, then sort_by_indices.
+    // nulls_first is accepted and ignored exactly like the reference does (:208).
+    struct SortCriteria { std::string column; bool descending = false; bool nulls_first = false; };
+    DataFrame sort(const std::vector<SortCriteria>& criteria) const {
+        if (criteria.empty()) throw DataFrameError(DataFrameError::ComputeError, "Sort criteria cannot be empty");
+        std::vector<rdf_array> cols;
+        std::vector<rdf_sort_options> opts;
+        for (auto& c : criteria) {
+            for (auto& a : column_by_name(c.column).data().chunks()) cols.push_back(a->view());
+            opts.push_back(rdf_sort_options{c.descending ? 1 : 0, 0});
+        }
+        auto idx = Array::make_out(DataType::UInt32, num_rows(), false);
+        rdf_out ov = idx->out_view(num_rows());
+        check(rdf_sort_to_indices(cols.data(), (int32_t)criteria.size(), (int64_t)num_chunks(), opts.data(), &ov));
+        idx->length = ov.length;
+        return take(idx);
+    }
     // sort_by_indices (:216-222): Column::take of every column (chunk size 4096 as in the reference)
     DataFrame take(const ArrayRef& indices) const {
         std::vector<Column> cols;
@@ -975,7 +996,13 @@ class Evaluate {
                 cols_ = keep;
             } break;
             case T::GroupAggregate: step_aggregate(t); break;
-            case T::Sort: throw DataFrameError(DataFrameError::ComputeError, "Sort is not on the accelerated path yet (SURVEY.md §8f)");
+            case T::Sort: {
+                DataFrame f = flush();
+                std::vector<DataFrame::SortCriteria> cr;
+                for (auto& n : t.names) cr.push_back(DataFrame::SortCriteria{n, false, false});
+                for (size_t i = 0; i < t.sort_descending.size() && i < cr.size(); ++i) cr[i].descending = t.sort_descending[i];
+                reset(f.sort(cr));
+            } break;
             case T::Join: throw DataFrameError(DataFrameError::ComputeError, "Join is not on the accelerated path yet (SURVEY.md §8f)");
             default: throw DataFrameError(DataFrameError::ComputeError, "Read inside evaluate: pass the frame in");
         }
@@ -1197,6 +1224,11 @@ class LazyFrame {
         for (auto& c : output_.columns) { bool x = false; for (auto& n : names) x |= c.name == n; if (!x) d.columns.push_back(c); }
         f.output_ = d;
         f.push({plan::Transformation::Drop_(names)});
+        return f;
+    }
+    LazyFrame sort(const std::vector<std::string>& cols, const std::vector<bool>& descending) const {
+        LazyFrame f = *this;
+        f.push({plan::Transformation::Sort_(cols, descending)});
         return f;
     }
     LazyFrame aggregate(const std::vector<std::string>& groups, const std::vector<plan::Aggregation>& aggr) const {

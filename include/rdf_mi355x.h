@@ -186,6 +186,19 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
  * array; null index -> null; out of range -> RDF_COMPUTE_ERROR.  out: ONE chunk (B4 in SURVEY.md). */
 rdf_status rdf_take(const rdf_array* chunks, int64_t nchunks, const rdf_array* indices, rdf_out* out);
 
+/* ------------------------------------------------------------------ sort */
+
+/* SortCriteria (src/expression.rs:305-318) as arrow's SortOptions: the reference always passes
+ * nulls_first = false (src/dataframe.rs:208), so nulls sort last whatever this field says. */
+typedef struct { int32_t descending; int32_t nulls_first; } rdf_sort_options;
+
+/* DataFrame::sort -> arrow::compute::lexsort_to_indices (src/dataframe.rs:194-214): the row order given
+ * by the sort columns, column 0 most significant; ties keep ascending row order (stable); floats in
+ * IEEE total order (NaN after +inf).  cols[c * nchunks + i]; indices refer to the concatenation of the
+ * chunks (what Column::take consumes).  out_indices: ONE RDF_U32 array of all rows. */
+rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nchunks, const rdf_sort_options* opts,
+                               rdf_out* out_indices);
+
 /* ------------------------------------------------------------------ group-by */
 
 /* Transformation::GroupAggregate(groups, [Sum, Count]) for ONE integer key column — planned by

@@ -912,6 +912,78 @@ rdf_status ora_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t 
     return st;
 }
 
+/* ------------------------------------------------------------------ sort
+ * DataFrame::sort (src/dataframe.rs:194-214): concat every sort column (Column::to_array), then
+ * arrow::compute::lexsort_to_indices with SortOptions{descending, nulls_first: false}.  Restated as a
+ * stable merge sort of row indices under the lexicographic comparator (nulls last, then value order,
+ * floats in IEEE total order). */
+typedef struct { const rdf_array* chunks; int64_t nchunks; const int64_t* row_start; int desc; } sortcol;
+static int g_sort_ncols; static const sortcol* g_sort_cols;
+static uint64_t sort_bits(const rdf_array* a, int64_t i, int* width) {
+    int64_t k = a->offset + i; uint64_t b;
+    switch (a->dtype) {
+        case RDF_I8: *width = 1; return (uint8_t)(((const uint8_t*)a->values)[k] ^ 0x80u);
+        case RDF_U8: *width = 1; return ((const uint8_t*)a->values)[k];
+        case RDF_I16: *width = 2; return (uint16_t)(((const uint16_t*)a->values)[k] ^ 0x8000u);
+        case RDF_U16: *width = 2; return ((const uint16_t*)a->values)[k];
+        case RDF_I32: *width = 4; return ((const uint32_t*)a->values)[k] ^ 0x80000000u;
+        case RDF_U32: *width = 4; return ((const uint32_t*)a->values)[k];
+        case RDF_F32: *width = 4; b = ((const uint32_t*)a->values)[k]; return (b & 0x80000000u) ? (uint32_t)~b : (b ^ 0x80000000u);
+        case RDF_I64: *width = 8; return ((const uint64_t*)a->values)[k] ^ 0x8000000000000000ULL;
+        case RDF_F64: *width = 8; b = ((const uint64_t*)a->values)[k]; return (b >> 63) ? ~b : (b ^ 0x8000000000000000ULL);
+        default: *width = 8; return ((const uint64_t*)a->values)[k];
+    }
+}
+static void sort_locate(const sortcol* sc, int64_t row, const rdf_array** a, int64_t* i) {
+    int64_t c = 0;
+    while (c + 1 < sc->nchunks && sc->row_start[c + 1] <= row) c++;
+    *a = &sc->chunks[c]; *i = row - sc->row_start[c];
+}
+static int sort_cmp_rows(uint32_t x, uint32_t y) {
+    for (int k = 0; k < g_sort_ncols; k++) {
+        const sortcol* sc = &g_sort_cols[k];
+        const rdf_array *ax, *ay; int64_t ix, iy; int w;
+        sort_locate(sc, x, &ax, &ix); sort_locate(sc, y, &ay, &iy);
+        int nx = !arr_valid(ax, ix), ny = !arr_valid(ay, iy);
+        if (nx != ny) return nx ? 1 : -1;         /* nulls last */
+        if (nx) continue;
+        uint64_t bx = sort_bits(ax, ix, &w), by = sort_bits(ay, iy, &w);
+        if (bx != by) { int lt = bx < by ? -1 : 1; return sc->desc ? -lt : lt; }
+    }
+    return 0;
+}
+static void sort_merge(uint32_t* v, uint32_t* tmp, int64_t n) {
+    if (n < 2) return;
+    int64_t h = n / 2;
+    sort_merge(v, tmp, h); sort_merge(v + h, tmp, n - h);
+    int64_t i = 0, j = h, o = 0;
+    while (i < h && j < n) tmp[o++] = sort_cmp_rows(v[j], v[i]) < 0 ? v[j++] : v[i++];   /* stable */
+    while (i < h) tmp[o++] = v[i++];
+    while (j < n) tmp[o++] = v[j++];
+    memcpy(v, tmp, (size_t)n * sizeof(uint32_t));
+}
+rdf_status ora_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nchunks, const rdf_sort_options* opts, rdf_out* out) {
+    if (ncols < 1) FAIL(RDF_COMPUTE_ERROR, "Sort criteria cannot be empty");
+    int64_t* row_start = (int64_t*)calloc((size_t)nchunks + 1, sizeof(int64_t));
+    sortcol* sc = (sortcol*)calloc((size_t)ncols, sizeof(sortcol));
+    for (int64_t c = 0; c < nchunks; c++) row_start[c + 1] = row_start[c] + cols[c].length;
+    int64_t n = row_start[nchunks];
+    for (int k = 0; k < ncols; k++) { sc[k].chunks = cols + (int64_t)k * nchunks; sc[k].nchunks = nchunks; sc[k].row_start = row_start; sc[k].desc = opts ? opts[k].descending : 0; }
+    rdf_status st = RDF_OK;
+    if (out->capacity < n) { st = RDF_MEMORY_ERROR; snprintf(g_err, sizeof g_err, "output capacity too small"); }
+    else {
+        uint32_t* v = (uint32_t*)out->values;
+        uint32_t* tmp = (uint32_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(uint32_t));
+        for (int64_t i = 0; i < n; i++) v[i] = (uint32_t)i;
+        g_sort_ncols = ncols; g_sort_cols = sc;
+        sort_merge(v, tmp, n);
+        free(tmp);
+        out_begin(out, n);
+    }
+    free(row_start); free(sc);
+    return st;
+}
+
 /* ------------------------------------------------------------------ group-by
  * Transformation::GroupAggregate has a schema (Dataset::try_aggregate, src/expression.rs:114-221) but no
  * execution in the reference (src/evaluation.rs:73: panic!("aggregations not supported")): PARITY

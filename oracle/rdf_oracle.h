@@ -46,6 +46,9 @@ rdf_status ora_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
                               int64_t nchunks, rdf_out* outs);
 rdf_status ora_take(const rdf_array* chunks, int64_t nchunks, const rdf_array* indices, rdf_out* out);
 
+rdf_status ora_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nchunks, const rdf_sort_options* opts,
+                               rdf_out* out_indices);
+
 rdf_status ora_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,
                            rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts);
 

@@ -66,6 +66,10 @@ class rdf_expr_node(C.Structure):
                 ("column", C.c_int32), ("f64", C.c_double), ("i64", C.c_int64)]
 
 
+class rdf_sort_options(C.Structure):
+    _fields_ = [("descending", C.c_int32), ("nulls_first", C.c_int32)]
+
+
 class rdf_program(C.Structure):
     _fields_ = [("nodes", C.POINTER(rdf_expr_node)), ("nnodes", C.c_int32), ("filter_root", C.c_int32),
                 ("nvalues", C.c_int32), ("value_roots", C.c_int32 * MAX_VALUES), ("sink", C.c_int32)]
@@ -280,7 +284,7 @@ class Api:
         self._err = getattr(lib, prefix + "last_error")
         self._err.restype = C.c_char_p
         for name in ("binary", "unary", "cast", "sum", "min", "max", "count", "avg", "predicate", "filter_count",
-                     "filter", "filter_columns", "take", "pipeline", "groupby_sum", "fill_uniform_f64",
+                     "filter", "filter_columns", "take", "pipeline", "groupby_sum", "sort_to_indices", "fill_uniform_f64",
                      "fill_uniform_i64", "fill_validity"):
             fn = getattr(lib, prefix + name)
             fn.restype = C.c_int
@@ -440,6 +444,17 @@ class Api:
         carr = (rdf_out * 1)(out.out_struct())
         idx = (rdf_array * 1)(indices.c_struct())
         self._check(self._fn("take")(_flat([chunks], n), C.c_int64(n), idx, carr))
+        return self._finish([out], carr)[0]
+
+    # ---- sort (DataFrame::sort -> lexsort_to_indices)
+    def sort_to_indices(self, cols: Sequence[Sequence], descending: Sequence[bool], out=None):
+        nchunks = len(cols[0])
+        n = sum(a.length for a in cols[0])
+        if out is None:
+            out = HostArray.empty_out(U32, n, False)
+        opts = (rdf_sort_options * len(cols))(*[rdf_sort_options(int(d), 0) for d in descending])
+        carr = (rdf_out * 1)(out.out_struct())
+        self._check(self._fn("sort_to_indices")(_flat(cols, nchunks), C.c_int32(len(cols)), C.c_int64(nchunks), opts, carr))
         return self._finish([out], carr)[0]
 
     # ---- group-by (Transformation::GroupAggregate with one integer key; SQL semantics)

@@ -1551,6 +1551,114 @@ rdf_status rdf_take(const rdf_array* chunks, int64_t nchunks, const rdf_array* i
     return RDF_OK;
 }
 
+// ---------------------------------------------------------------- sort
+
+rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nchunks, const rdf_sort_options* opts,
+                               rdf_out* out_indices) {
+    if (ncols < 1 || !cols) return fail(RDF_COMPUTE_ERROR, "Sort criteria cannot be empty");  // src/dataframe.rs:195-199
+    if (nchunks < 1 || !out_indices) return fail(RDF_INVALID_ARGUMENT, "sort: bad arguments");
+    int32_t mem = -1;
+    RDF_TRY(check_mem(cols, (int64_t)ncols * nchunks, &mem));
+    RDF_TRY(check_out_mem(out_indices, 1, mem));
+    if (out_indices->dtype != RDF_U32) return fail(RDF_INVALID_ARGUMENT, "sort: indices are UInt32");
+    std::vector<int64_t> row_start((size_t)nchunks + 1, 0);
+    for (int64_t c = 0; c < nchunks; ++c) row_start[(size_t)c + 1] = row_start[(size_t)c] + cols[c].length;
+    const int64_t n = row_start[(size_t)nchunks];
+    for (int k = 0; k < ncols; ++k)
+        for (int64_t c = 0; c < nchunks; ++c) {
+            const rdf_array& a = cols[(int64_t)k * nchunks + c];
+            if (!is_numeric(a.dtype) || a.dtype != cols[(int64_t)k * nchunks].dtype) return fail(RDF_INVALID_ARGUMENT, "sort: numeric columns of one dtype per column");
+            if (a.length != cols[c].length) return fail(RDF_COMPUTE_ERROR, "sort: columns of a batch differ in length");
+        }
+    if (n >= (int64_t)1 << 32) return fail(RDF_INVALID_ARGUMENT, "sort: UInt32 indices cap a column at 2^32-1 rows (src/table.rs:218)");
+    if (out_indices->capacity < n) return fail(RDF_MEMORY_ERROR, "output capacity too small");
+    if (n == 0) { out_indices->length = 0; out_indices->null_count = 0; return RDF_OK; }
+    RDF_TRY(ensure_ready());
+    Ctx& ctx = g_ctx;
+    arena_begin();
+    size_t pin_off = 0, used = 0;
+    InputStager in;
+    for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) in.add(&cols[i]);
+    RDF_TRY(in.finish(pin_off, &used));
+    pin_off += (used + 255) & ~(size_t)255;
+    TableBuilder tb;
+    const size_t o_ch = tb.reserve(sizeof(DevChunkCol) * in.dev.size());
+    const size_t o_rs = tb.reserve(sizeof(int64_t) * row_start.size());
+    memcpy(tb.at<char>(o_ch), in.dev.data(), sizeof(DevChunkCol) * in.dev.size());
+    memcpy(tb.at<char>(o_rs), row_start.data(), sizeof(int64_t) * row_start.size());
+    RDF_TRY(tb.alloc());
+    RDF_TRY(tb.upload(pin_off));
+    pin_off += (tb.host.size() + 255) & ~(size_t)255;
+
+    const int64_t ntiles = (n + kSortTile - 1) / kSortTile;
+    void *pk0, *pk1, *pi0, *pi1, *pnf, *ph0, *ph1;
+    RDF_TRY(arena_alloc((size_t)n * 8, &pk0));
+    RDF_TRY(arena_alloc((size_t)n * 8, &pk1));
+    RDF_TRY(arena_alloc((size_t)n * 4, &pi0));
+    RDF_TRY(arena_alloc((size_t)n * 4, &pi1));
+    RDF_TRY(arena_alloc((size_t)n, &pnf));
+    RDF_TRY(arena_alloc((size_t)(256 * ntiles + 1) * 8, &ph0));
+    RDF_TRY(arena_alloc((size_t)(256 * ntiles + 1) * 8, &ph1));
+    uint64_t* keys[2] = {(uint64_t*)pk0, (uint64_t*)pk1};
+    uint32_t* idxb[2] = {(uint32_t*)pi0, (uint32_t*)pi1};
+    int kcur = 0;               // keys[kcur] holds the current keys
+    const uint32_t* idx_cur = nullptr;  // nullptr = identity order
+    int icur = 1;               // idxb[icur ^ 1] receives the next order
+
+    KernelTimer kt;
+    for (int k = ncols - 1; k >= 0; --k) {  // LSD over the sort columns: least significant criterion first
+        const int dt = cols[(int64_t)k * nchunks].dtype;
+        bool has_nulls = false;
+        for (int64_t c = 0; c < nchunks; ++c) has_nulls |= cols[(int64_t)k * nchunks + c].validity != nullptr;
+        SortKeyArgs ka;
+        memset(&ka, 0, sizeof ka);
+        ka.chunks = tb.dev_at<DevChunkCol>(o_ch) + (size_t)k * (size_t)nchunks;
+        ka.chunk_row_start = tb.dev_at<int64_t>(o_rs);
+        ka.nchunks = nchunks;
+        ka.n = n;
+        ka.idx = idx_cur;
+        ka.keys = keys[kcur];
+        ka.nullflags = has_nulls ? (uint8_t*)pnf : nullptr;
+        ka.dtype = dt;
+        ka.descending = opts ? opts[k].descending : 0;
+        HIP_TRY(launch_sort_keys(ka, ctx.stream));
+        const int npass = dtype_size(dt) + (has_nulls ? 1 : 0);
+        for (int p = 0; p < npass; ++p) {
+            SortPassArgs pa;
+            memset(&pa, 0, sizeof pa);
+            pa.keys_in = keys[kcur];
+            pa.idx_in = idx_cur;
+            pa.keys_out = keys[kcur ^ 1];
+            pa.idx_out = idxb[icur ^ 1];
+            pa.nullflags = p == dtype_size(dt) ? (const uint8_t*)pnf : nullptr;  // the nulls-last pass
+            pa.hist = (int64_t*)ph0;
+            pa.n = n;
+            pa.ntiles = ntiles;
+            pa.shift = 8 * p;
+            HIP_TRY(launch_sort_hist(pa, ctx.stream));
+            HIP_TRY(launch_scan((const int64_t*)ph0, (int64_t*)ph1, 256 * ntiles, ctx.stream));
+            pa.hist = (int64_t*)ph1;
+            HIP_TRY(launch_sort_scatter(pa, ctx.stream));
+            kcur ^= 1;
+            icur ^= 1;
+            idx_cur = idxb[icur];
+        }
+    }
+    kt.stop();
+    ctx.last_kernel = "sort_scatter_kernel";
+    if (mem == RDF_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(out_indices->values, idx_cur, (size_t)n * 4, hipMemcpyDeviceToHost, ctx.stream));
+        if (out_indices->validity) memset(out_indices->validity, 0xFF, (size_t)((n + 7) / 8));
+    } else {
+        HIP_TRY(hipMemcpyAsync(out_indices->values, idx_cur, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx.stream));
+        if (out_indices->validity) HIP_TRY(hipMemsetAsync(out_indices->validity, 0xFF, (size_t)((n + 7) / 8), ctx.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    out_indices->length = n;
+    out_indices->null_count = 0;
+    return RDF_OK;
+}
+
 // ---------------------------------------------------------------- group-by
 
 rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,

@@ -123,6 +123,27 @@ struct FilterArgs {
     int32_t            esize[kMaxFilterCols];
 };
 
+// Stable LSD radix sort of (key, row index) pairs, 8 bits per pass (DataFrame::sort -> lexsort_to_indices).
+constexpr int kSortItems = 8;                       // items per thread per tile
+constexpr int kSortTile = kBlock * kSortItems;      // 2048 items per tile
+struct SortKeyArgs {                                 // key[i] = order-preserving transform of column[idx[i]]
+    const DevChunkCol* chunks;                       // [nchunks]
+    const int64_t*     chunk_row_start;              // [nchunks + 1]
+    int64_t            nchunks, n;
+    const uint32_t*    idx;                          // current order (nullptr = identity)
+    uint64_t*          keys;                         // out
+    uint8_t*           nullflags;                    // out (per ORIGINAL row), nullptr when the column has no bitmap
+    int32_t            dtype, descending;
+};
+struct SortPassArgs {
+    const uint64_t* keys_in;  const uint32_t* idx_in;   // idx_in nullptr = identity (first pass)
+    uint64_t*       keys_out; uint32_t*       idx_out;
+    const uint8_t*  nullflags;                       // digit source of the nulls-last pass (indexed by row), else nullptr
+    int64_t*        hist;                            // [256 * ntiles] digit-major counts, then their exclusive scan
+    int64_t         n, ntiles;
+    int32_t         shift;                           // bit offset of this pass's digit in the key
+};
+
 // Hash GROUP BY key -> {sum(value), count(value)}: open addressing, linear probing, 64-bit keys.
 struct GroupTable {
     unsigned long long* keys;   // [capacity] slot keys, kGroupEmpty = free
@@ -177,6 +198,9 @@ hipError_t launch_mask_count(const MaskTables& t, int64_t* tile_counts, hipStrea
 hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, hipStream_t s);
 hipError_t launch_compact(const FilterArgs& a, hipStream_t s);
 hipError_t launch_take(const TakeArgs& a, hipStream_t s);
+hipError_t launch_sort_keys(const SortKeyArgs& a, hipStream_t s);
+hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s);
+hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_groupby_build(const GroupByArgs& a, hipStream_t s);
 hipError_t launch_groupby_emit(const GroupEmitArgs& a, hipStream_t s);
 hipError_t launch_fill_f64(double* p, int64_t n, uint64_t seed, uint64_t col, int64_t first_row, double lo, double hi, hipStream_t s);

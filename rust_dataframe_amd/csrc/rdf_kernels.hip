@@ -376,6 +376,108 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const TakeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// sort to indices (DataFrame::sort -> arrow::compute::lexsort_to_indices, src/dataframe.rs:194-214): a
+// stable LSD radix sort of (key, row) pairs.  Per 8-bit pass: per-tile digit histograms (digit-major),
+// one exclusive scan, then a stable scatter whose in-tile ranks come from wave ballots (the lanes that
+// share my digit = AND over the 8 digit bits of the ballot or its complement) + an LDS prefix over the
+// (row-of-items, wave) groups.  Columns are applied last-to-first; nulls go last via one extra 1-bit pass.
+
+__device__ __forceinline__ uint64_t sort_key_bits(const DevChunkCol& cc, int dt, int64_t e) {
+    switch (dt) {
+        case RDF_I8: return (uint8_t)(((const uint8_t*)cc.values)[e] ^ 0x80u);
+        case RDF_U8: return ((const uint8_t*)cc.values)[e];
+        case RDF_I16: return (uint16_t)(((const uint16_t*)cc.values)[e] ^ 0x8000u);
+        case RDF_U16: return ((const uint16_t*)cc.values)[e];
+        case RDF_I32: return ((const uint32_t*)cc.values)[e] ^ 0x80000000u;
+        case RDF_U32: return ((const uint32_t*)cc.values)[e];
+        case RDF_F32: { const uint32_t b = ((const uint32_t*)cc.values)[e]; return (b & 0x80000000u) ? (uint32_t)~b : (b ^ 0x80000000u); }
+        case RDF_I64: return ((const uint64_t*)cc.values)[e] ^ 0x8000000000000000ull;
+        case RDF_F64: { const uint64_t b = ((const uint64_t*)cc.values)[e]; return (b >> 63) ? ~b : (b ^ 0x8000000000000000ull); }
+        default: return ((const uint64_t*)cc.values)[e];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sort_keys_kernel(const SortKeyArgs a, uint64_t width_mask) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t row = a.idx ? (int64_t)a.idx[i] : i;
+        const int64_t c = a.nchunks == 1 ? 0 : find_chunk(a.chunk_row_start, a.nchunks, row);
+        const DevChunkCol cc = a.chunks[c];
+        const int64_t e = cc.offset + row - a.chunk_row_start[c];
+        uint64_t k = sort_key_bits(cc, a.dtype, e);
+        if (a.descending) k = ~k & width_mask;
+        bool isnull = false;
+        if (cc.validity) isnull = !((cc.validity[e >> 3] >> (e & 7)) & 1);
+        a.keys[i] = isnull ? 0 : k;  // nulls are ordered by the nulls-last pass; equal keys keep them stable
+        if (a.nullflags) a.nullflags[row] = isnull;
+    }
+}
+
+__device__ __forceinline__ int sort_digit(const SortPassArgs& a, int64_t i) {
+    if (a.nullflags) return a.nullflags[a.idx_in ? (int64_t)a.idx_in[i] : i];
+    return (int)((a.keys_in[i] >> a.shift) & 255);
+}
+
+__global__ __launch_bounds__(kBlock) void sort_hist_kernel(const SortPassArgs a) {
+    __shared__ unsigned int h[256];
+    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const int64_t base = tile * kSortTile;
+#pragma unroll
+        for (int j = 0; j < kSortItems; ++j) {
+            const int64_t i = base + j * kBlock + threadIdx.x;
+            if (i < a.n) atomicAdd(&h[sort_digit(a, i)], 1u);
+        }
+        __syncthreads();
+        a.hist[(int64_t)threadIdx.x * a.ntiles + tile] = h[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs a) {
+    __shared__ unsigned short grp[kSortItems * (kBlock / 64)][256];  // count of each digit per (row-of-items, wave) group
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        for (int i = threadIdx.x; i < kSortItems * (kBlock / 64) * 256; i += kBlock) (&grp[0][0])[i] = 0;
+        __syncthreads();
+        const int64_t base = tile * kSortTile;
+        int digit[kSortItems], rank[kSortItems];
+#pragma unroll
+        for (int j = 0; j < kSortItems; ++j) {
+            const int64_t i = base + j * kBlock + threadIdx.x;
+            const bool in = i < a.n;
+            const int d = in ? sort_digit(a, i) : 0;
+            digit[j] = d;
+            uint64_t peers = __ballot(in);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint64_t m = __ballot((d >> b) & 1);
+                peers &= ((d >> b) & 1) ? m : ~m;
+            }
+            rank[j] = __popcll(peers & ((1ull << lane) - 1));
+            if (in && rank[j] == 0) grp[j * (kBlock / 64) + wave][d] = (unsigned short)__popcll(peers);  // the group's first holder of d
+        }
+        __syncthreads();
+        {   // thread d: exclusive prefix of digit d's counts over the groups, in item order
+            unsigned int run = 0;
+#pragma unroll
+            for (int g = 0; g < kSortItems * (kBlock / 64); ++g) { const unsigned int c = grp[g][threadIdx.x]; grp[g][threadIdx.x] = (unsigned short)run; run += c; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kSortItems; ++j) {
+            const int64_t i = base + j * kBlock + threadIdx.x;
+            if (i < a.n) {
+                const int64_t dst = a.hist[(int64_t)digit[j] * a.ntiles + tile] + grp[j * (kBlock / 64) + wave][digit[j]] + rank[j];
+                a.keys_out[dst] = a.keys_in[i];
+                a.idx_out[dst] = a.idx_in ? a.idx_in[i] : (uint32_t)i;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // hash GROUP BY (Transformation::GroupAggregate, planned by Dataset::try_aggregate src/expression.rs:114-221,
 // never executed by the reference: src/evaluation.rs:73 panics).  SQL semantics: NULL keys form one
 // group, NULL values are skipped.  One global open-addressing table in HBM (it lives in L2/Infinity
@@ -696,6 +798,27 @@ hipError_t launch_take(const TakeArgs& a, hipStream_t s) {
         case 2: launch_take_t<uint16_t>(a, (int)grid, s); break;
         default: launch_take_t<uint8_t>(a, (int)grid, s); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_sort_keys(const SortKeyArgs& a, hipStream_t s) {
+    int64_t grid = (a.n + kBlock - 1) / kBlock;
+    if (grid > eval_grid_limit()) grid = eval_grid_limit();
+    int w = 8;
+    switch (a.dtype) { case RDF_I8: case RDF_U8: w = 1; break; case RDF_I16: case RDF_U16: w = 2; break;
+                       case RDF_I32: case RDF_U32: case RDF_F32: w = 4; break; default: break; }
+    const uint64_t mask = w == 8 ? ~0ull : ((1ull << (8 * w)) - 1);
+    if (grid > 0) hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a, mask);
+    return hipGetLastError();
+}
+hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s) {
+    int64_t grid = a.ntiles < (int64_t)eval_grid_limit() ? a.ntiles : (int64_t)eval_grid_limit();
+    if (grid > 0) hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s) {
+    int64_t grid = a.ntiles < (int64_t)eval_grid_limit() ? a.ntiles : (int64_t)eval_grid_limit();
+    if (grid > 0) hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

@@ -115,6 +115,25 @@ TEST(test_sort_take) {
     CHECK_EQ(host<uint8_t>(sorted.column(1).data().chunk(0)), (std::vector<uint8_t>{8, 4, 7, 5, 9, 6}));
 }
 
+// the whole of test_sort: DataFrame::sort = lexsort_to_indices + take (src/dataframe.rs:963-1003)
+TEST(test_sort) {
+    const std::vector<bool> valid{1, 1, 0, 1, 1, 1};
+    auto a = Array::from_vec<int32_t>({1, 1, 0, 3, 3, 4}, &valid);
+    auto b = Array::from_vec<uint8_t>({9, 5, 6, 7, 4, 8});
+    DataFrame frame = DataFrame::from_columns({Column::from_arrays({a}, Field{"a", DataType::Int32, true}), Column::from_arrays({b}, Field{"b", DataType::UInt8, false})});
+    DataFrame sorted = frame.sort({{"a", true, false}, {"b", false, false}});
+    auto ac = sorted.column(0).data().chunks();
+    CHECK_EQ(ac.size(), 1u);
+    CHECK(ac[0]->is_null(5));
+    auto av = host<int32_t>(ac[0]);
+    CHECK_EQ(std::vector<int32_t>(av.begin(), av.begin() + 5), (std::vector<int32_t>{4, 3, 3, 1, 1}));
+    CHECK_EQ(host<uint8_t>(sorted.column(1).data().chunk(0)), (std::vector<uint8_t>{8, 4, 7, 5, 9, 6}));
+    CHECK_THROWS(frame.sort({}));  // "Sort criteria cannot be empty" (:195-199)
+    // through the lazy plan
+    DataFrame lz = LazyFrame::read(frame).sort({"a", "b"}, {true, false}).evaluate();
+    CHECK_EQ(host<uint8_t>(lz.column(1).data().chunk(0)), (std::vector<uint8_t>{8, 4, 7, 5, 9, 6}));
+}
+
 // ---------------------------------------------------------------- filter: DataFrame::filter + the fused filter -> aggregate
 TEST(test_filter_and_fused_aggregate) {
     DataFrame df = DataFrame::from_csv(g_csv).drop({"city"});

@@ -388,3 +388,31 @@ def test_specialised_kernels_are_the_ones_that_run(gpu, request):
         call()
         kern = lib.last_kernel()
         assert kern.startswith("spec_kernel<" if spec_mode else "eval_kernel<"), f"{name}: ran {kern}"
+
+
+def test_sort_reference_case(gpu, ora):
+    """test_sort (src/dataframe.rs:963-1003): a desc, b asc, nulls last -> a = [4,3,3,1,1,null], b = [8,4,7,5,9,6]."""
+    a = A.HostArray.from_numpy(np.array([1, 1, 0, 3, 3, 4], dtype=np.int32), valid=[1, 1, 0, 1, 1, 1])
+    b = A.HostArray.from_numpy(np.array([9, 5, 6, 7, 4, 8], dtype=np.uint8))
+    for api in (gpu, ora):
+        idx = api.sort_to_indices([[a], [b]], [True, False])
+        assert idx.to_numpy().tolist() == [5, 4, 3, 1, 0, 2]
+        assert api.take([a], idx).to_pylist() == [4, 3, 3, 1, 1, None]
+        assert api.take([b], idx).to_pylist() == [8, 4, 7, 5, 9, 6]
+
+
+@pytest.mark.parametrize("dtype", NUMERIC)
+def test_sort_to_indices(gpu, ora, dtype):
+    rng = np.random.default_rng(1200 + dtype)
+    for lens, nf, off in [([7], 0.0, 0), ([2048], 0.0, 0), ([1024, 1024, 576], 0.2, 3), ([700, 0, 5000], 0.1, 13), ([60_000], 0.05, 1)]:
+        kind = "special" if dtype in (A.F32, A.F64) else ("extreme" if len(lens) == 1 else "plain")
+        k1 = make_chunks(rng, dtype, lens, nf, off, kind)
+        k2 = make_chunks(rng, A.I16, lens, 0.0, 0, "plain")
+        for ch in k2:  # few distinct values -> many ties on the first key
+            ch.values[:] = ch.values % 5
+        for desc in ([False, False], [True, False], [False, True]):
+            for cols in ([k2, k1], [k1]):
+                d = desc[:len(cols)]
+                got = gpu.sort_to_indices(cols, d).to_numpy()
+                exp = ora.sort_to_indices(cols, d).to_numpy()
+                assert np.array_equal(got, exp), f"sort dtype={dtype} lens={lens} desc={d} ncols={len(cols)}"

@@ -142,6 +142,11 @@ def main():
     report("c3_chunked_1M", 32.0 * n, lambda: api.pipeline(e, [XC, YC, ZC, KC], [fma, ck]))
     oc1 = [out_like(A.F64, a_.length) for a_ in XC]
     report("add_store_chunked_1M", 24.0 * n, lambda: api.binary("add", XC, YC, oc1))
+    # DataFrame::sort: radix sort to indices on an i64 key (8 passes) and an i32-range key stored as i64
+    ns = min(n, 50_000_000)
+    KS = arr(k, A.I64, ns)
+    oi = out_like(A.U32, ns)
+    report("sort_to_indices_i64", 8.0 * ns, lambda: api.sort_to_indices([[KS]], [False], oi))
     # hash GROUP BY key -> sum(val): 1e6 groups (config C4's per-GPU leg) and 1e3 groups (contended)
     for ng in (1_000_000, 1_000):
         kk = dev_i64(n, 7, 0, ng)
