@@ -1597,8 +1597,9 @@ rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
     RDF_TRY(arena_alloc((size_t)n * 4, &pi0));
     RDF_TRY(arena_alloc((size_t)n * 4, &pi1));
     RDF_TRY(arena_alloc((size_t)n, &pnf));
-    RDF_TRY(arena_alloc((size_t)(256 * ntiles + 1) * 8, &ph0));
-    RDF_TRY(arena_alloc((size_t)(256 * ntiles + 1) * 8, &ph1));
+    const int64_t sgrid = sort_grid(ntiles);
+    RDF_TRY(arena_alloc((size_t)(256 * sgrid + 1) * 8, &ph0));
+    RDF_TRY(arena_alloc((size_t)(256 * sgrid + 1) * 8, &ph1));
     uint64_t* keys[2] = {(uint64_t*)pk0, (uint64_t*)pk1};
     uint32_t* idxb[2] = {(uint32_t*)pi0, (uint32_t*)pi1};
     int kcur = 0;               // keys[kcur] holds the current keys
@@ -1636,7 +1637,7 @@ rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
             pa.ntiles = ntiles;
             pa.shift = 8 * p;
             HIP_TRY(launch_sort_hist(pa, ctx.stream));
-            HIP_TRY(launch_scan((const int64_t*)ph0, (int64_t*)ph1, 256 * ntiles, ctx.stream));
+            HIP_TRY(launch_scan((const int64_t*)ph0, (int64_t*)ph1, 256 * sgrid, ctx.stream));
             pa.hist = (int64_t*)ph1;
             HIP_TRY(launch_sort_scatter(pa, ctx.stream));
             kcur ^= 1;

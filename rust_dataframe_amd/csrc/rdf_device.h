@@ -139,7 +139,7 @@ struct SortPassArgs {
     const uint64_t* keys_in;  const uint32_t* idx_in;   // idx_in nullptr = identity (first pass)
     uint64_t*       keys_out; uint32_t*       idx_out;
     const uint8_t*  nullflags;                       // digit source of the nulls-last pass (indexed by row), else nullptr
-    int64_t*        hist;                            // [256 * ntiles] digit-major counts, then their exclusive scan
+    int64_t*        hist;                            // [256 * sort_grid] digit-major per-block counts, then their exclusive scan
     int64_t         n, ntiles;
     int32_t         shift;                           // bit offset of this pass's digit in the key
 };
@@ -198,6 +198,7 @@ hipError_t launch_mask_count(const MaskTables& t, int64_t* tile_counts, hipStrea
 hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, hipStream_t s);
 hipError_t launch_compact(const FilterArgs& a, hipStream_t s);
 hipError_t launch_take(const TakeArgs& a, hipStream_t s);
+int  sort_grid(int64_t ntiles);
 hipError_t launch_sort_keys(const SortKeyArgs& a, hipStream_t s);
 hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s);

@@ -417,36 +417,51 @@ __device__ __forceinline__ int sort_digit(const SortPassArgs& a, int64_t i) {
     return (int)((a.keys_in[i] >> a.shift) & 255);
 }
 
+// Block b owns the contiguous tiles [b*tpb, (b+1)*tpb): one histogram row per BLOCK (256 x gridDim entries
+// to scan, a few MB), and the scatter walks its tiles in order carrying the running digit offsets in LDS.
 __global__ __launch_bounds__(kBlock) void sort_hist_kernel(const SortPassArgs a) {
     __shared__ unsigned int h[256];
-    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        h[threadIdx.x] = 0;
-        __syncthreads();
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t tpb = (a.ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * tpb, t1 = t0 + tpb < a.ntiles ? t0 + tpb : a.ntiles;
+    for (int64_t tile = t0; tile < t1; ++tile) {
         const int64_t base = tile * kSortTile;
 #pragma unroll
         for (int j = 0; j < kSortItems; ++j) {
             const int64_t i = base + j * kBlock + threadIdx.x;
             if (i < a.n) atomicAdd(&h[sort_digit(a, i)], 1u);
         }
-        __syncthreads();
-        a.hist[(int64_t)threadIdx.x * a.ntiles + tile] = h[threadIdx.x];
-        __syncthreads();
     }
+    __syncthreads();
+    a.hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
 
 __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs a) {
     __shared__ unsigned short grp[kSortItems * (kBlock / 64)][256];  // count of each digit per (row-of-items, wave) group
+    __shared__ unsigned short dbase[256];                            // tile-local exclusive prefix of the digit totals
+    __shared__ uint64_t lkeys[kSortTile];                            // the tile, locally sorted by digit (stable)
+    __shared__ uint32_t lidx[kSortTile];
+    __shared__ int64_t gbase[256];                                   // running global offset of each digit for this block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    gbase[threadIdx.x] = a.hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x];
+    const int64_t tpb = (a.ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * tpb, t1 = t0 + tpb < a.ntiles ? t0 + tpb : a.ntiles;
+    for (int64_t tile = t0; tile < t1; ++tile) {
         for (int i = threadIdx.x; i < kSortItems * (kBlock / 64) * 256; i += kBlock) (&grp[0][0])[i] = 0;
         __syncthreads();
         const int64_t base = tile * kSortTile;
+        const int count = (int)((a.n - base) < (int64_t)kSortTile ? (a.n - base) : (int64_t)kSortTile);
         int digit[kSortItems], rank[kSortItems];
+        uint64_t key[kSortItems];
+        uint32_t idx[kSortItems];
 #pragma unroll
         for (int j = 0; j < kSortItems; ++j) {
             const int64_t i = base + j * kBlock + threadIdx.x;
             const bool in = i < a.n;
-            const int d = in ? sort_digit(a, i) : 0;
+            key[j] = in ? a.keys_in[i] : 0;
+            idx[j] = in ? (a.idx_in ? a.idx_in[i] : (uint32_t)i) : 0;
+            const int d = in ? (a.nullflags ? (int)a.nullflags[idx[j]] : (int)((key[j] >> a.shift) & 255)) : 0;
             digit[j] = d;
             uint64_t peers = __ballot(in);
 #pragma unroll
@@ -458,21 +473,46 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs
             if (in && rank[j] == 0) grp[j * (kBlock / 64) + wave][d] = (unsigned short)__popcll(peers);  // the group's first holder of d
         }
         __syncthreads();
+        unsigned int total_d;
         {   // thread d: exclusive prefix of digit d's counts over the groups, in item order
             unsigned int run = 0;
 #pragma unroll
             for (int g = 0; g < kSortItems * (kBlock / 64); ++g) { const unsigned int c = grp[g][threadIdx.x]; grp[g][threadIdx.x] = (unsigned short)run; run += c; }
+            total_d = run;
         }
+        // exclusive scan of the 256 digit totals (wave scan + 4 wave sums)
+        unsigned int inc = total_d;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const unsigned int o = __shfl_up(inc, dd); if (lane >= dd) inc += o; }
+        __shared__ unsigned int wsum[kBlock / 64];
+        if (lane == 63) wsum[wave] = inc;
         __syncthreads();
+        unsigned int wb = 0;
+        for (int w = 0; w < wave; ++w) wb += wsum[w];
+        dbase[threadIdx.x] = (unsigned short)(wb + inc - total_d);
+        __syncthreads();
+        // local stable sort by digit into LDS
 #pragma unroll
         for (int j = 0; j < kSortItems; ++j) {
             const int64_t i = base + j * kBlock + threadIdx.x;
             if (i < a.n) {
-                const int64_t dst = a.hist[(int64_t)digit[j] * a.ntiles + tile] + grp[j * (kBlock / 64) + wave][digit[j]] + rank[j];
-                a.keys_out[dst] = a.keys_in[i];
-                a.idx_out[dst] = a.idx_in ? a.idx_in[i] : (uint32_t)i;
+                const int pos = dbase[digit[j]] + grp[j * (kBlock / 64) + wave][digit[j]] + rank[j];
+                lkeys[pos] = key[j];
+                lidx[pos] = idx[j];
             }
         }
+        __syncthreads();
+        // coalesced write-out: consecutive threads hold consecutive members of a digit run
+        for (int t = threadIdx.x; t < count; t += kBlock) {
+            const uint64_t kk = lkeys[t];
+            const uint32_t ii = lidx[t];
+            const int d = a.nullflags ? (int)a.nullflags[ii] : (int)((kk >> a.shift) & 255);
+            const int64_t dst = gbase[d] + (t - dbase[d]);
+            a.keys_out[dst] = kk;
+            a.idx_out[dst] = ii;
+        }
+        __syncthreads();
+        gbase[threadIdx.x] += total_d;  // the next tile of this block continues each digit's run
         __syncthreads();
     }
 }
@@ -811,14 +851,17 @@ hipError_t launch_sort_keys(const SortKeyArgs& a, hipStream_t s) {
     if (grid > 0) hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a, mask);
     return hipGetLastError();
 }
+int sort_grid(int64_t ntiles) {  // both sort kernels must agree on it: it fixes the tile -> block ownership
+    const int64_t lim = (int64_t)eval_grid_limit() / 2;  // 24.5 KiB of LDS per block: 4 blocks per CU
+    const int64_t g = ntiles < lim ? ntiles : lim;
+    return g < 1 ? 1 : (int)g;
+}
 hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s) {
-    int64_t grid = a.ntiles < (int64_t)eval_grid_limit() ? a.ntiles : (int64_t)eval_grid_limit();
-    if (grid > 0) hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(sort_grid(a.ntiles)), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s) {
-    int64_t grid = a.ntiles < (int64_t)eval_grid_limit() ? a.ntiles : (int64_t)eval_grid_limit();
-    if (grid > 0) hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(sort_grid(a.ntiles)), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
