@@ -1308,11 +1308,11 @@ rdf_status filter_prepare(FilterPrep& fp, const rdf_array* cols, int ncols, cons
     fp.mt.ntiles = fp.ntiles;
 
     void* p = nullptr;
-    RDF_TRY(arena_alloc(sizeof(int64_t) * (2 * (size_t)fp.ntiles + 2), &p));
+    RDF_TRY(arena_alloc(sizeof(int64_t) * (2 * (size_t)fp.ntiles + 2 + (size_t)scan_scratch_words(fp.ntiles)), &p));
     fp.d_counts = (int64_t*)p;
     fp.d_scan = fp.d_counts + fp.ntiles;
     HIP_TRY(launch_mask_count(fp.mt, fp.d_counts, ctx.stream));
-    HIP_TRY(launch_scan(fp.d_counts, fp.d_scan, fp.ntiles, ctx.stream));
+    HIP_TRY(launch_scan(fp.d_counts, fp.d_scan, fp.ntiles, fp.d_scan + fp.ntiles + 1, ctx.stream));
 
     // per-chunk totals = scan[tile_start[c+1]] - scan[tile_start[c]]: fetch the nchunks+1 boundary values
     totals.assign((size_t)nchunks, 0);
@@ -1599,7 +1599,7 @@ rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
     RDF_TRY(arena_alloc((size_t)n, &pnf));
     const int64_t sgrid = sort_grid(ntiles);
     RDF_TRY(arena_alloc((size_t)(256 * sgrid + 1) * 8, &ph0));
-    RDF_TRY(arena_alloc((size_t)(256 * sgrid + 1) * 8, &ph1));
+    RDF_TRY(arena_alloc((size_t)(256 * sgrid + 1 + scan_scratch_words(256 * sgrid)) * 8, &ph1));
     uint64_t* keys[2] = {(uint64_t*)pk0, (uint64_t*)pk1};
     uint32_t* idxb[2] = {(uint32_t*)pi0, (uint32_t*)pi1};
     int kcur = 0;               // keys[kcur] holds the current keys
@@ -1637,7 +1637,7 @@ rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
             pa.ntiles = ntiles;
             pa.shift = 8 * p;
             HIP_TRY(launch_sort_hist(pa, ctx.stream));
-            HIP_TRY(launch_scan((const int64_t*)ph0, (int64_t*)ph1, 256 * sgrid, ctx.stream));
+            HIP_TRY(launch_scan((const int64_t*)ph0, (int64_t*)ph1, 256 * sgrid, (int64_t*)ph1 + 256 * sgrid + 1, ctx.stream));
             pa.hist = (int64_t*)ph1;
             HIP_TRY(launch_sort_scatter(pa, ctx.stream));
             kcur ^= 1;

@@ -195,7 +195,8 @@ int  spec_catalog_size();
 hipError_t launch_spec(const char* sig, const SpecArgs& a, int grid, hipStream_t s);
 hipError_t launch_filter_agg_f64(const FilterAggF64Args& a, int cmp_op, int grid, hipStream_t s);
 hipError_t launch_mask_count(const MaskTables& t, int64_t* tile_counts, hipStream_t s);
-hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, hipStream_t s);
+hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, int64_t* scratch, hipStream_t s);
+int64_t scan_scratch_words(int64_t n);
 hipError_t launch_compact(const FilterArgs& a, hipStream_t s);
 hipError_t launch_take(const TakeArgs& a, hipStream_t s);
 int  sort_grid(int64_t ntiles);

@@ -182,34 +182,62 @@ __global__ __launch_bounds__(kBlock) void mask_count_kernel(const MaskTables t, 
     }
 }
 
-// Exclusive scan of n int64 counts into scan[0..n] (scan[n] = total).  One block; each thread owns
-// a contiguous segment (two cached passes over a few MB at most).
+// Exclusive scan of n int64 counts into scan[0..n] (scan[n] = total), hierarchical: every block scans a
+// 4096-entry segment (4 consecutive entries per thread: coalesced 32-byte reads), one block scans the
+// segment totals, a third pass adds the segment offsets.  (A single-block scan of the 48 828 tile counts
+// of a 1e8-row filter took 85 us — a quarter of the whole filter.)
 constexpr int kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void scan_kernel(const int64_t* counts, int64_t* scan, int64_t n) {
-    __shared__ int64_t wave_tot[kScanThreads / 64];
+constexpr int kScanPer = 4;
+constexpr int kScanSeg = kScanThreads * kScanPer;
+
+__device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* wave_tot, int64_t& total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t seg = (n + kScanThreads - 1) / kScanThreads;
-    const int64_t b = (int64_t)tid * seg, e = b + seg < n ? b + seg : n;
-    int64_t s = 0;
-    for (int64_t i = b; i < e; ++i) s += counts[i];
-    int64_t inc = s;
+    int64_t inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, d), hi = (uint32_t)__shfl_up((int)(uint32_t)((uint64_t)inc >> 32), d);
         int64_t o = (int64_t)(((uint64_t)hi << 32) | lo);
         if (lane >= d) inc += o;
     }
+    __syncthreads();
     if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
-    int64_t wbase = 0;
-    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
-    int64_t run = wbase + inc - s;  // exclusive prefix of this thread's segment
-    for (int64_t i = b; i < e; ++i) { scan[i] = run; run += counts[i]; }
-    if (tid == kScanThreads - 1) {
-        int64_t tot = 0;
-        for (int w = 0; w < kScanThreads / 64; ++w) tot += wave_tot[w];
-        scan[n] = tot;
+    int64_t wbase = 0, tot = 0;
+    for (int w = 0; w < kScanThreads / 64; ++w) { if (w < wave) wbase += wave_tot[w]; tot += wave_tot[w]; }
+    total = tot;
+    return wbase + inc - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_segments_kernel(const int64_t* counts, int64_t* scan, int64_t n, int64_t* seg_totals) {
+    __shared__ int64_t wave_tot[kScanThreads / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanSeg + (int64_t)threadIdx.x * kScanPer;
+    int64_t v[kScanPer], s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) { v[j] = base + j < n ? counts[base + j] : 0; s += v[j]; }
+    int64_t total;
+    int64_t run = block_exclusive_scan(s, wave_tot, total);
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) { if (base + j < n) scan[base + j] = run; run += v[j]; }
+    if (threadIdx.x == 0) seg_totals[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kScanThreads) void scan_totals_kernel(int64_t* seg_totals, int64_t nseg, int64_t* grand_total) {
+    __shared__ int64_t wave_tot[kScanThreads / 64];
+    int64_t carry = 0;
+    for (int64_t b = 0; b < nseg; b += kScanThreads) {
+        const int64_t i = b + threadIdx.x;
+        const int64_t v = i < nseg ? seg_totals[i] : 0;
+        int64_t total;
+        const int64_t ex = block_exclusive_scan(v, wave_tot, total);
+        if (i < nseg) seg_totals[i] = carry + ex;
+        carry += total;
     }
+    if (threadIdx.x == 0) *grand_total = carry;
+}
+__global__ __launch_bounds__(kScanThreads) void scan_add_kernel(int64_t* scan, int64_t n, const int64_t* seg_offsets) {
+    const int64_t off = seg_offsets[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * kScanSeg + (int64_t)threadIdx.x * kScanPer;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) if (base + j < n) scan[base + j] += off;
 }
 
 // Compaction of one column of one wave's 512 rows.  Ranks come from popcounts of the wave's keep words
@@ -803,10 +831,15 @@ hipError_t launch_mask_count(const MaskTables& t, int64_t* tile_counts, hipStrea
     if (grid > 0) hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, t, tile_counts);
     return hipGetLastError();
 }
-hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanThreads), 0, s, counts, scan, n);
+// `scratch` holds ceil(n / 4096) + 1 int64 words.
+hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, int64_t* scratch, hipStream_t s) {
+    const int64_t nseg = (n + kScanSeg - 1) / kScanSeg;
+    if (nseg > 0) hipLaunchKernelGGL(scan_segments_kernel, dim3((unsigned)nseg), dim3(kScanThreads), 0, s, counts, scan, n, scratch);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(kScanThreads), 0, s, scratch, nseg, scan + n);
+    if (nseg > 1) hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nseg), dim3(kScanThreads), 0, s, scan, n, scratch);
     return hipGetLastError();
 }
+int64_t scan_scratch_words(int64_t n) { return (n + kScanSeg - 1) / kScanSeg + 2; }
 hipError_t launch_compact(const FilterArgs& a, hipStream_t s) {
     int64_t grid = a.t.ntiles < (int64_t)eval_grid_limit() ? a.t.ntiles : (int64_t)eval_grid_limit();
     if (grid <= 0) return hipSuccess;
