@@ -43,7 +43,8 @@ struct Ctx {
     // tunables (rdf_set_option)
     bool   opt_spec = true;        // specialised straight-line kernels (rdf_spec.hip)
     bool   opt_fast_filter = true; // filter_agg_f64_kernel (handles 8-byte-misaligned columns)
-    bool   opt_vec_bitmap = true;  // bitmap words via vector loads instead of scalar loads (spec kernels)
+    bool   opt_vec_bitmap = true;  // bitmap words via vector loads (default) instead of scalar loads (spec kernels)
+    bool   opt_gb_partition = true; // high-cardinality GROUP BY: radix-partition + LDS aggregation instead of HBM atomics // bitmap words via vector loads instead of scalar loads (spec kernels)
     // kernel timing (bench.py roofline leg)
     bool   timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1707,13 +1708,145 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
     const size_t o_v = tb.reserve(sizeof(DevChunkCol) * (size_t)nchunks);
     const size_t o_ts = tb.reserve(sizeof(int64_t) * tile_start.size());
     const size_t o_len = tb.reserve(sizeof(int64_t) * clen.size());
+    std::vector<int64_t> row_start((size_t)nchunks + 1, 0);
+    for (int64_t c = 0; c < nchunks; ++c) row_start[(size_t)c + 1] = row_start[(size_t)c] + clen[(size_t)c];
+    const size_t o_rs = tb.reserve(sizeof(int64_t) * row_start.size());
     memcpy(tb.at<char>(o_k), in.dev.data(), sizeof(DevChunkCol) * (size_t)nchunks);
     if (values) memcpy(tb.at<char>(o_v), in.dev.data() + nchunks, sizeof(DevChunkCol) * (size_t)nchunks);
     memcpy(tb.at<char>(o_ts), tile_start.data(), sizeof(int64_t) * tile_start.size());
     memcpy(tb.at<char>(o_len), clen.data(), sizeof(int64_t) * clen.size());
+    memcpy(tb.at<char>(o_rs), row_start.data(), sizeof(int64_t) * row_start.size());
     RDF_TRY(tb.alloc());
     RDF_TRY(tb.upload(pin_off));
     pin_off += (tb.host.size() + 255) & ~(size_t)255;
+
+    // High cardinality: radix-partition on the hashed key, aggregate each partition in LDS (no HBM atomics per row).
+    bool value_nulls = false;
+    if (values) for (int64_t c = 0; c < nchunks; ++c) value_nulls |= values[c].validity != nullptr;
+    const int64_t nrows = row_start[(size_t)nchunks];
+    if (ctx.opt_gb_partition && max_groups > 1024 && !value_nulls && nrows > 0) {
+        const int npass = max_groups > 131072 ? 2 : 1;
+        const int64_t stiles = (nrows + kSortTile - 1) / kSortTile;
+        const int64_t sgrid = sort_grid(stiles);
+        void *ph[4], *hist0, *hist1, *ptmp, *pspec;
+        for (int i = 0; i < 4; ++i) RDF_TRY(arena_alloc((size_t)nrows * 8, &ph[i]));
+        RDF_TRY(arena_alloc((size_t)(256 * sgrid + 1) * 8, &hist0));
+        RDF_TRY(arena_alloc((size_t)(256 * sgrid + 1 + scan_scratch_words(256 * sgrid)) * 8, &hist1));
+        const int64_t cap_out = max_groups + 2;
+        RDF_TRY(arena_alloc((size_t)cap_out * 24 + 64, &ptmp));
+        RDF_TRY(arena_alloc(128, &pspec));
+        HIP_TRY(hipMemsetAsync(pspec, 0, 128, ctx.stream));
+        unsigned long long* sp_sums = (unsigned long long*)pspec;         // [2]
+        unsigned long long* sp_counts = sp_sums + 2;                      // [2]
+        unsigned int* sp_flag = (unsigned int*)(sp_counts + 2);           // [2]
+        unsigned int* d_cursor = sp_flag + 2;
+        uint32_t* d_flags2 = (uint32_t*)(sp_flag + 4);
+        GroupPrepArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.keys = tb.dev_at<DevChunkCol>(o_k);
+        pa.values = tb.dev_at<DevChunkCol>(o_v);
+        pa.chunk_tile_start = tb.dev_at<int64_t>(o_ts);
+        pa.chunk_len = tb.dev_at<int64_t>(o_len);
+        pa.chunk_row_start = tb.dev_at<int64_t>(o_rs);
+        pa.nchunks = nchunks;
+        pa.ntiles = tile_start[(size_t)nchunks];
+        pa.key_dtype = kdt;
+        pa.value_dtype = vdt;
+        pa.hkeys = (uint64_t*)ph[0];
+        pa.vals = (uint64_t*)ph[1];
+        pa.special_sums = sp_sums;
+        pa.special_counts = sp_counts;
+        pa.special = sp_flag;
+        KernelTimer kt;
+        HIP_TRY(launch_groupby_prepare(pa, ctx.stream));
+        int cur = 0;  // (ph[cur], ph[cur + 1]) hold the current streams
+        for (int p = 0; p < npass; ++p) {
+            SortPassArgs sa;
+            memset(&sa, 0, sizeof sa);
+            sa.keys_in = (const uint64_t*)ph[cur];
+            sa.pay_in = (const uint64_t*)ph[cur + 1];
+            sa.keys_out = (uint64_t*)ph[cur ^ 2];
+            sa.pay_out = (uint64_t*)ph[(cur ^ 2) + 1];
+            sa.hist = (int64_t*)hist0;
+            sa.n = nrows;
+            sa.ntiles = stiles;
+            sa.shift = 64 - 8 * npass + 8 * p;
+            HIP_TRY(launch_sort_hist64(sa, ctx.stream));
+            HIP_TRY(launch_scan((const int64_t*)hist0, (int64_t*)hist1, 256 * sgrid, (int64_t*)hist1 + 256 * sgrid + 1, ctx.stream));
+            sa.hist = (int64_t*)hist1;
+            HIP_TRY(launch_sort_scatter64(sa, ctx.stream));
+            cur ^= 2;
+        }
+        GroupAggArgs ga;
+        memset(&ga, 0, sizeof ga);
+        ga.hkeys = (const uint64_t*)ph[cur];
+        ga.vals = (const uint64_t*)ph[cur + 1];
+        ga.n = nrows;
+        ga.part_bits = 8 * npass;
+        ga.is_f64 = sdt == RDF_F64;
+        ga.has_values = values != nullptr;
+        ga.key_dtype = kdt;
+        char* tmp = (char*)ptmp;
+        ga.out_keys = tmp;
+        ga.out_sums = tmp + (size_t)cap_out * 8;
+        ga.out_counts = (int64_t*)(tmp + (size_t)cap_out * 16);
+        ga.cursor = d_cursor;
+        ga.flags = d_flags2;
+        ga.max_out = max_groups;
+        HIP_TRY(launch_groupby_partitions(ga, ctx.stream));
+        kt.stop();
+        ctx.last_kernel = "groupby_partitions_kernel";
+        // specials + cursor + flags
+        RDF_TRY(pinned_reserve(pin_off + 256));
+        HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, pspec, 128, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        unsigned long long hs[4];
+        unsigned int hf[8];
+        memcpy(hs, ctx.pinned + pin_off, 32);
+        memcpy(hf, ctx.pinned + pin_off + 32, 32);
+        const int64_t ng_main = hf[2];
+        if ((hf[4] & 4u) || ng_main > max_groups) return fail(RDF_MEMORY_ERROR, "groupby: more than max_groups (%lld) distinct keys", (long long)max_groups);
+        // append the two special groups on the host side of the copy
+        const size_t kes2 = (size_t)dtype_size(kdt);
+        int64_t ng = ng_main;
+        int64_t null_idx = -1;
+        auto put = [&](uint64_t key, unsigned long long sum, unsigned long long cnt) -> rdf_status {
+            HIP_TRY(hipMemcpyAsync((char*)ga.out_keys + (size_t)ng * kes2, &key, kes2, hipMemcpyHostToDevice, ctx.stream));
+            HIP_TRY(hipMemcpyAsync((char*)ga.out_sums + (size_t)ng * 8, &sum, 8, hipMemcpyHostToDevice, ctx.stream));
+            HIP_TRY(hipMemcpyAsync((char*)ga.out_counts + (size_t)ng * 8, &cnt, 8, hipMemcpyHostToDevice, ctx.stream));
+            HIP_TRY(hipStreamSynchronize(ctx.stream));
+            ++ng;
+            return RDF_OK;
+        };
+        if (hf[0]) {  // the key whose hash equals the LDS free marker: unmix on the host
+            uint64_t z = ~0ull;
+            z ^= z >> 31; z ^= z >> 62; z *= 0x319642b2d24d8ec3ull; z ^= z >> 27; z ^= z >> 54; z *= 0x96de1b173f119089ull; z ^= z >> 30; z ^= z >> 60;
+            RDF_TRY(put(z, hs[0], hs[2]));
+        }
+        if (hf[1]) { null_idx = ng; RDF_TRY(put(0, hs[1], hs[3])); }
+        const hipMemcpyKind kind = mem == RDF_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+        if (ng > 0) {
+            HIP_TRY(hipMemcpyAsync(out_keys->values, ga.out_keys, (size_t)ng * kes2, kind, ctx.stream));
+            HIP_TRY(hipMemcpyAsync(out_sums->values, ga.out_sums, (size_t)ng * 8, kind, ctx.stream));
+            HIP_TRY(hipMemcpyAsync(out_counts->values, ga.out_counts, (size_t)ng * 8, kind, ctx.stream));
+        }
+        rdf_out* outs3[3] = {out_keys, out_sums, out_counts};
+        for (rdf_out* o : outs3)
+            if (o->validity && ng > 0) {
+                if (mem == RDF_MEM_HOST) memset(o->validity, 0xFF, (size_t)((ng + 7) / 8));
+                else HIP_TRY(hipMemsetAsync(o->validity, 0xFF, (size_t)((ng + 7) / 8), ctx.stream));
+            }
+        if (null_idx >= 0) {
+            const uint8_t byte = (uint8_t)~(1u << (null_idx & 7));
+            if (mem == RDF_MEM_HOST) out_keys->validity[null_idx >> 3] &= byte;
+            else HIP_TRY(hipMemcpyAsync(out_keys->validity + (null_idx >> 3), &byte, 1, hipMemcpyHostToDevice, ctx.stream));
+        }
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        out_keys->length = out_sums->length = out_counts->length = ng;
+        out_keys->null_count = null_idx >= 0 ? 1 : 0;
+        out_sums->null_count = out_counts->null_count = 0;
+        return RDF_OK;
+    }
 
     int64_t capacity = 1024;
     while (capacity < 2 * max_groups) capacity <<= 1;
@@ -1834,6 +1967,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     if (strcmp(name, "spec") == 0) g_ctx.opt_spec = value != 0;
     else if (strcmp(name, "fast_filter") == 0) g_ctx.opt_fast_filter = value != 0;
     else if (strcmp(name, "vec_bitmap") == 0) g_ctx.opt_vec_bitmap = value != 0;
+    else if (strcmp(name, "gb_partition") == 0) g_ctx.opt_gb_partition = value != 0;
     else return fail(RDF_INVALID_ARGUMENT, "unknown option %s", name);
     return RDF_OK;
 }

@@ -138,10 +138,39 @@ struct SortKeyArgs {                                 // key[i] = order-preservin
 struct SortPassArgs {
     const uint64_t* keys_in;  const uint32_t* idx_in;   // idx_in nullptr = identity (first pass)
     uint64_t*       keys_out; uint32_t*       idx_out;
+    const uint64_t* pay_in;   uint64_t*       pay_out;  // 64-bit payload variant (group-by partitioning); idx_* unused then
     const uint8_t*  nullflags;                       // digit source of the nulls-last pass (indexed by row), else nullptr
     int64_t*        hist;                            // [256 * sort_grid] digit-major per-block counts, then their exclusive scan
     int64_t         n, ntiles;
     int32_t         shift;                           // bit offset of this pass's digit in the key
+};
+
+// Partitioned GROUP BY (high cardinality): keys are replaced by an invertible 64-bit mix, the (hashed key, value)
+// pairs are radix-partitioned on the top hash bits with the sort kernels, and every partition is aggregated
+// in an LDS table and emitted directly.
+struct GroupPrepArgs {
+    const DevChunkCol* keys;             // [nchunks]
+    const DevChunkCol* values;           // [nchunks]
+    const int64_t*     chunk_tile_start; // [nchunks + 1], tiles of kEvalTile rows
+    const int64_t*     chunk_len;
+    const int64_t*     chunk_row_start;  // [nchunks + 1]
+    int64_t            nchunks, ntiles;
+    int32_t            key_dtype, value_dtype;
+    uint64_t*          hkeys;            // [n] out: mix64(key)
+    uint64_t*          vals;             // [n] out: value bits (f64 bits / wrapping i64), 0 when there is no value column
+    unsigned long long* special_sums;    // [2]: rows whose hashed key equals the LDS free marker / rows with a NULL key
+    unsigned long long* special_counts;  // [2]
+    unsigned int*      special;          // [2] group exists
+};
+struct GroupAggArgs {
+    const uint64_t* hkeys; const uint64_t* vals;
+    int64_t         n;
+    int32_t         part_bits;           // partitions = 2^part_bits, partition id = hkey >> (64 - part_bits)
+    int32_t         is_f64, has_values, key_dtype;
+    void*           out_keys; void* out_sums; int64_t* out_counts;
+    unsigned int*   cursor;              // output cursor
+    uint32_t*       flags;               // bit 2: an LDS table overflowed (max_groups was too small for the data)
+    int64_t         max_out;
 };
 
 // Hash GROUP BY key -> {sum(value), count(value)}: open addressing, linear probing, 64-bit keys.
@@ -203,6 +232,10 @@ int  sort_grid(int64_t ntiles);
 hipError_t launch_sort_keys(const SortKeyArgs& a, hipStream_t s);
 hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s);
+hipError_t launch_sort_hist64(const SortPassArgs& a, hipStream_t s);
+hipError_t launch_sort_scatter64(const SortPassArgs& a, hipStream_t s);
+hipError_t launch_groupby_prepare(const GroupPrepArgs& a, hipStream_t s);
+hipError_t launch_groupby_partitions(const GroupAggArgs& a, hipStream_t s);
 hipError_t launch_groupby_build(const GroupByArgs& a, hipStream_t s);
 hipError_t launch_groupby_emit(const GroupEmitArgs& a, hipStream_t s);
 hipError_t launch_fill_f64(double* p, int64_t n, uint64_t seed, uint64_t col, int64_t first_row, double lo, double hi, hipStream_t s);

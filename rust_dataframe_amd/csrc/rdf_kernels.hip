@@ -465,11 +465,12 @@ __global__ __launch_bounds__(kBlock) void sort_hist_kernel(const SortPassArgs a)
     a.hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
 
+template <bool PAY64>
 __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs a) {
     __shared__ unsigned short grp[kSortItems * (kBlock / 64)][256];  // count of each digit per (row-of-items, wave) group
     __shared__ unsigned short dbase[256];                            // tile-local exclusive prefix of the digit totals
     __shared__ uint64_t lkeys[kSortTile];                            // the tile, locally sorted by digit (stable)
-    __shared__ uint32_t lidx[kSortTile];
+    __shared__ typename std::conditional<PAY64, uint64_t, uint32_t>::type lidx[kSortTile];
     __shared__ int64_t gbase[256];                                   // running global offset of each digit for this block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     gbase[threadIdx.x] = a.hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x];
@@ -482,14 +483,15 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs
         const int count = (int)((a.n - base) < (int64_t)kSortTile ? (a.n - base) : (int64_t)kSortTile);
         int digit[kSortItems], rank[kSortItems];
         uint64_t key[kSortItems];
-        uint32_t idx[kSortItems];
+        typename std::conditional<PAY64, uint64_t, uint32_t>::type idx[kSortItems];
 #pragma unroll
         for (int j = 0; j < kSortItems; ++j) {
             const int64_t i = base + j * kBlock + threadIdx.x;
             const bool in = i < a.n;
             key[j] = in ? a.keys_in[i] : 0;
-            idx[j] = in ? (a.idx_in ? a.idx_in[i] : (uint32_t)i) : 0;
-            const int d = in ? (a.nullflags ? (int)a.nullflags[idx[j]] : (int)((key[j] >> a.shift) & 255)) : 0;
+            if (PAY64) idx[j] = in ? a.pay_in[i] : 0;
+            else idx[j] = in ? (a.idx_in ? a.idx_in[i] : (uint32_t)i) : 0;
+            const int d = in ? ((!PAY64 && a.nullflags) ? (int)a.nullflags[idx[j]] : (int)((key[j] >> a.shift) & 255)) : 0;
             digit[j] = d;
             uint64_t peers = __ballot(in);
 #pragma unroll
@@ -533,11 +535,11 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs
         // coalesced write-out: consecutive threads hold consecutive members of a digit run
         for (int t = threadIdx.x; t < count; t += kBlock) {
             const uint64_t kk = lkeys[t];
-            const uint32_t ii = lidx[t];
-            const int d = a.nullflags ? (int)a.nullflags[ii] : (int)((kk >> a.shift) & 255);
+            const auto ii = lidx[t];
+            const int d = (!PAY64 && a.nullflags) ? (int)a.nullflags[ii] : (int)((kk >> a.shift) & 255);
             const int64_t dst = gbase[d] + (t - dbase[d]);
             a.keys_out[dst] = kk;
-            a.idx_out[dst] = ii;
+            if (PAY64) a.pay_out[dst] = ii; else a.idx_out[dst] = (uint32_t)ii;
         }
         __syncthreads();
         gbase[threadIdx.x] += total_d;  // the next tile of this block continues each digit's run
@@ -721,6 +723,118 @@ __device__ __forceinline__ void store_key(void* out, int dt, unsigned idx, uint6
     }
 }
 
+// ---- partitioned GROUP BY (high cardinality) ----
+__device__ __forceinline__ uint64_t unmix64(uint64_t z) {  // inverse of mix64 (it is a bijection on 64 bits)
+    z ^= z >> 31; z ^= z >> 62;
+    z *= 0x319642b2d24d8ec3ull;
+    z ^= z >> 27; z ^= z >> 54;
+    z *= 0x96de1b173f119089ull;
+    z ^= z >> 30; z ^= z >> 60;
+    return z;
+}
+constexpr unsigned long long kHashFree = ~0ull;  // LDS free marker in hashed-key space
+
+// (key, value) columns -> dense (mix64(key), value bits) streams; NULL keys and the one key whose hash is the
+// free marker go to two dedicated accumulators.
+__global__ __launch_bounds__(kBlock) void groupby_prepare_kernel(const GroupPrepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id();
+    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int64_t c = a.nchunks == 1 ? 0 : find_chunk(a.chunk_tile_start, a.nchunks, tile);
+        const int64_t r0 = (tile - a.chunk_tile_start[c]) * kEvalTile;
+        const int64_t clen = a.chunk_len[c];
+        const int64_t g0 = a.chunk_row_start[c];
+        const DevChunkCol kc = a.keys[c];
+        const DevChunkCol vc = a.value_dtype >= 0 ? a.values[c] : DevChunkCol{nullptr, nullptr, 0};
+        const int64_t rw = r0 + (int64_t)wave * (kVPT * 64);
+        uint64_t kvw[kVPT];
+        if (kc.validity) load_windows<kVPT>(kc.validity, kc.offset + rw, clen - rw, kvw);
+#pragma unroll
+        for (int j = 0; j < kVPT; ++j) {
+            const int64_t row = rw + j * 64 + lane;
+            if (row >= clen) continue;
+            const bool kvalid = !kc.validity || ((kvw[j] >> lane) & 1);
+            uint64_t v = 0;
+            if (a.value_dtype == RDF_F64) v = ((const uint64_t*)vc.values)[vc.offset + row];
+            else if (a.value_dtype == RDF_F32) v = d2u((double)((const float*)vc.values)[vc.offset + row]);
+            else if (a.value_dtype >= 0) v = (uint64_t)load_key(vc, a.value_dtype, row);
+            uint64_t hk = mix64((uint64_t)load_key(kc, a.key_dtype, row));
+            const bool is_f = a.value_dtype == RDF_F64 || a.value_dtype == RDF_F32;
+            if (!kvalid || hk == kHashFree) {
+                const int s = kvalid ? 0 : 1;
+                a.special[s] = 1;
+                if (is_f) unsafeAtomicAdd((double*)&a.special_sums[s], u2d(v)); else atomicAdd(&a.special_sums[s], (unsigned long long)v);
+                atomicAdd(&a.special_counts[s], 1ull);
+                // park the row in a partition where it is harmless: hashed key 0 with value 0 would create a bogus group,
+                // so give it the hash of its own neighbour-free marker and let the aggregation skip it
+                hk = kHashFree;
+                v = 0;
+            }
+            a.hkeys[g0 + row] = hk;
+            a.vals[g0 + row] = v;
+        }
+    }
+}
+
+// One block per partition (grid-stride): the partition's rows are a contiguous range of the sorted stream, found
+// by binary search on the top hash bits; its groups live in an LDS table and are written out directly.
+__global__ __launch_bounds__(kBlock) void groupby_partitions_kernel(const GroupAggArgs a) {
+    __shared__ unsigned long long lkeys[kLdsGroups];
+    __shared__ unsigned long long lsums[kLdsGroups];
+    __shared__ unsigned long long lcnts[kLdsGroups];
+    __shared__ unsigned int ngroups_s, obase_s;
+    const int64_t nparts = (int64_t)1 << a.part_bits;
+    const int shift = 64 - a.part_bits;
+    uint32_t err = 0;
+    for (int64_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+        // [lo, hi) = rows whose top bits equal p: lower bounds of p and p+1
+        auto lower_bound = [&](uint64_t part) -> int64_t {
+            if (part >= (uint64_t)nparts) return a.n;
+            int64_t lo = 0, hi = a.n;
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((a.hkeys[mid] >> shift) < part) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        const int64_t lo = lower_bound((uint64_t)p), hi = lower_bound((uint64_t)p + 1);
+        if (hi <= lo) continue;
+        for (int i = threadIdx.x; i < kLdsGroups; i += kBlock) { lkeys[i] = kHashFree; lsums[i] = 0; lcnts[i] = 0; }
+        if (threadIdx.x == 0) ngroups_s = 0;
+        __syncthreads();
+        for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+            const uint64_t hk = a.hkeys[i];
+            if (hk == kHashFree) continue;  // parked special rows
+            const uint64_t v = a.vals[i];
+            uint32_t s = (uint32_t)(hk >> 7) & (kLdsGroups - 1);  // bits below the partition bits are still well mixed
+            int slot = -1;
+            for (int probes = 0; probes < kLdsGroups; ++probes) {
+                const unsigned long long old = atomicCAS(&lkeys[s], kHashFree, (unsigned long long)hk);
+                if (old == kHashFree) { atomicAdd(&ngroups_s, 1u); slot = (int)s; break; }
+                if (old == hk) { slot = (int)s; break; }
+                s = (s + 1) & (kLdsGroups - 1);
+            }
+            if (slot < 0) { err |= 4u; continue; }
+            if (a.has_values) {
+                if (a.is_f64) unsafeAtomicAdd((double*)&lsums[slot], u2d(v)); else atomicAdd(&lsums[slot], (unsigned long long)v);
+            }
+            atomicAdd(&lcnts[slot], 1ull);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) obase_s = atomicAdd(a.cursor, ngroups_s);
+        __syncthreads();
+        if (threadIdx.x == 0) ngroups_s = 0;  // reused as the local emit cursor
+        __syncthreads();
+        for (int i = threadIdx.x; i < kLdsGroups; i += kBlock) {
+            if (lkeys[i] == kHashFree) continue;
+            const unsigned idx = obase_s + atomicAdd(&ngroups_s, 1u);
+            if ((int64_t)idx >= a.max_out) { err |= 4u; continue; }
+            store_key(a.out_keys, a.key_dtype, idx, unmix64(lkeys[i]));
+            ((uint64_t*)a.out_sums)[idx] = lsums[i];
+            a.out_counts[idx] = (int64_t)lcnts[i];
+        }
+        __syncthreads();
+    }
+    if (err) atomicOr(a.flags, err);
+}
+
 // Occupied slots -> dense outputs (order = claim order of the output cursor, i.e. unspecified).
 __global__ __launch_bounds__(kBlock) void groupby_emit_kernel(const GroupEmitArgs a) {
     const int64_t n = a.t.capacity + 2;
@@ -894,7 +1008,12 @@ hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(sort_grid(a.ntiles)), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((sort_scatter_kernel<false>), dim3(sort_grid(a.ntiles)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_sort_hist64(const SortPassArgs& a, hipStream_t s) { return launch_sort_hist(a, s); }
+hipError_t launch_sort_scatter64(const SortPassArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((sort_scatter_kernel<true>), dim3(sort_grid(a.ntiles)), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
@@ -903,6 +1022,18 @@ hipError_t launch_groupby_build(const GroupByArgs& a, hipStream_t s) {
     if (grid <= 0) return hipSuccess;
     if (a.max_groups <= kLdsGroups / 2) hipLaunchKernelGGL(groupby_build_lds_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL(groupby_build_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_groupby_prepare(const GroupPrepArgs& a, hipStream_t s) {
+    int64_t grid = a.ntiles < (int64_t)eval_grid_limit() ? a.ntiles : (int64_t)eval_grid_limit();
+    if (grid > 0) hipLaunchKernelGGL(groupby_prepare_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_groupby_partitions(const GroupAggArgs& a, hipStream_t s) {
+    int64_t grid = (int64_t)1 << a.part_bits;
+    const int64_t lim = 3 * (int64_t)eval_grid_limit() / 8;  // 48 KiB of LDS per block: 3 blocks per CU
+    if (grid > lim) grid = lim;
+    hipLaunchKernelGGL(groupby_partitions_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_groupby_emit(const GroupEmitArgs& a, hipStream_t s) {

@@ -416,3 +416,35 @@ def test_sort_to_indices(gpu, ora, dtype):
                 got = gpu.sort_to_indices(cols, d).to_numpy()
                 exp = ora.sort_to_indices(cols, d).to_numpy()
                 assert np.array_equal(got, exp), f"sort dtype={dtype} lens={lens} desc={d} ncols={len(cols)}"
+
+
+@pytest.mark.parametrize("ngroups,n", [(20_000, 150_000), (300_000, 700_000)])
+def test_groupby_partitioned_high_cardinality(gpu, ora, ngroups, n):
+    """More than 1024 groups: hashed keys are radix-partitioned (1 or 2 passes) and aggregated per partition in LDS.
+    NULL keys, the free-marker keys of both tables, multi-chunk input with offsets; both value classes."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(ngroups)
+    lens = [n // 3, 0, n - n // 3]
+    for val_dtype in (A.F64, A.I64, None):
+        keys, vals = [], ([] if val_dtype is not None else None)
+        for ln in lens:
+            kv = rng.integers(-ngroups // 2, ngroups // 2, ln).astype(np.int64)
+            if ln > 4:
+                kv[0], kv[1] = np.iinfo(np.int64).min, np.iinfo(np.int64).max
+                kv[2] = np.int64(-3487469807577879104)  # mix64(key) == 2^64 - 1, the LDS free marker of the partition tables
+            keys.append(A.HostArray.from_numpy(kv, valid=rng.uniform(size=ln) >= 0.01, offset=5, rng=rng))
+            if val_dtype is not None:
+                vals.append(A.HostArray.from_numpy(rng.uniform(-1, 1, ln) if val_dtype == A.F64 else rng.integers(-10 ** 9, 10 ** 9, ln), offset=2, dtype=val_dtype, rng=rng))
+        exp = _sorted_groups(*ora.groupby_sum(keys, vals, ngroups + 8))
+        for part in (1, 0):  # partitioned path, then the HBM-atomics path on the same data
+            lib.set_option("gb_partition", part)
+            got = _sorted_groups(*gpu.groupby_sum(keys, vals, ngroups + 8))
+            if part:
+                assert lib.last_kernel() == "groupby_partitions_kernel"
+            assert np.array_equal(got[1], exp[1]) and np.array_equal(got[0][exp[1]], exp[0][exp[1]]), f"keys part={part}"
+            assert np.array_equal(got[3], exp[3]), f"counts part={part}"
+            if val_dtype == A.F64:
+                np.testing.assert_allclose(got[2], exp[2], rtol=1e-6, atol=1e-9)
+            else:
+                assert np.array_equal(got[2], exp[2])
+        lib.set_option("gb_partition", 1)

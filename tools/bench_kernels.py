@@ -153,6 +153,10 @@ def main():
         KK = arr(kk, A.I64, n)
         ok_, os_, oc_ = out_like(A.I64, ng + 2), out_like(A.F64, ng + 2), out_like(A.I64, ng + 2)
         report(f"groupby_sum_{ng}_groups", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
+        if ng > 1024:
+            lib.set_option("gb_partition", 0)
+            report(f"groupby_sum_{ng}_groups_hbm_atomics", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
+            lib.set_option("gb_partition", 1)
     # A/B in one process: the specialised template kernel vs the dedicated filter_agg_f64 kernel on the headline shape
     for rep in range(3):
         lib.set_option("spec", 1)
