@@ -825,6 +825,26 @@ class DataFrame {
         }
         return DataFrame(schema_, std::move(result));
     }
+    // DataFrame::join (:626-719): equi-join indices on ONE key column per side, then Column::take of every column
+    // of both frames (left columns first).  JoinType as src/expression.rs:339-345.
+    enum class JoinType { LeftJoin = RDF_JOIN_LEFT, RightJoin = RDF_JOIN_RIGHT, InnerJoin = RDF_JOIN_INNER, FullJoin = RDF_JOIN_FULL };
+    struct JoinCriteria { JoinType join_type; std::vector<std::pair<std::string, std::string>> criteria; };
+    DataFrame join(const DataFrame& other, const JoinCriteria& jc) const {
+        if (jc.criteria.size() != 1) throw DataFrameError(DataFrameError::ComputeError, "join: one key column per side on the accelerated path");
+        const auto lk = column_by_name(jc.criteria[0].first).data().views();
+        const auto rk = other.column_by_name(jc.criteria[0].second).data().views();
+        int64_t rows = 0;
+        check(rdf_equijoin_indices(lk.data(), (int64_t)lk.size(), rk.data(), (int64_t)rk.size(), (int32_t)jc.join_type, nullptr, nullptr, &rows));
+        auto li = Array::make_out(DataType::UInt32, rows, true), ri = Array::make_out(DataType::UInt32, rows, true);
+        rdf_out lo = li->out_view(rows), ro = ri->out_view(rows);
+        check(rdf_equijoin_indices(lk.data(), (int64_t)lk.size(), rk.data(), (int64_t)rk.size(), (int32_t)jc.join_type, &lo, &ro, &rows));
+        li->length = ri->length = rows;
+        li->null_count = lo.null_count; ri->null_count = ro.null_count;
+        std::vector<Column> cols;
+        for (auto& c : columns_) cols.push_back(c.take(li, 4096));
+        for (auto& c : other.columns_) cols.push_back(c.take(ri, 4096));
+        return DataFrame::from_columns(cols);
+    }
     // DataFrame::sort (:194-214): lexsort_to_indices over the criteria columns, then sort_by_indices.
     // nulls_first is accepted and ignored exactly like the reference does (:208).
     struct SortCriteria { std::string column; bool descending = false; bool nulls_first = false; };

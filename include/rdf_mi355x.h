@@ -199,6 +199,23 @@ typedef struct { int32_t descending; int32_t nulls_first; } rdf_sort_options;
 rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nchunks, const rdf_sort_options* opts,
                                rdf_out* out_indices);
 
+/* ------------------------------------------------------------------ join */
+
+typedef enum { RDF_JOIN_LEFT = 0, RDF_JOIN_RIGHT = 1, RDF_JOIN_INNER = 2, RDF_JOIN_FULL = 3 } rdf_join_type;  /* JoinType, src/expression.rs:339-345 */
+
+/* calc_equijoin_indices (src/functions/join.rs:19-137) for ONE numeric key column per side (same dtype: the
+ * caller casts first, as join.rs:17-18 says): the (left row, right row) pairs of the equi-join, as two
+ * UInt32 index arrays with NULL where a side has no partner — exactly what DataFrame::join feeds to
+ * Column::take (src/dataframe.rs:705-711).  NULL keys never match; LEFT/RIGHT/FULL keep them with a
+ * NULL partner.  FULL is a true full outer join (the reference's FullJoin arm drops unmatched non-NULL
+ * rows: not copied).  Pair order: probe rows ascending, partners ascending, then (FULL) the unmatched
+ * build rows in unspecified order — the reference's order is HashMap iteration order.
+ * *out_rows = rows of the result; with out_left == out_right == NULL only the count is computed;
+ * capacity too small -> RDF_MEMORY_ERROR with *out_rows set. */
+rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks, const rdf_array* right_keys,
+                                int64_t right_nchunks, int32_t join_type, rdf_out* out_left, rdf_out* out_right,
+                                int64_t* out_rows);
+
 /* ------------------------------------------------------------------ group-by */
 
 /* Transformation::GroupAggregate(groups, [Sum, Count]) for ONE integer key column — planned by

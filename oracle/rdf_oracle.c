@@ -984,6 +984,60 @@ rdf_status ora_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
     return st;
 }
 
+/* ------------------------------------------------------------------ join
+ * calc_equijoin_indices (src/functions/join.rs:19-137): build HashMap<key bytes, Vec<row>> per side
+ * (build_hash_inputs :139-215; rows with a NULL criterion go to the `nulls` lists), then per join type emit
+ * (Some(l), Some(r)) for every pair of rows sharing a key, (Some(l), None) / (None, Some(r)) for the outer
+ * side's rows without a partner and for its NULL-key rows.  Restated with nested loops over the rows
+ * (quadratic, test sizes only) in a deterministic order: probe rows ascending, partners ascending, then —
+ * FULL — the unmatched build rows ascending.  FullJoin is implemented as a true full outer join (the
+ * reference's arm forgets the unmatched non-NULL rows). */
+static void join_locate(const rdf_array* chunks, int64_t nchunks, int64_t row, const rdf_array** a, int64_t* i) {
+    int64_t c = 0;
+    while (c + 1 < nchunks && row >= chunks[c].length) { row -= chunks[c].length; c++; }
+    *a = &chunks[c]; *i = row;
+}
+rdf_status ora_equijoin_indices(const rdf_array* lk, int64_t lnc, const rdf_array* rk, int64_t rnc, int32_t jt,
+                                rdf_out* out_left, rdf_out* out_right, int64_t* out_rows) {
+    int64_t nl = 0, nr = 0;
+    for (int64_t c = 0; c < lnc; c++) nl += lk[c].length;
+    for (int64_t c = 0; c < rnc; c++) nr += rk[c].length;
+    int swap = jt == RDF_JOIN_RIGHT, outer = jt != RDF_JOIN_INNER, full = jt == RDF_JOIN_FULL;
+    const rdf_array* pk = swap ? rk : lk; const rdf_array* bk = swap ? lk : rk;
+    int64_t pnc = swap ? rnc : lnc, bnc = swap ? lnc : rnc, np = swap ? nr : nl, nb = swap ? nl : nr;
+    uint64_t* bbits = (uint64_t*)malloc((size_t)(nb + 1) * 8); uint8_t* bnull = (uint8_t*)calloc((size_t)nb + 1, 1);
+    uint8_t* bmatched = (uint8_t*)calloc((size_t)nb + 1, 1);
+    for (int64_t j = 0; j < nb; j++) { const rdf_array* a; int64_t i; int w; join_locate(bk, bnc, j, &a, &i); bnull[j] = !arr_valid(a, i); bbits[j] = sort_bits(a, i, &w); }
+    rdf_out* op = swap ? out_right : out_left; rdf_out* ob = swap ? out_left : out_right;
+    int64_t rows = 0; rdf_status st = RDF_OK;
+    for (int pass = 0; pass < 2 && st == RDF_OK; pass++) {   /* pass 0 counts, pass 1 writes */
+        if (pass == 1) {
+            *out_rows = rows;
+            if (!out_left) break;
+            if (out_left->capacity < rows || out_right->capacity < rows) { st = RDF_MEMORY_ERROR; snprintf(g_err, sizeof g_err, "join: output capacity too small"); break; }
+            if ((outer && !ob->validity) || (full && !op->validity)) { st = RDF_INVALID_ARGUMENT; snprintf(g_err, sizeof g_err, "output validity buffer required"); break; }
+            out_begin(op, rows); out_begin(ob, rows);
+        }
+        int64_t o = 0;
+        for (int64_t x = 0; x < np; x++) {
+            const rdf_array* a; int64_t i; int w; join_locate(pk, pnc, x, &a, &i);
+            int pn = !arr_valid(a, i); uint64_t bits = sort_bits(a, i, &w); int64_t m = 0;
+            if (!pn) for (int64_t j = 0; j < nb; j++) if (!bnull[j] && bbits[j] == bits) {
+                if (pass == 1) { ((uint32_t*)op->values)[o] = (uint32_t)x; ((uint32_t*)ob->values)[o] = (uint32_t)j; }
+                bmatched[j] = 1; o++; m++;
+            }
+            if (m == 0 && outer) { if (pass == 1) { ((uint32_t*)op->values)[o] = (uint32_t)x; ((uint32_t*)ob->values)[o] = 0; out_null(ob, o); } o++; }
+        }
+        if (full) for (int64_t j = 0; j < nb; j++) if (!bmatched[j]) {
+            if (pass == 1) { ((uint32_t*)op->values)[o] = 0; ((uint32_t*)ob->values)[o] = (uint32_t)j; out_null(op, o); }
+            o++;
+        }
+        rows = o;
+    }
+    free(bbits); free(bnull); free(bmatched);
+    return st;
+}
+
 /* ------------------------------------------------------------------ group-by
  * Transformation::GroupAggregate has a schema (Dataset::try_aggregate, src/expression.rs:114-221) but no
  * execution in the reference (src/evaluation.rs:73: panic!("aggregations not supported")): PARITY

@@ -284,7 +284,7 @@ class Api:
         self._err = getattr(lib, prefix + "last_error")
         self._err.restype = C.c_char_p
         for name in ("binary", "unary", "cast", "sum", "min", "max", "count", "avg", "predicate", "filter_count",
-                     "filter", "filter_columns", "take", "pipeline", "groupby_sum", "sort_to_indices", "fill_uniform_f64",
+                     "filter", "filter_columns", "take", "pipeline", "groupby_sum", "sort_to_indices", "equijoin_indices", "fill_uniform_f64",
                      "fill_uniform_i64", "fill_validity"):
             fn = getattr(lib, prefix + name)
             fn.restype = C.c_int
@@ -456,6 +456,22 @@ class Api:
         carr = (rdf_out * 1)(out.out_struct())
         self._check(self._fn("sort_to_indices")(_flat(cols, nchunks), C.c_int32(len(cols)), C.c_int64(nchunks), opts, carr))
         return self._finish([out], carr)[0]
+
+    # ---- join (calc_equijoin_indices)
+    JOIN_TYPES = {"left": 0, "right": 1, "inner": 2, "full": 3}
+
+    def equijoin_indices(self, left_keys: Sequence, right_keys: Sequence, how: str):
+        """-> (left_indices, right_indices): UInt32 arrays with None where a side has no partner."""
+        jt = self.JOIN_TYPES[how]
+        rows = C.c_int64(0)
+        lk, rk = _flat([left_keys], len(left_keys)), _flat([right_keys], len(right_keys))
+        self._check(self._fn("equijoin_indices")(lk, C.c_int64(len(left_keys)), rk, C.c_int64(len(right_keys)), C.c_int32(jt), None, None, C.byref(rows)))
+        ol, orr = HostArray.empty_out(U32, rows.value, True), HostArray.empty_out(U32, rows.value, True)
+        cl, cr = (rdf_out * 1)(ol.out_struct()), (rdf_out * 1)(orr.out_struct())
+        self._check(self._fn("equijoin_indices")(lk, C.c_int64(len(left_keys)), rk, C.c_int64(len(right_keys)), C.c_int32(jt), cl, cr, C.byref(rows)))
+        self._finish([ol], cl)
+        self._finish([orr], cr)
+        return ol, orr
 
     # ---- group-by (Transformation::GroupAggregate with one integer key; SQL semantics)
     def groupby_sum(self, keys: Sequence, values: Optional[Sequence], max_groups: int, outs=None):

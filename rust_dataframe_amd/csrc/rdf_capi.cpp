@@ -1661,6 +1661,239 @@ rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
     return RDF_OK;
 }
 
+// ---------------------------------------------------------------- join
+
+namespace {
+// Radix-sort (key bits, row) pairs already produced by sort_keys_kernel: `width` key bytes, then the nulls-last pass.
+struct SortBuffers { uint64_t* keys[2]; uint32_t* idx[2]; void* nullflags; void* hist0; void* hist1; int64_t sgrid, ntiles; };
+rdf_status sort_buffers_alloc(int64_t n, SortBuffers& b) {
+    b.ntiles = (n + kSortTile - 1) / kSortTile;
+    b.sgrid = sort_grid(b.ntiles);
+    void* p;
+    for (int i = 0; i < 2; ++i) { RDF_TRY(arena_alloc((size_t)n * 8 + 8, &p)); b.keys[i] = (uint64_t*)p; }
+    for (int i = 0; i < 2; ++i) { RDF_TRY(arena_alloc((size_t)n * 4 + 8, &p)); b.idx[i] = (uint32_t*)p; }
+    RDF_TRY(arena_alloc((size_t)n + 8, &b.nullflags));
+    RDF_TRY(arena_alloc((size_t)(256 * b.sgrid + 1) * 8, &b.hist0));
+    RDF_TRY(arena_alloc((size_t)(256 * b.sgrid + 1 + scan_scratch_words(256 * b.sgrid)) * 8, &b.hist1));
+    return RDF_OK;
+}
+// keys[0] holds the unsorted key bits (identity order).  On return keys[*kcur] / idx[*icur] are sorted.
+rdf_status radix_sort_rows(const SortBuffers& b, int64_t n, int width, bool has_nulls, int* kcur_out, int* icur_out) {
+    Ctx& ctx = g_ctx;
+    int kcur = 0, icur = 1;
+    const uint32_t* idx_cur = nullptr;
+    const int npass = width + (has_nulls ? 1 : 0);
+    for (int p = 0; p < npass; ++p) {
+        SortPassArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.keys_in = b.keys[kcur];
+        pa.idx_in = idx_cur;
+        pa.keys_out = b.keys[kcur ^ 1];
+        pa.idx_out = b.idx[icur ^ 1];
+        pa.nullflags = p == width ? (const uint8_t*)b.nullflags : nullptr;
+        pa.hist = (int64_t*)b.hist0;
+        pa.n = n;
+        pa.ntiles = b.ntiles;
+        pa.shift = 8 * p;
+        HIP_TRY(launch_sort_hist(pa, ctx.stream));
+        HIP_TRY(launch_scan((const int64_t*)b.hist0, (int64_t*)b.hist1, 256 * b.sgrid, (int64_t*)b.hist1 + 256 * b.sgrid + 1, ctx.stream));
+        pa.hist = (int64_t*)b.hist1;
+        HIP_TRY(launch_sort_scatter(pa, ctx.stream));
+        kcur ^= 1;
+        icur ^= 1;
+        idx_cur = b.idx[icur];
+    }
+    *kcur_out = kcur;
+    *icur_out = icur;
+    return RDF_OK;
+}
+}  // namespace
+
+rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks, const rdf_array* right_keys, int64_t right_nchunks,
+                                int32_t join_type, rdf_out* out_left, rdf_out* out_right, int64_t* out_rows) {
+    if (!left_keys || !right_keys || left_nchunks < 1 || right_nchunks < 1 || !out_rows) return fail(RDF_INVALID_ARGUMENT, "join: bad arguments");
+    if (join_type < RDF_JOIN_LEFT || join_type > RDF_JOIN_FULL) return fail(RDF_INVALID_ARGUMENT, "join: bad join type");
+    if ((out_left == nullptr) != (out_right == nullptr)) return fail(RDF_INVALID_ARGUMENT, "join: give both outputs or neither (count only)");
+    int32_t mem = -1;
+    RDF_TRY(check_mem(left_keys, left_nchunks, &mem));
+    RDF_TRY(check_mem(right_keys, right_nchunks, &mem));
+    if (out_left) { RDF_TRY(check_out_mem(out_left, 1, mem)); RDF_TRY(check_out_mem(out_right, 1, mem)); }
+    const int dt = left_keys[0].dtype;
+    if (!is_numeric(dt)) return fail(RDF_INVALID_ARGUMENT, "join: numeric key columns only");
+    int64_t nleft = 0, nright = 0;
+    bool lnulls = false, rnulls = false;
+    for (int64_t c = 0; c < left_nchunks; ++c) { if (left_keys[c].dtype != dt) return fail(RDF_INVALID_ARGUMENT, "join: key columns must share one dtype (cast first)"); nleft += left_keys[c].length; lnulls |= left_keys[c].validity != nullptr; }
+    for (int64_t c = 0; c < right_nchunks; ++c) { if (right_keys[c].dtype != dt) return fail(RDF_INVALID_ARGUMENT, "join: key columns must share one dtype (cast first)"); nright += right_keys[c].length; rnulls |= right_keys[c].validity != nullptr; }
+    if (nleft >= (int64_t)1 << 32 || nright >= (int64_t)1 << 32) return fail(RDF_INVALID_ARGUMENT, "join: UInt32 indices cap a side at 2^32-1 rows");
+    if (out_left && (out_left->dtype != RDF_U32 || out_right->dtype != RDF_U32)) return fail(RDF_INVALID_ARGUMENT, "join: indices are UInt32");
+    const bool swap = join_type == RDF_JOIN_RIGHT;  // probe = right, build = left
+    const rdf_array* pk = swap ? right_keys : left_keys;
+    const rdf_array* bk = swap ? left_keys : right_keys;
+    const int64_t pnc = swap ? right_nchunks : left_nchunks, bnc = swap ? left_nchunks : right_nchunks;
+    const int64_t np = swap ? nright : nleft, nb = swap ? nleft : nright;
+    const bool pnulls = swap ? rnulls : lnulls, bnulls = swap ? lnulls : rnulls;
+    const bool outer = join_type != RDF_JOIN_INNER;
+    const bool full = join_type == RDF_JOIN_FULL;
+    if (np == 0 && (!full || nb == 0)) {
+        *out_rows = 0;
+        if (out_left) { out_left->length = out_right->length = 0; out_left->null_count = out_right->null_count = 0; }
+        return RDF_OK;
+    }
+    RDF_TRY(ensure_ready());
+    Ctx& ctx = g_ctx;
+    arena_begin();
+    size_t pin_off = 0, used = 0;
+    InputStager in;
+    for (int64_t c = 0; c < pnc; ++c) in.add(&pk[c]);
+    for (int64_t c = 0; c < bnc; ++c) in.add(&bk[c]);
+    RDF_TRY(in.finish(pin_off, &used));
+    pin_off += (used + 255) & ~(size_t)255;
+    std::vector<int64_t> prs((size_t)pnc + 1, 0), brs((size_t)bnc + 1, 0);
+    for (int64_t c = 0; c < pnc; ++c) prs[(size_t)c + 1] = prs[(size_t)c] + pk[c].length;
+    for (int64_t c = 0; c < bnc; ++c) brs[(size_t)c + 1] = brs[(size_t)c] + bk[c].length;
+    TableBuilder tb;
+    const size_t o_ch = tb.reserve(sizeof(DevChunkCol) * in.dev.size());
+    const size_t o_prs = tb.reserve(sizeof(int64_t) * prs.size());
+    const size_t o_brs = tb.reserve(sizeof(int64_t) * brs.size());
+    memcpy(tb.at<char>(o_ch), in.dev.data(), sizeof(DevChunkCol) * in.dev.size());
+    memcpy(tb.at<char>(o_prs), prs.data(), sizeof(int64_t) * prs.size());
+    memcpy(tb.at<char>(o_brs), brs.data(), sizeof(int64_t) * brs.size());
+    RDF_TRY(tb.alloc());
+    RDF_TRY(tb.upload(pin_off));
+    pin_off += (tb.host.size() + 255) & ~(size_t)255;
+
+    // build side: key bits + null flags, sorted (NULL keys last)
+    SortBuffers sb;
+    RDF_TRY(sort_buffers_alloc(nb > 0 ? nb : 1, sb));
+    void* p;
+    RDF_TRY(arena_alloc(64, &p));
+    unsigned long long* d_cnt = (unsigned long long*)p;  // [0] build nulls, [1] append cursor
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 64, ctx.stream));
+    KernelTimer kt;
+    int kcur = 0, icur = 0;
+    if (nb > 0) {
+        SortKeyArgs ka;
+        memset(&ka, 0, sizeof ka);
+        ka.chunks = tb.dev_at<DevChunkCol>(o_ch) + (size_t)pnc;
+        ka.chunk_row_start = tb.dev_at<int64_t>(o_brs);
+        ka.nchunks = bnc;
+        ka.n = nb;
+        ka.keys = sb.keys[0];
+        ka.nullflags = bnulls ? (uint8_t*)sb.nullflags : nullptr;
+        ka.dtype = dt;
+        HIP_TRY(launch_sort_keys(ka, ctx.stream));
+        if (bnulls) HIP_TRY(launch_count_bytes((const uint8_t*)sb.nullflags, nb, d_cnt, ctx.stream));
+        RDF_TRY(radix_sort_rows(sb, nb, dtype_size(dt), bnulls, &kcur, &icur));
+    }
+    // probe side: key bits + null flags in row order
+    void *ppk, *ppn, *pcounts, *poffs;
+    RDF_TRY(arena_alloc((size_t)(np > 0 ? np : 1) * 8, &ppk));
+    RDF_TRY(arena_alloc((size_t)(np > 0 ? np : 1) + 8, &ppn));
+    RDF_TRY(arena_alloc((size_t)(np + 1) * 8, &pcounts));
+    RDF_TRY(arena_alloc((size_t)(np + 2 + scan_scratch_words(np)) * 8, &poffs));
+    if (np > 0) {
+        SortKeyArgs ka;
+        memset(&ka, 0, sizeof ka);
+        ka.chunks = tb.dev_at<DevChunkCol>(o_ch);
+        ka.chunk_row_start = tb.dev_at<int64_t>(o_prs);
+        ka.nchunks = pnc;
+        ka.n = np;
+        ka.keys = (uint64_t*)ppk;
+        ka.nullflags = pnulls ? (uint8_t*)ppn : nullptr;
+        ka.dtype = dt;
+        HIP_TRY(launch_sort_keys(ka, ctx.stream));
+    }
+    RDF_TRY(pinned_reserve(pin_off + 256));
+    HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, d_cnt, 8, hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    unsigned long long bnull_count = 0;
+    memcpy(&bnull_count, ctx.pinned + pin_off, 8);
+    const int64_t nrv = nb - (int64_t)bnull_count;
+
+    void* pmatched = nullptr;
+    if (full) { RDF_TRY(arena_alloc((size_t)((nb + 31) / 32 + 1) * 4, &pmatched)); HIP_TRY(hipMemsetAsync(pmatched, 0, (size_t)((nb + 31) / 32 + 1) * 4, ctx.stream)); }
+    JoinProbeArgs ja;
+    memset(&ja, 0, sizeof ja);
+    ja.lkeys = (const uint64_t*)ppk;
+    ja.lnull = pnulls ? (const uint8_t*)ppn : nullptr;
+    ja.rkeys = sb.keys[kcur];
+    ja.ridx = sb.idx[icur];
+    ja.nl = np;
+    ja.nrv = nrv;
+    ja.outer = outer;
+    ja.counts = (int64_t*)pcounts;
+    ja.matched = (uint32_t*)pmatched;
+    ja.unmatched = d_cnt + 2;
+    HIP_TRY(launch_join_count(ja, ctx.stream));
+    HIP_TRY(launch_scan((const int64_t*)pcounts, (int64_t*)poffs, np, (int64_t*)poffs + np + 1, ctx.stream));
+    JoinAppendArgs aa;
+    memset(&aa, 0, sizeof aa);
+    if (full) {
+        aa.ridx = sb.idx[icur];
+        aa.matched = (const uint32_t*)pmatched;
+        aa.nr = nb;
+        aa.nrv = nrv;
+        aa.cursor = d_cnt + 1;
+        aa.count_only = 1;
+        HIP_TRY(launch_join_append(aa, ctx.stream));
+    }
+    HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, (int64_t*)poffs + np, 8, hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off + 8, d_cnt + 1, 16, hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    int64_t probe_rows = 0;
+    unsigned long long appended = 0, unmatched = 0;
+    memcpy(&probe_rows, ctx.pinned + pin_off, 8);
+    memcpy(&appended, ctx.pinned + pin_off + 8, 8);
+    memcpy(&unmatched, ctx.pinned + pin_off + 16, 8);
+    const int64_t total = probe_rows + (int64_t)appended;
+    *out_rows = total;
+    if (!out_left) { kt.stop(); return RDF_OK; }
+    if (out_left->capacity < total || out_right->capacity < total) return fail(RDF_MEMORY_ERROR, "join: output capacity too small (need %lld rows)", (long long)total);
+    rdf_out* out_probe = swap ? out_right : out_left;
+    rdf_out* out_build = swap ? out_left : out_right;
+    if ((outer && !out_build->validity) || (full && !out_probe->validity)) return fail(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    // device outputs
+    const size_t words = (size_t)((total + 31) / 32 + 2);
+    void *dop, *dob, *dvp, *dvb;
+    RDF_TRY(arena_alloc((size_t)(total + 1) * 4, &dop));
+    RDF_TRY(arena_alloc((size_t)(total + 1) * 4, &dob));
+    RDF_TRY(arena_alloc(words * 4, &dvp));
+    RDF_TRY(arena_alloc(words * 4, &dvb));
+    HIP_TRY(hipMemsetAsync(dvp, 0xFF, words * 4, ctx.stream));
+    HIP_TRY(hipMemsetAsync(dvb, 0xFF, words * 4, ctx.stream));
+    ja.offsets = (const int64_t*)poffs;
+    ja.out_probe = (uint32_t*)dop;
+    ja.out_build = (uint32_t*)dob;
+    ja.out_build_validity = (uint32_t*)dvb;
+    ja.matched = nullptr;
+    HIP_TRY(launch_join_write(ja, ctx.stream));
+    if (full) {
+        unsigned long long start = (unsigned long long)probe_rows;
+        HIP_TRY(hipMemcpyAsync(d_cnt + 1, &start, 8, hipMemcpyHostToDevice, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        aa.count_only = 0;
+        aa.out_probe = (uint32_t*)dop;
+        aa.out_build = (uint32_t*)dob;
+        aa.out_probe_validity = (uint32_t*)dvp;
+        HIP_TRY(launch_join_append(aa, ctx.stream));
+    }
+    kt.stop();
+    ctx.last_kernel = "join_write_kernel";
+    const hipMemcpyKind kind = mem == RDF_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (total > 0) {
+        HIP_TRY(hipMemcpyAsync(out_probe->values, dop, (size_t)total * 4, kind, ctx.stream));
+        HIP_TRY(hipMemcpyAsync(out_build->values, dob, (size_t)total * 4, kind, ctx.stream));
+        if (out_probe->validity) HIP_TRY(hipMemcpyAsync(out_probe->validity, dvp, (size_t)((total + 7) / 8), kind, ctx.stream));
+        if (out_build->validity) HIP_TRY(hipMemcpyAsync(out_build->validity, dvb, (size_t)((total + 7) / 8), kind, ctx.stream));
+    }
+    // null counts: build-side NULLs = probe rows without a partner; probe-side NULLs = appended rows
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    out_probe->length = out_build->length = total;
+    out_probe->null_count = (int64_t)appended;
+    out_build->null_count = (int64_t)unmatched;
+    return RDF_OK;
+}
+
 // ---------------------------------------------------------------- group-by
 
 rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,

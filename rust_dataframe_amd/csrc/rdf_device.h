@@ -145,6 +145,30 @@ struct SortPassArgs {
     int32_t         shift;                           // bit offset of this pass's digit in the key
 };
 
+// Equi-join indices (calc_equijoin_indices, src/functions/join.rs:19-137): sort the build side by key, binary-search
+// every probe row, count -> scan -> write.
+struct JoinProbeArgs {
+    const uint64_t* lkeys;     // [nl] order-preserving key bits of the probe side
+    const uint8_t*  lnull;     // [nl] 1 = NULL key (never matches), or nullptr
+    const uint64_t* rkeys;     // [nrv] sorted key bits of the build side (NULL keys excluded: they sort last)
+    const uint32_t* ridx;      // [nr] build-side row of each sorted position
+    int64_t         nl, nrv;
+    int32_t         outer;     // probe rows without a match are emitted with a NULL build index
+    int64_t*        counts;    // [nl] out (count phase)
+    const int64_t*  offsets;   // [nl + 1] exclusive scan of counts (write phase)
+    uint32_t*       out_probe; uint32_t* out_build;
+    uint32_t*       out_build_validity;   // bitmap words preset to ones; cleared where the build side is NULL
+    uint32_t*       matched;   // [ceil(nrv / 32)] sorted build positions that found a partner (FULL), or nullptr
+    unsigned long long* unmatched;  // count phase: probe rows without a partner
+};
+struct JoinAppendArgs {        // FULL: build rows nobody matched (and NULL-key build rows) with a NULL probe index
+    const uint32_t* ridx; const uint32_t* matched;
+    int64_t         nr, nrv;
+    unsigned long long* cursor; // running output row (starts at the probe phase's total)
+    uint32_t*       out_probe; uint32_t* out_build; uint32_t* out_probe_validity;
+    int32_t         count_only;
+};
+
 // Partitioned GROUP BY (high cardinality): keys are replaced by an invertible 64-bit mix, the (hashed key, value)
 // pairs are radix-partitioned on the top hash bits with the sort kernels, and every partition is aggregated
 // in an LDS table and emitted directly.
@@ -232,6 +256,10 @@ int  sort_grid(int64_t ntiles);
 hipError_t launch_sort_keys(const SortKeyArgs& a, hipStream_t s);
 hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s);
+hipError_t launch_join_count(const JoinProbeArgs& a, hipStream_t s);
+hipError_t launch_join_write(const JoinProbeArgs& a, hipStream_t s);
+hipError_t launch_join_append(const JoinAppendArgs& a, hipStream_t s);
+hipError_t launch_count_bytes(const uint8_t* p, int64_t n, unsigned long long* out, hipStream_t s);
 hipError_t launch_sort_hist64(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_sort_scatter64(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_groupby_prepare(const GroupPrepArgs& a, hipStream_t s);

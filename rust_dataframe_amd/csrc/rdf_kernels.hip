@@ -548,6 +548,71 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs
 }
 
 // ------------------------------------------------------------------------------------------------
+// equi-join indices (calc_equijoin_indices, src/functions/join.rs:19-137).  The reference hashes byte-encoded
+// keys into HashMap<Vec<u8>, Vec<usize>> row lists; here the build side is radix-sorted by key (the sort
+// kernels above), every probe row finds its partners' range with two binary searches, and the pairs are
+// written at offsets from an exclusive scan of the per-row match counts.  NULL keys never match.
+
+__device__ __forceinline__ void join_range(const JoinProbeArgs& a, int64_t i, int64_t& lo, int64_t& hi) {
+    lo = hi = 0;
+    if (a.lnull && a.lnull[i]) return;
+    const uint64_t k = a.lkeys[i];
+    int64_t l = 0, h = a.nrv;
+    while (l < h) { const int64_t m = (l + h) >> 1; if (a.rkeys[m] < k) l = m + 1; else h = m; }
+    lo = l;
+    h = a.nrv;
+    while (l < h) { const int64_t m = (l + h) >> 1; if (a.rkeys[m] <= k) l = m + 1; else h = m; }
+    hi = l;
+}
+__global__ __launch_bounds__(kBlock) void join_count_kernel(const JoinProbeArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.nl; i += (int64_t)gridDim.x * kBlock) {
+        int64_t lo, hi;
+        join_range(a, i, lo, hi);
+        const int64_t c = hi - lo;
+        a.counts[i] = (c == 0 && a.outer) ? 1 : c;
+        if (a.matched) for (int64_t p = lo; p < hi; ++p) atomicOr(&a.matched[p >> 5], 1u << (p & 31));
+        if (c == 0 && a.outer) atomicAdd(a.unmatched, 1ull);
+    }
+}
+__global__ __launch_bounds__(kBlock) void join_write_kernel(const JoinProbeArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.nl; i += (int64_t)gridDim.x * kBlock) {
+        int64_t lo, hi;
+        join_range(a, i, lo, hi);
+        int64_t o = a.offsets[i];
+        if (hi == lo) {
+            if (a.outer) {
+                a.out_probe[o] = (uint32_t)i;
+                a.out_build[o] = 0;
+                atomicAnd(&a.out_build_validity[o >> 5], ~(1u << (o & 31)));
+            }
+            continue;
+        }
+        for (int64_t p = lo; p < hi; ++p, ++o) {
+            a.out_probe[o] = (uint32_t)i;
+            a.out_build[o] = a.ridx[p];
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void join_append_kernel(const JoinAppendArgs a) {
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < a.nr; p += (int64_t)gridDim.x * kBlock) {
+        const bool un = p >= a.nrv || !((a.matched[p >> 5] >> (p & 31)) & 1);
+        if (!un) continue;
+        const unsigned long long o = atomicAdd(a.cursor, 1ull);
+        if (a.count_only) continue;
+        a.out_probe[o] = 0;
+        a.out_build[o] = a.ridx[p];
+        atomicAnd(&a.out_probe_validity[o >> 5], ~(1u << (o & 31)));
+    }
+}
+__global__ __launch_bounds__(kBlock) void count_bytes_kernel(const uint8_t* p, int64_t n, unsigned long long* out) {
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) c += p[i] != 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += shfl_xor64(c, m);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// ------------------------------------------------------------------------------------------------
 // hash GROUP BY (Transformation::GroupAggregate, planned by Dataset::try_aggregate src/expression.rs:114-221,
 // never executed by the reference: src/evaluation.rs:73 panics).  SQL semantics: NULL keys form one
 // group, NULL values are skipped.  One global open-addressing table in HBM (it lives in L2/Infinity
@@ -1022,6 +1087,27 @@ hipError_t launch_groupby_build(const GroupByArgs& a, hipStream_t s) {
     if (grid <= 0) return hipSuccess;
     if (a.max_groups <= kLdsGroups / 2) hipLaunchKernelGGL(groupby_build_lds_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL(groupby_build_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+static int rows_grid(int64_t n) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g > eval_grid_limit()) g = eval_grid_limit();
+    return g < 1 ? 1 : (int)g;
+}
+hipError_t launch_join_count(const JoinProbeArgs& a, hipStream_t s) {
+    if (a.nl > 0) hipLaunchKernelGGL(join_count_kernel, dim3(rows_grid(a.nl)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_join_write(const JoinProbeArgs& a, hipStream_t s) {
+    if (a.nl > 0) hipLaunchKernelGGL(join_write_kernel, dim3(rows_grid(a.nl)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_join_append(const JoinAppendArgs& a, hipStream_t s) {
+    if (a.nr > 0) hipLaunchKernelGGL(join_append_kernel, dim3(rows_grid(a.nr)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_count_bytes(const uint8_t* p, int64_t n, unsigned long long* out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(count_bytes_kernel, dim3(rows_grid(n)), dim3(kBlock), 0, s, p, n, out);
     return hipGetLastError();
 }
 hipError_t launch_groupby_prepare(const GroupPrepArgs& a, hipStream_t s) {

@@ -134,6 +134,29 @@ TEST(test_sort) {
     CHECK_EQ(host<uint8_t>(lz.column(1).data().chunk(0)), (std::vector<uint8_t>{8, 4, 7, 5, 9, 6}));
 }
 
+// test_left_join / test_right_join / test_inner_join (src/dataframe.rs:1006-1060) on the numeric columns of
+// join_test_j1 / join_test_j2 (sql/postgresql/002.sql) — no Postgres needed
+TEST(test_joins) {
+    const std::vector<bool> av{0, 1, 1, 0, 0, 1, 1};
+    DataFrame j1 = DataFrame::from_columns({Column::from_arrays({Array::from_vec<int32_t>({0, 2, 3, 0, 0, 6, 6}, &av)}, Field{"a", DataType::Int32, true}),
+                                            Column::from_arrays({Array::from_vec<int32_t>({1, 2, 3, 4, 5, 6, 60})}, Field{"b", DataType::Int32, false})});
+    const std::vector<bool> fv{1, 1, 1, 1, 0, 1, 1, 1, 1};
+    DataFrame j2 = DataFrame::from_columns({Column::from_arrays({Array::from_vec<int32_t>({1, 2, 3, 4, 4, 4, 5, 6, 7})}, Field{"d", DataType::Int32, false}),
+                                            Column::from_arrays({Array::from_vec<double>({1.1, 2.2, INFINITY, NAN, 0.0, 4.0, 5.0, 6.0, 7.000000000001}, &fv)}, Field{"f", DataType::Float64, true})});
+    using JT = DataFrame::JoinType;
+    DataFrame l = j1.join(j2, {JT::LeftJoin, {{"b", "d"}}});
+    CHECK_EQ(l.num_columns(), 4u);
+    CHECK_EQ(l.num_rows(), 9);
+    DataFrame r = j1.join(j2, {JT::RightJoin, {{"a", "d"}}});
+    CHECK_EQ(r.num_rows(), 10);
+    DataFrame i = j1.join(j2, {JT::InnerJoin, {{"a", "d"}}});
+    CHECK_EQ(i.num_rows(), 4);
+    CHECK_EQ(i.num_columns(), 4u);
+    CHECK_EQ(host<int32_t>(i.column_by_name("a").data().chunk(0)), (std::vector<int32_t>{2, 3, 6, 6}));
+    CHECK_EQ(host<int32_t>(i.column_by_name("d").data().chunk(0)), (std::vector<int32_t>{2, 3, 6, 6}));
+    CHECK_EQ(host<double>(i.column_by_name("f").data().chunk(0)), (std::vector<double>{2.2, INFINITY, 6.0, 6.0}));
+}
+
 // ---------------------------------------------------------------- filter: DataFrame::filter + the fused filter -> aggregate
 TEST(test_filter_and_fused_aggregate) {
     DataFrame df = DataFrame::from_csv(g_csv).drop({"city"});

@@ -448,3 +448,42 @@ def test_groupby_partitioned_high_cardinality(gpu, ora, ngroups, n):
             else:
                 assert np.array_equal(got[2], exp[2])
         lib.set_option("gb_partition", 1)
+
+
+def _pairs(l, r):
+    return sorted(zip(l.to_pylist(), r.to_pylist()), key=lambda p: (p[0] is None, p[0] or 0, p[1] is None, p[1] or 0))
+
+
+def test_join_reference_fixture(gpu, ora):
+    """join_test_j1 / join_test_j2 (sql/postgresql/002.sql) and the row counts the reference's join tests assert
+    (src/dataframe.rs:1006-1060): left join b=d -> 9 rows, right join a=d -> 10, inner join a=d -> 4."""
+    a = [A.HostArray.from_numpy(np.array([0, 2, 3, 0, 0, 6, 6], dtype=np.int32), valid=[0, 1, 1, 0, 0, 1, 1])]
+    b = [A.HostArray.from_numpy(np.array([1, 2, 3, 4, 5, 6, 60], dtype=np.int32))]
+    d = [A.HostArray.from_numpy(np.array([1, 2, 3, 4, 4, 4, 5, 6, 7], dtype=np.int32))]
+    for api in (gpu, ora):
+        l, r = api.equijoin_indices(b, d, "left")
+        assert l.length == 9 and r.null_count == 1            # b = 60 has no partner
+        l, r = api.equijoin_indices(a, d, "right")
+        assert l.length == 10 and l.null_count == 6
+        l, r = api.equijoin_indices(a, d, "inner")
+        assert l.length == 4 and _pairs(l, r) == [(1, 1), (2, 2), (5, 7), (6, 7)]
+        l, r = api.equijoin_indices(a, d, "full")               # true full outer: 4 pairs + 3 NULL-key lefts + 6 unmatched rights
+        assert l.length == 13 and l.null_count == 6 and r.null_count == 3
+
+
+@pytest.mark.parametrize("dtype", [A.I64, A.I32, A.U8, A.F64])
+@pytest.mark.parametrize("how", ["left", "right", "inner", "full"])
+def test_equijoin_indices(gpu, ora, dtype, how):
+    rng = np.random.default_rng(3000 + dtype)
+    for (llens, rlens, card, nf) in [([9], [7], 5, 0.0), ([700, 0, 1300], [1024, 500], 300, 0.1), ([3000], [2500], 5000, 0.05)]:
+        def side(lens, off):
+            out = []
+            for n in lens:
+                v = rng.integers(0, min(card, 250 if dtype == A.U8 else card), n).astype(A.NP_OF[dtype])
+                out.append(A.HostArray.from_numpy(v, valid=(rng.uniform(size=n) >= nf) if nf else None, offset=off, rng=rng))
+            return out
+        lk, rk = side(llens, 3), side(rlens, 5)
+        gl, gr = gpu.equijoin_indices(lk, rk, how)
+        el, er = ora.equijoin_indices(lk, rk, how)
+        assert gl.length == el.length and gl.null_count == el.null_count and gr.null_count == er.null_count
+        assert _pairs(gl, gr) == _pairs(el, er), f"join {how} dtype={dtype}"
