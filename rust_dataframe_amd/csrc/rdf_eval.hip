@@ -305,14 +305,51 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
     for (int k = 0; k < NVAL; ++k) nullacc[k] = 0;
     int64_t cur_chunk = -1;
 
-    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        int64_t c = 0, r0, clen;
-        if (a.nchunks == 1) { r0 = tile * kEvalTile; clen = a.inline_len; }
+    // Programs with ONE column in registers have little memory-level parallelism of their own (8 KB per
+    // block in flight): their NEXT tile's column loads are issued before the current tile is interpreted.
+    constexpr bool PF = NPRE == 1;  // (measured: with two columns the extra registers cost more occupancy than the prefetch buys)
+    struct TileLoc { int64_t c, r0, clen; };
+    auto locate = [&](int64_t tile) -> TileLoc {
+        TileLoc t;
+        if (a.nchunks == 1) { t.c = 0; t.r0 = tile * kEvalTile; t.clen = a.inline_len; }
         else {
-            c = find_chunk(a.chunk_tile_start, a.nchunks, tile);
-            r0 = (tile - a.chunk_tile_start[c]) * kEvalTile;
-            clen = a.chunk_len[c];
+            t.c = find_chunk(a.chunk_tile_start, a.nchunks, tile);
+            t.r0 = (tile - a.chunk_tile_start[t.c]) * kEvalTile;
+            t.clen = a.chunk_len[t.c];
         }
+        return t;
+    };
+    auto rows_in_range = [&](const TileLoc& t) -> uint32_t {
+        const int64_t rw_ = t.r0 + (int64_t)wave * (kVPT * 64);
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < kVPT; ++j) m |= (uint32_t)(rw_ + j * 64 + lane < t.clen) << j;
+        return m;
+    };
+    uint64_t pfv[PF ? NPRE : 1][kVPT];
+    uint32_t pfvalid[PF ? NPRE : 1];
+    auto preload = [&](const TileLoc& t, uint64_t (&v)[PF ? NPRE : 1][kVPT], uint32_t (&vv)[PF ? NPRE : 1]) {
+        const int64_t rw_ = t.r0 + (int64_t)wave * (kVPT * 64);
+        const uint32_t inr_ = rows_in_range(t);
+#pragma unroll
+        for (int p = 0; p < (PF ? NPRE : 0); ++p) {
+            if (p < a.ncols) {
+                const DevChunkCol cc = a.nchunks == 1 ? a.inline_cols[p] : a.cols[(int64_t)p * a.nchunks + t.c];
+                load_col(cc, a.col_dtype[p], rw_, t.clen, inr_, v[p], vv[p]);
+            } else {
+                vv[p] = 0;
+#pragma unroll
+                for (int j = 0; j < kVPT; ++j) v[p][j] = 0;
+            }
+        }
+    };
+    int64_t tile = blockIdx.x;
+    bool have = tile < a.ntiles;
+    TileLoc tl = have ? locate(tile) : TileLoc{0, 0, 0};
+    if (PF && have) preload(tl, pfv, pfvalid);
+
+    while (have) {
+        const int64_t c = tl.c, r0 = tl.r0, clen = tl.clen;
         if (SINK == SINK_STORE && c != cur_chunk) {
             if (cur_chunk >= 0 && lane == 0) {
 #pragma unroll
@@ -325,24 +362,36 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
             cur_chunk = c;
         }
         const int64_t rw = r0 + (int64_t)wave * (kVPT * 64);  // this wave's first row
-        uint32_t inr = 0;
-#pragma unroll
-        for (int j = 0; j < kVPT; ++j) inr |= (uint32_t)(rw + j * 64 + lane < clen) << j;
+        const uint32_t inr = rows_in_range(tl);
 
-        // (1) preload
+        // (1) this tile's columns: taken from the prefetch registers, or loaded now (all loads up front)
         uint64_t colv[NPRE][kVPT];
         uint32_t colvalid[NPRE];
+        if (PF) {
 #pragma unroll
-        for (int p = 0; p < NPRE; ++p) {
-            if (p < a.ncols) {
-                const DevChunkCol cc = a.nchunks == 1 ? a.inline_cols[p] : a.cols[(int64_t)p * a.nchunks + c];
-                load_col(cc, a.col_dtype[p], rw, clen, inr, colv[p], colvalid[p]);
-            } else {
-                colvalid[p] = 0;
+            for (int p = 0; p < NPRE; ++p) {
+                colvalid[p] = pfvalid[PF ? p : 0];
 #pragma unroll
-                for (int j = 0; j < kVPT; ++j) colv[p][j] = 0;
+                for (int j = 0; j < kVPT; ++j) colv[p][j] = pfv[PF ? p : 0][j];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NPRE; ++p) {
+                if (p < a.ncols) {
+                    const DevChunkCol cc = a.nchunks == 1 ? a.inline_cols[p] : a.cols[(int64_t)p * a.nchunks + c];
+                    load_col(cc, a.col_dtype[p], rw, clen, inr, colv[p], colvalid[p]);
+                } else {
+                    colvalid[p] = 0;
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) colv[p][j] = 0;
+                }
             }
         }
+        // the next tile of this block; its loads go in flight before this tile is interpreted
+        const int64_t ntile = tile + gridDim.x;
+        const bool nhave = ntile < a.ntiles;
+        const TileLoc ntl = nhave ? locate(ntile) : tl;
+        if (PF && nhave) preload(ntl, pfv, pfvalid);
 
         // (2) interpret
         uint64_t acc[kVPT];
@@ -466,6 +515,9 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
                 }
             }
         }
+        tile = ntile;
+        tl = ntl;
+        have = nhave;
     }
 
     if (SINK == SINK_STORE && cur_chunk >= 0 && lane == 0) {
