@@ -10,7 +10,7 @@ namespace rdfk {
 constexpr int kBlock = 256;          // 4 wavefronts of 64
 constexpr int kVPT = 4;              // rows per thread per tile in the fused evaluator
 constexpr int kEvalTile = kBlock * kVPT;   // 1024 rows: one reference RecordBatch (src/dataframe.rs:352)
-constexpr int kFilterTile = 2048;    // rows per compaction tile (32 mask words)
+constexpr int kFilterTile = 4096;    // rows per compaction tile (64 mask words, 16 per wave): measured best of 2048 / 4096 / 8192
 constexpr int kMaxCode = 56;         // accumulator-machine instructions per program
 constexpr int kMaxCols = 8;          // columns referenced by one program
 constexpr int kPreCols = 4;          // columns preloaded into registers per tile

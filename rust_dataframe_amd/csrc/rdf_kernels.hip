@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void filter_agg_f64_kernel(const FilterAggF
 
 // ------------------------------------------------------------------------------------------------
 // stream compaction (Column::filter).  Tiles of kFilterTile = 2048 rows = 32 mask words; wave w owns
-// the 512 consecutive rows (8 mask words) [512w, 512w+512) of a tile.
+// the 1024 consecutive rows (16 mask words) [1024w, 1024w+1024) of a tile.
 
 __device__ __forceinline__ void locate_tile(const MaskTables& t, int64_t tile, int64_t& c, int64_t& r0, int64_t& clen) {
     c = t.nchunks == 1 ? 0 : find_chunk(t.chunk_tile_start, t.nchunks, tile);
