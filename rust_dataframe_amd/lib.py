@@ -34,6 +34,13 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C rust_dataframe_amd/csrc). There is no fallback path.")
+        # torch bundles its own libamdhip64/libhsa-runtime64; when it shares the process it must be loaded
+        # FIRST so that both sides bind the same HIP runtime (two runtimes in one process cannot both own
+        # the device: whichever comes second reports "no HIP GPUs").  A pure C/C++ host never needs torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.rdf_version.restype = C.c_char_p
         _lib.rdf_last_error.restype = C.c_char_p

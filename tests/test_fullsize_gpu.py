@@ -1,0 +1,150 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties (the oracle only sees a
+sample prefix): partition-of-unity / linearity of the fused filter->sum, fused == materialised, idempotence of
+filter, shard sums == whole, bit-exact min/max between the fused and the stored a*b+c, sortedness after sort,
+group sums adding up to the column sum."""
+import pytest
+
+from rust_dataframe_amd import _abi as A
+
+pytestmark = pytest.mark.gpu
+
+N = 1_000_000_000
+
+
+def _dev(n, col, dtype, lo, hi, seed=42):
+    import torch
+    from rust_dataframe_amd import lib
+    if dtype == A.F64:
+        t = torch.empty(n, dtype=torch.float64, device="cuda")
+        lib.fill_uniform_f64(t.data_ptr(), n, seed, col, 0, lo, hi)
+    else:
+        t = torch.empty(n, dtype=torch.int64, device="cuda")
+        lib.fill_uniform_i64(t.data_ptr(), n, seed, col, 0, lo, hi)
+    return t
+
+
+def _arr(t, dtype, n, first=0):
+    return A.DeviceArray(t.data_ptr() + first * 8, None, 0, n, dtype, 0, keep=t)
+
+
+def _out(dtype, n, es=8):
+    import torch
+    pad = (n + 63) // 64 * 64
+    v = torch.empty(pad * es if es else pad // 8 + 8, dtype=torch.uint8, device="cuda")
+    return A.DeviceArray(v.data_ptr(), None, 0, n, dtype, 0, keep=v)
+
+
+def test_headline_1e9_properties(gpu, ora):
+    import torch
+    x = _dev(N, 0, A.F64, 0.0, 1.0)
+    X = _arr(x, A.F64, N)
+    e = A.Expr()
+    c = e.col(0)
+    gt, le = e.op("gt", c, e.scalar(0.5)), e.op("le", c, e.scalar(0.5))
+    hi = gpu.pipeline(e, [[X]], [c], gt)[0]
+    lo = gpu.pipeline(e, [[X]], [c], le)[0]
+    whole = gpu.pipeline(e, [[X]], [c])[0]
+    # partition of unity: the two filters split the rows exactly and the sums add up
+    assert hi.count + lo.count == N == whole.count
+    assert abs((hi.sum + lo.sum) - whole.sum) <= 1e-9 * whole.sum
+    assert hi.min > 0.5 >= lo.max and whole.min == lo.min and whole.max == hi.max
+    assert abs(hi.count / N - 0.5) < 1e-3 and abs(whole.sum / N - 0.5) < 1e-4      # U[0,1)
+    # shards == whole (the multi-GPU partitioning, on one device): 8 row ranges, folded in rank order
+    from rust_dataframe_amd import sharding
+    parts = []
+    for r in range(8):
+        b, en = sharding.shard_rows(N, 8, r)
+        parts.append(gpu.pipeline(e, [[_arr(x, A.F64, en - b, b)]], [c], gt)[0])
+    assert sum(p.count for p in parts) == hi.count
+    assert abs(sum(p.sum for p in parts) - hi.sum) <= 1e-12 * hi.sum
+    assert max(p.max for p in parts) == hi.max and min(p.min for p in parts) == hi.min
+    # chunked (1M-row RecordBatches) == one chunk: bit-exact count, 1e-12 sum
+    chunks = [_arr(x, A.F64, min(1 << 20, N - i), i) for i in range(0, N, 1 << 20)]
+    ch = gpu.pipeline(e, [chunks], [c], gt)[0]
+    assert ch.count == hi.count and abs(ch.sum - hi.sum) <= 1e-12 * hi.sum
+    # the oracle on a 2e6-row prefix agrees
+    n0 = 2_000_000
+    host = A.HostArray.from_numpy(x[:n0].cpu().numpy())
+    g0 = gpu.pipeline(e, [[_arr(x, A.F64, n0)]], [c], gt)[0]
+    o0 = ora.pipeline(e, [[host]], [c], gt)[0]
+    assert g0.count == o0.count and abs(g0.sum - o0.sum) <= 1e-6 * o0.sum
+    # fused == materialised: predicate -> mask, Column::filter, then sum; filtering again is idempotent
+    n1 = 200_000_000
+    X1 = _arr(x, A.F64, n1)
+    mask = _out(A.BOOL, n1, 0)
+    gpu.predicate(e, gt, [[X1]], [mask])
+    kept = gpu.filter_count([mask])[0]
+    fused = gpu.pipeline(e, [[X1]], [c], gt)[0]
+    assert kept == fused.count
+    out = _out(A.F64, kept)
+    gpu.filter([X1], [mask], [out])
+    assert out.length == kept
+    mat = gpu.pipeline(e, [[out]], [c])[0]
+    assert mat.count == kept and mat.min == fused.min and mat.max == fused.max
+    assert abs(mat.sum - fused.sum) <= 1e-9 * fused.sum
+    again = gpu.pipeline(e, [[out]], [c], gt)[0]
+    assert again.count == kept                      # everything already satisfies the predicate
+    del x, out, mask
+    torch.cuda.empty_cache()
+
+
+def test_c3_1e9_properties(gpu):
+    """Config C3: 1e9 rows x 4 columns (32 GB): fused a*b+c -> min/max/count and the key's min/max/count in one
+    pass; the stored y (two roundings, no FMA contraction) has bit-identical extrema."""
+    import torch
+    a, b, cc = (_dev(N, i, A.F64, -1.0, 1.0) for i in range(3))
+    k = _dev(N, 3, A.I64, -2 ** 31, 2 ** 31)
+    cols = [[_arr(t, dt, N)] for t, dt in ((a, A.F64), (b, A.F64), (cc, A.F64), (k, A.I64))]
+    e = A.Expr()
+    fma = e.op("add", e.op("multiply", e.col(0), e.col(1)), e.col(2))
+    y, kk = gpu.pipeline(e, cols, [fma, e.col(3)])
+    assert y.count == N == kk.count
+    assert -2.0 <= y.min < -1.9 and 1.9 < y.max <= 2.0 and abs(y.sum / N) < 1e-3
+    assert -2 ** 31 <= kk.min < -2 ** 31 + 100 and 2 ** 31 - 100 < kk.max < 2 ** 31
+    out = _out(A.F64, N)
+    gpu.pipeline(e, cols[:3], [fma], -1, A.SINK_STORE, [[out]])
+    ys = gpu.pipeline(e, [[out]], [e.col(0)])[0]
+    assert ys.min == y.min and ys.max == y.max and ys.count == N
+    assert abs(ys.sum - y.sum) <= 1e-9 * N          # |y| <= 2: absolute bound on the reassociated sum
+    k2 = gpu.pipeline(e, [cols[3]], [e.col(0)])[0]
+    assert (k2.sum, k2.min, k2.max) == (kk.sum, kk.min, kk.max)   # integers: bit-exact
+    del a, b, cc, k, out
+    torch.cuda.empty_cache()
+
+
+def test_sort_and_groupby_large_properties(gpu):
+    import torch
+    n = 50_000_000
+    k = _dev(n, 5, A.I64, -10 ** 12, 10 ** 12)
+    K = _arr(k, A.I64, n)
+    idx = _out(A.U32, n, 4)
+    gpu.sort_to_indices([[K]], [False], idx)
+    srt = _out(A.I64, n)
+    gpu.take([K], idx, srt)
+    # sortedness: s[i] <= s[i+1] everywhere (predicate over two shifted views); a permutation keeps sum/min/max
+    e = A.Expr()
+    le = e.op("le", e.col(0), e.col(1))
+    ok = gpu.pipeline(e, [[_arr(srt.keep, A.I64, n - 1)], [_arr(srt.keep, A.I64, n - 1, 1)]], [e.col(0)], le)[0]
+    assert ok.count == n - 1
+    s0, s1 = gpu.pipeline(e, [[K]], [e.col(0)])[0], gpu.pipeline(e, [[srt]], [e.col(0)])[0]
+    assert (s0.sum, s0.min, s0.max, s0.count) == (s1.sum, s1.min, s1.max, s1.count)
+    # GROUP BY: group sums add up to the column sum, counts to n, every key appears once
+    g = _dev(n, 6, A.I64, 0, 1_000_000)
+    v = _dev(n, 7, A.F64, 0.0, 1.0)
+    outs = (_out(A.I64, 1_000_002), _out(A.F64, 1_000_002), _out(A.I64, 1_000_002))
+    gk, gs, gc = gpu.groupby_sum([_arr(g, A.I64, n)], [_arr(v, A.F64, n)], 1_000_000, outs)
+    ng = gk.length
+    assert 999_000 < ng <= 1_000_000
+    tot = gpu.pipeline(e, [[_arr(v, A.F64, n)]], [e.col(0)])[0]
+    sums = gpu.pipeline(e, [[A.DeviceArray(gs.values_ptr, None, 0, ng, A.F64, 0)]], [e.col(0)])[0]
+    cnts = gpu.pipeline(e, [[A.DeviceArray(gc.values_ptr, None, 0, ng, A.I64, 0)]], [e.col(0)])[0]
+    assert cnts.sum == n and abs(sums.sum - tot.sum) <= 1e-9 * tot.sum
+    KG = A.DeviceArray(gk.values_ptr, None, 0, ng, A.I64, 0)
+    kidx = _out(A.U32, ng, 4)
+    gpu.sort_to_indices([[KG]], [False], kidx)
+    ks = _out(A.I64, ng)
+    gpu.take([KG], kidx, ks)
+    lt = e.op("lt", e.col(0), e.col(1))
+    strict = gpu.pipeline(e, [[_arr(ks.keep, A.I64, ng - 1)], [_arr(ks.keep, A.I64, ng - 1, 1)]], [e.col(0)], lt)[0]
+    assert strict.count == ng - 1    # strictly increasing: no key appears twice
+    torch.cuda.empty_cache()
