@@ -265,6 +265,38 @@ typedef struct {
 rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks,
                         rdf_out* outs, rdf_agg_result* aggs);
 
+/* ------------------------------------------------------------------ fused grouped aggregation */
+
+#define RDF_MAX_GROUP_VALUES 8
+#define RDF_MAX_GROUP_SLOTS  1024   /* (ngroups + 1) * nvalues must not exceed this */
+
+/* sum/count of one value expression inside one group.  sum in the value's class: f64 for F32/F64
+ * values (accumulated in f64), wrapping i64 otherwise (widened, not re-wrapped to the value's width). */
+typedef struct {
+    double  sum_f64;
+    int64_t sum_i64;
+    int64_t count;    /* rows of the group that passed the filter and whose value is not NULL */
+    int32_t is_some;  /* count > 0 */
+    int32_t dtype;    /* value dtype */
+} rdf_group_result;
+
+/* Transformation::GroupAggregate(groups, [Sum|Average|Count ...]) after a run of Calculate/Filter steps,
+ * for a SMALL DENSE group domain (TPC-H Q1's returnflag x linestatus; BASELINE.json config C5), fused into
+ * one pass per batch: rows are dropped by `filter_root` (or kept when -1), `group_root` is an
+ * integer-valued expression giving each row's group id in [0, ngroups) (e.g. flag * 2 + status over
+ * dictionary codes; a NULL id lands in the extra group `ngroups`), and every value expression is summed
+ * and counted per group: out[v * (ngroups + 1) + g].  group_rows[g] (may be NULL) = rows in group g after
+ * the filter, i.e. SQL count(*).  An id outside [0, ngroups) at a row that passed the filter ->
+ * RDF_COMPUTE_ERROR.  Averages are sum / count on the caller's side (AggregateFunctions::avg,
+ * src/functions/aggregate.rs:32-65).  The reference plans this step (Dataset::try_aggregate,
+ * src/expression.rs:114-221) but does not execute it (src/evaluation.rs:73 panics): semantics are SQL's,
+ * parity unpinned by the reference.  f64 sums: accumulation order is not deterministic (<= 1e-6 rel).
+ * Large or sparse key domains: rdf_groupby_sum. */
+rdf_status rdf_group_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_t filter_root, int32_t group_root,
+                              int32_t ngroups, const int32_t* value_roots, int32_t nvalues,
+                              const rdf_array* cols, int32_t ncols, int64_t nchunks,
+                              rdf_group_result* out, int64_t* group_rows);
+
 /* ------------------------------------------------------------------ synthetic data (bench/tests) */
 
 /* x[row] = lo + (hi-lo) * u(seed, column_id, first_row + row), u in [0,1) from a counter-based

@@ -912,6 +912,89 @@ rdf_status ora_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t 
     return st;
 }
 
+/* ------------------------------------------------------------------ grouped aggregation over a small dense domain
+ * Transformation::GroupAggregate after Calculate/Filter steps: planned by Dataset::try_aggregate
+ * (src/expression.rs:114-221), not executed by the reference (src/evaluation.rs:73 panics): PARITY UNPINNED BY
+ * THE REFERENCE, SQL semantics.  Restated unfused like the batch loop above: every expression (mask, group id,
+ * values) is materialised per batch, then one sequential scan folds the kept rows into per-group sums. */
+static int64_t int_at(const rdf_array* a, int64_t i) {
+    if (a->dtype == RDF_BOOL) return bit_get((const uint8_t*)a->values, a->offset + i);
+    if (a->dtype == RDF_U64) return (int64_t)((const uint64_t*)a->values)[a->offset + i];
+    int64_t k = a->offset + i;
+    switch (a->dtype) {
+        case RDF_I8: return ((const int8_t*)a->values)[k];
+        case RDF_I16: return ((const int16_t*)a->values)[k];
+        case RDF_I32: return ((const int32_t*)a->values)[k];
+        case RDF_U8: return ((const uint8_t*)a->values)[k];
+        case RDF_U16: return ((const uint16_t*)a->values)[k];
+        case RDF_U32: return ((const uint32_t*)a->values)[k];
+        default: return ((const int64_t*)a->values)[k];
+    }
+}
+rdf_status ora_group_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_t filter_root, int32_t group_root, int32_t ngroups,
+                              const int32_t* value_roots, int32_t nvalues, const rdf_array* cols, int32_t ncols, int64_t nchunks,
+                              rdf_group_result* out, int64_t* group_rows) {
+    if (!nodes || nnodes <= 0) FAIL(RDF_INVALID_ARGUMENT, "empty program");
+    if (!value_roots || nvalues < 1 || nvalues > RDF_MAX_GROUP_VALUES) FAIL(RDF_INVALID_ARGUMENT, "nvalues out of range");
+    if (group_root < 0 || group_root >= nnodes) FAIL(RDF_INVALID_ARGUMENT, "group_root out of range");
+    if (ngroups < 1 || (int64_t)(ngroups + 1) * nvalues > RDF_MAX_GROUP_SLOTS) FAIL(RDF_INVALID_ARGUMENT, "grouped aggregation: domain too large");
+    if (!out) FAIL(RDF_INVALID_ARGUMENT, "null output pointer");
+    const int S = ngroups + 1;
+    int64_t* rows = (int64_t*)calloc((size_t)S, sizeof(int64_t));
+    memset(out, 0, sizeof(rdf_group_result) * (size_t)S * (size_t)nvalues);
+    rdf_status st = RDF_OK;
+    int dtype_known = 0;
+    for (int64_t c = 0; c < nchunks && st == RDF_OK; c++) {
+        int64_t n = batch_length(cols, ncols, nchunks, c, &st);
+        if (st != RDF_OK) break;
+        tmparr mask, gid, val[RDF_MAX_GROUP_VALUES];
+        memset(&mask, 0, sizeof mask); memset(&gid, 0, sizeof gid); memset(val, 0, sizeof val);
+        if (filter_root >= 0) {
+            st = eval_node(nodes, nnodes, filter_root, cols, ncols, nchunks, c, n, &mask);
+            if (st == RDF_OK && mask.dtype != RDF_BOOL) { st = RDF_INVALID_ARGUMENT; snprintf(g_err, sizeof g_err, "predicate root must be boolean"); }
+        }
+        if (st == RDF_OK) st = eval_node(nodes, nnodes, group_root, cols, ncols, nchunks, c, n, &gid);
+        if (st == RDF_OK && !(gid.dtype == RDF_BOOL || (gid.dtype >= RDF_I8 && gid.dtype <= RDF_U64))) {
+            st = RDF_INVALID_ARGUMENT; snprintf(g_err, sizeof g_err, "group id expression must be integer-valued");
+        }
+        for (int32_t v = 0; v < nvalues && st == RDF_OK; v++) {
+            st = eval_node(nodes, nnodes, value_roots[v], cols, ncols, nchunks, c, n, &val[v]);
+            if (st == RDF_OK && !(is_numeric(val[v].dtype) || val[v].dtype == RDF_BOOL)) { st = RDF_INVALID_ARGUMENT; snprintf(g_err, sizeof g_err, "aggregate of a non-numeric value"); }
+        }
+        if (st == RDF_OK) {
+            rdf_array m = tmp_view(&mask), g = tmp_view(&gid);
+            if (!dtype_known) { for (int32_t v = 0; v < nvalues; v++) for (int k = 0; k < S; k++) out[(size_t)v * S + k].dtype = val[v].dtype; dtype_known = 1; }
+            for (int64_t i = 0; i < n && st == RDF_OK; i++) {
+                if (filter_root >= 0 && !mask_keep(&m, i)) continue;
+                int64_t slot = ngroups;
+                if (arr_valid(&g, i)) {
+                    slot = int_at(&g, i);
+                    if ((gid.dtype == RDF_U64 ? (uint64_t)slot >= (uint64_t)ngroups : (slot < 0 || slot >= ngroups))) {
+                        st = RDF_COMPUTE_ERROR; snprintf(g_err, sizeof g_err, "group id outside [0, %d)", ngroups); break;
+                    }
+                }
+                rows[slot]++;
+                for (int32_t v = 0; v < nvalues; v++) {
+                    rdf_array a = tmp_view(&val[v]);
+                    if (!arr_valid(&a, i)) continue;
+                    rdf_group_result* r = &out[(size_t)v * S + slot];
+                    if (is_float(a.dtype)) r->sum_f64 += arr_f64(&a, i);
+                    else r->sum_i64 = (int64_t)((uint64_t)r->sum_i64 + (uint64_t)int_at(&a, i));
+                    r->count++;
+                }
+            }
+        }
+        tmp_free(&mask); tmp_free(&gid);
+        for (int32_t v = 0; v < nvalues; v++) tmp_free(&val[v]);
+    }
+    if (st == RDF_OK) {
+        for (int64_t k = 0; k < (int64_t)S * nvalues; k++) out[k].is_some = out[k].count > 0;
+        if (group_rows) memcpy(group_rows, rows, sizeof(int64_t) * (size_t)S);
+    }
+    free(rows);
+    return st;
+}
+
 /* ------------------------------------------------------------------ sort
  * DataFrame::sort (src/dataframe.rs:194-214): concat every sort column (Column::to_array), then
  * arrow::compute::lexsort_to_indices with SortOptions{descending, nulls_first: false}.  Restated as a

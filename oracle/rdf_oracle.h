@@ -58,6 +58,10 @@ rdf_status ora_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
 rdf_status ora_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks,
                         rdf_out* outs, rdf_agg_result* aggs);
 
+rdf_status ora_group_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_t filter_root, int32_t group_root, int32_t ngroups,
+                              const int32_t* value_roots, int32_t nvalues, const rdf_array* cols, int32_t ncols, int64_t nchunks,
+                              rdf_group_result* out, int64_t* group_rows);
+
 rdf_status ora_fill_uniform_f64(double* ptr, int64_t n, uint64_t seed, uint64_t column_id,
                                 int64_t first_row, double lo, double hi);
 rdf_status ora_fill_uniform_i64(int64_t* ptr, int64_t n, uint64_t seed, uint64_t column_id,

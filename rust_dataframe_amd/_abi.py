@@ -81,6 +81,14 @@ class rdf_agg_result(C.Structure):
                 ("dtype", C.c_int32)]
 
 
+class rdf_group_result(C.Structure):
+    _fields_ = [("sum_f64", C.c_double), ("sum_i64", C.c_int64), ("count", C.c_int64), ("is_some", C.c_int32), ("dtype", C.c_int32)]
+
+
+MAX_GROUP_VALUES = 8
+MAX_GROUP_SLOTS = 1024
+
+
 class RdfError(Exception):
     """A non-OK rdf_status: DataFrameError / ArrowError as values (src/error.rs:6-15)."""
 
@@ -284,7 +292,7 @@ class Api:
         self._err = getattr(lib, prefix + "last_error")
         self._err.restype = C.c_char_p
         for name in ("binary", "unary", "cast", "sum", "min", "max", "count", "avg", "predicate", "filter_count",
-                     "filter", "filter_columns", "take", "pipeline", "groupby_sum", "sort_to_indices", "equijoin_indices", "fill_uniform_f64",
+                     "filter", "filter_columns", "take", "pipeline", "group_pipeline", "groupby_sum", "sort_to_indices", "equijoin_indices", "fill_uniform_f64",
                      "fill_uniform_i64", "fill_validity"):
             fn = getattr(lib, prefix + name)
             fn.restype = C.c_int
@@ -490,6 +498,29 @@ class Api:
             o.length = cc[0].length
             o.null_count = cc[0].null_count
         return outs
+
+    # ---- fused grouped aggregation over a small dense domain (TPC-H Q1 shape)
+    def group_pipeline(self, expr: Expr, cols: Sequence[Sequence], value_roots: Sequence[int], group_root: int, ngroups: int,
+                       filter_root: int = -1):
+        """-> (res, rows): res[v][g] = (sum, count) of value v in group g (g == ngroups: the NULL group), rows[g] = count(*)."""
+        nchunks = len(cols[0]) if cols else 0
+        nodes = expr.c_array()
+        nv = len(value_roots)
+        S = ngroups + 1
+        out = (rdf_group_result * max(1, nv * S))()
+        rows = (C.c_int64 * max(1, S))()
+        roots = (C.c_int32 * max(1, nv))(*value_roots)
+        self._check(self._fn("group_pipeline")(nodes, C.c_int32(len(expr.nodes)), C.c_int32(filter_root), C.c_int32(group_root),
+                                               C.c_int32(ngroups), roots, C.c_int32(nv), _flat(cols, nchunks), C.c_int32(len(cols)),
+                                               C.c_int64(nchunks), out, rows))
+        res = []
+        for v in range(nv):
+            row = []
+            for g in range(S):
+                r = out[v * S + g]
+                row.append((r.sum_f64 if r.dtype in (F32, F64) else r.sum_i64, r.count))
+            res.append(row)
+        return res, [rows[g] for g in range(S)]
 
     # ---- fused batch loop
     def pipeline(self, expr: Expr, cols: Sequence[Sequence], value_roots: Sequence[int], filter_root: int = -1,

@@ -668,9 +668,14 @@ struct ProgramSpec {
     int nnodes;
     int filter_root;
     int nvalues;
-    int value_roots[kMaxValues];
+    int value_roots[kMaxGroupValues];
     int sink;
+    // RDF_SINK_GROUP (internal): rdf_group_pipeline
+    int group_root = -1, ngroups = 0;
+    rdf_group_result* gout = nullptr;
+    int64_t* grows = nullptr;
 };
+constexpr int RDF_SINK_GROUP = 2;
 
 rdf_status launch_agg_pair(const EvalArgs* ea, const FilterAggF64Args* fa, int cmp, int feat, int grid, int nvalues,
                            const int* cls, AggPartial* partials, AggPartial* result, const char* spec_sig = nullptr,
@@ -712,7 +717,13 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
                        rdf_agg_result* aggs, const char* len_mismatch_msg) {
     if (nchunks < 0) return fail(RDF_INVALID_ARGUMENT, "negative chunk count");
     if (ncols < 0 || ncols > kMaxCols) return fail(RDF_INVALID_ARGUMENT, "a fused program reads at most %d columns", kMaxCols);
-    if (ps.nvalues < 1 || ps.nvalues > kMaxValues) return fail(RDF_INVALID_ARGUMENT, "nvalues out of range");
+    const bool grouped = ps.sink == RDF_SINK_GROUP;
+    if (ps.nvalues < 1 || ps.nvalues > (grouped ? kMaxGroupValues : kMaxValues)) return fail(RDF_INVALID_ARGUMENT, "nvalues out of range");
+    if (grouped) {
+        if (ps.ngroups < 1 || (int64_t)(ps.ngroups + 1) * ps.nvalues > RDF_MAX_GROUP_SLOTS)
+            return fail(RDF_INVALID_ARGUMENT, "grouped aggregation: (ngroups + 1) * nvalues must be in [2, %d] (large key domains: rdf_groupby_sum)", RDF_MAX_GROUP_SLOTS);
+        if (!ps.gout) return fail(RDF_INVALID_ARGUMENT, "null output pointer");
+    }
     if (ps.sink == RDF_SINK_STORE && ps.filter_root >= 0)
         return fail(RDF_INVALID_ARGUMENT, "SINK_STORE with a filter: use rdf_predicate + rdf_filter_columns");
     int32_t mem = -1;
@@ -744,7 +755,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
 
     // compile
     Compiler cc(ps.nodes, ps.nnodes, col_dtype, ncols);
-    int value_dtype[kMaxValues];
+    int value_dtype[kMaxGroupValues];
     if (ps.filter_root >= 0) {
         const int ft = cc.infer(ps.filter_root);
         if (cc.st != RDF_OK) return cc.st;
@@ -752,10 +763,19 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         cc.gen(ps.filter_root);
         cc.push(Compiler::mk(BC_FILTER));
     }
+    if (grouped) {
+        const int gt = cc.infer(ps.group_root);
+        if (cc.st != RDF_OK) return cc.st;
+        if (!(gt == RDF_BOOL || (gt >= RDF_I8 && gt <= RDF_U64))) return fail(RDF_INVALID_ARGUMENT, "group id expression must be integer-valued");
+        cc.gen(ps.group_root);
+        Instr g = Compiler::mk(BC_GROUP);
+        g.dtype = (uint8_t)gt;
+        cc.push(g);
+    }
     for (int v = 0; v < ps.nvalues; ++v) {
         value_dtype[v] = cc.infer(ps.value_roots[v]);
         if (cc.st != RDF_OK) return cc.st;
-        if (ps.sink == RDF_SINK_AGG && !(is_numeric(value_dtype[v]) || value_dtype[v] == RDF_BOOL))
+        if (ps.sink != RDF_SINK_STORE && !(is_numeric(value_dtype[v]) || value_dtype[v] == RDF_BOOL))
             return fail(RDF_INVALID_ARGUMENT, "aggregate of a non-numeric value");
         cc.gen(ps.value_roots[v]);
         Instr e = Compiler::mk(BC_EMIT);
@@ -783,6 +803,14 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     if (total_rows == 0) {
         if (ps.sink == RDF_SINK_STORE) {
             for (int64_t i = 0; i < (int64_t)ps.nvalues * nchunks; ++i) { outs[i].length = 0; outs[i].null_count = 0; }
+        } else if (grouped) {
+            for (int v = 0; v < ps.nvalues; ++v)
+                for (int g = 0; g <= ps.ngroups; ++g) {
+                    rdf_group_result& r = ps.gout[(size_t)v * (size_t)(ps.ngroups + 1) + (size_t)g];
+                    memset(&r, 0, sizeof r);
+                    r.dtype = value_dtype[v];
+                }
+            if (ps.grows) memset(ps.grows, 0, sizeof(int64_t) * (size_t)(ps.ngroups + 1));
         } else {
             for (int v = 0; v < ps.nvalues; ++v) { memset(&aggs[v], 0, sizeof aggs[v]); aggs[v].dtype = value_dtype[v]; }
         }
@@ -837,7 +865,8 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
 
     // device scratch: flags | null counts | partials | result
     const size_t n_nc = ps.sink == RDF_SINK_STORE ? (size_t)ps.nvalues * (size_t)nchunks : 0;
-    const size_t scratch_bytes = 16 + n_nc * 8 + ((size_t)grid + 1) * (size_t)ps.nvalues * sizeof(AggPartial);
+    const int gwords = grouped ? group_words(ps.ngroups, ps.nvalues) : 0;
+    const size_t scratch_bytes = 16 + n_nc * 8 + ((size_t)grid + 1) * (grouped ? (size_t)gwords * 8 : (size_t)ps.nvalues * sizeof(AggPartial));
     void* scratch = nullptr;
     RDF_TRY(arena_alloc(scratch_bytes, &scratch));
     uint32_t* d_flags = (uint32_t*)scratch;
@@ -858,7 +887,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     ea.out_null_counts = d_nullc;
     ea.partials = d_partials;
     for (int k = 0; k < ncols; ++k) ea.col_dtype[k] = col_dtype[k];
-    int cls[kMaxValues] = {0, 0, 0, 0};
+    int cls[kMaxGroupValues] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int v = 0; v < ps.nvalues; ++v) { cls[v] = value_class(value_dtype[v]); ea.value_cls[v] = cls[v]; }
     memcpy(ea.code, cc.code.data(), cc.code.size() * sizeof(Instr));
 
@@ -891,7 +920,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     TableBuilder stb;
     bool use_spec = false;
     int spec_rpb = 0;
-    if (ctx.opt_spec && build_spec_plan(cc, ps.filter_root, ps.nvalues, ps.value_roots, ps.sink, sp)) {
+    if (ctx.opt_spec && !grouped && build_spec_plan(cc, ps.filter_root, ps.nvalues, ps.value_roots, ps.sink, sp)) {
         memset(&sa, 0, sizeof sa);
         use_spec = true;
         spec_rpb = spec_rows_per_block_iter(sp.sig.c_str());
@@ -939,6 +968,52 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         grid = (int)(sa.ntiles < (int64_t)eval_grid_limit() ? sa.ntiles : (int64_t)eval_grid_limit());
         if (grid < 1) grid = 1;
         d_result = d_partials + (size_t)grid * (size_t)ps.nvalues;
+    }
+
+    if (grouped) {
+        ea.ngroups = ps.ngroups;
+        // LDS copies of the table: as many (power of two, <= 32) as fit in 32 KB next to the TMP spill area
+        const size_t tmp_bytes = (size_t)cc.tmp_max * (kVPT * kBlock * 8 + kBlock * 4);
+        int reps = 32;
+        while (reps > 1 && ((size_t)reps * (size_t)gwords * 8 > 32768 || tmp_bytes + (size_t)reps * (size_t)gwords * 8 > 65536)) reps >>= 1;
+        ea.group_replicas = reps;
+        uint64_t* d_gpart = (uint64_t*)d_partials;
+        uint64_t* d_gres = d_gpart + (size_t)grid * (size_t)gwords;
+        ea.group_partials = d_gpart;
+        {
+            KernelTimer kt;
+            ctx.last_kernel = "eval_kernel<GROUP>";
+            HIP_TRY(launch_eval(ea, SINK_GROUP, cc.feat(), grid, ctx.stream));
+            kt.stop();
+        }
+        GroupFinalArgs gf;
+        memset(&gf, 0, sizeof gf);
+        gf.partials = d_gpart; gf.result = d_gres; gf.nblocks = grid; gf.words = gwords; gf.ngroups = ps.ngroups; gf.nvalues = ps.nvalues;
+        for (int v = 0; v < ps.nvalues; ++v) gf.value_cls[v] = cls[v];
+        HIP_TRY(launch_group_final(gf, ctx.stream));
+        RDF_TRY(pinned_reserve(pin_off + 64 + (size_t)gwords * 8));
+        char* pin = ctx.pinned + pin_off;
+        HIP_TRY(hipMemcpyAsync(pin, d_flags, 16, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipMemcpyAsync(pin + 64, d_gres, (size_t)gwords * 8, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        uint32_t flags;
+        memcpy(&flags, pin, 4);
+        if (flags & 1u) return fail(RDF_DIVIDE_BY_ZERO, "Divide by zero error");
+        if (flags & 2u) return fail(RDF_COMPUTE_ERROR, "group id outside [0, %d)", ps.ngroups);
+        const uint64_t* w = (const uint64_t*)(pin + 64);
+        const int S = ps.ngroups + 1;
+        for (int v = 0; v < ps.nvalues; ++v)
+            for (int g = 0; g < S; ++g) {
+                rdf_group_result& r = ps.gout[(size_t)v * (size_t)S + (size_t)g];
+                memset(&r, 0, sizeof r);
+                r.dtype = value_dtype[v];
+                r.count = (int64_t)(w[2 * ps.nvalues * S + g] - w[(ps.nvalues + v) * S + g]);
+                r.is_some = r.count > 0;
+                if (is_float(value_dtype[v])) memcpy(&r.sum_f64, &w[v * S + g], 8);
+                else r.sum_i64 = (int64_t)w[v * S + g];
+            }
+        if (ps.grows) for (int g = 0; g < S; ++g) ps.grows[g] = (int64_t)w[2 * ps.nvalues * S + g];
+        return RDF_OK;
     }
 
     if (ps.sink == RDF_SINK_AGG) {
@@ -1252,6 +1327,20 @@ rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t 
     for (int v = 0; v < prog->nvalues; ++v) ps.value_roots[v] = prog->value_roots[v];
     if (ps.sink != RDF_SINK_STORE && ps.sink != RDF_SINK_AGG) return fail(RDF_INVALID_ARGUMENT, "bad sink");
     return run_program(ps, cols, ncols, nchunks, outs, aggs, "columns of a batch differ in length");
+}
+
+rdf_status rdf_group_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_t filter_root, int32_t group_root, int32_t ngroups,
+                              const int32_t* value_roots, int32_t nvalues, const rdf_array* cols, int32_t ncols, int64_t nchunks,
+                              rdf_group_result* out, int64_t* group_rows) {
+    if (!nodes || nnodes <= 0) return fail(RDF_INVALID_ARGUMENT, "empty program");
+    if (!value_roots || nvalues < 1 || nvalues > RDF_MAX_GROUP_VALUES) return fail(RDF_INVALID_ARGUMENT, "nvalues out of range");
+    if (group_root < 0 || group_root >= nnodes) return fail(RDF_INVALID_ARGUMENT, "group_root out of range");
+    ProgramSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.nodes = nodes; ps.nnodes = nnodes; ps.filter_root = filter_root; ps.nvalues = nvalues; ps.sink = RDF_SINK_GROUP;
+    for (int v = 0; v < nvalues; ++v) ps.value_roots[v] = value_roots[v];
+    ps.group_root = group_root; ps.ngroups = ngroups; ps.gout = out; ps.grows = group_rows;
+    return run_program(ps, cols, ncols, nchunks, nullptr, nullptr, "columns of a batch differ in length");
 }
 
 // ---------------------------------------------------------------- filter / take

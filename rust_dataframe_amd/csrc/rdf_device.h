@@ -16,6 +16,7 @@ constexpr int kMaxCols = 8;          // columns referenced by one program
 constexpr int kPreCols = 4;          // columns preloaded into registers per tile
 constexpr int kMaxTmp = 4;           // LDS spill slots for bushy expression trees
 constexpr int kMaxValues = RDF_MAX_VALUES;
+constexpr int kMaxGroupValues = RDF_MAX_GROUP_VALUES;   // value expressions of the grouped sink
 constexpr int kMaxFilterCols = 8;    // columns per compaction launch
 
 // One (column, chunk): an Arrow array resident in HBM.
@@ -31,7 +32,7 @@ struct DevOutChunk {
 
 // Accumulator-machine bytecode.  The host compiles an rdf_expr_node tree (Sethi-Ullman order) into
 // this; the opcode stream is wave-uniform, so the interpreter's branches are scalar branches.
-enum : uint8_t { BC_LOAD = 0, BC_STORE_TMP = 1, BC_BIN = 2, BC_UN = 3, BC_CAST = 4, BC_EMIT = 5, BC_FILTER = 6 };
+enum : uint8_t { BC_LOAD = 0, BC_STORE_TMP = 1, BC_BIN = 2, BC_UN = 3, BC_CAST = 4, BC_EMIT = 5, BC_FILTER = 6, BC_GROUP = 7 };
 enum : uint8_t { SRC_NONE = 0, SRC_COL = 1, SRC_IMM = 2, SRC_TMP = 3 };
 
 struct Instr {
@@ -53,7 +54,7 @@ struct AggPartial {
 };
 enum : int32_t { CLS_F64 = 0, CLS_SIGNED = 1, CLS_UNSIGNED = 2 };
 
-enum : int32_t { SINK_STORE = 0, SINK_AGG = 1 };
+enum : int32_t { SINK_STORE = 0, SINK_AGG = 1, SINK_GROUP = 2 };
 
 struct EvalArgs {
     // chunk tables (device memory) — or the inline copies below when nchunks == 1
@@ -63,15 +64,28 @@ struct EvalArgs {
     DevOutChunk*       outs;             // [nvalues * nchunks] (SINK_STORE)
     int64_t*           out_null_counts;  // [nvalues * nchunks] (SINK_STORE)
     AggPartial*        partials;         // [gridDim.x * nvalues] (SINK_AGG)
-    uint32_t*          flags;            // bit 0: divide by zero at a valid slot
+    uint64_t*          group_partials;   // [gridDim.x * group_words] (SINK_GROUP), see group_words()
+    uint32_t*          flags;            // bit 0: divide by zero at a valid slot; bit 1: group id out of range
     int64_t            nchunks, ntiles;
     DevChunkCol        inline_cols[kMaxCols];
     DevOutChunk        inline_outs[kMaxValues];
     int64_t            inline_len;
     int32_t            ncols, nvalues, ncode, ntmp;
     int32_t            col_dtype[kMaxCols];
-    int32_t            value_cls[kMaxValues];
+    int32_t            value_cls[kMaxGroupValues];
+    int32_t            ngroups, group_replicas;   // SINK_GROUP: ids in [0, ngroups) + the NULL group; LDS copies of the table
     Instr              code[kMaxCode];
+};
+
+// SINK_GROUP accumulator table, in 64-bit words, S = ngroups + 1 slots per row:
+//   [v * S + g] sum of value v in group g   |   [(nvalues + v) * S + g] its count   |   [2 * nvalues * S + g] rows of group g
+inline __host__ __device__ int group_words(int ngroups, int nvalues) { return (ngroups + 1) * (2 * nvalues + 1); }
+
+struct GroupFinalArgs {
+    const uint64_t* partials;   // [nblocks * words]
+    uint64_t*       result;     // [words]
+    int32_t         nblocks, words, ngroups, nvalues;
+    int32_t         value_cls[kMaxGroupValues];
 };
 
 struct AggFinalArgs {
@@ -241,6 +255,7 @@ struct TakeArgs {
 // ---- launch wrappers (defined in rdf_kernels.hip) ----
 int  eval_grid_limit();   // persistent grid size for streaming kernels
 hipError_t launch_eval(const EvalArgs& a, int sink, int feat, int grid, hipStream_t s);  // feat: 0 basic, 1 +int div, 2 +libm
+hipError_t launch_group_final(const GroupFinalArgs& a, hipStream_t s);
 hipError_t launch_agg_final(const AggFinalArgs& a, hipStream_t s);
 bool spec_available(const char* sig);
 int  spec_rows_per_block_iter(const char* sig);

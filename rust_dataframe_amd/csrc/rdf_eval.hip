@@ -298,6 +298,20 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
         for (int k = 0; k < NVAL; ++k) agg_init(k < a.nvalues ? a.value_cls[k] : CLS_F64, g_sum[k], g_mn[k], g_mx[k], g_cnt[k]);
     }
     uint32_t err = 0;
+    // SINK_GROUP: `group_replicas` copies of the accumulator table in LDS behind the TMP spill area (a lane
+    // works on copy lane % replicas, so lanes of one wave that hit the same group mostly hit different
+    // addresses); row j's group id stays in a register between BC_GROUP and the BC_EMITs
+    uint64_t* gtab = nullptr;
+    uint32_t gid[kVPT];
+    const int gS = a.ngroups + 1, gwords = group_words(a.ngroups, a.nvalues);
+    if (SINK == SINK_GROUP) {
+        gtab = (uint64_t*)(smem + (size_t)a.ntmp * (kVPT * kBlock * 8 + kBlock * 4));
+        for (int i = tid; i < gwords * a.group_replicas; i += kBlock) gtab[i] = 0;
+#pragma unroll
+        for (int j = 0; j < kVPT; ++j) gid[j] = 0;
+        __syncthreads();
+    }
+    uint64_t* const grep = SINK == SINK_GROUP ? gtab + (size_t)(lane & (a.group_replicas - 1)) * gwords : nullptr;
     // SINK_STORE: per-wave null counters, flushed with one atomic per (value, chunk) when the block
     // moves on to another chunk — never one atomic per tile
     uint32_t nullacc[NVAL];
@@ -464,9 +478,37 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
 #pragma unroll
                     for (int j = 0; j < kVPT; ++j) keep &= ~((uint32_t)(((acc[j] & 1) == 0) || (((accv >> j) & 1) == 0)) << j);
                     break;
+                case BC_GROUP:  // acc is the row's group id (an integer expression); NULL -> the extra group
+                    if (SINK == SINK_GROUP) {
+#pragma unroll
+                        for (int j = 0; j < kVPT; ++j) {
+                            uint64_t g = in.dtype == RDF_BOOL ? (acc[j] & 1) : acc[j];
+                            if (!((accv >> j) & 1)) g = (uint64_t)a.ngroups;
+                            else if (g >= (uint64_t)a.ngroups) {
+                                if ((keep >> j) & 1) err |= 2u;
+                                keep &= ~(1u << j);
+                                g = 0;
+                            }
+                            gid[j] = (uint32_t)g;
+                            if ((keep >> j) & 1) atomicAdd((unsigned long long*)&grep[2 * a.nvalues * gS + (int)g], 1ull);
+                        }
+                    }
+                    break;
                 default: {  // BC_EMIT: acc is value expression `in.src`
                     const int k = in.src;
-                    if (SINK == SINK_AGG) {
+                    if (SINK == SINK_GROUP) {
+                        const int cls = a.value_cls[k & (kMaxGroupValues - 1)];
+#pragma unroll
+                        for (int j = 0; j < kVPT; ++j)
+                            if ((keep >> j) & 1) {
+                                if ((accv >> j) & 1) {
+                                    uint64_t v = acc[j];
+                                    if (in.dtype == RDF_F32) v = d2u((double)u2f(v));
+                                    if (cls == CLS_F64) unsafeAtomicAdd((double*)&grep[k * gS + (int)gid[j]], u2d(v));
+                                    else atomicAdd((unsigned long long*)&grep[k * gS + (int)gid[j]], (unsigned long long)v);
+                                } else atomicAdd((unsigned long long*)&grep[(a.nvalues + k) * gS + (int)gid[j]], 1ull);  // NULL values are counted, not summed
+                            }
+                    } else if (SINK == SINK_AGG) {
                         const uint32_t live = keep & accv & inr;
 #pragma unroll
                         for (int kk = 0; kk < NVAL; ++kk)
@@ -527,6 +569,18 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
                 atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)k * a.nchunks + cur_chunk], (unsigned long long)nullacc[k]);
     }
     if (err) atomicOr(a.flags, err);
+    if (SINK == SINK_GROUP) {  // fold the LDS copies in copy order, one table per block
+        __syncthreads();
+        for (int w = tid; w < gwords; w += kBlock) {
+            const bool fsum = w < a.nvalues * gS && a.value_cls[(w / gS) & (kMaxGroupValues - 1)] == CLS_F64;
+            uint64_t acc0 = gtab[w];
+            for (int r = 1; r < a.group_replicas; ++r) {
+                const uint64_t x = gtab[(size_t)r * gwords + w];
+                acc0 = fsum ? d2u(u2d(acc0) + u2d(x)) : acc0 + x;
+            }
+            a.group_partials[(size_t)blockIdx.x * gwords + w] = acc0;
+        }
+    }
     if (SINK == SINK_AGG) {
 #pragma unroll
         for (int k = 0; k < NVAL; ++k)
@@ -558,9 +612,14 @@ static void launch_shape(const EvalArgs& a, int npre, int nval, int grid, size_t
 #define RDF_CAT2(a, b) a##b
 #define RDF_CAT(a, b) RDF_CAT2(a, b)
 hipError_t RDF_CAT(launch_eval_feat, RDF_FEAT)(const EvalArgs& a, int sink, int grid, hipStream_t s) {
-    const size_t lds = (size_t)a.ntmp * (kVPT * kBlock * 8 + kBlock * 4);
+    size_t lds = (size_t)a.ntmp * (kVPT * kBlock * 8 + kBlock * 4);
     const int npre = a.ncols < kPreCols ? a.ncols : kPreCols;
-    if (sink == SINK_AGG) launch_shape<SINK_AGG>(a, npre, a.nvalues, grid, lds, s);
+    if (sink == SINK_GROUP) {
+        lds += (size_t)group_words(a.ngroups, a.nvalues) * (size_t)a.group_replicas * 8;
+        if (npre <= 1) launch_one<SINK_GROUP, 1, 1>(a, grid, lds, s);
+        else if (npre <= 2) launch_one<SINK_GROUP, 2, 1>(a, grid, lds, s);
+        else launch_one<SINK_GROUP, 4, 1>(a, grid, lds, s);
+    } else if (sink == SINK_AGG) launch_shape<SINK_AGG>(a, npre, a.nvalues, grid, lds, s);
     else launch_shape<SINK_STORE>(a, npre, a.nvalues, grid, lds, s);
     return hipGetLastError();
 }

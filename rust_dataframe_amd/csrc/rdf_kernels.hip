@@ -976,6 +976,27 @@ hipError_t launch_eval(const EvalArgs& a, int sink, int feat, int grid, hipStrea
     return launch_eval_feat2(a, sink, grid, s);
 }
 
+// SINK_GROUP: per-block tables folded in block order (deterministic given the per-block tables)
+__global__ __launch_bounds__(kBlock) void group_final_kernel(const GroupFinalArgs a) {
+    const int w = blockIdx.x * kBlock + threadIdx.x;
+    if (w >= a.words) return;
+    const int S = a.ngroups + 1;
+    const bool fsum = w < a.nvalues * S && a.value_cls[(w / S) & (kMaxGroupValues - 1)] == CLS_F64;
+    uint64_t acc = 0;
+    if (fsum) {
+        double d = 0.0;
+        for (int b = 0; b < a.nblocks; ++b) d += u2d(a.partials[(size_t)b * a.words + w]);
+        acc = d2u(d);
+    } else {
+        for (int b = 0; b < a.nblocks; ++b) acc += a.partials[(size_t)b * a.words + w];
+    }
+    a.result[w] = acc;
+}
+hipError_t launch_group_final(const GroupFinalArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(group_final_kernel, dim3((a.words + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_agg_final(const AggFinalArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(agg_final_kernel, dim3(1), dim3(kBlock), 0, s, a);
     return hipGetLastError();
