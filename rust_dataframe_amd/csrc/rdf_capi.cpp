@@ -577,17 +577,23 @@ struct Compiler {
 
 struct SpecPlan {
     std::string sig;
-    int col_map[4];      // canonical column -> program column
+    int col_map[kGSpecCols];      // canonical column -> program column
     int ncols = 0;
-    uint64_t imm[4];
+    uint64_t imm[kGSpecImm];
+    char imm_tag[kGSpecImm];
     int nimm = 0;
     int width = 0;       // common element width of the columns (8 or 4)
     bool ok = true;
+    // spec_kernel: 4 columns of one width, 4 literals.  gspec_kernel (grouped sink): 8 columns of any widths,
+    // 8 literals, equal literals share one slot
+    int max_cols = 4, max_imm = 4;
+    bool mixed = false, dedup = false;
 };
 
 char spec_tag(int dt) {
     switch (dt) { case RDF_F64: return 'd'; case RDF_I64: return 'l'; case RDF_U64: return 'u'; case RDF_F32: return 'f';
-                  case RDF_I32: return 'i'; case RDF_U32: return 'j'; case RDF_BOOL: return 'b'; default: return 0; }
+                  case RDF_I32: return 'i'; case RDF_U32: return 'j'; case RDF_BOOL: return 'b';
+                  case RDF_I8: return 'a'; case RDF_U8: return 'h'; case RDF_I16: return 's'; case RDF_U16: return 't'; default: return 0; }
 }
 
 struct SpecSigBuilder {
@@ -601,11 +607,11 @@ struct SpecSigBuilder {
             const int dt = cc.col_dtype[nd.column];
             if (!spec_tag(dt) || dt == RDF_BOOL) { sp.ok = false; return "?"; }
             if (sp.width == 0) sp.width = dtype_size(dt);
-            else if (sp.width != dtype_size(dt)) { sp.ok = false; return "?"; }  // one width per program
+            else if (sp.width != dtype_size(dt) && !sp.mixed) { sp.ok = false; return "?"; }  // one width per program
             int id = -1;
             for (int i = 0; i < sp.ncols; ++i) if (sp.col_map[i] == nd.column) id = i;
             if (id < 0) {
-                if (sp.ncols >= 4) { sp.ok = false; return "?"; }
+                if (sp.ncols >= sp.max_cols) { sp.ok = false; return "?"; }
                 id = sp.ncols;
                 sp.col_map[sp.ncols++] = nd.column;
             }
@@ -613,9 +619,17 @@ struct SpecSigBuilder {
         }
         // scalar: payload converted to `dom`
         if (!spec_tag(dom) || dom == RDF_BOOL) { sp.ok = false; return "?"; }
-        if (nd.dtype == RDF_NULLTYPE || sp.nimm >= 4) { sp.ok = false; return "?"; }
-        const int id = sp.nimm;
-        sp.imm[sp.nimm++] = cc.imm_for(nd, dom);
+        if (nd.dtype == RDF_NULLTYPE) { sp.ok = false; return "?"; }
+        const uint64_t bits = cc.imm_for(nd, dom);
+        int id = -1;
+        if (sp.dedup)
+            for (int i = 0; i < sp.nimm; ++i) if (sp.imm[i] == bits && sp.imm_tag[i] == spec_tag(dom)) id = i;
+        if (id < 0) {
+            if (sp.nimm >= sp.max_imm) { sp.ok = false; return "?"; }
+            id = sp.nimm;
+            sp.imm_tag[sp.nimm] = spec_tag(dom);
+            sp.imm[sp.nimm++] = bits;
+        }
         return std::string("k") + char('0' + id) + spec_tag(dom);
     }
 
@@ -658,6 +672,23 @@ bool build_spec_plan(Compiler& cc, int filter_root, int nvalues, const int* valu
     if (!sp.ok) return false;
     sp.sig = s;
     return spec_available(s.c_str());
+}
+
+// Grouped sink: signature "G<g>;P:<pred|->;K:<group id>;V:<v0>;<v1>;..." for the smallest catalog G >= ngroups.
+bool build_gspec_plan(Compiler& cc, int filter_root, int group_root, int ngroups, int nvalues, const int* value_roots, SpecPlan& sp) {
+    sp.max_cols = kGSpecCols; sp.max_imm = kGSpecImm; sp.mixed = true; sp.dedup = true;
+    SpecSigBuilder b(cc, sp);
+    std::string s = ";P:";
+    s += filter_root >= 0 ? b.node(filter_root, RDF_F64) : std::string("-");
+    s += ";K:" + b.node(group_root, cc.infer(group_root)) + ";V:";
+    for (int v = 0; v < nvalues; ++v) s += b.node(value_roots[v], cc.infer(value_roots[v])) + ";";
+    if (!sp.ok) return false;
+    for (int g : {2, 4, 6, 8}) {
+        if (g < ngroups) continue;
+        const std::string full = "G" + std::to_string(g) + s;
+        if (gspec_available(full.c_str())) { sp.sig = full; return true; }
+    }
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -980,7 +1011,31 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         uint64_t* d_gpart = (uint64_t*)d_partials;
         uint64_t* d_gres = d_gpart + (size_t)grid * (size_t)gwords;
         ea.group_partials = d_gpart;
-        {
+        // a specialised register-accumulator kernel for this shape?  (every column aligned for 2-row vector loads)
+        SpecPlan gp;
+        bool use_gspec = ctx.opt_spec && ps.ngroups <= 8 &&
+                         build_gspec_plan(cc, ps.filter_root, ps.group_root, ps.ngroups, ps.nvalues, ps.value_roots, gp);
+        for (int k = 0; k < gp.ncols && use_gspec; ++k) {
+            const int w = dtype_size(col_dtype[gp.col_map[k]]);
+            for (int64_t c = 0; c < nchunks; ++c) {
+                const DevChunkCol& d = in.dev[(size_t)((int64_t)gp.col_map[k] * nchunks + c)];
+                if (clen[(size_t)c] > 0 && ((uintptr_t)((const char*)d.values + d.offset * w) & (uintptr_t)(2 * w - 1)) != 0) { use_gspec = false; break; }
+            }
+        }
+        if (use_gspec) {
+            GSpecArgs ga;
+            memset(&ga, 0, sizeof ga);
+            ga.cols_tab = ea.cols; ga.chunk_tile_start = ea.chunk_tile_start; ga.chunk_len = ea.chunk_len;
+            ga.nchunks = nchunks; ga.ntiles = ntiles; ga.n = clen[0];
+            for (int k = 0; k < gp.ncols; ++k) { ga.col_map[k] = gp.col_map[k]; if (nchunks == 1) ga.cols[k] = in.dev[(size_t)gp.col_map[k]]; }
+            for (int k = 0; k < gp.nimm; ++k) ga.imm[k] = gp.imm[k];
+            ga.group_partials = d_gpart; ga.flags = d_flags;
+            ga.ngroups = ps.ngroups; ga.nvalues = ps.nvalues; ga.vec_bitmap = ctx.opt_vec_bitmap ? 1 : 0;
+            KernelTimer kt;
+            ctx.last_kernel = "gspec_kernel<" + gp.sig + ">";
+            HIP_TRY(launch_gspec(gp.sig.c_str(), ga, grid, ctx.stream));
+            kt.stop();
+        } else {
             KernelTimer kt;
             ctx.last_kernel = "eval_kernel<GROUP>";
             HIP_TRY(launch_eval(ea, SINK_GROUP, cc.feat(), grid, ctx.stream));

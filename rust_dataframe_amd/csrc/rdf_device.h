@@ -81,6 +81,22 @@ struct EvalArgs {
 //   [v * S + g] sum of value v in group g   |   [(nvalues + v) * S + g] its count   |   [2 * nvalues * S + g] rows of group g
 inline __host__ __device__ int group_words(int ngroups, int nvalues) { return (ngroups + 1) * (2 * nvalues + 1); }
 
+// Ahead-of-time specialised grouped sink (rdf_gspec.hip): tiles of kEvalTile rows, same chunk tables as EvalArgs.
+constexpr int kGSpecCols = 8;
+constexpr int kGSpecImm = 8;
+struct GSpecArgs {
+    const DevChunkCol* cols_tab;         // [program column * nchunks + chunk] (nchunks > 1)
+    const int64_t*     chunk_tile_start; // [nchunks + 1]
+    const int64_t*     chunk_len;        // [nchunks]
+    DevChunkCol        cols[kGSpecCols]; // nchunks == 1: canonical column k
+    int32_t            col_map[kGSpecCols];  // canonical column -> program column
+    int64_t            nchunks, ntiles, n;
+    uint64_t           imm[kGSpecImm];
+    uint64_t*          group_partials;   // [gridDim.x * group_words(ngroups, nvalues)]
+    uint32_t*          flags;
+    int32_t            ngroups, nvalues, vec_bitmap;
+};
+
 struct GroupFinalArgs {
     const uint64_t* partials;   // [nblocks * words]
     uint64_t*       result;     // [words]
@@ -255,6 +271,9 @@ struct TakeArgs {
 // ---- launch wrappers (defined in rdf_kernels.hip) ----
 int  eval_grid_limit();   // persistent grid size for streaming kernels
 hipError_t launch_eval(const EvalArgs& a, int sink, int feat, int grid, hipStream_t s);  // feat: 0 basic, 1 +int div, 2 +libm
+bool gspec_available(const char* sig);
+hipError_t launch_gspec(const char* sig, const GSpecArgs& a, int grid, hipStream_t s);
+int gspec_catalog_size();
 hipError_t launch_group_final(const GroupFinalArgs& a, hipStream_t s);
 hipError_t launch_agg_final(const AggFinalArgs& a, hipStream_t s);
 bool spec_available(const char* sig);

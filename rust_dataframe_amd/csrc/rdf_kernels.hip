@@ -976,24 +976,29 @@ hipError_t launch_eval(const EvalArgs& a, int sink, int feat, int grid, hipStrea
     return launch_eval_feat2(a, sink, grid, s);
 }
 
-// SINK_GROUP: per-block tables folded in block order (deterministic given the per-block tables)
-__global__ __launch_bounds__(kBlock) void group_final_kernel(const GroupFinalArgs a) {
-    const int w = blockIdx.x * kBlock + threadIdx.x;
-    if (w >= a.words) return;
+// SINK_GROUP: per-block tables folded by one wave per table word (lane l takes blocks l, l+64, ...; then a
+// butterfly): a fixed order, so the result is deterministic given the per-block tables
+__global__ __launch_bounds__(64) void group_final_kernel(const GroupFinalArgs a) {
+    const int w = blockIdx.x, lane = threadIdx.x;
     const int S = a.ngroups + 1;
     const bool fsum = w < a.nvalues * S && a.value_cls[(w / S) & (kMaxGroupValues - 1)] == CLS_F64;
     uint64_t acc = 0;
     if (fsum) {
         double d = 0.0;
-        for (int b = 0; b < a.nblocks; ++b) d += u2d(a.partials[(size_t)b * a.words + w]);
+        for (int b = lane; b < a.nblocks; b += 64) d += u2d(a.partials[(size_t)b * a.words + w]);
         acc = d2u(d);
     } else {
-        for (int b = 0; b < a.nblocks; ++b) acc += a.partials[(size_t)b * a.words + w];
+        for (int b = lane; b < a.nblocks; b += 64) acc += a.partials[(size_t)b * a.words + w];
     }
-    a.result[w] = acc;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint64_t y = shfl_xor64(acc, m);
+        acc = fsum ? d2u(u2d(acc) + u2d(y)) : acc + y;
+    }
+    if (lane == 0) a.result[w] = acc;
 }
 hipError_t launch_group_final(const GroupFinalArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(group_final_kernel, dim3((a.words + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(group_final_kernel, dim3(a.words), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

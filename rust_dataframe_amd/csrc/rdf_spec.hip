@@ -18,202 +18,9 @@
 #include <string>
 #include <type_traits>
 
-#include "rdf_common.hip.h"
+#include "rdf_expr.hip.h"
 
 namespace rdfk {
-
-template <class S, int N> struct VecOf { typedef S type __attribute__((ext_vector_type(N))); };
-
-// ------------------------------------------------------------------------------------------------
-// expression templates
-
-template <int DT> struct CType;
-template <> struct CType<RDF_F64> { using T = double; static constexpr char tag = 'd'; static constexpr int width = 8; };
-template <> struct CType<RDF_I64> { using T = int64_t; static constexpr char tag = 'l'; static constexpr int width = 8; };
-template <> struct CType<RDF_U64> { using T = uint64_t; static constexpr char tag = 'u'; static constexpr int width = 8; };
-template <> struct CType<RDF_F32> { using T = float; static constexpr char tag = 'f'; static constexpr int width = 4; };
-template <> struct CType<RDF_I32> { using T = int32_t; static constexpr char tag = 'i'; static constexpr int width = 4; };
-template <> struct CType<RDF_U32> { using T = uint32_t; static constexpr char tag = 'j'; static constexpr int width = 4; };
-template <> struct CType<RDF_BOOL> { using T = bool; static constexpr char tag = 'b'; static constexpr int width = 0; };
-
-constexpr int merge_width(int a, int b) { return a == 0 ? b : (b == 0 || b == a ? a : -1); }
-constexpr bool dt_float(int dt) { return dt == RDF_F64 || dt == RDF_F32; }
-constexpr bool dt_signed(int dt) { return dt == RDF_I64 || dt == RDF_I32; }
-
-template <int NC, int R, class S>
-struct Ctx {
-    S        v[NC][R];   // raw elements, row r of column c
-    uint32_t valid[NC];  // bit r = row r of column c is valid
-    uint64_t imm[4];
-    uint32_t inr;        // bit r = row r exists
-    uint32_t err;
-};
-
-template <class T> __device__ __forceinline__ T from_bits(uint64_t x);
-template <> __device__ __forceinline__ double from_bits<double>(uint64_t x) { return u2d(x); }
-template <> __device__ __forceinline__ int64_t from_bits<int64_t>(uint64_t x) { return (int64_t)x; }
-template <> __device__ __forceinline__ uint64_t from_bits<uint64_t>(uint64_t x) { return x; }
-template <> __device__ __forceinline__ float from_bits<float>(uint64_t x) { return __uint_as_float((uint32_t)x); }
-template <> __device__ __forceinline__ int32_t from_bits<int32_t>(uint64_t x) { return (int32_t)(uint32_t)x; }
-template <> __device__ __forceinline__ uint32_t from_bits<uint32_t>(uint64_t x) { return (uint32_t)x; }
-template <> __device__ __forceinline__ bool from_bits<bool>(uint64_t x) { return x != 0; }
-__device__ __forceinline__ uint64_t to_bits(double x) { return d2u(x); }
-__device__ __forceinline__ uint64_t to_bits(int64_t x) { return (uint64_t)x; }
-__device__ __forceinline__ uint64_t to_bits(uint64_t x) { return x; }
-__device__ __forceinline__ uint64_t to_bits(float x) { return (uint64_t)__float_as_uint(x); }
-__device__ __forceinline__ uint64_t to_bits(int32_t x) { return (uint64_t)(uint32_t)x; }
-__device__ __forceinline__ uint64_t to_bits(uint32_t x) { return (uint64_t)x; }
-__device__ __forceinline__ uint64_t to_bits(bool x) { return (uint64_t)x; }
-
-template <int I, int DT>
-struct Col {
-    static constexpr int dt = DT;
-    static constexpr int ncols = I + 1;
-    static constexpr int width = CType<DT>::width;
-    using T = typename CType<DT>::T;
-    template <int r, class C> static __device__ __forceinline__ T eval(C& c) { return from_bits<T>((uint64_t)c.v[I][r]); }
-    template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return c.valid[I]; }
-    static std::string sig() { return std::string("c") + char('0' + I) + CType<DT>::tag; }
-};
-template <int K, int DT>
-struct Imm {
-    static constexpr int dt = DT;
-    static constexpr int ncols = 0;
-    static constexpr int width = 0;
-    using T = typename CType<DT>::T;
-    template <int r, class C> static __device__ __forceinline__ T eval(C& c) { return from_bits<T>(c.imm[K]); }
-    template <class C> static __device__ __forceinline__ uint32_t vmask(const C&) { return ~0u; }
-    static std::string sig() { return std::string("k") + char('0' + K) + CType<DT>::tag; }
-};
-
-template <class T> __device__ __forceinline__ double as_f64(T x) { return (double)x; }
-
-constexpr bool is_cmp(int op) { return op >= RDF_OP_GT && op <= RDF_OP_LE; }
-constexpr bool is_logic(int op) { return op == RDF_OP_AND || op == RDF_OP_OR; }
-
-template <int OP, class A, class B>
-struct Bin {
-    static_assert(is_cmp(OP) || A::dt == B::dt, "arithmetic operands share one dtype");
-    static constexpr int dt = (is_cmp(OP) || is_logic(OP)) ? RDF_BOOL : A::dt;
-    static constexpr int ncols = A::ncols > B::ncols ? A::ncols : B::ncols;
-    static constexpr int width = merge_width(A::width, B::width);
-    static_assert(width >= 0, "columns of one program share one element width");
-    using T = typename CType<dt>::T;
-    template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c) & B::vmask(c); }
-    template <int r, class C> static __device__ __forceinline__ T eval(C& c) {
-        const auto x = A::template eval<r>(c);
-        const auto y = B::template eval<r>(c);
-        if constexpr (is_cmp(OP)) {  // both sides cast to Float64 (src/expression.rs:844-845)
-            const double a = as_f64(x), b = as_f64(y);
-            if constexpr (OP == RDF_OP_GT) return a > b;
-            else if constexpr (OP == RDF_OP_GE) return a >= b;
-            else if constexpr (OP == RDF_OP_EQ) return a == b;
-            else if constexpr (OP == RDF_OP_NE) return a != b;
-            else if constexpr (OP == RDF_OP_LT) return a < b;
-            else return a <= b;
-        } else if constexpr (OP == RDF_OP_AND) return x && y;
-        else if constexpr (OP == RDF_OP_OR) return x || y;
-        else if constexpr (dt_float(A::dt)) {
-            if constexpr (OP == RDF_OP_ADD) return x + y;
-            else if constexpr (OP == RDF_OP_SUB) return x - y;
-            else if constexpr (OP == RDF_OP_MUL) return x * y;
-            else if constexpr (OP == RDF_OP_DIV) {
-                const bool z = y == (T)0;
-                if (z && ((vmask(c) & c.inr) >> r & 1)) c.err |= 1u;
-                return z ? (T)0 : x / y;
-            } else if constexpr (OP == RDF_OP_ATAN2) return atan2(x, y);
-            else if constexpr (OP == RDF_OP_HYPOT) return hypot(x, y);
-            else return log(x) / log(y);
-        } else {  // integers: wrapping
-            using U = typename std::make_unsigned<T>::type;
-            if constexpr (OP == RDF_OP_ADD) return (T)((U)x + (U)y);
-            else if constexpr (OP == RDF_OP_SUB) return (T)((U)x - (U)y);
-            else if constexpr (OP == RDF_OP_MUL) return (T)((U)x * (U)y);
-            else {
-                const bool z = y == 0;
-                if (z && ((vmask(c) & c.inr) >> r & 1)) c.err |= 1u;
-                if (z) return (T)0;
-                if constexpr (dt_signed(A::dt)) return y == -1 ? (T)((U)0 - (U)x) : x / y;
-                else return x / y;
-            }
-        }
-    }
-    static std::string sig() { return "(" + std::to_string(OP) + " " + A::sig() + " " + B::sig() + ")"; }
-};
-
-template <int OP, class A>
-struct Un {
-    static constexpr int dt = OP == RDF_OP_NOT ? RDF_BOOL : A::dt;
-    static constexpr int ncols = A::ncols;
-    static constexpr int width = A::width;
-    using T = typename CType<dt>::T;
-    template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c); }
-    template <int r, class C> static __device__ __forceinline__ T eval(C& c) {
-        const auto x = A::template eval<r>(c);
-        if constexpr (OP == RDF_OP_NOT) return !x;
-        else if constexpr (dt_signed(A::dt)) { using U = typename std::make_unsigned<T>::type; return x < 0 ? (T)((U)0 - (U)x) : x; }  // abs, MIN wraps
-        else if constexpr (A::dt == RDF_F32 && OP == RDF_OP_DEGREES) return x * 57.2957795130823208767981548141051703f;
-        else if constexpr (A::dt == RDF_F32 && OP == RDF_OP_RADIANS) return x * (3.14159265358979323846264338327950288f / 180.0f);
-        else if constexpr (OP == RDF_OP_ABS) return fabs(x);
-        else if constexpr (OP == RDF_OP_ACOS) return acos(x);
-        else if constexpr (OP == RDF_OP_ASIN) return asin(x);
-        else if constexpr (OP == RDF_OP_ATAN) return atan(x);
-        else if constexpr (OP == RDF_OP_CBRT) return cbrt(x);
-        else if constexpr (OP == RDF_OP_CEIL) return ceil(x);
-        else if constexpr (OP == RDF_OP_COS) return cos(x);
-        else if constexpr (OP == RDF_OP_COSH) return cosh(x);
-        else if constexpr (OP == RDF_OP_DEGREES) return x * (180.0 / 3.14159265358979323846264338327950288);
-        else if constexpr (OP == RDF_OP_EXP) return exp(x);
-        else if constexpr (OP == RDF_OP_EXPM1) return expm1(x);
-        else if constexpr (OP == RDF_OP_FLOOR) return floor(x);
-        else if constexpr (OP == RDF_OP_LOG10) return log10(x);
-        else if constexpr (OP == RDF_OP_LOG2) return log2(x);
-        else if constexpr (OP == RDF_OP_RADIANS) return x * (3.14159265358979323846264338327950288 / 180.0);
-        else if constexpr (OP == RDF_OP_ROUND) return round(x);
-        else if constexpr (OP == RDF_OP_SIN) return sin(x);
-        else if constexpr (OP == RDF_OP_SINH) return sinh(x);
-        else if constexpr (OP == RDF_OP_SQRT) return sqrt(x);
-        else if constexpr (OP == RDF_OP_TAN) return tan(x);
-        else return tanh(x);
-    }
-    static std::string sig() { return "[" + std::to_string(OP) + " " + A::sig() + "]"; }
-};
-
-template <int TO, class A>
-struct Cast {
-    static constexpr int dt = TO;
-    static constexpr int ncols = A::ncols;
-    static constexpr int width = merge_width(A::width, CType<TO>::width);
-    static_assert(width >= 0, "specialised casts keep the element width (8->8 or 4->4 bytes)");
-    using T = typename CType<TO>::T;
-    template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c); }
-    template <int r, class C> static __device__ __forceinline__ T eval(C& c) {
-        const auto x = A::template eval<r>(c);
-        if constexpr (TO == RDF_BOOL) return x != 0;
-        else if constexpr (dt_float(TO)) return (T)x;
-        else if constexpr (dt_float(A::dt)) {  // saturating `as`
-            const double f = (double)x;
-            if (f != f) return (T)0;
-            if constexpr (TO == RDF_I64) {
-                if (f >= 9223372036854775808.0) return INT64_MAX;
-                if (f <= -9223372036854775808.0) return INT64_MIN;
-                return (int64_t)f;
-            } else if constexpr (TO == RDF_U64) {
-                if (f <= 0.0) return (T)0;
-                if (f >= 18446744073709551616.0) return ~0ull;
-                return (uint64_t)f;
-            } else if constexpr (TO == RDF_I32) return (int32_t)(f < -2147483648.0 ? -2147483648.0 : f > 2147483647.0 ? 2147483647.0 : f);
-            else return (uint32_t)(f < 0.0 ? 0.0 : f > 4294967295.0 ? 4294967295.0 : f);
-        } else return (T)x;
-    }
-    static std::string sig() { return "{" + std::to_string(TO) + " " + A::sig() + "}"; }
-};
-
-struct None {
-    static constexpr int ncols = 0;
-    static constexpr int width = 0;
-    static std::string sig() { return "-"; }
-};
 
 // ------------------------------------------------------------------------------------------------
 // typed running aggregates

@@ -78,24 +78,30 @@ def test_oracle_q1_matches_numpy(ora):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lens,nf,off", [([5], 0.0, 0), ([1024, 1024, 576], 0.0, 0), ([700, 0, 3000], 0.15, 13), ([200_000], 0.02, 3), ([0], 0.0, 0)])
-def test_q1_parity(gpu, ora, lens, nf, off):
+@pytest.mark.parametrize("lens,nf,off", [([5], 0.0, 0), ([1024, 1024, 576], 0.0, 0), ([700, 0, 3000], 0.15, 13), ([200_000], 0.02, 3), ([0], 0.0, 0),
+                                         ([4096, 100, 70_001], 0.1, 0)])
+def test_q1_parity(gpu, ora, request, lens, nf, off):
     rng = np.random.default_rng(sum(lens) + off)
     cols = q1_columns(rng, lens, nf, off)
     e, pred, gid, vals = q1_program()
     exp = ora.group_pipeline(e, _cols_list(cols), vals, gid, 6, pred)
     got = gpu.group_pipeline(e, _cols_list(cols), vals, gid, 6, pred)
     check_groups(got, exp, f"lens={lens} nulls={nf}")
+    if sum(lens) and off == 0:  # the register-accumulator kernel must be the one that ran in 'spec' mode (aligned chunks)
+        from rust_dataframe_amd import lib
+        want = "gspec_kernel<G6;" if request.node.callspec.params["gpu"] == "spec" else "eval_kernel<GROUP>"
+        assert lib.last_kernel().startswith(want), lib.last_kernel()
     if nf == 0.0 and sum(lens):
         check_groups(got, numpy_q1(cols), "gpu vs numpy")
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("key_dtype,val_dtype", [(A.I8, A.I64), (A.U8, A.F32), (A.I64, A.F64), (A.U32, A.I32), (A.BOOL, A.F64)])
-def test_group_pipeline_types_and_shapes(gpu, ora, key_dtype, val_dtype):
+def test_group_pipeline_types_and_shapes(gpu, ora, request, key_dtype, val_dtype):
     """Integer sums wrap and are bit-exact; float sums 1e-6; the key column itself as group id; 1..8 values."""
     rng = np.random.default_rng(300 + key_dtype * 16 + val_dtype)
-    for lens, nf, off, ng in [([3000, 1], 0.1, 7, 2 if key_dtype == A.BOOL else 100), ([50_000], 0.0, 0, 2 if key_dtype == A.BOOL else 17)]:
+    for lens, nf, off, ng in [([3000, 1], 0.1, 7, 2 if key_dtype == A.BOOL else 100), ([50_000], 0.0, 0, 2 if key_dtype == A.BOOL else 17),
+                              ([50_000, 77], 0.05, 0, 2 if key_dtype == A.BOOL else 5)]:
         if key_dtype == A.BOOL:
             keys = [A.HostArray.from_numpy(rng.integers(0, 2, n).astype(bool), valid=(rng.uniform(size=n) >= nf) if nf else None, offset=off, rng=rng) for n in lens]
         else:
@@ -110,6 +116,9 @@ def test_group_pipeline_types_and_shapes(gpu, ora, key_dtype, val_dtype):
             exp = ora.group_pipeline(e, [keys, vals], roots, k, ng)
             got = gpu.group_pipeline(e, [keys, vals], roots, k, ng)
             check_groups(got, exp, f"key={key_dtype} val={val_dtype} nv={nv} lens={lens}")
+            if ng == 5 and nv == 1 and (key_dtype, val_dtype) in ((A.I8, A.I64), (A.I64, A.F64)) and request.node.callspec.params["gpu"] == "spec":
+                from rust_dataframe_amd import lib
+                assert lib.last_kernel().startswith("gspec_kernel<G8;P:-;K:c0"), lib.last_kernel()
 
 
 @pytest.mark.gpu

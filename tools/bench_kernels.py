@@ -157,6 +157,25 @@ def main():
             lib.set_option("gb_partition", 0)
             report(f"groupby_sum_{ng}_groups_hbm_atomics", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
             lib.set_option("gb_partition", 1)
+    # config C5 (TPC-H Q1 shape): filter(shipdate <= c) -> 5 sums + counts in 6 groups, 38 B/row
+    if not only or "q1_grouped" in only:
+        qty = torch.randint(1, 51, (n,), device="cuda").to(torch.float64)
+        price = dev_f64(n, 11, 900.0, 105000.0)
+        disc = torch.randint(0, 11, (n,), device="cuda").to(torch.float64) / 100.0
+        tax = torch.randint(0, 9, (n,), device="cuda").to(torch.float64) / 100.0
+        flag = torch.randint(0, 3, (n,), dtype=torch.int8, device="cuda")
+        status = torch.randint(0, 2, (n,), dtype=torch.int8, device="cuda")
+        ship = torch.randint(8036, 10562, (n,), dtype=torch.int32, device="cuda")
+        qcols = [[arr(qty, A.F64, n)], [arr(price, A.F64, n)], [arr(disc, A.F64, n)], [arr(tax, A.F64, n)],
+                 [arr(flag, A.I8, n)], [arr(status, A.I8, n)], [arr(ship, A.I32, n)]]
+        q = A.Expr()
+        c_ = [q.col(i) for i in range(7)]
+        pred = q.op("le", c_[6], q.scalar(10471, A.I32))
+        gid = q.op("add", q.op("multiply", q.cast(c_[4], A.I32), q.scalar(2, A.I32)), q.cast(c_[5], A.I32))
+        dp = q.op("multiply", c_[1], q.op("subtract", q.scalar(1.0), c_[2]))
+        ch = q.op("multiply", dp, q.op("add", q.scalar(1.0), c_[3]))
+        report("q1_grouped", 38.0 * n, lambda: api.group_pipeline(q, qcols, [c_[0], c_[1], dp, ch, c_[2]], gid, 6, pred))
+        del qty, price, disc, tax, flag, status, ship
     # A/B in one process: the specialised template kernel vs the dedicated filter_agg_f64 kernel on the headline shape
     for rep in range(3):
         lib.set_option("spec", 1)
@@ -170,7 +189,7 @@ def main():
             lib.set_option("vec_bitmap", vb)
             report(f"ab_filter_sum_validity_vecbitmap{vb}_{rep}", 8.125 * n, lambda: api.pipeline(e, [[XV]], [cx], gt))
             report(f"ab_sum_validity_vecbitmap{vb}_{rep}", 8.125 * n, lambda: api.pipeline(e, [[XV]], [cx]))
-    lib.set_option("vec_bitmap", 0)
+    lib.set_option("vec_bitmap", 1)
     return results
 
 
