@@ -57,6 +57,94 @@ def cpu_baseline(sample_rows: int, gpu_check=None):
             "_sum": r.sum, "_count": r.count}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# The other BASELINE.json configurations, selectable with --workload (the driver's default run stays the headline):
+# each returns (step, alg_bytes_per_launch, description, check) for this rank's HBM-resident shard.
+
+def workload_c3(torch, lib, api, A, sharding, dev, comm_dev, rank, rows):
+    """C3: fused a*b+c -> min/max/count and the i64 key's min/max/count, one pass over 4 columns (32 B/row)."""
+    first = rank * rows
+    cols = []
+    for cid in range(3):
+        t = torch.empty(rows, dtype=torch.float64, device=dev)
+        lib.fill_uniform_f64(t.data_ptr(), rows, SEED, cid, first, -1.0, 1.0)
+        cols.append([A.DeviceArray(t.data_ptr(), None, 0, rows, A.F64, 0, keep=t)])
+    k = torch.empty(rows, dtype=torch.int64, device=dev)
+    lib.fill_uniform_i64(k.data_ptr(), rows, SEED, 3, first, -2 ** 31, 2 ** 31)
+    cols.append([A.DeviceArray(k.data_ptr(), None, 0, rows, A.I64, 0, keep=k)])
+    e = A.Expr()
+    fma = e.op("add", e.op("multiply", e.col(0), e.col(1)), e.col(2))
+    roots = [fma, e.col(3)]
+
+    def step():
+        y, kk = sharding.all_combine(api.pipeline(e, cols, roots), device=comm_dev)
+        return {"min_y": y.min, "max_y": y.max, "count_y": y.count, "min_k": kk.min, "max_k": kk.max}
+    return step, 32.0 * rows, f"C3: fused a*b+c -> min/max/count + i64 key min/max/count over {rows:.0e} rows x 4 columns per GPU"
+
+
+def workload_c4(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, ngroups=1_000_000):
+    """C4: SELECT key, sum(val) GROUP BY key, 1e6 keys: local hash aggregate, then (N > 1) the all-to-all of partial groups."""
+    import numpy as np
+    first = rank * rows
+    kk = torch.empty(rows, dtype=torch.int64, device=dev)
+    lib.fill_uniform_i64(kk.data_ptr(), rows, SEED, 7, first, 0, ngroups)
+    v = torch.empty(rows, dtype=torch.float64, device=dev)
+    lib.fill_uniform_f64(v.data_ptr(), rows, SEED, 0, first, 0.0, 1.0)
+    K = A.DeviceArray(kk.data_ptr(), None, 0, rows, A.I64, 0, keep=kk)
+    V = A.DeviceArray(v.data_ptr(), None, 0, rows, A.F64, 0, keep=v)
+    cap = ngroups + 2
+    bufs = [torch.empty(cap * 8 + 64, dtype=torch.uint8, device=dev) for _ in range(3)]
+    outs = tuple(A.DeviceArray(b.data_ptr(), None, 0, cap, dt, 0, keep=b) for b, dt in zip(bufs, (A.I64, A.F64, A.I64)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    def step():
+        gk, gs, gc = api.groupby_sum([K], [V], ngroups, outs)
+        ng = gk.length
+        if world == 1:
+            return {"groups": ng}
+        # partial groups of this rank -> owners (RCCL all-to-all), merged there by a second, tiny group-by
+        hk = torch.empty(ng, dtype=torch.int64); hs = torch.empty(ng, dtype=torch.float64); hc = torch.empty(ng, dtype=torch.int64)
+        lib.load().rdf_copy_d2h(hk.data_ptr(), gk.values_ptr, ng * 8)
+        lib.load().rdf_copy_d2h(hs.data_ptr(), gs.values_ptr, ng * 8)
+        lib.load().rdf_copy_d2h(hc.data_ptr(), gc.values_ptr, ng * 8)
+        rk, rs, rc = sharding.exchange_groups(hk.numpy(), hs.numpy(), hc.numpy(), comm_dev)
+        Kh = [A.HostArray.from_numpy(rk)]
+        mk, ms, _ = api.groupby_sum(Kh, [A.HostArray.from_numpy(rs)], ngroups)
+        return {"groups_owned": mk.length}
+    return step, 16.0 * rows, f"C4: hash GROUP BY key -> sum(val), {ngroups:.0e} keys over {rows:.0e} rows per GPU"
+
+
+def workload_q1(torch, lib, api, A, sharding, dev, comm_dev, rank, rows):
+    """C5: TPC-H Q1 shape over a synthetic lineitem shard (38 B/row): filter(shipdate <= c) -> 5 sums + counts in 6 groups."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED + rank)
+    qty = torch.randint(1, 51, (rows,), device=dev, generator=g).to(torch.float64)
+    price = torch.empty(rows, dtype=torch.float64, device=dev)
+    lib.fill_uniform_f64(price.data_ptr(), rows, SEED, 11, rank * rows, 900.0, 105000.0)
+    disc = torch.randint(0, 11, (rows,), device=dev, generator=g).to(torch.float64) / 100.0
+    tax = torch.randint(0, 9, (rows,), device=dev, generator=g).to(torch.float64) / 100.0
+    flag = torch.randint(0, 3, (rows,), dtype=torch.int8, device=dev, generator=g)
+    status = torch.randint(0, 2, (rows,), dtype=torch.int8, device=dev, generator=g)
+    ship = torch.randint(8036, 10562, (rows,), dtype=torch.int32, device=dev, generator=g)
+    cols = [[A.DeviceArray(t.data_ptr(), None, 0, rows, dt, 0, keep=t)] for t, dt in
+            ((qty, A.F64), (price, A.F64), (disc, A.F64), (tax, A.F64), (flag, A.I8), (status, A.I8), (ship, A.I32))]
+    q = A.Expr()
+    c = [q.col(i) for i in range(7)]
+    pred = q.op("le", c[6], q.scalar(10471, A.I32))
+    gid = q.op("add", q.op("multiply", q.cast(c[4], A.I32), q.scalar(2, A.I32)), q.cast(c[5], A.I32))
+    dp = q.op("multiply", c[1], q.op("subtract", q.scalar(1.0), c[2]))
+    ch = q.op("multiply", dp, q.op("add", q.scalar(1.0), c[3]))
+    vals = [c[0], c[1], dp, ch, c[2]]
+
+    def step():
+        res, nrows = sharding.all_combine_groups(api.group_pipeline(q, cols, vals, gid, 6, pred), device=comm_dev)
+        return {"count_star": nrows[:6], "sum_qty": [r[0] for r in res[0][:6]]}
+    return step, 38.0 * rows, f"C5: TPC-H Q1 shape (filter -> 5 sums + counts in 6 groups) over a {rows:.0e}-row synthetic lineitem shard per GPU"
+
+
+WORKLOADS = {"c3": workload_c3, "c4": workload_c4, "q1": workload_q1}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +155,8 @@ def main():
     ap.add_argument("--null-fraction", type=float, default=0.0, help="attach a validity bitmap with this null rate")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for a smoke test)")
     ap.add_argument("--share-gpu", action="store_true", help="smoke test only: every rank uses device 0 (needs --backend gloo)")
+    ap.add_argument("--workload", default="headline", choices=["headline"] + sorted(WORKLOADS),
+                    help="headline = BASELINE.json's metric (the default, what the driver runs); c3 / c4 / q1 = the other configs")
     args = ap.parse_args()
 
     import torch
@@ -99,6 +189,8 @@ def main():
     comm_dev = dev if (world == 1 or args.backend == "nccl") else None   # gloo exchanges CPU tensors
 
     rows = args.rows
+    if args.workload != "headline":
+        return run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, world)
     first_row = rank * rows
     x = torch.empty(rows, dtype=torch.float64, device=dev)
     lib.fill_uniform_f64(x.data_ptr(), rows, SEED, 0, first_row, 0.0, 1.0)
@@ -189,6 +281,52 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, world):
+    """Same timing contract as the headline, for the other BASELINE.json configurations."""
+    rows = args.rows
+    step, alg_bytes, desc = WORKLOADS[args.workload](torch, lib, api, A, sharding, dev, comm_dev, rank, rows)
+
+    def sync():
+        torch.cuda.synchronize()
+        lib.synchronize()
+    sync()   # the synthetic columns were written on torch's stream; the library launches on its own
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    lib.kernel_timing_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kern_ms, kern_n = lib.kernel_timing_get()
+    kernel_name = lib.last_kernel()
+    lib.kernel_timing_reset(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+        dist.destroy_process_group()
+    if rank == 0:
+        per_launch_s = kern_ms / max(kern_n, 1) * 1e-3 * (kern_n / args.steps if kern_n else 0)   # all timed kernels of one step
+        achieved = alg_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        print(json.dumps({
+            "metric": f"rows/sec {args.workload}", "value": rows * world * args.steps / elapsed, "unit": "rows/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "rows_per_gpu": rows, "total_rows": rows * world, "result": res},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": kernel_name, "kernel_ms_per_step": per_launch_s * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }), flush=True)
 
 
 if __name__ == "__main__":

@@ -104,6 +104,61 @@ def all_combine(local: Sequence[AggResult], device=None) -> List[AggResult]:
     return out
 
 
+def combine_groups(parts):
+    """Fold per-rank results of Api.group_pipeline — (res[v][g] = (sum, count), rows[g]) — in rank order.
+    A dense group domain is tiny (<= 1024 slots): the combine is an all_gather, not a shuffle."""
+    res0, rows0 = parts[0]
+    res = [[(s, c) for (s, c) in row] for row in res0]
+    rows = list(rows0)
+    for r, rw in parts[1:]:
+        for v, row in enumerate(r):
+            for g, (s, c) in enumerate(row):
+                s0, c0 = res[v][g]
+                t = s0 + s
+                if isinstance(t, int):   # wrapping Int64 like the device fold
+                    t = (t + (1 << 63)) % (1 << 64) - (1 << 63)
+                res[v][g] = (t, c0 + c)
+        rows = [a + b for a, b in zip(rows, rw)]
+    return res, rows
+
+
+def all_combine_groups(local, device=None):
+    """all_gather every rank's (res, rows) of Api.group_pipeline and fold them identically on every rank.
+    f64 sums travel as f64, integer sums / counts as i64 (exact)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return combine_groups([local])
+    world = dist.get_world_size()
+    res, rows = local
+    nv, S = len(res), len(rows)
+    isf = [isinstance(res[v][0][0], float) for v in range(nv)]
+    f = torch.zeros(nv * S, dtype=torch.float64)
+    i = torch.zeros(2 * nv * S + S, dtype=torch.int64)
+    for v in range(nv):
+        for g in range(S):
+            s, c = res[v][g]
+            if isf[v]:
+                f[v * S + g] = s
+            else:
+                i[v * S + g] = s
+            i[nv * S + v * S + g] = c
+    for g in range(S):
+        i[2 * nv * S + g] = rows[g]
+    if device is not None:
+        f, i = f.to(device), i.to(device)
+    fs = [torch.zeros_like(f) for _ in range(world)]
+    is_ = [torch.zeros_like(i) for _ in range(world)]
+    dist.all_gather(fs, f)
+    dist.all_gather(is_, i)
+    parts = []
+    for r in range(world):
+        fl, il = fs[r].tolist(), is_[r].tolist()
+        rr = [[((fl[v * S + g] if isf[v] else int(il[v * S + g])), int(il[nv * S + v * S + g])) for g in range(S)] for v in range(nv)]
+        parts.append((rr, [int(il[2 * nv * S + g]) for g in range(S)]))
+    return combine_groups(parts)
+
+
 # ---------------------------------------------------------------- group-by across ranks (the one real exchange)
 def group_owner(keys, world: int):
     """Owning rank of each group key: a multiplicative hash of the key bits, mod world."""

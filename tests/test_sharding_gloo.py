@@ -156,3 +156,48 @@ def test_groupby_all_to_all_world_2_gloo(ora):
     assert got.keys() == exp.keys()
     for key, (sm, cnt) in exp.items():
         assert got[key][1] == cnt and abs(got[key][0] - sm) <= 1e-9 * max(abs(sm), 1.0)
+
+
+# ---------------------------------------------------------------- config C5 (Q1 shape) across ranks: dense groups, all_gather combine
+def _q1_inputs():
+    from test_group_pipeline import q1_columns, q1_program, _cols_list
+    cols = q1_columns(np.random.default_rng(17), LENS, null_frac=0.05)
+    return _cols_list(cols), q1_program()
+
+
+def _q1_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cols, (e, pred, gid, vals) = _q1_inputs()
+        first, last = sharding.shard_chunks(LENS, world)[rank]
+        local = oracle.api().group_pipeline(e, [c[first:last] for c in cols], vals, gid, 6, pred)
+        q.put((rank, sharding.all_combine_groups(local)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_q1_groups_world_2_gloo(ora):
+    """Row-sharded Q1: each rank aggregates its RecordBatches into the 6+1 dense groups, one all_gather of the
+    tiny tables, identical fold on every rank; equals the single-process result."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_group_pipeline import check_groups
+    world, port = 2, 33500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_q1_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0] == results[1]
+    cols, (e, pred, gid, vals) = _q1_inputs()
+    whole = ora.group_pipeline(e, cols, vals, gid, 6, pred)
+    check_groups(results[0], whole, "2 ranks vs whole")

@@ -50,6 +50,7 @@ def out_like(dtype, n, with_validity=False):
 
 
 def timed(fn, steps, warmup=2):
+    torch.cuda.synchronize()   # inputs made by torch ops live on torch's stream; the library launches on its own
     for _ in range(warmup):
         fn()
     lib.synchronize()
