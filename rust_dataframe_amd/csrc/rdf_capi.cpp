@@ -44,7 +44,8 @@ struct Ctx {
     bool   opt_spec = true;        // specialised straight-line kernels (rdf_spec.hip)
     bool   opt_fast_filter = true; // filter_agg_f64_kernel (handles 8-byte-misaligned columns)
     bool   opt_vec_bitmap = true;  // bitmap words via vector loads (default) instead of scalar loads (spec kernels)
-    bool   opt_gb_partition = true; // high-cardinality GROUP BY: radix-partition + LDS aggregation instead of HBM atomics // bitmap words via vector loads instead of scalar loads (spec kernels)
+    int    opt_gb_debug = 0;        // ablations of the partitioned GROUP BY (tools/bench_kernels.py): 1 = aggregate without LDS work, 2 = scatter without stores
+    int    opt_gb_partition = 1;    // high-cardinality GROUP BY: 1 = single scatter pass + LDS tables (default), 2 = the radix-sort based two-pass variant, 0 = HBM atomics // bitmap words via vector loads instead of scalar loads (spec kernels)
     // kernel timing (bench.py roofline leg)
     bool   timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -2040,6 +2041,64 @@ rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks
 
 // ---------------------------------------------------------------- group-by
 
+// Tail of both partitioned GROUP BY paths: read back {special sums, counts, flags, cursor}, append the two special
+// groups (the key whose hash is the LDS free marker; the NULL key) and copy the dense results to the caller.
+static rdf_status groupby_finish_partitioned(void* pspec, void* d_keys, void* d_sums, void* d_counts, int kdt, int64_t max_groups, int32_t mem,
+                                             rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts, size_t pin_off) {
+    Ctx& ctx = g_ctx;
+    struct { void* out_keys; void* out_sums; void* out_counts; } ga = {d_keys, d_sums, d_counts};
+        // specials + cursor + flags
+        RDF_TRY(pinned_reserve(pin_off + 256));
+        HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, pspec, 128, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        unsigned long long hs[4];
+        unsigned int hf[8];
+        memcpy(hs, ctx.pinned + pin_off, 32);
+        memcpy(hf, ctx.pinned + pin_off + 32, 32);
+        const int64_t ng_main = hf[2];
+        if ((hf[4] & 4u) || ng_main > max_groups) return fail(RDF_MEMORY_ERROR, "groupby: more than max_groups (%lld) distinct keys", (long long)max_groups);
+        // append the two special groups on the host side of the copy
+        const size_t kes2 = (size_t)dtype_size(kdt);
+        int64_t ng = ng_main;
+        int64_t null_idx = -1;
+        auto put = [&](uint64_t key, unsigned long long sum, unsigned long long cnt) -> rdf_status {
+            HIP_TRY(hipMemcpyAsync((char*)ga.out_keys + (size_t)ng * kes2, &key, kes2, hipMemcpyHostToDevice, ctx.stream));
+            HIP_TRY(hipMemcpyAsync((char*)ga.out_sums + (size_t)ng * 8, &sum, 8, hipMemcpyHostToDevice, ctx.stream));
+            HIP_TRY(hipMemcpyAsync((char*)ga.out_counts + (size_t)ng * 8, &cnt, 8, hipMemcpyHostToDevice, ctx.stream));
+            HIP_TRY(hipStreamSynchronize(ctx.stream));
+            ++ng;
+            return RDF_OK;
+        };
+        if (hf[0]) {  // the key whose hash equals the LDS free marker: unmix on the host
+            uint64_t z = ~0ull;
+            z ^= z >> 31; z ^= z >> 62; z *= 0x319642b2d24d8ec3ull; z ^= z >> 27; z ^= z >> 54; z *= 0x96de1b173f119089ull; z ^= z >> 30; z ^= z >> 60;
+            RDF_TRY(put(z, hs[0], hs[2]));
+        }
+        if (hf[1]) { null_idx = ng; RDF_TRY(put(0, hs[1], hs[3])); }
+        const hipMemcpyKind kind = mem == RDF_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+        if (ng > 0) {
+            HIP_TRY(hipMemcpyAsync(out_keys->values, ga.out_keys, (size_t)ng * kes2, kind, ctx.stream));
+            HIP_TRY(hipMemcpyAsync(out_sums->values, ga.out_sums, (size_t)ng * 8, kind, ctx.stream));
+            HIP_TRY(hipMemcpyAsync(out_counts->values, ga.out_counts, (size_t)ng * 8, kind, ctx.stream));
+        }
+        rdf_out* outs3[3] = {out_keys, out_sums, out_counts};
+        for (rdf_out* o : outs3)
+            if (o->validity && ng > 0) {
+                if (mem == RDF_MEM_HOST) memset(o->validity, 0xFF, (size_t)((ng + 7) / 8));
+                else HIP_TRY(hipMemsetAsync(o->validity, 0xFF, (size_t)((ng + 7) / 8), ctx.stream));
+            }
+        if (null_idx >= 0) {
+            const uint8_t byte = (uint8_t)~(1u << (null_idx & 7));
+            if (mem == RDF_MEM_HOST) out_keys->validity[null_idx >> 3] &= byte;
+            else HIP_TRY(hipMemcpyAsync(out_keys->validity + (null_idx >> 3), &byte, 1, hipMemcpyHostToDevice, ctx.stream));
+        }
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        out_keys->length = out_sums->length = out_counts->length = ng;
+        out_keys->null_count = null_idx >= 0 ? 1 : 0;
+        out_sums->null_count = out_counts->null_count = 0;
+    return RDF_OK;
+}
+
 rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,
                            rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts) {
     if (nchunks < 1 || !keys) return fail(RDF_INVALID_ARGUMENT, "groupby: a column has at least one chunk");
@@ -2101,6 +2160,70 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
     bool value_nulls = false;
     if (values) for (int64_t c = 0; c < nchunks; ++c) value_nulls |= values[c].validity != nullptr;
     const int64_t nrows = row_start[(size_t)nchunks];
+    if (ctx.opt_gb_partition && max_groups > 1024 && max_groups <= kGbMaxGroups && !value_nulls && nrows > 0 && ctx.opt_gb_partition != 2) {
+        // single scatter pass on 9 hash bits, then one LDS table per partition
+        constexpr int P = 1 << kGbPartBits;
+        const int64_t ntiles = tile_start[(size_t)nchunks];
+        const int64_t nsuper = (ntiles + kGbSuper / kEvalTile - 1) / (kGbSuper / kEvalTile);
+        int nb = (int)std::min<int64_t>(nsuper, (int64_t)eval_grid_limit() / 4);   // 2 resident blocks of 512 threads per CU
+        if (nb < 1) nb = 1;
+        const int64_t tiles_per_block = (nsuper + nb - 1) / nb * (kGbSuper / kEvalTile);
+        void *precs, *hist0, *hist1, *ptmp, *pspec;
+        RDF_TRY(arena_alloc((size_t)nrows * 16 + 64, &precs));
+        RDF_TRY(arena_alloc((size_t)((int64_t)P * nb + 1) * 8, &hist0));
+        RDF_TRY(arena_alloc((size_t)((int64_t)P * nb + 1 + scan_scratch_words((int64_t)P * nb)) * 8, &hist1));
+        const int64_t cap_out = max_groups + 2;
+        RDF_TRY(arena_alloc((size_t)cap_out * 24 + 64, &ptmp));
+        RDF_TRY(arena_alloc(128, &pspec));
+        HIP_TRY(hipMemsetAsync(pspec, 0, 128, ctx.stream));
+        unsigned long long* sp_sums = (unsigned long long*)pspec;         // [2]
+        unsigned long long* sp_counts = sp_sums + 2;                      // [2]
+        unsigned int* sp_flag = (unsigned int*)(sp_counts + 2);           // [2]
+        unsigned int* d_cursor = sp_flag + 2;
+        uint32_t* d_flags2 = (uint32_t*)(sp_flag + 4);
+        GbPartArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.keys = tb.dev_at<DevChunkCol>(o_k);
+        pa.values = tb.dev_at<DevChunkCol>(o_v);
+        pa.chunk_tile_start = tb.dev_at<int64_t>(o_ts);
+        pa.chunk_len = tb.dev_at<int64_t>(o_len);
+        pa.nchunks = nchunks;
+        pa.ntiles = ntiles;
+        pa.tiles_per_block = ctx.opt_gb_debug == 2 ? 1 : tiles_per_block;
+        pa.key_dtype = kdt;
+        pa.value_dtype = vdt;
+        pa.hist = (int64_t*)hist0;
+        pa.recs = (uint64_t*)precs;
+        pa.special_sums = sp_sums;
+        pa.special_counts = sp_counts;
+        pa.special = sp_flag;
+        KernelTimer kt;
+        HIP_TRY(launch_gb_hist(pa, nb, ctx.stream));
+        HIP_TRY(launch_scan((const int64_t*)hist0, (int64_t*)hist1, (int64_t)P * nb, (int64_t*)hist1 + (int64_t)P * nb + 1, ctx.stream));
+        pa.hist = (int64_t*)hist1;
+        HIP_TRY(launch_gb_scatter(pa, nb, ctx.stream));
+        GbAggArgs ga;
+        memset(&ga, 0, sizeof ga);
+        ga.recs = (const uint64_t*)precs;
+        ga.scan = (const int64_t*)hist1;
+        ga.nblocks = nb;
+        ga.is_f64 = sdt == RDF_F64;
+        ga.has_values = values != nullptr;
+        ga.key_dtype = kdt;
+        char* tmp = (char*)ptmp;
+        ga.out_keys = tmp;
+        ga.out_sums = tmp + (size_t)cap_out * 8;
+        ga.out_counts = (int64_t*)(tmp + (size_t)cap_out * 16);
+        ga.cursor = d_cursor;
+        ga.flags = d_flags2;
+        ga.max_out = max_groups;
+        ga.pad = ctx.opt_gb_debug == 1 ? 1 : 0;
+        HIP_TRY(launch_gb_aggregate(ga, ctx.stream));
+        kt.stop();
+        ctx.last_kernel = "gb_aggregate_kernel";
+        RDF_TRY(groupby_finish_partitioned(pspec, ga.out_keys, ga.out_sums, ga.out_counts, kdt, max_groups, mem, out_keys, out_sums, out_counts, pin_off));
+        return RDF_OK;
+    }
     if (ctx.opt_gb_partition && max_groups > 1024 && !value_nulls && nrows > 0) {
         const int npass = max_groups > 131072 ? 2 : 1;
         const int64_t stiles = (nrows + kSortTile - 1) / kSortTile;
@@ -2173,55 +2296,7 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
         HIP_TRY(launch_groupby_partitions(ga, ctx.stream));
         kt.stop();
         ctx.last_kernel = "groupby_partitions_kernel";
-        // specials + cursor + flags
-        RDF_TRY(pinned_reserve(pin_off + 256));
-        HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, pspec, 128, hipMemcpyDeviceToHost, ctx.stream));
-        HIP_TRY(hipStreamSynchronize(ctx.stream));
-        unsigned long long hs[4];
-        unsigned int hf[8];
-        memcpy(hs, ctx.pinned + pin_off, 32);
-        memcpy(hf, ctx.pinned + pin_off + 32, 32);
-        const int64_t ng_main = hf[2];
-        if ((hf[4] & 4u) || ng_main > max_groups) return fail(RDF_MEMORY_ERROR, "groupby: more than max_groups (%lld) distinct keys", (long long)max_groups);
-        // append the two special groups on the host side of the copy
-        const size_t kes2 = (size_t)dtype_size(kdt);
-        int64_t ng = ng_main;
-        int64_t null_idx = -1;
-        auto put = [&](uint64_t key, unsigned long long sum, unsigned long long cnt) -> rdf_status {
-            HIP_TRY(hipMemcpyAsync((char*)ga.out_keys + (size_t)ng * kes2, &key, kes2, hipMemcpyHostToDevice, ctx.stream));
-            HIP_TRY(hipMemcpyAsync((char*)ga.out_sums + (size_t)ng * 8, &sum, 8, hipMemcpyHostToDevice, ctx.stream));
-            HIP_TRY(hipMemcpyAsync((char*)ga.out_counts + (size_t)ng * 8, &cnt, 8, hipMemcpyHostToDevice, ctx.stream));
-            HIP_TRY(hipStreamSynchronize(ctx.stream));
-            ++ng;
-            return RDF_OK;
-        };
-        if (hf[0]) {  // the key whose hash equals the LDS free marker: unmix on the host
-            uint64_t z = ~0ull;
-            z ^= z >> 31; z ^= z >> 62; z *= 0x319642b2d24d8ec3ull; z ^= z >> 27; z ^= z >> 54; z *= 0x96de1b173f119089ull; z ^= z >> 30; z ^= z >> 60;
-            RDF_TRY(put(z, hs[0], hs[2]));
-        }
-        if (hf[1]) { null_idx = ng; RDF_TRY(put(0, hs[1], hs[3])); }
-        const hipMemcpyKind kind = mem == RDF_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-        if (ng > 0) {
-            HIP_TRY(hipMemcpyAsync(out_keys->values, ga.out_keys, (size_t)ng * kes2, kind, ctx.stream));
-            HIP_TRY(hipMemcpyAsync(out_sums->values, ga.out_sums, (size_t)ng * 8, kind, ctx.stream));
-            HIP_TRY(hipMemcpyAsync(out_counts->values, ga.out_counts, (size_t)ng * 8, kind, ctx.stream));
-        }
-        rdf_out* outs3[3] = {out_keys, out_sums, out_counts};
-        for (rdf_out* o : outs3)
-            if (o->validity && ng > 0) {
-                if (mem == RDF_MEM_HOST) memset(o->validity, 0xFF, (size_t)((ng + 7) / 8));
-                else HIP_TRY(hipMemsetAsync(o->validity, 0xFF, (size_t)((ng + 7) / 8), ctx.stream));
-            }
-        if (null_idx >= 0) {
-            const uint8_t byte = (uint8_t)~(1u << (null_idx & 7));
-            if (mem == RDF_MEM_HOST) out_keys->validity[null_idx >> 3] &= byte;
-            else HIP_TRY(hipMemcpyAsync(out_keys->validity + (null_idx >> 3), &byte, 1, hipMemcpyHostToDevice, ctx.stream));
-        }
-        HIP_TRY(hipStreamSynchronize(ctx.stream));
-        out_keys->length = out_sums->length = out_counts->length = ng;
-        out_keys->null_count = null_idx >= 0 ? 1 : 0;
-        out_sums->null_count = out_counts->null_count = 0;
+        RDF_TRY(groupby_finish_partitioned(pspec, ga.out_keys, ga.out_sums, ga.out_counts, kdt, max_groups, mem, out_keys, out_sums, out_counts, pin_off));
         return RDF_OK;
     }
 
@@ -2344,7 +2419,8 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     if (strcmp(name, "spec") == 0) g_ctx.opt_spec = value != 0;
     else if (strcmp(name, "fast_filter") == 0) g_ctx.opt_fast_filter = value != 0;
     else if (strcmp(name, "vec_bitmap") == 0) g_ctx.opt_vec_bitmap = value != 0;
-    else if (strcmp(name, "gb_partition") == 0) g_ctx.opt_gb_partition = value != 0;
+    else if (strcmp(name, "gb_partition") == 0) g_ctx.opt_gb_partition = (int)value;
+    else if (strcmp(name, "gb_debug") == 0) g_ctx.opt_gb_debug = (int)value;
     else return fail(RDF_INVALID_ARGUMENT, "unknown option %s", name);
     return RDF_OK;
 }

@@ -12,6 +12,12 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 // wave index inside the block as a scalar (the compiler cannot prove threadIdx.x >> 6 uniform)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// Pointers read out of chunk tables in memory are generic ("flat") to the compiler: flat loads count in lgkmcnt
+// as well as vmcnt, so the next scalar-load wait (s_waitcnt lgkmcnt(0)) also drains every vector load in flight.
+// Everything the ABI hands us lives in global memory: say so.
+template <class T> using GlobalPtr = const T __attribute__((address_space(1)))*;
+template <class T> __device__ __forceinline__ GlobalPtr<T> as_global(const void* p) { return (GlobalPtr<T>)p; }
+
 __device__ __forceinline__ int clamp64(int64_t v) { return v <= 0 ? 0 : (v >= 64 ? 64 : (int)v); }
 
 // NW consecutive 64-bit windows of an LSB-first bitmap starting at bit `bitpos` (wave-uniform), rows

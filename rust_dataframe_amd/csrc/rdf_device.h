@@ -227,6 +227,40 @@ struct GroupAggArgs {
     int64_t         max_out;
 };
 
+// Single-pass partitioned GROUP BY (the default for 1024 < max_groups <= kGbMaxGroups): rows are scattered ONCE on the
+// top kGbPartBits bits of mix64(key) as 16-byte (hashed key, value bits) records — per-block LDS staging turns the
+// scatter into runs of consecutive records — and every partition is aggregated in an LDS table.
+// HBM traffic: 8 (histogram) + 16 + 16 (scatter) + 16 (aggregate) = 56 B/row.
+constexpr int kGbBlock = 512;                       // threads per block of the three kernels
+constexpr int kGbRows = 8;                          // rows per thread per iteration
+constexpr int kGbSuper = kGbBlock * kGbRows;        // 4096 rows = 4 tiles of kEvalTile rows per block iteration
+constexpr int kGbPartBits = 9;                      // 512 partitions
+constexpr int kGbSlots = 4000;                      // LDS table slots per partition (20 B each: 2 blocks per CU)
+constexpr int64_t kGbMaxGroups = (int64_t)(1 << kGbPartBits) * 2600;   // keeps the expected load of a table under 0.65
+struct GbPartArgs {
+    const DevChunkCol* keys;             // [nchunks]
+    const DevChunkCol* values;           // [nchunks]
+    const int64_t*     chunk_tile_start; // [nchunks + 1], tiles of kEvalTile rows
+    const int64_t*     chunk_len;
+    int64_t            nchunks, ntiles, tiles_per_block;   // block b owns tiles [b * tiles_per_block, +tiles_per_block)
+    int32_t            key_dtype, value_dtype;
+    int64_t*           hist;             // histogram kernel: out counts [digit * gridDim.x + block]; scatter: their exclusive scan
+    uint64_t*          recs;             // scatter out: [2 * rows] (hashed key, value bits)
+    unsigned long long* special_sums;    // [2]: rows whose hashed key equals the LDS free marker / rows with a NULL key
+    unsigned long long* special_counts;  // [2]
+    unsigned int*      special;          // [2] group exists
+};
+struct GbAggArgs {
+    const uint64_t* recs;
+    const int64_t*  scan;                // [ (1 << kGbPartBits) * nblocks + 1 ] exclusive scan of the histogram
+    int64_t         nblocks;             // blocks of the histogram / scatter kernels
+    int32_t         is_f64, has_values, key_dtype, pad;
+    void*           out_keys; void* out_sums; int64_t* out_counts;
+    unsigned int*   cursor;
+    uint32_t*       flags;               // bit 2: an LDS table overflowed / more than max_out groups
+    int64_t         max_out;
+};
+
 // Hash GROUP BY key -> {sum(value), count(value)}: open addressing, linear probing, 64-bit keys.
 struct GroupTable {
     unsigned long long* keys;   // [capacity] slot keys, kGroupEmpty = free
@@ -296,6 +330,9 @@ hipError_t launch_join_append(const JoinAppendArgs& a, hipStream_t s);
 hipError_t launch_count_bytes(const uint8_t* p, int64_t n, unsigned long long* out, hipStream_t s);
 hipError_t launch_sort_hist64(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_sort_scatter64(const SortPassArgs& a, hipStream_t s);
+hipError_t launch_gb_hist(const GbPartArgs& a, int grid, hipStream_t s);
+hipError_t launch_gb_scatter(const GbPartArgs& a, int grid, hipStream_t s);
+hipError_t launch_gb_aggregate(const GbAggArgs& a, hipStream_t s);
 hipError_t launch_groupby_prepare(const GroupPrepArgs& a, hipStream_t s);
 hipError_t launch_groupby_partitions(const GroupAggArgs& a, hipStream_t s);
 hipError_t launch_groupby_build(const GroupByArgs& a, hipStream_t s);

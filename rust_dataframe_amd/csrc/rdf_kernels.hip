@@ -900,6 +900,259 @@ __global__ __launch_bounds__(kBlock) void groupby_partitions_kernel(const GroupA
     if (err) atomicOr(a.flags, err);
 }
 
+// ---- single-pass partitioned GROUP BY ----
+// A block iteration covers one super-tile: 4 tiles of kEvalTile rows (each inside one chunk), thread t takes the rows
+// q = j * kGbBlock + t.  All loads of the iteration are issued before anything depends on them (one row at a time
+// would leave a single 8-byte load in flight per lane: latency-bound at a quarter of the bandwidth).
+struct GbBatch {
+    uint64_t key[kGbRows], val[kGbRows];   // raw key (sign-/zero-extended), value bits
+    uint32_t exists, knull;                // bit j: row j exists / its key is NULL
+};
+__device__ __forceinline__ int gb_dtype_size(int dt) {
+    switch (dt) {
+        case RDF_I8: case RDF_U8: return 1;
+        case RDF_I16: case RDF_U16: return 2;
+        case RDF_I32: case RDF_U32: case RDF_F32: return 4;
+        default: return 8;
+    }
+}
+// raw element `row` of a column of `size`-byte elements, zero-extended; `size` is block-uniform, so the branch is
+// scalar and the loads of consecutive calls stay back to back
+__device__ __forceinline__ uint64_t gb_load_raw(const void* base, int size, int64_t idx, bool pred) {
+    uint64_t x = 0;
+    if (size == 8) { if (pred) x = as_global<uint64_t>(base)[idx]; }
+    else if (size == 4) { if (pred) x = as_global<uint32_t>(base)[idx]; }
+    else if (size == 2) { if (pred) x = as_global<uint16_t>(base)[idx]; }
+    else { if (pred) x = as_global<uint8_t>(base)[idx]; }
+    return x;
+}
+template <bool WITH_VALUES>
+__device__ __forceinline__ void gb_load_batch(const GbPartArgs& a, int64_t st, int64_t tile_end, int tid, GbBatch& b) {
+    static_assert(kGbBlock * 2 == kEvalTile && kGbRows == 8, "thread t holds rows t and t + 512 of each of the 4 tiles");
+    b.exists = 0; b.knull = 0;
+    const int ksz = gb_dtype_size(a.key_dtype), vsz = gb_dtype_size(a.value_dtype);
+    uint32_t vb[kGbRows];
+    int vbit[kGbRows];
+#pragma unroll
+    for (int tt = 0; tt < kGbRows / 2; ++tt) {
+        const int j0 = 2 * tt, j1 = 2 * tt + 1;
+        b.key[j0] = b.key[j1] = 0; b.val[j0] = b.val[j1] = 0;
+        vb[j0] = vb[j1] = 0xFFu; vbit[j0] = vbit[j1] = 0;
+        const int64_t tile = st + tt;                 // block-uniform: the chunk lookup below runs on the scalar unit
+        if (tile >= tile_end) continue;
+        const int64_t c = a.nchunks == 1 ? 0 : find_chunk(a.chunk_tile_start, a.nchunks, tile);
+        const int64_t r0 = (tile - a.chunk_tile_start[c]) * kEvalTile;
+        const int64_t clen = a.chunk_len[c];
+        const DevChunkCol kc = a.keys[c];
+        const int64_t row0 = r0 + tid, row1 = r0 + kGbBlock + tid;
+        const bool e0 = row0 < clen, e1 = row1 < clen;
+        b.exists |= ((uint32_t)e0 << j0) | ((uint32_t)e1 << j1);
+        b.key[j0] = gb_load_raw(kc.values, ksz, kc.offset + row0, e0);
+        b.key[j1] = gb_load_raw(kc.values, ksz, kc.offset + row1, e1);
+        if (kc.validity) {
+            const int64_t b0 = kc.offset + row0, b1 = kc.offset + row1;
+            if (e0) vb[j0] = as_global<uint8_t>(kc.validity)[b0 >> 3];
+            if (e1) vb[j1] = as_global<uint8_t>(kc.validity)[b1 >> 3];
+            vbit[j0] = (int)(b0 & 7); vbit[j1] = (int)(b1 & 7);
+        }
+        if (WITH_VALUES && a.value_dtype >= 0) {
+            const DevChunkCol vc = a.values[c];
+            b.val[j0] = gb_load_raw(vc.values, vsz, vc.offset + row0, e0);
+            b.val[j1] = gb_load_raw(vc.values, vsz, vc.offset + row1, e1);
+        }
+    }
+    // every load above is in flight by now; nothing before this point consumed one
+#pragma unroll
+    for (int j = 0; j < kGbRows; ++j) {
+        b.key[j] = normalize_int(a.key_dtype, b.key[j]);
+        b.knull |= (uint32_t)(((vb[j] >> vbit[j]) & 1u) == 0) << j;
+        if (WITH_VALUES) {
+            if (a.value_dtype == RDF_F32) b.val[j] = d2u((double)__uint_as_float((uint32_t)b.val[j]));
+            else if (a.value_dtype >= 0 && a.value_dtype != RDF_F64) b.val[j] = normalize_int(a.value_dtype, b.val[j]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kGbBlock) void gb_hist_kernel(const GbPartArgs a) {
+    constexpr int P = 1 << kGbPartBits;
+    __shared__ unsigned int lc[P];
+    for (int i = threadIdx.x; i < P; i += kGbBlock) lc[i] = 0;
+    __syncthreads();
+    // super-tiles are dealt round-robin (block b takes b, b + grid, ...); any assignment works as long as the
+    // histogram and the scatter agree (measured: no faster or slower than contiguous per-block ranges)
+    const int64_t t1 = a.ntiles;
+    for (int64_t st = (int64_t)blockIdx.x * (kGbSuper / kEvalTile); st < t1; st += (int64_t)gridDim.x * (kGbSuper / kEvalTile)) {
+        GbBatch b;
+        gb_load_batch<false>(a, st, t1, (int)threadIdx.x, b);
+#pragma unroll
+        for (int j = 0; j < kGbRows; ++j) {
+            const uint64_t hk = mix64(b.key[j]);
+            if (((b.exists & ~b.knull) >> j & 1) && hk != kHashFree) atomicAdd(&lc[(unsigned)(hk >> (64 - kGbPartBits))], 1u);
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < P; d += kGbBlock) a.hist[(int64_t)d * gridDim.x + blockIdx.x] = (int64_t)lc[d];
+}
+
+__global__ __launch_bounds__(kGbBlock) void gb_scatter_kernel(const GbPartArgs a) {
+    constexpr int P = 1 << kGbPartBits;
+    static_assert(P == kGbBlock, "one thread per partition counter");
+    extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
+    uint64_t* skey = gsm;                       // [kGbSuper] staged records, grouped by partition
+    uint64_t* sval = gsm + kGbSuper;            // [kGbSuper]
+    int64_t* gbase = (int64_t*)(gsm + 2 * kGbSuper);              // [P] next output record of (partition, this block)
+    unsigned int* lcount = (unsigned int*)(gbase + P);            // [P] rows of the partition in this iteration
+    unsigned int* lstart = lcount + P;                            // [P] their first staging slot
+    __shared__ unsigned int wave_tot[kGbBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    gbase[tid] = a.hist[(int64_t)tid * gridDim.x + blockIdx.x];
+    lcount[tid] = 0;
+    __syncthreads();
+    const bool is_f = a.value_dtype == RDF_F64 || a.value_dtype == RDF_F32;
+    // super-tiles are dealt round-robin (block b takes b, b + grid, ...); any assignment works as long as the
+    // histogram and the scatter agree (measured: no faster or slower than contiguous per-block ranges)
+    const int64_t t1 = a.ntiles;
+    for (int64_t st = (int64_t)blockIdx.x * (kGbSuper / kEvalTile); st < t1; st += (int64_t)gridDim.x * (kGbSuper / kEvalTile)) {
+        // (A) load everything, then hash and rank inside the partition (LDS atomics: 512 counters, random digits)
+        GbBatch b;
+        gb_load_batch<true>(a, st, t1, tid, b);
+        unsigned int rank[kGbRows];
+#pragma unroll
+        for (int j = 0; j < kGbRows; ++j) {
+            rank[j] = ~0u;
+            if (!((b.exists >> j) & 1)) continue;
+            const uint64_t hk = mix64(b.key[j]);
+            b.key[j] = hk;
+            const bool knull = (b.knull >> j) & 1;
+            if (!knull && hk != kHashFree) rank[j] = atomicAdd(&lcount[(unsigned)(hk >> (64 - kGbPartBits))], 1u);
+            else {   // the two special groups: global accumulators, never staged
+                const int s = knull ? 1 : 0;
+                a.special[s] = 1;
+                if (is_f) unsafeAtomicAdd((double*)&a.special_sums[s], u2d(b.val[j])); else atomicAdd(&a.special_sums[s], (unsigned long long)b.val[j]);
+                atomicAdd(&a.special_counts[s], 1ull);
+            }
+        }
+        __syncthreads();
+        // (B) exclusive scan of the P counters (one per thread)
+        const unsigned int cnt = lcount[tid];
+        unsigned int inc = cnt;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { const unsigned int y = (unsigned int)__shfl_up((int)inc, m); if (lane >= m) inc += y; }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        unsigned int woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kGbBlock / 64; ++w) { if (w < wave) woff += wave_tot[w]; total += wave_tot[w]; }
+        lstart[tid] = woff + inc - cnt;
+        __syncthreads();
+        // (C) stage the records grouped by partition
+#pragma unroll
+        for (int j = 0; j < kGbRows; ++j)
+            if (rank[j] != ~0u) {
+                const unsigned int pos = lstart[(unsigned)(b.key[j] >> (64 - kGbPartBits))] + rank[j];
+                skey[pos] = b.key[j];
+                sval[pos] = b.val[j];
+            }
+        __syncthreads();
+        // (D) write them out: consecutive staging slots of one partition are consecutive output records
+        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+        for (unsigned int i = tid; i < total; i += kGbBlock) {
+            const uint64_t k = skey[i];
+            const unsigned int d = (unsigned int)(k >> (64 - kGbPartBits));
+            u64x2 rec;
+            rec[0] = k; rec[1] = sval[i];
+            if (a.tiles_per_block != 1) ((u64x2*)a.recs)[gbase[d] + (int64_t)(i - lstart[d])] = rec;
+        }
+        __syncthreads();
+        // (E) advance the block's output positions
+        gbase[tid] += (int64_t)cnt;
+        lcount[tid] = 0;
+        __syncthreads();
+    }
+}
+
+// One block per partition: its records are the contiguous range [scan[p * nblocks], scan[(p + 1) * nblocks]).
+__global__ __launch_bounds__(kGbBlock) void gb_aggregate_kernel(const GbAggArgs a) {
+    constexpr int P = 1 << kGbPartBits;
+    extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
+    unsigned long long* lkeys = (unsigned long long*)gsm;                 // [kGbSlots]
+    unsigned long long* lsums = lkeys + kGbSlots;                         // [kGbSlots]
+    unsigned int* lcnts = (unsigned int*)(lsums + kGbSlots);              // [kGbSlots]
+    unsigned int* misc = lcnts + kGbSlots;                                // [0] groups, [1] output base
+    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+    uint32_t err = 0;
+    for (int p = blockIdx.x; p < P; p += gridDim.x) {
+        const int64_t lo = a.scan[(int64_t)p * a.nblocks], hi = a.scan[(int64_t)(p + 1) * a.nblocks];
+        if (hi <= lo) continue;
+        for (int i = threadIdx.x; i < kGbSlots; i += kGbBlock) { lkeys[i] = kHashFree; lsums[i] = 0; lcnts[i] = 0; }
+        if (threadIdx.x == 0) misc[0] = 0;
+        __syncthreads();
+        uint64_t dbg_acc = 0;
+        auto upsert = [&](const u64x2 rec) {
+            const uint64_t hk = rec[0];
+            if (a.pad == 1) { dbg_acc ^= hk ^ rec[1]; return; }
+            // slot from the bits below the partition bits (still well mixed); multiply-shift range reduction
+            uint32_t s = (uint32_t)(((uint64_t)(uint32_t)(hk >> 20) * (uint64_t)kGbSlots) >> 32);
+            int slot = -1;
+            for (int probes = 0; probes < kGbSlots; ++probes) {
+                unsigned long long old = lkeys[s];
+                if (old != hk) {
+                    if (old != kHashFree) { s = s + 1 == (uint32_t)kGbSlots ? 0 : s + 1; continue; }
+                    old = atomicCAS(&lkeys[s], kHashFree, (unsigned long long)hk);
+                    if (old == kHashFree) atomicAdd(&misc[0], 1u);
+                    else if (old != hk) { s = s + 1 == (uint32_t)kGbSlots ? 0 : s + 1; continue; }
+                }
+                slot = (int)s;
+                break;
+            }
+            if (slot < 0) { err |= 4u; return; }
+            if (a.has_values) {
+                if (a.is_f64) unsafeAtomicAdd((double*)&lsums[slot], u2d(rec[1])); else atomicAdd(&lsums[slot], (unsigned long long)rec[1]);
+            }
+            atomicAdd(&lcnts[slot], 1u);
+        };
+        const u64x2* recs = (const u64x2*)a.recs;
+        int64_t i = lo + threadIdx.x;
+        // 4 independent 16-byte loads per lane, and the NEXT batch is issued before the current one is folded into LDS
+        constexpr int B = 4;
+        u64x2 cur[B], nxt[B];
+        bool have = i + (B - 1) * kGbBlock < hi;
+        if (have) {
+#pragma unroll
+            for (int u = 0; u < B; ++u) cur[u] = __builtin_nontemporal_load(recs + i + u * kGbBlock);
+        }
+        while (have) {
+            const int64_t ni = i + B * kGbBlock;
+            const bool nhave = ni + (B - 1) * kGbBlock < hi;
+            if (nhave) {
+#pragma unroll
+                for (int u = 0; u < B; ++u) nxt[u] = __builtin_nontemporal_load(recs + ni + u * kGbBlock);
+            }
+#pragma unroll
+            for (int u = 0; u < B; ++u) upsert(cur[u]);
+#pragma unroll
+            for (int u = 0; u < B; ++u) cur[u] = nxt[u];
+            i = ni;
+            have = nhave;
+        }
+        for (; i < hi; i += kGbBlock) upsert(__builtin_nontemporal_load(recs + i));
+        if (a.pad == 1 && dbg_acc == 0x1234567) err |= 8u;
+        __syncthreads();
+        if (threadIdx.x == 0) { misc[1] = atomicAdd(a.cursor, misc[0]); misc[0] = 0; }
+        __syncthreads();
+        for (int k = threadIdx.x; k < kGbSlots; k += kGbBlock) {
+            if (lkeys[k] == kHashFree) continue;
+            const unsigned idx = misc[1] + atomicAdd(&misc[0], 1u);
+            if ((int64_t)idx >= a.max_out) { err |= 4u; continue; }
+            store_key(a.out_keys, a.key_dtype, idx, unmix64(lkeys[k]));
+            ((uint64_t*)a.out_sums)[idx] = lsums[k];
+            a.out_counts[idx] = (int64_t)lcnts[k];
+        }
+        __syncthreads();
+    }
+    if (err) atomicOr(a.flags, err);
+}
+
 // Occupied slots -> dense outputs (order = claim order of the output cursor, i.e. unspecified).
 __global__ __launch_bounds__(kBlock) void groupby_emit_kernel(const GroupEmitArgs a) {
     const int64_t n = a.t.capacity + 2;
@@ -1134,6 +1387,23 @@ hipError_t launch_join_append(const JoinAppendArgs& a, hipStream_t s) {
 }
 hipError_t launch_count_bytes(const uint8_t* p, int64_t n, unsigned long long* out, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(count_bytes_kernel, dim3(rows_grid(n)), dim3(kBlock), 0, s, p, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_gb_hist(const GbPartArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(gb_hist_kernel, dim3(grid), dim3(kGbBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gb_scatter(const GbPartArgs& a, int grid, hipStream_t s) {
+    constexpr int P = 1 << kGbPartBits;
+    const size_t lds = (size_t)2 * kGbSuper * 8 + (size_t)P * (8 + 4 + 4);
+    (void)hipFuncSetAttribute((const void*)gb_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // > 64 KB
+    hipLaunchKernelGGL(gb_scatter_kernel, dim3(grid), dim3(kGbBlock), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gb_aggregate(const GbAggArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)kGbSlots * 20 + 16;
+    (void)hipFuncSetAttribute((const void*)gb_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // > 64 KB
+    hipLaunchKernelGGL(gb_aggregate_kernel, dim3(1 << kGbPartBits), dim3(kGbBlock), lds, s, a);
     return hipGetLastError();
 }
 hipError_t launch_groupby_prepare(const GroupPrepArgs& a, hipStream_t s) {

@@ -418,9 +418,10 @@ def test_sort_to_indices(gpu, ora, dtype):
                 assert np.array_equal(got, exp), f"sort dtype={dtype} lens={lens} desc={d} ncols={len(cols)}"
 
 
-@pytest.mark.parametrize("ngroups,n", [(20_000, 150_000), (300_000, 700_000)])
+@pytest.mark.parametrize("ngroups,n", [(20_000, 150_000), (300_000, 700_000), (1_300_000, 2_000_000)])
 def test_groupby_partitioned_high_cardinality(gpu, ora, ngroups, n):
-    """More than 1024 groups: hashed keys are radix-partitioned (1 or 2 passes) and aggregated per partition in LDS.
+    """More than 1024 groups: records are scattered once on 9 hash bits (default) — or radix-sorted in 1-2 passes (the
+    earlier variant, kept for very large domains) — and aggregated per partition in LDS; the HBM-atomics table is the third path.
     NULL keys, the free-marker keys of both tables, multi-chunk input with offsets; both value classes."""
     from rust_dataframe_amd import lib
     rng = np.random.default_rng(ngroups)
@@ -436,11 +437,11 @@ def test_groupby_partitioned_high_cardinality(gpu, ora, ngroups, n):
             if val_dtype is not None:
                 vals.append(A.HostArray.from_numpy(rng.uniform(-1, 1, ln) if val_dtype == A.F64 else rng.integers(-10 ** 9, 10 ** 9, ln), offset=2, dtype=val_dtype, rng=rng))
         exp = _sorted_groups(*ora.groupby_sum(keys, vals, ngroups + 8))
-        for part in (1, 0):  # partitioned path, then the HBM-atomics path on the same data
+        for part in (1, 2, 0):  # single-pass partitioned, radix-sort partitioned, then the HBM-atomics path on the same data
             lib.set_option("gb_partition", part)
             got = _sorted_groups(*gpu.groupby_sum(keys, vals, ngroups + 8))
             if part:
-                assert lib.last_kernel() == "groupby_partitions_kernel"
+                assert lib.last_kernel() == ("gb_aggregate_kernel" if part == 1 else "groupby_partitions_kernel")
             assert np.array_equal(got[1], exp[1]) and np.array_equal(got[0][exp[1]], exp[0][exp[1]]), f"keys part={part}"
             assert np.array_equal(got[3], exp[3]), f"counts part={part}"
             if val_dtype == A.F64:

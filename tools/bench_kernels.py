@@ -153,8 +153,19 @@ def main():
         kk = dev_i64(n, 7, 0, ng)
         KK = arr(kk, A.I64, n)
         ok_, os_, oc_ = out_like(A.I64, ng + 2), out_like(A.F64, ng + 2), out_like(A.I64, ng + 2)
+        oc2_ = out_like(A.I64, ng + 2)
         report(f"groupby_sum_{ng}_groups", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
         if ng > 1024:
+            for dbg in (1, 2):
+                lib.set_option("gb_debug", dbg)
+                try:
+                    report(f"groupby_sum_{ng}_groups_ablate{dbg}", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
+                except Exception as ex:   # the ablations produce wrong results by construction
+                    print("ablation", dbg, ex)
+            lib.set_option("gb_debug", 0)
+            report(f"groupby_count_{ng}_groups", 8.0 * n, lambda: api.groupby_sum([KK], None, ng, (ok_, oc2_, oc_)))
+            lib.set_option("gb_partition", 2)
+            report(f"groupby_sum_{ng}_groups_radix_sort", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
             lib.set_option("gb_partition", 0)
             report(f"groupby_sum_{ng}_groups_hbm_atomics", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
             lib.set_option("gb_partition", 1)
