@@ -16,7 +16,9 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 // as well as vmcnt, so the next scalar-load wait (s_waitcnt lgkmcnt(0)) also drains every vector load in flight.
 // Everything the ABI hands us lives in global memory: say so.
 template <class T> using GlobalPtr = const T __attribute__((address_space(1)))*;
+template <class T> using GlobalMutPtr = T __attribute__((address_space(1)))*;
 template <class T> __device__ __forceinline__ GlobalPtr<T> as_global(const void* p) { return (GlobalPtr<T>)p; }
+template <class T> __device__ __forceinline__ GlobalMutPtr<T> as_global_mut(void* p) { return (GlobalMutPtr<T>)p; }
 
 __device__ __forceinline__ int clamp64(int64_t v) { return v <= 0 ? 0 : (v >= 64 ? 64 : (int)v); }
 
@@ -34,7 +36,7 @@ __device__ __forceinline__ void load_windows_s(const uint8_t* base, int64_t bitp
         return;
     }
     const uint64_t addr = uniform64((uint64_t)(uintptr_t)base + (uint64_t)(bitpos >> 3));
-    const uint64_t* w = (const uint64_t*)(uintptr_t)(addr & ~7ull);
+    const GlobalPtr<uint64_t> w = (GlobalPtr<uint64_t>)(uintptr_t)(addr & ~7ull);
     const int sh = __builtin_amdgcn_readfirstlane((int)(addr & 7) * 8 + (int)(bitpos & 7));
     const int64_t want = nbits < (int64_t)64 * NW ? nbits : (int64_t)64 * NW;
     const int last = __builtin_amdgcn_readfirstlane((int)((sh + want - 1) >> 6));  // index of the last needed word
@@ -65,7 +67,7 @@ __device__ __forceinline__ void load_windows(const uint8_t* base, int64_t bitpos
         return;
     }
     const uint64_t addr = uniform64((uint64_t)(uintptr_t)base + (uint64_t)(bitpos >> 3));
-    const uint64_t* w = (const uint64_t*)(uintptr_t)(addr & ~7ull);
+    const GlobalPtr<uint64_t> w = (GlobalPtr<uint64_t>)(uintptr_t)(addr & ~7ull);
     const int sh = __builtin_amdgcn_readfirstlane((int)(addr & 7) * 8 + (int)(bitpos & 7));
     const int64_t want = nbits < (int64_t)64 * NW ? nbits : (int64_t)64 * NW;
     const int last = __builtin_amdgcn_readfirstlane((int)((sh + want - 1) >> 6));

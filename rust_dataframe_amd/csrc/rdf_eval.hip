@@ -74,12 +74,12 @@ __device__ __forceinline__ void load_col(const DevChunkCol cc, int dt, int64_t r
     const int64_t e0 = cc.offset + rw + lane;
     switch (dt) {
         case RDF_I64: case RDF_U64: case RDF_F64: {
-            const uint64_t* p = (const uint64_t*)cc.values + e0;
+            const GlobalPtr<uint64_t> p = as_global<uint64_t>(cc.values) + e0;
 #pragma unroll
             for (int j = 0; j < kVPT; ++j) v[j] = (inr >> j) & 1 ? __builtin_nontemporal_load(p + j * 64) : 0;
         } break;
         case RDF_I32: case RDF_U32: case RDF_F32: {
-            const uint32_t* p = (const uint32_t*)cc.values + e0;
+            const GlobalPtr<uint32_t> p = as_global<uint32_t>(cc.values) + e0;
 #pragma unroll
             for (int j = 0; j < kVPT; ++j) {
                 uint32_t t = (inr >> j) & 1 ? __builtin_nontemporal_load(p + j * 64) : 0;
@@ -87,7 +87,7 @@ __device__ __forceinline__ void load_col(const DevChunkCol cc, int dt, int64_t r
             }
         } break;
         case RDF_I16: case RDF_U16: {
-            const uint16_t* p = (const uint16_t*)cc.values + e0;
+            const GlobalPtr<uint16_t> p = as_global<uint16_t>(cc.values) + e0;
 #pragma unroll
             for (int j = 0; j < kVPT; ++j) {
                 uint16_t t = (inr >> j) & 1 ? p[j * 64] : (uint16_t)0;
@@ -95,7 +95,7 @@ __device__ __forceinline__ void load_col(const DevChunkCol cc, int dt, int64_t r
             }
         } break;
         case RDF_I8: case RDF_U8: {
-            const uint8_t* p = (const uint8_t*)cc.values + e0;
+            const GlobalPtr<uint8_t> p = as_global<uint8_t>(cc.values) + e0;
 #pragma unroll
             for (int j = 0; j < kVPT; ++j) {
                 uint8_t t = (inr >> j) & 1 ? p[j * 64] : (uint8_t)0;
@@ -535,18 +535,18 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
                             const uint64_t ib = __ballot(ok);
                             if (dt == RDF_BOOL) {
                                 const uint64_t bits = __ballot(ok && valid && (v & 1));
-                                if (lane == 0 && ib) ((uint64_t*)oc.values)[(rw + j * 64) >> 6] = bits;
+                                if (lane == 0 && ib) as_global_mut<uint64_t>(oc.values)[(rw + j * 64) >> 6] = bits;
                             } else if (ok) {
                                 switch (dt) {
-                                    case RDF_I64: case RDF_U64: case RDF_F64: ((uint64_t*)oc.values)[row] = v; break;
-                                    case RDF_I32: case RDF_U32: case RDF_F32: ((uint32_t*)oc.values)[row] = (uint32_t)v; break;
-                                    case RDF_I16: case RDF_U16: ((uint16_t*)oc.values)[row] = (uint16_t)v; break;
-                                    default: ((uint8_t*)oc.values)[row] = (uint8_t)v; break;
+                                    case RDF_I64: case RDF_U64: case RDF_F64: as_global_mut<uint64_t>(oc.values)[row] = v; break;
+                                    case RDF_I32: case RDF_U32: case RDF_F32: as_global_mut<uint32_t>(oc.values)[row] = (uint32_t)v; break;
+                                    case RDF_I16: case RDF_U16: as_global_mut<uint16_t>(oc.values)[row] = (uint16_t)v; break;
+                                    default: as_global_mut<uint8_t>(oc.values)[row] = (uint8_t)v; break;
                                 }
                             }
                             const uint64_t vb = __ballot(ok && valid);
                             if (lane == 0 && ib) {
-                                if (oc.validity) ((uint64_t*)oc.validity)[(rw + j * 64) >> 6] = vb;
+                                if (oc.validity) as_global_mut<uint64_t>(oc.validity)[(rw + j * 64) >> 6] = vb;
                                 nn += (uint32_t)__popcll(ib & ~vb);
                             }
                         }

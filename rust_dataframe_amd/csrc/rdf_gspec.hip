@@ -79,7 +79,7 @@ __device__ __forceinline__ void load_col_full(C& c, const DevChunkCol& col, int6
     } else {
         using S = typename std::conditional<w == 8, uint64_t, typename std::conditional<w == 4, uint32_t, typename std::conditional<w == 2, uint16_t, uint8_t>::type>::type>::type;
         using V2 = typename VecOf<S, 2>::type;
-        const V2* p = (const V2*)((const S*)col.values + col.offset + rw) + lane;
+        const GlobalPtr<V2> p = (GlobalPtr<V2>)(as_global<S>(col.values) + col.offset + rw) + lane;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const V2 t = __builtin_nontemporal_load(p + u * 64);
@@ -101,10 +101,10 @@ __device__ __forceinline__ void load_col_tail(C& c, const DevChunkCol& col, int6
             uint64_t x = 0;
             if constexpr (w != 0) {
                 if ((c.inr >> r) & 1) {
-                    if constexpr (w == 8) x = ((const uint64_t*)col.values)[row];
-                    else if constexpr (w == 4) x = ((const uint32_t*)col.values)[row];
-                    else if constexpr (w == 2) x = ((const uint16_t*)col.values)[row];
-                    else x = ((const uint8_t*)col.values)[row];
+                    if constexpr (w == 8) x = as_global<uint64_t>(col.values)[row];
+                    else if constexpr (w == 4) x = as_global<uint32_t>(col.values)[row];
+                    else if constexpr (w == 2) x = as_global<uint16_t>(col.values)[row];
+                    else x = as_global<uint8_t>(col.values)[row];
                 }
             }
             c.v[k][r] = x;

@@ -250,7 +250,7 @@ __device__ __forceinline__ void compact_wave(const DevChunkCol col, const DevOut
                                              unsigned char* stage_raw, uint8_t* vstage, uint32_t& nulls) {
     const int lane = threadIdx.x & 63;
     T* stage = (T*)stage_raw;
-    const T* src = (const T*)col.values + col.offset + rw + lane;
+    const GlobalPtr<T> src = as_global<T>(col.values) + col.offset + rw + lane;
     uint64_t vw[kWW];
     const bool hasv = col.validity != nullptr;
     if (hasv) load_windows<kWW>(col.validity, col.offset + rw, clen - rw, vw);
@@ -269,7 +269,7 @@ __device__ __forceinline__ void compact_wave(const DevChunkCol col, const DevOut
         wb += __popcll(kw[i]);
     }
     __builtin_amdgcn_wave_barrier();  // same-wave LDS ops are executed in order; this only pins the compiler
-    T* dst = (T*)oc.values + wave_out;
+    const GlobalMutPtr<T> dst = as_global_mut<T>(oc.values) + wave_out;
     for (int i = lane; i < wave_cnt; i += 64) dst[i] = stage[i];
     if (hasv && oc.validity) {
         // out bits [wave_out, wave_out+wave_cnt): ballot 64 aligned positions at a time, OR into the
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const TakeArgs a) {
         }
         T v = 0;
         if (valid) {
-            const uint64_t ix = (uint64_t)((const IDX*)a.indices.values)[a.indices.offset + j];
+            const uint64_t ix = (uint64_t)as_global<IDX>(a.indices.values)[a.indices.offset + j];
             if (ix >= (uint64_t)a.total_rows) { err |= 2u; valid = false; }
             else {
                 int64_t c = 0;
@@ -387,15 +387,15 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const TakeArgs a) {
                 }
                 const DevChunkCol cc = a.chunks[c];
                 const int64_t e = cc.offset + (int64_t)ix - a.chunk_row_start[c];
-                v = ((const T*)cc.values)[e];
+                v = as_global<T>(cc.values)[e];
                 if (cc.validity) valid = (cc.validity[e >> 3] >> (e & 7)) & 1;
             }
         }
-        if (inr) ((T*)a.out.values)[j] = v;
+        if (inr) as_global_mut<T>(a.out.values)[j] = v;
         const uint64_t vb = __ballot(valid);
         const uint64_t ib = __ballot(inr);
         if (lane == 0) {
-            if (a.out.validity) ((uint64_t*)a.out.validity)[wv] = vb;
+            if (a.out.validity) as_global_mut<uint64_t>(a.out.validity)[wv] = vb;
             nulls += __popcll(ib & ~vb);
         }
     }
@@ -412,16 +412,16 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const TakeArgs a) {
 
 __device__ __forceinline__ uint64_t sort_key_bits(const DevChunkCol& cc, int dt, int64_t e) {
     switch (dt) {
-        case RDF_I8: return (uint8_t)(((const uint8_t*)cc.values)[e] ^ 0x80u);
-        case RDF_U8: return ((const uint8_t*)cc.values)[e];
-        case RDF_I16: return (uint16_t)(((const uint16_t*)cc.values)[e] ^ 0x8000u);
-        case RDF_U16: return ((const uint16_t*)cc.values)[e];
-        case RDF_I32: return ((const uint32_t*)cc.values)[e] ^ 0x80000000u;
-        case RDF_U32: return ((const uint32_t*)cc.values)[e];
-        case RDF_F32: { const uint32_t b = ((const uint32_t*)cc.values)[e]; return (b & 0x80000000u) ? (uint32_t)~b : (b ^ 0x80000000u); }
-        case RDF_I64: return ((const uint64_t*)cc.values)[e] ^ 0x8000000000000000ull;
-        case RDF_F64: { const uint64_t b = ((const uint64_t*)cc.values)[e]; return (b >> 63) ? ~b : (b ^ 0x8000000000000000ull); }
-        default: return ((const uint64_t*)cc.values)[e];
+        case RDF_I8: return (uint8_t)(as_global<uint8_t>(cc.values)[e] ^ 0x80u);
+        case RDF_U8: return as_global<uint8_t>(cc.values)[e];
+        case RDF_I16: return (uint16_t)(as_global<uint16_t>(cc.values)[e] ^ 0x8000u);
+        case RDF_U16: return as_global<uint16_t>(cc.values)[e];
+        case RDF_I32: return as_global<uint32_t>(cc.values)[e] ^ 0x80000000u;
+        case RDF_U32: return as_global<uint32_t>(cc.values)[e];
+        case RDF_F32: { const uint32_t b = as_global<uint32_t>(cc.values)[e]; return (b & 0x80000000u) ? (uint32_t)~b : (b ^ 0x80000000u); }
+        case RDF_I64: return as_global<uint64_t>(cc.values)[e] ^ 0x8000000000000000ull;
+        case RDF_F64: { const uint64_t b = as_global<uint64_t>(cc.values)[e]; return (b >> 63) ? ~b : (b ^ 0x8000000000000000ull); }
+        default: return as_global<uint64_t>(cc.values)[e];
     }
 }
 
@@ -626,13 +626,13 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 __device__ __forceinline__ int64_t load_key(const DevChunkCol& k, int dt, int64_t row) {
     const int64_t e = k.offset + row;
     switch (dt) {
-        case RDF_I32: return ((const int32_t*)k.values)[e];
-        case RDF_U32: return (int64_t)((const uint32_t*)k.values)[e];
-        case RDF_I16: return ((const int16_t*)k.values)[e];
-        case RDF_U16: return (int64_t)((const uint16_t*)k.values)[e];
-        case RDF_I8: return ((const int8_t*)k.values)[e];
-        case RDF_U8: return (int64_t)((const uint8_t*)k.values)[e];
-        default: return ((const int64_t*)k.values)[e];
+        case RDF_I32: return as_global<int32_t>(k.values)[e];
+        case RDF_U32: return (int64_t)as_global<uint32_t>(k.values)[e];
+        case RDF_I16: return as_global<int16_t>(k.values)[e];
+        case RDF_U16: return (int64_t)as_global<uint16_t>(k.values)[e];
+        case RDF_I8: return as_global<int8_t>(k.values)[e];
+        case RDF_U8: return (int64_t)as_global<uint8_t>(k.values)[e];
+        default: return as_global<int64_t>(k.values)[e];
     }
 }
 
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(kBlock) void groupby_build_kernel(const GroupByArgs
             if (err) break;
             if (vvalid) {
                 if (a.value_dtype == RDF_F64) unsafeAtomicAdd((double*)&a.t.sums[slot], ((const double*)vc.values)[vc.offset + row]);
-                else if (a.value_dtype == RDF_F32) unsafeAtomicAdd((double*)&a.t.sums[slot], (double)((const float*)vc.values)[vc.offset + row]);
+                else if (a.value_dtype == RDF_F32) unsafeAtomicAdd((double*)&a.t.sums[slot], (double)as_global<float>(vc.values)[vc.offset + row]);
                 else if (a.value_dtype >= 0) atomicAdd(&a.t.sums[slot], (unsigned long long)load_key(vc, a.value_dtype, row));
                 atomicAdd(&a.t.counts[slot], 1ull);
             }
@@ -741,8 +741,8 @@ __global__ __launch_bounds__(kBlock) void groupby_build_lds_kernel(const GroupBy
             const bool vvalid = a.value_dtype < 0 || !vc.validity || ((vvw[j] >> lane) & 1);
             const uint64_t key = (uint64_t)load_key(kc, a.key_dtype, row);
             uint64_t v = 0;
-            if (a.value_dtype == RDF_F64) v = ((const uint64_t*)vc.values)[vc.offset + row];
-            else if (a.value_dtype == RDF_F32) v = d2u((double)((const float*)vc.values)[vc.offset + row]);
+            if (a.value_dtype == RDF_F64) v = as_global<uint64_t>(vc.values)[vc.offset + row];
+            else if (a.value_dtype == RDF_F32) v = d2u((double)as_global<float>(vc.values)[vc.offset + row]);
             else if (a.value_dtype >= 0) v = (uint64_t)load_key(vc, a.value_dtype, row);
             int slot = -1;
             if (!kvalid) { slot = kLdsGroups + 1; lspecial[1] = 1; }
@@ -820,8 +820,8 @@ __global__ __launch_bounds__(kBlock) void groupby_prepare_kernel(const GroupPrep
             if (row >= clen) continue;
             const bool kvalid = !kc.validity || ((kvw[j] >> lane) & 1);
             uint64_t v = 0;
-            if (a.value_dtype == RDF_F64) v = ((const uint64_t*)vc.values)[vc.offset + row];
-            else if (a.value_dtype == RDF_F32) v = d2u((double)((const float*)vc.values)[vc.offset + row]);
+            if (a.value_dtype == RDF_F64) v = as_global<uint64_t>(vc.values)[vc.offset + row];
+            else if (a.value_dtype == RDF_F32) v = d2u((double)as_global<float>(vc.values)[vc.offset + row]);
             else if (a.value_dtype >= 0) v = (uint64_t)load_key(vc, a.value_dtype, row);
             uint64_t hk = mix64((uint64_t)load_key(kc, a.key_dtype, row));
             const bool is_f = a.value_dtype == RDF_F64 || a.value_dtype == RDF_F32;

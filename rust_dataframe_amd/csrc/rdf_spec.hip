@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             c.inr = (1u << R) - 1;
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                const VecS* p = (const VecS*)((const S*)col[k].values + col[k].offset) + wbase + lane;
+                const GlobalPtr<VecS> p = (GlobalPtr<VecS>)(as_global<S>(col[k].values) + col[k].offset) + wbase + lane;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const VecS t = __builtin_nontemporal_load(p + u * 64);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
                 for (int e = 0; e < RV; ++e) c.inr |= (uint32_t)((int64_t)RV * (wbase + u * 64 + lane) + e < n) << (RV * u + e);
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                const S* p = (const S*)col[k].values + col[k].offset;
+                const GlobalPtr<S> p = as_global<S>(col[k].values) + col[k].offset;
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
 #pragma unroll
                     for (int h = 0; h < RV; ++h) {
                         const uint64_t wv = interleave_word<RV>(bb, h, lane);
-                        if (lane == 0 && row0 + 64 * h < n) ((uint64_t*)out.values)[word0 + h] = wv;
+                        if (lane == 0 && row0 + 64 * h < n) as_global_mut<uint64_t>(out.values)[word0 + h] = wv;
                     }
                 } else {
                     using OT = typename CType<V0::dt>::T;
@@ -266,17 +266,17 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
                         VecS t;
 #pragma unroll
                         for (int e = 0; e < RV; ++e) t[e] = (S)x[e];
-                        ((VecS*)out.values)[i] = t;
+                        as_global_mut<VecS>(out.values)[i] = t;
                     } else {
 #pragma unroll
-                        for (int e = 0; e < RV; ++e) if ((inu >> e) & 1) ((S*)out.values)[(int64_t)RV * i + e] = (S)x[e];
+                        for (int e = 0; e < RV; ++e) if ((inu >> e) & 1) as_global_mut<S>(out.values)[(int64_t)RV * i + e] = (S)x[e];
                     }
                 }
                 if (out.validity) {
 #pragma unroll
                     for (int h = 0; h < RV; ++h) {
                         const uint64_t wv = interleave_word<RV>(vb, h, lane);
-                        if (lane == 0 && row0 + 64 * h < n) ((uint64_t*)out.validity)[word0 + h] = wv;
+                        if (lane == 0 && row0 + 64 * h < n) as_global_mut<uint64_t>(out.validity)[word0 + h] = wv;
                     }
                 }
                 if (lane == 0) {
