@@ -538,8 +538,8 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
                                 if (lane == 0 && ib) as_global_mut<uint64_t>(oc.values)[(rw + j * 64) >> 6] = bits;
                             } else if (ok) {
                                 switch (dt) {
-                                    case RDF_I64: case RDF_U64: case RDF_F64: as_global_mut<uint64_t>(oc.values)[row] = v; break;
-                                    case RDF_I32: case RDF_U32: case RDF_F32: as_global_mut<uint32_t>(oc.values)[row] = (uint32_t)v; break;
+                                    case RDF_I64: case RDF_U64: case RDF_F64: __builtin_nontemporal_store(v, as_global_mut<uint64_t>(oc.values) + row); break;
+                                    case RDF_I32: case RDF_U32: case RDF_F32: __builtin_nontemporal_store((uint32_t)v, as_global_mut<uint32_t>(oc.values) + row); break;
                                     case RDF_I16: case RDF_U16: as_global_mut<uint16_t>(oc.values)[row] = (uint16_t)v; break;
                                     default: as_global_mut<uint8_t>(oc.values)[row] = (uint8_t)v; break;
                                 }

@@ -270,7 +270,7 @@ __device__ __forceinline__ void compact_wave(const DevChunkCol col, const DevOut
     }
     __builtin_amdgcn_wave_barrier();  // same-wave LDS ops are executed in order; this only pins the compiler
     const GlobalMutPtr<T> dst = as_global_mut<T>(oc.values) + wave_out;
-    for (int i = lane; i < wave_cnt; i += 64) dst[i] = stage[i];
+    for (int i = lane; i < wave_cnt; i += 64) __builtin_nontemporal_store(stage[i], dst + i);
     if (hasv && oc.validity) {
         // out bits [wave_out, wave_out+wave_cnt): ballot 64 aligned positions at a time, OR into the
         // (pre-zeroed) bitmap; boundary words are shared with neighbouring waves/tiles, hence atomics.
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const TakeArgs a) {
                 if (cc.validity) valid = (cc.validity[e >> 3] >> (e & 7)) & 1;
             }
         }
-        if (inr) as_global_mut<T>(a.out.values)[j] = v;
+        if (inr) __builtin_nontemporal_store(v, as_global_mut<T>(a.out.values) + j);
         const uint64_t vb = __ballot(valid);
         const uint64_t ib = __ballot(inr);
         if (lane == 0) {

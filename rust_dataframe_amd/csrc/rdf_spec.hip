@@ -236,6 +236,8 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             uint64_t outv[R];
             eval_rows<V0, R, 0>(c, outv);
             const uint32_t vm = V0::vmask(c) & c.inr;
+            // bitmap words of this wave's 64*R rows: word w is parked in lane w, all R go out in ONE store
+            uint64_t word_val = 0, word_vld = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t i = wbase + u * 64 + lane;
@@ -248,8 +250,6 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
                     inb[e] = __ballot((inu >> e) & 1);
                     vb[e] = __ballot((vu >> e) & 1);
                 }
-                const int64_t row0 = rw + (int64_t)64 * RV * u;       // first row of this wave-load
-                const int64_t word0 = row0 >> 6;                      // its first bitmap word (row0 is a multiple of 64)
                 if constexpr (V0::dt == RDF_BOOL) {
                     uint64_t bb[RV];
 #pragma unroll
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
 #pragma unroll
                     for (int h = 0; h < RV; ++h) {
                         const uint64_t wv = interleave_word<RV>(bb, h, lane);
-                        if (lane == 0 && row0 + 64 * h < n) as_global_mut<uint64_t>(out.values)[word0 + h] = wv;
+                        if (lane == RV * u + h) word_val = wv;
                     }
                 } else {
                     using OT = typename CType<V0::dt>::T;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
                         VecS t;
 #pragma unroll
                         for (int e = 0; e < RV; ++e) t[e] = (S)x[e];
-                        as_global_mut<VecS>(out.values)[i] = t;
+                        __builtin_nontemporal_store(t, as_global_mut<VecS>(out.values) + i);   // streaming output: do not keep it in L2 / MALL
                     } else {
 #pragma unroll
                         for (int e = 0; e < RV; ++e) if ((inu >> e) & 1) as_global_mut<S>(out.values)[(int64_t)RV * i + e] = (S)x[e];
@@ -276,13 +276,15 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
 #pragma unroll
                     for (int h = 0; h < RV; ++h) {
                         const uint64_t wv = interleave_word<RV>(vb, h, lane);
-                        if (lane == 0 && row0 + 64 * h < n) as_global_mut<uint64_t>(out.validity)[word0 + h] = wv;
+                        if (lane == RV * u + h) word_vld = wv;
                     }
                 }
-                if (lane == 0) {
 #pragma unroll
-                    for (int e = 0; e < RV; ++e) nulls += (uint32_t)__popcll(inb[e] & ~vb[e]);
-                }
+                for (int e = 0; e < RV; ++e) nulls += (uint32_t)__popcll(inb[e] & ~vb[e]);   // wave-uniform: scalar unit
+            }
+            if (lane < R && rw + 64 * lane < n) {
+                if constexpr (V0::dt == RDF_BOOL) as_global_mut<uint64_t>(out.values)[(rw >> 6) + lane] = word_val;
+                if (out.validity) as_global_mut<uint64_t>(out.validity)[(rw >> 6) + lane] = word_vld;
             }
         }
     }
