@@ -1063,8 +1063,74 @@ class Evaluate {
     }
 
     // fused filter -> aggregates (GroupAggregate with no grouping columns)
+    // GroupAggregate WITH grouping columns: the reference plans it (Dataset::try_aggregate, src/expression.rs:114-221)
+    // and panics on execution (src/evaluation.rs:73).  Here: one integer grouping column, Sum / Count / Avg per group
+    // through rdf_groupby_sum; rows of the result are ordered by key (NULL group last) so every aggregate column lines up.
+    void step_group_aggregate(const plan::Transformation& t) {
+        using AF = plan::AggregateFunction;
+        if (t.names.size() != 1) throw DataFrameError(DataFrameError::ComputeError, "GroupAggregate: exactly one grouping column is supported");
+        DataFrame f = flush();   // lazy columns materialised, pending filters applied
+        const Column& kc = f.column_by_name(t.names[0]);
+        if (!is_integer(kc.data_type())) throw DataFrameError(DataFrameError::ComputeError, "GroupAggregate: the grouping column must be an integer column");
+        std::vector<rdf_array> keys;
+        bool key_nulls = false;
+        for (auto& a : kc.data().chunks()) { keys.push_back(a->view()); key_nulls |= a->validity != nullptr; }
+        const int64_t nrows = (int64_t)f.num_rows();
+        std::vector<Column> out_cols;
+        auto one = [&](AF fn, const std::string& col) {
+            if (fn != AF::Sum && fn != AF::Count && fn != AF::Avg) throw DataFrameError(DataFrameError::ComputeError, "Aggregation not yet supported");
+            const Column& vc = f.column_by_name(col);
+            const DataType vdt = vc.data_type();
+            if (!(is_integer(vdt) || is_float(vdt))) throw DataFrameError(DataFrameError::ComputeError, "Aggregating column must be numeric");
+            std::vector<rdf_array> vals;
+            for (auto& a : vc.data().chunks()) vals.push_back(a->view());
+            const DataType sdt = is_float(vdt) ? DataType::Float64 : DataType::Int64;
+            int64_t mg = std::max<int64_t>(1, std::min<int64_t>(nrows, (int64_t)1 << 20));
+            std::shared_ptr<Array> ok, os, oc;
+            for (;;) {   // the number of groups is not known in advance: grow the promise until it holds
+                ok = Array::make_out(kc.data_type(), mg + 2, key_nulls);
+                os = Array::make_out(sdt, mg + 2, false);
+                oc = Array::make_out(DataType::Int64, mg + 2, false);
+                rdf_out vk = ok->out_view(mg + 2), vs = os->out_view(mg + 2), vcn = oc->out_view(mg + 2);
+                const rdf_status st = rdf_groupby_sum(keys.data(), vals.data(), (int64_t)keys.size(), mg, &vk, &vs, &vcn);
+                if (st == RDF_MEMORY_ERROR && mg < nrows) { mg = std::min<int64_t>(nrows, mg * 16); continue; }
+                check(st);
+                ok->length = os->length = oc->length = vk.length;
+                ok->null_count = vk.null_count;
+                break;
+            }
+            DataFrame g = DataFrame::from_columns({Column::from_arrays({ok}, Field{"k", kc.data_type(), true}),
+                                                   Column::from_arrays({os}, Field{"s", sdt, false}),
+                                                   Column::from_arrays({oc}, Field{"c", DataType::Int64, false})})
+                              .sort({DataFrame::SortCriteria{"k", false, false}});
+            if (out_cols.empty()) out_cols.push_back(Column::from_arrays(g.column_by_name("k").data().chunks(), Field{t.names[0], kc.data_type(), true}));
+            const std::vector<ArrayRef> sums = g.column_by_name("s").data().chunks(), counts = g.column_by_name("c").data().chunks();
+            if (fn == AF::Sum) {
+                out_cols.push_back(Column::from_arrays(sdt == vdt ? sums : ScalarFunctions::cast(sums, vdt), Field{"sum(" + col + ")", vdt, true}));
+            } else if (fn == AF::Count) {
+                out_cols.push_back(Column::from_arrays(ScalarFunctions::cast(counts, DataType::UInt32), Field{"count(" + col + ")", DataType::UInt32, true}));
+            } else {   // avg = sum / count, NULL for a group without a non-null value (AggregateFunctions::avg, src/functions/aggregate.rs:32-65)
+                std::vector<ArrayRef> out;
+                const std::vector<ArrayRef> fs = sdt == DataType::Float64 ? sums : ScalarFunctions::cast(sums, DataType::Float64);
+                for (size_t i = 0; i < fs.size(); ++i) {
+                    const std::vector<double> sv = fs[i]->values_to_host<double>();
+                    const std::vector<int64_t> cv = counts[i]->values_to_host<int64_t>();
+                    std::vector<double> m(sv.size());
+                    std::vector<bool> valid(sv.size());
+                    for (size_t r = 0; r < sv.size(); ++r) { valid[r] = cv[r] > 0; m[r] = cv[r] > 0 ? sv[r] / (double)cv[r] : 0.0; }
+                    out.push_back(Array::from_vec(m, &valid));
+                }
+                out_cols.push_back(Column::from_arrays(out, Field{"avg(" + col + ")", DataType::Float64, true}));
+            }
+        };
+        for (auto& a : t.aggregations)
+            for (auto& c : a.columns) one(a.function, c);
+        if (out_cols.empty()) throw DataFrameError(DataFrameError::ComputeError, "GroupAggregate without aggregations");
+        reset(DataFrame::from_columns(out_cols));
+    }
+
     void step_aggregate(const plan::Transformation& t) {
-        if (!t.names.empty()) throw DataFrameError(DataFrameError::ComputeError, "aggregations not supported");  // evaluation.rs:73
+        if (!t.names.empty()) { step_group_aggregate(t); return; }
         struct Want { plan::AggregateFunction fn; std::string col; DataType dt; ExprRef e; };
         std::vector<Want> wants;
         for (auto& a : t.aggregations)

@@ -1,6 +1,7 @@
 // C++ mirrors of the reference's in-file #[test] functions for the hot path, run on the device through
 // rdf_frame.hpp (-> librdf_mi355x.so), plus fused-vs-oracle parity of the batch loop.  The oracle
 // (librdf_oracle.so) is linked here as the checker only.
+#include <map>
 #include <random>
 
 #include "mini_test.hpp"
@@ -264,6 +265,69 @@ TEST(test_fused_pipeline_matches_unfused_oracle) {
     auto e0 = host<double>(eager.column_by_name("s").data().chunk(0));
     for (size_t i = 0; i < 50; ++i)
         if (cols[0][0].valid[i] && cols[1][0].valid[i]) CHECK_EQ(e0[i], cols[0][0].v[i] + cols[1][0].v[i]);
+}
+
+// GroupAggregate with a grouping column: the reference has only the schema (Dataset::try_aggregate) and panics on
+// execution (src/evaluation.rs:73); expectations are SQL semantics computed on the host.
+TEST(test_group_aggregate_by_key) {
+    std::mt19937_64 rng(11);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    const std::vector<size_t> lens{1024, 500, 2000};
+    std::vector<ArrayRef> kch, vch, wch;
+    std::map<int32_t, double> sum_v; std::map<int32_t, int64_t> cnt_v, sum_w; double null_sum = 0; int64_t null_cnt = 0, null_w = 0; bool has_null = false;
+    for (size_t n : lens) {
+        std::vector<int32_t> k(n); std::vector<double> v(n); std::vector<int64_t> w(n);
+        std::vector<bool> kvalid(n), vvalid(n);
+        for (size_t i = 0; i < n; ++i) {
+            k[i] = (int32_t)(rng() % 37) - 5; v[i] = U(rng); w[i] = (int64_t)(rng() % 1000) - 500;
+            kvalid[i] = U(rng) > 0.02; vvalid[i] = U(rng) > 0.1;
+        }
+        kch.push_back(Array::from_vec(k, &kvalid)); vch.push_back(Array::from_vec(v, &vvalid)); wch.push_back(Array::from_vec(w));
+        for (size_t i = 0; i < n; ++i) {
+            if (!(v[i] > 0.25) || !vvalid[i]) continue;       // rows dropped by the filter v > 0.25 (NULL -> dropped)
+            if (!kvalid[i]) { has_null = true; null_sum += v[i]; ++null_cnt; null_w += w[i]; continue; }
+            sum_v[k[i]] += v[i]; ++cnt_v[k[i]]; sum_w[k[i]] += w[i];
+        }
+    }
+    DataFrame df = DataFrame::from_columns({Column::from_arrays(kch, Field{"k", DataType::Int32, true}),
+                                            Column::from_arrays(vch, Field{"v", DataType::Float64, true}),
+                                            Column::from_arrays(wch, Field{"w", DataType::Int64, false})});
+    using AF = P::AggregateFunction;
+    DataFrame g = LazyFrame::read(df)
+                      .filter(BooleanFilter::gt(BooleanFilter::column("v"), BooleanFilter::scalar(Scalar(0.25))))
+                      .aggregate({"k"}, {{AF::Sum, {"v", "w"}}, {AF::Count, {"v"}}, {AF::Avg, {"v"}}})
+                      .evaluate();
+    CHECK_EQ(g.num_columns(), 5u);
+    CHECK_EQ(g.schema().fields[0].name, std::string("k"));
+    CHECK_EQ(g.schema().fields[1].name, std::string("sum(v)"));
+    CHECK_EQ(g.schema().fields[2].name, std::string("sum(w)"));
+    CHECK_EQ(g.schema().fields[3].name, std::string("count(v)"));
+    CHECK_EQ(g.schema().fields[4].name, std::string("avg(v)"));
+    CHECK_EQ((size_t)g.num_rows(), sum_v.size() + (has_null ? 1 : 0));
+    auto gk = host<int32_t>(g.column(0).data().chunk(0));
+    auto gs = host<double>(g.column(1).data().chunk(0));
+    auto gw = host<int64_t>(g.column(2).data().chunk(0));
+    auto gc = host<uint32_t>(g.column(3).data().chunk(0));
+    auto ga = host<double>(g.column(4).data().chunk(0));
+    size_t r = 0;
+    for (auto& kv : sum_v) {   // std::map iterates in key order == the sorted result
+        CHECK_EQ(gk[r], kv.first);
+        CHECK_NEAR(gs[r], kv.second, 1e-9);
+        CHECK_EQ(gw[r], sum_w[kv.first]);
+        CHECK_EQ((int64_t)gc[r], cnt_v[kv.first]);
+        CHECK_NEAR(ga[r], kv.second / (double)cnt_v[kv.first], 1e-9);
+        ++r;
+    }
+    if (has_null) {            // the NULL group sorts last
+        CHECK(g.column(0).data().chunk(0)->is_null((int64_t)r));
+        CHECK_NEAR(gs[r], null_sum, 1e-9);
+        CHECK_EQ(gw[r], null_w);
+        CHECK_EQ((int64_t)gc[r], null_cnt);
+    }
+    // unsupported shapes are errors, not silent fallbacks
+    CHECK_THROWS(LazyFrame::read(df).aggregate({"k", "w"}, {{AF::Sum, {"v"}}}).evaluate());
+    CHECK_THROWS(LazyFrame::read(df).aggregate({"v"}, {{AF::Sum, {"w"}}}).evaluate());
+    CHECK_THROWS(LazyFrame::read(df).aggregate({"k"}, {{AF::Max, {"v"}}}).evaluate());
 }
 
 int main(int argc, char** argv) {
