@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <functional>
 #include <map>
 #include <memory>
@@ -651,6 +652,56 @@ struct RecordBatch {
     int64_t num_rows() const { return columns.empty() ? 0 : columns[0]->length; }
 };
 
+// arrow::compute::cast per chunk (Function::Cast, src/evaluation.rs:296-315) on device arrays
+inline std::vector<ArrayRef> cast_arrays(const std::vector<ArrayRef>& arr, DataType to) {
+    std::vector<rdf_array> a;
+    std::vector<std::shared_ptr<Array>> outs;
+    std::vector<rdf_out> ov;
+    for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(to, x->length, x->validity != nullptr)); ov.push_back(outs.back()->out_view(x->length)); }
+    check(rdf_cast(a.data(), (int64_t)a.size(), ov.data()));
+    std::vector<ArrayRef> res;
+    for (size_t i = 0; i < outs.size(); ++i) { outs[i]->length = ov[i].length; outs[i]->null_count = ov[i].null_count; res.push_back(outs[i]); }
+    return res;
+}
+
+// Minimal in-place flatbuffer reader for the Arrow IPC metadata (tables via vtables, vectors, strings, structs);
+// every access is bounds-checked against the file image.
+struct FlatBuf {
+    const uint8_t* base; size_t size;
+    [[noreturn]] static void oob() { throw DataFrameError(DataFrameError::IoError, "Arrow IPC: metadata out of bounds"); }
+    template <class T> T rd(size_t pos) const { if (pos + sizeof(T) > size) oob(); T v; std::memcpy(&v, base + pos, sizeof(T)); return v; }
+    size_t root(size_t pos) const { return pos + rd<uint32_t>(pos); }                 // position of the root table
+    // position of field `id` inside table `t`, or 0 when absent (default value)
+    size_t field_pos(size_t t, int id) const {
+        if (!t) return 0;
+        const int32_t so = rd<int32_t>(t);
+        const size_t vt = (size_t)((int64_t)t - so);
+        const uint16_t vsize = rd<uint16_t>(vt);
+        const size_t slot = 4 + 2 * (size_t)id;
+        if (slot + 2 > vsize) return 0;
+        const uint16_t off = rd<uint16_t>(vt + slot);
+        return off ? t + off : 0;
+    }
+    template <class T> T scalar(size_t t, int id, T def) const { const size_t p = field_pos(t, id); return p ? rd<T>(p) : def; }
+    size_t table_field(size_t t, int id) const { const size_t p = field_pos(t, id); return p ? p + rd<uint32_t>(p) : 0; }
+    std::string string(size_t t, int id) const {
+        const size_t p = field_pos(t, id);
+        if (!p) return "";
+        const size_t s = p + rd<uint32_t>(p);
+        const uint32_t n = rd<uint32_t>(s);
+        if (s + 4 + n > size) oob();
+        return std::string((const char*)base + s + 4, n);
+    }
+    // `fp` = position of a vector FIELD (from field_pos), 0 = absent
+    size_t vec_len(size_t fp) const { return fp ? rd<uint32_t>(fp + rd<uint32_t>(fp)) : 0; }
+    size_t vec_table(size_t fp, size_t i) const { const size_t e = fp + rd<uint32_t>(fp) + 4 + 4 * i; return e + rd<uint32_t>(e); }
+    const uint8_t* vec_struct(size_t fp, size_t i, size_t stride) const {
+        const size_t e = fp + rd<uint32_t>(fp) + 4 + stride * i;
+        if (e + stride > size) oob();
+        return base + e;
+    }
+};
+
 class DataFrame {
   public:
     DataFrame() = default;
@@ -700,6 +751,141 @@ class DataFrame {
                 if (n == 0) break;
             }
             cols.push_back(Column::from_arrays(chunks, Field{header[i], numeric ? DataType::Float64 : DataType::Utf8, true}));
+        }
+        return from_columns(std::move(cols));
+    }
+
+    // DataFrame::from_arrow (src/dataframe.rs:391-407: arrow::ipc::reader::FileReader -> Table::from_record_batches):
+    // reads an Arrow IPC FILE.  The flatbuffer metadata (Footer -> Schema, Blocks; Message -> RecordBatch) is decoded
+    // in place with a minimal reader; every column buffer goes from the file image straight to HBM with one H2D copy
+    // (no per-value parsing, no intermediate arrays): one chunk per record batch.  Primitive numeric and Boolean
+    // columns are on the compute path, Utf8 is carried opaquely; other types, dictionaries and compressed bodies are
+    // rejected with an error.
+    static DataFrame from_arrow(const std::string& path) {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) throw DataFrameError(DataFrameError::IoError, "cannot open " + path);
+        std::vector<uint8_t> img((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        return from_arrow_image(img.data(), img.size());
+    }
+    static DataFrame from_arrow_image(const uint8_t* img, size_t size) {
+        auto bad = [](const std::string& m) -> DataFrameError { return DataFrameError(DataFrameError::IoError, "Arrow IPC: " + m); };
+        if (size < 20 || std::memcmp(img, "ARROW1", 6) != 0 || std::memcmp(img + size - 6, "ARROW1", 6) != 0) throw bad("not an Arrow IPC file (magic)");
+        int32_t flen;
+        std::memcpy(&flen, img + size - 10, 4);
+        if (flen <= 0 || (size_t)flen + 18 > size) throw bad("bad footer length");
+        const FlatBuf fb{img, size};
+        const size_t footer = fb.root(size - 10 - (size_t)flen);
+        // Footer: 0 version, 1 schema, 2 dictionaries, 3 recordBatches
+        const size_t schema_t = fb.table_field(footer, 1);
+        if (!schema_t) throw bad("footer without a schema");
+        if (fb.vec_len(fb.field_pos(footer, 2)) != 0) throw bad("dictionary-encoded columns are not supported");
+        // Schema: 0 endianness, 1 fields
+        if (fb.scalar<int16_t>(schema_t, 0, 0) != 0) throw bad("big-endian files are not supported");
+        const size_t fields_v = fb.field_pos(schema_t, 1);
+        const size_t nfields = fb.vec_len(fields_v);
+        std::vector<Field> fields;
+        for (size_t i = 0; i < nfields; ++i) {
+            // Field: 0 name, 1 nullable, 2 type_type, 3 type, 4 dictionary, 5 children
+            const size_t ft = fb.vec_table(fields_v, i);
+            Field fld;
+            fld.name = fb.string(ft, 0);
+            fld.nullable = fb.scalar<uint8_t>(ft, 1, 0) != 0;
+            if (fb.field_pos(ft, 4)) throw bad("dictionary-encoded column " + fld.name);
+            const int tt = fb.scalar<uint8_t>(ft, 2, 0);
+            const size_t ty = fb.table_field(ft, 3);
+            if (tt == 2) {         // Int { 0 bitWidth, 1 is_signed }
+                const int bw = fb.scalar<int32_t>(ty, 0, 0);
+                const bool sg = fb.scalar<uint8_t>(ty, 1, 0) != 0;
+                switch (bw) {
+                    case 8: fld.data_type = sg ? DataType::Int8 : DataType::UInt8; break;
+                    case 16: fld.data_type = sg ? DataType::Int16 : DataType::UInt16; break;
+                    case 32: fld.data_type = sg ? DataType::Int32 : DataType::UInt32; break;
+                    case 64: fld.data_type = sg ? DataType::Int64 : DataType::UInt64; break;
+                    default: throw bad("integer width of column " + fld.name);
+                }
+            } else if (tt == 3) {  // FloatingPoint { 0 precision: HALF, SINGLE, DOUBLE }
+                const int pr = fb.scalar<int16_t>(ty, 0, 0);
+                if (pr == 1) fld.data_type = DataType::Float32; else if (pr == 2) fld.data_type = DataType::Float64; else throw bad("half floats (column " + fld.name + ")");
+            } else if (tt == 6) fld.data_type = DataType::Boolean;
+            else if (tt == 5) fld.data_type = DataType::Utf8;
+            else throw bad("column " + fld.name + ": unsupported type id " + std::to_string(tt));
+            fields.push_back(fld);
+        }
+        // record batch blocks: struct Block { int64 offset; int32 metaDataLength; (pad) int64 bodyLength; } = 24 bytes
+        const size_t blocks_v = fb.field_pos(footer, 3);
+        const size_t nblocks = fb.vec_len(blocks_v);
+        std::vector<std::vector<ArrayRef>> chunks(nfields);
+        for (size_t b = 0; b < nblocks; ++b) {
+            const uint8_t* blk = fb.vec_struct(blocks_v, b, 24);
+            int64_t off, body_len; int32_t meta_len;
+            std::memcpy(&off, blk, 8); std::memcpy(&meta_len, blk + 8, 4); std::memcpy(&body_len, blk + 16, 8);
+            if (off < 0 || meta_len < 8 || body_len < 0 || (uint64_t)off + (uint64_t)meta_len + (uint64_t)body_len > size) throw bad("block out of bounds");
+            size_t mpos = (size_t)off;
+            uint32_t first;
+            std::memcpy(&first, img + mpos, 4);
+            mpos += first == 0xFFFFFFFFu ? 8 : 4;   // continuation marker + length, or the pre-0.15 length only
+            const size_t msg = fb.root(mpos);
+            // Message: 0 version, 1 header_type, 2 header, 3 bodyLength
+            if (fb.scalar<uint8_t>(msg, 1, 0) != 3) throw bad("block is not a RecordBatch message");
+            const size_t rb = fb.table_field(msg, 2);
+            // RecordBatch: 0 length, 1 nodes [FieldNode{int64 length, int64 null_count}], 2 buffers [Buffer{int64 offset, int64 length}], 3 compression
+            if (fb.field_pos(rb, 3)) throw bad("compressed record batches are not supported");
+            const int64_t nrows = fb.scalar<int64_t>(rb, 0, 0);
+            const size_t nodes_v = fb.field_pos(rb, 1), bufs_v = fb.field_pos(rb, 2);
+            if (fb.vec_len(nodes_v) != nfields) throw bad("nested columns are not supported");
+            const uint8_t* body = img + (size_t)off + (size_t)meta_len;
+            size_t bi = 0;
+            auto next_buf = [&](int64_t& bo, int64_t& bl) {
+                if (bi >= fb.vec_len(bufs_v)) throw bad("buffer list too short");
+                const uint8_t* p = fb.vec_struct(bufs_v, bi++, 16);
+                std::memcpy(&bo, p, 8); std::memcpy(&bl, p + 8, 8);
+                if (bo < 0 || bl < 0 || bo + bl > body_len) throw bad("buffer out of bounds");
+            };
+            for (size_t c = 0; c < nfields; ++c) {
+                const uint8_t* node = fb.vec_struct(nodes_v, c, 16);
+                int64_t len, nulls;
+                std::memcpy(&len, node, 8); std::memcpy(&nulls, node + 8, 8);
+                if (len != nrows) throw bad("column length differs from the batch length");
+                int64_t vo, vl, do_, dl;
+                next_buf(vo, vl);   // validity
+                next_buf(do_, dl);  // values (Utf8: offsets)
+                const DataType dt = fields[c].data_type;
+                if (dt == DataType::Utf8) {
+                    int64_t so, sl;
+                    next_buf(so, sl);
+                    std::vector<std::string> strs((size_t)len);
+                    for (int64_t r = 0; r < len; ++r) {
+                        int32_t a0, a1;
+                        std::memcpy(&a0, body + do_ + 4 * r, 4); std::memcpy(&a1, body + do_ + 4 * (r + 1), 4);
+                        if (a0 < 0 || a1 < a0 || a1 > sl) throw bad("string offsets out of bounds");
+                        strs[(size_t)r].assign((const char*)body + so + a0, (size_t)(a1 - a0));
+                    }
+                    chunks[c].push_back(Array::from_strings(std::move(strs)));
+                    continue;
+                }
+                const int64_t need = dt == DataType::Boolean ? (len + 7) / 8 : len * (int64_t)type_size(dt);
+                if (dl < need) throw bad("values buffer of column " + fields[c].name + " is too short");
+                auto a = std::make_shared<Array>();
+                a->dtype = dt;
+                a->length = len;
+                a->values = std::make_shared<DeviceBuffer>(need + 8);
+                if (need) check(rdf_copy_h2d(a->values->data(), body + do_, need));
+                if (nulls > 0) {
+                    if (vl < (len + 7) / 8) throw bad("validity buffer of column " + fields[c].name + " is too short");
+                    a->validity = std::make_shared<DeviceBuffer>((len + 7) / 8 + 8);
+                    check(rdf_copy_h2d(a->validity->data(), body + vo, (len + 7) / 8));
+                    a->null_count = nulls;
+                }
+                chunks[c].push_back(a);
+            }
+        }
+        std::vector<Column> cols;
+        for (size_t c = 0; c < nfields; ++c) {
+            if (chunks[c].empty()) {   // a file without record batches still has its schema: one empty chunk per column
+                if (fields[c].data_type == DataType::Utf8) chunks[c].push_back(Array::from_strings({}));
+                else { auto a = Array::make_out(fields[c].data_type, 0, false); chunks[c].push_back(a); }
+            }
+            cols.push_back(Column::from_arrays(chunks[c], fields[c]));
         }
         return from_columns(std::move(cols));
     }
@@ -806,21 +992,56 @@ class DataFrame {
             std::vector<rdf_array> cv;
             std::vector<std::shared_ptr<Array>> outs;
             std::vector<rdf_out> ov;
+            std::vector<std::vector<ArrayRef>> widened(n);   // Boolean columns travel through the compaction as UInt8 (cast there and back on the device)
             for (size_t k = 0; k < n; ++k) {
                 const Column& c = columns_[base + k];
-                if (c.data_type() == DataType::Utf8 || c.data_type() == DataType::Boolean)
-                    throw DataFrameError(DataFrameError::ComputeError, "filter of " + std::string(type_name(c.data_type())) + " columns is outside the accelerated path");
+                const bool is_bool = c.data_type() == DataType::Boolean;
+                if (is_bool) widened[k] = cast_arrays(c.data().chunks(), DataType::UInt8);
                 for (size_t i = 0; i < nch; ++i) {
-                    cv.push_back(c.data().chunk(i)->view());
-                    outs.push_back(Array::make_out(c.data_type(), counts[i], c.data().chunk(i)->validity != nullptr));
+                    const ArrayRef& src = is_bool ? widened[k][i] : c.data().chunk(i);
+                    if (c.data_type() == DataType::Utf8) {   // opaque host strings: a placeholder keeps the column count of the call
+                        cv.push_back(rdf_array{}); outs.push_back(nullptr); ov.push_back(rdf_out{});
+                        continue;
+                    }
+                    cv.push_back(src->view());
+                    outs.push_back(Array::make_out(is_bool ? DataType::UInt8 : c.data_type(), counts[i], src->validity != nullptr));
                     ov.push_back(outs.back()->out_view(counts[i]));
                 }
             }
-            check(rdf_filter_columns(cv.data(), (int32_t)n, mv.data(), (int64_t)nch, ov.data()));
-            for (size_t k = 0; k < n; ++k) {
+            // device columns of this group, packed without the Utf8 placeholders
+            std::vector<rdf_array> dcv; std::vector<rdf_out> dov; std::vector<size_t> dmap;
+            for (size_t k = 0; k < n; ++k)
+                if (columns_[base + k].data_type() != DataType::Utf8) { dmap.push_back(k); for (size_t i = 0; i < nch; ++i) { dcv.push_back(cv[k * nch + i]); dov.push_back(ov[k * nch + i]); } }
+            if (!dmap.empty()) check(rdf_filter_columns(dcv.data(), (int32_t)dmap.size(), mv.data(), (int64_t)nch, dov.data()));
+            for (size_t d = 0; d < dmap.size(); ++d) {
+                const size_t k = dmap[d];
                 std::vector<ArrayRef> chunks;
-                for (size_t i = 0; i < nch; ++i) { auto& o = outs[k * nch + i]; o->length = ov[k * nch + i].length; o->null_count = ov[k * nch + i].null_count; chunks.push_back(o); }
+                for (size_t i = 0; i < nch; ++i) { auto& o = outs[k * nch + i]; o->length = dov[d * nch + i].length; o->null_count = dov[d * nch + i].null_count; chunks.push_back(o); }
+                if (columns_[base + k].data_type() == DataType::Boolean) chunks = cast_arrays(chunks, DataType::Boolean);
                 result[base + k] = Column::from_arrays(chunks, columns_[base + k].field());
+            }
+        }
+        // Utf8 columns are carried on the host: filtered there with the mask's bits (value AND validity, like Column::filter)
+        bool any_text = false;
+        for (auto& c : columns_) any_text |= c.data_type() == DataType::Utf8;
+        if (any_text) {
+            std::vector<std::vector<bool>> keep(nch);
+            for (size_t i = 0; i < nch; ++i) {
+                const auto bits = mask.data().chunk(i)->bools_to_host(), valid = mask.data().chunk(i)->valid_to_host();
+                keep[i].resize(bits.size());
+                for (size_t r = 0; r < bits.size(); ++r) keep[i][r] = bits[r] && valid[r];
+            }
+            for (size_t k = 0; k < columns_.size(); ++k) {
+                if (columns_[k].data_type() != DataType::Utf8) continue;
+                std::vector<ArrayRef> chunks;
+                for (size_t i = 0; i < nch; ++i) {
+                    const auto& src = *columns_[k].data().chunk(i)->strings;
+                    std::vector<std::string> out;
+                    const size_t first = (size_t)columns_[k].data().chunk(i)->offset;
+                    for (size_t r = 0; r < keep[i].size(); ++r) if (keep[i][r]) out.push_back(src[first + r]);
+                    chunks.push_back(Array::from_strings(std::move(out)));
+                }
+                result[k] = Column::from_arrays(chunks, columns_[k].field());
             }
         }
         return DataFrame(schema_, std::move(result));

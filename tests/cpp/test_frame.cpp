@@ -12,6 +12,7 @@ using namespace rdf;
 namespace P = rdf::plan;
 
 static std::string g_csv = "tests/golden/uk_cities_with_headers.csv";
+static std::string g_arrow = "tests/golden/mixed_batches.arrow";
 
 template <class T> static std::vector<T> host(const ArrayRef& a) { return a->values_to_host<T>(); }
 
@@ -330,7 +331,71 @@ TEST(test_group_aggregate_by_key) {
     CHECK_THROWS(LazyFrame::read(df).aggregate({"k"}, {{AF::Max, {"v"}}}).evaluate());
 }
 
+// DataFrame::from_arrow (src/dataframe.rs:391-407) on the committed pyarrow-written fixture: schema, chunking (one chunk
+// per record batch), every value and validity bit, then the device path over the loaded columns.
+TEST(test_from_arrow_ipc_file) {
+    DataFrame df = DataFrame::from_arrow(g_arrow);
+    const std::vector<std::string> names{"i8", "i32", "i64", "u16", "f32", "f64", "flag", "city"};
+    const std::vector<DataType> types{DataType::Int8, DataType::Int32, DataType::Int64, DataType::UInt16, DataType::Float32, DataType::Float64, DataType::Boolean, DataType::Utf8};
+    CHECK_EQ(df.num_columns(), names.size());
+    for (size_t c = 0; c < names.size(); ++c) { CHECK_EQ(df.schema().fields[c].name, names[c]); CHECK(df.schema().fields[c].data_type == types[c]); }
+    const std::vector<int64_t> lens{1024, 1024, 576};
+    CHECK_EQ(df.num_chunks(), lens.size());
+    CHECK_EQ(df.num_rows(), (int64_t)2624);
+    int64_t first = 0, f64_nulls = 0;
+    double f64_sum = 0;
+    for (size_t b = 0; b < lens.size(); ++b) {
+        const int64_t n = lens[b];
+        CHECK_EQ(df.column(0).data().chunk(b)->length, n);
+        auto v8 = host<int8_t>(df.column(0).data().chunk(b));
+        auto v32 = host<int32_t>(df.column(1).data().chunk(b));
+        auto v64 = host<int64_t>(df.column(2).data().chunk(b));
+        auto v16 = host<uint16_t>(df.column(3).data().chunk(b));
+        auto vf = host<float>(df.column(4).data().chunk(b));
+        auto vd = host<double>(df.column(5).data().chunk(b));
+        auto dvalid = df.column(5).data().chunk(b)->valid_to_host();
+        auto flag = df.column(6).data().chunk(b)->bools_to_host();
+        auto fvalid = df.column(6).data().chunk(b)->valid_to_host();
+        CHECK(df.column(1).data().chunk(b)->validity == nullptr);   // no nulls -> no bitmap uploaded
+        for (int64_t r = 0; r < n; ++r) {
+            const int64_t i = first + r;
+            CHECK_EQ((int)v8[(size_t)r], (int)((i % 200) - 100));
+            CHECK_EQ(v32[(size_t)r], (int32_t)(7 * i - 1000));
+            CHECK_EQ(v64[(size_t)r], i * 1000000000ll);
+            CHECK_EQ((int)v16[(size_t)r], (int)((13 * i) % 65536));
+            CHECK_EQ(vf[(size_t)r], (float)i / 8.0f);
+            CHECK_EQ((bool)dvalid[(size_t)r], i % 10 != 3);
+            if (i % 10 != 3) { CHECK_EQ(vd[(size_t)r], 0.5 * (double)i - 100.0); f64_sum += vd[(size_t)r]; } else ++f64_nulls;
+            CHECK_EQ((bool)fvalid[(size_t)r], i % 7 != 0);
+            if (i % 7 != 0) CHECK_EQ((bool)flag[(size_t)r], i % 3 == 0);
+        }
+        CHECK_EQ(df.column(7).data().chunk(b)->strings->at(5), "city" + std::to_string(first + 5));
+        first += n;
+    }
+    CHECK_EQ(df.column_by_name("f64").null_count(), f64_nulls);
+    // the loaded columns are ordinary device columns: aggregates and a fused filter run on them
+    CHECK_NEAR(*AggregateFunctions::sum<double>(df.column_by_name("f64").data()), f64_sum, 1e-12);
+    CHECK_EQ(*AggregateFunctions::sum<int64_t>(df.column_by_name("i64").data()), (int64_t)(2623ll * 2624 / 2) * 1000000000ll);
+    DataFrame kept = df.filter(BooleanFilter::gt(BooleanFilter::column("i32"), BooleanFilter::scalar(Scalar((int64_t)6000))));
+    CHECK_EQ(kept.num_rows(), (int64_t)(2624 - 1001));   // 7 i - 1000 > 6000  <=>  i >= 1001
+    CHECK_EQ(kept.num_chunks(), lens.size());            // chunking preserved; batch 0 (rows 0..1023) keeps 23 rows
+    CHECK_EQ(kept.column_by_name("city").data().chunk(0)->strings->at(0), std::string("city1001"));
+    {   // Boolean and Utf8 columns ride along: row r of the kept batch 1 is global row 1024 + r
+        auto flag = kept.column_by_name("flag").data().chunk(1)->bools_to_host();
+        auto fvalid = kept.column_by_name("flag").data().chunk(1)->valid_to_host();
+        CHECK_EQ(flag.size(), (size_t)1024);
+        for (size_t r = 0; r < flag.size(); ++r) {
+            const int64_t i = 1024 + (int64_t)r;
+            CHECK_EQ((bool)fvalid[r], i % 7 != 0);
+            if (i % 7 != 0) CHECK_EQ((bool)flag[r], i % 3 == 0);
+        }
+        CHECK_EQ(kept.column_by_name("city").data().chunk(2)->strings->back(), std::string("city2623"));
+    }
+    CHECK_THROWS(DataFrame::from_arrow("tests/golden/uk_cities_with_headers.csv"));   // not an IPC file
+}
+
 int main(int argc, char** argv) {
     if (argc > 1) g_csv = argv[1];
+    if (argc > 2) g_arrow = argv[2];
     return run_all();
 }

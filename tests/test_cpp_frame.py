@@ -39,4 +39,5 @@ def test_plan_builders_cpp():
 
 @pytest.mark.gpu
 def test_frame_mirror_cpp():
-    run(build("test_frame", True), os.path.join(ROOT, "tests", "golden", "uk_cities_with_headers.csv"))
+    run(build("test_frame", True), os.path.join(ROOT, "tests", "golden", "uk_cities_with_headers.csv"),
+        os.path.join(ROOT, "tests", "golden", "mixed_batches.arrow"))
