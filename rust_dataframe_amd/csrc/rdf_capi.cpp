@@ -2167,7 +2167,6 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
         const int64_t nsuper = (ntiles + kGbSuper / kEvalTile - 1) / (kGbSuper / kEvalTile);
         int nb = (int)std::min<int64_t>(nsuper, (int64_t)eval_grid_limit() / 4);   // 2 resident blocks of 512 threads per CU
         if (nb < 1) nb = 1;
-        const int64_t tiles_per_block = (nsuper + nb - 1) / nb * (kGbSuper / kEvalTile);
         void *precs, *hist0, *hist1, *ptmp, *pspec;
         RDF_TRY(arena_alloc((size_t)nrows * 16 + 64, &precs));
         RDF_TRY(arena_alloc((size_t)((int64_t)P * nb + 1) * 8, &hist0));
@@ -2189,7 +2188,7 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
         pa.chunk_len = tb.dev_at<int64_t>(o_len);
         pa.nchunks = nchunks;
         pa.ntiles = ntiles;
-        pa.tiles_per_block = ctx.opt_gb_debug == 2 ? 1 : tiles_per_block;
+        pa.ablate_stores = ctx.opt_gb_debug == 2;
         pa.key_dtype = kdt;
         pa.value_dtype = vdt;
         pa.hist = (int64_t*)hist0;
@@ -2217,7 +2216,7 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
         ga.cursor = d_cursor;
         ga.flags = d_flags2;
         ga.max_out = max_groups;
-        ga.pad = ctx.opt_gb_debug == 1 ? 1 : 0;
+        ga.ablate_lds = ctx.opt_gb_debug == 1;
         HIP_TRY(launch_gb_aggregate(ga, ctx.stream));
         kt.stop();
         ctx.last_kernel = "gb_aggregate_kernel";

@@ -242,8 +242,9 @@ struct GbPartArgs {
     const DevChunkCol* values;           // [nchunks]
     const int64_t*     chunk_tile_start; // [nchunks + 1], tiles of kEvalTile rows
     const int64_t*     chunk_len;
-    int64_t            nchunks, ntiles, tiles_per_block;   // block b owns tiles [b * tiles_per_block, +tiles_per_block)
+    int64_t            nchunks, ntiles;
     int32_t            key_dtype, value_dtype;
+    int32_t            ablate_stores, pad;   // bench ablation (rdf_set_option("gb_debug", 2)): run the scatter without its global stores
     int64_t*           hist;             // histogram kernel: out counts [digit * gridDim.x + block]; scatter: their exclusive scan
     uint64_t*          recs;             // scatter out: [2 * rows] (hashed key, value bits)
     unsigned long long* special_sums;    // [2]: rows whose hashed key equals the LDS free marker / rows with a NULL key
@@ -254,7 +255,8 @@ struct GbAggArgs {
     const uint64_t* recs;
     const int64_t*  scan;                // [ (1 << kGbPartBits) * nblocks + 1 ] exclusive scan of the histogram
     int64_t         nblocks;             // blocks of the histogram / scatter kernels
-    int32_t         is_f64, has_values, key_dtype, pad;
+    int32_t         is_f64, has_values, key_dtype;
+    int32_t         ablate_lds;          // bench ablation (rdf_set_option("gb_debug", 1)): stream the records without the LDS table work
     void*           out_keys; void* out_sums; int64_t* out_counts;
     unsigned int*   cursor;
     uint32_t*       flags;               // bit 2: an LDS table overflowed / more than max_out groups

@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(kGbBlock) void gb_scatter_kernel(const GbPartArgs a
             const unsigned int d = (unsigned int)(k >> (64 - kGbPartBits));
             u64x2 rec;
             rec[0] = k; rec[1] = sval[i];
-            if (a.tiles_per_block != 1) ((u64x2*)a.recs)[gbase[d] + (int64_t)(i - lstart[d])] = rec;
+            if (!a.ablate_stores) ((u64x2*)a.recs)[gbase[d] + (int64_t)(i - lstart[d])] = rec;
         }
         __syncthreads();
         // (E) advance the block's output positions
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(kGbBlock) void gb_aggregate_kernel(const GbAggArgs 
         uint64_t dbg_acc = 0;
         auto upsert = [&](const u64x2 rec) {
             const uint64_t hk = rec[0];
-            if (a.pad == 1) { dbg_acc ^= hk ^ rec[1]; return; }
+            if (a.ablate_lds) { dbg_acc ^= hk ^ rec[1]; return; }
             // slot from the bits below the partition bits (still well mixed); multiply-shift range reduction
             uint32_t s = (uint32_t)(((uint64_t)(uint32_t)(hk >> 20) * (uint64_t)kGbSlots) >> 32);
             int slot = -1;
@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(kGbBlock) void gb_aggregate_kernel(const GbAggArgs 
             have = nhave;
         }
         for (; i < hi; i += kGbBlock) upsert(__builtin_nontemporal_load(recs + i));
-        if (a.pad == 1 && dbg_acc == 0x1234567) err |= 8u;
+        if (a.ablate_lds && dbg_acc == 0x1234567) err |= 8u;   // keeps the loads alive
         __syncthreads();
         if (threadIdx.x == 0) { misc[1] = atomicAdd(a.cursor, misc[0]); misc[0] = 0; }
         __syncthreads();

@@ -148,3 +148,28 @@ def test_sort_and_groupby_large_properties(gpu):
     strict = gpu.pipeline(e, [[_arr(ks.keep, A.I64, ng - 1)], [_arr(ks.keep, A.I64, ng - 1, 1)]], [e.col(0)], lt)[0]
     assert strict.count == ng - 1    # strictly increasing: no key appears twice
     torch.cuda.empty_cache()
+
+
+def test_c1_csv_shape_1e6_rows_977_batches(gpu, ora):
+    """Config C1 (the reference's own CPU-runnable case): 1 000 000 f64 rows read in 1024-row batches (977 chunks, the
+    last one 576 rows), y = sin(x + 1.0), sum(y) — handed over as HOST buffers like the Rust shim would, so the
+    small-chunk staging path (one packed H2D copy) is what runs.  Oracle on the full input; numpy as a second anchor."""
+    import numpy as np
+    n = 1_000_000
+    x = np.random.default_rng(42).uniform(0.0, 1.0, n)
+    chunks = [A.HostArray.from_numpy(x[i:i + 1024]) for i in range(0, n, 1024)]
+    assert len(chunks) == 977 and chunks[-1].length == 576
+    e = A.Expr()
+    y = e.op("sin", e.op("add", e.col(0), e.scalar(1.0)))
+    g = gpu.pipeline(e, [chunks], [y])[0]
+    o = ora.pipeline(e, [chunks], [y])[0]
+    ref = float(np.sin(x + 1.0).sum())
+    assert g.count == o.count == n
+    assert abs(g.sum - o.sum) <= 1e-6 * abs(o.sum) and abs(g.sum - ref) <= 1e-9 * abs(ref)
+    assert abs(g.min - o.min) <= 1e-12 and abs(g.max - o.max) <= 1e-12
+    # unfused, like Evaluate::calculate twice: add -> new column, sin -> new column (chunking preserved), then sum
+    s1 = gpu.binary("add", chunks, [A.HostArray.from_numpy(np.full(c.length, 1.0)) for c in chunks])
+    s2 = gpu.unary("sin", s1)
+    assert [c.length for c in s2] == [c.length for c in chunks]
+    tot = gpu.sum(s2)
+    assert abs(tot - ref) <= 1e-9 * abs(ref)

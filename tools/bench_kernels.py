@@ -91,6 +91,29 @@ def main():
         results.append(r)
         print(json.dumps(r), flush=True)
 
+    if not only or "probe" in only:
+        # independent denominators: a read-only and a copy probe with stock torch kernels on the same box
+        px = torch.empty(n, dtype=torch.float64, device="cuda").uniform_()
+        py = torch.empty_like(px)
+        def probe(name, fn, nbytes):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.steps
+            r = {"kernel": name, "rows": n, "alg_bytes": nbytes, "kernel_ms": ms, "GBps": round(nbytes / ms / 1e6, 1), "frac_of_8TBps": round(nbytes / ms / 1e6 / PEAK, 3)}
+            results.append(r)
+            print(json.dumps(r), flush=True)
+        probe("probe_torch_sum_read_only", lambda: px.sum(), 8.0 * n)
+        probe("probe_torch_copy", lambda: py.copy_(px), 16.0 * n)
+        probe("probe_torch_add_store", lambda: torch.add(px, px, out=py), 16.0 * n)
+        del px, py
+        torch.cuda.empty_cache()
     x, y, z = dev_f64(n, 0, -1, 1), dev_f64(n, 1, -1, 1), dev_f64(n, 2, -1, 1)
     k = dev_i64(n, 3)
     vx = dev_validity(n, 0, 0.1)
