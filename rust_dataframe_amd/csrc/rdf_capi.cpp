@@ -675,6 +675,77 @@ bool build_spec_plan(Compiler& cc, int filter_root, int nvalues, const int* valu
     return spec_available(s.c_str());
 }
 
+// Second-level lookup: kernels specialised on the tree SHAPE with runtime operators (rdf_expr.hip.h *RT nodes, f64 only).
+// Every leaf occurrence gets its own canonical column / literal slot, operator slots are numbered in pre-order (predicate
+// first); a (scalar, column) or (leaf, subtree) operand pair is put in (column, scalar) / (subtree, leaf) order with
+// the swap bit of the operator set.
+struct ShapeSigBuilder {
+    Compiler& cc;
+    SpecPlan& sp;
+    int* rt;
+    int nslots = 0;
+    ShapeSigBuilder(Compiler& c, SpecPlan& s, int* r) : cc(c), sp(s), rt(r) {}
+    bool is_scalar(int idx) const { return cc.nodes[idx].kind == RDF_NODE_SCALAR; }
+    bool is_column(int idx) const { return cc.nodes[idx].kind == RDF_NODE_COLUMN; }
+    int strip(int idx) {   // skip no-op casts
+        while (cc.nodes[idx].kind == RDF_NODE_OP && cc.nodes[idx].op == RDF_OP_CAST && cc.infer(cc.nodes[idx].lhs) == cc.nodes[idx].dtype) idx = cc.nodes[idx].lhs;
+        return idx;
+    }
+    std::string leaf(int idx) {
+        const rdf_expr_node& nd = cc.nodes[idx];
+        if (nd.kind == RDF_NODE_COLUMN) {
+            if (cc.col_dtype[nd.column] != RDF_F64 || sp.ncols >= 4) { sp.ok = false; return "?"; }
+            sp.col_map[sp.ncols] = nd.column;
+            return std::string("c") + char('0' + sp.ncols++) + 'd';
+        }
+        if (nd.dtype == RDF_NULLTYPE || sp.nimm >= 4) { sp.ok = false; return "?"; }
+        sp.imm[sp.nimm] = cc.imm_for(nd, RDF_F64);
+        return std::string("k") + char('0' + sp.nimm++) + 'd';
+    }
+    std::string node(int idx) {
+        if (!sp.ok) return "?";
+        idx = strip(idx);
+        const rdf_expr_node& nd = cc.nodes[idx];
+        if (nd.kind != RDF_NODE_OP) return leaf(idx);
+        if (nslots >= 8) { sp.ok = false; return "?"; }
+        const int op = nd.op;
+        if (op == RDF_OP_SIN || op == RDF_OP_COS || op == RDF_OP_TAN) {
+            if (cc.infer(nd.lhs) != RDF_F64) { sp.ok = false; return "?"; }
+            const int slot = nslots++;
+            rt[slot] = op;
+            return "[T" + std::to_string(slot) + " " + node(nd.lhs) + "]";
+        }
+        const bool arith = op >= RDF_OP_ADD && op <= RDF_OP_DIV, cmp = op_is_cmp(op), logic = op == RDF_OP_AND || op == RDF_OP_OR;
+        if (!(arith || cmp || logic)) { sp.ok = false; return "?"; }
+        int l = strip(nd.lhs), r = strip(nd.rhs);
+        if (arith && (cc.infer(l) != RDF_F64 || cc.infer(r) != RDF_F64)) { sp.ok = false; return "?"; }
+        if (cmp && !((is_column(l) && is_scalar(r)) || (is_scalar(l) && is_column(r)))) { sp.ok = false; return "?"; }
+        const bool lleaf = cc.nodes[l].kind != RDF_NODE_OP, rleaf = cc.nodes[r].kind != RDF_NODE_OP;
+        bool swap = false;
+        if (!logic) {
+            if (is_scalar(l) && is_scalar(r)) { sp.ok = false; return "?"; }
+            if (!lleaf && !rleaf) { sp.ok = false; return "?"; }
+            if ((lleaf && !rleaf) || (is_scalar(l) && is_column(r))) swap = true;
+        }
+        const int slot = nslots++;
+        rt[slot] = op | (swap ? 0x100 : 0);
+        if (swap) std::swap(l, r);
+        const std::string a = node(l), b = node(r);
+        return std::string("(") + (arith ? 'A' : cmp ? 'C' : 'G') + std::to_string(slot) + " " + a + " " + b + ")";
+    }
+};
+bool build_shape_plan(Compiler& cc, int filter_root, int nvalues, const int* value_roots, int sink, SpecPlan& sp, int* rt) {
+    if (nvalues != 1) return false;
+    ShapeSigBuilder b(cc, sp, rt);
+    std::string s = "P:";
+    s += filter_root >= 0 ? b.node(filter_root) : std::string("-");
+    s += ";V:" + b.node(value_roots[0]) + ";-;S:" + std::to_string(sink == RDF_SINK_AGG ? SINK_AGG : SINK_STORE);
+    if (!sp.ok || b.nslots == 0) return false;
+    sp.width = 8;
+    sp.sig = s;
+    return spec_available(s.c_str());
+}
+
 // Grouped sink: signature "G<g>;P:<pred|->;K:<group id>;V:<v0>;<v1>;..." for the smallest catalog G >= ngroups.
 bool build_gspec_plan(Compiler& cc, int filter_root, int group_root, int ngroups, int nvalues, const int* value_roots, SpecPlan& sp) {
     sp.max_cols = kGSpecCols; sp.max_imm = kGSpecImm; sp.mixed = true; sp.dedup = true;
@@ -952,7 +1023,13 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     TableBuilder stb;
     bool use_spec = false;
     int spec_rpb = 0;
-    if (ctx.opt_spec && !grouped && build_spec_plan(cc, ps.filter_root, ps.nvalues, ps.value_roots, ps.sink, sp)) {
+    int rt_ops[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool have_plan = ctx.opt_spec && !grouped && build_spec_plan(cc, ps.filter_root, ps.nvalues, ps.value_roots, ps.sink, sp);
+    if (!have_plan && ctx.opt_spec && !grouped) {   // exact shape not in the catalog: a shape-specialised kernel with runtime operators?
+        sp = SpecPlan();
+        have_plan = build_shape_plan(cc, ps.filter_root, ps.nvalues, ps.value_roots, ps.sink, sp, rt_ops);
+    }
+    if (have_plan) {
         memset(&sa, 0, sizeof sa);
         use_spec = true;
         spec_rpb = spec_rows_per_block_iter(sp.sig.c_str());
@@ -967,6 +1044,11 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     }
     if (use_spec) {
         for (int k = 0; k < sp.nimm; ++k) sa.imm[k] = sp.imm[k];
+        for (int k = 0; k < 8; ++k) sa.rt[k] = rt_ops[k];
+        for (int k = 0; k < 4; ++k) {   // a repeated program column is loaded once
+            sa.alias[k] = -1;
+            for (int j = 0; j < k && k < sp.ncols; ++j) if (sp.col_map[j] == sp.col_map[k]) { sa.alias[k] = j; break; }
+        }
         sa.partials = d_partials;
         sa.flags = d_flags;
         sa.vec_bitmap = ctx.opt_vec_bitmap ? 1 : 0;

@@ -135,6 +135,8 @@ struct SpecArgs {
     AggPartial*        partials;         // SINK_AGG: [gridDim.x * nvalues]
     uint32_t*          flags;
     int32_t            vec_bitmap;       // 1: bitmap words through the vector memory path (default); 0: scalar loads (A/B)
+    int32_t            rt[8];            // shape-specialised kernels: operator of runtime-op node k (rdf_op | swap << 8)
+    int32_t            alias[4];         // canonical column k repeats column alias[k] < k (-1: its own column): registers are copied, not reloaded
 };
 
 struct MaskTables {

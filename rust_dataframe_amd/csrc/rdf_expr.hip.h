@@ -40,6 +40,7 @@ struct Ctx {
     uint64_t imm[4];
     uint32_t inr;        // bit r = row r exists
     uint32_t err;
+    int32_t  rt[8];      // runtime operators of the *RT nodes (wave-uniform)
 };
 
 template <class T> __device__ __forceinline__ T from_bits(uint64_t x);
@@ -207,6 +208,88 @@ struct Cast {
         } else return (T)x;
     }
     static std::string sig() { return "{" + std::to_string(TO) + " " + A::sig() + "}"; }
+};
+
+// ---- runtime-operator nodes (f64): ONE compiled kernel per tree SHAPE, the operators are wave-uniform kernel
+// arguments (c.rt[SLOT] = rdf_op | swap << 8), so a fused Calculate chain that is not in the exact catalog still runs
+// as straight-line code: the switch below is a handful of scalar compares per row, not an interpreter.
+template <int SLOT, class A, class B>
+struct ArithRT {   // add / subtract / multiply / divide
+    static_assert(A::dt == RDF_F64 && B::dt == RDF_F64, "runtime-op arithmetic is instantiated for f64");
+    static constexpr int dt = RDF_F64;
+    static constexpr int ncols = A::ncols > B::ncols ? A::ncols : B::ncols;
+    static constexpr int width = merge_width(A::width, B::width);
+    template <int k> static constexpr int colw() { return cmax(A::template colw<k>(), B::template colw<k>()); }
+    using T = double;
+    template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c) & B::vmask(c); }
+    template <int r, class C> static __device__ __forceinline__ double eval(C& c) {
+        const double x0 = A::template eval<r>(c), y0 = B::template eval<r>(c);
+        const int op = c.rt[SLOT] & 0xFF;
+        const bool sw = (c.rt[SLOT] >> 8) & 1;
+        const double x = sw ? y0 : x0, y = sw ? x0 : y0;
+        if (op == RDF_OP_ADD) return x + y;
+        if (op == RDF_OP_SUB) return x - y;
+        if (op == RDF_OP_MUL) return x * y;
+        const bool z = y == 0.0;
+        if (z && ((vmask(c) & c.inr) >> r & 1)) c.err |= 1u;
+        return z ? 0.0 : x / y;
+    }
+    static std::string sig() { return "(A" + std::to_string(SLOT) + " " + A::sig() + " " + B::sig() + ")"; }
+};
+template <int SLOT, class A>
+struct TrigRT {    // sin / cos / tan: the three the reference's Evaluate::calculate dispatches (src/evaluation.rs:250-293)
+    static_assert(A::dt == RDF_F64, "runtime-op trig is instantiated for f64");
+    static constexpr int dt = RDF_F64;
+    static constexpr int ncols = A::ncols;
+    static constexpr int width = A::width;
+    template <int k> static constexpr int colw() { return A::template colw<k>(); }
+    using T = double;
+    template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c); }
+    template <int r, class C> static __device__ __forceinline__ double eval(C& c) {
+        const double x = A::template eval<r>(c);
+        const int op = c.rt[SLOT] & 0xFF;
+        if (op == RDF_OP_SIN) return sin(x);
+        if (op == RDF_OP_COS) return cos(x);
+        return tan(x);
+    }
+    static std::string sig() { return "[T" + std::to_string(SLOT) + " " + A::sig() + "]"; }
+};
+template <int SLOT, class A, class B>
+struct CmpRT {     // gt / ge / eq / ne / lt / le, both sides as f64 (src/expression.rs:844-845)
+    static constexpr int dt = RDF_BOOL;
+    static constexpr int ncols = A::ncols > B::ncols ? A::ncols : B::ncols;
+    static constexpr int width = merge_width(A::width, B::width);
+    template <int k> static constexpr int colw() { return cmax(A::template colw<k>(), B::template colw<k>()); }
+    using T = bool;
+    template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c) & B::vmask(c); }
+    template <int r, class C> static __device__ __forceinline__ bool eval(C& c) {
+        const double x0 = (double)A::template eval<r>(c), y0 = (double)B::template eval<r>(c);
+        const int op = c.rt[SLOT] & 0xFF;
+        const bool sw = (c.rt[SLOT] >> 8) & 1;
+        const double a = sw ? y0 : x0, b = sw ? x0 : y0;
+        if (op == RDF_OP_GT) return a > b;
+        if (op == RDF_OP_GE) return a >= b;
+        if (op == RDF_OP_EQ) return a == b;
+        if (op == RDF_OP_NE) return a != b;
+        if (op == RDF_OP_LT) return a < b;
+        return a <= b;
+    }
+    static std::string sig() { return "(C" + std::to_string(SLOT) + " " + A::sig() + " " + B::sig() + ")"; }
+};
+template <int SLOT, class A, class B>
+struct LogicRT {   // and / or on booleans, NULL if either side is NULL (arrow::compute::and / or)
+    static_assert(A::dt == RDF_BOOL && B::dt == RDF_BOOL, "logic over boolean operands");
+    static constexpr int dt = RDF_BOOL;
+    static constexpr int ncols = A::ncols > B::ncols ? A::ncols : B::ncols;
+    static constexpr int width = merge_width(A::width, B::width);
+    template <int k> static constexpr int colw() { return cmax(A::template colw<k>(), B::template colw<k>()); }
+    using T = bool;
+    template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c) & B::vmask(c); }
+    template <int r, class C> static __device__ __forceinline__ bool eval(C& c) {
+        const bool x = A::template eval<r>(c), y = B::template eval<r>(c);
+        return (c.rt[SLOT] & 0xFF) == RDF_OP_AND ? (x && y) : (x || y);
+    }
+    static std::string sig() { return "(G" + std::to_string(SLOT) + " " + A::sig() + " " + B::sig() + ")"; }
 };
 
 struct None {

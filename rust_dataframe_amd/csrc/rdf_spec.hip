@@ -135,6 +135,8 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     c.err = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) c.imm[k] = a.imm[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.rt[k] = a.rt[k];
     AggT<V0::dt> g0;
     using V1e = typename std::conditional<has_v1, V1, V0>::type;
     AggT<V1e::dt> g1;
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             c.inr = (1u << R) - 1;
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
+                if (k > 0 && a.alias[k] >= 0) continue;   // a second use of a column already loaded for slot alias[k] (shape kernels)
                 const GlobalPtr<VecS> p = (GlobalPtr<VecS>)(as_global<S>(col[k].values) + col[k].offset) + wbase + lane;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -185,6 +188,14 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
                     for (int e = 0; e < RV; ++e) c.v[k][RV * u + e] = t[e];
                 }
             }
+#pragma unroll
+            for (int k = 1; k < NC; ++k)      // aliases copy registers once every load has been issued
+#pragma unroll
+                for (int j = 0; j < k; ++j)
+                    if (a.alias[k] == j) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) c.v[k][r] = c.v[j][r];
+                    }
         } else {
             c.inr = 0;
 #pragma unroll
@@ -206,6 +217,11 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             c.valid[k] = c.inr;
+            if (k > 0 && a.alias[k] >= 0) {
+#pragma unroll
+                for (int j = 0; j < k; ++j) if (a.alias[k] == j) c.valid[k] = c.valid[j];
+                continue;
+            }
             if (col[k].validity) {
                 uint64_t w[R];
                 if (a.vec_bitmap) load_windows<R>(col[k].validity, col[k].offset + rw, n - rw, w);
@@ -360,7 +376,50 @@ template <int OP> static void reg_unary_f64() {
     reg<Prog<None, Un<OP, F0>, None, SINK_STORE>>();                      // f32
 }
 
+// ---- shape-specialised kernels with runtime operators (rdf_expr.hip.h *RT nodes).  Every leaf OCCURRENCE has its own
+// canonical column / literal slot (the host maps two slots to the same column when a program reuses one: the second
+// load hits in cache), operator slots are numbered in pre-order, predicate first.
+template <int S, int C, int K> struct Shapes {
+    template <int I> using Cd = Col<I, RDF_F64>;
+    template <int I> using Kd = Imm<I, RDF_F64>;
+    using c = Cd<C>;
+    using cc = ArithRT<S, Cd<C>, Cd<C + 1>>;
+    using ck = ArithRT<S, Cd<C>, Kd<K>>;
+    using ccc = ArithRT<S, ArithRT<S + 1, Cd<C>, Cd<C + 1>>, Cd<C + 2>>;
+    using cck = ArithRT<S, ArithRT<S + 1, Cd<C>, Cd<C + 1>>, Kd<K>>;
+    using ckc = ArithRT<S, ArithRT<S + 1, Cd<C>, Kd<K>>, Cd<C + 1>>;
+    using ckk = ArithRT<S, ArithRT<S + 1, Cd<C>, Kd<K>>, Kd<K + 1>>;
+    using Tc = TrigRT<S, Cd<C>>;
+    using Tcc = TrigRT<S, ArithRT<S + 1, Cd<C>, Cd<C + 1>>>;
+    using Tck = TrigRT<S, ArithRT<S + 1, Cd<C>, Kd<K>>>;
+};
+template <class PRED, class V> static void reg_shape_agg() {
+    if constexpr ((PRED::ncols > V::ncols ? PRED::ncols : V::ncols) <= 4) reg<Prog<PRED, V, None, SINK_AGG>>();
+}
+template <class PRED, int S, int C, int K> static void reg_shape_aggs() {
+    using H = Shapes<S, C, K>;
+    reg_shape_agg<PRED, typename H::c>();
+    reg_shape_agg<PRED, typename H::cc>(); reg_shape_agg<PRED, typename H::ck>();
+    reg_shape_agg<PRED, typename H::ccc>(); reg_shape_agg<PRED, typename H::cck>();
+    reg_shape_agg<PRED, typename H::ckc>(); reg_shape_agg<PRED, typename H::ckk>();
+    reg_shape_agg<PRED, typename H::Tc>(); reg_shape_agg<PRED, typename H::Tcc>(); reg_shape_agg<PRED, typename H::Tck>();
+}
+static void reg_shape_family() {
+    using H0 = Shapes<0, 0, 0>;
+    reg<Prog<None, H0::cc, None, SINK_STORE>>(); reg<Prog<None, H0::ck, None, SINK_STORE>>();
+    reg<Prog<None, H0::ccc, None, SINK_STORE>>(); reg<Prog<None, H0::cck, None, SINK_STORE>>();
+    reg<Prog<None, H0::ckc, None, SINK_STORE>>(); reg<Prog<None, H0::ckk, None, SINK_STORE>>();
+    reg<Prog<None, H0::Tc, None, SINK_STORE>>(); reg<Prog<None, H0::Tcc, None, SINK_STORE>>(); reg<Prog<None, H0::Tck, None, SINK_STORE>>();
+    reg_shape_aggs<None, 0, 0, 0>();
+    using P1 = CmpRT<0, Col<0, RDF_F64>, Imm<0, RDF_F64>>;                                   // x CMP c
+    reg_shape_aggs<P1, 1, 1, 1>();
+    using P2 = LogicRT<0, CmpRT<1, Col<0, RDF_F64>, Imm<0, RDF_F64>>, CmpRT<2, Col<1, RDF_F64>, Imm<1, RDF_F64>>>;   // x CMP c AND|OR y CMP d
+    reg_shape_aggs<P2, 3, 2, 2>();
+    reg<Prog<None, P2, None, SINK_STORE>>();                                                   // ... as a mask
+}
+
 static void build_registry() {
+    reg_shape_family();
     // aggregates of a plain column (AggregateFunctions::sum/min/max/count/avg)
     reg<Prog<None, D0, None, SINK_AGG>>();
     reg<Prog<None, L0, None, SINK_AGG>>();

@@ -488,3 +488,64 @@ def test_equijoin_indices(gpu, ora, dtype, how):
         el, er = ora.equijoin_indices(lk, rk, how)
         assert gl.length == el.length and gl.null_count == el.null_count and gr.null_count == er.null_count
         assert _pairs(gl, gr) == _pairs(el, er), f"join {how} dtype={dtype}"
+
+
+def test_shape_specialised_runtime_op_kernels(gpu, ora, request):
+    """Fused Calculate chains that are not in the exact catalog run on kernels specialised on the tree SHAPE with
+    runtime operators: every arithmetic pair, scalar-first and right-nested operands (swap bit), trig on top, a
+    `x CMP c [AND|OR y CMP d]` predicate in front, both sinks; results equal the oracle's unfused evaluation."""
+    from rust_dataframe_amd import lib
+    spec_mode = request.node.callspec.params["gpu"] == "spec"
+    rng = np.random.default_rng(4242)
+    lens = [4096, 1000]
+    cols = [make_chunks(rng, A.F64, lens, nf, 0, kind="unit", nonzero=True) for nf in (0.0, 0.1, 0.0)]
+    e = A.Expr()
+    a, b, c = e.col(0), e.col(1), e.col(2)
+    k1, k2 = e.scalar(1.5), e.scalar(-0.25)
+    values = {}
+    for o1 in ("add", "subtract", "multiply", "divide"):
+        values[f"cc_{o1}"] = e.op(o1, a, b)
+        values[f"ck_{o1}"] = e.op(o1, a, k1)
+        values[f"kc_{o1}"] = e.op(o1, k1, a)                                   # scalar first: swap bit
+        for o2 in ("add", "multiply", "divide"):
+            values[f"ccc_{o1}_{o2}"] = e.op(o1, e.op(o2, a, b), c)
+            values[f"c_cc_{o1}_{o2}"] = e.op(o1, c, e.op(o2, a, b))            # right-nested: swap bit on the outer op
+            values[f"cck_{o1}_{o2}"] = e.op(o1, e.op(o2, a, b), k2)
+            values[f"ckc_{o1}_{o2}"] = e.op(o1, e.op(o2, a, k1), b)
+            values[f"ckk_{o1}_{o2}"] = e.op(o1, e.op(o2, k1, a), k2)
+    for t in ("sin", "cos", "tan"):
+        values[f"T_{t}_cc"] = e.op(t, e.op("subtract", a, b))
+        values[f"T_{t}_ck"] = e.op(t, e.op("multiply", a, k1))
+    preds = {"none": -1, "cmp": e.op("gt", a, e.scalar(-0.3)), "cmp_swapped": e.op("ge", e.scalar(0.2), b),
+             "and": e.op("and", e.op("gt", a, e.scalar(-0.5)), e.op("lt", b, e.scalar(0.6))),
+             "or": e.op("or", e.op("le", a, e.scalar(-0.5)), e.op("ne", c, e.scalar(0.0)))}
+    hits = 0
+    for vn, v in values.items():
+        for pn, p in preds.items():
+            exp = ora.pipeline(e, cols, [v], p)[0]
+            got = gpu.pipeline(e, cols, [v], p)[0]
+            k = lib.last_kernel()
+            hits += k.startswith("spec_kernel<") 
+            if spec_mode:
+                assert k.startswith("spec_kernel<") or pn in ("and", "or") and vn.startswith(("ccc", "c_cc")), f"{vn}/{pn} ran on {k}"   # 5 columns do not fit
+            assert got.count == exp.count, f"{vn}/{pn}"
+            assert abs(got.sum - exp.sum) <= 1e-6 * max(abs(exp.sum), 1.0), f"{vn}/{pn}: {got.sum} vs {exp.sum}"
+            if exp.count:
+                assert np.isclose(got.min, exp.min, rtol=1e-9, atol=0) and np.isclose(got.max, exp.max, rtol=1e-9, atol=0), f"{vn}/{pn}"
+        # SINK_STORE: the value as a new column
+        outs_e = [[A.HostArray.empty_out(A.F64, n, True) for n in lens]]
+        outs_g = [[A.HostArray.empty_out(A.F64, n, True) for n in lens]]
+        ora.pipeline(e, cols, [v], -1, A.SINK_STORE, outs_e)
+        gpu.pipeline(e, cols, [v], -1, A.SINK_STORE, outs_g)
+        for ge, ee in zip(outs_g[0], outs_e[0]):
+            assert_arrays_match(ge, ee, exact=not vn.startswith("T_"), what=vn)
+    assert (hits > 0) == spec_mode
+    # the combined predicate as a mask
+    m = e.op("and", e.op("gt", a, e.scalar(-0.5)), e.op("lt", b, e.scalar(0.6)))
+    for ge, ee in zip(gpu.predicate(e, m, cols), ora.predicate(e, m, cols)):
+        assert_arrays_match(ge, ee, exact=True, what="mask")
+    # division by a zero at a valid slot is still an error on this path
+    z = [A.HostArray.from_numpy(np.array([1.0, 0.0, 2.0]))]
+    with pytest.raises(A.RdfError) as ei:
+        gpu.pipeline(e, [z, z, z], [e.op("add", e.op("divide", a, b), c)], -1)
+    assert ei.value.status == A.RDF_DIVIDE_BY_ZERO

@@ -130,7 +130,19 @@ def main():
     report("filter_sum_fast", 8.0 * n, lambda: api.pipeline(e, [[X]], [cx], gt))
     report("filter_sum_fast_validity", 8.125 * n, lambda: api.pipeline(e, [[XV]], [cx], gt))
     report("filter_sum_other_col_fast", 16.0 * n, lambda: api.pipeline(e, [[X], [Y]], [cy], gt))
-    report("filter_sum_interp", 8.0 * n, lambda: api.pipeline(e, [[X]], [e_add0], gt))
+    report("filter_sum_add0_shape_rt", 8.0 * n, lambda: api.pipeline(e, [[X]], [e_add0], gt))   # shape-specialised, runtime operators
+    sin_ab = e.op("sin", e.op("subtract", cx, cy))
+    report("sin_a_minus_b_sum_shape_rt", 16.0 * n, lambda: api.pipeline(e, [[X], [Y]], [sin_ab]))
+    abc = e.op("multiply", e.op("add", cx, cy), cz)
+    report("a_plus_b_times_c_store_shape_rt", 32.0 * n, lambda: api.pipeline(e, [[X], [Y], [Z]], [abc], -1, A.SINK_STORE, [[out_like(A.F64, n)]]))
+    and2 = e.op("and", gt, e.op("lt", cy, e.scalar(0.5)))
+    report("filter_and2_sum_shape_rt", 16.0 * n, lambda: api.pipeline(e, [[X], [Y]], [cx], and2))
+    if not args.no_spec:
+        lib.set_option("spec", 0); lib.set_option("fast_filter", 0)
+    report("filter_sum_interp", 8.0 * n, lambda: api.pipeline(e, [[X]], [e_add0], gt))            # the general evaluator on the same program
+    report("filter_and2_sum_interp", 16.0 * n, lambda: api.pipeline(e, [[X], [Y]], [cx], and2))
+    if not args.no_spec:
+        lib.set_option("spec", 1); lib.set_option("fast_filter", 1)
     report("sum_interp", 8.0 * n, lambda: api.pipeline(e, [[X]], [cx]))
     report("sum_interp_validity", 8.125 * n, lambda: api.pipeline(e, [[XV]], [cx]))
     report("c3_fma_minmax_4col", 32.0 * n, lambda: api.pipeline(e, [[X], [Y], [Z], [K]], [fma, ck]))
