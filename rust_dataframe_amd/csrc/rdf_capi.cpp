@@ -691,34 +691,36 @@ struct ShapeSigBuilder {
         while (cc.nodes[idx].kind == RDF_NODE_OP && cc.nodes[idx].op == RDF_OP_CAST && cc.infer(cc.nodes[idx].lhs) == cc.nodes[idx].dtype) idx = cc.nodes[idx].lhs;
         return idx;
     }
-    std::string leaf(int idx) {
+    // a leaf in domain `dom` (RDF_F64 or RDF_I64): a column of exactly that dtype, or a literal converted to it
+    std::string leaf(int idx, int dom) {
         const rdf_expr_node& nd = cc.nodes[idx];
+        const char tag = dom == RDF_F64 ? 'd' : 'l';
         if (nd.kind == RDF_NODE_COLUMN) {
-            if (cc.col_dtype[nd.column] != RDF_F64 || sp.ncols >= 4) { sp.ok = false; return "?"; }
+            if (cc.col_dtype[nd.column] != dom || sp.ncols >= 4) { sp.ok = false; return "?"; }
             sp.col_map[sp.ncols] = nd.column;
-            return std::string("c") + char('0' + sp.ncols++) + 'd';
+            return std::string("c") + char('0' + sp.ncols++) + tag;
         }
         if (nd.dtype == RDF_NULLTYPE || sp.nimm >= 4) { sp.ok = false; return "?"; }
-        sp.imm[sp.nimm] = cc.imm_for(nd, RDF_F64);
-        return std::string("k") + char('0' + sp.nimm++) + 'd';
+        sp.imm[sp.nimm] = cc.imm_for(nd, dom);
+        return std::string("k") + char('0' + sp.nimm++) + tag;
     }
-    std::string node(int idx) {
+    std::string node(int idx, int dom) {
         if (!sp.ok) return "?";
         idx = strip(idx);
         const rdf_expr_node& nd = cc.nodes[idx];
-        if (nd.kind != RDF_NODE_OP) return leaf(idx);
+        if (nd.kind != RDF_NODE_OP) return leaf(idx, dom);
         if (nslots >= 8) { sp.ok = false; return "?"; }
         const int op = nd.op;
         if (op == RDF_OP_SIN || op == RDF_OP_COS || op == RDF_OP_TAN) {
-            if (cc.infer(nd.lhs) != RDF_F64) { sp.ok = false; return "?"; }
+            if (cc.infer(nd.lhs) != RDF_F64 || dom != RDF_F64) { sp.ok = false; return "?"; }
             const int slot = nslots++;
             rt[slot] = op;
-            return "[T" + std::to_string(slot) + " " + node(nd.lhs) + "]";
+            return "[T" + std::to_string(slot) + " " + node(nd.lhs, dom) + "]";
         }
         const bool arith = op >= RDF_OP_ADD && op <= RDF_OP_DIV, cmp = op_is_cmp(op), logic = op == RDF_OP_AND || op == RDF_OP_OR;
         if (!(arith || cmp || logic)) { sp.ok = false; return "?"; }
         int l = strip(nd.lhs), r = strip(nd.rhs);
-        if (arith && (cc.infer(l) != RDF_F64 || cc.infer(r) != RDF_F64)) { sp.ok = false; return "?"; }
+        if (arith && (cc.infer(idx) != dom || cc.infer(l) != dom || cc.infer(r) != dom)) { sp.ok = false; return "?"; }
         if (cmp && !((is_column(l) && is_scalar(r)) || (is_scalar(l) && is_column(r)))) { sp.ok = false; return "?"; }
         const bool lleaf = cc.nodes[l].kind != RDF_NODE_OP, rleaf = cc.nodes[r].kind != RDF_NODE_OP;
         bool swap = false;
@@ -730,16 +732,28 @@ struct ShapeSigBuilder {
         const int slot = nslots++;
         rt[slot] = op | (swap ? 0x100 : 0);
         if (swap) std::swap(l, r);
-        const std::string a = node(l), b = node(r);
+        std::string a, b;
+        if (cmp) {   // the column keeps its own dtype (f64 or i64), the literal is compared in f64 (src/expression.rs:844-845)
+            const int cdt = cc.col_dtype[cc.nodes[l].column];
+            if (cdt != RDF_F64 && cdt != RDF_I64) { sp.ok = false; return "?"; }
+            if (pred_dt >= 0 && pred_dt != cdt) { sp.ok = false; return "?"; }
+            pred_dt = cdt;
+            a = leaf(l, cdt);
+            b = leaf(r, RDF_F64);
+        } else { a = node(l, dom); b = node(r, dom); }
         return std::string("(") + (arith ? 'A' : cmp ? 'C' : 'G') + std::to_string(slot) + " " + a + " " + b + ")";
     }
+    int pred_dt = -1;
 };
 bool build_shape_plan(Compiler& cc, int filter_root, int nvalues, const int* value_roots, int sink, SpecPlan& sp, int* rt) {
     if (nvalues != 1) return false;
     ShapeSigBuilder b(cc, sp, rt);
+    const int vdt = cc.infer(value_roots[0]);
+    const int dom = vdt == RDF_BOOL ? RDF_F64 : vdt;   // a predicate as the value (mask output): its columns pick their own dtype
+    if (dom != RDF_F64 && dom != RDF_I64) return false;
     std::string s = "P:";
-    s += filter_root >= 0 ? b.node(filter_root) : std::string("-");
-    s += ";V:" + b.node(value_roots[0]) + ";-;S:" + std::to_string(sink == RDF_SINK_AGG ? SINK_AGG : SINK_STORE);
+    s += filter_root >= 0 ? b.node(filter_root, RDF_F64) : std::string("-");
+    s += ";V:" + b.node(value_roots[0], dom) + ";-;S:" + std::to_string(sink == RDF_SINK_AGG ? SINK_AGG : SINK_STORE);
     if (!sp.ok || b.nslots == 0) return false;
     sp.width = 8;
     sp.sig = s;

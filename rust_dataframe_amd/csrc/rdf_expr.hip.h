@@ -214,25 +214,35 @@ struct Cast {
 // arguments (c.rt[SLOT] = rdf_op | swap << 8), so a fused Calculate chain that is not in the exact catalog still runs
 // as straight-line code: the switch below is a handful of scalar compares per row, not an interpreter.
 template <int SLOT, class A, class B>
-struct ArithRT {   // add / subtract / multiply / divide
-    static_assert(A::dt == RDF_F64 && B::dt == RDF_F64, "runtime-op arithmetic is instantiated for f64");
-    static constexpr int dt = RDF_F64;
+struct ArithRT {   // add / subtract / multiply / divide on f64 or (wrapping) i64
+    static_assert(A::dt == B::dt && (A::dt == RDF_F64 || A::dt == RDF_I64), "runtime-op arithmetic is instantiated for f64 and i64");
+    static constexpr int dt = A::dt;
     static constexpr int ncols = A::ncols > B::ncols ? A::ncols : B::ncols;
     static constexpr int width = merge_width(A::width, B::width);
     template <int k> static constexpr int colw() { return cmax(A::template colw<k>(), B::template colw<k>()); }
-    using T = double;
+    using T = typename CType<dt>::T;
     template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c) & B::vmask(c); }
-    template <int r, class C> static __device__ __forceinline__ double eval(C& c) {
-        const double x0 = A::template eval<r>(c), y0 = B::template eval<r>(c);
+    template <int r, class C> static __device__ __forceinline__ T eval(C& c) {
+        const T x0 = A::template eval<r>(c), y0 = B::template eval<r>(c);
         const int op = c.rt[SLOT] & 0xFF;
         const bool sw = (c.rt[SLOT] >> 8) & 1;
-        const double x = sw ? y0 : x0, y = sw ? x0 : y0;
-        if (op == RDF_OP_ADD) return x + y;
-        if (op == RDF_OP_SUB) return x - y;
-        if (op == RDF_OP_MUL) return x * y;
-        const bool z = y == 0.0;
-        if (z && ((vmask(c) & c.inr) >> r & 1)) c.err |= 1u;
-        return z ? 0.0 : x / y;
+        const T x = sw ? y0 : x0, y = sw ? x0 : y0;
+        if constexpr (dt == RDF_F64) {
+            if (op == RDF_OP_ADD) return x + y;
+            if (op == RDF_OP_SUB) return x - y;
+            if (op == RDF_OP_MUL) return x * y;
+            const bool z = y == 0.0;
+            if (z && ((vmask(c) & c.inr) >> r & 1)) c.err |= 1u;
+            return z ? 0.0 : x / y;
+        } else {
+            if (op == RDF_OP_ADD) return (int64_t)((uint64_t)x + (uint64_t)y);
+            if (op == RDF_OP_SUB) return (int64_t)((uint64_t)x - (uint64_t)y);
+            if (op == RDF_OP_MUL) return (int64_t)((uint64_t)x * (uint64_t)y);
+            const bool z = y == 0;
+            if (z && ((vmask(c) & c.inr) >> r & 1)) c.err |= 1u;
+            if (z) return 0;
+            return y == -1 ? (int64_t)((uint64_t)0 - (uint64_t)x) : x / y;   // MIN / -1 wraps
+        }
     }
     static std::string sig() { return "(A" + std::to_string(SLOT) + " " + A::sig() + " " + B::sig() + ")"; }
 };

@@ -379,9 +379,9 @@ template <int OP> static void reg_unary_f64() {
 // ---- shape-specialised kernels with runtime operators (rdf_expr.hip.h *RT nodes).  Every leaf OCCURRENCE has its own
 // canonical column / literal slot (the host maps two slots to the same column when a program reuses one: the second
 // load hits in cache), operator slots are numbered in pre-order, predicate first.
-template <int S, int C, int K> struct Shapes {
-    template <int I> using Cd = Col<I, RDF_F64>;
-    template <int I> using Kd = Imm<I, RDF_F64>;
+template <int S, int C, int K, int DT> struct Shapes {
+    template <int I> using Cd = Col<I, DT>;
+    template <int I> using Kd = Imm<I, DT>;
     using c = Cd<C>;
     using cc = ArithRT<S, Cd<C>, Cd<C + 1>>;
     using ck = ArithRT<S, Cd<C>, Kd<K>>;
@@ -396,30 +396,38 @@ template <int S, int C, int K> struct Shapes {
 template <class PRED, class V> static void reg_shape_agg() {
     if constexpr ((PRED::ncols > V::ncols ? PRED::ncols : V::ncols) <= 4) reg<Prog<PRED, V, None, SINK_AGG>>();
 }
-template <class PRED, int S, int C, int K> static void reg_shape_aggs() {
-    using H = Shapes<S, C, K>;
+template <class PRED, int S, int C, int K, int DT> static void reg_shape_aggs() {
+    using H = Shapes<S, C, K, DT>;
     reg_shape_agg<PRED, typename H::c>();
     reg_shape_agg<PRED, typename H::cc>(); reg_shape_agg<PRED, typename H::ck>();
     reg_shape_agg<PRED, typename H::ccc>(); reg_shape_agg<PRED, typename H::cck>();
     reg_shape_agg<PRED, typename H::ckc>(); reg_shape_agg<PRED, typename H::ckk>();
-    reg_shape_agg<PRED, typename H::Tc>(); reg_shape_agg<PRED, typename H::Tcc>(); reg_shape_agg<PRED, typename H::Tck>();
+    if constexpr (DT == RDF_F64) { reg_shape_agg<PRED, typename H::Tc>(); reg_shape_agg<PRED, typename H::Tcc>(); reg_shape_agg<PRED, typename H::Tck>(); }
 }
-static void reg_shape_family() {
-    using H0 = Shapes<0, 0, 0>;
-    reg<Prog<None, H0::cc, None, SINK_STORE>>(); reg<Prog<None, H0::ck, None, SINK_STORE>>();
-    reg<Prog<None, H0::ccc, None, SINK_STORE>>(); reg<Prog<None, H0::cck, None, SINK_STORE>>();
-    reg<Prog<None, H0::ckc, None, SINK_STORE>>(); reg<Prog<None, H0::ckk, None, SINK_STORE>>();
-    reg<Prog<None, H0::Tc, None, SINK_STORE>>(); reg<Prog<None, H0::Tcc, None, SINK_STORE>>(); reg<Prog<None, H0::Tck, None, SINK_STORE>>();
-    reg_shape_aggs<None, 0, 0, 0>();
-    using P1 = CmpRT<0, Col<0, RDF_F64>, Imm<0, RDF_F64>>;                                   // x CMP c
-    reg_shape_aggs<P1, 1, 1, 1>();
-    using P2 = LogicRT<0, CmpRT<1, Col<0, RDF_F64>, Imm<0, RDF_F64>>, CmpRT<2, Col<1, RDF_F64>, Imm<1, RDF_F64>>>;   // x CMP c AND|OR y CMP d
-    reg_shape_aggs<P2, 3, 2, 2>();
-    reg<Prog<None, P2, None, SINK_STORE>>();                                                   // ... as a mask
+// DT = dtype of the value expression's columns and literals; PDT = dtype of the predicate's columns (compared in f64)
+template <int DT, int PDT> static void reg_shape_family() {
+    using H0 = Shapes<0, 0, 0, DT>;
+    if constexpr (DT == PDT) {
+        reg<Prog<None, typename H0::cc, None, SINK_STORE>>(); reg<Prog<None, typename H0::ck, None, SINK_STORE>>();
+        reg<Prog<None, typename H0::ccc, None, SINK_STORE>>(); reg<Prog<None, typename H0::cck, None, SINK_STORE>>();
+        reg<Prog<None, typename H0::ckc, None, SINK_STORE>>(); reg<Prog<None, typename H0::ckk, None, SINK_STORE>>();
+        if constexpr (DT == RDF_F64) {
+            reg<Prog<None, typename H0::Tc, None, SINK_STORE>>(); reg<Prog<None, typename H0::Tcc, None, SINK_STORE>>(); reg<Prog<None, typename H0::Tck, None, SINK_STORE>>();
+        }
+        reg_shape_aggs<None, 0, 0, 0, DT>();
+    }
+    using P1 = CmpRT<0, Col<0, PDT>, Imm<0, RDF_F64>>;                                   // x CMP c
+    reg_shape_aggs<P1, 1, 1, 1, DT>();
+    using P2 = LogicRT<0, CmpRT<1, Col<0, PDT>, Imm<0, RDF_F64>>, CmpRT<2, Col<1, PDT>, Imm<1, RDF_F64>>>;   // x CMP c AND|OR y CMP d
+    reg_shape_aggs<P2, 3, 2, 2, DT>();
+    if constexpr (DT == PDT) reg<Prog<None, P2, None, SINK_STORE>>();                                     // ... as a mask
 }
 
 static void build_registry() {
-    reg_shape_family();
+    reg_shape_family<RDF_F64, RDF_F64>();
+    reg_shape_family<RDF_I64, RDF_I64>();
+    reg_shape_family<RDF_F64, RDF_I64>();   // predicate on an i64 key, f64 measures
+    reg_shape_family<RDF_I64, RDF_F64>();
     // aggregates of a plain column (AggregateFunctions::sum/min/max/count/avg)
     reg<Prog<None, D0, None, SINK_AGG>>();
     reg<Prog<None, L0, None, SINK_AGG>>();
