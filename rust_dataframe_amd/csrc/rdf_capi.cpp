@@ -1795,6 +1795,29 @@ rdf_status rdf_take(const rdf_array* chunks, int64_t nchunks, const rdf_array* i
 
 // ---------------------------------------------------------------- sort
 
+namespace {
+// bit_stats protocol of sort_keys_kernel: [0] starts ~0 (min), [1] starts 0 (max)
+rdf_status sort_stats_reset(uint64_t* d_stats) {
+    HIP_TRY(hipMemsetAsync(d_stats, 0xFF, 8, g_ctx.stream));
+    HIP_TRY(hipMemsetAsync(d_stats + 1, 0x00, 8, g_ctx.stream));
+    return RDF_OK;
+}
+// -> bias (smallest non-null key) and the number of low bytes of (key - bias) that can differ between two rows
+rdf_status sort_key_range(const uint64_t* d_stats, size_t pin_off, uint64_t* bias, int* nbytes) {
+    Ctx& ctx = g_ctx;
+    RDF_TRY(pinned_reserve(pin_off + 64));
+    HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, d_stats, 16, hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    uint64_t st[2];
+    memcpy(st, ctx.pinned + pin_off, 16);
+    *bias = 0; *nbytes = 0;
+    if (st[0] > st[1]) return RDF_OK;   // no non-null key at all
+    *bias = st[0];
+    for (uint64_t range = st[1] - st[0]; range; range >>= 8) ++*nbytes;
+    return RDF_OK;
+}
+}  // namespace
+
 rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nchunks, const rdf_sort_options* opts,
                                rdf_out* out_indices) {
     if (ncols < 1 || !cols) return fail(RDF_COMPUTE_ERROR, "Sort criteria cannot be empty");  // src/dataframe.rs:195-199
@@ -1842,6 +1865,9 @@ rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
     const int64_t sgrid = sort_grid(ntiles);
     RDF_TRY(arena_alloc((size_t)(256 * sgrid + 1) * 8, &ph0));
     RDF_TRY(arena_alloc((size_t)(256 * sgrid + 1 + scan_scratch_words(256 * sgrid)) * 8, &ph1));
+    void* pstats;
+    RDF_TRY(arena_alloc(64, &pstats));
+    uint64_t* d_stats = (uint64_t*)pstats;
     uint64_t* keys[2] = {(uint64_t*)pk0, (uint64_t*)pk1};
     uint32_t* idxb[2] = {(uint32_t*)pi0, (uint32_t*)pi1};
     int kcur = 0;               // keys[kcur] holds the current keys
@@ -1864,11 +1890,20 @@ rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
         ka.nullflags = has_nulls ? (uint8_t*)pnf : nullptr;
         ka.dtype = dt;
         ka.descending = opts ? opts[k].descending : 0;
+        ka.bit_stats = d_stats;
+        RDF_TRY(sort_stats_reset(d_stats));
         HIP_TRY(launch_sort_keys(ka, ctx.stream));
+        // radix passes cover only the bytes of (max key - min key): a 32-bit range stored as i64 takes 4 passes, a dictionary code 1
+        uint64_t bias = 0;
+        int need = 0;
+        RDF_TRY(sort_key_range(d_stats, pin_off, &bias, &need));
+        if (k == 0 && idx_cur == nullptr && need == 0 && !has_nulls) need = 1;   // all keys equal: one pass still writes the identity order
         const int npass = dtype_size(dt) + (has_nulls ? 1 : 0);
         for (int p = 0; p < npass; ++p) {
+            if (p < dtype_size(dt) && p >= need) continue;
             SortPassArgs pa;
             memset(&pa, 0, sizeof pa);
+            pa.bias = bias;
             pa.keys_in = keys[kcur];
             pa.idx_in = idx_cur;
             pa.keys_out = keys[kcur ^ 1];
@@ -1919,14 +1954,20 @@ rdf_status sort_buffers_alloc(int64_t n, SortBuffers& b) {
     return RDF_OK;
 }
 // keys[0] holds the unsorted key bits (identity order).  On return keys[*kcur] / idx[*icur] are sorted.
-rdf_status radix_sort_rows(const SortBuffers& b, int64_t n, int width, bool has_nulls, int* kcur_out, int* icur_out) {
+rdf_status radix_sort_rows(const SortBuffers& b, int64_t n, int width, bool has_nulls, int* kcur_out, int* icur_out, const uint64_t* d_stats, size_t pin_off) {
     Ctx& ctx = g_ctx;
     int kcur = 0, icur = 1;
     const uint32_t* idx_cur = nullptr;
     const int npass = width + (has_nulls ? 1 : 0);
+    uint64_t bias = 0;
+    int need = 0;
+    RDF_TRY(sort_key_range(d_stats, pin_off, &bias, &need));
+    if (need == 0 && !has_nulls) need = 1;   // all keys equal: one pass still writes the identity order
     for (int p = 0; p < npass; ++p) {
+        if (p < width && p >= need) continue;
         SortPassArgs pa;
         memset(&pa, 0, sizeof pa);
+        pa.bias = bias;
         pa.keys_in = b.keys[kcur];
         pa.idx_in = idx_cur;
         pa.keys_out = b.keys[kcur ^ 1];
@@ -2022,9 +2063,13 @@ rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks
         ka.keys = sb.keys[0];
         ka.nullflags = bnulls ? (uint8_t*)sb.nullflags : nullptr;
         ka.dtype = dt;
+        void* pstats;
+        RDF_TRY(arena_alloc(64, &pstats));
+        ka.bit_stats = (uint64_t*)pstats;
+        RDF_TRY(sort_stats_reset(ka.bit_stats));
         HIP_TRY(launch_sort_keys(ka, ctx.stream));
         if (bnulls) HIP_TRY(launch_count_bytes((const uint8_t*)sb.nullflags, nb, d_cnt, ctx.stream));
-        RDF_TRY(radix_sort_rows(sb, nb, dtype_size(dt), bnulls, &kcur, &icur));
+        RDF_TRY(radix_sort_rows(sb, nb, dtype_size(dt), bnulls, &kcur, &icur, ka.bit_stats, pin_off));
     }
     // probe side: key bits + null flags in row order
     void *ppk, *ppn, *pcounts, *poffs;

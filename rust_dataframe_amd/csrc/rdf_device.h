@@ -165,6 +165,7 @@ struct SortKeyArgs {                                 // key[i] = order-preservin
     const uint32_t*    idx;                          // current order (nullptr = identity)
     uint64_t*          keys;                         // out
     uint8_t*           nullflags;                    // out (per ORIGINAL row), nullptr when the column has no bitmap
+    uint64_t*          bit_stats;                    // [2] in/out: min and max over the non-null keys written ([0] starts ~0, [1] starts 0)
     int32_t            dtype, descending;
 };
 struct SortPassArgs {
@@ -174,7 +175,8 @@ struct SortPassArgs {
     const uint8_t*  nullflags;                       // digit source of the nulls-last pass (indexed by row), else nullptr
     int64_t*        hist;                            // [256 * sort_grid] digit-major per-block counts, then their exclusive scan
     int64_t         n, ntiles;
-    int32_t         shift;                           // bit offset of this pass's digit in the key
+    int32_t         shift;                           // bit offset of this pass's digit in (key - bias)
+    uint64_t        bias;                            // smallest key of the column: digits are taken from key - bias, so a narrow key RANGE needs few passes
 };
 
 // Equi-join indices (calc_equijoin_indices, src/functions/join.rs:19-137): sort the build side by key, binary-search

@@ -426,6 +426,7 @@ __device__ __forceinline__ uint64_t sort_key_bits(const DevChunkCol& cc, int dt,
 }
 
 __global__ __launch_bounds__(kBlock) void sort_keys_kernel(const SortKeyArgs a, uint64_t width_mask) {
+    uint64_t kmin = ~0ull, kmax = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
         const int64_t row = a.idx ? (int64_t)a.idx[i] : i;
         const int64_t c = a.nchunks == 1 ? 0 : find_chunk(a.chunk_row_start, a.nchunks, row);
@@ -435,14 +436,24 @@ __global__ __launch_bounds__(kBlock) void sort_keys_kernel(const SortKeyArgs a, 
         if (a.descending) k = ~k & width_mask;
         bool isnull = false;
         if (cc.validity) isnull = !((cc.validity[e >> 3] >> (e & 7)) & 1);
-        a.keys[i] = isnull ? 0 : k;  // nulls are ordered by the nulls-last pass; equal keys keep them stable
+        const uint64_t kw = isnull ? 0 : k;  // nulls are ordered by the nulls-last pass; equal keys keep them stable
+        a.keys[i] = kw;
+        if (!isnull) { kmin = kw < kmin ? kw : kmin; kmax = kw > kmax ? kw : kmax; }
         if (a.nullflags) a.nullflags[row] = isnull;
+    }
+    if (a.bit_stats) {   // key range of the column: the radix passes work on key - min, so only the bytes of (max - min) need a pass
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint64_t x = shfl_xor64(kmin, m), y = shfl_xor64(kmax, m);
+            kmin = x < kmin ? x : kmin; kmax = y > kmax ? y : kmax;
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin((unsigned long long*)&a.bit_stats[0], (unsigned long long)kmin); atomicMax((unsigned long long*)&a.bit_stats[1], (unsigned long long)kmax); }
     }
 }
 
 __device__ __forceinline__ int sort_digit(const SortPassArgs& a, int64_t i) {
     if (a.nullflags) return a.nullflags[a.idx_in ? (int64_t)a.idx_in[i] : i];
-    return (int)((a.keys_in[i] >> a.shift) & 255);
+    return (int)(((a.keys_in[i] - a.bias) >> a.shift) & 255);
 }
 
 // Block b owns the contiguous tiles [b*tpb, (b+1)*tpb): one histogram row per BLOCK (256 x gridDim entries
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs
             key[j] = in ? a.keys_in[i] : 0;
             if (PAY64) idx[j] = in ? a.pay_in[i] : 0;
             else idx[j] = in ? (a.idx_in ? a.idx_in[i] : (uint32_t)i) : 0;
-            const int d = in ? ((!PAY64 && a.nullflags) ? (int)a.nullflags[idx[j]] : (int)((key[j] >> a.shift) & 255)) : 0;
+            const int d = in ? ((!PAY64 && a.nullflags) ? (int)a.nullflags[idx[j]] : (int)(((key[j] - a.bias) >> a.shift) & 255)) : 0;
             digit[j] = d;
             uint64_t peers = __ballot(in);
 #pragma unroll
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs
         for (int t = threadIdx.x; t < count; t += kBlock) {
             const uint64_t kk = lkeys[t];
             const auto ii = lidx[t];
-            const int d = (!PAY64 && a.nullflags) ? (int)a.nullflags[ii] : (int)((kk >> a.shift) & 255);
+            const int d = (!PAY64 && a.nullflags) ? (int)a.nullflags[ii] : (int)(((kk - a.bias) >> a.shift) & 255);
             const int64_t dst = gbase[d] + (t - dbase[d]);
             a.keys_out[dst] = kk;
             if (PAY64) a.pay_out[dst] = ii; else a.idx_out[dst] = (uint32_t)ii;

@@ -597,3 +597,31 @@ def test_shape_specialised_kernels_i64_and_mixed_predicates(gpu, ora, request):
     got = gpu.pipeline(e, [mn, m1, m1], [e.op("add", e.op("divide", k, l), e.scalar(0, A.I64))], -1)[0]
     exp = ora.pipeline(e, [mn, m1, m1], [e.op("add", e.op("divide", k, l), e.scalar(0, A.I64))], -1)[0]
     assert (got.sum, got.min, got.max) == (exp.sum, exp.min, exp.max)
+
+
+def test_sort_skips_constant_key_bytes(gpu, ora):
+    """Radix passes cover only the bytes of (max key - min key): constant keys (no pass needed at all), a 1-byte range
+    inside an i64, sparse byte patterns, negative small ranges (sign extension is not a range), two-valued floats, with
+    no / some / only NULLs — always the oracle's order."""
+    rng = np.random.default_rng(77)
+    n = 10_000
+    cases = {
+        "all_equal": np.full(n, 123456789, dtype=np.int64),
+        "one_byte": rng.integers(0, 200, n).astype(np.int64),
+        "bytes_2_and_5": (rng.integers(0, 256, n).astype(np.int64) << 16) | (rng.integers(0, 256, n).astype(np.int64) << 40),
+        "negative_small": -rng.integers(0, 1000, n).astype(np.int64),
+        "f64_two_values": rng.choice(np.array([1.5, -2.25]), n),
+    }
+    for name, v in cases.items():
+        for valid in (None, rng.uniform(size=n) > 0.3, np.zeros(n, dtype=bool)):
+            for desc in (False, True):
+                col = [A.HostArray.from_numpy(v[:6000], valid=None if valid is None else valid[:6000]),
+                       A.HostArray.from_numpy(v[6000:], valid=None if valid is None else valid[6000:])]
+                got = gpu.sort_to_indices([col], [desc]).to_numpy()
+                exp = ora.sort_to_indices([col], [desc]).to_numpy()
+                assert np.array_equal(got, exp), f"{name} desc={desc} nulls={'none' if valid is None else int((~valid).sum())}"
+    # two columns where the more significant one is constant
+    c0 = [A.HostArray.from_numpy(np.full(n, 7, dtype=np.int32))]
+    c1 = [A.HostArray.from_numpy(rng.integers(-50, 50, n).astype(np.int16))]
+    for cols in ([c0, c1], [c1, c0]):
+        assert np.array_equal(gpu.sort_to_indices(cols, [False, True]).to_numpy(), ora.sort_to_indices(cols, [False, True]).to_numpy())

@@ -182,7 +182,11 @@ def main():
     ns = min(n, 50_000_000)
     KS = arr(k, A.I64, ns)
     oi = out_like(A.U32, ns)
-    report("sort_to_indices_i64", 8.0 * ns, lambda: api.sort_to_indices([[KS]], [False], oi))
+    report("sort_to_indices_i64", 8.0 * ns, lambda: api.sort_to_indices([[KS]], [False], oi))   # keys in [-2^31, 2^31): 4 varying bytes + sign
+    kw = dev_i64(ns, 9, -2 ** 62, 2 ** 62)
+    report("sort_to_indices_i64_full_range", 8.0 * ns, lambda: api.sort_to_indices([[arr(kw, A.I64, ns)]], [False], oi))
+    kd = dev_i64(ns, 10, 0, 200)
+    report("sort_to_indices_i64_dictionary_codes", 8.0 * ns, lambda: api.sort_to_indices([[arr(kd, A.I64, ns)]], [False], oi))
     # hash GROUP BY key -> sum(val): 1e6 groups (config C4's per-GPU leg) and 1e3 groups (contended)
     for ng in (1_000_000, 1_000):
         kk = dev_i64(n, 7, 0, ng)
