@@ -468,11 +468,18 @@ class Api:
     # ---- join (calc_equijoin_indices)
     JOIN_TYPES = {"left": 0, "right": 1, "inner": 2, "full": 3}
 
-    def equijoin_indices(self, left_keys: Sequence, right_keys: Sequence, how: str):
-        """-> (left_indices, right_indices): UInt32 arrays with None where a side has no partner."""
+    def equijoin_indices(self, left_keys: Sequence, right_keys: Sequence, how: str, outs=None):
+        """-> (left_indices, right_indices): UInt32 arrays with None where a side has no partner.  `outs` = caller-allocated
+        (left, right) outputs (device-resident runs): the sizing call is skipped."""
         jt = self.JOIN_TYPES[how]
         rows = C.c_int64(0)
         lk, rk = _flat([left_keys], len(left_keys)), _flat([right_keys], len(right_keys))
+        if outs is not None:
+            ol, orr = outs
+            cl, cr = (rdf_out * 1)(ol.out_struct()), (rdf_out * 1)(orr.out_struct())
+            self._check(self._fn("equijoin_indices")(lk, C.c_int64(len(left_keys)), rk, C.c_int64(len(right_keys)), C.c_int32(jt), cl, cr, C.byref(rows)))
+            ol.length = orr.length = rows.value
+            return ol, orr
         self._check(self._fn("equijoin_indices")(lk, C.c_int64(len(left_keys)), rk, C.c_int64(len(right_keys)), C.c_int32(jt), None, None, C.byref(rows)))
         ol, orr = HostArray.empty_out(U32, rows.value, True), HostArray.empty_out(U32, rows.value, True)
         cl, cr = (rdf_out * 1)(ol.out_struct()), (rdf_out * 1)(orr.out_struct())

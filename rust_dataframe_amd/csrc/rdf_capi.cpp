@@ -1803,7 +1803,7 @@ rdf_status sort_stats_reset(uint64_t* d_stats) {
     return RDF_OK;
 }
 // -> bias (smallest non-null key) and the number of low bytes of (key - bias) that can differ between two rows
-rdf_status sort_key_range(const uint64_t* d_stats, size_t pin_off, uint64_t* bias, int* nbytes) {
+rdf_status sort_key_range(const uint64_t* d_stats, size_t pin_off, uint64_t* bias, int* nbytes, uint64_t* kmax_out = nullptr) {
     Ctx& ctx = g_ctx;
     RDF_TRY(pinned_reserve(pin_off + 64));
     HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, d_stats, 16, hipMemcpyDeviceToHost, ctx.stream));
@@ -1811,8 +1811,10 @@ rdf_status sort_key_range(const uint64_t* d_stats, size_t pin_off, uint64_t* bia
     uint64_t st[2];
     memcpy(st, ctx.pinned + pin_off, 16);
     *bias = 0; *nbytes = 0;
-    if (st[0] > st[1]) return RDF_OK;   // no non-null key at all
+    if (kmax_out) *kmax_out = 0;
+    if (st[0] > st[1]) { *bias = 1; return RDF_OK; }   // no non-null key at all: [bias, kmax] = [1, 0] is the empty range
     *bias = st[0];
+    if (kmax_out) *kmax_out = st[1];
     for (uint64_t range = st[1] - st[0]; range; range >>= 8) ++*nbytes;
     return RDF_OK;
 }
@@ -1954,14 +1956,16 @@ rdf_status sort_buffers_alloc(int64_t n, SortBuffers& b) {
     return RDF_OK;
 }
 // keys[0] holds the unsorted key bits (identity order).  On return keys[*kcur] / idx[*icur] are sorted.
-rdf_status radix_sort_rows(const SortBuffers& b, int64_t n, int width, bool has_nulls, int* kcur_out, int* icur_out, const uint64_t* d_stats, size_t pin_off) {
+rdf_status radix_sort_rows(const SortBuffers& b, int64_t n, int width, bool has_nulls, int* kcur_out, int* icur_out, const uint64_t* d_stats, size_t pin_off,
+                           uint64_t* kmin_out, uint64_t* kmax_out) {
     Ctx& ctx = g_ctx;
     int kcur = 0, icur = 1;
     const uint32_t* idx_cur = nullptr;
     const int npass = width + (has_nulls ? 1 : 0);
     uint64_t bias = 0;
     int need = 0;
-    RDF_TRY(sort_key_range(d_stats, pin_off, &bias, &need));
+    RDF_TRY(sort_key_range(d_stats, pin_off, &bias, &need, kmax_out));
+    *kmin_out = bias;
     if (need == 0 && !has_nulls) need = 1;   // all keys equal: one pass still writes the identity order
     for (int p = 0; p < npass; ++p) {
         if (p < width && p >= need) continue;
@@ -2053,6 +2057,7 @@ rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 64, ctx.stream));
     KernelTimer kt;
     int kcur = 0, icur = 0;
+    uint64_t bkmin = 1, bkmax = 0;   // key range of the non-NULL build keys ([1, 0] = none)
     if (nb > 0) {
         SortKeyArgs ka;
         memset(&ka, 0, sizeof ka);
@@ -2069,7 +2074,7 @@ rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks
         RDF_TRY(sort_stats_reset(ka.bit_stats));
         HIP_TRY(launch_sort_keys(ka, ctx.stream));
         if (bnulls) HIP_TRY(launch_count_bytes((const uint8_t*)sb.nullflags, nb, d_cnt, ctx.stream));
-        RDF_TRY(radix_sort_rows(sb, nb, dtype_size(dt), bnulls, &kcur, &icur, ka.bit_stats, pin_off));
+        RDF_TRY(radix_sort_rows(sb, nb, dtype_size(dt), bnulls, &kcur, &icur, ka.bit_stats, pin_off, &bkmin, &bkmax));
     }
     // probe side: key bits + null flags in row order
     void *ppk, *ppn, *pcounts, *poffs;
@@ -2098,8 +2103,26 @@ rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks
 
     void* pmatched = nullptr;
     if (full) { RDF_TRY(arena_alloc((size_t)((nb + 31) / 32 + 1) * 4, &pmatched)); HIP_TRY(hipMemsetAsync(pmatched, 0, (size_t)((nb + 31) / 32 + 1) * 4, ctx.stream)); }
+    // bucket index over the sorted build keys: about one bucket per build row, on the top bits of (key - min)
+    int64_t nbuckets = 1;
+    while (nbuckets < nrv && nbuckets < ((int64_t)1 << 24)) nbuckets <<= 1;
+    int bshift = 0;
+    if (bkmax >= bkmin) while (((bkmax - bkmin) >> bshift) >= (uint64_t)nbuckets) ++bshift;
+    void *pbuckets, *pfirst;
+    RDF_TRY(arena_alloc((size_t)nbuckets * 8, &pbuckets));
+    RDF_TRY(arena_alloc((size_t)(np > 0 ? np : 1) * 4, &pfirst));
+    HIP_TRY(hipMemsetAsync(pbuckets, 0, (size_t)nbuckets * 8, ctx.stream));
+    if (nrv > 0) {
+        JoinBucketArgs ba;
+        memset(&ba, 0, sizeof ba);
+        ba.rkeys = sb.keys[kcur]; ba.nrv = nrv; ba.buckets = (uint32_t*)pbuckets; ba.kmin = bkmin; ba.bucket_shift = bshift;
+        HIP_TRY(launch_join_buckets(ba, ctx.stream));
+    }
     JoinProbeArgs ja;
     memset(&ja, 0, sizeof ja);
+    ja.buckets = (const uint32_t*)pbuckets;
+    ja.kmin = bkmin; ja.kmax = bkmax; ja.bucket_shift = bshift;
+    ja.first = (uint32_t*)pfirst;
     ja.lkeys = (const uint64_t*)ppk;
     ja.lnull = pnulls ? (const uint8_t*)ppn : nullptr;
     ja.rkeys = sb.keys[kcur];

@@ -194,7 +194,14 @@ struct JoinProbeArgs {
     uint32_t*       out_build_validity;   // bitmap words preset to ones; cleared where the build side is NULL
     uint32_t*       matched;   // [ceil(nrv / 32)] sorted build positions that found a partner (FULL), or nullptr
     unsigned long long* unmatched;  // count phase: probe rows without a partner
+    // bucket index over the sorted build keys: bucket b = (key - kmin) >> bucket_shift holds the sorted positions
+    // [buckets[2b], buckets[2b + 1]) — a probe is one table read plus a search among the (usually 1-2) keys of its bucket
+    const uint32_t* buckets;   // [2 * nbuckets], zero = empty
+    uint64_t        kmin, kmax;
+    int32_t         bucket_shift, pad;
+    uint32_t*       first;     // [nl] count phase out / write phase in: first sorted build position of the row's partners, ~0 = none
 };
+struct JoinBucketArgs { const uint64_t* rkeys; int64_t nrv; uint32_t* buckets; uint64_t kmin; int32_t bucket_shift; };
 struct JoinAppendArgs {        // FULL: build rows nobody matched (and NULL-key build rows) with a NULL probe index
     const uint32_t* ridx; const uint32_t* matched;
     int64_t         nr, nrv;
@@ -330,6 +337,7 @@ int  sort_grid(int64_t ntiles);
 hipError_t launch_sort_keys(const SortKeyArgs& a, hipStream_t s);
 hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s);
+hipError_t launch_join_buckets(const JoinBucketArgs& a, hipStream_t s);
 hipError_t launch_join_count(const JoinProbeArgs& a, hipStream_t s);
 hipError_t launch_join_write(const JoinProbeArgs& a, hipStream_t s);
 hipError_t launch_join_append(const JoinAppendArgs& a, hipStream_t s);

@@ -564,14 +564,26 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs
 // kernels above), every probe row finds its partners' range with two binary searches, and the pairs are
 // written at offsets from an exclusive scan of the per-row match counts.  NULL keys never match.
 
+__global__ __launch_bounds__(kBlock) void join_buckets_kernel(const JoinBucketArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.nrv; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t b = (a.rkeys[i] - a.kmin) >> a.bucket_shift;
+        if (i == 0 || ((a.rkeys[i - 1] - a.kmin) >> a.bucket_shift) != b) a.buckets[2 * b] = (uint32_t)i;
+        if (i == a.nrv - 1 || ((a.rkeys[i + 1] - a.kmin) >> a.bucket_shift) != b) a.buckets[2 * b + 1] = (uint32_t)(i + 1);
+    }
+}
+// sorted build positions [lo, hi) whose key equals probe row i's key
 __device__ __forceinline__ void join_range(const JoinProbeArgs& a, int64_t i, int64_t& lo, int64_t& hi) {
     lo = hi = 0;
     if (a.lnull && a.lnull[i]) return;
     const uint64_t k = a.lkeys[i];
-    int64_t l = 0, h = a.nrv;
+    if (k < a.kmin || k > a.kmax) return;
+    const uint64_t b = (k - a.kmin) >> a.bucket_shift;
+    const uint2 se = *(const uint2*)(a.buckets + 2 * b);
+    int64_t l = se.x, h = se.y;
+    const int64_t e = h;
     while (l < h) { const int64_t m = (l + h) >> 1; if (a.rkeys[m] < k) l = m + 1; else h = m; }
     lo = l;
-    h = a.nrv;
+    h = e;
     while (l < h) { const int64_t m = (l + h) >> 1; if (a.rkeys[m] <= k) l = m + 1; else h = m; }
     hi = l;
 }
@@ -581,16 +593,17 @@ __global__ __launch_bounds__(kBlock) void join_count_kernel(const JoinProbeArgs 
         join_range(a, i, lo, hi);
         const int64_t c = hi - lo;
         a.counts[i] = (c == 0 && a.outer) ? 1 : c;
+        a.first[i] = c == 0 ? ~0u : (uint32_t)lo;   // the write phase does not search again
         if (a.matched) for (int64_t p = lo; p < hi; ++p) atomicOr(&a.matched[p >> 5], 1u << (p & 31));
         if (c == 0 && a.outer) atomicAdd(a.unmatched, 1ull);
     }
 }
 __global__ __launch_bounds__(kBlock) void join_write_kernel(const JoinProbeArgs a) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.nl; i += (int64_t)gridDim.x * kBlock) {
-        int64_t lo, hi;
-        join_range(a, i, lo, hi);
         int64_t o = a.offsets[i];
-        if (hi == lo) {
+        const int64_t cnt = a.offsets[i + 1] - o;
+        const uint32_t lo = a.first[i];
+        if (lo == ~0u) {
             if (a.outer) {
                 a.out_probe[o] = (uint32_t)i;
                 a.out_build[o] = 0;
@@ -598,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void join_write_kernel(const JoinProbeArgs 
             }
             continue;
         }
-        for (int64_t p = lo; p < hi; ++p, ++o) {
+        for (int64_t p = lo; p < (int64_t)lo + cnt; ++p, ++o) {
             a.out_probe[o] = (uint32_t)i;
             a.out_build[o] = a.ridx[p];
         }
@@ -1383,6 +1396,10 @@ static int rows_grid(int64_t n) {
     int64_t g = (n + kBlock - 1) / kBlock;
     if (g > eval_grid_limit()) g = eval_grid_limit();
     return g < 1 ? 1 : (int)g;
+}
+hipError_t launch_join_buckets(const JoinBucketArgs& a, hipStream_t s) {
+    if (a.nrv > 0) hipLaunchKernelGGL(join_buckets_kernel, dim3(rows_grid(a.nrv)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
 }
 hipError_t launch_join_count(const JoinProbeArgs& a, hipStream_t s) {
     if (a.nl > 0) hipLaunchKernelGGL(join_count_kernel, dim3(rows_grid(a.nl)), dim3(kBlock), 0, s, a);

@@ -625,3 +625,30 @@ def test_sort_skips_constant_key_bytes(gpu, ora):
     c1 = [A.HostArray.from_numpy(rng.integers(-50, 50, n).astype(np.int16))]
     for cols in ([c0, c1], [c1, c0]):
         assert np.array_equal(gpu.sort_to_indices(cols, [False, True]).to_numpy(), ora.sort_to_indices(cols, [False, True]).to_numpy())
+
+
+@pytest.mark.parametrize("how", ["left", "right", "inner", "full"])
+def test_equijoin_bucket_index_edge_cases(gpu, ora, how):
+    """The probe goes through a bucket index on the top bits of (key - min key): sparse keys over the whole i64 range
+    (many empty buckets, shift > 0), heavy skew (one bucket holds most rows), keys outside the build range, a single
+    distinct build key, extreme keys, negative floats and NaN-free f64 keys; pairs equal the oracle's nested loops."""
+    rng = np.random.default_rng(9100)
+    i64 = np.iinfo(np.int64)
+    def mk(v, nf=0.0):
+        v = np.asarray(v)
+        return [A.HostArray.from_numpy(v, valid=(rng.uniform(size=len(v)) >= nf) if nf else None)]
+    cases = []
+    sparse = rng.integers(i64.min // 2, i64.max // 2, 1500)
+    cases.append((mk(rng.choice(sparse, 2500)), mk(np.concatenate([sparse, sparse[:200]]), 0.05)))           # sparse, duplicates on the build side
+    skew = np.where(rng.uniform(size=2000) < 0.9, 42, rng.integers(0, 10 ** 9, 2000))
+    cases.append((mk(np.concatenate([np.full(30, 42), rng.integers(0, 10 ** 9, 500)])), mk(skew)))            # one hot key: 30 x 1800 pairs
+    cases.append((mk(rng.integers(-100, 300, 3000), 0.1), mk(rng.integers(0, 200, 1000))))                     # probe keys below / above the build range
+    cases.append((mk(rng.integers(5, 9, 500)), mk(np.full(40, 7))))                                            # single distinct build key
+    cases.append((mk(np.array([i64.min, i64.max, 0, -1, i64.min, 5])), mk(np.array([i64.max, i64.min, i64.min, 7]))))
+    cases.append((mk(np.round(rng.uniform(-3, 3, 2000), 1)), mk(np.round(rng.uniform(-3, 3, 700), 1), 0.05)))   # f64 keys incl. -0.0 / 0.0 patterns
+    cases.append((mk(rng.integers(0, 50, 100)), mk(np.array([], dtype=np.int64))))                            # empty build side
+    for lk, rk in cases:
+        gl, gr = gpu.equijoin_indices(lk, rk, how)
+        el, er = ora.equijoin_indices(lk, rk, how)
+        assert gl.length == el.length and gl.null_count == el.null_count and gr.null_count == er.null_count
+        assert _pairs(gl, gr) == _pairs(el, er), f"join {how}"

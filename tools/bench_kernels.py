@@ -187,6 +187,14 @@ def main():
     report("sort_to_indices_i64_full_range", 8.0 * ns, lambda: api.sort_to_indices([[arr(kw, A.I64, ns)]], [False], oi))
     kd = dev_i64(ns, 10, 0, 200)
     report("sort_to_indices_i64_dictionary_codes", 8.0 * ns, lambda: api.sort_to_indices([[arr(kd, A.I64, ns)]], [False], oi))
+    # DataFrame::join: 1e8 probe rows against 1e7 distinct build keys (inner: every probe row finds exactly one partner)
+    if not only or "join_inner_1e8_x_1e7" in only:
+        nl_, nr_ = min(n, 100_000_000), 10_000_000
+        lk_ = dev_i64(nl_, 12, 0, nr_)
+        rk_ = torch.randperm(nr_, device="cuda", dtype=torch.int64)
+        jl, jr = out_like(A.U32, nl_, True), out_like(A.U32, nl_, True)
+        report("join_inner_1e8_x_1e7", 8.0 * nl_ + 8.0 * nr_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk_, A.I64, nl_)], [arr(rk_, A.I64, nr_)], "inner", (jl, jr)))
+        del lk_, rk_
     # hash GROUP BY key -> sum(val): 1e6 groups (config C4's per-GPU leg) and 1e3 groups (contended)
     for ng in (1_000_000, 1_000):
         kk = dev_i64(n, 7, 0, ng)
