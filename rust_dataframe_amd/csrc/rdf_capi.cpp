@@ -2324,7 +2324,7 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
     bool value_nulls = false;
     if (values) for (int64_t c = 0; c < nchunks; ++c) value_nulls |= values[c].validity != nullptr;
     const int64_t nrows = row_start[(size_t)nchunks];
-    if (ctx.opt_gb_partition && max_groups > 1024 && max_groups <= kGbMaxGroups && !value_nulls && nrows > 0 && ctx.opt_gb_partition != 2) {
+    if (ctx.opt_gb_partition && max_groups > 1024 && max_groups <= kGbMaxGroups && nrows > 0 && ctx.opt_gb_partition != 2) {
         // single scatter pass on 9 hash bits, then one LDS table per partition
         constexpr int P = 1 << kGbPartBits;
         const int64_t ntiles = tile_start[(size_t)nchunks];
@@ -2364,12 +2364,25 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
         HIP_TRY(launch_gb_hist(pa, nb, ctx.stream));
         HIP_TRY(launch_scan((const int64_t*)hist0, (int64_t*)hist1, (int64_t)P * nb, (int64_t*)hist1 + (int64_t)P * nb + 1, ctx.stream));
         pa.hist = (int64_t*)hist1;
-        HIP_TRY(launch_gb_scatter(pa, nb, ctx.stream));
+        // skewed key distribution (one partition far above the average)?  Then equal keys are combined inside each
+        // super-tile before they are scattered, so a hot key does not serialise one block's LDS atomics.
+        unsigned int* d_skew = d_cursor + 1;
+        HIP_TRY(launch_gb_skew((const int64_t*)hist1, nb, d_skew, ctx.stream));
+        RDF_TRY(pinned_reserve(pin_off + 64));
+        HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, d_skew, 4, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        unsigned int skew = 0;
+        memcpy(&skew, ctx.pinned + pin_off, 4);
+        if (ctx.opt_gb_debug == 3) skew = 1;   // tests: force the combining variant
+        void* pemit = nullptr;
+        if (skew) { RDF_TRY(arena_alloc((size_t)((int64_t)P * nb + 1) * 8, &pemit)); pa.emitted = (int64_t*)pemit; }
+        HIP_TRY(launch_gb_scatter(pa, nb, skew != 0, ctx.stream));
         GbAggArgs ga;
         memset(&ga, 0, sizeof ga);
         ga.recs = (const uint64_t*)precs;
         ga.scan = (const int64_t*)hist1;
         ga.nblocks = nb;
+        ga.emitted = (const int64_t*)pemit;
         ga.is_f64 = sdt == RDF_F64;
         ga.has_values = values != nullptr;
         ga.key_dtype = kdt;
@@ -2383,7 +2396,7 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
         ga.ablate_lds = ctx.opt_gb_debug == 1;
         HIP_TRY(launch_gb_aggregate(ga, ctx.stream));
         kt.stop();
-        ctx.last_kernel = "gb_aggregate_kernel";
+        ctx.last_kernel = skew ? "gb_aggregate_kernel(combined)" : "gb_aggregate_kernel";
         RDF_TRY(groupby_finish_partitioned(pspec, ga.out_keys, ga.out_sums, ga.out_counts, kdt, max_groups, mem, out_keys, out_sums, out_counts, pin_off));
         return RDF_OK;
     }

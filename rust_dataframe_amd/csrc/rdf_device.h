@@ -257,7 +257,8 @@ struct GbPartArgs {
     int32_t            key_dtype, value_dtype;
     int32_t            ablate_stores, pad;   // bench ablation (rdf_set_option("gb_debug", 2)): run the scatter without its global stores
     int64_t*           hist;             // histogram kernel: out counts [digit * gridDim.x + block]; scatter: their exclusive scan
-    uint64_t*          recs;             // scatter out: [2 * rows] (hashed key, value bits)
+    uint64_t*          recs;             // scatter out: [2 * rows] records, see rdf_kernels.hip
+    int64_t*           emitted;          // combining scatter variant out: [digit * gridDim.x + block] records really written
     unsigned long long* special_sums;    // [2]: rows whose hashed key equals the LDS free marker / rows with a NULL key
     unsigned long long* special_counts;  // [2]
     unsigned int*      special;          // [2] group exists
@@ -265,6 +266,7 @@ struct GbPartArgs {
 struct GbAggArgs {
     const uint64_t* recs;
     const int64_t*  scan;                // [ (1 << kGbPartBits) * nblocks + 1 ] exclusive scan of the histogram
+    const int64_t*  emitted;             // combined (skewed) inputs: real record count of every (partition, block) range, else nullptr
     int64_t         nblocks;             // blocks of the histogram / scatter kernels
     int32_t         is_f64, has_values, key_dtype;
     int32_t         ablate_lds;          // bench ablation (rdf_set_option("gb_debug", 1)): stream the records without the LDS table work
@@ -345,7 +347,8 @@ hipError_t launch_count_bytes(const uint8_t* p, int64_t n, unsigned long long* o
 hipError_t launch_sort_hist64(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_sort_scatter64(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_gb_hist(const GbPartArgs& a, int grid, hipStream_t s);
-hipError_t launch_gb_scatter(const GbPartArgs& a, int grid, hipStream_t s);
+hipError_t launch_gb_skew(const int64_t* scan, int64_t nblocks, unsigned int* flag, hipStream_t s);
+hipError_t launch_gb_scatter(const GbPartArgs& a, int grid, bool dedup, hipStream_t s);
 hipError_t launch_gb_aggregate(const GbAggArgs& a, hipStream_t s);
 hipError_t launch_groupby_prepare(const GroupPrepArgs& a, hipStream_t s);
 hipError_t launch_groupby_partitions(const GroupAggArgs& a, hipStream_t s);

@@ -928,9 +928,17 @@ __global__ __launch_bounds__(kBlock) void groupby_partitions_kernel(const GroupA
 // A block iteration covers one super-tile: 4 tiles of kEvalTile rows (each inside one chunk), thread t takes the rows
 // q = j * kGbBlock + t.  All loads of the iteration are issued before anything depends on them (one row at a time
 // would leave a single 8-byte load in flight per lane: latency-bound at a quarter of the bandwidth).
+//
+// Record format (16 bytes): word 0 = (cnt << 55) | (hashed key & (2^55 - 1)), word 1 = sum bits.  The top 9 bits of the
+// hashed key are the partition number — known from where the record lies — so they carry cnt, the number of non-NULL
+// values summed into word 1: 1 for an ordinary row, 0 for a row whose value is NULL (the group must still exist),
+// up to kGbMaxCnt when the scatter pass has combined equal keys of one super-tile (skewed inputs).  ~0 = dead record.
+constexpr uint64_t kGbKeyMask = (1ull << (64 - kGbPartBits)) - 1;
+constexpr unsigned kGbMaxCnt = 510;
+constexpr uint64_t kGbDead = ~0ull;
 struct GbBatch {
     uint64_t key[kGbRows], val[kGbRows];   // raw key (sign-/zero-extended), value bits
-    uint32_t exists, knull;                // bit j: row j exists / its key is NULL
+    uint32_t exists, knull, vnull;         // bit j: row j exists / its key is NULL / its value is NULL
 };
 __device__ __forceinline__ int gb_dtype_size(int dt) {
     switch (dt) {
@@ -953,15 +961,15 @@ __device__ __forceinline__ uint64_t gb_load_raw(const void* base, int size, int6
 template <bool WITH_VALUES>
 __device__ __forceinline__ void gb_load_batch(const GbPartArgs& a, int64_t st, int64_t tile_end, int tid, GbBatch& b) {
     static_assert(kGbBlock * 2 == kEvalTile && kGbRows == 8, "thread t holds rows t and t + 512 of each of the 4 tiles");
-    b.exists = 0; b.knull = 0;
+    b.exists = 0; b.knull = 0; b.vnull = 0;
     const int ksz = gb_dtype_size(a.key_dtype), vsz = gb_dtype_size(a.value_dtype);
-    uint32_t vb[kGbRows];
-    int vbit[kGbRows];
+    uint32_t kb[kGbRows], vb[kGbRows];
+    int kbit[kGbRows], vbit[kGbRows];
 #pragma unroll
     for (int tt = 0; tt < kGbRows / 2; ++tt) {
         const int j0 = 2 * tt, j1 = 2 * tt + 1;
         b.key[j0] = b.key[j1] = 0; b.val[j0] = b.val[j1] = 0;
-        vb[j0] = vb[j1] = 0xFFu; vbit[j0] = vbit[j1] = 0;
+        kb[j0] = kb[j1] = vb[j0] = vb[j1] = 0xFFu; kbit[j0] = kbit[j1] = vbit[j0] = vbit[j1] = 0;
         const int64_t tile = st + tt;                 // block-uniform: the chunk lookup below runs on the scalar unit
         if (tile >= tile_end) continue;
         const int64_t c = a.nchunks == 1 ? 0 : find_chunk(a.chunk_tile_start, a.nchunks, tile);
@@ -975,24 +983,32 @@ __device__ __forceinline__ void gb_load_batch(const GbPartArgs& a, int64_t st, i
         b.key[j1] = gb_load_raw(kc.values, ksz, kc.offset + row1, e1);
         if (kc.validity) {
             const int64_t b0 = kc.offset + row0, b1 = kc.offset + row1;
-            if (e0) vb[j0] = as_global<uint8_t>(kc.validity)[b0 >> 3];
-            if (e1) vb[j1] = as_global<uint8_t>(kc.validity)[b1 >> 3];
-            vbit[j0] = (int)(b0 & 7); vbit[j1] = (int)(b1 & 7);
+            if (e0) kb[j0] = as_global<uint8_t>(kc.validity)[b0 >> 3];
+            if (e1) kb[j1] = as_global<uint8_t>(kc.validity)[b1 >> 3];
+            kbit[j0] = (int)(b0 & 7); kbit[j1] = (int)(b1 & 7);
         }
         if (WITH_VALUES && a.value_dtype >= 0) {
             const DevChunkCol vc = a.values[c];
             b.val[j0] = gb_load_raw(vc.values, vsz, vc.offset + row0, e0);
             b.val[j1] = gb_load_raw(vc.values, vsz, vc.offset + row1, e1);
+            if (vc.validity) {
+                const int64_t b0 = vc.offset + row0, b1 = vc.offset + row1;
+                if (e0) vb[j0] = as_global<uint8_t>(vc.validity)[b0 >> 3];
+                if (e1) vb[j1] = as_global<uint8_t>(vc.validity)[b1 >> 3];
+                vbit[j0] = (int)(b0 & 7); vbit[j1] = (int)(b1 & 7);
+            }
         }
     }
     // every load above is in flight by now; nothing before this point consumed one
 #pragma unroll
     for (int j = 0; j < kGbRows; ++j) {
         b.key[j] = normalize_int(a.key_dtype, b.key[j]);
-        b.knull |= (uint32_t)(((vb[j] >> vbit[j]) & 1u) == 0) << j;
+        b.knull |= (uint32_t)(((kb[j] >> kbit[j]) & 1u) == 0) << j;
         if (WITH_VALUES) {
+            b.vnull |= (uint32_t)(((vb[j] >> vbit[j]) & 1u) == 0) << j;
             if (a.value_dtype == RDF_F32) b.val[j] = d2u((double)__uint_as_float((uint32_t)b.val[j]));
             else if (a.value_dtype >= 0 && a.value_dtype != RDF_F64) b.val[j] = normalize_int(a.value_dtype, b.val[j]);
+            if ((b.vnull >> j) & 1) b.val[j] = 0;
         }
     }
 }
@@ -1018,48 +1034,106 @@ __global__ __launch_bounds__(kGbBlock) void gb_hist_kernel(const GbPartArgs a) {
     for (int d = threadIdx.x; d < P; d += kGbBlock) a.hist[(int64_t)d * gridDim.x + blockIdx.x] = (int64_t)lc[d];
 }
 
+// Skew detector (one block): *flag = 1 when the largest partition holds more than 4x the average.  Skewed inputs
+// (Zipf keys: SURVEY.md §8d C4 variant) take the scatter variant that combines equal keys inside a super-tile.
+__global__ __launch_bounds__(kGbBlock) void gb_skew_kernel(const int64_t* scan, int64_t nblocks, unsigned int* flag) {
+    constexpr int P = 1 << kGbPartBits;
+    __shared__ unsigned long long mx;
+    if (threadIdx.x == 0) mx = 0;
+    __syncthreads();
+    const int p = threadIdx.x;
+    const unsigned long long sz = (unsigned long long)(scan[(int64_t)(p + 1) * nblocks] - scan[(int64_t)p * nblocks]);
+    atomicMax(&mx, sz);
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned long long total = (unsigned long long)scan[(int64_t)P * nblocks]; *flag = (total > 65536 && mx * P > 4 * total) ? 1u : 0u; }
+}
+
+constexpr int kGbCache = 512;   // DEDUP: direct-mapped LDS cache of keys seen in the current super-tile
+template <bool DEDUP>
 __global__ __launch_bounds__(kGbBlock) void gb_scatter_kernel(const GbPartArgs a) {
     constexpr int P = 1 << kGbPartBits;
     static_assert(P == kGbBlock, "one thread per partition counter");
     extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
-    uint64_t* skey = gsm;                       // [kGbSuper] staged records, grouped by partition
+    uint64_t* skey = gsm;                       // [kGbSuper] staged records, grouped by partition (full hashed key)
     uint64_t* sval = gsm + kGbSuper;            // [kGbSuper]
     int64_t* gbase = (int64_t*)(gsm + 2 * kGbSuper);              // [P] next output record of (partition, this block)
-    unsigned int* lcount = (unsigned int*)(gbase + P);            // [P] rows of the partition in this iteration
-    unsigned int* lstart = lcount + P;                            // [P] their first staging slot
+    unsigned int* lcount = (unsigned int*)(gbase + P);            // [P] records of the partition in this iteration
+    unsigned short* lstart = (unsigned short*)(lcount + P);       // [P] their first staging slot
+    unsigned short* scnt = lstart + P;                            // [kGbSuper] cnt of the staged record
+    unsigned long long* ckey = (unsigned long long*)(scnt + kGbSuper);   // DEDUP [kGbCache] hashed key owning the slot (kHashFree = empty)
+    unsigned long long* cval = ckey + kGbCache;                   // DEDUP [kGbCache] sum of the absorbed rows' values
+    unsigned int* ccnt = (unsigned int*)(cval + kGbCache);        // DEDUP [kGbCache] non-NULL values among them
     __shared__ unsigned int wave_tot[kGbBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     gbase[tid] = a.hist[(int64_t)tid * gridDim.x + blockIdx.x];
     lcount[tid] = 0;
+    if (DEDUP) for (int i = tid; i < kGbCache; i += kGbBlock) { ckey[i] = kHashFree; cval[i] = 0; ccnt[i] = 0; }
     __syncthreads();
     const bool is_f = a.value_dtype == RDF_F64 || a.value_dtype == RDF_F32;
-    // super-tiles are dealt round-robin (block b takes b, b + grid, ...); any assignment works as long as the
-    // histogram and the scatter agree (measured: no faster or slower than contiguous per-block ranges)
+    const bool counts_rows = a.value_dtype < 0;   // no value column: cnt = rows
+    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
     const int64_t t1 = a.ntiles;
     for (int64_t st = (int64_t)blockIdx.x * (kGbSuper / kEvalTile); st < t1; st += (int64_t)gridDim.x * (kGbSuper / kEvalTile)) {
-        // (A) load everything, then hash and rank inside the partition (LDS atomics: 512 counters, random digits)
+        // (A) load everything, then hash; specials go to global accumulators, never staged
         GbBatch b;
         gb_load_batch<true>(a, st, t1, tid, b);
-        unsigned int rank[kGbRows];
+        unsigned int rank[kGbRows], cnt[kGbRows];
+        int cslot[kGbRows];
+        uint32_t live = 0;   // rows that will be emitted as records
 #pragma unroll
         for (int j = 0; j < kGbRows; ++j) {
-            rank[j] = ~0u;
+            rank[j] = ~0u; cslot[j] = -1;
+            cnt[j] = (counts_rows || !((b.vnull >> j) & 1)) ? 1u : 0u;
             if (!((b.exists >> j) & 1)) continue;
             const uint64_t hk = mix64(b.key[j]);
             b.key[j] = hk;
             const bool knull = (b.knull >> j) & 1;
-            if (!knull && hk != kHashFree) rank[j] = atomicAdd(&lcount[(unsigned)(hk >> (64 - kGbPartBits))], 1u);
-            else {   // the two special groups: global accumulators, never staged
+            if (knull || hk == kHashFree) {
                 const int s = knull ? 1 : 0;
                 a.special[s] = 1;
-                if (is_f) unsafeAtomicAdd((double*)&a.special_sums[s], u2d(b.val[j])); else atomicAdd(&a.special_sums[s], (unsigned long long)b.val[j]);
-                atomicAdd(&a.special_counts[s], 1ull);
+                if (cnt[j]) {
+                    if (a.value_dtype >= 0) { if (is_f) unsafeAtomicAdd((double*)&a.special_sums[s], u2d(b.val[j])); else atomicAdd(&a.special_sums[s], (unsigned long long)b.val[j]); }
+                    atomicAdd(&a.special_counts[s], 1ull);
+                }
+                continue;
+            }
+            live |= 1u << j;
+            if (DEDUP) {   // equal keys of this super-tile collapse into the record of the first row that claimed the slot
+                const int s = (int)((hk >> 24) & (kGbCache - 1));
+                const unsigned long long old = atomicCAS(&ckey[s], kHashFree, (unsigned long long)hk);
+                if (old == kHashFree) cslot[j] = s;   // owner: emits the combined record below
+                else if (old == hk) {
+                    if (cnt[j]) {
+                        if (a.value_dtype >= 0) { if (is_f) unsafeAtomicAdd((double*)&cval[s], u2d(b.val[j])); else atomicAdd(&cval[s], (unsigned long long)b.val[j]); }
+                        atomicAdd(&ccnt[s], 1u);
+                    }
+                    live &= ~(1u << j);   // absorbed
+                }
             }
         }
+        if (DEDUP) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kGbRows; ++j)
+                if (cslot[j] >= 0) {   // fold what the slot absorbed into the owner's record, free the slot for the next super-tile
+                    const int s = cslot[j];
+                    b.val[j] = is_f ? d2u(u2d(b.val[j]) + u2d(cval[s])) : b.val[j] + cval[s];
+                    cnt[j] += ccnt[s];
+                    ckey[s] = kHashFree; cval[s] = 0; ccnt[s] = 0;
+                }
+        }
+        // rank inside the partition (LDS atomics: 512 counters, random digits -> little contention).  A combined record
+        // whose cnt does not fit the 9-bit field is continued by (0-valued) records carrying the rest of the count.
+#pragma unroll
+        for (int j = 0; j < kGbRows; ++j)
+            if ((live >> j) & 1) {
+                const unsigned int nrec = cnt[j] <= kGbMaxCnt ? 1u : (cnt[j] + kGbMaxCnt - 1) / kGbMaxCnt;
+                rank[j] = atomicAdd(&lcount[(unsigned)(b.key[j] >> (64 - kGbPartBits))], nrec);
+            }
         __syncthreads();
         // (B) exclusive scan of the P counters (one per thread)
-        const unsigned int cnt = lcount[tid];
-        unsigned int inc = cnt;
+        const unsigned int pc = lcount[tid];
+        unsigned int inc = pc;
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) { const unsigned int y = (unsigned int)__shfl_up((int)inc, m); if (lane >= m) inc += y; }
         if (lane == 63) wave_tot[wave] = inc;
@@ -1067,32 +1141,45 @@ __global__ __launch_bounds__(kGbBlock) void gb_scatter_kernel(const GbPartArgs a
         unsigned int woff = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < kGbBlock / 64; ++w) { if (w < wave) woff += wave_tot[w]; total += wave_tot[w]; }
-        lstart[tid] = woff + inc - cnt;
+        lstart[tid] = (unsigned short)(woff + inc - pc);
         __syncthreads();
         // (C) stage the records grouped by partition
 #pragma unroll
         for (int j = 0; j < kGbRows; ++j)
             if (rank[j] != ~0u) {
-                const unsigned int pos = lstart[(unsigned)(b.key[j] >> (64 - kGbPartBits))] + rank[j];
+                unsigned int pos = lstart[(unsigned)(b.key[j] >> (64 - kGbPartBits))] + rank[j];
+                unsigned int left = cnt[j];
                 skey[pos] = b.key[j];
                 sval[pos] = b.val[j];
+                scnt[pos] = (unsigned short)(left < kGbMaxCnt ? left : kGbMaxCnt);
+                while (left > kGbMaxCnt) {   // (combining variant only)
+                    left -= kGbMaxCnt;
+                    ++pos;
+                    skey[pos] = b.key[j];
+                    sval[pos] = 0;
+                    scnt[pos] = (unsigned short)(left < kGbMaxCnt ? left : kGbMaxCnt);
+                }
             }
         __syncthreads();
-        // (D) write them out: consecutive staging slots of one partition are consecutive output records
-        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+        // (D) write them out: consecutive staging slots of one partition are consecutive output records; the partition bits
+        // of the key make room for cnt
         for (unsigned int i = tid; i < total; i += kGbBlock) {
             const uint64_t k = skey[i];
             const unsigned int d = (unsigned int)(k >> (64 - kGbPartBits));
             u64x2 rec;
-            rec[0] = k; rec[1] = sval[i];
+            rec[0] = ((uint64_t)scnt[i] << (64 - kGbPartBits)) | (k & kGbKeyMask);
+            rec[1] = sval[i];
             if (!a.ablate_stores) ((u64x2*)a.recs)[gbase[d] + (int64_t)(i - lstart[d])] = rec;
         }
         __syncthreads();
         // (E) advance the block's output positions
-        gbase[tid] += (int64_t)cnt;
+        gbase[tid] += (int64_t)pc;
         lcount[tid] = 0;
         __syncthreads();
     }
+    // absorbed rows were counted by the histogram, so a (partition, block) range may end early: the aggregation pass
+    // walks the ranges by their real lengths
+    if (DEDUP) a.emitted[(int64_t)tid * gridDim.x + blockIdx.x] = gbase[tid] - a.hist[(int64_t)tid * gridDim.x + blockIdx.x];
 }
 
 // One block per partition: its records are the contiguous range [scan[p * nblocks], scan[(p + 1) * nblocks]).
@@ -1112,8 +1199,11 @@ __global__ __launch_bounds__(kGbBlock) void gb_aggregate_kernel(const GbAggArgs 
         if (threadIdx.x == 0) misc[0] = 0;
         __syncthreads();
         uint64_t dbg_acc = 0;
+        const uint64_t ptop = (uint64_t)p << (64 - kGbPartBits);
         auto upsert = [&](const u64x2 rec) {
-            const uint64_t hk = rec[0];
+            if (rec[0] == kGbDead) return;
+            const unsigned int cnt = (unsigned int)(rec[0] >> (64 - kGbPartBits));
+            const uint64_t hk = (rec[0] & kGbKeyMask) | ptop;
             if (a.ablate_lds) { dbg_acc ^= hk ^ rec[1]; return; }
             // slot from the bits below the partition bits (still well mixed); multiply-shift range reduction
             uint32_t s = (uint32_t)(((uint64_t)(uint32_t)(hk >> 20) * (uint64_t)kGbSlots) >> 32);
@@ -1130,13 +1220,29 @@ __global__ __launch_bounds__(kGbBlock) void gb_aggregate_kernel(const GbAggArgs 
                 break;
             }
             if (slot < 0) { err |= 4u; return; }
+            if (cnt == 0) return;   // a NULL value: the group exists, nothing to add
             if (a.has_values) {
                 if (a.is_f64) unsafeAtomicAdd((double*)&lsums[slot], u2d(rec[1])); else atomicAdd(&lsums[slot], (unsigned long long)rec[1]);
             }
-            atomicAdd(&lcnts[slot], 1u);
+            atomicAdd(&lcnts[slot], cnt);
         };
         const u64x2* recs = (const u64x2*)a.recs;
-        int64_t i = lo + threadIdx.x;
+        if (a.emitted) {   // combined (skewed) inputs: per-(partition, block) sub-ranges with their real lengths, two at a time
+            for (int64_t b = 0; b < a.nblocks; b += 2) {
+                const int64_t s0 = a.scan[(int64_t)p * a.nblocks + b], n0 = a.emitted[(int64_t)p * a.nblocks + b];
+                const bool two = b + 1 < a.nblocks;
+                const int64_t s1 = two ? a.scan[(int64_t)p * a.nblocks + b + 1] : 0, n1 = two ? a.emitted[(int64_t)p * a.nblocks + b + 1] : 0;
+                const int64_t nmax = n0 > n1 ? n0 : n1;
+                for (int64_t i = threadIdx.x; i < nmax; i += kGbBlock) {
+                    u64x2 r0, r1;
+                    r0[0] = r1[0] = kGbDead; r0[1] = r1[1] = 0;
+                    if (i < n0) r0 = __builtin_nontemporal_load(recs + s0 + i);
+                    if (i < n1) r1 = __builtin_nontemporal_load(recs + s1 + i);
+                    upsert(r0); upsert(r1);
+                }
+            }
+        }
+        int64_t i = a.emitted ? hi : lo + threadIdx.x;
         // 4 independent 16-byte loads per lane, and the NEXT batch is issued before the current one is folded into LDS
         constexpr int B = 4;
         u64x2 cur[B], nxt[B];
@@ -1421,11 +1527,21 @@ hipError_t launch_gb_hist(const GbPartArgs& a, int grid, hipStream_t s) {
     hipLaunchKernelGGL(gb_hist_kernel, dim3(grid), dim3(kGbBlock), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_gb_scatter(const GbPartArgs& a, int grid, hipStream_t s) {
+hipError_t launch_gb_skew(const int64_t* scan, int64_t nblocks, unsigned int* flag, hipStream_t s) {
+    hipLaunchKernelGGL(gb_skew_kernel, dim3(1), dim3(kGbBlock), 0, s, scan, nblocks, flag);
+    return hipGetLastError();
+}
+hipError_t launch_gb_scatter(const GbPartArgs& a, int grid, bool dedup, hipStream_t s) {
     constexpr int P = 1 << kGbPartBits;
-    const size_t lds = (size_t)2 * kGbSuper * 8 + (size_t)P * (8 + 4 + 4);
-    (void)hipFuncSetAttribute((const void*)gb_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // > 64 KB
-    hipLaunchKernelGGL(gb_scatter_kernel, dim3(grid), dim3(kGbBlock), lds, s, a);
+    size_t lds = (size_t)2 * kGbSuper * 8 + (size_t)P * (8 + 4 + 2) + (size_t)kGbSuper * 2;   // 80 896 B: two blocks per CU
+    if (dedup) {
+        lds += (size_t)kGbCache * (8 + 8 + 4);
+        (void)hipFuncSetAttribute((const void*)gb_scatter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gb_scatter_kernel<true>), dim3(grid), dim3(kGbBlock), lds, s, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)gb_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // > 64 KB
+        hipLaunchKernelGGL((gb_scatter_kernel<false>), dim3(grid), dim3(kGbBlock), lds, s, a);
+    }
     return hipGetLastError();
 }
 hipError_t launch_gb_aggregate(const GbAggArgs& a, hipStream_t s) {

@@ -441,7 +441,7 @@ def test_groupby_partitioned_high_cardinality(gpu, ora, ngroups, n):
             lib.set_option("gb_partition", part)
             got = _sorted_groups(*gpu.groupby_sum(keys, vals, ngroups + 8))
             if part:
-                assert lib.last_kernel() == ("gb_aggregate_kernel" if part == 1 else "groupby_partitions_kernel")
+                assert lib.last_kernel().startswith("gb_aggregate_kernel" if part == 1 else "groupby_partitions_kernel")
             assert np.array_equal(got[1], exp[1]) and np.array_equal(got[0][exp[1]], exp[0][exp[1]]), f"keys part={part}"
             assert np.array_equal(got[3], exp[3]), f"counts part={part}"
             if val_dtype == A.F64:
@@ -652,3 +652,41 @@ def test_equijoin_bucket_index_edge_cases(gpu, ora, how):
         el, er = ora.equijoin_indices(lk, rk, how)
         assert gl.length == el.length and gl.null_count == el.null_count and gr.null_count == er.null_count
         assert _pairs(gl, gr) == _pairs(el, er), f"join {how}"
+
+
+@pytest.mark.parametrize("val_dtype", [A.F64, A.I64, A.F32, None])
+def test_groupby_partitioned_value_nulls_and_skew(gpu, ora, val_dtype):
+    """The single-pass partitioned GROUP BY with NULL values (a group whose values are all NULL still exists, count 0)
+    and with skewed keys: a Zipf-like distribution makes one partition dominate, the skew detector switches to the
+    scatter variant that combines equal keys inside a super-tile (cnt travels in the record); also forced on uniform keys."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(31337)
+    n, ngroups = 400_000, 50_000
+    uniform = rng.integers(0, ngroups, n).astype(np.int64)
+    zipf = np.minimum(rng.zipf(1.1, n), ngroups).astype(np.int64) * 7919          # a few very hot keys
+    hot = np.where(rng.uniform(size=n) < 0.6, 12345, rng.integers(0, ngroups, n)).astype(np.int64)
+    for name, kv, force in (("uniform", uniform, 0), ("uniform_forced_combine", uniform, 3), ("zipf", zipf, 0), ("hot_key", hot, 0)):
+        lens = [n // 2, n - n // 2]
+        keys, vals, pos = [], ([] if val_dtype is not None else None), 0
+        for ln in lens:
+            keys.append(A.HostArray.from_numpy(kv[pos:pos + ln], valid=rng.uniform(size=ln) >= 0.01, rng=rng))
+            if val_dtype is not None:
+                v = rng.uniform(-1, 1, ln) if val_dtype in (A.F64, A.F32) else rng.integers(-10 ** 9, 10 ** 9, ln)
+                valid = rng.uniform(size=ln) >= 0.3
+                valid[kv[pos:pos + ln] % 11 == 0] = False       # whole groups with only NULL values
+                vals.append(A.HostArray.from_numpy(v, valid=valid, dtype=val_dtype, rng=rng))
+            pos += ln
+        exp = _sorted_groups(*ora.groupby_sum(keys, vals, ngroups + 8))
+        lib.set_option("gb_debug", force)
+        got = _sorted_groups(*gpu.groupby_sum(keys, vals, ngroups + 8))
+        lib.set_option("gb_debug", 0)
+        k = lib.last_kernel()
+        assert k.startswith("gb_aggregate_kernel"), k
+        if name != "uniform":
+            assert k.endswith("(combined)"), f"{name}: {k}"
+        assert np.array_equal(got[1], exp[1]) and np.array_equal(got[0][exp[1]], exp[0][exp[1]]), f"keys {name}"
+        assert np.array_equal(got[3], exp[3]), f"counts {name}"
+        if val_dtype in (A.F64, A.F32):
+            np.testing.assert_allclose(got[2], exp[2], rtol=1e-6, atol=1e-9, err_msg=name)
+        else:
+            assert np.array_equal(got[2], exp[2]), f"sums {name}"

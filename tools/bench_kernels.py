@@ -203,6 +203,14 @@ def main():
         oc2_ = out_like(A.I64, ng + 2)
         report(f"groupby_sum_{ng}_groups", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
         if ng > 1024:
+            # skewed keys (SURVEY.md §8d C4 variant): Zipf-like s = 1.1 (inverse-CDF of the continuous power law, clamped) and one hot key
+            u = torch.rand(n, device="cuda", dtype=torch.float64).clamp_(min=1e-12)
+            kz = torch.clamp(torch.floor(u.pow(-1.0 / 0.1)), max=float(ng - 1)).to(torch.int64)
+            report(f"groupby_sum_{ng}_groups_zipf", 16.0 * n, lambda: api.groupby_sum([arr(kz, A.I64, n)], [X], ng, (ok_, os_, oc_)))
+            kh = torch.where(torch.rand(n, device="cuda") < 0.3, torch.full((n,), 7, device="cuda", dtype=torch.int64), kk)
+            report(f"groupby_sum_{ng}_groups_hot_key_30pct", 16.0 * n, lambda: api.groupby_sum([arr(kh, A.I64, n)], [X], ng, (ok_, os_, oc_)))
+            report(f"groupby_sum_{ng}_groups_null_values", 16.125 * n, lambda: api.groupby_sum([KK], [XV], ng, (ok_, os_, oc_)))
+            del u, kz, kh
             for dbg in (1, 2):
                 lib.set_option("gb_debug", dbg)
                 try:
