@@ -229,6 +229,38 @@ rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks
 rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,
                            rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts);
 
+/* ------------------------------------------------------------------ ArrayFunctions over List<primitive> columns */
+
+/* A ListArray with primitive numeric children as the reference's ArrayFunctions see it (src/functions/array.rs):
+ * row i is the slice values[value_offset(i) .. value_offset(i + 1)) of the child array.  `offsets` is the Int32
+ * value_offsets buffer described as an RDF_I32 array of rows + 1 elements whose validity / offset / null_count
+ * fields describe the LIST rows (bit i = list i is not NULL); `values` is the child array.  Child validity is
+ * ignored, exactly as the reference's value_slice() ignores it. */
+typedef struct {
+    rdf_array offsets;
+    rdf_array values;
+} rdf_list_array;
+
+/* ArrayFunctions::array_contains (array.rs:15-37): NULL list -> NULL, else whether the slice holds `value`
+ * (a native scalar of the child dtype; float equality is IEEE: NaN equals nothing).  out: RDF_BOOL, rows elements. */
+rdf_status rdf_list_contains(const rdf_list_array* list, const void* value, rdf_out* out);
+/* ArrayFunctions::array_position (array.rs:233-260): 1-based position of the first occurrence, 0 when absent or
+ * when the list is NULL (never NULL).  out: RDF_I32. */
+rdf_status rdf_list_position(const rdf_list_array* list, const void* value, rdf_out* out);
+/* ArrayFunctions::array_max / array_min (array.rs:182-231): per-row extremum, NULL for a NULL list.  An EMPTY
+ * list gives NULL (the reference unwraps None and panics); floats are accepted, NaN loses against any number
+ * (the column aggregates' rule).  out: child dtype. */
+rdf_status rdf_list_max(const rdf_list_array* list, rdf_out* out);
+rdf_status rdf_list_min(const rdf_list_array* list, rdf_out* out);
+/* ArrayFunctions::array_remove (array.rs:262-292): every element equal to `value` dropped, order kept; a NULL
+ * list becomes an empty (valid) list like the reference's ListBuilder::append(true).  out_offsets: RDF_I32 with
+ * rows + 1 elements (starting at 0), out_values: child dtype, capacity >= the slice total. */
+rdf_status rdf_list_remove(const rdf_list_array* list, const void* value, rdf_out* out_offsets, rdf_out* out_values);
+/* ArrayFunctions::array_sort (array.rs:320-354): every row's slice sorted ascending (floats in IEEE total order);
+ * the value_offsets do not change.  out_values: the child values of rows 0 .. rows-1 re-ordered, i.e.
+ * values[value_offset(0) .. value_offset(rows)). */
+rdf_status rdf_list_sort(const rdf_list_array* list, rdf_out* out_values);
+
 /* ------------------------------------------------------------------ fused batch loop */
 
 typedef enum {

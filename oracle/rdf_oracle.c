@@ -995,6 +995,154 @@ rdf_status ora_group_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_
     return st;
 }
 
+/* ------------------------------------------------------------------ ArrayFunctions over List<primitive>
+ * src/functions/array.rs: row i = value_slice(value_offset(i), value_length(i)) of the child values (child validity is
+ * not looked at, as in the reference).  Pinned by the reference's own tests (:421-640): array_contains over
+ * i32 / i64 / f64, array_position, array_remove, array_sort on the 16-value / 6-row fixture. */
+typedef struct { const int32_t* off; const rdf_array* vals; const rdf_array* lst; int64_t n; } listview;
+static rdf_status list_view(const rdf_list_array* l, listview* v) {
+    if (!l) FAIL(RDF_INVALID_ARGUMENT, "null list");
+    if (l->offsets.dtype != RDF_I32 || l->offsets.length < 1) FAIL(RDF_INVALID_ARGUMENT, "value_offsets must be Int32 with rows + 1 entries");
+    if (!is_numeric(l->values.dtype)) FAIL(RDF_INVALID_ARGUMENT, "primitive numeric child values only");
+    v->off = (const int32_t*)l->offsets.values + l->offsets.offset;
+    v->vals = &l->values; v->lst = &l->offsets; v->n = l->offsets.length - 1;
+    return RDF_OK;
+}
+static int list_valid(const listview* v, int64_t i) { return v->lst->validity == NULL || bit_get(v->lst->validity, v->lst->offset + i); }
+/* equality of child element e with the needle, in the child's own type (IEEE for floats) */
+static int elem_eq(const rdf_array* a, int64_t e, const void* needle) {
+    switch (a->dtype) {
+        case RDF_F64: return ((const double*)a->values)[a->offset + e] == *(const double*)needle;
+        case RDF_F32: return ((const float*)a->values)[a->offset + e] == *(const float*)needle;
+        default: return memcmp((const char*)a->values + (size_t)(a->offset + e) * (size_t)dtype_size(a->dtype), needle, (size_t)dtype_size(a->dtype)) == 0;
+    }
+}
+static rdf_status list_find(const rdf_list_array* l, const void* value, rdf_out* out, int want_position) {
+    listview v;
+    rdf_status st = list_view(l, &v);
+    if (st != RDF_OK) return st;
+    if (!value || !out) FAIL(RDF_INVALID_ARGUMENT, "null argument");
+    if (out->dtype != (want_position ? RDF_I32 : RDF_BOOL)) FAIL(RDF_INVALID_ARGUMENT, "output dtype");
+    if (out->capacity < v.n) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
+    if (!want_position && v.lst->validity && !out->validity) FAIL(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    out_begin(out, v.n);
+    for (int64_t i = 0; i < v.n; i++) {
+        int32_t pos = 0;
+        if (list_valid(&v, i))
+            for (int32_t e = v.off[i]; e < v.off[i + 1]; e++) if (elem_eq(v.vals, e, value)) { pos = e - v.off[i] + 1; break; }
+        if (want_position) ((int32_t*)out->values)[i] = pos;                 /* NULL list -> 0, array.rs:244 */
+        else if (!list_valid(&v, i)) out_null(out, i);                        /* NULL list -> NULL, array.rs:24 */
+        else bit_put((uint8_t*)out->values, i, pos != 0);
+    }
+    return RDF_OK;
+}
+rdf_status ora_list_contains(const rdf_list_array* l, const void* value, rdf_out* out) { return list_find(l, value, out, 0); }
+rdf_status ora_list_position(const rdf_list_array* l, const void* value, rdf_out* out) { return list_find(l, value, out, 1); }
+
+static int elem_less(const rdf_array* a, int64_t x, int64_t y) {   /* value order; NaN handled by the callers */
+    int64_t i = a->offset + x, j = a->offset + y;
+    switch (a->dtype) {
+        case RDF_I8: return ((const int8_t*)a->values)[i] < ((const int8_t*)a->values)[j];
+        case RDF_I16: return ((const int16_t*)a->values)[i] < ((const int16_t*)a->values)[j];
+        case RDF_I32: return ((const int32_t*)a->values)[i] < ((const int32_t*)a->values)[j];
+        case RDF_I64: return ((const int64_t*)a->values)[i] < ((const int64_t*)a->values)[j];
+        case RDF_U8: return ((const uint8_t*)a->values)[i] < ((const uint8_t*)a->values)[j];
+        case RDF_U16: return ((const uint16_t*)a->values)[i] < ((const uint16_t*)a->values)[j];
+        case RDF_U32: return ((const uint32_t*)a->values)[i] < ((const uint32_t*)a->values)[j];
+        case RDF_U64: return ((const uint64_t*)a->values)[i] < ((const uint64_t*)a->values)[j];
+        case RDF_F32: return ((const float*)a->values)[i] < ((const float*)a->values)[j];
+        default: return ((const double*)a->values)[i] < ((const double*)a->values)[j];
+    }
+}
+static int elem_nan(const rdf_array* a, int64_t x) {
+    if (a->dtype == RDF_F64) { double d = ((const double*)a->values)[a->offset + x]; return d != d; }
+    if (a->dtype == RDF_F32) { float d = ((const float*)a->values)[a->offset + x]; return d != d; }
+    return 0;
+}
+static rdf_status list_extreme(const rdf_list_array* l, rdf_out* out, int want_max) {
+    listview v;
+    rdf_status st = list_view(l, &v);
+    if (st != RDF_OK) return st;
+    if (!out || out->dtype != v.vals->dtype) FAIL(RDF_INVALID_ARGUMENT, "output must have the child dtype");
+    if (out->capacity < v.n) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
+    if (!out->validity) FAIL(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    out_begin(out, v.n);
+    size_t es = (size_t)dtype_size(v.vals->dtype);
+    for (int64_t i = 0; i < v.n; i++) {
+        int64_t best = -1, anynan = -1;
+        if (list_valid(&v, i))
+            for (int32_t e = v.off[i]; e < v.off[i + 1]; e++) {
+                if (elem_nan(v.vals, e)) { anynan = e; continue; }
+                if (best < 0 || (want_max ? elem_less(v.vals, best, e) : elem_less(v.vals, e, best))) best = e;
+            }
+        if (best < 0) best = anynan;
+        if (best < 0) { out_null(out, i); memset((char*)out->values + (size_t)i * es, 0, es); }   /* NULL or EMPTY list (the reference panics on empty) */
+        else memcpy((char*)out->values + (size_t)i * es, (const char*)v.vals->values + (size_t)(v.vals->offset + best) * es, es);
+    }
+    return RDF_OK;
+}
+rdf_status ora_list_max(const rdf_list_array* l, rdf_out* out) { return list_extreme(l, out, 1); }
+rdf_status ora_list_min(const rdf_list_array* l, rdf_out* out) { return list_extreme(l, out, 0); }
+
+rdf_status ora_list_remove(const rdf_list_array* l, const void* value, rdf_out* out_offsets, rdf_out* out_values) {
+    listview v;
+    rdf_status st = list_view(l, &v);
+    if (st != RDF_OK) return st;
+    if (!value || !out_offsets || !out_values) FAIL(RDF_INVALID_ARGUMENT, "null argument");
+    if (out_offsets->dtype != RDF_I32 || out_values->dtype != v.vals->dtype) FAIL(RDF_INVALID_ARGUMENT, "outputs are (Int32 offsets, child dtype values)");
+    if (out_offsets->capacity < v.n + 1) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
+    size_t es = (size_t)dtype_size(v.vals->dtype);
+    int64_t o = 0;
+    int32_t* oo = (int32_t*)out_offsets->values;
+    for (int64_t i = 0; i < v.n; i++) {
+        oo[i] = (int32_t)o;
+        if (!list_valid(&v, i)) continue;                                    /* b.append(true): an empty valid list, array.rs:273 */
+        for (int32_t e = v.off[i]; e < v.off[i + 1]; e++)
+            if (!elem_eq(v.vals, e, value)) {
+                if (o >= out_values->capacity) FAIL(RDF_MEMORY_ERROR, "values capacity too small");
+                memcpy((char*)out_values->values + (size_t)o * es, (const char*)v.vals->values + (size_t)(v.vals->offset + e) * es, es);
+                o++;
+            }
+    }
+    oo[v.n] = (int32_t)o;
+    out_offsets->length = v.n + 1; out_offsets->null_count = 0;
+    out_values->length = o; out_values->null_count = 0;
+    if (out_offsets->validity) memset(out_offsets->validity, 0xFF, (size_t)((v.n + 8) / 8));
+    if (out_values->validity) memset(out_values->validity, 0xFF, (size_t)((o + 7) / 8));
+    return RDF_OK;
+}
+
+static uint64_t sort_bits(const rdf_array* a, int64_t i, int* width);
+static const rdf_array* g_lsort_vals;
+static int lsort_cmp(const void* x, const void* y) {   /* ascending; floats in IEEE total order like the column sort */
+    int32_t a = *(const int32_t*)x, b = *(const int32_t*)y;
+    int w;
+    uint64_t ka = sort_bits(g_lsort_vals, a, &w), kb = sort_bits(g_lsort_vals, b, &w);
+    return ka < kb ? -1 : ka > kb ? 1 : (a < b ? -1 : a > b);
+}
+rdf_status ora_list_sort(const rdf_list_array* l, rdf_out* out_values) {
+    listview v;
+    rdf_status st = list_view(l, &v);
+    if (st != RDF_OK) return st;
+    if (!out_values || out_values->dtype != v.vals->dtype) FAIL(RDF_INVALID_ARGUMENT, "output must have the child dtype");
+    int64_t first = v.off[0], total = (int64_t)v.off[v.n] - first;
+    if (out_values->capacity < total) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
+    size_t es = (size_t)dtype_size(v.vals->dtype);
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
+    for (int64_t i = 0; i < v.n; i++) {
+        int32_t b = v.off[i], e = v.off[i + 1];
+        for (int32_t k = b; k < e; k++) idx[k - first] = k;
+        g_lsort_vals = v.vals;
+        qsort(idx + (b - first), (size_t)(e - b), sizeof(int32_t), lsort_cmp);
+    }
+    for (int64_t k = 0; k < total; k++)
+        memcpy((char*)out_values->values + (size_t)k * es, (const char*)v.vals->values + (size_t)(v.vals->offset + idx[k]) * es, es);
+    free(idx);
+    out_values->length = total; out_values->null_count = 0;
+    if (out_values->validity) memset(out_values->validity, 0xFF, (size_t)((total + 7) / 8));
+    return RDF_OK;
+}
+
 /* ------------------------------------------------------------------ sort
  * DataFrame::sort (src/dataframe.rs:194-214): concat every sort column (Column::to_array), then
  * arrow::compute::lexsort_to_indices with SortOptions{descending, nulls_first: false}.  Restated as a

@@ -62,6 +62,13 @@ rdf_status ora_group_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_
                               const int32_t* value_roots, int32_t nvalues, const rdf_array* cols, int32_t ncols, int64_t nchunks,
                               rdf_group_result* out, int64_t* group_rows);
 
+rdf_status ora_list_contains(const rdf_list_array* list, const void* value, rdf_out* out);
+rdf_status ora_list_position(const rdf_list_array* list, const void* value, rdf_out* out);
+rdf_status ora_list_max(const rdf_list_array* list, rdf_out* out);
+rdf_status ora_list_min(const rdf_list_array* list, rdf_out* out);
+rdf_status ora_list_remove(const rdf_list_array* list, const void* value, rdf_out* out_offsets, rdf_out* out_values);
+rdf_status ora_list_sort(const rdf_list_array* list, rdf_out* out_values);
+
 rdf_status ora_fill_uniform_f64(double* ptr, int64_t n, uint64_t seed, uint64_t column_id,
                                 int64_t first_row, double lo, double hi);
 rdf_status ora_fill_uniform_i64(int64_t* ptr, int64_t n, uint64_t seed, uint64_t column_id,

@@ -89,6 +89,10 @@ MAX_GROUP_VALUES = 8
 MAX_GROUP_SLOTS = 1024
 
 
+class rdf_list_array(C.Structure):
+    _fields_ = [("offsets", rdf_array), ("values", rdf_array)]
+
+
 class RdfError(Exception):
     """A non-OK rdf_status: DataFrameError / ArrowError as values (src/error.rs:6-15)."""
 
@@ -219,6 +223,58 @@ class DeviceArray:
         return rdf_out(self.values_ptr, self.validity_ptr, self.capacity, 0, 0, self.dtype, MEM_DEVICE)
 
 
+@dataclass
+class HostList:
+    """A ListArray with primitive children on the host: value_offsets (int32, rows + 1, possibly behind a row offset),
+    optional list validity, child values (a HostArray)."""
+    offsets: np.ndarray
+    values: "HostArray"
+    validity: Optional[np.ndarray] = None   # packed bits
+    offset: int = 0
+    length: int = 0
+
+    @staticmethod
+    def from_lists(rows, dtype: int, row_offset: int = 0, rng=None) -> "HostList":
+        """rows: list of (list of numbers | None)."""
+        pre = [[0] * 3] * row_offset     # dummy rows in front when a slice offset is requested
+        allrows = pre + list(rows)
+        offs = np.zeros(len(allrows) + 1, dtype=np.int32)
+        flat = []
+        for i, r in enumerate(allrows):
+            flat.extend([] if r is None else list(r))
+            offs[i + 1] = len(flat)
+        vals = HostArray.from_numpy(np.array(flat, dtype=NP_OF[dtype]) if flat else np.zeros(0, dtype=NP_OF[dtype]), dtype=dtype)
+        valid = None
+        if any(r is None for r in rows):
+            bits = np.array([True] * row_offset + [r is not None for r in rows])
+            valid = pack_bits(bits)
+        return HostList(offs, vals, valid, row_offset, len(rows))
+
+    def c_struct(self) -> "rdf_list_array":
+        o = rdf_array(self.offsets.ctypes.data, self.validity.ctypes.data if self.validity is not None else None, self.offset,
+                      self.length + 1, -1 if self.validity is not None else 0, I32, MEM_HOST)
+        return rdf_list_array(o, self.values.c_struct())
+
+    def row_slices(self):
+        o = self.offsets[self.offset:self.offset + self.length + 1]
+        return [(int(o[i]), int(o[i + 1])) for i in range(self.length)]
+
+
+@dataclass
+class DeviceList:
+    """A ListArray resident in HBM: device pointers of the int32 value_offsets (rows + 1) and of the child values."""
+    offsets_ptr: int
+    length: int
+    values: "DeviceArray"
+    validity_ptr: Optional[int] = None
+    offset: int = 0
+    keep: object = None
+
+    def c_struct(self) -> "rdf_list_array":
+        o = rdf_array(self.offsets_ptr, self.validity_ptr, self.offset, self.length + 1, -1 if self.validity_ptr else 0, I32, MEM_DEVICE)
+        return rdf_list_array(o, self.values.c_struct())
+
+
 # ---------------------------------------------------------------- expression trees
 class Expr:
     """Builder for rdf_expr_node arrays; mirrors BooleanFilter / Scalar (src/expression.rs:718-763)."""
@@ -292,7 +348,7 @@ class Api:
         self._err = getattr(lib, prefix + "last_error")
         self._err.restype = C.c_char_p
         for name in ("binary", "unary", "cast", "sum", "min", "max", "count", "avg", "predicate", "filter_count",
-                     "filter", "filter_columns", "take", "pipeline", "group_pipeline", "groupby_sum", "sort_to_indices", "equijoin_indices", "fill_uniform_f64",
+                     "filter", "filter_columns", "take", "pipeline", "group_pipeline", "groupby_sum", "list_contains", "list_position", "list_max", "list_min", "list_remove", "list_sort", "sort_to_indices", "equijoin_indices", "fill_uniform_f64",
                      "fill_uniform_i64", "fill_validity"):
             fn = getattr(lib, prefix + name)
             fn.restype = C.c_int
@@ -505,6 +561,47 @@ class Api:
             o.length = cc[0].length
             o.null_count = cc[0].null_count
         return outs
+
+    # ---- ArrayFunctions over List<primitive> (src/functions/array.rs)
+    def _scalar(self, value, dtype: int):
+        return np.array([value], dtype=NP_OF.get(dtype, np.int64))   # an unsupported child dtype is the library's to reject
+
+    def list_contains(self, lst, value, out=None):
+        out = out if out is not None else HostArray.empty_out(BOOL, lst.length, True)
+        carr = (rdf_out * 1)(out.out_struct())
+        v = self._scalar(value, lst.values.dtype)
+        self._check(self._fn("list_contains")(C.byref(lst.c_struct()), C.c_void_p(v.ctypes.data), carr))
+        return self._finish([out], carr)[0]
+
+    def list_position(self, lst, value, out=None):
+        out = out if out is not None else HostArray.empty_out(I32, lst.length, False)
+        carr = (rdf_out * 1)(out.out_struct())
+        v = self._scalar(value, lst.values.dtype)
+        self._check(self._fn("list_position")(C.byref(lst.c_struct()), C.c_void_p(v.ctypes.data), carr))
+        return self._finish([out], carr)[0]
+
+    def list_extreme(self, lst, want_max: bool, out=None):
+        out = out if out is not None else HostArray.empty_out(lst.values.dtype, lst.length, True)
+        carr = (rdf_out * 1)(out.out_struct())
+        self._check(self._fn("list_max" if want_max else "list_min")(C.byref(lst.c_struct()), carr))
+        return self._finish([out], carr)[0]
+
+    def list_remove(self, lst, value, outs=None):
+        """-> (offsets int32 [rows + 1], values)"""
+        oo, ov = outs if outs is not None else (HostArray.empty_out(I32, lst.length + 1, False),
+                                                HostArray.empty_out(lst.values.dtype, max(1, lst.values.length), False))
+        co, cv = (rdf_out * 1)(oo.out_struct()), (rdf_out * 1)(ov.out_struct())
+        v = self._scalar(value, lst.values.dtype)
+        self._check(self._fn("list_remove")(C.byref(lst.c_struct()), C.c_void_p(v.ctypes.data), co, cv))
+        self._finish([oo], co)
+        self._finish([ov], cv)
+        return oo, ov
+
+    def list_sort(self, lst, out=None):
+        ov = out if out is not None else HostArray.empty_out(lst.values.dtype, max(1, lst.values.length), False)
+        cv = (rdf_out * 1)(ov.out_struct())
+        self._check(self._fn("list_sort")(C.byref(lst.c_struct()), cv))
+        return self._finish([ov], cv)[0]
 
     # ---- fused grouped aggregation over a small dense domain (TPC-H Q1 shape)
     def group_pipeline(self, expr: Expr, cols: Sequence[Sequence], value_roots: Sequence[int], group_root: int, ngroups: int,

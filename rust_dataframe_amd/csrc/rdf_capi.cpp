@@ -1793,6 +1793,241 @@ rdf_status rdf_take(const rdf_array* chunks, int64_t nchunks, const rdf_array* i
     return RDF_OK;
 }
 
+// ---------------------------------------------------------------- ArrayFunctions over List<primitive>
+
+namespace {
+rdf_status list_check(const rdf_list_array* l, const char* fn, int64_t* rows, int32_t* mem) {
+    if (!l) return fail(RDF_INVALID_ARGUMENT, "%s: null list", fn);
+    if (l->offsets.dtype != RDF_I32) return fail(RDF_INVALID_ARGUMENT, "%s: value_offsets must be Int32", fn);
+    if (l->offsets.length < 1) return fail(RDF_INVALID_ARGUMENT, "%s: value_offsets hold rows + 1 entries", fn);
+    if (!is_numeric(l->values.dtype)) return fail(RDF_INVALID_ARGUMENT, "%s: primitive numeric child values only", fn);
+    *rows = l->offsets.length - 1;
+    *mem = -1;
+    RDF_TRY(check_mem(&l->offsets, 1, mem));
+    RDF_TRY(check_mem(&l->values, 1, mem));
+    return RDF_OK;
+}
+uint64_t scalar_bits(const void* value, int dt) {
+    uint64_t b = 0;
+    memcpy(&b, value, (size_t)dtype_size(dt));
+    return h_normalize_int(dt == RDF_F32 || dt == RDF_F64 ? RDF_U64 : dt, b);
+}
+// the four per-row reductions: contains / position / max / min
+rdf_status list_reduce(const rdf_list_array* l, int op, const void* value, rdf_out* out, const char* fn) {
+    int64_t n = 0;
+    int32_t mem = -1;
+    RDF_TRY(list_check(l, fn, &n, &mem));
+    if (!out) return fail(RDF_INVALID_ARGUMENT, "%s: null output", fn);
+    if ((op == LIST_CONTAINS || op == LIST_POSITION) && !value) return fail(RDF_INVALID_ARGUMENT, "%s: null value pointer", fn);
+    const int cdt = l->values.dtype;
+    const int odt = op == LIST_CONTAINS ? RDF_BOOL : op == LIST_POSITION ? RDF_I32 : cdt;
+    if (out->dtype != odt) return fail(RDF_INVALID_ARGUMENT, "%s: output dtype %d expected", fn, odt);
+    RDF_TRY(check_out_mem(out, 1, mem));
+    if (out->capacity < n) return fail(RDF_MEMORY_ERROR, "output capacity too small");
+    const bool nullable = op != LIST_POSITION && (l->offsets.validity != nullptr || op == LIST_MAX || op == LIST_MIN);
+    if (nullable && !out->validity) return fail(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    if (n == 0) { out->length = 0; out->null_count = 0; return RDF_OK; }
+    RDF_TRY(ensure_ready());
+    Ctx& ctx = g_ctx;
+    arena_begin();
+    size_t pin_off = 0, used = 0;
+    // value_offsets (n + 1 entries) and the list validity (n bits) are staged as two arrays: the bitmap is not read past bit n
+    rdf_array offs = l->offsets, lv = l->offsets;
+    offs.length = n + 1; offs.validity = nullptr; offs.null_count = 0;
+    lv.values = l->offsets.validity; lv.validity = nullptr; lv.dtype = RDF_BOOL; lv.length = n; lv.null_count = 0;
+    InputStager in;
+    in.add(&offs);
+    in.add(&l->values);
+    if (l->offsets.validity) in.add(&lv);
+    RDF_TRY(in.finish(pin_off, &used));
+    pin_off += (used + 255) & ~(size_t)255;
+    const size_t es = odt == RDF_BOOL ? 0 : (size_t)dtype_size(odt);
+    const size_t vbytes = odt == RDF_BOOL ? (size_t)((n + 63) / 64 * 8) : (size_t)n * es, bbytes = (size_t)((n + 63) / 64 * 8);
+    Region outr;
+    int vi = -1, bi = -1;
+    DevOutChunk doc;
+    if (mem == RDF_MEM_HOST) {
+        vi = outr.add(out->values, odt == RDF_BOOL ? (size_t)((n + 7) / 8) : vbytes);
+        if (out->validity) bi = outr.add(out->validity, (size_t)((n + 7) / 8));
+        RDF_TRY(outr.layout());
+        doc.values = outr.ptr(vi);
+        doc.validity = bi >= 0 ? (uint8_t*)outr.ptr(bi) : nullptr;
+    } else doc = DevOutChunk{out->values, out->validity};
+    void* p = nullptr;
+    RDF_TRY(arena_alloc(32, &p));
+    HIP_TRY(hipMemsetAsync(p, 0, 32, ctx.stream));
+    const int64_t nvals = l->values.length;
+    const bool wave_per_row = nvals / n >= 48;   // long lists: a wave per row; short lists: a row per lane
+    if (wave_per_row) {   // bitmap outputs are OR-ed in bit by bit
+        if (odt == RDF_BOOL) HIP_TRY(hipMemsetAsync(doc.values, 0, mem == RDF_MEM_HOST ? (size_t)((n + 7) / 8) : vbytes, ctx.stream));
+        if (doc.validity) HIP_TRY(hipMemsetAsync(doc.validity, 0, mem == RDF_MEM_HOST ? (size_t)((n + 7) / 8) : bbytes, ctx.stream));
+    }
+    ListArgs la;
+    memset(&la, 0, sizeof la);
+    la.offsets = in.dev[0];
+    if (l->offsets.validity) la.offsets.validity = (const uint8_t*)in.dev[2].values;   // same bit offset as the value_offsets by construction
+    la.values = in.dev[1];
+    la.n = n;
+    la.dtype = cdt;
+    la.op = op;
+    la.needle = value ? scalar_bits(value, cdt) : 0;
+    la.out = doc;
+    la.out_null_count = (int64_t*)((char*)p + 16);
+    {
+        KernelTimer kt;
+        ctx.last_kernel = wave_per_row ? "list_wave_kernel" : "list_rows_kernel";
+        HIP_TRY(launch_list_op(la, wave_per_row, ctx.stream));
+        kt.stop();
+    }
+    RDF_TRY(pinned_reserve(pin_off + 256 + outr.small_bytes + 256));
+    char* pin = ctx.pinned + pin_off;
+    HIP_TRY(hipMemcpyAsync(pin, p, 32, hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    if (mem == RDF_MEM_HOST) RDF_TRY(outr.download(pin_off + 256));
+    out->length = n;
+    memcpy(&out->null_count, pin + 16, 8);
+    return RDF_OK;
+}
+}  // namespace
+
+rdf_status rdf_list_contains(const rdf_list_array* list, const void* value, rdf_out* out) { return list_reduce(list, LIST_CONTAINS, value, out, "array_contains"); }
+rdf_status rdf_list_position(const rdf_list_array* list, const void* value, rdf_out* out) { return list_reduce(list, LIST_POSITION, value, out, "array_position"); }
+rdf_status rdf_list_max(const rdf_list_array* list, rdf_out* out) { return list_reduce(list, LIST_MAX, nullptr, out, "array_max"); }
+rdf_status rdf_list_min(const rdf_list_array* list, rdf_out* out) { return list_reduce(list, LIST_MIN, nullptr, out, "array_min"); }
+
+rdf_status rdf_list_remove(const rdf_list_array* list, const void* value, rdf_out* out_offsets, rdf_out* out_values) {
+    int64_t n = 0;
+    int32_t mem = -1;
+    RDF_TRY(list_check(list, "array_remove", &n, &mem));
+    if (!value || !out_offsets || !out_values) return fail(RDF_INVALID_ARGUMENT, "array_remove: null argument");
+    const int cdt = list->values.dtype;
+    if (out_offsets->dtype != RDF_I32 || out_values->dtype != cdt) return fail(RDF_INVALID_ARGUMENT, "array_remove: outputs are (Int32 offsets, child dtype values)");
+    RDF_TRY(check_out_mem(out_offsets, 1, mem));
+    RDF_TRY(check_out_mem(out_values, 1, mem));
+    if (out_offsets->capacity < n + 1) return fail(RDF_MEMORY_ERROR, "output capacity too small (offsets need rows + 1)");
+    RDF_TRY(ensure_ready());
+    Ctx& ctx = g_ctx;
+    arena_begin();
+    size_t pin_off = 0, used = 0;
+    rdf_array offs = list->offsets, lv = list->offsets;
+    offs.length = n + 1; offs.validity = nullptr; offs.null_count = 0;
+    lv.values = list->offsets.validity; lv.validity = nullptr; lv.dtype = RDF_BOOL; lv.length = n; lv.null_count = 0;
+    InputStager in;
+    in.add(&offs);
+    in.add(&list->values);
+    if (list->offsets.validity) in.add(&lv);
+    RDF_TRY(in.finish(pin_off, &used));
+    pin_off += (used + 255) & ~(size_t)255;
+    void *pkept, *pscan, *poff32;
+    RDF_TRY(arena_alloc((size_t)(n + 1) * 8, &pkept));
+    RDF_TRY(arena_alloc((size_t)(n + 2 + scan_scratch_words(n)) * 8, &pscan));
+    RDF_TRY(arena_alloc((size_t)(n + 1) * 4 + 8, &poff32));
+    ListArgs la;
+    memset(&la, 0, sizeof la);
+    la.offsets = in.dev[0];
+    if (list->offsets.validity) la.offsets.validity = (const uint8_t*)in.dev[2].values;
+    la.values = in.dev[1];
+    la.n = n;
+    la.dtype = cdt;
+    la.needle = scalar_bits(value, cdt);
+    la.kept = (int64_t*)pkept;
+    const bool wave_per_row = n > 0 && list->values.length / n >= 48;
+    KernelTimer kt;
+    ctx.last_kernel = wave_per_row ? "list_remove_wave_kernel" : "list_remove_kernel";
+    HIP_TRY(launch_list_remove(la, wave_per_row, ctx.stream));
+    HIP_TRY(launch_scan((const int64_t*)pkept, (int64_t*)pscan, n, (int64_t*)pscan + n + 1, ctx.stream));
+    HIP_TRY(launch_list_offsets((const int64_t*)pscan, n + 1, (int32_t*)poff32, ctx.stream));
+    RDF_TRY(pinned_reserve(pin_off + 64));
+    HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, (int64_t*)pscan + n, 8, hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    int64_t total = 0;
+    memcpy(&total, ctx.pinned + pin_off, 8);
+    if (out_values->capacity < total) return fail(RDF_MEMORY_ERROR, "array_remove: values capacity too small (need %lld)", (long long)total);
+    const size_t es = (size_t)dtype_size(cdt);
+    void* dvals = out_values->values;
+    if (mem == RDF_MEM_HOST) RDF_TRY(arena_alloc((size_t)total * es + 64, &dvals));
+    la.scan = (const int64_t*)pscan;
+    la.out = DevOutChunk{dvals, nullptr};
+    HIP_TRY(launch_list_remove(la, wave_per_row, ctx.stream));
+    kt.stop();
+    const hipMemcpyKind kind = mem == RDF_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIP_TRY(hipMemcpyAsync(out_offsets->values, poff32, (size_t)(n + 1) * 4, kind, ctx.stream));
+    if (mem == RDF_MEM_HOST && total > 0) HIP_TRY(hipMemcpyAsync(out_values->values, dvals, (size_t)total * es, kind, ctx.stream));
+    for (rdf_out* o : {out_offsets, out_values})
+        if (o->validity) {
+            const int64_t len = o == out_offsets ? n + 1 : total;
+            if (mem == RDF_MEM_HOST) memset(o->validity, 0xFF, (size_t)((len + 7) / 8));
+            else HIP_TRY(hipMemsetAsync(o->validity, 0xFF, (size_t)((len + 7) / 8), ctx.stream));
+        }
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    out_offsets->length = n + 1; out_offsets->null_count = 0;
+    out_values->length = total; out_values->null_count = 0;
+    return RDF_OK;
+}
+
+// array_sort = a two-column sort of the child elements by (row number, value), composed from the public entry points
+rdf_status rdf_list_sort(const rdf_list_array* list, rdf_out* out_values) {
+    int64_t n = 0;
+    int32_t mem = -1;
+    RDF_TRY(list_check(list, "array_sort", &n, &mem));
+    if (!out_values) return fail(RDF_INVALID_ARGUMENT, "array_sort: null output");
+    const int cdt = list->values.dtype;
+    if (out_values->dtype != cdt) return fail(RDF_INVALID_ARGUMENT, "array_sort: output must have the child dtype");
+    RDF_TRY(check_out_mem(out_values, 1, mem));
+    RDF_TRY(ensure_ready());
+    Ctx& ctx = g_ctx;
+    // the slice range [first, last) covered by rows 0 .. n-1
+    int32_t ends[2] = {0, 0};
+    const int32_t* hoff = (const int32_t*)list->offsets.values + list->offsets.offset;
+    if (mem == RDF_MEM_HOST) { ends[0] = hoff[0]; ends[1] = hoff[n]; }
+    else { RDF_TRY(rdf_copy_d2h(&ends[0], hoff, 4)); RDF_TRY(rdf_copy_d2h(&ends[1], hoff + n, 4)); }
+    const int64_t first = ends[0], total = (int64_t)ends[1] - ends[0];
+    if (total < 0 || ends[1] > list->values.length) return fail(RDF_INVALID_ARGUMENT, "array_sort: value_offsets outside the child array");
+    if (out_values->capacity < total) return fail(RDF_MEMORY_ERROR, "output capacity too small");
+    if (total == 0) { out_values->length = 0; out_values->null_count = 0; return RDF_OK; }
+    if (total >= (int64_t)1 << 32) return fail(RDF_INVALID_ARGUMENT, "array_sort: more than 2^32-1 child elements");
+    const size_t es = (size_t)dtype_size(cdt);
+    struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } t_off, t_vals, t_rows, t_idx, t_out;
+    HIP_TRY(hipMalloc(&t_rows.p, (size_t)total * 4 + 64));
+    HIP_TRY(hipMalloc(&t_idx.p, (size_t)total * 4 + 64));
+    // device views of the value_offsets and of the child slice
+    rdf_array doffs = list->offsets, dvals = list->values;
+    if (mem == RDF_MEM_HOST) {
+        HIP_TRY(hipMalloc(&t_off.p, (size_t)(n + 1) * 4 + 64));
+        HIP_TRY(hipMalloc(&t_vals.p, (size_t)total * es + 64));
+        RDF_TRY(rdf_copy_h2d(t_off.p, hoff, (n + 1) * 4));
+        RDF_TRY(rdf_copy_h2d(t_vals.p, (const char*)list->values.values + (size_t)(list->values.offset + first) * es, total * (int64_t)es));
+        doffs.values = t_off.p; doffs.offset = 0;
+        dvals.values = t_vals.p; dvals.offset = 0;
+    } else dvals.offset = list->values.offset + first;
+    dvals.length = total; dvals.validity = nullptr; dvals.null_count = 0; dvals.mem = RDF_MEM_DEVICE;
+    ListArgs la;
+    memset(&la, 0, sizeof la);
+    la.offsets = DevChunkCol{doffs.values, nullptr, doffs.offset};
+    la.n = n;
+    HIP_TRY(launch_list_row_ids(la, (uint32_t*)t_rows.p, (int32_t)first, ctx.stream));
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    rdf_array cols[2];
+    cols[0] = rdf_array{t_rows.p, nullptr, 0, total, 0, RDF_U32, RDF_MEM_DEVICE};
+    cols[1] = dvals;
+    rdf_out oi{t_idx.p, nullptr, total, 0, 0, RDF_U32, RDF_MEM_DEVICE};
+    RDF_TRY(rdf_sort_to_indices(cols, 2, 1, nullptr, &oi));
+    rdf_array idx{t_idx.p, nullptr, 0, total, 0, RDF_U32, RDF_MEM_DEVICE};
+    rdf_out ov = *out_values;
+    if (mem == RDF_MEM_HOST) { HIP_TRY(hipMalloc(&t_out.p, (size_t)total * es + 64)); ov.values = t_out.p; ov.validity = nullptr; ov.mem = RDF_MEM_DEVICE; }
+    else ov.validity = nullptr;
+    RDF_TRY(rdf_take(&dvals, 1, &idx, &ov));
+    if (mem == RDF_MEM_HOST) RDF_TRY(rdf_copy_d2h(out_values->values, t_out.p, total * (int64_t)es));
+    if (out_values->validity) {
+        if (mem == RDF_MEM_HOST) memset(out_values->validity, 0xFF, (size_t)((total + 7) / 8));
+        else { HIP_TRY(hipMemsetAsync(out_values->validity, 0xFF, (size_t)((total + 7) / 8), ctx.stream)); HIP_TRY(hipStreamSynchronize(ctx.stream)); }
+    }
+    out_values->length = total;
+    out_values->null_count = 0;
+    ctx.last_kernel = "list_row_ids_kernel + sort_scatter_kernel + take_kernel";
+    return RDF_OK;
+}
+
 // ---------------------------------------------------------------- sort
 
 namespace {

@@ -317,6 +317,24 @@ struct TakeArgs {
     int32_t            esize, idx64;
 };
 
+// ArrayFunctions over List<primitive> (rdf_list.hip)
+enum : int32_t { LIST_CONTAINS = 0, LIST_POSITION = 1, LIST_MAX = 2, LIST_MIN = 3 };
+struct ListArgs {
+    DevChunkCol offsets;     // int32 value_offsets [n + 1]; its validity bits are the LIST rows' validity
+    DevChunkCol values;      // child values
+    int64_t     n;           // list rows
+    int32_t     dtype, op;   // child dtype, LIST_*
+    uint64_t    needle;      // contains / position: the value, as raw bits of the child dtype
+    DevOutChunk out;
+    int64_t*    out_null_count;
+    int64_t*    kept;        // array_remove pass 1 out: kept elements per row
+    const int64_t* scan;     // array_remove pass 2 in: their exclusive scan (nullptr selects pass 1)
+};
+hipError_t launch_list_op(const ListArgs& a, bool wave_per_row, hipStream_t s);
+hipError_t launch_list_row_ids(const ListArgs& a, uint32_t* row_ids, int32_t first, hipStream_t s);
+hipError_t launch_list_remove(const ListArgs& a, bool wave_per_row, hipStream_t s);
+hipError_t launch_list_offsets(const int64_t* scan, int64_t n1, int32_t* out, hipStream_t s);
+
 // ---- launch wrappers (defined in rdf_kernels.hip) ----
 int  eval_grid_limit();   // persistent grid size for streaming kernels
 hipError_t launch_eval(const EvalArgs& a, int sink, int feat, int grid, hipStream_t s);  // feat: 0 basic, 1 +int div, 2 +libm

@@ -42,7 +42,7 @@ def arr(t, dtype, n, validity=None):
 
 
 def out_like(dtype, n, with_validity=False):
-    es = {A.F64: 8, A.I64: 8, A.U32: 4, A.BOOL: 0}[dtype]
+    es = {A.F64: 8, A.I64: 8, A.U32: 4, A.I32: 4, A.BOOL: 0}[dtype]
     pad = (n + 63) // 64 * 64
     v = torch.empty(pad * es if es else pad // 8 + 8, dtype=torch.uint8, device="cuda")
     b = torch.empty(pad // 8 + 8, dtype=torch.uint8, device="cuda") if with_validity else None
@@ -187,6 +187,29 @@ def main():
     report("sort_to_indices_i64_full_range", 8.0 * ns, lambda: api.sort_to_indices([[arr(kw, A.I64, ns)]], [False], oi))
     kd = dev_i64(ns, 10, 0, 200)
     report("sort_to_indices_i64_dictionary_codes", 8.0 * ns, lambda: api.sort_to_indices([[arr(kd, A.I64, ns)]], [False], oi))
+    # ArrayFunctions over a List<f64> column: rows of 10 elements (one row per lane) and of 1000 elements (one row per wave)
+    for rl in (10, 1000):
+        nm = f"list_rows_of_{rl}"
+        if only and not any(k.startswith(nm) for k in only):
+            continue
+        nv = min(n, 200_000_000) // rl * rl
+        nr = nv // rl
+        lo_ = (torch.arange(0, nr + 1, device="cuda", dtype=torch.int64) * rl).to(torch.int32)
+        lv_ = torch.floor(dev_f64(nv, 13, 0.0, 50.0))
+        L = A.DeviceList(lo_.data_ptr(), nr, arr(lv_, A.F64, nv), keep=(lo_, lv_))
+        ob, op, om = out_like(A.BOOL, nr, True), out_like(A.I32, nr), out_like(A.F64, nr, True)
+        lbytes = 8.0 * nv + 4.0 * nr
+        report(nm + "_contains", lbytes, lambda: api.list_contains(L, 7.0, ob))
+        report(nm + "_position", lbytes + 4.0 * nr, lambda: api.list_position(L, 7.0, op))
+        report(nm + "_max", lbytes + 8.0 * nr, lambda: api.list_extreme(L, True, om))
+        oro, orv = out_like(A.I32, nr + 1), out_like(A.F64, nv)
+        report(nm + "_remove", 2 * lbytes + 8.0 * nv * 0.98 + 4.0 * nr, lambda: api.list_remove(L, 7.0, (oro, orv)))
+        if rl == 10:
+            nsort = min(nv, 50_000_000)
+            Ls = A.DeviceList(lo_.data_ptr(), nsort // rl, arr(lv_, A.F64, nsort), keep=(lo_, lv_))
+            osv = out_like(A.F64, nsort)
+            report(nm + "_sort", 16.0 * nsort, lambda: api.list_sort(Ls, osv))
+        del lo_, lv_
     # DataFrame::join: 1e8 probe rows against 1e7 distinct build keys (inner: every probe row finds exactly one partner)
     if not only or "join_inner_1e8_x_1e7" in only:
         nl_, nr_ = min(n, 100_000_000), 10_000_000
