@@ -1046,19 +1046,25 @@ class DataFrame {
         }
         return DataFrame(schema_, std::move(result));
     }
-    // DataFrame::join (:626-719): equi-join indices on ONE key column per side, then Column::take of every column
+    // DataFrame::join (:626-719): equi-join indices on 1..4 key column pairs, then Column::take of every column
     // of both frames (left columns first).  JoinType as src/expression.rs:339-345.
     enum class JoinType { LeftJoin = RDF_JOIN_LEFT, RightJoin = RDF_JOIN_RIGHT, InnerJoin = RDF_JOIN_INNER, FullJoin = RDF_JOIN_FULL };
     struct JoinCriteria { JoinType join_type; std::vector<std::pair<std::string, std::string>> criteria; };
     DataFrame join(const DataFrame& other, const JoinCriteria& jc) const {
-        if (jc.criteria.size() != 1) throw DataFrameError(DataFrameError::ComputeError, "join: one key column per side on the accelerated path");
-        const auto lk = column_by_name(jc.criteria[0].first).data().views();
-        const auto rk = other.column_by_name(jc.criteria[0].second).data().views();
+        if (jc.criteria.empty() || jc.criteria.size() > 4) throw DataFrameError(DataFrameError::ComputeError, "join: 1 to 4 key column pairs");
+        // key pair k: this[criteria[k].first] against other[criteria[k].second], laid out [k * nchunks + chunk]
+        std::vector<rdf_array> lk, rk;
+        for (auto& c : jc.criteria) {
+            for (auto& v : column_by_name(c.first).data().views()) lk.push_back(v);
+            for (auto& v : other.column_by_name(c.second).data().views()) rk.push_back(v);
+        }
+        const int32_t nk = (int32_t)jc.criteria.size();
+        const int64_t lnc = (int64_t)num_chunks(), rnc = (int64_t)other.num_chunks();
         int64_t rows = 0;
-        check(rdf_equijoin_indices(lk.data(), (int64_t)lk.size(), rk.data(), (int64_t)rk.size(), (int32_t)jc.join_type, nullptr, nullptr, &rows));
+        check(rdf_equijoin_indices_multi(lk.data(), lnc, rk.data(), rnc, nk, (int32_t)jc.join_type, nullptr, nullptr, &rows));
         auto li = Array::make_out(DataType::UInt32, rows, true), ri = Array::make_out(DataType::UInt32, rows, true);
         rdf_out lo = li->out_view(rows), ro = ri->out_view(rows);
-        check(rdf_equijoin_indices(lk.data(), (int64_t)lk.size(), rk.data(), (int64_t)rk.size(), (int32_t)jc.join_type, &lo, &ro, &rows));
+        check(rdf_equijoin_indices_multi(lk.data(), lnc, rk.data(), rnc, nk, (int32_t)jc.join_type, &lo, &ro, &rows));
         li->length = ri->length = rows;
         li->null_count = lo.null_count; ri->null_count = ro.null_count;
         std::vector<Column> cols;

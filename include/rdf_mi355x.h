@@ -215,6 +215,13 @@ typedef enum { RDF_JOIN_LEFT = 0, RDF_JOIN_RIGHT = 1, RDF_JOIN_INNER = 2, RDF_JO
 rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks, const rdf_array* right_keys,
                                 int64_t right_nchunks, int32_t join_type, rdf_out* out_left, rdf_out* out_right,
                                 int64_t* out_rows);
+/* The same for 1..4 key columns per side (JoinCriteria.criteria holds a Vec of column pairs, src/expression.rs:332-337;
+ * build_hash_inputs hashes the tuple, src/functions/join.rs:139-235): left_keys[k * left_nchunks + i] pairs with
+ * right_keys[k * right_nchunks + i]; pair k shares one dtype; a row with a NULL in any key column never matches.
+ * Rows are matched through a 64-bit hash of the tuple and every candidate pair is verified column by column. */
+rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_nchunks, const rdf_array* right_keys,
+                                      int64_t right_nchunks, int32_t nkeys, int32_t join_type, rdf_out* out_left,
+                                      rdf_out* out_right, int64_t* out_rows);
 
 /* ------------------------------------------------------------------ group-by */
 

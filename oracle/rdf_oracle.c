@@ -1228,17 +1228,20 @@ static void join_locate(const rdf_array* chunks, int64_t nchunks, int64_t row, c
     while (c + 1 < nchunks && row >= chunks[c].length) { row -= chunks[c].length; c++; }
     *a = &chunks[c]; *i = row;
 }
-rdf_status ora_equijoin_indices(const rdf_array* lk, int64_t lnc, const rdf_array* rk, int64_t rnc, int32_t jt,
-                                rdf_out* out_left, rdf_out* out_right, int64_t* out_rows) {
+rdf_status ora_equijoin_indices_multi(const rdf_array* lk, int64_t lnc, const rdf_array* rk, int64_t rnc, int32_t nkeys, int32_t jt,
+                                      rdf_out* out_left, rdf_out* out_right, int64_t* out_rows) {
+    if (nkeys < 1 || nkeys > 4) FAIL(RDF_INVALID_ARGUMENT, "join: 1 to 4 key columns per side");
     int64_t nl = 0, nr = 0;
     for (int64_t c = 0; c < lnc; c++) nl += lk[c].length;
     for (int64_t c = 0; c < rnc; c++) nr += rk[c].length;
     int swap = jt == RDF_JOIN_RIGHT, outer = jt != RDF_JOIN_INNER, full = jt == RDF_JOIN_FULL;
     const rdf_array* pk = swap ? rk : lk; const rdf_array* bk = swap ? lk : rk;
     int64_t pnc = swap ? rnc : lnc, bnc = swap ? lnc : rnc, np = swap ? nr : nl, nb = swap ? nl : nr;
-    uint64_t* bbits = (uint64_t*)malloc((size_t)(nb + 1) * 8); uint8_t* bnull = (uint8_t*)calloc((size_t)nb + 1, 1);
+    /* key tuples as order-preserving bits, one row of nkeys words per table row; a NULL in any key column = NULL key */
+    uint64_t* bbits = (uint64_t*)malloc((size_t)(nb + 1) * 8 * (size_t)nkeys); uint8_t* bnull = (uint8_t*)calloc((size_t)nb + 1, 1);
     uint8_t* bmatched = (uint8_t*)calloc((size_t)nb + 1, 1);
-    for (int64_t j = 0; j < nb; j++) { const rdf_array* a; int64_t i; int w; join_locate(bk, bnc, j, &a, &i); bnull[j] = !arr_valid(a, i); bbits[j] = sort_bits(a, i, &w); }
+    for (int64_t j = 0; j < nb; j++)
+        for (int k = 0; k < nkeys; k++) { const rdf_array* a; int64_t i; int w; join_locate(bk + (int64_t)k * bnc, bnc, j, &a, &i); bnull[j] |= !arr_valid(a, i); bbits[j * nkeys + k] = sort_bits(a, i, &w); }
     rdf_out* op = swap ? out_right : out_left; rdf_out* ob = swap ? out_left : out_right;
     int64_t rows = 0; rdf_status st = RDF_OK;
     for (int pass = 0; pass < 2 && st == RDF_OK; pass++) {   /* pass 0 counts, pass 1 writes */
@@ -1251,9 +1254,13 @@ rdf_status ora_equijoin_indices(const rdf_array* lk, int64_t lnc, const rdf_arra
         }
         int64_t o = 0;
         for (int64_t x = 0; x < np; x++) {
-            const rdf_array* a; int64_t i; int w; join_locate(pk, pnc, x, &a, &i);
-            int pn = !arr_valid(a, i); uint64_t bits = sort_bits(a, i, &w); int64_t m = 0;
-            if (!pn) for (int64_t j = 0; j < nb; j++) if (!bnull[j] && bbits[j] == bits) {
+            uint64_t bits[4]; int pn = 0; int64_t m = 0;
+            for (int k = 0; k < nkeys; k++) { const rdf_array* a; int64_t i; int w; join_locate(pk + (int64_t)k * pnc, pnc, x, &a, &i); pn |= !arr_valid(a, i); bits[k] = sort_bits(a, i, &w); }
+            if (!pn) for (int64_t j = 0; j < nb; j++) {
+                if (bnull[j]) continue;
+                int eq = 1;
+                for (int k = 0; k < nkeys; k++) eq &= bbits[j * nkeys + k] == bits[k];
+                if (!eq) continue;
                 if (pass == 1) { ((uint32_t*)op->values)[o] = (uint32_t)x; ((uint32_t*)ob->values)[o] = (uint32_t)j; }
                 bmatched[j] = 1; o++; m++;
             }
@@ -1267,6 +1274,10 @@ rdf_status ora_equijoin_indices(const rdf_array* lk, int64_t lnc, const rdf_arra
     }
     free(bbits); free(bnull); free(bmatched);
     return st;
+}
+rdf_status ora_equijoin_indices(const rdf_array* lk, int64_t lnc, const rdf_array* rk, int64_t rnc, int32_t jt,
+                                rdf_out* out_left, rdf_out* out_right, int64_t* out_rows) {
+    return ora_equijoin_indices_multi(lk, lnc, rk, rnc, 1, jt, out_left, out_right, out_rows);
 }
 
 /* ------------------------------------------------------------------ group-by

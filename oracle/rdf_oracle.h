@@ -52,6 +52,9 @@ rdf_status ora_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
 rdf_status ora_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks, const rdf_array* right_keys, int64_t right_nchunks,
                                 int32_t join_type, rdf_out* out_left, rdf_out* out_right, int64_t* out_rows);
 
+rdf_status ora_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_nchunks, const rdf_array* right_keys, int64_t right_nchunks,
+                                      int32_t nkeys, int32_t join_type, rdf_out* out_left, rdf_out* out_right, int64_t* out_rows);
+
 rdf_status ora_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,
                            rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts);
 

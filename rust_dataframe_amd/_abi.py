@@ -348,7 +348,7 @@ class Api:
         self._err = getattr(lib, prefix + "last_error")
         self._err.restype = C.c_char_p
         for name in ("binary", "unary", "cast", "sum", "min", "max", "count", "avg", "predicate", "filter_count",
-                     "filter", "filter_columns", "take", "pipeline", "group_pipeline", "groupby_sum", "list_contains", "list_position", "list_max", "list_min", "list_remove", "list_sort", "sort_to_indices", "equijoin_indices", "fill_uniform_f64",
+                     "filter", "filter_columns", "take", "pipeline", "group_pipeline", "groupby_sum", "list_contains", "list_position", "list_max", "list_min", "list_remove", "list_sort", "sort_to_indices", "equijoin_indices", "equijoin_indices_multi", "fill_uniform_f64",
                      "fill_uniform_i64", "fill_validity"):
             fn = getattr(lib, prefix + name)
             fn.restype = C.c_int
@@ -540,6 +540,21 @@ class Api:
         ol, orr = HostArray.empty_out(U32, rows.value, True), HostArray.empty_out(U32, rows.value, True)
         cl, cr = (rdf_out * 1)(ol.out_struct()), (rdf_out * 1)(orr.out_struct())
         self._check(self._fn("equijoin_indices")(lk, C.c_int64(len(left_keys)), rk, C.c_int64(len(right_keys)), C.c_int32(jt), cl, cr, C.byref(rows)))
+        self._finish([ol], cl)
+        self._finish([orr], cr)
+        return ol, orr
+
+    def equijoin_indices_multi(self, left_cols: Sequence[Sequence], right_cols: Sequence[Sequence], how: str):
+        """Several key columns per side: left_cols[k][chunk] pairs with right_cols[k][chunk]."""
+        jt = self.JOIN_TYPES[how]
+        rows = C.c_int64(0)
+        nk, lnc, rnc = len(left_cols), len(left_cols[0]), len(right_cols[0])
+        lk, rk = _flat(left_cols, lnc), _flat(right_cols, rnc)
+        fn = self._fn("equijoin_indices_multi")
+        self._check(fn(lk, C.c_int64(lnc), rk, C.c_int64(rnc), C.c_int32(nk), C.c_int32(jt), None, None, C.byref(rows)))
+        ol, orr = HostArray.empty_out(U32, rows.value, True), HostArray.empty_out(U32, rows.value, True)
+        cl, cr = (rdf_out * 1)(ol.out_struct()), (rdf_out * 1)(orr.out_struct())
+        self._check(fn(lk, C.c_int64(lnc), rk, C.c_int64(rnc), C.c_int32(nk), C.c_int32(jt), cl, cr, C.byref(rows)))
         self._finish([ol], cl)
         self._finish([orr], cr)
         return ol, orr

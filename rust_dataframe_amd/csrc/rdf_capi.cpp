@@ -2232,19 +2232,32 @@ rdf_status radix_sort_rows(const SortBuffers& b, int64_t n, int width, bool has_
 
 rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks, const rdf_array* right_keys, int64_t right_nchunks,
                                 int32_t join_type, rdf_out* out_left, rdf_out* out_right, int64_t* out_rows) {
+    return rdf_equijoin_indices_multi(left_keys, left_nchunks, right_keys, right_nchunks, 1, join_type, out_left, out_right, out_rows);
+}
+
+rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_nchunks, const rdf_array* right_keys, int64_t right_nchunks,
+                                      int32_t nkeys, int32_t join_type, rdf_out* out_left, rdf_out* out_right, int64_t* out_rows) {
     if (!left_keys || !right_keys || left_nchunks < 1 || right_nchunks < 1 || !out_rows) return fail(RDF_INVALID_ARGUMENT, "join: bad arguments");
+    if (nkeys < 1 || nkeys > 4) return fail(RDF_INVALID_ARGUMENT, "join: 1 to 4 key columns per side");
     if (join_type < RDF_JOIN_LEFT || join_type > RDF_JOIN_FULL) return fail(RDF_INVALID_ARGUMENT, "join: bad join type");
     if ((out_left == nullptr) != (out_right == nullptr)) return fail(RDF_INVALID_ARGUMENT, "join: give both outputs or neither (count only)");
     int32_t mem = -1;
-    RDF_TRY(check_mem(left_keys, left_nchunks, &mem));
-    RDF_TRY(check_mem(right_keys, right_nchunks, &mem));
+    RDF_TRY(check_mem(left_keys, (int64_t)nkeys * left_nchunks, &mem));
+    RDF_TRY(check_mem(right_keys, (int64_t)nkeys * right_nchunks, &mem));
     if (out_left) { RDF_TRY(check_out_mem(out_left, 1, mem)); RDF_TRY(check_out_mem(out_right, 1, mem)); }
-    const int dt = left_keys[0].dtype;
-    if (!is_numeric(dt)) return fail(RDF_INVALID_ARGUMENT, "join: numeric key columns only");
+    int kdt[4] = {0, 0, 0, 0};
     int64_t nleft = 0, nright = 0;
     bool lnulls = false, rnulls = false;
-    for (int64_t c = 0; c < left_nchunks; ++c) { if (left_keys[c].dtype != dt) return fail(RDF_INVALID_ARGUMENT, "join: key columns must share one dtype (cast first)"); nleft += left_keys[c].length; lnulls |= left_keys[c].validity != nullptr; }
-    for (int64_t c = 0; c < right_nchunks; ++c) { if (right_keys[c].dtype != dt) return fail(RDF_INVALID_ARGUMENT, "join: key columns must share one dtype (cast first)"); nright += right_keys[c].length; rnulls |= right_keys[c].validity != nullptr; }
+    for (int k = 0; k < nkeys; ++k) {   // key pair k: left_keys[k * left_nchunks + c] against right_keys[k * right_nchunks + c]
+        kdt[k] = left_keys[(int64_t)k * left_nchunks].dtype;
+        if (!is_numeric(kdt[k])) return fail(RDF_INVALID_ARGUMENT, "join: numeric key columns only");
+        int64_t nl = 0, nr = 0;
+        for (int64_t c = 0; c < left_nchunks; ++c) { const rdf_array& a = left_keys[(int64_t)k * left_nchunks + c]; if (a.dtype != kdt[k]) return fail(RDF_INVALID_ARGUMENT, "join: key columns must share one dtype (cast first)"); nl += a.length; lnulls |= a.validity != nullptr; }
+        for (int64_t c = 0; c < right_nchunks; ++c) { const rdf_array& a = right_keys[(int64_t)k * right_nchunks + c]; if (a.dtype != kdt[k]) return fail(RDF_INVALID_ARGUMENT, "join: key columns must share one dtype (cast first)"); nr += a.length; rnulls |= a.validity != nullptr; }
+        if (k == 0) { nleft = nl; nright = nr; }
+        else if (nl != nleft || nr != nright) return fail(RDF_COMPUTE_ERROR, "join: key columns of one side differ in length");
+    }
+    const int dt = kdt[0];
     if (nleft >= (int64_t)1 << 32 || nright >= (int64_t)1 << 32) return fail(RDF_INVALID_ARGUMENT, "join: UInt32 indices cap a side at 2^32-1 rows");
     if (out_left && (out_left->dtype != RDF_U32 || out_right->dtype != RDF_U32)) return fail(RDF_INVALID_ARGUMENT, "join: indices are UInt32");
     const bool swap = join_type == RDF_JOIN_RIGHT;  // probe = right, build = left
@@ -2264,9 +2277,9 @@ rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks
     Ctx& ctx = g_ctx;
     arena_begin();
     size_t pin_off = 0, used = 0;
-    InputStager in;
-    for (int64_t c = 0; c < pnc; ++c) in.add(&pk[c]);
-    for (int64_t c = 0; c < bnc; ++c) in.add(&bk[c]);
+    InputStager in;   // staged order: probe key 0 chunks, probe key 1 chunks, ..., then the build side the same way
+    for (int64_t c = 0; c < (int64_t)nkeys * pnc; ++c) in.add(&pk[c]);
+    for (int64_t c = 0; c < (int64_t)nkeys * bnc; ++c) in.add(&bk[c]);
     RDF_TRY(in.finish(pin_off, &used));
     pin_off += (used + 255) & ~(size_t)255;
     std::vector<int64_t> prs((size_t)pnc + 1, 0), brs((size_t)bnc + 1, 0);
@@ -2293,23 +2306,51 @@ rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks
     KernelTimer kt;
     int kcur = 0, icur = 0;
     uint64_t bkmin = 1, bkmax = 0;   // key range of the non-NULL build keys ([1, 0] = none)
+    const uint64_t* pbits[4] = {nullptr, nullptr, nullptr, nullptr};
+    const uint64_t* bbits[4] = {nullptr, nullptr, nullptr, nullptr};
+    // One column per side: the order-preserving key bits ARE the join key.  Several: the key is a 64-bit hash of the
+    // tuple's key bits (candidates are verified column by column in the probe kernels), NULL in any column = NULL key.
+    auto side_keys = [&](bool build, int64_t n, int64_t nch, size_t chunk0, const int64_t* d_row_start, bool has_nulls, uint64_t* out_keys,
+                         uint8_t* nullflags, uint64_t* d_stats, const uint64_t** bits_out) -> rdf_status {
+        if (nkeys > 1 && has_nulls) HIP_TRY(hipMemsetAsync(nullflags, 0, (size_t)n, ctx.stream));
+        JoinCombineArgs ca;
+        memset(&ca, 0, sizeof ca);
+        for (int k = 0; k < nkeys; ++k) {
+            SortKeyArgs ka;
+            memset(&ka, 0, sizeof ka);
+            ka.chunks = tb.dev_at<DevChunkCol>(o_ch) + chunk0 + (size_t)k * (size_t)nch;
+            ka.chunk_row_start = d_row_start;
+            ka.nchunks = nch;
+            ka.n = n;
+            ka.nullflags = has_nulls ? nullflags : nullptr;
+            ka.dtype = kdt[k];
+            if (nkeys == 1) { ka.keys = out_keys; ka.bit_stats = d_stats; }
+            else {
+                void* pb;
+                RDF_TRY(arena_alloc((size_t)n * 8 + 8, &pb));
+                ka.keys = (uint64_t*)pb;
+                ka.null_or = 1;
+                bits_out[k] = ca.bits[k] = (const uint64_t*)pb;
+            }
+            HIP_TRY(launch_sort_keys(ka, ctx.stream));
+        }
+        if (nkeys > 1) {
+            ca.nkeys = nkeys; ca.n = n; ca.nullflags = has_nulls ? nullflags : nullptr; ca.out = out_keys; ca.bit_stats = d_stats;
+            HIP_TRY(launch_join_combine(ca, ctx.stream));
+        }
+        (void)build;
+        return RDF_OK;
+    };
+    void* pstats;
+    RDF_TRY(arena_alloc(128, &pstats));
+    uint64_t* d_bstats = (uint64_t*)pstats;
+    uint64_t* d_pstats = d_bstats + 4;
+    RDF_TRY(sort_stats_reset(d_bstats));
+    RDF_TRY(sort_stats_reset(d_pstats));
     if (nb > 0) {
-        SortKeyArgs ka;
-        memset(&ka, 0, sizeof ka);
-        ka.chunks = tb.dev_at<DevChunkCol>(o_ch) + (size_t)pnc;
-        ka.chunk_row_start = tb.dev_at<int64_t>(o_brs);
-        ka.nchunks = bnc;
-        ka.n = nb;
-        ka.keys = sb.keys[0];
-        ka.nullflags = bnulls ? (uint8_t*)sb.nullflags : nullptr;
-        ka.dtype = dt;
-        void* pstats;
-        RDF_TRY(arena_alloc(64, &pstats));
-        ka.bit_stats = (uint64_t*)pstats;
-        RDF_TRY(sort_stats_reset(ka.bit_stats));
-        HIP_TRY(launch_sort_keys(ka, ctx.stream));
+        RDF_TRY(side_keys(true, nb, bnc, (size_t)nkeys * (size_t)pnc, tb.dev_at<int64_t>(o_brs), bnulls, sb.keys[0], (uint8_t*)sb.nullflags, d_bstats, bbits));
         if (bnulls) HIP_TRY(launch_count_bytes((const uint8_t*)sb.nullflags, nb, d_cnt, ctx.stream));
-        RDF_TRY(radix_sort_rows(sb, nb, dtype_size(dt), bnulls, &kcur, &icur, ka.bit_stats, pin_off, &bkmin, &bkmax));
+        RDF_TRY(radix_sort_rows(sb, nb, nkeys == 1 ? dtype_size(dt) : 8, bnulls, &kcur, &icur, d_bstats, pin_off, &bkmin, &bkmax));
     }
     // probe side: key bits + null flags in row order
     void *ppk, *ppn, *pcounts, *poffs;
@@ -2317,18 +2358,7 @@ rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks
     RDF_TRY(arena_alloc((size_t)(np > 0 ? np : 1) + 8, &ppn));
     RDF_TRY(arena_alloc((size_t)(np + 1) * 8, &pcounts));
     RDF_TRY(arena_alloc((size_t)(np + 2 + scan_scratch_words(np)) * 8, &poffs));
-    if (np > 0) {
-        SortKeyArgs ka;
-        memset(&ka, 0, sizeof ka);
-        ka.chunks = tb.dev_at<DevChunkCol>(o_ch);
-        ka.chunk_row_start = tb.dev_at<int64_t>(o_prs);
-        ka.nchunks = pnc;
-        ka.n = np;
-        ka.keys = (uint64_t*)ppk;
-        ka.nullflags = pnulls ? (uint8_t*)ppn : nullptr;
-        ka.dtype = dt;
-        HIP_TRY(launch_sort_keys(ka, ctx.stream));
-    }
+    if (np > 0) RDF_TRY(side_keys(false, np, pnc, 0, tb.dev_at<int64_t>(o_prs), pnulls, (uint64_t*)ppk, (uint8_t*)ppn, d_pstats, pbits));
     RDF_TRY(pinned_reserve(pin_off + 256));
     HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, d_cnt, 8, hipMemcpyDeviceToHost, ctx.stream));
     HIP_TRY(hipStreamSynchronize(ctx.stream));
@@ -2358,6 +2388,8 @@ rdf_status rdf_equijoin_indices(const rdf_array* left_keys, int64_t left_nchunks
     ja.buckets = (const uint32_t*)pbuckets;
     ja.kmin = bkmin; ja.kmax = bkmax; ja.bucket_shift = bshift;
     ja.first = (uint32_t*)pfirst;
+    ja.nkeys = nkeys;
+    for (int k = 0; k < 4; ++k) { ja.pbits[k] = pbits[k]; ja.bbits[k] = bbits[k]; }
     ja.lkeys = (const uint64_t*)ppk;
     ja.lnull = pnulls ? (const uint8_t*)ppn : nullptr;
     ja.rkeys = sb.keys[kcur];

@@ -167,6 +167,7 @@ struct SortKeyArgs {                                 // key[i] = order-preservin
     uint8_t*           nullflags;                    // out (per ORIGINAL row), nullptr when the column has no bitmap
     uint64_t*          bit_stats;                    // [2] in/out: min and max over the non-null keys written ([0] starts ~0, [1] starts 0)
     int32_t            dtype, descending;
+    int32_t            null_or, pad;                 // multi-column join keys: nullflags[row] |= isnull (the buffer starts zeroed)
 };
 struct SortPassArgs {
     const uint64_t* keys_in;  const uint32_t* idx_in;   // idx_in nullptr = identity (first pass)
@@ -200,7 +201,12 @@ struct JoinProbeArgs {
     uint64_t        kmin, kmax;
     int32_t         bucket_shift, pad;
     uint32_t*       first;     // [nl] count phase out / write phase in: first sorted build position of the row's partners, ~0 = none
+    // multi-column keys: lkeys / rkeys are 64-bit hashes of the key tuple; a candidate pair is verified on every column's key bits
+    int32_t         nkeys, pad2;
+    const uint64_t* pbits[4];  // [nkeys][nl] key bits of the probe side, row order
+    const uint64_t* bbits[4];  // [nkeys][nr] key bits of the build side, ROW order (indexed through ridx)
 };
+struct JoinCombineArgs { const uint64_t* bits[4]; int32_t nkeys, pad; int64_t n; const uint8_t* nullflags; uint64_t* out; uint64_t* bit_stats; };
 struct JoinBucketArgs { const uint64_t* rkeys; int64_t nrv; uint32_t* buckets; uint64_t kmin; int32_t bucket_shift; };
 struct JoinAppendArgs {        // FULL: build rows nobody matched (and NULL-key build rows) with a NULL probe index
     const uint32_t* ridx; const uint32_t* matched;
@@ -358,6 +364,7 @@ hipError_t launch_sort_keys(const SortKeyArgs& a, hipStream_t s);
 hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_join_buckets(const JoinBucketArgs& a, hipStream_t s);
+hipError_t launch_join_combine(const JoinCombineArgs& a, hipStream_t s);
 hipError_t launch_join_count(const JoinProbeArgs& a, hipStream_t s);
 hipError_t launch_join_write(const JoinProbeArgs& a, hipStream_t s);
 hipError_t launch_join_append(const JoinAppendArgs& a, hipStream_t s);

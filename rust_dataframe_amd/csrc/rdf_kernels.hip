@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void sort_keys_kernel(const SortKeyArgs a, 
         const uint64_t kw = isnull ? 0 : k;  // nulls are ordered by the nulls-last pass; equal keys keep them stable
         a.keys[i] = kw;
         if (!isnull) { kmin = kw < kmin ? kw : kmin; kmax = kw > kmax ? kw : kmax; }
-        if (a.nullflags) a.nullflags[row] = isnull;
+        if (a.nullflags) { if (a.null_or) { if (isnull) a.nullflags[row] = 1; } else a.nullflags[row] = isnull; }
     }
     if (a.bit_stats) {   // key range of the column: the radix passes work on key - min, so only the bytes of (max - min) need a pass
 #pragma unroll
@@ -564,6 +564,36 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs
 // kernels above), every probe row finds its partners' range with two binary searches, and the pairs are
 // written at offsets from an exclusive scan of the per-row match counts.  NULL keys never match.
 
+// multi-column join keys: one 64-bit hash per row over the columns' order-preserving key bits (SplitMix64 finaliser per
+// column, chained); rows with a NULL in any key column keep hash 0 and are excluded through nullflags
+__device__ __forceinline__ uint64_t join_mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(kBlock) void join_combine_kernel(const JoinCombineArgs a) {
+    uint64_t kmin = ~0ull, kmax = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
+        const bool isnull = a.nullflags && a.nullflags[i];
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (int k = 0; k < a.nkeys; ++k) h = join_mix(h ^ a.bits[k][i]) + 0x9E3779B97F4A7C15ull * (uint64_t)(k + 1);
+        if (isnull) h = 0;
+        a.out[i] = h;
+        if (!isnull) { kmin = h < kmin ? h : kmin; kmax = h > kmax ? h : kmax; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint64_t x = shfl_xor64(kmin, m), y = shfl_xor64(kmax, m);
+        kmin = x < kmin ? x : kmin; kmax = y > kmax ? y : kmax;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin((unsigned long long*)&a.bit_stats[0], (unsigned long long)kmin); atomicMax((unsigned long long*)&a.bit_stats[1], (unsigned long long)kmax); }
+}
+__device__ __forceinline__ bool join_verify(const JoinProbeArgs& a, int64_t i, int64_t p) {   // hash match -> compare the key tuples
+    const uint32_t r = a.ridx[p];
+    bool eq = true;
+    for (int k = 0; k < a.nkeys; ++k) eq = eq && a.pbits[k][i] == a.bbits[k][r];
+    return eq;
+}
 __global__ __launch_bounds__(kBlock) void join_buckets_kernel(const JoinBucketArgs a) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.nrv; i += (int64_t)gridDim.x * kBlock) {
         const uint64_t b = (a.rkeys[i] - a.kmin) >> a.bucket_shift;
@@ -591,10 +621,14 @@ __global__ __launch_bounds__(kBlock) void join_count_kernel(const JoinProbeArgs 
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.nl; i += (int64_t)gridDim.x * kBlock) {
         int64_t lo, hi;
         join_range(a, i, lo, hi);
-        const int64_t c = hi - lo;
+        int64_t c = hi - lo;
+        if (a.nkeys > 1) {   // candidates share the tuple's hash: count (and mark) only the ones whose key tuples are equal
+            c = 0;
+            for (int64_t p = lo; p < hi; ++p)
+                if (join_verify(a, i, p)) { ++c; if (a.matched) atomicOr(&a.matched[p >> 5], 1u << (p & 31)); }
+        } else if (a.matched) for (int64_t p = lo; p < hi; ++p) atomicOr(&a.matched[p >> 5], 1u << (p & 31));
         a.counts[i] = (c == 0 && a.outer) ? 1 : c;
         a.first[i] = c == 0 ? ~0u : (uint32_t)lo;   // the write phase does not search again
-        if (a.matched) for (int64_t p = lo; p < hi; ++p) atomicOr(&a.matched[p >> 5], 1u << (p & 31));
         if (c == 0 && a.outer) atomicAdd(a.unmatched, 1ull);
     }
 }
@@ -609,6 +643,12 @@ __global__ __launch_bounds__(kBlock) void join_write_kernel(const JoinProbeArgs 
                 a.out_build[o] = 0;
                 atomicAnd(&a.out_build_validity[o >> 5], ~(1u << (o & 31)));
             }
+            continue;
+        }
+        if (a.nkeys > 1) {   // walk the hash range again and emit the verified pairs (cnt of them, in sorted-position order)
+            int64_t left = cnt;
+            for (int64_t p = lo; left > 0; ++p)
+                if (join_verify(a, i, p)) { a.out_probe[o] = (uint32_t)i; a.out_build[o] = a.ridx[p]; ++o; --left; }
             continue;
         }
         for (int64_t p = lo; p < (int64_t)lo + cnt; ++p, ++o) {
@@ -1505,6 +1545,10 @@ static int rows_grid(int64_t n) {
 }
 hipError_t launch_join_buckets(const JoinBucketArgs& a, hipStream_t s) {
     if (a.nrv > 0) hipLaunchKernelGGL(join_buckets_kernel, dim3(rows_grid(a.nrv)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_join_combine(const JoinCombineArgs& a, hipStream_t s) {
+    if (a.n > 0) hipLaunchKernelGGL(join_combine_kernel, dim3(rows_grid(a.n)), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_join_count(const JoinProbeArgs& a, hipStream_t s) {

@@ -268,6 +268,28 @@ TEST(test_fused_pipeline_matches_unfused_oracle) {
         if (cols[0][0].valid[i] && cols[1][0].valid[i]) CHECK_EQ(e0[i], cols[0][0].v[i] + cols[1][0].v[i]);
 }
 
+// DataFrame::join with two criteria (JoinCriteria.criteria is a Vec of column pairs, src/expression.rs:332-337)
+TEST(test_join_two_key_columns) {
+    auto L = DataFrame::from_columns({Column::from_arrays({Array::from_vec(std::vector<int32_t>{1, 1, 2, 2, 3})}, Field{"a", DataType::Int32, true}),
+                                      Column::from_arrays({Array::from_vec(std::vector<int64_t>{10, 20, 10, 20, 10})}, Field{"b", DataType::Int64, true}),
+                                      Column::from_arrays({Array::from_vec(std::vector<double>{0.1, 0.2, 0.3, 0.4, 0.5})}, Field{"x", DataType::Float64, true})});
+    auto R = DataFrame::from_columns({Column::from_arrays({Array::from_vec(std::vector<int32_t>{2, 1, 2, 4})}, Field{"c", DataType::Int32, true}),
+                                      Column::from_arrays({Array::from_vec(std::vector<int64_t>{20, 10, 20, 10})}, Field{"d", DataType::Int64, true}),
+                                      Column::from_arrays({Array::from_vec(std::vector<double>{7.0, 8.0, 9.0, 6.0})}, Field{"y", DataType::Float64, true})});
+    DataFrame::JoinCriteria jc{DataFrame::JoinType::InnerJoin, {{"a", "c"}, {"b", "d"}}};
+    DataFrame j = L.join(R, jc);
+    CHECK_EQ(j.num_rows(), (int64_t)3);   // (1,10)-(1,10), (2,20)-(2,20) twice
+    auto x = host<double>(j.column_by_name("x").data().chunk(0));
+    auto y = host<double>(j.column_by_name("y").data().chunk(0));
+    double sx = 0, sy = 0;
+    for (double v : x) sx += v;
+    for (double v : y) sy += v;
+    CHECK_NEAR(sx, 0.1 + 0.4 + 0.4, 1e-12);
+    CHECK_NEAR(sy, 8.0 + 7.0 + 9.0, 1e-12);
+    DataFrame::JoinCriteria lj{DataFrame::JoinType::LeftJoin, {{"a", "c"}, {"b", "d"}}};
+    CHECK_EQ(L.join(R, lj).num_rows(), (int64_t)6);   // 3 matches + 3 unmatched left rows
+}
+
 // GroupAggregate with a grouping column: the reference has only the schema (Dataset::try_aggregate) and panics on
 // execution (src/evaluation.rs:73); expectations are SQL semantics computed on the host.
 TEST(test_group_aggregate_by_key) {

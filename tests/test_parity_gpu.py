@@ -690,3 +690,28 @@ def test_groupby_partitioned_value_nulls_and_skew(gpu, ora, val_dtype):
             np.testing.assert_allclose(got[2], exp[2], rtol=1e-6, atol=1e-9, err_msg=name)
         else:
             assert np.array_equal(got[2], exp[2]), f"sums {name}"
+
+
+@pytest.mark.parametrize("how", ["left", "right", "inner", "full"])
+def test_equijoin_multi_column_keys(gpu, ora, how):
+    """JoinCriteria with several column pairs: rows match on the whole tuple (mixed dtypes per pair, NULL in any key column
+    never matches, duplicates on both sides, tuples that agree on one column only); pairs equal the oracle's nested loops."""
+    rng = np.random.default_rng(8800)
+    for (llens, rlens, nf) in [([9], [7], 0.0), ([700, 0, 900], [1000, 400], 0.08), ([2500], [2000], 0.02)]:
+        def side(lens, seed_off):
+            cols = [[], [], []]
+            for n in lens:
+                cols[0].append(A.HostArray.from_numpy(rng.integers(0, 12, n).astype(np.int64), valid=(rng.uniform(size=n) >= nf) if nf else None, offset=seed_off, rng=rng))
+                cols[1].append(A.HostArray.from_numpy(rng.integers(-3, 4, n).astype(np.int16), valid=(rng.uniform(size=n) >= nf) if nf else None, rng=rng))
+                cols[2].append(A.HostArray.from_numpy(np.round(rng.uniform(0, 2, n), 0), rng=rng))
+            return cols
+        L, R = side(llens, 3), side(rlens, 5)
+        for nk in (2, 3):
+            gl, gr = gpu.equijoin_indices_multi(L[:nk], R[:nk], how)
+            el, er = ora.equijoin_indices_multi(L[:nk], R[:nk], how)
+            assert gl.length == el.length and gl.null_count == el.null_count and gr.null_count == er.null_count, f"{how} nk={nk}"
+            assert _pairs(gl, gr) == _pairs(el, er), f"join {how} nk={nk}"
+    # one key column through the multi entry point == the single-key entry point
+    a = [[A.HostArray.from_numpy(rng.integers(0, 50, 500).astype(np.int32))]]
+    b = [[A.HostArray.from_numpy(rng.integers(0, 50, 300).astype(np.int32))]]
+    assert _pairs(*gpu.equijoin_indices_multi(a, b, how)) == _pairs(*gpu.equijoin_indices(a[0], b[0], how))
