@@ -63,43 +63,68 @@ def combine(parts: Sequence[AggResult]) -> AggResult:
     return AggResult(tot, mn if mn is not None else 0, mx if mx is not None else 0, cnt, cnt > 0, dt)
 
 
-def all_combine(local: Sequence[AggResult], device=None) -> List[AggResult]:
-    """all_gather every rank's partials and fold them identically on every rank.  f64 partials travel
-    as f64; integer partials as two's-complement i64 (exact)."""
+_gather_buffers = {}
+
+
+def _all_gather_words(words, device):
+    """One collective for a small int64 vector: returns [world][len(words)] as Python ints.  Buffers are cached per
+    (length, device) so the per-step cost is one all_gather and one D2H."""
     import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    key = (len(words), str(device))
+    if key not in _gather_buffers:
+        dev = device if device is not None else "cpu"
+        _gather_buffers[key] = (torch.zeros(len(words), dtype=torch.int64, device=dev), torch.zeros(world * len(words), dtype=torch.int64, device=dev))
+    inp, out = _gather_buffers[key]
+    inp.copy_(torch.tensor(words, dtype=torch.int64))
+    try:
+        dist.all_gather_into_tensor(out, inp)
+    except (RuntimeError, NotImplementedError, AttributeError):   # a backend without the flat variant
+        parts = [torch.zeros_like(inp) for _ in range(world)]
+        dist.all_gather(parts, inp)
+        out = torch.cat(parts)
+    flat = out.tolist()
+    n = len(words)
+    return [flat[r * n:(r + 1) * n] for r in range(world)]
+
+
+def _f64_bits(x: float) -> int:
+    import struct
+    return struct.unpack("<q", struct.pack("<d", float(x)))[0]
+
+
+def _bits_f64(b: int) -> float:
+    import struct
+    return struct.unpack("<d", struct.pack("<q", int(b)))[0]
+
+
+def all_combine(local: Sequence[AggResult], device=None) -> List[AggResult]:
+    """all_gather every rank's partials (ONE collective of 5 int64 words per value: f64 partials travel as their bit
+    patterns, integer partials as two's-complement i64 — both exact) and fold them identically on every rank."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [combine([p]) for p in local]
     world = dist.get_world_size()
-    nv = len(local)
-    f = torch.zeros(nv * 3, dtype=torch.float64)
-    i = torch.zeros(nv * 5, dtype=torch.int64)
-    for v, p in enumerate(local):
+    wrap = lambda x: x - (1 << 64) if x >= (1 << 63) else x
+    words = []
+    for p in local:
         if p.dtype in (F32, F64):
-            f[3 * v], f[3 * v + 1], f[3 * v + 2] = float(p.sum), float(p.min), float(p.max)
+            words += [_f64_bits(p.sum), _f64_bits(p.min), _f64_bits(p.max)]
         else:
-            wrap = lambda x: x - (1 << 64) if x >= (1 << 63) else x
-            i[5 * v], i[5 * v + 1], i[5 * v + 2] = wrap(int(p.sum)), wrap(int(p.min)), wrap(int(p.max))
-        i[5 * v + 3], i[5 * v + 4] = int(p.count), int(p.is_some)
-    if device is not None:
-        f, i = f.to(device), i.to(device)
-    fs = [torch.zeros_like(f) for _ in range(world)]
-    is_ = [torch.zeros_like(i) for _ in range(world)]
-    dist.all_gather(fs, f)
-    dist.all_gather(is_, i)
-    fs = [t.tolist() for t in fs]
-    is_ = [t.tolist() for t in is_]
+            words += [wrap(int(p.sum)), wrap(int(p.min)), wrap(int(p.max))]
+        words += [int(p.count), int(p.is_some)]
+    gathered = _all_gather_words(words, device)
     out = []
     for v, p in enumerate(local):
         parts = []
         for r in range(world):
+            s, a, b, cnt, some = gathered[r][5 * v:5 * v + 5]
             if p.dtype in (F32, F64):
-                s, a, b = fs[r][3 * v:3 * v + 3]
-            else:
-                s, a, b = is_[r][5 * v:5 * v + 3]
-                if p.dtype == 7:  # U64 travels as i64
-                    s, a, b = [x + (1 << 64) if x < 0 else x for x in (s, a, b)]
-            parts.append(AggResult(s, a, b, int(is_[r][5 * v + 3]), bool(is_[r][5 * v + 4]), p.dtype))
+                s, a, b = _bits_f64(s), _bits_f64(a), _bits_f64(b)
+            elif p.dtype == 7:  # U64 travels as i64
+                s, a, b = [x + (1 << 64) if x < 0 else x for x in (s, a, b)]
+            parts.append(AggResult(s, a, b, int(cnt), bool(some), p.dtype))
         out.append(combine(parts))
     return out
 
