@@ -715,3 +715,50 @@ def test_equijoin_multi_column_keys(gpu, ora, how):
     a = [[A.HostArray.from_numpy(rng.integers(0, 50, 500).astype(np.int32))]]
     b = [[A.HostArray.from_numpy(rng.integers(0, 50, 300).astype(np.int32))]]
     assert _pairs(*gpu.equijoin_indices_multi(a, b, how)) == _pairs(*gpu.equijoin_indices(a[0], b[0], how))
+
+
+def test_concurrent_callers(gpu, ora):
+    """The reference calls its kernels from rayon workers (src/functions/scalar.rs:28,99): the library is re-entrant with
+    per-thread state.  Eight threads run different entry points at once (ctypes releases the GIL inside the calls); every
+    result must equal the single-threaded oracle answer."""
+    import threading
+    rng = np.random.default_rng(2024)
+    lens = [30_000, 1000, 17]
+    jobs = []
+    for t in range(8):
+        a = make_chunks(rng, A.F64, lens, 0.1, t % 5, kind="unit", nonzero=True)
+        b = make_chunks(rng, A.F64, lens, 0.0, 0, kind="unit", nonzero=True)
+        k = make_chunks(rng, A.I64, lens, 0.05, 3, kind="plain")
+        jobs.append((a, b, k))
+    e = A.Expr()
+    x, y = e.col(0), e.col(1)
+    pred = e.op("gt", x, e.scalar(0.1))
+    val = e.op("add", e.op("multiply", x, y), e.scalar(0.5))
+    expected = []
+    for a, b, k in jobs:
+        expected.append((ora.pipeline(e, [a, b], [val], pred)[0], ora.binary("add", a, b), ora.sort_to_indices([k], [False]).to_numpy(),
+                         _sorted_groups(*ora.groupby_sum(k, a, 3000))))
+    errors = []
+
+    def worker(i):
+        try:
+            a, b, k = jobs[i]
+            for _ in range(5):
+                got = gpu.pipeline(e, [a, b], [val], pred)[0]
+                exp = expected[i][0]
+                assert got.count == exp.count and abs(got.sum - exp.sum) <= 1e-6 * max(abs(exp.sum), 1.0)
+                for g, x_ in zip(gpu.binary("add", a, b), expected[i][1]):
+                    assert_arrays_match(g, x_, exact=True, what=f"thread {i}")
+                assert np.array_equal(gpu.sort_to_indices([k], [False]).to_numpy(), expected[i][2])
+                gg = _sorted_groups(*gpu.groupby_sum(k, a, 3000))
+                assert np.array_equal(gg[1], expected[i][3][1]) and np.array_equal(gg[3], expected[i][3][3])
+                np.testing.assert_allclose(gg[2], expected[i][3][2], rtol=1e-6, atol=1e-9)
+        except Exception as ex:   # surfaced in the main thread
+            errors.append((i, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
