@@ -2660,7 +2660,7 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
         ga.cursor = d_cursor;
         ga.flags = d_flags2;
         ga.max_out = max_groups;
-        ga.ablate_lds = ctx.opt_gb_debug == 1;
+        ga.ablate_lds = (ctx.opt_gb_debug == 1 || (ctx.opt_gb_debug >= 4 && ctx.opt_gb_debug <= 6)) ? ctx.opt_gb_debug : 0;
         HIP_TRY(launch_gb_aggregate(ga, ctx.stream));
         kt.stop();
         ctx.last_kernel = skew ? "gb_aggregate_kernel(combined)" : "gb_aggregate_kernel";

@@ -252,7 +252,7 @@ constexpr int kGbBlock = 512;                       // threads per block of the 
 constexpr int kGbRows = 8;                          // rows per thread per iteration
 constexpr int kGbSuper = kGbBlock * kGbRows;        // 4096 rows = 4 tiles of kEvalTile rows per block iteration
 constexpr int kGbPartBits = 9;                      // 512 partitions
-constexpr int kGbSlots = 4000;                      // LDS table slots per partition (20 B each: 2 blocks per CU)
+constexpr int kGbSlots = 3989;                      // LDS table slots per partition: prime (double hashing), 20 B each -> 2 blocks per CU
 constexpr int64_t kGbMaxGroups = (int64_t)(1 << kGbPartBits) * 2600;   // keeps the expected load of a table under 0.65
 struct GbPartArgs {
     const DevChunkCol* keys;             // [nchunks]
