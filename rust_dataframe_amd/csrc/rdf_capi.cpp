@@ -2619,7 +2619,8 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
         pa.chunk_len = tb.dev_at<int64_t>(o_len);
         pa.nchunks = nchunks;
         pa.ntiles = ntiles;
-        pa.ablate_stores = ctx.opt_gb_debug == 2;
+        if (nchunks == 1) { pa.key0 = in.dev[0]; if (values) pa.val0 = in.dev[1]; pa.len0 = clen[0]; }
+        pa.ablate_stores = (ctx.opt_gb_debug == 2 || ctx.opt_gb_debug == 7 || ctx.opt_gb_debug == 8) ? ctx.opt_gb_debug : 0;
         pa.key_dtype = kdt;
         pa.value_dtype = vdt;
         pa.hist = (int64_t*)hist0;

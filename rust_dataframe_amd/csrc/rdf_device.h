@@ -260,6 +260,8 @@ struct GbPartArgs {
     const int64_t*     chunk_tile_start; // [nchunks + 1], tiles of kEvalTile rows
     const int64_t*     chunk_len;
     int64_t            nchunks, ntiles;
+    DevChunkCol        key0, val0;       // nchunks == 1: the chunk's descriptors inline (kernel arguments = scalar registers)
+    int64_t            len0;
     int32_t            key_dtype, value_dtype;
     int32_t            ablate_stores, pad;   // bench ablation (rdf_set_option("gb_debug", 2)): run the scatter without its global stores
     int64_t*           hist;             // histogram kernel: out counts [digit * gridDim.x + block]; scatter: their exclusive scan

@@ -234,7 +234,7 @@ def main():
             report(f"groupby_sum_{ng}_groups_hot_key_30pct", 16.0 * n, lambda: api.groupby_sum([arr(kh, A.I64, n)], [X], ng, (ok_, os_, oc_)))
             report(f"groupby_sum_{ng}_groups_null_values", 16.125 * n, lambda: api.groupby_sum([KK], [XV], ng, (ok_, os_, oc_)))
             del u, kz, kh
-            for dbg in (1, 2, 4, 5, 6):
+            for dbg in (1, 2, 4, 5, 6, 7, 8):
                 lib.set_option("gb_debug", dbg)
                 try:
                     report(f"groupby_sum_{ng}_groups_ablate{dbg}", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
