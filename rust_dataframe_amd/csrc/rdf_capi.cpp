@@ -2475,7 +2475,7 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
 // Tail of both partitioned GROUP BY paths: read back {special sums, counts, flags, cursor}, append the two special
 // groups (the key whose hash is the LDS free marker; the NULL key) and copy the dense results to the caller.
 static rdf_status groupby_finish_partitioned(void* pspec, void* d_keys, void* d_sums, void* d_counts, int kdt, int64_t max_groups, int32_t mem,
-                                             rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts, size_t pin_off) {
+                                             rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts, size_t pin_off, bool single_pass) {
     Ctx& ctx = g_ctx;
     struct { void* out_keys; void* out_sums; void* out_counts; } ga = {d_keys, d_sums, d_counts};
         // specials + cursor + flags
@@ -2502,7 +2502,8 @@ static rdf_status groupby_finish_partitioned(void* pspec, void* d_keys, void* d_
         };
         if (hf[0]) {  // the key whose hash equals the LDS free marker: unmix on the host
             uint64_t z = ~0ull;
-            z ^= z >> 31; z ^= z >> 62; z *= 0x319642b2d24d8ec3ull; z ^= z >> 27; z ^= z >> 54; z *= 0x96de1b173f119089ull; z ^= z >> 30; z ^= z >> 60;
+            if (single_pass) { z ^= z >> 32; z *= 0xF1DE83E19937733Dull; z ^= z >> 32; }   // inverse of gb_hash
+            else { z ^= z >> 31; z ^= z >> 62; z *= 0x319642b2d24d8ec3ull; z ^= z >> 27; z ^= z >> 54; z *= 0x96de1b173f119089ull; z ^= z >> 30; z ^= z >> 60; }   // inverse of mix64
             RDF_TRY(put(z, hs[0], hs[2]));
         }
         if (hf[1]) { null_idx = ng; RDF_TRY(put(0, hs[1], hs[3])); }
@@ -2665,7 +2666,7 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
         HIP_TRY(launch_gb_aggregate(ga, ctx.stream));
         kt.stop();
         ctx.last_kernel = skew ? "gb_aggregate_kernel(combined)" : "gb_aggregate_kernel";
-        RDF_TRY(groupby_finish_partitioned(pspec, ga.out_keys, ga.out_sums, ga.out_counts, kdt, max_groups, mem, out_keys, out_sums, out_counts, pin_off));
+        RDF_TRY(groupby_finish_partitioned(pspec, ga.out_keys, ga.out_sums, ga.out_counts, kdt, max_groups, mem, out_keys, out_sums, out_counts, pin_off, true));
         return RDF_OK;
     }
     if (ctx.opt_gb_partition && max_groups > 1024 && !value_nulls && nrows > 0) {
@@ -2740,7 +2741,7 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
         HIP_TRY(launch_groupby_partitions(ga, ctx.stream));
         kt.stop();
         ctx.last_kernel = "groupby_partitions_kernel";
-        RDF_TRY(groupby_finish_partitioned(pspec, ga.out_keys, ga.out_sums, ga.out_counts, kdt, max_groups, mem, out_keys, out_sums, out_counts, pin_off));
+        RDF_TRY(groupby_finish_partitioned(pspec, ga.out_keys, ga.out_sums, ga.out_counts, kdt, max_groups, mem, out_keys, out_sums, out_counts, pin_off, false));
         return RDF_OK;
     }
 

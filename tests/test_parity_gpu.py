@@ -433,6 +433,7 @@ def test_groupby_partitioned_high_cardinality(gpu, ora, ngroups, n):
             if ln > 4:
                 kv[0], kv[1] = np.iinfo(np.int64).min, np.iinfo(np.int64).max
                 kv[2] = np.int64(-3487469807577879104)  # mix64(key) == 2^64 - 1, the LDS free marker of the partition tables
+                kv[3] = np.int64(7406324358081711299)   # the same for the single-pass path's hash (gb_hash)
             keys.append(A.HostArray.from_numpy(kv, valid=rng.uniform(size=ln) >= 0.01, offset=5, rng=rng))
             if val_dtype is not None:
                 vals.append(A.HostArray.from_numpy(rng.uniform(-1, 1, ln) if val_dtype == A.F64 else rng.integers(-10 ** 9, 10 ** 9, ln), offset=2, dtype=val_dtype, rng=rng))

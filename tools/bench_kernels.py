@@ -232,6 +232,9 @@ def main():
             report(f"groupby_sum_{ng}_groups_zipf", 16.0 * n, lambda: api.groupby_sum([arr(kz, A.I64, n)], [X], ng, (ok_, os_, oc_)))
             kh = torch.where(torch.rand(n, device="cuda") < 0.3, torch.full((n,), 7, device="cuda", dtype=torch.int64), kk)
             report(f"groupby_sum_{ng}_groups_hot_key_30pct", 16.0 * n, lambda: api.groupby_sum([arr(kh, A.I64, n)], [X], ng, (ok_, os_, oc_)))
+            ks = (kk * 6364136223846793005 + 1442695040888963407) ^ (kk << 29)     # the same groups under scattered 64-bit key values
+            report(f"groupby_sum_{ng}_groups_scattered_keys", 16.0 * n, lambda: api.groupby_sum([arr(ks, A.I64, n)], [X], ng, (ok_, os_, oc_)))
+            del ks
             report(f"groupby_sum_{ng}_groups_null_values", 16.125 * n, lambda: api.groupby_sum([KK], [XV], ng, (ok_, os_, oc_)))
             del u, kz, kh
             for dbg in (1, 2, 4, 5, 6, 7, 8):
