@@ -148,23 +148,36 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     // A "tile" is one block iteration: kBlock*U vectors = kBlock*R rows of ONE chunk; wave w owns the
     // 64*R consecutive rows [64*R*w, +64*R) of it.
     constexpr int64_t per_iter = (int64_t)kBlock * U;
-    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        int64_t ch = 0, base, n;
-        DevChunkCol col[NC];
-        DevOutChunk out = a.out;
+    // Where a tile lives (chunk, first vector, chunk length, column descriptors): for chunked frames this is a binary
+    // search plus a handful of dependent table reads on the scalar unit.  The NEXT tile is located while the current
+    // tile's vector loads are in flight, so the lookup latency is off the critical path.
+    struct TileMeta { int64_t ch, base, n; DevChunkCol col[NC]; DevOutChunk out; };
+    auto locate = [&](int64_t tile) -> TileMeta {
+        TileMeta m;
+        m.ch = 0;
+        m.out = a.out;
         if (a.nchunks == 1) {
-            base = tile * per_iter;
-            n = a.n;
+            m.base = tile * per_iter;
+            m.n = a.n;
 #pragma unroll
-            for (int k = 0; k < NC; ++k) col[k] = a.cols[k];
+            for (int k = 0; k < NC; ++k) m.col[k] = a.cols[k];
         } else {
-            ch = find_chunk(a.chunk_tile_start, a.nchunks, tile);
-            base = (tile - a.chunk_tile_start[ch]) * per_iter;
-            n = a.chunk_len[ch];
+            m.ch = find_chunk(a.chunk_tile_start, a.nchunks, tile);
+            m.base = (tile - a.chunk_tile_start[m.ch]) * per_iter;
+            m.n = a.chunk_len[m.ch];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) col[k] = a.cols_tab[(int64_t)k * a.nchunks + ch];
-            if (P::SINK == SINK_STORE) out = a.outs_tab[ch];
+            for (int k = 0; k < NC; ++k) m.col[k] = a.cols_tab[(int64_t)k * a.nchunks + m.ch];
+            if (P::SINK == SINK_STORE) m.out = a.outs_tab[m.ch];
         }
+        return m;
+    };
+    TileMeta meta = locate(blockIdx.x < a.ntiles ? (int64_t)blockIdx.x : 0);
+    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int64_t ch = meta.ch, base = meta.base, n = meta.n;
+        DevChunkCol col[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) col[k] = meta.col[k];
+        const DevOutChunk out = meta.out;
         if (P::SINK == SINK_STORE && ch != cur_chunk) {  // one null-count atomic per (wave, chunk), not per tile
             if (cur_chunk >= 0 && lane == 0 && nulls) atomicAdd((unsigned long long*)&a.out_null_count[cur_chunk], (unsigned long long)nulls);
             nulls = 0;
@@ -211,6 +224,11 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
                     for (int e = 0; e < RV; ++e)
                         c.v[k][RV * u + e] = ((c.inr >> (RV * u + e)) & 1) ? p[(int64_t)RV * (wbase + u * 64 + lane) + e] : (S)0;
             }
+        }
+        {   // the loads above are in flight: locate the next tile now
+            const int64_t nt = tile + gridDim.x;
+            if (a.nchunks == 1) meta.base = nt * per_iter;
+            else if (nt < a.ntiles) meta = locate(nt);
         }
         // validity: R windows of 64 rows per column for this wave; lane l's RV bits of load u sit in window
         // RV*u + (RV*l >> 6) at bit (RV*l) & 63
