@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rdf_device.h"
@@ -206,6 +207,29 @@ struct StageItem {
     bool small;
 };
 
+// Packing many small host chunks (the reference's readers emit 1024-row batches = 8 KiB per f64 column) into the pinned
+// buffer is a CPU memcpy; above a few MB it is spread over a handful of threads, or it — not PCIe — bounds the call
+// (measured: 4.8 GB/s single-threaded against 52-55 GB/s for chunks that are DMA'd directly).
+inline void packed_copy(const std::vector<StageItem>& items, char* pin, bool to_pinned, size_t small_bytes) {
+    auto run = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const StageItem& it = items[i];
+            if (!it.small || !it.bytes) continue;
+            if (to_pinned) memcpy(pin + it.off, it.src, it.bytes); else memcpy((void*)it.src, pin + it.off, it.bytes);
+        }
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt > 8 ? 8 : nt;
+    if (small_bytes < ((size_t)4 << 20) || nt < 2 || items.size() < 2 * nt) { run(0, items.size()); return; }
+    std::vector<std::thread> th;
+    const size_t per = (items.size() + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t lo = (size_t)t * per, hi = std::min(items.size(), lo + per);
+        if (lo < hi) th.emplace_back(run, lo, hi);
+    }
+    for (auto& x : th) x.join();
+}
+
 struct Region {
     std::vector<StageItem> items;
     char* dev = nullptr;
@@ -233,8 +257,7 @@ struct Region {
         Ctx& c = g_ctx;
         if (small_bytes) {
             char* pin = c.pinned + pinned_off;
-            for (auto& it : items)
-                if (it.small && it.bytes) memcpy(pin + it.off, it.src, it.bytes);
+            packed_copy(items, pin, true, small_bytes);
             HIP_TRY(hipMemcpyAsync(dev, pin, small_bytes, hipMemcpyHostToDevice, c.stream));
         }
         *pinned_used = small_bytes;
@@ -250,9 +273,7 @@ struct Region {
             if (!it.small && it.bytes) HIP_TRY(hipMemcpyAsync((void*)it.src, dev + it.off, it.bytes, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
         if (small_bytes) {
-            const char* pin = c.pinned + pinned_off;
-            for (auto& it : items)
-                if (it.small && it.bytes) memcpy((void*)it.src, pin + it.off, it.bytes);
+            packed_copy(items, c.pinned + pinned_off, false, small_bytes);
         }
         return RDF_OK;
     }
