@@ -267,6 +267,24 @@ rdf_status rdf_list_remove(const rdf_list_array* list, const void* value, rdf_ou
  * the value_offsets do not change.  out_values: the child values of rows 0 .. rows-1 re-ordered, i.e.
  * values[value_offset(0) .. value_offset(rows)). */
 rdf_status rdf_list_sort(const rdf_list_array* list, rdf_out* out_values);
+/* The set-valued ArrayFunctions, each row rebuilt with the array_tool crate's Vec algebra (Cargo.toml:19) under the
+ * element type's `==` (NaN equals nothing).  Outputs as for rdf_list_remove; a NULL row of `list` / `a` becomes an
+ * empty valid list, `b`'s validity is not looked at (array.rs:82,126,372).
+ *   array_distinct  (array.rs:39-65):   `unique()`      first occurrences, in order.  The reference never closes the
+ *                                        row of a non-NULL list (no `b.append(true)`, a private, untested function);
+ *                                        this entry point returns the evident per-row result.
+ *   array_except    (array.rs:66-109):  `a.uniq(b)`     unique(a) without the members of b
+ *   array_intersect (array.rs:110-153): `a.intersect(b)` unique(a) restricted to the members of b
+ *   array_union     (array.rs:356-399): `a.union(b)`    unique(a ++ b)
+ *   array_repeat    (array.rs:294-326): `times(count)`  the row's slice `count` times over (count >= 0)
+ * a and b must have the same number of rows (RDF_COMPUTE_ERROR "Expected array a and b to have the same length")
+ * and the same child dtype; a result with more than 2^31-1 elements is RDF_COMPUTE_ERROR (Int32 value_offsets).
+ * out_values capacity: distinct / except / intersect <= elements of a, union <= a + b, repeat = a * count. */
+rdf_status rdf_list_distinct(const rdf_list_array* list, rdf_out* out_offsets, rdf_out* out_values);
+rdf_status rdf_list_except(const rdf_list_array* a, const rdf_list_array* b, rdf_out* out_offsets, rdf_out* out_values);
+rdf_status rdf_list_intersect(const rdf_list_array* a, const rdf_list_array* b, rdf_out* out_offsets, rdf_out* out_values);
+rdf_status rdf_list_union(const rdf_list_array* a, const rdf_list_array* b, rdf_out* out_offsets, rdf_out* out_values);
+rdf_status rdf_list_repeat(const rdf_list_array* list, int32_t count, rdf_out* out_offsets, rdf_out* out_values);
 
 /* ------------------------------------------------------------------ fused batch loop */
 

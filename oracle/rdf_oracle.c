@@ -1143,6 +1143,110 @@ rdf_status ora_list_sort(const rdf_list_array* l, rdf_out* out_values) {
     return RDF_OK;
 }
 
+/* The set-valued ArrayFunctions (array.rs:39-153,294-326,356-399) hand each row's slice(s) to the `array_tool` crate
+ * (Cargo.toml:19 `array_tool = "1"`, not under /root/reference): restated here from the crate's published
+ * vec.rs as operations on small element vectors, quadratic like the original —
+ *   unique():      for x in (0..len).rev() { for y in (x+1..len).rev() { if a[x] == a[y] { a.remove(y) } } }
+ *   uniq(other):   out = self.unique(); for x in other.unique() { for y in (0..out.len()).rev() { if x == out[y] { out.remove(y) } } }
+ *   intersect(o):  for x in self.unique() { for y in 0..o.len() { if x == o[y] { out.push(x); break } } }
+ *   union(o):      (self ++ o).unique()
+ *   times(q):      self.iter().cycle().take(len * q)
+ * with the crate's documented examples as known answers (tests/test_list_functions.py).  The reference has no test for
+ * any of the five (test_array_union is commented out, :609): parity unpinned by the reference. */
+typedef struct { const rdf_array* arr; int64_t e; } eref;
+static int eref_eq(eref x, eref y) {
+    size_t es = (size_t)dtype_size(x.arr->dtype);
+    const char* px = (const char*)x.arr->values + (size_t)(x.arr->offset + x.e) * es;
+    const char* py = (const char*)y.arr->values + (size_t)(y.arr->offset + y.e) * es;
+    if (x.arr->dtype == RDF_F64) return *(const double*)px == *(const double*)py;
+    if (x.arr->dtype == RDF_F32) return *(const float*)px == *(const float*)py;
+    return memcmp(px, py, es) == 0;
+}
+static void evec_remove(eref* v, int64_t* len, int64_t at) { memmove(v + at, v + at + 1, sizeof(eref) * (size_t)(*len - at - 1)); (*len)--; }
+static void evec_unique(eref* v, int64_t* len) {
+    for (int64_t x = *len - 1; x >= 0; x--)
+        for (int64_t y = *len - 1; y > x; y--)
+            if (eref_eq(v[x], v[y])) evec_remove(v, len, y);
+}
+enum { SET_DISTINCT, SET_EXCEPT, SET_INTERSECT, SET_UNION, SET_REPEAT };
+static rdf_status list_set(const rdf_list_array* la, const rdf_list_array* lb, int op, int32_t count, rdf_out* out_offsets, rdf_out* out_values) {
+    listview a, b;
+    memset(&b, 0, sizeof b);
+    rdf_status st = list_view(la, &a);
+    if (st != RDF_OK) return st;
+    if (lb) {
+        st = list_view(lb, &b);
+        if (st != RDF_OK) return st;
+        if (a.n != b.n) FAIL(RDF_COMPUTE_ERROR, "Expected array a and b to have the same length");   /* array.rs:72-76 */
+        if (a.vals->dtype != b.vals->dtype) FAIL(RDF_INVALID_ARGUMENT, "both lists must have the same child dtype");
+    }
+    if (!out_offsets || !out_values) FAIL(RDF_INVALID_ARGUMENT, "null argument");
+    if (op == SET_REPEAT && count < 0) FAIL(RDF_INVALID_ARGUMENT, "negative count");
+    if (out_offsets->dtype != RDF_I32 || out_values->dtype != a.vals->dtype) FAIL(RDF_INVALID_ARGUMENT, "outputs are (Int32 offsets, child dtype values)");
+    if (out_offsets->capacity < a.n + 1) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
+    size_t es = (size_t)dtype_size(a.vals->dtype);
+    int64_t o = 0;
+    int32_t* oo = (int32_t*)out_offsets->values;
+    for (int64_t i = 0; i < a.n; i++) {
+        oo[i] = (int32_t)o;
+        if (!list_valid(&a, i)) continue;                                   /* c.append(true): an empty valid list, array.rs:83 */
+        int64_t na = a.off[i + 1] - a.off[i], nb = lb ? b.off[i + 1] - b.off[i] : 0, nu = 0, no = 0;
+        eref* u = (eref*)malloc(sizeof(eref) * (size_t)(na + nb + 1));
+        eref* w = (eref*)malloc(sizeof(eref) * (size_t)(nb + 1));
+        eref* r = (eref*)malloc(sizeof(eref) * (size_t)(na + 1));
+        if (!u || !w || !r) { free(u); free(w); free(r); FAIL(RDF_MEMORY_ERROR, "out of memory"); }
+        for (int64_t k = 0; k < na; k++) u[nu++] = (eref){a.vals, a.off[i] + k};
+        for (int64_t k = 0; k < nb; k++) w[k] = (eref){b.vals, b.off[i] + k};
+        const eref* res = u;
+        int64_t nres = 0, reps = 1;
+        switch (op) {
+            case SET_DISTINCT: evec_unique(u, &nu); nres = nu; break;
+            case SET_EXCEPT: {
+                int64_t nw = nb;
+                evec_unique(u, &nu);
+                evec_unique(w, &nw);
+                for (int64_t x = 0; x < nw; x++)
+                    for (int64_t y = nu - 1; y >= 0; y--)
+                        if (eref_eq(w[x], u[y])) evec_remove(u, &nu, y);
+                nres = nu;
+                break;
+            }
+            case SET_INTERSECT:
+                evec_unique(u, &nu);
+                for (int64_t x = 0; x < nu; x++)
+                    for (int64_t y = 0; y < nb; y++)
+                        if (eref_eq(u[x], w[y])) { r[no++] = u[x]; break; }
+                res = r; nres = no;
+                break;
+            case SET_UNION:
+                for (int64_t k = 0; k < nb; k++) u[nu++] = w[k];
+                evec_unique(u, &nu);
+                nres = nu;
+                break;
+            default: nres = na; reps = count; break;                        /* times(count) */
+        }
+        for (int64_t t = 0; t < reps; t++)
+            for (int64_t k = 0; k < nres; k++) {
+                if (o >= out_values->capacity) { free(u); free(w); free(r); FAIL(RDF_MEMORY_ERROR, "values capacity too small"); }
+                memcpy((char*)out_values->values + (size_t)o * es, (const char*)res[k].arr->values + (size_t)(res[k].arr->offset + res[k].e) * es, es);
+                o++;
+            }
+        free(u); free(w); free(r);
+        if (o > INT32_MAX) FAIL(RDF_COMPUTE_ERROR, "result overflows the Int32 value_offsets");
+    }
+    oo[a.n] = (int32_t)o;
+    out_offsets->length = a.n + 1; out_offsets->null_count = 0;
+    out_values->length = o; out_values->null_count = 0;
+    if (out_offsets->validity) memset(out_offsets->validity, 0xFF, (size_t)((a.n + 8) / 8));
+    if (out_values->validity) memset(out_values->validity, 0xFF, (size_t)((o + 7) / 8));
+    return RDF_OK;
+}
+rdf_status ora_list_distinct(const rdf_list_array* l, rdf_out* oo, rdf_out* ov) { return list_set(l, NULL, SET_DISTINCT, 0, oo, ov); }
+rdf_status ora_list_except(const rdf_list_array* a, const rdf_list_array* b, rdf_out* oo, rdf_out* ov) { if (!b) FAIL(RDF_INVALID_ARGUMENT, "null list"); return list_set(a, b, SET_EXCEPT, 0, oo, ov); }
+rdf_status ora_list_intersect(const rdf_list_array* a, const rdf_list_array* b, rdf_out* oo, rdf_out* ov) { if (!b) FAIL(RDF_INVALID_ARGUMENT, "null list"); return list_set(a, b, SET_INTERSECT, 0, oo, ov); }
+rdf_status ora_list_union(const rdf_list_array* a, const rdf_list_array* b, rdf_out* oo, rdf_out* ov) { if (!b) FAIL(RDF_INVALID_ARGUMENT, "null list"); return list_set(a, b, SET_UNION, 0, oo, ov); }
+rdf_status ora_list_repeat(const rdf_list_array* l, int32_t count, rdf_out* oo, rdf_out* ov) { return list_set(l, NULL, SET_REPEAT, count, oo, ov); }
+
 /* ------------------------------------------------------------------ sort
  * DataFrame::sort (src/dataframe.rs:194-214): concat every sort column (Column::to_array), then
  * arrow::compute::lexsort_to_indices with SortOptions{descending, nulls_first: false}.  Restated as a

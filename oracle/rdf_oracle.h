@@ -71,6 +71,11 @@ rdf_status ora_list_max(const rdf_list_array* list, rdf_out* out);
 rdf_status ora_list_min(const rdf_list_array* list, rdf_out* out);
 rdf_status ora_list_remove(const rdf_list_array* list, const void* value, rdf_out* out_offsets, rdf_out* out_values);
 rdf_status ora_list_sort(const rdf_list_array* list, rdf_out* out_values);
+rdf_status ora_list_distinct(const rdf_list_array* list, rdf_out* out_offsets, rdf_out* out_values);
+rdf_status ora_list_except(const rdf_list_array* a, const rdf_list_array* b, rdf_out* out_offsets, rdf_out* out_values);
+rdf_status ora_list_intersect(const rdf_list_array* a, const rdf_list_array* b, rdf_out* out_offsets, rdf_out* out_values);
+rdf_status ora_list_union(const rdf_list_array* a, const rdf_list_array* b, rdf_out* out_offsets, rdf_out* out_values);
+rdf_status ora_list_repeat(const rdf_list_array* list, int32_t count, rdf_out* out_offsets, rdf_out* out_values);
 
 rdf_status ora_fill_uniform_f64(double* ptr, int64_t n, uint64_t seed, uint64_t column_id,
                                 int64_t first_row, double lo, double hi);

@@ -348,7 +348,7 @@ class Api:
         self._err = getattr(lib, prefix + "last_error")
         self._err.restype = C.c_char_p
         for name in ("binary", "unary", "cast", "sum", "min", "max", "count", "avg", "predicate", "filter_count",
-                     "filter", "filter_columns", "take", "pipeline", "group_pipeline", "groupby_sum", "list_contains", "list_position", "list_max", "list_min", "list_remove", "list_sort", "sort_to_indices", "equijoin_indices", "equijoin_indices_multi", "fill_uniform_f64",
+                     "filter", "filter_columns", "take", "pipeline", "group_pipeline", "groupby_sum", "list_contains", "list_position", "list_max", "list_min", "list_remove", "list_sort", "list_distinct", "list_except", "list_intersect", "list_union", "list_repeat", "sort_to_indices", "equijoin_indices", "equijoin_indices_multi", "fill_uniform_f64",
                      "fill_uniform_i64", "fill_validity"):
             fn = getattr(lib, prefix + name)
             fn.restype = C.c_int
@@ -608,6 +608,26 @@ class Api:
         co, cv = (rdf_out * 1)(oo.out_struct()), (rdf_out * 1)(ov.out_struct())
         v = self._scalar(value, lst.values.dtype)
         self._check(self._fn("list_remove")(C.byref(lst.c_struct()), C.c_void_p(v.ctypes.data), co, cv))
+        self._finish([oo], co)
+        self._finish([ov], cv)
+        return oo, ov
+
+    def list_set(self, op: str, lst, other=None, count: int = 0, outs=None):
+        """array_distinct / array_except / array_intersect / array_union / array_repeat -> (offsets int32 [rows + 1], values)"""
+        cap = {"distinct": lst.values.length, "except": lst.values.length, "intersect": lst.values.length,
+               "union": lst.values.length + (other.values.length if other is not None else 0),
+               "repeat": lst.values.length * max(0, count)}[op]
+        oo, ov = outs if outs is not None else (HostArray.empty_out(I32, lst.length + 1, False),
+                                                HostArray.empty_out(lst.values.dtype, max(1, cap), False))
+        co, cv = (rdf_out * 1)(oo.out_struct()), (rdf_out * 1)(ov.out_struct())
+        fn = self._fn("list_" + op)
+        if op == "distinct":
+            st = fn(C.byref(lst.c_struct()), co, cv)
+        elif op == "repeat":
+            st = fn(C.byref(lst.c_struct()), C.c_int32(count), co, cv)
+        else:
+            st = fn(C.byref(lst.c_struct()), C.byref(other.c_struct()) if other is not None else None, co, cv)
+        self._check(st)
         self._finish([oo], co)
         self._finish([ov], cv)
         return oo, ov

@@ -1916,13 +1916,23 @@ rdf_status rdf_list_position(const rdf_list_array* list, const void* value, rdf_
 rdf_status rdf_list_max(const rdf_list_array* list, rdf_out* out) { return list_reduce(list, LIST_MAX, nullptr, out, "array_max"); }
 rdf_status rdf_list_min(const rdf_list_array* list, rdf_out* out) { return list_reduce(list, LIST_MIN, nullptr, out, "array_min"); }
 
-rdf_status rdf_list_remove(const rdf_list_array* list, const void* value, rdf_out* out_offsets, rdf_out* out_values) {
-    int64_t n = 0;
+namespace {
+// The list-valued ArrayFunctions that rebuild every row from its own elements (array_remove, array_distinct,
+// array_except / intersect / union, array_repeat): count per row -> scan -> write at the scanned offsets.
+rdf_status list_rebuild(const rdf_list_array* list, const rdf_list_array* other, int op, uint64_t needle, int32_t count,
+                        rdf_out* out_offsets, rdf_out* out_values, const char* fn) {
+    int64_t n = 0, nb = 0;
     int32_t mem = -1;
-    RDF_TRY(list_check(list, "array_remove", &n, &mem));
-    if (!value || !out_offsets || !out_values) return fail(RDF_INVALID_ARGUMENT, "array_remove: null argument");
+    RDF_TRY(list_check(list, fn, &n, &mem));
+    if (!out_offsets || !out_values) return fail(RDF_INVALID_ARGUMENT, "%s: null argument", fn);
+    if (other) {
+        RDF_TRY(list_check(other, fn, &nb, &mem));
+        // array.rs:72-76,116-120,362-366
+        if (nb != n) return fail(RDF_COMPUTE_ERROR, "Expected array a and b to have the same length");
+        if (other->values.dtype != list->values.dtype) return fail(RDF_INVALID_ARGUMENT, "%s: both lists must have the same child dtype", fn);
+    }
     const int cdt = list->values.dtype;
-    if (out_offsets->dtype != RDF_I32 || out_values->dtype != cdt) return fail(RDF_INVALID_ARGUMENT, "array_remove: outputs are (Int32 offsets, child dtype values)");
+    if (out_offsets->dtype != RDF_I32 || out_values->dtype != cdt) return fail(RDF_INVALID_ARGUMENT, "%s: outputs are (Int32 offsets, child dtype values)", fn);
     RDF_TRY(check_out_mem(out_offsets, 1, mem));
     RDF_TRY(check_out_mem(out_values, 1, mem));
     if (out_offsets->capacity < n + 1) return fail(RDF_MEMORY_ERROR, "output capacity too small (offsets need rows + 1)");
@@ -1930,13 +1940,21 @@ rdf_status rdf_list_remove(const rdf_list_array* list, const void* value, rdf_ou
     Ctx& ctx = g_ctx;
     arena_begin();
     size_t pin_off = 0, used = 0;
-    rdf_array offs = list->offsets, lv = list->offsets;
+    rdf_array offs = list->offsets, lv = list->offsets, offs_b;
     offs.length = n + 1; offs.validity = nullptr; offs.null_count = 0;
     lv.values = list->offsets.validity; lv.validity = nullptr; lv.dtype = RDF_BOOL; lv.length = n; lv.null_count = 0;
     InputStager in;
     in.add(&offs);
     in.add(&list->values);
-    if (list->offsets.validity) in.add(&lv);
+    int ib = -1, iv = -1;
+    if (other) {
+        offs_b = other->offsets;
+        offs_b.length = n + 1; offs_b.validity = nullptr; offs_b.null_count = 0;
+        ib = 2;
+        in.add(&offs_b);
+        in.add(&other->values);
+    }
+    if (list->offsets.validity) { iv = other ? 4 : 2; in.add(&lv); }
     RDF_TRY(in.finish(pin_off, &used));
     pin_off += (used + 255) & ~(size_t)255;
     void *pkept, *pscan, *poff32;
@@ -1946,16 +1964,40 @@ rdf_status rdf_list_remove(const rdf_list_array* list, const void* value, rdf_ou
     ListArgs la;
     memset(&la, 0, sizeof la);
     la.offsets = in.dev[0];
-    if (list->offsets.validity) la.offsets.validity = (const uint8_t*)in.dev[2].values;
+    if (iv >= 0) la.offsets.validity = (const uint8_t*)in.dev[iv].values;
     la.values = in.dev[1];
+    if (other) { la.offsets_b = in.dev[ib]; la.values_b = in.dev[ib + 1]; }
     la.n = n;
     la.dtype = cdt;
-    la.needle = scalar_bits(value, cdt);
+    la.op = op;
+    la.needle = needle;
+    la.count = count;
     la.kept = (int64_t*)pkept;
-    const bool wave_per_row = n > 0 && list->values.length / n >= 48;
+    const int64_t nelem = list->values.length + (other ? other->values.length : 0);
+    const bool wave_per_row = n > 0 && nelem / n >= 48;
+    const bool is_remove = op == LIST_REMOVE;
+    if (!is_remove && op != LIST_REPEAT) {   // the row-per-wave kernel's tables (rdf_list.hip) and the worklist that feeds it
+        void *pta, *ptb = nullptr, *pwork;
+        RDF_TRY(arena_alloc((size_t)list->values.length * 8 + 64, &pta));
+        if (other) RDF_TRY(arena_alloc((size_t)other->values.length * 8 + 64, &ptb));
+        la.tab_a = (uint32_t*)pta;
+        la.tab_b = (uint32_t*)ptb;
+        if (!wave_per_row) {
+            RDF_TRY(arena_alloc((size_t)n * 4 + 64, &pwork));
+            la.work = (uint32_t*)pwork + 16;
+            la.work_count = (uint32_t*)pwork;
+            HIP_TRY(hipMemsetAsync(pwork, 0, 64, ctx.stream));
+        }
+    } else if (op == LIST_REPEAT && !wave_per_row) {
+        void* pwork;
+        RDF_TRY(arena_alloc((size_t)n * 4 + 64, &pwork));
+        la.work = (uint32_t*)pwork + 16;
+        la.work_count = (uint32_t*)pwork;
+        HIP_TRY(hipMemsetAsync(pwork, 0, 64, ctx.stream));
+    }
     KernelTimer kt;
-    ctx.last_kernel = wave_per_row ? "list_remove_wave_kernel" : "list_remove_kernel";
-    HIP_TRY(launch_list_remove(la, wave_per_row, ctx.stream));
+    ctx.last_kernel = is_remove ? (wave_per_row ? "list_remove_wave_kernel" : "list_remove_kernel") : (wave_per_row ? "list_set_wave_kernel" : "list_set_kernel + list_set_wave_kernel");
+    HIP_TRY(is_remove ? launch_list_remove(la, wave_per_row, ctx.stream) : launch_list_set(la, wave_per_row, ctx.stream));
     HIP_TRY(launch_scan((const int64_t*)pkept, (int64_t*)pscan, n, (int64_t*)pscan + n + 1, ctx.stream));
     HIP_TRY(launch_list_offsets((const int64_t*)pscan, n + 1, (int32_t*)poff32, ctx.stream));
     RDF_TRY(pinned_reserve(pin_off + 64));
@@ -1963,13 +2005,14 @@ rdf_status rdf_list_remove(const rdf_list_array* list, const void* value, rdf_ou
     HIP_TRY(hipStreamSynchronize(ctx.stream));
     int64_t total = 0;
     memcpy(&total, ctx.pinned + pin_off, 8);
-    if (out_values->capacity < total) return fail(RDF_MEMORY_ERROR, "array_remove: values capacity too small (need %lld)", (long long)total);
+    if (total > INT32_MAX) return fail(RDF_COMPUTE_ERROR, "%s: %lld result elements overflow the Int32 value_offsets", fn, (long long)total);
+    if (out_values->capacity < total) return fail(RDF_MEMORY_ERROR, "%s: values capacity too small (need %lld)", fn, (long long)total);
     const size_t es = (size_t)dtype_size(cdt);
     void* dvals = out_values->values;
     if (mem == RDF_MEM_HOST) RDF_TRY(arena_alloc((size_t)total * es + 64, &dvals));
     la.scan = (const int64_t*)pscan;
     la.out = DevOutChunk{dvals, nullptr};
-    HIP_TRY(launch_list_remove(la, wave_per_row, ctx.stream));
+    HIP_TRY(is_remove ? launch_list_remove(la, wave_per_row, ctx.stream) : launch_list_set(la, wave_per_row, ctx.stream));
     kt.stop();
     const hipMemcpyKind kind = mem == RDF_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     HIP_TRY(hipMemcpyAsync(out_offsets->values, poff32, (size_t)(n + 1) * 4, kind, ctx.stream));
@@ -1984,6 +2027,33 @@ rdf_status rdf_list_remove(const rdf_list_array* list, const void* value, rdf_ou
     out_offsets->length = n + 1; out_offsets->null_count = 0;
     out_values->length = total; out_values->null_count = 0;
     return RDF_OK;
+}
+}  // namespace
+
+rdf_status rdf_list_remove(const rdf_list_array* list, const void* value, rdf_out* out_offsets, rdf_out* out_values) {
+    if (!value) return fail(RDF_INVALID_ARGUMENT, "array_remove: null argument");
+    if (!list || !is_numeric(list->values.dtype)) return list_rebuild(list, nullptr, LIST_REMOVE, 0, 0, out_offsets, out_values, "array_remove");
+    return list_rebuild(list, nullptr, LIST_REMOVE, scalar_bits(value, list->values.dtype), 0, out_offsets, out_values, "array_remove");
+}
+rdf_status rdf_list_distinct(const rdf_list_array* list, rdf_out* out_offsets, rdf_out* out_values) {
+    return list_rebuild(list, nullptr, LIST_DISTINCT, 0, 0, out_offsets, out_values, "array_distinct");
+}
+rdf_status rdf_list_except(const rdf_list_array* a, const rdf_list_array* b, rdf_out* out_offsets, rdf_out* out_values) {
+    if (!b) return fail(RDF_INVALID_ARGUMENT, "array_except: null list");
+    return list_rebuild(a, b, LIST_EXCEPT, 0, 0, out_offsets, out_values, "array_except");
+}
+rdf_status rdf_list_intersect(const rdf_list_array* a, const rdf_list_array* b, rdf_out* out_offsets, rdf_out* out_values) {
+    if (!b) return fail(RDF_INVALID_ARGUMENT, "array_intersect: null list");
+    return list_rebuild(a, b, LIST_INTERSECT, 0, 0, out_offsets, out_values, "array_intersect");
+}
+rdf_status rdf_list_union(const rdf_list_array* a, const rdf_list_array* b, rdf_out* out_offsets, rdf_out* out_values) {
+    if (!b) return fail(RDF_INVALID_ARGUMENT, "array_union: null list");
+    return list_rebuild(a, b, LIST_UNION, 0, 0, out_offsets, out_values, "array_union");
+}
+rdf_status rdf_list_repeat(const rdf_list_array* list, int32_t count, rdf_out* out_offsets, rdf_out* out_values) {
+    // `times(count)` sizes a Vec with `count as usize`: a negative count aborts the reference (capacity overflow)
+    if (count < 0) return fail(RDF_INVALID_ARGUMENT, "array_repeat: negative count %d", count);
+    return list_rebuild(list, nullptr, LIST_REPEAT, 0, count, out_offsets, out_values, "array_repeat");
 }
 
 // array_sort = a two-column sort of the child elements by (row number, value), composed from the public entry points

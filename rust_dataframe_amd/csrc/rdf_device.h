@@ -326,7 +326,8 @@ struct TakeArgs {
 };
 
 // ArrayFunctions over List<primitive> (rdf_list.hip)
-enum : int32_t { LIST_CONTAINS = 0, LIST_POSITION = 1, LIST_MAX = 2, LIST_MIN = 3 };
+enum : int32_t { LIST_CONTAINS = 0, LIST_POSITION = 1, LIST_MAX = 2, LIST_MIN = 3,
+                 LIST_REMOVE = 4, LIST_DISTINCT = 5, LIST_EXCEPT = 6, LIST_INTERSECT = 7, LIST_UNION = 8, LIST_REPEAT = 9 };
 struct ListArgs {
     DevChunkCol offsets;     // int32 value_offsets [n + 1]; its validity bits are the LIST rows' validity
     DevChunkCol values;      // child values
@@ -337,10 +338,18 @@ struct ListArgs {
     int64_t*    out_null_count;
     int64_t*    kept;        // array_remove pass 1 out: kept elements per row
     const int64_t* scan;     // array_remove pass 2 in: their exclusive scan (nullptr selects pass 1)
+    DevChunkCol offsets_b;   // second list of except / intersect / union (its validity is not looked at, array.rs:82,126,372)
+    DevChunkCol values_b;
+    int32_t     count;       // array_repeat
+    uint32_t*   tab_a;       // set functions, one row per wave: value -> first index tables, 2 slots per child element
+    uint32_t*   tab_b;
+    uint32_t*   work;        // rows left to the row-per-wave kernel by the row-per-lane one (nullptr: all rows)
+    uint32_t*   work_count;
 };
 hipError_t launch_list_op(const ListArgs& a, bool wave_per_row, hipStream_t s);
 hipError_t launch_list_row_ids(const ListArgs& a, uint32_t* row_ids, int32_t first, hipStream_t s);
 hipError_t launch_list_remove(const ListArgs& a, bool wave_per_row, hipStream_t s);
+hipError_t launch_list_set(const ListArgs& a, bool wave_per_row, hipStream_t s);   // distinct / except / intersect / union / repeat
 hipError_t launch_list_offsets(const int64_t* scan, int64_t n1, int32_t* out, hipStream_t s);
 
 // ---- launch wrappers (defined in rdf_kernels.hip) ----

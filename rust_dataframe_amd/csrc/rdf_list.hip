@@ -8,7 +8,9 @@
 //   list_wave_kernel<T>  : one list row per WAVE (long lists): lanes stride the slice, butterfly reduction
 //   list_row_ids_kernel  : element -> row number (for the sort / remove compositions in rdf_capi.cpp)
 //   list_remove_kernel<T>: array_remove in two passes (count per row -> scan -> write at the scanned offsets)
+//   list_set_kernel<T>   : distinct / except / intersect / union / repeat, the same two passes with a membership rule
 #include "rdf_common.hip.h"
+#include <type_traits>
 
 namespace rdfk {
 
@@ -295,6 +297,227 @@ hipError_t launch_list_remove(const ListArgs& a, bool wave_per_row, hipStream_t 
     if (grid64 > eval_grid_limit()) grid64 = eval_grid_limit();
     const int grid = (int)grid64;
     if (wave_per_row) { RDF_LIST_DISPATCH(list_remove_wave_kernel) } else { RDF_LIST_DISPATCH(list_remove_kernel) }
+    return hipGetLastError();
+}
+// array_distinct / array_except / array_intersect / array_union / array_repeat (array.rs:39-153,294-399; the per-row
+// set algebra is the array_tool crate's: `unique` keeps first occurrences in order, `uniq(b)` = unique(a) without the
+// members of b, `intersect(b)` = unique(a) restricted to the members of b, `union(b)` = unique(a ++ b), `times(c)` =
+// the slice c times over).  Equality is the element type's `==` (NaN equals nothing, -0.0 == 0.0).  Every output
+// element is an input element that passes a membership test against the elements before it, so the kernels are the
+// array_remove ones with a different keep rule: pass 1 counts per row, pass 2 writes at the scanned offsets.
+//
+//   list_set_kernel      : one row per lane over runs of consecutive rows whose slices fit the LDS staging area
+//                          (<= 768 elements per input): the crate's quadratic compare loops, from LDS.  A row that
+//                          does not fit on its own goes to a worklist instead.
+//   list_set_wave_kernel : one row per wave, any length, linear work: an open-addressing table per row (2 slots per
+//                          element, in device scratch) maps a value to the SMALLEST element index holding it
+//                          (CAS to claim a slot, atomicMin on the index); "first occurrence" and "member of b" are then
+//                          table lookups.  Pass 1 builds the tables and counts, pass 2 only looks up.
+constexpr int kSetStage = 768;   // child elements of each input (and of the output) staged per wave: 72 KiB per block for 8-byte children
+constexpr uint32_t kSetEmpty = 0xFFFFFFFFu;
+
+template <class T> __device__ __forceinline__ uint32_t set_hash(T v) {
+    uint64_t bits;
+    if constexpr (sizeof(T) == 8 && !std::is_integral<T>::value) bits = d2u((double)v + 0.0);          // -0.0 hashes like 0.0
+    else if constexpr (!std::is_integral<T>::value) bits = __float_as_uint((float)v + 0.0f);
+    else bits = (uint64_t)(int64_t)v;
+    bits ^= bits >> 32;
+    bits *= 0x9E3779B97F4A7C15ull;
+    return (uint32_t)(bits >> 32);
+}
+__device__ __forceinline__ uint32_t set_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One row's table: `size` slots (>= 2 * elements) holding row-relative element indices
+template <class T> struct SetTable {
+    uint32_t* tab;
+    uint32_t size;
+    GlobalPtr<T> vals;   // the row's first element
+    __device__ __forceinline__ uint32_t home(T v) const { return (uint32_t)(((uint64_t)set_hash<T>(v) * size) >> 32); }
+    __device__ void insert(uint32_t i, T v) const {
+        uint32_t s = home(v);
+        for (;;) {
+            uint32_t cur = set_load(tab + s);
+            if (cur == kSetEmpty) {
+                cur = atomicCAS(tab + s, kSetEmpty, i);
+                if (cur == kSetEmpty) return;
+            }
+            if (vals[cur] == v) { atomicMin(tab + s, i); return; }
+            s = s + 1 == size ? 0 : s + 1;
+        }
+    }
+    // the smallest index holding v, kSetEmpty when v is not a member
+    __device__ uint32_t find(T v) const {
+        if (size == 0) return kSetEmpty;
+        uint32_t s = home(v);
+        for (;;) {
+            const uint32_t cur = set_load(tab + s);
+            if (cur == kSetEmpty || vals[cur] == v) return cur;
+            s = s + 1 == size ? 0 : s + 1;
+        }
+    }
+};
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void list_set_kernel(const ListArgs a) {
+    __shared__ T sa[kBlock / 64][kSetStage];
+    __shared__ T sb[kBlock / 64][kSetStage];
+    __shared__ T so[kBlock / 64][kSetStage];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const GlobalPtr<int32_t> offa = as_global<int32_t>(a.offsets.values) + a.offsets.offset;
+    const GlobalPtr<T> va = as_global<T>(a.values.values) + a.values.offset;
+    const bool two = a.op == LIST_EXCEPT || a.op == LIST_INTERSECT || a.op == LIST_UNION;
+    const GlobalPtr<int32_t> offb = two ? as_global<int32_t>(a.offsets_b.values) + a.offsets_b.offset : offa;
+    const GlobalPtr<T> vb = two ? as_global<T>(a.values_b.values) + a.values_b.offset : va;
+    const int64_t nwaves = (a.n + 63) >> 6;
+    for (int64_t wv = (int64_t)blockIdx.x * (kBlock / 64) + w; wv < nwaves; wv += (int64_t)gridDim.x * (kBlock / 64)) {
+        const int64_t row = wv * 64 + lane;
+        const bool inr = row < a.n;
+        bool lvalid = inr;
+        if (inr && a.offsets.validity) { const int64_t bi = a.offsets.offset + row; lvalid = (as_global<uint8_t>(a.offsets.validity)[bi >> 3] >> (bi & 7)) & 1; }
+        // value_offsets are monotone, also across NULL rows: consecutive rows cover one contiguous span of the child arrays
+        const int32_t la_lo = offa[inr ? row : a.n], la_hi = offa[inr ? row + 1 : a.n];
+        const int32_t lb_lo = two ? offb[inr ? row : a.n] : 0, lb_hi = two ? offb[inr ? row + 1 : a.n] : 0;
+        const int nrows = a.n - wv * 64 < 64 ? (int)(a.n - wv * 64) : 64;
+        if (!a.scan && inr) a.kept[row] = 0;
+        // the wave's rows are taken in runs of consecutive rows whose spans fit the staging areas (usually one run)
+        for (int start = 0; start < nrows;) {
+            const int32_t a0 = __shfl(la_lo, start), b0 = __shfl(lb_lo, start);
+            const bool fits = lane >= start && inr && la_hi - a0 <= kSetStage && lb_hi - b0 <= kSetStage;
+            const int cnt = __popcll(__ballot(fits));   // monotone in the lane: the run is [start, start + cnt)
+            if (cnt == 0) {   // this row alone is too long: it goes to the row-per-wave kernel
+                if (!a.scan && lane == start && lvalid && (la_hi > la_lo || lb_hi > lb_lo)) a.work[atomicAdd(a.work_count, 1u)] = (uint32_t)row;
+                ++start;
+                continue;
+            }
+            const int last = start + cnt - 1;
+            const int32_t an = __shfl(la_hi, last) - a0, bn = __shfl(lb_hi, last) - b0;
+            const bool mine = fits && lvalid;
+            const int32_t ba = mine ? la_lo : 0, ea = mine ? la_hi : 0, bb = mine ? lb_lo : 0, eb = mine ? lb_hi : 0;
+            for (int32_t i = lane; i < an; i += 64) sa[w][i] = va[a0 + i];
+            for (int32_t i = lane; i < bn; i += 64) sb[w][i] = vb[b0 + i];
+            __builtin_amdgcn_wave_barrier();
+            auto in_a = [&](T v, int32_t upto) { for (int32_t k = ba; k < upto; ++k) if (sa[w][k - a0] == v) return true; return false; };
+            auto in_b = [&](T v, int32_t upto) { for (int32_t k = bb; k < upto; ++k) if (sb[w][k - b0] == v) return true; return false; };
+            int64_t out0 = 0, out_n = 0, o = 0;
+            if (a.scan) { out0 = a.scan[wv * 64 + start]; out_n = a.scan[wv * 64 + last + 1] - out0; o = fits ? a.scan[row] : 0; }
+            const bool ostaged = a.scan && out_n <= kSetStage;
+            int64_t c = 0;
+            auto emit = [&](T v) {
+                if (a.scan) {
+                    if (ostaged) so[w][o - out0] = v; else as_global_mut<T>(a.out.values)[o] = v;
+                    ++o;
+                } else ++c;
+            };
+            if (a.op == LIST_REPEAT) {
+                if (!a.scan) c = (int64_t)(ea - ba) * a.count;
+                else for (int32_t r = 0; r < a.count; ++r) for (int32_t i = ba; i < ea; ++i) emit(sa[w][i - a0]);
+            } else {
+                for (int32_t j = ba; j < ea; ++j) {
+                    const T v = sa[w][j - a0];
+                    bool keep = !in_a(v, j);
+                    if (keep && a.op == LIST_EXCEPT) keep = !in_b(v, eb);
+                    if (keep && a.op == LIST_INTERSECT) keep = in_b(v, eb);
+                    if (keep) emit(v);
+                }
+                if (a.op == LIST_UNION)
+                    for (int32_t j = bb; j < eb; ++j) {
+                        const T v = sb[w][j - b0];
+                        if (!in_a(v, ea) && !in_b(v, j)) emit(v);
+                    }
+            }
+            if (!a.scan) { if (fits) a.kept[row] = c; }
+            else if (ostaged) {
+                __builtin_amdgcn_wave_barrier();
+                for (int64_t i = lane; i < out_n; i += 64) as_global_mut<T>(a.out.values)[out0 + i] = so[w][i];
+            }
+            __builtin_amdgcn_wave_barrier();   // the next run refills the staging areas
+            start += cnt;
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void list_set_wave_kernel(const ListArgs a) {
+    const int lane = threadIdx.x & 63;
+    const GlobalPtr<int32_t> offa = as_global<int32_t>(a.offsets.values) + a.offsets.offset;
+    const GlobalPtr<T> va = as_global<T>(a.values.values) + a.values.offset;
+    const bool two = a.op == LIST_EXCEPT || a.op == LIST_INTERSECT || a.op == LIST_UNION;
+    const GlobalPtr<int32_t> offb = two ? as_global<int32_t>(a.offsets_b.values) + a.offsets_b.offset : offa;
+    const GlobalPtr<T> vb = two ? as_global<T>(a.values_b.values) + a.values_b.offset : va;
+    const int64_t nwork = a.work ? (int64_t)*a.work_count : a.n;   // the worklist of list_set_kernel, or every row
+    for (int64_t wi = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); wi < nwork; wi += (int64_t)gridDim.x * (kBlock / 64)) {
+        const int64_t row = a.work ? (int64_t)a.work[wi] : wi;
+        bool lvalid = true;
+        if (a.offsets.validity) { const int64_t bi = a.offsets.offset + row; lvalid = (as_global<uint8_t>(a.offsets.validity)[bi >> 3] >> (bi & 7)) & 1; }
+        const int32_t ba = lvalid ? offa[row] : 0, ea = lvalid ? offa[row + 1] : 0;
+        const int32_t bb = lvalid && two ? offb[row] : 0, eb = lvalid && two ? offb[row + 1] : 0;
+        int64_t o = a.scan ? a.scan[row] : 0, c = 0;
+        if (a.op == LIST_REPEAT) {
+            const int64_t len = ea - ba, total = len * a.count;
+            if (a.scan) for (int64_t t = lane; t < total; t += 64) as_global_mut<T>(a.out.values)[o + t] = va[ba + t % len];
+            else if (lane == 0) a.kept[row] = total;
+            continue;
+        }
+        const SetTable<T> ta{a.tab_a + 2 * (int64_t)ba, (uint32_t)(2 * (ea - ba)), va + ba};
+        const SetTable<T> tb{a.tab_b + 2 * (int64_t)bb, (uint32_t)(2 * (eb - bb)), vb + bb};
+        if (!a.scan) {   // pass 1 builds the tables (pass 2 finds them as they were left)
+            for (uint32_t i = lane; i < ta.size; i += 64) ta.tab[i] = kSetEmpty;
+            for (uint32_t i = lane; i < tb.size; i += 64) tb.tab[i] = kSetEmpty;
+            __threadfence();
+            __builtin_amdgcn_wave_barrier();
+            for (int32_t i = ba + lane; i < ea; i += 64) { const T v = va[i]; if (!list_is_nan(v)) ta.insert((uint32_t)(i - ba), v); }
+            for (int32_t i = bb + lane; i < eb; i += 64) { const T v = vb[i]; if (!list_is_nan(v)) tb.insert((uint32_t)(i - bb), v); }
+            __threadfence();
+            __builtin_amdgcn_wave_barrier();
+        }
+        auto flush = [&](bool keep, T v) {
+            const uint64_t m = __ballot(keep);
+            if (a.scan) {
+                if (keep) as_global_mut<T>(a.out.values)[o + __popcll(m & ((1ull << lane) - 1))] = v;
+                o += __popcll(m);
+            } else c += __popcll(m);
+        };
+        for (int32_t i0 = ba; i0 < ea; i0 += 64) {   // candidates from a: first occurrence in a (+ the b membership rule)
+            const int32_t i = i0 + lane;
+            const bool have = i < ea;
+            const T v = have ? va[i] : (T)0;
+            bool keep = false;
+            if (have) {
+                const bool nan = list_is_nan(v);
+                keep = nan || ta.find(v) == (uint32_t)(i - ba);
+                if (a.op == LIST_EXCEPT) keep = keep && (nan || tb.find(v) == kSetEmpty);
+                if (a.op == LIST_INTERSECT) keep = keep && !nan && tb.find(v) != kSetEmpty;
+            }
+            flush(keep, v);
+        }
+        if (a.op == LIST_UNION)
+            for (int32_t i0 = bb; i0 < eb; i0 += 64) {   // candidates from b: not in a, first occurrence in b
+                const int32_t i = i0 + lane;
+                const bool have = i < eb;
+                const T v = have ? vb[i] : (T)0;
+                bool keep = false;
+                if (have) keep = list_is_nan(v) || (tb.find(v) == (uint32_t)(i - bb) && ta.find(v) == kSetEmpty);
+                flush(keep, v);
+            }
+        if (!a.scan && lane == 0) a.kept[row] = c;
+    }
+}
+// wave_per_row: every row through the table kernel; otherwise the row-per-lane kernel first and the table kernel over
+// the worklist it left behind (nothing to do when no group of 64 rows overflowed the staging area)
+hipError_t launch_list_set(const ListArgs& a, bool wave_per_row, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    if (!wave_per_row) {
+        int64_t grid64 = ((a.n + 63) / 64 + (kBlock / 64) - 1) / (kBlock / 64);
+        if (grid64 > eval_grid_limit()) grid64 = eval_grid_limit();
+        const int grid = (int)grid64;
+        RDF_LIST_DISPATCH(list_set_kernel)
+    }
+    {
+        int64_t grid64 = wave_per_row ? (a.n + (kBlock / 64) - 1) / (kBlock / 64) : eval_grid_limit();
+        if (grid64 > eval_grid_limit()) grid64 = eval_grid_limit();
+        const int grid = (int)grid64;
+        RDF_LIST_DISPATCH(list_set_wave_kernel)
+    }
     return hipGetLastError();
 }
 hipError_t launch_list_offsets(const int64_t* scan, int64_t n1, int32_t* out, hipStream_t s) {

@@ -38,6 +38,64 @@ def test_device_reference_known_answers(gpu):
     check_reference_answers(gpu)
 
 
+def list_rows(offs, vals):
+    o, v = offs.to_numpy().tolist(), vals.to_numpy().tolist()
+    return [v[o[i]:o[i + 1]] for i in range(len(o) - 1)]
+
+
+def check_set_known_answers(api):
+    """The array_tool crate's documented examples (vec.rs doc comments of `unique`, `uniq`, `intersect`, `union`, `times`),
+    one per row, plus a NULL row (-> empty valid list) and an empty row."""
+    one = lambda rows, dt=A.I64: A.HostList.from_lists(rows, dt)
+    assert list_rows(*api.list_set("distinct", one([[1, 2, 1, 3, 2, 3, 4, 5, 6], None, []]))) == [[1, 2, 3, 4, 5, 6], [], []]
+    assert list_rows(*api.list_set("except", one([[1, 2, 3, 4, 5, 6], None, [7, 7]]), one([[1, 2, 5, 7, 9], [1], []]))) == [[3, 4, 6], [], [7]]
+    assert list_rows(*api.list_set("intersect", one([[1, 1, 3, 5], None, [2]]), one([[1, 2, 3], [1], []]))) == [[1, 3], [], []]
+    assert list_rows(*api.list_set("union", one([[1, 2, 3, 4, 5, 6], None, [2, 2]]), one([[5, 6, 7, 8, 9], [1], [3, 2, 3]]))) == [list(range(1, 10)), [], [2, 3]]
+    assert list_rows(*api.list_set("repeat", one([[1, 2, 3], None, []]), count=3)) == [[1, 2, 3] * 3, [], []]
+    assert list_rows(*api.list_set("repeat", one([[1, 2, 3]]), count=0)) == [[]]
+    # the fixture of the reference's own tests through the set functions
+    assert list_rows(*api.list_set("distinct", fixture(A.I32))) == [[0], [1, 2], [3, 4], [5, 1, 3, 2], [3, 2], [8, 3]]
+    # IEEE equality: NaN equals nothing (every NaN is "distinct"), -0.0 == 0.0 (the first one stays)
+    offs, vals = api.list_set("distinct", one([[float("nan"), 1.0, float("nan"), -0.0, 0.0, 1.0]], A.F64))
+    v = vals.to_numpy()
+    assert offs.to_numpy().tolist() == [0, 4] and np.isnan(v[0]) and v[1] == 1.0 and np.isnan(v[2]) and np.signbit(v[3])
+
+
+def test_oracle_set_known_answers(ora):
+    check_set_known_answers(ora)
+
+
+@pytest.mark.gpu
+def test_device_set_known_answers(gpu):
+    check_set_known_answers(gpu)
+
+
+def py_set_rows(op, a_rows, b_rows, count):
+    """An independent statement of the five results with Python lists (integers only)."""
+    out = []
+    for i, ra in enumerate(a_rows):
+        if ra is None:
+            out.append([])
+            continue
+        rb = (b_rows[i] or []) if b_rows is not None else []
+        uniq = list(dict.fromkeys(ra))
+        out.append({"distinct": uniq, "except": [x for x in uniq if x not in rb], "intersect": [x for x in uniq if x in rb],
+                    "union": list(dict.fromkeys(ra + rb)), "repeat": ra * count}[op])
+    return out
+
+
+def test_oracle_set_functions_against_python(ora):
+    rng = np.random.default_rng(77)
+    for dtype in (A.I8, A.I32, A.I64, A.U16):
+        a_rows = random_lists(rng, dtype, 300, 9, 0.1)
+        b_rows = random_lists(rng, dtype, 300, 7, 0.1)
+        la, lb = A.HostList.from_lists(a_rows, dtype, row_offset=2), A.HostList.from_lists(b_rows, dtype)
+        for op in ("distinct", "except", "intersect", "union", "repeat"):
+            two = op in ("except", "intersect", "union")
+            got = list_rows(*ora.list_set(op, la, lb if two else None, count=3))
+            assert got == py_set_rows(op, a_rows, b_rows if two else None, 3), f"{op} dtype={dtype}"
+
+
 def random_lists(rng, dtype, nrows, max_len, null_frac):
     npdt = A.NP_OF[dtype]
     rows = []
@@ -84,6 +142,72 @@ def test_list_functions_parity(gpu, ora, dtype):
         assert gs.length == os_.length
         a, b = gs.to_numpy(), os_.to_numpy()
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), "sort (bit-exact incl. NaN payloads and signed zeros) " + what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [A.I8, A.I32, A.I64, A.U16, A.U64, A.F32, A.F64])
+def test_list_set_functions_parity(gpu, ora, dtype):
+    rng = np.random.default_rng(6000 + dtype)
+    for nrows, max_len, nf, off in [(1, 0, 0.0, 0), (200, 6, 0.1, 0), (3000, 12, 0.05, 3), (700, 40, 0.1, 1), (70, 300, 0.1, 1), (5, 3000, 0.0, 0)]:
+        la = A.HostList.from_lists(random_lists(rng, dtype, nrows, max_len, nf), dtype, row_offset=off)
+        lb = A.HostList.from_lists(random_lists(rng, dtype, nrows, max(1, max_len // 2), nf), dtype, row_offset=1)
+        for op in ("distinct", "except", "intersect", "union", "repeat"):
+            other = lb if op in ("except", "intersect", "union") else None
+            (go, gv), (oo, ov) = gpu.list_set(op, la, other, count=3), ora.list_set(op, la, other, count=3)
+            what = f"{op} dtype={dtype} rows={nrows} max_len={max_len}"
+            assert np.array_equal(go.to_numpy(), oo.to_numpy()) and gv.length == ov.length, "offsets " + what
+            assert np.array_equal(gv.to_numpy().view(np.uint8), ov.to_numpy().view(np.uint8)), "values (bit-exact) " + what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [A.I32, A.I64, A.F64])
+def test_list_set_functions_mixed_row_lengths(gpu, ora, dtype):
+    """Mostly short rows (one row per lane, LDS staging) with a few long ones in between: the groups of 64 rows that
+    overflow the staging area are handed to the row-per-wave table kernel; few distinct values and all-distinct rows."""
+    rng = np.random.default_rng(6100 + dtype)
+    npdt = A.NP_OF[dtype]
+
+    def rows(nrows, long_len, domain):
+        out = []
+        for r in range(nrows):
+            n = long_len if r % 97 == 13 else int(rng.integers(0, 5))
+            if rng.uniform() < 0.05:
+                out.append(None)
+            elif domain == 0:
+                out.append(rng.permutation(n).astype(npdt).tolist())                      # all distinct
+            else:
+                out.append(rng.integers(0, domain, n).astype(npdt).tolist())
+        return out
+
+    for long_len, domain in [(700, 7), (1500, 0), (3000, 1000)]:
+        la = A.HostList.from_lists(rows(1000, long_len, domain), dtype, row_offset=2)
+        lb = A.HostList.from_lists(rows(1000, long_len // 3, domain), dtype)
+        for op in ("distinct", "except", "intersect", "union", "repeat"):
+            other = lb if op in ("except", "intersect", "union") else None
+            (go, gv), (oo, ov) = gpu.list_set(op, la, other, count=2), ora.list_set(op, la, other, count=2)
+            what = f"{op} dtype={dtype} long_len={long_len} domain={domain}"
+            assert np.array_equal(go.to_numpy(), oo.to_numpy()) and gv.length == ov.length, "offsets " + what
+            assert np.array_equal(gv.to_numpy().view(np.uint8), ov.to_numpy().view(np.uint8)), "values (bit-exact) " + what
+
+
+@pytest.mark.gpu
+def test_list_set_function_errors(gpu, ora):
+    a, b5 = fixture(A.I32), A.HostList.from_lists([[1]] * 5, A.I32)
+    for api in (gpu, ora):
+        for op in ("except", "intersect", "union"):
+            with pytest.raises(A.RdfError) as ei:   # array.rs:72-76: "Expected array a and b to have the same length"
+                api.list_set(op, a, b5)
+            assert ei.value.status == A.RDF_COMPUTE_ERROR and "same length" in str(ei.value)
+            with pytest.raises(A.RdfError) as ei:
+                api.list_set(op, a, fixture(A.I64))
+            assert ei.value.status == A.RDF_INVALID_ARGUMENT
+        with pytest.raises(A.RdfError) as ei:
+            api.list_set("repeat", a, count=-1)
+        assert ei.value.status == A.RDF_INVALID_ARGUMENT
+        small = (A.HostArray.empty_out(A.I32, 7, False), A.HostArray.empty_out(A.I32, 3, False))
+        with pytest.raises(A.RdfError) as ei:
+            api.list_set("repeat", a, count=2, outs=small)
+        assert ei.value.status == A.RDF_MEMORY_ERROR
 
 
 @pytest.mark.gpu

@@ -204,6 +204,19 @@ def main():
         report(nm + "_max", lbytes + 8.0 * nr, lambda: api.list_extreme(L, True, om))
         oro, orv = out_like(A.I32, nr + 1), out_like(A.F64, nv)
         report(nm + "_remove", 2 * lbytes + 8.0 * nv * 0.98 + 4.0 * nr, lambda: api.list_remove(L, 7.0, (oro, orv)))
+        # the set-valued functions: reads in both passes (count, write) + the elements kept; quadratic compare work per row
+        osd = (out_like(A.I32, nr + 1), out_like(A.F64, nv))
+        kept = api.list_set("distinct", L, outs=osd)[1].length
+        report(nm + "_distinct", 2 * lbytes + 8.0 * kept + 4.0 * nr, lambda: api.list_set("distinct", L, outs=osd))
+        if rl == 10:
+            lv2_ = torch.floor(dev_f64(nv, 14, 0.0, 50.0))
+            L2 = A.DeviceList(lo_.data_ptr(), nr, arr(lv2_, A.F64, nv), keep=(lo_, lv2_))
+            osu = (out_like(A.I32, nr + 1), out_like(A.F64, 2 * nv))
+            kept = api.list_set("union", L, L2, outs=osu)[1].length
+            report(nm + "_union", 4 * lbytes + 8.0 * kept + 4.0 * nr, lambda: api.list_set("union", L, L2, outs=osu))
+            kept = api.list_set("intersect", L, L2, outs=osd)[1].length
+            report(nm + "_intersect", 4 * lbytes + 8.0 * kept + 4.0 * nr, lambda: api.list_set("intersect", L, L2, outs=osd))
+            del lv2_, osu
         if rl == 10:
             nsort = min(nv, 50_000_000)
             Ls = A.DeviceList(lo_.data_ptr(), nsort // rl, arr(lv_, A.F64, nsort), keep=(lo_, lv_))
