@@ -1177,6 +1177,146 @@ struct AggregateFunctions {  // src/functions/aggregate.rs:12-93
 };
 
 // ------------------------------------------------------------------------------------------------
+// ListArray over a primitive child + ArrayFunctions (src/functions/array.rs:15-399)
+
+struct ListArray {
+    ArrayRef offsets;  // Int32 value_offsets, len() + 1 entries; its validity buffer is the LIST validity (len() bits)
+    ArrayRef child;
+
+    int64_t len() const { return offsets->length - 1; }
+    ArrayRef values() const { return child; }
+    DataType value_type() const { return child->dtype; }
+    rdf_list_array view() const { rdf_list_array l; l.offsets = offsets->view(); l.values = child->view(); return l; }
+    std::vector<int32_t> value_offsets() const { return offsets->values_to_host<int32_t>(); }
+    int32_t value_offset(int64_t i) const { return offsets->value<int32_t>(i); }
+    int32_t value_length(int64_t i) const { return offsets->value<int32_t>(i + 1) - offsets->value<int32_t>(i); }
+    bool is_null(int64_t i) const { return offsets->validity && !offsets->bits_to_host(offsets->validity)[(size_t)i]; }
+
+    // ArrayData::builder(List(..)).add_buffer(value_offsets).add_child_data(values) of the reference's tests (array.rs:433-440)
+    static ListArray from_parts(const std::vector<int32_t>& value_offsets, ArrayRef values, const std::vector<bool>* valid = nullptr) {
+        return ListArray{Array::from_vec<int32_t>(value_offsets, valid), std::move(values)};
+    }
+    template <class T>
+    static ListArray from_rows(const std::vector<std::optional<std::vector<T>>>& rows) {
+        std::vector<int32_t> off{0};
+        std::vector<T> vals;
+        std::vector<bool> valid;
+        bool any_null = false;
+        for (auto& r : rows) {
+            valid.push_back(r.has_value());
+            any_null |= !r.has_value();
+            if (r) vals.insert(vals.end(), r->begin(), r->end());
+            off.push_back((int32_t)vals.size());
+        }
+        return from_parts(off, Array::from_vec<T>(vals), any_null ? &valid : nullptr);
+    }
+    template <class T>
+    std::vector<std::vector<T>> rows_to_host() const {
+        const auto off = value_offsets();
+        const auto vals = child->values_to_host<T>();
+        std::vector<std::vector<T>> out;
+        for (size_t i = 0; i + 1 < off.size(); ++i) out.emplace_back(vals.begin() + off[i], vals.begin() + off[i + 1]);
+        return out;
+    }
+};
+
+struct ArrayFunctions {
+    // array.rs:15-37: NULL list -> NULL, else whether the row's slice holds `val`
+    template <class T> static ArrayRef array_contains(const ListArray& array, T val) {
+        expect_child<T>(array, "array_contains");
+        auto out = Array::make_out(DataType::Boolean, array.len(), true);
+        return one(array, out, [&](const rdf_list_array* l, rdf_out* o) { return rdf_list_contains(l, &val, o); });
+    }
+    // array.rs:233-260: 1-based position of the first match, 0 when absent or the list is NULL
+    template <class T> static ArrayRef array_position(const ListArray& array, T val) {
+        expect_child<T>(array, "array_position");
+        auto out = Array::make_out(DataType::Int32, array.len(), false);
+        return one(array, out, [&](const rdf_list_array* l, rdf_out* o) { return rdf_list_position(l, &val, o); });
+    }
+    // array.rs:182-231
+    template <class T> static ArrayRef array_max(const ListArray& array) {
+        expect_child<T>(array, "array_max");
+        auto out = Array::make_out(array.value_type(), array.len(), true);
+        return one(array, out, [&](const rdf_list_array* l, rdf_out* o) { return rdf_list_max(l, o); });
+    }
+    template <class T> static ArrayRef array_min(const ListArray& array) {
+        expect_child<T>(array, "array_min");
+        auto out = Array::make_out(array.value_type(), array.len(), true);
+        return one(array, out, [&](const rdf_list_array* l, rdf_out* o) { return rdf_list_min(l, o); });
+    }
+    // array.rs:262-292
+    template <class T> static ListArray array_remove(const ListArray& array, T val) {
+        expect_child<T>(array, "array_remove");
+        return rebuild(array, array.child->length, [&](const rdf_list_array* l, rdf_out* oo, rdf_out* ov) { return rdf_list_remove(l, &val, oo, ov); });
+    }
+    // array.rs:39-65
+    template <class T> static ListArray array_distinct(const ListArray& array) {
+        expect_child<T>(array, "array_distinct");
+        return rebuild(array, array.child->length, [&](const rdf_list_array* l, rdf_out* oo, rdf_out* ov) { return rdf_list_distinct(l, oo, ov); });
+    }
+    // array.rs:66-153,356-399
+    template <class T> static ListArray array_except(const ListArray& a, const ListArray& b) {
+        expect_child<T>(a, "array_except");
+        const rdf_list_array lb = b.view();
+        return rebuild(a, a.child->length, [&](const rdf_list_array* l, rdf_out* oo, rdf_out* ov) { return rdf_list_except(l, &lb, oo, ov); });
+    }
+    template <class T> static ListArray array_intersect(const ListArray& a, const ListArray& b) {
+        expect_child<T>(a, "array_intersect");
+        const rdf_list_array lb = b.view();
+        return rebuild(a, a.child->length, [&](const rdf_list_array* l, rdf_out* oo, rdf_out* ov) { return rdf_list_intersect(l, &lb, oo, ov); });
+    }
+    template <class T> static ListArray array_union(const ListArray& a, const ListArray& b) {
+        expect_child<T>(a, "array_union");
+        const rdf_list_array lb = b.view();
+        return rebuild(a, a.child->length + b.child->length, [&](const rdf_list_array* l, rdf_out* oo, rdf_out* ov) { return rdf_list_union(l, &lb, oo, ov); });
+    }
+    // array.rs:294-326
+    template <class T> static ListArray array_repeat(const ListArray& array, int32_t count) {
+        expect_child<T>(array, "array_repeat");
+        return rebuild(array, array.child->length * (int64_t)(count > 0 ? count : 0), [&](const rdf_list_array* l, rdf_out* oo, rdf_out* ov) { return rdf_list_repeat(l, count, oo, ov); });
+    }
+    // array.rs:328-354: the value_offsets stay, every slice ascending
+    template <class T> static ListArray array_sort(const ListArray& array) {
+        expect_child<T>(array, "array_sort");
+        auto off = array.value_offsets();
+        const int64_t total = off.empty() ? 0 : (int64_t)off.back() - off.front();
+        auto vals = Array::make_out(array.value_type(), total, false);
+        const rdf_list_array l = array.view();
+        rdf_out ov = vals->out_view(total);
+        check(rdf_list_sort(&l, &ov));
+        vals->length = ov.length;
+        const int32_t first = off.empty() ? 0 : off.front();
+        for (auto& o : off) o -= first;   // the sorted values start at the first row's slice
+        std::vector<bool> valid;
+        if (array.offsets->validity) valid = array.offsets->bits_to_host(array.offsets->validity), valid.resize((size_t)array.len());
+        return ListArray::from_parts(off, vals, array.offsets->validity ? &valid : nullptr);
+    }
+
+  private:
+    template <class T> static void expect_child(const ListArray& a, const char* fn) {
+        if (a.value_type() != TypeOf<T>::value) throw DataFrameError(DataFrameError::ComputeError, std::string(fn) + ": the list's value type is not the requested one");
+    }
+    template <class F> static ArrayRef one(const ListArray& array, std::shared_ptr<Array> out, F call) {
+        const rdf_list_array l = array.view();
+        rdf_out o = out->out_view(array.len());
+        check(call(&l, &o));
+        out->length = o.length;
+        out->null_count = o.null_count;
+        return out;
+    }
+    template <class F> static ListArray rebuild(const ListArray& array, int64_t capacity, F call) {
+        auto off = Array::make_out(DataType::Int32, array.len() + 1, false);
+        auto vals = Array::make_out(array.value_type(), capacity, false);
+        const rdf_list_array l = array.view();
+        rdf_out oo = off->out_view(array.len() + 1), ov = vals->out_view(capacity);
+        check(call(&l, &oo, &ov));
+        off->length = oo.length;
+        vals->length = ov.length;
+        return ListArray{off, vals};
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
 // Evaluate (src/evaluation.rs:54-323), fusing
 
 inline int32_t scalar_function_op(plan::ScalarFunction f) {

@@ -416,6 +416,58 @@ TEST(test_from_arrow_ipc_file) {
     CHECK_THROWS(DataFrame::from_arrow("tests/golden/uk_cities_with_headers.csv"));   // not an IPC file
 }
 
+// src/functions/array.rs:421-640 — the reference's own ArrayFunctions tests on its 16-value / 6-row fixture
+template <class T> static ListArray array_fixture() {
+    std::vector<T> v;
+    for (int x : {0, 0, 0, 1, 2, 1, 3, 4, 5, 1, 3, 2, 3, 2, 8, 3}) v.push_back((T)x);
+    return ListArray::from_parts({0, 3, 6, 8, 12, 14, 16}, Array::from_vec<T>(v));
+}
+TEST(test_array_contains_i32s) {
+    auto bools = ArrayFunctions::array_contains<int32_t>(array_fixture<int32_t>(), 2)->bools_to_host();
+    CHECK(bools == std::vector<bool>({false, true, false, true, true, false}));
+}
+TEST(test_array_contains_i64s) {
+    auto bools = ArrayFunctions::array_contains<int64_t>(array_fixture<int64_t>(), 2)->bools_to_host();
+    CHECK(bools == std::vector<bool>({false, true, false, true, true, false}));
+}
+TEST(test_array_contains_f64s) {
+    auto bools = ArrayFunctions::array_contains<double>(array_fixture<double>(), 2.0)->bools_to_host();
+    CHECK(bools == std::vector<bool>({false, true, false, true, true, false}));
+}
+TEST(test_array_position) {
+    auto pos = ArrayFunctions::array_position<int64_t>(array_fixture<int64_t>(), 2)->values_to_host<int32_t>();
+    CHECK(pos == std::vector<int32_t>({0, 2, 0, 4, 2, 0}));
+}
+TEST(test_array_remove) {
+    auto b = ArrayFunctions::array_remove<int64_t>(array_fixture<int64_t>(), 2);
+    CHECK_EQ(b.len(), 6);
+    CHECK_EQ(b.values()->length, 13);
+    CHECK(b.value_offsets() == std::vector<int32_t>({0, 3, 5, 7, 10, 11, 13}));
+}
+TEST(test_array_sort) {
+    auto b = ArrayFunctions::array_sort<int64_t>(array_fixture<int64_t>());
+    CHECK_EQ(b.len(), 6);
+    CHECK_EQ(b.values()->length, 16);
+    CHECK(b.value_offsets() == std::vector<int32_t>({0, 3, 6, 8, 12, 14, 16}));
+    CHECK(b.values()->values_to_host<int64_t>() == std::vector<int64_t>({0, 0, 0, 1, 1, 2, 3, 4, 1, 2, 3, 5, 2, 3, 3, 8}));
+}
+// the set-valued functions on the array_tool crate's documented examples; a NULL row becomes an empty valid list
+TEST(test_array_set_functions) {
+    using Rows = std::vector<std::optional<std::vector<int64_t>>>;
+    using Out = std::vector<std::vector<int64_t>>;
+    auto L = [](const Rows& r) { return ListArray::from_rows<int64_t>(r); };
+    CHECK(ArrayFunctions::array_distinct<int64_t>(L({{{1, 2, 1, 3, 2, 3, 4, 5, 6}}, std::nullopt})).rows_to_host<int64_t>() == Out({{1, 2, 3, 4, 5, 6}, {}}));
+    CHECK(ArrayFunctions::array_except<int64_t>(L({{{1, 2, 3, 4, 5, 6}}}), L({{{1, 2, 5, 7, 9}}})).rows_to_host<int64_t>() == Out({{3, 4, 6}}));
+    CHECK(ArrayFunctions::array_intersect<int64_t>(L({{{1, 1, 3, 5}}}), L({{{1, 2, 3}}})).rows_to_host<int64_t>() == Out({{1, 3}}));
+    CHECK(ArrayFunctions::array_union<int64_t>(L({{{1, 2, 3, 4, 5, 6}}}), L({{{5, 6, 7, 8, 9}}})).rows_to_host<int64_t>() == Out({{1, 2, 3, 4, 5, 6, 7, 8, 9}}));
+    CHECK(ArrayFunctions::array_repeat<int64_t>(L({{{1, 2, 3}}, std::nullopt}), 3).rows_to_host<int64_t>() == Out({{1, 2, 3, 1, 2, 3, 1, 2, 3}, {}}));
+    CHECK(ArrayFunctions::array_max<int32_t>(array_fixture<int32_t>())->values_to_host<int32_t>() == std::vector<int32_t>({0, 2, 4, 5, 3, 8}));
+    CHECK(ArrayFunctions::array_min<int32_t>(array_fixture<int32_t>())->values_to_host<int32_t>() == std::vector<int32_t>({0, 1, 3, 1, 2, 3}));
+    bool threw = false;   // array.rs:72-76
+    try { ArrayFunctions::array_union<int64_t>(L({{{1}}}), L({{{1}}, {{2}}})); } catch (const DataFrameError& e) { threw = std::string(e.what()).find("same length") != std::string::npos; }
+    CHECK(threw);
+}
+
 int main(int argc, char** argv) {
     if (argc > 1) g_csv = argv[1];
     if (argc > 2) g_arrow = argv[2];
