@@ -1134,6 +1134,15 @@ struct ScalarFunctions {
         check(rdf_cast(a.data(), (int64_t)a.size(), ov.data()));
         return finish(outs, ov);
     }
+    // src/functions/scalar.rs:267-273: hour of day of a temporal column, given as its Int32 / Int64 storage + time unit
+    static std::vector<ArrayRef> hour(const std::vector<ArrayRef>& arr, rdf_time_unit unit) {
+        std::vector<rdf_array> a;
+        std::vector<std::shared_ptr<Array>> outs;
+        std::vector<rdf_out> ov;
+        for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(DataType::Int32, x->length, x->validity != nullptr)); ov.push_back(outs.back()->out_view(x->length)); }
+        check(rdf_hour(a.data(), (int64_t)a.size(), (int32_t)unit, ov.data()));
+        return finish(outs, ov);
+    }
     // src/functions/scalar.rs:16-103
     static std::vector<ArrayRef> add(const std::vector<ArrayRef>& l, const std::vector<ArrayRef>& r) { return binary(RDF_OP_ADD, l, r); }
     static std::vector<ArrayRef> subtract(const std::vector<ArrayRef>& l, const std::vector<ArrayRef>& r) { return binary(RDF_OP_SUB, l, r); }

@@ -94,8 +94,15 @@ typedef enum {
     RDF_OP_CAST = 29,
     /* BooleanFilter (src/expression.rs:752-763): comparisons are evaluated in f64 (:844-845) */
     RDF_OP_GT = 30, RDF_OP_GE = 31, RDF_OP_EQ = 32, RDF_OP_NE = 33, RDF_OP_LT = 34, RDF_OP_LE = 35,
-    RDF_OP_NOT = 36, RDF_OP_AND = 37, RDF_OP_OR = 38
+    RDF_OP_NOT = 36, RDF_OP_AND = 37, RDF_OP_OR = 38,
+    /* arrow::compute::hour via ScalarFunctions::hour (src/functions/scalar.rs:267-273), one opcode per time unit of
+     * the temporal input (Time32 s/ms, Time64 us/ns, Date64 ms, Timestamp s/ms/us/ns; Date32 counts days: hour 0).
+     * Operand Int32 or Int64 (the temporal types' storage), result of the operand's type, 0..23. */
+    RDF_OP_HOUR_S = 39, RDF_OP_HOUR_MS = 40, RDF_OP_HOUR_US = 41, RDF_OP_HOUR_NS = 42, RDF_OP_HOUR_DAY = 43
 } rdf_op;
+
+/* time units of the temporal arrays handed to rdf_hour */
+typedef enum { RDF_TIME_SECOND = 0, RDF_TIME_MILLISECOND = 1, RDF_TIME_MICROSECOND = 2, RDF_TIME_NANOSECOND = 3, RDF_TIME_DAY = 4 } rdf_time_unit;
 
 /* ------------------------------------------------------------------ library / device plumbing */
 
@@ -127,6 +134,15 @@ rdf_status rdf_unary(int32_t op, const rdf_array* a, int64_t nchunks, rdf_out* o
 /* Function::Cast arm (src/evaluation.rs:296-315): arrow::compute::cast per chunk to out[i].dtype
  * (numeric `as` conversions; numeric<->bool), validity carried. */
 rdf_status rdf_cast(const rdf_array* a, int64_t nchunks, rdf_out* out);
+
+/* ScalarFunctions::hour (src/functions/scalar.rs:267-273) = arrow::compute::hour per chunk: the hour of day of a
+ * Time32 / Time64 / Date32 / Date64 / Timestamp array, passed as its Int32 / Int64 storage plus its `unit`
+ * (rdf_time_unit; timestamps carry no time zone here, like the reference's).  out: RDF_I32 per chunk, NULL where
+ * the input is NULL.  hour = floor_mod(floor_div(value, units per second), 86400) / 3600 — chrono's
+ * NaiveDateTime::from_timestamp / NaiveTime::from_num_seconds_from_midnight for every value they accept; values
+ * the reference panics on (a time of day outside [0, 86400 s), a negative sub-second remainder) follow the same
+ * formula instead. */
+rdf_status rdf_hour(const rdf_array* a, int64_t nchunks, int32_t unit, rdf_out* out);
 
 /* ------------------------------------------------------------------ aggregate kernels */
 

@@ -365,6 +365,44 @@ rdf_status ora_cast(const rdf_array* a, int64_t nchunks, rdf_out* out) {
     return RDF_OK;
 }
 
+/* ScalarFunctions::hour (src/functions/scalar.rs:267-273) -> arrow::compute::hour (arrow crate, not under /root/reference):
+ * Time32 / Time64 go through PrimitiveArray::value_as_time = chrono NaiveTime::from_num_seconds_from_midnight(secs, nanos),
+ * Date32 / Date64 / Timestamp through value_as_datetime = NaiveDateTime::from_timestamp(secs, nanos), whose date / time
+ * split is div_mod_floor(secs, 86400); `.hour()` = second of the day / 3600.  secs = value / units_per_second for the
+ * values chrono accepts (non-negative remainder); the others make the reference panic and get floor semantics here.
+ * The reference has no test for hour: parity unpinned. */
+static int64_t floor_div64(int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+static int32_t hour_value(int64_t v, int32_t unit) {
+    static const int64_t per_sec[4] = {1, 1000, 1000000, 1000000000};
+    if (unit == RDF_TIME_DAY) return 0;                                     /* Date32: midnight of the day */
+    int64_t secs = floor_div64(v, per_sec[unit]);
+    int64_t sod = secs - floor_div64(secs, 86400) * 86400;                  /* div_mod_floor */
+    return (int32_t)(sod / 3600);
+}
+static rdf_status hour_chunk(const rdf_array* a, int32_t unit, rdf_out* o, int32_t odt) {
+    if (a->dtype != RDF_I32 && a->dtype != RDF_I64) FAIL(RDF_COMPUTE_ERROR, "hour does not support type %d", a->dtype);
+    if (o->dtype != odt) FAIL(RDF_INVALID_ARGUMENT, "hour: output dtype");
+    int64_t n = a->length;
+    if (o->capacity < n) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
+    if (a->validity && !o->validity) FAIL(RDF_INVALID_ARGUMENT, "output validity buffer required");
+    out_begin(o, n);
+    for (int64_t i = 0; i < n; i++) {
+        int32_t h = 0;
+        if (!arr_valid(a, i)) out_null(o, i);
+        else h = hour_value(a->dtype == RDF_I32 ? ((const int32_t*)a->values)[a->offset + i] : ((const int64_t*)a->values)[a->offset + i], unit);
+        if (odt == RDF_I32) ((int32_t*)o->values)[i] = h; else ((int64_t*)o->values)[i] = h;
+    }
+    return RDF_OK;
+}
+rdf_status ora_hour(const rdf_array* a, int64_t nchunks, int32_t unit, rdf_out* out) {
+    if (unit < RDF_TIME_SECOND || unit > RDF_TIME_DAY) FAIL(RDF_INVALID_ARGUMENT, "hour: unknown time unit %d", unit);
+    for (int64_t c = 0; c < nchunks; c++) {
+        rdf_status s = hour_chunk(&a[c], unit, &out[c], RDF_I32);
+        if (s != RDF_OK) return s;
+    }
+    return RDF_OK;
+}
+
 /* ------------------------------------------------------------------ AggregateFunctions
  * src/functions/aggregate.rs:12-93. */
 
@@ -620,6 +658,10 @@ static rdf_status eval_node(const rdf_expr_node* nodes, int32_t nnodes, int32_t 
     } else if (op >= RDF_OP_ABS && op <= RDF_OP_TANH) {
         if (!tmp_alloc(res, l.dtype, l.len, l.validity != NULL)) s = RDF_MEMORY_ERROR;
         else { rdf_array a = tmp_view(&l); rdf_out o = tmp_out(res); s = unary_chunk(op, &a, &o); }
+    } else if (op >= RDF_OP_HOUR_S && op <= RDF_OP_HOUR_DAY) {                /* result keeps the operand's storage type */
+        if (l.dtype != RDF_I32 && l.dtype != RDF_I64) { tmp_free(&l); FAIL(RDF_INVALID_ARGUMENT, "hour: Int32 / Int64 temporal storage required"); }
+        if (!tmp_alloc(res, l.dtype, l.len, l.validity != NULL)) s = RDF_MEMORY_ERROR;
+        else { rdf_array a = tmp_view(&l); rdf_out o = tmp_out(res); s = hour_chunk(&a, op - RDF_OP_HOUR_S, &o, l.dtype); }
     } else if (op == RDF_OP_CAST) {
         s = tmp_cast(&l, nd->dtype, res);
     } else if (op >= RDF_OP_GT && op <= RDF_OP_LE) {

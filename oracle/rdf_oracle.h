@@ -30,6 +30,7 @@ const char* ora_last_error(void);
 rdf_status ora_binary(int32_t op, const rdf_array* a, const rdf_array* b, int64_t nchunks, rdf_out* out);
 rdf_status ora_unary(int32_t op, const rdf_array* a, int64_t nchunks, rdf_out* out);
 rdf_status ora_cast(const rdf_array* a, int64_t nchunks, rdf_out* out);
+rdf_status ora_hour(const rdf_array* a, int64_t nchunks, int32_t unit, rdf_out* out);
 
 rdf_status ora_sum(const rdf_array* a, int64_t nchunks, void* out_scalar, int32_t* out_is_some);
 rdf_status ora_min(const rdf_array* a, int64_t nchunks, void* out_scalar, int32_t* out_is_some);

@@ -24,6 +24,8 @@ MEM_HOST, MEM_DEVICE = 0, 1
  OP_CEIL, OP_COS, OP_COSH, OP_DEGREES, OP_EXP, OP_EXPM1, OP_FLOOR, OP_LOG10, OP_LOG2, OP_RADIANS, OP_ROUND,
  OP_SIN, OP_SINH, OP_SQRT, OP_TAN, OP_TANH, OP_CAST, OP_GT, OP_GE, OP_EQ, OP_NE, OP_LT, OP_LE, OP_NOT,
  OP_AND, OP_OR) = range(1, 39)
+OP_HOUR_S, OP_HOUR_MS, OP_HOUR_US, OP_HOUR_NS, OP_HOUR_DAY = range(39, 44)
+TIME_SECOND, TIME_MILLISECOND, TIME_MICROSECOND, TIME_NANOSECOND, TIME_DAY = range(5)
 
 OP_NAMES = {
     "add": OP_ADD, "subtract": OP_SUB, "multiply": OP_MUL, "divide": OP_DIV, "atan2": OP_ATAN2,
@@ -33,6 +35,7 @@ OP_NAMES = {
     "round": OP_ROUND, "sin": OP_SIN, "sinh": OP_SINH, "sqrt": OP_SQRT, "tan": OP_TAN, "tanh": OP_TANH,
     "cast": OP_CAST, "gt": OP_GT, "ge": OP_GE, "eq": OP_EQ, "ne": OP_NE, "lt": OP_LT, "le": OP_LE,
     "not": OP_NOT, "and": OP_AND, "or": OP_OR,
+    "hour_s": OP_HOUR_S, "hour_ms": OP_HOUR_MS, "hour_us": OP_HOUR_US, "hour_ns": OP_HOUR_NS, "hour_day": OP_HOUR_DAY,
 }
 UNARY_OPS = [n for n, v in OP_NAMES.items() if OP_ABS <= v <= OP_TANH]
 
@@ -347,7 +350,7 @@ class Api:
         self.prefix = prefix
         self._err = getattr(lib, prefix + "last_error")
         self._err.restype = C.c_char_p
-        for name in ("binary", "unary", "cast", "sum", "min", "max", "count", "avg", "predicate", "filter_count",
+        for name in ("binary", "unary", "cast", "hour", "sum", "min", "max", "count", "avg", "predicate", "filter_count",
                      "filter", "filter_columns", "take", "pipeline", "group_pipeline", "groupby_sum", "list_contains", "list_position", "list_max", "list_min", "list_remove", "list_sort", "list_distinct", "list_except", "list_intersect", "list_union", "list_repeat", "sort_to_indices", "equijoin_indices", "equijoin_indices_multi", "fill_uniform_f64",
                      "fill_uniform_i64", "fill_validity"):
             fn = getattr(lib, prefix + name)
@@ -413,6 +416,17 @@ class Api:
         else:
             carr = (rdf_out * max(1, n))(*[o.out_struct() for o in outs])
         self._check(self._fn("cast")(ca, C.c_int64(n), carr))
+        return self._finish(outs, carr)
+
+    def hour(self, a: Sequence, unit: int, outs=None):
+        """ScalarFunctions::hour over the Int32 / Int64 storage of a temporal column with time unit `unit` -> Int32 chunks."""
+        n = len(a)
+        ca = _flat([a], n)
+        if outs is None:
+            outs, carr = self._mk_outs(I32, [x.length for x in a], [x.validity is not None for x in a])
+        else:
+            carr = (rdf_out * max(1, n))(*[o.out_struct() for o in outs])
+        self._check(self._fn("hour")(ca, C.c_int64(n), C.c_int32(unit), carr))
         return self._finish(outs, carr)
 
     # ---- aggregates (AggregateFunctions, src/functions/aggregate.rs)

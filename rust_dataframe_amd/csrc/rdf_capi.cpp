@@ -389,6 +389,7 @@ bool op_is_arith(int op) { return op >= RDF_OP_ADD && op <= RDF_OP_DIV; }
 bool op_is_fbinary(int op) { return op >= RDF_OP_ATAN2 && op <= RDF_OP_LOG; }
 bool op_is_unary_math(int op) { return op >= RDF_OP_ABS && op <= RDF_OP_TANH; }
 bool op_is_cmp(int op) { return op >= RDF_OP_GT && op <= RDF_OP_LE; }
+bool op_is_hour(int op) { return op >= RDF_OP_HOUR_S && op <= RDF_OP_HOUR_DAY; }
 bool op_is_binary(int op) { return op_is_arith(op) || op_is_fbinary(op) || op_is_cmp(op) || op == RDF_OP_AND || op == RDF_OP_OR; }
 bool op_is_heavy(int op) {
     if (op_is_fbinary(op)) return true;
@@ -458,6 +459,9 @@ struct Compiler {
                     if (!(is_float(l) || is_signed_int(l))) r = bad(RDF_INVALID_ARGUMENT, "abs: signed numeric type required");
                     else r = l;
                 } else if (!is_float(l)) r = bad(RDF_INVALID_ARGUMENT, "float type required");
+                else r = l;
+            } else if (op_is_hour(op)) {
+                if (l != RDF_I32 && l != RDF_I64) r = bad(RDF_INVALID_ARGUMENT, "hour: Int32 / Int64 temporal storage required");
                 else r = l;
             } else if (op == RDF_OP_CAST) {
                 if (!(is_numeric(nd.dtype) || nd.dtype == RDF_BOOL)) r = bad(RDF_INVALID_ARGUMENT, "cast: unsupported type");
@@ -548,7 +552,7 @@ struct Compiler {
         }
         const int op = nd.op;
         if (op_is_heavy(op)) heavy = true;
-        if (op == RDF_OP_DIV && !is_float(dt)) intdiv = true;
+        if ((op == RDF_OP_DIV && !is_float(dt)) || op_is_hour(op)) intdiv = true;
         if (!op_is_binary(op)) {
             gen(nd.lhs);
             const int l = infer(nd.lhs);
@@ -1426,6 +1430,19 @@ rdf_status rdf_unary(int32_t op, const rdf_array* a, int64_t nchunks, rdf_out* o
     ProgramSpec ps;
     memset(&ps, 0, sizeof ps);
     ps.nodes = nodes; ps.nnodes = 2; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = 1; ps.sink = RDF_SINK_STORE;
+    return run_program(ps, a, 1, nchunks, out, nullptr, "chunk length mismatch");
+}
+
+rdf_status rdf_hour(const rdf_array* a, int64_t nchunks, int32_t unit, rdf_out* out) {
+    if (unit < RDF_TIME_SECOND || unit > RDF_TIME_DAY) return fail(RDF_INVALID_ARGUMENT, "hour: unknown time unit %d", unit);
+    if (nchunks < 0 || (nchunks > 0 && (!a || !out))) return fail(RDF_INVALID_ARGUMENT, "bad chunk lists");
+    if (nchunks == 0) return RDF_OK;
+    // "hour does not support" anything but the temporal types: their storage is Int32 or Int64
+    if (a[0].dtype != RDF_I32 && a[0].dtype != RDF_I64) return fail(RDF_COMPUTE_ERROR, "hour does not support type %d", a[0].dtype);
+    rdf_expr_node nodes[3] = {node_col(0), node_op(RDF_OP_HOUR_S + unit, 0, -1), node_op(RDF_OP_CAST, 1, -1, RDF_I32)};
+    ProgramSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.nodes = nodes; ps.nnodes = 3; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = 2; ps.sink = RDF_SINK_STORE;
     return run_program(ps, a, 1, nchunks, out, nullptr, "chunk length mismatch");
 }
 

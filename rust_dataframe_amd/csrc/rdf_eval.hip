@@ -273,9 +273,27 @@ __device__ __forceinline__ void apply_binary(int op, int dt, uint64_t (&acc)[kVP
     }
 }
 
+// arrow::compute::hour: floor division to seconds, floor modulo to the second of the day (constant divisors per unit)
+template <int64_t U> __device__ __forceinline__ uint64_t hour_of(int64_t v) {
+    int64_t q = v / U;
+    if (v % U < 0) --q;
+    int64_t m = q % 86400;
+    if (m < 0) m += 86400;
+    return (uint64_t)(m / 3600);
+}
 template <int FEAT>
 __device__ __forceinline__ void apply_unary(int op, int dt, uint64_t (&acc)[kVPT]) {
     if (op == RDF_OP_NOT) { RDF_ROWS acc[j] = acc[j] ^ 1ull; return; }
+    if (FEAT >= 1 && op >= RDF_OP_HOUR_S) {
+        switch (op) {
+            case RDF_OP_HOUR_S: RDF_ROWS acc[j] = hour_of<1>((int64_t)acc[j]); break;
+            case RDF_OP_HOUR_MS: RDF_ROWS acc[j] = hour_of<1000>((int64_t)acc[j]); break;
+            case RDF_OP_HOUR_US: RDF_ROWS acc[j] = hour_of<1000000>((int64_t)acc[j]); break;
+            case RDF_OP_HOUR_NS: RDF_ROWS acc[j] = hour_of<1000000000>((int64_t)acc[j]); break;
+            default: RDF_ROWS acc[j] = 0; break;
+        }
+        return;
+    }
     if (dt == RDF_F64) { RDF_ROWS acc[j] = d2u(unary_f64<FEAT>(op, u2d(acc[j]))); return; }
     if (dt == RDF_F32) { RDF_ROWS acc[j] = f2u(unary_f32<FEAT>(op, u2f(acc[j]))); return; }
     // num::abs on signed integers; MIN wraps

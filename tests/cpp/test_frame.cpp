@@ -416,6 +416,17 @@ TEST(test_from_arrow_ipc_file) {
     CHECK_THROWS(DataFrame::from_arrow("tests/golden/uk_cities_with_headers.csv"));   // not an IPC file
 }
 
+// src/functions/scalar.rs:267-273 (no reference test): 2020-10-17T13:45:10Z in four units, a pre-epoch instant, a NULL
+TEST(test_hour_of_timestamps) {
+    const int64_t t = 1602942310;
+    std::vector<bool> valid{true, true, false};
+    CHECK(host<int32_t>(ScalarFunctions::hour({Array::from_vec<int64_t>({t, -1, 0}, &valid)}, RDF_TIME_SECOND)[0]) == std::vector<int32_t>({13, 23, 0}));
+    CHECK(host<int32_t>(ScalarFunctions::hour({Array::from_vec<int64_t>({t * 1000 + 999, -1})}, RDF_TIME_MILLISECOND)[0]) == std::vector<int32_t>({13, 23}));
+    CHECK(host<int32_t>(ScalarFunctions::hour({Array::from_vec<int64_t>({t * 1000000000})}, RDF_TIME_NANOSECOND)[0]) == std::vector<int32_t>({13}));
+    CHECK(host<int32_t>(ScalarFunctions::hour({Array::from_vec<int32_t>({49510})}, RDF_TIME_SECOND)[0]) == std::vector<int32_t>({13}));   // Time32(Second)
+    CHECK_EQ(ScalarFunctions::hour({Array::from_vec<int64_t>({t, -1, 0}, &valid)}, RDF_TIME_SECOND)[0]->null_count, 1);
+}
+
 // src/functions/array.rs:421-640 — the reference's own ArrayFunctions tests on its 16-value / 6-row fixture
 template <class T> static ListArray array_fixture() {
     std::vector<T> v;

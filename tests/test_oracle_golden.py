@@ -109,6 +109,38 @@ def test_oracle_vs_pyarrow_arithmetic_nulls(ora, dtype):
         assert np.array_equal(r.to_numpy()[m], ref.fill_null(1).to_numpy(zero_copy_only=False)[m]), op
 
 
+def test_oracle_hour_vs_numpy_and_pyarrow(ora):
+    """ScalarFunctions::hour (scalar.rs:267-273): the reference has no test for it, so the oracle is held to numpy's
+    datetime64 calendar and to pyarrow.compute.hour (today's version of the kernel the reference calls)."""
+    rng = np.random.default_rng(4242)
+    units = [(A.TIME_SECOND, "s", 1), (A.TIME_MILLISECOND, "ms", 10 ** 3), (A.TIME_MICROSECOND, "us", 10 ** 6), (A.TIME_NANOSECOND, "ns", 10 ** 9)]
+    for unit, code, per_sec in units:
+        # timestamps from 1900 to 2100 (negative values included), plus day / hour boundaries
+        secs = rng.integers(-2_208_988_800, 4_102_444_800, 4000)
+        v = secs * per_sec + rng.integers(0, per_sec, 4000)
+        v[:6] = [0, -1, 86400 * per_sec - 1, 86400 * per_sec, -86400 * per_sec, 3600 * per_sec]
+        valid = rng.uniform(size=v.size) > 0.1
+        h = A.HostArray.from_numpy(v.astype(np.int64), valid=valid, offset=3, rng=rng)
+        r = ora.hour([h], unit)[0]
+        assert r.dtype == A.I32 and np.array_equal(r.valid_mask(), valid)
+        dt = v.astype(f"datetime64[{code}]")
+        want = (dt.astype("datetime64[h]") - dt.astype("datetime64[D]")).astype(np.int64)
+        assert np.array_equal(r.to_numpy()[valid], want[valid]), code
+        ref = pc.hour(pa.array(v, type=pa.timestamp(code), mask=~valid))
+        assert np.array_equal(r.to_numpy()[valid], ref.fill_null(0).to_numpy(zero_copy_only=False)[valid]), code
+    # Time32(Second / Millisecond) storage is Int32: a time of day
+    for unit, per_sec, typ in [(A.TIME_SECOND, 1, pa.time32("s")), (A.TIME_MILLISECOND, 1000, pa.time32("ms"))]:
+        t = rng.integers(0, 86400 * per_sec, 3000).astype(np.int32)
+        r = ora.hour([A.HostArray.from_numpy(t)], unit)[0]
+        assert np.array_equal(r.to_numpy(), t // (3600 * per_sec))
+        assert np.array_equal(r.to_numpy(), pc.hour(pa.array(t, type=typ)).to_numpy())
+    # Date32 counts days: midnight
+    assert not ora.hour([A.HostArray.from_numpy(np.arange(-5, 5, dtype=np.int32))], A.TIME_DAY)[0].to_numpy().any()
+    with pytest.raises(A.RdfError) as ei:   # "hour does not support" a non-temporal type
+        ora.hour([A.HostArray.from_numpy(np.zeros(4))], A.TIME_SECOND)
+    assert ei.value.status == A.RDF_COMPUTE_ERROR
+
+
 def test_oracle_vs_pyarrow_filter_take_agg(ora):
     rng = np.random.default_rng(3)
     lens = [1024, 1024, 500]

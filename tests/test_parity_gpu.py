@@ -102,6 +102,31 @@ def test_cast_matrix(gpu, ora, src):
             assert_chunks_match(gpu.cast(a, dst), ora.cast(a, dst), exact=True, what=f"cast {src}->{dst}")
 
 
+@pytest.mark.parametrize("dtype", [A.I32, A.I64])
+def test_hour(gpu, ora, dtype):
+    """ScalarFunctions::hour over the storage of Time32 / Time64 / Date / Timestamp chunks, every time unit; and the
+    hour opcodes inside a fused pipeline (count of the rows after noon, sum of the hours)."""
+    rng = np.random.default_rng(900 + dtype)
+    for unit in (A.TIME_SECOND, A.TIME_MILLISECOND, A.TIME_MICROSECOND, A.TIME_NANOSECOND, A.TIME_DAY):
+        for lens, nf, off in LAYOUTS:
+            a = make_chunks(rng, dtype, lens, nf, off, "extreme")
+            assert_chunks_match(gpu.hour(a, unit), ora.hour(a, unit), exact=True, what=f"hour unit={unit} dtype={dtype} lens={lens}")
+    for name in ("hour_s", "hour_ms", "hour_us", "hour_ns"):
+        a = make_chunks(rng, dtype, [1024, 1024, 576], 0.1, 3, "extreme")
+        e = A.Expr()
+        h = e.op(name, e.col(0))
+        pred = e.op("gt", h, e.scalar(12))
+        for api_res in zip(gpu.pipeline(e, [a], [h], pred), ora.pipeline(e, [a], [h], pred)):
+            g, o = api_res
+            assert (g.sum, g.min, g.max, g.count, g.is_some) == (o.sum, o.min, o.max, o.count, o.is_some), name
+    with pytest.raises(A.RdfError) as ei:
+        gpu.hour(make_chunks(rng, A.F64, [10], 0.0, 0), A.TIME_SECOND)
+    assert ei.value.status == A.RDF_COMPUTE_ERROR
+    with pytest.raises(A.RdfError) as ei:
+        gpu.hour(make_chunks(rng, A.I64, [10], 0.0, 0), 7)
+    assert ei.value.status == A.RDF_INVALID_ARGUMENT
+
+
 @pytest.mark.parametrize("dtype", NUMERIC)
 def test_aggregates(gpu, ora, dtype):
     rng = np.random.default_rng(200 + dtype)
