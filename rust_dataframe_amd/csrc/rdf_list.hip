@@ -46,6 +46,7 @@ constexpr int kListStage = 1024;   // child elements per wave staged in LDS (8 K
 template <class T>
 __global__ __launch_bounds__(kBlock) void list_rows_kernel(const ListArgs a) {
     __shared__ T stage[kBlock / 64][kListStage];
+    __shared__ uint64_t match[kBlock / 64][kListStage / 64];
     const int lane = threadIdx.x & 63;
     const GlobalPtr<int32_t> off = as_global<int32_t>(a.offsets.values) + a.offsets.offset;
     const GlobalPtr<T> vals = as_global<T>(a.values.values) + a.values.offset;
@@ -71,6 +72,31 @@ __global__ __launch_bounds__(kBlock) void list_rows_kernel(const ListArgs a) {
         const int64_t rlast = wv * 64 + 64 < a.n ? wv * 64 + 64 : a.n;
         const int32_t span0 = off[wv * 64], span = off[rlast] - span0;
         const bool staged = span <= kListStage;
+        if (staged && (a.op == LIST_CONTAINS || a.op == LIST_POSITION)) {
+            // contains / position need no walk at all: the span is compared element-parallel (coalesced loads, one ballot
+            // per 64 elements = one word of the match mask), and a row's answer is the first set bit of its bit range
+            const int nw = (span + 63) >> 6;
+            for (int t0 = 0; t0 < nw; t0 += 4) {   // four loads in flight per lane
+                T v[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int32_t i = (t0 + u) * 64 + lane; ok[u] = i < span; v[u] = ok[u] ? vals[span0 + i] : (T)0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t m = __ballot(ok[u] && v[u] == needle);
+                    if (lane == u && t0 + u < nw) match[threadIdx.x >> 6][t0 + u] = m;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int32_t lo = b - span0, hi = e - span0;
+            for (int32_t wi = lo >> 6; b < e && !found && wi * 64 < hi; ++wi) {
+                uint64_t m = match[threadIdx.x >> 6][wi];
+                if (wi == lo >> 6) m &= ~0ull << (lo & 63);
+                if (hi - wi * 64 < 64) m &= (1ull << (hi - wi * 64)) - 1;
+                if (m) { found = true; pos = wi * 64 + __builtin_ctzll(m) - lo + 1; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
         if (staged) {
             for (int32_t i = lane; i < span; i += 64) stage[threadIdx.x >> 6][i] = vals[span0 + i];
             __builtin_amdgcn_wave_barrier();   // same-wave LDS operations execute in order; this pins the compiler
@@ -87,6 +113,7 @@ __global__ __launch_bounds__(kBlock) void list_rows_kernel(const ListArgs a) {
             }
         }
         __builtin_amdgcn_wave_barrier();   // the next iteration refills the staging area
+        }
         if (a.op == LIST_CONTAINS) {   // NULL list -> NULL, else true / false (array.rs:15-37)
             const uint64_t vb = __ballot(lvalid), bits = __ballot(lvalid && found), ib = __ballot(inr);
             if (lane == 0 && ib) {
@@ -183,11 +210,16 @@ __global__ __launch_bounds__(kBlock) void list_row_ids_kernel(const ListArgs a, 
 }
 
 // array_remove, pass 1: kept[row] = elements of the row that differ from the needle (a NULL list keeps none);
-// pass 2 (scan != nullptr): the kept elements are written at the scanned offsets, order preserved
+// pass 2 (scan != nullptr): the kept elements are written at the scanned offsets, order preserved.
+// Short rows (the 64 rows of a wave span <= kListStage child elements) are handled element-parallel: the span is
+// compared with coalesced loads, one ballot per 64 elements gives a word of the DROP mask (matches + the elements of NULL
+// rows), a row's count is a popcount over its bit range, and in pass 2 element i lands at
+// scan[first row] + i - (dropped elements before i): both passes stream.  Longer spans fall back to a walk per lane.
 template <class T>
 __global__ __launch_bounds__(kBlock) void list_remove_kernel(const ListArgs a) {
     __shared__ T stage_in[kBlock / 64][kListStage];
-    __shared__ T stage_out[kBlock / 64][kListStage];
+    __shared__ unsigned long long drop[kBlock / 64][kListStage / 64];
+    __shared__ uint32_t pre[kBlock / 64][kListStage / 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const GlobalPtr<int32_t> off = as_global<int32_t>(a.offsets.values) + a.offsets.offset;
     const GlobalPtr<T> vals = as_global<T>(a.values.values) + a.values.offset;
@@ -198,35 +230,71 @@ __global__ __launch_bounds__(kBlock) void list_remove_kernel(const ListArgs a) {
         const bool inr = row < a.n;
         bool lvalid = inr;
         if (inr && a.offsets.validity) { const int64_t bi = a.offsets.offset + row; lvalid = (as_global<uint8_t>(a.offsets.validity)[bi >> 3] >> (bi & 7)) & 1; }
-        const int32_t b = lvalid ? off[row] : 0, e = lvalid ? off[row + 1] : 0;
-        // the wave's 64 rows cover one contiguous span of the child array and of the output: both go through LDS when short
+        const int32_t rb = inr ? off[row] : 0, re = inr ? off[row + 1] : 0;   // the row's slice, NULL or not
+        const int32_t b = lvalid ? rb : 0, e = lvalid ? re : 0;
         const int64_t rlast = wv * 64 + 64 < a.n ? wv * 64 + 64 : a.n;
         const int32_t span0 = off[wv * 64], span = off[rlast] - span0;
-        const bool staged = span <= kListStage;
-        if (staged) {
-            for (int32_t i = lane; i < span; i += 64) stage_in[w][i] = vals[span0 + i];
+        if (span <= kListStage) {
+            const int nw = (span + 63) >> 6;
+            for (int t0 = 0; t0 < nw; t0 += 4) {   // four loads in flight per lane
+                T v[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int32_t i = (t0 + u) * 64 + lane; ok[u] = i < span; v[u] = ok[u] ? vals[span0 + i] : (T)0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t m = __ballot(!ok[u] || v[u] == needle);   // positions past the span count as dropped
+                    if (lane == u && t0 + u < nw) drop[w][t0 + u] = m;
+                    if (a.scan && ok[u]) stage_in[w][(t0 + u) * 64 + lane] = v[u];
+                }
+            }
             __builtin_amdgcn_wave_barrier();
+            if (inr && !lvalid && re > rb) {   // a NULL row that owns child elements: they are dropped
+                const int32_t lo = rb - span0, hi = re - span0;
+                for (int32_t wi = lo >> 6; wi * 64 < hi; ++wi) {
+                    unsigned long long m = ~0ull;
+                    if (wi == lo >> 6) m &= ~0ull << (lo & 63);
+                    if (hi - wi * 64 < 64) m &= (1ull << (hi - wi * 64)) - 1;
+                    atomicOr(&drop[w][wi], m);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (!a.scan) {
+                int64_t c = e - b;
+                const int32_t lo = b - span0, hi = e - span0;
+                for (int32_t wi = lo >> 6; b < e && wi * 64 < hi; ++wi) {
+                    unsigned long long m = drop[w][wi];
+                    if (wi == lo >> 6) m &= ~0ull << (lo & 63);
+                    if (hi - wi * 64 < 64) m &= (1ull << (hi - wi * 64)) - 1;
+                    c -= __popcll(m);
+                }
+                if (inr) a.kept[row] = c;
+            } else {
+                if (lane < nw) { uint32_t p = 0; for (int k = 0; k < lane; ++k) p += (uint32_t)__popcll(drop[w][k]); pre[w][lane] = p; }
+                __builtin_amdgcn_wave_barrier();
+                const int64_t out0 = a.scan[wv * 64];
+                for (int t = 0; t < nw; ++t) {
+                    const unsigned long long m = drop[w][t];
+                    if (!((m >> lane) & 1)) {
+                        const int32_t i = t * 64 + lane;
+                        as_global_mut<T>(a.out.values)[out0 + i - (int64_t)(pre[w][t] + (uint32_t)__popcll(m & ((1ull << lane) - 1)))] = stage_in[w][i];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // the next iteration refills the staging areas
+            continue;
         }
         if (!a.scan) {
             int64_t c = 0;
-            for (int32_t i = b; i < e; ++i) c += (staged ? stage_in[w][i - span0] : vals[i]) != needle;
+            for (int32_t i = b; i < e; ++i) c += vals[i] != needle;
             if (inr) a.kept[row] = c;
         } else {
-            const int64_t out0 = a.scan[wv * 64], out_n = a.scan[rlast] - out0;
             int64_t o = inr ? a.scan[row] : 0;
             for (int32_t i = b; i < e; ++i) {
-                const T v = staged ? stage_in[w][i - span0] : vals[i];
-                if (v != needle) {
-                    if (staged) stage_out[w][o - out0] = v; else as_global_mut<T>(a.out.values)[o] = v;
-                    ++o;
-                }
-            }
-            if (staged) {
-                __builtin_amdgcn_wave_barrier();
-                for (int64_t i = lane; i < out_n; i += 64) as_global_mut<T>(a.out.values)[out0 + i] = stage_out[w][i];
+                const T v = vals[i];
+                if (v != needle) as_global_mut<T>(a.out.values)[o++] = v;
             }
         }
-        __builtin_amdgcn_wave_barrier();   // the next iteration refills the staging areas
     }
 }
 
