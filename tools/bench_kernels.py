@@ -295,6 +295,12 @@ def main():
             lib.set_option("vec_bitmap", vb)
             report(f"ab_filter_sum_validity_vecbitmap{vb}_{rep}", 8.125 * n, lambda: api.pipeline(e, [[XV]], [cx], gt))
             report(f"ab_sum_validity_vecbitmap{vb}_{rep}", 8.125 * n, lambda: api.pipeline(e, [[XV]], [cx]))
+            # the same over chunked columns: 1 Mi-row chunks, and the reference's 1024-row batches on a 5e7-row prefix
+            XVC = [A.DeviceArray(x.data_ptr() + i * 8, vx.data_ptr() + i // 8, 0, min(1 << 20, n - i), A.F64, -1, keep=(x, vx)) for i in range(0, n, 1 << 20)]
+            report(f"ab_filter_sum_validity_chunked_1M_vecbitmap{vb}_{rep}", 8.125 * n, lambda: api.pipeline(e, [XVC], [cx], gt))
+            ns_ = min(n, 50_000_000)
+            XVS = [A.DeviceArray(x.data_ptr() + i * 8, vx.data_ptr() + i // 8, 0, min(1024, ns_ - i), A.F64, -1, keep=(x, vx)) for i in range(0, ns_, 1024)]
+            report(f"ab_filter_sum_validity_chunked_1024_vecbitmap{vb}_{rep}", 8.125 * ns_, lambda: api.pipeline(e, [XVS], [cx], gt))
     lib.set_option("vec_bitmap", 1)
     return results
 
