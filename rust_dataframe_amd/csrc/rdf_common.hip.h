@@ -180,4 +180,32 @@ __device__ __forceinline__ int64_t find_chunk(const int64_t* start, int64_t n, i
     return lo;
 }
 
+// The same for tile -> chunk lookups of the streaming kernels: frames usually carry equally sized RecordBatches (the
+// reader's 1024-row batches, src/dataframe.rs:352), where chunk c starts at tile c * tiles_per_chunk.  Interpolating
+// gives the answer with two dependent scalar loads instead of log2(n) (measured on 48 828 chunks of 1024 rows: the
+// binary search alone cost ~9 us per tile); any other layout fails the check and takes the search from the guess.
+__device__ __forceinline__ int64_t find_chunk_tile(const int64_t* start, int64_t n, int64_t t) {
+    if (n <= 1) return 0;
+    const int64_t last = start[n - 1];
+    if (t >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31)) return find_chunk(start, n, t);   // keeps t * (n - 1) in 64 bits
+    int64_t g = last > 0 ? (int64_t)((uint64_t)t * (uint64_t)(n - 1) / (uint64_t)last) : n - 1;
+    if (g > n - 1) g = n - 1;
+    const int64_t sg = start[g];
+    if (sg <= t) {
+        if (g + 1 == n || start[g + 1] > t) return g;
+        int64_t lo = g + 1, hi = n - 1;   // start[g + 1] <= t: the answer is at or after g + 1
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (start[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    }
+    int64_t lo = 0, hi = g - 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (start[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 }  // namespace rdfk

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
         TileLoc t;
         if (a.nchunks == 1) { t.c = 0; t.r0 = tile * kEvalTile; t.clen = a.inline_len; }
         else {
-            t.c = find_chunk(a.chunk_tile_start, a.nchunks, tile);
+            t.c = find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
             t.r0 = (tile - a.chunk_tile_start[t.c]) * kEvalTile;
             t.clen = a.chunk_len[t.c];
         }

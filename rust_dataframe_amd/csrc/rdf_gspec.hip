@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void gspec_kernel(const GSpecArgs a) {
 #pragma unroll
             for (int k = 0; k < NC; ++k) col[k] = a.cols[k];
         } else {
-            const int64_t ch = find_chunk(a.chunk_tile_start, a.nchunks, tile);
+            const int64_t ch = find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
             base = (tile - a.chunk_tile_start[ch]) * kEvalTile;
             n = a.chunk_len[ch];
 #pragma unroll

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void filter_agg_f64_kernel(const FilterAggF
 // the 1024 consecutive rows (16 mask words) [1024w, 1024w+1024) of a tile.
 
 __device__ __forceinline__ void locate_tile(const MaskTables& t, int64_t tile, int64_t& c, int64_t& r0, int64_t& clen) {
-    c = t.nchunks == 1 ? 0 : find_chunk(t.chunk_tile_start, t.nchunks, tile);
+    c = t.nchunks == 1 ? 0 : find_chunk_tile(t.chunk_tile_start, t.nchunks, tile);
     r0 = (tile - t.chunk_tile_start[c]) * kFilterTile;
     clen = t.chunk_len[c];
 }
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void groupby_build_kernel(const GroupByArgs
     const uint64_t mask = (uint64_t)a.t.capacity - 1;
     uint32_t err = 0;
     for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int64_t c = a.nchunks == 1 ? 0 : find_chunk(a.chunk_tile_start, a.nchunks, tile);
+        const int64_t c = a.nchunks == 1 ? 0 : find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
         const int64_t r0 = (tile - a.chunk_tile_start[c]) * kEvalTile;
         const int64_t clen = a.chunk_len[c];
         const DevChunkCol kc = a.keys[c];
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(kBlock) void groupby_build_lds_kernel(const GroupBy
     __syncthreads();
     uint32_t err = 0;
     for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int64_t c = a.nchunks == 1 ? 0 : find_chunk(a.chunk_tile_start, a.nchunks, tile);
+        const int64_t c = a.nchunks == 1 ? 0 : find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
         const int64_t r0 = (tile - a.chunk_tile_start[c]) * kEvalTile;
         const int64_t clen = a.chunk_len[c];
         const DevChunkCol kc = a.keys[c];
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(kBlock) void groupby_prepare_kernel(const GroupPrep
     const int lane = threadIdx.x & 63;
     const int wave = wave_id();
     for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int64_t c = a.nchunks == 1 ? 0 : find_chunk(a.chunk_tile_start, a.nchunks, tile);
+        const int64_t c = a.nchunks == 1 ? 0 : find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
         const int64_t r0 = (tile - a.chunk_tile_start[c]) * kEvalTile;
         const int64_t clen = a.chunk_len[c];
         const int64_t g0 = a.chunk_row_start[c];
@@ -1020,7 +1020,7 @@ __device__ __forceinline__ void gb_load_batch(const GbPartArgs& a, int64_t st, i
         if (tile >= tile_end) continue;
         if (a.nchunks == 1) { kc[tt] = a.key0; vc[tt] = a.val0; r0[tt] = tile * kEvalTile; clen[tt] = a.len0; }
         else {
-            const int64_t c = find_chunk(a.chunk_tile_start, a.nchunks, tile);
+            const int64_t c = find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
             r0[tt] = (tile - a.chunk_tile_start[c]) * kEvalTile;
             clen[tt] = a.chunk_len[c];
             kc[tt] = a.keys[c];

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
 #pragma unroll
             for (int k = 0; k < NC; ++k) m.col[k] = a.cols[k];
         } else {
-            m.ch = find_chunk(a.chunk_tile_start, a.nchunks, tile);
+            m.ch = find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
             m.base = (tile - a.chunk_tile_start[m.ch]) * per_iter;
             m.n = a.chunk_len[m.ch];
 #pragma unroll
