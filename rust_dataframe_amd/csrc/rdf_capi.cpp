@@ -1913,7 +1913,7 @@ rdf_status list_reduce(const rdf_list_array* l, int op, const void* value, rdf_o
     la.out_null_count = (int64_t*)((char*)p + 16);
     {
         KernelTimer kt;
-        ctx.last_kernel = wave_per_row ? "list_wave_kernel" : "list_rows_kernel";
+        ctx.last_kernel = wave_per_row ? "list_wave_kernel" : (op == LIST_CONTAINS || op == LIST_POSITION) ? "list_find_kernel" : "list_extreme_kernel";
         HIP_TRY(launch_list_op(la, wave_per_row, ctx.stream));
         kt.stop();
     }

@@ -208,4 +208,32 @@ __device__ __forceinline__ int64_t find_chunk_tile(const int64_t* start, int64_t
     return lo;
 }
 
+// Row -> chunk lookups done per LANE (take, sort keys): the same interpolation with the division replaced by a
+// multiplication with `inv` = (n - 1) / start[n - 1] (chunk_lookup_scale, computed once per kernel).  The guess is
+// exact or one off for equally sized chunks (three loads); other layouts finish with a search from the guess.
+__device__ __forceinline__ double chunk_lookup_scale(const int64_t* start, int64_t n) {
+    if (n <= 1) return 0.0;
+    const int64_t last = start[n - 1];
+    return last > 0 ? (double)(n - 1) / (double)last : 0.0;
+}
+__device__ __forceinline__ int64_t find_chunk_row(const int64_t* start, int64_t n, int64_t t, double inv) {
+    if (n <= 1) return 0;
+    int64_t g = (int64_t)((double)t * inv);
+    g = g < 0 ? 0 : (g > n - 1 ? n - 1 : g);
+    int64_t lo, hi;
+    if (start[g] <= t) {
+        if (g + 1 == n || start[g + 1] > t) return g;
+        if (g + 2 == n || start[g + 2] > t) return g + 1;
+        lo = g + 2; hi = n - 1;
+    } else {
+        if (g >= 1 && start[g - 1] <= t) return g - 1;
+        lo = 0; hi = g >= 2 ? g - 2 : 0;
+    }
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (start[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 }  // namespace rdfk

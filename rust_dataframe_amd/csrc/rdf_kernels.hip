@@ -366,6 +366,7 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const TakeArgs a) {
     uint32_t err = 0;
     int nulls = 0;
     const int64_t nwaves_total = (a.n + 63) >> 6;
+    const double inv = chunk_lookup_scale(a.chunk_row_start, a.nchunks);
     for (int64_t wv = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); wv < nwaves_total; wv += (int64_t)gridDim.x * (kBlock / 64)) {
         const int64_t j = wv * 64 + lane;
         const bool inr = j < a.n;
@@ -379,12 +380,7 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const TakeArgs a) {
             const uint64_t ix = (uint64_t)as_global<IDX>(a.indices.values)[a.indices.offset + j];
             if (ix >= (uint64_t)a.total_rows) { err |= 2u; valid = false; }
             else {
-                int64_t c = 0;
-                if (a.nchunks > 1) {
-                    int64_t lo = 0, hi = a.nchunks - 1;
-                    while (lo < hi) { int64_t mid = (lo + hi + 1) >> 1; if ((uint64_t)a.chunk_row_start[mid] <= ix) lo = mid; else hi = mid - 1; }
-                    c = lo;
-                }
+                const int64_t c = a.nchunks > 1 ? find_chunk_row(a.chunk_row_start, a.nchunks, (int64_t)ix, inv) : 0;
                 const DevChunkCol cc = a.chunks[c];
                 const int64_t e = cc.offset + (int64_t)ix - a.chunk_row_start[c];
                 v = as_global<T>(cc.values)[e];
@@ -427,9 +423,10 @@ __device__ __forceinline__ uint64_t sort_key_bits(const DevChunkCol& cc, int dt,
 
 __global__ __launch_bounds__(kBlock) void sort_keys_kernel(const SortKeyArgs a, uint64_t width_mask) {
     uint64_t kmin = ~0ull, kmax = 0;
+    const double inv = chunk_lookup_scale(a.chunk_row_start, a.nchunks);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
         const int64_t row = a.idx ? (int64_t)a.idx[i] : i;
-        const int64_t c = a.nchunks == 1 ? 0 : find_chunk(a.chunk_row_start, a.nchunks, row);
+        const int64_t c = a.nchunks == 1 ? 0 : find_chunk_row(a.chunk_row_start, a.nchunks, row, inv);
         const DevChunkCol cc = a.chunks[c];
         const int64_t e = cc.offset + row - a.chunk_row_start[c];
         uint64_t k = sort_key_bits(cc, a.dtype, e);

@@ -2,9 +2,10 @@
 // reference (one ListArray row = value_slice(value_offset(i), value_length(i)) of the child values) as segmented device
 // kernels.  Child validity is ignored exactly like the reference's value_slice() does.
 //
-//   list_rows_kernel<T>  : one LIST ROW per lane (short lists: neighbouring lanes walk neighbouring slices, every
-//                          64-byte sector is consumed within a few iterations), results leave as coalesced stores /
-//                          ballot-built bitmap words
+//   list_find_kernel<T>  : contains / position on short lists, 64 rows per wave: the rows' contiguous span is compared
+//                          element-parallel, a row's answer is the first set bit of its range of the match mask
+//   list_extreme_kernel<T>: max / min on short lists, one LIST ROW per lane walking the LDS-staged span; results
+//                          leave as coalesced stores / ballot-built bitmap words
 //   list_wave_kernel<T>  : one list row per WAVE (long lists): lanes stride the slice, butterfly reduction
 //   list_row_ids_kernel  : element -> row number (for the sort / remove compositions in rdf_capi.cpp)
 //   list_remove_kernel<T>: array_remove in two passes (count per row -> scan -> write at the scanned offsets)
@@ -43,76 +44,100 @@ RDF_LIST_NEEDLE(uint8_t) RDF_LIST_NEEDLE(uint16_t) RDF_LIST_NEEDLE(uint32_t) RDF
 template <class T> __device__ __forceinline__ bool list_is_nan(T v) { return v != v; }
 
 constexpr int kListStage = 1024;   // child elements per wave staged in LDS (8 KiB for 8-byte children)
-template <class T>
-__global__ __launch_bounds__(kBlock) void list_rows_kernel(const ListArgs a) {
-    __shared__ T stage[kBlock / 64][kListStage];
-    __shared__ uint64_t match[kBlock / 64][kListStage / 64];
-    const int lane = threadIdx.x & 63;
+// LDS of the two instantiations: the match mask of contains / position (128 B per wave — occupancy is then set by
+// registers alone) or the staged span of max / min
+template <class T, bool FIND> struct ListRowsLds;
+template <class T> struct ListRowsLds<T, true> { uint64_t match[kBlock / 64][kListStage / 64]; };
+template <class T> struct ListRowsLds<T, false> { T stage[kBlock / 64][kListStage]; };
+
+// What a wave needs to know about its 64 rows before it can touch the child values: the list validity word, the lane's
+// own slice and the span covered by all 64 (value_offsets are monotone, also across NULL rows).  None of the loads
+// depends on another, and the NEXT group's are issued before the current group's values are consumed: the
+// offsets -> values dependency costs one memory round trip per wave iteration instead of two or three.
+struct ListGroup { uint64_t lv; int32_t rb, re, span0, span1; };
+__device__ __forceinline__ ListGroup list_group_load(const ListArgs& a, GlobalPtr<int32_t> off, int64_t wv, int lane) {
+    ListGroup g;
+    const int64_t row = wv * 64 + lane;
+    const bool inr = row < a.n;
+    g.lv = ~0ull;
+    if (a.offsets.validity) g.lv = load_bits64(a.offsets.validity, a.offsets.offset + wv * 64, clamp64(a.n - wv * 64));
+    g.rb = off[inr ? row : a.n];
+    g.re = off[inr ? row + 1 : a.n];
+    const int64_t rlast = wv * 64 + 64 < a.n ? wv * 64 + 64 : a.n;
+    g.span0 = off[wv * 64];
+    g.span1 = off[rlast];
+    return g;
+}
+
+template <class T, bool FIND>
+__device__ __forceinline__ void list_rows_impl(const ListArgs& a) {
+    __shared__ ListRowsLds<T, FIND> lds;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const GlobalPtr<int32_t> off = as_global<int32_t>(a.offsets.values) + a.offsets.offset;
     const GlobalPtr<T> vals = as_global<T>(a.values.values) + a.values.offset;
     const T needle = list_needle<T>(a.needle);
     int nulls = 0;
-    const int64_t nwaves = (a.n + 63) >> 6;
-    for (int64_t wv = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); wv < nwaves; wv += (int64_t)gridDim.x * (kBlock / 64)) {
+    const int64_t nwaves = (a.n + 63) >> 6, stride = (int64_t)gridDim.x * (kBlock / 64);
+    int64_t wv = (int64_t)blockIdx.x * (kBlock / 64) + w;
+    ListGroup next = list_group_load(a, off, wv < nwaves ? wv : 0, lane);
+    for (; wv < nwaves; wv += stride) {
+        const ListGroup g = next;
+        if (wv + stride < nwaves) next = list_group_load(a, off, wv + stride, lane);
         const int64_t row = wv * 64 + lane;
         const bool inr = row < a.n;
-        uint64_t lv = ~0ull;
-        if (a.offsets.validity) lv = load_bits64(a.offsets.validity, a.offsets.offset + wv * 64, clamp64(a.n - wv * 64));
-        const bool lvalid = inr && ((lv >> lane) & 1);
-        int32_t b = 0, e = 0;
-        if (lvalid) { b = off[row]; e = off[row + 1]; }
+        const bool lvalid = inr && ((g.lv >> lane) & 1);
+        const int32_t b = lvalid ? g.rb : 0, e = lvalid ? g.re : 0;
+        const int32_t span0 = g.span0, span = g.span1 - g.span0;
+        const bool staged = span <= kListStage;
         bool found = false;
         int32_t pos = 0;
         uint64_t best = a.op == LIST_MAX ? 0 : ~0ull;
         bool any = false, nan_seen = false;
-        // The slices of the wave's 64 consecutive rows are one contiguous span of the child array (value_offsets are
-        // monotone, also across NULL rows): short spans are copied into LDS with coalesced loads and the lanes walk
-        // their slices there; a lane reading its slice straight from HBM touches a different cache line than its
-        // neighbours in every iteration (measured 0.20 of peak on rows of 10 f64).
-        const int64_t rlast = wv * 64 + 64 < a.n ? wv * 64 + 64 : a.n;
-        const int32_t span0 = off[wv * 64], span = off[rlast] - span0;
-        const bool staged = span <= kListStage;
-        if (staged && (a.op == LIST_CONTAINS || a.op == LIST_POSITION)) {
-            // contains / position need no walk at all: the span is compared element-parallel (coalesced loads, one ballot
-            // per 64 elements = one word of the match mask), and a row's answer is the first set bit of its bit range
-            const int nw = (span + 63) >> 6;
-            for (int t0 = 0; t0 < nw; t0 += 4) {   // four loads in flight per lane
-                T v[4];
-                bool ok[4];
+        if constexpr (FIND) {
+            if (staged) {
+                // contains / position need no walk at all: the span is compared element-parallel (coalesced loads, one
+                // ballot per 64 elements = one word of the match mask), and a row's answer is the first set bit of its range
+                const int nw = (span + 63) >> 6;
+                for (int t0 = 0; t0 < nw; t0 += 4) {   // four loads in flight per lane
+                    T v[4];
+                    bool ok[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int32_t i = (t0 + u) * 64 + lane; ok[u] = i < span; v[u] = ok[u] ? vals[span0 + i] : (T)0; }
+                    for (int u = 0; u < 4; ++u) { const int32_t i = (t0 + u) * 64 + lane; ok[u] = i < span; v[u] = ok[u] ? vals[span0 + i] : (T)0; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint64_t m = __ballot(ok[u] && v[u] == needle);
-                    if (lane == u && t0 + u < nw) match[threadIdx.x >> 6][t0 + u] = m;
+                    for (int u = 0; u < 4; ++u) {
+                        const uint64_t m = __ballot(ok[u] && v[u] == needle);
+                        if (lane == u && t0 + u < nw) lds.match[w][t0 + u] = m;
+                    }
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int32_t lo = b - span0, hi = e - span0;
-            for (int32_t wi = lo >> 6; b < e && !found && wi * 64 < hi; ++wi) {
-                uint64_t m = match[threadIdx.x >> 6][wi];
-                if (wi == lo >> 6) m &= ~0ull << (lo & 63);
-                if (hi - wi * 64 < 64) m &= (1ull << (hi - wi * 64)) - 1;
-                if (m) { found = true; pos = wi * 64 + __builtin_ctzll(m) - lo + 1; }
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else {
-        if (staged) {
-            for (int32_t i = lane; i < span; i += 64) stage[threadIdx.x >> 6][i] = vals[span0 + i];
-            __builtin_amdgcn_wave_barrier();   // same-wave LDS operations execute in order; this pins the compiler
-        }
-        for (int32_t i = b; i < e; ++i) {
-            const T v = staged ? stage[threadIdx.x >> 6][i - span0] : vals[i];
-            if (a.op == LIST_CONTAINS || a.op == LIST_POSITION) {
-                if (!found && v == needle) { found = true; pos = i - b + 1; }
+                __builtin_amdgcn_wave_barrier();
+                const int32_t lo = b - span0, hi = e - span0;
+                for (int32_t wi = lo >> 6; b < e && !found && wi * 64 < hi; ++wi) {
+                    uint64_t m = lds.match[w][wi];
+                    if (wi == lo >> 6) m &= ~0ull << (lo & 63);
+                    if (hi - wi * 64 < 64) m &= (1ull << (hi - wi * 64)) - 1;
+                    if (m) { found = true; pos = wi * 64 + __builtin_ctzll(m) - lo + 1; }
+                }
+                __builtin_amdgcn_wave_barrier();   // the next iteration rewrites the mask
             } else {
+                for (int32_t i = b; i < e && !found; ++i)
+                    if (vals[i] == needle) { found = true; pos = i - b + 1; }
+            }
+        } else {
+            // max / min: short spans are copied into LDS with coalesced loads and the lanes walk their slices there; a
+            // lane reading its slice straight from HBM touches a different cache line than its neighbours in every
+            // iteration (measured 0.20 of peak on rows of 10 f64)
+            if (staged) {
+                for (int32_t i = lane; i < span; i += 64) lds.stage[w][i] = vals[span0 + i];
+                __builtin_amdgcn_wave_barrier();   // same-wave LDS operations execute in order; this pins the compiler
+            }
+            for (int32_t i = b; i < e; ++i) {
+                const T v = staged ? lds.stage[w][i - span0] : vals[i];
                 if (list_is_nan(v)) { nan_seen = true; continue; }
                 const uint64_t k = ListKey<T>::key(v);
                 best = a.op == LIST_MAX ? (k > best ? k : best) : (k < best ? k : best);
                 any = true;
             }
-        }
-        __builtin_amdgcn_wave_barrier();   // the next iteration refills the staging area
+            __builtin_amdgcn_wave_barrier();   // the next iteration refills the staging area
         }
         if (a.op == LIST_CONTAINS) {   // NULL list -> NULL, else true / false (array.rs:15-37)
             const uint64_t vb = __ballot(lvalid), bits = __ballot(lvalid && found), ib = __ballot(inr);
@@ -140,6 +165,8 @@ __global__ __launch_bounds__(kBlock) void list_rows_kernel(const ListArgs a) {
     }
     if (lane == 0 && nulls) atomicAdd((unsigned long long*)a.out_null_count, (unsigned long long)nulls);
 }
+template <class T> __global__ __launch_bounds__(kBlock) void list_find_kernel(const ListArgs a) { list_rows_impl<T, true>(a); }
+template <class T> __global__ __launch_bounds__(kBlock) void list_extreme_kernel(const ListArgs a) { list_rows_impl<T, false>(a); }
 
 // One row per wave.  Bitmap outputs are pre-zeroed by the host and OR-ed in (rows of one word belong to different waves).
 template <class T>
@@ -224,16 +251,18 @@ __global__ __launch_bounds__(kBlock) void list_remove_kernel(const ListArgs a) {
     const GlobalPtr<int32_t> off = as_global<int32_t>(a.offsets.values) + a.offsets.offset;
     const GlobalPtr<T> vals = as_global<T>(a.values.values) + a.values.offset;
     const T needle = list_needle<T>(a.needle);
-    const int64_t nwaves = (a.n + 63) >> 6;
-    for (int64_t wv = (int64_t)blockIdx.x * (kBlock / 64) + w; wv < nwaves; wv += (int64_t)gridDim.x * (kBlock / 64)) {
+    const int64_t nwaves = (a.n + 63) >> 6, stride = (int64_t)gridDim.x * (kBlock / 64);
+    int64_t wv = (int64_t)blockIdx.x * (kBlock / 64) + w;
+    ListGroup next = list_group_load(a, off, wv < nwaves ? wv : 0, lane);
+    for (; wv < nwaves; wv += stride) {
+        const ListGroup g = next;
+        if (wv + stride < nwaves) next = list_group_load(a, off, wv + stride, lane);   // see list_rows_impl
         const int64_t row = wv * 64 + lane;
         const bool inr = row < a.n;
-        bool lvalid = inr;
-        if (inr && a.offsets.validity) { const int64_t bi = a.offsets.offset + row; lvalid = (as_global<uint8_t>(a.offsets.validity)[bi >> 3] >> (bi & 7)) & 1; }
-        const int32_t rb = inr ? off[row] : 0, re = inr ? off[row + 1] : 0;   // the row's slice, NULL or not
+        const bool lvalid = inr && ((g.lv >> lane) & 1);
+        const int32_t rb = inr ? g.rb : 0, re = inr ? g.re : 0;   // the row's slice, NULL or not
         const int32_t b = lvalid ? rb : 0, e = lvalid ? re : 0;
-        const int64_t rlast = wv * 64 + 64 < a.n ? wv * 64 + 64 : a.n;
-        const int32_t span0 = off[wv * 64], span = off[rlast] - span0;
+        const int32_t span0 = g.span0, span = g.span1 - g.span0;
         if (span <= kListStage) {
             const int nw = (span + 63) >> 6;
             for (int t0 = 0; t0 < nw; t0 += 4) {   // four loads in flight per lane
@@ -323,7 +352,9 @@ hipError_t launch_list_op(const ListArgs& a, bool wave_per_row, hipStream_t s) {
     int64_t grid64 = (units + (kBlock / 64) - 1) / (kBlock / 64);
     if (grid64 > eval_grid_limit()) grid64 = eval_grid_limit();
     const int grid = (int)(grid64 < 1 ? 1 : grid64);
-    if (wave_per_row) { RDF_LIST_DISPATCH(list_wave_kernel) } else { RDF_LIST_DISPATCH(list_rows_kernel) }
+    if (wave_per_row) { RDF_LIST_DISPATCH(list_wave_kernel) }
+    else if (a.op == LIST_CONTAINS || a.op == LIST_POSITION) { RDF_LIST_DISPATCH(list_find_kernel) }
+    else { RDF_LIST_DISPATCH(list_extreme_kernel) }
     return hipGetLastError();
 }
 hipError_t launch_list_row_ids(const ListArgs& a, uint32_t* row_ids, int32_t first, hipStream_t s) {

@@ -170,6 +170,20 @@ def main():
     sidx = torch.arange(0, nidx, dtype=torch.int64, device="cuda").to(torch.uint32)
     S = A.DeviceArray(sidx.data_ptr(), None, 0, nidx, A.U32, 0, keep=sidx)
     report("take_sequential_u32", (4 + 8 + 8) * nidx, lambda: api.take([X], S, ot))
+    # take from / sort of a column in the reference's 1024-row batches (a 1e8-row prefix = 97 657 chunks): every element
+    # resolves its chunk on its own (find_chunk_row)
+    nsrc = min(n, 100_000_000)
+    XS = [A.DeviceArray(x.data_ptr() + i * 8, None, 0, min(1024, nsrc - i), A.F64, 0, keep=x) for i in range(0, nsrc, 1024)]
+    nix = nsrc // 4
+    idx2 = torch.randint(0, nsrc, (nix,), dtype=torch.int64, device="cuda").to(torch.uint32)
+    I2 = A.DeviceArray(idx2.data_ptr(), None, 0, nix, A.U32, 0, keep=idx2)
+    ot2 = out_like(A.F64, nix)
+    report("take_random_u32_from_1024_row_chunks", (4 + 8 + 8) * nix, lambda: api.take(XS, I2, ot2))
+    nks = min(nsrc, 50_000_000)
+    KS1 = [A.DeviceArray(k.data_ptr() + i * 8, None, 0, min(1024, nks - i), A.I64, 0, keep=k) for i in range(0, nks, 1024)]
+    oi2 = out_like(A.U32, nks)
+    report("sort_to_indices_i64_1024_row_chunks", 8.0 * nks, lambda: api.sort_to_indices([KS1], [False], oi2))
+    del XS, KS1, idx2
     # chunked device-resident columns (what a frame looks like after a filter): 1M-row chunks
     def chunked(t, dtype, rows=1 << 20):
         return [A.DeviceArray(t.data_ptr() + i * 8, None, 0, min(rows, n - i), dtype, 0, keep=t) for i in range(0, n, rows)]
