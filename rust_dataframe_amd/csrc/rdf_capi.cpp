@@ -45,6 +45,7 @@ struct Ctx {
     bool   opt_spec = true;        // specialised straight-line kernels (rdf_spec.hip)
     bool   opt_fast_filter = true; // filter_agg_f64_kernel (handles 8-byte-misaligned columns)
     bool   opt_vec_bitmap = true;  // bitmap words via vector loads (default) instead of scalar loads (spec kernels)
+    int    opt_filter_tile = 0;     // 0: compaction tile chosen from the mean chunk length; 1024 / 4096 force one (A/B)
     int    opt_gb_debug = 0;        // ablations of the partitioned GROUP BY (tools/bench_kernels.py): 1 = aggregate without LDS work, 2 = scatter without stores
     int    opt_gb_partition = 1;    // high-cardinality GROUP BY: 1 = single scatter pass + LDS tables (default), 2 = the radix-sort based two-pass variant, 0 = HBM atomics // bitmap words via vector loads instead of scalar loads (spec kernels)
     // kernel timing (bench.py roofline leg)
@@ -1541,6 +1542,7 @@ struct FilterPrep {
     InputStager in;         // mask chunks first, then the columns
     TableBuilder tb;
     MaskTables mt;
+    int tile_rows = kFilterTile;   // kFilterTile or kFilterTileSmall, picked from the mean chunk length
     std::vector<int64_t> clen, tile_start;
     int64_t ntiles = 0;
     int64_t* d_counts = nullptr;  // [ntiles]
@@ -1561,9 +1563,15 @@ rdf_status filter_prepare(FilterPrep& fp, const rdf_array* cols, int ncols, cons
 
     fp.clen.resize((size_t)nchunks);
     fp.tile_start.assign((size_t)nchunks + 1, 0);
+    // tiles never span chunks: frames in the reader's 1024-row batches get 1024-row tiles (a 4096-row tile would leave
+    // three of the four waves of a block without rows), long chunks the 4096-row ones
+    int64_t rows_total = 0;
+    for (int64_t c = 0; c < nchunks; ++c) rows_total += mask[c].length;
+    int tile_rows = nchunks > 0 && rows_total / nchunks <= 2048 ? kFilterTileSmall : kFilterTile;
+    if (ctx.opt_filter_tile == kFilterTileSmall || ctx.opt_filter_tile == kFilterTile) tile_rows = ctx.opt_filter_tile;
     for (int64_t c = 0; c < nchunks; ++c) {
         fp.clen[(size_t)c] = mask[c].length;
-        fp.tile_start[(size_t)c + 1] = fp.tile_start[(size_t)c] + (mask[c].length + kFilterTile - 1) / kFilterTile;
+        fp.tile_start[(size_t)c + 1] = fp.tile_start[(size_t)c] + (mask[c].length + tile_rows - 1) / tile_rows;
     }
     fp.ntiles = fp.tile_start[(size_t)nchunks];
 
@@ -1586,12 +1594,13 @@ rdf_status filter_prepare(FilterPrep& fp, const rdf_array* cols, int ncols, cons
     fp.mt.chunk_len = fp.tb.dev_at<int64_t>(o_len);
     fp.mt.nchunks = nchunks;
     fp.mt.ntiles = fp.ntiles;
+    fp.tile_rows = tile_rows;
 
     void* p = nullptr;
     RDF_TRY(arena_alloc(sizeof(int64_t) * (2 * (size_t)fp.ntiles + 2 + (size_t)scan_scratch_words(fp.ntiles)), &p));
     fp.d_counts = (int64_t*)p;
     fp.d_scan = fp.d_counts + fp.ntiles;
-    HIP_TRY(launch_mask_count(fp.mt, fp.d_counts, ctx.stream));
+    HIP_TRY(launch_mask_count(fp.mt, fp.tile_rows, fp.d_counts, ctx.stream));
     HIP_TRY(launch_scan(fp.d_counts, fp.d_scan, fp.ntiles, fp.d_scan + fp.ntiles + 1, ctx.stream));
 
     // per-chunk totals = scan[tile_start[c+1]] - scan[tile_start[c]]: fetch the nchunks+1 boundary values
@@ -1719,7 +1728,7 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
             fa.tile_scan = fp.d_scan;
             fa.ncols = ncols - g < kMaxFilterCols ? ncols - g : kMaxFilterCols;
             for (int k = 0; k < fa.ncols; ++k) fa.esize[k] = dtype_size(cols[(int64_t)(g + k) * nchunks].dtype);
-            HIP_TRY(launch_compact(fa, ctx.stream));
+            HIP_TRY(launch_compact(fa, fp.tile_rows, ctx.stream));
         }
         kt.stop();
     }
@@ -2974,6 +2983,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "vec_bitmap") == 0) g_ctx.opt_vec_bitmap = value != 0;
     else if (strcmp(name, "gb_partition") == 0) g_ctx.opt_gb_partition = (int)value;
     else if (strcmp(name, "gb_debug") == 0) g_ctx.opt_gb_debug = (int)value;
+    else if (strcmp(name, "filter_tile") == 0) g_ctx.opt_filter_tile = (int)value;
     else return fail(RDF_INVALID_ARGUMENT, "unknown option %s", name);
     return RDF_OK;
 }

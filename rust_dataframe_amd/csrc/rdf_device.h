@@ -11,6 +11,7 @@ constexpr int kBlock = 256;          // 4 wavefronts of 64
 constexpr int kVPT = 4;              // rows per thread per tile in the fused evaluator
 constexpr int kEvalTile = kBlock * kVPT;   // 1024 rows: one reference RecordBatch (src/dataframe.rs:352)
 constexpr int kFilterTile = 4096;    // rows per compaction tile (64 mask words, 16 per wave): measured best of 2048 / 4096 / 8192
+constexpr int kFilterTileSmall = 1024;   // the tile for frames in small RecordBatches (mean chunk length <= 2048 rows)
 constexpr int kMaxCode = 56;         // accumulator-machine instructions per program
 constexpr int kMaxCols = 8;          // columns referenced by one program
 constexpr int kPreCols = 4;          // columns preloaded into registers per tile
@@ -365,10 +366,10 @@ int  spec_rows_per_block_iter(const char* sig);
 int  spec_catalog_size();
 hipError_t launch_spec(const char* sig, const SpecArgs& a, int grid, hipStream_t s);
 hipError_t launch_filter_agg_f64(const FilterAggF64Args& a, int cmp_op, int grid, hipStream_t s);
-hipError_t launch_mask_count(const MaskTables& t, int64_t* tile_counts, hipStream_t s);
+hipError_t launch_mask_count(const MaskTables& t, int tile_rows, int64_t* tile_counts, hipStream_t s);   // tile_rows: kFilterTile or kFilterTileSmall
 hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, int64_t* scratch, hipStream_t s);
 int64_t scan_scratch_words(int64_t n);
-hipError_t launch_compact(const FilterArgs& a, hipStream_t s);
+hipError_t launch_compact(const FilterArgs& a, int tile_rows, hipStream_t s);
 hipError_t launch_take(const TakeArgs& a, hipStream_t s);
 int  sort_grid(int64_t ntiles);
 hipError_t launch_sort_keys(const SortKeyArgs& a, hipStream_t s);

@@ -141,18 +141,22 @@ __global__ __launch_bounds__(kBlock) void filter_agg_f64_kernel(const FilterAggF
 }
 
 // ------------------------------------------------------------------------------------------------
-// stream compaction (Column::filter).  Tiles of kFilterTile = 2048 rows = 32 mask words; wave w owns
-// the 1024 consecutive rows (16 mask words) [1024w, 1024w+1024) of a tile.
+// stream compaction (Column::filter).  A tile never spans two chunks, and wave w of the block owns WW consecutive mask
+// words of it: WW = 16 (tiles of kFilterTile = 4096 rows, 1024 per wave: the best of 2048 / 4096 / 8192 on long chunks) or
+// WW = 4 (tiles of kFilterTileSmall = 1024 rows) for frames held in the reader's 1024-row RecordBatches, where a
+// 4096-row tile would leave three of the four waves without rows.  The host picks per call (filter_prepare).
+template <int WW> constexpr int filter_tile_rows() { return WW * 64 * (kBlock / 64); }
+static_assert(filter_tile_rows<16>() == kFilterTile && filter_tile_rows<4>() == kFilterTileSmall, "tile sizes of the two instantiations");
 
+template <int WW>
 __device__ __forceinline__ void locate_tile(const MaskTables& t, int64_t tile, int64_t& c, int64_t& r0, int64_t& clen) {
     c = t.nchunks == 1 ? 0 : find_chunk_tile(t.chunk_tile_start, t.nchunks, tile);
-    r0 = (tile - t.chunk_tile_start[c]) * kFilterTile;
+    r0 = (tile - t.chunk_tile_start[c]) * filter_tile_rows<WW>();
     clen = t.chunk_len[c];
 }
 
-constexpr int kWW = kFilterTile / 64 / (kBlock / 64);  // mask words per wave per tile (8)
-
-// keep-words of this wave's 512 rows: mask value bits AND mask validity bits, rows past the chunk end cleared
+// keep-words of this wave's WW * 64 rows: mask value bits AND mask validity bits, rows past the chunk end cleared
+template <int kWW>
 __device__ __forceinline__ void keep_words(const DevChunkCol& m, int64_t rw, int64_t clen, uint64_t (&kw)[kWW]) {
     load_windows<kWW>((const uint8_t*)m.values, m.offset + rw, clen - rw, kw);
     if (m.validity) {
@@ -163,15 +167,16 @@ __device__ __forceinline__ void keep_words(const DevChunkCol& m, int64_t rw, int
     }
 }
 
-// One wave per tile-quarter: counts the kept rows of 512 rows with scalar loads + s_bcnt1; reads 1 bit/row.
+// One wave per tile-quarter: counts the kept rows of its WW words (s_bcnt1); reads 1 bit/row.
+template <int kWW>
 __global__ __launch_bounds__(kBlock) void mask_count_kernel(const MaskTables t, int64_t* tile_counts) {
     __shared__ int wave_cnt[kBlock / 64];
     const int wave = wave_id();
     for (int64_t tile = blockIdx.x; tile < t.ntiles; tile += gridDim.x) {
         int64_t c, r0, clen;
-        locate_tile(t, tile, c, r0, clen);
+        locate_tile<kWW>(t, tile, c, r0, clen);
         uint64_t kw[kWW];
-        keep_words(t.mask[c], r0 + (int64_t)wave * (kWW * 64), clen, kw);
+        keep_words<kWW>(t.mask[c], r0 + (int64_t)wave * (kWW * 64), clen, kw);
         int cnt = 0;
 #pragma unroll
         for (int i = 0; i < kWW; ++i) cnt += __popcll(kw[i]);
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_add_kernel(int64_t* scan, i
 // (scalar prefix + lane prefix): no shuffles, no atomics for the values.  Kept values are staged in the
 // wave's PRIVATE 4 KiB LDS region at their rank and written out as one contiguous, coalesced run at
 // the wave's output offset — waves never wait for each other inside a column.
-template <typename T>
+template <typename T, int kWW>
 __device__ __forceinline__ void compact_wave(const DevChunkCol col, const DevOutChunk oc, int64_t rw, int64_t clen,
                                              int64_t wave_out, const uint64_t (&kw)[kWW], int wave_cnt,
                                              unsigned char* stage_raw, uint8_t* vstage, uint32_t& nulls) {
@@ -293,9 +298,9 @@ __device__ __forceinline__ void compact_wave(const DevChunkCol col, const DevOut
 constexpr int kCompactCols = 8;  // columns per launch (the host loops over wider frames)
 
 // ES = common element size of all columns of the launch (8/4/2/1) or 0 for mixed sizes.
-template <int ES>
+template <int ES, int kWW>
 __global__ __launch_bounds__(kBlock) void compact_kernel(const FilterArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char stage[kBlock / 64][kWW * 64 * 8];  // 4 KiB per wave
+    __shared__ __attribute__((aligned(16))) unsigned char stage[kBlock / 64][kWW * 64 * 8];  // 8 KiB (WW = 16) or 2 KiB per wave
     __shared__ uint8_t vstage[kBlock / 64][kWW * 64];
     __shared__ int wave_cnt[2][kBlock / 64];
     const int lane = threadIdx.x & 63;
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const FilterArgs a) {
     int parity = 0;
     for (int64_t tile = blockIdx.x; tile < a.t.ntiles; tile += gridDim.x, parity ^= 1) {
         int64_t c, r0, clen;
-        locate_tile(a.t, tile, c, r0, clen);
+        locate_tile<kWW>(a.t, tile, c, r0, clen);
         if (c != cur_chunk) {
             if (cur_chunk >= 0 && lane == 0) {
 #pragma unroll
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const FilterArgs a) {
         }
         const int64_t rw = r0 + (int64_t)wave * (kWW * 64);
         uint64_t kw[kWW];
-        keep_words(a.t.mask[c], rw, clen, kw);
+        keep_words<kWW>(a.t.mask[c], rw, clen, kw);
         int cnt = 0;
 #pragma unroll
         for (int i = 0; i < kWW; ++i) cnt += __popcll(kw[i]);
@@ -339,10 +344,10 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const FilterArgs a) {
                 const DevOutChunk oc = a.outs[(int64_t)k * a.t.nchunks + c];
                 uint32_t nn = 0;
                 const int es = ES ? ES : a.esize[k];
-                if (es == 8) compact_wave<uint64_t>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
-                else if (es == 4) compact_wave<uint32_t>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
-                else if (es == 2) compact_wave<uint16_t>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
-                else compact_wave<uint8_t>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+                if (es == 8) compact_wave<uint64_t, kWW>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+                else if (es == 4) compact_wave<uint32_t, kWW>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+                else if (es == 2) compact_wave<uint16_t, kWW>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+                else compact_wave<uint8_t, kWW>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
 #pragma unroll
                 for (int kk = 0; kk < kCompactCols; ++kk)
                     if (kk == k) nullacc[kk] += nn;
@@ -1528,9 +1533,12 @@ hipError_t launch_filter_agg_f64(const FilterAggF64Args& a, int cmp_op, int grid
     return hipGetLastError();
 }
 
-hipError_t launch_mask_count(const MaskTables& t, int64_t* tile_counts, hipStream_t s) {
+hipError_t launch_mask_count(const MaskTables& t, int tile_rows, int64_t* tile_counts, hipStream_t s) {
     int64_t grid = t.ntiles < (int64_t)eval_grid_limit() ? t.ntiles : (int64_t)eval_grid_limit();
-    if (grid > 0) hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, t, tile_counts);
+    if (grid > 0) {
+        if (tile_rows == kFilterTileSmall) hipLaunchKernelGGL(mask_count_kernel<4>, dim3((unsigned)grid), dim3(kBlock), 0, s, t, tile_counts);
+        else hipLaunchKernelGGL(mask_count_kernel<16>, dim3((unsigned)grid), dim3(kBlock), 0, s, t, tile_counts);
+    }
     return hipGetLastError();
 }
 // `scratch` holds ceil(n / 4096) + 1 int64 words.
@@ -1542,18 +1550,21 @@ hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, int64_t*
     return hipGetLastError();
 }
 int64_t scan_scratch_words(int64_t n) { return (n + kScanSeg - 1) / kScanSeg + 2; }
-hipError_t launch_compact(const FilterArgs& a, hipStream_t s) {
+hipError_t launch_compact(const FilterArgs& a, int tile_rows, hipStream_t s) {
     int64_t grid = a.t.ntiles < (int64_t)eval_grid_limit() ? a.t.ntiles : (int64_t)eval_grid_limit();
     if (grid <= 0) return hipSuccess;
     int es = a.esize[0];
     for (int k = 1; k < a.ncols; ++k) if (a.esize[k] != es) es = 0;
-    switch (es) {
-        case 8: hipLaunchKernelGGL((compact_kernel<8>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((compact_kernel<4>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((compact_kernel<2>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
-        case 1: hipLaunchKernelGGL((compact_kernel<1>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
-        default: hipLaunchKernelGGL((compact_kernel<0>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
+#define RDF_COMPACT_LAUNCH(WW)                                                                                          \
+    switch (es) {                                                                                                       \
+        case 8: hipLaunchKernelGGL((compact_kernel<8, WW>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;        \
+        case 4: hipLaunchKernelGGL((compact_kernel<4, WW>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;        \
+        case 2: hipLaunchKernelGGL((compact_kernel<2, WW>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;        \
+        case 1: hipLaunchKernelGGL((compact_kernel<1, WW>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;        \
+        default: hipLaunchKernelGGL((compact_kernel<0, WW>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;       \
     }
+    if (tile_rows == kFilterTileSmall) { RDF_COMPACT_LAUNCH(4) } else { RDF_COMPACT_LAUNCH(16) }
+#undef RDF_COMPACT_LAUNCH
     return hipGetLastError();
 }
 

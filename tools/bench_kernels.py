@@ -162,6 +162,23 @@ def main():
     report("filter_count", n / 8.0, lambda: api.filter_count([m]))
     report("filter_1col", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
     report("filter_2col", (16 + 16 * sel + 0.25) * n, lambda: api.filter_columns([[X], [K]], [m], [[of], [ok2]]))
+    for ft in (1024, 4096):   # A/B of the two compaction tile sizes on one long chunk (auto picks 4096)
+        lib.set_option("filter_tile", ft)
+        report(f"filter_1col_tile_{ft}", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
+        report(f"filter_2col_tile_{ft}", (16 + 16 * sel + 0.25) * n, lambda: api.filter_columns([[X], [K]], [m], [[of], [ok2]]))
+    lib.set_option("filter_tile", 0)
+    # the same filter over a frame in the reference's 1024-row RecordBatches (a 1e8-row prefix = 97 657 chunks): 1024-row
+    # compaction tiles (picked from the mean chunk length) against the 4096-row tiles of long chunks forced onto it
+    nfc = min(n, 100_000_000)
+    XF = [A.DeviceArray(x.data_ptr() + i * 8, None, 0, min(1024, nfc - i), A.F64, 0, keep=x) for i in range(0, nfc, 1024)]
+    MF = [A.DeviceArray(m.values_ptr + i // 8, None, 0, min(1024, nfc - i), A.BOOL, 0, keep=m) for i in range(0, nfc, 1024)]
+    ofb = torch.empty(nfc, dtype=torch.float64, device="cuda")
+    OF = [A.DeviceArray(ofb.data_ptr() + i * 8, None, 0, min(1024, nfc - i), A.F64, 0, keep=ofb) for i in range(0, nfc, 1024)]
+    for ft in (0, 4096):
+        lib.set_option("filter_tile", ft)
+        report(f"filter_1col_1024_row_chunks_tile_{'auto' if ft == 0 else ft}", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))
+    lib.set_option("filter_tile", 0)
+    del XF, MF, OF, ofb
     nidx = n // 4
     idx = torch.randint(0, n, (nidx,), dtype=torch.int64, device="cuda").to(torch.uint32 if hasattr(torch, "uint32") else torch.int32)
     I = A.DeviceArray(idx.data_ptr(), None, 0, nidx, A.U32, 0, keep=idx)
