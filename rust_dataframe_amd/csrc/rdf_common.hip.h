@@ -170,6 +170,78 @@ __device__ __forceinline__ void block_reduce_agg(int cls, uint64_t sum, uint64_t
     }
 }
 
+// f64 sin / cos / tan for the fused kernels.  The device libm's versions cost ~100 lane-cycles per element (the C1-shape
+// kernel sum(sin(x + c)) ran at 0.40 of the HBM peak, VALU-bound); these are the classic two-step evaluation written
+// out directly: Cody-Waite reduction by pi/2 in four FMA steps (the first three constants hold 33 bits each, so
+// k * constant is exact for |k| < 2^16 and the chain keeps the RELATIVE accuracy of r even next to a zero of the
+// function), then a polynomial kernel.  tan divides the two degree-13 / degree-12 minimax kernels of fdlibm's k_sin.c /
+// k_cos.c on |r| <= pi/4.  Checked on the host against glibc over 2e7 points incl. the neighbourhood of every multiple of
+// pi/2 below 1e5: <= 2 ulp, relative error <= 3.2e-16.  Arguments with |x| >= 1e5, infinities and NaNs take the libm path.
+__device__ __forceinline__ void trig_reduce(double x, double& r, int& q) {
+    const double kd = rint(x * 6.36619772367581382433e-01);   // 2 / pi
+    q = (int)kd;
+    double t = fma(-kd, 1.57079632673412561417e+00, x);       // pi/2, bits 1..33
+    t = fma(-kd, 6.07710050630396597660e-11, t);              // bits 34..66
+    t = fma(-kd, 2.02226624871116645580e-21, t);              // bits 67..99
+    r = fma(-kd, 8.47842766036889956997e-32, t);              // the tail
+}
+__device__ __forceinline__ double trig_ksin(double r) {
+    const double z = r * r, v = z * r;
+    const double p = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    return fma(v, fma(z, p, -1.66666666666666324348e-01), r);
+}
+__device__ __forceinline__ double trig_kcos(double r) {
+    const double z = r * r;
+    const double p = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                            2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    return 1.0 - (0.5 * z - z * p);
+}
+// sin / cos use ONE odd polynomial on [-pi/2, pi/2] instead (x = m * pi/2 + r with m even for sin, odd for cos; the sign is
+// the parity of m / 2): sin r = r + r z P(z), P of degree 7 in z = r^2 fitted at Chebyshev nodes in 60-digit arithmetic
+// (relative error 3.6e-17 before rounding).  About half the arithmetic of evaluating both quarter-pi kernels and
+// selecting; same host check: <= 2 ulp, relative error <= 2.7e-16, cos(0) == 1, sin(-0.0) == -0.0.
+__device__ __forceinline__ double trig_reduce_m(double x, double md) {
+    double t = fma(-md, 1.57079632673412561417e+00, x);
+    t = fma(-md, 6.07710050630396597660e-11, t);
+    t = fma(-md, 2.02226624871116645580e-21, t);
+    return fma(-md, 8.47842766036889956997e-32, t);
+}
+__device__ __forceinline__ double trig_psin(double r, int k) {
+    const double z = r * r;
+    double p = 2.73143472074881618678e-15;
+    p = fma(p, z, -7.64396949104287201694e-13);
+    p = fma(p, z, 1.60589772872252839761e-10);
+    p = fma(p, z, -2.50521076166068844386e-08);
+    p = fma(p, z, 2.75573192191601764039e-06);
+    p = fma(p, z, -1.98412698412549632883e-04);
+    p = fma(p, z, 8.33333333333331587045e-03);
+    p = fma(p, z, -1.66666666666666657415e-01);
+    const double v = fma(r * z, p, r);
+    return u2d(d2u(v) ^ ((uint64_t)(k & 1) << 63));
+}
+__device__ __forceinline__ double rdf_sin(double x) {
+    const double ax = fabs(x);
+    if (!(ax < 1.0e5)) return sin(x);
+    if (ax < 0x1p-26) return x;            // also keeps -0.0
+    const double kd = rint(x * 3.18309886183790671538e-01);   // 1 / pi
+    return trig_psin(trig_reduce_m(x, 2.0 * kd), (int)kd);
+}
+__device__ __forceinline__ double rdf_cos(double x) {
+    if (!(fabs(x) < 1.0e5)) return cos(x);
+    const double kd = rint(fma(x, 3.18309886183790671538e-01, -0.5));
+    return trig_psin(trig_reduce_m(x, fma(2.0, kd, 1.0)), (int)kd + 1);
+}
+__device__ __forceinline__ double rdf_tan(double x) {
+    const double ax = fabs(x);
+    if (!(ax < 1.0e5)) return tan(x);
+    if (ax < 0x1p-26) return x;
+    double r; int q;
+    trig_reduce(x, r, q);
+    const double s = trig_ksin(r), c = trig_kcos(r);
+    return (q & 1) ? -c / s : s / c;
+}
+
 // largest c in [0, n) with start[c] <= t (start is a non-decreasing prefix table; scalar loads)
 __device__ __forceinline__ int64_t find_chunk(const int64_t* start, int64_t n, int64_t t) {
     int64_t lo = 0, hi = n - 1;

@@ -140,15 +140,15 @@ __device__ __forceinline__ double unary_f64(int op, double x) {
             case RDF_OP_ASIN: return asin(x);
             case RDF_OP_ATAN: return atan(x);
             case RDF_OP_CBRT: return cbrt(x);
-            case RDF_OP_COS: return cos(x);
+            case RDF_OP_COS: return rdf_cos(x);
             case RDF_OP_COSH: return cosh(x);
             case RDF_OP_EXP: return exp(x);
             case RDF_OP_EXPM1: return expm1(x);
             case RDF_OP_LOG10: return log10(x);
             case RDF_OP_LOG2: return log2(x);
-            case RDF_OP_SIN: return sin(x);
+            case RDF_OP_SIN: return rdf_sin(x);
             case RDF_OP_SINH: return sinh(x);
-            case RDF_OP_TAN: return tan(x);
+            case RDF_OP_TAN: return rdf_tan(x);
             case RDF_OP_TANH: return tanh(x);
             default: break;
         }

@@ -161,7 +161,7 @@ struct Un {
         else if constexpr (OP == RDF_OP_ATAN) return atan(x);
         else if constexpr (OP == RDF_OP_CBRT) return cbrt(x);
         else if constexpr (OP == RDF_OP_CEIL) return ceil(x);
-        else if constexpr (OP == RDF_OP_COS) return cos(x);
+        else if constexpr (OP == RDF_OP_COS) return rdf_cos(x);
         else if constexpr (OP == RDF_OP_COSH) return cosh(x);
         else if constexpr (OP == RDF_OP_DEGREES) return x * (180.0 / 3.14159265358979323846264338327950288);
         else if constexpr (OP == RDF_OP_EXP) return exp(x);
@@ -171,10 +171,10 @@ struct Un {
         else if constexpr (OP == RDF_OP_LOG2) return log2(x);
         else if constexpr (OP == RDF_OP_RADIANS) return x * (3.14159265358979323846264338327950288 / 180.0);
         else if constexpr (OP == RDF_OP_ROUND) return round(x);
-        else if constexpr (OP == RDF_OP_SIN) return sin(x);
+        else if constexpr (OP == RDF_OP_SIN) return rdf_sin(x);
         else if constexpr (OP == RDF_OP_SINH) return sinh(x);
         else if constexpr (OP == RDF_OP_SQRT) return sqrt(x);
-        else if constexpr (OP == RDF_OP_TAN) return tan(x);
+        else if constexpr (OP == RDF_OP_TAN) return rdf_tan(x);
         else return tanh(x);
     }
     static std::string sig() { return "[" + std::to_string(OP) + " " + A::sig() + "]"; }
@@ -258,9 +258,9 @@ struct TrigRT {    // sin / cos / tan: the three the reference's Evaluate::calcu
     template <int r, class C> static __device__ __forceinline__ double eval(C& c) {
         const double x = A::template eval<r>(c);
         const int op = c.rt[SLOT] & 0xFF;
-        if (op == RDF_OP_SIN) return sin(x);
-        if (op == RDF_OP_COS) return cos(x);
-        return tan(x);
+        if (op == RDF_OP_SIN) return rdf_sin(x);
+        if (op == RDF_OP_COS) return rdf_cos(x);
+        return rdf_tan(x);
     }
     static std::string sig() { return "[T" + std::to_string(SLOT) + " " + A::sig() + "]"; }
 };
