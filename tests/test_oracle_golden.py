@@ -276,3 +276,44 @@ def test_oracle_reproduces_golden_vectors(ora):
 def test_gpu_reproduces_golden_vectors(gpu):
     """The HIP path against the committed vectors (bit-exact ints/bitmaps/IEEE ops; 1e-6 rel for libm + sums)."""
     check_golden(gpu, exact_floats=False)
+
+
+# ---------------------------------------------------------------- vectors_v2: hour + the List<Int64> functions
+def check_golden_v2(api):
+    """Everything in vectors_v2.npz is integer / index / bitmap work: bit-exact for the oracle and the HIP path alike."""
+    g = np.load(os.path.join(GOLDEN, "vectors_v2.npz"))
+    valid = g["hour_valid"]
+    for unit, code in [(A.TIME_SECOND, "s"), (A.TIME_MILLISECOND, "ms"), (A.TIME_MICROSECOND, "us"), (A.TIME_NANOSECOND, "ns")]:
+        r = api.hour([A.HostArray.from_numpy(g[f"hour_{code}_in"], valid)], unit)[0]
+        assert r.dtype == A.I32 and np.array_equal(r.valid_mask(), valid), code
+        assert np.array_equal(r.to_numpy()[valid], g[f"hour_{code}_out"][valid]), code
+    r = api.hour([A.HostArray.from_numpy(g["hour_time32_in"])], A.TIME_SECOND)[0]
+    assert np.array_equal(r.to_numpy(), g["hour_time32_out"])
+
+    def load_list(name):
+        o, v, ok = g[name + "_offsets"], g[name + "_values"], g[name + "_valid"]
+        return A.HostList.from_lists([v[o[i]:o[i + 1]].tolist() if ok[i] else None for i in range(len(ok))], A.I64)
+
+    la, lb = load_list("la"), load_list("lb")
+    c = api.list_contains(la, 2)
+    assert np.array_equal(c.valid_mask(), g["contains_valid"])
+    assert np.array_equal(c.to_numpy()[g["contains_valid"]], g["contains_values"][g["contains_valid"]])
+    assert np.array_equal(api.list_position(la, 2).to_numpy(), g["position_values"])
+    for nm, want_max in (("max", True), ("min", False)):
+        m = api.list_extreme(la, want_max)
+        assert np.array_equal(m.valid_mask(), g[nm + "_valid"]) and np.array_equal(m.to_numpy()[g[nm + "_valid"]], g[nm + "_values"][g[nm + "_valid"]]), nm
+    assert np.array_equal(api.list_sort(la).to_numpy(), g["sort_values"])
+    for op in ("remove", "distinct", "except", "intersect", "union", "repeat"):
+        two = op in ("except", "intersect", "union")
+        offs, vals = api.list_remove(la, 2) if op == "remove" else api.list_set(op, la, lb if two else None, count=3)
+        assert np.array_equal(offs.to_numpy(), g[op + "_offsets"]), op
+        assert vals.length == len(g[op + "_values"]) and np.array_equal(vals.to_numpy()[:vals.length], g[op + "_values"]), op
+
+
+def test_oracle_reproduces_golden_vectors_v2(ora):
+    check_golden_v2(ora)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_vectors_v2(gpu):
+    check_golden_v2(gpu)
