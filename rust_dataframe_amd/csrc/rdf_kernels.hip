@@ -305,24 +305,24 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const FilterArgs a) {
     __shared__ int wave_cnt[2][kBlock / 64];
     const int lane = threadIdx.x & 63;
     const int wave = wave_id();
-    // per-wave null counters per column, flushed once per (column, chunk) — not once per tile
-    uint32_t nullacc[kCompactCols];
-#pragma unroll
-    for (int k = 0; k < kCompactCols; ++k) nullacc[k] = 0;
+    // per-wave null counters per column (in LDS: the kernel has no registers to spare), flushed once per
+    // (column, chunk) — not once per tile
+    __shared__ uint32_t nullacc[kBlock / 64][kCompactCols];
+    if (lane < kCompactCols) nullacc[wave][lane] = 0;
+    __builtin_amdgcn_wave_barrier();
     int64_t cur_chunk = -1;
     int parity = 0;
     for (int64_t tile = blockIdx.x; tile < a.t.ntiles; tile += gridDim.x, parity ^= 1) {
         int64_t c, r0, clen;
         locate_tile<kWW>(a.t, tile, c, r0, clen);
+        // where this tile's kept rows start in the chunk's output: asked for before the mask words are waited on
+        const int64_t out_base = a.tile_scan[tile] - a.tile_scan[a.t.chunk_tile_start[c]];
         if (c != cur_chunk) {
-            if (cur_chunk >= 0 && lane == 0) {
-#pragma unroll
-                for (int k = 0; k < kCompactCols; ++k)
-                    if (k < a.ncols && nullacc[k]) {
-                        atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)k * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[k]);
-                        nullacc[k] = 0;
-                    }
+            if (cur_chunk >= 0 && lane < a.ncols && nullacc[wave][lane]) {
+                atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)lane * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[wave][lane]);
+                nullacc[wave][lane] = 0;
             }
+            __builtin_amdgcn_wave_barrier();
             cur_chunk = c;
         }
         const int64_t rw = r0 + (int64_t)wave * (kWW * 64);
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const FilterArgs a) {
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) if (w < wave) wave_base += wave_cnt[parity][w];
         if (cnt > 0) {
-            const int64_t wave_out = a.tile_scan[tile] - a.tile_scan[a.t.chunk_tile_start[c]] + wave_base;
+            const int64_t wave_out = out_base + wave_base;
 #pragma unroll 1
             for (int k = 0; k < a.ncols; ++k) {
                 const DevChunkCol col = a.cols[(int64_t)k * a.t.nchunks + c];
@@ -348,18 +348,13 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const FilterArgs a) {
                 else if (es == 4) compact_wave<uint32_t, kWW>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
                 else if (es == 2) compact_wave<uint16_t, kWW>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
                 else compact_wave<uint8_t, kWW>(col, oc, rw, clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
-#pragma unroll
-                for (int kk = 0; kk < kCompactCols; ++kk)
-                    if (kk == k) nullacc[kk] += nn;
+                if (lane == 0 && nn) nullacc[wave][k] += nn;
             }
         }
     }
-    if (cur_chunk >= 0 && lane == 0) {
-#pragma unroll
-        for (int k = 0; k < kCompactCols; ++k)
-            if (k < a.ncols && nullacc[k])
-                atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)k * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[k]);
-    }
+    __builtin_amdgcn_wave_barrier();
+    if (cur_chunk >= 0 && lane < a.ncols && nullacc[wave][lane])
+        atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)lane * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[wave][lane]);
 }
 
 // ------------------------------------------------------------------------------------------------
