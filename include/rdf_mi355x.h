@@ -388,7 +388,8 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * "vec_bitmap" (bitmap words through the vector / scalar memory path), "gb_partition" (hash GROUP BY above 1024
  * groups: 1 = single scatter pass + LDS tables, default; 2 = radix-sort partitioning; 0 = one table in HBM),
  * "gb_debug" (1 / 2: ablations of the aggregate / scatter pass, results invalid; 3: force the skew variant),
- * "filter_tile" (0: compaction tile from the mean chunk length; 1024 / 4096 force one). */
+ * "filter_tile" (0: compaction tile from the mean chunk length; 1024 / 4096 force one), "filter_one" (one-chunk
+ * compaction kernel with kernel-argument descriptors, default on). */
 rdf_status rdf_set_option(const char* name, int64_t value);
 /* Number of program shapes with a specialised kernel. */
 int32_t    rdf_spec_catalog_size(void);

@@ -45,6 +45,7 @@ struct Ctx {
     bool   opt_spec = true;        // specialised straight-line kernels (rdf_spec.hip)
     bool   opt_fast_filter = true; // filter_agg_f64_kernel (handles 8-byte-misaligned columns)
     bool   opt_vec_bitmap = true;  // bitmap words via vector loads (default) instead of scalar loads (spec kernels)
+    bool   opt_filter_one = true;   // one-chunk compaction kernel with its descriptors in the kernel arguments (A/B)
     int    opt_filter_tile = 0;     // 0: compaction tile chosen from the mean chunk length; 1024 / 4096 force one (A/B)
     int    opt_gb_debug = 0;        // ablations of the partitioned GROUP BY (tools/bench_kernels.py): 1 = aggregate without LDS work, 2 = scatter without stores
     int    opt_gb_partition = 1;    // high-cardinality GROUP BY: 1 = single scatter pass + LDS tables (default), 2 = the radix-sort based two-pass variant, 0 = HBM atomics // bitmap words via vector loads instead of scalar loads (spec kernels)
@@ -1719,6 +1720,23 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
     {
         KernelTimer kt;
         for (int g = 0; g < ncols; g += kMaxFilterCols) {  // ranks are recomputed per group of columns (1 bit/row)
+            if (nchunks == 1 && fp.tile_rows == kFilterTile && ctx.opt_filter_one) {   // one long chunk: descriptors in the kernel arguments
+                FilterOneArgs oa;
+                memset(&oa, 0, sizeof oa);
+                oa.mask = fp.in.dev[0];
+                oa.clen = fp.clen[0];
+                oa.ntiles = fp.ntiles;
+                oa.tile_scan = fp.d_scan;
+                oa.out_null_counts = d_nullc + (size_t)g;
+                oa.ncols = ncols - g < kMaxFilterCols ? ncols - g : kMaxFilterCols;
+                for (int k = 0; k < oa.ncols; ++k) {
+                    oa.esize[k] = dtype_size(cols[g + k].dtype);
+                    oa.cols[k] = fp.in.dev[(size_t)(1 + g + k)];
+                    oa.outs[k] = dev_outs[(size_t)(g + k)];
+                }
+                HIP_TRY(launch_compact_one(oa, ctx.stream));
+                continue;
+            }
             FilterArgs fa;
             memset(&fa, 0, sizeof fa);
             fa.t = fp.mt;
@@ -2984,6 +3002,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "gb_partition") == 0) g_ctx.opt_gb_partition = (int)value;
     else if (strcmp(name, "gb_debug") == 0) g_ctx.opt_gb_debug = (int)value;
     else if (strcmp(name, "filter_tile") == 0) g_ctx.opt_filter_tile = (int)value;
+    else if (strcmp(name, "filter_one") == 0) g_ctx.opt_filter_one = value != 0;
     else return fail(RDF_INVALID_ARGUMENT, "unknown option %s", name);
     return RDF_OK;
 }

@@ -156,6 +156,20 @@ struct FilterArgs {
     int32_t            esize[kMaxFilterCols];
 };
 
+// Compaction of a frame held in ONE chunk (the long-column case): every descriptor travels in the kernel arguments, so no
+// table is read between the data loads of a tile.
+struct FilterOneArgs {
+    DevChunkCol        mask;
+    int64_t            clen, ntiles;
+    const int64_t*     tile_scan;        // [ntiles + 1]
+    int64_t*           out_null_counts;  // [ncols]
+    int32_t            ncols;
+    int32_t            esize[kMaxFilterCols];
+    DevChunkCol        cols[kMaxFilterCols];
+    DevOutChunk        outs[kMaxFilterCols];
+};
+hipError_t launch_compact_one(const FilterOneArgs& a, hipStream_t s);   // kFilterTile-row tiles
+
 // Stable LSD radix sort of (key, row index) pairs, 8 bits per pass (DataFrame::sort -> lexsort_to_indices).
 constexpr int kSortItems = 8;                       // items per thread per tile
 constexpr int kSortTile = kBlock * kSortItems;      // 2048 items per tile

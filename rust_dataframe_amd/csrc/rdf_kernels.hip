@@ -357,6 +357,51 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const FilterArgs a) {
         atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)lane * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[wave][lane]);
 }
 
+// The same for a frame in one chunk, descriptors in the kernel arguments (FilterOneArgs): the per-tile chain is
+// mask words -> barrier -> values -> store, without the chunk lookup and the two descriptor-table reads in between.
+template <int ES>
+__global__ __launch_bounds__(kBlock) void compact_one_kernel(const FilterOneArgs a) {
+    constexpr int kWW = 16;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[kBlock / 64][kWW * 64 * 8];
+    __shared__ uint8_t vstage[kBlock / 64][kWW * 64];
+    __shared__ int wave_cnt[2][kBlock / 64];
+    __shared__ uint32_t nullacc[kBlock / 64][kCompactCols];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id();
+    if (lane < kCompactCols) nullacc[wave][lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    int parity = 0;
+    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, parity ^= 1) {
+        const int64_t out_base = a.tile_scan[tile];
+        const int64_t rw = tile * filter_tile_rows<kWW>() + (int64_t)wave * (kWW * 64);
+        uint64_t kw[kWW];
+        keep_words<kWW>(a.mask, rw, a.clen, kw);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < kWW; ++i) cnt += __popcll(kw[i]);
+        if (lane == 0) wave_cnt[parity][wave] = cnt;
+        __syncthreads();
+        int wave_base = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) if (w < wave) wave_base += wave_cnt[parity][w];
+        if (cnt > 0) {
+            const int64_t wave_out = out_base + wave_base;
+#pragma unroll 1
+            for (int k = 0; k < a.ncols; ++k) {
+                uint32_t nn = 0;
+                const int es = ES ? ES : a.esize[k];
+                if (es == 8) compact_wave<uint64_t, kWW>(a.cols[k], a.outs[k], rw, a.clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+                else if (es == 4) compact_wave<uint32_t, kWW>(a.cols[k], a.outs[k], rw, a.clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+                else if (es == 2) compact_wave<uint16_t, kWW>(a.cols[k], a.outs[k], rw, a.clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+                else compact_wave<uint8_t, kWW>(a.cols[k], a.outs[k], rw, a.clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+                if (lane == 0 && nn) nullacc[wave][k] += nn;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < a.ncols && nullacc[wave][lane]) atomicAdd((unsigned long long*)&a.out_null_counts[lane], (unsigned long long)nullacc[wave][lane]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // take: out[j] = concat(chunks)[idx[j]] without materialising the concat.
 
@@ -1560,6 +1605,21 @@ hipError_t launch_compact(const FilterArgs& a, int tile_rows, hipStream_t s) {
     }
     if (tile_rows == kFilterTileSmall) { RDF_COMPACT_LAUNCH(4) } else { RDF_COMPACT_LAUNCH(16) }
 #undef RDF_COMPACT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_one(const FilterOneArgs& a, hipStream_t s) {
+    int64_t grid = a.ntiles < (int64_t)eval_grid_limit() ? a.ntiles : (int64_t)eval_grid_limit();
+    if (grid <= 0) return hipSuccess;
+    int es = a.esize[0];
+    for (int k = 1; k < a.ncols; ++k) if (a.esize[k] != es) es = 0;
+    switch (es) {
+        case 8: hipLaunchKernelGGL((compact_one_kernel<8>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((compact_one_kernel<4>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((compact_one_kernel<2>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((compact_one_kernel<1>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
+        default: hipLaunchKernelGGL((compact_one_kernel<0>), dim3((unsigned)grid), dim3(kBlock), 0, s, a); break;
+    }
     return hipGetLastError();
 }
 

@@ -162,6 +162,11 @@ def main():
     report("filter_count", n / 8.0, lambda: api.filter_count([m]))
     report("filter_1col", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
     report("filter_2col", (16 + 16 * sel + 0.25) * n, lambda: api.filter_columns([[X], [K]], [m], [[of], [ok2]]))
+    for fo in (0, 1, 0, 1):   # A/B: the one-chunk kernel with its descriptors in the kernel arguments (1, default) vs the table-driven one
+        lib.set_option("filter_one", fo)
+        report(f"filter_1col_one_chunk_kernel_{fo}", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
+        report(f"filter_2col_one_chunk_kernel_{fo}", (16 + 16 * sel + 0.25) * n, lambda: api.filter_columns([[X], [K]], [m], [[of], [ok2]]))
+    lib.set_option("filter_one", 1)
     for ft in (1024, 4096):   # A/B of the two compaction tile sizes on one long chunk (auto picks 4096)
         lib.set_option("filter_tile", ft)
         report(f"filter_1col_tile_{ft}", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
