@@ -412,6 +412,7 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const TakeArgs a) {
     int nulls = 0;
     const int64_t nwaves_total = (a.n + 63) >> 6;
     const double inv = chunk_lookup_scale(a.chunk_row_start, a.nchunks);
+    const DevChunkCol first = a.chunks[0];   // a one-chunk column reads its descriptor once, not per element ahead of the gather
     for (int64_t wv = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); wv < nwaves_total; wv += (int64_t)gridDim.x * (kBlock / 64)) {
         const int64_t j = wv * 64 + lane;
         const bool inr = j < a.n;
@@ -425,9 +426,14 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const TakeArgs a) {
             const uint64_t ix = (uint64_t)as_global<IDX>(a.indices.values)[a.indices.offset + j];
             if (ix >= (uint64_t)a.total_rows) { err |= 2u; valid = false; }
             else {
-                const int64_t c = a.nchunks > 1 ? find_chunk_row(a.chunk_row_start, a.nchunks, (int64_t)ix, inv) : 0;
-                const DevChunkCol cc = a.chunks[c];
-                const int64_t e = cc.offset + (int64_t)ix - a.chunk_row_start[c];
+                int64_t c = 0, start = 0;
+                DevChunkCol cc = first;
+                if (a.nchunks > 1) {
+                    c = find_chunk_row(a.chunk_row_start, a.nchunks, (int64_t)ix, inv);
+                    cc = a.chunks[c];
+                    start = a.chunk_row_start[c];
+                }
+                const int64_t e = cc.offset + (int64_t)ix - start;
                 v = as_global<T>(cc.values)[e];
                 if (cc.validity) valid = (cc.validity[e >> 3] >> (e & 7)) & 1;
             }
@@ -469,11 +475,17 @@ __device__ __forceinline__ uint64_t sort_key_bits(const DevChunkCol& cc, int dt,
 __global__ __launch_bounds__(kBlock) void sort_keys_kernel(const SortKeyArgs a, uint64_t width_mask) {
     uint64_t kmin = ~0ull, kmax = 0;
     const double inv = chunk_lookup_scale(a.chunk_row_start, a.nchunks);
+    const DevChunkCol first = a.chunks[0];
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
         const int64_t row = a.idx ? (int64_t)a.idx[i] : i;
-        const int64_t c = a.nchunks == 1 ? 0 : find_chunk_row(a.chunk_row_start, a.nchunks, row, inv);
-        const DevChunkCol cc = a.chunks[c];
-        const int64_t e = cc.offset + row - a.chunk_row_start[c];
+        int64_t start = 0;
+        DevChunkCol cc = first;
+        if (a.nchunks > 1) {
+            const int64_t c = find_chunk_row(a.chunk_row_start, a.nchunks, row, inv);
+            cc = a.chunks[c];
+            start = a.chunk_row_start[c];
+        }
+        const int64_t e = cc.offset + row - start;
         uint64_t k = sort_key_bits(cc, a.dtype, e);
         if (a.descending) k = ~k & width_mask;
         bool isnull = false;
