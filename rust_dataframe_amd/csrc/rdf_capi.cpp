@@ -1601,7 +1601,8 @@ rdf_status filter_prepare(FilterPrep& fp, const rdf_array* cols, int ncols, cons
     RDF_TRY(arena_alloc(sizeof(int64_t) * (2 * (size_t)fp.ntiles + 2 + (size_t)scan_scratch_words(fp.ntiles)), &p));
     fp.d_counts = (int64_t*)p;
     fp.d_scan = fp.d_counts + fp.ntiles;
-    HIP_TRY(launch_mask_count(fp.mt, fp.tile_rows, fp.d_counts, ctx.stream));
+    if (nchunks == 1 && fp.tile_rows == kFilterTile && ctx.opt_filter_one) HIP_TRY(launch_mask_count_one(fp.in.dev[0], fp.clen[0], fp.ntiles, fp.d_counts, ctx.stream));
+    else HIP_TRY(launch_mask_count(fp.mt, fp.tile_rows, fp.d_counts, ctx.stream));
     HIP_TRY(launch_scan(fp.d_counts, fp.d_scan, fp.ntiles, fp.d_scan + fp.ntiles + 1, ctx.stream));
 
     // per-chunk totals = scan[tile_start[c+1]] - scan[tile_start[c]]: fetch the nchunks+1 boundary values

@@ -169,6 +169,7 @@ struct FilterOneArgs {
     DevOutChunk        outs[kMaxFilterCols];
 };
 hipError_t launch_compact_one(const FilterOneArgs& a, hipStream_t s);   // kFilterTile-row tiles
+hipError_t launch_mask_count_one(const DevChunkCol& mask, int64_t clen, int64_t ntiles, int64_t* tile_counts, hipStream_t s);
 
 // Stable LSD radix sort of (key, row index) pairs, 8 bits per pass (DataFrame::sort -> lexsort_to_indices).
 constexpr int kSortItems = 8;                       // items per thread per tile

@@ -187,6 +187,24 @@ __global__ __launch_bounds__(kBlock) void mask_count_kernel(const MaskTables t, 
     }
 }
 
+// The same for a mask held in one chunk: its descriptor and length travel in the kernel arguments.
+__global__ __launch_bounds__(kBlock) void mask_count_one_kernel(const DevChunkCol mask, int64_t clen, int64_t ntiles, int64_t* tile_counts) {
+    constexpr int kWW = 16;
+    __shared__ int wave_cnt[kBlock / 64];
+    const int wave = wave_id();
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint64_t kw[kWW];
+        keep_words<kWW>(mask, tile * filter_tile_rows<kWW>() + (int64_t)wave * (kWW * 64), clen, kw);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < kWW; ++i) cnt += __popcll(kw[i]);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) wave_cnt[wave] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_counts[tile] = (int64_t)wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    }
+}
+
 // Exclusive scan of n int64 counts into scan[0..n] (scan[n] = total), hierarchical: every block scans a
 // 4096-entry segment (4 consecutive entries per thread: coalesced 32-byte reads), one block scans the
 // segment totals, a third pass adds the segment offsets.  (A single-block scan of the 48 828 tile counts
@@ -1585,6 +1603,11 @@ hipError_t launch_filter_agg_f64(const FilterAggF64Args& a, int cmp_op, int grid
     return hipGetLastError();
 }
 
+hipError_t launch_mask_count_one(const DevChunkCol& mask, int64_t clen, int64_t ntiles, int64_t* tile_counts, hipStream_t s) {
+    const int64_t grid = ntiles < (int64_t)eval_grid_limit() ? ntiles : (int64_t)eval_grid_limit();
+    if (grid > 0) hipLaunchKernelGGL(mask_count_one_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, mask, clen, ntiles, tile_counts);
+    return hipGetLastError();
+}
 hipError_t launch_mask_count(const MaskTables& t, int tile_rows, int64_t* tile_counts, hipStream_t s) {
     int64_t grid = t.ntiles < (int64_t)eval_grid_limit() ? t.ntiles : (int64_t)eval_grid_limit();
     if (grid > 0) {
