@@ -242,6 +242,29 @@ def test_filter_columns_one_pass(gpu, ora):
         assert_chunks_match(got[k], exp[k], exact=True, what=f"column {k}")
 
 
+@pytest.mark.parametrize("lens", [[9000], [5000, 4097], [1024] * 9 + [100]])
+def test_filter_wide_frames_every_kernel_variant(gpu, ora, lens):
+    """11 columns (two launches of <= 8 columns) of mixed and of equal element sizes through the three compaction paths:
+    one long chunk (descriptors in the kernel arguments), long chunks (4096-row tiles), reader batches (1024-row tiles)."""
+    rng = np.random.default_rng(4000 + len(lens))
+    for dts in ([A.F64, A.I64, A.I32, A.U8, A.F32, A.I16, A.U64, A.F64, A.I8, A.U16, A.I64], [A.F64] * 6 + [A.I64] * 5):
+        cols = [make_chunks(rng, dt, lens, 0.2 if k % 3 == 0 else 0.0, k % 4) for k, dt in enumerate(dts)]
+        e = A.Expr()
+        root = e.op("gt", e.col(0), e.scalar(0.1))
+        mask = ora.predicate(e, root, cols)
+        got, exp = gpu.filter_columns(cols, mask), ora.filter_columns(cols, mask)
+        for k in range(len(cols)):
+            assert_chunks_match(got[k], exp[k], exact=True, what=f"lens={lens} column {k} dtype={dts[k]}")
+        from rust_dataframe_amd import lib
+        lib.set_option("filter_one", 0)   # the table-driven kernels on the same input
+        try:
+            got = gpu.filter_columns(cols, mask)
+        finally:
+            lib.set_option("filter_one", 1)
+        for k in range(len(cols)):
+            assert_chunks_match(got[k], exp[k], exact=True, what=f"table-driven, lens={lens} column {k}")
+
+
 @pytest.mark.parametrize("dtype", NUMERIC)
 @pytest.mark.parametrize("idx_dtype", [A.U32, A.U64])
 def test_take(gpu, ora, dtype, idx_dtype):
