@@ -16,6 +16,7 @@
 // Where the reference materialises one DataFrame per plan step, Evaluate::evaluate here FUSES maximal
 // runs of Calculate / Filter / aggregate steps into single passes over HBM (rdf_pipeline).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -1453,6 +1454,7 @@ class Evaluate {
         for (auto& a : kc.data().chunks()) { keys.push_back(a->view()); key_nulls |= a->validity != nullptr; }
         const int64_t nrows = (int64_t)f.num_rows();
         std::vector<Column> out_cols;
+        if (dense_group_aggregate(f, kc, t, out_cols)) { reset(DataFrame::from_columns(out_cols)); return; }
         auto one = [&](AF fn, const std::string& col) {
             if (fn != AF::Sum && fn != AF::Count && fn != AF::Avg) throw DataFrameError(DataFrameError::ComputeError, "Aggregation not yet supported");
             const Column& vc = f.column_by_name(col);
@@ -1503,6 +1505,92 @@ class Evaluate {
             for (auto& c : a.columns) one(a.function, c);
         if (out_cols.empty()) throw DataFrameError(DataFrameError::ComputeError, "GroupAggregate without aggregations");
         reset(DataFrame::from_columns(out_cols));
+    }
+
+    // GroupAggregate over a SMALL DENSE key domain (dictionary codes, flags: TPC-H Q1's shape): every aggregation of the step in
+    // ONE pass over the rows through rdf_group_pipeline (group id = key - min(key)), instead of one hash GROUP BY per
+    // aggregation.  Same output as the hash path: groups in ascending key order, the NULL key last.  -> false when the
+    // domain or the number of value columns does not fit the dense kernel (RDF_MAX_GROUP_SLOTS / RDF_MAX_GROUP_VALUES).
+    static bool dense_group_aggregate(const DataFrame& f, const Column& kc, const plan::Transformation& t, std::vector<Column>& out_cols) {
+        using AF = plan::AggregateFunction;
+        const std::vector<rdf_array> kv = kc.data().views();
+        unsigned char lo[8] = {0}, hi[8] = {0};
+        int32_t some_lo = 0, some_hi = 0;
+        check(rdf_min(kv.data(), (int64_t)kv.size(), lo, &some_lo));
+        check(rdf_max(kv.data(), (int64_t)kv.size(), hi, &some_hi));
+        if (!some_lo || !some_hi) return false;   // no non-NULL key at all
+        auto as_i64 = [&](const unsigned char* p, bool& ok) -> int64_t {
+            ok = true;
+            switch (kc.data_type()) {
+                case DataType::Int8: { int8_t v; std::memcpy(&v, p, 1); return v; }
+                case DataType::Int16: { int16_t v; std::memcpy(&v, p, 2); return v; }
+                case DataType::Int32: { int32_t v; std::memcpy(&v, p, 4); return v; }
+                case DataType::Int64: { int64_t v; std::memcpy(&v, p, 8); return v; }
+                case DataType::UInt8: { uint8_t v; std::memcpy(&v, p, 1); return v; }
+                case DataType::UInt16: { uint16_t v; std::memcpy(&v, p, 2); return v; }
+                case DataType::UInt32: { uint32_t v; std::memcpy(&v, p, 4); return v; }
+                default: { uint64_t v; std::memcpy(&v, p, 8); ok = v <= (uint64_t)INT64_MAX; return (int64_t)v; }
+            }
+        };
+        bool ok_lo = false, ok_hi = false;
+        const int64_t kmin = as_i64(lo, ok_lo), kmax = as_i64(hi, ok_hi);
+        if (!ok_lo || !ok_hi || (uint64_t)kmax - (uint64_t)kmin >= (uint64_t)RDF_MAX_GROUP_SLOTS) return false;
+        const int64_t domain = kmax - kmin + 1;
+        // the distinct value columns of the step (Sum / Count / Avg of one column share its per-group sum and count)
+        std::vector<std::string> vcols;
+        for (auto& a : t.aggregations) {
+            if (a.function != AF::Sum && a.function != AF::Count && a.function != AF::Avg) throw DataFrameError(DataFrameError::ComputeError, "Aggregation not yet supported");
+            for (auto& c : a.columns) {
+                const DataType vdt = f.column_by_name(c).data_type();
+                if (!(is_integer(vdt) || is_float(vdt))) throw DataFrameError(DataFrameError::ComputeError, "Aggregating column must be numeric");
+                if (std::find(vcols.begin(), vcols.end(), c) == vcols.end()) vcols.push_back(c);
+            }
+        }
+        if (vcols.empty()) return false;
+        if (vcols.size() > (size_t)RDF_MAX_GROUP_VALUES || (size_t)(domain + 1) * vcols.size() > (size_t)RDF_MAX_GROUP_SLOTS) return false;
+        Lowered low;
+        const std::string kname = kc.name();
+        const int group_root = low.add(Expr::make(RDF_OP_SUB, Expr::make(RDF_OP_CAST, Expr::col(kname), nullptr, RDF_I64), Expr::literal(Scalar((int64_t)kmin), RDF_I64)));
+        int32_t value_roots[RDF_MAX_GROUP_VALUES] = {0};
+        for (size_t v = 0; v < vcols.size(); ++v) value_roots[v] = low.add(Expr::col(vcols[v]));
+        std::vector<rdf_array> cols;
+        for (auto& cn : low.columns) for (auto& a : f.column_by_name(cn).data().chunks()) cols.push_back(a->view());
+        const size_t S = (size_t)domain + 1;
+        std::vector<rdf_group_result> res(S * vcols.size());
+        std::vector<int64_t> rows(S, 0);
+        check(rdf_group_pipeline(low.nodes.data(), (int32_t)low.nodes.size(), -1, group_root, (int32_t)domain, value_roots, (int32_t)vcols.size(),
+                                 cols.data(), (int32_t)low.columns.size(), (int64_t)f.num_chunks(), res.data(), rows.data()));
+        // groups that hold rows, ascending key, the NULL key (slot `domain`) last
+        std::vector<size_t> slots;
+        for (size_t g = 0; g < S; ++g) if (rows[g] > 0) slots.push_back(g);
+        const bool null_group = !slots.empty() && slots.back() == (size_t)domain;
+        std::vector<int64_t> keys;
+        std::vector<bool> kvalid;
+        for (size_t g : slots) { keys.push_back(g == (size_t)domain ? 0 : kmin + (int64_t)g); kvalid.push_back(g != (size_t)domain); }
+        const ArrayRef k64 = Array::from_vec<int64_t>(keys, null_group ? &kvalid : nullptr);
+        out_cols.push_back(Column::from_arrays(kc.data_type() == DataType::Int64 ? std::vector<ArrayRef>{k64} : ScalarFunctions::cast({k64}, kc.data_type()),
+                                               Field{kname, kc.data_type(), true}));
+        for (auto& a : t.aggregations)
+            for (auto& c : a.columns) {
+                const size_t v = (size_t)(std::find(vcols.begin(), vcols.end(), c) - vcols.begin());
+                const DataType vdt = f.column_by_name(c).data_type();
+                std::vector<double> fs;
+                std::vector<int64_t> is, cs;
+                for (size_t g : slots) { const rdf_group_result& r = res[v * S + g]; fs.push_back(r.sum_f64); is.push_back(r.sum_i64); cs.push_back(r.count); }
+                if (a.function == AF::Sum) {
+                    const ArrayRef sums = is_float(vdt) ? Array::from_vec<double>(fs) : Array::from_vec<int64_t>(is);
+                    const DataType sdt = is_float(vdt) ? DataType::Float64 : DataType::Int64;
+                    out_cols.push_back(Column::from_arrays(sdt == vdt ? std::vector<ArrayRef>{sums} : ScalarFunctions::cast({sums}, vdt), Field{"sum(" + c + ")", vdt, true}));
+                } else if (a.function == AF::Count) {
+                    out_cols.push_back(Column::from_arrays(ScalarFunctions::cast({Array::from_vec<int64_t>(cs)}, DataType::UInt32), Field{"count(" + c + ")", DataType::UInt32, true}));
+                } else {
+                    std::vector<double> m(slots.size());
+                    std::vector<bool> valid(slots.size());
+                    for (size_t r = 0; r < slots.size(); ++r) { valid[r] = cs[r] > 0; m[r] = cs[r] > 0 ? (is_float(vdt) ? fs[r] : (double)is[r]) / (double)cs[r] : 0.0; }
+                    out_cols.push_back(Column::from_arrays({Array::from_vec(m, &valid)}, Field{"avg(" + c + ")", DataType::Float64, true}));
+                }
+            }
+        return true;
     }
 
     void step_aggregate(const plan::Transformation& t) {

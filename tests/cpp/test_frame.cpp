@@ -292,7 +292,9 @@ TEST(test_join_two_key_columns) {
 
 // GroupAggregate with a grouping column: the reference has only the schema (Dataset::try_aggregate) and panics on
 // execution (src/evaluation.rs:73); expectations are SQL semantics computed on the host.
-TEST(test_group_aggregate_by_key) {
+// `stride` spreads the 37 keys: 1 = a small dense domain (one fused rdf_group_pipeline pass for all aggregations),
+// 100003 = a sparse one (rdf_groupby_sum per aggregation); both must give the same frame
+static void group_aggregate_by_key(int32_t stride) {
     std::mt19937_64 rng(11);
     std::uniform_real_distribution<double> U(0.0, 1.0);
     const std::vector<size_t> lens{1024, 500, 2000};
@@ -302,7 +304,7 @@ TEST(test_group_aggregate_by_key) {
         std::vector<int32_t> k(n); std::vector<double> v(n); std::vector<int64_t> w(n);
         std::vector<bool> kvalid(n), vvalid(n);
         for (size_t i = 0; i < n; ++i) {
-            k[i] = (int32_t)(rng() % 37) - 5; v[i] = U(rng); w[i] = (int64_t)(rng() % 1000) - 500;
+            k[i] = ((int32_t)(rng() % 37) - 5) * stride; v[i] = U(rng); w[i] = (int64_t)(rng() % 1000) - 500;
             kvalid[i] = U(rng) > 0.02; vvalid[i] = U(rng) > 0.1;
         }
         kch.push_back(Array::from_vec(k, &kvalid)); vch.push_back(Array::from_vec(v, &vvalid)); wch.push_back(Array::from_vec(w));
@@ -352,6 +354,8 @@ TEST(test_group_aggregate_by_key) {
     CHECK_THROWS(LazyFrame::read(df).aggregate({"v"}, {{AF::Sum, {"w"}}}).evaluate());
     CHECK_THROWS(LazyFrame::read(df).aggregate({"k"}, {{AF::Max, {"v"}}}).evaluate());
 }
+TEST(test_group_aggregate_by_key) { group_aggregate_by_key(1); }
+TEST(test_group_aggregate_by_sparse_key) { group_aggregate_by_key(100003); }
 
 // DataFrame::from_arrow (src/dataframe.rs:391-407) on the committed pyarrow-written fixture: schema, chunking (one chunk
 // per record batch), every value and validity bit, then the device path over the loaded columns.
