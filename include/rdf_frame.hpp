@@ -1445,7 +1445,8 @@ class Evaluate {
     // through rdf_groupby_sum; rows of the result are ordered by key (NULL group last) so every aggregate column lines up.
     void step_group_aggregate(const plan::Transformation& t) {
         using AF = plan::AggregateFunction;
-        if (t.names.size() != 1) throw DataFrameError(DataFrameError::ComputeError, "GroupAggregate: exactly one grouping column is supported");
+        if (fused_dense_group_aggregate(t)) return;   // small dense key domain(s): filter + expressions + grouping in one pass
+        if (t.names.size() != 1) throw DataFrameError(DataFrameError::ComputeError, "GroupAggregate: several grouping columns are supported over small dense NULL-free integer domains only");
         DataFrame f = flush();   // lazy columns materialised, pending filters applied
         const Column& kc = f.column_by_name(t.names[0]);
         if (!is_integer(kc.data_type())) throw DataFrameError(DataFrameError::ComputeError, "GroupAggregate: the grouping column must be an integer column");
@@ -1507,90 +1508,142 @@ class Evaluate {
         reset(DataFrame::from_columns(out_cols));
     }
 
-    // GroupAggregate over a SMALL DENSE key domain (dictionary codes, flags: TPC-H Q1's shape): every aggregation of the step in
-    // ONE pass over the rows through rdf_group_pipeline (group id = key - min(key)), instead of one hash GROUP BY per
-    // aggregation.  Same output as the hash path: groups in ascending key order, the NULL key last.  -> false when the
-    // domain or the number of value columns does not fit the dense kernel (RDF_MAX_GROUP_SLOTS / RDF_MAX_GROUP_VALUES).
-    static bool dense_group_aggregate(const DataFrame& f, const Column& kc, const plan::Transformation& t, std::vector<Column>& out_cols) {
+    // GroupAggregate over a SMALL DENSE key domain (dictionary codes, flags: TPC-H Q1's returnflag x linestatus): the pending
+    // filter, the lazy value expressions, the grouping and every aggregation of the step in ONE pass over the rows through
+    // rdf_group_pipeline (group id = mixed-radix number of the keys' offsets from their minima), instead of materialising the
+    // computed columns and running one hash GROUP BY per aggregation.  Same output as the hash path: groups in ascending key
+    // order, the NULL key (single grouping column only) last.  -> false when the shape does not fit the dense kernel
+    // (RDF_MAX_GROUP_SLOTS / RDF_MAX_GROUP_VALUES, NULLs in one of several grouping columns, a non-integer key).
+    struct DenseKey { std::string column, out_name; DataType dtype; };               // `column`: its name in `frame`
+    struct DenseVal { plan::AggregateFunction fn; std::string name; DataType dtype; ExprRef e; };
+    static bool dense_groups(const DataFrame& frame, const std::vector<DenseKey>& keys, const ExprRef& filter, const std::vector<DenseVal>& vals,
+                             std::vector<Column>& out_cols) {
         using AF = plan::AggregateFunction;
-        const std::vector<rdf_array> kv = kc.data().views();
-        unsigned char lo[8] = {0}, hi[8] = {0};
-        int32_t some_lo = 0, some_hi = 0;
-        check(rdf_min(kv.data(), (int64_t)kv.size(), lo, &some_lo));
-        check(rdf_max(kv.data(), (int64_t)kv.size(), hi, &some_hi));
-        if (!some_lo || !some_hi) return false;   // no non-NULL key at all
-        auto as_i64 = [&](const unsigned char* p, bool& ok) -> int64_t {
-            ok = true;
-            switch (kc.data_type()) {
-                case DataType::Int8: { int8_t v; std::memcpy(&v, p, 1); return v; }
-                case DataType::Int16: { int16_t v; std::memcpy(&v, p, 2); return v; }
-                case DataType::Int32: { int32_t v; std::memcpy(&v, p, 4); return v; }
-                case DataType::Int64: { int64_t v; std::memcpy(&v, p, 8); return v; }
-                case DataType::UInt8: { uint8_t v; std::memcpy(&v, p, 1); return v; }
-                case DataType::UInt16: { uint16_t v; std::memcpy(&v, p, 2); return v; }
-                case DataType::UInt32: { uint32_t v; std::memcpy(&v, p, 4); return v; }
-                default: { uint64_t v; std::memcpy(&v, p, 8); ok = v <= (uint64_t)INT64_MAX; return (int64_t)v; }
-            }
-        };
-        bool ok_lo = false, ok_hi = false;
-        const int64_t kmin = as_i64(lo, ok_lo), kmax = as_i64(hi, ok_hi);
-        if (!ok_lo || !ok_hi || (uint64_t)kmax - (uint64_t)kmin >= (uint64_t)RDF_MAX_GROUP_SLOTS) return false;
-        const int64_t domain = kmax - kmin + 1;
-        // the distinct value columns of the step (Sum / Count / Avg of one column share its per-group sum and count)
-        std::vector<std::string> vcols;
-        for (auto& a : t.aggregations) {
-            if (a.function != AF::Sum && a.function != AF::Count && a.function != AF::Avg) throw DataFrameError(DataFrameError::ComputeError, "Aggregation not yet supported");
-            for (auto& c : a.columns) {
-                const DataType vdt = f.column_by_name(c).data_type();
-                if (!(is_integer(vdt) || is_float(vdt))) throw DataFrameError(DataFrameError::ComputeError, "Aggregating column must be numeric");
-                if (std::find(vcols.begin(), vcols.end(), c) == vcols.end()) vcols.push_back(c);
-            }
+        if (keys.empty() || vals.empty()) return false;
+        std::vector<int64_t> kmin(keys.size()), dom(keys.size());
+        uint64_t total = 1;
+        for (size_t i = 0; i < keys.size(); ++i) {
+            if (!is_integer(keys[i].dtype)) return false;
+            const Column& kc = frame.column_by_name(keys[i].column);
+            const std::vector<rdf_array> kv = kc.data().views();
+            if (keys.size() > 1) for (auto& a : kv) if (a.validity && a.null_count != 0) return false;   // NULLs would need one extra code per column
+            unsigned char lo[8] = {0}, hi[8] = {0};
+            int32_t some_lo = 0, some_hi = 0;
+            check(rdf_min(kv.data(), (int64_t)kv.size(), lo, &some_lo));
+            check(rdf_max(kv.data(), (int64_t)kv.size(), hi, &some_hi));
+            if (!some_lo || !some_hi) return false;   // no non-NULL key at all
+            auto as_i64 = [&](const unsigned char* p, bool& ok) -> int64_t {
+                ok = true;
+                switch (keys[i].dtype) {
+                    case DataType::Int8: { int8_t v; std::memcpy(&v, p, 1); return v; }
+                    case DataType::Int16: { int16_t v; std::memcpy(&v, p, 2); return v; }
+                    case DataType::Int32: { int32_t v; std::memcpy(&v, p, 4); return v; }
+                    case DataType::Int64: { int64_t v; std::memcpy(&v, p, 8); return v; }
+                    case DataType::UInt8: { uint8_t v; std::memcpy(&v, p, 1); return v; }
+                    case DataType::UInt16: { uint16_t v; std::memcpy(&v, p, 2); return v; }
+                    case DataType::UInt32: { uint32_t v; std::memcpy(&v, p, 4); return v; }
+                    default: { uint64_t v; std::memcpy(&v, p, 8); ok = v <= (uint64_t)INT64_MAX; return (int64_t)v; }
+                }
+            };
+            bool ok_lo = false, ok_hi = false;
+            const int64_t mn = as_i64(lo, ok_lo), mx = as_i64(hi, ok_hi);
+            if (!ok_lo || !ok_hi || (uint64_t)mx - (uint64_t)mn >= (uint64_t)RDF_MAX_GROUP_SLOTS) return false;
+            kmin[i] = mn;
+            dom[i] = mx - mn + 1;
+            total *= (uint64_t)dom[i];
+            if (total > (uint64_t)RDF_MAX_GROUP_SLOTS) return false;
         }
-        if (vcols.empty()) return false;
-        if (vcols.size() > (size_t)RDF_MAX_GROUP_VALUES || (size_t)(domain + 1) * vcols.size() > (size_t)RDF_MAX_GROUP_SLOTS) return false;
+        // the distinct value expressions of the step (Sum / Count / Avg of one column share its per-group sum and count)
+        std::vector<std::string> vnames;
+        std::vector<ExprRef> vexprs;
+        for (auto& v : vals) {
+            if (v.fn != AF::Sum && v.fn != AF::Count && v.fn != AF::Avg) throw DataFrameError(DataFrameError::ComputeError, "Aggregation not yet supported");
+            if (!(is_integer(v.dtype) || is_float(v.dtype))) throw DataFrameError(DataFrameError::ComputeError, "Aggregating column must be numeric");
+            if (std::find(vnames.begin(), vnames.end(), v.name) == vnames.end()) { vnames.push_back(v.name); vexprs.push_back(v.e); }
+        }
+        if (vnames.size() > (size_t)RDF_MAX_GROUP_VALUES || (size_t)(total + 1) * vnames.size() > (size_t)RDF_MAX_GROUP_SLOTS) return false;
         Lowered low;
-        const std::string kname = kc.name();
-        const int group_root = low.add(Expr::make(RDF_OP_SUB, Expr::make(RDF_OP_CAST, Expr::col(kname), nullptr, RDF_I64), Expr::literal(Scalar((int64_t)kmin), RDF_I64)));
+        const int filter_root = filter ? low.add(filter) : -1;
+        ExprRef gid;
+        for (size_t i = 0; i < keys.size(); ++i) {
+            ExprRef d = Expr::make(RDF_OP_SUB, Expr::make(RDF_OP_CAST, Expr::col(keys[i].column), nullptr, RDF_I64), Expr::literal(Scalar((int64_t)kmin[i]), RDF_I64));
+            gid = i == 0 ? d : Expr::make(RDF_OP_ADD, Expr::make(RDF_OP_MUL, gid, Expr::literal(Scalar((int64_t)dom[i]), RDF_I64)), d);
+        }
+        const int group_root = low.add(gid);
         int32_t value_roots[RDF_MAX_GROUP_VALUES] = {0};
-        for (size_t v = 0; v < vcols.size(); ++v) value_roots[v] = low.add(Expr::col(vcols[v]));
+        for (size_t v = 0; v < vexprs.size(); ++v) value_roots[v] = low.add(vexprs[v]);
         std::vector<rdf_array> cols;
-        for (auto& cn : low.columns) for (auto& a : f.column_by_name(cn).data().chunks()) cols.push_back(a->view());
-        const size_t S = (size_t)domain + 1;
-        std::vector<rdf_group_result> res(S * vcols.size());
+        for (auto& cn : low.columns) for (auto& a : frame.column_by_name(cn).data().chunks()) cols.push_back(a->view());
+        const size_t S = (size_t)total + 1;
+        std::vector<rdf_group_result> res(S * vnames.size());
         std::vector<int64_t> rows(S, 0);
-        check(rdf_group_pipeline(low.nodes.data(), (int32_t)low.nodes.size(), -1, group_root, (int32_t)domain, value_roots, (int32_t)vcols.size(),
-                                 cols.data(), (int32_t)low.columns.size(), (int64_t)f.num_chunks(), res.data(), rows.data()));
-        // groups that hold rows, ascending key, the NULL key (slot `domain`) last
+        check(rdf_group_pipeline(low.nodes.data(), (int32_t)low.nodes.size(), filter_root, group_root, (int32_t)total, value_roots, (int32_t)vnames.size(),
+                                 cols.data(), (int32_t)low.columns.size(), (int64_t)frame.num_chunks(), res.data(), rows.data()));
+        // groups that hold rows, ascending (key 1, key 2, ..) = ascending slot, the NULL key (slot `total`) last
         std::vector<size_t> slots;
         for (size_t g = 0; g < S; ++g) if (rows[g] > 0) slots.push_back(g);
-        const bool null_group = !slots.empty() && slots.back() == (size_t)domain;
-        std::vector<int64_t> keys;
-        std::vector<bool> kvalid;
-        for (size_t g : slots) { keys.push_back(g == (size_t)domain ? 0 : kmin + (int64_t)g); kvalid.push_back(g != (size_t)domain); }
-        const ArrayRef k64 = Array::from_vec<int64_t>(keys, null_group ? &kvalid : nullptr);
-        out_cols.push_back(Column::from_arrays(kc.data_type() == DataType::Int64 ? std::vector<ArrayRef>{k64} : ScalarFunctions::cast({k64}, kc.data_type()),
-                                               Field{kname, kc.data_type(), true}));
+        const bool null_group = !slots.empty() && slots.back() == (size_t)total;
+        for (size_t i = 0; i < keys.size(); ++i) {
+            uint64_t below = 1;   // product of the domains of the keys after i
+            for (size_t j = i + 1; j < keys.size(); ++j) below *= (uint64_t)dom[j];
+            std::vector<int64_t> kvv;
+            std::vector<bool> kvalid;
+            for (size_t g : slots) {
+                const bool isnull = g == (size_t)total;
+                kvv.push_back(isnull ? 0 : kmin[i] + (int64_t)(((uint64_t)g / below) % (uint64_t)dom[i]));
+                kvalid.push_back(!isnull);
+            }
+            const ArrayRef k64 = Array::from_vec<int64_t>(kvv, null_group ? &kvalid : nullptr);
+            out_cols.push_back(Column::from_arrays(keys[i].dtype == DataType::Int64 ? std::vector<ArrayRef>{k64} : ScalarFunctions::cast({k64}, keys[i].dtype),
+                                                   Field{keys[i].out_name, keys[i].dtype, true}));
+        }
+        for (auto& val : vals) {
+            const size_t v = (size_t)(std::find(vnames.begin(), vnames.end(), val.name) - vnames.begin());
+            const DataType vdt = val.dtype;
+            std::vector<double> fs;
+            std::vector<int64_t> is, cs;
+            for (size_t g : slots) { const rdf_group_result& r = res[v * S + g]; fs.push_back(r.sum_f64); is.push_back(r.sum_i64); cs.push_back(r.count); }
+            if (val.fn == AF::Sum) {
+                const ArrayRef sums = is_float(vdt) ? Array::from_vec<double>(fs) : Array::from_vec<int64_t>(is);
+                const DataType sdt = is_float(vdt) ? DataType::Float64 : DataType::Int64;
+                out_cols.push_back(Column::from_arrays(sdt == vdt ? std::vector<ArrayRef>{sums} : ScalarFunctions::cast({sums}, vdt), Field{"sum(" + val.name + ")", vdt, true}));
+            } else if (val.fn == AF::Count) {
+                out_cols.push_back(Column::from_arrays(ScalarFunctions::cast({Array::from_vec<int64_t>(cs)}, DataType::UInt32), Field{"count(" + val.name + ")", DataType::UInt32, true}));
+            } else {
+                std::vector<double> m(slots.size());
+                std::vector<bool> valid(slots.size());
+                for (size_t r = 0; r < slots.size(); ++r) { valid[r] = cs[r] > 0; m[r] = cs[r] > 0 ? (is_float(vdt) ? fs[r] : (double)is[r]) / (double)cs[r] : 0.0; }
+                out_cols.push_back(Column::from_arrays({Array::from_vec(m, &valid)}, Field{"avg(" + val.name + ")", DataType::Float64, true}));
+            }
+        }
+        return true;
+    }
+    // the step as it stands in the lazy state: grouping columns that are columns of base_, the pending filter, lazy value expressions
+    bool fused_dense_group_aggregate(const plan::Transformation& t) {
+        if (t.names.empty() || t.names.size() > 4) return false;
+        std::vector<DenseKey> keys;
+        for (auto& n : t.names) {
+            Entry* e = find(n);
+            if (!e || e->def) return false;   // unknown (the caller reports it) or computed: not a column of base_
+            keys.push_back(DenseKey{e->source, n, e->dtype});
+        }
+        std::vector<DenseVal> vals;
         for (auto& a : t.aggregations)
             for (auto& c : a.columns) {
-                const size_t v = (size_t)(std::find(vcols.begin(), vcols.end(), c) - vcols.begin());
-                const DataType vdt = f.column_by_name(c).data_type();
-                std::vector<double> fs;
-                std::vector<int64_t> is, cs;
-                for (size_t g : slots) { const rdf_group_result& r = res[v * S + g]; fs.push_back(r.sum_f64); is.push_back(r.sum_i64); cs.push_back(r.count); }
-                if (a.function == AF::Sum) {
-                    const ArrayRef sums = is_float(vdt) ? Array::from_vec<double>(fs) : Array::from_vec<int64_t>(is);
-                    const DataType sdt = is_float(vdt) ? DataType::Float64 : DataType::Int64;
-                    out_cols.push_back(Column::from_arrays(sdt == vdt ? std::vector<ArrayRef>{sums} : ScalarFunctions::cast({sums}, vdt), Field{"sum(" + c + ")", vdt, true}));
-                } else if (a.function == AF::Count) {
-                    out_cols.push_back(Column::from_arrays(ScalarFunctions::cast({Array::from_vec<int64_t>(cs)}, DataType::UInt32), Field{"count(" + c + ")", DataType::UInt32, true}));
-                } else {
-                    std::vector<double> m(slots.size());
-                    std::vector<bool> valid(slots.size());
-                    for (size_t r = 0; r < slots.size(); ++r) { valid[r] = cs[r] > 0; m[r] = cs[r] > 0 ? (is_float(vdt) ? fs[r] : (double)is[r]) / (double)cs[r] : 0.0; }
-                    out_cols.push_back(Column::from_arrays({Array::from_vec(m, &valid)}, Field{"avg(" + c + ")", DataType::Float64, true}));
-                }
+                Entry* e = find(c);
+                if (!e) return false;
+                vals.push_back(DenseVal{a.function, c, e->dtype, ref(c)});
             }
+        std::vector<Column> out_cols;
+        if (!dense_groups(base_, keys, pending_, vals, out_cols)) return false;
+        reset(DataFrame::from_columns(out_cols));
         return true;
+    }
+    static bool dense_group_aggregate(const DataFrame& f, const Column& kc, const plan::Transformation& t, std::vector<Column>& out_cols) {
+        std::vector<DenseVal> vals;
+        for (auto& a : t.aggregations)
+            for (auto& c : a.columns) vals.push_back(DenseVal{a.function, c, f.column_by_name(c).data_type(), Expr::col(c)});
+        return dense_groups(f, {DenseKey{kc.name(), kc.name(), kc.data_type()}}, nullptr, vals, out_cols);
     }
 
     void step_aggregate(const plan::Transformation& t) {

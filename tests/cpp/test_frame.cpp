@@ -354,6 +354,64 @@ static void group_aggregate_by_key(int32_t stride) {
     CHECK_THROWS(LazyFrame::read(df).aggregate({"v"}, {{AF::Sum, {"w"}}}).evaluate());
     CHECK_THROWS(LazyFrame::read(df).aggregate({"k"}, {{AF::Max, {"v"}}}).evaluate());
 }
+// TPC-H Q1's shape through the lazy API (BASELINE.json config C5): filter -> two computed columns -> GROUP BY two
+// dictionary-coded columns with sums / average / count.  Everything runs as ONE fused pass (rdf_group_pipeline).
+TEST(test_group_aggregate_q1_shape_two_keys) {
+    std::mt19937_64 rng(23);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    const std::vector<size_t> lens{1024, 1024, 700};
+    std::vector<ArrayRef> fch, sch, qch, pch, dch, och, hch;
+    struct G { double qty = 0, price = 0, dp = 0; int64_t n = 0; };
+    std::map<std::pair<int, int>, G> exp;
+    for (size_t n : lens) {
+        std::vector<int8_t> fl(n), st(n); std::vector<double> q(n), pr(n), di(n), one(n, 1.0); std::vector<int32_t> sh(n);
+        std::vector<bool> qvalid(n);
+        for (size_t i = 0; i < n; ++i) {
+            fl[i] = (int8_t)(rng() % 3); st[i] = (int8_t)(rng() % 2);
+            q[i] = 1.0 + (double)(rng() % 50); pr[i] = 900.0 + 1000.0 * U(rng); di[i] = (double)(rng() % 11) / 100.0;
+            sh[i] = 8036 + (int32_t)(rng() % 2526); qvalid[i] = U(rng) > 0.05;
+            if (sh[i] > 10471) continue;
+            G& g = exp[{fl[i], st[i]}];
+            g.price += pr[i]; g.dp += pr[i] * (1.0 - di[i]);
+            if (qvalid[i]) { g.qty += q[i]; ++g.n; }
+        }
+        fch.push_back(Array::from_vec(fl)); sch.push_back(Array::from_vec(st)); qch.push_back(Array::from_vec(q, &qvalid)); pch.push_back(Array::from_vec(pr));
+        dch.push_back(Array::from_vec(di)); och.push_back(Array::from_vec(one)); hch.push_back(Array::from_vec(sh));
+    }
+    DataFrame df = DataFrame::from_columns({Column::from_arrays(fch, Field{"returnflag", DataType::Int8, false}), Column::from_arrays(sch, Field{"linestatus", DataType::Int8, false}),
+                                            Column::from_arrays(qch, Field{"quantity", DataType::Float64, true}), Column::from_arrays(pch, Field{"extendedprice", DataType::Float64, false}),
+                                            Column::from_arrays(dch, Field{"discount", DataType::Float64, false}), Column::from_arrays(och, Field{"one", DataType::Float64, false}),
+                                            Column::from_arrays(hch, Field{"shipdate", DataType::Int32, false})});
+    using AF = P::AggregateFunction;
+    DataFrame g = LazyFrame::read(df)
+                      .filter(BooleanFilter::le(BooleanFilter::column("shipdate"), BooleanFilter::scalar(Scalar((int32_t)10471))))
+                      .with_column("one_minus_discount", P::Function::Scalar_(P::ScalarFunction::Subtract), {"one", "discount"})
+                      .with_column("disc_price", P::Function::Scalar_(P::ScalarFunction::Multiply), {"extendedprice", "one_minus_discount"})
+                      .aggregate({"returnflag", "linestatus"}, {{AF::Sum, {"quantity", "extendedprice", "disc_price"}}, {AF::Avg, {"quantity"}}, {AF::Count, {"quantity"}}})
+                      .evaluate();
+    CHECK_EQ(g.num_columns(), 7u);
+    CHECK_EQ(g.schema().fields[0].name, std::string("returnflag"));
+    CHECK_EQ(g.schema().fields[1].name, std::string("linestatus"));
+    CHECK_EQ(g.schema().fields[4].name, std::string("sum(disc_price)"));
+    CHECK_EQ(g.schema().fields[5].name, std::string("avg(quantity)"));
+    CHECK_EQ(g.schema().fields[6].name, std::string("count(quantity)"));
+    CHECK_EQ((size_t)g.num_rows(), exp.size());
+    auto kf = host<int8_t>(g.column(0).data().chunk(0)), ks = host<int8_t>(g.column(1).data().chunk(0));
+    auto sq = host<double>(g.column(2).data().chunk(0)), sp = host<double>(g.column(3).data().chunk(0)), sd = host<double>(g.column(4).data().chunk(0));
+    auto aq = host<double>(g.column(5).data().chunk(0));
+    auto cq = host<uint32_t>(g.column(6).data().chunk(0));
+    size_t r = 0;
+    for (auto& kv : exp) {   // std::map<pair> iterates in (returnflag, linestatus) order == the result's row order
+        CHECK_EQ((int)kf[r], kv.first.first);
+        CHECK_EQ((int)ks[r], kv.first.second);
+        CHECK_NEAR(sq[r], kv.second.qty, 1e-9 * kv.second.qty);
+        CHECK_NEAR(sp[r], kv.second.price, 1e-9 * kv.second.price);
+        CHECK_NEAR(sd[r], kv.second.dp, 1e-9 * kv.second.dp);
+        CHECK_NEAR(aq[r], kv.second.qty / (double)kv.second.n, 1e-9);
+        CHECK_EQ((int64_t)cq[r], kv.second.n);
+        ++r;
+    }
+}
 TEST(test_group_aggregate_by_key) { group_aggregate_by_key(1); }
 TEST(test_group_aggregate_by_sparse_key) { group_aggregate_by_key(100003); }
 
