@@ -1400,7 +1400,7 @@ class Evaluate {
                 for (size_t i = 0; i < t.sort_descending.size() && i < cr.size(); ++i) cr[i].descending = t.sort_descending[i];
                 reset(f.sort(cr));
             } break;
-            case T::Join: throw DataFrameError(DataFrameError::ComputeError, "Join is not on the accelerated path yet (SURVEY.md §8f)");
+            case T::Join: throw DataFrameError(DataFrameError::ComputeError, "Join inside a computation list: LazyFrame::join evaluates both sides and joins the frames");
             default: throw DataFrameError(DataFrameError::ComputeError, "Read inside evaluate: pass the frame in");
         }
     }
@@ -1836,6 +1836,29 @@ class LazyFrame {
     LazyFrame sort(const std::vector<std::string>& cols, const std::vector<bool>& descending) const {
         LazyFrame f = *this;
         f.push({plan::Transformation::Sort_(cols, descending)});
+        return f;
+    }
+    // LazyFrame::join (:225-251) with Dataset::try_join's checks and output naming (src/expression.rs:223-285): both key
+    // columns must exist and have the same type; a column name present on both sides comes out as "a.<name>" / "b.<name>".
+    // Evaluation is the reference's (src/evaluation.rs:75-84): both sub-plans are evaluated, then DataFrame::join (the
+    // index pairs come from rdf_equijoin_indices_multi, the columns from rdf_take); the joined frame is the new source.
+    LazyFrame join(const LazyFrame& other, const DataFrame::JoinCriteria& jc) const {
+        for (auto& c : jc.criteria) {
+            const auto a = output_.get_column(c.first), b = other.output_.get_column(c.second);
+            if (a && b) { if (a->second.data_type != b->second.data_type) throw DataFrameError(DataFrameError::ComputeError, "Join columns must have compatible types"); }
+            else if (!a && b) throw DataFrameError(DataFrameError::ComputeError, "Join column does not exist in table A");
+            else if (a && !b) throw DataFrameError(DataFrameError::ComputeError, "Join column does not exist in table B");
+            else throw DataFrameError(DataFrameError::ComputeError, "Join columns do not exist in tables");
+        }
+        auto has = [](const plan::Dataset& d, const std::string& n) { for (auto& c : d.columns) if (c.name == n) return true; return false; };
+        const DataFrame fa = evaluate(), fb = other.evaluate();
+        const DataFrame j = fa.join(fb, jc);
+        std::vector<Column> cols;
+        size_t k = 0;
+        for (auto& c : output_.columns) cols.push_back(has(other.output_, c.name) ? j.column(k++).renamed("a." + c.name) : j.column(k++));
+        for (auto& c : other.output_.columns) cols.push_back(has(output_, c.name) ? j.column(k++).renamed("b." + c.name) : j.column(k++));
+        LazyFrame f = LazyFrame::read(DataFrame::from_columns(cols));
+        f.output_.name = "joined_dataframe";
         return f;
     }
     LazyFrame aggregate(const std::vector<std::string>& groups, const std::vector<plan::Aggregation>& aggr) const {

@@ -159,6 +159,29 @@ TEST(test_joins) {
     CHECK_EQ(host<double>(i.column_by_name("f").data().chunk(0)), (std::vector<double>{2.2, INFINITY, 6.0, 6.0}));
 }
 
+// test_lazy_join (src/lazyframe.rs:410-470) builds rename -> two sine columns -> inner join of two reads of the cities
+// file (on the city names) and only prints the plan.  Here the same plan shape on the numeric join fixture, evaluated:
+// computed columns survive the join, a name present on both sides is prefixed, try_join's errors are raised.
+TEST(test_lazy_join) {
+    const std::vector<bool> av{0, 1, 1, 0, 0, 1, 1};
+    DataFrame j1 = DataFrame::from_columns({Column::from_arrays({Array::from_vec<int32_t>({0, 2, 3, 0, 0, 6, 6}, &av)}, Field{"a", DataType::Int32, true}),
+                                            Column::from_arrays({Array::from_vec<double>({1, 2, 3, 4, 5, 6, 60})}, Field{"x", DataType::Float64, false})});
+    DataFrame j2 = DataFrame::from_columns({Column::from_arrays({Array::from_vec<int32_t>({1, 2, 3, 4, 4, 4, 5, 6, 7})}, Field{"d", DataType::Int32, false}),
+                                            Column::from_arrays({Array::from_vec<double>({1.5, 2.5, 3.5, 4.5, 4.5, 4.5, 5.5, 6.5, 7.5})}, Field{"x", DataType::Float64, false})});
+    LazyFrame frame = LazyFrame::read(j1).with_column_renamed("a", "key").with_column("sin_x", P::Function::Scalar_(P::ScalarFunction::Sine), {"x"});
+    LazyFrame joined = frame.join(LazyFrame::read(j2), {DataFrame::JoinType::InnerJoin, {{"key", "d"}}});
+    CHECK_EQ(joined.output().name, std::string("joined_dataframe"));
+    DataFrame r = joined.with_column("sum_x", P::Function::Scalar_(P::ScalarFunction::Add), {"a.x", "b.x"}).evaluate();
+    CHECK_EQ(r.num_rows(), 4);
+    CHECK_EQ(r.num_columns(), 6u);   // key, a.x, sin_x, d, b.x, sum_x
+    CHECK_EQ(host<int32_t>(r.column_by_name("key").data().chunk(0)), (std::vector<int32_t>{2, 3, 6, 6}));
+    CHECK_EQ(host<double>(r.column_by_name("a.x").data().chunk(0)), (std::vector<double>{2, 3, 6, 60}));
+    CHECK_EQ(host<double>(r.column_by_name("sum_x").data().chunk(0)), (std::vector<double>{4.5, 6.5, 12.5, 66.5}));
+    CHECK_NEAR(host<double>(r.column_by_name("sin_x").data().chunk(0))[3], std::sin(60.0), 1e-15);
+    CHECK_THROWS(frame.join(LazyFrame::read(j2), {DataFrame::JoinType::InnerJoin, {{"nope", "d"}}}));   // not in table A
+    CHECK_THROWS(frame.join(LazyFrame::read(j2), {DataFrame::JoinType::InnerJoin, {{"key", "x"}}}));    // incompatible types
+}
+
 // ---------------------------------------------------------------- filter: DataFrame::filter + the fused filter -> aggregate
 TEST(test_filter_and_fused_aggregate) {
     DataFrame df = DataFrame::from_csv(g_csv).drop({"city"});
