@@ -530,6 +530,56 @@ inline std::string debug(const std::vector<Calculation>& v) {
 }
 struct Aggregation { AggregateFunction function; std::vector<std::string> columns; };
 
+// Dataset::try_aggregate (src/expression.rs:114-221): the planned output of GroupAggregate — the grouping columns, then one
+// column per (aggregation, input column) named "avg(x)" / "sum(x)" / "max(x)" / "min(x)" / "count(x)" / "count_distinct(x)"
+// / "first(x)" / "last(x)", typed like the input except the counts (UInt32); the remaining functions are
+// "Aggregation not yet supported".  (The reference PLANS avg with the input's type; evaluated, an average is Float64 —
+// AggregateFunctions::avg, src/functions/aggregate.rs:32.)
+inline Dataset try_aggregate(const Dataset& self, const std::vector<std::string>& groups, const std::vector<Aggregation>& aggr) {
+    Dataset out;
+    out.name = "aggregated_dataset";
+    for (auto& g : groups) {
+        const auto c = self.get_column(g);
+        if (!c) throw DataFrameError(DataFrameError::ComputeError, "Grouping column \"" + g + "\" does not exist");
+        out.columns.push_back(c->second);
+    }
+    for (auto& a : aggr)
+        for (auto& name : a.columns) {
+            const auto c = self.get_column(name);
+            if (!c) throw DataFrameError(DataFrameError::ComputeError, "Aggregating column \"" + name + "\" does not exist");
+            const DataType t = c->second.data_type;
+            switch (a.function) {
+                case AggregateFunction::Avg: out.columns.push_back(Column{"avg(" + name + ")", t}); break;
+                case AggregateFunction::Sum: out.columns.push_back(Column{"sum(" + name + ")", t}); break;
+                case AggregateFunction::Max: out.columns.push_back(Column{"max(" + name + ")", t}); break;
+                case AggregateFunction::Min: out.columns.push_back(Column{"min(" + name + ")", t}); break;
+                case AggregateFunction::Count: out.columns.push_back(Column{"count(" + name + ")", DataType::UInt32}); break;
+                case AggregateFunction::CountDistinct: out.columns.push_back(Column{"count_distinct(" + name + ")", DataType::UInt32}); break;
+                case AggregateFunction::First: out.columns.push_back(Column{"first(" + name + ")", t}); break;
+                case AggregateFunction::Last: out.columns.push_back(Column{"last(" + name + ")", t}); break;
+                default: throw DataFrameError(DataFrameError::ComputeError, "Aggregation not yet supported");
+            }
+        }
+    return out;
+}
+
+// Dataset::try_join (src/expression.rs:223-285): both key columns must exist and have the same type; the output holds the
+// columns of both sides, a name present on both sides as "a.<name>" / "b.<name>"
+inline Dataset try_join(const Dataset& a, const Dataset& b, const std::vector<std::pair<std::string, std::string>>& on) {
+    for (auto& c : on) {
+        const auto ca = a.get_column(c.first), cb = b.get_column(c.second);
+        if (ca && cb) { if (ca->second.data_type != cb->second.data_type) throw DataFrameError(DataFrameError::ComputeError, "Join columns must have compatible types"); }
+        else if (!ca && cb) throw DataFrameError(DataFrameError::ComputeError, "Join column does not exist in table A");
+        else if (ca && !cb) throw DataFrameError(DataFrameError::ComputeError, "Join column does not exist in table B");
+        else throw DataFrameError(DataFrameError::ComputeError, "Join columns do not exist in tables");
+    }
+    Dataset out;
+    out.name = "joined_dataframe";
+    for (auto& c : a.columns) out.columns.push_back(b.get_column(c.name) ? Column{"a." + c.name, c.data_type} : c);
+    for (auto& c : b.columns) out.columns.push_back(a.get_column(c.name) ? Column{"b." + c.name, c.data_type} : c);
+    return out;
+}
+
 struct ArrowError : DataFrameError { using DataFrameError::DataFrameError; };
 
 // CastOperation (src/operation/scalar.rs:95-137)
@@ -1843,26 +1893,17 @@ class LazyFrame {
     // Evaluation is the reference's (src/evaluation.rs:75-84): both sub-plans are evaluated, then DataFrame::join (the
     // index pairs come from rdf_equijoin_indices_multi, the columns from rdf_take); the joined frame is the new source.
     LazyFrame join(const LazyFrame& other, const DataFrame::JoinCriteria& jc) const {
-        for (auto& c : jc.criteria) {
-            const auto a = output_.get_column(c.first), b = other.output_.get_column(c.second);
-            if (a && b) { if (a->second.data_type != b->second.data_type) throw DataFrameError(DataFrameError::ComputeError, "Join columns must have compatible types"); }
-            else if (!a && b) throw DataFrameError(DataFrameError::ComputeError, "Join column does not exist in table A");
-            else if (a && !b) throw DataFrameError(DataFrameError::ComputeError, "Join column does not exist in table B");
-            else throw DataFrameError(DataFrameError::ComputeError, "Join columns do not exist in tables");
-        }
-        auto has = [](const plan::Dataset& d, const std::string& n) { for (auto& c : d.columns) if (c.name == n) return true; return false; };
-        const DataFrame fa = evaluate(), fb = other.evaluate();
-        const DataFrame j = fa.join(fb, jc);
+        const plan::Dataset planned = plan::try_join(output_, other.output_, jc.criteria);
+        const DataFrame j = evaluate().join(other.evaluate(), jc);
         std::vector<Column> cols;
-        size_t k = 0;
-        for (auto& c : output_.columns) cols.push_back(has(other.output_, c.name) ? j.column(k++).renamed("a." + c.name) : j.column(k++));
-        for (auto& c : other.output_.columns) cols.push_back(has(output_, c.name) ? j.column(k++).renamed("b." + c.name) : j.column(k++));
+        for (size_t k = 0; k < planned.columns.size(); ++k) cols.push_back(j.column(k).renamed(planned.columns[k].name));
         LazyFrame f = LazyFrame::read(DataFrame::from_columns(cols));
-        f.output_.name = "joined_dataframe";
+        f.output_.name = planned.name;
         return f;
     }
-    LazyFrame aggregate(const std::vector<std::string>& groups, const std::vector<plan::Aggregation>& aggr) const {
+    LazyFrame aggregate(const std::vector<std::string>& groups, const std::vector<plan::Aggregation>& aggr) const {   // :285-309
         LazyFrame f = *this;
+        f.output_ = plan::try_aggregate(output_, groups, aggr);
         f.push({plan::Transformation::GroupAggregate_(groups, aggr)});
         return f;
     }

@@ -79,6 +79,29 @@ TEST(test_lazy_pipeline) {
     CHECK_NEAR(df.column_by_name("sin_lat").data().chunk(0)->value<double>(0), 0.8933816410476535, 1e-12);
     CHECK_NEAR(df.column_by_name("sin_lng").data().chunk(0)->value<double>(0), 0.1929142713855381, 1e-12);
 }
+// test_projection (src/lazyframe.rs:472-511): rename, two sine columns, select three, drop one — evaluated here
+TEST(test_projection) {
+    LazyFrame frame = LazyFrame::read(DataFrame::from_csv(g_csv));
+    frame = frame.with_column_renamed("city", "town");
+    frame = frame.with_column("sin_lat", P::Function::Scalar_(P::ScalarFunction::Sine), {"lat"});
+    frame = frame.with_column("sin_lng", P::Function::Scalar_(P::ScalarFunction::Sine), {"lng"});
+    frame = frame.select({"town", "sin_lat", "sin_lng"});
+    frame = frame.drop({"town"});
+    CHECK_EQ(frame.output().columns.size(), 2u);
+    DataFrame df = frame.evaluate();
+    CHECK_EQ(df.num_columns(), 2u);
+    CHECK_EQ(df.num_rows(), 37);
+    CHECK_EQ(df.schema().fields[0].name, std::string("sin_lat"));
+    CHECK_EQ(df.schema().fields[1].name, std::string("sin_lng"));
+    CHECK_NEAR(df.column(0).data().chunk(0)->value<double>(0), 0.8933816410476535, 1e-12);
+    // test_group_aggregate (:513-540) plans max(lat), max(lng) by city: the plan's output schema, and the evaluation error
+    using AF = P::AggregateFunction;
+    LazyFrame agg = LazyFrame::read(DataFrame::from_csv(g_csv)).aggregate({"city"}, {{AF::Max, {"lat", "lng"}}});
+    CHECK_EQ(agg.output().name, std::string("aggregated_dataset"));
+    CHECK_EQ(agg.output().columns[1].name, std::string("max(lat)"));
+    CHECK_THROWS(agg.evaluate());   // "aggregations not supported" in the reference (evaluation.rs:73); a string grouping column here
+    CHECK_THROWS(LazyFrame::read(DataFrame::from_csv(g_csv)).aggregate({"town"}, {{AF::Max, {"lat"}}}));   // Grouping column "town" does not exist
+}
 TEST(test_with_columns) {
     LazyFrame frame = LazyFrame::read(DataFrame::from_csv(g_csv));
     frame = frame.with_column("sum", P::Function::Scalar_(P::ScalarFunction::Add), {"lat", "lng"});

@@ -72,4 +72,42 @@ TEST(calculation_dispatch) {
     CHECK(d2.columns[0].data_type == DataType::Int64);
 }
 
+// test_group_aggregate (src/lazyframe.rs:513-540) plans max(lat), max(lng) by city on the cities file and prints the plan:
+// the planned output is Dataset::try_aggregate's (src/expression.rs:114-221)
+TEST(test_group_aggregate_plan) {
+    Dataset cities;
+    cities.name = "source";
+    cities.columns = {Column{"city", DataType::Utf8}, Column{"lat", DataType::Float64}, Column{"lng", DataType::Float64}};
+    const Dataset out = try_aggregate(cities, {"city"}, {Aggregation{AggregateFunction::Max, {"lat", "lng"}}});
+    CHECK_EQ(out.name, std::string("aggregated_dataset"));
+    CHECK_EQ(out.columns.size(), 3u);
+    CHECK_EQ(out.columns[0].debug(), std::string("Column { name: \"city\", column_type: Scalar(Utf8) }"));
+    CHECK_EQ(out.columns[1].debug(), std::string("Column { name: \"max(lat)\", column_type: Scalar(Float64) }"));
+    CHECK_EQ(out.columns[2].name, std::string("max(lng)"));
+    const Dataset counts = try_aggregate(cities, {}, {Aggregation{AggregateFunction::Count, {"city"}}, Aggregation{AggregateFunction::Avg, {"lat"}}});
+    CHECK_EQ(counts.columns[0].debug(), std::string("Column { name: \"count(city)\", column_type: Scalar(UInt32) }"));
+    CHECK_EQ(counts.columns[1].name, std::string("avg(lat)"));
+    CHECK_THROWS(try_aggregate(cities, {"town"}, {}));                                                   // Grouping column "town" does not exist
+    CHECK_THROWS(try_aggregate(cities, {}, {Aggregation{AggregateFunction::Sum, {"nope"}}}));            // Aggregating column "nope" does not exist
+    CHECK_THROWS(try_aggregate(cities, {}, {Aggregation{AggregateFunction::StdDev, {"lat"}}}));          // Aggregation not yet supported
+}
+
+// Dataset::try_join (src/expression.rs:223-285), the planning half of test_lazy_join (src/lazyframe.rs:410-470)
+TEST(test_join_plan) {
+    Dataset a, b;
+    a.columns = {Column{"town", DataType::Utf8}, Column{"lat", DataType::Float64}, Column{"sin_lat", DataType::Float64}};
+    b.columns = {Column{"city", DataType::Utf8}, Column{"lat", DataType::Float64}};
+    const Dataset j = try_join(a, b, {{"town", "city"}});
+    CHECK_EQ(j.name, std::string("joined_dataframe"));
+    CHECK_EQ(j.columns.size(), 5u);
+    CHECK_EQ(j.columns[1].name, std::string("a.lat"));
+    CHECK_EQ(j.columns[2].name, std::string("sin_lat"));
+    CHECK_EQ(j.columns[3].name, std::string("city"));
+    CHECK_EQ(j.columns[4].name, std::string("b.lat"));
+    CHECK_THROWS(try_join(a, b, {{"nope", "city"}}));   // not in table A
+    CHECK_THROWS(try_join(a, b, {{"town", "nope"}}));   // not in table B
+    CHECK_THROWS(try_join(a, b, {{"x", "y"}}));         // in neither
+    CHECK_THROWS(try_join(a, b, {{"town", "lat"}}));    // incompatible types
+}
+
 int main() { return run_all(); }
