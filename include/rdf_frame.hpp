@@ -1431,7 +1431,13 @@ class Evaluate {
         switch (t.kind) {
             case T::Calculate: step_calculate(t.calc); break;
             case T::Filter: step_filter(t.filter); break;
-            case T::Limit: { DataFrame f = flush(); reset(f.limit(t.limit)); } break;
+            case T::Limit:
+                // the optimiser's limit push-down (src/optimiser.rs:56-75): pending Calculate steps are row-wise, so the limit
+                // is taken on the source columns (zero-copy slices) and the lazy columns are then computed for those rows only;
+                // a pending filter changes which rows come first, so it is applied before the limit
+                if (!pending_) base_ = base_.limit(t.limit);
+                else { DataFrame f = flush(); reset(f.limit(t.limit)); }
+                break;
             case T::Select: {
                 std::vector<Entry> keep;
                 for (auto& e : cols_) for (auto& n : t.names) if (e.name == n) { keep.push_back(e); break; }

@@ -113,10 +113,20 @@ TEST(test_lazy_evaluation) {
     frame = frame.with_column_renamed("city", "town");
     frame = frame.with_column("sin_lat", P::Function::Scalar_(P::ScalarFunction::Sine), {"lat"});
     frame = frame.with_column("sin_lng", P::Function::Scalar_(P::ScalarFunction::Sine), {"lng"});
+    DataFrame all = frame.evaluate();
     frame = frame.limit(25);
     DataFrame df = frame.evaluate();
     CHECK_EQ(df.num_columns(), 5u);
     CHECK_EQ(df.num_rows(), 25);
+    {   // the limit is taken on the source before the pending sines run (limit push-down): same rows, same values
+        auto full = host<double>(all.column_by_name("sin_lng").data().chunk(0)), lim = host<double>(df.column_by_name("sin_lng").data().chunk(0));
+        CHECK_EQ(lim.size(), 25u);
+        CHECK(std::equal(lim.begin(), lim.end(), full.begin()));
+        // behind a filter the limit counts FILTERED rows
+        DataFrame fl = LazyFrame::read(DataFrame::from_csv(g_csv)).filter(BooleanFilter::gt(BooleanFilter::column("lat"), BooleanFilter::scalar(Scalar(55.0)))).limit(3).evaluate();
+        CHECK_EQ(fl.num_rows(), 3);
+        for (double v : host<double>(fl.column_by_name("lat").data().chunk(0))) CHECK(v > 55.0);
+    }
     // ops after a limit see sliced (offset) arrays
     DataFrame lim = DataFrame::from_csv(g_csv).limit(30).limit(10);
     auto s = host<double>(ScalarFunctions::sin(lim.column_by_name("lat").data().chunks())[0]);
