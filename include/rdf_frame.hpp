@@ -981,6 +981,21 @@ class DataFrame {
         }
         return out;
     }
+    // DataFrame::with_id (:234-249): a UInt64 column counting from 100 000 * chunk index + 1 within every chunk (the
+    // reference's "no record batch has 100k rows" assumption included).  The ids are built on the host and uploaded.
+    DataFrame with_id(const std::string& name) const {
+        std::vector<ArrayRef> arrays;
+        if (!columns_.empty()) {
+            size_t index = 0;
+            for (auto& ch : columns_[0].data().chunks()) {
+                std::vector<uint64_t> ids((size_t)ch->length);
+                for (size_t i = 0; i < ids.size(); ++i) ids[i] = 100000ull * index + 1 + i;
+                arrays.push_back(Array::from_vec<uint64_t>(ids));
+                ++index;
+            }
+        }
+        return with_column(name, Column::from_arrays(arrays, Field{name, DataType::UInt64, false}));
+    }
     DataFrame limit(size_t count) const {  // :166-175, zero-copy slices
         std::vector<Column> cols;
         for (auto& c : columns_) cols.push_back(c.slice(0, (int64_t)count));

@@ -66,6 +66,21 @@ TEST(test_dataframe_ops) {
     CHECK_EQ(df.schema().fields.back().name, std::string("lat"));
 }
 
+// test_create_empty_dataframe / test_read_csv_to_dataframe / test_increasing_id (src/dataframe.rs:737-750, 945-960)
+TEST(test_create_empty_and_read_csv_and_increasing_id) {
+    DataFrame empty = DataFrame::empty();
+    CHECK_EQ(empty.num_columns(), 0u);
+    CHECK_EQ(empty.schema().fields.size(), 0u);
+    DataFrame dataframe = DataFrame::from_csv(g_csv);
+    CHECK_EQ(dataframe.num_columns(), 3u);
+    CHECK_EQ(dataframe.num_rows(), 37);
+    dataframe = dataframe.limit(10).with_id("id");
+    const Column& id = dataframe.column_by_name("id");
+    CHECK(id.data_type() == DataType::UInt64);
+    CHECK_EQ(id.name(), std::string("id"));
+    CHECK_EQ(host<uint64_t>(id.data().chunk(0)), (std::vector<uint64_t>{1, 2, 3, 4, 5, 6, 7, 8, 9, 10}));
+}
+
 // ---------------------------------------------------------------- src/lazyframe.rs:324-408, src/evaluation.rs:359-434
 TEST(test_lazy_pipeline) {
     LazyFrame frame = LazyFrame::read(DataFrame::from_csv(g_csv));
