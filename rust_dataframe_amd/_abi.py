@@ -180,9 +180,18 @@ class HostArray:
         length = max(0, min(length, self.length - offset))
         return HostArray(self.values, self.validity, self.offset + offset, length, self.dtype, -1)
 
+    def _pointers(self):
+        """(values address, validity address): looked up once per buffer pair — `ndarray.ctypes.data` costs about a
+        microsecond, which is most of the per-chunk marshalling time of a frame in 1024-row batches."""
+        cached = self.__dict__.get("_ptrs")
+        if cached is None or cached[0] is not self.values or cached[1] is not self.validity:
+            cached = (self.values, self.validity, self.values.ctypes.data, self.validity.ctypes.data if self.validity is not None else None)
+            self.__dict__["_ptrs"] = cached
+        return cached[2], cached[3]
+
     def c_struct(self, unknown_null_count: bool = False) -> rdf_array:
-        return rdf_array(self.values.ctypes.data, self.validity.ctypes.data if self.validity is not None else None,
-                         self.offset, self.length, -1 if unknown_null_count else self.null_count, self.dtype, MEM_HOST)
+        vp, bp = self._pointers()
+        return rdf_array(vp, bp, self.offset, self.length, -1 if unknown_null_count else self.null_count, self.dtype, MEM_HOST)
 
     @staticmethod
     def empty_out(dtype: int, capacity: int, with_validity: bool) -> "HostArray":
@@ -194,8 +203,8 @@ class HostArray:
         return HostArray(vals, vbuf, 0, capacity, dtype, 0)
 
     def out_struct(self) -> rdf_out:
-        return rdf_out(self.values.ctypes.data, self.validity.ctypes.data if self.validity is not None else None,
-                       self.length, 0, 0, self.dtype, MEM_HOST)
+        vp, bp = self._pointers()
+        return rdf_out(vp, bp, self.length, 0, 0, self.dtype, MEM_HOST)
 
 
 @dataclass
