@@ -10,19 +10,27 @@ ranks is the job time; rank 0 prints ONE JSON line.
   value     = rows all ranks processed / job time            (whole-job rows/s, inputs resident in HBM)
   roofline  = algorithmic bytes per launch (8 B/row) / average duration of the dominant
               kernel (the specialised filter->aggregate kernel, rdf_spec.hip), from hipEvents the library records on ITS stream around
-              that launch, against the 8 TB/s HBM3E peak (MI355X_MICROARCH.md)
+              that launch, against the 8 TB/s HBM3E peak (MI355X_MICROARCH.md); `peak_measured` = a stock read-only
+              probe (torch.sum over the same column) timed in the same run, the second denominator SURVEY.md §8d asks for
   cpu_baseline = the oracle's structurally faithful restatement of the reference CPU path (const-array
               materialisation -> f64 casts -> compare -> bitmap -> Column::filter -> sum, one thread,
-              2^20-row chunks) timed on a bounded sample, rank 0 at N = 1 only.  Test infrastructure
+              2^20-row chunks) on a bounded sample, median of 5 warmed runs, rank 0 at N = 1 only; `c1` = BASELINE
+              config 1 (1e6 rows in 1024-row batches, sin(x + 1.0) -> sum, unfused).  Test infrastructure
               used here as the reported baseline only, never as the measured product.
 
 Multi-GPU: row ranges are sharded across ranks (rank r owns rows [r*R, (r+1)*R), weak scaling); the only
-exchange is the tiny combine of per-rank {sum, count} partials (all_gather over RCCL, folded in rank
-order for determinism).
+exchange of the headline is the tiny combine of per-rank {sum, count} partials (all_gather over RCCL, folded in rank
+order for determinism).  `--workload c4` (hash GROUP BY) has the one real exchange: device-resident partial groups
+-> all_to_all_single over RCCL -> local merge on device buffers.
+
+Every synthetic column is a counter-based hash of (seed, column id, global row) (rdf_fill_uniform_*), so any prefix can
+be re-created on the host: each workload checks its device result on a sample prefix against the oracle
+(`parity_on_sample`) and through size-independent invariants on the full result (`self_check`).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,10 +41,22 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
 THRESHOLD = 0.5
 SEED = 42
+CHECK_ROWS = 2_000_000  # prefix every --workload is checked on against the oracle
 
 
-def cpu_baseline(sample_rows: int, gpu_check=None):
-    """Time the oracle (kind = "port") on rows [0, sample_rows) of the same synthetic column."""
+def _median_time(fn, runs=5, warm=1):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        r = fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), r, ts
+
+
+def cpu_baseline(sample_rows: int):
+    """Time the oracle (kind = "port") on rows [0, sample_rows) of the same synthetic column: median of 5 warmed runs."""
     import numpy as np
     from oracle import oracle
     from rust_dataframe_amd import _abi as A
@@ -48,112 +68,269 @@ def cpu_baseline(sample_rows: int, gpu_check=None):
     e = A.Expr()
     c = e.col(0)
     pred = e.op("gt", c, e.scalar(THRESHOLD))
-    t0 = time.perf_counter()
-    r = o.pipeline(e, [chunks], [c], pred)[0]
-    dt = time.perf_counter() - t0
+    dt, r, ts = _median_time(lambda: o.pipeline(e, [chunks], [c], pred)[0])
     # "all host cores" variant: the same path over disjoint chunk ranges on every core, like rayon over
     # chunks (src/functions/scalar.rs:28); ctypes releases the GIL during the call.  Reported beside, never instead of, `value`.
     import concurrent.futures
     ncores = os.cpu_count() or 1
     parts = [chunks[i::ncores] for i in range(ncores) if chunks[i::ncores]]
-    t1 = time.perf_counter()
     with concurrent.futures.ThreadPoolExecutor(len(parts)) as ex:
-        rs = list(ex.map(lambda p: o.pipeline(e, [p], [c], pred)[0], parts))
-    dt_all = time.perf_counter() - t1
-    assert sum(x.count for x in rs) == r.count
+        dt_all, rs, _ = _median_time(lambda: list(ex.map(lambda p: o.pipeline(e, [p], [c], pred)[0], parts)), runs=3)
+    assert sum(q.count for q in rs) == r.count
+    # BASELINE config 1 (the reference's own CPU-runnable case): 1e6 f64 rows in the CSV reader's 1024-row batches
+    # (src/dataframe.rs:352), y = sin(x + 1.0) materialised step by step (src/evaluation.rs:66-96), then sum(y)
+    n1 = 1_000_000
+    c1_chunks = [A.HostArray(x, None, i, min(1024, n1 - i), A.F64, 0) for i in range(0, min(n1, sample_rows), 1024)]
+    e1 = A.Expr()
+    y = e1.op("sin", e1.op("add", e1.col(0), e1.scalar(1.0)))
+    dt1, r1, _ = _median_time(lambda: o.pipeline(e1, [c1_chunks], [y])[0])
     return {"value": sample_rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
             "sample": f"rows [0,{sample_rows}) of the same column, 2^20-row chunks, reference-shaped unfused path "
-                      f"(oracle/rdf_oracle.c ora_pipeline), {dt:.2f} s",
+                      f"(oracle/rdf_oracle.c ora_pipeline), median of 5 warmed runs ({dt:.2f} s each; min {min(ts):.2f}, max {max(ts):.2f})",
             "all_cores": {"value": sample_rows / dt_all, "cores": len(parts), "seconds": dt_all},
+            "c1": {"value": len(c1_chunks) * 1024 / dt1 if dt1 > 0 else 0.0, "unit": "rows/s", "cores": 1, "kind": "port",
+                   "sample": f"BASELINE config 1: {len(c1_chunks)} batches of 1024 rows, sin(x + 1.0) -> sum, unfused; median of 5 warmed runs, {dt1 * 1e3:.1f} ms each",
+                   "result_sum": r1.sum},
             "_sum": r.sum, "_count": r.count}
 
 
 # ---------------------------------------------------------------------------------------------------------
-# The other BASELINE.json configurations, selectable with --workload (the driver's default run stays the headline):
-# each returns (step, alg_bytes_per_launch, description, check) for this rank's HBM-resident shard.
+# The other BASELINE.json configurations, selectable with --workload (the driver's default run stays the headline).
+# Each builder returns (step, algorithmic bytes per launch, description, check) for this rank's HBM-resident shard;
+# check(result of the last step) -> dict with `self_check` (invariants of the full-size result) and, on rank 0,
+# `parity_on_sample` (device vs oracle on the first CHECK_ROWS rows) and the oracle's rows/s on that sample.
+
+class Gen:
+    """Race-free synthetic columns: the library fills on ITS stream (and synchronises it), torch converts on its own;
+    torch's stream is drained before the library touches a buffer the caching allocator may have just recycled."""
+
+    def __init__(self, torch, lib, dev):
+        self.torch, self.lib, self.dev = torch, lib, dev
+
+    def f64(self, rows, col, first, lo, hi):
+        self.torch.cuda.synchronize()
+        t = self.torch.empty(rows, dtype=self.torch.float64, device=self.dev)
+        self.lib.fill_uniform_f64(t.data_ptr(), rows, SEED, col, first, lo, hi)
+        return t
+
+    def i64(self, rows, col, first, lo, hi):
+        self.torch.cuda.synchronize()
+        t = self.torch.empty(rows, dtype=self.torch.int64, device=self.dev)
+        self.lib.fill_uniform_i64(t.data_ptr(), rows, SEED, col, first, lo, hi)
+        return t
+
+    def done(self):
+        self.torch.cuda.synchronize()
+        self.lib.synchronize()
+
+
+def _host_f64(o, rows, col, first, lo, hi):
+    import numpy as np
+    x = np.empty(rows, dtype=np.float64)
+    o.lib.ora_fill_uniform_f64(x.ctypes.data, rows, SEED, col, first, lo, hi)
+    return x
+
+
+def _host_i64(o, rows, col, first, lo, hi):
+    import numpy as np
+    x = np.empty(rows, dtype=np.int64)
+    o.lib.ora_fill_uniform_i64(x.ctypes.data, rows, SEED, col, first, lo, hi)
+    return x
+
+
+def _close(a, b, rtol=1e-6):
+    return a == b or abs(a - b) <= rtol * max(abs(a), abs(b))
+
 
 def workload_c3(torch, lib, api, A, sharding, dev, comm_dev, rank, rows):
     """C3: fused a*b+c -> min/max/count and the i64 key's min/max/count, one pass over 4 columns (32 B/row)."""
     first = rank * rows
-    cols = []
-    for cid in range(3):
-        t = torch.empty(rows, dtype=torch.float64, device=dev)
-        lib.fill_uniform_f64(t.data_ptr(), rows, SEED, cid, first, -1.0, 1.0)
-        cols.append([A.DeviceArray(t.data_ptr(), None, 0, rows, A.F64, 0, keep=t)])
-    k = torch.empty(rows, dtype=torch.int64, device=dev)
-    lib.fill_uniform_i64(k.data_ptr(), rows, SEED, 3, first, -2 ** 31, 2 ** 31)
-    cols.append([A.DeviceArray(k.data_ptr(), None, 0, rows, A.I64, 0, keep=k)])
+    g = Gen(torch, lib, dev)
+    ts = [g.f64(rows, cid, first, -1.0, 1.0) for cid in range(3)] + [g.i64(rows, 3, first, -2 ** 31, 2 ** 31)]
+    g.done()
+    dts = (A.F64, A.F64, A.F64, A.I64)
+    cols = [[A.DeviceArray(t.data_ptr(), None, 0, rows, dt, 0, keep=t)] for t, dt in zip(ts, dts)]
     e = A.Expr()
     fma = e.op("add", e.op("multiply", e.col(0), e.col(1)), e.col(2))
     roots = [fma, e.col(3)]
 
     def step():
         y, kk = sharding.all_combine(api.pipeline(e, cols, roots), device=comm_dev)
-        return {"min_y": y.min, "max_y": y.max, "count_y": y.count, "min_k": kk.min, "max_k": kk.max}
-    return step, 32.0 * rows, f"C3: fused a*b+c -> min/max/count + i64 key min/max/count over {rows:.0e} rows x 4 columns per GPU"
+        return {"min_y": y.min, "max_y": y.max, "count_y": y.count, "min_k": kk.min, "max_k": kk.max, "count_k": kk.count}
+
+    def check(res, world):
+        out = {"self_check": bool(res["count_y"] == rows * world == res["count_k"] and -2.0 <= res["min_y"] < res["max_y"] <= 2.0
+                                  and -2 ** 31 <= res["min_k"] < res["max_k"] < 2 ** 31)}
+        if rank == 0:
+            from oracle import oracle
+            o = oracle.api()
+            n = min(CHECK_ROWS, rows)
+            sub = [[A.DeviceArray(t.data_ptr(), None, 0, n, dt, 0)] for t, dt in zip(ts, dts)]
+            gy, gk = api.pipeline(e, sub, roots)
+            hc = [[A.HostArray.from_numpy(_host_f64(o, n, cid, 0, -1.0, 1.0))] for cid in range(3)] + [[A.HostArray.from_numpy(_host_i64(o, n, 3, 0, -2 ** 31, 2 ** 31))]]
+            dt_o, (oy, ok), _ = _median_time(lambda: o.pipeline(e, hc, roots), runs=3)
+            out["parity_on_sample"] = bool(gy.count == oy.count and gy.min == oy.min and gy.max == oy.max and _close(gy.sum, oy.sum)
+                                           and (gk.min, gk.max, gk.count, gk.sum) == (ok.min, ok.max, ok.count, ok.sum))
+            out["cpu_baseline"] = {"value": n / dt_o, "unit": "rows/s", "cores": 1, "kind": "port",
+                                   "sample": f"rows [0,{n}): multiply -> add materialised, then min/max/count (oracle), median of 3 warmed runs"}
+        return out
+    return step, 32.0 * rows, f"C3: fused a*b+c -> min/max/count + i64 key min/max/count over {rows:.0e} rows x 4 columns per GPU", check
 
 
 def workload_c4(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, ngroups=1_000_000):
     """C4: SELECT key, sum(val) GROUP BY key, 1e6 keys: local hash aggregate, then (N > 1) the all-to-all of partial groups."""
-    import numpy as np
     first = rank * rows
-    kk = torch.empty(rows, dtype=torch.int64, device=dev)
-    lib.fill_uniform_i64(kk.data_ptr(), rows, SEED, 7, first, 0, ngroups)
-    v = torch.empty(rows, dtype=torch.float64, device=dev)
-    lib.fill_uniform_f64(v.data_ptr(), rows, SEED, 0, first, 0.0, 1.0)
+    g = Gen(torch, lib, dev)
+    kk = g.i64(rows, 7, first, 0, ngroups)
+    v = g.f64(rows, 0, first, 0.0, 1.0)
+    g.done()
     K = A.DeviceArray(kk.data_ptr(), None, 0, rows, A.I64, 0, keep=kk)
     V = A.DeviceArray(v.data_ptr(), None, 0, rows, A.F64, 0, keep=v)
-    cap = ngroups + 2
-    bufs = [torch.empty(cap * 8 + 64, dtype=torch.uint8, device=dev) for _ in range(3)]
-    outs = tuple(A.DeviceArray(b.data_ptr(), None, 0, cap, dt, 0, keep=b) for b, dt in zip(bufs, (A.I64, A.F64, A.I64)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    cap = ngroups + 2
+
+    def outs3():
+        bufs = [torch.empty(cap * 8 + 64, dtype=torch.uint8, device=dev) for _ in range(3)]
+        return tuple(A.DeviceArray(b.data_ptr(), None, 0, cap, dt, 0, keep=b) for b, dt in zip(bufs, (A.I64, A.F64, A.I64)))
+    outs = outs3()
+    ex = sharding.GroupExchange(api, lib, torch, dev, comm_dev, cap) if world > 1 else None
+    last = {}
 
     def step():
         gk, gs, gc = api.groupby_sum([K], [V], ngroups, outs)
         ng = gk.length
         if world == 1:
+            last["groups"] = (gk, gs, gc)
             return {"groups": ng}
-        # partial groups of this rank -> owners (RCCL all-to-all), merged there by a second, tiny group-by
-        hk = torch.empty(ng, dtype=torch.int64); hs = torch.empty(ng, dtype=torch.float64); hc = torch.empty(ng, dtype=torch.int64)
-        lib.load().rdf_copy_d2h(hk.data_ptr(), gk.values_ptr, ng * 8)
-        lib.load().rdf_copy_d2h(hs.data_ptr(), gs.values_ptr, ng * 8)
-        lib.load().rdf_copy_d2h(hc.data_ptr(), gc.values_ptr, ng * 8)
-        rk, rs, rc = sharding.exchange_groups(hk.numpy(), hs.numpy(), hc.numpy(), comm_dev)
-        Kh = [A.HostArray.from_numpy(rk)]
-        mk, ms, _ = api.groupby_sum(Kh, [A.HostArray.from_numpy(rs)], ngroups)
-        return {"groups_owned": mk.length}
-    return step, 16.0 * rows, f"C4: hash GROUP BY key -> sum(val), {ngroups:.0e} keys over {rows:.0e} rows per GPU"
+        # partial groups of this rank -> owners (RCCL all-to-all on device buffers), merged there by a second, tiny group-by
+        mk_, ms_, mc_ = ex.exchange_and_merge(gk, gs, gc, ngroups)
+        last["groups"] = (mk_, ms_, mc_)
+        return {"groups_owned": mk_.length}
+
+    def check(res, world_):
+        import numpy as np
+        gk, gs, gc = last["groups"]
+        n = gk.length
+        hk = torch.empty(n, dtype=torch.int64); hs = torch.empty(n, dtype=torch.float64); hc = torch.empty(n, dtype=torch.int64)
+        L = lib.load()
+        L.rdf_copy_d2h(hk.data_ptr(), gk.values_ptr, n * 8); L.rdf_copy_d2h(hs.data_ptr(), gs.values_ptr, n * 8); L.rdf_copy_d2h(hc.data_ptr(), gc.values_ptr, n * 8)
+        hk, hs, hc = hk.numpy(), hs.numpy(), hc.numpy()
+        # invariants of the full-size result: no key twice, every count positive, counts add up to the rows and the
+        # group sums to the column sum (all ranks' shares together when N > 1)
+        e = A.Expr()
+        col_sum = sharding.all_combine(api.pipeline(e, [[V]], [e.col(0)]), device=comm_dev)[0].sum
+        tot = [float(hs.sum()), int(hc.sum()), int(n)]
+        if world_ > 1:
+            import torch.distributed as dist
+            t = torch.tensor(tot, dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
+            dist.all_reduce(t)
+            tot = [t[0].item(), int(t[1].item()), int(t[2].item())]
+        ok = (len(np.unique(hk)) == n and int(hc.min(initial=1)) >= 1 and tot[1] == rows * world_ and _close(tot[0], col_sum, 1e-9)
+              and tot[2] <= ngroups and (rows * world_ < 20 * ngroups or tot[2] == ngroups) and (n == 0 or (0 <= hk.min() and hk.max() < ngroups)))
+        out = {"self_check": bool(ok), "groups_total": tot[2]}
+        if rank == 0:
+            from oracle import oracle
+            o = oracle.api()
+            m = min(CHECK_ROWS, rows)
+            Ks, Vs = A.DeviceArray(kk.data_ptr(), None, 0, m, A.I64, 0), A.DeviceArray(v.data_ptr(), None, 0, m, A.F64, 0)
+            dk, ds, dc = api.groupby_sum([Ks], [Vs], ngroups, outs3())
+            dn = dk.length
+            a = [torch.empty(dn, dtype=d) for d in (torch.int64, torch.float64, torch.int64)]
+            for t_, src in zip(a, (dk, ds, dc)):
+                L.rdf_copy_d2h(t_.data_ptr(), src.values_ptr, dn * 8)
+            hkeys, hvals = A.HostArray.from_numpy(_host_i64(o, m, 7, 0, 0, ngroups)), A.HostArray.from_numpy(_host_f64(o, m, 0, 0, 0.0, 1.0))
+            dt_o, (ok_, os_, oc_), _ = _median_time(lambda: o.groupby_sum([hkeys], [hvals], ngroups), runs=3)
+            o1, o2 = np.argsort(a[0].numpy()), np.argsort(ok_.to_numpy())
+            out["parity_on_sample"] = bool(dn == ok_.length and np.array_equal(a[0].numpy()[o1], ok_.to_numpy()[o2])
+                                           and np.array_equal(a[2].numpy()[o1], oc_.to_numpy()[o2])
+                                           and np.allclose(a[1].numpy()[o1], os_.to_numpy()[o2], rtol=1e-6, atol=0))
+            out["cpu_baseline"] = {"value": m / dt_o, "unit": "rows/s", "cores": 1, "kind": "port",
+                                   "sample": f"rows [0,{m}): hash GROUP BY key -> sum, count (oracle), median of 3 warmed runs"}
+        return out
+    return step, 16.0 * rows, f"C4: hash GROUP BY key -> sum(val), {ngroups:.0e} keys over {rows:.0e} rows per GPU", check
 
 
-def workload_q1(torch, lib, api, A, sharding, dev, comm_dev, rank, rows):
-    """C5: TPC-H Q1 shape over a synthetic lineitem shard (38 B/row): filter(shipdate <= c) -> 5 sums + counts in 6 groups."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(SEED + rank)
-    qty = torch.randint(1, 51, (rows,), device=dev, generator=g).to(torch.float64)
-    price = torch.empty(rows, dtype=torch.float64, device=dev)
-    lib.fill_uniform_f64(price.data_ptr(), rows, SEED, 11, rank * rows, 900.0, 105000.0)
-    disc = torch.randint(0, 11, (rows,), device=dev, generator=g).to(torch.float64) / 100.0
-    tax = torch.randint(0, 9, (rows,), device=dev, generator=g).to(torch.float64) / 100.0
-    flag = torch.randint(0, 3, (rows,), dtype=torch.int8, device=dev, generator=g)
-    status = torch.randint(0, 2, (rows,), dtype=torch.int8, device=dev, generator=g)
-    ship = torch.randint(8036, 10562, (rows,), dtype=torch.int32, device=dev, generator=g)
-    cols = [[A.DeviceArray(t.data_ptr(), None, 0, rows, dt, 0, keep=t)] for t, dt in
-            ((qty, A.F64), (price, A.F64), (disc, A.F64), (tax, A.F64), (flag, A.I8), (status, A.I8), (ship, A.I32))]
+def q1_program(A):
     q = A.Expr()
     c = [q.col(i) for i in range(7)]
     pred = q.op("le", c[6], q.scalar(10471, A.I32))
     gid = q.op("add", q.op("multiply", q.cast(c[4], A.I32), q.scalar(2, A.I32)), q.cast(c[5], A.I32))
     dp = q.op("multiply", c[1], q.op("subtract", q.scalar(1.0), c[2]))
     ch = q.op("multiply", dp, q.op("add", q.scalar(1.0), c[3]))
-    vals = [c[0], c[1], dp, ch, c[2]]
+    return q, [c[0], c[1], dp, ch, c[2]], gid, pred
+
+
+def workload_q1(torch, lib, api, A, sharding, dev, comm_dev, rank, rows):
+    """C5: TPC-H Q1 shape over a synthetic lineitem shard (38 B/row): filter(shipdate <= c) -> 5 sums + counts in 6 groups.
+    Columns per the TPC-H distributions: quantity 1..50, extendedprice, discount 0.00..0.10, tax 0.00..0.08
+    as f64; returnflag (3) / linestatus (2) dictionary codes as i8; shipdate as date32 days."""
+    first = rank * rows
+    g = Gen(torch, lib, dev)
+    qty = g.i64(rows, 12, first, 1, 51).to(torch.float64)
+    price = g.f64(rows, 11, first, 900.0, 105000.0)
+    disc = g.i64(rows, 13, first, 0, 11).to(torch.float64) / 100.0
+    tax = g.i64(rows, 14, first, 0, 9).to(torch.float64) / 100.0
+    flag = g.i64(rows, 15, first, 0, 3).to(torch.int8)
+    status = g.i64(rows, 16, first, 0, 2).to(torch.int8)
+    ship = g.i64(rows, 17, first, 8036, 10562).to(torch.int32)
+    g.done()
+    ts = (qty, price, disc, tax, flag, status, ship)
+    dts = (A.F64, A.F64, A.F64, A.F64, A.I8, A.I8, A.I32)
+    cols = [[A.DeviceArray(t.data_ptr(), None, 0, rows, dt, 0, keep=t)] for t, dt in zip(ts, dts)]
+    q, vals, gid, pred = q1_program(A)
 
     def step():
         res, nrows = sharding.all_combine_groups(api.group_pipeline(q, cols, vals, gid, 6, pred), device=comm_dev)
-        return {"count_star": nrows[:6], "sum_qty": [r[0] for r in res[0][:6]]}
-    return step, 38.0 * rows, f"C5: TPC-H Q1 shape (filter -> 5 sums + counts in 6 groups) over a {rows:.0e}-row synthetic lineitem shard per GPU"
+        return {"count_star": nrows[:6], "sum_qty": [r[0] for r in res[0][:6]], "sum_disc": [r[0] for r in res[4][:6]],
+                "sum_price": [r[0] for r in res[1][:6]], "sum_disc_price": [r[0] for r in res[2][:6]], "sum_charge": [r[0] for r in res[3][:6]]}
+
+    def check(res, world):
+        cs = res["count_star"]
+        sel = (10471 - 8036 + 1) / (10562 - 8036)
+        ok = abs(sum(cs) / (rows * world) - sel) < 1e-3
+        for gi in range(6):
+            c_ = max(cs[gi], 1)
+            ok = ok and 1.0 <= res["sum_qty"][gi] / c_ <= 50.0 and 0.0 <= res["sum_disc"][gi] / c_ <= 0.10
+            ok = ok and 900.0 <= res["sum_price"][gi] / c_ <= 105000.0
+            ok = ok and 0.9 * res["sum_price"][gi] <= res["sum_disc_price"][gi] <= res["sum_price"][gi] <= res["sum_charge"][gi] / 0.9 <= 1.2 * res["sum_price"][gi]
+            ok = ok and abs(cs[gi] / max(sum(cs), 1) - 1 / 6) < 1e-2
+        out = {"self_check": bool(ok)}
+        if rank == 0:
+            import numpy as np
+            from oracle import oracle
+            o = oracle.api()
+            n = min(CHECK_ROWS, rows)
+            sub = [[A.DeviceArray(t.data_ptr(), None, 0, n, dt, 0)] for t, dt in zip(ts, dts)]
+            gres, grows = api.group_pipeline(q, sub, vals, gid, 6, pred)
+            hi = lambda col, lo, hi_: _host_i64(o, n, col, 0, lo, hi_)
+            hcols = [hi(12, 1, 51).astype(np.float64), _host_f64(o, n, 11, 0, 900.0, 105000.0), hi(13, 0, 11).astype(np.float64) / 100.0,
+                     hi(14, 0, 9).astype(np.float64) / 100.0, hi(15, 0, 3).astype(np.int8), hi(16, 0, 2).astype(np.int8), hi(17, 8036, 10562).astype(np.int32)]
+            hc = [[A.HostArray.from_numpy(x)] for x in hcols]
+            dt_o, (ores, orows), _ = _median_time(lambda: o.group_pipeline(q, hc, vals, gid, 6, pred), runs=3)
+            same = list(grows) == list(orows)
+            for vi in range(len(vals)):
+                for gi in range(7):
+                    same = same and gres[vi][gi][1] == ores[vi][gi][1] and _close(gres[vi][gi][0], ores[vi][gi][0])
+            out["parity_on_sample"] = bool(same)
+            out["cpu_baseline"] = {"value": n / dt_o, "unit": "rows/s", "cores": 1, "kind": "port",
+                                   "sample": f"rows [0,{n}): filter -> expressions -> 6 groups x (5 sums + counts), one materialised array per step (oracle), median of 3 warmed runs"}
+        return out
+    return step, 38.0 * rows, f"C5: TPC-H Q1 shape (filter -> 5 sums + counts in 6 groups) over a {rows:.0e}-row synthetic lineitem shard per GPU", check
 
 
 WORKLOADS = {"c3": workload_c3, "c4": workload_c4, "q1": workload_q1}
+
+
+def read_probe(torch, x, runs=5):
+    """Stock read-only streaming kernel over the same column (torch.sum), median of `runs`: GB/s."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(runs + 1)]
+    for a, b in ev:
+        a.record()
+        torch.sum(x)
+        b.record()
+    torch.cuda.synchronize()
+    ms = statistics.median(a.elapsed_time(b) for a, b in ev[1:])
+    return x.numel() * x.element_size() / (ms * 1e-3) / 1e9
 
 
 def main():
@@ -162,8 +339,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU (f64, 8 B/row)")
-    ap.add_argument("--cpu-sample", type=int, default=200_000_000, help="rows for the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=50_000_000, help="rows for the CPU baseline leg (0 = skip)")
     ap.add_argument("--null-fraction", type=float, default=0.0, help="attach a validity bitmap with this null rate")
+    ap.add_argument("--chunk-rows", type=int, default=0, help="hand the column over as RecordBatches of this many rows (0 = one chunk; 1024 = the reference readers' batch)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for a smoke test)")
     ap.add_argument("--share-gpu", action="store_true", help="smoke test only: every rank uses device 0 (needs --backend gloo)")
     ap.add_argument("--workload", default="headline", choices=["headline"] + sorted(WORKLOADS),
@@ -203,20 +381,28 @@ def main():
     if args.workload != "headline":
         return run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, world)
     first_row = rank * rows
-    x = torch.empty(rows, dtype=torch.float64, device=dev)
-    lib.fill_uniform_f64(x.data_ptr(), rows, SEED, 0, first_row, 0.0, 1.0)
+    g = Gen(torch, lib, dev)
+    x = g.f64(rows, 0, first_row, 0.0, 1.0)
     vptr, vkeep = None, None
     if args.null_fraction > 0:
         vkeep = torch.zeros((rows + 63) // 64 * 8 + 64, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
         lib.fill_validity(vkeep.data_ptr(), rows, SEED, 0, first_row, args.null_fraction)
         vptr = vkeep.data_ptr()
-    col = A.DeviceArray(x.data_ptr(), vptr, 0, rows, A.F64, -1, keep=(x, vkeep))
+    g.done()
+    if args.chunk_rows > 0:
+        cr = args.chunk_rows
+        assert cr % 64 == 0, "--chunk-rows must keep chunk bitmaps 8-byte aligned"
+        col = [A.DeviceArray(x.data_ptr() + 8 * i, (vptr + i // 8) if vptr else None, 0, min(cr, rows - i), A.F64, -1, keep=(x, vkeep))
+               for i in range(0, rows, cr)]
+    else:
+        col = [A.DeviceArray(x.data_ptr(), vptr, 0, rows, A.F64, -1, keep=(x, vkeep))]
 
     e = A.Expr()
     c = e.col(0)
     pred = e.op("gt", c, e.scalar(THRESHOLD))
     def step():
-        local = api.pipeline(e, [[col]], [c], pred)          # fused filter -> {sum,min,max,count}, one pass over HBM
+        local = api.pipeline(e, [col], [c], pred)          # fused filter -> {sum,min,max,count}, one pass over HBM
         tot = sharding.all_combine(local, device=comm_dev)[0]      # N > 1: all_gather the partials (RCCL), fold in rank order
         return tot.sum, tot.count
 
@@ -254,27 +440,32 @@ def main():
         alg_bytes = rows * 8.0 + (rows / 8.0 if vptr else 0.0)   # per launch (one rank's launch)
         avg_kernel_s = kern_ms / max(kern_n, 1) * 1e-3
         achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):   # PMC-derived HBM bytes per launch, measured in a separate rocprofv3 --pmc pass
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
-                if int(tj.get("rows", -1)) == rows and bool(tj.get("validity", False)) == bool(vptr):
+                if int(tj.get("rows", -1)) == rows and bool(tj.get("validity", False)) == bool(vptr) and args.chunk_rows == 0:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (" + str(tj.get("source", "committed profile")) + "), not re-measured in this run"
             except Exception:
                 traffic = None
+        probe = read_probe(torch, x)
         out = {
             "metric": "rows/sec filter+sum over 1e9 f64 Arrow rows; %HBM bw at 1/2/4/8 GPU",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"filter(x>{THRESHOLD})->sum over a {rows:.0e}-row f64 Arrow RecordBatch per GPU, HBM-resident"
-                                   + (f", {args.null_fraction:.0%} nulls (validity bitmap)" if vptr else ", no validity bitmap"),
+                                   + (f", {args.null_fraction:.0%} nulls (validity bitmap)" if vptr else ", no validity bitmap")
+                                   + (f", {len(col)} RecordBatches of {args.chunk_rows} rows" if args.chunk_rows else ""),
                        "rows_per_gpu": rows, "total_rows": total_rows, "selectivity": res[1] / total_rows,
                        "result_sum": res[0], "result_count": res[1], "sharding": "row ranges per rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "peak_measured": probe, "peak_measured_kind": "torch.sum over the same column (stock read-only stream), median of 5",
+                         "frac_of_measured": achieved / probe if probe > 0 else None,
                          "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3, "launches": kern_n,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
@@ -282,11 +473,18 @@ def main():
             sample = min(args.cpu_sample, rows)
             cb = cpu_baseline(sample)
             # not timed: the device result on the same sample prefix agrees with the oracle
-            sub = A.DeviceArray(x.data_ptr(), vptr, 0, sample, A.F64, -1)
             if not vptr:
-                g = api.pipeline(e, [[sub]], [c], pred)[0]
-                ok = g.count == cb["_count"] and abs(g.sum - cb["_sum"]) <= 1e-6 * abs(cb["_sum"])
+                sub = A.DeviceArray(x.data_ptr(), None, 0, sample, A.F64, -1)
+                gq = api.pipeline(e, [[sub]], [c], pred)[0]
+                ok = gq.count == cb["_count"] and abs(gq.sum - cb["_sum"]) <= 1e-6 * abs(cb["_sum"])
                 cb["parity_on_sample"] = bool(ok)
+                # config 1 on the device: the same 977 batches through the C ABI (host buffers in, fused sin(x + 1.0) -> sum)
+                e1 = A.Expr()
+                y = e1.op("sin", e1.op("add", e1.col(0), e1.scalar(1.0)))
+                n1 = min(1_000_000, sample)
+                d1 = [A.DeviceArray(x.data_ptr() + 8 * i, None, 0, min(1024, n1 - i), A.F64, 0) for i in range(0, n1, 1024)]
+                g1 = api.pipeline(e1, [d1], [y])[0]
+                cb["c1"]["parity"] = bool(abs(g1.sum - cb["c1"]["result_sum"]) <= 1e-6 * abs(cb["c1"]["result_sum"]))
             cb.pop("_sum"), cb.pop("_count")
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
@@ -297,7 +495,7 @@ def main():
 def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, world):
     """Same timing contract as the headline, for the other BASELINE.json configurations."""
     rows = args.rows
-    step, alg_bytes, desc = WORKLOADS[args.workload](torch, lib, api, A, sharding, dev, comm_dev, rank, rows)
+    step, alg_bytes, desc, check = WORKLOADS[args.workload](torch, lib, api, A, sharding, dev, comm_dev, rank, rows)
 
     def sync():
         torch.cuda.synchronize()
@@ -325,19 +523,27 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    chk = check(res, world)     # untimed; collective when N > 1 (every rank takes part)
+    if world > 1:
         dist.destroy_process_group()
     if rank == 0:
         per_launch_s = kern_ms / max(kern_n, 1) * 1e-3 * (kern_n / args.steps if kern_n else 0)   # all timed kernels of one step
         achieved = alg_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-        print(json.dumps({
+        cb = chk.pop("cpu_baseline", None)
+        line = {
             "metric": f"rows/sec {args.workload}", "value": rows * world * args.steps / elapsed, "unit": "rows/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "rows_per_gpu": rows, "total_rows": rows * world, "result": res},
+            "config": {"workload": desc, "rows_per_gpu": rows, "total_rows": rows * world, "result": res, **chk},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": kernel_name, "kernel_ms_per_step": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes},
-        }), flush=True)
+        }
+        if cb is not None:
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+        if not chk.get("self_check", False) or chk.get("parity_on_sample") is False:
+            sys.exit(f"bench.py --workload {args.workload}: result check FAILED: {chk}")
 
 
 if __name__ == "__main__":

@@ -250,7 +250,46 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
  * max_groups distinct keys -> RDF_MEMORY_ERROR.  f64 sums are accumulated with hardware atomics:
  * the rounding order is not deterministic (within 1e-6 relative of any sequential order). */
 rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,
-                           rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts);
+                           rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts);   /* = rdf_groupby_agg(keys, 1, values, ..., RDF_AGG_SUM, ...) */
+
+/* AggregateFunction (src/expression.rs:696-711).  Avg is Sum / Count on the caller's side (AggregateFunctions::avg,
+ * src/functions/aggregate.rs:32-65). */
+typedef enum { RDF_AGG_SUM = 0, RDF_AGG_MIN = 1, RDF_AGG_MAX = 2, RDF_AGG_COUNT = 3 } rdf_agg_fn;
+
+#define RDF_MAX_GROUP_KEYS 4
+
+/* Transformation::GroupAggregate(groups, [aggregation]) for 1..RDF_MAX_GROUP_KEYS integer grouping columns and ONE
+ * aggregation of one value column (Dataset::try_aggregate, src/expression.rs:114-221, plans a list of them: one call
+ * each; the reference never executes the step, src/evaluation.rs:73 panics — SQL semantics, parity unpinned by the
+ * reference).  keys[k * nchunks + i] = chunk i of grouping column k; a NULL in a grouping column is a group value of
+ * its own; NULL values are skipped; counts[g] = non-NULL values of group g (rows, for RDF_AGG_COUNT / values == NULL).
+ * out_keys: nkeys one-chunk outputs (key dtypes; validity required for a nullable grouping column);
+ * out_values: Float64 for float values, UInt64 for MIN / MAX of UInt64 values, Int64 otherwise (sums wrap);
+ *   MIN / MAX of a group without a non-NULL value is NULL (validity required when the value column is nullable);
+ *   NaN never wins a MIN / MAX unless every value of the group is NaN (the column aggregates' rule, rdf_min / rdf_max);
+ * out_counts: Int64.  Capacities >= min(max_groups, rows) + 2; group order unspecified.  More than max_groups distinct key
+ * tuples -> RDF_MEMORY_ERROR.  Several grouping columns are packed into one 64-bit key after range compression
+ * (bits(max - min) per column, + 1 code for NULL): tuples needing more than 64 bits -> RDF_INVALID_ARGUMENT.
+ * f64 sums are accumulated with hardware atomics: the rounding order is not deterministic (<= 1e-6 relative). */
+rdf_status rdf_groupby_agg(const rdf_array* keys, int32_t nkeys, const rdf_array* values, int64_t nchunks, int32_t agg,
+                           int64_t max_groups, rdf_out* out_keys, rdf_out* out_values, rdf_out* out_counts);
+
+/* Merge of partial groups: (key, partial aggregate, count) triples -> one row per key, partials combined by `agg`
+ * (sums added, minima / maxima compared, counts added).  What a rank does with the partial groups it receives in the
+ * multi-GPU GROUP BY (replaces the panic! at src/evaluation.rs:73 for RecordBatches sharded over GPUs).
+ * One chunk each: keys Int64 / UInt64, partial Float64 / Int64 / UInt64 (may be NULL for counts only), counts Int64;
+ * a partial with count 0 (or a NULL one) contributes nothing but its key.  Outputs as rdf_groupby_agg. */
+rdf_status rdf_groupby_merge(const rdf_array* keys, const rdf_array* partial, const rdf_array* counts, int32_t agg,
+                             int64_t max_groups, rdf_out* out_keys, rdf_out* out_values, rdf_out* out_counts);
+
+/* The exchange itself, device-resident: rows (key, partial, count) of this rank's local groups are bucketed by owning
+ * rank, owner = ((key * 0x9E3779B97F4A7C15) >> 33) % world, into `packed_dev` — n rows of 3 x 64-bit words, the rows of
+ * owner 0 first — and owner_counts[r] (host) receives the number of rows for rank r: exactly the send buffer and split
+ * sizes of an all_to_all(v) (RCCL over xGMI on the GPU box).  _unpack splits a received buffer back into three columns
+ * for rdf_groupby_merge.  RDF_MEM_DEVICE only; 8-byte key and partial dtypes; no NULL keys. */
+rdf_status rdf_group_exchange_pack(const rdf_array* keys, const rdf_array* partial, const rdf_array* counts, int32_t world,
+                                   void* packed_dev, int64_t* owner_counts);
+rdf_status rdf_group_exchange_unpack(const void* packed_dev, int64_t n, rdf_out* keys, rdf_out* partial, rdf_out* counts);
 
 /* ------------------------------------------------------------------ ArrayFunctions over List<primitive> columns */
 
@@ -385,8 +424,10 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
 
 /* Per-thread tunables, for tests and ablations: "spec" (1 = use the ahead-of-time specialised kernels
  * when the program shape is in the catalogs, default; 0 = always the general evaluator), "fast_filter",
- * "vec_bitmap" (bitmap words through the vector / scalar memory path), "gb_partition" (hash GROUP BY above 1024
- * groups: 1 = single scatter pass + LDS tables, default; 2 = radix-sort partitioning; 0 = one table in HBM),
+ * "vec_bitmap" (bitmap words through the vector / scalar memory path), "gb_partition" (hash GROUP BY: 3 = second
+ * generation, default: LDS-table stream <= 2048 groups, line-aligned scatter + LDS tables <= 1.3 M, else one table in HBM;
+ * 4 = its scatter path whatever max_groups says; 1 = first-generation histogram + scatter; 2 = radix-sort partitioning;
+ * 0 = one table in HBM),
  * "gb_debug" (1 / 2: ablations of the aggregate / scatter pass, results invalid; 3: force the skew variant),
  * "filter_tile" (0: compaction tile from the mean chunk length; 1024 / 4096 force one), "filter_one" (one-chunk
  * compaction kernel with kernel-argument descriptors, default on). */

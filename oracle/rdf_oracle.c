@@ -1505,6 +1505,136 @@ rdf_status ora_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
     return st;
 }
 
+/* GroupAggregate(groups, [Sum | Min | Max | Count]) over 1..4 grouping columns (AggregateFunction, src/expression.rs:696-711;
+ * planned by Dataset::try_aggregate :114-221, never executed: PARITY UNPINNED BY THE REFERENCE).  SQL semantics with a
+ * sequential scan: a NULL in a grouping column is a value of its own, NULL values are skipped, MIN / MAX of a group
+ * without a non-NULL value is NULL, NaN loses against every number (the rule of ora_min / ora_max).  Groups in first-seen order. */
+static rdf_status groupby_generic(const rdf_array* keys, int32_t nkeys, const rdf_array* values, const rdf_array* weights,
+                                  int64_t nchunks, int32_t agg, int64_t max_groups,
+                                  rdf_out* out_keys, rdf_out* out_values, rdf_out* out_counts) {
+    if (nchunks < 1) FAIL(RDF_INVALID_ARGUMENT, "groupby: a column has at least one chunk");
+    if (nkeys < 1 || nkeys > RDF_MAX_GROUP_KEYS) FAIL(RDF_INVALID_ARGUMENT, "groupby: 1..4 grouping columns");
+    if (agg < RDF_AGG_SUM || agg > RDF_AGG_COUNT) FAIL(RDF_INVALID_ARGUMENT, "groupby: unknown aggregate");
+    if (agg == RDF_AGG_COUNT) values = NULL; else if (!values) agg = RDF_AGG_COUNT;
+    for (int k = 0; k < nkeys; k++) {
+        int kdt = keys[(int64_t)k * nchunks].dtype;
+        if (!(kdt >= RDF_I8 && kdt <= RDF_U64)) FAIL(RDF_INVALID_ARGUMENT, "groupby: integer key column required");
+    }
+    int vdt = values ? values[0].dtype : -1;
+    if (values && !is_numeric(vdt)) FAIL(RDF_INVALID_ARGUMENT, "groupby: numeric value column required");
+    int fval = values && is_float(vdt), uval = values && vdt == RDF_U64;
+    int64_t cap = 1024;
+    while (cap < 4 * (max_groups + 2)) cap <<= 1;
+    int64_t G = max_groups + 2;
+    int64_t* slot_of = (int64_t*)malloc(sizeof(int64_t) * (size_t)cap);
+    int64_t* gkey = (int64_t*)malloc(sizeof(int64_t) * (size_t)G * (size_t)nkeys);
+    uint8_t* gnull = (uint8_t*)calloc((size_t)G * (size_t)nkeys, 1);
+    double* gf = (double*)calloc((size_t)G, sizeof(double));
+    uint64_t* gi = (uint64_t*)calloc((size_t)G, sizeof(uint64_t));
+    int64_t* gcnt = (int64_t*)calloc((size_t)G, sizeof(int64_t));
+    uint8_t* ghas = (uint8_t*)calloc((size_t)G, 1);   /* MIN / MAX: a non-NaN value has been seen */
+    if (!slot_of || !gkey || !gnull || !gf || !gi || !gcnt || !ghas) FAIL(RDF_MEMORY_ERROR, "out of memory");
+    for (int64_t i = 0; i < cap; i++) slot_of[i] = -1;
+    int64_t ng = 0;
+    rdf_status st = RDF_OK;
+    for (int64_t c = 0; c < nchunks && st == RDF_OK; c++) {
+        int64_t len = keys[c].length;
+        for (int k = 1; k < nkeys; k++) if (keys[(int64_t)k * nchunks + c].length != len) { st = RDF_COMPUTE_ERROR; snprintf(g_err, sizeof g_err, "groupby: grouping columns differ in length"); }
+        if (values && values[c].length != len) { st = RDF_COMPUTE_ERROR; snprintf(g_err, sizeof g_err, "groupby: key and value chunks differ in length"); }
+        if (weights && weights[c].length != len) { st = RDF_COMPUTE_ERROR; snprintf(g_err, sizeof g_err, "groupby_merge: arrays differ in length"); }
+        if (st != RDF_OK) break;
+        for (int64_t i = 0; i < len; i++) {
+            int64_t kv[RDF_MAX_GROUP_KEYS]; uint8_t kn[RDF_MAX_GROUP_KEYS];
+            uint64_t h = 0x9E3779B97F4A7C15ULL;
+            for (int k = 0; k < nkeys; k++) {
+                const rdf_array* ka = &keys[(int64_t)k * nchunks + c];
+                kn[k] = !arr_valid(ka, i);
+                kv[k] = kn[k] ? 0 : key_at(ka, i);
+                h = (h ^ (uint64_t)kv[k] ^ ((uint64_t)kn[k] << 63)) * 0xBF58476D1CE4E5B9ULL;
+                h ^= h >> 29;
+            }
+            int64_t s = (int64_t)(h & (uint64_t)(cap - 1));
+            for (;;) {
+                int64_t g0 = slot_of[s];
+                if (g0 < 0) break;
+                int same = 1;
+                for (int k = 0; k < nkeys; k++) if (gkey[g0 * nkeys + k] != kv[k] || gnull[g0 * nkeys + k] != kn[k]) same = 0;
+                if (same) break;
+                s = (s + 1) & (cap - 1);
+            }
+            if (slot_of[s] < 0) {
+                if (ng >= G) { st = RDF_MEMORY_ERROR; snprintf(g_err, sizeof g_err, "groupby: more than max_groups distinct keys"); break; }
+                slot_of[s] = ng;
+                for (int k = 0; k < nkeys; k++) { gkey[ng * nkeys + k] = kv[k]; gnull[ng * nkeys + k] = kn[k]; }
+                ng++;
+            }
+            int64_t g = slot_of[s];
+            int64_t w = weights ? ((const int64_t*)weights[c].values)[weights[c].offset + i] : 1;
+            if (!values) { gcnt[g] += w; continue; }
+            if (!arr_valid(&values[c], i) || w == 0) continue;
+            gcnt[g] += w;
+            if (agg == RDF_AGG_SUM) {
+                if (fval) gf[g] += arr_f64(&values[c], i); else gi[g] += (uint64_t)key_at(&values[c], i);
+            } else if (fval) {
+                double v = arr_f64(&values[c], i);
+                if (v != v) continue;
+                if (!ghas[g] || (agg == RDF_AGG_MIN ? v < gf[g] : v > gf[g])) gf[g] = v;
+                ghas[g] = 1;
+            } else if (uval) {
+                uint64_t v = ((const uint64_t*)values[c].values)[values[c].offset + i];
+                if (!ghas[g] || (agg == RDF_AGG_MIN ? v < gi[g] : v > gi[g])) gi[g] = v;
+                ghas[g] = 1;
+            } else {
+                int64_t v = key_at(&values[c], i);
+                if (!ghas[g] || (agg == RDF_AGG_MIN ? v < (int64_t)gi[g] : v > (int64_t)gi[g])) gi[g] = (uint64_t)v;
+                ghas[g] = 1;
+            }
+        }
+    }
+    if (st == RDF_OK && ng > max_groups + 2) { st = RDF_MEMORY_ERROR; snprintf(g_err, sizeof g_err, "groupby: more than max_groups distinct keys"); }
+    for (int k = 0; k < nkeys && st == RDF_OK; k++) if (out_keys[k].capacity < ng) { st = RDF_MEMORY_ERROR; snprintf(g_err, sizeof g_err, "output capacity too small"); }
+    if (st == RDF_OK && (out_values->capacity < ng || out_counts->capacity < ng)) { st = RDF_MEMORY_ERROR; snprintf(g_err, sizeof g_err, "output capacity too small"); }
+    if (st == RDF_OK) {
+        for (int k = 0; k < nkeys; k++) out_begin(&out_keys[k], ng);
+        out_begin(out_values, ng); out_begin(out_counts, ng);
+        for (int64_t g = 0; g < ng && st == RDF_OK; g++) {
+            for (int k = 0; k < nkeys; k++) {
+                int es = dtype_size(out_keys[k].dtype);
+                uint64_t kvv = (uint64_t)gkey[g * nkeys + k];
+                memcpy((char*)out_keys[k].values + g * es, &kvv, (size_t)es);
+                if (gnull[g * nkeys + k]) {
+                    if (!out_keys[k].validity) { st = RDF_INVALID_ARGUMENT; snprintf(g_err, sizeof g_err, "output validity buffer required"); break; }
+                    out_null(&out_keys[k], g);
+                }
+            }
+            if (st != RDF_OK) break;
+            if (agg == RDF_AGG_MIN || agg == RDF_AGG_MAX) {
+                if (gcnt[g] == 0) {
+                    if (!out_values->validity) { st = RDF_INVALID_ARGUMENT; snprintf(g_err, sizeof g_err, "output validity buffer required"); break; }
+                    ((uint64_t*)out_values->values)[g] = 0;
+                    out_null(out_values, g);
+                } else if (fval) ((double*)out_values->values)[g] = ghas[g] ? gf[g] : (double)NAN;
+                else ((uint64_t*)out_values->values)[g] = gi[g];
+            } else if (fval) ((double*)out_values->values)[g] = gf[g];
+            else ((int64_t*)out_values->values)[g] = (int64_t)gi[g];
+            ((int64_t*)out_counts->values)[g] = gcnt[g];
+        }
+    }
+    free(slot_of); free(gkey); free(gnull); free(gf); free(gi); free(gcnt); free(ghas);
+    return st;
+}
+rdf_status ora_groupby_agg(const rdf_array* keys, int32_t nkeys, const rdf_array* values, int64_t nchunks, int32_t agg, int64_t max_groups,
+                           rdf_out* out_keys, rdf_out* out_values, rdf_out* out_counts) {
+    return groupby_generic(keys, nkeys, values, NULL, nchunks, agg, max_groups, out_keys, out_values, out_counts);
+}
+/* merge of partial groups: the same scan with the partial's count as the row's weight (a partial with count 0 only
+ * contributes its key) */
+rdf_status ora_groupby_merge(const rdf_array* keys, const rdf_array* partial, const rdf_array* counts, int32_t agg, int64_t max_groups,
+                             rdf_out* out_keys, rdf_out* out_values, rdf_out* out_counts) {
+    if (!counts || counts->dtype != RDF_I64) FAIL(RDF_INVALID_ARGUMENT, "groupby_merge: counts are Int64");
+    return groupby_generic(keys, 1, partial, counts, 1, partial ? agg : RDF_AGG_COUNT, max_groups, out_keys, out_values, out_counts);
+}
+
 /* ------------------------------------------------------------------ synthetic data
  * Counter-based generator shared (by restating the same few lines) with the device fill kernels:
  * SplitMix64 finaliser over (seed, column_id, row). */

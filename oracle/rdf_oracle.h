@@ -59,6 +59,11 @@ rdf_status ora_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
 rdf_status ora_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,
                            rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts);
 
+rdf_status ora_groupby_agg(const rdf_array* keys, int32_t nkeys, const rdf_array* values, int64_t nchunks, int32_t agg, int64_t max_groups,
+                           rdf_out* out_keys, rdf_out* out_values, rdf_out* out_counts);
+rdf_status ora_groupby_merge(const rdf_array* keys, const rdf_array* partial, const rdf_array* counts, int32_t agg, int64_t max_groups,
+                             rdf_out* out_keys, rdf_out* out_values, rdf_out* out_counts);
+
 rdf_status ora_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks,
                         rdf_out* outs, rdf_agg_result* aggs);
 

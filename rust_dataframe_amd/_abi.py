@@ -360,7 +360,7 @@ class Api:
         self._err = getattr(lib, prefix + "last_error")
         self._err.restype = C.c_char_p
         for name in ("binary", "unary", "cast", "hour", "sum", "min", "max", "count", "avg", "predicate", "filter_count",
-                     "filter", "filter_columns", "take", "pipeline", "group_pipeline", "groupby_sum", "list_contains", "list_position", "list_max", "list_min", "list_remove", "list_sort", "list_distinct", "list_except", "list_intersect", "list_union", "list_repeat", "sort_to_indices", "equijoin_indices", "equijoin_indices_multi", "fill_uniform_f64",
+                     "filter", "filter_columns", "take", "pipeline", "group_pipeline", "groupby_sum", "groupby_agg", "groupby_merge", "list_contains", "list_position", "list_max", "list_min", "list_remove", "list_sort", "list_distinct", "list_except", "list_intersect", "list_union", "list_repeat", "sort_to_indices", "equijoin_indices", "equijoin_indices_multi", "fill_uniform_f64",
                      "fill_uniform_i64", "fill_validity"):
             fn = getattr(lib, prefix + name)
             fn.restype = C.c_int
@@ -599,6 +599,71 @@ class Api:
             o.length = cc[0].length
             o.null_count = cc[0].null_count
         return outs
+
+    AGGS = {"sum": 0, "min": 1, "max": 2, "count": 3}
+
+    @staticmethod
+    def _agg_out_dtype(agg: int, vdt) -> int:
+        if vdt is None:
+            return I64
+        if vdt in (F32, F64):
+            return F64
+        return U64 if (agg in (1, 2) and vdt == U64) else I64
+
+    def groupby_agg(self, key_cols: Sequence[Sequence], values: Optional[Sequence], agg, max_groups: int, outs=None):
+        """GroupAggregate(groups, [agg]) over 1..4 grouping columns: key_cols[k][chunk].  -> ([key arrays], values, counts)."""
+        code = self.AGGS[agg] if isinstance(agg, str) else int(agg)
+        nk, n = len(key_cols), len(key_cols[0])
+        vdt = values[0].dtype if values is not None and code != 3 else None
+        if outs is None:
+            cap = max_groups + 2
+            nullable_v = values is not None and any(v.validity is not None for v in values)
+            outs = ([HostArray.empty_out(col[0].dtype, cap, any(k.validity is not None for k in col)) for col in key_cols],
+                    HostArray.empty_out(self._agg_out_dtype(code, vdt), cap, nullable_v and code in (1, 2)), HostArray.empty_out(I64, cap, False))
+        ok, ov, oc = outs
+        ck = (rdf_out * nk)(*[o.out_struct() for o in ok])
+        cv, cc = (rdf_out * 1)(ov.out_struct()), (rdf_out * 1)(oc.out_struct())
+        cvals = _flat([values], n) if values is not None else None
+        self._check(self._fn("groupby_agg")(_flat(key_cols, n), C.c_int32(nk), cvals, C.c_int64(n), C.c_int32(code), C.c_int64(max_groups), ck, cv, cc))
+        for i, o in enumerate(ok):
+            o.length, o.null_count = ck[i].length, ck[i].null_count
+        ov.length, ov.null_count = cv[0].length, cv[0].null_count
+        oc.length, oc.null_count = cc[0].length, cc[0].null_count
+        return ok, ov, oc
+
+    def groupby_merge(self, keys, partial, counts, agg, max_groups: int, outs=None):
+        """(key, partial aggregate, count) triples (one array each) -> one row per key.  -> (keys, values, counts)."""
+        code = self.AGGS[agg] if isinstance(agg, str) else int(agg)
+        if outs is None:
+            cap = max_groups + 2
+            outs = (HostArray.empty_out(keys.dtype, cap, keys.validity is not None),
+                    HostArray.empty_out(partial.dtype if partial is not None else I64, cap, code in (1, 2)), HostArray.empty_out(I64, cap, False))
+        carr = [(rdf_out * 1)(o.out_struct()) for o in outs]
+        ck = (rdf_array * 1)(keys.c_struct())
+        cp = (rdf_array * 1)(partial.c_struct()) if partial is not None else None
+        cc = (rdf_array * 1)(counts.c_struct())
+        self._check(self._fn("groupby_merge")(ck, cp, cc, C.c_int32(code), C.c_int64(max_groups), carr[0], carr[1], carr[2]))
+        for o, c_ in zip(outs, carr):
+            o.length, o.null_count = c_[0].length, c_[0].null_count
+        return outs
+
+    def group_exchange_pack(self, keys, partial, counts, world: int, packed_ptr: int) -> List[int]:
+        """Device-resident partial groups -> `packed_ptr` ([n][3] int64 words grouped by owning rank); returns rows per rank."""
+        oc = (C.c_int64 * world)()
+        fn = self._fn("group_exchange_pack")
+        fn.restype = C.c_int
+        self._check(fn((rdf_array * 1)(keys.c_struct()), (rdf_array * 1)(partial.c_struct()), (rdf_array * 1)(counts.c_struct()),
+                       C.c_int32(world), C.c_void_p(packed_ptr), oc))
+        return [oc[r] for r in range(world)]
+
+    def group_exchange_unpack(self, packed_ptr: int, n: int, keys, partial, counts):
+        fn = self._fn("group_exchange_unpack")
+        fn.restype = C.c_int
+        carr = [(rdf_out * 1)(o.out_struct()) for o in (keys, partial, counts)]
+        self._check(fn(C.c_void_p(packed_ptr), C.c_int64(n), carr[0], carr[1], carr[2]))
+        for o in (keys, partial, counts):
+            o.length = n
+        return keys, partial, counts
 
     # ---- ArrayFunctions over List<primitive> (src/functions/array.rs)
     def _scalar(self, value, dtype: int):

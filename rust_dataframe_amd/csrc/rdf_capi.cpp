@@ -48,7 +48,7 @@ struct Ctx {
     bool   opt_filter_one = true;   // one-chunk compaction kernel with its descriptors in the kernel arguments (A/B)
     int    opt_filter_tile = 0;     // 0: compaction tile chosen from the mean chunk length; 1024 / 4096 force one (A/B)
     int    opt_gb_debug = 0;        // ablations of the partitioned GROUP BY (tools/bench_kernels.py): 1 = aggregate without LDS work, 2 = scatter without stores
-    int    opt_gb_partition = 1;    // high-cardinality GROUP BY: 1 = single scatter pass + LDS tables (default), 2 = the radix-sort based two-pass variant, 0 = HBM atomics // bitmap words via vector loads instead of scalar loads (spec kernels)
+    int    opt_gb_partition = 3;    // hash GROUP BY: 3 = second generation (rdf_groupby.hip: stream / line-aligned scatter / table by max_groups, default), 4 = its partition path whatever max_groups says, 1 = first-generation histogram + scatter, 2 = first-generation radix sort, 0 = one table in HBM
     // kernel timing (bench.py roofline leg)
     bool   timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -2667,8 +2667,13 @@ static rdf_status groupby_finish_partitioned(void* pspec, void* d_keys, void* d_
     return RDF_OK;
 }
 
-rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,
-                           rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts) {
+}  // extern "C"
+namespace {
+// The first-generation hash GROUP BY (sum / count of one key column): histogram -> scatter (with the combining variant for
+// skewed keys) -> aggregate, the radix-sort variant and the single HBM table.  Since round 2 the default is rdf_groupby_agg
+// (rdf_capi_groupby.inc); this stays as its fallback for heavily skewed keys and as the A/B baseline (gb_partition = 1 / 2).
+rdf_status legacy_groupby_sum(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int64_t max_groups,
+                              rdf_out* out_keys, rdf_out* out_sums, rdf_out* out_counts) {
     if (nchunks < 1 || !keys) return fail(RDF_INVALID_ARGUMENT, "groupby: a column has at least one chunk");
     if (!out_keys || !out_sums || !out_counts) return fail(RDF_INVALID_ARGUMENT, "groupby: null output");
     if (max_groups < 1) return fail(RDF_INVALID_ARGUMENT, "groupby: max_groups must be positive");
@@ -2972,6 +2977,11 @@ rdf_status rdf_groupby_sum(const rdf_array* keys, const rdf_array* values, int64
     if (mem == RDF_MEM_DEVICE) HIP_TRY(hipStreamSynchronize(ctx.stream));
     return RDF_OK;
 }
+}  // namespace
+
+#include "rdf_capi_groupby.inc"
+
+extern "C" {
 
 // ---------------------------------------------------------------- synthetic data / timing
 

@@ -329,6 +329,100 @@ struct GroupEmitArgs {
     int32_t    key_dtype;
 };
 
+// ---- second-generation GROUP BY (rdf_groupby.hip): sum / min / max per group, no histogram pass ----
+enum : int32_t { AGG_SUM = 0, AGG_MIN = 1, AGG_MAX = 2 };
+// MIN / MAX accumulate order-preserving 64-bit images of the values (ord_bits): unsigned atomic min / max then serve every
+// value class; the identity (~0 for MIN, 0 for MAX) is what a NULL or NaN value contributes.
+constexpr int kG2Block = 1024;                      // scatter: one block of 16 waves per CU (140 KB of LDS)
+constexpr int kG2Rows = 4;                          // rows per thread per super-tile
+constexpr int kG2Super = kG2Block * kG2Rows;        // 4096 rows = 4 tiles of kEvalTile rows
+constexpr int kG2Line = 8;                          // records per 128-byte line: the only unit ever written
+constexpr int kG2StreamGroups = 2048;               // up to here one LDS table per block holds every group (gb2_stream_kernel)
+struct Gb2Args {
+    const DevChunkCol* keys;             // [nchunks]
+    const DevChunkCol* values;           // [nchunks]
+    const int64_t*     chunk_tile_start; // [nchunks + 1], tiles of kEvalTile rows
+    const int64_t*     chunk_len;
+    int64_t            nchunks, ntiles;
+    DevChunkCol        key0, val0;       // nchunks == 1: descriptors inline
+    int64_t            len0;
+    int32_t            key_dtype, value_dtype;   // value_dtype < 0: count rows
+    int32_t            op, vcls;         // AGG_*, CLS_* of the accumulator
+    // scatter output: region (partition p, block b) = lines [(p * nb + b) * cap_lines, +nlines[p * nb + b])
+    uint64_t*          recs;
+    uint32_t*          nlines;           // [P * nb]
+    int64_t            cap_lines;
+    unsigned long long* special_sums;    // [2]: the key whose hash is the LDS free marker / the NULL key
+    unsigned long long* special_counts;  // [2]
+    unsigned int*      special;          // [2] group exists
+    uint32_t*          flags;            // bit 2: more groups than promised; bit 4: a region overflowed (skewed keys)
+    // stream kernel: the global table the block tables are merged into
+    GroupTable         t;
+    int32_t            replicas, sub_slots;   // LDS table = replicas sub-tables of sub_slots slots (lane % replicas picks one)
+};
+struct Gb2AggArgs {
+    const uint64_t* recs;
+    const uint32_t* nlines;              // [P * nb]
+    int64_t         nb, cap_lines;
+    int32_t         op, vcls, has_values, key_dtype;
+    void*           out_keys; uint64_t* out_acc; int64_t* out_counts;   // dense, raw accumulators (gb2_finish_kernel converts)
+    unsigned int*   cursor;
+    uint32_t*       flags;
+    int64_t         max_out;
+};
+// (key, accumulator, count) triples -> global table: the merge of partial groups (multi-GPU exchange) and the path for
+// more groups than LDS tables hold
+struct Gb2MergeArgs {
+    const uint64_t* keys; const uint64_t* acc; const int64_t* counts;   // [n] raw 64-bit keys, accumulators in table form (ord bits for MIN / MAX)
+    const uint8_t*  key_validity;        // bit i = 0: row i belongs to the NULL-key group (nullptr: none)
+    int64_t         n;
+    int32_t         op, vcls;
+    GroupTable      t;
+};
+struct Gb2FinishArgs {                    // raw accumulators -> output values (+ validity for MIN / MAX of all-NULL groups)
+    uint64_t*       acc; const int64_t* counts;
+    uint8_t*        validity;            // may be nullptr
+    int64_t         n;
+    int32_t         op, vcls, native_in; // native_in: acc holds native bits to be turned INTO table form (the merge's input side)
+    unsigned long long* nulls;           // out: groups whose value is NULL
+};
+// multi-GPU exchange of partial groups: rows -> owner = hash(key) % world, packed [n][3] words grouped by owner
+struct GxPackArgs {
+    const uint64_t* keys; const uint64_t* acc; const int64_t* counts;
+    int64_t         n;
+    int32_t         world, phase;        // phase 0: count rows per owner; 1: scatter to offsets
+    unsigned long long* owner_counts;    // [world]
+    unsigned long long* cursors;         // [world] running write positions (start = exclusive scan of owner_counts)
+    uint64_t*       packed;              // [n * 3]
+};
+// several key columns <-> one packed 64-bit key (range-compressed fields; code 0 of a nullable field = NULL)
+constexpr int kMaxKeyCols = 4;
+struct KeyPackArgs {
+    const DevChunkCol* cols;             // [nkeys * nchunks]
+    const int64_t*     chunk_row_start;  // [nchunks + 1]
+    int64_t            nchunks, n;
+    int32_t            nkeys;
+    int32_t            dtype[kMaxKeyCols], shift[kMaxKeyCols], nullable[kMaxKeyCols];
+    uint64_t           bias[kMaxKeyCols], mask[kMaxKeyCols];   // field = ((order-preserving bits - bias) + nullable) << shift
+    uint64_t*          packed;           // pack: out [n]; unpack: in [n]
+    void*              out_values[kMaxKeyCols];   // unpack: dense outputs
+    uint8_t*           out_validity[kMaxKeyCols];
+    unsigned long long* out_nulls;       // unpack: [nkeys] null counts
+};
+hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s);
+hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s);
+hipError_t launch_gb2_aggregate(const Gb2AggArgs& a, hipStream_t s);
+hipError_t launch_gb2_merge(const Gb2MergeArgs& a, hipStream_t s);
+hipError_t launch_gb2_table_rows(const Gb2Args& a, hipStream_t s);
+hipError_t launch_gb2_emit(const GroupEmitArgs& a, hipStream_t s);
+hipError_t launch_gb2_finish(const Gb2FinishArgs& a, hipStream_t s);
+hipError_t launch_gb2_fill(uint64_t* p, int64_t n, uint64_t v, hipStream_t s);
+hipError_t launch_gx_pack(const GxPackArgs& a, hipStream_t s);
+hipError_t launch_gx_unpack(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts, hipStream_t s);
+hipError_t launch_key_pack(const KeyPackArgs& a, hipStream_t s);
+hipError_t launch_key_unpack(const KeyPackArgs& a, hipStream_t s);
+size_t gb2_scatter_lds_bytes();
+
 struct TakeArgs {
     const DevChunkCol* chunks;           // [nchunks]
     const int64_t*     chunk_row_start;  // [nchunks + 1]

@@ -1,0 +1,767 @@
+// rdf_groupby.hip — hash GROUP BY key -> {sum | min | max, count}, second generation.
+//
+//   Transformation::GroupAggregate(groups, [AggregateFunction::{Sum, Min, Max, Count, Avg}]) is planned by
+//   Dataset::try_aggregate (src/expression.rs:114-221, :696-711) and never executed by the reference
+//   (src/evaluation.rs:73 panics): SQL semantics, parity unpinned by the reference.
+//
+// Three shapes, chosen by the promised number of groups:
+//   gb2_stream_kernel     <= 2048 groups: every block folds its rows straight from the columns into an LDS table
+//                         (the probe loop of the partition aggregation, fed by 16-byte-record-free column loads) and
+//                         merges its few groups into the global table once.
+//   gb2_scatter_kernel -> gb2_aggregate_kernel   <= 1.3 M groups: ONE scatter pass on the top 9 bits of an invertible
+//                         hash, NO histogram pass: every (partition, block) owns a fixed-capacity region and the block
+//                         writes nothing but whole, aligned 128-byte lines (8 records) — a partition's records wait in an
+//                         LDS carry until a line is full.  Measured on MI355X (tools/ubench_scatter.hip): aligned 128-byte
+//                         lines to 131 072 streams go out at 5.4-5.5 TB/s, the unaligned runs of the first-generation
+//                         scatter at 2.5-2.9.  Traffic: 16 (read) + 16 (lines) + 16 (aggregate) = 48 B/row.
+//                         A region that overflows (heavily skewed keys) sets a flag and the host re-runs the
+//                         first-generation histogram + combining path (rdf_kernels.hip).
+//   gb2_table_rows_kernel / gb2_merge_kernel   any number of groups: one open-addressing table in HBM, 64-bit CAS +
+//                         hardware atomics; also the merge step of the multi-GPU exchange of partial groups.
+#include "rdf_common.hip.h"
+
+namespace rdfk {
+
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kP = 1 << kGbPartBits;                 // 512 partitions
+constexpr unsigned long long kFree = ~0ull;          // LDS free marker in hashed-key space
+constexpr uint64_t kKeyMask = (1ull << (64 - kGbPartBits)) - 1;
+constexpr uint64_t kDead = ~0ull;
+constexpr int kMaxFlushLines = 1024;                 // >= (7 * kP + kG2Super) / 8 = 960
+
+__device__ __forceinline__ uint64_t g2_hash(uint64_t x) { x ^= x >> 32; x *= 0x9E3779B97F4A7C15ull; return x ^ (x >> 32); }
+__device__ __forceinline__ uint64_t g2_unhash(uint64_t x) { x ^= x >> 32; x *= 0xF1DE83E19937733Dull; return x ^ (x >> 32); }
+__device__ __forceinline__ uint64_t mix64b(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// order-preserving 64-bit image of a value of class `cls` (unsigned compare == the class's compare; IEEE total order for f64)
+__device__ __forceinline__ uint64_t ord_bits(int cls, uint64_t b) {
+    if (cls == CLS_F64) return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    if (cls == CLS_SIGNED) return b ^ 0x8000000000000000ull;
+    return b;
+}
+__device__ __forceinline__ uint64_t unord_bits(int cls, uint64_t o) {
+    if (cls == CLS_F64) return (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o;
+    if (cls == CLS_SIGNED) return o ^ 0x8000000000000000ull;
+    return o;
+}
+__device__ __forceinline__ uint64_t agg_identity(int op) { return op == AGG_MIN ? ~0ull : 0ull; }
+
+// what a row contributes to its group's accumulator, in table form
+__device__ __forceinline__ uint64_t to_table_form(int op, int cls, uint64_t native_bits, bool is_null) {
+    if (op == AGG_SUM) return is_null ? 0ull : native_bits;
+    if (is_null) return agg_identity(op);
+    if (cls == CLS_F64) { const double d = u2d(native_bits); if (d != d) return agg_identity(op); }   // NaN never wins (the column aggregates' rule)
+    return ord_bits(cls, native_bits);
+}
+
+template <class P>
+__device__ __forceinline__ void acc_apply(P* p, int op, int cls, uint64_t v) {
+    if (op == AGG_SUM) {
+        if (cls == CLS_F64) unsafeAtomicAdd((double*)p, u2d(v)); else atomicAdd(p, (unsigned long long)v);
+    } else if (op == AGG_MIN) atomicMin(p, (unsigned long long)v);
+    else atomicMax(p, (unsigned long long)v);
+}
+
+__device__ __forceinline__ int g2_dtype_size(int dt) {
+    switch (dt) {
+        case RDF_I8: case RDF_U8: return 1;
+        case RDF_I16: case RDF_U16: return 2;
+        case RDF_I32: case RDF_U32: case RDF_F32: return 4;
+        default: return 8;
+    }
+}
+__device__ __forceinline__ uint64_t g2_load_raw(const void* base, int size, int64_t idx, bool pred) {
+    uint64_t x = 0;
+    if (size == 8) { if (pred) x = __builtin_nontemporal_load(as_global<uint64_t>(base) + idx); }
+    else if (size == 4) { if (pred) x = __builtin_nontemporal_load(as_global<uint32_t>(base) + idx); }
+    else if (size == 2) { if (pred) x = as_global<uint16_t>(base)[idx]; }
+    else { if (pred) x = as_global<uint8_t>(base)[idx]; }
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows of one super-tile: thread t holds row t of each of NT consecutive tiles of kEvalTile rows (a tile lies inside one chunk)
+
+template <int NT>
+struct G2Raw {
+    uint64_t key[NT], val[NT];
+    uint32_t kb[NT], vb[NT];       // the validity BYTE holding the row's bit (0xFF: no bitmap)
+    uint32_t kbit, vbit;           // 3 bits per row: bit position inside that byte
+    uint32_t exists;
+};
+
+// All table lookups first (block-uniform, scalar unit), then every data load back to back; nothing consumes a load here.
+template <int NT, int BLOCK>
+__device__ __forceinline__ void g2_load(const Gb2Args& a, int64_t st, int tid, G2Raw<NT>& r) {
+    static_assert(BLOCK == kEvalTile || BLOCK * 2 == kEvalTile, "a block covers a tile in one or two rows per thread");
+    constexpr int RPT = kEvalTile / BLOCK;   // rows per thread per tile
+    static_assert(NT % RPT == 0, "NT counts rows per thread");
+    const int ksz = g2_dtype_size(a.key_dtype), vsz = g2_dtype_size(a.value_dtype);
+    DevChunkCol kc[NT / RPT], vc[NT / RPT];
+    int64_t r0[NT / RPT], clen[NT / RPT];
+#pragma unroll
+    for (int tt = 0; tt < NT / RPT; ++tt) {
+        const int64_t tile = st + tt;
+        kc[tt] = DevChunkCol{nullptr, nullptr, 0}; vc[tt] = kc[tt]; r0[tt] = 0; clen[tt] = 0;
+        if (tile >= a.ntiles) continue;
+        if (a.nchunks == 1) { kc[tt] = a.key0; vc[tt] = a.val0; r0[tt] = tile * kEvalTile; clen[tt] = a.len0; }
+        else {
+            const int64_t c = find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
+            r0[tt] = (tile - a.chunk_tile_start[c]) * kEvalTile;
+            clen[tt] = a.chunk_len[c];
+            kc[tt] = a.keys[c];
+            if (a.value_dtype >= 0) vc[tt] = a.values[c];
+        }
+    }
+    r.exists = 0; r.kbit = 0; r.vbit = 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int tt = j / RPT;
+        const int64_t row = r0[tt] + (int64_t)(j % RPT) * BLOCK + tid;
+        const bool e = row < clen[tt];
+        r.exists |= (uint32_t)e << j;
+        r.key[j] = g2_load_raw(kc[tt].values, ksz, kc[tt].offset + row, e);
+        r.kb[j] = 0xFFu;
+        if (kc[tt].validity) {
+            const int64_t b = kc[tt].offset + row;
+            if (e) r.kb[j] = as_global<uint8_t>(kc[tt].validity)[b >> 3];
+            r.kbit |= (uint32_t)(b & 7) << (3 * j);
+        }
+        r.val[j] = 0;
+        r.vb[j] = 0xFFu;
+        if (a.value_dtype >= 0) {
+            r.val[j] = g2_load_raw(vc[tt].values, vsz, vc[tt].offset + row, e);
+            if (vc[tt].validity) {
+                const int64_t b = vc[tt].offset + row;
+                if (e) r.vb[j] = as_global<uint8_t>(vc[tt].validity)[b >> 3];
+                r.vbit |= (uint32_t)(b & 7) << (3 * j);
+            }
+        }
+    }
+}
+
+// Raw rows -> (hashed key, accumulator contribution, count).  live bit j: the row becomes a record / a table update;
+// NULL keys and the one key whose hash is the free marker go straight to two global accumulators.
+template <int NT>
+struct G2Rows { uint64_t hk[NT], val[NT]; uint32_t cnt, live; };   // cnt bit j: the value is not NULL
+
+template <int NT>
+__device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r, G2Rows<NT>& o) {
+    o.cnt = 0; o.live = 0;
+    const bool counts_rows = a.value_dtype < 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const bool e = (r.exists >> j) & 1;
+        const bool knull = ((r.kb[j] >> ((r.kbit >> (3 * j)) & 7)) & 1u) == 0;
+        const bool vnull = !counts_rows && ((r.vb[j] >> ((r.vbit >> (3 * j)) & 7)) & 1u) == 0;
+        uint64_t v = r.val[j];
+        if (a.value_dtype == RDF_F32) v = d2u((double)__uint_as_float((uint32_t)v));
+        else if (a.value_dtype >= 0 && a.value_dtype != RDF_F64) v = normalize_int(a.value_dtype, v);
+        v = counts_rows ? 0ull : to_table_form(a.op, a.vcls, v, vnull);
+        const uint64_t hk = g2_hash(normalize_int(a.key_dtype, r.key[j]));
+        o.hk[j] = hk;
+        o.val[j] = v;
+        const bool c1 = !vnull;
+        if (e && c1) o.cnt |= 1u << j;
+        if (!e) continue;
+        if (knull || hk == kFree) {
+            const int s = knull ? 1 : 0;
+            a.special[s] = 1;
+            if (c1) {
+                if (!counts_rows) acc_apply(&a.special_sums[s], a.op, a.vcls, v);
+                atomicAdd(&a.special_counts[s], 1ull);
+            }
+            continue;
+        }
+        o.live |= 1u << j;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS table: open addressing over hashed keys, double hashing inside a (sub-)table of a prime number of slots
+
+struct LdsTab {
+    unsigned long long* keys;   // [slots] hashed key, kFree = empty
+    unsigned long long* acc;    // [slots]
+    unsigned int*       cnt;    // [slots]
+    unsigned int*       ngroups;
+};
+
+// Up to B pending (hashed key, value, count) updates per lane, probes interleaved: one LDS round trip serves all pending
+// updates of the lane (the probe's dependent latency, not the atomics, is what a table costs).
+template <int B>
+__device__ __forceinline__ void tab_upsert(const LdsTab& t, int op, int cls, bool has_values, uint32_t base, uint32_t slots,
+                                           const uint64_t (&hk)[B], const uint64_t (&val)[B], const uint32_t (&cnt)[B], uint32_t pending, uint32_t& err) {
+    uint32_t s[B], step[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+        // slot from the 32 bits right below the partition bits (the best-mixed bits of a multiplicative hash)
+        s[u] = (uint32_t)(((uint64_t)(uint32_t)(hk[u] >> (32 - kGbPartBits)) * (uint64_t)slots) >> 32);
+        step[u] = 1u + (uint32_t)(((uint64_t)(uint32_t)(hk[u] >> 3) * (uint64_t)(slots - 1)) >> 32);
+    }
+    uint32_t guard = 0;
+    while (__any(pending != 0)) {
+        unsigned long long old[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) old[u] = ((pending >> u) & 1) ? t.keys[base + s[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            if (!((pending >> u) & 1)) continue;
+            unsigned long long o = old[u];
+            if (o == kFree) {
+                o = atomicCAS(&t.keys[base + s[u]], kFree, (unsigned long long)hk[u]);
+                if (o == kFree) { atomicAdd(t.ngroups, 1u); o = hk[u]; }
+            }
+            if (o == hk[u]) {
+                pending &= ~(1u << u);
+                if (cnt[u]) {
+                    if (has_values) acc_apply(&t.acc[base + s[u]], op, cls, val[u]);
+                    atomicAdd(&t.cnt[base + s[u]], cnt[u]);
+                }
+            } else {
+                s[u] += step[u];
+                if (s[u] >= slots) s[u] -= slots;
+            }
+        }
+        if (++guard > slots) { if (pending) err |= 4u; break; }   // table full: more groups than promised
+    }
+}
+
+// Insert-or-find `key` (raw key bits) in the global table and fold (v, cnt) into its slot.  False on overflow.
+__device__ __forceinline__ bool g2_global_upsert(const GroupTable& t, uint64_t key, int op, int cls, bool has_values, uint64_t v, uint64_t cnt) {
+    const uint64_t mask = (uint64_t)t.capacity - 1;
+    uint64_t s = mix64b(key) & mask;
+    int64_t probes = 0;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&t.keys[s], kGroupEmpty, (unsigned long long)key);
+        if (old == kGroupEmpty) { atomicAdd(t.ngroups, 1u); break; }
+        if (old == key) break;
+        s = (s + 1) & mask;
+        if (++probes > t.capacity) return false;
+    }
+    if (cnt) {
+        if (has_values) acc_apply(&t.sums[s], op, cls, v);
+        atomicAdd(&t.counts[s], (unsigned long long)cnt);
+    }
+    return true;
+}
+__device__ __forceinline__ void g2_global_special(const GroupTable& t, int which, int op, int cls, bool has_values, uint64_t v, uint64_t cnt) {
+    const int64_t gs = t.capacity + which;
+    t.special[which] = 1;
+    if (cnt) {
+        if (has_values) acc_apply(&t.sums[gs], op, cls, v);
+        atomicAdd(&t.counts[gs], (unsigned long long)cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// <= 2048 groups: columns -> per-block LDS table -> global table
+
+constexpr int kStreamBlock = kGbBlock;       // 512 threads, 2 blocks per CU (80 KB of LDS each)
+constexpr int kStreamRows = 4;               // rows per thread per batch = two tiles per block iteration
+__global__ __launch_bounds__(kStreamBlock) void gb2_stream_kernel(const Gb2Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
+    LdsTab t;
+    t.keys = (unsigned long long*)gsm;
+    t.acc = t.keys + kGbSlots;
+    t.cnt = (unsigned int*)(t.acc + kGbSlots);
+    t.ngroups = t.cnt + kGbSlots;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long ident = agg_identity(a.op);
+    for (int i = tid; i < kGbSlots; i += kStreamBlock) { t.keys[i] = kFree; t.acc[i] = ident; t.cnt[i] = 0; }
+    if (tid == 0) *t.ngroups = 0;
+    __syncthreads();
+    const bool has_values = a.value_dtype >= 0;
+    const uint32_t base = (uint32_t)(lane & (a.replicas - 1)) * (uint32_t)a.sub_slots;
+    uint32_t err = 0;
+    constexpr int TPI = kStreamRows * kStreamBlock / kEvalTile;   // tiles per block iteration
+    const int64_t stride = (int64_t)gridDim.x * TPI;
+    int64_t st = (int64_t)blockIdx.x * TPI;
+    G2Raw<kStreamRows> cur;
+    if (st < a.ntiles) g2_load<kStreamRows, kStreamBlock>(a, st, tid, cur);
+    for (; st < a.ntiles; st += stride) {
+        G2Raw<kStreamRows> nxt;
+        const bool more = st + stride < a.ntiles;
+        if (more) g2_load<kStreamRows, kStreamBlock>(a, st + stride, tid, nxt);   // in flight while this batch is folded
+        G2Rows<kStreamRows> rows;
+        g2_prepare<kStreamRows>(a, cur, rows);
+        uint32_t cnt[kStreamRows];
+#pragma unroll
+        for (int j = 0; j < kStreamRows; ++j) cnt[j] = (rows.cnt >> j) & 1;
+        tab_upsert<kStreamRows>(t, a.op, a.vcls, has_values, base, (uint32_t)a.sub_slots, rows.hk, rows.val, cnt, rows.live, err);
+        if (more) cur = nxt;
+    }
+    __syncthreads();
+    // the block's groups -> the global table (keys un-hashed: the global table is addressed by raw key bits)
+    for (int i = tid; i < kGbSlots; i += kStreamBlock) {
+        const unsigned long long hk = t.keys[i];
+        if (hk == kFree) continue;
+        const uint64_t key = g2_unhash(hk);
+        if (key == kGroupEmpty) g2_global_special(a.t, 0, a.op, a.vcls, has_values, t.acc[i], t.cnt[i]);
+        else if (!g2_global_upsert(a.t, key, a.op, a.vcls, has_values, t.acc[i], t.cnt[i])) err |= 4u;
+        // a group whose every value was NULL still exists: the upsert above inserted its key with cnt == 0
+    }
+    if (err) atomicOr(a.flags, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// <= 1.3 M groups, pass 1: scatter 16-byte records into (partition, block) regions, whole aligned lines only.
+// Record: word 0 = (cnt << 55) | (hashed key & (2^55 - 1)) — the partition bits are implied by where the record lies and
+// make room for cnt (0: the value was NULL, the group must still exist) —, word 1 = accumulator contribution; ~0 = dead.
+
+__global__ __launch_bounds__(kG2Block) void gb2_scatter_kernel(const Gb2Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
+    u64x2* stage = (u64x2*)gsm;                           // [kG2Super] this tile's records, grouped by partition
+    u64x2* carry = stage + kG2Super;                      // [kP * 8] records waiting for their line to fill
+    uint32_t* tcnt = (uint32_t*)(carry + kP * kG2Line);   // [kP] rank counters of the tile
+    uint32_t* ccnt = tcnt + kP;                           // [kP] records in the carry
+    uint32_t* written = ccnt + kP;                        // [kP] lines of the region already written
+    uint32_t* lstart = written + kP;                      // [kP] first staging slot of the partition
+    uint32_t* cfl = lstart + kP;                          // [kP] carry count the flush works with
+    uint32_t* wfl = cfl + kP;                             // [kP] written count the flush works with
+    uint32_t* linestart = wfl + kP;                       // [kP] first flush line of the partition
+    uint16_t* linepart = (uint16_t*)(linestart + kP);     // [kMaxFlushLines] partition of flush line i
+    __shared__ uint32_t wtot_t[kP / 64], wtot_k[kP / 64], ltot, abort_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < kP) { tcnt[tid] = 0; ccnt[tid] = 0; written[tid] = 0; }
+    if (tid == 0) abort_s = 0;
+    __syncthreads();
+    const int64_t nb = gridDim.x, bid = blockIdx.x;
+    const int64_t cap = a.cap_lines;
+    u64x2* const recs = (u64x2*)a.recs;
+    uint32_t err = 0;
+    constexpr int TPI = kG2Super / kEvalTile;
+    const int64_t stride = nb * TPI;
+    int64_t st = bid * TPI;
+    G2Raw<kG2Rows> raw;
+    G2Rows<kG2Rows> rows;
+    if (st < a.ntiles) { g2_load<kG2Rows, kG2Block>(a, st, tid, raw); g2_prepare<kG2Rows>(a, raw, rows); }
+    for (; st < a.ntiles; st += stride) {
+        const bool more = st + stride < a.ntiles;
+        if (more) g2_load<kG2Rows, kG2Block>(a, st + stride, tid, raw);   // the next tile's loads fly during the LDS phases
+        // (B) rank inside the partition
+        uint32_t rank[kG2Rows];
+#pragma unroll
+        for (int j = 0; j < kG2Rows; ++j)
+            if ((rows.live >> j) & 1) rank[j] = atomicAdd(&tcnt[(uint32_t)(rows.hk[j] >> (64 - kGbPartBits))], 1u);
+        __syncthreads();
+        // (C) per partition: staging offset, number of whole lines it can now flush, their place in the flush list
+        uint32_t tc = 0, cc = 0, kk = 0, inc_t = 0, inc_k = 0;
+        if (tid < kP) {
+            tc = tcnt[tid]; cc = ccnt[tid];
+            kk = (cc + tc) >> 3;
+            inc_t = tc; inc_k = kk;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const uint32_t yt = (uint32_t)__shfl_up((int)inc_t, m), yk = (uint32_t)__shfl_up((int)inc_k, m);
+                if (lane >= m) { inc_t += yt; inc_k += yk; }
+            }
+            if (lane == 63) { wtot_t[wave] = inc_t; wtot_k[wave] = inc_k; }
+        }
+        if (tid == 0) abort_s = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u;
+        __syncthreads();
+        if (abort_s) break;     // some block overflowed a region: the host re-runs the histogram path
+        if (tid < kP) {
+            uint32_t off_t = 0, off_k = 0;
+#pragma unroll
+            for (int w = 0; w < kP / 64; ++w) if (w < wave) { off_t += wtot_t[w]; off_k += wtot_k[w]; }
+            const uint32_t ex_t = off_t + inc_t - tc, ex_k = off_k + inc_k - kk;
+            lstart[tid] = ex_t;
+            linestart[tid] = ex_k;
+            cfl[tid] = cc;
+            wfl[tid] = written[tid];
+            for (uint32_t j = 0; j < kk; ++j) linepart[ex_k + j] = (uint16_t)tid;
+            ccnt[tid] = cc + tc - 8 * kk;
+            written[tid] += kk;
+            tcnt[tid] = 0;
+            if (tid == kP - 1) ltot = ex_k + kk;
+        }
+        __syncthreads();
+        // (D) stage the tile's records grouped by partition
+#pragma unroll
+        for (int j = 0; j < kG2Rows; ++j)
+            if ((rows.live >> j) & 1) {
+                const uint32_t d = (uint32_t)(rows.hk[j] >> (64 - kGbPartBits));
+                u64x2 rec;
+                rec[0] = ((uint64_t)((rows.cnt >> j) & 1) << (64 - kGbPartBits)) | (rows.hk[j] & kKeyMask);
+                rec[1] = rows.val[j];
+                stage[lstart[d] + rank[j]] = rec;
+            }
+        __syncthreads();
+        // the next tile's rows: waiting for its loads HERE keeps the flush stores below out of that wait
+        if (more) g2_prepare<kG2Rows>(a, raw, rows);
+        // (E) flush whole lines: 8 consecutive lanes write one aligned 128-byte line of a region
+        const uint32_t nl = ltot;
+        for (uint32_t i = (uint32_t)tid >> 3; i < nl; i += kG2Block / 8) {
+            const uint32_t d = linepart[i], j = i - linestart[d], l8 = (uint32_t)tid & 7, pos = 8 * j + l8, c = cfl[d];
+            const u64x2 rec = pos < c ? carry[d * kG2Line + pos] : stage[lstart[d] + pos - c];
+            const int64_t line = (int64_t)wfl[d] + j;
+            if (line < cap) recs[(((int64_t)d * nb + bid) * cap + line) * kG2Line + l8] = rec;
+            else err |= 16u;
+            if (j == 0) {   // the partition's new carry: the tail of its tile records (this lane read its old carry slot above)
+                const uint32_t k = written[d] - wfl[d], r = ccnt[d];
+                if (l8 < r) carry[d * kG2Line + l8] = stage[lstart[d] + 8 * k - c + l8];
+            }
+        }
+        if (tid < kP && written[tid] == wfl[tid]) {   // no line to flush: the tile's records join the carry
+            const uint32_t c = cfl[tid], t2 = ccnt[tid] - c;
+            for (uint32_t i = 0; i < t2; ++i) carry[tid * kG2Line + c + i] = stage[lstart[tid] + i];
+        }
+        if (err & 16u) atomicOr(a.flags, 16u);
+        __syncthreads();
+    }
+    // what is left in the carries goes out as one last line per partition, padded with dead records
+    __syncthreads();
+    for (uint32_t d = (uint32_t)tid >> 3; d < (uint32_t)kP; d += kG2Block / 8) {
+        const uint32_t c = ccnt[d], l8 = (uint32_t)tid & 7;
+        if (c == 0) continue;
+        u64x2 rec;
+        rec[0] = kDead; rec[1] = 0;
+        if (l8 < c) rec = carry[d * kG2Line + l8];
+        const int64_t line = written[d];
+        if (line < cap) recs[(((int64_t)d * nb + bid) * cap + line) * kG2Line + l8] = rec;
+        else err |= 16u;
+    }
+    __syncthreads();
+    if (tid < kP) a.nlines[(int64_t)tid * nb + bid] = written[tid] + (ccnt[tid] ? 1u : 0u);
+    if (err) atomicOr(a.flags, err);
+}
+
+// pass 2: one block per partition; its records are the nb line ranges the scatter blocks wrote
+constexpr int kAggBatch = 4;
+__global__ __launch_bounds__(kGbBlock) void gb2_aggregate_kernel(const Gb2AggArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
+    LdsTab t;
+    t.keys = (unsigned long long*)gsm;
+    t.acc = t.keys + kGbSlots;
+    t.cnt = (unsigned int*)(t.acc + kGbSlots);
+    t.ngroups = t.cnt + kGbSlots;
+    unsigned int* misc = t.ngroups + 1;   // [0] output base, [1] emit cursor
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id();
+    constexpr int NW = kGbBlock / 64;
+    const unsigned long long ident = agg_identity(a.op);
+    uint32_t err = 0;
+    const u64x2* const recs = (const u64x2*)a.recs;
+    for (int p = blockIdx.x; p < kP; p += gridDim.x) {
+        for (int i = tid; i < kGbSlots; i += kGbBlock) { t.keys[i] = kFree; t.acc[i] = ident; t.cnt[i] = 0; }
+        if (tid == 0) *t.ngroups = 0;
+        __syncthreads();
+        const uint64_t ptop = (uint64_t)p << (64 - kGbPartBits);
+        // wave w streams the regions b = w, w + NW, ...: kAggBatch x 64 consecutive records per step, the next step's loads
+        // issued before the current step is folded into the table
+        int64_t b = wave;
+        int64_t off = 0;
+        int64_t nrec = 0;
+        const u64x2* base = recs;
+        auto open_region = [&]() {
+            while (b < a.nb) {
+                nrec = (int64_t)a.nlines[(int64_t)p * a.nb + b] * kG2Line;
+                if (nrec > 0) { base = recs + ((int64_t)p * a.nb + b) * a.cap_lines * kG2Line; off = 0; return true; }
+                b += NW;
+            }
+            return false;
+        };
+        auto load_batch = [&](u64x2 (&r)[kAggBatch]) -> bool {   // false: this wave's regions are exhausted
+            if (off >= nrec) { if (off > 0 || nrec == 0) { if (nrec > 0) b += NW; if (!open_region()) return false; } }
+#pragma unroll
+            for (int u = 0; u < kAggBatch; ++u) {
+                const int64_t i = off + u * 64 + lane;
+                r[u][0] = kDead; r[u][1] = 0;
+                if (i < nrec) r[u] = __builtin_nontemporal_load(base + i);
+            }
+            off += kAggBatch * 64;
+            return true;
+        };
+        u64x2 cur[kAggBatch], nxt[kAggBatch];
+        bool have = load_batch(cur);
+        while (have) {
+            const bool nhave = load_batch(nxt);
+            uint64_t hk[kAggBatch], val[kAggBatch];
+            uint32_t cnt[kAggBatch], pending = 0;
+#pragma unroll
+            for (int u = 0; u < kAggBatch; ++u) {
+                hk[u] = (cur[u][0] & kKeyMask) | ptop;
+                val[u] = cur[u][1];
+                cnt[u] = (uint32_t)(cur[u][0] >> (64 - kGbPartBits));
+                if (cur[u][0] != kDead) pending |= 1u << u;
+            }
+            tab_upsert<kAggBatch>(t, a.op, a.vcls, a.has_values != 0, 0u, (uint32_t)kGbSlots, hk, val, cnt, pending, err);
+            if (nhave) {
+#pragma unroll
+                for (int u = 0; u < kAggBatch; ++u) cur[u] = nxt[u];
+            }
+            have = nhave;
+        }
+        __syncthreads();
+        if (tid == 0) { misc[0] = atomicAdd(a.cursor, *t.ngroups); misc[1] = 0; }
+        __syncthreads();
+        for (int k = tid; k < kGbSlots; k += kGbBlock) {
+            if (t.keys[k] == kFree) continue;
+            const unsigned idx = misc[0] + atomicAdd(&misc[1], 1u);
+            if ((int64_t)idx >= a.max_out) { err |= 4u; continue; }
+            const uint64_t key = g2_unhash(t.keys[k]);
+            switch (a.key_dtype) {
+                case RDF_I32: case RDF_U32: ((uint32_t*)a.out_keys)[idx] = (uint32_t)key; break;
+                case RDF_I16: case RDF_U16: ((uint16_t*)a.out_keys)[idx] = (uint16_t)key; break;
+                case RDF_I8: case RDF_U8: ((uint8_t*)a.out_keys)[idx] = (uint8_t)key; break;
+                default: ((uint64_t*)a.out_keys)[idx] = key; break;
+            }
+            a.out_acc[idx] = t.acc[k];
+            a.out_counts[idx] = (int64_t)t.cnt[k];
+        }
+        __syncthreads();
+    }
+    if (err) atomicOr(a.flags, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one table in HBM: rows -> table (any number of groups), and (key, accumulator, count) triples -> table (merge)
+
+__global__ __launch_bounds__(kStreamBlock) void gb2_table_rows_kernel(const Gb2Args a) {
+    const int tid = threadIdx.x;
+    const bool has_values = a.value_dtype >= 0;
+    uint32_t err = 0;
+    constexpr int TPI = kStreamRows * kStreamBlock / kEvalTile;
+    for (int64_t st = (int64_t)blockIdx.x * TPI; st < a.ntiles; st += (int64_t)gridDim.x * TPI) {
+        G2Raw<kStreamRows> raw;
+        g2_load<kStreamRows, kStreamBlock>(a, st, tid, raw);
+        G2Rows<kStreamRows> rows;
+        g2_prepare<kStreamRows>(a, raw, rows);
+#pragma unroll
+        for (int j = 0; j < kStreamRows; ++j)
+            if ((rows.live >> j) & 1) {
+                const uint64_t key = g2_unhash(rows.hk[j]);
+                const uint64_t c = (rows.cnt >> j) & 1;
+                if (key == kGroupEmpty) g2_global_special(a.t, 0, a.op, a.vcls, has_values, rows.val[j], c);
+                else if (!g2_global_upsert(a.t, key, a.op, a.vcls, has_values, rows.val[j], c)) err |= 4u;
+            }
+    }
+    if (err) atomicOr(a.flags, err);
+}
+__global__ __launch_bounds__(kBlock) void gb2_merge_kernel(const Gb2MergeArgs a) {
+    uint32_t err = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t key = a.keys[i], v = a.acc ? a.acc[i] : 0, c = a.counts ? (uint64_t)a.counts[i] : 1;
+        const bool knull = a.key_validity && !((a.key_validity[i >> 3] >> (i & 7)) & 1);
+        if (knull) g2_global_special(a.t, 1, a.op, a.vcls, a.acc != nullptr, v, c);
+        else if (key == kGroupEmpty) g2_global_special(a.t, 0, a.op, a.vcls, a.acc != nullptr, v, c);
+        else if (!g2_global_upsert(a.t, key, a.op, a.vcls, a.acc != nullptr, v, c)) err |= 4u;
+    }
+    if (err) atomicOr(a.t.flags, err);
+}
+// occupied slots -> dense (keys, raw accumulators, counts); the two special groups last
+__global__ __launch_bounds__(kBlock) void gb2_emit_kernel(const GroupEmitArgs a) {
+    const int64_t n = a.t.capacity + 2;
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < n; s += (int64_t)gridDim.x * kBlock) {
+        bool occ; uint64_t key = 0; bool knull = false;
+        if (s < a.t.capacity) { key = a.t.keys[s]; occ = key != kGroupEmpty; }
+        else if (s == a.t.capacity) { key = kGroupEmpty; occ = a.t.special[0] != 0; }
+        else { knull = true; occ = a.t.special[1] != 0; }
+        if (!occ) continue;
+        const unsigned idx = atomicAdd(a.cursor, 1u);
+        switch (a.key_dtype) {
+            case RDF_I32: case RDF_U32: ((uint32_t*)a.out_keys)[idx] = (uint32_t)key; break;
+            case RDF_I16: case RDF_U16: ((uint16_t*)a.out_keys)[idx] = (uint16_t)key; break;
+            case RDF_I8: case RDF_U8: ((uint8_t*)a.out_keys)[idx] = (uint8_t)key; break;
+            default: ((uint64_t*)a.out_keys)[idx] = key; break;
+        }
+        if (a.out_keys_validity && !knull) atomicOr((unsigned int*)a.out_keys_validity + (idx >> 5), 1u << (idx & 31));
+        ((uint64_t*)a.out_sums)[idx] = a.t.sums[s];
+        a.out_counts[idx] = (int64_t)a.t.counts[s];
+    }
+}
+
+// raw accumulators <-> values: MIN / MAX un-order their images, a group without a non-NULL value is NULL
+__global__ __launch_bounds__(kBlock) void gb2_finish_kernel(const Gb2FinishArgs a) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long nulls = 0;
+    const int64_t n64 = (a.n + 63) & ~(int64_t)63;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n64; i += (int64_t)gridDim.x * kBlock) {
+        const bool in = i < a.n;
+        bool valid = in;
+        if (in) {
+            const int64_t c = a.counts ? a.counts[i] : 1;
+            uint64_t v = a.acc[i];
+            if (a.native_in) v = to_table_form(a.op, a.vcls, v, c == 0);
+            else if (a.op != AGG_SUM) { valid = c > 0; v = valid ? unord_bits(a.vcls, v) : 0; }
+            a.acc[i] = v;
+        }
+        const uint64_t vb = __ballot(valid);
+        if (a.validity && !a.native_in && lane == 0 && i < a.n) ((uint64_t*)a.validity)[i >> 6] = vb;
+        if (lane == 0 && !a.native_in) nulls += (unsigned long long)__popcll(__ballot(in) & ~vb);
+    }
+    if (lane == 0 && nulls && a.nulls) atomicAdd(a.nulls, nulls);
+}
+__global__ void gb2_fill_kernel(uint64_t* p, int64_t n, uint64_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU exchange of partial groups (the one real collective of the path): owner = hash(key) % world
+
+__device__ __forceinline__ uint32_t gx_owner(uint64_t key, int world) { return (uint32_t)(((key * 0x9E3779B97F4A7C15ull) >> 33) % (uint64_t)world); }
+__global__ __launch_bounds__(kBlock) void gx_pack_kernel(const GxPackArgs a) {
+    __shared__ unsigned int lc[64];
+    __shared__ unsigned long long lbase[64];
+    if (threadIdx.x < 64) lc[threadIdx.x] = 0;
+    __syncthreads();
+    // a block handles a contiguous slice so that phase 1 needs one global atomic per (block, owner)
+    const int64_t per = (a.n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < a.n ? lo + per : a.n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) atomicAdd(&lc[gx_owner(a.keys[i], a.world)], 1u);
+    __syncthreads();
+    if (a.phase == 0) {
+        if (threadIdx.x < a.world && lc[threadIdx.x]) atomicAdd(&a.owner_counts[threadIdx.x], (unsigned long long)lc[threadIdx.x]);
+        return;
+    }
+    if (threadIdx.x < a.world) { lbase[threadIdx.x] = lc[threadIdx.x] ? atomicAdd(&a.cursors[threadIdx.x], (unsigned long long)lc[threadIdx.x]) : 0; lc[threadIdx.x] = 0; }
+    __syncthreads();
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+        const uint64_t k = a.keys[i];
+        const uint32_t o = gx_owner(k, a.world);
+        const unsigned long long pos = lbase[o] + atomicAdd(&lc[o], 1u);
+        a.packed[3 * pos] = k;
+        a.packed[3 * pos + 1] = a.acc[i];
+        a.packed[3 * pos + 2] = (uint64_t)a.counts[i];
+    }
+}
+__global__ __launch_bounds__(kBlock) void gx_unpack_kernel(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        keys[i] = packed[3 * i]; acc[i] = packed[3 * i + 1]; counts[i] = (int64_t)packed[3 * i + 2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// several grouping columns <-> one packed 64-bit key
+
+__device__ __forceinline__ uint64_t key_order_bits(int dt, uint64_t raw) {   // order-preserving unsigned image of an integer key
+    return dt <= RDF_I64 ? normalize_int(dt, raw) ^ 0x8000000000000000ull : normalize_int(dt, raw);
+}
+__global__ __launch_bounds__(kBlock) void key_pack_kernel(const KeyPackArgs a) {
+    const double inv = chunk_lookup_scale(a.chunk_row_start, a.nchunks);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t c = find_chunk_row(a.chunk_row_start, a.nchunks, i, inv);
+        const int64_t r = i - a.chunk_row_start[c];
+        uint64_t packed = 0;
+        for (int k = 0; k < a.nkeys; ++k) {
+            const DevChunkCol cc = a.cols[(int64_t)k * a.nchunks + c];
+            const int64_t e = cc.offset + r;
+            const bool valid = !cc.validity || ((as_global<uint8_t>(cc.validity)[e >> 3] >> (e & 7)) & 1);
+            uint64_t f = 0;
+            if (valid) f = key_order_bits(a.dtype[k], g2_load_raw(cc.values, g2_dtype_size(a.dtype[k]), e, true)) - a.bias[k] + (uint64_t)a.nullable[k];
+            packed |= f << a.shift[k];
+        }
+        a.packed[i] = packed;
+    }
+}
+__global__ __launch_bounds__(kBlock) void key_unpack_kernel(const KeyPackArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n64 = (a.n + 63) & ~(int64_t)63;
+    unsigned long long nulls[kMaxKeyCols] = {0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n64; i += (int64_t)gridDim.x * kBlock) {
+        const bool in = i < a.n;
+        const uint64_t packed = in ? a.packed[i] : 0;
+#pragma unroll
+        for (int k = 0; k < kMaxKeyCols; ++k) {
+            if (k >= a.nkeys) break;
+            const uint64_t f = (packed >> a.shift[k]) & a.mask[k];
+            const bool valid = in && !(a.nullable[k] && f == 0);
+            uint64_t ob = valid ? f - (uint64_t)a.nullable[k] + a.bias[k] : 0;
+            if (valid && a.dtype[k] <= RDF_I64) ob ^= 0x8000000000000000ull;
+            if (in) switch (g2_dtype_size(a.dtype[k])) {
+                case 8: ((uint64_t*)a.out_values[k])[i] = ob; break;
+                case 4: ((uint32_t*)a.out_values[k])[i] = (uint32_t)ob; break;
+                case 2: ((uint16_t*)a.out_values[k])[i] = (uint16_t)ob; break;
+                default: ((uint8_t*)a.out_values[k])[i] = (uint8_t)ob; break;
+            }
+            const uint64_t vb = __ballot(valid);
+            if (lane == 0 && i < a.n) {
+                if (a.out_validity[k]) ((uint64_t*)a.out_validity[k])[i >> 6] = vb;
+                nulls[k] += (unsigned long long)__popcll(__ballot(in) & ~vb);
+            }
+        }
+    }
+    if (lane == 0)
+        for (int k = 0; k < a.nkeys; ++k) if (nulls[k]) atomicAdd(&a.out_nulls[k], nulls[k]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+
+size_t gb2_scatter_lds_bytes() {
+    return (size_t)kG2Super * 16 + (size_t)kP * kG2Line * 16 + (size_t)kP * 4 * 7 + (size_t)kMaxFlushLines * 2;
+}
+hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s) {
+    const size_t lds = (size_t)kGbSlots * 20 + 16;
+    (void)hipFuncSetAttribute((const void*)gb2_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(gb2_stream_kernel, dim3(grid), dim3(kStreamBlock), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s) {
+    const size_t lds = gb2_scatter_lds_bytes();
+    (void)hipFuncSetAttribute((const void*)gb2_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(gb2_scatter_kernel, dim3(grid), dim3(kG2Block), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gb2_aggregate(const Gb2AggArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)kGbSlots * 20 + 32;
+    (void)hipFuncSetAttribute((const void*)gb2_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(gb2_aggregate_kernel, dim3(kP), dim3(kGbBlock), lds, s, a);
+    return hipGetLastError();
+}
+static int g2_rows_grid(int64_t n) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g > eval_grid_limit()) g = eval_grid_limit();
+    return g < 1 ? 1 : (int)g;
+}
+hipError_t launch_gb2_merge(const Gb2MergeArgs& a, hipStream_t s) {
+    if (a.n > 0) hipLaunchKernelGGL(gb2_merge_kernel, dim3(g2_rows_grid(a.n)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gb2_table_rows(const Gb2Args& a, hipStream_t s) {
+    constexpr int TPI = kStreamRows * kStreamBlock / kEvalTile;
+    int64_t grid = (a.ntiles + TPI - 1) / TPI;
+    if (grid > eval_grid_limit() / 2) grid = eval_grid_limit() / 2;
+    if (grid > 0) hipLaunchKernelGGL(gb2_table_rows_kernel, dim3((unsigned)grid), dim3(kStreamBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gb2_emit(const GroupEmitArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(gb2_emit_kernel, dim3(g2_rows_grid(a.t.capacity + 2)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gb2_finish(const Gb2FinishArgs& a, hipStream_t s) {
+    if (a.n > 0) hipLaunchKernelGGL(gb2_finish_kernel, dim3(g2_rows_grid(a.n)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gb2_fill(uint64_t* p, int64_t n, uint64_t v, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(gb2_fill_kernel, dim3(g2_rows_grid(n)), dim3(kBlock), 0, s, p, n, v);
+    return hipGetLastError();
+}
+hipError_t launch_gx_pack(const GxPackArgs& a, hipStream_t s) {
+    if (a.n > 0) {
+        int64_t grid = (a.n + 4 * kBlock - 1) / (4 * kBlock);
+        if (grid > 1024) grid = 1024;
+        hipLaunchKernelGGL(gx_pack_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_gx_unpack(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(gx_unpack_kernel, dim3(g2_rows_grid(n)), dim3(kBlock), 0, s, packed, n, keys, acc, counts);
+    return hipGetLastError();
+}
+hipError_t launch_key_pack(const KeyPackArgs& a, hipStream_t s) {
+    if (a.n > 0) hipLaunchKernelGGL(key_pack_kernel, dim3(g2_rows_grid(a.n)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_key_unpack(const KeyPackArgs& a, hipStream_t s) {
+    if (a.n > 0) hipLaunchKernelGGL(key_unpack_kernel, dim3(g2_rows_grid(a.n)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace rdfk

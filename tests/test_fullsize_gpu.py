@@ -173,3 +173,52 @@ def test_c1_csv_shape_1e6_rows_977_batches(gpu, ora):
     assert [c.length for c in s2] == [c.length for c in chunks]
     tot = gpu.sum(s2)
     assert abs(tot - ref) <= 1e-9 * abs(ref)
+
+
+def _bench_workload(name, rows):
+    """bench.py's own --workload builder, step and check (so the benchmark's generator and self-checks are what is tested)."""
+    import torch
+    import bench
+    from rust_dataframe_amd import lib, sharding
+    dev = torch.device("cuda", 0)
+    step, alg_bytes, desc, check = bench.WORKLOADS[name](torch, lib, lib.api(), A, sharding, dev, dev, 0, rows)
+    return step, check
+
+
+def test_groupby_1e9_1e6keys_properties(gpu):
+    """Config C4 at full single-GPU size: 1e9 rows, i64 keys = hash(row) mod 1e6, f64 values.  Size-independent
+    properties (no key twice, every count positive, counts add up to the rows, group sums to the column sum, exactly
+    1e6 groups, keys inside the domain) + the oracle on a 2e6-row prefix, through bench.py's own workload."""
+    import torch
+    from rust_dataframe_amd import lib
+    step, check = _bench_workload("c4", N)
+    res = step()
+    assert res["groups"] == 1_000_000
+    assert lib.last_kernel().startswith("gb2_scatter_kernel"), lib.last_kernel()
+    chk = check(res, 1)
+    assert chk["self_check"] is True and chk["parity_on_sample"] is True and chk["groups_total"] == 1_000_000, chk
+    del step, check
+    torch.cuda.empty_cache()
+
+
+def test_q1_6e8_properties(gpu):
+    """Config C5 at SF100 size (6e8 lineitem rows): per-group averages inside the columns' domains, the filter's
+    selectivity, groups of equal weight, discounted price <= price <= charge / 0.9; oracle parity on a 2e6-row prefix."""
+    import torch
+    step, check = _bench_workload("q1", 600_000_000)
+    res = step()
+    chk = check(res, 1)
+    assert chk["self_check"] is True and chk["parity_on_sample"] is True, (chk, res)
+    assert all(1.0 <= s / c <= 50.0 for s, c in zip(res["sum_qty"], res["count_star"]))
+    del step, check
+    torch.cuda.empty_cache()
+
+
+def test_c3_bench_workload_checks(gpu):
+    import torch
+    step, check = _bench_workload("c3", 200_000_000)
+    res = step()
+    chk = check(res, 1)
+    assert chk["self_check"] is True and chk["parity_on_sample"] is True, (chk, res)
+    del step, check
+    torch.cuda.empty_cache()

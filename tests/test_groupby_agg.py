@@ -1,0 +1,284 @@
+"""GroupAggregate(groups, [Sum | Min | Max | Count]) — rdf_groupby_agg / rdf_groupby_merge / the exchange helpers.
+
+The reference plans the step (Dataset::try_aggregate src/expression.rs:114-221, AggregateFunction :696-711) and never
+executes it (src/evaluation.rs:73 panics): SQL semantics, PARITY UNPINNED BY THE REFERENCE.  The oracle's sequential
+restatement is held to an independent pandas statement here (CPU tests); the HIP paths are held to the oracle (GPU tests)
+on every path the host can pick: LDS-table stream (<= 2048 groups), line-aligned scatter + LDS tables, one table in HBM.
+"""
+import numpy as np
+import pytest
+
+from rust_dataframe_amd import _abi as A
+from util import make_chunks
+
+AGGS = ["sum", "min", "max", "count"]
+
+
+def _groups(keys_out, vals_out, counts_out):
+    """-> {key tuple (None = NULL): (value or None, count)}"""
+    cols = [k.to_pylist() for k in keys_out]
+    v, c = vals_out.to_pylist(), counts_out.to_numpy().tolist()
+    out = {}
+    for i in range(counts_out.length):
+        kt = tuple(col[i] for col in cols)
+        assert kt not in out, f"group {kt} twice"
+        out[kt] = (v[i], c[i])
+    return out
+
+
+def _assert_same_groups(got, exp, float_vals, what):
+    assert got.keys() == exp.keys(), f"{what}: group keys differ ({len(got)} vs {len(exp)})"
+    for k, (ev, ec) in exp.items():
+        gv, gc = got[k]
+        assert gc == ec, f"{what}: count of {k}: {gc} != {ec}"
+        if ev is None or gv is None:
+            assert ev is None and gv is None, f"{what}: NULL value of {k}: {gv} vs {ev}"
+        elif float_vals:
+            assert gv == ev or (np.isnan(ev) and np.isnan(gv)) or abs(gv - ev) <= 1e-6 * max(abs(ev), 1e-300) + 1e-9, f"{what}: value of {k}: {gv} vs {ev}"
+        else:
+            assert gv == ev, f"{what}: value of {k}: {gv} vs {ev}"
+
+
+def _key_chunks(rng, dtype, lens, ngroups, nf, off, lo=0):
+    hi = min(lo + ngroups, np.iinfo(A.NP_OF[dtype]).max)
+    return [A.HostArray.from_numpy(rng.integers(lo, hi, n).astype(A.NP_OF[dtype]), valid=(rng.uniform(size=n) >= nf) if nf else None, offset=off, rng=rng)
+            for n in lens]
+
+
+def _pandas_groups(key_cols, vals, agg):
+    import pandas as pd
+    frame = {}
+    for k, col in enumerate(key_cols):
+        frame[f"k{k}"] = pd.array([x for ch in col for x in ch.to_pylist()], dtype="object")
+    if vals is not None:
+        frame["v"] = pd.array([x for ch in vals for x in ch.to_pylist()], dtype="object")
+    df = pd.DataFrame(frame)
+    out = {}
+    knames = [f"k{k}" for k in range(len(key_cols))]
+    for kt, g in df.groupby(knames, dropna=False, sort=False):
+        kt = kt if isinstance(kt, tuple) else (kt,)
+        kt = tuple(None if (x is None or x is pd.NA or (isinstance(x, float) and np.isnan(x))) else int(x) for x in kt)
+        if vals is None or agg == "count":
+            out[kt] = (None, len(g))
+            continue
+        v = [x for x in g["v"].tolist() if x is not None]
+        cnt = len(v)
+        if agg == "sum":
+            out[kt] = (sum(v) if v else 0, cnt)
+        else:
+            nn = [x for x in v if not (isinstance(x, float) and np.isnan(x))]
+            if cnt == 0:
+                out[kt] = (None, 0)
+            elif not nn:
+                out[kt] = (float("nan"), cnt)
+            else:
+                out[kt] = ((min if agg == "min" else max)(nn), cnt)
+    return out
+
+
+@pytest.mark.parametrize("agg", AGGS)
+@pytest.mark.parametrize("val_dtype", [A.F64, A.I64, A.U64, A.I32, A.F32])
+def test_oracle_groupby_agg_matches_pandas(ora, agg, val_dtype):
+    rng = np.random.default_rng(77 + val_dtype)
+    lens = [300, 0, 1200]
+    for nkeys in (1, 2):
+        key_cols = [_key_chunks(rng, dt, lens, ng, 0.05, 3) for dt, ng in ((A.I64, 40), (A.I16, 5))[:nkeys]]
+        vals = make_chunks(rng, val_dtype, lens, 0.2, 1, kind="special" if val_dtype in (A.F64, A.F32) and agg != "sum" else "plain")
+        ok, ov, oc = ora.groupby_agg(key_cols, vals, agg, 1000)
+        got = _groups(ok, ov, oc)
+        exp = _pandas_groups(key_cols, vals, agg)
+        if agg == "count":
+            assert {k: c for k, (_, c) in got.items()} == {k: c for k, (_, c) in exp.items()}
+            continue
+        if val_dtype in (A.I64, A.I32) and agg == "sum":   # wrapping sums
+            exp = {k: (((v + 2 ** 63) % 2 ** 64 - 2 ** 63) if v is not None else None, c) for k, (v, c) in exp.items()}
+        if val_dtype == A.U64 and agg == "sum":
+            exp = {k: (((v + 2 ** 63) % 2 ** 64 - 2 ** 63), c) for k, (v, c) in exp.items()}
+        _assert_same_groups(got, exp, val_dtype in (A.F64, A.F32), f"oracle vs pandas agg={agg} nkeys={nkeys}")
+
+
+def test_oracle_groupby_merge(ora):
+    """Merging the partial groups of two halves equals grouping the whole (sum, min, max) — and keeps integer sums above 2^53 exact."""
+    rng = np.random.default_rng(5)
+    n = 4000
+    keys = rng.integers(-50, 50, n).astype(np.int64)
+    for vals, agg in ((rng.uniform(-1, 1, n), "sum"), (rng.integers(2 ** 60, 2 ** 61, n).astype(np.int64), "sum"), (rng.uniform(-1, 1, n), "min"),
+                      (rng.integers(-10 ** 12, 10 ** 12, n).astype(np.int64), "max")):
+        valid = rng.uniform(size=n) > 0.3
+        whole = _groups(*ora.groupby_agg([[A.HostArray.from_numpy(keys)]], [A.HostArray.from_numpy(vals, valid=valid)], agg, 200))
+        parts = []
+        for sl in (slice(0, n // 2), slice(n // 2, n)):
+            pk, pv, pc = ora.groupby_agg([[A.HostArray.from_numpy(keys[sl])]], [A.HostArray.from_numpy(vals[sl], valid=valid[sl])], agg, 200)
+            parts.append((pk[0].to_numpy()[:pc.length], pv.to_numpy()[:pc.length], pv.valid_mask()[:pc.length], pc.to_numpy()[:pc.length]))
+        ck = np.concatenate([p[0] for p in parts]); cv = np.concatenate([p[1] for p in parts])
+        cm = np.concatenate([p[2] for p in parts]); cc = np.concatenate([p[3] for p in parts])
+        mk, mv, mc = ora.groupby_merge(A.HostArray.from_numpy(ck), A.HostArray.from_numpy(cv, valid=cm), A.HostArray.from_numpy(cc), agg, 200)
+        _assert_same_groups(_groups([mk], mv, mc), whole, vals.dtype.kind == "f", f"merge {agg}")
+
+
+# ---------------------------------------------------------------- GPU parity
+def _cfg_paths():
+    # (gb_partition option, max_groups slack) -> which kernel must run
+    return [(3, "auto"), (4, "gb2_scatter_kernel"), (0, "gb2_table_rows_kernel")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agg", AGGS)
+@pytest.mark.parametrize("key_dtype,val_dtype", [(A.I64, A.F64), (A.I32, A.I64), (A.U8, A.F32), (A.I16, A.U64), (A.U64, A.I8), (A.I64, A.U32)])
+def test_groupby_agg_parity_every_path(gpu, ora, agg, key_dtype, val_dtype):
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(1000 + 7 * key_dtype + val_dtype)
+    try:
+        for lens, nf, off, ngroups in [([5], 0.0, 0, 3), ([1024, 1024, 576], 0.0, 0, 50), ([700, 0, 3000], 0.15, 13, 200), ([40_000], 0.05, 3, 1500), ([0], 0.0, 0, 4)]:
+            keys = _key_chunks(rng, key_dtype, lens, ngroups, nf, off)
+            if key_dtype == A.I64 and lens[0] > 4:
+                raw = keys[0].values
+                raw[off], raw[off + 1] = np.iinfo(np.int64).min, np.iinfo(np.int64).max   # the global table's free marker is a legal key
+                raw[off + 2] = np.int64(7406324358081711299)                                 # g2_hash(key) == 2^64 - 1: the LDS free marker
+            kind = "special" if val_dtype in (A.F64, A.F32) and agg in ("min", "max") else "plain"
+            vals = make_chunks(rng, val_dtype, lens, nf, off, kind=kind)
+            exp = _groups(*ora.groupby_agg([keys], vals, agg, ngroups + 8))
+            for opt, kernel in _cfg_paths():
+                lib.set_option("gb_partition", opt)
+                got = _groups(*gpu.groupby_agg([keys], vals, agg, ngroups + 8))
+                if kernel != "auto" and sum(lens) > 0:
+                    assert lib.last_kernel().startswith(kernel), lib.last_kernel()
+                _assert_same_groups(got, exp, val_dtype in (A.F64, A.F32), f"agg={agg} keys={key_dtype} vals={val_dtype} lens={lens} path={opt}")
+    finally:
+        lib.set_option("gb_partition", 3)
+
+
+@pytest.mark.gpu
+def test_groupby_agg_stream_replicas_and_group_counts(gpu, ora):
+    """The LDS-table stream kernel across its sub-table layouts (2..2000 groups), keys far apart, value NULLs that leave
+    whole groups without a value, more distinct keys than promised -> MemoryError."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(4242)
+    n = 150_000
+    for ngroups in (2, 40, 100, 240, 490, 990, 2000):
+        kv = (rng.integers(0, ngroups, n).astype(np.int64) - ngroups // 2) * 1_000_003
+        valid = rng.uniform(size=n) > 0.25
+        valid[kv % 7 == 0] = False
+        keys = [A.HostArray.from_numpy(kv[:n // 2], rng=rng), A.HostArray.from_numpy(kv[n // 2:], offset=9, rng=rng)]
+        vals = [A.HostArray.from_numpy(rng.uniform(-1, 1, n // 2), valid=valid[:n // 2], rng=rng), A.HostArray.from_numpy(rng.uniform(-1, 1, n - n // 2), valid=valid[n // 2:], offset=9, rng=rng)]
+        for agg in ("sum", "max"):
+            exp = _groups(*ora.groupby_agg([keys], vals, agg, ngroups))
+            got = _groups(*gpu.groupby_agg([keys], vals, agg, ngroups))
+            assert lib.last_kernel() == "gb2_stream_kernel"
+            _assert_same_groups(got, exp, True, f"stream ngroups={ngroups} agg={agg}")
+    with pytest.raises(A.RdfError) as ei:
+        gpu.groupby_agg([[A.HostArray.from_numpy(np.arange(5000, dtype=np.int64))]], None, "count", 100)
+    assert ei.value.status == A.RDF_MEMORY_ERROR
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agg", ["sum", "min", "count"])
+def test_groupby_agg_partition_path_large(gpu, ora, agg):
+    """The line-aligned scatter at a size where every region sees many tiles and carries: 3e6 rows, 60 000 groups,
+    three chunks with offsets, NULL keys and NULL values; then keys skewed enough to overflow a region (fallback)."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(99)
+    n, ngroups = 3_000_000, 60_000
+    lens = [n // 3, 17, n - n // 3 - 17]
+    kv = rng.integers(-ngroups // 2, ngroups // 2, n).astype(np.int64) * 2_654_435_761
+    keys, vals, pos = [], [], 0
+    for ln in lens:
+        keys.append(A.HostArray.from_numpy(kv[pos:pos + ln], valid=rng.uniform(size=ln) >= 0.001, offset=5, rng=rng))
+        vals.append(A.HostArray.from_numpy(rng.uniform(-1, 1, ln), valid=rng.uniform(size=ln) >= 0.1, offset=2, rng=rng))
+        pos += ln
+    exp = _groups(*ora.groupby_agg([keys], vals, agg, ngroups + 8))
+    got = _groups(*gpu.groupby_agg([keys], vals, agg, ngroups + 8))
+    assert lib.last_kernel().startswith("gb2_scatter_kernel"), lib.last_kernel()
+    _assert_same_groups(got, exp, True, f"partition path agg={agg}")
+    hot = np.where(rng.uniform(size=n) < 0.5, 424242, kv)
+    keys = [A.HostArray.from_numpy(hot)]
+    vals1 = [A.HostArray.from_numpy(rng.uniform(-1, 1, n))]
+    exp = _groups(*ora.groupby_agg([keys], vals1, agg, ngroups + 8))
+    got = _groups(*gpu.groupby_agg([keys], vals1, agg, ngroups + 8))
+    assert not lib.last_kernel().startswith("gb2_scatter_kernel"), "a hot key overflows its region: another path must have produced the result"
+    _assert_same_groups(got, exp, True, f"skew fallback agg={agg}")
+
+
+@pytest.mark.gpu
+def test_groupby_agg_multi_column_keys(gpu, ora):
+    """Two to four grouping columns of mixed integer types, sparse values (range-compressed into one 64-bit key), NULLs in
+    every grouping column; a tuple that cannot fit 64 bits is an InvalidArgument."""
+    rng = np.random.default_rng(2024)
+    lens = [5000, 0, 12_000]
+    specs = [(A.I64, 30, -10 ** 15), (A.I8, 7, -3), (A.U32, 50, 4_000_000_000 - 25), (A.I16, 4, 100)]
+    for nkeys in (2, 3, 4):
+        key_cols = [_key_chunks(rng, dt, lens, ng, nf, 7, lo=lo) for (dt, ng, lo), nf in zip(specs[:nkeys], (0.02, 0.0, 0.05, 0.1))]
+        vals = make_chunks(rng, A.F64, lens, 0.1, 7)
+        for agg in ("sum", "max", "count"):
+            exp = _groups(*ora.groupby_agg(key_cols, vals, agg, 60_000))
+            got = _groups(*gpu.groupby_agg(key_cols, vals, agg, 60_000))
+            _assert_same_groups(got, exp, True, f"nkeys={nkeys} agg={agg}")
+    wide = [[A.HostArray.from_numpy(rng.integers(-2 ** 62, 2 ** 62, 1000).astype(np.int64))] for _ in range(2)]
+    with pytest.raises(A.RdfError) as ei:
+        gpu.groupby_agg(wide, None, "count", 2000)
+    assert ei.value.status == A.RDF_INVALID_ARGUMENT
+
+
+def _dev_array(lib, np_arr, dtype):
+    import ctypes as C
+    L = lib.load()
+    p = C.c_void_p(0)
+    nbytes = max(np_arr.nbytes, 8) + 64
+    assert L.rdf_dev_alloc(C.byref(p), nbytes) == 0
+    if np_arr.nbytes:
+        assert L.rdf_copy_h2d(p, np_arr.ctypes.data, np_arr.nbytes) == 0
+    return A.DeviceArray(p.value, None, 0, len(np_arr), dtype, 0, capacity=len(np_arr))
+
+
+def _dev_fetch(lib, darr, n, npdt):
+    out = np.empty(n, dtype=npdt)
+    if n:
+        assert lib.load().rdf_copy_d2h(out.ctypes.data, darr.values_ptr, out.nbytes) == 0
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agg", ["sum", "min", "max"])
+def test_groupby_merge_and_exchange_on_device(gpu, ora, agg):
+    """The merge step (host and device memory) and the device-resident exchange helpers: pack buckets rows by owner
+    (matching sharding.group_owner), unpack restores the columns, merging the buckets' unions equals the oracle's merge."""
+    from rust_dataframe_amd import lib, sharding
+    import ctypes as C
+    rng = np.random.default_rng(31)
+    n = 50_000
+    keys = rng.integers(-4000, 4000, n).astype(np.int64) * 97
+    part = rng.uniform(-5, 5, n)
+    cnts = rng.integers(0, 4, n).astype(np.int64)
+    exp = _groups(*[x if i else [x] for i, x in enumerate(ora.groupby_merge(A.HostArray.from_numpy(keys), A.HostArray.from_numpy(part), A.HostArray.from_numpy(cnts), agg, 9000))])
+    got = gpu.groupby_merge(A.HostArray.from_numpy(keys), A.HostArray.from_numpy(part), A.HostArray.from_numpy(cnts), agg, 9000)
+    _assert_same_groups(_groups([got[0]], got[1], got[2]), exp, True, f"merge host {agg}")
+    # device-resident: pack for 4 owners, check the buckets, unpack, merge everything again
+    dk, dp, dc = _dev_array(lib, keys, A.I64), _dev_array(lib, part, A.F64), _dev_array(lib, cnts, A.I64)
+    world = 4
+    packed = _dev_array(lib, np.zeros(3 * n, dtype=np.int64), A.I64)
+    counts = gpu.group_exchange_pack(dk, dp, dc, world, packed.values_ptr)
+    owner = sharding.group_owner(keys, world)
+    assert counts == np.bincount(owner, minlength=world).tolist()
+    words = _dev_fetch(lib, packed, 3 * n, np.int64).reshape(n, 3)
+    pos = 0
+    for r in range(world):
+        seg = words[pos:pos + counts[r]]
+        assert np.all(sharding.group_owner(seg[:, 0], world) == r)
+        pos += counts[r]
+    order = np.lexsort((words[:, 2], words[:, 1], words[:, 0]))
+    ref = np.stack([keys, part.view(np.int64), cnts], axis=1)
+    assert np.array_equal(words[order], ref[np.lexsort((ref[:, 2], ref[:, 1], ref[:, 0]))]), "the packed rows are a permutation of the input rows"
+    uk, up, uc = (_dev_array(lib, np.zeros(n, dtype=np.int64), dt) for dt in (A.I64, A.F64, A.I64))
+    gpu.group_exchange_unpack(packed.values_ptr, n, uk, up, uc)
+    assert np.array_equal(_dev_fetch(lib, uk, n, np.int64), words[:, 0]) and np.array_equal(_dev_fetch(lib, uc, n, np.int64), words[:, 2])
+    outs = (_dev_array(lib, np.zeros(9002, dtype=np.int64), A.I64), _dev_array(lib, np.zeros(9002, dtype=np.float64), A.F64), _dev_array(lib, np.zeros(9002, dtype=np.int64), A.I64))
+    if agg != "sum":
+        vb = _dev_array(lib, np.zeros(9002 // 8 + 16, dtype=np.uint8), A.U8)
+        outs[1].validity_ptr = vb.values_ptr
+    mk, mv, mc = gpu.groupby_merge(uk, up, uc, agg, 9000, outs=outs)
+    ng = mk.length
+    hk, hv, hc = _dev_fetch(lib, mk, ng, np.int64), _dev_fetch(lib, mv, ng, np.float64), _dev_fetch(lib, mc, ng, np.int64)
+    got = {(int(k),): ((None if (agg != "sum" and c == 0) else float(v)), int(c)) for k, v, c in zip(hk, hv, hc)}
+    _assert_same_groups(got, exp, True, f"merge device {agg}")
+    for d in (dk, dp, dc, packed, uk, up, uc) + outs:
+        lib.load().rdf_dev_free(C.c_void_p(d.values_ptr))

@@ -486,18 +486,20 @@ def test_groupby_partitioned_high_cardinality(gpu, ora, ngroups, n):
             if val_dtype is not None:
                 vals.append(A.HostArray.from_numpy(rng.uniform(-1, 1, ln) if val_dtype == A.F64 else rng.integers(-10 ** 9, 10 ** 9, ln), offset=2, dtype=val_dtype, rng=rng))
         exp = _sorted_groups(*ora.groupby_sum(keys, vals, ngroups + 8))
-        for part in (1, 2, 0):  # single-pass partitioned, radix-sort partitioned, then the HBM-atomics path on the same data
+        for part in (3, 4, 1, 2, 0):  # second generation (auto / scatter path forced), first-generation single-pass and radix-sort partitioning, the HBM table
             lib.set_option("gb_partition", part)
             got = _sorted_groups(*gpu.groupby_sum(keys, vals, ngroups + 8))
-            if part:
+            if part in (1, 2):
                 assert lib.last_kernel().startswith("gb_aggregate_kernel" if part == 1 else "groupby_partitions_kernel")
+            elif part:
+                assert lib.last_kernel().startswith("gb2_"), lib.last_kernel()
             assert np.array_equal(got[1], exp[1]) and np.array_equal(got[0][exp[1]], exp[0][exp[1]]), f"keys part={part}"
             assert np.array_equal(got[3], exp[3]), f"counts part={part}"
             if val_dtype == A.F64:
                 np.testing.assert_allclose(got[2], exp[2], rtol=1e-6, atol=1e-9)
             else:
                 assert np.array_equal(got[2], exp[2])
-        lib.set_option("gb_partition", 1)
+        lib.set_option("gb_partition", 3)
 
 
 def _pairs(l, r):
@@ -730,9 +732,12 @@ def test_groupby_partitioned_value_nulls_and_skew(gpu, ora, val_dtype):
         got = _sorted_groups(*gpu.groupby_sum(keys, vals, ngroups + 8))
         lib.set_option("gb_debug", 0)
         k = lib.last_kernel()
-        assert k.startswith("gb_aggregate_kernel"), k
-        if name != "uniform":
-            assert k.endswith("(combined)"), f"{name}: {k}"
+        # uniform keys: the second-generation line-aligned scatter; skewed keys overflow one of its fixed-capacity regions and
+        # the call falls back to the first-generation histogram + combining scatter
+        if name == "uniform":
+            assert k.startswith("gb2_scatter_kernel"), k
+        else:
+            assert k == "gb_aggregate_kernel(combined)", f"{name}: {k}"
         assert np.array_equal(got[1], exp[1]) and np.array_equal(got[0][exp[1]], exp[0][exp[1]]), f"keys {name}"
         assert np.array_equal(got[3], exp[3]), f"counts {name}"
         if val_dtype in (A.F64, A.F32):

@@ -158,6 +158,53 @@ def test_groupby_all_to_all_world_2_gloo(ora):
         assert got[key][1] == cnt and abs(got[key][0] - sm) <= 1e-9 * max(abs(sm), 1.0)
 
 
+def _gb_int_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from oracle import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        keys, vals = _gb_int_data()
+        b, e = sharding.shard_rows(len(keys), world, rank)
+        k, s, c = sharding.distributed_groupby_sum(oracle.api(), [A.HostArray.from_numpy(keys[b:e])], [A.HostArray.from_numpy(vals[b:e])], 1000)
+        q.put((rank, str(k.dtype), str(s.dtype), k.tolist(), s.tolist(), c.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _gb_int_data():
+    rng = np.random.default_rng(6)
+    n = 6000
+    return rng.integers(0, 200, n).astype(np.uint64) + np.uint64(2 ** 63), rng.integers(2 ** 58, 2 ** 59, n).astype(np.int64)
+
+
+@pytest.mark.timeout(120)
+def test_groupby_exchange_keeps_integer_sums_exact_world_2_gloo(ora):
+    """Integer sums far above 2^53 and UInt64 keys above 2^63 travel as raw 64-bit words: dtypes and values of the
+    multi-rank result equal the single-rank one bit for bit (wrapping Int64 sums)."""
+    world, port = 2, 33500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gb_int_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    keys, vals = _gb_int_data()
+    k, s, c = ora.groupby_sum([A.HostArray.from_numpy(keys)], [A.HostArray.from_numpy(vals)], 1000)
+    exp = {int(a): (int(b), int(d)) for a, b, d in zip(k.to_numpy(), s.to_numpy(), c.to_numpy())}
+    got = {}
+    for rank, kdt, sdt, gk, gs, gc in res:
+        assert kdt == "uint64" and sdt == "int64"
+        for a, b, d in zip(gk, gs, gc):
+            assert a not in got
+            got[int(a)] = (int(b), int(d))
+    assert got == exp
+
+
 # ---------------------------------------------------------------- config C5 (Q1 shape) across ranks: dense groups, all_gather combine
 def _q1_inputs():
     from test_group_pipeline import q1_columns, q1_program, _cols_list
