@@ -333,10 +333,14 @@ struct GroupEmitArgs {
 enum : int32_t { AGG_SUM = 0, AGG_MIN = 1, AGG_MAX = 2 };
 // MIN / MAX accumulate order-preserving 64-bit images of the values (ord_bits): unsigned atomic min / max then serve every
 // value class; the identity (~0 for MIN, 0 for MAX) is what a NULL or NaN value contributes.
-constexpr int kG2Block = 1024;                      // scatter: one block of 16 waves per CU (140 KB of LDS)
+constexpr int kG2PartBits = 8;                      // 256 partitions: carry (32 KB) + staging (32 KB) leave room for TWO scatter blocks per CU
+constexpr int kG2Block = 512;                       // scatter block: 8 waves; the two blocks of a CU overlap each other's load / LDS / store phases
 constexpr int kG2Rows = 4;                          // rows per thread per super-tile
-constexpr int kG2Super = kG2Block * kG2Rows;        // 4096 rows = 4 tiles of kEvalTile rows
+constexpr int kG2Super = kG2Block * kG2Rows;        // 2048 rows = 2 tiles of kEvalTile rows
 constexpr int kG2Line = 8;                          // records per 128-byte line: the only unit ever written
+constexpr int kG2Slots = 7919;                      // aggregation: LDS table slots per partition (prime; 20 B each = 158 KB, one 1024-thread block per CU)
+constexpr int kG2AggBlock = 1024;
+constexpr int64_t kG2MaxGroups = (int64_t)(1 << kG2PartBits) * 5100;   // expected table load <= 0.65
 constexpr int kG2StreamGroups = 2048;               // up to here one LDS table per block holds every group (gb2_stream_kernel)
 struct Gb2Args {
     const DevChunkCol* keys;             // [nchunks]
@@ -359,6 +363,7 @@ struct Gb2Args {
     // stream kernel: the global table the block tables are merged into
     GroupTable         t;
     int32_t            replicas, sub_slots;   // LDS table = replicas sub-tables of sub_slots slots (lane % replicas picks one)
+    int32_t            ablate, pad;           // bench ablations of the scatter (rdf_set_option("gb_debug", 21..24)): results invalid
 };
 struct Gb2AggArgs {
     const uint64_t* recs;

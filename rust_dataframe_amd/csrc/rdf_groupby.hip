@@ -24,11 +24,11 @@ namespace rdfk {
 
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kP = 1 << kGbPartBits;                 // 512 partitions
+constexpr int kP = 1 << kG2PartBits;                 // 256 partitions
 constexpr unsigned long long kFree = ~0ull;          // LDS free marker in hashed-key space
-constexpr uint64_t kKeyMask = (1ull << (64 - kGbPartBits)) - 1;
+constexpr uint64_t kKeyMask = (1ull << (64 - kG2PartBits)) - 1;
 constexpr uint64_t kDead = ~0ull;
-constexpr int kMaxFlushLines = 1024;                 // >= (7 * kP + kG2Super) / 8 = 960
+constexpr int kMaxFlushLines = 512;                  // >= (7 * kP + kG2Super) / 8 = 480
 
 __device__ __forceinline__ uint64_t g2_hash(uint64_t x) { x ^= x >> 32; x *= 0x9E3779B97F4A7C15ull; return x ^ (x >> 32); }
 __device__ __forceinline__ uint64_t g2_unhash(uint64_t x) { x ^= x >> 32; x *= 0xF1DE83E19937733Dull; return x ^ (x >> 32); }
@@ -194,15 +194,19 @@ struct LdsTab {
 
 // Up to B pending (hashed key, value, count) updates per lane, probes interleaved: one LDS round trip serves all pending
 // updates of the lane (the probe's dependent latency, not the atomics, is what a table costs).
-template <int B>
+// PB = partition bits above the slot bits.  PB == 0: the table holds every key (stream kernel) and the slot comes from the
+// hash's top 32 bits — Fibonacci hashing proper, collision-free for dense key ranges.  PB > 0: inside a partition the top
+// PB bits are the same for all keys and the slot comes from the 32 bits below them.  (Taking bits 23..54 over a WHOLE key
+// range turns the golden-ratio rotation into one close to 13/30: 2000 dense keys then build probe chains of up to 52
+// steps, and a wave waits for its unluckiest lane — measured 16.2 ms instead of 5.2 ms per 1e9 rows.)
+template <int B, int PB>
 __device__ __forceinline__ void tab_upsert(const LdsTab& t, int op, int cls, bool has_values, uint32_t base, uint32_t slots,
                                            const uint64_t (&hk)[B], const uint64_t (&val)[B], const uint32_t (&cnt)[B], uint32_t pending, uint32_t& err) {
     uint32_t s[B], step[B];
 #pragma unroll
     for (int u = 0; u < B; ++u) {
-        // slot from the 32 bits right below the partition bits (the best-mixed bits of a multiplicative hash)
-        s[u] = (uint32_t)(((uint64_t)(uint32_t)(hk[u] >> (32 - kGbPartBits)) * (uint64_t)slots) >> 32);
-        step[u] = 1u + (uint32_t)(((uint64_t)(uint32_t)(hk[u] >> 3) * (uint64_t)(slots - 1)) >> 32);
+        s[u] = (uint32_t)(((uint64_t)(uint32_t)(hk[u] >> (32 - PB)) * (uint64_t)slots) >> 32);
+        step[u] = 1u + (uint32_t)(((uint64_t)(uint32_t)(PB ? hk[u] >> 3 : hk[u]) * (uint64_t)(slots - 1)) >> 32);
     }
     uint32_t guard = 0;
     while (__any(pending != 0)) {
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(kStreamBlock) void gb2_stream_kernel(const Gb2Args 
         uint32_t cnt[kStreamRows];
 #pragma unroll
         for (int j = 0; j < kStreamRows; ++j) cnt[j] = (rows.cnt >> j) & 1;
-        tab_upsert<kStreamRows>(t, a.op, a.vcls, has_values, base, (uint32_t)a.sub_slots, rows.hk, rows.val, cnt, rows.live, err);
+        tab_upsert<kStreamRows, 0>(t, a.op, a.vcls, has_values, base, (uint32_t)a.sub_slots, rows.hk, rows.val, cnt, rows.live, err);
         if (more) cur = nxt;
     }
     __syncthreads();
@@ -311,44 +315,50 @@ __global__ __launch_bounds__(kStreamBlock) void gb2_stream_kernel(const Gb2Args 
 
 // ------------------------------------------------------------------------------------------------
 // <= 1.3 M groups, pass 1: scatter 16-byte records into (partition, block) regions, whole aligned lines only.
-// Record: word 0 = (cnt << 55) | (hashed key & (2^55 - 1)) — the partition bits are implied by where the record lies and
+// Record: word 0 = (cnt << 56) | (hashed key & (2^56 - 1)) — the partition bits are implied by where the record lies and
 // make room for cnt (0: the value was NULL, the group must still exist) —, word 1 = accumulator contribution; ~0 = dead.
+//
+// Two blocks per CU (72 KB of LDS each): measured on the one-block-per-CU version (tools/abl_gb2.py) a tile's phases did
+// not overlap at all — loads + hash 3.8 ms, ranking + staging 2.3 ms, flush 3.3 ms per 1e9 rows added up to the
+// kernel's 9.5 ms — so the second block is what fills the memory pipe while the first one is in its LDS phases.
+// Per flushed line ONE 64-bit descriptor (destination line, staging index, carry length, partition) is all the flush
+// phase reads before it moves the line: the partition's owner thread writes it while it does the bookkeeping.
 
-__global__ __launch_bounds__(kG2Block) void gb2_scatter_kernel(const Gb2Args a) {
+__global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
     u64x2* stage = (u64x2*)gsm;                           // [kG2Super] this tile's records, grouped by partition
     u64x2* carry = stage + kG2Super;                      // [kP * 8] records waiting for their line to fill
-    uint32_t* tcnt = (uint32_t*)(carry + kP * kG2Line);   // [kP] rank counters of the tile
+    uint64_t* ldesc = (uint64_t*)(carry + kP * kG2Line);  // [kMaxFlushLines] per flush line: dst line | (stage index + 8) << 32 | c << 48 | j0 << 51 | d << 52
+    uint32_t* tcnt = (uint32_t*)(ldesc + kMaxFlushLines); // [kP] rank counters of the tile
     uint32_t* ccnt = tcnt + kP;                           // [kP] records in the carry
     uint32_t* written = ccnt + kP;                        // [kP] lines of the region already written
     uint32_t* lstart = written + kP;                      // [kP] first staging slot of the partition
-    uint32_t* cfl = lstart + kP;                          // [kP] carry count the flush works with
-    uint32_t* wfl = cfl + kP;                             // [kP] written count the flush works with
-    uint32_t* linestart = wfl + kP;                       // [kP] first flush line of the partition
-    uint16_t* linepart = (uint16_t*)(linestart + kP);     // [kMaxFlushLines] partition of flush line i
+    uint32_t* tail = lstart + kP;                         // [kP] staging index of the partition's new carry (partitions that flush)
     __shared__ uint32_t wtot_t[kP / 64], wtot_k[kP / 64], ltot, abort_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < kP) { tcnt[tid] = 0; ccnt[tid] = 0; written[tid] = 0; }
     if (tid == 0) abort_s = 0;
     __syncthreads();
-    const int64_t nb = gridDim.x, bid = blockIdx.x;
-    const int64_t cap = a.cap_lines;
+    const uint32_t nb = gridDim.x, bid = blockIdx.x;
+    const uint32_t cap = (uint32_t)a.cap_lines;
+    const uint32_t region0 = tid < kP ? ((uint32_t)tid * nb + bid) * cap : 0;   // first line of this thread's partition's region
     u64x2* const recs = (u64x2*)a.recs;
     uint32_t err = 0;
     constexpr int TPI = kG2Super / kEvalTile;
-    const int64_t stride = nb * TPI;
-    int64_t st = bid * TPI;
+    const int64_t stride = (int64_t)nb * TPI;
+    int64_t st = (int64_t)bid * TPI;
     G2Raw<kG2Rows> raw;
     G2Rows<kG2Rows> rows;
     if (st < a.ntiles) { g2_load<kG2Rows, kG2Block>(a, st, tid, raw); g2_prepare<kG2Rows>(a, raw, rows); }
     for (; st < a.ntiles; st += stride) {
         const bool more = st + stride < a.ntiles;
         if (more) g2_load<kG2Rows, kG2Block>(a, st + stride, tid, raw);   // the next tile's loads fly during the LDS phases
+        if (a.ablate == 24) { uint64_t x = 0; for (int j = 0; j < kG2Rows; ++j) x ^= rows.hk[j] ^ rows.val[j]; if (x == 0x1234567) a.special[0] = 1; if (more) g2_prepare<kG2Rows>(a, raw, rows); continue; }   // loads + hash only
         // (B) rank inside the partition
         uint32_t rank[kG2Rows];
 #pragma unroll
         for (int j = 0; j < kG2Rows; ++j)
-            if ((rows.live >> j) & 1) rank[j] = atomicAdd(&tcnt[(uint32_t)(rows.hk[j] >> (64 - kGbPartBits))], 1u);
+            if ((rows.live >> j) & 1) rank[j] = atomicAdd(&tcnt[(uint32_t)(rows.hk[j] >> (64 - kG2PartBits))], 1u);
         __syncthreads();
         // (C) per partition: staging offset, number of whole lines it can now flush, their place in the flush list
         uint32_t tc = 0, cc = 0, kk = 0, inc_t = 0, inc_k = 0;
@@ -365,19 +375,24 @@ __global__ __launch_bounds__(kG2Block) void gb2_scatter_kernel(const Gb2Args a) 
         }
         if (tid == 0) abort_s = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u;
         __syncthreads();
-        if (abort_s) break;     // some block overflowed a region: the host re-runs the histogram path
+        if (abort_s) break;     // some block overflowed a region: the host re-runs another path
         if (tid < kP) {
             uint32_t off_t = 0, off_k = 0;
 #pragma unroll
             for (int w = 0; w < kP / 64; ++w) if (w < wave) { off_t += wtot_t[w]; off_k += wtot_k[w]; }
             const uint32_t ex_t = off_t + inc_t - tc, ex_k = off_k + inc_k - kk;
+            const uint32_t w0 = written[tid];
             lstart[tid] = ex_t;
-            linestart[tid] = ex_k;
-            cfl[tid] = cc;
-            wfl[tid] = written[tid];
-            for (uint32_t j = 0; j < kk; ++j) linepart[ex_k + j] = (uint16_t)tid;
+            tail[tid] = ex_t + 8 * kk - cc;
+            if (w0 + kk > cap) err |= 16u;
+            for (uint32_t j = 0; j < kk; ++j) {
+                const uint32_t dst = w0 + j < cap ? region0 + w0 + j : 0xFFFFFFFFu;
+                // stage index of the line's lane 0, biased by 8 (line 0 starts c slots before the partition's staging run)
+                ldesc[ex_k + j] = (uint64_t)dst | ((uint64_t)(ex_t + 8 * j + 8 - cc) << 32) | ((uint64_t)(j == 0 ? cc : 0) << 48)
+                                  | ((uint64_t)(j == 0) << 51) | ((uint64_t)tid << 52);
+            }
             ccnt[tid] = cc + tc - 8 * kk;
-            written[tid] += kk;
+            written[tid] = w0 + kk;
             tcnt[tid] = 0;
             if (tid == kP - 1) ltot = ex_k + kk;
         }
@@ -385,10 +400,10 @@ __global__ __launch_bounds__(kG2Block) void gb2_scatter_kernel(const Gb2Args a) 
         // (D) stage the tile's records grouped by partition
 #pragma unroll
         for (int j = 0; j < kG2Rows; ++j)
-            if ((rows.live >> j) & 1) {
-                const uint32_t d = (uint32_t)(rows.hk[j] >> (64 - kGbPartBits));
+            if (((rows.live >> j) & 1) && a.ablate != 23) {
+                const uint32_t d = (uint32_t)(rows.hk[j] >> (64 - kG2PartBits));
                 u64x2 rec;
-                rec[0] = ((uint64_t)((rows.cnt >> j) & 1) << (64 - kGbPartBits)) | (rows.hk[j] & kKeyMask);
+                rec[0] = ((uint64_t)((rows.cnt >> j) & 1) << (64 - kG2PartBits)) | (rows.hk[j] & kKeyMask);
                 rec[1] = rows.val[j];
                 stage[lstart[d] + rank[j]] = rec;
             }
@@ -396,21 +411,18 @@ __global__ __launch_bounds__(kG2Block) void gb2_scatter_kernel(const Gb2Args a) 
         // the next tile's rows: waiting for its loads HERE keeps the flush stores below out of that wait
         if (more) g2_prepare<kG2Rows>(a, raw, rows);
         // (E) flush whole lines: 8 consecutive lanes write one aligned 128-byte line of a region
-        const uint32_t nl = ltot;
+        const uint32_t nl = (a.ablate == 22 || a.ablate == 23) ? 0u : ltot;
         for (uint32_t i = (uint32_t)tid >> 3; i < nl; i += kG2Block / 8) {
-            const uint32_t d = linepart[i], j = i - linestart[d], l8 = (uint32_t)tid & 7, pos = 8 * j + l8, c = cfl[d];
-            const u64x2 rec = pos < c ? carry[d * kG2Line + pos] : stage[lstart[d] + pos - c];
-            const int64_t line = (int64_t)wfl[d] + j;
-            if (line < cap) recs[(((int64_t)d * nb + bid) * cap + line) * kG2Line + l8] = rec;
-            else err |= 16u;
-            if (j == 0) {   // the partition's new carry: the tail of its tile records (this lane read its old carry slot above)
-                const uint32_t k = written[d] - wfl[d], r = ccnt[d];
-                if (l8 < r) carry[d * kG2Line + l8] = stage[lstart[d] + 8 * k - c + l8];
+            const uint64_t ds = ldesc[i];
+            const uint32_t l8 = (uint32_t)tid & 7, dst = (uint32_t)ds, src = (uint32_t)(ds >> 32) & 0xFFFFu, c = (uint32_t)(ds >> 48) & 7u, d = (uint32_t)(ds >> 52);
+            const u64x2 rec = l8 < c ? carry[d * kG2Line + l8] : stage[src + l8 - 8];
+            if (dst != 0xFFFFFFFFu) { if (a.ablate != 21) recs[(uint64_t)dst * kG2Line + l8] = rec; else if (rec[0] == 0x1234567) a.special[0] = 1; }
+            if ((ds >> 51) & 1) {   // the partition's new carry: the tail of its tile records (this lane read its old carry slot above)
+                if (l8 < ccnt[d]) carry[d * kG2Line + l8] = stage[tail[d] + l8];
             }
         }
-        if (tid < kP && written[tid] == wfl[tid]) {   // no line to flush: the tile's records join the carry
-            const uint32_t c = cfl[tid], t2 = ccnt[tid] - c;
-            for (uint32_t i = 0; i < t2; ++i) carry[tid * kG2Line + c + i] = stage[lstart[tid] + i];
+        if (tid < kP && kk == 0 && tc) {   // no line to flush: the tile's records join the carry
+            for (uint32_t i = 0; i < tc; ++i) carry[tid * kG2Line + cc + i] = stage[lstart[tid] + i];
         }
         if (err & 16u) atomicOr(a.flags, 16u);
         __syncthreads();
@@ -423,8 +435,8 @@ __global__ __launch_bounds__(kG2Block) void gb2_scatter_kernel(const Gb2Args a) 
         u64x2 rec;
         rec[0] = kDead; rec[1] = 0;
         if (l8 < c) rec = carry[d * kG2Line + l8];
-        const int64_t line = written[d];
-        if (line < cap) recs[(((int64_t)d * nb + bid) * cap + line) * kG2Line + l8] = rec;
+        const uint32_t line = written[d];
+        if (line < cap) recs[((uint64_t)(d * nb + bid) * cap + line) * kG2Line + l8] = rec;
         else err |= 16u;
     }
     __syncthreads();
@@ -434,41 +446,39 @@ __global__ __launch_bounds__(kG2Block) void gb2_scatter_kernel(const Gb2Args a) 
 
 // pass 2: one block per partition; its records are the nb line ranges the scatter blocks wrote
 constexpr int kAggBatch = 4;
-__global__ __launch_bounds__(kGbBlock) void gb2_aggregate_kernel(const Gb2AggArgs a) {
+__global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2AggArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
     LdsTab t;
     t.keys = (unsigned long long*)gsm;
-    t.acc = t.keys + kGbSlots;
-    t.cnt = (unsigned int*)(t.acc + kGbSlots);
-    t.ngroups = t.cnt + kGbSlots;
+    t.acc = t.keys + kG2Slots;
+    t.cnt = (unsigned int*)(t.acc + kG2Slots);
+    t.ngroups = t.cnt + kG2Slots;
     unsigned int* misc = t.ngroups + 1;   // [0] output base, [1] emit cursor
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id();
-    constexpr int NW = kGbBlock / 64;
+    constexpr int NW = kG2AggBlock / 64;
     const unsigned long long ident = agg_identity(a.op);
     uint32_t err = 0;
     const u64x2* const recs = (const u64x2*)a.recs;
     for (int p = blockIdx.x; p < kP; p += gridDim.x) {
-        for (int i = tid; i < kGbSlots; i += kGbBlock) { t.keys[i] = kFree; t.acc[i] = ident; t.cnt[i] = 0; }
+        for (int i = tid; i < kG2Slots; i += kG2AggBlock) { t.keys[i] = kFree; t.acc[i] = ident; t.cnt[i] = 0; }
         if (tid == 0) *t.ngroups = 0;
         __syncthreads();
-        const uint64_t ptop = (uint64_t)p << (64 - kGbPartBits);
+        const uint64_t ptop = (uint64_t)p << (64 - kG2PartBits);
         // wave w streams the regions b = w, w + NW, ...: kAggBatch x 64 consecutive records per step, the next step's loads
         // issued before the current step is folded into the table
-        int64_t b = wave;
-        int64_t off = 0;
-        int64_t nrec = 0;
+        int64_t b = (int64_t)wave - NW, off = 0, nrec = 0;
         const u64x2* base = recs;
-        auto open_region = [&]() {
-            while (b < a.nb) {
+        bool open = false;
+        auto advance = [&]() {
+            open = false;
+            for (b += NW; b < a.nb; b += NW) {
                 nrec = (int64_t)a.nlines[(int64_t)p * a.nb + b] * kG2Line;
-                if (nrec > 0) { base = recs + ((int64_t)p * a.nb + b) * a.cap_lines * kG2Line; off = 0; return true; }
-                b += NW;
+                if (nrec > 0) { base = recs + ((int64_t)p * a.nb + b) * a.cap_lines * kG2Line; off = 0; open = true; return; }
             }
-            return false;
         };
         auto load_batch = [&](u64x2 (&r)[kAggBatch]) -> bool {   // false: this wave's regions are exhausted
-            if (off >= nrec) { if (off > 0 || nrec == 0) { if (nrec > 0) b += NW; if (!open_region()) return false; } }
+            if (!open) return false;
 #pragma unroll
             for (int u = 0; u < kAggBatch; ++u) {
                 const int64_t i = off + u * 64 + lane;
@@ -476,8 +486,10 @@ __global__ __launch_bounds__(kGbBlock) void gb2_aggregate_kernel(const Gb2AggArg
                 if (i < nrec) r[u] = __builtin_nontemporal_load(base + i);
             }
             off += kAggBatch * 64;
+            if (off >= nrec) advance();
             return true;
         };
+        advance();
         u64x2 cur[kAggBatch], nxt[kAggBatch];
         bool have = load_batch(cur);
         while (have) {
@@ -488,10 +500,10 @@ __global__ __launch_bounds__(kGbBlock) void gb2_aggregate_kernel(const Gb2AggArg
             for (int u = 0; u < kAggBatch; ++u) {
                 hk[u] = (cur[u][0] & kKeyMask) | ptop;
                 val[u] = cur[u][1];
-                cnt[u] = (uint32_t)(cur[u][0] >> (64 - kGbPartBits));
+                cnt[u] = (uint32_t)(cur[u][0] >> (64 - kG2PartBits));
                 if (cur[u][0] != kDead) pending |= 1u << u;
             }
-            tab_upsert<kAggBatch>(t, a.op, a.vcls, a.has_values != 0, 0u, (uint32_t)kGbSlots, hk, val, cnt, pending, err);
+            tab_upsert<kAggBatch, kG2PartBits>(t, a.op, a.vcls, a.has_values != 0, 0u, (uint32_t)kG2Slots, hk, val, cnt, pending, err);
             if (nhave) {
 #pragma unroll
                 for (int u = 0; u < kAggBatch; ++u) cur[u] = nxt[u];
@@ -501,7 +513,7 @@ __global__ __launch_bounds__(kGbBlock) void gb2_aggregate_kernel(const Gb2AggArg
         __syncthreads();
         if (tid == 0) { misc[0] = atomicAdd(a.cursor, *t.ngroups); misc[1] = 0; }
         __syncthreads();
-        for (int k = tid; k < kGbSlots; k += kGbBlock) {
+        for (int k = tid; k < kG2Slots; k += kG2AggBlock) {
             if (t.keys[k] == kFree) continue;
             const unsigned idx = misc[0] + atomicAdd(&misc[1], 1u);
             if ((int64_t)idx >= a.max_out) { err |= 4u; continue; }
@@ -695,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void key_unpack_kernel(const KeyPackArgs a)
 // launchers
 
 size_t gb2_scatter_lds_bytes() {
-    return (size_t)kG2Super * 16 + (size_t)kP * kG2Line * 16 + (size_t)kP * 4 * 7 + (size_t)kMaxFlushLines * 2;
+    return (size_t)kG2Super * 16 + (size_t)kP * kG2Line * 16 + (size_t)kMaxFlushLines * 8 + (size_t)kP * 4 * 5;
 }
 hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s) {
     const size_t lds = (size_t)kGbSlots * 20 + 16;
@@ -710,9 +722,9 @@ hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_gb2_aggregate(const Gb2AggArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)kGbSlots * 20 + 32;
+    const size_t lds = (size_t)kG2Slots * 20 + 32;
     (void)hipFuncSetAttribute((const void*)gb2_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gb2_aggregate_kernel, dim3(kP), dim3(kGbBlock), lds, s, a);
+    hipLaunchKernelGGL(gb2_aggregate_kernel, dim3(kP), dim3(kG2AggBlock), lds, s, a);
     return hipGetLastError();
 }
 static int g2_rows_grid(int64_t n) {

@@ -268,13 +268,17 @@ def main():
         report("join_inner_1e8_x_1e7", 8.0 * nl_ + 8.0 * nr_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk_, A.I64, nl_)], [arr(rk_, A.I64, nr_)], "inner", (jl, jr)))
         del lk_, rk_
     # hash GROUP BY key -> sum(val): 1e6 groups (config C4's per-GPU leg) and 1e3 groups (contended)
-    for ng in (1_000_000, 1_000):
+    for ng in (1_000_000, 2_000, 1_000, 100, 8):
         kk = dev_i64(n, 7, 0, ng)
         KK = arr(kk, A.I64, n)
         ok_, os_, oc_ = out_like(A.I64, ng + 2), out_like(A.F64, ng + 2), out_like(A.I64, ng + 2)
         oc2_ = out_like(A.I64, ng + 2)
         report(f"groupby_sum_{ng}_groups", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
-        if ng > 1024:
+        report(f"groupby_max_{ng}_groups", 16.0 * n, lambda: api.groupby_agg([[KK]], [X], "max", ng, ([ok_], os_, oc_)))
+        lib.set_option("gb_partition", 1)
+        report(f"groupby_sum_{ng}_groups_first_generation", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
+        lib.set_option("gb_partition", 3)
+        if ng > 2048:
             # skewed keys (SURVEY.md §8d C4 variant): Zipf-like s = 1.1 (inverse-CDF of the continuous power law, clamped) and one hot key
             u = torch.rand(n, device="cuda", dtype=torch.float64).clamp_(min=1e-12)
             kz = torch.clamp(torch.floor(u.pow(-1.0 / 0.1)), max=float(ng - 1)).to(torch.int64)
@@ -286,7 +290,7 @@ def main():
             del ks
             report(f"groupby_sum_{ng}_groups_null_values", 16.125 * n, lambda: api.groupby_sum([KK], [XV], ng, (ok_, os_, oc_)))
             del u, kz, kh
-            for dbg in (1, 2, 4, 5, 6, 7, 8):
+            for dbg in ((1, 2, 4, 5, 6, 7, 8) if "ablate" in args.only else ()):   # ablations of the FIRST-generation passes
                 lib.set_option("gb_debug", dbg)
                 try:
                     report(f"groupby_sum_{ng}_groups_ablate{dbg}", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
@@ -298,7 +302,7 @@ def main():
             report(f"groupby_sum_{ng}_groups_radix_sort", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
             lib.set_option("gb_partition", 0)
             report(f"groupby_sum_{ng}_groups_hbm_atomics", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
-            lib.set_option("gb_partition", 1)
+            lib.set_option("gb_partition", 3)
     # config C5 (TPC-H Q1 shape): filter(shipdate <= c) -> 5 sums + counts in 6 groups, 38 B/row
     if not only or "q1_grouped" in only:
         qty = torch.randint(1, 51, (n,), device="cuda").to(torch.float64)

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(512) void k_lines(u32x4* __restrict__ out, int P, i
 static float time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
 int main(int argc, char** argv) {
+    const bool only_lines = argc > 1;   // any argument: Exp 2 only
     const int64_t GB = 1ll << 30;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -69,7 +70,7 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     const int grid = 2048;
     // ---- Exp 1
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < (only_lines ? 0 : 2); ++nt)
         for (int64_t S : {16ll << 20, 32ll << 20, 64ll << 20, 128ll << 20, 256ll << 20, 1024ll << 20}) {
             for (int fixed = 1; fixed >= 0; --fixed) {
                 const int64_t nslab = T / S;
@@ -90,7 +91,7 @@ int main(int argc, char** argv) {
             }
         }
     // read-only and copy denominators on the same buffers
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < (only_lines ? 0 : 2); ++rep) {
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(k_r, dim3(grid), dim3(256), 0, 0, (const u32x4*)in, T / 16, sink, 1);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -107,8 +108,8 @@ int main(int argc, char** argv) {
     CK(hipFree(in));
     // ---- Exp 2: total 8 GB written per configuration
     struct Cfg { int nb, P; };
-    for (Cfg c : {Cfg{256, 256}, Cfg{512, 256}, Cfg{512, 512}, Cfg{2048, 512}})
-        for (int line : {128, 256, 512, 1024})
+    for (Cfg c : {Cfg{256, 256}, Cfg{512, 256}, Cfg{512, 512}, Cfg{2048, 512}, Cfg{256, 512}})
+        for (int line : {64, 128, 256, 512, 1024})
             for (int shift : {0, 3})
                 for (int nt = 0; nt < 2; ++nt) {
                     const int64_t total_lines = T / line;
@@ -118,7 +119,8 @@ int main(int argc, char** argv) {
                     float ms = 0;
                     for (int rep = 0; rep < 2; ++rep) {
                         CK(hipEventRecord(e0));
-                        if (line == 128) hipLaunchKernelGGL(k_lines<128>, dim3(c.nb), dim3(512), 0, 0, (u32x4*)rec, c.P, cap_lines, iters, shift, nt);
+                        if (line == 64) hipLaunchKernelGGL(k_lines<64>, dim3(c.nb), dim3(512), 0, 0, (u32x4*)rec, c.P, cap_lines, iters, shift, nt);
+                        else if (line == 128) hipLaunchKernelGGL(k_lines<128>, dim3(c.nb), dim3(512), 0, 0, (u32x4*)rec, c.P, cap_lines, iters, shift, nt);
                         else if (line == 256) hipLaunchKernelGGL(k_lines<256>, dim3(c.nb), dim3(512), 0, 0, (u32x4*)rec, c.P, cap_lines, iters, shift, nt);
                         else if (line == 512) hipLaunchKernelGGL(k_lines<512>, dim3(c.nb), dim3(512), 0, 0, (u32x4*)rec, c.P, cap_lines, iters, shift, nt);
                         else hipLaunchKernelGGL(k_lines<1024>, dim3(c.nb), dim3(512), 0, 0, (u32x4*)rec, c.P, cap_lines, iters, shift, nt);
