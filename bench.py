@@ -398,11 +398,12 @@ def main():
     else:
         col = [A.DeviceArray(x.data_ptr(), vptr, 0, rows, A.F64, -1, keep=(x, vkeep))]
 
+    frame = A.Prepared([col])   # the descriptor array is marshalled once (ctypes costs ~1 us per RecordBatch; a Rust / C++ caller has it as is)
     e = A.Expr()
     c = e.col(0)
     pred = e.op("gt", c, e.scalar(THRESHOLD))
     def step():
-        local = api.pipeline(e, [col], [c], pred)          # fused filter -> {sum,min,max,count}, one pass over HBM
+        local = api.pipeline(e, frame, [c], pred)          # fused filter -> {sum,min,max,count}, one pass over HBM
         tot = sharding.all_combine(local, device=comm_dev)[0]      # N > 1: all_gather the partials (RCCL), fold in rank order
         return tot.sum, tot.count
 

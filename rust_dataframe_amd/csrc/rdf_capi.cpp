@@ -46,6 +46,7 @@ struct Ctx {
     bool   opt_fast_filter = true; // filter_agg_f64_kernel (handles 8-byte-misaligned columns)
     bool   opt_vec_bitmap = true;  // bitmap words via vector loads (default) instead of scalar loads (spec kernels)
     bool   opt_filter_one = true;   // one-chunk compaction kernel with its descriptors in the kernel arguments (A/B)
+    int    opt_filter_gen = 2;      // compaction kernels: 2 = wave-granular tiles (rdf_filter.hip, default), 1 = first-generation block tiles (A/B)
     int    opt_filter_tile = 0;     // 0: compaction tile chosen from the mean chunk length; 1024 / 4096 force one (A/B)
     int    opt_gb_debug = 0;        // ablations of the partitioned GROUP BY (tools/bench_kernels.py): 1 = aggregate without LDS work, 2 = scatter without stores
     int    opt_gb_partition = 3;    // hash GROUP BY: 3 = second generation (rdf_groupby.hip: stream / line-aligned scatter / table by max_groups, default), 4 = its partition path whatever max_groups says, 1 = first-generation histogram + scatter, 2 = first-generation radix sort, 0 = one table in HBM
@@ -1010,7 +1011,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     // device scratch: flags | null counts | partials | result
     const size_t n_nc = ps.sink == RDF_SINK_STORE ? (size_t)ps.nvalues * (size_t)nchunks : 0;
     const int gwords = grouped ? group_words(ps.ngroups, ps.nvalues) : 0;
-    const size_t scratch_bytes = 16 + n_nc * 8 + ((size_t)grid + 1) * (grouped ? (size_t)gwords * 8 : (size_t)ps.nvalues * sizeof(AggPartial));
+    const size_t scratch_bytes = 16 + n_nc * 8 + ((size_t)grid + 4) * (grouped ? (size_t)gwords * 8 : (size_t)ps.nvalues * sizeof(AggPartial));   // + 4: the specialised kernels' grid (wave-granular tiles) may round up past this one
     void* scratch = nullptr;
     RDF_TRY(arena_alloc(scratch_bytes, &scratch));
     uint32_t* d_flags = (uint32_t*)scratch;
@@ -1073,7 +1074,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     if (have_plan) {
         memset(&sa, 0, sizeof sa);
         use_spec = true;
-        spec_rpb = spec_rows_per_block_iter(sp.sig.c_str());
+        spec_rpb = spec_rows_per_tile(sp.sig.c_str());
         for (int k = 0; k < sp.ncols && use_spec; ++k)
             for (int64_t c = 0; c < nchunks; ++c) {
                 const DevChunkCol& d = in.dev[(size_t)((int64_t)sp.col_map[k] * nchunks + c)];
@@ -1098,6 +1099,9 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         std::vector<int64_t> sts((size_t)nchunks + 1, 0);
         for (int64_t c = 0; c < nchunks; ++c) sts[(size_t)c + 1] = sts[(size_t)c] + (clen[(size_t)c] + spec_rpb - 1) / spec_rpb;
         sa.ntiles = sts[(size_t)nchunks];
+        sa.tile_inv = 0;
+        if (nchunks > 1 && sts[(size_t)nchunks - 1] > 0 && nchunks - 1 < ((int64_t)1 << 31))
+            sa.tile_inv = (uint64_t)(((unsigned __int128)(uint64_t)(nchunks - 1) << 32) / (unsigned __int128)(uint64_t)sts[(size_t)nchunks - 1]);
         if (nchunks == 1) {
             for (int k = 0; k < sp.ncols; ++k) sa.cols[k] = in.dev[(size_t)sp.col_map[k]];
             sa.n = clen[0];
@@ -1120,7 +1124,8 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             sa.chunk_len = stb.dev_at<int64_t>(o_l);
             sa.outs_tab = stb.dev_at<DevOutChunk>(o_o);
         }
-        grid = (int)(sa.ntiles < (int64_t)eval_grid_limit() ? sa.ntiles : (int64_t)eval_grid_limit());
+        const int64_t btiles = (sa.ntiles + kBlock / 64 - 1) / (kBlock / 64);   // a block's waves take consecutive tiles
+        grid = (int)(btiles < (int64_t)eval_grid_limit() ? btiles : (int64_t)eval_grid_limit());
         if (grid < 1) grid = 1;
         d_result = d_partials + (size_t)grid * (size_t)ps.nvalues;
     }
@@ -1548,60 +1553,44 @@ struct FilterPrep {
     int64_t ntiles = 0;
     int64_t* d_counts = nullptr;  // [ntiles]
     int64_t* d_scan = nullptr;    // [ntiles + 1]
+    bool wave = true;             // wave-granular tiles (rdf_filter.hip)
+    bool dma_ok = false;          // every column 8 / 4 bytes wide, chunks of >= 1024 rows: the LDS-DMA kernel may take the frame
+    FilterWArgs wa;
     size_t o_cols = 0, o_outs = 0;
     size_t pin_off = 0;
 };
 
-// Stage mask (+ columns), build the tile tables, run count + scan; leaves per-chunk keep totals in `totals`.
-rdf_status filter_prepare(FilterPrep& fp, const rdf_array* cols, int ncols, const rdf_array* mask, int64_t nchunks,
-                          std::vector<int64_t>& totals) {
+// Tiles of `tile_rows` rows (never spanning chunks): prefix table, per-tile keep counts, their scan; leaves the per-chunk
+// keep totals in `totals`.  Callable again with another tile size (the staged inputs and descriptor tables stay).
+rdf_status filter_tiles(FilterPrep& fp, int tile_rows, int64_t nchunks, std::vector<int64_t>& totals) {
     Ctx& ctx = g_ctx;
-    for (int64_t c = 0; c < nchunks; ++c) fp.in.add(&mask[c]);
-    for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) fp.in.add(&cols[i]);
-    size_t used = 0;
-    RDF_TRY(fp.in.finish(fp.pin_off, &used));
-    fp.pin_off += (used + 255) & ~(size_t)255;
-
-    fp.clen.resize((size_t)nchunks);
-    fp.tile_start.assign((size_t)nchunks + 1, 0);
-    // tiles never span chunks: frames in the reader's 1024-row batches get 1024-row tiles (a 4096-row tile would leave
-    // three of the four waves of a block without rows), long chunks the 4096-row ones
-    int64_t rows_total = 0;
-    for (int64_t c = 0; c < nchunks; ++c) rows_total += mask[c].length;
-    int tile_rows = nchunks > 0 && rows_total / nchunks <= 2048 ? kFilterTileSmall : kFilterTile;
-    if (ctx.opt_filter_tile == kFilterTileSmall || ctx.opt_filter_tile == kFilterTile) tile_rows = ctx.opt_filter_tile;
-    for (int64_t c = 0; c < nchunks; ++c) {
-        fp.clen[(size_t)c] = mask[c].length;
-        fp.tile_start[(size_t)c + 1] = fp.tile_start[(size_t)c] + (mask[c].length + tile_rows - 1) / tile_rows;
-    }
-    fp.ntiles = fp.tile_start[(size_t)nchunks];
-
-    const size_t o_mask = fp.tb.reserve(sizeof(DevChunkCol) * (size_t)nchunks);
-    const size_t o_ts = fp.tb.reserve(sizeof(int64_t) * fp.tile_start.size());
-    const size_t o_len = fp.tb.reserve(sizeof(int64_t) * fp.clen.size());
-    fp.o_cols = fp.tb.reserve(sizeof(DevChunkCol) * ((size_t)ncols * (size_t)nchunks + 1));
-    fp.o_outs = fp.tb.reserve(sizeof(DevOutChunk) * ((size_t)ncols * (size_t)nchunks + 1));
-    memcpy(fp.tb.at<char>(o_mask), fp.in.dev.data(), sizeof(DevChunkCol) * (size_t)nchunks);
-    memcpy(fp.tb.at<char>(o_ts), fp.tile_start.data(), sizeof(int64_t) * fp.tile_start.size());
-    memcpy(fp.tb.at<char>(o_len), fp.clen.data(), sizeof(int64_t) * fp.clen.size());
-    if (ncols > 0) memcpy(fp.tb.at<char>(fp.o_cols), fp.in.dev.data() + nchunks, sizeof(DevChunkCol) * (size_t)ncols * (size_t)nchunks);
-    RDF_TRY(fp.tb.alloc());
-    // the outs table is filled in later (after the counts are known): upload the front part now
-    RDF_TRY(fp.tb.upload(fp.pin_off));
-    fp.pin_off += (fp.tb.host.size() + 255) & ~(size_t)255;
-
-    fp.mt.mask = fp.tb.dev_at<DevChunkCol>(o_mask);
-    fp.mt.chunk_tile_start = fp.tb.dev_at<int64_t>(o_ts);
-    fp.mt.chunk_len = fp.tb.dev_at<int64_t>(o_len);
-    fp.mt.nchunks = nchunks;
-    fp.mt.ntiles = fp.ntiles;
     fp.tile_rows = tile_rows;
+    fp.tile_start.assign((size_t)nchunks + 1, 0);
+    for (int64_t c = 0; c < nchunks; ++c) fp.tile_start[(size_t)c + 1] = fp.tile_start[(size_t)c] + (fp.clen[(size_t)c] + tile_rows - 1) / tile_rows;
+    fp.ntiles = fp.tile_start[(size_t)nchunks];
+    void* pts = nullptr;
+    const size_t ts_bytes = sizeof(int64_t) * fp.tile_start.size();
+    RDF_TRY(arena_alloc(ts_bytes, &pts));
+    RDF_TRY(pinned_reserve(fp.pin_off + ts_bytes + 256));
+    memcpy(ctx.pinned + fp.pin_off, fp.tile_start.data(), ts_bytes);
+    HIP_TRY(hipMemcpyAsync(pts, ctx.pinned + fp.pin_off, ts_bytes, hipMemcpyHostToDevice, ctx.stream));
+    fp.pin_off += (ts_bytes + 255) & ~(size_t)255;
+    fp.mt.chunk_tile_start = (const int64_t*)pts;
+    fp.mt.ntiles = fp.ntiles;
 
     void* p = nullptr;
     RDF_TRY(arena_alloc(sizeof(int64_t) * (2 * (size_t)fp.ntiles + 2 + (size_t)scan_scratch_words(fp.ntiles)), &p));
     fp.d_counts = (int64_t*)p;
     fp.d_scan = fp.d_counts + fp.ntiles;
-    if (nchunks == 1 && fp.tile_rows == kFilterTile && ctx.opt_filter_one) HIP_TRY(launch_mask_count_one(fp.in.dev[0], fp.clen[0], fp.ntiles, fp.d_counts, ctx.stream));
+    if (fp.wave) {
+        memset(&fp.wa, 0, sizeof fp.wa);
+        fp.wa.t = fp.mt;
+        fp.wa.prefetch = ctx.opt_filter_gen != 3;   // (3: A/B without the look-ahead)
+        if (nchunks == 1) { fp.wa.mask0 = fp.in.dev[0]; fp.wa.len0 = fp.clen[0]; }
+        if (nchunks > 1 && fp.tile_start[(size_t)nchunks - 1] > 0 && nchunks - 1 < ((int64_t)1 << 31))
+            fp.wa.tile_inv = (uint64_t)(((unsigned __int128)(uint64_t)(nchunks - 1) << 32) / (unsigned __int128)(uint64_t)fp.tile_start[(size_t)nchunks - 1]);
+        HIP_TRY(launch_fcount(fp.wa, fp.tile_rows, fp.d_counts, ctx.stream));
+    } else if (nchunks == 1 && fp.tile_rows == kFilterTile && ctx.opt_filter_one) HIP_TRY(launch_mask_count_one(fp.in.dev[0], fp.clen[0], fp.ntiles, fp.d_counts, ctx.stream));
     else HIP_TRY(launch_mask_count(fp.mt, fp.tile_rows, fp.d_counts, ctx.stream));
     HIP_TRY(launch_scan(fp.d_counts, fp.d_scan, fp.ntiles, fp.d_scan + fp.ntiles + 1, ctx.stream));
 
@@ -1620,6 +1609,61 @@ rdf_status filter_prepare(FilterPrep& fp, const rdf_array* cols, int ncols, cons
         HIP_TRY(hipMemcpyAsync(pin, fp.d_scan, 8 * ((size_t)fp.ntiles + 1), hipMemcpyDeviceToHost, ctx.stream));
         HIP_TRY(hipStreamSynchronize(ctx.stream));
         for (int64_t c = 0; c < nchunks; ++c) totals[(size_t)c] = pin[fp.tile_start[(size_t)c + 1]] - pin[fp.tile_start[(size_t)c]];
+    }
+    return RDF_OK;
+}
+
+// Stage mask (+ columns), build the descriptor tables, pick the compaction kernels and their tile size, count + scan.
+rdf_status filter_prepare(FilterPrep& fp, const rdf_array* cols, int ncols, const rdf_array* mask, int64_t nchunks,
+                          std::vector<int64_t>& totals) {
+    Ctx& ctx = g_ctx;
+    for (int64_t c = 0; c < nchunks; ++c) fp.in.add(&mask[c]);
+    for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) fp.in.add(&cols[i]);
+    size_t used = 0;
+    RDF_TRY(fp.in.finish(fp.pin_off, &used));
+    fp.pin_off += (used + 255) & ~(size_t)255;
+
+    fp.clen.resize((size_t)nchunks);
+    int64_t rows_total = 0;
+    for (int64_t c = 0; c < nchunks; ++c) { fp.clen[(size_t)c] = mask[c].length; rows_total += mask[c].length; }
+    const int64_t mean_len = nchunks > 0 ? rows_total / nchunks : 0;
+    // first generation (block tiles, one barrier per tile): 1024-row tiles for frames in the reader's batches, 4096 otherwise
+    int tile_rows = nchunks > 0 && mean_len <= 2048 ? kFilterTileSmall : kFilterTile;
+    if (ctx.opt_filter_tile == kFilterTileSmall || ctx.opt_filter_tile == kFilterTile) tile_rows = ctx.opt_filter_tile;
+    // wave-granular kernels (rdf_filter.hip) — the default, with one exception: ONE column of ONE long chunk is still
+    // faster on the first-generation block tiles when the LDS-DMA kernel cannot take it (measured per 1e9 rows: 2.34 ms
+    // against 2.8 ms for the register-staged wave tiles)
+    bool all_wide = ncols > 0;
+    for (int k = 0; k < ncols; ++k) { const int es = dtype_size(cols[(int64_t)k * nchunks].dtype); all_wide &= es == 8 || es == 4; }
+    fp.dma_ok = all_wide && rows_total >= nchunks * (int64_t)(kWDmaTile * 3 / 4) && ctx.opt_filter_gen == 2;   // most tiles full (the reader's last batch is short)
+    fp.wave = ctx.opt_filter_gen >= 2 && !(ctx.opt_filter_gen == 2 && nchunks == 1 && ncols == 1 && !fp.dma_ok);
+    if (fp.wave) {
+        tile_rows = fp.dma_ok ? kWDmaTile : nchunks > 0 && mean_len <= 256 ? kWTileSmall : kWTile;
+        if (!fp.dma_ok && (ctx.opt_filter_tile == kWTileSmall || ctx.opt_filter_tile == kWTile)) tile_rows = ctx.opt_filter_tile;
+    }
+
+    const size_t o_mask = fp.tb.reserve(sizeof(DevChunkCol) * (size_t)nchunks);
+    const size_t o_len = fp.tb.reserve(sizeof(int64_t) * fp.clen.size());
+    fp.o_cols = fp.tb.reserve(sizeof(DevChunkCol) * ((size_t)ncols * (size_t)nchunks + 1));
+    fp.o_outs = fp.tb.reserve(sizeof(DevOutChunk) * ((size_t)ncols * (size_t)nchunks + 1));
+    memcpy(fp.tb.at<char>(o_mask), fp.in.dev.data(), sizeof(DevChunkCol) * (size_t)nchunks);
+    memcpy(fp.tb.at<char>(o_len), fp.clen.data(), sizeof(int64_t) * fp.clen.size());
+    if (ncols > 0) memcpy(fp.tb.at<char>(fp.o_cols), fp.in.dev.data() + nchunks, sizeof(DevChunkCol) * (size_t)ncols * (size_t)nchunks);
+    RDF_TRY(fp.tb.alloc());
+    // the outs table is filled in later (after the counts are known): upload the front part now
+    RDF_TRY(fp.tb.upload(fp.pin_off));
+    fp.pin_off += (fp.tb.host.size() + 255) & ~(size_t)255;
+
+    fp.mt.mask = fp.tb.dev_at<DevChunkCol>(o_mask);
+    fp.mt.chunk_len = fp.tb.dev_at<int64_t>(o_len);
+    fp.mt.nchunks = nchunks;
+    RDF_TRY(filter_tiles(fp, tile_rows, nchunks, totals));
+    if (fp.tile_rows == kWDmaTile) {
+        // the LDS-DMA kernel fetches every sector of a tile: a selective filter (< 1/8 of the rows kept) goes to the
+        // register-staged wave tiles, which only touch the sectors that hold a kept row
+        int64_t kept = 0;
+        for (int64_t c = 0; c < nchunks; ++c) kept += totals[(size_t)c];
+        if (kept * 8 < rows_total) RDF_TRY(filter_tiles(fp, kWTile, nchunks, totals));
     }
     return RDF_OK;
 }
@@ -1721,6 +1765,20 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
     {
         KernelTimer kt;
         for (int g = 0; g < ncols; g += kMaxFilterCols) {  // ranks are recomputed per group of columns (1 bit/row)
+            if (fp.wave) {
+                FilterWArgs& wa = fp.wa;
+                wa.cols = fp.tb.dev_at<DevChunkCol>(fp.o_cols) + (size_t)g * (size_t)nchunks;
+                wa.outs = fp.tb.dev_at<DevOutChunk>(fp.o_outs) + (size_t)g * (size_t)nchunks;
+                wa.out_null_counts = d_nullc + (size_t)g * (size_t)nchunks;
+                wa.tile_scan = fp.d_scan;
+                wa.ncols = ncols - g < kMaxFilterCols ? ncols - g : kMaxFilterCols;
+                for (int k = 0; k < wa.ncols; ++k) {
+                    wa.esize[k] = dtype_size(cols[(int64_t)(g + k) * nchunks].dtype);
+                    if (nchunks == 1) { wa.cols0[k] = fp.in.dev[(size_t)(1 + g + k)]; wa.outs0[k] = dev_outs[(size_t)(g + k)]; }
+                }
+                HIP_TRY(launch_fcompact(wa, fp.tile_rows, ctx.stream));
+                continue;
+            }
             if (nchunks == 1 && fp.tile_rows == kFilterTile && ctx.opt_filter_one) {   // one long chunk: descriptors in the kernel arguments
                 FilterOneArgs oa;
                 memset(&oa, 0, sizeof oa);
@@ -3014,6 +3072,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "gb_debug") == 0) g_ctx.opt_gb_debug = (int)value;
     else if (strcmp(name, "filter_tile") == 0) g_ctx.opt_filter_tile = (int)value;
     else if (strcmp(name, "filter_one") == 0) g_ctx.opt_filter_one = value != 0;
+    else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
     else return fail(RDF_INVALID_ARGUMENT, "unknown option %s", name);
     return RDF_OK;
 }

@@ -280,6 +280,29 @@ __device__ __forceinline__ int64_t find_chunk_tile(const int64_t* start, int64_t
     return lo;
 }
 
+// The same with the division replaced by a multiplication: inv = floor(((n - 1) << 32) / start[n - 1]) comes from the host.
+// For equally long batches the guess is exact or one short; both neighbours are tried before any search.  (An explicit
+// "uniform batches" fast path next to the search cost the specialised kernels 20 VGPRs and with them a third of their
+// occupancy; this single path costs none.)
+__device__ __forceinline__ int64_t find_chunk_tile_inv(const int64_t* start, int64_t n, int64_t t, uint64_t inv) {
+    if (n <= 1) return 0;
+    if (inv == 0 || t >= ((int64_t)1 << 32)) return find_chunk(start, n, t);
+    int64_t g = (int64_t)(((uint64_t)(uint32_t)t * inv) >> 32);
+    if (g > n - 1) g = n - 1;
+    const int64_t sg = start[g], s1 = start[g + 1 < n ? g + 1 : g];
+    if (sg <= t) {
+        if (g + 1 == n || s1 > t) return g;
+        if (g + 2 == n || start[g + 2] > t) return g + 1;
+        int64_t lo = g + 2, hi = n - 1;
+        while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (start[mid] <= t) lo = mid; else hi = mid - 1; }
+        return lo;
+    }
+    if (g >= 1 && start[g - 1] <= t) return g - 1;
+    int64_t lo = 0, hi = g >= 2 ? g - 2 : 0;
+    while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (start[mid] <= t) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
 // Row -> chunk lookups done per LANE (take, sort keys): the same interpolation with the division replaced by a
 // multiplication with `inv` = (n - 1) / start[n - 1] (chunk_lookup_scale, computed once per kernel).  The guess is
 // exact or one off for equally sized chunks (three loads); other layouts finish with a search from the guess.

@@ -127,10 +127,11 @@ struct SpecArgs {
     DevOutChunk        out;              // nchunks == 1, SINK_STORE
     const DevChunkCol* cols_tab;         // nchunks > 1: [NC * nchunks], canonical column order
     const DevOutChunk* outs_tab;         // nchunks > 1, SINK_STORE: [nchunks]
-    const int64_t*     chunk_tile_start; // nchunks > 1: [nchunks + 1], tiles of rows_per_block_iter rows
+    const int64_t*     chunk_tile_start; // nchunks > 1: [nchunks + 1], tiles of spec_rows_per_tile rows (one wave iteration)
     const int64_t*     chunk_len;        // nchunks > 1: [nchunks]
     int64_t            nchunks, ntiles;
     int64_t            n;                // nchunks == 1: rows
+    uint64_t           tile_inv;         // floor(((nchunks - 1) << 32) / chunk_tile_start[nchunks - 1]): the tile -> chunk guess is a multiply (0: search)
     uint64_t           imm[4];
     int64_t*           out_null_count;   // SINK_STORE: [nchunks]
     AggPartial*        partials;         // SINK_AGG: [gridDim.x * nvalues]
@@ -169,6 +170,27 @@ struct FilterOneArgs {
     DevOutChunk        outs[kMaxFilterCols];
 };
 hipError_t launch_compact_one(const FilterOneArgs& a, hipStream_t s);   // kFilterTile-row tiles
+
+// Wave-granular compaction (rdf_filter.hip, the default): a tile is one wave's kWTile (or kWTileSmall) rows of one chunk.
+constexpr int kWTile = 512;          // 8 mask words per wave: half a reference RecordBatch (16 words cost 192 VGPRs: 2 waves per SIMD)
+constexpr int kWDmaTile = 1024;      // LDS-DMA compaction: 16 mask words per wave = one reference RecordBatch
+constexpr int kWTileSmall = 256;     // frames whose chunks are shorter still (mean chunk length <= 256 rows)
+struct FilterWArgs {
+    MaskTables         t;                // tiles of kWTile / kWTileSmall rows
+    DevChunkCol        mask0;            // nchunks == 1: descriptors inline
+    int64_t            len0;
+    const DevChunkCol* cols;             // [ncols * nchunks]
+    const DevOutChunk* outs;             // [ncols * nchunks]
+    int64_t*           out_null_counts;  // [ncols * nchunks]
+    const int64_t*     tile_scan;        // [ntiles + 1] exclusive scan of the per-tile keep counts
+    uint64_t           tile_inv;         // see find_chunk_tile_inv
+    int32_t            ncols, prefetch;  // prefetch: look the next tile up under the current tile's loads (chunked frames)
+    int32_t            esize[kMaxFilterCols];
+    DevChunkCol        cols0[kMaxFilterCols];   // nchunks == 1
+    DevOutChunk        outs0[kMaxFilterCols];
+};
+hipError_t launch_fcount(const FilterWArgs& a, int tile_rows, int64_t* tile_counts, hipStream_t s);
+hipError_t launch_fcompact(const FilterWArgs& a, int tile_rows, hipStream_t s);
 hipError_t launch_mask_count_one(const DevChunkCol& mask, int64_t clen, int64_t ntiles, int64_t* tile_counts, hipStream_t s);
 
 // Stable LSD radix sort of (key, row index) pairs, 8 bits per pass (DataFrame::sort -> lexsort_to_indices).
@@ -476,7 +498,7 @@ int gspec_catalog_size();
 hipError_t launch_group_final(const GroupFinalArgs& a, hipStream_t s);
 hipError_t launch_agg_final(const AggFinalArgs& a, hipStream_t s);
 bool spec_available(const char* sig);
-int  spec_rows_per_block_iter(const char* sig);
+int  spec_rows_per_tile(const char* sig);
 int  spec_catalog_size();
 hipError_t launch_spec(const char* sig, const SpecArgs& a, int grid, hipStream_t s);
 hipError_t launch_filter_agg_f64(const FilterAggF64Args& a, int cmp_op, int grid, hipStream_t s);

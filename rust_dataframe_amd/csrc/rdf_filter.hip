@@ -1,0 +1,535 @@
+// rdf_filter.hip — order-preserving stream compaction, wave-granular (Column::filter -> ChunkedArray::filter ->
+// arrow::compute::filter per chunk pair, src/table.rs:97-107,213-215; DataFrame::filter's per-column loop,
+// src/dataframe.rs:178-189, as ONE pass over the mask).
+//
+//   fcount_kernel -> scan -> fcompact_kernel
+//
+// A tile is ONE WAVE's work: WW mask words = WW * 64 rows of ONE chunk (WW = 8: 512 rows, half of one of the reference
+// readers' RecordBatches, src/dataframe.rs:352 — 16 words per wave cost 192 VGPRs —; WW = 4 for frames of even shorter chunks).  The scan runs over wave
+// tiles, so a wave knows where its kept rows go without talking to its neighbours: no block barrier, no block-wide tile
+// that a 1024-row chunk would fill to a quarter (first generation: 0.28 of the HBM peak on 1024-row batches), and a
+// block's four waves work on four different chunks at once.  Per tile and column:
+//   * dense tiles (>= 1/4 of the rows kept, all rows present, 16-byte aligned) load whole 16-byte vectors — half the
+//     load instructions of the per-row form; sparse tiles load only the kept rows (a 64-byte sector with no kept row is
+//     never fetched);
+//   * ranks = scalar prefix over the wave's keep-words + popcount of the lane's word below its bit: no shuffles;
+//   * kept values are staged in the wave's private LDS region, shifted by (output position mod vector) so that aligned
+//     16-byte vectors of the staging area are aligned 16-byte vectors of the output: the run leaves as dwordx4 stores.
+#include <type_traits>
+
+#include "rdf_common.hip.h"
+
+namespace rdfk {
+
+template <int WW> constexpr int wtile_rows() { return WW * 64; }
+
+template <int WW>
+__device__ __forceinline__ void wkeep_words(const DevChunkCol& m, int64_t rw, int64_t clen, uint64_t (&kw)[WW]) {
+    load_windows<WW>((const uint8_t*)m.values, m.offset + rw, clen - rw, kw);
+    if (m.validity) {
+        uint64_t vw[WW];
+        load_windows<WW>(m.validity, m.offset + rw, clen - rw, vw);
+#pragma unroll
+        for (int i = 0; i < WW; ++i) kw[i] &= vw[i];
+    }
+}
+
+struct WTile { int64_t c, r0, clen; };
+template <int WW>
+__device__ __forceinline__ WTile wlocate(const FilterWArgs& a, int64_t tile) {
+    WTile t;
+    if (a.t.nchunks == 1) { t.c = 0; t.r0 = tile * wtile_rows<WW>(); t.clen = a.len0; }
+    else {
+        t.c = find_chunk_tile_inv(a.t.chunk_tile_start, a.t.nchunks, tile, a.tile_inv);
+        t.r0 = (tile - a.t.chunk_tile_start[t.c]) * wtile_rows<WW>();
+        t.clen = a.t.chunk_len[t.c];
+    }
+    return t;
+}
+
+template <int WW>
+__global__ __launch_bounds__(kBlock) void fcount_kernel(const FilterWArgs a, int64_t* tile_counts) {
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id();
+    constexpr int kWaves = kBlock / 64;
+    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < a.t.ntiles; tile += (int64_t)gridDim.x * kWaves) {
+        const WTile t = wlocate<WW>(a, tile);
+        const DevChunkCol m = a.t.nchunks == 1 ? a.mask0 : a.t.mask[t.c];
+        uint64_t kw[WW];
+        wkeep_words<WW>(m, t.r0, t.clen, kw);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < WW; ++i) cnt += __popcll(kw[i]);
+        if (lane == 0) tile_counts[tile] = cnt;
+    }
+}
+
+template <class T> struct Vec16 { typedef T type __attribute__((ext_vector_type(16 / sizeof(T)))); };
+
+// Vector loads of one column's tile.
+template <typename T, int WW>
+__device__ __forceinline__ bool wvec_ok(const DevChunkCol& col, int64_t rw, int64_t clen) {
+    constexpr int E = 16 / (int)sizeof(T);
+    return E > 1 && WW % E == 0 && rw + WW * 64 <= clen && (((uintptr_t)(const void*)(as_global<T>(col.values) + col.offset + rw)) & 15) == 0;
+}
+template <typename T, int WW>
+__device__ __forceinline__ void wvec_load(const DevChunkCol& col, int64_t rw, typename Vec16<T>::type (&v)[WW * (int)sizeof(T) / 16 > 0 ? WW * (int)sizeof(T) / 16 : 1]) {
+    constexpr int E = 16 / (int)sizeof(T);
+    using V = typename Vec16<T>::type;
+    const int lane = threadIdx.x & 63;
+    const GlobalPtr<V> p = (GlobalPtr<V>)(as_global<T>(col.values) + col.offset + rw) + lane;
+#pragma unroll
+    for (int g = 0; g < WW / E; ++g) v[g] = __builtin_nontemporal_load(p + g * 64);
+}
+
+// One column of one wave tile.  `stage`: (WW * 64 + 16 / sizeof(T)) elements of the wave's private LDS region.
+template <typename T, int WW>
+__device__ __forceinline__ void wcompact(const DevChunkCol col, const DevOutChunk oc, int64_t rw, int64_t clen, int64_t wave_out,
+                                         const uint64_t (&kw)[WW], int cnt, unsigned char* stage_raw, uint8_t* vstage, uint32_t& nulls) {
+    constexpr int E = 16 / (int)sizeof(T);        // elements per 16-byte vector
+    using V = typename Vec16<T>::type;
+    const int lane = threadIdx.x & 63;
+    T* stage = (T*)stage_raw;
+    const bool hasv = col.validity != nullptr;
+    uint64_t vw[WW];
+    if (hasv) load_windows<WW>(col.validity, col.offset + rw, clen - rw, vw);
+    const GlobalPtr<T> src0 = as_global<T>(col.values) + col.offset + rw;
+    const bool vec_out = (((uintptr_t)oc.values) & 15) == 0;
+    const int shift = vec_out ? (int)(wave_out & (E - 1)) : 0;
+    const bool dense = cnt * 4 >= WW * 64 && wvec_ok<T, WW>(col, rw, clen);
+    if (dense) {
+        if constexpr (E > 1 && WW % E == 0) {
+            constexpr int NG = WW / E;                // groups of 64 vectors = 64 * E rows = E mask words
+            V v[NG];
+            wvec_load<T, WW>(col, rw, v);
+            const int widx = (E * lane) >> 6, bit = (E * lane) & 63;    // this lane's E rows: bits [bit, bit + E) of word E * g + widx
+            int wb = shift;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                uint64_t w = kw[E * g], wv = hasv ? vw[E * g] : 0;
+                int before = wb;
+#pragma unroll
+                for (int h = 1; h < E; ++h) {
+                    if (widx >= h) before += __popcll(kw[E * g + h - 1]);
+                    if (widx == h) { w = kw[E * g + h]; if (hasv) wv = vw[E * g + h]; }
+                }
+                before += __popcll(w & ((1ull << bit) - 1));
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if ((w >> (bit + e)) & 1) {
+                        stage[before] = v[g][e];
+                        if (hasv) vstage[before] = (uint8_t)((wv >> (bit + e)) & 1);
+                        ++before;
+                    }
+#pragma unroll
+                for (int h = 0; h < E; ++h) wb += __popcll(kw[E * g + h]);
+            }
+        }
+    } else {
+        const GlobalPtr<T> src = src0 + lane;
+        T val[WW];
+#pragma unroll
+        for (int i = 0; i < WW; ++i)
+            if ((kw[i] >> lane) & 1) val[i] = __builtin_nontemporal_load(src + i * 64);
+        int wb = shift;
+#pragma unroll
+        for (int i = 0; i < WW; ++i) {
+            if ((kw[i] >> lane) & 1) {
+                const int rank = wb + __popcll(kw[i] & ((1ull << lane) - 1));
+                stage[rank] = val[i];
+                if (hasv) vstage[rank] = (uint8_t)((vw[i] >> lane) & 1);
+            }
+            wb += __popcll(kw[i]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // same-wave LDS ops are executed in order; this only pins the compiler
+    // slots [shift, shift + cnt) of the staging area are output elements [wave_out, wave_out + cnt)
+    const int total = shift + cnt;
+    if (vec_out && E > 1) {
+        const GlobalMutPtr<T> dst0 = as_global_mut<T>(oc.values) + (wave_out - shift);
+        for (int j = lane; j * E < total; j += 64) {
+            const int s0 = j * E;
+            if (s0 >= shift && s0 + E <= total) __builtin_nontemporal_store(*(const V*)&stage[s0], (GlobalMutPtr<V>)dst0 + j);
+            else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) if (s0 + e >= shift && s0 + e < total) dst0[s0 + e] = stage[s0 + e];
+            }
+        }
+    } else {
+        const GlobalMutPtr<T> dst = as_global_mut<T>(oc.values) + wave_out;
+        for (int i = lane; i < cnt; i += 64) __builtin_nontemporal_store(stage[shift + i], dst + i);
+    }
+    if (hasv && oc.validity) {
+        // out bits [wave_out, wave_out + cnt): ballot 64 aligned positions at a time, OR into the (pre-zeroed) bitmap;
+        // boundary words are shared with neighbouring tiles, hence atomics
+        const int64_t end = wave_out + cnt;
+        for (int64_t wpos = wave_out & ~63ll; wpos < end; wpos += 64) {
+            const int64_t pos = wpos + lane;
+            const bool inside = pos >= wave_out && pos < end;
+            const bool bitv = inside && vstage[shift + (pos - wave_out)];
+            const uint64_t word = __ballot(bitv);
+            const uint64_t inw = __ballot(inside);
+            if (lane == 0) {
+                if (word) atomicOr((unsigned long long*)oc.validity + (wpos >> 6), (unsigned long long)word);
+                nulls += (uint32_t)__popcll(inw & ~word);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ES = common element size of all columns of the launch (8 / 4 / 2 / 1) or 0 for mixed sizes.
+// PF: the NEXT tile's place (chunk search, chunk length, output offset, mask descriptor — a chain of dependent scalar
+// loads for chunked frames) is looked up while the current tile's values are in flight.
+template <int ES, int WW, bool PF>
+__global__ __launch_bounds__(kBlock, ES ? 4 : 2) void fcompact_kernel(const FilterWArgs a) {
+    constexpr int kWaves = kBlock / 64;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[kWaves][WW * 64 * 8 + 16];
+    __shared__ uint8_t vstage[kWaves][WW * 64 + 16];
+    __shared__ uint32_t nullacc[kWaves][kMaxFilterCols];   // per-wave null counters per column, flushed once per (column, chunk)
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id();
+    if (lane < kMaxFilterCols) nullacc[wave][lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    int64_t cur_chunk = -1;
+    const bool one = a.t.nchunks == 1;
+    struct Meta { WTile t; int64_t wave_out; DevChunkCol m; };
+    auto locate_all = [&](int64_t tile) -> Meta {
+        Meta mt;
+        mt.t = wlocate<WW>(a, tile);
+        // where this tile's kept rows start in the chunk's output
+        mt.wave_out = one ? a.tile_scan[tile] : a.tile_scan[tile] - a.tile_scan[a.t.chunk_tile_start[mt.t.c]];
+        mt.m = one ? a.mask0 : a.t.mask[mt.t.c];
+        return mt;
+    };
+    const int64_t tile0 = (int64_t)blockIdx.x * kWaves + wave, tstride = (int64_t)gridDim.x * kWaves;
+    Meta meta;
+    if (PF && tile0 < a.t.ntiles) meta = locate_all(tile0);
+    for (int64_t tile = tile0; tile < a.t.ntiles; tile += tstride) {
+        if (!PF) meta = locate_all(tile);
+        const WTile t = meta.t;
+        const int64_t wave_out = meta.wave_out;
+        if (t.c != cur_chunk) {
+            if (cur_chunk >= 0 && lane < a.ncols && nullacc[wave][lane]) {
+                atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)lane * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[wave][lane]);
+                nullacc[wave][lane] = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            cur_chunk = t.c;
+        }
+        // (Requesting column 0's vectors before the mask words are known, and column k + 1's while column k is staged,
+        // was measured and dropped: the double-buffered vectors push the kernel past 128 VGPRs — one column 2.8 -> 3.1 ms,
+        // two 4.4 -> 4.9 ms per 1e9 rows.)
+        uint64_t kw[WW];
+        wkeep_words<WW>(meta.m, t.r0, t.clen, kw);
+        if (PF && tile + tstride < a.t.ntiles) meta = locate_all(tile + tstride);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < WW; ++i) cnt += __popcll(kw[i]);
+        if (cnt == 0) continue;
+#pragma unroll 1
+        for (int k = 0; k < a.ncols; ++k) {
+            const DevChunkCol col = one ? a.cols0[k] : a.cols[(int64_t)k * a.t.nchunks + t.c];
+            const DevOutChunk oc = one ? a.outs0[k] : a.outs[(int64_t)k * a.t.nchunks + t.c];
+            uint32_t nn = 0;
+            const int es = ES ? ES : a.esize[k];
+            if (es == 8) wcompact<uint64_t, WW>(col, oc, t.r0, t.clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+            else if (es == 4) wcompact<uint32_t, WW>(col, oc, t.r0, t.clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+            else if (es == 2) wcompact<uint16_t, WW>(col, oc, t.r0, t.clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+            else wcompact<uint8_t, WW>(col, oc, t.r0, t.clen, wave_out, kw, cnt, stage[wave], vstage[wave], nn);
+            if (lane == 0 && nn) nullacc[wave][k] += nn;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (cur_chunk >= 0 && lane < a.ncols && nullacc[wave][lane])
+        atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)lane * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[wave][lane]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA compaction: a wave's 1024-row tile of an 8- or 4-byte column goes global -> LDS with buffer-less
+// `global_load_lds_dwordx4` (no VGPRs hold data in flight: 8 KB per wave, 16 waves per CU = 128 KB per CU under way,
+// twice what the register-staged kernels manage at their 120-190 VGPRs), is compacted IN PLACE in LDS (a kept element
+// moves to a lower address than any element not yet read), and leaves as aligned 16-byte stores.  The DMA is issued
+// before the mask words are waited for: one memory round trip per tile and column instead of two.  Tiles that are not
+// full or not 16-byte aligned, and 1- / 2-byte columns, take the register path (two 512-row halves).
+// Chosen by the host for filters that keep at least 1/8 of the rows (a selective filter should not fetch every sector).
+
+typedef __attribute__((address_space(3))) void* LdsPtr;
+
+// 64-bit windows of a bitmap kept ONE PER LANE (lane j < NW holds window j = bits [bitpos + 64 j, +64), rows past nbits
+// cleared): sixteen windows as scalars are 32 SGPRs — with the validity words 64 of the wave's ~100 — and the spills they
+// cause cost the kernel its occupancy; a window is read back with v_readlane where it is used.
+template <int NW>
+struct LaneWin { uint64_t w0, w1; int sh; int64_t nbits; };
+template <int NW>
+__device__ __forceinline__ LaneWin<NW> lane_windows_issue(const uint8_t* base, int64_t bitpos, int64_t nbits) {
+    const int lane = threadIdx.x & 63;
+    LaneWin<NW> r;
+    r.w0 = 0; r.w1 = 0; r.sh = 0; r.nbits = nbits;
+    if (nbits <= 0) return r;
+    const uint64_t addr = uniform64((uint64_t)(uintptr_t)base + (uint64_t)(bitpos >> 3));
+    const GlobalPtr<uint64_t> w = (GlobalPtr<uint64_t>)(uintptr_t)(addr & ~7ull);
+    r.sh = __builtin_amdgcn_readfirstlane((int)(addr & 7) * 8 + (int)(bitpos & 7));
+    const int64_t want = nbits < (int64_t)64 * NW ? nbits : (int64_t)64 * NW;
+    const int last = __builtin_amdgcn_readfirstlane((int)((r.sh + want - 1) >> 6));   // index of the last word holding a requested bit
+    if (lane < NW) { r.w0 = w[lane < last ? lane : last]; r.w1 = w[lane + 1 < last ? lane + 1 : last]; }
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ uint64_t lane_windows_finish(const LaneWin<NW>& q) {
+    const int lane = threadIdx.x & 63;
+    if (q.nbits <= 0) return 0;
+    uint64_t r = q.w0 >> q.sh;
+    if (q.sh) r |= q.w1 << (64 - q.sh);
+    const int64_t left = q.nbits - (int64_t)64 * lane;
+    if (left < 64) r = left <= 0 ? 0 : (r & ((1ull << left) - 1));
+    return lane < NW ? r : 0;
+}
+template <int NW>
+__device__ __forceinline__ uint64_t lane_windows(const uint8_t* base, int64_t bitpos, int64_t nbits) {
+    return lane_windows_finish<NW>(lane_windows_issue<NW>(base, bitpos, nbits));
+}
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int i) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, i), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), i);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <typename T>
+__device__ __forceinline__ void dma_tile(const DevChunkCol& col, int64_t rw, unsigned char* raw_bytes) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const GlobalPtr<T> src = as_global<T>(col.values) + col.offset + rw;
+    constexpr int NI = kWDmaTile * (int)sizeof(T) / 1024;    // 1 KiB per wave instruction
+#pragma unroll
+    for (int g = 0; g < NI; ++g)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g * 64 + lane) * E),
+                                         (LdsPtr)(raw_bytes + 16 + g * 1024), 16, 0, 0);
+}
+
+// raw tile at element index E.. of `raw`; kept elements end up at [shift, shift + cnt).  kwv: lane i = keep-word i.
+template <typename T>
+__device__ __forceinline__ void dma_compact(const DevChunkCol col, const DevOutChunk oc, int64_t rw, int64_t clen, int64_t wave_out,
+                                            uint64_t kwv, int cnt, unsigned char* raw_bytes, uint8_t* vstage, uint32_t& nulls) {
+    constexpr int E = 16 / (int)sizeof(T);
+    using V = typename Vec16<T>::type;
+    const int lane = threadIdx.x & 63;
+    T* raw = (T*)raw_bytes;
+    const bool hasv = col.validity != nullptr;
+    uint64_t vwv = 0;
+    if (hasv) vwv = lane_windows<16>(col.validity, col.offset + rw, clen - rw);
+    const int shift = (int)(wave_out & (E - 1));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tile has landed in LDS (nothing else orders a ds_read behind an LDS-DMA)
+    int wb = shift;
+#pragma unroll
+    for (int b = 0; b < 16; b += 4) {   // four words per step: the reads of a step complete before its writes start, and every
+        T x[4];                         // write lands below the step's read frontier
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = raw[E + (b + i) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t w = rl64(kwv, b + i);
+            if ((w >> lane) & 1) {
+                const int pos = wb + __popcll(w & ((1ull << lane) - 1));
+                raw[pos] = x[i];
+                if (hasv) vstage[pos] = (uint8_t)((rl64(vwv, b + i) >> lane) & 1);
+            }
+            wb += __popcll(w);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int total = shift + cnt;
+    const GlobalMutPtr<T> dst0 = as_global_mut<T>(oc.values) + (wave_out - shift);
+    for (int j = lane; j * E < total; j += 64) {
+        const int s0 = j * E;
+        if (s0 >= shift && s0 + E <= total) __builtin_nontemporal_store(*(const V*)&raw[s0], (GlobalMutPtr<V>)dst0 + j);
+        else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (s0 + e >= shift && s0 + e < total) dst0[s0 + e] = raw[s0 + e];
+        }
+    }
+    if (hasv && oc.validity) {
+        const int64_t end = wave_out + cnt;
+        for (int64_t wpos = wave_out & ~63ll; wpos < end; wpos += 64) {
+            const int64_t pos = wpos + lane;
+            const bool inside = pos >= wave_out && pos < end;
+            const bool bitv = inside && vstage[shift + (pos - wave_out)];
+            const uint64_t word = __ballot(bitv);
+            const uint64_t inw = __ballot(inside);
+            if (lane == 0) {
+                if (word) atomicOr((unsigned long long*)oc.validity + (wpos >> 6), (unsigned long long)word);
+                nulls += (uint32_t)__popcll(inw & ~word);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// A tile the DMA path cannot take (launches hold 8- and 4-byte columns only: the host sends anything else to fcompact_kernel).
+template <typename T>
+__device__ __forceinline__ void slow_compact(const DevChunkCol col, const DevOutChunk oc, int64_t rw, int64_t wave_out, uint64_t kwv, int cnt,
+                                          unsigned char* stage_raw, uint8_t* vstage, uint32_t& nulls) {
+    const int lane = threadIdx.x & 63;
+    T* stage = (T*)stage_raw;
+    const bool hasv = col.validity != nullptr;
+    const GlobalPtr<T> src = as_global<T>(col.values) + col.offset + rw + lane;
+    int wb = 0;
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kwv, i), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(kwv >> 32), i);
+        const uint64_t w = ((uint64_t)hi << 32) | lo;
+        if (w == 0) continue;
+        if ((w >> lane) & 1) {
+            const int pos = wb + __popcll(w & ((1ull << lane) - 1));
+            stage[pos] = src[i * 64];
+            if (hasv) {
+                const int64_t e = col.offset + rw + i * 64 + lane;
+                vstage[pos] = (uint8_t)((as_global<uint8_t>(col.validity)[e >> 3] >> (e & 7)) & 1);
+            }
+        }
+        wb += __popcll(w);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const GlobalMutPtr<T> dst = as_global_mut<T>(oc.values) + wave_out;
+    for (int i = lane; i < cnt; i += 64) dst[i] = stage[i];
+    if (hasv && oc.validity) {
+        const int64_t end = wave_out + cnt;
+        for (int64_t wpos = wave_out & ~63ll; wpos < end; wpos += 64) {
+            const int64_t pos = wpos + lane;
+            const bool inside = pos >= wave_out && pos < end;
+            const bool bitv = inside && vstage[pos - wave_out];
+            const uint64_t word = __ballot(bitv);
+            const uint64_t inw = __ballot(inside);
+            if (lane == 0) {
+                if (word) atomicOr((unsigned long long*)oc.validity + (wpos >> 6), (unsigned long long)word);
+                nulls += (uint32_t)__popcll(inw & ~word);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(kBlock, 4) void fcompact_dma_kernel(const FilterWArgs a) {
+    constexpr int WW = kWDmaTile / 64, kWaves = kBlock / 64;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[kWaves][WW * 64 * 8 + 32];
+    __shared__ uint8_t vstage[kWaves][WW * 64 + 16];
+    __shared__ uint32_t nullacc[kWaves][kMaxFilterCols];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id();
+    if (lane < kMaxFilterCols) nullacc[wave][lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    int64_t cur_chunk = -1;
+    const bool one = a.t.nchunks == 1;
+    // A tile's place — chunk search, chunk length, output offset, mask and column-0 descriptors: three rounds of dependent
+    // scalar loads that miss every cache for a frame of ~1e6 batches — is looked up one iteration ahead, BETWEEN the issue
+    // of the current tile's loads (LDS-DMA + mask words) and their first use: scalar loads wait on their own counter, so
+    // the lookup runs under the vector loads' latency (measured: the lookups cost 1024-row batches 1.3 ms per 1e9 rows).
+    struct Meta { WTile t; int64_t wave_out; DevChunkCol m, c0; };
+    auto locate_all = [&](int64_t tile) -> Meta {
+        Meta mt;
+        mt.t = wlocate<WW>(a, tile);
+        mt.wave_out = one ? a.tile_scan[tile] : a.tile_scan[tile] - a.tile_scan[a.t.chunk_tile_start[mt.t.c]];
+        mt.m = one ? a.mask0 : a.t.mask[mt.t.c];
+        mt.c0 = one ? a.cols0[0] : a.cols[mt.t.c];
+        return mt;
+    };
+    const int64_t tile0 = (int64_t)blockIdx.x * kWaves + wave, tstride = (int64_t)gridDim.x * kWaves;
+    Meta meta;
+    if (tile0 < a.t.ntiles) meta = locate_all(tile0);
+    for (int64_t tile = tile0; tile < a.t.ntiles; tile += tstride) {
+        const WTile t = meta.t;
+        const int64_t wave_out = meta.wave_out;
+        const DevChunkCol m = meta.m;
+        if (t.c != cur_chunk) {
+            if (cur_chunk >= 0 && lane < a.ncols && nullacc[wave][lane]) {
+                atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)lane * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[wave][lane]);
+                nullacc[wave][lane] = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            cur_chunk = t.c;
+        }
+        const bool full = t.r0 + WW * 64 <= t.clen;
+        // column 0's tile is requested before the mask words are waited for
+        DevChunkCol col = meta.c0;
+        int es = a.esize[0];
+        auto dma_ok = [&](const DevChunkCol& c, int e) {
+            return full && (e == 8 || e == 4) && (((uintptr_t)((const char*)c.values + (c.offset + t.r0) * e)) & 15) == 0;
+        };
+        bool dma = dma_ok(col, es);
+        if (dma) { if (es == 8) dma_tile<uint64_t>(col, t.r0, stage[wave]); else dma_tile<uint32_t>(col, t.r0, stage[wave]); }
+        const LaneWin<WW> q0 = lane_windows_issue<WW>((const uint8_t*)m.values, m.offset + t.r0, t.clen - t.r0);
+        LaneWin<WW> q1 = q0;
+        if (m.validity) q1 = lane_windows_issue<WW>(m.validity, m.offset + t.r0, t.clen - t.r0);
+        if (tile + tstride < a.t.ntiles) meta = locate_all(tile + tstride);      // under the loads just issued
+        uint64_t kwv = lane_windows_finish<WW>(q0);                              // lane i = keep-word i
+        if (m.validity) kwv &= lane_windows_finish<WW>(q1);
+        int cnt = __popcll(kwv);
+#pragma unroll
+        for (int d = 1; d < WW; d <<= 1) cnt += __shfl_xor(cnt, d);
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
+        if (cnt == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; }   // the DMA must not land in the next tile's buffer
+#pragma unroll 1
+        for (int k = 0; k < a.ncols; ++k) {
+            if (k > 0) {
+                col = one ? a.cols0[k] : a.cols[(int64_t)k * a.t.nchunks + t.c];
+                es = a.esize[k];
+                dma = dma_ok(col, es);
+                if (dma) { if (es == 8) dma_tile<uint64_t>(col, t.r0, stage[wave]); else dma_tile<uint32_t>(col, t.r0, stage[wave]); }
+            }
+            const DevOutChunk oc = one ? a.outs0[k] : a.outs[(int64_t)k * a.t.nchunks + t.c];
+            const bool vec_out = (((uintptr_t)oc.values) & 15) == 0;
+            uint32_t nn = 0;
+            if (dma && vec_out) {
+                if (es == 8) dma_compact<uint64_t>(col, oc, t.r0, t.clen, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
+                else dma_compact<uint32_t>(col, oc, t.r0, t.clen, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
+            } else {
+                if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // chunk tails and slices that are not 16-byte aligned: one mask word at a time
+                if (es == 8) slow_compact<uint64_t>(col, oc, t.r0, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
+                else slow_compact<uint32_t>(col, oc, t.r0, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
+            }
+            if (lane == 0 && nn) nullacc[wave][k] += nn;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (cur_chunk >= 0 && lane < a.ncols && nullacc[wave][lane])
+        atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)lane * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[wave][lane]);
+}
+
+static int wgrid(int64_t ntiles, int per_cu) {
+    const int64_t blocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+    const int64_t lim = (int64_t)eval_grid_limit() / 8 * per_cu;
+    return (int)(blocks < lim ? (blocks < 1 ? 1 : blocks) : lim);
+}
+hipError_t launch_fcount(const FilterWArgs& a, int tile_rows, int64_t* tile_counts, hipStream_t s) {
+    if (a.t.ntiles <= 0) return hipSuccess;
+    const int grid = wgrid(a.t.ntiles, 8);
+    if (tile_rows == kWDmaTile) hipLaunchKernelGGL(fcount_kernel<16>, dim3(grid), dim3(kBlock), 0, s, a, tile_counts);
+    else if (tile_rows == kWTileSmall) hipLaunchKernelGGL(fcount_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a, tile_counts);
+    else hipLaunchKernelGGL(fcount_kernel<8>, dim3(grid), dim3(kBlock), 0, s, a, tile_counts);
+    return hipGetLastError();
+}
+hipError_t launch_fcompact(const FilterWArgs& a, int tile_rows, hipStream_t s) {
+    if (a.t.ntiles <= 0) return hipSuccess;
+    if (tile_rows == kWDmaTile) {
+        hipLaunchKernelGGL(fcompact_dma_kernel, dim3(wgrid(a.t.ntiles, 4)), dim3(kBlock), 0, s, a);
+        return hipGetLastError();
+    }
+    int es = a.esize[0];
+    for (int k = 1; k < a.ncols; ++k) if (a.esize[k] != es) es = 0;
+    const int grid = wgrid(a.t.ntiles, tile_rows == kWTileSmall ? 8 : 4);   // 19 KB of LDS per block at WW = 8
+    const bool pf = a.t.nchunks > 1 && a.prefetch;   // one chunk: nothing to look up
+#define RDF_FCOMPACT_LAUNCH(WW, PF)                                                                                    \
+    switch (es) {                                                                                                      \
+        case 8: hipLaunchKernelGGL((fcompact_kernel<8, WW, PF>), dim3(grid), dim3(kBlock), 0, s, a); break;            \
+        case 4: hipLaunchKernelGGL((fcompact_kernel<4, WW, PF>), dim3(grid), dim3(kBlock), 0, s, a); break;            \
+        case 2: hipLaunchKernelGGL((fcompact_kernel<2, WW, PF>), dim3(grid), dim3(kBlock), 0, s, a); break;            \
+        case 1: hipLaunchKernelGGL((fcompact_kernel<1, WW, PF>), dim3(grid), dim3(kBlock), 0, s, a); break;            \
+        default: hipLaunchKernelGGL((fcompact_kernel<0, WW, PF>), dim3(grid), dim3(kBlock), 0, s, a); break;           \
+    }
+    if (tile_rows == kWTileSmall) { if (pf) { RDF_FCOMPACT_LAUNCH(4, true) } else { RDF_FCOMPACT_LAUNCH(4, false) } }
+    else { if (pf) { RDF_FCOMPACT_LAUNCH(8, true) } else { RDF_FCOMPACT_LAUNCH(8, false) } }
+#undef RDF_FCOMPACT_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace rdfk

@@ -145,25 +145,29 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     uint32_t nulls = 0;
     int64_t cur_chunk = -1;
 
-    // A "tile" is one block iteration: kBlock*U vectors = kBlock*R rows of ONE chunk; wave w owns the
-    // 64*R consecutive rows [64*R*w, +64*R) of it.
-    constexpr int64_t per_iter = (int64_t)kBlock * U;
-    // Where a tile lives (chunk, first vector, chunk length, column descriptors): for chunked frames this is a binary
-    // search plus a handful of dependent table reads on the scalar unit.  The NEXT tile is located while the current
-    // tile's vector loads are in flight, so the lookup latency is off the critical path.
+    // A "tile" is one WAVE iteration: 64*U vectors = 64*R consecutive rows of ONE chunk.  Waves walk the tile list
+    // independently (wave w of block b starts at tile 4b + w), so a frame held in the reference's 1024-row batches
+    // (src/dataframe.rs:352) keeps every wave busy: with block-wide tiles of 2048 rows a 1024-row chunk left two of the
+    // four waves without rows.  The scalar work per wave and iteration is what it was (every wave located the block's
+    // tile redundantly before).
+    constexpr int64_t per_tile = (int64_t)64 * U;
+    constexpr int kWaves = kBlock / 64;
+    // Where a tile lives (chunk, first vector, chunk length, column descriptors): an interpolated guess into the prefix
+    // table (exact or one off for equally long batches) checked against its two neighbours, all on the scalar unit.  The
+    // NEXT tile is located while the current tile's vector loads are in flight, so the lookup latency is off the critical path.
     struct TileMeta { int64_t ch, base, n; DevChunkCol col[NC]; DevOutChunk out; };
     auto locate = [&](int64_t tile) -> TileMeta {
         TileMeta m;
         m.ch = 0;
         m.out = a.out;
         if (a.nchunks == 1) {
-            m.base = tile * per_iter;
+            m.base = tile * per_tile;
             m.n = a.n;
 #pragma unroll
             for (int k = 0; k < NC; ++k) m.col[k] = a.cols[k];
         } else {
-            m.ch = find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
-            m.base = (tile - a.chunk_tile_start[m.ch]) * per_iter;
+            m.ch = find_chunk_tile_inv(a.chunk_tile_start, a.nchunks, tile, a.tile_inv);
+            m.base = (tile - a.chunk_tile_start[m.ch]) * per_tile;
             m.n = a.chunk_len[m.ch];
 #pragma unroll
             for (int k = 0; k < NC; ++k) m.col[k] = a.cols_tab[(int64_t)k * a.nchunks + m.ch];
@@ -171,8 +175,9 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
         }
         return m;
     };
-    TileMeta meta = locate(blockIdx.x < a.ntiles ? (int64_t)blockIdx.x : 0);
-    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int64_t tile0 = (int64_t)blockIdx.x * kWaves + wave, tstride = (int64_t)gridDim.x * kWaves;
+    TileMeta meta = locate(tile0 < a.ntiles ? tile0 : 0);
+    for (int64_t tile = tile0; tile < a.ntiles; tile += tstride) {
         const int64_t ch = meta.ch, base = meta.base, n = meta.n;
         DevChunkCol col[NC];
 #pragma unroll
@@ -183,8 +188,8 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             nulls = 0;
             cur_chunk = ch;
         }
-        const int64_t wbase = base + (int64_t)wave * (U * 64);  // first vector of this wave
-        const int64_t rw = (int64_t)RV * wbase;                 // first row of this wave
+        const int64_t wbase = base;                             // first vector of this wave's tile
+        const int64_t rw = (int64_t)RV * wbase;                 // its first row
         // `full` (wave-uniform) = every row of this wave's span exists: the common case runs without
         // per-lane bounds checks or predicated loads
         const bool full = rw + 64 * R <= n;
@@ -226,8 +231,8 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             }
         }
         {   // the loads above are in flight: locate the next tile now
-            const int64_t nt = tile + gridDim.x;
-            if (a.nchunks == 1) meta.base = nt * per_iter;
+            const int64_t nt = tile + tstride;
+            if (a.nchunks == 1) meta.base = nt * per_tile;
             else if (nt < a.ntiles) meta = locate(nt);
         }
         // validity: R windows of 64 rows per column for this wave; lane l's RV bits of load u sit in window
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
 // the catalog
 
 typedef void (*SpecLaunch)(const SpecArgs&, int, hipStream_t);
-struct SpecEntry { SpecLaunch launch; int rows_per_block_iter; };
+struct SpecEntry { SpecLaunch launch; int rows_per_tile; };
 
 template <class P>
 static void launch_prog(const SpecArgs& a, int grid, hipStream_t s) {
@@ -348,7 +353,7 @@ static std::map<std::string, SpecEntry>& registry() {
     return r;
 }
 template <class P>
-static void reg() { registry()[P::sig()] = SpecEntry{&launch_prog<P>, kBlock * P::R}; }
+static void reg() { registry()[P::sig()] = SpecEntry{&launch_prog<P>, 64 * P::R}; }
 
 using D0 = Col<0, RDF_F64>; using D1 = Col<1, RDF_F64>; using D2 = Col<2, RDF_F64>;
 using L0 = Col<0, RDF_I64>; using L1 = Col<1, RDF_I64>; using L3 = Col<3, RDF_I64>;
@@ -490,9 +495,9 @@ const SpecEntry* spec_lookup(const char* sig) {
     return it == registry().end() ? nullptr : &it->second;
 }
 
-int spec_rows_per_block_iter(const char* sig) {
+int spec_rows_per_tile(const char* sig) {   // rows one wave iteration covers: tiles never straddle chunks
     const SpecEntry* e = spec_lookup(sig);
-    return e ? e->rows_per_block_iter : 0;
+    return e ? e->rows_per_tile : 0;
 }
 bool spec_available(const char* sig) { return spec_lookup(sig) != nullptr; }
 hipError_t launch_spec(const char* sig, const SpecArgs& a, int grid, hipStream_t s) {

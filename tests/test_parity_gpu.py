@@ -265,6 +265,29 @@ def test_filter_wide_frames_every_kernel_variant(gpu, ora, lens):
             assert_chunks_match(got[k], exp[k], exact=True, what=f"table-driven, lens={lens} column {k}")
 
 
+@pytest.mark.parametrize("dtype", [A.F64, A.I64, A.F32, A.I32, A.I16, A.U8])
+def test_filter_wave_granular_and_first_generation(gpu, ora, dtype):
+    """Both compaction generations (rdf_set_option("filter_gen", 2 | 1)) on the shapes that separate their code paths:
+    dense tiles (vector loads + 16-byte stores), sparse tiles (kept rows only), tiles that start at odd output positions,
+    chunk slices whose values are not 16-byte aligned, the reader's 1024-row batches (two wave tiles per chunk), chunks
+    shorter than a tile, empty chunks, all-kept / none-kept masks, NULLs in mask and column."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(700 + dtype)
+    try:
+        for lens, nf, off in [([5000], 0.0, 0), ([1024] * 7 + [333], 0.15, 0), ([4096, 0, 777, 2048], 0.1, 1), ([100, 300, 50, 1, 0, 600], 0.2, 5), ([20000], 0.05, 3)]:
+            col = make_chunks(rng, dtype, lens, nf, off, "extreme" if dtype <= A.U64 else "special")
+            for sel in (0.9, 0.5, 0.05, 1.0, 0.0):
+                mask = [A.HostArray.from_numpy(rng.uniform(size=n) < sel, valid=(rng.uniform(size=n) > 0.1) if nf else None,
+                                               offset=(off * 3) % 11, dtype=A.BOOL, rng=rng) for n in lens]
+                exp = ora.filter(col, mask)
+                for gen in (2, 3, 1):   # default (LDS-DMA tiles where eligible), register-staged wave tiles, first generation
+                    lib.set_option("filter_gen", gen)
+                    assert gpu.filter_count(mask) == ora.filter_count(mask), f"count gen={gen}"
+                    assert_chunks_match(gpu.filter(col, mask), exp, exact=True, what=f"filter gen={gen} {dtype} {lens} sel={sel}")
+    finally:
+        lib.set_option("filter_gen", 2)
+
+
 @pytest.mark.parametrize("dtype", NUMERIC)
 @pytest.mark.parametrize("idx_dtype", [A.U32, A.U64])
 def test_take(gpu, ora, dtype, idx_dtype):

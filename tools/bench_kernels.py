@@ -162,28 +162,43 @@ def main():
     report("filter_count", n / 8.0, lambda: api.filter_count([m]))
     report("filter_1col", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
     report("filter_2col", (16 + 16 * sel + 0.25) * n, lambda: api.filter_columns([[X], [K]], [m], [[of], [ok2]]))
-    for fo in (0, 1, 0, 1):   # A/B: the one-chunk kernel with its descriptors in the kernel arguments (1, default) vs the table-driven one
-        lib.set_option("filter_one", fo)
-        report(f"filter_1col_one_chunk_kernel_{fo}", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
-        report(f"filter_2col_one_chunk_kernel_{fo}", (16 + 16 * sel + 0.25) * n, lambda: api.filter_columns([[X], [K]], [m], [[of], [ok2]]))
-    lib.set_option("filter_one", 1)
-    for ft in (1024, 4096):   # A/B of the two compaction tile sizes on one long chunk (auto picks 4096)
-        lib.set_option("filter_tile", ft)
-        report(f"filter_1col_tile_{ft}", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
-        report(f"filter_2col_tile_{ft}", (16 + 16 * sel + 0.25) * n, lambda: api.filter_columns([[X], [K]], [m], [[of], [ok2]]))
-    lib.set_option("filter_tile", 0)
-    # the same filter over a frame in the reference's 1024-row RecordBatches (a 1e8-row prefix = 97 657 chunks): 1024-row
-    # compaction tiles (picked from the mean chunk length) against the 4096-row tiles of long chunks forced onto it
-    nfc = min(n, 100_000_000)
-    XF = [A.DeviceArray(x.data_ptr() + i * 8, None, 0, min(1024, nfc - i), A.F64, 0, keep=x) for i in range(0, nfc, 1024)]
-    MF = [A.DeviceArray(m.values_ptr + i // 8, None, 0, min(1024, nfc - i), A.BOOL, 0, keep=m) for i in range(0, nfc, 1024)]
+    for gen in (1, 3, 2):   # A/B: first-generation block tiles (one barrier per tile), register-staged wave tiles, default (LDS-DMA wave tiles)
+        lib.set_option("filter_gen", gen)
+        report(f"filter_1col_gen{gen}", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
+        report(f"filter_2col_gen{gen}", (16 + 16 * sel + 0.25) * n, lambda: api.filter_columns([[X], [K]], [m], [[of], [ok2]]))
+    lib.set_option("filter_gen", 2)
+    # selective filters: 1 row in 16 kept (sparse tiles fetch only the sectors that hold a kept row)
+    m16 = out_like(A.BOOL, n)
+    api.predicate(e, e.op("gt", cx, e.scalar(0.875)), [[X]], [m16])
+    sel16 = api.filter_count([m16])[0] / n
+    report("filter_1col_selectivity_1_16", (8 + 8 * sel16 + 0.25) * n, lambda: api.filter([X], [m16], [of]))
+    # the same filter over a frame in the reference's 1024-row RecordBatches (the whole column = 976 563 chunks at 1e9 rows)
+    nfc = n
+    XF = A.PreparedCol([A.DeviceArray(x.data_ptr() + i * 8, None, 0, min(1024, nfc - i), A.F64, 0, keep=x) for i in range(0, nfc, 1024)])
+    MF = A.PreparedCol([A.DeviceArray(m.values_ptr + i // 8, None, 0, min(1024, nfc - i), A.BOOL, 0, keep=m) for i in range(0, nfc, 1024)])
     ofb = torch.empty(nfc, dtype=torch.float64, device="cuda")
     OF = [A.DeviceArray(ofb.data_ptr() + i * 8, None, 0, min(1024, nfc - i), A.F64, 0, keep=ofb) for i in range(0, nfc, 1024)]
-    for ft in (0, 4096):
-        lib.set_option("filter_tile", ft)
-        report(f"filter_1col_1024_row_chunks_tile_{'auto' if ft == 0 else ft}", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))
-    lib.set_option("filter_tile", 0)
-    del XF, MF, OF, ofb
+    for gen in (1, 2, 3):   # 3 = wave-granular without the next-tile look-ahead
+        lib.set_option("filter_gen", gen)
+        report(f"filter_1col_1024_row_chunks_gen{gen}", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))
+    lib.set_option("filter_gen", 2)
+    # the same with output chunks sized by rdf_filter_count and packed back to back (what a two-phase caller allocates):
+    # the slots above leave every other 4 KB of the output buffer untouched
+    import itertools
+    cnts = api.filter_count(MF)
+    offs = [0] + list(itertools.accumulate((c + 7) // 8 * 8 for c in cnts))
+    OFP = [A.DeviceArray(ofb.data_ptr() + o * 8, None, 0, c, A.F64, 0, keep=ofb, capacity=(c + 7) // 8 * 8) for o, c in zip(offs, cnts)]
+    report("filter_1col_1024_row_chunks_packed_outputs", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OFP))
+    del OFP
+    lib.set_option("filter_gen", 2)
+    del XF, MF, OF
+    for cr in (4096, 65536):   # the per-chunk cost: the same filter on longer batches
+        XF = A.PreparedCol([A.DeviceArray(x.data_ptr() + i * 8, None, 0, min(cr, nfc - i), A.F64, 0, keep=x) for i in range(0, nfc, cr)])
+        MF = A.PreparedCol([A.DeviceArray(m.values_ptr + i // 8, None, 0, min(cr, nfc - i), A.BOOL, 0, keep=m) for i in range(0, nfc, cr)])
+        OF = [A.DeviceArray(ofb.data_ptr() + i * 8, None, 0, min(cr, nfc - i), A.F64, 0, keep=ofb) for i in range(0, nfc, cr)]
+        report(f"filter_1col_{cr}_row_chunks", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))
+        del XF, MF, OF
+    del ofb
     nidx = n // 4
     idx = torch.randint(0, n, (nidx,), dtype=torch.int64, device="cuda").to(torch.uint32 if hasattr(torch, "uint32") else torch.int32)
     I = A.DeviceArray(idx.data_ptr(), None, 0, nidx, A.U32, 0, keep=idx)
