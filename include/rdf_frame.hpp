@@ -708,7 +708,7 @@ inline std::vector<ArrayRef> cast_arrays(const std::vector<ArrayRef>& arr, DataT
     std::vector<rdf_array> a;
     std::vector<std::shared_ptr<Array>> outs;
     std::vector<rdf_out> ov;
-    for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(to, x->length, x->validity != nullptr)); ov.push_back(outs.back()->out_view(x->length)); }
+    for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(to, x->length, true)); ov.push_back(outs.back()->out_view(x->length)); }   // (a value the target type cannot hold becomes NULL: always a bitmap)
     check(rdf_cast(a.data(), (int64_t)a.size(), ov.data()));
     std::vector<ArrayRef> res;
     for (size_t i = 0; i < outs.size(); ++i) { outs[i]->length = ov[i].length; outs[i]->null_count = ov[i].null_count; res.push_back(outs[i]); }
@@ -1196,7 +1196,7 @@ struct ScalarFunctions {
         std::vector<rdf_array> a;
         std::vector<std::shared_ptr<Array>> outs;
         std::vector<rdf_out> ov;
-        for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(to, x->length, x->validity != nullptr)); ov.push_back(outs.back()->out_view(x->length)); }
+        for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(to, x->length, true)); ov.push_back(outs.back()->out_view(x->length)); }   // (a value the target type cannot hold becomes NULL: always a bitmap)
         check(rdf_cast(a.data(), (int64_t)a.size(), ov.data()));
         return finish(outs, ov);
     }

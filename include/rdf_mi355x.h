@@ -131,8 +131,13 @@ rdf_status rdf_binary(int32_t op, const rdf_array* a, const rdf_array* b, int64_
  * out[i] = f(a[i]) where valid, null elsewhere. */
 rdf_status rdf_unary(int32_t op, const rdf_array* a, int64_t nchunks, rdf_out* out);
 
-/* Function::Cast arm (src/evaluation.rs:296-315): arrow::compute::cast per chunk to out[i].dtype
- * (numeric `as` conversions; numeric<->bool), validity carried. */
+/* Function::Cast arm (src/evaluation.rs:296-315): arrow::compute::cast per chunk to out[i].dtype.  The arrow crate of
+ * the reference's era casts numeric arrays element by element through num::cast::cast and appends NULL where that
+ * returns None: an integer that the target type cannot represent (-1 -> UInt8, 300 -> UInt8), NaN / an out-of-range
+ * float on the way to an integer (floats truncate toward zero when the truncated value fits); int -> float, float -> float
+ * and numeric <-> Boolean always succeed; input NULLs stay NULL.  Since a narrowing / sign-changing / float -> integer cast
+ * can produce NULLs, its outputs need a validity buffer even when the input has none.  The same rule holds for
+ * RDF_OP_CAST inside fused programs (the NULLs it produces are skipped by aggregates, dropped by filters). */
 rdf_status rdf_cast(const rdf_array* a, int64_t nchunks, rdf_out* out);
 
 /* ScalarFunctions::hour (src/functions/scalar.rs:267-273) = arrow::compute::hour per chunk: the hour of day of a

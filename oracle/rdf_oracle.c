@@ -275,22 +275,46 @@ rdf_status ora_unary(int32_t op, const rdf_array* a, int64_t nchunks, rdf_out* o
 }
 
 /* ------------------------------------------------------------------ cast
- * src/evaluation.rs:296-315 -> arrow::compute::cast per chunk: numeric `as` conversions
- * (float->int saturating, NaN -> 0, like Rust `as`), numeric->bool = (x != 0), bool->numeric = 1/0. */
+ * src/evaluation.rs:296-315 -> arrow::compute::cast per chunk.  The arrow crate of the reference's era (branch
+ * rust-parquet-arrow-writer, Aug-Oct 2020, not under /root/reference) casts numeric arrays element by element through
+ * num::cast::cast (num-traits 0.2, Cargo.toml:14-15) and appends NULL where that returns None ("some casts return None,
+ * such as a negative value to u{8|16|32|64}"):
+ *   int -> int      Some iff the value is representable in the target type;
+ *   int -> float    always Some (rounded);
+ *   float -> int    None for NaN; else truncation toward zero, Some iff the truncated value fits: num-traits tests
+ *                   MIN - 1 < f < MAX + 1 (float wider than the int) or MIN <= f < MAX + 1 (otherwise), unsigned: -1 < f < MAX + 1;
+ *   float -> float  always Some (f64 -> f32 is `as`: rounds, overflows to infinity);
+ *   numeric -> Boolean = (x != 0), Boolean -> numeric = 1 / 0 (cast_numeric_to_bool / cast_bool_to_numeric): always valid.
+ * Input NULLs stay NULL.  No reference test pins a lossy cast (PARITY UNPINNED BY THE REFERENCE for those); the value
+ * rules are checked against numpy / pyarrow where the value is representable (tests/test_oracle_golden.py). */
 
-static inline int64_t f64_to_i64_sat(double x) {
-    if (x != x) return 0;
-    if (x >= 9223372036854775808.0) return INT64_MAX;
-    if (x <= -9223372036854775808.0) return INT64_MIN;
-    return (int64_t)x;
+/* 1 if a cast from -> to can turn a valid slot into NULL */
+static int cast_can_null(int32_t from, int32_t to) {
+    if (from == to || to == RDF_BOOL || to == RDF_F32 || to == RDF_F64 || from == RDF_BOOL) return 0;
+    if (from == RDF_F32 || from == RDF_F64) return 1;               /* float -> int */
+    int fs = from <= RDF_I64, ts = to <= RDF_I64;
+    int fb = dtype_size(from), tb = dtype_size(to);
+    if (fs == ts) return tb < fb;                                     /* same signedness: narrowing only */
+    if (fs) return 1;                                                 /* signed -> unsigned: negatives */
+    return tb <= fb;                                                  /* unsigned -> signed of the same or a smaller width */
 }
-static inline uint64_t f64_to_u64_sat(double x) {
-    if (x != x || x <= 0.0) return 0;
-    if (x >= 18446744073709551616.0) return UINT64_MAX;
-    return (uint64_t)x;
+/* truncating float -> integer of `bits` bits; *ok = representable per num-traits */
+static int64_t f64_to_int_checked(double f, int bits, int is_signed, int* ok) {
+    *ok = 0;
+    if (f != f) return 0;
+    if (is_signed) {
+        double lim = ldexp(1.0, bits - 1);
+        if (bits == 64 ? !(f >= -lim && f < lim) : !(f > -lim - 1.0 && f < lim)) return 0;
+        *ok = 1;
+        return (int64_t)f;
+    }
+    double lim = ldexp(1.0, bits);
+    if (!(f > -1.0 && f < lim)) return 0;
+    *ok = 1;
+    return (int64_t)(uint64_t)f;
 }
-/* Convert element i of `a` to dtype `to`, written at z[k]. */
-static void cast_elem(const rdf_array* a, int64_t i, int32_t to, void* zv, int64_t k) {
+/* Convert element i of `a` to dtype `to`, written at z[k] (0 where the result is NULL).  Returns 1 if representable. */
+static int cast_elem(const rdf_array* a, int64_t i, int32_t to, void* zv, int64_t k) {
     int64_t s = a->offset + i;
     int from = a->dtype;
     /* fetch as (i64 | u64 | f64) by class */
@@ -311,48 +335,48 @@ static void cast_elem(const rdf_array* a, int64_t i, int32_t to, void* zv, int64
     if (to == RDF_BOOL) {
         int v = cls == 0 ? (si != 0) : cls == 1 ? (ui != 0) : (f != 0.0);
         bit_put((uint8_t*)zv, k, v);
-        return;
+        return 1;
     }
     if (to == RDF_F64 || to == RDF_F32) {
         double d = cls == 0 ? (double)si : cls == 1 ? (double)ui : f;
         if (to == RDF_F64) ((double*)zv)[k] = d;
         else ((float*)zv)[k] = cls == 0 ? (float)si : cls == 1 ? (float)ui : (float)f;
-        return;
+        return 1;
     }
-    /* integer targets: int->int wraps (truncation), float->int saturates per target width */
-    if (cls == 2) {
-        switch (to) {
-            case RDF_I8: { double c = f != f ? 0 : f < -128.0 ? -128.0 : f > 127.0 ? 127.0 : f; ((int8_t*)zv)[k] = (int8_t)c; } break;
-            case RDF_I16: { double c = f != f ? 0 : f < -32768.0 ? -32768.0 : f > 32767.0 ? 32767.0 : f; ((int16_t*)zv)[k] = (int16_t)c; } break;
-            case RDF_I32: { double c = f != f ? 0 : f < -2147483648.0 ? -2147483648.0 : f > 2147483647.0 ? 2147483647.0 : f; ((int32_t*)zv)[k] = (int32_t)c; } break;
-            case RDF_I64: ((int64_t*)zv)[k] = f64_to_i64_sat(f); break;
-            case RDF_U8: { double c = f != f ? 0 : f < 0.0 ? 0.0 : f > 255.0 ? 255.0 : f; ((uint8_t*)zv)[k] = (uint8_t)c; } break;
-            case RDF_U16: { double c = f != f ? 0 : f < 0.0 ? 0.0 : f > 65535.0 ? 65535.0 : f; ((uint16_t*)zv)[k] = (uint16_t)c; } break;
-            case RDF_U32: { double c = f != f ? 0 : f < 0.0 ? 0.0 : f > 4294967295.0 ? 4294967295.0 : f; ((uint32_t*)zv)[k] = (uint32_t)c; } break;
-            default: ((uint64_t*)zv)[k] = f64_to_u64_sat(f); break;
+    int tbits = 8 * dtype_size(to), tsigned = to <= RDF_I64, ok = 1;
+    uint64_t bits;
+    if (cls == 2) bits = (uint64_t)f64_to_int_checked(f, tbits, tsigned, &ok);
+    else {
+        bits = cls == 0 ? (uint64_t)si : ui;
+        if (tsigned) {
+            int64_t hi = tbits == 64 ? INT64_MAX : ((int64_t)1 << (tbits - 1)) - 1, lo = -hi - 1;
+            ok = cls == 0 ? (si >= lo && si <= hi) : (ui <= (uint64_t)hi);
+        } else {
+            uint64_t hi = tbits == 64 ? UINT64_MAX : (((uint64_t)1 << tbits) - 1);
+            ok = cls == 0 ? (si >= 0 && (uint64_t)si <= hi) : (ui <= hi);
         }
-        return;
     }
-    uint64_t bits = cls == 0 ? (uint64_t)si : ui;
+    if (!ok) bits = 0;
     switch (to) {
         case RDF_I8: case RDF_U8: ((uint8_t*)zv)[k] = (uint8_t)bits; break;
         case RDF_I16: case RDF_U16: ((uint16_t*)zv)[k] = (uint16_t)bits; break;
         case RDF_I32: case RDF_U32: ((uint32_t*)zv)[k] = (uint32_t)bits; break;
         default: ((uint64_t*)zv)[k] = bits; break;
     }
+    return ok;
 }
 
 static rdf_status cast_chunk(const rdf_array* a, rdf_out* o) {
     int64_t n = a->length;
     if (o->capacity < n) FAIL(RDF_MEMORY_ERROR, "output capacity too small");
-    if (a->validity && !o->validity) FAIL(RDF_INVALID_ARGUMENT, "output validity buffer required");
     if (!(is_numeric(a->dtype) || a->dtype == RDF_BOOL) || !(is_numeric(o->dtype) || o->dtype == RDF_BOOL))
         FAIL(RDF_INVALID_ARGUMENT, "cast: unsupported type");
+    if ((a->validity || cast_can_null(a->dtype, o->dtype)) && !o->validity) FAIL(RDF_INVALID_ARGUMENT, "output validity buffer required");
     out_begin(o, n);
     if (o->dtype == RDF_BOOL) memset(o->values, 0, (size_t)((n + 7) / 8));
     for (int64_t i = 0; i < n; i++) {
-        cast_elem(a, i, o->dtype, o->values, i);
-        if (!arr_valid(a, i)) out_null(o, i);
+        int ok = cast_elem(a, i, o->dtype, o->values, i);
+        if (!arr_valid(a, i) || !ok) out_null(o, i);
     }
     return RDF_OK;
 }
@@ -615,7 +639,7 @@ static int tmp_from_scalar(tmparr* t, const rdf_expr_node* nd, int64_t n) {
 }
 
 static rdf_status tmp_cast(const tmparr* in, int32_t to, tmparr* out) {
-    if (!tmp_alloc(out, to, in->len, in->validity != NULL)) FAIL(RDF_MEMORY_ERROR, "out of memory");
+    if (!tmp_alloc(out, to, in->len, in->validity != NULL || cast_can_null(in->dtype, to))) FAIL(RDF_MEMORY_ERROR, "out of memory");
     rdf_array a = tmp_view(in);
     rdf_out o = tmp_out(out);
     return cast_chunk(&a, &o);

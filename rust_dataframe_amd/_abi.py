@@ -450,8 +450,8 @@ class Api:
     def cast(self, a: Sequence, to: int, outs=None):
         n = len(a)
         ca = _flat([a], n)
-        if outs is None:
-            outs, carr = self._mk_outs(to, [x.length for x in a], [x.validity is not None for x in a])
+        if outs is None:   # a lossy cast yields NULL where the value does not fit: always hand over a validity buffer
+            outs, carr = self._mk_outs(to, [x.length for x in a], [True for x in a])
         else:
             carr = (rdf_out * max(1, n))(*[o.out_struct() for o in outs])
         self._check(self._fn("cast")(ca, C.c_int64(n), carr))

@@ -413,6 +413,7 @@ struct Compiler {
     std::vector<int> memo;
     int tmp_used = 0, tmp_max = 0;
     bool heavy = false, intdiv = false;
+    bool lossy_cast = false;   // the program holds a cast that can turn a valid value into NULL (arrow::compute::cast: None -> NULL)
     rdf_status st = RDF_OK;
     int feat() const { return heavy ? 2 : intdiv ? 1 : 0; }
 
@@ -533,8 +534,18 @@ struct Compiler {
         }
         in.dtype = (uint8_t)dom;
     }
+    static bool cast_can_null(int from, int to) {
+        if (from == to || to == RDF_BOOL || to == RDF_F32 || to == RDF_F64 || from == RDF_BOOL) return false;
+        if (is_float(from)) return true;
+        const bool fs = is_signed_int(from), ts = is_signed_int(to);
+        const int fb = dtype_size(from), tb = dtype_size(to);
+        if (fs == ts) return tb < fb;
+        if (fs) return true;
+        return tb <= fb;
+    }
     void cast_acc(int from, int to) {
         if (from == to) return;
+        lossy_cast |= cast_can_null(from, to);
         Instr in = mk(BC_CAST);
         in.src_dtype = (uint8_t)from;
         in.dtype = (uint8_t)to;
@@ -819,6 +830,7 @@ struct ProgramSpec {
     int group_root = -1, ngroups = 0;
     rdf_group_result* gout = nullptr;
     int64_t* grows = nullptr;
+    bool casts_always_fit = false;   // internal programs whose narrowing cast cannot fail (rdf_hour: 0..23 into Int32): no output bitmap needed for it
 };
 constexpr int RDF_SINK_GROUP = 2;
 
@@ -929,6 +941,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         cc.push(e);
     }
     if (cc.st != RDF_OK) return cc.st;
+    if (ps.casts_always_fit) cc.lossy_cast = false;
 
     // output validation (SINK_STORE)
     if (ps.sink == RDF_SINK_STORE) {
@@ -937,7 +950,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
                 rdf_out& o = outs[(int64_t)v * nchunks + c];
                 if (o.dtype != value_dtype[v]) return fail(RDF_INVALID_ARGUMENT, "output dtype %d != expression dtype %d", o.dtype, value_dtype[v]);
                 if (o.capacity < clen[(size_t)c]) return fail(RDF_MEMORY_ERROR, "output capacity too small");
-                bool nullable = false;
+                bool nullable = cc.lossy_cast;   // a cast to a narrower / differently signed / integer type yields NULL where the value does not fit
                 for (int k = 0; k < ncols; ++k) nullable |= cols[(int64_t)k * nchunks + c].validity != nullptr;
                 if (nullable && !o.validity) return fail(RDF_INVALID_ARGUMENT, "output validity buffer required");
                 if (clen[(size_t)c] > 0 && !o.values) return fail(RDF_INVALID_ARGUMENT, "null output values pointer");
@@ -1450,6 +1463,7 @@ rdf_status rdf_hour(const rdf_array* a, int64_t nchunks, int32_t unit, rdf_out* 
     ProgramSpec ps;
     memset(&ps, 0, sizeof ps);
     ps.nodes = nodes; ps.nnodes = 3; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = 2; ps.sink = RDF_SINK_STORE;
+    ps.casts_always_fit = true;
     return run_program(ps, a, 1, nchunks, out, nullptr, "chunk length mismatch");
 }
 

@@ -25,9 +25,11 @@
 namespace rdfk {
 
 // ------------------------------------------------------------------------------------------------
-// conversions (arrow::compute::cast: Rust `as` semantics — float->int saturates, NaN -> 0)
+// conversions (arrow::compute::cast of the reference's era = num::cast::cast per element, NULL where it returns None:
+// an integer that does not fit the target, NaN or an out-of-range float on the way to an integer — num-traits 0.2 range tests)
 
-__device__ __forceinline__ uint64_t cast_value(int from, int to, uint64_t x) {
+__device__ __forceinline__ uint64_t cast_value(int from, int to, uint64_t x, bool& ok) {
+    ok = true;
     if (from == to) return x;
     double f = 0.0;
     bool src_float = false;
@@ -42,27 +44,31 @@ __device__ __forceinline__ uint64_t cast_value(int from, int to, uint64_t x) {
         if (from == RDF_F64) return f2u((float)u2d(x));
         return f2u(dt_is_signed(from) ? (float)(int64_t)x : (float)x);
     }
-    if (src_float) {
-        if (f != f) return 0;
-        switch (to) {
-            case RDF_I8: return (uint64_t)(int64_t)(f < -128.0 ? -128.0 : f > 127.0 ? 127.0 : f);
-            case RDF_I16: return (uint64_t)(int64_t)(f < -32768.0 ? -32768.0 : f > 32767.0 ? 32767.0 : f);
-            case RDF_I32: return (uint64_t)(int64_t)(f < -2147483648.0 ? -2147483648.0 : f > 2147483647.0 ? 2147483647.0 : f);
-            case RDF_I64:
-                if (f >= 9223372036854775808.0) return (uint64_t)INT64_MAX;
-                if (f <= -9223372036854775808.0) return (uint64_t)INT64_MIN;
-                return (uint64_t)(int64_t)f;
-            case RDF_U8: return (uint64_t)(f < 0.0 ? 0.0 : f > 255.0 ? 255.0 : f);
-            case RDF_U16: return (uint64_t)(f < 0.0 ? 0.0 : f > 65535.0 ? 65535.0 : f);
-            case RDF_U32: return (uint64_t)(f < 0.0 ? 0.0 : f > 4294967295.0 ? 4294967295.0 : f);
-            default:
-                if (f <= 0.0) return 0;
-                if (f >= 18446744073709551616.0) return ~0ull;
-                return (uint64_t)f;
+    const bool tsigned = dt_is_signed(to);
+    int tbits = 64;
+    switch (to) { case RDF_I8: case RDF_U8: tbits = 8; break; case RDF_I16: case RDF_U16: tbits = 16; break; case RDF_I32: case RDF_U32: tbits = 32; break; default: break; }
+    if (src_float) {   // truncation toward zero when the truncated value fits (num-traits' range tests)
+        if (tsigned) {
+            const double lim = tbits == 64 ? 9223372036854775808.0 : (double)(1ll << (tbits - 1));
+            ok = tbits == 64 ? (f >= -lim && f < lim) : (f > -lim - 1.0 && f < lim);
+            return ok ? (uint64_t)(int64_t)f : 0;
         }
+        const double lim = tbits == 64 ? 18446744073709551616.0 : (double)(1ull << tbits);
+        ok = f > -1.0 && f < lim;
+        return ok ? (uint64_t)f : 0;
     }
-    return normalize_int(to, x);  // int/bool -> int: truncate
+    // integer (or Boolean) -> integer: NULL unless representable
+    if (from == RDF_BOOL) return x & 1;
+    if (tsigned) {
+        const int64_t hi = tbits == 64 ? INT64_MAX : ((int64_t)1 << (tbits - 1)) - 1, lo = -hi - 1;
+        ok = dt_is_signed(from) ? ((int64_t)x >= lo && (int64_t)x <= hi) : (x <= (uint64_t)hi);
+    } else {
+        const uint64_t hi = tbits == 64 ? ~0ull : ((1ull << tbits) - 1);
+        ok = dt_is_signed(from) ? ((int64_t)x >= 0 && x <= hi) : (x <= hi);
+    }
+    return ok ? x : 0;
 }
+__device__ __forceinline__ uint64_t cast_value(int from, int to, uint64_t x) { bool ok; return cast_value(from, to, x, ok); }
 
 // ------------------------------------------------------------------------------------------------
 // column loads: row(j) of this lane = r0 + 256*wave + 64*j + lane
@@ -488,9 +494,13 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
                 case BC_UN:
                     apply_unary<FEAT>(in.op, in.dtype, acc);
                     break;
-                case BC_CAST:
+                case BC_CAST:   // a value the target type cannot represent becomes NULL
 #pragma unroll
-                    for (int j = 0; j < kVPT; ++j) acc[j] = cast_value(in.src_dtype, in.dtype, acc[j]);
+                    for (int j = 0; j < kVPT; ++j) {
+                        bool ok;
+                        acc[j] = cast_value(in.src_dtype, in.dtype, acc[j], ok);
+                        if (!ok) accv &= ~(1u << j);
+                    }
                     break;
                 case BC_FILTER:  // DataFrame::filter: rows whose predicate is false or null are dropped
 #pragma unroll

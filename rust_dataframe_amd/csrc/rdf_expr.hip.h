@@ -3,6 +3,7 @@
 // A node exposes: dt, ncols, width (common column width, -1 when mixed), colw<k>() (element width of
 // canonical column k inside this expression, 0 when unused), eval<r>(ctx), vmask(ctx), sig().
 #pragma once
+#include <limits>
 #include <string>
 #include <type_traits>
 
@@ -35,6 +36,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 template <int NC, int R, class S>
 struct Ctx {
+    static constexpr int rows = R;
     S        v[NC][R];   // raw elements, row r of column c
     uint32_t valid[NC];  // bit r = row r of column c is valid
     uint64_t imm[4];
@@ -180,6 +182,46 @@ struct Un {
     static std::string sig() { return "[" + std::to_string(OP) + " " + A::sig() + "]"; }
 };
 
+// arrow::compute::cast of the reference's era: num::cast::cast per element, NULL where the target type cannot represent
+// the value.  A lossy cast therefore narrows the validity mask by looking at the values.
+constexpr bool cast_lossy(int from, int to) {
+    if (from == to || to == RDF_BOOL || to == RDF_F32 || to == RDF_F64 || from == RDF_BOOL) return false;
+    if (dt_float(from)) return true;
+    const bool fs = dt_signed(from), ts = dt_signed(to);
+    const int fb = CType<RDF_I8>::width * 0 + (from == RDF_I8 || from == RDF_U8 ? 1 : from == RDF_I16 || from == RDF_U16 ? 2 : from == RDF_I32 || from == RDF_U32 ? 4 : 8);
+    const int tb = to == RDF_I8 || to == RDF_U8 ? 1 : to == RDF_I16 || to == RDF_U16 ? 2 : to == RDF_I32 || to == RDF_U32 ? 4 : 8;
+    if (fs == ts) return tb < fb;
+    if (fs) return true;
+    return tb <= fb;
+}
+template <int TO, class X>
+__device__ __forceinline__ bool cast_fits(X x) {
+    using T = typename CType<TO>::T;
+    constexpr int tbits = 8 * (int)sizeof(T);
+    if constexpr (std::is_floating_point<X>::value) {
+        const double f = (double)x;
+        if constexpr (dt_signed(TO)) {
+            constexpr double lim = tbits == 64 ? 9223372036854775808.0 : (double)(1ll << (tbits - 1));
+            return tbits == 64 ? (f >= -lim && f < lim) : (f > -lim - 1.0 && f < lim);
+        } else {
+            constexpr double lim = tbits == 64 ? 18446744073709551616.0 : (double)(1ull << (tbits % 64));
+            return f > -1.0 && f < lim;
+        }
+    } else if constexpr (std::is_signed<X>::value) {
+        if constexpr (dt_signed(TO)) return (int64_t)x >= (int64_t)std::numeric_limits<T>::min() && (int64_t)x <= (int64_t)std::numeric_limits<T>::max();
+        else return x >= 0 && (uint64_t)x <= (uint64_t)std::numeric_limits<T>::max();
+    } else {
+        return (uint64_t)x <= (uint64_t)std::numeric_limits<T>::max();
+    }
+}
+template <int TO, class A, int R, int r, class C>
+__device__ __forceinline__ void cast_fit_rows(C& c, uint32_t& m) {
+    if constexpr (r < R) {
+        if (!cast_fits<TO>(A::template eval<r>(c))) m &= ~(1u << r);
+        cast_fit_rows<TO, A, R, r + 1>(c, m);
+    }
+}
+
 template <int TO, class A>
 struct Cast {
     static constexpr int dt = TO;
@@ -187,25 +229,16 @@ struct Cast {
     static constexpr int width = merge_width(A::width, CType<TO>::width);   // spec_kernel: casts keep the element width
     template <int k> static constexpr int colw() { return A::template colw<k>(); }
     using T = typename CType<TO>::T;
-    template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c); }
+    template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) {
+        uint32_t m = A::vmask(c);
+        if constexpr (cast_lossy(A::dt, TO)) cast_fit_rows<TO, A, C::rows, 0>(const_cast<C&>(c), m);
+        return m;
+    }
     template <int r, class C> static __device__ __forceinline__ T eval(C& c) {
         const auto x = A::template eval<r>(c);
         if constexpr (TO == RDF_BOOL) return x != 0;
-        else if constexpr (dt_float(TO)) return (T)x;
-        else if constexpr (dt_float(A::dt)) {  // saturating `as`
-            const double f = (double)x;
-            if (f != f) return (T)0;
-            if constexpr (TO == RDF_I64) {
-                if (f >= 9223372036854775808.0) return INT64_MAX;
-                if (f <= -9223372036854775808.0) return INT64_MIN;
-                return (int64_t)f;
-            } else if constexpr (TO == RDF_U64) {
-                if (f <= 0.0) return (T)0;
-                if (f >= 18446744073709551616.0) return ~0ull;
-                return (uint64_t)f;
-            } else if constexpr (TO == RDF_I32) return (int32_t)(f < -2147483648.0 ? -2147483648.0 : f > 2147483647.0 ? 2147483647.0 : f);
-            else return (uint32_t)(f < 0.0 ? 0.0 : f > 4294967295.0 ? 4294967295.0 : f);
-        } else return (T)x;
+        else if constexpr (cast_lossy(A::dt, TO)) return cast_fits<TO>(x) ? (T)x : (T)0;   // (a float out of range must not reach the conversion)
+        else return (T)x;
     }
     static std::string sig() { return "{" + std::to_string(TO) + " " + A::sig() + "}"; }
 };

@@ -29,6 +29,7 @@ constexpr int cmaxl(std::initializer_list<int> l) {
 
 template <int NC, int R>
 struct GCtx {
+    static constexpr int rows = R;
     uint64_t v[NC][R];   // raw elements zero-extended (typed views re-narrow them)
     uint32_t valid[NC];
     uint64_t imm[kGSpecImm];

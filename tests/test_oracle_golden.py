@@ -317,3 +317,34 @@ def test_oracle_reproduces_golden_vectors_v2(ora):
 @pytest.mark.gpu
 def test_gpu_reproduces_golden_vectors_v2(gpu):
     check_golden_v2(gpu)
+
+
+def test_cast_yields_null_where_the_target_cannot_hold_the_value(ora):
+    """arrow::compute::cast of the reference's era = num::cast::cast per element, None -> NULL (ADVICE r1): integers that do
+    not fit, NaN and out-of-range floats on the way to an integer; floats truncate toward zero when the truncated value fits."""
+    def cast(vals, src, dst):
+        return ora.cast([A.HostArray.from_numpy(np.array(vals, dtype=A.NP_OF[src]))], dst)[0].to_pylist()
+    assert cast([-1, 0, 255, 256, 300], A.I64, A.U8) == [None, 0, 255, None, None]
+    assert cast([-129, -128, 127, 128], A.I32, A.I8) == [None, -128, 127, None]
+    assert cast([2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1], A.U32, A.I32) == [2 ** 31 - 1, None, None]
+    assert cast([2 ** 63 - 1, 2 ** 63, 2 ** 64 - 1], A.U64, A.I64) == [2 ** 63 - 1, None, None]
+    assert cast([-1, 5], A.I8, A.U64) == [None, 5]
+    assert cast([np.iinfo(np.int64).min, -7], A.I64, A.I32) == [None, -7]
+    nan, inf = float("nan"), float("inf")
+    assert cast([nan, inf, -inf, 1e20, -1e20, 2.0 ** 63, -(2.0 ** 63), 9.2e18, -0.9, 3.99], A.F64, A.I64) == \
+        [None, None, None, None, None, None, -2 ** 63, 9200000000000000000, 0, 3]
+    assert cast([-0.5, -1.0, 255.9, 256.0, nan], A.F64, A.U8) == [0, None, 255, None, None]
+    assert cast([4294967295.9, 4294967296.0, -0.99], A.F64, A.U32) == [4294967295, None, 0]
+    assert cast([2147483647.9, 2147483648.0, -2147483648.9, -2147483649.0], A.F64, A.I32) == [2147483647, None, -2147483648, None]
+    assert cast([2.0 ** 31, -(2.0 ** 31), 1.5e9], A.F32, A.I32) == [None, -2 ** 31, 1500000000]
+    assert cast([1.8446742e19, 2.0 ** 64, -1.0], A.F32, A.U64) == [int(np.float32(1.8446742e19)), None, None]
+    # lossless directions never produce NULLs
+    assert cast([-1, 2 ** 62], A.I64, A.F64) == [-1.0, float(2 ** 62)]
+    assert cast([1e300, -1e300, 1.5], A.F64, A.F32) == [inf, -inf, 1.5]
+    assert cast([0, -3, 7], A.I32, A.BOOL) == [False, True, True]
+    # input NULLs stay NULL; a fused pipeline skips the NULLs a cast produced
+    a = A.HostArray.from_numpy(np.array([1.0, 300.0, 2.0, -5.0]), valid=[True, True, False, True])
+    assert ora.cast([a], A.U8)[0].to_pylist() == [1, None, None, None]
+    e = A.Expr()
+    r = ora.pipeline(e, [[A.HostArray.from_numpy(np.array([1.0, 300.0, 2.0, -5.0, 7.9]))]], [e.cast(e.col(0), A.U8)])[0]
+    assert (r.count, r.sum, r.min, r.max) == (3, 10, 1, 7)

@@ -8,7 +8,7 @@ import pytest
 
 from rust_dataframe_amd import _abi as A
 
-from util import assert_arrays_match, assert_chunks_match, assert_scalar_close, make_chunks
+from util import rand_values, assert_arrays_match, assert_chunks_match, assert_scalar_close, make_chunks
 
 pytestmark = pytest.mark.gpu
 
@@ -100,6 +100,32 @@ def test_cast_matrix(gpu, ora, src):
                         if ch.length >= 16:
                             ch.values[ch.offset + 8:ch.offset + 16] = [300.7, -300.7, 7e4, -7e4, 5e9, -5e9, 3e19, -3e19]
             assert_chunks_match(gpu.cast(a, dst), ora.cast(a, dst), exact=True, what=f"cast {src}->{dst}")
+
+
+def test_cast_nulls_where_unrepresentable(gpu, ora, request):
+    """The edge values of every lossy direction through rdf_cast, through a fused aggregate of a cast, and through a stored
+    fused expression holding a cast (specialised kernels and the evaluator): NULL exactly where the oracle says so."""
+    nan, inf = float("nan"), float("inf")
+    cases = [(A.I64, A.U8, [-1, 0, 255, 256, 300]), (A.I32, A.I8, [-129, -128, 127, 128]), (A.U32, A.I32, [2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1]),
+             (A.U64, A.I64, [2 ** 63 - 1, 2 ** 63, 2 ** 64 - 1]), (A.I8, A.U64, [-1, 5]), (A.I64, A.I32, [-2 ** 63, -7, 2 ** 31]),
+             (A.F64, A.I64, [nan, inf, -inf, 1e20, -1e20, 2.0 ** 63, -(2.0 ** 63), 9.2e18, -0.9, 3.99]), (A.F64, A.U8, [-0.5, -1.0, 255.9, 256.0, nan]),
+             (A.F64, A.U32, [4294967295.9, 4294967296.0, -0.99]), (A.F64, A.I32, [2147483647.9, 2147483648.0, -2147483648.9, -2147483649.0]),
+             (A.F32, A.I32, [2.0 ** 31, -(2.0 ** 31), 1.5e9]), (A.F32, A.U64, [1.8446742e19, 2.0 ** 64, -1.0]), (A.F64, A.U64, [1.8e19, 2.0 ** 64, -1.0, nan]),
+             (A.F64, A.I16, [32767.5, 32768.0, -32768.5, -32769.0]), (A.U16, A.I8, [127, 128]), (A.I16, A.U16, [-1, 65535 // 2])]
+    rng = np.random.default_rng(3)
+    for src, dst, vals in cases:
+        base = np.array(vals, dtype=A.NP_OF[src])
+        # long enough for full vector tiles, with the edge values scattered among ordinary ones
+        body = rand_values(rng, src, 5000, "special" if src in (A.F32, A.F64) else "extreme")
+        body[rng.integers(0, 5000, 10 * len(base))] = np.tile(base, 10)
+        for arr in (A.HostArray.from_numpy(base), A.HostArray.from_numpy(body), A.HostArray.from_numpy(body, valid=rng.uniform(size=5000) > 0.2, offset=3, rng=rng)):
+            assert_chunks_match(gpu.cast([arr], dst), ora.cast([arr], dst), exact=True, what=f"cast {src}->{dst}")
+            e = A.Expr()
+            c = e.cast(e.col(0), dst)
+            g, o = gpu.pipeline(e, [[arr]], [c])[0], ora.pipeline(e, [[arr]], [c])[0]
+            assert (g.count, g.is_some) == (o.count, o.is_some), f"count of cast {src}->{dst}"
+            if o.is_some:
+                assert (g.min, g.max) == (o.min, o.max) and (g.sum == o.sum or abs(g.sum - o.sum) <= 1e-9 * abs(o.sum)), f"aggregates of cast {src}->{dst}"
 
 
 @pytest.mark.parametrize("dtype", [A.I32, A.I64])
