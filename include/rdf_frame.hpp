@@ -18,6 +18,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cerrno>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -246,6 +247,8 @@ struct Array {
     }
 };
 
+inline std::vector<ArrayRef> cast_arrays(const std::vector<ArrayRef>& arr, DataType to);   // arrow::compute::cast per chunk, below
+
 // ------------------------------------------------------------------------------------------------
 // ChunkedArray (src/table.rs:13-112)
 
@@ -350,7 +353,43 @@ class Column {
 
     // src/table.rs:218-241: gather over the concatenation of the chunks; the result is ONE chunk whatever
     // chunk_size says.  indices: UInt32 (drop-in) or UInt64.
-    Column take(const ArrayRef& indices, size_t /*chunk_size*/) const {
+    Column take(const ArrayRef& indices, size_t chunk_size) const {
+        if (data_type() == DataType::Utf8) {
+            // text columns are carried on the host: gather there (a NULL index gives a NULL, i.e. an empty slot marked invalid)
+            std::vector<const std::string*> flat;
+            std::vector<bool> flat_valid;
+            for (auto& c : data_.chunks()) {
+                const std::vector<bool> v = c->valid_to_host();
+                for (int64_t r = 0; r < c->length; ++r) { flat.push_back(&(*c->strings)[(size_t)(c->offset + r)]); flat_valid.push_back(v[(size_t)r]); }
+            }
+            const std::vector<bool> iv_valid = indices->valid_to_host();
+            std::vector<uint64_t> idx;
+            if (indices->dtype == DataType::UInt32) { for (uint32_t x : indices->values_to_host<uint32_t>()) idx.push_back(x); }
+            else if (indices->dtype == DataType::UInt64) { for (uint64_t x : indices->values_to_host<uint64_t>()) idx.push_back(x); }
+            else throw DataFrameError(DataFrameError::ComputeError, "take: indices must be UInt32 / UInt64");
+            std::vector<std::string> out(idx.size());
+            std::vector<bool> valid(idx.size(), true);
+            bool any_null = false;
+            for (size_t j = 0; j < idx.size(); ++j) {
+                if (!iv_valid[j]) { valid[j] = false; any_null = true; continue; }
+                if (idx[j] >= flat.size()) throw DataFrameError(DataFrameError::ComputeError, "take: index out of bounds");
+                out[j] = *flat[(size_t)idx[j]];
+                if (!flat_valid[(size_t)idx[j]]) { valid[j] = false; any_null = true; }
+            }
+            auto a = std::const_pointer_cast<Array>(Array::from_strings(std::move(out)));
+            if (any_null) {
+                const auto bits = pack_bits(valid);
+                a->validity = std::make_shared<DeviceBuffer>((int64_t)bits.size());
+                check(rdf_copy_h2d(a->validity->data(), bits.data(), (int64_t)bits.size()));
+                for (bool b : valid) a->null_count += !b;
+            }
+            return Column(ChunkedArray::from_arrays({ArrayRef(a)}), field_);
+        }
+        if (data_type() == DataType::Boolean) {   // Boolean columns travel through the gather as UInt8 (cast there and back on the device)
+            const Column wide(ChunkedArray::from_arrays(cast_arrays(data_.chunks(), DataType::UInt8)), Field{field_.name, DataType::UInt8, field_.nullable});
+            const Column taken = wide.take(indices, chunk_size);
+            return Column(ChunkedArray::from_arrays(cast_arrays(taken.data().chunks(), DataType::Boolean)), field_);
+        }
         const auto cv = data_.views();
         const rdf_array iv = indices->view();
         bool nullable = indices->validity != nullptr;
@@ -765,8 +804,12 @@ class DataFrame {
             if (c.num_rows() != cols[0].num_rows()) throw DataFrameError(DataFrameError::ComputeError, "columns differ in length");
         return DataFrame(std::move(s), std::move(cols));
     }
-    // Reads the numeric columns of a CSV with a header row into 1024-row batches (DataFrame::from_csv,
-    // src/dataframe.rs:349-389: batch_size 1024); quoted text columns are carried as opaque Utf8.
+    // DataFrame::from_csv (src/dataframe.rs:349-389: arrow::csv::Reader with an inferred schema, batch_size 1024).
+    // Schema inference as the Arrow CSV reader does it — a column whose non-empty cells all parse as integers is Int64,
+    // as numbers Float64, as true / false Boolean, anything else Utf8; an empty cell is a NULL.  A typed column is parsed
+    // into ONE host buffer (+ validity bitmap) and reaches HBM with ONE copy; its 1024-row RecordBatches are zero-copy
+    // slices of that buffer (chunk i = offset 1024 i), so the chunk structure the reference's reader produces is kept
+    // without one small copy per batch.  Quoted text columns are carried as opaque Utf8 on the host.
     static DataFrame from_csv(const std::string& path, size_t batch_size = 1024) {
         std::ifstream f(path);
         if (!f) throw DataFrameError(DataFrameError::IoError, "cannot open " + path);
@@ -786,22 +829,50 @@ class DataFrame {
             v.resize(header.size());
             for (size_t i = 0; i < header.size(); ++i) cells[i].push_back(v[i]);
         }
+        auto is_int = [](const std::string& s) { char* e = nullptr; errno = 0; (void)std::strtoll(s.c_str(), &e, 10); return e != s.c_str() && !*e && errno == 0; };
+        auto is_num = [](const std::string& s) { char* e = nullptr; (void)std::strtod(s.c_str(), &e); return e != s.c_str() && !*e; };
+        auto is_bool = [](const std::string& s) { return s == "true" || s == "false" || s == "True" || s == "False" || s == "TRUE" || s == "FALSE"; };
         std::vector<Column> cols;
         for (size_t i = 0; i < header.size(); ++i) {
-            bool numeric = !cells[i].empty();
-            for (auto& s : cells[i]) { char* e = nullptr; std::strtod(s.c_str(), &e); if (e == s.c_str() || *e) { numeric = false; break; } }
-            std::vector<ArrayRef> chunks;
             const size_t n = cells[i].size();
-            for (size_t b = 0; b < n || chunks.empty(); b += batch_size) {
-                const size_t e = std::min(n, b + batch_size);
-                if (numeric) {
-                    std::vector<double> v;
-                    for (size_t k = b; k < e; ++k) v.push_back(std::strtod(cells[i][k].c_str(), nullptr));
-                    chunks.push_back(Array::from_vec(v));
-                } else chunks.push_back(Array::from_strings(std::vector<std::string>(cells[i].begin() + b, cells[i].begin() + e)));
-                if (n == 0) break;
+            bool all_int = true, all_num = true, all_bool = true, any = false, any_null = false;
+            for (auto& s : cells[i]) {
+                if (s.empty()) { any_null = true; continue; }
+                any = true;
+                all_int = all_int && is_int(s); all_num = all_num && is_num(s); all_bool = all_bool && is_bool(s);
             }
-            cols.push_back(Column::from_arrays(chunks, Field{header[i], numeric ? DataType::Float64 : DataType::Utf8, true}));
+            const DataType dt = !any ? DataType::Utf8 : all_int ? DataType::Int64 : all_num ? DataType::Float64 : all_bool ? DataType::Boolean : DataType::Utf8;
+            std::vector<ArrayRef> chunks;
+            if (dt == DataType::Utf8) {
+                for (size_t b = 0; b < n || chunks.empty(); b += batch_size) {
+                    const size_t e = std::min(n, b + batch_size);
+                    chunks.push_back(Array::from_strings(std::vector<std::string>(cells[i].begin() + b, cells[i].begin() + e)));
+                    if (n == 0) break;
+                }
+            } else {
+                std::vector<bool> valid(n, true);
+                ArrayRef whole;
+                if (dt == DataType::Int64) {
+                    std::vector<int64_t> v(n, 0);
+                    for (size_t k = 0; k < n; ++k) { if (cells[i][k].empty()) valid[k] = false; else v[k] = std::strtoll(cells[i][k].c_str(), nullptr, 10); }
+                    whole = Array::from_vec(v, any_null ? &valid : nullptr);
+                } else if (dt == DataType::Float64) {
+                    std::vector<double> v(n, 0.0);
+                    for (size_t k = 0; k < n; ++k) { if (cells[i][k].empty()) valid[k] = false; else v[k] = std::strtod(cells[i][k].c_str(), nullptr); }
+                    whole = Array::from_vec(v, any_null ? &valid : nullptr);
+                } else {
+                    std::vector<bool> v(n, false);
+                    for (size_t k = 0; k < n; ++k) { if (cells[i][k].empty()) valid[k] = false; else v[k] = cells[i][k][0] == 't' || cells[i][k][0] == 'T'; }
+                    whole = Array::from_bools(v, any_null ? &valid : nullptr);
+                }
+                for (size_t b = 0; b < n || chunks.empty(); b += batch_size) {   // RecordBatches = zero-copy slices of the one buffer
+                    auto c = std::const_pointer_cast<Array>(whole->slice((int64_t)b, (int64_t)std::min(batch_size, n - b)));
+                    if (any_null) { c->null_count = 0; for (size_t k = b; k < std::min(n, b + batch_size); ++k) c->null_count += !valid[k]; }
+                    chunks.push_back(c);
+                    if (n == 0) break;
+                }
+            }
+            cols.push_back(Column::from_arrays(chunks, Field{header[i], dt, true}));
         }
         return from_columns(std::move(cols));
     }
@@ -1001,7 +1072,8 @@ class DataFrame {
         for (auto& c : columns_) cols.push_back(c.slice(0, (int64_t)count));
         return DataFrame(schema_, std::move(cols));
     }
-    DataFrame select(const std::vector<std::string>& names) const {  // :258-297 — unknown names are omitted
+    DataFrame select(const std::vector<std::string>& names) const {  // :258-297 — unknown names are omitted; "*" keeps every column (:272)
+        for (auto& n : names) if (n == "*") return *this;
         Schema s; std::vector<Column> cols;
         for (size_t i = 0; i < columns_.size(); ++i)
             for (auto& n : names) if (schema_.fields[i].name == n) { s.fields.push_back(schema_.fields[i]); cols.push_back(columns_[i]); break; }
@@ -1517,46 +1589,68 @@ class Evaluate {
     void step_group_aggregate(const plan::Transformation& t) {
         using AF = plan::AggregateFunction;
         if (fused_dense_group_aggregate(t)) return;   // small dense key domain(s): filter + expressions + grouping in one pass
-        if (t.names.size() != 1) throw DataFrameError(DataFrameError::ComputeError, "GroupAggregate: several grouping columns are supported over small dense NULL-free integer domains only");
         DataFrame f = flush();   // lazy columns materialised, pending filters applied
-        const Column& kc = f.column_by_name(t.names[0]);
-        if (!is_integer(kc.data_type())) throw DataFrameError(DataFrameError::ComputeError, "GroupAggregate: the grouping column must be an integer column");
-        std::vector<rdf_array> keys;
-        bool key_nulls = false;
-        for (auto& a : kc.data().chunks()) { keys.push_back(a->view()); key_nulls |= a->validity != nullptr; }
+        const size_t nk = t.names.size();
+        if (nk < 1 || nk > RDF_MAX_GROUP_KEYS) throw DataFrameError(DataFrameError::ComputeError, "GroupAggregate: 1.." + std::to_string(RDF_MAX_GROUP_KEYS) + " grouping columns");
+        std::vector<const Column*> kcs;
+        for (auto& n : t.names) {
+            kcs.push_back(&f.column_by_name(n));
+            if (!is_integer(kcs.back()->data_type())) throw DataFrameError(DataFrameError::ComputeError, "GroupAggregate: the grouping columns must be integer columns");
+        }
+        const size_t nch = kcs[0]->data().num_chunks();
+        std::vector<rdf_array> keys;          // [k * nch + i]
+        std::vector<bool> key_nulls(nk, false);
+        for (size_t k = 0; k < nk; ++k)
+            for (auto& a : kcs[k]->data().chunks()) { keys.push_back(a->view()); if (a->validity != nullptr) key_nulls[k] = true; }
         const int64_t nrows = (int64_t)f.num_rows();
         std::vector<Column> out_cols;
-        if (dense_group_aggregate(f, kc, t, out_cols)) { reset(DataFrame::from_columns(out_cols)); return; }
+        if (nk == 1 && dense_group_aggregate(f, *kcs[0], t, out_cols)) { reset(DataFrame::from_columns(out_cols)); return; }
+        // Sparse or NULL-holding keys: one rdf_groupby_agg per aggregation (hash GROUP BY; several grouping columns are
+        // range-compressed into one 64-bit key on the device), results ordered by the grouping columns
         auto one = [&](AF fn, const std::string& col) {
-            if (fn != AF::Sum && fn != AF::Count && fn != AF::Avg) throw DataFrameError(DataFrameError::ComputeError, "Aggregation not yet supported");
+            if (fn != AF::Sum && fn != AF::Count && fn != AF::Avg && fn != AF::Min && fn != AF::Max) throw DataFrameError(DataFrameError::ComputeError, "Aggregation not yet supported");
             const Column& vc = f.column_by_name(col);
             const DataType vdt = vc.data_type();
             if (!(is_integer(vdt) || is_float(vdt))) throw DataFrameError(DataFrameError::ComputeError, "Aggregating column must be numeric");
             std::vector<rdf_array> vals;
-            for (auto& a : vc.data().chunks()) vals.push_back(a->view());
-            const DataType sdt = is_float(vdt) ? DataType::Float64 : DataType::Int64;
+            bool val_nulls = false;
+            for (auto& a : vc.data().chunks()) { vals.push_back(a->view()); val_nulls |= a->validity != nullptr; }
+            const int32_t agg = fn == AF::Min ? RDF_AGG_MIN : fn == AF::Max ? RDF_AGG_MAX : RDF_AGG_SUM;
+            const bool extremum = agg != RDF_AGG_SUM;
+            const DataType sdt = is_float(vdt) ? DataType::Float64 : (extremum && vdt == DataType::UInt64) ? DataType::UInt64 : DataType::Int64;
             int64_t mg = std::max<int64_t>(1, std::min<int64_t>(nrows, (int64_t)1 << 20));
-            std::shared_ptr<Array> ok, os, oc;
+            std::vector<std::shared_ptr<Array>> ok(nk);
+            std::shared_ptr<Array> os, oc;
             for (;;) {   // the number of groups is not known in advance: grow the promise until it holds
-                ok = Array::make_out(kc.data_type(), mg + 2, key_nulls);
-                os = Array::make_out(sdt, mg + 2, false);
+                std::vector<rdf_out> vk(nk);
+                for (size_t k = 0; k < nk; ++k) { ok[k] = Array::make_out(kcs[k]->data_type(), mg + 2, key_nulls[k]); vk[k] = ok[k]->out_view(mg + 2); }
+                os = Array::make_out(sdt, mg + 2, extremum && val_nulls);
                 oc = Array::make_out(DataType::Int64, mg + 2, false);
-                rdf_out vk = ok->out_view(mg + 2), vs = os->out_view(mg + 2), vcn = oc->out_view(mg + 2);
-                const rdf_status st = rdf_groupby_sum(keys.data(), vals.data(), (int64_t)keys.size(), mg, &vk, &vs, &vcn);
+                rdf_out vs = os->out_view(mg + 2), vcn = oc->out_view(mg + 2);
+                const rdf_status st = rdf_groupby_agg(keys.data(), (int32_t)nk, vals.data(), (int64_t)nch, agg, mg, vk.data(), &vs, &vcn);
                 if (st == RDF_MEMORY_ERROR && mg < nrows) { mg = std::min<int64_t>(nrows, mg * 16); continue; }
                 check(st);
-                ok->length = os->length = oc->length = vk.length;
-                ok->null_count = vk.null_count;
+                for (size_t k = 0; k < nk; ++k) { ok[k]->length = vk[k].length; ok[k]->null_count = vk[k].null_count; }
+                os->length = oc->length = vs.length;
+                os->null_count = vs.null_count;
                 break;
             }
-            DataFrame g = DataFrame::from_columns({Column::from_arrays({ok}, Field{"k", kc.data_type(), true}),
-                                                   Column::from_arrays({os}, Field{"s", sdt, false}),
-                                                   Column::from_arrays({oc}, Field{"c", DataType::Int64, false})})
-                              .sort({DataFrame::SortCriteria{"k", false, false}});
-            if (out_cols.empty()) out_cols.push_back(Column::from_arrays(g.column_by_name("k").data().chunks(), Field{t.names[0], kc.data_type(), true}));
+            std::vector<Column> gc;
+            std::vector<DataFrame::SortCriteria> order;
+            for (size_t k = 0; k < nk; ++k) {
+                gc.push_back(Column::from_arrays({ok[k]}, Field{"k" + std::to_string(k), kcs[k]->data_type(), true}));
+                order.push_back(DataFrame::SortCriteria{"k" + std::to_string(k), false, false});
+            }
+            gc.push_back(Column::from_arrays({os}, Field{"s", sdt, true}));
+            gc.push_back(Column::from_arrays({oc}, Field{"c", DataType::Int64, false}));
+            DataFrame g = DataFrame::from_columns(gc).sort(order);
+            if (out_cols.empty())
+                for (size_t k = 0; k < nk; ++k) out_cols.push_back(Column::from_arrays(g.column_by_name("k" + std::to_string(k)).data().chunks(), Field{t.names[k], kcs[k]->data_type(), true}));
             const std::vector<ArrayRef> sums = g.column_by_name("s").data().chunks(), counts = g.column_by_name("c").data().chunks();
             if (fn == AF::Sum) {
                 out_cols.push_back(Column::from_arrays(sdt == vdt ? sums : ScalarFunctions::cast(sums, vdt), Field{"sum(" + col + ")", vdt, true}));
+            } else if (fn == AF::Min || fn == AF::Max) {   // typed like the input (try_aggregate): the extremum of a group always fits
+                out_cols.push_back(Column::from_arrays(sdt == vdt ? sums : ScalarFunctions::cast(sums, vdt), Field{std::string(fn == AF::Min ? "min(" : "max(") + col + ")", vdt, true}));
             } else if (fn == AF::Count) {
                 out_cols.push_back(Column::from_arrays(ScalarFunctions::cast(counts, DataType::UInt32), Field{"count(" + col + ")", DataType::UInt32, true}));
             } else {   // avg = sum / count, NULL for a group without a non-null value (AggregateFunctions::avg, src/functions/aggregate.rs:32-65)

@@ -274,7 +274,9 @@ typedef enum { RDF_AGG_SUM = 0, RDF_AGG_MIN = 1, RDF_AGG_MAX = 2, RDF_AGG_COUNT 
  *   NaN never wins a MIN / MAX unless every value of the group is NaN (the column aggregates' rule, rdf_min / rdf_max);
  * out_counts: Int64.  Capacities >= min(max_groups, rows) + 2; group order unspecified.  More than max_groups distinct key
  * tuples -> RDF_MEMORY_ERROR.  Several grouping columns are packed into one 64-bit key after range compression
- * (bits(max - min) per column, + 1 code for NULL): tuples needing more than 64 bits -> RDF_INVALID_ARGUMENT.
+ * (bits(max - min) per column, + 1 code for NULL); when the ranges together pass 64 bits (several sparse columns) the
+ * widest columns are dictionary-coded instead (rank among the column's distinct values, found by a count-only GROUP BY
+ * of that column).  Tuples needing more than 64 bits either way -> RDF_INVALID_ARGUMENT.
  * f64 sums are accumulated with hardware atomics: the rounding order is not deterministic (<= 1e-6 relative). */
 rdf_status rdf_groupby_agg(const rdf_array* keys, int32_t nkeys, const rdf_array* values, int64_t nchunks, int32_t agg,
                            int64_t max_groups, rdf_out* out_keys, rdf_out* out_values, rdf_out* out_counts);

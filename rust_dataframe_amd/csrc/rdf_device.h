@@ -431,6 +431,8 @@ struct KeyPackArgs {
     int32_t            nkeys;
     int32_t            dtype[kMaxKeyCols], shift[kMaxKeyCols], nullable[kMaxKeyCols];
     uint64_t           bias[kMaxKeyCols], mask[kMaxKeyCols];   // field = ((order-preserving bits - bias) + nullable) << shift
+    const uint64_t*    dict[kMaxKeyCols];   // non-null: the column's sorted distinct order-preserving images; field = (rank + nullable) << shift
+    int64_t            dict_n[kMaxKeyCols];
     uint64_t*          packed;           // pack: out [n]; unpack: in [n]
     void*              out_values[kMaxKeyCols];   // unpack: dense outputs
     uint8_t*           out_validity[kMaxKeyCols];

@@ -666,7 +666,16 @@ __global__ __launch_bounds__(kBlock) void key_pack_kernel(const KeyPackArgs a) {
             const int64_t e = cc.offset + r;
             const bool valid = !cc.validity || ((as_global<uint8_t>(cc.validity)[e >> 3] >> (e & 7)) & 1);
             uint64_t f = 0;
-            if (valid) f = key_order_bits(a.dtype[k], g2_load_raw(cc.values, g2_dtype_size(a.dtype[k]), e, true)) - a.bias[k] + (uint64_t)a.nullable[k];
+            if (valid) {
+                const uint64_t ob = key_order_bits(a.dtype[k], g2_load_raw(cc.values, g2_dtype_size(a.dtype[k]), e, true));
+                if (a.dict[k]) {   // rank in the column's sorted dictionary (every value of the column is in it)
+                    int64_t lo = 0, hi = a.dict_n[k] - 1;
+                    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.dict[k][mid] < ob) lo = mid + 1; else hi = mid; }
+                    f = (uint64_t)lo + (uint64_t)a.nullable[k];
+                } else {
+                    f = ob - a.bias[k] + (uint64_t)a.nullable[k];
+                }
+            }
             packed |= f << a.shift[k];
         }
         a.packed[i] = packed;
@@ -684,7 +693,8 @@ __global__ __launch_bounds__(kBlock) void key_unpack_kernel(const KeyPackArgs a)
             if (k >= a.nkeys) break;
             const uint64_t f = (packed >> a.shift[k]) & a.mask[k];
             const bool valid = in && !(a.nullable[k] && f == 0);
-            uint64_t ob = valid ? f - (uint64_t)a.nullable[k] + a.bias[k] : 0;
+            uint64_t ob = 0;
+            if (valid) ob = a.dict[k] ? a.dict[k][f - (uint64_t)a.nullable[k]] : f - (uint64_t)a.nullable[k] + a.bias[k];
             if (valid && a.dtype[k] <= RDF_I64) ob ^= 0x8000000000000000ull;
             if (in) switch (g2_dtype_size(a.dtype[k])) {
                 case 8: ((uint64_t*)a.out_values[k])[i] = ob; break;

@@ -3,6 +3,10 @@
 // (librdf_oracle.so) is linked here as the checker only.
 #include <map>
 #include <random>
+#include <tuple>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 
 #include "mini_test.hpp"
 #include "rdf_frame.hpp"
@@ -421,9 +425,7 @@ static void group_aggregate_by_key(int32_t stride) {
         CHECK_EQ((int64_t)gc[r], null_cnt);
     }
     // unsupported shapes are errors, not silent fallbacks
-    CHECK_THROWS(LazyFrame::read(df).aggregate({"k", "w"}, {{AF::Sum, {"v"}}}).evaluate());
-    CHECK_THROWS(LazyFrame::read(df).aggregate({"v"}, {{AF::Sum, {"w"}}}).evaluate());
-    CHECK_THROWS(LazyFrame::read(df).aggregate({"k"}, {{AF::Max, {"v"}}}).evaluate());
+    CHECK_THROWS(LazyFrame::read(df).aggregate({"v"}, {{AF::Sum, {"w"}}}).evaluate());   // a Float64 grouping column
 }
 // TPC-H Q1's shape through the lazy API (BASELINE.json config C5): filter -> two computed columns -> GROUP BY two
 // dictionary-coded columns with sums / average / count.  Everything runs as ONE fused pass (rdf_group_pipeline).
@@ -485,6 +487,157 @@ TEST(test_group_aggregate_q1_shape_two_keys) {
 }
 TEST(test_group_aggregate_by_key) { group_aggregate_by_key(1); }
 TEST(test_group_aggregate_by_sparse_key) { group_aggregate_by_key(100003); }
+
+// ---------------------------------------------------------------- typed CSV (src/dataframe.rs:349-389: arrow's csv reader infers the schema)
+static std::string write_temp_csv(const std::string& body) {
+    char name[] = "/tmp/rdf_csv_XXXXXX";
+    const int fd = mkstemp(name);
+    CHECK(fd >= 0);
+    FILE* f = fdopen(fd, "w");
+    fputs(body.c_str(), f);
+    fclose(f);
+    return name;
+}
+TEST(test_read_csv_infers_types_and_nulls) {
+    std::string body = "id,score,flag,name,qty\n";
+    const size_t n = 2500;   // three batches of 1024 rows
+    int64_t want_qty = 0, qty_nulls = 0;
+    for (size_t i = 0; i < n; ++i) {
+        body += std::to_string((int64_t)i - 7) + "," + std::to_string(0.5 * (double)i) + "," + (i % 3 ? "true" : "false") + ",\"row, " + std::to_string(i) + "\",";
+        if (i % 10 == 3) { ++qty_nulls; } else { body += std::to_string(i * 3); want_qty += (int64_t)i * 3; }
+        body += "\n";
+    }
+    const std::string path = write_temp_csv(body);
+    DataFrame df = DataFrame::from_csv(path);
+    std::remove(path.c_str());
+    CHECK_EQ(df.num_columns(), 5u);
+    CHECK_EQ(df.num_rows(), (int64_t)n);
+    CHECK_EQ(df.num_chunks(), 3u);
+    CHECK(df.column_by_name("id").data_type() == DataType::Int64);
+    CHECK(df.column_by_name("score").data_type() == DataType::Float64);
+    CHECK(df.column_by_name("flag").data_type() == DataType::Boolean);
+    CHECK(df.column_by_name("name").data_type() == DataType::Utf8);
+    CHECK(df.column_by_name("qty").data_type() == DataType::Int64);
+    CHECK_EQ(df.column_by_name("qty").null_count(), qty_nulls);
+    CHECK_EQ(df.column_by_name("id").null_count(), (int64_t)0);
+    CHECK_EQ(host<int64_t>(df.column_by_name("id").data().chunk(1))[0], (int64_t)1024 - 7);
+    CHECK_EQ((*df.column_by_name("name").data().chunk(2)->strings)[0], std::string("row, 2048"));
+    CHECK(df.column_by_name("qty").data().chunk(0)->is_null(3));
+    CHECK(!df.column_by_name("qty").data().chunk(0)->is_null(4));
+    CHECK_EQ(*AggregateFunctions::sum<int64_t>(df.column_by_name("qty").data()), want_qty);
+    CHECK_EQ(*AggregateFunctions::count(df.column_by_name("qty").data()), (int64_t)n - qty_nulls);
+    // the typed columns are on the compute path: a filter on the Boolean column, then a sum of an Int64 one
+    DataFrame kept = df.filter_by_mask(df.column_by_name("flag"));
+    int64_t want_kept = 0, want_id = 0;
+    for (size_t i = 0; i < n; ++i) if (i % 3) { ++want_kept; want_id += (int64_t)i - 7; }
+    CHECK_EQ(kept.num_rows(), want_kept);
+    CHECK_EQ(*AggregateFunctions::sum<int64_t>(kept.column_by_name("id").data()), want_id);
+    CHECK_EQ(kept.column_by_name("name").num_rows(), want_kept);
+    // select("*") keeps every column (:272)
+    CHECK_EQ(df.select({"*"}).num_columns(), 5u);
+    CHECK_EQ(df.select({"id", "nope"}).num_columns(), 1u);
+}
+
+// sort / join / take of a frame holding text and Boolean columns (Column::take, src/table.rs:218-241, is type-generic)
+TEST(test_sort_and_join_carry_text_and_boolean_columns) {
+    DataFrame df = DataFrame::from_csv(g_csv);   // city (Utf8), lat, lng
+    std::vector<std::string> city;
+    std::vector<double> lat;
+    for (auto& c : df.column_by_name("city").data().chunks()) city.insert(city.end(), c->strings->begin(), c->strings->end());
+    for (auto& c : df.column_by_name("lat").data().chunks()) { auto v = host<double>(c); lat.insert(lat.end(), v.begin(), v.end()); }
+    std::vector<size_t> order(lat.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return lat[a] < lat[b]; });
+    DataFrame sorted = df.sort({{"lat", false, false}});
+    CHECK_EQ(sorted.num_columns(), 3u);
+    CHECK_EQ(sorted.num_rows(), 37);
+    const auto& sc = *sorted.column_by_name("city").data().chunk(0)->strings;
+    auto sl = host<double>(sorted.column_by_name("lat").data().chunk(0));
+    for (size_t i = 0; i < order.size(); ++i) { CHECK_EQ(sc[i], city[order[i]]); CHECK_EQ(sl[i], lat[order[i]]); }
+    // a Boolean column and a NULL index
+    std::vector<bool> north(lat.size());
+    for (size_t i = 0; i < lat.size(); ++i) north[i] = lat[i] > 53.0;
+    DataFrame with_flag = df.with_column("north", Column::from_arrays({Array::from_bools(north)}, Field{"north", DataType::Boolean, false}));
+    const std::vector<bool> iv{1, 0, 1, 1};
+    DataFrame t = with_flag.take(Array::from_vec<uint32_t>({36, 0, 5, 5}, &iv));
+    CHECK_EQ(t.num_rows(), 4);
+    const auto tn = t.column_by_name("north").data().chunk(0);
+    CHECK(tn->dtype == DataType::Boolean);
+    CHECK_EQ(tn->bools_to_host()[0], (bool)north[36]);
+    CHECK_EQ(tn->bools_to_host()[2], (bool)north[5]);
+    CHECK(tn->is_null(1));
+    const auto tc = t.column_by_name("city").data().chunk(0);
+    CHECK_EQ((*tc->strings)[0], city[36]);
+    CHECK_EQ((*tc->strings)[3], city[5]);
+    CHECK(tc->is_null(1) && !tc->is_null(0));
+    // join of the frame with a numeric one on an Int64 id: the text column rides through the gather
+    DataFrame left = df.with_id("id");
+    DataFrame right = DataFrame::from_columns({Column::from_arrays({Array::from_vec<uint64_t>({3, 1, 37, 99})}, Field{"rid", DataType::UInt64, false}),
+                                               Column::from_arrays({Array::from_vec<double>({30.0, 10.0, 370.0, 990.0})}, Field{"w", DataType::Float64, false})});
+    DataFrame j = left.join(right, {DataFrame::JoinType::InnerJoin, {{"id", "rid"}}});
+    CHECK_EQ(j.num_rows(), 3);
+    auto jid = host<uint64_t>(j.column_by_name("id").data().chunk(0));
+    const auto& jc = *j.column_by_name("city").data().chunk(0)->strings;
+    auto jw = host<double>(j.column_by_name("w").data().chunk(0));
+    for (size_t r = 0; r < 3; ++r) { CHECK_EQ(jc[r], city[(size_t)jid[r] - 1]); CHECK_EQ(jw[r], 10.0 * (double)jid[r]); }
+}
+
+// GroupAggregate with min / max and with several sparse grouping columns (what the reference's plan can express,
+// src/lazyframe.rs:200-258, evaluated on the device; the reference's evaluator stops at "aggregations not supported")
+TEST(test_group_aggregate_min_max_and_sparse_key_columns) {
+    std::mt19937_64 rng(99);
+    std::uniform_real_distribution<double> U(-100.0, 100.0);
+    const size_t nchunks = 4, n = 6000;
+    struct G { double sum = 0, mn = INFINITY, mx = -INFINITY; int64_t imn = INT64_MAX, imx = INT64_MIN; int64_t cnt = 0; };
+    std::map<std::tuple<int64_t, int32_t, int16_t>, G> exp;
+    std::vector<ArrayRef> ach, bch, cch, xch, ych;
+    for (size_t c = 0; c < nchunks; ++c) {
+        std::vector<int64_t> a(n), y(n);
+        std::vector<int32_t> b(n);
+        std::vector<int16_t> k3(n);
+        std::vector<double> x(n);
+        std::vector<bool> xv(n);
+        for (size_t i = 0; i < n; ++i) {
+            a[i] = (int64_t)(rng() % 7) * 1000000007LL - 3000000000LL;   // 7 values spread over 6e9
+            b[i] = (int32_t)(rng() % 5) * 400000 - 800000;               // 5 values spread over 1.6e6
+            k3[i] = (int16_t)((int)(rng() % 3) * 9000 - 9000);           // 3 values spread over 18000
+            x[i] = U(rng); xv[i] = rng() % 17 != 0; y[i] = (int64_t)(rng() % 2000001) - 1000000;
+            G& g = exp[{a[i], b[i], k3[i]}];
+            if (xv[i]) { g.sum += x[i]; g.mn = std::min(g.mn, x[i]); g.mx = std::max(g.mx, x[i]); ++g.cnt; }
+            g.imn = std::min(g.imn, y[i]); g.imx = std::max(g.imx, y[i]);
+        }
+        ach.push_back(Array::from_vec(a)); bch.push_back(Array::from_vec(b)); cch.push_back(Array::from_vec(k3));
+        xch.push_back(Array::from_vec(x, &xv)); ych.push_back(Array::from_vec(y));
+    }
+    DataFrame df = DataFrame::from_columns({Column::from_arrays(ach, Field{"a", DataType::Int64, false}), Column::from_arrays(bch, Field{"b", DataType::Int32, false}),
+                                            Column::from_arrays(cch, Field{"c", DataType::Int16, false}), Column::from_arrays(xch, Field{"x", DataType::Float64, true}),
+                                            Column::from_arrays(ych, Field{"y", DataType::Int64, false})});
+    using AF = P::AggregateFunction;
+    DataFrame g = LazyFrame::read(df).aggregate({"a", "b", "c"}, {{AF::Min, {"x", "y"}}, {AF::Max, {"x", "y"}}, {AF::Sum, {"x"}}, {AF::Count, {"x"}}}).evaluate();
+    CHECK_EQ(g.num_columns(), 9u);
+    CHECK_EQ((size_t)g.num_rows(), exp.size());
+    CHECK_EQ(g.schema().fields[3].name, std::string("min(x)"));
+    CHECK_EQ(g.schema().fields[4].name, std::string("min(y)"));
+    CHECK_EQ(g.schema().fields[5].name, std::string("max(x)"));
+    CHECK_EQ(g.schema().fields[6].name, std::string("max(y)"));
+    CHECK(g.schema().fields[4].data_type == DataType::Int64);   // min / max keep the input type
+    CHECK(g.schema().fields[3].data_type == DataType::Float64);
+    auto ka = host<int64_t>(g.column(0).data().chunk(0));
+    auto kb = host<int32_t>(g.column(1).data().chunk(0));
+    auto kc = host<int16_t>(g.column(2).data().chunk(0));
+    auto mnx = host<double>(g.column(3).data().chunk(0)), mxx = host<double>(g.column(5).data().chunk(0)), sx = host<double>(g.column(7).data().chunk(0));
+    auto mny = host<int64_t>(g.column(4).data().chunk(0)), mxy = host<int64_t>(g.column(6).data().chunk(0));
+    auto cx = host<uint32_t>(g.column(8).data().chunk(0));
+    size_t r = 0;
+    for (auto& kv : exp) {   // std::map<tuple> iterates in (a, b, c) order == the result's row order
+        CHECK_EQ(ka[r], std::get<0>(kv.first)); CHECK_EQ(kb[r], std::get<1>(kv.first)); CHECK_EQ(kc[r], std::get<2>(kv.first));
+        CHECK_EQ(mnx[r], kv.second.mn); CHECK_EQ(mxx[r], kv.second.mx);
+        CHECK_EQ(mny[r], kv.second.imn); CHECK_EQ(mxy[r], kv.second.imx);
+        CHECK_NEAR(sx[r], kv.second.sum, 1e-9 * (1.0 + std::fabs(kv.second.sum)));
+        CHECK_EQ((int64_t)cx[r], kv.second.cnt);
+        ++r;
+    }
+}
 
 // DataFrame::from_arrow (src/dataframe.rs:391-407) on the committed pyarrow-written fixture: schema, chunking (one chunk
 // per record batch), every value and validity bit, then the device path over the loaded columns.

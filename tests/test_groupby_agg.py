@@ -203,8 +203,8 @@ def test_groupby_agg_partition_path_large(gpu, ora, agg):
 
 @pytest.mark.gpu
 def test_groupby_agg_multi_column_keys(gpu, ora):
-    """Two to four grouping columns of mixed integer types, sparse values (range-compressed into one 64-bit key), NULLs in
-    every grouping column; a tuple that cannot fit 64 bits is an InvalidArgument."""
+    """Two to four grouping columns of mixed integer types, sparse values (range-compressed or dictionary-coded into one
+    64-bit key), NULLs in every grouping column; a tuple that cannot fit 64 bits either way is an InvalidArgument."""
     rng = np.random.default_rng(2024)
     lens = [5000, 0, 12_000]
     specs = [(A.I64, 30, -10 ** 15), (A.I8, 7, -3), (A.U32, 50, 4_000_000_000 - 25), (A.I16, 4, 100)]
@@ -215,9 +215,26 @@ def test_groupby_agg_multi_column_keys(gpu, ora):
             exp = _groups(*ora.groupby_agg(key_cols, vals, agg, 60_000))
             got = _groups(*gpu.groupby_agg(key_cols, vals, agg, 60_000))
             _assert_same_groups(got, exp, True, f"nkeys={nkeys} agg={agg}")
+    # several sparse columns whose ranges together pass 64 bits: the widest are dictionary-coded (rank among the
+    # column's distinct values), NULLs included
+    pools = [rng.integers(-2 ** 62, 2 ** 62, 40), rng.integers(0, 2 ** 63, 25).astype(np.uint64), rng.integers(-2 ** 31, 2 ** 31, 9)]
+    dts = [A.I64, A.U64, A.I32]
+    sparse = [[A.HostArray.from_numpy(rng.choice(pool, n).astype(A.NP_OF[dt]), valid=(rng.uniform(size=n) >= nf) if nf else None, offset=3, rng=rng) for n in lens]
+              for pool, dt, nf in zip(pools, dts, (0.03, 0.0, 0.05))]
+    vals = make_chunks(rng, A.I64, lens, 0.1, 3)
+    for agg in ("sum", "min", "count"):
+        exp = _groups(*ora.groupby_agg(sparse, vals, agg, 20_000))
+        got = _groups(*gpu.groupby_agg(sparse, vals, agg, 20_000))
+        assert len(exp) > 5000
+        _assert_same_groups(got, exp, False, f"dictionary-coded keys agg={agg}")
     wide = [[A.HostArray.from_numpy(rng.integers(-2 ** 62, 2 ** 62, 1000).astype(np.int64))] for _ in range(2)]
+    exp = _groups(*ora.groupby_agg(wide, None, "count", 2000))
+    got = _groups(*gpu.groupby_agg(wide, None, "count", 2000))
+    _assert_same_groups(got, exp, False, "two full-range columns")
+    # four columns of ~70 000 distinct sparse values each cannot fit 64 bits even dictionary-coded: InvalidArgument
+    wide = [[A.HostArray.from_numpy(rng.integers(-2 ** 62, 2 ** 62, 70_000).astype(np.int64))] for _ in range(4)]
     with pytest.raises(A.RdfError) as ei:
-        gpu.groupby_agg(wide, None, "count", 2000)
+        gpu.groupby_agg(wide, None, "count", 100_000)
     assert ei.value.status == A.RDF_INVALID_ARGUMENT
 
 
