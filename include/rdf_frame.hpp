@@ -656,7 +656,10 @@ using DivideOperation = BinaryOperation<ScalarFunction::Divide>;
 // SinOperation (:227-318) + the same shape for cosine / tangent: integers are cast to Float64 first
 template <ScalarFunction F>
 struct TrigOperation {
-    static const char* name() { return F == ScalarFunction::Sine ? "sin" : F == ScalarFunction::Cosine ? "cos" : "tan"; }
+    static const char* name() {
+        return F == ScalarFunction::Sine ? "sin" : F == ScalarFunction::Cosine ? "cos" : F == ScalarFunction::Tangent ? "tan"
+             : F == ScalarFunction::Cotangent ? "cot" : F == ScalarFunction::Secant ? "sec" : "csc";
+    }
     static std::vector<Calculation> transform(const std::vector<Column>& inputs, std::optional<std::string> out_name, std::optional<DataType>) {
         if (inputs.size() != 1) throw DataFrameError(DataFrameError::ComputeError, "Sine operation expects 2 inputs");  // sic, :242
         const Column& a = inputs[0];
@@ -673,6 +676,11 @@ struct TrigOperation {
 using SinOperation = TrigOperation<ScalarFunction::Sine>;
 using CosOperation = TrigOperation<ScalarFunction::Cosine>;
 using TanOperation = TrigOperation<ScalarFunction::Tangent>;
+// ScalarFunction::{Cotangent, Secant, Cosecant} (:670-672): the reference's builder panics on them (:487-489); planned
+// here with the sine's shape and evaluated as RDF_OP_COT / SEC / CSC
+using CotOperation = TrigOperation<ScalarFunction::Cotangent>;
+using SecOperation = TrigOperation<ScalarFunction::Secant>;
+using CscOperation = TrigOperation<ScalarFunction::Cosecant>;
 
 struct Transformation {
     enum Kind { GroupAggregate, Calculate, Select, Drop, Limit, Filter, Sort, Join, Read } kind = Calculate;
@@ -723,6 +731,9 @@ inline std::vector<Transformation> calculate(const Dataset& ds, const std::vecto
                 case ScalarFunction::Sine: ops = SinOperation::transform(inputs, out_col_name, out_col_type); break;
                 case ScalarFunction::Cosine: ops = CosOperation::transform(inputs, out_col_name, out_col_type); break;
                 case ScalarFunction::Tangent: ops = TanOperation::transform(inputs, out_col_name, out_col_type); break;
+                case ScalarFunction::Cotangent: ops = CotOperation::transform(inputs, out_col_name, out_col_type); break;
+                case ScalarFunction::Secant: ops = SecOperation::transform(inputs, out_col_name, out_col_type); break;
+                case ScalarFunction::Cosecant: ops = CscOperation::transform(inputs, out_col_name, out_col_type); break;
                 default: throw DataFrameError(DataFrameError::ComputeError, std::string("Scalar Function ") + scalar_function_name(function.scalar) + " not supported");
             }
     }
@@ -1291,6 +1302,9 @@ struct ScalarFunctions {
     static std::vector<ArrayRef> sin(const std::vector<ArrayRef>& a) { return unary(RDF_OP_SIN, a); }
     static std::vector<ArrayRef> cos(const std::vector<ArrayRef>& a) { return unary(RDF_OP_COS, a); }
     static std::vector<ArrayRef> tan(const std::vector<ArrayRef>& a) { return unary(RDF_OP_TAN, a); }
+    static std::vector<ArrayRef> cot(const std::vector<ArrayRef>& a) { return unary(RDF_OP_COT, a); }
+    static std::vector<ArrayRef> sec(const std::vector<ArrayRef>& a) { return unary(RDF_OP_SEC, a); }
+    static std::vector<ArrayRef> csc(const std::vector<ArrayRef>& a) { return unary(RDF_OP_CSC, a); }
     static std::vector<ArrayRef> acos(const std::vector<ArrayRef>& a) { return unary(RDF_OP_ACOS, a); }
 
   private:
@@ -1472,6 +1486,7 @@ inline int32_t scalar_function_op(plan::ScalarFunction f) {
         case SF::Add: return RDF_OP_ADD; case SF::Subtract: return RDF_OP_SUB; case SF::Multiply: return RDF_OP_MUL;
         case SF::Divide: return RDF_OP_DIV; case SF::Abs: return RDF_OP_ABS; case SF::Sine: return RDF_OP_SIN;
         case SF::Cosine: return RDF_OP_COS; case SF::Tangent: return RDF_OP_TAN;
+        case SF::Cotangent: return RDF_OP_COT; case SF::Secant: return RDF_OP_SEC; case SF::Cosecant: return RDF_OP_CSC;
         default: throw DataFrameError(DataFrameError::ComputeError, std::string("Scalar Function ") + plan::scalar_function_name(f) + " not supported");
     }
 }

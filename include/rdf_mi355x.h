@@ -98,7 +98,11 @@ typedef enum {
     /* arrow::compute::hour via ScalarFunctions::hour (src/functions/scalar.rs:267-273), one opcode per time unit of
      * the temporal input (Time32 s/ms, Time64 us/ns, Date64 ms, Timestamp s/ms/us/ns; Date32 counts days: hour 0).
      * Operand Int32 or Int64 (the temporal types' storage), result of the operand's type, 0..23. */
-    RDF_OP_HOUR_S = 39, RDF_OP_HOUR_MS = 40, RDF_OP_HOUR_US = 41, RDF_OP_HOUR_NS = 42, RDF_OP_HOUR_DAY = 43
+    RDF_OP_HOUR_S = 39, RDF_OP_HOUR_MS = 40, RDF_OP_HOUR_US = 41, RDF_OP_HOUR_NS = 42, RDF_OP_HOUR_DAY = 43,
+    /* ScalarFunction::{Cotangent, Secant, Cosecant} (src/expression.rs:670-672): plannable names the reference never
+     * evaluates (its plan builder panics, :487-489).  Unary math like the others: 1 / tan(x), 1 / cos(x), 1 / sin(x) in
+     * the operand's float type (IEEE division: cot(0) = +inf). */
+    RDF_OP_COT = 44, RDF_OP_SEC = 45, RDF_OP_CSC = 46
 } rdf_op;
 
 /* time units of the temporal arrays handed to rdf_hour */

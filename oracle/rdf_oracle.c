@@ -189,6 +189,9 @@ static double un_f64(int32_t op, double x) {
         case RDF_OP_SINH: return sinh(x);
         case RDF_OP_SQRT: return sqrt(x);
         case RDF_OP_TAN: return tan(x);
+        case RDF_OP_COT: return 1.0 / tan(x);   /* ScalarFunction::{Cotangent,Secant,Cosecant} (src/expression.rs:670-672): */
+        case RDF_OP_SEC: return 1.0 / cos(x);   /* named by the plan, never evaluated by the reference (:487-489 panic) --    */
+        case RDF_OP_CSC: return 1.0 / sin(x);   /* the textbook reciprocals, PARITY UNPINNED BY THE REFERENCE                 */
         default: return tanh(x);
     }
 }
@@ -214,6 +217,9 @@ static float un_f32(int32_t op, float x) {
         case RDF_OP_SINH: return sinhf(x);
         case RDF_OP_SQRT: return sqrtf(x);
         case RDF_OP_TAN: return tanf(x);
+        case RDF_OP_COT: return 1.0f / tanf(x);
+        case RDF_OP_SEC: return 1.0f / cosf(x);
+        case RDF_OP_CSC: return 1.0f / sinf(x);
         default: return tanhf(x);
     }
 }
@@ -266,7 +272,7 @@ static rdf_status unary_chunk(int32_t op, const rdf_array* a, rdf_out* o) {
 }
 
 rdf_status ora_unary(int32_t op, const rdf_array* a, int64_t nchunks, rdf_out* out) {
-    if (op < RDF_OP_ABS || op > RDF_OP_TANH) FAIL(RDF_INVALID_ARGUMENT, "not a unary op: %d", op);
+    if (!((op >= RDF_OP_ABS && op <= RDF_OP_TANH) || (op >= RDF_OP_COT && op <= RDF_OP_CSC))) FAIL(RDF_INVALID_ARGUMENT, "not a unary op: %d", op);
     for (int64_t c = 0; c < nchunks; c++) { /* array.iter().map(|a| scalar_op(a, ..)) scalar.rs:111 */
         rdf_status s = unary_chunk(op, &a[c], &out[c]);
         if (s != RDF_OK) return s;
@@ -679,7 +685,7 @@ static rdf_status eval_node(const rdf_expr_node* nodes, int32_t nnodes, int32_t 
     if (op >= RDF_OP_ADD && op <= RDF_OP_LOG) {
         if (!tmp_alloc(res, l.dtype, l.len, l.validity || r.validity)) s = RDF_MEMORY_ERROR;
         else { rdf_array a = tmp_view(&l), b = tmp_view(&r); rdf_out o = tmp_out(res); s = binary_chunk(op, &a, &b, &o); }
-    } else if (op >= RDF_OP_ABS && op <= RDF_OP_TANH) {
+    } else if ((op >= RDF_OP_ABS && op <= RDF_OP_TANH) || (op >= RDF_OP_COT && op <= RDF_OP_CSC)) {
         if (!tmp_alloc(res, l.dtype, l.len, l.validity != NULL)) s = RDF_MEMORY_ERROR;
         else { rdf_array a = tmp_view(&l); rdf_out o = tmp_out(res); s = unary_chunk(op, &a, &o); }
     } else if (op >= RDF_OP_HOUR_S && op <= RDF_OP_HOUR_DAY) {                /* result keeps the operand's storage type */

@@ -25,6 +25,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
  OP_SIN, OP_SINH, OP_SQRT, OP_TAN, OP_TANH, OP_CAST, OP_GT, OP_GE, OP_EQ, OP_NE, OP_LT, OP_LE, OP_NOT,
  OP_AND, OP_OR) = range(1, 39)
 OP_HOUR_S, OP_HOUR_MS, OP_HOUR_US, OP_HOUR_NS, OP_HOUR_DAY = range(39, 44)
+OP_COT, OP_SEC, OP_CSC = range(44, 47)
 TIME_SECOND, TIME_MILLISECOND, TIME_MICROSECOND, TIME_NANOSECOND, TIME_DAY = range(5)
 
 OP_NAMES = {
@@ -35,9 +36,10 @@ OP_NAMES = {
     "round": OP_ROUND, "sin": OP_SIN, "sinh": OP_SINH, "sqrt": OP_SQRT, "tan": OP_TAN, "tanh": OP_TANH,
     "cast": OP_CAST, "gt": OP_GT, "ge": OP_GE, "eq": OP_EQ, "ne": OP_NE, "lt": OP_LT, "le": OP_LE,
     "not": OP_NOT, "and": OP_AND, "or": OP_OR,
+    "cot": OP_COT, "sec": OP_SEC, "csc": OP_CSC,
     "hour_s": OP_HOUR_S, "hour_ms": OP_HOUR_MS, "hour_us": OP_HOUR_US, "hour_ns": OP_HOUR_NS, "hour_day": OP_HOUR_DAY,
 }
-UNARY_OPS = [n for n, v in OP_NAMES.items() if OP_ABS <= v <= OP_TANH]
+UNARY_OPS = [n for n, v in OP_NAMES.items() if OP_ABS <= v <= OP_TANH or OP_COT <= v <= OP_CSC]
 
 NODE_COLUMN, NODE_SCALAR, NODE_OP = 0, 1, 2
 SINK_STORE, SINK_AGG = 0, 1

@@ -390,7 +390,7 @@ rdf_status check_out_mem(const rdf_out* outs, int64_t n, int32_t mem) {
 
 bool op_is_arith(int op) { return op >= RDF_OP_ADD && op <= RDF_OP_DIV; }
 bool op_is_fbinary(int op) { return op >= RDF_OP_ATAN2 && op <= RDF_OP_LOG; }
-bool op_is_unary_math(int op) { return op >= RDF_OP_ABS && op <= RDF_OP_TANH; }
+bool op_is_unary_math(int op) { return (op >= RDF_OP_ABS && op <= RDF_OP_TANH) || (op >= RDF_OP_COT && op <= RDF_OP_CSC); }
 bool op_is_cmp(int op) { return op >= RDF_OP_GT && op <= RDF_OP_LE; }
 bool op_is_hour(int op) { return op >= RDF_OP_HOUR_S && op <= RDF_OP_HOUR_DAY; }
 bool op_is_binary(int op) { return op_is_arith(op) || op_is_fbinary(op) || op_is_cmp(op) || op == RDF_OP_AND || op == RDF_OP_OR; }
@@ -714,28 +714,43 @@ bool build_spec_plan(Compiler& cc, int filter_root, int nvalues, const int* valu
     return spec_available(s.c_str());
 }
 
-// Second-level lookup: kernels specialised on the tree SHAPE with runtime operators (rdf_expr.hip.h *RT nodes, f64 only).
-// Every leaf occurrence gets its own canonical column / literal slot, operator slots are numbered in pre-order (predicate
-// first); a (scalar, column) or (leaf, subtree) operand pair is put in (column, scalar) / (subtree, leaf) order with
-// the swap bit of the operator set.
+// Second-level lookup: kernels specialised on the tree SHAPE with runtime operators (rdf_expr.hip.h *RT nodes; the 8- and
+// 4-byte numeric types).  Every leaf occurrence gets its own canonical column / literal slot, operator slots are numbered
+// in pre-order (predicate first).  Canonical operand order, reached by setting the operator's swap bit: the deeper
+// subtree first, a subtree before a leaf, a column before a literal (rdf_spec_kernel.hip.h lists the compiled shapes:
+// up to three levels of arithmetic, sin / cos / tan over up to two levels, behind no predicate, x CMP c, or
+// x CMP c AND|OR y CMP d).
 struct ShapeSigBuilder {
     Compiler& cc;
     SpecPlan& sp;
     int* rt;
     int nslots = 0;
+    int width = 0;      // element width of the program's columns (one width per program)
+    int pred_dt = -1;
     ShapeSigBuilder(Compiler& c, SpecPlan& s, int* r) : cc(c), sp(s), rt(r) {}
     bool is_scalar(int idx) const { return cc.nodes[idx].kind == RDF_NODE_SCALAR; }
     bool is_column(int idx) const { return cc.nodes[idx].kind == RDF_NODE_COLUMN; }
+    static bool shape_dtype(int dt) { return dt == RDF_F64 || dt == RDF_I64 || dt == RDF_U64 || dt == RDF_F32 || dt == RDF_I32 || dt == RDF_U32; }
     int strip(int idx) {   // skip no-op casts
         while (cc.nodes[idx].kind == RDF_NODE_OP && cc.nodes[idx].op == RDF_OP_CAST && cc.infer(cc.nodes[idx].lhs) == cc.nodes[idx].dtype) idx = cc.nodes[idx].lhs;
         return idx;
     }
-    // a leaf in domain `dom` (RDF_F64 or RDF_I64): a column of exactly that dtype, or a literal converted to it
+    int depth(int idx) {   // levels of operators under (and including) idx; anything the shapes do not hold counts as too deep
+        idx = strip(idx);
+        const rdf_expr_node& nd = cc.nodes[idx];
+        if (nd.kind != RDF_NODE_OP) return 0;
+        if (nd.op == RDF_OP_SIN || nd.op == RDF_OP_COS || nd.op == RDF_OP_TAN) return 1 + depth(nd.lhs);
+        if (nd.op >= RDF_OP_ADD && nd.op <= RDF_OP_DIV) return 1 + std::max(depth(nd.lhs), depth(nd.rhs));
+        return 100;
+    }
+    // a leaf in domain `dom`: a column of exactly that dtype, or a literal converted to it
     std::string leaf(int idx, int dom) {
         const rdf_expr_node& nd = cc.nodes[idx];
-        const char tag = dom == RDF_F64 ? 'd' : 'l';
+        const char tag = spec_tag(dom);
         if (nd.kind == RDF_NODE_COLUMN) {
             if (cc.col_dtype[nd.column] != dom || sp.ncols >= 4) { sp.ok = false; return "?"; }
+            if (width && width != dtype_size(dom)) { sp.ok = false; return "?"; }
+            width = dtype_size(dom);
             sp.col_map[sp.ncols] = nd.column;
             return std::string("c") + char('0' + sp.ncols++) + tag;
         }
@@ -751,7 +766,7 @@ struct ShapeSigBuilder {
         if (nslots >= 8) { sp.ok = false; return "?"; }
         const int op = nd.op;
         if (op == RDF_OP_SIN || op == RDF_OP_COS || op == RDF_OP_TAN) {
-            if (cc.infer(nd.lhs) != RDF_F64 || dom != RDF_F64) { sp.ok = false; return "?"; }
+            if (!(dom == RDF_F64 || dom == RDF_F32) || cc.infer(nd.lhs) != dom) { sp.ok = false; return "?"; }
             const int slot = nslots++;
             rt[slot] = op;
             return "[T" + std::to_string(slot) + " " + node(nd.lhs, dom) + "]";
@@ -761,20 +776,19 @@ struct ShapeSigBuilder {
         int l = strip(nd.lhs), r = strip(nd.rhs);
         if (arith && (cc.infer(idx) != dom || cc.infer(l) != dom || cc.infer(r) != dom)) { sp.ok = false; return "?"; }
         if (cmp && !((is_column(l) && is_scalar(r)) || (is_scalar(l) && is_column(r)))) { sp.ok = false; return "?"; }
-        const bool lleaf = cc.nodes[l].kind != RDF_NODE_OP, rleaf = cc.nodes[r].kind != RDF_NODE_OP;
         bool swap = false;
         if (!logic) {
+            const int dl = depth(l), dr = depth(r);
             if (is_scalar(l) && is_scalar(r)) { sp.ok = false; return "?"; }
-            if (!lleaf && !rleaf) { sp.ok = false; return "?"; }
-            if ((lleaf && !rleaf) || (is_scalar(l) && is_column(r))) swap = true;
+            if (dl < dr || (dl == 0 && dr == 0 && is_scalar(l) && is_column(r))) swap = true;
         }
         const int slot = nslots++;
         rt[slot] = op | (swap ? 0x100 : 0);
         if (swap) std::swap(l, r);
         std::string a, b;
-        if (cmp) {   // the column keeps its own dtype (f64 or i64), the literal is compared in f64 (src/expression.rs:844-845)
+        if (cmp) {   // the column keeps its own dtype, the literal is compared in f64 (src/expression.rs:844-845)
             const int cdt = cc.col_dtype[cc.nodes[l].column];
-            if (cdt != RDF_F64 && cdt != RDF_I64) { sp.ok = false; return "?"; }
+            if (!shape_dtype(cdt)) { sp.ok = false; return "?"; }
             if (pred_dt >= 0 && pred_dt != cdt) { sp.ok = false; return "?"; }
             pred_dt = cdt;
             a = leaf(l, cdt);
@@ -782,19 +796,18 @@ struct ShapeSigBuilder {
         } else { a = node(l, dom); b = node(r, dom); }
         return std::string("(") + (arith ? 'A' : cmp ? 'C' : 'G') + std::to_string(slot) + " " + a + " " + b + ")";
     }
-    int pred_dt = -1;
 };
 bool build_shape_plan(Compiler& cc, int filter_root, int nvalues, const int* value_roots, int sink, SpecPlan& sp, int* rt) {
     if (nvalues != 1) return false;
     ShapeSigBuilder b(cc, sp, rt);
     const int vdt = cc.infer(value_roots[0]);
     const int dom = vdt == RDF_BOOL ? RDF_F64 : vdt;   // a predicate as the value (mask output): its columns pick their own dtype
-    if (dom != RDF_F64 && dom != RDF_I64) return false;
+    if (!ShapeSigBuilder::shape_dtype(dom)) return false;
     std::string s = "P:";
     s += filter_root >= 0 ? b.node(filter_root, RDF_F64) : std::string("-");
     s += ";V:" + b.node(value_roots[0], dom) + ";-;S:" + std::to_string(sink == RDF_SINK_AGG ? SINK_AGG : SINK_STORE);
-    if (!sp.ok || b.nslots == 0) return false;
-    sp.width = 8;
+    if (!sp.ok || b.nslots == 0 || b.width == 0) return false;
+    sp.width = b.width;
     sp.sig = s;
     return spec_available(s.c_str());
 }

@@ -242,6 +242,11 @@ __device__ __forceinline__ double rdf_tan(double x) {
     return (q & 1) ? -c / s : s / c;
 }
 
+// f32 columns compute in f32 (num::Float on f32, src/functions/scalar.rs:106-452): the device libm's single-precision routines
+__device__ __forceinline__ float rdf_sin(float x) { return sinf(x); }
+__device__ __forceinline__ float rdf_cos(float x) { return cosf(x); }
+__device__ __forceinline__ float rdf_tan(float x) { return tanf(x); }
+
 // largest c in [0, n) with start[c] <= t (start is a non-decreasing prefix table; scalar loads)
 __device__ __forceinline__ int64_t find_chunk(const int64_t* start, int64_t n, int64_t t) {
     int64_t lo = 0, hi = n - 1;

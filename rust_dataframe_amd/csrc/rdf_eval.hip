@@ -156,6 +156,9 @@ __device__ __forceinline__ double unary_f64(int op, double x) {
             case RDF_OP_SINH: return sinh(x);
             case RDF_OP_TAN: return rdf_tan(x);
             case RDF_OP_TANH: return tanh(x);
+            case RDF_OP_COT: return 1.0 / rdf_tan(x);
+            case RDF_OP_SEC: return 1.0 / rdf_cos(x);
+            case RDF_OP_CSC: return 1.0 / rdf_sin(x);
             default: break;
         }
     }
@@ -189,6 +192,9 @@ __device__ __forceinline__ float unary_f32(int op, float x) {
             case RDF_OP_SINH: return sinhf(x);
             case RDF_OP_TAN: return tanf(x);
             case RDF_OP_TANH: return tanhf(x);
+            case RDF_OP_COT: return 1.0f / tanf(x);
+            case RDF_OP_SEC: return 1.0f / cosf(x);
+            case RDF_OP_CSC: return 1.0f / sinf(x);
             default: break;
         }
     }
@@ -290,7 +296,7 @@ template <int64_t U> __device__ __forceinline__ uint64_t hour_of(int64_t v) {
 template <int FEAT>
 __device__ __forceinline__ void apply_unary(int op, int dt, uint64_t (&acc)[kVPT]) {
     if (op == RDF_OP_NOT) { RDF_ROWS acc[j] = acc[j] ^ 1ull; return; }
-    if (FEAT >= 1 && op >= RDF_OP_HOUR_S) {
+    if (FEAT >= 1 && op >= RDF_OP_HOUR_S && op <= RDF_OP_HOUR_DAY) {
         switch (op) {
             case RDF_OP_HOUR_S: RDF_ROWS acc[j] = hour_of<1>((int64_t)acc[j]); break;
             case RDF_OP_HOUR_MS: RDF_ROWS acc[j] = hour_of<1000>((int64_t)acc[j]); break;

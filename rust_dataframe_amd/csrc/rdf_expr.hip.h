@@ -177,6 +177,9 @@ struct Un {
         else if constexpr (OP == RDF_OP_SINH) return sinh(x);
         else if constexpr (OP == RDF_OP_SQRT) return sqrt(x);
         else if constexpr (OP == RDF_OP_TAN) return rdf_tan(x);
+        else if constexpr (OP == RDF_OP_COT) return (T)1 / rdf_tan(x);
+        else if constexpr (OP == RDF_OP_SEC) return (T)1 / rdf_cos(x);
+        else if constexpr (OP == RDF_OP_CSC) return (T)1 / rdf_sin(x);
         else return tanh(x);
     }
     static std::string sig() { return "[" + std::to_string(OP) + " " + A::sig() + "]"; }
@@ -247,8 +250,8 @@ struct Cast {
 // arguments (c.rt[SLOT] = rdf_op | swap << 8), so a fused Calculate chain that is not in the exact catalog still runs
 // as straight-line code: the switch below is a handful of scalar compares per row, not an interpreter.
 template <int SLOT, class A, class B>
-struct ArithRT {   // add / subtract / multiply / divide on f64 or (wrapping) i64
-    static_assert(A::dt == B::dt && (A::dt == RDF_F64 || A::dt == RDF_I64), "runtime-op arithmetic is instantiated for f64 and i64");
+struct ArithRT {   // add / subtract / multiply / divide on f64 / f32 or (wrapping) i64 / u64 / i32 / u32
+    static_assert(A::dt == B::dt && (CType<A::dt>::width == 8 || CType<A::dt>::width == 4), "runtime-op arithmetic is instantiated for the 8- and 4-byte numeric types");
     static constexpr int dt = A::dt;
     static constexpr int ncols = A::ncols > B::ncols ? A::ncols : B::ncols;
     static constexpr int width = merge_width(A::width, B::width);
@@ -260,36 +263,38 @@ struct ArithRT {   // add / subtract / multiply / divide on f64 or (wrapping) i6
         const int op = c.rt[SLOT] & 0xFF;
         const bool sw = (c.rt[SLOT] >> 8) & 1;
         const T x = sw ? y0 : x0, y = sw ? x0 : y0;
-        if constexpr (dt == RDF_F64) {
+        if constexpr (dt_float(dt)) {
             if (op == RDF_OP_ADD) return x + y;
             if (op == RDF_OP_SUB) return x - y;
             if (op == RDF_OP_MUL) return x * y;
-            const bool z = y == 0.0;
+            const bool z = y == (T)0;
             if (z && ((vmask(c) & c.inr) >> r & 1)) c.err |= 1u;
-            return z ? 0.0 : x / y;
+            return z ? (T)0 : x / y;
         } else {
-            if (op == RDF_OP_ADD) return (int64_t)((uint64_t)x + (uint64_t)y);
-            if (op == RDF_OP_SUB) return (int64_t)((uint64_t)x - (uint64_t)y);
-            if (op == RDF_OP_MUL) return (int64_t)((uint64_t)x * (uint64_t)y);
+            using U = typename std::make_unsigned<T>::type;
+            if (op == RDF_OP_ADD) return (T)((U)x + (U)y);
+            if (op == RDF_OP_SUB) return (T)((U)x - (U)y);
+            if (op == RDF_OP_MUL) return (T)((U)x * (U)y);
             const bool z = y == 0;
             if (z && ((vmask(c) & c.inr) >> r & 1)) c.err |= 1u;
-            if (z) return 0;
-            return y == -1 ? (int64_t)((uint64_t)0 - (uint64_t)x) : x / y;   // MIN / -1 wraps
+            if (z) return (T)0;
+            if constexpr (dt_signed(dt)) return y == -1 ? (T)((U)0 - (U)x) : x / y;   // MIN / -1 wraps
+            else return x / y;
         }
     }
     static std::string sig() { return "(A" + std::to_string(SLOT) + " " + A::sig() + " " + B::sig() + ")"; }
 };
 template <int SLOT, class A>
 struct TrigRT {    // sin / cos / tan: the three the reference's Evaluate::calculate dispatches (src/evaluation.rs:250-293)
-    static_assert(A::dt == RDF_F64, "runtime-op trig is instantiated for f64");
-    static constexpr int dt = RDF_F64;
+    static_assert(dt_float(A::dt), "runtime-op trig is instantiated for f64 and f32");
+    static constexpr int dt = A::dt;
     static constexpr int ncols = A::ncols;
     static constexpr int width = A::width;
     template <int k> static constexpr int colw() { return A::template colw<k>(); }
-    using T = double;
+    using T = typename CType<dt>::T;
     template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return A::vmask(c); }
-    template <int r, class C> static __device__ __forceinline__ double eval(C& c) {
-        const double x = A::template eval<r>(c);
+    template <int r, class C> static __device__ __forceinline__ T eval(C& c) {
+        const T x = A::template eval<r>(c);
         const int op = c.rt[SLOT] & 0xFF;
         if (op == RDF_OP_SIN) return rdf_sin(x);
         if (op == RDF_OP_COS) return rdf_cos(x);

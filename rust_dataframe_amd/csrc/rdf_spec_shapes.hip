@@ -1,0 +1,41 @@
+// rdf_spec_shapes.hip — shape-level specialised kernels beyond the basic f64 / i64 families of rdf_spec.hip, compiled in
+// slices (-DRDF_SHAPE_TU=1..6) so the slices build in parallel:
+//   1-3: three-level f64 / i64 trees (((l.l).l).l, (l.l).(l.l), ((l.l).l).(l.l)), plain and behind the two predicate forms;
+//   4:   the basic shapes for u64 and the 4-byte types f32 / i32 / u32 (Evaluate::calculate's type matrix,
+//        src/evaluation.rs:107-293);
+//   5-6: three-level trees of the 4-byte types and u64.
+#include "rdf_spec_kernel.hip.h"
+
+#ifndef RDF_SHAPE_TU
+#error "compile with -DRDF_SHAPE_TU=1..6"
+#endif
+
+namespace rdfk {
+
+#define RDF_CAT2(a, b) a##b
+#define RDF_CAT(a, b) RDF_CAT2(a, b)
+void RDF_CAT(spec_register_shapes, RDF_SHAPE_TU)() {
+#if RDF_SHAPE_TU == 1
+    reg_shape_family_deep<RDF_F64, RDF_F64>();
+#elif RDF_SHAPE_TU == 2
+    reg_shape_family_deep<RDF_I64, RDF_I64>();
+#elif RDF_SHAPE_TU == 3
+    reg_shape_family_deep<RDF_F64, RDF_I64>();   // predicate on an i64 key, f64 measures
+    reg_shape_family_deep<RDF_I64, RDF_F64>();
+#elif RDF_SHAPE_TU == 4
+    reg_shape_family_basic<RDF_U64, RDF_U64>();
+    reg_shape_family_basic<RDF_F32, RDF_F32>();
+    reg_shape_family_basic<RDF_I32, RDF_I32>();
+    reg_shape_family_basic<RDF_U32, RDF_U32>();
+    reg_shape_family_basic<RDF_F32, RDF_I32>();
+    reg_shape_family_basic<RDF_I32, RDF_F32>();
+#elif RDF_SHAPE_TU == 5
+    reg_shape_family_deep<RDF_F32, RDF_F32>();
+    reg_shape_family_deep<RDF_I32, RDF_I32>();
+#else
+    reg_shape_family_deep<RDF_U32, RDF_U32>();
+    reg_shape_family_deep<RDF_U64, RDF_U64>();
+#endif
+}
+
+}  // namespace rdfk

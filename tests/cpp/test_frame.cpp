@@ -98,6 +98,30 @@ TEST(test_lazy_pipeline) {
     CHECK_NEAR(df.column_by_name("sin_lat").data().chunk(0)->value<double>(0), 0.8933816410476535, 1e-12);
     CHECK_NEAR(df.column_by_name("sin_lng").data().chunk(0)->value<double>(0), 0.1929142713855381, 1e-12);
 }
+// ScalarFunction::{Cotangent, Secant, Cosecant} (src/expression.rs:670-672) through the lazy plan: the reference's builder
+// panics on them (:487-489); here they are planned like the sine and run as RDF_OP_COT / SEC / CSC in the fused batch loop
+TEST(test_reciprocal_trig_functions) {
+    LazyFrame frame = LazyFrame::read(DataFrame::from_csv(g_csv));
+    frame = frame.with_column("cot_lat", P::Function::Scalar_(P::ScalarFunction::Cotangent), {"lat"});
+    frame = frame.with_column("sec_lat", P::Function::Scalar_(P::ScalarFunction::Secant), {"lat"});
+    frame = frame.with_column("csc_lng", P::Function::Scalar_(P::ScalarFunction::Cosecant), {"lng"});
+    CHECK_EQ(frame.output().columns.size(), 6u);
+    DataFrame df = frame.evaluate();
+    auto lat = host<double>(df.column_by_name("lat").data().chunk(0)), lng = host<double>(df.column_by_name("lng").data().chunk(0));
+    auto cot = host<double>(df.column_by_name("cot_lat").data().chunk(0)), sec = host<double>(df.column_by_name("sec_lat").data().chunk(0));
+    auto csc = host<double>(df.column_by_name("csc_lng").data().chunk(0));
+    for (size_t i = 0; i < lat.size(); ++i) {
+        CHECK_NEAR(cot[i], 1.0 / std::tan(lat[i]), 1e-12 * std::fabs(cot[i]));
+        CHECK_NEAR(sec[i], 1.0 / std::cos(lat[i]), 1e-12 * std::fabs(sec[i]));
+        CHECK_NEAR(csc[i], 1.0 / std::sin(lng[i]), 1e-12 * std::fabs(csc[i]));
+    }
+    auto a = Array::from_vec<double>({0.5, -1.25, 0.0});
+    auto c = host<double>(ScalarFunctions::cot({a})[0]);
+    CHECK_NEAR(c[0], 1.0 / std::tan(0.5), 1e-15);
+    CHECK(std::isinf(c[2]) && c[2] > 0);
+    CHECK_NEAR(host<double>(ScalarFunctions::sec({a})[0])[1], 1.0 / std::cos(-1.25), 1e-14);
+    CHECK_NEAR(host<double>(ScalarFunctions::csc({a})[0])[1], 1.0 / std::sin(-1.25), 1e-14);
+}
 // test_projection (src/lazyframe.rs:472-511): rename, two sine columns, select three, drop one — evaluated here
 TEST(test_projection) {
     LazyFrame frame = LazyFrame::read(DataFrame::from_csv(g_csv));

@@ -65,7 +65,12 @@ TEST(calculation_dispatch) {
     CHECK_EQ(t.size(), 1u);
     CHECK(t[0].kind == Transformation::Calculate);
     CHECK_THROWS(calculate(ds, {"nope"}, Function::Scalar_(ScalarFunction::Add), std::nullopt, std::nullopt));
-    CHECK_THROWS(calculate(ds, {"lat"}, Function::Scalar_(ScalarFunction::Cosecant), std::nullopt, std::nullopt));
+    // Cosecant / Secant / Cotangent panic in the reference's builder (:487-489); here they plan like the sine
+    auto csc = calculate(ds, {"lat"}, Function::Scalar_(ScalarFunction::Cosecant), std::nullopt, std::nullopt);
+    CHECK_EQ(csc.size(), 1u);
+    CHECK_EQ(csc[0].calc.name, std::string("csc"));
+    CHECK(csc[0].calc.output.data_type == DataType::Float64);
+    CHECK_THROWS(calculate(ds, {"lat", "lng"}, Function::Scalar_(ScalarFunction::Secant), std::nullopt, std::nullopt));   // one input
     // Dataset::append_column replaces in place (src/expression.rs:95-112)
     auto d2 = ds.append_column(Column{"lat", DataType::Int64});
     CHECK_EQ(d2.columns.size(), 2u);

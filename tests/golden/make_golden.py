@@ -68,13 +68,14 @@ def main():
         assert np.array_equal(ki.to_numpy()[ki.valid_mask()], (k * k)[valid_b])
     # unary (libm)
     for op, npf in [("sin", np.sin), ("cos", np.cos), ("tan", np.tan), ("abs", np.abs), ("sqrt", np.sqrt), ("exp", np.exp),
-                    ("floor", np.floor), ("tanh", np.tanh)]:
+                    ("floor", np.floor), ("tanh", np.tanh), ("cot", lambda x: 1.0 / np.tan(x)), ("sec", lambda x: 1.0 / np.cos(x)),
+                    ("csc", lambda x: 1.0 / np.sin(x))]:
         src = A_ if op != "sqrt" else A.HostArray.from_numpy(np.abs(a), valid_a)
         r = o.unary(op, [src])[0]
         with np.errstate(all="ignore"):
             np.testing.assert_allclose(r.to_numpy()[valid_a], npf(src.to_numpy())[valid_a], rtol=1e-15, atol=0)
         put(op, r)
-    for op in ["sin", "cos", "tan"]:
+    for op in ["sin", "cos", "tan", "cot", "sec", "csc"]:
         put(op + "_special", o.unary(op, [SP_])[0])
     # cast i64 -> f64 and f64 -> i32 (saturating `as`)
     put("cast_k_f64", o.cast([K_], A.F64)[0])

@@ -206,10 +206,10 @@ def golden_cases(api, g):
     for op in ["add", "subtract", "multiply", "divide"]:
         yield op, api.binary(op, [a_], [b_])[0], (g[op + "_values"], g[op + "_valid"]), True
     yield "mul_i64_wrap", api.binary("multiply", [k_], [k_])[0], (g["mul_i64_wrap_values"], g["mul_i64_wrap_valid"]), True
-    for op in ["sin", "cos", "tan", "abs", "sqrt", "exp", "floor", "tanh"]:
+    for op in ["sin", "cos", "tan", "abs", "sqrt", "exp", "floor", "tanh", "cot", "sec", "csc"]:
         src = a_ if op != "sqrt" else H(np.abs(g["a"]), g["valid_a"])
         yield op, api.unary(op, [src])[0], (g[op + "_values"], g[op + "_valid"]), op in ("abs", "sqrt", "floor")
-    for op in ["sin", "cos", "tan"]:
+    for op in ["sin", "cos", "tan", "cot", "sec", "csc"]:
         yield op + "_special", api.unary(op, [sp_])[0], (g[op + "_special_values"], g[op + "_special_valid"]), False
     yield "cast_k_f64", api.cast([k_], A.F64)[0], (g["cast_k_f64_values"], g["cast_k_f64_valid"]), True
     yield "cast_f64_i32", api.cast([H(g["cast_src_f64"])], A.I32)[0], (g["cast_f64_i32_values"], g["cast_f64_i32_valid"]), True

@@ -65,7 +65,7 @@ def test_unary_large_arguments_and_specials(gpu, ora):
     """sin/cos/tan far outside [-pi, pi] (Payne-Hanek territory), NaN/inf/±0 inputs."""
     v = np.array([1e6, -1e9, 1e15, 1e22, 3.0e300, -7.5e-310, 0.0, -0.0, np.nan, np.inf, -np.inf, 0.5, 1e-8, 710.0, -745.0])
     a = [A.HostArray.from_numpy(v)]
-    for op in ["sin", "cos", "tan", "exp", "tanh", "atan", "cbrt", "floor", "round", "abs"]:
+    for op in ["sin", "cos", "tan", "cot", "sec", "csc", "exp", "tanh", "atan", "cbrt", "floor", "round", "abs"]:
         g, e = gpu.unary(op, a)[0], ora.unary(op, a)[0]
         with np.errstate(all="ignore"):
             np.testing.assert_allclose(g.to_numpy(), e.to_numpy(), rtol=1e-6, atol=0, equal_nan=True, err_msg=op)
@@ -481,6 +481,15 @@ def test_specialised_kernels_are_the_ones_that_run(gpu, request):
     fma = e.op("add", e.op("multiply", c0, c1), e.col(2))
     cases.append(("C3", lambda: gpu.pipeline(e, [x, y, z, k], [fma, e.col(3)])))
     cases.append(("C1", lambda: gpu.pipeline(e, [x], [e.op("sin", e.op("add", c0, e.scalar(1.0)))])))
+    # fused Calculate chains outside the exact catalog: shape-level kernels for every 8- / 4-byte type, up to three levels
+    for dt in (A.F64, A.I64, A.U64, A.F32, A.I32, A.U32):
+        cols = [make_chunks(rng, dt, [n], 0.0, 0, nonzero=True) for _ in range(3)]
+        ks = e.scalar(2.0 if dt in (A.F64, A.F32) else 2, dt)
+        two = e.op("subtract", e.op("multiply", c0, ks), c1)
+        three = e.op("multiply", e.op("multiply", c0, e.op("subtract", ks, c1)), e.op("add", ks, e.col(2)))
+        cases.append((f"two-level {dt}", lambda cols=cols, two=two: gpu.pipeline(e, cols, [two])))
+        cases.append((f"three-level {dt}", lambda cols=cols, three=three: gpu.pipeline(e, cols, [three])))
+        cases.append((f"three-level behind a filter {dt}", lambda cols=cols, three=three: gpu.pipeline(e, cols, [three], e.op("gt", c0, e.scalar(0.0)))))
     for name, call in cases:
         call()
         kern = lib.last_kernel()
@@ -697,6 +706,80 @@ def test_shape_specialised_kernels_i64_and_mixed_predicates(gpu, ora, request):
     got = gpu.pipeline(e, [mn, m1, m1], [e.op("add", e.op("divide", k, l), e.scalar(0, A.I64))], -1)[0]
     exp = ora.pipeline(e, [mn, m1, m1], [e.op("add", e.op("divide", k, l), e.scalar(0, A.I64))], -1)[0]
     assert (got.sum, got.min, got.max) == (exp.sum, exp.min, exp.max)
+
+
+@pytest.mark.parametrize("dtype", [A.F64, A.I64, A.U64, A.F32, A.I32, A.U32])
+def test_shape_kernels_three_levels_and_every_wide_type(gpu, ora, request, dtype):
+    """Evaluate::calculate's type matrix (src/evaluation.rs:107-293) as fused chains: one- to three-level arithmetic trees
+    (left-deep, balanced, a two-level beside a one-level subtree, in either operand order), sin / cos / tan on top for
+    the float types, plain and behind `x CMP c`, both sinks, on every 8- and 4-byte numeric type.  In 'spec' mode they
+    must run on a shape-specialised kernel; the results equal the oracle's unfused evaluation (integers bit-exact)."""
+    from rust_dataframe_amd import lib
+    spec_mode = request.node.callspec.params["gpu"] == "spec"
+    rng = np.random.default_rng(500 + dtype)
+    lens = [4096, 1500]
+    is_float = dtype in (A.F64, A.F32)
+    cols = [make_chunks(rng, dtype, lens, nf, 0, kind="unit" if is_float else "plain", nonzero=True) for nf in (0.0, 0.1, 0.0, 0.05)]
+    e = A.Expr()
+    a, b, c, d = (e.col(i) for i in range(4))
+    k1, k2 = (e.scalar(1.5, dtype), e.scalar(-0.25, dtype)) if is_float else (e.scalar(3, dtype), e.scalar(7, dtype))
+    ops3 = ("add", "subtract", "multiply")
+    values = {}
+    for i, o1 in enumerate(("add", "subtract", "multiply", "divide")):
+        o2, o3 = ops3[i % 3], ops3[(i + 1) % 3]
+        values[f"cc_{o1}"] = e.op(o1, a, b)
+        values[f"kc_{o1}"] = e.op(o1, k1, a)
+        values[f"ccc_{o1}"] = e.op(o1, e.op(o2, a, b), c)
+        values[f"ckk_{o1}"] = e.op(o1, e.op(o2, k1, a), k2)
+        # three levels, left-deep
+        values[f"cccc_{o1}"] = e.op(o1, e.op(o2, e.op(o3, a, b), c), d)
+        values[f"cckc_{o1}"] = e.op(o1, e.op(o2, e.op(o3, a, b), k1), c)
+        values[f"ckck_{o1}"] = e.op(o1, e.op(o2, e.op(o3, a, k1), b), k2)
+        values[f"ckkc_{o1}"] = e.op(o1, e.op(o2, e.op(o3, k2, a), k1), b)
+        values[f"c_ccc_{o1}"] = e.op(o2, d, e.op(o3, e.op(o1, a, b), c))          # right-nested twice: swap bits
+        # balanced and (two-level)(one-level); a division keeps a leaf divisor
+        values[f"cc_cc_{o2}_{o1}"] = e.op(o2, e.op(o1, a, b), e.op(o3, c, d))
+        values[f"ck_cc_{o2}_{o1}"] = e.op(o2, e.op(o1, a, k1), e.op(o3, b, c))
+        values[f"ck_ck_{o2}_{o1}"] = e.op(o2, e.op(o1, k1, a), e.op(o3, b, k2))
+        values[f"ccc_ck_{o2}_{o1}"] = e.op(o2, e.op(o3, e.op(o1, a, b), c), e.op(o3, d, k1))
+        values[f"ck_ckc_{o2}_{o1}"] = e.op(o2, e.op(o3, k2, c), e.op(o3, e.op(o1, a, k1), b))   # the deeper subtree second: swap
+    values["q1_charge"] = e.op("multiply", e.op("multiply", a, e.op("subtract", k1, b)), e.op("add", k1, c))   # price * (1 - disc) * (1 + tax)
+    if is_float:
+        for t in ("sin", "cos", "tan"):
+            values[f"T_{t}_c"] = e.op(t, a)
+            values[f"T_{t}_ck"] = e.op(t, e.op("multiply", a, k1))
+            values[f"T_{t}_cck"] = e.op(t, e.op("add", e.op("multiply", a, b), k2))
+    preds = {"none": -1, "cmp": e.op("gt", c, e.scalar(-0.3 if is_float else -200.0))}
+    rtol = 1e-6 if dtype == A.F64 else 1e-4
+    for vn, v in values.items():
+        for pn, p in preds.items():
+            exp = ora.pipeline(e, cols, [v], p)[0]
+            got = gpu.pipeline(e, cols, [v], p)[0]
+            k = lib.last_kernel()
+            if spec_mode and not (pn == "cmp" and vn.startswith(("cccc", "c_ccc", "cc_cc", "ccc_ck"))):   # 4 value columns + the predicate's do not fit
+                assert k.startswith("spec_kernel<"), f"{vn}/{pn} ran on {k}"
+            if not spec_mode:
+                assert k.startswith("eval_kernel<"), f"{vn}/{pn} ran on {k}"
+            assert got.count == exp.count, f"{vn}/{pn}"
+            if is_float:
+                assert abs(got.sum - exp.sum) <= rtol * max(abs(exp.sum), 1.0), f"{vn}/{pn}: {got.sum} vs {exp.sum}"
+                if exp.count:
+                    assert np.isclose(got.min, exp.min, rtol=rtol, atol=0) and np.isclose(got.max, exp.max, rtol=rtol, atol=0), f"{vn}/{pn}"
+            else:
+                assert (got.sum, got.min, got.max) == (exp.sum, exp.min, exp.max), f"{vn}/{pn}"
+        outs_e = [[A.HostArray.empty_out(dtype, n, True) for n in lens]]
+        outs_g = [[A.HostArray.empty_out(dtype, n, True) for n in lens]]
+        ora.pipeline(e, cols, [v], -1, A.SINK_STORE, outs_e)
+        gpu.pipeline(e, cols, [v], -1, A.SINK_STORE, outs_g)
+        if spec_mode:
+            assert lib.last_kernel().startswith("spec_kernel<"), f"{vn}/store ran on {lib.last_kernel()}"
+        for ge, ee in zip(outs_g[0], outs_e[0]):
+            assert_arrays_match(ge, ee, exact=not vn.startswith("T_"), what=f"{vn} dtype={dtype}")
+    # a zero divisor at a valid slot is an error on these kernels too
+    z = [A.HostArray.from_numpy(np.array([4, 0, 9]).astype(A.NP_OF[dtype]))]
+    with pytest.raises(A.RdfError) as ei:
+        gpu.pipeline(e, [z, z, z, z], [e.op("add", e.op("multiply", e.op("divide", a, b), c), d)], -1)
+    assert ei.value.status == A.RDF_DIVIDE_BY_ZERO
 
 
 def test_sort_skips_constant_key_bytes(gpu, ora):

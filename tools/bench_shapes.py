@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Shape-level specialised kernels (runtime-operator trees, rdf_spec_kernel.hip.h) on HBM-resident columns: achieved
+algorithmic GB/s for one- to three-level Calculate chains on every 8- and 4-byte numeric type, both sinks, with the
+kernel that ran.  The numbers behind DESIGN.md's "interpreter only for exotic trees" claim (profiles/rNN_shapes.jsonl).
+Usage: python tools/bench_shapes.py [--rows N] [--steps K] [--interp]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import torch  # noqa: E402
+
+from rust_dataframe_amd import _abi as A  # noqa: E402
+from rust_dataframe_amd import lib  # noqa: E402
+from bench_kernels import timed  # noqa: E402
+
+PEAK = 8000.0
+TORCH_OF = {A.F64: torch.float64, A.I64: torch.int64, A.U64: torch.int64, A.F32: torch.float32, A.I32: torch.int32, A.U32: torch.int32}
+NAME = {A.F64: "f64", A.I64: "i64", A.U64: "u64", A.F32: "f32", A.I32: "i32", A.U32: "u32"}
+
+
+def column(dt, n, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    if dt in (A.F64, A.F32):
+        t = torch.empty(n, dtype=TORCH_OF[dt], device="cuda").uniform_(-1.0, 1.0, generator=g)
+    else:
+        t = torch.randint(1, 1000, (n,), dtype=TORCH_OF[dt], device="cuda", generator=g)
+    return A.DeviceArray(t.data_ptr(), None, 0, n, dt, 0, keep=(t,))
+
+
+def out(dt, n):
+    es = 8 if dt in (A.F64, A.I64, A.U64) else 4
+    v = torch.empty((n + 63) // 64 * 64 * es, dtype=torch.uint8, device="cuda")
+    return A.DeviceArray(v.data_ptr(), None, 0, n, dt, 0, keep=(v,))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=250_000_000)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--interp", action="store_true", help="also time the general evaluator on the same programs")
+    ap.add_argument("--dtypes", type=str, default="f64,i64,u64,f32,i32,u32")
+    ap.add_argument("--programs", type=str, default="", help="comma list of program names (default: all)")
+    ap.add_argument("--sinks", type=str, default="agg,store,filter_agg")
+    args = ap.parse_args()
+    n = args.rows
+    lib.set_device(0)
+    api = lib.api()
+    for dt in (A.F64, A.I64, A.U64, A.F32, A.I32, A.U32):
+        if NAME[dt] not in args.dtypes.split(","):
+            continue
+        es = 8 if dt in (A.F64, A.I64, A.U64) else 4
+        is_float = dt in (A.F64, A.F32)
+        cols = [[column(dt, n, 10 * dt + i)] for i in range(3)]
+        o = out(dt, n)
+        e = A.Expr()
+        a, b, c = e.col(0), e.col(1), e.col(2)
+        k = e.scalar(1.0 if is_float else 1, dt)
+        two = e.op("subtract", e.op("multiply", a, k), b)
+        deep = e.op("subtract", e.op("multiply", e.op("add", a, b), c), k)
+        q1 = e.op("multiply", e.op("multiply", a, e.op("subtract", k, b)), e.op("add", k, c))
+        flt = e.op("gt", a, e.scalar(0.0 if is_float else 500.0))
+        progs = [("two_level_2col", two, 2), ("three_level_left_deep_3col", deep, 3), ("three_level_q1_charge_3col", q1, 3)]
+        if is_float:
+            progs.append(("sin_of_two_level_2col", e.op("sin", e.op("add", e.op("multiply", a, b), k)), 2))
+        for spec in ((1, 0) if args.interp else (1,)):
+            lib.set_option("spec", spec)
+            for name, root, nc in progs:
+                if args.programs and name not in args.programs.split(","):
+                    continue
+                cases = [("agg", es * nc * n, lambda root=root, nc=nc: api.pipeline(e, cols[:nc], [root])),
+                         ("store", es * (nc + 1) * n, lambda root=root, nc=nc: api.pipeline(e, cols[:nc], [root], -1, A.SINK_STORE, [[o]])),
+                         ("filter_agg", es * nc * n, lambda root=root, nc=nc: api.pipeline(e, cols[:nc], [root], flt))]
+                for sink, alg, fn in cases:
+                    if sink not in args.sinks.split(","):
+                        continue
+                    wall, kern = timed(fn, args.steps)
+                    gbs = alg / kern / 1e9 if kern > 0 else 0.0
+                    print(json.dumps({"dtype": NAME[dt], "program": name, "sink": sink, "rows": n, "alg_bytes": alg, "kernel_ms": round(kern * 1e3, 4),
+                                      "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 3), "kernel": lib.last_kernel()[:120]}), flush=True)
+        lib.set_option("spec", 1)
+        del cols, o
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
