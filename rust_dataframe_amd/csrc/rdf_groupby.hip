@@ -96,7 +96,9 @@ struct G2Raw {
 };
 
 // All table lookups first (block-uniform, scalar unit), then every data load back to back; nothing consumes a load here.
-template <int NT, int BLOCK>
+// FAST (host-checked): 8-byte integer keys, 8-byte values (or none), no validity bitmap anywhere, 16-byte aligned chunks.
+// A thread then holds rows 2t, 2t + 1 of each tile: ONE 16-byte load per tile and column, no bitmap bytes, no dtype switches.
+template <int NT, int BLOCK, bool FAST = false>
 __device__ __forceinline__ void g2_load(const Gb2Args& a, int64_t st, int tid, G2Raw<NT>& r) {
     static_assert(BLOCK == kEvalTile || BLOCK * 2 == kEvalTile, "a block covers a tile in one or two rows per thread");
     constexpr int RPT = kEvalTile / BLOCK;   // rows per thread per tile
@@ -119,6 +121,25 @@ __device__ __forceinline__ void g2_load(const Gb2Args& a, int64_t st, int tid, G
         }
     }
     r.exists = 0; r.kbit = 0; r.vbit = 0;
+    if constexpr (FAST) {
+        static_assert(RPT == 2, "the fast loader takes two rows per thread and tile");
+#pragma unroll
+        for (int tt = 0; tt < NT / 2; ++tt) {
+            const int64_t row = r0[tt] + 2 * tid;
+            const bool e0 = row < clen[tt], e1 = row + 1 < clen[tt];
+            r.exists |= ((uint32_t)e0 | (uint32_t)e1 << 1) << (2 * tt);
+            u64x2 k = {0, 0}, v = {0, 0};
+            if (e1) k = __builtin_nontemporal_load((GlobalPtr<u64x2>)(as_global<uint64_t>(kc[tt].values) + kc[tt].offset + row));
+            else if (e0) k[0] = __builtin_nontemporal_load(as_global<uint64_t>(kc[tt].values) + kc[tt].offset + row);
+            if (a.value_dtype >= 0) {
+                if (e1) v = __builtin_nontemporal_load((GlobalPtr<u64x2>)(as_global<uint64_t>(vc[tt].values) + vc[tt].offset + row));
+                else if (e0) v[0] = __builtin_nontemporal_load(as_global<uint64_t>(vc[tt].values) + vc[tt].offset + row);
+            }
+            r.key[2 * tt] = k[0]; r.key[2 * tt + 1] = k[1];
+            r.val[2 * tt] = v[0]; r.val[2 * tt + 1] = v[1];
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int tt = j / RPT;
@@ -150,10 +171,29 @@ __device__ __forceinline__ void g2_load(const Gb2Args& a, int64_t st, int tid, G
 template <int NT>
 struct G2Rows { uint64_t hk[NT], val[NT]; uint32_t cnt, live; };   // cnt bit j: the value is not NULL
 
-template <int NT>
+template <int NT, bool FAST = false>
 __device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r, G2Rows<NT>& o) {
     o.cnt = 0; o.live = 0;
     const bool counts_rows = a.value_dtype < 0;
+    if constexpr (FAST) {
+        o.cnt = r.exists;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const uint64_t v = counts_rows ? 0ull : to_table_form(a.op, a.vcls, r.val[j], false);
+            const uint64_t hk = g2_hash(r.key[j]);
+            o.hk[j] = hk;
+            o.val[j] = v;
+            if (!((r.exists >> j) & 1)) continue;
+            if (hk == kFree) {   // the one key whose hash is the free marker
+                a.special[0] = 1;
+                if (!counts_rows) acc_apply(&a.special_sums[0], a.op, a.vcls, v);
+                atomicAdd(&a.special_counts[0], 1ull);
+                continue;
+            }
+            o.live |= 1u << j;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const bool e = (r.exists >> j) & 1;
@@ -268,6 +308,7 @@ __device__ __forceinline__ void g2_global_special(const GroupTable& t, int which
 
 constexpr int kStreamBlock = kGbBlock;       // 512 threads, 2 blocks per CU (80 KB of LDS each)
 constexpr int kStreamRows = 4;               // rows per thread per batch = two tiles per block iteration
+template <bool FAST>
 __global__ __launch_bounds__(kStreamBlock) void gb2_stream_kernel(const Gb2Args a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
     LdsTab t;
@@ -287,13 +328,13 @@ __global__ __launch_bounds__(kStreamBlock) void gb2_stream_kernel(const Gb2Args 
     const int64_t stride = (int64_t)gridDim.x * TPI;
     int64_t st = (int64_t)blockIdx.x * TPI;
     G2Raw<kStreamRows> cur;
-    if (st < a.ntiles) g2_load<kStreamRows, kStreamBlock>(a, st, tid, cur);
+    if (st < a.ntiles) g2_load<kStreamRows, kStreamBlock, FAST>(a, st, tid, cur);
     for (; st < a.ntiles; st += stride) {
         G2Raw<kStreamRows> nxt;
         const bool more = st + stride < a.ntiles;
-        if (more) g2_load<kStreamRows, kStreamBlock>(a, st + stride, tid, nxt);   // in flight while this batch is folded
+        if (more) g2_load<kStreamRows, kStreamBlock, FAST>(a, st + stride, tid, nxt);   // in flight while this batch is folded
         G2Rows<kStreamRows> rows;
-        g2_prepare<kStreamRows>(a, cur, rows);
+        g2_prepare<kStreamRows, FAST>(a, cur, rows);
         uint32_t cnt[kStreamRows];
 #pragma unroll
         for (int j = 0; j < kStreamRows; ++j) cnt[j] = (rows.cnt >> j) & 1;
@@ -324,6 +365,7 @@ __global__ __launch_bounds__(kStreamBlock) void gb2_stream_kernel(const Gb2Args 
 // Per flushed line ONE 64-bit descriptor (destination line, staging index, carry length, partition) is all the flush
 // phase reads before it moves the line: the partition's owner thread writes it while it does the bookkeeping.
 
+template <bool FAST>
 __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
     u64x2* stage = (u64x2*)gsm;                           // [kG2Super] this tile's records, grouped by partition
@@ -349,11 +391,11 @@ __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args 
     int64_t st = (int64_t)bid * TPI;
     G2Raw<kG2Rows> raw;
     G2Rows<kG2Rows> rows;
-    if (st < a.ntiles) { g2_load<kG2Rows, kG2Block>(a, st, tid, raw); g2_prepare<kG2Rows>(a, raw, rows); }
+    if (st < a.ntiles) { g2_load<kG2Rows, kG2Block, FAST>(a, st, tid, raw); g2_prepare<kG2Rows, FAST>(a, raw, rows); }
     for (; st < a.ntiles; st += stride) {
         const bool more = st + stride < a.ntiles;
-        if (more) g2_load<kG2Rows, kG2Block>(a, st + stride, tid, raw);   // the next tile's loads fly during the LDS phases
-        if (a.ablate == 24) { uint64_t x = 0; for (int j = 0; j < kG2Rows; ++j) x ^= rows.hk[j] ^ rows.val[j]; if (x == 0x1234567) a.special[0] = 1; if (more) g2_prepare<kG2Rows>(a, raw, rows); continue; }   // loads + hash only
+        if (more) g2_load<kG2Rows, kG2Block, FAST>(a, st + stride, tid, raw);   // the next tile's loads fly during the LDS phases
+        if (a.ablate == 24) { uint64_t x = 0; for (int j = 0; j < kG2Rows; ++j) x ^= rows.hk[j] ^ rows.val[j]; if (x == 0x1234567) a.special[0] = 1; if (more) g2_prepare<kG2Rows, FAST>(a, raw, rows); continue; }   // loads + hash only
         // (B) rank inside the partition
         uint32_t rank[kG2Rows];
 #pragma unroll
@@ -409,7 +451,7 @@ __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args 
             }
         __syncthreads();
         // the next tile's rows: waiting for its loads HERE keeps the flush stores below out of that wait
-        if (more) g2_prepare<kG2Rows>(a, raw, rows);
+        if (more) g2_prepare<kG2Rows, FAST>(a, raw, rows);
         // (E) flush whole lines: 8 consecutive lanes write one aligned 128-byte line of a region
         const uint32_t nl = (a.ablate == 22 || a.ablate == 23) ? 0u : ltot;
         for (uint32_t i = (uint32_t)tid >> 3; i < nl; i += kG2Block / 8) {
@@ -721,14 +763,24 @@ size_t gb2_scatter_lds_bytes() {
 }
 hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s) {
     const size_t lds = (size_t)kGbSlots * 20 + 16;
-    (void)hipFuncSetAttribute((const void*)gb2_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gb2_stream_kernel, dim3(grid), dim3(kStreamBlock), lds, s, a);
+    if (a.fast) {
+        (void)hipFuncSetAttribute((const void*)gb2_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gb2_stream_kernel<true>, dim3(grid), dim3(kStreamBlock), lds, s, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)gb2_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gb2_stream_kernel<false>, dim3(grid), dim3(kStreamBlock), lds, s, a);
+    }
     return hipGetLastError();
 }
 hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s) {
     const size_t lds = gb2_scatter_lds_bytes();
-    (void)hipFuncSetAttribute((const void*)gb2_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gb2_scatter_kernel, dim3(grid), dim3(kG2Block), lds, s, a);
+    if (a.fast) {
+        (void)hipFuncSetAttribute((const void*)gb2_scatter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gb2_scatter_kernel<true>, dim3(grid), dim3(kG2Block), lds, s, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)gb2_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gb2_scatter_kernel<false>, dim3(grid), dim3(kG2Block), lds, s, a);
+    }
     return hipGetLastError();
 }
 hipError_t launch_gb2_aggregate(const Gb2AggArgs& a, hipStream_t s) {

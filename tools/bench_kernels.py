@@ -21,18 +21,21 @@ PEAK = 8000.0
 
 def dev_f64(n, col, lo=0.0, hi=1.0, seed=42):
     t = torch.empty(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()   # the block may be one torch just freed with work still queued on torch's stream; the fill runs on the library's
     lib.fill_uniform_f64(t.data_ptr(), n, seed, col, 0, lo, hi)
     return t
 
 
 def dev_i64(n, col, lo=-2 ** 31, hi=2 ** 31, seed=42):
     t = torch.empty(n, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
     lib.fill_uniform_i64(t.data_ptr(), n, seed, col, 0, lo, hi)
     return t
 
 
 def dev_validity(n, col, frac, seed=42):
     t = torch.zeros((n + 63) // 64 * 8 + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     lib.fill_validity(t.data_ptr(), n, seed, col, 0, frac)
     return t
 
