@@ -18,6 +18,19 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 template <class T> using GlobalPtr = const T __attribute__((address_space(1)))*;
 template <class T> using GlobalMutPtr = T __attribute__((address_space(1)))*;
 template <class T> __device__ __forceinline__ GlobalPtr<T> as_global(const void* p) { return (GlobalPtr<T>)p; }
+// Host-built lookup tables (chunk descriptors, tile prefix sums) are never written by a kernel: read through the
+// CONSTANT address space they become scalar loads (s_load, lgkmcnt) even in kernels that also store / do atomics.  As
+// plain global loads the compiler has to assume a clobber and issues them on the vector memory path, where waiting for a
+// descriptor (vmcnt(0)) also waits for every data load in flight — the prefetch pipeline of the streaming kernels then
+// degenerates to one exposed memory latency per batch.
+template <class T> using ConstPtr = const T __attribute__((address_space(4)))*;
+template <class T> __device__ __forceinline__ ConstPtr<T> as_const(const void* p) { return (ConstPtr<T>)p; }
+__device__ __forceinline__ DevChunkCol const_col(const DevChunkCol* table, int64_t i) {   // table[i] through the constant address space
+    const ConstPtr<DevChunkCol> t = as_const<DevChunkCol>(table);
+    DevChunkCol c;
+    c.values = t[i].values; c.validity = t[i].validity; c.offset = t[i].offset;
+    return c;
+}
 template <class T> __device__ __forceinline__ GlobalMutPtr<T> as_global_mut(void* p) { return (GlobalMutPtr<T>)p; }
 
 __device__ __forceinline__ int clamp64(int64_t v) { return v <= 0 ? 0 : (v >= 64 ? 64 : (int)v); }
@@ -248,7 +261,8 @@ __device__ __forceinline__ float rdf_cos(float x) { return cosf(x); }
 __device__ __forceinline__ float rdf_tan(float x) { return tanf(x); }
 
 // largest c in [0, n) with start[c] <= t (start is a non-decreasing prefix table; scalar loads)
-__device__ __forceinline__ int64_t find_chunk(const int64_t* start, int64_t n, int64_t t) {
+template <class P>
+__device__ __forceinline__ int64_t find_chunk(P start, int64_t n, int64_t t) {
     int64_t lo = 0, hi = n - 1;
     while (lo < hi) {
         const int64_t mid = (lo + hi + 1) >> 1;
@@ -261,7 +275,8 @@ __device__ __forceinline__ int64_t find_chunk(const int64_t* start, int64_t n, i
 // reader's 1024-row batches, src/dataframe.rs:352), where chunk c starts at tile c * tiles_per_chunk.  Interpolating
 // gives the answer with two dependent scalar loads instead of log2(n) (measured on 48 828 chunks of 1024 rows: the
 // binary search alone cost ~9 us per tile); any other layout fails the check and takes the search from the guess.
-__device__ __forceinline__ int64_t find_chunk_tile(const int64_t* start, int64_t n, int64_t t) {
+template <class P>
+__device__ __forceinline__ int64_t find_chunk_tile(P start, int64_t n, int64_t t) {
     if (n <= 1) return 0;
     const int64_t last = start[n - 1];
     if (t >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31)) return find_chunk(start, n, t);   // keeps t * (n - 1) in 64 bits
@@ -289,7 +304,8 @@ __device__ __forceinline__ int64_t find_chunk_tile(const int64_t* start, int64_t
 // For equally long batches the guess is exact or one short; both neighbours are tried before any search.  (An explicit
 // "uniform batches" fast path next to the search cost the specialised kernels 20 VGPRs and with them a third of their
 // occupancy; this single path costs none.)
-__device__ __forceinline__ int64_t find_chunk_tile_inv(const int64_t* start, int64_t n, int64_t t, uint64_t inv) {
+template <class P>
+__device__ __forceinline__ int64_t find_chunk_tile_inv(P start, int64_t n, int64_t t, uint64_t inv) {
     if (n <= 1) return 0;
     if (inv == 0 || t >= ((int64_t)1 << 32)) return find_chunk(start, n, t);
     int64_t g = (int64_t)(((uint64_t)(uint32_t)t * inv) >> 32);

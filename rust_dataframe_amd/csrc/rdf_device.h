@@ -385,6 +385,7 @@ struct Gb2Args {
     // stream kernel: the global table the block tables are merged into
     GroupTable         t;
     int32_t            replicas, sub_slots;   // LDS table = replicas sub-tables of sub_slots slots (lane % replicas picks one)
+    int32_t            table_slots, pad2;     // slots of the block's LDS table (20 B each)
     int32_t            ablate, fast;          // fast: 8-byte keys / values, no bitmaps, 16-byte aligned chunks (host-checked); bench ablations of the scatter (rdf_set_option("gb_debug", 21..24)): results invalid
 };
 struct Gb2AggArgs {

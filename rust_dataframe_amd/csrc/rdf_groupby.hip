@@ -113,11 +113,12 @@ __device__ __forceinline__ void g2_load(const Gb2Args& a, int64_t st, int tid, G
         if (tile >= a.ntiles) continue;
         if (a.nchunks == 1) { kc[tt] = a.key0; vc[tt] = a.val0; r0[tt] = tile * kEvalTile; clen[tt] = a.len0; }
         else {
-            const int64_t c = find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
-            r0[tt] = (tile - a.chunk_tile_start[c]) * kEvalTile;
-            clen[tt] = a.chunk_len[c];
-            kc[tt] = a.keys[c];
-            if (a.value_dtype >= 0) vc[tt] = a.values[c];
+            const ConstPtr<int64_t> tile_start = as_const<int64_t>(a.chunk_tile_start);
+            const int64_t c = find_chunk_tile(tile_start, a.nchunks, tile);
+            r0[tt] = (tile - tile_start[c]) * kEvalTile;
+            clen[tt] = as_const<int64_t>(a.chunk_len)[c];
+            kc[tt] = const_col(a.keys, c);
+            if (a.value_dtype >= 0) vc[tt] = const_col(a.values, c);
         }
     }
     r.exists = 0; r.kbit = 0; r.vbit = 0;
@@ -126,14 +127,24 @@ __device__ __forceinline__ void g2_load(const Gb2Args& a, int64_t st, int tid, G
 #pragma unroll
         for (int tt = 0; tt < NT / 2; ++tt) {
             const int64_t row = r0[tt] + 2 * tid;
-            const bool e0 = row < clen[tt], e1 = row + 1 < clen[tt];
-            r.exists |= ((uint32_t)e0 | (uint32_t)e1 << 1) << (2 * tt);
+            const GlobalPtr<uint64_t> kp = as_global<uint64_t>(kc[tt].values) + kc[tt].offset + row;
+            const GlobalPtr<uint64_t> vp = as_global<uint64_t>(vc[tt].values) + vc[tt].offset + row;
             u64x2 k = {0, 0}, v = {0, 0};
-            if (e1) k = __builtin_nontemporal_load((GlobalPtr<u64x2>)(as_global<uint64_t>(kc[tt].values) + kc[tt].offset + row));
-            else if (e0) k[0] = __builtin_nontemporal_load(as_global<uint64_t>(kc[tt].values) + kc[tt].offset + row);
-            if (a.value_dtype >= 0) {
-                if (e1) v = __builtin_nontemporal_load((GlobalPtr<u64x2>)(as_global<uint64_t>(vc[tt].values) + vc[tt].offset + row));
-                else if (e0) v[0] = __builtin_nontemporal_load(as_global<uint64_t>(vc[tt].values) + vc[tt].offset + row);
+            // every register is the target of ONE load on either side of this block-uniform branch: a second load into a
+            // register with one possibly in flight makes the compiler wait for vmcnt(0), i.e. for the prefetched batches too
+            if (r0[tt] + kEvalTile <= clen[tt]) {
+                r.exists |= 3u << (2 * tt);
+                k = __builtin_nontemporal_load((GlobalPtr<u64x2>)kp);
+                if (a.value_dtype >= 0) v = __builtin_nontemporal_load((GlobalPtr<u64x2>)vp);
+            } else {   // the last tile of a chunk
+                const bool e0 = row < clen[tt], e1 = row + 1 < clen[tt];
+                r.exists |= ((uint32_t)e0 | (uint32_t)e1 << 1) << (2 * tt);
+                if (e0) k[0] = __builtin_nontemporal_load(kp);
+                if (e1) k[1] = __builtin_nontemporal_load(kp + 1);
+                if (a.value_dtype >= 0) {
+                    if (e0) v[0] = __builtin_nontemporal_load(vp);
+                    if (e1) v[1] = __builtin_nontemporal_load(vp + 1);
+                }
             }
             r.key[2 * tt] = k[0]; r.key[2 * tt + 1] = k[1];
             r.val[2 * tt] = v[0]; r.val[2 * tt + 1] = v[1];
@@ -171,8 +182,14 @@ __device__ __forceinline__ void g2_load(const Gb2Args& a, int64_t st, int tid, G
 template <int NT>
 struct G2Rows { uint64_t hk[NT], val[NT]; uint32_t cnt, live; };   // cnt bit j: the value is not NULL
 
+// Where the two groups that never enter a hash table (the NULL key; the key whose hash is the free marker) accumulate.
+// The stream kernel keeps them in LDS and flushes once per block: a global store / atomic inside the streaming loop — even
+// one that practically never executes — puts a WRITE next to the prefetch loads in the vector-memory counter, reads and
+// writes return out of order, and the compiler then has to wait for vmcnt(0) wherever it waits at all.
+struct LdsSpecial { unsigned long long* acc; unsigned int* cnt; unsigned int* flag; };   // [2] each; acc == nullptr: global
+
 template <int NT, bool FAST = false>
-__device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r, G2Rows<NT>& o) {
+__device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r, G2Rows<NT>& o, const LdsSpecial ls = LdsSpecial{nullptr, nullptr, nullptr}) {
     o.cnt = 0; o.live = 0;
     const bool counts_rows = a.value_dtype < 0;
     if constexpr (FAST) {
@@ -185,9 +202,15 @@ __device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r,
             o.val[j] = v;
             if (!((r.exists >> j) & 1)) continue;
             if (hk == kFree) {   // the one key whose hash is the free marker
-                a.special[0] = 1;
-                if (!counts_rows) acc_apply(&a.special_sums[0], a.op, a.vcls, v);
-                atomicAdd(&a.special_counts[0], 1ull);
+                if (ls.acc) {
+                    ls.flag[0] = 1;
+                    if (!counts_rows) acc_apply(&ls.acc[0], a.op, a.vcls, v);
+                    atomicAdd(&ls.cnt[0], 1u);
+                } else {
+                    a.special[0] = 1;
+                    if (!counts_rows) acc_apply(&a.special_sums[0], a.op, a.vcls, v);
+                    atomicAdd(&a.special_counts[0], 1ull);
+                }
                 continue;
             }
             o.live |= 1u << j;
@@ -211,10 +234,18 @@ __device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r,
         if (!e) continue;
         if (knull || hk == kFree) {
             const int s = knull ? 1 : 0;
-            a.special[s] = 1;
-            if (c1) {
-                if (!counts_rows) acc_apply(&a.special_sums[s], a.op, a.vcls, v);
-                atomicAdd(&a.special_counts[s], 1ull);
+            if (ls.acc) {
+                ls.flag[s] = 1;
+                if (c1) {
+                    if (!counts_rows) acc_apply(&ls.acc[s], a.op, a.vcls, v);
+                    atomicAdd(&ls.cnt[s], 1u);
+                }
+            } else {
+                a.special[s] = 1;
+                if (c1) {
+                    if (!counts_rows) acc_apply(&a.special_sums[s], a.op, a.vcls, v);
+                    atomicAdd(&a.special_counts[s], 1ull);
+                }
             }
             continue;
         }
@@ -308,18 +339,26 @@ __device__ __forceinline__ void g2_global_special(const GroupTable& t, int which
 
 constexpr int kStreamBlock = kGbBlock;       // 512 threads, 2 blocks per CU (80 KB of LDS each)
 constexpr int kStreamRows = 4;               // rows per thread per batch = two tiles per block iteration
+// The kernel is latency-bound (PMC at 4.3 TB/s: waves waiting 74 % of their cycles, VALU 29 %, LDS 24 % busy): what it needs
+// is an unbroken load pipeline (see the loop below) and few registers; the fast variant is held to 80 VGPRs.
 template <bool FAST>
-__global__ __launch_bounds__(kStreamBlock) void gb2_stream_kernel(const Gb2Args a) {
+__global__ __launch_bounds__(kStreamBlock, FAST ? 6 : 4) void gb2_stream_kernel(const Gb2Args a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
+    const int slots = a.table_slots;
     LdsTab t;
     t.keys = (unsigned long long*)gsm;
-    t.acc = t.keys + kGbSlots;
-    t.cnt = (unsigned int*)(t.acc + kGbSlots);
-    t.ngroups = t.cnt + kGbSlots;
+    t.acc = t.keys + slots;
+    t.cnt = (unsigned int*)(t.acc + slots);
+    t.ngroups = t.cnt + slots;
+    LdsSpecial ls;
+    ls.acc = (unsigned long long*)(gsm + ((size_t)slots * 20 + 4 + 7) / 8);   // behind keys, acc, cnt, ngroups (8-byte aligned)
+    ls.cnt = (unsigned int*)(ls.acc + 2);
+    ls.flag = ls.cnt + 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long ident = agg_identity(a.op);
-    for (int i = tid; i < kGbSlots; i += kStreamBlock) { t.keys[i] = kFree; t.acc[i] = ident; t.cnt[i] = 0; }
+    for (int i = tid; i < slots; i += kStreamBlock) { t.keys[i] = kFree; t.acc[i] = ident; t.cnt[i] = 0; }
     if (tid == 0) *t.ngroups = 0;
+    if (tid < 2) { ls.acc[tid] = ident; ls.cnt[tid] = 0; ls.flag[tid] = 0; }
     __syncthreads();
     const bool has_values = a.value_dtype >= 0;
     const uint32_t base = (uint32_t)(lane & (a.replicas - 1)) * (uint32_t)a.sub_slots;
@@ -327,23 +366,42 @@ __global__ __launch_bounds__(kStreamBlock) void gb2_stream_kernel(const Gb2Args 
     constexpr int TPI = kStreamRows * kStreamBlock / kEvalTile;   // tiles per block iteration
     const int64_t stride = (int64_t)gridDim.x * TPI;
     int64_t st = (int64_t)blockIdx.x * TPI;
-    G2Raw<kStreamRows> cur;
-    if (st < a.ntiles) g2_load<kStreamRows, kStreamBlock, FAST>(a, st, tid, cur);
-    for (; st < a.ntiles; st += stride) {
-        G2Raw<kStreamRows> nxt;
-        const bool more = st + stride < a.ntiles;
-        if (more) g2_load<kStreamRows, kStreamBlock, FAST>(a, st + stride, tid, nxt);   // in flight while this batch is folded
+    // FAST: two batches of column loads stay in flight behind the one being folded.  With 16 waves per CU (the LDS tables
+    // allow no more) one batch ahead is 64 KB per CU in flight, which is what bounded the kernel (PMC: waves waiting 74 % of
+    // their cycles, VALU 29 % and LDS 24 % busy at 4.3 TB/s); two are 128 KB.  (The general loader keeps one batch ahead: a
+    // second one would cost it the registers that let two blocks share a CU.)
+    auto fold = [&](const G2Raw<kStreamRows>& raw) {
         G2Rows<kStreamRows> rows;
-        g2_prepare<kStreamRows, FAST>(a, cur, rows);
+        g2_prepare<kStreamRows, FAST>(a, raw, rows, ls);
         uint32_t cnt[kStreamRows];
 #pragma unroll
         for (int j = 0; j < kStreamRows; ++j) cnt[j] = (rows.cnt >> j) & 1;
         tab_upsert<kStreamRows, 0>(t, a.op, a.vcls, has_values, base, (uint32_t)a.sub_slots, rows.hk, rows.val, cnt, rows.live, err);
-        if (more) cur = nxt;
+    };
+    // Software pipeline: the next batch's loads fly while this one is folded.  The batches ROTATE through two register sets
+    // by unrolling, never by copying (`cur = nxt` is a read of nxt: a wait for the loads just issued), and the prefetch is
+    // issued UNCONDITIONALLY (past the end the block's last batch is loaded again and never folded).  Deeper prefetch does
+    // not pay: the compiler waits with vmcnt(0) at every fold whatever the depth (measured: two batches ahead = one).
+    const int64_t last_st = ((a.ntiles - 1) / TPI) * TPI;
+    auto prefetch = [&](G2Raw<kStreamRows>& dst, int64_t at) { g2_load<kStreamRows, kStreamBlock, FAST>(a, at < a.ntiles ? at : last_st, tid, dst); };
+    if (st < a.ntiles) {
+        G2Raw<kStreamRows> ra, rb;
+        prefetch(ra, st);
+        for (;;) {
+            prefetch(rb, st + stride); fold(ra); st += stride; if (st >= a.ntiles) break;
+            prefetch(ra, st + stride); fold(rb); st += stride; if (st >= a.ntiles) break;
+        }
     }
     __syncthreads();
+    if (tid < 2 && ls.flag[tid]) {   // the block's share of the two special groups
+        a.special[tid] = 1;
+        if (ls.cnt[tid]) {
+            if (has_values) acc_apply(&a.special_sums[tid], a.op, a.vcls, ls.acc[tid]);
+            atomicAdd(&a.special_counts[tid], (unsigned long long)ls.cnt[tid]);
+        }
+    }
     // the block's groups -> the global table (keys un-hashed: the global table is addressed by raw key bits)
-    for (int i = tid; i < kGbSlots; i += kStreamBlock) {
+    for (int i = tid; i < slots; i += kStreamBlock) {
         const unsigned long long hk = t.keys[i];
         if (hk == kFree) continue;
         const uint64_t key = g2_unhash(hk);
@@ -762,7 +820,7 @@ size_t gb2_scatter_lds_bytes() {
     return (size_t)kG2Super * 16 + (size_t)kP * kG2Line * 16 + (size_t)kMaxFlushLines * 8 + (size_t)kP * 4 * 5;
 }
 hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s) {
-    const size_t lds = (size_t)kGbSlots * 20 + 16;
+    const size_t lds = (size_t)a.table_slots * 20 + 16 + 48;   // table, group counter, the two special groups
     if (a.fast) {
         (void)hipFuncSetAttribute((const void*)gb2_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(gb2_stream_kernel<true>, dim3(grid), dim3(kStreamBlock), lds, s, a);
