@@ -531,13 +531,22 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
         per_launch_s = kern_ms / max(kern_n, 1) * 1e-3 * (kern_n / args.steps if kern_n else 0)   # all timed kernels of one step
         achieved = alg_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
         cb = chk.pop("cpu_baseline", None)
+        traffic, traffic_source = None, None
+        try:   # PMC-derived HBM bytes of one step's kernels, measured in separate rocprofv3 --pmc passes (tools/profile_round.sh)
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+                tw = json.load(f).get("workloads", {}).get(args.workload)
+            if tw and int(tw.get("rows", -1)) == rows and world == 1:
+                traffic = tw.get("hbm_bytes_per_step")
+                traffic_source = "profiles/hbm_traffic.json (" + str(tw.get("source")) + "), not re-measured in this run"
+        except Exception:
+            traffic = None
         line = {
             "metric": f"rows/sec {args.workload}", "value": rows * world * args.steps / elapsed, "unit": "rows/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "rows_per_gpu": rows, "total_rows": rows * world, "result": res, **chk},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": kernel_name, "kernel_ms_per_step": per_launch_s * 1e3,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms_per_step": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if cb is not None:

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -289,6 +290,18 @@ struct InPlan {
 };
 
 // Stage (or alias) a list of arrays.  After finish(), dev[i] is the HBM view of arrays[i].
+struct DbgTimer {   // RDF_DEBUG=1: host-side phase times of a call (stderr)
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    DbgTimer() : on(getenv("RDF_DEBUG") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rdf] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 struct InputStager {
     Region region;
     std::vector<InPlan> plans;
@@ -298,6 +311,8 @@ struct InputStager {
 
     void add(const rdf_array* a) {
         arrays.push_back(a);
+        if (a->mem != RDF_MEM_HOST && !host) return;   // device-resident calls (one memory space per call) need no staging plan
+        if (plans.size() + 1 < arrays.size()) plans.resize(arrays.size() - 1);   // (device arrays ahead of a host one: plans stay index-aligned)
         InPlan p;
         if (a->mem == RDF_MEM_HOST) {
             host = true;
@@ -343,28 +358,33 @@ struct InputStager {
 };
 
 // Small host tables (chunk descriptors, prefix arrays) uploaded in one copy.
-struct TableBuilder {
-    std::vector<char> host;
+struct TableBuilder {   // reserve() every table, bind() to a place in the pinned staging buffer, fill through at(), alloc() + upload()
+    size_t size = 0;
+    char* base = nullptr;   // the tables are written straight into pinned memory: a frame of a million 1024-row batches has 40 MB of them
     char* dev = nullptr;
     size_t reserve(size_t bytes) {
-        size_t off = (host.size() + 15) & ~(size_t)15;
-        host.resize(off + bytes);
+        size_t off = (size + 15) & ~(size_t)15;
+        size = off + bytes;
         return off;
     }
-    template <typename T> T* at(size_t off) { return (T*)(host.data() + off); }
+    rdf_status bind(size_t pinned_off) {
+        RDF_TRY(pinned_reserve(pinned_off + size + 16));
+        base = g_ctx.pinned + pinned_off;
+        return RDF_OK;
+    }
+    template <typename T> T* at(size_t off) { return (T*)(base + off); }
     template <typename T> T* dev_at(size_t off) const { return (T*)(dev + off); }
     rdf_status alloc() {
         void* p = nullptr;
-        RDF_TRY(arena_alloc(host.size() ? host.size() : 16, &p));
+        RDF_TRY(arena_alloc(size ? size : 16, &p));
         dev = (char*)p;
         return RDF_OK;
     }
     rdf_status upload(size_t pinned_off) {
         Ctx& c = g_ctx;
-        if (host.empty()) return RDF_OK;
-        RDF_TRY(pinned_reserve(pinned_off + host.size()));
-        memcpy(c.pinned + pinned_off, host.data(), host.size());
-        HIP_TRY(hipMemcpyAsync(dev, c.pinned + pinned_off, host.size(), hipMemcpyHostToDevice, c.stream));
+        if (size == 0) return RDF_OK;
+        if (base != c.pinned + pinned_off) return fail(RDF_COMPUTE_ERROR, "internal: table builder not bound to its staging offset");
+        HIP_TRY(hipMemcpyAsync(dev, base, size, hipMemcpyHostToDevice, c.stream));
         return RDF_OK;
     }
 };
@@ -905,6 +925,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     }
     if (ps.sink == RDF_SINK_AGG && !aggs) return fail(RDF_INVALID_ARGUMENT, "aggs is null");
 
+    DbgTimer dbg;
     // column dtypes: chunk 0 decides, every chunk must agree (ChunkedArray::from_arrays, src/table.rs:24-40)
     int col_dtype[kMaxCols];
     for (int k = 0; k < ncols; ++k) {
@@ -923,6 +944,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         total_rows += clen[(size_t)c];
     }
 
+    dbg.mark("validate");
     // compile
     Compiler cc(ps.nodes, ps.nnodes, col_dtype, ncols);
     int value_dtype[kMaxGroupValues];
@@ -995,9 +1017,12 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
 
     // inputs
     InputStager in;
+    in.arrays.reserve((size_t)ncols * (size_t)nchunks);
+    in.plans.reserve((size_t)ncols * (size_t)nchunks);
     for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) in.add(&cols[i]);
     RDF_TRY(in.finish(pin_off, &pin_used));
     pin_off += (pin_used + 255) & ~(size_t)255;
+    dbg.mark("stage inputs");
 
     // outputs (SINK_STORE)
     Region outr;
@@ -1062,29 +1087,37 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     for (int v = 0; v < ps.nvalues; ++v) { cls[v] = value_class(value_dtype[v]); ea.value_cls[v] = cls[v]; }
     memcpy(ea.code, cc.code.data(), cc.code.size() * sizeof(Instr));
 
+    // The general evaluator's chunk tables (descriptors, tile prefix, lengths): built only when that kernel (or the grouped
+    // sink, which shares them) is going to run — for a frame of a million 1024-row batches they are 40 MB of host work
+    // and upload that a specialised kernel, which carries its own tables, never reads.
     TableBuilder tb;
-    if (nchunks == 1) {
-        for (int k = 0; k < ncols; ++k) ea.inline_cols[k] = in.dev[(size_t)k];
-        for (int v = 0; v < ps.nvalues && ps.sink == RDF_SINK_STORE; ++v) ea.inline_outs[v] = dev_outs[(size_t)v];
-        ea.inline_len = clen[0];
-    } else {
-        const size_t o_cols = tb.reserve(sizeof(DevChunkCol) * in.dev.size());
-        const size_t o_ts = tb.reserve(sizeof(int64_t) * tile_start.size());
-        const size_t o_len = tb.reserve(sizeof(int64_t) * clen.size());
-        const size_t o_outs = tb.reserve(sizeof(DevOutChunk) * (dev_outs.size() + 1));
-        memcpy(tb.at<char>(o_cols), in.dev.data(), sizeof(DevChunkCol) * in.dev.size());
-        memcpy(tb.at<char>(o_ts), tile_start.data(), sizeof(int64_t) * tile_start.size());
-        memcpy(tb.at<char>(o_len), clen.data(), sizeof(int64_t) * clen.size());
-        if (!dev_outs.empty()) memcpy(tb.at<char>(o_outs), dev_outs.data(), sizeof(DevOutChunk) * dev_outs.size());
-        RDF_TRY(tb.alloc());
-        RDF_TRY(tb.upload(pin_off));
-        pin_off += (tb.host.size() + 255) & ~(size_t)255;
-        ea.cols = tb.dev_at<DevChunkCol>(o_cols);
-        ea.chunk_tile_start = tb.dev_at<int64_t>(o_ts);
-        ea.chunk_len = tb.dev_at<int64_t>(o_len);
-        ea.outs = tb.dev_at<DevOutChunk>(o_outs);
-    }
-
+    auto build_eval_tables = [&]() -> rdf_status {
+        if (nchunks == 1) {
+            for (int k = 0; k < ncols; ++k) ea.inline_cols[k] = in.dev[(size_t)k];
+            for (int v = 0; v < ps.nvalues && ps.sink == RDF_SINK_STORE; ++v) ea.inline_outs[v] = dev_outs[(size_t)v];
+            ea.inline_len = clen[0];
+        } else {
+            const size_t o_cols = tb.reserve(sizeof(DevChunkCol) * in.dev.size());
+            const size_t o_ts = tb.reserve(sizeof(int64_t) * tile_start.size());
+            const size_t o_len = tb.reserve(sizeof(int64_t) * clen.size());
+            const size_t o_outs = tb.reserve(sizeof(DevOutChunk) * (dev_outs.size() + 1));
+            RDF_TRY(tb.bind(pin_off));
+            memcpy(tb.at<char>(o_cols), in.dev.data(), sizeof(DevChunkCol) * in.dev.size());
+            memcpy(tb.at<char>(o_ts), tile_start.data(), sizeof(int64_t) * tile_start.size());
+            memcpy(tb.at<char>(o_len), clen.data(), sizeof(int64_t) * clen.size());
+            if (!dev_outs.empty()) memcpy(tb.at<char>(o_outs), dev_outs.data(), sizeof(DevOutChunk) * dev_outs.size());
+            RDF_TRY(tb.alloc());
+            RDF_TRY(tb.upload(pin_off));
+            pin_off += (tb.size + 255) & ~(size_t)255;
+            ea.cols = tb.dev_at<DevChunkCol>(o_cols);
+            ea.chunk_tile_start = tb.dev_at<int64_t>(o_ts);
+            ea.chunk_len = tb.dev_at<int64_t>(o_len);
+            ea.outs = tb.dev_at<DevOutChunk>(o_outs);
+        }
+        return RDF_OK;
+    };
+    if (grouped) RDF_TRY(build_eval_tables());
+    dbg.mark("interpreter tables");
     // specialised straight-line kernel for this program shape? (8-byte columns, every chunk 16-byte aligned)
     SpecPlan sp;
     SpecArgs sa;
@@ -1137,6 +1170,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             const size_t o_t = stb.reserve(sizeof(int64_t) * sts.size());
             const size_t o_l = stb.reserve(sizeof(int64_t) * clen.size());
             const size_t o_o = stb.reserve(sizeof(DevOutChunk) * ((size_t)nchunks + 1));
+            RDF_TRY(stb.bind(pin_off));
             for (int k = 0; k < sp.ncols; ++k)
                 memcpy(stb.at<DevChunkCol>(o_c) + (size_t)k * (size_t)nchunks, in.dev.data() + (size_t)sp.col_map[k] * (size_t)nchunks, sizeof(DevChunkCol) * (size_t)nchunks);
             memcpy(stb.at<char>(o_t), sts.data(), sizeof(int64_t) * sts.size());
@@ -1144,7 +1178,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             if (ps.sink == RDF_SINK_STORE) memcpy(stb.at<char>(o_o), dev_outs.data(), sizeof(DevOutChunk) * (size_t)nchunks);
             RDF_TRY(stb.alloc());
             RDF_TRY(stb.upload(pin_off));
-            pin_off += (stb.host.size() + 255) & ~(size_t)255;
+            pin_off += (stb.size + 255) & ~(size_t)255;
             sa.cols_tab = stb.dev_at<DevChunkCol>(o_c);
             sa.chunk_tile_start = stb.dev_at<int64_t>(o_t);
             sa.chunk_len = stb.dev_at<int64_t>(o_l);
@@ -1156,6 +1190,8 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         d_result = d_partials + (size_t)grid * (size_t)ps.nvalues;
     }
 
+    dbg.mark("specialised tables");
+    if (!grouped && !use_spec) RDF_TRY(build_eval_tables());
     if (grouped) {
         ea.ngroups = ps.ngroups;
         // LDS copies of the table: as many (power of two, <= 32) as fit in 32 KB next to the TMP spill area
@@ -1281,6 +1317,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         HIP_TRY(hipMemcpyAsync(pin, d_flags, 16, hipMemcpyDeviceToHost, ctx.stream));
         HIP_TRY(hipMemcpyAsync(pin + 64, d_result, sizeof(AggPartial) * (size_t)ps.nvalues, hipMemcpyDeviceToHost, ctx.stream));
         HIP_TRY(hipStreamSynchronize(ctx.stream));
+        dbg.mark("kernel + result");
         uint32_t flags;
         memcpy(&flags, pin, 4);
         if (flags & 1u) return fail(RDF_DIVIDE_BY_ZERO, "Divide by zero error");
@@ -1673,13 +1710,14 @@ rdf_status filter_prepare(FilterPrep& fp, const rdf_array* cols, int ncols, cons
     const size_t o_len = fp.tb.reserve(sizeof(int64_t) * fp.clen.size());
     fp.o_cols = fp.tb.reserve(sizeof(DevChunkCol) * ((size_t)ncols * (size_t)nchunks + 1));
     fp.o_outs = fp.tb.reserve(sizeof(DevOutChunk) * ((size_t)ncols * (size_t)nchunks + 1));
+    RDF_TRY(fp.tb.bind(fp.pin_off));
     memcpy(fp.tb.at<char>(o_mask), fp.in.dev.data(), sizeof(DevChunkCol) * (size_t)nchunks);
     memcpy(fp.tb.at<char>(o_len), fp.clen.data(), sizeof(int64_t) * fp.clen.size());
     if (ncols > 0) memcpy(fp.tb.at<char>(fp.o_cols), fp.in.dev.data() + nchunks, sizeof(DevChunkCol) * (size_t)ncols * (size_t)nchunks);
     RDF_TRY(fp.tb.alloc());
     // the outs table is filled in later (after the counts are known): upload the front part now
     RDF_TRY(fp.tb.upload(fp.pin_off));
-    fp.pin_off += (fp.tb.host.size() + 255) & ~(size_t)255;
+    fp.pin_off += (fp.tb.size + 255) & ~(size_t)255;
 
     fp.mt.mask = fp.tb.dev_at<DevChunkCol>(o_mask);
     fp.mt.chunk_len = fp.tb.dev_at<int64_t>(o_len);
@@ -1892,11 +1930,12 @@ rdf_status rdf_take(const rdf_array* chunks, int64_t nchunks, const rdf_array* i
     TableBuilder tb;
     const size_t o_ch = tb.reserve(sizeof(DevChunkCol) * (size_t)nchunks);
     const size_t o_rs = tb.reserve(sizeof(int64_t) * row_start.size());
+    RDF_TRY(tb.bind(pin_off));
     memcpy(tb.at<char>(o_ch), in.dev.data() + 1, sizeof(DevChunkCol) * (size_t)nchunks);
     memcpy(tb.at<char>(o_rs), row_start.data(), sizeof(int64_t) * row_start.size());
     RDF_TRY(tb.alloc());
     RDF_TRY(tb.upload(pin_off));
-    pin_off += (tb.host.size() + 255) & ~(size_t)255;
+    pin_off += (tb.size + 255) & ~(size_t)255;
 
     const size_t es = (size_t)dtype_size(dt);
     Region outr;
@@ -2307,11 +2346,12 @@ rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
     TableBuilder tb;
     const size_t o_ch = tb.reserve(sizeof(DevChunkCol) * in.dev.size());
     const size_t o_rs = tb.reserve(sizeof(int64_t) * row_start.size());
+    RDF_TRY(tb.bind(pin_off));
     memcpy(tb.at<char>(o_ch), in.dev.data(), sizeof(DevChunkCol) * in.dev.size());
     memcpy(tb.at<char>(o_rs), row_start.data(), sizeof(int64_t) * row_start.size());
     RDF_TRY(tb.alloc());
     RDF_TRY(tb.upload(pin_off));
-    pin_off += (tb.host.size() + 255) & ~(size_t)255;
+    pin_off += (tb.size + 255) & ~(size_t)255;
 
     const int64_t ntiles = (n + kSortTile - 1) / kSortTile;
     void *pk0, *pk1, *pi0, *pi1, *pnf, *ph0, *ph1;
@@ -2510,12 +2550,13 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
     const size_t o_ch = tb.reserve(sizeof(DevChunkCol) * in.dev.size());
     const size_t o_prs = tb.reserve(sizeof(int64_t) * prs.size());
     const size_t o_brs = tb.reserve(sizeof(int64_t) * brs.size());
+    RDF_TRY(tb.bind(pin_off));
     memcpy(tb.at<char>(o_ch), in.dev.data(), sizeof(DevChunkCol) * in.dev.size());
     memcpy(tb.at<char>(o_prs), prs.data(), sizeof(int64_t) * prs.size());
     memcpy(tb.at<char>(o_brs), brs.data(), sizeof(int64_t) * brs.size());
     RDF_TRY(tb.alloc());
     RDF_TRY(tb.upload(pin_off));
-    pin_off += (tb.host.size() + 255) & ~(size_t)255;
+    pin_off += (tb.size + 255) & ~(size_t)255;
 
     // build side: key bits + null flags, sorted (NULL keys last)
     SortBuffers sb;
@@ -2805,6 +2846,7 @@ rdf_status legacy_groupby_sum(const rdf_array* keys, const rdf_array* values, in
     std::vector<int64_t> row_start((size_t)nchunks + 1, 0);
     for (int64_t c = 0; c < nchunks; ++c) row_start[(size_t)c + 1] = row_start[(size_t)c] + clen[(size_t)c];
     const size_t o_rs = tb.reserve(sizeof(int64_t) * row_start.size());
+    RDF_TRY(tb.bind(pin_off));
     memcpy(tb.at<char>(o_k), in.dev.data(), sizeof(DevChunkCol) * (size_t)nchunks);
     if (values) memcpy(tb.at<char>(o_v), in.dev.data() + nchunks, sizeof(DevChunkCol) * (size_t)nchunks);
     memcpy(tb.at<char>(o_ts), tile_start.data(), sizeof(int64_t) * tile_start.size());
@@ -2812,7 +2854,7 @@ rdf_status legacy_groupby_sum(const rdf_array* keys, const rdf_array* values, in
     memcpy(tb.at<char>(o_rs), row_start.data(), sizeof(int64_t) * row_start.size());
     RDF_TRY(tb.alloc());
     RDF_TRY(tb.upload(pin_off));
-    pin_off += (tb.host.size() + 255) & ~(size_t)255;
+    pin_off += (tb.size + 255) & ~(size_t)255;
 
     // High cardinality: radix-partition on the hashed key, aggregate each partition in LDS (no HBM atomics per row).
     bool value_nulls = false;

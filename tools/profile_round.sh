@@ -1,20 +1,44 @@
 #!/bin/bash
 # Re-creates the evidence under profiles/ for one round, on the GPU box:
-#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r01'   then   python tools/collect_profiles.py r01
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r02'   then   python tools/collect_profiles.py r02
 # Everything is written under gpurun_out/profile_<round>/ (scratch); collect_profiles.py copies the summaries.
 # Counters are collected in their own passes (one --pmc counter per pass, kernel trace only), as the MI355X guide asks.
 set -u
-R=${1:-r01}
+R=${1:-r02}
+PART=${2:-all}      # all | micro (only the per-entry counter passes of step 3b)
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profile_$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+pmc() {   # pmc <tag> <command...>: FETCH_SIZE and WRITE_SIZE of every kernel of the command, two passes
+    local tag=$1; shift
+    for c in FETCH_SIZE WRITE_SIZE; do
+        timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_${tag}_$c" -o p -- "$@" > "$OUT/pmc_${tag}_$c.out" 2> "$OUT/pmc_${tag}_$c.err"
+    done
+}
+if [ "$PART" = "all" ]; then
+# 1. the driver's bench line, the same under the kernel trace, and on the reference's 1024-row batches
 python "$REPO/bench.py" > "$OUT/bench_1e9.json" 2> "$OUT/bench_1e9.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python "$REPO/bench.py" --cpu-sample 0 > "$OUT/bench_1e9_under_rocprof.json" 2> "$OUT/trace.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o bench -- python "$REPO/bench.py" --steps 5 --warmup 1 --cpu-sample 0 > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o bench -- python "$REPO/bench.py" --steps 5 --warmup 1 --cpu-sample 0 > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
+python "$REPO/bench.py" --cpu-sample 0 --chunk-rows 1024 > "$OUT/bench_1e9_1024_row_batches.json" 2>> "$OUT/bench_1e9.err"
+python "$REPO/bench.py" --cpu-sample 0 --null-fraction 0.1 > "$OUT/bench_1e9_validity.json" 2>> "$OUT/bench_1e9.err"
+pmc headline python "$REPO/bench.py" --steps 5 --warmup 1 --cpu-sample 0
+# 2. the other configs of BASELINE.json: bench lines + HBM counters of their kernels
+for w in c3 c4 q1; do
+    python "$REPO/bench.py" --workload $w --steps 5 --warmup 2 2>> "$OUT/workloads.err" | tail -1 >> "$OUT/workloads.jsonl"
+    pmc $w python "$REPO/bench.py" --workload $w --steps 3 --warmup 1 --cpu-sample 0
+done
+# 3. per-kernel micro-benchmarks, shape kernels, compaction / take counters
 python "$REPO/tools/bench_kernels.py" --rows 1000000000 --steps 5 2> "$OUT/kernels.err" | grep kernel_ms > "$OUT/kernels_1e9_microbench.jsonl"
-for w in c3 c4 q1; do python "$REPO/bench.py" --workload $w --steps 5 --warmup 2 2>> "$OUT/workloads.err" | tail -1 >> "$OUT/workloads.jsonl"; done
+python "$REPO/tools/bench_shapes.py" --interp 2> "$OUT/shapes.err" | grep kernel_ms > "$OUT/shapes_2p5e8.jsonl"
+fi
+# 3b. HBM counters of compaction / take / small-group GROUP BY, one micro-benchmark entry per pass (the entries share kernels)
+for e in filter_1col filter_2col filter_1col_selectivity_1_16 take_random_u32 take_sequential_u32 groupby_sum_1000_groups; do
+    pmc micro_$e python "$REPO/tools/bench_kernels.py" --rows 1000000000 --steps 3 --only $e
+done
+# 4. the scatter micro-benchmark behind the C4 bound
+if [ -x "$REPO/tools/ubench_scatter.bin" ]; then timeout 300 "$REPO/tools/ubench_scatter.bin" > "$OUT/ubench_scatter.txt" 2>&1; fi
 # keep the merged payload small: the raw traces stay on the box, the stats / counter CSVs travel
-find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
-ls -la "$OUT" "$OUT"/*/ 2>/dev/null | head -40
+find "$OUT" -name "*kernel_trace.csv" -delete
+find "$OUT" -name "*agent_info.csv" -delete
+ls -la "$OUT" | head -60
