@@ -16,6 +16,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "rdf_device.h"
 
@@ -55,9 +57,25 @@ struct Ctx {
     bool   timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
+    ~Ctx();
 };
 
 thread_local Ctx g_ctx;
+
+// A worker thread that exits (the reference runs its kernels on rayon workers, src/functions/scalar.rs:28,99) gives back
+// its arena, pinned staging buffer, events and stream.  The main thread's context is left to process teardown: its
+// destructor runs inside exit(), where calling into a HIP runtime that may already be shutting down is not worth the risk.
+Ctx::~Ctx() {
+    if (!ready || (long)syscall(SYS_gettid) == (long)getpid()) return;
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (void* p : arena.overflow) (void)hipFree(p);
+    if (arena.base) (void)hipFree(arena.base);
+    if (pinned) (void)hipHostFree(pinned);
+    for (auto& ev : events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+    ready = false;
+}
 
 rdf_status fail(rdf_status st, const char* fmt, ...) {
     char buf[512];
@@ -66,6 +84,9 @@ rdf_status fail(rdf_status st, const char* fmt, ...) {
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_ctx.err = buf;
+    // an error return may leave asynchronous copies out of the pinned staging buffer (or into caller memory) queued: drain
+    // them, so that the next call — or the caller freeing its buffers — cannot race them
+    if (g_ctx.ready && g_ctx.stream) (void)hipStreamSynchronize(g_ctx.stream);
     return st;
 }
 

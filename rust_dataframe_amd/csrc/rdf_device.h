@@ -441,6 +441,7 @@ struct KeyPackArgs {
 };
 hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s);
 hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s);
+hipError_t launch_gb2_skew_probe(const Gb2Args& a, int64_t tile_step, unsigned int* hist, hipStream_t s);
 hipError_t launch_gb2_aggregate(const Gb2AggArgs& a, hipStream_t s);
 hipError_t launch_gb2_merge(const Gb2MergeArgs& a, hipStream_t s);
 hipError_t launch_gb2_table_rows(const Gb2Args& a, hipStream_t s);

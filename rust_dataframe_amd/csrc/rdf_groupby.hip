@@ -18,6 +18,8 @@
 //                         first-generation histogram + combining path (rdf_kernels.hip).
 //   gb2_table_rows_kernel / gb2_merge_kernel   any number of groups: one open-addressing table in HBM, 64-bit CAS +
 //                         hardware atomics; also the merge step of the multi-GPU exchange of partial groups.
+#include <algorithm>
+
 #include "rdf_common.hip.h"
 
 namespace rdfk {
@@ -410,6 +412,38 @@ __global__ __launch_bounds__(kStreamBlock, FAST ? 6 : 4) void gb2_stream_kernel(
         // a group whose every value was NULL still exists: the upsert above inserted its key with cnt == 0
     }
     if (err) atomicOr(a.flags, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skew probe in front of the scatter pass: the partition histogram of a sample of the keys (64 rows out of every sampled
+// tile, tiles spread evenly over the input, about 1 M keys in all).  The scatter's (partition, block) regions hold 1.19 x
+// their mean: a partition whose share is above that overflows them near the END of the pass, so without the probe heavily
+// skewed keys paid for a whole wasted scatter (~9 ms per 1e9 rows) before the combining path ran.
+__global__ __launch_bounds__(256) void gb2_skew_probe_kernel(const Gb2Args a, int64_t tile_step, unsigned int* hist) {
+    __shared__ unsigned int h[kP];
+    for (int i = threadIdx.x; i < kP; i += 256) h[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ksz = g2_dtype_size(a.key_dtype);
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i * tile_step < a.ntiles; i += (int64_t)gridDim.x * 4) {
+        const int64_t tile = i * tile_step;
+        DevChunkCol kc = a.key0;
+        int64_t r0 = tile * kEvalTile, clen = a.len0;
+        if (a.nchunks > 1) {
+            const ConstPtr<int64_t> ts = as_const<int64_t>(a.chunk_tile_start);
+            const int64_t c = find_chunk_tile(ts, a.nchunks, tile);
+            r0 = (tile - ts[c]) * kEvalTile;
+            clen = as_const<int64_t>(a.chunk_len)[c];
+            kc = const_col(a.keys, c);
+        }
+        const int64_t row = r0 + lane * 16 + (int)((tile * 7) & 15);
+        if (row < clen) {
+            const uint64_t hk = g2_hash(normalize_int(a.key_dtype, g2_load_raw(kc.values, ksz, kc.offset + row, true)));
+            atomicAdd(&h[(uint32_t)(hk >> (64 - kG2PartBits))], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kP; i += 256) if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -828,6 +862,12 @@ hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)gb2_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(gb2_stream_kernel<false>, dim3(grid), dim3(kStreamBlock), lds, s, a);
     }
+    return hipGetLastError();
+}
+hipError_t launch_gb2_skew_probe(const Gb2Args& a, int64_t tile_step, unsigned int* hist, hipStream_t s) {
+    const int64_t sampled = (a.ntiles + tile_step - 1) / tile_step;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((sampled + 3) / 4, 1024));
+    hipLaunchKernelGGL(gb2_skew_probe_kernel, dim3(grid), dim3(256), 0, s, a, tile_step, hist);
     return hipGetLastError();
 }
 hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s) {

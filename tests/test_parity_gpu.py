@@ -496,6 +496,41 @@ def test_specialised_kernels_are_the_ones_that_run(gpu, request):
         assert kern.startswith("spec_kernel<" if spec_mode else "eval_kernel<"), f"{name}: ran {kern}"
 
 
+def test_worker_threads_own_their_contexts(gpu, ora):
+    """Every entry point is re-entrant with per-thread state (the reference runs its kernels on rayon workers,
+    src/functions/scalar.rs:28,99): calls from short-lived threads give the oracle's results, an error in one thread
+    leaves the others alone, and the contexts of exited threads are released (the main thread keeps working)."""
+    import threading
+    rng = np.random.default_rng(5)
+    a = make_chunks(rng, A.F64, [5000, 1200], 0.1, 0)
+    b = make_chunks(rng, A.F64, [5000, 1200], 0.0, 0, nonzero=True)
+    zeros = [A.HostArray.from_numpy(np.zeros(n)) for n in (5000, 1200)]
+    exp = ora.binary("divide", a, b)
+    exp_sum = ora.sum(a)
+    results, errors = {}, {}
+
+    def work(i):
+        try:
+            if i == 3:   # a failing call, found out on the device: a zero divisor at a valid slot
+                gpu.binary("divide", a, zeros)
+            results[i] = (gpu.binary("divide", a, b), gpu.sum(a))
+        except Exception as ex:   # noqa: BLE001
+            errors[i] = ex
+
+    for _ in range(2):
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert set(errors) == {3} and isinstance(errors[3], A.RdfError) and errors[3].status == A.RDF_DIVIDE_BY_ZERO
+        for i, (chunks, total) in results.items():
+            assert_chunks_match(chunks, exp, exact=True, what=f"thread {i}")
+            assert abs(total - exp_sum) <= 1e-9 * max(1.0, abs(exp_sum))
+        results.clear(); errors.clear()
+    assert_chunks_match(gpu.binary("divide", a, b), exp, exact=True, what="main thread afterwards")
+
+
 def test_sort_reference_case(gpu, ora):
     """test_sort (src/dataframe.rs:963-1003): a desc, b asc, nulls last -> a = [4,3,3,1,1,null], b = [8,4,7,5,9,6]."""
     a = A.HostArray.from_numpy(np.array([1, 1, 0, 3, 3, 4], dtype=np.int32), valid=[1, 1, 0, 1, 1, 1])
