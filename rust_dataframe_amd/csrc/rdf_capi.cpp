@@ -47,7 +47,7 @@ struct Ctx {
     // tunables (rdf_set_option)
     bool   opt_spec = true;        // specialised straight-line kernels (rdf_spec.hip)
     bool   opt_fast_filter = true; // filter_agg_f64_kernel (handles 8-byte-misaligned columns)
-    bool   opt_vec_bitmap = true;  // bitmap words via vector loads (default) instead of scalar loads (spec kernels)
+    bool   opt_vec_bitmap = false; // validity words of the specialised kernels: scalar loads (default since the wave-granular tiles: 1.30 vs 1.355 ms on the 1e9-row filter->sum with nulls) or one vector load by lanes 0..NW + readlane (A/B; it was the faster one with block-wide tiles)
     bool   opt_filter_one = true;   // one-chunk compaction kernel with its descriptors in the kernel arguments (A/B)
     int    opt_filter_gen = 2;      // compaction kernels: 2 = wave-granular tiles (rdf_filter.hip, default), 1 = first-generation block tiles (A/B)
     int    opt_filter_tile = 0;     // 0: compaction tile chosen from the mean chunk length; 1024 / 4096 force one (A/B)

@@ -36,7 +36,7 @@ template <class T> __device__ __forceinline__ GlobalMutPtr<T> as_global_mut(void
 __device__ __forceinline__ int clamp64(int64_t v) { return v <= 0 ? 0 : (v >= 64 ? 64 : (int)v); }
 
 // NW consecutive 64-bit windows of an LSB-first bitmap starting at bit `bitpos` (wave-uniform), rows
-// past `nbits` cleared.  Scalar-load variant (kept as the A/B baseline, rdf_set_option("vec_bitmap", 0)):
+// past `nbits` cleared.  Scalar-load variant (the specialised kernels' default):
 // all NW+1 aligned words are fetched with independent scalar loads (indices
 // clamped to the last word that holds a requested bit, so nothing outside the ABI's "readable to the
 // next 8-byte boundary" is touched) and funnel-shifted on the scalar unit: no branches between the
@@ -66,10 +66,11 @@ __device__ __forceinline__ void load_windows_s(const uint8_t* base, int64_t bitp
     }
 }
 
-// The default: same result, but the aligned words travel through the VECTOR memory path (one
-// global_load_dwordx2 by lanes 0..NW, then v_readlane into scalars).  The scalar data cache is not built
-// for streaming a bitmap every wave touches exactly once: measured on MI355X at 1e9 rows, filter->sum with
-// a validity bitmap runs at 0.80 of HBM peak this way vs 0.69-0.74 with scalar loads (profiles/).
+// Same result, but the aligned words travel through the VECTOR memory path (one global_load_dwordx2 by lanes 0..NW, then
+// v_readlane into scalars).  With block-wide tiles (round 1) this was the faster way to stream a bitmap every wave touches
+// once (0.80 of peak vs 0.69-0.74 with scalar loads); with wave-granular tiles and the next tile located under the
+// current tile's loads the scalar variant is level or ahead (1.30 vs 1.355 ms per 1e9 rows) and is the default; kept as
+// the A/B (rdf_set_option("vec_bitmap", 1)) and for the kernels that have every lane busy anyway.
 // Must be called with all lanes of the wave active.
 template <int NW>
 __device__ __forceinline__ void load_windows(const uint8_t* base, int64_t bitpos, int64_t nbits, uint64_t (&win)[NW]) {

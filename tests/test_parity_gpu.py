@@ -496,6 +496,30 @@ def test_specialised_kernels_are_the_ones_that_run(gpu, request):
         assert kern.startswith("spec_kernel<" if spec_mode else "eval_kernel<"), f"{name}: ran {kern}"
 
 
+def test_validity_window_load_paths_agree(gpu, ora):
+    """The specialised kernels fetch a wave's validity words either with scalar loads (default) or with one vector load by
+    lanes 0..NW and readlane (rdf_set_option("vec_bitmap", 1)): both give the oracle's aggregates and bitmaps on aligned,
+    offset and many-chunk layouts."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(77)
+    e = A.Expr()
+    c0, c1 = e.col(0), e.col(1)
+    pred = e.op("gt", c0, e.scalar(0.1))
+    try:
+        for lens, off in [([8192], 0), ([5000, 0, 3000, 1024], 0), ([1024] * 9 + [700], 0), ([4096, 1000], 16)]:
+            x = make_chunks(rng, A.F64, lens, 0.2, off, "unit")
+            y = make_chunks(rng, A.F64, lens, 0.1, off, "unit")
+            exp = ora.pipeline(e, [x, y], [c1], pred)[0]
+            exp_add = ora.binary("add", x, y)
+            for vb in (0, 1):
+                lib.set_option("vec_bitmap", vb)
+                got = gpu.pipeline(e, [x, y], [c1], pred)[0]
+                assert got.count == exp.count and abs(got.sum - exp.sum) <= 1e-9 * max(1.0, abs(exp.sum)), f"vec_bitmap={vb} lens={lens}"
+                assert_chunks_match(gpu.binary("add", x, y), exp_add, exact=True, what=f"vec_bitmap={vb} lens={lens}")
+    finally:
+        lib.set_option("vec_bitmap", 0)
+
+
 def test_worker_threads_own_their_contexts(gpu, ora):
     """Every entry point is re-entrant with per-thread state (the reference runs its kernels on rayon workers,
     src/functions/scalar.rs:28,99): calls from short-lived threads give the oracle's results, an error in one thread

@@ -369,7 +369,7 @@ def main():
                 cc, aggs, fn = A._flat([XVS], len(XVS)), (A.rdf_agg_result * A.MAX_VALUES)(), api._fn("pipeline")
                 report("filter_sum_validity_chunked_1024_descriptors_prebuilt", 8.125 * ns_,
                        lambda: api._check(fn(C.byref(prog), cc, C.c_int32(1), C.c_int64(len(XVS)), None, aggs)))
-    lib.set_option("vec_bitmap", 1)
+    lib.set_option("vec_bitmap", 0)
     return results
 
 
