@@ -889,11 +889,13 @@ class DataFrame {
     }
 
     // DataFrame::from_arrow (src/dataframe.rs:391-407: arrow::ipc::reader::FileReader -> Table::from_record_batches):
-    // reads an Arrow IPC FILE.  The flatbuffer metadata (Footer -> Schema, Blocks; Message -> RecordBatch) is decoded
-    // in place with a minimal reader; every column buffer goes from the file image straight to HBM with one H2D copy
-    // (no per-value parsing, no intermediate arrays): one chunk per record batch.  Primitive numeric and Boolean
-    // columns are on the compute path, Utf8 is carried opaquely; other types, dictionaries and compressed bodies are
-    // rejected with an error.
+    // reads an Arrow IPC FILE or an IPC STREAM (told apart by the magic).  The flatbuffer metadata (Footer -> Schema,
+    // Blocks; Message -> Schema / DictionaryBatch / RecordBatch) is decoded in place with a minimal reader; every column
+    // buffer goes from the file image straight to HBM with one H2D copy (no per-value parsing, no intermediate arrays):
+    // one chunk per record batch.  Primitive numeric and Boolean columns are on the compute path, Utf8 is carried
+    // opaquely.  Dictionary-encoded columns (numeric or Utf8 values, any integer index type; delta and replacement
+    // dictionaries of the stream format) are decoded while loading — the frame holds plain columns, as the reference's
+    // kernels expect.  Nested types and compressed bodies are rejected with an error.
     static DataFrame from_arrow(const std::string& path) {
         std::ifstream f(path, std::ios::binary);
         if (!f) throw DataFrameError(DataFrameError::IoError, "cannot open " + path);
@@ -901,128 +903,274 @@ class DataFrame {
         return from_arrow_image(img.data(), img.size());
     }
     static DataFrame from_arrow_image(const uint8_t* img, size_t size) {
-        auto bad = [](const std::string& m) -> DataFrameError { return DataFrameError(DataFrameError::IoError, "Arrow IPC: " + m); };
-        if (size < 20 || std::memcmp(img, "ARROW1", 6) != 0 || std::memcmp(img + size - 6, "ARROW1", 6) != 0) throw bad("not an Arrow IPC file (magic)");
-        int32_t flen;
-        std::memcpy(&flen, img + size - 10, 4);
-        if (flen <= 0 || (size_t)flen + 18 > size) throw bad("bad footer length");
-        const FlatBuf fb{img, size};
-        const size_t footer = fb.root(size - 10 - (size_t)flen);
-        // Footer: 0 version, 1 schema, 2 dictionaries, 3 recordBatches
-        const size_t schema_t = fb.table_field(footer, 1);
-        if (!schema_t) throw bad("footer without a schema");
-        if (fb.vec_len(fb.field_pos(footer, 2)) != 0) throw bad("dictionary-encoded columns are not supported");
-        // Schema: 0 endianness, 1 fields
-        if (fb.scalar<int16_t>(schema_t, 0, 0) != 0) throw bad("big-endian files are not supported");
-        const size_t fields_v = fb.field_pos(schema_t, 1);
-        const size_t nfields = fb.vec_len(fields_v);
-        std::vector<Field> fields;
-        for (size_t i = 0; i < nfields; ++i) {
-            // Field: 0 name, 1 nullable, 2 type_type, 3 type, 4 dictionary, 5 children
-            const size_t ft = fb.vec_table(fields_v, i);
-            Field fld;
-            fld.name = fb.string(ft, 0);
-            fld.nullable = fb.scalar<uint8_t>(ft, 1, 0) != 0;
-            if (fb.field_pos(ft, 4)) throw bad("dictionary-encoded column " + fld.name);
-            const int tt = fb.scalar<uint8_t>(ft, 2, 0);
-            const size_t ty = fb.table_field(ft, 3);
-            if (tt == 2) {         // Int { 0 bitWidth, 1 is_signed }
-                const int bw = fb.scalar<int32_t>(ty, 0, 0);
-                const bool sg = fb.scalar<uint8_t>(ty, 1, 0) != 0;
-                switch (bw) {
-                    case 8: fld.data_type = sg ? DataType::Int8 : DataType::UInt8; break;
-                    case 16: fld.data_type = sg ? DataType::Int16 : DataType::UInt16; break;
-                    case 32: fld.data_type = sg ? DataType::Int32 : DataType::UInt32; break;
-                    case 64: fld.data_type = sg ? DataType::Int64 : DataType::UInt64; break;
-                    default: throw bad("integer width of column " + fld.name);
-                }
-            } else if (tt == 3) {  // FloatingPoint { 0 precision: HALF, SINGLE, DOUBLE }
-                const int pr = fb.scalar<int16_t>(ty, 0, 0);
-                if (pr == 1) fld.data_type = DataType::Float32; else if (pr == 2) fld.data_type = DataType::Float64; else throw bad("half floats (column " + fld.name + ")");
-            } else if (tt == 6) fld.data_type = DataType::Boolean;
-            else if (tt == 5) fld.data_type = DataType::Utf8;
-            else throw bad("column " + fld.name + ": unsupported type id " + std::to_string(tt));
-            fields.push_back(fld);
+        IpcReader r(img, size);
+        if (size >= 20 && std::memcmp(img, "ARROW1", 6) == 0) r.read_file(); else r.read_stream();
+        return r.finish();
+    }
+
+  private:
+    struct IpcReader {
+        struct Dict { bool utf8 = false; DataType dt = DataType::Int64; std::vector<std::string> strs; std::vector<uint8_t> values; std::vector<bool> valid; int64_t n = 0; };
+        struct Col { Field field; bool dict = false; int64_t dict_id = 0; DataType index_type = DataType::Int32; };
+        const uint8_t* img; size_t size; FlatBuf fb;
+        std::vector<Col> cols;
+        std::map<int64_t, Dict> dicts;
+        std::vector<std::vector<ArrayRef>> chunks;
+        IpcReader(const uint8_t* i, size_t n) : img(i), size(n), fb{i, n} {}
+        static DataFrameError bad(const std::string& m) { return DataFrameError(DataFrameError::IoError, "Arrow IPC: " + m); }
+
+        static DataType int_type(const FlatBuf& fb, size_t ty, const std::string& name) {   // Int { 0 bitWidth, 1 is_signed }
+            const int bw = fb.scalar<int32_t>(ty, 0, 0);
+            const bool sg = fb.scalar<uint8_t>(ty, 1, 0) != 0;
+            switch (bw) {
+                case 8: return sg ? DataType::Int8 : DataType::UInt8;
+                case 16: return sg ? DataType::Int16 : DataType::UInt16;
+                case 32: return sg ? DataType::Int32 : DataType::UInt32;
+                case 64: return sg ? DataType::Int64 : DataType::UInt64;
+                default: throw bad("integer width of column " + name);
+            }
         }
-        // record batch blocks: struct Block { int64 offset; int32 metaDataLength; (pad) int64 bodyLength; } = 24 bytes
-        const size_t blocks_v = fb.field_pos(footer, 3);
-        const size_t nblocks = fb.vec_len(blocks_v);
-        std::vector<std::vector<ArrayRef>> chunks(nfields);
-        for (size_t b = 0; b < nblocks; ++b) {
-            const uint8_t* blk = fb.vec_struct(blocks_v, b, 24);
-            int64_t off, body_len; int32_t meta_len;
-            std::memcpy(&off, blk, 8); std::memcpy(&meta_len, blk + 8, 4); std::memcpy(&body_len, blk + 16, 8);
-            if (off < 0 || meta_len < 8 || body_len < 0 || (uint64_t)off + (uint64_t)meta_len + (uint64_t)body_len > size) throw bad("block out of bounds");
-            size_t mpos = (size_t)off;
-            uint32_t first;
-            std::memcpy(&first, img + mpos, 4);
-            mpos += first == 0xFFFFFFFFu ? 8 : 4;   // continuation marker + length, or the pre-0.15 length only
-            const size_t msg = fb.root(mpos);
-            // Message: 0 version, 1 header_type, 2 header, 3 bodyLength
-            if (fb.scalar<uint8_t>(msg, 1, 0) != 3) throw bad("block is not a RecordBatch message");
-            const size_t rb = fb.table_field(msg, 2);
-            // RecordBatch: 0 length, 1 nodes [FieldNode{int64 length, int64 null_count}], 2 buffers [Buffer{int64 offset, int64 length}], 3 compression
+        void read_schema(size_t schema_t) {   // Schema: 0 endianness, 1 fields
+            if (!schema_t) throw bad("no schema");
+            if (fb.scalar<int16_t>(schema_t, 0, 0) != 0) throw bad("big-endian data is not supported");
+            const size_t fields_v = fb.field_pos(schema_t, 1);
+            const size_t nfields = fb.vec_len(fields_v);
+            for (size_t i = 0; i < nfields; ++i) {
+                // Field: 0 name, 1 nullable, 2 type_type, 3 type, 4 dictionary, 5 children
+                const size_t ft = fb.vec_table(fields_v, i);
+                Col c;
+                c.field.name = fb.string(ft, 0);
+                c.field.nullable = fb.scalar<uint8_t>(ft, 1, 0) != 0;
+                const int tt = fb.scalar<uint8_t>(ft, 2, 0);
+                const size_t ty = fb.table_field(ft, 3);
+                if (tt == 2) c.field.data_type = int_type(fb, ty, c.field.name);
+                else if (tt == 3) {  // FloatingPoint { 0 precision: HALF, SINGLE, DOUBLE }
+                    const int pr = fb.scalar<int16_t>(ty, 0, 0);
+                    if (pr == 1) c.field.data_type = DataType::Float32; else if (pr == 2) c.field.data_type = DataType::Float64; else throw bad("half floats (column " + c.field.name + ")");
+                } else if (tt == 6) c.field.data_type = DataType::Boolean;
+                else if (tt == 5) c.field.data_type = DataType::Utf8;
+                else throw bad("column " + c.field.name + ": unsupported type id " + std::to_string(tt));
+                if (const size_t de = fb.table_field(ft, 4)) {   // DictionaryEncoding { 0 id, 1 indexType: Int (default int32), 2 isOrdered, 3 dictionaryKind }
+                    c.dict = true;
+                    c.dict_id = fb.scalar<int64_t>(de, 0, 0);
+                    const size_t it = fb.table_field(de, 1);
+                    c.index_type = it ? int_type(fb, it, c.field.name) : DataType::Int32;
+                    if (c.field.data_type == DataType::Boolean) throw bad("dictionary of Boolean values (column " + c.field.name + ")");
+                }
+                cols.push_back(c);
+            }
+            chunks.assign(cols.size(), {});
+        }
+        struct Body { const uint8_t* p; int64_t len; };
+        // one column's buffers out of a RecordBatch table: validity, values (Utf8: offsets, data)
+        struct ColBufs { int64_t len, nulls, vo, vl, d0, dl, so, sl; };
+        struct BatchCursor { size_t nodes_v, bufs_v, ni = 0, bi = 0; };
+        ColBufs next_col(BatchCursor& cur, const Body& body, bool utf8) {
+            if (cur.ni >= fb.vec_len(cur.nodes_v)) throw bad("field node list too short");
+            const uint8_t* node = fb.vec_struct(cur.nodes_v, cur.ni++, 16);
+            ColBufs b{};
+            std::memcpy(&b.len, node, 8); std::memcpy(&b.nulls, node + 8, 8);
+            auto next_buf = [&](int64_t& bo, int64_t& bl) {
+                if (cur.bi >= fb.vec_len(cur.bufs_v)) throw bad("buffer list too short");
+                const uint8_t* p = fb.vec_struct(cur.bufs_v, cur.bi++, 16);
+                std::memcpy(&bo, p, 8); std::memcpy(&bl, p + 8, 8);
+                if (bo < 0 || bl < 0 || bo + bl > body.len) throw bad("buffer out of bounds");
+            };
+            next_buf(b.vo, b.vl);
+            next_buf(b.d0, b.dl);
+            if (utf8) next_buf(b.so, b.sl);
+            if (b.len < 0 || (b.nulls > 0 && b.vl < (b.len + 7) / 8)) throw bad("validity buffer too short");
+            return b;
+        }
+        static bool bit(const uint8_t* p, int64_t i) { return (p[i >> 3] >> (i & 7)) & 1; }
+        std::vector<std::string> read_strings(const ColBufs& b, const Body& body) {
+            if (b.dl < 4 * (b.len + 1) && b.len > 0) throw bad("string offsets buffer too short");
+            std::vector<std::string> strs((size_t)b.len);
+            for (int64_t r = 0; r < b.len; ++r) {
+                int32_t a0, a1;
+                std::memcpy(&a0, body.p + b.d0 + 4 * r, 4); std::memcpy(&a1, body.p + b.d0 + 4 * (r + 1), 4);
+                if (a0 < 0 || a1 < a0 || a1 > b.sl) throw bad("string offsets out of bounds");
+                strs[(size_t)r].assign((const char*)body.p + b.so + a0, (size_t)(a1 - a0));
+            }
+            return strs;
+        }
+        static ArrayRef strings_with_validity(std::vector<std::string> strs, const std::vector<bool>* valid) {
+            auto a = std::const_pointer_cast<Array>(Array::from_strings(std::move(strs)));
+            if (valid) {
+                const auto bits = pack_bits(*valid);
+                a->validity = std::make_shared<DeviceBuffer>((int64_t)bits.size() + 8);
+                check(rdf_copy_h2d(a->validity->data(), bits.data(), (int64_t)bits.size()));
+                for (bool v : *valid) a->null_count += !v;
+            }
+            return a;
+        }
+        // RecordBatch: 0 length, 1 nodes [FieldNode{int64 length, int64 null_count}], 2 buffers [Buffer{int64 offset, int64 length}], 3 compression
+        void read_record_batch(size_t rb, const Body& body) {
             if (fb.field_pos(rb, 3)) throw bad("compressed record batches are not supported");
             const int64_t nrows = fb.scalar<int64_t>(rb, 0, 0);
-            const size_t nodes_v = fb.field_pos(rb, 1), bufs_v = fb.field_pos(rb, 2);
-            if (fb.vec_len(nodes_v) != nfields) throw bad("nested columns are not supported");
-            const uint8_t* body = img + (size_t)off + (size_t)meta_len;
-            size_t bi = 0;
-            auto next_buf = [&](int64_t& bo, int64_t& bl) {
-                if (bi >= fb.vec_len(bufs_v)) throw bad("buffer list too short");
-                const uint8_t* p = fb.vec_struct(bufs_v, bi++, 16);
-                std::memcpy(&bo, p, 8); std::memcpy(&bl, p + 8, 8);
-                if (bo < 0 || bl < 0 || bo + bl > body_len) throw bad("buffer out of bounds");
-            };
-            for (size_t c = 0; c < nfields; ++c) {
-                const uint8_t* node = fb.vec_struct(nodes_v, c, 16);
-                int64_t len, nulls;
-                std::memcpy(&len, node, 8); std::memcpy(&nulls, node + 8, 8);
-                if (len != nrows) throw bad("column length differs from the batch length");
-                int64_t vo, vl, do_, dl;
-                next_buf(vo, vl);   // validity
-                next_buf(do_, dl);  // values (Utf8: offsets)
-                const DataType dt = fields[c].data_type;
+            BatchCursor cur{fb.field_pos(rb, 1), fb.field_pos(rb, 2)};
+            if (fb.vec_len(cur.nodes_v) != cols.size()) throw bad("nested columns are not supported");
+            for (size_t c = 0; c < cols.size(); ++c) {
+                const Col& col = cols[c];
+                const DataType dt = col.field.data_type;
+                const ColBufs b = next_col(cur, body, dt == DataType::Utf8 && !col.dict);
+                if (b.len != nrows) throw bad("column length differs from the batch length");
+                if (col.dict) { chunks[c].push_back(decode_dictionary_column(col, b, body)); continue; }
                 if (dt == DataType::Utf8) {
-                    int64_t so, sl;
-                    next_buf(so, sl);
-                    std::vector<std::string> strs((size_t)len);
-                    for (int64_t r = 0; r < len; ++r) {
-                        int32_t a0, a1;
-                        std::memcpy(&a0, body + do_ + 4 * r, 4); std::memcpy(&a1, body + do_ + 4 * (r + 1), 4);
-                        if (a0 < 0 || a1 < a0 || a1 > sl) throw bad("string offsets out of bounds");
-                        strs[(size_t)r].assign((const char*)body + so + a0, (size_t)(a1 - a0));
-                    }
-                    chunks[c].push_back(Array::from_strings(std::move(strs)));
+                    std::vector<bool> valid;
+                    if (b.nulls > 0) { valid.resize((size_t)b.len); for (int64_t r = 0; r < b.len; ++r) valid[(size_t)r] = bit(body.p + b.vo, r); }
+                    chunks[c].push_back(strings_with_validity(read_strings(b, body), b.nulls > 0 ? &valid : nullptr));
                     continue;
                 }
-                const int64_t need = dt == DataType::Boolean ? (len + 7) / 8 : len * (int64_t)type_size(dt);
-                if (dl < need) throw bad("values buffer of column " + fields[c].name + " is too short");
+                const int64_t need = dt == DataType::Boolean ? (b.len + 7) / 8 : b.len * (int64_t)type_size(dt);
+                if (b.dl < need) throw bad("values buffer of column " + col.field.name + " is too short");
                 auto a = std::make_shared<Array>();
                 a->dtype = dt;
-                a->length = len;
+                a->length = b.len;
                 a->values = std::make_shared<DeviceBuffer>(need + 8);
-                if (need) check(rdf_copy_h2d(a->values->data(), body + do_, need));
-                if (nulls > 0) {
-                    if (vl < (len + 7) / 8) throw bad("validity buffer of column " + fields[c].name + " is too short");
-                    a->validity = std::make_shared<DeviceBuffer>((len + 7) / 8 + 8);
-                    check(rdf_copy_h2d(a->validity->data(), body + vo, (len + 7) / 8));
-                    a->null_count = nulls;
+                if (need) check(rdf_copy_h2d(a->values->data(), body.p + b.d0, need));
+                if (b.nulls > 0) {
+                    a->validity = std::make_shared<DeviceBuffer>((b.len + 7) / 8 + 8);
+                    check(rdf_copy_h2d(a->validity->data(), body.p + b.vo, (b.len + 7) / 8));
+                    a->null_count = b.nulls;
                 }
                 chunks[c].push_back(a);
             }
         }
-        std::vector<Column> cols;
-        for (size_t c = 0; c < nfields; ++c) {
-            if (chunks[c].empty()) {   // a file without record batches still has its schema: one empty chunk per column
-                if (fields[c].data_type == DataType::Utf8) chunks[c].push_back(Array::from_strings({}));
-                else { auto a = Array::make_out(fields[c].data_type, 0, false); chunks[c].push_back(a); }
+        // DictionaryBatch { 0 id, 1 data: RecordBatch (one column = the dictionary's values), 2 isDelta }
+        void read_dictionary_batch(size_t db, const Body& body) {
+            const int64_t id = fb.scalar<int64_t>(db, 0, 0);
+            const bool delta = fb.scalar<uint8_t>(db, 2, 0) != 0;
+            const size_t rb = fb.table_field(db, 1);
+            if (!rb) throw bad("dictionary batch without data");
+            if (fb.field_pos(rb, 3)) throw bad("compressed dictionary batches are not supported");
+            const Col* owner = nullptr;
+            for (auto& c : cols) if (c.dict && c.dict_id == id) owner = &c;
+            if (!owner) throw bad("dictionary " + std::to_string(id) + " belongs to no column");
+            BatchCursor cur{fb.field_pos(rb, 1), fb.field_pos(rb, 2)};
+            const bool utf8 = owner->field.data_type == DataType::Utf8;
+            const ColBufs b = next_col(cur, body, utf8);
+            Dict fresh;
+            Dict& d = delta && dicts.count(id) ? dicts[id] : fresh;
+            d.utf8 = utf8; d.dt = owner->field.data_type;
+            for (int64_t r = 0; r < b.len; ++r) d.valid.push_back(b.nulls > 0 ? bit(body.p + b.vo, r) : true);
+            if (utf8) { auto s = read_strings(b, body); d.strs.insert(d.strs.end(), s.begin(), s.end()); }
+            else {
+                const int64_t es = (int64_t)type_size(d.dt);
+                if (b.dl < b.len * es) throw bad("dictionary values buffer too short");
+                d.values.insert(d.values.end(), body.p + b.d0, body.p + b.d0 + b.len * es);
             }
-            cols.push_back(Column::from_arrays(chunks[c], fields[c]));
+            d.n += b.len;
+            if (&d == &fresh) dicts[id] = std::move(fresh);   // first sight of the id, or a replacement dictionary (stream format)
         }
-        return from_columns(std::move(cols));
-    }
+        ArrayRef decode_dictionary_column(const Col& col, const ColBufs& b, const Body& body) {
+            auto it = dicts.find(col.dict_id);
+            if (it == dicts.end()) throw bad("record batch before the dictionary of column " + col.field.name);
+            const Dict& d = it->second;
+            const int64_t is = (int64_t)type_size(col.index_type);
+            if (b.dl < b.len * is) throw bad("index buffer of column " + col.field.name + " is too short");
+            const bool sg = col.index_type == DataType::Int8 || col.index_type == DataType::Int16 || col.index_type == DataType::Int32 || col.index_type == DataType::Int64;
+            std::vector<bool> valid((size_t)b.len, true);
+            bool any_null = false;
+            std::vector<int64_t> idx((size_t)b.len, 0);
+            for (int64_t r = 0; r < b.len; ++r) {
+                if (b.nulls > 0 && !bit(body.p + b.vo, r)) { valid[(size_t)r] = false; any_null = true; continue; }
+                uint64_t raw = 0;
+                std::memcpy(&raw, body.p + b.d0 + r * is, (size_t)is);
+                int64_t v = (int64_t)raw;
+                if (sg && is < 8) { const int sh = 64 - 8 * (int)is; v = (int64_t)(raw << sh) >> sh; }
+                if (v < 0 || v >= d.n) throw bad("dictionary index out of range in column " + col.field.name);
+                if (!d.valid[(size_t)v]) { valid[(size_t)r] = false; any_null = true; continue; }
+                idx[(size_t)r] = v;
+            }
+            if (d.utf8) {
+                std::vector<std::string> strs((size_t)b.len);
+                for (int64_t r = 0; r < b.len; ++r) if (valid[(size_t)r]) strs[(size_t)r] = d.strs[(size_t)idx[(size_t)r]];
+                return strings_with_validity(std::move(strs), any_null ? &valid : nullptr);
+            }
+            const int64_t es = (int64_t)type_size(d.dt);
+            std::vector<uint8_t> vals((size_t)(b.len * es) + 8, 0);
+            for (int64_t r = 0; r < b.len; ++r) if (valid[(size_t)r]) std::memcpy(vals.data() + r * es, d.values.data() + idx[(size_t)r] * es, (size_t)es);
+            auto a = std::make_shared<Array>();
+            a->dtype = d.dt;
+            a->length = b.len;
+            a->values = std::make_shared<DeviceBuffer>(b.len * es + 8);
+            if (b.len) check(rdf_copy_h2d(a->values->data(), vals.data(), b.len * es));
+            if (any_null) {
+                const auto bits = pack_bits(valid);
+                a->validity = std::make_shared<DeviceBuffer>((int64_t)bits.size() + 8);
+                check(rdf_copy_h2d(a->validity->data(), bits.data(), (int64_t)bits.size()));
+                for (bool v : valid) a->null_count += !v;
+            }
+            return a;
+        }
+        // one encapsulated message at `pos`: [0xFFFFFFFF] int32 metadata length, flatbuffer Message, body.  Returns the position
+        // behind the body, 0 at the end-of-stream marker.  Message: 0 version, 1 header_type, 2 header, 3 bodyLength
+        size_t read_message(size_t pos, int64_t known_body_len, bool want_batches_only) {
+            if (pos + 4 > size) return 0;
+            uint32_t first;
+            std::memcpy(&first, img + pos, 4);
+            size_t mpos = pos + 4;
+            uint32_t meta_len = first;
+            if (first == 0xFFFFFFFFu) { if (pos + 8 > size) return 0; std::memcpy(&meta_len, img + pos + 4, 4); mpos = pos + 8; }
+            if (meta_len == 0) return 0;   // end of stream
+            if (mpos + meta_len > size) throw bad("message metadata out of bounds");
+            const size_t msg = fb.root(mpos);
+            const int kind = fb.scalar<uint8_t>(msg, 1, 0);
+            const int64_t body_len = known_body_len >= 0 ? known_body_len : fb.scalar<int64_t>(msg, 3, 0);
+            const size_t body_pos = mpos + meta_len;
+            if (body_len < 0 || body_pos + (uint64_t)body_len > size) throw bad("message body out of bounds");
+            const Body body{img + body_pos, body_len};
+            const size_t hdr = fb.table_field(msg, 2);
+            if (kind == 1) { if (!want_batches_only && cols.empty()) read_schema(hdr); }
+            else if (kind == 2) read_dictionary_batch(hdr, body);
+            else if (kind == 3) read_record_batch(hdr, body);
+            else throw bad("unsupported message type " + std::to_string(kind));
+            return body_pos + (size_t)body_len;
+        }
+        void read_stream() {
+            size_t pos = 0;
+            while (pos < size) {
+                const size_t next = read_message(pos, -1, false);
+                if (!next) break;
+                if (cols.empty()) throw bad("stream does not start with a schema");
+                pos = (next + 7) & ~(size_t)7;
+            }
+            if (cols.empty()) throw bad("not an Arrow IPC file or stream");
+        }
+        void read_file() {
+            if (std::memcmp(img + size - 6, "ARROW1", 6) != 0) throw bad("not an Arrow IPC file (magic)");
+            int32_t flen;
+            std::memcpy(&flen, img + size - 10, 4);
+            if (flen <= 0 || (size_t)flen + 18 > size) throw bad("bad footer length");
+            const size_t footer = fb.root(size - 10 - (size_t)flen);
+            // Footer: 0 version, 1 schema, 2 dictionaries, 3 recordBatches; Block { int64 offset; int32 metaDataLength; (pad) int64 bodyLength } = 24 bytes
+            read_schema(fb.table_field(footer, 1));
+            for (int list : {2, 3}) {
+                const size_t blocks_v = fb.field_pos(footer, list);
+                for (size_t b = 0; b < fb.vec_len(blocks_v); ++b) {
+                    const uint8_t* blk = fb.vec_struct(blocks_v, b, 24);
+                    int64_t off, body_len; int32_t meta_len;
+                    std::memcpy(&off, blk, 8); std::memcpy(&meta_len, blk + 8, 4); std::memcpy(&body_len, blk + 16, 8);
+                    if (off < 0 || meta_len < 8 || body_len < 0 || (uint64_t)off + (uint64_t)meta_len + (uint64_t)body_len > size) throw bad("block out of bounds");
+                    read_message((size_t)off, body_len, true);
+                }
+            }
+        }
+        DataFrame finish() {
+            std::vector<Column> out;
+            for (size_t c = 0; c < cols.size(); ++c) {
+                if (chunks[c].empty()) {   // no record batches: the schema alone, one empty chunk per column
+                    if (cols[c].field.data_type == DataType::Utf8) chunks[c].push_back(Array::from_strings({}));
+                    else chunks[c].push_back(Array::make_out(cols[c].field.data_type, 0, false));
+                }
+                out.push_back(Column::from_arrays(chunks[c], cols[c].field));
+            }
+            return from_columns(std::move(out));
+        }
+    };
 
+  public:
     const Schema& schema() const { return schema_; }
     size_t num_columns() const { return columns_.size(); }
     size_t num_chunks() const { return columns_.empty() ? 0 : columns_[0].data().num_chunks(); }

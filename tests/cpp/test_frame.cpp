@@ -727,6 +727,55 @@ TEST(test_from_arrow_ipc_file) {
 }
 
 // src/functions/scalar.rs:267-273 (no reference test): 2020-10-17T13:45:10Z in four units, a pre-epoch instant, a NULL
+// Dictionary-encoded columns and the IPC STREAM format (tests/golden/make_arrow_fixture.py: closed formulas of the global
+// row number): utf8 / float64 / int32 dictionaries under int8 / int16 / uint8 indices, NULL indices, delta dictionaries
+// between the batches of the stream; the FILE holds the same rows under one unified dictionary.  Decoded while loading.
+static void check_dictionary_frame(const DataFrame& df) {
+    const std::vector<int64_t> lens{700, 300, 524};
+    const std::vector<int64_t> ks{5, 8, 11};
+    CHECK_EQ(df.num_columns(), 4u);
+    CHECK_EQ(df.num_chunks(), lens.size());
+    CHECK_EQ(df.num_rows(), (int64_t)1524);
+    CHECK(df.column_by_name("i64").data_type() == DataType::Int64);
+    CHECK(df.column_by_name("code").data_type() == DataType::Utf8);
+    CHECK(df.column_by_name("level").data_type() == DataType::Float64);
+    CHECK(df.column_by_name("small").data_type() == DataType::Int32);
+    int64_t first = 0, level_nulls = 0, code_nulls = 0;
+    for (size_t b = 0; b < lens.size(); ++b) {
+        const auto ic = df.column_by_name("i64").data().chunk(b);
+        const auto cc = df.column_by_name("code").data().chunk(b);
+        const auto lc = df.column_by_name("level").data().chunk(b);
+        const auto sc = df.column_by_name("small").data().chunk(b);
+        CHECK_EQ(ic->length, lens[b]); CHECK_EQ(cc->length, lens[b]); CHECK_EQ(lc->length, lens[b]); CHECK_EQ(sc->length, lens[b]);
+        const auto iv = host<int64_t>(ic);
+        const auto lv = host<double>(lc);
+        const auto sv = host<int32_t>(sc);
+        const auto lvalid = lc->valid_to_host(), cvalid = cc->valid_to_host();
+        for (int64_t r = 0; r < lens[b]; ++r) {
+            const int64_t i = first + r;
+            CHECK_EQ(iv[(size_t)r], i);
+            CHECK_EQ((int64_t)sv[(size_t)r], ((5 * i) % 4) * 1000 - 1500);
+            if (i % 13 == 0) { CHECK(!lvalid[(size_t)r]); ++level_nulls; } else { CHECK(lvalid[(size_t)r]); CHECK_EQ(lv[(size_t)r], 0.25 * (double)((3 * i) % 6)); }
+            if (i % 11 == 5) { CHECK(!cvalid[(size_t)r]); ++code_nulls; } else { CHECK(cvalid[(size_t)r]); CHECK_EQ((*cc->strings)[(size_t)r], "cat" + std::to_string((7 * i) % ks[b])); }
+        }
+        first += lens[b];
+    }
+    CHECK_EQ(df.column_by_name("level").null_count(), level_nulls);
+    CHECK_EQ(df.column_by_name("code").null_count(), code_nulls);
+    // the decoded columns are ordinary compute-path columns
+    int64_t want = 0;
+    for (int64_t i = 0; i < 1524; ++i) want += ((5 * i) % 4) * 1000 - 1500;
+    CHECK_EQ((int64_t)*AggregateFunctions::sum<int32_t>(df.column_by_name("small").data()), (int64_t)(int32_t)want);
+    CHECK_EQ(*AggregateFunctions::count(df.column_by_name("level").data()), (int64_t)1524 - level_nulls);
+}
+TEST(test_from_arrow_stream_with_delta_dictionaries) { check_dictionary_frame(DataFrame::from_arrow("tests/golden/dict_batches.arrows")); }
+TEST(test_from_arrow_file_with_dictionaries) { check_dictionary_frame(DataFrame::from_arrow("tests/golden/dict_batches.arrow")); }
+TEST(test_from_arrow_rejects_garbage) {
+    const std::vector<uint8_t> junk(64, 0x5A);
+    CHECK_THROWS(DataFrame::from_arrow_image(junk.data(), junk.size()));
+    CHECK_THROWS(DataFrame::from_arrow("tests/golden/uk_cities_with_headers.csv"));
+}
+
 TEST(test_hour_of_timestamps) {
     const int64_t t = 1602942310;
     std::vector<bool> valid{true, true, false};
