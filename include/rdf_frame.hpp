@@ -511,6 +511,56 @@ struct Lowered {
 // ------------------------------------------------------------------------------------------------
 // plan types (src/expression.rs:286-712) and operation builders (src/operation/scalar.rs)
 
+// ------------------------------------------------------------------------------------------------
+// CSV text -> cells and inferred column types, on the host (shared by DataFrame::from_csv and plan::Reader::get_dataset)
+struct CsvCells {
+    std::vector<std::string> header;
+    std::vector<std::vector<std::string>> cells;   // [column][row]
+};
+inline CsvCells read_csv_cells(const std::string& path, bool has_headers = true, char delimiter = ',', std::optional<size_t> max_records = std::nullopt) {
+    std::ifstream f(path);
+    if (!f) throw DataFrameError(DataFrameError::IoError, "cannot open " + path);
+    auto split = [delimiter](const std::string& line) {
+        std::vector<std::string> out; std::string cur; bool q = false;
+        for (char ch : line) { if (ch == '"') q = !q; else if (ch == delimiter && !q) { out.push_back(cur); cur.clear(); } else if (ch != '\r') cur += ch; }
+        out.push_back(cur);
+        return out;
+    };
+    CsvCells t;
+    std::string line;
+    bool first = true;
+    size_t rows = 0;
+    while (std::getline(f, line)) {
+        if (line.empty()) continue;
+        auto v = split(line);
+        if (first) {
+            first = false;
+            if (has_headers) { t.header = v; t.cells.resize(v.size()); continue; }
+            for (size_t i = 0; i < v.size(); ++i) t.header.push_back("column_" + std::to_string(i + 1));   // arrow's csv reader names
+            t.cells.resize(v.size());
+        }
+        if (max_records && rows >= *max_records) break;
+        v.resize(t.header.size());
+        for (size_t i = 0; i < t.header.size(); ++i) t.cells[i].push_back(v[i]);
+        ++rows;
+    }
+    return t;
+}
+// a column whose non-empty cells all parse as integers is Int64, as numbers Float64, as true / false Boolean, else Utf8
+inline DataType infer_csv_type(const std::vector<std::string>& col, bool* any_null = nullptr) {
+    auto is_int = [](const std::string& x) { char* e = nullptr; errno = 0; (void)std::strtoll(x.c_str(), &e, 10); return e != x.c_str() && !*e && errno == 0; };
+    auto is_num = [](const std::string& x) { char* e = nullptr; (void)std::strtod(x.c_str(), &e); return e != x.c_str() && !*e; };
+    auto is_bool = [](const std::string& x) { return x == "true" || x == "false" || x == "True" || x == "False" || x == "TRUE" || x == "FALSE"; };
+    bool all_int = true, all_num = true, all_bool = true, any = false, nulls = false;
+    for (auto& x : col) {
+        if (x.empty()) { nulls = true; continue; }
+        any = true;
+        all_int = all_int && is_int(x); all_num = all_num && is_num(x); all_bool = all_bool && is_bool(x);
+    }
+    if (any_null) *any_null = nulls;
+    return !any ? DataType::Utf8 : all_int ? DataType::Int64 : all_num ? DataType::Float64 : all_bool ? DataType::Boolean : DataType::Utf8;
+}
+
 namespace plan {
 
 struct Column {  // expression::Column {name, column_type: Scalar(dtype)}
@@ -682,14 +732,45 @@ using CotOperation = TrigOperation<ScalarFunction::Cotangent>;
 using SecOperation = TrigOperation<ScalarFunction::Secant>;
 using CscOperation = TrigOperation<ScalarFunction::Cosecant>;
 
+// Reader / DataSourceType / CsvReadOptions (src/expression.rs:344-378): where a plan's rows come from.  CSV and Arrow IPC are the
+// sources this mirror loads (the others are IO outside the hot path); the CSV options are what the optimiser pushes into.
+struct CsvReadOptions {
+    bool has_headers = true;
+    std::optional<uint8_t> delimiter;
+    std::optional<size_t> max_records;
+    size_t batch_size = 1024;
+    std::optional<std::vector<size_t>> projection;
+};
+struct Reader {
+    enum Source { Csv, Json, Arrow, Sql, Parquet } source = Csv;
+    std::string path;
+    CsvReadOptions csv;
+    static Reader Csv_(std::string p, CsvReadOptions o = CsvReadOptions()) { Reader r; r.source = Csv; r.path = std::move(p); r.csv = std::move(o); return r; }
+    static Reader Arrow_(std::string p) { Reader r; r.source = Arrow; r.path = std::move(p); return r; }
+    // Reader::get_dataset: the schema the source will produce (CSV: inferred from the text, host only)
+    Dataset get_dataset() const {
+        if (source != Csv) throw DataFrameError(DataFrameError::ComputeError, "get_dataset: only CSV sources are planned here");
+        const CsvCells t = read_csv_cells(path, csv.has_headers, (char)csv.delimiter.value_or((uint8_t)','), csv.max_records);
+        Dataset d;
+        d.name = "csv_source";
+        for (size_t i = 0; i < t.header.size(); ++i) {
+            if (csv.projection && std::find(csv.projection->begin(), csv.projection->end(), i) == csv.projection->end()) continue;
+            d.columns.push_back(Column{t.header[i], infer_csv_type(t.cells[i])});
+        }
+        return d;
+    }
+};
+
 struct Transformation {
     enum Kind { GroupAggregate, Calculate, Select, Drop, Limit, Filter, Sort, Join, Read } kind = Calculate;
+    Reader reader;                          // Read
     Calculation calc;                       // Calculate
     std::vector<std::string> names;         // Select / Drop / group columns
     std::vector<Aggregation> aggregations;  // GroupAggregate
     size_t limit = 0;
     FilterRef filter;
     std::vector<bool> sort_descending;      // Sort: per criterion (names holds the columns)
+    static Transformation Read_(Reader r) { Transformation t; t.kind = Read; t.reader = std::move(r); return t; }
     static Transformation Calculate_(Calculation c) { Transformation t; t.kind = Calculate; t.calc = std::move(c); return t; }
     static Transformation Filter_(FilterRef f) { Transformation t; t.kind = Filter; t.filter = std::move(f); return t; }
     static Transformation Limit_(size_t n) { Transformation t; t.kind = Limit; t.limit = n; return t; }
@@ -706,7 +787,111 @@ struct Computation {
     std::vector<Dataset> input;
     std::vector<Transformation> transformations;
     Dataset output;
+    static Computation empty() { return Computation(); }
+    // Computation::compute_read (src/expression.rs:571-578)
+    static Computation compute_read(const Reader& read) {
+        Computation c;
+        c.transformations = {Transformation::Read_(read)};
+        c.output = read.get_dataset();
+        return c;
+    }
+    bool is_single(Transformation::Kind k) const { return transformations.size() == 1 && transformations[0].kind == k; }
 };
+
+// optimise (src/optimiser.rs:5-101) over an unrolled plan (newest computation first, the read last), with its two helpers
+// (:103-181 optimise_read, :183-235 optimise_project_calc).  The same rules: two Limits merge into the smaller; a Limit sinks
+// below the computation that follows it; a Select / Limit in front of a CSV Read becomes the reader's projection /
+// max_records; a Select that names a computed column and all of its inputs is pushed above the Calculate, a Calculate whose
+// output is not selected is dropped.  Deliberate differences (intent reproduced, bugs not copied — this plan is evaluated, the
+// reference's is only printed): the projection indices are taken against the READ's columns (the reference enumerates the
+// Select's own output, right only while the selected columns are a prefix of the file's); the computation still pending when
+// the list ends is emitted (the reference returns without it unless optimise_read happened to emit it: [Calculate, Read] comes
+// back as [Calculate]); and where the reference's optimise_project_calc says "drop calculation" it returns the calculation and
+// drops the SELECT (its `project` argument is the calculate computation) — here the calculation goes and the select stays.
+inline std::pair<std::vector<Computation>, Computation> optimise_read(const Computation& input, const Computation& read, const Transformation& x, bool* emitted) {
+    std::vector<Computation> output;
+    Computation mutated = read;
+    const Reader& reader = read.transformations[0].reader;
+    *emitted = false;
+    if (reader.source != Reader::Csv) { output.push_back(input); return {output, mutated}; }   // no projection support (Arrow / Json / Parquet / Sql)
+    CsvReadOptions options = reader.csv;
+    if (x.kind == Transformation::Select && !options.projection) {
+        std::vector<size_t> proj;
+        Dataset out_ds;
+        out_ds.name = read.output.name;
+        for (size_t i = 0; i < read.output.columns.size(); ++i)
+            if (std::find(x.names.begin(), x.names.end(), read.output.columns[i].name) != x.names.end()) { proj.push_back(i); out_ds.columns.push_back(read.output.columns[i]); }
+        options.projection = proj;
+        mutated.transformations = {Transformation::Read_(Reader::Csv_(reader.path, options))};
+        mutated.output = out_ds;
+        output.push_back(mutated);
+        *emitted = true;
+    } else if (x.kind == Transformation::Limit) {
+        options.max_records = options.max_records ? std::min(*options.max_records, x.limit) : x.limit;
+        mutated.transformations = {Transformation::Read_(Reader::Csv_(reader.path, options))};
+        output.push_back(mutated);
+        *emitted = true;
+    } else {
+        output.push_back(input);   // Drop, a second projection, anything else: kept as it is
+    }
+    return {output, mutated};
+}
+inline std::pair<std::vector<Computation>, Computation> optimise_project_calc(const Computation& input, const Computation& project, const Transformation& x, const Calculation& calc) {
+    std::vector<Computation> output;
+    Computation mutated = project;
+    if (x.kind == Transformation::Select) {
+        const bool selected_output = std::find(x.names.begin(), x.names.end(), calc.output.name) != x.names.end();
+        if (!selected_output) return {output, input};     // the calculated column is not selected: the calculation is dropped, the select stays pending
+        size_t selected_inputs = 0;
+        for (auto& in : calc.inputs) selected_inputs += std::find(x.names.begin(), x.names.end(), in.name) != x.names.end();
+        if (selected_inputs == calc.inputs.size()) {     // every input is selected: the select moves above the calculation
+            output.push_back(input);
+            Dataset d;
+            d.name = mutated.output.name;
+            for (auto& c : mutated.output.columns) if (c.name != calc.output.name) d.columns.push_back(c);
+            mutated.output = d;
+            return {output, mutated};
+        }
+        output.push_back(input);   // an input of the calculation is not selected: both steps stay as they are
+    } else {
+        output.push_back(input);   // Drop
+    }
+    return {output, mutated};
+}
+inline std::vector<Computation> optimise(const std::vector<Computation>& computations) {
+    std::vector<Computation> output;
+    Computation input = Computation::empty();
+    bool pending = false;   // `input` holds a computation that is not in `output` yet
+    auto emit = [&](const Computation& c) { output.push_back(c); };
+    for (const Computation& c : computations) {
+        if (input.transformations.empty()) { input = c; pending = true; continue; }
+        const size_t ci = c.input.size(), ii = input.input.size();
+        if (ci == 0 && ii == 1 && c.is_single(Transformation::Read) && input.transformations.size() == 1) {
+            bool emitted = false;
+            auto r = optimise_read(input, c, input.transformations[0], &emitted);
+            for (auto& o : r.first) emit(o);
+            input = r.second;
+            pending = !emitted;
+        } else if (ci == 1 && ii == 1 && input.is_single(Transformation::Limit) && c.is_single(Transformation::Limit)) {
+            input.transformations = {Transformation::Limit_(std::min(input.transformations[0].limit, c.transformations[0].limit))};
+            emit(input);
+            pending = false;
+        } else if (ci == 1 && ii == 1 && input.is_single(Transformation::Limit) && !c.is_single(Transformation::Limit)) {
+            emit(c);               // the limit sinks below the computation that follows it; it stays the pending input
+        } else if (ci == 1 && ii == 1 && (input.is_single(Transformation::Select) || input.is_single(Transformation::Drop)) && c.is_single(Transformation::Calculate)) {
+            auto r = optimise_project_calc(input, c, input.transformations[0], c.transformations[0].calc);
+            for (auto& o : r.first) emit(o);
+            input = r.second;
+            pending = true;
+        } else {
+            if (pending) emit(input);
+            input = c;
+            pending = true;
+        }
+    }
+    if (pending && !input.transformations.empty()) emit(input);
+    return output;
+}
 
 // Calculation::calculate (src/expression.rs:433-499): name lookup + dispatch to the operation builders.
 inline std::vector<Transformation> calculate(const Dataset& ds, const std::vector<std::string>& in_col_names, const Function& function,
@@ -822,37 +1007,30 @@ class DataFrame {
     // slices of that buffer (chunk i = offset 1024 i), so the chunk structure the reference's reader produces is kept
     // without one small copy per batch.  Quoted text columns are carried as opaque Utf8 on the host.
     static DataFrame from_csv(const std::string& path, size_t batch_size = 1024) {
-        std::ifstream f(path);
-        if (!f) throw DataFrameError(DataFrameError::IoError, "cannot open " + path);
-        auto split = [](const std::string& line) {
-            std::vector<std::string> out; std::string cur; bool q = false;
-            for (char ch : line) { if (ch == '"') q = !q; else if (ch == ',' && !q) { out.push_back(cur); cur.clear(); } else if (ch != '\r') cur += ch; }
-            out.push_back(cur);
-            return out;
-        };
-        std::string line;
-        std::getline(f, line);
-        const auto header = split(line);
-        std::vector<std::vector<std::string>> cells(header.size());
-        while (std::getline(f, line)) {
-            if (line.empty()) continue;
-            auto v = split(line);
-            v.resize(header.size());
-            for (size_t i = 0; i < header.size(); ++i) cells[i].push_back(v[i]);
+        plan::CsvReadOptions o;
+        o.batch_size = batch_size;
+        return from_csv(path, o);
+    }
+    // ... with the reader's options (src/expression.rs:372-378): header row, delimiter, max_records, batch_size, projection —
+    // what plan::optimise pushes a Limit / Select into
+    static DataFrame from_csv(const std::string& path, const plan::CsvReadOptions& options) {
+        const size_t batch_size = options.batch_size ? options.batch_size : 1024;
+        CsvCells t = read_csv_cells(path, options.has_headers, (char)options.delimiter.value_or((uint8_t)','), options.max_records);
+        if (options.projection) {
+            CsvCells p;
+            for (size_t i : *options.projection) {
+                if (i >= t.header.size()) throw DataFrameError(DataFrameError::ComputeError, "csv projection index out of range");
+                p.header.push_back(t.header[i]); p.cells.push_back(std::move(t.cells[i]));
+            }
+            t = std::move(p);
         }
-        auto is_int = [](const std::string& s) { char* e = nullptr; errno = 0; (void)std::strtoll(s.c_str(), &e, 10); return e != s.c_str() && !*e && errno == 0; };
-        auto is_num = [](const std::string& s) { char* e = nullptr; (void)std::strtod(s.c_str(), &e); return e != s.c_str() && !*e; };
-        auto is_bool = [](const std::string& s) { return s == "true" || s == "false" || s == "True" || s == "False" || s == "TRUE" || s == "FALSE"; };
+        const std::vector<std::string>& header = t.header;
+        std::vector<std::vector<std::string>>& cells = t.cells;
         std::vector<Column> cols;
         for (size_t i = 0; i < header.size(); ++i) {
             const size_t n = cells[i].size();
-            bool all_int = true, all_num = true, all_bool = true, any = false, any_null = false;
-            for (auto& s : cells[i]) {
-                if (s.empty()) { any_null = true; continue; }
-                any = true;
-                all_int = all_int && is_int(s); all_num = all_num && is_num(s); all_bool = all_bool && is_bool(s);
-            }
-            const DataType dt = !any ? DataType::Utf8 : all_int ? DataType::Int64 : all_num ? DataType::Float64 : all_bool ? DataType::Boolean : DataType::Utf8;
+            bool any_null = false;
+            const DataType dt = infer_csv_type(cells[i], &any_null);
             std::vector<ArrayRef> chunks;
             if (dt == DataType::Utf8) {
                 for (size_t b = 0; b < n || chunks.empty(); b += batch_size) {
@@ -2120,8 +2298,35 @@ class LazyFrame {
         for (auto& fld : source.schema().fields) f.output_.columns.push_back(plan::Column{fld.name, fld.data_type});
         return f;
     }
+    // LazyFrame::read(Computation) (src/lazyframe.rs:25-38): the plan starts at a Reader; nothing is loaded until evaluate(),
+    // which first runs plan::optimise over the unrolled plan — a Limit / Select next to a CSV read becomes the reader's
+    // max_records / projection, so the rows and columns that are not wanted are never parsed, uploaded or computed on.
+    static LazyFrame read(const plan::Computation& read_computation) {
+        if (!read_computation.is_single(plan::Transformation::Read)) throw DataFrameError(DataFrameError::ComputeError, "LazyFrame::read expects a read computation");
+        LazyFrame f;
+        f.read_ = std::make_shared<plan::Computation>(read_computation);
+        f.output_ = read_computation.output;
+        return f;
+    }
     std::optional<std::pair<size_t, plan::Column>> column(const std::string& name) const { return output_.get_column(name); }
     const plan::Dataset& output() const { return output_; }
+    // Expression::unroll (src/expression.rs:516-553): newest computation first, the read (if the plan has one) last
+    std::vector<plan::Computation> unroll() const {
+        std::vector<plan::Computation> u(comps_.rbegin(), comps_.rend());
+        if (read_) u.push_back(*read_);
+        return u;
+    }
+    // the plan after plan::optimise to a fixed point (the reference's tests apply it twice to merge a Select and a Limit into the read)
+    std::vector<plan::Computation> optimised() const {
+        std::vector<plan::Computation> u = unroll();
+        for (int pass = 0; pass < 4; ++pass) {
+            std::vector<plan::Computation> o = plan::optimise(u);
+            const bool same = o.size() == u.size();
+            u = std::move(o);
+            if (same && pass > 0) break;
+        }
+        return u;
+    }
 
     LazyFrame with_column(const std::string& col_name, const plan::Function& function, const std::vector<std::string>& input_col_names,
                           std::optional<DataType> as_type = std::nullopt) const {  // :58-96
@@ -2131,7 +2336,7 @@ class LazyFrame {
             if (t.kind != plan::Transformation::Calculate) throw DataFrameError(DataFrameError::ComputeError, "can't create column from a non-calculation transformation");
             f.output_ = f.output_.append_column(t.calc.output);
         }
-        f.push(ops);
+        f.push(ops, output_);
         return f;
     }
     LazyFrame with_column_renamed(const std::string& old_name, const std::string& new_name) const {  // :98-131
@@ -2140,17 +2345,17 @@ class LazyFrame {
         LazyFrame f = *this;
         f.output_.columns[c->first].name = new_name;
         f.output_.name = "renamed_dataset";
-        f.push({plan::Transformation::Calculate_(plan::Calculation{"rename", {c->second}, plan::Column{new_name, c->second.data_type}, plan::Function::Rename_()})});
+        f.push({plan::Transformation::Calculate_(plan::Calculation{"rename", {c->second}, plan::Column{new_name, c->second.data_type}, plan::Function::Rename_()})}, output_);
         return f;
     }
-    LazyFrame filter(const FilterRef& cond) const { LazyFrame f = *this; f.push({plan::Transformation::Filter_(cond)}); return f; }
-    LazyFrame limit(size_t n) const { LazyFrame f = *this; f.push({plan::Transformation::Limit_(n)}); return f; }
+    LazyFrame filter(const FilterRef& cond) const { LazyFrame f = *this; f.push({plan::Transformation::Filter_(cond)}, output_); return f; }
+    LazyFrame limit(size_t n) const { LazyFrame f = *this; f.push({plan::Transformation::Limit_(n)}, output_); return f; }
     LazyFrame select(const std::vector<std::string>& names) const {
         LazyFrame f = *this;
         plan::Dataset d; d.name = output_.name;
         for (auto& c : output_.columns) for (auto& n : names) if (c.name == n) { d.columns.push_back(c); break; }
         f.output_ = d;
-        f.push({plan::Transformation::Select_(names)});
+        f.push({plan::Transformation::Select_(names)}, output_);
         return f;
     }
     LazyFrame drop(const std::vector<std::string>& names) const {
@@ -2158,12 +2363,12 @@ class LazyFrame {
         plan::Dataset d; d.name = output_.name;
         for (auto& c : output_.columns) { bool x = false; for (auto& n : names) x |= c.name == n; if (!x) d.columns.push_back(c); }
         f.output_ = d;
-        f.push({plan::Transformation::Drop_(names)});
+        f.push({plan::Transformation::Drop_(names)}, output_);
         return f;
     }
     LazyFrame sort(const std::vector<std::string>& cols, const std::vector<bool>& descending) const {
         LazyFrame f = *this;
-        f.push({plan::Transformation::Sort_(cols, descending)});
+        f.push({plan::Transformation::Sort_(cols, descending)}, output_);
         return f;
     }
     // LazyFrame::join (:225-251) with Dataset::try_join's checks and output naming (src/expression.rs:223-285): both key
@@ -2182,23 +2387,36 @@ class LazyFrame {
     LazyFrame aggregate(const std::vector<std::string>& groups, const std::vector<plan::Aggregation>& aggr) const {   // :285-309
         LazyFrame f = *this;
         f.output_ = plan::try_aggregate(output_, groups, aggr);
-        f.push({plan::Transformation::GroupAggregate_(groups, aggr)});
+        f.push({plan::Transformation::GroupAggregate_(groups, aggr)}, output_);
         return f;
     }
     // LazyFrame::evaluate (:311-315): unroll (newest first) and hand to Evaluate
     DataFrame evaluate() const {
-        std::vector<plan::Computation> unrolled(comps_.rbegin(), comps_.rend());
-        return Evaluate::evaluate(*source_, unrolled);
+        if (!read_) {
+            std::vector<plan::Computation> unrolled(comps_.rbegin(), comps_.rend());
+            return Evaluate::evaluate(*source_, unrolled);
+        }
+        std::vector<plan::Computation> plan_ = optimised();
+        if (plan_.empty() || !plan_.back().is_single(plan::Transformation::Read)) throw DataFrameError(DataFrameError::ComputeError, "optimised plan does not end in a read");
+        const plan::Reader& r = plan_.back().transformations[0].reader;
+        DataFrame source = r.source == plan::Reader::Csv ? DataFrame::from_csv(r.path, r.csv)
+                         : r.source == plan::Reader::Arrow ? DataFrame::from_arrow(r.path)
+                         : throw DataFrameError(DataFrameError::ComputeError, "only CSV and Arrow IPC sources are loaded here");
+        plan_.pop_back();
+        return Evaluate::evaluate(source, plan_);
     }
 
   private:
-    void push(std::vector<plan::Transformation> t) {
+    // one Computation per pushed step: input = the dataset before it (what `this` planned), output = the dataset after it
+    void push(std::vector<plan::Transformation> t, const plan::Dataset& before) {
         plan::Computation c;
+        c.input = {before};
         c.transformations = std::move(t);
         c.output = output_;
         comps_.push_back(std::move(c));
     }
     std::shared_ptr<DataFrame> source_;
+    std::shared_ptr<plan::Computation> read_;   // set when the plan starts at a Reader instead of a loaded frame
     plan::Dataset output_;
     std::vector<plan::Computation> comps_;  // oldest first
 };

@@ -145,6 +145,40 @@ TEST(test_projection) {
     CHECK_THROWS(agg.evaluate());   // "aggregations not supported" in the reference (evaluation.rs:73); a string grouping column here
     CHECK_THROWS(LazyFrame::read(DataFrame::from_csv(g_csv)).aggregate({"town"}, {{AF::Max, {"lat"}}}));   // Grouping column "town" does not exist
 }
+// A plan that starts at a Reader (LazyFrame::read(Computation), src/lazyframe.rs:25-38) is optimised before it runs
+// (src/optimiser.rs): select + limit end up in the CSV reader's projection / max_records, so only 2 columns x 32 rows are
+// parsed and uploaded; the result equals the same steps over the fully loaded frame.
+TEST(test_reader_plan_is_optimised_then_evaluated) {
+    P::CsvReadOptions o;
+    o.batch_size = 1024;
+    const P::Computation read = P::Computation::compute_read(P::Reader::Csv_(g_csv, o));
+    LazyFrame frame = LazyFrame::read(read).select({"city", "lat"}).limit(32);
+    CHECK_EQ(frame.optimised().size(), 1u);
+    DataFrame df = frame.evaluate();
+    CHECK_EQ(df.num_columns(), 2u);
+    CHECK_EQ(df.num_rows(), 32);
+    DataFrame full = DataFrame::from_csv(g_csv);
+    CHECK_EQ(host<double>(df.column_by_name("lat").data().chunk(0)), host<double>(full.limit(32).column_by_name("lat").data().chunk(0)));
+    CHECK_EQ((*df.column_by_name("city").data().chunk(0)->strings)[31], (*full.column_by_name("city").data().chunk(0)->strings)[31]);
+    // computed columns and a filter behind the read: the select reaches the reader, the rest runs fused on the device
+    LazyFrame g = LazyFrame::read(read)
+                      .select({"lat", "lng"})
+                      .with_column("sin_lat", P::Function::Scalar_(P::ScalarFunction::Sine), {"lat"})
+                      .filter(BooleanFilter::gt(BooleanFilter::column("lng"), BooleanFilter::scalar(Scalar(-2.0))));
+    DataFrame got = g.evaluate();
+    DataFrame want = LazyFrame::read(full).select({"lat", "lng"})
+                         .with_column("sin_lat", P::Function::Scalar_(P::ScalarFunction::Sine), {"lat"})
+                         .filter(BooleanFilter::gt(BooleanFilter::column("lng"), BooleanFilter::scalar(Scalar(-2.0)))).evaluate();
+    CHECK_EQ(got.num_columns(), 3u);
+    CHECK_EQ(got.num_rows(), want.num_rows());
+    CHECK(got.num_rows() > 0 && got.num_rows() < 37);
+    CHECK_EQ(host<double>(got.column_by_name("sin_lat").data().chunk(0)), host<double>(want.column_by_name("sin_lat").data().chunk(0)));
+    // a projection that is not a prefix of the file's columns (the reference's index bug, not copied)
+    DataFrame tail = LazyFrame::read(read).select({"lat", "lng"}).evaluate();
+    CHECK_EQ(tail.schema().fields[0].name, std::string("lat"));
+    CHECK_EQ(tail.schema().fields[1].name, std::string("lng"));
+    CHECK_EQ(host<double>(tail.column(1).data().chunk(0)), host<double>(full.column_by_name("lng").data().chunk(0)));
+}
 TEST(test_with_columns) {
     LazyFrame frame = LazyFrame::read(DataFrame::from_csv(g_csv));
     frame = frame.with_column("sum", P::Function::Scalar_(P::ScalarFunction::Add), {"lat", "lng"});

@@ -115,4 +115,81 @@ TEST(test_join_plan) {
     CHECK_THROWS(try_join(a, b, {{"town", "lat"}}));    // incompatible types
 }
 
+// ---------------------------------------------------------------- src/optimiser.rs:237-420 (the module's own #[test]s)
+static const char* kCities = "tests/golden/uk_cities_with_headers.csv";
+static Reader cities_reader(std::optional<size_t> max_records = std::nullopt) {
+    CsvReadOptions o;
+    o.has_headers = true; o.delimiter = (uint8_t)','; o.max_records = max_records; o.batch_size = 1024;
+    return Reader::Csv_(kCities, o);
+}
+TEST(test_read_project) {   // :241-274
+    const Computation computation = Computation::compute_read(cities_reader());
+    CHECK_EQ(computation.output.columns.size(), 3u);
+    CHECK(computation.output.columns[0].data_type == DataType::Utf8 && computation.output.columns[1].data_type == DataType::Float64);
+    Computation select;
+    select.input = {computation.output};
+    select.transformations = {Transformation::Select_({"city", "lat"})};
+    select.output = computation.output;
+    const std::vector<Computation> optimised = optimise({select, computation});   // read comes last
+    CHECK_EQ(optimised.size(), 1u);
+    CHECK_EQ(optimised[0].output.columns.size(), 2u);
+    CHECK(optimised[0].is_single(Transformation::Read));
+    CHECK(optimised[0].transformations[0].reader.csv.projection == std::optional<std::vector<size_t>>(std::vector<size_t>{0, 1}));
+}
+TEST(test_read_limit_project) {   // :276-305
+    rdf::LazyFrame frame = rdf::LazyFrame::read(Computation::compute_read(cities_reader()));
+    frame = frame.select({"city", "lat"});
+    frame = frame.limit(32);
+    const std::vector<Computation> computations = frame.unroll();
+    CHECK_EQ(computations.size(), 3u);
+    std::vector<Computation> optimised = optimise(computations);
+    CHECK_EQ(optimised.size(), 2u);
+    CHECK_EQ(optimised[0].output.columns.size(), 2u);
+    optimised = optimise(optimised);   // optimise again to join the select with the limit
+    CHECK_EQ(optimised.size(), 1u);
+    CHECK_EQ(optimised[0].output.columns.size(), 2u);
+    const CsvReadOptions& o = optimised[0].transformations[0].reader.csv;
+    CHECK(o.max_records == std::optional<size_t>(32));
+    CHECK(o.projection == std::optional<std::vector<size_t>>(std::vector<size_t>{0, 1}));
+    CHECK_EQ(frame.optimised().size(), 1u);   // the fixed point the evaluator uses
+}
+TEST(test_optimise_filter_and_limits) {   // :380-404 (test_filter only prints the plan) + the Limit rules (:58-75)
+    rdf::LazyFrame frame = rdf::LazyFrame::read(Computation::compute_read(cities_reader()));
+    frame = frame.select({"city", "lat", "lng"});
+    frame = frame.filter(rdf::BooleanFilter::gt(rdf::BooleanFilter::column("lat"), rdf::BooleanFilter::scalar(rdf::Scalar((int64_t)0))));
+    const std::vector<Computation> computations = frame.unroll();
+    CHECK_EQ(computations.size(), 3u);
+    const std::vector<Computation> optimised = optimise(computations);   // the filter is a barrier: the select still reaches the read
+    CHECK_EQ(optimised.size(), 2u);
+    CHECK(optimised[0].is_single(Transformation::Filter));
+    CHECK(optimised[1].is_single(Transformation::Read) && optimised[1].transformations[0].reader.csv.projection.has_value());
+    // two limits merge into the smaller one, and a limit next to the read becomes max_records
+    rdf::LazyFrame two = rdf::LazyFrame::read(Computation::compute_read(cities_reader())).limit(20).limit(7);
+    const std::vector<Computation> merged = two.optimised();
+    CHECK(merged.back().is_single(Transformation::Read));
+    CHECK(merged.back().transformations[0].reader.csv.max_records == std::optional<size_t>(7));
+    // an existing max_records is only ever lowered
+    rdf::LazyFrame capped = rdf::LazyFrame::read(Computation::compute_read(cities_reader(5))).limit(20);
+    CHECK(capped.optimised().back().transformations[0].reader.csv.max_records == std::optional<size_t>(5));
+}
+TEST(test_optimise_select_and_calculate) {   // optimise_project_calc (:183-235) and the pending-computation fix
+    rdf::LazyFrame frame = rdf::LazyFrame::read(Computation::compute_read(cities_reader()));
+    // the selected columns include the computed one and its input: the select moves above the calculation
+    rdf::LazyFrame a = frame.with_column("sin_lat", Function::Scalar_(ScalarFunction::Sine), {"lat"}).select({"lat", "sin_lat"});
+    std::vector<Computation> o = optimise(a.unroll());
+    CHECK(!o.empty() && o.back().is_single(Transformation::Read));   // nothing is lost: the read is still the plan's last step
+    // the computed column is not selected: the calculation is dropped
+    rdf::LazyFrame b = frame.with_column("sin_lat", Function::Scalar_(ScalarFunction::Sine), {"lat"}).select({"city"});
+    o = b.optimised();
+    bool has_calc = false;
+    for (auto& c : o) for (auto& t : c.transformations) has_calc |= t.kind == Transformation::Calculate;
+    CHECK(!has_calc);
+    CHECK(o.back().transformations[0].reader.csv.projection == std::optional<std::vector<size_t>>(std::vector<size_t>{0}));
+    // [Calculate, Read]: the reference's optimise returns [Calculate] and loses the read; here the pending read is emitted
+    rdf::LazyFrame c = frame.with_column("sin_lat", Function::Scalar_(ScalarFunction::Sine), {"lat"});
+    o = optimise(c.unroll());
+    CHECK_EQ(o.size(), 2u);
+    CHECK(o[1].is_single(Transformation::Read));
+}
+
 int main() { return run_all(); }
