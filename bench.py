@@ -398,7 +398,9 @@ def main():
     else:
         col = [A.DeviceArray(x.data_ptr(), vptr, 0, rows, A.F64, -1, keep=(x, vkeep))]
 
-    frame = A.Prepared([col])   # the descriptor array is marshalled once (ctypes costs ~1 us per RecordBatch; a Rust / C++ caller has it as is)
+    # One chunk: the plain call.  A frame of RecordBatches (--chunk-rows): pinned once with rdf_frame_pin, as a DataFrame holding
+    # its batches for its lifetime would be — the per-call walk over a million descriptors (14 ms) is not part of a query.
+    frame = A.PinnedFrame(api, [col]) if args.chunk_rows else A.Prepared([col])
     e = A.Expr()
     c = e.col(0)
     pred = e.op("gt", c, e.scalar(THRESHOLD))

@@ -388,6 +388,19 @@ typedef struct {
 rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks,
                         rdf_out* outs, rdf_agg_result* aggs);
 
+/* A frame handle for repeated calls over the same device-resident columns.  The reference's DataFrame holds its
+ * RecordBatches for its lifetime (src/dataframe.rs:30-48) and every query walks them again; with the reader's 1024-row
+ * batches (src/dataframe.rs:352) a 1e9-row frame is a million chunks, and validating / translating a million rdf_array
+ * descriptors per call (14 ms) costs ten times the kernel (1.2 ms).  rdf_frame_pin does that work once: dtypes and batch
+ * lengths checked, descriptors and tile tables kept in HBM.  cols[c * nchunks + i], RDF_MEM_DEVICE only; the buffers
+ * must stay alive and unchanged until rdf_frame_release.  rdf_pipeline_frame = rdf_pipeline over the pinned columns
+ * (column index c of the program = column c of the pin call); outputs and results exactly as rdf_pipeline.  A handle
+ * belongs to the device it was pinned on and is used by one thread at a time. */
+typedef struct rdf_frame rdf_frame;
+rdf_status rdf_frame_pin(const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_frame** out);
+rdf_status rdf_frame_release(rdf_frame* frame);
+rdf_status rdf_pipeline_frame(const rdf_program* prog, rdf_frame* frame, rdf_out* outs, rdf_agg_result* aggs);
+
 /* ------------------------------------------------------------------ fused grouped aggregation */
 
 #define RDF_MAX_GROUP_VALUES 8

@@ -57,6 +57,7 @@ pub mod sys {
     pub struct rdf_group_result { pub sum_f64: f64, pub sum_i64: i64, pub count: i64, pub is_some: i32, pub dtype: i32 }
     #[repr(C)] #[derive(Clone, Copy)] pub struct rdf_sort_options { pub descending: i32, pub nulls_first: i32 }
     #[repr(C)] #[derive(Clone, Copy)] pub struct rdf_list_array { pub offsets: rdf_array, pub values: rdf_array }
+    #[repr(C)] pub struct rdf_frame { _opaque: [u8; 0] }
 
     #[link(name = "rdf_mi355x")]
     extern "C" {
@@ -126,6 +127,10 @@ pub mod sys {
         // the fused batch loop (src/evaluation.rs:66-96)
         pub fn rdf_pipeline(prog: *const rdf_program, cols: *const rdf_array, ncols: i32, nchunks: i64, outs: *mut rdf_out,
                             aggs: *mut rdf_agg_result) -> i32;
+        // a frame pinned for repeated queries: descriptors validated once, tables kept in HBM (device-resident columns)
+        pub fn rdf_frame_pin(cols: *const rdf_array, ncols: i32, nchunks: i64, out: *mut *mut rdf_frame) -> i32;
+        pub fn rdf_frame_release(frame: *mut rdf_frame) -> i32;
+        pub fn rdf_pipeline_frame(prog: *const rdf_program, frame: *mut rdf_frame, outs: *mut rdf_out, aggs: *mut rdf_agg_result) -> i32;
         // synthetic data, switches, introspection (bench / tests)
         pub fn rdf_fill_uniform_f64(dev_ptr: *mut f64, n: i64, seed: u64, column_id: u64, first_row: i64, lo: f64, hi: f64) -> i32;
         pub fn rdf_fill_uniform_i64(dev_ptr: *mut i64, n: i64, seed: u64, column_id: u64, first_row: i64, lo: i64, hi: i64) -> i32;

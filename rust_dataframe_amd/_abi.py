@@ -360,6 +360,43 @@ class Prepared:
         return iter(self.cols)
 
 
+class PinnedFrame:
+    """rdf_frame_pin: device-resident columns validated once, their descriptors and tile tables kept in HBM; hand it to
+    Api.pipeline in place of the column lists.  The arrays are kept alive by the handle; release() (or the context
+    manager) frees the device tables."""
+
+    def __init__(self, api, cols: Sequence[Sequence]):
+        self.api = api
+        self.cols = cols            # keeps the device buffers alive
+        nchunks = len(cols[0])
+        carr = _flat(cols, nchunks)
+        h = C.c_void_p(0)
+        fn = api._fn("frame_pin")
+        fn.restype = C.c_int
+        api._check(fn(carr, C.c_int32(len(cols)), C.c_int64(nchunks), C.byref(h)))
+        self.handle = h
+        api._fn("pipeline_frame").restype = C.c_int
+
+    def release(self):
+        if self.handle is not None and self.handle.value:
+            fn = self.api._fn("frame_release")
+            fn.restype = C.c_int
+            fn(self.handle)
+        self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:   # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 class PreparedCol(list):
     """ONE column (its chunk list) with its descriptor array marshalled once, for the entry points that take a column."""
 
@@ -784,20 +821,27 @@ class Api:
     # ---- fused batch loop
     def pipeline(self, expr: Expr, cols: Sequence[Sequence], value_roots: Sequence[int], filter_root: int = -1,
                  sink: int = SINK_AGG, outs=None):
-        nchunks = len(cols[0]) if cols else 0
         nodes = expr.c_array()
         prog = rdf_program(C.cast(nodes, C.POINTER(rdf_expr_node)), len(expr.nodes), filter_root, len(value_roots),
                            (C.c_int32 * MAX_VALUES)(*(list(value_roots) + [0] * (MAX_VALUES - len(value_roots)))), sink)
-        cc = _flat(cols, nchunks)
+        if isinstance(cols, PinnedFrame):   # rdf_pipeline_frame: descriptors validated and kept on the device once
+            def call(carr, aggs):
+                return self._fn("pipeline_frame")(C.byref(prog), cols.handle, carr, aggs)
+        else:
+            nchunks = len(cols[0]) if cols else 0
+            cc = _flat(cols, nchunks)
+
+            def call(carr, aggs):
+                return self._fn("pipeline")(C.byref(prog), cc, C.c_int32(len(cols)), C.c_int64(nchunks), carr, aggs)
         aggs = (rdf_agg_result * MAX_VALUES)()
         if sink == SINK_STORE:
             assert outs is not None, "SINK_STORE needs caller-allocated outputs: outs[v][chunk]"
             flat = [o for v in outs for o in v]
             carr = (rdf_out * max(1, len(flat)))(*[o.out_struct() for o in flat])
-            self._check(self._fn("pipeline")(C.byref(prog), cc, C.c_int32(len(cols)), C.c_int64(nchunks), carr, aggs))
+            self._check(call(carr, aggs))
             self._finish(flat, carr)
             return outs
-        self._check(self._fn("pipeline")(C.byref(prog), cc, C.c_int32(len(cols)), C.c_int64(nchunks), None, aggs))
+        self._check(call(None, aggs))
         res = []
         for v in range(len(value_roots)):
             r = aggs[v]

@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <chrono>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -924,8 +926,68 @@ void fill_agg_result(rdf_agg_result* r, int dt, const AggPartial& p) {
     }
 }
 
+}  // namespace
+
+// rdf_frame (rdf_frame_pin): what a call over a frame of many RecordBatches would otherwise re-derive from the caller's
+// rdf_array list every time — validated dtypes and batch lengths, the device descriptors, tile prefix tables per tile
+// size, descriptor tables in a program's canonical column order, alignment of every column — kept on the host and in HBM.
+struct rdf_frame {
+    int device = 0;
+    int ncols = 0;
+    int64_t nchunks = 0, total_rows = 0;
+    int col_dtype[kMaxCols];
+    bool col_aligned16[kMaxCols];            // every non-empty chunk of the column starts on a 16-byte boundary
+    std::vector<int64_t> clen;
+    std::vector<DevChunkCol> dev;            // [ncols * nchunks]
+    std::vector<uint8_t> chunk_nullable;     // [nchunks]: some column of the batch carries a validity bitmap
+    DevChunkCol* d_cols = nullptr;           // device copies
+    int64_t* d_clen = nullptr;
+    struct Tiles { int64_t ntiles = 0; uint64_t tile_inv = 0; int64_t* d_start = nullptr; };
+    std::map<int, Tiles> tiles;              // rows per tile -> prefix table
+    std::map<std::vector<int>, DevChunkCol*> col_tabs;   // canonical column order of a specialised program -> descriptor table
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+rdf_status frame_tiles(rdf_frame& f, int rows_per_tile, const rdf_frame::Tiles** out) {
+    auto it = f.tiles.find(rows_per_tile);
+    if (it == f.tiles.end()) {
+        std::vector<int64_t> ts((size_t)f.nchunks + 1, 0);
+        for (int64_t c = 0; c < f.nchunks; ++c) ts[(size_t)c + 1] = ts[(size_t)c] + (f.clen[(size_t)c] + rows_per_tile - 1) / rows_per_tile;
+        rdf_frame::Tiles t;
+        t.ntiles = ts[(size_t)f.nchunks];
+        if (f.nchunks > 1 && ts[(size_t)f.nchunks - 1] > 0 && f.nchunks - 1 < ((int64_t)1 << 31))
+            t.tile_inv = (uint64_t)(((unsigned __int128)(uint64_t)(f.nchunks - 1) << 32) / (unsigned __int128)(uint64_t)ts[(size_t)f.nchunks - 1]);
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, ts.size() * 8 + 64));
+        f.allocs.push_back(p);
+        HIP_TRY(hipMemcpy(p, ts.data(), ts.size() * 8, hipMemcpyHostToDevice));
+        t.d_start = (int64_t*)p;
+        it = f.tiles.emplace(rows_per_tile, t).first;
+    }
+    *out = &it->second;
+    return RDF_OK;
+}
+rdf_status frame_col_tab(rdf_frame& f, const int* col_map, int n, DevChunkCol** out) {
+    if (n <= 0) { *out = f.d_cols; return RDF_OK; }
+    std::vector<int> key(col_map, col_map + n);
+    auto it = f.col_tabs.find(key);
+    if (it == f.col_tabs.end()) {
+        std::vector<DevChunkCol> tab((size_t)n * (size_t)f.nchunks);
+        for (int k = 0; k < n; ++k) memcpy(tab.data() + (size_t)k * (size_t)f.nchunks, f.dev.data() + (size_t)col_map[k] * (size_t)f.nchunks, sizeof(DevChunkCol) * (size_t)f.nchunks);
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, tab.size() * sizeof(DevChunkCol) + 64));
+        f.allocs.push_back(p);
+        HIP_TRY(hipMemcpy(p, tab.data(), tab.size() * sizeof(DevChunkCol), hipMemcpyHostToDevice));
+        it = f.col_tabs.emplace(key, (DevChunkCol*)p).first;
+    }
+    *out = it->second;
+    return RDF_OK;
+}
+
 rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, int64_t nchunks, rdf_out* outs,
-                       rdf_agg_result* aggs, const char* len_mismatch_msg) {
+                       rdf_agg_result* aggs, const char* len_mismatch_msg, rdf_frame* fc = nullptr) {
     if (nchunks < 0) return fail(RDF_INVALID_ARGUMENT, "negative chunk count");
     if (ncols < 0 || ncols > kMaxCols) return fail(RDF_INVALID_ARGUMENT, "a fused program reads at most %d columns", kMaxCols);
     const bool grouped = ps.sink == RDF_SINK_GROUP;
@@ -937,8 +999,8 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     }
     if (ps.sink == RDF_SINK_STORE && ps.filter_root >= 0)
         return fail(RDF_INVALID_ARGUMENT, "SINK_STORE with a filter: use rdf_predicate + rdf_filter_columns");
-    int32_t mem = -1;
-    RDF_TRY(check_mem(cols, (int64_t)ncols * nchunks, &mem));
+    int32_t mem = fc ? RDF_MEM_DEVICE : -1;
+    if (!fc) RDF_TRY(check_mem(cols, (int64_t)ncols * nchunks, &mem));
     if (mem < 0) mem = ps.sink == RDF_SINK_STORE && outs && nchunks > 0 ? outs[0].mem : RDF_MEM_HOST;
     if (ps.sink == RDF_SINK_STORE && nchunks > 0) {
         if (!outs) return fail(RDF_INVALID_ARGUMENT, "outs is null");
@@ -949,22 +1011,28 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     DbgTimer dbg;
     // column dtypes: chunk 0 decides, every chunk must agree (ChunkedArray::from_arrays, src/table.rs:24-40)
     int col_dtype[kMaxCols];
-    for (int k = 0; k < ncols; ++k) {
-        col_dtype[k] = nchunks > 0 ? cols[(int64_t)k * nchunks].dtype : RDF_F64;
-        if (!(is_numeric(col_dtype[k]) || col_dtype[k] == RDF_BOOL)) return fail(RDF_INVALID_ARGUMENT, "column %d: unsupported dtype %d", k, col_dtype[k]);
-        for (int64_t c = 0; c < nchunks; ++c)
-            if (cols[(int64_t)k * nchunks + c].dtype != col_dtype[k]) return fail(RDF_INVALID_ARGUMENT, "column %d: chunks differ in dtype", k);
-    }
-    // batch lengths: all columns of RecordBatch c have one length
-    std::vector<int64_t> clen((size_t)nchunks, 0);
+    std::vector<int64_t> clen_own;
     int64_t total_rows = 0;
-    for (int64_t c = 0; c < nchunks; ++c) {
-        clen[(size_t)c] = ncols > 0 ? cols[c].length : 0;
-        for (int k = 1; k < ncols; ++k)
-            if (cols[(int64_t)k * nchunks + c].length != clen[(size_t)c]) return fail(RDF_COMPUTE_ERROR, "%s", len_mismatch_msg);
-        total_rows += clen[(size_t)c];
+    if (fc) {
+        for (int k = 0; k < ncols; ++k) col_dtype[k] = fc->col_dtype[k];
+        total_rows = fc->total_rows;
+    } else {
+        for (int k = 0; k < ncols; ++k) {
+            col_dtype[k] = nchunks > 0 ? cols[(int64_t)k * nchunks].dtype : RDF_F64;
+            if (!(is_numeric(col_dtype[k]) || col_dtype[k] == RDF_BOOL)) return fail(RDF_INVALID_ARGUMENT, "column %d: unsupported dtype %d", k, col_dtype[k]);
+            for (int64_t c = 0; c < nchunks; ++c)
+                if (cols[(int64_t)k * nchunks + c].dtype != col_dtype[k]) return fail(RDF_INVALID_ARGUMENT, "column %d: chunks differ in dtype", k);
+        }
+        // batch lengths: all columns of RecordBatch c have one length
+        clen_own.assign((size_t)nchunks, 0);
+        for (int64_t c = 0; c < nchunks; ++c) {
+            clen_own[(size_t)c] = ncols > 0 ? cols[c].length : 0;
+            for (int k = 1; k < ncols; ++k)
+                if (cols[(int64_t)k * nchunks + c].length != clen_own[(size_t)c]) return fail(RDF_COMPUTE_ERROR, "%s", len_mismatch_msg);
+            total_rows += clen_own[(size_t)c];
+        }
     }
-
+    const std::vector<int64_t>& clen = fc ? fc->clen : clen_own;
     dbg.mark("validate");
     // compile
     Compiler cc(ps.nodes, ps.nnodes, col_dtype, ncols);
@@ -1007,7 +1075,8 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
                 if (o.dtype != value_dtype[v]) return fail(RDF_INVALID_ARGUMENT, "output dtype %d != expression dtype %d", o.dtype, value_dtype[v]);
                 if (o.capacity < clen[(size_t)c]) return fail(RDF_MEMORY_ERROR, "output capacity too small");
                 bool nullable = cc.lossy_cast;   // a cast to a narrower / differently signed / integer type yields NULL where the value does not fit
-                for (int k = 0; k < ncols; ++k) nullable |= cols[(int64_t)k * nchunks + c].validity != nullptr;
+                if (fc) nullable |= fc->chunk_nullable[(size_t)c] != 0;
+                else for (int k = 0; k < ncols; ++k) nullable |= cols[(int64_t)k * nchunks + c].validity != nullptr;
                 if (nullable && !o.validity) return fail(RDF_INVALID_ARGUMENT, "output validity buffer required");
                 if (clen[(size_t)c] > 0 && !o.values) return fail(RDF_INVALID_ARGUMENT, "null output values pointer");
             }
@@ -1038,11 +1107,14 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
 
     // inputs
     InputStager in;
-    in.arrays.reserve((size_t)ncols * (size_t)nchunks);
-    in.plans.reserve((size_t)ncols * (size_t)nchunks);
-    for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) in.add(&cols[i]);
-    RDF_TRY(in.finish(pin_off, &pin_used));
-    pin_off += (pin_used + 255) & ~(size_t)255;
+    if (!fc) {
+        in.arrays.reserve((size_t)ncols * (size_t)nchunks);
+        in.plans.reserve((size_t)ncols * (size_t)nchunks);
+        for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) in.add(&cols[i]);
+        RDF_TRY(in.finish(pin_off, &pin_used));
+        pin_off += (pin_used + 255) & ~(size_t)255;
+    }
+    const std::vector<DevChunkCol>& in_dev = fc ? fc->dev : in.dev;
     dbg.mark("stage inputs");
 
     // outputs (SINK_STORE)
@@ -1075,9 +1147,14 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     }
 
     // tiles
-    std::vector<int64_t> tile_start((size_t)nchunks + 1, 0);
-    for (int64_t c = 0; c < nchunks; ++c) tile_start[(size_t)c + 1] = tile_start[(size_t)c] + (clen[(size_t)c] + kEvalTile - 1) / kEvalTile;
-    const int64_t ntiles = tile_start[(size_t)nchunks];
+    std::vector<int64_t> tile_start;
+    const rdf_frame::Tiles* eval_tiles = nullptr;
+    if (fc) RDF_TRY(frame_tiles(*fc, kEvalTile, &eval_tiles));
+    else {
+        tile_start.assign((size_t)nchunks + 1, 0);
+        for (int64_t c = 0; c < nchunks; ++c) tile_start[(size_t)c + 1] = tile_start[(size_t)c] + (clen[(size_t)c] + kEvalTile - 1) / kEvalTile;
+    }
+    const int64_t ntiles = fc ? eval_tiles->ntiles : tile_start[(size_t)nchunks];
     int grid = (int)(ntiles < (int64_t)eval_grid_limit() ? ntiles : (int64_t)eval_grid_limit());
 
     // device scratch: flags | null counts | partials | result
@@ -1114,16 +1191,27 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     TableBuilder tb;
     auto build_eval_tables = [&]() -> rdf_status {
         if (nchunks == 1) {
-            for (int k = 0; k < ncols; ++k) ea.inline_cols[k] = in.dev[(size_t)k];
+            for (int k = 0; k < ncols; ++k) ea.inline_cols[k] = in_dev[(size_t)k];
             for (int v = 0; v < ps.nvalues && ps.sink == RDF_SINK_STORE; ++v) ea.inline_outs[v] = dev_outs[(size_t)v];
             ea.inline_len = clen[0];
+        } else if (fc) {   // the frame's own tables; only the outputs' descriptors are per call
+            ea.cols = fc->d_cols;
+            ea.chunk_tile_start = eval_tiles->d_start;
+            ea.chunk_len = fc->d_clen;
+            const size_t o_outs = tb.reserve(sizeof(DevOutChunk) * (dev_outs.size() + 1));
+            RDF_TRY(tb.bind(pin_off));
+            if (!dev_outs.empty()) memcpy(tb.at<char>(o_outs), dev_outs.data(), sizeof(DevOutChunk) * dev_outs.size());
+            RDF_TRY(tb.alloc());
+            RDF_TRY(tb.upload(pin_off));
+            pin_off += (tb.size + 255) & ~(size_t)255;
+            ea.outs = tb.dev_at<DevOutChunk>(o_outs);
         } else {
-            const size_t o_cols = tb.reserve(sizeof(DevChunkCol) * in.dev.size());
+            const size_t o_cols = tb.reserve(sizeof(DevChunkCol) * in_dev.size());
             const size_t o_ts = tb.reserve(sizeof(int64_t) * tile_start.size());
             const size_t o_len = tb.reserve(sizeof(int64_t) * clen.size());
             const size_t o_outs = tb.reserve(sizeof(DevOutChunk) * (dev_outs.size() + 1));
             RDF_TRY(tb.bind(pin_off));
-            memcpy(tb.at<char>(o_cols), in.dev.data(), sizeof(DevChunkCol) * in.dev.size());
+            memcpy(tb.at<char>(o_cols), in_dev.data(), sizeof(DevChunkCol) * in_dev.size());
             memcpy(tb.at<char>(o_ts), tile_start.data(), sizeof(int64_t) * tile_start.size());
             memcpy(tb.at<char>(o_len), clen.data(), sizeof(int64_t) * clen.size());
             if (!dev_outs.empty()) memcpy(tb.at<char>(o_outs), dev_outs.data(), sizeof(DevOutChunk) * dev_outs.size());
@@ -1155,11 +1243,13 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         memset(&sa, 0, sizeof sa);
         use_spec = true;
         spec_rpb = spec_rows_per_tile(sp.sig.c_str());
-        for (int k = 0; k < sp.ncols && use_spec; ++k)
+        for (int k = 0; k < sp.ncols && use_spec; ++k) {
+            if (fc) { use_spec = fc->col_aligned16[sp.col_map[k]]; continue; }
             for (int64_t c = 0; c < nchunks; ++c) {
-                const DevChunkCol& d = in.dev[(size_t)((int64_t)sp.col_map[k] * nchunks + c)];
+                const DevChunkCol& d = in_dev[(size_t)((int64_t)sp.col_map[k] * nchunks + c)];
                 if (clen[(size_t)c] > 0 && ((uintptr_t)((const char*)d.values + d.offset * sp.width) & 15) != 0) { use_spec = false; break; }
             }
+        }
         if (ps.sink == RDF_SINK_STORE)
             for (int64_t c = 0; c < nchunks && use_spec; ++c)
                 if (clen[(size_t)c] > 0 && (((uintptr_t)dev_outs[(size_t)c].values & 15) != 0 || ((uintptr_t)dev_outs[(size_t)c].validity & 7) != 0)) use_spec = false;
@@ -1176,16 +1266,39 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         sa.vec_bitmap = ctx.opt_vec_bitmap ? 1 : 0;
         sa.out_null_count = d_nullc;
         sa.nchunks = nchunks;
-        std::vector<int64_t> sts((size_t)nchunks + 1, 0);
-        for (int64_t c = 0; c < nchunks; ++c) sts[(size_t)c + 1] = sts[(size_t)c] + (clen[(size_t)c] + spec_rpb - 1) / spec_rpb;
-        sa.ntiles = sts[(size_t)nchunks];
-        sa.tile_inv = 0;
-        if (nchunks > 1 && sts[(size_t)nchunks - 1] > 0 && nchunks - 1 < ((int64_t)1 << 31))
-            sa.tile_inv = (uint64_t)(((unsigned __int128)(uint64_t)(nchunks - 1) << 32) / (unsigned __int128)(uint64_t)sts[(size_t)nchunks - 1]);
+        std::vector<int64_t> sts;
+        const rdf_frame::Tiles* spec_tiles = nullptr;
+        if (fc) {
+            RDF_TRY(frame_tiles(*fc, spec_rpb, &spec_tiles));
+            sa.ntiles = spec_tiles->ntiles;
+            sa.tile_inv = spec_tiles->tile_inv;
+        } else {
+            sts.assign((size_t)nchunks + 1, 0);
+            for (int64_t c = 0; c < nchunks; ++c) sts[(size_t)c + 1] = sts[(size_t)c] + (clen[(size_t)c] + spec_rpb - 1) / spec_rpb;
+            sa.ntiles = sts[(size_t)nchunks];
+            sa.tile_inv = 0;
+            if (nchunks > 1 && sts[(size_t)nchunks - 1] > 0 && nchunks - 1 < ((int64_t)1 << 31))
+                sa.tile_inv = (uint64_t)(((unsigned __int128)(uint64_t)(nchunks - 1) << 32) / (unsigned __int128)(uint64_t)sts[(size_t)nchunks - 1]);
+        }
         if (nchunks == 1) {
-            for (int k = 0; k < sp.ncols; ++k) sa.cols[k] = in.dev[(size_t)sp.col_map[k]];
+            for (int k = 0; k < sp.ncols; ++k) sa.cols[k] = in_dev[(size_t)sp.col_map[k]];
             sa.n = clen[0];
             if (ps.sink == RDF_SINK_STORE) sa.out = dev_outs[0];
+        } else if (fc) {
+            DevChunkCol* tab = nullptr;
+            RDF_TRY(frame_col_tab(*fc, sp.col_map, sp.ncols, &tab));
+            sa.cols_tab = tab;
+            sa.chunk_tile_start = spec_tiles->d_start;
+            sa.chunk_len = fc->d_clen;
+            if (ps.sink == RDF_SINK_STORE) {   // the outputs' descriptors are per call
+                const size_t o_o = stb.reserve(sizeof(DevOutChunk) * ((size_t)nchunks + 1));
+                RDF_TRY(stb.bind(pin_off));
+                memcpy(stb.at<char>(o_o), dev_outs.data(), sizeof(DevOutChunk) * (size_t)nchunks);
+                RDF_TRY(stb.alloc());
+                RDF_TRY(stb.upload(pin_off));
+                pin_off += (stb.size + 255) & ~(size_t)255;
+                sa.outs_tab = stb.dev_at<DevOutChunk>(o_o);
+            }
         } else {
             const size_t o_c = stb.reserve(sizeof(DevChunkCol) * (size_t)(sp.ncols > 0 ? sp.ncols : 1) * (size_t)nchunks);
             const size_t o_t = stb.reserve(sizeof(int64_t) * sts.size());
@@ -1193,7 +1306,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             const size_t o_o = stb.reserve(sizeof(DevOutChunk) * ((size_t)nchunks + 1));
             RDF_TRY(stb.bind(pin_off));
             for (int k = 0; k < sp.ncols; ++k)
-                memcpy(stb.at<DevChunkCol>(o_c) + (size_t)k * (size_t)nchunks, in.dev.data() + (size_t)sp.col_map[k] * (size_t)nchunks, sizeof(DevChunkCol) * (size_t)nchunks);
+                memcpy(stb.at<DevChunkCol>(o_c) + (size_t)k * (size_t)nchunks, in_dev.data() + (size_t)sp.col_map[k] * (size_t)nchunks, sizeof(DevChunkCol) * (size_t)nchunks);
             memcpy(stb.at<char>(o_t), sts.data(), sizeof(int64_t) * sts.size());
             memcpy(stb.at<char>(o_l), clen.data(), sizeof(int64_t) * clen.size());
             if (ps.sink == RDF_SINK_STORE) memcpy(stb.at<char>(o_o), dev_outs.data(), sizeof(DevOutChunk) * (size_t)nchunks);
@@ -1230,7 +1343,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         for (int k = 0; k < gp.ncols && use_gspec; ++k) {
             const int w = dtype_size(col_dtype[gp.col_map[k]]);
             for (int64_t c = 0; c < nchunks; ++c) {
-                const DevChunkCol& d = in.dev[(size_t)((int64_t)gp.col_map[k] * nchunks + c)];
+                const DevChunkCol& d = in_dev[(size_t)((int64_t)gp.col_map[k] * nchunks + c)];
                 if (clen[(size_t)c] > 0 && ((uintptr_t)((const char*)d.values + d.offset * w) & (uintptr_t)(2 * w - 1)) != 0) { use_gspec = false; break; }
             }
         }
@@ -1239,7 +1352,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             memset(&ga, 0, sizeof ga);
             ga.cols_tab = ea.cols; ga.chunk_tile_start = ea.chunk_tile_start; ga.chunk_len = ea.chunk_len;
             ga.nchunks = nchunks; ga.ntiles = ntiles; ga.n = clen[0];
-            for (int k = 0; k < gp.ncols; ++k) { ga.col_map[k] = gp.col_map[k]; if (nchunks == 1) ga.cols[k] = in.dev[(size_t)gp.col_map[k]]; }
+            for (int k = 0; k < gp.ncols; ++k) { ga.col_map[k] = gp.col_map[k]; if (nchunks == 1) ga.cols[k] = in_dev[(size_t)gp.col_map[k]]; }
             for (int k = 0; k < gp.nimm; ++k) ga.imm[k] = gp.imm[k];
             ga.group_partials = d_gpart; ga.flags = d_flags;
             ga.ngroups = ps.ngroups; ga.nvalues = ps.nvalues; ga.vec_bitmap = ctx.opt_vec_bitmap ? 1 : 0;
@@ -1303,8 +1416,8 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
                     cmp = fr.op == RDF_OP_GT ? RDF_OP_LT : fr.op == RDF_OP_GE ? RDF_OP_LE : fr.op == RDF_OP_LT ? RDF_OP_GT : fr.op == RDF_OP_LE ? RDF_OP_GE : fr.op;
                 }
                 if (coln && col_dtype[coln->column] == RDF_F64 && sc->dtype != RDF_NULLTYPE && (is_numeric(sc->dtype) || sc->dtype == RDF_BOOL)) {
-                    const DevChunkCol& x = in.dev[(size_t)coln->column];
-                    const DevChunkCol& y = in.dev[(size_t)vr.column];
+                    const DevChunkCol& x = in_dev[(size_t)coln->column];
+                    const DevChunkCol& y = in_dev[(size_t)vr.column];
                     const uintptr_t xa = (uintptr_t)((const double*)x.values + x.offset), ya = (uintptr_t)((const double*)y.values + y.offset);
                     if ((xa & 7) == 0 && (ya & 7) == 0 && (xa & 15) == (ya & 15)) {
                         memset(&fa, 0, sizeof fa);
@@ -1609,6 +1722,75 @@ rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t 
     for (int v = 0; v < prog->nvalues; ++v) ps.value_roots[v] = prog->value_roots[v];
     if (ps.sink != RDF_SINK_STORE && ps.sink != RDF_SINK_AGG) return fail(RDF_INVALID_ARGUMENT, "bad sink");
     return run_program(ps, cols, ncols, nchunks, outs, aggs, "columns of a batch differ in length");
+}
+
+rdf_status rdf_frame_pin(const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_frame** out) {
+    if (!out) return fail(RDF_INVALID_ARGUMENT, "frame_pin: null output pointer");
+    *out = nullptr;
+    if (!cols || ncols < 1 || ncols > kMaxCols || nchunks < 1) return fail(RDF_INVALID_ARGUMENT, "frame_pin: 1..%d columns of at least one chunk", kMaxCols);
+    int32_t mem = -1;
+    RDF_TRY(check_mem(cols, (int64_t)ncols * nchunks, &mem));
+    if (mem != RDF_MEM_DEVICE) return fail(RDF_INVALID_ARGUMENT, "frame_pin: device-resident columns only (host buffers are staged per call)");
+    RDF_TRY(ensure_ready());
+    std::unique_ptr<rdf_frame> f(new rdf_frame());
+    f->device = g_ctx.device;
+    f->ncols = ncols;
+    f->nchunks = nchunks;
+    f->clen.assign((size_t)nchunks, 0);
+    f->chunk_nullable.assign((size_t)nchunks, 0);
+    f->dev.resize((size_t)ncols * (size_t)nchunks);
+    for (int k = 0; k < ncols; ++k) {
+        const int dt = cols[(int64_t)k * nchunks].dtype;
+        if (!(is_numeric(dt) || dt == RDF_BOOL)) return fail(RDF_INVALID_ARGUMENT, "column %d: unsupported dtype %d", k, dt);
+        f->col_dtype[k] = dt;
+        f->col_aligned16[k] = dt != RDF_BOOL;
+        const size_t es = dt == RDF_BOOL ? 1 : (size_t)dtype_size(dt);
+        for (int64_t c = 0; c < nchunks; ++c) {
+            const rdf_array& a = cols[(int64_t)k * nchunks + c];
+            if (a.dtype != dt) return fail(RDF_INVALID_ARGUMENT, "column %d: chunks differ in dtype", k);
+            if (k == 0) { f->clen[(size_t)c] = a.length; f->total_rows += a.length; }
+            else if (a.length != f->clen[(size_t)c]) return fail(RDF_COMPUTE_ERROR, "columns of a batch differ in length");
+            if (a.validity) f->chunk_nullable[(size_t)c] = 1;
+            f->dev[(size_t)((int64_t)k * nchunks + c)] = DevChunkCol{a.values, a.validity, a.offset};
+            if (a.length > 0 && (((uintptr_t)a.values + (uintptr_t)a.offset * es) & 15) != 0) f->col_aligned16[k] = false;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, f->dev.size() * sizeof(DevChunkCol) + 64);
+    if (e != hipSuccess) return fail(RDF_MEMORY_ERROR, "frame_pin: hipMalloc: %s", hipGetErrorString(e));
+    f->allocs.push_back(p);
+    f->d_cols = (DevChunkCol*)p;
+    e = hipMalloc(&p, f->clen.size() * 8 + 64);
+    if (e != hipSuccess) { for (void* q : f->allocs) (void)hipFree(q); return fail(RDF_MEMORY_ERROR, "frame_pin: hipMalloc: %s", hipGetErrorString(e)); }
+    f->allocs.push_back(p);
+    f->d_clen = (int64_t*)p;
+    e = hipMemcpy(f->d_cols, f->dev.data(), f->dev.size() * sizeof(DevChunkCol), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(f->d_clen, f->clen.data(), f->clen.size() * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { for (void* q : f->allocs) (void)hipFree(q); return fail(RDF_DEVICE_ERROR, "frame_pin: %s", hipGetErrorString(e)); }
+    *out = f.release();
+    return RDF_OK;
+}
+
+rdf_status rdf_frame_release(rdf_frame* frame) {
+    if (!frame) return RDF_OK;
+    if (g_ctx.ready && g_ctx.stream) (void)hipStreamSynchronize(g_ctx.stream);   // kernels of this thread may still read the tables
+    for (void* q : frame->allocs) (void)hipFree(q);
+    delete frame;
+    return RDF_OK;
+}
+
+rdf_status rdf_pipeline_frame(const rdf_program* prog, rdf_frame* frame, rdf_out* outs, rdf_agg_result* aggs) {
+    if (!frame) return fail(RDF_INVALID_ARGUMENT, "pipeline_frame: null frame");
+    if (!prog || !prog->nodes || prog->nnodes <= 0) return fail(RDF_INVALID_ARGUMENT, "empty program");
+    if (prog->nvalues < 1 || prog->nvalues > RDF_MAX_VALUES) return fail(RDF_INVALID_ARGUMENT, "nvalues out of range");
+    RDF_TRY(ensure_ready());
+    if (frame->device != g_ctx.device) return fail(RDF_INVALID_ARGUMENT, "pipeline_frame: the frame was pinned on device %d", frame->device);
+    ProgramSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.nodes = prog->nodes; ps.nnodes = prog->nnodes; ps.filter_root = prog->filter_root; ps.nvalues = prog->nvalues; ps.sink = prog->sink;
+    for (int v = 0; v < prog->nvalues; ++v) ps.value_roots[v] = prog->value_roots[v];
+    if (ps.sink != RDF_SINK_STORE && ps.sink != RDF_SINK_AGG) return fail(RDF_INVALID_ARGUMENT, "bad sink");
+    return run_program(ps, nullptr, frame->ncols, frame->nchunks, outs, aggs, "columns of a batch differ in length", frame);
 }
 
 rdf_status rdf_group_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_t filter_root, int32_t group_root, int32_t ngroups,

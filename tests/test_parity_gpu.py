@@ -496,6 +496,63 @@ def test_specialised_kernels_are_the_ones_that_run(gpu, request):
         assert kern.startswith("spec_kernel<" if spec_mode else "eval_kernel<"), f"{name}: ran {kern}"
 
 
+def test_pinned_frame_pipeline(gpu, ora, request):
+    """rdf_frame_pin / rdf_pipeline_frame: the same results as rdf_pipeline over the same device-resident columns — both
+    sinks, specialised and interpreted programs, several programs on one handle (cached tables per tile size and column
+    order), nullable and unaligned chunk layouts, one chunk; host buffers and released handles are refused."""
+    import ctypes as C
+    import torch
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(404)
+    e = A.Expr()
+    c0, c1, c2 = e.col(0), e.col(1), e.col(2)
+    programs = [([c0], e.op("gt", c0, e.scalar(0.1))),                                     # the headline shape
+                ([e.op("add", e.op("multiply", c0, c1), c2)], -1),                          # C3's value
+                ([e.op("multiply", c1, e.op("subtract", e.scalar(1.0), c2))], e.op("le", c0, e.scalar(0.5))),
+                ([e.op("atan2", c0, c1)], -1)]                                              # interpreter
+    for lens, off, nf in [([1024] * 7 + [500], 0, 0.0), ([4096, 0, 1000, 64], 0, 0.2), ([3000, 2000], 3, 0.1), ([5000], 0, 0.0)]:
+        host = [make_chunks(rng, A.F64, lens, nf, off, "unit", nonzero=True) for _ in range(3)]
+        keep, dev = [], []
+        for col in host:   # the same chunks in device memory (values + bitmaps keep their element / bit offsets)
+            dcol = []
+            for ch in col:
+                vt = torch.from_numpy(np.frombuffer(ch.values.tobytes() + b"\0" * 64, dtype=np.uint8).copy()).cuda()
+                bt = None
+                if ch.validity is not None:
+                    bt = torch.from_numpy(np.frombuffer(ch.validity.tobytes() + b"\0" * 64, dtype=np.uint8).copy()).cuda()
+                keep += [vt, bt]
+                dcol.append(A.DeviceArray(vt.data_ptr(), bt.data_ptr() if bt is not None else None, ch.offset, ch.length, ch.dtype, -1))
+            dev.append(dcol)
+        torch.cuda.synchronize()
+        with A.PinnedFrame(gpu, dev) as frame:
+            for values, pred in programs:
+                exp = ora.pipeline(e, host, values, pred)[0]
+                got = gpu.pipeline(e, frame, values, pred)[0]
+                plain = gpu.pipeline(e, dev, values, pred)[0]
+                what = f"lens={lens} off={off}"
+                assert got.count == exp.count == plain.count, what
+                assert abs(got.sum - exp.sum) <= 1e-9 * max(1.0, abs(exp.sum)) and abs(got.sum - plain.sum) <= 1e-9 * max(1.0, abs(exp.sum)), what
+                if exp.count:
+                    assert (got.min, got.max) == (plain.min, plain.max), what
+            # SINK_STORE through the handle
+            v = e.op("add", e.op("multiply", c0, c1), c2)
+            outs_e = [[A.HostArray.empty_out(A.F64, n, True) for n in lens]]
+            ora.pipeline(e, host, [v], -1, A.SINK_STORE, outs_e)
+            bufs = [(torch.zeros(n * 8 + 64, dtype=torch.uint8, device="cuda"), torch.zeros(n // 8 + 72, dtype=torch.uint8, device="cuda")) for n in lens]
+            outs_g = [[A.DeviceArray(vb.data_ptr(), bb.data_ptr(), 0, n, A.F64, 0, keep=(vb, bb), capacity=n) for (vb, bb), n in zip(bufs, lens)]]
+            torch.cuda.synchronize()
+            gpu.pipeline(e, frame, [v], -1, A.SINK_STORE, outs_g)
+            lib.synchronize()
+            for (vb, bb), o, ee in zip(bufs, outs_g[0], outs_e[0]):
+                assert o.length == ee.length and o.null_count == ee.null_count
+                gv = vb.cpu().numpy()[:ee.length * 8].view(np.float64)
+                m = ee.valid_mask()
+                gm = np.unpackbits(bb.cpu().numpy()[:(ee.length + 7) // 8], bitorder="little")[:ee.length].astype(bool)
+                assert np.array_equal(gm, m) and np.array_equal(gv[m], ee.to_numpy()[m])
+    with pytest.raises(A.RdfError):       # host buffers are staged per call: nothing to pin
+        A.PinnedFrame(gpu, [make_chunks(rng, A.F64, [100], 0.0, 0)])
+
+
 def test_validity_window_load_paths_agree(gpu, ora):
     """The specialised kernels fetch a wave's validity words either with scalar loads (default) or with one vector load by
     lanes 0..NW and readlane (rdf_set_option("vec_bitmap", 1)): both give the oracle's aggregates and bitmaps on aligned,
