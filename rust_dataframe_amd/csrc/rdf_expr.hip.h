@@ -63,6 +63,8 @@ __device__ __forceinline__ uint64_t to_bits(uint64_t x) { return x; }
 __device__ __forceinline__ uint64_t to_bits(float x) { return (uint64_t)__float_as_uint(x); }
 __device__ __forceinline__ uint64_t to_bits(int32_t x) { return (uint64_t)(uint32_t)x; }
 __device__ __forceinline__ uint64_t to_bits(uint32_t x) { return (uint64_t)x; }
+__device__ __forceinline__ uint64_t to_bits(int16_t x) { return (uint64_t)(uint16_t)x; }
+__device__ __forceinline__ uint64_t to_bits(uint16_t x) { return (uint64_t)x; }
 __device__ __forceinline__ uint64_t to_bits(bool x) { return (uint64_t)x; }
 
 template <int I, int DT>
@@ -251,7 +253,7 @@ struct Cast {
 // as straight-line code: the switch below is a handful of scalar compares per row, not an interpreter.
 template <int SLOT, class A, class B>
 struct ArithRT {   // add / subtract / multiply / divide on f64 / f32 or (wrapping) i64 / u64 / i32 / u32
-    static_assert(A::dt == B::dt && (CType<A::dt>::width == 8 || CType<A::dt>::width == 4), "runtime-op arithmetic is instantiated for the 8- and 4-byte numeric types");
+    static_assert(A::dt == B::dt && (CType<A::dt>::width == 8 || CType<A::dt>::width == 4 || CType<A::dt>::width == 2), "runtime-op arithmetic is instantiated for the 8-, 4- and 2-byte numeric types");
     static constexpr int dt = A::dt;
     static constexpr int ncols = A::ncols > B::ncols ? A::ncols : B::ncols;
     static constexpr int width = merge_width(A::width, B::width);

@@ -66,6 +66,12 @@ template <> struct AggT<RDF_I32> : AggT<RDF_I64> {
 template <> struct AggT<RDF_U32> : AggT<RDF_U64> {
     __device__ __forceinline__ void add(uint32_t v) { AggT<RDF_U64>::add((uint64_t)v); }
 };
+template <> struct AggT<RDF_I16> : AggT<RDF_I64> {
+    __device__ __forceinline__ void add(int16_t v) { AggT<RDF_I64>::add((int64_t)v); }
+};
+template <> struct AggT<RDF_U16> : AggT<RDF_U64> {
+    __device__ __forceinline__ void add(uint16_t v) { AggT<RDF_U64>::add((uint64_t)v); }
+};
 
 // Lane l of a 16-byte-load wave holds RV consecutive rows (RV = 2 for 8-byte, 4 for 4-byte elements), so
 // the RV per-element ballots must be interleaved into Arrow's row-ordered bitmap words.  Every lane j picks
@@ -90,9 +96,9 @@ struct Prog {
                                    ? (PRED::ncols > V0::ncols ? PRED::ncols : V0::ncols) : V1::ncols;
     static constexpr int NC = NC_ < 1 ? 1 : NC_;
     static constexpr int W = merge_width(merge_width(PRED::width, V0::width), V1::width);  // element width of every column
-    static_assert(W == 8 || W == 4, "a program reads columns of one width (8 or 4 bytes)");
+    static_assert(W == 8 || W == 4 || W == 2, "a program reads columns of one width (8, 4 or 2 bytes)");
     static constexpr int RV = 16 / W;                 // rows per 16-byte vector
-    static constexpr int R = NC <= 2 ? 8 : 4;         // rows per lane per iteration (measured: 8 rows for 3-4 four-byte columns is slower, 0.65 -> 0.58 on a store)
+    static constexpr int R = (NC <= 2 || W == 2) ? 8 : 4;   // rows per lane per iteration; a 16-byte vector of 2-byte elements is 8 rows (measured: 8 rows for 3-4 four-byte columns is slower, 0.65 -> 0.58 on a store)
     static constexpr int U = R / RV;                  // 16-byte vectors per lane per column per iteration
     static std::string sig() { return "P:" + PRED::sig() + ";V:" + V0::sig() + ";" + V1::sig() + ";S:" + std::to_string(SINK_); }
 };
@@ -123,7 +129,7 @@ __device__ __forceinline__ void eval_rows(C& c, uint64_t (&out)[R]) {
 template <class P>
 __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     constexpr int NC = P::NC, U = P::U, R = P::R, RV = P::RV, W = P::W;
-    using S = typename std::conditional<W == 8, uint64_t, uint32_t>::type;
+    using S = typename std::conditional<W == 8, uint64_t, typename std::conditional<W == 4, uint32_t, uint16_t>::type>::type;
     using VecS = typename VecOf<S, RV>::type;
     using Pred = typename P::Pred;
     using V0 = typename P::Val0;
@@ -437,5 +443,6 @@ void spec_register_shapes3();
 void spec_register_shapes4();
 void spec_register_shapes5();
 void spec_register_shapes6();
+void spec_register_shapes7();
 
 }  // namespace rdfk

@@ -1,13 +1,14 @@
 // rdf_spec_shapes.hip — shape-level specialised kernels beyond the basic f64 / i64 families of rdf_spec.hip, compiled in
-// slices (-DRDF_SHAPE_TU=1..6) so the slices build in parallel:
+// slices (-DRDF_SHAPE_TU=1..7) so the slices build in parallel:
 //   1-3: three-level f64 / i64 trees (((l.l).l).l, (l.l).(l.l), ((l.l).l).(l.l)), plain and behind the two predicate forms;
 //   4:   the basic shapes for u64 and the 4-byte types f32 / i32 / u32 (Evaluate::calculate's type matrix,
 //        src/evaluation.rs:107-293);
-//   5-6: three-level trees of the 4-byte types and u64.
+//   5-6: three-level trees of the 4-byte types and u64;
+//   7:   i16 / u16, basic and three-level.
 #include "rdf_spec_kernel.hip.h"
 
 #ifndef RDF_SHAPE_TU
-#error "compile with -DRDF_SHAPE_TU=1..6"
+#error "compile with -DRDF_SHAPE_TU=1..7"
 #endif
 
 namespace rdfk {
@@ -32,9 +33,16 @@ void RDF_CAT(spec_register_shapes, RDF_SHAPE_TU)() {
 #elif RDF_SHAPE_TU == 5
     reg_shape_family_deep<RDF_F32, RDF_F32>();
     reg_shape_family_deep<RDF_I32, RDF_I32>();
-#else
+#elif RDF_SHAPE_TU == 6
     reg_shape_family_deep<RDF_U32, RDF_U32>();
     reg_shape_family_deep<RDF_U64, RDF_U64>();
+#else
+    // Int16 / UInt16: the narrowest types of Evaluate::calculate's matrix (src/evaluation.rs:107-238; Int8 / UInt8 are
+    // rejected there, :239).  Eight rows per 16-byte vector.
+    reg_shape_family_basic<RDF_I16, RDF_I16>();
+    reg_shape_family_basic<RDF_U16, RDF_U16>();
+    reg_shape_family_deep<RDF_I16, RDF_I16>();
+    reg_shape_family_deep<RDF_U16, RDF_U16>();
 #endif
 }
 

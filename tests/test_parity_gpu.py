@@ -481,8 +481,8 @@ def test_specialised_kernels_are_the_ones_that_run(gpu, request):
     fma = e.op("add", e.op("multiply", c0, c1), e.col(2))
     cases.append(("C3", lambda: gpu.pipeline(e, [x, y, z, k], [fma, e.col(3)])))
     cases.append(("C1", lambda: gpu.pipeline(e, [x], [e.op("sin", e.op("add", c0, e.scalar(1.0)))])))
-    # fused Calculate chains outside the exact catalog: shape-level kernels for every 8- / 4-byte type, up to three levels
-    for dt in (A.F64, A.I64, A.U64, A.F32, A.I32, A.U32):
+    # fused Calculate chains outside the exact catalog: shape-level kernels for every 8- / 4- / 2-byte type, up to three levels
+    for dt in (A.F64, A.I64, A.U64, A.F32, A.I32, A.U32, A.I16, A.U16):
         cols = [make_chunks(rng, dt, [n], 0.0, 0, nonzero=True) for _ in range(3)]
         ks = e.scalar(2.0 if dt in (A.F64, A.F32) else 2, dt)
         two = e.op("subtract", e.op("multiply", c0, ks), c1)
@@ -824,11 +824,11 @@ def test_shape_specialised_kernels_i64_and_mixed_predicates(gpu, ora, request):
     assert (got.sum, got.min, got.max) == (exp.sum, exp.min, exp.max)
 
 
-@pytest.mark.parametrize("dtype", [A.F64, A.I64, A.U64, A.F32, A.I32, A.U32])
+@pytest.mark.parametrize("dtype", [A.F64, A.I64, A.U64, A.F32, A.I32, A.U32, A.I16, A.U16])
 def test_shape_kernels_three_levels_and_every_wide_type(gpu, ora, request, dtype):
     """Evaluate::calculate's type matrix (src/evaluation.rs:107-293) as fused chains: one- to three-level arithmetic trees
     (left-deep, balanced, a two-level beside a one-level subtree, in either operand order), sin / cos / tan on top for
-    the float types, plain and behind `x CMP c`, both sinks, on every 8- and 4-byte numeric type.  In 'spec' mode they
+    the float types, plain and behind `x CMP c`, both sinks, on every 8-, 4- and 2-byte numeric type.  In 'spec' mode they
     must run on a shape-specialised kernel; the results equal the oracle's unfused evaluation (integers bit-exact)."""
     from rust_dataframe_amd import lib
     spec_mode = request.node.callspec.params["gpu"] == "spec"

@@ -19,8 +19,9 @@ from rust_dataframe_amd import lib  # noqa: E402
 from bench_kernels import timed  # noqa: E402
 
 PEAK = 8000.0
-TORCH_OF = {A.F64: torch.float64, A.I64: torch.int64, A.U64: torch.int64, A.F32: torch.float32, A.I32: torch.int32, A.U32: torch.int32}
-NAME = {A.F64: "f64", A.I64: "i64", A.U64: "u64", A.F32: "f32", A.I32: "i32", A.U32: "u32"}
+ES = {A.F64: 8, A.I64: 8, A.U64: 8, A.F32: 4, A.I32: 4, A.U32: 4, A.I16: 2, A.U16: 2}
+TORCH_OF = {A.F64: torch.float64, A.I64: torch.int64, A.U64: torch.int64, A.F32: torch.float32, A.I32: torch.int32, A.U32: torch.int32, A.I16: torch.int16, A.U16: torch.int16}
+NAME = {A.F64: "f64", A.I64: "i64", A.U64: "u64", A.F32: "f32", A.I32: "i32", A.U32: "u32", A.I16: "i16", A.U16: "u16"}
 
 
 def column(dt, n, seed):
@@ -33,7 +34,7 @@ def column(dt, n, seed):
 
 
 def out(dt, n):
-    es = 8 if dt in (A.F64, A.I64, A.U64) else 4
+    es = ES[dt]
     v = torch.empty((n + 63) // 64 * 64 * es, dtype=torch.uint8, device="cuda")
     return A.DeviceArray(v.data_ptr(), None, 0, n, dt, 0, keep=(v,))
 
@@ -43,17 +44,17 @@ def main():
     ap.add_argument("--rows", type=int, default=250_000_000)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--interp", action="store_true", help="also time the general evaluator on the same programs")
-    ap.add_argument("--dtypes", type=str, default="f64,i64,u64,f32,i32,u32")
+    ap.add_argument("--dtypes", type=str, default="f64,i64,u64,f32,i32,u32,i16,u16")
     ap.add_argument("--programs", type=str, default="", help="comma list of program names (default: all)")
     ap.add_argument("--sinks", type=str, default="agg,store,filter_agg")
     args = ap.parse_args()
     n = args.rows
     lib.set_device(0)
     api = lib.api()
-    for dt in (A.F64, A.I64, A.U64, A.F32, A.I32, A.U32):
+    for dt in (A.F64, A.I64, A.U64, A.F32, A.I32, A.U32, A.I16, A.U16):
         if NAME[dt] not in args.dtypes.split(","):
             continue
-        es = 8 if dt in (A.F64, A.I64, A.U64) else 4
+        es = ES[dt]
         is_float = dt in (A.F64, A.F32)
         cols = [[column(dt, n, 10 * dt + i)] for i in range(3)]
         o = out(dt, n)
