@@ -826,7 +826,14 @@ struct ShapeSigBuilder {
             if (dl < dr || (dl == 0 && dr == 0 && is_scalar(l) && is_column(r))) swap = true;
         }
         const int slot = nslots++;
-        rt[slot] = op | (swap ? 0x100 : 0);
+        if (swap && cmp) {          // x CMP c with the literal first: the mirrored operator, operands in canonical order
+            const int m = op == RDF_OP_GT ? RDF_OP_LT : op == RDF_OP_GE ? RDF_OP_LE : op == RDF_OP_LT ? RDF_OP_GT : op == RDF_OP_LE ? RDF_OP_GE : op;
+            rt[slot] = m;
+        } else if (swap && (op == RDF_OP_ADD || op == RDF_OP_MUL)) {
+            rt[slot] = op;          // commutative (IEEE addition / multiplication and the wrapping integer ones): no swap needed
+        } else {
+            rt[slot] = op | (swap ? 0x100 : 0);
+        }
         if (swap) std::swap(l, r);
         std::string a, b;
         if (cmp) {   // the column keeps its own dtype, the literal is compared in f64 (src/expression.rs:844-845)
