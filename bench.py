@@ -196,7 +196,14 @@ def workload_c4(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, ngroups
     ex = sharding.GroupExchange(api, lib, torch, dev, comm_dev, cap) if world > 1 else None
     last = {}
 
+    # with about as many groups as rows pre-aggregation cannot shrink the shard: the rows are shuffled instead
+    shuffle = world > 1 and (os.environ.get("RDF_C4_SHUFFLE_ROWS") == "1" or sharding.shuffle_rows_pays(rows, ngroups))
+
     def step():
+        if shuffle:
+            ok_, mk2, mc2 = ex.shuffle_rows_and_aggregate(K, V, ngroups)
+            last["groups"] = (ok_[0], mk2, mc2)
+            return {"groups_owned": ok_[0].length, "exchange": "rows"}
         gk, gs, gc = api.groupby_sum([K], [V], ngroups, outs)
         ng = gk.length
         if world == 1:

@@ -301,6 +301,11 @@ rdf_status rdf_groupby_merge(const rdf_array* keys, const rdf_array* partial, co
 rdf_status rdf_group_exchange_pack(const rdf_array* keys, const rdf_array* partial, const rdf_array* counts, int32_t world,
                                    void* packed_dev, int64_t* owner_counts);
 rdf_status rdf_group_exchange_unpack(const void* packed_dev, int64_t n, rdf_out* keys, rdf_out* partial, rdf_out* counts);
+/* The row-shuffle fallback of the same exchange: when a rank's rows hold about as many groups as rows, pre-aggregating
+ * them gains nothing — the rows themselves are bucketed by owner (16 bytes each: key, value; no NULLs), exchanged the
+ * same way, and every rank runs rdf_groupby_agg over the rows it received.  packed_dev: 16 * rows bytes. */
+rdf_status rdf_row_exchange_pack(const rdf_array* keys, const rdf_array* values, int32_t world, void* packed_dev, int64_t* owner_counts);
+rdf_status rdf_row_exchange_unpack(const void* packed_dev, int64_t n, rdf_out* keys, rdf_out* values);
 
 /* ------------------------------------------------------------------ ArrayFunctions over List<primitive> columns */
 

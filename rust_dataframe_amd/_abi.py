@@ -734,6 +734,23 @@ class Api:
             o.length = n
         return keys, partial, counts
 
+    def row_exchange_pack(self, keys, values, world: int, packed_ptr: int) -> List[int]:
+        """Device-resident ROWS (key, value) -> `packed_ptr` ([n][2] int64 words grouped by owning rank); returns rows per rank."""
+        oc = (C.c_int64 * world)()
+        fn = self._fn("row_exchange_pack")
+        fn.restype = C.c_int
+        self._check(fn((rdf_array * 1)(keys.c_struct()), (rdf_array * 1)(values.c_struct()), C.c_int32(world), C.c_void_p(packed_ptr), oc))
+        return [oc[r] for r in range(world)]
+
+    def row_exchange_unpack(self, packed_ptr: int, n: int, keys, values):
+        fn = self._fn("row_exchange_unpack")
+        fn.restype = C.c_int
+        carr = [(rdf_out * 1)(o.out_struct()) for o in (keys, values)]
+        self._check(fn(C.c_void_p(packed_ptr), C.c_int64(n), carr[0], carr[1]))
+        for o in (keys, values):
+            o.length = n
+        return keys, values
+
     # ---- ArrayFunctions over List<primitive> (src/functions/array.rs)
     def _scalar(self, value, dtype: int):
         return np.array([value], dtype=NP_OF.get(dtype, np.int64))   # an unsupported child dtype is the library's to reject

@@ -421,7 +421,8 @@ struct GxPackArgs {
     int32_t         world, phase;        // phase 0: count rows per owner; 1: scatter to offsets
     unsigned long long* owner_counts;    // [world]
     unsigned long long* cursors;         // [world] running write positions (start = exclusive scan of owner_counts)
-    uint64_t*       packed;              // [n * 3]
+    uint64_t*       packed;              // [n * words]
+    int32_t         words, pad;          // 3: (key, partial, count) triples; 2: (key, value) rows (counts == nullptr)
 };
 // several key columns <-> one packed 64-bit key (range-compressed fields; code 0 of a nullable field = NULL)
 constexpr int kMaxKeyCols = 4;
@@ -449,7 +450,7 @@ hipError_t launch_gb2_emit(const GroupEmitArgs& a, hipStream_t s);
 hipError_t launch_gb2_finish(const Gb2FinishArgs& a, hipStream_t s);
 hipError_t launch_gb2_fill(uint64_t* p, int64_t n, uint64_t v, hipStream_t s);
 hipError_t launch_gx_pack(const GxPackArgs& a, hipStream_t s);
-hipError_t launch_gx_unpack(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts, hipStream_t s);
+hipError_t launch_gx_unpack(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts, int words, hipStream_t s);
 hipError_t launch_key_pack(const KeyPackArgs& a, hipStream_t s);
 hipError_t launch_key_unpack(const KeyPackArgs& a, hipStream_t s);
 size_t gb2_scatter_lds_bytes();

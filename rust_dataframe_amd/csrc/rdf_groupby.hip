@@ -772,14 +772,15 @@ __global__ __launch_bounds__(kBlock) void gx_pack_kernel(const GxPackArgs a) {
         const uint64_t k = a.keys[i];
         const uint32_t o = gx_owner(k, a.world);
         const unsigned long long pos = lbase[o] + atomicAdd(&lc[o], 1u);
-        a.packed[3 * pos] = k;
-        a.packed[3 * pos + 1] = a.acc[i];
-        a.packed[3 * pos + 2] = (uint64_t)a.counts[i];
+        a.packed[a.words * pos] = k;
+        a.packed[a.words * pos + 1] = a.acc[i];
+        if (a.words == 3) a.packed[3 * pos + 2] = (uint64_t)a.counts[i];
     }
 }
-__global__ __launch_bounds__(kBlock) void gx_unpack_kernel(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts) {
+__global__ __launch_bounds__(kBlock) void gx_unpack_kernel(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts, int words) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        keys[i] = packed[3 * i]; acc[i] = packed[3 * i + 1]; counts[i] = (int64_t)packed[3 * i + 2];
+        keys[i] = packed[words * i]; acc[i] = packed[words * i + 1];
+        if (words == 3) counts[i] = (int64_t)packed[3 * i + 2];
     }
 }
 
@@ -923,8 +924,8 @@ hipError_t launch_gx_pack(const GxPackArgs& a, hipStream_t s) {
     }
     return hipGetLastError();
 }
-hipError_t launch_gx_unpack(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(gx_unpack_kernel, dim3(g2_rows_grid(n)), dim3(kBlock), 0, s, packed, n, keys, acc, counts);
+hipError_t launch_gx_unpack(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts, int words, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(gx_unpack_kernel, dim3(g2_rows_grid(n)), dim3(kBlock), 0, s, packed, n, keys, acc, counts, words);
     return hipGetLastError();
 }
 hipError_t launch_key_pack(const KeyPackArgs& a, hipStream_t s) {

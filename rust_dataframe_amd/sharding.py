@@ -227,12 +227,34 @@ def exchange_groups(keys, sums, counts, device=None):
     return r[:, 0].copy().view(keys.dtype), r[:, 1].copy().view(sums.dtype), r[:, 2].copy().view(counts.dtype)
 
 
-def distributed_groupby_sum(api, keys_chunks, value_chunks, max_groups: int, device=None):
+def shuffle_rows_pays(local_rows: int, max_groups: int) -> bool:
+    """pre-aggregating a shard only pays when it shrinks it.  With about as many groups as rows (the promise
+    `max_groups` is at least half the shard's rows) the rows themselves are exchanged and aggregated once, at their owner."""
+    return 2 * max_groups >= local_rows
+
+
+def distributed_groupby_sum(api, keys_chunks, value_chunks, max_groups: int, device=None, shuffle_rows=None):
     """GROUP BY over row-sharded data with host-resident results: local hash aggregate -> exchange_groups -> ONE merge of
-    the received partials (rdf_groupby_merge: sums added, counts added, dtypes kept).  `api` is the engine.  Returns numpy
-    (keys, sums, counts) of the groups this rank owns, sorted by key; the union over ranks is the full result."""
+    the received partials (rdf_groupby_merge: sums added, counts added, dtypes kept) — or, when pre-aggregation cannot
+    shrink the shard (`shuffle_rows`, default shuffle_rows_pays), the rows are exchanged and aggregated at their owner.
+    `api` is the engine.  Returns numpy (keys, sums, counts) of the groups this rank owns, sorted by key; the union over
+    ranks is the full result."""
     import numpy as np
     from ._abi import HostArray
+    local_rows = sum(ch.length for ch in keys_chunks)
+    if shuffle_rows is None:
+        shuffle_rows = shuffle_rows_pays(local_rows, max_groups)
+    if shuffle_rows and all(ch.validity is None for ch in list(keys_chunks) + list(value_chunks)):
+        kk = np.concatenate([ch.to_numpy() for ch in keys_chunks]) if keys_chunks else np.zeros(0, np.int64)
+        vv = np.concatenate([ch.to_numpy() for ch in value_chunks]) if value_chunks else np.zeros(0)
+        wide = np.uint64 if kk.dtype.kind == "u" else np.int64
+        vwide = np.float64 if vv.dtype.kind == "f" else (np.uint64 if vv.dtype.kind == "u" else np.int64)
+        rk, rv, _ = exchange_groups(kk.astype(wide), vv.astype(vwide), np.ones(len(kk), dtype=np.int64), device)
+        if len(rk) == 0:
+            return rk, rv, np.zeros(0, dtype=np.int64)
+        mk, ms, mc = api.groupby_sum([HostArray.from_numpy(rk)], [HostArray.from_numpy(rv)], max_groups)
+        o = np.argsort(mk.to_numpy())
+        return mk.to_numpy()[o], ms.to_numpy()[o], mc.to_numpy()[o]
     k, s, c = api.groupby_sum(keys_chunks, value_chunks, max_groups)
     if k.null_count:
         raise ValueError("distributed group-by: NULL keys are not supported in the exchange")
@@ -293,3 +315,36 @@ class GroupExchange:
         torch.cuda.current_stream().synchronize()
         self.api.group_exchange_unpack(recv.data_ptr(), m, rk, rs, rc)
         return self.api.groupby_merge(rk, rs, rc, agg, max_groups, outs=self._merged(gk.dtype, gs.dtype))
+
+    def shuffle_rows_and_aggregate(self, K, V, max_groups: int, agg: str = "sum"):
+        """The row-shuffle fallback: the shard's ROWS (one device chunk of 8-byte keys, one of 8-byte values, no
+        NULLs) are bucketed by owner on the device (rdf_row_exchange_pack, 16 bytes per row), travel with one
+        all_to_all_single, and the owner runs one rdf_groupby_agg over what it received."""
+        import torch.distributed as dist
+        from ._abi import DeviceArray
+        torch = self.torch
+        world = dist.get_world_size()
+        n = K.length
+        if getattr(self, "_rows_packed", None) is None or self._rows_packed.numel() < 2 * n + 8:
+            self._rows_packed = torch.empty(2 * n + 8, dtype=torch.int64, device=self.dev)
+        torch.cuda.current_stream().synchronize()
+        send_counts = self.api.row_exchange_pack(K, V, world, self._rows_packed.data_ptr())
+        cd = self.comm_dev if self.comm_dev is not None else "cpu"
+        t_sc = torch.tensor(send_counts, dtype=torch.int64, device=cd)
+        t_rc = torch.zeros(world, dtype=torch.int64, device=cd)
+        dist.all_to_all_single(t_rc, t_sc)
+        recv_counts = [int(x) for x in t_rc.tolist()]
+        m = sum(recv_counts)
+        send = self._rows_packed[:2 * n].view(n, 2)
+        if self.comm_dev is None:
+            send = send.cpu()
+        recv = torch.empty((m, 2), dtype=torch.int64, device=cd)
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts)
+        if self.comm_dev is None:
+            recv = recv.to(self.dev)
+        cols = [torch.empty(m + 8, dtype=torch.int64, device=self.dev) for _ in range(2)]
+        rk, rv = (DeviceArray(t.data_ptr(), None, 0, m, dt, 0, keep=t, capacity=m) for t, dt in zip(cols, (K.dtype, V.dtype)))
+        torch.cuda.current_stream().synchronize()
+        self.api.row_exchange_unpack(recv.data_ptr(), m, rk, rv)
+        ko, so, co = self._merged(K.dtype, self.api._agg_out_dtype(self.api.AGGS[agg], V.dtype))
+        return self.api.groupby_agg([[rk]], [rv], agg, max_groups, ([ko], so, co))

@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(workload, gpus, rows, port):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(workload, gpus, rows, port, **extra_env):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     base = [os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--rows", str(rows), "--cpu-sample", "0",
             "--workload", workload]
     if gpus > 1:
@@ -44,6 +44,14 @@ def test_c4_two_ranks_device_exchange():
     cfg = two["config"]
     assert two["n_gpus"] == 2 and cfg["self_check"] is True and cfg["parity_on_sample"] is True, cfg
     assert cfg["groups_total"] == 1_000_000          # every key owned by exactly one rank, none lost, none twice
+
+
+def test_c4_two_ranks_row_shuffle():
+    """SURVEY.md 8e's fallback: the rows themselves are bucketed on the device, exchanged and aggregated at their owner."""
+    two = _run("c4", 2, 10_000_000, 29641, RDF_C4_SHUFFLE_ROWS="1")
+    cfg = two["config"]
+    assert two["n_gpus"] == 2 and cfg["self_check"] is True and cfg["parity_on_sample"] is True, cfg
+    assert cfg["groups_total"] == 1_000_000 and cfg["result"].get("exchange") == "rows", cfg
 
 
 def test_q1_two_ranks_equal_one():

@@ -118,7 +118,8 @@ def _gb_worker(rank, world, port, q):
         keys, vals = _gb_data()
         n = len(keys)
         b, e = sharding.shard_rows(n, world, rank)
-        k, s, c = sharding.distributed_groupby_sum(oracle.api(), [A.HostArray.from_numpy(keys[b:e])], [A.HostArray.from_numpy(vals[b:e])], 1000)
+        k, s, c = sharding.distributed_groupby_sum(oracle.api(), [A.HostArray.from_numpy(keys[b:e])], [A.HostArray.from_numpy(vals[b:e])], 1000,
+                                                   shuffle_rows=os.environ.get("RDF_TEST_SHUFFLE_ROWS") == "1")
         q.put((rank, k.tolist(), s.tolist(), c.tolist()))
     finally:
         dist.destroy_process_group()
@@ -131,9 +132,13 @@ def _gb_data():
 
 
 @pytest.mark.timeout(120)
-def test_groupby_all_to_all_world_2_gloo(ora):
-    """Local pre-aggregation -> hash-partitioned all-to-all of partial groups -> local merge."""
-    world, port = 2, 31500 + os.getpid() % 2000
+@pytest.mark.parametrize("shuffle_rows", [False, True])
+def test_groupby_all_to_all_world_2_gloo(ora, shuffle_rows, monkeypatch):
+    """Local pre-aggregation -> hash-partitioned all-to-all of partial groups -> local merge, and the
+    row-shuffle fallback of the same section (rows exchanged, aggregated once at their owner): the same groups either way."""
+    monkeypatch.setenv("RDF_TEST_SHUFFLE_ROWS", "1" if shuffle_rows else "0")
+    assert sharding.shuffle_rows_pays(1000, 600) and not sharding.shuffle_rows_pays(10_000_000, 1_000_000)
+    world, port = 2, 31500 + os.getpid() % 2000 + (50 if shuffle_rows else 0)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_gb_worker, args=(r, world, port, q)) for r in range(world)]

@@ -5,7 +5,7 @@
 # Counters are collected in their own passes (one --pmc counter per pass, kernel trace only), as the MI355X guide asks.
 set -u
 R=${1:-r02}
-PART=${2:-all}      # all | micro (only the per-entry counter passes of step 3b)
+PART=${2:-all}      # all | micro (only the per-entry counter passes of step 3b) | workloads (only the three bench lines of step 2)
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profile_$R
 mkdir -p "$OUT"
@@ -16,6 +16,11 @@ pmc() {   # pmc <tag> <command...>: FETCH_SIZE and WRITE_SIZE of every kernel of
         timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_${tag}_$c" -o p -- "$@" > "$OUT/pmc_${tag}_$c.out" 2> "$OUT/pmc_${tag}_$c.err"
     done
 }
+if [ "$PART" = "workloads" ]; then
+    rm -f "$OUT/workloads.jsonl"
+    for w in c3 c4 q1; do python "$REPO/bench.py" --workload $w --steps 10 --warmup 3 2>> "$OUT/workloads.err" | tail -1 >> "$OUT/workloads.jsonl"; done
+    exit 0
+fi
 if [ "$PART" = "all" ]; then
 # 1. the driver's bench line, the same under the kernel trace, and on the reference's 1024-row batches
 python "$REPO/bench.py" > "$OUT/bench_1e9.json" 2> "$OUT/bench_1e9.err"
@@ -25,7 +30,7 @@ python "$REPO/bench.py" --cpu-sample 0 --null-fraction 0.1 > "$OUT/bench_1e9_val
 pmc headline python "$REPO/bench.py" --steps 5 --warmup 1 --cpu-sample 0
 # 2. the other configs of BASELINE.json: bench lines + HBM counters of their kernels
 for w in c3 c4 q1; do
-    python "$REPO/bench.py" --workload $w --steps 5 --warmup 2 2>> "$OUT/workloads.err" | tail -1 >> "$OUT/workloads.jsonl"
+    python "$REPO/bench.py" --workload $w --steps 10 --warmup 3 2>> "$OUT/workloads.err" | tail -1 >> "$OUT/workloads.jsonl"
     pmc $w python "$REPO/bench.py" --workload $w --steps 3 --warmup 1 --cpu-sample 0
 done
 # 3. per-kernel micro-benchmarks, shape kernels, compaction / take counters
