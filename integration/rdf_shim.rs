@@ -109,6 +109,9 @@ pub mod sys {
                                        packed_dev: *mut c_void, owner_counts: *mut i64) -> i32;
         pub fn rdf_group_exchange_unpack(packed_dev: *const c_void, n: i64, keys: *mut rdf_out, partial: *mut rdf_out,
                                          counts: *mut rdf_out) -> i32;
+        pub fn rdf_row_exchange_pack(keys: *const rdf_array, values: *const rdf_array, world: i32, packed_dev: *mut c_void,
+                                     owner_counts: *mut i64) -> i32;
+        pub fn rdf_row_exchange_unpack(packed_dev: *const c_void, n: i64, keys: *mut rdf_out, values: *mut rdf_out) -> i32;
         pub fn rdf_group_pipeline(nodes: *const rdf_expr_node, nnodes: i32, filter_root: i32, group_root: i32, ngroups: i32,
                                   value_roots: *const i32, nvalues: i32, cols: *const rdf_array, ncols: i32, nchunks: i64,
                                   out: *mut rdf_group_result, group_rows: *mut i64) -> i32;
