@@ -67,6 +67,17 @@ __device__ __forceinline__ uint64_t to_bits(int16_t x) { return (uint64_t)(uint1
 __device__ __forceinline__ uint64_t to_bits(uint16_t x) { return (uint64_t)x; }
 __device__ __forceinline__ uint64_t to_bits(bool x) { return (uint64_t)x; }
 
+// Rows at once.  Every node also answers eval_rows<R>(ctx, out[R]); the default walks eval<r>.  The runtime-operator nodes
+// override it: they take their children's R values first and test the (wave-uniform) operator word ONCE per wave iteration
+// instead of once per row — a 4- or 2-byte program is bound by instruction issue, not by HBM, and the per-row form spends
+// as many scalar compare / branch instructions on dispatch as it spends vector instructions on data.
+template <class E, int R, int r = 0, class C, class T>
+__device__ __forceinline__ void eval_each(C& c, T (&out)[R]) {
+    if constexpr (r < R) { out[r] = E::template eval<r>(c); eval_each<E, R, r + 1>(c, out); }
+}
+#define RDF_DEFAULT_EVAL_ROWS(SELF)                                                                                          \
+    template <int R, class C> static __device__ __forceinline__ void eval_rows(C& c, T (&out)[R]) { eval_each<SELF, R>(c, out); }
+
 template <int I, int DT>
 struct Col {
     static constexpr int dt = DT;
@@ -75,6 +86,7 @@ struct Col {
     using T = typename CType<DT>::T;
     template <int k> static constexpr int colw() { return k == I ? CType<DT>::width : 0; }
     template <int r, class C> static __device__ __forceinline__ T eval(C& c) { return from_bits<T>((uint64_t)c.v[I][r]); }
+    RDF_DEFAULT_EVAL_ROWS(Col)
     template <class C> static __device__ __forceinline__ uint32_t vmask(const C& c) { return c.valid[I]; }
     static std::string sig() { return std::string("c") + char('0' + I) + CType<DT>::tag; }
 };
@@ -86,6 +98,7 @@ struct Imm {
     using T = typename CType<DT>::T;
     template <int k> static constexpr int colw() { return 0; }
     template <int r, class C> static __device__ __forceinline__ T eval(C& c) { return from_bits<T>(c.imm[K]); }
+    RDF_DEFAULT_EVAL_ROWS(Imm)
     template <class C> static __device__ __forceinline__ uint32_t vmask(const C&) { return ~0u; }
     static std::string sig() { return std::string("k") + char('0' + K) + CType<DT>::tag; }
 };
@@ -142,6 +155,7 @@ struct Bin {
             }
         }
     }
+    RDF_DEFAULT_EVAL_ROWS(Bin)
     static std::string sig() { return "(" + std::to_string(OP) + " " + A::sig() + " " + B::sig() + ")"; }
 };
 
@@ -184,6 +198,7 @@ struct Un {
         else if constexpr (OP == RDF_OP_CSC) return (T)1 / rdf_sin(x);
         else return tanh(x);
     }
+    RDF_DEFAULT_EVAL_ROWS(Un)
     static std::string sig() { return "[" + std::to_string(OP) + " " + A::sig() + "]"; }
 };
 
@@ -245,6 +260,7 @@ struct Cast {
         else if constexpr (cast_lossy(A::dt, TO)) return cast_fits<TO>(x) ? (T)x : (T)0;   // (a float out of range must not reach the conversion)
         else return (T)x;
     }
+    RDF_DEFAULT_EVAL_ROWS(Cast)
     static std::string sig() { return "{" + std::to_string(TO) + " " + A::sig() + "}"; }
 };
 
@@ -302,6 +318,45 @@ struct ArithRT {   // add / subtract / multiply / divide on f64 / f32 or (wrappi
             else return x / y;
         }
     }
+    template <int R, class C> static __device__ __forceinline__ void eval_rows(C& c, T (&out)[R]) {
+        T a[R], b[R];
+        A::template eval_rows<R>(c, a);
+        B::template eval_rows<R>(c, b);
+        const int rt = c.rt[SLOT];
+        using U0 = typename std::conditional<std::is_floating_point<T>::value, T, typename std::make_unsigned<typename std::conditional<std::is_floating_point<T>::value, int, T>::type>::type>::type;
+        if (rt == RDF_OP_ADD) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) out[r] = (T)((U0)a[r] + (U0)b[r]);
+            return;
+        }
+        if (rt == RDF_OP_MUL) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) out[r] = (T)((U0)a[r] * (U0)b[r]);
+            return;
+        }
+        if (rt == RDF_OP_SUB) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) out[r] = (T)((U0)a[r] - (U0)b[r]);
+            return;
+        }
+        if (rt == (RDF_OP_SUB | 0x100)) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) out[r] = (T)((U0)b[r] - (U0)a[r]);
+            return;
+        }
+        // division (either operand order); a zero divisor at a live row raises the error flag
+        const bool sw = (rt >> 8) & 1;
+        const uint32_t live = vmask(c) & c.inr;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const T x = sw ? b[r] : a[r], y = sw ? a[r] : b[r];
+            const bool z = y == (T)0;
+            if (z && ((live >> r) & 1)) c.err |= 1u;
+            if constexpr (dt_float(dt)) out[r] = z ? (T)0 : x / y;
+            else if constexpr (dt_signed(dt)) { using U = typename std::make_unsigned<T>::type; out[r] = z ? (T)0 : (y == (T)-1 ? (T)((U)0 - (U)x) : (T)(x / y)); }
+            else out[r] = z ? (T)0 : (T)(x / y);
+        }
+    }
     static std::string sig() { return "(A" + std::to_string(SLOT) + " " + A::sig() + " " + B::sig() + ")"; }
 };
 template <int SLOT, class A>
@@ -319,6 +374,21 @@ struct TrigRT {    // sin / cos / tan: the three the reference's Evaluate::calcu
         if (op == RDF_OP_SIN) return rdf_sin(x);
         if (op == RDF_OP_COS) return rdf_cos(x);
         return rdf_tan(x);
+    }
+    template <int R, class C> static __device__ __forceinline__ void eval_rows(C& c, T (&out)[R]) {
+        T a[R];
+        A::template eval_rows<R>(c, a);
+        const int op = c.rt[SLOT] & 0xFF;
+        if (op == RDF_OP_SIN) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) out[r] = rdf_sin(a[r]);
+        } else if (op == RDF_OP_COS) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) out[r] = rdf_cos(a[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) out[r] = rdf_tan(a[r]);
+        }
     }
     static std::string sig() { return "[T" + std::to_string(SLOT) + " " + A::sig() + "]"; }
 };
@@ -340,6 +410,30 @@ struct CmpRT {     // gt / ge / eq / ne / lt / le, both sides as f64 (src/expres
         if (op == RDF_OP_LT) return a < b;
         return a <= b;
     }
+    // bit r = the comparison holds at row r (operator tested once, not per row)
+    static constexpr bool has_row_mask = true;
+    template <int R, class C> static __device__ __forceinline__ uint32_t eval_mask(C& c) {
+        typename A::T a[R];
+        typename B::T b[R];
+        A::template eval_rows<R>(c, a);
+        B::template eval_rows<R>(c, b);
+        const int op = c.rt[SLOT] & 0xFF;
+        uint32_t m = 0;
+#define RDF_CMP_ROWS(REL) _Pragma("unroll") for (int r = 0; r < R; ++r) m |= (uint32_t)((double)a[r] REL (double)b[r]) << r
+        if (op == RDF_OP_GT) { RDF_CMP_ROWS(>); }
+        else if (op == RDF_OP_GE) { RDF_CMP_ROWS(>=); }
+        else if (op == RDF_OP_EQ) { RDF_CMP_ROWS(==); }
+        else if (op == RDF_OP_NE) { RDF_CMP_ROWS(!=); }
+        else if (op == RDF_OP_LT) { RDF_CMP_ROWS(<); }
+        else { RDF_CMP_ROWS(<=); }
+#undef RDF_CMP_ROWS
+        return m;
+    }
+    template <int R, class C> static __device__ __forceinline__ void eval_rows(C& c, bool (&out)[R]) {
+        const uint32_t m = eval_mask<R>(c);
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[r] = (m >> r) & 1;
+    }
     static std::string sig() { return "(C" + std::to_string(SLOT) + " " + A::sig() + " " + B::sig() + ")"; }
 };
 template <int SLOT, class A, class B>
@@ -354,6 +448,16 @@ struct LogicRT {   // and / or on booleans, NULL if either side is NULL (arrow::
     template <int r, class C> static __device__ __forceinline__ bool eval(C& c) {
         const bool x = A::template eval<r>(c), y = B::template eval<r>(c);
         return (c.rt[SLOT] & 0xFF) == RDF_OP_AND ? (x && y) : (x || y);
+    }
+    static constexpr bool has_row_mask = true;
+    template <int R, class C> static __device__ __forceinline__ uint32_t eval_mask(C& c) {
+        const uint32_t x = A::template eval_mask<R>(c), y = B::template eval_mask<R>(c);
+        return (c.rt[SLOT] & 0xFF) == RDF_OP_AND ? (x & y) : (x | y);
+    }
+    template <int R, class C> static __device__ __forceinline__ void eval_rows(C& c, bool (&out)[R]) {
+        const uint32_t m = eval_mask<R>(c);
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[r] = (m >> r) & 1;
     }
     static std::string sig() { return "(G" + std::to_string(SLOT) + " " + A::sig() + " " + B::sig() + ")"; }
 };

@@ -103,27 +103,35 @@ struct Prog {
     static std::string sig() { return "P:" + PRED::sig() + ";V:" + V0::sig() + ";" + V1::sig() + ";S:" + std::to_string(SINK_); }
 };
 
+// sinks over the R rows of a wave iteration (rows-at-once evaluation, rdf_expr.hip.h)
 template <class E, int R, int r, class C, class AGG>
 __device__ __forceinline__ void agg_rows(C& c, uint32_t live, AGG& g) {
-    if constexpr (r < R) {
-        const auto v = E::template eval<r>(c);
-        if ((live >> r) & 1) g.add(v);
-        agg_rows<E, R, r + 1>(c, live, g);
-    }
+    static_assert(r == 0, "all rows at once");
+    typename E::T v[R];
+    E::template eval_rows<R>(c, v);
+#pragma unroll
+    for (int i = 0; i < R; ++i) if ((live >> i) & 1) g.add(v[i]);
 }
+template <class E, class = void> struct HasRowMask : std::false_type {};
+template <class E> struct HasRowMask<E, typename std::enable_if<E::has_row_mask>::type> : std::true_type {};
 template <class E, int R, int r, class C>
 __device__ __forceinline__ void pred_rows(C& c, uint32_t& keep) {
-    if constexpr (r < R) {
-        if (!E::template eval<r>(c)) keep &= ~(1u << r);
-        pred_rows<E, R, r + 1>(c, keep);
+    static_assert(r == 0, "all rows at once");
+    if constexpr (HasRowMask<E>::value) keep &= E::template eval_mask<R>(c);
+    else {
+        bool v[R];
+        E::template eval_rows<R>(c, v);
+#pragma unroll
+        for (int i = 0; i < R; ++i) if (!v[i]) keep &= ~(1u << i);
     }
 }
 template <class E, int R, int r, class C>
 __device__ __forceinline__ void eval_rows(C& c, uint64_t (&out)[R]) {
-    if constexpr (r < R) {
-        out[r] = to_bits(E::template eval<r>(c));
-        eval_rows<E, R, r + 1>(c, out);
-    }
+    static_assert(r == 0, "all rows at once");
+    typename E::T v[R];
+    E::template eval_rows<R>(c, v);
+#pragma unroll
+    for (int i = 0; i < R; ++i) out[i] = to_bits(v[i]);
 }
 
 template <class P>
