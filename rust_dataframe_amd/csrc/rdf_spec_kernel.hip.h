@@ -98,7 +98,10 @@ struct Prog {
     static constexpr int W = merge_width(merge_width(PRED::width, V0::width), V1::width);  // element width of every column
     static_assert(W == 8 || W == 4 || W == 2, "a program reads columns of one width (8, 4 or 2 bytes)");
     static constexpr int RV = 16 / W;                 // rows per 16-byte vector
-    static constexpr int R = (NC <= 2 || W == 2) ? 8 : 4;   // rows per lane per iteration; a 16-byte vector of 2-byte elements is 8 rows (measured: 8 rows for 3-4 four-byte columns is slower, 0.65 -> 0.58 on a store)
+    // rows per lane per iteration.  A 16-byte vector of 2-byte elements is 8 rows.  Measured on the 4-byte types: 8 rows pay for
+    // a 3-column aggregate (0.62 -> 0.75 of peak: half the per-iteration overhead) but cost a 3-column store (0.70 -> 0.65) and
+    // 4-column programs (0.75 -> 0.73) more in registers than they save
+    static constexpr int R = (NC <= 2 || W == 2 || (W == 4 && NC == 3 && SINK_ == SINK_AGG)) ? 8 : 4;
     static constexpr int U = R / RV;                  // 16-byte vectors per lane per column per iteration
     static std::string sig() { return "P:" + PRED::sig() + ";V:" + V0::sig() + ";" + V1::sig() + ";S:" + std::to_string(SINK_); }
 };
