@@ -665,7 +665,8 @@ struct SpecPlan {
     uint64_t imm[kGSpecImm];
     char imm_tag[kGSpecImm];
     int nimm = 0;
-    int width = 0;       // common element width of the columns (8 or 4)
+    int width = 0;       // element width of the columns (gspec: of the first one); spec_kernel with `widest`: the program's widest element
+    bool widest = false;
     bool ok = true;
     // spec_kernel: 4 columns of one width, 4 literals.  gspec_kernel (grouped sink): 8 columns of any widths,
     // 8 literals, equal literals share one slot
@@ -689,7 +690,7 @@ struct SpecSigBuilder {
         if (nd.kind == RDF_NODE_COLUMN) {
             const int dt = cc.col_dtype[nd.column];
             if (!spec_tag(dt) || dt == RDF_BOOL) { sp.ok = false; return "?"; }
-            if (sp.width == 0) sp.width = dtype_size(dt);
+            if (sp.width == 0 || sp.widest) sp.width = std::max(sp.width, dtype_size(dt));   // spec_kernel: the widest element decides the row layout
             else if (sp.width != dtype_size(dt) && !sp.mixed) { sp.ok = false; return "?"; }  // one width per program
             int id = -1;
             for (int i = 0; i < sp.ncols; ++i) if (sp.col_map[i] == nd.column) id = i;
@@ -746,6 +747,7 @@ struct SpecSigBuilder {
 // Builds the plan; returns true when a specialised kernel exists for this program.
 bool build_spec_plan(Compiler& cc, int filter_root, int nvalues, const int* value_roots, int sink, SpecPlan& sp) {
     if (nvalues > 2 || (sink == RDF_SINK_STORE && nvalues != 1)) return false;
+    sp.widest = true;
     SpecSigBuilder b(cc, sp);
     std::string s = "P:";
     s += filter_root >= 0 ? b.node(filter_root, RDF_F64) : std::string("-");
@@ -753,6 +755,7 @@ bool build_spec_plan(Compiler& cc, int filter_root, int nvalues, const int* valu
     s += ";" + (nvalues > 1 ? b.node(value_roots[1], cc.infer(value_roots[1])) : std::string("-"));
     s += ";S:" + std::to_string(sink == RDF_SINK_AGG ? SINK_AGG : SINK_STORE);
     if (!sp.ok) return false;
+    if (sink == RDF_SINK_STORE && cc.infer(value_roots[0]) != RDF_BOOL) sp.width = std::max(sp.width, dtype_size(cc.infer(value_roots[0])));
     sp.sig = s;
     return spec_available(s.c_str());
 }
@@ -782,6 +785,7 @@ struct ShapeSigBuilder {
         idx = strip(idx);
         const rdf_expr_node& nd = cc.nodes[idx];
         if (nd.kind != RDF_NODE_OP) return 0;
+        if (nd.op == RDF_OP_CAST && is_column(strip(nd.lhs))) return 0;   // a cast column is a leaf (the plan builders' cast of an operand)
         if (nd.op == RDF_OP_SIN || nd.op == RDF_OP_COS || nd.op == RDF_OP_TAN) return 1 + depth(nd.lhs);
         if (nd.op >= RDF_OP_ADD && nd.op <= RDF_OP_DIV) return 1 + std::max(depth(nd.lhs), depth(nd.rhs));
         return 100;
@@ -792,8 +796,7 @@ struct ShapeSigBuilder {
         const char tag = spec_tag(dom);
         if (nd.kind == RDF_NODE_COLUMN) {
             if (cc.col_dtype[nd.column] != dom || sp.ncols >= 4) { sp.ok = false; return "?"; }
-            if (width && width != dtype_size(dom)) { sp.ok = false; return "?"; }
-            width = dtype_size(dom);
+            width = std::max(width, dtype_size(dom));   // the program's widest element; narrower columns are read with narrower vectors
             sp.col_map[sp.ncols] = nd.column;
             return std::string("c") + char('0' + sp.ncols++) + tag;
         }
@@ -808,6 +811,13 @@ struct ShapeSigBuilder {
         if (nd.kind != RDF_NODE_OP) return leaf(idx, dom);
         if (nslots >= 8) { sp.ok = false; return "?"; }
         const int op = nd.op;
+        if (op == RDF_OP_CAST) {   // cast(column) to the domain's type: a leaf that keeps its own dtype and width in memory
+            const int child = strip(nd.lhs);
+            if (!is_column(child) || nd.dtype != dom) { sp.ok = false; return "?"; }
+            const int from = cc.col_dtype[cc.nodes[child].column];
+            if (!shape_dtype(from) || from == dom) { sp.ok = false; return "?"; }
+            return "{" + std::to_string(dom) + " " + leaf(child, from) + "}";
+        }
         if (op == RDF_OP_SIN || op == RDF_OP_COS || op == RDF_OP_TAN) {
             if (!(dom == RDF_F64 || dom == RDF_F32) || cc.infer(nd.lhs) != dom) { sp.ok = false; return "?"; }
             const int slot = nslots++;
@@ -857,7 +867,7 @@ bool build_shape_plan(Compiler& cc, int filter_root, int nvalues, const int* val
     s += filter_root >= 0 ? b.node(filter_root, RDF_F64) : std::string("-");
     s += ";V:" + b.node(value_roots[0], dom) + ";-;S:" + std::to_string(sink == RDF_SINK_AGG ? SINK_AGG : SINK_STORE);
     if (!sp.ok || b.nslots == 0 || b.width == 0) return false;
-    sp.width = b.width;
+    sp.width = sink == RDF_SINK_STORE && vdt != RDF_BOOL ? std::max(b.width, dtype_size(dom)) : b.width;   // a stored value counts too
     sp.sig = s;
     return spec_available(s.c_str());
 }
@@ -1252,9 +1262,11 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         spec_rpb = spec_rows_per_tile(sp.sig.c_str());
         for (int k = 0; k < sp.ncols && use_spec; ++k) {
             if (fc) { use_spec = fc->col_aligned16[sp.col_map[k]]; continue; }
+            const int es = dtype_size(col_dtype[sp.col_map[k]]);                       // a vector slot of this column: 16 / width of its elements
+            const uintptr_t amask = (uintptr_t)(16 / std::max(sp.width, 1)) * (uintptr_t)es - 1;
             for (int64_t c = 0; c < nchunks; ++c) {
                 const DevChunkCol& d = in_dev[(size_t)((int64_t)sp.col_map[k] * nchunks + c)];
-                if (clen[(size_t)c] > 0 && ((uintptr_t)((const char*)d.values + d.offset * sp.width) & 15) != 0) { use_spec = false; break; }
+                if (clen[(size_t)c] > 0 && ((uintptr_t)((const char*)d.values + d.offset * es) & amask) != 0) { use_spec = false; break; }
             }
         }
         if (ps.sink == RDF_SINK_STORE)

@@ -64,7 +64,7 @@ static void build_registry() {
     reg_shape_family_basic<RDF_F64, RDF_I64>();   // predicate on an i64 key, f64 measures
     reg_shape_family_basic<RDF_I64, RDF_F64>();
     spec_register_shapes1(); spec_register_shapes2(); spec_register_shapes3();
-    spec_register_shapes4(); spec_register_shapes5(); spec_register_shapes6(); spec_register_shapes7();
+    spec_register_shapes4(); spec_register_shapes5(); spec_register_shapes6(); spec_register_shapes7(); spec_register_shapes8();
     // aggregates of a plain column (AggregateFunctions::sum/min/max/count/avg)
     reg<Prog<None, D0, None, SINK_AGG>>();
     reg<Prog<None, L0, None, SINK_AGG>>();

@@ -88,6 +88,12 @@ __device__ __forceinline__ uint64_t interleave_word(const uint64_t (&b)[RV], int
 // ------------------------------------------------------------------------------------------------
 // the kernel
 
+template <int BYTES> struct UIntOf;
+template <> struct UIntOf<8> { using type = uint64_t; };
+template <> struct UIntOf<4> { using type = uint32_t; };
+template <> struct UIntOf<2> { using type = uint16_t; };
+template <> struct UIntOf<1> { using type = uint8_t; };
+
 template <class PRED, class V0, class V1, int SINK_>
 struct Prog {
     using Pred = PRED; using Val0 = V0; using Val1 = V1;
@@ -95,9 +101,17 @@ struct Prog {
     static constexpr int NC_ = (PRED::ncols > V0::ncols ? PRED::ncols : V0::ncols) > V1::ncols
                                    ? (PRED::ncols > V0::ncols ? PRED::ncols : V0::ncols) : V1::ncols;
     static constexpr int NC = NC_ < 1 ? 1 : NC_;
-    static constexpr int W = merge_width(merge_width(PRED::width, V0::width), V1::width);  // element width of every column
-    static_assert(W == 8 || W == 4 || W == 2, "a program reads columns of one width (8, 4 or 2 bytes)");
-    static constexpr int RV = 16 / W;                 // rows per 16-byte vector
+    // element width of canonical column k (0: the program does not read slot k) and the program's WIDEST element — its columns
+    // and, for a stored value, the output.  Columns narrower than W (a cast leaf: add(a: i64, cast(b: i32))) are read with
+    // proportionally narrower vectors of the same rows.
+    template <int k> static constexpr int colw() { return cmax(cmax(PRED::template colw<k>(), V0::template colw<k>()), V1::template colw<k>()); }
+    static constexpr int out_width() {
+        if constexpr (SINK_ == SINK_STORE && !std::is_same<V0, None>::value) return V0::dt == RDF_BOOL ? 0 : CType<V0::dt>::width;
+        else return 0;
+    }
+    static constexpr int W = cmax(cmax(cmax(colw<0>(), colw<1>()), cmax(colw<2>(), colw<3>())), out_width());
+    static_assert(W == 8 || W == 4 || W == 2, "the widest element of a program is 8, 4 or 2 bytes");
+    static constexpr int RV = 16 / W;                 // rows per vector slot (a 16-byte vector of the widest type)
     // rows per lane per iteration.  A 16-byte vector of 2-byte elements is 8 rows.  Measured on the 4-byte types: 8 rows pay for
     // a 3-column aggregate (0.62 -> 0.75 of peak: half the per-iteration overhead) but cost a 3-column store (0.70 -> 0.65) and
     // 4-column programs (0.75 -> 0.73) more in registers than they save
@@ -137,11 +151,45 @@ __device__ __forceinline__ void eval_rows(C& c, uint64_t (&out)[R]) {
     for (int i = 0; i < R; ++i) out[i] = to_bits(v[i]);
 }
 
+// Column loads of one wave iteration.  Lane l takes the RV rows of vector slot `vec + 64 u` (u < U) from EVERY column: a column of
+// the program's widest type with one 16-byte load per slot, a narrower one (a cast leaf) with a load of RV of its own elements.
+template <class P, int k, class C>
+__device__ __forceinline__ void load_full_cols(const DevChunkCol (&col)[P::NC], const SpecArgs& a, int64_t vec, C& c) {
+    if constexpr (k < P::NC) {
+        if (!(k > 0 && a.alias[k] >= 0)) {
+            constexpr int wk = P::template colw<k>() ? P::template colw<k>() : P::W;
+            using Sk = typename UIntOf<wk>::type;
+            using VecK = typename VecOf<Sk, P::RV>::type;
+            const GlobalPtr<VecK> p = (GlobalPtr<VecK>)(as_global<Sk>(col[k].values) + col[k].offset) + vec;
+#pragma unroll
+            for (int u = 0; u < P::U; ++u) {
+                const VecK t = __builtin_nontemporal_load(p + u * 64);
+#pragma unroll
+                for (int e = 0; e < P::RV; ++e) c.v[k][P::RV * u + e] = t[e];
+            }
+        }
+        load_full_cols<P, k + 1>(col, a, vec, c);
+    }
+}
+template <class P, int k, class C>
+__device__ __forceinline__ void load_tail_cols(const DevChunkCol (&col)[P::NC], int64_t vec, C& c) {
+    if constexpr (k < P::NC) {
+        constexpr int wk = P::template colw<k>() ? P::template colw<k>() : P::W;
+        using Sk = typename UIntOf<wk>::type;
+        const GlobalPtr<Sk> p = as_global<Sk>(col[k].values) + col[k].offset;
+#pragma unroll
+        for (int u = 0; u < P::U; ++u)
+#pragma unroll
+            for (int e = 0; e < P::RV; ++e)
+                c.v[k][P::RV * u + e] = ((c.inr >> (P::RV * u + e)) & 1) ? p[(int64_t)P::RV * (vec + u * 64) + e] : (Sk)0;
+        load_tail_cols<P, k + 1>(col, vec, c);
+    }
+}
+
 template <class P>
 __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     constexpr int NC = P::NC, U = P::U, R = P::R, RV = P::RV, W = P::W;
-    using S = typename std::conditional<W == 8, uint64_t, typename std::conditional<W == 4, uint32_t, uint16_t>::type>::type;
-    using VecS = typename VecOf<S, RV>::type;
+    using S = typename UIntOf<W>::type;
     using Pred = typename P::Pred;
     using V0 = typename P::Val0;
     using V1 = typename P::Val1;
@@ -215,17 +263,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
         const bool full = rw + 64 * R <= n;
         if (full) {
             c.inr = (1u << R) - 1;
-#pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                if (k > 0 && a.alias[k] >= 0) continue;   // a second use of a column already loaded for slot alias[k] (shape kernels)
-                const GlobalPtr<VecS> p = (GlobalPtr<VecS>)(as_global<S>(col[k].values) + col[k].offset) + wbase + lane;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const VecS t = __builtin_nontemporal_load(p + u * 64);
-#pragma unroll
-                    for (int e = 0; e < RV; ++e) c.v[k][RV * u + e] = t[e];
-                }
-            }
+            load_full_cols<P, 0>(col, a, wbase + lane, c);   // (a slot that repeats an earlier column — alias[k] >= 0, shape kernels — is not loaded again)
 #pragma unroll
             for (int k = 1; k < NC; ++k)      // aliases copy registers once every load has been issued
 #pragma unroll
@@ -240,15 +278,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int e = 0; e < RV; ++e) c.inr |= (uint32_t)((int64_t)RV * (wbase + u * 64 + lane) + e < n) << (RV * u + e);
-#pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                const GlobalPtr<S> p = as_global<S>(col[k].values) + col[k].offset;
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int e = 0; e < RV; ++e)
-                        c.v[k][RV * u + e] = ((c.inr >> (RV * u + e)) & 1) ? p[(int64_t)RV * (wbase + u * 64 + lane) + e] : (S)0;
-            }
+            load_tail_cols<P, 0>(col, wbase + lane, c);
         }
         {   // the loads above are in flight: locate the next tile now
             const int64_t nt = tile + tstride;
@@ -319,16 +349,16 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
                         if (lane == RV * u + h) word_val = wv;
                     }
                 } else {
-                    using OT = typename CType<V0::dt>::T;
-                    static_assert(sizeof(OT) == W, "value width equals the column width");
+                    using So = typename UIntOf<CType<V0::dt>::width>::type;     // the output's own element width (<= W)
+                    using VecO = typename VecOf<So, RV>::type;
                     if (inu == (1u << RV) - 1) {
-                        VecS t;
+                        VecO t;
 #pragma unroll
-                        for (int e = 0; e < RV; ++e) t[e] = (S)x[e];
-                        __builtin_nontemporal_store(t, as_global_mut<VecS>(out.values) + i);   // streaming output: do not keep it in L2 / MALL
+                        for (int e = 0; e < RV; ++e) t[e] = (So)x[e];
+                        __builtin_nontemporal_store(t, as_global_mut<VecO>(out.values) + i);   // streaming output: do not keep it in L2 / MALL
                     } else {
 #pragma unroll
-                        for (int e = 0; e < RV; ++e) if ((inu >> e) & 1) as_global_mut<S>(out.values)[(int64_t)RV * i + e] = (S)x[e];
+                        for (int e = 0; e < RV; ++e) if ((inu >> e) & 1) as_global_mut<So>(out.values)[(int64_t)RV * i + e] = (So)x[e];
                     }
                 }
                 if (out.validity) {
@@ -378,11 +408,16 @@ static void reg() { spec_registry()[P::sig()] = SpecEntry{&launch_prog<P>, 64 * 
 // second load is an alias of the first).  Canonical operand order (the host sets the operator's swap bit to get there):
 // the deeper subtree first, a subtree before a leaf, a column before a literal.
 struct Lc; struct Lk;
+template <int FROM> struct Lx;          // a column of dtype FROM cast to the family's dtype (the plan builders' cast of the second operand)
 template <class X, class Y> struct Op;
 template <class X> struct Tr;
 template <class Sh, int S, int C, int K, int DT> struct Build;
 template <int S, int C, int K, int DT> struct Build<Lc, S, C, K, DT> {
     using type = Col<C, DT>;
+    static constexpr int nS = S, nC = C + 1, nK = K;
+};
+template <int FROM, int S, int C, int K, int DT> struct Build<Lx<FROM>, S, C, K, DT> {
+    using type = Cast<DT, Col<C, FROM>>;
     static constexpr int nS = S, nC = C + 1, nK = K;
 };
 template <int S, int C, int K, int DT> struct Build<Lk, S, C, K, DT> {
@@ -455,5 +490,26 @@ void spec_register_shapes4();
 void spec_register_shapes5();
 void spec_register_shapes6();
 void spec_register_shapes7();
+void spec_register_shapes8();
+
+// a OP cast(b): the two-column calculation the reference plans for operands of different types (AddOperation ... DivideOperation,
+// src/operation/scalar.rs:47-72: the second operand is cast to the first one's type), the cast on its own (CastOperation /
+// Function::Cast, src/evaluation.rs:296-315), and sin / cos / tan of a cast column (SinOperation casts integers to Float64 first,
+// src/operation/scalar.rs:256-294).  Columns keep their own widths in memory (rdf_spec_kernel: per-column load widths).
+template <int DT, int FROM> static void reg_cast_pair() {
+    if constexpr (DT != FROM) {
+        reg_shape_list<PredNone<DT>, DT, SINK_STORE>(ShapeList<Op<Lc, Lx<FROM>>>{});
+        reg_shape_list<PredNone<DT>, DT, SINK_AGG>(ShapeList<Op<Lc, Lx<FROM>>>{});
+        reg<Prog<None, Cast<DT, Col<0, FROM>>, None, SINK_STORE>>();
+        if constexpr (dt_float(DT)) {
+            reg_shape_list<PredNone<DT>, DT, SINK_STORE>(ShapeList<Tr<Lx<FROM>>>{});
+            reg_shape_list<PredNone<DT>, DT, SINK_AGG>(ShapeList<Tr<Lx<FROM>>>{});
+        }
+    }
+}
+template <int DT> static void reg_cast_family() {
+    reg_cast_pair<DT, RDF_F64>(); reg_cast_pair<DT, RDF_I64>(); reg_cast_pair<DT, RDF_U64>(); reg_cast_pair<DT, RDF_F32>();
+    reg_cast_pair<DT, RDF_I32>(); reg_cast_pair<DT, RDF_U32>(); reg_cast_pair<DT, RDF_I16>(); reg_cast_pair<DT, RDF_U16>();
+}
 
 }  // namespace rdfk

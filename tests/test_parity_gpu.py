@@ -898,6 +898,61 @@ def test_shape_kernels_three_levels_and_every_wide_type(gpu, ora, request, dtype
     assert ei.value.status == A.RDF_DIVIDE_BY_ZERO
 
 
+@pytest.mark.parametrize("to_dt,from_dt", [(A.I64, A.I32), (A.F64, A.F32), (A.F64, A.I64), (A.I32, A.I64), (A.F32, A.I16), (A.U16, A.I64),
+                                           (A.I64, A.F64), (A.U32, A.F32), (A.F64, A.U16), (A.I16, A.U64)])
+def test_operands_of_different_types_run_specialised(gpu, ora, request, to_dt, from_dt):
+    """The reference plans `a OP b` over columns of different types as cast(b -> a's type) then OP (AddOperation ... DivideOperation,
+    src/operation/scalar.rs:47-72), casts on their own (Function::Cast, src/evaluation.rs:296-315) and sin / cos / tan of an integer
+    column as cast -> Float64 -> sin (SinOperation, :256-294).  Fused, those are programs whose columns differ in WIDTH: they run on
+    the specialised kernels with per-column load widths (spec mode) and equal the oracle's unfused evaluation, lossy casts included
+    (a value the target cannot hold is NULL and stays NULL through the arithmetic)."""
+    from rust_dataframe_amd import lib
+    spec_mode = request.node.callspec.params["gpu"] == "spec"
+    rng = np.random.default_rng(900 + 16 * to_dt + from_dt)
+    lens = [4096, 1000]
+    to_float, from_float = to_dt in (A.F64, A.F32), from_dt in (A.F64, A.F32)
+    a = make_chunks(rng, to_dt, lens, 0.1, 0, kind="unit" if to_float else "plain", nonzero=True)
+    # the cast operand: mostly small values, a few that the target type cannot hold (lossy pairs) / NaN
+    b = []
+    for n in lens:
+        v = rng.uniform(1.0, 900.0, n) * rng.choice([-1.0, 1.0], n) if from_float else rng.integers(-900 if from_dt in (A.I64, A.I32, A.I16) else 0, 900, n)   # (|v| >= 1: a cast to an integer must not make a zero divisor)
+        v = np.asarray(v).astype(A.NP_OF[from_dt])
+        v[v == 0] = 1
+        big = {A.I64: 2 ** 40, A.U64: 2 ** 40, A.I32: 2 ** 30, A.U32: 2 ** 31 + 5, A.F64: 1e30, A.F32: 1e30, A.I16: 30000, A.U16: 60000}[from_dt]
+        v[::97] = big
+        if from_float and not to_float:   # NaN -> integer is NULL (between floats a NaN would only test sign / payload conventions)
+            v[5::131] = np.nan
+        b.append(A.HostArray.from_numpy(v, valid=rng.uniform(size=n) >= 0.05))
+    e = A.Expr()
+    c0, c1 = e.col(0), e.col(1)
+    cb = e.cast(c1, to_dt)
+    values = {op: e.op(op, c0, cb) for op in ("add", "subtract", "multiply", "divide")}
+    if to_float:
+        values["sin_cast"] = e.op("sin", cb)
+    for name, v in values.items():
+        exp = ora.pipeline(e, [a, b], [v])[0]
+        got = gpu.pipeline(e, [a, b], [v])[0]
+        if spec_mode:
+            assert lib.last_kernel().startswith("spec_kernel<"), f"{name}: ran {lib.last_kernel()}"
+        assert got.count == exp.count, name
+        if to_float:
+            assert abs(got.sum - exp.sum) <= 1e-5 * max(abs(exp.sum), 1.0) or (np.isnan(exp.sum) and np.isnan(got.sum)) or (np.isinf(exp.sum) and got.sum == exp.sum), f"{name}: {got.sum} vs {exp.sum}"
+        else:
+            assert (got.sum, got.min, got.max) == (exp.sum, exp.min, exp.max), name
+        outs_e = [[A.HostArray.empty_out(to_dt, n, True) for n in lens]]
+        outs_g = [[A.HostArray.empty_out(to_dt, n, True) for n in lens]]
+        ora.pipeline(e, [a, b], [v], -1, A.SINK_STORE, outs_e)
+        gpu.pipeline(e, [a, b], [v], -1, A.SINK_STORE, outs_g)
+        if spec_mode:
+            assert lib.last_kernel().startswith("spec_kernel<"), f"{name}/store: ran {lib.last_kernel()}"
+        for ge, ee in zip(outs_g[0], outs_e[0]):
+            assert_arrays_match(ge, ee, exact=name != "sin_cast", what=f"{name} {from_dt}->{to_dt}")
+    # the cast alone
+    assert_chunks_match(gpu.cast(b, to_dt), ora.cast(b, to_dt), exact=True, what=f"cast {from_dt}->{to_dt}")
+    if spec_mode:
+        assert lib.last_kernel().startswith("spec_kernel<"), f"cast: ran {lib.last_kernel()}"
+
+
 def test_sort_skips_constant_key_bytes(gpu, ora):
     """Radix passes cover only the bytes of (max key - min key): constant keys (no pass needed at all), a 1-byte range
     inside an i64, sparse byte patterns, negative small ranges (sign extension is not a range), two-valued floats, with
