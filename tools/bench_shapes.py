@@ -86,6 +86,31 @@ def main():
         lib.set_option("spec", 1)
         del cols, o
         torch.cuda.empty_cache()
+    # operands of different types: a OP cast(b -> a's type), the plan the reference builds for unequal column types
+    if "mixed" in args.dtypes.split(",") or args.dtypes == ap.get_default("dtypes"):
+        for to_dt, from_dt in ((A.I64, A.I32), (A.F64, A.F32), (A.F64, A.I64), (A.I32, A.I16)):
+            a_, b_ = [column(to_dt, n, 501)], [column(from_dt, n, 502)]
+            o = out(to_dt, n)
+            e = A.Expr()
+            prog = e.op("multiply", e.col(0), e.cast(e.col(1), to_dt))
+            progs = [("a_times_cast_b", prog, ES[to_dt] + ES[from_dt])]
+            if to_dt == A.F64:
+                progs.append(("sin_cast_b", e.op("sin", e.cast(e.col(1), to_dt)), None))
+            for spec in ((1, 0) if args.interp else (1,)):
+                lib.set_option("spec", spec)
+                for name, root, rb in progs:
+                    for sink in ("agg", "store"):
+                        cols2 = [a_, b_]
+                        read = rb if rb is not None else ES[from_dt]
+                        alg = (read + (ES[to_dt] if sink == "store" else 0)) * n
+                        fn = (lambda root=root: api.pipeline(e, cols2, [root])) if sink == "agg" else (lambda root=root: api.pipeline(e, cols2, [root], -1, A.SINK_STORE, [[o]]))
+                        wall, kern = timed(fn, args.steps)
+                        gbs = alg / kern / 1e9 if kern > 0 else 0.0
+                        print(json.dumps({"dtype": f"{NAME[to_dt]}<-{NAME[from_dt]}", "program": name, "sink": sink, "rows": n, "alg_bytes": alg, "kernel_ms": round(kern * 1e3, 4),
+                                          "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 3), "kernel": lib.last_kernel()[:120]}), flush=True)
+            lib.set_option("spec", 1)
+            del a_, b_, o
+            torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
