@@ -34,6 +34,15 @@ def test_library_exports_every_declared_symbol():
     assert "gfx950" in lib.version()
 
 
+def test_integration_notes_bind_every_declared_symbol():
+    """INTEGRATION.md (the reference-side binding) and integration/rdf_shim.rs name every entry point of the header."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shim = open(os.path.join(ROOT, "integration", "rdf_shim.rs")).read()
+    for n in declared_functions():
+        assert n in doc, f"INTEGRATION.md does not mention {n}"
+        assert n in shim, f"integration/rdf_shim.rs does not declare {n}"
+
+
 def test_oracle_exports_the_mirror_symbols(ora):
     for n in ["binary", "unary", "cast", "sum", "min", "max", "count", "avg", "predicate", "filter_count", "filter",
               "filter_columns", "take", "pipeline", "fill_uniform_f64", "fill_uniform_i64", "fill_validity"]:
