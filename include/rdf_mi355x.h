@@ -437,6 +437,11 @@ rdf_status rdf_group_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_
                               int32_t ngroups, const int32_t* value_roots, int32_t nvalues,
                               const rdf_array* cols, int32_t ncols, int64_t nchunks,
                               rdf_group_result* out, int64_t* group_rows);
+/* rdf_group_pipeline / rdf_predicate over the pinned columns (same results, same errors). */
+rdf_status rdf_group_pipeline_frame(const rdf_expr_node* nodes, int32_t nnodes, int32_t filter_root, int32_t group_root, int32_t ngroups,
+                                    const int32_t* value_roots, int32_t nvalues, rdf_frame* frame, rdf_group_result* out,
+                                    int64_t* group_rows);
+rdf_status rdf_predicate_frame(const rdf_expr_node* nodes, int32_t nnodes, int32_t root, rdf_frame* frame, rdf_out* mask);
 
 /* ------------------------------------------------------------------ synthetic data (bench/tests) */
 

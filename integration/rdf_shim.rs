@@ -134,6 +134,10 @@ pub mod sys {
         pub fn rdf_frame_pin(cols: *const rdf_array, ncols: i32, nchunks: i64, out: *mut *mut rdf_frame) -> i32;
         pub fn rdf_frame_release(frame: *mut rdf_frame) -> i32;
         pub fn rdf_pipeline_frame(prog: *const rdf_program, frame: *mut rdf_frame, outs: *mut rdf_out, aggs: *mut rdf_agg_result) -> i32;
+        pub fn rdf_group_pipeline_frame(nodes: *const rdf_expr_node, nnodes: i32, filter_root: i32, group_root: i32, ngroups: i32,
+                                        value_roots: *const i32, nvalues: i32, frame: *mut rdf_frame, out: *mut rdf_group_result,
+                                        group_rows: *mut i64) -> i32;
+        pub fn rdf_predicate_frame(nodes: *const rdf_expr_node, nnodes: i32, root: i32, frame: *mut rdf_frame, mask: *mut rdf_out) -> i32;
         // synthetic data, switches, introspection (bench / tests)
         pub fn rdf_fill_uniform_f64(dev_ptr: *mut f64, n: i64, seed: u64, column_id: u64, first_row: i64, lo: f64, hi: f64) -> i32;
         pub fn rdf_fill_uniform_i64(dev_ptr: *mut i64, n: i64, seed: u64, column_id: u64, first_row: i64, lo: i64, hi: i64) -> i32;

@@ -542,8 +542,11 @@ class Api:
 
     # ---- expressions
     def predicate(self, expr: Expr, root: int, cols: Sequence[Sequence], outs=None):
+        frame = cols if isinstance(cols, PinnedFrame) else None
+        if frame is not None:
+            cols = frame.cols
         nchunks = len(cols[0]) if cols else 0
-        cc = _flat(cols, nchunks)
+        cc = None if frame is not None else _flat(cols, nchunks)
         if outs is None:
             lens = [cols[0][i].length for i in range(nchunks)]
             nullable = [any(col[i].validity is not None for col in cols) for i in range(nchunks)]
@@ -551,8 +554,13 @@ class Api:
         else:
             carr = (rdf_out * max(1, nchunks))(*[o.out_struct() for o in outs])
         nodes = expr.c_array()
-        self._check(self._fn("predicate")(nodes, C.c_int32(len(expr.nodes)), C.c_int32(root), cc, C.c_int32(len(cols)),
-                                          C.c_int64(nchunks), carr))
+        if frame is not None:   # rdf_predicate_frame
+            fn = self._fn("predicate_frame")
+            fn.restype = C.c_int
+            self._check(fn(nodes, C.c_int32(len(expr.nodes)), C.c_int32(root), frame.handle, carr))
+        else:
+            self._check(self._fn("predicate")(nodes, C.c_int32(len(expr.nodes)), C.c_int32(root), cc, C.c_int32(len(cols)),
+                                              C.c_int64(nchunks), carr))
         return self._finish(outs, carr)
 
     # ---- filter / take
@@ -816,16 +824,22 @@ class Api:
     def group_pipeline(self, expr: Expr, cols: Sequence[Sequence], value_roots: Sequence[int], group_root: int, ngroups: int,
                        filter_root: int = -1):
         """-> (res, rows): res[v][g] = (sum, count) of value v in group g (g == ngroups: the NULL group), rows[g] = count(*)."""
-        nchunks = len(cols[0]) if cols else 0
+        nchunks = 0 if isinstance(cols, PinnedFrame) or not cols else len(cols[0])
         nodes = expr.c_array()
         nv = len(value_roots)
         S = ngroups + 1
         out = (rdf_group_result * max(1, nv * S))()
         rows = (C.c_int64 * max(1, S))()
         roots = (C.c_int32 * max(1, nv))(*value_roots)
-        self._check(self._fn("group_pipeline")(nodes, C.c_int32(len(expr.nodes)), C.c_int32(filter_root), C.c_int32(group_root),
-                                               C.c_int32(ngroups), roots, C.c_int32(nv), _flat(cols, nchunks), C.c_int32(len(cols)),
-                                               C.c_int64(nchunks), out, rows))
+        if isinstance(cols, PinnedFrame):   # rdf_group_pipeline_frame
+            fn = self._fn("group_pipeline_frame")
+            fn.restype = C.c_int
+            self._check(fn(nodes, C.c_int32(len(expr.nodes)), C.c_int32(filter_root), C.c_int32(group_root), C.c_int32(ngroups),
+                           roots, C.c_int32(nv), cols.handle, out, rows))
+        else:
+            self._check(self._fn("group_pipeline")(nodes, C.c_int32(len(expr.nodes)), C.c_int32(filter_root), C.c_int32(group_root),
+                                                   C.c_int32(ngroups), roots, C.c_int32(nv), _flat(cols, nchunks), C.c_int32(len(cols)),
+                                                   C.c_int64(nchunks), out, rows))
         res = []
         for v in range(nv):
             row = []

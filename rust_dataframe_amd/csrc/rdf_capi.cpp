@@ -1826,6 +1826,38 @@ rdf_status rdf_group_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_
     return run_program(ps, cols, ncols, nchunks, nullptr, nullptr, "columns of a batch differ in length");
 }
 
+rdf_status rdf_group_pipeline_frame(const rdf_expr_node* nodes, int32_t nnodes, int32_t filter_root, int32_t group_root, int32_t ngroups,
+                                    const int32_t* value_roots, int32_t nvalues, rdf_frame* frame, rdf_group_result* out,
+                                    int64_t* group_rows) {
+    if (!frame) return fail(RDF_INVALID_ARGUMENT, "group_pipeline_frame: null frame");
+    if (!nodes || nnodes <= 0) return fail(RDF_INVALID_ARGUMENT, "empty program");
+    if (!value_roots || nvalues < 1 || nvalues > RDF_MAX_GROUP_VALUES) return fail(RDF_INVALID_ARGUMENT, "nvalues out of range");
+    if (group_root < 0 || group_root >= nnodes) return fail(RDF_INVALID_ARGUMENT, "group_root out of range");
+    RDF_TRY(ensure_ready());
+    if (frame->device != g_ctx.device) return fail(RDF_INVALID_ARGUMENT, "group_pipeline_frame: the frame was pinned on device %d", frame->device);
+    ProgramSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.nodes = nodes; ps.nnodes = nnodes; ps.filter_root = filter_root; ps.nvalues = nvalues; ps.sink = RDF_SINK_GROUP;
+    for (int v = 0; v < nvalues; ++v) ps.value_roots[v] = value_roots[v];
+    ps.group_root = group_root; ps.ngroups = ngroups; ps.gout = out; ps.grows = group_rows;
+    return run_program(ps, nullptr, frame->ncols, frame->nchunks, nullptr, nullptr, "columns of a batch differ in length", frame);
+}
+
+rdf_status rdf_predicate_frame(const rdf_expr_node* nodes, int32_t nnodes, int32_t root, rdf_frame* frame, rdf_out* mask) {
+    if (!frame) return fail(RDF_INVALID_ARGUMENT, "predicate_frame: null frame");
+    if (!nodes || nnodes <= 0) return fail(RDF_INVALID_ARGUMENT, "empty expression");
+    if (frame->nchunks > 0 && !mask) return fail(RDF_INVALID_ARGUMENT, "bad chunk lists");
+    if (frame->nchunks == 0) return RDF_OK;
+    RDF_TRY(ensure_ready());
+    if (frame->device != g_ctx.device) return fail(RDF_INVALID_ARGUMENT, "predicate_frame: the frame was pinned on device %d", frame->device);
+    ProgramSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.nodes = nodes; ps.nnodes = nnodes; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = root; ps.sink = RDF_SINK_STORE;
+    for (int64_t c = 0; c < frame->nchunks; ++c)
+        if (mask[c].dtype != RDF_BOOL) return fail(RDF_INVALID_ARGUMENT, "predicate root must be boolean");
+    return run_program(ps, nullptr, frame->ncols, frame->nchunks, mask, nullptr, "columns of a batch differ in length", frame);
+}
+
 // ---------------------------------------------------------------- filter / take
 
 namespace {

@@ -497,8 +497,8 @@ def test_specialised_kernels_are_the_ones_that_run(gpu, request):
 
 
 def test_pinned_frame_pipeline(gpu, ora, request):
-    """rdf_frame_pin / rdf_pipeline_frame: the same results as rdf_pipeline over the same device-resident columns — both
-    sinks, specialised and interpreted programs, several programs on one handle (cached tables per tile size and column
+    """rdf_frame_pin / rdf_pipeline_frame (and the _frame forms of rdf_predicate / rdf_group_pipeline): the same results as
+    the plain calls over the same device-resident columns — both sinks, specialised and interpreted programs, several programs on one handle (cached tables per tile size and column
     order), nullable and unaligned chunk layouts, one chunk; host buffers and released handles are refused."""
     import ctypes as C
     import torch
@@ -549,6 +549,31 @@ def test_pinned_frame_pipeline(gpu, ora, request):
                 m = ee.valid_mask()
                 gm = np.unpackbits(bb.cpu().numpy()[:(ee.length + 7) // 8], bitorder="little")[:ee.length].astype(bool)
                 assert np.array_equal(gm, m) and np.array_equal(gv[m], ee.to_numpy()[m])
+            # rdf_predicate_frame: the mask of a comparison, device outputs
+            pr = e.op("and", e.op("gt", c0, e.scalar(0.3)), e.op("lt", c1, c2))
+            exp_m = ora.predicate(e, pr, host)
+            mb = [(torch.zeros(n // 8 + 72, dtype=torch.uint8, device="cuda"), torch.zeros(n // 8 + 72, dtype=torch.uint8, device="cuda")) for n in lens]
+            outs_m = [A.DeviceArray(vb.data_ptr(), bb.data_ptr(), 0, n, A.BOOL, 0, keep=(vb, bb), capacity=n) for (vb, bb), n in zip(mb, lens)]
+            torch.cuda.synchronize()
+            gpu.predicate(e, pr, frame, outs_m)
+            lib.synchronize()
+            for (vb, bb), o, ee in zip(mb, outs_m, exp_m):
+                assert o.length == ee.length and o.null_count == ee.null_count
+                m = ee.valid_mask()
+                gv = np.unpackbits(vb.cpu().numpy()[:(ee.length + 7) // 8], bitorder="little")[:ee.length].astype(bool)
+                gm = np.unpackbits(bb.cpu().numpy()[:(ee.length + 7) // 8], bitorder="little")[:ee.length].astype(bool)
+                assert np.array_equal(gm, m) and np.array_equal(gv[m], ee.to_numpy()[m])
+            # rdf_group_pipeline_frame: grouped sums (a key derived from column 0, filtered) — specialised and interpreted
+            gk = e.cast(e.op("multiply", c0, e.scalar(7.0)), A.I64)
+            for values, pred in [([e.op("multiply", c1, c2), c1], e.op("le", c2, e.scalar(0.8))), ([e.op("atan2", c1, c2)], -1)]:
+                exp_g = ora.group_pipeline(e, host, values, gk, 8, pred)
+                got_g = gpu.group_pipeline(e, frame, values, gk, 8, pred)
+                plain_g = gpu.group_pipeline(e, dev, values, gk, 8, pred)
+                assert got_g[1] == exp_g[1] == plain_g[1]
+                for rv_g, rv_e, rv_p in zip(got_g[0], exp_g[0], plain_g[0]):
+                    for (sg, cg), (se, ce), (sp, cp) in zip(rv_g, rv_e, rv_p):
+                        assert cg == ce == cp
+                        assert abs(sg - se) <= 1e-9 * max(1.0, abs(se)) and abs(sg - sp) <= 1e-9 * max(1.0, abs(se))
     with pytest.raises(A.RdfError):       # host buffers are staged per call: nothing to pin
         A.PinnedFrame(gpu, [make_chunks(rng, A.F64, [100], 0.0, 0)])
 
