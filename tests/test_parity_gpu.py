@@ -564,11 +564,11 @@ def test_pinned_frame_pipeline(gpu, ora, request):
                 gm = np.unpackbits(bb.cpu().numpy()[:(ee.length + 7) // 8], bitorder="little")[:ee.length].astype(bool)
                 assert np.array_equal(gm, m) and np.array_equal(gv[m], ee.to_numpy()[m])
             # rdf_group_pipeline_frame: grouped sums (a key derived from column 0, filtered) — specialised and interpreted
-            gk = e.cast(e.op("multiply", c0, e.scalar(7.0)), A.I64)
+            gk = e.cast(e.op("multiply", e.op("abs", c0), e.scalar(7.0)), A.I64)   # |x| <= 1 -> groups 0..7
             for values, pred in [([e.op("multiply", c1, c2), c1], e.op("le", c2, e.scalar(0.8))), ([e.op("atan2", c1, c2)], -1)]:
-                exp_g = ora.group_pipeline(e, host, values, gk, 8, pred)
-                got_g = gpu.group_pipeline(e, frame, values, gk, 8, pred)
-                plain_g = gpu.group_pipeline(e, dev, values, gk, 8, pred)
+                exp_g = ora.group_pipeline(e, host, values, gk, 9, pred)
+                got_g = gpu.group_pipeline(e, frame, values, gk, 9, pred)
+                plain_g = gpu.group_pipeline(e, dev, values, gk, 9, pred)
                 assert got_g[1] == exp_g[1] == plain_g[1]
                 for rv_g, rv_e, rv_p in zip(got_g[0], exp_g[0], plain_g[0]):
                     for (sg, cg), (se, ce), (sp, cp) in zip(rv_g, rv_e, rv_p):
