@@ -256,6 +256,52 @@ __device__ __forceinline__ double rdf_tan(double x) {
     return (q & 1) ? -c / s : s / c;
 }
 
+// R rows of one lane at once.  rdf_sin / rdf_cos / rdf_tan above test every argument for the libm path (|x| >= 1e5, inf,
+// NaN) and for tiny values with their own branches: per row two compare + exec-mask + branch sequences, and the branches
+// fence each row's ~20-deep FMA chain off from its neighbours.  Here ONE wave-wide test covers all R rows (a single lane
+// holding one large argument sends the wave's R rows down the per-row path — rare, and still correct), and the common path
+// is branch-free: R independent chains the scheduler interleaves, the tiny-argument result picked by a select.
+// KIND 0 = sin, 1 = cos, 2 = tan.  Same arithmetic per element as the scalar functions: bit-identical results.
+template <int KIND, int R>
+__device__ __forceinline__ void rdf_trig_rows(const double (&a)[R], double (&out)[R]) {
+    bool big = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) big |= !(fabs(a[r]) < 1.0e5);
+    if (__ballot(big) != 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[r] = KIND == 0 ? rdf_sin(a[r]) : KIND == 1 ? rdf_cos(a[r]) : rdf_tan(a[r]);
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double x = a[r];
+        if (KIND == 0) {
+            const double kd = rint(x * 3.18309886183790671538e-01);
+            // trig_reduce_m(x, 2 kd) with the factor 2 folded into the constants (a power of two: the same roundings)
+            double t = fma(-kd, 2.0 * 1.57079632673412561417e+00, x);
+            t = fma(-kd, 2.0 * 6.07710050630396597660e-11, t);
+            t = fma(-kd, 2.0 * 2.02226624871116645580e-21, t);
+            t = fma(-kd, 2.0 * 8.47842766036889956997e-32, t);
+            const double v = trig_psin(t, (int)kd);
+            out[r] = fabs(x) < 0x1p-26 ? x : v;
+        } else if (KIND == 1) {
+            const double kd = rint(fma(x, 3.18309886183790671538e-01, -0.5));
+            out[r] = trig_psin(trig_reduce_m(x, fma(2.0, kd, 1.0)), (int)kd + 1);
+        } else {
+            double t; int q;
+            trig_reduce(x, t, q);
+            const double sn = trig_ksin(t), cs = trig_kcos(t);
+            const double v = (q & 1) ? -cs / sn : sn / cs;
+            out[r] = fabs(x) < 0x1p-26 ? x : v;
+        }
+    }
+}
+template <int KIND, int R>
+__device__ __forceinline__ void rdf_trig_rows(const float (&a)[R], float (&out)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r] = KIND == 0 ? sinf(a[r]) : KIND == 1 ? cosf(a[r]) : tanf(a[r]);
+}
+
 // f32 columns compute in f32 (num::Float on f32, src/functions/scalar.rs:106-452): the device libm's single-precision routines
 __device__ __forceinline__ float rdf_sin(float x) { return sinf(x); }
 __device__ __forceinline__ float rdf_cos(float x) { return cosf(x); }

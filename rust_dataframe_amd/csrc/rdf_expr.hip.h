@@ -198,7 +198,19 @@ struct Un {
         else if constexpr (OP == RDF_OP_CSC) return (T)1 / rdf_sin(x);
         else return tanh(x);
     }
-    RDF_DEFAULT_EVAL_ROWS(Un)
+    template <int R, class C> static __device__ __forceinline__ void eval_rows(C& c, T (&out)[R]) {
+        constexpr bool trig = dt_float(A::dt) && (OP == RDF_OP_SIN || OP == RDF_OP_COS || OP == RDF_OP_TAN || OP == RDF_OP_COT ||
+                                                  OP == RDF_OP_SEC || OP == RDF_OP_CSC);
+        if constexpr (trig) {   // one wave-wide argument test for the R rows, then R interleaved branch-free chains
+            T a[R];
+            A::template eval_rows<R>(c, a);
+            rdf_trig_rows<(OP == RDF_OP_SIN || OP == RDF_OP_CSC) ? 0 : (OP == RDF_OP_COS || OP == RDF_OP_SEC) ? 1 : 2, R>(a, out);
+            if constexpr (OP == RDF_OP_COT || OP == RDF_OP_SEC || OP == RDF_OP_CSC) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) out[r] = (T)1 / out[r];
+            }
+        } else eval_each<Un, R>(c, out);
+    }
     static std::string sig() { return "[" + std::to_string(OP) + " " + A::sig() + "]"; }
 };
 
@@ -379,16 +391,9 @@ struct TrigRT {    // sin / cos / tan: the three the reference's Evaluate::calcu
         T a[R];
         A::template eval_rows<R>(c, a);
         const int op = c.rt[SLOT] & 0xFF;
-        if (op == RDF_OP_SIN) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) out[r] = rdf_sin(a[r]);
-        } else if (op == RDF_OP_COS) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) out[r] = rdf_cos(a[r]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) out[r] = rdf_tan(a[r]);
-        }
+        if (op == RDF_OP_SIN) rdf_trig_rows<0, R>(a, out);
+        else if (op == RDF_OP_COS) rdf_trig_rows<1, R>(a, out);
+        else rdf_trig_rows<2, R>(a, out);
     }
     static std::string sig() { return "[T" + std::to_string(SLOT) + " " + A::sig() + "]"; }
 };

@@ -156,7 +156,12 @@ __device__ __forceinline__ void agg_rows(C& c, uint32_t live, AGG& g) {
     typename E::T v[R];
     E::template eval_rows<R>(c, v);
     if constexpr (HasAddRows<AGG>::value) g.template add_rows<R>(v, live);
-    else {
+    else if (__ballot((live & ((1u << R) - 1)) != (1u << R) - 1) == 0) {
+        // every row of every lane counts (no filter, no nulls, a full tile — wave-uniform): the same folds in the same order
+        // without the per-row bit test and exec mask (13 -> 4 VALU instructions per f64 row; sum(sin(x + c)) was VALU-bound)
+#pragma unroll
+        for (int i = 0; i < R; ++i) g.add(v[i]);
+    } else {
 #pragma unroll
         for (int i = 0; i < R; ++i) if ((live >> i) & 1) g.add(v[i]);
     }
