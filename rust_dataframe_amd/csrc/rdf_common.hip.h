@@ -262,6 +262,10 @@ __device__ __forceinline__ double rdf_tan(double x) {
 // holding one large argument sends the wave's R rows down the per-row path — rare, and still correct), and the common path
 // is branch-free: R independent chains the scheduler interleaves, the tiny-argument result picked by a select.
 // KIND 0 = sin, 1 = cos, 2 = tan.  Same arithmetic per element as the scalar functions: bit-identical results.
+// (the per-row path is a real call: inlined R times, libm's Payne-Hanek reduction set the kernel's register count — 117
+// VGPRs, 4 waves per SIMD — for a path that almost never runs)
+template <int KIND>
+__device__ __attribute__((noinline)) double rdf_trig_any(double x) { return KIND == 0 ? rdf_sin(x) : KIND == 1 ? rdf_cos(x) : rdf_tan(x); }
 template <int KIND, int R>
 __device__ __forceinline__ void rdf_trig_rows(const double (&a)[R], double (&out)[R]) {
     bool big = false;
@@ -269,7 +273,7 @@ __device__ __forceinline__ void rdf_trig_rows(const double (&a)[R], double (&out
     for (int r = 0; r < R; ++r) big |= !(fabs(a[r]) < 1.0e5);
     if (__ballot(big) != 0) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) out[r] = KIND == 0 ? rdf_sin(a[r]) : KIND == 1 ? rdf_cos(a[r]) : rdf_tan(a[r]);
+        for (int r = 0; r < R; ++r) out[r] = rdf_trig_any<KIND>(a[r]);
         return;
     }
 #pragma unroll
