@@ -182,19 +182,19 @@ __device__ __forceinline__ float unary_f32(int op, float x) {
             case RDF_OP_ASIN: return asinf(x);
             case RDF_OP_ATAN: return atanf(x);
             case RDF_OP_CBRT: return cbrtf(x);
-            case RDF_OP_COS: return cosf(x);
+            case RDF_OP_COS: return rdf_cos(x);
             case RDF_OP_COSH: return coshf(x);
             case RDF_OP_EXP: return expf(x);
             case RDF_OP_EXPM1: return expm1f(x);
             case RDF_OP_LOG10: return log10f(x);
             case RDF_OP_LOG2: return log2f(x);
-            case RDF_OP_SIN: return sinf(x);
+            case RDF_OP_SIN: return rdf_sin(x);
             case RDF_OP_SINH: return sinhf(x);
             case RDF_OP_TAN: return tanf(x);
             case RDF_OP_TANH: return tanhf(x);
             case RDF_OP_COT: return 1.0f / tanf(x);
-            case RDF_OP_SEC: return 1.0f / cosf(x);
-            case RDF_OP_CSC: return 1.0f / sinf(x);
+            case RDF_OP_SEC: return 1.0f / rdf_cos(x);
+            case RDF_OP_CSC: return 1.0f / rdf_sin(x);
             default: break;
         }
     }

@@ -57,8 +57,24 @@ template <> struct AggT<RDF_U64> {
     __device__ __forceinline__ uint64_t b() const { return mx; }
 };
 template <> struct AggT<RDF_BOOL> : AggT<RDF_U64> {};
-template <> struct AggT<RDF_F32> : AggT<RDF_F64> {   // f32 values fold in f64 (rounded once at the end by the host)
-    __device__ __forceinline__ void add(float v) { AggT<RDF_F64>::add((double)v); }
+template <> struct AggT<RDF_F32> : AggT<RDF_F64> {   // f32 sums fold in f64 (rounded once at the end by the host); min / max stay f32
+    float mn32, mx32;
+    __device__ __forceinline__ void init() { AggT<RDF_F64>::init(); mn32 = mx32 = __uint_as_float(0x7FC00000u); }
+    __device__ __forceinline__ void add(float v) { sum += (double)v; mn32 = fminf(mn32, v); mx32 = fmaxf(mx32, v); ++cnt; }
+    // dead rows contribute the identities (NaN to fmin / fmax, -0.0 to the sum) through selects instead of exec masks
+    template <int R, bool ALL, class T> __device__ __forceinline__ void add_rows(const T* v, uint32_t live) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const bool on = ALL || ((live >> i) & 1);
+            const float xs = on ? (float)v[i] : __uint_as_float(0x7FC00000u);
+            mn32 = fminf(mn32, xs);
+            mx32 = fmaxf(mx32, xs);
+            sum += (double)(on ? (float)v[i] : -0.0f);
+        }
+        cnt += ALL ? R : __popc(live & ((1u << R) - 1));
+    }
+    __device__ __forceinline__ uint64_t a() const { return d2u((double)mn32); }
+    __device__ __forceinline__ uint64_t b() const { return d2u((double)mx32); }
 };
 // 4- and 2-byte integers: min / max stay 32 bits wide (one v_min / v_max per row instead of a 64-bit compare and two selects);
 // 2-byte values also sum a wave iteration's rows in 32 bits (R <= 8 rows of 16 bits cannot overflow) before widening once.
@@ -75,13 +91,13 @@ template <class T32, class BASE, bool SUM32> struct AggNarrow : BASE {
         mx32 = v > mx32 ? v : mx32;
         ++this->cnt;
     }
-    template <int R, class T> __device__ __forceinline__ void add_rows(const T* v, uint32_t live) {
+    template <int R, bool ALL, class T> __device__ __forceinline__ void add_rows(const T* v, uint32_t live) {
         using Wide = typename std::conditional<std::is_signed<T32>::value, int64_t, uint64_t>::type;
         const T32 lo = std::is_signed<T32>::value ? (T32)INT32_MAX : (T32)~0u, hi = std::is_signed<T32>::value ? (T32)INT32_MIN : (T32)0;
         T32 s32 = 0;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const bool on = (live >> i) & 1;
+            const bool on = ALL || ((live >> i) & 1);
             const T32 x = (T32)v[i];
             const T32 xl = on ? x : lo, xh = on ? x : hi;
             mn32 = xl < mn32 ? xl : mn32;
@@ -90,7 +106,7 @@ template <class T32, class BASE, bool SUM32> struct AggNarrow : BASE {
             else this->sum += (uint64_t)(Wide)(on ? x : (T32)0);
         }
         if (SUM32) this->sum += (uint64_t)(Wide)s32;
-        this->cnt += __popc(live & ((1u << R) - 1));
+        this->cnt += ALL ? R : __popc(live & ((1u << R) - 1));
     }
     __device__ __forceinline__ uint64_t a() const { return (uint64_t)(typename std::conditional<std::is_signed<T32>::value, int64_t, uint64_t>::type)mn32; }
     __device__ __forceinline__ uint64_t b() const { return (uint64_t)(typename std::conditional<std::is_signed<T32>::value, int64_t, uint64_t>::type)mx32; }
@@ -155,8 +171,11 @@ __device__ __forceinline__ void agg_rows(C& c, uint32_t live, AGG& g) {
     static_assert(r == 0, "all rows at once");
     typename E::T v[R];
     E::template eval_rows<R>(c, v);
-    if constexpr (HasAddRows<AGG>::value) g.template add_rows<R>(v, live);
-    else if (__ballot((live & ((1u << R) - 1)) != (1u << R) - 1) == 0) {
+    const bool all_live = __ballot((live & ((1u << R) - 1)) != (1u << R) - 1) == 0;
+    if constexpr (HasAddRows<AGG>::value) {
+        if (all_live) g.template add_rows<R, true>(v, live);
+        else g.template add_rows<R, false>(v, live);
+    } else if (all_live) {
         // every row of every lane counts (no filter, no nulls, a full tile — wave-uniform): the same folds in the same order
         // without the per-row bit test and exec mask (13 -> 4 VALU instructions per f64 row; sum(sin(x + c)) was VALU-bound)
 #pragma unroll

@@ -74,6 +74,26 @@ def test_unary_large_arguments_and_specials(gpu, ora):
     assert r.tolist() == [1.0, 2.0, 3.0, -1.0, -2.0, -3.0]
 
 
+def test_unary_f32_trig_reduction_range(gpu, ora):
+    """f32 sin / cos / sec / csc run the library's own routine (f64 argument reduction + an f32 polynomial) below 1e9 and the
+    device libm above: arguments next to multiples of pi/2 (where the relative accuracy of the reduced argument decides), large
+    ones on both sides of the hand-over, tiny ones, -0.0 (sign kept), inf / NaN."""
+    near = []
+    for k in [1, 2, 3, 7, 100, 1001, 31416, 1_000_003, 12_345_678, 200_000_001]:
+        for h in (0.0, 0.5):
+            c = np.float32((k + h) * np.pi)
+            near += [c, np.nextafter(c, np.float32(np.inf)), np.nextafter(c, np.float32(-np.inf)), -c]
+    v = np.array(near + [1e6, -3.3e7, 9.9e8, 1.0e9, 1.1e9, -2.5e9, 3e20, 1e38, 1e-5, -1e-5, 1e-20, -1e-30, 1e-45, 0.0, -0.0, 0.5, -1.5707964,
+                         np.nan, np.inf, -np.inf], dtype=np.float32)
+    a = [A.HostArray.from_numpy(v)]
+    for op in ["sin", "cos", "sec", "csc", "tan", "cot"]:
+        g, e = gpu.unary(op, a)[0], ora.unary(op, a)[0]
+        with np.errstate(all="ignore"):
+            np.testing.assert_allclose(g.to_numpy(), e.to_numpy(), rtol=1e-6, atol=0, equal_nan=True, err_msg=op)
+    s = gpu.unary("sin", [A.HostArray.from_numpy(np.array([-0.0, 0.0], dtype=np.float32))])[0].to_numpy()
+    assert np.signbit(s[0]) and not np.signbit(s[1])
+
+
 @pytest.mark.parametrize("dtype", [A.I8, A.I16, A.I32, A.I64])
 def test_abs_signed_int(gpu, ora, dtype):
     rng = np.random.default_rng(3)
