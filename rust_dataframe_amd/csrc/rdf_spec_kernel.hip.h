@@ -122,6 +122,7 @@ template <> struct AggT<RDF_U16> : AggNarrow<uint32_t, AggT<RDF_U64>, true> {};
 // ballots again: a handful of VALU instructions per word for the whole wave.
 template <int RV>
 __device__ __forceinline__ uint64_t interleave_word(const uint64_t (&b)[RV], int h, int lane) {
+    if constexpr (RV == 1) return b[0];     // one row per lane: the ballot is already in row order
     uint64_t src = b[0];
 #pragma unroll
     for (int e = 1; e < RV; ++e) if ((lane % RV) == e) src = b[e];
@@ -154,7 +155,15 @@ struct Prog {
     }
     static constexpr int W = cmax(cmax(cmax(colw<0>(), colw<1>()), cmax(colw<2>(), colw<3>())), out_width());
     static_assert(W == 8 || W == 4 || W == 2, "the widest element of a program is 8, 4 or 2 bytes");
-    static constexpr int RV = 16 / W;                 // rows per vector slot (a 16-byte vector of the widest type)
+    // rows per vector slot: a 16-byte vector of the widest type — except for predicates stored as bit masks, which load 8 bytes
+    // per lane: with one f64 per lane a compare's lane mask IS the Arrow bitmap word of those 64 rows, and every halving of the
+    // rows per lane halves the ballot-and-interleave work that puts the bits in row order (25.9 vector instructions per row
+    // with 16-byte loads, PMC)
+    static constexpr bool bool_store() {
+        if constexpr (SINK_ == SINK_STORE && !std::is_same<V0, None>::value) return V0::dt == RDF_BOOL;
+        else return false;
+    }
+    static constexpr int RV = (bool_store() ? 8 : 16) / W;
     // rows per lane per iteration.  A 16-byte vector of 2-byte elements is 8 rows.  Measured on the 4-byte types: 8 rows pay for
     // a 3-column aggregate (0.62 -> 0.75 of peak: half the per-iteration overhead) but cost a 3-column store (0.70 -> 0.65) and
     // 4-column programs (0.75 -> 0.73) more in registers than they save
