@@ -112,6 +112,30 @@ def test_c3_1e9_properties(gpu):
     torch.cuda.empty_cache()
 
 
+def test_trig_identities_1e9(gpu):
+    """The kernels' own sine / cosine at full size, through identities that need no oracle: sin^2 + cos^2 == 1 per row
+    (min / max within a few ulp of 1, so the sum is the row count), sin(-x) == -sin(x) (odd: the two sums cancel
+    exactly), and the stored sin(x) aggregates to what the fused kernel folded (same per-row arithmetic on both paths,
+    rows-at-once or not)."""
+    import torch
+    x = _dev(N, 0, A.F64, -1000.0, 1000.0)
+    cols = [[_arr(x, A.F64, N)]]
+    e = A.Expr()
+    s, c = e.op("sin", e.col(0)), e.op("cos", e.col(0))
+    one = gpu.pipeline(e, cols, [e.op("add", e.op("multiply", s, s), e.op("multiply", c, c))])[0]
+    assert one.count == N and abs(one.min - 1.0) < 1e-15 and abs(one.max - 1.0) < 1e-15 and abs(one.sum - N) <= 1e-9 * N
+    sp = gpu.pipeline(e, cols, [s])[0]
+    sn = gpu.pipeline(e, cols, [e.op("sin", e.op("subtract", e.scalar(0.0), e.col(0)))])[0]
+    assert sp.count == sn.count == N and sn.sum == -sp.sum and sn.min == -sp.max and sn.max == -sp.min
+    assert -1.0 <= sp.min < -0.999999 and 0.999999 < sp.max <= 1.0
+    out = _out(A.F64, N)
+    gpu.pipeline(e, cols, [s], -1, A.SINK_STORE, [[out]])
+    ss = gpu.pipeline(e, [[out]], [e.col(0)])[0]
+    assert (ss.min, ss.max, ss.count) == (sp.min, sp.max, N) and ss.sum == sp.sum     # same values, same fold order
+    del x, out
+    torch.cuda.empty_cache()
+
+
 def test_sort_and_groupby_large_properties(gpu):
     import torch
     n = 50_000_000
