@@ -131,14 +131,15 @@ def _gb_data():
     return rng.integers(-300, 300, n).astype(np.int64), rng.uniform(0, 1, n)
 
 
-@pytest.mark.timeout(120)
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("shuffle_rows", [False, True])
-def test_groupby_all_to_all_world_2_gloo(ora, shuffle_rows, monkeypatch):
+def test_groupby_all_to_all_world_2_gloo(ora, shuffle_rows, world, monkeypatch):
     """Local pre-aggregation -> hash-partitioned all-to-all of partial groups -> local merge, and the
     row-shuffle fallback of the same section (rows exchanged, aggregated once at their owner): the same groups either way."""
     monkeypatch.setenv("RDF_TEST_SHUFFLE_ROWS", "1" if shuffle_rows else "0")
     assert sharding.shuffle_rows_pays(1000, 600) and not sharding.shuffle_rows_pays(10_000_000, 1_000_000)
-    world, port = 2, 31500 + os.getpid() % 2000 + (50 if shuffle_rows else 0)
+    port = 31500 + os.getpid() % 2000 + (50 if shuffle_rows else 0) + 7 * world      # (world 4: the uneven splits of the driver's N = 4 / 8 runs)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_gb_worker, args=(r, world, port, q)) for r in range(world)]
