@@ -46,6 +46,19 @@ def test_c4_two_ranks_device_exchange():
     assert cfg["groups_total"] == 1_000_000          # every key owned by exactly one rank, none lost, none twice
 
 
+def test_c4_four_ranks_device_exchange():
+    """Four ranks (the uneven per-owner splits of the driver's N = 4 / 8 runs): partial groups packed on the device,
+    exchanged, merged at their owners; and the headline's row ranges at four ranks."""
+    four = _run("c4", 4, 5_000_000, 29651)
+    cfg = four["config"]
+    assert four["n_gpus"] == 4 and cfg["self_check"] is True and cfg["parity_on_sample"] is True, cfg
+    assert cfg["groups_total"] == 1_000_000
+    h4 = _run("headline", 4, 10_000_000, 29661)
+    h1 = _run("headline", 1, 40_000_000, 0)
+    assert h4["config"]["result_count"] == h1["config"]["result_count"]
+    assert abs(h4["config"]["result_sum"] - h1["config"]["result_sum"]) <= 1e-12 * h1["config"]["result_sum"]
+
+
 def test_c4_two_ranks_row_shuffle():
     """SURVEY.md 8e's fallback: the rows themselves are bucketed on the device, exchanged and aggregated at their owner."""
     two = _run("c4", 2, 10_000_000, 29641, RDF_C4_SHUFFLE_ROWS="1")
