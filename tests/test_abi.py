@@ -100,6 +100,34 @@ def test_argument_validation_needs_no_device():
     assert api.unary("sin", [A.HostArray.from_numpy(np.zeros(0))])[0].length == 0
 
 
+def test_frame_entry_points_validate_before_the_device():
+    """rdf_frame_pin refuses host buffers and empty lists, and the _frame calls refuse a NULL handle — all as RDF_INVALID_ARGUMENT
+    values, before any device work."""
+    so = lib.load()
+    api = lib.api()
+    with pytest.raises(A.RdfError) as ei:      # host buffers are staged per call: nothing to pin
+        A.PinnedFrame(api, [[A.HostArray.from_numpy(np.arange(4.0))]])
+    assert ei.value.status == A.RDF_INVALID_ARGUMENT and "device-resident" in ei.value.message
+    h = C.c_void_p(0)
+    so.rdf_frame_pin.restype = C.c_int
+    assert so.rdf_frame_pin(None, C.c_int32(1), C.c_int64(1), C.byref(h)) == A.RDF_INVALID_ARGUMENT and not h.value
+    assert so.rdf_frame_pin(None, C.c_int32(1), C.c_int64(1), None) == A.RDF_INVALID_ARGUMENT
+    e = A.Expr()
+    c0 = e.col(0)
+    nodes = e.c_array()
+    prog = A.rdf_program(C.cast(nodes, C.POINTER(A.rdf_expr_node)), len(e.nodes), -1, 1, (C.c_int32 * A.MAX_VALUES)(c0), A.SINK_AGG)
+    aggs = (A.rdf_agg_result * A.MAX_VALUES)()
+    for fn, args in [(so.rdf_pipeline_frame, (C.byref(prog), None, None, aggs)),
+                     (so.rdf_predicate_frame, (nodes, C.c_int32(len(e.nodes)), C.c_int32(c0), None, None)),
+                     (so.rdf_group_pipeline_frame, (nodes, C.c_int32(len(e.nodes)), C.c_int32(-1), C.c_int32(c0), C.c_int32(4),
+                                                    (C.c_int32 * 1)(c0), C.c_int32(1), None, None, None))]:
+        fn.restype = C.c_int
+        assert fn(*args) == A.RDF_INVALID_ARGUMENT
+        assert b"null frame" in so.rdf_last_error()
+    so.rdf_frame_release.restype = C.c_int
+    assert so.rdf_frame_release(None) == A.RDF_OK      # releasing nothing is not an error (Drop of a frame that was never pinned)
+
+
 @pytest.mark.skipif(lib.device_count() > 0, reason="a GPU is visible")
 def test_no_gpu_means_loud_device_error_not_a_fallback():
     api = lib.api()
