@@ -100,6 +100,30 @@ def test_argument_validation_needs_no_device():
     assert api.unary("sin", [A.HostArray.from_numpy(np.zeros(0))])[0].length == 0
 
 
+def _build_c_example(d):
+    exe = os.path.join(d, "example")
+    libdir = os.path.dirname(lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "integration", "example.c"),
+                           "-L", libdir, "-lrdf_mi355x", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+@pytest.mark.skipif(lib.device_count() > 0, reason="a GPU is visible")
+def test_c_example_links_and_fails_loudly_without_a_gpu():
+    """integration/example.c: a plain C caller of the ABI builds against the header and the library; with no device its one
+    compute call reports RDF_DEVICE_ERROR (no CPU fallback)."""
+    with tempfile.TemporaryDirectory() as d:
+        p = subprocess.run([_build_c_example(d)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "gfx950" in p.stdout and "status 5" in p.stdout and "no CPU fallback" in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_runs_on_the_gpu():
+    with tempfile.TemporaryDirectory() as d:
+        p = subprocess.run([_build_c_example(d)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "sum = 3.25 over 4 rows" in p.stdout, p.stdout + p.stderr
+
+
 def test_frame_entry_points_validate_before_the_device():
     """rdf_frame_pin refuses host buffers and empty lists, and the _frame calls refuse a NULL handle — all as RDF_INVALID_ARGUMENT
     values, before any device work."""
