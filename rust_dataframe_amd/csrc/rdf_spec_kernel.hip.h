@@ -97,13 +97,15 @@ template <class T32, class BASE, bool SUM32> struct AggNarrow : BASE {
         T32 s32 = 0;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const bool on = ALL || ((live >> i) & 1);
-            const T32 x = (T32)v[i];
-            const T32 xl = on ? x : lo, xh = on ? x : hi;
+            // dead rows contribute the identities through a 0 / ~0 mask (one bit-field extract, then v_bfi / v_and): no compare,
+            // no selects
+            const uint32_t m = ALL ? ~0u : 0u - ((live >> i) & 1u);
+            const uint32_t xb = (uint32_t)(T32)v[i];
+            const T32 xl = (T32)((xb & m) | ((uint32_t)lo & ~m)), xh = (T32)((xb & m) | ((uint32_t)hi & ~m)), xz = (T32)(xb & m);
             mn32 = xl < mn32 ? xl : mn32;
             mx32 = xh > mx32 ? xh : mx32;
-            if (SUM32) s32 += on ? x : (T32)0;
-            else this->sum += (uint64_t)(Wide)(on ? x : (T32)0);
+            if (SUM32) s32 += xz;
+            else this->sum += (uint64_t)(Wide)xz;
         }
         if (SUM32) this->sum += (uint64_t)(Wide)s32;
         this->cnt += ALL ? R : __popc(live & ((1u << R) - 1));
