@@ -11,7 +11,8 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librdf_mi355x.so")
+# RDF_LIB_PATH: another build of the same library (tools/ab_libs.py alternates two builds on one box); default: the in-tree build
+LIB_PATH = os.environ.get("RDF_LIB_PATH") or os.path.join(_HERE, "librdf_mi355x.so")
 
 # Every symbol include/rdf_mi355x.h declares (tests check the library exports all of them).
 EXPORTS = [
