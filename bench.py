@@ -142,9 +142,8 @@ def _close(a, b, rtol=1e-6):
     return a == b or abs(a - b) <= rtol * max(abs(a), abs(b))
 
 
-def workload_c3(torch, lib, api, A, sharding, dev, comm_dev, rank, rows):
+def workload_c3(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, total, opts):
     """C3: fused a*b+c -> min/max/count and the i64 key's min/max/count, one pass over 4 columns (32 B/row)."""
-    first = rank * rows
     g = Gen(torch, lib, dev)
     ts = [g.f64(rows, cid, first, -1.0, 1.0) for cid in range(3)] + [g.i64(rows, 3, first, -2 ** 31, 2 ** 31)]
     g.done()
@@ -159,7 +158,7 @@ def workload_c3(torch, lib, api, A, sharding, dev, comm_dev, rank, rows):
         return {"min_y": y.min, "max_y": y.max, "count_y": y.count, "min_k": kk.min, "max_k": kk.max, "count_k": kk.count}
 
     def check(res, world):
-        out = {"self_check": bool(res["count_y"] == rows * world == res["count_k"] and -2.0 <= res["min_y"] < res["max_y"] <= 2.0
+        out = {"self_check": bool(res["count_y"] == total == res["count_k"] and -2.0 <= res["min_y"] < res["max_y"] <= 2.0
                                   and -2 ** 31 <= res["min_k"] < res["max_k"] < 2 ** 31)}
         if rank == 0:
             from oracle import oracle
@@ -177,9 +176,8 @@ def workload_c3(torch, lib, api, A, sharding, dev, comm_dev, rank, rows):
     return step, 32.0 * rows, f"C3: fused a*b+c -> min/max/count + i64 key min/max/count over {rows:.0e} rows x 4 columns per GPU", check
 
 
-def workload_c4(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, ngroups=1_000_000):
+def workload_c4(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, total, opts, ngroups=1_000_000):
     """C4: SELECT key, sum(val) GROUP BY key, 1e6 keys: local hash aggregate, then (N > 1) the all-to-all of partial groups."""
-    first = rank * rows
     g = Gen(torch, lib, dev)
     kk = g.i64(rows, 7, first, 0, ngroups)
     v = g.f64(rows, 0, first, 0.0, 1.0)
@@ -187,32 +185,33 @@ def workload_c4(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, ngroups
     K = A.DeviceArray(kk.data_ptr(), None, 0, rows, A.I64, 0, keep=kk)
     V = A.DeviceArray(v.data_ptr(), None, 0, rows, A.F64, 0, keep=v)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    exchange_on = world > 1 or opts.get("force_exchange", False)     # a 1-rank communicator still runs the whole exchange
     cap = ngroups + 2
 
     def outs3():
         bufs = [torch.empty(cap * 8 + 64, dtype=torch.uint8, device=dev) for _ in range(3)]
         return tuple(A.DeviceArray(b.data_ptr(), None, 0, cap, dt, 0, keep=b) for b, dt in zip(bufs, (A.I64, A.F64, A.I64)))
     outs = outs3()
-    ex = sharding.GroupExchange(api, lib, torch, dev, comm_dev, cap) if world > 1 else None
+    ex = sharding.GroupExchange(api, lib, torch, dev, comm_dev, cap) if exchange_on else None
     last = {}
 
     # with about as many groups as rows pre-aggregation cannot shrink the shard: the rows are shuffled instead
-    shuffle = world > 1 and (os.environ.get("RDF_C4_SHUFFLE_ROWS") == "1" or sharding.shuffle_rows_pays(rows, ngroups))
+    shuffle = exchange_on and (os.environ.get("RDF_C4_SHUFFLE_ROWS") == "1" or sharding.shuffle_rows_pays(rows, ngroups))
 
     def step():
         if shuffle:
             ok_, mk2, mc2 = ex.shuffle_rows_and_aggregate(K, V, ngroups)
             last["groups"] = (ok_[0], mk2, mc2)
-            return {"groups_owned": ok_[0].length, "exchange": "rows"}
+            return {"groups_owned": ok_[0].length, "exchange": "rows", **ex.stats}
         gk, gs, gc = api.groupby_sum([K], [V], ngroups, outs)
         ng = gk.length
-        if world == 1:
+        if not exchange_on:
             last["groups"] = (gk, gs, gc)
             return {"groups": ng}
         # partial groups of this rank -> owners (RCCL all-to-all on device buffers), merged there by a second, tiny group-by
         mk_, ms_, mc_ = ex.exchange_and_merge(gk, gs, gc, ngroups)
         last["groups"] = (mk_, ms_, mc_)
-        return {"groups_owned": mk_.length}
+        return {"groups_owned": mk_.length, "exchange": "partial groups", **ex.stats}
 
     def check(res, world_):
         import numpy as np
@@ -227,13 +226,13 @@ def workload_c4(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, ngroups
         e = A.Expr()
         col_sum = sharding.all_combine(api.pipeline(e, [[V]], [e.col(0)]), device=comm_dev)[0].sum
         tot = [float(hs.sum()), int(hc.sum()), int(n)]
-        if world_ > 1:
-            import torch.distributed as dist
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
             t = torch.tensor(tot, dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
             dist.all_reduce(t)
             tot = [t[0].item(), int(t[1].item()), int(t[2].item())]
-        ok = (len(np.unique(hk)) == n and int(hc.min(initial=1)) >= 1 and tot[1] == rows * world_ and _close(tot[0], col_sum, 1e-9)
-              and tot[2] <= ngroups and (rows * world_ < 20 * ngroups or tot[2] == ngroups) and (n == 0 or (0 <= hk.min() and hk.max() < ngroups)))
+        ok = (len(np.unique(hk)) == n and int(hc.min(initial=1)) >= 1 and tot[1] == total and _close(tot[0], col_sum, 1e-9)
+              and tot[2] <= ngroups and (total < 20 * ngroups or tot[2] == ngroups) and (n == 0 or (0 <= hk.min() and hk.max() < ngroups)))
         out = {"self_check": bool(ok), "groups_total": tot[2]}
         if rank == 0:
             from oracle import oracle
@@ -267,11 +266,10 @@ def q1_program(A):
     return q, [c[0], c[1], dp, ch, c[2]], gid, pred
 
 
-def workload_q1(torch, lib, api, A, sharding, dev, comm_dev, rank, rows):
+def workload_q1(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, total, opts):
     """C5: TPC-H Q1 shape over a synthetic lineitem shard (38 B/row): filter(shipdate <= c) -> 5 sums + counts in 6 groups.
     Columns per the TPC-H distributions: quantity 1..50, extendedprice, discount 0.00..0.10, tax 0.00..0.08
     as f64; returnflag (3) / linestatus (2) dictionary codes as i8; shipdate as date32 days."""
-    first = rank * rows
     g = Gen(torch, lib, dev)
     qty = g.i64(rows, 12, first, 1, 51).to(torch.float64)
     price = g.f64(rows, 11, first, 900.0, 105000.0)
@@ -294,7 +292,7 @@ def workload_q1(torch, lib, api, A, sharding, dev, comm_dev, rank, rows):
     def check(res, world):
         cs = res["count_star"]
         sel = (10471 - 8036 + 1) / (10562 - 8036)
-        ok = abs(sum(cs) / (rows * world) - sel) < 1e-3
+        ok = abs(sum(cs) / total - sel) < 1e-3
         for gi in range(6):
             c_ = max(cs[gi], 1)
             ok = ok and 1.0 <= res["sum_qty"][gi] / c_ <= 50.0 and 0.0 <= res["sum_disc"][gi] / c_ <= 0.10
@@ -340,20 +338,55 @@ def read_probe(torch, x, runs=5):
     return x.numel() * x.element_size() / (ms * 1e-3) / 1e9
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start one rank per GPU under torch.distributed.run
+    (127.0.0.1 rendezvous on a free port), pass the command line through, let rank 0's JSON line reach stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RDF_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def _rccl_version(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU (f64, 8 B/row)")
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU (weak scaling; f64, 8 B/row)")
+    ap.add_argument("--total-rows", type=int, default=0,
+                    help="strong scaling: this many rows in total, cut into contiguous row ranges of whole 1024-row batches over the ranks "
+                         "(BASELINE config C4 as stated: --workload c4 --total-rows 1000000000 --gpus 8)")
     ap.add_argument("--cpu-sample", type=int, default=50_000_000, help="rows for the CPU baseline leg (0 = skip)")
     ap.add_argument("--null-fraction", type=float, default=0.0, help="attach a validity bitmap with this null rate")
     ap.add_argument("--chunk-rows", type=int, default=0, help="hand the column over as RecordBatches of this many rows (0 = one chunk; 1024 = the reference readers' batch)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for a smoke test)")
     ap.add_argument("--share-gpu", action="store_true", help="smoke test only: every rank uses device 0 (needs --backend gloo)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1 only: still create the process group (a 1-rank RCCL communicator with --backend nccl) and run every "
+                         "collective of the N > 1 path — all_gather of partials, the device-resident all_to_all of the group-by")
     ap.add_argument("--workload", default="headline", choices=["headline"] + sorted(WORKLOADS),
                     help="headline = BASELINE.json's metric (the default, what the driver runs); c3 / c4 / q1 = the other configs")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(_self_launch(args))       # the driver's plain `python bench.py --gpus N`
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
     from rust_dataframe_amd import _abi as A
@@ -361,33 +394,47 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
-    if world > 1:
+    if args.share_gpu:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible "
+                 "(one rank per GPU; --share-gpu --backend gloo is the single-GPU smoke mode)")
+    torch.cuda.set_device(local_rank)
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
+        sharding.FORCE_COLLECTIVES = bool(args.force_exchange)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.share_gpu:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
+        if world == 1:
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(args.backend)
-    else:
-        torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     lib.set_device(local_rank)
     api = lib.api()
     dev = torch.device("cuda", local_rank)
-    comm_dev = dev if (world == 1 or args.backend == "nccl") else None   # gloo exchanges CPU tensors
+    comm_dev = dev if (dist is None or args.backend == "nccl") else None   # gloo exchanges CPU tensors
+    comm = {"ranks": dist.get_world_size() if dist is not None else 1,
+            "backend": (args.backend if dist is not None else None),
+            "rccl_version": _rccl_version(torch) if (dist is not None and args.backend == "nccl") else None,
+            "launcher": "self (torch.distributed.run)" if os.environ.get("RDF_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else None)}
 
-    rows = args.rows
+    # weak scaling: every rank owns --rows rows; strong scaling (--total-rows): contiguous ranges of whole 1024-row batches
+    if args.total_rows > 0:
+        first_row, end_row = sharding.shard_rows(args.total_rows, world, rank)
+        rows, total_rows, scaling = end_row - first_row, args.total_rows, "strong"
+    else:
+        rows, first_row, total_rows, scaling = args.rows, rank * args.rows, args.rows * world, "weak"
+    args.rows, args.first_row, args.total, args.scaling, args.comm = rows, first_row, total_rows, scaling, comm
     if args.workload != "headline":
         return run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, world)
-    first_row = rank * rows
     g = Gen(torch, lib, dev)
     x = g.f64(rows, 0, first_row, 0.0, 1.0)
     vptr, vkeep = None, None
@@ -411,9 +458,13 @@ def main():
     e = A.Expr()
     c = e.col(0)
     pred = e.op("gt", c, e.scalar(THRESHOLD))
+    combine_s = [0.0]
+
     def step():
         local = api.pipeline(e, frame, [c], pred)          # fused filter -> {sum,min,max,count}, one pass over HBM
+        tc = time.perf_counter()
         tot = sharding.all_combine(local, device=comm_dev)[0]      # N > 1: all_gather the partials (RCCL), fold in rank order
+        combine_s[0] += time.perf_counter() - tc
         return tot.sum, tot.count
 
     def sync():
@@ -423,7 +474,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     sync()
     lib.kernel_timing_reset(True)
@@ -431,20 +482,19 @@ def main():
     for _ in range(args.steps):
         res = step()
     sync()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = lib.kernel_timing_get()
     kernel_name = lib.last_kernel()
     lib.kernel_timing_reset(False)
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
     if rank == 0:
-        total_rows = rows * world
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rows * args.steps / elapsed
         alg_bytes = rows * 8.0 + (rows / 8.0 if vptr else 0.0)   # per launch (one rank's launch)
@@ -465,13 +515,14 @@ def main():
         out = {
             "metric": "rows/sec filter+sum over 1e9 f64 Arrow rows; %HBM bw at 1/2/4/8 GPU",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"filter(x>{THRESHOLD})->sum over a {rows:.0e}-row f64 Arrow RecordBatch per GPU, HBM-resident"
                                    + (f", {args.null_fraction:.0%} nulls (validity bitmap)" if vptr else ", no validity bitmap")
                                    + (f", {len(col)} RecordBatches of {args.chunk_rows} rows" if args.chunk_rows else ""),
                        "rows_per_gpu": rows, "total_rows": total_rows, "selectivity": res[1] / total_rows,
-                       "result_sum": res[0], "result_count": res[1], "sharding": "row ranges per rank, no data-path collective"},
+                       "result_sum": res[0], "result_count": res[1], "sharding": "row ranges per rank, no data-path collective",
+                       "combine_ms_per_step": combine_s[0] / max(args.steps + args.warmup, 1) * 1e3, **comm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "peak_measured": probe, "peak_measured_kind": "torch.sum over the same column (stock read-only stream), median of 5",
@@ -498,14 +549,15 @@ def main():
             cb.pop("_sum"), cb.pop("_count")
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
 def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, world):
     """Same timing contract as the headline, for the other BASELINE.json configurations."""
-    rows = args.rows
-    step, alg_bytes, desc, check = WORKLOADS[args.workload](torch, lib, api, A, sharding, dev, comm_dev, rank, rows)
+    rows, total = args.rows, args.total
+    opts = {"force_exchange": args.force_exchange}
+    step, alg_bytes, desc, check = WORKLOADS[args.workload](torch, lib, api, A, sharding, dev, comm_dev, rank, rows, args.first_row, total, opts)
 
     def sync():
         torch.cuda.synchronize()
@@ -514,7 +566,7 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
     for _ in range(args.warmup):
         step()
     sync()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     sync()
     lib.kernel_timing_reset(True)
@@ -522,19 +574,19 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
     for _ in range(args.steps):
         res = step()
     sync()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = lib.kernel_timing_get()
     kernel_name = lib.last_kernel()
     lib.kernel_timing_reset(False)
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     chk = check(res, world)     # untimed; collective when N > 1 (every rank takes part)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
         per_launch_s = kern_ms / max(kern_n, 1) * 1e-3 * (kern_n / args.steps if kern_n else 0)   # all timed kernels of one step
@@ -550,10 +602,10 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
         except Exception:
             traffic = None
         line = {
-            "metric": f"rows/sec {args.workload}", "value": rows * world * args.steps / elapsed, "unit": "rows/s", "n_gpus": world,
+            "metric": f"rows/sec {args.workload}", "value": total * args.steps / elapsed, "unit": "rows/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "rows_per_gpu": rows, "total_rows": rows * world, "result": res, **chk},
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "rows_per_gpu": rows, "total_rows": total, "result": res, **chk, **args.comm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms_per_step": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes},

@@ -2026,6 +2026,8 @@ class Evaluate {
                              std::vector<Column>& out_cols) {
         using AF = plan::AggregateFunction;
         if (keys.empty() || vals.empty()) return false;
+        // the dense kernel folds sums and counts; per-group Min / Max go through the hash path (rdf_groupby_agg)
+        for (auto& v : vals) if (v.fn != AF::Sum && v.fn != AF::Count && v.fn != AF::Avg) return false;
         std::vector<int64_t> kmin(keys.size()), dom(keys.size());
         uint64_t total = 1;
         for (size_t i = 0; i < keys.size(); ++i) {
@@ -2063,7 +2065,6 @@ class Evaluate {
         std::vector<std::string> vnames;
         std::vector<ExprRef> vexprs;
         for (auto& v : vals) {
-            if (v.fn != AF::Sum && v.fn != AF::Count && v.fn != AF::Avg) throw DataFrameError(DataFrameError::ComputeError, "Aggregation not yet supported");
             if (!(is_integer(v.dtype) || is_float(v.dtype))) throw DataFrameError(DataFrameError::ComputeError, "Aggregating column must be numeric");
             if (std::find(vnames.begin(), vnames.end(), v.name) == vnames.end()) { vnames.push_back(v.name); vexprs.push_back(v.e); }
         }

@@ -3023,6 +3023,8 @@ static rdf_status groupby_finish_partitioned(void* pspec, void* d_keys, void* d_
             RDF_TRY(put(z, hs[0], hs[2]));
         }
         if (hf[1]) { null_idx = ng; RDF_TRY(put(0, hs[1], hs[3])); }
+        if (ng > out_keys->capacity || ng > out_sums->capacity || ng > out_counts->capacity)
+            return fail(RDF_MEMORY_ERROR, "groupby: more than max_groups (%lld) distinct keys", (long long)max_groups);
         const hipMemcpyKind kind = mem == RDF_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
         if (ng > 0) {
             HIP_TRY(hipMemcpyAsync(out_keys->values, ga.out_keys, (size_t)ng * kes2, kind, ctx.stream));
@@ -3080,7 +3082,9 @@ rdf_status legacy_groupby_sum(const rdf_array* keys, const rdf_array* values, in
         tile_start[(size_t)c + 1] = tile_start[(size_t)c] + (keys[c].length + kEvalTile - 1) / kEvalTile;
     }
     if (null_keys && !out_keys->validity) return fail(RDF_INVALID_ARGUMENT, "output validity buffer required");
-    const int64_t cap_needed = std::min<int64_t>(max_groups + 2, tile_start[(size_t)nchunks] * kEvalTile + 2);
+    int64_t nrows_total = 0;
+    for (int64_t c = 0; c < nchunks; ++c) nrows_total += keys[c].length;
+    const int64_t cap_needed = std::min<int64_t>(max_groups + 2, nrows_total + 2);    // the contract rdf_groupby_agg states
     if (out_keys->capacity < cap_needed || out_sums->capacity < cap_needed || out_counts->capacity < cap_needed)
         return fail(RDF_MEMORY_ERROR, "output capacity too small (need max_groups + 2)");
     RDF_TRY(ensure_ready());

@@ -274,7 +274,8 @@ struct LdsTab {
 // steps, and a wave waits for its unluckiest lane — measured 16.2 ms instead of 5.2 ms per 1e9 rows.)
 template <int B, int PB>
 __device__ __forceinline__ void tab_upsert(const LdsTab& t, int op, int cls, bool has_values, uint32_t base, uint32_t slots,
-                                           const uint64_t (&hk)[B], const uint64_t (&val)[B], const uint32_t (&cnt)[B], uint32_t pending, uint32_t& err) {
+                                           const uint64_t (&hk)[B], const uint64_t (&val)[B], const uint32_t (&cnt)[B], uint32_t pending, uint32_t& err,
+                                           uint32_t full_flag = 4u) {
     uint32_t s[B], step[B];
 #pragma unroll
     for (int u = 0; u < B; ++u) {
@@ -305,7 +306,7 @@ __device__ __forceinline__ void tab_upsert(const LdsTab& t, int op, int cls, boo
                 if (s[u] >= slots) s[u] -= slots;
             }
         }
-        if (++guard > slots) { if (pending) err |= 4u; break; }   // table full: more groups than promised
+        if (++guard > slots) { if (pending) err |= full_flag; break; }   // table full: more groups than promised (stream) / than one partition's table holds (aggregate)
     }
 }
 
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
                 cnt[u] = (uint32_t)(cur[u][0] >> (64 - kG2PartBits));
                 if (cur[u][0] != kDead) pending |= 1u << u;
             }
-            tab_upsert<kAggBatch, kG2PartBits>(t, a.op, a.vcls, a.has_values != 0, 0u, (uint32_t)kG2Slots, hk, val, cnt, pending, err);
+            tab_upsert<kAggBatch, kG2PartBits>(t, a.op, a.vcls, a.has_values != 0, 0u, (uint32_t)kG2Slots, hk, val, cnt, pending, err, 32u);   // 32: this partition's LDS table is full — says nothing about max_groups, the host retries on the HBM table
             if (nhave) {
 #pragma unroll
                 for (int u = 0; u < kAggBatch; ++u) cur[u] = nxt[u];

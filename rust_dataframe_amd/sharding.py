@@ -65,6 +65,14 @@ def combine(parts: Sequence[AggResult]) -> AggResult:
 
 _gather_buffers = {}
 
+# A 1-rank process group normally short-circuits every combine.  bench.py --force-exchange (and the -m gpu nccl test) set
+# this so that the collectives themselves run on a 1-rank RCCL communicator: the N > 1 code path, one GPU.
+FORCE_COLLECTIVES = False
+
+
+def _single(dist) -> bool:
+    return not dist.is_initialized() or (dist.get_world_size() == 1 and not FORCE_COLLECTIVES)
+
 
 def _all_gather_words(words, device):
     """One collective for a small int64 vector: returns [world][len(words)] as Python ints.  Buffers are cached per
@@ -103,7 +111,7 @@ def all_combine(local: Sequence[AggResult], device=None) -> List[AggResult]:
     """all_gather every rank's partials (ONE collective of 5 int64 words per value: f64 partials travel as their bit
     patterns, integer partials as two's-complement i64 — both exact) and fold them identically on every rank."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(dist):
         return [combine([p]) for p in local]
     world = dist.get_world_size()
     wrap = lambda x: x - (1 << 64) if x >= (1 << 63) else x
@@ -152,7 +160,7 @@ def all_combine_groups(local, device=None):
     f64 sums travel as f64, integer sums / counts as i64 (exact)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(dist):
         return combine_groups([local])
     world = dist.get_world_size()
     res, rows = local
@@ -202,7 +210,7 @@ def exchange_groups(keys, sums, counts, device=None):
     import numpy as np
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(dist):
         return keys, sums, counts
     world = dist.get_world_size()
     keys, sums, counts = np.ascontiguousarray(keys), np.ascontiguousarray(sums), np.ascontiguousarray(counts)
@@ -280,6 +288,18 @@ class GroupExchange:
         self.api, self.lib, self.torch, self.dev, self.comm_dev, self.cap = api, lib, torch, dev, comm_dev, cap
         self.packed = torch.empty(cap * 3 + 8, dtype=torch.int64, device=dev)
         self._bufs = [torch.empty(cap + 8, dtype=torch.int64, device=dev) for _ in range(3)]
+        # what the last exchange moved, for the bench line: bytes this rank sent (all owners / other ranks only), bytes it
+        # received, and the host-clock time from "pack" to "received and unpacked" (collectives + pack / unpack kernels)
+        self.stats = {}
+
+    def _note(self, t0, send_counts, recv_counts, width):
+        import time
+        import torch.distributed as dist
+        me = dist.get_rank()
+        self.stats = {"exchange_ms": (time.perf_counter() - t0) * 1e3,
+                      "exchange_bytes_sent": int(sum(send_counts)) * width,
+                      "exchange_bytes_sent_remote": int(sum(c for r, c in enumerate(send_counts) if r != me)) * width,
+                      "exchange_bytes_received": int(sum(recv_counts)) * width}
 
     def _merged(self, kdt, sdt):
         from ._abi import I64, DeviceArray
@@ -290,7 +310,11 @@ class GroupExchange:
         from ._abi import DeviceArray
         torch = self.torch
         world = dist.get_world_size()
+        import time
         n = gk.length
+        if n > self.cap:
+            raise ValueError(f"GroupExchange: {n} partial groups exceed the capacity {self.cap} this exchange was sized for")
+        t0 = time.perf_counter()
         K = DeviceArray(gk.values_ptr, None, 0, n, gk.dtype, 0)
         S = DeviceArray(gs.values_ptr, None, 0, n, gs.dtype, 0)
         Cn = DeviceArray(gc.values_ptr, None, 0, n, gc.dtype, 0)
@@ -314,6 +338,7 @@ class GroupExchange:
         rk, rs, rc = (DeviceArray(t.data_ptr(), None, 0, m, dt, 0, keep=t, capacity=m) for t, dt in zip(cols, (gk.dtype, gs.dtype, gc.dtype)))
         torch.cuda.current_stream().synchronize()
         self.api.group_exchange_unpack(recv.data_ptr(), m, rk, rs, rc)
+        self._note(t0, send_counts, recv_counts, 24)
         return self.api.groupby_merge(rk, rs, rc, agg, max_groups, outs=self._merged(gk.dtype, gs.dtype))
 
     def shuffle_rows_and_aggregate(self, K, V, max_groups: int, agg: str = "sum"):
@@ -324,7 +349,9 @@ class GroupExchange:
         from ._abi import DeviceArray
         torch = self.torch
         world = dist.get_world_size()
+        import time
         n = K.length
+        t0 = time.perf_counter()
         if getattr(self, "_rows_packed", None) is None or self._rows_packed.numel() < 2 * n + 8:
             self._rows_packed = torch.empty(2 * n + 8, dtype=torch.int64, device=self.dev)
         torch.cuda.current_stream().synchronize()
@@ -346,5 +373,6 @@ class GroupExchange:
         rk, rv = (DeviceArray(t.data_ptr(), None, 0, m, dt, 0, keep=t, capacity=m) for t, dt in zip(cols, (K.dtype, V.dtype)))
         torch.cuda.current_stream().synchronize()
         self.api.row_exchange_unpack(recv.data_ptr(), m, rk, rv)
+        self._note(t0, send_counts, recv_counts, 16)
         ko, so, co = self._merged(K.dtype, self.api._agg_out_dtype(self.api.AGGS[agg], V.dtype))
         return self.api.groupby_agg([[rk]], [rv], agg, max_groups, ([ko], so, co))

@@ -697,6 +697,47 @@ TEST(test_group_aggregate_min_max_and_sparse_key_columns) {
     }
 }
 
+// Per-group Min / Max over a SMALL DENSE key domain (keys 0..9): the dense one-pass kernel folds only sums and counts, so
+// the step must take the hash path instead of failing (round-2 review: dense_groups threw "Aggregation not yet supported").
+TEST(test_group_aggregate_min_max_dense_keys) {
+    std::mt19937_64 rng(5);
+    std::uniform_real_distribution<double> U(-50.0, 50.0);
+    const size_t nchunks = 3, n = 4000;
+    struct G { double sum = 0, mn = INFINITY, mx = -INFINITY; int64_t cnt = 0; };
+    std::map<int64_t, G> exp;
+    std::vector<ArrayRef> kch, xch;
+    for (size_t c = 0; c < nchunks; ++c) {
+        std::vector<int64_t> k(n);
+        std::vector<double> x(n);
+        for (size_t i = 0; i < n; ++i) {
+            k[i] = (int64_t)(rng() % 10); x[i] = U(rng);
+            G& g = exp[k[i]];
+            g.sum += x[i]; g.mn = std::min(g.mn, x[i]); g.mx = std::max(g.mx, x[i]); ++g.cnt;
+        }
+        kch.push_back(Array::from_vec(k)); xch.push_back(Array::from_vec(x));
+    }
+    DataFrame df = DataFrame::from_columns({Column::from_arrays(kch, Field{"k", DataType::Int64, false}), Column::from_arrays(xch, Field{"x", DataType::Float64, false})});
+    using AF = P::AggregateFunction;
+    DataFrame g = LazyFrame::read(df).aggregate({"k"}, {{AF::Min, {"x"}}, {AF::Max, {"x"}}, {AF::Sum, {"x"}}, {AF::Count, {"x"}}}).evaluate();
+    CHECK_EQ(g.num_columns(), 5u);
+    CHECK_EQ((size_t)g.num_rows(), exp.size());
+    auto kk = host<int64_t>(g.column(0).data().chunk(0));
+    auto mn = host<double>(g.column(1).data().chunk(0)), mx = host<double>(g.column(2).data().chunk(0)), sx = host<double>(g.column(3).data().chunk(0));
+    auto cx = host<uint32_t>(g.column(4).data().chunk(0));
+    size_t r = 0;
+    for (auto& kv : exp) {
+        CHECK_EQ(kk[r], kv.first); CHECK_EQ(mn[r], kv.second.mn); CHECK_EQ(mx[r], kv.second.mx);
+        CHECK_NEAR(sx[r], kv.second.sum, 1e-9 * (1.0 + std::fabs(kv.second.sum)));
+        CHECK_EQ((int64_t)cx[r], kv.second.cnt);
+        ++r;
+    }
+    // and the sums-only form of the same frame still takes the dense kernel with the same answers
+    DataFrame d = LazyFrame::read(df).aggregate({"k"}, {{AF::Sum, {"x"}}, {AF::Count, {"x"}}}).evaluate();
+    auto ds = host<double>(d.column(1).data().chunk(0));
+    r = 0;
+    for (auto& kv : exp) { CHECK_NEAR(ds[r], kv.second.sum, 1e-9 * (1.0 + std::fabs(kv.second.sum))); ++r; }
+}
+
 // DataFrame::from_arrow (src/dataframe.rs:391-407) on the committed pyarrow-written fixture: schema, chunking (one chunk
 // per record batch), every value and validity bit, then the device path over the loaded columns.
 TEST(test_from_arrow_ipc_file) {

@@ -15,13 +15,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(workload, gpus, rows, port, **extra_env):
+def _run(workload, gpus, rows, port, launcher="torchrun", flags=(), **extra_env):
+    """launcher = "torchrun": the driver's N > 1 command line; "self": plain `python bench.py --gpus N`, which must start
+    its own ranks.  Both ranks share the test box's one GPU, so N > 1 here means gloo + --share-gpu."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    base = [os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--rows", str(rows), "--cpu-sample", "0",
-            "--workload", workload]
-    if gpus > 1:
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    base = [os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--cpu-sample", "0",
+            "--workload", workload] + (["--rows", str(rows)] if rows else []) + list(flags)
+    if gpus > 1 and launcher == "torchrun":
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port)] + base + ["--backend", "gloo", "--share-gpu"]
+    elif gpus > 1:
+        cmd = [sys.executable] + base + ["--backend", "gloo", "--share-gpu"]
     else:
         cmd = [sys.executable] + base
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -76,3 +82,56 @@ def test_q1_two_ranks_equal_one():
     for name in ("sum_qty", "sum_price", "sum_disc_price", "sum_charge", "sum_disc"):
         for x, y in zip(a["result"][name], b["result"][name]):
             assert abs(x - y) <= 1e-9 * abs(y), name
+
+
+# ------------------------------------------------------------------ the driver's plain command line, strong scaling, RCCL
+def test_self_launch_two_ranks_headline_and_c4():
+    """`python bench.py --gpus 2` with no launcher around it (what the driver runs): bench.py starts its own ranks under
+    torch.distributed.run and rank 0's single JSON line comes back."""
+    two = _run("headline", 2, 20_000_000, 0, launcher="self")
+    one = _run("headline", 1, 40_000_000, 0)
+    assert two["n_gpus"] == 2 and two["config"]["ranks"] == 2 and two["config"]["launcher"].startswith("self")
+    assert two["config"]["result_count"] == one["config"]["result_count"]
+    c4 = _run("c4", 2, 10_000_000, 0, launcher="self")
+    cfg = c4["config"]
+    assert cfg["ranks"] == 2 and cfg["self_check"] is True and cfg["parity_on_sample"] is True and cfg["groups_total"] == 1_000_000, cfg
+    assert cfg["result"]["exchange_bytes_sent"] > 0 and cfg["result"]["exchange_ms"] > 0, cfg
+
+
+def test_strong_scaling_total_rows():
+    """--total-rows: one global row range cut over the ranks (BASELINE C4 is stated that way: 1e9 rows over 8 GPUs)."""
+    total = 30_000_000 + 1024 * 3 + 17          # ragged: the last rank's shard ends inside a batch
+    two = _run("c4", 2, 0, 0, launcher="self", flags=["--total-rows", str(total)])
+    one = _run("c4", 1, 0, 0, flags=["--total-rows", str(total)])
+    a, b = two["config"], one["config"]
+    assert two["scaling"] == "strong" == one["scaling"] and a["total_rows"] == b["total_rows"] == total
+    assert a["self_check"] is True and b["self_check"] is True and a["groups_total"] == b["groups_total"]
+    h2 = _run("headline", 2, 0, 0, launcher="self", flags=["--total-rows", str(total)])
+    h1 = _run("headline", 1, 0, 0, flags=["--total-rows", str(total)])
+    assert h2["config"]["result_count"] == h1["config"]["result_count"] and h2["config"]["total_rows"] == total
+    assert abs(h2["config"]["result_sum"] - h1["config"]["result_sum"]) <= 1e-12 * h1["config"]["result_sum"]
+
+
+@pytest.mark.parametrize("workload,env", [("headline", {}), ("q1", {}), ("c3", {}), ("c4", {}), ("c4", {"RDF_C4_SHUFFLE_ROWS": "1"})])
+def test_rccl_one_rank_communicator(workload, env):
+    """The production backend: init_process_group("nccl", device_id=...) and every collective of the N > 1 path on DEVICE
+    tensors — all_gather of the partials, all_to_all_single of the split sizes, all_to_all_single of the packed HBM buffers
+    with uneven split lists — on a 1-rank RCCL communicator (the test box has one GPU; 2 ranks on one GPU is not a
+    configuration RCCL accepts).  Results equal the run without any process group."""
+    rows = 10_000_000
+    nc = _run(workload, 1, rows, 0, flags=["--force-exchange", "--backend", "nccl"], **env)
+    plain = _run(workload, 1, rows, 0)
+    cfg, ref = nc["config"], plain["config"]
+    assert cfg["ranks"] == 1 and cfg["backend"] == "nccl" and cfg["rccl_version"], cfg
+    if workload == "headline":
+        assert cfg["result_count"] == ref["result_count"] and cfg["result_sum"] == ref["result_sum"]
+        return
+    assert cfg["self_check"] is True and cfg["parity_on_sample"] is True, cfg
+    if workload == "c4":
+        assert cfg["groups_total"] == ref["groups_total"] == 1_000_000
+        assert cfg["result"]["exchange"] == ("rows" if env else "partial groups")
+        width = 16 * rows if env else 24 * 1_000_000
+        assert cfg["result"]["exchange_bytes_sent"] == width == cfg["result"]["exchange_bytes_received"], cfg
+        assert cfg["result"]["exchange_bytes_sent_remote"] == 0
+    else:
+        assert cfg["result"] == ref["result"]
