@@ -353,6 +353,28 @@ def _self_launch(args):
     return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
+_JSON_FD = None
+
+
+def _quiet_stdout():
+    """RCCL prints a version banner on C stdout (buffered: it would land AFTER the result).  From here on everything
+    written to fd 1 — by any library, in any rank — goes to stderr, and the one JSON line is written to the real stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def _rccl_version(torch):
     try:
         v = torch.cuda.nccl.version()
@@ -403,6 +425,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_exchange:
         import torch.distributed as dist
+        _quiet_stdout()
         sharding.FORCE_COLLECTIVES = bool(args.force_exchange)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -548,7 +571,7 @@ def main():
                 cb["c1"]["parity"] = bool(abs(g1.sum - cb["c1"]["result_sum"]) <= 1e-6 * abs(cb["c1"]["result_sum"]))
             cb.pop("_sum"), cb.pop("_count")
             out["cpu_baseline"] = cb
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -612,7 +635,7 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
         }
         if cb is not None:
             line["cpu_baseline"] = cb
-        print(json.dumps(line), flush=True)
+        emit(line)
         if not chk.get("self_check", False) or chk.get("parity_on_sample") is False:
             sys.exit(f"bench.py --workload {args.workload}: result check FAILED: {chk}")
 

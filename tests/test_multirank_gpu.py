@@ -118,7 +118,7 @@ def test_rccl_one_rank_communicator(workload, env):
     tensors — all_gather of the partials, all_to_all_single of the split sizes, all_to_all_single of the packed HBM buffers
     with uneven split lists — on a 1-rank RCCL communicator (the test box has one GPU; 2 ranks on one GPU is not a
     configuration RCCL accepts).  Results equal the run without any process group."""
-    rows = 10_000_000
+    rows = 20_000_000 if workload == "c4" else 10_000_000      # 20 rows per key: every one of the 1e6 keys occurs
     nc = _run(workload, 1, rows, 0, flags=["--force-exchange", "--backend", "nccl"], **env)
     plain = _run(workload, 1, rows, 0)
     cfg, ref = nc["config"], plain["config"]
