@@ -406,6 +406,44 @@ rdf_status rdf_frame_pin(const rdf_array* cols, int32_t ncols, int64_t nchunks, 
 rdf_status rdf_frame_release(rdf_frame* frame);
 rdf_status rdf_pipeline_frame(const rdf_program* prog, rdf_frame* frame, rdf_out* outs, rdf_agg_result* aggs);
 
+/* ------------------------------------------------------------------ frame-level operators
+ *
+ * DataFrame::filter / take / sort and GroupAggregate over a pinned frame, returning a NEW frame whose buffers the library
+ * owns (rdf_frame_release gives them back).  Nothing per RecordBatch crosses to the host: descriptor tables are built by
+ * kernels, so a frame held in the readers' 1024-row batches (src/dataframe.rs:352: 976 563 batches for 1e9 rows) costs what
+ * its kernels cost — the list-taking entry points above pay O(batches) host work per call (walking rdf_array / rdf_out lists).
+ * Frames returned here are ordinary frames: rdf_pipeline_frame, rdf_filter_frame, ... run over them (<= 8 columns for the
+ * program-evaluating entry points), rdf_frame_column exports their descriptors.  Every batch of an owned frame starts on a
+ * 64-row boundary of its column buffer (values 16-byte, bitmaps 8-byte aligned); null counts are reported as unknown (-1). */
+
+/* columns, batches, rows of a frame */
+rdf_status rdf_frame_info(rdf_frame* frame, int32_t* ncols, int64_t* nchunks, int64_t* rows);
+/* The rdf_array descriptors of one column (nchunks entries, RDF_MEM_DEVICE, borrowed from the frame): the bridge back to
+ * the list-taking entry points and to arrow::array::ArrayData on the Rust side.  O(batches) host work, once per frame. */
+rdf_status rdf_frame_column(rdf_frame* frame, int32_t col, rdf_array* chunks);
+/* DataFrame::filter(&BooleanFilter) (src/dataframe.rs:178-189): the predicate is evaluated over every batch
+ * (BooleanFilter::eval_to_array, src/expression.rs:766-861) and EVERY column of the frame is compacted with it in one pass
+ * (Column::filter per column in the reference); batch boundaries are kept (ChunkedArray::filter, src/table.rs:97-107), a
+ * batch may become empty.  `root` must be boolean-typed; column index c of the expression = column c of the frame. */
+rdf_status rdf_filter_frame(rdf_frame* frame, const rdf_expr_node* nodes, int32_t nnodes, int32_t root, rdf_frame** out);
+/* DataFrame::take's per-column loop (src/dataframe.rs:216-222; DataFrame::join's, :705-711) as ONE gather pass: the index
+ * list is read once, each row is resolved to (batch, element) once, and the gathers of all columns of a row are in flight
+ * together.  cols[c * nchunks + i]; indices: ONE RDF_U32 / RDF_U64 array; outs: ncols one-chunk outputs.  Semantics per
+ * column exactly rdf_take's (null index -> null, out of range -> RDF_COMPUTE_ERROR). */
+rdf_status rdf_take_columns(const rdf_array* cols, int32_t ncols, int64_t nchunks, const rdf_array* indices, rdf_out* outs);
+/* The same over a pinned frame -> a one-batch frame of indices->length rows (indices: host or device memory). */
+rdf_status rdf_take_frame(rdf_frame* frame, const rdf_array* indices, rdf_frame** out);
+/* DataFrame::sort (src/dataframe.rs:194-222): lexsort_to_indices over columns sort_cols[0..nsort) of the frame (criterion 0
+ * most significant, rdf_sort_to_indices' rules), then the take of every column by that order in one pass.  out_indices
+ * (optional, RDF_U32, device memory) receives the row order; out (optional) the sorted one-batch frame. */
+rdf_status rdf_sort_frame(rdf_frame* frame, const int32_t* sort_cols, int32_t nsort, const rdf_sort_options* opts,
+                          rdf_out* out_indices, rdf_frame** out);
+/* rdf_groupby_agg over columns of a frame: grouping columns key_cols[0..nkeys), ONE aggregation of column value_col
+ * (ignored for RDF_AGG_COUNT).  -> a one-batch frame of nkeys + 2 columns: the group keys, the aggregate (rdf_groupby_agg's
+ * output type), the counts (Int64).  One grouping column runs on the frame's own tables; several are packed first. */
+rdf_status rdf_groupby_agg_frame(rdf_frame* frame, const int32_t* key_cols, int32_t nkeys, int32_t value_col, int32_t agg,
+                                 int64_t max_groups, rdf_frame** out);
+
 /* ------------------------------------------------------------------ fused grouped aggregation */
 
 #define RDF_MAX_GROUP_VALUES 8

@@ -138,6 +138,16 @@ pub mod sys {
                                         value_roots: *const i32, nvalues: i32, frame: *mut rdf_frame, out: *mut rdf_group_result,
                                         group_rows: *mut i64) -> i32;
         pub fn rdf_predicate_frame(nodes: *const rdf_expr_node, nnodes: i32, root: i32, frame: *mut rdf_frame, mask: *mut rdf_out) -> i32;
+        // frame in, frame out: DataFrame::filter / take / sort (src/dataframe.rs:178-222) and GroupAggregate without walking the batch list
+        pub fn rdf_frame_info(frame: *mut rdf_frame, ncols: *mut i32, nchunks: *mut i64, rows: *mut i64) -> i32;
+        pub fn rdf_frame_column(frame: *mut rdf_frame, col: i32, chunks: *mut rdf_array) -> i32;
+        pub fn rdf_filter_frame(frame: *mut rdf_frame, nodes: *const rdf_expr_node, nnodes: i32, root: i32, out: *mut *mut rdf_frame) -> i32;
+        pub fn rdf_take_columns(cols: *const rdf_array, ncols: i32, nchunks: i64, indices: *const rdf_array, outs: *mut rdf_out) -> i32;
+        pub fn rdf_take_frame(frame: *mut rdf_frame, indices: *const rdf_array, out: *mut *mut rdf_frame) -> i32;
+        pub fn rdf_sort_frame(frame: *mut rdf_frame, sort_cols: *const i32, nsort: i32, opts: *const rdf_sort_options,
+                              out_indices: *mut rdf_out, out: *mut *mut rdf_frame) -> i32;
+        pub fn rdf_groupby_agg_frame(frame: *mut rdf_frame, key_cols: *const i32, nkeys: i32, value_col: i32, agg: i32,
+                                     max_groups: i64, out: *mut *mut rdf_frame) -> i32;
         // synthetic data, switches, introspection (bench / tests)
         pub fn rdf_fill_uniform_f64(dev_ptr: *mut f64, n: i64, seed: u64, column_id: u64, first_row: i64, lo: f64, hi: f64) -> i32;
         pub fn rdf_fill_uniform_i64(dev_ptr: *mut i64, n: i64, seed: u64, column_id: u64, first_row: i64, lo: i64, hi: i64) -> i32;
@@ -277,6 +287,36 @@ pub fn take_chunks<T: ArrowNumericType>(chunks: &[&PrimitiveArray<T>], indices: 
     let mut out = buf.as_out();
     status(unsafe { rdf_take(c.as_ptr(), c.len() as i64, &i, &mut out) })?;
     Ok(buf.finish(&out))
+}
+
+/// A DataFrame resident in HBM: the handle is pinned once and every operator returns a new handle (released in Drop).
+pub struct GpuFrame { handle: *mut rdf_frame }
+impl Drop for GpuFrame { fn drop(&mut self) { unsafe { rdf_frame_release(self.handle); } } }
+impl GpuFrame {
+    /// DataFrame::filter (src/dataframe.rs:178-189): predicate over every batch, every column compacted in one pass.
+    pub fn filter(&self, nodes: &[rdf_expr_node], root: i32) -> Result<GpuFrame, ArrowError> {
+        let mut out: *mut rdf_frame = std::ptr::null_mut();
+        status(unsafe { rdf_filter_frame(self.handle, nodes.as_ptr(), nodes.len() as i32, root, &mut out) })?;
+        Ok(GpuFrame { handle: out })
+    }
+    /// DataFrame::sort (src/dataframe.rs:194-222): lexsort_to_indices + Column::take of every column.
+    pub fn sort(&self, sort_cols: &[i32], opts: &[rdf_sort_options]) -> Result<GpuFrame, ArrowError> {
+        let mut out: *mut rdf_frame = std::ptr::null_mut();
+        status(unsafe { rdf_sort_frame(self.handle, sort_cols.as_ptr(), sort_cols.len() as i32, opts.as_ptr(), std::ptr::null_mut(), &mut out) })?;
+        Ok(GpuFrame { handle: out })
+    }
+    /// DataFrame::take (src/dataframe.rs:216-222).
+    pub fn take(&self, indices: &UInt32Array) -> Result<GpuFrame, ArrowError> {
+        let (i, mut out) = (view(indices), std::ptr::null_mut());
+        status(unsafe { rdf_take_frame(self.handle, &i, &mut out) })?;
+        Ok(GpuFrame { handle: out })
+    }
+    /// (columns, batches, rows); rdf_frame_column(handle, c, views) then gives the device views of a column.
+    pub fn shape(&self) -> (i32, i64, i64) {
+        let (mut c, mut b, mut r) = (0i32, 0i64, 0i64);
+        unsafe { rdf_frame_info(self.handle, &mut c, &mut b, &mut r) };
+        (c, b, r)
+    }
 }
 
 /// Transformation::GroupAggregate(groups, [aggregation]) — `Evaluate::evaluate` panics here today (src/evaluation.rs:73).

@@ -360,7 +360,72 @@ class Prepared:
         return iter(self.cols)
 
 
-class PinnedFrame:
+class Frame:
+    """A frame the library returned (rdf_filter_frame, rdf_take_frame, rdf_sort_frame, rdf_groupby_agg_frame): its buffers live
+    in HBM and belong to the handle.  Usable wherever a PinnedFrame is (Api.pipeline, the frame operators)."""
+
+    def __init__(self, api, handle, parents=()):
+        self.api = api
+        self.handle = handle
+        self.parents = parents      # frames whose buffers must outlive this one (none today: outputs are copies)
+
+    def info(self):
+        nc, nch, rows = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        fn = self.api._fn("frame_info")
+        fn.restype = C.c_int
+        self.api._check(fn(self.handle, C.byref(nc), C.byref(nch), C.byref(rows)))
+        return nc.value, nch.value, rows.value
+
+    def column(self, c: int) -> List["DeviceArray"]:
+        """The column's batches as DeviceArrays borrowed from the frame."""
+        _, nch, _ = self.info()
+        arr = (rdf_array * max(1, nch))()
+        fn = self.api._fn("frame_column")
+        fn.restype = C.c_int
+        self.api._check(fn(self.handle, C.c_int32(c), arr))
+        return [DeviceArray(arr[i].values, arr[i].validity, arr[i].offset, arr[i].length, arr[i].dtype, arr[i].null_count, keep=self) for i in range(nch)]
+
+    def column_to_host(self, c: int) -> List["HostArray"]:
+        """Download a column batch by batch (tests)."""
+        out = []
+        d2h = self.api._fn("copy_d2h")
+        d2h.restype = C.c_int
+        d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        for a in self.column(c):
+            es = np.dtype(NP_OF[a.dtype]).itemsize
+            vals = np.zeros(max(a.length, 1), dtype=NP_OF[a.dtype])
+            if a.length:
+                self.api._check(d2h(vals.ctypes.data, a.values_ptr + a.offset * es, a.length * es))
+            valid = None
+            if a.validity_ptr:
+                assert a.offset % 8 == 0
+                valid = np.zeros((a.length + 7) // 8 + 8, dtype=np.uint8)
+                if a.length:
+                    self.api._check(d2h(valid.ctypes.data, a.validity_ptr + a.offset // 8, (a.length + 7) // 8))
+            out.append(HostArray(vals[:a.length] if a.length else vals[:0], valid, 0, a.length, a.dtype, -1))
+        return out
+
+    def release(self):
+        if self.handle is not None and self.handle.value:
+            fn = self.api._fn("frame_release")
+            fn.restype = C.c_int
+            fn(self.handle)
+        self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:   # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class PinnedFrame(Frame):
     """rdf_frame_pin: device-resident columns validated once, their descriptors and tile tables kept in HBM; hand it to
     Api.pipeline in place of the column lists.  The arrays are kept alive by the handle; release() (or the context
     manager) frees the device tables."""
@@ -542,7 +607,7 @@ class Api:
 
     # ---- expressions
     def predicate(self, expr: Expr, root: int, cols: Sequence[Sequence], outs=None):
-        frame = cols if isinstance(cols, PinnedFrame) else None
+        frame = cols if isinstance(cols, Frame) else None
         if frame is not None:
             cols = frame.cols
         nchunks = len(cols[0]) if cols else 0
@@ -609,6 +674,50 @@ class Api:
         idx = (rdf_array * 1)(indices.c_struct())
         self._check(self._fn("take")(_flat([chunks], n), C.c_int64(n), idx, carr))
         return self._finish([out], carr)[0]
+
+    def take_columns(self, cols: Sequence[Sequence], indices, outs=None):
+        """DataFrame::take's per-column loop as one gather pass: cols[c][chunk] -> one array per column."""
+        nchunks = len(cols[0])
+        if outs is None:
+            outs = [HostArray.empty_out(col[0].dtype, indices.length, indices.validity is not None or any(c.validity is not None for c in col)) for col in cols]
+        carr = (rdf_out * len(cols))(*[o.out_struct() for o in outs])
+        idx = (rdf_array * 1)(indices.c_struct())
+        fn = self._fn("take_columns")
+        fn.restype = C.c_int
+        self._check(fn(_flat(cols, nchunks), C.c_int32(len(cols)), C.c_int64(nchunks), idx, carr))
+        return self._finish(outs, carr)
+
+    # ---- frame-level operators (a frame in, a frame out; nothing per batch on the host)
+    def _new_frame(self, fn_name, *args):
+        h = C.c_void_p(0)
+        fn = self._fn(fn_name)
+        fn.restype = C.c_int
+        self._check(fn(*args, C.byref(h)))
+        return Frame(self, h)
+
+    def filter_frame(self, frame, expr: "Expr", root: int) -> "Frame":
+        return self._new_frame("filter_frame", frame.handle, expr.c_array(), C.c_int32(len(expr.nodes)), C.c_int32(root))
+
+    def take_frame(self, frame, indices) -> "Frame":
+        return self._new_frame("take_frame", frame.handle, (rdf_array * 1)(indices.c_struct()))
+
+    def sort_frame(self, frame, sort_cols: Sequence[int], descending: Sequence[bool], out_indices=None, want_frame=True):
+        """-> (sorted frame or None, out_indices)."""
+        sc = (C.c_int32 * len(sort_cols))(*sort_cols)
+        opts = (rdf_sort_options * len(sort_cols))(*[rdf_sort_options(int(d), 0) for d in descending])
+        carr = (rdf_out * 1)(out_indices.out_struct()) if out_indices is not None else None
+        h = C.c_void_p(0)
+        fn = self._fn("sort_frame")
+        fn.restype = C.c_int
+        self._check(fn(frame.handle, sc, C.c_int32(len(sort_cols)), opts, carr, C.byref(h) if want_frame else None))
+        if out_indices is not None:
+            out_indices.length = carr[0].length
+        return (Frame(self, h) if want_frame else None), out_indices
+
+    def groupby_agg_frame(self, frame, key_cols: Sequence[int], value_col: int, agg, max_groups: int) -> "Frame":
+        code = self.AGGS[agg] if isinstance(agg, str) else int(agg)
+        kc = (C.c_int32 * len(key_cols))(*key_cols)
+        return self._new_frame("groupby_agg_frame", frame.handle, kc, C.c_int32(len(key_cols)), C.c_int32(value_col), C.c_int32(code), C.c_int64(max_groups))
 
     # ---- sort (DataFrame::sort -> lexsort_to_indices)
     def sort_to_indices(self, cols: Sequence[Sequence], descending: Sequence[bool], out=None):
@@ -824,14 +933,14 @@ class Api:
     def group_pipeline(self, expr: Expr, cols: Sequence[Sequence], value_roots: Sequence[int], group_root: int, ngroups: int,
                        filter_root: int = -1):
         """-> (res, rows): res[v][g] = (sum, count) of value v in group g (g == ngroups: the NULL group), rows[g] = count(*)."""
-        nchunks = 0 if isinstance(cols, PinnedFrame) or not cols else len(cols[0])
+        nchunks = 0 if isinstance(cols, Frame) or not cols else len(cols[0])
         nodes = expr.c_array()
         nv = len(value_roots)
         S = ngroups + 1
         out = (rdf_group_result * max(1, nv * S))()
         rows = (C.c_int64 * max(1, S))()
         roots = (C.c_int32 * max(1, nv))(*value_roots)
-        if isinstance(cols, PinnedFrame):   # rdf_group_pipeline_frame
+        if isinstance(cols, Frame):   # rdf_group_pipeline_frame
             fn = self._fn("group_pipeline_frame")
             fn.restype = C.c_int
             self._check(fn(nodes, C.c_int32(len(expr.nodes)), C.c_int32(filter_root), C.c_int32(group_root), C.c_int32(ngroups),
@@ -855,7 +964,7 @@ class Api:
         nodes = expr.c_array()
         prog = rdf_program(C.cast(nodes, C.POINTER(rdf_expr_node)), len(expr.nodes), filter_root, len(value_roots),
                            (C.c_int32 * MAX_VALUES)(*(list(value_roots) + [0] * (MAX_VALUES - len(value_roots)))), sink)
-        if isinstance(cols, PinnedFrame):   # rdf_pipeline_frame: descriptors validated and kept on the device once
+        if isinstance(cols, Frame):   # rdf_pipeline_frame: descriptors validated and kept on the device once
             def call(carr, aggs):
                 return self._fn("pipeline_frame")(C.byref(prog), cols.handle, carr, aggs)
         else:

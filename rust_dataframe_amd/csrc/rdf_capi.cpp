@@ -59,6 +59,10 @@ struct Ctx {
     bool   timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
+    // buffers of released frames, kept for the next frame-level operator (size -> pointer): the outputs of
+    // rdf_filter_frame / rdf_take_frame / ... are GBs, and a hipMalloc + hipFree pair per call costs more than the kernels
+    std::multimap<size_t, void*> pool_free;
+    size_t pool_cached = 0;
     ~Ctx();
 };
 
@@ -74,6 +78,7 @@ Ctx::~Ctx() {
     for (void* p : arena.overflow) (void)hipFree(p);
     if (arena.base) (void)hipFree(arena.base);
     if (pinned) (void)hipHostFree(pinned);
+    for (auto& kv : pool_free) (void)hipFree(kv.second);
     for (auto& ev : events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (own_stream) (void)hipStreamDestroy(own_stream);
     ready = false;
@@ -169,6 +174,41 @@ rdf_status pinned_reserve(size_t bytes) {
     c.pinned = (char*)p;
     c.pinned_cap = want;
     return RDF_OK;
+}
+
+// ---- pool: device buffers owned by frames ----
+constexpr size_t kPoolGranule = (size_t)2 << 20;
+constexpr size_t kPoolMaxCached = (size_t)96 << 30;   // of 288 GB
+rdf_status pool_alloc(size_t bytes, void** out, size_t* got) {
+    Ctx& c = g_ctx;
+    const size_t gran = bytes < ((size_t)1 << 20) ? (size_t)4096 : kPoolGranule;   // descriptor tables of small frames stay small
+    const size_t want = (bytes + 256 + gran - 1) / gran * gran;
+    auto it = c.pool_free.lower_bound(want);
+    if (it != c.pool_free.end() && it->first <= want + want / 4 + gran) {
+        *out = it->second; *got = it->first;
+        c.pool_cached -= it->first;
+        c.pool_free.erase(it);
+        return RDF_OK;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess && !c.pool_free.empty()) {   // give the cache back and retry
+        if (c.stream) (void)hipStreamSynchronize(c.stream);
+        for (auto& kv : c.pool_free) (void)hipFree(kv.second);
+        c.pool_free.clear();
+        c.pool_cached = 0;
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) return fail(RDF_MEMORY_ERROR, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    *out = p; *got = want;
+    return RDF_OK;
+}
+void pool_release(void* p, size_t bytes) {
+    Ctx& c = g_ctx;
+    if (!p) return;
+    if (c.pool_cached + bytes > kPoolMaxCached) { (void)hipFree(p); return; }
+    c.pool_free.emplace(bytes, p);
+    c.pool_cached += bytes;
 }
 
 // ---- kernel timing ----
@@ -904,6 +944,12 @@ struct ProgramSpec {
     rdf_group_result* gout = nullptr;
     int64_t* grows = nullptr;
     bool casts_always_fit = false;   // internal programs whose narrowing cast cannot fail (rdf_hour: 0..23 into Int32): no output bitmap needed for it
+    // SINK_STORE into buffers a frame owns (frame-level operators): the outputs' descriptors are a DEVICE table laid out
+    // [nvalues * nchunks], 16-byte aligned values / 8-byte aligned bitmaps per chunk, every chunk with room for its batch;
+    // no rdf_out list is walked, lengths / null counts are not reported.  frame_out0 = chunk 0's descriptors (nchunks == 1).
+    const DevOutChunk* frame_outs = nullptr;
+    DevOutChunk frame_out0[kMaxValues] = {};
+    int frame_out_dtype[kMaxValues] = {0, 0, 0, 0};
 };
 constexpr int RDF_SINK_GROUP = 2;
 
@@ -952,8 +998,13 @@ struct rdf_frame {
     int device = 0;
     int ncols = 0;
     int64_t nchunks = 0, total_rows = 0;
-    int col_dtype[kMaxCols];
-    bool col_aligned16[kMaxCols];            // every non-empty chunk of the column starts on a 16-byte boundary
+    int col_dtype[kMaxFrameCols];
+    bool col_aligned16[kMaxFrameCols];       // every non-empty chunk of the column starts on a 16-byte boundary
+    bool col_nullable[kMaxFrameCols];        // some chunk of the column carries a validity bitmap
+    bool host_valid = true;                  // clen / dev / chunk_nullable below mirror the device tables (frames built by an operator
+                                             // fill them on first need: frame_host)
+    bool owned = false;                      // the column buffers belong to the frame (outputs of frame-level operators)
+    int64_t uniform_len = 0;                 // > 0: every chunk but the last holds this many rows (the readers' batches)
     std::vector<int64_t> clen;
     std::vector<DevChunkCol> dev;            // [ncols * nchunks]
     std::vector<uint8_t> chunk_nullable;     // [nchunks]: some column of the batch carries a validity bitmap
@@ -963,6 +1014,14 @@ struct rdf_frame {
     std::map<int, Tiles> tiles;              // rows per tile -> prefix table
     std::map<std::vector<int>, DevChunkCol*> col_tabs;   // canonical column order of a specialised program -> descriptor table
     std::vector<void*> allocs;
+    int64_t* d_row_start = nullptr;          // [nchunks + 1] prefix of the batch lengths (take / sort: row -> chunk)
+    // rdf_filter_frame: the predicate's mask lives in the frame (bit-packed, batch c at bit mask_pos[c], 64-bit aligned)
+    uint8_t* mask_values = nullptr;
+    uint8_t* mask_validity = nullptr;
+    DevOutChunk* d_mask_outs = nullptr;
+    DevChunkCol* d_mask_cols = nullptr;
+    DevOutChunk mask_out0 = {nullptr, nullptr};
+    std::vector<std::pair<void*, size_t>> pooled;   // buffers taken from the per-thread pool, returned at release
 };
 
 namespace {
@@ -1019,7 +1078,9 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     int32_t mem = fc ? RDF_MEM_DEVICE : -1;
     if (!fc) RDF_TRY(check_mem(cols, (int64_t)ncols * nchunks, &mem));
     if (mem < 0) mem = ps.sink == RDF_SINK_STORE && outs && nchunks > 0 ? outs[0].mem : RDF_MEM_HOST;
-    if (ps.sink == RDF_SINK_STORE && nchunks > 0) {
+    const bool frame_store = ps.sink == RDF_SINK_STORE && ps.frame_outs != nullptr;
+    if (frame_store && !fc) return fail(RDF_INVALID_ARGUMENT, "frame-owned outputs need a frame");
+    if (ps.sink == RDF_SINK_STORE && nchunks > 0 && !frame_store) {
         if (!outs) return fail(RDF_INVALID_ARGUMENT, "outs is null");
         RDF_TRY(check_out_mem(outs, (int64_t)ps.nvalues * nchunks, mem));
     }
@@ -1085,7 +1146,10 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     if (ps.casts_always_fit) cc.lossy_cast = false;
 
     // output validation (SINK_STORE)
-    if (ps.sink == RDF_SINK_STORE) {
+    if (frame_store) {
+        for (int v = 0; v < ps.nvalues; ++v)
+            if (ps.frame_out_dtype[v] != value_dtype[v]) return fail(RDF_INVALID_ARGUMENT, "output dtype %d != expression dtype %d", ps.frame_out_dtype[v], value_dtype[v]);
+    } else if (ps.sink == RDF_SINK_STORE) {
         for (int v = 0; v < ps.nvalues; ++v)
             for (int64_t c = 0; c < nchunks; ++c) {
                 rdf_out& o = outs[(int64_t)v * nchunks + c];
@@ -1101,6 +1165,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
 
     // nothing to launch
     if (total_rows == 0) {
+        if (frame_store) return RDF_OK;
         if (ps.sink == RDF_SINK_STORE) {
             for (int64_t i = 0; i < (int64_t)ps.nvalues * nchunks; ++i) { outs[i].length = 0; outs[i].null_count = 0; }
         } else if (grouped) {
@@ -1138,7 +1203,9 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     Region outr;
     std::vector<DevOutChunk> dev_outs;
     std::vector<int> out_val_item, out_vld_item;
-    if (ps.sink == RDF_SINK_STORE) {
+    if (frame_store) {   // descriptors live on the device; chunk 0's are mirrored for the one-chunk kernels
+        if (nchunks == 1) { dev_outs.resize((size_t)ps.nvalues); for (int v = 0; v < ps.nvalues; ++v) dev_outs[(size_t)v] = ps.frame_out0[v]; }
+    } else if (ps.sink == RDF_SINK_STORE) {
         dev_outs.resize((size_t)ps.nvalues * nchunks);
         if (mem == RDF_MEM_HOST) {
             out_val_item.assign(dev_outs.size(), -1);
@@ -1211,6 +1278,11 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             for (int k = 0; k < ncols; ++k) ea.inline_cols[k] = in_dev[(size_t)k];
             for (int v = 0; v < ps.nvalues && ps.sink == RDF_SINK_STORE; ++v) ea.inline_outs[v] = dev_outs[(size_t)v];
             ea.inline_len = clen[0];
+        } else if (fc && frame_store) {
+            ea.cols = fc->d_cols;
+            ea.chunk_tile_start = eval_tiles->d_start;
+            ea.chunk_len = fc->d_clen;
+            ea.outs = const_cast<DevOutChunk*>(ps.frame_outs);
         } else if (fc) {   // the frame's own tables; only the outputs' descriptors are per call
             ea.cols = fc->d_cols;
             ea.chunk_tile_start = eval_tiles->d_start;
@@ -1269,7 +1341,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
                 if (clen[(size_t)c] > 0 && ((uintptr_t)((const char*)d.values + d.offset * es) & amask) != 0) { use_spec = false; break; }
             }
         }
-        if (ps.sink == RDF_SINK_STORE)
+        if (ps.sink == RDF_SINK_STORE && !frame_store)
             for (int64_t c = 0; c < nchunks && use_spec; ++c)
                 if (clen[(size_t)c] > 0 && (((uintptr_t)dev_outs[(size_t)c].values & 15) != 0 || ((uintptr_t)dev_outs[(size_t)c].validity & 7) != 0)) use_spec = false;
     }
@@ -1309,7 +1381,8 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             sa.cols_tab = tab;
             sa.chunk_tile_start = spec_tiles->d_start;
             sa.chunk_len = fc->d_clen;
-            if (ps.sink == RDF_SINK_STORE) {   // the outputs' descriptors are per call
+            if (frame_store) sa.outs_tab = ps.frame_outs;
+            else if (ps.sink == RDF_SINK_STORE) {   // the outputs' descriptors are per call
                 const size_t o_o = stb.reserve(sizeof(DevOutChunk) * ((size_t)nchunks + 1));
                 RDF_TRY(stb.bind(pin_off));
                 memcpy(stb.at<char>(o_o), dev_outs.data(), sizeof(DevOutChunk) * (size_t)nchunks);
@@ -1488,6 +1561,15 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         if (use_spec) { ctx.last_kernel = "spec_kernel<" + sp.sig + ">"; HIP_TRY(launch_spec(sp.sig.c_str(), sa, grid, ctx.stream)); }
         else { ctx.last_kernel = "eval_kernel<STORE>"; HIP_TRY(launch_eval(ea, SINK_STORE, cc.feat(), grid, ctx.stream)); }
         kt.stop();
+    }
+    if (frame_store) {   // flags only: lengths are the frame's batch lengths, null counts stay on the device
+        RDF_TRY(pinned_reserve(pin_off + 64));
+        HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, scratch, 16, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        uint32_t fl;
+        memcpy(&fl, ctx.pinned + pin_off, 4);
+        if (fl & 1u) return fail(RDF_DIVIDE_BY_ZERO, "Divide by zero error");
+        return RDF_OK;
     }
     RDF_TRY(pinned_reserve(pin_off + 64 + n_nc * 8 + outr.small_bytes + 256));
     char* pin = ctx.pinned + pin_off;
@@ -1746,7 +1828,7 @@ rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t 
 rdf_status rdf_frame_pin(const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_frame** out) {
     if (!out) return fail(RDF_INVALID_ARGUMENT, "frame_pin: null output pointer");
     *out = nullptr;
-    if (!cols || ncols < 1 || ncols > kMaxCols || nchunks < 1) return fail(RDF_INVALID_ARGUMENT, "frame_pin: 1..%d columns of at least one chunk", kMaxCols);
+    if (!cols || ncols < 1 || ncols > kMaxFrameCols || nchunks < 1) return fail(RDF_INVALID_ARGUMENT, "frame_pin: 1..%d columns of at least one chunk", kMaxFrameCols);
     int32_t mem = -1;
     RDF_TRY(check_mem(cols, (int64_t)ncols * nchunks, &mem));
     if (mem != RDF_MEM_DEVICE) return fail(RDF_INVALID_ARGUMENT, "frame_pin: device-resident columns only (host buffers are staged per call)");
@@ -1762,6 +1844,7 @@ rdf_status rdf_frame_pin(const rdf_array* cols, int32_t ncols, int64_t nchunks, 
         const int dt = cols[(int64_t)k * nchunks].dtype;
         if (!(is_numeric(dt) || dt == RDF_BOOL)) return fail(RDF_INVALID_ARGUMENT, "column %d: unsupported dtype %d", k, dt);
         f->col_dtype[k] = dt;
+        f->col_nullable[k] = false;
         f->col_aligned16[k] = dt != RDF_BOOL;
         const size_t es = dt == RDF_BOOL ? 1 : (size_t)dtype_size(dt);
         for (int64_t c = 0; c < nchunks; ++c) {
@@ -1769,11 +1852,14 @@ rdf_status rdf_frame_pin(const rdf_array* cols, int32_t ncols, int64_t nchunks, 
             if (a.dtype != dt) return fail(RDF_INVALID_ARGUMENT, "column %d: chunks differ in dtype", k);
             if (k == 0) { f->clen[(size_t)c] = a.length; f->total_rows += a.length; }
             else if (a.length != f->clen[(size_t)c]) return fail(RDF_COMPUTE_ERROR, "columns of a batch differ in length");
-            if (a.validity) f->chunk_nullable[(size_t)c] = 1;
+            if (a.validity) { f->chunk_nullable[(size_t)c] = 1; f->col_nullable[k] = true; }
             f->dev[(size_t)((int64_t)k * nchunks + c)] = DevChunkCol{a.values, a.validity, a.offset};
             if (a.length > 0 && (((uintptr_t)a.values + (uintptr_t)a.offset * es) & 15) != 0) f->col_aligned16[k] = false;
         }
     }
+    f->uniform_len = nchunks > 1 ? f->clen[0] : 0;
+    for (int64_t c = 0; c + 1 < nchunks && f->uniform_len > 0; ++c) if (f->clen[(size_t)c] != f->uniform_len) f->uniform_len = 0;
+    if (f->uniform_len > 0 && f->clen[(size_t)nchunks - 1] > f->uniform_len) f->uniform_len = 0;
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, f->dev.size() * sizeof(DevChunkCol) + 64);
     if (e != hipSuccess) return fail(RDF_MEMORY_ERROR, "frame_pin: hipMalloc: %s", hipGetErrorString(e));
@@ -1794,6 +1880,7 @@ rdf_status rdf_frame_release(rdf_frame* frame) {
     if (!frame) return RDF_OK;
     if (g_ctx.ready && g_ctx.stream) (void)hipStreamSynchronize(g_ctx.stream);   // kernels of this thread may still read the tables
     for (void* q : frame->allocs) (void)hipFree(q);
+    for (auto& pb : frame->pooled) pool_release(pb.first, pb.second);
     delete frame;
     return RDF_OK;
 }
@@ -2569,44 +2656,13 @@ rdf_status sort_key_range(const uint64_t* d_stats, size_t pin_off, uint64_t* bia
 }
 }  // namespace
 
-rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nchunks, const rdf_sort_options* opts,
-                               rdf_out* out_indices) {
-    if (ncols < 1 || !cols) return fail(RDF_COMPUTE_ERROR, "Sort criteria cannot be empty");  // src/dataframe.rs:195-199
-    if (nchunks < 1 || !out_indices) return fail(RDF_INVALID_ARGUMENT, "sort: bad arguments");
-    int32_t mem = -1;
-    RDF_TRY(check_mem(cols, (int64_t)ncols * nchunks, &mem));
-    RDF_TRY(check_out_mem(out_indices, 1, mem));
-    if (out_indices->dtype != RDF_U32) return fail(RDF_INVALID_ARGUMENT, "sort: indices are UInt32");
-    std::vector<int64_t> row_start((size_t)nchunks + 1, 0);
-    for (int64_t c = 0; c < nchunks; ++c) row_start[(size_t)c + 1] = row_start[(size_t)c] + cols[c].length;
-    const int64_t n = row_start[(size_t)nchunks];
-    for (int k = 0; k < ncols; ++k)
-        for (int64_t c = 0; c < nchunks; ++c) {
-            const rdf_array& a = cols[(int64_t)k * nchunks + c];
-            if (!is_numeric(a.dtype) || a.dtype != cols[(int64_t)k * nchunks].dtype) return fail(RDF_INVALID_ARGUMENT, "sort: numeric columns of one dtype per column");
-            if (a.length != cols[c].length) return fail(RDF_COMPUTE_ERROR, "sort: columns of a batch differ in length");
-        }
-    if (n >= (int64_t)1 << 32) return fail(RDF_INVALID_ARGUMENT, "sort: UInt32 indices cap a column at 2^32-1 rows (src/table.rs:218)");
-    if (out_indices->capacity < n) return fail(RDF_MEMORY_ERROR, "output capacity too small");
-    if (n == 0) { out_indices->length = 0; out_indices->null_count = 0; return RDF_OK; }
-    RDF_TRY(ensure_ready());
+namespace {
+// The radix passes of DataFrame::sort over device-resident descriptor tables: d_chunks[k * nchunks + c] = chunk c of sort
+// column k (column 0 most significant), d_row_start = prefix of the batch lengths.  *idx_out = the sorted row order (u32,
+// arena memory, valid until the next arena_begin).  Shared by rdf_sort_to_indices and rdf_sort_frame.
+rdf_status sort_core(const DevChunkCol* d_chunks, const int64_t* d_row_start, int64_t nchunks, int64_t n, int ncols, const int* dts,
+                     const bool* nullable, const rdf_sort_options* opts, size_t pin_off, const uint32_t** idx_out) {
     Ctx& ctx = g_ctx;
-    arena_begin();
-    size_t pin_off = 0, used = 0;
-    InputStager in;
-    for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) in.add(&cols[i]);
-    RDF_TRY(in.finish(pin_off, &used));
-    pin_off += (used + 255) & ~(size_t)255;
-    TableBuilder tb;
-    const size_t o_ch = tb.reserve(sizeof(DevChunkCol) * in.dev.size());
-    const size_t o_rs = tb.reserve(sizeof(int64_t) * row_start.size());
-    RDF_TRY(tb.bind(pin_off));
-    memcpy(tb.at<char>(o_ch), in.dev.data(), sizeof(DevChunkCol) * in.dev.size());
-    memcpy(tb.at<char>(o_rs), row_start.data(), sizeof(int64_t) * row_start.size());
-    RDF_TRY(tb.alloc());
-    RDF_TRY(tb.upload(pin_off));
-    pin_off += (tb.size + 255) & ~(size_t)255;
-
     const int64_t ntiles = (n + kSortTile - 1) / kSortTile;
     void *pk0, *pk1, *pi0, *pi1, *pnf, *ph0, *ph1;
     RDF_TRY(arena_alloc((size_t)n * 8, &pk0));
@@ -2628,13 +2684,12 @@ rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
 
     KernelTimer kt;
     for (int k = ncols - 1; k >= 0; --k) {  // LSD over the sort columns: least significant criterion first
-        const int dt = cols[(int64_t)k * nchunks].dtype;
-        bool has_nulls = false;
-        for (int64_t c = 0; c < nchunks; ++c) has_nulls |= cols[(int64_t)k * nchunks + c].validity != nullptr;
+        const int dt = dts[k];
+        const bool has_nulls = nullable[k];
         SortKeyArgs ka;
         memset(&ka, 0, sizeof ka);
-        ka.chunks = tb.dev_at<DevChunkCol>(o_ch) + (size_t)k * (size_t)nchunks;
-        ka.chunk_row_start = tb.dev_at<int64_t>(o_rs);
+        ka.chunks = d_chunks + (size_t)k * (size_t)nchunks;
+        ka.chunk_row_start = d_row_start;
         ka.nchunks = nchunks;
         ka.n = n;
         ka.idx = idx_cur;
@@ -2676,6 +2731,59 @@ rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nch
     }
     kt.stop();
     ctx.last_kernel = "sort_scatter_kernel";
+    *idx_out = idx_cur;
+    return RDF_OK;
+}
+}  // namespace
+
+rdf_status rdf_sort_to_indices(const rdf_array* cols, int32_t ncols, int64_t nchunks, const rdf_sort_options* opts,
+                               rdf_out* out_indices) {
+    if (ncols < 1 || !cols) return fail(RDF_COMPUTE_ERROR, "Sort criteria cannot be empty");  // src/dataframe.rs:195-199
+    if (nchunks < 1 || !out_indices) return fail(RDF_INVALID_ARGUMENT, "sort: bad arguments");
+    int32_t mem = -1;
+    RDF_TRY(check_mem(cols, (int64_t)ncols * nchunks, &mem));
+    RDF_TRY(check_out_mem(out_indices, 1, mem));
+    if (out_indices->dtype != RDF_U32) return fail(RDF_INVALID_ARGUMENT, "sort: indices are UInt32");
+    std::vector<int64_t> row_start((size_t)nchunks + 1, 0);
+    for (int64_t c = 0; c < nchunks; ++c) row_start[(size_t)c + 1] = row_start[(size_t)c] + cols[c].length;
+    const int64_t n = row_start[(size_t)nchunks];
+    for (int k = 0; k < ncols; ++k)
+        for (int64_t c = 0; c < nchunks; ++c) {
+            const rdf_array& a = cols[(int64_t)k * nchunks + c];
+            if (!is_numeric(a.dtype) || a.dtype != cols[(int64_t)k * nchunks].dtype) return fail(RDF_INVALID_ARGUMENT, "sort: numeric columns of one dtype per column");
+            if (a.length != cols[c].length) return fail(RDF_COMPUTE_ERROR, "sort: columns of a batch differ in length");
+        }
+    if (n >= (int64_t)1 << 32) return fail(RDF_INVALID_ARGUMENT, "sort: UInt32 indices cap a column at 2^32-1 rows (src/table.rs:218)");
+    if (out_indices->capacity < n) return fail(RDF_MEMORY_ERROR, "output capacity too small");
+    if (n == 0) { out_indices->length = 0; out_indices->null_count = 0; return RDF_OK; }
+    RDF_TRY(ensure_ready());
+    Ctx& ctx = g_ctx;
+    arena_begin();
+    size_t pin_off = 0, used = 0;
+    InputStager in;
+    for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) in.add(&cols[i]);
+    RDF_TRY(in.finish(pin_off, &used));
+    pin_off += (used + 255) & ~(size_t)255;
+    TableBuilder tb;
+    const size_t o_ch = tb.reserve(sizeof(DevChunkCol) * in.dev.size());
+    const size_t o_rs = tb.reserve(sizeof(int64_t) * row_start.size());
+    RDF_TRY(tb.bind(pin_off));
+    memcpy(tb.at<char>(o_ch), in.dev.data(), sizeof(DevChunkCol) * in.dev.size());
+    memcpy(tb.at<char>(o_rs), row_start.data(), sizeof(int64_t) * row_start.size());
+    RDF_TRY(tb.alloc());
+    RDF_TRY(tb.upload(pin_off));
+    pin_off += (tb.size + 255) & ~(size_t)255;
+
+    int dts[kMaxFrameCols];
+    bool nullable[kMaxFrameCols];
+    if (ncols > kMaxFrameCols) return fail(RDF_INVALID_ARGUMENT, "sort: at most %d sort columns", kMaxFrameCols);
+    for (int k = 0; k < ncols; ++k) {
+        dts[k] = cols[(int64_t)k * nchunks].dtype;
+        nullable[k] = false;
+        for (int64_t c = 0; c < nchunks; ++c) nullable[k] |= cols[(int64_t)k * nchunks + c].validity != nullptr;
+    }
+    const uint32_t* idx_cur = nullptr;
+    RDF_TRY(sort_core(tb.dev_at<DevChunkCol>(o_ch), tb.dev_at<int64_t>(o_rs), nchunks, n, ncols, dts, nullable, opts, pin_off, &idx_cur));
     if (mem == RDF_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(out_indices->values, idx_cur, (size_t)n * 4, hipMemcpyDeviceToHost, ctx.stream));
         if (out_indices->validity) memset(out_indices->validity, 0xFF, (size_t)((n + 7) / 8));
@@ -3365,6 +3473,7 @@ rdf_status legacy_groupby_sum(const rdf_array* keys, const rdf_array* values, in
 }  // namespace
 
 #include "rdf_capi_groupby.inc"
+#include "rdf_capi_frame.inc"
 
 extern "C" {
 

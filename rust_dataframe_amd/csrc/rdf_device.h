@@ -14,6 +14,7 @@ constexpr int kFilterTile = 4096;    // rows per compaction tile (64 mask words,
 constexpr int kFilterTileSmall = 1024;   // the tile for frames in small RecordBatches (mean chunk length <= 2048 rows)
 constexpr int kMaxCode = 56;         // accumulator-machine instructions per program
 constexpr int kMaxCols = 8;          // columns referenced by one program
+constexpr int kMaxFrameCols = 64;    // columns of a pinned frame (programs run over frames of <= kMaxCols columns)
 constexpr int kPreCols = 4;          // columns preloaded into registers per tile
 constexpr int kMaxTmp = 4;           // LDS spill slots for bushy expression trees
 constexpr int kMaxValues = RDF_MAX_VALUES;
@@ -466,6 +467,38 @@ struct TakeArgs {
     uint32_t*          flags;            // bit 1: index out of bounds
     int32_t            esize, idx64;
 };
+
+// ---- frame-level operators (rdf_frameops.hip) ----
+struct FrameTabArgs {                      // descriptors of up to kMaxFilterCols columns whose chunk c starts pos[c] elements into its buffer
+    const int64_t* pos;                    // [nchunks]
+    int64_t        nchunks;
+    int32_t        ncols, pad;
+    char*          values[kMaxFilterCols];
+    uint8_t*       validity[kMaxFilterCols];   // nullptr: the column carries no bitmap
+    int32_t        esize[kMaxFilterCols];
+    DevOutChunk*   outs;                   // [ncols * nchunks] or nullptr
+    DevChunkCol*   cols;                   // [ncols * nchunks] or nullptr
+};
+struct TakeColsArgs {                      // one gather pass over up to kMaxFilterCols columns of a frame
+    const DevChunkCol* cols_tab;           // [ncols * nchunks] (nchunks > 1)
+    const int64_t*     chunk_row_start;    // [nchunks + 1]
+    int64_t            nchunks, total_rows;
+    int64_t            uniform_len;        // > 0: every chunk but the last holds this many rows (the readers' batches): lookup by arithmetic
+    DevChunkCol        indices;            // u32 or u64
+    int64_t            n;
+    int64_t*           out_null_counts;    // [ncols]
+    uint32_t*          flags;              // bit 1: index out of bounds
+    int32_t            ncols, idx64;
+    int32_t            esize[kMaxFilterCols];
+    int32_t            col_nullable[kMaxFilterCols];
+    DevChunkCol        cols0[kMaxFilterCols];   // nchunks == 1
+    DevOutChunk        outs[kMaxFilterCols];
+};
+hipError_t launch_frame_totals(const int64_t* tile_scan, const int64_t* chunk_tile_start, int64_t nchunks, int64_t* out_len, int64_t* padded, hipStream_t s);
+hipError_t launch_frame_tables(const FrameTabArgs& a, hipStream_t s);
+hipError_t launch_frame_mask_tables(const int64_t* pos, int64_t nchunks, uint8_t* values, uint8_t* validity, DevOutChunk* outs, DevChunkCol* cols, hipStream_t s);
+hipError_t launch_frame_pad(const int64_t* len, int64_t n, int64_t* padded, hipStream_t s);
+hipError_t launch_take_cols(const TakeColsArgs& a, hipStream_t s);
 
 // ArrayFunctions over List<primitive> (rdf_list.hip)
 enum : int32_t { LIST_CONTAINS = 0, LIST_POSITION = 1, LIST_MAX = 2, LIST_MIN = 3,

@@ -1,0 +1,212 @@
+// rdf_frameops.hip — device side of the frame-level operators (rdf_filter_frame / rdf_take_columns / rdf_take_frame /
+// rdf_sort_frame / rdf_groupby_agg_frame): what turns "a DataFrame holds its RecordBatches for its lifetime"
+// (src/dataframe.rs:30-48) into device-resident descriptor tables, so that an operator over a frame of a million
+// 1024-row batches (src/dataframe.rs:352) launches kernels and never walks the batch list on the host.
+//
+//   frame_totals_kernel    per-chunk kept rows of a compaction from the per-tile scan; 64-row padded lengths
+//   frame_tables_kernel    positions (scan of the padded lengths) -> output descriptors of every column and the
+//                          descriptor table of the frame the operator returns
+//   take_cols_kernel       DataFrame::take's per-column loop (src/dataframe.rs:216-222, 705-711) as ONE gather pass: the
+//                          index list is read once, the row -> chunk lookup is done once, and the M gathers of a row are
+//                          in flight together
+#include "rdf_common.hip.h"
+
+namespace rdfk {
+
+// kept rows of chunk c = scan[tile_start[c + 1]] - scan[tile_start[c]]; the returned frame keeps the batch boundaries
+// (ChunkedArray::filter, src/table.rs:97-107) and starts every batch on a 64-row boundary of the column's buffer, so
+// values stay 16-byte aligned and bitmaps 8-byte aligned whatever the keep counts are.
+__global__ __launch_bounds__(kBlock) void frame_totals_kernel(const int64_t* __restrict__ tile_scan, const int64_t* __restrict__ chunk_tile_start,
+                                                              int64_t nchunks, int64_t* __restrict__ out_len, int64_t* __restrict__ padded) {
+    for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * kBlock) {
+        const int64_t n = tile_scan[chunk_tile_start[c + 1]] - tile_scan[chunk_tile_start[c]];
+        out_len[c] = n;
+        padded[c] = (n + 63) & ~(int64_t)63;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void frame_tables_kernel(const FrameTabArgs a) {
+    for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < a.nchunks; c += (int64_t)gridDim.x * kBlock) {
+        const int64_t pos = a.pos[c];
+#pragma unroll 1
+        for (int k = 0; k < a.ncols; ++k) {
+            char* v = a.values[k] + pos * a.esize[k];
+            uint8_t* b = a.validity[k] ? a.validity[k] + (pos >> 3) : nullptr;
+            const int64_t i = (int64_t)k * a.nchunks + c;
+            if (a.outs) a.outs[i] = DevOutChunk{v, b};
+            if (a.cols) a.cols[i] = DevChunkCol{v, b, 0};
+        }
+    }
+}
+
+// Layout of a frame's OWN buffers when the batch lengths are known on the device only: one kernel writes the descriptors of
+// a column whose chunk c starts `pos[c]` elements into the buffer.  BOOL columns (bit-packed masks) use pos / 8 bytes.
+__global__ __launch_bounds__(kBlock) void frame_mask_tables_kernel(const int64_t* __restrict__ pos, int64_t nchunks, uint8_t* values, uint8_t* validity,
+                                                                  DevOutChunk* __restrict__ outs, DevChunkCol* __restrict__ cols) {
+    for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * kBlock) {
+        uint8_t* v = values + (pos[c] >> 3);
+        uint8_t* b = validity ? validity + (pos[c] >> 3) : nullptr;
+        outs[c] = DevOutChunk{v, b};
+        cols[c] = DevChunkCol{v, nullptr, 0};     // the value bit of a NULL predicate row is 0: compaction needs the values only
+    }
+}
+
+// padded[c] = round_up(len[c], 64)
+__global__ __launch_bounds__(kBlock) void frame_pad_kernel(const int64_t* __restrict__ len, int64_t n, int64_t* __restrict__ padded) {
+    for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < n; c += (int64_t)gridDim.x * kBlock) padded[c] = (len[c] + 63) & ~(int64_t)63;
+}
+
+// ------------------------------------------------------------------------------------------------
+// take over every column of a frame at once.  A wave owns kTakeU x 64 consecutive output rows per iteration: their indices
+// come in with kTakeU coalesced loads, each lane resolves its kTakeU rows to (chunk, element) ONCE, and then the
+// kTakeU x ncols gathers are issued back to back — a random 8-byte read costs a whole memory transaction whichever column
+// it is for, so what the per-column loop of the reference pays M times over (index read, lookup, latency) is paid once,
+// and the M transactions of a row overlap.
+constexpr int kTakeU = 4;
+
+template <typename T>
+__device__ __forceinline__ void take_store(const DevOutChunk& out, int64_t j, bool inr, T v) {
+    if (inr) __builtin_nontemporal_store(v, as_global_mut<T>(out.values) + j);
+}
+
+template <typename IDX>
+__global__ __launch_bounds__(kBlock) void take_cols_kernel(const TakeColsArgs a) {
+    const int lane = threadIdx.x & 63;
+    uint32_t err = 0;
+    uint32_t nulls[kMaxFilterCols];
+#pragma unroll
+    for (int k = 0; k < kMaxFilterCols; ++k) nulls[k] = 0;
+    const int64_t per_wave = (int64_t)kTakeU * 64;
+    const int64_t nw = (a.n + per_wave - 1) / per_wave;
+    const double inv = a.uniform_len > 0 ? 1.0 / (double)a.uniform_len : chunk_lookup_scale(a.chunk_row_start, a.nchunks);
+    for (int64_t wv = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); wv < nw; wv += (int64_t)gridDim.x * (kBlock / 64)) {
+        const int64_t j0 = wv * per_wave;
+        uint64_t ix[kTakeU];
+        bool valid[kTakeU], inr[kTakeU];
+        // indices (+ their validity words)
+#pragma unroll
+        for (int u = 0; u < kTakeU; ++u) {
+            const int64_t j = j0 + u * 64 + lane;
+            inr[u] = j < a.n;
+            ix[u] = inr[u] ? (uint64_t)__builtin_nontemporal_load(as_global<IDX>(a.indices.values) + a.indices.offset + j) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kTakeU; ++u) {
+            valid[u] = inr[u];
+            if (a.indices.validity) {
+                const uint64_t w = load_bits64(a.indices.validity, a.indices.offset + j0 + u * 64, clamp64(a.n - (j0 + u * 64)));
+                valid[u] = valid[u] && ((w >> lane) & 1);
+            }
+            if (valid[u] && ix[u] >= (uint64_t)a.total_rows) { err |= 2u; valid[u] = false; }
+        }
+        // row -> (chunk, element within the chunk): once for all columns
+        int64_t ch[kTakeU], el[kTakeU];
+#pragma unroll
+        for (int u = 0; u < kTakeU; ++u) {
+            ch[u] = 0; el[u] = (int64_t)ix[u];
+            if (a.nchunks > 1 && valid[u]) {
+                if (a.uniform_len > 0) {
+                    int64_t g = (int64_t)((double)ix[u] * inv);
+                    if (g * a.uniform_len > (int64_t)ix[u]) --g;
+                    else if ((g + 1) * a.uniform_len <= (int64_t)ix[u]) ++g;
+                    ch[u] = g; el[u] = (int64_t)ix[u] - g * a.uniform_len;
+                } else {
+                    ch[u] = find_chunk_row(a.chunk_row_start, a.nchunks, (int64_t)ix[u], inv);
+                    el[u] = (int64_t)ix[u] - a.chunk_row_start[ch[u]];
+                }
+            }
+        }
+#pragma unroll 1
+        for (int k = 0; k < a.ncols; ++k) {
+            const int es = a.esize[k];
+            uint64_t v[kTakeU];
+            bool vv[kTakeU];
+            int64_t e[kTakeU];
+            const uint8_t* vb[kTakeU];
+#pragma unroll
+            for (int u = 0; u < kTakeU; ++u) {
+                v[u] = 0; vv[u] = valid[u]; vb[u] = nullptr; e[u] = 0;
+                if (!valid[u]) continue;
+                DevChunkCol cc = a.cols0[k];
+                if (a.nchunks > 1) {
+                    const DevChunkCol* t = a.cols_tab + ((int64_t)k * a.nchunks + ch[u]);
+                    cc.values = t->values; cc.validity = t->validity; cc.offset = t->offset;
+                }
+                e[u] = cc.offset + el[u];
+                vb[u] = cc.validity;
+                switch (es) {
+                    case 8: v[u] = as_global<uint64_t>(cc.values)[e[u]]; break;
+                    case 4: v[u] = as_global<uint32_t>(cc.values)[e[u]]; break;
+                    case 2: v[u] = as_global<uint16_t>(cc.values)[e[u]]; break;
+                    default: v[u] = as_global<uint8_t>(cc.values)[e[u]]; break;
+                }
+            }
+            if (a.col_nullable[k]) {
+#pragma unroll
+                for (int u = 0; u < kTakeU; ++u)
+                    if (vv[u] && vb[u]) vv[u] = (as_global<uint8_t>(vb[u])[e[u] >> 3] >> (e[u] & 7)) & 1;
+            }
+            const DevOutChunk out = a.outs[k];
+#pragma unroll
+            for (int u = 0; u < kTakeU; ++u) {
+                const int64_t j = j0 + u * 64 + lane;
+                switch (es) {
+                    case 8: take_store<uint64_t>(out, j, inr[u], v[u]); break;
+                    case 4: take_store<uint32_t>(out, j, inr[u], (uint32_t)v[u]); break;
+                    case 2: take_store<uint16_t>(out, j, inr[u], (uint16_t)v[u]); break;
+                    default: take_store<uint8_t>(out, j, inr[u], (uint8_t)v[u]); break;
+                }
+                if (out.validity) {
+                    const uint64_t bal = __ballot(vv[u]);
+                    const uint64_t ib = __ballot(inr[u]);
+                    if (lane == 0 && ib) {
+                        as_global_mut<uint64_t>(out.validity)[(j0 >> 6) + u] = bal;
+                        nulls[k] += (uint32_t)__popcll(ib & ~bal);
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < kMaxFilterCols; ++k)
+            if (k < a.ncols && nulls[k]) atomicAdd((unsigned long long*)&a.out_null_counts[k], (unsigned long long)nulls[k]);
+    }
+    if (err) atomicOr(a.flags, err);
+}
+
+hipError_t launch_frame_totals(const int64_t* tile_scan, const int64_t* chunk_tile_start, int64_t nchunks, int64_t* out_len, int64_t* padded, hipStream_t s) {
+    if (nchunks <= 0) return hipSuccess;
+    const int64_t grid = std::min<int64_t>((nchunks + kBlock - 1) / kBlock, eval_grid_limit());
+    hipLaunchKernelGGL(frame_totals_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, tile_scan, chunk_tile_start, nchunks, out_len, padded);
+    return hipGetLastError();
+}
+hipError_t launch_frame_tables(const FrameTabArgs& a, hipStream_t s) {
+    if (a.nchunks <= 0) return hipSuccess;
+    const int64_t grid = std::min<int64_t>((a.nchunks + kBlock - 1) / kBlock, eval_grid_limit());
+    hipLaunchKernelGGL(frame_tables_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_frame_mask_tables(const int64_t* pos, int64_t nchunks, uint8_t* values, uint8_t* validity, DevOutChunk* outs, DevChunkCol* cols, hipStream_t s) {
+    if (nchunks <= 0) return hipSuccess;
+    const int64_t grid = std::min<int64_t>((nchunks + kBlock - 1) / kBlock, eval_grid_limit());
+    hipLaunchKernelGGL(frame_mask_tables_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, pos, nchunks, values, validity, outs, cols);
+    return hipGetLastError();
+}
+hipError_t launch_frame_pad(const int64_t* len, int64_t n, int64_t* padded, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int64_t grid = std::min<int64_t>((n + kBlock - 1) / kBlock, eval_grid_limit());
+    hipLaunchKernelGGL(frame_pad_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, len, n, padded);
+    return hipGetLastError();
+}
+hipError_t launch_take_cols(const TakeColsArgs& a, hipStream_t s) {
+    const int64_t nw = (a.n + (int64_t)kTakeU * 64 - 1) / ((int64_t)kTakeU * 64);
+    int64_t grid = (nw + (kBlock / 64) - 1) / (kBlock / 64);
+    if (grid > eval_grid_limit()) grid = eval_grid_limit();
+    if (grid <= 0) return hipSuccess;
+    if (a.idx64) hipLaunchKernelGGL((take_cols_kernel<uint64_t>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((take_cols_kernel<uint32_t>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace rdfk

@@ -1,0 +1,209 @@
+"""Frame-level operators (rdf_filter_frame / rdf_take_columns / rdf_take_frame / rdf_sort_frame / rdf_groupby_agg_frame) against
+the oracle's per-column statements of the same reference functions: DataFrame::filter (src/dataframe.rs:178-189) =
+BooleanFilter::eval_to_array + Column::filter per column; DataFrame::take / sort (:194-222) = lexsort_to_indices +
+Column::take per column; GroupAggregate (SQL semantics, parity unpinned by the reference).  Inputs live in HBM, a frame goes
+in and a frame comes out; the test downloads the result batch by batch and holds it to the oracle bit for bit."""
+import numpy as np
+import pytest
+
+from rust_dataframe_amd import _abi as A
+from util import assert_arrays_match, assert_chunks_match, make_chunks
+
+pytestmark = pytest.mark.gpu
+
+
+def to_device(cols):
+    """The same chunks in device memory (values and bitmaps keep their element / bit offsets) -> (device columns, keep-alive)."""
+    import torch
+    keep, dev = [], []
+    for col in cols:
+        dcol = []
+        for ch in col:
+            vt = torch.from_numpy(np.frombuffer(ch.values.tobytes() + b"\0" * 64, dtype=np.uint8).copy()).cuda()
+            bt = None
+            if ch.validity is not None:
+                bt = torch.from_numpy(np.frombuffer(ch.validity.tobytes() + b"\0" * 64, dtype=np.uint8).copy()).cuda()
+            keep += [vt, bt]
+            dcol.append(A.DeviceArray(vt.data_ptr(), bt.data_ptr() if bt is not None else None, ch.offset, ch.length, ch.dtype, -1, keep=(vt, bt)))
+        dev.append(dcol)
+    torch.cuda.synchronize()
+    return dev, keep
+
+
+def frame_columns(frame):
+    nc, _, _ = frame.info()
+    return [frame.column_to_host(c) for c in range(nc)]
+
+
+def match_unknown_nulls(got, exp, what):
+    """Frames report null counts as unknown: compare lengths, bitmaps and values."""
+    assert len(got) == len(exp), what
+    for i, (g, e) in enumerate(zip(got, exp)):
+        g.null_count = e.null_count if g.validity is not None else 0
+        if g.validity is None and e.validity is not None:
+            assert e.null_count == 0, f"{what} chunk {i}: bitmap missing"
+            e = A.HostArray(e.values, None, e.offset, e.length, e.dtype, 0)
+        elif g.validity is not None and e.validity is None:
+            assert g.valid_mask().all(), f"{what} chunk {i}"
+            g = A.HostArray(g.values, None, g.offset, g.length, g.dtype, 0)
+        assert_arrays_match(g, e, exact=True, what=f"{what} chunk {i}")
+
+
+LAYOUTS = [([1024] * 9 + [100], 0, 0.0), ([5000], 0, 0.1), ([4096, 0, 1000, 64], 0, 0.2), ([3000, 2000, 1], 3, 0.1), ([100] * 40, 0, 0.0)]
+
+
+@pytest.mark.parametrize("lens,off,nf", LAYOUTS)
+@pytest.mark.parametrize("dts", [[A.F64, A.I64, A.F32, A.I32], [A.F64, A.I16, A.U8, A.I64, A.F32], [A.F64]])
+def test_filter_frame_parity(gpu, ora, lens, off, nf, dts):
+    rng = np.random.default_rng(31 + len(lens) + len(dts))
+    host = [make_chunks(rng, dt, lens, nf if k % 2 == 0 else 0.0, off, "unit" if dt in (A.F64, A.F32) else "plain") for k, dt in enumerate(dts)]
+    dev, keep = to_device(host)
+    e = A.Expr()
+    for sel, root in [("half", e.op("gt", e.col(0), e.scalar(0.0))), ("few", e.op("gt", e.col(0), e.scalar(0.9))), ("none", e.op("gt", e.col(0), e.scalar(5.0))),
+                      ("all", e.op("le", e.col(0), e.scalar(5.0)))]:
+        mask = ora.predicate(e, root, host)
+        exp = ora.filter_columns(host, mask)
+        with A.PinnedFrame(gpu, dev) as frame:
+            out = gpu.filter_frame(frame, e, root)
+            nc, nch, rows = out.info()
+            assert (nc, nch) == (len(dts), len(lens)) and rows == sum(x.length for x in exp[0]), sel
+            got = frame_columns(out)
+            for k in range(len(dts)):
+                match_unknown_nulls(got[k], exp[k], f"{sel} lens={lens} column {k}")
+            # the returned frame is an ordinary frame: aggregate it, filter it again
+            agg = gpu.pipeline(e, out, [e.col(0)])[0]
+            ref = ora.pipeline(e, [exp[0]], [e.col(0)])[0]
+            assert agg.count == ref.count and abs(agg.sum - ref.sum) <= 1e-9 * max(1.0, abs(ref.sum)), sel
+            again = gpu.filter_frame(out, e, e.op("lt", e.col(0), e.scalar(0.95)))
+            m2 = ora.predicate(e, e.op("lt", e.col(0), e.scalar(0.95)), exp)
+            exp2 = ora.filter_columns(exp, m2)
+            got2 = frame_columns(again)
+            for k in range(len(dts)):
+                match_unknown_nulls(got2[k], exp2[k], f"{sel} twice column {k}")
+            again.release()
+            out.release()
+
+
+def test_filter_frame_errors(gpu):
+    rng = np.random.default_rng(5)
+    dev, keep = to_device([make_chunks(rng, A.F64, [1000, 24], 0.0, 0)])
+    e = A.Expr()
+    with A.PinnedFrame(gpu, dev) as frame:
+        with pytest.raises(A.RdfError):
+            gpu.filter_frame(frame, e, e.col(0))               # not boolean
+        with pytest.raises(A.RdfError):
+            gpu.filter_frame(frame, A.Expr(), 0)               # empty expression
+
+
+@pytest.mark.parametrize("lens,off,nf", [([5000], 0, 0.0), ([1024] * 5 + [77], 0, 0.2), ([700, 0, 1300, 64, 1], 5, 0.1)])
+@pytest.mark.parametrize("idt", [A.U32, A.U64])
+def test_take_columns_parity(gpu, ora, lens, off, nf, idt):
+    rng = np.random.default_rng(77 + len(lens))
+    dts = [A.F64, A.I64, A.I32, A.F32, A.I16, A.U8, A.U64, A.I8, A.U16, A.F64]     # ten columns: two gather launches
+    host = [make_chunks(rng, dt, lens, nf if k % 3 == 0 else 0.0, off) for k, dt in enumerate(dts)]
+    total = sum(lens)
+    for n, inull in [(0, 0.0), (1, 0.0), (63, 0.0), (1000, 0.3), (3 * total + 5, 0.0)]:
+        iv = rng.integers(0, total, n).astype(A.NP_OF[idt])
+        idx = A.HostArray.from_numpy(iv, valid=(rng.uniform(size=n) >= inull) if inull else None, dtype=idt, offset=3 if n > 10 else 0, rng=rng)
+        got = gpu.take_columns(host, idx)
+        for k in range(len(dts)):
+            exp = ora.take(host[k], idx)
+            assert_arrays_match(got[k], exp, exact=True, what=f"take_columns lens={lens} n={n} column {k}")
+            assert_arrays_match(gpu.take(host[k], idx), exp, exact=True, what=f"take lens={lens} n={n} column {k}")
+    bad = A.HostArray.from_numpy(np.array([0, total], dtype=A.NP_OF[idt]), dtype=idt)
+    with pytest.raises(A.RdfError):
+        gpu.take_columns(host, bad)
+
+
+@pytest.mark.parametrize("lens,nf", [([6000], 0.0), ([1024] * 6 + [300], 0.15), ([512, 3000, 17], 0.0)])
+def test_take_frame_and_sort_frame(gpu, ora, lens, nf):
+    import torch
+    rng = np.random.default_rng(13 + len(lens))
+    dts = [A.I64, A.F64, A.I32, A.F32]
+    host = [make_chunks(rng, dt, lens, nf if k in (0, 1) else 0.0, 0) for k, dt in enumerate(dts)]
+    host[2] = [A.HostArray.from_numpy((c.to_numpy() % 7).astype(np.int32), dtype=A.I32) for c in host[2]]     # many ties for the second criterion
+    dev, keep = to_device(host)
+    total = sum(lens)
+    with A.PinnedFrame(gpu, dev) as frame:
+        iv = rng.integers(0, total, 2 * total + 3).astype(np.uint32)
+        idx = A.HostArray.from_numpy(iv, valid=rng.uniform(size=len(iv)) >= 0.1, dtype=A.U32)
+        out = gpu.take_frame(frame, idx)
+        assert out.info() == (len(dts), 1, len(iv))
+        got = frame_columns(out)
+        for k in range(len(dts)):
+            match_unknown_nulls(got[k], [ora.take(host[k], idx)], f"take_frame column {k}")
+        out.release()
+        # indices already in HBM
+        it = torch.from_numpy(iv.copy()).cuda()
+        didx = A.DeviceArray(it.data_ptr(), None, 0, len(iv), A.U32, 0, keep=it)
+        out = gpu.take_frame(frame, didx)
+        got = frame_columns(out)
+        plain = A.HostArray.from_numpy(iv, dtype=A.U32)
+        for k in range(len(dts)):
+            match_unknown_nulls(got[k], [ora.take(host[k], plain)], f"take_frame (device indices) column {k}")
+        out.release()
+        with pytest.raises(A.RdfError):
+            gpu.take_frame(frame, A.HostArray.from_numpy(np.array([total], dtype=np.uint32), dtype=A.U32))
+        # DataFrame::sort: criteria (column 2 ascending, column 0 descending), then every column taken by the order
+        for sort_cols, desc in [([2, 0], [False, True]), ([1], [False]), ([0, 1, 2], [True, False, True])]:
+            order = ora.sort_to_indices([host[c] for c in sort_cols], desc)
+            ib = torch.zeros(total * 4 + 64, dtype=torch.uint8, device="cuda")
+            oi = A.DeviceArray(ib.data_ptr(), None, 0, total, A.U32, 0, keep=ib, capacity=total)
+            torch.cuda.synchronize()
+            sf, oi = gpu.sort_frame(frame, sort_cols, desc, out_indices=oi)
+            assert np.array_equal(ib.cpu().numpy()[:total * 4].view(np.uint32), order.to_numpy()), f"sort order {sort_cols}"
+            got = frame_columns(sf)
+            for k in range(len(dts)):
+                match_unknown_nulls(got[k], [ora.take(host[k], order)], f"sort_frame {sort_cols} column {k}")
+            # the sorted frame is an ordinary frame
+            e = A.Expr()
+            a = gpu.pipeline(e, sf, [e.col(1)])[0]
+            r = ora.pipeline(e, [host[1]], [e.col(1)])[0]
+            assert a.count == r.count and abs(a.sum - r.sum) <= 1e-9 * max(1.0, abs(r.sum))
+            sf.release()
+            only_idx, _ = gpu.sort_frame(frame, sort_cols, desc, out_indices=oi, want_frame=False)
+            assert only_idx is None
+
+
+@pytest.mark.parametrize("lens,knf,vnf", [([20000], 0.0, 0.0), ([1024] * 11 + [5], 0.1, 0.2), ([3000, 0, 4000], 0.0, 0.3)])
+def test_groupby_agg_frame(gpu, ora, lens, knf, vnf):
+    rng = np.random.default_rng(55 + len(lens))
+    total = sum(lens)
+    def keycol(card, dt, nf):
+        return [A.HostArray.from_numpy(rng.integers(-card // 2, card // 2, n).astype(A.NP_OF[dt]), valid=(rng.uniform(size=n) >= nf) if nf else None, dtype=dt) for n in lens]
+    host = [keycol(300, A.I64, knf), keycol(5, A.I32, 0.0), make_chunks(rng, A.F64, lens, vnf, 0, "unit"), make_chunks(rng, A.I64, lens, 0.0, 0)]
+    dev, keep = to_device(host)
+
+    def table(keys, vals, counts, vvalid=None):
+        rows = {}
+        for i in range(len(counts)):
+            rows[tuple(k[i] for k in keys)] = (vals[i] if vvalid is None or vvalid[i] else None, counts[i])
+        return rows
+
+    def host_table(ok, ov, oc):
+        keys = [[None if not m else v for v, m in zip(o.to_numpy().tolist(), o.valid_mask().tolist())] for o in ok]
+        return table(keys, ov.to_numpy().tolist(), oc.to_numpy().tolist(), ov.valid_mask().tolist())
+
+    with A.PinnedFrame(gpu, dev) as frame:
+        for key_cols, vcol, agg in [([0], 2, "sum"), ([0], 2, "min"), ([0], 2, "max"), ([0], -1, "count"), ([0], 3, "sum"), ([1, 0], 2, "sum"), ([0, 1], 3, "max")]:
+            exp = host_table(*ora.groupby_agg([host[c] for c in key_cols], host[vcol] if vcol >= 0 else None, agg, total + 2))
+            out = gpu.groupby_agg_frame(frame, key_cols, vcol, agg, 4096)
+            nc, nch, ng = out.info()
+            assert (nc, nch) == (len(key_cols) + 2, 1)
+            cols = [c[0] for c in frame_columns(out)]
+            got = host_table(cols[:len(key_cols)], cols[len(key_cols)], cols[len(key_cols) + 1])
+            assert ng == len(exp) == len(got), (key_cols, agg)
+            for k, (v, c) in exp.items():
+                gv, gc = got[k]
+                assert gc == c, (key_cols, agg, k)
+                if v is None or gv is None:
+                    assert v is None and gv is None, (key_cols, agg, k)
+                elif isinstance(v, float):
+                    assert abs(gv - v) <= 1e-9 * max(1.0, abs(v)), (key_cols, agg, k)
+                else:
+                    assert gv == v, (key_cols, agg, k)
+            out.release()
+        with pytest.raises(A.RdfError):
+            gpu.groupby_agg_frame(frame, [0], 2, "sum", 10)       # more than max_groups distinct keys
+        with pytest.raises(A.RdfError):
+            gpu.groupby_agg_frame(frame, [2], 3, "sum", 100)      # float grouping column
