@@ -158,7 +158,7 @@ def test_take_frame_and_sort_frame(gpu, ora, lens, nf):
             # the sorted frame is an ordinary frame
             e = A.Expr()
             a = gpu.pipeline(e, sf, [e.col(1)])[0]
-            r = ora.pipeline(e, [host[1]], [e.col(1)])[0]
+            r = ora.pipeline(e, host, [e.col(1)])[0]
             assert a.count == r.count and abs(a.sum - r.sum) <= 1e-9 * max(1.0, abs(r.sum))
             sf.release()
             only_idx, _ = gpu.sort_frame(frame, sort_cols, desc, out_indices=oi, want_frame=False)
