@@ -1001,6 +1001,8 @@ struct rdf_frame {
     int col_dtype[kMaxFrameCols];
     bool col_aligned16[kMaxFrameCols];       // every non-empty chunk of the column starts on a 16-byte boundary
     bool col_nullable[kMaxFrameCols];        // some chunk of the column carries a validity bitmap
+    bool col_contig[kMaxFrameCols];          // the column's batches are consecutive slices of ONE buffer (values and bitmap): row -> element
+                                             // needs no batch lookup (take / sort read it as one chunk through dev[k * nchunks])
     bool host_valid = true;                  // clen / dev / chunk_nullable below mirror the device tables (frames built by an operator
                                              // fill them on first need: frame_host)
     bool owned = false;                      // the column buffers belong to the frame (outputs of frame-level operators)
@@ -1856,6 +1858,22 @@ rdf_status rdf_frame_pin(const rdf_array* cols, int32_t ncols, int64_t nchunks, 
             f->dev[(size_t)((int64_t)k * nchunks + c)] = DevChunkCol{a.values, a.validity, a.offset};
             if (a.length > 0 && (((uintptr_t)a.values + (uintptr_t)a.offset * es) & 15) != 0) f->col_aligned16[k] = false;
         }
+    }
+    for (int k = 0; k < ncols; ++k) {   // zero-copy slices of one buffer (DataFrame::from_csv's batches, a sliced Table): contiguous columns
+        const size_t es = f->col_dtype[k] == RDF_BOOL ? 0 : (size_t)dtype_size(f->col_dtype[k]);
+        const DevChunkCol& d0 = f->dev[(size_t)((int64_t)k * nchunks)];
+        bool contig = es != 0;
+        int64_t row = 0;
+        for (int64_t c = 0; c < nchunks && contig; ++c) {
+            const DevChunkCol& d = f->dev[(size_t)((int64_t)k * nchunks + c)];
+            if (f->clen[(size_t)c] > 0) {
+                if ((uintptr_t)d.values + (uintptr_t)d.offset * es != (uintptr_t)d0.values + (uintptr_t)(d0.offset + row) * es) contig = false;
+                if ((d.validity == nullptr) != (d0.validity == nullptr)) contig = false;
+                else if (d.validity && (uintptr_t)d.validity * 8 + (uintptr_t)d.offset != (uintptr_t)d0.validity * 8 + (uintptr_t)(d0.offset + row)) contig = false;
+            }
+            row += f->clen[(size_t)c];
+        }
+        f->col_contig[k] = contig;
     }
     f->uniform_len = nchunks > 1 ? f->clen[0] : 0;
     for (int64_t c = 0; c + 1 < nchunks && f->uniform_len > 0; ++c) if (f->clen[(size_t)c] != f->uniform_len) f->uniform_len = 0;

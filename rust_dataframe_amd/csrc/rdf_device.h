@@ -489,9 +489,11 @@ struct TakeColsArgs {                      // one gather pass over up to kMaxFil
     int64_t*           out_null_counts;    // [ncols]
     uint32_t*          flags;              // bit 1: index out of bounds
     int32_t            ncols, idx64;
+    int32_t            need_lookup, pad;        // some column of this launch needs the row -> (batch, element) lookup
     int32_t            esize[kMaxFilterCols];
     int32_t            col_nullable[kMaxFilterCols];
-    DevChunkCol        cols0[kMaxFilterCols];   // nchunks == 1
+    int32_t            contig[kMaxFilterCols];  // the column is one run of memory (one chunk, or consecutive slices of one buffer): cols0[k], element = row
+    DevChunkCol        cols0[kMaxFilterCols];
     DevOutChunk        outs[kMaxFilterCols];
 };
 hipError_t launch_frame_totals(const int64_t* tile_scan, const int64_t* chunk_tile_start, int64_t nchunks, int64_t* out_len, int64_t* padded, hipStream_t s);

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void take_cols_kernel(const TakeColsArgs a)
 #pragma unroll
         for (int u = 0; u < kTakeU; ++u) {
             ch[u] = 0; el[u] = (int64_t)ix[u];
-            if (a.nchunks > 1 && valid[u]) {
+            if (a.need_lookup && valid[u]) {
                 if (a.uniform_len > 0) {
                     int64_t g = (int64_t)((double)ix[u] * inv);
                     if (g * a.uniform_len > (int64_t)ix[u]) --g;
@@ -128,11 +128,13 @@ __global__ __launch_bounds__(kBlock) void take_cols_kernel(const TakeColsArgs a)
                 v[u] = 0; vv[u] = valid[u]; vb[u] = nullptr; e[u] = 0;
                 if (!valid[u]) continue;
                 DevChunkCol cc = a.cols0[k];
-                if (a.nchunks > 1) {
+                int64_t within = (int64_t)ix[u];
+                if (!a.contig[k]) {
                     const DevChunkCol* t = a.cols_tab + ((int64_t)k * a.nchunks + ch[u]);
                     cc.values = t->values; cc.validity = t->validity; cc.offset = t->offset;
+                    within = el[u];
                 }
-                e[u] = cc.offset + el[u];
+                e[u] = cc.offset + within;
                 vb[u] = cc.validity;
                 switch (es) {
                     case 8: v[u] = as_global<uint64_t>(cc.values)[e[u]]; break;

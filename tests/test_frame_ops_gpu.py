@@ -30,6 +30,32 @@ def to_device(cols):
     return dev, keep
 
 
+def to_device_contiguous(cols):
+    """The same columns as consecutive slices of ONE device buffer each (what DataFrame::from_csv's zero-copy 1024-row batches of
+    one parsed column look like): chunk c starts at row r_c of the buffer, addressed as (pointer to row r_c - r_c % 8, offset r_c % 8)."""
+    import torch
+    keep, dev = [], []
+    for col in cols:
+        dt = col[0].dtype
+        es = np.dtype(A.NP_OF[dt]).itemsize
+        vals = np.concatenate([c.to_numpy() for c in col]) if col else np.zeros(0, A.NP_OF[dt])
+        nullable = any(c.validity is not None for c in col)
+        vt = torch.from_numpy(np.frombuffer(vals.tobytes() + b"\0" * 64, dtype=np.uint8).copy()).cuda()
+        bt = None
+        if nullable:
+            bits = np.concatenate([c.valid_mask() for c in col])
+            bt = torch.from_numpy(np.frombuffer(A.pack_bits(bits).tobytes() + b"\0" * 64, dtype=np.uint8).copy()).cuda()
+        keep += [vt, bt]
+        dcol, r = [], 0
+        for c in col:
+            a = r - r % 8
+            dcol.append(A.DeviceArray(vt.data_ptr() + a * es, bt.data_ptr() + a // 8 if bt is not None else None, r % 8, c.length, dt, -1, keep=(vt, bt)))
+            r += c.length
+        dev.append(dcol)
+    torch.cuda.synchronize()
+    return dev, keep
+
+
 def frame_columns(frame):
     nc, _, _ = frame.info()
     return [frame.column_to_host(c) for c in range(nc)]
@@ -115,14 +141,15 @@ def test_take_columns_parity(gpu, ora, lens, off, nf, idt):
         gpu.take_columns(host, bad)
 
 
+@pytest.mark.parametrize("contiguous", [False, True])
 @pytest.mark.parametrize("lens,nf", [([6000], 0.0), ([1024] * 6 + [300], 0.15), ([512, 3000, 17], 0.0)])
-def test_take_frame_and_sort_frame(gpu, ora, lens, nf):
+def test_take_frame_and_sort_frame(gpu, ora, lens, nf, contiguous):
     import torch
     rng = np.random.default_rng(13 + len(lens))
     dts = [A.I64, A.F64, A.I32, A.F32]
     host = [make_chunks(rng, dt, lens, nf if k in (0, 1) else 0.0, 0) for k, dt in enumerate(dts)]
     host[2] = [A.HostArray.from_numpy((c.to_numpy() % 7).astype(np.int32), dtype=A.I32) for c in host[2]]     # many ties for the second criterion
-    dev, keep = to_device(host)
+    dev, keep = to_device_contiguous(host) if contiguous else to_device(host)
     total = sum(lens)
     with A.PinnedFrame(gpu, dev) as frame:
         iv = rng.integers(0, total, 2 * total + 3).astype(np.uint32)
