@@ -502,7 +502,8 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * 0 = one table in HBM),
  * "gb_debug" (1 / 2: ablations of the aggregate / scatter pass, results invalid; 3: force the skew variant),
  * "filter_tile" (0: compaction tile from the mean chunk length; 1024 / 4096 force one), "filter_one" (one-chunk
- * compaction kernel with kernel-argument descriptors, default on). */
+ * compaction kernel with kernel-argument descriptors, default on), "take_rows" (rdf_take_frame / rdf_sort_frame: 1 = gather
+ * interleaved row records when the index list is long and the frame wide, default; 0 = always column by column; 2 = always records). */
 rdf_status rdf_set_option(const char* name, int64_t value);
 /* Number of program shapes with a specialised kernel. */
 int32_t    rdf_spec_catalog_size(void);

@@ -496,6 +496,24 @@ struct TakeColsArgs {                      // one gather pass over up to kMaxFil
     DevChunkCol        cols0[kMaxFilterCols];
     DevOutChunk        outs[kMaxFilterCols];
 };
+constexpr int kMaxRowSlots = 16;            // 8-byte slots of a row record (<= one 128-byte line)
+struct TakeRowsArgs {                      // take through interleaved row records (rows_pack_kernel -> rows_gather_kernel)
+    const DevChunkCol* cols_tab;           // [ncols * nchunks]
+    const int64_t*     chunk_row_start;
+    int64_t            nchunks, total_rows, uniform_len;
+    DevChunkCol        indices;
+    int64_t            n;
+    uint64_t*          recs;               // [total_rows * nslot]
+    int64_t*           out_null_counts;    // [ncols]
+    uint32_t*          flags;
+    int32_t            ncols, idx64, need_lookup, nslot;
+    int32_t            flag_slot, pad;     // slot of the validity flags (bit k = column k valid) or -1
+    int32_t            esize[kMaxRowSlots];
+    int32_t            contig[kMaxRowSlots];
+    DevChunkCol        cols0[kMaxRowSlots];
+    DevOutChunk        outs[kMaxRowSlots];
+};
+hipError_t launch_take_rows(const TakeRowsArgs& a, hipStream_t s);
 hipError_t launch_frame_totals(const int64_t* tile_scan, const int64_t* chunk_tile_start, int64_t nchunks, int64_t* out_len, int64_t* padded, hipStream_t s);
 hipError_t launch_frame_tables(const FrameTabArgs& a, hipStream_t s);
 hipError_t launch_frame_mask_tables(const int64_t* pos, int64_t nchunks, uint8_t* values, uint8_t* validity, DevOutChunk* outs, DevChunkCol* cols, hipStream_t s);

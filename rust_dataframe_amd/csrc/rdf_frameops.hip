@@ -13,6 +13,8 @@
 
 namespace rdfk {
 
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+
 // kept rows of chunk c = scan[tile_start[c + 1]] - scan[tile_start[c]]; the returned frame keeps the batch boundaries
 // (ChunkedArray::filter, src/table.rs:97-107) and starts every batch on a 64-row boundary of the column's buffer, so
 // values stay 16-byte aligned and bitmaps 8-byte aligned whatever the keep counts are.
@@ -175,6 +177,146 @@ __global__ __launch_bounds__(kBlock) void take_cols_kernel(const TakeColsArgs a)
             if (k < a.ncols && nulls[k]) atomicAdd((unsigned long long*)&a.out_null_counts[k], (unsigned long long)nulls[k]);
     }
     if (err) atomicOr(a.flags, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// take through row records.  A random 8-byte read costs a whole 128-byte memory transaction (PMC: 140 B per gathered element,
+// profiles/r02_pmc_hbm_traffic_by_kernel.json), so gathering M columns by the same index list costs M transactions per row
+// however the loads are scheduled.  When the index list is long compared with the frame (DataFrame::sort and join take EVERY
+// row, src/dataframe.rs:216-222, 705-711) it is cheaper to first interleave the columns into row records of NSLOT 8-byte
+// slots (one streaming pass: M x 8 bytes read, one record written per row) and then gather RECORDS: one transaction per row
+// brings all M values, which leave as M coalesced column stores.  Validity bits of the row ride in one more slot.
+template <int NSLOT>
+__global__ __launch_bounds__(kBlock) void rows_pack_kernel(const TakeRowsArgs a) {
+    const double inv = a.uniform_len > 0 ? 1.0 / (double)a.uniform_len : chunk_lookup_scale(a.chunk_row_start, a.nchunks);
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < a.total_rows; r += (int64_t)gridDim.x * kBlock) {
+        int64_t ch = 0, el = r;
+        if (a.need_lookup) {
+            if (a.uniform_len > 0) {
+                int64_t g = (int64_t)((double)r * inv);
+                if (g * a.uniform_len > r) --g;
+                else if ((g + 1) * a.uniform_len <= r) ++g;
+                ch = g; el = r - g * a.uniform_len;
+            } else {
+                ch = find_chunk_row(a.chunk_row_start, a.nchunks, r, inv);
+                el = r - a.chunk_row_start[ch];
+            }
+        }
+        uint64_t rec[NSLOT];
+        uint64_t flags = 0;
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            rec[k] = 0;
+            if (k >= a.ncols) continue;
+            DevChunkCol cc = a.cols0[k];
+            int64_t within = r;
+            if (!a.contig[k]) {
+                const DevChunkCol* t = a.cols_tab + ((int64_t)k * a.nchunks + ch);
+                cc.values = t->values; cc.validity = t->validity; cc.offset = t->offset;
+                within = el;
+            }
+            const int64_t e = cc.offset + within;
+            switch (a.esize[k]) {
+                case 8: rec[k] = as_global<uint64_t>(cc.values)[e]; break;
+                case 4: rec[k] = as_global<uint32_t>(cc.values)[e]; break;
+                case 2: rec[k] = as_global<uint16_t>(cc.values)[e]; break;
+                default: rec[k] = as_global<uint8_t>(cc.values)[e]; break;
+            }
+            bool ok = true;
+            if (cc.validity) ok = (as_global<uint8_t>(cc.validity)[e >> 3] >> (e & 7)) & 1;
+            flags |= (uint64_t)ok << k;
+        }
+        if (a.flag_slot >= 0) {
+#pragma unroll
+            for (int k = 0; k < NSLOT; ++k) if (k == a.flag_slot) rec[k] = flags;
+        }
+        GlobalMutPtr<u64x2> dst = (GlobalMutPtr<u64x2>)(a.recs + r * NSLOT);
+#pragma unroll
+        for (int k = 0; k < NSLOT; k += 2) { u64x2 w; w[0] = rec[k]; w[1] = rec[k + 1]; __builtin_nontemporal_store(w, dst + k / 2); }
+    }
+}
+
+template <int NSLOT, typename IDX>
+__global__ __launch_bounds__(kBlock) void rows_gather_kernel(const TakeRowsArgs a) {
+    const int lane = threadIdx.x & 63;
+    uint32_t err = 0;
+    uint32_t nulls[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) nulls[k] = 0;
+    const int64_t nw = (a.n + 63) >> 6;
+    for (int64_t wv = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); wv < nw; wv += (int64_t)gridDim.x * (kBlock / 64)) {
+        const int64_t j = wv * 64 + lane;
+        const bool inr = j < a.n;
+        bool valid = inr;
+        if (a.indices.validity) {
+            const uint64_t w = load_bits64(a.indices.validity, a.indices.offset + wv * 64, clamp64(a.n - wv * 64));
+            valid = valid && ((w >> lane) & 1);
+        }
+        uint64_t ix = 0;
+        if (valid) {
+            ix = (uint64_t)__builtin_nontemporal_load(as_global<IDX>(a.indices.values) + a.indices.offset + j);
+            if (ix >= (uint64_t)a.total_rows) { err |= 2u; valid = false; }
+        }
+        uint64_t rec[NSLOT];
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) rec[k] = 0;
+        if (valid) {
+            GlobalPtr<u64x2> src = (GlobalPtr<u64x2>)(a.recs + ix * NSLOT);
+#pragma unroll
+            for (int k = 0; k < NSLOT; k += 2) { const u64x2 w = src[k / 2]; rec[k] = w[0]; rec[k + 1] = w[1]; }
+        }
+        uint64_t flags = ~0ull;
+        if (a.flag_slot >= 0) {
+#pragma unroll
+            for (int k = 0; k < NSLOT; ++k) if (k == a.flag_slot) flags = rec[k];
+        }
+        const uint64_t ib = __ballot(inr);
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            if (k >= a.ncols) continue;
+            const DevOutChunk out = a.outs[k];
+            if (inr) {
+                switch (a.esize[k]) {
+                    case 8: __builtin_nontemporal_store(rec[k], as_global_mut<uint64_t>(out.values) + j); break;
+                    case 4: __builtin_nontemporal_store((uint32_t)rec[k], as_global_mut<uint32_t>(out.values) + j); break;
+                    case 2: __builtin_nontemporal_store((uint16_t)rec[k], as_global_mut<uint16_t>(out.values) + j); break;
+                    default: __builtin_nontemporal_store((uint8_t)rec[k], as_global_mut<uint8_t>(out.values) + j); break;
+                }
+            }
+            if (out.validity) {
+                const uint64_t bal = __ballot(valid && ((flags >> k) & 1));
+                if (lane == 0) { as_global_mut<uint64_t>(out.validity)[wv] = bal; nulls[k] += (uint32_t)__popcll(ib & ~bal); }
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k)
+            if (k < a.ncols && nulls[k]) atomicAdd((unsigned long long*)&a.out_null_counts[k], (unsigned long long)nulls[k]);
+    }
+    if (err) atomicOr(a.flags, err);
+}
+
+template <int NSLOT>
+static void launch_rows_t(const TakeRowsArgs& a, hipStream_t s) {
+    int64_t g1 = (a.total_rows + kBlock - 1) / kBlock;
+    if (g1 > (int64_t)eval_grid_limit() * 4) g1 = (int64_t)eval_grid_limit() * 4;
+    if (g1 > 0) hipLaunchKernelGGL((rows_pack_kernel<NSLOT>), dim3((unsigned)g1), dim3(kBlock), 0, s, a);
+    const int64_t nw = (a.n + 63) >> 6;
+    int64_t g2 = (nw + (kBlock / 64) - 1) / (kBlock / 64);
+    if (g2 > (int64_t)eval_grid_limit() * 4) g2 = (int64_t)eval_grid_limit() * 4;
+    if (g2 <= 0) return;
+    if (a.idx64) hipLaunchKernelGGL((rows_gather_kernel<NSLOT, uint64_t>), dim3((unsigned)g2), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((rows_gather_kernel<NSLOT, uint32_t>), dim3((unsigned)g2), dim3(kBlock), 0, s, a);
+}
+hipError_t launch_take_rows(const TakeRowsArgs& a, hipStream_t s) {
+    switch (a.nslot) {
+        case 2: launch_rows_t<2>(a, s); break;
+        case 4: launch_rows_t<4>(a, s); break;
+        case 8: launch_rows_t<8>(a, s); break;
+        default: launch_rows_t<16>(a, s); break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_frame_totals(const int64_t* tile_scan, const int64_t* chunk_tile_start, int64_t nchunks, int64_t* out_len, int64_t* padded, hipStream_t s) {

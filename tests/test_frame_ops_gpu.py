@@ -141,9 +141,18 @@ def test_take_columns_parity(gpu, ora, lens, off, nf, idt):
         gpu.take_columns(host, bad)
 
 
+@pytest.fixture(params=["columns", "row-records"])
+def take_path(request):
+    """Both gather strategies of rdf_take_frame / rdf_sort_frame: column by column, and through interleaved row records."""
+    from rust_dataframe_amd import lib
+    lib.set_option("take_rows", 0 if request.param == "columns" else 2)
+    yield request.param
+    lib.set_option("take_rows", 1)
+
+
 @pytest.mark.parametrize("contiguous", [False, True])
 @pytest.mark.parametrize("lens,nf", [([6000], 0.0), ([1024] * 6 + [300], 0.15), ([512, 3000, 17], 0.0)])
-def test_take_frame_and_sort_frame(gpu, ora, lens, nf, contiguous):
+def test_take_frame_and_sort_frame(gpu, ora, lens, nf, contiguous, take_path):
     import torch
     rng = np.random.default_rng(13 + len(lens))
     dts = [A.I64, A.F64, A.I32, A.F32]
@@ -234,3 +243,24 @@ def test_groupby_agg_frame(gpu, ora, lens, knf, vnf):
             gpu.groupby_agg_frame(frame, [0], 2, "sum", 10)       # more than max_groups distinct keys
         with pytest.raises(A.RdfError):
             gpu.groupby_agg_frame(frame, [2], 3, "sum", 100)      # float grouping column
+
+
+def test_take_frame_wide_frames_through_row_records(gpu, ora, take_path):
+    """20 columns of every width (two record groups of <= 15 columns + the validity slot), nullable and not, null indices."""
+    rng = np.random.default_rng(99)
+    lens = [1024] * 4 + [500]
+    dts = [A.F64, A.I64, A.I32, A.F32, A.I16, A.U8, A.U64, A.I8, A.U16, A.U32] * 2
+    host = [make_chunks(rng, dt, lens, 0.2 if k % 4 == 0 else 0.0, 0) for k, dt in enumerate(dts)]
+    dev, keep = to_device(host)
+    total = sum(lens)
+    with A.PinnedFrame(gpu, dev) as frame:
+        for n, inull in [(total, 0.0), (777, 0.25), (1, 0.0)]:
+            iv = rng.permutation(total)[:n].astype(np.uint32) if n == total else rng.integers(0, total, n).astype(np.uint32)
+            idx = A.HostArray.from_numpy(iv, valid=(rng.uniform(size=n) >= inull) if inull else None, dtype=A.U32)
+            out = gpu.take_frame(frame, idx)
+            got = frame_columns(out)
+            for k in range(len(dts)):
+                match_unknown_nulls(got[k], [ora.take(host[k], idx)], f"{take_path} n={n} column {k}")
+            out.release()
+        with pytest.raises(A.RdfError):
+            gpu.take_frame(frame, A.HostArray.from_numpy(np.array([3, total + 7], dtype=np.uint32), dtype=A.U32))
