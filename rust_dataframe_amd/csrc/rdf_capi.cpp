@@ -54,6 +54,7 @@ struct Ctx {
     int    opt_filter_gen = 2;      // compaction kernels: 2 = wave-granular tiles (rdf_filter.hip, default), 1 = first-generation block tiles (A/B)
     int    opt_filter_tile = 0;     // 0: compaction tile chosen from the mean chunk length; 1024 / 4096 force one (A/B)
     int    opt_gb_debug = 0;        // ablations of the partitioned GROUP BY (tools/bench_kernels.py): 1 = aggregate without LDS work, 2 = scatter without stores
+    int    opt_sort_gen = 3;        // radix passes: 3 = one read + one write of the pairs per digit, decoupled look-back between 4096-pair tiles (rdf_sort.hip, default); 2 = count -> scan -> scatter over static tile ranges with the same wave-ranked tiles (A/B: slower, see rdf_sort.hip); 1 = first generation (rdf_kernels.hip)
     int    opt_take_rows = 1;       // take over a frame through interleaved row records: 1 = when the transaction model says so (default), 0 = never, 2 = always (tests, A/B)
     int    opt_gb_partition = 3;    // hash GROUP BY: 3 = second generation (rdf_groupby.hip: stream / line-aligned scatter / table by max_groups, default), 4 = its partition path whatever max_groups says, 1 = first-generation histogram + scatter, 2 = first-generation radix sort, 0 = one table in HBM
     // kernel timing (bench.py roofline leg)
@@ -2676,6 +2677,82 @@ rdf_status sort_key_range(const uint64_t* d_stats, size_t pin_off, uint64_t* bia
 }  // namespace
 
 namespace {
+
+// The digit passes of one sort column over (keys, idx) ping-pong buffers, second generation (rdf_sort.hip): every digit's
+// histogram from ONE read of the keys, then one read + one write of the pairs per digit.  `need` low bytes of (key - bias) vary.
+struct OsScratch { unsigned long long* state = nullptr; unsigned long long* tickets = nullptr; int64_t* hist = nullptr; int64_t ntiles = 0; int seq = 0;
+                   int64_t* bh0 = nullptr; int64_t* bh1 = nullptr; int64_t sgrid = 0; };
+rdf_status os_scratch_alloc(int64_t n, OsScratch& o) {
+    o.ntiles = (n + os_tile_items() - 1) / os_tile_items();
+    void* p = nullptr;
+    if (g_ctx.opt_sort_gen == 2) {   // static ranges: per-block digit counts and their scan
+        o.sgrid = sr_grid(o.ntiles);
+        RDF_TRY(arena_alloc((size_t)(256 * o.sgrid + 1) * 8, &p));
+        o.bh0 = (int64_t*)p;
+        RDF_TRY(arena_alloc((size_t)(256 * o.sgrid + 1 + scan_scratch_words(256 * o.sgrid)) * 8, &p));
+        o.bh1 = (int64_t*)p;
+        return RDF_OK;
+    }
+    RDF_TRY(arena_alloc((size_t)o.ntiles * 256 * 8 + 64, &p));
+    o.state = (unsigned long long*)p;
+    HIP_TRY(hipMemsetAsync(p, 0, (size_t)o.ntiles * 256 * 8, g_ctx.stream));
+    RDF_TRY(arena_alloc(16 * 8 + 9 * 256 * 8, &p));
+    o.tickets = (unsigned long long*)p;
+    o.hist = (int64_t*)((char*)p + 16 * 8);
+    o.seq = 0;
+    return RDF_OK;
+}
+rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* const idxb[2], const uint8_t* nullflags, int64_t n, uint64_t bias, int need,
+                            bool null_pass, int& kcur, int& icur, const uint32_t*& idx_cur) {
+    Ctx& ctx = g_ctx;
+    if (need == 0 && !null_pass) return RDF_OK;
+    if (ctx.opt_sort_gen == 2) {
+        for (int p = 0; p < need + (null_pass ? 1 : 0); ++p) {
+            const bool np = p == need;
+            OsPassArgs pa;
+            memset(&pa, 0, sizeof pa);
+            pa.keys_in = keys[kcur]; pa.idx_in = idx_cur; pa.keys_out = keys[kcur ^ 1]; pa.idx_out = idxb[icur ^ 1];
+            pa.nullflags = np ? nullflags : nullptr;
+            pa.n = n; pa.ntiles = o.ntiles; pa.bias = bias; pa.shift = 8 * p;
+            HIP_TRY(launch_sr_hist(pa, o.bh0, ctx.stream));
+            HIP_TRY(launch_scan(o.bh0, o.bh1, 256 * o.sgrid, o.bh1 + 256 * o.sgrid + 1, ctx.stream));
+            HIP_TRY(launch_sr_scatter(pa, o.bh1, ctx.stream));
+            kcur ^= 1; icur ^= 1; idx_cur = idxb[icur];
+        }
+        return RDF_OK;
+    }
+    HIP_TRY(hipMemsetAsync(o.tickets, 0, 16 * 8 + 9 * 256 * 8, ctx.stream));
+    OsHistArgs ha;
+    memset(&ha, 0, sizeof ha);
+    ha.keys = keys[kcur]; ha.nullflags = null_pass ? nullflags : nullptr; ha.n = n; ha.bias = bias; ha.npass = need; ha.hist = o.hist;
+    HIP_TRY(launch_os_hist(ha, ctx.stream));
+    int launched = 0;
+    for (int p = 0; p < need + (null_pass ? 1 : 0); ++p) {
+        const bool np = p == need;
+        if (o.seq >= 16000) { HIP_TRY(hipMemsetAsync(o.state, 0, (size_t)o.ntiles * 256 * 8, ctx.stream)); o.seq = 0; }
+        OsPassArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.keys_in = keys[kcur]; pa.idx_in = idx_cur; pa.keys_out = keys[kcur ^ 1]; pa.idx_out = idxb[icur ^ 1];
+        pa.nullflags = np ? nullflags : nullptr;
+        pa.state = o.state; pa.ticket = o.tickets + launched; pa.bases = o.hist + (np ? 8 : p) * 256;
+        pa.n = n; pa.ntiles = o.ntiles; pa.bias = bias; pa.shift = 8 * p; pa.seq = ++o.seq;
+        static const bool dbg = getenv("RDF_DEBUG_SORT") != nullptr;
+        if (dbg) { pa.debug = o.tickets + 8; }
+        HIP_TRY(launch_os_scatter(pa, ctx.stream));
+        if (dbg) {
+            unsigned long long h[6];
+            HIP_TRY(hipMemcpyAsync(h, pa.debug, 48, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_TRY(hipStreamSynchronize(ctx.stream));
+            HIP_TRY(hipMemsetAsync(pa.debug, 0, 48, ctx.stream));
+            const double t = (double)std::max<unsigned long long>(h[5], 1);
+            fprintf(stderr, "[rdf] os_scatter pass %d: per tile cycles (s_memtime, 100 MHz): ticket %.0f load+rank %.0f barrier %.0f look-back %.0f sort+write %.0f (%llu tiles)\n", p, h[0] / t, h[1] / t, h[2] / t, h[3] / t, h[4] / t, h[5]);
+        }
+        ++launched;
+        kcur ^= 1; icur ^= 1; idx_cur = idxb[icur];
+    }
+    return RDF_OK;
+}
+
 // The radix passes of DataFrame::sort over device-resident descriptor tables: d_chunks[k * nchunks + c] = chunk c of sort
 // column k (column 0 most significant), d_row_start = prefix of the batch lengths.  *idx_out = the sorted row order (u32,
 // arena memory, valid until the next arena_begin).  Shared by rdf_sort_to_indices and rdf_sort_frame.
@@ -2701,6 +2778,9 @@ rdf_status sort_core(const DevChunkCol* d_chunks, const int64_t* d_row_start, in
     const uint32_t* idx_cur = nullptr;  // nullptr = identity order
     int icur = 1;               // idxb[icur ^ 1] receives the next order
 
+    OsScratch os;
+    const bool gen2 = ctx.opt_sort_gen >= 2;   // rdf_sort.hip
+    if (gen2) RDF_TRY(os_scratch_alloc(n, os));
     KernelTimer kt;
     for (int k = ncols - 1; k >= 0; --k) {  // LSD over the sort columns: least significant criterion first
         const int dt = dts[k];
@@ -2724,6 +2804,7 @@ rdf_status sort_core(const DevChunkCol* d_chunks, const int64_t* d_row_start, in
         int need = 0;
         RDF_TRY(sort_key_range(d_stats, pin_off, &bias, &need));
         if (k == 0 && idx_cur == nullptr && need == 0 && !has_nulls) need = 1;   // all keys equal: one pass still writes the identity order
+        if (gen2) { RDF_TRY(os_column_passes(os, keys, idxb, (const uint8_t*)pnf, n, bias, std::min(need, dtype_size(dt)), has_nulls, kcur, icur, idx_cur)); continue; }
         const int npass = dtype_size(dt) + (has_nulls ? 1 : 0);
         for (int p = 0; p < npass; ++p) {
             if (p < dtype_size(dt) && p >= need) continue;
@@ -2844,6 +2925,14 @@ rdf_status radix_sort_rows(const SortBuffers& b, int64_t n, int width, bool has_
     RDF_TRY(sort_key_range(d_stats, pin_off, &bias, &need, kmax_out));
     *kmin_out = bias;
     if (need == 0 && !has_nulls) need = 1;   // all keys equal: one pass still writes the identity order
+    if (ctx.opt_sort_gen >= 2) {
+        OsScratch os;
+        RDF_TRY(os_scratch_alloc(n, os));
+        RDF_TRY(os_column_passes(os, b.keys, b.idx, (const uint8_t*)b.nullflags, n, bias, std::min(need, width), has_nulls, kcur, icur, idx_cur));
+        *kcur_out = kcur;
+        *icur_out = icur;
+        return RDF_OK;
+    }
     for (int p = 0; p < npass; ++p) {
         if (p < width && p >= need) continue;
         SortPassArgs pa;
@@ -3528,6 +3617,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "filter_tile") == 0) g_ctx.opt_filter_tile = (int)value;
     else if (strcmp(name, "filter_one") == 0) g_ctx.opt_filter_one = value != 0;
     else if (strcmp(name, "take_rows") == 0) g_ctx.opt_take_rows = (int)value;
+    else if (strcmp(name, "sort_gen") == 0) g_ctx.opt_sort_gen = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
     else return fail(RDF_INVALID_ARGUMENT, "unknown option %s", name);
     return RDF_OK;

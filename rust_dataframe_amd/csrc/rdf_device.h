@@ -219,6 +219,36 @@ struct SortPassArgs {
     uint64_t        bias;                            // smallest key of the column: digits are taken from key - bias, so a narrow key RANGE needs few passes
 };
 
+// Second-generation radix passes (rdf_sort.hip): all digit histograms in one read, then one read + one write per digit with
+// decoupled look-back between tiles.
+constexpr int kOsItems = 16;                         // items per thread per tile: 4096-item tiles
+struct OsHistArgs {
+    const uint64_t* keys;                            // [n] current order
+    const uint8_t*  nullflags;                       // [n] by original row, or nullptr: its 1s are counted for the nulls-last pass
+    int64_t         n;
+    uint64_t        bias;
+    int32_t         npass, pad;                      // digits 0..npass-1 of (key - bias)
+    int64_t*        hist;                            // [9 * 256] zeroed; on return the exclusive scan of every pass's counts (row 8: the nulls-last pass)
+};
+struct OsPassArgs {
+    const uint64_t* keys_in;  const uint32_t* idx_in;   // idx_in nullptr = identity
+    uint64_t*       keys_out; uint32_t*       idx_out;
+    const uint8_t*  nullflags;                       // the nulls-last pass: digit = nullflags[row], else nullptr
+    unsigned long long* state;                       // [ntiles * 256] tile states {seq | flag | value}, zeroed once per sort
+    unsigned long long* ticket;                      // next tile of this pass (zeroed)
+    const int64_t*  bases;                           // [256] global start of each digit's run in this pass
+    int64_t         n, ntiles;
+    uint64_t        bias;
+    int32_t         shift, seq;                      // seq: 1, 2, ... one per pass launched on `state`
+    unsigned long long* debug;                       // RDF_DEBUG: [6] cycle sums of the phases (ticket, load + rank, barrier, look-back, sort + write), tiles
+};
+hipError_t launch_os_hist(const OsHistArgs& a, hipStream_t s);
+hipError_t launch_os_scatter(const OsPassArgs& a, hipStream_t s);
+int os_tile_items();
+int sr_grid(int64_t ntiles);
+hipError_t launch_sr_hist(const OsPassArgs& a, int64_t* hist, hipStream_t s);      // hist: [256 * sr_grid] digit-major per-block counts
+hipError_t launch_sr_scatter(const OsPassArgs& a, const int64_t* hist, hipStream_t s);   // hist: their exclusive scan
+
 // Equi-join indices (calc_equijoin_indices, src/functions/join.rs:19-137): sort the build side by key, binary-search
 // every probe row, count -> scan -> write.
 struct JoinProbeArgs {

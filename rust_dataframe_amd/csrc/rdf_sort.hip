@@ -1,0 +1,391 @@
+// rdf_sort.hip — second-generation radix passes of DataFrame::sort (-> arrow::compute::lexsort_to_indices,
+// src/dataframe.rs:194-214): ONE kernel per 8-bit digit that reads the (key, row) pairs once and writes them once.
+//
+// The first generation (sort_hist_kernel -> scan -> sort_scatter_kernel, rdf_kernels.hip) reads the pairs twice per digit
+// (histogram, then scatter) with a scan launch in between, and ranks a tile through 16 KB of per-(row, wave) LDS counters and
+// seven block barriers.  Here:
+//   os_hist_kernel     one read of the keys builds the digit histograms of EVERY pass of the column at once
+//   os_bases_kernel    their exclusive scans = where each digit's run starts in every pass
+//   os_scatter_kernel  per pass: a block takes the next tile (ticket), ranks it with per-WAVE digit counters (a wave's lanes
+//                      that share a digit are found with 8 ballots; the run's first lane bumps the counter — no atomics),
+//                      publishes the tile's digit counts, finds its global offsets by DECOUPLED LOOK-BACK over the tiles
+//                      before it (each digit's thread walks back until it meets a tile whose inclusive prefix is published),
+//                      and writes the locally sorted tile out in digit runs.
+// Stable: tiles are ticketed in index order and a tile's offsets are the prefix over lower-numbered tiles only.
+//
+// Cross-XCD visibility: the per-XCD L2s are not coherent, so a tile's state word is ONE naturally aligned 8-byte
+// {sequence | flag | value} granule written and read with agent-scope atomics (write-through / L2-bypassing on gfx950,
+// MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility": an 8-byte granule needs no further
+// ordering).  The sequence field makes words of earlier passes read as "not published", so the state array is zeroed once
+// per sort, not once per pass.
+#include "rdf_common.hip.h"
+
+namespace rdfk {
+
+// Phase timers of os_scatter_kernel (build with -DRDF_SORT_TIMERS, run with RDF_DEBUG_SORT=1): reading the clock drains the
+// memory counters, so the timed build is ~8 % slower and is not the one that ships.
+#ifdef RDF_SORT_TIMERS
+#define OS_TIMERS_DECL unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}
+#define OS_TICK(c) const unsigned long long c = __builtin_readcyclecounter()
+#define OS_TIMERS_ADD do { tph[0] += c1 - c0; tph[1] += c2 - c1; tph[2] += c3 - c2; tph[3] += c4 - c3; tph[4] += c5 - c4; tph[5] += 1; } while (0)
+#define OS_TIMERS_FLUSH do { if (a.debug && threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomicAdd(a.debug + i, tph[i]); } while (0)
+#else
+#define OS_TIMERS_DECL
+#define OS_TICK(c)
+#define OS_TIMERS_ADD
+#define OS_TIMERS_FLUSH
+#endif
+
+constexpr int kOsWaves = kBlock / 64;
+constexpr int kOsLook = 8;                  // predecessors read per look-back step
+constexpr uint64_t kOsValueMask = (1ull << 48) - 1;
+constexpr uint64_t kOsLocal = 1ull << 48, kOsInclusive = 2ull << 48;
+
+__device__ __forceinline__ int os_digit(uint64_t key, uint64_t bias, int shift) { return (int)(((key - bias) >> shift) & 255); }
+
+// Histograms of all `npass` digits of (key - bias) in one read of the keys (+ the NULL count for the nulls-last pass).
+__global__ __launch_bounds__(kBlock) void os_hist_kernel(const OsHistArgs a) {
+    __shared__ unsigned int h[9][256];
+    for (int p = 0; p < 9; ++p) h[p][threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t k = __builtin_nontemporal_load(as_global<uint64_t>(a.keys) + i) - a.bias;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if (p >= a.npass) break;
+            const int d = (int)((k >> (8 * p)) & 255);
+            // a wave whose rows all share the digit (the upper bytes of a narrow range, dictionary codes): one add, not 64 serialised ones
+            const int d0 = __builtin_amdgcn_readfirstlane(d);
+            const uint64_t same = __ballot(d == d0);
+            if (same == __ballot(1)) { if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(same)) atomicAdd(&h[p][d0], (unsigned)__popcll(same)); }
+            else atomicAdd(&h[p][d], 1u);
+        }
+        if (a.nullflags) { if (as_global<uint8_t>(a.nullflags)[i]) atomicAdd(&h[8][1], 1u); }
+    }
+    __syncthreads();
+    for (int p = 0; p < a.npass; ++p) { const unsigned int c = h[p][threadIdx.x]; if (c) atomicAdd((unsigned long long*)&a.hist[p * 256 + threadIdx.x], (unsigned long long)c); }
+    if (a.nullflags && threadIdx.x == 1 && h[8][1]) atomicAdd((unsigned long long*)&a.hist[8 * 256 + 1], (unsigned long long)h[8][1]);
+}
+
+// exclusive scan of each pass's 256 counts (block p = pass p; pass 8 = the nulls-last pass: bin 0 = n - nulls)
+__global__ __launch_bounds__(256) void os_bases_kernel(int64_t* hist, int64_t n) {
+    __shared__ int64_t s[256];
+    const int p = blockIdx.x;
+    int64_t c = hist[p * 256 + threadIdx.x];
+    if (p == 8 && threadIdx.x == 0) c = n - hist[8 * 256 + 1];
+    s[threadIdx.x] = c;
+    __syncthreads();
+    int64_t run = 0;
+    for (int i = 0; i < (int)threadIdx.x; ++i) run += s[i];
+    hist[p * 256 + threadIdx.x] = run;
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) {
+    constexpr int TILE = kBlock * ITEMS;
+    __shared__ uint64_t lkeys[TILE];
+    __shared__ uint32_t lidx[TILE];
+    __shared__ uint8_t ldig[TILE];
+    __shared__ unsigned int whist[kOsWaves][256];      // per-wave digit counts, then the wave's exclusive offset inside the digit's run
+    __shared__ unsigned int dbase[256];                // tile-local start of each digit's run
+    __shared__ int64_t gbase[256];                     // global start of this tile's part of each digit's run
+    __shared__ unsigned int wsum[kOsWaves];
+    __shared__ int64_t tile_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t seq = (uint64_t)a.seq << 50;
+    OS_TIMERS_DECL;
+    for (;;) {
+        OS_TICK(c0);
+        if (threadIdx.x == 0) tile_s = (int64_t)atomicAdd((unsigned long long*)a.ticket, 1ull);
+#pragma unroll
+        for (int w = 0; w < kOsWaves; ++w) whist[w][threadIdx.x] = 0;
+        __syncthreads();
+        const int64_t tile = tile_s;
+        if (tile >= a.ntiles) break;
+        const int64_t base = tile * TILE;
+        const int count = (int)((a.n - base) < (int64_t)TILE ? (a.n - base) : (int64_t)TILE);
+        // ---- load (a wave owns ITEMS consecutive rows of 64 items) and rank inside the wave
+        uint64_t key[ITEMS];
+        uint32_t idx[ITEMS];
+        int digit[ITEMS], rank[ITEMS];
+        OS_TICK(c1);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
+            const bool in = i < a.n;
+            key[j] = in ? __builtin_nontemporal_load(as_global<uint64_t>(a.keys_in) + i) : 0;
+            idx[j] = in ? (a.idx_in ? __builtin_nontemporal_load(as_global<uint32_t>(a.idx_in) + i) : (uint32_t)i) : 0;
+        }
+        // ranks inside the wave: the lanes of a row that share my digit (8 ballots); the run's first lane bumps the wave's counter
+        // of the digit (plain read + write: the LDS serves a wave's instructions in order, rows are taken in order: stable).
+        // (Measured alternatives, both slower on the whole sort: one returning LDS add per row issued back to back for all rows
+        // — it keeps four more values per item live, 5.97 against 5.49 ms per 5e7 full-range keys — and 2048-pair tiles at
+        // five blocks per CU, 996 against 653 us per pass: more tiles in flight, longer waits in the look-back.)
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
+            const bool in = i < a.n;
+            int d = 0;
+            if (in) d = a.nullflags ? (int)as_global<uint8_t>(a.nullflags)[idx[j]] : os_digit(key[j], a.bias, a.shift);
+            digit[j] = d;
+            uint64_t peers = __ballot(in);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint64_t m = __ballot((d >> b) & 1);
+                peers &= ((d >> b) & 1) ? m : ~m;
+            }
+            const int leader = __builtin_ctzll(peers | (1ull << 63));
+            unsigned int before = 0;
+            if (in && lane == leader) { before = whist[wave][d]; whist[wave][d] = before + (unsigned)__popcll(peers); }
+            before = __shfl(before, leader);
+            rank[j] = (int)before + __popcll(peers & ((1ull << lane) - 1));
+        }
+        OS_TICK(c2);
+        __syncthreads();
+        OS_TICK(c3);
+        // ---- thread d: the waves' counts of digit d -> their offsets inside the run, the tile's total
+        unsigned int total_d = 0;
+#pragma unroll
+        for (int w = 0; w < kOsWaves; ++w) { const unsigned int c = whist[w][threadIdx.x]; whist[w][threadIdx.x] = total_d; total_d += c; }
+        // publish the tile's count of digit d, then look back for what lies before the tile
+        unsigned long long* st = a.state + tile * 256 + threadIdx.x;
+        if (tile > 0) __hip_atomic_store(st, seq | kOsLocal | total_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int inc = total_d;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const unsigned int o = __shfl_up(inc, dd); if (lane >= dd) inc += o; }
+        if (lane == 63) wsum[wave] = inc;
+        // kOsLook predecessors are read at once (independent loads) and consumed nearest first
+        int64_t excl = 0;
+        for (int64_t t = tile - 1; t >= 0;) {
+            unsigned long long w[kOsLook];
+#pragma unroll
+            for (int u = 0; u < kOsLook; ++u)
+                w[u] = t - u >= 0 ? __hip_atomic_load(a.state + (t - u) * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (seq | kOsInclusive);
+            int used = 0;
+            bool done = false, stalled = false;
+#pragma unroll
+            for (int u = 0; u < kOsLook; ++u) {
+                if (done || stalled) continue;
+                if ((w[u] >> 50) != (unsigned long long)a.seq) { stalled = true; continue; }   // not published yet in THIS pass
+                excl += (int64_t)(w[u] & kOsValueMask);
+                ++used;
+                if (w[u] & kOsInclusive) done = true;
+            }
+            if (done) break;
+            t -= used;
+            if (stalled) __builtin_amdgcn_s_sleep(1);
+        }
+        __hip_atomic_store(st, seq | kOsInclusive | (unsigned long long)(excl + total_d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gbase[threadIdx.x] = a.bases[threadIdx.x] + excl;
+        OS_TICK(c4);
+        __syncthreads();
+        unsigned int wb = 0;
+        for (int w = 0; w < wave; ++w) wb += wsum[w];
+        dbase[threadIdx.x] = wb + inc - total_d;
+        __syncthreads();
+        // ---- local stable sort by digit into LDS
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
+            if (i < a.n) {
+                const int pos = (int)(dbase[digit[j]] + whist[wave][digit[j]]) + rank[j];
+                lkeys[pos] = key[j];
+                lidx[pos] = idx[j];
+                ldig[pos] = (uint8_t)digit[j];
+            }
+        }
+        __syncthreads();
+        // ---- write-out: consecutive threads hold consecutive members of a digit run
+        for (int t = threadIdx.x; t < count; t += kBlock) {
+            const int d = ldig[t];
+            const int64_t dst = gbase[d] + (t - (int)dbase[d]);
+            __builtin_nontemporal_store(lkeys[t], as_global_mut<uint64_t>(a.keys_out) + dst);
+            __builtin_nontemporal_store(lidx[t], as_global_mut<uint32_t>(a.idx_out) + dst);
+        }
+        __syncthreads();
+        OS_TICK(c5);
+        OS_TIMERS_ADD;
+    }
+    OS_TIMERS_FLUSH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Static ranges: block b owns the contiguous tiles [b * tpb, (b + 1) * tpb).  A count pass gives every block its digit counts
+// (sr_hist_kernel, keys only: 8 bytes per row), one scan turns them into where each block's part of each digit's run starts,
+// and the scatter walks its tiles in order carrying the running offsets in LDS: no block ever waits for another one; the next
+// tile's pairs are loaded while the current tile is ranked, sorted and written (registers double-buffered by unrolling the
+// tile loop by two).  Kept as the A/B partner of the look-back kernel (rdf_set_option("sort_gen", 2)): per pass of 5e7 pairs
+// it measured 708 + 215 us (scatter + count) against 653 us — double buffering the tile costs the kernel its second block per
+// CU (256 VGPRs), and the count pass re-reads the keys.  What the look-back kernel pays instead is waiting: a tile cannot
+// resolve its offsets before EVERY tile ticketed before it has published its counts (12 us of a 27 us tile by the phase
+// timers, RDF_DEBUG_SORT=1, whatever the look-back width).
+__global__ __launch_bounds__(kBlock) void sr_hist_kernel(const OsPassArgs a, int64_t* hist) {
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    constexpr int TILE = kBlock * kOsItems;
+    const int64_t tpb = (a.ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * tpb, t1 = t0 + tpb < a.ntiles ? t0 + tpb : a.ntiles;
+    const int64_t lo = t0 * TILE, hi = t1 * TILE < a.n ? t1 * TILE : a.n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+        int d;
+        if (a.nullflags) d = as_global<uint8_t>(a.nullflags)[a.idx_in ? (int64_t)as_global<uint32_t>(a.idx_in)[i] : i];
+        else d = os_digit(__builtin_nontemporal_load(as_global<uint64_t>(a.keys_in) + i), a.bias, a.shift);
+        const int d0 = __builtin_amdgcn_readfirstlane(d);
+        const uint64_t same = __ballot(d == d0);
+        if (same == __ballot(1)) { if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(same)) atomicAdd(&h[d0], (unsigned)__popcll(same)); }
+        else atomicAdd(&h[d], 1u);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+template <int ITEMS>
+struct SrTile { uint64_t key[ITEMS]; uint32_t idx[ITEMS]; };
+
+template <int ITEMS>
+__device__ __forceinline__ void sr_load(const OsPassArgs& a, int64_t tile, int wave, int lane, SrTile<ITEMS>& r) {
+    const int64_t base = tile * (kBlock * ITEMS);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
+        const bool in = i < a.n;
+        r.key[j] = in ? __builtin_nontemporal_load(as_global<uint64_t>(a.keys_in) + i) : 0;
+        r.idx[j] = in ? (a.idx_in ? __builtin_nontemporal_load(as_global<uint32_t>(a.idx_in) + i) : (uint32_t)i) : 0;
+    }
+}
+
+template <int ITEMS>
+struct SrLds {
+    uint64_t lkeys[kBlock * ITEMS];
+    uint32_t lidx[kBlock * ITEMS];
+    uint8_t ldig[kBlock * ITEMS];
+    unsigned int whist[kOsWaves][256];
+    unsigned int dbase[256];
+    int64_t gbase[256];
+    unsigned int wsum[kOsWaves];
+};
+
+// one tile: rank (as os_scatter_kernel), local sort, write-out at the block's running offsets
+template <int ITEMS>
+__device__ __forceinline__ void sr_tile(const OsPassArgs& a, SrLds<ITEMS>& L, int64_t tile, int wave, int lane, const SrTile<ITEMS>& r) {
+    constexpr int TILE = kBlock * ITEMS;
+    const int64_t base = tile * TILE;
+    const int count = (int)((a.n - base) < (int64_t)TILE ? (a.n - base) : (int64_t)TILE);
+#pragma unroll
+    for (int w = 0; w < kOsWaves; ++w) L.whist[w][threadIdx.x] = 0;
+    __syncthreads();
+    // per item ONE register: digit (8 bits) | first peer lane (6) | peers below me (6) | peers (7)
+    unsigned int pk[ITEMS], before[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
+        const bool in = i < a.n;
+        int d = 0;
+        if (in) d = a.nullflags ? (int)as_global<uint8_t>(a.nullflags)[r.idx[j]] : os_digit(r.key[j], a.bias, a.shift);
+        uint64_t peers = __ballot(in);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        const unsigned int leader = (unsigned)__builtin_ctzll(peers | (1ull << 63));
+        pk[j] = (unsigned)d | (leader << 8) | ((unsigned)__popcll(peers & ((1ull << lane) - 1)) << 14) | ((unsigned)__popcll(peers) << 20);
+        __builtin_amdgcn_sched_barrier(0);     // one row's ballots at a time: sixteen rows' masks in flight spill hundreds of scalar registers
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
+        unsigned int old = 0;
+        if (i < a.n && (unsigned)lane == ((pk[j] >> 8) & 63)) old = atomicAdd(&L.whist[wave][pk[j] & 255], pk[j] >> 20);
+        before[j] = old;
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) before[j] = __shfl(before[j], (int)((pk[j] >> 8) & 63)) + ((pk[j] >> 14) & 63);   // rank inside the wave's run of the digit
+    __syncthreads();
+    unsigned int total_d = 0;
+#pragma unroll
+    for (int w = 0; w < kOsWaves; ++w) { const unsigned int c = L.whist[w][threadIdx.x]; L.whist[w][threadIdx.x] = total_d; total_d += c; }
+    unsigned int inc = total_d;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) { const unsigned int o = __shfl_up(inc, dd); if (lane >= dd) inc += o; }
+    if (lane == 63) L.wsum[wave] = inc;
+    __syncthreads();
+    unsigned int wb = 0;
+    for (int w = 0; w < wave; ++w) wb += L.wsum[w];
+    L.dbase[threadIdx.x] = wb + inc - total_d;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
+        if (i < a.n) {
+            const int d = (int)(pk[j] & 255);
+            const int pos = (int)(L.dbase[d] + L.whist[wave][d] + before[j]);
+            L.lkeys[pos] = r.key[j];
+            L.lidx[pos] = r.idx[j];
+            L.ldig[pos] = (uint8_t)d;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < count; t += kBlock) {
+        const int d = L.ldig[t];
+        const int64_t dst = L.gbase[d] + (t - (int)L.dbase[d]);
+        __builtin_nontemporal_store(L.lkeys[t], as_global_mut<uint64_t>(a.keys_out) + dst);
+        __builtin_nontemporal_store(L.lidx[t], as_global_mut<uint32_t>(a.idx_out) + dst);
+    }
+    __syncthreads();
+    L.gbase[threadIdx.x] += total_d;      // the block's next tile continues each digit's run
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kBlock) void sr_scatter_kernel(const OsPassArgs a, const int64_t* hist) {
+    __shared__ SrLds<ITEMS> L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    L.gbase[threadIdx.x] = hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x];
+    const int64_t tpb = (a.ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * tpb, t1 = t0 + tpb < a.ntiles ? t0 + tpb : a.ntiles;
+    if (t0 >= t1) return;
+    SrTile<ITEMS> ra, rb;
+    sr_load<ITEMS>(a, t0, wave, lane, ra);
+    for (int64_t tile = t0; tile < t1; tile += 2) {
+        if (tile + 1 < t1) sr_load<ITEMS>(a, tile + 1, wave, lane, rb);
+        sr_tile<ITEMS>(a, L, tile, wave, lane, ra);
+        if (tile + 1 >= t1) break;
+        if (tile + 2 < t1) sr_load<ITEMS>(a, tile + 2, wave, lane, ra);
+        sr_tile<ITEMS>(a, L, tile + 1, wave, lane, rb);
+    }
+}
+
+int sr_grid(int64_t ntiles) {
+    const int64_t lim = (int64_t)(eval_grid_limit() / 8) * 2;      // ~59 KB of LDS per block: two blocks per CU
+    const int64_t g = ntiles < lim ? ntiles : lim;
+    return g < 1 ? 1 : (int)g;
+}
+hipError_t launch_sr_hist(const OsPassArgs& a, int64_t* hist, hipStream_t s) {
+    hipLaunchKernelGGL(sr_hist_kernel, dim3(sr_grid(a.ntiles)), dim3(kBlock), 0, s, a, hist);
+    return hipGetLastError();
+}
+hipError_t launch_sr_scatter(const OsPassArgs& a, const int64_t* hist, hipStream_t s) {
+    hipLaunchKernelGGL((sr_scatter_kernel<kOsItems>), dim3(sr_grid(a.ntiles)), dim3(kBlock), 0, s, a, hist);
+    return hipGetLastError();
+}
+
+hipError_t launch_os_hist(const OsHistArgs& a, hipStream_t s) {
+    int64_t grid = (a.n + (int64_t)kBlock * 16 - 1) / ((int64_t)kBlock * 16);
+    if (grid > eval_grid_limit()) grid = eval_grid_limit();
+    if (grid <= 0) return hipSuccess;
+    hipLaunchKernelGGL(os_hist_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(os_bases_kernel, dim3(9), dim3(256), 0, s, a.hist, a.n);
+    return hipGetLastError();
+}
+int os_tile_items() { return kBlock * kOsItems; }
+hipError_t launch_os_scatter(const OsPassArgs& a, hipStream_t s) {
+    // every block must be RESIDENT (a ticketed tile waits for its predecessors): 3 blocks of ~57 KB LDS per CU
+    int64_t grid = (int64_t)(eval_grid_limit() / 8) * (kOsItems >= 16 ? 2 : 5);
+    if (grid > a.ntiles) grid = a.ntiles;
+    if (grid <= 0) return hipSuccess;
+    hipLaunchKernelGGL((os_scatter_kernel<kOsItems>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace rdfk

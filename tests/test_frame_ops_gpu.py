@@ -264,3 +264,24 @@ def test_take_frame_wide_frames_through_row_records(gpu, ora, take_path):
             out.release()
         with pytest.raises(A.RdfError):
             gpu.take_frame(frame, A.HostArray.from_numpy(np.array([3, total + 7], dtype=np.uint32), dtype=A.U32))
+
+
+@pytest.mark.parametrize("sort_gen", [1, 2, 3])
+def test_sort_generations(gpu, ora, sort_gen):
+    """The three radix-pass implementations behind rdf_sort_to_indices / rdf_sort_frame (rdf_set_option("sort_gen", ..)):
+    first generation, static tile ranges, decoupled look-back — many tiles (the look-back crosses tiles and XCDs), full-range
+    and narrow keys, ties, NULLs, several criteria, descending."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(1000 + sort_gen)
+    lib.set_option("sort_gen", sort_gen)
+    try:
+        for n, lens in [(70_001, [70_001]), (200_000, [65_536, 1, 100_000, 34_463])]:
+            wide = [A.HostArray.from_numpy(rng.integers(-2 ** 62, 2 ** 62, m), valid=rng.uniform(size=m) >= 0.05, dtype=A.I64) for m in lens]
+            ties = [A.HostArray.from_numpy(rng.integers(0, 5, m).astype(np.int32), dtype=A.I32) for m in lens]
+            f = [A.HostArray.from_numpy(rng.normal(size=m), dtype=A.F64) for m in lens]
+            for cols, desc in [([wide], [False]), ([ties, wide], [True, False]), ([f], [True]), ([ties, f, wide], [False, False, True])]:
+                got = gpu.sort_to_indices(cols, desc)
+                exp = ora.sort_to_indices(cols, desc)
+                assert np.array_equal(got.to_numpy(), exp.to_numpy()), (sort_gen, n, desc)
+    finally:
+        lib.set_option("sort_gen", 3)
