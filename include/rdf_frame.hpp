@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cerrno>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -123,6 +124,31 @@ class DeviceBuffer {
     int64_t bytes_;
 };
 using BufferRef = std::shared_ptr<DeviceBuffer>;
+
+// Page-locked host memory (rdf_host_alloc): what a reader parses into / reads a file into, so that its uploads are plain DMA
+// (no runtime staging copy) and can run on the copy stream while the reader goes on (rdf_copy_h2d_async ... rdf_copy_fence).
+class PinnedBuffer {
+  public:
+    explicit PinnedBuffer(int64_t bytes) : bytes_(bytes) { check(rdf_host_alloc(&ptr_, bytes + 64)); }
+    ~PinnedBuffer() { if (ptr_) (void)rdf_host_free(ptr_); }
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    uint8_t* data() const { return (uint8_t*)ptr_; }
+    int64_t bytes() const { return bytes_; }
+  private:
+    void* ptr_ = nullptr;
+    int64_t bytes_;
+};
+// One load (from_csv / from_arrow): uploads from pinned memory are queued, ONE fence at the end.  `bytes` counts what went up.
+struct IngestStats { int64_t bytes = 0, async_copies = 0, blocking_copies = 0; double seconds = 0, parse_seconds = 0; };
+inline IngestStats& last_ingest() { static thread_local IngestStats s; return s; }
+inline void upload(void* dst, const void* src, int64_t bytes, bool src_pinned) {
+    if (bytes <= 0) return;
+    IngestStats& st = last_ingest();
+    st.bytes += bytes;
+    if (src_pinned) { check(rdf_copy_h2d_async(dst, src, bytes)); ++st.async_copies; }
+    else { check(rdf_copy_h2d(dst, src, bytes)); ++st.blocking_copies; }
+}
 
 inline std::vector<uint8_t> pack_bits(const std::vector<bool>& bits) {
     std::vector<uint8_t> out((bits.size() + 63) / 64 * 8 + 8, 0);
@@ -1015,6 +1041,9 @@ class DataFrame {
     // what plan::optimise pushes a Limit / Select into
     static DataFrame from_csv(const std::string& path, const plan::CsvReadOptions& options) {
         const size_t batch_size = options.batch_size ? options.batch_size : 1024;
+        const auto t_start = std::chrono::steady_clock::now();
+        last_ingest() = IngestStats();
+        std::vector<std::unique_ptr<PinnedBuffer>> staged;   // the parsed columns: alive until the fence
         CsvCells t = read_csv_cells(path, options.has_headers, (char)options.delimiter.value_or((uint8_t)','), options.max_records);
         if (options.projection) {
             CsvCells p;
@@ -1039,21 +1068,36 @@ class DataFrame {
                     if (n == 0) break;
                 }
             } else {
+                // typed values are parsed STRAIGHT into a page-locked column buffer (+ bitmap) and queued for upload: column i
+                // travels over the link while column i + 1 is being parsed; one fence after the last column
                 std::vector<bool> valid(n, true);
-                ArrayRef whole;
-                if (dt == DataType::Int64) {
-                    std::vector<int64_t> v(n, 0);
-                    for (size_t k = 0; k < n; ++k) { if (cells[i][k].empty()) valid[k] = false; else v[k] = std::strtoll(cells[i][k].c_str(), nullptr, 10); }
-                    whole = Array::from_vec(v, any_null ? &valid : nullptr);
-                } else if (dt == DataType::Float64) {
-                    std::vector<double> v(n, 0.0);
-                    for (size_t k = 0; k < n; ++k) { if (cells[i][k].empty()) valid[k] = false; else v[k] = std::strtod(cells[i][k].c_str(), nullptr); }
-                    whole = Array::from_vec(v, any_null ? &valid : nullptr);
-                } else {
-                    std::vector<bool> v(n, false);
-                    for (size_t k = 0; k < n; ++k) { if (cells[i][k].empty()) valid[k] = false; else v[k] = cells[i][k][0] == 't' || cells[i][k][0] == 'T'; }
-                    whole = Array::from_bools(v, any_null ? &valid : nullptr);
+                const int64_t vbytes = dt == DataType::Boolean ? (int64_t)((n + 63) / 64 * 8 + 8) : (int64_t)(n * 8);
+                const int64_t bbytes = (int64_t)((n + 63) / 64 * 8 + 8);
+                staged.push_back(std::make_unique<PinnedBuffer>(vbytes + bbytes));
+                uint8_t* pv = staged.back()->data();
+                uint8_t* pb = pv + vbytes;
+                std::memset(pb, 0, (size_t)bbytes);
+                if (dt == DataType::Boolean) std::memset(pv, 0, (size_t)vbytes);
+                int64_t nulls = 0;
+                for (size_t k = 0; k < n; ++k) {
+                    const std::string& c = cells[i][k];
+                    if (c.empty()) { valid[k] = false; ++nulls; if (dt != DataType::Boolean) std::memset(pv + 8 * k, 0, 8); continue; }
+                    pb[k >> 3] |= (uint8_t)(1u << (k & 7));
+                    if (dt == DataType::Int64) { const int64_t v = std::strtoll(c.c_str(), nullptr, 10); std::memcpy(pv + 8 * k, &v, 8); }
+                    else if (dt == DataType::Float64) { const double v = std::strtod(c.c_str(), nullptr); std::memcpy(pv + 8 * k, &v, 8); }
+                    else if (c[0] == 't' || c[0] == 'T') pv[k >> 3] |= (uint8_t)(1u << (k & 7));
                 }
+                auto w = std::make_shared<Array>();
+                w->dtype = dt;
+                w->length = (int64_t)n;
+                w->null_count = nulls;
+                w->values = std::make_shared<DeviceBuffer>(vbytes + 8);
+                upload(w->values->data(), pv, dt == DataType::Boolean ? (int64_t)((n + 7) / 8) : vbytes, true);
+                if (any_null) {
+                    w->validity = std::make_shared<DeviceBuffer>(bbytes);
+                    upload(w->validity->data(), pb, bbytes - 8, true);
+                }
+                ArrayRef whole = w;
                 for (size_t b = 0; b < n || chunks.empty(); b += batch_size) {   // RecordBatches = zero-copy slices of the one buffer
                     auto c = std::const_pointer_cast<Array>(whole->slice((int64_t)b, (int64_t)std::min(batch_size, n - b)));
                     if (any_null) { c->null_count = 0; for (size_t k = b; k < std::min(n, b + batch_size); ++k) c->null_count += !valid[k]; }
@@ -1063,6 +1107,8 @@ class DataFrame {
             }
             cols.push_back(Column::from_arrays(chunks, Field{header[i], dt, true}));
         }
+        check(rdf_copy_fence());
+        last_ingest().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         return from_columns(std::move(cols));
     }
 
@@ -1074,23 +1120,54 @@ class DataFrame {
     // opaquely.  Dictionary-encoded columns (numeric or Utf8 values, any integer index type; delta and replacement
     // dictionaries of the stream format) are decoded while loading — the frame holds plain columns, as the reference's
     // kernels expect.  Nested types and compressed bodies are rejected with an error.
+    // The file is read into ONE page-locked buffer; every record batch's column buffers are queued for upload straight out of
+    // it (rdf_copy_h2d_async, the copy stream) while the next batch's metadata is decoded, and one fence ends the load:
+    // no intermediate arrays, no runtime staging copy, no synchronisation per buffer.  last_ingest() tells what went up.
     static DataFrame from_arrow(const std::string& path) {
-        std::ifstream f(path, std::ios::binary);
+        const auto t0 = std::chrono::steady_clock::now();
+        std::ifstream f(path, std::ios::binary | std::ios::ate);
         if (!f) throw DataFrameError(DataFrameError::IoError, "cannot open " + path);
-        std::vector<uint8_t> img((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-        return from_arrow_image(img.data(), img.size());
+        const int64_t size = (int64_t)f.tellg();
+        f.seekg(0);
+        PinnedBuffer img(size);
+        if (size > 0 && !f.read((char*)img.data(), size)) throw DataFrameError(DataFrameError::IoError, "cannot read " + path);
+        last_ingest() = IngestStats();
+        last_ingest().parse_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();   // reading the file
+        DataFrame df = load_arrow_image(img.data(), (size_t)size, true);
+        last_ingest().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return df;
     }
+    // An image the caller holds: pinned in place (rdf_host_register) for the duration of the load when the platform allows it.
     static DataFrame from_arrow_image(const uint8_t* img, size_t size) {
-        IpcReader r(img, size);
-        if (size >= 20 && std::memcmp(img, "ARROW1", 6) == 0) r.read_file(); else r.read_stream();
-        return r.finish();
+        const auto t0 = std::chrono::steady_clock::now();
+        last_ingest() = IngestStats();
+        const bool reg = size > 0 && rdf_host_register(const_cast<uint8_t*>(img), (int64_t)size) == RDF_OK;
+        DataFrame df;
+        try { df = load_arrow_image(img, size, reg); }
+        catch (...) { if (reg) { (void)rdf_copy_fence(); (void)rdf_host_unregister(const_cast<uint8_t*>(img)); } throw; }
+        if (reg) check(rdf_host_unregister(const_cast<uint8_t*>(img)));
+        last_ingest().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return df;
     }
+  private:
+    static DataFrame load_arrow_image(const uint8_t* img, size_t size, bool pinned) {
+        IpcReader r(img, size);
+        r.pinned = pinned;
+        try {
+            if (size >= 20 && std::memcmp(img, "ARROW1", 6) == 0) r.read_file(); else r.read_stream();
+            DataFrame df = r.finish();
+            check(rdf_copy_fence());     // the image may go away (and kernels may run) after this
+            return df;
+        } catch (...) { (void)rdf_copy_fence(); throw; }
+    }
+  public:
 
   private:
     struct IpcReader {
         struct Dict { bool utf8 = false; DataType dt = DataType::Int64; std::vector<std::string> strs; std::vector<uint8_t> values; std::vector<bool> valid; int64_t n = 0; };
         struct Col { Field field; bool dict = false; int64_t dict_id = 0; DataType index_type = DataType::Int32; };
         const uint8_t* img; size_t size; FlatBuf fb;
+        bool pinned = false;     // the image is page-locked: column buffers go up asynchronously, straight out of it
         std::vector<Col> cols;
         std::map<int64_t, Dict> dicts;
         std::vector<std::vector<ArrayRef>> chunks;
@@ -1206,10 +1283,10 @@ class DataFrame {
                 a->dtype = dt;
                 a->length = b.len;
                 a->values = std::make_shared<DeviceBuffer>(need + 8);
-                if (need) check(rdf_copy_h2d(a->values->data(), body.p + b.d0, need));
+                upload(a->values->data(), body.p + b.d0, need, pinned);
                 if (b.nulls > 0) {
                     a->validity = std::make_shared<DeviceBuffer>((b.len + 7) / 8 + 8);
-                    check(rdf_copy_h2d(a->validity->data(), body.p + b.vo, (b.len + 7) / 8));
+                    upload(a->validity->data(), body.p + b.vo, (b.len + 7) / 8, pinned);
                     a->null_count = b.nulls;
                 }
                 chunks[c].push_back(a);

@@ -122,6 +122,18 @@ rdf_status  rdf_dev_alloc(void** ptr, int64_t bytes);
 rdf_status  rdf_dev_free(void* ptr);
 rdf_status  rdf_copy_h2d(void* dst_dev, const void* src_host, int64_t bytes);
 rdf_status  rdf_copy_d2h(void* dst_host, const void* src_dev, int64_t bytes);
+/* Ingestion (DataFrame::from_csv / from_arrow, src/dataframe.rs:349-407): page-locked host buffers and uploads that do not
+ * block the reader.  rdf_host_alloc gives a pinned buffer (a CSV parser writes its typed column into it, an IPC file is read
+ * into it); rdf_host_register pins memory the caller already holds (a file image) — RDF_MEMORY_ERROR when the platform
+ * refuses, the caller then uses rdf_copy_h2d.  rdf_copy_h2d_async queues the upload on the thread's copy stream and returns:
+ * the source must be pinned and stay untouched until rdf_copy_fence, which waits for every queued upload of the thread.
+ * Kernels launched after the fence see the data. */
+rdf_status  rdf_host_alloc(void** ptr, int64_t bytes);
+rdf_status  rdf_host_free(void* ptr);
+rdf_status  rdf_host_register(void* ptr, int64_t bytes);
+rdf_status  rdf_host_unregister(void* ptr);
+rdf_status  rdf_copy_h2d_async(void* dst_dev, const void* src_host_pinned, int64_t bytes);
+rdf_status  rdf_copy_fence(void);
 
 /* ------------------------------------------------------------------ scalar kernels */
 

@@ -148,6 +148,13 @@ pub mod sys {
                               out_indices: *mut rdf_out, out: *mut *mut rdf_frame) -> i32;
         pub fn rdf_groupby_agg_frame(frame: *mut rdf_frame, key_cols: *const i32, nkeys: i32, value_col: i32, agg: i32,
                                      max_groups: i64, out: *mut *mut rdf_frame) -> i32;
+        // ingestion: pinned reader buffers, uploads that do not block the reader, one fence per load (src/dataframe.rs:349-407)
+        pub fn rdf_host_alloc(ptr: *mut *mut c_void, bytes: i64) -> i32;
+        pub fn rdf_host_free(ptr: *mut c_void) -> i32;
+        pub fn rdf_host_register(ptr: *mut c_void, bytes: i64) -> i32;
+        pub fn rdf_host_unregister(ptr: *mut c_void) -> i32;
+        pub fn rdf_copy_h2d_async(dst_dev: *mut c_void, src_host_pinned: *const c_void, bytes: i64) -> i32;
+        pub fn rdf_copy_fence() -> i32;
         // synthetic data, switches, introspection (bench / tests)
         pub fn rdf_fill_uniform_f64(dev_ptr: *mut f64, n: i64, seed: u64, column_id: u64, first_row: i64, lo: f64, hi: f64) -> i32;
         pub fn rdf_fill_uniform_i64(dev_ptr: *mut i64, n: i64, seed: u64, column_id: u64, first_row: i64, lo: i64, hi: i64) -> i32;

@@ -41,6 +41,8 @@ struct Ctx {
     int         device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // own_stream or the caller's
+    hipStream_t copy_stream = nullptr;   // ingestion uploads (rdf_copy_h2d_async): overlap with parsing on the host and with kernels
+    bool copy_pending = false;
     Arena       arena;
     char*       pinned = nullptr;
     size_t      pinned_cap = 0;
@@ -82,6 +84,7 @@ Ctx::~Ctx() {
     if (pinned) (void)hipHostFree(pinned);
     for (auto& kv : pool_free) (void)hipFree(kv.second);
     for (auto& ev : events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     if (own_stream) (void)hipStreamDestroy(own_stream);
     ready = false;
 }
@@ -1705,6 +1708,49 @@ rdf_status rdf_copy_h2d(void* dst_dev, const void* src_host, int64_t bytes) {
     }
     return RDF_OK;
 }
+// ---- ingestion: page-locked host memory + uploads that do not block the caller (DataFrame::from_csv / from_arrow,
+// src/dataframe.rs:349-407: the reader's buffers are pinned, every record batch's buffers go up on a copy stream while the
+// next batch is being parsed, and ONE fence ends the load)
+rdf_status rdf_host_alloc(void** ptr, int64_t bytes) {
+    if (!ptr || bytes < 0) return fail(RDF_INVALID_ARGUMENT, "host_alloc: bad arguments");
+    RDF_TRY(ensure_ready());
+    hipError_t e = hipHostMalloc(ptr, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(RDF_MEMORY_ERROR, "hipHostMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(e));
+    return RDF_OK;
+}
+rdf_status rdf_host_free(void* ptr) {
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return RDF_OK;
+}
+rdf_status rdf_host_register(void* ptr, int64_t bytes) {
+    if (!ptr || bytes <= 0) return fail(RDF_INVALID_ARGUMENT, "host_register: bad arguments");
+    RDF_TRY(ensure_ready());
+    hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); g_ctx.err = std::string("hipHostRegister: ") + hipGetErrorString(e); return RDF_MEMORY_ERROR; }   // the caller falls back to blocking copies
+    return RDF_OK;
+}
+rdf_status rdf_host_unregister(void* ptr) {
+    if (ptr) HIP_TRY(hipHostUnregister(ptr));
+    return RDF_OK;
+}
+rdf_status rdf_copy_h2d_async(void* dst_dev, const void* src_host, int64_t bytes) {
+    RDF_TRY(ensure_ready());
+    Ctx& c = g_ctx;
+    if (!c.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    if (bytes > 0) {
+        HIP_TRY(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, c.copy_stream));
+        c.copy_pending = true;
+    }
+    return RDF_OK;
+}
+rdf_status rdf_copy_fence(void) {
+    RDF_TRY(ensure_ready());
+    Ctx& c = g_ctx;
+    if (c.copy_stream && c.copy_pending) HIP_TRY(hipStreamSynchronize(c.copy_stream));
+    c.copy_pending = false;
+    return RDF_OK;
+}
+
 rdf_status rdf_copy_d2h(void* dst_host, const void* src_dev, int64_t bytes) {
     RDF_TRY(ensure_ready());
     if (bytes > 0) {
