@@ -821,7 +821,7 @@ struct ShapeSigBuilder {
     ShapeSigBuilder(Compiler& c, SpecPlan& s, int* r) : cc(c), sp(s), rt(r) {}
     bool is_scalar(int idx) const { return cc.nodes[idx].kind == RDF_NODE_SCALAR; }
     bool is_column(int idx) const { return cc.nodes[idx].kind == RDF_NODE_COLUMN; }
-    static bool shape_dtype(int dt) { return dt == RDF_F64 || dt == RDF_I64 || dt == RDF_U64 || dt == RDF_F32 || dt == RDF_I32 || dt == RDF_U32 || dt == RDF_I16 || dt == RDF_U16; }
+    static bool shape_dtype(int dt) { return dt == RDF_F64 || dt == RDF_I64 || dt == RDF_U64 || dt == RDF_F32 || dt == RDF_I32 || dt == RDF_U32 || dt == RDF_I16 || dt == RDF_U16 || dt == RDF_I8 || dt == RDF_U8; }
     int strip(int idx) {   // skip no-op casts
         while (cc.nodes[idx].kind == RDF_NODE_OP && cc.nodes[idx].op == RDF_OP_CAST && cc.infer(cc.nodes[idx].lhs) == cc.nodes[idx].dtype) idx = cc.nodes[idx].lhs;
         return idx;

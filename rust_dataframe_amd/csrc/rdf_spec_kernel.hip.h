@@ -117,6 +117,8 @@ template <> struct AggT<RDF_I32> : AggNarrow<int32_t, AggT<RDF_I64>, false> {};
 template <> struct AggT<RDF_U32> : AggNarrow<uint32_t, AggT<RDF_U64>, false> {};
 template <> struct AggT<RDF_I16> : AggNarrow<int32_t, AggT<RDF_I64>, true> {};
 template <> struct AggT<RDF_U16> : AggNarrow<uint32_t, AggT<RDF_U64>, true> {};
+template <> struct AggT<RDF_I8> : AggNarrow<int32_t, AggT<RDF_I64>, true> {};      // 16 rows of 8 bits per iteration: no overflow in 32 bits either
+template <> struct AggT<RDF_U8> : AggNarrow<uint32_t, AggT<RDF_U64>, true> {};
 
 // Lane l of a 16-byte-load wave holds RV consecutive rows (RV = 2 for 8-byte, 4 for 4-byte elements), so
 // the RV per-element ballots must be interleaved into Arrow's row-ordered bitmap words.  Every lane j picks
@@ -156,7 +158,7 @@ struct Prog {
         else return 0;
     }
     static constexpr int W = cmax(cmax(cmax(colw<0>(), colw<1>()), cmax(colw<2>(), colw<3>())), out_width());
-    static_assert(W == 8 || W == 4 || W == 2, "the widest element of a program is 8, 4 or 2 bytes");
+    static_assert(W == 8 || W == 4 || W == 2 || W == 1, "the widest element of a program is 8, 4, 2 or 1 bytes");
     // rows per vector slot: a 16-byte vector of the widest type — except for predicates stored as bit masks, which load 8 bytes
     // per lane: with one f64 per lane a compare's lane mask IS the Arrow bitmap word of those 64 rows, and every halving of the
     // rows per lane halves the ballot-and-interleave work that puts the bits in row order (25.9 vector instructions per row
@@ -169,7 +171,7 @@ struct Prog {
     // rows per lane per iteration.  A 16-byte vector of 2-byte elements is 8 rows.  Measured on the 4-byte types: 8 rows pay for
     // a 3-column aggregate (0.62 -> 0.75 of peak: half the per-iteration overhead) but cost a 3-column store (0.70 -> 0.65) and
     // 4-column programs (0.75 -> 0.73) more in registers than they save
-    static constexpr int R = (NC <= 2 || W == 2 || (W == 4 && NC == 3 && SINK_ == SINK_AGG)) ? 8 : 4;
+    static constexpr int R = (W == 1 && !bool_store()) ? 16 : (NC <= 2 || W == 2 || (W == 4 && NC == 3 && SINK_ == SINK_AGG)) ? 8 : 4;   // Int8 / UInt8: a 16-byte vector is 16 rows
     static constexpr int U = R / RV;                  // 16-byte vectors per lane per column per iteration
     static std::string sig() { return "P:" + PRED::sig() + ";V:" + V0::sig() + ";" + V1::sig() + ";S:" + std::to_string(SINK_); }
 };
@@ -598,6 +600,28 @@ template <int DT, int FROM> static void reg_cast_pair() {
 template <int DT> static void reg_cast_family() {
     reg_cast_pair<DT, RDF_F64>(); reg_cast_pair<DT, RDF_I64>(); reg_cast_pair<DT, RDF_U64>(); reg_cast_pair<DT, RDF_F32>();
     reg_cast_pair<DT, RDF_I32>(); reg_cast_pair<DT, RDF_U32>(); reg_cast_pair<DT, RDF_I16>(); reg_cast_pair<DT, RDF_U16>();
+    // Int8 / UInt8 columns reach the path through casts and filters only (Evaluate::calculate rejects their arithmetic,
+    // src/evaluation.rs:239; Function::Cast accepts them, :296-315): a OP cast(b: i8), cast(b: i8), trig(cast(b: i8))
+    reg_cast_pair<DT, RDF_I8>(); reg_cast_pair<DT, RDF_U8>();
+}
+// the 1-byte types on their own: column aggregates, x CMP c -> mask / -> aggregates of x or of a column of type V, narrowing casts
+template <int B> static void reg_byte_family() {
+    using X = Col<0, B>;
+    using K = Imm<0, RDF_F64>;
+    reg_shape_list<PredNone<B>, B, SINK_AGG>(ShapeList<Lc>{});             // aggregates of the column
+    reg<Prog<None, Cast<RDF_F64, X>, None, SINK_AGG>>();                   // avg
+    reg_shape_list<Pred1<B>, B, SINK_AGG>(ShapeList<Lc>{});                // filter(x CMP c) -> aggregates of a 1-byte column
+    reg_shape_list<Pred2<B>, B, SINK_AGG>(ShapeList<Lc>{});
+    reg_shape_list<Pred1<B>, RDF_F64, SINK_AGG>(ShapeList<Lc>{});          // ... of an f64 / i64 measure (a flag or code column filters a fact table)
+    reg_shape_list<Pred1<B>, RDF_I64, SINK_AGG>(ShapeList<Lc>{});
+    reg<Prog<None, typename Pred2<B>::type, None, SINK_STORE>>();          // masks
+    reg<Prog<None, Bin<RDF_OP_GT, X, K>, None, SINK_STORE>>(); reg<Prog<None, Bin<RDF_OP_GE, X, K>, None, SINK_STORE>>();
+    reg<Prog<None, Bin<RDF_OP_EQ, X, K>, None, SINK_STORE>>(); reg<Prog<None, Bin<RDF_OP_NE, X, K>, None, SINK_STORE>>();
+    reg<Prog<None, Bin<RDF_OP_LT, X, K>, None, SINK_STORE>>(); reg<Prog<None, Bin<RDF_OP_LE, X, K>, None, SINK_STORE>>();
+    reg<Prog<None, Cast<B, Col<0, RDF_I64>>, None, SINK_STORE>>();         // narrowing casts into the 1-byte types
+    reg<Prog<None, Cast<B, Col<0, RDF_I32>>, None, SINK_STORE>>();
+    reg<Prog<None, Cast<B, Col<0, RDF_I16>>, None, SINK_STORE>>();
+    reg<Prog<None, Cast<B, Col<0, RDF_F64>>, None, SINK_STORE>>();
 }
 
 }  // namespace rdfk

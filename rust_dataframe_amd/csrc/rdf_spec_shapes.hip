@@ -44,6 +44,9 @@ void RDF_CAT(spec_register_shapes, RDF_SHAPE_TU)() {
     reg_shape_family_basic<RDF_U16, RDF_U16>();
     reg_shape_family_deep<RDF_I16, RDF_I16>();
     reg_shape_family_deep<RDF_U16, RDF_U16>();
+    // Int8 / UInt8: sixteen rows per 16-byte vector
+    reg_byte_family<RDF_I8>();
+    reg_byte_family<RDF_U8>();
 #else
     // operands of different types: a OP cast(b), cast(b), trig(cast(b)) over every pair of the eight types
     reg_cast_family<RDF_F64>(); reg_cast_family<RDF_I64>(); reg_cast_family<RDF_U64>(); reg_cast_family<RDF_F32>();
