@@ -418,7 +418,12 @@ struct Gb2Args {
     int32_t            replicas, sub_slots;   // LDS table = replicas sub-tables of sub_slots slots (lane % replicas picks one)
     int32_t            table_slots, pad2;     // slots of the block's LDS table (20 B each)
     int32_t            ablate, fast;          // fast: 8-byte keys / values, no bitmaps, 16-byte aligned chunks (host-checked); bench ablations of the scatter (rdf_set_option("gb_debug", 21..24)): results invalid
+    // skewed keys (capacity plan from the skew probe's histogram): partition p's regions start at line part_off[p] and hold
+    // part_cap[p] lines each (region (p, b) = part_off[p] + b * part_cap[p]); nullptr: every region holds cap_lines lines
+    const uint32_t*    part_off;
+    const uint32_t*    part_cap;
 };
+struct Gb2Work { int32_t p, b0, b1, multi; };   // aggregate work item: regions [b0, b1) of partition p; multi: the partition is cut into several items
 struct Gb2AggArgs {
     const uint64_t* recs;
     const uint32_t* nlines;              // [P * nb]
@@ -428,6 +433,13 @@ struct Gb2AggArgs {
     unsigned int*   cursor;
     uint32_t*       flags;
     int64_t         max_out;
+    // capacity plan (skewed keys): per-partition region layout, and a work list that cuts the big partitions into several
+    // items — their groups meet in the global table `t` (HBM atomics), the others are emitted straight from LDS as always
+    const uint32_t* part_off;
+    const uint32_t* part_cap;
+    const Gb2Work*  work;
+    int32_t         nwork, pad;
+    GroupTable      t;
 };
 // (key, accumulator, count) triples -> global table: the merge of partial groups (multi-GPU exchange) and the path for
 // more groups than LDS tables hold

@@ -475,8 +475,8 @@ __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args 
     if (tid == 0) abort_s = 0;
     __syncthreads();
     const uint32_t nb = gridDim.x, bid = blockIdx.x;
-    const uint32_t cap = (uint32_t)a.cap_lines;
-    const uint32_t region0 = tid < kP ? ((uint32_t)tid * nb + bid) * cap : 0;   // first line of this thread's partition's region
+    const uint32_t cap = tid < kP && a.part_cap ? as_const<uint32_t>(a.part_cap)[tid] : (uint32_t)a.cap_lines;   // lines of this thread's partition's region
+    const uint32_t region0 = tid < kP ? (a.part_off ? as_const<uint32_t>(a.part_off)[tid] + bid * cap : ((uint32_t)tid * nb + bid) * cap) : 0;   // its first line
     u64x2* const recs = (u64x2*)a.recs;
     uint32_t err = 0;
     constexpr int TPI = kG2Super / kEvalTile;
@@ -571,12 +571,54 @@ __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args 
         rec[0] = kDead; rec[1] = 0;
         if (l8 < c) rec = carry[d * kG2Line + l8];
         const uint32_t line = written[d];
-        if (line < cap) recs[((uint64_t)(d * nb + bid) * cap + line) * kG2Line + l8] = rec;
+        const uint32_t dcap = a.part_cap ? as_const<uint32_t>(a.part_cap)[d] : (uint32_t)a.cap_lines;
+        const uint64_t dreg = a.part_off ? (uint64_t)as_const<uint32_t>(a.part_off)[d] + (uint64_t)bid * dcap : (uint64_t)(d * nb + bid) * dcap;
+        if (line < dcap) recs[(dreg + line) * kG2Line + l8] = rec;
         else err |= 16u;
     }
     __syncthreads();
     if (tid < kP) a.nlines[(int64_t)tid * nb + bid] = written[tid] + (ccnt[tid] ? 1u : 0u);
     if (err) atomicOr(a.flags, err);
+}
+
+// A heavy partition is heavy because of a few keys: almost every record of such a partition carries the same hashed key, and
+// 64 lanes adding into ONE LDS slot serialise (the hot-key input measured 12.9 ms in this kernel against 2.8 ms for uniform
+// keys).  Before the table is touched, the lanes that hold the key of the wave's first pending lane reduce their contributions
+// with a butterfly and leave ONE record; two rounds per batch element take care of the two heaviest keys of a wave.
+__device__ __forceinline__ uint64_t g2_combine(int op, int cls, uint64_t a, uint64_t b) {
+    if (op == AGG_SUM) return cls == CLS_F64 ? d2u(u2d(a) + u2d(b)) : a + b;
+    if (op == AGG_MIN) return a < b ? a : b;
+    return a > b ? a : b;
+}
+template <int B>
+__device__ __forceinline__ void wave_combine(int op, int cls, const uint64_t (&hk)[B], uint64_t (&val)[B], uint32_t (&cnt)[B], uint32_t& pending) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+        bool active = (pending >> u) & 1;
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            const uint64_t m = __ballot(active);
+            if (__popcll(m) < 8) break;
+            const int leader = __builtin_ctzll(m);
+            const uint64_t lk = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(hk[u] >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)hk[u], leader);
+            const bool same = active && hk[u] == lk;
+            if (__popcll(__ballot(same)) >= 8) {
+                uint64_t v = same ? val[u] : agg_identity(op);
+                uint32_t c = same ? cnt[u] : 0u;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const uint64_t ov = shfl_xor64(v, d);
+                    const uint32_t oc = (uint32_t)__shfl_xor((int)c, d);
+                    v = g2_combine(op, cls, v, ov);
+                    c += oc;
+                }
+                if (lane == leader) { val[u] = v; cnt[u] = c; }
+                else if (same) pending &= ~(1u << u);
+            }
+            active = active && !same;
+        }
+    }
 }
 
 // pass 2: one block per partition; its records are the nb line ranges the scatter blocks wrote
@@ -595,24 +637,30 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
     const unsigned long long ident = agg_identity(a.op);
     uint32_t err = 0;
     const u64x2* const recs = (const u64x2*)a.recs;
-    for (int p = blockIdx.x; p < kP; p += gridDim.x) {
+    const int nitems = a.nwork > 0 ? a.nwork : kP;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        int p = item, rb0 = 0, rb1 = (int)a.nb, multi = 0;
+        if (a.nwork > 0) { const Gb2Work w = a.work[item]; p = w.p; rb0 = w.b0; rb1 = w.b1; multi = w.multi; }
+        const int64_t pcap = a.part_cap ? (int64_t)a.part_cap[p] : a.cap_lines;
+        const int64_t pline0 = a.part_off ? (int64_t)a.part_off[p] : (int64_t)p * a.nb * a.cap_lines;
         for (int i = tid; i < kG2Slots; i += kG2AggBlock) { t.keys[i] = kFree; t.acc[i] = ident; t.cnt[i] = 0; }
         if (tid == 0) *t.ngroups = 0;
         __syncthreads();
         const uint64_t ptop = (uint64_t)p << (64 - kG2PartBits);
-        // wave w streams the regions b = w, w + NW, ...: kAggBatch x 64 consecutive records per step, the next step's loads
-        // issued before the current step is folded into the table
-        int64_t b = (int64_t)wave - NW, off = 0, nrec = 0;
+        // every wave walks every region of the item and takes the batches w, w + NW, ... of kAggBatch x 64 consecutive records
+        // (whole regions per wave left most waves idle on an item that is a slice of a heavy partition: one or two regions);
+        // the next batch's loads are issued before the current one is folded into the table
+        int64_t b = (int64_t)rb0 - 1, off = 0, nrec = 0;
         const u64x2* base = recs;
         bool open = false;
         auto advance = [&]() {
             open = false;
-            for (b += NW; b < a.nb; b += NW) {
+            for (++b; b < rb1; ++b) {
                 nrec = (int64_t)a.nlines[(int64_t)p * a.nb + b] * kG2Line;
-                if (nrec > 0) { base = recs + ((int64_t)p * a.nb + b) * a.cap_lines * kG2Line; off = 0; open = true; return; }
+                if (nrec > (int64_t)wave * kAggBatch * 64) { base = recs + (pline0 + b * pcap) * kG2Line; off = (int64_t)wave * kAggBatch * 64; open = true; return; }
             }
         };
-        auto load_batch = [&](u64x2 (&r)[kAggBatch]) -> bool {   // false: this wave's regions are exhausted
+        auto load_batch = [&](u64x2 (&r)[kAggBatch]) -> bool {   // false: this wave's share of the item is exhausted
             if (!open) return false;
 #pragma unroll
             for (int u = 0; u < kAggBatch; ++u) {
@@ -620,7 +668,7 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
                 r[u][0] = kDead; r[u][1] = 0;
                 if (i < nrec) r[u] = __builtin_nontemporal_load(base + i);
             }
-            off += kAggBatch * 64;
+            off += (int64_t)NW * kAggBatch * 64;
             if (off >= nrec) advance();
             return true;
         };
@@ -638,6 +686,7 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
                 cnt[u] = (uint32_t)(cur[u][0] >> (64 - kG2PartBits));
                 if (cur[u][0] != kDead) pending |= 1u << u;
             }
+            if (multi) wave_combine<kAggBatch>(a.op, a.vcls, hk, val, cnt, pending);
             tab_upsert<kAggBatch, kG2PartBits>(t, a.op, a.vcls, a.has_values != 0, 0u, (uint32_t)kG2Slots, hk, val, cnt, pending, err, 32u);   // 32: this partition's LDS table is full — says nothing about max_groups, the host retries on the HBM table
             if (nhave) {
 #pragma unroll
@@ -646,6 +695,16 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
             have = nhave;
         }
         __syncthreads();
+        if (multi) {   // one of several items of a big partition: its groups meet the other items' in the global table
+            for (int k = tid; k < kG2Slots; k += kG2AggBlock) {
+                if (t.keys[k] == kFree) continue;
+                const uint64_t key = g2_unhash(t.keys[k]);
+                if (key == kGroupEmpty) g2_global_special(a.t, 0, a.op, a.vcls, a.has_values != 0, t.acc[k], t.cnt[k]);
+                else if (!g2_global_upsert(a.t, key, a.op, a.vcls, a.has_values != 0, t.acc[k], t.cnt[k])) err |= 4u;
+            }
+            __syncthreads();
+            continue;
+        }
         if (tid == 0) { misc[0] = atomicAdd(a.cursor, *t.ngroups); misc[1] = 0; }
         __syncthreads();
         for (int k = tid; k < kG2Slots; k += kG2AggBlock) {
@@ -886,7 +945,8 @@ hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s) {
 hipError_t launch_gb2_aggregate(const Gb2AggArgs& a, hipStream_t s) {
     const size_t lds = (size_t)kG2Slots * 20 + 32;
     (void)hipFuncSetAttribute((const void*)gb2_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gb2_aggregate_kernel, dim3(kP), dim3(kG2AggBlock), lds, s, a);
+    // work list (skewed keys): one block per CU walks the items with the grid's stride — the list is sorted largest first
+    hipLaunchKernelGGL(gb2_aggregate_kernel, dim3(a.nwork > 0 ? std::min(a.nwork, eval_grid_limit() / 8) : kP), dim3(kG2AggBlock), lds, s, a);
     return hipGetLastError();
 }
 static int g2_rows_grid(int64_t n) {

@@ -301,3 +301,40 @@ def test_groupby_merge_and_exchange_on_device(gpu, ora, agg):
     _assert_same_groups(got, exp, True, f"merge device {agg}")
     for d in (dk, dp, dc, packed, uk, up, uc) + outs:
         lib.load().rdf_dev_free(C.c_void_p(d.values_ptr))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agg", ["sum", "min", "count"])
+def test_groupby_skewed_keys_capacity_plan(gpu, ora, agg):
+    """Skewed keys on the second-generation path (rdf_set_option("gb_skew_plan", 2) forces the plan at test sizes): regions sized
+    per partition from the probe's histogram, the heavy partitions cut into several aggregate items whose groups meet in the
+    global table while the light ones are emitted straight from LDS.  One key holding a third of the rows, Zipf-like keys, a
+    run of equal keys at the end (the regions of the late blocks overflow -> the fallback path answers), the special keys."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(77)
+    n, ngroups = 600_000, 5000
+    zipf = np.minimum(rng.zipf(1.2, n), ngroups - 1).astype(np.int64) * 7919 - 3
+    hot = rng.integers(0, ngroups, n).astype(np.int64)
+    hot[rng.uniform(size=n) < 0.34] = 4242
+    tail = rng.integers(0, ngroups, n).astype(np.int64)
+    tail[-n // 5:] = 17
+    lib.set_option("gb_partition", 4)
+    lib.set_option("gb_skew_plan", 2)
+    try:
+        for name, kv in (("zipf", zipf), ("hot key", hot), ("late run", tail)):
+            kv = kv.copy()
+            kv[5], kv[6], kv[7] = np.iinfo(np.int64).min, np.iinfo(np.int64).max, np.int64(7406324358081711299)
+            keys = [A.HostArray.from_numpy(kv[:n // 3], valid=rng.uniform(size=n // 3) > 0.01, rng=rng), A.HostArray.from_numpy(kv[n // 3:], offset=5, rng=rng)]
+            vals = None if agg == "count" else [A.HostArray.from_numpy(rng.uniform(-1, 1, n // 3), valid=rng.uniform(size=n // 3) > 0.1, rng=rng),
+                                                A.HostArray.from_numpy(rng.uniform(-1, 1, n - n // 3), offset=5, rng=rng)]
+            exp = _groups(*ora.groupby_agg([keys], vals, agg, ngroups + 8))
+            got = _groups(*gpu.groupby_agg([keys], vals, agg, ngroups + 8))
+            if name != "late run":
+                assert "capacity plan" in lib.last_kernel(), (name, lib.last_kernel())
+            _assert_same_groups(got, exp, agg != "count", f"skew plan: {name} agg={agg}")
+        with pytest.raises(A.RdfError) as ei:          # the promise still holds on this path
+            gpu.groupby_agg([[A.HostArray.from_numpy(zipf)]], None, "count", 100)
+        assert ei.value.status == A.RDF_MEMORY_ERROR
+    finally:
+        lib.set_option("gb_partition", 3)
+        lib.set_option("gb_skew_plan", 1)

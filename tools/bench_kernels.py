@@ -84,12 +84,13 @@ def main():
         lib.set_option("fast_filter", 0)
     results = []
 
-    def report(name, alg_bytes, fn):
+    def report(name, alg_bytes, fn, rows=None):
+        """rows = the rows THIS entry processes (take / sort / join / list entries run on fewer rows than --rows)."""
         if only and name not in only:
             return
         wall, kern = timed(fn, args.steps)
         gbs = alg_bytes / kern / 1e9 if kern > 0 else 0.0
-        r = {"kernel": name, "rows": n, "alg_bytes": alg_bytes, "wall_ms": wall * 1e3, "kernel_ms": kern * 1e3,
+        r = {"kernel": name, "rows": n if rows is None else rows, "alg_bytes": alg_bytes, "wall_ms": wall * 1e3, "kernel_ms": kern * 1e3,
              "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 3)}
         results.append(r)
         print(json.dumps(r), flush=True)
@@ -206,10 +207,10 @@ def main():
     idx = torch.randint(0, n, (nidx,), dtype=torch.int64, device="cuda").to(torch.uint32 if hasattr(torch, "uint32") else torch.int32)
     I = A.DeviceArray(idx.data_ptr(), None, 0, nidx, A.U32, 0, keep=idx)
     ot = out_like(A.F64, nidx)
-    report("take_random_u32", (4 + 8 + 8) * nidx, lambda: api.take([X], I, ot))
+    report("take_random_u32", (4 + 8 + 8) * nidx, lambda: api.take([X], I, ot), rows=nidx)
     sidx = torch.arange(0, nidx, dtype=torch.int64, device="cuda").to(torch.uint32)
     S = A.DeviceArray(sidx.data_ptr(), None, 0, nidx, A.U32, 0, keep=sidx)
-    report("take_sequential_u32", (4 + 8 + 8) * nidx, lambda: api.take([X], S, ot))
+    report("take_sequential_u32", (4 + 8 + 8) * nidx, lambda: api.take([X], S, ot), rows=nidx)
     # take from / sort of a column in the reference's 1024-row batches (a 1e8-row prefix = 97 657 chunks): every element
     # resolves its chunk on its own (find_chunk_row)
     nsrc = min(n, 100_000_000)
@@ -218,11 +219,11 @@ def main():
     idx2 = torch.randint(0, nsrc, (nix,), dtype=torch.int64, device="cuda").to(torch.uint32)
     I2 = A.DeviceArray(idx2.data_ptr(), None, 0, nix, A.U32, 0, keep=idx2)
     ot2 = out_like(A.F64, nix)
-    report("take_random_u32_from_1024_row_chunks", (4 + 8 + 8) * nix, lambda: api.take(XS, I2, ot2))
+    report("take_random_u32_from_1024_row_chunks", (4 + 8 + 8) * nix, lambda: api.take(XS, I2, ot2), rows=nix)
     nks = min(nsrc, 50_000_000)
     KS1 = [A.DeviceArray(k.data_ptr() + i * 8, None, 0, min(1024, nks - i), A.I64, 0, keep=k) for i in range(0, nks, 1024)]
     oi2 = out_like(A.U32, nks)
-    report("sort_to_indices_i64_1024_row_chunks", 8.0 * nks, lambda: api.sort_to_indices([KS1], [False], oi2))
+    report("sort_to_indices_i64_1024_row_chunks", 8.0 * nks, lambda: api.sort_to_indices([KS1], [False], oi2), rows=nks)
     del XS, KS1, idx2
     # chunked device-resident columns (what a frame looks like after a filter): 1M-row chunks
     def chunked(t, dtype, rows=1 << 20):
@@ -236,11 +237,11 @@ def main():
     ns = min(n, 50_000_000)
     KS = arr(k, A.I64, ns)
     oi = out_like(A.U32, ns)
-    report("sort_to_indices_i64", 8.0 * ns, lambda: api.sort_to_indices([[KS]], [False], oi))   # keys in [-2^31, 2^31): 4 varying bytes + sign
+    report("sort_to_indices_i64", 8.0 * ns, lambda: api.sort_to_indices([[KS]], [False], oi), rows=ns)   # keys in [-2^31, 2^31): 4 varying bytes + sign
     kw = dev_i64(ns, 9, -2 ** 62, 2 ** 62)
-    report("sort_to_indices_i64_full_range", 8.0 * ns, lambda: api.sort_to_indices([[arr(kw, A.I64, ns)]], [False], oi))
+    report("sort_to_indices_i64_full_range", 8.0 * ns, lambda: api.sort_to_indices([[arr(kw, A.I64, ns)]], [False], oi), rows=ns)
     kd = dev_i64(ns, 10, 0, 200)
-    report("sort_to_indices_i64_dictionary_codes", 8.0 * ns, lambda: api.sort_to_indices([[arr(kd, A.I64, ns)]], [False], oi))
+    report("sort_to_indices_i64_dictionary_codes", 8.0 * ns, lambda: api.sort_to_indices([[arr(kd, A.I64, ns)]], [False], oi), rows=ns)
     # ArrayFunctions over a List<f64> column: rows of 10 elements (one row per lane) and of 1000 elements (one row per wave)
     for rl in (10, 1000):
         nm = f"list_rows_of_{rl}"
@@ -253,29 +254,29 @@ def main():
         L = A.DeviceList(lo_.data_ptr(), nr, arr(lv_, A.F64, nv), keep=(lo_, lv_))
         ob, op, om = out_like(A.BOOL, nr, True), out_like(A.I32, nr), out_like(A.F64, nr, True)
         lbytes = 8.0 * nv + 4.0 * nr
-        report(nm + "_contains", lbytes, lambda: api.list_contains(L, 7.0, ob))
-        report(nm + "_position", lbytes + 4.0 * nr, lambda: api.list_position(L, 7.0, op))
-        report(nm + "_max", lbytes + 8.0 * nr, lambda: api.list_extreme(L, True, om))
+        report(nm + "_contains", lbytes, lambda: api.list_contains(L, 7.0, ob), rows=nr)
+        report(nm + "_position", lbytes + 4.0 * nr, lambda: api.list_position(L, 7.0, op), rows=nr)
+        report(nm + "_max", lbytes + 8.0 * nr, lambda: api.list_extreme(L, True, om), rows=nr)
         oro, orv = out_like(A.I32, nr + 1), out_like(A.F64, nv)
-        report(nm + "_remove", 2 * lbytes + 8.0 * nv * 0.98 + 4.0 * nr, lambda: api.list_remove(L, 7.0, (oro, orv)))
+        report(nm + "_remove", 2 * lbytes + 8.0 * nv * 0.98 + 4.0 * nr, lambda: api.list_remove(L, 7.0, (oro, orv)), rows=nr)
         # the set-valued functions: reads in both passes (count, write) + the elements kept; quadratic compare work per row
         osd = (out_like(A.I32, nr + 1), out_like(A.F64, nv))
         kept = api.list_set("distinct", L, outs=osd)[1].length
-        report(nm + "_distinct", 2 * lbytes + 8.0 * kept + 4.0 * nr, lambda: api.list_set("distinct", L, outs=osd))
+        report(nm + "_distinct", 2 * lbytes + 8.0 * kept + 4.0 * nr, lambda: api.list_set("distinct", L, outs=osd), rows=nr)
         if rl == 10:
             lv2_ = torch.floor(dev_f64(nv, 14, 0.0, 50.0))
             L2 = A.DeviceList(lo_.data_ptr(), nr, arr(lv2_, A.F64, nv), keep=(lo_, lv2_))
             osu = (out_like(A.I32, nr + 1), out_like(A.F64, 2 * nv))
             kept = api.list_set("union", L, L2, outs=osu)[1].length
-            report(nm + "_union", 4 * lbytes + 8.0 * kept + 4.0 * nr, lambda: api.list_set("union", L, L2, outs=osu))
+            report(nm + "_union", 4 * lbytes + 8.0 * kept + 4.0 * nr, lambda: api.list_set("union", L, L2, outs=osu), rows=nr)
             kept = api.list_set("intersect", L, L2, outs=osd)[1].length
-            report(nm + "_intersect", 4 * lbytes + 8.0 * kept + 4.0 * nr, lambda: api.list_set("intersect", L, L2, outs=osd))
+            report(nm + "_intersect", 4 * lbytes + 8.0 * kept + 4.0 * nr, lambda: api.list_set("intersect", L, L2, outs=osd), rows=nr)
             del lv2_, osu
         if rl == 10:
             nsort = min(nv, 50_000_000)
             Ls = A.DeviceList(lo_.data_ptr(), nsort // rl, arr(lv_, A.F64, nsort), keep=(lo_, lv_))
             osv = out_like(A.F64, nsort)
-            report(nm + "_sort", 16.0 * nsort, lambda: api.list_sort(Ls, osv))
+            report(nm + "_sort", 16.0 * nsort, lambda: api.list_sort(Ls, osv), rows=nsort)
         del lo_, lv_
     # DataFrame::join: 1e8 probe rows against 1e7 distinct build keys (inner: every probe row finds exactly one partner)
     if not only or "join_inner_1e8_x_1e7" in only:
@@ -283,7 +284,7 @@ def main():
         lk_ = dev_i64(nl_, 12, 0, nr_)
         rk_ = torch.randperm(nr_, device="cuda", dtype=torch.int64)
         jl, jr = out_like(A.U32, nl_, True), out_like(A.U32, nl_, True)
-        report("join_inner_1e8_x_1e7", 8.0 * nl_ + 8.0 * nr_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk_, A.I64, nl_)], [arr(rk_, A.I64, nr_)], "inner", (jl, jr)))
+        report("join_inner_1e8_x_1e7", 8.0 * nl_ + 8.0 * nr_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk_, A.I64, nl_)], [arr(rk_, A.I64, nr_)], "inner", (jl, jr)), rows=nl_)
         del lk_, rk_
     # hash GROUP BY key -> sum(val): 1e6 groups (config C4's per-GPU leg) and 1e3 groups (contended)
     for ng in (1_000_000, 2_000, 1_000, 100, 8):
