@@ -90,6 +90,7 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
     __shared__ unsigned int dbase[256];                // tile-local start of each digit's run
     __shared__ int64_t gbase[256];                     // global start of this tile's part of each digit's run
     __shared__ unsigned int wsum[kOsWaves];
+    __shared__ unsigned int thist[256];                // the tile's digit counts, taken before the ranking so that they can be published early
     __shared__ int64_t tile_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t seq = (uint64_t)a.seq << 50;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
         if (threadIdx.x == 0) tile_s = (int64_t)atomicAdd((unsigned long long*)a.ticket, 1ull);
 #pragma unroll
         for (int w = 0; w < kOsWaves; ++w) whist[w][threadIdx.x] = 0;
+        thist[threadIdx.x] = 0;
         __syncthreads();
         const int64_t tile = tile_s;
         if (tile >= a.ntiles) break;
@@ -116,6 +118,23 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
             key[j] = in ? __builtin_nontemporal_load(as_global<uint64_t>(a.keys_in) + i) : 0;
             idx[j] = in ? (a.idx_in ? __builtin_nontemporal_load(as_global<uint32_t>(a.idx_in) + i) : (uint32_t)i) : 0;
         }
+        // The tile's digit counts first, with plain LDS adds, and PUBLISHED at once: every tile ticketed after this one waits for
+        // them in its look-back, and the ranking below (~6 us of dependent LDS round trips) then runs while this tile in turn
+        // waits for the tiles before it, instead of in front of everybody's wait.
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
+            int d = 0;
+            if (i < a.n) {
+                d = a.nullflags ? (int)as_global<uint8_t>(a.nullflags)[idx[j]] : os_digit(key[j], a.bias, a.shift);
+                atomicAdd(&thist[d], 1u);
+            }
+            digit[j] = d;
+        }
+        __syncthreads();
+        const unsigned int total_d = thist[threadIdx.x];
+        unsigned long long* st = a.state + tile * 256 + threadIdx.x;
+        if (tile > 0) __hip_atomic_store(st, seq | kOsLocal | total_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ranks inside the wave: the lanes of a row that share my digit (8 ballots); the run's first lane bumps the wave's counter
         // of the digit (plain read + write: the LDS serves a wave's instructions in order, rows are taken in order: stable).
         // (Measured alternatives, both slower on the whole sort: one returning LDS add per row issued back to back for all rows
@@ -125,9 +144,7 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
         for (int j = 0; j < ITEMS; ++j) {
             const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
             const bool in = i < a.n;
-            int d = 0;
-            if (in) d = a.nullflags ? (int)as_global<uint8_t>(a.nullflags)[idx[j]] : os_digit(key[j], a.bias, a.shift);
-            digit[j] = d;
+            const int d = digit[j];
             uint64_t peers = __ballot(in);
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
@@ -143,13 +160,13 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
         OS_TICK(c2);
         __syncthreads();
         OS_TICK(c3);
-        // ---- thread d: the waves' counts of digit d -> their offsets inside the run, the tile's total
-        unsigned int total_d = 0;
+        // ---- thread d: the waves' counts of digit d -> their offsets inside the run
+        {
+            unsigned int run = 0;
 #pragma unroll
-        for (int w = 0; w < kOsWaves; ++w) { const unsigned int c = whist[w][threadIdx.x]; whist[w][threadIdx.x] = total_d; total_d += c; }
-        // publish the tile's count of digit d, then look back for what lies before the tile
-        unsigned long long* st = a.state + tile * 256 + threadIdx.x;
-        if (tile > 0) __hip_atomic_store(st, seq | kOsLocal | total_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int w = 0; w < kOsWaves; ++w) { const unsigned int c = whist[w][threadIdx.x]; whist[w][threadIdx.x] = run; run += c; }
+        }
+        // look back for what lies before the tile
         unsigned int inc = total_d;
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) { const unsigned int o = __shfl_up(inc, dd); if (lane >= dd) inc += o; }
