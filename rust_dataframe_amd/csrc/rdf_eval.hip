@@ -71,57 +71,100 @@ __device__ __forceinline__ uint64_t cast_value(int from, int to, uint64_t x, boo
 __device__ __forceinline__ uint64_t cast_value(int from, int to, uint64_t x) { bool ok; return cast_value(from, to, x, ok); }
 
 // ------------------------------------------------------------------------------------------------
-// column loads: row(j) of this lane = r0 + 256*wave + 64*j + lane
+// column loads.  A wave owns 256 consecutive rows of its tile; lane l holds rows 4 l .. 4 l + 3 (row(j) = rw + 4 l + j), so
+// a full tile of an aligned column comes in with ONE 16-byte load per lane for 4-byte types, two for 8-byte types (8 / 4
+// bytes for 2- / 1-byte types) — the interpreter used to load one element per lane and instruction (row(j) = rw + 64 j + l),
+// which was most of its distance to the specialised kernels on narrow types.  Partial tiles and columns whose chunk does not
+// start on a vector boundary take one load per element of the same rows.
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+typedef uint8_t u8x4 __attribute__((ext_vector_type(4)));
+
+// the lane's 4 bits (rows 4 l .. 4 l + 3) of a 256-bit window held as four 64-bit words
+__device__ __forceinline__ uint32_t lane_nibble(const uint64_t (&w)[kVPT], int lane) {
+    const int q = lane >> 4;
+    const uint64_t word = q == 0 ? w[0] : q == 1 ? w[1] : q == 2 ? w[2] : w[3];
+    return (uint32_t)(word >> ((lane & 15) * 4)) & 15u;
+}
+// the inverse: every lane's 4 bits -> the four 64-bit words of the wave's 256 rows (valid in lanes 0, 16, 32, 48: word lane / 16)
+__device__ __forceinline__ uint64_t nibbles_to_word(uint32_t nib, int lane) {
+    uint64_t x = (uint64_t)(nib & 15u) << ((lane & 15) * 4);
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) x |= shfl_xor64(x, m);
+    return x;
+}
 
 __device__ __forceinline__ void load_col(const DevChunkCol cc, int dt, int64_t rw, int64_t clen, uint32_t inr,
                                          uint64_t (&v)[kVPT], uint32_t& valid) {
     // rw = first row of this wave's 256-row span (wave-uniform)
     const int lane = threadIdx.x & 63;
-    const int64_t e0 = cc.offset + rw + lane;
+    const int64_t e0 = cc.offset + rw + (int64_t)lane * kVPT;
+    const bool full = __ballot(inr != (1u << kVPT) - 1) == 0;    // every row of every lane exists
     switch (dt) {
         case RDF_I64: case RDF_U64: case RDF_F64: {
             const GlobalPtr<uint64_t> p = as_global<uint64_t>(cc.values) + e0;
+            if (full && (((uintptr_t)cc.values + (uintptr_t)(cc.offset + rw) * 8) & 15) == 0) {
+                typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+                const u64x2 a0 = __builtin_nontemporal_load((GlobalPtr<u64x2>)p), a1 = __builtin_nontemporal_load((GlobalPtr<u64x2>)p + 1);
+                v[0] = a0[0]; v[1] = a0[1]; v[2] = a1[0]; v[3] = a1[1];
+            } else {
 #pragma unroll
-            for (int j = 0; j < kVPT; ++j) v[j] = (inr >> j) & 1 ? __builtin_nontemporal_load(p + j * 64) : 0;
+                for (int j = 0; j < kVPT; ++j) v[j] = (inr >> j) & 1 ? __builtin_nontemporal_load(p + j) : 0;
+            }
         } break;
         case RDF_I32: case RDF_U32: case RDF_F32: {
             const GlobalPtr<uint32_t> p = as_global<uint32_t>(cc.values) + e0;
+            uint32_t t[kVPT];
+            if (full && (((uintptr_t)cc.values + (uintptr_t)(cc.offset + rw) * 4) & 15) == 0) {
+                const u32x4 a0 = __builtin_nontemporal_load((GlobalPtr<u32x4>)p);
+                t[0] = a0[0]; t[1] = a0[1]; t[2] = a0[2]; t[3] = a0[3];
+            } else {
 #pragma unroll
-            for (int j = 0; j < kVPT; ++j) {
-                uint32_t t = (inr >> j) & 1 ? __builtin_nontemporal_load(p + j * 64) : 0;
-                v[j] = dt == RDF_I32 ? (uint64_t)(int64_t)(int32_t)t : (uint64_t)t;
+                for (int j = 0; j < kVPT; ++j) t[j] = (inr >> j) & 1 ? __builtin_nontemporal_load(p + j) : 0;
             }
+#pragma unroll
+            for (int j = 0; j < kVPT; ++j) v[j] = dt == RDF_I32 ? (uint64_t)(int64_t)(int32_t)t[j] : (uint64_t)t[j];
         } break;
         case RDF_I16: case RDF_U16: {
             const GlobalPtr<uint16_t> p = as_global<uint16_t>(cc.values) + e0;
+            uint16_t t[kVPT];
+            if (full && (((uintptr_t)cc.values + (uintptr_t)(cc.offset + rw) * 2) & 7) == 0) {
+                const u16x4 a0 = __builtin_nontemporal_load((GlobalPtr<u16x4>)p);
+                t[0] = a0[0]; t[1] = a0[1]; t[2] = a0[2]; t[3] = a0[3];
+            } else {
 #pragma unroll
-            for (int j = 0; j < kVPT; ++j) {
-                uint16_t t = (inr >> j) & 1 ? p[j * 64] : (uint16_t)0;
-                v[j] = dt == RDF_I16 ? (uint64_t)(int64_t)(int16_t)t : (uint64_t)t;
+                for (int j = 0; j < kVPT; ++j) t[j] = (inr >> j) & 1 ? p[j] : (uint16_t)0;
             }
+#pragma unroll
+            for (int j = 0; j < kVPT; ++j) v[j] = dt == RDF_I16 ? (uint64_t)(int64_t)(int16_t)t[j] : (uint64_t)t[j];
         } break;
         case RDF_I8: case RDF_U8: {
             const GlobalPtr<uint8_t> p = as_global<uint8_t>(cc.values) + e0;
+            uint8_t t[kVPT];
+            if (full && (((uintptr_t)cc.values + (uintptr_t)(cc.offset + rw)) & 3) == 0) {
+                const u8x4 a0 = __builtin_nontemporal_load((GlobalPtr<u8x4>)p);
+                t[0] = a0[0]; t[1] = a0[1]; t[2] = a0[2]; t[3] = a0[3];
+            } else {
 #pragma unroll
-            for (int j = 0; j < kVPT; ++j) {
-                uint8_t t = (inr >> j) & 1 ? p[j * 64] : (uint8_t)0;
-                v[j] = dt == RDF_I8 ? (uint64_t)(int64_t)(int8_t)t : (uint64_t)t;
+                for (int j = 0; j < kVPT; ++j) t[j] = (inr >> j) & 1 ? p[j] : (uint8_t)0;
             }
+#pragma unroll
+            for (int j = 0; j < kVPT; ++j) v[j] = dt == RDF_I8 ? (uint64_t)(int64_t)(int8_t)t[j] : (uint64_t)t[j];
         } break;
         default: {  // RDF_BOOL: bit-packed values
             uint64_t w[kVPT];
             load_windows<kVPT>((const uint8_t*)cc.values, cc.offset + rw, clen - rw, w);
+            const uint32_t nib = lane_nibble(w, lane);
 #pragma unroll
-            for (int j = 0; j < kVPT; ++j) v[j] = (w[j] >> lane) & 1;
+            for (int j = 0; j < kVPT; ++j) v[j] = (nib >> j) & 1;
         }
     }
     valid = (1u << kVPT) - 1;
     if (cc.validity) {
         uint64_t w[kVPT];
         load_windows<kVPT>(cc.validity, cc.offset + rw, clen - rw, w);
-        valid = 0;
-#pragma unroll
-        for (int j = 0; j < kVPT; ++j) valid |= (uint32_t)((w[j] >> lane) & 1) << j;
+        valid = lane_nibble(w, lane);
     }
 }
 
@@ -367,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
         const int64_t rw_ = t.r0 + (int64_t)wave * (kVPT * 64);
         uint32_t m = 0;
 #pragma unroll
-        for (int j = 0; j < kVPT; ++j) m |= (uint32_t)(rw_ + j * 64 + lane < t.clen) << j;
+        for (int j = 0; j < kVPT; ++j) m |= (uint32_t)(rw_ + (int64_t)lane * kVPT + j < t.clen) << j;
         return m;
     };
     uint64_t pfv[PF ? NPRE : 1][kVPT];
@@ -560,30 +603,61 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
                         const DevOutChunk oc = a.nchunks == 1 ? a.inline_outs[k & (kMaxValues - 1)] : a.outs[(int64_t)k * a.nchunks + c];
                         const int dt = in.dtype;
                         uint32_t nn = 0;
+                        // the lane's rows 4 l .. 4 l + 3 leave as one vector store (two for 8-byte values) when the tile is full;
+                        // bitmaps: the lanes' nibbles are OR-reduced over groups of 16 lanes into the four words of the wave's rows
+                        const int64_t row0 = rw + (int64_t)lane * kVPT;
+                        const bool fullt = __ballot(inr != (1u << kVPT) - 1) == 0;
+                        uint64_t vv[kVPT];
 #pragma unroll
-                        for (int j = 0; j < kVPT; ++j) {
-                            const int64_t row = rw + j * 64 + lane;
-                            const bool ok = (inr >> j) & 1;
-                            const bool valid = (accv >> j) & 1;
-                            const uint64_t v = valid ? acc[j] : 0;  // null slots hold 0
-                            const uint64_t ib = __ballot(ok);
-                            if (dt == RDF_BOOL) {
-                                const uint64_t bits = __ballot(ok && valid && (v & 1));
-                                if (lane == 0 && ib) as_global_mut<uint64_t>(oc.values)[(rw + j * 64) >> 6] = bits;
-                            } else if (ok) {
-                                switch (dt) {
-                                    case RDF_I64: case RDF_U64: case RDF_F64: __builtin_nontemporal_store(v, as_global_mut<uint64_t>(oc.values) + row); break;
-                                    case RDF_I32: case RDF_U32: case RDF_F32: __builtin_nontemporal_store((uint32_t)v, as_global_mut<uint32_t>(oc.values) + row); break;
-                                    case RDF_I16: case RDF_U16: as_global_mut<uint16_t>(oc.values)[row] = (uint16_t)v; break;
-                                    default: as_global_mut<uint8_t>(oc.values)[row] = (uint8_t)v; break;
+                        for (int j = 0; j < kVPT; ++j) vv[j] = ((accv >> j) & 1) ? acc[j] : 0;   // null slots hold 0
+                        const uint32_t live = accv & inr;
+                        if (dt == RDF_BOOL) {
+                            uint32_t bits = 0;
+#pragma unroll
+                            for (int j = 0; j < kVPT; ++j) bits |= (uint32_t)(((live >> j) & 1) && (vv[j] & 1)) << j;
+                            const uint64_t word = nibbles_to_word(bits, lane);
+                            const uint64_t any = nibbles_to_word(inr, lane);
+                            if ((lane & 15) == 0 && any) as_global_mut<uint64_t>(oc.values)[(rw >> 6) + (lane >> 4)] = word;
+                        } else {
+                            const int es = dt == RDF_I64 || dt == RDF_U64 || dt == RDF_F64 ? 8 : dt == RDF_I32 || dt == RDF_U32 || dt == RDF_F32 ? 4 : dt == RDF_I16 || dt == RDF_U16 ? 2 : 1;
+                            const bool vec = fullt && (((uintptr_t)oc.values + (uintptr_t)rw * (uintptr_t)es) & (es >= 4 ? 15 : es == 2 ? 7 : 3)) == 0;
+                            if (vec) {
+                                switch (es) {
+                                    case 8: {
+                                        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+                                        u64x2 s0, s1; s0[0] = vv[0]; s0[1] = vv[1]; s1[0] = vv[2]; s1[1] = vv[3];
+                                        GlobalMutPtr<u64x2> q = (GlobalMutPtr<u64x2>)(as_global_mut<uint64_t>(oc.values) + row0);
+                                        __builtin_nontemporal_store(s0, q); __builtin_nontemporal_store(s1, q + 1);
+                                    } break;
+                                    case 4: { u32x4 s0; s0[0] = (uint32_t)vv[0]; s0[1] = (uint32_t)vv[1]; s0[2] = (uint32_t)vv[2]; s0[3] = (uint32_t)vv[3];
+                                              __builtin_nontemporal_store(s0, (GlobalMutPtr<u32x4>)(as_global_mut<uint32_t>(oc.values) + row0)); } break;
+                                    case 2: { u16x4 s0; s0[0] = (uint16_t)vv[0]; s0[1] = (uint16_t)vv[1]; s0[2] = (uint16_t)vv[2]; s0[3] = (uint16_t)vv[3];
+                                              __builtin_nontemporal_store(s0, (GlobalMutPtr<u16x4>)(as_global_mut<uint16_t>(oc.values) + row0)); } break;
+                                    default: { u8x4 s0; s0[0] = (uint8_t)vv[0]; s0[1] = (uint8_t)vv[1]; s0[2] = (uint8_t)vv[2]; s0[3] = (uint8_t)vv[3];
+                                               __builtin_nontemporal_store(s0, (GlobalMutPtr<u8x4>)(as_global_mut<uint8_t>(oc.values) + row0)); } break;
                                 }
-                            }
-                            const uint64_t vb = __ballot(ok && valid);
-                            if (lane == 0 && ib) {
-                                if (oc.validity) as_global_mut<uint64_t>(oc.validity)[(rw + j * 64) >> 6] = vb;
-                                nn += (uint32_t)__popcll(ib & ~vb);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < kVPT; ++j)
+                                    if ((inr >> j) & 1) {
+                                        switch (es) {
+                                            case 8: __builtin_nontemporal_store(vv[j], as_global_mut<uint64_t>(oc.values) + row0 + j); break;
+                                            case 4: __builtin_nontemporal_store((uint32_t)vv[j], as_global_mut<uint32_t>(oc.values) + row0 + j); break;
+                                            case 2: as_global_mut<uint16_t>(oc.values)[row0 + j] = (uint16_t)vv[j]; break;
+                                            default: as_global_mut<uint8_t>(oc.values)[row0 + j] = (uint8_t)vv[j]; break;
+                                        }
+                                    }
                             }
                         }
+                        {
+                            const uint64_t vword = nibbles_to_word(live, lane);
+                            const uint64_t iword = nibbles_to_word(inr, lane);
+                            if ((lane & 15) == 0 && iword) {
+                                if (oc.validity) as_global_mut<uint64_t>(oc.validity)[(rw >> 6) + (lane >> 4)] = vword;
+                                nn += (uint32_t)__popcll(iword & ~vword);
+                            }
+                        }
+                        nn = (uint32_t)__shfl((int)nn, 0) + (uint32_t)__shfl((int)nn, 16) + (uint32_t)__shfl((int)nn, 32) + (uint32_t)__shfl((int)nn, 48);
 #pragma unroll
                         for (int kk = 0; kk < NVAL; ++kk)
                             if (kk == k) nullacc[kk] += nn;
