@@ -61,7 +61,8 @@ def main():
     os.makedirs(dst, exist_ok=True)
     bench = json.loads(open(os.path.join(src, "bench_1e9.json")).read().strip().splitlines()[-1])
     for name in ("bench_1e9.json", "bench_1e9_under_rocprof.json", "bench_1e9_1024_row_batches.json", "bench_1e9_validity.json",
-                 "kernels_1e9_microbench.jsonl", "shapes_2p5e8.jsonl", "ubench_scatter.txt"):
+                 "kernels_1e9_microbench.jsonl", "shapes_2p5e8.jsonl", "ubench_scatter.txt", "frames_1e9.jsonl", "ingest.jsonl", "bytes_2p5e8.jsonl",
+                 "rccl_one_rank.jsonl", "c4_total_rows_1e9.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
     for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
@@ -70,7 +71,8 @@ def main():
         shutil.copy(os.path.join(src, "workloads.jsonl"), os.path.join(dst, f"{rnd}_workloads_c3_c4_q1.jsonl"))
     note = "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024: gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM / rocprofv3 section); one --pmc counter per pass, kernel trace only"
     pmc = {"round": int(rnd[1:]), "note": note, "commands": "tools/profile_round.sh (function pmc)"}
-    tags = ["headline", "c3", "c4", "q1"] + sorted(os.path.basename(d)[4:-11] for d in glob.glob(os.path.join(src, "pmc_micro_*_FETCH_SIZE")))
+    tags = ["headline", "c3", "c4", "q1"] + sorted(os.path.basename(d)[4:-11] for d in glob.glob(os.path.join(src, "pmc_micro_*_FETCH_SIZE"))) \
+        + sorted(os.path.basename(d)[4:-11] for d in glob.glob(os.path.join(src, "pmc_frames_*_FETCH_SIZE")))
     for tag in tags:
         pmc[tag] = pmc_table(src, tag)
     json.dump(pmc, open(os.path.join(dst, f"{rnd}_pmc_hbm_traffic_by_kernel.json"), "w"), indent=1)

@@ -41,6 +41,20 @@ fi
 for e in filter_1col filter_2col filter_1col_selectivity_1_16 take_random_u32 take_sequential_u32 groupby_sum_1000_groups; do
     pmc micro_$e python "$REPO/tools/bench_kernels.py" --rows 1000000000 --steps 3 --only $e
 done
+# 3c. round 3: frame-level operators on 976 563 batches of 1024 rows (wall against kernel time), ingestion, Int8 / UInt8 kernels,
+#     the multi-GPU code path on a 1-rank RCCL communicator (every collective on device tensors), PMC of the frame take paths
+if [ "$PART" = "all" ] || [ "$PART" = "r3" ]; then
+python "$REPO/tools/bench_frames.py" 2> "$OUT/frames.err" | grep kernel_ms > "$OUT/frames_1e9.jsonl"
+python "$REPO/tools/bench_ingest.py" 2> "$OUT/ingest.err" | grep '"case"' > "$OUT/ingest.jsonl"
+python "$REPO/tools/bench_bytes.py" 2> "$OUT/bytes.err" | grep program > "$OUT/bytes_2p5e8.jsonl"
+rm -f "$OUT/rccl_one_rank.jsonl"
+for w in headline c4 q1; do python "$REPO/bench.py" --workload $w --rows 200000000 --steps 10 --warmup 3 --cpu-sample 0 --force-exchange --backend nccl 2>> "$OUT/rccl.err" | tail -1 >> "$OUT/rccl_one_rank.jsonl"; done
+RDF_C4_SHUFFLE_ROWS=1 python "$REPO/bench.py" --workload c4 --rows 200000000 --steps 10 --warmup 3 --cpu-sample 0 --force-exchange --backend nccl 2>> "$OUT/rccl.err" | tail -1 >> "$OUT/rccl_one_rank.jsonl"
+python "$REPO/bench.py" --workload c4 --total-rows 1000000000 --steps 10 --warmup 3 --cpu-sample 0 2>> "$OUT/rccl.err" | tail -1 > "$OUT/c4_total_rows_1e9.json"
+for e in take_frame_random_1col take_frame_random_4col; do
+    pmc frames_$e python "$REPO/tools/bench_frames.py" --steps 2 --only $e
+done
+fi
 # 4. the scatter micro-benchmark behind the C4 bound
 if [ -x "$REPO/tools/ubench_scatter.bin" ]; then timeout 300 "$REPO/tools/ubench_scatter.bin" > "$OUT/ubench_scatter.txt" 2>&1; fi
 # keep the merged payload small: the raw traces stay on the box, the stats / counter CSVs travel
