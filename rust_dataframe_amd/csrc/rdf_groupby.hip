@@ -686,7 +686,7 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
                 cnt[u] = (uint32_t)(cur[u][0] >> (64 - kG2PartBits));
                 if (cur[u][0] != kDead) pending |= 1u << u;
             }
-            if (multi) wave_combine<kAggBatch>(a.op, a.vcls, hk, val, cnt, pending);
+            if (a.nwork > 0) wave_combine<kAggBatch>(a.op, a.vcls, hk, val, cnt, pending);   // skewed input: also the partitions that were not cut hold keys that fill a third of a wave
             tab_upsert<kAggBatch, kG2PartBits>(t, a.op, a.vcls, a.has_values != 0, 0u, (uint32_t)kG2Slots, hk, val, cnt, pending, err, 32u);   // 32: this partition's LDS table is full — says nothing about max_groups, the host retries on the HBM table
             if (nhave) {
 #pragma unroll
