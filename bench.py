@@ -233,7 +233,7 @@ def workload_c4(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, 
             tot = [t[0].item(), int(t[1].item()), int(t[2].item())]
         ok = (len(np.unique(hk)) == n and int(hc.min(initial=1)) >= 1 and tot[1] == total and _close(tot[0], col_sum, 1e-9)
               and tot[2] <= ngroups and (total < 20 * ngroups or tot[2] == ngroups) and (n == 0 or (0 <= hk.min() and hk.max() < ngroups)))
-        out = {"self_check": bool(ok), "groups_total": tot[2]}
+        out = {"self_check": bool(ok), "groups_total": tot[2], "check_totals": {"sum_of_group_sums": tot[0], "column_sum": col_sum, "sum_of_group_counts": tot[1], "rows": total}}
         if rank == 0:
             from oracle import oracle
             o = oracle.api()

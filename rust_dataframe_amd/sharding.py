@@ -301,6 +301,44 @@ class GroupExchange:
                       "exchange_bytes_sent_remote": int(sum(c for r, c in enumerate(send_counts) if r != me)) * width,
                       "exchange_bytes_received": int(sum(recv_counts)) * width}
 
+    # One all_to_all_single call moves at most this many bytes out of a rank.  Measured on this image (torch 2.10 + RCCL 2.26.6,
+    # tools/rccl_a2a_probe.py): a call whose buffer passes ~1 GiB delivers only the first half of it on a 1-rank communicator
+    # (0.96 GB arrives whole, 1.12 GB does not) without any error — the exchange is therefore cut into rounds well below that.
+    MAX_BYTES_PER_CALL = int(__import__("os").environ.get("RDF_A2A_MAX_BYTES", 256 << 20))   # (the tests shrink it to run the rounds on small inputs)
+
+    def _all_to_all_rows(self, send, send_counts, recv_counts, width):
+        """send: [n, width] int64 rows grouped by destination rank (send_counts[r] rows for rank r) -> [m, width] rows received,
+        grouped by round and source rank (the consumers aggregate the rows: their order is free).  Collective."""
+        import torch.distributed as dist
+        torch = self.torch
+        world = dist.get_world_size()
+        cd = self.comm_dev if self.comm_dev is not None else "cpu"
+        m = sum(recv_counts)
+        chunk = max(1, self.MAX_BYTES_PER_CALL // (8 * width) // world)          # rows per (round, destination)
+        rounds = max(1, max((c + chunk - 1) // chunk for c in list(send_counts) + list(recv_counts)))
+        if rounds == 1:
+            if self.comm_dev is None:
+                send = send.cpu()
+            recv = torch.empty((m, width), dtype=torch.int64, device=cd)
+            dist.all_to_all_single(recv, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
+            return recv if self.comm_dev is not None else recv.to(self.dev)
+        starts = [0]
+        for c in send_counts:
+            starts.append(starts[-1] + c)
+        recv = torch.empty((m, width), dtype=torch.int64, device=self.dev)
+        at = 0
+        for r in range(rounds):
+            ins = [max(0, min(chunk, c - r * chunk)) for c in send_counts]
+            outs = [max(0, min(chunk, c - r * chunk)) for c in recv_counts]
+            part = torch.cat([send[starts[o] + r * chunk: starts[o] + r * chunk + ins[o]] for o in range(world)]) if sum(ins) else send[:0]
+            if self.comm_dev is None:
+                part = part.cpu()
+            got = torch.empty((sum(outs), width), dtype=torch.int64, device=cd)
+            dist.all_to_all_single(got, part, output_split_sizes=outs, input_split_sizes=ins)
+            recv[at:at + sum(outs)] = got if self.comm_dev is not None else got.to(self.dev)
+            at += sum(outs)
+        return recv
+
     def _merged(self, kdt, sdt):
         from ._abi import I64, DeviceArray
         return tuple(DeviceArray(b.data_ptr(), None, 0, self.cap, dt, 0, keep=b) for b, dt in zip(self._bufs, (kdt, sdt, I64)))
@@ -326,13 +364,7 @@ class GroupExchange:
         dist.all_to_all_single(t_rc, t_sc)
         recv_counts = [int(x) for x in t_rc.tolist()]
         m = sum(recv_counts)
-        send = self.packed[:3 * n].view(n, 3)
-        if self.comm_dev is None:                                     # CPU-only backend: stage for the collective alone
-            send = send.cpu()
-        recv = torch.empty((m, 3), dtype=torch.int64, device=cd)
-        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts)
-        if self.comm_dev is None:
-            recv = recv.to(self.dev)
+        recv = self._all_to_all_rows(self.packed[:3 * n].view(n, 3), send_counts, recv_counts, 3)   # CPU-only backend: staged for the collective alone
         torch.cuda.current_stream().synchronize()                     # the library reads `recv` on its own stream
         cols = [torch.empty(m + 8, dtype=torch.int64, device=self.dev) for _ in range(3)]
         rk, rs, rc = (DeviceArray(t.data_ptr(), None, 0, m, dt, 0, keep=t, capacity=m) for t, dt in zip(cols, (gk.dtype, gs.dtype, gc.dtype)))
@@ -362,13 +394,7 @@ class GroupExchange:
         dist.all_to_all_single(t_rc, t_sc)
         recv_counts = [int(x) for x in t_rc.tolist()]
         m = sum(recv_counts)
-        send = self._rows_packed[:2 * n].view(n, 2)
-        if self.comm_dev is None:
-            send = send.cpu()
-        recv = torch.empty((m, 2), dtype=torch.int64, device=cd)
-        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts)
-        if self.comm_dev is None:
-            recv = recv.to(self.dev)
+        recv = self._all_to_all_rows(self._rows_packed[:2 * n].view(n, 2), send_counts, recv_counts, 2)
         cols = [torch.empty(m + 8, dtype=torch.int64, device=self.dev) for _ in range(2)]
         rk, rv = (DeviceArray(t.data_ptr(), None, 0, m, dt, 0, keep=t, capacity=m) for t, dt in zip(cols, (K.dtype, V.dtype)))
         torch.cuda.current_stream().synchronize()

@@ -135,3 +135,15 @@ def test_rccl_one_rank_communicator(workload, env):
         assert cfg["result"]["exchange_bytes_sent_remote"] == 0
     else:
         assert cfg["result"] == ref["result"]
+
+
+def test_exchange_in_rounds():
+    """all_to_all_single calls are kept below 256 MiB (a call past ~1 GiB delivers half its buffer on this RCCL: see
+    tools/rccl_a2a_probe.py): with the cap shrunk to 1 MiB both exchanges of the group-by run in dozens of rounds — 2 ranks under
+    gloo, 1 rank under RCCL — and still produce every group once."""
+    for env in ({}, {"RDF_C4_SHUFFLE_ROWS": "1"}):
+        two = _run("c4", 2, 6_000_000, 0, launcher="self", RDF_A2A_MAX_BYTES=str(1 << 20), **env)
+        cfg = two["config"]
+        assert cfg["self_check"] is True and cfg["parity_on_sample"] is True and 999_000 < cfg["groups_total"] <= 1_000_000, cfg
+        one = _run("c4", 1, 12_000_000, 0, flags=["--force-exchange", "--backend", "nccl"], RDF_A2A_MAX_BYTES=str(1 << 20), **env)
+        assert one["config"]["self_check"] is True and one["config"]["groups_total"] == cfg["groups_total"], one["config"]
