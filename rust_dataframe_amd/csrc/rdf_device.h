@@ -556,6 +556,7 @@ struct TakeRowsArgs {                      // take through interleaved row recor
     DevOutChunk        outs[kMaxRowSlots];
 };
 hipError_t launch_take_rows(const TakeRowsArgs& a, hipStream_t s);
+hipError_t launch_idx_locality(const DevChunkCol& indices, int64_t n, bool idx64, unsigned int* near, hipStream_t s);   // *near (zeroed) += sampled neighbours (of 4096) less than 64 rows apart
 hipError_t launch_frame_totals(const int64_t* tile_scan, const int64_t* chunk_tile_start, int64_t nchunks, int64_t* out_len, int64_t* padded, hipStream_t s);
 hipError_t launch_frame_tables(const FrameTabArgs& a, hipStream_t s);
 hipError_t launch_frame_mask_tables(const int64_t* pos, int64_t nchunks, uint8_t* values, uint8_t* validity, DevOutChunk* outs, DevChunkCol* cols, hipStream_t s);

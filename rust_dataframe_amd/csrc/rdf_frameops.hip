@@ -319,6 +319,28 @@ hipError_t launch_take_rows(const TakeRowsArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// How local is an index list?  4096 sampled neighbours: |idx[i + 1] - idx[i]| < 64 rows counts as "near".  A sorted or
+// sequential list gathers whole lines column by column at streaming speed and must not take the row-record detour.
+template <typename IDX>
+__global__ __launch_bounds__(kBlock) void idx_locality_kernel(const DevChunkCol indices, int64_t n, unsigned int* near) {
+    const int64_t samples = 4096;
+    unsigned int c = 0;
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < samples; s += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = (n - 1) / samples * s;
+        if (i + 1 < n) {
+            const int64_t a0 = (int64_t)as_global<IDX>(indices.values)[indices.offset + i], a1 = (int64_t)as_global<IDX>(indices.values)[indices.offset + i + 1];
+            const int64_t d = a1 - a0;
+            c += (d < 64 && d > -64) ? 1u : 0u;
+        }
+    }
+    if (c) atomicAdd(near, c);
+}
+hipError_t launch_idx_locality(const DevChunkCol& indices, int64_t n, bool idx64, unsigned int* near, hipStream_t s) {
+    if (idx64) hipLaunchKernelGGL((idx_locality_kernel<uint64_t>), dim3(16), dim3(kBlock), 0, s, indices, n, near);
+    else hipLaunchKernelGGL((idx_locality_kernel<uint32_t>), dim3(16), dim3(kBlock), 0, s, indices, n, near);
+    return hipGetLastError();
+}
+
 hipError_t launch_frame_totals(const int64_t* tile_scan, const int64_t* chunk_tile_start, int64_t nchunks, int64_t* out_len, int64_t* padded, hipStream_t s) {
     if (nchunks <= 0) return hipSuccess;
     const int64_t grid = std::min<int64_t>((nchunks + kBlock - 1) / kBlock, eval_grid_limit());

@@ -205,7 +205,7 @@ def _bench_workload(name, rows):
     import bench
     from rust_dataframe_amd import lib, sharding
     dev = torch.device("cuda", 0)
-    step, alg_bytes, desc, check = bench.WORKLOADS[name](torch, lib, lib.api(), A, sharding, dev, dev, 0, rows)
+    step, alg_bytes, desc, check = bench.WORKLOADS[name](torch, lib, lib.api(), A, sharding, dev, dev, 0, rows, 0, rows, {})
     return step, check
 
 
