@@ -114,7 +114,9 @@ struct Schema {
 class DeviceBuffer {
   public:
     explicit DeviceBuffer(int64_t bytes) : bytes_(bytes) { check(rdf_dev_alloc(&ptr_, bytes + 64)); }
-    ~DeviceBuffer() { if (ptr_) (void)rdf_dev_free(ptr_); }
+    // memory that belongs to something else (a frame the library returned): `keep` holds the owner alive
+    DeviceBuffer(void* borrowed, int64_t bytes, std::shared_ptr<void> keep) : ptr_(borrowed), bytes_(bytes), keep_(std::move(keep)) {}
+    ~DeviceBuffer() { if (ptr_ && !keep_) (void)rdf_dev_free(ptr_); }
     DeviceBuffer(const DeviceBuffer&) = delete;
     DeviceBuffer& operator=(const DeviceBuffer&) = delete;
     void* data() const { return ptr_; }
@@ -122,6 +124,7 @@ class DeviceBuffer {
   private:
     void* ptr_ = nullptr;
     int64_t bytes_;
+    std::shared_ptr<void> keep_;
 };
 using BufferRef = std::shared_ptr<DeviceBuffer>;
 
@@ -176,6 +179,7 @@ struct Array {
         a.offset = offset; a.length = length; a.null_count = null_count; a.dtype = (int32_t)dtype; a.mem = RDF_MEM_DEVICE;
         return a;
     }
+    rdf_array view_unknown_nulls() const { rdf_array a = view(); a.null_count = -1; return a; }
     rdf_out out_view(int64_t capacity) const {
         rdf_out o;
         o.values = values ? values->data() : nullptr;
@@ -1651,6 +1655,154 @@ class DataFrame {
   private:
     Schema schema_;
     std::vector<Column> columns_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// GpuFrame: a DataFrame of numeric columns pinned in HBM behind a frame handle (rdf_frame_pin), and the reference's
+// frame-producing operators — DataFrame::filter (src/dataframe.rs:178-189), DataFrame::take / sort (:194-222), GroupAggregate —
+// as handle-in / handle-out calls: nothing per RecordBatch is marshalled, so a frame held in the readers' 1024-row batches
+// costs what its kernels cost, and a chain df.pin().filter(..).sort(..) never leaves the device.  to_dataframe() materialises
+// the columns (one descriptor walk) when a caller wants Arrow arrays back; they alias the frame's buffers and keep it alive.
+class GpuFrame {
+  public:
+    static GpuFrame pin(const DataFrame& df) {
+        if (df.num_columns() == 0 || df.num_chunks() == 0) throw DataFrameError(DataFrameError::ComputeError, "cannot pin an empty frame");
+        std::vector<rdf_array> views;
+        for (size_t c = 0; c < df.num_columns(); ++c) {
+            const DataType dt = df.column(c).data_type();
+            if (dt == DataType::Utf8 || dt == DataType::Boolean) throw DataFrameError(DataFrameError::ComputeError, "GpuFrame holds numeric columns (column " + df.column(c).name() + ")");
+            for (auto& a : df.column(c).data().chunks()) views.push_back(a->view());
+        }
+        rdf_frame* h = nullptr;
+        check(rdf_frame_pin(views.data(), (int32_t)df.num_columns(), (int64_t)df.num_chunks(), &h));
+        GpuFrame g;
+        g.schema_ = df.schema();
+        g.h_ = std::shared_ptr<Handle>(new Handle{h, std::make_shared<DataFrame>(df)});   // the pinned buffers live as long as the handle
+        return g;
+    }
+    const Schema& schema() const { return schema_; }
+    size_t num_columns() const { return schema_.fields.size(); }
+    int64_t num_rows() const { int64_t r = 0; check(rdf_frame_info(h_->h, nullptr, nullptr, &r)); return r; }
+    int64_t num_chunks() const { int64_t c = 0; check(rdf_frame_info(h_->h, nullptr, &c, nullptr)); return c; }
+
+    // DataFrame::filter: the predicate over every batch, every column compacted in one pass, batch boundaries kept
+    GpuFrame filter(const FilterRef& condition) const {
+        Lowered low;
+        for (auto& f : schema_.fields) low.columns.push_back(f.name);     // expression column c = frame column c
+        const int root = low.add(filter_to_expr(condition, [this](const std::string& n) {
+            if (!schema_.column_with_name(n)) throw DataFrameError(DataFrameError::ComputeError, "Cannot find column " + n);
+            return Expr::col(n);
+        }));
+        rdf_frame* out = nullptr;
+        check(rdf_filter_frame(h_->h, low.nodes.data(), (int32_t)low.nodes.size(), root, &out));
+        return derived(out, schema_);
+    }
+    // DataFrame::take / sort_by_indices: every column gathered by one index list in one pass -> one batch per column
+    GpuFrame take(const ArrayRef& indices) const {
+        const rdf_array idx = indices->view();
+        rdf_frame* out = nullptr;
+        check(rdf_take_frame(h_->h, &idx, &out));
+        return derived(out, nullable_schema());
+    }
+    // DataFrame::sort: lexsort_to_indices over the criteria columns, then the take of every column by that order
+    GpuFrame sort(const std::vector<DataFrame::SortCriteria>& criteria) const {
+        if (criteria.empty()) throw DataFrameError(DataFrameError::ComputeError, "Sort criteria cannot be empty");
+        std::vector<int32_t> cols;
+        std::vector<rdf_sort_options> opts;
+        for (auto& c : criteria) {
+            const auto f = schema_.column_with_name(c.column);
+            if (!f) throw DataFrameError(DataFrameError::ComputeError, "Cannot find column " + c.column);
+            cols.push_back((int32_t)f->first);
+            opts.push_back(rdf_sort_options{c.descending ? 1 : 0, 0});
+        }
+        rdf_frame* out = nullptr;
+        check(rdf_sort_frame(h_->h, cols.data(), (int32_t)cols.size(), opts.data(), nullptr, &out));
+        return derived(out, schema_);
+    }
+    // GroupAggregate(groups, [one aggregation]) -> columns: the grouping columns, "<fn>(<value>)", "count"
+    GpuFrame group_aggregate(const std::vector<std::string>& groups, const std::string& value, plan::AggregateFunction fn, int64_t max_groups) const {
+        using AF = plan::AggregateFunction;
+        std::vector<int32_t> keys;
+        Schema s;
+        for (auto& g : groups) {
+            const auto f = schema_.column_with_name(g);
+            if (!f) throw DataFrameError(DataFrameError::ComputeError, "Grouping column " + g + " does not exist");
+            keys.push_back((int32_t)f->first);
+            s.fields.push_back(f->second);
+        }
+        int32_t vcol = -1;
+        DataType vdt = DataType::Int64;
+        if (fn != AF::Count) {
+            const auto f = schema_.column_with_name(value);
+            if (!f) throw DataFrameError(DataFrameError::ComputeError, "Aggregating column " + value + " does not exist");
+            vcol = (int32_t)f->first; vdt = f->second.data_type;
+        }
+        if (fn == AF::Avg) throw DataFrameError(DataFrameError::ComputeError, "avg = sum / count on the caller's side");
+        const int32_t agg = fn == AF::Sum ? RDF_AGG_SUM : fn == AF::Min ? RDF_AGG_MIN : fn == AF::Max ? RDF_AGG_MAX : RDF_AGG_COUNT;
+        const bool fl = vdt == DataType::Float32 || vdt == DataType::Float64;
+        const DataType odt = fn == AF::Count ? DataType::Int64 : fl ? DataType::Float64 : (agg != RDF_AGG_SUM && vdt == DataType::UInt64) ? DataType::UInt64 : DataType::Int64;
+        const char* names[] = {"sum", "min", "max", "count"};
+        s.fields.push_back(Field{std::string(names[agg]) + "(" + (fn == AF::Count ? std::string("*") : value) + ")", odt, true});
+        s.fields.push_back(Field{"count", DataType::Int64, false});
+        rdf_frame* out = nullptr;
+        check(rdf_groupby_agg_frame(h_->h, keys.data(), (int32_t)keys.size(), vcol, agg, max_groups, &out));
+        return derived(out, s);
+    }
+    // AggregateFunctions over a column of the pinned frame (sum / min / max / count in one fused pass)
+    rdf_agg_result aggregate(const std::string& column) const {
+        const auto f = schema_.column_with_name(column);
+        if (!f) throw DataFrameError(DataFrameError::ComputeError, "Cannot find column " + column);
+        if (num_columns() > 8) throw DataFrameError(DataFrameError::ComputeError, "programs run over frames of at most 8 columns: select first");
+        rdf_expr_node n;
+        std::memset(&n, 0, sizeof n);
+        n.kind = RDF_NODE_COLUMN; n.column = (int32_t)f->first; n.lhs = n.rhs = -1;
+        rdf_program p;
+        std::memset(&p, 0, sizeof p);
+        p.nodes = &n; p.nnodes = 1; p.filter_root = -1; p.nvalues = 1; p.value_roots[0] = 0; p.sink = RDF_SINK_AGG;
+        rdf_agg_result r;
+        check(rdf_pipeline_frame(&p, h_->h, nullptr, &r));
+        return r;
+    }
+    // Arrow arrays back: one descriptor walk; the arrays alias the frame's buffers and keep the handle alive
+    DataFrame to_dataframe() const {
+        int32_t nc = 0; int64_t nch = 0, rows = 0;
+        check(rdf_frame_info(h_->h, &nc, &nch, &rows));
+        std::vector<Column> cols;
+        std::vector<rdf_array> views((size_t)std::max<int64_t>(nch, 1));
+        for (int32_t c = 0; c < nc; ++c) {
+            check(rdf_frame_column(h_->h, c, views.data()));
+            std::vector<ArrayRef> chunks;
+            for (int64_t i = 0; i < nch; ++i) {
+                auto a = std::make_shared<Array>();
+                a->dtype = schema_.fields[(size_t)c].data_type;
+                a->offset = views[(size_t)i].offset;
+                a->length = views[(size_t)i].length;
+                a->values = std::make_shared<DeviceBuffer>(const_cast<void*>(views[(size_t)i].values), a->length * (int64_t)type_size(a->dtype), h_);
+                if (views[(size_t)i].validity) {
+                    a->validity = std::make_shared<DeviceBuffer>(const_cast<uint8_t*>(views[(size_t)i].validity), (a->offset + a->length + 7) / 8, h_);
+                    int64_t valid = 0; int32_t some = 0;
+                    const rdf_array one = a->view_unknown_nulls();
+                    check(rdf_count(&one, 1, &valid, &some));
+                    a->null_count = a->length - valid;
+                }
+                chunks.push_back(a);
+            }
+            cols.push_back(Column::from_arrays(chunks, schema_.fields[(size_t)c]));
+        }
+        return DataFrame::from_columns(std::move(cols));
+    }
+
+  private:
+    struct Handle { rdf_frame* h; std::shared_ptr<DataFrame> pinned; ~Handle() { if (h) (void)rdf_frame_release(h); } };
+    Schema schema_;
+    std::shared_ptr<Handle> h_;
+    GpuFrame derived(rdf_frame* out, const Schema& s) const {
+        GpuFrame g;
+        g.schema_ = s;
+        g.h_ = std::shared_ptr<Handle>(new Handle{out, nullptr});      // the new frame owns its buffers
+        return g;
+    }
+    Schema nullable_schema() const { Schema s = schema_; for (auto& f : s.fields) f.nullable = true; return s; }
 };
 
 // ------------------------------------------------------------------------------------------------

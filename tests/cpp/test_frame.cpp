@@ -738,6 +738,69 @@ TEST(test_group_aggregate_min_max_dense_keys) {
     for (auto& kv : exp) { CHECK_NEAR(ds[r], kv.second.sum, 1e-9 * (1.0 + std::fabs(kv.second.sum))); ++r; }
 }
 
+// GpuFrame: the frame-producing operators as handle-in / handle-out calls give what the per-column / per-batch paths of the
+// mirror give — DataFrame::filter (src/dataframe.rs:178-189), sort (:194-222), take, GroupAggregate — and chain on the device.
+TEST(test_gpu_frame_operators_match_the_dataframe_paths) {
+    std::mt19937_64 rng(2024);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    const std::vector<size_t> lens{1024, 1024, 1024, 300, 0, 77};
+    std::vector<ArrayRef> xc, kc, yc;
+    for (size_t n : lens) {
+        std::vector<double> x(n), y(n);
+        std::vector<int64_t> k(n);
+        std::vector<bool> yv(n);
+        for (size_t i = 0; i < n; ++i) { x[i] = U(rng); y[i] = U(rng); yv[i] = rng() % 9 != 0; k[i] = (int64_t)(rng() % 23) - 11; }
+        xc.push_back(Array::from_vec(x)); kc.push_back(Array::from_vec(k)); yc.push_back(Array::from_vec(y, &yv));
+    }
+    DataFrame df = DataFrame::from_columns({Column::from_arrays(xc, Field{"x", DataType::Float64, false}), Column::from_arrays(kc, Field{"k", DataType::Int64, false}),
+                                            Column::from_arrays(yc, Field{"y", DataType::Float64, true})});
+    GpuFrame g = GpuFrame::pin(df);
+    CHECK_EQ(g.num_rows(), df.num_rows());
+    CHECK_EQ((size_t)g.num_chunks(), lens.size());
+    auto same = [&](const DataFrame& a, const DataFrame& b) {
+        CHECK_EQ(a.num_columns(), b.num_columns());
+        CHECK_EQ(a.num_rows(), b.num_rows());
+        CHECK_EQ(a.num_chunks(), b.num_chunks());
+        for (size_t c = 0; c < a.num_columns() && c < b.num_columns(); ++c)
+            for (size_t i = 0; i < a.num_chunks() && i < b.num_chunks(); ++i) {
+                const ArrayRef p = a.column(c).data().chunk(i), q = b.column(c).data().chunk(i);
+                CHECK_EQ(p->length, q->length);
+                CHECK_EQ(p->null_count, q->null_count);
+                if (a.column(c).data_type() == DataType::Int64) CHECK_EQ(host<int64_t>(p), host<int64_t>(q));
+                else {
+                    auto hv = host<double>(p), hw = host<double>(q);
+                    auto vp = p->valid_to_host(), vq = q->valid_to_host();
+                    CHECK_EQ(hv.size(), hw.size());
+                    for (size_t r = 0; r < hv.size() && r < hw.size(); ++r) { CHECK_EQ(vp[r], vq[r]); if (vp[r]) CHECK_EQ(hv[r], hw[r]); }
+                }
+            }
+    };
+    const FilterRef cond = BooleanFilter::and_(BooleanFilter::gt(BooleanFilter::column("x"), BooleanFilter::scalar(Scalar(0.1))),
+                                               BooleanFilter::lt(BooleanFilter::column("k"), BooleanFilter::scalar(Scalar((int64_t)7))));
+    same(g.filter(cond).to_dataframe(), df.filter(cond));
+    const std::vector<DataFrame::SortCriteria> crit{{"k", true, false}, {"x", false, false}};
+    same(g.sort(crit).to_dataframe(), df.sort(crit));
+    // a chain that never leaves the device, against the same chain through the per-batch paths
+    same(g.filter(cond).sort(crit).to_dataframe(), df.filter(cond).sort(crit));
+    // aggregates over the pinned and over a derived frame
+    const rdf_agg_result r = g.filter(cond).aggregate("x");
+    const Column fx = df.filter(cond).column_by_name("x");
+    CHECK_EQ(r.count, fx.num_rows());
+    CHECK_NEAR(r.sum_f64, AggregateFunctions::sum<double>(fx.data()).value_or(0.0), 1e-9);
+    // GroupAggregate on the handle: sum(y) by k, NULL values skipped
+    DataFrame ga = g.group_aggregate({"k"}, "y", P::AggregateFunction::Sum, 64).sort({{"k", false, false}}).to_dataframe();
+    std::map<int64_t, std::pair<double, int64_t>> exp;
+    for (size_t c = 0; c < lens.size(); ++c) {
+        auto kk = host<int64_t>(kc[c]); auto yy = host<double>(yc[c]); auto vv = yc[c]->valid_to_host();
+        for (size_t i = 0; i < kk.size(); ++i) { auto& e = exp[kk[i]]; if (vv[i]) { e.first += yy[i]; ++e.second; } }
+    }
+    CHECK_EQ((size_t)ga.num_rows(), exp.size());
+    auto gk = host<int64_t>(ga.column(0).data().chunk(0)); auto gs = host<double>(ga.column(1).data().chunk(0)); auto gc = host<int64_t>(ga.column(2).data().chunk(0));
+    size_t row = 0;
+    for (auto& kv : exp) { CHECK_EQ(gk[row], kv.first); CHECK_NEAR(gs[row], kv.second.first, 1e-9); CHECK_EQ(gc[row], kv.second.second); ++row; }
+    CHECK_THROWS(g.filter(BooleanFilter::gt(BooleanFilter::column("nope"), BooleanFilter::scalar(Scalar(0.0)))));
+}
+
 // DataFrame::from_arrow (src/dataframe.rs:391-407) on the committed pyarrow-written fixture: schema, chunking (one chunk
 // per record batch), every value and validity bit, then the device path over the loaded columns.
 TEST(test_from_arrow_ipc_file) {
