@@ -1034,7 +1034,10 @@ struct rdf_frame {
 
 namespace {
 
+rdf_status frame_host(rdf_frame& f);   // rdf_capi_frame.inc: host mirrors of a frame an operator built on the device
+
 rdf_status frame_tiles(rdf_frame& f, int rows_per_tile, const rdf_frame::Tiles** out) {
+    RDF_TRY(frame_host(f));
     auto it = f.tiles.find(rows_per_tile);
     if (it == f.tiles.end()) {
         std::vector<int64_t> ts((size_t)f.nchunks + 1, 0);
@@ -1084,6 +1087,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     if (ps.sink == RDF_SINK_STORE && ps.filter_root >= 0)
         return fail(RDF_INVALID_ARGUMENT, "SINK_STORE with a filter: use rdf_predicate + rdf_filter_columns");
     int32_t mem = fc ? RDF_MEM_DEVICE : -1;
+    if (fc) RDF_TRY(frame_host(*fc));     // a frame returned by an operator mirrors its tables on first need
     if (!fc) RDF_TRY(check_mem(cols, (int64_t)ncols * nchunks, &mem));
     if (mem < 0) mem = ps.sink == RDF_SINK_STORE && outs && nchunks > 0 ? outs[0].mem : RDF_MEM_HOST;
     const bool frame_store = ps.sink == RDF_SINK_STORE && ps.frame_outs != nullptr;

@@ -91,7 +91,9 @@ def test_filter_frame_parity(gpu, ora, lens, off, nf, dts):
         exp = ora.filter_columns(host, mask)
         with A.PinnedFrame(gpu, dev) as frame:
             out = gpu.filter_frame(frame, e, root)
+            first = gpu.pipeline(e, out, [e.col(0)])[0]     # the returned frame's host mirrors are fetched on first need
             nc, nch, rows = out.info()
+            assert first.count <= rows
             assert (nc, nch) == (len(dts), len(lens)) and rows == sum(x.length for x in exp[0]), sel
             got = frame_columns(out)
             for k in range(len(dts)):
