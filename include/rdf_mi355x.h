@@ -436,7 +436,8 @@ rdf_status rdf_frame_column(rdf_frame* frame, int32_t col, rdf_array* chunks);
 /* DataFrame::filter(&BooleanFilter) (src/dataframe.rs:178-189): the predicate is evaluated over every batch
  * (BooleanFilter::eval_to_array, src/expression.rs:766-861) and EVERY column of the frame is compacted with it in one pass
  * (Column::filter per column in the reference); batch boundaries are kept (ChunkedArray::filter, src/table.rs:97-107), a
- * batch may become empty.  `root` must be boolean-typed; column index c of the expression = column c of the frame. */
+ * batch may become empty.  `root` must be boolean-typed; column index c of the expression = column c of the frame.  The frame may
+ * have up to 64 columns; the predicate reads at most 8 of them. */
 rdf_status rdf_filter_frame(rdf_frame* frame, const rdf_expr_node* nodes, int32_t nnodes, int32_t root, rdf_frame** out);
 /* DataFrame::take's per-column loop (src/dataframe.rs:216-222; DataFrame::join's, :705-711) as ONE gather pass: the index
  * list is read once, each row is resolved to (batch, element) once, and the gathers of all columns of a row are in flight

@@ -1030,6 +1030,9 @@ struct rdf_frame {
     DevChunkCol* d_mask_cols = nullptr;
     DevOutChunk mask_out0 = {nullptr, nullptr};
     std::vector<std::pair<void*, size_t>> pooled;   // buffers taken from the per-thread pool, returned at release
+    // projections onto <= kMaxCols columns (a predicate over a wide frame reads a few of its columns): frames that share this
+    // frame's buffers and own only their descriptor tables; built once per column list
+    std::map<std::vector<int>, rdf_frame*> projections;
 };
 
 namespace {
@@ -1952,6 +1955,10 @@ rdf_status rdf_frame_release(rdf_frame* frame) {
     if (g_ctx.ready && g_ctx.stream) (void)hipStreamSynchronize(g_ctx.stream);   // kernels of this thread may still read the tables
     for (void* q : frame->allocs) (void)hipFree(q);
     for (auto& pb : frame->pooled) pool_release(pb.first, pb.second);
+    for (auto& pr : frame->projections) {
+        for (void* q : pr.second->allocs) (void)hipFree(q);
+        delete pr.second;
+    }
     delete frame;
     return RDF_OK;
 }

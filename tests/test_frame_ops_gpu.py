@@ -287,3 +287,23 @@ def test_sort_generations(gpu, ora, sort_gen):
                 assert np.array_equal(got.to_numpy(), exp.to_numpy()), (sort_gen, n, desc)
     finally:
         lib.set_option("sort_gen", 3)
+
+
+def test_filter_frame_wider_than_a_program(gpu, ora):
+    """A frame of 12 columns (lineitem has 16): the predicate reads columns 9 and 2 — a projection onto the columns it reads runs
+    the fused predicate, the compaction takes all twelve (two launches of <= 8 columns)."""
+    rng = np.random.default_rng(314)
+    lens = [1024] * 5 + [333]
+    dts = [A.F64, A.I64, A.F64, A.I32, A.F32, A.I16, A.U8, A.I64, A.F64, A.F64, A.U16, A.I8]
+    host = [make_chunks(rng, dt, lens, 0.1 if k in (2, 7) else 0.0, 0, "unit" if dt in (A.F64, A.F32) else "plain") for k, dt in enumerate(dts)]
+    dev, keep = to_device(host)
+    e = A.Expr()
+    root = e.op("and", e.op("gt", e.col(9), e.scalar(-0.2)), e.op("lt", e.col(2), e.scalar(0.7)))
+    exp = ora.filter_columns(host, ora.predicate(e, root, host))
+    with A.PinnedFrame(gpu, dev) as frame:
+        for _ in range(2):     # the projection is cached in the frame
+            out = gpu.filter_frame(frame, e, root)
+            got = frame_columns(out)
+            for k in range(len(dts)):
+                match_unknown_nulls(got[k], exp[k], f"wide frame column {k}")
+            out.release()
