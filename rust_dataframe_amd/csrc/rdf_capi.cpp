@@ -1029,6 +1029,7 @@ struct rdf_frame {
     DevOutChunk* d_mask_outs = nullptr;
     DevChunkCol* d_mask_cols = nullptr;
     DevOutChunk mask_out0 = {nullptr, nullptr};
+    int64_t* d_mask_pos = nullptr;           // [nchunks + 1] bit position of every batch's mask (multiples of 64)
     std::vector<std::pair<void*, size_t>> pooled;   // buffers taken from the per-thread pool, returned at release
     // projections onto <= kMaxCols columns (a predicate over a wide frame reads a few of its columns): frames that share this
     // frame's buffers and own only their descriptor tables; built once per column list

@@ -561,6 +561,8 @@ hipError_t launch_frame_totals(const int64_t* tile_scan, const int64_t* chunk_ti
 hipError_t launch_frame_tables(const FrameTabArgs& a, hipStream_t s);
 hipError_t launch_frame_mask_tables(const int64_t* pos, int64_t nchunks, uint8_t* values, uint8_t* validity, DevOutChunk* outs, DevChunkCol* cols, hipStream_t s);
 hipError_t launch_frame_pad(const int64_t* len, int64_t n, int64_t* padded, hipStream_t s);
+hipError_t launch_frame_mask_count(const uint64_t* mask, const int64_t* pos, const int64_t* chunk_tile_start, const int64_t* chunk_len, int64_t nchunks,
+                                   int64_t ntiles, int tile_rows, uint64_t tile_inv, int64_t* counts, hipStream_t s);
 hipError_t launch_take_cols(const TakeColsArgs& a, hipStream_t s);
 
 // ArrayFunctions over List<primitive> (rdf_list.hip)
