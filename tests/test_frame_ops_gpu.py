@@ -203,14 +203,15 @@ def test_take_frame_and_sort_frame(gpu, ora, lens, nf, contiguous, take_path):
             assert only_idx is None
 
 
+@pytest.mark.parametrize("contiguous", [False, True])
 @pytest.mark.parametrize("lens,knf,vnf", [([20000], 0.0, 0.0), ([1024] * 11 + [5], 0.1, 0.2), ([3000, 0, 4000], 0.0, 0.3)])
-def test_groupby_agg_frame(gpu, ora, lens, knf, vnf):
+def test_groupby_agg_frame(gpu, ora, lens, knf, vnf, contiguous):
     rng = np.random.default_rng(55 + len(lens))
     total = sum(lens)
     def keycol(card, dt, nf):
         return [A.HostArray.from_numpy(rng.integers(-card // 2, card // 2, n).astype(A.NP_OF[dt]), valid=(rng.uniform(size=n) >= nf) if nf else None, dtype=dt) for n in lens]
     host = [keycol(300, A.I64, knf), keycol(5, A.I32, 0.0), make_chunks(rng, A.F64, lens, vnf, 0, "unit"), make_chunks(rng, A.I64, lens, 0.0, 0)]
-    dev, keep = to_device(host)
+    dev, keep = to_device_contiguous(host) if contiguous else to_device(host)
 
     def table(keys, vals, counts, vvalid=None):
         rows = {}
