@@ -391,6 +391,10 @@ constexpr int kG2Block = 512;                       // scatter block: 8 waves; t
 constexpr int kG2Rows = 4;                          // rows per thread per super-tile
 constexpr int kG2Super = kG2Block * kG2Rows;        // 2048 rows = 2 tiles of kEvalTile rows
 constexpr int kG2Line = 8;                          // records per 128-byte line: the only unit ever written
+// 12-byte records (keys inside a window of 2^39): a unit of 16 records = one 128-byte line of values + 64 bytes of key words
+// (value not NULL : 1 | hash remainder : 31), the two halves in areas of their own; 4-byte records when only rows are counted
+constexpr int kG2LineC = 16;
+constexpr uint64_t kG2cMul = 0x4F1BBD2385ull, kG2cInv = 0x4B1AF15D4Dull;   // the compact hash: multiplication mod 2^39 and its inverse (rdf_groupby.hip)
 constexpr int kG2Slots = 7919;                      // aggregation: LDS table slots per partition (prime; 20 B each = 158 KB, one 1024-thread block per CU)
 constexpr int kG2AggBlock = 1024;
 constexpr int64_t kG2MaxGroups = (int64_t)(1 << kG2PartBits) * 5100;   // expected table load <= 0.65
@@ -407,7 +411,7 @@ struct Gb2Args {
     int32_t            op, vcls;         // AGG_*, CLS_* of the accumulator
     // scatter output: region (partition p, block b) = lines [(p * nb + b) * cap_lines, +nlines[p * nb + b])
     uint64_t*          recs;
-    uint32_t*          nlines;           // [P * nb]
+    uint32_t*          nlines;           // [P * nb] lines written (compact records: RECORDS written — their key words have no dead marker)
     int64_t            cap_lines;
     unsigned long long* special_sums;    // [2]: the key whose hash is the LDS free marker / the NULL key
     unsigned long long* special_counts;  // [2]
@@ -422,6 +426,11 @@ struct Gb2Args {
     // part_cap[p] lines each (region (p, b) = part_off[p] + b * part_cap[p]); nullptr: every region holds cap_lines lines
     const uint32_t*    part_off;
     const uint32_t*    part_cap;
+    // compact records: key word j of line l at recs_k[l * 16 + j], value at recs[l * 16 + j]; the key's hash is taken of
+    // (key - key_base) in 39 bits — a key outside [key_base, key_base + 2^39) sets flag bit 6 and the host re-runs with 16-byte records
+    uint32_t*          recs_k;
+    uint64_t           key_base;
+    int32_t            compact, pad3;
 };
 struct Gb2Work { int32_t p, b0, b1, multi; };   // aggregate work item: regions [b0, b1) of partition p; multi: the partition is cut into several items
 struct Gb2AggArgs {
@@ -438,8 +447,10 @@ struct Gb2AggArgs {
     const uint32_t* part_off;
     const uint32_t* part_cap;
     const Gb2Work*  work;
-    int32_t         nwork, pad;
+    int32_t         nwork, compact;
     GroupTable      t;
+    const uint32_t* recs_k;              // compact records (see Gb2Args)
+    uint64_t        key_base;
 };
 // (key, accumulator, count) triples -> global table: the merge of partial groups (multi-GPU exchange) and the path for
 // more groups than LDS tables hold
@@ -485,7 +496,7 @@ struct KeyPackArgs {
 };
 hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s);
 hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s);
-hipError_t launch_gb2_skew_probe(const Gb2Args& a, int64_t tile_step, unsigned int* hist, hipStream_t s);
+hipError_t launch_gb2_skew_probe(const Gb2Args& a, int64_t tile_step, unsigned int* hist, unsigned long long* minmax /* [2], may be nullptr */, hipStream_t s);
 hipError_t launch_gb2_aggregate(const Gb2AggArgs& a, hipStream_t s);
 hipError_t launch_gb2_merge(const Gb2MergeArgs& a, hipStream_t s);
 hipError_t launch_gb2_table_rows(const Gb2Args& a, hipStream_t s);
@@ -496,7 +507,7 @@ hipError_t launch_gx_pack(const GxPackArgs& a, hipStream_t s);
 hipError_t launch_gx_unpack(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts, int words, hipStream_t s);
 hipError_t launch_key_pack(const KeyPackArgs& a, hipStream_t s);
 hipError_t launch_key_unpack(const KeyPackArgs& a, hipStream_t s);
-size_t gb2_scatter_lds_bytes();
+size_t gb2_scatter_lds_bytes(bool compact);
 
 struct TakeArgs {
     const DevChunkCol* chunks;           // [nchunks]

@@ -34,6 +34,20 @@ constexpr int kMaxFlushLines = 512;                  // >= (7 * kP + kG2Super) /
 
 __device__ __forceinline__ uint64_t g2_hash(uint64_t x) { x ^= x >> 32; x *= 0x9E3779B97F4A7C15ull; return x ^ (x >> 32); }
 __device__ __forceinline__ uint64_t g2_unhash(uint64_t x) { x ^= x >> 32; x *= 0xF1DE83E19937733Dull; return x ^ (x >> 32); }
+// Compact records: keys inside [base, base + 2^39) are hashed to 39 bits — 8 partition bits, implied by where a record lies,
+// and the 31 bits a 4-byte key word holds next to the "value is not NULL" flag — by an invertible multiplication mod 2^39.
+// The multiplier matters: a dense key range must land on the table's slots as evenly as under the 64-bit golden-ratio hash (no
+// collisions at all; a wave waits for its unluckiest lane, so the tail of the probe lengths is what an LDS table costs).  The
+// golden ratio rounded to 39 bits stops being golden past ~5e5 points (continued fraction 1,1,...,1 x 27, then 4, 2, 2, 1, 3, 3,
+// 1, 1, 1, 22, ...); 0x4F1BBD2385 / 2^39 = [0; 1 x 17, 3, 1, 3, 1, 1, 1, 2, 3, ...] has no partial quotient above 3 and spreads
+// 1e5 ... 1.3e6 consecutive (and strided) keys without a single first-probe collision (simulated per partition; the first try,
+// 0x9E3779B1 mod 2^32, measured 50 ms per 1e9 rows in the aggregate pass against 2.8).
+// The 64-bit image keeps the layout the tables expect: partition bits on top, the slot taken from the bits below them, mixed
+// low bits for the probe step; it is a function of the key alone, and g2c_unhash gives the key back from its top 39 bits.
+constexpr uint64_t kC39 = (1ull << 39) - 1;
+__device__ __forceinline__ uint64_t g2c_image(uint64_t h39) { return (h39 << 25) | (((h39 * 0x2545F491ull) >> 7) & ((1ull << 25) - 1)); }
+__device__ __forceinline__ uint64_t g2c_hash(uint64_t key, uint64_t base) { return g2c_image(((key - base) * kG2cMul) & kC39); }
+__device__ __forceinline__ uint64_t g2c_unhash(uint64_t hk, uint64_t base) { return base + (((hk >> 25) * kG2cInv) & kC39); }
 __device__ __forceinline__ uint64_t mix64b(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -182,7 +196,7 @@ __device__ __forceinline__ void g2_load(const Gb2Args& a, int64_t st, int tid, G
 // Raw rows -> (hashed key, accumulator contribution, count).  live bit j: the row becomes a record / a table update;
 // NULL keys and the one key whose hash is the free marker go straight to two global accumulators.
 template <int NT>
-struct G2Rows { uint64_t hk[NT], val[NT]; uint32_t cnt, live; };   // cnt bit j: the value is not NULL
+struct G2Rows { uint64_t hk[NT], val[NT]; uint32_t cnt, live, bad; };   // cnt bit j: the value is not NULL; bad (compact hashing): a key outside the 32-bit window
 
 // Where the two groups that never enter a hash table (the NULL key; the key whose hash is the free marker) accumulate.
 // The stream kernel keeps them in LDS and flushes once per block: a global store / atomic inside the streaming loop — even
@@ -190,19 +204,20 @@ struct G2Rows { uint64_t hk[NT], val[NT]; uint32_t cnt, live; };   // cnt bit j:
 // writes return out of order, and the compiler then has to wait for vmcnt(0) wherever it waits at all.
 struct LdsSpecial { unsigned long long* acc; unsigned int* cnt; unsigned int* flag; };   // [2] each; acc == nullptr: global
 
-template <int NT, bool FAST = false>
+template <int NT, bool FAST = false, bool COMPACT = false>
 __device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r, G2Rows<NT>& o, const LdsSpecial ls = LdsSpecial{nullptr, nullptr, nullptr}) {
-    o.cnt = 0; o.live = 0;
+    o.cnt = 0; o.live = 0; o.bad = 0;
     const bool counts_rows = a.value_dtype < 0;
     if constexpr (FAST) {
         o.cnt = r.exists;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const uint64_t v = counts_rows ? 0ull : to_table_form(a.op, a.vcls, r.val[j], false);
-            const uint64_t hk = g2_hash(r.key[j]);
+            const uint64_t hk = COMPACT ? g2c_hash(r.key[j], a.key_base) : g2_hash(r.key[j]);
             o.hk[j] = hk;
             o.val[j] = v;
             if (!((r.exists >> j) & 1)) continue;
+            if (COMPACT && ((r.key[j] - a.key_base) >> 39)) { o.bad = 1; continue; }
             if (hk == kFree) {   // the one key whose hash is the free marker
                 if (ls.acc) {
                     ls.flag[0] = 1;
@@ -228,12 +243,14 @@ __device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r,
         if (a.value_dtype == RDF_F32) v = d2u((double)__uint_as_float((uint32_t)v));
         else if (a.value_dtype >= 0 && a.value_dtype != RDF_F64) v = normalize_int(a.value_dtype, v);
         v = counts_rows ? 0ull : to_table_form(a.op, a.vcls, v, vnull);
-        const uint64_t hk = g2_hash(normalize_int(a.key_dtype, r.key[j]));
+        const uint64_t nk = normalize_int(a.key_dtype, r.key[j]);
+        const uint64_t hk = COMPACT ? g2c_hash(nk, a.key_base) : g2_hash(nk);
         o.hk[j] = hk;
         o.val[j] = v;
         const bool c1 = !vnull;
         if (e && c1) o.cnt |= 1u << j;
         if (!e) continue;
+        if (COMPACT && !knull && ((nk - a.key_base) >> 39)) { o.bad = 1; continue; }
         if (knull || hk == kFree) {
             const int s = knull ? 1 : 0;
             if (ls.acc) {
@@ -420,9 +437,16 @@ __global__ __launch_bounds__(kStreamBlock, FAST ? 6 : 4) void gb2_stream_kernel(
 // tile, tiles spread evenly over the input, about 1 M keys in all).  The scatter's (partition, block) regions hold 1.19 x
 // their mean: a partition whose share is above that overflows them near the END of the pass, so without the probe heavily
 // skewed keys paid for a whole wasted scatter (~9 ms per 1e9 rows) before the combining path ran.
-__global__ __launch_bounds__(256) void gb2_skew_probe_kernel(const Gb2Args a, int64_t tile_step, unsigned int* hist) {
-    __shared__ unsigned int h[kP];
-    for (int i = threadIdx.x; i < kP; i += 256) h[i] = 0;
+// minmax (optional): the smallest / largest sampled key in the key type's order (sign bit flipped for the signed types), NULL
+// keys left out — what the host sizes the 32-bit window of the compact records from.
+__global__ __launch_bounds__(256) void gb2_skew_probe_kernel(const Gb2Args a, int64_t tile_step, unsigned int* hist, unsigned long long* minmax) {
+    // hist[0 .. kP): partitions of the 64-bit hash; hist[kP .. 2 kP): partitions of the compact hash taken with base 0 — the host
+    // picks window bases that are multiples of 2^31, for which the real partition numbers are these rotated by a constant
+    __shared__ unsigned int h[2 * kP];
+    __shared__ unsigned long long mm[2];
+    for (int i = threadIdx.x; i < 2 * kP; i += 256) h[i] = 0;
+    if (threadIdx.x == 0) { mm[0] = ~0ull; mm[1] = 0ull; }
+    const uint64_t flip = (a.key_dtype == RDF_I64 || a.key_dtype == RDF_I32 || a.key_dtype == RDF_I16 || a.key_dtype == RDF_I8) ? 0x8000000000000000ull : 0ull;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ksz = g2_dtype_size(a.key_dtype);
@@ -439,12 +463,20 @@ __global__ __launch_bounds__(256) void gb2_skew_probe_kernel(const Gb2Args a, in
         }
         const int64_t row = r0 + lane * 16 + (int)((tile * 7) & 15);
         if (row < clen) {
-            const uint64_t hk = g2_hash(normalize_int(a.key_dtype, g2_load_raw(kc.values, ksz, kc.offset + row, true)));
+            const uint64_t nk = normalize_int(a.key_dtype, g2_load_raw(kc.values, ksz, kc.offset + row, true));
+            const uint64_t hk = g2_hash(nk);
             atomicAdd(&h[(uint32_t)(hk >> (64 - kG2PartBits))], 1u);
+            atomicAdd(&h[kP + (uint32_t)(g2c_hash(nk, 0) >> (64 - kG2PartBits))], 1u);
+            if (minmax) {
+                bool valid = true;
+                if (kc.validity) { const int64_t b = kc.offset + row; valid = (as_global<uint8_t>(kc.validity)[b >> 3] >> (b & 7)) & 1; }
+                if (valid) { atomicMin(&mm[0], (unsigned long long)(nk ^ flip)); atomicMax(&mm[1], (unsigned long long)(nk ^ flip)); }
+            }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kP; i += 256) if (h[i]) atomicAdd(&hist[i], h[i]);
+    for (int i = threadIdx.x; i < 2 * kP; i += 256) if (h[i]) atomicAdd(&hist[i], h[i]);
+    if (minmax && threadIdx.x == 0 && mm[0] <= mm[1]) { atomicMin(&minmax[0], mm[0]); atomicMax(&minmax[1], mm[1]); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -458,12 +490,20 @@ __global__ __launch_bounds__(256) void gb2_skew_probe_kernel(const Gb2Args a, in
 // Per flushed line ONE 64-bit descriptor (destination line, staging index, carry length, partition) is all the flush
 // phase reads before it moves the line: the partition's owner thread writes it while it does the bookkeeping.
 
-template <bool FAST>
+template <bool FAST, bool COMPACT>
 __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args a) {
+    // COMPACT: 12-byte records in units of 16 (a 128-byte line of values in `recs`, 64 bytes of key words in `recs_k`), the
+    // LDS staging split the same way; a "line" below is a unit of L records in either layout.
+    constexpr int L = COMPACT ? kG2LineC : kG2Line, LS = COMPACT ? 4 : 3;
+    constexpr int CS = COMPACT ? L - 1 : L;   // carry slots per partition (a carry never holds a whole line)
     extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
     u64x2* stage = (u64x2*)gsm;                           // [kG2Super] this tile's records, grouped by partition
     u64x2* carry = stage + kG2Super;                      // [kP * 8] records waiting for their line to fill
-    uint64_t* ldesc = (uint64_t*)(carry + kP * kG2Line);  // [kMaxFlushLines] per flush line: dst line | (stage index + 8) << 32 | c << 48 | j0 << 51 | d << 52
+    uint64_t* stage_v = gsm;                              // COMPACT: [kG2Super] values, [kP * 15] carried values,
+    uint64_t* carry_v = stage_v + kG2Super;               //          [kG2Super] key words, [kP * 15] carried key words
+    uint32_t* stage_k = (uint32_t*)(carry_v + kP * CS);
+    uint32_t* carry_k = stage_k + kG2Super;
+    uint64_t* ldesc = COMPACT ? (uint64_t*)(carry_k + kP * CS) : (uint64_t*)(carry + kP * kG2Line);  // [kMaxFlushLines] per flush line: dst line | (stage index + L) << 32 | c << 48 | j0 << (48 + LS) | d << (49 + LS)
     uint32_t* tcnt = (uint32_t*)(ldesc + kMaxFlushLines); // [kP] rank counters of the tile
     uint32_t* ccnt = tcnt + kP;                           // [kP] records in the carry
     uint32_t* written = ccnt + kP;                        // [kP] lines of the region already written
@@ -478,17 +518,21 @@ __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args 
     const uint32_t cap = tid < kP && a.part_cap ? as_const<uint32_t>(a.part_cap)[tid] : (uint32_t)a.cap_lines;   // lines of this thread's partition's region
     const uint32_t region0 = tid < kP ? (a.part_off ? as_const<uint32_t>(a.part_off)[tid] + bid * cap : ((uint32_t)tid * nb + bid) * cap) : 0;   // its first line
     u64x2* const recs = (u64x2*)a.recs;
+    uint64_t* const recs_v = a.recs;
+    uint32_t* const recs_k = a.recs_k;
+    const bool has_values = a.value_dtype >= 0;
     uint32_t err = 0;
     constexpr int TPI = kG2Super / kEvalTile;
     const int64_t stride = (int64_t)nb * TPI;
     int64_t st = (int64_t)bid * TPI;
     G2Raw<kG2Rows> raw;
     G2Rows<kG2Rows> rows;
-    if (st < a.ntiles) { g2_load<kG2Rows, kG2Block, FAST>(a, st, tid, raw); g2_prepare<kG2Rows, FAST>(a, raw, rows); }
+    if (st < a.ntiles) { g2_load<kG2Rows, kG2Block, FAST>(a, st, tid, raw); g2_prepare<kG2Rows, FAST, COMPACT>(a, raw, rows); }
     for (; st < a.ntiles; st += stride) {
         const bool more = st + stride < a.ntiles;
         if (more) g2_load<kG2Rows, kG2Block, FAST>(a, st + stride, tid, raw);   // the next tile's loads fly during the LDS phases
-        if (a.ablate == 24) { uint64_t x = 0; for (int j = 0; j < kG2Rows; ++j) x ^= rows.hk[j] ^ rows.val[j]; if (x == 0x1234567) a.special[0] = 1; if (more) g2_prepare<kG2Rows, FAST>(a, raw, rows); continue; }   // loads + hash only
+        if (a.ablate == 24) { uint64_t x = 0; for (int j = 0; j < kG2Rows; ++j) x ^= rows.hk[j] ^ rows.val[j]; if (x == 0x1234567) a.special[0] = 1; if (more) g2_prepare<kG2Rows, FAST, COMPACT>(a, raw, rows); continue; }   // loads + hash only
+        if (COMPACT && rows.bad) { err |= 64u; atomicOr(a.flags, 64u); }   // a key outside the 32-bit window: every block stops at its next tile
         // (B) rank inside the partition
         uint32_t rank[kG2Rows];
 #pragma unroll
@@ -496,11 +540,12 @@ __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args 
             if ((rows.live >> j) & 1) rank[j] = atomicAdd(&tcnt[(uint32_t)(rows.hk[j] >> (64 - kG2PartBits))], 1u);
         __syncthreads();
         // (C) per partition: staging offset, number of whole lines it can now flush, their place in the flush list
-        uint32_t tc = 0, cc = 0, kk = 0, inc_t = 0, inc_k = 0;
+        uint32_t tc = 0, cc = 0, kk = 0, nd = 0, inc_t = 0, inc_k = 0;
         if (tid < kP) {
             tc = tcnt[tid]; cc = ccnt[tid];
-            kk = (cc + tc) >> 3;
-            inc_t = tc; inc_k = kk;
+            kk = (cc + tc) >> LS;
+            nd = kk;
+            inc_t = tc; inc_k = nd;
 #pragma unroll
             for (int m = 1; m < 64; m <<= 1) {
                 const uint32_t yt = (uint32_t)__shfl_up((int)inc_t, m), yk = (uint32_t)__shfl_up((int)inc_k, m);
@@ -508,28 +553,30 @@ __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args 
             }
             if (lane == 63) { wtot_t[wave] = inc_t; wtot_k[wave] = inc_k; }
         }
-        if (tid == 0) abort_s = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u;
+        if (tid == 0) abort_s = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (16u | 64u);
         __syncthreads();
-        if (abort_s) break;     // some block overflowed a region: the host re-runs another path
+        if (abort_s) break;     // some block overflowed a region / met a key outside the window: the host re-runs another path
         if (tid < kP) {
             uint32_t off_t = 0, off_k = 0;
 #pragma unroll
             for (int w = 0; w < kP / 64; ++w) if (w < wave) { off_t += wtot_t[w]; off_k += wtot_k[w]; }
-            const uint32_t ex_t = off_t + inc_t - tc, ex_k = off_k + inc_k - kk;
+            const uint32_t ex_t = off_t + inc_t - tc, ex_k = off_k + inc_k - nd;
             const uint32_t w0 = written[tid];
-            lstart[tid] = ex_t;
-            tail[tid] = ex_t + 8 * kk - cc;
+            // no line to flush: the tile's records go straight to the carry in phase (D) (bit 31: lstart is a carry index) — a loop
+            // in this thread, or descriptors of their own in phase (E), sat on every tile's critical path
+            lstart[tid] = kk == 0 ? (0x80000000u | ((uint32_t)tid * (COMPACT ? CS : kG2Line) + cc)) : ex_t;
+            tail[tid] = ex_t + L * kk - cc;
             if (w0 + kk > cap) err |= 16u;
             for (uint32_t j = 0; j < kk; ++j) {
                 const uint32_t dst = w0 + j < cap ? region0 + w0 + j : 0xFFFFFFFFu;
-                // stage index of the line's lane 0, biased by 8 (line 0 starts c slots before the partition's staging run)
-                ldesc[ex_k + j] = (uint64_t)dst | ((uint64_t)(ex_t + 8 * j + 8 - cc) << 32) | ((uint64_t)(j == 0 ? cc : 0) << 48)
-                                  | ((uint64_t)(j == 0) << 51) | ((uint64_t)tid << 52);
+                // stage index of the line's lane 0, biased by L (line 0 starts c slots before the partition's staging run)
+                ldesc[ex_k + j] = (uint64_t)dst | ((uint64_t)(ex_t + L * j + L - cc) << 32) | ((uint64_t)(j == 0 ? cc : 0) << 48)
+                                  | ((uint64_t)(j == 0) << (48 + LS)) | ((uint64_t)tid << (49 + LS));
             }
-            ccnt[tid] = cc + tc - 8 * kk;
+            ccnt[tid] = cc + tc - L * kk;
             written[tid] = w0 + kk;
             tcnt[tid] = 0;
-            if (tid == kP - 1) ltot = ex_k + kk;
+            if (tid == kP - 1) ltot = ex_k + nd;
         }
         __syncthreads();
         // (D) stage the tile's records grouped by partition
@@ -537,47 +584,105 @@ __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args 
         for (int j = 0; j < kG2Rows; ++j)
             if (((rows.live >> j) & 1) && a.ablate != 23) {
                 const uint32_t d = (uint32_t)(rows.hk[j] >> (64 - kG2PartBits));
-                u64x2 rec;
-                rec[0] = ((uint64_t)((rows.cnt >> j) & 1) << (64 - kG2PartBits)) | (rows.hk[j] & kKeyMask);
-                rec[1] = rows.val[j];
-                stage[lstart[d] + rank[j]] = rec;
+                const uint32_t at = lstart[d] + rank[j], ci = at & 0x7FFFFFFFu;
+                const bool to_carry = at >> 31;
+                if constexpr (COMPACT) {
+                    const uint32_t kw = (((rows.cnt >> j) & 1u) << 31) | ((uint32_t)(rows.hk[j] >> 25) & 0x7FFFFFFFu);
+                    if (to_carry) { carry_k[ci] = kw; if (has_values) carry_v[ci] = rows.val[j]; }
+                    else { stage_k[ci] = kw; if (has_values) stage_v[ci] = rows.val[j]; }
+                } else {
+                    u64x2 rec;
+                    rec[0] = ((uint64_t)((rows.cnt >> j) & 1) << (64 - kG2PartBits)) | (rows.hk[j] & kKeyMask);
+                    rec[1] = rows.val[j];
+                    if (to_carry) carry[ci] = rec; else stage[ci] = rec;
+                }
             }
         __syncthreads();
         // the next tile's rows: waiting for its loads HERE keeps the flush stores below out of that wait
-        if (more) g2_prepare<kG2Rows, FAST>(a, raw, rows);
-        // (E) flush whole lines: 8 consecutive lanes write one aligned 128-byte line of a region
+        if (more) g2_prepare<kG2Rows, FAST, COMPACT>(a, raw, rows);
+        // (E) flush whole lines: L consecutive lanes write one aligned line of a region (COMPACT: 128 bytes of values + 64 of key
+        // words).  An iteration is a chain of dependent LDS round trips (descriptor -> record -> new carry); the chains of
+        // different lines are independent (a line reads its partition's OLD carry, only that partition's first line writes the
+        // new one), so the compact layout — half as many lines per pass of the block — takes two lines per lane group and
+        // iteration, every LDS read of both before the first store.  (The 16-byte layout spills registers when it does that:
+        // measured 10.1 against 9.6 ms per 1e9 rows.)
         const uint32_t nl = (a.ablate == 22 || a.ablate == 23) ? 0u : ltot;
-        for (uint32_t i = (uint32_t)tid >> 3; i < nl; i += kG2Block / 8) {
+        struct Line { uint64_t v, nv; uint32_t kw, nkw, dst, slot; u64x2 rec, nrec; bool live, carry_w; };
+        const uint32_t l8 = (uint32_t)tid & (L - 1);
+        auto line_load = [&](uint32_t i, Line& ln) {
+            ln.live = i < nl; ln.carry_w = false;
+            if (!ln.live) return;
             const uint64_t ds = ldesc[i];
-            const uint32_t l8 = (uint32_t)tid & 7, dst = (uint32_t)ds, src = (uint32_t)(ds >> 32) & 0xFFFFu, c = (uint32_t)(ds >> 48) & 7u, d = (uint32_t)(ds >> 52);
-            const u64x2 rec = l8 < c ? carry[d * kG2Line + l8] : stage[src + l8 - 8];
-            if (dst != 0xFFFFFFFFu) { if (a.ablate != 21) recs[(uint64_t)dst * kG2Line + l8] = rec; else if (rec[0] == 0x1234567) a.special[0] = 1; }
-            if ((ds >> 51) & 1) {   // the partition's new carry: the tail of its tile records (this lane read its old carry slot above)
-                if (l8 < ccnt[d]) carry[d * kG2Line + l8] = stage[tail[d] + l8];
+            const uint32_t src = (uint32_t)(ds >> 32) & 0xFFFFu, c = (uint32_t)(ds >> 48) & (uint32_t)(L - 1), d = (uint32_t)(ds >> (49 + LS));
+            ln.dst = (uint32_t)ds;
+            ln.slot = d * (COMPACT ? CS : kG2Line) + l8;
+            const bool fc = l8 < c;
+            if constexpr (COMPACT) {
+                ln.kw = fc ? carry_k[ln.slot] : stage_k[src + l8 - L];
+                ln.v = 0;
+                if (has_values) ln.v = fc ? carry_v[ln.slot] : stage_v[src + l8 - L];
+            } else ln.rec = fc ? carry[ln.slot] : stage[src + l8 - L];
+            if (((ds >> (48 + LS)) & 1) && l8 < ccnt[d]) {   // the partition's new carry: the tail of its tile records
+                ln.carry_w = true;
+                const uint32_t t = tail[d] + l8;
+                if constexpr (COMPACT) { ln.nkw = stage_k[t]; if (has_values) ln.nv = stage_v[t]; }
+                else ln.nrec = stage[t];
             }
-        }
-        if (tid < kP && kk == 0 && tc) {   // no line to flush: the tile's records join the carry
-            for (uint32_t i = 0; i < tc; ++i) carry[tid * kG2Line + cc + i] = stage[lstart[tid] + i];
+        };
+        auto line_store = [&](const Line& ln) {
+            if (!ln.live) return;
+            if constexpr (COMPACT) {
+                if (ln.dst != 0xFFFFFFFFu) {
+                    if (a.ablate != 21) { recs_k[(uint64_t)ln.dst * L + l8] = ln.kw; if (has_values) recs_v[(uint64_t)ln.dst * L + l8] = ln.v; }
+                    else if (ln.kw == 0x1234567u && ln.v == 1) a.special[0] = 1;
+                }
+                if (ln.carry_w) { carry_k[ln.slot] = ln.nkw; if (has_values) carry_v[ln.slot] = ln.nv; }
+            } else {
+                if (ln.dst != 0xFFFFFFFFu) { if (a.ablate != 21) recs[(uint64_t)ln.dst * kG2Line + l8] = ln.rec; else if (ln.rec[0] == 0x1234567) a.special[0] = 1; }
+                if (ln.carry_w) carry[ln.slot] = ln.nrec;
+            }
+        };
+        constexpr uint32_t G = kG2Block / L;   // lines per pass of the block
+        if constexpr (COMPACT) {
+            for (uint32_t i = (uint32_t)tid >> LS; i < nl; i += 2 * G) {
+                Line l0, l1;
+                line_load(i, l0);
+                line_load(i + G, l1);
+                line_store(l0);
+                line_store(l1);
+            }
+        } else {
+            for (uint32_t i = (uint32_t)tid >> LS; i < nl; i += G) {
+                Line l0;
+                line_load(i, l0);
+                line_store(l0);
+            }
         }
         if (err & 16u) atomicOr(a.flags, 16u);
         __syncthreads();
     }
     // what is left in the carries goes out as one last line per partition, padded with dead records
     __syncthreads();
-    for (uint32_t d = (uint32_t)tid >> 3; d < (uint32_t)kP; d += kG2Block / 8) {
-        const uint32_t c = ccnt[d], l8 = (uint32_t)tid & 7;
+    for (uint32_t d = (uint32_t)tid >> LS; d < (uint32_t)kP; d += kG2Block / L) {
+        const uint32_t c = ccnt[d], l8 = (uint32_t)tid & (L - 1);
         if (c == 0) continue;
-        u64x2 rec;
-        rec[0] = kDead; rec[1] = 0;
-        if (l8 < c) rec = carry[d * kG2Line + l8];
         const uint32_t line = written[d];
         const uint32_t dcap = a.part_cap ? as_const<uint32_t>(a.part_cap)[d] : (uint32_t)a.cap_lines;
         const uint64_t dreg = a.part_off ? (uint64_t)as_const<uint32_t>(a.part_off)[d] + (uint64_t)bid * dcap : (uint64_t)(d * nb + bid) * dcap;
-        if (line < dcap) recs[(dreg + line) * kG2Line + l8] = rec;
-        else err |= 16u;
+        if constexpr (COMPACT) {
+            // (no dead marker in a 4-byte key word: nlines holds the region's RECORD count in this layout)
+            if (line >= dcap) err |= 16u;
+            else if (l8 < c) { recs_k[(dreg + line) * L + l8] = carry_k[d * CS + l8]; if (has_values) recs_v[(dreg + line) * L + l8] = carry_v[d * CS + l8]; }
+        } else {
+            u64x2 rec;
+            rec[0] = kDead; rec[1] = 0;
+            if (l8 < c) rec = carry[d * kG2Line + l8];
+            if (line < dcap) recs[(dreg + line) * kG2Line + l8] = rec;
+            else err |= 16u;
+        }
     }
     __syncthreads();
-    if (tid < kP) a.nlines[(int64_t)tid * nb + bid] = written[tid] + (ccnt[tid] ? 1u : 0u);
+    if (tid < kP) a.nlines[(int64_t)tid * nb + bid] = COMPACT ? written[tid] * L + ccnt[tid] : written[tid] + (ccnt[tid] ? 1u : 0u);
     if (err) atomicOr(a.flags, err);
 }
 
@@ -637,6 +742,8 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
     const unsigned long long ident = agg_identity(a.op);
     uint32_t err = 0;
     const u64x2* const recs = (const u64x2*)a.recs;
+    const bool compact = a.compact != 0;
+    const int L = compact ? kG2LineC : kG2Line;
     const int nitems = a.nwork > 0 ? a.nwork : kP;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         int p = item, rb0 = 0, rb1 = (int)a.nb, multi = 0;
@@ -650,23 +757,42 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
         // every wave walks every region of the item and takes the batches w, w + NW, ... of kAggBatch x 64 consecutive records
         // (whole regions per wave left most waves idle on an item that is a slice of a heavy partition: one or two regions);
         // the next batch's loads are issued before the current one is folded into the table
-        int64_t b = (int64_t)rb0 - 1, off = 0, nrec = 0;
-        const u64x2* base = recs;
+        int64_t b = (int64_t)rb0 - 1, off = 0, nrec = 0, base_i = 0;
         bool open = false;
         auto advance = [&]() {
             open = false;
             for (++b; b < rb1; ++b) {
-                nrec = (int64_t)a.nlines[(int64_t)p * a.nb + b] * kG2Line;
-                if (nrec > (int64_t)wave * kAggBatch * 64) { base = recs + (pline0 + b * pcap) * kG2Line; off = (int64_t)wave * kAggBatch * 64; open = true; return; }
+                nrec = compact ? (int64_t)a.nlines[(int64_t)p * a.nb + b] : (int64_t)a.nlines[(int64_t)p * a.nb + b] * L;
+                if (nrec > (int64_t)wave * kAggBatch * 64) { base_i = (pline0 + b * pcap) * L; off = (int64_t)wave * kAggBatch * 64; open = true; return; }
             }
         };
         auto load_batch = [&](u64x2 (&r)[kAggBatch]) -> bool {   // false: this wave's share of the item is exhausted
             if (!open) return false;
+            if (compact) {
+                // 12-byte records -> the 16-byte form the fold below reads: cnt : 8 | the key's image below its partition bits
+                uint32_t kw[kAggBatch];
 #pragma unroll
-            for (int u = 0; u < kAggBatch; ++u) {
-                const int64_t i = off + u * 64 + lane;
-                r[u][0] = kDead; r[u][1] = 0;
-                if (i < nrec) r[u] = __builtin_nontemporal_load(base + i);
+                for (int u = 0; u < kAggBatch; ++u) {
+                    const int64_t i = off + u * 64 + lane;
+                    kw[u] = 0; r[u][1] = 0;
+                    if (i < nrec) {
+                        kw[u] = __builtin_nontemporal_load(a.recs_k + base_i + i);
+                        if (a.has_values) r[u][1] = __builtin_nontemporal_load(a.recs + base_i + i);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kAggBatch; ++u) {
+                    const int64_t i = off + u * 64 + lane;
+                    const uint64_t h39 = ((uint64_t)p << 31) | (kw[u] & 0x7FFFFFFFu);
+                    r[u][0] = i < nrec ? (((uint64_t)(kw[u] >> 31) << 56) | (g2c_image(h39) & kKeyMask)) : kDead;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kAggBatch; ++u) {
+                    const int64_t i = off + u * 64 + lane;
+                    r[u][0] = kDead; r[u][1] = 0;
+                    if (i < nrec) r[u] = __builtin_nontemporal_load(recs + base_i + i);
+                }
             }
             off += (int64_t)NW * kAggBatch * 64;
             if (off >= nrec) advance();
@@ -698,7 +824,7 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
         if (multi) {   // one of several items of a big partition: its groups meet the other items' in the global table
             for (int k = tid; k < kG2Slots; k += kG2AggBlock) {
                 if (t.keys[k] == kFree) continue;
-                const uint64_t key = g2_unhash(t.keys[k]);
+                const uint64_t key = compact ? g2c_unhash(t.keys[k], a.key_base) : g2_unhash(t.keys[k]);
                 if (key == kGroupEmpty) g2_global_special(a.t, 0, a.op, a.vcls, a.has_values != 0, t.acc[k], t.cnt[k]);
                 else if (!g2_global_upsert(a.t, key, a.op, a.vcls, a.has_values != 0, t.acc[k], t.cnt[k])) err |= 4u;
             }
@@ -711,7 +837,7 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
             if (t.keys[k] == kFree) continue;
             const unsigned idx = misc[0] + atomicAdd(&misc[1], 1u);
             if ((int64_t)idx >= a.max_out) { err |= 4u; continue; }
-            const uint64_t key = g2_unhash(t.keys[k]);
+            const uint64_t key = compact ? g2c_unhash(t.keys[k], a.key_base) : g2_unhash(t.keys[k]);
             switch (a.key_dtype) {
                 case RDF_I32: case RDF_U32: ((uint32_t*)a.out_keys)[idx] = (uint32_t)key; break;
                 case RDF_I16: case RDF_U16: ((uint16_t*)a.out_keys)[idx] = (uint16_t)key; break;
@@ -911,8 +1037,10 @@ __global__ __launch_bounds__(kBlock) void key_unpack_kernel(const KeyPackArgs a)
 // ------------------------------------------------------------------------------------------------
 // launchers
 
-size_t gb2_scatter_lds_bytes() {
-    return (size_t)kG2Super * 16 + (size_t)kP * kG2Line * 16 + (size_t)kMaxFlushLines * 8 + (size_t)kP * 4 * 5;
+size_t gb2_scatter_lds_bytes(bool compact) {
+    const size_t bookkeeping = (size_t)kMaxFlushLines * 8 + (size_t)kP * 4 * 5;
+    if (compact) return ((size_t)kG2Super + (size_t)kP * (kG2LineC - 1)) * 12 + bookkeeping;   // 78 KB: still two blocks per CU
+    return (size_t)kG2Super * 16 + (size_t)kP * kG2Line * 16 + bookkeeping;
 }
 hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s) {
     const size_t lds = (size_t)a.table_slots * 20 + 16 + 48;   // table, group counter, the two special groups
@@ -925,21 +1053,20 @@ hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s) {
     }
     return hipGetLastError();
 }
-hipError_t launch_gb2_skew_probe(const Gb2Args& a, int64_t tile_step, unsigned int* hist, hipStream_t s) {
+hipError_t launch_gb2_skew_probe(const Gb2Args& a, int64_t tile_step, unsigned int* hist, unsigned long long* minmax, hipStream_t s) {
     const int64_t sampled = (a.ntiles + tile_step - 1) / tile_step;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((sampled + 3) / 4, 1024));
-    hipLaunchKernelGGL(gb2_skew_probe_kernel, dim3(grid), dim3(256), 0, s, a, tile_step, hist);
+    hipLaunchKernelGGL(gb2_skew_probe_kernel, dim3(grid), dim3(256), 0, s, a, tile_step, hist, minmax);
     return hipGetLastError();
 }
 hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s) {
-    const size_t lds = gb2_scatter_lds_bytes();
-    if (a.fast) {
-        (void)hipFuncSetAttribute((const void*)gb2_scatter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(gb2_scatter_kernel<true>, dim3(grid), dim3(kG2Block), lds, s, a);
-    } else {
-        (void)hipFuncSetAttribute((const void*)gb2_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(gb2_scatter_kernel<false>, dim3(grid), dim3(kG2Block), lds, s, a);
-    }
+    const size_t lds = gb2_scatter_lds_bytes(a.compact != 0);
+    auto go = [&](auto kernel) {
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kG2Block), lds, s, a);
+    };
+    if (a.compact) { if (a.fast) go(gb2_scatter_kernel<true, true>); else go(gb2_scatter_kernel<false, true>); }
+    else { if (a.fast) go(gb2_scatter_kernel<true, false>); else go(gb2_scatter_kernel<false, false>); }
     return hipGetLastError();
 }
 hipError_t launch_gb2_aggregate(const Gb2AggArgs& a, hipStream_t s) {

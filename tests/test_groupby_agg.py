@@ -338,3 +338,73 @@ def test_groupby_skewed_keys_capacity_plan(gpu, ora, agg):
     finally:
         lib.set_option("gb_partition", 3)
         lib.set_option("gb_skew_plan", 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agg", AGGS)
+def test_groupby_compact_records(gpu, ora, agg):
+    """The partition path's 12-byte records (4-byte when only rows are counted): 8-byte keys whose sampled span fits a window
+    of 2^39 keys — in the middle of the key type's range, at either end of it (the window is clamped), behind NULL keys — against the
+    oracle; a key outside the window at a row the probe does not sample (the scatter notices, the call answers from 16-byte
+    records); a span too wide for the window; the A/B switch."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(2024)
+    n, ngroups = 400_000, 20_000
+    base = rng.integers(0, ngroups, n)
+    i64, u64 = np.iinfo(np.int64), np.iinfo(np.uint64)
+    cases = [
+        ("middle", A.I64, (base.astype(np.int64) - ngroups // 2) * 3 + (1 << 40), True),
+        ("bottom of i64", A.I64, (i64.min + base * 5).astype(np.int64), True),
+        ("top of i64", A.I64, (i64.max - base * 5).astype(np.int64), True),
+        ("top of u64", A.U64, (np.uint64(u64.max) - (base * 7).astype(np.uint64)), True),
+        ("bottom of u64", A.U64, base.astype(np.uint64), True),
+        ("span 2^34", A.I64, (base.astype(np.int64) << 20) - 5, True),
+        ("span 2^40", A.I64, (base.astype(np.int64) << 26) - 5, False),
+    ]
+    outlier = (base.astype(np.int64) * 11) - 77
+    outlier[1] = 1 << 45        # rows 0, 16, 32, ... of the first tile are sampled: row 1 is not
+    cases.append(("outlier", A.I64, outlier, False))
+    lib.set_option("gb_partition", 4)
+    lib.set_option("gb_compact", 2)          # the default compacts COUNT only
+    try:
+        for name, kdt, kv, compact in cases:
+            lens = [n // 3, 11, n - n // 3 - 11]
+            keys, vals, pos = [], [], 0
+            for ln in lens:
+                keys.append(A.HostArray.from_numpy(kv[pos:pos + ln], valid=rng.uniform(size=ln) >= 0.002, offset=3, rng=rng))
+                vals.append(A.HostArray.from_numpy(rng.uniform(-1, 1, ln), valid=rng.uniform(size=ln) >= 0.1, offset=6, rng=rng))
+                pos += ln
+            if name == "outlier":
+                keys = [A.HostArray.from_numpy(kv)]           # no NULLs: the outlier stays a key
+                vals = [A.HostArray.from_numpy(rng.uniform(-1, 1, n))]
+            v = None if agg == "count" else vals
+            exp = _groups(*ora.groupby_agg([keys], v, agg, ngroups + 8))
+            got = _groups(*gpu.groupby_agg([keys], v, agg, ngroups + 8))
+            assert lib.last_kernel().startswith("gb2_scatter_kernel"), (name, lib.last_kernel())
+            assert ("12-byte records" in lib.last_kernel()) == compact, (name, lib.last_kernel())
+            _assert_same_groups(got, exp, agg != "count", f"compact records: {name} agg={agg}")
+            if name == "middle":
+                for opt in (0, 1):
+                    lib.set_option("gb_compact", opt)
+                    got = _groups(*gpu.groupby_agg([keys], v, agg, ngroups + 8))
+                    assert ("12-byte records" in lib.last_kernel()) == (opt == 1 and agg == "count"), (opt, lib.last_kernel())
+                    _assert_same_groups(got, exp, agg != "count", f"gb_compact={opt}: {name} agg={agg}")
+                lib.set_option("gb_compact", 2)
+        # 4-byte and 2-byte keys always fit their type's window; the skew plan on compact records
+        lib.set_option("gb_skew_plan", 2)
+        for kdt, npdt in ((A.I32, np.int32), (A.U16, np.uint16)):
+            hot = rng.integers(0, min(ngroups, np.iinfo(npdt).max), n).astype(npdt)
+            hot[rng.uniform(size=n) < 0.3] = 4242
+            if kdt == A.I32:
+                hot[3], hot[4] = np.iinfo(npdt).min, np.iinfo(npdt).max
+            keys = [A.HostArray.from_numpy(hot[:n // 2], rng=rng), A.HostArray.from_numpy(hot[n // 2:], valid=rng.uniform(size=n - n // 2) > 0.01, offset=1, rng=rng)]
+            vals = [A.HostArray.from_numpy(rng.uniform(-1, 1, n // 2), rng=rng), A.HostArray.from_numpy(rng.uniform(-1, 1, n - n // 2), rng=rng)]
+            v = None if agg == "count" else vals
+            exp = _groups(*ora.groupby_agg([keys], v, agg, ngroups + 8))
+            got = _groups(*gpu.groupby_agg([keys], v, agg, ngroups + 8))
+            assert "12-byte records, capacity plan" in lib.last_kernel(), lib.last_kernel()
+            _assert_same_groups(got, exp, agg != "count", f"compact records + plan: keys={kdt} agg={agg}")
+    finally:
+        lib.set_option("gb_partition", 3)
+        lib.set_option("gb_skew_plan", 1)
+        lib.set_option("gb_compact", 1)

@@ -12,7 +12,9 @@ K = A.DeviceArray(k.data_ptr(), None, 0, n, A.I64, 0); V = A.DeviceArray(v.data_
 bufs = [torch.empty((ng + 2) * 8 + 64, dtype=torch.uint8, device="cuda") for _ in range(3)]
 outs = tuple(A.DeviceArray(b.data_ptr(), None, 0, ng + 2, dt, 0) for b, dt in zip(bufs, (A.I64, A.F64, A.I64)))
 torch.cuda.synchronize()
-for dbg, what in ((0, "full"), (21, "no global stores"), (22, "no flush phase (E)"), (23, "no staging, no flush (D, E)"), (24, "loads + hash only")):
+for compact in (2, 0):
+  lib.set_option("gb_compact", compact)
+  for dbg, what in ((0, "full"), (21, "no global stores"), (22, "no flush phase (E)"), (23, "no staging, no flush (D, E)"), (24, "loads + hash only")):
     lib.set_option("gb_debug", dbg)
     for it in range(3):
         if it == 1:
@@ -22,5 +24,6 @@ for dbg, what in ((0, "full"), (21, "no global stores"), (22, "no flush phase (E
         except Exception as ex:
             pass
     ms, cnt = lib.kernel_timing_get(); lib.kernel_timing_reset(False)
-    print(json.dumps({"ablation": dbg, "what": what, "scatter+aggregate_ms": ms / max(cnt, 1)}), flush=True)
+    print(json.dumps({"records": "12-byte" if compact else "16-byte", "ablation": dbg, "what": what, "scatter+aggregate_ms": ms / max(cnt, 1)}), flush=True)
 lib.set_option("gb_debug", 0)
+lib.set_option("gb_compact", 1)

@@ -317,6 +317,11 @@ def main():
                     print("ablation", dbg, ex)
             lib.set_option("gb_debug", 0)
             report(f"groupby_count_{ng}_groups", 8.0 * n, lambda: api.groupby_sum([KK], None, ng, (ok_, oc2_, oc_)))
+            lib.set_option("gb_compact", 0)      # A/B: 16-byte records for COUNT too
+            report(f"groupby_count_{ng}_groups_16_byte_records", 8.0 * n, lambda: api.groupby_sum([KK], None, ng, (ok_, oc2_, oc_)))
+            lib.set_option("gb_compact", 2)      # A/B: 12-byte records (key word + value) for SUM
+            report(f"groupby_sum_{ng}_groups_12_byte_records", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
+            lib.set_option("gb_compact", 1)
             lib.set_option("gb_partition", 2)
             report(f"groupby_sum_{ng}_groups_radix_sort", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
             lib.set_option("gb_partition", 0)
