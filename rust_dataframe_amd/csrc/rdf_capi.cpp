@@ -57,6 +57,8 @@ struct Ctx {
     int    opt_filter_tile = 0;     // 0: compaction tile chosen from the mean chunk length; 1024 / 4096 force one (A/B)
     int    opt_gb_debug = 0;        // ablations of the partitioned GROUP BY (tools/bench_kernels.py): 1 = aggregate without LDS work, 2 = scatter without stores
     int    opt_sort_gen = 3;        // radix passes: 3 = one read + one write of the pairs per digit, decoupled look-back between 4096-pair tiles (rdf_sort.hip, default); 2 = count -> scan -> scatter over static tile ranges with the same wave-ranked tiles (A/B: slower, see rdf_sort.hip); 1 = first generation (rdf_kernels.hip)
+    bool   sort_used_local = false; // the last sort finished at least one column with os_local_kernel
+    int    opt_sort_msd = 1;        // sort keys that vary in more than 32 bits: passes over the top bits, then every bucket sorted in LDS (1, default); 0 = one pass per byte (A/B)
     int    opt_take_rows = 1;       // take over a frame through interleaved row records: 1 = when the transaction model says so (default), 0 = never, 2 = always (tests, A/B)
     int    opt_gb_skew_plan = 1;    // skewed keys: per-partition region sizes + big partitions cut into several aggregate items (1 = when the probe finds skew, default; 0 = the first-generation combining path instead, A/B; 2 = always, tests)
     int    opt_gb_compact = 1;      // partition path, keys inside a window of 2^39: 1 = 4-byte records when only rows are counted (default); 2 = also 12-byte records (key word + value) for the other aggregates (measured slower than 16-byte records, kept for A/B); 0 = 16-byte records always
@@ -2763,7 +2765,7 @@ rdf_status os_scratch_alloc(int64_t n, OsScratch& o) {
     return RDF_OK;
 }
 rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* const idxb[2], const uint8_t* nullflags, int64_t n, uint64_t bias, int need,
-                            bool null_pass, int& kcur, int& icur, const uint32_t*& idx_cur) {
+                            bool null_pass, int& kcur, int& icur, const uint32_t*& idx_cur, uint64_t range = ~0ull /* max key - bias, when known */) {
     Ctx& ctx = g_ctx;
     if (need == 0 && !null_pass) return RDF_OK;
     if (ctx.opt_sort_gen == 2) {
@@ -2781,6 +2783,105 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
         }
         return RDF_OK;
     }
+    auto one_pass = [&](int hist_row, int shift, int mask, bool np, int& launched, int64_t rows) -> rdf_status {
+        if (o.seq >= 16000) { HIP_TRY(hipMemsetAsync(o.state, 0, (size_t)o.ntiles * 256 * 8, ctx.stream)); o.seq = 0; }
+        OsPassArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.keys_in = keys[kcur]; pa.idx_in = idx_cur; pa.keys_out = keys[kcur ^ 1]; pa.idx_out = idxb[icur ^ 1];
+        pa.nullflags = np ? nullflags : nullptr;
+        pa.state = o.state; pa.ticket = o.tickets + launched; pa.bases = o.hist + hist_row * 256;
+        pa.n = rows; pa.ntiles = (rows + os_tile_items() - 1) / os_tile_items(); pa.bias = bias; pa.shift = shift; pa.mask = mask; pa.seq = ++o.seq;
+        HIP_TRY(launch_os_scatter(pa, ctx.stream));
+        ++launched;
+        kcur ^= 1; icur ^= 1; idx_cur = idxb[icur];
+        return RDF_OK;
+    };
+    // Keys that vary in 25 bits or more: stable passes over the TOP bits only (as many as leave buckets of ~1000 rows), then every
+    // bucket is sorted on its remaining bits by one block in LDS — 2 (3 from ~2.7e8 rows) passes + one read and write of the
+    // pairs instead of 4 .. 8 passes.  NULL keys (they all carry one key value: one huge bucket) are moved behind the others
+    // FIRST by the stable NULLs-last pass and stay there, in order, while the rows in front of them are sorted.  A bucket above
+    // kOsLocalMax rows (keys crowded on few top-bit patterns) sends the column through the byte passes below, which sort any order.
+    int sig = 8 * need;                       // bits of (key - bias) that vary
+    if (range != ~0ull) { sig = 0; for (uint64_t r = range; r; r >>= 1) ++sig; sig = std::min(sig, 8 * need); }
+    int B = 12;
+    while ((n >> B) > 1024 && B < 24) ++B;
+    if (ctx.opt_sort_msd && n >= 65536 && n < ((int64_t)1 << 32) && (n >> B) <= 1024 && (sig + 7) / 8 >= (B + 7) / 8 + 2 && sig - B <= 52) {
+        const int R = sig - B;
+        const int npass = (B + 7) / 8;
+        const int nbuckets = 1 << B;
+        int launched = 0;
+        int64_t nv = n;                       // rows in front of the NULL keys
+        int ks = -1, is = -1;                 // the buffers the NULL rows were left in
+        HIP_TRY(hipMemsetAsync(o.tickets, 0, 16 * 8 + 9 * 256 * 8, ctx.stream));
+        OsHistArgs ha;
+        memset(&ha, 0, sizeof ha);
+        ha.bias = bias; ha.hist = o.hist; ha.generic = 1;
+        if (null_pass) {
+            ha.keys = keys[kcur]; ha.nullflags = nullflags; ha.n = n; ha.npass = 0;
+            HIP_TRY(launch_os_hist(ha, ctx.stream));
+            RDF_TRY(one_pass(8, 0, 255, true, launched, n));
+            ks = kcur; is = icur;
+            int64_t front = 0;
+            HIP_TRY(hipMemcpyAsync(&front, o.hist + 8 * 256 + 1, 8, hipMemcpyDeviceToHost, ctx.stream));   // where the NULL run starts
+            HIP_TRY(hipStreamSynchronize(ctx.stream));
+            nv = front;
+            HIP_TRY(hipMemsetAsync(o.hist, 0, 9 * 256 * 8, ctx.stream));
+        }
+        if (nv > 0) {
+            ha.keys = keys[kcur]; ha.nullflags = nullptr; ha.n = nv; ha.npass = npass;
+            int sh = R;
+            for (int p = 0; p < npass; ++p) {
+                const int w = p == 0 ? B - 8 * (npass - 1) : 8;
+                ha.shift[p] = sh; ha.mask[p] = (1 << w) - 1;
+                sh += w;
+            }
+            HIP_TRY(launch_os_hist(ha, ctx.stream));
+            static const bool dbg = getenv("RDF_DEBUG_SORT") != nullptr;
+            {   // the top digit's counts tell crowded keys (floats of one sign and a few exponents, ...) before any pass is spent on
+                // them: a top-digit value held by more rows than its share of the buckets could take at kOsLocalMax rows each
+                int64_t top[257];
+                HIP_TRY(hipMemcpyAsync(top, o.hist + (npass - 1) * 256, 256 * 8, hipMemcpyDeviceToHost, ctx.stream));
+                HIP_TRY(hipStreamSynchronize(ctx.stream));
+                top[256] = nv;
+                const int wtop = npass == 1 ? B : 8;
+                int64_t most = 0;
+                for (int i = 0; i < (1 << wtop); ++i) most = std::max(most, top[i + 1 == (1 << wtop) ? 256 : i + 1] - top[i]);
+                if (most > ((int64_t)kOsLocalMax << (B - wtop))) {
+                    if (dbg) fprintf(stderr, "[rdf] sort: %lld of %lld rows share their top %d bits -> byte passes\n", (long long)most, (long long)nv, wtop);
+                    goto byte_passes;
+                }
+            }
+            for (int p = 0; p < npass; ++p) RDF_TRY(one_pass(p, ha.shift[p], ha.mask[p], false, launched, nv));
+            void* pb = nullptr;
+            RDF_TRY(arena_alloc((size_t)(nbuckets + 2) * 4 + 64, &pb));
+            uint32_t* bstart = (uint32_t*)pb;
+            unsigned int* dmax = (unsigned int*)(bstart + nbuckets + 1);
+            HIP_TRY(hipMemsetAsync(dmax, 0, 4, ctx.stream));
+            HIP_TRY(launch_os_bounds(keys[kcur], nv, bias, R, nbuckets, bstart, dmax, ctx.stream));
+            unsigned int maxlen = 0;
+            HIP_TRY(hipMemcpyAsync(&maxlen, dmax, 4, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_TRY(hipStreamSynchronize(ctx.stream));
+            if (dbg) fprintf(stderr, "[rdf] sort: %lld rows (+ %lld NULL keys), %d top bits of %d in %d passes, %d buckets, largest %u rows -> %s\n", (long long)nv, (long long)(n - nv), B, sig, npass, nbuckets, maxlen, maxlen <= (unsigned)kOsLocalMax ? "LDS finish" : "byte passes");
+            if (maxlen <= (unsigned)kOsLocalMax) {
+                OsLocalArgs la;
+                memset(&la, 0, sizeof la);
+                la.keys_in = keys[kcur]; la.idx_in = idx_cur; la.keys_out = keys[kcur ^ 1]; la.idx_out = idxb[icur ^ 1];
+                la.bstart = bstart; la.bias = bias; la.rbits = R; la.nbuckets = nbuckets;
+                la.lds_items = 256;
+                while (la.lds_items < (int)maxlen) la.lds_items <<= 1;
+                HIP_TRY(launch_os_local(la, ctx.stream));
+                ctx.sort_used_local = true;
+                kcur ^= 1; icur ^= 1; idx_cur = idxb[icur];
+                if (nv < n) {   // the NULL rows follow the sorted ones into the buffers that now hold the order
+                    if (ks != kcur) HIP_TRY(hipMemcpyAsync(keys[kcur] + nv, keys[ks] + nv, (size_t)(n - nv) * 8, hipMemcpyDeviceToDevice, ctx.stream));
+                    if (is != icur) HIP_TRY(hipMemcpyAsync(idxb[icur] + nv, idxb[is] + nv, (size_t)(n - nv) * 4, hipMemcpyDeviceToDevice, ctx.stream));
+                }
+                return RDF_OK;
+            }
+            // (the byte passes below start from whatever order the rows are in now, NULLs-last pass included)
+        } else return RDF_OK;                 // every key is NULL: the NULLs-last pass was the whole sort
+    }
+byte_passes:
     HIP_TRY(hipMemsetAsync(o.tickets, 0, 16 * 8 + 9 * 256 * 8, ctx.stream));
     OsHistArgs ha;
     memset(&ha, 0, sizeof ha);
@@ -2839,6 +2940,7 @@ rdf_status sort_core(const DevChunkCol* d_chunks, const int64_t* d_row_start, in
     int icur = 1;               // idxb[icur ^ 1] receives the next order
 
     OsScratch os;
+    ctx.sort_used_local = false;
     const bool gen2 = ctx.opt_sort_gen >= 2;   // rdf_sort.hip
     if (gen2) RDF_TRY(os_scratch_alloc(n, os));
     KernelTimer kt;
@@ -2862,9 +2964,10 @@ rdf_status sort_core(const DevChunkCol* d_chunks, const int64_t* d_row_start, in
         // radix passes cover only the bytes of (max key - min key): a 32-bit range stored as i64 takes 4 passes, a dictionary code 1
         uint64_t bias = 0;
         int need = 0;
-        RDF_TRY(sort_key_range(d_stats, pin_off, &bias, &need));
+        uint64_t kmax = 0;
+        RDF_TRY(sort_key_range(d_stats, pin_off, &bias, &need, &kmax));
         if (k == 0 && idx_cur == nullptr && need == 0 && !has_nulls) need = 1;   // all keys equal: one pass still writes the identity order
-        if (gen2) { RDF_TRY(os_column_passes(os, keys, idxb, (const uint8_t*)pnf, n, bias, std::min(need, dtype_size(dt)), has_nulls, kcur, icur, idx_cur)); continue; }
+        if (gen2) { RDF_TRY(os_column_passes(os, keys, idxb, (const uint8_t*)pnf, n, bias, std::min(need, dtype_size(dt)), has_nulls, kcur, icur, idx_cur, kmax >= bias ? kmax - bias : ~0ull)); continue; }
         const int npass = dtype_size(dt) + (has_nulls ? 1 : 0);
         for (int p = 0; p < npass; ++p) {
             if (p < dtype_size(dt) && p >= need) continue;
@@ -2890,7 +2993,7 @@ rdf_status sort_core(const DevChunkCol* d_chunks, const int64_t* d_row_start, in
         }
     }
     kt.stop();
-    ctx.last_kernel = "sort_scatter_kernel";
+    ctx.last_kernel = ctx.sort_used_local ? "os_scatter_kernel+os_local_kernel" : "sort_scatter_kernel";
     *idx_out = idx_cur;
     return RDF_OK;
 }
@@ -2982,13 +3085,15 @@ rdf_status radix_sort_rows(const SortBuffers& b, int64_t n, int width, bool has_
     const int npass = width + (has_nulls ? 1 : 0);
     uint64_t bias = 0;
     int need = 0;
-    RDF_TRY(sort_key_range(d_stats, pin_off, &bias, &need, kmax_out));
+    uint64_t kmax = 0;
+    RDF_TRY(sort_key_range(d_stats, pin_off, &bias, &need, &kmax));
+    if (kmax_out) *kmax_out = kmax;
     *kmin_out = bias;
     if (need == 0 && !has_nulls) need = 1;   // all keys equal: one pass still writes the identity order
     if (ctx.opt_sort_gen >= 2) {
         OsScratch os;
         RDF_TRY(os_scratch_alloc(n, os));
-        RDF_TRY(os_column_passes(os, b.keys, b.idx, (const uint8_t*)b.nullflags, n, bias, std::min(need, width), has_nulls, kcur, icur, idx_cur));
+        RDF_TRY(os_column_passes(os, b.keys, b.idx, (const uint8_t*)b.nullflags, n, bias, std::min(need, width), has_nulls, kcur, icur, idx_cur, kmax >= bias ? kmax - bias : ~0ull));
         *kcur_out = kcur;
         *icur_out = icur;
         return RDF_OK;
@@ -3678,6 +3783,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "filter_one") == 0) g_ctx.opt_filter_one = value != 0;
     else if (strcmp(name, "take_rows") == 0) g_ctx.opt_take_rows = (int)value;
     else if (strcmp(name, "sort_gen") == 0) g_ctx.opt_sort_gen = (int)value;
+    else if (strcmp(name, "sort_msd") == 0) g_ctx.opt_sort_msd = (int)value;
     else if (strcmp(name, "gb_skew_plan") == 0) g_ctx.opt_gb_skew_plan = (int)value;
     else if (strcmp(name, "gb_compact") == 0) g_ctx.opt_gb_compact = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;

@@ -227,8 +227,9 @@ struct OsHistArgs {
     const uint8_t*  nullflags;                       // [n] by original row, or nullptr: its 1s are counted for the nulls-last pass
     int64_t         n;
     uint64_t        bias;
-    int32_t         npass, pad;                      // digits 0..npass-1 of (key - bias)
+    int32_t         npass, generic;                  // digits 0..npass-1 of (key - bias): bytes, or (generic) the fields shift[p], mask[p]
     int64_t*        hist;                            // [9 * 256] zeroed; on return the exclusive scan of every pass's counts (row 8: the nulls-last pass)
+    int32_t         shift[8], mask[8];
 };
 struct OsPassArgs {
     const uint64_t* keys_in;  const uint32_t* idx_in;   // idx_in nullptr = identity
@@ -240,8 +241,23 @@ struct OsPassArgs {
     int64_t         n, ntiles;
     uint64_t        bias;
     int32_t         shift, seq;                      // seq: 1, 2, ... one per pass launched on `state`
+    int32_t         mask, pad;                       // digit = ((key - bias) >> shift) & mask; 0 = 255
     unsigned long long* debug;                       // RDF_DEBUG: [6] cycle sums of the phases (ticket, load + rank, barrier, look-back, sort + write), tiles
 };
+// Most-significant-digits-first finish (keys that vary in more than 32 bits): after stable passes over the TOP bits of the keys
+// the rows lie in buckets of <= kOsLocalMax rows that share those bits; every bucket is then sorted on the remaining `rbits`
+// low bits by one block in LDS — one read + one write of the pairs instead of one per remaining byte.
+constexpr int kOsLocalMax = 4096;
+struct OsLocalArgs {
+    const uint64_t* keys_in;  const uint32_t* idx_in;   // idx_in nullptr = identity
+    uint64_t*       keys_out; uint32_t*       idx_out;
+    const uint32_t* bstart;                          // [nbuckets + 1] first row of every bucket
+    uint64_t        bias;
+    int32_t         rbits, nbuckets;                 // bucket = (key - bias) >> rbits
+    int32_t         lds_items, pad;                  // LDS the launch carries: the next power of two >= the largest bucket
+};
+hipError_t launch_os_bounds(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, uint32_t* bstart, unsigned int* maxlen, hipStream_t s);
+hipError_t launch_os_local(const OsLocalArgs& a, hipStream_t s);
 hipError_t launch_os_hist(const OsHistArgs& a, hipStream_t s);
 hipError_t launch_os_scatter(const OsPassArgs& a, hipStream_t s);
 int os_tile_items();
@@ -388,7 +404,11 @@ enum : int32_t { AGG_SUM = 0, AGG_MIN = 1, AGG_MAX = 2 };
 // value class; the identity (~0 for MIN, 0 for MAX) is what a NULL or NaN value contributes.
 constexpr int kG2PartBits = 8;                      // 256 partitions: carry (32 KB) + staging (32 KB) leave room for TWO scatter blocks per CU
 constexpr int kG2Block = 512;                       // scatter block: 8 waves; the two blocks of a CU overlap each other's load / LDS / store phases
-constexpr int kG2Rows = 4;                          // rows per thread per super-tile
+#ifndef RDF_G2_ROWS
+#define RDF_G2_ROWS 4
+#endif
+constexpr int kG2Rows = RDF_G2_ROWS;                // rows per thread per super-tile (4: two blocks per CU; 2: LDS and registers for three)
+constexpr int kG2BlocksPerCU = kG2Rows == 2 ? 3 : 2;
 constexpr int kG2Super = kG2Block * kG2Rows;        // 2048 rows = 2 tiles of kEvalTile rows
 constexpr int kG2Line = 8;                          // records per 128-byte line: the only unit ever written
 // 12-byte records (keys inside a window of 2^39): a unit of 16 records = one 128-byte line of values + 64 bytes of key words

@@ -30,7 +30,7 @@ constexpr int kP = 1 << kG2PartBits;                 // 256 partitions
 constexpr unsigned long long kFree = ~0ull;          // LDS free marker in hashed-key space
 constexpr uint64_t kKeyMask = (1ull << (64 - kG2PartBits)) - 1;
 constexpr uint64_t kDead = ~0ull;
-constexpr int kMaxFlushLines = 512;                  // >= (7 * kP + kG2Super) / 8 = 480
+constexpr int kMaxFlushLines = (7 * kP + kG2Super) / 8 + 32;   // lines a tile can flush: every carry full but one record, plus the tile (16-record lines: fewer)
 
 __device__ __forceinline__ uint64_t g2_hash(uint64_t x) { x ^= x >> 32; x *= 0x9E3779B97F4A7C15ull; return x ^ (x >> 32); }
 __device__ __forceinline__ uint64_t g2_unhash(uint64_t x) { x ^= x >> 32; x *= 0xF1DE83E19937733Dull; return x ^ (x >> 32); }
@@ -491,19 +491,19 @@ __global__ __launch_bounds__(256) void gb2_skew_probe_kernel(const Gb2Args a, in
 // phase reads before it moves the line: the partition's owner thread writes it while it does the bookkeeping.
 
 template <bool FAST, bool COMPACT>
-__global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args a) {
+__global__ __launch_bounds__(kG2Block, 2 * kG2BlocksPerCU) void gb2_scatter_kernel(const Gb2Args a) {
     // COMPACT: 12-byte records in units of 16 (a 128-byte line of values in `recs`, 64 bytes of key words in `recs_k`), the
     // LDS staging split the same way; a "line" below is a unit of L records in either layout.
     constexpr int L = COMPACT ? kG2LineC : kG2Line, LS = COMPACT ? 4 : 3;
-    constexpr int CS = COMPACT ? L - 1 : L;   // carry slots per partition (a carry never holds a whole line)
+    constexpr int CS = L - 1;                 // carry slots per partition (a carry never holds a whole line)
     extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
     u64x2* stage = (u64x2*)gsm;                           // [kG2Super] this tile's records, grouped by partition
-    u64x2* carry = stage + kG2Super;                      // [kP * 8] records waiting for their line to fill
+    u64x2* carry = stage + kG2Super;                      // [kP * 7] records waiting for their line to fill
     uint64_t* stage_v = gsm;                              // COMPACT: [kG2Super] values, [kP * 15] carried values,
     uint64_t* carry_v = stage_v + kG2Super;               //          [kG2Super] key words, [kP * 15] carried key words
     uint32_t* stage_k = (uint32_t*)(carry_v + kP * CS);
     uint32_t* carry_k = stage_k + kG2Super;
-    uint64_t* ldesc = COMPACT ? (uint64_t*)(carry_k + kP * CS) : (uint64_t*)(carry + kP * kG2Line);  // [kMaxFlushLines] per flush line: dst line | (stage index + L) << 32 | c << 48 | j0 << (48 + LS) | d << (49 + LS)
+    uint64_t* ldesc = COMPACT ? (uint64_t*)(carry_k + kP * CS + (kP * CS & 1)) : (uint64_t*)(carry + kP * CS);  // [kMaxFlushLines] per flush line: dst line | (stage index + L) << 32 | c << 48 | j0 << (48 + LS) | d << (49 + LS)
     uint32_t* tcnt = (uint32_t*)(ldesc + kMaxFlushLines); // [kP] rank counters of the tile
     uint32_t* ccnt = tcnt + kP;                           // [kP] records in the carry
     uint32_t* written = ccnt + kP;                        // [kP] lines of the region already written
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args 
             const uint32_t w0 = written[tid];
             // no line to flush: the tile's records go straight to the carry in phase (D) (bit 31: lstart is a carry index) — a loop
             // in this thread, or descriptors of their own in phase (E), sat on every tile's critical path
-            lstart[tid] = kk == 0 ? (0x80000000u | ((uint32_t)tid * (COMPACT ? CS : kG2Line) + cc)) : ex_t;
+            lstart[tid] = kk == 0 ? (0x80000000u | ((uint32_t)tid * CS + cc)) : ex_t;
             tail[tid] = ex_t + L * kk - cc;
             if (w0 + kk > cap) err |= 16u;
             for (uint32_t j = 0; j < kk; ++j) {
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args 
             const uint64_t ds = ldesc[i];
             const uint32_t src = (uint32_t)(ds >> 32) & 0xFFFFu, c = (uint32_t)(ds >> 48) & (uint32_t)(L - 1), d = (uint32_t)(ds >> (49 + LS));
             ln.dst = (uint32_t)ds;
-            ln.slot = d * (COMPACT ? CS : kG2Line) + l8;
+            ln.slot = d * CS + l8;
             const bool fc = l8 < c;
             if constexpr (COMPACT) {
                 ln.kw = fc ? carry_k[ln.slot] : stage_k[src + l8 - L];
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(kG2Block, 4) void gb2_scatter_kernel(const Gb2Args 
         } else {
             u64x2 rec;
             rec[0] = kDead; rec[1] = 0;
-            if (l8 < c) rec = carry[d * kG2Line + l8];
+            if (l8 < c) rec = carry[d * CS + l8];
             if (line < dcap) recs[(dreg + line) * kG2Line + l8] = rec;
             else err |= 16u;
         }
@@ -1039,8 +1039,8 @@ __global__ __launch_bounds__(kBlock) void key_unpack_kernel(const KeyPackArgs a)
 
 size_t gb2_scatter_lds_bytes(bool compact) {
     const size_t bookkeeping = (size_t)kMaxFlushLines * 8 + (size_t)kP * 4 * 5;
-    if (compact) return ((size_t)kG2Super + (size_t)kP * (kG2LineC - 1)) * 12 + bookkeeping;   // 78 KB: still two blocks per CU
-    return (size_t)kG2Super * 16 + (size_t)kP * kG2Line * 16 + bookkeeping;
+    if (compact) return ((size_t)kG2Super + (size_t)kP * (kG2LineC - 1)) * 12 + 8 + bookkeeping;   // 78 KB: still two blocks per CU
+    return (size_t)kG2Super * 16 + (size_t)kP * (kG2Line - 1) * 16 + bookkeeping;
 }
 hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s) {
     const size_t lds = (size_t)a.table_slots * 20 + 16 + 48;   // table, group counter, the two special groups

@@ -41,7 +41,7 @@ constexpr int kOsLook = 8;                  // predecessors read per look-back s
 constexpr uint64_t kOsValueMask = (1ull << 48) - 1;
 constexpr uint64_t kOsLocal = 1ull << 48, kOsInclusive = 2ull << 48;
 
-__device__ __forceinline__ int os_digit(uint64_t key, uint64_t bias, int shift) { return (int)(((key - bias) >> shift) & 255); }
+__device__ __forceinline__ int os_digit(uint64_t key, uint64_t bias, int shift, int mask = 255) { return (int)(((key - bias) >> shift) & (uint64_t)mask); }
 
 // Histograms of all `npass` digits of (key - bias) in one read of the keys (+ the NULL count for the nulls-last pass).
 __global__ __launch_bounds__(kBlock) void os_hist_kernel(const OsHistArgs a) {
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void os_hist_kernel(const OsHistArgs a) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             if (p >= a.npass) break;
-            const int d = (int)((k >> (8 * p)) & 255);
+            const int d = a.generic ? (int)((k >> a.shift[p]) & (uint64_t)a.mask[p]) : (int)((k >> (8 * p)) & 255);
             // a wave whose rows all share the digit (the upper bytes of a narrow range, dictionary codes): one add, not 64 serialised ones
             const int d0 = __builtin_amdgcn_readfirstlane(d);
             const uint64_t same = __ballot(d == d0);
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
             const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
             int d = 0;
             if (i < a.n) {
-                d = a.nullflags ? (int)as_global<uint8_t>(a.nullflags)[idx[j]] : os_digit(key[j], a.bias, a.shift);
+                d = a.nullflags ? (int)as_global<uint8_t>(a.nullflags)[idx[j]] : os_digit(key[j], a.bias, a.shift, a.mask);
                 atomicAdd(&thist[d], 1u);
             }
             digit[j] = d;
@@ -401,7 +401,91 @@ hipError_t launch_os_scatter(const OsPassArgs& a, hipStream_t s) {
     int64_t grid = (int64_t)(eval_grid_limit() / 8) * (kOsItems >= 16 ? 2 : 5);
     if (grid > a.ntiles) grid = a.ntiles;
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((os_scatter_kernel<kOsItems>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    OsPassArgs b = a;
+    if (b.mask == 0) b.mask = 255;
+    hipLaunchKernelGGL((os_scatter_kernel<kOsItems>), dim3((unsigned)grid), dim3(kBlock), 0, s, b);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The finish of the most-significant-digits-first order (see OsLocalArgs): bucket boundaries, then one block per bucket.
+
+// bstart[b] = first row whose bucket is >= b (rows are sorted by bucket); thread i writes the entries of the buckets that END in
+// front of row i — every entry of bstart[0 .. nbuckets] exactly once, empty buckets included
+__global__ __launch_bounds__(kBlock) void os_bounds_kernel(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, uint32_t* bstart) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t cur = i < n ? (int64_t)((as_global<uint64_t>(keys)[i] - bias) >> rbits) : (int64_t)nbuckets;
+        const int64_t prev = i > 0 ? (int64_t)((as_global<uint64_t>(keys)[i - 1] - bias) >> rbits) : -1;
+        for (int64_t b = prev + 1; b <= cur; ++b) bstart[b] = (uint32_t)i;
+    }
+}
+__global__ __launch_bounds__(kBlock) void os_bucket_max_kernel(const uint32_t* bstart, int nbuckets, unsigned int* out) {
+    unsigned int m = 0;
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < nbuckets; b += (int64_t)gridDim.x * kBlock) {
+        const unsigned int len = bstart[b + 1] - bstart[b];
+        m = len > m ? len : m;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned int o = (unsigned int)__shfl_xor((int)m, d); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// Bitonic network over P 64-bit words in LDS.  A word is (the key's low rbits) << 12 | (the row's place in the bucket): the
+// places make the words distinct, so the order of equal keys is the order the rows came in — the sort is stable, which the
+// column-by-column lexicographic order and the NULLs-last pass after it rely on.
+template <int P>
+__device__ __forceinline__ void os_bitonic(uint64_t* s) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int q = threadIdx.x; q < P / 2; q += kBlock) {
+                const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+                const uint64_t x = s[i], y = s[i | j];
+                if ((x > y) == ((i & k) == 0)) { s[i] = y; s[i | j] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void os_local_kernel(const OsLocalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s[];
+    const int64_t bucket = blockIdx.x;
+    const uint32_t start = a.bstart[bucket], len = a.bstart[bucket + 1] - start;
+    if (len == 0) return;
+    int P = 256;
+    while (P < (int)len) P <<= 1;
+    const uint64_t low = (1ull << a.rbits) - 1;
+    for (int i = threadIdx.x; i < P; i += kBlock) {
+        uint64_t w = ~0ull;
+        if (i < (int)len) w = (((__builtin_nontemporal_load(as_global<uint64_t>(a.keys_in) + start + i) - a.bias) & low) << 12) | (uint64_t)i;
+        s[i] = w;
+    }
+    __syncthreads();
+    switch (P) {
+        case 256: os_bitonic<256>(s); break;
+        case 512: os_bitonic<512>(s); break;
+        case 1024: os_bitonic<1024>(s); break;
+        case 2048: os_bitonic<2048>(s); break;
+        default: os_bitonic<kOsLocalMax>(s); break;
+    }
+    const uint64_t top = (uint64_t)bucket << a.rbits;
+    for (int j = threadIdx.x; j < (int)len; j += kBlock) {
+        const uint64_t w = s[j];
+        const uint32_t from = start + (uint32_t)(w & 4095);
+        __builtin_nontemporal_store((top | (w >> 12)) + a.bias, as_global_mut<uint64_t>(a.keys_out) + start + j);
+        __builtin_nontemporal_store(a.idx_in ? as_global<uint32_t>(a.idx_in)[from] : from, as_global_mut<uint32_t>(a.idx_out) + start + j);
+    }
+}
+hipError_t launch_os_bounds(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, uint32_t* bstart, unsigned int* maxlen, hipStream_t s) {
+    int64_t grid = (n + 1 + kBlock - 1) / kBlock;
+    if (grid > eval_grid_limit()) grid = eval_grid_limit();
+    hipLaunchKernelGGL(os_bounds_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, keys, n, bias, rbits, nbuckets, bstart);
+    int64_t g2 = ((int64_t)nbuckets + kBlock - 1) / kBlock;
+    if (g2 > eval_grid_limit()) g2 = eval_grid_limit();
+    hipLaunchKernelGGL(os_bucket_max_kernel, dim3((unsigned)g2), dim3(kBlock), 0, s, bstart, nbuckets, maxlen);
+    return hipGetLastError();
+}
+hipError_t launch_os_local(const OsLocalArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(os_local_kernel, dim3((unsigned)a.nbuckets), dim3(kBlock), (size_t)a.lds_items * 8, s, a);
     return hipGetLastError();
 }
 

@@ -290,6 +290,37 @@ def test_sort_generations(gpu, ora, sort_gen):
         lib.set_option("sort_gen", 3)
 
 
+def test_sort_top_bits_then_lds_buckets(gpu, ora):
+    """Keys that vary in more than 32 bits: stable passes over the top bits, then every bucket sorted in LDS (os_local_kernel).
+    Buckets of every LDS size class (a quarter of the rows crowd an eighth of the key range), ties inside buckets (stability),
+    NULLs last (they are moved behind the other rows first), descending, a second criterion; keys crowded on a few top-bit
+    patterns — doubles of one magnitude, eight patterns of integer keys — go through the byte passes instead; the A/B switch
+    gives the same order."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(777)
+    n = 4_000_000
+    kv = rng.integers(-2 ** 61, 2 ** 61, n)
+    crowd = rng.uniform(size=n) < 0.25
+    kv[crowd] = rng.integers(2 ** 58, 2 ** 58 + 2 ** 59, int(crowd.sum()))
+    kv[rng.integers(0, n, n // 50)] = kv[rng.integers(0, n, n // 50)]          # ties
+    wide = [A.HostArray.from_numpy(kv, valid=rng.uniform(size=n) >= 0.01, dtype=A.I64)]
+    ties = [A.HostArray.from_numpy(rng.integers(0, 3, n).astype(np.int8), dtype=A.I8)]
+    fl = [A.HostArray.from_numpy(rng.normal(size=n) * 1e6, dtype=A.F64)]
+    crowded = [A.HostArray.from_numpy((rng.integers(0, 8, n) << 59) + rng.integers(0, 2 ** 40, n), dtype=A.I64)]
+    for cols, desc, local in [([wide], [False], True), ([ties, wide], [False, True], True), ([fl], [False], False), ([crowded], [False], False)]:
+        exp = ora.sort_to_indices(cols, desc).to_numpy()
+        got = gpu.sort_to_indices(cols, desc).to_numpy()
+        assert ("os_local_kernel" in lib.last_kernel()) == local, lib.last_kernel()
+        assert np.array_equal(got, exp), (desc, local)
+        lib.set_option("sort_msd", 0)
+        try:
+            got0 = gpu.sort_to_indices(cols, desc).to_numpy()
+            assert "os_local_kernel" not in lib.last_kernel()
+        finally:
+            lib.set_option("sort_msd", 1)
+        assert np.array_equal(got0, exp), (desc, "byte passes")
+
+
 def test_filter_frame_wider_than_a_program(gpu, ora):
     """A frame of 12 columns (lineitem has 16): the predicate reads columns 9 and 2 — a projection onto the columns it reads runs
     the fused predicate, the compaction takes all twelve (two launches of <= 8 columns)."""

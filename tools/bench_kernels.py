@@ -240,6 +240,15 @@ def main():
     report("sort_to_indices_i64", 8.0 * ns, lambda: api.sort_to_indices([[KS]], [False], oi), rows=ns)   # keys in [-2^31, 2^31): 4 varying bytes + sign
     kw = dev_i64(ns, 9, -2 ** 62, 2 ** 62)
     report("sort_to_indices_i64_full_range", 8.0 * ns, lambda: api.sort_to_indices([[arr(kw, A.I64, ns)]], [False], oi), rows=ns)
+    lib.set_option("sort_msd", 0)      # A/B: one pass per byte
+    report("sort_to_indices_i64_full_range_byte_passes", 8.0 * ns, lambda: api.sort_to_indices([[arr(kw, A.I64, ns)]], [False], oi), rows=ns)
+    lib.set_option("sort_msd", 1)
+    if n >= 200_000_000:
+        ns2 = min(n, 1_000_000_000)
+        kw2 = dev_i64(ns2, 9, -2 ** 62, 2 ** 62)
+        oi2_ = out_like(A.U32, ns2)
+        report("sort_to_indices_i64_full_range_1e9", 8.0 * ns2, lambda: api.sort_to_indices([[arr(kw2, A.I64, ns2)]], [False], oi2_), rows=ns2)
+        del kw2, oi2_
     kd = dev_i64(ns, 10, 0, 200)
     report("sort_to_indices_i64_dictionary_codes", 8.0 * ns, lambda: api.sort_to_indices([[arr(kd, A.I64, ns)]], [False], oi), rows=ns)
     # ArrayFunctions over a List<f64> column: rows of 10 elements (one row per lane) and of 1000 elements (one row per wave)
