@@ -430,46 +430,76 @@ __global__ __launch_bounds__(kBlock) void os_bucket_max_kernel(const uint32_t* b
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
-// Bitonic network over P 64-bit words in LDS.  A word is (the key's low rbits) << 12 | (the row's place in the bucket): the
-// places make the words distinct, so the order of equal keys is the order the rows came in — the sort is stable, which the
-// column-by-column lexicographic order and the NULLs-last pass after it rely on.
-template <int P>
-__device__ __forceinline__ void os_bitonic(uint64_t* s) {
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int q = threadIdx.x; q < P / 2; q += kBlock) {
-                const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
-                const uint64_t x = s[i], y = s[i | j];
-                if ((x > y) == ((i & k) == 0)) { s[i] = y; s[i | j] = x; }
+// Bitonic network over P 64-bit words in LDS, ONE WAVE per bucket.  A word is (the key's low rbits) << 12 | (the row's place in
+// the bucket): the places make the words distinct, so the order of equal keys is the order the rows came in — the sort is
+// stable, which the column-by-column lexicographic order and the NULLs-last pass rely on.
+// A lane takes 2^MB words whose indices differ in MB consecutive stride bits and runs the MB sub-stages of those strides in
+// registers: one LDS round trip per four sub-stages (18 for 1024 words instead of 55 — the first version, one sub-stage per
+// round trip and block barrier, was bound by LDS bandwidth: 1.04 ms per 5e7 rows), no block barrier at all.  Words are padded by
+// one per 16 (a lane's 16 consecutive words would otherwise put all 64 lanes on the same banks).
+__device__ __forceinline__ int os_pad(int i) { return i + (i >> 4); }
+template <int MB>
+__device__ __forceinline__ void os_chunk(uint64_t* s, int P, int k, int jl_log) {
+    constexpr int E = 1 << MB;
+    for (int q = threadIdx.x; q < (P >> MB); q += 64) {
+        const int i = ((q >> jl_log) << (jl_log + MB)) | (q & ((1 << jl_log) - 1));
+        uint64_t v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = s[os_pad(i | (e << jl_log))];
+        const bool asc = (i & k) == 0;
+#pragma unroll
+        for (int b = MB - 1; b >= 0; --b) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (e & (1 << b)) continue;
+                const uint64_t x = v[e], y = v[e | (1 << b)];
+                const bool sw = (x > y) == asc;
+                v[e] = sw ? y : x;
+                v[e | (1 << b)] = sw ? x : y;
             }
-            __syncthreads();
         }
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[os_pad(i | (e << jl_log))] = v[e];
     }
 }
-__global__ __launch_bounds__(kBlock) void os_local_kernel(const OsLocalArgs a) {
+__global__ __launch_bounds__(64) void os_local_kernel(const OsLocalArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s[];
     const int64_t bucket = blockIdx.x;
     const uint32_t start = a.bstart[bucket], len = a.bstart[bucket + 1] - start;
     if (len == 0) return;
-    int P = 256;
-    while (P < (int)len) P <<= 1;
+    if (len == 1) {
+        if (threadIdx.x == 0) {
+            as_global_mut<uint64_t>(a.keys_out)[start] = as_global<uint64_t>(a.keys_in)[start];
+            as_global_mut<uint32_t>(a.idx_out)[start] = a.idx_in ? as_global<uint32_t>(a.idx_in)[start] : start;
+        }
+        return;
+    }
+    int P = 2, plog = 1;
+    while (P < (int)len) { P <<= 1; ++plog; }
     const uint64_t low = (1ull << a.rbits) - 1;
-    for (int i = threadIdx.x; i < P; i += kBlock) {
+    for (int i = threadIdx.x; i < P; i += 64) {
         uint64_t w = ~0ull;
         if (i < (int)len) w = (((__builtin_nontemporal_load(as_global<uint64_t>(a.keys_in) + start + i) - a.bias) & low) << 12) | (uint64_t)i;
-        s[i] = w;
+        s[os_pad(i)] = w;
     }
     __syncthreads();
-    switch (P) {
-        case 256: os_bitonic<256>(s); break;
-        case 512: os_bitonic<512>(s); break;
-        case 1024: os_bitonic<1024>(s); break;
-        case 2048: os_bitonic<2048>(s); break;
-        default: os_bitonic<kOsLocalMax>(s); break;
+    for (int ks = 1; ks <= plog; ++ks) {
+        for (int jlog = ks - 1; jlog >= 0;) {
+            const int mb = jlog + 1 < 4 ? jlog + 1 : 4;
+            const int jl_log = jlog - mb + 1;
+            switch (mb) {
+                case 4: os_chunk<4>(s, P, 1 << ks, jl_log); break;
+                case 3: os_chunk<3>(s, P, 1 << ks, jl_log); break;
+                case 2: os_chunk<2>(s, P, 1 << ks, jl_log); break;
+                default: os_chunk<1>(s, P, 1 << ks, jl_log); break;
+            }
+            __syncthreads();   // one wave: orders the LDS traffic for the compiler, costs nothing
+            jlog = jl_log - 1;
+        }
     }
     const uint64_t top = (uint64_t)bucket << a.rbits;
-    for (int j = threadIdx.x; j < (int)len; j += kBlock) {
-        const uint64_t w = s[j];
+    for (int j = threadIdx.x; j < (int)len; j += 64) {
+        const uint64_t w = s[os_pad(j)];
         const uint32_t from = start + (uint32_t)(w & 4095);
         __builtin_nontemporal_store((top | (w >> 12)) + a.bias, as_global_mut<uint64_t>(a.keys_out) + start + j);
         __builtin_nontemporal_store(a.idx_in ? as_global<uint32_t>(a.idx_in)[from] : from, as_global_mut<uint32_t>(a.idx_out) + start + j);
@@ -485,7 +515,7 @@ hipError_t launch_os_bounds(const uint64_t* keys, int64_t n, uint64_t bias, int 
     return hipGetLastError();
 }
 hipError_t launch_os_local(const OsLocalArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(os_local_kernel, dim3((unsigned)a.nbuckets), dim3(kBlock), (size_t)a.lds_items * 8, s, a);
+    hipLaunchKernelGGL(os_local_kernel, dim3((unsigned)a.nbuckets), dim3(64), (size_t)(a.lds_items + a.lds_items / 16 + 1) * 8, s, a);
     return hipGetLastError();
 }
 
