@@ -59,6 +59,7 @@ struct Ctx {
     int    opt_sort_gen = 3;        // radix passes: 3 = one read + one write of the pairs per digit, decoupled look-back between 4096-pair tiles (rdf_sort.hip, default); 2 = count -> scan -> scatter over static tile ranges with the same wave-ranked tiles (A/B: slower, see rdf_sort.hip); 1 = first generation (rdf_kernels.hip)
     bool   sort_used_local = false; // the last sort finished at least one column with os_local_kernel
     int    opt_sort_msd = 1;        // sort keys that vary in more than 32 bits: passes over the top bits, then every bucket sorted in LDS (1, default); 0 = one pass per byte (A/B)
+    int    opt_join_table = 1;      // equi-join on one key column: probe a table of the distinct build keys (1, default); 0 = the bucket index over the sorted build keys (A/B)
     int    opt_take_rows = 1;       // take over a frame through interleaved row records: 1 = when the transaction model says so (default), 0 = never, 2 = always (tests, A/B)
     int    opt_gb_skew_plan = 1;    // skewed keys: per-partition region sizes + big partitions cut into several aggregate items (1 = when the probe finds skew, default; 0 = the first-generation combining path instead, A/B; 2 = always, tests)
     int    opt_gb_compact = 1;      // partition path, keys inside a window of 2^39: 1 = 4-byte records when only rows are counted (default); 2 = also 12-byte records (key word + value) for the other aggregates (measured slower than 16-byte records, kept for A/B); 0 = 16-byte records always
@@ -3274,7 +3275,20 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
     RDF_TRY(arena_alloc((size_t)nbuckets * 8, &pbuckets));
     RDF_TRY(arena_alloc((size_t)(np > 0 ? np : 1) * 4, &pfirst));
     HIP_TRY(hipMemsetAsync(pbuckets, 0, (size_t)nbuckets * 8, ctx.stream));
-    if (nrv > 0) {
+    // one key column: a table of the distinct build keys at load <= 0.5 instead — one random transaction per probe row, where the
+    // bucket index costs three (bucket, sorted keys, build row)
+    const bool use_table = nkeys == 1 && nrv > 0 && nb < ((int64_t)1 << 31) - 1 && ctx.opt_join_table;
+    void* ptable = nullptr;
+    int tbits = 10;
+    if (use_table) {
+        while (((int64_t)1 << tbits) < 2 * nrv) ++tbits;
+        RDF_TRY(arena_alloc(((size_t)16 << tbits) + 64, &ptable));
+        HIP_TRY(hipMemsetAsync(ptable, 0, (size_t)16 << tbits, ctx.stream));
+        JoinTableArgs ta;
+        memset(&ta, 0, sizeof ta);
+        ta.rkeys = sb.keys[kcur]; ta.ridx = sb.idx[icur]; ta.nrv = nrv; ta.table = (uint64_t*)ptable; ta.tmask = ((uint64_t)1 << tbits) - 1; ta.tshift = 64 - tbits;
+        HIP_TRY(launch_join_table(ta, ctx.stream));
+    } else if (nrv > 0) {
         JoinBucketArgs ba;
         memset(&ba, 0, sizeof ba);
         ba.rkeys = sb.keys[kcur]; ba.nrv = nrv; ba.buckets = (uint32_t*)pbuckets; ba.kmin = bkmin; ba.bucket_shift = bshift;
@@ -3285,6 +3299,7 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
     ja.buckets = (const uint32_t*)pbuckets;
     ja.kmin = bkmin; ja.kmax = bkmax; ja.bucket_shift = bshift;
     ja.first = (uint32_t*)pfirst;
+    if (use_table) { ja.table = (const uint64_t*)ptable; ja.tmask = ((uint64_t)1 << tbits) - 1; ja.tshift = 64 - tbits; }
     ja.nkeys = nkeys;
     for (int k = 0; k < 4; ++k) { ja.pbits[k] = pbits[k]; ja.bbits[k] = bbits[k]; }
     ja.lkeys = (const uint64_t*)ppk;
@@ -3784,6 +3799,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "take_rows") == 0) g_ctx.opt_take_rows = (int)value;
     else if (strcmp(name, "sort_gen") == 0) g_ctx.opt_sort_gen = (int)value;
     else if (strcmp(name, "sort_msd") == 0) g_ctx.opt_sort_msd = (int)value;
+    else if (strcmp(name, "join_table") == 0) g_ctx.opt_join_table = (int)value;
     else if (strcmp(name, "gb_skew_plan") == 0) g_ctx.opt_gb_skew_plan = (int)value;
     else if (strcmp(name, "gb_compact") == 0) g_ctx.opt_gb_compact = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;

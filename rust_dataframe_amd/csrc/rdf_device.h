@@ -290,7 +290,15 @@ struct JoinProbeArgs {
     int32_t         nkeys, pad2;
     const uint64_t* pbits[4];  // [nkeys][nl] key bits of the probe side, row order
     const uint64_t* bbits[4];  // [nkeys][nr] key bits of the build side, ROW order (indexed through ridx)
+    // one key column, fewer than 2^31 build rows: an open-addressing table over the DISTINCT build keys, 16 bytes per slot:
+    // {key bits, first sorted position << 32 | info}, info = the key's build rows (>= 2) or 1 << 31 | the build row of a key that
+    // occurs once, 0 = empty slot.  A probe is ONE random memory transaction: the count phase leaves the build row itself in
+    // `first` (bit 31 set) for such keys and the write phase never touches ridx.
+    const uint64_t* table;     // [2 * (tmask + 1)] or nullptr: the bucket index above
+    uint64_t        tmask;
+    int32_t         tshift, pad3;   // slot = (key * golden ratio) >> tshift
 };
+struct JoinTableArgs { const uint64_t* rkeys; const uint32_t* ridx; int64_t nrv; uint64_t* table; uint64_t tmask; int32_t tshift, pad; };
 struct JoinCombineArgs { const uint64_t* bits[4]; int32_t nkeys, pad; int64_t n; const uint8_t* nullflags; uint64_t* out; uint64_t* bit_stats; };
 struct JoinBucketArgs { const uint64_t* rkeys; int64_t nrv; uint32_t* buckets; uint64_t kmin; int32_t bucket_shift; };
 struct JoinAppendArgs {        // FULL: build rows nobody matched (and NULL-key build rows) with a NULL probe index
@@ -646,6 +654,7 @@ hipError_t launch_sort_keys(const SortKeyArgs& a, hipStream_t s);
 hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_join_buckets(const JoinBucketArgs& a, hipStream_t s);
+hipError_t launch_join_table(const JoinTableArgs& a, hipStream_t s);
 hipError_t launch_join_combine(const JoinCombineArgs& a, hipStream_t s);
 hipError_t launch_join_count(const JoinProbeArgs& a, hipStream_t s);
 hipError_t launch_join_write(const JoinProbeArgs& a, hipStream_t s);

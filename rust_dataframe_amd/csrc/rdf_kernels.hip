@@ -673,12 +673,45 @@ __global__ __launch_bounds__(kBlock) void join_buckets_kernel(const JoinBucketAr
         if (i == a.nrv - 1 || ((a.rkeys[i + 1] - a.kmin) >> a.bucket_shift) != b) a.buckets[2 * b + 1] = (uint32_t)(i + 1);
     }
 }
-// sorted build positions [lo, hi) whose key equals probe row i's key
-__device__ __forceinline__ void join_range(const JoinProbeArgs& a, int64_t i, int64_t& lo, int64_t& hi) {
+// the table of distinct build keys: the thread at the start of a run of equal sorted keys inserts it (distinct keys: an empty slot
+// is claimed with one CAS on its second word, nobody compares keys while the table is built)
+__global__ __launch_bounds__(kBlock) void join_table_kernel(const JoinTableArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.nrv; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t k = a.rkeys[i];
+        if (i > 0 && a.rkeys[i - 1] == k) continue;
+        int64_t j = i + 1;
+        while (j < a.nrv && a.rkeys[j] == k) ++j;
+        const uint32_t info = j - i == 1 ? (0x80000000u | a.ridx[i]) : (uint32_t)(j - i);
+        const unsigned long long w1 = ((unsigned long long)i << 32) | info;
+        uint64_t s = (k * 0x9E3779B97F4A7C15ull) >> a.tshift;
+        for (;;) {
+            if (atomicCAS((unsigned long long*)&a.table[2 * s + 1], 0ull, w1) == 0ull) { a.table[2 * s] = k; break; }
+            s = (s + 1) & a.tmask;
+        }
+    }
+}
+typedef uint64_t join_u64x2 __attribute__((ext_vector_type(2)));
+// sorted build positions [lo, hi) whose key equals probe row i's key; direct = the build row itself when the key occurs once (table path)
+__device__ __forceinline__ void join_range(const JoinProbeArgs& a, int64_t i, int64_t& lo, int64_t& hi, uint32_t& direct) {
     lo = hi = 0;
+    direct = 0;
     if (a.lnull && a.lnull[i]) return;
     const uint64_t k = a.lkeys[i];
     if (k < a.kmin || k > a.kmax) return;
+    if (a.table) {
+        uint64_t s = (k * 0x9E3779B97F4A7C15ull) >> a.tshift;
+        for (;;) {
+            const join_u64x2 e = *(const join_u64x2*)(a.table + 2 * s);
+            if (e[1] == 0) return;
+            if (e[0] == k) {
+                const uint32_t info = (uint32_t)e[1];
+                lo = (int64_t)(e[1] >> 32);
+                if (info >> 31) { hi = lo + 1; direct = info; } else hi = lo + info;
+                return;
+            }
+            s = (s + 1) & a.tmask;
+        }
+    }
     const uint64_t b = (k - a.kmin) >> a.bucket_shift;
     const uint2 se = *(const uint2*)(a.buckets + 2 * b);
     int64_t l = se.x, h = se.y;
@@ -692,7 +725,8 @@ __device__ __forceinline__ void join_range(const JoinProbeArgs& a, int64_t i, in
 __global__ __launch_bounds__(kBlock) void join_count_kernel(const JoinProbeArgs a) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.nl; i += (int64_t)gridDim.x * kBlock) {
         int64_t lo, hi;
-        join_range(a, i, lo, hi);
+        uint32_t direct;
+        join_range(a, i, lo, hi, direct);
         int64_t c = hi - lo;
         if (a.nkeys > 1) {   // candidates share the tuple's hash: count (and mark) only the ones whose key tuples are equal
             c = 0;
@@ -700,7 +734,7 @@ __global__ __launch_bounds__(kBlock) void join_count_kernel(const JoinProbeArgs 
                 if (join_verify(a, i, p)) { ++c; if (a.matched) atomicOr(&a.matched[p >> 5], 1u << (p & 31)); }
         } else if (a.matched) for (int64_t p = lo; p < hi; ++p) atomicOr(&a.matched[p >> 5], 1u << (p & 31));
         a.counts[i] = (c == 0 && a.outer) ? 1 : c;
-        a.first[i] = c == 0 ? ~0u : (uint32_t)lo;   // the write phase does not search again
+        a.first[i] = c == 0 ? ~0u : direct ? direct : (uint32_t)lo;   // the write phase does not search again (bit 31: not a position but the one build row itself)
         if (c == 0 && a.outer) atomicAdd(a.unmatched, 1ull);
     }
 }
@@ -715,6 +749,11 @@ __global__ __launch_bounds__(kBlock) void join_write_kernel(const JoinProbeArgs 
                 a.out_build[o] = 0;
                 atomicAnd(&a.out_build_validity[o >> 5], ~(1u << (o & 31)));
             }
+            continue;
+        }
+        if (a.table && (lo >> 31)) {   // a key that occurs once on the build side: its row came with the table entry
+            a.out_probe[o] = (uint32_t)i;
+            a.out_build[o] = lo & 0x7FFFFFFFu;
             continue;
         }
         if (a.nkeys > 1) {   // walk the hash range again and emit the verified pairs (cnt of them, in sorted-position order)
@@ -1720,6 +1759,10 @@ static int rows_grid(int64_t n) {
 }
 hipError_t launch_join_buckets(const JoinBucketArgs& a, hipStream_t s) {
     if (a.nrv > 0) hipLaunchKernelGGL(join_buckets_kernel, dim3(rows_grid(a.nrv)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_join_table(const JoinTableArgs& a, hipStream_t s) {
+    if (a.nrv > 0) hipLaunchKernelGGL(join_table_kernel, dim3(rows_grid(a.nrv)), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_join_combine(const JoinCombineArgs& a, hipStream_t s) {

@@ -1028,7 +1028,8 @@ def test_sort_skips_constant_key_bytes(gpu, ora):
 
 @pytest.mark.parametrize("how", ["left", "right", "inner", "full"])
 def test_equijoin_bucket_index_edge_cases(gpu, ora, how):
-    """The probe goes through a bucket index on the top bits of (key - min key): sparse keys over the whole i64 range
+    """The probe goes through a table of the distinct build keys, or (A/B, and for several key columns) through a bucket index on
+    the top bits of (key - min key): sparse keys over the whole i64 range
     (many empty buckets, shift > 0), heavy skew (one bucket holds most rows), keys outside the build range, a single
     distinct build key, extreme keys, negative floats and NaN-free f64 keys; pairs equal the oracle's nested loops."""
     rng = np.random.default_rng(9100)
@@ -1046,11 +1047,17 @@ def test_equijoin_bucket_index_edge_cases(gpu, ora, how):
     cases.append((mk(np.array([i64.min, i64.max, 0, -1, i64.min, 5])), mk(np.array([i64.max, i64.min, i64.min, 7]))))
     cases.append((mk(np.round(rng.uniform(-3, 3, 2000), 1)), mk(np.round(rng.uniform(-3, 3, 700), 1), 0.05)))   # f64 keys incl. -0.0 / 0.0 patterns
     cases.append((mk(rng.integers(0, 50, 100)), mk(np.array([], dtype=np.int64))))                            # empty build side
+    from rust_dataframe_amd import lib
     for lk, rk in cases:
-        gl, gr = gpu.equijoin_indices(lk, rk, how)
         el, er = ora.equijoin_indices(lk, rk, how)
-        assert gl.length == el.length and gl.null_count == el.null_count and gr.null_count == er.null_count
-        assert _pairs(gl, gr) == _pairs(el, er), f"join {how}"
+        for table in (1, 0):     # the table of distinct build keys (default) and the bucket index over the sorted build keys
+            lib.set_option("join_table", table)
+            try:
+                gl, gr = gpu.equijoin_indices(lk, rk, how)
+            finally:
+                lib.set_option("join_table", 1)
+            assert gl.length == el.length and gl.null_count == el.null_count and gr.null_count == er.null_count
+            assert _pairs(gl, gr) == _pairs(el, er), f"join {how} table={table}"
 
 
 @pytest.mark.parametrize("val_dtype", [A.F64, A.I64, A.F32, None])

@@ -288,12 +288,15 @@ def main():
             report(nm + "_sort", 16.0 * nsort, lambda: api.list_sort(Ls, osv), rows=nsort)
         del lo_, lv_
     # DataFrame::join: 1e8 probe rows against 1e7 distinct build keys (inner: every probe row finds exactly one partner)
-    if not only or "join_inner_1e8_x_1e7" in only:
+    if not only or "join_inner_1e8_x_1e7" in only or "join_inner_1e8_x_1e7_bucket_index" in only:
         nl_, nr_ = min(n, 100_000_000), 10_000_000
         lk_ = dev_i64(nl_, 12, 0, nr_)
         rk_ = torch.randperm(nr_, device="cuda", dtype=torch.int64)
         jl, jr = out_like(A.U32, nl_, True), out_like(A.U32, nl_, True)
         report("join_inner_1e8_x_1e7", 8.0 * nl_ + 8.0 * nr_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk_, A.I64, nl_)], [arr(rk_, A.I64, nr_)], "inner", (jl, jr)), rows=nl_)
+        lib.set_option("join_table", 0)      # A/B: bucket index over the sorted build keys
+        report("join_inner_1e8_x_1e7_bucket_index", 8.0 * nl_ + 8.0 * nr_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk_, A.I64, nl_)], [arr(rk_, A.I64, nr_)], "inner", (jl, jr)), rows=nl_)
+        lib.set_option("join_table", 1)
         del lk_, rk_
     # hash GROUP BY key -> sum(val): 1e6 groups (config C4's per-GPU leg) and 1e3 groups (contended)
     for ng in (1_000_000, 2_000, 1_000, 100, 8):
