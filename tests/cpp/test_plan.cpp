@@ -1,6 +1,7 @@
 // Plan builders (src/operation/scalar.rs) — no device needed.
 #include "mini_test.hpp"
 #include "rdf_frame.hpp"
+#include <unistd.h>
 
 using namespace rdf::plan;
 using rdf::DataType;
@@ -190,6 +191,127 @@ TEST(test_optimise_select_and_calculate) {   // optimise_project_calc (:183-235)
     o = optimise(c.unroll());
     CHECK_EQ(o.size(), 2u);
     CHECK(o[1].is_single(Transformation::Read));
+}
+
+// ---- the CSV text layer of DataFrame::from_csv / Reader::get_dataset (host only): records, cells, inferred types, parsed values
+static std::string write_tmp(const std::string& name, const std::string& text) {
+    const std::string path = std::string("/tmp/rdf_csv_") + name + "_" + std::to_string((long)getpid()) + ".csv";
+    FILE* f = std::fopen(path.c_str(), "wb");
+    std::fwrite(text.data(), 1, text.size(), f);
+    std::fclose(f);
+    return path;
+}
+struct ParsedCsv {
+    rdf::csv::Text text;
+    std::vector<rdf::csv::Inferred> types;
+    std::vector<std::vector<uint8_t>> values, validity;
+    std::vector<rdf::csv::Filled> filled;
+    int64_t i64(size_t c, size_t r) const { int64_t v; std::memcpy(&v, values[c].data() + 8 * r, 8); return v; }
+    double f64(size_t c, size_t r) const { double v; std::memcpy(&v, values[c].data() + 8 * r, 8); return v; }
+    bool bit(const std::vector<uint8_t>& b, size_t r) const { return (b[r >> 3] >> (r & 7)) & 1; }
+};
+static ParsedCsv parse_csv(const std::string& path, bool headers = true, char delim = ',', std::optional<size_t> max_records = std::nullopt, int threads = 0) {
+    ParsedCsv p;
+    p.text = rdf::csv::load(path, headers, delim, max_records);
+    std::vector<size_t> cols;
+    for (size_t i = 0; i < p.text.header.size(); ++i) cols.push_back(i);
+    p.types = rdf::csv::infer(p.text, cols, threads);
+    const size_t n = p.text.records.size();
+    std::vector<uint8_t*> pv, pb;
+    p.values.resize(cols.size()); p.validity.resize(cols.size());
+    for (size_t k = 0; k < cols.size(); ++k) {
+        p.values[k].assign(n * 8 + 64, 0xAB);
+        p.validity[k].assign(n / 8 + 64, 0xAB);
+        pv.push_back(p.types[k].dtype == DataType::Utf8 ? nullptr : p.values[k].data());
+        pb.push_back(p.types[k].dtype == DataType::Utf8 ? nullptr : p.validity[k].data());
+    }
+    p.filled = rdf::csv::fill(p.text, cols, p.types, pv, pb, threads);
+    return p;
+}
+
+TEST(csv_cells_types_and_values) {
+    const std::string path = write_tmp("mixed",
+        "id,price,flag,name,big,\"quoted, header\"\r\n"
+        "1,1.5,true,alpha,1,\"x, y\"\r\n"
+        "\n"                                             // a zero-length line is skipped
+        "-2,,False,\"be\"\"ta\",99999999999999999999,z\r\n"
+        "+3,1e3,TRUE,,3,\n"
+        "4,-0.0,false,delta\n"                           // a short record: the missing cells are NULL
+        " 5,inf,true,eps,5,a,extra,cells\n");            // a long one is cut; strtoll / strtod take leading blanks
+    const ParsedCsv p = parse_csv(path);
+    CHECK_EQ(p.text.header.size(), 6u);
+    CHECK_EQ(p.text.header[5], std::string("quoted, header"));
+    CHECK_EQ(p.text.records.size(), 5u);
+    CHECK(p.types[0].dtype == DataType::Int64 && !p.types[0].any_null);
+    CHECK(p.types[1].dtype == DataType::Float64 && p.types[1].any_null);
+    CHECK(p.types[2].dtype == DataType::Boolean);
+    CHECK(p.types[3].dtype == DataType::Utf8);
+    CHECK(p.types[4].dtype == DataType::Float64);        // one cell overflows Int64: the column is numbers
+    CHECK(p.types[5].dtype == DataType::Utf8);
+    const int64_t ids[5] = {1, -2, 3, 4, 5};
+    for (size_t r = 0; r < 5; ++r) { CHECK_EQ(p.i64(0, r), ids[r]); CHECK(p.bit(p.validity[0], r)); }
+    CHECK_EQ(p.f64(1, 0), 1.5); CHECK(!p.bit(p.validity[1], 1)); CHECK_EQ(p.f64(1, 1), 0.0); CHECK_EQ(p.f64(1, 2), 1000.0);
+    CHECK(std::signbit(p.f64(1, 3)) && p.f64(1, 3) == 0.0); CHECK(std::isinf(p.f64(1, 4)));
+    CHECK_EQ(p.filled[1].nulls, (int64_t)1);
+    const bool flags[5] = {true, false, true, false, true};
+    for (size_t r = 0; r < 5; ++r) CHECK_EQ(p.bit(p.values[2], r), flags[r]);
+    CHECK_EQ(p.filled[3].strings[1], std::string("beta"));   // quotes toggle and are dropped wherever they stand
+    CHECK_EQ(p.filled[3].strings[2], std::string(""));
+    CHECK_EQ(p.f64(4, 1), 1e20); CHECK(!p.bit(p.validity[4], 3)); CHECK_EQ(p.filled[4].nulls, (int64_t)1);
+    CHECK_EQ(p.filled[5].strings[0], std::string("x, y")); CHECK_EQ(p.filled[5].strings[3], std::string("")); CHECK_EQ(p.filled[5].strings[4], std::string("a"));
+    // no header row: arrow's column_N names, the first line is data; another delimiter; max_records
+    const std::string p2 = write_tmp("nohdr", "1;2.5\n3;4.5\n5;6.5\n");
+    const ParsedCsv q = parse_csv(p2, false, ';', (size_t)2);
+    CHECK_EQ(q.text.header[0], std::string("column_1")); CHECK_EQ(q.text.header[1], std::string("column_2"));
+    CHECK_EQ(q.text.records.size(), 2u);
+    CHECK(q.types[0].dtype == DataType::Int64 && q.types[1].dtype == DataType::Float64);
+    CHECK_EQ(q.i64(0, 1), (int64_t)3); CHECK_EQ(q.f64(1, 1), 4.5);
+    // a column of empty cells only is Utf8; the planner's reader sees the same schema
+    const std::string p3 = write_tmp("empty", "a,b\n1,\n2,\n");
+    const ParsedCsv e = parse_csv(p3);
+    CHECK(e.types[1].dtype == DataType::Utf8);
+    const Dataset d = Reader::Csv_(path).get_dataset();
+    CHECK_EQ(d.columns.size(), 6u);
+    CHECK(d.columns[1].data_type == DataType::Float64 && d.columns[2].data_type == DataType::Boolean && d.columns[3].data_type == DataType::Utf8);
+    std::remove(path.c_str()); std::remove(p2.c_str()); std::remove(p3.c_str());
+}
+
+TEST(csv_worker_threads_agree_with_one_thread) {
+    // 100 003 records (several ranges of records, the last one ragged): integers, doubles printed with 17 significant digits
+    // (they must come back bit for bit), a NULL every 7th / 11th row, a type that only the LAST range breaks
+    std::string text = "k,x,late\n";
+    const size_t n = 100003;
+    std::vector<double> xs(n);
+    uint64_t st = 88172645463325252ull;
+    for (size_t r = 0; r < n; ++r) {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        xs[r] = (double)(int64_t)(st >> 11) / 9007199254740992.0 * 2000.0 - 1000.0;
+        char buf[96];
+        std::snprintf(buf, sizeof buf, "%lld,%s%.17g,%s\n", (long long)r * 7 - 1000, "", xs[r], r + 1 == n ? "1.25" : "7");
+        std::string line = buf;
+        if (r % 7 == 3) line = std::to_string((long long)r * 7 - 1000) + ",," + (r + 1 == n ? "1.25" : "7") + "\n";
+        if (r % 11 == 5) line = "," + line.substr(line.find(',') + 1);
+        text += line;
+    }
+    const std::string path = write_tmp("big", text);
+    const ParsedCsv one = parse_csv(path, true, ',', std::nullopt, 1), many = parse_csv(path, true, ',', std::nullopt, 5);
+    CHECK_EQ(one.text.records.size(), n);
+    for (const ParsedCsv* p : {&one, &many}) {
+        CHECK(p->types[0].dtype == DataType::Int64 && p->types[0].any_null);
+        CHECK(p->types[1].dtype == DataType::Float64 && p->types[1].any_null);
+        CHECK(p->types[2].dtype == DataType::Float64 && !p->types[2].any_null);   // "1.25" in the last record only
+        int64_t nulls0 = 0, nulls1 = 0;
+        for (size_t r = 0; r < n; ++r) {
+            const bool k_null = r % 11 == 5, x_null = r % 7 == 3;
+            CHECK_EQ(p->bit(p->validity[0], r), !k_null);
+            CHECK_EQ(p->bit(p->validity[1], r), !x_null);
+            if (!k_null) CHECK_EQ(p->i64(0, r), (int64_t)r * 7 - 1000); else { ++nulls0; CHECK_EQ(p->i64(0, r), (int64_t)0); }
+            if (!x_null) CHECK_EQ(p->f64(1, r), xs[r]); else ++nulls1;
+            CHECK_EQ(p->f64(2, r), r + 1 == n ? 1.25 : 7.0);
+        }
+        CHECK_EQ(p->filled[0].nulls, nulls0); CHECK_EQ(p->filled[1].nulls, nulls1);
+    }
+    std::remove(path.c_str());
 }
 
 int main() { return run_all(); }

@@ -16,7 +16,7 @@ ORA = os.path.join(ROOT, "oracle")
 
 def build(name, with_oracle):
     out = os.path.join(tempfile.gettempdir(), f"rdf_{name}_{os.getpid()}")
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", ORA,
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", ORA,
            os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", out, "-L", PKG, "-lrdf_mi355x", f"-Wl,-rpath,{PKG}"]
     if with_oracle:
         if not os.path.exists(os.path.join(ORA, "librdf_oracle.so")):

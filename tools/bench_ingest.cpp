@@ -63,7 +63,7 @@ int main(int argc, char** argv) {
             const double s = since(t0);
             const rdf::IngestStats st = rdf::last_ingest();
             if (rep == 1) std::printf("{\"case\": \"from_csv\", \"rows\": %lld, \"batches\": %zu, \"bytes_to_hbm\": %lld, \"seconds\": %.6f, \"GBps\": %.3f, \"async_copies\": %lld, \"blocking_copies\": %lld, "
-                                      "\"note\": \"bound by the host text parser (strtod per cell), not by the link\"}\n",
+                                      "\"note\": \"bound by the host text parser (std::from_chars on worker threads over ranges of records), not by the link\"}\n",
                                       (long long)df.num_rows(), df.num_chunks(), (long long)st.bytes, s, st.bytes / s / 1e9, (long long)st.async_copies, (long long)st.blocking_copies);
         }
     } catch (const std::exception& e) { std::fprintf(stderr, "bench_ingest: %s\n", e.what()); return 1; }
