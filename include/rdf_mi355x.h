@@ -514,6 +514,8 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * 4 = its scatter path whatever max_groups says; 1 = first-generation histogram + scatter; 2 = radix-sort partitioning;
  * 0 = one table in HBM),
  * "gb_debug" (1 / 2: ablations of the aggregate / scatter pass, results invalid; 3: force the skew variant),
+ * "jit" (a program shape no catalog holds: 1 = compile the specialised kernel template for it at run time — `hipcc` as a child
+ * process, about half a second, kept for the life of the process —, default; 0 = the general evaluator interprets it),
  * "gb_compact" (scatter path, keys inside a window of 2^39: 1 = 4-byte records when only rows are counted, default; 2 = also
  * 12-byte records for sum / min / max; 0 = 16-byte records always), "gb_skew_plan" (1 = per-partition capacity plan when the probe finds a few heavy
  * partitions, default; 0 = the first-generation combining path instead; 2 = always),

@@ -60,6 +60,7 @@ struct Ctx {
     bool   sort_used_local = false; // the last sort finished at least one column with os_local_kernel
     int    opt_sort_msd = 1;        // sort keys that vary in more than 32 bits: passes over the top bits, then every bucket sorted in LDS (1, default); 0 = one pass per byte (A/B)
     int    opt_join_table = 1;      // equi-join on one key column: probe a table of the distinct build keys (1, default); 0 = the bucket index over the sorted build keys (A/B)
+    int    opt_jit = 1;             // a program shape outside the catalogs: compile spec_kernel<Prog> for it at run time (hiprtc) instead of interpreting it (1, default; 0 = interpreter)
     int    opt_take_rows = 1;       // take over a frame through interleaved row records: 1 = when the transaction model says so (default), 0 = never, 2 = always (tests, A/B)
     int    opt_gb_skew_plan = 1;    // skewed keys: per-partition region sizes + big partitions cut into several aggregate items (1 = when the probe finds skew, default; 0 = the first-generation combining path instead, A/B; 2 = always, tests)
     int    opt_gb_compact = 1;      // partition path, keys inside a window of 2^39: 1 = 4-byte records when only rows are counted (default); 2 = also 12-byte records (key word + value) for the other aggregates (measured slower than 16-byte records, kept for A/B); 0 = 16-byte records always
@@ -807,7 +808,7 @@ bool build_spec_plan(Compiler& cc, int filter_root, int nvalues, const int* valu
     if (!sp.ok) return false;
     if (sink == RDF_SINK_STORE && cc.infer(value_roots[0]) != RDF_BOOL) sp.width = std::max(sp.width, dtype_size(cc.infer(value_roots[0])));
     sp.sig = s;
-    return spec_available(s.c_str());
+    return spec_available(s.c_str()) || (g_ctx.opt_jit && jit_find(s.c_str()) != nullptr);   // in the catalog, or compiled earlier in this process (rdf_jit.cpp)
 }
 
 // Second-level lookup: kernels specialised on the tree SHAPE with runtime operators (rdf_expr.hip.h *RT nodes; the 8- and
@@ -968,7 +969,7 @@ rdf_status launch_agg_pair(const EvalArgs* ea, const FilterAggF64Args* fa, int c
                            const SpecArgs* sa = nullptr) {
     Ctx& c = g_ctx;
     KernelTimer kt;
-    if (sa) { c.last_kernel = std::string("spec_kernel<") + spec_sig + ">"; HIP_TRY(launch_spec(spec_sig, *sa, grid, c.stream)); }
+    if (sa) { c.last_kernel = std::string("spec_kernel<") + spec_sig + ">" + (jit_find(spec_sig) ? " [compiled at run time]" : ""); HIP_TRY(launch_spec(spec_sig, *sa, grid, c.stream)); }
     else if (fa) { c.last_kernel = "filter_agg_f64_kernel"; HIP_TRY(launch_filter_agg_f64(*fa, cmp, grid, c.stream)); }
     else { c.last_kernel = "eval_kernel<AGG>"; HIP_TRY(launch_eval(*ea, SINK_AGG, feat, grid, c.stream)); }
     kt.stop();
@@ -1348,6 +1349,15 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         sp = SpecPlan();
         have_plan = build_shape_plan(cc, ps.filter_root, ps.nvalues, ps.value_roots, ps.sink, sp, rt_ops);
     }
+    if (!have_plan && ctx.opt_spec && ctx.opt_jit && !grouped) {
+        // neither: the same kernel template instantiated for exactly this program at run time (rdf_jit.cpp) — up to 4 columns and
+        // 4 literals, any tree over them; a second or so the first time a process meets the shape, then cached
+        sp = SpecPlan();
+        for (int k = 0; k < 8; ++k) rt_ops[k] = 0;
+        (void)build_spec_plan(cc, ps.filter_root, ps.nvalues, ps.value_roots, ps.sink, sp);
+        if (getenv("RDF_DEBUG_JIT")) fprintf(stderr, "[rdf] jit: candidate %s (ok %d)\n", sp.sig.c_str(), (int)sp.ok);
+        have_plan = sp.ok && !sp.sig.empty() && jit_spec_kernel(sp.sig.c_str()) != nullptr;
+    }
     if (have_plan) {
         memset(&sa, 0, sizeof sa);
         use_spec = true;
@@ -1578,7 +1588,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     // SINK_STORE
     {
         KernelTimer kt;
-        if (use_spec) { ctx.last_kernel = "spec_kernel<" + sp.sig + ">"; HIP_TRY(launch_spec(sp.sig.c_str(), sa, grid, ctx.stream)); }
+        if (use_spec) { ctx.last_kernel = "spec_kernel<" + sp.sig + ">" + (jit_find(sp.sig.c_str()) ? " [compiled at run time]" : ""); HIP_TRY(launch_spec(sp.sig.c_str(), sa, grid, ctx.stream)); }
         else { ctx.last_kernel = "eval_kernel<STORE>"; HIP_TRY(launch_eval(ea, SINK_STORE, cc.feat(), grid, ctx.stream)); }
         kt.stop();
     }
@@ -3800,6 +3810,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "sort_gen") == 0) g_ctx.opt_sort_gen = (int)value;
     else if (strcmp(name, "sort_msd") == 0) g_ctx.opt_sort_msd = (int)value;
     else if (strcmp(name, "join_table") == 0) g_ctx.opt_join_table = (int)value;
+    else if (strcmp(name, "jit") == 0) g_ctx.opt_jit = (int)value;
     else if (strcmp(name, "gb_skew_plan") == 0) g_ctx.opt_gb_skew_plan = (int)value;
     else if (strcmp(name, "gb_compact") == 0) g_ctx.opt_gb_compact = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;

@@ -109,14 +109,20 @@ const SpecEntry* spec_lookup(const char* sig) {
     return it == registry().end() ? nullptr : &it->second;
 }
 
+// (a signature the catalog does not hold may have been compiled at run time: rdf_jit.cpp)
 int spec_rows_per_tile(const char* sig) {   // rows one wave iteration covers: tiles never straddle chunks
     const SpecEntry* e = spec_lookup(sig);
-    return e ? e->rows_per_tile : 0;
+    if (e) return e->rows_per_tile;
+    const JitKernel* j = jit_find(sig);
+    return j ? j->rows_per_tile : 0;
 }
-bool spec_available(const char* sig) { return spec_lookup(sig) != nullptr; }
+bool spec_available(const char* sig) { return spec_lookup(sig) != nullptr; }   // the catalog proper; the caller asks jit_find itself
 hipError_t launch_spec(const char* sig, const SpecArgs& a, int grid, hipStream_t s) {
     const SpecEntry* e = spec_lookup(sig);
-    if (!e) return hipErrorInvalidValue;
+    if (!e) {
+        const JitKernel* j = jit_find(sig);
+        return j ? jit_launch(*j, a, grid, s) : hipErrorInvalidValue;
+    }
     e->launch(a, grid, s);
     return hipGetLastError();
 }

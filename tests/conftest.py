@@ -30,6 +30,10 @@ def gpu(request):
         pytest.fail("GPU test selected but no HIP device is visible")
     lib.set_option("spec", 1 if request.param == "spec" else 0)
     lib.set_option("fast_filter", 1 if request.param == "spec" else 0)
+    # shapes outside the catalogs are compiled at run time by default (rdf_jit.cpp, about a second each): the parity suites walk
+    # hundreds of such shapes and hold them to the interpreter, test_kernels_compiled_at_run_time turns the compiler on
+    lib.set_option("jit", 0)
     yield api
     lib.set_option("spec", 1)
     lib.set_option("fast_filter", 1)
+    lib.set_option("jit", 1)

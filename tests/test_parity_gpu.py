@@ -821,6 +821,70 @@ def test_shape_specialised_runtime_op_kernels(gpu, ora, request):
     assert ei.value.status == A.RDF_DIVIDE_BY_ZERO
 
 
+def test_kernels_compiled_at_run_time(gpu, ora, request):
+    """Program shapes outside the catalogs — four levels of arithmetic, a function inside a chain, casts below the leaves, a
+    wrapping integer tree — get spec_kernel<Prog> instantiated for them at run time (hiprtc, rdf_jit.cpp) instead of the
+    interpreter: aggregates (plain and behind predicates) and new columns against the oracle, the second call served from the
+    process's cache, the interpreter with the switch off, and a program the kernel template cannot hold (five columns)."""
+    from rust_dataframe_amd import lib
+    if request.node.callspec.params["gpu"] != "spec":
+        pytest.skip("with the specialised kernels off nothing is compiled")
+    rng = np.random.default_rng(20260927)
+    lens = [4096, 1000, 0, 2500]
+    F = [make_chunks(rng, A.F64, lens, nf, 0, kind="unit", nonzero=True) for nf in (0.0, 0.1, 0.0, 0.05)]
+    I32 = make_chunks(rng, A.I32, lens, 0.05, 0, kind="plain", nonzero=True)
+    L = [make_chunks(rng, A.I64, lens, nf, 0, kind="plain", nonzero=True) for nf in (0.0, 0.1)]
+    cols = F + [I32] + L
+    e = A.Expr()
+    a, b, c, d, i, l, m = (e.col(k) for k in range(7))
+    k1, k2 = e.scalar(1.5), e.scalar(-0.25)
+    programs = {
+        "four_levels": (e.op("multiply", e.op("subtract", e.op("divide", e.op("add", e.op("multiply", a, b), c), d), k1), a), A.F64),
+        "function_inside": (e.op("add", e.op("multiply", e.op("sin", a), b), e.op("sqrt", e.op("abs", c))), A.F64),
+        "casts_below": (e.op("multiply", e.op("add", e.cast(i, A.F64), a), e.cast(l, A.F64)), A.F64),
+        "integer_tree": (e.op("subtract", e.op("multiply", e.op("add", l, e.scalar(3, A.I64)), l), e.op("multiply", m, e.op("add", m, e.scalar(7, A.I64)))), A.I64),
+    }
+    preds = {"none": -1, "cmp": e.op("gt", a, e.scalar(-0.3)), "two_columns": e.op("and", e.op("gt", a, e.scalar(-0.6)), e.op("ne", l, e.scalar(3, A.I64)))}
+    lib.set_option("jit", 1)
+    try:
+        for vn, (v, dt) in programs.items():
+            for pn, p in preds.items():
+                if vn == "four_levels" and pn == "two_columns":
+                    continue                                    # five columns: see below
+                exp = ora.pipeline(e, cols, [v], p)[0]
+                for attempt in range(2):                        # compiled, then found in the cache
+                    got = gpu.pipeline(e, cols, [v], p)[0]
+                    assert lib.last_kernel().startswith("spec_kernel<") and lib.last_kernel().endswith("[compiled at run time]"), f"{vn}/{pn} ran on {lib.last_kernel()}"
+                    assert got.count == exp.count, f"{vn}/{pn}"
+                    if dt == A.F64:
+                        assert abs(got.sum - exp.sum) <= 1e-6 * max(abs(exp.sum), 1.0), f"{vn}/{pn}: {got.sum} vs {exp.sum}"
+                        if exp.count:
+                            assert np.isclose(got.min, exp.min, rtol=1e-9, atol=0) and np.isclose(got.max, exp.max, rtol=1e-9, atol=0), f"{vn}/{pn}"
+                    else:
+                        assert (got.sum, got.min, got.max) == (exp.sum, exp.min, exp.max), f"{vn}/{pn}"
+            outs_e = [[A.HostArray.empty_out(dt, n, True) for n in lens]]
+            outs_g = [[A.HostArray.empty_out(dt, n, True) for n in lens]]
+            ora.pipeline(e, cols, [v], -1, A.SINK_STORE, outs_e)
+            gpu.pipeline(e, cols, [v], -1, A.SINK_STORE, outs_g)
+            assert lib.last_kernel().endswith("[compiled at run time]"), f"{vn} store ran on {lib.last_kernel()}"
+            for ge, ee in zip(outs_g[0], outs_e[0]):
+                assert_arrays_match(ge, ee, exact=vn != "function_inside", what=vn)
+        # five distinct columns do not fit the kernel template: the interpreter answers, as it does with the switch off
+        v, p = programs["four_levels"][0], preds["two_columns"]
+        exp = ora.pipeline(e, cols, [v], p)[0]
+        got = gpu.pipeline(e, cols, [v], p)[0]
+        assert lib.last_kernel().startswith("eval_kernel<"), lib.last_kernel()
+        assert got.count == exp.count and abs(got.sum - exp.sum) <= 1e-6 * max(abs(exp.sum), 1.0)
+        lib.set_option("jit", 0)
+        v = e.op("multiply", e.op("subtract", e.op("divide", e.op("add", e.op("multiply", b, c), d), a), k2), b)   # a shape not met above
+        exp = ora.pipeline(e, cols, [v], -1)[0]
+        got = gpu.pipeline(e, cols, [v], -1)[0]
+        assert lib.last_kernel().startswith("eval_kernel<"), lib.last_kernel()
+        assert got.count == exp.count and abs(got.sum - exp.sum) <= 1e-6 * max(abs(exp.sum), 1.0)
+    finally:
+        lib.set_option("jit", 0)
+
+
 def test_shape_specialised_kernels_i64_and_mixed_predicates(gpu, ora, request):
     """The runtime-operator kernels for wrapping i64 arithmetic (bit-exact, incl. MIN / -1 and the divide-by-zero
     error), and predicates on a column of the other dtype (an i64 key in front of f64 measures and vice versa)."""

@@ -39,6 +39,47 @@ def out(dt, n):
     return A.DeviceArray(v.data_ptr(), None, 0, n, dt, 0, keep=(v,))
 
 
+def beyond_the_catalogs(api, n, steps):
+    """Program shapes no catalog holds: four levels of arithmetic, a function inside a chain, casts below the leaves, a four-level
+    i64 / f32 tree.  jit = 1: spec_kernel<Prog> compiled for the program at run time (rdf_jit.cpp; the first call's compile time
+    is reported on its own); jit = 0: the general evaluator."""
+    import time
+    for dt in (A.F64, A.I64, A.F32):
+        es = ES[dt]
+        is_float = dt in (A.F64, A.F32)
+        cols = [[column(dt, n, 10 * dt + i)] for i in range(4)]
+        i32 = [column(A.I32, n, 777)]
+        o = out(dt, n)
+        e = A.Expr()
+        a, b, c, d, i = (e.col(k) for k in range(5))
+        k = e.scalar(1.5 if is_float else 3, dt)
+        progs = [("four_levels_4col", e.op("multiply", e.op("subtract", e.op("add", e.op("multiply", a, b), c), d), e.op("add", a, k)), cols, 4 * es)]
+        if is_float:
+            progs.append(("function_inside_3col", e.op("add", e.op("multiply", e.op("sin", a), b), e.op("sqrt", e.op("abs", c))), cols, 3 * es))
+        if dt == A.F64:
+            progs.append(("casts_below_2col", e.op("multiply", e.op("add", e.cast(i, A.F64), a), e.op("subtract", a, k)), cols + [i32], es + 4))
+        flt = e.op("gt", b, e.scalar(0.0 if is_float else 500.0))
+        for name, root, pc, read in progs:
+            for jit in (1, 0):
+                lib.set_option("jit", jit)
+                t0 = time.perf_counter()
+                api.pipeline(e, pc, [root])                 # jit = 1: compiles here
+                first = time.perf_counter() - t0
+                cases = [("agg", read * n, lambda: api.pipeline(e, pc, [root])),
+                         ("store", (read + es) * n, lambda: api.pipeline(e, pc, [root], -1, A.SINK_STORE, [[o]])),
+                         ("filter_agg", read * n, lambda: api.pipeline(e, pc, [root], flt))]
+                for sink, alg, fn in cases:
+                    fn()
+                    wall, kern = timed(fn, steps)
+                    gbs = alg / kern / 1e9 if kern > 0 else 0.0
+                    print(json.dumps({"dtype": NAME[dt], "program": name, "sink": sink, "jit": jit, "rows": n, "alg_bytes": alg, "kernel_ms": round(kern * 1e3, 4),
+                                      "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 3), "first_call_s": round(first, 3) if sink == "agg" else None,
+                                      "kernel": lib.last_kernel()[:140]}), flush=True)
+        lib.set_option("jit", 1)
+        del cols, o, i32
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=250_000_000)
@@ -47,10 +88,14 @@ def main():
     ap.add_argument("--dtypes", type=str, default="f64,i64,u64,f32,i32,u32,i16,u16")
     ap.add_argument("--programs", type=str, default="", help="comma list of program names (default: all)")
     ap.add_argument("--sinks", type=str, default="agg,store,filter_agg")
+    ap.add_argument("--beyond", action="store_true", help="ONLY the programs outside the catalogs: the kernel compiled at run time against the interpreter")
     args = ap.parse_args()
     n = args.rows
     lib.set_device(0)
     api = lib.api()
+    if args.beyond:
+        beyond_the_catalogs(api, n, args.steps)
+        return
     for dt in (A.F64, A.I64, A.U64, A.F32, A.I32, A.U32, A.I16, A.U16):
         if NAME[dt] not in args.dtypes.split(","):
             continue
