@@ -47,6 +47,7 @@ if [ "$PART" = "all" ] || [ "$PART" = "r3" ]; then
 python "$REPO/tools/bench_frames.py" 2> "$OUT/frames.err" | grep kernel_ms > "$OUT/frames_1e9.jsonl"
 python "$REPO/tools/bench_ingest.py" 2> "$OUT/ingest.err" | grep '"case"' > "$OUT/ingest.jsonl"
 python "$REPO/tools/bench_bytes.py" 2> "$OUT/bytes.err" | grep program > "$OUT/bytes_2p5e8.jsonl"
+python "$REPO/tools/bench_shapes.py" --beyond 2> "$OUT/beyond.err" | grep kernel_ms > "$OUT/beyond_catalogs_2p5e8.jsonl"   # shapes no catalog holds: compiled at run time vs interpreted
 rm -f "$OUT/rccl_one_rank.jsonl"
 for w in headline c4 q1; do python "$REPO/bench.py" --workload $w --rows 200000000 --steps 10 --warmup 3 --cpu-sample 0 --force-exchange --backend nccl 2>> "$OUT/rccl.err" | tail -1 >> "$OUT/rccl_one_rank.jsonl"; done
 RDF_C4_SHUFFLE_ROWS=1 python "$REPO/bench.py" --workload c4 --rows 200000000 --steps 10 --warmup 3 --cpu-sample 0 --force-exchange --backend nccl 2>> "$OUT/rccl.err" | tail -1 >> "$OUT/rccl_one_rank.jsonl"
