@@ -222,6 +222,10 @@ struct SortPassArgs {
 // Second-generation radix passes (rdf_sort.hip): all digit histograms in one read, then one read + one write per digit with
 // decoupled look-back between tiles.
 constexpr int kOsItems = 16;                         // items per thread per tile: 4096-item tiles
+// f64 keys: the top bits of the key bits are sign and exponent — doubles of one magnitude crowd a few of their patterns —, so the
+// most-significant-first passes take their digits from the VALUE bucket floor((x - lo) * scale) instead (monotone in the key bits:
+// rounding is monotone; NaNs go below / above everything as their bits order them), bits > 0 turns it on
+struct OsBucket { double lo, scale; int32_t bits, flip; };   // flip: the stored keys are ~(key bits) (descending)
 struct OsHistArgs {
     const uint64_t* keys;                            // [n] current order
     const uint8_t*  nullflags;                       // [n] by original row, or nullptr: its 1s are counted for the nulls-last pass
@@ -230,6 +234,7 @@ struct OsHistArgs {
     int32_t         npass, generic;                  // digits 0..npass-1 of (key - bias): bytes, or (generic) the fields shift[p], mask[p]
     int64_t*        hist;                            // [9 * 256] zeroed; on return the exclusive scan of every pass's counts (row 8: the nulls-last pass)
     int32_t         shift[8], mask[8];
+    OsBucket        fb;
 };
 struct OsPassArgs {
     const uint64_t* keys_in;  const uint32_t* idx_in;   // idx_in nullptr = identity
@@ -242,6 +247,7 @@ struct OsPassArgs {
     uint64_t        bias;
     int32_t         shift, seq;                      // seq: 1, 2, ... one per pass launched on `state`
     int32_t         mask, pad;                       // digit = ((key - bias) >> shift) & mask; 0 = 255
+    OsBucket        fb;                              // ... or (value bucket >> shift) & mask
     unsigned long long* debug;                       // RDF_DEBUG: [6] cycle sums of the phases (ticket, load + rank, barrier, look-back, sort + write), tiles
 };
 // Most-significant-digits-first finish (keys that vary in more than 32 bits): after stable passes over the TOP bits of the keys
@@ -254,9 +260,10 @@ struct OsLocalArgs {
     const uint32_t* bstart;                          // [nbuckets + 1] first row of every bucket
     uint64_t        bias;
     int32_t         rbits, nbuckets;                 // bucket = (key - bias) >> rbits
-    int32_t         lds_items, pad;                  // LDS the launch carries: the next power of two >= the largest bucket
+    int32_t         lds_items, wide;                 // LDS the launch carries: the next power of two >= the largest bucket; wide: value
+                                                     // buckets — the rows of a bucket share no key bits, the whole key is compared
 };
-hipError_t launch_os_bounds(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, uint32_t* bstart, unsigned int* maxlen, hipStream_t s);
+hipError_t launch_os_bounds(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, const OsBucket& fb, uint32_t* bstart, unsigned int* maxlen, hipStream_t s);
 hipError_t launch_os_local(const OsLocalArgs& a, hipStream_t s);
 hipError_t launch_os_hist(const OsHistArgs& a, hipStream_t s);
 hipError_t launch_os_scatter(const OsPassArgs& a, hipStream_t s);

@@ -42,6 +42,17 @@ constexpr uint64_t kOsValueMask = (1ull << 48) - 1;
 constexpr uint64_t kOsLocal = 1ull << 48, kOsInclusive = 2ull << 48;
 
 __device__ __forceinline__ int os_digit(uint64_t key, uint64_t bias, int shift, int mask = 255) { return (int)(((key - bias) >> shift) & (uint64_t)mask); }
+// the value bucket of an f64 key (OsBucket): order-preserving key bits -> the double -> floor((x - lo) * scale), clamped
+__device__ __forceinline__ uint32_t os_value_bucket(uint64_t key, const OsBucket& f) {
+    const uint64_t ord = f.flip ? ~key : key;
+    const uint64_t b = (ord >> 63) ? (ord ^ 0x8000000000000000ull) : ~ord;
+    const double t = (u2d(b) - f.lo) * f.scale;
+    const uint32_t top = (1u << f.bits) - 1;
+    uint32_t k;
+    if (t != t) k = (b >> 63) ? 0u : top;
+    else k = t <= 0.0 ? 0u : (t >= (double)top ? top : (uint32_t)t);
+    return f.flip ? top - k : k;
+}
 
 // Histograms of all `npass` digits of (key - bias) in one read of the keys (+ the NULL count for the nulls-last pass).
 __global__ __launch_bounds__(kBlock) void os_hist_kernel(const OsHistArgs a) {
@@ -49,7 +60,8 @@ __global__ __launch_bounds__(kBlock) void os_hist_kernel(const OsHistArgs a) {
     for (int p = 0; p < 9; ++p) h[p][threadIdx.x] = 0;
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
-        const uint64_t k = __builtin_nontemporal_load(as_global<uint64_t>(a.keys) + i) - a.bias;
+        uint64_t k = __builtin_nontemporal_load(as_global<uint64_t>(a.keys) + i);
+        k = a.fb.bits ? (uint64_t)os_value_bucket(k, a.fb) : k - a.bias;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             if (p >= a.npass) break;
@@ -126,7 +138,8 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
             const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
             int d = 0;
             if (i < a.n) {
-                d = a.nullflags ? (int)as_global<uint8_t>(a.nullflags)[idx[j]] : os_digit(key[j], a.bias, a.shift, a.mask);
+                d = a.nullflags ? (int)as_global<uint8_t>(a.nullflags)[idx[j]]
+                                : a.fb.bits ? (int)((os_value_bucket(key[j], a.fb) >> a.shift) & (uint32_t)a.mask) : os_digit(key[j], a.bias, a.shift, a.mask);
                 atomicAdd(&thist[d], 1u);
             }
             digit[j] = d;
@@ -412,10 +425,14 @@ hipError_t launch_os_scatter(const OsPassArgs& a, hipStream_t s) {
 
 // bstart[b] = first row whose bucket is >= b (rows are sorted by bucket); thread i writes the entries of the buckets that END in
 // front of row i — every entry of bstart[0 .. nbuckets] exactly once, empty buckets included
-__global__ __launch_bounds__(kBlock) void os_bounds_kernel(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, uint32_t* bstart) {
+__global__ __launch_bounds__(kBlock) void os_bounds_kernel(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, const OsBucket fb, uint32_t* bstart) {
+    auto bucket = [&](int64_t i) -> int64_t {
+        const uint64_t k = as_global<uint64_t>(keys)[i];
+        return fb.bits ? (int64_t)os_value_bucket(k, fb) : (int64_t)((k - bias) >> rbits);
+    };
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= n; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t cur = i < n ? (int64_t)((as_global<uint64_t>(keys)[i] - bias) >> rbits) : (int64_t)nbuckets;
-        const int64_t prev = i > 0 ? (int64_t)((as_global<uint64_t>(keys)[i - 1] - bias) >> rbits) : -1;
+        const int64_t cur = i < n ? bucket(i) : (int64_t)nbuckets;
+        const int64_t prev = i > 0 ? bucket(i - 1) : -1;
         for (int64_t b = prev + 1; b <= cur; ++b) bstart[b] = (uint32_t)i;
     }
 }
@@ -462,6 +479,75 @@ __device__ __forceinline__ void os_chunk(uint64_t* s, int P, int k, int jl_log) 
         for (int e = 0; e < E; ++e) s[os_pad(i | (e << jl_log))] = v[e];
     }
 }
+// ... over (whole key, place) pairs: value buckets (f64 keys) — the rows of a bucket share no key bits
+template <int MB>
+__device__ __forceinline__ void os_chunk_wide(uint64_t* s, uint32_t* sp, int P, int k, int jl_log) {
+    constexpr int E = 1 << MB;
+    for (int q = threadIdx.x; q < (P >> MB); q += 64) {
+        const int i = ((q >> jl_log) << (jl_log + MB)) | (q & ((1 << jl_log) - 1));
+        uint64_t v[E];
+        uint32_t w[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { v[e] = s[os_pad(i | (e << jl_log))]; w[e] = sp[os_pad(i | (e << jl_log))]; }
+        const bool asc = (i & k) == 0;
+#pragma unroll
+        for (int b = MB - 1; b >= 0; --b) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (e & (1 << b)) continue;
+                const int f = e | (1 << b);
+                const bool gt = v[e] > v[f] || (v[e] == v[f] && w[e] > w[f]);
+                const bool sw = gt == asc;
+                const uint64_t x = v[e], y = v[f];
+                const uint32_t px = w[e], py = w[f];
+                v[e] = sw ? y : x; v[f] = sw ? x : y;
+                w[e] = sw ? py : px; w[f] = sw ? px : py;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) { s[os_pad(i | (e << jl_log))] = v[e]; sp[os_pad(i | (e << jl_log))] = w[e]; }
+    }
+}
+__global__ __launch_bounds__(64) void os_local_wide_kernel(const OsLocalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s[];
+    const int64_t bucket = blockIdx.x;
+    const uint32_t start = a.bstart[bucket], len = a.bstart[bucket + 1] - start;
+    if (len == 0) return;
+    if (len == 1) {
+        if (threadIdx.x == 0) {
+            as_global_mut<uint64_t>(a.keys_out)[start] = as_global<uint64_t>(a.keys_in)[start];
+            as_global_mut<uint32_t>(a.idx_out)[start] = a.idx_in ? as_global<uint32_t>(a.idx_in)[start] : start;
+        }
+        return;
+    }
+    int P = 2, plog = 1;
+    while (P < (int)len) { P <<= 1; ++plog; }
+    uint32_t* sp = (uint32_t*)(s + os_pad(a.lds_items) + 1);
+    for (int i = threadIdx.x; i < P; i += 64) {
+        // padding sorts behind every row: the largest key with a place no row has
+        s[os_pad(i)] = i < (int)len ? __builtin_nontemporal_load(as_global<uint64_t>(a.keys_in) + start + i) : ~0ull;
+        sp[os_pad(i)] = i < (int)len ? (uint32_t)i : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int ks = 1; ks <= plog; ++ks) {
+        for (int jlog = ks - 1; jlog >= 0;) {
+            const int mb = jlog + 1 < 3 ? jlog + 1 : 3;      // 8 pairs per lane: the registers of 16 words
+            const int jl_log = jlog - mb + 1;
+            switch (mb) {
+                case 3: os_chunk_wide<3>(s, sp, P, 1 << ks, jl_log); break;
+                case 2: os_chunk_wide<2>(s, sp, P, 1 << ks, jl_log); break;
+                default: os_chunk_wide<1>(s, sp, P, 1 << ks, jl_log); break;
+            }
+            __syncthreads();
+            jlog = jl_log - 1;
+        }
+    }
+    for (int j = threadIdx.x; j < (int)len; j += 64) {
+        const uint32_t from = start + sp[os_pad(j)];
+        __builtin_nontemporal_store(s[os_pad(j)], as_global_mut<uint64_t>(a.keys_out) + start + j);
+        __builtin_nontemporal_store(a.idx_in ? as_global<uint32_t>(a.idx_in)[from] : from, as_global_mut<uint32_t>(a.idx_out) + start + j);
+    }
+}
 __global__ __launch_bounds__(64) void os_local_kernel(const OsLocalArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s[];
     const int64_t bucket = blockIdx.x;
@@ -505,17 +591,23 @@ __global__ __launch_bounds__(64) void os_local_kernel(const OsLocalArgs a) {
         __builtin_nontemporal_store(a.idx_in ? as_global<uint32_t>(a.idx_in)[from] : from, as_global_mut<uint32_t>(a.idx_out) + start + j);
     }
 }
-hipError_t launch_os_bounds(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, uint32_t* bstart, unsigned int* maxlen, hipStream_t s) {
+hipError_t launch_os_bounds(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, const OsBucket& fb, uint32_t* bstart, unsigned int* maxlen, hipStream_t s) {
     int64_t grid = (n + 1 + kBlock - 1) / kBlock;
     if (grid > eval_grid_limit()) grid = eval_grid_limit();
-    hipLaunchKernelGGL(os_bounds_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, keys, n, bias, rbits, nbuckets, bstart);
+    hipLaunchKernelGGL(os_bounds_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, keys, n, bias, rbits, nbuckets, fb, bstart);
     int64_t g2 = ((int64_t)nbuckets + kBlock - 1) / kBlock;
     if (g2 > eval_grid_limit()) g2 = eval_grid_limit();
     hipLaunchKernelGGL(os_bucket_max_kernel, dim3((unsigned)g2), dim3(kBlock), 0, s, bstart, nbuckets, maxlen);
     return hipGetLastError();
 }
 hipError_t launch_os_local(const OsLocalArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(os_local_kernel, dim3((unsigned)a.nbuckets), dim3(64), (size_t)(a.lds_items + a.lds_items / 16 + 1) * 8, s, a);
+    const size_t words = (size_t)(a.lds_items + a.lds_items / 16 + 1);
+    if (a.wide) {
+        (void)hipFuncSetAttribute((const void*)os_local_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(words * 12 + 16));
+        hipLaunchKernelGGL(os_local_wide_kernel, dim3((unsigned)a.nbuckets), dim3(64), words * 12 + 16, s, a);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(os_local_kernel, dim3((unsigned)a.nbuckets), dim3(64), words * 8, s, a);
     return hipGetLastError();
 }
 

@@ -294,8 +294,11 @@ def test_sort_top_bits_then_lds_buckets(gpu, ora):
     """Keys that vary in more than 32 bits: stable passes over the top bits, then every bucket sorted in LDS (os_local_kernel).
     Buckets of every LDS size class (a quarter of the rows crowd an eighth of the key range), ties inside buckets (stability),
     NULLs last (they are moved behind the other rows first), descending, a second criterion; keys crowded on a few top-bit
-    patterns — doubles of one magnitude, eight patterns of integer keys — go through the byte passes instead; the A/B switch
-    gives the same order."""
+    patterns (eight patterns of integer keys) go through the byte passes instead.  Doubles: their buckets are cut in VALUE
+    space (sign and exponent would crowd the key bits' top patterns) and the whole key is compared inside a bucket — uniform
+    values ascending, descending and behind another criterion; a column with infinities (no finite value range) and one whose
+    values crowd a few value buckets keep the byte passes; zeros of both signs, NaNs and denormals order as the oracle's.  The
+    A/B switch gives the same order."""
     from rust_dataframe_amd import lib
     rng = np.random.default_rng(777)
     n = 4_000_000
@@ -305,9 +308,17 @@ def test_sort_top_bits_then_lds_buckets(gpu, ora):
     kv[rng.integers(0, n, n // 50)] = kv[rng.integers(0, n, n // 50)]          # ties
     wide = [A.HostArray.from_numpy(kv, valid=rng.uniform(size=n) >= 0.01, dtype=A.I64)]
     ties = [A.HostArray.from_numpy(rng.integers(0, 3, n).astype(np.int8), dtype=A.I8)]
-    fl = [A.HostArray.from_numpy(rng.normal(size=n) * 1e6, dtype=A.F64)]
+    fv = rng.normal(size=n) * 1e6
+    fv[rng.integers(0, n, 2000)] = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -np.nan, 5e-324, -5e-324, 1e300, -1e300])[rng.integers(0, 10, 2000)]
+    fl = [A.HostArray.from_numpy(fv, valid=rng.uniform(size=n) >= 0.01, dtype=A.F64)]                 # doubles of one magnitude: VALUE buckets
+    fu = rng.uniform(size=n)
+    fu[rng.integers(0, n, 4000)] = np.array([0.0, -0.0, 5e-324, -5e-324, 0.5, 0.5])[rng.integers(0, 6, 4000)]
+    funi = [A.HostArray.from_numpy(fu, valid=rng.uniform(size=n) >= 0.01, dtype=A.F64)]
+    fnorm = [A.HostArray.from_numpy(rng.normal(size=n) * 1e3 + 7.0, dtype=A.F64)]
+    fexp = [A.HostArray.from_numpy(rng.exponential(size=n) ** 6, dtype=A.F64)]                       # nearly all of it in a few value buckets: byte passes
     crowded = [A.HostArray.from_numpy((rng.integers(0, 8, n) << 59) + rng.integers(0, 2 ** 40, n), dtype=A.I64)]
-    for cols, desc, local in [([wide], [False], True), ([ties, wide], [False, True], True), ([fl], [False], False), ([crowded], [False], False)]:
+    for cols, desc, local in [([wide], [False], True), ([ties, wide], [False, True], True), ([funi], [False], True), ([funi], [True], True), ([fnorm], [False], True), ([ties, funi], [True, False], True),
+                              ([fl], [False], False), ([fl], [True], False), ([fexp], [False], False), ([crowded], [False], False)]:
         exp = ora.sort_to_indices(cols, desc).to_numpy()
         got = gpu.sort_to_indices(cols, desc).to_numpy()
         assert ("os_local_kernel" in lib.last_kernel()) == local, lib.last_kernel()

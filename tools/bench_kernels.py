@@ -251,6 +251,14 @@ def main():
         del kw2, oi2_
     kd = dev_i64(ns, 10, 0, 200)
     report("sort_to_indices_i64_dictionary_codes", 8.0 * ns, lambda: api.sort_to_indices([[arr(kd, A.I64, ns)]], [False], oi), rows=ns)
+    xs_ = dev_f64(ns, 13, 0.0, 1.0)
+    report("sort_to_indices_f64_uniform", 8.0 * ns, lambda: api.sort_to_indices([[arr(xs_, A.F64, ns)]], [False], oi), rows=ns)
+    xn_ = torch.randn(ns, device="cuda", dtype=torch.float64)
+    report("sort_to_indices_f64_normal", 8.0 * ns, lambda: api.sort_to_indices([[arr(xn_, A.F64, ns)]], [False], oi), rows=ns)
+    lib.set_option("sort_msd", 0)
+    report("sort_to_indices_f64_uniform_byte_passes", 8.0 * ns, lambda: api.sort_to_indices([[arr(xs_, A.F64, ns)]], [False], oi), rows=ns)
+    lib.set_option("sort_msd", 1)
+    del xs_, xn_
     # ArrayFunctions over a List<f64> column: rows of 10 elements (one row per lane) and of 1000 elements (one row per wave)
     for rl in (10, 1000):
         nm = f"list_rows_of_{rl}"
