@@ -44,7 +44,7 @@ bool file_exists(const std::string& p) { FILE* f = std::fopen(p.c_str(), "rb"); 
 
 // where the kernel sources and the compiler's headers are: RDF_JIT_SRC (the directory that holds rdf_spec_kernel.hip.h) or
 // <directory of this library>/csrc; ROCM_PATH or /opt/rocm
-struct Paths { std::string src, hipcc; bool ok = false; std::string why; };
+struct Paths { std::string src, hipcc, stamp; bool ok = false; std::string why; };
 const Paths& paths() {
     static Paths p;
     static bool tried = false;
@@ -57,6 +57,8 @@ const Paths& paths() {
             std::string lib = info.dli_fname;
             const size_t slash = lib.rfind('/');
             p.src = (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/csrc";
+            struct stat st;
+            if (stat(lib.c_str(), &st) == 0) p.stamp = std::to_string((long long)st.st_size) + "." + std::to_string((long long)st.st_mtime);   // a rebuilt library invalidates cached code objects
         }
     }
     if (p.src.empty() || !file_exists(p.src + "/rdf_spec_kernel.hip.h")) { p.why = "kernel sources not found (" + p.src + "/rdf_spec_kernel.hip.h; set RDF_JIT_SRC)"; return p; }
@@ -173,31 +175,34 @@ bool kernel_symbol(const std::vector<char>& elf, std::string& name) {
     return false;
 }
 
-bool build(const char* sig, Entry& e, std::string& why) {
-    const Paths& ps = paths();
-    if (!ps.ok) { why = ps.why; return false; }
-    std::string type;
-    if (!prog_type(sig, type)) { why = "not an exact-program signature"; return false; }
-    static const bool dbg = getenv("RDF_DEBUG_JIT") != nullptr;
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { why = "no device"; return false; }
-    const std::string arch_opt = std::string("--offload-arch=") + prop.gcnArchName;     // "gfx950:sramecc+:xnack-"
+// RDF_JIT_CACHE=<directory>: code objects are kept there across processes, keyed by signature, architecture and the library's
+// size + modification time (a new process then loads a known shape in milliseconds instead of compiling it again)
+std::string cache_file(const char* sig, const std::string& arch, const Paths& ps) {
+    const char* dir = getenv("RDF_JIT_CACHE");
+    if (!dir || !*dir) return std::string();
+    uint64_t h = 1469598103934665603ull;
+    for (const std::string& part : {std::string(sig), arch, ps.stamp})
+        for (unsigned char c : part + "|") { h ^= c; h *= 1099511628211ull; }
+    char name[32];
+    std::snprintf(name, sizeof name, "%016llx.hsaco", (unsigned long long)h);
+    (void)mkdir(dir, 0700);
+    return std::string(dir) + "/" + name;
+}
+
+// one run of the compiler: the kernel source in a scratch directory, hipcc as a child process with build()'s flags (csrc/Makefile),
+// device side only, the code object itself (no offload bundle)
+bool compile(const Paths& ps, const std::string& arch_opt, const std::string& type, std::vector<char>& code, std::string& why) {
     char dir_t[] = "/tmp/rdf_jit_XXXXXX";
     if (!mkdtemp(dir_t)) { why = "mkdtemp failed"; return false; }
     const std::string dir = dir_t, src_path = dir + "/k.hip", obj_path = dir + "/k.hsaco", log_path = dir + "/k.log";
     bool ok = false;
-    hipModule_t mod = nullptr;
     do {
-        {
-            FILE* f = std::fopen(src_path.c_str(), "wb");
-            if (!f) { why = "cannot write " + src_path; break; }
-            std::fprintf(f, "#include \"rdf_spec_kernel.hip.h\"\nusing P = %s;\ntemplate __global__ void rdfk::spec_kernel<P>(const rdfk::SpecArgs);\n"
-                            "extern \"C\" __global__ void rdf_jit_meta(int* out) { out[0] = P::R; out[1] = P::U; out[2] = P::W; out[3] = P::NC; }\n", type.c_str());
-            std::fclose(f);
-        }
+        FILE* f = std::fopen(src_path.c_str(), "wb");
+        if (!f) { why = "cannot write " + src_path; break; }
+        std::fprintf(f, "#include \"rdf_spec_kernel.hip.h\"\nusing P = %s;\ntemplate __global__ void rdfk::spec_kernel<P>(const rdfk::SpecArgs);\n"
+                        "extern \"C\" __global__ void rdf_jit_meta(int* out) { out[0] = P::R; out[1] = P::U; out[2] = P::W; out[3] = P::NC; }\n", type.c_str());
+        std::fclose(f);
         const std::string inc = "-I" + ps.src;
-        // build()'s flags (csrc/Makefile), device side only, the code object itself (no offload bundle)
         std::vector<std::string> argv_s = {ps.hipcc, arch_opt, "--cuda-device-only", "--no-gpu-bundle-output", "-O3", "-std=c++17", "-ffp-contract=off", inc, "-c", src_path, "-o", obj_path};
         std::vector<char*> argv;
         for (std::string& a : argv_s) argv.push_back(&a[0]);
@@ -212,18 +217,52 @@ bool build(const char* sig, Entry& e, std::string& why) {
         if (rc != 0) { why = "cannot start " + ps.hipcc; break; }
         int status = 0;
         while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
-        std::vector<char> code;
         if (!WIFEXITED(status) || WEXITSTATUS(status) != 0 || !read_file(obj_path, code)) {
             std::vector<char> log;
             (void)read_file(log_path, log);
             why = "compilation failed: " + std::string(log.begin(), log.begin() + std::min<size_t>(log.size(), 1500));
             break;
         }
-        std::string kname;
-        if (!kernel_symbol(code, kname)) { why = "kernel symbol not found in the code object"; break; }
-        if (dbg) fprintf(stderr, "[rdf] jit: %zu bytes of code, loading %s\n", code.size(), kname.c_str());
-        hipFunction_t fn = nullptr, meta = nullptr;
-        if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { why = "hipModuleLoadData failed"; mod = nullptr; break; }
+        ok = true;
+    } while (false);
+    if (!getenv("RDF_JIT_KEEP")) { (void)unlink(src_path.c_str()); (void)unlink(obj_path.c_str()); (void)unlink(log_path.c_str()); (void)rmdir(dir.c_str()); }
+    return ok;
+}
+
+bool build(const char* sig, Entry& e, std::string& why) {
+    const Paths& ps = paths();
+    if (!ps.ok) { why = ps.why; return false; }
+    std::string type;
+    if (!prog_type(sig, type)) { why = "not an exact-program signature"; return false; }
+    static const bool dbg = getenv("RDF_DEBUG_JIT") != nullptr;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { why = "no device"; return false; }
+    const std::string arch_opt = std::string("--offload-arch=") + prop.gcnArchName;     // "gfx950:sramecc+:xnack-"
+    const std::string cached = cache_file(sig, prop.gcnArchName, ps);
+    std::vector<char> code;
+    if (!cached.empty() && read_file(cached, code)) {
+        if (dbg) fprintf(stderr, "[rdf] jit: %s from %s\n", sig, cached.c_str());
+    } else {
+        if (!compile(ps, arch_opt, type, code, why)) return false;
+        if (!cached.empty()) {   // written under another name and renamed: a concurrent reader never sees half a file
+            const std::string tmp = cached + "." + std::to_string((long)getpid());
+            FILE* c = std::fopen(tmp.c_str(), "wb");
+            if (c) {
+                const bool w = std::fwrite(code.data(), 1, code.size(), c) == code.size();
+                std::fclose(c);
+                if (!w || rename(tmp.c_str(), cached.c_str()) != 0) (void)unlink(tmp.c_str());
+            }
+        }
+    }
+    std::string kname;
+    if (!kernel_symbol(code, kname)) { why = "kernel symbol not found in the code object"; return false; }
+    if (dbg) fprintf(stderr, "[rdf] jit: %zu bytes of code, loading %s\n", code.size(), kname.c_str());
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr, meta = nullptr;
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { why = "hipModuleLoadData failed"; return false; }
+    bool ok = false;
+    do {
         if (hipModuleGetFunction(&fn, mod, kname.c_str()) != hipSuccess || hipModuleGetFunction(&meta, mod, "rdf_jit_meta") != hipSuccess) { why = "kernel not found in the code object"; break; }
         int* d_meta = nullptr;
         int h_meta[4] = {0, 0, 0, 0};
@@ -237,8 +276,7 @@ bool build(const char* sig, Entry& e, std::string& why) {
         e.k.rows_per_tile = 64 * h_meta[0];
         ok = true;
     } while (false);
-    if (!getenv("RDF_JIT_KEEP")) { (void)unlink(src_path.c_str()); (void)unlink(obj_path.c_str()); (void)unlink(log_path.c_str()); (void)rmdir(dir.c_str()); }
-    if (!ok && mod) (void)hipModuleUnload(mod);
+    if (!ok) (void)hipModuleUnload(mod);
     return ok;
 }
 
