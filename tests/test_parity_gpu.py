@@ -3,6 +3,8 @@
 Mirrors the reference's own test style (in-file unit tests per kernel) with two-sided
 checks: integers/bitmaps bit-exact, floats within util.RTOL = 1e-6 relative.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -883,6 +885,35 @@ def test_kernels_compiled_at_run_time(gpu, ora, request):
         assert got.count == exp.count and abs(got.sum - exp.sum) <= 1e-6 * max(abs(exp.sum), 1.0)
     finally:
         lib.set_option("jit", 0)
+
+
+def test_kernels_compiled_at_run_time_cached_across_processes(tmp_path):
+    """RDF_JIT_CACHE: the first process compiles the program's kernel and leaves the code object in the directory, the second one
+    loads it from there (no compiler run) and computes the same aggregate."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from rust_dataframe_amd import _abi as A, lib
+        lib.set_device(0); api = lib.api()
+        x = [A.HostArray.from_numpy(np.arange(5000, dtype=np.float64) / 7.0)]
+        e = A.Expr(); a = e.col(0)
+        v = e.op("add", e.op("multiply", e.op("sqrt", a), a), e.op("divide", e.op("subtract", a, e.scalar(2.0)), e.op("add", a, e.scalar(1.0))))
+        r = api.pipeline(e, [x], [v], -1)[0]
+        print("RESULT", repr(r.sum), lib.last_kernel())
+    """ % root)
+    env = dict(os.environ, RDF_JIT_CACHE=str(tmp_path / "jit"), RDF_DEBUG_JIT="1")
+    outs = []
+    for _ in range(2):
+        p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(p)
+    res = [[l for l in p.stdout.splitlines() if l.startswith("RESULT")][0] for p in outs]
+    assert res[0] == res[1] and "[compiled at run time]" in res[0], res
+    assert "loading" in outs[0].stderr and " from " not in outs[0].stderr.split("loading")[0]
+    assert " from " + str(tmp_path / "jit") in outs[1].stderr, outs[1].stderr[-1500:]
+    assert len(list((tmp_path / "jit").glob("*.hsaco"))) == 1
 
 
 def test_shape_specialised_kernels_i64_and_mixed_predicates(gpu, ora, request):
