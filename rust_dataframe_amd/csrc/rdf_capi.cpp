@@ -935,8 +935,15 @@ bool build_gspec_plan(Compiler& cc, int filter_root, int group_root, int ngroups
     for (int g : {2, 4, 6, 8}) {
         if (g < ngroups) continue;
         const std::string full = "G" + std::to_string(g) + s;
-        if (gspec_available(full.c_str())) { sp.sig = full; return true; }
+        if (gspec_available(full.c_str()) || (g_ctx.opt_jit && jit_find(full.c_str()))) { sp.sig = full; return true; }
     }
+    if (g_ctx.opt_jit)   // no catalog holds the program: the grouped kernel template compiled for it at run time (rdf_jit.cpp)
+        for (int g : {2, 4, 6, 8}) {
+            if (g < ngroups) continue;
+            const std::string full = "G" + std::to_string(g) + s;
+            if (jit_spec_kernel(full.c_str())) { sp.sig = full; return true; }
+            break;
+        }
     return false;
 }
 
@@ -1479,7 +1486,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             ga.group_partials = d_gpart; ga.flags = d_flags;
             ga.ngroups = ps.ngroups; ga.nvalues = ps.nvalues; ga.vec_bitmap = ctx.opt_vec_bitmap ? 1 : 0;
             KernelTimer kt;
-            ctx.last_kernel = "gspec_kernel<" + gp.sig + ">";
+            ctx.last_kernel = "gspec_kernel<" + gp.sig + ">" + (jit_find(gp.sig.c_str()) ? " [compiled at run time]" : "");
             HIP_TRY(launch_gspec(gp.sig.c_str(), ga, grid, ctx.stream));
             kt.stop();
         } else {

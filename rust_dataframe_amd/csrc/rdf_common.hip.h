@@ -446,4 +446,13 @@ __device__ __forceinline__ int64_t find_chunk_row(const int64_t* start, int64_t 
     return lo;
 }
 
+// arrow::compute::hour: floor division to seconds, floor modulo to the second of the day (constant divisors per unit)
+template <int64_t U> __device__ __forceinline__ uint64_t hour_of(int64_t v) {
+    int64_t q = v / U;
+    if (v % U < 0) --q;
+    int64_t m = q % 86400;
+    if (m < 0) m += 86400;
+    return (uint64_t)(m / 3600);
+}
+
 }  // namespace rdfk

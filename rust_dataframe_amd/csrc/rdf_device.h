@@ -651,10 +651,11 @@ int  spec_rows_per_tile(const char* sig);
 int  spec_catalog_size();
 hipError_t launch_spec(const char* sig, const SpecArgs& a, int grid, hipStream_t s);
 // rdf_jit.cpp: spec_kernel<Prog> instantiated at run time (hiprtc) for an exact-program signature the catalog does not hold
-struct JitKernel { void* fn; int rows_per_tile; };
+struct JitKernel { void* fn; int rows_per_tile; int nvalues; };   // nvalues: grouped programs ("G..." signatures, gspec_kernel)
 const JitKernel* jit_find(const char* sig);          // compiled earlier in this process, or nullptr
 const JitKernel* jit_spec_kernel(const char* sig);   // ... compiling it now if need be; nullptr: not possible (remembered)
 hipError_t jit_launch(const JitKernel& k, const SpecArgs& a, int grid, hipStream_t s);
+hipError_t jit_launch_grouped(const JitKernel& k, const GSpecArgs& a, int grid, hipStream_t s);
 int jit_compiled_count();
 hipError_t launch_filter_agg_f64(const FilterAggF64Args& a, int cmp_op, int grid, hipStream_t s);
 hipError_t launch_mask_count(const MaskTables& t, int tile_rows, int64_t* tile_counts, hipStream_t s);   // tile_rows: kFilterTile or kFilterTileSmall

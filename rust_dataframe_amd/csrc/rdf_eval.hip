@@ -328,14 +328,6 @@ __device__ __forceinline__ void apply_binary(int op, int dt, uint64_t (&acc)[kVP
     }
 }
 
-// arrow::compute::hour: floor division to seconds, floor modulo to the second of the day (constant divisors per unit)
-template <int64_t U> __device__ __forceinline__ uint64_t hour_of(int64_t v) {
-    int64_t q = v / U;
-    if (v % U < 0) --q;
-    int64_t m = q % 86400;
-    if (m < 0) m += 86400;
-    return (uint64_t)(m / 3600);
-}
 template <int FEAT>
 __device__ __forceinline__ void apply_unary(int op, int dt, uint64_t (&acc)[kVPT]) {
     if (op == RDF_OP_NOT) { RDF_ROWS acc[j] = acc[j] ^ 1ull; return; }

@@ -105,12 +105,30 @@ struct Imm {
 
 template <class T> __device__ __forceinline__ double as_f64(T x) { return (double)x; }
 
+// which (operator, operand type) pairs the nodes below implement: the catalogs only ever named valid ones, a program compiled at
+// run time (rdf_jit.cpp) is whatever the caller wrote — an unsupported pair must fail to compile (the interpreter then runs it)
+constexpr bool un_float_op(int op) { return (op >= RDF_OP_ABS && op <= RDF_OP_TANH) || op == RDF_OP_COT || op == RDF_OP_SEC || op == RDF_OP_CSC; }
+constexpr bool is_hour(int op) { return op >= RDF_OP_HOUR_S && op <= RDF_OP_HOUR_DAY; }
+constexpr bool un_supported(int op, int dt) {
+    return op == RDF_OP_NOT ? dt == RDF_BOOL
+         : is_hour(op) ? (dt == RDF_I32 || dt == RDF_I64)
+         : dt_float(dt) ? un_float_op(op)
+         : (dt_signed(dt) && op == RDF_OP_ABS);
+}
+constexpr bool bin_supported(int op, int dt) {   // dt: the operands' type (comparisons convert both sides to f64: any numeric type)
+    return (op >= RDF_OP_GT && op <= RDF_OP_LE) ? dt != RDF_BOOL
+         : (op == RDF_OP_AND || op == RDF_OP_OR) ? dt == RDF_BOOL
+         : dt_float(dt) ? (op >= RDF_OP_ADD && op <= RDF_OP_LOG)
+         : (dt != RDF_BOOL && op >= RDF_OP_ADD && op <= RDF_OP_DIV);
+}
+
 constexpr bool is_cmp(int op) { return op >= RDF_OP_GT && op <= RDF_OP_LE; }
 constexpr bool is_logic(int op) { return op == RDF_OP_AND || op == RDF_OP_OR; }
 
 template <int OP, class A, class B>
 struct Bin {
     static_assert(is_cmp(OP) || A::dt == B::dt, "arithmetic operands share one dtype");
+    static_assert(bin_supported(OP, A::dt) && (!is_cmp(OP) || B::dt != RDF_BOOL), "binary operator / operand type not implemented by the specialised kernels");
     static constexpr int dt = (is_cmp(OP) || is_logic(OP)) ? RDF_BOOL : A::dt;
     static constexpr int ncols = A::ncols > B::ncols ? A::ncols : B::ncols;
     static constexpr int width = merge_width(A::width, B::width);   // -1: mixed (only the grouped kernels take that)
@@ -161,6 +179,7 @@ struct Bin {
 
 template <int OP, class A>
 struct Un {
+    static_assert(un_supported(OP, A::dt), "unary operator / operand type not implemented by the specialised kernels");
     static constexpr int dt = OP == RDF_OP_NOT ? RDF_BOOL : A::dt;
     static constexpr int ncols = A::ncols;
     static constexpr int width = A::width;
@@ -170,6 +189,11 @@ struct Un {
     template <int r, class C> static __device__ __forceinline__ T eval(C& c) {
         const auto x = A::template eval<r>(c);
         if constexpr (OP == RDF_OP_NOT) return !x;
+        else if constexpr (OP == RDF_OP_HOUR_S) return (T)hour_of<1>((int64_t)x);
+        else if constexpr (OP == RDF_OP_HOUR_MS) return (T)hour_of<1000>((int64_t)x);
+        else if constexpr (OP == RDF_OP_HOUR_US) return (T)hour_of<1000000>((int64_t)x);
+        else if constexpr (OP == RDF_OP_HOUR_NS) return (T)hour_of<1000000000>((int64_t)x);
+        else if constexpr (OP == RDF_OP_HOUR_DAY) return (T)0;
         else if constexpr (dt_signed(A::dt)) { using U = typename std::make_unsigned<T>::type; return x < 0 ? (T)((U)0 - (U)x) : x; }  // abs, MIN wraps
         else if constexpr (A::dt == RDF_F32 && OP == RDF_OP_DEGREES) return x * 57.2957795130823208767981548141051703f;
         else if constexpr (A::dt == RDF_F32 && OP == RDF_OP_RADIANS) return x * (3.14159265358979323846264338327950288f / 180.0f);

@@ -121,6 +121,29 @@ bool expr(const char*& p, std::string& out, int depth = 0) {
     }
     return true;
 }
+// the grouped sink's programs (rdf_gspec_kernel.hip.h): "G<g>;P:<pred>;K:<group id>;V:<v0>;<v1>;...;"
+bool gprog_type(const char* sig, std::string& out) {
+    const char* p = sig;
+    std::string g, pred, key, vals, v;
+    if (*p != 'G') return false;
+    ++p;
+    if (!number(p, g) || strncmp(p, ";P:", 3) != 0) return false;
+    p += 3;
+    if (!expr(p, pred) || strncmp(p, ";K:", 3) != 0) return false;
+    p += 3;
+    if (!expr(p, key) || strncmp(p, ";V:", 3) != 0) return false;
+    p += 3;
+    int nv = 0;
+    while (*p) {
+        if (!expr(p, v) || *p != ';') return false;
+        ++p;
+        vals += ", " + v;
+        ++nv;
+    }
+    if (nv < 1) return false;
+    out = "rdfk::GProg<" + g + ", " + pred + ", " + key + vals + ">";
+    return true;
+}
 bool prog_type(const char* sig, std::string& out) {   // "P:<pred>;V:<v0>;<v1>;S:<sink>"
     const char* p = sig;
     std::string pred, v0, v1, sink;
@@ -137,7 +160,7 @@ bool prog_type(const char* sig, std::string& out) {   // "P:<pred>;V:<v0>;<v1>;S
     return true;
 }
 
-struct Entry { JitKernel k{nullptr, 0}; bool failed = false; };
+struct Entry { JitKernel k{nullptr, 0, 0}; bool failed = false; };
 std::mutex g_mu;
 std::map<std::string, Entry> g_kernels;
 int g_compiled = 0;
@@ -154,7 +177,7 @@ bool read_file(const std::string& path, std::vector<char>& out) {
     return ok;
 }
 // the mangled name of the one spec_kernel instantiation in a code object (ELF64, little endian): its dynamic symbol table
-bool kernel_symbol(const std::vector<char>& elf, std::string& name) {
+bool kernel_symbol(const std::vector<char>& elf, const char* prefix, std::string& name) {
     if (elf.size() < sizeof(Elf64_Ehdr) || memcmp(elf.data(), ELFMAG, SELFMAG) != 0) return false;
     const Elf64_Ehdr* eh = (const Elf64_Ehdr*)elf.data();
     if (eh->e_shoff == 0 || eh->e_shoff + (uint64_t)eh->e_shnum * sizeof(Elf64_Shdr) > elf.size()) return false;
@@ -169,7 +192,7 @@ bool kernel_symbol(const std::vector<char>& elf, std::string& name) {
         for (size_t k = 0; k < nsym; ++k) {
             if (ELF64_ST_TYPE(sym[k].st_info) != STT_FUNC || sym[k].st_name >= str.sh_size) continue;
             const char* s = elf.data() + str.sh_offset + sym[k].st_name;
-            if (strncmp(s, "_ZN4rdfk11spec_kernel", 21) == 0) { name = s; return true; }
+            if (strncmp(s, prefix, strlen(prefix)) == 0) { name = s; return true; }
         }
     }
     return false;
@@ -191,7 +214,7 @@ std::string cache_file(const char* sig, const std::string& arch, const Paths& ps
 
 // one run of the compiler: the kernel source in a scratch directory, hipcc as a child process with build()'s flags (csrc/Makefile),
 // device side only, the code object itself (no offload bundle)
-bool compile(const Paths& ps, const std::string& arch_opt, const std::string& type, std::vector<char>& code, std::string& why) {
+bool compile(const Paths& ps, const std::string& arch_opt, const std::string& type, bool grouped, std::vector<char>& code, std::string& why) {
     char dir_t[] = "/tmp/rdf_jit_XXXXXX";
     if (!mkdtemp(dir_t)) { why = "mkdtemp failed"; return false; }
     const std::string dir = dir_t, src_path = dir + "/k.hip", obj_path = dir + "/k.hsaco", log_path = dir + "/k.log";
@@ -199,8 +222,12 @@ bool compile(const Paths& ps, const std::string& arch_opt, const std::string& ty
     do {
         FILE* f = std::fopen(src_path.c_str(), "wb");
         if (!f) { why = "cannot write " + src_path; break; }
-        std::fprintf(f, "#include \"rdf_spec_kernel.hip.h\"\nusing P = %s;\ntemplate __global__ void rdfk::spec_kernel<P>(const rdfk::SpecArgs);\n"
-                        "extern \"C\" __global__ void rdf_jit_meta(int* out) { out[0] = P::R; out[1] = P::U; out[2] = P::W; out[3] = P::NC; }\n", type.c_str());
+        if (grouped)
+            std::fprintf(f, "#include \"rdf_gspec_kernel.hip.h\"\nusing P = %s;\ntemplate __global__ void rdfk::gspec_kernel<P>(const rdfk::GSpecArgs);\n"
+                            "extern \"C\" __global__ void rdf_jit_meta(int* out) { out[0] = P::R; out[1] = P::NV; out[2] = P::G; out[3] = P::NC; }\n", type.c_str());
+        else
+            std::fprintf(f, "#include \"rdf_spec_kernel.hip.h\"\nusing P = %s;\ntemplate __global__ void rdfk::spec_kernel<P>(const rdfk::SpecArgs);\n"
+                            "extern \"C\" __global__ void rdf_jit_meta(int* out) { out[0] = P::R; out[1] = P::U; out[2] = P::W; out[3] = P::NC; }\n", type.c_str());
         std::fclose(f);
         const std::string inc = "-I" + ps.src;
         std::vector<std::string> argv_s = {ps.hipcc, arch_opt, "--cuda-device-only", "--no-gpu-bundle-output", "-O3", "-std=c++17", "-ffp-contract=off", inc, "-c", src_path, "-o", obj_path};
@@ -233,7 +260,8 @@ bool build(const char* sig, Entry& e, std::string& why) {
     const Paths& ps = paths();
     if (!ps.ok) { why = ps.why; return false; }
     std::string type;
-    if (!prog_type(sig, type)) { why = "not an exact-program signature"; return false; }
+    const bool grouped = sig[0] == 'G';
+    if (!(grouped ? gprog_type(sig, type) : prog_type(sig, type))) { why = "not an exact-program signature"; return false; }
     static const bool dbg = getenv("RDF_DEBUG_JIT") != nullptr;
     hipDeviceProp_t prop;
     int dev = 0;
@@ -244,7 +272,7 @@ bool build(const char* sig, Entry& e, std::string& why) {
     if (!cached.empty() && read_file(cached, code)) {
         if (dbg) fprintf(stderr, "[rdf] jit: %s from %s\n", sig, cached.c_str());
     } else {
-        if (!compile(ps, arch_opt, type, code, why)) return false;
+        if (!compile(ps, arch_opt, type, grouped, code, why)) return false;
         if (!cached.empty()) {   // written under another name and renamed: a concurrent reader never sees half a file
             const std::string tmp = cached + "." + std::to_string((long)getpid());
             FILE* c = std::fopen(tmp.c_str(), "wb");
@@ -256,7 +284,7 @@ bool build(const char* sig, Entry& e, std::string& why) {
         }
     }
     std::string kname;
-    if (!kernel_symbol(code, kname)) { why = "kernel symbol not found in the code object"; return false; }
+    if (!kernel_symbol(code, grouped ? "_ZN4rdfk12gspec_kernel" : "_ZN4rdfk11spec_kernel", kname)) { why = "kernel symbol not found in the code object"; return false; }
     if (dbg) fprintf(stderr, "[rdf] jit: %zu bytes of code, loading %s\n", code.size(), kname.c_str());
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr, meta = nullptr;
@@ -273,7 +301,8 @@ bool build(const char* sig, Entry& e, std::string& why) {
         (void)hipFree(d_meta);
         if (!launched || h_meta[0] <= 0) { why = "the kernel's tile size could not be read"; break; }
         e.k.fn = (void*)fn;
-        e.k.rows_per_tile = 64 * h_meta[0];
+        e.k.rows_per_tile = grouped ? kEvalTile : 64 * h_meta[0];
+        e.k.nvalues = grouped ? h_meta[1] : 0;
         ok = true;
     } while (false);
     if (!ok) (void)hipModuleUnload(mod);
@@ -311,6 +340,12 @@ hipError_t jit_launch(const JitKernel& k, const SpecArgs& a, int grid, hipStream
     SpecArgs copy = a;
     void* args[] = {(void*)&copy};
     return hipModuleLaunchKernel((hipFunction_t)k.fn, (unsigned)grid, 1, 1, kBlock, 1, 1, 0, s, args, nullptr);
+}
+hipError_t jit_launch_grouped(const JitKernel& k, const GSpecArgs& a, int grid, hipStream_t s) {
+    GSpecArgs copy = a;
+    void* args[] = {(void*)&copy};
+    const unsigned lds = (unsigned)group_words(a.ngroups, k.nvalues) * 8u;     // the block's group table, as launch_gprog sizes it
+    return hipModuleLaunchKernel((hipFunction_t)k.fn, (unsigned)grid, 1, 1, kBlock, 1, 1, lds, s, args, nullptr);
 }
 
 }  // namespace rdfk

@@ -144,3 +144,41 @@ def test_group_pipeline_errors(gpu, ora):
         with pytest.raises(A.RdfError) as ei:  # domain too large for the fused sink
             api.group_pipeline(e, [keys, vals], [v], k, 5000)
         assert ei.value.status == A.RDF_INVALID_ARGUMENT
+
+
+@pytest.mark.gpu
+def test_grouped_kernels_compiled_at_run_time(gpu, ora, request):
+    """A grouped program the catalog of rdf_gspec.hip does not hold (it has the Q1 shape and sums of plain columns per key): the
+    group id computed from a float column, three value expressions (a tree, a function inside a chain, an i64 product), behind a
+    two-column predicate — gspec_kernel<GProg> is compiled for it at run time (rdf_jit.cpp) instead of the interpreter's grouped
+    sink; chunked inputs with NULLs; the second call comes from the process's cache; with the switch off the interpreter answers."""
+    from rust_dataframe_amd import lib
+    if request.node.callspec.params["gpu"] != "spec":
+        pytest.skip("with the specialised kernels off nothing is compiled")
+    rng = np.random.default_rng(909)
+    lens = [4096, 700, 0, 3000]
+    x = make_chunks(rng, A.F64, lens, 0.05, 0, kind="unit")
+    y = make_chunks(rng, A.F64, lens, 0.1, 0, kind="unit")
+    k = make_chunks(rng, A.I64, lens, 0.0, 0, kind="plain")
+    m = make_chunks(rng, A.I32, lens, 0.02, 0, kind="plain")
+    cols = [x, y, k, m]
+    e = A.Expr()
+    cx, cy, ck, cm = (e.col(i) for i in range(4))
+    gid = e.cast(e.op("multiply", e.op("abs", cx), e.scalar(4.999)), A.I32)                    # |x| <= 1 -> groups 0..4
+    vals = [e.op("add", e.op("multiply", cx, cy), e.op("divide", cy, e.scalar(3.0))),
+            e.op("multiply", e.op("sin", cx), e.op("sqrt", e.op("abs", cy))),
+            e.op("multiply", ck, e.cast(cm, A.I64))]
+    pred = e.op("and", e.op("gt", cx, e.scalar(-0.8)), e.op("ne", cm, e.scalar(7, A.I32)))
+    exp = ora.group_pipeline(e, cols, vals, gid, 5, pred)
+    lib.set_option("jit", 1)
+    try:
+        for _ in range(2):
+            got = gpu.group_pipeline(e, cols, vals, gid, 5, pred)
+            assert lib.last_kernel().startswith("gspec_kernel<G6;") and lib.last_kernel().endswith("[compiled at run time]"), lib.last_kernel()
+            check_groups(got, exp, "grouped program compiled at run time")
+        lib.set_option("jit", 0)
+        got = gpu.group_pipeline(e, cols, vals, gid, 5, pred)
+        assert lib.last_kernel().startswith("eval_kernel<GROUP>"), lib.last_kernel()
+        check_groups(got, exp, "grouped program interpreted")
+    finally:
+        lib.set_option("jit", 0)
