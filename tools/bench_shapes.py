@@ -75,6 +75,22 @@ def beyond_the_catalogs(api, n, steps):
                     print(json.dumps({"dtype": NAME[dt], "program": name, "sink": sink, "jit": jit, "rows": n, "alg_bytes": alg, "kernel_ms": round(kern * 1e3, 4),
                                       "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 3), "first_call_s": round(first, 3) if sink == "agg" else None,
                                       "kernel": lib.last_kernel()[:140]}), flush=True)
+        if dt == A.F64:   # the grouped sink: 5 groups from a float column, two value expressions, behind a predicate (24 B/row)
+            gid = e.cast(e.op("multiply", e.op("abs", a), e.scalar(4.999)), A.I32)
+            gvals = [e.op("add", e.op("multiply", a, b), c), e.op("multiply", e.op("sin", a), b)]
+            gpred = e.op("gt", c, e.scalar(-0.5))
+            for jit in (1, 0):
+                lib.set_option("jit", jit)
+                t0 = time.perf_counter()
+                api.group_pipeline(e, cols[:3], gvals, gid, 5, gpred)
+                first = time.perf_counter() - t0
+                fn = lambda: api.group_pipeline(e, cols[:3], gvals, gid, 5, gpred)
+                fn()
+                wall, kern = timed(fn, steps)
+                alg = 3 * es * n
+                gbs = alg / kern / 1e9 if kern > 0 else 0.0
+                print(json.dumps({"dtype": NAME[dt], "program": "grouped_5_groups_2_values_3col", "sink": "group", "jit": jit, "rows": n, "alg_bytes": alg, "kernel_ms": round(kern * 1e3, 4),
+                                  "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 3), "first_call_s": round(first, 3), "kernel": lib.last_kernel()[:140]}), flush=True)
         lib.set_option("jit", 1)
         del cols, o, i32
         torch.cuda.empty_cache()
