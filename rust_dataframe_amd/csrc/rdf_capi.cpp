@@ -2825,9 +2825,20 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
     // kOsLocalMax rows (keys crowded on few top-bit patterns) sends the column through the byte passes below, which sort any order.
     int sig = 8 * need;                       // bits of (key - bias) that vary
     if (range != ~0ull) { sig = 0; for (uint64_t r = range; r; r >>= 1) ++sig; sig = std::min(sig, 8 * need); }
+    // Top bits: as few passes of <= 8 bits as leave buckets the LDS finish takes, then as many bits as those passes carry for
+    // free — integer keys: 2 passes (16 bits) up to ~1.2e8 rows (1e8 rows: 1526 rows per bucket on average, sorted as 2048),
+    // a third pass beyond with ~500 rows per bucket; value buckets of doubles: ~500 per bucket always (a bell-shaped column's
+    // densest bucket holds 4-5 x the average; measured at 5e7 rows: 800 per bucket sorts uniform doubles in 3.20 instead of
+    // 3.35 ms but sends normally distributed ones to the byte passes, 5.5 instead of 4.3 ms)
+    const int per_bucket = f64_keys ? 512 : 1800;
     int B = 12;
-    const int per_bucket = f64_keys ? 512 : 1024;   // value buckets of a bell-shaped column: the densest holds ~4-5 x the average (measured at 5e7 rows: 800 per bucket sorts uniform doubles in 3.20 instead of 3.35 ms but sends normal ones to the byte passes, 5.5 instead of 4.3 ms)
-    while ((n >> B) > per_bucket && B < 24) ++B;
+    while ((n >> B) > 512 && B < 24) ++B;
+    if (!f64_keys) {
+        int np = 1;
+        while (np < 3 && (n >> (8 * np)) > per_bucket) ++np;
+        B = std::max(12, std::min(B, 8 * np));
+        if ((n >> B) > per_bucket) B = 24;      // (no pass count fits: the condition below fails)
+    }
     if (f64_keys && range != ~0ull) {
         // doubles: sign and exponent crowd the key bits' top patterns, so the buckets are cut in VALUE space (OsBucket)
         auto value_of = [&](uint64_t stored) { const uint64_t ord = f64_keys == 2 ? ~stored : stored; const uint64_t b = (ord >> 63) ? (ord ^ 0x8000000000000000ull) : ~ord; double x; memcpy(&x, &b, 8); return x; };
