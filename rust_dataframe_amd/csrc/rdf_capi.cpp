@@ -799,6 +799,7 @@ struct SpecSigBuilder {
 bool build_spec_plan(Compiler& cc, int filter_root, int nvalues, const int* value_roots, int sink, SpecPlan& sp) {
     if (nvalues > 2 || (sink == RDF_SINK_STORE && nvalues != 1)) return false;
     sp.widest = true;
+    sp.max_cols = kSpecCols; sp.max_imm = kSpecImm;   // (the catalogs' programs stop at 4 and 4; rdf_jit.cpp compiles up to these)
     SpecSigBuilder b(cc, sp);
     std::string s = "P:";
     s += filter_root >= 0 ? b.node(filter_root, RDF_F64) : std::string("-");
@@ -1385,7 +1386,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     if (use_spec) {
         for (int k = 0; k < sp.nimm; ++k) sa.imm[k] = sp.imm[k];
         for (int k = 0; k < 8; ++k) sa.rt[k] = rt_ops[k];
-        for (int k = 0; k < 4; ++k) {   // a repeated program column is loaded once
+        for (int k = 0; k < kSpecCols; ++k) {   // a repeated program column is loaded once
             sa.alias[k] = -1;
             for (int j = 0; j < k && k < sp.ncols; ++j) if (sp.col_map[j] == sp.col_map[k]) { sa.alias[k] = j; break; }
         }

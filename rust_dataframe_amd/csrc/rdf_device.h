@@ -122,9 +122,12 @@ struct FilterAggF64Args {
     AggPartial*    partials;   // [gridDim.x]
 };
 
-// Specialised straight-line kernels (rdf_spec.hip): up to 4 eight-byte columns, one chunk.
+// Specialised straight-line kernels (rdf_spec_kernel.hip.h): up to kSpecCols columns and kSpecImm literals (the catalogs' programs
+// read at most 4 of each; a program compiled at run time may use them all).
+constexpr int kSpecCols = 8;
+constexpr int kSpecImm = 8;
 struct SpecArgs {
-    DevChunkCol        cols[4];          // nchunks == 1: inline descriptors
+    DevChunkCol        cols[kSpecCols];  // nchunks == 1: inline descriptors
     DevOutChunk        out;              // nchunks == 1, SINK_STORE
     const DevChunkCol* cols_tab;         // nchunks > 1: [NC * nchunks], canonical column order
     const DevOutChunk* outs_tab;         // nchunks > 1, SINK_STORE: [nchunks]
@@ -133,13 +136,13 @@ struct SpecArgs {
     int64_t            nchunks, ntiles;
     int64_t            n;                // nchunks == 1: rows
     uint64_t           tile_inv;         // floor(((nchunks - 1) << 32) / chunk_tile_start[nchunks - 1]): the tile -> chunk guess is a multiply (0: search)
-    uint64_t           imm[4];
+    uint64_t           imm[kSpecImm];
     int64_t*           out_null_count;   // SINK_STORE: [nchunks]
     AggPartial*        partials;         // SINK_AGG: [gridDim.x * nvalues]
     uint32_t*          flags;
     int32_t            vec_bitmap;       // 1: bitmap words through the vector memory path (default); 0: scalar loads (A/B)
     int32_t            rt[8];            // shape-specialised kernels: operator of runtime-op node k (rdf_op | swap << 8)
-    int32_t            alias[4];         // canonical column k repeats column alias[k] < k (-1: its own column): registers are copied, not reloaded
+    int32_t            alias[kSpecCols]; // canonical column k repeats column alias[k] < k (-1: its own column): registers are copied, not reloaded
 };
 
 struct MaskTables {

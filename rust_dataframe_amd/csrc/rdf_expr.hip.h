@@ -39,7 +39,7 @@ struct Ctx {
     static constexpr int rows = R;
     S        v[NC][R];   // raw elements, row r of column c
     uint32_t valid[NC];  // bit r = row r of column c is valid
-    uint64_t imm[4];
+    uint64_t imm[kSpecImm];
     uint32_t inr;        // bit r = row r exists
     uint32_t err;
     int32_t  rt[8];      // runtime operators of the *RT nodes (wave-uniform)

@@ -157,7 +157,8 @@ struct Prog {
         if constexpr (SINK_ == SINK_STORE && !std::is_same<V0, None>::value) return V0::dt == RDF_BOOL ? 0 : CType<V0::dt>::width;
         else return 0;
     }
-    static constexpr int W = cmax(cmax(cmax(colw<0>(), colw<1>()), cmax(colw<2>(), colw<3>())), out_width());
+    static constexpr int W = cmax(cmax(cmax(cmax(colw<0>(), colw<1>()), cmax(colw<2>(), colw<3>())), cmax(cmax(colw<4>(), colw<5>()), cmax(colw<6>(), colw<7>()))), out_width());
+    static_assert(NC <= kSpecCols, "a program reads at most kSpecCols columns");
     static_assert(W == 8 || W == 4 || W == 2 || W == 1, "the widest element of a program is 8, 4, 2 or 1 bytes");
     // rows per vector slot: a 16-byte vector of the widest type — except for predicates stored as bit masks, which load 8 bytes
     // per lane: with one f64 per lane a compare's lane mask IS the Arrow bitmap word of those 64 rows, and every halving of the
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     Ctx<NC, R, S> c;
     c.err = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) c.imm[k] = a.imm[k];
+    for (int k = 0; k < kSpecImm; ++k) c.imm[k] = a.imm[k];
 #pragma unroll
     for (int k = 0; k < 8; ++k) c.rt[k] = a.rt[k];
     AggT<V0::dt> g0;

@@ -826,8 +826,9 @@ def test_shape_specialised_runtime_op_kernels(gpu, ora, request):
 def test_kernels_compiled_at_run_time(gpu, ora, request):
     """Program shapes outside the catalogs — four levels of arithmetic, a function inside a chain, casts below the leaves, a
     wrapping integer tree — get spec_kernel<Prog> instantiated for them at run time (hiprtc, rdf_jit.cpp) instead of the
-    interpreter: aggregates (plain and behind predicates) and new columns against the oracle, the second call served from the
-    process's cache, the interpreter with the switch off, and a program the kernel template cannot hold (five columns)."""
+    interpreter: aggregates (plain and behind predicates, up to five distinct columns) and new columns against the oracle, the
+    second call served from the process's cache, the interpreter with the switch off, and a program the kernel template cannot
+    hold (more than eight literals)."""
     from rust_dataframe_amd import lib
     if request.node.callspec.params["gpu"] != "spec":
         pytest.skip("with the specialised kernels off nothing is compiled")
@@ -851,8 +852,6 @@ def test_kernels_compiled_at_run_time(gpu, ora, request):
     try:
         for vn, (v, dt) in programs.items():
             for pn, p in preds.items():
-                if vn == "four_levels" and pn == "two_columns":
-                    continue                                    # five columns: see below
                 exp = ora.pipeline(e, cols, [v], p)[0]
                 for attempt in range(2):                        # compiled, then found in the cache
                     got = gpu.pipeline(e, cols, [v], p)[0]
@@ -871,10 +870,12 @@ def test_kernels_compiled_at_run_time(gpu, ora, request):
             assert lib.last_kernel().endswith("[compiled at run time]"), f"{vn} store ran on {lib.last_kernel()}"
             for ge, ee in zip(outs_g[0], outs_e[0]):
                 assert_arrays_match(ge, ee, exact=vn != "function_inside", what=vn)
-        # five distinct columns do not fit the kernel template: the interpreter answers, as it does with the switch off
-        v, p = programs["four_levels"][0], preds["two_columns"]
-        exp = ora.pipeline(e, cols, [v], p)[0]
-        got = gpu.pipeline(e, cols, [v], p)[0]
+        # nine literals do not fit the kernel template (eight): the interpreter answers, as it does for everything with the switch off
+        v = a
+        for j in range(9):
+            v = e.op("add", e.op("multiply", v, e.scalar(1.0 + 0.125 * j)), e.scalar(0.5 + j)) if j < 4 else e.op("subtract", v, e.scalar(0.03125 * (j + 1)))
+        exp = ora.pipeline(e, cols, [v], -1)[0]
+        got = gpu.pipeline(e, cols, [v], -1)[0]
         assert lib.last_kernel().startswith("eval_kernel<"), lib.last_kernel()
         assert got.count == exp.count and abs(got.sum - exp.sum) <= 1e-6 * max(abs(exp.sum), 1.0)
         lib.set_option("jit", 0)
