@@ -5,7 +5,7 @@
 # Counters are collected in their own passes (one --pmc counter per pass, kernel trace only), as the MI355X guide asks.
 set -u
 R=${1:-r02}
-PART=${2:-all}      # all | micro (only the per-entry counter passes of step 3b) | workloads (only the three bench lines of step 2)
+PART=${2:-all}      # all | micro (only the per-entry counter passes of step 3b) | workloads (only the three bench lines of step 2) | r3 | new (the counter passes of the round-3 entries only)
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profile_$R
 mkdir -p "$OUT"
@@ -16,6 +16,13 @@ pmc() {   # pmc <tag> <command...>: FETCH_SIZE and WRITE_SIZE of every kernel of
         timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_${tag}_$c" -o p -- "$@" > "$OUT/pmc_${tag}_$c.out" 2> "$OUT/pmc_${tag}_$c.err"
     done
 }
+if [ "$PART" = "new" ]; then
+    for e in sort_to_indices_i64_full_range groupby_count_1000000_groups join_inner_1e8_x_1e7; do
+        pmc micro_$e python "$REPO/tools/bench_kernels.py" --rows 1000000000 --steps 3 --only $e
+    done
+    find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*agent_info.csv" -delete
+    exit 0
+fi
 if [ "$PART" = "workloads" ]; then
     rm -f "$OUT/workloads.jsonl"
     for w in c3 c4 q1; do python "$REPO/bench.py" --workload $w --steps 10 --warmup 3 2>> "$OUT/workloads.err" | tail -1 >> "$OUT/workloads.jsonl"; done
@@ -38,7 +45,8 @@ python "$REPO/tools/bench_kernels.py" --rows 1000000000 --steps 5 2> "$OUT/kerne
 python "$REPO/tools/bench_shapes.py" --interp 2> "$OUT/shapes.err" | grep kernel_ms > "$OUT/shapes_2p5e8.jsonl"
 fi
 # 3b. HBM counters of compaction / take / small-group GROUP BY, one micro-benchmark entry per pass (the entries share kernels)
-for e in filter_1col filter_2col filter_1col_selectivity_1_16 take_random_u32 take_sequential_u32 groupby_sum_1000_groups; do
+for e in filter_1col filter_2col filter_1col_selectivity_1_16 take_random_u32 take_sequential_u32 groupby_sum_1000_groups \
+         sort_to_indices_i64_full_range groupby_count_1000000_groups join_inner_1e8_x_1e7; do
     pmc micro_$e python "$REPO/tools/bench_kernels.py" --rows 1000000000 --steps 3 --only $e
 done
 # 3c. round 3: frame-level operators on 976 563 batches of 1024 rows (wall against kernel time), ingestion, Int8 / UInt8 kernels,
