@@ -30,6 +30,10 @@
 #include <sstream>
 #include <stdexcept>
 #include <charconv>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <string>
 #include <thread>
 #include <utility>
@@ -154,6 +158,61 @@ inline void upload(void* dst, const void* src, int64_t bytes, bool src_pinned) {
     if (src_pinned) { check(rdf_copy_h2d_async(dst, src, bytes)); ++st.async_copies; }
     else { check(rdf_copy_h2d(dst, src, bytes)); ++st.blocking_copies; }
 }
+
+// Uploads out of PAGEABLE memory (a file mapped into the address space): page-locking a whole multi-GB image costs more than moving
+// it (hipHostMalloc of 2.57 GB: 0.44 s; the link moves it in 0.05 s), so the bytes go through two page-locked staging buffers of
+// kGroup bytes that live as long as the thread: worker threads copy the pieces of one group out of the page cache while the
+// copy stream drains the other.  Never pins more than 2 x kGroup, whatever the file's size.
+class StagedUploader {
+  public:
+    static StagedUploader& instance() { static thread_local StagedUploader u; return u; }
+    void push(void* dst, const void* src, int64_t bytes) {
+        IngestStats& st = last_ingest();
+        st.bytes += bytes > 0 ? bytes : 0;
+        const uint8_t* p = (const uint8_t*)src;
+        uint8_t* d = (uint8_t*)dst;
+        while (bytes > 0) {
+            if (!grp_[0]) { grp_[0] = std::make_unique<PinnedBuffer>(kGroup); grp_[1] = std::make_unique<PinnedBuffer>(kGroup); }
+            const int64_t take = std::min(bytes, kGroup - used_);
+            pieces_.push_back(Piece{d, p, take, used_});
+            used_ += (take + 255) / 256 * 256;
+            d += take; p += take; bytes -= take;
+            if (used_ >= kGroup) flush();
+        }
+    }
+    void flush() {      // the current group: pages -> staging buffer (threads), staging buffer -> HBM (queued on the copy stream)
+        if (pieces_.empty()) return;
+        uint8_t* base = grp_[cur_]->data();
+        {   // long pieces are cut so that every thread has work: a group usually holds a few dozen column buffers
+            std::vector<Piece> cut;
+            for (const Piece& q : pieces_)
+                for (int64_t o = 0; o < q.bytes; o += kSlice) cut.push_back(Piece{q.dst + o, q.src + o, std::min(kSlice, q.bytes - o), q.off + o});
+            pieces_.swap(cut);
+        }
+        const int T = (int)std::max<size_t>(1, std::min<size_t>({pieces_.size(), (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)12}));
+        auto work = [&](int t) { for (size_t k = (size_t)t; k < pieces_.size(); k += (size_t)T) std::memcpy(base + pieces_[k].off, pieces_[k].src, (size_t)pieces_[k].bytes); };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+        IngestStats& st = last_ingest();
+        for (const Piece& q : pieces_) { check(rdf_copy_h2d_async(q.dst, base + q.off, q.bytes)); ++st.async_copies; }
+        pieces_.clear();
+        used_ = 0;
+        inflight_[cur_] = true;
+        cur_ ^= 1;
+        if (inflight_[cur_]) { check(rdf_copy_fence()); inflight_[0] = inflight_[1] = false; }   // the buffer we turn to must have left
+    }
+    void finish() { flush(); check(rdf_copy_fence()); inflight_[0] = inflight_[1] = false; }
+  private:
+    struct Piece { uint8_t* dst; const uint8_t* src; int64_t bytes, off; };
+    static constexpr int64_t kGroup = (int64_t)128 << 20, kSlice = (int64_t)4 << 20;
+    std::unique_ptr<PinnedBuffer> grp_[2];
+    std::vector<Piece> pieces_;
+    int64_t used_ = 0;
+    int cur_ = 0;
+    bool inflight_[2] = {false, false};
+};
 
 inline std::vector<uint8_t> pack_bits(const std::vector<bool>& bits) {
     std::vector<uint8_t> out((bits.size() + 63) / 64 * 8 + 8, 0);
@@ -1285,15 +1344,30 @@ class DataFrame {
     // no intermediate arrays, no runtime staging copy, no synchronisation per buffer.  last_ingest() tells what went up.
     static DataFrame from_arrow(const std::string& path) {
         const auto t0 = std::chrono::steady_clock::now();
-        std::ifstream f(path, std::ios::binary | std::ios::ate);
-        if (!f) throw DataFrameError(DataFrameError::IoError, "cannot open " + path);
-        const int64_t size = (int64_t)f.tellg();
-        f.seekg(0);
-        PinnedBuffer img(size);
-        if (size > 0 && !f.read((char*)img.data(), size)) throw DataFrameError(DataFrameError::IoError, "cannot read " + path);
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw DataFrameError(DataFrameError::IoError, "cannot open " + path);
+        struct stat st;
+        if (::fstat(fd, &st) != 0) { ::close(fd); throw DataFrameError(DataFrameError::IoError, "cannot stat " + path); }
+        const size_t size = (size_t)st.st_size;
+        // the file is MAPPED, not read into a page-locked copy: the metadata is decoded from the mapping and the column buffers
+        // travel through the staging buffers of StagedUploader (page-locking 2.57 GB took 0.44 of the load's 0.49 s)
+        void* map = size ? ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+        ::close(fd);
+        if (size && map == MAP_FAILED) throw DataFrameError(DataFrameError::IoError, "cannot map " + path);
         last_ingest() = IngestStats();
-        last_ingest().parse_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();   // reading the file
-        DataFrame df = load_arrow_image(img.data(), (size_t)size, true);
+        DataFrame df;
+        try {
+            IpcReader r((const uint8_t*)map, size);
+            r.staged = true;
+            if (size >= 20 && std::memcmp(map, "ARROW1", 6) == 0) r.read_file(); else r.read_stream();
+            df = r.finish();
+            StagedUploader::instance().finish();
+        } catch (...) {
+            try { StagedUploader::instance().finish(); } catch (...) {}
+            if (map) ::munmap(map, size);
+            throw;
+        }
+        if (map) ::munmap(map, size);
         last_ingest().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return df;
     }
@@ -1328,6 +1402,7 @@ class DataFrame {
         struct Col { Field field; bool dict = false; int64_t dict_id = 0; DataType index_type = DataType::Int32; };
         const uint8_t* img; size_t size; FlatBuf fb;
         bool pinned = false;     // the image is page-locked: column buffers go up asynchronously, straight out of it
+        bool staged = false;     // the image is pageable (a mapped file): column buffers go through StagedUploader
         std::vector<Col> cols;
         std::map<int64_t, Dict> dicts;
         std::vector<std::vector<ArrayRef>> chunks;
@@ -1443,10 +1518,10 @@ class DataFrame {
                 a->dtype = dt;
                 a->length = b.len;
                 a->values = std::make_shared<DeviceBuffer>(need + 8);
-                upload(a->values->data(), body.p + b.d0, need, pinned);
+                if (staged) StagedUploader::instance().push(a->values->data(), body.p + b.d0, need); else upload(a->values->data(), body.p + b.d0, need, pinned);
                 if (b.nulls > 0) {
                     a->validity = std::make_shared<DeviceBuffer>((b.len + 7) / 8 + 8);
-                    upload(a->validity->data(), body.p + b.vo, (b.len + 7) / 8, pinned);
+                    if (staged) StagedUploader::instance().push(a->validity->data(), body.p + b.vo, (b.len + 7) / 8); else upload(a->validity->data(), body.p + b.vo, (b.len + 7) / 8, pinned);
                     a->null_count = b.nulls;
                 }
                 chunks[c].push_back(a);
