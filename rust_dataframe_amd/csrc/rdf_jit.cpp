@@ -215,9 +215,10 @@ std::string cache_file(const char* sig, const std::string& arch, const Paths& ps
 // one run of the compiler: the kernel source in a scratch directory, hipcc as a child process with build()'s flags (csrc/Makefile),
 // device side only, the code object itself (no offload bundle)
 bool compile(const Paths& ps, const std::string& arch_opt, const std::string& type, bool grouped, std::vector<char>& code, std::string& why) {
-    char dir_t[] = "/tmp/rdf_jit_XXXXXX";
-    if (!mkdtemp(dir_t)) { why = "mkdtemp failed"; return false; }
-    const std::string dir = dir_t, src_path = dir + "/k.hip", obj_path = dir + "/k.hsaco", log_path = dir + "/k.log";
+    const char* tmp = getenv("TMPDIR");
+    std::string dir_s = std::string(tmp && *tmp ? tmp : "/tmp") + "/rdf_jit_XXXXXX";
+    if (!mkdtemp(&dir_s[0])) { why = "mkdtemp failed under " + dir_s; return false; }
+    const std::string dir = dir_s, src_path = dir + "/k.hip", obj_path = dir + "/k.hsaco", log_path = dir + "/k.log";
     bool ok = false;
     do {
         FILE* f = std::fopen(src_path.c_str(), "wb");
