@@ -733,11 +733,11 @@ inline int range_count(size_t n, int threads) {
     return (int)((n + per - 1) / per);
 }
 
-struct Inferred { DataType dtype = DataType::Utf8; bool any_null = false; };
-// the types of the columns `cols` (indices into the header)
-inline std::vector<Inferred> infer(const Text& t, const std::vector<size_t>& cols, int threads = 0) {
+struct Inferred { DataType dtype = DataType::Utf8; bool any_null = false, any = false; };   // any: some cell of the column is not empty
+// the types of the columns `cols` (indices into the header), from the first `limit` records
+inline std::vector<Inferred> infer(const Text& t, const std::vector<size_t>& cols, int threads = 0, size_t limit = (size_t)-1) {
     struct Flags { bool all_int = true, all_num = true, all_bool = true, any = false, nulls = false; };
-    const size_t nh = t.header.size(), n = t.records.size();
+    const size_t nh = t.header.size(), n = std::min(t.records.size(), limit);
     const int nr = range_count(n, threads);
     std::vector<std::vector<Flags>> part((size_t)nr, std::vector<Flags>(cols.size()));
     for_ranges(n, threads, [&](int w, size_t r0, size_t r1) {
@@ -765,6 +765,7 @@ inline std::vector<Inferred> infer(const Text& t, const std::vector<size_t>& col
         for (auto& p : part) { m.all_int &= p[k].all_int; m.all_num &= p[k].all_num; m.all_bool &= p[k].all_bool; m.any |= p[k].any; m.nulls |= p[k].nulls; }
         // (a range that met no cell that breaks "integer" never tried "number": an integer is a number)
         out[k].any_null = m.nulls;
+        out[k].any = m.any;
         out[k].dtype = !m.any ? DataType::Utf8 : m.all_int ? DataType::Int64 : m.all_num ? DataType::Float64 : m.all_bool ? DataType::Boolean : DataType::Utf8;
     }
     return out;
@@ -773,8 +774,11 @@ inline std::vector<Inferred> infer(const Text& t, const std::vector<size_t>& col
 struct Filled { int64_t nulls = 0; std::vector<std::string> strings; };   // strings: the cells of a Utf8 column
 // Parse column cols[k] of every record into values[k] (8 bytes per row; Boolean: one bit per row) and validity[k] (one bit per
 // row, 1 = valid); both zeroed here.  Utf8 columns (values[k] == nullptr) come back as strings.
+// `violated` (optional, one flag per column): a non-empty cell did not parse as the column's type — the types came from a sample
+// of the records and the caller has to infer them from all of them after all.
 inline std::vector<Filled> fill(const Text& t, const std::vector<size_t>& cols, const std::vector<Inferred>& types,
-                                const std::vector<uint8_t*>& values, const std::vector<uint8_t*>& validity, int threads = 0) {
+                                const std::vector<uint8_t*>& values, const std::vector<uint8_t*>& validity, int threads = 0,
+                                std::vector<char>* violated = nullptr) {
     const size_t nh = t.header.size(), n = t.records.size();
     std::vector<Filled> out(cols.size());
     for (size_t k = 0; k < cols.size(); ++k) {
@@ -796,9 +800,11 @@ inline std::vector<Filled> fill(const Text& t, const std::vector<size_t>& cols, 
                 if (dt == DataType::Utf8) { out[k].strings[r].assign(c.b, c.e); continue; }
                 if (c.b == c.e) { ++nulls[(size_t)w][k]; continue; }
                 validity[k][r >> 3] |= (uint8_t)(1u << (r & 7));
-                if (dt == DataType::Int64) { int64_t v = 0; (void)parse_i64(c.b, c.e, v); std::memcpy(values[k] + 8 * r, &v, 8); }
-                else if (dt == DataType::Float64) { double v = 0; (void)parse_f64(c.b, c.e, v); std::memcpy(values[k] + 8 * r, &v, 8); }
-                else { bool v = false; (void)is_bool(c.b, c.e, &v); if (v) values[k][r >> 3] |= (uint8_t)(1u << (r & 7)); }
+                bool ok;
+                if (dt == DataType::Int64) { int64_t v = 0; ok = parse_i64(c.b, c.e, v); std::memcpy(values[k] + 8 * r, &v, 8); }
+                else if (dt == DataType::Float64) { double v = 0; ok = parse_f64(c.b, c.e, v); std::memcpy(values[k] + 8 * r, &v, 8); }
+                else { bool v = false; ok = is_bool(c.b, c.e, &v); if (v) values[k][r >> 3] |= (uint8_t)(1u << (r & 7)); }
+                if (!ok && violated) (*violated)[k] = 1;     // (a racing store of the same value from several threads)
             }
         }
     });
@@ -1275,21 +1281,40 @@ class DataFrame {
             }
         } else for (size_t i = 0; i < t.header.size(); ++i) sel.push_back(i);
         const size_t n = t.records.size();
-        const std::vector<csv::Inferred> types = csv::infer(t, sel);
+        // The types of a long file are taken from its first records and every cell is parsed ONCE against them; a cell that does
+        // not fit (or a column whose sampled cells were all empty) sends the file through inference over all records and a second
+        // parse — the result is always what inference over the whole file gives.
+        const size_t kSample = 16384;
+        bool sampled = n > 4 * kSample;
+        std::vector<csv::Inferred> types = csv::infer(t, sel, 0, sampled ? kSample : n);
+        if (sampled) for (auto& ty : types) if (!ty.any) { sampled = false; break; }
+        if (!sampled && n > 4 * kSample) types = csv::infer(t, sel);
         // typed values are parsed STRAIGHT into page-locked column buffers (+ bitmaps) by the worker threads, then every column
         // is queued for upload; one fence after the last one
         const int64_t bbytes = (int64_t)((n + 63) / 64 * 8 + 8);
-        std::vector<uint8_t*> pvs(sel.size(), nullptr), pbs(sel.size(), nullptr);
-        std::vector<int64_t> vbytes_of(sel.size(), 0);
-        for (size_t k = 0; k < sel.size(); ++k) {
-            if (types[k].dtype == DataType::Utf8) continue;
-            vbytes_of[k] = types[k].dtype == DataType::Boolean ? bbytes : (int64_t)(n * 8);
-            staged.push_back(std::make_unique<PinnedBuffer>(vbytes_of[k] + bbytes));
-            pvs[k] = staged.back()->data();
-            pbs[k] = pvs[k] + vbytes_of[k];
-            std::memset(pvs[k], 0, (size_t)(vbytes_of[k] + bbytes));
+        std::vector<uint8_t*> pvs, pbs;
+        std::vector<int64_t> vbytes_of;
+        auto buffers = [&]() {
+            staged.clear();
+            pvs.assign(sel.size(), nullptr); pbs.assign(sel.size(), nullptr); vbytes_of.assign(sel.size(), 0);
+            for (size_t k = 0; k < sel.size(); ++k) {
+                if (types[k].dtype == DataType::Utf8) continue;
+                vbytes_of[k] = types[k].dtype == DataType::Boolean ? bbytes : (int64_t)(n * 8);
+                staged.push_back(std::make_unique<PinnedBuffer>(vbytes_of[k] + bbytes));
+                pvs[k] = staged.back()->data();
+                pbs[k] = pvs[k] + vbytes_of[k];
+                std::memset(pvs[k], 0, (size_t)(vbytes_of[k] + bbytes));
+            }
+        };
+        buffers();
+        std::vector<char> violated(sel.size(), 0);
+        std::vector<csv::Filled> filled = csv::fill(t, sel, types, pvs, pbs, 0, sampled ? &violated : nullptr);
+        if (sampled && std::find(violated.begin(), violated.end(), (char)1) != violated.end()) {
+            types = csv::infer(t, sel);
+            buffers();
+            filled = csv::fill(t, sel, types, pvs, pbs);
         }
-        std::vector<csv::Filled> filled = csv::fill(t, sel, types, pvs, pbs);
+        for (size_t k = 0; k < sel.size(); ++k) types[k].any_null = filled[k].nulls > 0;
         std::vector<Column> cols;
         for (size_t k = 0; k < sel.size(); ++k) {
             const DataType dt = types[k].dtype;

@@ -596,6 +596,46 @@ TEST(test_read_csv_infers_types_and_nulls) {
     CHECK_EQ(df.select({"id", "nope"}).num_columns(), 1u);
 }
 
+// A long file: the types come from the first 16 384 records and every cell is parsed once against them; what only a late record
+// shows — a fraction in a column of integers, text in a column of booleans, the first value of a column that was empty so far —
+// must give the types inference over the WHOLE file gives, and the values with them.
+TEST(test_read_long_csv_types_hold_for_late_records) {
+    const size_t n = 70000;
+    for (int variant = 0; variant < 2; ++variant) {     // 0: every column keeps its sampled type; 1: late records change three of them
+        std::string body = "a,b,c,d\n";
+        int64_t want_b = 0;
+        double want_a = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const bool late = variant == 1 && i == n - 10;
+            body += late ? "2.5" : std::to_string((int64_t)i - 100);
+            want_a += late ? 2.5 : (double)((int64_t)i - 100);
+            body += "," + std::to_string((int64_t)i * 2) + ",";
+            want_b += (int64_t)i * 2;
+            if (variant == 1 && i >= 20000) body += std::to_string((int64_t)i % 7);      // column c: empty in the sampled records
+            body += std::string(",") + (variant == 1 && i == n - 5 ? "maybe" : (i % 2 ? "true" : "false")) + "\n";
+        }
+        const std::string path = write_temp_csv(body);
+        DataFrame df = DataFrame::from_csv(path);
+        std::remove(path.c_str());
+        CHECK_EQ(df.num_rows(), (int64_t)n);
+        CHECK(df.column_by_name("b").data_type() == DataType::Int64);
+        CHECK_EQ(*AggregateFunctions::sum<int64_t>(df.column_by_name("b").data()), want_b);
+        if (variant == 0) {
+            CHECK(df.column_by_name("a").data_type() == DataType::Int64);
+            CHECK(df.column_by_name("c").data_type() == DataType::Utf8);           // no value anywhere
+            CHECK(df.column_by_name("d").data_type() == DataType::Boolean);
+            CHECK_EQ(*AggregateFunctions::sum<int64_t>(df.column_by_name("a").data()), (int64_t)want_a);
+        } else {
+            CHECK(df.column_by_name("a").data_type() == DataType::Float64);
+            CHECK_NEAR(*AggregateFunctions::sum<double>(df.column_by_name("a").data()), want_a, 1e-12);
+            CHECK(df.column_by_name("c").data_type() == DataType::Int64);
+            CHECK_EQ(df.column_by_name("c").null_count(), (int64_t)20000);
+            CHECK(df.column_by_name("d").data_type() == DataType::Utf8);
+            CHECK_EQ((*df.column_by_name("d").data().chunk((n - 5) / 1024)->strings)[(n - 5) % 1024], std::string("maybe"));
+        }
+    }
+}
+
 // sort / join / take of a frame holding text and Boolean columns (Column::take, src/table.rs:218-241, is type-generic)
 TEST(test_sort_and_join_carry_text_and_boolean_columns) {
     DataFrame df = DataFrame::from_csv(g_csv);   // city (Utf8), lat, lng
