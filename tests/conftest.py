@@ -32,7 +32,7 @@ def gpu(request):
     lib.set_option("fast_filter", 1 if request.param == "spec" else 0)
     # shapes outside the catalogs are compiled at run time by default (rdf_jit.cpp, about a second each): the parity suites walk
     # hundreds of such shapes and hold them to the interpreter, test_kernels_compiled_at_run_time turns the compiler on
-    lib.set_option("jit", 0)
+    lib.set_option("jit", 1 if os.environ.get("RDF_TEST_JIT") == "1" and request.param == "spec" else 0)   # RDF_TEST_JIT=1: the whole suite through the run-time compiler (minutes of compiles)
     yield api
     lib.set_option("spec", 1)
     lib.set_option("fast_filter", 1)
