@@ -14,6 +14,15 @@ from rust_dataframe_amd import _abi as A
 from rust_dataframe_amd import sharding
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    """A port nobody listens on right now (a fixed port reused by consecutive tests can still sit in TIME_WAIT: the next
+    rendezvous then waits for its time-out)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 LENS = [1024] * 9 + [576]
 SEED = 99
 
@@ -85,7 +94,7 @@ def test_combine_matches_whole(ora):
 
 @pytest.mark.timeout(120)
 def test_world_size_2_gloo(ora):
-    world, port = 2, 29500 + os.getpid() % 2000
+    world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -138,7 +147,7 @@ def test_groupby_all_to_all_world_2_gloo(ora, shuffle_rows, world, monkeypatch):
     row-shuffle fallback of the same section (rows exchanged, aggregated once at their owner): the same groups either way."""
     monkeypatch.setenv("RDF_TEST_SHUFFLE_ROWS", "1" if shuffle_rows else "0")
     assert sharding.shuffle_rows_pays(1000, 600) and not sharding.shuffle_rows_pays(10_000_000, 1_000_000)
-    port = 31500 + os.getpid() % 2000 + (50 if shuffle_rows else 0) + 7 * world      # (world 4: the uneven splits of the driver's N = 4 / 8 runs)
+    port = _free_port()      # (world 4: the uneven splits of the driver's N = 4 / 8 runs)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_gb_worker, args=(r, world, port, q)) for r in range(world)]
@@ -188,7 +197,7 @@ def _gb_int_data():
 def test_groupby_exchange_keeps_integer_sums_exact_world_2_gloo(ora):
     """Integer sums far above 2^53 and UInt64 keys above 2^63 travel as raw 64-bit words: dtypes and values of the
     multi-rank result equal the single-rank one bit for bit (wrapping Int64 sums)."""
-    world, port = 2, 33500 + os.getpid() % 2000
+    world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_gb_int_worker, args=(r, world, port, q)) for r in range(world)]
@@ -239,7 +248,7 @@ def test_q1_groups_world_2_gloo(ora):
     tiny tables, identical fold on every rank; equals the single-process result."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_group_pipeline import check_groups
-    world, port = 2, 33500 + os.getpid() % 2000
+    world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_q1_worker, args=(r, world, port, q)) for r in range(world)]
