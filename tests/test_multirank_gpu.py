@@ -24,6 +24,10 @@ def _run(workload, gpus, rows, port, launcher="torchrun", flags=(), **extra_env)
     base = [os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--cpu-sample", "0",
             "--workload", workload] + (["--rows", str(rows)] if rows else []) + list(flags)
     if gpus > 1 and launcher == "torchrun":
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:   # a port nobody listens on (the number passed in is only a label)
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port)] + base + ["--backend", "gloo", "--share-gpu"]
     elif gpus > 1:
