@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <elf.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <hip/hip_runtime.h>
 #include <spawn.h>
 #include <sys/stat.h>
@@ -243,8 +244,27 @@ bool compile(const Paths& ps, const std::string& arch_opt, const std::string& ty
         const int rc = posix_spawn(&pid, ps.hipcc.c_str(), &fa, nullptr, argv.data(), environ);
         posix_spawn_file_actions_destroy(&fa);
         if (rc != 0) { why = "cannot start " + ps.hipcc; break; }
+        // the caller's thread waits for the compiler, but not for ever: RDF_JIT_TIMEOUT seconds (default 120), then the child is killed
         int status = 0;
-        while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+        {
+            const char* te = getenv("RDF_JIT_TIMEOUT");
+            const long limit_ms = (te && atol(te) > 0 ? atol(te) : 120) * 1000L;
+            long waited_ms = 0;
+            bool done = false;
+            while (!done) {
+                const pid_t r = waitpid(pid, &status, WNOHANG);
+                if (r == pid) done = true;
+                else if (r < 0 && errno != EINTR) { status = -1; done = true; }
+                else if (waited_ms >= limit_ms) {
+                    (void)kill(pid, SIGKILL);
+                    while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+                    why = "the compiler did not finish in time";
+                    status = -1;
+                    done = true;
+                } else { usleep(5000); waited_ms += 5; }
+            }
+        }
+        if (status == -1 && !why.empty()) break;
         if (!WIFEXITED(status) || WEXITSTATUS(status) != 0 || !read_file(obj_path, code)) {
             std::vector<char> log;
             (void)read_file(log_path, log);
