@@ -690,24 +690,57 @@ inline Text load(const std::string& path, bool has_headers = true, char delimite
     if (size > 0 && !f.read(&t.buf[0], size)) throw DataFrameError(DataFrameError::IoError, "cannot read " + path);
     const char* base = t.buf.data();
     const char* end = base + t.buf.size();
-    bool first = true;
-    for (const char* p = base; p < end;) {
+    // the header: the first line that is not empty (or, without a header row, just its number of cells)
+    const char* p = base;
+    while (p < end) {
         const char* nl = (const char*)std::memchr(p, '\n', (size_t)(end - p));
         const char* le = nl ? nl : end;
         if (le > p) {
-            if (first) {
-                first = false;
-                size_t ncols = 1;
-                { bool q = false; for (const char* c = p; c < le; ++c) { if (*c == '"') q = !q; else if (*c == delimiter && !q) ++ncols; } }
-                std::vector<Cell> cells(ncols);
-                split(p, le, delimiter, ncols, cells.data());
-                if (has_headers) { for (auto& c : cells) t.header.push_back(cell_text(c)); p = nl ? nl + 1 : end; continue; }
-                for (size_t i = 0; i < ncols; ++i) t.header.push_back("column_" + std::to_string(i + 1));   // arrow's csv reader names
-            }
-            if (max_records && t.records.size() >= *max_records) break;
-            t.records.emplace_back((size_t)(p - base), (size_t)(le - base));
+            size_t ncols = 1;
+            { bool q = false; for (const char* c = p; c < le; ++c) { if (*c == '"') q = !q; else if (*c == delimiter && !q) ++ncols; } }
+            std::vector<Cell> cells(ncols);
+            split(p, le, delimiter, ncols, cells.data());
+            if (has_headers) { for (auto& c : cells) t.header.push_back(cell_text(c)); p = nl ? nl + 1 : end; }
+            else for (size_t i = 0; i < ncols; ++i) t.header.push_back("column_" + std::to_string(i + 1));   // arrow's csv reader names
+            break;
         }
         p = nl ? nl + 1 : end;
+    }
+    // the records: [begin, end) of every line that is not empty.  A long file is cut into byte ranges, one thread each; a thread
+    // takes the lines that START in its range (it finds its first line start behind the first '\n' at or after the range's
+    // begin - 1) and follows its last line past the range's end.
+    const char* body = p;
+    auto scan = [&](const char* from, const char* upto, std::vector<std::pair<size_t, size_t>>& out, size_t stop_after) {
+        const char* q = from;
+        while (q < upto && out.size() < stop_after) {
+            const char* nl = (const char*)std::memchr(q, '\n', (size_t)(end - q));
+            const char* le = nl ? nl : end;
+            if (le > q) out.emplace_back((size_t)(q - base), (size_t)(le - base));
+            q = nl ? nl + 1 : end;
+        }
+    };
+    const size_t limit = max_records ? *max_records : (size_t)-1;
+    const size_t bytes = (size_t)(end - body);
+    const int T = (int)std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, bytes / ((size_t)4 << 20) + 1});
+    if (T <= 1 || max_records) scan(body, end, t.records, limit);
+    else {
+        std::vector<std::vector<std::pair<size_t, size_t>>> part((size_t)T);
+        std::vector<std::thread> pool;
+        for (int w = 0; w < T; ++w)
+            pool.emplace_back([&, w]() {
+                const char* b = body + bytes * (size_t)w / (size_t)T;
+                const char* e = body + bytes * (size_t)(w + 1) / (size_t)T;
+                if (w > 0) {   // the first line start at or behind b: one past the first '\n' at or behind b - 1
+                    const char* nl = (const char*)std::memchr(b - 1, '\n', (size_t)(end - (b - 1)));
+                    b = nl ? nl + 1 : end;
+                }
+                scan(b, e, part[(size_t)w], (size_t)-1);
+            });
+        for (auto& th : pool) th.join();
+        size_t total = 0;
+        for (auto& v : part) total += v.size();
+        t.records.reserve(total);
+        for (auto& v : part) t.records.insert(t.records.end(), v.begin(), v.end());
     }
     return t;
 }

@@ -277,10 +277,10 @@ TEST(csv_cells_types_and_values) {
 }
 
 TEST(csv_worker_threads_agree_with_one_thread) {
-    // 100 003 records (several ranges of records, the last one ragged): integers, doubles printed with 17 significant digits
+    // 300 007 records (several ranges of records, the last one ragged): integers, doubles printed with 17 significant digits
     // (they must come back bit for bit), a NULL every 7th / 11th row, a type that only the LAST range breaks
     std::string text = "k,x,late\n";
-    const size_t n = 100003;
+    const size_t n = 300007;     // ~11 MB of text: csv::load indexes the records with several threads too
     std::vector<double> xs(n);
     uint64_t st = 88172645463325252ull;
     for (size_t r = 0; r < n; ++r) {
