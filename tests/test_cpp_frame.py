@@ -37,6 +37,18 @@ def test_plan_builders_cpp():
     run(build("test_plan", False))
 
 
+def test_jit_signatures_cpp():
+    """rdf_jit.cpp's host logic (signature -> template argument, refusals, code-object symbol lookup) — built with hipcc because the
+    file includes the HIP runtime's headers; nothing in it touches a device."""
+    out = os.path.join(tempfile.gettempdir(), f"rdf_test_jit_sig_{os.getpid()}")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    subprocess.check_call([hipcc, "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "rust_dataframe_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "test_jit_sig.cpp"), "-o", out, "-ldl"])
+    run(out)
+
+
 @pytest.mark.gpu
 def test_frame_mirror_cpp():
     run(build("test_frame", True), os.path.join(ROOT, "tests", "golden", "uk_cities_with_headers.csv"),
