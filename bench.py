@@ -153,8 +153,11 @@ def workload_c3(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, 
     fma = e.op("add", e.op("multiply", e.col(0), e.col(1)), e.col(2))
     roots = [fma, e.col(3)]
 
+    native = opts.get("native")
+
     def step():
-        y, kk = sharding.all_combine(api.pipeline(e, cols, roots), device=comm_dev)
+        local = api.pipeline(e, cols, roots)
+        y, kk = native.agg_combine(local) if native is not None else sharding.all_combine(local, device=comm_dev)
         return {"min_y": y.min, "max_y": y.max, "count_y": y.count, "min_k": kk.min, "max_k": kk.max, "count_k": kk.count}
 
     def check(res, world):
@@ -192,13 +195,21 @@ def workload_c4(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, 
         bufs = [torch.empty(cap * 8 + 64, dtype=torch.uint8, device=dev) for _ in range(3)]
         return tuple(A.DeviceArray(b.data_ptr(), None, 0, cap, dt, 0, keep=b) for b, dt in zip(bufs, (A.I64, A.F64, A.I64)))
     outs = outs3()
-    ex = sharding.GroupExchange(api, lib, torch, dev, comm_dev, cap) if exchange_on else None
+    native = opts.get("native")           # the library's own communicator (RCCL behind the C ABI); None: the torch.distributed harness
+    ex = sharding.GroupExchange(api, lib, torch, dev, comm_dev, cap) if (exchange_on and native is None) else None
     last = {}
 
     # with about as many groups as rows pre-aggregation cannot shrink the shard: the rows are shuffled instead
     shuffle = exchange_on and (os.environ.get("RDF_C4_SHUFFLE_ROWS") == "1" or sharding.shuffle_rows_pays(rows, ngroups))
 
+    merged = outs3() if native is not None else None
+
     def step():
+        if native is not None and exchange_on:
+            # rdf_groupby_agg_dist: local aggregate -> pack -> ncclSend / ncclRecv -> merge, all inside the library
+            mk_, ms_, mc_ = native.groupby_agg([K], [V], "sum", ngroups, merged, "rows" if os.environ.get("RDF_C4_SHUFFLE_ROWS") == "1" else "auto")
+            last["groups"] = (mk_, ms_, mc_)
+            return {"groups_owned": mk_.length, **native.stats}
         if shuffle:
             ok_, mk2, mc2 = ex.shuffle_rows_and_aggregate(K, V, ngroups)
             last["groups"] = (ok_[0], mk2, mc2)
@@ -224,7 +235,8 @@ def workload_c4(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, 
         # invariants of the full-size result: no key twice, every count positive, counts add up to the rows and the
         # group sums to the column sum (all ranks' shares together when N > 1)
         e = A.Expr()
-        col_sum = sharding.all_combine(api.pipeline(e, [[V]], [e.col(0)]), device=comm_dev)[0].sum
+        lsum = api.pipeline(e, [[V]], [e.col(0)])
+        col_sum = (native.agg_combine(lsum) if native is not None else sharding.all_combine(lsum, device=comm_dev))[0].sum
         tot = [float(hs.sum()), int(hc.sum()), int(n)]
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
@@ -284,8 +296,11 @@ def workload_q1(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, 
     cols = [[A.DeviceArray(t.data_ptr(), None, 0, rows, dt, 0, keep=t)] for t, dt in zip(ts, dts)]
     q, vals, gid, pred = q1_program(A)
 
+    native = opts.get("native")
+
     def step():
-        res, nrows = sharding.all_combine_groups(api.group_pipeline(q, cols, vals, gid, 6, pred), device=comm_dev)
+        local = api.group_pipeline(q, cols, vals, gid, 6, pred)
+        res, nrows = native.group_combine(local) if native is not None else sharding.all_combine_groups(local, device=comm_dev)
         return {"count_star": nrows[:6], "sum_qty": [r[0] for r in res[0][:6]], "sum_disc": [r[0] for r in res[4][:6]],
                 "sum_price": [r[0] for r in res[1][:6]], "sum_disc_price": [r[0] for r in res[2][:6]], "sum_charge": [r[0] for r in res[3][:6]]}
 
@@ -396,6 +411,10 @@ def main():
     ap.add_argument("--null-fraction", type=float, default=0.0, help="attach a validity bitmap with this null rate")
     ap.add_argument("--chunk-rows", type=int, default=0, help="hand the column over as RecordBatches of this many rows (0 = one chunk; 1024 = the reference readers' batch)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for a smoke test)")
+    ap.add_argument("--comm", default="native", choices=["native", "torch"],
+                    help="who runs the N > 1 collectives with --backend nccl: native = the library's own communicator (rdf_comm_*: RCCL loaded "
+                         "behind the C ABI, ncclAllGather + grouped ncclSend / ncclRecv; torch.distributed only launches the ranks, hands the "
+                         "unique id around and times the run), the default; torch = the torch.distributed harness of rust_dataframe_amd/sharding.py")
     ap.add_argument("--share-gpu", action="store_true", help="smoke test only: every rank uses device 0 (needs --backend gloo)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: still create the process group (a 1-rank RCCL communicator with --backend nccl) and run every "
@@ -436,17 +455,48 @@ def main():
                 os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
+        want_native = args.backend == "nccl" and args.comm == "native"
+        if want_native:
+            # CPU tensors (the unique id, barriers, the max-over-ranks clock) travel over gloo; torch's own RCCL communicator is
+            # created only if the library's cannot be (CUDA tensors of the fallback harness)
+            dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        elif args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     lib.set_device(local_rank)
     api = lib.api()
     dev = torch.device("cuda", local_rank)
-    comm_dev = dev if (dist is None or args.backend == "nccl") else None   # gloo exchanges CPU tensors
+    native, native_note = None, None
+    if dist is not None and args.backend == "nccl" and args.comm == "native":
+        idt = torch.zeros(A.COMM_ID_BYTES + 1, dtype=torch.uint8)
+        if rank == 0:
+            try:
+                idt[:A.COMM_ID_BYTES] = torch.frombuffer(bytearray(A.Comm.unique_id(api)), dtype=torch.uint8)
+                idt[A.COMM_ID_BYTES] = 1
+            except Exception as ex_:          # no librccl for the library to load
+                native_note = f"rdf_comm_unique_id: {ex_}"
+        dist.broadcast(idt, 0)
+        if int(idt[A.COMM_ID_BYTES]) == 1:
+            try:
+                native = A.Comm.init_rank(api, world, rank, bytes(idt[:A.COMM_ID_BYTES].tolist()))
+            except Exception as ex_:
+                native_note = f"rdf_comm_init_rank: {ex_}"
+        flag = torch.tensor([1 if native is not None else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:                # every rank or none
+            if native is not None:
+                native.destroy()
+            native, native_note = None, (native_note or "another rank could not create its communicator")
+            print(f"bench.py: the library's communicator is not available ({native_note}); using torch.distributed", file=sys.stderr)
+    args.native = native
+    comm_dev = None if native is not None else (dev if (dist is None or args.backend == "nccl") else None)   # gloo / the control plane exchange CPU tensors
+    ninfo = native.info() if native is not None else None
     comm = {"ranks": dist.get_world_size() if dist is not None else 1,
             "backend": (args.backend if dist is not None else None),
-            "rccl_version": _rccl_version(torch) if (dist is not None and args.backend == "nccl") else None,
+            "collectives": (None if dist is None else "librdf_mi355x (rdf_comm_*: RCCL behind the C ABI)" if native is not None
+                            else "torch.distributed (sharding.py)" + (f"; native unavailable: {native_note}" if native_note else "")),
+            "rccl_version": (ninfo["rccl_version"] if ninfo else _rccl_version(torch) if (dist is not None and args.backend == "nccl") else None),
             "launcher": "self (torch.distributed.run)" if os.environ.get("RDF_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else None)}
 
     # weak scaling: every rank owns --rows rows; strong scaling (--total-rows): contiguous ranges of whole 1024-row batches
@@ -486,7 +536,8 @@ def main():
     def step():
         local = api.pipeline(e, frame, [c], pred)          # fused filter -> {sum,min,max,count}, one pass over HBM
         tc = time.perf_counter()
-        tot = sharding.all_combine(local, device=comm_dev)[0]      # N > 1: all_gather the partials (RCCL), fold in rank order
+        # N > 1: all-gather the partials (RCCL), fold in rank order — rdf_agg_combine inside the library, or the torch harness
+        tot = (native.agg_combine(local) if native is not None else sharding.all_combine(local, device=comm_dev))[0]
         combine_s[0] += time.perf_counter() - tc
         return tot.sum, tot.count
 
@@ -494,11 +545,11 @@ def main():
         torch.cuda.synchronize()
         lib.synchronize()
 
+    barrier = _barrier(torch, dist, native)
     for _ in range(args.warmup):
         step()
     sync()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     sync()
     lib.kernel_timing_reset(True)
     combine_s[0] = 0.0          # (the warm-up steps carry the communicator's lazy initialisation)
@@ -506,8 +557,7 @@ def main():
     for _ in range(args.steps):
         res = step()
     sync()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     sync()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = lib.kernel_timing_get()
@@ -573,14 +623,29 @@ def main():
             cb.pop("_sum"), cb.pop("_count")
             out["cpu_baseline"] = cb
         emit(out)
+    if native is not None:
+        native.destroy()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _barrier(torch, dist, native):
+    """All ranks meet.  With the library's communicator the process group is a control plane (gloo for CPU tensors): a tiny
+    all_reduce of a CPU tensor, so that torch never creates an RCCL communicator of its own next to the library's."""
+    if dist is None:
+        return lambda: None
+    if native is not None:
+        z = torch.zeros(1, dtype=torch.int32)
+        return lambda: dist.all_reduce(z)
+    return dist.barrier
 
 
 def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, world):
     """Same timing contract as the headline, for the other BASELINE.json configurations."""
     rows, total = args.rows, args.total
-    opts = {"force_exchange": args.force_exchange}
+    native = args.native
+    opts = {"force_exchange": args.force_exchange, "native": native}
+    barrier = _barrier(torch, dist, native)
     step, alg_bytes, desc, check = WORKLOADS[args.workload](torch, lib, api, A, sharding, dev, comm_dev, rank, rows, args.first_row, total, opts)
 
     def sync():
@@ -590,16 +655,14 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
     for _ in range(args.warmup):
         step()
     sync()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     sync()
     lib.kernel_timing_reset(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     sync()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     sync()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = lib.kernel_timing_get()
@@ -610,6 +673,8 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     chk = check(res, world)     # untimed; collective when N > 1 (every rank takes part)
+    if native is not None:
+        native.destroy()
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -17,6 +17,7 @@
 // runs of Calculate / Filter / aggregate steps into single passes over HBM (rdf_pipeline).
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cstdint>
 #include <cerrno>
 #include <chrono>
@@ -2082,6 +2083,7 @@ class GpuFrame {
     }
 
   private:
+    friend class ShardedFrame;
     struct Handle { rdf_frame* h; std::shared_ptr<DataFrame> pinned; ~Handle() { if (h) (void)rdf_frame_release(h); } };
     Schema schema_;
     std::shared_ptr<Handle> h_;
@@ -2092,6 +2094,98 @@ class GpuFrame {
         return g;
     }
     Schema nullable_schema() const { Schema s = schema_; for (auto& f : s.fields) f.nullable = true; return s; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// ShardedFrame: one rank's shard of a DataFrame whose RecordBatches are spread over the GPUs of a node by row ranges
+//  — the N-GPU form of what LazyFrame::evaluate (src/lazyframe.rs:311-315) drives.  Every reference kernel is
+// per-chunk independent, so filter / take-within-shard / elementwise steps are the GpuFrame's own (no communication: the
+// outputs stay sharded in rank order); AggregateFunctions fold the ranks' partials (rdf_agg_combine) and GroupAggregate — the
+// panic! at src/evaluation.rs:73 — runs the library's exchange (rdf_groupby_agg_frame_dist: local aggregate, partial groups or
+// rows to their owners over RCCL / peer copies, merge).  One ShardedFrame per rank, used by the thread that drives its GPU.
+class Communicator {
+  public:
+    // one process (or thread) per GPU: rank 0 makes the id (unique_id()) and hands it to the others
+    static std::array<uint8_t, RDF_COMM_ID_BYTES> unique_id() { std::array<uint8_t, RDF_COMM_ID_BYTES> id{}; check(rdf_comm_unique_id(id.data())); return id; }
+    static std::shared_ptr<Communicator> init_rank(int world, int rank, const std::array<uint8_t, RDF_COMM_ID_BYTES>& id) {
+        rdf_comm* c = nullptr;
+        check(rdf_comm_init_rank(world, rank, id.data(), &c));
+        return std::shared_ptr<Communicator>(new Communicator(c));
+    }
+    // a single process driving every GPU: communicator i belongs to the thread that called rdf_set_device(devices[i])
+    static std::vector<std::shared_ptr<Communicator>> init_all(const std::vector<int32_t>& devices, rdf_comm_kind kind = RDF_COMM_RCCL) {
+        std::vector<rdf_comm*> raw(devices.size(), nullptr);
+        check(rdf_comm_init_all((int32_t)devices.size(), devices.data(), kind, raw.data()));
+        std::vector<std::shared_ptr<Communicator>> out;
+        for (rdf_comm* c : raw) out.push_back(std::shared_ptr<Communicator>(new Communicator(c)));
+        return out;
+    }
+    ~Communicator() { if (c_) (void)rdf_comm_destroy(c_); }
+    Communicator(const Communicator&) = delete;
+    Communicator& operator=(const Communicator&) = delete;
+    int world() const { int32_t w = 1; check(rdf_comm_info(c_, &w, nullptr, nullptr, nullptr, nullptr)); return w; }
+    int rank() const { int32_t r = 0; check(rdf_comm_info(c_, nullptr, &r, nullptr, nullptr, nullptr)); return r; }
+    void barrier() const { check(rdf_comm_barrier(c_)); }
+    rdf_comm* raw() const { return c_; }
+
+  private:
+    explicit Communicator(rdf_comm* c) : c_(c) {}
+    rdf_comm* c_;
+};
+
+class ShardedFrame {
+  public:
+    ShardedFrame(GpuFrame local, std::shared_ptr<Communicator> comm) : local_(std::move(local)), comm_(std::move(comm)) {}
+    const GpuFrame& local() const { return local_; }
+    const Communicator& comm() const { return *comm_; }
+    // shard-local operators: row order across ranks = rank order
+    ShardedFrame filter(const FilterRef& condition) const { return ShardedFrame(local_.filter(condition), comm_); }
+    // rows of the whole frame
+    int64_t num_rows() const {
+        int64_t mine = local_.num_rows(), total = 0;
+        std::vector<int64_t> all((size_t)comm_->world());
+        check(rdf_comm_allgather(comm_->raw(), &mine, 8, all.data()));
+        for (int64_t x : all) total += x;
+        return total;
+    }
+    // AggregateFunctions::{sum, min, max, count} of a column over ALL shards: identical bits on every rank
+    rdf_agg_result aggregate(const std::string& column) const {
+        rdf_agg_result r = local_.aggregate(column);
+        check(rdf_agg_combine(comm_->raw(), &r, 1));
+        return r;
+    }
+    // GroupAggregate(groups = [one Int64 / UInt64 column], [one aggregation]) over all shards -> the groups THIS rank owns
+    // (the union over the ranks is the result; owner = hash(key) % world); columns: key, "<fn>(<value>)", "count"
+    GpuFrame group_aggregate(const std::string& group, const std::string& value, plan::AggregateFunction fn, int64_t max_groups,
+                             rdf_exchange_mode exchange = RDF_EXCHANGE_AUTO, rdf_exchange_stats* stats = nullptr) const {
+        using AF = plan::AggregateFunction;
+        const Schema& sc = local_.schema();
+        const auto kf = sc.column_with_name(group);
+        if (!kf) throw DataFrameError(DataFrameError::ComputeError, "Grouping column " + group + " does not exist");
+        if (fn == AF::Avg) throw DataFrameError(DataFrameError::ComputeError, "avg = sum / count on the caller's side");
+        int32_t vcol = -1;
+        DataType vdt = DataType::Int64;
+        if (fn != AF::Count) {
+            const auto f = sc.column_with_name(value);
+            if (!f) throw DataFrameError(DataFrameError::ComputeError, "Aggregating column " + value + " does not exist");
+            vcol = (int32_t)f->first; vdt = f->second.data_type;
+        }
+        const int32_t agg = fn == AF::Sum ? RDF_AGG_SUM : fn == AF::Min ? RDF_AGG_MIN : fn == AF::Max ? RDF_AGG_MAX : RDF_AGG_COUNT;
+        const bool fl = vdt == DataType::Float32 || vdt == DataType::Float64;
+        const DataType odt = fn == AF::Count ? DataType::Int64 : fl ? DataType::Float64 : (agg != RDF_AGG_SUM && vdt == DataType::UInt64) ? DataType::UInt64 : DataType::Int64;
+        const char* names[] = {"sum", "min", "max", "count"};
+        Schema s;
+        s.fields.push_back(kf->second);
+        s.fields.push_back(Field{std::string(names[agg]) + "(" + (fn == AF::Count ? std::string("*") : value) + ")", odt, true});
+        s.fields.push_back(Field{"count", DataType::Int64, false});
+        rdf_frame* out = nullptr;
+        check(rdf_groupby_agg_frame_dist(comm_->raw(), local_.h_->h, (int32_t)kf->first, vcol, agg, max_groups, exchange, &out, stats));
+        return local_.derived(out, s);
+    }
+
+  private:
+    GpuFrame local_;
+    std::shared_ptr<Communicator> comm_;
 };
 
 // ------------------------------------------------------------------------------------------------

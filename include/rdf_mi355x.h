@@ -494,6 +494,82 @@ rdf_status rdf_group_pipeline_frame(const rdf_expr_node* nodes, int32_t nnodes, 
                                     int64_t* group_rows);
 rdf_status rdf_predicate_frame(const rdf_expr_node* nodes, int32_t nnodes, int32_t root, rdf_frame* frame, rdf_out* mask);
 
+/* ------------------------------------------------------------------ multi-GPU: the exchange behind the boundary
+ *
+ * Where the reference panics (Transformation::GroupAggregate, src/evaluation.rs:73) and everywhere its batch loop is
+ * per-chunk independent (src/evaluation.rs:66-96, src/functions/aggregate.rs:88-90), RecordBatches shard over the GPUs of a
+ * node by contiguous row ranges.  A communicator is ONE RANK's end of the group: rank r runs on one GPU and is
+ * driven by one host thread (one process per GPU, or one thread per GPU inside a single process — the shape a single-process
+ * library like the reference needs).  Two transports, same entry points:
+ *   RDF_COMM_RCCL  librccl.so (loaded on first use, never linked): ncclAllGather for the split sizes and the partial
+ *                  aggregates, grouped ncclSend / ncclRecv over xGMI for the all-to-all(v) of partial groups / rows, on the
+ *                  communicator's own stream, ordered against the thread's compute stream by events;
+ *   RDF_COMM_PEER  single process only, no RCCL: every rank pulls its share out of the other ranks' send buffers with
+ *                  hipMemcpyPeerAsync (xGMI DMA between the devices of one process).  `devices` may name one GPU several
+ *                  times (ranks sharing a GPU: how the N > 1 logic is tested on a one-GPU box).
+ * Every rank must make the same sequence of collective calls (rdf_comm_barrier / _allgather, rdf_agg_combine,
+ * rdf_group_combine, rdf_groupby_agg_dist, rdf_groupby_agg_frame_dist) with matching arguments; an error one rank meets
+ * before its exchange is carried to every rank by the exchange itself (all of them return an error, nobody waits for a
+ * peer that left).  A communicator belongs to the device it was created for and is used by one thread at a time. */
+typedef struct rdf_comm rdf_comm;
+#define RDF_COMM_ID_BYTES 128
+#define RDF_COMM_MAX_RANKS 64
+typedef enum { RDF_COMM_RCCL = 0, RDF_COMM_PEER = 1 } rdf_comm_kind;
+
+/* ncclGetUniqueId: rank 0 makes one and hands it to every rank through whatever channel the host has (a file, a socket,
+ * MPI, torch's store); every rank then calls rdf_comm_init_rank on the device it selected with rdf_set_device. */
+rdf_status rdf_comm_unique_id(uint8_t id[RDF_COMM_ID_BYTES]);
+rdf_status rdf_comm_init_rank(int32_t world, int32_t rank, const uint8_t id[RDF_COMM_ID_BYTES], rdf_comm** out);
+/* Single process: all `ndev` communicators at once (ncclCommInitAll / the peer-copy transport); out[i] is then used by the
+ * thread that called rdf_set_device(devices[i]). */
+rdf_status rdf_comm_init_all(int32_t ndev, const int32_t* devices, int32_t kind, rdf_comm** out);
+rdf_status rdf_comm_destroy(rdf_comm* comm);
+/* world size, rank, device, transport, RCCL's version code (0 for RDF_COMM_PEER); any pointer may be NULL */
+rdf_status rdf_comm_info(rdf_comm* comm, int32_t* world, int32_t* rank, int32_t* device, int32_t* kind, int32_t* rccl_version);
+rdf_status rdf_comm_barrier(rdf_comm* comm);
+/* `bytes` of host memory from every rank, in rank order, into all_host (world * bytes); bytes <= 1 MiB. */
+rdf_status rdf_comm_allgather(rdf_comm* comm, const void* mine_host, int64_t bytes, void* all_host);
+
+/* AggregateFunctions over row-sharded batches: every rank passes the rdf_agg_result of its shard (rdf_pipeline's SINK_AGG
+ * output) and gets the aggregates of the whole column back — the partials are all-gathered (world x 72 bytes per value) and
+ * folded in rank order on every rank, exactly AggregateFunctions' own left fold over chunks (src/functions/aggregate.rs:82-93)
+ * with ranks in place of chunks: identical bits on every rank; integer sums wrap to the value's width; NaN never displaces a
+ * number in min / max. */
+rdf_status rdf_agg_combine(rdf_comm* comm, rdf_agg_result* aggs, int32_t nvalues);
+/* The same for rdf_group_pipeline's output (small dense group domain, TPC-H Q1): out[nvalues * (ngroups + 1)] and
+ * group_rows[ngroups + 1] (may be NULL) are replaced by the totals over all ranks. */
+rdf_status rdf_group_combine(rdf_comm* comm, rdf_group_result* out, int64_t* group_rows, int32_t ngroups, int32_t nvalues);
+
+typedef enum { RDF_EXCHANGE_AUTO = 0, RDF_EXCHANGE_GROUPS = 1, RDF_EXCHANGE_ROWS = 2 } rdf_exchange_mode;
+/* what the last exchange of a rank moved (bench lines, tests) */
+typedef struct {
+    int32_t exchange;            /* RDF_EXCHANGE_GROUPS or RDF_EXCHANGE_ROWS: what travelled */
+    int32_t rounds;              /* grouped send / recv rounds (every rank runs the same number) */
+    int64_t local_groups;        /* partial groups of this rank before the exchange (rows, for RDF_EXCHANGE_ROWS) */
+    int64_t rows_sent, rows_sent_remote, rows_received;   /* records to all owners / to other ranks / from all ranks */
+    int64_t bytes_sent, bytes_sent_remote, bytes_received;
+    double  exchange_ms;         /* device time from the start of the pack to the end of the unpack (hipEvents) */
+} rdf_exchange_stats;
+
+/* Transformation::GroupAggregate over row-sharded batches (replaces the panic! at src/evaluation.rs:73 for N GPUs; SURVEY.md
+ * 8e): this rank's shard is aggregated locally (rdf_groupby_agg), its partial groups are bucketed by owner on the device
+ * (owner = ((key * 0x9E3779B97F4A7C15) >> 33) % world, rdf_group_exchange_pack's rule), the (key, partial, count) triples
+ * travel to their owners, and every rank merges what it receives (rdf_groupby_merge: sums added, minima / maxima compared,
+ * counts added).  The outputs hold the groups THIS RANK OWNS — the union over the ranks is the result, no key twice.
+ * RDF_EXCHANGE_ROWS shuffles the shard's rows instead (16 bytes each) and aggregates them once, at their owner: what pays
+ * when pre-aggregation cannot shrink a shard (RDF_EXCHANGE_AUTO: when 2 * max_groups * world >= the rows of all ranks,
+ * decided from an all-gather of the shard sizes so that every rank takes the same path; needs one chunk per column, no NULLs).
+ * ONE grouping column of Int64 / UInt64 without NULLs (cast narrower keys first), device-resident inputs and outputs
+ * (RDF_MEM_DEVICE); values / agg / max_groups / output types and capacities as rdf_groupby_agg (max_groups bounds the groups
+ * of the whole result; capacity >= min(max_groups, rows of all ranks) + 2 is always enough).  stats may be NULL. */
+rdf_status rdf_groupby_agg_dist(rdf_comm* comm, const rdf_array* keys, const rdf_array* values, int64_t nchunks, int32_t agg,
+                                int64_t max_groups, int32_t exchange, rdf_out* out_keys, rdf_out* out_values, rdf_out* out_counts,
+                                rdf_exchange_stats* stats);
+/* The same over a pinned frame: grouping column key_col, ONE aggregation of column value_col -> a one-batch frame of the
+ * groups this rank owns: (key, aggregate, count) as rdf_groupby_agg_frame's. */
+rdf_status rdf_groupby_agg_frame_dist(rdf_comm* comm, rdf_frame* frame, int32_t key_col, int32_t value_col, int32_t agg,
+                                      int64_t max_groups, int32_t exchange, rdf_frame** out, rdf_exchange_stats* stats);
+
 /* ------------------------------------------------------------------ synthetic data (bench/tests) */
 
 /* x[row] = lo + (hi-lo) * u(seed, column_id, first_row + row), u in [0,1) from a counter-based
@@ -521,7 +597,9 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * partitions, default; 0 = the first-generation combining path instead; 2 = always),
  * "filter_tile" (0: compaction tile from the mean chunk length; 1024 / 4096 force one), "filter_one" (one-chunk
  * compaction kernel with kernel-argument descriptors, default on), "take_rows" (rdf_take_frame / rdf_sort_frame: 1 = gather
- * interleaved row records when the index list is long and the frame wide, default; 0 = always column by column; 2 = always records). */
+ * interleaved row records when the index list is long and the frame wide, default; 0 = always column by column; 2 = always records),
+ * "comm_max_bytes" (most bytes one ncclSend / peer copy of the group-by exchange moves, default 256 MiB: larger shares go in
+ * several rounds; every rank of a communicator must use the same value). */
 rdf_status rdf_set_option(const char* name, int64_t value);
 /* Number of program shapes with a specialised kernel. */
 int32_t    rdf_spec_catalog_size(void);

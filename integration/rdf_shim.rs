@@ -58,6 +58,12 @@ pub mod sys {
     #[repr(C)] #[derive(Clone, Copy)] pub struct rdf_sort_options { pub descending: i32, pub nulls_first: i32 }
     #[repr(C)] #[derive(Clone, Copy)] pub struct rdf_list_array { pub offsets: rdf_array, pub values: rdf_array }
     #[repr(C)] pub struct rdf_frame { _opaque: [u8; 0] }
+    #[repr(C)] pub struct rdf_comm { _opaque: [u8; 0] }
+    #[repr(C)] #[derive(Clone, Copy, Default)]
+    pub struct rdf_exchange_stats { pub exchange: i32, pub rounds: i32, pub local_groups: i64, pub rows_sent: i64, pub rows_sent_remote: i64,
+                                    pub rows_received: i64, pub bytes_sent: i64, pub bytes_sent_remote: i64, pub bytes_received: i64, pub exchange_ms: f64 }
+    pub const RDF_COMM_RCCL: i32 = 0; pub const RDF_COMM_PEER: i32 = 1;
+    pub const RDF_EXCHANGE_AUTO: i32 = 0; pub const RDF_EXCHANGE_GROUPS: i32 = 1; pub const RDF_EXCHANGE_ROWS: i32 = 2;
 
     #[link(name = "rdf_mi355x")]
     extern "C" {
@@ -112,6 +118,22 @@ pub mod sys {
         pub fn rdf_row_exchange_pack(keys: *const rdf_array, values: *const rdf_array, world: i32, packed_dev: *mut c_void,
                                      owner_counts: *mut i64) -> i32;
         pub fn rdf_row_exchange_unpack(packed_dev: *const c_void, n: i64, keys: *mut rdf_out, values: *mut rdf_out) -> i32;
+        // several GPUs: the communicator and every collective of the path live behind the boundary —
+        // the library loads RCCL itself; Evaluate::evaluate's GroupAggregate arm (src/evaluation.rs:73) calls rdf_groupby_agg_dist
+        pub fn rdf_comm_unique_id(id: *mut u8) -> i32;                                   // 128 bytes (ncclUniqueId)
+        pub fn rdf_comm_init_rank(world: i32, rank: i32, id: *const u8, out: *mut *mut rdf_comm) -> i32;
+        pub fn rdf_comm_init_all(ndev: i32, devices: *const i32, kind: i32, out: *mut *mut rdf_comm) -> i32;
+        pub fn rdf_comm_destroy(comm: *mut rdf_comm) -> i32;
+        pub fn rdf_comm_info(comm: *mut rdf_comm, world: *mut i32, rank: *mut i32, device: *mut i32, kind: *mut i32, rccl_version: *mut i32) -> i32;
+        pub fn rdf_comm_barrier(comm: *mut rdf_comm) -> i32;
+        pub fn rdf_comm_allgather(comm: *mut rdf_comm, mine_host: *const c_void, bytes: i64, all_host: *mut c_void) -> i32;
+        pub fn rdf_agg_combine(comm: *mut rdf_comm, aggs: *mut rdf_agg_result, nvalues: i32) -> i32;
+        pub fn rdf_group_combine(comm: *mut rdf_comm, out: *mut rdf_group_result, group_rows: *mut i64, ngroups: i32, nvalues: i32) -> i32;
+        pub fn rdf_groupby_agg_dist(comm: *mut rdf_comm, keys: *const rdf_array, values: *const rdf_array, nchunks: i64, agg: i32,
+                                    max_groups: i64, exchange: i32, out_keys: *mut rdf_out, out_values: *mut rdf_out,
+                                    out_counts: *mut rdf_out, stats: *mut rdf_exchange_stats) -> i32;
+        pub fn rdf_groupby_agg_frame_dist(comm: *mut rdf_comm, frame: *mut rdf_frame, key_col: i32, value_col: i32, agg: i32,
+                                          max_groups: i64, exchange: i32, out: *mut *mut rdf_frame, stats: *mut rdf_exchange_stats) -> i32;
         pub fn rdf_group_pipeline(nodes: *const rdf_expr_node, nnodes: i32, filter_root: i32, group_root: i32, ngroups: i32,
                                   value_roots: *const i32, nvalues: i32, cols: *const rdf_array, ncols: i32, nchunks: i64,
                                   out: *mut rdf_group_result, group_rows: *mut i64) -> i32;
@@ -295,6 +317,34 @@ pub fn take_chunks<T: ArrowNumericType>(chunks: &[&PrimitiveArray<T>], indices: 
     status(unsafe { rdf_take(c.as_ptr(), c.len() as i64, &i, &mut out) })?;
     Ok(buf.finish(&out))
 }
+
+/// One rank's shard of a DataFrame sharded over the GPUs of a node by row ranges: what Evaluate::evaluate's
+/// GroupAggregate arm (src/evaluation.rs:73, a panic in the reference) and AggregateFunctions run on when N > 1.
+pub struct ShardedFrame { pub local: GpuFrame, comm: *mut rdf_comm }
+impl ShardedFrame {
+    /// `id`: rdf_comm_unique_id of rank 0, handed over by the host (file, socket, ...); the calling thread drives `local`'s device.
+    pub fn new(local: GpuFrame, world: i32, rank: i32, id: &[u8; 128]) -> Result<ShardedFrame, ArrowError> {
+        let mut comm: *mut rdf_comm = std::ptr::null_mut();
+        status(unsafe { rdf_comm_init_rank(world, rank, id.as_ptr(), &mut comm) })?;
+        Ok(ShardedFrame { local, comm })
+    }
+    /// GroupAggregate(group column, [agg(value column)]) over all shards -> the groups THIS rank owns (key, aggregate, count).
+    pub fn group_aggregate(&self, key_col: i32, value_col: i32, agg: i32, max_groups: i64) -> Result<(GpuFrame, rdf_exchange_stats), ArrowError> {
+        let (mut out, mut st) = (std::ptr::null_mut(), rdf_exchange_stats::default());
+        status(unsafe { rdf_groupby_agg_frame_dist(self.comm, self.local.handle, key_col, value_col, agg, max_groups, RDF_EXCHANGE_AUTO, &mut out, &mut st) })?;
+        Ok((GpuFrame { handle: out }, st))
+    }
+    /// AggregateFunctions::{sum, min, max, count} of a fused program over the whole sharded column: partials of the shard in,
+    /// totals out, identical on every rank (rank-order fold).
+    pub fn aggregate(&self, prog: &rdf_program, nvalues: usize) -> Result<Vec<rdf_agg_result>, ArrowError> {
+        let mut aggs = vec![rdf_agg_result::default(); 4];
+        status(unsafe { rdf_pipeline_frame(prog, self.local.handle, std::ptr::null_mut(), aggs.as_mut_ptr()) })?;
+        status(unsafe { rdf_agg_combine(self.comm, aggs.as_mut_ptr(), nvalues as i32) })?;
+        aggs.truncate(nvalues);
+        Ok(aggs)
+    }
+}
+impl Drop for ShardedFrame { fn drop(&mut self) { unsafe { rdf_comm_destroy(self.comm); } } }
 
 /// A DataFrame resident in HBM: the handle is pinned once and every operator returns a new handle (released in Drop).
 pub struct GpuFrame { handle: *mut rdf_frame }

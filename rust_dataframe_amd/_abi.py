@@ -98,6 +98,17 @@ class rdf_list_array(C.Structure):
     _fields_ = [("offsets", rdf_array), ("values", rdf_array)]
 
 
+class rdf_exchange_stats(C.Structure):
+    _fields_ = [("exchange", C.c_int32), ("rounds", C.c_int32), ("local_groups", C.c_int64), ("rows_sent", C.c_int64),
+                ("rows_sent_remote", C.c_int64), ("rows_received", C.c_int64), ("bytes_sent", C.c_int64),
+                ("bytes_sent_remote", C.c_int64), ("bytes_received", C.c_int64), ("exchange_ms", C.c_double)]
+
+
+COMM_ID_BYTES = 128
+COMM_RCCL, COMM_PEER = 0, 1
+EXCHANGE_AUTO, EXCHANGE_GROUPS, EXCHANGE_ROWS = 0, 1, 2
+
+
 class RdfError(Exception):
     """A non-OK rdf_status: DataFrameError / ArrowError as values (src/error.rs:6-15)."""
 
@@ -991,3 +1002,155 @@ class Api:
                 fix = (lambda x: x + 2 ** 64 if x < 0 else x) if r.dtype == U64 else (lambda x: x)
                 res.append(AggResult(fix(r.sum_i64), fix(r.min_i64), fix(r.max_i64), r.count, bool(r.is_some), r.dtype))
         return res
+
+
+# ---------------------------------------------------------------- multi-GPU: one rank's end of a communicator
+class Comm:
+    """rdf_comm: the exchange of the N > 1 path behind the C ABI (RCCL loaded by the library itself, or peer copies between
+    the threads of one process).  One Comm per rank, used by the thread that drives the rank's device."""
+
+    EXCHANGES = {"auto": EXCHANGE_AUTO, "groups": EXCHANGE_GROUPS, "rows": EXCHANGE_ROWS}
+
+    def __init__(self, api: "Api", handle):
+        self.api, self.handle = api, handle
+        self.stats = {}
+
+    # -- construction
+    @staticmethod
+    def unique_id(api: "Api") -> bytes:
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        fn = api._fn("comm_unique_id")
+        fn.restype = C.c_int
+        api._check(fn(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def init_rank(api: "Api", world: int, rank: int, uid: bytes) -> "Comm":
+        assert len(uid) == COMM_ID_BYTES
+        h = C.c_void_p(0)
+        fn = api._fn("comm_init_rank")
+        fn.restype = C.c_int
+        api._check(fn(C.c_int32(world), C.c_int32(rank), (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid), C.byref(h)))
+        return Comm(api, h)
+
+    @staticmethod
+    def init_all(api: "Api", devices: Sequence[int], kind: int = COMM_RCCL) -> List["Comm"]:
+        n = len(devices)
+        hs = (C.c_void_p * n)()
+        fn = api._fn("comm_init_all")
+        fn.restype = C.c_int
+        api._check(fn(C.c_int32(n), (C.c_int32 * n)(*devices), C.c_int32(kind), hs))
+        return [Comm(api, C.c_void_p(hs[i])) for i in range(n)]
+
+    def destroy(self):
+        if self.handle is not None:
+            fn = self.api._fn("comm_destroy")
+            fn.restype = C.c_int
+            fn(self.handle)
+            self.handle = None
+
+    def info(self) -> dict:
+        v = [C.c_int32(0) for _ in range(5)]
+        fn = self.api._fn("comm_info")
+        fn.restype = C.c_int
+        self.api._check(fn(self.handle, *[C.byref(x) for x in v]))
+        ver = v[4].value
+        return {"world": v[0].value, "rank": v[1].value, "device": v[2].value, "kind": "rccl" if v[3].value == COMM_RCCL else "peer",
+                "rccl_version": (f"{ver // 10000}.{ver // 100 % 100}.{ver % 100}" if ver else None)}
+
+    # -- collectives
+    def barrier(self):
+        fn = self.api._fn("comm_barrier")
+        fn.restype = C.c_int
+        self.api._check(fn(self.handle))
+
+    def allgather(self, mine: bytes) -> List[bytes]:
+        world = self.info()["world"]
+        out = (C.c_uint8 * (len(mine) * world))()
+        fn = self.api._fn("comm_allgather")
+        fn.restype = C.c_int
+        self.api._check(fn(self.handle, (C.c_uint8 * len(mine)).from_buffer_copy(mine), C.c_int64(len(mine)), out))
+        raw = bytes(out)
+        return [raw[r * len(mine):(r + 1) * len(mine)] for r in range(world)]
+
+    def agg_combine(self, local: Sequence[AggResult]) -> List[AggResult]:
+        """Per-rank partial aggregates (Api.pipeline's results) -> the aggregates over all ranks, folded in rank order."""
+        n = len(local)
+        arr = (rdf_agg_result * n)()
+        for i, p in enumerate(local):
+            r = arr[i]
+            r.dtype, r.count, r.is_some = p.dtype, p.count, int(p.is_some)
+            if p.dtype in (F32, F64):
+                r.sum_f64, r.min_f64, r.max_f64 = p.sum, p.min, p.max
+            else:
+                wrap = lambda x: x - (1 << 64) if x >= (1 << 63) else x
+                r.sum_i64, r.min_i64, r.max_i64 = wrap(int(p.sum)), wrap(int(p.min)), wrap(int(p.max))
+        fn = self.api._fn("agg_combine")
+        fn.restype = C.c_int
+        self.api._check(fn(self.handle, arr, C.c_int32(n)))
+        out = []
+        for i in range(n):
+            r = arr[i]
+            if r.dtype in (F32, F64):
+                out.append(AggResult(r.sum_f64, r.min_f64, r.max_f64, r.count, bool(r.is_some), r.dtype))
+            else:
+                fix = (lambda x: x + 2 ** 64 if x < 0 else x) if r.dtype == U64 else (lambda x: x)
+                out.append(AggResult(fix(r.sum_i64), fix(r.min_i64), fix(r.max_i64), r.count, bool(r.is_some), r.dtype))
+        return out
+
+    def group_combine(self, local):
+        """(res, rows) of Api.group_pipeline on this rank -> the same over all ranks."""
+        res, rows = local
+        nv, S = len(res), len(rows)
+        isf = [isinstance(res[v][0][0], float) for v in range(nv)]
+        out = (rdf_group_result * (nv * S))()
+        for v in range(nv):
+            for g in range(S):
+                s_, c_ = res[v][g]
+                r = out[v * S + g]
+                r.dtype = F64 if isf[v] else I64
+                r.count, r.is_some = c_, int(c_ > 0)
+                if isf[v]:
+                    r.sum_f64 = s_
+                else:
+                    r.sum_i64 = s_
+        crow = (C.c_int64 * S)(*rows)
+        fn = self.api._fn("group_combine")
+        fn.restype = C.c_int
+        self.api._check(fn(self.handle, out, crow, C.c_int32(S - 1), C.c_int32(nv)))
+        return ([[((out[v * S + g].sum_f64 if isf[v] else out[v * S + g].sum_i64), out[v * S + g].count) for g in range(S)] for v in range(nv)],
+                [crow[g] for g in range(S)])
+
+    def _stats(self, st):
+        self.stats = {"exchange": {EXCHANGE_GROUPS: "partial groups", EXCHANGE_ROWS: "rows"}.get(st.exchange, "none"), "rounds": st.rounds,
+                      "local_groups": st.local_groups, "exchange_ms": st.exchange_ms, "exchange_bytes_sent": st.bytes_sent,
+                      "exchange_bytes_sent_remote": st.bytes_sent_remote, "exchange_bytes_received": st.bytes_received}
+
+    def groupby_agg(self, keys: Sequence, values: Optional[Sequence], agg, max_groups: int, outs, exchange="auto"):
+        """GROUP BY over this rank's shard (device arrays) + the exchange + the merge: -> (keys, values, counts) of the groups
+        this rank owns, in the caller's device outputs `outs`."""
+        code = self.api.AGGS[agg] if isinstance(agg, str) else int(agg)
+        n = len(keys)
+        ok, ov, oc = outs
+        carr = [(rdf_out * 1)(o.out_struct()) for o in (ok, ov, oc)]
+        st = rdf_exchange_stats()
+        fn = self.api._fn("groupby_agg_dist")
+        fn.restype = C.c_int
+        cv = _flat([values], n) if values is not None else None
+        self.api._check(fn(self.handle, _flat([keys], n), cv, C.c_int64(n), C.c_int32(code), C.c_int64(max_groups),
+                           C.c_int32(self.EXCHANGES[exchange] if isinstance(exchange, str) else int(exchange)), carr[0], carr[1], carr[2], C.byref(st)))
+        for o, c_ in zip((ok, ov, oc), carr):
+            o.length, o.null_count = c_[0].length, c_[0].null_count
+        self._stats(st)
+        return ok, ov, oc
+
+    def groupby_agg_frame(self, frame, key_col: int, value_col: int, agg, max_groups: int, exchange="auto") -> "Frame":
+        code = self.api.AGGS[agg] if isinstance(agg, str) else int(agg)
+        st = rdf_exchange_stats()
+        h = C.c_void_p(0)
+        fn = self.api._fn("groupby_agg_frame_dist")
+        fn.restype = C.c_int
+        self.api._check(fn(self.handle, frame.handle, C.c_int32(key_col), C.c_int32(value_col), C.c_int32(code), C.c_int64(max_groups),
+                           C.c_int32(self.EXCHANGES[exchange] if isinstance(exchange, str) else int(exchange)), C.byref(h), C.byref(st)))
+        self._stats(st)
+        return Frame(self.api, h)

@@ -542,6 +542,7 @@ hipError_t launch_gb2_emit(const GroupEmitArgs& a, hipStream_t s);
 hipError_t launch_gb2_finish(const Gb2FinishArgs& a, hipStream_t s);
 hipError_t launch_gb2_fill(uint64_t* p, int64_t n, uint64_t v, hipStream_t s);
 hipError_t launch_gx_pack(const GxPackArgs& a, hipStream_t s);
+hipError_t launch_gx_scan(const unsigned long long* counts, unsigned long long* cursors, int world, hipStream_t s);
 hipError_t launch_gx_unpack(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts, int words, hipStream_t s);
 hipError_t launch_key_pack(const KeyPackArgs& a, hipStream_t s);
 hipError_t launch_key_unpack(const KeyPackArgs& a, hipStream_t s);

@@ -963,6 +963,15 @@ __global__ __launch_bounds__(kBlock) void gx_pack_kernel(const GxPackArgs a) {
         if (a.words == 3) a.packed[3 * pos + 2] = (uint64_t)a.counts[i];
     }
 }
+// exclusive scan of the per-owner counts into the pack's write cursors — on the device, so that the scatter phase can be queued
+// behind the count phase without the host looking at the counts first (rdf_groupby_agg_dist: the counts travel to the peers
+// meanwhile).  counts[world] is left intact: it is this rank's row of the all-gathered split-size matrix.
+__global__ void gx_scan_kernel(const unsigned long long* counts, unsigned long long* cursors, int world) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int r = 0; r < world; ++r) { cursors[r] = run; run += counts[r]; }
+    }
+}
 __global__ __launch_bounds__(kBlock) void gx_unpack_kernel(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts, int words) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         keys[i] = packed[words * i]; acc[i] = packed[words * i + 1];
@@ -1110,6 +1119,10 @@ hipError_t launch_gx_pack(const GxPackArgs& a, hipStream_t s) {
         if (grid > 1024) grid = 1024;
         hipLaunchKernelGGL(gx_pack_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, a);
     }
+    return hipGetLastError();
+}
+hipError_t launch_gx_scan(const unsigned long long* counts, unsigned long long* cursors, int world, hipStream_t s) {
+    hipLaunchKernelGGL(gx_scan_kernel, dim3(1), dim3(64), 0, s, counts, cursors, world);
     return hipGetLastError();
 }
 hipError_t launch_gx_unpack(const uint64_t* packed, int64_t n, uint64_t* keys, uint64_t* acc, int64_t* counts, int words, hipStream_t s) {

@@ -315,7 +315,12 @@ class GroupExchange:
         cd = self.comm_dev if self.comm_dev is not None else "cpu"
         m = sum(recv_counts)
         chunk = max(1, self.MAX_BYTES_PER_CALL // (8 * width) // world)          # rows per (round, destination)
-        rounds = max(1, max((c + chunk - 1) // chunk for c in list(send_counts) + list(recv_counts)))
+        # The number of rounds must be the SAME on every rank: the largest pair count s_ij is known to ranks i and j only, so a
+        # rank deriving it from its own counts could take the one-call path while its peers loop (a hang, or truncated buffers).
+        # One MAX all_reduce of the local maximum settles it (the native path reads it off the all-gathered matrix instead).
+        t_big = torch.tensor([max(list(send_counts) + list(recv_counts) + [0])], dtype=torch.int64, device=cd)
+        dist.all_reduce(t_big, op=dist.ReduceOp.MAX)
+        rounds = max(1, (int(t_big.item()) + chunk - 1) // chunk)
         if rounds == 1:
             if self.comm_dev is None:
                 send = send.cpu()
@@ -350,8 +355,10 @@ class GroupExchange:
         world = dist.get_world_size()
         import time
         n = gk.length
-        if n > self.cap:
-            raise ValueError(f"GroupExchange: {n} partial groups exceed the capacity {self.cap} this exchange was sized for")
+        if 3 * n + 8 > self.packed.numel():
+            # more partial groups than the exchange was sized for: grow the send buffer.  (Raising here, on ONE rank and before
+            # the collectives, would leave the other ranks waiting in all_to_all_single for ever.)
+            self.packed = torch.empty(3 * (n + n // 4) + 8, dtype=torch.int64, device=self.dev)
         t0 = time.perf_counter()
         K = DeviceArray(gk.values_ptr, None, 0, n, gk.dtype, 0)
         S = DeviceArray(gs.values_ptr, None, 0, n, gs.dtype, 0)

@@ -3,6 +3,7 @@
 // (librdf_oracle.so) is linked here as the checker only.
 #include <map>
 #include <random>
+#include <thread>
 #include <tuple>
 #include <cstdio>
 #include <cstdlib>
@@ -840,6 +841,71 @@ TEST(test_gpu_frame_operators_match_the_dataframe_paths) {
     for (auto& kv : exp) { CHECK_EQ(gk[row], kv.first); CHECK_NEAR(gs[row], kv.second.first, 1e-9); CHECK_EQ(gc[row], kv.second.second); ++row; }
     CHECK_THROWS(g.filter(BooleanFilter::gt(BooleanFilter::column("nope"), BooleanFilter::scalar(Scalar(0.0)))));
 }
+
+// ShardedFrame: a DataFrame's RecordBatches sharded over ranks by row ranges — what stands where the reference
+// panics for GroupAggregate (src/evaluation.rs:73) when N > 1.  One thread per rank; the test box has one GPU, so the ranks share
+// device 0 over the peer-copy transport (RDF_COMM_PEER), and a 1-rank RCCL communicator runs the same calls through librccl.
+static void sharded_frame_case(rdf_comm_kind kind, int world) {
+    std::mt19937_64 rng(99);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    const size_t total = 50000;
+    std::vector<int64_t> k(total);
+    std::vector<double> v(total);
+    std::map<int64_t, std::pair<double, int64_t>> exp;
+    double vsum = 0.0;
+    for (size_t i = 0; i < total; ++i) { k[i] = (int64_t)(rng() % 1500) * 7919 - 3000000; v[i] = U(rng); auto& e = exp[k[i]]; e.first += v[i]; ++e.second; vsum += v[i]; }
+    std::vector<int32_t> devices((size_t)world, 0);
+    auto comms = Communicator::init_all(devices, kind);
+    std::vector<std::map<int64_t, std::pair<double, int64_t>>> owned((size_t)world);
+    std::vector<std::string> errors((size_t)world);
+    std::vector<rdf_agg_result> totals((size_t)world);
+    std::vector<int64_t> rows((size_t)world, 0), big((size_t)world, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r)
+        th.emplace_back([&, r] {
+            try {
+                check(rdf_set_device(0));
+                // contiguous row ranges of whole 1024-row batches, ragged on purpose
+                const size_t lo = total * (size_t)r / (size_t)world / 1024 * 1024, hi = r + 1 == world ? total : total * (size_t)(r + 1) / (size_t)world / 1024 * 1024;
+                std::vector<ArrayRef> kc, vc;
+                for (size_t a = lo; a < hi; a += 1024) {
+                    const size_t b = std::min(hi, a + 1024);
+                    kc.push_back(Array::from_vec(std::vector<int64_t>(k.begin() + (long)a, k.begin() + (long)b)));
+                    vc.push_back(Array::from_vec(std::vector<double>(v.begin() + (long)a, v.begin() + (long)b)));
+                }
+                DataFrame df = DataFrame::from_columns({Column::from_arrays(kc, Field{"k", DataType::Int64, false}), Column::from_arrays(vc, Field{"v", DataType::Float64, false})});
+                ShardedFrame sf(GpuFrame::pin(df), comms[(size_t)r]);
+                rows[(size_t)r] = sf.num_rows();
+                totals[(size_t)r] = sf.aggregate("v");
+                rdf_exchange_stats st;
+                DataFrame g = sf.group_aggregate("k", "v", P::AggregateFunction::Sum, 2000, RDF_EXCHANGE_AUTO, &st).to_dataframe();
+                auto gk = host<int64_t>(g.column(0).data().chunk(0)); auto gs = host<double>(g.column(1).data().chunk(0)); auto gc = host<int64_t>(g.column(2).data().chunk(0));
+                for (size_t i = 0; i < gk.size(); ++i) owned[(size_t)r][gk[i]] = {gs[i], gc[i]};
+                if (st.exchange != RDF_EXCHANGE_GROUPS) errors[(size_t)r] = "expected the partial-group exchange";
+                // shard-local filter, then the aggregates of what is left over all ranks
+                ShardedFrame f2 = sf.filter(BooleanFilter::gt(BooleanFilter::column("v"), BooleanFilter::scalar(Scalar(0.5))));
+                big[(size_t)r] = f2.aggregate("v").count;
+                sf.comm().barrier();
+            } catch (const std::exception& e) { errors[(size_t)r] = e.what(); }
+        });
+    for (auto& t : th) t.join();
+    for (int r = 0; r < world; ++r) { if (!errors[(size_t)r].empty()) std::printf("rank %d: %s\n", r, errors[(size_t)r].c_str()); CHECK(errors[(size_t)r].empty()); }
+    std::map<int64_t, std::pair<double, int64_t>> got;
+    for (auto& m : owned) for (auto& kv : m) { CHECK(got.find(kv.first) == got.end()); got[kv.first] = kv.second; }
+    CHECK_EQ(got.size(), exp.size());
+    for (auto& kv : exp) { CHECK(got.count(kv.first) == 1); CHECK_EQ(got[kv.first].second, kv.second.second); CHECK_NEAR(got[kv.first].first, kv.second.first, 1e-9); }
+    int64_t above = 0;
+    for (double x : v) above += x > 0.5;
+    for (int r = 0; r < world; ++r) {
+        CHECK_EQ(rows[(size_t)r], (int64_t)total);
+        CHECK_EQ(totals[(size_t)r].count, (int64_t)total);
+        CHECK_NEAR(totals[(size_t)r].sum_f64, vsum, 1e-9);
+        CHECK_EQ(totals[(size_t)r].sum_f64, totals[0].sum_f64);     // rank-order fold: the same bits everywhere
+        CHECK_EQ(big[(size_t)r], above);
+    }
+}
+TEST(test_sharded_frame_four_ranks_peer_transport) { sharded_frame_case(RDF_COMM_PEER, 4); }
+TEST(test_sharded_frame_one_rank_rccl) { sharded_frame_case(RDF_COMM_RCCL, 1); }
 
 // DataFrame::from_arrow (src/dataframe.rs:391-407) on the committed pyarrow-written fixture: schema, chunking (one chunk
 // per record batch), every value and validity bit, then the device path over the loaded columns.

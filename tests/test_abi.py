@@ -62,6 +62,7 @@ int main(void) {
   S(rdf_expr_node); O(rdf_expr_node, column); O(rdf_expr_node, f64); O(rdf_expr_node, i64);
   S(rdf_program); O(rdf_program, nnodes); O(rdf_program, filter_root); O(rdf_program, value_roots); O(rdf_program, sink);
   S(rdf_agg_result); O(rdf_agg_result, sum_i64); O(rdf_agg_result, count); O(rdf_agg_result, is_some); O(rdf_agg_result, dtype);
+  S(rdf_exchange_stats); O(rdf_exchange_stats, rounds); O(rdf_exchange_stats, local_groups); O(rdf_exchange_stats, bytes_sent); O(rdf_exchange_stats, exchange_ms);
   printf("enum %d %d %d %d %d\n", RDF_OP_TANH, RDF_OP_CAST, RDF_OP_OR, RDF_BOOL, RDF_DEVICE_ERROR);
   return 0; }
 '''
@@ -72,7 +73,7 @@ int main(void) {
         subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), src, "-o", exe])  # header is plain C
         out = dict(line.rsplit(" ", 1) for line in subprocess.check_output([exe], text=True).splitlines() if not line.startswith("enum"))
         enums = subprocess.check_output([exe], text=True).splitlines()[-1]
-    for cls in (A.rdf_array, A.rdf_out, A.rdf_expr_node, A.rdf_program, A.rdf_agg_result):
+    for cls in (A.rdf_array, A.rdf_out, A.rdf_expr_node, A.rdf_program, A.rdf_agg_result, A.rdf_exchange_stats):
         assert int(out[cls.__name__]) == C.sizeof(cls), cls.__name__
         for key, val in out.items():
             if key.startswith(cls.__name__ + "."):
@@ -100,10 +101,10 @@ def test_argument_validation_needs_no_device():
     assert api.unary("sin", [A.HostArray.from_numpy(np.zeros(0))])[0].length == 0
 
 
-def _build_c_example(d):
-    exe = os.path.join(d, "example")
+def _build_c_example(d, name="example"):
+    exe = os.path.join(d, name)
     libdir = os.path.dirname(lib.LIB_PATH)
-    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "integration", "example.c"),
+    subprocess.check_call(["gcc", "-std=c11", "-pthread", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "integration", name + ".c"),
                            "-L", libdir, "-lrdf_mi355x", "-Wl,-rpath," + libdir, "-o", exe])
     return exe
 
@@ -122,6 +123,46 @@ def test_c_example_runs_on_the_gpu():
     with tempfile.TemporaryDirectory() as d:
         p = subprocess.run([_build_c_example(d)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "sum = 3.25 over 4 rows" in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.skipif(lib.device_count() > 0, reason="a GPU is visible")
+def test_c_dist_example_links_without_a_gpu():
+    """integration/example_dist.c (the N-GPU GROUP BY from plain C) builds against the header and the library
+    alone — RCCL is not on its link line — and says so when there is no device."""
+    with tempfile.TemporaryDirectory() as d:
+        p = subprocess.run([_build_c_example(d, "example_dist")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "no gfx950 device" in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,expect", [(["peer", "4"], "ok: 1000 groups over 4 rank(s)"), (["rccl"], "ok: 1000 groups over 1 rank(s)")])
+def test_c_dist_example_runs_on_the_gpu(args, expect):
+    """the same program on the GPU box: four ranks sharing the one device over the peer-copy transport, and one rank on a
+    real RCCL communicator (ncclCommInitAll through the library)."""
+    with tempfile.TemporaryDirectory() as d:
+        p = subprocess.run([_build_c_example(d, "example_dist")] + args, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, RDF_COMM_TIMEOUT_S="60"))
+    assert p.returncode == 0 and expect in p.stdout, p.stdout + p.stderr
+
+
+def test_comm_entry_points_validate_before_the_device():
+    """rdf_comm_* argument checks are values, not crashes: NULL communicators, bad rank counts, unknown transports."""
+    so = lib.load()
+    api = lib.api()
+    so.rdf_comm_barrier.restype = C.c_int
+    assert so.rdf_comm_barrier(None) == A.RDF_INVALID_ARGUMENT and b"null communicator" in so.rdf_last_error()
+    assert so.rdf_comm_destroy(None) == A.RDF_OK
+    h = C.c_void_p(0)
+    uid = (C.c_uint8 * A.COMM_ID_BYTES)()
+    assert so.rdf_comm_init_rank(C.c_int32(0), C.c_int32(0), uid, C.byref(h)) == A.RDF_INVALID_ARGUMENT
+    assert so.rdf_comm_init_rank(C.c_int32(2), C.c_int32(2), uid, C.byref(h)) == A.RDF_INVALID_ARGUMENT
+    hs = (C.c_void_p * 2)()
+    assert so.rdf_comm_init_all(C.c_int32(2), (C.c_int32 * 2)(0, 0), C.c_int32(7), hs) == A.RDF_INVALID_ARGUMENT
+    assert so.rdf_comm_init_all(C.c_int32(0), (C.c_int32 * 2)(0, 0), C.c_int32(A.COMM_PEER), hs) == A.RDF_INVALID_ARGUMENT
+    if lib.device_count() == 0:
+        with pytest.raises(A.RdfError) as ei:
+            A.Comm.init_all(api, [0, 0], A.COMM_PEER)
+        assert ei.value.status == A.RDF_DEVICE_ERROR
 
 
 def test_frame_entry_points_validate_before_the_device():

@@ -1,0 +1,411 @@
+"""The multi-GPU exchange behind the C ABI (rdf_comm_*, rdf_agg_combine, rdf_group_combine, rdf_groupby_agg_dist,
+rdf_groupby_agg_frame_dist) on the MI355X.
+
+Where the reference panics (Transformation::GroupAggregate, src/evaluation.rs:73) this library shards RecordBatches over
+ranks.  The GPU box has ONE device, so the N > 1 logic — uneven splits between real peers, rounds agreed from
+the all-gathered split-size matrix, empty shards, errors carried across ranks — runs here on the in-process transport
+(RDF_COMM_PEER): N host threads, N communicators, every rank with its own stream, buffers and shard on device 0, the ranks
+pulling their shares out of each other's send buffers with device copies.  The RCCL transport runs on a 1-rank communicator
+(RCCL refuses two ranks on one GPU): ncclCommInitRank / ncclCommInitAll, ncclAllGather, grouped ncclSend / ncclRecv, the event
+ordering between the communicator's stream and the compute stream.  Every result is held to the CPU oracle's GROUP BY /
+aggregates over the unsharded data."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+os.environ.setdefault("RDF_COMM_TIMEOUT_S", "60")   # a rank that dies must fail the others, not hang the box
+
+from rust_dataframe_amd import _abi as A   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+AGGS = ["sum", "min", "max", "count"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from rust_dataframe_amd import lib
+    api = lib.api()
+    if lib.device_count() < 1:
+        pytest.fail("GPU test selected but no HIP device is visible")
+    return lib, api
+
+
+def run_ranks(world, body):
+    """body(rank) on one thread per rank (a rank is driven by one host thread); the first exception is re-raised."""
+    res, err = [None] * world, [None] * world
+
+    def run(r):
+        try:
+            res[r] = body(r)
+        except BaseException as e:   # noqa: BLE001
+            err[r] = e
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+        assert not t.is_alive(), "a rank is stuck"
+    for e in err:
+        if e is not None:
+            raise e
+    return res
+
+
+class Dev:
+    """device buffers of one rank (allocated and freed by the rank's thread)"""
+
+    def __init__(self, lib):
+        self.L = lib.load()
+        self.ptrs = []
+
+    def array(self, np_arr, dtype, valid=None, capacity=None):
+        p = C.c_void_p(0)
+        n = len(np_arr)
+        assert self.L.rdf_dev_alloc(C.byref(p), max(np_arr.nbytes, 8) + 1024) == 0
+        self.ptrs.append(p)
+        if np_arr.nbytes:
+            assert self.L.rdf_copy_h2d(p, np_arr.ctypes.data, np_arr.nbytes) == 0
+        vp = None
+        if valid is not None:
+            bits = A.pack_bits(valid)
+            q = C.c_void_p(0)
+            assert self.L.rdf_dev_alloc(C.byref(q), bits.nbytes + 1024) == 0
+            self.ptrs.append(q)
+            assert self.L.rdf_copy_h2d(q, bits.ctypes.data, bits.nbytes) == 0
+            vp = q.value
+        return A.DeviceArray(p.value, vp, 0, n, dtype, -1 if valid is not None else 0, capacity=capacity if capacity is not None else n)
+
+    def out(self, dtype, cap, with_validity=False):
+        a = self.array(np.zeros(cap + 64, dtype=A.NP_OF[dtype]), dtype, capacity=cap)
+        if with_validity:
+            q = C.c_void_p(0)
+            assert self.L.rdf_dev_alloc(C.byref(q), cap // 8 + 1024) == 0
+            self.ptrs.append(q)
+            a.validity_ptr = q.value
+        return a
+
+    def fetch(self, darr, n, dtype):
+        out = np.empty(n, dtype=A.NP_OF[dtype])
+        if n:
+            assert self.L.rdf_copy_d2h(out.ctypes.data, darr.values_ptr, out.nbytes) == 0
+        return out
+
+    def fetch_valid(self, darr, n):
+        raw = np.empty((n + 7) // 8 + 8, dtype=np.uint8)
+        assert self.L.rdf_copy_d2h(raw.ctypes.data, darr.validity_ptr, raw.nbytes) == 0
+        return A.unpack_bits(raw, 0, n)
+
+    def free(self):
+        for p in self.ptrs:
+            self.L.rdf_dev_free(p)
+        self.ptrs = []
+
+
+def owner_of(keys, world):
+    from rust_dataframe_amd import sharding
+    return sharding.group_owner(np.asarray(keys), world)
+
+
+def make_shards(rng, world, val_dtype, ngroups, null_frac, base_rows, chunks_per_rank):
+    """Ragged shards: rank r holds base_rows + 997 * r rows (rank 2 of a world >= 4 holds NONE), keys drawn so that the
+    per-pair split sizes are far from balanced (rank 0's keys mostly belong to the last rank)."""
+    pool = (rng.integers(-(1 << 40), 1 << 40, ngroups)).astype(np.int64)
+    pool_owner = owner_of(pool, world)
+    shards = []
+    for r in range(world):
+        n = 0 if (world >= 4 and r == 2) else base_rows + 997 * r
+        if r == 0 and np.any(pool_owner == world - 1):
+            fav = pool[pool_owner == world - 1]
+            k = np.where(rng.uniform(size=n) < 0.8, fav[rng.integers(0, len(fav), n)], pool[rng.integers(0, ngroups, n)])
+        else:
+            k = pool[rng.integers(0, ngroups, n)]
+        if val_dtype == A.F64:
+            v = rng.uniform(-100, 100, n)
+        else:
+            v = rng.integers(-1000, 1000, n).astype(A.NP_OF[val_dtype])
+        valid = (rng.uniform(size=n) >= null_frac) if null_frac > 0 else None
+        cuts = sorted(rng.integers(0, n + 1, chunks_per_rank - 1).tolist()) if chunks_per_rank > 1 else []
+        bounds = [0] + cuts + [n]
+        shards.append([(k[a:b], v[a:b], None if valid is None else valid[a:b]) for a, b in zip(bounds[:-1], bounds[1:])])
+    return shards
+
+
+def oracle_groups(ora, shards, val_dtype, agg, max_groups):
+    k = np.concatenate([c[0] for s in shards for c in s])
+    v = np.concatenate([c[1] for s in shards for c in s])
+    has_valid = any(c[2] is not None for s in shards for c in s)
+    valid = np.concatenate([c[2] if c[2] is not None else np.ones(len(c[0]), bool) for s in shards for c in s]) if has_valid else None
+    ok, ov, oc = ora.groupby_agg([[A.HostArray.from_numpy(k)]], None if agg == "count" else [A.HostArray.from_numpy(v, valid=valid, dtype=val_dtype)], agg, max_groups)
+    keys, vals, cnts = ok[0].to_pylist(), ov.to_pylist(), oc.to_numpy().tolist()
+    return {keys[i]: (vals[i], cnts[i]) for i in range(oc.length)}
+
+
+def check_union(per_rank, exp, world, float_vals, what):
+    got = {}
+    for r, groups in enumerate(per_rank):
+        if groups:
+            assert np.all(owner_of(np.array(list(groups.keys()), dtype=np.int64), world) == r), f"{what}: rank {r} holds a key it does not own"
+        for k, v in groups.items():
+            assert k not in got, f"{what}: key {k} on two ranks"
+            got[k] = v
+    assert got.keys() == exp.keys(), f"{what}: {len(got)} groups, expected {len(exp)}"
+    for k, (ev, ec) in exp.items():
+        gv, gc = got[k]
+        assert gc == ec, f"{what}: count of {k}: {gc} != {ec}"
+        if ev is None or gv is None:
+            assert ev is None and gv is None, f"{what}: NULL value of {k}: {gv} vs {ev}"
+        elif float_vals:
+            assert gv == ev or abs(gv - ev) <= 1e-6 * max(abs(ev), 1e-300) + 1e-9, f"{what}: value of {k}: {gv} vs {ev}"   # 1e-6 relative: north_star's f64 sum tolerance
+        else:
+            assert gv == ev, f"{what}: value of {k}: {gv} vs {ev}"
+
+
+def dist_groupby_on_peer_ranks(eng, ora, world, agg, exchange, val_dtype, null_frac, ngroups, base_rows, chunks, max_bytes, frame=False):
+    lib, api = eng
+    rng = np.random.default_rng(77 + world * 13 + len(agg) + ngroups)
+    shards = make_shards(rng, world, val_dtype, ngroups, null_frac, base_rows, chunks)
+    max_groups = ngroups + 5
+    exp = oracle_groups(ora, shards, val_dtype, agg, max_groups)
+    comms = A.Comm.init_all(api, [0] * world, A.COMM_PEER)
+    stats = [None] * world
+    odt = api._agg_out_dtype(api.AGGS[agg], None if agg == "count" else val_dtype)
+
+    def body(r):
+        lib.set_device(0)
+        lib.set_option("comm_max_bytes", max_bytes)
+        d = Dev(lib)
+        try:
+            K = [d.array(np.ascontiguousarray(c[0]), A.I64) for c in shards[r]]
+            V = [d.array(np.ascontiguousarray(c[1]), val_dtype, valid=c[2]) for c in shards[r]]
+            if frame:
+                with A.PinnedFrame(api, [K, V]) as fr:
+                    out = comms[r].groupby_agg_frame(fr, 0, 1, agg, max_groups, exchange)
+                    try:
+                        nc, nch, ng = out.info()
+                        assert (nc, nch) == (3, 1)
+                        cols = [out.column_to_host(c)[0] for c in range(3)]
+                        hk, hv, hc = cols[0].to_pylist(), cols[1].to_pylist(), cols[2].to_numpy().tolist()
+                    finally:
+                        out.release()
+            else:
+                outs = (d.out(A.I64, max_groups + 2), d.out(odt, max_groups + 2, with_validity=True), d.out(A.I64, max_groups + 2))
+                ok, ov, oc = comms[r].groupby_agg(K, None if agg == "count" else V, agg, max_groups, outs, exchange)
+                ng = ok.length
+                assert ov.length == ng and oc.length == ng
+                hk = d.fetch(ok, ng, A.I64).tolist()
+                hv = d.fetch(ov, ng, odt).tolist()
+                hc = d.fetch(oc, ng, A.I64).tolist()
+                if agg in ("min", "max") and null_frac > 0 and ng:
+                    vm = d.fetch_valid(ov, ng)
+                    hv = [x if m else None for x, m in zip(hv, vm)]
+            stats[r] = dict(comms[r].stats)
+            return {hk[i]: (hv[i], hc[i]) for i in range(ng)}
+        finally:
+            d.free()
+            lib.set_option("comm_max_bytes", 0)
+    try:
+        per_rank = run_ranks(world, body)
+    finally:
+        for c in comms:
+            c.destroy()
+    if agg == "count":   # the value column of a COUNT is unspecified on both sides: keys and counts only
+        per_rank = [{k: (0, v[1]) for k, v in g.items()} for g in per_rank]
+        exp = {k: (0, c) for k, (_, c) in exp.items()}
+    check_union(per_rank, exp, world, val_dtype == A.F64, f"world={world} agg={agg} exchange={exchange}")
+    return stats
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("agg", AGGS)
+def test_dist_groupby_partial_groups_between_peer_ranks(eng, ora, world, agg):
+    """local aggregate -> pack by owner -> exchange -> merge, ragged multi-chunk shards (one of them empty), NULL values, split
+    sizes far from balanced and a per-call byte cap small enough that the exchange takes many rounds — every rank derives the
+    same number of rounds from the all-gathered matrix (the torch harness of round 3 derived it from its own counts)."""
+    stats = dist_groupby_on_peer_ranks(eng, ora, world, agg, "groups", A.F64, 0.1, 3000, 20_000, 3, 24 * 40)
+    assert all(s["exchange"] == "partial groups" for s in stats)
+    assert len({s["rounds"] for s in stats}) == 1 and stats[0]["rounds"] > 3, stats
+    assert sum(s["exchange_bytes_sent"] for s in stats) == sum(s["exchange_bytes_received"] for s in stats)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("agg", ["sum", "min", "max"])
+def test_dist_groupby_row_shuffle_between_peer_ranks(eng, ora, world, agg):
+    """with about as many groups as rows the ROWS travel (16 bytes each) and are aggregated once, at their owner."""
+    stats = dist_groupby_on_peer_ranks(eng, ora, world, agg, "rows", A.I64, 0.0, 30_000, 9000, 1, 16 * 300)
+    assert all(s["exchange"] == "rows" for s in stats)
+    assert len({s["rounds"] for s in stats}) == 1 and stats[0]["rounds"] > 3, stats
+
+
+@pytest.mark.parametrize("ngroups,expect", [(200, "partial groups"), (40_000, "rows")])
+def test_dist_groupby_auto_takes_one_path_on_every_rank(eng, ora, ngroups, expect):
+    """RDF_EXCHANGE_AUTO is decided from the all-gathered shard sizes: ragged shards (one empty) still agree."""
+    stats = dist_groupby_on_peer_ranks(eng, ora, 4, "sum", "auto", A.F64, 0.0, ngroups, 8000, 1, 0)
+    assert all(s["exchange"] == expect for s in stats), stats
+    assert all(s["rounds"] <= 1 for s in stats)
+
+
+@pytest.mark.parametrize("exchange", ["groups", "rows"])
+def test_dist_groupby_frames_between_peer_ranks(eng, ora, exchange):
+    """rdf_groupby_agg_frame_dist: a pinned frame per rank in, a frame of the owned groups out."""
+    dist_groupby_on_peer_ranks(eng, ora, 4, "sum", exchange, A.F64, 0.0, 1500, 6000, 1, 0, frame=True)
+    dist_groupby_on_peer_ranks(eng, ora, 2, "max", "groups", A.I64, 0.2, 700, 5000, 3, 24 * 64, frame=True)
+
+
+def test_dist_groupby_error_on_one_rank_reaches_every_rank(eng):
+    """One rank's shard holds more distinct keys than max_groups: its local aggregation fails, it still takes part in the
+    all-gather of the split sizes, and every rank returns an error — nobody waits for a peer that left.  Mismatched
+    arguments (max_groups, exchange mode) and an ineligible forced row shuffle are refused on every rank as well."""
+    lib, api = eng
+    world = 3
+    comms = A.Comm.init_all(api, [0] * world, A.COMM_PEER)
+    rng = np.random.default_rng(5)
+    n = 5000
+    all_keys = [rng.integers(0, 100_000 if r == 1 else 50, n).astype(np.int64) for r in range(world)]
+
+    def body(r):
+        lib.set_device(0)
+        d = Dev(lib)
+        out = {}
+        try:
+            keys = all_keys[r]
+            K, V = d.array(keys, A.I64), d.array(np.ones(n), A.F64)
+            outs = (d.out(A.I64, 1002), d.out(A.F64, 1002), d.out(A.I64, 1002))
+            with pytest.raises(A.RdfError) as ei:
+                comms[r].groupby_agg([K], [V], "sum", 1000, outs, "groups")
+            out["overflow"] = (ei.value.status, str(ei.value))
+            with pytest.raises(A.RdfError) as ei:
+                comms[r].groupby_agg([K], [V], "sum", 1000 + r, outs, "groups")
+            out["mismatch"] = ei.value.status
+            Vn = d.array(np.ones(n), A.F64, valid=np.arange(n) % 7 != 0) if r == 2 else V
+            with pytest.raises(A.RdfError) as ei:
+                comms[r].groupby_agg([K], [Vn], "sum", 200_000, outs, "rows")
+            out["rows"] = ei.value.status
+            # and the communicator is still usable
+            ok, ov, oc = comms[r].groupby_agg([K], [V], "sum", 200_000, (d.out(A.I64, 200_002), d.out(A.F64, 200_002), d.out(A.I64, 200_002)), "groups")
+            out["groups"] = ok.length
+            out["sum"] = float(d.fetch(ov, ok.length, A.F64).sum())
+            return out
+        finally:
+            d.free()
+    try:
+        res = run_ranks(world, body)
+    finally:
+        for c in comms:
+            c.destroy()
+    assert res[1]["overflow"][0] == A.RDF_MEMORY_ERROR and "max_groups" in res[1]["overflow"][1]
+    for r in (0, 2):
+        assert res[r]["overflow"][0] == A.RDF_COMPUTE_ERROR and "rank 1 failed" in res[r]["overflow"][1], res[r]
+    assert all(x["mismatch"] == A.RDF_INVALID_ARGUMENT and x["rows"] == A.RDF_INVALID_ARGUMENT for x in res)
+    assert sum(x["sum"] for x in res) == 15000.0
+
+
+def test_agg_and_group_combine_between_peer_ranks(eng, ora):
+    """rdf_agg_combine / rdf_group_combine: every rank ends with the aggregates of the whole column, bit-identical across
+    ranks (fixed rank-order fold), integer sums wrapped to the value's width, U64 extrema compared unsigned."""
+    lib, api = eng
+    world = 4
+    rng = np.random.default_rng(11)
+    cols = {A.F64: rng.uniform(-5, 5, 40_000), A.I32: rng.integers(-2**31, 2**31 - 1, 40_000).astype(np.int32),
+            A.U64: rng.integers(0, 2**64 - 1, 40_000, dtype=np.uint64), A.I64: rng.integers(-2**62, 2**62, 40_000).astype(np.int64)}
+    cols[A.F32] = rng.uniform(-5, 5, 40_000).astype(np.float32)
+    cols[A.F32][100] = np.nan             # a NaN partial never displaces a number in min / max; the sum is NaN on both sides
+    bounds = [0, 9000, 9000, 25_000, 40_000]          # rank 1 holds nothing
+    comms = A.Comm.init_all(api, [0] * world, A.COMM_PEER)
+
+    def body(r):
+        lib.set_device(0)
+        d = Dev(lib)
+        try:
+            out = {}
+            for dt, full in cols.items():
+                part = np.ascontiguousarray(full[bounds[r]:bounds[r + 1]])
+                e = A.Expr()
+                local = api.pipeline(e, [[d.array(part, dt)]], [e.col(0)])
+                out[dt] = comms[r].agg_combine(local)[0]
+            # Q1-shaped grouped sums
+            q = A.Expr()
+            gid = np.ascontiguousarray((np.arange(bounds[r], bounds[r + 1]) % 6).astype(np.int32))
+            val = np.ascontiguousarray(cols[A.F64][bounds[r]:bounds[r + 1]].copy())
+            val[np.isnan(val)] = 0.0
+            res = api.group_pipeline(q, [[d.array(gid, A.I32)], [d.array(val, A.F64)]], [q.col(1)], q.col(0), 6)
+            out["groups"] = comms[r].group_combine(res)
+            comms[r].barrier()
+            out["gather"] = comms[r].allgather(bytes([r]) * 5)
+            return out
+        finally:
+            d.free()
+    try:
+        res = run_ranks(world, body)
+    finally:
+        for c in comms:
+            c.destroy()
+    for dt, full in cols.items():
+        e = A.Expr()
+        exp = ora.pipeline(e, [[A.HostArray.from_numpy(full)]], [e.col(0)])[0]
+        for r in range(world):
+            got = res[r][dt]
+            assert got.count == exp.count and got.dtype == dt
+            if dt == A.F32:
+                assert np.isnan(got.sum) and np.isnan(exp.sum) and got.min == exp.min and got.max == exp.max
+            elif dt == A.F64:
+                assert abs(got.sum - exp.sum) <= 1e-6 * abs(exp.sum) and got.min == exp.min and got.max == exp.max   # north_star: 1e-6 relative for f64 sums
+                assert got.sum == res[0][dt].sum, "the fold order is fixed: identical bits on every rank"
+            else:
+                assert (got.sum, got.min, got.max) == (exp.sum, exp.min, exp.max), (dt, got, exp)
+    gsum = [float(np.nansum(np.where(np.arange(40_000) % 6 == g, np.nan_to_num(cols[A.F64]), 0.0))) for g in range(6)]
+    for r in range(world):
+        rr, rows = res[r]["groups"]
+        assert rows[:6] == [int(np.sum(np.arange(40_000) % 6 == g)) for g in range(6)] and rows[6] == 0
+        for g in range(6):
+            assert abs(rr[0][g][0] - gsum[g]) <= 1e-6 * max(1.0, abs(gsum[g])) and rr[0][g][1] == rows[g]
+        assert rr == res[0]["groups"][0]
+        assert res[r]["gather"] == [bytes([q]) * 5 for q in range(world)]
+
+
+@pytest.mark.parametrize("how", ["init_rank", "init_all"])
+def test_rccl_one_rank_communicator(eng, ora, how):
+    """The RCCL transport itself, on the one GPU of the test box: librccl.so loaded by the library, ncclCommInitRank from a
+    unique id (or ncclCommInitAll), ncclAllGather of the split sizes and of the partials, grouped ncclSend / ncclRecv to self
+    in several rounds, stream ordering by events — both exchanges, results equal to the plain single-GPU call."""
+    lib, api = eng
+    lib.set_device(0)
+    if how == "init_rank":
+        uid = A.Comm.unique_id(api)
+        comm = A.Comm.init_rank(api, 1, 0, uid)
+    else:
+        comm = A.Comm.init_all(api, [0], A.COMM_RCCL)[0]
+    d = Dev(lib)
+    try:
+        info = comm.info()
+        assert info["world"] == 1 and info["rank"] == 0 and info["kind"] == "rccl" and info["rccl_version"], info
+        rng = np.random.default_rng(3)
+        n, ngroups = 300_000, 20_000
+        keys = rng.integers(0, ngroups, n).astype(np.int64) * 1_000_003
+        vals = rng.uniform(0, 1, n)
+        K, V = d.array(keys, A.I64), d.array(vals, A.F64)
+        exp = oracle_groups(ora, [[(keys, vals, None)]], A.F64, "sum", ngroups)
+        lib.set_option("comm_max_bytes", 24 * 4096)
+        for exchange in ("groups", "rows", "auto"):
+            outs = (d.out(A.I64, ngroups + 2), d.out(A.F64, ngroups + 2), d.out(A.I64, ngroups + 2))
+            ok, ov, oc = comm.groupby_agg([K], [V], "sum", ngroups, outs, exchange)
+            ng = ok.length
+            got = {k: (v, c) for k, v, c in zip(d.fetch(ok, ng, A.I64).tolist(), d.fetch(ov, ng, A.F64).tolist(), d.fetch(oc, ng, A.I64).tolist())}
+            check_union([got], exp, 1, True, f"rccl one rank {exchange}")
+            st = comm.stats
+            assert st["exchange"] == ("rows" if exchange == "rows" else "partial groups")
+            assert st["rounds"] >= (70 if exchange == "rows" else 4) and st["exchange_bytes_sent"] == st["exchange_bytes_received"] > 0 and st["exchange_bytes_sent_remote"] == 0
+            assert st["exchange_ms"] > 0
+        e = A.Expr()
+        local = api.pipeline(e, [[V]], [e.col(0)])
+        tot = comm.agg_combine(local)[0]
+        assert tot.sum == local[0].sum and tot.count == n
+        comm.barrier()
+        assert comm.allgather(b"abc") == [b"abc"]
+    finally:
+        lib.set_option("comm_max_bytes", 0)
+        d.free()
+        comm.destroy()

@@ -262,3 +262,50 @@ def test_q1_groups_world_2_gloo(ora):
     cols, (e, pred, gid, vals) = _q1_inputs()
     whole = ora.group_pipeline(e, cols, vals, gid, 6, pred)
     check_groups(results[0], whole, "2 ranks vs whole")
+
+
+def _a2a_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # pair counts far from balanced: ONE pair (0 -> 2) is just over a multiple of the per-round chunk, every other pair is
+        # below one chunk — the ranks outside that pair see only small counts
+        counts = [[3, 2, 41], [1, 0, 4], [2, 5, 3]]          # counts[src][dst]
+        ex = sharding.GroupExchange.__new__(sharding.GroupExchange)
+        ex.torch, ex.dev, ex.comm_dev = torch, "cpu", None
+        ex.MAX_BYTES_PER_CALL = 8 * 2 * world * 10            # chunk = 10 rows per (round, destination): 5 rounds for the big pair
+        send_counts = counts[rank]
+        recv_counts = [counts[s][rank] for s in range(world)]
+        rows = []
+        for dst in range(world):
+            for i in range(counts[rank][dst]):
+                rows.append([rank * 1000 + dst * 100 + i, -(rank * 1000 + dst * 100 + i)])
+        send = torch.tensor(rows, dtype=torch.int64).reshape(-1, 2)
+        got = ex._all_to_all_rows(send, send_counts, recv_counts, 2)
+        q.put((rank, sorted(got[:, 0].tolist()), bool(torch.equal(got[:, 0], -got[:, 1]))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_rounds_agree_when_pair_counts_are_unbalanced():
+    """the number of all_to_all rounds must not be derived from a rank's own split sizes.  Three gloo ranks,
+    one pair just over a multiple of the chunk: every rank runs the same five rounds and receives exactly its rows."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_a2a_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, keys, paired = q.get(timeout=120)
+        res[r] = (keys, paired)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts = [[3, 2, 41], [1, 0, 4], [2, 5, 3]]
+    for dst in range(world):
+        exp = sorted(src * 1000 + dst * 100 + i for src in range(world) for i in range(counts[src][dst]))
+        assert res[dst] == (exp, True), dst
