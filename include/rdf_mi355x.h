@@ -598,6 +598,9 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * "filter_tile" (0: compaction tile from the mean chunk length; 1024 / 4096 force one), "filter_one" (one-chunk
  * compaction kernel with kernel-argument descriptors, default on), "take_rows" (rdf_take_frame / rdf_sort_frame: 1 = gather
  * interleaved row records when the index list is long and the frame wide, default; 0 = always column by column; 2 = always records),
+ * "filter_fused" (rdf_filter_frame with a `column CMP literal [AND | OR column CMP literal]` predicate over 4- / 8-byte columns: 1 = the
+ * predicate runs inside the compaction kernel, one pass, when no batch is longer than 65 536 rows, default; 2 = always; 0 = predicate -> mask,
+ * count, compact),
  * "comm_max_bytes" (most bytes one ncclSend / peer copy of the group-by exchange moves, default 256 MiB: larger shares go in
  * several rounds; every rank of a communicator must use the same value). */
 rdf_status rdf_set_option(const char* name, int64_t value);

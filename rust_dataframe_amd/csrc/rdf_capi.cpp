@@ -54,6 +54,7 @@ struct Ctx {
     bool   opt_vec_bitmap = false; // validity words of the specialised kernels: scalar loads (default since the wave-granular tiles: 1.30 vs 1.355 ms on the 1e9-row filter->sum with nulls) or one vector load by lanes 0..NW + readlane (A/B; it was the faster one with block-wide tiles)
     bool   opt_filter_one = true;   // one-chunk compaction kernel with its descriptors in the kernel arguments (A/B)
     int    opt_filter_gen = 2;      // compaction kernels: 2 = wave-granular tiles (rdf_filter.hip, default), 1 = first-generation block tiles (A/B)
+    int    opt_filter_fused = 1;    // rdf_filter_frame: `col CMP literal [AND|OR col CMP literal]` predicates evaluated inside the compaction kernel, one pass (1, default); 0 = predicate -> mask, count, compact (A/B)
     int    opt_filter_tile = 0;     // 0: compaction tile chosen from the mean chunk length; 1024 / 4096 force one (A/B)
     int    opt_gb_debug = 0;        // ablations of the partitioned GROUP BY (tools/bench_kernels.py): 1 = aggregate without LDS work, 2 = scatter without stores
     int    opt_sort_gen = 3;        // radix passes: 3 = one read + one write of the pairs per digit, decoupled look-back between 4096-pair tiles (rdf_sort.hip, default); 2 = count -> scan -> scatter over static tile ranges with the same wave-ranked tiles (A/B: slower, see rdf_sort.hip); 1 = first generation (rdf_kernels.hip)
@@ -1044,6 +1045,8 @@ struct rdf_frame {
     DevChunkCol* d_mask_cols = nullptr;
     DevOutChunk mask_out0 = {nullptr, nullptr};
     int64_t* d_mask_pos = nullptr;           // [nchunks + 1] bit position of every batch's mask (multiples of 64)
+    int64_t mask_padded_rows = 0;            // d_mask_pos[nchunks]: rows of a buffer that holds every batch at its mask position
+    int64_t max_clen = 0;                    // longest batch
     std::vector<std::pair<void*, size_t>> pooled;   // buffers taken from the per-thread pool, returned at release
     // projections onto <= kMaxCols columns (a predicate over a wide frame reads a few of its columns): frames that share this
     // frame's buffers and own only their descriptor tables; built once per column list
@@ -3848,6 +3851,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "gb_skew_plan") == 0) g_ctx.opt_gb_skew_plan = (int)value;
     else if (strcmp(name, "gb_compact") == 0) g_ctx.opt_gb_compact = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
+    else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
     else if (strcmp(name, "comm_max_bytes") == 0) g_ctx.opt_comm_max_bytes = value;
     else return fail(RDF_INVALID_ARGUMENT, "unknown option %s", name);
     return RDF_OK;

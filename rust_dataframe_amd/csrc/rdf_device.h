@@ -193,6 +193,22 @@ struct FilterWArgs {
     DevChunkCol        cols0[kMaxFilterCols];   // nchunks == 1
     DevOutChunk        outs0[kMaxFilterCols];
 };
+// DataFrame::filter in ONE pass (rdf_filter_frame, predicates of the form `col CMP literal [AND|OR col CMP literal]`): the
+// predicate is evaluated on the tile the compaction has just brought into LDS — no mask is written, counted or read back —
+// and every batch of the output starts where the input batch's mask would (64-row rounded positions), so a tile needs no
+// prefix beyond its own batch: none at all for the readers' 1024-row batches, a decoupled look-back between the tiles of a
+// longer batch.  (rdf_filter.hip: ffilter_dma_kernel)
+struct FusedTerm { int32_t col, op, dtype, pad; double lit; };   // frame column CMP (double)literal, compared in f64 (src/expression.rs:844-845)
+struct FusedFilterArgs {
+    FilterWArgs         w;            // tile tables, column / output descriptors, null counters (mask / tile_scan unused)
+    FusedTerm           term[2];
+    int32_t             nterms, combine;     // combine: RDF_OP_AND / RDF_OP_OR of the two terms
+    int32_t             lookback, pad;       // some batch spans several tiles: tiles are taken by ticket, prefixes by look-back
+    int64_t*            out_len;             // [nchunks] kept rows per batch (pre-zeroed)
+    unsigned long long* tile_state;          // (lookback; pre-zeroed) [ntiles] tile states, status << 62 | rows; 8 spare words; [ntiles] super-tile states
+    unsigned int*       ticket;              // (lookback; pre-zeroed) 64 counters, 128 bytes apart
+};
+hipError_t launch_ffilter(const FusedFilterArgs& a, hipStream_t s);
 hipError_t launch_fcount(const FilterWArgs& a, int tile_rows, int64_t* tile_counts, hipStream_t s);
 hipError_t launch_fcompact(const FilterWArgs& a, int tile_rows, hipStream_t s);
 hipError_t launch_mask_count_one(const DevChunkCol& mask, int64_t clen, int64_t ntiles, int64_t* tile_counts, hipStream_t s);

@@ -495,6 +495,245 @@ __global__ __launch_bounds__(kBlock, 4) void fcompact_dma_kernel(const FilterWAr
         atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)lane * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[wave][lane]);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One-pass DataFrame::filter (src/dataframe.rs:178-189): BooleanFilter::eval_to_array (src/expression.rs:766-861) of a
+// `column CMP literal [AND | OR column CMP literal]` predicate evaluated on the tile the LDS-DMA compaction has just fetched,
+// then every column compacted with the ranks — 8 B read + 8 s B written per row and column, nothing else: the three-pass form
+// (predicate -> mask, count, compact) moves the predicate's columns twice and a mask three times.
+//
+// Where do a tile's kept rows go?  Batch c of the OUTPUT starts at the 64-row rounded position batch c's mask has in the
+// frame (the descriptors come from frame_tables_kernel before this kernel runs), so positions are relative to the batch:
+// a batch that is one tile (the readers' 1024-row batches, src/dataframe.rs:352) needs nothing from its neighbours; the
+// tiles of a longer batch are taken by ticket and find their offsets by decoupled look-back over the tiles of the SAME
+// batch (8-byte {status, rows} granules, agent scope: the XCDs' L2s are not coherent).  The price is an output buffer
+// as long as the input (288 GB of HBM: the kept rows alone are written).
+
+__device__ __forceinline__ bool fcmp(int op, double x, double c) {
+    switch (op) {
+        case RDF_OP_GT: return x > c;
+        case RDF_OP_GE: return x >= c;
+        case RDF_OP_EQ: return x == c;
+        case RDF_OP_NE: return x != c;
+        case RDF_OP_LT: return x < c;
+        default: return x <= c;
+    }
+}
+// keep-words of a full tile that sits in LDS (dma_tile's layout): lane i < 16 ends up holding word i
+template <typename T>
+__device__ __forceinline__ uint64_t pred_words_lds(const unsigned char* raw_bytes, int op, double lit) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const T* raw = (const T*)raw_bytes;
+    uint64_t kw = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint64_t w = __ballot(fcmp(op, (double)raw[E + i * 64 + lane], lit));
+        if (lane == i) kw = w;
+    }
+    return kw;
+}
+// the same straight from memory: chunk tails and slices the DMA cannot take
+template <typename T>
+__device__ __forceinline__ uint64_t pred_words_global(const DevChunkCol& col, int64_t rw, int64_t clen, int op, double lit) {
+    const int lane = threadIdx.x & 63;
+    const GlobalPtr<T> src = as_global<T>(col.values) + col.offset + rw + lane;
+    uint64_t kw = 0;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const bool in = rw + i * 64 + lane < clen;
+        const T x = in ? src[i * 64] : T(0);
+        const uint64_t w = __ballot(in && fcmp(op, (double)x, lit));
+        if (lane == i) kw = w;
+    }
+    return kw;
+}
+__device__ __forceinline__ uint64_t pred_words(const FusedTerm& tm, const DevChunkCol& col, int64_t rw, int64_t clen, bool in_lds, const unsigned char* raw) {
+    switch (tm.dtype) {
+        case RDF_F64: return in_lds ? pred_words_lds<double>(raw, tm.op, tm.lit) : pred_words_global<double>(col, rw, clen, tm.op, tm.lit);
+        case RDF_I64: return in_lds ? pred_words_lds<int64_t>(raw, tm.op, tm.lit) : pred_words_global<int64_t>(col, rw, clen, tm.op, tm.lit);
+        case RDF_U64: return in_lds ? pred_words_lds<uint64_t>(raw, tm.op, tm.lit) : pred_words_global<uint64_t>(col, rw, clen, tm.op, tm.lit);
+        case RDF_F32: return in_lds ? pred_words_lds<float>(raw, tm.op, tm.lit) : pred_words_global<float>(col, rw, clen, tm.op, tm.lit);
+        case RDF_I32: return in_lds ? pred_words_lds<int32_t>(raw, tm.op, tm.lit) : pred_words_global<int32_t>(col, rw, clen, tm.op, tm.lit);
+        default: return in_lds ? pred_words_lds<uint32_t>(raw, tm.op, tm.lit) : pred_words_global<uint32_t>(col, rw, clen, tm.op, tm.lit);
+    }
+}
+
+constexpr unsigned long long kFfAggregate = 1ull << 62, kFfPrefix = 2ull << 62, kFfValue = (1ull << 62) - 1;
+
+__global__ __launch_bounds__(kBlock, 4) void ffilter_dma_kernel(const FusedFilterArgs fa) {
+    const FilterWArgs& a = fa.w;
+    constexpr int WW = kWDmaTile / 64, kWaves = kBlock / 64;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[kWaves][WW * 64 * 8 + 32];
+    __shared__ uint8_t vstage[kWaves][WW * 64 + 16];
+    __shared__ uint32_t nullacc[kWaves][kMaxFilterCols];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id();
+    if (lane < kMaxFilterCols) nullacc[wave][lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    int64_t cur_chunk = -1;
+    const bool one = a.t.nchunks == 1;
+    const int pc0 = fa.term[0].col, pc1 = fa.nterms > 1 ? fa.term[1].col : fa.term[0].col;
+    struct Meta { WTile t; int64_t first; DevChunkCol p0; };
+    auto locate_all = [&](int64_t tile) -> Meta {
+        Meta mt;
+        mt.t = wlocate<WW>(a, tile);
+        mt.first = tile - mt.t.r0 / (WW * 64);            // the batch's first tile
+        mt.p0 = one ? a.cols0[pc0] : a.cols[(int64_t)pc0 * a.t.nchunks + mt.t.c];
+        return mt;
+    };
+    const int64_t tstride = (int64_t)gridDim.x * kWaves;
+    // Look-back mode hands tiles out in order — a tile's predecessors are then finished or held by a running wave, whatever
+    // part of the grid is resident.  ONE ticket counter serialises a million same-address atomics (23 ns each, measured:
+    // 23 ms per 1e9 rows); 64 counters a cache line apart, wave (block, wave) drawing tile 64 v + its counter's number, take
+    // 1/64 of that each — every counter is served by many waves, so the counters advance together.
+    constexpr int kCounters = 64;
+    const int my_counter = (int)((blockIdx.x * kWaves + wave) % kCounters);
+    auto take = [&](int64_t prev) -> int64_t {           // the next tile of this wave
+        if (!fa.lookback) return prev < 0 ? (int64_t)blockIdx.x * kWaves + wave : prev + tstride;
+        unsigned int tk = 0;
+        if (lane == 0) tk = atomicAdd(fa.ticket + my_counter * 32, 1u);
+        return (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)tk) * kCounters + my_counter;
+    };
+    int64_t tile = take(-1);
+    Meta meta;
+    if (!fa.lookback && tile < a.t.ntiles) meta = locate_all(tile);
+    while (tile < a.t.ntiles) {
+        // look-back mode: a ticket is drawn only when the wave is ready to work on it — a tile held while its wave still compacts
+        // the previous one keeps every later tile of the batch waiting for its row count
+        if (fa.lookback) meta = locate_all(tile);
+        const WTile t = meta.t;
+        const int64_t first = meta.first;
+        if (t.c != cur_chunk) {
+            if (cur_chunk >= 0 && lane < a.ncols && nullacc[wave][lane]) {
+                atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)lane * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[wave][lane]);
+                nullacc[wave][lane] = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            cur_chunk = t.c;
+        }
+        const bool full = t.r0 + WW * 64 <= t.clen;
+        auto dma_ok = [&](const DevChunkCol& c, int e) {
+            return full && (e == 8 || e == 4) && (((uintptr_t)((const char*)c.values + (c.offset + t.r0) * e)) & 15) == 0;
+        };
+        // ---- the predicate, on the tile(s) it reads
+        DevChunkCol col = meta.p0;
+        int es = a.esize[pc0];
+        bool dma = dma_ok(col, es);
+        if (dma) { if (es == 8) dma_tile<uint64_t>(col, t.r0, stage[wave]); else dma_tile<uint32_t>(col, t.r0, stage[wave]); }
+        LaneWin<WW> qv = lane_windows_issue<WW>(col.validity, col.offset + t.r0, col.validity ? t.clen - t.r0 : 0);
+        int64_t next = 0;
+        if (!fa.lookback) {
+            next = take(tile);
+            if (next < a.t.ntiles) meta = locate_all(next);           // under the loads just issued
+        }
+        if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint64_t kwv = pred_words(fa.term[0], col, t.r0, t.clen, dma, stage[wave]);
+        if (col.validity) kwv &= lane_windows_finish<WW>(qv);
+        int in_lds = dma ? pc0 : -1;
+        if (fa.nterms > 1) {
+            if (pc1 != pc0) {
+                col = one ? a.cols0[pc1] : a.cols[(int64_t)pc1 * a.t.nchunks + t.c];
+                es = a.esize[pc1];
+                dma = dma_ok(col, es);
+                if (dma) {
+                    if (es == 8) dma_tile<uint64_t>(col, t.r0, stage[wave]); else dma_tile<uint32_t>(col, t.r0, stage[wave]);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                in_lds = dma ? pc1 : -1;
+            }
+            uint64_t k1 = pred_words(fa.term[1], col, t.r0, t.clen, in_lds == pc1, stage[wave]);
+            uint64_t v0 = ~0ull, v1 = ~0ull;                          // Arrow's and / or: NULL if either side is NULL -> the row is dropped
+            if (col.validity) v1 = lane_windows<WW>(col.validity, col.offset + t.r0, t.clen - t.r0);
+            // (term 0's validity is already folded into kwv: a NULL there cleared the bit; for OR the other side must not set it again)
+            const DevChunkCol c0 = one ? a.cols0[pc0] : a.cols[(int64_t)pc0 * a.t.nchunks + t.c];
+            if (c0.validity) v0 = lane_windows<WW>(c0.validity, c0.offset + t.r0, t.clen - t.r0);
+            kwv = (fa.combine == RDF_OP_AND ? (kwv & k1) : (kwv | k1)) & v0 & v1;
+        }
+        int cnt = __popcll(kwv);
+#pragma unroll
+        for (int d = 1; d < WW; d <<= 1) cnt += __shfl_xor(cnt, d);
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
+        // ---- where the kept rows go inside the batch's output
+        int64_t wave_out = 0;
+        const bool last = t.r0 + WW * 64 >= t.clen;
+        if (fa.lookback) {
+            // Two levels, so that a tile never walks the whole window of tiles in flight (4096 waves: a flat look-back spent
+            // ~60 dependent memory round trips per tile, 23 ms per 1e9 rows of ONE batch): inside a super-tile of 64 tiles the
+            // predecessors' row counts come with ONE 64-wide read; the super-tiles' totals form a second chain, 64 times shorter,
+            // walked the same way.  A tile publishes its count before it waits for anything, a super-tile's last tile publishes
+            // the total as soon as its own local prefix is known: nobody waits for a tile that waits.
+            auto ld = [](const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            auto st = [&](unsigned long long* p, unsigned long long v) { if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            unsigned long long* super_state = fa.tile_state + a.t.ntiles + 8;
+            st(fa.tile_state + tile, kFfAggregate | (unsigned long long)cnt);
+            const int64_t j = tile - first;                 // tile of its batch
+            const int64_t sfirst = first + (j & ~63ll);     // first tile of its super-tile
+            const int nb = (int)(tile - sfirst);
+            long long local = 0;
+            if (nb > 0) {
+                for (;;) {
+                    const unsigned long long w = lane < nb ? ld(fa.tile_state + sfirst + lane) : kFfAggregate;
+                    if (__ballot((w >> 62) != 0) == ~0ull) { local = (long long)(w & kFfValue); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) local += __shfl_xor(local, d);
+            }
+            const bool closes = (j & 63) == 63 || last;    // the super-tile's last tile
+            if (closes) st(super_state + sfirst, kFfAggregate | (unsigned long long)(local + cnt));
+            long long before = 0;
+            int64_t q = (j >> 6) - 1;                       // super-tiles of this batch before mine
+            while (q >= 0) {
+                const int64_t idx = q - lane;
+                const unsigned long long w = idx >= 0 ? ld(super_state + first + idx * 64) : kFfPrefix;
+                const uint64_t ready = __ballot((w >> 62) != 0), pref = __ballot((w >> 62) == 2);
+                const int pl = pref ? __builtin_ctzll(pref) : 63;                    // the nearest super-tile that knows its prefix
+                const uint64_t need = pl == 63 ? ~0ull : ((2ull << pl) - 1);
+                if ((ready & need) != need) { __builtin_amdgcn_s_sleep(2); continue; }
+                long long v = lane <= pl ? (long long)(w & kFfValue) : 0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+                before += v;
+                if (pref) break;
+                q -= 64;
+            }
+            if (closes) st(super_state + sfirst, kFfPrefix | (unsigned long long)(before + local + cnt));
+            wave_out = before + local;
+        }
+        if (last && lane == 0) fa.out_len[t.c] = wave_out + cnt;
+        if (cnt > 0) {
+            const bool sparse = cnt * 8 < WW * 64;        // few rows kept: the other columns fetch only the sectors that hold one
+#pragma unroll 1
+            for (int kk = 0; kk < a.ncols; ++kk) {
+                // the column whose tile is already in LDS goes first
+                const int k = in_lds < 0 ? kk : (kk == 0 ? in_lds : (kk <= in_lds ? kk - 1 : kk));
+                const bool have = k == in_lds;
+                col = one ? a.cols0[k] : a.cols[(int64_t)k * a.t.nchunks + t.c];
+                es = a.esize[k];
+                dma = have || (!sparse && dma_ok(col, es));
+                if (dma && !have) { if (es == 8) dma_tile<uint64_t>(col, t.r0, stage[wave]); else dma_tile<uint32_t>(col, t.r0, stage[wave]); }
+                const DevOutChunk oc = one ? a.outs0[k] : a.outs[(int64_t)k * a.t.nchunks + t.c];
+                const bool vec_out = (((uintptr_t)oc.values) & 15) == 0;
+                uint32_t nn = 0;
+                if (dma && vec_out) {
+                    if (es == 8) dma_compact<uint64_t>(col, oc, t.r0, t.clen, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
+                    else dma_compact<uint32_t>(col, oc, t.r0, t.clen, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
+                } else {
+                    if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (es == 8) slow_compact<uint64_t>(col, oc, t.r0, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
+                    else slow_compact<uint32_t>(col, oc, t.r0, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
+                }
+                if (lane == 0 && nn) nullacc[wave][k] += nn;
+            }
+        }
+        tile = fa.lookback ? take(tile) : next;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (cur_chunk >= 0 && lane < a.ncols && nullacc[wave][lane])
+        atomicAdd((unsigned long long*)&a.out_null_counts[(int64_t)lane * a.t.nchunks + cur_chunk], (unsigned long long)nullacc[wave][lane]);
+}
+
 static int wgrid(int64_t ntiles, int per_cu) {
     const int64_t blocks = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
     const int64_t lim = (int64_t)eval_grid_limit() / 8 * per_cu;
@@ -506,6 +745,11 @@ hipError_t launch_fcount(const FilterWArgs& a, int tile_rows, int64_t* tile_coun
     if (tile_rows == kWDmaTile) hipLaunchKernelGGL(fcount_kernel<16>, dim3(grid), dim3(kBlock), 0, s, a, tile_counts);
     else if (tile_rows == kWTileSmall) hipLaunchKernelGGL(fcount_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a, tile_counts);
     else hipLaunchKernelGGL(fcount_kernel<8>, dim3(grid), dim3(kBlock), 0, s, a, tile_counts);
+    return hipGetLastError();
+}
+hipError_t launch_ffilter(const FusedFilterArgs& a, hipStream_t s) {
+    if (a.w.t.ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ffilter_dma_kernel, dim3(wgrid(a.w.t.ntiles, 4)), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_fcompact(const FilterWArgs& a, int tile_rows, hipStream_t s) {

@@ -350,3 +350,59 @@ def test_filter_frame_wider_than_a_program(gpu, ora):
             for k in range(len(dts)):
                 match_unknown_nulls(got[k], exp[k], f"wide frame column {k}")
             out.release()
+
+
+@pytest.mark.parametrize("lens,off,nf", [([1024] * 300 + [500], 0, 0.0), ([1024] * 40, 0, 0.15), ([200_000], 0, 0.1), ([70_000, 1024, 3000, 0, 50_000], 0, 0.0),
+                                         ([5000, 4000], 5, 0.1)])
+def test_filter_frame_one_pass_predicates(gpu, ora, lens, off, nf):
+    """`column CMP literal [AND | OR column CMP literal]` predicates run inside the compaction kernel (ffilter_dma_kernel: no mask
+    written, counted or read back; tiles of a batch longer than 1024 rows find their offsets by look-back).  Held to the oracle's
+    BooleanFilter::eval_to_array + Column::filter per column AND to the three-pass device path, bit for bit: comparisons in f64
+    (src/expression.rs:844-845), a NULL on either side of and / or drops the row, NaN compares false."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(404 + len(lens))
+    dts = [A.F64, A.I64, A.F32, A.U64, A.I32]
+    host = [make_chunks(rng, dt, lens, nf if k in (0, 1, 2) else 0.0, off, "special" if dt == A.F64 and sum(lens) > 5000 else "unit" if dt in (A.F64, A.F32) else "plain")
+            for k, dt in enumerate(dts)]
+    for ch in host[3]:                                   # UInt64 values beyond 2^63: compared as f64, not as i64
+        ch.values[ch.offset:ch.offset + ch.length:3] += np.uint64(2 ** 63)
+    dev, keep = to_device(host)
+    e = A.Expr()
+    preds = {
+        "literal first": e.op("lt", e.scalar(0.25), e.col(0)),
+        "i64 >= int literal": e.op("ge", e.col(1), e.scalar(17, A.I64)),
+        "i64 != float literal": e.op("ne", e.col(1), e.scalar(-3.0)),
+        "f32 <= f32 literal": e.op("le", e.col(2), e.scalar(0.1, A.F32)),
+        "u64 > 2^63": e.op("gt", e.col(3), e.scalar(float(2 ** 63))),
+        "range on one column": e.op("and", e.op("gt", e.col(0), e.scalar(-0.5)), e.op("lt", e.col(0), e.scalar(0.5))),
+        "and over two nullable columns": e.op("and", e.op("gt", e.col(0), e.scalar(0.0)), e.op("le", e.col(1), e.scalar(500, A.I32))),
+        "or over two nullable columns": e.op("or", e.op("gt", e.col(2), e.scalar(0.9)), e.op("lt", e.col(1), e.scalar(-900, A.I64))),
+        "eq keeps almost nothing": e.op("eq", e.col(4), e.scalar(7, A.I32)),
+    }
+    with A.PinnedFrame(gpu, dev) as frame:
+        for name, root in preds.items():
+            exp = ora.filter_columns(host, ora.predicate(e, root, host))
+            try:
+                for fused in (2, 1, 0):               # 2: the one-pass kernel whatever the batch lengths; 1: the default choice; 0: three passes
+                    lib.set_option("filter_fused", fused)
+                    out = gpu.filter_frame(frame, e, root)
+                    kern = lib.last_kernel()
+                    if fused != 1:
+                        assert (kern == "ffilter_dma_kernel") == bool(fused), (name, kern)
+                    elif max(lens) <= 65536:
+                        assert kern == "ffilter_dma_kernel", (name, kern)
+                    nc, nch, rows = out.info()
+                    assert (nc, nch) == (len(dts), len(lens)) and rows == sum(x.length for x in exp[0]), (name, fused)
+                    got = frame_columns(out)
+                    for k in range(len(dts)):
+                        match_unknown_nulls(got[k], exp[k], f"{name} fused={fused} lens={lens} column {k}")
+                    # the new frame is an ordinary frame: filter it again (its batches sit at the input's stride)
+                    again = gpu.filter_frame(out, e, e.op("gt", e.col(4), e.scalar(0, A.I32)))
+                    exp2 = ora.filter_columns(exp, ora.predicate(e, e.op("gt", e.col(4), e.scalar(0, A.I32)), exp))
+                    got2 = frame_columns(again)
+                    for k in range(len(dts)):
+                        match_unknown_nulls(got2[k], exp2[k], f"{name} fused={fused} twice column {k}")
+                    again.release()
+                    out.release()
+            finally:
+                lib.set_option("filter_fused", 1)

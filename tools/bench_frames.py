@@ -118,7 +118,11 @@ def main():
             def run():
                 out = api.filter_frame(fr, e, gt)
                 out.release()
-            report(f"filter_frame_{m}col", n, (8.125 + (8 + 8 * sel) * m + 0.25) * n, run, selectivity=sel)
+            # algorithmic bytes (materialising filter of M columns): 8 M read + 8 M s written per row
+            report(f"filter_frame_{m}col", n, (8 + 8 * sel) * m * n, run, selectivity=sel, path="one pass: predicate inside the compaction kernel")
+            lib.set_option("filter_fused", 0)
+            report(f"filter_frame_{m}col_three_pass", n, (8 + 8 * sel) * m * n, run, selectivity=sel, path="predicate -> mask, count, compact (round 3)")
+            lib.set_option("filter_fused", 1)
     # ---- DataFrame::take: random / sequential indices, every column in one gather pass
     nidx = n // 4
     ridx = torch.randint(0, n, (nidx,), dtype=torch.int64, device="cuda").to(torch.uint32)
