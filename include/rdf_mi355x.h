@@ -404,6 +404,16 @@ typedef struct {
  * SINK_AGG: aggs[v] receives the aggregates, outs may be NULL. */
 rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks,
                         rdf_out* outs, rdf_agg_result* aggs);
+/* Host-resident frames are STREAMED: when the RDF_MEM_HOST arrays of a SINK_AGG call hold more than one slab of bytes
+ * (rdf_set_option("stream_slab_bytes", ...), default 256 MiB) the batch list is cut into slabs of whole batches (a longer batch
+ * on 64-row boundaries), slab k + 1 crosses the link on the copy stream while the fused kernel runs over slab k, and the
+ * slabs' partial aggregates are folded in slab order — the batch loop of Evaluate::evaluate (src/evaluation.rs:66-96) over
+ * what a reader produced (DataFrame::from_csv / from_arrow, src/dataframe.rs:349-407), with two slabs of HBM in use whatever
+ * the frame's size.  Column buffers in page-locked memory (rdf_host_alloc / rdf_host_register) of at least 256 KiB leave with
+ * one asynchronous copy each; pageable memory and the readers' small batches are packed into a page-locked staging buffer by
+ * a few host threads first.  rdf_stream_stats: slabs (0 = the last rdf_pipeline call of this thread was not streamed), bytes
+ * that went through the staging buffer, bytes copied straight out of the caller's page-locked memory. */
+rdf_status rdf_stream_stats(int64_t* slabs, int64_t* bytes_staged, int64_t* bytes_direct);
 
 /* A frame handle for repeated calls over the same device-resident columns.  The reference's DataFrame holds its
  * RecordBatches for its lifetime (src/dataframe.rs:30-48) and every query walks them again; with the reader's 1024-row
@@ -601,6 +611,7 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * "filter_fused" (rdf_filter_frame with a `column CMP literal [AND | OR column CMP literal]` predicate over 4- / 8-byte columns: 1 = the
  * predicate runs inside the compaction kernel, one pass, when no batch is longer than 65 536 rows, default; 2 = always; 0 = predicate -> mask,
  * count, compact),
+ * "stream_slab_bytes" (rdf_pipeline over host memory: bytes per slab of the streamed batch loop, 0 = 256 MiB, -1 = never stream),
  * "comm_max_bytes" (most bytes one ncclSend / peer copy of the group-by exchange moves, default 256 MiB: larger shares go in
  * several rounds; every rank of a communicator must use the same value). */
 rdf_status rdf_set_option(const char* name, int64_t value);

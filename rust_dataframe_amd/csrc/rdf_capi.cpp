@@ -15,6 +15,8 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <condition_variable>
 #include <string>
 #include <thread>
 #include <vector>
@@ -75,6 +77,13 @@ struct Ctx {
     // rdf_filter_frame / rdf_take_frame / ... are GBs, and a hipMalloc + hipFree pair per call costs more than the kernels
     std::multimap<size_t, void*> pool_free;
     size_t pool_cached = 0;
+    // streamed batch loop over host-resident frames (rdf_capi_stream.inc): two slab buffers in HBM, two page-locked staging buffers
+    int64_t opt_stream_slab = 0;    // bytes per slab (0 = 256 MiB); rdf_pipeline streams host inputs above one slab; -1 = never
+    void*  sbuf_dev[2] = {nullptr, nullptr};
+    void*  sbuf_pin[2] = {nullptr, nullptr};
+    size_t sbuf_dev_cap = 0, sbuf_pin_cap = 0;
+    hipEvent_t sbuf_ev[2] = {nullptr, nullptr};
+    int64_t stream_slabs = 0, stream_bytes_staged = 0, stream_bytes_direct = 0;   // what the last rdf_pipeline call streamed
     ~Ctx();
 };
 
@@ -91,6 +100,7 @@ Ctx::~Ctx() {
     if (arena.base) (void)hipFree(arena.base);
     if (pinned) (void)hipHostFree(pinned);
     for (auto& kv : pool_free) (void)hipFree(kv.second);
+    for (int b = 0; b < 2; ++b) { if (sbuf_dev[b]) (void)hipFree(sbuf_dev[b]); if (sbuf_pin[b]) (void)hipHostFree(sbuf_pin[b]); if (sbuf_ev[b]) (void)hipEventDestroy(sbuf_ev[b]); }
     for (auto& ev : events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -1634,6 +1644,10 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
 rdf_expr_node node_col(int c) { rdf_expr_node n; memset(&n, 0, sizeof n); n.kind = RDF_NODE_COLUMN; n.column = c; n.lhs = n.rhs = -1; return n; }
 rdf_expr_node node_op(int op, int l, int r, int dtype = 0) { rdf_expr_node n; memset(&n, 0, sizeof n); n.kind = RDF_NODE_OP; n.op = op; n.lhs = l; n.rhs = r; n.dtype = dtype; return n; }
 
+rdf_status pipeline_stream(const ProgramSpec& ps, const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_agg_result* aggs, const char* msg);   // rdf_capi_stream.inc
+int64_t host_input_bytes(const rdf_array* cols, int32_t ncols, int64_t nchunks);
+int64_t stream_slab_bytes();
+
 rdf_status agg_column(const rdf_array* a, int64_t nchunks, bool as_f64, rdf_agg_result* r) {
     rdf_expr_node nodes[2] = {node_col(0), node_op(RDF_OP_CAST, 0, -1, RDF_F64)};
     ProgramSpec ps;
@@ -1907,7 +1921,22 @@ rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t 
     ps.nodes = prog->nodes; ps.nnodes = prog->nnodes; ps.filter_root = prog->filter_root; ps.nvalues = prog->nvalues; ps.sink = prog->sink;
     for (int v = 0; v < prog->nvalues; ++v) ps.value_roots[v] = prog->value_roots[v];
     if (ps.sink != RDF_SINK_STORE && ps.sink != RDF_SINK_AGG) return fail(RDF_INVALID_ARGUMENT, "bad sink");
+    g_ctx.stream_slabs = 0;
+    // host-resident batches beyond one slab: streamed — slab k + 1 crosses the link while the kernel runs over slab k
+    if (ps.sink == RDF_SINK_AGG && aggs && cols && ncols >= 1 && ncols <= kMaxCols && nchunks >= 1 && g_ctx.opt_stream_slab >= 0) {
+        bool host = true;
+        for (int64_t i = 0; i < (int64_t)ncols * nchunks && host; ++i) host = cols[i].mem == RDF_MEM_HOST && cols[i].length >= 0 && cols[i].offset >= 0 && (cols[i].length == 0 || cols[i].values);
+        if (host && host_input_bytes(cols, ncols, nchunks) > stream_slab_bytes())
+            return pipeline_stream(ps, cols, ncols, nchunks, aggs, "columns of a batch differ in length");
+    }
     return run_program(ps, cols, ncols, nchunks, outs, aggs, "columns of a batch differ in length");
+}
+
+rdf_status rdf_stream_stats(int64_t* slabs, int64_t* bytes_staged, int64_t* bytes_direct) {
+    if (slabs) *slabs = g_ctx.stream_slabs;
+    if (bytes_staged) *bytes_staged = g_ctx.stream_bytes_staged;
+    if (bytes_direct) *bytes_direct = g_ctx.stream_bytes_direct;
+    return RDF_OK;
 }
 
 rdf_status rdf_frame_pin(const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_frame** out) {
@@ -3808,6 +3837,7 @@ rdf_status legacy_groupby_sum(const rdf_array* keys, const rdf_array* values, in
 
 #include "rdf_capi_groupby.inc"
 #include "rdf_capi_frame.inc"
+#include "rdf_capi_stream.inc"
 #include "rdf_capi_comm.inc"
 
 extern "C" {
@@ -3853,6 +3883,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
     else if (strcmp(name, "comm_max_bytes") == 0) g_ctx.opt_comm_max_bytes = value;
+    else if (strcmp(name, "stream_slab_bytes") == 0) g_ctx.opt_stream_slab = value;
     else return fail(RDF_INVALID_ARGUMENT, "unknown option %s", name);
     return RDF_OK;
 }
