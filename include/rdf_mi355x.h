@@ -600,8 +600,10 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * 4 = its scatter path whatever max_groups says; 1 = first-generation histogram + scatter; 2 = radix-sort partitioning;
  * 0 = one table in HBM),
  * "gb_debug" (1 / 2: ablations of the aggregate / scatter pass, results invalid; 3: force the skew variant),
- * "jit" (a program shape no catalog holds: 1 = compile the specialised kernel template for it at run time — `hipcc` as a child
- * process, about half a second, kept for the life of the process —, default; 0 = the general evaluator interprets it),
+ * "jit" (a program shape no catalog holds: 1 = the specialised kernel template is compiled for it at run time — `hipcc` as a child
+ * process on a helper thread, about half a second; THIS call and the ones until it is ready are answered by the general evaluator,
+ * a code object found in the cache directory is loaded at once —, default; 2 = the call waits for the compiler; 0 = always the
+ * general evaluator),
  * "gb_compact" (scatter path, keys inside a window of 2^39: 1 = 4-byte records when only rows are counted, default; 2 = also
  * 12-byte records for sum / min / max; 0 = 16-byte records always), "gb_skew_plan" (1 = per-partition capacity plan when the probe finds a few heavy
  * partitions, default; 0 = the first-generation combining path instead; 2 = always),
@@ -617,6 +619,11 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
 rdf_status rdf_set_option(const char* name, int64_t value);
 /* Number of program shapes with a specialised kernel. */
 int32_t    rdf_spec_catalog_size(void);
+/* One line about the run-time compiler of shapes outside the catalogs: whether `hipcc` and the kernel sources were found (and
+ * where), the code-object cache directory ($RDF_JIT_CACHE, else $XDG_CACHE_HOME/rdf_mi355x/jit, else ~/.cache/rdf_mi355x/jit;
+ * RDF_JIT_CACHE=off disables it), and how many kernels were compiled / read from the cache / failed / are being compiled.
+ * Without a compiler such programs run on the interpreter (same results, 3-20 x slower) unless the cache holds them. */
+const char* rdf_jit_status(void);
 /* Name of the dominant kernel the last rdf_pipeline-family call of this thread launched. */
 const char* rdf_last_kernel(void);
 

@@ -150,6 +150,7 @@ pub mod sys {
         pub fn rdf_list_union(a: *const rdf_list_array, b: *const rdf_list_array, out_offsets: *mut rdf_out, out_values: *mut rdf_out) -> i32;
         pub fn rdf_list_repeat(list: *const rdf_list_array, count: i32, out_offsets: *mut rdf_out, out_values: *mut rdf_out) -> i32;
         // the fused batch loop (src/evaluation.rs:66-96); host-resident frames above one slab are streamed (rdf_stream_stats says how)
+        pub fn rdf_jit_status() -> *const c_char;          // the run-time compiler: found or not, cache directory, counts
         pub fn rdf_stream_stats(slabs: *mut i64, bytes_staged: *mut i64, bytes_direct: *mut i64) -> i32;
         pub fn rdf_pipeline(prog: *const rdf_program, cols: *const rdf_array, ncols: i32, nchunks: i64, outs: *mut rdf_out,
                             aggs: *mut rdf_agg_result) -> i32;

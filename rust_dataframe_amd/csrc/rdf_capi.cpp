@@ -63,7 +63,7 @@ struct Ctx {
     bool   sort_used_local = false; // the last sort finished at least one column with os_local_kernel
     int    opt_sort_msd = 1;        // sort keys that vary in more than 32 bits: passes over the top bits, then every bucket sorted in LDS (1, default); 0 = one pass per byte (A/B)
     int    opt_join_table = 1;      // equi-join on one key column: probe a table of the distinct build keys (1, default); 0 = the bucket index over the sorted build keys (A/B)
-    int    opt_jit = 1;             // a program shape outside the catalogs: compile spec_kernel<Prog> for it at run time (hiprtc) instead of interpreting it (1, default; 0 = interpreter)
+    int    opt_jit = 1;             // a program shape outside the catalogs: 1 = compile spec_kernel<Prog> for it on a helper thread (the interpreter answers until the kernel is ready; a code object in the cache directory is loaded at once), default; 2 = the call waits for the compiler; 0 = always the interpreter
     int    opt_take_rows = 1;       // take over a frame through interleaved row records: 1 = when the transaction model says so (default), 0 = never, 2 = always (tests, A/B)
     int    opt_gb_skew_plan = 1;    // skewed keys: per-partition region sizes + big partitions cut into several aggregate items (1 = when the probe finds skew, default; 0 = the first-generation combining path instead, A/B; 2 = always, tests)
     int    opt_gb_compact = 1;      // partition path, keys inside a window of 2^39: 1 = 4-byte records when only rows are counted (default); 2 = also 12-byte records (key word + value) for the other aggregates (measured slower than 16-byte records, kept for A/B); 0 = 16-byte records always
@@ -954,7 +954,7 @@ bool build_gspec_plan(Compiler& cc, int filter_root, int group_root, int ngroups
         for (int g : {2, 4, 6, 8}) {
             if (g < ngroups) continue;
             const std::string full = "G" + std::to_string(g) + s;
-            if (jit_spec_kernel(full.c_str())) { sp.sig = full; return true; }
+            if (jit_spec_kernel(full.c_str(), g_ctx.opt_jit >= 2)) { sp.sig = full; return true; }
             break;
         }
     return false;
@@ -984,12 +984,21 @@ struct ProgramSpec {
 };
 constexpr int RDF_SINK_GROUP = 2;
 
+// a kernel compiled at run time could not be launched (it is marked failed): the caller runs the program again, interpreted
+const rdf_status kRetryInterpreted = static_cast<rdf_status>(77);
+
 rdf_status launch_agg_pair(const EvalArgs* ea, const FilterAggF64Args* fa, int cmp, int feat, int grid, int nvalues,
                            const int* cls, AggPartial* partials, AggPartial* result, const char* spec_sig = nullptr,
                            const SpecArgs* sa = nullptr) {
     Ctx& c = g_ctx;
     KernelTimer kt;
-    if (sa) { c.last_kernel = std::string("spec_kernel<") + spec_sig + ">" + (jit_find(spec_sig) ? " [compiled at run time]" : ""); HIP_TRY(launch_spec(spec_sig, *sa, grid, c.stream)); }
+    if (sa) {
+        const bool jit = jit_find(spec_sig) != nullptr;
+        c.last_kernel = std::string("spec_kernel<") + spec_sig + ">" + (jit ? " [compiled at run time]" : "");
+        const hipError_t le = launch_spec(spec_sig, *sa, grid, c.stream);
+        if (le != hipSuccess && jit) { (void)hipGetLastError(); return kRetryInterpreted; }
+        if (le != hipSuccess) return fail(RDF_DEVICE_ERROR, "launch_spec: %s", hipGetErrorString(le));
+    }
     else if (fa) { c.last_kernel = "filter_agg_f64_kernel"; HIP_TRY(launch_filter_agg_f64(*fa, cmp, grid, c.stream)); }
     else { c.last_kernel = "eval_kernel<AGG>"; HIP_TRY(launch_eval(*ea, SINK_AGG, feat, grid, c.stream)); }
     kt.stop();
@@ -1378,7 +1387,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         for (int k = 0; k < 8; ++k) rt_ops[k] = 0;
         (void)build_spec_plan(cc, ps.filter_root, ps.nvalues, ps.value_roots, ps.sink, sp);
         if (getenv("RDF_DEBUG_JIT")) fprintf(stderr, "[rdf] jit: candidate %s (ok %d)\n", sp.sig.c_str(), (int)sp.ok);
-        have_plan = sp.ok && !sp.sig.empty() && jit_spec_kernel(sp.sig.c_str()) != nullptr;
+        have_plan = sp.ok && !sp.sig.empty() && jit_spec_kernel(sp.sig.c_str(), ctx.opt_jit >= 2) != nullptr;
     }
     if (have_plan) {
         memset(&sa, 0, sizeof sa);
@@ -1502,7 +1511,12 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             ga.ngroups = ps.ngroups; ga.nvalues = ps.nvalues; ga.vec_bitmap = ctx.opt_vec_bitmap ? 1 : 0;
             KernelTimer kt;
             ctx.last_kernel = "gspec_kernel<" + gp.sig + ">" + (jit_find(gp.sig.c_str()) ? " [compiled at run time]" : "");
-            HIP_TRY(launch_gspec(gp.sig.c_str(), ga, grid, ctx.stream));
+            const hipError_t le = launch_gspec(gp.sig.c_str(), ga, grid, ctx.stream);
+            if (le != hipSuccess && jit_find(gp.sig.c_str()) == nullptr && !gspec_available(gp.sig.c_str())) {     // a run-time kernel that could not be launched (now marked failed)
+                (void)hipGetLastError();
+                return run_program(ps, cols, ncols, nchunks, outs, aggs, len_mismatch_msg, fc);
+            }
+            if (le != hipSuccess) return fail(RDF_DEVICE_ERROR, "launch_gspec: %s", hipGetErrorString(le));
             kt.stop();
         } else {
             KernelTimer kt;
@@ -1577,7 +1591,9 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             }
         }
         if (use_spec) {
-            RDF_TRY(launch_agg_pair(nullptr, nullptr, 0, 0, grid, ps.nvalues, cls, d_partials, d_result, sp.sig.c_str(), &sa));
+            const rdf_status ls = launch_agg_pair(nullptr, nullptr, 0, 0, grid, ps.nvalues, cls, d_partials, d_result, sp.sig.c_str(), &sa);
+            if (ls == kRetryInterpreted) return run_program(ps, cols, ncols, nchunks, outs, aggs, len_mismatch_msg, fc);
+            RDF_TRY(ls);
         } else if (fast) {
             const int64_t per_block = (int64_t)kBlock * 4 * 2;  // rows per block iteration
             int64_t want = (clen[0] + per_block - 1) / per_block;
@@ -1610,7 +1626,13 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
     // SINK_STORE
     {
         KernelTimer kt;
-        if (use_spec) { ctx.last_kernel = "spec_kernel<" + sp.sig + ">" + (jit_find(sp.sig.c_str()) ? " [compiled at run time]" : ""); HIP_TRY(launch_spec(sp.sig.c_str(), sa, grid, ctx.stream)); }
+        if (use_spec) {
+            const bool jit = jit_find(sp.sig.c_str()) != nullptr;
+            ctx.last_kernel = "spec_kernel<" + sp.sig + ">" + (jit ? " [compiled at run time]" : "");
+            const hipError_t le = launch_spec(sp.sig.c_str(), sa, grid, ctx.stream);
+            if (le != hipSuccess && jit) { (void)hipGetLastError(); return run_program(ps, cols, ncols, nchunks, outs, aggs, len_mismatch_msg, fc); }   // marked failed: interpreted this time and from now on
+            if (le != hipSuccess) return fail(RDF_DEVICE_ERROR, "launch_spec: %s", hipGetErrorString(le));
+        }
         else { ctx.last_kernel = "eval_kernel<STORE>"; HIP_TRY(launch_eval(ea, SINK_STORE, cc.feat(), grid, ctx.stream)); }
         kt.stop();
     }
@@ -3888,6 +3910,11 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     return RDF_OK;
 }
 int32_t rdf_spec_catalog_size(void) { return spec_catalog_size(); }
+const char* rdf_jit_status(void) {
+    thread_local std::string line;
+    line = jit_status();
+    return line.c_str();
+}
 const char* rdf_last_kernel(void) { return g_ctx.last_kernel.c_str(); }
 
 rdf_status rdf_kernel_timing_reset(int32_t enable) {

@@ -3,6 +3,8 @@
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime.h>
+
+#include <string>
 #include "../../include/rdf_mi355x.h"
 
 namespace rdfk {
@@ -672,8 +674,12 @@ int  spec_catalog_size();
 hipError_t launch_spec(const char* sig, const SpecArgs& a, int grid, hipStream_t s);
 // rdf_jit.cpp: spec_kernel<Prog> instantiated at run time (hiprtc) for an exact-program signature the catalog does not hold
 struct JitKernel { void* fn; int rows_per_tile; int nvalues; };   // nvalues: grouped programs ("G..." signatures, gspec_kernel)
-const JitKernel* jit_find(const char* sig);          // compiled earlier in this process, or nullptr
-const JitKernel* jit_spec_kernel(const char* sig);   // ... compiling it now if need be; nullptr: not possible (remembered)
+const JitKernel* jit_find(const char* sig);          // ready on the current device (compiled earlier, or read from the cache directory), or nullptr
+// ... compiling it if need be: wait = false starts the compiler on a helper thread and returns nullptr (the interpreter answers
+// this call, the kernel takes over when it is ready); wait = true waits for it.  nullptr afterwards: not possible (remembered)
+const JitKernel* jit_spec_kernel(const char* sig, bool wait);
+void jit_mark_failed(const char* sig);               // a launch failed: this (device, signature) is interpreted from now on
+std::string jit_status();                            // one line: compiler / sources / cache directory found or not, counts
 hipError_t jit_launch(const JitKernel& k, const SpecArgs& a, int grid, hipStream_t s);
 hipError_t jit_launch_grouped(const JitKernel& k, const GSpecArgs& a, int grid, hipStream_t s);
 int jit_compiled_count();

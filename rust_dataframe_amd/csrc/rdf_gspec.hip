@@ -71,7 +71,10 @@ hipError_t launch_gspec(const char* sig, const GSpecArgs& a, int grid, hipStream
     GSpecLaunch f = gspec_lookup(sig);
     if (!f) {   // not in the catalog: compiled at run time? (rdf_jit.cpp)
         const JitKernel* j = jit_find(sig);
-        return j ? jit_launch_grouped(*j, a, grid, s) : hipErrorInvalidValue;
+        if (!j) return hipErrorInvalidValue;
+        const hipError_t e = jit_launch_grouped(*j, a, grid, s);
+        if (e != hipSuccess) jit_mark_failed(sig);
+        return e;
     }
     f(a, grid, s);
     return hipGetLastError();

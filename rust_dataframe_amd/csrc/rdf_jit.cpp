@@ -30,8 +30,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rdf_device.h"
@@ -161,10 +164,23 @@ bool prog_type(const char* sig, std::string& out) {   // "P:<pred>;V:<v0>;<v1>;S
     return true;
 }
 
-struct Entry { JitKernel k{nullptr, 0, 0}; bool failed = false; };
+// What is known about a signature.  The CODE OBJECT belongs to the signature (compiled once per process, or read from the
+// cache directory); a hipFunction_t belongs to the device it was loaded on, so the loaded kernels are keyed by (device, signature):
+// a second thread on another device loads the same bytes there instead of borrowing the first device's handle.
+enum CodeState { kCompiling = 0, kReady = 1, kFailed = 2 };
+struct Code {
+    int state = kCompiling;
+    bool grouped = false;
+    std::vector<char> bytes;
+    std::string kname, why;
+};
+struct Loaded { JitKernel k{nullptr, 0, 0}; bool failed = false; };
 std::mutex g_mu;
-std::map<std::string, Entry> g_kernels;
-int g_compiled = 0;
+std::condition_variable g_cv;                                     // a signature left kCompiling
+std::map<std::string, std::shared_ptr<Code>> g_code;
+std::map<std::pair<int, std::string>, Loaded> g_loaded;
+int g_compiled = 0, g_from_cache = 0, g_failed = 0, g_running = 0;
+constexpr int kMaxCompilers = 6;                                  // hipcc children at a time (a burst of new shapes queues behind them)
 
 bool read_file(const std::string& path, std::vector<char>& out) {
     FILE* f = std::fopen(path.c_str(), "rb");
@@ -199,18 +215,91 @@ bool kernel_symbol(const std::vector<char>& elf, const char* prefix, std::string
     return false;
 }
 
-// RDF_JIT_CACHE=<directory>: code objects are kept there across processes, keyed by signature, architecture and the library's
-// size + modification time (a new process then loads a known shape in milliseconds instead of compiling it again)
+// ---- the code-object cache: ON by default, across processes
+// Directory: RDF_JIT_CACHE (empty, "0" or "off": no cache), else $XDG_CACHE_HOME/rdf_mi355x/jit, else $HOME/.cache/rdf_mi355x/jit.
+// A file is named by a hash of (signature, architecture, the library's size + mtime, the CONTENTS of the kernel headers the
+// compiler reads, the compile flags) and carries its signature, which is compared on load: an edited header, another build or
+// a hash collision can only miss.  A directory that is not the user's own, or that group / others may write, is not used —
+// GPU code is loaded from it.
+const char* kJitFlags = "-O3 -std=c++17 -ffp-contract=off --cuda-device-only";
+uint64_t fnv(uint64_t h, const void* p, size_t n) { const unsigned char* c = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; } return h; }
+uint64_t sources_hash(const Paths& ps) {
+    static uint64_t h = 0;
+    static bool done = false;
+    if (done) return h;
+    done = true;
+    h = 1469598103934665603ull;
+    for (const char* name : {"/rdf_spec_kernel.hip.h", "/rdf_gspec_kernel.hip.h", "/rdf_expr.hip.h", "/rdf_common.hip.h", "/rdf_device.h", "/../../include/rdf_mi355x.h"}) {
+        std::vector<char> buf;
+        if (read_file(ps.src + name, buf)) h = fnv(h, buf.data(), buf.size());
+        h = fnv(h, name, strlen(name));
+    }
+    return h;
+}
+struct CacheDir { std::string dir, why; };
+const CacheDir& cache_dir() {
+    static CacheDir c;
+    static bool tried = false;
+    if (tried) return c;
+    tried = true;
+    const char* e = getenv("RDF_JIT_CACHE");
+    std::string d;
+    if (e) {
+        if (!*e || strcmp(e, "0") == 0 || strcmp(e, "off") == 0) { c.why = "switched off (RDF_JIT_CACHE)"; return c; }
+        d = e;
+    } else {
+        const char* x = getenv("XDG_CACHE_HOME");
+        const char* h = getenv("HOME");
+        if (x && *x) d = std::string(x) + "/rdf_mi355x/jit";
+        else if (h && *h) d = std::string(h) + "/.cache/rdf_mi355x/jit";
+        else { c.why = "no RDF_JIT_CACHE, XDG_CACHE_HOME or HOME"; return c; }
+    }
+    for (size_t i = 1; i <= d.size(); ++i)                                     // mkdir -p, every new level private
+        if (i == d.size() || d[i] == '/') { const std::string part = d.substr(0, i); (void)mkdir(part.c_str(), 0700); }
+    struct stat st;
+    if (stat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) { c.why = "cannot create " + d; return c; }
+    if (st.st_uid != geteuid()) { c.why = d + " belongs to another user"; return c; }
+    if (st.st_mode & (S_IWGRP | S_IWOTH)) { c.why = d + " is writable by group / others"; return c; }
+    c.dir = d;
+    return c;
+}
 std::string cache_file(const char* sig, const std::string& arch, const Paths& ps) {
-    const char* dir = getenv("RDF_JIT_CACHE");
-    if (!dir || !*dir) return std::string();
+    const CacheDir& cd = cache_dir();
+    if (cd.dir.empty()) return std::string();
     uint64_t h = 1469598103934665603ull;
-    for (const std::string& part : {std::string(sig), arch, ps.stamp})
-        for (unsigned char c : part + "|") { h ^= c; h *= 1099511628211ull; }
+    const uint64_t sh = sources_hash(ps);
+    for (const std::string& part : {std::string(sig), arch, ps.stamp, std::string(kJitFlags)}) { h = fnv(h, part.data(), part.size()); h = fnv(h, "|", 1); }
+    h = fnv(h, &sh, 8);
     char name[32];
     std::snprintf(name, sizeof name, "%016llx.hsaco", (unsigned long long)h);
-    (void)mkdir(dir, 0700);
-    return std::string(dir) + "/" + name;
+    return cd.dir + "/" + name;
+}
+const char kCacheMagic[8] = {'R', 'D', 'F', 'J', 'I', 'T', '1', 0};
+bool cache_read(const std::string& path, const char* sig, std::vector<char>& code) {
+    std::vector<char> raw;
+    if (path.empty() || !read_file(path, raw)) return false;
+    const size_t sl = strlen(sig);
+    if (raw.size() < 8 + 4 + sl + 8 || memcmp(raw.data(), kCacheMagic, 8) != 0) return false;
+    uint32_t n = 0;
+    memcpy(&n, raw.data() + 8, 4);
+    if (n != sl || memcmp(raw.data() + 12, sig, sl) != 0) return false;           // another program's file under this name: a miss
+    uint64_t cl = 0;
+    memcpy(&cl, raw.data() + 12 + sl, 8);
+    if (cl == 0 || 12 + sl + 8 + cl != raw.size()) return false;
+    code.assign(raw.begin() + (long)(12 + sl + 8), raw.end());
+    return true;
+}
+void cache_write(const std::string& path, const char* sig, const std::vector<char>& code) {
+    if (path.empty()) return;
+    const std::string tmp = path + "." + std::to_string((long)getpid()) + "." + std::to_string((long)(uintptr_t)&code & 0xffff);   // renamed into place: a reader never sees half a file
+    FILE* c = std::fopen(tmp.c_str(), "wb");
+    if (!c) return;
+    const uint32_t n = (uint32_t)strlen(sig);
+    const uint64_t cl = code.size();
+    const bool w = std::fwrite(kCacheMagic, 1, 8, c) == 8 && std::fwrite(&n, 4, 1, c) == 1 && std::fwrite(sig, 1, n, c) == n && std::fwrite(&cl, 8, 1, c) == 1 &&
+                   std::fwrite(code.data(), 1, code.size(), c) == code.size();
+    std::fclose(c);
+    if (!w || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
 }
 
 // one run of the compiler: the kernel source in a scratch directory, hipcc as a child process with build()'s flags (csrc/Makefile),
@@ -232,7 +321,7 @@ bool compile(const Paths& ps, const std::string& arch_opt, const std::string& ty
                             "extern \"C\" __global__ void rdf_jit_meta(int* out) { out[0] = P::R; out[1] = P::U; out[2] = P::W; out[3] = P::NC; }\n", type.c_str());
         std::fclose(f);
         const std::string inc = "-I" + ps.src;
-        std::vector<std::string> argv_s = {ps.hipcc, arch_opt, "--cuda-device-only", "--no-gpu-bundle-output", "-O3", "-std=c++17", "-ffp-contract=off", inc, "-c", src_path, "-o", obj_path};
+        std::vector<std::string> argv_s = {ps.hipcc, arch_opt, "--cuda-device-only", "--no-gpu-bundle-output", "-O3", "-std=c++17", "-ffp-contract=off", inc, "-c", src_path, "-o", obj_path};   // (kJitFlags: part of the cache key)
         std::vector<char*> argv;
         for (std::string& a : argv_s) argv.push_back(&a[0]);
         argv.push_back(nullptr);
@@ -277,42 +366,39 @@ bool compile(const Paths& ps, const std::string& arch_opt, const std::string& ty
     return ok;
 }
 
-bool build(const char* sig, Entry& e, std::string& why) {
+// the code object of a signature: from the cache directory, or one run of the compiler.  No HIP call in here: it runs on
+// helper threads as well.
+bool obtain_code(const char* sig, const std::string& arch, Code& c) {
     const Paths& ps = paths();
-    if (!ps.ok) { why = ps.why; return false; }
-    std::string type;
-    const bool grouped = sig[0] == 'G';
-    if (!(grouped ? gprog_type(sig, type) : prog_type(sig, type))) { why = "not an exact-program signature"; return false; }
     static const bool dbg = getenv("RDF_DEBUG_JIT") != nullptr;
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { why = "no device"; return false; }
-    const std::string arch_opt = std::string("--offload-arch=") + prop.gcnArchName;     // "gfx950:sramecc+:xnack-"
-    const std::string cached = cache_file(sig, prop.gcnArchName, ps);
-    std::vector<char> code;
-    if (!cached.empty() && read_file(cached, code)) {
+    std::string type;
+    c.grouped = sig[0] == 'G';
+    if (!(c.grouped ? gprog_type(sig, type) : prog_type(sig, type))) { c.why = "not an exact-program signature"; return false; }
+    const std::string cached = ps.ok || !ps.stamp.empty() ? cache_file(sig, arch, ps) : std::string();
+    bool from_cache = false;
+    if (cache_read(cached, sig, c.bytes)) {
+        from_cache = true;
         if (dbg) fprintf(stderr, "[rdf] jit: %s from %s\n", sig, cached.c_str());
     } else {
-        if (!compile(ps, arch_opt, type, grouped, code, why)) return false;
-        if (!cached.empty()) {   // written under another name and renamed: a concurrent reader never sees half a file
-            const std::string tmp = cached + "." + std::to_string((long)getpid());
-            FILE* c = std::fopen(tmp.c_str(), "wb");
-            if (c) {
-                const bool w = std::fwrite(code.data(), 1, code.size(), c) == code.size();
-                std::fclose(c);
-                if (!w || rename(tmp.c_str(), cached.c_str()) != 0) (void)unlink(tmp.c_str());
-            }
-        }
+        if (!ps.ok) { c.why = ps.why; return false; }
+        if (!compile(ps, "--offload-arch=" + arch, type, c.grouped, c.bytes, c.why)) return false;
+        cache_write(cached, sig, c.bytes);
     }
-    std::string kname;
-    if (!kernel_symbol(code, grouped ? "_ZN4rdfk12gspec_kernel" : "_ZN4rdfk11spec_kernel", kname)) { why = "kernel symbol not found in the code object"; return false; }
-    if (dbg) fprintf(stderr, "[rdf] jit: %zu bytes of code, loading %s\n", code.size(), kname.c_str());
+    if (!kernel_symbol(c.bytes, c.grouped ? "_ZN4rdfk12gspec_kernel" : "_ZN4rdfk11spec_kernel", c.kname)) { c.why = "kernel symbol not found in the code object"; return false; }
+    if (dbg) fprintf(stderr, "[rdf] jit: %zu bytes of code, loading %s\n", c.bytes.size(), c.kname.c_str());
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (from_cache) ++g_from_cache; else ++g_compiled;
+    return true;
+}
+
+// load a ready code object on the CURRENT device and read its tile size
+bool load_here(const Code& c, Loaded& l, std::string& why) {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr, meta = nullptr;
-    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { why = "hipModuleLoadData failed"; return false; }
+    if (hipModuleLoadData(&mod, c.bytes.data()) != hipSuccess) { (void)hipGetLastError(); why = "hipModuleLoadData failed"; return false; }
     bool ok = false;
     do {
-        if (hipModuleGetFunction(&fn, mod, kname.c_str()) != hipSuccess || hipModuleGetFunction(&meta, mod, "rdf_jit_meta") != hipSuccess) { why = "kernel not found in the code object"; break; }
+        if (hipModuleGetFunction(&fn, mod, c.kname.c_str()) != hipSuccess || hipModuleGetFunction(&meta, mod, "rdf_jit_meta") != hipSuccess) { why = "kernel not found in the code object"; break; }
         int* d_meta = nullptr;
         int h_meta[4] = {0, 0, 0, 0};
         if (hipMalloc((void**)&d_meta, 16) != hipSuccess) { why = "hipMalloc failed"; break; }
@@ -321,41 +407,122 @@ bool build(const char* sig, Entry& e, std::string& why) {
                               hipMemcpy(h_meta, d_meta, 16, hipMemcpyDeviceToHost) == hipSuccess;
         (void)hipFree(d_meta);
         if (!launched || h_meta[0] <= 0) { why = "the kernel's tile size could not be read"; break; }
-        e.k.fn = (void*)fn;
-        e.k.rows_per_tile = grouped ? kEvalTile : 64 * h_meta[0];
-        e.k.nvalues = grouped ? h_meta[1] : 0;
+        l.k.fn = (void*)fn;
+        l.k.rows_per_tile = c.grouped ? kEvalTile : 64 * h_meta[0];
+        l.k.nvalues = c.grouped ? h_meta[1] : 0;
         ok = true;
     } while (false);
-    if (!ok) (void)hipModuleUnload(mod);
+    if (!ok) { (void)hipGetLastError(); (void)hipModuleUnload(mod); }
     return ok;
+}
+
+// (g_mu held) the kernel of `sig` on device `dev`, loading the ready code object there on first use
+const JitKernel* find_locked(int dev, const char* sig) {
+    auto key = std::make_pair(dev, std::string(sig));
+    auto it = g_loaded.find(key);
+    if (it != g_loaded.end()) return it->second.failed ? nullptr : &it->second.k;
+    auto ci = g_code.find(sig);
+    if (ci == g_code.end() || ci->second->state != kReady) return nullptr;
+    Loaded l;
+    std::string why;
+    l.failed = !load_here(*ci->second, l, why);
+    static const bool dbg = getenv("RDF_DEBUG") != nullptr || getenv("RDF_DEBUG_JIT") != nullptr;
+    if (dbg) {
+        if (l.failed) fprintf(stderr, "[rdf] jit: %s on device %d -> interpreter (%s)\n", sig, dev, why.c_str());
+        else fprintf(stderr, "[rdf] jit: compiled spec_kernel<%s>, %d rows per wave iteration (device %d)\n", sig, l.k.rows_per_tile, dev);
+    }
+    auto ins = g_loaded.emplace(key, l);
+    return l.failed ? nullptr : &ins.first->second.k;
+}
+
+void finish_code(const std::string& sig, const std::string& arch, std::shared_ptr<Code> c) {
+    {
+        std::unique_lock<std::mutex> lock(g_mu);
+        g_cv.wait(lock, [] { return g_running < kMaxCompilers; });
+        ++g_running;
+    }
+    const bool ok = obtain_code(sig.c_str(), arch, *c);
+    static const bool dbg = getenv("RDF_DEBUG") != nullptr || getenv("RDF_DEBUG_JIT") != nullptr;
+    if (!ok && dbg) fprintf(stderr, "[rdf] jit: %s -> interpreter (%s)\n", sig.c_str(), c->why.c_str());
+    std::lock_guard<std::mutex> lock(g_mu);
+    --g_running;
+    if (!ok) ++g_failed;
+    c->state = ok ? kReady : kFailed;
+    g_cv.notify_all();
 }
 
 }  // namespace
 
 const JitKernel* jit_find(const char* sig) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_kernels.find(sig);
-    return it == g_kernels.end() || it->second.failed ? nullptr : &it->second.k;
+    return find_locked(dev, sig);
 }
 
-const JitKernel* jit_spec_kernel(const char* sig) {
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_kernels.find(sig);
-    if (it != g_kernels.end()) return it->second.failed ? nullptr : &it->second.k;
-    Entry e;
-    std::string why;
-    e.failed = !build(sig, e, why);
-    static const bool dbg = getenv("RDF_DEBUG") != nullptr || getenv("RDF_DEBUG_JIT") != nullptr;
-    if (dbg) {
-        if (e.failed) fprintf(stderr, "[rdf] jit: %s -> interpreter (%s)\n", sig, why.c_str());
-        else fprintf(stderr, "[rdf] jit: compiled spec_kernel<%s>, %d rows per wave iteration\n", sig, e.k.rows_per_tile);
+// wait = false: a shape met for the first time is compiled on a helper thread and THIS call is answered by the interpreter
+// (nullptr); the kernel takes over once it is ready.  wait = true: the caller waits for the compiler (tests, warm-up runs).
+// A code object found in the cache directory is loaded at once either way.
+const JitKernel* jit_spec_kernel(const char* sig, bool wait) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const std::string arch = prop.gcnArchName;                                  // "gfx950:sramecc+:xnack-"
+    std::shared_ptr<Code> c;
+    bool mine = false;
+    {
+        std::unique_lock<std::mutex> lock(g_mu);
+        if (const JitKernel* k = find_locked(dev, sig)) return k;
+        auto it = g_code.find(sig);
+        if (it == g_code.end()) {
+            c = std::make_shared<Code>();
+            g_code.emplace(sig, c);
+            mine = true;
+        } else {
+            c = it->second;
+            if (c->state == kFailed) return nullptr;
+            if (c->state == kReady) return nullptr;                             // ready but not loadable on this device (remembered in g_loaded)
+            if (!wait) return nullptr;                                          // somebody is compiling it: interpret this once more
+            g_cv.wait(lock, [&] { return c->state != kCompiling; });
+            return find_locked(dev, sig);
+        }
     }
-    if (!e.failed) ++g_compiled;
-    auto ins = g_kernels.emplace(sig, e);
-    return e.failed ? nullptr : &ins.first->second.k;
+    // a cached code object answers at once (no compiler run): look before deciding who waits
+    if (mine) {
+        const Paths& ps = paths();
+        std::vector<char> probe;
+        const bool cached = cache_read((ps.ok || !ps.stamp.empty()) ? cache_file(sig, arch, ps) : std::string(), sig, probe);
+        if (wait || cached) finish_code(sig, arch, c);
+        else { std::thread(finish_code, std::string(sig), arch, c).detach(); return nullptr; }
+    }
+    std::lock_guard<std::mutex> lock(g_mu);
+    return find_locked(dev, sig);
 }
 
-int jit_compiled_count() { std::lock_guard<std::mutex> lock(g_mu); return g_compiled; }
+// a launch of a run-time kernel failed: this (device, signature) goes to the interpreter from now on
+void jit_mark_failed(const char* sig) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_loaded[std::make_pair(dev, std::string(sig))].failed = true;
+}
+
+int jit_compiled_count() { std::lock_guard<std::mutex> lock(g_mu); return g_compiled + g_from_cache; }
+
+// one line for rdf_jit_status(): can shapes outside the catalogs be compiled here, and what has happened so far
+std::string jit_status() {
+    const Paths& ps = paths();
+    const CacheDir& cd = cache_dir();
+    std::lock_guard<std::mutex> lock(g_mu);
+    int compiling = 0;
+    for (auto& kv : g_code) compiling += kv.second->state == kCompiling;
+    char counts[160];
+    std::snprintf(counts, sizeof counts, "%d compiled, %d from the cache, %d failed, %d in progress", g_compiled, g_from_cache, g_failed, compiling);
+    if (!ps.ok)
+        return "run-time compiler unavailable: " + ps.why + " — program shapes outside the catalogs run on the interpreter"
+               + (cd.dir.empty() ? std::string() : " unless " + cd.dir + " holds their code objects") + " (" + counts + ")";
+    return "run-time compiler ready: " + ps.hipcc + ", kernel sources " + ps.src + ", code-object cache " + (cd.dir.empty() ? "off (" + cd.why + ")" : cd.dir) + " (" + counts + ")";
+}
 
 hipError_t jit_launch(const JitKernel& k, const SpecArgs& a, int grid, hipStream_t s) {
     SpecArgs copy = a;

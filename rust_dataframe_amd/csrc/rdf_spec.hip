@@ -121,7 +121,10 @@ hipError_t launch_spec(const char* sig, const SpecArgs& a, int grid, hipStream_t
     const SpecEntry* e = spec_lookup(sig);
     if (!e) {
         const JitKernel* j = jit_find(sig);
-        return j ? jit_launch(*j, a, grid, s) : hipErrorInvalidValue;
+        if (!j) return hipErrorInvalidValue;
+        const hipError_t e = jit_launch(*j, a, grid, s);
+        if (e != hipSuccess) jit_mark_failed(sig);
+        return e;
     }
     e->launch(a, grid, s);
     return hipGetLastError();

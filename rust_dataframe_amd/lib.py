@@ -23,7 +23,7 @@ EXPORTS = [
     "rdf_comm_unique_id", "rdf_comm_init_rank", "rdf_comm_init_all", "rdf_comm_destroy", "rdf_comm_info", "rdf_comm_barrier", "rdf_comm_allgather",
     "rdf_agg_combine", "rdf_group_combine", "rdf_groupby_agg_dist", "rdf_groupby_agg_frame_dist",
     "rdf_fill_uniform_f64", "rdf_fill_uniform_i64", "rdf_fill_validity",
-    "rdf_kernel_timing_reset", "rdf_kernel_timing_get", "rdf_set_option", "rdf_spec_catalog_size", "rdf_last_kernel",
+    "rdf_kernel_timing_reset", "rdf_kernel_timing_get", "rdf_set_option", "rdf_spec_catalog_size", "rdf_jit_status", "rdf_last_kernel",
 ]
 
 _lib = None
@@ -138,3 +138,8 @@ def stream_stats():
     a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
     _check(load().rdf_stream_stats(C.byref(a), C.byref(b), C.byref(c)))
     return a.value, b.value, c.value
+
+
+def jit_status() -> str:
+    load().rdf_jit_status.restype = C.c_char_p
+    return (load().rdf_jit_status() or b"").decode()

@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The run-time compiler keeps its code objects across processes (~/.cache/rdf_mi355x/jit by default).  A test session gets a
+# directory of its own, so that "met for the first time" means the same thing on a fresh box and on one that ran the suite before.
+import tempfile  # noqa: E402
+os.environ.setdefault("RDF_JIT_CACHE", tempfile.mkdtemp(prefix="rdf_jit_cache_"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
@@ -32,7 +38,7 @@ def gpu(request):
     lib.set_option("fast_filter", 1 if request.param == "spec" else 0)
     # shapes outside the catalogs are compiled at run time by default (rdf_jit.cpp, about a second each): the parity suites walk
     # hundreds of such shapes and hold them to the interpreter, test_kernels_compiled_at_run_time turns the compiler on
-    lib.set_option("jit", 1 if os.environ.get("RDF_TEST_JIT") == "1" and request.param == "spec" else 0)   # RDF_TEST_JIT=1: the whole suite through the run-time compiler (minutes of compiles)
+    lib.set_option("jit", 2 if os.environ.get("RDF_TEST_JIT") == "1" and request.param == "spec" else 0)   # RDF_TEST_JIT=1: the whole suite through the run-time compiler (2 = every call waits for its kernel; minutes of compiles)
     yield api
     lib.set_option("spec", 1)
     lib.set_option("fast_filter", 1)

@@ -170,7 +170,7 @@ def test_grouped_kernels_compiled_at_run_time(gpu, ora, request):
             e.op("multiply", ck, e.cast(cm, A.I64))]
     pred = e.op("and", e.op("gt", cx, e.scalar(-0.8)), e.op("ne", cm, e.scalar(7, A.I32)))
     exp = ora.group_pipeline(e, cols, vals, gid, 5, pred)
-    lib.set_option("jit", 1)
+    lib.set_option("jit", 2)      # the call waits for the compiler
     try:
         for _ in range(2):
             got = gpu.group_pipeline(e, cols, vals, gid, 5, pred)

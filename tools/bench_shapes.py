@@ -61,7 +61,7 @@ def beyond_the_catalogs(api, n, steps):
         flt = e.op("gt", b, e.scalar(0.0 if is_float else 500.0))
         for name, root, pc, read in progs:
             for jit in (1, 0):
-                lib.set_option("jit", jit)
+                lib.set_option("jit", 2 if jit else 0)
                 t0 = time.perf_counter()
                 api.pipeline(e, pc, [root])                 # jit = 1: compiles here
                 first = time.perf_counter() - t0
@@ -80,7 +80,7 @@ def beyond_the_catalogs(api, n, steps):
             gvals = [e.op("add", e.op("multiply", a, b), c), e.op("multiply", e.op("sin", a), b)]
             gpred = e.op("gt", c, e.scalar(-0.5))
             for jit in (1, 0):
-                lib.set_option("jit", jit)
+                lib.set_option("jit", 2 if jit else 0)
                 t0 = time.perf_counter()
                 api.group_pipeline(e, cols[:3], gvals, gid, 5, gpred)
                 first = time.perf_counter() - t0
