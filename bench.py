@@ -343,7 +343,7 @@ def workload_q1(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, 
             out["cpu_baseline"] = {"value": n / dt_o, "unit": "rows/s", "cores": 1, "kind": "port",
                                    "sample": f"rows [0,{n}): filter -> expressions -> 6 groups x (5 sums + counts), one materialised array per step (oracle), median of 3 warmed runs"}
         return out
-    return step, 38.0 * rows, f"C5: TPC-H Q1 shape (filter -> 5 sums + counts in 6 groups) over a {rows:.0e}-row synthetic lineitem shard per GPU", check
+    return step, 38.0 * rows, f"C5: TPC-H Q1 shape (filter -> 5 sums + counts in 6 uniform groups = 3 return flags x 2 line statuses; TPC-H's own data has 4 non-empty ones) over a {rows:.0e}-row synthetic lineitem shard per GPU", check
 
 
 WORKLOADS = {"c3": workload_c3, "c4": workload_c4, "q1": workload_q1}

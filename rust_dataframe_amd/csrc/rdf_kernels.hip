@@ -679,8 +679,16 @@ __global__ __launch_bounds__(kBlock) void join_table_kernel(const JoinTableArgs 
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.nrv; i += (int64_t)gridDim.x * kBlock) {
         const uint64_t k = a.rkeys[i];
         if (i > 0 && a.rkeys[i - 1] == k) continue;
+        // the end of the run of equal keys that starts here: galloping, then a binary search (one lane walking a hot key's
+        // millions of duplicates one dependent load at a time would hold its wave for as long)
         int64_t j = i + 1;
-        while (j < a.nrv && a.rkeys[j] == k) ++j;
+        if (j < a.nrv && a.rkeys[j] == k) {
+            int64_t step = 2;
+            while (i + step < a.nrv && a.rkeys[i + step] == k) step <<= 1;
+            int64_t l = i + (step >> 1), h = i + step < a.nrv ? i + step : a.nrv;     // rkeys[l] == k; rkeys[h] != k or h == nrv
+            while (l + 1 < h) { const int64_t mid = l + ((h - l) >> 1); if (a.rkeys[mid] == k) l = mid; else h = mid; }
+            j = h;
+        }
         const uint32_t info = j - i == 1 ? (0x80000000u | a.ridx[i]) : (uint32_t)(j - i);
         const unsigned long long w1 = ((unsigned long long)i << 32) | info;
         uint64_t s = (k * 0x9E3779B97F4A7C15ull) >> a.tshift;

@@ -47,6 +47,18 @@ def test_ref_aggregate_count_and_mean(ora):  # src/functions/aggregate.rs:123-14
     assert ora.avg([d, b]) == 4.5
 
 
+def test_avg_with_a_leading_empty_or_all_null_chunk(ora):
+    """Documented divergence (DESIGN.md section 6): AggregateFunctions::avg (src/functions/aggregate.rs:32-65) merges chunk means as
+    `mean = (mean * count + chunk_mean * chunk_count) / (count + chunk_count)` WITHOUT looking at the counts (:56-59), so a leading
+    empty or all-NULL chunk makes the first merge 0 / 0 = NaN and the whole average NaN.  The oracle (and the device) skip chunks
+    that contribute no value: the mean of the valid values, None only when there are none."""
+    empty = A.HostArray.from_numpy(np.zeros(0, dtype=np.int32))
+    nulls = A.HostArray.from_numpy(np.array([7, 8, 9], dtype=np.int32), valid=[0, 0, 0])
+    b = A.HostArray.from_numpy(np.arange(5, 10, dtype=np.int32))
+    assert ora.avg([empty, b]) == 7.0 and ora.avg([nulls, b]) == 7.0 and ora.avg([empty, nulls, b, empty]) == 7.0
+    assert ora.avg([empty]) is None and ora.avg([nulls, empty]) is None
+
+
 def test_ref_sort_take(ora):  # src/dataframe.rs:963-1003: a desc, b asc, nulls last -> indices [5,4,3,1,0,2]
     a = H(np.array([1, 1, 0, 3, 3, 4], dtype=np.int32), valid=[1, 1, 0, 1, 1, 1])
     b = H(np.array([9, 5, 6, 7, 4, 8], dtype=np.uint8))

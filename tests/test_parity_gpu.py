@@ -214,6 +214,10 @@ def test_aggregates_nan_and_reference_known_answers(gpu, ora):
     assert gpu.avg([a, b]) == 4.5
     d = A.HostArray.from_numpy(np.array([0, 0, 1, 0, 2, 3, 4], dtype=np.int32), valid=[1, 0, 1, 0, 1, 1, 1])
     assert gpu.avg([d, b]) == 4.5
+    # a leading empty / all-NULL chunk: the reference's merge divides 0 by 0 there (aggregate.rs:56-59) — not copied
+    empty = A.HostArray.from_numpy(np.zeros(0, dtype=np.int32))
+    nulls = A.HostArray.from_numpy(np.array([7, 8, 9], dtype=np.int32), valid=[0, 0, 0])
+    assert gpu.avg([empty, b]) == 7.0 == ora.avg([empty, b]) and gpu.avg([nulls, b, empty]) == 7.0 and gpu.avg([nulls, empty]) is None
 
 
 def _pred_cases(e, ncols):

@@ -384,7 +384,7 @@ def main():
             report(f"ab_filter_sum_validity_chunked_1M_vecbitmap{vb}_{rep}", 8.125 * n, lambda: api.pipeline(e, [XVC], [cx], gt))
             ns_ = min(n, 50_000_000)
             XVS = [A.DeviceArray(x.data_ptr() + i * 8, vx.data_ptr() + i // 8, 0, min(1024, ns_ - i), A.F64, -1, keep=(x, vx)) for i in range(0, ns_, 1024)]
-            report(f"ab_filter_sum_validity_chunked_1024_vecbitmap{vb}_{rep}", 8.125 * ns_, lambda: api.pipeline(e, [XVS], [cx], gt))
+            report(f"ab_filter_sum_validity_chunked_1024_vecbitmap{vb}_{rep}", 8.125 * ns_, lambda: api.pipeline(e, [XVS], [cx], gt), rows=ns_)
             if vb == 1 and rep == 0:
                 # the same call with the ctypes descriptors built once: wall_ms is then the library's own per-call host
                 # work for 48 828 chunks (chunk tables, their upload, the launch), without the Python marshalling
@@ -394,7 +394,7 @@ def main():
                                      (C.c_int32 * A.MAX_VALUES)(*([cx] + [0] * (A.MAX_VALUES - 1))), A.SINK_AGG)
                 cc, aggs, fn = A._flat([XVS], len(XVS)), (A.rdf_agg_result * A.MAX_VALUES)(), api._fn("pipeline")
                 report("filter_sum_validity_chunked_1024_descriptors_prebuilt", 8.125 * ns_,
-                       lambda: api._check(fn(C.byref(prog), cc, C.c_int32(1), C.c_int64(len(XVS)), None, aggs)))
+                       lambda: api._check(fn(C.byref(prog), cc, C.c_int32(1), C.c_int64(len(XVS)), None, aggs)), rows=ns_)
     lib.set_option("vec_bitmap", 0)
     return results
 

@@ -65,8 +65,19 @@ def main():
                  "rccl_one_rank.jsonl", "c4_total_rows_1e9.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
+    agree = None
     for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, f"{rnd}_bench_1e9_kernel_stats.csv"))
+        # the profiler's average duration of the dominant kernel must agree with the HIP-event average the SAME run printed
+        # (roofline.avg_kernel_ms of bench_1e9_under_rocprof.json): more than 2 % apart and the collection fails
+        under = os.path.join(src, "bench_1e9_under_rocprof.json")
+        if os.path.exists(under):
+            line = json.loads(open(under).read().strip().splitlines()[-1])
+            ev_ms = line["roofline"]["avg_kernel_ms"]
+            rows_ = [r for r in csv.DictReader(open(f)) if "spec_kernel" in r.get("Name", "")]
+            if rows_:
+                prof_ms = float(max(rows_, key=lambda r: float(r["TotalDurationNs"]))["AverageNs"]) / 1e6
+                agree = {"rocprofv3_avg_ms": prof_ms, "hip_event_avg_ms": ev_ms, "relative_difference": abs(prof_ms - ev_ms) / ev_ms}
     if os.path.exists(os.path.join(src, "workloads.jsonl")):
         shutil.copy(os.path.join(src, "workloads.jsonl"), os.path.join(dst, f"{rnd}_workloads_c3_c4_q1.jsonl"))
     note = "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024: gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM / rocprofv3 section); one --pmc counter per pass, kernel trace only"
@@ -98,6 +109,11 @@ def main():
                                 "kernels": [e["kernel"][:80] for e in ks], "source": f"profiles/{rnd}_pmc_hbm_traffic_by_kernel.json"}
         json.dump({"rows": rows, "validity": False, "hbm_bytes_per_launch": hbm, "source": f"profiles/{rnd}_bench_1e9_pmc_summary.json", "workloads": workloads},
                   open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+    if agree is not None:
+        json.dump(agree, open(os.path.join(dst, f"{rnd}_bench_1e9_kernel_time_agreement.json"), "w"), indent=1)
+        if agree["relative_difference"] > 0.02:
+            sys.exit(f"collect_profiles: rocprofv3 says {agree['rocprofv3_avg_ms']:.4f} ms per launch, the bench's HIP events {agree['hip_event_avg_ms']:.4f} ms "
+                     f"({agree['relative_difference']:.1%} apart, limit 2 %): the roofline line and the profile do not describe the same thing")
     print(json.dumps({"value": bench["value"], "frac": bench["roofline"]["frac"], "avg_kernel_ms": bench["roofline"]["avg_kernel_ms"],
                       "cpu": bench["cpu_baseline"]["value"], "hbm_bytes": hbm, "ratio": hbm / alg if alg else None}))
 
