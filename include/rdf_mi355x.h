@@ -610,6 +610,10 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * "filter_tile" (0: compaction tile from the mean chunk length; 1024 / 4096 force one), "filter_one" (one-chunk
  * compaction kernel with kernel-argument descriptors, default on), "take_rows" (rdf_take_frame / rdf_sort_frame: 1 = gather
  * interleaved row records when the index list is long and the frame wide, default; 0 = always column by column; 2 = always records),
+ * "gb_hot" (skewed keys on the scatter path: 1 = the few dozen hash classes that hold the heavy hitters get a pass of their own — folded in
+ * LDS per block — and the scatter takes the other rows, default; 0 = capacity plan / first-generation combining path),
+ * "gb_bucket" (partition tables of the scatter path's aggregate pass: 0 = one key per probe for keys packed into at most 4 x max_groups
+ * values — the multiplicative hash never collides there —, four keys per 32-byte bucket otherwise, default; 1 / 4 force one),
  * "filter_fused" (rdf_filter_frame with a `column CMP literal [AND | OR column CMP literal]` predicate over 4- / 8-byte columns: 1 = the
  * predicate runs inside the compaction kernel, one pass, when no batch is longer than 65 536 rows, default; 2 = always; 0 = predicate -> mask,
  * count, compact),

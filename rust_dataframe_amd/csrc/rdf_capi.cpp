@@ -68,6 +68,8 @@ struct Ctx {
     int    opt_gb_skew_plan = 1;    // skewed keys: per-partition region sizes + big partitions cut into several aggregate items (1 = when the probe finds skew, default; 0 = the first-generation combining path instead, A/B; 2 = always, tests)
     int    opt_gb_compact = 1;      // partition path, keys inside a window of 2^39: 1 = 4-byte records when only rows are counted (default); 2 = also 12-byte records (key word + value) for the other aggregates (measured slower than 16-byte records, kept for A/B); 0 = 16-byte records always
     int64_t opt_comm_max_bytes = 0;  // group-by exchange: most bytes one ncclSend / peer copy moves (0 = 256 MiB); larger shares travel in several rounds
+    int    opt_gb_hot = 1;          // skewed keys: 1 = heavy-hitter split (the hot hash classes through gb2_stream_kernel, the scatter path over the rest), default; 0 = capacity plan / first-generation path as in round 3 (A/B)
+    int    opt_gb_bucket = 0;       // partition tables of the aggregate pass: 4 = four keys per 32-byte bucket, 1 = one key per probe, 0 = by the sampled key range (default: one key per probe for keys packed into <= 4 x max_groups values, buckets otherwise)
     int    opt_gb_partition = 3;    // hash GROUP BY: 3 = second generation (rdf_groupby.hip: stream / line-aligned scatter / table by max_groups, default), 4 = its partition path whatever max_groups says, 1 = first-generation histogram + scatter, 2 = first-generation radix sort, 0 = one table in HBM
     // kernel timing (bench.py roofline leg)
     bool   timing = false;
@@ -3902,6 +3904,8 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "jit") == 0) g_ctx.opt_jit = (int)value;
     else if (strcmp(name, "gb_skew_plan") == 0) g_ctx.opt_gb_skew_plan = (int)value;
     else if (strcmp(name, "gb_compact") == 0) g_ctx.opt_gb_compact = (int)value;
+    else if (strcmp(name, "gb_bucket") == 0) g_ctx.opt_gb_bucket = (int)value;
+    else if (strcmp(name, "gb_hot") == 0) g_ctx.opt_gb_hot = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
     else if (strcmp(name, "comm_max_bytes") == 0) g_ctx.opt_comm_max_bytes = value;

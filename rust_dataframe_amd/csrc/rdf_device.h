@@ -486,7 +486,12 @@ struct Gb2Args {
     // (key - key_base) in 39 bits — a key outside [key_base, key_base + 2^39) sets flag bit 6 and the host re-runs with 16-byte records
     uint32_t*          recs_k;
     uint64_t           key_base;
-    int32_t            compact, pad3;
+    int32_t            compact;
+    // heavy hitters (Zipf-like keys): the up to ~100 keys that hold most of a skewed input (found by the probe: classes of the hash's
+    // top 16 bits far above the mean, then the keys inside them).  hot_mode 2 (gb2_stream_kernel): only their rows, folded in LDS
+    // per block and merged into the global table `t`; hot_mode 1 (gb2_scatter_kernel): every other row; 0: no split
+    int32_t            hot_mode;
+    const uint32_t*    hot_bitmap;       // [2048] class bitmap, then [256] x 64-bit slots: the hashed hot keys, open addressing from (hash >> 24) & 255, ~0 = free
 };
 struct Gb2Work { int32_t p, b0, b1, multi; };   // aggregate work item: regions [b0, b1) of partition p; multi: the partition is cut into several items
 struct Gb2AggArgs {
@@ -552,7 +557,8 @@ struct KeyPackArgs {
 };
 hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s);
 hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s);
-hipError_t launch_gb2_skew_probe(const Gb2Args& a, int64_t tile_step, unsigned int* hist, unsigned long long* minmax /* [2], may be nullptr */, hipStream_t s);
+hipError_t launch_gb2_skew_probe(const Gb2Args& a, int64_t tile_step, unsigned int* hist, unsigned long long* minmax /* [2], may be nullptr */, unsigned int* hbins /* [65536] by the hash's top 16 bits, may be nullptr */,
+                                 unsigned long long* ktab /* [2 * 4096] (hashed key, samples) of the keys in the classes of a.hot_bitmap, may be nullptr */, hipStream_t s);
 hipError_t launch_gb2_aggregate(const Gb2AggArgs& a, hipStream_t s);
 hipError_t launch_gb2_merge(const Gb2MergeArgs& a, hipStream_t s);
 hipError_t launch_gb2_table_rows(const Gb2Args& a, hipStream_t s);

@@ -205,9 +205,37 @@ struct G2Rows { uint64_t hk[NT], val[NT]; uint32_t cnt, live, bad; };   // cnt b
 struct LdsSpecial { unsigned long long* acc; unsigned int* cnt; unsigned int* flag; };   // [2] each; acc == nullptr: global
 
 template <int NT, bool FAST = false, bool COMPACT = false>
-__device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r, G2Rows<NT>& o, const LdsSpecial ls = LdsSpecial{nullptr, nullptr, nullptr}) {
+__device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r, G2Rows<NT>& o, const LdsSpecial ls = LdsSpecial{nullptr, nullptr, nullptr},
+                                           const uint32_t* hot_lds = nullptr) {
     o.cnt = 0; o.live = 0; o.bad = 0;
     const bool counts_rows = a.value_dtype < 0;
+    // heavy-hitter split: this pass takes the rows of the hot hash prefixes (mode 2) or all the others (mode 1); the two special
+    // groups (NULL key, the key that hashes to the free marker) belong to the pass over the others.  The class bitmap sits in
+    // LDS: read from global memory it put a wait for EVERY load in flight — the prefetched batches too — behind each tile
+    // (7.5 ms per 1e9 rows for the hot pass alone).
+    auto hot_filter = [&]() {
+        if (!a.hot_mode || !hot_lds) return;
+        const uint32_t want = a.hot_mode == 2 ? 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (!((o.live >> j) & 1)) continue;
+            const uint32_t bin = (uint32_t)(o.hk[j] >> 48);
+            uint32_t is_hot = (hot_lds[bin >> 5] >> (bin & 31)) & 1u;          // the key's class holds a heavy hitter ...
+            if (is_hot) {                                                          // ... and the key is one: 256-slot table of the hashed hot keys
+                const unsigned long long* kt = (const unsigned long long*)(hot_lds + 2048);
+                uint32_t sl = (uint32_t)(o.hk[j] >> 24) & 255u;
+                is_hot = 0;
+                for (;;) {
+                    const unsigned long long k = kt[sl];
+                    if (k == (unsigned long long)o.hk[j]) { is_hot = 1; break; }
+                    if (k == kFree) break;
+                    sl = (sl + 1) & 255u;
+                }
+            }
+            if (is_hot != want) o.live &= ~(1u << j);
+        }
+    };
+    const bool skip_special = a.hot_mode == 2;
     if constexpr (FAST) {
         o.cnt = r.exists;
 #pragma unroll
@@ -219,6 +247,7 @@ __device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r,
             if (!((r.exists >> j) & 1)) continue;
             if (COMPACT && ((r.key[j] - a.key_base) >> 39)) { o.bad = 1; continue; }
             if (hk == kFree) {   // the one key whose hash is the free marker
+                if (skip_special) continue;
                 if (ls.acc) {
                     ls.flag[0] = 1;
                     if (!counts_rows) acc_apply(&ls.acc[0], a.op, a.vcls, v);
@@ -232,6 +261,7 @@ __device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r,
             }
             o.live |= 1u << j;
         }
+        hot_filter();
         return;
     }
 #pragma unroll
@@ -253,6 +283,7 @@ __device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r,
         if (COMPACT && !knull && ((nk - a.key_base) >> 39)) { o.bad = 1; continue; }
         if (knull || hk == kFree) {
             const int s = knull ? 1 : 0;
+            if (skip_special) continue;
             if (ls.acc) {
                 ls.flag[s] = 1;
                 if (c1) {
@@ -270,6 +301,7 @@ __device__ __forceinline__ void g2_prepare(const Gb2Args& a, const G2Raw<NT>& r,
         }
         o.live |= 1u << j;
     }
+    hot_filter();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -327,6 +359,66 @@ __device__ __forceinline__ void tab_upsert(const LdsTab& t, int op, int cls, boo
     }
 }
 
+// The partition tables of the aggregate pass, four keys per 32-byte BUCKET: one LDS round trip looks at all four, and a lane
+// moves on only when all are somebody else's.  With one key per probe a table at load 0.5 costs a wave the chain of its
+// unluckiest lane — 256 look-ups per batch, 8-10 dependent round trips for keys that hash like random numbers (scattered 64-bit
+// key values: 7.9 ms per 1e9 rows in this pass against 2.8 ms for dense keys, whose multiplicative hash never collides; buckets
+// of two: 6.6 ms).  A key's second bucket comes from other hash bits (a step of its own), so a crowded neighbourhood is left
+// in one jump.  A bucket fills its slots in order and keys never leave, so two lanes with one key cannot both insert it:
+// whoever loses a CAS looks at the bucket again.
+constexpr uint32_t kG2Buckets = 1973;                 // prime; 4 x 1973 <= kG2Slots
+static_assert(4 * kG2Buckets <= kG2Slots, "bucketed table larger than the LDS arrays");
+template <int B, int PB>
+__device__ __forceinline__ void tab_upsert_b4(const LdsTab& t, int op, int cls, bool has_values, const uint64_t (&hk)[B], const uint64_t (&val)[B],
+                                              const uint32_t (&cnt)[B], uint32_t pending, uint32_t& err, uint32_t full_flag) {
+    uint32_t b[B], step[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+        b[u] = (uint32_t)(((uint64_t)(uint32_t)(hk[u] >> (32 - PB)) * (uint64_t)kG2Buckets) >> 32);
+        step[u] = 1u + (uint32_t)(((uint64_t)(uint32_t)(hk[u] >> 3) * (uint64_t)(kG2Buckets - 1)) >> 32);
+    }
+    uint32_t guard = 0;
+    while (__any(pending != 0)) {
+        u64x2 ka[B], kb[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            ka[u][0] = 0; ka[u][1] = 0; kb[u] = ka[u];
+            if ((pending >> u) & 1) { ka[u] = *(const u64x2*)&t.keys[4 * b[u]]; kb[u] = *(const u64x2*)&t.keys[4 * b[u] + 2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            if (!((pending >> u) & 1)) continue;
+            const unsigned long long h = (unsigned long long)hk[u];
+            const unsigned long long k[4] = {ka[u][0], ka[u][1], kb[u][0], kb[u][1]};
+            int slot = -1, free_at = -1;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) { if (k[j] == kFree) free_at = j; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (k[j] == h) slot = (int)(4 * b[u]) + j;
+            if (slot < 0) {
+                if (free_at >= 0) {
+                    const uint32_t at = 4 * b[u] + (uint32_t)free_at;
+                    const unsigned long long o = atomicCAS(&t.keys[at], kFree, h);
+                    if (o == kFree) { atomicAdd(t.ngroups, 1u); slot = (int)at; }
+                    else if (o == h) slot = (int)at;
+                    // else: another key took the slot meanwhile — the bucket is read again
+                } else {
+                    b[u] += step[u];
+                    if (b[u] >= kG2Buckets) b[u] -= kG2Buckets;
+                }
+            }
+            if (slot >= 0) {
+                pending &= ~(1u << u);
+                if (cnt[u]) {
+                    if (has_values) acc_apply(&t.acc[slot], op, cls, val[u]);
+                    atomicAdd(&t.cnt[slot], cnt[u]);
+                }
+            }
+        }
+        if (++guard > 6 * kG2Buckets) { if (pending) err |= full_flag; break; }   // this partition's table is full
+    }
+}
+
 // Insert-or-find `key` (raw key bits) in the global table and fold (v, cnt) into its slot.  False on overflow.
 __device__ __forceinline__ bool g2_global_upsert(const GroupTable& t, uint64_t key, int op, int cls, bool has_values, uint64_t v, uint64_t cnt) {
     const uint64_t mask = (uint64_t)t.capacity - 1;
@@ -354,6 +446,46 @@ __device__ __forceinline__ void g2_global_special(const GroupTable& t, int which
     }
 }
 
+// A heavy partition is heavy because of a few keys: almost every record of such a partition carries the same hashed key, and
+// 64 lanes adding into ONE LDS slot serialise (the hot-key input measured 12.9 ms in this kernel against 2.8 ms for uniform
+// keys).  Before the table is touched, the lanes that hold the key of the wave's first pending lane reduce their contributions
+// with a butterfly and leave ONE record; two rounds per batch element take care of the two heaviest keys of a wave.
+__device__ __forceinline__ uint64_t g2_combine(int op, int cls, uint64_t a, uint64_t b) {
+    if (op == AGG_SUM) return cls == CLS_F64 ? d2u(u2d(a) + u2d(b)) : a + b;
+    if (op == AGG_MIN) return a < b ? a : b;
+    return a > b ? a : b;
+}
+template <int B>
+__device__ __forceinline__ void wave_combine(int op, int cls, const uint64_t (&hk)[B], uint64_t (&val)[B], uint32_t (&cnt)[B], uint32_t& pending) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+        bool active = (pending >> u) & 1;
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            const uint64_t m = __ballot(active);
+            if (__popcll(m) < 8) break;
+            const int leader = __builtin_ctzll(m);
+            const uint64_t lk = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(hk[u] >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)hk[u], leader);
+            const bool same = active && hk[u] == lk;
+            if (__popcll(__ballot(same)) >= 8) {
+                uint64_t v = same ? val[u] : agg_identity(op);
+                uint32_t c = same ? cnt[u] : 0u;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const uint64_t ov = shfl_xor64(v, d);
+                    const uint32_t oc = (uint32_t)__shfl_xor((int)c, d);
+                    v = g2_combine(op, cls, v, ov);
+                    c += oc;
+                }
+                if (lane == leader) { val[u] = v; cnt[u] = c; }
+                else if (same) pending &= ~(1u << u);
+            }
+            active = active && !same;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // <= 2048 groups: columns -> per-block LDS table -> global table
 
@@ -374,8 +506,10 @@ __global__ __launch_bounds__(kStreamBlock, FAST ? 6 : 4) void gb2_stream_kernel(
     ls.acc = (unsigned long long*)(gsm + ((size_t)slots * 20 + 4 + 7) / 8);   // behind keys, acc, cnt, ngroups (8-byte aligned)
     ls.cnt = (unsigned int*)(ls.acc + 2);
     ls.flag = ls.cnt + 2;
+    uint32_t* hot_lds = a.hot_mode ? (uint32_t*)(ls.acc + 6) : nullptr;          // [2048] the hot classes' bitmap + [256] hashed hot keys, behind the special groups (48 bytes)
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long ident = agg_identity(a.op);
+    if (hot_lds) for (int i = tid; i < 2048 + 512; i += kStreamBlock) hot_lds[i] = as_global<uint32_t>(a.hot_bitmap)[i];
     for (int i = tid; i < slots; i += kStreamBlock) { t.keys[i] = kFree; t.acc[i] = ident; t.cnt[i] = 0; }
     if (tid == 0) *t.ngroups = 0;
     if (tid < 2) { ls.acc[tid] = ident; ls.cnt[tid] = 0; ls.flag[tid] = 0; }
@@ -392,11 +526,13 @@ __global__ __launch_bounds__(kStreamBlock, FAST ? 6 : 4) void gb2_stream_kernel(
     // second one would cost it the registers that let two blocks share a CU.)
     auto fold = [&](const G2Raw<kStreamRows>& raw) {
         G2Rows<kStreamRows> rows;
-        g2_prepare<kStreamRows, FAST>(a, raw, rows, ls);
+        g2_prepare<kStreamRows, FAST>(a, raw, rows, ls, hot_lds);
         uint32_t cnt[kStreamRows];
 #pragma unroll
         for (int j = 0; j < kStreamRows; ++j) cnt[j] = (rows.cnt >> j) & 1;
-        tab_upsert<kStreamRows, 0>(t, a.op, a.vcls, has_values, base, (uint32_t)a.sub_slots, rows.hk, rows.val, cnt, rows.live, err);
+        // (hot_mode 2, the heavy hitters' pass: at most ~100 keys, which the replicated sub-tables take like any small GROUP BY; a
+        // full table — cannot happen with the host's sizes — raises flag 128 and the host runs the call again without the split)
+        tab_upsert<kStreamRows, 0>(t, a.op, a.vcls, has_values, base, (uint32_t)a.sub_slots, rows.hk, rows.val, cnt, rows.live, err, a.hot_mode == 2 ? 128u : 4u);
     };
     // Software pipeline: the next batch's loads fly while this one is folded.  The batches ROTATE through two register sets
     // by unrolling, never by copying (`cur = nxt` is a read of nxt: a wait for the loads just issued), and the prefetch is
@@ -439,11 +575,16 @@ __global__ __launch_bounds__(kStreamBlock, FAST ? 6 : 4) void gb2_stream_kernel(
 // skewed keys paid for a whole wasted scatter (~9 ms per 1e9 rows) before the combining path ran.
 // minmax (optional): the smallest / largest sampled key in the key type's order (sign bit flipped for the signed types), NULL
 // keys left out — what the host sizes the 32-bit window of the compact records from.
-__global__ __launch_bounds__(256) void gb2_skew_probe_kernel(const Gb2Args a, int64_t tile_step, unsigned int* hist, unsigned long long* minmax) {
+__global__ __launch_bounds__(256) void gb2_skew_probe_kernel(const Gb2Args a, int64_t tile_step, unsigned int* hist, unsigned long long* minmax, unsigned int* hbins, unsigned long long* ktab) {
     // hist[0 .. kP): partitions of the 64-bit hash; hist[kP .. 2 kP): partitions of the compact hash taken with base 0 — the host
     // picks window bases that are multiples of 2^31, for which the real partition numbers are these rotated by a constant
     __shared__ unsigned int h[2 * kP];
     __shared__ unsigned long long mm[2];
+    // the block's own counters for the classes it meets (class -> slot by its low bits, first come first kept): a skewed input
+    // sends a quarter of the samples to ONE class, and a million same-address global atomics took 3 ms
+    constexpr int kCache = 4096;
+    __shared__ unsigned int cls_of[kCache], cls_n[kCache];
+    for (int i = threadIdx.x; i < kCache; i += 256) { cls_of[i] = 0xFFFFFFFFu; cls_n[i] = 0; }
     for (int i = threadIdx.x; i < 2 * kP; i += 256) h[i] = 0;
     if (threadIdx.x == 0) { mm[0] = ~0ull; mm[1] = 0ull; }
     const uint64_t flip = (a.key_dtype == RDF_I64 || a.key_dtype == RDF_I32 || a.key_dtype == RDF_I16 || a.key_dtype == RDF_I8) ? 0x8000000000000000ull : 0ull;
@@ -462,20 +603,55 @@ __global__ __launch_bounds__(256) void gb2_skew_probe_kernel(const Gb2Args a, in
             kc = const_col(a.keys, c);
         }
         const int64_t row = r0 + lane * 16 + (int)((tile * 7) & 15);
+        uint32_t hbin = 0xFFFFFFFFu;
+        uint64_t khot = 0;
+        bool kact = false;
         if (row < clen) {
             const uint64_t nk = normalize_int(a.key_dtype, g2_load_raw(kc.values, ksz, kc.offset + row, true));
             const uint64_t hk = g2_hash(nk);
             atomicAdd(&h[(uint32_t)(hk >> (64 - kG2PartBits))], 1u);
             atomicAdd(&h[kP + (uint32_t)(g2c_hash(nk, 0) >> (64 - kG2PartBits))], 1u);
+            hbin = (uint32_t)(hk >> 48);
+            if (ktab && hk != kFree && ((as_global<uint32_t>(a.hot_bitmap)[hbin >> 5] >> (hbin & 31)) & 1u)) { khot = hk; kact = true; }
             if (minmax) {
                 bool valid = true;
                 if (kc.validity) { const int64_t b = kc.offset + row; valid = (as_global<uint8_t>(kc.validity)[b >> 3] >> (b & 7)) & 1; }
                 if (valid) { atomicMin(&mm[0], (unsigned long long)(nk ^ flip)); atomicMax(&mm[1], (unsigned long long)(nk ^ flip)); }
             }
         }
+        if (hbins && hbin != 0xFFFFFFFFu) {
+            // 65 536 classes by the hash's top 16 bits: where the heavy hitters are
+            const uint32_t sl = hbin & (kCache - 1);
+            const unsigned int o = atomicCAS(&cls_of[sl], 0xFFFFFFFFu, hbin);
+            if (o == 0xFFFFFFFFu || o == hbin) atomicAdd(&cls_n[sl], 1u);
+            else atomicAdd(&hbins[hbin], 1u);
+        }
+        if (ktab) {
+            // second run, over the same sample: the KEYS inside the hot classes, counted in a 4096-slot table (hashed key, samples) —
+            // a class is 1 / 65 536 of the key space, the heavy hitter in it is one key
+#pragma unroll 1
+            for (int round = 0; round < 64; ++round) {
+                const uint64_t mact = __ballot(kact);
+                if (!mact) break;
+                const int leader = __builtin_ctzll(mact);
+                const uint64_t lk = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(khot >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)khot, leader);
+                const bool same = kact && khot == lk;
+                const unsigned long long c = (unsigned long long)__popcll(__ballot(same));
+                if (lane == leader) {
+                    uint32_t sl = (uint32_t)(lk >> 20) & 4095u;
+                    for (int probe = 0; probe < 4096; ++probe) {
+                        const unsigned long long o = atomicCAS(&ktab[2 * sl], 0ull, (unsigned long long)lk);
+                        if (o == 0ull || o == (unsigned long long)lk) { atomicAdd(&ktab[2 * sl + 1], c); break; }
+                        sl = (sl + 1) & 4095u;
+                    }
+                }
+                kact = kact && !same;
+            }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * kP; i += 256) if (h[i]) atomicAdd(&hist[i], h[i]);
+    if (hbins) for (int i = threadIdx.x; i < kCache; i += 256) if (cls_n[i]) atomicAdd(&hbins[cls_of[i]], cls_n[i]);
     if (minmax && threadIdx.x == 0 && mm[0] <= mm[1]) { atomicMin(&minmax[0], mm[0]); atomicMax(&minmax[1], mm[1]); }
 }
 
@@ -509,8 +685,10 @@ __global__ __launch_bounds__(kG2Block, 2 * kG2BlocksPerCU) void gb2_scatter_kern
     uint32_t* written = ccnt + kP;                        // [kP] lines of the region already written
     uint32_t* lstart = written + kP;                      // [kP] first staging slot of the partition
     uint32_t* tail = lstart + kP;                         // [kP] staging index of the partition's new carry (partitions that flush)
+    uint32_t* hot_lds = a.hot_mode ? tail + kP : nullptr; // [2048] heavy-hitter split: bitmap of the hash classes another pass takes
     __shared__ uint32_t wtot_t[kP / 64], wtot_k[kP / 64], ltot, abort_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (hot_lds) for (int i = tid; i < 2048 + 512; i += kG2Block) hot_lds[i] = as_global<uint32_t>(a.hot_bitmap)[i];
     if (tid < kP) { tcnt[tid] = 0; ccnt[tid] = 0; written[tid] = 0; }
     if (tid == 0) abort_s = 0;
     __syncthreads();
@@ -527,11 +705,11 @@ __global__ __launch_bounds__(kG2Block, 2 * kG2BlocksPerCU) void gb2_scatter_kern
     int64_t st = (int64_t)bid * TPI;
     G2Raw<kG2Rows> raw;
     G2Rows<kG2Rows> rows;
-    if (st < a.ntiles) { g2_load<kG2Rows, kG2Block, FAST>(a, st, tid, raw); g2_prepare<kG2Rows, FAST, COMPACT>(a, raw, rows); }
+    if (st < a.ntiles) { g2_load<kG2Rows, kG2Block, FAST>(a, st, tid, raw); g2_prepare<kG2Rows, FAST, COMPACT>(a, raw, rows, LdsSpecial{nullptr, nullptr, nullptr}, hot_lds); }
     for (; st < a.ntiles; st += stride) {
         const bool more = st + stride < a.ntiles;
         if (more) g2_load<kG2Rows, kG2Block, FAST>(a, st + stride, tid, raw);   // the next tile's loads fly during the LDS phases
-        if (a.ablate == 24) { uint64_t x = 0; for (int j = 0; j < kG2Rows; ++j) x ^= rows.hk[j] ^ rows.val[j]; if (x == 0x1234567) a.special[0] = 1; if (more) g2_prepare<kG2Rows, FAST, COMPACT>(a, raw, rows); continue; }   // loads + hash only
+        if (a.ablate == 24) { uint64_t x = 0; for (int j = 0; j < kG2Rows; ++j) x ^= rows.hk[j] ^ rows.val[j]; if (x == 0x1234567) a.special[0] = 1; if (more) g2_prepare<kG2Rows, FAST, COMPACT>(a, raw, rows, LdsSpecial{nullptr, nullptr, nullptr}, hot_lds); continue; }   // loads + hash only
         if (COMPACT && rows.bad) { err |= 64u; atomicOr(a.flags, 64u); }   // a key outside the 32-bit window: every block stops at its next tile
         // (B) rank inside the partition
         uint32_t rank[kG2Rows];
@@ -599,7 +777,7 @@ __global__ __launch_bounds__(kG2Block, 2 * kG2BlocksPerCU) void gb2_scatter_kern
             }
         __syncthreads();
         // the next tile's rows: waiting for its loads HERE keeps the flush stores below out of that wait
-        if (more) g2_prepare<kG2Rows, FAST, COMPACT>(a, raw, rows);
+        if (more) g2_prepare<kG2Rows, FAST, COMPACT>(a, raw, rows, LdsSpecial{nullptr, nullptr, nullptr}, hot_lds);
         // (E) flush whole lines: L consecutive lanes write one aligned line of a region (COMPACT: 128 bytes of values + 64 of key
         // words).  An iteration is a chain of dependent LDS round trips (descriptor -> record -> new carry); the chains of
         // different lines are independent (a line reads its partition's OLD carry, only that partition's first line writes the
@@ -686,46 +864,6 @@ __global__ __launch_bounds__(kG2Block, 2 * kG2BlocksPerCU) void gb2_scatter_kern
     if (err) atomicOr(a.flags, err);
 }
 
-// A heavy partition is heavy because of a few keys: almost every record of such a partition carries the same hashed key, and
-// 64 lanes adding into ONE LDS slot serialise (the hot-key input measured 12.9 ms in this kernel against 2.8 ms for uniform
-// keys).  Before the table is touched, the lanes that hold the key of the wave's first pending lane reduce their contributions
-// with a butterfly and leave ONE record; two rounds per batch element take care of the two heaviest keys of a wave.
-__device__ __forceinline__ uint64_t g2_combine(int op, int cls, uint64_t a, uint64_t b) {
-    if (op == AGG_SUM) return cls == CLS_F64 ? d2u(u2d(a) + u2d(b)) : a + b;
-    if (op == AGG_MIN) return a < b ? a : b;
-    return a > b ? a : b;
-}
-template <int B>
-__device__ __forceinline__ void wave_combine(int op, int cls, const uint64_t (&hk)[B], uint64_t (&val)[B], uint32_t (&cnt)[B], uint32_t& pending) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int u = 0; u < B; ++u) {
-        bool active = (pending >> u) & 1;
-#pragma unroll 1
-        for (int round = 0; round < 2; ++round) {
-            const uint64_t m = __ballot(active);
-            if (__popcll(m) < 8) break;
-            const int leader = __builtin_ctzll(m);
-            const uint64_t lk = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(hk[u] >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)hk[u], leader);
-            const bool same = active && hk[u] == lk;
-            if (__popcll(__ballot(same)) >= 8) {
-                uint64_t v = same ? val[u] : agg_identity(op);
-                uint32_t c = same ? cnt[u] : 0u;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    const uint64_t ov = shfl_xor64(v, d);
-                    const uint32_t oc = (uint32_t)__shfl_xor((int)c, d);
-                    v = g2_combine(op, cls, v, ov);
-                    c += oc;
-                }
-                if (lane == leader) { val[u] = v; cnt[u] = c; }
-                else if (same) pending &= ~(1u << u);
-            }
-            active = active && !same;
-        }
-    }
-}
-
 // pass 2: one block per partition; its records are the nb line ranges the scatter blocks wrote
 constexpr int kAggBatch = 4;
 __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2AggArgs a) {
@@ -742,7 +880,7 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
     const unsigned long long ident = agg_identity(a.op);
     uint32_t err = 0;
     const u64x2* const recs = (const u64x2*)a.recs;
-    const bool compact = a.compact != 0;
+    const bool compact = (a.compact & 1) != 0, single = (a.compact & 256) != 0;
     const int L = compact ? kG2LineC : kG2Line;
     const int nitems = a.nwork > 0 ? a.nwork : kP;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
@@ -813,7 +951,8 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
                 if (cur[u][0] != kDead) pending |= 1u << u;
             }
             if (a.nwork > 0) wave_combine<kAggBatch>(a.op, a.vcls, hk, val, cnt, pending);   // skewed input: also the partitions that were not cut hold keys that fill a third of a wave
-            tab_upsert<kAggBatch, kG2PartBits>(t, a.op, a.vcls, a.has_values != 0, 0u, (uint32_t)kG2Slots, hk, val, cnt, pending, err, 32u);   // 32: this partition's LDS table is full — says nothing about max_groups, the host retries on the HBM table
+            if (single) tab_upsert<kAggBatch, kG2PartBits>(t, a.op, a.vcls, a.has_values != 0, 0u, (uint32_t)kG2Slots, hk, val, cnt, pending, err, 32u);
+            else tab_upsert_b4<kAggBatch, kG2PartBits>(t, a.op, a.vcls, a.has_values != 0, hk, val, cnt, pending, err, 32u);   // 32: this partition's LDS table is full — says nothing about max_groups, the host retries on the HBM table
             if (nhave) {
 #pragma unroll
                 for (int u = 0; u < kAggBatch; ++u) cur[u] = nxt[u];
@@ -1052,7 +1191,7 @@ size_t gb2_scatter_lds_bytes(bool compact) {
     return (size_t)kG2Super * 16 + (size_t)kP * (kG2Line - 1) * 16 + bookkeeping;
 }
 hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s) {
-    const size_t lds = (size_t)a.table_slots * 20 + 16 + 48;   // table, group counter, the two special groups
+    const size_t lds = (size_t)a.table_slots * 20 + 16 + 48 + (a.hot_mode ? 8192 + 2048 + 16 : 0);   // table, group counter, the two special groups (, the hot classes' bitmap and the hot keys)
     if (a.fast) {
         (void)hipFuncSetAttribute((const void*)gb2_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(gb2_stream_kernel<true>, dim3(grid), dim3(kStreamBlock), lds, s, a);
@@ -1062,14 +1201,14 @@ hipError_t launch_gb2_stream(const Gb2Args& a, int grid, hipStream_t s) {
     }
     return hipGetLastError();
 }
-hipError_t launch_gb2_skew_probe(const Gb2Args& a, int64_t tile_step, unsigned int* hist, unsigned long long* minmax, hipStream_t s) {
+hipError_t launch_gb2_skew_probe(const Gb2Args& a, int64_t tile_step, unsigned int* hist, unsigned long long* minmax, unsigned int* hbins, unsigned long long* ktab, hipStream_t s) {
     const int64_t sampled = (a.ntiles + tile_step - 1) / tile_step;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((sampled + 3) / 4, 1024));
-    hipLaunchKernelGGL(gb2_skew_probe_kernel, dim3(grid), dim3(256), 0, s, a, tile_step, hist, minmax);
+    hipLaunchKernelGGL(gb2_skew_probe_kernel, dim3(grid), dim3(256), 0, s, a, tile_step, hist, minmax, hbins, ktab);
     return hipGetLastError();
 }
 hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s) {
-    const size_t lds = gb2_scatter_lds_bytes(a.compact != 0);
+    const size_t lds = gb2_scatter_lds_bytes(a.compact != 0) + (a.hot_mode ? 8192 + 2048 : 0);   // (+ the hot classes' bitmap and the hot keys: 79 KB, still two blocks per CU)
     auto go = [&](auto kernel) {
         (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kG2Block), lds, s, a);

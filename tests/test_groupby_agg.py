@@ -320,6 +320,7 @@ def test_groupby_skewed_keys_capacity_plan(gpu, ora, agg):
     tail[-n // 5:] = 17
     lib.set_option("gb_partition", 4)
     lib.set_option("gb_skew_plan", 2)
+    lib.set_option("gb_hot", 0)          # (the heavy-hitter split has a test of its own)
     try:
         for name, kv in (("zipf", zipf), ("hot key", hot), ("late run", tail)):
             kv = kv.copy()
@@ -338,6 +339,48 @@ def test_groupby_skewed_keys_capacity_plan(gpu, ora, agg):
     finally:
         lib.set_option("gb_partition", 3)
         lib.set_option("gb_skew_plan", 1)
+        lib.set_option("gb_hot", 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agg", AGGS)
+def test_groupby_heavy_hitter_split(gpu, ora, agg):
+    """Skewed keys, round 4: the sample's histogram over the hash's top 16 bits names the few dozen classes that hold the heavy
+    hitters; their rows are folded by gb2_stream_kernel (LDS tables per block, same-key lanes reduced by a butterfly first) and
+    merged into a small table in HBM, the scatter path runs over the other rows and both sets of groups are emitted together.
+    Zipf-like keys and one key holding a third of the rows, NULL keys and values, the special keys, 200 000 groups (a hot class
+    shares its 16 hash bits with a few cold keys: they travel with it)."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(404)
+    n, ngroups = 2_300_000, 200_000
+    zipf = np.minimum(rng.zipf(1.15, n), ngroups - 1).astype(np.int64) * 7919 - 3
+    hot = rng.integers(0, ngroups, n).astype(np.int64)
+    hot[rng.uniform(size=n) < 0.34] = 4242
+    lib.set_option("gb_partition", 4)
+    lib.set_option("gb_skew_plan", 2)
+    try:
+        for name, kv in (("zipf", zipf), ("hot key", hot)):
+            kv = kv.copy()
+            kv[5], kv[6], kv[7] = np.iinfo(np.int64).min, np.iinfo(np.int64).max, np.int64(7406324358081711299)
+            keys = [A.HostArray.from_numpy(kv[:n // 3], valid=rng.uniform(size=n // 3) > 0.01, rng=rng), A.HostArray.from_numpy(kv[n // 3:], offset=5, rng=rng)]
+            vals = None if agg == "count" else [A.HostArray.from_numpy(rng.uniform(-1, 1, n // 3), valid=rng.uniform(size=n // 3) > 0.1, rng=rng),
+                                                A.HostArray.from_numpy(rng.uniform(-1, 1, n - n // 3), offset=5, rng=rng)]
+            exp = _groups(*ora.groupby_agg([keys], vals, agg, ngroups + 8))
+            got = _groups(*gpu.groupby_agg([keys], vals, agg, ngroups + 8))
+            assert lib.last_kernel().startswith("gb2_stream_kernel (heavy hitters)"), (name, lib.last_kernel())
+            _assert_same_groups(got, exp, agg != "count", f"heavy hitters: {name} agg={agg}")
+            lib.set_option("gb_hot", 0)              # the same input without the split: the same groups
+            got0 = _groups(*gpu.groupby_agg([keys], vals, agg, ngroups + 8))
+            lib.set_option("gb_hot", 1)
+            assert "heavy hitters" not in lib.last_kernel()
+            _assert_same_groups(got0, exp, agg != "count", f"no split: {name} agg={agg}")
+        with pytest.raises(A.RdfError) as ei:          # the promise still holds on this path
+            gpu.groupby_agg([[A.HostArray.from_numpy(zipf)]], None, "count", 100)
+        assert ei.value.status == A.RDF_MEMORY_ERROR
+    finally:
+        lib.set_option("gb_partition", 3)
+        lib.set_option("gb_skew_plan", 1)
+        lib.set_option("gb_hot", 1)
 
 
 @pytest.mark.gpu

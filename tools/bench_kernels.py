@@ -324,8 +324,17 @@ def main():
             report(f"groupby_sum_{ng}_groups_zipf", 16.0 * n, lambda: api.groupby_sum([arr(kz, A.I64, n)], [X], ng, (ok_, os_, oc_)))
             kh = torch.where(torch.rand(n, device="cuda") < 0.3, torch.full((n,), 7, device="cuda", dtype=torch.int64), kk)
             report(f"groupby_sum_{ng}_groups_hot_key_30pct", 16.0 * n, lambda: api.groupby_sum([arr(kh, A.I64, n)], [X], ng, (ok_, os_, oc_)))
+            lib.set_option("gb_hot", 0)         # A/B: without the heavy-hitter split (round 3: first-generation path / capacity plan)
+            report(f"groupby_sum_{ng}_groups_zipf_no_split", 16.0 * n, lambda: api.groupby_sum([arr(kz, A.I64, n)], [X], ng, (ok_, os_, oc_)))
+            report(f"groupby_sum_{ng}_groups_hot_key_30pct_no_split", 16.0 * n, lambda: api.groupby_sum([arr(kh, A.I64, n)], [X], ng, (ok_, os_, oc_)))
+            lib.set_option("gb_hot", 1)
             ks = (kk * 6364136223846793005 + 1442695040888963407) ^ (kk << 29)     # the same groups under scattered 64-bit key values
             report(f"groupby_sum_{ng}_groups_scattered_keys", 16.0 * n, lambda: api.groupby_sum([arr(ks, A.I64, n)], [X], ng, (ok_, os_, oc_)))
+            lib.set_option("gb_bucket", 1)      # A/B: one key per probe in the aggregate pass's partition tables (round 3)
+            report(f"groupby_sum_{ng}_groups_scattered_keys_single_slot_tables", 16.0 * n, lambda: api.groupby_sum([arr(ks, A.I64, n)], [X], ng, (ok_, os_, oc_)))
+            lib.set_option("gb_bucket", 4)
+            report(f"groupby_sum_{ng}_groups_bucket_tables", 16.0 * n, lambda: api.groupby_sum([KK], [X], ng, (ok_, os_, oc_)))
+            lib.set_option("gb_bucket", 0)
             del ks
             report(f"groupby_sum_{ng}_groups_null_values", 16.125 * n, lambda: api.groupby_sum([KK], [XV], ng, (ok_, os_, oc_)))
             del u, kz, kh
