@@ -2747,8 +2747,6 @@ rdf_status rdf_list_sort(const rdf_list_array* list, rdf_out* out_values) {
     if (total >= (int64_t)1 << 32) return fail(RDF_INVALID_ARGUMENT, "array_sort: more than 2^32-1 child elements");
     const size_t es = (size_t)dtype_size(cdt);
     struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } t_off, t_vals, t_rows, t_idx, t_out;
-    HIP_TRY(hipMalloc(&t_rows.p, (size_t)total * 4 + 64));
-    HIP_TRY(hipMalloc(&t_idx.p, (size_t)total * 4 + 64));
     // device views of the value_offsets and of the child slice
     rdf_array doffs = list->offsets, dvals = list->values;
     if (mem == RDF_MEM_HOST) {
@@ -2764,6 +2762,46 @@ rdf_status rdf_list_sort(const rdf_list_array* list, rdf_out* out_values) {
     memset(&la, 0, sizeof la);
     la.offsets = DevChunkCol{doffs.values, nullptr, doffs.offset};
     la.n = n;
+    rdf_out ov = *out_values;
+    if (mem == RDF_MEM_HOST) { HIP_TRY(hipMalloc(&t_out.p, (size_t)total * es + 64)); ov.values = t_out.p; ov.validity = nullptr; ov.mem = RDF_MEM_DEVICE; }
+    else ov.validity = nullptr;
+    {
+        // rows sorted where they lie, keys in LDS (rdf_list.hip: list_sort_lane_kernel / list_sort_block_kernel); a row beyond
+        // 4096 elements sends the call through the radix sort below
+        arena_begin();
+        void* pw = nullptr;
+        RDF_TRY(arena_alloc(((size_t)n + 4) * 4 + 64, &pw));
+        uint32_t* wc = (uint32_t*)pw;
+        HIP_TRY(hipMemsetAsync(wc, 0, 16, ctx.stream));
+        la.values = DevChunkCol{dvals.values, nullptr, dvals.offset};
+        la.dtype = cdt;
+        la.count = (int32_t)first;
+        la.out = DevOutChunk{ov.values, nullptr};
+        la.work_count = wc;
+        la.work = wc + 4;
+        KernelTimer kt;
+        HIP_TRY(launch_list_sort(la, total / std::max<int64_t>(n, 1) < 24, ctx.stream));
+        kt.stop();
+        RDF_TRY(pinned_reserve(64));
+        HIP_TRY(hipMemcpyAsync(ctx.pinned, wc, 8, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        uint32_t hw[2];
+        memcpy(hw, ctx.pinned, 8);
+        if (!(hw[1] & 1u)) {
+            if (mem == RDF_MEM_HOST) RDF_TRY(rdf_copy_d2h(out_values->values, t_out.p, total * (int64_t)es));
+            if (out_values->validity) {
+                if (mem == RDF_MEM_HOST) memset(out_values->validity, 0xFF, (size_t)((total + 7) / 8));
+                else { HIP_TRY(hipMemsetAsync(out_values->validity, 0xFF, (size_t)((total + 7) / 8), ctx.stream)); HIP_TRY(hipStreamSynchronize(ctx.stream)); }
+            }
+            out_values->length = total;
+            out_values->null_count = 0;
+            ctx.last_kernel = "list_sort_lane_kernel + list_sort_block_kernel";
+            return RDF_OK;
+        }
+        la.work = nullptr; la.work_count = nullptr; la.count = 0;
+    }
+    HIP_TRY(hipMalloc(&t_rows.p, (size_t)total * 4 + 64));
+    HIP_TRY(hipMalloc(&t_idx.p, (size_t)total * 4 + 64));
     HIP_TRY(launch_list_row_ids(la, (uint32_t*)t_rows.p, (int32_t)first, ctx.stream));
     HIP_TRY(hipStreamSynchronize(ctx.stream));
     rdf_array cols[2];
@@ -2772,9 +2810,6 @@ rdf_status rdf_list_sort(const rdf_list_array* list, rdf_out* out_values) {
     rdf_out oi{t_idx.p, nullptr, total, 0, 0, RDF_U32, RDF_MEM_DEVICE};
     RDF_TRY(rdf_sort_to_indices(cols, 2, 1, nullptr, &oi));
     rdf_array idx{t_idx.p, nullptr, 0, total, 0, RDF_U32, RDF_MEM_DEVICE};
-    rdf_out ov = *out_values;
-    if (mem == RDF_MEM_HOST) { HIP_TRY(hipMalloc(&t_out.p, (size_t)total * es + 64)); ov.values = t_out.p; ov.validity = nullptr; ov.mem = RDF_MEM_DEVICE; }
-    else ov.validity = nullptr;
     RDF_TRY(rdf_take(&dvals, 1, &idx, &ov));
     if (mem == RDF_MEM_HOST) RDF_TRY(rdf_copy_d2h(out_values->values, t_out.p, total * (int64_t)es));
     if (out_values->validity) {

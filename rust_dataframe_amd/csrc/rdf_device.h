@@ -664,6 +664,7 @@ hipError_t launch_list_op(const ListArgs& a, bool wave_per_row, hipStream_t s);
 hipError_t launch_list_row_ids(const ListArgs& a, uint32_t* row_ids, int32_t first, hipStream_t s);
 hipError_t launch_list_remove(const ListArgs& a, bool wave_per_row, hipStream_t s);
 hipError_t launch_list_set(const ListArgs& a, bool wave_per_row, hipStream_t s);   // distinct / except / intersect / union / repeat
+hipError_t launch_list_sort(const ListArgs& a, bool lane_first, hipStream_t s);   // rows sorted in LDS; a.count = child index of the first element, a.work_count[1] = flag "a row too long"
 hipError_t launch_list_offsets(const int64_t* scan, int64_t n1, int32_t* out, hipStream_t s);
 
 // ---- launch wrappers (defined in rdf_kernels.hip) ----

@@ -412,6 +412,7 @@ hipError_t launch_list_remove(const ListArgs& a, bool wave_per_row, hipStream_t 
 //                          element, in device scratch) maps a value to the SMALLEST element index holding it
 //                          (CAS to claim a slot, atomicMin on the index); "first occurrence" and "member of b" are then
 //                          table lookups.  Pass 1 builds the tables and counts, pass 2 only looks up.
+constexpr int kSetBlockMax = 1024;   // elements per input of a row the block-per-row kernel takes (tables in LDS)
 constexpr int kSetStage = 768;   // child elements of each input (and of the output) staged per wave: 72 KiB per block for 8-byte children
 constexpr uint32_t kSetEmpty = 0xFFFFFFFFu;
 
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(kBlock) void list_set_wave_kernel(const ListArgs a)
         const int32_t ba = lvalid ? offa[row] : 0, ea = lvalid ? offa[row + 1] : 0;
         const int32_t bb = lvalid && two ? offb[row] : 0, eb = lvalid && two ? offb[row + 1] : 0;
         int64_t o = a.scan ? a.scan[row] : 0, c = 0;
+        if (a.op != LIST_REPEAT && ea - ba <= kSetBlockMax && eb - bb <= kSetBlockMax) continue;   // list_set_block_kernel took this row
         if (a.op == LIST_REPEAT) {
             const int64_t len = ea - ba, total = len * a.count;
             if (a.scan) for (int64_t t = lane; t < total; t += 64) as_global_mut<T>(a.out.values)[o + t] = va[ba + t % len];
@@ -601,6 +603,147 @@ __global__ __launch_bounds__(kBlock) void list_set_wave_kernel(const ListArgs a)
         if (!a.scan && lane == 0) a.kept[row] = c;
     }
 }
+//   list_set_block_kernel: one row per 256-thread BLOCK for rows of up to kSetBlockMax elements per input — the row's values and
+//                          its value -> smallest-index tables live in LDS (CAS / min there, no global atomics, no scratch
+//                          traffic): rows of 1000 elements ran at 0.017 of the HBM roofline through the global-scratch tables
+//                          of the row-per-wave kernel, which keeps the rows longer than this.
+
+template <class T>
+struct SetTableLds {
+    uint32_t* tab;         // [2 * kSetBlockMax] LDS
+    const T* vals;         // LDS copy of the row
+    uint32_t size;         // power of two >= 2 * elements
+    __device__ __forceinline__ uint32_t home(T v) const { return set_hash<T>(v) & (size - 1); }
+    __device__ __forceinline__ void insert(uint32_t i, T v) const {
+        uint32_t s = home(v);
+        for (;;) {
+            uint32_t cur = tab[s];
+            if (cur == kSetEmpty) {
+                cur = atomicCAS(tab + s, kSetEmpty, i);
+                if (cur == kSetEmpty) return;
+            }
+            if (vals[cur] == v) { atomicMin(tab + s, i); return; }
+            s = (s + 1) & (size - 1);
+        }
+    }
+    __device__ __forceinline__ uint32_t find(T v) const {
+        if (size == 0) return kSetEmpty;
+        uint32_t s = home(v);
+        for (;;) {
+            const uint32_t cur = tab[s];
+            if (cur == kSetEmpty || vals[cur] == v) return cur;
+            s = (s + 1) & (size - 1);
+        }
+    }
+};
+template <class T>
+__global__ __launch_bounds__(kBlock) void list_set_block_kernel(const ListArgs a) {
+    // dynamic LDS: the row's values + its table, twice for the two-input functions (one-input calls get twice the blocks per CU)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    T* const sa = (T*)lsm;
+    uint32_t* const ta_ = (uint32_t*)(sa + kSetBlockMax);
+    T* const sb = (T*)(ta_ + 2 * kSetBlockMax);
+    uint32_t* const tb_ = (uint32_t*)(sb + kSetBlockMax);
+    __shared__ uint32_t wtot[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const GlobalPtr<int32_t> offa = as_global<int32_t>(a.offsets.values) + a.offsets.offset;
+    const GlobalPtr<T> va = as_global<T>(a.values.values) + a.values.offset;
+    const bool two = a.op == LIST_EXCEPT || a.op == LIST_INTERSECT || a.op == LIST_UNION;
+    const GlobalPtr<int32_t> offb = two ? as_global<int32_t>(a.offsets_b.values) + a.offsets_b.offset : offa;
+    const GlobalPtr<T> vb = two ? as_global<T>(a.values_b.values) + a.values_b.offset : va;
+    const int64_t nwork = a.work ? (int64_t)*a.work_count : a.n;
+    for (int64_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const int64_t row = a.work ? (int64_t)a.work[wi] : wi;
+        bool lvalid = true;
+        if (a.offsets.validity) { const int64_t bi = a.offsets.offset + row; lvalid = (as_global<uint8_t>(a.offsets.validity)[bi >> 3] >> (bi & 7)) & 1; }
+        const int32_t ba = lvalid ? offa[row] : 0, ea = lvalid ? offa[row + 1] : 0;
+        const int32_t bb = lvalid && two ? offb[row] : 0, eb = lvalid && two ? offb[row + 1] : 0;
+        const int32_t na = ea - ba, nb = eb - bb;
+        if (na > kSetBlockMax || nb > kSetBlockMax) continue;           // the row-per-wave kernel's
+        uint32_t sza = 2, szb = 2;
+        while ((int32_t)sza < 2 * na) sza <<= 1;
+        while ((int32_t)szb < 2 * nb) szb <<= 1;
+        __syncthreads();                                                  // the previous row's tables are done with
+        for (int32_t i = tid; i < na; i += kBlock) sa[i] = va[ba + i];
+        for (int32_t i = tid; i < nb; i += kBlock) sb[i] = vb[bb + i];
+        for (uint32_t i = tid; i < sza; i += kBlock) ta_[i] = kSetEmpty;
+        if (two) for (uint32_t i = tid; i < szb; i += kBlock) tb_[i] = kSetEmpty;       // (one-input calls have no second table in their LDS)
+        __syncthreads();
+        const SetTableLds<T> ta{ta_, sa, na ? sza : 0u}, tb{tb_, sb, nb ? szb : 0u};
+        for (int32_t i = tid; i < na; i += kBlock) { const T v = sa[i]; if (!list_is_nan(v)) ta.insert((uint32_t)i, v); }
+        for (int32_t i = tid; i < nb; i += kBlock) { const T v = sb[i]; if (!list_is_nan(v)) tb.insert((uint32_t)i, v); }
+        __syncthreads();
+        // Pass 1 (this code): the keep bit of every candidate, as one ballot word per (chunk of kBlock candidates, wave), left in the
+        // row's own slice of the scratch tables (8 bytes per element are reserved there, a row needs 1 bit per element) — pass 2
+        // ranks and writes from those words alone: no table is built twice.
+        unsigned long long* const mask_a = (unsigned long long*)(a.tab_a + 2 * (int64_t)ba);     // [ceil(na / 64)] words (<= 16)
+        unsigned long long* const mask_b = (unsigned long long*)(a.tab_b + 2 * (int64_t)bb);
+        uint32_t c = 0;
+        for (int32_t i0 = 0; i0 < na; i0 += kBlock) {   // candidates from a: first occurrence in a (+ the b membership rule)
+            const int32_t i = i0 + tid;
+            const bool have = i < na;
+            const T v = have ? sa[i] : (T)0;
+            bool keep = false;
+            if (have) {
+                const bool nan = list_is_nan(v);
+                keep = nan || ta.find(v) == (uint32_t)i;
+                if (a.op == LIST_EXCEPT) keep = keep && (nan || tb.find(v) == kSetEmpty);
+                if (a.op == LIST_INTERSECT) keep = keep && !nan && tb.find(v) != kSetEmpty;
+            }
+            const uint64_t m = __ballot(keep);
+            if (lane == 0 && i0 + w * 64 < na) mask_a[(i0 >> 6) + w] = m;
+            c += (uint32_t)__popcll(m);
+        }
+        if (a.op == LIST_UNION)
+            for (int32_t i0 = 0; i0 < nb; i0 += kBlock) {   // candidates from b: not in a, first occurrence in b
+                const int32_t i = i0 + tid;
+                const bool have = i < nb;
+                const T v = have ? sb[i] : (T)0;
+                bool keep = false;
+                if (have) keep = list_is_nan(v) || (tb.find(v) == (uint32_t)i && ta.find(v) == kSetEmpty);
+                const uint64_t m = __ballot(keep);
+                if (lane == 0 && i0 + w * 64 < nb) mask_b[(i0 >> 6) + w] = m;
+                c += (uint32_t)__popcll(m);
+            }
+        if (lane == 0) wtot[w] = c;
+        __syncthreads();
+        if (tid == 0) { uint32_t t = 0; for (int k = 0; k < kBlock / 64; ++k) t += wtot[k]; a.kept[row] = t; }
+    }
+}
+// pass 2 of the same rows: a wave per row, the keep words of pass 1 -> ranks -> the kept elements at the row's scanned offset
+template <class T>
+__global__ __launch_bounds__(kBlock) void list_set_block_write_kernel(const ListArgs a) {
+    const int lane = threadIdx.x & 63;
+    const GlobalPtr<int32_t> offa = as_global<int32_t>(a.offsets.values) + a.offsets.offset;
+    const GlobalPtr<T> va = as_global<T>(a.values.values) + a.values.offset;
+    const bool two = a.op == LIST_EXCEPT || a.op == LIST_INTERSECT || a.op == LIST_UNION;
+    const GlobalPtr<int32_t> offb = two ? as_global<int32_t>(a.offsets_b.values) + a.offsets_b.offset : offa;
+    const GlobalPtr<T> vb = two ? as_global<T>(a.values_b.values) + a.values_b.offset : va;
+    const int64_t nwork = a.work ? (int64_t)*a.work_count : a.n;
+    for (int64_t wi = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); wi < nwork; wi += (int64_t)gridDim.x * (kBlock / 64)) {
+        const int64_t row = a.work ? (int64_t)a.work[wi] : wi;
+        bool lvalid = true;
+        if (a.offsets.validity) { const int64_t bi = a.offsets.offset + row; lvalid = (as_global<uint8_t>(a.offsets.validity)[bi >> 3] >> (bi & 7)) & 1; }
+        const int32_t ba = lvalid ? offa[row] : 0, ea = lvalid ? offa[row + 1] : 0;
+        const int32_t bb = lvalid && two ? offb[row] : 0, eb = lvalid && two ? offb[row + 1] : 0;
+        const int32_t na = ea - ba, nb = eb - bb;
+        if (na > kSetBlockMax || nb > kSetBlockMax) continue;
+        int64_t o = a.scan[row];
+        const unsigned long long* const mask_a = (const unsigned long long*)(a.tab_a + 2 * (int64_t)ba);
+        const unsigned long long* const mask_b = (const unsigned long long*)(a.tab_b + 2 * (int64_t)bb);
+        for (int32_t i0 = 0; i0 < na; i0 += 64) {
+            const uint64_t m = mask_a[i0 >> 6];
+            if ((m >> lane) & 1) as_global_mut<T>(a.out.values)[o + __popcll(m & ((1ull << lane) - 1))] = va[ba + i0 + lane];
+            o += __popcll(m);
+        }
+        if (a.op == LIST_UNION)
+            for (int32_t i0 = 0; i0 < nb; i0 += 64) {
+                const uint64_t m = mask_b[i0 >> 6];
+                if ((m >> lane) & 1) as_global_mut<T>(a.out.values)[o + __popcll(m & ((1ull << lane) - 1))] = vb[bb + i0 + lane];
+                o += __popcll(m);
+            }
+    }
+}
 // wave_per_row: every row through the table kernel; otherwise the row-per-lane kernel first and the table kernel over
 // the worklist it left behind (nothing to do when no group of 64 rows overflowed the staging area)
 hipError_t launch_list_set(const ListArgs& a, bool wave_per_row, hipStream_t s) {
@@ -611,11 +754,161 @@ hipError_t launch_list_set(const ListArgs& a, bool wave_per_row, hipStream_t s) 
         const int grid = (int)grid64;
         RDF_LIST_DISPATCH(list_set_kernel)
     }
+    if (a.op != LIST_REPEAT) {   // rows of up to kSetBlockMax elements per input (every row, or what the row-per-lane kernel left): tables in LDS
+        if (!a.scan) {
+            const bool two_in = a.op == LIST_EXCEPT || a.op == LIST_INTERSECT || a.op == LIST_UNION;
+            const int es = a.dtype == RDF_I8 || a.dtype == RDF_U8 ? 1 : a.dtype == RDF_I16 || a.dtype == RDF_U16 ? 2 : a.dtype == RDF_I32 || a.dtype == RDF_U32 || a.dtype == RDF_F32 ? 4 : 8;
+            const size_t lds = (size_t)(two_in ? 2 : 1) * (size_t)kSetBlockMax * (size_t)(es + 8);   // <= 32 KB
+            const int per_cu = (int)std::min<size_t>(8, (size_t)(150 * 1024) / lds);
+            int64_t grid64 = wave_per_row ? a.n : eval_grid_limit();
+            if (grid64 > per_cu * (int64_t)(eval_grid_limit() / 8)) grid64 = per_cu * (int64_t)(eval_grid_limit() / 8);
+            const int grid = (int)(grid64 < 1 ? 1 : grid64);
+#define RDF_LIST_DISPATCH_LDS(KERNEL)                                                                                       \
+    switch (a.dtype) {                                                                                                      \
+        case RDF_I8: hipLaunchKernelGGL((KERNEL<int8_t>), dim3(grid), dim3(kBlock), lds, s, a); break;                      \
+        case RDF_I16: hipLaunchKernelGGL((KERNEL<int16_t>), dim3(grid), dim3(kBlock), lds, s, a); break;                    \
+        case RDF_I32: hipLaunchKernelGGL((KERNEL<int32_t>), dim3(grid), dim3(kBlock), lds, s, a); break;                    \
+        case RDF_I64: hipLaunchKernelGGL((KERNEL<int64_t>), dim3(grid), dim3(kBlock), lds, s, a); break;                    \
+        case RDF_U8: hipLaunchKernelGGL((KERNEL<uint8_t>), dim3(grid), dim3(kBlock), lds, s, a); break;                     \
+        case RDF_U16: hipLaunchKernelGGL((KERNEL<uint16_t>), dim3(grid), dim3(kBlock), lds, s, a); break;                   \
+        case RDF_U32: hipLaunchKernelGGL((KERNEL<uint32_t>), dim3(grid), dim3(kBlock), lds, s, a); break;                   \
+        case RDF_U64: hipLaunchKernelGGL((KERNEL<uint64_t>), dim3(grid), dim3(kBlock), lds, s, a); break;                   \
+        case RDF_F32: hipLaunchKernelGGL((KERNEL<float>), dim3(grid), dim3(kBlock), lds, s, a); break;                      \
+        default: hipLaunchKernelGGL((KERNEL<double>), dim3(grid), dim3(kBlock), lds, s, a); break;                          \
+    }
+            RDF_LIST_DISPATCH_LDS(list_set_block_kernel)
+#undef RDF_LIST_DISPATCH_LDS
+        } else {
+            int64_t grid64 = wave_per_row ? (a.n + (kBlock / 64) - 1) / (kBlock / 64) : eval_grid_limit();
+            if (grid64 > eval_grid_limit()) grid64 = eval_grid_limit();
+            const int grid = (int)(grid64 < 1 ? 1 : grid64);
+            RDF_LIST_DISPATCH(list_set_block_write_kernel)
+        }
+    }
     {
         int64_t grid64 = wave_per_row ? (a.n + (kBlock / 64) - 1) / (kBlock / 64) : eval_grid_limit();
         if (grid64 > eval_grid_limit()) grid64 = eval_grid_limit();
         const int grid = (int)grid64;
         RDF_LIST_DISPATCH(list_set_wave_kernel)
+    }
+    return hipGetLastError();
+}
+// ------------------------------------------------------------------------------------------------
+// array_sort (array.rs:328-354: every row's slice sorted ascending, value_offsets unchanged).  Rows are sorted where they
+// lie — keys in LDS — instead of through a (row id, value) two-column radix sort of the whole child array plus a take
+// (rows of 10 elements: 0.011 of the HBM roofline that way):
+//   list_sort_lane_kernel  : a row per lane over runs of consecutive short rows (<= kSortLaneMax elements each) whose span fits
+//                            the wave's staging area — loaded and written back coalesced, insertion-sorted in LDS by their lanes;
+//                            anything longer goes to a worklist
+//   list_sort_block_kernel : a row per 256-thread block, up to kSortBlockMax elements: bitonic network over the row's
+//                            order-preserving keys (ListKey: IEEE total order for floats), padded with the largest key
+// A row longer than that raises a flag and the host sends the whole call through the radix sort as before.
+constexpr int kSortStage = 1024, kSortLaneMax = 40, kSortBlockMax = 4096;
+template <class T> struct SortKeyOf { typedef uint32_t type; };
+template <> struct SortKeyOf<double> { typedef uint64_t type; };
+template <> struct SortKeyOf<int64_t> { typedef uint64_t type; };
+template <> struct SortKeyOf<uint64_t> { typedef uint64_t type; };
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void list_sort_lane_kernel(const ListArgs a) {
+    using K = typename SortKeyOf<T>::type;
+    __shared__ K st[kBlock / 64][kSortStage];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const GlobalPtr<int32_t> off = as_global<int32_t>(a.offsets.values) + a.offsets.offset;
+    const int32_t first = a.count;                                   // child index of the slice's first element
+    const GlobalPtr<T> va = as_global<T>(a.values.values) + a.values.offset - first;
+    const GlobalMutPtr<T> out = as_global_mut<T>(a.out.values) - first;
+    const int64_t nwaves = (a.n + 63) >> 6;
+    for (int64_t wv = (int64_t)blockIdx.x * (kBlock / 64) + w; wv < nwaves; wv += (int64_t)gridDim.x * (kBlock / 64)) {
+        const int64_t row = wv * 64 + lane;
+        const bool inr = row < a.n;
+        const int32_t lo = off[inr ? row : a.n], hi = off[inr ? row + 1 : a.n];
+        const int nrows = a.n - wv * 64 < 64 ? (int)(a.n - wv * 64) : 64;
+        for (int start = 0; start < nrows;) {
+            const int32_t a0 = __shfl(lo, start);
+            const bool fits = lane >= start && inr && hi - a0 <= kSortStage && hi - lo <= kSortLaneMax;
+            const uint64_t m = __ballot(fits) >> start;
+            const int cnt = m == ~0ull ? 64 - start : __builtin_ctzll(~m);       // the run [start, start + cnt)
+            if (cnt == 0) {   // this row is too long for a lane: the block kernel's
+                if (lane == start && hi - lo > 1) a.work[atomicAdd(a.work_count, 1u)] = (uint32_t)row;
+                else if (lane == start && hi - lo == 1) out[lo] = va[lo];
+                ++start;
+                continue;
+            }
+            const int last = start + cnt - 1;
+            const int32_t an = __shfl(hi, last) - a0;
+            for (int32_t i = lane; i < an; i += 64) st[w][i] = (K)ListKey<T>::key(va[a0 + i]);
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= start && lane <= last) {
+                K* r = &st[w][lo - a0];
+                const int len = hi - lo;
+                for (int i = 1; i < len; ++i) {
+                    const K x = r[i];
+                    int j = i - 1;
+                    while (j >= 0 && r[j] > x) { r[j + 1] = r[j]; --j; }
+                    r[j + 1] = x;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int32_t i = lane; i < an; i += 64) out[a0 + i] = ListKey<T>::unkey((uint64_t)st[w][i]);
+            __builtin_amdgcn_wave_barrier();
+            start += cnt;
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void list_sort_block_kernel(const ListArgs a) {
+    using K = typename SortKeyOf<T>::type;
+    __shared__ K sk[kSortBlockMax];
+    const int tid = threadIdx.x;
+    const GlobalPtr<int32_t> off = as_global<int32_t>(a.offsets.values) + a.offsets.offset;
+    const int32_t first = a.count;
+    const GlobalPtr<T> va = as_global<T>(a.values.values) + a.values.offset - first;
+    const GlobalMutPtr<T> out = as_global_mut<T>(a.out.values) - first;
+    const int64_t nwork = a.work ? (int64_t)*a.work_count : a.n;
+    for (int64_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const int64_t row = a.work ? (int64_t)a.work[wi] : wi;
+        const int32_t lo = off[row], hi = off[row + 1], len = hi - lo;
+        if (len <= 0) continue;
+        if (len > kSortBlockMax) { if (tid == 0) atomicOr(a.work_count + 1, 1u); continue; }     // the host falls back to the radix sort
+        int N = 2;
+        while (N < len) N <<= 1;
+        __syncthreads();
+        for (int i = tid; i < N; i += kBlock) sk[i] = i < len ? (K)ListKey<T>::key(va[lo + i]) : (K)~(K)0;
+        __syncthreads();
+        for (int k = 2; k <= N; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < N / 2; t += kBlock) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // the lower index of pair t at distance j
+                    const int p = i | j;
+                    const bool up = (i & k) == 0;
+                    const K x = sk[i], y = sk[p];
+                    if ((x > y) == up) { sk[i] = y; sk[p] = x; }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < len; i += kBlock) out[lo + i] = ListKey<T>::unkey((uint64_t)sk[i]);
+    }
+}
+// lane_first: short rows on average — the row-per-lane kernel first, the block kernel over its worklist; otherwise every row
+// through the block kernel.  a.work: [n] row numbers, a.work_count: [0] worklist length, [1] flag "a row beyond kSortBlockMax"
+hipError_t launch_list_sort(const ListArgs& a, bool lane_first, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    if (lane_first) {
+        int64_t grid64 = ((a.n + 63) / 64 + (kBlock / 64) - 1) / (kBlock / 64);
+        if (grid64 > eval_grid_limit()) grid64 = eval_grid_limit();
+        const int grid = (int)grid64;
+        RDF_LIST_DISPATCH(list_sort_lane_kernel)
+    }
+    {
+        ListArgs b = a;
+        if (!lane_first) b.work = nullptr;
+        const ListArgs& a = b;
+        int64_t grid64 = lane_first ? eval_grid_limit() / 2 : a.n;
+        if (grid64 > 5 * (int64_t)(eval_grid_limit() / 8)) grid64 = 5 * (int64_t)(eval_grid_limit() / 8);
+        const int grid = (int)(grid64 < 1 ? 1 : grid64);
+        RDF_LIST_DISPATCH(list_sort_block_kernel)
     }
     return hipGetLastError();
 }

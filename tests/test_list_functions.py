@@ -124,7 +124,7 @@ def random_lists(rng, dtype, nrows, max_len, null_frac):
 def test_list_functions_parity(gpu, ora, dtype):
     rng = np.random.default_rng(5000 + dtype)
     needle = 2.0 if dtype in (A.F32, A.F64) else 2
-    for nrows, max_len, nf, off in [(1, 0, 0.0, 0), (200, 6, 0.1, 0), (3000, 12, 0.05, 3), (70, 400, 0.1, 1), (5, 5000, 0.0, 0)]:
+    for nrows, max_len, nf, off in [(1, 0, 0.0, 0), (200, 6, 0.1, 0), (3000, 12, 0.05, 3), (70, 400, 0.1, 1), (40, 3000, 0.0, 2), (500, 60, 0.05, 0), (5, 5000, 0.0, 0)]:
         lst = A.HostList.from_lists(random_lists(rng, dtype, nrows, max_len, nf), dtype, row_offset=off)
         what = f"dtype={dtype} rows={nrows} max_len={max_len}"
         g, o = gpu.list_contains(lst, needle), ora.list_contains(lst, needle)
