@@ -68,6 +68,7 @@ struct Ctx {
     int    opt_gb_skew_plan = 1;    // skewed keys: per-partition region sizes + big partitions cut into several aggregate items (1 = when the probe finds skew, default; 0 = the first-generation combining path instead, A/B; 2 = always, tests)
     int    opt_gb_compact = 1;      // partition path, keys inside a window of 2^39: 1 = 4-byte records when only rows are counted (default); 2 = also 12-byte records (key word + value) for the other aggregates (measured slower than 16-byte records, kept for A/B); 0 = 16-byte records always
     int64_t opt_comm_max_bytes = 0;  // group-by exchange: most bytes one ncclSend / peer copy moves (0 = 256 MiB); larger shares travel in several rounds
+    int    opt_spec_blocks = 0;     // resident blocks of the specialised kernels per CU (persistent grid = CUs x this); 0 = by the program (4 / 5 / 8, see run_program)
     int    opt_gb_hot = 1;          // skewed keys: 1 = heavy-hitter split (the hot hash classes through gb2_stream_kernel, the scatter path over the rest), default; 0 = capacity plan / first-generation path as in round 3 (A/B)
     int    opt_gb_bucket = 0;       // partition tables of the aggregate pass: 4 = four keys per 32-byte bucket, 1 = one key per probe, 0 = by the sampled key range (default: one key per probe for keys packed into <= 4 x max_groups values, buckets otherwise)
     int    opt_gb_partition = 3;    // hash GROUP BY: 3 = second generation (rdf_groupby.hip: stream / line-aligned scatter / table by max_groups, default), 4 = its partition path whatever max_groups says, 1 = first-generation histogram + scatter, 2 = first-generation radix sort, 0 = one table in HBM
@@ -148,6 +149,7 @@ rdf_status ensure_ready() {
         return fail(RDF_DEVICE_ERROR, "device %d is %s; this library carries gfx950 (MI355X) code only", c.device, prop.gcnArchName);
     HIP_TRY(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
     c.stream = c.own_stream;
+    if (const char* e = getenv("RDF_SPEC_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 0 && v <= 8) c.opt_spec_blocks = v; }   // (A/B without touching the caller)
     c.ready = true;
     return RDF_OK;
 }
@@ -1474,7 +1476,22 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             sa.outs_tab = stb.dev_at<DevOutChunk>(o_o);
         }
         const int64_t btiles = (sa.ntiles + kBlock / 64 - 1) / (kBlock / 64);   // a block's waves take consecutive tiles
-        grid = (int)(btiles < (int64_t)eval_grid_limit() ? btiles : (int64_t)eval_grid_limit());
+        // Resident blocks per CU of the persistent grid.  More is not always better on this part: a one-column filter -> aggregate
+        // over a column without a bitmap keeps 128 KB per CU in flight with eight blocks and runs at 0.826-0.844 of the HBM peak;
+        // with three (48 KB in flight) at 0.876-0.879, with four 0.866-0.868, with five 0.824-0.830 (bench.py, same box, three
+        // alternating rounds; tools/ubench_stream's bare loop shows the same: 4 blocks x 64 B per lane 0.86-0.88, 8 blocks 0.80).
+        // Programs over several columns, with bitmaps, or with a store sink measured within the box-to-box noise at 4-6 blocks
+        // and keep eight.  rdf_set_option("spec_blocks_per_cu", n) pins a value (A/B).
+        int blocks_per_cu = ctx.opt_spec_blocks;
+        if (blocks_per_cu <= 0) {
+            bool any_bitmap = false;
+            for (int k = 0; k < sp.ncols; ++k) any_bitmap |= fc ? fc->col_nullable[sp.col_map[k]] : (nchunks > 0 && in_dev[(size_t)((int64_t)sp.col_map[k] * nchunks)].validity != nullptr);
+            bool heavy = false;
+            for (int i = 0; i < ps.nnodes; ++i) heavy |= ps.nodes[i].kind == RDF_NODE_OP && op_is_heavy(ps.nodes[i].op);
+            blocks_per_cu = (ps.sink == RDF_SINK_AGG && sp.ncols == 1 && !any_bitmap && !heavy && nchunks == 1) ? 3 : 8;
+        }
+        const int64_t spec_limit = (int64_t)(eval_grid_limit() / 8) * std::max(1, std::min(8, blocks_per_cu));
+        grid = (int)(btiles < spec_limit ? btiles : spec_limit);
         if (grid < 1) grid = 1;
         d_result = d_partials + (size_t)grid * (size_t)ps.nvalues;
     }
@@ -3941,6 +3958,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "gb_compact") == 0) g_ctx.opt_gb_compact = (int)value;
     else if (strcmp(name, "gb_bucket") == 0) g_ctx.opt_gb_bucket = (int)value;
     else if (strcmp(name, "gb_hot") == 0) g_ctx.opt_gb_hot = (int)value;
+    else if (strcmp(name, "spec_blocks_per_cu") == 0) g_ctx.opt_spec_blocks = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
     else if (strcmp(name, "comm_max_bytes") == 0) g_ctx.opt_comm_max_bytes = value;
