@@ -617,6 +617,9 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * "filter_fused" (rdf_filter_frame with a `column CMP literal [AND | OR column CMP literal]` predicate over 4- / 8-byte columns: 1 = the
  * predicate runs inside the compaction kernel, one pass, when no batch is longer than 65 536 rows, default; 2 = always; 0 = predicate -> mask,
  * count, compact),
+ * "sort_msd" (keys that vary in 25 bits or more: 1 = passes over the top bits, buckets finished in LDS, default; 0 = one pass per byte),
+ * "sort_sample" (Float64 sort keys: 1 = the value buckets of those passes are planned from a sample of the keys — the range the rows lie
+ * in without far outliers / infinities / NaNs, as many bucket bits as the densest region needs —, default; 0 = [min, max], ~500 rows per bucket),
  * "stream_slab_bytes" (rdf_pipeline over host memory: bytes per slab of the streamed batch loop, 0 = 256 MiB, -1 = never stream),
  * "comm_max_bytes" (most bytes one ncclSend / peer copy of the group-by exchange moves, default 256 MiB: larger shares go in
  * several rounds; every rank of a communicator must use the same value). */

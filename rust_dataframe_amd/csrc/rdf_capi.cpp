@@ -62,6 +62,7 @@ struct Ctx {
     int    opt_sort_gen = 3;        // radix passes: 3 = one read + one write of the pairs per digit, decoupled look-back between 4096-pair tiles (rdf_sort.hip, default); 2 = count -> scan -> scatter over static tile ranges with the same wave-ranked tiles (A/B: slower, see rdf_sort.hip); 1 = first generation (rdf_kernels.hip)
     bool   sort_used_local = false; // the last sort finished at least one column with os_local_kernel
     int    opt_sort_msd = 1;        // sort keys that vary in more than 32 bits: passes over the top bits, then every bucket sorted in LDS (1, default); 0 = one pass per byte (A/B)
+    int    opt_sort_sample = 1;     // doubles: value buckets planned from a sample of the keys (range without outliers, bucket bits from the densest region); 0 = [min, max] and ~500 rows per bucket (round 3, A/B)
     int    opt_join_table = 1;      // equi-join on one key column: probe a table of the distinct build keys (1, default); 0 = the bucket index over the sorted build keys (A/B)
     int    opt_jit = 1;             // a program shape outside the catalogs: 1 = compile spec_kernel<Prog> for it on a helper thread (the interpreter answers until the kernel is ready; a code object in the cache directory is loaded at once), default; 2 = the call waits for the compiler; 0 = always the interpreter
     int    opt_take_rows = 1;       // take over a frame through interleaved row records: 1 = when the transaction model says so (default), 0 = never, 2 = always (tests, A/B)
@@ -2942,6 +2943,7 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
     // 3.35 ms but sends normally distributed ones to the byte passes, 5.5 instead of 4.3 ms)
     const int per_bucket = f64_keys ? 512 : 1800;
     int B = 12;
+    bool sampled = false;                     // the bucket bits of a column of doubles were planned from a sample
     while ((n >> B) > 512 && B < 24) ++B;
     if (!f64_keys) {
         int np = 1;
@@ -2952,11 +2954,87 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
     if (f64_keys && range != ~0ull) {
         // doubles: sign and exponent crowd the key bits' top patterns, so the buckets are cut in VALUE space (OsBucket)
         auto value_of = [&](uint64_t stored) { const uint64_t ord = f64_keys == 2 ? ~stored : stored; const uint64_t b = (ord >> 63) ? (ord ^ 0x8000000000000000ull) : ~ord; double x; memcpy(&x, &b, 8); return x; };
-        const double x0 = value_of(bias), x1 = value_of(bias + range), lo = std::min(x0, x1), hi = std::max(x0, x1);
+        const double x0 = value_of(bias), x1 = value_of(bias + range);
+        double lo = std::min(x0, x1), hi = std::max(x0, x1);
+        if (!(lo == lo) || !(hi == hi)) { lo = -HUGE_VAL; hi = HUGE_VAL; }          // a NaN at either end of the key range
+        // The bucket map is linear between lo and hi and clamps outside, so what it needs is the range the ROWS lie in, not the
+        // range of the keys: a few far outliers, infinities or NaNs would stretch [min, max] until every other row shares a
+        // bucket.  A sample of <= 8192 keys gives that range (extended by half its width on either side: the tails of 1e9 draws
+        // of a bell curve reach 1.6 x as far as those of 8192) and the densest of 64 coarse value bins, from which the number
+        // of bucket bits is chosen so that the densest bucket is expected well inside the LDS finish — uniform doubles then
+        // take two passes where the flat 512-rows-per-bucket rule spent a third on one bit.  Rows outside the clamped range
+        // collect in the first / last bucket and are ordered there by their whole keys like any bucket's.
+        if (ctx.opt_sort_msd && ctx.opt_sort_sample && n >= 65536 && n < ((int64_t)1 << 32)) {
+            const int S = (int)std::min<int64_t>(8192, n);
+            void* ps = nullptr;
+            RDF_TRY(arena_alloc((size_t)S * 8, &ps));
+            HIP_TRY(launch_os_sample(keys[kcur], n, S, (uint64_t*)ps, ctx.stream));
+            std::vector<uint64_t> hs((size_t)S);
+            HIP_TRY(hipMemcpyAsync(hs.data(), ps, (size_t)S * 8, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_TRY(hipStreamSynchronize(ctx.stream));
+            std::vector<double> xs;
+            xs.reserve((size_t)S);
+            int outside = 0, taken = 0, most_equal = 1;
+            {   // the same key twice in the sample = a value held by ~2 n / S rows, which no bucket bits can split
+                std::vector<uint64_t> seen(16384, 0);
+                std::vector<uint16_t> times(16384, 0);
+                for (uint64_t k : hs) {
+                    if (k < bias || k - bias > range) continue;                    // a NULL row's placeholder key
+                    ++taken;
+                    const double x = value_of(k);
+                    if (!std::isfinite(x)) { ++outside; continue; }
+                    xs.push_back(x);
+                    size_t h = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 50);
+                    while (times[h] && seen[h] != k) h = (h + 1) & 16383;
+                    seen[h] = k;
+                    most_equal = std::max<int>(most_equal, ++times[h]);
+                }
+            }
+            const double rows_per_sample = taken > 0 ? (double)n / (double)taken : 0.0;
+            const bool spike = most_equal >= 2 && (double)most_equal * rows_per_sample > 3000.0;
+            double smin = HUGE_VAL, smax = -HUGE_VAL;
+            for (double x : xs) { smin = std::min(smin, x); smax = std::max(smax, x); }
+            static const bool dbg = getenv("RDF_DEBUG_SORT") != nullptr;
+            // infinities / NaNs end in the first / last bucket with the finite outliers: a few of them fit
+            if (xs.size() >= 256 && (double)outside * rows_per_sample <= 1500.0 && smax > smin && !spike) {
+                const double ext = 0.5 * (smax - smin);
+                const double lo2 = std::max(lo, smin - ext), hi2 = std::min(hi, smax + ext);
+                // densest region against the average, level by level: 64 bins over the range, then 8 over the densest bin while
+                // it still holds enough of the sample to say anything (a bell curve stops after one refinement, x^6 of an
+                // exponential keeps concentrating and ends on the byte passes, where it belongs)
+                double dense = 1.0, blo = lo2, bhi = hi2;
+                std::vector<double> cur(xs), nxt;
+                for (int level = 0; level < 6; ++level) {
+                    const int nb = level == 0 ? 64 : 8;
+                    if (level > 0 && cur.size() < 512) break;
+                    int cnt[64] = {0};
+                    const double cs = (double)nb / (bhi - blo);
+                    if (!std::isfinite(cs)) break;
+                    for (double x : cur) ++cnt[std::min(nb - 1, std::max(0, (int)((x - blo) * cs)))];
+                    const int at = (int)(std::max_element(cnt, cnt + nb) - cnt);
+                    dense *= (double)nb * (double)cnt[at] / (double)cur.size();
+                    const double w = (bhi - blo) / nb, l2 = blo + at * w;
+                    nxt.clear();
+                    for (double x : cur) if (std::min(nb - 1, std::max(0, (int)((x - blo) * cs))) == at) nxt.push_back(x);
+                    cur.swap(nxt);
+                    blo = l2; bhi = l2 + w;
+                }
+                // bits that leave <= 2500 expected rows (with 30 % for the sample's noise) in the densest bucket; that fixes the
+                // pass count, and the bits are then raised to what those passes carry, up to the flat rule's ~500 rows per bucket
+                int need_bits = 12;
+                while (need_bits < 24 && (double)n * dense * 1.3 / (double)((int64_t)1 << need_bits) > 2500.0) ++need_bits;
+                const int np = (need_bits + 7) / 8;
+                B = std::max(need_bits, std::min(8 * np, B));
+                lo = lo2; hi = hi2;
+                sampled = (double)n * dense * 1.3 / (double)((int64_t)1 << B) <= 2500.0;
+                if (dbg) fprintf(stderr, "[rdf] sort: sample of %zu: values in [%g, %g] of [%g, %g], densest region %.1f x the average -> %d bucket bits%s\n", xs.size(), smin, smax, std::min(x0, x1), std::max(x0, x1), dense, B, sampled ? "" : " (crowded: byte passes)");
+            } else if (dbg) fprintf(stderr, "[rdf] sort: sample of %zu finite keys, %d not finite, most equal %d -> byte passes\n", xs.size(), outside, most_equal);
+            if (!sampled) { lo = -HUGE_VAL; hi = HUGE_VAL; }   // not finite often, a spike of equal values, crowded whatever the bits: the byte passes
+        }
         const double scale = (double)((int64_t)1 << B) / (hi - lo);
         if (std::isfinite(lo) && std::isfinite(hi) && hi > lo && std::isfinite(scale)) { fb.lo = lo; fb.scale = scale; fb.bits = B; fb.flip = f64_keys == 2; }
     }
-    if (ctx.opt_sort_msd && n >= 65536 && n < ((int64_t)1 << 32) && (n >> B) <= per_bucket && (sig + 7) / 8 >= (B + 7) / 8 + 2 && (fb.bits || sig - B <= 52)) {
+    if (ctx.opt_sort_msd && n >= 65536 && n < ((int64_t)1 << 32) && ((n >> B) <= per_bucket || (sampled && fb.bits)) && (sig + 7) / 8 >= (B + 7) / 8 + 2 && (fb.bits || sig - B <= 52)) {
         const int R = fb.bits ? 0 : sig - B;
         const int npass = (B + 7) / 8;
         const int nbuckets = 1 << B;
@@ -3952,6 +4030,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "take_rows") == 0) g_ctx.opt_take_rows = (int)value;
     else if (strcmp(name, "sort_gen") == 0) g_ctx.opt_sort_gen = (int)value;
     else if (strcmp(name, "sort_msd") == 0) g_ctx.opt_sort_msd = (int)value;
+    else if (strcmp(name, "sort_sample") == 0) g_ctx.opt_sort_sample = (int)value;
     else if (strcmp(name, "join_table") == 0) g_ctx.opt_join_table = (int)value;
     else if (strcmp(name, "jit") == 0) g_ctx.opt_jit = (int)value;
     else if (strcmp(name, "gb_skew_plan") == 0) g_ctx.opt_gb_skew_plan = (int)value;

@@ -286,6 +286,7 @@ struct OsLocalArgs {
 };
 hipError_t launch_os_bounds(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, const OsBucket& fb, uint32_t* bstart, unsigned int* maxlen, hipStream_t s);
 hipError_t launch_os_local(const OsLocalArgs& a, hipStream_t s);
+hipError_t launch_os_sample(const uint64_t* keys, int64_t n, int nsamp, uint64_t* out, hipStream_t s);   // nsamp keys from jittered strides
 hipError_t launch_os_hist(const OsHistArgs& a, hipStream_t s);
 hipError_t launch_os_scatter(const OsPassArgs& a, hipStream_t s);
 int os_tile_items();

@@ -591,6 +591,23 @@ __global__ __launch_bounds__(64) void os_local_kernel(const OsLocalArgs a) {
         __builtin_nontemporal_store(a.idx_in ? as_global<uint32_t>(a.idx_in)[from] : from, as_global_mut<uint32_t>(a.idx_out) + start + j);
     }
 }
+// A sample of the keys for the host's bucket plan (value range without the outliers, densest region): one key from every stride,
+// at a hashed place inside it (a column with a period would alias with fixed places).
+__global__ __launch_bounds__(kBlock) void os_sample_kernel(const uint64_t* keys, int64_t n, int64_t stride, int nsamp, uint64_t* out) {
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (i >= nsamp) return;
+    uint64_t h = (uint64_t)i * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    int64_t pos = (int64_t)i * stride + (int64_t)(h % (uint64_t)stride);
+    if (pos >= n) pos = n - 1;
+    out[i] = as_global<uint64_t>(keys)[pos];
+}
+hipError_t launch_os_sample(const uint64_t* keys, int64_t n, int nsamp, uint64_t* out, hipStream_t s) {
+    if (nsamp < 1 || n < 1) return hipSuccess;
+    const int64_t stride = n / nsamp > 0 ? n / nsamp : 1;
+    hipLaunchKernelGGL(os_sample_kernel, dim3((unsigned)((nsamp + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, keys, n, stride, nsamp, out);
+    return hipGetLastError();
+}
 hipError_t launch_os_bounds(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, const OsBucket& fb, uint32_t* bstart, unsigned int* maxlen, hipStream_t s) {
     int64_t grid = (n + 1 + kBlock - 1) / kBlock;
     if (grid > eval_grid_limit()) grid = eval_grid_limit();

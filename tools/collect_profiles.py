@@ -62,7 +62,7 @@ def main():
     bench = json.loads(open(os.path.join(src, "bench_1e9.json")).read().strip().splitlines()[-1])
     for name in ("bench_1e9.json", "bench_1e9_under_rocprof.json", "bench_1e9_1024_row_batches.json", "bench_1e9_validity.json",
                  "kernels_1e9_microbench.jsonl", "shapes_2p5e8.jsonl", "ubench_scatter.txt", "frames_1e9.jsonl", "ingest.jsonl", "bytes_2p5e8.jsonl", "beyond_catalogs_2p5e8.jsonl",
-                 "rccl_one_rank.jsonl", "c4_total_rows_1e9.json"):
+                 "rccl_one_rank.jsonl", "c4_total_rows_1e9.json", "rccl_one_rank_torch.jsonl", "example_dist.txt", "stream_16GB.jsonl", "stream_4GB_hbm_left_1p5GB.jsonl", "ubench_stream.txt"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
     agree = None

@@ -46,7 +46,8 @@ python "$REPO/tools/bench_shapes.py" --interp 2> "$OUT/shapes.err" | grep kernel
 fi
 # 3b. HBM counters of compaction / take / small-group GROUP BY, one micro-benchmark entry per pass (the entries share kernels)
 for e in filter_1col filter_2col filter_1col_selectivity_1_16 take_random_u32 take_sequential_u32 groupby_sum_1000_groups \
-         sort_to_indices_i64_full_range groupby_count_1000000_groups join_inner_1e8_x_1e7; do
+         sort_to_indices_i64_full_range groupby_count_1000000_groups join_inner_1e8_x_1e7 \
+         groupby_sum_1000000_groups_zipf groupby_sum_1000000_groups_scattered_keys list_rows_of_1000_distinct; do
     pmc micro_$e python "$REPO/tools/bench_kernels.py" --rows 1000000000 --steps 3 --only $e
 done
 # 3c. round 3: frame-level operators on 976 563 batches of 1024 rows (wall against kernel time), ingestion, Int8 / UInt8 kernels,
@@ -60,9 +61,18 @@ rm -f "$OUT/rccl_one_rank.jsonl"
 for w in headline c4 q1; do python "$REPO/bench.py" --workload $w --rows 200000000 --steps 10 --warmup 3 --cpu-sample 0 --force-exchange --backend nccl 2>> "$OUT/rccl.err" | tail -1 >> "$OUT/rccl_one_rank.jsonl"; done
 RDF_C4_SHUFFLE_ROWS=1 python "$REPO/bench.py" --workload c4 --rows 200000000 --steps 10 --warmup 3 --cpu-sample 0 --force-exchange --backend nccl 2>> "$OUT/rccl.err" | tail -1 >> "$OUT/rccl_one_rank.jsonl"
 python "$REPO/bench.py" --workload c4 --total-rows 1000000000 --steps 10 --warmup 3 --cpu-sample 0 2>> "$OUT/rccl.err" | tail -1 > "$OUT/c4_total_rows_1e9.json"
-for e in take_frame_random_1col take_frame_random_4col; do
+for e in take_frame_random_1col take_frame_random_4col filter_frame_1col filter_frame_4col; do
     pmc frames_$e python "$REPO/tools/bench_frames.py" --steps 2 --only $e
 done
+# 3d. round 4: the same collectives through the torch.distributed harness (A/B against the library's own communicator, which the
+#     lines above use by default), the N-GPU GROUP BY from plain C, the streamed batch loop over host-resident frames (16 GB; and
+#     4 GB with 1.5 GB of HBM left), FETCH_SIZE on gather patterns, the bare streaming loop by grid size
+rm -f "$OUT/rccl_one_rank_torch.jsonl"
+for w in headline c4; do python "$REPO/bench.py" --workload $w --rows 200000000 --steps 10 --warmup 3 --cpu-sample 0 --force-exchange --backend nccl --comm torch 2>> "$OUT/rccl.err" | tail -1 >> "$OUT/rccl_one_rank_torch.jsonl"; done
+gcc -std=c11 -pthread -I "$REPO/include" "$REPO/integration/example_dist.c" -L "$REPO/rust_dataframe_amd" -lrdf_mi355x -Wl,-rpath,"$REPO/rust_dataframe_amd" -o /tmp/example_dist && { /tmp/example_dist peer 4; /tmp/example_dist rccl; } > "$OUT/example_dist.txt" 2>&1
+python "$REPO/tools/bench_stream.py" --gb 16 2> "$OUT/stream.err" | grep '"bench"' > "$OUT/stream_16GB.jsonl"
+python "$REPO/tools/bench_stream.py" --gb 4 --hbm-left-gb 1.5 2>> "$OUT/stream.err" | grep '"bench"' > "$OUT/stream_4GB_hbm_left_1p5GB.jsonl"
+if [ -x "$REPO/tools/ubench_stream.bin" ]; then timeout 300 "$REPO/tools/ubench_stream.bin" > "$OUT/ubench_stream.txt" 2>&1; fi
 fi
 # 4. the scatter micro-benchmark behind the C4 bound
 if [ -x "$REPO/tools/ubench_scatter.bin" ]; then timeout 300 "$REPO/tools/ubench_scatter.bin" > "$OUT/ubench_scatter.txt" 2>&1; fi
