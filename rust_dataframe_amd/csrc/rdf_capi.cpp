@@ -2955,15 +2955,17 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
         // doubles: sign and exponent crowd the key bits' top patterns, so the buckets are cut in VALUE space (OsBucket)
         auto value_of = [&](uint64_t stored) { const uint64_t ord = f64_keys == 2 ? ~stored : stored; const uint64_t b = (ord >> 63) ? (ord ^ 0x8000000000000000ull) : ~ord; double x; memcpy(&x, &b, 8); return x; };
         const double x0 = value_of(bias), x1 = value_of(bias + range);
-        double lo = std::min(x0, x1), hi = std::max(x0, x1);
-        if (!(lo == lo) || !(hi == hi)) { lo = -HUGE_VAL; hi = HUGE_VAL; }          // a NaN at either end of the key range
-        // The bucket map is linear between lo and hi and clamps outside, so what it needs is the range the ROWS lie in, not the
-        // range of the keys: a few far outliers, infinities or NaNs would stretch [min, max] until every other row shares a
-        // bucket.  A sample of <= 8192 keys gives that range (extended by half its width on either side: the tails of 1e9 draws
-        // of a bell curve reach 1.6 x as far as those of 8192) and the densest of 64 coarse value bins, from which the number
-        // of bucket bits is chosen so that the densest bucket is expected well inside the LDS finish — uniform doubles then
-        // take two passes where the flat 512-rows-per-bucket rule spent a third on one bit.  Rows outside the clamped range
-        // collect in the first / last bucket and are ordered there by their whole keys like any bucket's.
+        double lo = -HUGE_VAL, hi = HUGE_VAL;
+        if (x0 == x0 && x1 == x1) { lo = std::min(x0, x1); hi = std::max(x0, x1); }          // (a NaN at either end of the key range: no range)
+        // The buckets are cut from the range the ROWS lie in and as their values are distributed, not from [min, max] in equal
+        // widths: a sample of <= 8192 keys gives (a) that range — extended by half its width on either side (the tails of 1e9
+        // draws of a bell curve reach 1.6 x as far as those of 8192); keys outside fall into 1/32 of the buckets at either end,
+        // laid out geometrically (OsBucket::tail): far outliers, infinities, NaNs and the thin ends of heavy-tailed columns —, (b) the share of every
+        // one of 256 equal-width segments of it, which gets that share of the buckets (OsSeg: a piecewise-linear, monotone map
+        // that fills the buckets of bell-shaped and heavy-tailed columns as evenly as those of uniform ones), and (c) warnings
+        // that no map helps: a key met twice (a value held by thousands of rows), a region that keeps concentrating however
+        // far one zooms in (x^6 of an exponential), infinities / NaNs by the thousand — those columns take the byte passes at
+        // once instead of finding out at the bucket-size check after the passes.
         if (ctx.opt_sort_msd && ctx.opt_sort_sample && n >= 65536 && n < ((int64_t)1 << 32)) {
             const int S = (int)std::min<int64_t>(8192, n);
             void* ps = nullptr;
@@ -2975,7 +2977,7 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
             std::vector<double> xs;
             xs.reserve((size_t)S);
             int outside = 0, taken = 0, most_equal = 1;
-            {   // the same key twice in the sample = a value held by ~2 n / S rows, which no bucket bits can split
+            {
                 std::vector<uint64_t> seen(16384, 0);
                 std::vector<uint16_t> times(16384, 0);
                 for (uint64_t k : hs) {
@@ -2995,44 +2997,112 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
             double smin = HUGE_VAL, smax = -HUGE_VAL;
             for (double x : xs) { smin = std::min(smin, x); smax = std::max(smax, x); }
             static const bool dbg = getenv("RDF_DEBUG_SORT") != nullptr;
-            // infinities / NaNs end in the first / last bucket with the finite outliers: a few of them fit
-            if (xs.size() >= 256 && (double)outside * rows_per_sample <= 1500.0 && smax > smin && !spike) {
+            if (xs.size() >= 1024 && (double)outside * rows_per_sample <= 1500.0 && smax > smin && !spike) {
                 const double ext = 0.5 * (smax - smin);
                 const double lo2 = std::max(lo, smin - ext), hi2 = std::min(hi, smax + ext);
-                // densest region against the average, level by level: 64 bins over the range, then 8 over the densest bin while
-                // it still holds enough of the sample to say anything (a bell curve stops after one refinement, x^6 of an
-                // exponential keeps concentrating and ends on the byte passes, where it belongs)
-                double dense = 1.0, blo = lo2, bhi = hi2;
-                std::vector<double> cur(xs), nxt;
-                for (int level = 0; level < 6; ++level) {
-                    const int nb = level == 0 ? 64 : 8;
-                    if (level > 0 && cur.size() < 512) break;
-                    int cnt[64] = {0};
-                    const double cs = (double)nb / (bhi - blo);
-                    if (!std::isfinite(cs)) break;
-                    for (double x : cur) ++cnt[std::min(nb - 1, std::max(0, (int)((x - blo) * cs)))];
-                    const int at = (int)(std::max_element(cnt, cnt + nb) - cnt);
-                    dense *= (double)nb * (double)cnt[at] / (double)cur.size();
-                    const double w = (bhi - blo) / nb, l2 = blo + at * w;
-                    nxt.clear();
-                    for (double x : cur) if (std::min(nb - 1, std::max(0, (int)((x - blo) * cs))) == at) nxt.push_back(x);
-                    cur.swap(nxt);
-                    blo = l2; bhi = l2 + w;
+                const int nseg = 256;
+                const double cs = (double)nseg / (hi2 - lo2);
+                std::vector<int> cnt((size_t)nseg, 0);
+                auto seg_of = [&](double x) { return std::min(nseg - 1, std::max(0, (int)((x - lo2) * cs))); };
+                for (double x : xs) ++cnt[(size_t)seg_of(x)];
+                // how uneven the fullest segment is inside: 8 sub-bins, again inside the fullest of those, ... while the sample
+                // still has 512 values there (smooth columns never do: 32 per segment on average)
+                double within = 1.0;
+                {
+                    const int at0 = (int)(std::max_element(cnt.begin(), cnt.end()) - cnt.begin());
+                    double blo = lo2 + at0 / cs, bhi = lo2 + (at0 + 1) / cs;
+                    std::vector<double> cur, nxt;
+                    for (double x : xs) if (seg_of(x) == at0) cur.push_back(x);
+                    for (int level = 0; level < 6 && cur.size() >= 512; ++level) {
+                        int c8[8] = {0};
+                        const double s8 = 8.0 / (bhi - blo);
+                        if (!std::isfinite(s8)) { within = 1e30; break; }
+                        auto sub = [&](double x) { return std::min(7, std::max(0, (int)((x - blo) * s8))); };
+                        for (double x : cur) ++c8[sub(x)];
+                        const int at = (int)(std::max_element(c8, c8 + 8) - c8);
+                        within *= 8.0 * (double)c8[at] / (double)cur.size();
+                        nxt.clear();
+                        for (double x : cur) if (sub(x) == at) nxt.push_back(x);
+                        cur.swap(nxt);
+                        const double w = (bhi - blo) / 8.0;
+                        blo += at * w; bhi = blo + w;
+                    }
                 }
-                // bits that leave <= 2500 expected rows (with 30 % for the sample's noise) in the densest bucket; that fixes the
-                // pass count, and the bits are then raised to what those passes carry, up to the flat rule's ~500 rows per bucket
-                int need_bits = 12;
-                while (need_bits < 24 && (double)n * dense * 1.3 / (double)((int64_t)1 << need_bits) > 2500.0) ++need_bits;
-                const int np = (need_bits + 7) / 8;
-                B = std::max(need_bits, std::min(8 * np, B));
-                lo = lo2; hi = hi2;
-                sampled = (double)n * dense * 1.3 / (double)((int64_t)1 << B) <= 2500.0;
-                if (dbg) fprintf(stderr, "[rdf] sort: sample of %zu: values in [%g, %g] of [%g, %g], densest region %.1f x the average -> %d bucket bits%s\n", xs.size(), smin, smax, std::min(x0, x1), std::max(x0, x1), dense, B, sampled ? "" : " (crowded: byte passes)");
-            } else if (dbg) fprintf(stderr, "[rdf] sort: sample of %zu finite keys, %d not finite, most equal %d -> byte passes\n", xs.size(), outside, most_equal);
-            if (!sampled) { lo = -HUGE_VAL; hi = HUGE_VAL; }   // not finite often, a spike of equal values, crowded whatever the bits: the byte passes
+                // bucket bits: the fewest that leave <= 2500 rows expected in the fullest bucket, with 30 % for the noise of a
+                // segment's count (32 sample values on average) and 30 % for the slope inside a segment
+                // (1/16 of the buckets are the two geometric tails; <= 1000 rows wanted: measured at 5e7 bell-shaped keys, 17 bits with a
+                // tenth of the buckets in the 1024-row LDS class sort in 3.65 ms, 18 bits with every bucket <= 512 rows in 3.83; up to
+                // 2500 accepted at 24 bits)
+                auto fullest = [&](int bits_) { return (double)n / ((double)((int64_t)1 << bits_) * (15.0 / 16.0)) * 1.69 * within; };
+                int bits = 12;
+                while (bits < 24 && fullest(bits) > 1000.0) ++bits;
+                sampled = fullest(bits) <= 2500.0;
+                if (sampled) {
+                    B = bits;
+                    const int64_t T = ((int64_t)1 << B) / 32;
+                    const int64_t nb = ((int64_t)1 << B) - 2 * T;
+                    std::vector<OsSeg> segs((size_t)nseg);
+                    // shares with two pseudo-counts per segment (the tails beyond the sample's extremes are not empty), at least
+                    // one bucket each, the rounding's remainder dealt to the fullest segments
+                    const double total = (double)xs.size() + 2.0 * nseg;
+                    std::vector<int64_t> share((size_t)nseg);
+                    int64_t given = 0;
+                    for (int c = 0; c < nseg; ++c) { share[(size_t)c] = std::max<int64_t>(1, (int64_t)((double)nb * ((double)cnt[(size_t)c] + 2.0) / total)); given += share[(size_t)c]; }
+                    std::vector<int> order((size_t)nseg);
+                    for (int c = 0; c < nseg; ++c) order[(size_t)c] = c;
+                    std::sort(order.begin(), order.end(), [&](int a, int b) { return cnt[(size_t)a] > cnt[(size_t)b]; });
+                    for (int r = 0; given != nb; r = (r + 1) % nseg) {
+                        const int c = order[(size_t)r];
+                        if (given < nb) { ++share[(size_t)c]; ++given; }
+                        else if (share[(size_t)c] > 1) { --share[(size_t)c]; --given; }
+                    }
+                    int64_t base = T;
+                    for (int c = 0; c < nseg; ++c) {
+                        segs[(size_t)c].base = (uint32_t)base;
+                        segs[(size_t)c].share = (uint32_t)share[(size_t)c];
+                        base += share[(size_t)c];
+                    }
+                    fb.lo = lo2; fb.scale = cs; fb.bits = B; fb.flip = f64_keys == 2; fb.seg = nullptr; fb.nseg = nseg;
+                    fb.hi = hi2; fb.tail = (int32_t)T; fb.tinv = 1.0 / ext;
+                    // evenly spread between the sample's extremes (chi-square over the segments there, 3 sigma)?  Then the
+                    // segments all get the same share and the kernels skip the table: uniform columns keep the cost of one map
+                    {
+                        const int c0 = seg_of(smin) + 1, c1 = seg_of(smax) - 1;
+                        if (c1 - c0 >= 16) {
+                            double tot = 0.0, chi = 0.0;
+                            for (int c = c0; c <= c1; ++c) tot += cnt[(size_t)c];
+                            const double e = tot / (double)(c1 - c0 + 1);
+                            for (int c = c0; c <= c1; ++c) chi += ((double)cnt[(size_t)c] - e) * ((double)cnt[(size_t)c] - e) / e;
+                            const double dof = (double)(c1 - c0);
+                            if (e >= 8.0 && chi < dof + 3.0 * std::sqrt(2.0 * dof)) {
+                                fb.flat = 1; fb.flat_scale = (double)nb / (double)nseg;
+                                // (no shares to starve the empty margins of buckets: the linear part hugs the sample's range)
+                                const double m = 0.02 * (smax - smin), lo3 = std::max(lo, smin - m), hi3 = std::min(hi, smax + m);
+                                fb.lo = lo3; fb.hi = hi3; fb.scale = (double)nseg / (hi3 - lo3);
+                                // Poisson noise only: avg + 5 sqrt(avg) <= 512 fits a bit fewer
+                                while (B > 12) {
+                                    const double avg = (double)n / ((double)((int64_t)1 << (B - 1)) * (15.0 / 16.0));
+                                    if (avg + 5.0 * std::sqrt(avg) > 512.0) break;
+                                    --B;
+                                }
+                                if (B != bits) { const int64_t T2 = ((int64_t)1 << B) / 32; fb.bits = B; fb.tail = (int32_t)T2; fb.flat_scale = (double)(((int64_t)1 << B) - 2 * T2) / (double)nseg; }
+                            }
+                        }
+                    }
+                    if (!fb.flat) {
+                        void* pseg = nullptr;
+                        RDF_TRY(arena_alloc(sizeof(OsSeg) * (size_t)nseg, &pseg));
+                        HIP_TRY(hipMemcpyAsync(pseg, segs.data(), sizeof(OsSeg) * (size_t)nseg, hipMemcpyHostToDevice, ctx.stream));
+                        HIP_TRY(hipStreamSynchronize(ctx.stream));        // (segs is a local)
+                        fb.seg = (const OsSeg*)pseg;
+                    }
+                }
+                if (dbg) fprintf(stderr, "[rdf] sort: sample of %zu (%d not finite, a key at most %d times): values in [%g, %g] of [%g, %g], fullest segment %.1f x uneven inside -> %s, %d bucket bits\n", xs.size(), outside, most_equal, smin, smax, lo, hi, within, sampled ? (fb.flat ? "evenly spread: one linear map between the tails" : "buckets by segment shares") : "byte passes", sampled ? B : bits);
+            } else if (dbg) fprintf(stderr, "[rdf] sort: sample of %zu finite keys, %d not finite, a key at most %d times -> byte passes\n", xs.size(), outside, most_equal);
+        } else {
+            const double scale = (double)((int64_t)1 << B) / (hi - lo);
+            if (std::isfinite(lo) && std::isfinite(hi) && hi > lo && std::isfinite(scale)) { fb.lo = lo; fb.scale = scale; fb.bits = B; fb.flip = f64_keys == 2; }
         }
-        const double scale = (double)((int64_t)1 << B) / (hi - lo);
-        if (std::isfinite(lo) && std::isfinite(hi) && hi > lo && std::isfinite(scale)) { fb.lo = lo; fb.scale = scale; fb.bits = B; fb.flip = f64_keys == 2; }
     }
     if (ctx.opt_sort_msd && n >= 65536 && n < ((int64_t)1 << 32) && ((n >> B) <= per_bucket || (sampled && fb.bits)) && (sig + 7) / 8 >= (B + 7) / 8 + 2 && (fb.bits || sig - B <= 52)) {
         const int R = fb.bits ? 0 : sig - B;

@@ -43,25 +43,59 @@ constexpr uint64_t kOsLocal = 1ull << 48, kOsInclusive = 2ull << 48;
 
 __device__ __forceinline__ int os_digit(uint64_t key, uint64_t bias, int shift, int mask = 255) { return (int)(((key - bias) >> shift) & (uint64_t)mask); }
 // the value bucket of an f64 key (OsBucket): order-preserving key bits -> the double -> floor((x - lo) * scale), clamped
-__device__ __forceinline__ uint32_t os_value_bucket(uint64_t key, const OsBucket& f) {
+constexpr int kOsSegs = 256;                // segments of a piecewise-linear bucket map (OsBucket::seg); every kernel that maps keys holds them in LDS
+__device__ __forceinline__ void os_load_segs(const OsBucket& f, uint2* lds) {      // whole block; one entry per thread of 256
+    if (!f.seg || f.flat) return;
+    for (int i = threadIdx.x; i < kOsSegs; i += blockDim.x) lds[i] = make_uint2(as_global<uint32_t>(f.seg)[2 * i], as_global<uint32_t>(f.seg)[2 * i + 1]);
+    __syncthreads();
+}
+__device__ __forceinline__ uint32_t os_value_bucket(uint64_t key, const OsBucket& f, const uint2* segs) {
     const uint64_t ord = f.flip ? ~key : key;
     const uint64_t b = (ord >> 63) ? (ord ^ 0x8000000000000000ull) : ~ord;
-    const double t = (u2d(b) - f.lo) * f.scale;
+    const double x = u2d(b);
+    const double t = (x - f.lo) * f.scale;
     const uint32_t top = (1u << f.bits) - 1;
     uint32_t k;
     if (t != t) k = (b >> 63) ? 0u : top;
-    else k = t <= 0.0 ? 0u : (t >= (double)top ? top : (uint32_t)t);
+    else if (f.tail) {
+        // piecewise linear: t is monotone in x (a subtraction of and a multiplication by constants round monotonically), its
+        // integer part picks the segment, its fraction the bucket among the segment's own
+        const uint32_t T = (uint32_t)f.tail;
+        if (t < 0.0 || t >= (double)f.nseg) {
+            // a tail: y = 1 + distance from the range; the bits of a double >= 1 are a piecewise-linear log2 of it
+            const bool low = t < 0.0;
+            double y = (low ? f.lo - x : x - f.hi) * f.tinv + 1.0;
+            y = y >= 1.0 ? y : 1.0;                       // (a key the rounding of t put outside by an ulp)
+            const uint64_t g64 = (d2u(y) - 0x3FF0000000000000ull) >> 49;
+            const uint32_t g = g64 < (uint64_t)(T - 1) ? (uint32_t)g64 : T - 1;
+            k = low ? T - 1 - g : top - (T - 1) + g;
+            return f.flip ? top - k : k;
+        }
+        if (f.flat) {                                  // the sample found the column evenly spread: one linear map between the tails
+            const uint32_t mid = top + 1 - 2 * T;
+            const uint32_t w = (uint32_t)(t * f.flat_scale);
+            k = T + (w < mid ? w : mid - 1);
+        } else {
+            const int c = (int)t;
+            const uint2 sg = segs[c];
+            const uint32_t sbase = sg.x, share = sg.y;
+            const uint32_t w = (uint32_t)((t - (double)c) * (double)share);  // the place inside the segment: frac(t), monotone in t
+            k = sbase + (w < share ? w : share - 1);
+        }
+    } else k = t <= 0.0 ? 0u : (t >= (double)top ? top : (uint32_t)t);
     return f.flip ? top - k : k;
 }
 
 // Histograms of all `npass` digits of (key - bias) in one read of the keys (+ the NULL count for the nulls-last pass).
 __global__ __launch_bounds__(kBlock) void os_hist_kernel(const OsHistArgs a) {
     __shared__ unsigned int h[9][256];
+    __shared__ uint2 segs[kOsSegs];
+    os_load_segs(a.fb, segs);
     for (int p = 0; p < 9; ++p) h[p][threadIdx.x] = 0;
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
         uint64_t k = __builtin_nontemporal_load(as_global<uint64_t>(a.keys) + i);
-        k = a.fb.bits ? (uint64_t)os_value_bucket(k, a.fb) : k - a.bias;
+        k = a.fb.bits ? (uint64_t)os_value_bucket(k, a.fb, segs) : k - a.bias;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             if (p >= a.npass) break;
@@ -104,6 +138,8 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
     __shared__ unsigned int wsum[kOsWaves];
     __shared__ unsigned int thist[256];                // the tile's digit counts, taken before the ranking so that they can be published early
     __shared__ int64_t tile_s;
+    __shared__ uint2 segs[kOsSegs];
+    os_load_segs(a.fb, segs);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t seq = (uint64_t)a.seq << 50;
     OS_TIMERS_DECL;
@@ -139,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
             int d = 0;
             if (i < a.n) {
                 d = a.nullflags ? (int)as_global<uint8_t>(a.nullflags)[idx[j]]
-                                : a.fb.bits ? (int)((os_value_bucket(key[j], a.fb) >> a.shift) & (uint32_t)a.mask) : os_digit(key[j], a.bias, a.shift, a.mask);
+                                : a.fb.bits ? (int)((os_value_bucket(key[j], a.fb, segs) >> a.shift) & (uint32_t)a.mask) : os_digit(key[j], a.bias, a.shift, a.mask);
                 atomicAdd(&thist[d], 1u);
             }
             digit[j] = d;
@@ -426,9 +462,11 @@ hipError_t launch_os_scatter(const OsPassArgs& a, hipStream_t s) {
 // bstart[b] = first row whose bucket is >= b (rows are sorted by bucket); thread i writes the entries of the buckets that END in
 // front of row i — every entry of bstart[0 .. nbuckets] exactly once, empty buckets included
 __global__ __launch_bounds__(kBlock) void os_bounds_kernel(const uint64_t* keys, int64_t n, uint64_t bias, int rbits, int nbuckets, const OsBucket fb, uint32_t* bstart) {
+    __shared__ uint2 segs[kOsSegs];
+    os_load_segs(fb, segs);
     auto bucket = [&](int64_t i) -> int64_t {
         const uint64_t k = as_global<uint64_t>(keys)[i];
-        return fb.bits ? (int64_t)os_value_bucket(k, fb) : (int64_t)((k - bias) >> rbits);
+        return fb.bits ? (int64_t)os_value_bucket(k, fb, segs) : (int64_t)((k - bias) >> rbits);
     };
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= n; i += (int64_t)gridDim.x * kBlock) {
         const int64_t cur = i < n ? bucket(i) : (int64_t)nbuckets;
@@ -512,7 +550,7 @@ __global__ __launch_bounds__(64) void os_local_wide_kernel(const OsLocalArgs a) 
     extern __shared__ __attribute__((aligned(16))) uint64_t s[];
     const int64_t bucket = blockIdx.x;
     const uint32_t start = a.bstart[bucket], len = a.bstart[bucket + 1] - start;
-    if (len == 0) return;
+    if (len <= a.len_lo || len > a.len_hi) return;
     if (len == 1) {
         if (threadIdx.x == 0) {
             as_global_mut<uint64_t>(a.keys_out)[start] = as_global<uint64_t>(a.keys_in)[start];
@@ -552,7 +590,7 @@ __global__ __launch_bounds__(64) void os_local_kernel(const OsLocalArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s[];
     const int64_t bucket = blockIdx.x;
     const uint32_t start = a.bstart[bucket], len = a.bstart[bucket + 1] - start;
-    if (len == 0) return;
+    if (len <= a.len_lo || len > a.len_hi) return;
     if (len == 1) {
         if (threadIdx.x == 0) {
             as_global_mut<uint64_t>(a.keys_out)[start] = as_global<uint64_t>(a.keys_in)[start];
@@ -617,7 +655,26 @@ hipError_t launch_os_bounds(const uint64_t* keys, int64_t n, uint64_t bias, int 
     hipLaunchKernelGGL(os_bucket_max_kernel, dim3((unsigned)g2), dim3(kBlock), 0, s, bstart, nbuckets, maxlen);
     return hipGetLastError();
 }
-hipError_t launch_os_local(const OsLocalArgs& a, hipStream_t s) {
+static hipError_t launch_os_local_class(const OsLocalArgs& a, hipStream_t s);
+hipError_t launch_os_local(const OsLocalArgs& a0, hipStream_t s) {
+    // the LDS a block asks for decides how many blocks (of one wave) a CU holds: the few buckets beyond 1024 rows (tails,
+    // outliers, a crowded value) get launches of their own (classes of <= 512, <= 1024, more rows) instead of setting the LDS
+    // size of every bucket's block
+    OsLocalArgs a = a0;
+    a.len_lo = 0; a.len_hi = 0xFFFFFFFFu;
+    if (a0.lds_items <= 512) return launch_os_local_class(a, s);
+    a.lds_items = 512; a.len_hi = 512;
+    hipError_t e = launch_os_local_class(a, s);
+    if (e != hipSuccess) return e;
+    if (a0.lds_items > 1024) {
+        a.lds_items = 1024; a.len_lo = 512; a.len_hi = 1024;
+        e = launch_os_local_class(a, s);
+        if (e != hipSuccess) return e;
+    }
+    a.lds_items = a0.lds_items; a.len_lo = a0.lds_items > 1024 ? 1024 : 512; a.len_hi = 0xFFFFFFFFu;
+    return launch_os_local_class(a, s);
+}
+static hipError_t launch_os_local_class(const OsLocalArgs& a, hipStream_t s) {
     const size_t words = (size_t)(a.lds_items + a.lds_items / 16 + 1);
     if (a.wide) {
         (void)hipFuncSetAttribute((const void*)os_local_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(words * 12 + 16));

@@ -258,6 +258,24 @@ def main():
     lib.set_option("sort_msd", 0)
     report("sort_to_indices_f64_uniform_byte_passes", 8.0 * ns, lambda: api.sort_to_indices([[arr(xs_, A.F64, ns)]], [False], oi), rows=ns)
     lib.set_option("sort_msd", 1)
+    # value buckets planned from a sample (round 4) against buckets over [min, max] with ~500 rows each (round 3); a handful of far
+    # outliers / infinities / NaNs in the column; a heavy-tailed column
+    lib.set_option("sort_sample", 0)
+    report("sort_to_indices_f64_uniform_buckets_over_min_max", 8.0 * ns, lambda: api.sort_to_indices([[arr(xs_, A.F64, ns)]], [False], oi), rows=ns)
+    report("sort_to_indices_f64_normal_buckets_over_min_max", 8.0 * ns, lambda: api.sort_to_indices([[arr(xn_, A.F64, ns)]], [False], oi), rows=ns)
+    lib.set_option("sort_sample", 1)
+    xo_ = xn_.clone()
+    xo_[torch.randint(0, ns, (12,), device="cuda")] = torch.tensor([float("inf"), float("-inf"), float("nan"), 1e300, -1e300, 1e15] * 2, device="cuda", dtype=torch.float64)
+    report("sort_to_indices_f64_normal_with_outliers", 8.0 * ns, lambda: api.sort_to_indices([[arr(xo_, A.F64, ns)]], [False], oi), rows=ns)
+    lib.set_option("sort_sample", 0)
+    report("sort_to_indices_f64_normal_with_outliers_buckets_over_min_max", 8.0 * ns, lambda: api.sort_to_indices([[arr(xo_, A.F64, ns)]], [False], oi), rows=ns)
+    lib.set_option("sort_sample", 1)
+    xl_ = torch.exp(xn_)
+    report("sort_to_indices_f64_lognormal", 8.0 * ns, lambda: api.sort_to_indices([[arr(xl_, A.F64, ns)]], [False], oi), rows=ns)
+    lib.set_option("sort_sample", 0)
+    report("sort_to_indices_f64_lognormal_buckets_over_min_max", 8.0 * ns, lambda: api.sort_to_indices([[arr(xl_, A.F64, ns)]], [False], oi), rows=ns)
+    lib.set_option("sort_sample", 1)
+    del xo_, xl_
     del xs_, xn_
     # ArrayFunctions over a List<f64> column: rows of 10 elements (one row per lane) and of 1000 elements (one row per wave)
     for rl in (10, 1000):
