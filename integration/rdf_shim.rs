@@ -300,6 +300,10 @@ pub fn sum<T: ArrowNumericType>(chunks: &[&PrimitiveArray<T>]) -> Result<Option<
 }
 
 /// ChunkedArray::filter / Column::filter (src/table.rs:97-107, 213-215): chunk boundaries are kept.
+/// NOTE: this per-call form marshals one descriptor per chunk on the host: on a column held in the readers' 1024-row batches
+/// (1e9 rows = a million chunks) the call is host-bound (1 s of marshalling around a 2.5 ms kernel).  A DataFrame-level caller
+/// (`DataFrame::filter`, `::take`, `::sort`) should pin the frame once and use `GpuFrame::filter / take / sort` below, which cost
+/// what their kernels cost whatever the batch size; these two bodies are for one-off calls on a few large chunks.
 pub fn filter_chunks<T: ArrowNumericType>(chunks: &[&PrimitiveArray<T>], mask: &[&BooleanArray]) -> Result<Vec<ArrayRef>, ArrowError> {
     let (c, m) = (views(chunks), mask.iter().map(|x| view(*x)).collect::<Vec<_>>());
     let mut counts = vec![0i64; m.len()];
