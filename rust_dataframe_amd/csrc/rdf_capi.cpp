@@ -2976,129 +2976,30 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
             HIP_TRY(hipStreamSynchronize(ctx.stream));
             std::vector<double> xs;
             xs.reserve((size_t)S);
-            int outside = 0, taken = 0, most_equal = 1;
-            {
-                std::vector<uint64_t> seen(16384, 0);
-                std::vector<uint16_t> times(16384, 0);
-                for (uint64_t k : hs) {
-                    if (k < bias || k - bias > range) continue;                    // a NULL row's placeholder key
-                    ++taken;
-                    const double x = value_of(k);
-                    if (!std::isfinite(x)) { ++outside; continue; }
-                    xs.push_back(x);
-                    size_t h = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 50);
-                    while (times[h] && seen[h] != k) h = (h + 1) & 16383;
-                    seen[h] = k;
-                    most_equal = std::max<int>(most_equal, ++times[h]);
+            int outside = 0;
+            for (uint64_t k : hs) {
+                if (k < bias || k - bias > range) continue;                        // a NULL row's placeholder key
+                const double x = value_of(k);
+                if (std::isfinite(x)) xs.push_back(x); else ++outside;
+            }
+            OsPlan plan;
+            os_plan_f64(xs.data(), xs.size(), outside, n, lo, hi, f64_keys == 2 ? 1 : 0, plan);       // rdf_sort_map.h
+            sampled = plan.sampled;
+            if (sampled) {
+                fb = plan.fb;
+                B = fb.bits;
+                if (!fb.flat) {
+                    void* pseg = nullptr;
+                    RDF_TRY(arena_alloc(sizeof(OsSeg) * plan.segs.size(), &pseg));
+                    HIP_TRY(hipMemcpyAsync(pseg, plan.segs.data(), sizeof(OsSeg) * plan.segs.size(), hipMemcpyHostToDevice, ctx.stream));
+                    HIP_TRY(hipStreamSynchronize(ctx.stream));                     // (plan is a local)
+                    fb.seg = (const OsSeg*)pseg;
                 }
             }
-            const double rows_per_sample = taken > 0 ? (double)n / (double)taken : 0.0;
-            const bool spike = most_equal >= 2 && (double)most_equal * rows_per_sample > 3000.0;
-            double smin = HUGE_VAL, smax = -HUGE_VAL;
-            for (double x : xs) { smin = std::min(smin, x); smax = std::max(smax, x); }
             static const bool dbg = getenv("RDF_DEBUG_SORT") != nullptr;
-            if (xs.size() >= 1024 && (double)outside * rows_per_sample <= 1500.0 && smax > smin && !spike) {
-                const double ext = 0.5 * (smax - smin);
-                const double lo2 = std::max(lo, smin - ext), hi2 = std::min(hi, smax + ext);
-                const int nseg = 256;
-                const double cs = (double)nseg / (hi2 - lo2);
-                std::vector<int> cnt((size_t)nseg, 0);
-                auto seg_of = [&](double x) { return std::min(nseg - 1, std::max(0, (int)((x - lo2) * cs))); };
-                for (double x : xs) ++cnt[(size_t)seg_of(x)];
-                // how uneven the fullest segment is inside: 8 sub-bins, again inside the fullest of those, ... while the sample
-                // still has 512 values there (smooth columns never do: 32 per segment on average)
-                double within = 1.0;
-                {
-                    const int at0 = (int)(std::max_element(cnt.begin(), cnt.end()) - cnt.begin());
-                    double blo = lo2 + at0 / cs, bhi = lo2 + (at0 + 1) / cs;
-                    std::vector<double> cur, nxt;
-                    for (double x : xs) if (seg_of(x) == at0) cur.push_back(x);
-                    for (int level = 0; level < 6 && cur.size() >= 512; ++level) {
-                        int c8[8] = {0};
-                        const double s8 = 8.0 / (bhi - blo);
-                        if (!std::isfinite(s8)) { within = 1e30; break; }
-                        auto sub = [&](double x) { return std::min(7, std::max(0, (int)((x - blo) * s8))); };
-                        for (double x : cur) ++c8[sub(x)];
-                        const int at = (int)(std::max_element(c8, c8 + 8) - c8);
-                        within *= 8.0 * (double)c8[at] / (double)cur.size();
-                        nxt.clear();
-                        for (double x : cur) if (sub(x) == at) nxt.push_back(x);
-                        cur.swap(nxt);
-                        const double w = (bhi - blo) / 8.0;
-                        blo += at * w; bhi = blo + w;
-                    }
-                }
-                // bucket bits: the fewest that leave <= 2500 rows expected in the fullest bucket, with 30 % for the noise of a
-                // segment's count (32 sample values on average) and 30 % for the slope inside a segment
-                // (1/16 of the buckets are the two geometric tails; <= 1000 rows wanted: measured at 5e7 bell-shaped keys, 17 bits with a
-                // tenth of the buckets in the 1024-row LDS class sort in 3.65 ms, 18 bits with every bucket <= 512 rows in 3.83; up to
-                // 2500 accepted at 24 bits)
-                auto fullest = [&](int bits_) { return (double)n / ((double)((int64_t)1 << bits_) * (15.0 / 16.0)) * 1.69 * within; };
-                int bits = 12;
-                while (bits < 24 && fullest(bits) > 1000.0) ++bits;
-                sampled = fullest(bits) <= 2500.0;
-                if (sampled) {
-                    B = bits;
-                    const int64_t T = ((int64_t)1 << B) / 32;
-                    const int64_t nb = ((int64_t)1 << B) - 2 * T;
-                    std::vector<OsSeg> segs((size_t)nseg);
-                    // shares with two pseudo-counts per segment (the tails beyond the sample's extremes are not empty), at least
-                    // one bucket each, the rounding's remainder dealt to the fullest segments
-                    const double total = (double)xs.size() + 2.0 * nseg;
-                    std::vector<int64_t> share((size_t)nseg);
-                    int64_t given = 0;
-                    for (int c = 0; c < nseg; ++c) { share[(size_t)c] = std::max<int64_t>(1, (int64_t)((double)nb * ((double)cnt[(size_t)c] + 2.0) / total)); given += share[(size_t)c]; }
-                    std::vector<int> order((size_t)nseg);
-                    for (int c = 0; c < nseg; ++c) order[(size_t)c] = c;
-                    std::sort(order.begin(), order.end(), [&](int a, int b) { return cnt[(size_t)a] > cnt[(size_t)b]; });
-                    for (int r = 0; given != nb; r = (r + 1) % nseg) {
-                        const int c = order[(size_t)r];
-                        if (given < nb) { ++share[(size_t)c]; ++given; }
-                        else if (share[(size_t)c] > 1) { --share[(size_t)c]; --given; }
-                    }
-                    int64_t base = T;
-                    for (int c = 0; c < nseg; ++c) {
-                        segs[(size_t)c].base = (uint32_t)base;
-                        segs[(size_t)c].share = (uint32_t)share[(size_t)c];
-                        base += share[(size_t)c];
-                    }
-                    fb.lo = lo2; fb.scale = cs; fb.bits = B; fb.flip = f64_keys == 2; fb.seg = nullptr; fb.nseg = nseg;
-                    fb.hi = hi2; fb.tail = (int32_t)T; fb.tinv = 1.0 / ext;
-                    // evenly spread between the sample's extremes (chi-square over the segments there, 3 sigma)?  Then the
-                    // segments all get the same share and the kernels skip the table: uniform columns keep the cost of one map
-                    {
-                        const int c0 = seg_of(smin) + 1, c1 = seg_of(smax) - 1;
-                        if (c1 - c0 >= 16) {
-                            double tot = 0.0, chi = 0.0;
-                            for (int c = c0; c <= c1; ++c) tot += cnt[(size_t)c];
-                            const double e = tot / (double)(c1 - c0 + 1);
-                            for (int c = c0; c <= c1; ++c) chi += ((double)cnt[(size_t)c] - e) * ((double)cnt[(size_t)c] - e) / e;
-                            const double dof = (double)(c1 - c0);
-                            if (e >= 8.0 && chi < dof + 3.0 * std::sqrt(2.0 * dof)) {
-                                fb.flat = 1; fb.flat_scale = (double)nb / (double)nseg;
-                                // (no shares to starve the empty margins of buckets: the linear part hugs the sample's range)
-                                const double m = 0.02 * (smax - smin), lo3 = std::max(lo, smin - m), hi3 = std::min(hi, smax + m);
-                                fb.lo = lo3; fb.hi = hi3; fb.scale = (double)nseg / (hi3 - lo3);
-                                // Poisson noise only: avg + 5 sqrt(avg) <= 512 fits a bit fewer
-                                while (B > 12) {
-                                    const double avg = (double)n / ((double)((int64_t)1 << (B - 1)) * (15.0 / 16.0));
-                                    if (avg + 5.0 * std::sqrt(avg) > 512.0) break;
-                                    --B;
-                                }
-                                if (B != bits) { const int64_t T2 = ((int64_t)1 << B) / 32; fb.bits = B; fb.tail = (int32_t)T2; fb.flat_scale = (double)(((int64_t)1 << B) - 2 * T2) / (double)nseg; }
-                            }
-                        }
-                    }
-                    if (!fb.flat) {
-                        void* pseg = nullptr;
-                        RDF_TRY(arena_alloc(sizeof(OsSeg) * (size_t)nseg, &pseg));
-                        HIP_TRY(hipMemcpyAsync(pseg, segs.data(), sizeof(OsSeg) * (size_t)nseg, hipMemcpyHostToDevice, ctx.stream));
-                        HIP_TRY(hipStreamSynchronize(ctx.stream));        // (segs is a local)
-                        fb.seg = (const OsSeg*)pseg;
-                    }
-                }
-                if (dbg) fprintf(stderr, "[rdf] sort: sample of %zu (%d not finite, a key at most %d times): values in [%g, %g] of [%g, %g], fullest segment %.1f x uneven inside -> %s, %d bucket bits\n", xs.size(), outside, most_equal, smin, smax, lo, hi, within, sampled ? (fb.flat ? "evenly spread: one linear map between the tails" : "buckets by segment shares") : "byte passes", sampled ? B : bits);
-            } else if (dbg) fprintf(stderr, "[rdf] sort: sample of %zu finite keys, %d not finite, a key at most %d times -> byte passes\n", xs.size(), outside, most_equal);
+            if (dbg) fprintf(stderr, "[rdf] sort: sample of %zu finite keys (%d not finite, a value at most %d times) in [%g, %g] of [%g, %g], fullest segment %.1f x uneven inside -> %s, %d bucket bits\n",
+                             xs.size(), outside, plan.most_equal, plan.smin, plan.smax, lo, hi, plan.within,
+                             sampled ? (fb.flat ? "evenly spread: one linear map between the tails" : "buckets by segment shares") : "byte passes", plan.bits);
         } else {
             const double scale = (double)((int64_t)1 << B) / (hi - lo);
             if (std::isfinite(lo) && std::isfinite(hi) && hi > lo && std::isfinite(scale)) { fb.lo = lo; fb.scale = scale; fb.bits = B; fb.flip = f64_keys == 2; }

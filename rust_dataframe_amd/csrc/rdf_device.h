@@ -1,6 +1,7 @@
 // rdf_device.h — structures shared by the HIP kernels (rdf_kernels.hip) and the host side of the
 // C ABI (rdf_capi.cpp).  Not part of the public interface.
 #pragma once
+#include "rdf_sort_map.h"
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 
@@ -246,19 +247,7 @@ constexpr int kOsItems = 16;                         // items per thread per til
 // f64 keys: the top bits of the key bits are sign and exponent — doubles of one magnitude crowd a few of their patterns —, so the
 // most-significant-first passes take their digits from the VALUE bucket floor((x - lo) * scale) instead (monotone in the key bits:
 // rounding is monotone; NaNs go below / above everything as their bits order them), bits > 0 turns it on
-// One segment of the piecewise-linear bucket map of a column of doubles: the value range is cut into nseg equal-width segments,
-// segment c owns the buckets base .. base + span, as many as its share of a sample of the keys asks for (an equi-depth map:
-// bell-shaped and heavy-tailed columns fill their buckets as evenly as uniform ones).
-struct OsSeg { uint32_t base, share; };       // the segment's first bucket and how many it owns: bucket = base + floor(frac(t) * share), t = (x - lo) * scale
-struct OsBucket {
-    double lo, scale; int32_t bits, flip;            // flip: the stored keys are ~(key bits) (descending)
-    // tail == 0: one linear map, bucket = floor((x - lo) * scale), clamped.  Else (x - lo) * scale = the segment of [lo, hi)
-    // the key lies in, the first / last `tail` buckets take the keys below lo / from hi on in GEOMETRIC steps (eight buckets per
-    // doubling of the distance from the range, in units of 1 / tinv): far outliers, infinities and the thin ends of heavy-tailed
-    // columns spread over them instead of piling up in one end bucket
-    const OsSeg* seg; int32_t nseg, tail; double hi, tinv;
-    int32_t flat, pad; double flat_scale;            // flat: every segment has the same share — bucket = tail + floor(t * flat_scale), no table
-};
+// (OsSeg, OsBucket: rdf_sort_map.h — the bucket map of a Float64 sort column, shared with the host planner and its CPU test)
 struct OsHistArgs {
     const uint64_t* keys;                            // [n] current order
     const uint8_t*  nullflags;                       // [n] by original row, or nullptr: its 1s are counted for the nulls-last pass

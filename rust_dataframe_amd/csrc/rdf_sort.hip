@@ -42,48 +42,19 @@ constexpr uint64_t kOsValueMask = (1ull << 48) - 1;
 constexpr uint64_t kOsLocal = 1ull << 48, kOsInclusive = 2ull << 48;
 
 __device__ __forceinline__ int os_digit(uint64_t key, uint64_t bias, int shift, int mask = 255) { return (int)(((key - bias) >> shift) & (uint64_t)mask); }
-// the value bucket of an f64 key (OsBucket): order-preserving key bits -> the double -> floor((x - lo) * scale), clamped
-constexpr int kOsSegs = 256;                // segments of a piecewise-linear bucket map (OsBucket::seg); every kernel that maps keys holds them in LDS
-__device__ __forceinline__ void os_load_segs(const OsBucket& f, uint2* lds) {      // whole block; one entry per thread of 256
+// every kernel that maps keys holds the plan's segment table (OsBucket::seg, rdf_sort_map.h) in LDS: as a dependent global load per
+// key it cost the histogram and boundary kernels 0.1 - 0.15 ms each per 5e7 keys
+__device__ __forceinline__ void os_load_segs(const OsBucket& f, uint2* lds) {      // whole block
     if (!f.seg || f.flat) return;
     for (int i = threadIdx.x; i < kOsSegs; i += blockDim.x) lds[i] = make_uint2(as_global<uint32_t>(f.seg)[2 * i], as_global<uint32_t>(f.seg)[2 * i + 1]);
     __syncthreads();
 }
+// the value bucket of an f64 key (OsBucket): order-preserving key bits -> the double -> os_map_value
 __device__ __forceinline__ uint32_t os_value_bucket(uint64_t key, const OsBucket& f, const uint2* segs) {
     const uint64_t ord = f.flip ? ~key : key;
     const uint64_t b = (ord >> 63) ? (ord ^ 0x8000000000000000ull) : ~ord;
-    const double x = u2d(b);
-    const double t = (x - f.lo) * f.scale;
-    const uint32_t top = (1u << f.bits) - 1;
-    uint32_t k;
-    if (t != t) k = (b >> 63) ? 0u : top;
-    else if (f.tail) {
-        // piecewise linear: t is monotone in x (a subtraction of and a multiplication by constants round monotonically), its
-        // integer part picks the segment, its fraction the bucket among the segment's own
-        const uint32_t T = (uint32_t)f.tail;
-        if (t < 0.0 || t >= (double)f.nseg) {
-            // a tail: y = 1 + distance from the range; the bits of a double >= 1 are a piecewise-linear log2 of it
-            const bool low = t < 0.0;
-            double y = (low ? f.lo - x : x - f.hi) * f.tinv + 1.0;
-            y = y >= 1.0 ? y : 1.0;                       // (a key the rounding of t put outside by an ulp)
-            const uint64_t g64 = (d2u(y) - 0x3FF0000000000000ull) >> 49;
-            const uint32_t g = g64 < (uint64_t)(T - 1) ? (uint32_t)g64 : T - 1;
-            k = low ? T - 1 - g : top - (T - 1) + g;
-            return f.flip ? top - k : k;
-        }
-        if (f.flat) {                                  // the sample found the column evenly spread: one linear map between the tails
-            const uint32_t mid = top + 1 - 2 * T;
-            const uint32_t w = (uint32_t)(t * f.flat_scale);
-            k = T + (w < mid ? w : mid - 1);
-        } else {
-            const int c = (int)t;
-            const uint2 sg = segs[c];
-            const uint32_t sbase = sg.x, share = sg.y;
-            const uint32_t w = (uint32_t)((t - (double)c) * (double)share);  // the place inside the segment: frac(t), monotone in t
-            k = sbase + (w < share ? w : share - 1);
-        }
-    } else k = t <= 0.0 ? 0u : (t >= (double)top ? top : (uint32_t)t);
-    return f.flip ? top - k : k;
+    const uint32_t k = os_map_value(u2d(b), (b >> 63) != 0, f, segs);
+    return f.flip ? ((1u << f.bits) - 1) - k : k;
 }
 
 // Histograms of all `npass` digits of (key - bias) in one read of the keys (+ the NULL count for the nulls-last pass).

@@ -49,6 +49,15 @@ def test_jit_signatures_cpp():
     run(out)
 
 
+def test_sort_bucket_map_cpp():
+    """The bucket map of Float64 sort keys (csrc/rdf_sort_map.h: the function the kernels run, under the planner the host runs) on
+    the CPU: monotone over sorted columns of every shape and across every seam, inside its buckets, the fullest bucket inside the
+    LDS finish; columns no map can split are refused by the plan."""
+    out = os.path.join(tempfile.gettempdir(), f"rdf_test_sort_map_{os.getpid()}")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", os.path.join(ROOT, "tests", "cpp", "test_sort_map.cpp"), "-o", out])
+    run(out)
+
+
 @pytest.mark.gpu
 def test_frame_mirror_cpp():
     run(build("test_frame", True), os.path.join(ROOT, "tests", "golden", "uk_cities_with_headers.csv"),
