@@ -229,7 +229,7 @@ uint64_t sources_hash(const Paths& ps) {
     if (done) return h;
     done = true;
     h = 1469598103934665603ull;
-    for (const char* name : {"/rdf_spec_kernel.hip.h", "/rdf_gspec_kernel.hip.h", "/rdf_expr.hip.h", "/rdf_common.hip.h", "/rdf_device.h", "/../../include/rdf_mi355x.h"}) {
+    for (const char* name : {"/rdf_spec_kernel.hip.h", "/rdf_gspec_kernel.hip.h", "/rdf_expr.hip.h", "/rdf_common.hip.h", "/rdf_device.h", "/rdf_sort_map.h", "/../../include/rdf_mi355x.h"}) {
         std::vector<char> buf;
         if (read_file(ps.src + name, buf)) h = fnv(h, buf.data(), buf.size());
         h = fnv(h, name, strlen(name));
