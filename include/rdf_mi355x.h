@@ -615,7 +615,7 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * "gb_bucket" (partition tables of the scatter path's aggregate pass: 0 = one key per probe for keys packed into at most 4 x max_groups
  * values — the multiplicative hash never collides there —, four keys per 32-byte bucket otherwise, default; 1 / 4 force one),
  * "filter_fused" (rdf_filter_frame with a `column CMP literal [AND | OR column CMP literal]` predicate over 4- / 8-byte columns: 1 = the
- * predicate runs inside the compaction kernel, one pass, when no batch is longer than 65 536 rows, default; 2 = always; 0 = predicate -> mask,
+ * predicate runs inside the compaction kernel, one pass, when no batch is longer than 1 048 576 rows, default; 2 = always; 0 = predicate -> mask,
  * count, compact),
  * "sort_msd" (keys that vary in 25 bits or more: 1 = passes over the top bits, buckets finished in LDS, default; 0 = one pass per byte),
  * "sort_sample" (Float64 sort keys: 1 = the value buckets of those passes are planned from a sample of the keys — the range the rows lie

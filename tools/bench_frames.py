@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--sort-rows", type=int, default=100_000_000)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--fused", type=int, default=1, help="rdf_set_option(\"filter_fused\") of the filter_frame_* entries: 2 forces the one-pass kernel on batches of any length")
     args = ap.parse_args()
     n, cr = args.rows, args.chunk_rows
     only = set(filter(None, args.only.split(",")))
@@ -119,6 +120,7 @@ def main():
                 out = api.filter_frame(fr, e, gt)
                 out.release()
             # algorithmic bytes (materialising filter of M columns): 8 M read + 8 M s written per row
+            lib.set_option("filter_fused", args.fused)
             report(f"filter_frame_{m}col", n, (8 + 8 * sel) * m * n, run, selectivity=sel, path="one pass: predicate inside the compaction kernel")
             lib.set_option("filter_fused", 0)
             report(f"filter_frame_{m}col_three_pass", n, (8 + 8 * sel) * m * n, run, selectivity=sel, path="predicate -> mask, count, compact (round 3)")
