@@ -49,6 +49,14 @@ def test_jit_signatures_cpp():
     run(out)
 
 
+def test_stage_copy_cpp():
+    """packed_copy (csrc/rdf_stage_copy.h): host chunks into / out of the staging buffer, cut by bytes over threads — every staged byte
+    exactly once, nothing else touched, for a handful of huge pieces, thousands of tiny batches, empty and unstaged items."""
+    out = os.path.join(tempfile.gettempdir(), f"rdf_test_stage_copy_{os.getpid()}")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_stage_copy.cpp"), "-o", out])
+    run(out)
+
+
 def test_sort_bucket_map_cpp():
     """The bucket map of Float64 sort keys (csrc/rdf_sort_map.h: the function the kernels run, under the planner the host runs) on
     the CPU: monotone over sorted columns of every shape and across every seam, inside its buckets, the fullest bucket inside the
