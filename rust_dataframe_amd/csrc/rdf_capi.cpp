@@ -1453,14 +1453,17 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         // with three (48 KB in flight) at 0.876-0.879, with four 0.866-0.868, with five 0.824-0.830 (bench.py, same box, three
         // alternating rounds; tools/ubench_stream's bare loop shows the same: 4 blocks x 64 B per lane 0.86-0.88, 8 blocks 0.80).
         // Programs over several columns, with bitmaps, or with a store sink measured within the box-to-box noise at 4-6 blocks
-        // and keep eight.  rdf_set_option("spec_blocks_per_cu", n) pins a value (A/B).
+        // and keep eight.  The same program over the readers' 1024-row batches (a descriptor per two tiles): four blocks 0.825-0.830,
+        // five 0.810, eight 0.788-0.796, three 0.764, six 0.740-0.745 (two boxes, alternating rounds).
+        // rdf_set_option("spec_blocks_per_cu", n) pins a value (A/B).
         int blocks_per_cu = ctx.opt_spec_blocks;
         if (blocks_per_cu <= 0) {
             bool any_bitmap = false;
             for (int k = 0; k < sp.ncols; ++k) any_bitmap |= fc ? fc->col_nullable[sp.col_map[k]] : (nchunks > 0 && in_dev[(size_t)((int64_t)sp.col_map[k] * nchunks)].validity != nullptr);
             bool heavy = false;
             for (int i = 0; i < ps.nnodes; ++i) heavy |= ps.nodes[i].kind == RDF_NODE_OP && op_is_heavy(ps.nodes[i].op);
-            blocks_per_cu = (ps.sink == RDF_SINK_AGG && sp.ncols == 1 && !any_bitmap && !heavy && nchunks == 1) ? 3 : 8;
+            const bool lean = ps.sink == RDF_SINK_AGG && sp.ncols == 1 && !any_bitmap && !heavy;
+            blocks_per_cu = !lean ? 8 : nchunks == 1 ? 3 : 4;
         }
         const int64_t spec_limit = (int64_t)(eval_grid_limit() / 8) * std::max(1, std::min(8, blocks_per_cu));
         grid = (int)(btiles < spec_limit ? btiles : spec_limit);
