@@ -1452,8 +1452,12 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         // over a column without a bitmap keeps 128 KB per CU in flight with eight blocks and runs at 0.826-0.844 of the HBM peak;
         // with three (48 KB in flight) at 0.876-0.879, with four 0.866-0.868, with five 0.824-0.830 (bench.py, same box, three
         // alternating rounds; tools/ubench_stream's bare loop shows the same: 4 blocks x 64 B per lane 0.86-0.88, 8 blocks 0.80).
-        // Programs over several columns, with bitmaps, or with a store sink measured within the box-to-box noise at 4-6 blocks
-        // and keep eight.  The same program over the readers' 1024-row batches (a descriptor per two tiles): four blocks 0.825-0.830,
+        // Aggregates over several columns follow it: a*b+c -> min / max / count over four columns (config C3) 0.824-0.840 with three
+        // against 0.786-0.813 with eight (two boxes, alternating rounds), `x > c AND y < d -> sum` 2.32 against 2.62 ms per 1e9
+        // rows; EVEN counts are the bad ones (four: 0.767 on C3, six: 0.770 — the strides between the blocks' tiles then line up
+        // with the memory channels' interleave).  Store sinks (new columns): seven — a + b 4.2-4.4 ms per 1e9 rows against 4.6-4.8
+        // with eight, with a validity bitmap 4.0-4.1 against 4.8-4.9, a*b+c 5.7-5.95 against 6.2-6.3 (two boxes).  Aggregates over
+        // columns with bitmaps measured best at eight (1.34 against 1.35 / 1.46 ms with seven / three) and keep it.  The same program over the readers' 1024-row batches (a descriptor per two tiles): four blocks 0.825-0.830,
         // five 0.810, eight 0.788-0.796, three 0.764, six 0.740-0.745 (two boxes, alternating rounds).
         // rdf_set_option("spec_blocks_per_cu", n) pins a value (A/B).
         int blocks_per_cu = ctx.opt_spec_blocks;
@@ -1462,8 +1466,10 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             for (int k = 0; k < sp.ncols; ++k) any_bitmap |= fc ? fc->col_nullable[sp.col_map[k]] : (nchunks > 0 && in_dev[(size_t)((int64_t)sp.col_map[k] * nchunks)].validity != nullptr);
             bool heavy = false;
             for (int i = 0; i < ps.nnodes; ++i) heavy |= ps.nodes[i].kind == RDF_NODE_OP && op_is_heavy(ps.nodes[i].op);
-            const bool lean = ps.sink == RDF_SINK_AGG && sp.ncols == 1 && !any_bitmap && !heavy;
-            blocks_per_cu = !lean ? 8 : nchunks == 1 ? 3 : 4;
+            const bool lean = ps.sink == RDF_SINK_AGG && !any_bitmap && !heavy;
+            if (lean) blocks_per_cu = nchunks == 1 ? 3 : sp.ncols == 1 ? 4 : 8;
+            else if (ps.sink == RDF_SINK_STORE && nchunks == 1) blocks_per_cu = 7;
+            else blocks_per_cu = 8;
         }
         const int64_t spec_limit = (int64_t)(eval_grid_limit() / 8) * std::max(1, std::min(8, blocks_per_cu));
         grid = (int)(btiles < spec_limit ? btiles : spec_limit);
