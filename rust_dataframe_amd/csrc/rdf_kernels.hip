@@ -1580,6 +1580,10 @@ int eval_grid_limit() {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             limit = prop.multiProcessorCount * 8;  // 8 blocks of 4 waves = the CU's 32-wave capacity
+        // (A/B of persistent grid sizes: the specialised kernels run best at ODD numbers of resident blocks per CU — even ones
+        // line their tiles' strides up with the memory channels' interleave — RDF_GRID_BLOCKS_PER_CU=7 / 5 tries the same on every
+        // kernel that sizes its grid from this limit)
+        if (const char* e = getenv("RDF_GRID_BLOCKS_PER_CU")) { const int m = atoi(e); if (m >= 1 && m <= 8 && prop.multiProcessorCount > 0) limit = prop.multiProcessorCount * m; }
         else
             limit = 2048;
     }
