@@ -229,6 +229,10 @@ struct Array {
     int64_t offset = 0, length = 0, null_count = 0;
     DataType dtype = DataType::Float64;
     std::shared_ptr<const std::vector<std::string>> strings;  // Utf8 columns are carried opaquely on the host
+    // The buffers are HOST memory (DataFrame::from_arrow_host: views into the mapped file): the array can feed aggregates —
+    // AggregateFunctions::*, a LazyFrame that ends in aggregate() — which the library then streams through HBM slab by slab
+    // (rdf_pipeline over RDF_MEM_HOST, rdf_capi_stream.inc); operators that produce device columns want to_device() first.
+    bool host = false;
 
     size_t len() const { return (size_t)length; }
     DataType data_type() const { return dtype; }
@@ -238,7 +242,7 @@ struct Array {
         rdf_array a;
         a.values = values ? values->data() : nullptr;
         a.validity = validity ? (const uint8_t*)validity->data() : nullptr;
-        a.offset = offset; a.length = length; a.null_count = null_count; a.dtype = (int32_t)dtype; a.mem = RDF_MEM_DEVICE;
+        a.offset = offset; a.length = length; a.null_count = null_count; a.dtype = (int32_t)dtype; a.mem = host ? RDF_MEM_HOST : RDF_MEM_DEVICE;
         return a;
     }
     rdf_array view_unknown_nulls() const { rdf_array a = view(); a.null_count = -1; return a; }
@@ -246,7 +250,7 @@ struct Array {
         rdf_out o;
         o.values = values ? values->data() : nullptr;
         o.validity = validity ? (uint8_t*)validity->data() : nullptr;
-        o.capacity = capacity; o.length = 0; o.null_count = 0; o.dtype = (int32_t)dtype; o.mem = RDF_MEM_DEVICE;
+        o.capacity = capacity; o.length = 0; o.null_count = 0; o.dtype = (int32_t)dtype; o.mem = host ? RDF_MEM_HOST : RDF_MEM_DEVICE;
         return o;
     }
     // freshly allocated output array (capacity rounded up to 64 elements as the ABI asks)
@@ -1430,6 +1434,52 @@ class DataFrame {
         last_ingest().seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return df;
     }
+    // The same file as a HOST-resident frame: the file is mapped, its metadata decoded, and every primitive / Boolean column chunk
+    // becomes a view into the mapping (nothing is uploaded, nothing is copied; the frame keeps the mapping alive).  What such a
+    // frame is for: `LazyFrame::read(DataFrame::from_arrow_host(path)).filter(..).aggregate({}, ..).evaluate()` — Evaluate fuses
+    // the steps into one rdf_pipeline call over RDF_MEM_HOST batches, which the library streams (slab k + 1 crosses the link while
+    // the kernel runs over slab k): compute starts with the first slab instead of after the file is in HBM, and a file larger
+    // than free HBM is aggregated in two slabs of it.  Utf8 columns ride along on the host as in from_arrow; dictionary-encoded
+    // columns are refused (they are decoded on the device).  to_device() turns the frame into an ordinary device-resident one.
+    static DataFrame from_arrow_host(const std::string& path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw DataFrameError(DataFrameError::IoError, "cannot open " + path);
+        struct stat st;
+        if (::fstat(fd, &st) != 0) { ::close(fd); throw DataFrameError(DataFrameError::IoError, "cannot stat " + path); }
+        const size_t size = (size_t)st.st_size;
+        void* map = size ? ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+        ::close(fd);
+        if (size && map == MAP_FAILED) throw DataFrameError(DataFrameError::IoError, "cannot map " + path);
+        if (!map) throw DataFrameError(DataFrameError::IoError, "Arrow IPC: empty file " + path);
+        std::shared_ptr<void> keep(map, [size](void* p) { ::munmap(p, size); });
+        IpcReader r((const uint8_t*)map, size);
+        r.host_keep = keep;
+        if (size >= 20 && std::memcmp(map, "ARROW1", 6) == 0) r.read_file(); else r.read_stream();
+        return r.finish();
+    }
+    // every host-resident chunk uploaded (blocking copies; an already device-resident frame is returned as it is)
+    DataFrame to_device() const {
+        std::vector<Column> out;
+        for (const Column& c : columns_) {
+            std::vector<ArrayRef> arrs;
+            for (const ArrayRef& a : c.data().chunks()) {
+                if (!a->host) { arrs.push_back(a); continue; }
+                auto d = std::make_shared<Array>(*a);
+                d->host = false;
+                const int64_t vb = a->dtype == DataType::Boolean ? (a->offset + a->length + 7) / 8 : (a->offset + a->length) * (int64_t)type_size(a->dtype);
+                d->values = std::make_shared<DeviceBuffer>(vb + 8);
+                if (vb > 0) check(rdf_copy_h2d(d->values->data(), a->values->data(), vb));
+                if (a->validity) {
+                    const int64_t bb = (a->offset + a->length + 7) / 8;
+                    d->validity = std::make_shared<DeviceBuffer>(bb + 8);
+                    if (bb > 0) check(rdf_copy_h2d(d->validity->data(), a->validity->data(), bb));
+                }
+                arrs.push_back(d);
+            }
+            out.push_back(Column::from_arrays(arrs, c.field()));
+        }
+        return from_columns(std::move(out));
+    }
     // An image the caller holds: pinned in place (rdf_host_register) for the duration of the load when the platform allows it.
     static DataFrame from_arrow_image(const uint8_t* img, size_t size) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -1462,6 +1512,7 @@ class DataFrame {
         const uint8_t* img; size_t size; FlatBuf fb;
         bool pinned = false;     // the image is page-locked: column buffers go up asynchronously, straight out of it
         bool staged = false;     // the image is pageable (a mapped file): column buffers go through StagedUploader
+        std::shared_ptr<void> host_keep;   // set: nothing is uploaded — the arrays are views into the image, which this keeps alive
         std::vector<Col> cols;
         std::map<int64_t, Dict> dicts;
         std::vector<std::vector<ArrayRef>> chunks;
@@ -1564,6 +1615,7 @@ class DataFrame {
                 const DataType dt = col.field.data_type;
                 const ColBufs b = next_col(cur, body, dt == DataType::Utf8 && !col.dict);
                 if (b.len != nrows) throw bad("column length differs from the batch length");
+                if (col.dict && host_keep) throw bad("dictionary-encoded column " + col.field.name + " is decoded on the device: load the file with from_arrow()");
                 if (col.dict) { chunks[c].push_back(decode_dictionary_column(col, b, body)); continue; }
                 if (dt == DataType::Utf8) {
                     std::vector<bool> valid;
@@ -1576,6 +1628,16 @@ class DataFrame {
                 auto a = std::make_shared<Array>();
                 a->dtype = dt;
                 a->length = b.len;
+                if (host_keep) {     // a view: the values and the bitmap stay where the file's image has them
+                    a->host = true;
+                    a->values = std::make_shared<DeviceBuffer>(const_cast<uint8_t*>(body.p + b.d0), need, host_keep);
+                    if (b.nulls > 0) {
+                        a->validity = std::make_shared<DeviceBuffer>(const_cast<uint8_t*>(body.p + b.vo), (b.len + 7) / 8, host_keep);
+                        a->null_count = b.nulls;
+                    }
+                    chunks[c].push_back(a);
+                    continue;
+                }
                 a->values = std::make_shared<DeviceBuffer>(need + 8);
                 if (staged) StagedUploader::instance().push(a->values->data(), body.p + b.d0, need); else upload(a->values->data(), body.p + b.d0, need, pinned);
                 if (b.nulls > 0) {

@@ -1012,6 +1012,58 @@ static void check_dictionary_frame(const DataFrame& df) {
     CHECK_EQ((int64_t)*AggregateFunctions::sum<int32_t>(df.column_by_name("small").data()), (int64_t)(int32_t)want);
     CHECK_EQ(*AggregateFunctions::count(df.column_by_name("level").data()), (int64_t)1524 - level_nulls);
 }
+// DataFrame::from_arrow_host: the same file as views into its mapping — nothing uploaded —, aggregated by a LazyFrame whose fused
+// filter -> aggregate pass the library streams out of host memory (rdf_pipeline over RDF_MEM_HOST, slab by slab when the frame is
+// larger than a slab).  Results equal the device-resident load's; operators that produce device columns want to_device().
+TEST(test_from_arrow_host_resident_frame_is_streamed) {
+    using AF = P::AggregateFunction;
+    DataFrame h = DataFrame::from_arrow_host(g_arrow);
+    DataFrame d = DataFrame::from_arrow(g_arrow);
+    CHECK_EQ(h.num_rows(), d.num_rows());
+    CHECK_EQ(h.num_chunks(), d.num_chunks());
+    CHECK(h.column_by_name("f64").data().chunk(0)->host && !d.column_by_name("f64").data().chunk(0)->host);
+    CHECK_EQ(h.column_by_name("f64").null_count(), d.column_by_name("f64").null_count());
+    CHECK_EQ(h.column_by_name("city").data().chunk(1)->strings->at(3), d.column_by_name("city").data().chunk(1)->strings->at(3));
+    auto cond = BooleanFilter::gt(BooleanFilter::column("i32"), BooleanFilter::scalar(Scalar((int64_t)6000)));
+    const std::vector<P::Aggregation> aggs{{AF::Sum, {"f64", "i64"}}, {AF::Count, {"f64"}}, {AF::Min, {"f32"}}, {AF::Max, {"u16"}}, {AF::Avg, {"i8"}}};
+    auto run = [&](const DataFrame& f) { return LazyFrame::read(f).filter(cond).aggregate({}, aggs).evaluate(); };
+    const DataFrame want = run(d);
+    auto same = [&](const DataFrame& got) {
+        CHECK_EQ(got.num_columns(), want.num_columns());
+        for (size_t c = 0; c < want.num_columns(); ++c) {
+            CHECK_EQ(got.schema().fields[c].name, want.schema().fields[c].name);
+            CHECK(got.schema().fields[c].data_type == want.schema().fields[c].data_type);
+        }
+        CHECK_NEAR(got.column(0).data().chunk(0)->value<double>(0), want.column(0).data().chunk(0)->value<double>(0), 1e-12);
+        CHECK_EQ(got.column(1).data().chunk(0)->value<int64_t>(0), want.column(1).data().chunk(0)->value<int64_t>(0));
+        CHECK_EQ(got.column(2).data().chunk(0)->value<uint32_t>(0), want.column(2).data().chunk(0)->value<uint32_t>(0));
+        CHECK_EQ(got.column(3).data().chunk(0)->value<float>(0), want.column(3).data().chunk(0)->value<float>(0));
+        CHECK_EQ((int)got.column(4).data().chunk(0)->value<uint16_t>(0), (int)want.column(4).data().chunk(0)->value<uint16_t>(0));
+        CHECK_NEAR(got.column(5).data().chunk(0)->value<double>(0), want.column(5).data().chunk(0)->value<double>(0), 1e-12);
+    };
+    int64_t slabs = -1, staged = 0, direct = 0;
+    same(run(h));                                     // below one slab: staged whole, one fused pass
+    check(rdf_stream_stats(&slabs, &staged, &direct));
+    CHECK_EQ(slabs, (int64_t)0);
+    check(rdf_set_option("stream_slab_bytes", 8192));  // now the 2624 rows are many slabs: uploader thread, partials folded in slab order
+    try {
+        same(run(h));
+        check(rdf_stream_stats(&slabs, &staged, &direct));
+        CHECK(slabs >= 2);
+        CHECK(staged > 0);
+    } catch (...) { (void)rdf_set_option("stream_slab_bytes", 0); throw; }
+    check(rdf_set_option("stream_slab_bytes", 0));
+    // column aggregates straight from the mapping
+    CHECK_NEAR(*AggregateFunctions::sum<double>(h.column_by_name("f64").data()), *AggregateFunctions::sum<double>(d.column_by_name("f64").data()), 1e-12);
+    // an operator that returns device columns does not mix memory spaces: an error, not a wrong answer; to_device() first
+    CHECK_THROWS(h.filter(cond));
+    DataFrame up = h.to_device();
+    CHECK(!up.column_by_name("f64").data().chunk(0)->host);
+    CHECK_EQ(up.filter(cond).num_rows(), (int64_t)(2624 - 1001));
+    same(run(up));
+    // dictionary-encoded columns are decoded on the device: refused here
+    CHECK_THROWS(DataFrame::from_arrow_host("tests/golden/dict_batches.arrow"));
+}
 TEST(test_from_arrow_stream_with_delta_dictionaries) { check_dictionary_frame(DataFrame::from_arrow("tests/golden/dict_batches.arrows")); }
 TEST(test_from_arrow_file_with_dictionaries) { check_dictionary_frame(DataFrame::from_arrow("tests/golden/dict_batches.arrow")); }
 TEST(test_from_arrow_rejects_garbage) {
