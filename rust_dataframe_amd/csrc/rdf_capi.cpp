@@ -71,6 +71,10 @@ struct Ctx {
     int    opt_gb_compact = 1;      // partition path, keys inside a window of 2^39: 1 = 4-byte records when only rows are counted (default); 2 = also 12-byte records (key word + value) for the other aggregates (measured slower than 16-byte records, kept for A/B); 0 = 16-byte records always
     int64_t opt_comm_max_bytes = 0;  // group-by exchange: most bytes one ncclSend / peer copy moves (0 = 256 MiB); larger shares travel in several rounds
     int    opt_spec_blocks = 0;     // resident blocks of the specialised kernels per CU (persistent grid = CUs x this); 0 = by the program (4 / 5 / 8, see run_program)
+    int    opt_spec_tile_rot = 0;   // specialised kernels' tile walk: wave p of row i takes tile i * S + (p + i * 4 * this) mod S (S = the grid's waves); 0 = plain grid stride (SpecArgs::tile_rot)
+    int    opt_spec_xcd_swz = 0;    // 1: XCD x (block index mod 8) walks the x-th contiguous eighth of every row of tiles (SpecArgs::xcd_swz)
+    int    opt_spec_grid_adj = 0;   // added to the specialised kernels' persistent grid (A/B of grids that are not a multiple of the CU count)
+    int    opt_gspec_blocks = 0;    // resident blocks per CU of the grouped register-accumulator kernel (0 = 2: what its ~220 VGPRs allow)
     int    opt_gb_hot = 1;          // skewed keys: 1 = heavy-hitter split (the hot hash classes through gb2_stream_kernel, the scatter path over the rest), default; 0 = capacity plan / first-generation path as in round 3 (A/B)
     int    opt_gb_bucket = 0;       // partition tables of the aggregate pass: 4 = four keys per 32-byte bucket, 1 = one key per probe, 0 = by the sampled key range (default: one key per probe for keys packed into <= 4 x max_groups values, buckets otherwise)
     int    opt_gb_partition = 3;    // hash GROUP BY: 3 = second generation (rdf_groupby.hip: stream / line-aligned scatter / table by max_groups, default), 4 = its partition path whatever max_groups says, 1 = first-generation histogram + scatter, 2 = first-generation radix sort, 0 = one table in HBM
@@ -152,6 +156,10 @@ rdf_status ensure_ready() {
     HIP_TRY(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
     c.stream = c.own_stream;
     if (const char* e = getenv("RDF_SPEC_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 0 && v <= 8) c.opt_spec_blocks = v; }   // (A/B without touching the caller)
+    if (const char* e = getenv("RDF_SPEC_TILE_ROT")) { const int v = atoi(e); if (v >= 0) c.opt_spec_tile_rot = v; }
+    if (const char* e = getenv("RDF_SPEC_XCD_SWZ")) c.opt_spec_xcd_swz = atoi(e) != 0;
+    if (const char* e = getenv("RDF_SPEC_GRID_ADJ")) c.opt_spec_grid_adj = atoi(e);
+    if (const char* e = getenv("RDF_GSPEC_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 0 && v <= 8) c.opt_gspec_blocks = v; }
     c.ready = true;
     return RDF_OK;
 }
@@ -1473,7 +1481,13 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         }
         const int64_t spec_limit = (int64_t)(eval_grid_limit() / 8) * std::max(1, std::min(8, blocks_per_cu));
         grid = (int)(btiles < spec_limit ? btiles : spec_limit);
+        if (grid == spec_limit && ctx.opt_spec_grid_adj != 0) grid = std::max(1, std::min(eval_grid_limit(), grid + ctx.opt_spec_grid_adj));
         if (grid < 1) grid = 1;
+        {
+            const int64_t nwv = (int64_t)grid * (kBlock / 64);
+            sa.tile_rot = ((int64_t)ctx.opt_spec_tile_rot * (kBlock / 64)) % nwv;
+            sa.xcd_swz = ctx.opt_spec_xcd_swz ? 1 : 0;
+        }
         d_result = d_partials + (size_t)grid * (size_t)ps.nvalues;
     }
 
@@ -1509,6 +1523,14 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             for (int k = 0; k < gp.nimm; ++k) ga.imm[k] = gp.imm[k];
             ga.group_partials = d_gpart; ga.flags = d_flags;
             ga.ngroups = ps.ngroups; ga.nvalues = ps.nvalues; ga.vec_bitmap = ctx.opt_vec_bitmap ? 1 : 0;
+            // the kernel keeps G x NV accumulators per lane (~220 VGPRs for Q1): two waves per SIMD = two blocks per CU are resident
+            // whatever is launched; launching just those keeps the grid persistent (one prologue / epilogue per block, and the
+            // next-tile prefetch of rdf_gspec_kernel.hip.h never runs dry at a block's end)
+            {
+                const int per_cu = ctx.opt_gspec_blocks > 0 ? ctx.opt_gspec_blocks : 2;
+                const int64_t lim = (int64_t)(eval_grid_limit() / 8) * per_cu;
+                if (grid > lim) grid = (int)lim;
+            }
             KernelTimer kt;
             ctx.last_kernel = "gspec_kernel<" + gp.sig + ">" + (jit_find(gp.sig.c_str()) ? " [compiled at run time]" : "");
             const hipError_t le = launch_gspec(gp.sig.c_str(), ga, grid, ctx.stream);
@@ -3989,6 +4011,10 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "gb_bucket") == 0) g_ctx.opt_gb_bucket = (int)value;
     else if (strcmp(name, "gb_hot") == 0) g_ctx.opt_gb_hot = (int)value;
     else if (strcmp(name, "spec_blocks_per_cu") == 0) g_ctx.opt_spec_blocks = (int)value;
+    else if (strcmp(name, "spec_tile_rot") == 0) g_ctx.opt_spec_tile_rot = value < 0 ? 0 : (int)value;
+    else if (strcmp(name, "spec_xcd_swz") == 0) g_ctx.opt_spec_xcd_swz = value != 0;
+    else if (strcmp(name, "spec_grid_adj") == 0) g_ctx.opt_spec_grid_adj = (int)value;
+    else if (strcmp(name, "gspec_blocks_per_cu") == 0) g_ctx.opt_gspec_blocks = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
     else if (strcmp(name, "comm_max_bytes") == 0) g_ctx.opt_comm_max_bytes = value;

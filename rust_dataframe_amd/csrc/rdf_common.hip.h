@@ -66,6 +66,27 @@ __device__ __forceinline__ void load_windows_s(const uint8_t* base, int64_t bitp
     }
 }
 
+// The common case of the above: all 64 * NW rows exist (a full tile).  No end-of-chunk masks — as 64-bit shifts and selects
+// on wave-uniform values they were ~100 vector-ALU instructions per tile (SALU has no 64-bit relational compare, so the compiler
+// moves such arithmetic to the vector unit), a quarter of what the headline kernel may spend per 512-row tile at the HBM rate —,
+// NW consecutive words in fixed places and the one word beyond them only when the window is not word-aligned.
+template <int NW>
+__device__ __forceinline__ void load_windows_full_s(const uint8_t* base, int64_t bitpos, uint64_t (&win)[NW]) {
+    const uint64_t addr = uniform64((uint64_t)(uintptr_t)base + (uint64_t)(bitpos >> 3));
+    const GlobalPtr<uint64_t> w = (GlobalPtr<uint64_t>)(uintptr_t)(addr & ~7ull);
+    const int sh = __builtin_amdgcn_readfirstlane((int)(addr & 7) * 8 + (int)(bitpos & 7));
+    uint64_t word[NW + 1];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) word[i] = w[i];
+    word[NW] = w[sh ? NW : NW - 1];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        uint64_t r = word[j] >> sh;
+        if (sh) r |= word[j + 1] << (64 - sh);
+        win[j] = r;
+    }
+}
+
 // Same result, but the aligned words travel through the VECTOR memory path (one global_load_dwordx2 by lanes 0..NW, then
 // v_readlane into scalars).  With block-wide tiles (round 1) this was the faster way to stream a bitmap every wave touches
 // once (0.80 of peak vs 0.69-0.74 with scalar loads); with wave-granular tiles and the next tile located under the

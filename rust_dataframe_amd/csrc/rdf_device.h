@@ -146,6 +146,8 @@ struct SpecArgs {
     int32_t            vec_bitmap;       // 1: bitmap words through the vector memory path (default); 0: scalar loads (A/B)
     int32_t            rt[8];            // shape-specialised kernels: operator of runtime-op node k (rdf_op | swap << 8)
     int32_t            alias[kSpecCols]; // canonical column k repeats column alias[k] < k (-1: its own column): registers are copied, not reloaded
+    int64_t            tile_rot;         // tile walk: wave p of row i takes tile i * S + (p + i * tile_rot) mod S (S = waves of the grid); 0 <= tile_rot < S, a multiple of the waves per block
+    int32_t            xcd_swz, pad0;    // 1: XCD x (= block index mod 8) walks the x-th contiguous eighth of every row of S tiles
 };
 
 struct MaskTables {
@@ -694,6 +696,7 @@ std::string jit_status();                            // one line: compiler / sou
 hipError_t jit_launch(const JitKernel& k, const SpecArgs& a, int grid, hipStream_t s);
 hipError_t jit_launch_grouped(const JitKernel& k, const GSpecArgs& a, int grid, hipStream_t s);
 int jit_compiled_count();
+void jit_shutdown();                                 // kills compilers in flight and joins every helper thread (atexit / library unload; idempotent)
 hipError_t launch_filter_agg_f64(const FilterAggF64Args& a, int cmp_op, int grid, hipStream_t s);
 hipError_t launch_mask_count(const MaskTables& t, int tile_rows, int64_t* tile_counts, hipStream_t s);   // tile_rows: kFilterTile or kFilterTileSmall
 hipError_t launch_scan(const int64_t* counts, int64_t* scan, int64_t n, int64_t* scratch, hipStream_t s);

@@ -61,13 +61,13 @@ template <bool F> __device__ __forceinline__ uint64_t acc_add(uint64_t a, uint64
     if constexpr (F) return d2u(u2d(a) + u2d(b)); else return a + b;
 }
 
-template <class P, int k, class C>
-__device__ __forceinline__ void load_col_full(C& c, const DevChunkCol& col, int64_t rw, int lane) {
+template <class P, int k>
+__device__ __forceinline__ void load_col_full(uint64_t (&v)[P::NC][P::R], const DevChunkCol& col, int64_t rw, int lane) {
     constexpr int w = P::template colw<k>();
     constexpr int U = P::R / 2;
     if constexpr (w == 0) {
 #pragma unroll
-        for (int r = 0; r < P::R; ++r) c.v[k][r] = 0;
+        for (int r = 0; r < P::R; ++r) v[k][r] = 0;
     } else {
         using S = typename std::conditional<w == 8, uint64_t, typename std::conditional<w == 4, uint32_t, typename std::conditional<w == 2, uint16_t, uint8_t>::type>::type>::type;
         using V2 = typename VecOf<S, 2>::type;
@@ -75,13 +75,13 @@ __device__ __forceinline__ void load_col_full(C& c, const DevChunkCol& col, int6
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const V2 t = __builtin_nontemporal_load(p + u * 64);
-            c.v[k][2 * u] = (uint64_t)t[0];
-            c.v[k][2 * u + 1] = (uint64_t)t[1];
+            v[k][2 * u] = (uint64_t)t[0];
+            v[k][2 * u + 1] = (uint64_t)t[1];
         }
     }
 }
-template <class P, int k, class C>
-__device__ __forceinline__ void load_col_tail(C& c, const DevChunkCol& col, int64_t rw, int lane) {
+template <class P, int k>
+__device__ __forceinline__ void load_col_tail(uint64_t (&v)[P::NC][P::R], const DevChunkCol& col, int64_t rw, int lane, uint32_t inr) {
     constexpr int w = P::template colw<k>();
     constexpr int U = P::R / 2;
 #pragma unroll
@@ -92,20 +92,20 @@ __device__ __forceinline__ void load_col_tail(C& c, const DevChunkCol& col, int6
             const int64_t row = col.offset + rw + 128 * u + 2 * lane + e;
             uint64_t x = 0;
             if constexpr (w != 0) {
-                if ((c.inr >> r) & 1) {
+                if ((inr >> r) & 1) {
                     if constexpr (w == 8) x = as_global<uint64_t>(col.values)[row];
                     else if constexpr (w == 4) x = as_global<uint32_t>(col.values)[row];
                     else if constexpr (w == 2) x = as_global<uint16_t>(col.values)[row];
                     else x = as_global<uint8_t>(col.values)[row];
                 }
             }
-            c.v[k][r] = x;
+            v[k][r] = x;
         }
 }
-template <class P, class C, size_t... K>
-__device__ __forceinline__ void load_all(C& c, const DevChunkCol (&col)[P::NC], int64_t rw, int lane, bool full, std::index_sequence<K...>) {
-    if (full) (load_col_full<P, (int)K>(c, col[K], rw, lane), ...);
-    else (load_col_tail<P, (int)K>(c, col[K], rw, lane), ...);
+template <class P, size_t... K>
+__device__ __forceinline__ void load_all(uint64_t (&v)[P::NC][P::R], const DevChunkCol (&col)[P::NC], int64_t rw, int lane, uint32_t inr, bool full, std::index_sequence<K...>) {
+    if (full) (load_col_full<P, (int)K>(v, col[K], rw, lane), ...);
+    else (load_col_tail<P, (int)K>(v, col[K], rw, lane, inr), ...);
 }
 
 template <class P, int r, class C, size_t... I>
@@ -203,36 +203,73 @@ __global__ __launch_bounds__(kBlock) void gspec_kernel(const GSpecArgs a) {
         for (int v = 0; v < NV; ++v) sum[g][v] = 0;   // +0.0 and integer 0 share the bit pattern
     }
 
-    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        int64_t base, n;
-        DevChunkCol col[NC];
+    // Where a tile lives: every table through the constant address space (scalar loads, results in SGPRs — as generic pointers
+    // out of the argument struct they were flat loads whose results, and everything computed from them, lived in VGPRs).
+    struct TileMeta { int64_t base, n; DevChunkCol col[NC]; };
+    auto locate = [&](int64_t tile) -> TileMeta {
+        TileMeta m;
         if (a.nchunks == 1) {
-            base = tile * kEvalTile;
-            n = a.n;
+            m.base = tile * kEvalTile;
+            m.n = a.n;
 #pragma unroll
-            for (int k = 0; k < NC; ++k) col[k] = a.cols[k];
+            for (int k = 0; k < NC; ++k) m.col[k] = a.cols[k];
         } else {
-            const int64_t ch = find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
-            base = (tile - a.chunk_tile_start[ch]) * kEvalTile;
-            n = a.chunk_len[ch];
+            const ConstPtr<int64_t> ts = as_const<int64_t>(a.chunk_tile_start);
+            const int64_t ch = find_chunk_tile(ts, a.nchunks, tile);
+            m.base = (tile - ts[ch]) * kEvalTile;
+            m.n = as_const<int64_t>(a.chunk_len)[ch];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) col[k] = a.cols_tab[(int64_t)a.col_map[k] * a.nchunks + ch];
+            for (int k = 0; k < NC; ++k) m.col[k] = const_col(a.cols_tab, (int64_t)a.col_map[k] * a.nchunks + ch);
         }
-        const int64_t rw = base + (int64_t)wave * (64 * R);   // first row of this wave
+        return m;
+    };
+    // The kernel holds G * NV accumulators per lane, so two waves per SIMD is all that fits: while a wave folds a tile nothing of
+    // its own would be in flight.  The NEXT tile's column loads are therefore issued before the current tile is folded (when that
+    // tile is a full one: the common case) and are waited for at the top of the next iteration.
+    uint64_t nx[NC][R];
+    bool have_next = false;
+    int64_t tile = blockIdx.x;
+    TileMeta meta = locate(tile < a.ntiles ? tile : 0);
+    while (tile < a.ntiles) {
+        const int64_t n = meta.n;
+        DevChunkCol col[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) col[k] = meta.col[k];
+        const int64_t rw = meta.base + (int64_t)wave * (64 * R);   // first row of this wave
         const bool full = rw + 64 * R <= n;
-        c.inr = 0;
+        if (full) {
+            c.inr = (1u << R) - 1;
+            if (have_next) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+                for (int k = 0; k < NC; ++k)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) c.inr |= (uint32_t)(rw + 128 * u + 2 * lane + e < n) << (2 * u + e);
-        load_all<P>(c, col, rw, lane, full, std::make_index_sequence<NC>());
+                    for (int r = 0; r < R; ++r) c.v[k][r] = nx[k][r];
+            } else load_all<P>(c.v, col, rw, lane, c.inr, true, std::make_index_sequence<NC>());
+        } else {
+            c.inr = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) c.inr |= (uint32_t)(rw + 128 * u + 2 * lane + e < n) << (2 * u + e);
+            load_all<P>(c.v, col, rw, lane, c.inr, false, std::make_index_sequence<NC>());
+        }
+        tile += gridDim.x;
+        have_next = false;
+        if (tile < a.ntiles) {
+            meta = locate(tile);
+            const int64_t nrw = meta.base + (int64_t)wave * (64 * R);
+            if (nrw + 64 * R <= meta.n) {
+                load_all<P>(nx, meta.col, nrw, lane, (1u << R) - 1, true, std::make_index_sequence<NC>());
+                have_next = true;
+            }
+        }
         // validity: R windows of 64 rows per column; lane l's 2 bits of load u sit in window 2u + (2l >> 6) at bit (2l) & 63
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             c.valid[k] = c.inr;
             if (col[k].validity) {
                 uint64_t w[R];
-                if (a.vec_bitmap) load_windows<R>(col[k].validity, col[k].offset + rw, n - rw, w);
+                if (full) load_windows_full_s<R>(col[k].validity, col[k].offset + rw, w);
                 else load_windows_s<R>(col[k].validity, col[k].offset + rw, n - rw, w);
                 uint32_t m = 0;
                 const int sh = (2 * lane) & 63, wsel = (2 * lane) >> 6;

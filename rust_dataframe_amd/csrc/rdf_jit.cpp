@@ -25,6 +25,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -50,7 +51,7 @@ bool file_exists(const std::string& p) { FILE* f = std::fopen(p.c_str(), "rb"); 
 // <directory of this library>/csrc; ROCM_PATH or /opt/rocm
 struct Paths { std::string src, hipcc, stamp; bool ok = false; std::string why; };
 const Paths& paths() {
-    static Paths p;
+    static Paths& p = *new Paths;          // (never destroyed: helper threads read it, see g_mu)
     static bool tried = false;
     if (tried) return p;
     tried = true;
@@ -175,11 +176,19 @@ struct Code {
     std::string kname, why;
 };
 struct Loaded { JitKernel k{nullptr, 0, 0}; bool failed = false; };
-std::mutex g_mu;
-std::condition_variable g_cv;                                     // a signature left kCompiling
-std::map<std::string, std::shared_ptr<Code>> g_code;
-std::map<std::pair<int, std::string>, Loaded> g_loaded;
+// The shared state lives in heap objects that are never destroyed: helper threads (finish_code) may still hold it while the
+// process runs its static destructors — a short-lived host that met a new shape and returned from main —, and objects with
+// static storage duration would be torn down under them.  What ends the helpers is jit_shutdown() below.
+std::mutex& g_mu = *new std::mutex;
+std::condition_variable& g_cv = *new std::condition_variable;     // a signature left kCompiling
+std::map<std::string, std::shared_ptr<Code>>& g_code = *new std::map<std::string, std::shared_ptr<Code>>;
+std::map<std::pair<int, std::string>, Loaded>& g_loaded = *new std::map<std::pair<int, std::string>, Loaded>;
 int g_compiled = 0, g_from_cache = 0, g_failed = 0, g_running = 0;
+// helper threads are joinable and kept here (g_mu) together with a flag each sets as its last act; finished ones are reaped when
+// the next one starts, the rest by jit_shutdown()
+struct Helper { std::thread t; std::shared_ptr<std::atomic<bool>> done; };
+std::vector<Helper>& g_helpers = *new std::vector<Helper>;
+std::atomic<bool> g_shutdown{false};                              // set once: compilers in flight are killed, no new helper starts
 constexpr int kMaxCompilers = 6;                                  // hipcc children at a time (a burst of new shapes queues behind them)
 
 bool read_file(const std::string& path, std::vector<char>& out) {
@@ -238,7 +247,7 @@ uint64_t sources_hash(const Paths& ps) {
 }
 struct CacheDir { std::string dir, why; };
 const CacheDir& cache_dir() {
-    static CacheDir c;
+    static CacheDir& c = *new CacheDir;    // (never destroyed: helper threads read it)
     static bool tried = false;
     if (tried) return c;
     tried = true;
@@ -344,10 +353,10 @@ bool compile(const Paths& ps, const std::string& arch_opt, const std::string& ty
                 const pid_t r = waitpid(pid, &status, WNOHANG);
                 if (r == pid) done = true;
                 else if (r < 0 && errno != EINTR) { status = -1; done = true; }
-                else if (waited_ms >= limit_ms) {
-                    (void)kill(pid, SIGKILL);
+                else if (waited_ms >= limit_ms || g_shutdown.load(std::memory_order_acquire)) {
+                    (void)kill(pid, SIGKILL);                              // no orphaned hipcc: the child is reaped before the scratch directory goes
                     while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
-                    why = "the compiler did not finish in time";
+                    why = waited_ms >= limit_ms ? "the compiler did not finish in time" : "the library is shutting down";
                     status = -1;
                     done = true;
                 } else { usleep(5000); waited_ms += 5; }
@@ -436,12 +445,15 @@ const JitKernel* find_locked(int dev, const char* sig) {
 }
 
 void finish_code(const std::string& sig, const std::string& arch, std::shared_ptr<Code> c) {
+    bool run = true;
     {
         std::unique_lock<std::mutex> lock(g_mu);
-        g_cv.wait(lock, [] { return g_running < kMaxCompilers; });
+        g_cv.wait(lock, [] { return g_running < kMaxCompilers || g_shutdown.load(std::memory_order_acquire); });
+        run = !g_shutdown.load(std::memory_order_acquire);
         ++g_running;
     }
-    const bool ok = obtain_code(sig.c_str(), arch, *c);
+    if (!run) c->why = "the library is shutting down";
+    const bool ok = run && obtain_code(sig.c_str(), arch, *c);
     static const bool dbg = getenv("RDF_DEBUG") != nullptr || getenv("RDF_DEBUG_JIT") != nullptr;
     if (!ok && dbg) fprintf(stderr, "[rdf] jit: %s -> interpreter (%s)\n", sig.c_str(), c->why.c_str());
     std::lock_guard<std::mutex> lock(g_mu);
@@ -451,7 +463,49 @@ void finish_code(const std::string& sig, const std::string& arch, std::shared_pt
     g_cv.notify_all();
 }
 
+void helper_main(std::string sig, std::string arch, std::shared_ptr<Code> c, std::shared_ptr<std::atomic<bool>> done) {
+    finish_code(sig, arch, c);
+    done->store(true, std::memory_order_release);
+}
+// (g_mu NOT held) start a helper for `sig`; helpers that have finished are joined on the way.  false: shutting down.
+bool start_helper(const char* sig, const std::string& arch, const std::shared_ptr<Code>& c) {
+    std::vector<std::thread> finished;
+    bool started = false;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        for (size_t i = 0; i < g_helpers.size();) {
+            if (g_helpers[i].done->load(std::memory_order_acquire)) { finished.push_back(std::move(g_helpers[i].t)); g_helpers.erase(g_helpers.begin() + (long)i); }
+            else ++i;
+        }
+        if (!g_shutdown.load(std::memory_order_acquire)) {
+            static const bool registered = (atexit(jit_shutdown), true);   // exit() from any thread: before the static destructors of this library run
+            (void)registered;
+            Helper h;
+            h.done = std::make_shared<std::atomic<bool>>(false);
+            h.t = std::thread(helper_main, std::string(sig), arch, c, h.done);
+            g_helpers.push_back(std::move(h));
+            started = true;
+        }
+    }
+    for (std::thread& t : finished) t.join();
+    return started;
+}
+
 }  // namespace
+
+// End of the process (atexit) or of the library (its destructor, dlclose): compilers in flight are killed, their scratch
+// directories removed by the helpers that own them, and every helper thread is joined — nothing of this library runs afterwards.
+void jit_shutdown() {
+    std::vector<Helper> all;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        g_shutdown.store(true, std::memory_order_release);
+        all.swap(g_helpers);
+        g_cv.notify_all();
+    }
+    for (Helper& h : all) if (h.t.joinable()) h.t.join();
+}
+namespace { __attribute__((destructor)) void jit_library_unload() { jit_shutdown(); } }
 
 const JitKernel* jit_find(const char* sig) {
     int dev = 0;
@@ -493,7 +547,15 @@ const JitKernel* jit_spec_kernel(const char* sig, bool wait) {
         std::vector<char> probe;
         const bool cached = cache_read((ps.ok || !ps.stamp.empty()) ? cache_file(sig, arch, ps) : std::string(), sig, probe);
         if (wait || cached) finish_code(sig, arch, c);
-        else { std::thread(finish_code, std::string(sig), arch, c).detach(); return nullptr; }
+        else {
+            if (!start_helper(sig, arch, c)) {                                  // shutting down: nobody will compile it
+                std::lock_guard<std::mutex> lock(g_mu);
+                c->state = kFailed;
+                c->why = "the library is shutting down";
+                g_cv.notify_all();
+            }
+            return nullptr;
+        }
     }
     std::lock_guard<std::mutex> lock(g_mu);
     return find_locked(dev, sig);

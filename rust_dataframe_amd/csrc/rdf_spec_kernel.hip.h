@@ -172,7 +172,10 @@ struct Prog {
     // rows per lane per iteration.  A 16-byte vector of 2-byte elements is 8 rows.  Measured on the 4-byte types: 8 rows pay for
     // a 3-column aggregate (0.62 -> 0.75 of peak: half the per-iteration overhead) but cost a 3-column store (0.70 -> 0.65) and
     // 4-column programs (0.75 -> 0.73) more in registers than they save
-    static constexpr int R = (W == 1 && !bool_store()) ? 16 : (NC <= 2 || W == 2 || (W == 4 && NC == 3 && SINK_ == SINK_AGG)) ? 8 : 4;   // Int8 / UInt8: a 16-byte vector is 16 rows
+#ifndef RDF_SPEC_R8_WIDE
+#define RDF_SPEC_R8_WIDE 0      // A/B (round 5): 8 rows per lane also for 3- / 4-column aggregates of 8-byte columns (C3)
+#endif
+    static constexpr int R = (W == 1 && !bool_store()) ? 16 : (NC <= 2 || W == 2 || (W == 4 && NC == 3 && SINK_ == SINK_AGG) || (RDF_SPEC_R8_WIDE && W == 8 && NC <= 4 && SINK_ == SINK_AGG)) ? 8 : 4;   // Int8 / UInt8: a 16-byte vector is 16 rows
     static constexpr int U = R / RV;                  // 16-byte vectors per lane per column per iteration
     static std::string sig() { return "P:" + PRED::sig() + ";V:" + V0::sig() + ";" + V1::sig() + ";S:" + std::to_string(SINK_); }
 };
@@ -296,6 +299,9 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     // table (exact or one off for equally long batches) checked against its two neighbours, all on the scalar unit.  The
     // NEXT tile is located while the current tile's vector loads are in flight, so the lookup latency is off the critical path.
     struct TileMeta { int64_t ch, base, n; DevChunkCol col[NC]; DevOutChunk out; };
+    // (every table is read through the CONSTANT address space: as generic pointers out of the by-value argument struct the
+    // first lookup became flat loads on the vector path, its results lived in VGPRs, and through the loop's phi so did every
+    // later descriptor — the wave-uniform address and bitmap arithmetic of each tile then ran on the vector ALU)
     auto locate = [&](int64_t tile) -> TileMeta {
         TileMeta m;
         m.ch = 0;
@@ -306,18 +312,33 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
 #pragma unroll
             for (int k = 0; k < NC; ++k) m.col[k] = a.cols[k];
         } else {
-            m.ch = find_chunk_tile_inv(a.chunk_tile_start, a.nchunks, tile, a.tile_inv);
-            m.base = (tile - a.chunk_tile_start[m.ch]) * per_tile;
-            m.n = a.chunk_len[m.ch];
+            const ConstPtr<int64_t> ts = as_const<int64_t>(a.chunk_tile_start);
+            m.ch = find_chunk_tile_inv(ts, a.nchunks, tile, a.tile_inv);
+            m.base = (tile - ts[m.ch]) * per_tile;
+            m.n = as_const<int64_t>(a.chunk_len)[m.ch];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) m.col[k] = a.cols_tab[(int64_t)k * a.nchunks + m.ch];
-            if (P::SINK == SINK_STORE) m.out = a.outs_tab[m.ch];
+            for (int k = 0; k < NC; ++k) m.col[k] = const_col(a.cols_tab, (int64_t)k * a.nchunks + m.ch);
+            if (P::SINK == SINK_STORE) {
+                const ConstPtr<DevOutChunk> ot = as_const<DevOutChunk>(a.outs_tab);
+                m.out.values = ot[m.ch].values;
+                m.out.validity = ot[m.ch].validity;
+            }
         }
         return m;
     };
-    const int64_t tile0 = (int64_t)blockIdx.x * kWaves + wave, tstride = (int64_t)gridDim.x * kWaves;
-    TileMeta meta = locate(tile0 < a.ntiles ? tile0 : 0);
-    for (int64_t tile = tile0; tile < a.ntiles; tile += tstride) {
+    // The tile walk.  The grid's S = gridDim.x * kWaves waves take the tile list row by row (S consecutive tiles per row);
+    // wave p of row i works on tile i * S + (p + i * tile_rot) mod S.  tile_rot = 0 is the plain grid-stride walk, where a wave's
+    // successive tiles lie S tiles apart — a power-of-two multiple of the CU count times the tile bytes for the usual grids,
+    // i.e. always on the same memory channels; a rotation (a multiple of kWaves, so a block's waves stay on consecutive tiles)
+    // makes the distance S + tile_rot whatever the grid.  xcd_swz: blocks are dealt to the XCDs round-robin (block b -> XCD
+    // b mod 8); with it set, XCD x works on the x-th contiguous eighth of every row instead of on every eighth 16 KB piece.
+    const int64_t nwv = (int64_t)gridDim.x * kWaves;
+    int64_t vblock = blockIdx.x;
+    if (a.xcd_swz && (gridDim.x & 7u) == 0) vblock = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    int64_t pos = vblock * kWaves + wave, rowb = 0;
+    int64_t tile = pos;
+    TileMeta meta = locate(tile < a.ntiles ? tile : 0);
+    while (tile < a.ntiles) {
         const int64_t ch = meta.ch, base = meta.base, n = meta.n;
         DevChunkCol col[NC];
 #pragma unroll
@@ -353,9 +374,12 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             load_tail_cols<P, 0>(col, wbase + lane, c);
         }
         {   // the loads above are in flight: locate the next tile now
-            const int64_t nt = tile + tstride;
-            if (a.nchunks == 1) meta.base = nt * per_tile;
-            else if (nt < a.ntiles) meta = locate(nt);
+            rowb += nwv;
+            pos += a.tile_rot;
+            if (pos >= nwv) pos -= nwv;
+            tile = rowb + pos;
+            if (a.nchunks == 1) meta.base = tile * per_tile;
+            else if (tile < a.ntiles) meta = locate(tile);
         }
         // validity: R windows of 64 rows per column for this wave; lane l's RV bits of load u sit in window
         // RV*u + (RV*l >> 6) at bit (RV*l) & 63
@@ -369,7 +393,9 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             }
             if (col[k].validity) {
                 uint64_t w[R];
-                if (a.vec_bitmap) load_windows<R>(col[k].validity, col[k].offset + rw, n - rw, w);
+                // (the vector-path variant of the window loads, rdf_set_option("vec_bitmap", 1), is gone from this kernel since
+                // round 5: the compiler hoisted the arithmetic its two paths shared above the branch, onto every tile)
+                if (full) load_windows_full_s<R>(col[k].validity, col[k].offset + rw, w);   // every row exists: no end-of-chunk masks
                 else load_windows_s<R>(col[k].validity, col[k].offset + rw, n - rw, w);
                 uint32_t m = 0;
                 const int sh = (RV * lane) & 63, wsel = (RV * lane) >> 6;
