@@ -404,6 +404,16 @@ typedef struct {
  * SINK_AGG: aggs[v] receives the aggregates, outs may be NULL. */
 rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks,
                         rdf_out* outs, rdf_agg_result* aggs);
+/* DataFrame::filter(&BooleanFilter) (src/dataframe.rs:178-189) over HOST-resident RecordBatches in ONE call: the predicate
+ * (BooleanFilter::eval_to_array, src/expression.rs:766-861) is evaluated and every column compacted on the device, slab by
+ * slab — slab k + 1 crosses the link while slab k is filtered and slab k - 1's kept rows travel back on a third stream —,
+ * so a frame of any size (larger than free HBM included) is filtered at the link's rate with two slabs of HBM.  Column
+ * index c of the expression = column c of `cols`; cols / outs laid out [c * nchunks + i], RDF_MEM_HOST; outs[c * nchunks + i]
+ * needs the capacity of its input batch (and a validity buffer where the column carries one) and receives the kept rows of
+ * batch i (ChunkedArray::filter keeps batch boundaries, src/table.rs:97-107).  What rdf_predicate + rdf_filter_columns do in
+ * two calls with the mask making a round trip through the host; a device-resident frame is filtered with rdf_filter_frame. */
+rdf_status rdf_filter_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_t root, const rdf_array* cols, int32_t ncols,
+                               int64_t nchunks, rdf_out* outs);
 /* Host-resident frames are STREAMED: when the RDF_MEM_HOST arrays of a SINK_AGG call hold more than one slab of bytes
  * (rdf_set_option("stream_slab_bytes", ...), default 256 MiB) the batch list is cut into slabs of whole batches (a longer batch
  * on 64-row boundaries), slab k + 1 crosses the link on the copy stream while the fused kernel runs over slab k, and the

@@ -95,6 +95,9 @@ pub mod sys {
         pub fn rdf_filter_count(mask: *const rdf_array, nchunks: i64, counts: *mut i64) -> i32;
         pub fn rdf_filter(col: *const rdf_array, mask: *const rdf_array, nchunks: i64, out: *mut rdf_out) -> i32;
         pub fn rdf_filter_columns(cols: *const rdf_array, ncols: i32, mask: *const rdf_array, nchunks: i64, outs: *mut rdf_out) -> i32;
+        // DataFrame::filter over host-resident batches in one streamed call (src/dataframe.rs:178-189)
+        pub fn rdf_filter_pipeline(nodes: *const rdf_expr_node, nnodes: i32, root: i32, cols: *const rdf_array, ncols: i32,
+                                   nchunks: i64, outs: *mut rdf_out) -> i32;
         pub fn rdf_take(chunks: *const rdf_array, nchunks: i64, indices: *const rdf_array, out: *mut rdf_out) -> i32;
         // sort / join (src/dataframe.rs:194-222, src/functions/join.rs:19-137)
         pub fn rdf_sort_to_indices(cols: *const rdf_array, ncols: i32, nchunks: i64, opts: *const rdf_sort_options,

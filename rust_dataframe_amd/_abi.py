@@ -666,6 +666,20 @@ class Api:
         self._finish(flat, carr)
         return outs_all
 
+    def filter_pipeline(self, expr: Expr, root: int, cols: Sequence[Sequence], outs=None):
+        """DataFrame::filter over host-resident batches in one streamed call (rdf_filter_pipeline): -> outs[c][i] = kept rows of batch i."""
+        nchunks = len(cols[0]) if cols else 0
+        if outs is None:
+            outs = [[HostArray.empty_out(col[i].dtype, col[i].length, col[i].validity is not None) for i in range(nchunks)] for col in cols]
+        flat = [o for col in outs for o in col]
+        carr = (rdf_out * max(1, len(flat)))(*[o.out_struct() for o in flat])
+        nodes = expr.c_array()
+        fn = self._fn("filter_pipeline")
+        fn.restype = C.c_int
+        self._check(fn(nodes, C.c_int32(len(expr.nodes)), C.c_int32(root), _flat(cols, nchunks), C.c_int32(len(cols)), C.c_int64(nchunks), carr))
+        self._finish(flat, carr)
+        return outs
+
     def filter(self, col: Sequence, mask: Sequence, outs=None):
         nchunks = len(mask)
         if outs is None:

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <chrono>
+#include <functional>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -92,7 +93,15 @@ struct Ctx {
     void*  sbuf_pin[2] = {nullptr, nullptr};
     size_t sbuf_dev_cap = 0, sbuf_pin_cap = 0;
     hipEvent_t sbuf_ev[2] = {nullptr, nullptr};
+    // the way back of the streamed batch loop (sinks that materialise on the host): two output slabs in HBM, two page-locked
+    // staging buffers, a third stream for the device-to-host copies
+    void*  dbuf_dev[2] = {nullptr, nullptr};
+    void*  dbuf_pin[2] = {nullptr, nullptr};
+    size_t dbuf_dev_cap = 0, dbuf_pin_cap = 0;
+    hipEvent_t dbuf_ev[2] = {nullptr, nullptr};
+    hipStream_t d2h_stream = nullptr;
     int64_t stream_slabs = 0, stream_bytes_staged = 0, stream_bytes_direct = 0;   // what the last rdf_pipeline call streamed
+    bool in_stream = false;          // a streamed call is running its per-slab calls on this thread (they are not streamed again)
     ~Ctx();
 };
 
@@ -110,6 +119,9 @@ Ctx::~Ctx() {
     if (pinned) (void)hipHostFree(pinned);
     for (auto& kv : pool_free) (void)hipFree(kv.second);
     for (int b = 0; b < 2; ++b) { if (sbuf_dev[b]) (void)hipFree(sbuf_dev[b]); if (sbuf_pin[b]) (void)hipHostFree(sbuf_pin[b]); if (sbuf_ev[b]) (void)hipEventDestroy(sbuf_ev[b]); }
+    if (d2h_stream) (void)hipStreamSynchronize(d2h_stream);
+    for (int b = 0; b < 2; ++b) { if (dbuf_dev[b]) (void)hipFree(dbuf_dev[b]); if (dbuf_pin[b]) (void)hipHostFree(dbuf_pin[b]); if (dbuf_ev[b]) (void)hipEventDestroy(dbuf_ev[b]); }
+    if (d2h_stream) (void)hipStreamDestroy(d2h_stream);
     for (auto& ev : events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -1691,13 +1703,40 @@ rdf_expr_node node_op(int op, int l, int r, int dtype = 0) { rdf_expr_node n; me
 rdf_status pipeline_stream(const ProgramSpec& ps, const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_agg_result* aggs, const char* msg);   // rdf_capi_stream.inc
 int64_t host_input_bytes(const rdf_array* cols, int32_t ncols, int64_t nchunks);
 int64_t stream_slab_bytes();
+rdf_status pipeline_stream_store(const ProgramSpec& ps, const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_out* outs, const char* msg);
+rdf_status group_pipeline_stream(const ProgramSpec& ps, const rdf_array* cols, int32_t ncols, int64_t nchunks, const char* msg);
+rdf_status filter_stream(const rdf_expr_node* nodes, int32_t nnodes, int32_t root, const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_out* outs);
+rdf_status groupby_stream(const rdf_array* keys, const rdf_array* values, int64_t nchunks, int32_t agg, int64_t max_groups,
+                          rdf_out* out_keys, rdf_out* out_values, rdf_out* out_counts);
+
+// Every entry point that takes chunk lists comes through here.  Host-resident batches beyond one slab are streamed (slab k + 1
+// crosses the link while the kernel runs over slab k, and — for sinks that materialise on the host — slab k - 1's results
+// leave on a third stream): aggregates, new columns / masks, the fused grouped aggregation.  Anything else is one run_program.
+rdf_status run_program_any(const ProgramSpec& ps, const rdf_array* cols, int ncols, int64_t nchunks, rdf_out* outs, rdf_agg_result* aggs, const char* msg) {
+    g_ctx.stream_slabs = 0;
+    if (cols && ncols >= 1 && ncols <= kMaxCols && nchunks >= 1 && g_ctx.opt_stream_slab >= 0) {
+        bool host = true;
+        for (int64_t i = 0; i < (int64_t)ncols * nchunks && host; ++i) host = cols[i].mem == RDF_MEM_HOST && cols[i].length >= 0 && cols[i].offset >= 0 && (cols[i].length == 0 || cols[i].values);
+        if (host && host_input_bytes(cols, ncols, nchunks) > stream_slab_bytes()) {
+            if (ps.sink == RDF_SINK_AGG && aggs) return pipeline_stream(ps, cols, ncols, nchunks, aggs, msg);
+            if (ps.sink == RDF_SINK_GROUP && ps.gout && ps.ngroups >= 1 && ps.nvalues >= 1 && (int64_t)(ps.ngroups + 1) * ps.nvalues <= RDF_MAX_GROUP_SLOTS)
+                return group_pipeline_stream(ps, cols, ncols, nchunks, msg);
+            if (ps.sink == RDF_SINK_STORE && outs && ps.nvalues == 1 && ps.filter_root < 0 && !ps.frame_outs) {
+                bool ohost = true;
+                for (int64_t c = 0; c < nchunks && ohost; ++c) ohost = outs[c].mem == RDF_MEM_HOST;
+                if (ohost) return pipeline_stream_store(ps, cols, ncols, nchunks, outs, msg);
+            }
+        }
+    }
+    return run_program(ps, cols, ncols, nchunks, outs, aggs, msg);
+}
 
 rdf_status agg_column(const rdf_array* a, int64_t nchunks, bool as_f64, rdf_agg_result* r) {
     rdf_expr_node nodes[2] = {node_col(0), node_op(RDF_OP_CAST, 0, -1, RDF_F64)};
     ProgramSpec ps;
     memset(&ps, 0, sizeof ps);
     ps.nodes = nodes; ps.nnodes = 2; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = as_f64 ? 1 : 0; ps.sink = RDF_SINK_AGG;
-    return run_program(ps, a, 1, nchunks, nullptr, r, "chunk length mismatch");
+    return run_program_any(ps, a, 1, nchunks, nullptr, r, "chunk length mismatch");
 }
 
 void store_native(void* out, int dt, const rdf_agg_result& r, int which /*0 sum 1 min 2 max*/) {
@@ -1867,7 +1906,7 @@ rdf_status rdf_binary(int32_t op, const rdf_array* a, const rdf_array* b, int64_
     ProgramSpec ps;
     memset(&ps, 0, sizeof ps);
     ps.nodes = nodes; ps.nnodes = 3; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = 2; ps.sink = RDF_SINK_STORE;
-    return run_program(ps, cols.data(), 2, nchunks, out, nullptr, "Cannot perform math operation on arrays of different length");
+    return run_program_any(ps, cols.data(), 2, nchunks, out, nullptr, "Cannot perform math operation on arrays of different length");
 }
 
 rdf_status rdf_unary(int32_t op, const rdf_array* a, int64_t nchunks, rdf_out* out) {
@@ -1878,7 +1917,7 @@ rdf_status rdf_unary(int32_t op, const rdf_array* a, int64_t nchunks, rdf_out* o
     ProgramSpec ps;
     memset(&ps, 0, sizeof ps);
     ps.nodes = nodes; ps.nnodes = 2; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = 1; ps.sink = RDF_SINK_STORE;
-    return run_program(ps, a, 1, nchunks, out, nullptr, "chunk length mismatch");
+    return run_program_any(ps, a, 1, nchunks, out, nullptr, "chunk length mismatch");
 }
 
 rdf_status rdf_hour(const rdf_array* a, int64_t nchunks, int32_t unit, rdf_out* out) {
@@ -1892,7 +1931,7 @@ rdf_status rdf_hour(const rdf_array* a, int64_t nchunks, int32_t unit, rdf_out* 
     memset(&ps, 0, sizeof ps);
     ps.nodes = nodes; ps.nnodes = 3; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = 2; ps.sink = RDF_SINK_STORE;
     ps.casts_always_fit = true;
-    return run_program(ps, a, 1, nchunks, out, nullptr, "chunk length mismatch");
+    return run_program_any(ps, a, 1, nchunks, out, nullptr, "chunk length mismatch");
 }
 
 rdf_status rdf_cast(const rdf_array* a, int64_t nchunks, rdf_out* out) {
@@ -1902,7 +1941,7 @@ rdf_status rdf_cast(const rdf_array* a, int64_t nchunks, rdf_out* out) {
     ProgramSpec ps;
     memset(&ps, 0, sizeof ps);
     ps.nodes = nodes; ps.nnodes = 2; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = 1; ps.sink = RDF_SINK_STORE;
-    return run_program(ps, a, 1, nchunks, out, nullptr, "chunk length mismatch");
+    return run_program_any(ps, a, 1, nchunks, out, nullptr, "chunk length mismatch");
 }
 
 // ---------------------------------------------------------------- aggregates
@@ -1953,7 +1992,7 @@ rdf_status rdf_predicate(const rdf_expr_node* nodes, int32_t nnodes, int32_t roo
     ps.nodes = nodes; ps.nnodes = nnodes; ps.filter_root = -1; ps.nvalues = 1; ps.value_roots[0] = root; ps.sink = RDF_SINK_STORE;
     for (int64_t c = 0; c < nchunks; ++c)
         if (mask[c].dtype != RDF_BOOL) return fail(RDF_INVALID_ARGUMENT, "predicate root must be boolean");
-    return run_program(ps, cols, ncols, nchunks, mask, nullptr, "columns of a batch differ in length");
+    return run_program_any(ps, cols, ncols, nchunks, mask, nullptr, "columns of a batch differ in length");
 }
 
 rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_out* outs,
@@ -1965,15 +2004,19 @@ rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t 
     ps.nodes = prog->nodes; ps.nnodes = prog->nnodes; ps.filter_root = prog->filter_root; ps.nvalues = prog->nvalues; ps.sink = prog->sink;
     for (int v = 0; v < prog->nvalues; ++v) ps.value_roots[v] = prog->value_roots[v];
     if (ps.sink != RDF_SINK_STORE && ps.sink != RDF_SINK_AGG) return fail(RDF_INVALID_ARGUMENT, "bad sink");
-    g_ctx.stream_slabs = 0;
-    // host-resident batches beyond one slab: streamed — slab k + 1 crosses the link while the kernel runs over slab k
-    if (ps.sink == RDF_SINK_AGG && aggs && cols && ncols >= 1 && ncols <= kMaxCols && nchunks >= 1 && g_ctx.opt_stream_slab >= 0) {
-        bool host = true;
-        for (int64_t i = 0; i < (int64_t)ncols * nchunks && host; ++i) host = cols[i].mem == RDF_MEM_HOST && cols[i].length >= 0 && cols[i].offset >= 0 && (cols[i].length == 0 || cols[i].values);
-        if (host && host_input_bytes(cols, ncols, nchunks) > stream_slab_bytes())
-            return pipeline_stream(ps, cols, ncols, nchunks, aggs, "columns of a batch differ in length");
+    return run_program_any(ps, cols, ncols, nchunks, outs, aggs, "columns of a batch differ in length");
+}
+
+rdf_status rdf_filter_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_t root, const rdf_array* cols, int32_t ncols, int64_t nchunks, rdf_out* outs) {
+    if (!nodes || nnodes <= 0 || root < 0 || root >= nnodes) return fail(RDF_INVALID_ARGUMENT, "filter_pipeline: empty expression / root out of range");
+    if (nchunks < 0 || ncols < 1 || ncols > kMaxFrameCols || (nchunks > 0 && (!cols || !outs))) return fail(RDF_INVALID_ARGUMENT, "filter_pipeline: 1..%d columns, chunk lists and outputs", kMaxFrameCols);
+    if (nchunks == 0) return RDF_OK;
+    for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) {
+        const rdf_array& a = cols[i];
+        if (a.mem != RDF_MEM_HOST) return fail(RDF_INVALID_ARGUMENT, "filter_pipeline: host-resident batches (RDF_MEM_HOST); a device-resident frame is filtered with rdf_filter_frame");
+        if (a.length < 0 || a.offset < 0 || (a.length > 0 && !a.values)) return fail(RDF_INVALID_ARGUMENT, "filter_pipeline: bad chunk %lld", (long long)i);
     }
-    return run_program(ps, cols, ncols, nchunks, outs, aggs, "columns of a batch differ in length");
+    return filter_stream(nodes, nnodes, root, cols, ncols, nchunks, outs);
 }
 
 rdf_status rdf_stream_stats(int64_t* slabs, int64_t* bytes_staged, int64_t* bytes_direct) {
@@ -2088,7 +2131,7 @@ rdf_status rdf_group_pipeline(const rdf_expr_node* nodes, int32_t nnodes, int32_
     ps.nodes = nodes; ps.nnodes = nnodes; ps.filter_root = filter_root; ps.nvalues = nvalues; ps.sink = RDF_SINK_GROUP;
     for (int v = 0; v < nvalues; ++v) ps.value_roots[v] = value_roots[v];
     ps.group_root = group_root; ps.ngroups = ngroups; ps.gout = out; ps.grows = group_rows;
-    return run_program(ps, cols, ncols, nchunks, nullptr, nullptr, "columns of a batch differ in length");
+    return run_program_any(ps, cols, ncols, nchunks, nullptr, nullptr, "columns of a batch differ in length");
 }
 
 rdf_status rdf_group_pipeline_frame(const rdf_expr_node* nodes, int32_t nnodes, int32_t filter_root, int32_t group_root, int32_t ngroups,

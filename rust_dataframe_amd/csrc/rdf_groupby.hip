@@ -866,6 +866,7 @@ __global__ __launch_bounds__(kG2Block, 2 * kG2BlocksPerCU) void gb2_scatter_kern
 
 // pass 2: one block per partition; its records are the nb line ranges the scatter blocks wrote
 constexpr int kAggBatch = 4;
+constexpr int kAggMaxRegions = 512;      // scatter blocks (two per CU of the 256): what an item's region list may hold in LDS
 __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2AggArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
     LdsTab t;
@@ -874,6 +875,8 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
     t.cnt = (unsigned int*)(t.acc + kG2Slots);
     t.ngroups = t.cnt + kG2Slots;
     unsigned int* misc = t.ngroups + 1;   // [0] output base, [1] emit cursor
+    unsigned int* s_nrec = misc + 3;      // [kAggMaxRegions] records of the item's regions
+    unsigned int* s_pre = s_nrec + kAggMaxRegions;   // [kAggMaxRegions + 1] exclusive prefix of their batch counts
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id();
     constexpr int NW = kG2AggBlock / 64;
@@ -892,20 +895,48 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
         if (tid == 0) *t.ngroups = 0;
         __syncthreads();
         const uint64_t ptop = (uint64_t)p << (64 - kG2PartBits);
-        // every wave walks every region of the item and takes the batches w, w + NW, ... of kAggBatch x 64 consecutive records
-        // (whole regions per wave left most waves idle on an item that is a slice of a heavy partition: one or two regions);
-        // the next batch's loads are issued before the current one is folded into the table
-        int64_t b = (int64_t)rb0 - 1, off = 0, nrec = 0, base_i = 0;
-        bool open = false;
-        auto advance = [&]() {
-            open = false;
-            for (++b; b < rb1; ++b) {
-                nrec = compact ? (int64_t)a.nlines[(int64_t)p * a.nb + b] : (int64_t)a.nlines[(int64_t)p * a.nb + b] * L;
-                if (nrec > (int64_t)wave * kAggBatch * 64) { base_i = (pline0 + b * pcap) * L; off = (int64_t)wave * kAggBatch * 64; open = true; return; }
+        // The item's records are the line ranges ("regions") the scatter blocks rb0 .. rb1 wrote for this partition.  Their record
+        // counts are staged in LDS once per item together with an exclusive prefix of their BATCH counts (a batch = kAggBatch x 64
+        // consecutive records of one region), and wave w takes the batches w, w + NW, ... of the whole item: every wave gets the
+        // same number of batches whatever the regions' lengths, and stepping from one region to the next costs two LDS reads.
+        // (Until round 5 every wave walked every region and read each region's count from memory when it got there — a dependent
+        // global load per region and wave, ~1 ms per launch whatever the input's size: 512 regions x a memory latency; and a
+        // region of 954 records, 1.25e8 rows, fed 4 of the 16 waves.)  The next batch's loads are issued before the current one
+        // is folded into the table.
+        const int nreg = rb1 - rb0;
+        for (int i = tid; i < nreg; i += kG2AggBlock) {
+            const int64_t nl = (int64_t)as_const<uint32_t>(a.nlines)[(int64_t)p * a.nb + rb0 + i];
+            s_nrec[i] = (uint32_t)(compact ? nl : nl * L);
+        }
+        __syncthreads();
+        if (wave == 0) {   // exclusive prefix of ceil(nrec / batch) over <= kAggMaxRegions regions: 8 per lane + a wave scan
+            constexpr int PER = kAggMaxRegions / 64;
+            uint32_t loc[PER], sum = 0;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int i = lane * PER + j;
+                loc[j] = sum;
+                sum += i < nreg ? (s_nrec[i] + kAggBatch * 64 - 1) / (kAggBatch * 64) : 0u;
             }
-        };
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+            const uint32_t excl = incl - sum;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) { const int i = lane * PER + j; if (i <= nreg) s_pre[i] = excl + loc[j]; }
+            if (lane == 63 && nreg == kAggMaxRegions) s_pre[nreg] = incl;
+        }
+        __syncthreads();
+        const int64_t vtotal = (int64_t)s_pre[nreg];
+        int64_t vb = wave;
+        int reg = 0;
+        uint32_t reg_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pre[1 < nreg ? 1 : nreg]);
         auto load_batch = [&](u64x2 (&r)[kAggBatch]) -> bool {   // false: this wave's share of the item is exhausted
-            if (!open) return false;
+            if (vb >= vtotal) return false;
+            while ((int64_t)reg_end <= vb) { ++reg; reg_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pre[reg + 1]); }
+            const int64_t nrec = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_nrec[reg]);
+            const int64_t off = (vb - (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_pre[reg])) * (kAggBatch * 64);
+            const int64_t base_i = (pline0 + (int64_t)(rb0 + reg) * pcap) * L;
             if (compact) {
                 // 12-byte records -> the 16-byte form the fold below reads: cnt : 8 | the key's image below its partition bits
                 uint32_t kw[kAggBatch];
@@ -932,11 +963,9 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
                     if (i < nrec) r[u] = __builtin_nontemporal_load(recs + base_i + i);
                 }
             }
-            off += (int64_t)NW * kAggBatch * 64;
-            if (off >= nrec) advance();
+            vb += NW;
             return true;
         };
-        advance();
         u64x2 cur[kAggBatch], nxt[kAggBatch];
         bool have = load_batch(cur);
         while (have) {
@@ -1218,7 +1247,8 @@ hipError_t launch_gb2_scatter(const Gb2Args& a, int grid, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_gb2_aggregate(const Gb2AggArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)kG2Slots * 20 + 32;
+    if (a.nb > kAggMaxRegions) return hipErrorInvalidValue;   // (the host plans at most two scatter blocks per CU)
+    const size_t lds = (size_t)kG2Slots * 20 + 32 + (size_t)(2 * kAggMaxRegions + 1) * 4;
     (void)hipFuncSetAttribute((const void*)gb2_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // work list (skewed keys): one block per CU walks the items with the grid's stride — the list is sorted largest first
     hipLaunchKernelGGL(gb2_aggregate_kernel, dim3(a.nwork > 0 ? std::min(a.nwork, eval_grid_limit() / 8) : kP), dim3(kG2AggBlock), lds, s, a);

@@ -172,11 +172,20 @@ struct Prog {
     // rows per lane per iteration.  A 16-byte vector of 2-byte elements is 8 rows.  Measured on the 4-byte types: 8 rows pay for
     // a 3-column aggregate (0.62 -> 0.75 of peak: half the per-iteration overhead) but cost a 3-column store (0.70 -> 0.65) and
     // 4-column programs (0.75 -> 0.73) more in registers than they save
+    // Round 5: 8 rows per lane also for 3- / 4-column aggregates of 8-byte columns (config C3: 118 VGPRs, still four waves per
+    // SIMD since the descriptors left the vector registers).  Same box, 14 launch shapes (blocks per CU x tile walk): 0.828-0.836 of
+    // peak whatever the shape, against 0.767-0.833 with 4 rows (profiles/r05_tilewalk_*.jsonl); -DRDF_SPEC_R8_WIDE=0 builds the old rule.
 #ifndef RDF_SPEC_R8_WIDE
-#define RDF_SPEC_R8_WIDE 0      // A/B (round 5): 8 rows per lane also for 3- / 4-column aggregates of 8-byte columns (C3)
+#define RDF_SPEC_R8_WIDE 1
 #endif
     static constexpr int R = (W == 1 && !bool_store()) ? 16 : (NC <= 2 || W == 2 || (W == 4 && NC == 3 && SINK_ == SINK_AGG) || (RDF_SPEC_R8_WIDE && W == 8 && NC <= 4 && SINK_ == SINK_AGG)) ? 8 : 4;   // Int8 / UInt8: a 16-byte vector is 16 rows
     static constexpr int U = R / RV;                  // 16-byte vectors per lane per column per iteration
+    // A/B (round 5): the NEXT tile's column loads are issued before the current tile is folded (aggregates over <= 32 VGPRs of
+    // column data per tile: the bytes a wave has in flight no longer drop to zero while it computes)
+#ifndef RDF_SPEC_PF
+#define RDF_SPEC_PF 0
+#endif
+    static constexpr bool PF = RDF_SPEC_PF && SINK_ == SINK_AGG && NC * R * W <= 128;
     static std::string sig() { return "P:" + PRED::sig() + ";V:" + V0::sig() + ";" + V1::sig() + ";S:" + std::to_string(SINK_); }
 };
 
@@ -226,8 +235,8 @@ __device__ __forceinline__ void eval_rows(C& c, uint64_t (&out)[R]) {
 
 // Column loads of one wave iteration.  Lane l takes the RV rows of vector slot `vec + 64 u` (u < U) from EVERY column: a column of
 // the program's widest type with one 16-byte load per slot, a narrower one (a cast leaf) with a load of RV of its own elements.
-template <class P, int k, class C>
-__device__ __forceinline__ void load_full_cols(const DevChunkCol (&col)[P::NC], const SpecArgs& a, int64_t vec, C& c) {
+template <class P, int k, class V>
+__device__ __forceinline__ void load_full_cols(const DevChunkCol (&col)[P::NC], const SpecArgs& a, int64_t vec, V& v) {
     if constexpr (k < P::NC) {
         if (!(k > 0 && a.alias[k] >= 0)) {
             constexpr int wk = P::template colw<k>() ? P::template colw<k>() : P::W;
@@ -238,10 +247,10 @@ __device__ __forceinline__ void load_full_cols(const DevChunkCol (&col)[P::NC], 
             for (int u = 0; u < P::U; ++u) {
                 const VecK t = __builtin_nontemporal_load(p + u * 64);
 #pragma unroll
-                for (int e = 0; e < P::RV; ++e) c.v[k][P::RV * u + e] = t[e];
+                for (int e = 0; e < P::RV; ++e) v[k][P::RV * u + e] = t[e];
             }
         }
-        load_full_cols<P, k + 1>(col, a, vec, c);
+        load_full_cols<P, k + 1>(col, a, vec, v);
     }
 }
 template <class P, int k, class C>
@@ -338,6 +347,8 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
     int64_t pos = vblock * kWaves + wave, rowb = 0;
     int64_t tile = pos;
     TileMeta meta = locate(tile < a.ntiles ? tile : 0);
+    S nx[NC][R];
+    bool have_next = false;
     while (tile < a.ntiles) {
         const int64_t ch = meta.ch, base = meta.base, n = meta.n;
         DevChunkCol col[NC];
@@ -356,7 +367,12 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
         const bool full = rw + 64 * R <= n;
         if (full) {
             c.inr = (1u << R) - 1;
-            load_full_cols<P, 0>(col, a, wbase + lane, c);   // (a slot that repeats an earlier column — alias[k] >= 0, shape kernels — is not loaded again)
+            if (P::PF && have_next) {
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) c.v[k][r] = nx[k][r];
+            } else load_full_cols<P, 0>(col, a, wbase + lane, c.v);   // (a slot that repeats an earlier column — alias[k] >= 0, shape kernels — is not loaded again)
 #pragma unroll
             for (int k = 1; k < NC; ++k)      // aliases copy registers once every load has been issued
 #pragma unroll
@@ -380,6 +396,13 @@ __global__ __launch_bounds__(kBlock) void spec_kernel(const SpecArgs a) {
             tile = rowb + pos;
             if (a.nchunks == 1) meta.base = tile * per_tile;
             else if (tile < a.ntiles) meta = locate(tile);
+            if constexpr (P::PF) {
+                have_next = false;
+                if (tile < a.ntiles && (int64_t)RV * meta.base + 64 * R <= meta.n) {
+                    load_full_cols<P, 0>(meta.col, a, meta.base + lane, nx);
+                    have_next = true;
+                }
+            }
         }
         // validity: R windows of 64 rows per column for this wave; lane l's RV bits of load u sit in window
         // RV*u + (RV*l >> 6) at bit (RV*l) & 63
