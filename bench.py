@@ -164,8 +164,11 @@ def workload_c3(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, 
     native = opts.get("native")
 
     def step():
-        local = api.pipeline(e, cols, roots)
-        y, kk = native.agg_combine(local) if native is not None else sharding.all_combine(local, device=comm_dev)
+        if native is not None and not os.environ.get("RDF_BENCH_HOST_COMBINE"):
+            y, kk = native.pipeline_dist(e, cols, roots)        # kernel + all-gather + fold on the device, one host wait
+        else:
+            local = api.pipeline(e, cols, roots)
+            y, kk = native.agg_combine(local) if native is not None else sharding.all_combine(local, device=comm_dev)
         return {"min_y": y.min, "max_y": y.max, "count_y": y.count, "min_k": kk.min, "max_k": kk.max, "count_k": kk.count}
 
     def check(res, world):
@@ -217,6 +220,7 @@ def workload_c4(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, 
             # rdf_groupby_agg_dist: local aggregate -> pack -> ncclSend / ncclRecv -> merge, all inside the library
             mk_, ms_, mc_ = native.groupby_agg([K], [V], "sum", ngroups, merged, "rows" if os.environ.get("RDF_C4_SHUFFLE_ROWS") == "1" else "auto")
             last["groups"] = (mk_, ms_, mc_)
+            opts.setdefault("exchange_ms_total", [0.0])[0] += float(native.stats.get("exchange_ms", 0.0))
             return {"groups_owned": mk_.length, **native.stats}
         if shuffle:
             ok_, mk2, mc2 = ex.shuffle_rows_and_aggregate(K, V, ngroups)
@@ -541,7 +545,14 @@ def main():
     pred = e.op("gt", c, e.scalar(THRESHOLD))
     combine_s = [0.0]
 
+    fused_combine = native is not None and not os.environ.get("RDF_BENCH_HOST_COMBINE")
+
     def step():
+        if fused_combine:
+            # N > 1, the library's communicator: kernel, all-gather of the partials and their fold in ONE call, all on the device
+            # (rdf_pipeline_dist / rdf_pipeline_frame_dist): the host waits once per step
+            tot = native.pipeline_dist(e, frame, [c], pred)[0]
+            return tot.sum, tot.count
         local = api.pipeline(e, frame, [c], pred)          # fused filter -> {sum,min,max,count}, one pass over HBM
         tc = time.perf_counter()
         # N > 1: all-gather the partials (RCCL), fold in rank order — rdf_agg_combine inside the library, or the torch harness
@@ -571,7 +582,9 @@ def main():
     kern_ms, kern_n = lib.kernel_timing_get()
     kernel_name = lib.last_kernel()
     lib.kernel_timing_reset(False)
+    per_rank = None
     if dist is not None:
+        per_rank = _per_rank(torch, dist, comm_dev, elapsed, kern_ms, kern_n, args.steps)
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -604,7 +617,11 @@ def main():
                                    + (f", {len(col)} RecordBatches of {args.chunk_rows} rows" if args.chunk_rows else ""),
                        "rows_per_gpu": rows, "total_rows": total_rows, "selectivity": res[1] / total_rows,
                        "result_sum": res[0], "result_count": res[1], "sharding": "row ranges per rank, no data-path collective",
-                       "combine_ms_per_step": combine_s[0] / max(args.steps, 1) * 1e3, **comm},
+                       "combine": ("on the device inside rdf_pipeline_dist (all-gather + fold behind the kernel, one host wait per step)" if fused_combine
+                                   else "on the host after rdf_pipeline (all-gather of the partials, fold in rank order)"),
+                       "combine_ms_per_step": ((elapsed / max(args.steps, 1) - kern_ms / max(kern_n, 1) * 1e-3 * (kern_n / args.steps if kern_n else 0)) * 1e3
+                                               if fused_combine else combine_s[0] / max(args.steps, 1) * 1e3),
+                       **({"per_rank": per_rank} if per_rank else {}), **comm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "peak_measured": probe, "peak_measured_kind": "torch.sum over the same column (stock read-only stream), median of 5",
@@ -653,6 +670,20 @@ def main():
         dist.destroy_process_group()
 
 
+def _per_rank(torch, dist, comm_dev, elapsed, kern_ms, kern_n, steps, extra=None):
+    """What every rank measured, gathered on all ranks (rank order): wall and kernel time per step, and whatever the workload adds
+    (exchange time) — so that a scaling curve explains itself: a slow rank, a slow kernel or a slow exchange."""
+    mine = [elapsed / max(steps, 1) * 1e3, kern_ms / max(kern_n, 1) * (kern_n / steps if kern_n else 0)] + list(extra or [])
+    t = torch.tensor(mine, dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
+    allr = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(allr, t)
+    rows = [[round(float(x), 4) for x in r.tolist()] for r in allr]
+    out = {"step_ms": [r[0] for r in rows], "kernel_ms_per_step": [r[1] for r in rows]}
+    if extra is not None:
+        out["exchange_ms_per_step"] = [r[2] for r in rows]
+    return out
+
+
 def _barrier(torch, dist, native):
     """All ranks meet.  With the library's communicator the process group is a control plane (gloo for CPU tensors): a tiny
     all_reduce of a CPU tensor, so that torch never creates an RCCL communicator of its own next to the library's."""
@@ -682,6 +713,8 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
     barrier()
     sync()
     lib.kernel_timing_reset(True)
+    if "exchange_ms_total" in opts:
+        opts["exchange_ms_total"][0] = 0.0          # (the warm-up steps' exchanges)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
@@ -692,7 +725,10 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
     kern_ms, kern_n = lib.kernel_timing_get()
     kernel_name = lib.last_kernel()
     lib.kernel_timing_reset(False)
+    per_rank = None
     if dist is not None:
+        ex = opts.get("exchange_ms_total")
+        per_rank = _per_rank(torch, dist, comm_dev, elapsed, kern_ms, kern_n, args.steps, None if ex is None else [ex[0] / max(args.steps, 1)])
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -718,7 +754,7 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
             "metric": f"rows/sec {args.workload}", "value": total * args.steps / elapsed, "unit": "rows/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "rows_per_gpu": rows, "total_rows": total, "result": res, **chk, **args.comm},
+            "config": {"workload": desc, "rows_per_gpu": rows, "total_rows": total, "result": res, **chk, **({"per_rank": per_rank} if per_rank else {}), **args.comm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms_per_step": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes},

@@ -556,6 +556,16 @@ rdf_status rdf_comm_allgather(rdf_comm* comm, const void* mine_host, int64_t byt
  * with ranks in place of chunks: identical bits on every rank; integer sums wrap to the value's width; NaN never displaces a
  * number in min / max. */
 rdf_status rdf_agg_combine(rdf_comm* comm, rdf_agg_result* aggs, int32_t nvalues);
+/* rdf_pipeline (an aggregating program, RDF_SINK_AGG) + rdf_agg_combine in ONE call over this rank's device-resident shard:
+ * the shard's partial {sum, min, max, count} never visit the host — they are all-gathered (RCCL, on the communicator's stream,
+ * ordered behind the kernel by an event) and folded on the device by the same fixed-order tree on every rank, and the total is
+ * the first thing the host reads: one wait per step instead of two (the per-step host round trip of the pair of calls is
+ * latency, the same at any number of GPUs).  An error a rank's kernel raises (a zero divisor) is returned on every rank.
+ * The peer transport, and host-resident batches (which may stream), run the two calls this replaces.
+ * rdf_pipeline_frame_dist: the same over a pinned frame. */
+rdf_status rdf_pipeline_dist(rdf_comm* comm, const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks,
+                             rdf_agg_result* aggs);
+rdf_status rdf_pipeline_frame_dist(rdf_comm* comm, const rdf_program* prog, rdf_frame* frame, rdf_agg_result* aggs);
 /* The same for rdf_group_pipeline's output (small dense group domain, TPC-H Q1): out[nvalues * (ngroups + 1)] and
  * group_rows[ngroups + 1] (may be NULL) are replaced by the totals over all ranks. */
 rdf_status rdf_group_combine(rdf_comm* comm, rdf_group_result* out, int64_t* group_rows, int32_t ngroups, int32_t nvalues);

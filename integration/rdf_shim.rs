@@ -131,6 +131,9 @@ pub mod sys {
         pub fn rdf_comm_barrier(comm: *mut rdf_comm) -> i32;
         pub fn rdf_comm_allgather(comm: *mut rdf_comm, mine_host: *const c_void, bytes: i64, all_host: *mut c_void) -> i32;
         pub fn rdf_agg_combine(comm: *mut rdf_comm, aggs: *mut rdf_agg_result, nvalues: i32) -> i32;
+        pub fn rdf_pipeline_dist(comm: *mut rdf_comm, prog: *const rdf_program, cols: *const rdf_array, ncols: i32, nchunks: i64,
+                                 aggs: *mut rdf_agg_result) -> i32;
+        pub fn rdf_pipeline_frame_dist(comm: *mut rdf_comm, prog: *const rdf_program, frame: *mut rdf_frame, aggs: *mut rdf_agg_result) -> i32;
         pub fn rdf_group_combine(comm: *mut rdf_comm, out: *mut rdf_group_result, group_rows: *mut i64, ngroups: i32, nvalues: i32) -> i32;
         pub fn rdf_groupby_agg_dist(comm: *mut rdf_comm, keys: *const rdf_array, values: *const rdf_array, nchunks: i64, agg: i32,
                                     max_groups: i64, exchange: i32, out_keys: *mut rdf_out, out_values: *mut rdf_out,
@@ -346,9 +349,9 @@ impl ShardedFrame {
     /// AggregateFunctions::{sum, min, max, count} of a fused program over the whole sharded column: partials of the shard in,
     /// totals out, identical on every rank (rank-order fold).
     pub fn aggregate(&self, prog: &rdf_program, nvalues: usize) -> Result<Vec<rdf_agg_result>, ArrowError> {
-        let mut aggs = vec![rdf_agg_result::default(); 4];
-        status(unsafe { rdf_pipeline_frame(prog, self.local.handle, std::ptr::null_mut(), aggs.as_mut_ptr()) })?;
-        status(unsafe { rdf_agg_combine(self.comm, aggs.as_mut_ptr(), nvalues as i32) })?;
+        let mut aggs = vec![rdf_agg_result::default(); RDF_MAX_VALUES];
+        // (kernel, all-gather of the partials and their fold stay on the device: one host wait per call)
+        status(unsafe { rdf_pipeline_frame_dist(self.comm, prog, self.local.handle, aggs.as_mut_ptr()) })?;
         aggs.truncate(nvalues);
         Ok(aggs)
     }

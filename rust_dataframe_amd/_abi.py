@@ -1112,6 +1112,33 @@ class Comm:
                 out.append(AggResult(fix(r.sum_i64), fix(r.min_i64), fix(r.max_i64), r.count, bool(r.is_some), r.dtype))
         return out
 
+    def pipeline_dist(self, expr: Expr, cols, value_roots: Sequence[int], filter_root: int = -1) -> List[AggResult]:
+        """Api.pipeline (aggregating) + agg_combine in one call (rdf_pipeline_dist / rdf_pipeline_frame_dist): this rank's shard in,
+        the aggregates over all ranks out — the partials are all-gathered and folded on the device, the host waits once."""
+        nodes = expr.c_array()
+        prog = rdf_program(C.cast(nodes, C.POINTER(rdf_expr_node)), len(expr.nodes), filter_root, len(value_roots),
+                           (C.c_int32 * MAX_VALUES)(*(list(value_roots) + [0] * (MAX_VALUES - len(value_roots)))), SINK_AGG)
+        aggs = (rdf_agg_result * MAX_VALUES)()
+        if isinstance(cols, Frame):
+            fn = self.api._fn("pipeline_frame_dist")
+            fn.restype = C.c_int
+            self.api._check(fn(self.handle, C.byref(prog), cols.handle, aggs))
+        else:
+            nchunks = len(cols[0]) if cols else 0
+            cc = cols.carr if isinstance(cols, Prepared) else _flat(cols, nchunks)
+            fn = self.api._fn("pipeline_dist")
+            fn.restype = C.c_int
+            self.api._check(fn(self.handle, C.byref(prog), cc, C.c_int32(len(cols)), C.c_int64(nchunks), aggs))
+        out = []
+        for i in range(len(value_roots)):
+            r = aggs[i]
+            if r.dtype in (F32, F64):
+                out.append(AggResult(r.sum_f64, r.min_f64, r.max_f64, r.count, bool(r.is_some), r.dtype))
+            else:
+                fix = (lambda x: x + 2 ** 64 if x < 0 else x) if r.dtype == U64 else (lambda x: x)
+                out.append(AggResult(fix(r.sum_i64), fix(r.min_i64), fix(r.max_i64), r.count, bool(r.is_some), r.dtype))
+        return out
+
     def group_combine(self, local):
         """(res, rows) of Api.group_pipeline on this rank -> the same over all ranks."""
         res, rows = local

@@ -72,8 +72,8 @@ struct Ctx {
     int    opt_gb_compact = 1;      // partition path, keys inside a window of 2^39: 1 = 4-byte records when only rows are counted (default); 2 = also 12-byte records (key word + value) for the other aggregates (measured slower than 16-byte records, kept for A/B); 0 = 16-byte records always
     int64_t opt_comm_max_bytes = 0;  // group-by exchange: most bytes one ncclSend / peer copy moves (0 = 256 MiB); larger shares travel in several rounds
     int    opt_spec_blocks = 0;     // resident blocks of the specialised kernels per CU (persistent grid = CUs x this); 0 = by the program (4 / 5 / 8, see run_program)
-    int    opt_spec_tile_rot = 0;   // specialised kernels' tile walk: wave p of row i takes tile i * S + (p + i * 4 * this) mod S (S = the grid's waves); 0 = plain grid stride (SpecArgs::tile_rot)
-    int    opt_spec_xcd_swz = 0;    // 1: XCD x (block index mod 8) walks the x-th contiguous eighth of every row of tiles (SpecArgs::xcd_swz)
+    int    opt_spec_tile_rot = -1;  // specialised kernels' tile walk: wave p of row i takes tile i * S + (p + i * 4 * this) mod S (S = the grid's waves); 0 = plain grid stride (SpecArgs::tile_rot); -1 = by the program (run_program)
+    int    opt_spec_xcd_swz = -1;   // 1: XCD x (block index mod 8) walks the x-th contiguous eighth of every row of tiles (SpecArgs::xcd_swz); 0: plain; -1 = by the program
     int    opt_spec_grid_adj = 0;   // added to the specialised kernels' persistent grid (A/B of grids that are not a multiple of the CU count)
     int    opt_gspec_blocks = 0;    // resident blocks per CU of the grouped register-accumulator kernel (0 = 2: what its ~220 VGPRs allow)
     int    opt_gb_hot = 1;          // skewed keys: 1 = heavy-hitter split (the hot hash classes through gb2_stream_kernel, the scatter path over the rest), default; 0 = capacity plan / first-generation path as in round 3 (A/B)
@@ -102,6 +102,7 @@ struct Ctx {
     hipStream_t d2h_stream = nullptr;
     int64_t stream_slabs = 0, stream_bytes_staged = 0, stream_bytes_direct = 0;   // what the last rdf_pipeline call streamed
     bool in_stream = false;          // a streamed call is running its per-slab calls on this thread (they are not streamed again)
+    ::rdf_comm* agg_comm = nullptr;   // rdf_pipeline_dist: the next aggregate's device-resident partials are all-gathered and folded on the device before the host reads anything
     ~Ctx();
 };
 
@@ -168,8 +169,8 @@ rdf_status ensure_ready() {
     HIP_TRY(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
     c.stream = c.own_stream;
     if (const char* e = getenv("RDF_SPEC_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 0 && v <= 8) c.opt_spec_blocks = v; }   // (A/B without touching the caller)
-    if (const char* e = getenv("RDF_SPEC_TILE_ROT")) { const int v = atoi(e); if (v >= 0) c.opt_spec_tile_rot = v; }
-    if (const char* e = getenv("RDF_SPEC_XCD_SWZ")) c.opt_spec_xcd_swz = atoi(e) != 0;
+    if (const char* e = getenv("RDF_SPEC_TILE_ROT")) c.opt_spec_tile_rot = atoi(e);
+    if (const char* e = getenv("RDF_SPEC_XCD_SWZ")) c.opt_spec_xcd_swz = atoi(e);
     if (const char* e = getenv("RDF_SPEC_GRID_ADJ")) c.opt_spec_grid_adj = atoi(e);
     if (const char* e = getenv("RDF_GSPEC_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 0 && v <= 8) c.opt_gspec_blocks = v; }
     c.ready = true;
@@ -1109,6 +1110,9 @@ rdf_status frame_col_tab(rdf_frame& f, const int* col_map, int n, DevChunkCol** 
     return RDF_OK;
 }
 
+// rdf_capi_comm.inc: this rank's device-resident partial aggregates -> all ranks' -> folded on the device -> host (one wait)
+rdf_status agg_dist_finish(::rdf_comm& c, const AggPartial* d_result, const uint32_t* d_flags, int nvalues, const int* cls, AggPartial* h_out, uint32_t* h_flags);
+
 rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, int64_t nchunks, rdf_out* outs,
                        rdf_agg_result* aggs, const char* len_mismatch_msg, rdf_frame* fc = nullptr) {
     if (nchunks < 0) return fail(RDF_INVALID_ARGUMENT, "negative chunk count");
@@ -1480,16 +1484,28 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         // columns with bitmaps measured best at eight (1.34 against 1.35 / 1.46 ms with seven / three) and keep it.  The same program over the readers' 1024-row batches (a descriptor per two tiles): four blocks 0.825-0.830,
         // five 0.810, eight 0.788-0.796, three 0.764, six 0.740-0.745 (two boxes, alternating rounds).
         // rdf_set_option("spec_blocks_per_cu", n) pins a value (A/B).
+        // Round 5 (tools/exp_tilewalk.py, three boxes, profiles/r05_tilewalk_*.jsonl): with the chunk tables in SGPRs and the
+        // full-tile bitmap path, aggregates run best with 48-64 KB per CU in flight — TWO blocks per CU for the one-column
+        // headline shape (0.886-0.894 against 0.869-0.877 with three), three where a bitmap or a batch table adds scalar work
+        // per tile (0.858-0.866 with 10 % NULLs, 0.76 in round 4; 1024-row batches 0.863-0.875, 0.82) — and with a tile walk that
+        // does not depend on the grid: XCD x takes the x-th contiguous eighth of every row of tiles (xcd_swz), rows rotated by
+        // one block per iteration where several columns or batches are walked (tile_rot).  The plain grid stride swung
+        // 0.78-0.83 from box to box on C3; rotated / swizzled walks and 8 rows per lane hold 0.827-0.842 on every grid tried.
         int blocks_per_cu = ctx.opt_spec_blocks;
-        if (blocks_per_cu <= 0) {
+        int walk_rot = ctx.opt_spec_tile_rot, walk_swz = ctx.opt_spec_xcd_swz;     // (< 0: by the program, below)
+        {
             bool any_bitmap = false;
             for (int k = 0; k < sp.ncols; ++k) any_bitmap |= fc ? fc->col_nullable[sp.col_map[k]] : (nchunks > 0 && in_dev[(size_t)((int64_t)sp.col_map[k] * nchunks)].validity != nullptr);
             bool heavy = false;
             for (int i = 0; i < ps.nnodes; ++i) heavy |= ps.nodes[i].kind == RDF_NODE_OP && op_is_heavy(ps.nodes[i].op);
-            const bool lean = ps.sink == RDF_SINK_AGG && !any_bitmap && !heavy;
-            if (lean) blocks_per_cu = nchunks == 1 ? 3 : sp.ncols == 1 ? 4 : 8;
-            else if (ps.sink == RDF_SINK_STORE && nchunks == 1) blocks_per_cu = 7;
-            else blocks_per_cu = 8;
+            const bool agg = ps.sink == RDF_SINK_AGG && !heavy;
+            if (blocks_per_cu <= 0) {
+                if (agg) blocks_per_cu = (nchunks == 1 && !any_bitmap) ? 2 : 3;
+                else if (ps.sink == RDF_SINK_STORE && nchunks == 1) blocks_per_cu = 7;
+                else blocks_per_cu = 8;
+            }
+            if (walk_swz < 0) walk_swz = agg ? 1 : 0;
+            if (walk_rot < 0) walk_rot = agg && (nchunks > 1 || sp.ncols > 1) ? 1 : 0;
         }
         const int64_t spec_limit = (int64_t)(eval_grid_limit() / 8) * std::max(1, std::min(8, blocks_per_cu));
         grid = (int)(btiles < spec_limit ? btiles : spec_limit);
@@ -1497,8 +1513,8 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
         if (grid < 1) grid = 1;
         {
             const int64_t nwv = (int64_t)grid * (kBlock / 64);
-            sa.tile_rot = ((int64_t)ctx.opt_spec_tile_rot * (kBlock / 64)) % nwv;
-            sa.xcd_swz = ctx.opt_spec_xcd_swz ? 1 : 0;
+            sa.tile_rot = ((int64_t)walk_rot * (kBlock / 64)) % nwv;
+            sa.xcd_swz = walk_swz ? 1 : 0;
         }
         d_result = d_partials + (size_t)grid * (size_t)ps.nvalues;
     }
@@ -1640,6 +1656,15 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             RDF_TRY(launch_agg_pair(&ea, nullptr, 0, cc.feat(), grid, ps.nvalues, cls, d_partials, d_result));
         }
         // results: flags + aggregates in one D2H
+        if (ctx.agg_comm) {
+            // rdf_pipeline_dist: the partials never visit this host — all-gathered and folded on the device, one wait for the total
+            AggPartial hp[kMaxValues];
+            uint32_t flags = 0;
+            RDF_TRY(agg_dist_finish(*ctx.agg_comm, d_result, d_flags, ps.nvalues, cls, hp, &flags));
+            if (flags & 1u) return fail(RDF_DIVIDE_BY_ZERO, "Divide by zero error");
+            for (int v = 0; v < ps.nvalues; ++v) fill_agg_result(&aggs[v], value_dtype[v], hp[v]);
+            return RDF_OK;
+        }
         RDF_TRY(pinned_reserve(pin_off + 64 + sizeof(AggPartial) * kMaxValues));
         char* pin = ctx.pinned + pin_off;
         HIP_TRY(hipMemcpyAsync(pin, d_flags, 16, hipMemcpyDeviceToHost, ctx.stream));
@@ -4054,8 +4079,8 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "gb_bucket") == 0) g_ctx.opt_gb_bucket = (int)value;
     else if (strcmp(name, "gb_hot") == 0) g_ctx.opt_gb_hot = (int)value;
     else if (strcmp(name, "spec_blocks_per_cu") == 0) g_ctx.opt_spec_blocks = (int)value;
-    else if (strcmp(name, "spec_tile_rot") == 0) g_ctx.opt_spec_tile_rot = value < 0 ? 0 : (int)value;
-    else if (strcmp(name, "spec_xcd_swz") == 0) g_ctx.opt_spec_xcd_swz = value != 0;
+    else if (strcmp(name, "spec_tile_rot") == 0) g_ctx.opt_spec_tile_rot = value < 0 ? -1 : (int)value;
+    else if (strcmp(name, "spec_xcd_swz") == 0) g_ctx.opt_spec_xcd_swz = value < 0 ? -1 : value != 0;
     else if (strcmp(name, "spec_grid_adj") == 0) g_ctx.opt_spec_grid_adj = (int)value;
     else if (strcmp(name, "gspec_blocks_per_cu") == 0) g_ctx.opt_gspec_blocks = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;

@@ -21,7 +21,7 @@ EXPORTS = [
     "rdf_binary", "rdf_unary", "rdf_cast", "rdf_hour", "rdf_sum", "rdf_min", "rdf_max", "rdf_count", "rdf_avg",
     "rdf_predicate", "rdf_filter_count", "rdf_filter", "rdf_filter_columns", "rdf_filter_pipeline", "rdf_take", "rdf_list_contains", "rdf_list_position", "rdf_list_max", "rdf_list_min", "rdf_list_remove", "rdf_list_sort", "rdf_list_distinct", "rdf_list_except", "rdf_list_intersect", "rdf_list_union", "rdf_list_repeat", "rdf_pipeline", "rdf_stream_stats", "rdf_frame_pin", "rdf_frame_release", "rdf_pipeline_frame", "rdf_group_pipeline_frame", "rdf_predicate_frame", "rdf_frame_info", "rdf_frame_column", "rdf_filter_frame", "rdf_take_columns", "rdf_take_frame", "rdf_sort_frame", "rdf_groupby_agg_frame", "rdf_group_pipeline", "rdf_groupby_sum", "rdf_groupby_agg", "rdf_groupby_merge", "rdf_group_exchange_pack", "rdf_group_exchange_unpack", "rdf_row_exchange_pack", "rdf_row_exchange_unpack", "rdf_sort_to_indices", "rdf_equijoin_indices", "rdf_equijoin_indices_multi",
     "rdf_comm_unique_id", "rdf_comm_init_rank", "rdf_comm_init_all", "rdf_comm_destroy", "rdf_comm_info", "rdf_comm_barrier", "rdf_comm_allgather",
-    "rdf_agg_combine", "rdf_group_combine", "rdf_groupby_agg_dist", "rdf_groupby_agg_frame_dist",
+    "rdf_agg_combine", "rdf_pipeline_dist", "rdf_pipeline_frame_dist", "rdf_group_combine", "rdf_groupby_agg_dist", "rdf_groupby_agg_frame_dist",
     "rdf_fill_uniform_f64", "rdf_fill_uniform_i64", "rdf_fill_validity",
     "rdf_kernel_timing_reset", "rdf_kernel_timing_get", "rdf_set_option", "rdf_spec_catalog_size", "rdf_jit_status", "rdf_last_kernel",
 ]

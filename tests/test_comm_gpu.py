@@ -326,6 +326,8 @@ def test_agg_and_group_combine_between_peer_ranks(eng, ora):
                 e = A.Expr()
                 local = api.pipeline(e, [[d.array(part, dt)]], [e.col(0)])
                 out[dt] = comms[r].agg_combine(local)[0]
+                both = comms[r].pipeline_dist(e, [[d.array(part, dt)]], [e.col(0)])[0]      # (peer transport: the two calls it replaces)
+                assert (both.count, both.dtype) == (out[dt].count, out[dt].dtype) and (both.sum == out[dt].sum or (both.sum != both.sum and out[dt].sum != out[dt].sum))
             # Q1-shaped grouped sums
             q = A.Expr()
             gid = np.ascontiguousarray((np.arange(bounds[r], bounds[r + 1]) % 6).astype(np.int32))
@@ -403,6 +405,24 @@ def test_rccl_one_rank_communicator(eng, ora, how):
         local = api.pipeline(e, [[V]], [e.col(0)])
         tot = comm.agg_combine(local)[0]
         assert tot.sum == local[0].sum and tot.count == n
+        # rdf_pipeline_dist / rdf_pipeline_frame_dist: kernel + all-gather + fold of the partials on the device, one host wait:
+        # on a 1-rank communicator the result IS the local one, through both all-gathers and the fold kernel
+        pred = e.op("gt", e.col(1), e.scalar(0.25))
+        KI = d.array((keys % 1000).astype(np.int32), A.I32)
+        for cols, roots in (([[KI], [V]], [e.col(1), e.col(0)]), ([[KI], [V]], [e.op("multiply", e.col(1), e.scalar(2.0))])):
+            want = api.pipeline(e, cols, roots, pred)
+            got = comm.pipeline_dist(e, cols, roots, pred)
+            for g, w in zip(got, want):
+                assert (g.count, g.min, g.max, g.dtype, g.is_some) == (w.count, w.min, w.max, w.dtype, w.is_some), (g, w)
+                assert g.sum == w.sum, "one rank: the fold of one partial is the partial"
+        fr = A.PinnedFrame(api, [[KI], [V]])
+        got = comm.pipeline_dist(e, fr, [e.col(1)], pred)[0]
+        want = api.pipeline(e, fr, [e.col(1)], pred)[0]
+        assert (got.sum, got.count, got.min, got.max) == (want.sum, want.count, want.min, want.max)
+        zero = d.array(np.zeros(1000, dtype=np.int32), A.I32)
+        with pytest.raises(A.RdfError) as ei:        # a kernel's error flag travels with the partials: DivideByZero on every rank
+            comm.pipeline_dist(e, [[zero], [zero]], [e.op("divide", e.col(0), e.col(1))])
+        assert ei.value.status == A.RDF_DIVIDE_BY_ZERO
         comm.barrier()
         assert comm.allgather(b"abc") == [b"abc"]
     finally:

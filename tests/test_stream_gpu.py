@@ -136,10 +136,12 @@ def test_streamed_store_sinks_match_oracle_and_one_shot(gpu, ora, lens, off, nf)
         assert lib.stream_stats()[0] == 0
         for slab in (256 << 10, 2 << 20):
             lib.set_option("stream_slab_bytes", slab)
-            for what, got, one, exp in (("add", gpu.binary("add", a, b), one_add, ora.binary("add", a, b)),
-                                        ("sin", gpu.unary("sin", a), one_sin, ora.unary("sin", a)),
-                                        ("cast", gpu.cast(k, A.F64), one_cast, ora.cast(k, A.F64))):
-                assert lib.stream_stats()[0] >= 2, (what, slab, lib.stream_stats())
+            for what, run, one, exp in (("add", lambda: gpu.binary("add", a, b), one_add, ora.binary("add", a, b)),
+                                        ("sin", lambda: gpu.unary("sin", a), one_sin, ora.unary("sin", a)),
+                                        ("cast", lambda: gpu.cast(k, A.F64), one_cast, ora.cast(k, A.F64))):
+                got = run()
+                in_bytes = sum(lens) * (16 if what == "add" else 8 if what == "sin" else 4)
+                assert lib.stream_stats()[0] >= 2 or in_bytes <= slab, (what, slab, lib.stream_stats())
                 assert_chunks_match(got, exp, exact=(what != "sin"), what=f"streamed {what} slab={slab} vs oracle")
                 assert_chunks_match(got, one, exact=True, what=f"streamed {what} slab={slab} vs one shot")
             # a fused program with a new column as its sink, and a predicate mask (bit-packed values)
@@ -147,13 +149,13 @@ def test_streamed_store_sinks_match_oracle_and_one_shot(gpu, ora, lens, off, nf)
             y = e.op("sin", e.op("add", e.col(0), e.scalar(1.0)))
             outs = [[A.HostArray.empty_out(A.F64, n, nf > 0) for n in lens]]
             got = gpu.pipeline(e, [a], [y], sink=A.SINK_STORE, outs=outs)[0]
-            assert lib.stream_stats()[0] >= 2
+            assert lib.stream_stats()[0] >= 2 or sum(lens) * 8 <= slab
             exp = ora.pipeline(e, [a], [y], sink=A.SINK_STORE, outs=[[A.HostArray.empty_out(A.F64, n, nf > 0) for n in lens]])[0]
             assert_chunks_match(got, exp, exact=False, what=f"sin(x + 1) -> column, slab={slab}")
             p = A.Expr()
             pred = p.op("and", p.op("gt", p.col(0), p.scalar(0.25)), p.op("le", p.col(1), p.scalar(0.75)))
             gm, em = gpu.predicate(p, pred, [a, b]), ora.predicate(p, pred, [a, b])
-            assert lib.stream_stats()[0] >= 2
+            assert lib.stream_stats()[0] >= 2 or sum(lens) * 16 <= slab
             assert_chunks_match(gm, em, exact=True, what=f"predicate mask slab={slab}")
     finally:
         lib.set_option("stream_slab_bytes", 0)

@@ -56,8 +56,8 @@ def main():
         lib.fill_uniform_i64(t.data_ptr(), rows, SEED, col, 0, lo, hi)
         return t
 
-    # (blocks per CU, tile_rot, xcd_swz, grid_adj)
-    variants = [(0, 0, 0, 0), (3, 0, 0, 0), (4, 0, 0, 0), (5, 0, 0, 0), (6, 0, 0, 0), (8, 0, 0, 0),
+    # (blocks per CU, tile_rot, xcd_swz, grid_adj); 0 / -1 / -1 / 0 = what run_program picks for the program
+    variants = [(0, -1, -1, 0), (3, 0, 0, 0), (4, 0, 0, 0), (5, 0, 0, 0), (6, 0, 0, 0), (8, 0, 0, 0),
                 (4, 37, 0, 0), (8, 37, 0, 0), (4, 1, 0, 0), (8, 1, 0, 0), (3, 37, 0, 0),
                 (4, 0, 1, 0), (8, 0, 1, 0), (3, 0, 1, 0), (8, 37, 1, 0),
                 (4, 0, 0, -1), (8, 0, 0, -1), (8, 0, 0, -3)]
@@ -80,8 +80,11 @@ def main():
             ms = timed(fn, a.steps)
             print(json.dumps({"exp": "tilewalk", "config": name, "rows": n, "blocks_per_cu": b, "tile_rot": rot, "xcd_swz": swz, "grid_adj": adj,
                               "kernel_ms": round(ms, 4), "frac_of_8TBps": round(alg_bytes / ms / 1e6 / 8000.0, 4), "kernel": lib.last_kernel()}), flush=True)
-        for k in ("spec_blocks_per_cu", "spec_tile_rot", "spec_xcd_swz", "spec_grid_adj"):
-            opt(k, 0)
+        for k, v in (("spec_blocks_per_cu", 0), ("spec_tile_rot", -1), ("spec_xcd_swz", -1), ("spec_grid_adj", 0)):
+            try:
+                lib.set_option(k, v)
+            except Exception:
+                pass
 
     e = A.Expr()
     c = e.col(0)
@@ -127,7 +130,7 @@ def main():
         A1 = [A.DeviceArray(xa.data_ptr(), None, 0, n, A.F64, 0, keep=xa)]
         B1 = [A.DeviceArray(xb.data_ptr(), None, 0, n, A.F64, 0, keep=xb)]
         sweep("add_store", 24.0 * n, lambda: api.binary("add", A1, B1, [out]),
-              vs=[(0, 0, 0, 0), (7, 0, 0, 0), (8, 0, 0, 0), (5, 0, 0, 0), (8, 37, 0, 0), (8, 0, 1, 0), (7, 0, 1, 0), (8, 0, 0, -1)])
+              vs=[(0, -1, -1, 0), (7, 0, 0, 0), (8, 0, 0, 0), (5, 0, 0, 0), (8, 37, 0, 0), (8, 0, 1, 0), (7, 0, 1, 0), (8, 0, 0, -1)])
         del xa, xb, ov
         torch.cuda.empty_cache()
 
