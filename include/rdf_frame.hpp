@@ -254,13 +254,27 @@ struct Array {
         return o;
     }
     // freshly allocated output array (capacity rounded up to 64 elements as the ABI asks)
-    static std::shared_ptr<Array> make_out(DataType t, int64_t capacity, bool with_validity) {
+    // `on_host`: the output of an operator over a host-resident frame (DataFrame::from_arrow_host) lives in page-locked host
+    // memory — the library streams such calls and its copies back are plain DMA into these buffers
+    static std::shared_ptr<Array> make_out(DataType t, int64_t capacity, bool with_validity, bool on_host = false) {
         auto a = std::make_shared<Array>();
         const int64_t cap = (capacity + 63) / 64 * 64;
         a->dtype = t;
-        a->values = std::make_shared<DeviceBuffer>(t == DataType::Boolean ? cap / 8 + 8 : cap * type_size(t) + 8);
-        if (with_validity) a->validity = std::make_shared<DeviceBuffer>(cap / 8 + 8);
+        a->host = on_host;
+        auto buf = [&](int64_t bytes) -> BufferRef {
+            if (!on_host) return std::make_shared<DeviceBuffer>(bytes);
+            auto pin = std::make_shared<PinnedBuffer>(bytes);
+            return std::make_shared<DeviceBuffer>(pin->data(), bytes, pin);
+        };
+        a->values = buf(t == DataType::Boolean ? cap / 8 + 8 : cap * type_size(t) + 8);
+        if (with_validity) a->validity = buf(cap / 8 + 8);
         return a;
+    }
+    // bytes of this array's buffers on the caller's side of the link: a copy off the device, or straight out of host memory
+    void fetch(void* dst, const void* src, int64_t bytes) const {
+        if (bytes <= 0) return;
+        if (host) std::memcpy(dst, src, (size_t)bytes);
+        else check(rdf_copy_d2h(dst, src, bytes));
     }
     template <class T>
     static ArrayRef from_vec(const std::vector<T>& v, const std::vector<bool>* valid = nullptr) {
@@ -314,7 +328,7 @@ struct Array {
         if (!buf || length == 0) return out;
         const int64_t b0 = offset >> 3, b1 = (offset + length + 7) >> 3;
         std::vector<uint8_t> raw((size_t)(b1 - b0));
-        check(rdf_copy_d2h(raw.data(), (const uint8_t*)buf->data() + b0, b1 - b0));
+        fetch(raw.data(), (const uint8_t*)buf->data() + b0, b1 - b0);
         for (int64_t i = 0; i < length; ++i) { const int64_t k = (offset & 7) + i; out[(size_t)i] = (raw[(size_t)(k >> 3)] >> (k & 7)) & 1; }
         return out;
     }
@@ -324,13 +338,13 @@ struct Array {
     std::vector<T> values_to_host() const {
         if (TypeOf<T>::value != dtype) throw DataFrameError(DataFrameError::ComputeError, "values_to_host: type mismatch");
         std::vector<T> out((size_t)length);
-        if (length) check(rdf_copy_d2h(out.data(), (const T*)values->data() + offset, length * (int64_t)sizeof(T)));
+        if (length) fetch(out.data(), (const T*)values->data() + offset, length * (int64_t)sizeof(T));
         return out;
     }
     bool is_null(int64_t i) const { return validity && !valid_to_host()[(size_t)i]; }
     template <class T> T value(int64_t i) const {
         T v;
-        check(rdf_copy_d2h(&v, (const T*)values->data() + offset + i, (int64_t)sizeof(T)));
+        fetch(&v, (const T*)values->data() + offset + i, (int64_t)sizeof(T));
         return v;
     }
     int64_t count_nulls() const {  // resolves an unknown null_count on the device
@@ -1235,7 +1249,7 @@ inline std::vector<ArrayRef> cast_arrays(const std::vector<ArrayRef>& arr, DataT
     std::vector<rdf_array> a;
     std::vector<std::shared_ptr<Array>> outs;
     std::vector<rdf_out> ov;
-    for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(to, x->length, true)); ov.push_back(outs.back()->out_view(x->length)); }   // (a value the target type cannot hold becomes NULL: always a bitmap)
+    for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(to, x->length, true, x->host)); ov.push_back(outs.back()->out_view(x->length)); }   // (a value the target type cannot hold becomes NULL: always a bitmap)
     check(rdf_cast(a.data(), (int64_t)a.size(), ov.data()));
     std::vector<ArrayRef> res;
     for (size_t i = 0; i < outs.size(); ++i) { outs[i]->length = ov[i].length; outs[i]->null_count = ov[i].null_count; res.push_back(outs[i]); }
@@ -1877,7 +1891,8 @@ class DataFrame {
         std::vector<std::shared_ptr<Array>> outs;
         std::vector<rdf_out> ov;
         const auto counts = columns_[0].data().chunk_counts();
-        for (size_t i = 0; i < nch; ++i) { outs.push_back(Array::make_out(DataType::Boolean, counts[i], nullable)); ov.push_back(outs.back()->out_view(counts[i])); }
+        const bool on_host = is_host();
+        for (size_t i = 0; i < nch; ++i) { outs.push_back(Array::make_out(DataType::Boolean, counts[i], nullable, on_host)); ov.push_back(outs.back()->out_view(counts[i])); }
         if (low.columns.empty()) {  // constant predicate: the batch length comes from column 0
             for (auto& a : columns_[0].data().chunks()) cols.push_back(a->view());
             check(rdf_predicate(low.nodes.data(), (int32_t)low.nodes.size(), root, cols.data(), 1, (int64_t)nch, ov.data()));
@@ -1887,8 +1902,53 @@ class DataFrame {
         for (size_t i = 0; i < nch; ++i) { outs[i]->length = ov[i].length; outs[i]->null_count = ov[i].null_count; res.push_back(outs[i]); }
         return Column::from_arrays(res, Field{"bool_filter", DataType::Boolean, true});
     }
-    // DataFrame::filter (:178-189): the mask, then EVERY column compacted by it in one pass (rdf_filter_columns)
-    DataFrame filter(const FilterRef& condition) const { return filter_by_mask(evaluate_boolean_filter(condition)); }
+    // the frame's numeric / Boolean column chunks are views into host memory (from_arrow_host, or the result of an operator over such a frame)
+    bool is_host() const {
+        for (auto& c : columns_) for (auto& a : c.data().chunks()) if (a->dtype != DataType::Utf8 && a->host) return true;
+        return false;
+    }
+    // DataFrame::filter (:178-189): the mask, then EVERY column compacted by it in one pass (rdf_filter_columns).
+    // A host-resident frame of numeric columns takes ONE call instead (rdf_filter_pipeline): predicate and compaction run on the
+    // device slab by slab while the next slab comes in and the kept rows of the previous one go back — the result is a
+    // host-resident frame again, and a frame larger than free HBM is filtered all the same.
+    DataFrame filter(const FilterRef& condition) const {
+        bool all_numeric = !columns_.empty();
+        for (auto& c : columns_) all_numeric = all_numeric && (is_integer(c.data_type()) || is_float(c.data_type()));
+        if (!(is_host() && all_numeric && columns_.size() <= 64)) return filter_by_mask(evaluate_boolean_filter(condition));
+        Lowered low;
+        const int root = low.add(filter_to_expr(condition, [this](const std::string& n) {
+            if (!has_column(n)) throw DataFrameError(DataFrameError::ComputeError, "Cannot find column " + n);
+            return Expr::col(n);
+        }));
+        // the call's column order: the predicate's columns first (the expression indexes them), then the rest of the frame
+        std::vector<size_t> order;
+        for (auto& n : low.columns) order.push_back(schema_.column_with_name(n)->first);
+        for (size_t k = 0; k < columns_.size(); ++k) if (std::find(order.begin(), order.end(), k) == order.end()) order.push_back(k);
+        if (order.size() != columns_.size()) return filter_by_mask(evaluate_boolean_filter(condition));   // (a column named twice by the predicate's lowering)
+        const size_t nch = num_chunks();
+        std::vector<rdf_array> cv;
+        std::vector<std::shared_ptr<Array>> outs;
+        std::vector<rdf_out> ov;
+        for (size_t k : order)
+            for (auto& a : columns_[k].data().chunks()) {
+                cv.push_back(a->view());
+                outs.push_back(Array::make_out(a->dtype, a->length, a->validity != nullptr, true));
+                ov.push_back(outs.back()->out_view(a->length));
+            }
+        check(rdf_filter_pipeline(low.nodes.data(), (int32_t)low.nodes.size(), root, cv.data(), (int32_t)order.size(), (int64_t)nch, ov.data()));
+        std::vector<Column> result(columns_.size());
+        for (size_t j = 0; j < order.size(); ++j) {
+            std::vector<ArrayRef> chunks;
+            for (size_t i = 0; i < nch; ++i) {
+                auto& o = outs[j * nch + i];
+                o->length = ov[j * nch + i].length;
+                o->null_count = ov[j * nch + i].null_count;
+                chunks.push_back(o);
+            }
+            result[order[j]] = Column::from_arrays(chunks, columns_[order[j]].field());
+        }
+        return DataFrame(schema_, std::move(result));
+    }
     DataFrame filter_by_mask(const Column& mask) const {
         const size_t nch = num_chunks();
         const auto mv = mask.data().views();
@@ -1912,7 +1972,7 @@ class DataFrame {
                         continue;
                     }
                     cv.push_back(src->view());
-                    outs.push_back(Array::make_out(is_bool ? DataType::UInt8 : c.data_type(), counts[i], src->validity != nullptr));
+                    outs.push_back(Array::make_out(is_bool ? DataType::UInt8 : c.data_type(), counts[i], src->validity != nullptr, src->host));
                     ov.push_back(outs.back()->out_view(counts[i]));
                 }
             }
@@ -2261,7 +2321,7 @@ struct ScalarFunctions {
         std::vector<rdf_out> ov;
         for (size_t i = 0; i < left.size(); ++i) {
             a.push_back(left[i]->view()); b.push_back(right[i]->view());
-            outs.push_back(Array::make_out(left[i]->dtype, left[i]->length, left[i]->validity || right[i]->validity));
+            outs.push_back(Array::make_out(left[i]->dtype, left[i]->length, left[i]->validity || right[i]->validity, left[i]->host));
             ov.push_back(outs.back()->out_view(left[i]->length));
         }
         check(rdf_binary(op, a.data(), b.data(), (int64_t)a.size(), ov.data()));
@@ -2271,7 +2331,7 @@ struct ScalarFunctions {
         std::vector<rdf_array> a;
         std::vector<std::shared_ptr<Array>> outs;
         std::vector<rdf_out> ov;
-        for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(x->dtype, x->length, x->validity != nullptr)); ov.push_back(outs.back()->out_view(x->length)); }
+        for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(x->dtype, x->length, x->validity != nullptr, x->host)); ov.push_back(outs.back()->out_view(x->length)); }
         check(rdf_unary(op, a.data(), (int64_t)a.size(), ov.data()));
         return finish(outs, ov);
     }
@@ -2279,7 +2339,7 @@ struct ScalarFunctions {
         std::vector<rdf_array> a;
         std::vector<std::shared_ptr<Array>> outs;
         std::vector<rdf_out> ov;
-        for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(to, x->length, true)); ov.push_back(outs.back()->out_view(x->length)); }   // (a value the target type cannot hold becomes NULL: always a bitmap)
+        for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(to, x->length, true, x->host)); ov.push_back(outs.back()->out_view(x->length)); }   // (a value the target type cannot hold becomes NULL: always a bitmap)
         check(rdf_cast(a.data(), (int64_t)a.size(), ov.data()));
         return finish(outs, ov);
     }
@@ -2288,7 +2348,7 @@ struct ScalarFunctions {
         std::vector<rdf_array> a;
         std::vector<std::shared_ptr<Array>> outs;
         std::vector<rdf_out> ov;
-        for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(DataType::Int32, x->length, x->validity != nullptr)); ov.push_back(outs.back()->out_view(x->length)); }
+        for (auto& x : arr) { a.push_back(x->view()); outs.push_back(Array::make_out(DataType::Int32, x->length, x->validity != nullptr, x->host)); ov.push_back(outs.back()->out_view(x->length)); }
         check(rdf_hour(a.data(), (int64_t)a.size(), (int32_t)unit, ov.data()));
         return finish(outs, ov);
     }
@@ -2638,9 +2698,10 @@ class Evaluate {
             std::shared_ptr<Array> os, oc;
             for (;;) {   // the number of groups is not known in advance: grow the promise until it holds
                 std::vector<rdf_out> vk(nk);
-                for (size_t k = 0; k < nk; ++k) { ok[k] = Array::make_out(kcs[k]->data_type(), mg + 2, key_nulls[k]); vk[k] = ok[k]->out_view(mg + 2); }
-                os = Array::make_out(sdt, mg + 2, extremum && val_nulls);
-                oc = Array::make_out(DataType::Int64, mg + 2, false);
+                const bool on_host = f.is_host();      // host-resident batches: the library streams them, the groups come back to the host
+                for (size_t k = 0; k < nk; ++k) { ok[k] = Array::make_out(kcs[k]->data_type(), mg + 2, key_nulls[k], on_host); vk[k] = ok[k]->out_view(mg + 2); }
+                os = Array::make_out(sdt, mg + 2, extremum && val_nulls, on_host);
+                oc = Array::make_out(DataType::Int64, mg + 2, false, on_host);
                 rdf_out vs = os->out_view(mg + 2), vcn = oc->out_view(mg + 2);
                 const rdf_status st = rdf_groupby_agg(keys.data(), (int32_t)nk, vals.data(), (int64_t)nch, agg, mg, vk.data(), &vs, &vcn);
                 if (st == RDF_MEMORY_ERROR && mg < nrows) { mg = std::min<int64_t>(nrows, mg * 16); continue; }
@@ -2931,7 +2992,7 @@ class Evaluate {
             std::vector<std::shared_ptr<Array>> outs;
             std::vector<rdf_out> ov;
             for (size_t k = 0; k < n; ++k)
-                for (size_t i = 0; i < nch; ++i) { outs.push_back(Array::make_out(cols_[lazy[b + k]].dtype, counts[i], true)); ov.push_back(outs.back()->out_view(counts[i])); }
+                for (size_t i = 0; i < nch; ++i) { outs.push_back(Array::make_out(cols_[lazy[b + k]].dtype, counts[i], true, base_.is_host())); ov.push_back(outs.back()->out_view(counts[i])); }
             check(rdf_pipeline(&prog, cv.data(), (int32_t)low.columns.size(), (int64_t)nch, ov.data(), nullptr));
             for (size_t k = 0; k < n; ++k) {
                 std::vector<ArrayRef> chunks;

@@ -1073,6 +1073,16 @@ namespace {
 
 rdf_status frame_host(rdf_frame& f);   // rdf_capi_frame.inc: host mirrors of a frame an operator built on the device
 
+// A frame's small device tables (descriptors, batch lengths, tile prefixes) come out of the thread's buffer pool like its column
+// buffers: hipFree waits for the whole device — every stream, the streamed batch loop's copies included — and a frame per slab
+// was a wait per slab.
+rdf_status frame_table_alloc(rdf_frame& f, size_t bytes, void** out) {
+    size_t got = 0;
+    RDF_TRY(pool_alloc(bytes, out, &got));
+    f.pooled.emplace_back(*out, got);
+    return RDF_OK;
+}
+
 rdf_status frame_tiles(rdf_frame& f, int rows_per_tile, const rdf_frame::Tiles** out) {
     RDF_TRY(frame_host(f));
     auto it = f.tiles.find(rows_per_tile);
@@ -1084,8 +1094,7 @@ rdf_status frame_tiles(rdf_frame& f, int rows_per_tile, const rdf_frame::Tiles**
         if (f.nchunks > 1 && ts[(size_t)f.nchunks - 1] > 0 && f.nchunks - 1 < ((int64_t)1 << 31))
             t.tile_inv = (uint64_t)(((unsigned __int128)(uint64_t)(f.nchunks - 1) << 32) / (unsigned __int128)(uint64_t)ts[(size_t)f.nchunks - 1]);
         void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, ts.size() * 8 + 64));
-        f.allocs.push_back(p);
+        RDF_TRY(frame_table_alloc(f, ts.size() * 8 + 64, &p));
         HIP_TRY(hipMemcpy(p, ts.data(), ts.size() * 8, hipMemcpyHostToDevice));
         t.d_start = (int64_t*)p;
         it = f.tiles.emplace(rows_per_tile, t).first;
@@ -1101,8 +1110,7 @@ rdf_status frame_col_tab(rdf_frame& f, const int* col_map, int n, DevChunkCol** 
         std::vector<DevChunkCol> tab((size_t)n * (size_t)f.nchunks);
         for (int k = 0; k < n; ++k) memcpy(tab.data() + (size_t)k * (size_t)f.nchunks, f.dev.data() + (size_t)col_map[k] * (size_t)f.nchunks, sizeof(DevChunkCol) * (size_t)f.nchunks);
         void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, tab.size() * sizeof(DevChunkCol) + 64));
-        f.allocs.push_back(p);
+        RDF_TRY(frame_table_alloc(f, tab.size() * sizeof(DevChunkCol) + 64, &p));
         HIP_TRY(hipMemcpy(p, tab.data(), tab.size() * sizeof(DevChunkCol), hipMemcpyHostToDevice));
         it = f.col_tabs.emplace(key, (DevChunkCol*)p).first;
     }
@@ -2103,17 +2111,14 @@ rdf_status rdf_frame_pin(const rdf_array* cols, int32_t ncols, int64_t nchunks, 
     for (int64_t c = 0; c + 1 < nchunks && f->uniform_len > 0; ++c) if (f->clen[(size_t)c] != f->uniform_len) f->uniform_len = 0;
     if (f->uniform_len > 0 && f->clen[(size_t)nchunks - 1] > f->uniform_len) f->uniform_len = 0;
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, f->dev.size() * sizeof(DevChunkCol) + 64);
-    if (e != hipSuccess) return fail(RDF_MEMORY_ERROR, "frame_pin: hipMalloc: %s", hipGetErrorString(e));
-    f->allocs.push_back(p);
+    auto undo = [&]() { for (auto& pb : f->pooled) pool_release(pb.first, pb.second); f->pooled.clear(); };
+    if (frame_table_alloc(*f, f->dev.size() * sizeof(DevChunkCol) + 64, &p) != RDF_OK) return RDF_MEMORY_ERROR;
     f->d_cols = (DevChunkCol*)p;
-    e = hipMalloc(&p, f->clen.size() * 8 + 64);
-    if (e != hipSuccess) { for (void* q : f->allocs) (void)hipFree(q); return fail(RDF_MEMORY_ERROR, "frame_pin: hipMalloc: %s", hipGetErrorString(e)); }
-    f->allocs.push_back(p);
+    if (frame_table_alloc(*f, f->clen.size() * 8 + 64, &p) != RDF_OK) { undo(); return RDF_MEMORY_ERROR; }
     f->d_clen = (int64_t*)p;
-    e = hipMemcpy(f->d_cols, f->dev.data(), f->dev.size() * sizeof(DevChunkCol), hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(f->d_cols, f->dev.data(), f->dev.size() * sizeof(DevChunkCol), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(f->d_clen, f->clen.data(), f->clen.size() * 8, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { for (void* q : f->allocs) (void)hipFree(q); return fail(RDF_DEVICE_ERROR, "frame_pin: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { undo(); return fail(RDF_DEVICE_ERROR, "frame_pin: %s", hipGetErrorString(e)); }
     *out = f.release();
     return RDF_OK;
 }
@@ -2125,6 +2130,7 @@ rdf_status rdf_frame_release(rdf_frame* frame) {
     for (auto& pb : frame->pooled) pool_release(pb.first, pb.second);
     for (auto& pr : frame->projections) {
         for (void* q : pr.second->allocs) (void)hipFree(q);
+        for (auto& pb : pr.second->pooled) pool_release(pb.first, pb.second);
         delete pr.second;
     }
     delete frame;

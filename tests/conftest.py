@@ -10,8 +10,13 @@ if ROOT not in sys.path:
 
 # The run-time compiler keeps its code objects across processes (~/.cache/rdf_mi355x/jit by default).  A test session gets a
 # directory of its own, so that "met for the first time" means the same thing on a fresh box and on one that ran the suite before.
+import atexit  # noqa: E402
+import shutil  # noqa: E402
 import tempfile  # noqa: E402
-os.environ.setdefault("RDF_JIT_CACHE", tempfile.mkdtemp(prefix="rdf_jit_cache_"))
+if "RDF_JIT_CACHE" not in os.environ:          # (only then: a directory is created, and removed again when the session ends)
+    _jit_dir = tempfile.mkdtemp(prefix="rdf_jit_cache_")
+    os.environ["RDF_JIT_CACHE"] = _jit_dir
+    atexit.register(shutil.rmtree, _jit_dir, ignore_errors=True)
 
 
 def pytest_configure(config):

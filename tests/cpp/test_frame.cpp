@@ -1055,12 +1055,54 @@ TEST(test_from_arrow_host_resident_frame_is_streamed) {
     check(rdf_set_option("stream_slab_bytes", 0));
     // column aggregates straight from the mapping
     CHECK_NEAR(*AggregateFunctions::sum<double>(h.column_by_name("f64").data()), *AggregateFunctions::sum<double>(d.column_by_name("f64").data()), 1e-12);
-    // an operator that returns device columns does not mix memory spaces: an error, not a wrong answer; to_device() first
-    CHECK_THROWS(h.filter(cond));
+    // round 5: operators over a host-resident frame return host-resident frames — the library streams the batches through HBM and
+    // the results come back (the values are read straight out of host memory: no device copy behind value<T>()).
     DataFrame up = h.to_device();
     CHECK(!up.column_by_name("f64").data().chunk(0)->host);
     CHECK_EQ(up.filter(cond).num_rows(), (int64_t)(2624 - 1001));
     same(run(up));
+    {
+        // (a) DataFrame::filter with text columns aboard: streamed predicate -> host mask, every column compacted by it
+        const DataFrame hf = h.filter(cond), df = up.filter(cond);
+        CHECK_EQ(hf.num_rows(), df.num_rows());
+        CHECK(hf.column_by_name("f64").data().chunk(0)->host);
+        CHECK_EQ(hf.column_by_name("city").data().chunk(2)->strings->size(), df.column_by_name("city").data().chunk(2)->strings->size());
+        // (b) the numeric columns alone: ONE rdf_filter_pipeline call, also across many slabs
+        const DataFrame hn = h.select({"f64", "i64", "i32", "f32", "u16", "i8"}), dn = up.select({"f64", "i64", "i32", "f32", "u16", "i8"});
+        auto cmp_frames = [&](const DataFrame& a, const DataFrame& b) {
+            CHECK_EQ(a.num_rows(), b.num_rows());
+            CHECK_EQ(a.num_chunks(), b.num_chunks());
+            for (size_t c = 0; c < b.num_columns(); ++c)
+                for (size_t i = 0; i < b.num_chunks(); ++i) {
+                    const auto &x = a.column(c).data().chunk(i), &y = b.column(c).data().chunk(i);
+                    CHECK_EQ(x->length, y->length);
+                    CHECK_EQ(x->count_nulls(), y->count_nulls());
+                    CHECK(x->valid_to_host() == y->valid_to_host());
+                }
+            CHECK(a.column_by_name("i64").data().chunk(1)->values_to_host<int64_t>() == b.column_by_name("i64").data().chunk(1)->values_to_host<int64_t>());
+            CHECK(a.column_by_name("u16").data().chunk(2)->values_to_host<uint16_t>() == b.column_by_name("u16").data().chunk(2)->values_to_host<uint16_t>());
+        };
+        const DataFrame want_n = dn.filter(cond);
+        cmp_frames(hn.filter(cond), want_n);
+        check(rdf_set_option("stream_slab_bytes", 8192));
+        try {
+            const DataFrame got = hn.filter(cond);
+            check(rdf_stream_stats(&slabs, &staged, &direct));
+            CHECK(slabs >= 2);
+            CHECK(got.column(0).data().chunk(0)->host);
+            cmp_frames(got, want_n);
+            // (c) a Calculate step (new column) and a hash GROUP BY over the host-resident frame: streamed, host-resident results
+            auto calc = [&](const DataFrame& f) {
+                return LazyFrame::read(f).with_column("y", P::Function::Scalar_(P::ScalarFunction::Sine), {"f64"}).evaluate();
+            };
+            const DataFrame hy = calc(hn), dy = calc(dn);
+            CHECK(hy.column_by_name("y").data().chunk(0)->host);
+            const auto a = hy.column_by_name("y").data().chunk(1)->values_to_host<double>(), b = dy.column_by_name("y").data().chunk(1)->values_to_host<double>();
+            CHECK_EQ(a.size(), b.size());
+            for (size_t i = 0; i < a.size(); ++i) CHECK(a[i] == b[i] || (a[i] != a[i] && b[i] != b[i]));
+        } catch (...) { (void)rdf_set_option("stream_slab_bytes", 0); throw; }
+        check(rdf_set_option("stream_slab_bytes", 0));
+    }
     // dictionary-encoded columns are decoded on the device: refused here
     CHECK_THROWS(DataFrame::from_arrow_host("tests/golden/dict_batches.arrow"));
 }

@@ -246,3 +246,205 @@ def test_c3_bench_workload_checks(gpu):
     assert chk["self_check"] is True and chk["parity_on_sample"] is True, (chk, res)
     del step, check
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 5: the FRAME operators at full size, on the reference readers' batches (src/dataframe.rs:352: 1024 rows) — 1e9 rows are
+# 976 563 RecordBatches, i.e. ~1e6 tiles behind the one-pass filter's ticketed look-back and ~1e6 descriptors per column in every
+# table a kernel builds.  Size-independent properties, the fused path against the per-column path, the oracle on a prefix.
+
+def _batched_frame(api, cols, rows, chunk_rows, keep):
+    """cols: [(torch tensor, rdf dtype)] -> a frame pinned from a numpy-built descriptor table (no Python loop per batch)."""
+    import ctypes as C
+    import numpy as np
+    rec = np.dtype([("values", "u8"), ("validity", "u8"), ("offset", "i8"), ("length", "i8"), ("null_count", "i8"), ("dtype", "i4"), ("mem", "i4")])
+    assert rec.itemsize == C.sizeof(A.rdf_array)
+    starts = np.arange(0, rows, chunk_rows, dtype=np.int64)
+    nch = len(starts)
+    tab = np.zeros(len(cols) * nch, dtype=rec)
+    for k, (t, dt) in enumerate(cols):
+        v = tab[k * nch:(k + 1) * nch]
+        v["values"] = t.data_ptr() + starts * 8
+        v["length"] = np.minimum(chunk_rows, rows - starts)
+        v["dtype"] = dt
+        v["mem"] = A.MEM_DEVICE
+    h = C.c_void_p(0)
+    fn = api._fn("frame_pin")
+    fn.restype = C.c_int
+    api._check(fn(C.c_void_p(tab.ctypes.data), C.c_int32(len(cols)), C.c_int64(nch), C.byref(h)))
+    f = A.Frame(api, h)
+    f.keep = keep
+    return f, nch
+
+
+def _same_aggs(got, want, what):
+    for v, (g, w) in enumerate(zip(got, want)):
+        assert (g.count, g.min, g.max, g.dtype) == (w.count, w.min, w.max, w.dtype), (what, v, g, w)
+        if g.dtype == A.F64:
+            assert abs(g.sum - w.sum) <= 1e-9 * max(abs(w.sum), 1.0), (what, v, g, w)     # different fold orders of ~5e8 doubles
+        else:
+            assert g.sum == w.sum, (what, v, g, w)
+
+
+@pytest.mark.parametrize("ncols", [1, 4])
+def test_filter_frame_1e9_rows_in_1024_row_batches(gpu, ora, ncols):
+    import numpy as np
+    import torch
+    from rust_dataframe_amd import lib
+    from util import assert_chunks_match
+    x = _dev(N, 0, A.F64, -1.0, 1.0)
+    ts = [(x, A.F64)]
+    if ncols == 4:
+        ts += [(_dev(N, 3, A.I64, -2 ** 31, 2 ** 31), A.I64), (_dev(N, 1, A.F64, -1.0, 1.0), A.F64), (_dev(N, 2, A.F64, -1.0, 1.0), A.F64)]
+    lib.synchronize()
+    fr, nch = _batched_frame(gpu, ts, N, 1024, ts)
+    assert nch == 976_563
+    e = A.Expr()
+    vals = [e.col(k) for k in range(ncols)]
+    gt, le = e.op("gt", e.col(0), e.scalar(0.0)), e.op("le", e.col(0), e.scalar(0.0))
+    want = gpu.pipeline(e, fr, vals, gt)                      # the per-column path: fused filter -> aggregates, nothing materialised
+    n_le = gpu.pipeline(e, fr, [e.col(0)], le)[0].count
+    try:
+        for fused, what in ((1, "one pass (predicate inside the compaction kernel)"), (0, "predicate -> mask, count, compact")):
+            lib.set_option("filter_fused", fused)
+            out = gpu.filter_frame(fr, e, gt)
+            nc, nb, rows = out.info()
+            assert (nc, nb) == (ncols, nch) and rows == want[0].count and rows + n_le == N, (what, rows, want[0].count, n_le)
+            _same_aggs(gpu.pipeline(e, out, vals), want, what)           # every column of the result against the per-column path
+            assert gpu.pipeline(e, out, [e.col(0)], le)[0].count == 0
+            again = gpu.filter_frame(out, e, gt)                         # idempotent
+            assert again.info() == (ncols, nch, rows)
+            _same_aggs(gpu.pipeline(e, again, vals), want, what + ", applied twice")
+            again.release()
+            # batch boundaries are kept: the lengths of a few batches against a count over the same rows
+            for b in (0, nch // 2, nch - 1):
+                a = out.column(0)[b]
+                nb_rows = min(1024, N - b * 1024)
+                cnt = gpu.pipeline(e, [[A.DeviceArray(x.data_ptr() + 8 * b * 1024, None, 0, nb_rows, A.F64, 0)]], [e.col(0)], gt)[0].count
+                assert a.length == cnt, (what, b, a.length, cnt)
+            out.release()
+        # the oracle on a prefix of 2 000 batches, both forms
+        m = 2000 * 1024
+        pf, _ = _batched_frame(gpu, ts, m, 1024, ts)
+        host = []
+        for t, dt in ts:
+            h = torch.empty(m, dtype=t.dtype)
+            lib.load().rdf_copy_d2h(h.data_ptr(), t.data_ptr(), m * 8)
+            hv = h.numpy()
+            host.append([A.HostArray(hv, None, i, 1024, dt, 0) for i in range(0, m, 1024)])
+        mask = ora.predicate(e, gt, host)
+        exp = ora.filter_columns(host, mask)
+        for fused in (1, 0):
+            lib.set_option("filter_fused", fused)
+            po = gpu.filter_frame(pf, e, gt)
+            for k in range(ncols):
+                assert_chunks_match(po.column_to_host(k), exp[k], exact=True, what=f"prefix, fused={fused}, column {k}")
+            po.release()
+        pf.release()
+    finally:
+        lib.set_option("filter_fused", 1)
+        fr.release()
+    del ts, x
+    torch.cuda.empty_cache()
+
+
+def test_take_frame_1e9_rows_in_1024_row_batches(gpu):
+    import torch
+    from rust_dataframe_amd import lib
+    x, k = _dev(N, 0, A.F64, -1.0, 1.0), _dev(N, 3, A.I64, -2 ** 31, 2 ** 31)
+    lib.synchronize()
+    fr, nch = _batched_frame(gpu, [(x, A.F64), (k, A.I64)], N, 1024, (x, k))
+    e = A.Expr()
+    vals = [e.col(0), e.col(1)]
+    try:
+        # consecutive rows (recognised as a sequential list): the first quarter of the frame, bit for bit in every aggregate
+        nq = N // 4
+        seq = torch.arange(0, nq, dtype=torch.int64, device="cuda").to(torch.uint32)
+        torch.cuda.synchronize()
+        out = gpu.take_frame(fr, A.DeviceArray(seq.data_ptr(), None, 0, nq, A.U32, 0, keep=seq))
+        assert out.info()[2] == nq
+        want = gpu.pipeline(e, [[_arr(x, A.F64, nq)], [_arr(k, A.I64, nq)]], vals)
+        _same_aggs(gpu.pipeline(e, out, vals), want, "sequential take")
+        out.release()
+        del seq
+        # random rows with repeats: against torch's gather of the same indices (an independent gather)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        ridx = torch.randint(0, N, (nq,), dtype=torch.int64, device="cuda", generator=g)
+        r32 = ridx.to(torch.uint32)
+        torch.cuda.synchronize()
+        out = gpu.take_frame(fr, A.DeviceArray(r32.data_ptr(), None, 0, nq, A.U32, 0, keep=r32))
+        assert out.info()[2] == nq
+        got = gpu.pipeline(e, out, vals)
+        tx, tk = x[ridx], k[ridx]
+        assert got[0].count == nq and got[0].min == tx.min().item() and got[0].max == tx.max().item()
+        assert abs(got[0].sum - tx.sum().item()) <= 1e-9 * nq
+        assert (got[1].sum, got[1].min, got[1].max) == (tk.sum().item(), tk.min().item(), tk.max().item())
+        # a few single rows, bit for bit
+        for j in (0, nq // 3, nq - 1):
+            b, r = divmod(j, 1024)
+            a = out.column(0)[b]
+            one = gpu.pipeline(e, [[A.DeviceArray(a.values_ptr + 8 * (a.offset + r), None, 0, 1, A.F64, 0)]], [e.col(0)])[0]
+            assert one.sum == x[ridx[j]].item()
+        out.release()
+    finally:
+        fr.release()
+    del x, k
+    torch.cuda.empty_cache()
+
+
+def test_sort_frame_1e8_rows_in_1024_row_batches(gpu):
+    import torch
+    from rust_dataframe_amd import lib
+    n = 100_000_000
+    k, p = _dev(n, 5, A.I64, -10 ** 12, 10 ** 12), _dev(n, 6, A.I64, -2 ** 20, 2 ** 20)
+    lib.synchronize()
+    fr, nch = _batched_frame(gpu, [(k, A.I64), (p, A.I64)], n, 1024, (k, p))
+    e = A.Expr()
+    pair = e.op("multiply", e.col(0), e.col(1))              # sum(k * p) wraps, and changes if a row's two values part company
+    try:
+        before = gpu.pipeline(e, fr, [e.col(0), e.col(1), pair])
+        sf, _ = gpu.sort_frame(fr, [0], [False])
+        assert sf.info() == (2, nch, n)
+        after = gpu.pipeline(e, sf, [e.col(0), e.col(1), pair])
+        for b_, a_ in zip(before, after):
+            assert (b_.sum, b_.min, b_.max, b_.count) == (a_.sum, a_.min, a_.max, a_.count)      # a permutation of whole rows
+        # sortedness over the whole frame: the batches of the result are consecutive in the column's buffer (64-row boundaries, 1024-row batches)
+        ck = sf.column(0)
+        base = ck[0].values_ptr + 8 * ck[0].offset
+        for b in (1, nch // 2, nch - 1):
+            assert ck[b].values_ptr + 8 * ck[b].offset == base + 8 * 1024 * b
+        le = e.op("le", e.col(0), e.col(1))
+        ok = gpu.pipeline(e, [[A.DeviceArray(base, None, 0, n - 1, A.I64, 0)], [A.DeviceArray(base + 8, None, 0, n - 1, A.I64, 0)]], [e.col(0)], le)[0]
+        assert ok.count == n - 1
+        sf.release()
+    finally:
+        fr.release()
+    del k, p
+    torch.cuda.empty_cache()
+
+
+def test_groupby_agg_frame_1e9_rows_in_1024_row_batches(gpu):
+    import torch
+    from rust_dataframe_amd import lib
+    ng = 1_000_000
+    kk, v = _dev(N, 7, A.I64, 0, ng), _dev(N, 0, A.F64, 0.0, 1.0)
+    lib.synchronize()
+    fr, nch = _batched_frame(gpu, [(kk, A.I64), (v, A.F64)], N, 1024, (kk, v))
+    e = A.Expr()
+    try:
+        tot = gpu.pipeline(e, fr, [e.col(1)])[0]
+        out = gpu.groupby_agg_frame(fr, [0], 1, "sum", ng)
+        nc, _, rows = out.info()
+        assert nc == 3 and rows == ng                              # 1e9 uniform draws: every one of the 1e6 keys appears
+        sq = e.op("multiply", e.col(0), e.col(0))
+        keys, sums, counts, keys2 = gpu.pipeline(e, out, [e.col(0), e.col(1), e.col(2), sq])
+        assert (keys.min, keys.max, keys.count) == (0, ng - 1, ng)
+        assert keys.sum == ng * (ng - 1) // 2 and keys2.sum == (ng - 1) * ng * (2 * ng - 1) // 6      # 1e6 values of [0, 1e6) with these power sums: each key once
+        assert counts.sum == N and counts.min >= 1 and abs(counts.sum / ng - N / ng) < 1
+        assert abs(sums.sum - tot.sum) <= 1e-9 * tot.sum
+        out.release()
+    finally:
+        fr.release()
+    del kk, v
+    torch.cuda.empty_cache()

@@ -53,7 +53,24 @@ def main():
         t0 = time.perf_counter(); L.rdf_copy_h2d(d, hp, gib); up.append(gib / (time.perf_counter() - t0) / 1e9)
         t0 = time.perf_counter(); L.rdf_copy_d2h(hp, d, gib); dn.append(gib / (time.perf_counter() - t0) / 1e9)
     link_up, link_dn = max(up[1:]), max(dn[1:])
-    L.rdf_dev_free(d); L.rdf_host_free(hp)
+    # ... and both directions at once (two streams, two buffers): what a full-duplex link gives each direction under load
+    hp2, d2 = pinned(gib), C.c_void_p(0)
+    assert L.rdf_dev_alloc(C.byref(d2), gib) == 0
+    import threading
+    both = []
+    for _ in range(4):
+        def down():
+            lib.set_device(0)
+            L.rdf_copy_d2h(hp2, d2, gib)
+        th = threading.Thread(target=down)
+        t0 = time.perf_counter()
+        th.start()
+        L.rdf_copy_h2d(d, hp, gib)
+        th.join()
+        both.append(gib / (time.perf_counter() - t0) / 1e9)
+    L.rdf_dev_free(d2)
+    link_both = max(both[1:])
+    L.rdf_dev_free(d); L.rdf_host_free(hp); L.rdf_host_free(hp2)
     hog = []
     if args.hbm_left_gb > 0:
         free, total = torch.cuda.mem_get_info()
@@ -77,7 +94,7 @@ def main():
         slabs, staged, direct = lib.stream_stats()
         print(json.dumps(dict({"bench": name, "bytes_in": in_bytes, "bytes_out": out_bytes, "seconds": seconds,
                                "GBps_in": in_bytes / seconds / 1e9, "GBps_out": out_bytes / seconds / 1e9,
-                               "link_up_GBps": link_up, "link_down_GBps": link_dn, "frac_of_link_in": in_bytes / seconds / 1e9 / link_up,
+                               "link_up_GBps": link_up, "link_down_GBps": link_dn, "link_each_way_when_both_run_GBps": link_both, "frac_of_link_in": in_bytes / seconds / 1e9 / link_up,
                                "frac_of_link_out": out_bytes / seconds / 1e9 / link_dn, "slabs": slabs, "bytes_staged": staged, "bytes_direct": direct,
                                "hbm_free_before_GB": free_now / 1e9}, **extra)), flush=True)
 
