@@ -291,7 +291,7 @@ def test_filter_frame_1e9_rows_in_1024_row_batches(gpu, ora, ncols):
     import numpy as np
     import torch
     from rust_dataframe_amd import lib
-    from util import assert_chunks_match
+    from test_frame_ops_gpu import match_unknown_nulls
     x = _dev(N, 0, A.F64, -1.0, 1.0)
     ts = [(x, A.F64)]
     if ncols == 4:
@@ -338,7 +338,7 @@ def test_filter_frame_1e9_rows_in_1024_row_batches(gpu, ora, ncols):
             lib.set_option("filter_fused", fused)
             po = gpu.filter_frame(pf, e, gt)
             for k in range(ncols):
-                assert_chunks_match(po.column_to_host(k), exp[k], exact=True, what=f"prefix, fused={fused}, column {k}")
+                match_unknown_nulls(po.column_to_host(k), exp[k], f"prefix, fused={fused}, column {k}")
             po.release()
         pf.release()
     finally:
@@ -380,12 +380,12 @@ def test_take_frame_1e9_rows_in_1024_row_batches(gpu):
         assert got[0].count == nq and got[0].min == tx.min().item() and got[0].max == tx.max().item()
         assert abs(got[0].sum - tx.sum().item()) <= 1e-9 * nq
         assert (got[1].sum, got[1].min, got[1].max) == (tk.sum().item(), tk.min().item(), tk.max().item())
-        # a few single rows, bit for bit
-        for j in (0, nq // 3, nq - 1):
-            b, r = divmod(j, 1024)
-            a = out.column(0)[b]
-            one = gpu.pipeline(e, [[A.DeviceArray(a.values_ptr + 8 * (a.offset + r), None, 0, 1, A.F64, 0)]], [e.col(0)])[0]
-            assert one.sum == x[ridx[j]].item()
+        # the head of the result, bit for bit and in order (whatever batches the operator cut it into)
+        a0 = out.column(0)[0]
+        m = min(a0.length, 4096)
+        h = torch.empty(m, dtype=torch.float64)
+        lib.load().rdf_copy_d2h(h.data_ptr(), a0.values_ptr + 8 * a0.offset, m * 8)
+        assert torch.equal(h, x[ridx[:m]].cpu())
         out.release()
     finally:
         fr.release()

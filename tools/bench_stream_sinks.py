@@ -58,16 +58,25 @@ def main():
     assert L.rdf_dev_alloc(C.byref(d2), gib) == 0
     import threading
     both = []
-    for _ in range(4):
+    reps = 6
+    for _ in range(3):
+        go = threading.Barrier(2)
+
         def down():
             lib.set_device(0)
-            L.rdf_copy_d2h(hp2, d2, gib)
+            L.rdf_copy_d2h(hp2, d2, 1 << 20)         # (the thread's context and stream exist before the clock starts)
+            go.wait()
+            for _r in range(reps):
+                L.rdf_copy_d2h(hp2, d2, gib)
         th = threading.Thread(target=down)
-        t0 = time.perf_counter()
         th.start()
-        L.rdf_copy_h2d(d, hp, gib)
+        go.wait()
+        t0 = time.perf_counter()
+        for _r in range(reps):
+            L.rdf_copy_h2d(d, hp, gib)
+        t_up = time.perf_counter() - t0
         th.join()
-        both.append(gib / (time.perf_counter() - t0) / 1e9)
+        both.append(reps * gib / max(t_up, time.perf_counter() - t0) / 1e9)
     L.rdf_dev_free(d2)
     link_both = max(both[1:])
     L.rdf_dev_free(d); L.rdf_host_free(hp); L.rdf_host_free(hp2)
