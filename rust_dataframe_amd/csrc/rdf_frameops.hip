@@ -93,14 +93,13 @@ __global__ __launch_bounds__(kBlock) void frame_pad_kernel(const int64_t* __rest
 // kTakeU x ncols gathers are issued back to back — a random 8-byte read costs a whole memory transaction whichever column
 // it is for, so what the per-column loop of the reference pays M times over (index read, lookup, latency) is paid once,
 // and the M transactions of a row overlap.
-constexpr int kTakeU = 4;
 
 template <typename T>
 __device__ __forceinline__ void take_store(const DevOutChunk& out, int64_t j, bool inr, T v) {
     if (inr) __builtin_nontemporal_store(v, as_global_mut<T>(out.values) + j);
 }
 
-template <typename IDX>
+template <typename IDX, int kTakeU>
 __global__ __launch_bounds__(kBlock) void take_cols_kernel(const TakeColsArgs a) {
     const int lane = threadIdx.x & 63;
     uint32_t err = 0;
@@ -154,17 +153,12 @@ __global__ __launch_bounds__(kBlock) void take_cols_kernel(const TakeColsArgs a)
             bool vv[kTakeU];
             int64_t e[kTakeU];
             const uint8_t* vb[kTakeU];
-#pragma unroll
-            for (int u = 0; u < kTakeU; ++u) {
-                v[u] = 0; vv[u] = valid[u]; vb[u] = nullptr; e[u] = 0;
-                if (!valid[u]) continue;
-                DevChunkCol cc = a.cols0[k];
-                int64_t within = (int64_t)ix[u];
-                if (!a.contig[k]) {
-                    const DevChunkCol* t = a.cols_tab + ((int64_t)k * a.nchunks + ch[u]);
-                    cc.values = t->values; cc.validity = t->validity; cc.offset = t->offset;
-                    within = el[u];
-                }
+            // A column whose batches are consecutive slices of one buffer is ONE descriptor, read from the kernel arguments on the
+            // scalar unit; only a column of separately allocated batches fetches a descriptor per row.  (As one `cc = contig ?
+            // cols0[k] : table[..]` the compiler selected between two POINTERS and loaded the descriptor per lane through the flat
+            // path for both — a dependent memory latency in front of every gather: a sequential take ran at 0.34 of peak where
+            // take_kernel reaches 0.63.)
+            auto fetch = [&](int u, const DevChunkCol& cc, int64_t within) {
                 e[u] = cc.offset + within;
                 vb[u] = cc.validity;
                 switch (es) {
@@ -172,6 +166,25 @@ __global__ __launch_bounds__(kBlock) void take_cols_kernel(const TakeColsArgs a)
                     case 4: v[u] = as_global<uint32_t>(cc.values)[e[u]]; break;
                     case 2: v[u] = as_global<uint16_t>(cc.values)[e[u]]; break;
                     default: v[u] = as_global<uint8_t>(cc.values)[e[u]]; break;
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < kTakeU; ++u) { v[u] = 0; vv[u] = valid[u]; vb[u] = nullptr; e[u] = 0; }
+            if (a.contig[k]) {
+                DevChunkCol c0;
+                c0.values = (const void*)uniform64((uint64_t)(uintptr_t)a.cols0[k].values);
+                c0.validity = (const uint8_t*)uniform64((uint64_t)(uintptr_t)a.cols0[k].validity);
+                c0.offset = (int64_t)uniform64((uint64_t)a.cols0[k].offset);
+#pragma unroll
+                for (int u = 0; u < kTakeU; ++u) if (valid[u]) fetch(u, c0, (int64_t)ix[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < kTakeU; ++u) {
+                    if (!valid[u]) continue;
+                    const DevChunkCol* t = a.cols_tab + ((int64_t)k * a.nchunks + ch[u]);
+                    DevChunkCol cc;
+                    cc.values = t->values; cc.validity = t->validity; cc.offset = t->offset;
+                    fetch(u, cc, el[u]);
                 }
             }
             if (a.col_nullable[k]) {
@@ -394,13 +407,23 @@ hipError_t launch_frame_pad(const int64_t* len, int64_t n, int64_t* padded, hipS
     hipLaunchKernelGGL(frame_pad_kernel, dim3((unsigned)grid), dim3(kBlock), 0, s, len, n, padded);
     return hipGetLastError();
 }
-hipError_t launch_take_cols(const TakeColsArgs& a, hipStream_t s) {
-    const int64_t nw = (a.n + (int64_t)kTakeU * 64 - 1) / ((int64_t)kTakeU * 64);
+template <int U>
+static void launch_take_cols_u(const TakeColsArgs& a, hipStream_t s) {
+    const int64_t nw = (a.n + (int64_t)U * 64 - 1) / ((int64_t)U * 64);
     int64_t grid = (nw + (kBlock / 64) - 1) / (kBlock / 64);
     if (grid > eval_grid_limit()) grid = eval_grid_limit();
-    if (grid <= 0) return hipSuccess;
-    if (a.idx64) hipLaunchKernelGGL((take_cols_kernel<uint64_t>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((take_cols_kernel<uint32_t>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    if (grid <= 0) return;
+    if (a.idx64) hipLaunchKernelGGL((take_cols_kernel<uint64_t, U>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((take_cols_kernel<uint32_t, U>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+}
+hipError_t launch_take_cols(const TakeColsArgs& a, hipStream_t s) {
+    // rows per lane and iteration: 4 puts the gathers of several columns of a row in flight together (random lists: the
+    // transactions overlap); a single column gathers best one row at a time, like take_kernel (RDF_TAKE_U overrides for A/B)
+    static const int forced = [] { const char* e = getenv("RDF_TAKE_U"); return e ? atoi(e) : 0; }();
+    const int u = forced == 1 || forced == 2 || forced == 4 ? forced : 4;
+    if (u == 1) launch_take_cols_u<1>(a, s);
+    else if (u == 2) launch_take_cols_u<2>(a, s);
+    else launch_take_cols_u<4>(a, s);
     return hipGetLastError();
 }
 
