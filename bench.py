@@ -164,7 +164,7 @@ def workload_c3(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, 
     native = opts.get("native")
 
     def step():
-        if native is not None and not os.environ.get("RDF_BENCH_HOST_COMBINE"):
+        if native is not None and os.environ.get("RDF_BENCH_FUSED_COMBINE"):
             y, kk = native.pipeline_dist(e, cols, roots)        # kernel + all-gather + fold on the device, one host wait
         else:
             local = api.pipeline(e, cols, roots)
@@ -545,7 +545,11 @@ def main():
     pred = e.op("gt", c, e.scalar(THRESHOLD))
     combine_s = [0.0]
 
-    fused_combine = native is not None and not os.environ.get("RDF_BENCH_HOST_COMBINE")
+    # rdf_pipeline_dist (kernel + all-gather + fold on the device, one host wait) against rdf_pipeline + rdf_agg_combine (two waits):
+    # on the 1-rank RCCL communicator the pair is the faster one (0.2845 against 0.2931 ms/step at 2e8 rows: the second all-gather
+    # and the fold kernel cost more than the host round trip they replace), so the pair stays the default; RDF_BENCH_FUSED_COMBINE=1
+    # times the fused call (profiles/r05_rccl_one_rank.jsonl has both)
+    fused_combine = native is not None and bool(os.environ.get("RDF_BENCH_FUSED_COMBINE"))
 
     def step():
         if fused_combine:

@@ -100,6 +100,7 @@ struct GSpecArgs {
     uint64_t*          group_partials;   // [gridDim.x * group_words(ngroups, nvalues)]
     uint32_t*          flags;
     int32_t            ngroups, nvalues, vec_bitmap;
+    int32_t            xcd_swz, tile_rot, pad1;   // tile walk as in SpecArgs: XCD x takes the x-th contiguous eighth of every row of gridDim.x tiles; rows rotated by tile_rot blocks
 };
 
 struct GroupFinalArgs {

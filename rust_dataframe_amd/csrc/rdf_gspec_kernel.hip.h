@@ -228,7 +228,10 @@ __global__ __launch_bounds__(kBlock) void gspec_kernel(const GSpecArgs a) {
     // tile is a full one: the common case) and are waited for at the top of the next iteration.
     uint64_t nx[NC][R];
     bool have_next = false;
-    int64_t tile = blockIdx.x;
+    // tile walk (block-wide tiles): row i of gridDim.x tiles, block p takes tile i * gridDim.x + (p + i * tile_rot) mod gridDim.x
+    int64_t pos = blockIdx.x, rowb = 0;
+    if (a.xcd_swz && (gridDim.x & 7u) == 0) pos = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    int64_t tile = pos;
     TileMeta meta = locate(tile < a.ntiles ? tile : 0);
     while (tile < a.ntiles) {
         const int64_t n = meta.n;
@@ -253,7 +256,10 @@ __global__ __launch_bounds__(kBlock) void gspec_kernel(const GSpecArgs a) {
                 for (int e = 0; e < 2; ++e) c.inr |= (uint32_t)(rw + 128 * u + 2 * lane + e < n) << (2 * u + e);
             load_all<P>(c.v, col, rw, lane, c.inr, false, std::make_index_sequence<NC>());
         }
-        tile += gridDim.x;
+        rowb += gridDim.x;
+        pos += a.tile_rot;
+        if (pos >= (int64_t)gridDim.x) pos -= gridDim.x;
+        tile = rowb + pos;
         have_next = false;
         if (tile < a.ntiles) {
             meta = locate(tile);

@@ -276,6 +276,21 @@ def main():
     report("sort_to_indices_f64_lognormal_buckets_over_min_max", 8.0 * ns, lambda: api.sort_to_indices([[arr(xl_, A.F64, ns)]], [False], oi), rows=ns)
     lib.set_option("sort_sample", 1)
     del xo_, xl_
+    # the reference's own sort case (src/dataframe.rs:963-1003: two criteria, `a` descending then `b` ascending) at size: a = a
+    # category column of 1000 values, b = a measure; and an f32 key column (value buckets since round 5, byte passes before)
+    ka_ = dev_i64(ns, 11, 0, 1000)
+    report("sort_to_indices_2keys_i64_desc_f64_asc", 16.0 * ns, lambda: api.sort_to_indices([[arr(ka_, A.I64, ns)], [arr(xs_, A.F64, ns)]], [True, False], oi), rows=ns)
+    report("sort_to_indices_2keys_i64_asc_i64_asc", 16.0 * ns, lambda: api.sort_to_indices([[arr(ka_, A.I64, ns)], [arr(kw, A.I64, ns)]], [False, False], oi), rows=ns)
+    xf_ = xs_.to(torch.float32)
+    xfn_ = xn_.to(torch.float32)
+    torch.cuda.synchronize()
+    F32 = lambda t: A.DeviceArray(t.data_ptr(), None, 0, ns, A.F32, -1, keep=t)
+    report("sort_to_indices_f32_uniform", 4.0 * ns, lambda: api.sort_to_indices([[F32(xf_)]], [False], oi), rows=ns)
+    report("sort_to_indices_f32_normal", 4.0 * ns, lambda: api.sort_to_indices([[F32(xfn_)]], [False], oi), rows=ns)
+    lib.set_option("sort_msd", 0)
+    report("sort_to_indices_f32_uniform_byte_passes", 4.0 * ns, lambda: api.sort_to_indices([[F32(xf_)]], [False], oi), rows=ns)
+    lib.set_option("sort_msd", 1)
+    del ka_, xf_, xfn_
     del xs_, xn_
     # ArrayFunctions over a List<f64> column: rows of 10 elements (one row per lane) and of 1000 elements (one row per wave)
     for rl in (10, 1000):
@@ -324,6 +339,14 @@ def main():
         report("join_inner_1e8_x_1e7_bucket_index", 8.0 * nl_ + 8.0 * nr_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk_, A.I64, nl_)], [arr(rk_, A.I64, nr_)], "inner", (jl, jr)), rows=nl_)
         lib.set_option("join_table", 1)
         del lk_, rk_
+        # a build side as long as the probe side: 1e8 distinct keys (a 3.2 GB table of 16-byte slots at load 0.5: every probe is a
+        # random line from HBM; the case a radix-partitioned join was priced for)
+        if n >= 100_000_000:
+            nb_ = 100_000_000
+            rk8 = torch.randperm(nb_, device="cuda", dtype=torch.int64)
+            lk8 = dev_i64(nl_, 12, 0, nb_)
+            report("join_inner_1e8_x_1e8", 8.0 * nl_ + 8.0 * nb_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk8, A.I64, nl_)], [arr(rk8, A.I64, nb_)], "inner", (jl, jr)), rows=nl_)
+            del lk8, rk8
     # hash GROUP BY key -> sum(val): 1e6 groups (config C4's per-GPU leg) and 1e3 groups (contended)
     for ng in (1_000_000, 2_000, 1_000, 100, 8):
         kk = dev_i64(n, 7, 0, ng)
