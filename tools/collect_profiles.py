@@ -62,7 +62,9 @@ def main():
     bench = json.loads(open(os.path.join(src, "bench_1e9.json")).read().strip().splitlines()[-1])
     for name in ("bench_1e9.json", "bench_1e9_under_rocprof.json", "bench_1e9_1024_row_batches.json", "bench_1e9_validity.json",
                  "kernels_1e9_microbench.jsonl", "shapes_2p5e8.jsonl", "ubench_scatter.txt", "frames_1e9.jsonl", "ingest.jsonl", "bytes_2p5e8.jsonl", "beyond_catalogs_2p5e8.jsonl",
-                 "rccl_one_rank.jsonl", "c4_total_rows_1e9.json", "rccl_one_rank_torch.jsonl", "example_dist.txt", "stream_16GB.jsonl", "stream_4GB_hbm_left_1p5GB.jsonl", "ubench_stream.txt"):
+                 "rccl_one_rank.jsonl", "c4_total_rows_1e9.json", "rccl_one_rank_torch.jsonl", "example_dist.txt", "stream_16GB.jsonl", "stream_4GB_hbm_left_1p5GB.jsonl", "ubench_stream.txt",
+                 "tilewalk.jsonl", "stream_sinks_16GB.jsonl", "stream_sinks_4GB_hbm_left_1p5GB.jsonl", "rccl_one_rank_fused_combine.jsonl", "groupby_1p25e8_rows.jsonl",
+                 "groupby_1p25e8_rows_round4_build.jsonl", "gb_window.jsonl"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
     agree = None
@@ -109,6 +111,21 @@ def main():
                                 "kernels": [e["kernel"][:80] for e in ks], "source": f"profiles/{rnd}_pmc_hbm_traffic_by_kernel.json"}
         json.dump({"rows": rows, "validity": False, "hbm_bytes_per_launch": hbm, "source": f"profiles/{rnd}_bench_1e9_pmc_summary.json", "workloads": workloads},
                   open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+    valu = {}
+    for d in sorted(glob.glob(os.path.join(src, "pmc_valu_*"))):
+        if not os.path.isdir(d):
+            continue
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        tag = os.path.basename(d)[len("pmc_valu_"):]
+        for k, e in per_kernel(files[0], "SQ_INSTS_VALU").items():
+            if "spec_kernel" in k and e["mean_KB"] > 1e6:      # (mean_KB is just the counter's mean here: wave-instructions per launch)
+                valu[tag] = {"kernel": k[:160], "vgpr": e["vgpr"], "grid": e["grid"], "SQ_INSTS_VALU_per_launch": e["mean_KB"],
+                             "wave_instructions_per_row_of_64": e["mean_KB"] / (rows / 64.0)}
+    if valu:
+        json.dump({"round": int(rnd[1:]), "what": "vector-ALU wave-instructions of the headline kernel per 64 rows, no bitmap (nf0) and 10 % NULLs (nf0.1), this round's build and round 4's on the same box",
+                   "by_build_and_null_fraction": valu}, open(os.path.join(dst, f"{rnd}_pmc_valu_per_row_headline.json"), "w"), indent=1)
     if agree is not None:
         json.dump(agree, open(os.path.join(dst, f"{rnd}_bench_1e9_kernel_time_agreement.json"), "w"), indent=1)
         if agree["relative_difference"] > 0.02:

@@ -74,6 +74,27 @@ python "$REPO/tools/bench_stream.py" --gb 16 2> "$OUT/stream.err" | grep '"bench
 python "$REPO/tools/bench_stream.py" --gb 4 --hbm-left-gb 1.5 2>> "$OUT/stream.err" | grep '"bench"' > "$OUT/stream_4GB_hbm_left_1p5GB.jsonl"
 if [ -x "$REPO/tools/ubench_stream.bin" ]; then timeout 300 "$REPO/tools/ubench_stream.bin" > "$OUT/ubench_stream.txt" 2>&1; fi
 fi
+# 3e. round 5: launch shapes of the specialised kernels (blocks per CU x tile walk) on data built once; the sinks that materialise,
+#     host -> host, 16 GB and 4 GB with 1.5 GB of HBM left; vector-ALU instructions per row of the headline kernel with and without a
+#     validity bitmap, this build against round 4's (rust_dataframe_amd/librdf_base_r04.so, when it travelled); the fused combine against
+#     the pair of calls on the 1-rank communicator; C4 at the 8-GPU configuration's per-rank size
+if [ "$PART" = "all" ] || [ "$PART" = "r5" ]; then
+python "$REPO/tools/exp_tilewalk.py" --steps 20 2> "$OUT/tilewalk.err" > "$OUT/tilewalk.jsonl"
+python "$REPO/tools/bench_stream_sinks.py" --gb 16 2> "$OUT/stream_sinks.err" | grep '"bench"' > "$OUT/stream_sinks_16GB.jsonl"
+python "$REPO/tools/bench_stream_sinks.py" --gb 4 --hbm-left-gb 1.5 2>> "$OUT/stream_sinks.err" | grep '"bench"' > "$OUT/stream_sinks_4GB_hbm_left_1p5GB.jsonl"
+for lib in librdf_mi355x.so librdf_base_r04.so; do
+    [ -f "$REPO/rust_dataframe_amd/$lib" ] || continue
+    for nf in 0 0.1; do
+        RDF_LIB_PATH="$REPO/rust_dataframe_amd/$lib" timeout 600 rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d "$OUT/pmc_valu_${lib}_nf$nf" -o p -- \
+            python "$REPO/bench.py" --steps 5 --warmup 1 --cpu-sample 0 --null-fraction $nf > "$OUT/pmc_valu_${lib}_nf$nf.out" 2> "$OUT/pmc_valu_${lib}_nf$nf.err"
+    done
+done
+rm -f "$OUT/rccl_one_rank_fused_combine.jsonl"
+for fc in "" 1; do RDF_BENCH_FUSED_COMBINE=$fc python "$REPO/bench.py" --rows 200000000 --steps 50 --warmup 5 --cpu-sample 0 --force-exchange --backend nccl 2>> "$OUT/rccl.err" | tail -1 >> "$OUT/rccl_one_rank_fused_combine.jsonl"; done
+python "$REPO/tools/bench_kernels.py" --rows 125000000 --steps 5 --only groupby_sum_1000000_groups,groupby_count_1000000_groups,groupby_max_1000000_groups,groupby_sum_1000000_groups_zipf,groupby_sum_1000000_groups_scattered_keys,groupby_sum_1000000_groups_hot_key_30pct 2>> "$OUT/kernels.err" | grep kernel_ms > "$OUT/groupby_1p25e8_rows.jsonl"
+RDF_LIB_PATH="$REPO/rust_dataframe_amd/librdf_base_r04.so" python "$REPO/tools/bench_kernels.py" --rows 125000000 --steps 5 --only groupby_sum_1000000_groups,groupby_count_1000000_groups 2>> "$OUT/kernels.err" | grep kernel_ms > "$OUT/groupby_1p25e8_rows_round4_build.jsonl"
+python "$REPO/tools/exp_gb_window.py" --windows 8,32,64,128,256 --reps 2 2>> "$OUT/kernels.err" > "$OUT/gb_window.jsonl"
+fi
 # 4. the scatter micro-benchmark behind the C4 bound
 if [ -x "$REPO/tools/ubench_scatter.bin" ]; then timeout 300 "$REPO/tools/ubench_scatter.bin" > "$OUT/ubench_scatter.txt" 2>&1; fi
 # keep the merged payload small: the raw traces stay on the box, the stats / counter CSVs travel
