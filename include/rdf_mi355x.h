@@ -399,7 +399,16 @@ typedef struct {
     int32_t dtype;    /* value dtype */
 } rdf_agg_result;
 
-/* cols[c * nchunks + i].  SINK_STORE: outs[v * nchunks + i] receives value v of batch i
+/* Host-resident batches (RDF_MEM_HOST) beyond one slab (256 MiB; rdf_set_option("stream_slab_bytes", n), -1 = never) are STREAMED
+ * by every entry point that takes chunk lists — rdf_pipeline (both sinks), rdf_binary / rdf_unary / rdf_cast / rdf_hour /
+ * rdf_predicate, the column aggregates, rdf_group_pipeline, rdf_groupby_agg (one Int64 / UInt64 key column), rdf_filter_pipeline:
+ * slab k + 1 crosses the link while the kernel runs over slab k, results that are columns leave on a third stream, aggregates
+ * are folded in slab order.  Float SUMS of a streamed call are therefore folded per slab (f64): their low bits depend on where the
+ * slabs are cut (stream_slab_bytes, the batch lengths) and — with the run-time compiler working in the background, jit = 1 —
+ * on which slab was the first to run compiled; every such result is within the 1e-6 relative the path promises for f64 sums, but
+ * two calls need not agree bit for bit.  Integer results, extrema, counts, columns, masks and filtered rows do not depend on it.
+ *
+ * cols[c * nchunks + i].  SINK_STORE: outs[v * nchunks + i] receives value v of batch i
  * (filter_root must be -1: filter then store is rdf_predicate + rdf_filter_columns).
  * SINK_AGG: aggs[v] receives the aggregates, outs may be NULL. */
 rdf_status rdf_pipeline(const rdf_program* prog, const rdf_array* cols, int32_t ncols, int64_t nchunks,

@@ -684,6 +684,21 @@ __global__ __launch_bounds__(kBlock, 4) void ffilter_dma_kernel(const FusedFilte
             if (closes) st(super_state + sfirst, kFfAggregate | (unsigned long long)(local + cnt));
             long long before = 0;
             int64_t q = (j >> 6) - 1;                       // super-tiles of this batch before mine
+            // Round 5 (lookback == 2): the walk over the super-tiles' totals — one word per super-tile, a cache line apart: up to 64
+            // line fetches per step — is done by ONE tile per super-tile, its first, which leaves what it found (the rows of the batch
+            // in front of the super-tile) in a word of its own; the other 63 tiles poll that one word.  Every wait is for a tile with an
+            // earlier ticket, as before.  A batch of any length now costs a tile one 64-wide read of its neighbours' counts and one word.
+            unsigned long long* super_excl = super_state + a.t.ntiles + 8;
+            const bool follower = fa.lookback == 2 && q >= 0 && (j & 63) != 0;
+            if (follower) {
+                for (;;) {
+                    const unsigned long long w = ld(super_excl + sfirst);
+                    if ((w >> 62) != 0) { before = (long long)(w & kFfValue); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                q = -1;
+            }
+            const bool leads = fa.lookback == 2 && q >= 0;
             while (q >= 0) {
                 const int64_t idx = q - lane;
                 const unsigned long long w = idx >= 0 ? ld(super_state + first + idx * 64) : kFfPrefix;
@@ -698,6 +713,7 @@ __global__ __launch_bounds__(kBlock, 4) void ffilter_dma_kernel(const FusedFilte
                 if (pref) break;
                 q -= 64;
             }
+            if (leads) st(super_excl + sfirst, kFfPrefix | (unsigned long long)before);
             if (closes) st(super_state + sfirst, kFfPrefix | (unsigned long long)(before + local + cnt));
             wave_out = before + local;
         }

@@ -1578,14 +1578,15 @@ int eval_grid_limit() {
     if (limit == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            limit = prop.multiProcessorCount * 8;  // 8 blocks of 4 waves = the CU's 32-wave capacity
-        // (A/B of persistent grid sizes: the specialised kernels run best at ODD numbers of resident blocks per CU — even ones
-        // line their tiles' strides up with the memory channels' interleave — RDF_GRID_BLOCKS_PER_CU=7 / 5 tries the same on every
-        // kernel that sizes its grid from this limit)
-        if (const char* e = getenv("RDF_GRID_BLOCKS_PER_CU")) { const int m = atoi(e); if (m >= 1 && m <= 8 && prop.multiProcessorCount > 0) limit = prop.multiProcessorCount * m; }
-        else
-            limit = 2048;
+        int cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        // 8 blocks of 4 waves = the CU's 32-wave capacity: 2048 on the 256-CU MI355X in SPX mode.  The blocks-per-CU choices of
+        // run_program (and the XCD-contiguous tile walk: blocks are dealt to 8 XCDs round-robin) were measured on that part; a
+        // partitioned (CPX / DPX) or down-binned device gets a grid in proportion to ITS CUs, the same ratios, and a walk that is
+        // merely a permutation there — nothing breaks, the fractions of DESIGN.md are not claimed for it.
+        limit = cus > 0 ? cus * 8 : 2048;
+        // (A/B of persistent grid sizes on every kernel that sizes its grid from this limit: RDF_GRID_BLOCKS_PER_CU=7 / 5 / ...)
+        if (const char* e = getenv("RDF_GRID_BLOCKS_PER_CU")) { const int m = atoi(e); if (m >= 1 && m <= 8 && cus > 0) limit = cus * m; }
     }
     return limit;
 }

@@ -427,3 +427,34 @@ def test_filter_frame_one_pass_predicates(gpu, ora, lens, off, nf):
                     out.release()
             finally:
                 lib.set_option("filter_fused", 1)
+
+
+@pytest.mark.parametrize("lens,nf", [([3_000_000, 1024, 200_000], 0.0), ([1_500_000, 700_001], 0.1)])
+def test_filter_frame_one_pass_on_long_batches(gpu, ora, lens, nf):
+    """Batches far longer than a super-tile of 64 tiles: the offsets inside a batch come from the two-level look-back — round 5: the
+    super-tiles' totals are walked once per super-tile by its first tile (`filter_lookback` 2, the default, any batch length), round 4:
+    by every tile (1).  Both against the oracle and the three-pass path, bit for bit."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(77)
+    dts = [A.F64, A.I64]
+    host = [make_chunks(rng, dt, lens, nf, 0, "unit" if dt == A.F64 else "plain") for dt in dts]
+    dev, keep = to_device(host)
+    e = A.Expr()
+    preds = {"one term": e.op("gt", e.col(0), e.scalar(0.3)),
+             "two columns": e.op("or", e.op("lt", e.col(0), e.scalar(0.05)), e.op("gt", e.col(1), e.scalar(0, A.I64)))}
+    with A.PinnedFrame(gpu, dev) as frame:
+        try:
+            for name, root in preds.items():
+                exp = ora.filter_columns(host, ora.predicate(e, root, host))
+                for fused, lookback in ((1, 2), (2, 1), (0, 2)):
+                    lib.set_option("filter_fused", fused)
+                    lib.set_option("filter_lookback", lookback)
+                    out = gpu.filter_frame(frame, e, root)
+                    assert (lib.last_kernel() == "ffilter_dma_kernel") == (fused != 0), (name, fused, lookback, lib.last_kernel())
+                    got = frame_columns(out)
+                    for k in range(len(dts)):
+                        match_unknown_nulls(got[k], exp[k], f"{name} fused={fused} lookback={lookback} column {k}")
+                    out.release()
+        finally:
+            lib.set_option("filter_fused", 1)
+            lib.set_option("filter_lookback", 2)

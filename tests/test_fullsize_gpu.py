@@ -452,3 +452,36 @@ def test_groupby_agg_frame_1e9_rows_in_1024_row_batches(gpu):
         fr.release()
     del kk, v
     torch.cuda.empty_cache()
+
+
+def test_filter_frame_1e9_rows_one_batch(gpu):
+    """ONE RecordBatch of 1e9 rows = 976 563 tiles in 15 259 super-tiles of one look-back chain (round 5: walked once per super-tile)."""
+    import torch
+    from rust_dataframe_amd import lib
+    x, k = _dev(N, 0, A.F64, -1.0, 1.0), _dev(N, 3, A.I64, -2 ** 31, 2 ** 31)
+    lib.synchronize()
+    fr, nch = _batched_frame(gpu, [(x, A.F64), (k, A.I64)], N, N, (x, k))
+    assert nch == 1
+    e = A.Expr()
+    vals = [e.col(0), e.col(1)]
+    gt = e.op("gt", e.col(0), e.scalar(0.25))
+    want = gpu.pipeline(e, fr, vals, gt)
+    try:
+        for fused in (1, 0):
+            lib.set_option("filter_fused", fused)
+            out = gpu.filter_frame(fr, e, gt)
+            assert (lib.last_kernel() == "ffilter_dma_kernel") == bool(fused), lib.last_kernel()
+            assert out.info() == (2, 1, want[0].count)
+            _same_aggs(gpu.pipeline(e, out, vals), want, f"one batch, fused={fused}")
+            # order is kept: the first kept rows are the first rows of x that pass
+            a0 = out.column(0)[0]
+            h = torch.empty(4096, dtype=torch.float64)
+            lib.load().rdf_copy_d2h(h.data_ptr(), a0.values_ptr + 8 * a0.offset, 4096 * 8)
+            head = x[:20000]
+            assert torch.equal(h, head[head > 0.25][:4096].cpu())
+            out.release()
+    finally:
+        lib.set_option("filter_fused", 1)
+        fr.release()
+    del x, k
+    torch.cuda.empty_cache()
