@@ -59,7 +59,7 @@ struct Ctx {
     bool   opt_filter_one = true;   // one-chunk compaction kernel with its descriptors in the kernel arguments (A/B)
     int    opt_filter_gen = 2;      // compaction kernels: 2 = wave-granular tiles (rdf_filter.hip, default), 1 = first-generation block tiles (A/B)
     int    opt_filter_fused = 1;    // rdf_filter_frame: `col CMP literal [AND|OR col CMP literal]` predicates evaluated inside the compaction kernel, one pass (1, default); 0 = predicate -> mask, count, compact (A/B)
-    int    opt_filter_lookback = 2; // one-pass rdf_filter_frame, batches longer than a tile: 2 = a super-tile's first tile walks the super-tile totals for all 64 (default), 1 = every tile walks them (round 4; batches of at most 1024 tiles) — A/B
+    int    opt_filter_lookback = 3; // one-pass rdf_filter_frame, batches longer than a tile: 3 = a super-tile's first tile finds the rows in front of the super-tile for all 64, from the nearest super-tiles' tile counts and the older ones' totals (default); 2 = from totals only; 1 = every tile walks the totals (round 4; batches of at most 1024 tiles) — A/B
     int    opt_filter_tile = 0;     // 0: compaction tile chosen from the mean chunk length; 1024 / 4096 force one (A/B)
     int    opt_gb_debug = 0;        // ablations of the partitioned GROUP BY (tools/bench_kernels.py): 1 = aggregate without LDS work, 2 = scatter without stores
     int    opt_sort_gen = 3;        // radix passes: 3 = one read + one write of the pairs per digit, decoupled look-back between 4096-pair tiles (rdf_sort.hip, default); 2 = count -> scan -> scatter over static tile ranges with the same wave-ranked tiles (A/B: slower, see rdf_sort.hip); 1 = first generation (rdf_kernels.hip)
@@ -4098,7 +4098,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "gspec_blocks_per_cu") == 0) g_ctx.opt_gspec_blocks = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
-    else if (strcmp(name, "filter_lookback") == 0) g_ctx.opt_filter_lookback = value == 1 ? 1 : 2;
+    else if (strcmp(name, "filter_lookback") == 0) g_ctx.opt_filter_lookback = value == 1 ? 1 : value == 2 ? 2 : 3;
     else if (strcmp(name, "comm_max_bytes") == 0) g_ctx.opt_comm_max_bytes = value;
     else if (strcmp(name, "stream_slab_bytes") == 0) g_ctx.opt_stream_slab = value;
     else return fail(RDF_INVALID_ARGUMENT, "unknown option %s", name);

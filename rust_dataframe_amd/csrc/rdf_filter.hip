@@ -670,48 +670,85 @@ __global__ __launch_bounds__(kBlock, 4) void ffilter_dma_kernel(const FusedFilte
             const int64_t j = tile - first;                 // tile of its batch
             const int64_t sfirst = first + (j & ~63ll);     // first tile of its super-tile
             const int nb = (int)(tile - sfirst);
-            long long local = 0;
-            if (nb > 0) {
-                for (;;) {
-                    const unsigned long long w = lane < nb ? ld(fa.tile_state + sfirst + lane) : kFfAggregate;
-                    if (__ballot((w >> 62) != 0) == ~0ull) { local = (long long)(w & kFfValue); break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) local += __shfl_xor(local, d);
-            }
+            long long local = 0, before = 0;
             const bool closes = (j & 63) == 63 || last;    // the super-tile's last tile
-            if (closes) st(super_state + sfirst, kFfAggregate | (unsigned long long)(local + cnt));
-            long long before = 0;
             int64_t q = (j >> 6) - 1;                       // super-tiles of this batch before mine
             // Round 5 (lookback == 2): the walk over the super-tiles' totals — one word per super-tile, a cache line apart: up to 64
             // line fetches per step — is done by ONE tile per super-tile, its first, which leaves what it found (the rows of the batch
-            // in front of the super-tile) in a word of its own; the other 63 tiles poll that one word.  Every wait is for a tile with an
-            // earlier ticket, as before.  A batch of any length now costs a tile one 64-wide read of its neighbours' counts and one word.
+            // in front of the super-tile) in a word of its own; the other 63 tiles read that one word — with lane 63 of the SAME
+            // 64-wide read that brings their neighbours' counts (a tile has at most 63 neighbours before it), so a tile of a batch of
+            // any length pays one memory round trip for its position, as a tile of a 64-tile batch does.  Every wait is for a tile
+            // with an earlier ticket, as before.
             unsigned long long* super_excl = super_state + a.t.ntiles + 8;
-            const bool follower = fa.lookback == 2 && q >= 0 && (j & 63) != 0;
-            if (follower) {
-                for (;;) {
-                    const unsigned long long w = ld(super_excl + sfirst);
-                    if ((w >> 62) != 0) { before = (long long)(w & kFfValue); break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                q = -1;
-            }
-            const bool leads = fa.lookback == 2 && q >= 0;
-            while (q >= 0) {
-                const int64_t idx = q - lane;
-                const unsigned long long w = idx >= 0 ? ld(super_state + first + idx * 64) : kFfPrefix;
-                const uint64_t ready = __ballot((w >> 62) != 0), pref = __ballot((w >> 62) == 2);
-                const int pl = pref ? __builtin_ctzll(pref) : 63;                    // the nearest super-tile that knows its prefix
-                const uint64_t need = pl == 63 ? ~0ull : ((2ull << pl) - 1);
-                if ((ready & need) != need) { __builtin_amdgcn_s_sleep(2); continue; }
-                long long v = lane <= pl ? (long long)(w & kFfValue) : 0;
+            const bool follower = fa.lookback >= 2 && q >= 0 && (j & 63) != 0;
+            bool need_local = nb > 0, need_before = follower;
+            if (!need_local && closes) st(super_state + sfirst, kFfAggregate | (unsigned long long)cnt);
+            while (need_local || need_before) {
+                const unsigned long long w = need_local && lane < nb ? ld(fa.tile_state + sfirst + lane) : kFfAggregate;
+                const unsigned long long lw = need_before && lane == 63 ? ld(super_excl + sfirst) : kFfPrefix;
+                bool progress = false;
+                if (need_local && __ballot((w >> 62) != 0) == ~0ull) {
+                    local = lane < nb ? (long long)(w & kFfValue) : 0;
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
-                before += v;
-                if (pref) break;
-                q -= 64;
+                    for (int d = 1; d < 64; d <<= 1) local += __shfl_xor(local, d);
+                    need_local = false;
+                    progress = true;
+                    // the super-tile's total leaves as soon as it is known: the tile that walks the totals never waits for a tile that waits
+                    if (closes) st(super_state + sfirst, kFfAggregate | (unsigned long long)(local + cnt));
+                }
+                if (need_before && __ballot((lw >> 62) != 0) == ~0ull) {
+                    before = (long long)(__shfl(lw, 63) & kFfValue);
+                    need_before = false;
+                    progress = true;
+                }
+                if (!progress) __builtin_amdgcn_s_sleep(2);
+            }
+            if (follower) q = -1;
+            const bool leads = fa.lookback >= 2 && q >= 0;
+            // lookback == 3: the leader adds up the nearest super-tiles from their tiles' OWN counts (one 64-wide read each, all in
+            // flight together with the walk over the older totals) instead of waiting for each of them to be added up by its last
+            // tile first — a total is one more memory round trip away than the counts it is made of, and every tile of the leader's
+            // super-tile waits that long.  Super-tiles further back than kRawSupers have their totals out by the time anybody asks.
+            constexpr int kRawSupers = 8;
+            const int nraw = leads && fa.lookback == 3 ? (int)(q + 1 < kRawSupers ? q + 1 : kRawSupers) : 0;
+            bool need_raw = nraw > 0;
+            q -= nraw;
+            while (q >= 0 || need_raw) {
+                unsigned long long r[kRawSupers];
+#pragma unroll
+                for (int k = 0; k < kRawSupers; ++k) r[k] = need_raw && k < nraw ? ld(fa.tile_state + sfirst - 64 * (k + 1) + lane) : kFfAggregate;
+                const int64_t idx = q - lane;
+                const unsigned long long w = q >= 0 && idx >= 0 ? ld(super_state + first + idx * 64) : kFfPrefix;
+                bool progress = false;
+                if (need_raw) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < kRawSupers; ++k) ok = ok && (r[k] >> 62) != 0;
+                    if (__ballot(ok) == ~0ull) {
+                        long long v = 0;
+#pragma unroll
+                        for (int k = 0; k < kRawSupers; ++k) v += (long long)(r[k] & kFfValue);
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+                        before += v;
+                        need_raw = false;
+                        progress = true;
+                    }
+                }
+                if (q >= 0) {
+                    const uint64_t ready = __ballot((w >> 62) != 0), pref = __ballot((w >> 62) == 2);
+                    const int pl = pref ? __builtin_ctzll(pref) : 63;                    // the nearest super-tile that knows its prefix
+                    const uint64_t need = pl == 63 ? ~0ull : ((2ull << pl) - 1);
+                    if ((ready & need) == need) {
+                        long long v = lane <= pl ? (long long)(w & kFfValue) : 0;
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+                        before += v;
+                        q = pref ? -1 : q - 64;
+                        progress = true;
+                    }
+                }
+                if (!progress) __builtin_amdgcn_s_sleep(2);
             }
             if (leads) st(super_excl + sfirst, kFfPrefix | (unsigned long long)before);
             if (closes) st(super_state + sfirst, kFfPrefix | (unsigned long long)(before + local + cnt));

@@ -432,8 +432,9 @@ def test_filter_frame_one_pass_predicates(gpu, ora, lens, off, nf):
 @pytest.mark.parametrize("lens,nf", [([3_000_000, 1024, 200_000], 0.0), ([1_500_000, 700_001], 0.1)])
 def test_filter_frame_one_pass_on_long_batches(gpu, ora, lens, nf):
     """Batches far longer than a super-tile of 64 tiles: the offsets inside a batch come from the two-level look-back — round 5: the
-    super-tiles' totals are walked once per super-tile by its first tile (`filter_lookback` 2, the default, any batch length), round 4:
-    by every tile (1).  Both against the oracle and the three-pass path, bit for bit."""
+    rows in front of a super-tile are found once per super-tile by its first tile (`filter_lookback` 3, the default: from the nearest
+    super-tiles' tile counts and the older ones' totals; 2: from totals only; any batch length), round 4: by every tile (1).  All
+    against the oracle and the three-pass path, bit for bit."""
     from rust_dataframe_amd import lib
     rng = np.random.default_rng(77)
     dts = [A.F64, A.I64]
@@ -446,7 +447,7 @@ def test_filter_frame_one_pass_on_long_batches(gpu, ora, lens, nf):
         try:
             for name, root in preds.items():
                 exp = ora.filter_columns(host, ora.predicate(e, root, host))
-                for fused, lookback in ((1, 2), (2, 1), (0, 2)):
+                for fused, lookback in ((1, 3), (1, 2), (2, 1), (0, 3)):
                     lib.set_option("filter_fused", fused)
                     lib.set_option("filter_lookback", lookback)
                     out = gpu.filter_frame(frame, e, root)
@@ -457,4 +458,4 @@ def test_filter_frame_one_pass_on_long_batches(gpu, ora, lens, nf):
                     out.release()
         finally:
             lib.set_option("filter_fused", 1)
-            lib.set_option("filter_lookback", 2)
+            lib.set_option("filter_lookback", 3)

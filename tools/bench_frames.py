@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--sort-rows", type=int, default=100_000_000)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--fused", type=int, default=1, help="rdf_set_option(\"filter_fused\") of the filter_frame_* entries: 2 forces the one-pass kernel on batches of any length")
-    ap.add_argument("--lookback", type=int, default=2, help="rdf_set_option(\"filter_lookback\"): 2 = a super-tile's first tile walks the super-tile totals (round 5), 1 = every tile does (round 4)")
+    ap.add_argument("--lookback", type=int, default=3, help="rdf_set_option(\"filter_lookback\"): 3 = a super-tile's first tile finds the rows in front of it from tile counts + older totals (default), 2 = from totals only, 1 = every tile walks the totals (round 4)")
     args = ap.parse_args()
     n, cr = args.rows, args.chunk_rows
     only = set(filter(None, args.only.split(",")))
