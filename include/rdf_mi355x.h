@@ -624,7 +624,7 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
 
 /* Per-thread tunables, for tests and ablations: "spec" (1 = use the ahead-of-time specialised kernels
  * when the program shape is in the catalogs, default; 0 = always the general evaluator), "fast_filter",
- * "vec_bitmap" (bitmap words through the vector / scalar memory path), "gb_partition" (hash GROUP BY: 3 = second
+ * "vec_bitmap" (accepted and ignored since round 5: the specialised kernels read bitmap words on the scalar unit only), "gb_partition" (hash GROUP BY: 3 = second
  * generation, default: LDS-table stream <= 2048 groups, line-aligned scatter + LDS tables <= 1.3 M, else one table in HBM;
  * 4 = its scatter path whatever max_groups says; 1 = first-generation histogram + scatter; 2 = radix-sort partitioning;
  * 0 = one table in HBM),

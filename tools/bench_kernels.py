@@ -329,7 +329,7 @@ def main():
             report(nm + "_sort", 16.0 * nsort, lambda: api.list_sort(Ls, osv), rows=nsort)
         del lo_, lv_
     # DataFrame::join: 1e8 probe rows against 1e7 distinct build keys (inner: every probe row finds exactly one partner)
-    if not only or "join_inner_1e8_x_1e7" in only or "join_inner_1e8_x_1e7_bucket_index" in only:
+    if not only or any(k.startswith("join_inner_") for k in only):
         nl_, nr_ = min(n, 100_000_000), 10_000_000
         lk_ = dev_i64(nl_, 12, 0, nr_)
         rk_ = torch.randperm(nr_, device="cuda", dtype=torch.int64)
