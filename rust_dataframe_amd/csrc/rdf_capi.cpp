@@ -66,7 +66,7 @@ struct Ctx {
     bool   sort_used_local = false; // the last sort finished at least one column with os_local_kernel
     int    opt_sort_msd = 1;        // sort keys that vary in more than 32 bits: passes over the top bits, then every bucket sorted in LDS (1, default); 0 = one pass per byte (A/B)
     int    opt_sort_sample = 1;     // doubles: value buckets planned from a sample of the keys (range without outliers, bucket bits from the densest region); 0 = [min, max] and ~500 rows per bucket (round 3, A/B)
-    int    opt_join_table = 1;      // equi-join on one key column: probe a table of the distinct build keys (1, default); 0 = the bucket index over the sorted build keys (A/B)
+    int    opt_join_table = 2;      // equi-join on one key column: probe a table of the distinct build keys — 2 (default, round 5): the build side sorted by hash, the table placed by a scan (no atomics); 1: sorted by key, slots claimed by compare-and-swap (round 3); 0 = the bucket index over the sorted build keys (A/B)
     int    opt_jit = 1;             // a program shape outside the catalogs: 1 = compile spec_kernel<Prog> for it on a helper thread (the interpreter answers until the kernel is ready; a code object in the cache directory is loaded at once), default; 2 = the call waits for the compiler; 0 = always the interpreter
     int    opt_take_rows = 1;       // take over a frame through interleaved row records: 1 = when the transaction model says so (default), 0 = never, 2 = always (tests, A/B)
     int    opt_gb_skew_plan = 1;    // skewed keys: per-partition region sizes + big partitions cut into several aggregate items (1 = when the probe finds skew, default; 0 = the first-generation combining path instead, A/B; 2 = always, tests)
@@ -3487,6 +3487,15 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
     KernelTimer kt;
     int kcur = 0, icur = 0;
     uint64_t bkmin = 1, bkmax = 0;   // key range of the non-NULL build keys ([1, 0] = none)
+    // Round 5: one key column -> the build side is sorted by key * golden ratio and the table of its distinct keys is laid out by a
+    // scan (JoinPlaceArgs) — join_table_kernel's compare-and-swap per distinct key on a random line was 8.6 of the 18.9 ms of a
+    // 1e8 x 1e8 join.  Equal keys stay adjacent and in row order (the sort is stable), so the pairs come out as before.
+    const bool hashed = nkeys == 1 && ctx.opt_join_table == 2 && nb > 0 && nb < ((int64_t)1 << 31) - 1;
+    void* pstats;
+    RDF_TRY(arena_alloc(128, &pstats));
+    uint64_t* d_bstats = (uint64_t*)pstats;
+    uint64_t* d_pstats = d_bstats + 4;
+    uint64_t* d_ostats = d_bstats + 8;     // (hashed build) the build keys' own [min, max]
     const uint64_t* pbits[4] = {nullptr, nullptr, nullptr, nullptr};
     const uint64_t* bbits[4] = {nullptr, nullptr, nullptr, nullptr};
     // One column per side: the order-preserving key bits ARE the join key.  Several: the key is a 64-bit hash of the
@@ -3505,7 +3514,7 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
             ka.n = n;
             ka.nullflags = has_nulls ? nullflags : nullptr;
             ka.dtype = kdt[k];
-            if (nkeys == 1) { ka.keys = out_keys; ka.bit_stats = d_stats; }
+            if (nkeys == 1) { ka.keys = out_keys; ka.bit_stats = d_stats; if (build && hashed) { ka.hash_mul = 0x9E3779B97F4A7C15ull; ka.raw_stats = d_ostats; } }   // (the key range stays what the probe's early-out compares against; the sort sees the hashed keys' range)
             else {
                 void* pb;
                 RDF_TRY(arena_alloc((size_t)n * 8 + 8, &pb));
@@ -3519,19 +3528,15 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
             ca.nkeys = nkeys; ca.n = n; ca.nullflags = has_nulls ? nullflags : nullptr; ca.out = out_keys; ca.bit_stats = d_stats;
             HIP_TRY(launch_join_combine(ca, ctx.stream));
         }
-        (void)build;
         return RDF_OK;
     };
-    void* pstats;
-    RDF_TRY(arena_alloc(128, &pstats));
-    uint64_t* d_bstats = (uint64_t*)pstats;
-    uint64_t* d_pstats = d_bstats + 4;
     RDF_TRY(sort_stats_reset(d_bstats));
     RDF_TRY(sort_stats_reset(d_pstats));
+    RDF_TRY(sort_stats_reset(d_ostats));
     if (nb > 0) {
         RDF_TRY(side_keys(true, nb, bnc, (size_t)nkeys * (size_t)pnc, tb.dev_at<int64_t>(o_brs), bnulls, sb.keys[0], (uint8_t*)sb.nullflags, d_bstats, bbits));
         if (bnulls) HIP_TRY(launch_count_bytes((const uint8_t*)sb.nullflags, nb, d_cnt, ctx.stream));
-        RDF_TRY(radix_sort_rows(sb, nb, nkeys == 1 ? dtype_size(dt) : 8, bnulls, &kcur, &icur, d_bstats, pin_off, &bkmin, &bkmax));
+        RDF_TRY(radix_sort_rows(sb, nb, nkeys == 1 && !hashed ? dtype_size(dt) : 8, bnulls, &kcur, &icur, d_bstats, pin_off, &bkmin, &bkmax));
     }
     // probe side: key bits + null flags in row order
     void *ppk, *ppn, *pcounts, *poffs;
@@ -3542,9 +3547,15 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
     if (np > 0) RDF_TRY(side_keys(false, np, pnc, 0, tb.dev_at<int64_t>(o_prs), pnulls, (uint64_t*)ppk, (uint8_t*)ppn, d_pstats, pbits));
     RDF_TRY(pinned_reserve(pin_off + 256));
     HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, d_cnt, 8, hipMemcpyDeviceToHost, ctx.stream));
+    if (hashed) HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off + 8, d_ostats, 16, hipMemcpyDeviceToHost, ctx.stream));
     HIP_TRY(hipStreamSynchronize(ctx.stream));
     unsigned long long bnull_count = 0;
     memcpy(&bnull_count, ctx.pinned + pin_off, 8);
+    if (hashed) {
+        uint64_t st[2];
+        memcpy(st, ctx.pinned + pin_off + 8, 16);
+        if (st[0] > st[1]) { bkmin = 1; bkmax = 0; } else { bkmin = st[0]; bkmax = st[1]; }
+    }
     const int64_t nrv = nb - (int64_t)bnull_count;
 
     void* pmatched = nullptr;
@@ -3563,7 +3574,20 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
     const bool use_table = nkeys == 1 && nrv > 0 && nb < ((int64_t)1 << 31) - 1 && ctx.opt_join_table;
     void* ptable = nullptr;
     int tbits = 10;
-    if (use_table) {
+    if (use_table && hashed) {
+        while (((int64_t)1 << tbits) < 2 * nrv) ++tbits;
+        const int64_t cap = ((int64_t)1 << tbits) + (1 << 16);      // no wrap-around: the last home slot's cluster runs into the margin
+        RDF_TRY(arena_alloc((size_t)cap * 16 + 64, &ptable));      // (not cleared: the placement writes every slot, the empty ones included)
+        JoinPlaceArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.rkeys = sb.keys[kcur]; pa.ridx = sb.idx[icur]; pa.nrv = nrv; pa.table = (uint64_t*)ptable; pa.cap = cap; pa.tshift = 64 - tbits;
+        pa.ntiles = (nrv + kJoinPlaceTile - 1) / kJoinPlaceTile;
+        void* ptiles;
+        RDF_TRY(arena_alloc((size_t)pa.ntiles * 16 + 16, &ptiles));
+        pa.tiles = (int64_t*)ptiles;
+        pa.flags = d_cnt + 3;
+        HIP_TRY(launch_join_place(pa, ctx.stream));
+    } else if (use_table) {
         while (((int64_t)1 << tbits) < 2 * nrv) ++tbits;
         RDF_TRY(arena_alloc(((size_t)16 << tbits) + 64, &ptable));
         HIP_TRY(hipMemsetAsync(ptable, 0, (size_t)16 << tbits, ctx.stream));
@@ -3582,7 +3606,7 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
     ja.buckets = (const uint32_t*)pbuckets;
     ja.kmin = bkmin; ja.kmax = bkmax; ja.bucket_shift = bshift;
     ja.first = (uint32_t*)pfirst;
-    if (use_table) { ja.table = (const uint64_t*)ptable; ja.tmask = ((uint64_t)1 << tbits) - 1; ja.tshift = 64 - tbits; }
+    if (use_table) { ja.table = (const uint64_t*)ptable; ja.tmask = hashed ? ~0ull : ((uint64_t)1 << tbits) - 1; ja.tshift = 64 - tbits; ja.hashed = hashed ? 1 : 0; }
     ja.nkeys = nkeys;
     for (int k = 0; k < 4; ++k) { ja.pbits[k] = pbits[k]; ja.bbits[k] = bbits[k]; }
     ja.lkeys = (const uint64_t*)ppk;
@@ -3609,13 +3633,21 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
         HIP_TRY(launch_join_append(aa, ctx.stream));
     }
     HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, (int64_t*)poffs + np, 8, hipMemcpyDeviceToHost, ctx.stream));
-    HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off + 8, d_cnt + 1, 16, hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off + 8, d_cnt + 1, 24, hipMemcpyDeviceToHost, ctx.stream));
     HIP_TRY(hipStreamSynchronize(ctx.stream));
     int64_t probe_rows = 0;
-    unsigned long long appended = 0, unmatched = 0;
+    unsigned long long appended = 0, unmatched = 0, place_overflow = 0;
     memcpy(&probe_rows, ctx.pinned + pin_off, 8);
     memcpy(&appended, ctx.pinned + pin_off + 8, 8);
     memcpy(&unmatched, ctx.pinned + pin_off + 16, 8);
+    memcpy(&place_overflow, ctx.pinned + pin_off + 24, 8);
+    if (hashed && place_overflow) {     // a cluster ran past the table's margin (keys that crowd on the last slots): the round-3 table takes the call
+        kt.stop();
+        ctx.opt_join_table = 1;
+        const rdf_status st = rdf_equijoin_indices_multi(left_keys, left_nchunks, right_keys, right_nchunks, nkeys, join_type, out_left, out_right, out_rows);
+        ctx.opt_join_table = 2;
+        return st;
+    }
     const int64_t total = probe_rows + (int64_t)appended;
     *out_rows = total;
     if (!out_left) { kt.stop(); return RDF_OK; }
@@ -4085,7 +4117,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "sort_gen") == 0) g_ctx.opt_sort_gen = (int)value;
     else if (strcmp(name, "sort_msd") == 0) g_ctx.opt_sort_msd = (int)value;
     else if (strcmp(name, "sort_sample") == 0) g_ctx.opt_sort_sample = (int)value;
-    else if (strcmp(name, "join_table") == 0) g_ctx.opt_join_table = (int)value;
+    else if (strcmp(name, "join_table") == 0) g_ctx.opt_join_table = value < 0 || value > 2 ? 2 : (int)value;
     else if (strcmp(name, "jit") == 0) g_ctx.opt_jit = (int)value;
     else if (strcmp(name, "gb_skew_plan") == 0) g_ctx.opt_gb_skew_plan = (int)value;
     else if (strcmp(name, "gb_compact") == 0) g_ctx.opt_gb_compact = (int)value;

@@ -232,6 +232,8 @@ struct SortKeyArgs {                                 // key[i] = order-preservin
     uint64_t*          bit_stats;                    // [2] in/out: min and max over the non-null keys written ([0] starts ~0, [1] starts 0)
     int32_t            dtype, descending;
     int32_t            null_or, pad;                 // multi-column join keys: nullflags[row] |= isnull (the buffer starts zeroed)
+    uint64_t           hash_mul;                     // != 0 (the join's hash-ordered build side): keys[i] = key bits * hash_mul, bit_stats over THOSE,
+    uint64_t*          raw_stats;                    //   and [min, max] of the key bits themselves here
 };
 struct SortPassArgs {
     const uint64_t* keys_in;  const uint32_t* idx_in;   // idx_in nullptr = identity (first pass)
@@ -331,9 +333,18 @@ struct JoinProbeArgs {
     // `first` (bit 31 set) for such keys and the write phase never touches ridx.
     const uint64_t* table;     // [2 * (tmask + 1)] or nullptr: the bucket index above
     uint64_t        tmask;
-    int32_t         tshift, pad3;   // slot = (key * golden ratio) >> tshift
+    int32_t         tshift;    // slot = (key * golden ratio) >> tshift
+    int32_t         hashed;    // the table holds key * golden ratio (a bijection) in slot order, placed by a scan: no wrap-around (tmask = ~0)
 };
 struct JoinTableArgs { const uint64_t* rkeys; const uint32_t* ridx; int64_t nrv; uint64_t* table; uint64_t tmask; int32_t tshift, pad; };
+// Round 5: the same table WITHOUT atomics.  The build side is sorted by h = key * golden ratio (odd multiplier: a bijection on 64 bits),
+// so the distinct keys arrive in slot order and linear probing's layout is a scan: slot(r) = max(home(r), slot(r - 1) + 1) = r +
+// max over q <= r of (home(q) - q) for the r-th distinct key.  Phase 0: per tile of 2048 sorted rows {distinct keys, max(home - local
+// index)}; phase 1 (one block): their exclusive prefixes under (cA, mA) + (cB, mB) = (cA + cB, max(mA, mB - cA)); phase 2: every tile
+// places its keys — near-sequential 16-byte stores instead of 1e8 compare-and-swaps on random lines.  No wrap-around: the table has
+// `cap` slots >= 2^tbits + a margin, a slot beyond it raises flags[0] and the host falls back to join_table_kernel.
+struct JoinPlaceArgs { const uint64_t* rkeys; const uint32_t* ridx; int64_t nrv; uint64_t* table; int64_t cap; int64_t* tiles; int64_t ntiles;
+                       unsigned long long* flags; int32_t tshift, phase; };
 struct JoinCombineArgs { const uint64_t* bits[4]; int32_t nkeys, pad; int64_t n; const uint8_t* nullflags; uint64_t* out; uint64_t* bit_stats; };
 struct JoinBucketArgs { const uint64_t* rkeys; int64_t nrv; uint32_t* buckets; uint64_t kmin; int32_t bucket_shift; };
 struct JoinAppendArgs {        // FULL: build rows nobody matched (and NULL-key build rows) with a NULL probe index
@@ -710,6 +721,8 @@ hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_join_buckets(const JoinBucketArgs& a, hipStream_t s);
 hipError_t launch_join_table(const JoinTableArgs& a, hipStream_t s);
+hipError_t launch_join_place(JoinPlaceArgs a, hipStream_t s);     // the three phases
+constexpr int kJoinPlaceTile = 2048;
 hipError_t launch_join_combine(const JoinCombineArgs& a, hipStream_t s);
 hipError_t launch_join_count(const JoinProbeArgs& a, hipStream_t s);
 hipError_t launch_join_write(const JoinProbeArgs& a, hipStream_t s);

@@ -491,7 +491,7 @@ __device__ __forceinline__ uint64_t sort_key_bits(const DevChunkCol& cc, int dt,
 }
 
 __global__ __launch_bounds__(kBlock) void sort_keys_kernel(const SortKeyArgs a, uint64_t width_mask) {
-    uint64_t kmin = ~0ull, kmax = 0;
+    uint64_t kmin = ~0ull, kmax = 0, rmin = ~0ull, rmax = 0;
     const double inv = chunk_lookup_scale(a.chunk_row_start, a.nchunks);
     const DevChunkCol first = a.chunks[0];
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
@@ -508,6 +508,7 @@ __global__ __launch_bounds__(kBlock) void sort_keys_kernel(const SortKeyArgs a, 
         if (a.descending) k = ~k & width_mask;
         bool isnull = false;
         if (cc.validity) isnull = !((cc.validity[e >> 3] >> (e & 7)) & 1);
+        if (a.hash_mul && !isnull) { rmin = k < rmin ? k : rmin; rmax = k > rmax ? k : rmax; k *= a.hash_mul; }
         const uint64_t kw = isnull ? 0 : k;  // nulls are ordered by the nulls-last pass; equal keys keep them stable
         a.keys[i] = kw;
         if (!isnull) { kmin = kw < kmin ? kw : kmin; kmax = kw > kmax ? kw : kmax; }
@@ -520,6 +521,14 @@ __global__ __launch_bounds__(kBlock) void sort_keys_kernel(const SortKeyArgs a, 
             kmin = x < kmin ? x : kmin; kmax = y > kmax ? y : kmax;
         }
         if ((threadIdx.x & 63) == 0) { atomicMin((unsigned long long*)&a.bit_stats[0], (unsigned long long)kmin); atomicMax((unsigned long long*)&a.bit_stats[1], (unsigned long long)kmax); }
+    }
+    if (a.hash_mul && a.raw_stats) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint64_t x = shfl_xor64(rmin, m), y = shfl_xor64(rmax, m);
+            rmin = x < rmin ? x : rmin; rmax = y > rmax ? y : rmax;
+        }
+        if ((threadIdx.x & 63) == 0 && rmin <= rmax) { atomicMin((unsigned long long*)&a.raw_stats[0], (unsigned long long)rmin); atomicMax((unsigned long long*)&a.raw_stats[1], (unsigned long long)rmax); }
     }
 }
 
@@ -638,6 +647,7 @@ __global__ __launch_bounds__(kBlock) void sort_scatter_kernel(const SortPassArgs
 
 // multi-column join keys: one 64-bit hash per row over the columns' order-preserving key bits (SplitMix64 finaliser per
 // column, chained); rows with a NULL in any key column keep hash 0 and are excluded through nullflags
+constexpr uint64_t kJoinMul = 0x9E3779B97F4A7C15ull;     // slot = (key * kJoinMul) >> tshift; odd: key -> key * kJoinMul is a bijection
 __device__ __forceinline__ uint64_t join_mix(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -691,7 +701,7 @@ __global__ __launch_bounds__(kBlock) void join_table_kernel(const JoinTableArgs 
         }
         const uint32_t info = j - i == 1 ? (0x80000000u | a.ridx[i]) : (uint32_t)(j - i);
         const unsigned long long w1 = ((unsigned long long)i << 32) | info;
-        uint64_t s = (k * 0x9E3779B97F4A7C15ull) >> a.tshift;
+        uint64_t s = (k * kJoinMul) >> a.tshift;
         for (;;) {
             if (atomicCAS((unsigned long long*)&a.table[2 * s + 1], 0ull, w1) == 0ull) { a.table[2 * s] = k; break; }
             s = (s + 1) & a.tmask;
@@ -699,6 +709,130 @@ __global__ __launch_bounds__(kBlock) void join_table_kernel(const JoinTableArgs 
     }
 }
 typedef uint64_t join_u64x2 __attribute__((ext_vector_type(2)));
+constexpr long long kPlaceNone = -(1ll << 62);
+struct PlaceCM { long long c, m; };
+__device__ __forceinline__ PlaceCM place_join(PlaceCM a, PlaceCM b) { PlaceCM r; r.c = a.c + b.c; const long long bm = b.m - a.c; r.m = a.m > bm ? a.m : bm; return r; }
+// exclusive prefix of v over the block's threads (NT threads); total in *total
+template <int NT>
+__device__ __forceinline__ PlaceCM place_block_scan(PlaceCM v, PlaceCM* total) {
+    __shared__ PlaceCM wtot[NT / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    PlaceCM inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        PlaceCM o; o.c = __shfl_up(inc.c, d); o.m = __shfl_up(inc.m, d);
+        if (lane >= d) inc = place_join(o, inc);
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    PlaceCM ex; ex.c = __shfl_up(inc.c, 1); ex.m = __shfl_up(inc.m, 1);
+    if (lane == 0) { ex.c = 0; ex.m = kPlaceNone; }
+    PlaceCM wp; wp.c = 0; wp.m = kPlaceNone;
+    for (int w = 0; w < wave; ++w) wp = place_join(wp, wtot[w]);
+    if (total) { PlaceCM t = wp; for (int w = wave; w < NT / 64; ++w) t = place_join(t, wtot[w]); *total = t; }
+    __syncthreads();
+    return place_join(wp, ex);
+}
+__global__ __launch_bounds__(1024) void join_place_scan_kernel(const JoinPlaceArgs a) {     // phase 1: one block
+    const int64_t per = (a.ntiles + 1023) / 1024;
+    const int64_t t0 = (int64_t)threadIdx.x * per, t1 = t0 + per < a.ntiles ? t0 + per : a.ntiles;
+    PlaceCM acc; acc.c = 0; acc.m = kPlaceNone;
+    for (int64_t t = t0; t < t1; ++t) { PlaceCM v; v.c = a.tiles[2 * t]; v.m = a.tiles[2 * t + 1]; acc = place_join(acc, v); }
+    PlaceCM run = place_block_scan<1024>(acc, nullptr);
+    for (int64_t t = t0; t < t1; ++t) {
+        PlaceCM v; v.c = a.tiles[2 * t]; v.m = a.tiles[2 * t + 1];
+        a.tiles[2 * t] = run.c; a.tiles[2 * t + 1] = run.m;
+        run = place_join(run, v);
+    }
+}
+__global__ __launch_bounds__(kBlock) void join_place_kernel(const JoinPlaceArgs a) {         // phases 0 and 2: one tile per block
+    constexpr int kPer = kJoinPlaceTile / kBlock;                 // consecutive sorted rows per thread while the positions are computed
+    constexpr int kPad = kJoinPlaceTile + kJoinPlaceTile / kPer + 1;     // one word of padding per thread's run: conflict-free in both access orders
+    __shared__ uint64_t sk[kPad];
+    __shared__ uint32_t spos[kPad], sgap[kPad];
+    const int64_t base = (int64_t)blockIdx.x * kJoinPlaceTile;
+    const int n = (int)(a.nrv - base < kJoinPlaceTile ? a.nrv - base : kJoinPlaceTile);
+    for (int e = threadIdx.x; e < n; e += kBlock) sk[e + e / kPer] = a.rkeys[base + e];
+    __syncthreads();
+    const int e0 = threadIdx.x * kPer;
+    const uint64_t before = e0 == 0 ? (base > 0 ? a.rkeys[base - 1] : 0) : sk[(e0 - 1) + (e0 - 1) / kPer];
+    const bool no_prev = e0 == 0 && base == 0;
+    uint64_t prev = before;
+    PlaceCM loc; loc.c = 0; loc.m = kPlaceNone;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int e = e0 + j;
+        if (e >= n) break;
+        const uint64_t h = sk[e + e / kPer];
+        if ((j == 0 && no_prev) || h != prev) {
+            const long long g = (long long)(h >> a.tshift) - loc.c;
+            loc.m = g > loc.m ? g : loc.m;
+            ++loc.c;
+        }
+        prev = h;
+    }
+    PlaceCM total;
+    const PlaceCM ex = place_block_scan<kBlock>(loc, &total);
+    if (a.phase == 0) {
+        if (threadIdx.x == 0) { a.tiles[2 * blockIdx.x] = total.c; a.tiles[2 * blockIdx.x + 1] = total.m; }
+        return;
+    }
+    PlaceCM carry; carry.c = a.tiles[2 * blockIdx.x]; carry.m = a.tiles[2 * blockIdx.x + 1];
+    // this tile owns the slots from the one behind the previous tiles' last key up to its own last key (the last tile: up to the end):
+    // it writes the empty ones too, so nobody clears the table beforehand and every line leaves whole
+    const long long p0 = carry.c > 0 ? carry.c + carry.m : 0;
+    PlaceCM run = place_join(carry, ex);        // {distinct keys before this thread's rows, max(home - index) over them}: absolute
+    long long last = run.c > 0 ? run.c - 1 + run.m : -1;       // slot of the distinct key before this thread's rows
+    prev = before;
+    bool too_far = false;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int e = e0 + j;
+        if (e >= n) break;
+        const uint64_t h = sk[e + e / kPer];
+        uint32_t off = ~0u, gap = 0;
+        if ((j == 0 && no_prev) || h != prev) {
+            const long long g = (long long)(h >> a.tshift) - run.c;
+            run.m = g > run.m ? g : run.m;
+            const long long pos = run.c + run.m;
+            ++run.c;
+            if (pos + 1 >= a.cap || pos - p0 >= 0xFFFFFFFFll) too_far = true;       // (the slot behind the last key stays empty: probes end there)
+            else { off = (uint32_t)(pos - p0); gap = (uint32_t)(pos - last - 1); }
+            last = pos;
+        }
+        spos[e + e / kPer] = off;
+        sgap[e + e / kPer] = gap;
+        prev = h;
+    }
+    if (too_far) atomicOr(a.flags, 1ull);
+    __syncthreads();
+    // consecutive lanes now take consecutive rows: their slots are neighbours, the stores of a wave fall into a few lines
+    const join_u64x2 zero = {0, 0};
+    for (int e = threadIdx.x; e < n; e += kBlock) {
+        const uint32_t off = spos[e + e / kPer];
+        if (off == ~0u) continue;
+        const uint64_t h = sk[e + e / kPer];
+        const long long pos = p0 + off;
+        // the end of the run of equal keys that starts here (galloping, then a binary search: see join_table_kernel)
+        const int64_t i = base + e;
+        int64_t jn = i + 1;
+        if (jn < a.nrv && (e + 1 < n ? sk[(e + 1) + (e + 1) / kPer] : a.rkeys[jn]) == h) {
+            int64_t step = 2;
+            while (i + step < a.nrv && a.rkeys[i + step] == h) step <<= 1;
+            int64_t l = i + (step >> 1), hh = i + step < a.nrv ? i + step : a.nrv;
+            while (l + 1 < hh) { const int64_t mid = l + ((hh - l) >> 1); if (a.rkeys[mid] == h) l = mid; else hh = mid; }
+            jn = hh;
+        }
+        const uint32_t info = jn - i == 1 ? (0x80000000u | a.ridx[i]) : (uint32_t)(jn - i);
+        join_u64x2 w; w[0] = h; w[1] = ((unsigned long long)i << 32) | info;
+        *(join_u64x2*)(a.table + 2 * pos) = w;
+        for (uint32_t g = 1, gap = sgap[e + e / kPer]; g <= gap; ++g) *(join_u64x2*)(a.table + 2 * (pos - g)) = zero;
+    }
+    if (blockIdx.x == gridDim.x - 1) {          // the slots behind the last key: empty up to the end of the table
+        const long long end_of_keys = total.c + carry.c > 0 ? place_join(carry, total).c - 1 + place_join(carry, total).m + 1 : 0;
+        for (long long q = end_of_keys + threadIdx.x; q < a.cap; q += kBlock) *(join_u64x2*)(a.table + 2 * q) = zero;
+    }
+}
 // sorted build positions [lo, hi) whose key equals probe row i's key; direct = the build row itself when the key occurs once (table path)
 __device__ __forceinline__ void join_range(const JoinProbeArgs& a, int64_t i, int64_t& lo, int64_t& hi, uint32_t& direct) {
     lo = hi = 0;
@@ -707,11 +841,14 @@ __device__ __forceinline__ void join_range(const JoinProbeArgs& a, int64_t i, in
     const uint64_t k = a.lkeys[i];
     if (k < a.kmin || k > a.kmax) return;
     if (a.table) {
-        uint64_t s = (k * 0x9E3779B97F4A7C15ull) >> a.tshift;
+        const uint64_t h = k * kJoinMul;
+        const uint64_t want = a.hashed ? h : k;
+        uint64_t s = h >> a.tshift;
         for (;;) {
             const join_u64x2 e = *(const join_u64x2*)(a.table + 2 * s);
             if (e[1] == 0) return;
-            if (e[0] == k) {
+            if (a.hashed && e[0] > want) return;     // a scan-placed table holds its keys in hash order: a larger one ends the search
+            if (e[0] == want) {
                 const uint32_t info = (uint32_t)e[1];
                 lo = (int64_t)(e[1] >> 32);
                 if (info >> 31) { hi = lo + 1; direct = info; } else hi = lo + info;
@@ -1776,6 +1913,15 @@ hipError_t launch_join_buckets(const JoinBucketArgs& a, hipStream_t s) {
 }
 hipError_t launch_join_table(const JoinTableArgs& a, hipStream_t s) {
     if (a.nrv > 0) hipLaunchKernelGGL(join_table_kernel, dim3(rows_grid(a.nrv)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_join_place(JoinPlaceArgs a, hipStream_t s) {
+    if (a.nrv <= 0) return hipSuccess;
+    a.phase = 0;
+    hipLaunchKernelGGL(join_place_kernel, dim3((unsigned)a.ntiles), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(join_place_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+    a.phase = 2;
+    hipLaunchKernelGGL(join_place_kernel, dim3((unsigned)a.ntiles), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_join_combine(const JoinCombineArgs& a, hipStream_t s) {

@@ -1240,14 +1240,65 @@ def test_equijoin_bucket_index_edge_cases(gpu, ora, how):
     from rust_dataframe_amd import lib
     for lk, rk in cases:
         el, er = ora.equijoin_indices(lk, rk, how)
-        for table in (1, 0):     # the table of distinct build keys (default) and the bucket index over the sorted build keys
+        # the table of distinct build keys — laid out by a scan over the hash-ordered build side (2, default) or claimed slot by slot
+        # with compare-and-swap (1, round 3) — and the bucket index over the sorted build keys (0)
+        for table in (2, 1, 0):
             lib.set_option("join_table", table)
             try:
                 gl, gr = gpu.equijoin_indices(lk, rk, how)
             finally:
-                lib.set_option("join_table", 1)
+                lib.set_option("join_table", 2)
             assert gl.length == el.length and gl.null_count == el.null_count and gr.null_count == er.null_count
             assert _pairs(gl, gr) == _pairs(el, er), f"join {how} table={table}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["distinct", "duplicates", "crowded_slots"])
+def test_equijoin_table_placed_by_scan(gpu, shape):
+    """Round 5: the table of distinct build keys is laid out without atomics — the build side sorted by key * golden ratio, slot(r) =
+    r + prefix-max(home - r) over the distinct keys (three kernels: per-tile aggregates, one block scanning them, placement).  Sizes
+    that span thousands of 4096-row tiles (the one-block scan handles several tiles per thread), against the compare-and-swap table
+    of round 3: identical index arrays (the probe rows' order and, inside a probe row, the build rows' order do not depend on how the
+    table was built), pair counts against numpy.  `crowded_slots`: keys whose hashes pile onto the table's last home slot, far beyond its
+    margin — the placement flags it and the call falls back to the round-3 table."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(515)
+    if shape == "distinct":
+        nb, npb = 6_000_000, 3_000_000
+        bk = rng.permutation(nb).astype(np.int64) * 3
+        pk = rng.integers(0, 3 * nb, npb).astype(np.int64)
+    elif shape == "duplicates":
+        nb, npb = 5_000_000, 500_000
+        bk = rng.integers(0, 1_000_000, nb).astype(np.int64)          # ~5 build rows per key
+        pk = rng.integers(-1000, 1_001_000, npb).astype(np.int64)
+    else:
+        # keys whose hashes are the LARGEST 64-bit numbers: every key's home slot is the table's last one, the cluster runs 300 000 slots
+        # past it — beyond the 65 536-slot margin (the scan-placed table does not wrap around)
+        inv = pow(0x9E3779B97F4A7C15, -1, 1 << 64)
+        nb, npb = 300_000, 100_000
+        with np.errstate(over="ignore"):
+            bk = ((np.uint64(0xFFFFFFFFFFFFFFFF) - np.arange(nb, dtype=np.uint64)) * np.uint64(inv)).astype(np.int64)
+        pk = np.concatenate([bk[: npb // 2], rng.integers(0, 1 << 62, npb - npb // 2).astype(np.int64)])
+    L, R = [A.HostArray.from_numpy(pk)], [A.HostArray.from_numpy(bk)]
+    uniq, cnt = np.unique(bk, return_counts=True)
+    pos = np.searchsorted(uniq, pk)
+    hit = (pos < len(uniq)) & (uniq[np.minimum(pos, len(uniq) - 1)] == pk)
+    inner_rows = int(cnt[pos[hit]].sum())
+    for how, rows in (("inner", inner_rows), ("left", inner_rows + int((~hit).sum()))):
+        got = {}
+        for table in (2, 1):
+            lib.set_option("join_table", table)
+            try:
+                gl, gr = gpu.equijoin_indices(L, R, how)
+            finally:
+                lib.set_option("join_table", 2)
+            assert gl.length == rows, (shape, how, table)
+            got[table] = (gl.to_numpy(), gr.to_numpy(), gr.null_count)
+        assert np.array_equal(got[2][0], got[1][0]) and got[2][2] == got[1][2], (shape, how)
+        m = got[1][1] if how == "inner" else None
+        if how == "inner":
+            assert np.array_equal(got[2][1], m), shape
+            assert np.array_equal(pk[got[2][0]], bk[got[2][1]]), shape          # every pair joins equal keys
 
 
 @pytest.mark.parametrize("val_dtype", [A.F64, A.I64, A.F32, None])

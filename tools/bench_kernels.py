@@ -335,9 +335,11 @@ def main():
         rk_ = torch.randperm(nr_, device="cuda", dtype=torch.int64)
         jl, jr = out_like(A.U32, nl_, True), out_like(A.U32, nl_, True)
         report("join_inner_1e8_x_1e7", 8.0 * nl_ + 8.0 * nr_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk_, A.I64, nl_)], [arr(rk_, A.I64, nr_)], "inner", (jl, jr)), rows=nl_)
+        lib.set_option("join_table", 1)      # A/B: the build side sorted by key, table slots claimed by compare-and-swap (round 3)
+        report("join_inner_1e8_x_1e7_cas_table", 8.0 * nl_ + 8.0 * nr_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk_, A.I64, nl_)], [arr(rk_, A.I64, nr_)], "inner", (jl, jr)), rows=nl_)
         lib.set_option("join_table", 0)      # A/B: bucket index over the sorted build keys
         report("join_inner_1e8_x_1e7_bucket_index", 8.0 * nl_ + 8.0 * nr_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk_, A.I64, nl_)], [arr(rk_, A.I64, nr_)], "inner", (jl, jr)), rows=nl_)
-        lib.set_option("join_table", 1)
+        lib.set_option("join_table", 2)
         del lk_, rk_
         # a build side as long as the probe side: 1e8 distinct keys (a 3.2 GB table of 16-byte slots at load 0.5: every probe is a
         # random line from HBM; the case a radix-partitioned join was priced for)
@@ -346,6 +348,9 @@ def main():
             rk8 = torch.randperm(nb_, device="cuda", dtype=torch.int64)
             lk8 = dev_i64(nl_, 12, 0, nb_)
             report("join_inner_1e8_x_1e8", 8.0 * nl_ + 8.0 * nb_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk8, A.I64, nl_)], [arr(rk8, A.I64, nb_)], "inner", (jl, jr)), rows=nl_)
+            lib.set_option("join_table", 1)
+            report("join_inner_1e8_x_1e8_cas_table", 8.0 * nl_ + 8.0 * nb_ + 8.0 * nl_, lambda: api.equijoin_indices([arr(lk8, A.I64, nl_)], [arr(rk8, A.I64, nb_)], "inner", (jl, jr)), rows=nl_)
+            lib.set_option("join_table", 2)
             del lk8, rk8
     # hash GROUP BY key -> sum(val): 1e6 groups (config C4's per-GPU leg) and 1e3 groups (contended)
     for ng in (1_000_000, 2_000, 1_000, 100, 8):
