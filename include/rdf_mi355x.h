@@ -644,8 +644,12 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * "gb_bucket" (partition tables of the scatter path's aggregate pass: 0 = one key per probe for keys packed into at most 4 x max_groups
  * values — the multiplicative hash never collides there —, four keys per 32-byte bucket otherwise, default; 1 / 4 force one),
  * "filter_fused" (rdf_filter_frame with a `column CMP literal [AND | OR column CMP literal]` predicate over 4- / 8-byte columns: 1 = the
- * predicate runs inside the compaction kernel, one pass, when no batch is longer than 1 048 576 rows, default; 2 = always; 0 = predicate -> mask,
- * count, compact),
+ * predicate runs inside the compaction kernel, one pass, default; 2 = the same (it forced the kernel on long batches while those took
+ * three passes); 0 = predicate -> mask, count, compact),
+ * "filter_lookback" (that kernel on batches longer than a tile: 3 = one tile per 64 finds the rows in front of them all, from tile
+ * counts and older totals, default; 2 = from totals only; 1 = every tile walks the totals and batches beyond 1 048 576 rows take the three passes),
+ * "join_table" (equi-join on one key column: 2 = the build side sorted by hash, the table of its distinct keys laid out by a scan,
+ * default; 1 = sorted by key, table slots claimed by compare-and-swap; 0 = a bucket index over the sorted build keys),
  * "sort_msd" (keys that vary in 25 bits or more: 1 = passes over the top bits, buckets finished in LDS, default; 0 = one pass per byte),
  * "sort_sample" (Float64 sort keys: 1 = the value buckets of those passes are planned from a sample of the keys — the range the rows lie
  * in without far outliers / infinities / NaNs, as many bucket bits as the densest region needs —, default; 0 = [min, max], ~500 rows per bucket),

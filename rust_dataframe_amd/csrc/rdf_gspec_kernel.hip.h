@@ -177,8 +177,14 @@ __device__ __forceinline__ void gpred_rows(C& c, uint32_t& keep) {
     }
 }
 
+#ifndef RDF_GSPEC_PF
+#define RDF_GSPEC_PF 1
+#endif
+#ifndef RDF_GSPEC_WAVES
+#define RDF_GSPEC_WAVES 2
+#endif
 template <class P>
-__global__ __launch_bounds__(kBlock) void gspec_kernel(const GSpecArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RDF_GSPEC_WAVES, 8))) void gspec_kernel(const GSpecArgs a) {
     constexpr int NC = P::NC, R = P::R, U = R / 2, G = P::G, NV = P::NV;
     using Pred = typename P::Pred;
     constexpr bool has_pred = !std::is_same<Pred, None>::value;
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void gspec_kernel(const GSpecArgs a) {
         if (tile < a.ntiles) {
             meta = locate(tile);
             const int64_t nrw = meta.base + (int64_t)wave * (64 * R);
-            if (nrw + 64 * R <= meta.n) {
+            if (RDF_GSPEC_PF && nrw + 64 * R <= meta.n) {
                 load_all<P>(nx, meta.col, nrw, lane, (1u << R) - 1, true, std::make_index_sequence<NC>());
                 have_next = true;
             }
