@@ -22,6 +22,7 @@
 //                             [Column::take src/table.rs:218-241]
 //   fill_*                    counter-based synthetic data (bench / tests)
 #include "rdf_common.hip.h"
+#include "rdf_join_place.h"
 
 namespace rdfk {
 
@@ -709,9 +710,6 @@ __global__ __launch_bounds__(kBlock) void join_table_kernel(const JoinTableArgs 
     }
 }
 typedef uint64_t join_u64x2 __attribute__((ext_vector_type(2)));
-constexpr long long kPlaceNone = -(1ll << 62);
-struct PlaceCM { long long c, m; };
-__device__ __forceinline__ PlaceCM place_join(PlaceCM a, PlaceCM b) { PlaceCM r; r.c = a.c + b.c; const long long bm = b.m - a.c; r.m = a.m > bm ? a.m : bm; return r; }
 // exclusive prefix of v over the block's threads (NT threads); total in *total
 template <int NT>
 __device__ __forceinline__ PlaceCM place_block_scan(PlaceCM v, PlaceCM* total) {
@@ -726,8 +724,8 @@ __device__ __forceinline__ PlaceCM place_block_scan(PlaceCM v, PlaceCM* total) {
     if (lane == 63) wtot[wave] = inc;
     __syncthreads();
     PlaceCM ex; ex.c = __shfl_up(inc.c, 1); ex.m = __shfl_up(inc.m, 1);
-    if (lane == 0) { ex.c = 0; ex.m = kPlaceNone; }
-    PlaceCM wp; wp.c = 0; wp.m = kPlaceNone;
+    if (lane == 0) ex = place_empty();
+    PlaceCM wp = place_empty();
     for (int w = 0; w < wave; ++w) wp = place_join(wp, wtot[w]);
     if (total) { PlaceCM t = wp; for (int w = wave; w < NT / 64; ++w) t = place_join(t, wtot[w]); *total = t; }
     __syncthreads();
@@ -736,7 +734,7 @@ __device__ __forceinline__ PlaceCM place_block_scan(PlaceCM v, PlaceCM* total) {
 __global__ __launch_bounds__(1024) void join_place_scan_kernel(const JoinPlaceArgs a) {     // phase 1: one block
     const int64_t per = (a.ntiles + 1023) / 1024;
     const int64_t t0 = (int64_t)threadIdx.x * per, t1 = t0 + per < a.ntiles ? t0 + per : a.ntiles;
-    PlaceCM acc; acc.c = 0; acc.m = kPlaceNone;
+    PlaceCM acc = place_empty();
     for (int64_t t = t0; t < t1; ++t) { PlaceCM v; v.c = a.tiles[2 * t]; v.m = a.tiles[2 * t + 1]; acc = place_join(acc, v); }
     PlaceCM run = place_block_scan<1024>(acc, nullptr);
     for (int64_t t = t0; t < t1; ++t) {
@@ -758,17 +756,13 @@ __global__ __launch_bounds__(kBlock) void join_place_kernel(const JoinPlaceArgs 
     const uint64_t before = e0 == 0 ? (base > 0 ? a.rkeys[base - 1] : 0) : sk[(e0 - 1) + (e0 - 1) / kPer];
     const bool no_prev = e0 == 0 && base == 0;
     uint64_t prev = before;
-    PlaceCM loc; loc.c = 0; loc.m = kPlaceNone;
+    PlaceCM loc = place_empty();
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const int e = e0 + j;
         if (e >= n) break;
         const uint64_t h = sk[e + e / kPer];
-        if ((j == 0 && no_prev) || h != prev) {
-            const long long g = (long long)(h >> a.tshift) - loc.c;
-            loc.m = g > loc.m ? g : loc.m;
-            ++loc.c;
-        }
+        if ((j == 0 && no_prev) || h != prev) (void)place_push(loc, (long long)(h >> a.tshift));
         prev = h;
     }
     PlaceCM total;
@@ -780,9 +774,9 @@ __global__ __launch_bounds__(kBlock) void join_place_kernel(const JoinPlaceArgs 
     PlaceCM carry; carry.c = a.tiles[2 * blockIdx.x]; carry.m = a.tiles[2 * blockIdx.x + 1];
     // this tile owns the slots from the one behind the previous tiles' last key up to its own last key (the last tile: up to the end):
     // it writes the empty ones too, so nobody clears the table beforehand and every line leaves whole
-    const long long p0 = carry.c > 0 ? carry.c + carry.m : 0;
+    const long long p0 = place_last(carry) + 1;
     PlaceCM run = place_join(carry, ex);        // {distinct keys before this thread's rows, max(home - index) over them}: absolute
-    long long last = run.c > 0 ? run.c - 1 + run.m : -1;       // slot of the distinct key before this thread's rows
+    long long last = place_last(run);                          // slot of the distinct key before this thread's rows
     prev = before;
     bool too_far = false;
 #pragma unroll
@@ -792,10 +786,7 @@ __global__ __launch_bounds__(kBlock) void join_place_kernel(const JoinPlaceArgs 
         const uint64_t h = sk[e + e / kPer];
         uint32_t off = ~0u, gap = 0;
         if ((j == 0 && no_prev) || h != prev) {
-            const long long g = (long long)(h >> a.tshift) - run.c;
-            run.m = g > run.m ? g : run.m;
-            const long long pos = run.c + run.m;
-            ++run.c;
+            const long long pos = place_push(run, (long long)(h >> a.tshift));
             if (pos + 1 >= a.cap || pos - p0 >= 0xFFFFFFFFll) too_far = true;       // (the slot behind the last key stays empty: probes end there)
             else { off = (uint32_t)(pos - p0); gap = (uint32_t)(pos - last - 1); }
             last = pos;
@@ -829,7 +820,7 @@ __global__ __launch_bounds__(kBlock) void join_place_kernel(const JoinPlaceArgs 
         for (uint32_t g = 1, gap = sgap[e + e / kPer]; g <= gap; ++g) *(join_u64x2*)(a.table + 2 * (pos - g)) = zero;
     }
     if (blockIdx.x == gridDim.x - 1) {          // the slots behind the last key: empty up to the end of the table
-        const long long end_of_keys = total.c + carry.c > 0 ? place_join(carry, total).c - 1 + place_join(carry, total).m + 1 : 0;
+        const long long end_of_keys = place_last(place_join(carry, total)) + 1;
         for (long long q = end_of_keys + threadIdx.x; q < a.cap; q += kBlock) *(join_u64x2*)(a.table + 2 * q) = zero;
     }
 }

@@ -66,6 +66,15 @@ def test_sort_bucket_map_cpp():
     run(out)
 
 
+def test_join_place_cpp():
+    """The scan that lays out the equi-join's table of distinct build keys (csrc/rdf_join_place.h, the code the kernels run) on the CPU:
+    run summaries combine associatively, tiles cut any way place every key where sequential linear probing would, a probe walking from a
+    key's home slot meets no empty slot before the key."""
+    out = os.path.join(tempfile.gettempdir(), f"rdf_test_join_place_{os.getpid()}")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", os.path.join(ROOT, "tests", "cpp", "test_join_place.cpp"), "-o", out])
+    run(out)
+
+
 @pytest.mark.gpu
 def test_frame_mirror_cpp():
     run(build("test_frame", True), os.path.join(ROOT, "tests", "golden", "uk_cities_with_headers.csv"),
