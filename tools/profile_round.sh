@@ -94,6 +94,15 @@ for fc in "" 1; do RDF_BENCH_FUSED_COMBINE=$fc python "$REPO/bench.py" --rows 20
 python "$REPO/tools/bench_kernels.py" --rows 125000000 --steps 5 --only groupby_sum_1000000_groups,groupby_count_1000000_groups,groupby_max_1000000_groups,groupby_sum_1000000_groups_zipf,groupby_sum_1000000_groups_scattered_keys,groupby_sum_1000000_groups_hot_key_30pct 2>> "$OUT/kernels.err" | grep kernel_ms > "$OUT/groupby_1p25e8_rows.jsonl"
 RDF_LIB_PATH="$REPO/rust_dataframe_amd/librdf_base_r04.so" python "$REPO/tools/bench_kernels.py" --rows 125000000 --steps 5 --only groupby_sum_1000000_groups,groupby_count_1000000_groups 2>> "$OUT/kernels.err" | grep kernel_ms > "$OUT/groupby_1p25e8_rows_round4_build.jsonl"
 python "$REPO/tools/exp_gb_window.py" --windows 8,32,64,128,256 --reps 2 2>> "$OUT/kernels.err" > "$OUT/gb_window.jsonl"
+grep '"probe"' "$OUT/stream_sinks.err" | head -1 > "$OUT/link_probe.jsonl"       # each direction alone, both at once (bench_stream_sinks.py prints it first)
+# rdf_filter_frame on long batches: the one pass (look-back 3 = default, 1 = round 4's) against the three passes
+rm -f "$OUT/filter_frame_long_batches.jsonl"
+for cr in 16777216 1000000000; do for lb in 3 1; do
+    python "$REPO/tools/bench_frames.py" --rows 1000000000 --chunk-rows $cr --steps 5 --lookback $lb --fused 2 --only filter_frame 2>> "$OUT/frames.err" | grep kernel_ms | sed "s/^{/{\"chunk_rows\": $cr, \"lookback\": $lb, /" >> "$OUT/filter_frame_long_batches.jsonl"
+done; done
+# equi-join: the scan-placed table (default) against the compare-and-swap table
+python "$REPO/tools/bench_kernels.py" --rows 1000000000 --steps 3 --only join_inner_1e8_x_1e7,join_inner_1e8_x_1e7_cas_table,join_inner_1e8_x_1e8,join_inner_1e8_x_1e8_cas_table 2>> "$OUT/kernels.err" | grep kernel_ms > "$OUT/join_table_ab.jsonl"
+if [ -x "$REPO/tools/ubench_streams.bin" ]; then timeout 300 "$REPO/tools/ubench_streams.bin" > "$OUT/ubench_streams.txt" 2>&1; fi
 fi
 # 4. the scatter micro-benchmark behind the C4 bound
 if [ -x "$REPO/tools/ubench_scatter.bin" ]; then timeout 300 "$REPO/tools/ubench_scatter.bin" > "$OUT/ubench_scatter.txt" 2>&1; fi
