@@ -2978,7 +2978,7 @@ rdf_status os_scratch_alloc(int64_t n, OsScratch& o) {
 }
 rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* const idxb[2], const uint8_t* nullflags, int64_t n, uint64_t bias, int need,
                             bool null_pass, int& kcur, int& icur, const uint32_t*& idx_cur, uint64_t range = ~0ull /* max key - bias, when known */,
-                            int f64_keys = 0 /* 1: the keys are the bits of doubles (2: stored inverted, descending) */) {
+                            int f64_keys = 0 /* 1: the keys are the bits of doubles (2: stored inverted, descending); -1: of 4-byte floats */) {
     Ctx& ctx = g_ctx;
     if (need == 0 && !null_pass) return RDF_OK;
     if (ctx.opt_sort_gen == 2) {
@@ -3024,17 +3024,17 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
     // a third pass beyond with ~500 rows per bucket; value buckets of doubles: ~500 per bucket always (a bell-shaped column's
     // densest bucket holds 4-5 x the average; measured at 5e7 rows: 800 per bucket sorts uniform doubles in 3.20 instead of
     // 3.35 ms but sends normally distributed ones to the byte passes, 5.5 instead of 4.3 ms)
-    const int per_bucket = f64_keys ? 512 : 1800;
+    const int per_bucket = f64_keys > 0 ? 512 : 1800;
     int B = 12;
     bool sampled = false;                     // the bucket bits of a column of doubles were planned from a sample
     while ((n >> B) > 512 && B < 24) ++B;
-    if (!f64_keys) {
+    if (f64_keys <= 0) {
         int np = 1;
         while (np < 3 && (n >> (8 * np)) > per_bucket) ++np;
         B = std::max(12, std::min(B, 8 * np));
         if ((n >> B) > per_bucket) B = 24;      // (no pass count fits: the condition below fails)
     }
-    if (f64_keys && range != ~0ull) {
+    if (f64_keys > 0 && range != ~0ull) {
         // doubles: sign and exponent crowd the key bits' top patterns, so the buckets are cut in VALUE space (OsBucket)
         auto value_of = [&](uint64_t stored) { const uint64_t ord = f64_keys == 2 ? ~stored : stored; const uint64_t b = (ord >> 63) ? (ord ^ 0x8000000000000000ull) : ~ord; double x; memcpy(&x, &b, 8); return x; };
         const double x0 = value_of(bias), x1 = value_of(bias + range);
@@ -3088,7 +3088,10 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
             if (std::isfinite(lo) && std::isfinite(hi) && hi > lo && std::isfinite(scale)) { fb.lo = lo; fb.scale = scale; fb.bits = B; fb.flip = f64_keys == 2; }
         }
     }
-    if (ctx.opt_sort_msd && n >= 65536 && n < ((int64_t)1 << 32) && ((n >> B) <= per_bucket || (sampled && fb.bits)) && (sig + 7) / 8 >= (B + 7) / 8 + 2 && (fb.bits || sig - B <= 52)) {
+    // (f64_keys < 0: the bit patterns of 4-byte floats — sign and exponent crowd their top digit like a double's, the top-digit check below
+    // would send them to the byte passes after a histogram and a host round trip, 0.17 ms per 5e7 keys; four byte passes are what a
+    // value-bucket map would have to beat, and it would not: DESIGN.md 7.3)
+    if (ctx.opt_sort_msd && f64_keys >= 0 && n >= 65536 && n < ((int64_t)1 << 32) && ((n >> B) <= per_bucket || (sampled && fb.bits)) && (sig + 7) / 8 >= (B + 7) / 8 + 2 && (fb.bits || sig - B <= 52)) {
         const int R = fb.bits ? 0 : sig - B;
         const int npass = (B + 7) / 8;
         const int nbuckets = 1 << B;
@@ -3120,8 +3123,10 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
             }
             HIP_TRY(launch_os_hist(ha, ctx.stream));
             static const bool dbg = getenv("RDF_DEBUG_SORT") != nullptr;
-            {   // the top digit's counts tell crowded keys (floats of one sign and a few exponents, ...) before any pass is spent on
+            if (!(sampled && fb.bits)) {   // the top digit's counts tell crowded keys (floats of one sign and a few exponents, ...) before any pass is spent on
                 // them: a top-digit value held by more rows than its share of the buckets could take at kOsLocalMax rows each
+                // (a map planned from a sample of the keys has answered that already: no host round trip for it; a plan that
+                // misjudged the column is caught by the largest bucket below, two passes later)
                 int64_t top[257];
                 HIP_TRY(hipMemcpyAsync(top, o.hist + (npass - 1) * 256, 256 * 8, hipMemcpyDeviceToHost, ctx.stream));
                 HIP_TRY(hipStreamSynchronize(ctx.stream));
@@ -3251,7 +3256,7 @@ rdf_status sort_core(const DevChunkCol* d_chunks, const int64_t* d_row_start, in
         uint64_t kmax = 0;
         RDF_TRY(sort_key_range(d_stats, pin_off, &bias, &need, &kmax));
         if (k == 0 && idx_cur == nullptr && need == 0 && !has_nulls) need = 1;   // all keys equal: one pass still writes the identity order
-        if (gen2) { RDF_TRY(os_column_passes(os, keys, idxb, (const uint8_t*)pnf, n, bias, std::min(need, dtype_size(dt)), has_nulls, kcur, icur, idx_cur, kmax >= bias ? kmax - bias : ~0ull, dt == RDF_F64 ? (ka.descending ? 2 : 1) : 0)); continue; }
+        if (gen2) { RDF_TRY(os_column_passes(os, keys, idxb, (const uint8_t*)pnf, n, bias, std::min(need, dtype_size(dt)), has_nulls, kcur, icur, idx_cur, kmax >= bias ? kmax - bias : ~0ull, dt == RDF_F64 ? (ka.descending ? 2 : 1) : dt == RDF_F32 ? -1 : 0)); continue; }
         const int npass = dtype_size(dt) + (has_nulls ? 1 : 0);
         for (int p = 0; p < npass; ++p) {
             if (p < dtype_size(dt) && p >= need) continue;
