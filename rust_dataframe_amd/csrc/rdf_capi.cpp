@@ -103,6 +103,9 @@ struct Ctx {
     hipStream_t d2h_stream = nullptr;
     int64_t stream_slabs = 0, stream_bytes_staged = 0, stream_bytes_direct = 0;   // what the last rdf_pipeline call streamed
     bool in_stream = false;          // a streamed call is running its per-slab calls on this thread (they are not streamed again)
+    bool streaming = false;          // stream_run is active: slabs are in flight on the copy engines (frame_table_upload)
+    int  opt_stream_table_kernel = 1;   // 1 = while streaming, a frame's tables reach the device through a kernel instead of the copy engine (A/B: 0)
+    char* tab_pin = nullptr; size_t tab_pin_cap = 0, tab_pin_used = 0;   // page-locked ring the tables are staged in for that kernel
     ::rdf_comm* agg_comm = nullptr;   // rdf_pipeline_dist: the next aggregate's device-resident partials are all-gathered and folded on the device before the host reads anything
     ~Ctx();
 };
@@ -121,6 +124,7 @@ Ctx::~Ctx() {
     if (pinned) (void)hipHostFree(pinned);
     for (auto& kv : pool_free) (void)hipFree(kv.second);
     for (int b = 0; b < 2; ++b) { if (sbuf_dev[b]) (void)hipFree(sbuf_dev[b]); if (sbuf_pin[b]) (void)hipHostFree(sbuf_pin[b]); if (sbuf_ev[b]) (void)hipEventDestroy(sbuf_ev[b]); }
+    if (tab_pin) (void)hipHostFree(tab_pin);
     if (d2h_stream) (void)hipStreamSynchronize(d2h_stream);
     for (int b = 0; b < 2; ++b) { if (dbuf_dev[b]) (void)hipFree(dbuf_dev[b]); if (dbuf_pin[b]) (void)hipHostFree(dbuf_pin[b]); if (dbuf_ev[b]) (void)hipEventDestroy(dbuf_ev[b]); }
     if (d2h_stream) (void)hipStreamDestroy(d2h_stream);
@@ -173,6 +177,7 @@ rdf_status ensure_ready() {
     if (const char* e = getenv("RDF_SPEC_TILE_ROT")) c.opt_spec_tile_rot = atoi(e);
     if (const char* e = getenv("RDF_SPEC_XCD_SWZ")) c.opt_spec_xcd_swz = atoi(e);
     if (const char* e = getenv("RDF_SPEC_GRID_ADJ")) c.opt_spec_grid_adj = atoi(e);
+    if (const char* e = getenv("RDF_STREAM_TABLE_KERNEL")) c.opt_stream_table_kernel = atoi(e) != 0;
     if (const char* e = getenv("RDF_GSPEC_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 0 && v <= 8) c.opt_gspec_blocks = v; }
     c.ready = true;
     return RDF_OK;
@@ -1084,6 +1089,32 @@ rdf_status frame_table_alloc(rdf_frame& f, size_t bytes, void** out) {
     return RDF_OK;
 }
 
+// A frame's tables, host vectors -> HBM.  Plain frames: hipMemcpy.  Frames made per slab by the streamed batch loop: the copy engine is
+// busy with the next slab's 256 MiB for milliseconds and a hipMemcpy queues behind it — the tables are staged in a page-locked ring and
+// fetched by a kernel on the compute stream instead (rdf_set_option("stream_table_kernel", 0): A/B).
+rdf_status frame_table_upload(void* dst, const void* src, size_t bytes) {
+    Ctx& c = g_ctx;
+    if (bytes == 0) return RDF_OK;
+    constexpr size_t kRing = (size_t)32 << 20;
+    if (c.streaming && c.opt_stream_table_kernel && bytes <= kRing / 4) {
+        if (!c.tab_pin) {
+            void* p = nullptr;
+            hipError_t e = hipHostMalloc(&p, kRing, hipHostMallocDefault);
+            if (e != hipSuccess) return fail(RDF_MEMORY_ERROR, "hipHostMalloc(%zu) for the table ring failed: %s", kRing, hipGetErrorString(e));
+            c.tab_pin = (char*)p; c.tab_pin_cap = kRing; c.tab_pin_used = 0;
+        }
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (c.tab_pin_used + need > c.tab_pin_cap) { HIP_TRY(hipStreamSynchronize(c.stream)); c.tab_pin_used = 0; }     // the kernels that read the ring's old contents are done
+        char* pin = c.tab_pin + c.tab_pin_used;
+        c.tab_pin_used += need;
+        memcpy(pin, src, bytes);
+        HIP_TRY(launch_copy_small(pin, dst, bytes, c.stream));
+        return RDF_OK;
+    }
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return RDF_OK;
+}
+
 rdf_status frame_tiles(rdf_frame& f, int rows_per_tile, const rdf_frame::Tiles** out) {
     RDF_TRY(frame_host(f));
     auto it = f.tiles.find(rows_per_tile);
@@ -1096,7 +1127,7 @@ rdf_status frame_tiles(rdf_frame& f, int rows_per_tile, const rdf_frame::Tiles**
             t.tile_inv = (uint64_t)(((unsigned __int128)(uint64_t)(f.nchunks - 1) << 32) / (unsigned __int128)(uint64_t)ts[(size_t)f.nchunks - 1]);
         void* p = nullptr;
         RDF_TRY(frame_table_alloc(f, ts.size() * 8 + 64, &p));
-        HIP_TRY(hipMemcpy(p, ts.data(), ts.size() * 8, hipMemcpyHostToDevice));
+        RDF_TRY(frame_table_upload(p, ts.data(), ts.size() * 8));
         t.d_start = (int64_t*)p;
         it = f.tiles.emplace(rows_per_tile, t).first;
     }
@@ -1112,7 +1143,7 @@ rdf_status frame_col_tab(rdf_frame& f, const int* col_map, int n, DevChunkCol** 
         for (int k = 0; k < n; ++k) memcpy(tab.data() + (size_t)k * (size_t)f.nchunks, f.dev.data() + (size_t)col_map[k] * (size_t)f.nchunks, sizeof(DevChunkCol) * (size_t)f.nchunks);
         void* p = nullptr;
         RDF_TRY(frame_table_alloc(f, tab.size() * sizeof(DevChunkCol) + 64, &p));
-        HIP_TRY(hipMemcpy(p, tab.data(), tab.size() * sizeof(DevChunkCol), hipMemcpyHostToDevice));
+        RDF_TRY(frame_table_upload(p, tab.data(), tab.size() * sizeof(DevChunkCol)));
         it = f.col_tabs.emplace(key, (DevChunkCol*)p).first;
     }
     *out = it->second;
@@ -2121,9 +2152,8 @@ rdf_status rdf_frame_pin(const rdf_array* cols, int32_t ncols, int64_t nchunks, 
     f->d_cols = (DevChunkCol*)p;
     if (frame_table_alloc(*f, f->clen.size() * 8 + 64, &p) != RDF_OK) { undo(); return RDF_MEMORY_ERROR; }
     f->d_clen = (int64_t*)p;
-    hipError_t e = hipMemcpy(f->d_cols, f->dev.data(), f->dev.size() * sizeof(DevChunkCol), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(f->d_clen, f->clen.data(), f->clen.size() * 8, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { undo(); return fail(RDF_DEVICE_ERROR, "frame_pin: %s", hipGetErrorString(e)); }
+    if (frame_table_upload(f->d_cols, f->dev.data(), f->dev.size() * sizeof(DevChunkCol)) != RDF_OK ||
+        frame_table_upload(f->d_clen, f->clen.data(), f->clen.size() * 8) != RDF_OK) { undo(); return RDF_DEVICE_ERROR; }
     *out = f.release();
     return RDF_OK;
 }
@@ -4122,6 +4152,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "sort_gen") == 0) g_ctx.opt_sort_gen = (int)value;
     else if (strcmp(name, "sort_msd") == 0) g_ctx.opt_sort_msd = (int)value;
     else if (strcmp(name, "sort_sample") == 0) g_ctx.opt_sort_sample = (int)value;
+    else if (strcmp(name, "stream_table_kernel") == 0) g_ctx.opt_stream_table_kernel = value != 0;
     else if (strcmp(name, "join_table") == 0) g_ctx.opt_join_table = value < 0 || value > 2 ? 2 : (int)value;
     else if (strcmp(name, "jit") == 0) g_ctx.opt_jit = (int)value;
     else if (strcmp(name, "gb_skew_plan") == 0) g_ctx.opt_gb_skew_plan = (int)value;

@@ -720,6 +720,7 @@ hipError_t launch_sort_keys(const SortKeyArgs& a, hipStream_t s);
 hipError_t launch_sort_hist(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_sort_scatter(const SortPassArgs& a, hipStream_t s);
 hipError_t launch_join_buckets(const JoinBucketArgs& a, hipStream_t s);
+hipError_t launch_copy_small(const void* src_pinned, void* dst_dev, size_t bytes, hipStream_t s);   // src: page-locked, device-mapped host memory
 hipError_t launch_join_table(const JoinTableArgs& a, hipStream_t s);
 hipError_t launch_join_place(JoinPlaceArgs a, hipStream_t s);     // the three phases
 constexpr int kJoinPlaceTile = 2048;

@@ -1898,6 +1898,24 @@ static int rows_grid(int64_t n) {
     if (g > eval_grid_limit()) g = eval_grid_limit();
     return g < 1 ? 1 : (int)g;
 }
+// A few KB ... MB of tables out of page-locked host memory, fetched by a kernel over the link instead of queued on a copy engine: while
+// the streamed batch loop has a slab's upload in flight, a host-to-device copy — hipMemcpy most of all — waits behind it in the
+// engine's queue (measured: rdf_frame_pin took 3 ms per slab, most of a slab's upload time, for 1.5 KB of tables).
+__global__ __launch_bounds__(kBlock) void copy_small_kernel(const uint8_t* src, uint8_t* dst, size_t bytes) {
+    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x, nt = (size_t)gridDim.x * kBlock;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 7) == 0) {
+        const size_t nw = bytes >> 3;
+        for (size_t i = tid; i < nw; i += nt) ((uint64_t*)dst)[i] = ((const uint64_t*)src)[i];
+        for (size_t i = (nw << 3) + tid; i < bytes; i += nt) dst[i] = src[i];
+    } else for (size_t i = tid; i < bytes; i += nt) dst[i] = src[i];
+}
+hipError_t launch_copy_small(const void* src_pinned, void* dst_dev, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    size_t g = (bytes / 8 + kBlock - 1) / kBlock;
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(copy_small_kernel, dim3((unsigned)(g < 1 ? 1 : g)), dim3(kBlock), 0, s, (const uint8_t*)src_pinned, (uint8_t*)dst_dev, bytes);
+    return hipGetLastError();
+}
 hipError_t launch_join_buckets(const JoinBucketArgs& a, hipStream_t s) {
     if (a.nrv > 0) hipLaunchKernelGGL(join_buckets_kernel, dim3(rows_grid(a.nrv)), dim3(kBlock), 0, s, a);
     return hipGetLastError();

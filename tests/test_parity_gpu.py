@@ -995,7 +995,10 @@ def test_run_time_compiler_in_the_background_then_swapped_in(gpu, ora, request, 
             check(name, gpu.pipeline(e, cols, [v], p)[0], exps[name])
             interpreted += lib.last_kernel().startswith("eval_kernel<")
         first_pass = time.perf_counter() - t0
-        assert interpreted >= len(progs) - 2, f"{interpreted} of {len(progs)} first calls interpreted"   # (a code object already in the cache directory loads at once)
+        # (a code object already in the cache directory loads at once; under RDF_TEST_JIT=1 the tests before this one have compiled
+        # some of these shapes into the session's cache, so "first meeting" is not what the count can hold them to there)
+        if os.environ.get("RDF_TEST_JIT") != "1":
+            assert interpreted >= len(progs) - 2, f"{interpreted} of {len(progs)} first calls interpreted"
         lib.set_option("jit", 2)                     # now wait for each kernel: it was compiled meanwhile, or is finished here
         for name, v, p in progs:
             check(name + " compiled", gpu.pipeline(e, cols, [v], p)[0], exps[name])
@@ -1005,7 +1008,10 @@ def test_run_time_compiler_in_the_background_then_swapped_in(gpu, ora, request, 
             gpu.pipeline(e, cols, [v], p)
             assert lib.last_kernel().endswith("[compiled at run time]"), name
         st = lib.jit_status()
-        assert "0 failed" in st and "0 in progress" in st, st
+        import re
+        failed = lambda text: int(re.search(r"(\d+) failed", text).group(1))
+        # (none of THESE thirty failed to compile; under RDF_TEST_JIT=1 earlier tests have met shapes the kernel template refuses by design)
+        assert failed(st) == failed(before) and "0 in progress" in st, (before, st)
         print(f"{len(progs)} shapes: first pass (interpreted) {first_pass:.2f} s, all compiled after {time.perf_counter() - t0:.2f} s; {st}")
     finally:
         lib.set_option("jit", 0)
