@@ -193,6 +193,40 @@ def test_frame_entry_points_validate_before_the_device():
     assert so.rdf_frame_release(None) == A.RDF_OK      # releasing nothing is not an error (Drop of a frame that was never pinned)
 
 
+def test_round5_entry_points_validate_before_the_device():
+    """rdf_filter_pipeline (host-resident batches only, an expression, outputs) and rdf_pipeline_dist / rdf_pipeline_frame_dist (a live
+    communicator, an aggregating program, a frame) answer bad arguments with RDF_INVALID_ARGUMENT and a message — no device needed."""
+    so = lib.load()
+    e = A.Expr()
+    root = e.op("gt", e.col(0), e.scalar(0.5))
+    nodes = e.c_array()
+    so.rdf_filter_pipeline.restype = C.c_int
+    col = A.HostArray.from_numpy(np.arange(8.0))
+    arr = (A.rdf_array * 1)(col.c_struct())
+    out = (A.rdf_out * 1)()
+    # no expression / root out of range / no columns / no outputs
+    assert so.rdf_filter_pipeline(None, C.c_int32(0), C.c_int32(0), arr, C.c_int32(1), C.c_int64(1), out) == A.RDF_INVALID_ARGUMENT
+    assert so.rdf_filter_pipeline(nodes, C.c_int32(len(e.nodes)), C.c_int32(len(e.nodes)), arr, C.c_int32(1), C.c_int64(1), out) == A.RDF_INVALID_ARGUMENT
+    assert so.rdf_filter_pipeline(nodes, C.c_int32(len(e.nodes)), C.c_int32(root), None, C.c_int32(1), C.c_int64(1), out) == A.RDF_INVALID_ARGUMENT
+    assert so.rdf_filter_pipeline(nodes, C.c_int32(len(e.nodes)), C.c_int32(root), arr, C.c_int32(1), C.c_int64(1), None) == A.RDF_INVALID_ARGUMENT
+    assert so.rdf_filter_pipeline(nodes, C.c_int32(len(e.nodes)), C.c_int32(root), arr, C.c_int32(0), C.c_int64(1), out) == A.RDF_INVALID_ARGUMENT
+    # a device-resident batch belongs to rdf_filter_frame
+    dev = (A.rdf_array * 1)(col.c_struct())
+    dev[0].mem = A.MEM_DEVICE
+    assert so.rdf_filter_pipeline(nodes, C.c_int32(len(e.nodes)), C.c_int32(root), dev, C.c_int32(1), C.c_int64(1), out) == A.RDF_INVALID_ARGUMENT
+    assert b"rdf_filter_frame" in so.rdf_last_error()
+    # zero batches: nothing to do, not an error
+    assert so.rdf_filter_pipeline(nodes, C.c_int32(len(e.nodes)), C.c_int32(root), None, C.c_int32(1), C.c_int64(0), None) == A.RDF_OK
+    c0 = e.col(0)
+    prog = A.rdf_program(C.cast(nodes, C.POINTER(A.rdf_expr_node)), len(e.nodes), -1, 1, (C.c_int32 * A.MAX_VALUES)(c0), A.SINK_AGG)
+    aggs = (A.rdf_agg_result * A.MAX_VALUES)()
+    so.rdf_pipeline_dist.restype = C.c_int
+    so.rdf_pipeline_frame_dist.restype = C.c_int
+    assert so.rdf_pipeline_dist(None, C.byref(prog), arr, C.c_int32(1), C.c_int64(1), aggs) == A.RDF_INVALID_ARGUMENT
+    assert b"null communicator" in so.rdf_last_error()
+    assert so.rdf_pipeline_frame_dist(None, C.byref(prog), None, aggs) == A.RDF_INVALID_ARGUMENT
+
+
 @pytest.mark.skipif(lib.device_count() > 0, reason="a GPU is visible")
 def test_no_gpu_means_loud_device_error_not_a_fallback():
     api = lib.api()
