@@ -178,7 +178,12 @@ struct Prog {
 #ifndef RDF_SPEC_R8_WIDE
 #define RDF_SPEC_R8_WIDE 1
 #endif
-    static constexpr int R = (W == 1 && !bool_store()) ? 16 : (NC <= 2 || W == 2 || (W == 4 && NC == 3 && SINK_ == SINK_AGG) || (RDF_SPEC_R8_WIDE && W == 8 && NC <= 4 && SINK_ == SINK_AGG)) ? 8 : 4;   // Int8 / UInt8: a 16-byte vector is 16 rows
+#ifndef RDF_SPEC_R4_ONECOL
+#define RDF_SPEC_R4_ONECOL 0        // A/B: one-column aggregates of 8-byte values with 4 rows (two 16-byte vectors) per lane and iteration instead of 8
+                                    // (measured, same box: 0.80 of peak at 3 resident blocks per CU, 0.855-0.859 at 4 + XCD swizzle, 0.62 at 2, against 0.859-0.862
+                                    // for 8 rows at 2 blocks: profiles/r05_headline_4_rows_per_lane_ab_box22.jsonl)
+#endif
+    static constexpr int R = (W == 1 && !bool_store()) ? 16 : (RDF_SPEC_R4_ONECOL && W == 8 && NC == 1 && SINK_ == SINK_AGG) ? 4 : (NC <= 2 || W == 2 || (W == 4 && NC == 3 && SINK_ == SINK_AGG) || (RDF_SPEC_R8_WIDE && W == 8 && NC <= 4 && SINK_ == SINK_AGG)) ? 8 : 4;   // Int8 / UInt8: a 16-byte vector is 16 rows
     static constexpr int U = R / RV;                  // 16-byte vectors per lane per column per iteration
     // A/B (round 5): the NEXT tile's column loads are issued before the current tile is folded (aggregates over <= 32 VGPRs of
     // column data per tile: the bytes a wave has in flight no longer drop to zero while it computes)
