@@ -1,0 +1,503 @@
+// rdf_bfilter.hip — order-preserving compaction of LONG batches in one pass, block tiles held in registers
+// (DataFrame::filter, src/dataframe.rs:178-189, = BooleanFilter::eval_to_array, src/expression.rs:766-861, + Column::filter on
+// every column, src/table.rs:97-107,213-215; and Column::filter with a mask that is given).
+//
+// Why a second kernel next to rdf_filter.hip: there a tile is one WAVE's 1024 rows, which is right for the readers' 1024-row
+// RecordBatches (a batch is a tile, nothing to add up) — but a batch of 1e9 rows is a million tiles whose offsets depend on
+// each other, and every hop of that dependency is a memory round trip during which the wave moves no data (round 5: 3.8 ms per
+// 1e9 rows against 2.5 ms for the same rows in 1024-row batches).  Here (tools/ubench_compact.hip is the probe this design was
+// measured with before it was built):
+//
+//   * a tile is a BLOCK's rows: 8 waves x G x 64 sixteen-byte vectors per column (8192 rows of an 8-byte column at G = 8) —
+//     8 times fewer participants in the prefix, one count exchange in LDS per tile;
+//   * the rows stay in REGISTERS (G vectors per lane), the kept ones are staged in LDS at their rank and leave as aligned
+//     16-byte stores; the predicate column of tile n + 1 is in flight while tile n is staged and stored;
+//   * the prefix is not looked back for: every tile publishes its row count, ONE wave of the grid (block 0) turns counts into
+//     prefixes in tile order with DPP scans, a tile polls its own 8-byte word.  Two hops instead of a walk over the window of
+//     tiles in flight — and the count of tile n + 1 goes out a whole iteration BEFORE its prefix is asked for (while tile n
+//     is being staged and stored), so the hops are not waited for.
+//
+// Measured by the probe, 1e9 f64 rows, x > 0.5, one batch: 2.02 ms (0.74 of the 8 TB/s peak on 12 GB of algorithmic traffic) with
+// the prefix found this way, against 2.18 ms on the same box with the offsets handed in from a scan computed beforehand.
+#include "rdf_common.hip.h"
+#include "rdf_lanewin.hip.h"
+
+namespace rdfk {
+
+namespace {
+
+constexpr int kBfWaves = 8, kBfBlock = kBfWaves * 64;
+constexpr unsigned long long kBfCount = 1ull << 62, kBfPrefix = 2ull << 62, kBfValue = (1ull << 62) - 1;
+
+__device__ __forceinline__ unsigned long long bf_ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void bf_st(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int mbcnt64(uint64_t m, int init) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, init)); }
+
+// inclusive scan over the 64 lanes: four row shifts inside the rows of 16, two row broadcasts across them (gfx9 DPP)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// The scanner: tile_state[t] goes  0 -> kBfCount | rows (written by the tile's block) -> kBfPrefix | rows of the FRAME in front of
+// tile t (written here).  Counts are taken as far as they have been published without a gap, up to 512 tiles per round trip.
+__device__ __forceinline__ void bf_scanner(unsigned long long* state, int64_t ntiles) {
+    const int lane = threadIdx.x & 63;
+    constexpr int K = 8;
+    int64_t cur = 0;
+    unsigned long long running = 0;
+    while (cur < ntiles) {
+        unsigned long long w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int64_t idx = cur + k * 64 + lane;
+            w[k] = idx < ntiles ? bf_ld(state + idx) : 0;
+        }
+        int64_t base = cur;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint64_t ready = __ballot((w[k] >> 62) != 0);
+            const int f = ready == ~0ull ? 64 : __builtin_ctzll(~ready);
+            if (f == 0) break;
+            const int val = lane < f ? (int)(w[k] & kBfValue) : 0;
+            const int inc = wave_incl_scan(val);
+            if (lane < f) bf_st(state + base + lane, kBfPrefix | (running + (unsigned long long)(inc - val)));
+            running += (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(inc, 63);
+            base += f;
+            if (f < 64) break;
+        }
+        if (base == cur) __builtin_amdgcn_s_sleep(1);
+        cur = base;
+    }
+}
+
+// E consecutive bits of a row-order bitmap window kept one word per lane (lane i = the wave's rows [64 i, 64 i + 64)): the bits of
+// rows g * 64 E + lane * E + [0, E) — the rows the lane holds in vector g of a column
+template <int E>
+__device__ __forceinline__ uint32_t lane_bits(uint64_t win, int g) {
+    const int lane = threadIdx.x & 63;
+    uint64_t w = rl64(win, g * E);
+#pragma unroll
+    for (int j = 1; j < E; ++j) { const uint64_t wj = rl64(win, g * E + j); if (((lane * E) >> 6) == j) w = wj; }
+    return (uint32_t)(w >> ((lane * E) & 63)) & ((1u << E) - 1);
+}
+
+template <typename T, int G, typename S, class Cmp>
+__device__ __forceinline__ void bf_cmp_fields(const typename Vec16<T>::type (&x)[G], double lit, uint32_t (&kf)[G], Cmp cmp) {
+    constexpr int E = 16 / (int)sizeof(T);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        uint32_t f = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const T raw = x[g][e];
+            const S v = __builtin_bit_cast(S, raw);
+            f |= (cmp((double)v, lit) ? 1u : 0u) << e;
+        }
+        kf[g] = f;
+    }
+}
+template <typename T, int G, typename S>
+__device__ __forceinline__ void bf_op_fields(const typename Vec16<T>::type (&x)[G], int op, double lit, uint32_t (&kf)[G]) {
+    switch (op) {      // wave-uniform: one scalar branch per tile, not one per element
+        case RDF_OP_GT: bf_cmp_fields<T, G, S>(x, lit, kf, [](double a, double c) { return a > c; }); break;
+        case RDF_OP_GE: bf_cmp_fields<T, G, S>(x, lit, kf, [](double a, double c) { return a >= c; }); break;
+        case RDF_OP_EQ: bf_cmp_fields<T, G, S>(x, lit, kf, [](double a, double c) { return a == c; }); break;
+        case RDF_OP_NE: bf_cmp_fields<T, G, S>(x, lit, kf, [](double a, double c) { return a != c; }); break;
+        case RDF_OP_LT: bf_cmp_fields<T, G, S>(x, lit, kf, [](double a, double c) { return a < c; }); break;
+        default: bf_cmp_fields<T, G, S>(x, lit, kf, [](double a, double c) { return a <= c; }); break;
+    }
+}
+// `column CMP literal`, both sides as f64 (src/expression.rs:844-845), on the registers of one tile: E result bits per vector.
+// Integer columns never convert: x -> (double)x is monotone, so `(double)x CMP literal` holds on an interval of x, which the host
+// has worked out (bf_term, rdf_capi_frame.inc) — two integer compares per element instead of an emulated i64 -> f64 conversion
+// (16 of them unrolled were what pushed this kernel past its 128 registers).
+template <typename T, int G>
+__device__ __forceinline__ void bf_term_fields(const BfTerm& tm, const typename Vec16<T>::type (&x)[G], uint32_t (&kf)[G]) {
+    constexpr int E = 16 / (int)sizeof(T);
+    if (tm.kind == 1) {
+        const T lo = (T)tm.lo, hi = (T)tm.hi, bias = (T)tm.bias;      // keep  <=>  lo <= (x ^ bias) <= hi  (unsigned), then inverted for `!=`
+        const uint32_t inv = tm.inv ? (1u << E) - 1 : 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            uint32_t f = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const T u = x[g][e] ^ bias;
+                f |= (u >= lo && u <= hi ? 1u : 0u) << e;
+            }
+            kf[g] = f ^ inv;
+        }
+    } else if constexpr (sizeof(T) == 8) bf_op_fields<T, G, double>(x, tm.op, tm.lit, kf);
+    else bf_op_fields<T, G, float>(x, tm.op, tm.lit, kf);
+}
+
+struct BfTile { int64_t tile, c, r0, clen, first; };
+
+}  // namespace
+
+// T: the columns' element as raw bits (uint64_t / uint32_t: all columns of a launch are equally wide); G: 16-byte vectors per lane
+// and column; MULTI: more than one column (a third register set carries the columns that follow the first); NULLS: some column,
+// or the mask, has a validity bitmap; BYMASK: Column::filter with the mask given, else the predicate is evaluated here.
+template <typename T, int G, bool MULTI, bool NULLS, bool BYMASK>
+__global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs a) {
+    constexpr int E = 16 / (int)sizeof(T), WR = G * 64 * E, TR = kBfWaves * WR, NWW = G * E;
+    static_assert(NWW <= 32, "one keep-word per lane, two words fetched per lane");
+    using V = typename Vec16<T>::type;
+    __shared__ __attribute__((aligned(16))) T stage[TR + E];
+    __shared__ uint8_t vstage[NULLS ? TR : 1];
+    __shared__ int wcnt[2][kBfWaves];
+    __shared__ int nullacc[kMaxFilterCols];
+    __shared__ int64_t sh_base, sh_tile[2];
+    const FilterWArgs& fa = a.w;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.x == 0) { if (wave == 0) bf_scanner(a.tile_state, fa.t.ntiles); return; }
+    const int64_t ntiles = fa.t.ntiles;
+    const bool one = fa.t.nchunks == 1;
+    const int ncols = fa.ncols;
+    constexpr bool by_mask = BYMASK;       // the kept rows are given by a mask (a.nterms == 0)
+    const int pc0 = by_mask ? 0 : a.bterm[0].col, pc1 = a.nterms > 1 ? a.bterm[1].col : pc0;
+    if (tid < kMaxFilterCols) nullacc[tid] = 0;
+
+    // tiles are handed out in order by `nclass` ticket counters (a single one would serialise every draw of the grid: 23 ns each);
+    // block b draws from counter (b - 1) mod nclass, which numbers the tiles  nclass * k + its own index
+    const int nclass = a.nclass, ctr = (int)((blockIdx.x - 1) % (unsigned)nclass);
+    auto draw = [&]() __attribute__((always_inline)) -> int64_t { return (int64_t)atomicAdd(a.ticket + ctr * 32, 1u) * nclass + ctr; };
+    auto locate = [&](int64_t tile) __attribute__((always_inline)) -> BfTile {
+        BfTile t;
+        t.tile = tile;
+        if (one) { t.c = 0; t.first = 0; t.r0 = tile * TR; t.clen = fa.len0; }
+        else {
+            const ConstPtr<int64_t> start = as_const<int64_t>(fa.t.chunk_tile_start);
+            t.c = find_chunk_tile_inv(start, fa.t.nchunks, tile, fa.tile_inv);
+            t.first = start[t.c];
+            t.r0 = (tile - t.first) * TR;
+            t.clen = as_const<int64_t>(fa.t.chunk_len)[t.c];
+        }
+        return t;
+    };
+    auto col_of = [&](int k, int64_t c) __attribute__((always_inline)) -> DevChunkCol { return one ? fa.cols0[k] : const_col(fa.cols, (int64_t)k * fa.t.nchunks + c); };
+    auto out_of = [&](int k, int64_t c) __attribute__((always_inline)) -> DevOutChunk {
+        if (one) return fa.outs0[k];
+        const ConstPtr<DevOutChunk> t = as_const<DevOutChunk>(fa.outs);
+        DevOutChunk o;
+        o.values = t[(int64_t)k * fa.t.nchunks + c].values; o.validity = t[(int64_t)k * fa.t.nchunks + c].validity;
+        return o;
+    };
+    // this wave's rows of a tile: [rw, rw + WR) of the chunk
+    auto wave_row = [&](const BfTile& t) __attribute__((always_inline)) -> int64_t { return t.r0 + (int64_t)wave * WR; };
+    // one column's vectors; SPARSE: only the 16-byte vectors that hold a wanted row (`need`: E-bit fields) are fetched
+    auto load_col = [&](const DevChunkCol& col, const BfTile& t, V (&x)[G], bool sparse, const uint32_t (&need)[G]) {
+        const int64_t rw = wave_row(t);
+        const GlobalPtr<T> src = as_global<T>(col.values) + col.offset + rw;
+        const bool fast = rw + WR <= t.clen && (((uintptr_t)(const void*)src) & 15) == 0;
+        const V zero = {};
+        if (fast) {
+            const GlobalPtr<V> p = (GlobalPtr<V>)src + lane;
+            if (sparse) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) { x[g] = zero; if (need[g]) x[g] = __builtin_nontemporal_load(p + g * 64); }
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; ++g) x[g] = __builtin_nontemporal_load(p + g * 64);
+            }
+        } else {
+            // the ragged end of a batch, a slice that is not 16-byte aligned: element by element
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int q = g * 64 * E + lane * E + e;
+                    x[g][e] = rw + q < t.clen ? src[q] : T(0);
+                }
+        }
+    };
+    auto win_issue = [&](const uint8_t* bitmap, int64_t offset, const BfTile& t) __attribute__((always_inline)) -> LaneWin<NWW> {
+        const int64_t rw = wave_row(t);
+        return lane_windows_issue<NWW>(bitmap, offset + rw, bitmap ? t.clen - rw : 0);
+    };
+    const uint32_t all_rows[G] = {};
+
+    // What the count of a tile needs, requested one iteration ahead: the first predicate column's vectors and its validity
+    // words (by_mask: the mask's value and validity words instead).
+    struct Pre { V y[G]; LaneWin<NWW> q0, q1; };
+    auto prefetch = [&](const BfTile& t, Pre& p) __attribute__((always_inline)) {
+        if (by_mask) {
+            const DevChunkCol m = one ? fa.mask0 : const_col(fa.t.mask, t.c);
+            p.q0 = win_issue((const uint8_t*)m.values, m.offset, t);
+            p.q1 = win_issue(m.validity, m.offset, t);
+        } else {
+            const DevChunkCol col = col_of(pc0, t.c);
+            load_col(col, t, p.y, false, all_rows);
+            if (NULLS) p.q0 = win_issue(col.validity, col.offset, t);
+        }
+    };
+    V U[MULTI ? G : 1];
+    // keep-words of the wave's rows in the REGISTER layout (word g * E + e, bit = lane: element e of vector g), one word per lane;
+    // the block's row count is published.
+    auto count_publish = [&](Pre& p, const BfTile& t, int par, uint64_t& km, int& wbase, int& bcnt) __attribute__((always_inline)) {
+        uint32_t kf[G];
+        if (by_mask) {
+            uint64_t keep = lane_windows_finish<NWW>(p.q0);                // rows past the end of the batch are already cleared
+            const DevChunkCol m = one ? fa.mask0 : const_col(fa.t.mask, t.c);
+            if (m.validity) keep &= lane_windows_finish<NWW>(p.q1);
+#pragma unroll
+            for (int g = 0; g < G; ++g) kf[g] = lane_bits<E>(keep, g);
+        } else {
+            bf_term_fields<T, G>(a.bterm[0], p.y, kf);
+            uint64_t vv = ~0ull;
+            bool anyv = false;
+            if (NULLS) {
+                const DevChunkCol c0 = col_of(pc0, t.c);
+                if (c0.validity) { vv &= lane_windows_finish<NWW>(p.q0); anyv = true; }
+            }
+            if (a.nterms > 1) {
+                uint32_t k1[G];
+                bool done = false;
+                if constexpr (MULTI) {
+                    if (pc1 != pc0) {
+                        const DevChunkCol c1 = col_of(pc1, t.c);
+                        load_col(c1, t, U, false, all_rows);
+                        if (NULLS && c1.validity) { vv &= lane_windows_finish<NWW>(win_issue(c1.validity, c1.offset, t)); anyv = true; }
+                        bf_term_fields<T, G>(a.bterm[1], U, k1);
+                        done = true;
+                    }
+                }
+                if (!done) bf_term_fields<T, G>(a.bterm[1], p.y, k1);
+                // Arrow's and / or: NULL where either side is NULL -> the row is dropped (the validity words are ANDed below)
+#pragma unroll
+                for (int g = 0; g < G; ++g) kf[g] = a.combine == RDF_OP_AND ? (kf[g] & k1[g]) : (kf[g] | k1[g]);
+            }
+            if (NULLS && anyv) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) kf[g] &= lane_bits<E>(vv, g);
+            }
+            const int64_t rw = wave_row(t);
+            if (rw + WR > t.clen) {        // a tile at the end of its batch: rows that do not exist
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    uint32_t f = 0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) f |= (rw + g * 64 * E + lane * E + e < t.clen ? 1u : 0u) << e;
+                    kf[g] &= f;
+                }
+            }
+        }
+        km = 0;
+        int cnt = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint64_t w = __ballot((kf[g] >> e) & 1);
+                if (lane == g * E + e) km = w;
+                cnt += __popcll(w);
+            }
+        if (lane == 0) wcnt[par][wave] = cnt;
+        __syncthreads();
+        wbase = 0; bcnt = 0;
+#pragma unroll
+        for (int w = 0; w < kBfWaves; ++w) { const int c = __builtin_amdgcn_readfirstlane(wcnt[par][w]); if (w < wave) wbase += c; bcnt += c; }
+        if (tid == 0) bf_st(a.tile_state + t.tile, kBfCount | (unsigned long long)bcnt);
+    };
+
+    if (tid == 0) { sh_tile[0] = draw(); sh_tile[1] = draw(); }
+    __syncthreads();
+    int64_t Tc = (int64_t)uniform64((uint64_t)sh_tile[0]), Tn = (int64_t)uniform64((uint64_t)sh_tile[1]);     // (block-uniform by construction: say so, or every address derived from them is per-lane arithmetic)
+    __syncthreads();
+    if (Tc >= ntiles) return;
+    BfTile tc = locate(Tc), tn = tc;
+    Pre PA, PB;
+    uint64_t km_c = 0, km_n = 0;
+    int wbase_c = 0, bcnt_c = 0, wbase_n = 0, bcnt_n = 0, par = 1;
+    int64_t cur_chunk = tc.c;
+    prefetch(tc, PA);
+    if (Tn < ntiles) { tn = locate(Tn); prefetch(tn, PB); }
+    count_publish(PA, tc, 0, km_c, wbase_c, bcnt_c);
+
+    auto flush_nulls = [&]() __attribute__((always_inline)) {      // (between two block barriers)
+        if (NULLS && tid < ncols && nullacc[tid]) {
+            atomicAdd((unsigned long long*)&fa.out_null_counts[(int64_t)tid * fa.t.nchunks + cur_chunk], (unsigned long long)nullacc[tid]);
+            nullacc[tid] = 0;
+        }
+    };
+
+    // One iteration.  X: the current tile's prefetched registers (counted, the count published one iteration ago), Y: the next tile's.
+    auto step = [&](Pre& X, Pre& Y) __attribute__((always_inline)) -> bool {
+        int64_t drawn = 0;
+        if (tid == 0) drawn = draw();                    // the tile after the next: the atomic returns under everything below
+        // a. the next tile: count, publish
+        if (Tn < ntiles) count_publish(Y, tn, par, km_n, wbase_n, bcnt_n);
+        else __syncthreads();                            // (the staging buffer, sh_base and nullacc are reused below)
+        par ^= 1;
+        if (tc.c != cur_chunk) { flush_nulls(); cur_chunk = tc.c; }
+        // b. rows of the batch in front of the current tile
+        if (tid == 0) {
+            int64_t base = 0;               // a batch's first tile starts the batch's output
+            if (tc.first != Tc) {
+                unsigned long long w;
+                for (;;) { w = bf_ld(a.tile_state + Tc); if ((w >> 62) == 2) break; __builtin_amdgcn_s_sleep(2); }
+                base = (int64_t)(w & kBfValue);
+                // the scanner's prefixes count the rows of the FRAME: take off what lies in front of the batch (its first tile was
+                // passed before this one)
+                for (;;) { w = bf_ld(a.tile_state + tc.first); if ((w >> 62) == 2) break; __builtin_amdgcn_s_sleep(2); }
+                base -= (int64_t)(w & kBfValue);
+            }
+            sh_base = base;
+            sh_tile[par] = drawn;
+        }
+        // c. every column: stage at the ranks, store
+        uint64_t B[G][E];
+        uint32_t need[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            need[g] = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { B[g][e] = rl64(km_c, g * E + e); need[g] |= (uint32_t)((B[g][e] >> lane) & 1) << e; }
+        }
+        const bool sparse = bcnt_c * 8 < TR;
+        // one column's registers (and, NULLS, its validity bits) to the staging buffer, at the ranks of the kept rows
+        auto stage_col = [&](const V (&x)[G], bool has_validity, const LaneWin<NWW>& q) {
+            uint64_t vw = 0;
+            if (NULLS && has_validity) vw = lane_windows_finish<NWW>(q);
+            int base = wbase_c;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                int r = base;
+#pragma unroll
+                for (int e = 0; e < E; ++e) r = mbcnt64(B[g][e], r);
+                uint32_t vb = (1u << E) - 1;
+                if (NULLS && has_validity) vb = lane_bits<E>(vw, g);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((need[g] >> e) & 1) {
+                        stage[r] = x[g][e];
+                        if (NULLS) vstage[r] = (uint8_t)((vb >> e) & 1);
+                        ++r;
+                    }
+                    base += __popcll(B[g][e]);
+                }
+            }
+        };
+        // the staged run [0, bcnt_c) -> rows [tbase, tbase + bcnt_c) of the batch's output: aligned 16-byte stores
+        auto store_col = [&](int k, const DevOutChunk& oc, int64_t tbase, bool has_validity) __attribute__((always_inline)) {
+            const GlobalMutPtr<T> o = as_global_mut<T>(oc.values) + tbase;
+            int head = (int)(((16 - (((uintptr_t)oc.values + (uintptr_t)tbase * sizeof(T)) & 15)) & 15) / sizeof(T));   // elements in front of the first aligned vector
+            if (head > bcnt_c) head = bcnt_c;
+            if (tid < head) o[tid] = stage[tid];
+            const int nv = (bcnt_c - head) / E;
+            for (int q = tid; q < nv; q += kBfBlock) {
+                const int i0 = head + q * E;
+                V x;
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[e] = stage[i0 + e];
+                __builtin_nontemporal_store(x, (GlobalMutPtr<V>)(o + i0));
+            }
+            const int tail0 = head + nv * E;
+            if (tid < bcnt_c - tail0) o[tail0 + tid] = stage[tail0 + tid];
+            if (NULLS && oc.validity) {
+                // out bits [tbase, tbase + bcnt_c): 64 aligned positions per wave step; the run's first and last word are shared with
+                // the neighbouring tiles (the bitmap is pre-zeroed)
+                const int64_t end = tbase + bcnt_c, w0 = tbase >> 6, w1 = (end + 63) >> 6;
+                int nn = 0;
+                for (int64_t wq = w0 + wave; wq < w1; wq += kBfWaves) {
+                    const int64_t pos = wq * 64 + lane;
+                    const bool inside = pos >= tbase && pos < end;
+                    const bool bitv = inside && (!has_validity || vstage[inside ? pos - tbase : 0]);
+                    const uint64_t word = __ballot(bitv), inw = __ballot(inside);
+                    if (lane == 0) {
+                        if (inw == ~0ull) ((GlobalMutPtr<uint64_t>)(void*)oc.validity)[wq] = word;
+                        else if (word) atomicOr((unsigned long long*)oc.validity + wq, (unsigned long long)word);
+                        nn += __popcll(inw & ~word);
+                    }
+                }
+                if (lane == 0 && nn) atomicAdd(&nullacc[k], nn);
+            }
+        };
+        // column kk of the loop is frame column col_at(kk): the first predicate column comes first (its vectors are in X.y)
+        auto col_at = [&](int kk) __attribute__((always_inline)) -> int { return by_mask ? kk : (kk == 0 ? pc0 : (kk <= pc0 ? kk - 1 : kk)); };
+        DevChunkCol col = col_of(col_at(0), tc.c);
+        LaneWin<NWW> qx = X.q0, qu = X.q0;
+        if (by_mask) {
+            load_col(col, tc, X.y, sparse, need);
+            if (NULLS) qx = win_issue(col.validity, col.offset, tc);
+        }
+        int64_t tbase = 0, Tnn = 0;
+        if constexpr (!MULTI) {
+            stage_col(X.y, col.validity != nullptr, qx);
+            __syncthreads();
+            tbase = (int64_t)uniform64((uint64_t)sh_base); Tnn = (int64_t)uniform64((uint64_t)sh_tile[par]);
+            store_col(col_at(0), out_of(col_at(0), tc.c), tbase, col.validity != nullptr);
+        } else {
+            // two register sets take turns: while column kk is staged and stored, column kk + 1 is in flight
+#pragma unroll 1
+            for (int kk = 0; kk < ncols; kk += 2) {
+                DevChunkCol col1 = col;
+                if (kk + 1 < ncols) {
+                    col1 = col_of(col_at(kk + 1), tc.c);
+                    load_col(col1, tc, U, sparse, need);
+                    if (NULLS) qu = win_issue(col1.validity, col1.offset, tc);
+                }
+                if (kk > 0) __syncthreads();               // the previous column has left the staging buffer
+                stage_col(X.y, col.validity != nullptr, qx);
+                __syncthreads();
+                if (kk == 0) { tbase = (int64_t)uniform64((uint64_t)sh_base); Tnn = (int64_t)uniform64((uint64_t)sh_tile[par]); }
+                store_col(col_at(kk), out_of(col_at(kk), tc.c), tbase, col.validity != nullptr);
+                if (kk + 1 < ncols) {
+                    if (kk + 2 < ncols) {
+                        col = col_of(col_at(kk + 2), tc.c);
+                        load_col(col, tc, X.y, sparse, need);
+                        if (NULLS) qx = win_issue(col.validity, col.offset, tc);
+                    }
+                    __syncthreads();
+                    stage_col(U, col1.validity != nullptr, qu);
+                    __syncthreads();
+                    store_col(col_at(kk + 1), out_of(col_at(kk + 1), tc.c), tbase, col1.validity != nullptr);
+                }
+            }
+        }
+        if (tid == 0 && a.out_len && tc.r0 + TR >= tc.clen) a.out_len[tc.c] = tbase + bcnt_c;      // the batch's last tile
+        // the tile after the next: its registers are the ones the current tile has left
+        BfTile tnn = tn;
+        if (Tnn < ntiles) { tnn = locate(Tnn); prefetch(tnn, X); }
+        tc = tn; Tc = Tn; tn = tnn; Tn = Tnn;
+        km_c = km_n; wbase_c = wbase_n; bcnt_c = bcnt_n;
+        return Tc < ntiles;
+    };
+    for (;;) {
+        if (!step(PA, PB)) break;
+        if (!step(PB, PA)) break;
+    }
+    __syncthreads();
+    flush_nulls();
+}
+
+int bfilter_tile_rows(int esize, int ncols) {
+    const int E = 16 / esize;
+    const int G = esize == 8 ? (ncols > 1 ? 4 : 8) : (ncols > 1 ? 2 : 4);      // (launch_bfilter's choice)
+    return kBfWaves * G * 64 * E;
+}
+
+hipError_t launch_bfilter(const BFilterArgs& a, int esize, bool nulls, hipStream_t s) {
+    if (a.w.t.ntiles <= 0) return hipSuccess;
+    const bool multi = a.w.ncols > 1, by_mask = a.nterms == 0;
+    const dim3 grid((unsigned)(a.nworkers + 1)), block(kBfBlock);
+#define RDF_BF_LAUNCH2(T, G, MULTI, NULLS) \
+    do { if (by_mask) hipLaunchKernelGGL((bfilter_kernel<T, G, MULTI, NULLS, true>), grid, block, 0, s, a); \
+         else hipLaunchKernelGGL((bfilter_kernel<T, G, MULTI, NULLS, false>), grid, block, 0, s, a); } while (0)
+#define RDF_BF_LAUNCH(T, G, MULTI) \
+    do { if (nulls) RDF_BF_LAUNCH2(T, G, MULTI, true); else RDF_BF_LAUNCH2(T, G, MULTI, false); } while (0)
+    if (esize == 8) { if (multi) RDF_BF_LAUNCH(uint64_t, 4, true); else RDF_BF_LAUNCH(uint64_t, 8, false); }
+    else if (multi) RDF_BF_LAUNCH(uint32_t, 2, true);       // (four rows per vector: twice the keep-words per vector of an 8-byte column)
+    else RDF_BF_LAUNCH(uint32_t, 4, false);
+#undef RDF_BF_LAUNCH
+#undef RDF_BF_LAUNCH2
+    return hipGetLastError();
+}
+
+}  // namespace rdfk

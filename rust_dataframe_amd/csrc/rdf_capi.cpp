@@ -58,6 +58,8 @@ struct Ctx {
     bool   opt_vec_bitmap = false; // validity words of the specialised kernels: scalar loads (default since the wave-granular tiles: 1.30 vs 1.355 ms on the 1e9-row filter->sum with nulls) or one vector load by lanes 0..NW + readlane (A/B; it was the faster one with block-wide tiles)
     bool   opt_filter_one = true;   // one-chunk compaction kernel with its descriptors in the kernel arguments (A/B)
     int    opt_filter_gen = 2;      // compaction kernels: 2 = wave-granular tiles (rdf_filter.hip, default), 1 = first-generation block tiles (A/B)
+    int    opt_filter_block = 1;    // one-pass compaction of LONG batches on block tiles held in registers, prefixes from a scanner wave (rdf_bfilter.hip, round 6; default); 0 = the wave-tile kernels only (A/B)
+    int    opt_filter_block_rows = 32768;   // ... for frames whose mean batch length is at least this many rows
     int    opt_filter_fused = 1;    // rdf_filter_frame: `col CMP literal [AND|OR col CMP literal]` predicates evaluated inside the compaction kernel, one pass (1, default); 0 = predicate -> mask, count, compact (A/B)
     int    opt_filter_lookback = 3; // one-pass rdf_filter_frame, batches longer than a tile: 3 = a super-tile's first tile finds the rows in front of the super-tile for all 64, from the nearest super-tiles' tile counts and the older ones' totals (default); 2 = from totals only; 1 = every tile walks the totals (round 4; batches of at most 1024 tiles) — A/B
     int    opt_filter_tile = 0;     // 0: compaction tile chosen from the mean chunk length; 1024 / 4096 force one (A/B)
@@ -4166,6 +4168,8 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "gspec_blocks_per_cu") == 0) g_ctx.opt_gspec_blocks = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
+    else if (strcmp(name, "filter_block") == 0) g_ctx.opt_filter_block = value != 0;
+    else if (strcmp(name, "filter_block_rows") == 0) g_ctx.opt_filter_block_rows = value < 1 ? 1 : (int)value;
     else if (strcmp(name, "filter_lookback") == 0) g_ctx.opt_filter_lookback = value == 1 ? 1 : value == 2 ? 2 : 3;
     else if (strcmp(name, "comm_max_bytes") == 0) g_ctx.opt_comm_max_bytes = value;
     else if (strcmp(name, "stream_slab_bytes") == 0) g_ctx.opt_stream_slab = value;

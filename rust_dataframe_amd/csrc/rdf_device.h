@@ -215,6 +215,27 @@ struct FusedFilterArgs {
     unsigned int*       ticket;              // (lookback; pre-zeroed) 64 counters, 128 bytes apart
 };
 hipError_t launch_ffilter(const FusedFilterArgs& a, hipStream_t s);
+// The same operators on LONG batches (rdf_bfilter.hip): a tile is a BLOCK's rows held in registers, every tile publishes its row
+// count one iteration before it asks for its offset, and one wave of the grid (block 0) turns counts into prefixes — no walk over
+// the window of tiles in flight.  All columns of a launch are equally wide (8 or 4 bytes).
+// `column CMP literal` as the block kernel evaluates it: float columns compare (double)x with the literal; for integer columns the
+// host has turned the comparison into the interval of x on which `(double)x CMP literal` holds (x -> (double)x is monotone)
+struct BfTerm {
+    int32_t  col, kind, op, inv;      // kind 0: float compare `op` against lit; 1: keep <=> lo <= (x ^ bias) <= hi as unsigned, inverted if inv
+    double   lit;
+    uint64_t lo, hi, bias;
+};
+struct BFilterArgs {
+    FilterWArgs         w;            // tables over tiles of bfilter_tile_rows() rows; t.mask / mask0 used when nterms == 0; tile_scan unused
+    BfTerm              bterm[2];
+    int32_t             nterms, combine;     // nterms == 0: the kept rows are given by a mask (Column::filter); else `term[0] [combine term[1]]`
+    int32_t             nclass, nworkers;    // ticket counters in use (min(64, nworkers)), worker blocks (the grid is nworkers + 1: block 0 scans)
+    int64_t*            out_len;             // [nchunks] kept rows per batch (pre-zeroed), or nullptr
+    unsigned long long* tile_state;          // (pre-zeroed) [ntiles]: 0 -> count -> prefix
+    unsigned int*       ticket;              // (pre-zeroed) 64 counters, 128 bytes apart
+};
+int bfilter_tile_rows(int esize, int ncols);
+hipError_t launch_bfilter(const BFilterArgs& a, int esize, bool nulls, hipStream_t s);
 hipError_t launch_fcount(const FilterWArgs& a, int tile_rows, int64_t* tile_counts, hipStream_t s);
 hipError_t launch_fcompact(const FilterWArgs& a, int tile_rows, hipStream_t s);
 hipError_t launch_mask_count_one(const DevChunkCol& mask, int64_t clen, int64_t ntiles, int64_t* tile_counts, hipStream_t s);

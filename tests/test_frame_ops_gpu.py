@@ -447,15 +447,82 @@ def test_filter_frame_one_pass_on_long_batches(gpu, ora, lens, nf):
         try:
             for name, root in preds.items():
                 exp = ora.filter_columns(host, ora.predicate(e, root, host))
-                for fused, lookback in ((1, 3), (1, 2), (2, 1), (0, 3)):
+                for fused, lookback, block in ((1, 3, 1), (1, 3, 0), (1, 2, 0), (2, 1, 0), (0, 3, 1)):
                     lib.set_option("filter_fused", fused)
                     lib.set_option("filter_lookback", lookback)
+                    lib.set_option("filter_block", block)      # round 6: block tiles + scanner wave (the default for batches this long)
                     out = gpu.filter_frame(frame, e, root)
-                    assert (lib.last_kernel() == "ffilter_dma_kernel") == (fused != 0), (name, fused, lookback, lib.last_kernel())
+                    want_kernel = "bfilter_kernel" if fused and block else "ffilter_dma_kernel" if fused else None
+                    assert want_kernel is None or lib.last_kernel() == want_kernel, (name, fused, lookback, block, lib.last_kernel())
+                    assert fused or lib.last_kernel() not in ("bfilter_kernel", "ffilter_dma_kernel")
                     got = frame_columns(out)
                     for k in range(len(dts)):
-                        match_unknown_nulls(got[k], exp[k], f"{name} fused={fused} lookback={lookback} column {k}")
+                        match_unknown_nulls(got[k], exp[k], f"{name} fused={fused} lookback={lookback} block={block} column {k}")
                     out.release()
         finally:
             lib.set_option("filter_fused", 1)
             lib.set_option("filter_lookback", 3)
+            lib.set_option("filter_block", 1)
+
+
+BLOCK_LAYOUTS = [([200_000], 0, 0.1), ([70_000, 1024, 3000, 0, 50_000], 0, 0.0), ([8192 * 3], 0, 0.2), ([8191, 8193, 16384 + 7, 1], 5, 0.1),
+                 ([1_500_000, 700_001], 3, 0.05), ([40_000] * 7, 1, 0.0)]
+
+
+@pytest.mark.parametrize("lens,off,nf", BLOCK_LAYOUTS)
+@pytest.mark.parametrize("dts", [[A.F64], [A.I64, A.F64, A.U64], [A.F32, A.I32, A.U32], [A.U32], [A.I64] * 8])
+def test_filter_frame_block_tiles(gpu, ora, lens, off, nf, dts):
+    """Round 6: DataFrame::filter of long batches on BLOCK tiles held in registers (rdf_bfilter.hip) — counts published one iteration
+    ahead, prefixes from the scanner wave.  `filter_block_rows` = 1 sends every layout there: batches that are not multiples of a
+    tile, a batch shorter than a tile, an empty batch, slices that are not 16-byte aligned (element-wise loads), validity bitmaps
+    at odd bit offsets, 8- and 4-byte columns, up to 8 columns.  Integer columns are compared through the interval of x on which
+    `(double)x CMP literal` holds (no conversion on the device): the literals sit where that matters (beyond 2^53, at the type's
+    ends, fractional, NaN).  Held to the oracle's eval_to_array + Column::filter per column, bit for bit."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(6006 + len(lens) + len(dts))
+    host = []
+    for k, dt in enumerate(dts):
+        kind = "special" if dt in (A.F64, A.F32) and k == 0 and sum(lens) > 100_000 else "unit" if dt in (A.F64, A.F32) else "extreme" if k % 2 == 0 else "plain"
+        host.append(make_chunks(rng, dt, lens, nf if k < 3 else 0.0, off, kind))
+    dev, keep = to_device(host)
+    e = A.Expr()
+    d0 = dts[0]
+    is_f = d0 in (A.F64, A.F32)
+    wide = d0 in (A.I64, A.U64)
+    preds = {}
+    if is_f:
+        preds["gt"] = e.op("gt", e.col(0), e.scalar(0.25))
+        preds["le literal first"] = e.op("ge", e.scalar(-0.5), e.col(0))
+        preds["ne"] = e.op("ne", e.col(0), e.scalar(1.0))
+        preds["nan literal"] = e.op("lt", e.col(0), e.scalar(float("nan")))
+        preds["keeps almost nothing"] = e.op("gt", e.col(0), e.scalar(0.999))
+        preds["keeps everything"] = e.op("le", e.col(0), e.scalar(float("inf")))
+    else:
+        big = float(2 ** 62) if wide else float(2 ** 30)
+        preds["gt 0"] = e.op("gt", e.col(0), e.scalar(0, A.I64))
+        preds["ge fractional"] = e.op("ge", e.col(0), e.scalar(-0.5))
+        preds["lt beyond 2^53"] = e.op("lt", e.col(0), e.scalar(big + 1.0))
+        preds["le at the rounding edge"] = e.op("le", e.col(0), e.scalar(float(2 ** 53 + 2) if wide else float(2 ** 24 + 1)))
+        preds["eq"] = e.op("eq", e.col(0), e.scalar(float(np.iinfo(A.NP_OF[d0]).max)))
+        preds["ne"] = e.op("ne", e.col(0), e.scalar(float(np.iinfo(A.NP_OF[d0]).min)))
+        preds["nan literal ne"] = e.op("ne", e.col(0), e.scalar(float("nan")))
+        preds["keeps almost nothing"] = e.op("gt", e.col(0), e.scalar(big))
+    if len(dts) > 1:
+        preds["and over two columns"] = e.op("and", preds[next(iter(preds))], e.op("lt", e.col(1), e.scalar(0.3)))
+        preds["or over two columns"] = e.op("or", e.op("gt", e.col(len(dts) - 1), e.scalar(0.9)), e.op("le", e.col(1), e.scalar(-0.7)))
+        preds["range on the last column"] = e.op("and", e.op("gt", e.col(len(dts) - 1), e.scalar(-0.5)), e.op("lt", e.col(len(dts) - 1), e.scalar(500.0)))
+    with A.PinnedFrame(gpu, dev) as frame:
+        try:
+            lib.set_option("filter_block_rows", 1)
+            for name, root in preds.items():
+                exp = ora.filter_columns(host, ora.predicate(e, root, host))
+                out = gpu.filter_frame(frame, e, root)
+                assert lib.last_kernel() == "bfilter_kernel", (name, lib.last_kernel())
+                nc, nch, rows = out.info()
+                assert (nc, nch) == (len(dts), len(lens)) and rows == sum(x.length for x in exp[0]), (name, rows)
+                got = frame_columns(out)
+                for k in range(len(dts)):
+                    match_unknown_nulls(got[k], exp[k], f"{name} lens={lens} column {k}")
+                out.release()
+        finally:
+            lib.set_option("filter_block_rows", 32768)

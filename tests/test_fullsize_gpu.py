@@ -455,7 +455,9 @@ def test_groupby_agg_frame_1e9_rows_in_1024_row_batches(gpu):
 
 
 def test_filter_frame_1e9_rows_one_batch(gpu):
-    """ONE RecordBatch of 1e9 rows = 976 563 tiles in 15 259 super-tiles of one look-back chain (round 5: walked once per super-tile)."""
+    """ONE RecordBatch of 1e9 rows: 244 141 block tiles of 4096 rows (two columns), their prefixes from the scanner wave
+    (rdf_bfilter.hip, round 6; round 5: 976 563 wave tiles in 15 259 super-tiles of one look-back chain) — same rows, same order
+    as the three-pass path."""
     import torch
     from rust_dataframe_amd import lib
     x, k = _dev(N, 0, A.F64, -1.0, 1.0), _dev(N, 3, A.I64, -2 ** 31, 2 ** 31)
@@ -470,7 +472,7 @@ def test_filter_frame_1e9_rows_one_batch(gpu):
         for fused in (1, 0):
             lib.set_option("filter_fused", fused)
             out = gpu.filter_frame(fr, e, gt)
-            assert (lib.last_kernel() == "ffilter_dma_kernel") == bool(fused), lib.last_kernel()
+            assert (lib.last_kernel() == "bfilter_kernel") == bool(fused), lib.last_kernel()      # round 6: block tiles + scanner wave
             assert out.info() == (2, 1, want[0].count)
             _same_aggs(gpu.pipeline(e, out, vals), want, f"one batch, fused={fused}")
             # order is kept: the first kept rows are the first rows of x that pass

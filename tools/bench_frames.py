@@ -75,12 +75,17 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--fused", type=int, default=1, help="rdf_set_option(\"filter_fused\") of the filter_frame_* entries: 2 forces the one-pass kernel on batches of any length")
     ap.add_argument("--lookback", type=int, default=3, help="rdf_set_option(\"filter_lookback\"): 3 = a super-tile's first tile finds the rows in front of it from tile counts + older totals (default), 2 = from totals only, 1 = every tile walks the totals (round 4)")
+    ap.add_argument("--block", type=int, default=1, help="rdf_set_option(\"filter_block\"): 1 = long batches on block tiles with a scanner wave (rdf_bfilter.hip, round 6, default), 0 = wave tiles + look-back (round 5)")
+    ap.add_argument("--block-rows", type=int, default=0, help="rdf_set_option(\"filter_block_rows\"): the mean batch length from which the block kernel is taken (0: the library's default)")
     args = ap.parse_args()
     n, cr = args.rows, args.chunk_rows
     only = set(filter(None, args.only.split(",")))
     lib.set_device(0)
     api = lib.api()
     lib.set_option("filter_lookback", args.lookback)
+    lib.set_option("filter_block", args.block)
+    if args.block_rows > 0:
+        lib.set_option("filter_block_rows", args.block_rows)
 
     def timed(fn, steps, warmup=2):
         torch.cuda.synchronize()
@@ -103,7 +108,7 @@ def main():
         wall, kern = timed(fn, args.steps)
         gbs = alg_bytes / kern / 1e9 if kern > 0 else 0.0
         r = {"kernel": name, "rows": rows, "batches": (rows + cr - 1) // cr, "alg_bytes": alg_bytes, "wall_ms": round(wall * 1e3, 3), "kernel_ms": round(kern * 1e3, 3),
-             "wall_over_kernel": round(wall / kern, 3) if kern > 0 else None, "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 3), **extra}
+             "wall_over_kernel": round(wall / kern, 3) if kern > 0 else None, "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 3), "last_kernel": lib.last_kernel(), **extra}
         print(json.dumps(r), flush=True)
 
     x, y, z = fill_f64(n, 0), fill_f64(n, 1), fill_f64(n, 2)
