@@ -2238,6 +2238,22 @@ rdf_status rdf_predicate_frame(const rdf_expr_node* nodes, int32_t nnodes, int32
 
 namespace {
 
+// tile states and ticket counters of one launch_bfilter (arena), the grid: two blocks of 8 waves per CU draw tiles by ticket
+rdf_status bfilter_scratch(BFilterArgs& ba) {
+    Ctx& ctx = g_ctx;
+    const int64_t ntiles = ba.w.t.ntiles;
+    const int64_t cap = (int64_t)(eval_grid_limit() / 8) * 2;
+    ba.nworkers = (int32_t)std::max<int64_t>(1, std::min<int64_t>(cap, ntiles));
+    ba.nclass = std::min(64, ba.nworkers);
+    void* ps = nullptr;
+    const size_t words = (size_t)ntiles + 8 + 64 * 16;
+    RDF_TRY(arena_alloc(sizeof(unsigned long long) * words, &ps));
+    HIP_TRY(hipMemsetAsync(ps, 0, sizeof(unsigned long long) * words, ctx.stream));
+    ba.tile_state = (unsigned long long*)ps;
+    ba.ticket = (unsigned int*)((unsigned long long*)ps + (size_t)ntiles + 8);
+    return RDF_OK;
+}
+
 struct FilterPrep {
     InputStager in;         // mask chunks first, then the columns
     TableBuilder tb;
@@ -2311,7 +2327,7 @@ rdf_status filter_tiles(FilterPrep& fp, int tile_rows, int64_t nchunks, std::vec
 
 // Stage mask (+ columns), build the descriptor tables, pick the compaction kernels and their tile size, count + scan.
 rdf_status filter_prepare(FilterPrep& fp, const rdf_array* cols, int ncols, const rdf_array* mask, int64_t nchunks,
-                          std::vector<int64_t>& totals) {
+                          std::vector<int64_t>& totals, bool count = true) {
     Ctx& ctx = g_ctx;
     for (int64_t c = 0; c < nchunks; ++c) fp.in.add(&mask[c]);
     for (int64_t i = 0; i < (int64_t)ncols * nchunks; ++i) fp.in.add(&cols[i]);
@@ -2354,6 +2370,7 @@ rdf_status filter_prepare(FilterPrep& fp, const rdf_array* cols, int ncols, cons
     fp.mt.mask = fp.tb.dev_at<DevChunkCol>(o_mask);
     fp.mt.chunk_len = fp.tb.dev_at<int64_t>(o_len);
     fp.mt.nchunks = nchunks;
+    if (!count) return RDF_OK;          // (the one-pass block kernel: staged inputs and descriptor tables only)
     RDF_TRY(filter_tiles(fp, tile_rows, nchunks, totals));
     if (fp.tile_rows == kWDmaTile) {
         // the LDS-DMA kernel fetches every sector of a tile: a selective filter (< 1/8 of the rows kept) goes to the
@@ -2380,6 +2397,96 @@ rdf_status filter_validate(const rdf_array* cols, int ncols, const rdf_array* ma
     return RDF_OK;
 }
 
+
+// Column::filter (src/table.rs:97-107,213-215) with the mask given, device-resident, in one pass on block tiles: groups of up to
+// kMaxFilterCols columns per launch; lengths and null counts come back from the kernel.
+rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols, const rdf_array* mask, int64_t nchunks, rdf_out* outs, int es0) {
+    Ctx& ctx = g_ctx;
+    std::vector<int64_t> unused;
+    RDF_TRY(filter_prepare(fp, cols, ncols, mask, nchunks, unused, false));
+    const size_t nout = (size_t)ncols * (size_t)nchunks;
+    std::vector<DevOutChunk> dev_outs(nout);
+    bool nulls = false;
+    for (int64_t c = 0; c < nchunks; ++c) nulls |= mask[c].validity != nullptr;
+    for (size_t i = 0; i < nout; ++i) {
+        dev_outs[i] = DevOutChunk{outs[i].values, cols[i].validity ? outs[i].validity : nullptr};
+        nulls |= cols[i].validity != nullptr;
+        const int64_t n = mask[i % (size_t)nchunks].length;           // an upper bound of the rows kept: the bitmap words they can touch
+        if (dev_outs[i].validity && n > 0) HIP_TRY(hipMemsetAsync(dev_outs[i].validity, 0, (size_t)((n + 63) / 64 * 8), ctx.stream));
+    }
+    void* p = nullptr;
+    RDF_TRY(arena_alloc(sizeof(int64_t) * (nout + (size_t)nchunks) + 64, &p));
+    int64_t* d_nullc = (int64_t*)p;
+    int64_t* d_len = d_nullc + nout;
+    HIP_TRY(hipMemsetAsync(d_nullc, 0, sizeof(int64_t) * (nout + (size_t)nchunks), ctx.stream));
+    RDF_TRY(pinned_reserve(fp.pin_off + sizeof(DevOutChunk) * nout + 256));
+    memcpy(ctx.pinned + fp.pin_off, dev_outs.data(), sizeof(DevOutChunk) * nout);
+    HIP_TRY(hipMemcpyAsync(fp.tb.dev + fp.o_outs, ctx.pinned + fp.pin_off, sizeof(DevOutChunk) * nout, hipMemcpyHostToDevice, ctx.stream));
+    fp.pin_off += (sizeof(DevOutChunk) * nout + 255) & ~(size_t)255;
+    {
+        KernelTimer kt;
+        int table_rows = 0;
+        const int64_t* d_tile_start = nullptr;
+        int64_t ntiles = 0;
+        uint64_t tile_inv = 0;
+        for (int g = 0; g < ncols; g += kMaxFilterCols) {
+            const int nc = ncols - g < kMaxFilterCols ? ncols - g : kMaxFilterCols;
+            const int tr = bfilter_tile_rows(es0, nc);
+            if (tr != table_rows) {           // (a last group of one column has longer tiles than the groups before it)
+                std::vector<int64_t> ts((size_t)nchunks + 1, 0);
+                for (int64_t c = 0; c < nchunks; ++c) ts[(size_t)c + 1] = ts[(size_t)c] + (fp.clen[(size_t)c] + tr - 1) / tr;
+                ntiles = ts[(size_t)nchunks];
+                tile_inv = 0;
+                if (nchunks > 1 && ts[(size_t)nchunks - 1] > 0 && nchunks - 1 < ((int64_t)1 << 31))
+                    tile_inv = (uint64_t)(((unsigned __int128)(uint64_t)(nchunks - 1) << 32) / (unsigned __int128)(uint64_t)ts[(size_t)nchunks - 1]);
+                void* pts = nullptr;
+                const size_t ts_bytes = sizeof(int64_t) * ts.size();
+                RDF_TRY(arena_alloc(ts_bytes, &pts));
+                RDF_TRY(pinned_reserve(fp.pin_off + ts_bytes + 256));
+                memcpy(ctx.pinned + fp.pin_off, ts.data(), ts_bytes);
+                HIP_TRY(hipMemcpyAsync(pts, ctx.pinned + fp.pin_off, ts_bytes, hipMemcpyHostToDevice, ctx.stream));
+                fp.pin_off += (ts_bytes + 255) & ~(size_t)255;
+                d_tile_start = (const int64_t*)pts;
+                table_rows = tr;
+            }
+            BFilterArgs ba;
+            memset(&ba, 0, sizeof ba);
+            FilterWArgs& wa = ba.w;
+            wa.t = fp.mt;
+            wa.t.chunk_tile_start = d_tile_start;
+            wa.t.ntiles = ntiles;
+            wa.tile_inv = tile_inv;
+            wa.cols = fp.tb.dev_at<DevChunkCol>(fp.o_cols) + (size_t)g * (size_t)nchunks;
+            wa.outs = fp.tb.dev_at<DevOutChunk>(fp.o_outs) + (size_t)g * (size_t)nchunks;
+            wa.out_null_counts = d_nullc + (size_t)g * (size_t)nchunks;
+            wa.ncols = nc;
+            if (nchunks == 1) { wa.mask0 = fp.in.dev[0]; wa.len0 = fp.clen[0]; }
+            for (int k = 0; k < nc; ++k) {
+                wa.esize[k] = es0;
+                if (nchunks == 1) { wa.cols0[k] = fp.in.dev[(size_t)(1 + g + k)]; wa.outs0[k] = dev_outs[(size_t)(g + k)]; }
+            }
+            ba.nterms = 0;
+            ba.out_len = d_len;
+            RDF_TRY(bfilter_scratch(ba));
+            HIP_TRY(launch_bfilter(ba, es0, nulls, ctx.stream));
+        }
+        kt.stop();
+    }
+    ctx.last_kernel = "bfilter_kernel";
+    RDF_TRY(pinned_reserve(fp.pin_off + 8 * (nout + (size_t)nchunks) + 256));
+    int64_t* pin = (int64_t*)(ctx.pinned + fp.pin_off);
+    HIP_TRY(hipMemcpyAsync(pin, d_nullc, 8 * (nout + (size_t)nchunks), hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    const int64_t* len = pin + nout;
+    for (size_t i = 0; i < nout; ++i) {
+        const int64_t n = len[i % (size_t)nchunks];
+        outs[i].length = n;
+        outs[i].null_count = cols[i].validity ? pin[i] : 0;
+        if (!cols[i].validity && outs[i].validity && n > 0) HIP_TRY(hipMemsetAsync(outs[i].validity, 0xFF, (size_t)((n + 7) / 8), ctx.stream));   // no input bitmap: everything kept is valid
+    }
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    return RDF_OK;
+}
 }  // namespace
 
 rdf_status rdf_filter_count(const rdf_array* mask, int64_t nchunks, int64_t* counts) {
@@ -2416,6 +2523,20 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
     arena_begin();
     FilterPrep fp;
     std::vector<int64_t> totals;
+    // Long device-resident chunks of equally wide columns whose outputs can hold every row: ONE pass on block tiles (rdf_bfilter.hip)
+    // — no count pass, no scan: a tile's offset comes from the scanner wave.  (An output sized by rdf_filter_count keeps the
+    // count -> scan -> compact path: its capacity has to be checked before anything is written.)
+    {
+        int es0 = dtype_size(cols[0].dtype);
+        bool roomy = mem == RDF_MEM_DEVICE && (es0 == 8 || es0 == 4) && ctx.opt_filter_block != 0;
+        int64_t rows_total = 0;
+        for (int64_t c = 0; c < nchunks; ++c) rows_total += mask[c].length;
+        for (int k = 0; k < ncols && roomy; ++k) {
+            roomy = dtype_size(cols[(int64_t)k * nchunks].dtype) == es0;
+            for (int64_t c = 0; c < nchunks && roomy; ++c) roomy = outs[(int64_t)k * nchunks + c].capacity >= mask[c].length;
+        }
+        if (roomy && rows_total >= nchunks * (int64_t)ctx.opt_filter_block_rows) return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0);
+    }
     RDF_TRY(filter_prepare(fp, cols, ncols, mask, nchunks, totals));
     for (int k = 0; k < ncols; ++k)
         for (int64_t c = 0; c < nchunks; ++c)
@@ -2506,6 +2627,7 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
         }
         kt.stop();
     }
+    ctx.last_kernel = fp.wave ? (fp.tile_rows == kWDmaTile ? "fcompact_dma_kernel" : "fcompact_kernel") : "compact_kernel";
     RDF_TRY(pinned_reserve(fp.pin_off + 8 * nout + 256 + outr.small_bytes + 256));
     int64_t* pin_nc = (int64_t*)(ctx.pinned + fp.pin_off);
     HIP_TRY(hipMemcpyAsync(pin_nc, d_nullc, 8 * nout, hipMemcpyDeviceToHost, ctx.stream));

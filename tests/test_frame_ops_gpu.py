@@ -526,3 +526,68 @@ def test_filter_frame_block_tiles(gpu, ora, lens, off, nf, dts):
                 out.release()
         finally:
             lib.set_option("filter_block_rows", 32768)
+
+
+@pytest.mark.parametrize("lens,off,nf", BLOCK_LAYOUTS)
+@pytest.mark.parametrize("dts", [[A.F64], [A.I64, A.F64], [A.F32, A.I32, A.U32], [A.I64] * 11])
+def test_filter_columns_device_block_tiles(gpu, ora, lens, off, nf, dts):
+    """Column::filter (src/table.rs:97-107,213-215) with the mask GIVEN, device-resident, outputs that can hold every row: one pass on
+    block tiles (rdf_bfilter.hip, mask form) — no count pass, lengths and null counts come back from the kernel.  Nullable masks at
+    odd bit offsets, nullable columns, 11 columns (a launch of 8 and one of 3), 4-byte columns; a second call with outputs sized by
+    rdf_filter_count takes the count -> scan -> compact path and must give the same bytes."""
+    import torch
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(6100 + len(lens) + len(dts))
+    host = [make_chunks(rng, dt, lens, nf if k % 2 == 0 else 0.0, (off + k) % 7, "extreme" if dt not in (A.F64, A.F32) else "unit") for k, dt in enumerate(dts)]
+    for sel in (0.5, 0.01, 1.0):
+        mask = [A.HostArray.from_numpy(rng.uniform(size=n) < sel, valid=(rng.uniform(size=n) > 0.1) if nf else None, offset=(off * 3) % 11, dtype=A.BOOL, rng=rng)
+                for n in lens]
+        exp = ora.filter_columns(host, mask)
+        dev, keep = to_device(host)
+        dmask, keep2 = to_device([mask])
+
+        def outputs(rows):
+            bufs, outs = [], []
+            for k, dt in enumerate(dts):
+                es = np.dtype(A.NP_OF[dt]).itemsize
+                col = []
+                for c, n in enumerate(rows):
+                    vb = torch.full((n * es + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+                    bb = torch.full(((n + 63) // 64 * 8 + 64,), 0xAB, dtype=torch.uint8, device="cuda") if host[k][c].validity is not None else None
+                    bufs.append((vb, bb))
+                    col.append(A.DeviceArray(vb.data_ptr(), bb.data_ptr() if bb is not None else None, 0, 0, dt, 0, keep=(vb, bb), capacity=n))
+                outs.append(col)
+            torch.cuda.synchronize()
+            return bufs, outs
+
+        def check(bufs, outs, what):
+            lib.synchronize()
+            i = 0
+            for k, dt in enumerate(dts):
+                es = np.dtype(A.NP_OF[dt]).itemsize
+                for c in range(len(lens)):
+                    ee, o, (vb, bb) = exp[k][c], outs[k][c], bufs[i]
+                    i += 1
+                    assert o.length == ee.length and o.null_count == ee.null_count, (what, k, c, o.length, ee.length, o.null_count, ee.null_count)
+                    gv = vb.cpu().numpy()[:ee.length * es].view(A.NP_OF[dt])
+                    m = ee.valid_mask()
+                    if bb is not None:
+                        gm = np.unpackbits(bb.cpu().numpy()[:(ee.length + 7) // 8], bitorder="little")[:ee.length].astype(bool)
+                        assert np.array_equal(gm, m), (what, k, c)
+                    assert np.array_equal(gv[m].view(np.uint8), ee.to_numpy()[m].view(np.uint8)), (what, k, c)
+
+        try:
+            lib.set_option("filter_block_rows", 1)
+            bufs, outs = outputs(lens)
+            gpu.filter_columns(dev, dmask[0], outs)
+            assert lib.last_kernel() == "bfilter_kernel", lib.last_kernel()
+            check(bufs, outs, f"one pass sel={sel}")
+            counts = gpu.filter_count(dmask[0])
+            assert counts == [x.length for x in exp[0]]
+            if any(c < n for c, n in zip(counts, lens)):
+                bufs, outs = outputs(counts)               # a two-phase caller's outputs: too small to skip the count
+                gpu.filter_columns(dev, dmask[0], outs)
+                assert lib.last_kernel() != "bfilter_kernel", lib.last_kernel()
+                check(bufs, outs, f"counted sel={sel}")
+        finally:
+            lib.set_option("filter_block_rows", 32768)
