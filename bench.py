@@ -44,6 +44,31 @@ SEED = 42
 CHECK_ROWS = 2_000_000  # prefix every --workload is checked on against the oracle
 
 
+KERNEL_SOURCES = ("rdf_spec_kernel.hip.h", "rdf_spec.hip", "rdf_common.hip.h", "rdf_expr.hip.h", "rdf_gspec_kernel.hip.h", "rdf_groupby.hip", "rdf_eval.hip")
+
+
+def kernel_sources_sha():
+    """sha256 over the sources of the kernels whose HBM traffic profiles/hbm_traffic.json holds: a traffic figure measured on other
+    sources is not reported (tools/collect_profiles.py writes the same stamp next to the figures)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "rust_dataframe_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _traffic_current(tj):
+    """-> (ok, note): the committed traffic figures belong to the kernels of this tree."""
+    try:
+        stamp, mine = tj.get("kernel_sources_sha"), kernel_sources_sha()
+    except Exception as ex_:
+        return False, f"kernel sources not readable ({ex_})"
+    if stamp != mine:
+        return False, f"profiles/hbm_traffic.json was measured on other kernel sources (stamp {stamp}, this tree {mine}): not reported — re-run tools/profile_round.sh"
+    return True, None
+
+
 def _median_time(fn, runs=5, warm=1):
     for _ in range(warm):
         fn()
@@ -353,6 +378,70 @@ def workload_q1(torch, lib, api, A, sharding, dev, comm_dev, rank, rows, first, 
 WORKLOADS = {"c3": workload_c3, "c4": workload_c4, "q1": workload_q1}
 
 
+def run_ref_bench(args, lib, api, A):
+    """The reference's ONLY benchmark shape (`bench_multiply_i32`, src/functions/scalar.rs:621-671): par_multiply::<Int32Type> over
+    380 chunks of 5 values [None, 200, None, -256, None] on both sides — 1900 rows in 380 arrays, the launch-latency regime in
+    which a device path is expected to LOSE to the host: which is why it is timed here, end to end (host buffers in, host buffers
+    out through rdf_binary) next to the oracle's restatement of the same call on one core.  The descriptor arrays are built once, as a
+    caller that holds its arrays has them; every call is checked against the known answer [None, 40000, None, 65536, None]."""
+    import ctypes as C
+    import numpy as np
+    from oracle import oracle
+    o = oracle.api()
+    n = 380
+    vals = np.array([0, 200, 0, -256, 0], dtype=np.int32)
+    valid = np.array([False, True, False, True, False])
+    a = [A.HostArray.from_numpy(vals.copy(), valid=valid, dtype=A.I32) for _ in range(n)]
+    ca, cb = A._flat([a], n), A._flat([a], n)
+    want = np.array([200 * 200, 65536], dtype=np.int32)
+
+    def caller(x):
+        outs = [A.HostArray.empty_out(A.I32, 5, True) for _ in range(n)]
+        carr = (A.rdf_out * n)(*[q.out_struct() for q in outs])
+        fn = x._fn("binary")
+        code = C.c_int32(A.OP_NAMES["multiply"])
+        return outs, carr, (lambda: x._check(fn(code, ca, cb, C.c_int64(n), carr)))
+
+    def ok(outs, carr):
+        for i, q in enumerate(outs):
+            q.length, q.null_count = carr[i].length, carr[i].null_count
+            m = q.valid_mask()
+            if q.length != 5 or q.null_count != 3 or list(m) != list(valid) or not np.array_equal(q.to_numpy()[m], want):
+                return False
+        return True
+
+    calls = max(1000, args.steps)
+    res = {}
+    for name, x in (("gpu", api), ("cpu", o)):
+        outs, carr, call = caller(x)
+        for _ in range(max(20, args.warmup)):
+            call()
+        ts = []
+        t_all = time.perf_counter()
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            call()
+            ts.append(time.perf_counter() - t0)
+        t_all = time.perf_counter() - t_all
+        res[name] = {"median_us": statistics.median(ts) * 1e6, "mean_us": t_all / calls * 1e6, "min_us": min(ts) * 1e6,
+                     "p99_us": sorted(ts)[int(0.99 * (calls - 1))] * 1e6, "parity": bool(ok(outs, carr))}
+    g, c_ = res["gpu"], res["cpu"]
+    line = {"metric": "calls/s par_multiply::<Int32Type>, 380 chunks x 5 values (the reference's bench_multiply_i32)", "value": 1e6 / g["median_us"], "unit": "calls/s",
+            "n_gpus": 1, "steps": calls, "warmup": max(20, args.warmup), "ms_per_step": g["median_us"] * 1e-3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i32", "data": "the reference's own vector",
+            "config": {"workload": "rdf_binary(MULTIPLY, Int32) over 380 host-resident chunks of [None, 200, None, -256, None] on both sides, host buffers in, host buffers out "
+                                   "(src/functions/scalar.rs:621-671); one call = 1900 rows", "rows_per_call": 1900, "gpu": g, "kernel": lib.last_kernel()},
+            "roofline": None,
+            "cpu_baseline": {"value": 1e6 / c_["median_us"], "unit": "calls/s", "cores": 1, "kind": "port",
+                             "sample": f"the same call through the oracle (ora_binary: one wrapping multiply loop per chunk, validity ANDed), median of {calls} calls", **c_},
+            "gpu_over_cpu_time": g["median_us"] / c_["median_us"],
+            "verdict": ("the host path wins this shape" if g["median_us"] > c_["median_us"] else "the device path wins this shape")
+                       + f": {g['median_us']:.1f} us per call on the device path end to end against {c_['median_us']:.1f} us on one host core"}
+    emit(line)
+    if not (g["parity"] and c_["parity"]):
+        sys.exit("bench.py --workload ref_bench: a result differs from the known answer")
+
+
 def read_probe(torch, x, runs=5):
     """Stock read-only streaming kernel over the same column (torch.sum), median of `runs`: GB/s."""
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(runs + 1)]
@@ -431,8 +520,9 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: still create the process group (a 1-rank RCCL communicator with --backend nccl) and run every "
                          "collective of the N > 1 path — all_gather of partials, the device-resident all_to_all of the group-by")
-    ap.add_argument("--workload", default="headline", choices=["headline"] + sorted(WORKLOADS),
-                    help="headline = BASELINE.json's metric (the default, what the driver runs); c3 / c4 / q1 = the other configs")
+    ap.add_argument("--workload", default="headline", choices=["headline", "ref_bench"] + sorted(WORKLOADS),
+                    help="headline = BASELINE.json's metric (the default, what the driver runs); c3 / c4 / q1 = the other configs; "
+                         "ref_bench = the reference's own bench_multiply_i32 shape (380 chunks x 5 Int32 values), device path end to end against the oracle")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -518,6 +608,10 @@ def main():
     else:
         rows, first_row, total_rows, scaling = args.rows, rank * args.rows, args.rows * world, "weak"
     args.rows, args.first_row, args.total, args.scaling, args.comm = rows, first_row, total_rows, scaling, comm
+    if args.workload == "ref_bench":
+        if world != 1:
+            sys.exit("bench.py --workload ref_bench runs on one GPU")
+        return run_ref_bench(args, lib, api, A)
     if args.workload != "headline":
         return run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, world)
     g = Gen(torch, lib, dev)
@@ -588,10 +682,19 @@ def main():
     lib.kernel_timing_reset(False)
     per_rank = None
     if dist is not None:
-        per_rank = _per_rank(torch, dist, comm_dev, elapsed, kern_ms, kern_n, args.steps)
+        # every rank's own share of the result (its shard alone, one more untimed call) travels with its times: the shares must add up
+        # to the combined result BEFORE anything is printed, and a rank that ran slow or on the wrong rows shows in the line
+        mine = api.pipeline(e, frame, [c], pred)[0]
+        per_rank = _per_rank(torch, dist, comm_dev, elapsed, kern_ms, kern_n, args.steps, None, [float(mine.count), float(rows) * 8.0 + (rows / 8.0 if vptr else 0.0)])
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        counts = [int(v) for v in per_rank.pop("extra0")]
+        algb = per_rank.pop("extra1")
+        per_rank["result_count"] = counts
+        per_rank["roofline_frac"] = [round(b / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k > 0 else None for b, k in zip(algb, per_rank["kernel_ms_per_step"])]
+        if sum(counts) != res[1]:
+            sys.exit(f"bench.py: the ranks' result counts {counts} add up to {sum(counts)}, the combined result says {res[1]}")
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -606,11 +709,23 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 if int(tj.get("rows", -1)) == rows and bool(tj.get("validity", False)) == bool(vptr) and args.chunk_rows == 0:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_source = "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (" + str(tj.get("source", "committed profile")) + "), not re-measured in this run"
+                    cur, note = _traffic_current(tj)
+                    if cur:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                        traffic_source = ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (" + str(tj.get("source", "committed profile"))
+                                          + "), kernel sources " + str(tj.get("kernel_sources_sha")) + " = this tree's; not re-measured in this run")
+                    else:
+                        traffic_source = note
             except Exception:
                 traffic = None
-        probe = read_probe(torch, x)
+        probe_torch = read_probe(torch, x)
+        # the second denominator: the best BARE 16-byte streaming read of the same column (rdf_probe_stream: nothing but an xor fold
+        # behind the loads, several loop shapes and grids) — a ceiling the kernel can be held against, which torch.sum (slower than
+        # the kernel by 15 %) was not
+        try:
+            probe, probe_shape = lib.probe_stream(0, x.data_ptr(), nbytes=rows * 8, reps=5)
+        except Exception as ex_:
+            probe, probe_shape = 0.0, f"rdf_probe_stream failed: {ex_}"
         out = {
             "metric": "rows/sec filter+sum over 1e9 f64 Arrow rows; %HBM bw at 1/2/4/8 GPU",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -628,8 +743,10 @@ def main():
                        **({"per_rank": per_rank} if per_rank else {}), **comm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "peak_measured": probe, "peak_measured_kind": "torch.sum over the same column (stock read-only stream), median of 5",
+                         "frac_wall": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,     # the same bytes over the wall-clock step (launch, result copy, combine included): what the driver's own clock can check
+                         "peak_measured": probe, "peak_measured_kind": "best bare read-only stream over the same column (rdf_probe_stream: " + probe_shape + ")",
                          "frac_of_measured": achieved / probe if probe > 0 else None,
+                         "torch_sum_GBps": probe_torch,
                          "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3, "launches": kern_n,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
@@ -674,10 +791,10 @@ def main():
         dist.destroy_process_group()
 
 
-def _per_rank(torch, dist, comm_dev, elapsed, kern_ms, kern_n, steps, extra=None):
+def _per_rank(torch, dist, comm_dev, elapsed, kern_ms, kern_n, steps, extra=None, more=None):
     """What every rank measured, gathered on all ranks (rank order): wall and kernel time per step, and whatever the workload adds
     (exchange time) — so that a scaling curve explains itself: a slow rank, a slow kernel or a slow exchange."""
-    mine = [elapsed / max(steps, 1) * 1e3, kern_ms / max(kern_n, 1) * (kern_n / steps if kern_n else 0)] + list(extra or [])
+    mine = [elapsed / max(steps, 1) * 1e3, kern_ms / max(kern_n, 1) * (kern_n / steps if kern_n else 0)] + list(extra or []) + list(more or [])
     t = torch.tensor(mine, dtype=torch.float64, device=comm_dev if comm_dev is not None else "cpu")
     allr = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(allr, t)
@@ -685,6 +802,9 @@ def _per_rank(torch, dist, comm_dev, elapsed, kern_ms, kern_n, steps, extra=None
     out = {"step_ms": [r[0] for r in rows], "kernel_ms_per_step": [r[1] for r in rows]}
     if extra is not None:
         out["exchange_ms_per_step"] = [r[2] for r in rows]
+    base = 2 + len(extra or [])
+    for j in range(len(more or [])):
+        out[f"extra{j}"] = [float(a[base + j]) for a in allr]      # (unrounded: counts)
     return out
 
 
@@ -748,10 +868,15 @@ def run_other(args, torch, lib, api, A, sharding, dev, comm_dev, dist, rank, wor
         traffic, traffic_source = None, None
         try:   # PMC-derived HBM bytes of one step's kernels, measured in separate rocprofv3 --pmc passes (tools/profile_round.sh)
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-                tw = json.load(f).get("workloads", {}).get(args.workload)
+                tj_all = json.load(f)
+            tw = tj_all.get("workloads", {}).get(args.workload)
             if tw and int(tw.get("rows", -1)) == rows and world == 1:
-                traffic = tw.get("hbm_bytes_per_step")
-                traffic_source = "profiles/hbm_traffic.json (" + str(tw.get("source")) + "), not re-measured in this run"
+                cur, note = _traffic_current(tj_all)
+                if cur:
+                    traffic = tw.get("hbm_bytes_per_step")
+                    traffic_source = "profiles/hbm_traffic.json (" + str(tw.get("source")) + "), kernel sources " + str(tj_all.get("kernel_sources_sha")) + " = this tree's; not re-measured in this run"
+                else:
+                    traffic_source = note
         except Exception:
             traffic = None
         line = {

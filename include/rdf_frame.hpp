@@ -1907,6 +1907,12 @@ class DataFrame {
         for (auto& c : columns_) for (auto& a : c.data().chunks()) if (a->dtype != DataType::Utf8 && a->host) return true;
         return false;
     }
+    // ... ALL of them are (a host frame with a device-computed column added is not: the streamed calls take host chunks only)
+    bool all_host() const {
+        bool any = false;
+        for (auto& c : columns_) for (auto& a : c.data().chunks()) if (a->dtype != DataType::Utf8) { if (!a->host) return false; any = true; }
+        return any;
+    }
     // DataFrame::filter (:178-189): the mask, then EVERY column compacted by it in one pass (rdf_filter_columns).
     // A host-resident frame of numeric columns takes ONE call instead (rdf_filter_pipeline): predicate and compaction run on the
     // device slab by slab while the next slab comes in and the kept rows of the previous one go back — the result is a
@@ -1914,7 +1920,7 @@ class DataFrame {
     DataFrame filter(const FilterRef& condition) const {
         bool all_numeric = !columns_.empty();
         for (auto& c : columns_) all_numeric = all_numeric && (is_integer(c.data_type()) || is_float(c.data_type()));
-        if (!(is_host() && all_numeric && columns_.size() <= 64)) return filter_by_mask(evaluate_boolean_filter(condition));
+        if (!(all_host() && all_numeric && columns_.size() <= 64)) return filter_by_mask(evaluate_boolean_filter(condition));
         Lowered low;
         const int root = low.add(filter_to_expr(condition, [this](const std::string& n) {
             if (!has_column(n)) throw DataFrameError(DataFrameError::ComputeError, "Cannot find column " + n);

@@ -672,6 +672,13 @@ const char* rdf_last_kernel(void);
 rdf_status rdf_kernel_timing_reset(int32_t enable);
 rdf_status rdf_kernel_timing_get(double* total_ms, int64_t* launches);
 
+/* Measurement helper, not an operator: what BARE streaming kernels reach on this device, GB/s of bytes moved — kind 0: read `bytes`
+ * of a (xor fold, the cheapest consumer), 1: copy a -> b, 2: a, b -> c (two reads, one write).  Several loop shapes and grids are
+ * timed with HIP events on the library's stream, `reps` launches each after one warm-up; the best is returned with its description
+ * in `shape` (may be NULL).  These are the denominators bench.py's `roofline.peak_measured` and DESIGN.md's memory model use; the
+ * reference has no counterpart (its benches time kernels on the CPU, src/functions/scalar.rs:621-671). */
+rdf_status rdf_probe_stream(int32_t kind, const void* a, void* b, void* c, int64_t bytes, int32_t reps, double* best_gbps, char* shape, int32_t shape_len);
+
 #ifdef __cplusplus
 }
 #endif

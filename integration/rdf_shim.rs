@@ -194,6 +194,7 @@ pub mod sys {
         pub fn rdf_last_kernel() -> *const c_char;
         pub fn rdf_kernel_timing_reset(enable: i32) -> i32;
         pub fn rdf_kernel_timing_get(total_ms: *mut f64, launches: *mut i64) -> i32;
+        pub fn rdf_probe_stream(kind: i32, a: *const c_void, b: *mut c_void, c: *mut c_void, bytes: i64, reps: i32, best_gbps: *mut f64, shape: *mut c_char, shape_len: i32) -> i32;
     }
 }
 

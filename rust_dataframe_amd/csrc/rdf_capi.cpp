@@ -108,6 +108,7 @@ struct Ctx {
     bool streaming = false;          // stream_run is active: slabs are in flight on the copy engines (frame_table_upload)
     int  opt_stream_table_kernel = 1;   // 1 = while streaming, a frame's tables reach the device through a kernel instead of the copy engine (A/B: 0)
     char* tab_pin = nullptr; size_t tab_pin_cap = 0, tab_pin_used = 0;   // page-locked ring the tables are staged in for that kernel
+    bool   agg_comm_entered = false;  // ... and this call has entered agg_dist_finish's collectives (a rank that fails before them still has to: pipeline_dist)
     ::rdf_comm* agg_comm = nullptr;   // rdf_pipeline_dist: the next aggregate's device-resident partials are all-gathered and folded on the device before the host reads anything
     ~Ctx();
 };
@@ -1270,6 +1271,35 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
                     r.dtype = value_dtype[v];
                 }
             if (ps.grows) memset(ps.grows, 0, sizeof(int64_t) * (size_t)(ps.ngroups + 1));
+        } else if (g_ctx.agg_comm) {
+            // rdf_pipeline_dist over an EMPTY shard: the other ranks are about to enter the all-gathers of agg_dist_finish, so this
+            // one must too (returning its local zeros left them in the collective until the watchdog aborted the communicator).
+            // Its contribution is the fold's identity, built on the host and handed over like a kernel's partials.
+            RDF_TRY(ensure_ready());
+            Ctx& cx = g_ctx;
+            arena_begin();
+            void* scr = nullptr;
+            const size_t pb = sizeof(AggPartial) * (size_t)ps.nvalues;
+            RDF_TRY(arena_alloc(64 + pb, &scr));
+            RDF_TRY(pinned_reserve(64 + pb));
+            memset(cx.pinned, 0, 64 + pb);
+            int cls[kMaxValues];
+            for (int v = 0; v < ps.nvalues; ++v) {
+                cls[v] = value_class(value_dtype[v]);
+                AggPartial id;
+                memset(&id, 0, sizeof id);
+                if (cls[v] == CLS_F64) id.mn = id.mx = 0x7FF8000000000000ull;                     // (agg_init, rdf_common.hip.h)
+                else if (cls[v] == CLS_SIGNED) { id.mn = (uint64_t)INT64_MAX; id.mx = (uint64_t)INT64_MIN; }
+                else { id.mn = ~0ull; id.mx = 0; }
+                memcpy(cx.pinned + 64 + sizeof(AggPartial) * (size_t)v, &id, sizeof id);
+            }
+            HIP_TRY(hipMemcpyAsync(scr, cx.pinned, 64 + pb, hipMemcpyHostToDevice, cx.stream));
+            AggPartial hp[kMaxValues];
+            uint32_t flags = 0;
+            RDF_TRY(agg_dist_finish(*cx.agg_comm, (const AggPartial*)((char*)scr + 64), (const uint32_t*)scr, ps.nvalues, cls, hp, &flags));
+            if (flags & 2u) return fail(RDF_COMPUTE_ERROR, "pipeline_dist: another rank failed before the combine");
+            if (flags & 1u) return fail(RDF_DIVIDE_BY_ZERO, "Divide by zero error");
+            for (int v = 0; v < ps.nvalues; ++v) fill_agg_result(&aggs[v], value_dtype[v], hp[v]);
         } else {
             for (int v = 0; v < ps.nvalues; ++v) { memset(&aggs[v], 0, sizeof aggs[v]); aggs[v].dtype = value_dtype[v]; }
         }
@@ -1707,6 +1737,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             AggPartial hp[kMaxValues];
             uint32_t flags = 0;
             RDF_TRY(agg_dist_finish(*ctx.agg_comm, d_result, d_flags, ps.nvalues, cls, hp, &flags));
+            if (flags & 2u) return fail(RDF_COMPUTE_ERROR, "pipeline_dist: another rank failed before the combine");
             if (flags & 1u) return fail(RDF_DIVIDE_BY_ZERO, "Divide by zero error");
             for (int v = 0; v < ps.nvalues; ++v) fill_agg_result(&aggs[v], value_dtype[v], hp[v]);
             return RDF_OK;
@@ -3746,6 +3777,20 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
         pa.tiles = (int64_t*)ptiles;
         pa.flags = d_cnt + 3;
         HIP_TRY(launch_join_place(pa, ctx.stream));
+        // The table is not cleared: a placement that overflowed (a cluster ran past the margin) leaves the slots behind the last
+        // key it placed unwritten, and a probe would walk them.  Look at the flag BEFORE anything probes (one 8-byte copy and a wait:
+        // microseconds against the milliseconds of a join this size); the round-3 table takes the call if it is set.
+        unsigned long long overflow = 0;
+        HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, d_cnt + 3, 8, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_TRY(hipStreamSynchronize(ctx.stream));
+        memcpy(&overflow, ctx.pinned + pin_off, 8);
+        if (overflow) {
+            kt.stop();
+            ctx.opt_join_table = 1;
+            const rdf_status st = rdf_equijoin_indices_multi(left_keys, left_nchunks, right_keys, right_nchunks, nkeys, join_type, out_left, out_right, out_rows);
+            ctx.opt_join_table = 2;
+            return st;
+        }
     } else if (use_table) {
         while (((int64_t)1 << tbits) < 2 * nrv) ++tbits;
         RDF_TRY(arena_alloc(((size_t)16 << tbits) + 64, &ptable));
@@ -4305,6 +4350,50 @@ const char* rdf_jit_status(void) {
     return line.c_str();
 }
 const char* rdf_last_kernel(void) { return g_ctx.last_kernel.c_str(); }
+
+// What bare streaming kernels reach on this device (rdf_probe.hip): the denominators measurements are held against.
+rdf_status rdf_probe_stream(int32_t kind, const void* a, void* b, void* c, int64_t bytes, int32_t reps, double* best_gbps, char* shape, int32_t shape_len) {
+    if (kind < 0 || kind > 2 || !a || (kind >= 1 && !b) || (kind == 2 && !c) || bytes < 16 || !best_gbps) return fail(RDF_INVALID_ARGUMENT, "probe_stream: kind 0..2 with its device buffers, bytes >= 16");
+    RDF_TRY(ensure_ready());
+    Ctx& ctx = g_ctx;
+    arena_begin();
+    void* sink = nullptr;
+    RDF_TRY(arena_alloc(64, &sink));
+    const int64_t nvec = bytes / 16;
+    const double moved = (double)nvec * 16.0 * (kind == 0 ? 1.0 : kind == 1 ? 2.0 : 3.0);
+    const int ncu = std::max(1, eval_grid_limit() / 8);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    double best = 0.0;
+    int best_u = 0, best_b = 0;
+    if (reps < 1) reps = 3;
+    rdf_status st = RDF_OK;
+    for (int u : {1, 4})
+        for (int per_cu : {4, 8, 16}) {
+            const int64_t want = (nvec + (int64_t)kBlock * u - 1) / ((int64_t)kBlock * u);
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ncu * per_cu));
+            for (int r = 0; r <= reps && st == RDF_OK; ++r) {          // (the first launch of a shape is not counted)
+                hipError_t e = hipEventRecord(e0, ctx.stream);
+                if (e == hipSuccess) e = launch_probe(kind, u, grid, a, b, c, nvec, (uint32_t*)sink, ctx.stream);
+                if (e == hipSuccess) e = hipEventRecord(e1, ctx.stream);
+                if (e == hipSuccess) e = hipEventSynchronize(e1);
+                float ms = 0;
+                if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+                if (e != hipSuccess) { st = fail(RDF_DEVICE_ERROR, "probe_stream: %s", hipGetErrorString(e)); break; }
+                const double gbps = ms > 0 ? moved / (ms * 1e-3) / 1e9 : 0.0;
+                if (r > 0 && gbps > best) { best = gbps; best_u = u; best_b = per_cu; }
+            }
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    RDF_TRY(st);
+    *best_gbps = best;
+    if (shape && shape_len > 0)
+        snprintf(shape, (size_t)shape_len, "%s, %d x 16-byte vectors per lane and iteration, %d blocks of 256 threads per CU, nontemporal, best of %d launches",
+                 kind == 0 ? "read-only (xor fold)" : kind == 1 ? "copy" : "two reads + one write", best_u, best_b, reps);
+    return RDF_OK;
+}
 
 rdf_status rdf_kernel_timing_reset(int32_t enable) {
     RDF_TRY(ensure_ready());

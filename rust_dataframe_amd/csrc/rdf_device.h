@@ -484,6 +484,7 @@ constexpr int kG2Block = 512;                       // scatter block: 8 waves; t
 #endif
 constexpr int kG2Rows = RDF_G2_ROWS;                // rows per thread per super-tile (4: two blocks per CU; 2: LDS and registers for three)
 constexpr int kG2BlocksPerCU = kG2Rows == 2 ? 3 : 2;
+constexpr int kG2MaxBlocks = 512;      // scatter blocks of one call: what the aggregate pass's region list holds in LDS (two per CU of the MI355X's 256; a part with more CUs runs the same 512)
 constexpr int kG2Super = kG2Block * kG2Rows;        // 2048 rows = 2 tiles of kEvalTile rows
 constexpr int kG2Line = 8;                          // records per 128-byte line: the only unit ever written
 // 12-byte records (keys inside a window of 2^39): a unit of 16 records = one 128-byte line of values + 64 bytes of key words
@@ -708,6 +709,7 @@ hipError_t launch_list_offsets(const int64_t* scan, int64_t n1, int32_t* out, hi
 
 // ---- launch wrappers (defined in rdf_kernels.hip) ----
 int  eval_grid_limit();   // persistent grid size for streaming kernels
+hipError_t launch_probe(int kind, int u, int grid, const void* a, void* b, void* c, int64_t nvec, uint32_t* sink, hipStream_t s);   // rdf_probe.hip: bare streams
 hipError_t launch_eval(const EvalArgs& a, int sink, int feat, int grid, hipStream_t s);  // feat: 0 basic, 1 +int div, 2 +libm
 bool gspec_available(const char* sig);
 hipError_t launch_gspec(const char* sig, const GSpecArgs& a, int grid, hipStream_t s);

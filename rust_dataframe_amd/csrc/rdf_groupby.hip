@@ -866,7 +866,7 @@ __global__ __launch_bounds__(kG2Block, 2 * kG2BlocksPerCU) void gb2_scatter_kern
 
 // pass 2: one block per partition; its records are the nb line ranges the scatter blocks wrote
 constexpr int kAggBatch = 4;
-constexpr int kAggMaxRegions = 512;      // scatter blocks (two per CU of the 256): what an item's region list may hold in LDS
+constexpr int kAggMaxRegions = kG2MaxBlocks;      // scatter blocks (two per CU of the 256): what an item's region list may hold in LDS
 __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2AggArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t gsm[];
     LdsTab t;

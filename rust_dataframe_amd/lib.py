@@ -23,7 +23,7 @@ EXPORTS = [
     "rdf_comm_unique_id", "rdf_comm_init_rank", "rdf_comm_init_all", "rdf_comm_destroy", "rdf_comm_info", "rdf_comm_barrier", "rdf_comm_allgather",
     "rdf_agg_combine", "rdf_pipeline_dist", "rdf_pipeline_frame_dist", "rdf_group_combine", "rdf_groupby_agg_dist", "rdf_groupby_agg_frame_dist",
     "rdf_fill_uniform_f64", "rdf_fill_uniform_i64", "rdf_fill_validity",
-    "rdf_kernel_timing_reset", "rdf_kernel_timing_get", "rdf_set_option", "rdf_spec_catalog_size", "rdf_jit_status", "rdf_last_kernel",
+    "rdf_kernel_timing_reset", "rdf_kernel_timing_get", "rdf_probe_stream", "rdf_set_option", "rdf_spec_catalog_size", "rdf_jit_status", "rdf_last_kernel",
 ]
 
 _lib = None
@@ -100,6 +100,16 @@ def synchronize():
 def set_option(name: str, value: int):
     load().rdf_set_option.argtypes = [C.c_char_p, C.c_int64]
     _check(load().rdf_set_option(name.encode(), value))
+
+
+def probe_stream(kind: int, a: int, b: int = 0, c: int = 0, nbytes: int = 0, reps: int = 5):
+    """-> (GB/s of bytes moved, shape): the best bare streaming kernel of `kind` (0 read, 1 copy, 2 two reads + one write) on device buffers."""
+    gbps = C.c_double(0.0)
+    shape = C.create_string_buffer(256)
+    fn = load().rdf_probe_stream
+    fn.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.c_int32]
+    _check(fn(kind, a, b or None, c or None, nbytes, reps, C.byref(gbps), shape, 256))
+    return gbps.value, shape.value.decode()
 
 
 def last_kernel() -> str:

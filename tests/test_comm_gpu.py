@@ -423,9 +423,32 @@ def test_rccl_one_rank_communicator(eng, ora, how):
         with pytest.raises(A.RdfError) as ei:        # a kernel's error flag travels with the partials: DivideByZero on every rank
             comm.pipeline_dist(e, [[zero], [zero]], [e.op("divide", e.col(0), e.col(1))])
         assert ei.value.status == A.RDF_DIVIDE_BY_ZERO
+        # an EMPTY shard still goes through the combine (round 5 returned its local zeros without entering the all-gathers and
+        # left the other ranks waiting for the watchdog): the fold's identity travels in its place
+        E32, EV = d.array(np.zeros(0, dtype=np.int32), A.I32), d.array(np.zeros(0), A.F64)
+        for got in comm.pipeline_dist(e, [[E32], [EV]], [e.col(1), e.col(0)], pred):
+            assert got.count == 0 and not got.is_some and got.sum == 0
+        # ... and so does a rank whose call fails BEFORE the combine: it joins with nothing and a flag, then reports its own error
+        with pytest.raises(A.RdfError) as ei:
+            comm.pipeline_dist(e, [[KI], [V]], [e.col(1)], e.col(1))         # predicate root is not boolean
+        assert ei.value.status == A.RDF_INVALID_ARGUMENT and "boolean" in str(ei.value)
+        got = comm.pipeline_dist(e, [[KI], [V]], [e.col(1)], pred)[0]           # the communicator is still usable
+        assert got.count == want.count
         comm.barrier()
         assert comm.allgather(b"abc") == [b"abc"]
     finally:
         lib.set_option("comm_max_bytes", 0)
         d.free()
         comm.destroy()
+
+
+def test_first_contact_selftest_on_the_peer_transport(eng, ora):
+    """What __graft_entry__.smoke() runs over real peers when more than one device is visible (rust_dataframe_amd/selftest.py: a
+    communicator over all devices, one thread per rank, a hash GROUP BY across the ranks and a distributed filter -> aggregate, the
+    LAST rank holding no rows) — here on four in-process ranks of the one GPU, against the oracle."""
+    from rust_dataframe_amd import selftest
+    lib, api = eng
+    out = selftest.multi_device_groupby(lib, api, [0, 0, 0, 0], rows=300_000, ngroups=20_000, kind=A.COMM_PEER)
+    assert out["rows_per_rank"][-1] == 0 and sum(out["rows_per_rank"]) == 300_000
+    assert selftest.check_against_oracle(out, ora)
+    lib.set_device(0)

@@ -77,6 +77,25 @@ def test_c4_two_ranks_row_shuffle():
     assert cfg["groups_total"] == 1_000_000 and cfg["result"].get("exchange") == "rows", cfg
 
 
+def test_eight_ranks_small_shards_through_bench_main():
+    """The driver's N = 8 command line end to end through bench.py's own main() at 1e6 rows per rank (eight processes on the one
+    GPU, gloo): every rank's share of the result is gathered and must add up to the combined count before the line is printed;
+    the line carries every rank's step time, kernel time and roofline fraction.  C4 at eight ranks: every key owned once."""
+    h8 = _run("headline", 8, 1_000_000, 0)
+    h1 = _run("headline", 1, 8_000_000, 0)
+    cfg = h8["config"]
+    assert h8["n_gpus"] == 8 and cfg["total_rows"] == 8_000_000 and cfg["result_count"] == h1["config"]["result_count"]
+    assert abs(cfg["result_sum"] - h1["config"]["result_sum"]) <= 1e-12 * h1["config"]["result_sum"]
+    pr = cfg["per_rank"]
+    assert len(pr["result_count"]) == 8 and sum(pr["result_count"]) == cfg["result_count"] and min(pr["result_count"]) > 0
+    assert len(pr["roofline_frac"]) == 8 and all(f is not None and 0 < f < 1 for f in pr["roofline_frac"]), pr
+    assert h8["roofline"]["frac_wall"] <= h8["roofline"]["frac"] * 1.05
+    c8 = _run("c4", 8, 1_000_000, 0)
+    cc = c8["config"]
+    assert c8["n_gpus"] == 8 and cc["self_check"] is True and cc["parity_on_sample"] is True, cc
+    assert cc["check_totals"]["sum_of_group_counts"] == 8_000_000
+
+
 def test_q1_two_ranks_equal_one():
     two = _run("q1", 2, 10_000_000, 29631)
     one = _run("q1", 1, 20_000_000, 0)

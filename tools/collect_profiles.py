@@ -109,7 +109,10 @@ def main():
             if ks and w in wrows:
                 workloads[w] = {"rows": wrows[w], "hbm_bytes_per_step": sum(e["hbm_bytes_per_launch"] for e in ks),
                                 "kernels": [e["kernel"][:80] for e in ks], "source": f"profiles/{rnd}_pmc_hbm_traffic_by_kernel.json"}
-        json.dump({"rows": rows, "validity": False, "hbm_bytes_per_launch": hbm, "source": f"profiles/{rnd}_bench_1e9_pmc_summary.json", "workloads": workloads},
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        import bench as _bench     # the stamp bench.py compares: figures measured on other kernel sources are not reported
+        json.dump({"rows": rows, "validity": False, "hbm_bytes_per_launch": hbm, "source": f"profiles/{rnd}_bench_1e9_pmc_summary.json",
+                   "kernel_sources_sha": _bench.kernel_sources_sha(), "kernel_sources": list(_bench.KERNEL_SOURCES), "workloads": workloads},
                   open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
     valu = {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_valu_*"))):
