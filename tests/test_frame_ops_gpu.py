@@ -525,7 +525,7 @@ def test_filter_frame_block_tiles(gpu, ora, lens, off, nf, dts):
                     match_unknown_nulls(got[k], exp[k], f"{name} lens={lens} column {k}")
                 out.release()
         finally:
-            lib.set_option("filter_block_rows", 32768)
+            lib.set_option("filter_block_rows", 8192)
 
 
 @pytest.mark.parametrize("lens,off,nf", BLOCK_LAYOUTS)
@@ -590,4 +590,4 @@ def test_filter_columns_device_block_tiles(gpu, ora, lens, off, nf, dts):
                 assert lib.last_kernel() != "bfilter_kernel", lib.last_kernel()
                 check(bufs, outs, f"counted sel={sel}")
         finally:
-            lib.set_option("filter_block_rows", 32768)
+            lib.set_option("filter_block_rows", 8192)
