@@ -655,6 +655,8 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * "join_table" (equi-join on one key column: 2 = the build side sorted by hash, the table of its distinct keys laid out by a scan,
  * default; 1 = sorted by key, table slots claimed by compare-and-swap; 0 = a bucket index over the sorted build keys),
  * "sort_msd" (keys that vary in 25 bits or more: 1 = passes over the top bits, buckets finished in LDS, default; 0 = one pass per byte),
+ * "sort_pipe" (the digit passes: 0 = decoupled look-back between the tiles, default; 1 = a tile's digit counts go out one iteration before
+ * its offsets are asked for and scanner blocks turn counts into offsets — round 6's experiment, measured slower, kept for A/B),
  * "sort_sample" (Float64 sort keys: 1 = the value buckets of those passes are planned from a sample of the keys — the range the rows lie
  * in without far outliers / infinities / NaNs, as many bucket bits as the densest region needs —, default; 0 = [min, max], ~500 rows per bucket),
  * "stream_slab_bytes" (rdf_pipeline over host memory: bytes per slab of the streamed batch loop, 0 = 256 MiB, -1 = never stream),

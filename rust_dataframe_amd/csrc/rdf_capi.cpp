@@ -66,6 +66,7 @@ struct Ctx {
     int    opt_gb_debug = 0;        // ablations of the partitioned GROUP BY (tools/bench_kernels.py): 1 = aggregate without LDS work, 2 = scatter without stores
     int    opt_sort_gen = 3;        // radix passes: 3 = one read + one write of the pairs per digit, decoupled look-back between 4096-pair tiles (rdf_sort.hip, default); 2 = count -> scan -> scatter over static tile ranges with the same wave-ranked tiles (A/B: slower, see rdf_sort.hip); 1 = first generation (rdf_kernels.hip)
     bool   sort_used_local = false; // the last sort finished at least one column with os_local_kernel
+    int    opt_sort_pipe = 0;       // the digit passes of rdf_sort.hip: 0 = decoupled look-back between the tiles (os_scatter_kernel, default); 1 = a tile's digit counts are published one iteration before its offsets are asked for and scanner blocks turn counts into offsets (os_scatter3_kernel, round 6: built, correct, measured 4-16 % SLOWER — profiles/r06_sort_digit_pass_ab.jsonl — kept as the A/B)
     int    opt_sort_msd = 1;        // sort keys that vary in more than 32 bits: passes over the top bits, then every bucket sorted in LDS (1, default); 0 = one pass per byte (A/B)
     int    opt_sort_sample = 1;     // doubles: value buckets planned from a sample of the keys (range without outliers, bucket bits from the densest region); 0 = [min, max] and ~500 rows per bucket (round 3, A/B)
     int    opt_join_table = 2;      // equi-join on one key column: probe a table of the distinct build keys — 2 (default, round 5): the build side sorted by hash, the table placed by a scan (no atomics); 1: sorted by key, slots claimed by compare-and-swap (round 3); 0 = the bucket index over the sorted build keys (A/B)
@@ -3139,7 +3140,8 @@ namespace {
 
 // The digit passes of one sort column over (keys, idx) ping-pong buffers, second generation (rdf_sort.hip): every digit's
 // histogram from ONE read of the keys, then one read + one write of the pairs per digit.  `need` low bytes of (key - bias) vary.
-struct OsScratch { unsigned long long* state = nullptr; unsigned long long* tickets = nullptr; int64_t* hist = nullptr; int64_t ntiles = 0; int seq = 0;
+constexpr size_t kOsClassTicketBytes = (size_t)16 * 64 * 128;
+struct OsScratch { unsigned long long* state = nullptr; unsigned long long* tickets = nullptr; unsigned int* ctick = nullptr; int64_t* hist = nullptr; int64_t ntiles = 0; int seq = 0;
                    int64_t* bh0 = nullptr; int64_t* bh1 = nullptr; int64_t sgrid = 0; };
 rdf_status os_scratch_alloc(int64_t n, OsScratch& o) {
     o.ntiles = (n + os_tile_items() - 1) / os_tile_items();
@@ -3152,13 +3154,17 @@ rdf_status os_scratch_alloc(int64_t n, OsScratch& o) {
         o.bh1 = (int64_t*)p;
         return RDF_OK;
     }
-    RDF_TRY(arena_alloc((size_t)o.ntiles * 256 * 8 + 64, &p));
+    RDF_TRY(arena_alloc((size_t)(o.ntiles + kOsStatePadTiles) * 256 * 8 + 64, &p));
     o.state = (unsigned long long*)p;
-    HIP_TRY(hipMemsetAsync(p, 0, (size_t)o.ntiles * 256 * 8, g_ctx.stream));
+    HIP_TRY(hipMemsetAsync(p, 0, (size_t)(o.ntiles + kOsStatePadTiles) * 256 * 8, g_ctx.stream));
     RDF_TRY(arena_alloc(16 * 8 + 9 * 256 * 8, &p));
     o.tickets = (unsigned long long*)p;
     o.hist = (int64_t*)((char*)p + 16 * 8);
     o.seq = 0;
+    // os_scatter3_kernel: 64 ticket counters per pass, 128 bytes apart, for the up to 16 passes of one column
+    RDF_TRY(arena_alloc(kOsClassTicketBytes, &p));
+    o.ctick = (unsigned int*)p;
+    HIP_TRY(hipMemsetAsync(p, 0, kOsClassTicketBytes, g_ctx.stream));
     return RDF_OK;
 }
 rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* const idxb[2], const uint8_t* nullflags, int64_t n, uint64_t bias, int need,
@@ -3189,10 +3195,19 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
         memset(&pa, 0, sizeof pa);
         pa.keys_in = keys[kcur]; pa.idx_in = idx_cur; pa.keys_out = keys[kcur ^ 1]; pa.idx_out = idxb[icur ^ 1];
         pa.nullflags = np ? nullflags : nullptr;
-        pa.state = o.state; pa.ticket = o.tickets + launched; pa.bases = o.hist + hist_row * 256;
+        pa.state = o.state; pa.ticket = o.tickets + launched; pa.class_tickets = ctx.opt_sort_pipe ? o.ctick + (size_t)launched * 64 * 32 : nullptr; pa.bases = o.hist + hist_row * 256;
         pa.n = rows; pa.ntiles = (rows + os_tile_items() - 1) / os_tile_items(); pa.bias = bias; pa.shift = shift; pa.mask = mask; pa.seq = ++o.seq;
         if (!np) pa.fb = fb;
+        static const bool dbg3 = getenv("RDF_DEBUG_SORT") != nullptr;
+        if (dbg3) { pa.debug = o.tickets + 8; HIP_TRY(hipMemsetAsync(pa.debug, 0, 48, ctx.stream)); }
         HIP_TRY(launch_os_scatter(pa, ctx.stream));
+        if (dbg3) {
+            unsigned long long h[6];
+            HIP_TRY(hipMemcpyAsync(h, pa.debug, 48, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_TRY(hipStreamSynchronize(ctx.stream));
+            fprintf(stderr, "[rdf] digit pass (shift %d, %lld tiles): waiting for offsets %.2f us per tile of %.2f us; scanner rounds %llu, idle %llu, partial %llu\n", shift, (long long)pa.ntiles,
+                    h[5] ? h[0] * 0.01 / h[5] : 0.0, h[5] ? h[1] * 0.01 / h[5] : 0.0, h[2], h[3], h[4]);
+        }
         ++launched;
         kcur ^= 1; icur ^= 1; idx_cur = idxb[icur];
         return RDF_OK;
@@ -3284,6 +3299,7 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
         int64_t nv = n;                       // rows in front of the NULL keys
         int ks = -1, is = -1;                 // the buffers the NULL rows were left in
         HIP_TRY(hipMemsetAsync(o.tickets, 0, 16 * 8 + 9 * 256 * 8, ctx.stream));
+    HIP_TRY(hipMemsetAsync(o.ctick, 0, kOsClassTicketBytes, ctx.stream));
         OsHistArgs ha;
         memset(&ha, 0, sizeof ha);
         ha.bias = bias; ha.hist = o.hist; ha.generic = 1; ha.fb = fb;
@@ -3357,6 +3373,7 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
 byte_passes:
     fb.bits = 0;
     HIP_TRY(hipMemsetAsync(o.tickets, 0, 16 * 8 + 9 * 256 * 8, ctx.stream));
+    HIP_TRY(hipMemsetAsync(o.ctick, 0, kOsClassTicketBytes, ctx.stream));
     OsHistArgs ha;
     memset(&ha, 0, sizeof ha);
     ha.keys = keys[kcur]; ha.nullflags = null_pass ? nullflags : nullptr; ha.n = n; ha.bias = bias; ha.npass = need; ha.hist = o.hist;
@@ -3369,7 +3386,7 @@ byte_passes:
         memset(&pa, 0, sizeof pa);
         pa.keys_in = keys[kcur]; pa.idx_in = idx_cur; pa.keys_out = keys[kcur ^ 1]; pa.idx_out = idxb[icur ^ 1];
         pa.nullflags = np ? nullflags : nullptr;
-        pa.state = o.state; pa.ticket = o.tickets + launched; pa.bases = o.hist + (np ? 8 : p) * 256;
+        pa.state = o.state; pa.ticket = o.tickets + launched; pa.class_tickets = ctx.opt_sort_pipe ? o.ctick + (size_t)launched * 64 * 32 : nullptr; pa.bases = o.hist + (np ? 8 : p) * 256;
         pa.n = n; pa.ntiles = o.ntiles; pa.bias = bias; pa.shift = 8 * p; pa.seq = ++o.seq;
         static const bool dbg = getenv("RDF_DEBUG_SORT") != nullptr;
         if (dbg) { pa.debug = o.tickets + 8; }
@@ -4320,6 +4337,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "take_rows") == 0) g_ctx.opt_take_rows = (int)value;
     else if (strcmp(name, "sort_gen") == 0) g_ctx.opt_sort_gen = (int)value;
     else if (strcmp(name, "sort_msd") == 0) g_ctx.opt_sort_msd = (int)value;
+    else if (strcmp(name, "sort_pipe") == 0) g_ctx.opt_sort_pipe = value != 0;
     else if (strcmp(name, "sort_sample") == 0) g_ctx.opt_sort_sample = (int)value;
     else if (strcmp(name, "stream_table_kernel") == 0) g_ctx.opt_stream_table_kernel = value != 0;
     else if (strcmp(name, "join_table") == 0) g_ctx.opt_join_table = value < 0 || value > 2 ? 2 : (int)value;

@@ -269,6 +269,7 @@ struct SortPassArgs {
 
 // Second-generation radix passes (rdf_sort.hip): all digit histograms in one read, then one read + one write per digit with
 // decoupled look-back between tiles.
+constexpr int kOsStatePadTiles = 768;                // zeroed tile states behind the last tile: what os_scatter3_kernel's scanners may read past the end (two windows of 256 tiles and a run)
 constexpr int kOsItems = 16;                         // items per thread per tile: 4096-item tiles
 // f64 keys: the top bits of the key bits are sign and exponent — doubles of one magnitude crowd a few of their patterns —, so the
 // most-significant-first passes take their digits from the VALUE bucket floor((x - lo) * scale) instead (monotone in the key bits:
@@ -297,6 +298,8 @@ struct OsPassArgs {
     int32_t         mask, pad;                       // digit = ((key - bias) >> shift) & mask; 0 = 255
     OsBucket        fb;                              // ... or (value bucket >> shift) & mask
     unsigned long long* debug;                       // RDF_DEBUG: [6] cycle sums of the phases (ticket, load + rank, barrier, look-back, sort + write), tiles
+    unsigned int*   class_tickets;                   // os_scatter3_kernel (round 6): 64 ticket counters of this pass, 128 bytes apart (zeroed); nullptr = os_scatter_kernel
+    int32_t         nclass, pad2;                    // counters in use (set by the launcher)
 };
 // Most-significant-digits-first finish (keys that vary in more than 32 bits): after stable passes over the TOP bits of the keys
 // the rows lie in buckets of <= kOsLocalMax rows that share those bits; every bucket is then sorted on the remaining `rbits`

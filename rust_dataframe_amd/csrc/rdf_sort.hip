@@ -247,6 +247,255 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 6: the same pass with the waiting taken out (os_scatter3_kernel; rdf_set_option("sort_pipe", 0) brings the kernel above
+// back for A/B).  By the phase timers a tile above spends 12 of its 27 us waiting in the look-back: its offsets need the counts of
+// EVERY tile ticketed before it, those tiles are being counted at the same moment, and a count is one memory round trip away
+// from its reader.  The compaction kernel of rdf_bfilter.hip met the same wall and got past it with two changes, taken over here:
+//   * the counts of tile n + 1 are published a whole iteration BEFORE its offsets are asked for: a block holds two tiles in
+//     registers — the current one (counted last iteration) and the next one (loads in flight while the current one is ranked,
+//     sorted in LDS and written out);
+//   * nobody walks back over the tiles in flight (with counts out that early a flat look-back would cross ~1000 tiles): the
+//     first kOsScanBlocks blocks of the grid are SCANNERS.  A scanner wave owns 8 of the 256 digits, reads the count words of
+//     256 tiles x 8 digits per round, adds them up in tile order and writes the exclusive prefixes back over the counts;
+//     thread d of a tile polls its own word.
+// Tiles are handed out by up to 64 ticket counters (one counter serialises its draws at ~23 ns each: 5.6 ms per pass of 1e9 keys).
+
+
+// A scanner wave owns DPW = 8 digits.  Lanes (g, d) = (lane & 7, lane >> 3): digit d0 + d of the 32 CONSECUTIVE tiles 32 g .. 32 g + 31
+// of a 256-tile window — a lane adds up its own run serially, the eight runs of a digit are joined by one scan over the lanes of the
+// digit (three DPP row shifts), and the first tile whose words are not all out is a wave minimum.  (First form: 16 digits per wave,
+// the four tiles of a row in a quad, a cross-lane step per row: 1100 wave instructions per 128 tiles — the scanners, not the memory,
+// were what every tile waited for: 10 us per round, 13 tiles per us where the pass needs 35.)
+constexpr int kOsScanDigits = 8;                    // digits per scanner wave
+constexpr int kOsScanBlocks = 256 / kOsScanDigits / kOsWaves;      // 8 blocks = 32 scanner waves
+__device__ __forceinline__ void os_scanner_wave(const OsPassArgs& a, int d0) {
+    constexpr int K = 32, G = 64 / kOsScanDigits, W = G * K;      // 8 groups x 32 tiles
+    const int lane = threadIdx.x & 63, g = lane & (G - 1), d = lane >> 3;
+    const unsigned long long seq = (unsigned long long)a.seq;
+    unsigned long long running = 0;             // rows of digit d0 + d in front of tile `cur`
+    int64_t cur = 0;
+    unsigned long long w[K], wn[K];
+    // (no end-of-array tests: the state array carries kOsStatePadTiles tiles of zeroed words behind the last tile — words that are
+    // never published; with a test per load the loop spilled its 64-bit tile numbers and ran 15 us per round)
+    auto fetch = [&](int64_t at, unsigned long long (&x)[K]) __attribute__((always_inline)) {
+        const unsigned long long* p = a.state + (at + K * g) * 256 + d0 + d;
+#pragma unroll
+        for (int k = 0; k < K; ++k) x[k] = __hip_atomic_load(p + k * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    unsigned long long n_rounds = 0, n_idle = 0, n_part = 0;
+    fetch(cur, w);
+    while (cur < a.ntiles) {
+        ++n_rounds;
+        // this lane's first word that is not out yet, as a tile of the window; the window's: the minimum over the wave
+        int bad = W;
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) if (!((w[k] >> 50) == seq && (w[k] & kOsLocal))) bad = K * g + k;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(bad, m); bad = o < bad ? o : bad; }
+        const int f = __builtin_amdgcn_readfirstlane(bad);          // (tiles past the end are never published: f stops there)
+        if (f == 0) { ++n_idle; __builtin_amdgcn_s_sleep(2); fetch(cur, w); continue; }
+        const bool whole = f == W;
+        if (!whole) ++n_part;
+        if (whole) fetch(cur + W, wn);                              // the next window travels while this one is written
+        // counts of my run that take part (tiles below f)
+        const int mine_n = f - K * g;                               // how many of my 32 tiles
+        unsigned int tot = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) tot += k < mine_n ? (unsigned int)(w[k] & kOsValueMask) : 0u;
+        // the runs of the digit in front of mine: lanes g' < g of the same digit = the lanes before me in my row of 8
+        unsigned int inc = tot;
+        { const unsigned int o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false); if (g >= 1) inc += o; }
+        { const unsigned int o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false); if (g >= 2) inc += o; }
+        { const unsigned int o = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false); if (g >= 4) inc += o; }
+        unsigned long long at = running + (inc - tot);
+        unsigned long long* q = a.state + (cur + K * g) * 256 + d0 + d;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (k < mine_n) {
+                __hip_atomic_store(q + k * 256, (seq << 50) | kOsInclusive | at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                at += w[k] & kOsValueMask;
+            }
+        running += (unsigned int)__shfl((int)inc, (lane & ~(G - 1)) | (G - 1));       // the digit's total over the window: its last lane's inclusive sum
+        cur += f;
+        if (cur >= a.ntiles) break;
+        if (whole) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) w[k] = wn[k];
+        } else fetch(cur, w);
+    }
+    if (a.debug && lane == 0 && d0 == 0) { a.debug[2] = n_rounds; a.debug[3] = n_idle; a.debug[4] = n_part; }
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kBlock, 2) void os_scatter3_kernel(const OsPassArgs a) {     // (two blocks per CU: the LDS's limit)
+    constexpr int TILE = kBlock * ITEMS;
+    __shared__ uint64_t lkeys[TILE];
+    __shared__ uint32_t lidx[TILE];
+    __shared__ uint8_t ldig[TILE];
+    __shared__ unsigned int whist[kOsWaves][256];
+    __shared__ unsigned int dbase[256];
+    __shared__ int64_t gbase[256];
+    __shared__ unsigned int wsum[kOsWaves];
+    __shared__ unsigned int thist[2][256];              // the counts of the tile being published, and of the one published before
+    __shared__ int64_t tile_s[2];
+    __shared__ uint2 segs[kOsSegs];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x < kOsScanBlocks) { os_scanner_wave(a, (int)(blockIdx.x * kOsWaves + wave) * kOsScanDigits); return; }
+    os_load_segs(a.fb, segs);
+    const unsigned long long seq = (unsigned long long)a.seq << 50;
+    const int ctr = (int)((blockIdx.x - kOsScanBlocks) % (unsigned)a.nclass);
+    auto draw = [&]() __attribute__((always_inline)) -> int64_t { return (int64_t)atomicAdd(a.class_tickets + ctr * 32, 1u) * a.nclass + ctr; };
+    struct Regs { uint64_t key[ITEMS]; uint32_t idx[ITEMS]; };
+    // A tile's rows are addressed as (tile's first row: wave-uniform) + (32-bit place in the tile): the base goes in scalar registers
+    // and the loads take a 32-bit lane offset — with 64-bit row numbers per item the two tiles in flight did not fit 256 registers.
+    const int r0 = wave * ITEMS * 64 + lane;              // place of this lane's item 0 in a tile; item j: r0 + 64 j
+    auto rows_of = [&](int64_t tile) __attribute__((always_inline)) -> int {
+        const int64_t left = a.n - tile * TILE;
+        return (int)(left < (int64_t)TILE ? left : (int64_t)TILE);
+    };
+    auto load = [&](int64_t tile, Regs& r) __attribute__((always_inline)) {
+        const int64_t base = (int64_t)uniform64((uint64_t)(tile * TILE));
+        const int count = __builtin_amdgcn_readfirstlane(rows_of(tile));
+        const GlobalPtr<uint64_t> kp = as_global<uint64_t>(a.keys_in) + base;
+        const GlobalPtr<uint32_t> ip = as_global<uint32_t>(a.idx_in) + base;
+        const bool has_idx = a.idx_in != nullptr;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int rel = r0 + 64 * j;
+            const bool in = rel < count;
+            r.key[j] = in ? __builtin_nontemporal_load(kp + rel) : 0;
+            r.idx[j] = in ? (has_idx ? __builtin_nontemporal_load(ip + rel) : (uint32_t)base + (uint32_t)rel) : 0;
+        }
+    };
+    auto digit_of = [&](const Regs& r, int j) __attribute__((always_inline)) -> int {
+        return a.nullflags ? (int)as_global<uint8_t>(a.nullflags)[r.idx[j]]
+                           : a.fb.bits ? (int)((os_value_bucket(r.key[j], a.fb, segs) >> a.shift) & (uint32_t)a.mask) : os_digit(r.key[j], a.bias, a.shift, a.mask);
+    };
+    // the tile's digit counts, published (thread d: digit d); thist[par ^ 1] is cleared for the tile after this one
+    auto count_publish = [&](const Regs& r, int64_t tile, int par) __attribute__((always_inline)) -> unsigned int {
+        const int count = __builtin_amdgcn_readfirstlane(rows_of(tile));
+        thist[par ^ 1][threadIdx.x] = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (r0 + 64 * j < count) atomicAdd(&thist[par][digit_of(r, j)], 1u);
+        __syncthreads();
+        const unsigned int total_d = thist[par][threadIdx.x];
+        __hip_atomic_store(a.state + tile * 256 + threadIdx.x, seq | kOsLocal | total_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return total_d;
+    };
+    thist[0][threadIdx.x] = 0;
+    if (threadIdx.x == 0) { tile_s[0] = draw(); tile_s[1] = draw(); }
+    __syncthreads();
+    int64_t T = (int64_t)uniform64((uint64_t)tile_s[0]), Tn = (int64_t)uniform64((uint64_t)tile_s[1]);
+    __syncthreads();
+    if (T >= a.ntiles) return;
+    Regs A, B;
+    load(T, A);
+    if (Tn < a.ntiles) load(Tn, B);
+    unsigned int total_c = count_publish(A, T, 0), total_n = 0;
+    int par = 1;
+    unsigned long long t_poll = 0, t_loop = wall_clock64(), n_tiles = 0;
+    auto step = [&](Regs& X, Regs& Y) __attribute__((always_inline)) -> bool {
+        int64_t drawn = 0;
+        if (threadIdx.x == 0) drawn = draw();
+#pragma unroll
+        for (int w = 0; w < kOsWaves; ++w) whist[w][threadIdx.x] = 0;
+        // a. the next tile: count, publish (its offsets are asked for one iteration from now)
+        if (Tn < a.ntiles) total_n = count_publish(Y, Tn, par);
+        else __syncthreads();
+        par ^= 1;
+        const int count = __builtin_amdgcn_readfirstlane(rows_of(T));
+        // b. ranks inside the wave (as os_scatter_kernel)
+        uint32_t dr[ITEMS];       // digit | rank inside the wave << 8 (a tile holds 4096 pairs)
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool in = r0 + 64 * j < count;
+            const int d = in ? digit_of(X, j) : 0;
+            uint64_t peers = __ballot(in);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint64_t m = __ballot((d >> b) & 1);
+                peers &= ((d >> b) & 1) ? m : ~m;
+            }
+            const int leader = __builtin_ctzll(peers | (1ull << 63));
+            unsigned int before = 0;
+            if (in && lane == leader) { before = whist[wave][d]; whist[wave][d] = before + (unsigned)__popcll(peers); }
+            before = __shfl(before, leader);
+            dr[j] = (uint32_t)d | (((uint32_t)before + (uint32_t)__popcll(peers & ((1ull << lane) - 1))) << 8);
+        }
+        __syncthreads();
+        {
+            unsigned int run = 0;
+#pragma unroll
+            for (int w = 0; w < kOsWaves; ++w) { const unsigned int c = whist[w][threadIdx.x]; whist[w][threadIdx.x] = run; run += c; }
+        }
+        unsigned int inc = total_c;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const unsigned int o = __shfl_up(inc, dd); if (lane >= dd) inc += o; }
+        if (lane == 63) wsum[wave] = inc;
+        // c. rows of digit d in front of the tile: the scanner's word
+        {
+            // (a scanner wave writes 16 digits of a tile with one store: while the word is not there only one thread in 16 asks again —
+            // 512 blocks x 256 polling threads would be a terabyte per second of 8-byte reads in front of the scanners' own)
+            unsigned long long w;
+            const unsigned long long tp0 = a.debug ? wall_clock64() : 0;
+            for (;;) {
+                w = __hip_atomic_load(a.state + T * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = (w >> 50) == (unsigned long long)a.seq && (w & kOsInclusive);
+                if (__ballot(!ok) == 0) break;
+                // lanes 15, 31, 47, 63 keep asking for their groups; the others wait for them
+                for (;;) {
+                    bool gok = true;
+                    if ((lane & 15) == 15) {
+                        const unsigned long long v = __hip_atomic_load(a.state + T * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gok = (v >> 50) == (unsigned long long)a.seq && (v & kOsInclusive);
+                    }
+                    if (__ballot(!gok) == 0) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            gbase[threadIdx.x] = a.bases[threadIdx.x] + (int64_t)(w & kOsValueMask);
+            if (a.debug) { t_poll += wall_clock64() - tp0; ++n_tiles; }
+        }
+        if (threadIdx.x == 0) tile_s[par] = drawn;
+        __syncthreads();
+        unsigned int wb = 0;
+        for (int w = 0; w < wave; ++w) wb += wsum[w];
+        dbase[threadIdx.x] = wb + inc - total_c;
+        const int64_t Tnn = (int64_t)uniform64((uint64_t)tile_s[par]);
+        __syncthreads();
+        // d. local stable sort by digit into LDS
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (r0 + 64 * j < count) {
+                const int dg = (int)(dr[j] & 255u);
+                const int pos = (int)(dbase[dg] + whist[wave][dg]) + (int)(dr[j] >> 8);
+                lkeys[pos] = X.key[j];
+                lidx[pos] = X.idx[j];
+                ldig[pos] = (uint8_t)dg;
+            }
+        }
+        __syncthreads();
+        // the tile after the next one: into the registers the current tile has left; in flight during the write-out and the next count
+        if (Tnn < a.ntiles) load(Tnn, X);
+        for (int t = threadIdx.x; t < count; t += kBlock) {
+            const int d = ldig[t];
+            const int64_t dst = gbase[d] + (t - (int)dbase[d]);
+            __builtin_nontemporal_store(lkeys[t], as_global_mut<uint64_t>(a.keys_out) + dst);
+            __builtin_nontemporal_store(lidx[t], as_global_mut<uint32_t>(a.idx_out) + dst);
+        }
+        __syncthreads();
+        T = Tn; Tn = Tnn; total_c = total_n;
+        return T < a.ntiles;
+    };
+    for (;;) {
+        if (!step(A, B)) break;
+        if (!step(B, A)) break;
+    }
+    if (a.debug && threadIdx.x == 0) { atomicAdd(a.debug + 0, t_poll); atomicAdd(a.debug + 1, wall_clock64() - t_loop); atomicAdd(a.debug + 5, n_tiles); }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Static ranges: block b owns the contiguous tiles [b * tpb, (b + 1) * tpb).  A count pass gives every block its digit counts
 // (sr_hist_kernel, keys only: 8 bytes per row), one scan turns them into where each block's part of each digit's run starts,
 // and the scatter walks its tiles in order carrying the running offsets in LDS: no block ever waits for another one; the next
@@ -423,6 +672,11 @@ hipError_t launch_os_scatter(const OsPassArgs& a, hipStream_t s) {
     if (grid <= 0) return hipSuccess;
     OsPassArgs b = a;
     if (b.mask == 0) b.mask = 255;
+    if (b.class_tickets) {      // round 6: counts published an iteration ahead, offsets from scanner blocks
+        b.nclass = (int32_t)(grid < 64 ? grid : 64);
+        hipLaunchKernelGGL((os_scatter3_kernel<kOsItems>), dim3((unsigned)(grid + kOsScanBlocks)), dim3(kBlock), 0, s, b);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((os_scatter_kernel<kOsItems>), dim3((unsigned)grid), dim3(kBlock), 0, s, b);
     return hipGetLastError();
 }

@@ -691,6 +691,30 @@ def test_sort_to_indices(gpu, ora, dtype):
                 assert np.array_equal(got, exp), f"sort dtype={dtype} lens={lens} desc={d} ncols={len(cols)}"
 
 
+@pytest.mark.parametrize("dtype", [A.I64, A.F64, A.I32])
+def test_sort_digit_passes_with_scanner_blocks(gpu, ora, dtype):
+    """rdf_set_option("sort_pipe", 1): the digit passes publish a tile's counts one iteration before its offsets are asked for and
+    take the offsets from scanner blocks (os_scatter3_kernel, round 6; measured slower than the look-back kernel and not the default —
+    kept as the A/B partner, so it is held to the same oracle): several tiles per block, a ragged last tile, NULL keys (the
+    NULLs-last pass), ties, descending, two key columns."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(1300 + dtype)
+    try:
+        lib.set_option("sort_pipe", 1)
+        for lens, nf in [([300_000, 1, 123_457], 0.05), ([2_500_000], 0.0)]:
+            kind = "special" if dtype == A.F64 else "extreme"
+            k1 = make_chunks(rng, dtype, lens, nf, 3, kind)
+            k2 = make_chunks(rng, A.I16, lens, 0.0, 0, "plain")
+            for ch in k2:
+                ch.values[:] = ch.values % 3
+            for cols, d in (([k1], [False]), ([k2, k1], [True, False])):
+                got = gpu.sort_to_indices(cols, d).to_numpy()
+                exp = ora.sort_to_indices(cols, d).to_numpy()
+                assert np.array_equal(got, exp), f"sort_pipe=1 dtype={dtype} lens={lens} desc={d}"
+    finally:
+        lib.set_option("sort_pipe", 0)
+
+
 @pytest.mark.parametrize("ngroups,n", [(20_000, 150_000), (300_000, 700_000), (1_300_000, 2_000_000)])
 def test_groupby_partitioned_high_cardinality(gpu, ora, ngroups, n):
     """More than 1024 groups: records are scattered once on 9 hash bits (default) — or radix-sorted in 1-2 passes (the
