@@ -2567,7 +2567,7 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
             roomy = dtype_size(cols[(int64_t)k * nchunks].dtype) == es0;
             for (int64_t c = 0; c < nchunks && roomy; ++c) roomy = outs[(int64_t)k * nchunks + c].capacity >= mask[c].length;
         }
-        if (roomy && rows_total >= nchunks * (int64_t)ctx.opt_filter_block_rows) return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0);
+        if (roomy && (rows_total + nchunks - 1) / nchunks >= (int64_t)ctx.opt_filter_block_rows) return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0);
     }
     RDF_TRY(filter_prepare(fp, cols, ncols, mask, nchunks, totals));
     for (int k = 0; k < ncols; ++k)

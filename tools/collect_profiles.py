@@ -64,7 +64,8 @@ def main():
                  "kernels_1e9_microbench.jsonl", "shapes_2p5e8.jsonl", "ubench_scatter.txt", "frames_1e9.jsonl", "ingest.jsonl", "bytes_2p5e8.jsonl", "beyond_catalogs_2p5e8.jsonl",
                  "rccl_one_rank.jsonl", "c4_total_rows_1e9.json", "rccl_one_rank_torch.jsonl", "example_dist.txt", "stream_16GB.jsonl", "stream_4GB_hbm_left_1p5GB.jsonl", "ubench_stream.txt",
                  "tilewalk.jsonl", "stream_sinks_16GB.jsonl", "stream_sinks_4GB_hbm_left_1p5GB.jsonl", "rccl_one_rank_fused_combine.jsonl", "groupby_1p25e8_rows.jsonl",
-                 "groupby_1p25e8_rows_round4_build.jsonl", "gb_window.jsonl", "ubench_streams.txt", "link_probe.jsonl", "filter_frame_long_batches.jsonl", "join_table_ab.jsonl"):
+                 "groupby_1p25e8_rows_round4_build.jsonl", "gb_window.jsonl", "ubench_streams.txt", "link_probe.jsonl", "filter_frame_long_batches.jsonl", "join_table_ab.jsonl",
+                 "ref_bench.json", "probe_stream.jsonl", "memory_model_same_box.jsonl", "memory_model_same_box_kernel_stats.csv", "ubench_compact.jsonl", "ubench_take_binned.jsonl"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
     agree = None
@@ -112,7 +113,9 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
         import bench as _bench     # the stamp bench.py compares: figures measured on other kernel sources are not reported
         json.dump({"rows": rows, "validity": False, "hbm_bytes_per_launch": hbm, "source": f"profiles/{rnd}_bench_1e9_pmc_summary.json",
-                   "kernel_sources_sha": _bench.kernel_sources_sha(), "kernel_sources": list(_bench.KERNEL_SOURCES), "workloads": workloads},
+                   "kernel_sources_sha": (open(os.path.join(src, "kernel_sources_sha.txt")).read().strip() if os.path.exists(os.path.join(src, "kernel_sources_sha.txt"))
+                                          else _bench.kernel_sources_sha()),      # (taken on the GPU box by profile_round.sh; round 6's run predates that line: its tree is this one)
+                   "kernel_sources": list(_bench.KERNEL_SOURCES), "workloads": workloads},
                   open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
     valu = {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_valu_*"))):

@@ -9,6 +9,8 @@ PART=${2:-all}      # all | micro (only the per-entry counter passes of step 3b)
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profile_$R
 mkdir -p "$OUT"
+# the kernel sources these measurements are taken on (bench.py reports a committed traffic figure only for the same sources)
+( cd "$REPO" && python -c "import bench; print(bench.kernel_sources_sha())" > "$OUT/kernel_sources_sha.txt" 2>/dev/null )
 cd /tmp && export TMPDIR=/tmp
 pmc() {   # pmc <tag> <command...>: FETCH_SIZE and WRITE_SIZE of every kernel of the command, two passes
     local tag=$1; shift
@@ -95,14 +97,39 @@ python "$REPO/tools/bench_kernels.py" --rows 125000000 --steps 5 --only groupby_
 RDF_LIB_PATH="$REPO/rust_dataframe_amd/librdf_base_r04.so" python "$REPO/tools/bench_kernels.py" --rows 125000000 --steps 5 --only groupby_sum_1000000_groups,groupby_count_1000000_groups 2>> "$OUT/kernels.err" | grep kernel_ms > "$OUT/groupby_1p25e8_rows_round4_build.jsonl"
 python "$REPO/tools/exp_gb_window.py" --windows 8,32,64,128,256 --reps 2 2>> "$OUT/kernels.err" > "$OUT/gb_window.jsonl"
 grep '"probe"' "$OUT/stream_sinks.err" | head -1 > "$OUT/link_probe.jsonl"       # each direction alone, both at once (bench_stream_sinks.py prints it first)
-# rdf_filter_frame on long batches: the one pass (look-back 3 = default, 1 = round 4's) against the three passes
-rm -f "$OUT/filter_frame_long_batches.jsonl"
-for cr in 16777216 1000000000; do for lb in 3 1; do
-    python "$REPO/tools/bench_frames.py" --rows 1000000000 --chunk-rows $cr --steps 5 --lookback $lb --fused 2 --only filter_frame 2>> "$OUT/frames.err" | grep kernel_ms | sed "s/^{/{\"chunk_rows\": $cr, \"lookback\": $lb, /" >> "$OUT/filter_frame_long_batches.jsonl"
-done; done
+# (rdf_filter_frame on long batches: step 3f)
 # equi-join: the scan-placed table (default) against the compare-and-swap table
 python "$REPO/tools/bench_kernels.py" --rows 1000000000 --steps 3 --only join_inner_1e8_x_1e7,join_inner_1e8_x_1e7_cas_table,join_inner_1e8_x_1e8,join_inner_1e8_x_1e8_cas_table 2>> "$OUT/kernels.err" | grep kernel_ms > "$OUT/join_table_ab.jsonl"
 if [ -x "$REPO/tools/ubench_streams.bin" ]; then timeout 300 "$REPO/tools/ubench_streams.bin" > "$OUT/ubench_streams.txt" 2>&1; fi
+fi
+# 3f. round 6: the one-pass filter on block tiles (rdf_bfilter.hip) against the wave-tile kernel by batch length, its HBM counters on ONE
+#     batch of 1e9 rows, the mask-given form, the design probe (tools/ubench_compact.bin), the bare-stream probes the memory model is
+#     fitted on (rdf_probe_stream), the reference's own benchmark shape, the take through page-sorted pairs, the two digit-pass kernels
+if [ "$PART" = "all" ] || [ "$PART" = "r6" ]; then
+rm -f "$OUT/filter_frame_long_batches.jsonl"
+for cr in 8192 65536 1048576 16777216 1000000000; do for b in 1 0; do
+    python "$REPO/tools/bench_frames.py" --rows 1000000000 --chunk-rows $cr --steps 5 --block $b --only filter_frame_1col,filter_frame_2col,filter_frame_4col 2>> "$OUT/frames.err" | grep kernel_ms | sed "s/^{/{\"chunk_rows\": $cr, \"filter_block\": $b, /" >> "$OUT/filter_frame_long_batches.jsonl"
+done; done
+pmc frames_long_filter_frame_1col python "$REPO/tools/bench_frames.py" --rows 1000000000 --chunk-rows 1000000000 --steps 2 --only filter_frame_1col
+pmc frames_long_filter_frame_4col python "$REPO/tools/bench_frames.py" --rows 1000000000 --chunk-rows 1000000000 --steps 2 --only filter_frame_4col
+python "$REPO/bench.py" --workload ref_bench 2>> "$OUT/bench_1e9.err" | tail -1 > "$OUT/ref_bench.json"
+python - > "$OUT/probe_stream.jsonl" 2>> "$OUT/kernels.err" <<PY
+import json, sys
+sys.path.insert(0, "$REPO")
+import torch
+from rust_dataframe_amd import lib
+lib.set_device(0)
+n = 1_000_000_000
+a = torch.empty(n, dtype=torch.float64, device="cuda"); b = torch.empty_like(a); c = torch.empty_like(a)
+a.uniform_(); b.uniform_(); torch.cuda.synchronize()
+for kind, name in ((0, "read"), (1, "copy"), (2, "two reads + one write")):
+    g, shape = lib.probe_stream(kind, a.data_ptr(), b.data_ptr(), c.data_ptr(), n * 8, 7)
+    print(json.dumps({"probe": name, "bytes_per_stream": n * 8, "GBps_of_bytes_moved": round(g, 1), "frac_of_8TBps": round(g / 8000.0, 3), "shape": shape}))
+PY
+mkdir -p "$OUT/model"; rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/model" -o m -- python "$REPO/tools/model_check.py" > "$OUT/memory_model_same_box.jsonl" 2>> "$OUT/kernels.err"
+cp "$(find "$OUT/model" -name '*kernel_stats.csv' | head -1)" "$OUT/memory_model_same_box_kernel_stats.csv" 2>/dev/null
+if [ -x "$REPO/tools/ubench_compact.bin" ]; then timeout 300 "$REPO/tools/ubench_compact.bin" 1e9 7 > "$OUT/ubench_compact.jsonl" 2>> "$OUT/kernels.err"; fi
+if [ -x "$REPO/tools/ubench_take_binned.bin" ]; then timeout 300 "$REPO/tools/ubench_take_binned.bin" > "$OUT/ubench_take_binned.jsonl" 2>> "$OUT/kernels.err"; fi
 fi
 # 4. the scatter micro-benchmark behind the C4 bound
 if [ -x "$REPO/tools/ubench_scatter.bin" ]; then timeout 300 "$REPO/tools/ubench_scatter.bin" > "$OUT/ubench_scatter.txt" 2>&1; fi
