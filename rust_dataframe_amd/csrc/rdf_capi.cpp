@@ -2432,7 +2432,7 @@ rdf_status filter_validate(const rdf_array* cols, int ncols, const rdf_array* ma
 
 // Column::filter (src/table.rs:97-107,213-215) with the mask given, device-resident, in one pass on block tiles: groups of up to
 // kMaxFilterCols columns per launch; lengths and null counts come back from the kernel.
-rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols, const rdf_array* mask, int64_t nchunks, rdf_out* outs, int es0) {
+rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols, const rdf_array* mask, int64_t nchunks, rdf_out* outs, int es0, bool short_chunks) {
     Ctx& ctx = g_ctx;
     std::vector<int64_t> unused;
     RDF_TRY(filter_prepare(fp, cols, ncols, mask, nchunks, unused, false));
@@ -2456,14 +2456,14 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
     HIP_TRY(hipMemcpyAsync(fp.tb.dev + fp.o_outs, ctx.pinned + fp.pin_off, sizeof(DevOutChunk) * nout, hipMemcpyHostToDevice, ctx.stream));
     fp.pin_off += (sizeof(DevOutChunk) * nout + 255) & ~(size_t)255;
     {
-        KernelTimer kt;
+        std::unique_ptr<KernelTimer> kt;      // (started at the first launch: the tile tables of a million-chunk frame are a millisecond of host work the device would sit out inside the timed region)
         int table_rows = 0;
         const int64_t* d_tile_start = nullptr;
         int64_t ntiles = 0;
         uint64_t tile_inv = 0;
         for (int g = 0; g < ncols; g += kMaxFilterCols) {
             const int nc = ncols - g < kMaxFilterCols ? ncols - g : kMaxFilterCols;
-            const int tr = bfilter_tile_rows(es0, nc);
+            const int tr = short_chunks ? kWDmaTile : bfilter_tile_rows(es0, nc);
             if (tr != table_rows) {           // (a last group of one column has longer tiles than the groups before it)
                 std::vector<int64_t> ts((size_t)nchunks + 1, 0);
                 for (int64_t c = 0; c < nchunks; ++c) ts[(size_t)c + 1] = ts[(size_t)c] + (fp.clen[(size_t)c] + tr - 1) / tr;
@@ -2497,14 +2497,24 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
                 wa.esize[k] = es0;
                 if (nchunks == 1) { wa.cols0[k] = fp.in.dev[(size_t)(1 + g + k)]; wa.outs0[k] = dev_outs[(size_t)(g + k)]; }
             }
+            if (short_chunks) {
+                // the readers' batches: a chunk is ONE wave tile, its kept rows start its output — the wave-tile LDS-DMA kernel without
+                // the count and scan passes in front of it (it writes the lengths itself)
+                wa.out_len = d_len;
+                wa.prefetch = 1;
+                if (!kt) kt.reset(new KernelTimer());
+                HIP_TRY(launch_fcompact(wa, kWDmaTile, ctx.stream));
+                continue;
+            }
             ba.nterms = 0;
             ba.out_len = d_len;
             RDF_TRY(bfilter_scratch(ba));
+            if (!kt) kt.reset(new KernelTimer());
             HIP_TRY(launch_bfilter(ba, es0, nulls, ctx.stream));
         }
-        kt.stop();
+        if (kt) kt->stop();
     }
-    ctx.last_kernel = "bfilter_kernel";
+    ctx.last_kernel = short_chunks ? "fcompact_dma_kernel (one pass)" : "bfilter_kernel";
     RDF_TRY(pinned_reserve(fp.pin_off + 8 * (nout + (size_t)nchunks) + 256));
     int64_t* pin = (int64_t*)(ctx.pinned + fp.pin_off);
     HIP_TRY(hipMemcpyAsync(pin, d_nullc, 8 * (nout + (size_t)nchunks), hipMemcpyDeviceToHost, ctx.stream));
@@ -2567,7 +2577,12 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
             roomy = dtype_size(cols[(int64_t)k * nchunks].dtype) == es0;
             for (int64_t c = 0; c < nchunks && roomy; ++c) roomy = outs[(int64_t)k * nchunks + c].capacity >= mask[c].length;
         }
-        if (roomy && (rows_total + nchunks - 1) / nchunks >= (int64_t)ctx.opt_filter_block_rows) return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0);
+        if (roomy && (rows_total + nchunks - 1) / nchunks >= (int64_t)ctx.opt_filter_block_rows) return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, false);
+        // ... and the readers' batches (no chunk longer than one wave tile of 1024 rows, most of them full): one pass as well
+        int64_t max_len = 0;
+        for (int64_t c = 0; c < nchunks; ++c) max_len = std::max<int64_t>(max_len, mask[c].length);
+        if (roomy && max_len <= kWDmaTile && rows_total >= nchunks * (int64_t)(kWDmaTile * 3 / 4) && ctx.opt_filter_gen == 2)
+            return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, true);
     }
     RDF_TRY(filter_prepare(fp, cols, ncols, mask, nchunks, totals));
     for (int k = 0; k < ncols; ++k)

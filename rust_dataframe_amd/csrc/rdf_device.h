@@ -198,6 +198,7 @@ struct FilterWArgs {
     int32_t            esize[kMaxFilterCols];
     DevChunkCol        cols0[kMaxFilterCols];   // nchunks == 1
     DevOutChunk        outs0[kMaxFilterCols];
+    int64_t*           out_len;          // fcompact_dma_kernel with tile_scan == nullptr (every chunk is ONE tile: its kept rows start its output): [nchunks] kept rows per chunk (pre-zeroed)
 };
 // DataFrame::filter in ONE pass (rdf_filter_frame, predicates of the form `col CMP literal [AND|OR col CMP literal]`): the
 // predicate is evaluated on the tile the compaction has just brought into LDS — no mask is written, counted or read back —

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kBlock, 4) void fcompact_dma_kernel(const FilterWAr
     auto locate_all = [&](int64_t tile) -> Meta {
         Meta mt;
         mt.t = wlocate<WW>(a, tile);
-        mt.wave_out = one ? a.tile_scan[tile] : a.tile_scan[tile] - a.tile_scan[a.t.chunk_tile_start[mt.t.c]];
+        mt.wave_out = !a.tile_scan ? 0 : one ? a.tile_scan[tile] : a.tile_scan[tile] - a.tile_scan[a.t.chunk_tile_start[mt.t.c]];      // (no scan: every chunk is one tile)
         mt.m = one ? a.mask0 : a.t.mask[mt.t.c];
         mt.c0 = one ? a.cols0[0] : a.cols[mt.t.c];
         return mt;
@@ -426,6 +426,7 @@ __global__ __launch_bounds__(kBlock, 4) void fcompact_dma_kernel(const FilterWAr
 #pragma unroll
         for (int d = 1; d < WW; d <<= 1) cnt += __shfl_xor(cnt, d);
         cnt = __builtin_amdgcn_readfirstlane(cnt);
+        if (a.out_len && lane == 0 && cnt) a.out_len[t.c] = cnt;      // (one-pass Column::filter over one-tile chunks: the count never existed before)
         if (cnt == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; }   // the DMA must not land in the next tile's buffer
 #pragma unroll 1
         for (int k = 0; k < a.ncols; ++k) {

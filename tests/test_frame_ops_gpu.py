@@ -591,3 +591,48 @@ def test_filter_columns_device_block_tiles(gpu, ora, lens, off, nf, dts):
                 check(bufs, outs, f"counted sel={sel}")
         finally:
             lib.set_option("filter_block_rows", 8192)
+
+
+@pytest.mark.parametrize("lens,off,nf", [([1024] * 40 + [500], 0, 0.1), ([1024, 0, 1024, 777, 1024], 3, 0.0), ([1000] * 9, 0, 0.2)])
+@pytest.mark.parametrize("dts", [[A.F64], [A.I64, A.F64, A.U64], [A.F32, A.I32]])
+def test_filter_columns_device_one_pass_reader_batches(gpu, ora, lens, off, nf, dts):
+    """Column::filter over the readers' 1024-row batches, device-resident, outputs that can hold every row: a chunk is ONE wave tile
+    whose kept rows start its output, so the count and scan passes are skipped and the LDS-DMA kernel writes the lengths itself
+    (round 6).  Same oracle, same bytes as the counted path."""
+    import torch
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(6200 + len(lens) + len(dts))
+    host = [make_chunks(rng, dt, lens, nf if k % 2 == 0 else 0.0, (off + k) % 7, "extreme" if dt not in (A.F64, A.F32) else "unit") for k, dt in enumerate(dts)]
+    for sel in (0.5, 0.02, 1.0):
+        mask = [A.HostArray.from_numpy(rng.uniform(size=n) < sel, valid=(rng.uniform(size=n) > 0.1) if nf else None, offset=(off * 3) % 11, dtype=A.BOOL, rng=rng)
+                for n in lens]
+        exp = ora.filter_columns(host, mask)
+        dev, keep = to_device(host)
+        dmask, keep2 = to_device([mask])
+        bufs, outs = [], []
+        for k, dt in enumerate(dts):
+            es = np.dtype(A.NP_OF[dt]).itemsize
+            col = []
+            for c, n in enumerate(lens):
+                vb = torch.full((n * es + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+                bb = torch.full(((n + 63) // 64 * 8 + 64,), 0xAB, dtype=torch.uint8, device="cuda") if host[k][c].validity is not None else None
+                bufs.append((vb, bb))
+                col.append(A.DeviceArray(vb.data_ptr(), bb.data_ptr() if bb is not None else None, 0, 0, dt, 0, keep=(vb, bb), capacity=n))
+            outs.append(col)
+        torch.cuda.synchronize()
+        gpu.filter_columns(dev, dmask[0], outs)
+        assert lib.last_kernel() == "fcompact_dma_kernel (one pass)", lib.last_kernel()
+        lib.synchronize()
+        i = 0
+        for k, dt in enumerate(dts):
+            es = np.dtype(A.NP_OF[dt]).itemsize
+            for c in range(len(lens)):
+                ee, o, (vb, bb) = exp[k][c], outs[k][c], bufs[i]
+                i += 1
+                assert o.length == ee.length and o.null_count == ee.null_count, (sel, k, c, o.length, ee.length, o.null_count, ee.null_count)
+                gv = vb.cpu().numpy()[:ee.length * es].view(A.NP_OF[dt])
+                m = ee.valid_mask()
+                if bb is not None:
+                    gm = np.unpackbits(bb.cpu().numpy()[:(ee.length + 7) // 8], bitorder="little")[:ee.length].astype(bool)
+                    assert np.array_equal(gm, m), (sel, k, c)
+                assert np.array_equal(gv[m].view(np.uint8), ee.to_numpy()[m].view(np.uint8)), (sel, k, c)
