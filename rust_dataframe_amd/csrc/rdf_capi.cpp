@@ -3797,7 +3797,12 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
     void* ptable = nullptr;
     int tbits = 10;
     if (use_table && hashed) {
-        while (((int64_t)1 << tbits) < 2 * nrv) ++tbits;
+        // the table holds the DISTINCT build keys: no more of them than rows, and no more than the key range spans — a build side of
+        // 1e8 rows over a few dozen dictionary codes gets a table of 1024 slots, not 2e8 whose empty stretches a few lanes would
+        // have to write one slot after another (the placement fills the gaps in front of its keys itself)
+        int64_t nd = nrv;
+        if (bkmax >= bkmin && bkmax - bkmin < (uint64_t)nrv) nd = (int64_t)(bkmax - bkmin) + 1;
+        while (((int64_t)1 << tbits) < 2 * nd) ++tbits;
         const int64_t cap = ((int64_t)1 << tbits) + (1 << 16);      // no wrap-around: the last home slot's cluster runs into the margin
         RDF_TRY(arena_alloc((size_t)cap * 16 + 64, &ptable));      // (not cleared: the placement writes every slot, the empty ones included)
         JoinPlaceArgs pa;

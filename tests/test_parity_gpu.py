@@ -1283,7 +1283,7 @@ def test_equijoin_bucket_index_edge_cases(gpu, ora, how):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["distinct", "duplicates", "crowded_slots"])
+@pytest.mark.parametrize("shape", ["distinct", "duplicates", "few_keys", "crowded_slots"])
 def test_equijoin_table_placed_by_scan(gpu, shape):
     """Round 5: the table of distinct build keys is laid out without atomics — the build side sorted by key * golden ratio, slot(r) =
     r + prefix-max(home - r) over the distinct keys (three kernels: per-tile aggregates, one block scanning them, placement).  Sizes
@@ -1297,6 +1297,12 @@ def test_equijoin_table_placed_by_scan(gpu, shape):
         nb, npb = 6_000_000, 3_000_000
         bk = rng.permutation(nb).astype(np.int64) * 3
         pk = rng.integers(0, 3 * nb, npb).astype(np.int64)
+    elif shape == "few_keys":
+        # a build side of 3e6 rows over 37 dictionary codes: the table is sized from the key RANGE (64 slots), not from the rows (round 6:
+        # 6e6 slots whose empty stretches a handful of lanes had to write one after another); 1 probe row in 100 finds a key
+        nb, npb = 3_000_000, 2_000
+        bk = rng.integers(0, 37, nb).astype(np.int64)
+        pk = rng.integers(0, 3700, npb).astype(np.int64)
     elif shape == "duplicates":
         nb, npb = 5_000_000, 500_000
         bk = rng.integers(0, 1_000_000, nb).astype(np.int64)          # ~5 build rows per key
