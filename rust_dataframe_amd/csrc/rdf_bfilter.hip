@@ -46,11 +46,15 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 
 // The scanner: tile_state[t] goes  0 -> kBfCount | rows (written by the tile's block) -> kBfPrefix | rows of the FRAME in front of
 // tile t (written here).  Counts are taken as far as they have been published without a gap, up to 512 tiles per round trip.
-__device__ __forceinline__ void bf_scanner(unsigned long long* state, int64_t ntiles) {
+// (every wait of this kernel gives up after kBfWaitSeconds without progress and raises abort_flag: the other waiters then leave too)
+constexpr unsigned long long kBfWaitTicks = (unsigned long long)kBfWaitSeconds * 100000000ull;      // wall_clock64: 100 MHz
+__device__ __forceinline__ bool bf_aborted(unsigned int* flag) { return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
+__device__ __forceinline__ void bf_scanner(unsigned long long* state, int64_t ntiles, unsigned int* abort_flag) {
     const int lane = threadIdx.x & 63;
     constexpr int K = 8;
     int64_t cur = 0;
     unsigned long long running = 0;
+    unsigned long long idle_since = 0;
     while (cur < ntiles) {
         unsigned long long w[K];
 #pragma unroll
@@ -71,7 +75,15 @@ __device__ __forceinline__ void bf_scanner(unsigned long long* state, int64_t nt
             base += f;
             if (f < 64) break;
         }
-        if (base == cur) __builtin_amdgcn_s_sleep(1);
+        if (base == cur) {
+            __builtin_amdgcn_s_sleep(1);
+            const unsigned long long now = wall_clock64();
+            if (idle_since == 0) idle_since = now;
+            else if (now - idle_since > kBfWaitTicks || bf_aborted(abort_flag)) {       // (wave-uniform: every lane reads the same clock and flag)
+                if (lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        } else idle_since = 0;
         cur = base;
     }
 }
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
     __shared__ int64_t sh_base, sh_tile[2];
     const FilterWArgs& fa = a.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (blockIdx.x == 0) { if (wave == 0) bf_scanner(a.tile_state, fa.t.ntiles); return; }
+    if (blockIdx.x == 0) { if (wave == 0 && !a.stall_test) bf_scanner(a.tile_state, fa.t.ntiles, a.abort_flag); return; }
     const int64_t ntiles = fa.t.ntiles;
     const bool one = fa.t.nchunks == 1;
     const int ncols = fa.ncols;
@@ -340,13 +352,27 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
         if (tid == 0) {
             int64_t base = 0;               // a batch's first tile starts the batch's output
             if (tc.first != Tc) {
-                unsigned long long w;
-                for (;;) { w = bf_ld(a.tile_state + Tc); if ((w >> 62) == 2) break; __builtin_amdgcn_s_sleep(2); }
+                unsigned long long w, t0 = 0;
+                int spins = 0;
+                auto wait_for = [&](const unsigned long long* p) __attribute__((always_inline)) {
+                    for (;;) {
+                        w = bf_ld(p);
+                        if ((w >> 62) == 2) return;
+                        __builtin_amdgcn_s_sleep(2);
+                        if ((++spins & 255) == 0) {          // every ~50 us of waiting: the clock and the flag
+                            const unsigned long long now = wall_clock64();
+                            if (t0 == 0) t0 = now;
+                            if (now - t0 > kBfWaitTicks || bf_aborted(a.abort_flag)) { __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); w = 0; return; }
+                        }
+                    }
+                };
+                wait_for(a.tile_state + Tc);
                 base = (int64_t)(w & kBfValue);
                 // the scanner's prefixes count the rows of the FRAME: take off what lies in front of the batch (its first tile was
                 // passed before this one)
-                for (;;) { w = bf_ld(a.tile_state + tc.first); if ((w >> 62) == 2) break; __builtin_amdgcn_s_sleep(2); }
+                wait_for(a.tile_state + tc.first);
                 base -= (int64_t)(w & kBfValue);
+                if (base < 0 || base > tc.r0) base = 0;      // (only after an abort: keep the stores inside the batch's output)
             }
             sh_base = base;
             sh_tile[par] = drawn;

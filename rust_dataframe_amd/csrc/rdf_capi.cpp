@@ -2283,6 +2283,17 @@ rdf_status bfilter_scratch(BFilterArgs& ba) {
     HIP_TRY(hipMemsetAsync(ps, 0, sizeof(unsigned long long) * words, ctx.stream));
     ba.tile_state = (unsigned long long*)ps;
     ba.ticket = (unsigned int*)((unsigned long long*)ps + (size_t)ntiles + 8);
+    ba.abort_flag = (unsigned int*)((unsigned long long*)ps + (size_t)ntiles + 4);      // (one of the 8 spare words between the two)
+    ba.stall_test = ctx.opt_filter_block == 3 ? 1 : 0;
+    return RDF_OK;
+}
+// after the kernel (stream already synchronised by the caller's result copy): did a wait give up?
+rdf_status bfilter_check(const BFilterArgs& ba) {
+    Ctx& ctx = g_ctx;
+    unsigned int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, ba.abort_flag, 4, hipMemcpyDeviceToHost, ctx.stream));
+    HIP_TRY(hipStreamSynchronize(ctx.stream));
+    if (flag) return fail(RDF_DEVICE_ERROR, "filter: a tile waited %d s for its offset (the prefix of the block-tile kernel made no progress); rdf_set_option(\"filter_block\", 0) takes the wave-tile kernels", kBfWaitSeconds);
     return RDF_OK;
 }
 
@@ -2455,6 +2466,7 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
     memcpy(ctx.pinned + fp.pin_off, dev_outs.data(), sizeof(DevOutChunk) * nout);
     HIP_TRY(hipMemcpyAsync(fp.tb.dev + fp.o_outs, ctx.pinned + fp.pin_off, sizeof(DevOutChunk) * nout, hipMemcpyHostToDevice, ctx.stream));
     fp.pin_off += (sizeof(DevOutChunk) * nout + 255) & ~(size_t)255;
+    std::vector<BFilterArgs> launched;
     {
         std::unique_ptr<KernelTimer> kt;      // (started at the first launch: the tile tables of a million-chunk frame are a millisecond of host work the device would sit out inside the timed region)
         int table_rows = 0;
@@ -2511,6 +2523,7 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
             RDF_TRY(bfilter_scratch(ba));
             if (!kt) kt.reset(new KernelTimer());
             HIP_TRY(launch_bfilter(ba, es0, nulls, ctx.stream));
+            launched.push_back(ba);
         }
         if (kt) kt->stop();
     }
@@ -2519,6 +2532,7 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
     int64_t* pin = (int64_t*)(ctx.pinned + fp.pin_off);
     HIP_TRY(hipMemcpyAsync(pin, d_nullc, 8 * (nout + (size_t)nchunks), hipMemcpyDeviceToHost, ctx.stream));
     HIP_TRY(hipStreamSynchronize(ctx.stream));
+    for (const BFilterArgs& b : launched) RDF_TRY(bfilter_check(b));
     const int64_t* len = pin + nout;
     for (size_t i = 0; i < nout; ++i) {
         const int64_t n = len[i % (size_t)nchunks];
@@ -4373,7 +4387,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "gspec_blocks_per_cu") == 0) g_ctx.opt_gspec_blocks = (int)value;
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
-    else if (strcmp(name, "filter_block") == 0) g_ctx.opt_filter_block = value != 0;
+    else if (strcmp(name, "filter_block") == 0) g_ctx.opt_filter_block = value == 3 ? 3 : value != 0;      // (3: tests — the scanner wave stays idle, every wait must time out)
     else if (strcmp(name, "filter_block_rows") == 0) g_ctx.opt_filter_block_rows = value < 1 ? 1 : (int)value;
     else if (strcmp(name, "filter_lookback") == 0) g_ctx.opt_filter_lookback = value == 1 ? 1 : value == 2 ? 2 : 3;
     else if (strcmp(name, "comm_max_bytes") == 0) g_ctx.opt_comm_max_bytes = value;

@@ -234,7 +234,10 @@ struct BFilterArgs {
     int64_t*            out_len;             // [nchunks] kept rows per batch (pre-zeroed), or nullptr
     unsigned long long* tile_state;          // (pre-zeroed) [ntiles]: 0 -> count -> prefix
     unsigned int*       ticket;              // (pre-zeroed) 64 counters, 128 bytes apart
+    int32_t             stall_test, pad;     // tests: 1 = the scanner does nothing (every wait must give up and the call must fail, not hang)
+    unsigned int*       abort_flag;          // (pre-zeroed) set by a wait that saw no progress for kBfWaitSeconds: every waiter then leaves, the host reports a device error — a stuck prefix must cost a call, not the GPU
 };
+constexpr int kBfWaitSeconds = 4;
 int bfilter_tile_rows(int esize, int ncols);
 hipError_t launch_bfilter(const BFilterArgs& a, int esize, bool nulls, hipStream_t s);
 hipError_t launch_fcount(const FilterWArgs& a, int tile_rows, int64_t* tile_counts, hipStream_t s);

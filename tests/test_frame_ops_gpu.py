@@ -636,3 +636,26 @@ def test_filter_columns_device_one_pass_reader_batches(gpu, ora, lens, off, nf, 
                     gm = np.unpackbits(bb.cpu().numpy()[:(ee.length + 7) // 8], bitorder="little")[:ee.length].astype(bool)
                     assert np.array_equal(gm, m), (sel, k, c)
                 assert np.array_equal(gv[m].view(np.uint8), ee.to_numpy()[m].view(np.uint8)), (sel, k, c)
+
+
+def test_filter_block_tiles_stuck_prefix_fails_the_call_not_the_gpu(gpu, ora):
+    """The block-tile kernel's tiles wait for a word another wave writes.  If that word never comes (here: `filter_block` 3 keeps
+    the scanner wave idle) every wait gives up after a few seconds, the call returns a device error, and the next call works."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(99)
+    host = [make_chunks(rng, A.F64, [100_000], 0.0, 0, "unit")]
+    dev, keep = to_device(host)
+    e = A.Expr()
+    root = e.op("gt", e.col(0), e.scalar(0.0))
+    with A.PinnedFrame(gpu, dev) as frame:
+        try:
+            lib.set_option("filter_block", 3)
+            with pytest.raises(A.RdfError) as ei:
+                gpu.filter_frame(frame, e, root)
+            assert ei.value.status == A.RDF_DEVICE_ERROR and "no progress" in str(ei.value)
+        finally:
+            lib.set_option("filter_block", 1)
+        out = gpu.filter_frame(frame, e, root)
+        exp = ora.filter_columns(host, ora.predicate(e, root, host))
+        match_unknown_nulls(frame_columns(out)[0], exp[0], "after the stuck call")
+        out.release()
