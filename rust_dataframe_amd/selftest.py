@@ -1,7 +1,8 @@
-"""First-contact check of the multi-GPU path on real peers (used by __graft_entry__.smoke() when more than one device is
+"""First-contact driver of the multi-GPU path on real peers (used by __graft_entry__.smoke() when more than one device is
 visible, and by tests): one RCCL communicator over the devices (rdf_comm_init_all), one host thread per rank, a hash GROUP BY
 whose partial groups cross xGMI (rdf_groupby_agg_dist), one distributed filter -> aggregate (rdf_pipeline_dist) with an EMPTY
-shard among the ranks — results handed back for the caller to hold against the oracle.  Nothing here is on the product path."""
+shard among the ranks.  It only drives the library and hands the results (and the inputs) back: the caller checks them
+(tests/multi_device_check.py).  Nothing here is on the product path."""
 import ctypes as C
 import threading
 
@@ -22,7 +23,7 @@ def _dev_array(L, ptrs, np_arr, dtype, capacity=None):
 
 def multi_device_groupby(lib, api, devices, rows=1_000_000, ngroups=50_000, seed=11, kind=None, timeout_s=300):
     """-> dict(keys, sums, counts: the union of the ranks' groups; per_rank_groups; pipeline: the distributed aggregate;
-    inputs: (keys, values) as numpy for the caller's oracle).  The last rank holds NO rows (an empty shard must still join)."""
+    inputs: (keys, values) as numpy for the caller's check).  The last rank holds NO rows (an empty shard must still join)."""
     world = len(devices)
     rng = np.random.default_rng(seed)
     keys = (rng.integers(0, ngroups, rows).astype(np.int64) * 1_000_003) - 7
@@ -75,21 +76,3 @@ def multi_device_groupby(lib, api, devices, rows=1_000_000, ngroups=50_000, seed
     return {"keys": np.concatenate([r[0] for r in res]), "sums": np.concatenate([r[1] for r in res]), "counts": np.concatenate([r[2] for r in res]),
             "per_rank_groups": [len(r[0]) for r in res], "pipeline": [r[3] for r in res], "stats": [r[4] for r in res],
             "inputs": (keys, vals), "rows_per_rank": [cuts[r + 1] - cuts[r] for r in range(world)]}
-
-
-def check_against_oracle(out, ora, rtol=1e-6):
-    """The union of the ranks' groups equals the oracle's GROUP BY over the unsharded rows (keys and counts exactly, sums within
-    rtol: north_star's f64 tolerance); every rank got the same distributed aggregate, equal to the oracle's."""
-    keys, vals = out["inputs"]
-    ok, ov, oc = ora.groupby_agg([[A.HostArray.from_numpy(keys)]], [A.HostArray.from_numpy(vals)], "sum", len(np.unique(keys)) + 8)
-    n = oc.length
-    ek, es, ec = ok[0].to_numpy()[:n], ov.to_numpy()[:n], oc.to_numpy()[:n]
-    o1, o2 = np.argsort(out["keys"]), np.argsort(ek)
-    assert len(out["keys"]) == n and np.array_equal(out["keys"][o1], ek[o2]), "group keys differ"
-    assert np.array_equal(out["counts"][o1], ec[o2]), "group counts differ"
-    assert np.allclose(out["sums"][o1], es[o2], rtol=rtol, atol=0), "group sums differ"
-    e = A.Expr()
-    exp = ora.pipeline(e, [[A.HostArray.from_numpy(keys)], [A.HostArray.from_numpy(vals)]], [e.col(1)], e.op("gt", e.col(1), e.scalar(0.5)))[0]
-    for s, c, mn, mx in out["pipeline"]:
-        assert c == exp.count and mn == exp.min and mx == exp.max and abs(s - exp.sum) <= rtol * abs(exp.sum), "distributed aggregate differs"
-    return True

@@ -447,8 +447,9 @@ def test_first_contact_selftest_on_the_peer_transport(eng, ora):
     communicator over all devices, one thread per rank, a hash GROUP BY across the ranks and a distributed filter -> aggregate, the
     LAST rank holding no rows) — here on four in-process ranks of the one GPU, against the oracle."""
     from rust_dataframe_amd import selftest
+    import multi_device_check
     lib, api = eng
     out = selftest.multi_device_groupby(lib, api, [0, 0, 0, 0], rows=300_000, ngroups=20_000, kind=A.COMM_PEER)
     assert out["rows_per_rank"][-1] == 0 and sum(out["rows_per_rank"]) == 300_000
-    assert selftest.check_against_oracle(out, ora)
+    assert multi_device_check.check_against_oracle(out, ora)
     lib.set_device(0)
