@@ -552,10 +552,13 @@ def test_filter_columns_device_block_tiles(gpu, ora, lens, off, nf, dts):
                 es = np.dtype(A.NP_OF[dt]).itemsize
                 col = []
                 for c, n in enumerate(rows):
-                    vb = torch.full((n * es + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+                    # every other chunk's values start one element past a 16-byte boundary: the stores' scalar head / tail
+                    skew = es if (k + c) % 2 else 0
+                    vb0 = torch.full((n * es + 96,), 0xAB, dtype=torch.uint8, device="cuda")
+                    vb = vb0[skew:]
                     bb = torch.full(((n + 63) // 64 * 8 + 64,), 0xAB, dtype=torch.uint8, device="cuda") if host[k][c].validity is not None else None
                     bufs.append((vb, bb))
-                    col.append(A.DeviceArray(vb.data_ptr(), bb.data_ptr() if bb is not None else None, 0, 0, dt, 0, keep=(vb, bb), capacity=n))
+                    col.append(A.DeviceArray(vb0.data_ptr() + skew, bb.data_ptr() if bb is not None else None, 0, 0, dt, 0, keep=(vb0, bb), capacity=n))
                 outs.append(col)
             torch.cuda.synchronize()
             return bufs, outs
