@@ -646,8 +646,7 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * "filter_fused" (rdf_filter_frame with a `column CMP literal [AND | OR column CMP literal]` predicate over 4- / 8-byte columns: 1 = the
  * predicate runs inside the compaction kernel, one pass, default; 2 = the same (it forced the kernel on long batches while those took
  * three passes); 0 = predicate -> mask, count, compact),
- * "filter_block" (rdf_filter_frame's one-pass form and rdf_filter / rdf_filter_columns over device-resident chunks whose outputs can hold
- * every row, on frames of equally wide 4- / 8-byte columns in LONG batches: 1 = block tiles held in registers, every tile's row count
+ * "filter_block" (rdf_filter_frame's one-pass form and rdf_filter / rdf_filter_columns over device-resident chunks, on frames of equally wide 4- / 8-byte columns in LONG batches: 1 = block tiles held in registers, every tile's row count
  * published one iteration before its offset is asked for, offsets from one scanner wave, default; 0 = the wave-tile kernels),
  * "filter_block_rows" (the mean batch length from which that kernel is taken, default 8192),
  * "filter_lookback" (the wave-tile kernel on batches longer than a tile: 3 = one tile per 64 finds the rows in front of them all, from tile

@@ -454,11 +454,13 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
             if (NULLS) qx = win_issue(col.validity, col.offset, tc);
         }
         int64_t tbase = 0, Tnn = 0;
+        // outputs sized by an earlier count that does not hold any more: the batch's rows are not written (the host sees out_len > capacity)
+        auto room = [&](int64_t tb) __attribute__((always_inline)) -> bool { return !fa.out_cap || tb + bcnt_c <= as_const<int64_t>(fa.out_cap)[tc.c]; };
         if constexpr (!MULTI) {
             stage_col(X.y, col.validity != nullptr, qx);
             __syncthreads();
             tbase = (int64_t)uniform64((uint64_t)sh_base); Tnn = (int64_t)uniform64((uint64_t)sh_tile[par]);
-            store_col(col_at(0), out_of(col_at(0), tc.c), tbase, col.validity != nullptr);
+            if (room(tbase)) store_col(col_at(0), out_of(col_at(0), tc.c), tbase, col.validity != nullptr);
         } else {
             // two register sets take turns: while column kk is staged and stored, column kk + 1 is in flight
 #pragma unroll 1
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
                 stage_col(X.y, col.validity != nullptr, qx);
                 __syncthreads();
                 if (kk == 0) { tbase = (int64_t)uniform64((uint64_t)sh_base); Tnn = (int64_t)uniform64((uint64_t)sh_tile[par]); }
-                store_col(col_at(kk), out_of(col_at(kk), tc.c), tbase, col.validity != nullptr);
+                if (room(tbase)) store_col(col_at(kk), out_of(col_at(kk), tc.c), tbase, col.validity != nullptr);
                 if (kk + 1 < ncols) {
                     if (kk + 2 < ncols) {
                         col = col_of(col_at(kk + 2), tc.c);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
                     __syncthreads();
                     stage_col(U, col1.validity != nullptr, qu);
                     __syncthreads();
-                    store_col(col_at(kk + 1), out_of(col_at(kk + 1), tc.c), tbase, col1.validity != nullptr);
+                    if (room(tbase)) store_col(col_at(kk + 1), out_of(col_at(kk + 1), tc.c), tbase, col1.validity != nullptr);
                 }
             }
         }

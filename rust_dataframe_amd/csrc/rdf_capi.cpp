@@ -2454,8 +2454,27 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
     for (size_t i = 0; i < nout; ++i) {
         dev_outs[i] = DevOutChunk{outs[i].values, cols[i].validity ? outs[i].validity : nullptr};
         nulls |= cols[i].validity != nullptr;
-        const int64_t n = mask[i % (size_t)nchunks].length;           // an upper bound of the rows kept: the bitmap words they can touch
+        const int64_t n = std::min<int64_t>(mask[i % (size_t)nchunks].length, outs[i].capacity);           // an upper bound of the rows written: the bitmap words they can touch
         if (dev_outs[i].validity && n > 0) HIP_TRY(hipMemsetAsync(dev_outs[i].validity, 0, (size_t)((n + 63) / 64 * 8), ctx.stream));
+    }
+    // rows every output of chunk c can take (outputs sized by an earlier rdf_filter_count hold fewer than the chunk has)
+    std::vector<int64_t> cap((size_t)nchunks);
+    bool tight = false;
+    for (int64_t c = 0; c < nchunks; ++c) {
+        int64_t m = INT64_MAX;
+        for (int k = 0; k < ncols; ++k) m = std::min<int64_t>(m, outs[(int64_t)k * nchunks + c].capacity);
+        cap[(size_t)c] = m;
+        tight |= m < mask[c].length;
+    }
+    const int64_t* d_cap = nullptr;
+    if (tight) {
+        void* pc = nullptr;
+        RDF_TRY(arena_alloc(8 * (size_t)nchunks + 64, &pc));
+        RDF_TRY(pinned_reserve(fp.pin_off + 8 * (size_t)nchunks + 256));
+        memcpy(ctx.pinned + fp.pin_off, cap.data(), 8 * (size_t)nchunks);
+        HIP_TRY(hipMemcpyAsync(pc, ctx.pinned + fp.pin_off, 8 * (size_t)nchunks, hipMemcpyHostToDevice, ctx.stream));
+        fp.pin_off += (8 * (size_t)nchunks + 255) & ~(size_t)255;
+        d_cap = (const int64_t*)pc;
     }
     void* p = nullptr;
     RDF_TRY(arena_alloc(sizeof(int64_t) * (nout + (size_t)nchunks) + 64, &p));
@@ -2503,6 +2522,7 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
             wa.cols = fp.tb.dev_at<DevChunkCol>(fp.o_cols) + (size_t)g * (size_t)nchunks;
             wa.outs = fp.tb.dev_at<DevOutChunk>(fp.o_outs) + (size_t)g * (size_t)nchunks;
             wa.out_null_counts = d_nullc + (size_t)g * (size_t)nchunks;
+            wa.out_cap = d_cap;
             wa.ncols = nc;
             if (nchunks == 1) { wa.mask0 = fp.in.dev[0]; wa.len0 = fp.clen[0]; }
             for (int k = 0; k < nc; ++k) {
@@ -2534,6 +2554,8 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
     HIP_TRY(hipStreamSynchronize(ctx.stream));
     for (const BFilterArgs& b : launched) RDF_TRY(bfilter_check(b));
     const int64_t* len = pin + nout;
+    for (int64_t c = 0; c < nchunks; ++c)
+        if (len[c] > cap[(size_t)c]) return fail(RDF_MEMORY_ERROR, "output capacity too small");
     for (size_t i = 0; i < nout; ++i) {
         const int64_t n = len[i % (size_t)nchunks];
         outs[i].length = n;
@@ -2579,18 +2601,16 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
     arena_begin();
     FilterPrep fp;
     std::vector<int64_t> totals;
-    // Long device-resident chunks of equally wide columns whose outputs can hold every row: ONE pass on block tiles (rdf_bfilter.hip)
-    // — no count pass, no scan: a tile's offset comes from the scanner wave.  (An output sized by rdf_filter_count keeps the
-    // count -> scan -> compact path: its capacity has to be checked before anything is written.)
+    // Long device-resident chunks of equally wide columns: ONE pass on block tiles (rdf_bfilter.hip) — no count pass, no scan: a
+    // tile's offset comes from the scanner wave.
     {
         int es0 = dtype_size(cols[0].dtype);
         bool roomy = mem == RDF_MEM_DEVICE && (es0 == 8 || es0 == 4) && ctx.opt_filter_block != 0;
         int64_t rows_total = 0;
         for (int64_t c = 0; c < nchunks; ++c) rows_total += mask[c].length;
-        for (int k = 0; k < ncols && roomy; ++k) {
-            roomy = dtype_size(cols[(int64_t)k * nchunks].dtype) == es0;
-            for (int64_t c = 0; c < nchunks && roomy; ++c) roomy = outs[(int64_t)k * nchunks + c].capacity >= mask[c].length;
-        }
+        for (int k = 0; k < ncols && roomy; ++k) roomy = dtype_size(cols[(int64_t)k * nchunks].dtype) == es0;
+        // (outputs smaller than their chunk — a caller that sized them with rdf_filter_count — take the one pass as well: the kernel
+        // knows every output's capacity, a chunk that keeps more than it holds is not written and the count it reports fails the call)
         if (roomy && (rows_total + nchunks - 1) / nchunks >= (int64_t)ctx.opt_filter_block_rows) return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, false);
         // ... and the readers' batches (no chunk longer than one wave tile of 1024 rows, most of them full): one pass as well
         int64_t max_len = 0;

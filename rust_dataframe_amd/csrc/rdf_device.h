@@ -198,6 +198,7 @@ struct FilterWArgs {
     int32_t            esize[kMaxFilterCols];
     DevChunkCol        cols0[kMaxFilterCols];   // nchunks == 1
     DevOutChunk        outs0[kMaxFilterCols];
+    const int64_t*     out_cap;          // (one-pass paths) [nchunks] rows every output of chunk c can hold, or nullptr = as many as the chunk has: a chunk that keeps more is NOT written (its count still is: the host reports the capacity error)
     int64_t*           out_len;          // fcompact_dma_kernel with tile_scan == nullptr (every chunk is ONE tile: its kept rows start its output): [nchunks] kept rows per chunk (pre-zeroed)
 };
 // DataFrame::filter in ONE pass (rdf_filter_frame, predicates of the form `col CMP literal [AND|OR col CMP literal]`): the

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(kBlock, 4) void fcompact_dma_kernel(const FilterWAr
         for (int d = 1; d < WW; d <<= 1) cnt += __shfl_xor(cnt, d);
         cnt = __builtin_amdgcn_readfirstlane(cnt);
         if (a.out_len && lane == 0 && cnt) a.out_len[t.c] = cnt;      // (one-pass Column::filter over one-tile chunks: the count never existed before)
-        if (cnt == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; }   // the DMA must not land in the next tile's buffer
+        const bool no_room = a.out_cap && (int64_t)cnt > a.out_cap[t.c];      // outputs sized by an earlier count that does not hold any more: nothing is written
+        if (cnt == 0 || no_room) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; }   // the DMA must not land in the next tile's buffer
 #pragma unroll 1
         for (int k = 0; k < a.ncols; ++k) {
             if (k > 0) {

@@ -534,7 +534,8 @@ def test_filter_columns_device_block_tiles(gpu, ora, lens, off, nf, dts):
     """Column::filter (src/table.rs:97-107,213-215) with the mask GIVEN, device-resident, outputs that can hold every row: one pass on
     block tiles (rdf_bfilter.hip, mask form) — no count pass, lengths and null counts come back from the kernel.  Nullable masks at
     odd bit offsets, nullable columns, 11 columns (a launch of 8 and one of 3), 4-byte columns; a second call with outputs sized by
-    rdf_filter_count takes the count -> scan -> compact path and must give the same bytes."""
+    rdf_filter_count (a two-phase caller) takes the same one pass — the kernel knows every output's capacity — and must give the same
+    bytes; a third with an output one row too small fails with MemoryError and writes nothing past a buffer."""
     import torch
     from rust_dataframe_amd import lib
     rng = np.random.default_rng(6100 + len(lens) + len(dts))
@@ -588,10 +589,25 @@ def test_filter_columns_device_block_tiles(gpu, ora, lens, off, nf, dts):
             counts = gpu.filter_count(dmask[0])
             assert counts == [x.length for x in exp[0]]
             if any(c < n for c, n in zip(counts, lens)):
-                bufs, outs = outputs(counts)               # a two-phase caller's outputs: too small to skip the count
+                bufs, outs = outputs(counts)               # a two-phase caller's outputs, sized by rdf_filter_count: the same one pass, every output's capacity known to the kernel
                 gpu.filter_columns(dev, dmask[0], outs)
-                assert lib.last_kernel() != "bfilter_kernel", lib.last_kernel()
+                assert lib.last_kernel() == "bfilter_kernel", lib.last_kernel()
                 check(bufs, outs, f"counted sel={sel}")
+                short = [max(c - 1, 0) if i == len(counts) - 1 or c > 5 else c for i, c in enumerate(counts)]
+                if short != counts:                        # an output one row too small: the chunk is not written, the call fails
+                    bufs, outs = outputs(short)
+                    with pytest.raises(A.RdfError) as ei:
+                        gpu.filter_columns(dev, dmask[0], outs)
+                    assert ei.value.status == A.RDF_MEMORY_ERROR, ei.value
+                    lib.synchronize()
+                    i = 0
+                    for k, dt in enumerate(dts):             # nothing was written past any output's capacity
+                        es = np.dtype(A.NP_OF[dt]).itemsize
+                        for c in range(len(lens)):
+                            vb, _ = bufs[i]
+                            i += 1
+                            guard = vb.cpu().numpy()[short[c] * es: short[c] * es + 32]
+                            assert (guard == 0xAB).all(), (k, c)
         finally:
             lib.set_option("filter_block_rows", 8192)
 
