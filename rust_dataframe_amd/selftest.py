@@ -59,7 +59,7 @@ def multi_device_groupby(lib, api, devices, rows=1_000_000, ngroups=50_000, seed
             for p in ptrs:
                 L.rdf_dev_free(p)
 
-    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    th = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]      # (daemon: a rank stuck in a collective must not keep the process from ending)
     for t in th:
         t.start()
     for t in th:
