@@ -166,11 +166,13 @@ def main():
     report("filter_count", n / 8.0, lambda: api.filter_count([m]))
     report("filter_1col", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
     report("filter_2col", (16 + 16 * sel + 0.25) * n, lambda: api.filter_columns([[X], [K]], [m], [[of], [ok2]]))
+    lib.set_option("filter_block", 0)     # (the A/B of the count -> scan -> compact kernels: round 6's one-pass block kernel would take all three otherwise)
     for gen in (1, 3, 2):   # A/B: first-generation block tiles (one barrier per tile), register-staged wave tiles, default (LDS-DMA wave tiles)
         lib.set_option("filter_gen", gen)
         report(f"filter_1col_gen{gen}", (8 + 8 * sel + 0.25) * n, lambda: api.filter([X], [m], [of]))
         report(f"filter_2col_gen{gen}", (16 + 16 * sel + 0.25) * n, lambda: api.filter_columns([[X], [K]], [m], [[of], [ok2]]))
     lib.set_option("filter_gen", 2)
+    lib.set_option("filter_block", 1)
     # selective filters: 1 row in 16 kept (sparse tiles fetch only the sectors that hold a kept row)
     m16 = out_like(A.BOOL, n)
     api.predicate(e, e.op("gt", cx, e.scalar(0.875)), [[X]], [m16])
@@ -182,10 +184,13 @@ def main():
     MF = A.PreparedCol([A.DeviceArray(m.values_ptr + i // 8, None, 0, min(1024, nfc - i), A.BOOL, 0, keep=m) for i in range(0, nfc, 1024)])
     ofb = torch.empty(nfc, dtype=torch.float64, device="cuda")
     OF = [A.DeviceArray(ofb.data_ptr() + i * 8, None, 0, min(1024, nfc - i), A.F64, 0, keep=ofb) for i in range(0, nfc, 1024)]
+    report("filter_1col_1024_row_chunks", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))     # round 6: one pass (a chunk is one wave tile), no count / scan
+    lib.set_option("filter_block", 0)
     for gen in (1, 2, 3):   # 3 = wave-granular without the next-tile look-ahead
         lib.set_option("filter_gen", gen)
         report(f"filter_1col_1024_row_chunks_gen{gen}", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))
     lib.set_option("filter_gen", 2)
+    lib.set_option("filter_block", 1)
     # the same with output chunks sized by rdf_filter_count and packed back to back (what a two-phase caller allocates):
     # the slots above leave every other 4 KB of the output buffer untouched
     import itertools
