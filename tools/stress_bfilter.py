@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Round 6: randomised A/B of the two one-pass filter kernels — the block-tile kernel with the scanner wave (rdf_bfilter.hip) against the
+wave-tile kernel with the look-back (rdf_filter.hip) — on the same device-resident frames: random batch counts and lengths (empty,
+ragged, shorter and longer than a tile), 8- or 4-byte columns, validity bitmaps at odd bit offsets, one- and two-term predicates.
+The protocol between tiles and scanner is timing-dependent; this hunts for rare orderings the parity tests' fixed layouts do not
+produce.  Any difference (or a call that fails) stops the run.   python tools/stress_bfilter.py [--iters 300] [--seed 1]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from rust_dataframe_amd import _abi as A  # noqa: E402
+from rust_dataframe_amd import lib  # noqa: E402
+from util import make_chunks  # noqa: E402
+from test_frame_ops_gpu import to_device, frame_columns  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    lib.set_device(0)
+    gpu = lib.api()
+    rng = np.random.default_rng(args.seed)
+    rows_done = 0
+    for it in range(args.iters):
+        wide = rng.uniform() < 0.7
+        pool = [A.F64, A.I64, A.U64] if wide else [A.F32, A.I32, A.U32]
+        ncols = int(rng.integers(1, 5))
+        dts = [pool[int(rng.integers(0, 3))] for _ in range(ncols)]
+        nch = int(rng.integers(1, 12))
+        shape = rng.integers(0, 4)
+        lens = []
+        for _ in range(nch):
+            if shape == 0:
+                lens.append(int(rng.integers(0, 40_000)))
+            elif shape == 1:
+                lens.append(int(rng.integers(8000, 9000)))
+            elif shape == 2:
+                lens.append(int(rng.integers(0, 3)) * 8192 + int(rng.integers(0, 2)) * int(rng.integers(1, 8192)))
+            else:
+                lens.append(int(rng.integers(100_000, 700_000)))
+        if sum(lens) == 0:
+            lens[0] = 5000
+        nf = float(rng.choice([0.0, 0.0, 0.1, 0.5]))
+        off = int(rng.integers(0, 9))
+        host = [make_chunks(rng, dt, lens, nf if rng.uniform() < 0.6 else 0.0, off, "unit" if dt in (A.F64, A.F32) else "plain") for dt in dts]
+        dev, keep = to_device(host)
+        e = A.Expr()
+        ops = ["gt", "ge", "lt", "le", "ne", "eq"]
+        lit = float(rng.choice([0.0, 0.25, -0.5, 0.999, -2.0, 3.0])) if dts[0] in (A.F64, A.F32) else float(rng.integers(-1001, 1001))
+        t0 = e.op(ops[int(rng.integers(0, 6))], e.col(0), e.scalar(lit))
+        root = t0
+        if rng.uniform() < 0.4:
+            c1 = int(rng.integers(0, ncols))
+            lit1 = float(rng.choice([0.0, 0.5, -0.25])) if dts[c1] in (A.F64, A.F32) else float(rng.integers(-500, 500))
+            root = e.op("and" if rng.uniform() < 0.5 else "or", t0, e.op(ops[int(rng.integers(0, 4))], e.col(c1), e.scalar(lit1)))
+        with A.PinnedFrame(gpu, dev) as frame:
+            res = {}
+            for block in (1, 0):
+                lib.set_option("filter_block", block)
+                lib.set_option("filter_block_rows", 1)
+                lib.set_option("filter_fused", 2)
+                out = gpu.filter_frame(frame, e, root)
+                res[block] = (out.info(), frame_columns(out), lib.last_kernel())
+                out.release()
+            assert res[1][2] == "bfilter_kernel" and res[0][2] == "ffilter_dma_kernel", (res[1][2], res[0][2])
+            assert res[1][0] == res[0][0], ("info", it, lens, dts, res[1][0], res[0][0])
+            for k in range(ncols):
+                for c in range(nch):
+                    a, b = res[1][1][k][c], res[0][1][k][c]
+                    assert a.length == b.length, ("length", it, k, c, lens, dts)
+                    ma, mb = a.valid_mask(), b.valid_mask()
+                    assert np.array_equal(ma, mb), ("validity", it, k, c, lens, dts)
+                    assert np.array_equal(a.to_numpy()[ma].view(np.uint8), b.to_numpy()[mb].view(np.uint8)), ("values", it, k, c, lens, dts)
+        rows_done += sum(lens)
+        if (it + 1) % 50 == 0:
+            print(f"{it + 1} frames, {rows_done} rows: identical", flush=True)
+    lib.set_option("filter_block", 1); lib.set_option("filter_block_rows", 8192); lib.set_option("filter_fused", 1)
+    print(f"stress_bfilter: {args.iters} random frames ({rows_done} rows), block-tile kernel == wave-tile kernel on every column of every batch")
+
+
+if __name__ == "__main__":
+    main()
