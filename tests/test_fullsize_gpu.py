@@ -487,3 +487,67 @@ def test_filter_frame_1e9_rows_one_batch(gpu):
         fr.release()
     del x, k
     torch.cuda.empty_cache()
+
+
+def test_filter_frame_1e9_rows_in_ragged_long_batches(gpu):
+    """1e9 rows in 41 RecordBatches of uneven lengths (3 rows ... 1.2e8 rows, one empty) through the block-tile kernel with the scanner
+    wave (rdf_bfilter.hip), next to a row-number column: per batch the kept count equals a filter -> count over that batch alone,
+    the row numbers that come out are STRICTLY INCREASING inside every batch (order kept, nothing twice) and stay inside the batch's
+    row range, and the aggregates over the whole result equal the fused filter -> aggregate over the input (nothing lost)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from rust_dataframe_amd import lib
+    x = _dev(N, 0, A.F64, -1.0, 1.0)
+    k = torch.arange(N, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    lib.synchronize()
+    rng = np.random.default_rng(606)
+    cuts = np.sort(rng.integers(0, N, 37))
+    cuts = np.concatenate([[0, 3, 3], cuts, [N - 8191 - 17, N]]).astype(np.int64)        # a 3-row batch, an empty one, a last one of 8208 rows
+    cuts = np.unique(np.concatenate([cuts, [3]]))
+    starts, lens = cuts[:-1], np.diff(cuts)
+    starts, lens = np.insert(starts, 2, 3), np.insert(lens, 2, 0)                        # the empty batch
+    nch = len(starts)
+    rec = np.dtype([("values", "u8"), ("validity", "u8"), ("offset", "i8"), ("length", "i8"), ("null_count", "i8"), ("dtype", "i4"), ("mem", "i4")])
+    tab = np.zeros(2 * nch, dtype=rec)
+    for j, (t, dt) in enumerate(((x, A.F64), (k, A.I64))):
+        v = tab[j * nch:(j + 1) * nch]
+        v["values"] = t.data_ptr() + starts * 8
+        v["length"] = lens
+        v["dtype"] = dt
+        v["mem"] = A.MEM_DEVICE
+    h = C.c_void_p(0)
+    fn = gpu._fn("frame_pin")
+    fn.restype = C.c_int
+    gpu._check(fn(C.c_void_p(tab.ctypes.data), C.c_int32(2), C.c_int64(nch), C.byref(h)))
+    fr = A.Frame(gpu, h)
+    fr.keep = (x, k)
+    e = A.Expr()
+    gt = e.op("gt", e.col(0), e.scalar(0.25))
+    try:
+        want = gpu.pipeline(e, fr, [e.col(0), e.col(1)], gt)
+        out = gpu.filter_frame(fr, e, gt)
+        assert lib.last_kernel() == "bfilter_kernel", lib.last_kernel()
+        assert out.info() == (2, nch, want[0].count)
+        _same_aggs(gpu.pipeline(e, out, [e.col(0), e.col(1)]), want, "ragged long batches")
+        ox, ok_ = out.column(0), out.column(1)
+        e2 = A.Expr()
+        inc = e2.op("lt", e2.col(0), e2.col(1))
+        for c in range(nch):
+            n = ok_[c].length
+            alone = gpu.pipeline(e, [[_arr(x, A.F64, int(lens[c]), int(starts[c]))]], [e.col(0)], gt)[0].count if lens[c] else 0
+            assert n == alone == ox[c].length, (c, n, alone)
+            if n == 0:
+                continue
+            base = ok_[c].values_ptr + 8 * ok_[c].offset
+            rows = gpu.pipeline(e2, [[A.DeviceArray(base, None, 0, n, A.I64, 0)]], [e2.col(0)])[0]
+            assert rows.min >= starts[c] and rows.max < starts[c] + lens[c], (c, rows.min, rows.max)
+            if n > 1:        # row numbers strictly increasing: k[i] < k[i + 1] for every i
+                ordered = gpu.pipeline(e2, [[A.DeviceArray(base, None, 0, n - 1, A.I64, 0)], [A.DeviceArray(base + 8, None, 0, n - 1, A.I64, 0)]], [e2.col(0)], inc)[0]
+                assert ordered.count == n - 1, (c, ordered.count, n - 1)
+        out.release()
+    finally:
+        fr.release()
+    del x, k
+    torch.cuda.empty_cache()
