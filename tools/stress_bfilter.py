@@ -29,6 +29,7 @@ def main():
     gpu = lib.api()
     rng = np.random.default_rng(args.seed)
     rows_done = 0
+    skipped = 0
     for it in range(args.iters):
         wide = rng.uniform() < 0.7
         pool = [A.F64, A.I64, A.U64] if wide else [A.F32, A.I32, A.U32]
@@ -70,7 +71,10 @@ def main():
                 out = gpu.filter_frame(frame, e, root)
                 res[block] = (out.info(), frame_columns(out), lib.last_kernel())
                 out.release()
-            assert res[1][2] == "bfilter_kernel" and res[0][2] == "ffilter_dma_kernel", (res[1][2], res[0][2])
+            if res[1][2] != "bfilter_kernel":        # (a frame of mostly tiny batches: both runs took the three passes — nothing to compare)
+                skipped += 1
+                continue
+            assert res[0][2] == "ffilter_dma_kernel", (res[1][2], res[0][2])
             assert res[1][0] == res[0][0], ("info", it, lens, dts, res[1][0], res[0][0])
             for k in range(ncols):
                 for c in range(nch):
@@ -83,7 +87,7 @@ def main():
         if (it + 1) % 50 == 0:
             print(f"{it + 1} frames, {rows_done} rows: identical", flush=True)
     lib.set_option("filter_block", 1); lib.set_option("filter_block_rows", 8192); lib.set_option("filter_fused", 1)
-    print(f"stress_bfilter: {args.iters} random frames ({rows_done} rows), block-tile kernel == wave-tile kernel on every column of every batch")
+    print(f"stress_bfilter: {args.iters - skipped} random frames ({rows_done} rows; {skipped} more were not of the one-pass shape), block-tile kernel == wave-tile kernel on every column of every batch")
 
 
 if __name__ == "__main__":
