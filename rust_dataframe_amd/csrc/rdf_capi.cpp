@@ -59,6 +59,7 @@ struct Ctx {
     bool   opt_filter_one = true;   // one-chunk compaction kernel with its descriptors in the kernel arguments (A/B)
     int    opt_filter_gen = 2;      // compaction kernels: 2 = wave-granular tiles (rdf_filter.hip, default), 1 = first-generation block tiles (A/B)
     int    opt_filter_block = 1;    // one-pass compaction of LONG batches on block tiles held in registers, prefixes from a scanner wave (rdf_bfilter.hip, round 6; default); 0 = the wave-tile kernels only (A/B)
+    int    opt_interp_lean = 1;             // interpreted aggregate programs whose every step has a lean handler run on eval_lean_kernel (rdf_eval_lean.hip); 0: always eval_kernel (the A/B)
     int    opt_filter_block_rows = 8192;    // ... for frames whose mean batch length is at least this many rows (one block tile of a single 8-byte column; measured ahead of the wave-tile kernel from 8192-row batches up: profiles/r06_filter_frame_batch_length_sweep.jsonl)
     int    opt_filter_fused = 1;    // rdf_filter_frame: `col CMP literal [AND|OR col CMP literal]` predicates evaluated inside the compaction kernel, one pass (1, default); 0 = predicate -> mask, count, compact (A/B)
     int    opt_filter_lookback = 3; // one-pass rdf_filter_frame, batches longer than a tile: 3 = a super-tile's first tile finds the rows in front of the super-tile for all 64, from the nearest super-tiles' tile counts and the older ones' totals (default); 2 = from totals only; 1 = every tile walks the totals (round 4; batches of at most 1024 tiles) — A/B
@@ -994,6 +995,64 @@ constexpr int RDF_SINK_GROUP = 2;
 // a kernel compiled at run time could not be launched (it is marked failed): the caller runs the program again, interpreted
 const rdf_status kRetryInterpreted = static_cast<rdf_status>(77);
 
+// Which handler of eval_lean_kernel runs each step of an aggregate program, if every step has one (LH_* in rdf_device.h, the
+// kernel's header says what it covers): columns of 8-byte types all held in registers, f64 comparisons, f64 / 64-bit integer
+// arithmetic, Boolean connectives, i64 / u64 -> f64 casts, the filter, aggregate sinks of 8-byte values.  The indices go into
+// bits 1..7 of Instr::swapped of `lean`, a copy — the program eval_kernel would run is not touched.
+bool lean_assign(const EvalArgs& ea, EvalArgs& lean) {
+    if (ea.ncols < 1 || ea.ncols > kPreCols || ea.nvalues < 1 || ea.nvalues > kMaxValues || ea.ncode < 1) return false;
+    auto wide = [](int dt) { return dt == RDF_F64 || dt == RDF_I64 || dt == RDF_U64; };
+    for (int c = 0; c < ea.ncols; ++c) if (!wide(ea.col_dtype[c])) return false;
+    lean = ea;
+    for (int i = 0; i < ea.ncode; ++i) {
+        const Instr& in = ea.code[i];
+        const bool same = in.src_dtype == in.dtype;
+        int h = LH_NONE;
+        switch (in.bc) {
+            case BC_LOAD:
+                if (in.src_kind == SRC_COL && same && wide(in.dtype) && in.src < ea.ncols) h = LH_LOAD;
+                else if (in.src_kind == SRC_IMM && same) h = LH_LOAD;   // (the payload is already in the step's domain)
+                break;
+            case BC_STORE_TMP: h = LH_STORE_TMP; break;
+            case BC_FILTER: h = LH_FILTER; break;
+            case BC_EMIT: if (wide(in.dtype) && in.src < ea.nvalues) h = LH_EMIT; break;
+            case BC_UN: if (in.op == RDF_OP_NOT) h = LH_NOT; break;
+            case BC_CAST:
+                if (in.dtype == RDF_F64 && in.src_dtype == RDF_I64) h = LH_CAST_I2F;
+                else if (in.dtype == RDF_F64 && in.src_dtype == RDF_U64) h = LH_CAST_U2F;
+                break;
+            case BC_BIN: {
+                if (!same) break;
+                if (in.src_kind == SRC_COL && !(in.src < ea.ncols)) break;
+                if (in.src_kind != SRC_COL && in.src_kind != SRC_IMM && in.src_kind != SRC_TMP) break;
+                const bool sw = in.swapped & 1;
+                const int op = in.op;
+                if (op >= RDF_OP_GT && op <= RDF_OP_LE) {
+                    // acc CMP b; swapped (b CMP acc) is the mirrored comparison of acc with b
+                    static const int fwd[6] = {LH_F_GT, LH_F_GE, LH_F_EQ, LH_F_NE, LH_F_LT, LH_F_LE};
+                    static const int mir[6] = {LH_F_LT, LH_F_LE, LH_F_EQ, LH_F_NE, LH_F_GT, LH_F_GE};
+                    h = (sw ? mir : fwd)[op - RDF_OP_GT];
+                } else if (op == RDF_OP_AND) h = LH_AND;
+                else if (op == RDF_OP_OR) h = LH_OR;
+                else if (in.dtype == RDF_F64) {
+                    if (op == RDF_OP_ADD) h = LH_F_ADD;
+                    else if (op == RDF_OP_MUL) h = LH_F_MUL;
+                    else if (op == RDF_OP_SUB) h = sw ? LH_F_RSUB : LH_F_SUB;
+                    else if (op == RDF_OP_DIV) h = sw ? LH_F_RDIV : LH_F_DIV;
+                } else if (in.dtype == RDF_I64 || in.dtype == RDF_U64) {
+                    if (op == RDF_OP_ADD) h = LH_I_ADD;
+                    else if (op == RDF_OP_MUL) h = LH_I_MUL;
+                    else if (op == RDF_OP_SUB) h = sw ? LH_I_RSUB : LH_I_SUB;
+                }
+            } break;
+            default: break;
+        }
+        if (h == LH_NONE) return false;
+        lean.code[i].swapped = (uint8_t)((in.swapped & 1) | (h << 1));
+    }
+    return true;
+}
+
 rdf_status launch_agg_pair(const EvalArgs* ea, const FilterAggF64Args* fa, int cmp, int feat, int grid, int nvalues,
                            const int* cls, AggPartial* partials, AggPartial* result, const char* spec_sig = nullptr,
                            const SpecArgs* sa = nullptr) {
@@ -1007,7 +1066,11 @@ rdf_status launch_agg_pair(const EvalArgs* ea, const FilterAggF64Args* fa, int c
         if (le != hipSuccess) return fail(RDF_DEVICE_ERROR, "launch_spec: %s", hipGetErrorString(le));
     }
     else if (fa) { c.last_kernel = "filter_agg_f64_kernel"; HIP_TRY(launch_filter_agg_f64(*fa, cmp, grid, c.stream)); }
-    else { c.last_kernel = "eval_kernel<AGG>"; HIP_TRY(launch_eval(*ea, SINK_AGG, feat, grid, c.stream)); }
+    else {
+        EvalArgs lean;
+        if (c.opt_interp_lean && feat == 0 && lean_assign(*ea, lean)) { c.last_kernel = "eval_kernel<AGG, lean>"; HIP_TRY(launch_eval_lean(lean, grid, c.stream)); }
+        else { c.last_kernel = "eval_kernel<AGG>"; HIP_TRY(launch_eval(*ea, SINK_AGG, feat, grid, c.stream)); }
+    }
     kt.stop();
     AggFinalArgs f;
     memset(&f, 0, sizeof f);
@@ -4408,6 +4471,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
     else if (strcmp(name, "filter_block") == 0) g_ctx.opt_filter_block = value == 3 ? 3 : value != 0;      // (3: tests — the scanner wave stays idle, every wait must time out)
+    else if (strcmp(name, "interp_lean") == 0) g_ctx.opt_interp_lean = value != 0;
     else if (strcmp(name, "filter_block_rows") == 0) g_ctx.opt_filter_block_rows = value < 1 ? 1 : (int)value;
     else if (strcmp(name, "filter_lookback") == 0) g_ctx.opt_filter_lookback = value == 1 ? 1 : value == 2 ? 2 : 3;
     else if (strcmp(name, "comm_max_bytes") == 0) g_ctx.opt_comm_max_bytes = value;

@@ -51,6 +51,13 @@ struct Instr {
     uint64_t imm;        // SRC_IMM payload already in the `dtype` domain
 };
 static_assert(sizeof(Instr) == 16, "Instr must stay 16 bytes");
+// eval_lean_kernel (rdf_eval_lean.hip) dispatches a step on a handler index the host wrote into Instr::swapped bits 1..7
+// (lean_assign, rdf_capi.cpp; bit 0 stays the swap flag, which is all eval_kernel reads).  LH_NONE: the step has no handler.
+enum : int {
+    LH_NONE = 0, LH_LOAD, LH_STORE_TMP, LH_FILTER, LH_EMIT, LH_NOT, LH_CAST_I2F, LH_CAST_U2F,
+    LH_F_GT, LH_F_GE, LH_F_EQ, LH_F_NE, LH_F_LT, LH_F_LE, LH_F_ADD, LH_F_SUB, LH_F_RSUB, LH_F_MUL, LH_F_DIV, LH_F_RDIV,
+    LH_I_ADD, LH_I_SUB, LH_I_RSUB, LH_I_MUL, LH_AND, LH_OR
+};
 
 // Per-block partial aggregate of one value expression ({sum,min,max,count}, AggregateFunctions).
 struct AggPartial {
@@ -718,6 +725,7 @@ hipError_t launch_list_offsets(const int64_t* scan, int64_t n1, int32_t* out, hi
 // ---- launch wrappers (defined in rdf_kernels.hip) ----
 int  eval_grid_limit();   // persistent grid size for streaming kernels
 hipError_t launch_probe(int kind, int u, int grid, const void* a, void* b, void* c, int64_t nvec, uint32_t* sink, hipStream_t s);   // rdf_probe.hip: bare streams
+hipError_t launch_eval_lean(const EvalArgs& a, int grid, hipStream_t s);   // SINK_AGG programs whose every step has a lean handler (rdf_eval_lean.hip)
 hipError_t launch_eval(const EvalArgs& a, int sink, int feat, int grid, hipStream_t s);  // feat: 0 basic, 1 +int div, 2 +libm
 bool gspec_available(const char* sig);
 hipError_t launch_gspec(const char* sig, const GSpecArgs& a, int grid, hipStream_t s);

@@ -347,6 +347,25 @@ __device__ __forceinline__ void apply_unary(int op, int dt, uint64_t (&acc)[kVPT
     RDF_ROWS { int64_t x = (int64_t)acc[j]; acc[j] = normalize_int(dt, x < 0 ? (uint64_t)0 - (uint64_t)x : (uint64_t)x); }
 }
 
+// The steps most programs are made of, written without the generic operand registers: acc OP b where b(j) is a column's
+// register or the step's immediate (a scalar register: no copy at all).  f64 comparisons and + - * only — what
+// apply_binary does for the same (op, RDF_F64), minus the moves.
+__device__ __forceinline__ bool fast_f64_op(int op) { return (op >= RDF_OP_GT && op <= RDF_OP_LE) || (op >= RDF_OP_ADD && op <= RDF_OP_MUL); }
+template <class B>
+__device__ __forceinline__ void fast_f64(int op, uint64_t (&acc)[kVPT], B b) {
+    switch (op) {
+        case RDF_OP_GT: RDF_ROWS acc[j] = u2d(acc[j]) > b(j); break;
+        case RDF_OP_GE: RDF_ROWS acc[j] = u2d(acc[j]) >= b(j); break;
+        case RDF_OP_EQ: RDF_ROWS acc[j] = u2d(acc[j]) == b(j); break;
+        case RDF_OP_NE: RDF_ROWS acc[j] = u2d(acc[j]) != b(j); break;
+        case RDF_OP_LT: RDF_ROWS acc[j] = u2d(acc[j]) < b(j); break;
+        case RDF_OP_LE: RDF_ROWS acc[j] = u2d(acc[j]) <= b(j); break;
+        case RDF_OP_ADD: RDF_ROWS acc[j] = d2u(u2d(acc[j]) + b(j)); break;
+        case RDF_OP_SUB: RDF_ROWS acc[j] = d2u(u2d(acc[j]) - b(j)); break;
+        default: RDF_ROWS acc[j] = d2u(u2d(acc[j]) * b(j)); break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 
 template <int FEAT, int SINK, int NPRE, int NVAL>
@@ -422,6 +441,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
             }
         }
     };
+    const uint64_t* const code_words = (const uint64_t*)a.code;
     int64_t tile = blockIdx.x;
     bool have = tile < a.ntiles;
     TileLoc tl = have ? locate(tile) : TileLoc{0, 0, 0};
@@ -478,8 +498,49 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
 #pragma unroll
         for (int j = 0; j < kVPT; ++j) acc[j] = 0;
 
+        uint64_t nw0 = code_words[0], nw1 = code_words[1];
         for (int pc = 0; pc < a.ncode; ++pc) {
-            const Instr in = a.code[pc];
+            // One step = 16 bytes, fetched as two 8-byte SCALAR loads and taken apart with scalar shifts.  (Read field by field, the
+            // one- and two-byte members came through the VECTOR memory path — the scalar unit has no sub-dword loads — and each
+            // was followed by s_waitcnt vmcnt(0): a full round trip per step, and the first of them also waited for the NEXT tile's
+            // column loads issued just above, i.e. the prefetch hid nothing.  Round 6, read off the ISA.)
+            // The NEXT step's words are asked for now and used one trip later, so the scalar-cache round trip runs under this step.
+            const uint64_t iw0 = nw0, iw1 = nw1;
+            if (pc + 1 < a.ncode) { nw0 = code_words[2 * pc + 2]; nw1 = code_words[2 * pc + 3]; }
+            Instr in;
+            in.bc = (uint8_t)iw0; in.op = (uint8_t)(iw0 >> 8); in.dtype = (uint8_t)(iw0 >> 16); in.src_kind = (uint8_t)(iw0 >> 24);
+            in.src_dtype = (uint8_t)(iw0 >> 32); in.swapped = (uint8_t)(iw0 >> 40) & 1; in.src = (uint16_t)(iw0 >> 48); in.imm = iw1;
+            // Fast steps (round 6): a column that is already in registers is used where it lies, an immediate stays in scalar
+            // registers.  Everything else falls through to the generic step below, which copies its operand into `opnd` first
+            // (measured on filter -> sum: 431 vector instructions per 256-row wave tile, ~20 of every LOAD / BIN step moves).
+            if (in.src_dtype == in.dtype && (int)in.src < NPRE) {
+                if (in.bc == BC_LOAD && in.src_kind == SRC_COL) {
+#pragma unroll
+                    for (int p = 0; p < NPRE; ++p)
+                        if (p == (int)in.src) {
+                            accv = colvalid[p];
+#pragma unroll
+                            for (int j = 0; j < kVPT; ++j) acc[j] = colv[p][j];
+                        }
+                    continue;
+                }
+                if (in.bc == BC_BIN && !in.swapped && fast_f64_op(in.op) && (in.dtype == RDF_F64 || in.op >= RDF_OP_GT)) {
+                    if (in.src_kind == SRC_IMM) {
+                        const double bi = u2d(in.imm);
+                        fast_f64(in.op, acc, [&](int) { return bi; });
+                        continue;
+                    }
+                    if (in.src_kind == SRC_COL) {
+#pragma unroll
+                        for (int p = 0; p < NPRE; ++p)
+                            if (p == (int)in.src) {
+                                accv &= colvalid[p];
+                                fast_f64(in.op, acc, [&](int j) { return u2d(colv[p][j]); });
+                            }
+                        continue;
+                    }
+                }
+            }
             uint64_t opnd[kVPT];
             uint32_t opv = (1u << kVPT) - 1;
             if (in.bc == BC_LOAD || in.bc == BC_BIN) {
@@ -497,6 +558,11 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
                     if (!hit) {
                         const DevChunkCol cc = a.nchunks == 1 ? a.inline_cols[ci & (kMaxCols - 1)] : a.cols[(int64_t)ci * a.nchunks + c];
                         load_col(cc, a.col_dtype[ci & (kMaxCols - 1)], rw, clen, inr, opnd, opv);
+                        // the loaded values are waited for HERE, on the path that loaded them: left to the compiler the wait lands
+                        // where the paths join, as vmcnt(0), and every step of every program then waits for the next tile's prefetch
+#pragma unroll
+                        for (int j = 0; j < kVPT; ++j) asm volatile("" : "+v"(opnd[j]));
+                        asm volatile("" : "+v"(opv));
                     }
                 } else if (in.src_kind == SRC_IMM) {
 #pragma unroll
@@ -544,8 +610,12 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
                     }
                     break;
                 case BC_FILTER:  // DataFrame::filter: rows whose predicate is false or null are dropped
+                    {
+                        uint32_t pass = 0;
 #pragma unroll
-                    for (int j = 0; j < kVPT; ++j) keep &= ~((uint32_t)(((acc[j] & 1) == 0) || (((accv >> j) & 1) == 0)) << j);
+                        for (int j = 0; j < kVPT; ++j) pass |= ((uint32_t)acc[j] & 1u) << j;
+                        keep &= pass & accv;
+                    }
                     break;
                 case BC_GROUP:  // acc is the row's group id (an integer expression); NULL -> the extra group
                     if (SINK == SINK_GROUP) {

@@ -1,0 +1,337 @@
+// rdf_eval_lean.hip — the interpreter's kernel for the programs most programs are (round 6).
+//
+//   eval_lean_kernel<NPRE, NVAL>      [the same steps as rdf_eval.hip's eval_kernel<FEAT 0, SINK_AGG>: Evaluate::calculate
+//     src/evaluation.rs:97-323, BooleanFilter::eval_to_array src/expression.rs:766-861, AggregateFunctions
+//     src/functions/aggregate.rs:12-93 — filter -> {sum, min, max, count} of value expressions in one pass]
+//
+// Why a second kernel.  Read off the general kernel's ISA and counters (profiles/r06_pmc_interpreter_*.txt): a 256-row wave
+// tile of filter -> sum cost 431 vector + 405 scalar instructions — 70 + 65 per bytecode step — and a SIMD retired about one
+// instruction of either kind per four cycles, so the instruction COUNT was the kernel's time.  Two causes, neither a property
+// of interpretation:
+//   * the general kernel holds a step's operand in generic registers (`opnd`), so every LOAD / BIN step began by copying a
+//     column or a literal there, and the paths of its big switch met again through register moves;
+//   * some of its cases branch per LANE (guarded tail loads, divide-by-zero flags, aggregate updates under `if (live)`,
+//     the vector-path bitmap loads), and one divergent branch anywhere makes the compiler structurize the WHOLE loop nest:
+//     the wave-uniform dispatch is then lowered to flag registers and re-tests ("Flow" blocks) instead of plain scalar
+//     branches — most of the 65 scalar instructions per step.
+// This kernel has NO divergent branch — tails read clamped addresses, per-row conditions are selects, bitmaps come through
+// the scalar path — and every step is dispatched on a handler index the HOST assigned (Instr::swapped bits 1..7, see
+// lean_assign in rdf_capi.cpp); a binary step reads its operand where it lies: a column's registers, a scalar register
+// pair (literals), or LDS (temporaries).  It takes the programs whose every step has a handler: columns of 8-byte types
+// (f64 / i64 / u64) all held in registers (<= 4), f64 comparisons, f64 and 64-bit integer + - *, f64 /, AND / OR / NOT,
+// i64 / u64 -> f64 casts, the filter, aggregate sinks.  Everything else runs on eval_kernel as before; results are the
+// same bit for bit (the fold order of a lane's rows, of the lanes and of the blocks is eval_kernel's).
+#include "rdf_common.hip.h"
+
+namespace rdfk {
+
+#define RDF_ROWS _Pragma("unroll") for (int j = 0; j < kVPT; ++j)
+
+typedef uint64_t lean_u64x2 __attribute__((ext_vector_type(2)));
+
+// the lane's 4 bits (rows 4 l .. 4 l + 3) of a 256-bit window held as four 64-bit words (selects, no branch)
+__device__ __forceinline__ uint32_t lean_nibble(const uint64_t (&w)[kVPT], int lane) {
+    // (written as masks: left as `q == 0 ? w[0] : ...` the compiler branches per lane on q)
+    const uint32_t q = (uint32_t)lane >> 4, sh = ((uint32_t)lane & 15u) * 4u;
+    const uint32_t c0 = (uint32_t)(w[0] >> sh), c1 = (uint32_t)(w[1] >> sh), c2 = (uint32_t)(w[2] >> sh), c3 = (uint32_t)(w[3] >> sh);
+    const uint32_t m0 = 0u - (uint32_t)(q == 0), m1 = 0u - (uint32_t)(q == 1), m2 = 0u - (uint32_t)(q == 2), m3 = 0u - (uint32_t)(q == 3);
+    return ((c0 & m0) | (c1 & m1) | (c2 & m2) | (c3 & m3)) & 15u;
+}
+
+// An 8-byte column's rows rw + 4 l .. + 3 of a chunk of clen rows.  Full, 16-byte aligned spans: two vector loads per lane;
+// anything else: four loads whose row index is clamped to the chunk's last row (rows past the end are never looked at: the
+// step masks start from `inr`).  Both branches are wave-uniform.
+__device__ __forceinline__ void lean_load8(const DevChunkCol cc, int64_t rw, int64_t clen, bool full, uint64_t (&v)[kVPT], uint32_t& valid) {
+    const int lane = threadIdx.x & 63;
+    const GlobalPtr<uint64_t> base = as_global<uint64_t>(cc.values) + cc.offset;
+    if (full && (((uintptr_t)cc.values + (uintptr_t)(cc.offset + rw) * 8) & 15) == 0) {
+        const GlobalPtr<lean_u64x2> p = (GlobalPtr<lean_u64x2>)(base + rw + (int64_t)lane * kVPT);
+        const lean_u64x2 a0 = __builtin_nontemporal_load(p), a1 = __builtin_nontemporal_load(p + 1);
+        v[0] = a0[0]; v[1] = a0[1]; v[2] = a1[0]; v[3] = a1[1];
+    } else {
+        const int64_t last = clen - 1;
+        RDF_ROWS {
+            const int64_t r = rw + (int64_t)lane * kVPT + j;
+            v[j] = __builtin_nontemporal_load(base + (r < last ? r : last));
+        }
+    }
+    valid = (1u << kVPT) - 1;
+    if (cc.validity) {
+        uint64_t w[kVPT];
+        load_windows_s<kVPT>(cc.validity, cc.offset + rw, clen - rw, w);
+        valid = lean_nibble(w, lane);
+    }
+}
+
+// acc = acc OP b(j) for the binary handlers; `live` = rows where both sides are valid and in range (a zero divisor is an
+// error only there, like arrow's math_divide; the quotient of such a slot is 0 as in eval_kernel)
+template <class B>
+__device__ __forceinline__ void lean_bin(int h, uint64_t (&acc)[kVPT], B b, uint32_t live, uint32_t& err) {
+    switch (h) {
+        case LH_F_GT: RDF_ROWS acc[j] = u2d(acc[j]) > u2d(b(j)); break;
+        case LH_F_GE: RDF_ROWS acc[j] = u2d(acc[j]) >= u2d(b(j)); break;
+        case LH_F_EQ: RDF_ROWS acc[j] = u2d(acc[j]) == u2d(b(j)); break;
+        case LH_F_NE: RDF_ROWS acc[j] = u2d(acc[j]) != u2d(b(j)); break;
+        case LH_F_LT: RDF_ROWS acc[j] = u2d(acc[j]) < u2d(b(j)); break;
+        case LH_F_LE: RDF_ROWS acc[j] = u2d(acc[j]) <= u2d(b(j)); break;
+        case LH_F_ADD: RDF_ROWS acc[j] = d2u(u2d(acc[j]) + u2d(b(j))); break;
+        case LH_F_SUB: RDF_ROWS acc[j] = d2u(u2d(acc[j]) - u2d(b(j))); break;
+        case LH_F_RSUB: RDF_ROWS acc[j] = d2u(u2d(b(j)) - u2d(acc[j])); break;
+        case LH_F_MUL: RDF_ROWS acc[j] = d2u(u2d(acc[j]) * u2d(b(j))); break;
+        case LH_F_DIV:
+            RDF_ROWS {
+                const bool z = u2d(b(j)) == 0.0;
+                err |= (uint32_t)z & (live >> j) & 1u;
+                double q = u2d(acc[j]) / u2d(b(j));
+                asm volatile("" : "+v"(q));   // (keeps the division out of a per-lane branch the compiler would form around it)
+                acc[j] = z ? 0 : d2u(q);
+            }
+            break;
+        case LH_F_RDIV:
+            RDF_ROWS {
+                const bool z = u2d(acc[j]) == 0.0;
+                err |= (uint32_t)z & (live >> j) & 1u;
+                double q = u2d(b(j)) / u2d(acc[j]);
+                asm volatile("" : "+v"(q));
+                acc[j] = z ? 0 : d2u(q);
+            }
+            break;
+        case LH_I_ADD: RDF_ROWS acc[j] = acc[j] + b(j); break;
+        case LH_I_SUB: RDF_ROWS acc[j] = acc[j] - b(j); break;
+        case LH_I_RSUB: RDF_ROWS acc[j] = b(j) - acc[j]; break;
+        case LH_I_MUL: RDF_ROWS acc[j] = acc[j] * b(j); break;
+        case LH_AND: RDF_ROWS acc[j] = acc[j] & b(j); break;
+        default: RDF_ROWS acc[j] = acc[j] | b(j); break;   // LH_OR
+    }
+}
+
+// block_reduce_agg (rdf_common.hip.h) without its per-lane branches — ONE divergent branch anywhere in the function and the
+// compiler structurizes all of it, the step dispatch included (checked on the ISA: 162 flag-carrying "Flow" blocks in this
+// kernel with the shared reduction, none with this one).  Same fold, same result: the butterfly runs in every lane, lane 0's
+// totals are broadcast through scalar registers and written by all lanes, and every thread folds the four wave totals in wave
+// order and stores the block's partial (256 stores of one value).
+__device__ __forceinline__ void lean_block_reduce(int cls, uint64_t sum, uint64_t mn, uint64_t mx, int64_t cnt, AggPartial* lds4, AggPartial* out) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint64_t s2 = shfl_xor64(sum, m), mn2 = shfl_xor64(mn, m), mx2 = shfl_xor64(mx, m);
+        const int64_t c2 = (int64_t)shfl_xor64((uint64_t)cnt, m);
+        agg_merge(cls, sum, mn, mx, cnt, s2, mn2, mx2, c2);
+    }
+    sum = uniform64(sum); mn = uniform64(mn); mx = uniform64(mx); cnt = (int64_t)uniform64((uint64_t)cnt);   // lane 0's, as block_reduce_agg keeps
+    const int wave = wave_id();   // (a scalar: with a per-lane index the totals read back count as per-lane values, and the fold's selects as per-lane branches)
+    __syncthreads();
+    lds4[wave].sum = sum; lds4[wave].mn = mn; lds4[wave].mx = mx; lds4[wave].cnt = cnt;
+    __syncthreads();
+    uint64_t s = lds4[0].sum, lo = lds4[0].mn, hi = lds4[0].mx;
+    int64_t c = lds4[0].cnt;
+    for (int w = 1; w < kBlock / 64; ++w) agg_merge(cls, s, lo, hi, c, lds4[w].sum, lds4[w].mn, lds4[w].mx, lds4[w].cnt);
+    out->sum = s; out->mn = lo; out->mx = hi; out->cnt = c;
+}
+
+template <int NPRE, int NVAL>
+__global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ AggPartial red_lds[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id();
+
+    uint64_t g_sum[NVAL], g_mn[NVAL], g_mx[NVAL];
+    int64_t g_cnt[NVAL];
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k) agg_init(k < a.nvalues ? a.value_cls[k] : CLS_F64, g_sum[k], g_mn[k], g_mx[k], g_cnt[k]);
+    uint32_t err = 0;
+
+    struct TileLoc { int64_t c, r0, clen; };
+    auto locate = [&](int64_t tile) -> TileLoc {
+        TileLoc t;
+        if (a.nchunks == 1) { t.c = 0; t.r0 = tile * kEvalTile; t.clen = a.inline_len; }
+        else {
+            t.c = find_chunk_tile(as_const<int64_t>(a.chunk_tile_start), a.nchunks, tile);
+            t.r0 = (tile - as_const<int64_t>(a.chunk_tile_start)[t.c]) * kEvalTile;
+            t.clen = as_const<int64_t>(a.chunk_len)[t.c];
+        }
+        return t;
+    };
+    // rows of this lane that exist, and whether every row of the wave's span does (wave-uniform)
+    auto rows_in_range = [&](const TileLoc& t, bool& full) -> uint32_t {
+        const int64_t rw_ = t.r0 + (int64_t)wave * (kVPT * 64);
+        const int64_t left = t.clen - rw_ - (int64_t)lane * kVPT;       // rows from this lane's first to the chunk's end
+        full = t.clen - rw_ >= (int64_t)kVPT * 64;
+        const int64_t n = left < 0 ? 0 : left > kVPT ? kVPT : left;
+        return (1u << (uint32_t)n) - 1u;
+    };
+    auto load_tile = [&](const TileLoc& t, uint64_t (&v)[NPRE][kVPT], uint32_t (&vv)[NPRE], uint32_t& inr_) {
+        const int64_t rw_ = t.r0 + (int64_t)wave * (kVPT * 64);
+        bool full;
+        inr_ = rows_in_range(t, full);
+#pragma unroll
+        for (int p = 0; p < NPRE; ++p) {
+            if (p < a.ncols) {
+                // (the table through the constant address space: a scalar load.  `a.nchunks == 1 ? inline : a.cols[..]` selects
+                // between a kernel-argument address and a global one, i.e. a FLAT vector load whose result the compiler must
+                // treat as different in every lane — every test on the descriptor then becomes a divergent branch)
+                DevChunkCol cc;
+                if (a.nchunks == 1) cc = a.inline_cols[p];
+                else cc = const_col(a.cols, (int64_t)p * a.nchunks + t.c);
+                lean_load8(cc, rw_, t.clen, full, v[p], vv[p]);
+            } else {
+                vv[p] = 0;
+                RDF_ROWS v[p][j] = 0;
+            }
+        }
+    };
+
+    const uint64_t* const code_words = (const uint64_t*)a.code;
+    uint64_t* const tmp_vals = (uint64_t*)smem;                                          // [ntmp][kVPT][kBlock]
+    uint32_t* const tmp_valid = (uint32_t*)(smem + (size_t)a.ntmp * kVPT * kBlock * 8);  // [ntmp][kBlock]
+
+    int64_t tile = blockIdx.x;
+    bool have = tile < a.ntiles;
+    TileLoc tl = have ? locate(tile) : TileLoc{0, 0, 1};
+    uint64_t pfv[NPRE][kVPT];
+    uint32_t pfvalid[NPRE], pfinr = 0;
+    if (have) load_tile(tl, pfv, pfvalid, pfinr);
+
+    while (have) {
+        // this tile's columns are the ones asked for one trip ago; the next tile's loads go out before this one is interpreted
+        uint64_t colv[NPRE][kVPT];
+        uint32_t colvalid[NPRE];
+        const uint32_t inr = pfinr;
+#pragma unroll
+        for (int p = 0; p < NPRE; ++p) {
+            colvalid[p] = pfvalid[p];
+            RDF_ROWS colv[p][j] = pfv[p][j];
+        }
+        const int64_t ntile = tile + gridDim.x;
+        const bool nhave = ntile < a.ntiles;
+        const TileLoc ntl = nhave ? locate(ntile) : tl;
+        if (nhave) load_tile(ntl, pfv, pfvalid, pfinr);
+
+        uint64_t acc[kVPT];
+        uint32_t accv = 0, keep = inr;
+        RDF_ROWS acc[j] = 0;
+
+        uint64_t nw0 = code_words[0], nw1 = code_words[1];
+        for (int pc = 0; pc < a.ncode; ++pc) {
+            const uint64_t iw0 = nw0, imm = nw1;
+            if (pc + 1 < a.ncode) { nw0 = code_words[2 * pc + 2]; nw1 = code_words[2 * pc + 3]; }
+            const int h = (int)(iw0 >> 41) & 127, kind = (int)(iw0 >> 24) & 255, src = (int)(iw0 >> 48);
+            switch (h) {
+                case LH_LOAD:
+                    if (kind == SRC_COL) {
+#pragma unroll
+                        for (int p = 0; p < NPRE; ++p)
+                            if (p == src) { accv = colvalid[p]; RDF_ROWS acc[j] = colv[p][j]; }
+                    } else if (kind == SRC_IMM) {
+                        accv = (1u << kVPT) - 1;
+                        RDF_ROWS acc[j] = imm;
+                    } else {
+                        const uint64_t* tv = tmp_vals + (size_t)src * kVPT * kBlock + tid;
+                        RDF_ROWS acc[j] = tv[j * kBlock];
+                        accv = tmp_valid[src * kBlock + tid];
+                    }
+                    break;
+                case LH_STORE_TMP: {
+                    uint64_t* tv = tmp_vals + (size_t)src * kVPT * kBlock + tid;
+                    RDF_ROWS tv[j * kBlock] = acc[j];
+                    tmp_valid[src * kBlock + tid] = accv;
+                } break;
+                case LH_FILTER: {   // DataFrame::filter: rows whose predicate is false or null are dropped
+                    uint32_t pass = 0;
+                    RDF_ROWS pass |= ((uint32_t)acc[j] & 1u) << j;
+                    keep &= pass & accv;
+                } break;
+                case LH_NOT: RDF_ROWS acc[j] ^= 1ull; break;
+                case LH_CAST_I2F: RDF_ROWS acc[j] = d2u((double)(int64_t)acc[j]); break;
+                case LH_CAST_U2F: RDF_ROWS acc[j] = d2u((double)acc[j]); break;
+                case LH_EMIT: {   // acc is value expression `src`: folded into the lane's running {sum, min, max, count}
+                    const uint32_t live = keep & accv;
+#pragma unroll
+                    for (int kk = 0; kk < NVAL; ++kk)
+                        if (kk == src) {
+                            const int cls = a.value_cls[kk];
+                            g_cnt[kk] += (int64_t)__popc(live);
+                            if (cls == CLS_F64) {
+                                // a dead row adds +0.0 (the sum starts at +0.0 and can never become -0.0, so that is the identity) and
+                                // offers fmin / fmax the running value itself (fmin(x, x) = x bit for bit, NaN included)
+                                RDF_ROWS {
+                                    const bool l = (live >> j) & 1;
+                                    const uint64_t s = l ? acc[j] : 0ull, lo = l ? acc[j] : g_mn[kk], hi = l ? acc[j] : g_mx[kk];
+                                    g_sum[kk] = d2u(u2d(g_sum[kk]) + u2d(s));
+                                    g_mn[kk] = d2u(fmin(u2d(g_mn[kk]), u2d(lo)));
+                                    g_mx[kk] = d2u(fmax(u2d(g_mx[kk]), u2d(hi)));
+                                }
+                            } else if (cls == CLS_SIGNED) {
+                                RDF_ROWS {
+                                    const bool l = (live >> j) & 1;
+                                    const int64_t v = (int64_t)acc[j], mn = (int64_t)g_mn[kk], mx = (int64_t)g_mx[kk];
+                                    g_sum[kk] += l ? acc[j] : 0ull;
+                                    g_mn[kk] = (uint64_t)(l && v < mn ? v : mn);
+                                    g_mx[kk] = (uint64_t)(l && v > mx ? v : mx);
+                                }
+                            } else {
+                                RDF_ROWS {
+                                    const bool l = (live >> j) & 1;
+                                    g_sum[kk] += l ? acc[j] : 0ull;
+                                    g_mn[kk] = l && acc[j] < g_mn[kk] ? acc[j] : g_mn[kk];
+                                    g_mx[kk] = l && acc[j] > g_mx[kk] ? acc[j] : g_mx[kk];
+                                }
+                            }
+                        }
+                } break;
+                default:   // the binary handlers: the operand is read where it lies
+                    if (kind == SRC_IMM) {
+                        lean_bin(h, acc, [&](int) { return imm; }, accv & inr, err);
+                    } else if (kind == SRC_COL) {
+#pragma unroll
+                        for (int p = 0; p < NPRE; ++p)
+                            if (p == src) {
+                                accv &= colvalid[p];
+                                lean_bin(h, acc, [&](int j) { return colv[p][j]; }, accv & inr, err);
+                            }
+                    } else {
+                        const uint64_t* tv = tmp_vals + (size_t)src * kVPT * kBlock + tid;
+                        uint64_t opnd[kVPT];
+                        RDF_ROWS opnd[j] = tv[j * kBlock];
+                        accv &= tmp_valid[src * kBlock + tid];
+                        lean_bin(h, acc, [&](int j) { return opnd[j]; }, accv & inr, err);
+                    }
+                    break;
+            }
+        }
+        tile = ntile;
+        tl = ntl;
+        have = nhave;
+    }
+
+    // divide by zero at a live slot: bit 0 is the only flag this kernel can raise and the host cleared the word before the
+    // launch, so a plain store by every lane says what atomicOr would (an atomic on one address is rewritten by the compiler
+    // into "the first active lane does it": a per-lane branch)
+    if (__ballot(err != 0) != 0) *(volatile uint32_t*)a.flags = 1u;
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k)
+        if (k < a.nvalues)
+            lean_block_reduce(a.value_cls[k], g_sum[k], g_mn[k], g_mx[k], g_cnt[k], red_lds, &a.partials[(int64_t)blockIdx.x * a.nvalues + k]);
+}
+
+template <int NPRE, int NVAL>
+static void lean_launch_one(const EvalArgs& a, int grid, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((eval_lean_kernel<NPRE, NVAL>), dim3(grid), dim3(kBlock), lds, s, a);
+}
+
+// (NPRE, NVAL) in {(1,1),(2,1),(2,2),(4,1),(4,2),(4,4)} like eval_kernel
+hipError_t launch_eval_lean(const EvalArgs& a, int grid, hipStream_t s) {
+    const size_t lds = (size_t)a.ntmp * (kVPT * kBlock * 8 + kBlock * 4);
+    const int npre = a.ncols, nval = a.nvalues;
+    if (nval <= 1) {
+        if (npre <= 1) lean_launch_one<1, 1>(a, grid, lds, s);
+        else if (npre <= 2) lean_launch_one<2, 1>(a, grid, lds, s);
+        else lean_launch_one<4, 1>(a, grid, lds, s);
+    } else if (nval <= 2) {
+        if (npre <= 2) lean_launch_one<2, 2>(a, grid, lds, s);
+        else lean_launch_one<4, 2>(a, grid, lds, s);
+    } else lean_launch_one<4, 4>(a, grid, lds, s);
+    return hipGetLastError();
+}
+
+}  // namespace rdfk

@@ -938,22 +938,17 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
             const int64_t off = (vb - (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)s_pre[reg])) * (kAggBatch * 64);
             const int64_t base_i = (pline0 + (int64_t)(rb0 + reg) * pcap) * L;
             if (compact) {
-                // 12-byte records -> the 16-byte form the fold below reads: cnt : 8 | the key's image below its partition bits
-                uint32_t kw[kAggBatch];
+                // 12-byte records: the key WORD travels as it was read (zero-extended: never kDead) and becomes the 16-byte form in
+                // the fold.  (Converted here, the words were waited for right after their loads were issued — the next batch was
+                // never in flight under the current one.  Round 6, read off the ISA.)
 #pragma unroll
                 for (int u = 0; u < kAggBatch; ++u) {
                     const int64_t i = off + u * 64 + lane;
-                    kw[u] = 0; r[u][1] = 0;
+                    r[u][0] = kDead; r[u][1] = 0;
                     if (i < nrec) {
-                        kw[u] = __builtin_nontemporal_load(a.recs_k + base_i + i);
+                        r[u][0] = (uint64_t)__builtin_nontemporal_load(a.recs_k + base_i + i);
                         if (a.has_values) r[u][1] = __builtin_nontemporal_load(a.recs + base_i + i);
                     }
-                }
-#pragma unroll
-                for (int u = 0; u < kAggBatch; ++u) {
-                    const int64_t i = off + u * 64 + lane;
-                    const uint64_t h39 = ((uint64_t)p << 31) | (kw[u] & 0x7FFFFFFFu);
-                    r[u][0] = i < nrec ? (((uint64_t)(kw[u] >> 31) << 56) | (g2c_image(h39) & kKeyMask)) : kDead;
                 }
             } else {
 #pragma unroll
@@ -972,6 +967,15 @@ __global__ __launch_bounds__(kG2AggBlock) void gb2_aggregate_kernel(const Gb2Agg
             const bool nhave = load_batch(nxt);
             uint64_t hk[kAggBatch], val[kAggBatch];
             uint32_t cnt[kAggBatch], pending = 0;
+            if (compact) {   // key word -> cnt : 8 | the key's image below its partition bits
+#pragma unroll
+                for (int u = 0; u < kAggBatch; ++u)
+                    if (cur[u][0] != kDead) {
+                        const uint32_t kw = (uint32_t)cur[u][0];
+                        const uint64_t h39 = ((uint64_t)p << 31) | (kw & 0x7FFFFFFFu);
+                        cur[u][0] = ((uint64_t)(kw >> 31) << 56) | (g2c_image(h39) & kKeyMask);
+                    }
+            }
 #pragma unroll
             for (int u = 0; u < kAggBatch; ++u) {
                 hk[u] = (cur[u][0] & kKeyMask) | ptop;
