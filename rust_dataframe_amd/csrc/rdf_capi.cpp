@@ -1022,7 +1022,8 @@ bool lean_assign(const EvalArgs& ea, EvalArgs& lean) {
                 else if (in.dtype == RDF_F64 && in.src_dtype == RDF_U64) h = LH_CAST_U2F;
                 break;
             case BC_BIN: {
-                if (!same) break;
+                // (a 64-bit integer column as the operand of an f64 step is converted on the way in)
+                if (!same && !(in.src_kind == SRC_COL && in.dtype == RDF_F64 && (in.src_dtype == RDF_I64 || in.src_dtype == RDF_U64))) break;
                 if (in.src_kind == SRC_COL && !(in.src < ea.ncols)) break;
                 if (in.src_kind != SRC_COL && in.src_kind != SRC_IMM && in.src_kind != SRC_TMP) break;
                 const bool sw = in.swapped & 1;

@@ -368,6 +368,15 @@ __device__ __forceinline__ void fast_f64(int op, uint64_t (&acc)[kVPT], B b) {
 
 // ------------------------------------------------------------------------------------------------
 
+// Chunk c of column p: the one-batch copy in the kernel arguments, or the host-built table read through the constant address
+// space.  (`a.nchunks == 1 ? a.inline_cols[p] : a.cols[..]` selects between a kernel-argument address and a global one: ONE flat
+// load on the vector memory path, waited for with vmcnt(0) — i.e. together with every column load in flight — and its result
+// counts as different in every lane, so each test on the descriptor became a per-lane branch.  Round 6, read off the ISA.)
+__device__ __forceinline__ DevChunkCol chunk_col(const EvalArgs& a, int p, int64_t c) {
+    if (a.nchunks == 1) return a.inline_cols[p];
+    return const_col(a.cols, (int64_t)p * a.nchunks + c);
+}
+
 template <int FEAT, int SINK, int NPRE, int NVAL>
 __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -411,9 +420,9 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
         TileLoc t;
         if (a.nchunks == 1) { t.c = 0; t.r0 = tile * kEvalTile; t.clen = a.inline_len; }
         else {
-            t.c = find_chunk_tile(a.chunk_tile_start, a.nchunks, tile);
-            t.r0 = (tile - a.chunk_tile_start[t.c]) * kEvalTile;
-            t.clen = a.chunk_len[t.c];
+            t.c = find_chunk_tile(as_const<int64_t>(a.chunk_tile_start), a.nchunks, tile);
+            t.r0 = (tile - as_const<int64_t>(a.chunk_tile_start)[t.c]) * kEvalTile;
+            t.clen = as_const<int64_t>(a.chunk_len)[t.c];
         }
         return t;
     };
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
 #pragma unroll
         for (int p = 0; p < (PF ? NPRE : 0); ++p) {
             if (p < a.ncols) {
-                const DevChunkCol cc = a.nchunks == 1 ? a.inline_cols[p] : a.cols[(int64_t)p * a.nchunks + t.c];
+                const DevChunkCol cc = chunk_col(a, p, t.c);
                 load_col(cc, a.col_dtype[p], rw_, t.clen, inr_, v[p], vv[p]);
             } else {
                 vv[p] = 0;
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
 #pragma unroll
             for (int p = 0; p < NPRE; ++p) {
                 if (p < a.ncols) {
-                    const DevChunkCol cc = a.nchunks == 1 ? a.inline_cols[p] : a.cols[(int64_t)p * a.nchunks + c];
+                    const DevChunkCol cc = chunk_col(a, p, c);
                     load_col(cc, a.col_dtype[p], rw, clen, inr, colv[p], colvalid[p]);
                 } else {
                     colvalid[p] = 0;
@@ -556,7 +565,7 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
                             for (int j = 0; j < kVPT; ++j) opnd[j] = colv[p][j];
                         }
                     if (!hit) {
-                        const DevChunkCol cc = a.nchunks == 1 ? a.inline_cols[ci & (kMaxCols - 1)] : a.cols[(int64_t)ci * a.nchunks + c];
+                        const DevChunkCol cc = chunk_col(a, ci & (kMaxCols - 1), c);
                         load_col(cc, a.col_dtype[ci & (kMaxCols - 1)], rw, clen, inr, opnd, opv);
                         // the loaded values are waited for HERE, on the path that loaded them: left to the compiler the wait lands
                         // where the paths join, as vmcnt(0), and every step of every program then waits for the next tile's prefetch
@@ -662,7 +671,12 @@ __global__ __launch_bounds__(kBlock) void eval_kernel(const EvalArgs a) {
                                     }
                             }
                     } else {
-                        const DevOutChunk oc = a.nchunks == 1 ? a.inline_outs[k & (kMaxValues - 1)] : a.outs[(int64_t)k * a.nchunks + c];
+                        DevOutChunk oc;
+                        if (a.nchunks == 1) oc = a.inline_outs[k & (kMaxValues - 1)];
+                        else {
+                            const ConstPtr<DevOutChunk> ot = as_const<DevOutChunk>(a.outs) + ((int64_t)k * a.nchunks + c);
+                            oc.values = ot->values; oc.validity = ot->validity;
+                        }
                         const int dt = in.dtype;
                         uint32_t nn = 0;
                         // the lane's rows 4 l .. 4 l + 3 leave as one vector store (two for 8-byte values) when the tile is full;

@@ -279,10 +279,11 @@ __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
                             }
                         }
                 } break;
-                default:   // the binary handlers: the operand is read where it lies
+                default: {   // the binary handlers: the operand is read where it lies
+                    const int sdt = (int)(iw0 >> 32) & 255, ddt = (int)(iw0 >> 16) & 255;   // an integer column met in the f64 domain is converted on the way
                     if (kind == SRC_IMM) {
                         lean_bin(h, acc, [&](int) { return imm; }, accv & inr, err);
-                    } else if (kind == SRC_COL) {
+                    } else if (kind == SRC_COL && sdt == ddt) {
 #pragma unroll
                         for (int p = 0; p < NPRE; ++p)
                             if (p == src) {
@@ -290,13 +291,23 @@ __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
                                 lean_bin(h, acc, [&](int j) { return colv[p][j]; }, accv & inr, err);
                             }
                     } else {
-                        const uint64_t* tv = tmp_vals + (size_t)src * kVPT * kBlock + tid;
                         uint64_t opnd[kVPT];
-                        RDF_ROWS opnd[j] = tv[j * kBlock];
-                        accv &= tmp_valid[src * kBlock + tid];
+                        uint32_t opv = 0;
+                        if (kind == SRC_COL) {
+#pragma unroll
+                            for (int p = 0; p < NPRE; ++p)
+                                if (p == src) { opv = colvalid[p]; RDF_ROWS opnd[j] = colv[p][j]; }
+                            if (sdt == RDF_I64) RDF_ROWS opnd[j] = d2u((double)(int64_t)opnd[j]);
+                            else RDF_ROWS opnd[j] = d2u((double)opnd[j]);
+                        } else {
+                            const uint64_t* tv = tmp_vals + (size_t)src * kVPT * kBlock + tid;
+                            RDF_ROWS opnd[j] = tv[j * kBlock];
+                            opv = tmp_valid[src * kBlock + tid];
+                        }
+                        accv &= opv;
                         lean_bin(h, acc, [&](int j) { return opnd[j]; }, accv & inr, err);
                     }
-                    break;
+                } break;
             }
         }
         tile = ntile;

@@ -1,0 +1,135 @@
+"""eval_lean_kernel (rdf_eval_lean.hip): the interpreter's branch-free kernel for aggregate programs over 8-byte columns.
+Held to the oracle like every other device path, and to eval_kernel bit for bit (the two must be interchangeable).
+[Evaluate::calculate src/evaluation.rs:97-323, BooleanFilter::eval_to_array src/expression.rs:766-861,
+ AggregateFunctions src/functions/aggregate.rs:12-93]"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from rust_dataframe_amd import _abi as A
+
+from util import make_chunks
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture
+def interp():
+    """the product with the specialised kernels and the run-time compiler off: every program is interpreted"""
+    from rust_dataframe_amd import lib
+    api = lib.api()
+    if lib.device_count() < 1:
+        pytest.fail("GPU test selected but no HIP device is visible")
+    lib.set_option("spec", 0)
+    lib.set_option("fast_filter", 0)
+    lib.set_option("jit", 0)
+    lib.set_option("interp_lean", 1)
+    yield api, lib
+    lib.set_option("spec", 1)
+    lib.set_option("fast_filter", 1)
+    lib.set_option("jit", 1)
+    lib.set_option("interp_lean", 1)
+
+
+def _programs(e):
+    a, b, k, u = e.col(0), e.col(1), e.col(2), e.col(3)
+    gt = e.op("gt", a, e.scalar(0.5))
+    return {
+        "filter_sum": dict(values=[e.op("add", a, e.scalar(0.0))], filt=gt),
+        "filter_and_or_not": dict(values=[a, b], filt=e.op("or", e.op("and", gt, e.op("lt", b, e.scalar(0.25))), e.op("not", e.op("ge", a, b)))),
+        "literal_on_the_left": dict(values=[e.op("subtract", e.scalar(1.0), a), e.op("divide", e.scalar(2.0), e.op("add", e.op("multiply", a, a), e.scalar(1.0)))],
+                                    filt=e.op("lt", e.scalar(0.25), b)),
+        "bushy_with_temporaries": dict(values=[e.op("multiply", e.op("add", a, b), e.op("subtract", a, e.op("multiply", b, e.scalar(3.0))))], filt=-1),
+        "integer_sums": dict(values=[e.op("add", e.op("multiply", k, k), e.scalar(1, A.I64)), e.op("subtract", e.scalar(7, A.U64), u), k, u],
+                             filt=e.op("ne", k, e.scalar(0, A.I64))),
+        "casts_to_f64": dict(values=[e.op("add", e.cast(k, A.F64), a), e.op("multiply", e.cast(u, A.F64), b)], filt=e.op("gt", u, k)),
+        "no_filter_four_values": dict(values=[a, b, k, u], filt=-1),
+    }
+
+
+LAYOUTS = [([1], 0.0, 0), ([255, 257, 1024, 1], 0.1, 3), ([1024] * 20 + [576], 0.05, 0), ([300_001], 0.0, 1), ([70_000, 5], 0.9, 2)]
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_lean_kernel_against_the_oracle(interp, ora, layout):
+    api, lib = interp
+    lens, nf, off = layout
+    rng = np.random.default_rng(606)
+    cols = [make_chunks(rng, A.F64, lens, nf, off, "unit"), make_chunks(rng, A.F64, lens, nf, off, "unit"),
+            make_chunks(rng, A.I64, lens, nf, off, "plain"), make_chunks(rng, A.U64, lens, nf, off, "plain")]
+    e = A.Expr()
+    for name, p in _programs(e).items():
+        exp = ora.pipeline(e, cols, p["values"], p["filt"])
+        got = api.pipeline(e, cols, p["values"], p["filt"])
+        assert lib.last_kernel() == "eval_kernel<AGG, lean>", f"{name} ran on {lib.last_kernel()}"
+        for v, (g, x) in enumerate(zip(got, exp)):
+            what = f"{name} value {v} lens={lens[:3]} nf={nf}"
+            assert g.count == x.count and g.is_some == x.is_some and g.dtype == x.dtype, what
+            if not x.is_some:
+                continue
+            if g.dtype in (A.F32, A.F64):   # the sum's order differs from the oracle's row order: 1e-6 relative, as for every fused aggregate
+                assert abs(g.sum - x.sum) <= 1e-6 * max(abs(x.sum), 1e-9) + 1e-9, f"sum {what}: {g.sum} vs {x.sum}"
+                assert g.min == x.min and g.max == x.max, what
+            else:
+                assert (g.sum, g.min, g.max) == (x.sum, x.min, x.max), what
+
+
+def test_lean_kernel_and_general_kernel_give_the_same_bits(interp):
+    """Random trees over f64 / i64 / u64 columns with NaN, +-0, infinities, NULLs, ragged batches at odd offsets
+    (tools/lean_ab.py): every rdf_agg_result field equal as a bit pattern, errors (divide by zero) equal too."""
+    api, lib = interp
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lean_ab
+    r = lean_ab.run(api, 150, 2026)
+    assert r["mismatches"] == 0, r["examples"]
+    assert r["took_the_lean_kernel"] >= r["programs"] // 2, r
+
+
+def test_programs_outside_the_lean_class_take_the_general_kernel(interp, ora):
+    api, lib = interp
+    rng = np.random.default_rng(5)
+    lens = [1024, 300]
+    f = [make_chunks(rng, A.F64, lens, 0.0, 0, "unit") for _ in range(5)]
+    i32 = make_chunks(rng, A.I32, lens, 0.0, 0, "plain")
+    e = A.Expr()
+    cases = {
+        "a libm function": ([f[0]], [e.op("sin", e.col(0))], -1),
+        "a 4-byte column": ([f[0], i32], [e.col(0)], e.op("gt", e.col(1), e.scalar(0, A.I32))),
+        "five columns": (f, [e.op("add", e.col(0), e.col(4))], e.op("gt", e.col(1), e.op("add", e.col(2), e.col(3)))),
+        "a narrowing cast": ([f[0]], [e.cast(e.op("multiply", e.col(0), e.scalar(100.0)), A.I64)], -1),
+    }
+    for name, (cols, values, filt) in cases.items():
+        exp = ora.pipeline(e, cols, values, filt)
+        got = api.pipeline(e, cols, values, filt)
+        assert lib.last_kernel() == "eval_kernel<AGG>", f"{name} ran on {lib.last_kernel()}"
+        assert got[0].count == exp[0].count, name
+    lib.set_option("interp_lean", 0)
+    api.pipeline(e, [f[0]], [e.col(0)], e.op("gt", e.col(0), e.scalar(0.5)))
+    assert lib.last_kernel() == "eval_kernel<AGG>", lib.last_kernel()
+
+
+def test_divide_by_zero_at_a_live_slot_is_an_error_on_the_lean_kernel_too(interp):
+    """arrow's math_divide (Evaluate::calculate's divide, src/evaluation.rs:120-128): a zero divisor where both sides are valid
+    fails the call; at a NULL slot it does not."""
+    api, lib = interp
+    x = np.array([1.0, 2.0, 3.0, 4.0] * 300)
+    d = np.array([1.0, 0.0, 2.0, 4.0] * 300)
+    e = A.Expr()
+    q = e.op("divide", e.col(0), e.col(1))
+    with pytest.raises(Exception) as ei:
+        api.pipeline(e, [[A.HostArray.from_numpy(x)], [A.HostArray.from_numpy(d)]], [q], -1)
+    assert lib.last_kernel() == "eval_kernel<AGG, lean>", lib.last_kernel()
+    msg_lean = str(ei.value)
+    lib.set_option("interp_lean", 0)
+    with pytest.raises(Exception) as ei:
+        api.pipeline(e, [[A.HostArray.from_numpy(x)], [A.HostArray.from_numpy(d)]], [q], -1)
+    assert str(ei.value) == msg_lean
+    lib.set_option("interp_lean", 1)
+    valid = d != 0.0
+    got = api.pipeline(e, [[A.HostArray.from_numpy(x)], [A.HostArray.from_numpy(d, valid=valid)]], [q], -1)[0]
+    assert lib.last_kernel() == "eval_kernel<AGG, lean>", lib.last_kernel()
+    assert got.count == int(valid.sum()) and got.sum == pytest.approx(float((x[valid] / d[valid]).sum()), rel=1e-12)

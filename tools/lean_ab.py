@@ -114,22 +114,12 @@ def random_tree(rng, e, dts, depth, want):
     return itree(depth)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--programs", type=int, default=300)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--time", action="store_true")
-    ap.add_argument("--rows", type=int, default=1_000_000_000)
-    args = ap.parse_args()
-    lib.set_device(0)
-    api = lib.api()
-    lib.set_option("spec", 0)
-    lib.set_option("fast_filter", 0)
-    lib.set_option("jit", 0)
-    rng = np.random.default_rng(args.seed)
+def run(api, programs, seed):
+    """-> the summary dict; the caller has switched the specialised kernels and run-time compilation off"""
+    rng = np.random.default_rng(seed)
     ran = lean = bad = failed_both = 0
     examples = []
-    for pi in range(args.programs):
+    for pi in range(programs):
         ncols = int(rng.integers(1, 5))
         dts = [int(rng.choice([A.F64, A.F64, A.I64, A.U64])) for _ in range(ncols)]
         nb = int(rng.choice([1, 1, 2, 5]))
@@ -162,7 +152,24 @@ def main():
             if len(examples) < 5:
                 examples.append({"program": pi, "dtypes": dts, "lens": lens, "general": str(out[0][:2])[:300], "lean": str(out[1][:2])[:300]})
         failed_both += out[0][0] == "err"
-    line = {"programs": ran, "took_the_lean_kernel": lean, "calls_that_failed_on_both (divide by zero)": failed_both, "mismatches": bad, "examples": examples, "seed": args.seed}
+    lib.set_option("interp_lean", 1)
+    return {"programs": ran, "took_the_lean_kernel": lean, "calls_that_failed_on_both (divide by zero)": failed_both, "mismatches": bad, "examples": examples, "seed": seed}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--programs", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--time", action="store_true")
+    ap.add_argument("--rows", type=int, default=1_000_000_000)
+    args = ap.parse_args()
+    lib.set_device(0)
+    api = lib.api()
+    lib.set_option("spec", 0)
+    lib.set_option("fast_filter", 0)
+    lib.set_option("jit", 0)
+    line = run(api, args.programs, args.seed)
+    bad = line["mismatches"]
     if args.time:
         import tools.bench_kernels as bk   # noqa
         n = args.rows
