@@ -20,7 +20,8 @@
 // pair (literals), or LDS (temporaries).  It takes the programs whose every step has a handler: columns of 8-byte types
 // (f64 / i64 / u64) all held in registers (<= 4), f64 comparisons, f64 and 64-bit integer + - *, f64 /, AND / OR / NOT,
 // i64 / u64 -> f64 casts, the filter, aggregate sinks.  Everything else runs on eval_kernel as before; results are the
-// same bit for bit (the fold order of a lane's rows, of the lanes and of the blocks is eval_kernel's).
+// same bit for bit (the fold order of a lane's rows, of the lanes and of the blocks is eval_kernel's), except WHICH NaN a NaN
+// result is (sign, payload: that follows the operand order and source modifiers of the compiled code, in either kernel).
 #include "rdf_common.hip.h"
 
 namespace rdfk {
@@ -251,30 +252,33 @@ __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
                         if (kk == src) {
                             const int cls = a.value_cls[kk];
                             g_cnt[kk] += (int64_t)__popc(live);
+                            // A dead row offers each fold its identity: +0.0 / 0 to the sum (an f64 sum starts at +0.0 and can never
+                            // become -0.0, so adding +0.0 changes no bit), the running minimum / maximum to min / max (fmin(x, x) = x
+                            // bit for bit, NaN included).  Picked with bit masks, not `live ? a : b`: several selects on one per-lane
+                            // condition are what the compiler turns into a per-lane branch.
                             if (cls == CLS_F64) {
-                                // a dead row adds +0.0 (the sum starts at +0.0 and can never become -0.0, so that is the identity) and
-                                // offers fmin / fmax the running value itself (fmin(x, x) = x bit for bit, NaN included)
                                 RDF_ROWS {
-                                    const bool l = (live >> j) & 1;
-                                    const uint64_t s = l ? acc[j] : 0ull, lo = l ? acc[j] : g_mn[kk], hi = l ? acc[j] : g_mx[kk];
+                                    const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
+                                    const uint64_t s = acc[j] & m, lo = (acc[j] & m) | (g_mn[kk] & ~m), hi = (acc[j] & m) | (g_mx[kk] & ~m);
                                     g_sum[kk] = d2u(u2d(g_sum[kk]) + u2d(s));
                                     g_mn[kk] = d2u(fmin(u2d(g_mn[kk]), u2d(lo)));
                                     g_mx[kk] = d2u(fmax(u2d(g_mx[kk]), u2d(hi)));
                                 }
                             } else if (cls == CLS_SIGNED) {
                                 RDF_ROWS {
-                                    const bool l = (live >> j) & 1;
-                                    const int64_t v = (int64_t)acc[j], mn = (int64_t)g_mn[kk], mx = (int64_t)g_mx[kk];
-                                    g_sum[kk] += l ? acc[j] : 0ull;
-                                    g_mn[kk] = (uint64_t)(l && v < mn ? v : mn);
-                                    g_mx[kk] = (uint64_t)(l && v > mx ? v : mx);
+                                    const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
+                                    const int64_t lo = (int64_t)((acc[j] & m) | (g_mn[kk] & ~m)), hi = (int64_t)((acc[j] & m) | (g_mx[kk] & ~m));
+                                    g_sum[kk] += acc[j] & m;
+                                    g_mn[kk] = (uint64_t)(lo < (int64_t)g_mn[kk] ? lo : (int64_t)g_mn[kk]);
+                                    g_mx[kk] = (uint64_t)(hi > (int64_t)g_mx[kk] ? hi : (int64_t)g_mx[kk]);
                                 }
                             } else {
                                 RDF_ROWS {
-                                    const bool l = (live >> j) & 1;
-                                    g_sum[kk] += l ? acc[j] : 0ull;
-                                    g_mn[kk] = l && acc[j] < g_mn[kk] ? acc[j] : g_mn[kk];
-                                    g_mx[kk] = l && acc[j] > g_mx[kk] ? acc[j] : g_mx[kk];
+                                    const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
+                                    const uint64_t lo = (acc[j] & m) | (g_mn[kk] & ~m), hi = (acc[j] & m) | (g_mx[kk] & ~m);
+                                    g_sum[kk] += acc[j] & m;
+                                    g_mn[kk] = lo < g_mn[kk] ? lo : g_mn[kk];
+                                    g_mx[kk] = hi > g_mx[kk] ? hi : g_mx[kk];
                                 }
                             }
                         }

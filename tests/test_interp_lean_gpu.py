@@ -1,5 +1,5 @@
 """eval_lean_kernel (rdf_eval_lean.hip): the interpreter's branch-free kernel for aggregate programs over 8-byte columns.
-Held to the oracle like every other device path, and to eval_kernel bit for bit (the two must be interchangeable).
+Held to the oracle like every other device path, and to eval_kernel bit for bit, any NaN counting as NaN (the two must be interchangeable).
 [Evaluate::calculate src/evaluation.rs:97-323, BooleanFilter::eval_to_array src/expression.rs:766-861,
  AggregateFunctions src/functions/aggregate.rs:12-93]"""
 import os
@@ -80,7 +80,8 @@ def test_lean_kernel_against_the_oracle(interp, ora, layout):
 
 def test_lean_kernel_and_general_kernel_give_the_same_bits(interp):
     """Random trees over f64 / i64 / u64 columns with NaN, +-0, infinities, NULLs, ragged batches at odd offsets
-    (tools/lean_ab.py): every rdf_agg_result field equal as a bit pattern, errors (divide by zero) equal too."""
+    (tools/lean_ab.py): every rdf_agg_result field equal as a bit pattern (a NaN equals any NaN: which one an operation hands on
+    depends on the compiled operand order), errors (divide by zero) equal too."""
     api, lib = interp
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import lean_ab

@@ -3,7 +3,7 @@
 Random expression trees over f64 / i64 / u64 columns — comparisons, + - * /, AND / OR / NOT, casts to f64, literals on either
 side — on data with NaN, +-0, infinities, NULLs, ragged multi-batch columns whose batches start at odd offsets; every program
 runs with rdf_set_option("interp_lean", 0) and 1 (specialised kernels and run-time compilation off) and the two
-rdf_agg_result lists are compared field by field as bit patterns.  Prints one JSON line: programs run, how many took the lean
+rdf_agg_result lists are compared field by field as bit patterns (a NaN equals any NaN).  Prints one JSON line: programs run, how many took the lean
 kernel, mismatches.  --time adds the two kernels' times on filter -> sum at --rows.
 Usage (GPU box): python tools/lean_ab.py [--programs 300] [--seed 1] [--time --rows 1000000000]"""
 import argparse
@@ -23,7 +23,11 @@ from rust_dataframe_amd import lib  # noqa: E402
 
 
 def bits(x):
-    return struct.pack("<d", x) if isinstance(x, float) else int(x)
+    """the value as a bit pattern; every NaN is one value (which NaN an f64 operation hands on — sign, payload — depends on the
+    operand order and the source modifiers the compiler picked: the parity tests against the oracle treat NaN the same way)"""
+    if isinstance(x, float):
+        return b"nan" if x != x else struct.pack("<d", x)
+    return int(x)
 
 
 def same(r0, r1):
