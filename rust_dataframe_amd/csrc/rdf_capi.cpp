@@ -999,7 +999,7 @@ const rdf_status kRetryInterpreted = static_cast<rdf_status>(77);
 // kernel's header says what it covers): columns of 8-byte types all held in registers, f64 comparisons, f64 / 64-bit integer
 // arithmetic, Boolean connectives, i64 / u64 -> f64 casts, the filter, aggregate sinks of 8-byte values.  The indices go into
 // bits 1..7 of Instr::swapped of `lean`, a copy — the program eval_kernel would run is not touched.
-bool lean_assign(const EvalArgs& ea, EvalArgs& lean) {
+bool lean_assign(const EvalArgs& ea, EvalArgs& lean, int sink = SINK_AGG) {
     if (ea.ncols < 1 || ea.ncols > kPreCols || ea.nvalues < 1 || ea.nvalues > kMaxValues || ea.ncode < 1) return false;
     auto wide = [](int dt) { return dt == RDF_F64 || dt == RDF_I64 || dt == RDF_U64; };
     for (int c = 0; c < ea.ncols; ++c) if (!wide(ea.col_dtype[c])) return false;
@@ -1015,7 +1015,7 @@ bool lean_assign(const EvalArgs& ea, EvalArgs& lean) {
                 break;
             case BC_STORE_TMP: h = LH_STORE_TMP; break;
             case BC_FILTER: h = LH_FILTER; break;
-            case BC_EMIT: if (wide(in.dtype) && in.src < ea.nvalues) h = LH_EMIT; break;
+            case BC_EMIT: if ((wide(in.dtype) || (sink == SINK_STORE && in.dtype == RDF_BOOL)) && in.src < ea.nvalues) h = LH_EMIT; break;   // (stored: 8-byte values, or a predicate's bitmap)
             case BC_UN: if (in.op == RDF_OP_NOT) h = LH_NOT; break;
             case BC_CAST:
                 if (in.dtype == RDF_F64 && in.src_dtype == RDF_I64) h = LH_CAST_I2F;
@@ -1069,7 +1069,7 @@ rdf_status launch_agg_pair(const EvalArgs* ea, const FilterAggF64Args* fa, int c
     else if (fa) { c.last_kernel = "filter_agg_f64_kernel"; HIP_TRY(launch_filter_agg_f64(*fa, cmp, grid, c.stream)); }
     else {
         EvalArgs lean;
-        if (c.opt_interp_lean && feat == 0 && lean_assign(*ea, lean)) { c.last_kernel = "eval_kernel<AGG, lean>"; HIP_TRY(launch_eval_lean(lean, grid, c.stream)); }
+        if (c.opt_interp_lean && feat == 0 && lean_assign(*ea, lean)) { c.last_kernel = "eval_kernel<AGG, lean>"; HIP_TRY(launch_eval_lean(lean, SINK_AGG, grid, c.stream)); }
         else { c.last_kernel = "eval_kernel<AGG>"; HIP_TRY(launch_eval(*ea, SINK_AGG, feat, grid, c.stream)); }
     }
     kt.stop();
@@ -1834,7 +1834,16 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             if (le != hipSuccess && jit) { (void)hipGetLastError(); return run_program(ps, cols, ncols, nchunks, outs, aggs, len_mismatch_msg, fc); }   // marked failed: interpreted this time and from now on
             if (le != hipSuccess) return fail(RDF_DEVICE_ERROR, "launch_spec: %s", hipGetErrorString(le));
         }
-        else { ctx.last_kernel = "eval_kernel<STORE>"; HIP_TRY(launch_eval(ea, SINK_STORE, cc.feat(), grid, ctx.stream)); }
+        else {
+            // (the lean kernel adds a tile's NULLs into the low word of the chunk's 64-bit count: chunks of 2^32 rows and more stay on eval_kernel)
+            int64_t longest = 0;
+            for (int64_t i = 0; i < nchunks; ++i) longest = std::max(longest, clen[(size_t)i]);
+            EvalArgs lean;
+            if (ctx.opt_interp_lean && cc.feat() == 0 && longest < ((int64_t)1 << 32) && lean_assign(ea, lean, SINK_STORE)) {
+                ctx.last_kernel = "eval_kernel<STORE, lean>";
+                HIP_TRY(launch_eval_lean(lean, SINK_STORE, grid, ctx.stream));
+            } else { ctx.last_kernel = "eval_kernel<STORE>"; HIP_TRY(launch_eval(ea, SINK_STORE, cc.feat(), grid, ctx.stream)); }
+        }
         kt.stop();
     }
     if (frame_store) {   // flags only: lengths are the frame's batch lengths, null counts stay on the device

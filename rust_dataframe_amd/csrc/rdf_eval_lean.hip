@@ -29,6 +29,7 @@ namespace rdfk {
 #define RDF_ROWS _Pragma("unroll") for (int j = 0; j < kVPT; ++j)
 
 typedef uint64_t lean_u64x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t lean_u32x2 __attribute__((ext_vector_type(2)));
 
 // the lane's 4 bits (rows 4 l .. 4 l + 3) of a 256-bit window held as four 64-bit words (selects, no branch)
 __device__ __forceinline__ uint32_t lean_nibble(const uint64_t (&w)[kVPT], int lane) {
@@ -129,7 +130,24 @@ __device__ __forceinline__ void lean_block_reduce(int cls, uint64_t sum, uint64_
     out->sum = s; out->mn = lo; out->mx = hi; out->cnt = c;
 }
 
-template <int NPRE, int NVAL>
+// SINK_STORE: the four 64-bit words of a wave's 256 rows in a bitmap (validity, or the values of a Boolean output).  The word of
+// rows 64 q .. 64 q + 63 is assembled in lanes 16 q .. 16 q + 15 (nibbles OR-ed over the 16 lanes) and written by lane 16 q
+// through a buffer descriptor that ends with the chunk: the other lanes' offsets lie outside it, as do words past the chunk's
+// last row, and the hardware drops such stores — no per-lane branch.
+__device__ __forceinline__ void lean_store_words(uint8_t* bitmap, int64_t rw, int64_t rows_left, uint32_t nibble, int lane) {
+    uint64_t x = (uint64_t)(nibble & 15u) << (((uint32_t)lane & 15u) * 4u);
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) x |= shfl_xor64(x, m);
+    const int64_t span = rows_left < 0 ? 0 : rows_left < (int64_t)kVPT * 64 ? rows_left : (int64_t)kVPT * 64;   // (a wave past the chunk's end: an empty descriptor)
+    const int nwords = (int)((span + 63) >> 6);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(bitmap + (rw >> 6) * 8, 0, nwords * 8, 0x00020000);
+    lean_u32x2 w;
+    w[0] = (uint32_t)x; w[1] = (uint32_t)(x >> 32);
+    const uint32_t off = ((uint32_t)lane & 15u) == 0 ? ((uint32_t)lane >> 4) * 8u : 0x7FFFFFF0u;
+    __builtin_amdgcn_raw_buffer_store_b64(w, rs, (int)off, 0, 0);
+}
+
+template <int SINK, int NPRE, int NVAL>
 __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ AggPartial red_lds[kBlock / 64];
@@ -138,8 +156,10 @@ __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
 
     uint64_t g_sum[NVAL], g_mn[NVAL], g_mx[NVAL];
     int64_t g_cnt[NVAL];
+    if constexpr (SINK == SINK_AGG) {
 #pragma unroll
-    for (int k = 0; k < NVAL; ++k) agg_init(k < a.nvalues ? a.value_cls[k] : CLS_F64, g_sum[k], g_mn[k], g_mx[k], g_cnt[k]);
+        for (int k = 0; k < NVAL; ++k) agg_init(k < a.nvalues ? a.value_cls[k] : CLS_F64, g_sum[k], g_mn[k], g_mx[k], g_cnt[k]);
+    }
     uint32_t err = 0;
 
     struct TileLoc { int64_t c, r0, clen; };
@@ -245,43 +265,86 @@ __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
                 case LH_NOT: RDF_ROWS acc[j] ^= 1ull; break;
                 case LH_CAST_I2F: RDF_ROWS acc[j] = d2u((double)(int64_t)acc[j]); break;
                 case LH_CAST_U2F: RDF_ROWS acc[j] = d2u((double)acc[j]); break;
-                case LH_EMIT: {   // acc is value expression `src`: folded into the lane's running {sum, min, max, count}
-                    const uint32_t live = keep & accv;
+                case LH_EMIT: {   // acc is value expression `src`
+                    if constexpr (SINK == SINK_AGG) {   // folded into the lane's running {sum, min, max, count}
+                        const uint32_t live = keep & accv;
 #pragma unroll
-                    for (int kk = 0; kk < NVAL; ++kk)
-                        if (kk == src) {
-                            const int cls = a.value_cls[kk];
-                            g_cnt[kk] += (int64_t)__popc(live);
-                            // A dead row offers each fold its identity: +0.0 / 0 to the sum (an f64 sum starts at +0.0 and can never
-                            // become -0.0, so adding +0.0 changes no bit), the running minimum / maximum to min / max (fmin(x, x) = x
-                            // bit for bit, NaN included).  Picked with bit masks, not `live ? a : b`: several selects on one per-lane
-                            // condition are what the compiler turns into a per-lane branch.
-                            if (cls == CLS_F64) {
-                                RDF_ROWS {
-                                    const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
-                                    const uint64_t s = acc[j] & m, lo = (acc[j] & m) | (g_mn[kk] & ~m), hi = (acc[j] & m) | (g_mx[kk] & ~m);
-                                    g_sum[kk] = d2u(u2d(g_sum[kk]) + u2d(s));
-                                    g_mn[kk] = d2u(fmin(u2d(g_mn[kk]), u2d(lo)));
-                                    g_mx[kk] = d2u(fmax(u2d(g_mx[kk]), u2d(hi)));
+                        for (int kk = 0; kk < NVAL; ++kk)
+                            if (kk == src) {
+                                const int cls = a.value_cls[kk];
+                                g_cnt[kk] += (int64_t)__popc(live);
+                                // A dead row offers each fold its identity: +0.0 / 0 to the sum (an f64 sum starts at +0.0 and can never
+                                // become -0.0, so adding +0.0 changes no bit), the running minimum / maximum to min / max (fmin(x, x) = x
+                                // bit for bit, NaN included).  Picked with bit masks, not `live ? a : b`: several selects on one per-lane
+                                // condition are what the compiler turns into a per-lane branch.
+                                if (cls == CLS_F64) {
+                                    RDF_ROWS {
+                                        const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
+                                        const uint64_t s = acc[j] & m, lo = (acc[j] & m) | (g_mn[kk] & ~m), hi = (acc[j] & m) | (g_mx[kk] & ~m);
+                                        g_sum[kk] = d2u(u2d(g_sum[kk]) + u2d(s));
+                                        g_mn[kk] = d2u(fmin(u2d(g_mn[kk]), u2d(lo)));
+                                        g_mx[kk] = d2u(fmax(u2d(g_mx[kk]), u2d(hi)));
+                                    }
+                                } else if (cls == CLS_SIGNED) {
+                                    RDF_ROWS {
+                                        const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
+                                        const int64_t lo = (int64_t)((acc[j] & m) | (g_mn[kk] & ~m)), hi = (int64_t)((acc[j] & m) | (g_mx[kk] & ~m));
+                                        g_sum[kk] += acc[j] & m;
+                                        g_mn[kk] = (uint64_t)(lo < (int64_t)g_mn[kk] ? lo : (int64_t)g_mn[kk]);
+                                        g_mx[kk] = (uint64_t)(hi > (int64_t)g_mx[kk] ? hi : (int64_t)g_mx[kk]);
+                                    }
+                                } else {
+                                    RDF_ROWS {
+                                        const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
+                                        const uint64_t lo = (acc[j] & m) | (g_mn[kk] & ~m), hi = (acc[j] & m) | (g_mx[kk] & ~m);
+                                        g_sum[kk] += acc[j] & m;
+                                        g_mn[kk] = lo < g_mn[kk] ? lo : g_mn[kk];
+                                        g_mx[kk] = hi > g_mx[kk] ? hi : g_mx[kk];
+                                    }
                                 }
-                            } else if (cls == CLS_SIGNED) {
+                            }
+                    } else {   // SINK_STORE: the tile's rows of output column `src` (NULL slots hold 0), its validity words, its NULL count
+                        const int64_t rw = tl.r0 + (int64_t)wave * (kVPT * 64), left = tl.clen - rw;   // (left <= 0: a wave past the chunk's end writes nothing)
+                        DevOutChunk oc;
+                        if (a.nchunks == 1) oc = a.inline_outs[src & (kMaxValues - 1)];
+                        else {
+                            const ConstPtr<DevOutChunk> ot = as_const<DevOutChunk>(a.outs) + ((int64_t)src * a.nchunks + tl.c);
+                            oc.values = ot->values; oc.validity = ot->validity;
+                        }
+                        const uint32_t live = accv & inr;
+                        const int ddt = (int)(iw0 >> 16) & 255;
+                        if (ddt == RDF_BOOL) {
+                            uint32_t bits = 0;
+                            RDF_ROWS bits |= ((uint32_t)acc[j] & 1u) << j;
+                            lean_store_words((uint8_t*)oc.values, rw, left, bits & live, lane);
+                        } else {
+                            uint64_t vv[kVPT];
+                            RDF_ROWS vv[j] = acc[j] & (0ull - (uint64_t)((accv >> j) & 1u));
+                            if (left >= (int64_t)kVPT * 64 && (((uintptr_t)oc.values + (uintptr_t)rw * 8) & 15) == 0) {
+                                lean_u64x2 s0, s1;
+                                s0[0] = vv[0]; s0[1] = vv[1]; s1[0] = vv[2]; s1[1] = vv[3];
+                                GlobalMutPtr<lean_u64x2> q = (GlobalMutPtr<lean_u64x2>)(as_global_mut<uint64_t>(oc.values) + rw + (int64_t)lane * kVPT);
+                                __builtin_nontemporal_store(s0, q); __builtin_nontemporal_store(s1, q + 1);
+                            } else {   // a tail or an odd start: one bounds-checked store per row, rows past the chunk's end dropped by the hardware
+                                const int64_t span = left < 0 ? 0 : left < (int64_t)kVPT * 64 ? left : (int64_t)kVPT * 64;
+                                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((uint64_t*)oc.values + rw, 0, (int)span * 8, 0x00020000);
                                 RDF_ROWS {
-                                    const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
-                                    const int64_t lo = (int64_t)((acc[j] & m) | (g_mn[kk] & ~m)), hi = (int64_t)((acc[j] & m) | (g_mx[kk] & ~m));
-                                    g_sum[kk] += acc[j] & m;
-                                    g_mn[kk] = (uint64_t)(lo < (int64_t)g_mn[kk] ? lo : (int64_t)g_mn[kk]);
-                                    g_mx[kk] = (uint64_t)(hi > (int64_t)g_mx[kk] ? hi : (int64_t)g_mx[kk]);
-                                }
-                            } else {
-                                RDF_ROWS {
-                                    const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
-                                    const uint64_t lo = (acc[j] & m) | (g_mn[kk] & ~m), hi = (acc[j] & m) | (g_mx[kk] & ~m);
-                                    g_sum[kk] += acc[j] & m;
-                                    g_mn[kk] = lo < g_mn[kk] ? lo : g_mn[kk];
-                                    g_mx[kk] = hi > g_mx[kk] ? hi : g_mx[kk];
+                                    lean_u32x2 w;
+                                    w[0] = (uint32_t)vv[j]; w[1] = (uint32_t)(vv[j] >> 32);
+                                    __builtin_amdgcn_raw_buffer_store_b64(w, rs, (lane * kVPT + j) * 8, 0, 0);
                                 }
                             }
                         }
+                        if (oc.validity) lean_store_words(oc.validity, rw, left, live, lane);
+                        // NULLs of the tile: in-range rows that are not live, counted on the scalar unit; the (rare) add goes out
+                        // through a one-word descriptor that only lane 0's offset falls into
+                        uint32_t nn = 0;
+                        RDF_ROWS nn += (uint32_t)__popcll(__ballot(((inr & ~live) >> j) & 1u));
+                        if (nn != 0) {
+                            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(a.out_null_counts + ((int64_t)src * a.nchunks + tl.c), 0, 4, 0x00020000);
+                            (void)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)nn, rc, lane == 0 ? 0 : 0x7FFFFFF0, 0, 0);
+                        }
+                    }
                 } break;
                 default: {   // the binary handlers: the operand is read where it lies
                     const int sdt = (int)(iw0 >> 32) & 255, ddt = (int)(iw0 >> 16) & 255;   // an integer column met in the f64 domain is converted on the way
@@ -323,29 +386,35 @@ __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
     // launch, so a plain store by every lane says what atomicOr would (an atomic on one address is rewritten by the compiler
     // into "the first active lane does it": a per-lane branch)
     if (__ballot(err != 0) != 0) *(volatile uint32_t*)a.flags = 1u;
+    if constexpr (SINK == SINK_AGG) {
 #pragma unroll
-    for (int k = 0; k < NVAL; ++k)
-        if (k < a.nvalues)
-            lean_block_reduce(a.value_cls[k], g_sum[k], g_mn[k], g_mx[k], g_cnt[k], red_lds, &a.partials[(int64_t)blockIdx.x * a.nvalues + k]);
+        for (int k = 0; k < NVAL; ++k)
+            if (k < a.nvalues)
+                lean_block_reduce(a.value_cls[k], g_sum[k], g_mn[k], g_mx[k], g_cnt[k], red_lds, &a.partials[(int64_t)blockIdx.x * a.nvalues + k]);
+    }
 }
 
-template <int NPRE, int NVAL>
+template <int SINK, int NPRE, int NVAL>
 static void lean_launch_one(const EvalArgs& a, int grid, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((eval_lean_kernel<NPRE, NVAL>), dim3(grid), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((eval_lean_kernel<SINK, NPRE, NVAL>), dim3(grid), dim3(kBlock), lds, s, a);
 }
 
-// (NPRE, NVAL) in {(1,1),(2,1),(2,2),(4,1),(4,2),(4,4)} like eval_kernel
-hipError_t launch_eval_lean(const EvalArgs& a, int grid, hipStream_t s) {
+// SINK_AGG: (NPRE, NVAL) in {(1,1),(2,1),(2,2),(4,1),(4,2),(4,4)} like eval_kernel; SINK_STORE keeps no per-value state: NPRE only
+hipError_t launch_eval_lean(const EvalArgs& a, int sink, int grid, hipStream_t s) {
     const size_t lds = (size_t)a.ntmp * (kVPT * kBlock * 8 + kBlock * 4);
     const int npre = a.ncols, nval = a.nvalues;
-    if (nval <= 1) {
-        if (npre <= 1) lean_launch_one<1, 1>(a, grid, lds, s);
-        else if (npre <= 2) lean_launch_one<2, 1>(a, grid, lds, s);
-        else lean_launch_one<4, 1>(a, grid, lds, s);
+    if (sink == SINK_STORE) {
+        if (npre <= 1) lean_launch_one<SINK_STORE, 1, 1>(a, grid, lds, s);
+        else if (npre <= 2) lean_launch_one<SINK_STORE, 2, 1>(a, grid, lds, s);
+        else lean_launch_one<SINK_STORE, 4, 1>(a, grid, lds, s);
+    } else if (nval <= 1) {
+        if (npre <= 1) lean_launch_one<SINK_AGG, 1, 1>(a, grid, lds, s);
+        else if (npre <= 2) lean_launch_one<SINK_AGG, 2, 1>(a, grid, lds, s);
+        else lean_launch_one<SINK_AGG, 4, 1>(a, grid, lds, s);
     } else if (nval <= 2) {
-        if (npre <= 2) lean_launch_one<2, 2>(a, grid, lds, s);
-        else lean_launch_one<4, 2>(a, grid, lds, s);
-    } else lean_launch_one<4, 4>(a, grid, lds, s);
+        if (npre <= 2) lean_launch_one<SINK_AGG, 2, 2>(a, grid, lds, s);
+        else lean_launch_one<SINK_AGG, 4, 2>(a, grid, lds, s);
+    } else lean_launch_one<SINK_AGG, 4, 4>(a, grid, lds, s);
     return hipGetLastError();
 }
 

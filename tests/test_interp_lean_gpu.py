@@ -134,3 +134,114 @@ def test_divide_by_zero_at_a_live_slot_is_an_error_on_the_lean_kernel_too(interp
     got = api.pipeline(e, [[A.HostArray.from_numpy(x)], [A.HostArray.from_numpy(d, valid=valid)]], [q], -1)[0]
     assert lib.last_kernel() == "eval_kernel<AGG, lean>", lib.last_kernel()
     assert got.count == int(valid.sum()) and got.sum == pytest.approx(float((x[valid] / d[valid]).sum()), rel=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ SINK_STORE
+# Evaluate::calculate's own shape (src/evaluation.rs:97-323): a computed column per value expression, NULL where an input is NULL;
+# BooleanFilter::eval_to_array (src/expression.rs:766-861): a predicate's Boolean array.
+
+def _store_programs(e):
+    a, b, k, u = e.col(0), e.col(1), e.col(2), e.col(3)
+    return {
+        "fma": ([e.op("add", e.op("multiply", a, b), e.scalar(0.25))], [A.F64]),
+        "two_columns": ([e.op("subtract", e.scalar(1.0), a), e.op("divide", a, e.op("add", e.op("multiply", b, b), e.scalar(1.0)))], [A.F64, A.F64]),
+        "integers": ([e.op("add", e.op("multiply", k, k), e.scalar(3, A.I64)), e.op("multiply", u, e.scalar(5, A.U64))], [A.I64, A.U64]),
+        "cast_and_add": ([e.op("add", e.cast(k, A.F64), a)], [A.F64]),
+        "predicate": ([e.op("and", e.op("gt", a, e.scalar(0.5)), e.op("not", e.op("lt", b, a))), e.op("ne", k, e.scalar(0, A.I64))], [A.BOOL, A.BOOL]),
+        "predicate_and_value": ([e.op("ge", u, k), e.op("multiply", a, e.scalar(2.0))], [A.BOOL, A.F64]),
+        "bushy_with_temporaries": ([e.op("multiply", e.op("add", a, b), e.op("subtract", a, e.op("multiply", b, e.scalar(3.0))))], [A.F64]),
+    }
+
+
+def _assert_same_chunks(got, exp, what):
+    """two results of the SAME computation: lengths, NULL counts, validity bits and the values at valid slots as bit patterns (NaN = NaN)"""
+    assert len(got) == len(exp), what
+    for i, (g, x) in enumerate(zip(got, exp)):
+        w = f"{what} chunk {i}"
+        assert (g.dtype, g.length, g.null_count) == (x.dtype, x.length, x.null_count), f"{w}: {(g.dtype, g.length, g.null_count)} vs {(x.dtype, x.length, x.null_count)}"
+        gm, xm = g.valid_mask(), x.valid_mask()
+        assert np.array_equal(gm, xm), f"{w}: validity bitmaps differ"
+        gv, xv = g.to_numpy()[xm], x.to_numpy()[xm]
+        if g.dtype == A.F64:
+            nan = np.isnan(xv)
+            assert np.array_equal(np.isnan(gv), nan), w
+            assert np.array_equal(gv[~nan].view(np.uint64), xv[~nan].view(np.uint64)), w
+        else:
+            assert np.array_equal(gv, xv), w
+
+
+@pytest.mark.parametrize("layout", LAYOUTS + [([4096 + 17], 0.3, 1)])
+@pytest.mark.parametrize("with_validity", [True, False])
+def test_lean_store_against_the_oracle_and_the_general_kernel(interp, ora, layout, with_validity):
+    from util import assert_chunks_match
+    api, lib = interp
+    lens, nf, off = layout
+    if not with_validity and nf > 0:
+        pytest.skip("NULLs in the inputs need an output bitmap")
+    rng = np.random.default_rng(707)
+    cols = [make_chunks(rng, A.F64, lens, nf, off, "unit"), make_chunks(rng, A.F64, lens, nf, off, "unit"),
+            make_chunks(rng, A.I64, lens, nf, off, "plain"), make_chunks(rng, A.U64, lens, nf, off, "plain")]
+    e = A.Expr()
+    for name, (vals, dts) in _store_programs(e).items():
+        mk = lambda: [[A.HostArray.empty_out(dt, n, with_validity) for n in lens] for dt in dts]
+        exp = ora.pipeline(e, cols, vals, -1, A.SINK_STORE, mk())
+        lib.set_option("interp_lean", 1)
+        got = api.pipeline(e, cols, vals, -1, A.SINK_STORE, mk())
+        assert lib.last_kernel() == "eval_kernel<STORE, lean>", f"{name} ran on {lib.last_kernel()}"
+        lib.set_option("interp_lean", 0)
+        gen = api.pipeline(e, cols, vals, -1, A.SINK_STORE, mk())
+        assert lib.last_kernel() == "eval_kernel<STORE>", lib.last_kernel()
+        lib.set_option("interp_lean", 1)
+        for v in range(len(vals)):
+            assert_chunks_match(got[v], exp[v], exact=True, what=f"{name} value {v} lens={lens[:3]} (oracle)")
+            _assert_same_chunks(got[v], gen[v], f"{name} value {v} lens={lens[:3]} (general kernel)")
+
+
+def test_lean_store_random_programs_same_as_general_kernel(interp):
+    """random trees (tools/lean_ab.py's generator) stored as columns: the two kernels' outputs chunk by chunk"""
+    api, lib = interp
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lean_ab
+    rng = np.random.default_rng(808)
+    ran = took = 0
+    for pi in range(60):
+        ncols = int(rng.integers(1, 5))
+        dts = [int(rng.choice([A.F64, A.F64, A.I64, A.U64])) for _ in range(ncols)]
+        lens = [int(rng.choice([1, 3, 255, 256, 257, 1024, 1025, 4096 + 17])) for _ in range(int(rng.choice([1, 2, 4])))]
+        nf = float(rng.choice([0.0, 0.1, 0.9]))
+        off = int(rng.integers(0, 4))
+        cols = [make_chunks(rng, dt, lens, nf, off, "unit" if dt == A.F64 else "plain") for dt in dts]
+        e = A.Expr()
+        try:
+            vals, odts = [], []
+            for _ in range(int(rng.integers(1, 4))):
+                icols = [c for c in range(ncols) if dts[c] != A.F64]
+                want = str(rng.choice(["f", "b"] + (["i"] if icols else [])))
+                node = lean_ab.random_tree(rng, e, dts, int(rng.integers(0, 3)), want)
+                vals.append(node)
+                odts.append(want)
+        except Exception:
+            continue
+        outs = []
+        for mode in (0, 1):
+            lib.set_option("interp_lean", mode)
+            # the output type of an integer tree is its columns' type: ask the library by trying the candidates
+            res = None
+            for cand in ([A.I64, A.U64] if "i" in odts else [None]):
+                mk = [[A.HostArray.empty_out(A.F64 if w == "f" else A.BOOL if w == "b" else cand, n, True) for n in lens] for w in odts]
+                try:
+                    res = ("ok", api.pipeline(e, cols, vals, -1, A.SINK_STORE, mk), lib.last_kernel())
+                    break
+                except Exception as ex:
+                    res = ("err", str(ex)[:60], lib.last_kernel())
+            outs.append(res)
+        lib.set_option("interp_lean", 1)
+        assert outs[0][0] == outs[1][0], (pi, outs[0][:2], outs[1][:2])
+        if outs[0][0] == "err":
+            assert outs[0][1] == outs[1][1], (pi, outs[0][1], outs[1][1])
+            continue
+        ran += 1
+        took += "lean" in outs[1][2]
+        for v in range(len(vals)):
+            _assert_same_chunks(outs[1][1][v], outs[0][1][v], f"program {pi} value {v} dtypes {dts} lens {lens}")
+    assert ran >= 20 and took >= ran // 2, (ran, took)
