@@ -649,6 +649,9 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * "filter_block" (rdf_filter_frame's one-pass form and rdf_filter / rdf_filter_columns over device-resident chunks, on frames of equally wide 4- / 8-byte columns in LONG batches: 1 = block tiles held in registers, every tile's row count
  * published one iteration before its offset is asked for, offsets from one scanner wave, default; 0 = the wave-tile kernels),
  * "filter_block_rows" (the mean batch length from which that kernel is taken, default 8192),
+ * "interp_lean" (interpreted programs — no specialised kernel, no compiler — over at most 4 columns of 8-byte types whose every step is a
+ * comparison, f64 / 64-bit integer arithmetic, a Boolean connective, an integer -> f64 cast or the filter, aggregated or stored: 1 = the
+ * interpreter's branch-free kernel with host-assigned step handlers (eval_lean_kernel, 2-3 x the general kernel), default; 0 = eval_kernel),
  * "filter_lookback" (the wave-tile kernel on batches longer than a tile: 3 = one tile per 64 finds the rows in front of them all, from tile
  * counts and older totals, default; 2 = from totals only; 1 = every tile walks the totals and batches beyond 1 048 576 rows take the three passes),
  * "join_table" (equi-join on one key column: 2 = the build side sorted by hash, the table of its distinct keys laid out by a scan,
@@ -667,7 +670,7 @@ int32_t    rdf_spec_catalog_size(void);
 /* One line about the run-time compiler of shapes outside the catalogs: whether `hipcc` and the kernel sources were found (and
  * where), the code-object cache directory ($RDF_JIT_CACHE, else $XDG_CACHE_HOME/rdf_mi355x/jit, else ~/.cache/rdf_mi355x/jit;
  * RDF_JIT_CACHE=off disables it), and how many kernels were compiled / read from the cache / failed / are being compiled.
- * Without a compiler such programs run on the interpreter (same results, 3-20 x slower) unless the cache holds them. */
+ * Without a compiler such programs run on the interpreter (same results; 1.4-2.5 x slower on its lean kernel's class, 3-20 x otherwise) unless the cache holds them. */
 const char* rdf_jit_status(void);
 /* Name of the dominant kernel the last rdf_pipeline-family call of this thread launched. */
 const char* rdf_last_kernel(void);

@@ -65,7 +65,7 @@ def main():
                  "rccl_one_rank.jsonl", "c4_total_rows_1e9.json", "rccl_one_rank_torch.jsonl", "example_dist.txt", "stream_16GB.jsonl", "stream_4GB_hbm_left_1p5GB.jsonl", "ubench_stream.txt",
                  "tilewalk.jsonl", "stream_sinks_16GB.jsonl", "stream_sinks_4GB_hbm_left_1p5GB.jsonl", "rccl_one_rank_fused_combine.jsonl", "groupby_1p25e8_rows.jsonl",
                  "groupby_1p25e8_rows_round4_build.jsonl", "gb_window.jsonl", "ubench_streams.txt", "link_probe.jsonl", "filter_frame_long_batches.jsonl", "join_table_ab.jsonl",
-                 "ref_bench.json", "probe_stream.jsonl", "memory_model_same_box.jsonl", "memory_model_same_box_kernel_stats.csv", "ubench_compact.jsonl", "ubench_take_binned.jsonl"):
+                 "ref_bench.json", "probe_stream.jsonl", "memory_model_same_box.jsonl", "memory_model_same_box_kernel_stats.csv", "ubench_compact.jsonl", "ubench_take_binned.jsonl", "interpreter_lean_ab.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
     agree = None

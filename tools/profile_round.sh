@@ -104,7 +104,8 @@ if [ -x "$REPO/tools/ubench_streams.bin" ]; then timeout 300 "$REPO/tools/ubench
 fi
 # 3f. round 6: the one-pass filter on block tiles (rdf_bfilter.hip) against the wave-tile kernel by batch length, its HBM counters on ONE
 #     batch of 1e9 rows, the mask-given form, the design probe (tools/ubench_compact.bin), the bare-stream probes the memory model is
-#     fitted on (rdf_probe_stream), the reference's own benchmark shape, the take through page-sorted pairs, the two digit-pass kernels
+#     fitted on (rdf_probe_stream), the reference's own benchmark shape, the take through page-sorted pairs, the two digit-pass kernels,
+#     the interpreter's two kernels (tools/lean_ab.py)
 if [ "$PART" = "all" ] || [ "$PART" = "r6" ]; then
 rm -f "$OUT/filter_frame_long_batches.jsonl"
 for cr in 8192 65536 1048576 16777216 1000000000; do for b in 1 0; do
@@ -130,6 +131,8 @@ mkdir -p "$OUT/model"; rocprofv3 --kernel-trace --stats --output-format csv -d "
 cp "$(find "$OUT/model" -name '*kernel_stats.csv' | head -1)" "$OUT/memory_model_same_box_kernel_stats.csv" 2>/dev/null
 if [ -x "$REPO/tools/ubench_compact.bin" ]; then timeout 300 "$REPO/tools/ubench_compact.bin" 1e9 7 > "$OUT/ubench_compact.jsonl" 2>> "$OUT/kernels.err"; fi
 if [ -x "$REPO/tools/ubench_take_binned.bin" ]; then timeout 300 "$REPO/tools/ubench_take_binned.bin" > "$OUT/ubench_take_binned.jsonl" 2>> "$OUT/kernels.err"; fi
+# the interpreter: eval_lean_kernel against eval_kernel, 400 random programs compared field by field + both kernels timed on 1e9 rows
+python "$REPO/tools/lean_ab.py" --programs 400 --seed 21 --time 2>> "$OUT/kernels.err" | tail -1 > "$OUT/interpreter_lean_ab.json"
 fi
 # 4. the scatter micro-benchmark behind the C4 bound
 if [ -x "$REPO/tools/ubench_scatter.bin" ]; then timeout 300 "$REPO/tools/ubench_scatter.bin" > "$OUT/ubench_scatter.txt" 2>&1; fi
