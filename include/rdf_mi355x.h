@@ -651,7 +651,8 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * "filter_block_rows" (the mean batch length from which that kernel is taken, default 8192),
  * "interp_lean" (interpreted programs — no specialised kernel, no compiler — over at most 4 columns of 8-byte types whose every step is a
  * comparison, f64 / 64-bit integer arithmetic, a Boolean connective, an integer -> f64 cast or the filter, aggregated or stored: 1 = the
- * interpreter's branch-free kernel with host-assigned step handlers (eval_lean_kernel, 2-3 x the general kernel), default; 0 = eval_kernel),
+ * interpreter's branch-free kernel with host-assigned step handlers (eval_lean_kernel, 1.4-2.2 x the general kernel on aggregates), default;
+ * 2 = the same with one tile per trip of its step loop (the A/B of its two-tile form); 0 = eval_kernel),
  * "filter_lookback" (the wave-tile kernel on batches longer than a tile: 3 = one tile per 64 finds the rows in front of them all, from tile
  * counts and older totals, default; 2 = from totals only; 1 = every tile walks the totals and batches beyond 1 048 576 rows take the three passes),
  * "join_table" (equi-join on one key column: 2 = the build side sorted by hash, the table of its distinct keys laid out by a scan,

@@ -1069,7 +1069,7 @@ rdf_status launch_agg_pair(const EvalArgs* ea, const FilterAggF64Args* fa, int c
     else if (fa) { c.last_kernel = "filter_agg_f64_kernel"; HIP_TRY(launch_filter_agg_f64(*fa, cmp, grid, c.stream)); }
     else {
         EvalArgs lean;
-        if (c.opt_interp_lean && feat == 0 && lean_assign(*ea, lean)) { c.last_kernel = "eval_kernel<AGG, lean>"; HIP_TRY(launch_eval_lean(lean, SINK_AGG, grid, c.stream)); }
+        if (c.opt_interp_lean && feat == 0 && lean_assign(*ea, lean)) { c.last_kernel = "eval_kernel<AGG, lean>"; HIP_TRY(launch_eval_lean(lean, SINK_AGG, grid, c.stream, c.opt_interp_lean == 2)); }
         else { c.last_kernel = "eval_kernel<AGG>"; HIP_TRY(launch_eval(*ea, SINK_AGG, feat, grid, c.stream)); }
     }
     kt.stop();
@@ -1841,7 +1841,7 @@ rdf_status run_program(const ProgramSpec& ps, const rdf_array* cols, int ncols, 
             EvalArgs lean;
             if (ctx.opt_interp_lean && cc.feat() == 0 && longest < ((int64_t)1 << 32) && lean_assign(ea, lean, SINK_STORE)) {
                 ctx.last_kernel = "eval_kernel<STORE, lean>";
-                HIP_TRY(launch_eval_lean(lean, SINK_STORE, grid, ctx.stream));
+                HIP_TRY(launch_eval_lean(lean, SINK_STORE, grid, ctx.stream, ctx.opt_interp_lean == 2));
             } else { ctx.last_kernel = "eval_kernel<STORE>"; HIP_TRY(launch_eval(ea, SINK_STORE, cc.feat(), grid, ctx.stream)); }
         }
         kt.stop();
@@ -4481,7 +4481,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "filter_gen") == 0) g_ctx.opt_filter_gen = (int)value;
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
     else if (strcmp(name, "filter_block") == 0) g_ctx.opt_filter_block = value == 3 ? 3 : value != 0;      // (3: tests — the scanner wave stays idle, every wait must time out)
-    else if (strcmp(name, "interp_lean") == 0) g_ctx.opt_interp_lean = value != 0;
+    else if (strcmp(name, "interp_lean") == 0) g_ctx.opt_interp_lean = value == 2 ? 2 : value != 0;   // (2: the lean kernel with one tile per trip of its step loop — the A/B of its two-tile form)
     else if (strcmp(name, "filter_block_rows") == 0) g_ctx.opt_filter_block_rows = value < 1 ? 1 : (int)value;
     else if (strcmp(name, "filter_lookback") == 0) g_ctx.opt_filter_lookback = value == 1 ? 1 : value == 2 ? 2 : 3;
     else if (strcmp(name, "comm_max_bytes") == 0) g_ctx.opt_comm_max_bytes = value;

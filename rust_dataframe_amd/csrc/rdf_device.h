@@ -725,7 +725,7 @@ hipError_t launch_list_offsets(const int64_t* scan, int64_t n1, int32_t* out, hi
 // ---- launch wrappers (defined in rdf_kernels.hip) ----
 int  eval_grid_limit();   // persistent grid size for streaming kernels
 hipError_t launch_probe(int kind, int u, int grid, const void* a, void* b, void* c, int64_t nvec, uint32_t* sink, hipStream_t s);   // rdf_probe.hip: bare streams
-hipError_t launch_eval_lean(const EvalArgs& a, int sink, int grid, hipStream_t s);   // SINK_AGG / SINK_STORE programs whose every step has a lean handler (rdf_eval_lean.hip)
+hipError_t launch_eval_lean(const EvalArgs& a, int sink, int grid, hipStream_t s, bool one_tile = false);   // SINK_AGG / SINK_STORE programs whose every step has a lean handler (rdf_eval_lean.hip)
 hipError_t launch_eval(const EvalArgs& a, int sink, int feat, int grid, hipStream_t s);  // feat: 0 basic, 1 +int div, 2 +libm
 bool gspec_available(const char* sig);
 hipError_t launch_gspec(const char* sig, const GSpecArgs& a, int grid, hipStream_t s);

@@ -65,45 +65,46 @@ __device__ __forceinline__ void lean_load8(const DevChunkCol cc, int64_t rw, int
     }
 }
 
-// acc = acc OP b(j) for the binary handlers; `live` = rows where both sides are valid and in range (a zero divisor is an
-// error only there, like arrow's math_divide; the quotient of such a slot is 0 as in eval_kernel)
-template <class B>
-__device__ __forceinline__ void lean_bin(int h, uint64_t (&acc)[kVPT], B b, uint32_t live, uint32_t& err) {
+// acc = acc OP b(r) for the binary handlers over the R rows a lane holds per trip; `live` = rows where both sides are valid and
+// in range (a zero divisor is an error only there, like arrow's math_divide; the quotient of such a slot is 0 as in eval_kernel)
+#define RDF_ROWS_R _Pragma("unroll") for (int r = 0; r < R; ++r)
+template <int R, class B>
+__device__ __forceinline__ void lean_bin(int h, uint64_t (&acc)[R], B b, uint32_t live, uint32_t& err) {
     switch (h) {
-        case LH_F_GT: RDF_ROWS acc[j] = u2d(acc[j]) > u2d(b(j)); break;
-        case LH_F_GE: RDF_ROWS acc[j] = u2d(acc[j]) >= u2d(b(j)); break;
-        case LH_F_EQ: RDF_ROWS acc[j] = u2d(acc[j]) == u2d(b(j)); break;
-        case LH_F_NE: RDF_ROWS acc[j] = u2d(acc[j]) != u2d(b(j)); break;
-        case LH_F_LT: RDF_ROWS acc[j] = u2d(acc[j]) < u2d(b(j)); break;
-        case LH_F_LE: RDF_ROWS acc[j] = u2d(acc[j]) <= u2d(b(j)); break;
-        case LH_F_ADD: RDF_ROWS acc[j] = d2u(u2d(acc[j]) + u2d(b(j))); break;
-        case LH_F_SUB: RDF_ROWS acc[j] = d2u(u2d(acc[j]) - u2d(b(j))); break;
-        case LH_F_RSUB: RDF_ROWS acc[j] = d2u(u2d(b(j)) - u2d(acc[j])); break;
-        case LH_F_MUL: RDF_ROWS acc[j] = d2u(u2d(acc[j]) * u2d(b(j))); break;
+        case LH_F_GT: RDF_ROWS_R acc[r] = u2d(acc[r]) > u2d(b(r)); break;
+        case LH_F_GE: RDF_ROWS_R acc[r] = u2d(acc[r]) >= u2d(b(r)); break;
+        case LH_F_EQ: RDF_ROWS_R acc[r] = u2d(acc[r]) == u2d(b(r)); break;
+        case LH_F_NE: RDF_ROWS_R acc[r] = u2d(acc[r]) != u2d(b(r)); break;
+        case LH_F_LT: RDF_ROWS_R acc[r] = u2d(acc[r]) < u2d(b(r)); break;
+        case LH_F_LE: RDF_ROWS_R acc[r] = u2d(acc[r]) <= u2d(b(r)); break;
+        case LH_F_ADD: RDF_ROWS_R acc[r] = d2u(u2d(acc[r]) + u2d(b(r))); break;
+        case LH_F_SUB: RDF_ROWS_R acc[r] = d2u(u2d(acc[r]) - u2d(b(r))); break;
+        case LH_F_RSUB: RDF_ROWS_R acc[r] = d2u(u2d(b(r)) - u2d(acc[r])); break;
+        case LH_F_MUL: RDF_ROWS_R acc[r] = d2u(u2d(acc[r]) * u2d(b(r))); break;
         case LH_F_DIV:
-            RDF_ROWS {
-                const bool z = u2d(b(j)) == 0.0;
-                err |= (uint32_t)z & (live >> j) & 1u;
-                double q = u2d(acc[j]) / u2d(b(j));
+            RDF_ROWS_R {
+                const bool z = u2d(b(r)) == 0.0;
+                err |= (uint32_t)z & (live >> r) & 1u;
+                double q = u2d(acc[r]) / u2d(b(r));
                 asm volatile("" : "+v"(q));   // (keeps the division out of a per-lane branch the compiler would form around it)
-                acc[j] = z ? 0 : d2u(q);
+                acc[r] = z ? 0 : d2u(q);
             }
             break;
         case LH_F_RDIV:
-            RDF_ROWS {
-                const bool z = u2d(acc[j]) == 0.0;
-                err |= (uint32_t)z & (live >> j) & 1u;
-                double q = u2d(b(j)) / u2d(acc[j]);
+            RDF_ROWS_R {
+                const bool z = u2d(acc[r]) == 0.0;
+                err |= (uint32_t)z & (live >> r) & 1u;
+                double q = u2d(b(r)) / u2d(acc[r]);
                 asm volatile("" : "+v"(q));
-                acc[j] = z ? 0 : d2u(q);
+                acc[r] = z ? 0 : d2u(q);
             }
             break;
-        case LH_I_ADD: RDF_ROWS acc[j] = acc[j] + b(j); break;
-        case LH_I_SUB: RDF_ROWS acc[j] = acc[j] - b(j); break;
-        case LH_I_RSUB: RDF_ROWS acc[j] = b(j) - acc[j]; break;
-        case LH_I_MUL: RDF_ROWS acc[j] = acc[j] * b(j); break;
-        case LH_AND: RDF_ROWS acc[j] = acc[j] & b(j); break;
-        default: RDF_ROWS acc[j] = acc[j] | b(j); break;   // LH_OR
+        case LH_I_ADD: RDF_ROWS_R acc[r] = acc[r] + b(r); break;
+        case LH_I_SUB: RDF_ROWS_R acc[r] = acc[r] - b(r); break;
+        case LH_I_RSUB: RDF_ROWS_R acc[r] = b(r) - acc[r]; break;
+        case LH_I_MUL: RDF_ROWS_R acc[r] = acc[r] * b(r); break;
+        case LH_AND: RDF_ROWS_R acc[r] = acc[r] & b(r); break;
+        default: RDF_ROWS_R acc[r] = acc[r] | b(r); break;   // LH_OR
     }
 }
 
@@ -147,8 +148,14 @@ __device__ __forceinline__ void lean_store_words(uint8_t* bitmap, int64_t rw, in
     __builtin_amdgcn_raw_buffer_store_b64(w, rs, (int)off, 0, 0);
 }
 
-template <int SINK, int NPRE, int NVAL>
+// T = tiles per trip of the step loop.  With T = 2 a block interprets its tile AND the next one it would visit (tile + gridDim.x)
+// in one pass over the bytecode — a lane holds 8 rows, a step's dispatch is paid once for both — and two tiles' columns are in
+// flight per wave while it does.  A lane's rows meet its running aggregates in the order they always did (this tile's four, then
+// the next tile's four), so the result does not depend on T.
+template <int SINK, int NPRE, int NVAL, int T>
 __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
+    constexpr int R = T * kVPT;
+    constexpr uint32_t kAllRows = (1u << R) - 1u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ AggPartial red_lds[kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -181,7 +188,14 @@ __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
         const int64_t n = left < 0 ? 0 : left > kVPT ? kVPT : left;
         return (1u << (uint32_t)n) - 1u;
     };
-    auto load_tile = [&](const TileLoc& t, uint64_t (&v)[NPRE][kVPT], uint32_t (&vv)[NPRE], uint32_t& inr_) {
+    // one tile's columns into v / vv, its row mask into inr_; a tile that does not exist (past the last one) has no rows
+    auto load_tile = [&](bool exists, const TileLoc& t, uint64_t (&v)[NPRE][kVPT], uint32_t (&vv)[NPRE], uint32_t& inr_) {
+        if (!exists) {
+            inr_ = 0;
+#pragma unroll
+            for (int p = 0; p < NPRE; ++p) { vv[p] = 0; RDF_ROWS v[p][j] = 0; }
+            return;
+        }
         const int64_t rw_ = t.r0 + (int64_t)wave * (kVPT * 64);
         bool full;
         inr_ = rows_in_range(t, full);
@@ -203,37 +217,57 @@ __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
     };
 
     const uint64_t* const code_words = (const uint64_t*)a.code;
-    uint64_t* const tmp_vals = (uint64_t*)smem;                                          // [ntmp][kVPT][kBlock]
-    uint32_t* const tmp_valid = (uint32_t*)(smem + (size_t)a.ntmp * kVPT * kBlock * 8);  // [ntmp][kBlock]
+    uint64_t* const tmp_vals = (uint64_t*)smem;                                        // [ntmp][R][kBlock]
+    uint32_t* const tmp_valid = (uint32_t*)(smem + (size_t)a.ntmp * R * kBlock * 8);   // [ntmp][kBlock]: R bits each
 
+    // the trip's tiles: tile, tile + gridDim.x, ... (T of them); the NEXT trip's columns are asked for before this one is interpreted
     int64_t tile = blockIdx.x;
+    TileLoc tl[T];
+    uint64_t pfv[T][NPRE][kVPT];
+    uint32_t pfvalid[T][NPRE], pfinr[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int64_t tt = tile + (int64_t)t * gridDim.x;
+        const bool ex = tt < a.ntiles;
+        tl[t] = ex ? locate(tt) : TileLoc{0, 0, 0};
+        load_tile(ex, tl[t], pfv[t], pfvalid[t], pfinr[t]);
+    }
     bool have = tile < a.ntiles;
-    TileLoc tl = have ? locate(tile) : TileLoc{0, 0, 1};
-    uint64_t pfv[NPRE][kVPT];
-    uint32_t pfvalid[NPRE], pfinr = 0;
-    if (have) load_tile(tl, pfv, pfvalid, pfinr);
 
     while (have) {
-        // this tile's columns are the ones asked for one trip ago; the next tile's loads go out before this one is interpreted
-        uint64_t colv[NPRE][kVPT];
-        uint32_t colvalid[NPRE];
-        const uint32_t inr = pfinr;
+        uint64_t colv[T][NPRE][kVPT];
+        uint32_t colvalid[NPRE];      // R bits per column: tile t's rows at bits 4 t .. 4 t + 3
+        uint32_t inr = 0;
+        TileLoc cur[T];
 #pragma unroll
-        for (int p = 0; p < NPRE; ++p) {
-            colvalid[p] = pfvalid[p];
-            RDF_ROWS colv[p][j] = pfv[p][j];
+        for (int p = 0; p < NPRE; ++p) colvalid[p] = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            cur[t] = tl[t];
+            inr |= pfinr[t] << (kVPT * t);
+#pragma unroll
+            for (int p = 0; p < NPRE; ++p) {
+                colvalid[p] |= pfvalid[t][p] << (kVPT * t);
+                RDF_ROWS colv[t][p][j] = pfv[t][p][j];
+            }
         }
-        const int64_t ntile = tile + gridDim.x;
+        const int64_t ntile = tile + (int64_t)T * gridDim.x;
         const bool nhave = ntile < a.ntiles;
-        const TileLoc ntl = nhave ? locate(ntile) : tl;
-        if (nhave) load_tile(ntl, pfv, pfvalid, pfinr);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int64_t tt = ntile + (int64_t)t * gridDim.x;
+            const bool ex = tt < a.ntiles;
+            tl[t] = ex ? locate(tt) : TileLoc{0, 0, 0};
+            load_tile(ex, tl[t], pfv[t], pfvalid[t], pfinr[t]);
+        }
 
-        uint64_t acc[kVPT];
+        uint64_t acc[R];
         uint32_t accv = 0, keep = inr;
-        RDF_ROWS acc[j] = 0;
+        RDF_ROWS_R acc[r] = 0;
 
         uint64_t nw0 = code_words[0], nw1 = code_words[1];
         for (int pc = 0; pc < a.ncode; ++pc) {
+            // one step = 16 bytes in scalar registers; the next step's words are asked for now and used one trip later
             const uint64_t iw0 = nw0, imm = nw1;
             if (pc + 1 < a.ncode) { nw0 = code_words[2 * pc + 2]; nw1 = code_words[2 * pc + 3]; }
             const int h = (int)(iw0 >> 41) & 127, kind = (int)(iw0 >> 24) & 255, src = (int)(iw0 >> 48);
@@ -242,31 +276,31 @@ __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
                     if (kind == SRC_COL) {
 #pragma unroll
                         for (int p = 0; p < NPRE; ++p)
-                            if (p == src) { accv = colvalid[p]; RDF_ROWS acc[j] = colv[p][j]; }
+                            if (p == src) { accv = colvalid[p]; RDF_ROWS_R acc[r] = colv[r / kVPT][p][r % kVPT]; }
                     } else if (kind == SRC_IMM) {
-                        accv = (1u << kVPT) - 1;
-                        RDF_ROWS acc[j] = imm;
+                        accv = kAllRows;
+                        RDF_ROWS_R acc[r] = imm;
                     } else {
-                        const uint64_t* tv = tmp_vals + (size_t)src * kVPT * kBlock + tid;
-                        RDF_ROWS acc[j] = tv[j * kBlock];
+                        const uint64_t* tv = tmp_vals + (size_t)src * R * kBlock + tid;
+                        RDF_ROWS_R acc[r] = tv[r * kBlock];
                         accv = tmp_valid[src * kBlock + tid];
                     }
                     break;
                 case LH_STORE_TMP: {
-                    uint64_t* tv = tmp_vals + (size_t)src * kVPT * kBlock + tid;
-                    RDF_ROWS tv[j * kBlock] = acc[j];
+                    uint64_t* tv = tmp_vals + (size_t)src * R * kBlock + tid;
+                    RDF_ROWS_R tv[r * kBlock] = acc[r];
                     tmp_valid[src * kBlock + tid] = accv;
                 } break;
                 case LH_FILTER: {   // DataFrame::filter: rows whose predicate is false or null are dropped
                     uint32_t pass = 0;
-                    RDF_ROWS pass |= ((uint32_t)acc[j] & 1u) << j;
+                    RDF_ROWS_R pass |= ((uint32_t)acc[r] & 1u) << r;
                     keep &= pass & accv;
                 } break;
-                case LH_NOT: RDF_ROWS acc[j] ^= 1ull; break;
-                case LH_CAST_I2F: RDF_ROWS acc[j] = d2u((double)(int64_t)acc[j]); break;
-                case LH_CAST_U2F: RDF_ROWS acc[j] = d2u((double)acc[j]); break;
+                case LH_NOT: RDF_ROWS_R acc[r] ^= 1ull; break;
+                case LH_CAST_I2F: RDF_ROWS_R acc[r] = d2u((double)(int64_t)acc[r]); break;
+                case LH_CAST_U2F: RDF_ROWS_R acc[r] = d2u((double)acc[r]); break;
                 case LH_EMIT: {   // acc is value expression `src`
-                    if constexpr (SINK == SINK_AGG) {   // folded into the lane's running {sum, min, max, count}
+                    if constexpr (SINK == SINK_AGG) {   // folded into the lane's running {sum, min, max, count}, rows in trip order
                         const uint32_t live = keep & accv;
 #pragma unroll
                         for (int kk = 0; kk < NVAL; ++kk)
@@ -278,107 +312,109 @@ __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
                                 // bit for bit, NaN included).  Picked with bit masks, not `live ? a : b`: several selects on one per-lane
                                 // condition are what the compiler turns into a per-lane branch.
                                 if (cls == CLS_F64) {
-                                    RDF_ROWS {
-                                        const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
-                                        const uint64_t s = acc[j] & m, lo = (acc[j] & m) | (g_mn[kk] & ~m), hi = (acc[j] & m) | (g_mx[kk] & ~m);
+                                    RDF_ROWS_R {
+                                        const uint64_t m = 0ull - (uint64_t)((live >> r) & 1u);
+                                        const uint64_t s = acc[r] & m, lo = (acc[r] & m) | (g_mn[kk] & ~m), hi = (acc[r] & m) | (g_mx[kk] & ~m);
                                         g_sum[kk] = d2u(u2d(g_sum[kk]) + u2d(s));
                                         g_mn[kk] = d2u(fmin(u2d(g_mn[kk]), u2d(lo)));
                                         g_mx[kk] = d2u(fmax(u2d(g_mx[kk]), u2d(hi)));
                                     }
                                 } else if (cls == CLS_SIGNED) {
-                                    RDF_ROWS {
-                                        const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
-                                        const int64_t lo = (int64_t)((acc[j] & m) | (g_mn[kk] & ~m)), hi = (int64_t)((acc[j] & m) | (g_mx[kk] & ~m));
-                                        g_sum[kk] += acc[j] & m;
+                                    RDF_ROWS_R {
+                                        const uint64_t m = 0ull - (uint64_t)((live >> r) & 1u);
+                                        const int64_t lo = (int64_t)((acc[r] & m) | (g_mn[kk] & ~m)), hi = (int64_t)((acc[r] & m) | (g_mx[kk] & ~m));
+                                        g_sum[kk] += acc[r] & m;
                                         g_mn[kk] = (uint64_t)(lo < (int64_t)g_mn[kk] ? lo : (int64_t)g_mn[kk]);
                                         g_mx[kk] = (uint64_t)(hi > (int64_t)g_mx[kk] ? hi : (int64_t)g_mx[kk]);
                                     }
                                 } else {
-                                    RDF_ROWS {
-                                        const uint64_t m = 0ull - (uint64_t)((live >> j) & 1u);
-                                        const uint64_t lo = (acc[j] & m) | (g_mn[kk] & ~m), hi = (acc[j] & m) | (g_mx[kk] & ~m);
-                                        g_sum[kk] += acc[j] & m;
+                                    RDF_ROWS_R {
+                                        const uint64_t m = 0ull - (uint64_t)((live >> r) & 1u);
+                                        const uint64_t lo = (acc[r] & m) | (g_mn[kk] & ~m), hi = (acc[r] & m) | (g_mx[kk] & ~m);
+                                        g_sum[kk] += acc[r] & m;
                                         g_mn[kk] = lo < g_mn[kk] ? lo : g_mn[kk];
                                         g_mx[kk] = hi > g_mx[kk] ? hi : g_mx[kk];
                                     }
                                 }
                             }
-                    } else {   // SINK_STORE: the tile's rows of output column `src` (NULL slots hold 0), its validity words, its NULL count
-                        const int64_t rw = tl.r0 + (int64_t)wave * (kVPT * 64), left = tl.clen - rw;   // (left <= 0: a wave past the chunk's end writes nothing)
-                        DevOutChunk oc;
-                        if (a.nchunks == 1) oc = a.inline_outs[src & (kMaxValues - 1)];
-                        else {
-                            const ConstPtr<DevOutChunk> ot = as_const<DevOutChunk>(a.outs) + ((int64_t)src * a.nchunks + tl.c);
-                            oc.values = ot->values; oc.validity = ot->validity;
-                        }
-                        const uint32_t live = accv & inr;
+                    } else {   // SINK_STORE: each tile's rows of output column `src` (NULL slots hold 0), its validity words, its NULL count
                         const int ddt = (int)(iw0 >> 16) & 255;
-                        if (ddt == RDF_BOOL) {
-                            uint32_t bits = 0;
-                            RDF_ROWS bits |= ((uint32_t)acc[j] & 1u) << j;
-                            lean_store_words((uint8_t*)oc.values, rw, left, bits & live, lane);
-                        } else {
-                            uint64_t vv[kVPT];
-                            RDF_ROWS vv[j] = acc[j] & (0ull - (uint64_t)((accv >> j) & 1u));
-                            if (left >= (int64_t)kVPT * 64 && (((uintptr_t)oc.values + (uintptr_t)rw * 8) & 15) == 0) {
-                                lean_u64x2 s0, s1;
-                                s0[0] = vv[0]; s0[1] = vv[1]; s1[0] = vv[2]; s1[1] = vv[3];
-                                GlobalMutPtr<lean_u64x2> q = (GlobalMutPtr<lean_u64x2>)(as_global_mut<uint64_t>(oc.values) + rw + (int64_t)lane * kVPT);
-                                __builtin_nontemporal_store(s0, q); __builtin_nontemporal_store(s1, q + 1);
-                            } else {   // a tail or an odd start: one bounds-checked store per row, rows past the chunk's end dropped by the hardware
-                                const int64_t span = left < 0 ? 0 : left < (int64_t)kVPT * 64 ? left : (int64_t)kVPT * 64;
-                                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((uint64_t*)oc.values + rw, 0, (int)span * 8, 0x00020000);
-                                RDF_ROWS {
-                                    lean_u32x2 w;
-                                    w[0] = (uint32_t)vv[j]; w[1] = (uint32_t)(vv[j] >> 32);
-                                    __builtin_amdgcn_raw_buffer_store_b64(w, rs, (lane * kVPT + j) * 8, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < T; ++t) {
+                            const int64_t rw = cur[t].r0 + (int64_t)wave * (kVPT * 64), left = cur[t].clen - rw;   // (left <= 0: nothing of this wave's span exists — also a tile past the last one — and nothing is written)
+                            DevOutChunk oc;
+                            if (a.nchunks == 1) oc = a.inline_outs[src & (kMaxValues - 1)];
+                            else {
+                                const ConstPtr<DevOutChunk> ot = as_const<DevOutChunk>(a.outs) + ((int64_t)src * a.nchunks + cur[t].c);
+                                oc.values = ot->values; oc.validity = ot->validity;
+                            }
+                            const uint32_t inr_t = (inr >> (kVPT * t)) & 15u, accv_t = (accv >> (kVPT * t)) & 15u, live = accv_t & inr_t;
+                            if (ddt == RDF_BOOL) {
+                                uint32_t bits = 0;
+                                RDF_ROWS bits |= ((uint32_t)acc[kVPT * t + j] & 1u) << j;
+                                lean_store_words((uint8_t*)oc.values, rw, left, bits & live, lane);
+                            } else {
+                                uint64_t vv[kVPT];
+                                RDF_ROWS vv[j] = acc[kVPT * t + j] & (0ull - (uint64_t)((accv_t >> j) & 1u));
+                                if (left >= (int64_t)kVPT * 64 && (((uintptr_t)oc.values + (uintptr_t)rw * 8) & 15) == 0) {
+                                    lean_u64x2 s0, s1;
+                                    s0[0] = vv[0]; s0[1] = vv[1]; s1[0] = vv[2]; s1[1] = vv[3];
+                                    GlobalMutPtr<lean_u64x2> q = (GlobalMutPtr<lean_u64x2>)(as_global_mut<uint64_t>(oc.values) + rw + (int64_t)lane * kVPT);
+                                    __builtin_nontemporal_store(s0, q); __builtin_nontemporal_store(s1, q + 1);
+                                } else {   // a tail or an odd start: one bounds-checked store per row, rows past the chunk's end dropped by the hardware
+                                    const int64_t span = left < 0 ? 0 : left < (int64_t)kVPT * 64 ? left : (int64_t)kVPT * 64;
+                                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((uint64_t*)oc.values + rw, 0, (int)span * 8, 0x00020000);
+                                    RDF_ROWS {
+                                        lean_u32x2 w;
+                                        w[0] = (uint32_t)vv[j]; w[1] = (uint32_t)(vv[j] >> 32);
+                                        __builtin_amdgcn_raw_buffer_store_b64(w, rs, (lane * kVPT + j) * 8, 0, 0);
+                                    }
                                 }
                             }
-                        }
-                        if (oc.validity) lean_store_words(oc.validity, rw, left, live, lane);
-                        // NULLs of the tile: in-range rows that are not live, counted on the scalar unit; the (rare) add goes out
-                        // through a one-word descriptor that only lane 0's offset falls into
-                        uint32_t nn = 0;
-                        RDF_ROWS nn += (uint32_t)__popcll(__ballot(((inr & ~live) >> j) & 1u));
-                        if (nn != 0) {
-                            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(a.out_null_counts + ((int64_t)src * a.nchunks + tl.c), 0, 4, 0x00020000);
-                            (void)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)nn, rc, lane == 0 ? 0 : 0x7FFFFFF0, 0, 0);
+                            if (oc.validity) lean_store_words(oc.validity, rw, left, live, lane);
+                            // NULLs of the tile: in-range rows that are not live, counted on the scalar unit; the (rare) add goes out
+                            // through a one-word descriptor that only lane 0's offset falls into
+                            uint32_t nn = 0;
+                            RDF_ROWS nn += (uint32_t)__popcll(__ballot(((inr_t & ~live) >> j) & 1u));
+                            if (nn != 0) {
+                                const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(a.out_null_counts + ((int64_t)src * a.nchunks + cur[t].c), 0, 4, 0x00020000);
+                                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)nn, rc, lane == 0 ? 0 : 0x7FFFFFF0, 0, 0);
+                            }
                         }
                     }
                 } break;
                 default: {   // the binary handlers: the operand is read where it lies
                     const int sdt = (int)(iw0 >> 32) & 255, ddt = (int)(iw0 >> 16) & 255;   // an integer column met in the f64 domain is converted on the way
                     if (kind == SRC_IMM) {
-                        lean_bin(h, acc, [&](int) { return imm; }, accv & inr, err);
+                        lean_bin<R>(h, acc, [&](int) { return imm; }, accv & inr, err);
                     } else if (kind == SRC_COL && sdt == ddt) {
 #pragma unroll
                         for (int p = 0; p < NPRE; ++p)
                             if (p == src) {
                                 accv &= colvalid[p];
-                                lean_bin(h, acc, [&](int j) { return colv[p][j]; }, accv & inr, err);
+                                lean_bin<R>(h, acc, [&](int r) { return colv[r / kVPT][p][r % kVPT]; }, accv & inr, err);
                             }
                     } else {
-                        uint64_t opnd[kVPT];
+                        uint64_t opnd[R];
                         uint32_t opv = 0;
                         if (kind == SRC_COL) {
 #pragma unroll
                             for (int p = 0; p < NPRE; ++p)
-                                if (p == src) { opv = colvalid[p]; RDF_ROWS opnd[j] = colv[p][j]; }
-                            if (sdt == RDF_I64) RDF_ROWS opnd[j] = d2u((double)(int64_t)opnd[j]);
-                            else RDF_ROWS opnd[j] = d2u((double)opnd[j]);
+                                if (p == src) { opv = colvalid[p]; RDF_ROWS_R opnd[r] = colv[r / kVPT][p][r % kVPT]; }
+                            if (sdt == RDF_I64) RDF_ROWS_R opnd[r] = d2u((double)(int64_t)opnd[r]);
+                            else RDF_ROWS_R opnd[r] = d2u((double)opnd[r]);
                         } else {
-                            const uint64_t* tv = tmp_vals + (size_t)src * kVPT * kBlock + tid;
-                            RDF_ROWS opnd[j] = tv[j * kBlock];
+                            const uint64_t* tv = tmp_vals + (size_t)src * R * kBlock + tid;
+                            RDF_ROWS_R opnd[r] = tv[r * kBlock];
                             opv = tmp_valid[src * kBlock + tid];
                         }
                         accv &= opv;
-                        lean_bin(h, acc, [&](int j) { return opnd[j]; }, accv & inr, err);
+                        lean_bin<R>(h, acc, [&](int r) { return opnd[r]; }, accv & inr, err);
                     }
                 } break;
             }
         }
         tile = ntile;
-        tl = ntl;
         have = nhave;
     }
 
@@ -394,27 +430,32 @@ __global__ __launch_bounds__(kBlock) void eval_lean_kernel(const EvalArgs a) {
     }
 }
 
-template <int SINK, int NPRE, int NVAL>
-static void lean_launch_one(const EvalArgs& a, int grid, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((eval_lean_kernel<SINK, NPRE, NVAL>), dim3(grid), dim3(kBlock), lds, s, a);
+template <int SINK, int NPRE, int NVAL, int T>
+static void lean_launch_one(const EvalArgs& a, int grid, hipStream_t s) {
+    const size_t lds = (size_t)a.ntmp * ((size_t)T * kVPT * kBlock * 8 + kBlock * 4);
+    hipLaunchKernelGGL((eval_lean_kernel<SINK, NPRE, NVAL, T>), dim3(grid), dim3(kBlock), lds, s, a);
 }
 
-// SINK_AGG: (NPRE, NVAL) in {(1,1),(2,1),(2,2),(4,1),(4,2),(4,4)} like eval_kernel; SINK_STORE keeps no per-value state: NPRE only
-hipError_t launch_eval_lean(const EvalArgs& a, int sink, int grid, hipStream_t s) {
-    const size_t lds = (size_t)a.ntmp * (kVPT * kBlock * 8 + kBlock * 4);
+// SINK_AGG: (NPRE, NVAL) in {(1,1),(2,1),(2,2),(4,1),(4,2),(4,4)} like eval_kernel; SINK_STORE keeps no per-value state: NPRE only.
+// Two tiles per trip where it measured ahead (1e9 rows, tools/lean_ab.py --time): one-column programs (filter -> sum 1.83 -> 1.51 ms,
+// stored 3.49 -> 3.41) and two-column aggregates (3.21 -> 3.01, 2.72 -> 2.71: 157-165 registers, three waves per SIMD instead of
+// four, about pay for the saved dispatch); two-column stores lose 3 % and four columns' worth of rows for two tiles would cost
+// more occupancy still.  The temporaries must fit 64 KB of LDS that way; one_tile forces one (rdf_set_option("interp_lean", 2)).
+hipError_t launch_eval_lean(const EvalArgs& a, int sink, int grid, hipStream_t s, bool one_tile) {
     const int npre = a.ncols, nval = a.nvalues;
+    const bool two = !one_tile && (npre <= 1 || (npre <= 2 && sink == SINK_AGG)) && (size_t)a.ntmp * (2 * kVPT * kBlock * 8 + kBlock * 4) <= 65536;
     if (sink == SINK_STORE) {
-        if (npre <= 1) lean_launch_one<SINK_STORE, 1, 1>(a, grid, lds, s);
-        else if (npre <= 2) lean_launch_one<SINK_STORE, 2, 1>(a, grid, lds, s);
-        else lean_launch_one<SINK_STORE, 4, 1>(a, grid, lds, s);
+        if (npre <= 1) { if (two) lean_launch_one<SINK_STORE, 1, 1, 2>(a, grid, s); else lean_launch_one<SINK_STORE, 1, 1, 1>(a, grid, s); }
+        else if (npre <= 2) lean_launch_one<SINK_STORE, 2, 1, 1>(a, grid, s);
+        else lean_launch_one<SINK_STORE, 4, 1, 1>(a, grid, s);
     } else if (nval <= 1) {
-        if (npre <= 1) lean_launch_one<SINK_AGG, 1, 1>(a, grid, lds, s);
-        else if (npre <= 2) lean_launch_one<SINK_AGG, 2, 1>(a, grid, lds, s);
-        else lean_launch_one<SINK_AGG, 4, 1>(a, grid, lds, s);
+        if (npre <= 1) { if (two) lean_launch_one<SINK_AGG, 1, 1, 2>(a, grid, s); else lean_launch_one<SINK_AGG, 1, 1, 1>(a, grid, s); }
+        else if (npre <= 2) { if (two) lean_launch_one<SINK_AGG, 2, 1, 2>(a, grid, s); else lean_launch_one<SINK_AGG, 2, 1, 1>(a, grid, s); }
+        else lean_launch_one<SINK_AGG, 4, 1, 1>(a, grid, s);
     } else if (nval <= 2) {
-        if (npre <= 2) lean_launch_one<SINK_AGG, 2, 2>(a, grid, lds, s);
-        else lean_launch_one<SINK_AGG, 4, 2>(a, grid, lds, s);
-    } else lean_launch_one<SINK_AGG, 4, 4>(a, grid, lds, s);
+        if (npre <= 2) { if (two) lean_launch_one<SINK_AGG, 2, 2, 2>(a, grid, s); else lean_launch_one<SINK_AGG, 2, 2, 1>(a, grid, s); }
+        else lean_launch_one<SINK_AGG, 4, 2, 1>(a, grid, s);
+    } else lean_launch_one<SINK_AGG, 4, 4, 1>(a, grid, s);
     return hipGetLastError();
 }
 

@@ -54,6 +54,19 @@ def _programs(e):
 LAYOUTS = [([1], 0.0, 0), ([255, 257, 1024, 1], 0.1, 3), ([1024] * 20 + [576], 0.05, 0), ([300_001], 0.0, 1), ([70_000, 5], 0.9, 2)]
 
 
+def _check_aggregates(got, exp, what):
+    for v, (g, x) in enumerate(zip(got, exp)):
+        w = f"{what} value {v}"
+        assert g.count == x.count and g.is_some == x.is_some and g.dtype == x.dtype, w
+        if not x.is_some:
+            continue
+        if g.dtype in (A.F32, A.F64):   # the sum's order differs from the oracle's row order: 1e-6 relative, as for every fused aggregate
+            assert abs(g.sum - x.sum) <= 1e-6 * max(abs(x.sum), 1e-9) + 1e-9, f"sum {w}: {g.sum} vs {x.sum}"
+            assert g.min == x.min and g.max == x.max, w
+        else:
+            assert (g.sum, g.min, g.max) == (x.sum, x.min, x.max), w
+
+
 @pytest.mark.parametrize("layout", LAYOUTS)
 def test_lean_kernel_against_the_oracle(interp, ora, layout):
     api, lib = interp
@@ -64,18 +77,19 @@ def test_lean_kernel_against_the_oracle(interp, ora, layout):
     e = A.Expr()
     for name, p in _programs(e).items():
         exp = ora.pipeline(e, cols, p["values"], p["filt"])
-        got = api.pipeline(e, cols, p["values"], p["filt"])
-        assert lib.last_kernel() == "eval_kernel<AGG, lean>", f"{name} ran on {lib.last_kernel()}"
-        for v, (g, x) in enumerate(zip(got, exp)):
-            what = f"{name} value {v} lens={lens[:3]} nf={nf}"
-            assert g.count == x.count and g.is_some == x.is_some and g.dtype == x.dtype, what
-            if not x.is_some:
-                continue
-            if g.dtype in (A.F32, A.F64):   # the sum's order differs from the oracle's row order: 1e-6 relative, as for every fused aggregate
-                assert abs(g.sum - x.sum) <= 1e-6 * max(abs(x.sum), 1e-9) + 1e-9, f"sum {what}: {g.sum} vs {x.sum}"
-                assert g.min == x.min and g.max == x.max, what
-            else:
-                assert (g.sum, g.min, g.max) == (x.sum, x.min, x.max), what
+        forms = []
+        for mode in (1, 2):   # two tiles per trip of the step loop where the launcher picks that; one tile forced
+            lib.set_option("interp_lean", mode)
+            got = api.pipeline(e, cols, p["values"], p["filt"])
+            lib.set_option("interp_lean", 1)
+            assert lib.last_kernel() == "eval_kernel<AGG, lean>", f"{name} ran on {lib.last_kernel()}"
+            _check_aggregates(got, exp, f"{name} lens={lens[:3]} nf={nf} interp_lean={mode}")
+            forms.append(got)
+        # a lane's rows meet its running aggregates in the same order either way: the two forms agree to the bit
+        for g, x in zip(*forms):
+            assert (g.count, g.is_some) == (x.count, x.is_some), name
+            if g.is_some:
+                assert (g.min, g.max) == (x.min, x.max) and (g.sum == x.sum or (g.sum != g.sum and x.sum != x.sum)), name
 
 
 def test_lean_kernel_and_general_kernel_give_the_same_bits(interp):
