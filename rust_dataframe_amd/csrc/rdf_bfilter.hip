@@ -149,14 +149,19 @@ __device__ __forceinline__ void bf_term_fields(const BfTerm& tm, const typename 
     else bf_op_fields<T, G, float>(x, tm.op, tm.lit, kf);
 }
 
-struct BfTile { int64_t tile, c, r0, clen, first; };
+struct BfTile { int64_t tile, c, r0, clen, first, rw; bool valid; };      // rw: this wave's first row of the batch; valid: the batch exists (SHORT: a tile's last batches may lie past the frame's end)
 
 }  // namespace
 
 // T: the columns' element as raw bits (uint64_t / uint32_t: all columns of a launch are equally wide); G: 16-byte vectors per lane
 // and column; MULTI: more than one column (a third register set carries the columns that follow the first); NULLS: some column,
 // or the mask, has a validity bitmap; BYMASK: Column::filter with the mask given, else the predicate is evaluated here.
-template <typename T, int G, bool MULTI, bool NULLS, bool BYMASK>
+// SHORT: no batch is longer than a tile (the readers' 1024-row RecordBatches, chunks of a few thousand rows).  A batch then takes
+// S = a.short_waves (1, 2, 4 or 8: the frame's longest batch decides) consecutive waves of ONE block, a tile is 8 / S consecutive
+// batches, and a batch's kept rows start its own output: the waves of a batch add their counts up in LDS and that is the whole
+// prefix — no scanner block, no tile states, nothing to wait for.  Everything else (registers, staging at the ranks, aligned
+// 16-byte stores, the next tile counted under the current tile's stores) is the long-batch kernel's.
+template <typename T, int G, bool MULTI, bool NULLS, bool BYMASK, bool SHORT>
 __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs a) {
     constexpr int E = 16 / (int)sizeof(T), WR = G * 64 * E, TR = kBfWaves * WR, NWW = G * E;
     static_assert(NWW <= 32, "one keep-word per lane, two words fetched per lane");
@@ -168,7 +173,11 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
     __shared__ int64_t sh_base, sh_tile[2];
     const FilterWArgs& fa = a.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (blockIdx.x == 0) { if (wave == 0 && !a.stall_test) bf_scanner(a.tile_state, fa.t.ntiles, a.abort_flag); return; }
+    if constexpr (!SHORT) { if (blockIdx.x == 0) { if (wave == 0 && !a.stall_test) bf_scanner(a.tile_state, fa.t.ntiles, a.abort_flag); return; } }
+    // the waves that share a batch: all eight of the block, or (SHORT) S of them — group wg, wave wj of its group
+    const int sshift = SHORT ? a.short_shift : 3, S = 1 << sshift;
+    const int wg = SHORT ? wave >> sshift : 0, wj = SHORT ? wave & (S - 1) : wave;
+    const int gsz = S * 64, gt = wj * 64 + lane, gbase = wg * S * WR;         // threads of the group, this thread's index in it, the group's part of the staging buffer
     const int64_t ntiles = fa.t.ntiles;
     const bool one = fa.t.nchunks == 1;
     const int ncols = fa.ncols;
@@ -178,11 +187,21 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
 
     // tiles are handed out in order by `nclass` ticket counters (a single one would serialise every draw of the grid: 23 ns each);
     // block b draws from counter (b - 1) mod nclass, which numbers the tiles  nclass * k + its own index
-    const int nclass = a.nclass, ctr = (int)((blockIdx.x - 1) % (unsigned)nclass);
+    const int nclass = a.nclass, ctr = (int)((blockIdx.x - (SHORT ? 0 : 1)) % (unsigned)nclass);
     auto draw = [&]() __attribute__((always_inline)) -> int64_t { return (int64_t)atomicAdd(a.ticket + ctr * 32, 1u) * nclass + ctr; };
     auto locate = [&](int64_t tile) __attribute__((always_inline)) -> BfTile {
         BfTile t;
         t.tile = tile;
+        t.valid = true;
+        if constexpr (SHORT) {
+            const int64_t c = (tile << (3 - sshift)) + wg;
+            t.valid = c < fa.t.nchunks;
+            t.c = t.valid ? c : fa.t.nchunks - 1;
+            t.first = tile; t.r0 = 0;
+            t.clen = !t.valid ? 0 : one ? fa.len0 : as_const<int64_t>(fa.t.chunk_len)[t.c];
+            t.rw = (int64_t)wj * WR;
+            return t;
+        }
         if (one) { t.c = 0; t.first = 0; t.r0 = tile * TR; t.clen = fa.len0; }
         else {
             const ConstPtr<int64_t> start = as_const<int64_t>(fa.t.chunk_tile_start);
@@ -191,6 +210,7 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
             t.r0 = (tile - t.first) * TR;
             t.clen = as_const<int64_t>(fa.t.chunk_len)[t.c];
         }
+        t.rw = t.r0 + (int64_t)wave * WR;
         return t;
     };
     auto col_of = [&](int k, int64_t c) __attribute__((always_inline)) -> DevChunkCol { return one ? fa.cols0[k] : const_col(fa.cols, (int64_t)k * fa.t.nchunks + c); };
@@ -202,7 +222,7 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
         return o;
     };
     // this wave's rows of a tile: [rw, rw + WR) of the chunk
-    auto wave_row = [&](const BfTile& t) __attribute__((always_inline)) -> int64_t { return t.r0 + (int64_t)wave * WR; };
+    auto wave_row = [&](const BfTile& t) __attribute__((always_inline)) -> int64_t { return t.rw; };
     // one column's vectors; SPARSE: only the 16-byte vectors that hold a wanted row (`need`: E-bit fields) are fetched
     auto load_col = [&](const DevChunkCol& col, const BfTile& t, V (&x)[G], bool sparse, const uint32_t (&need)[G]) {
         const int64_t rw = wave_row(t);
@@ -217,6 +237,20 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
             } else {
 #pragma unroll
                 for (int g = 0; g < G; ++g) x[g] = __builtin_nontemporal_load(p + g * 64);
+            }
+        } else if (SHORT && (((uintptr_t)(const void*)src) & 15) == 0) {
+            // the ragged end of a batch (SHORT: every batch that is not a multiple of the wave's rows ends in one): whole vectors
+            // as far as they exist, the one across the end element by element
+            const GlobalPtr<V> p = (GlobalPtr<V>)src + lane;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int q0 = g * 64 * E + lane * E;
+                x[g] = zero;
+                if (rw + q0 + E <= t.clen) { if (!sparse || need[g]) x[g] = __builtin_nontemporal_load(p + g * 64); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) if (rw + q0 + e < t.clen) x[g][e] = src[q0 + e];
+                }
             }
         } else {
             // the ragged end of a batch, a slice that is not 16-byte aligned: element by element
@@ -313,9 +347,19 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
         if (lane == 0) wcnt[par][wave] = cnt;
         __syncthreads();
         wbase = 0; bcnt = 0;
+        if constexpr (SHORT) {
+            // the batch's waves only; wbase is the wave's place in the staging buffer (its group's part + the group's waves in front of it)
 #pragma unroll
-        for (int w = 0; w < kBfWaves; ++w) { const int c = __builtin_amdgcn_readfirstlane(wcnt[par][w]); if (w < wave) wbase += c; bcnt += c; }
-        if (tid == 0) bf_st(a.tile_state + t.tile, kBfCount | (unsigned long long)bcnt);
+            for (int w = 0; w < kBfWaves; ++w) {
+                const int c = __builtin_amdgcn_readfirstlane(wcnt[par][w]);
+                if ((w >> sshift) == wg) { if (w < wave) wbase += c; bcnt += c; }
+            }
+            wbase += gbase;
+        } else {
+#pragma unroll
+            for (int w = 0; w < kBfWaves; ++w) { const int c = __builtin_amdgcn_readfirstlane(wcnt[par][w]); if (w < wave) wbase += c; bcnt += c; }
+            if (tid == 0) bf_st(a.tile_state + t.tile, kBfCount | (unsigned long long)bcnt);
+        }
     };
 
     if (tid == 0) { sh_tile[0] = draw(); sh_tile[1] = draw(); }
@@ -347,11 +391,11 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
         if (Tn < ntiles) count_publish(Y, tn, par, km_n, wbase_n, bcnt_n);
         else __syncthreads();                            // (the staging buffer, sh_base and nullacc are reused below)
         par ^= 1;
-        if (tc.c != cur_chunk) { flush_nulls(); cur_chunk = tc.c; }
+        if constexpr (!SHORT) { if (tc.c != cur_chunk) { flush_nulls(); cur_chunk = tc.c; } }
         // b. rows of the batch in front of the current tile
         if (tid == 0) {
             int64_t base = 0;               // a batch's first tile starts the batch's output
-            if (tc.first != Tc) {
+            if (!SHORT && tc.first != Tc) {
                 unsigned long long w, t0 = 0;
                 int spins = 0;
                 auto wait_for = [&](const unsigned long long* p) __attribute__((always_inline)) {
@@ -386,7 +430,7 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
 #pragma unroll
             for (int e = 0; e < E; ++e) { B[g][e] = rl64(km_c, g * E + e); need[g] |= (uint32_t)((B[g][e] >> lane) & 1) << e; }
         }
-        const bool sparse = bcnt_c * 8 < TR;
+        const bool sparse = bcnt_c * 8 < S * WR;
         // one column's registers (and, NULLS, its validity bits) to the staging buffer, at the ranks of the kept rows
         auto stage_col = [&](const V (&x)[G], bool has_validity, const LaneWin<NWW>& q) {
             uint64_t vw = 0;
@@ -415,26 +459,26 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
             const GlobalMutPtr<T> o = as_global_mut<T>(oc.values) + tbase;
             int head = (int)(((16 - (((uintptr_t)oc.values + (uintptr_t)tbase * sizeof(T)) & 15)) & 15) / sizeof(T));   // elements in front of the first aligned vector
             if (head > bcnt_c) head = bcnt_c;
-            if (tid < head) o[tid] = stage[tid];
+            if (gt < head) o[gt] = stage[gbase + gt];
             const int nv = (bcnt_c - head) / E;
-            for (int q = tid; q < nv; q += kBfBlock) {
+            for (int q = gt; q < nv; q += gsz) {
                 const int i0 = head + q * E;
                 V x;
 #pragma unroll
-                for (int e = 0; e < E; ++e) x[e] = stage[i0 + e];
+                for (int e = 0; e < E; ++e) x[e] = stage[gbase + i0 + e];
                 __builtin_nontemporal_store(x, (GlobalMutPtr<V>)(o + i0));
             }
             const int tail0 = head + nv * E;
-            if (tid < bcnt_c - tail0) o[tail0 + tid] = stage[tail0 + tid];
+            if (gt < bcnt_c - tail0) o[tail0 + gt] = stage[gbase + tail0 + gt];
             if (NULLS && oc.validity) {
                 // out bits [tbase, tbase + bcnt_c): 64 aligned positions per wave step; the run's first and last word are shared with
                 // the neighbouring tiles (the bitmap is pre-zeroed)
                 const int64_t end = tbase + bcnt_c, w0 = tbase >> 6, w1 = (end + 63) >> 6;
                 int nn = 0;
-                for (int64_t wq = w0 + wave; wq < w1; wq += kBfWaves) {
+                for (int64_t wq = w0 + wj; wq < w1; wq += S) {
                     const int64_t pos = wq * 64 + lane;
                     const bool inside = pos >= tbase && pos < end;
-                    const bool bitv = inside && (!has_validity || vstage[inside ? pos - tbase : 0]);
+                    const bool bitv = inside && (!has_validity || vstage[inside ? gbase + pos - tbase : 0]);
                     const uint64_t word = __ballot(bitv), inw = __ballot(inside);
                     if (lane == 0) {
                         if (inw == ~0ull) ((GlobalMutPtr<uint64_t>)(void*)oc.validity)[wq] = word;
@@ -442,7 +486,8 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
                         nn += __popcll(inw & ~word);
                     }
                 }
-                if (lane == 0 && nn) atomicAdd(&nullacc[k], nn);
+                if constexpr (SHORT) { if (lane == 0 && nn) atomicAdd((unsigned long long*)&fa.out_null_counts[(int64_t)k * fa.t.nchunks + tc.c], (unsigned long long)nn); }
+                else if (lane == 0 && nn) atomicAdd(&nullacc[k], nn);
             }
         };
         // column kk of the loop is frame column col_at(kk): the first predicate column comes first (its vectors are in X.y)
@@ -489,7 +534,8 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
                 }
             }
         }
-        if (tid == 0 && a.out_len && tc.r0 + TR >= tc.clen) a.out_len[tc.c] = tbase + bcnt_c;      // the batch's last tile
+        if constexpr (SHORT) { if (gt == 0 && a.out_len && tc.valid) a.out_len[tc.c] = bcnt_c; }
+        else if (tid == 0 && a.out_len && tc.r0 + TR >= tc.clen) a.out_len[tc.c] = tbase + bcnt_c;      // the batch's last tile
         // the tile after the next: its registers are the ones the current tile has left
         BfTile tnn = tn;
         if (Tnn < ntiles) { tnn = locate(Tnn); prefetch(tnn, X); }
@@ -502,7 +548,15 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
         if (!step(PB, PA)) break;
     }
     __syncthreads();
-    flush_nulls();
+    if constexpr (!SHORT) flush_nulls();
+}
+
+// SHORT mode: log2 of the waves a batch takes (0..3) for a frame whose longest batch has max_len rows, or -1 when a batch is
+// longer than a tile
+int bfilter_short_shift(int esize, int ncols, int64_t max_len) {
+    const int wr = bfilter_tile_rows(esize, ncols) / kBfWaves;
+    for (int sh = 0; sh <= 3; ++sh) if (max_len <= ((int64_t)wr << sh)) return sh;
+    return -1;
 }
 
 int bfilter_tile_rows(int esize, int ncols) {
@@ -514,10 +568,13 @@ int bfilter_tile_rows(int esize, int ncols) {
 hipError_t launch_bfilter(const BFilterArgs& a, int esize, bool nulls, hipStream_t s) {
     if (a.w.t.ntiles <= 0) return hipSuccess;
     const bool multi = a.w.ncols > 1, by_mask = a.nterms == 0;
-    const dim3 grid((unsigned)(a.nworkers + 1)), block(kBfBlock);
+    const bool shrt = a.short_mode != 0;
+    const dim3 grid((unsigned)(a.nworkers + (shrt ? 0 : 1))), block(kBfBlock);
+#define RDF_BF_LAUNCH3(T, G, MULTI, NULLS, BYMASK) \
+    do { if (shrt) hipLaunchKernelGGL((bfilter_kernel<T, G, MULTI, NULLS, BYMASK, true>), grid, block, 0, s, a); \
+         else hipLaunchKernelGGL((bfilter_kernel<T, G, MULTI, NULLS, BYMASK, false>), grid, block, 0, s, a); } while (0)
 #define RDF_BF_LAUNCH2(T, G, MULTI, NULLS) \
-    do { if (by_mask) hipLaunchKernelGGL((bfilter_kernel<T, G, MULTI, NULLS, true>), grid, block, 0, s, a); \
-         else hipLaunchKernelGGL((bfilter_kernel<T, G, MULTI, NULLS, false>), grid, block, 0, s, a); } while (0)
+    do { if (by_mask) RDF_BF_LAUNCH3(T, G, MULTI, NULLS, true); else RDF_BF_LAUNCH3(T, G, MULTI, NULLS, false); } while (0)
 #define RDF_BF_LAUNCH(T, G, MULTI) \
     do { if (nulls) RDF_BF_LAUNCH2(T, G, MULTI, true); else RDF_BF_LAUNCH2(T, G, MULTI, false); } while (0)
     if (esize == 8) { if (multi) RDF_BF_LAUNCH(uint64_t, 4, true); else RDF_BF_LAUNCH(uint64_t, 8, false); }
@@ -525,6 +582,7 @@ hipError_t launch_bfilter(const BFilterArgs& a, int esize, bool nulls, hipStream
     else RDF_BF_LAUNCH(uint32_t, 4, false);
 #undef RDF_BF_LAUNCH
 #undef RDF_BF_LAUNCH2
+#undef RDF_BF_LAUNCH3
     return hipGetLastError();
 }
 

@@ -60,6 +60,7 @@ struct Ctx {
     int    opt_filter_gen = 2;      // compaction kernels: 2 = wave-granular tiles (rdf_filter.hip, default), 1 = first-generation block tiles (A/B)
     int    opt_filter_block = 1;    // one-pass compaction of LONG batches on block tiles held in registers, prefixes from a scanner wave (rdf_bfilter.hip, round 6; default); 0 = the wave-tile kernels only (A/B)
     int    opt_interp_lean = 1;             // interpreted aggregate programs whose every step has a lean handler run on eval_lean_kernel (rdf_eval_lean.hip); 0: always eval_kernel (the A/B)
+    int    opt_filter_short = 1;    // batches / chunks no longer than a block tile on the block kernel's short-batch mode (round 6; default); 0 = the wave-tile kernels (A/B)
     int    opt_filter_block_rows = 8192;    // ... for frames whose mean batch length is at least this many rows (one block tile of a single 8-byte column; measured ahead of the wave-tile kernel from 8192-row batches up: profiles/r06_filter_frame_batch_length_sweep.jsonl)
     int    opt_filter_fused = 1;    // rdf_filter_frame: `col CMP literal [AND|OR col CMP literal]` predicates evaluated inside the compaction kernel, one pass (1, default); 0 = predicate -> mask, count, compact (A/B)
     int    opt_filter_lookback = 3; // one-pass rdf_filter_frame, batches longer than a tile: 3 = a super-tile's first tile finds the rows in front of the super-tile for all 64, from the nearest super-tiles' tile counts and the older ones' totals (default); 2 = from totals only; 1 = every tile walks the totals (round 4; batches of at most 1024 tiles) — A/B
@@ -2516,7 +2517,10 @@ rdf_status filter_validate(const rdf_array* cols, int ncols, const rdf_array* ma
 
 // Column::filter (src/table.rs:97-107,213-215) with the mask given, device-resident, in one pass on block tiles: groups of up to
 // kMaxFilterCols columns per launch; lengths and null counts come back from the kernel.
-rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols, const rdf_array* mask, int64_t nchunks, rdf_out* outs, int es0, bool short_chunks) {
+rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols, const rdf_array* mask, int64_t nchunks, rdf_out* outs, int es0, int mode, int64_t max_len = 0) {
+    // mode 0: long chunks (block tiles, scanner wave); 1: chunks of at most one wave tile on the wave-tile LDS-DMA kernel; 2: chunks no longer
+    // than a block tile on the block kernel's short-batch mode (a chunk on 1 / 2 / 4 / 8 waves of a block)
+    const bool short_chunks = mode == 1, block_short = mode == 2;
     Ctx& ctx = g_ctx;
     std::vector<int64_t> unused;
     RDF_TRY(filter_prepare(fp, cols, ncols, mask, nchunks, unused, false));
@@ -2568,7 +2572,12 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
         for (int g = 0; g < ncols; g += kMaxFilterCols) {
             const int nc = ncols - g < kMaxFilterCols ? ncols - g : kMaxFilterCols;
             const int tr = short_chunks ? kWDmaTile : bfilter_tile_rows(es0, nc);
-            if (tr != table_rows) {           // (a last group of one column has longer tiles than the groups before it)
+            const int short_shift = block_short ? bfilter_short_shift(es0, nc, max_len) : -1;
+            if (block_short) {
+                if (short_shift < 0) return fail(RDF_DEVICE_ERROR, "filter: a chunk longer than a block tile on the short-batch path");
+                ntiles = (nchunks + (8 >> short_shift) - 1) / (8 >> short_shift);
+                d_tile_start = nullptr; tile_inv = 0; table_rows = 0;
+            } else if (tr != table_rows) {           // (a last group of one column has longer tiles than the groups before it)
                 std::vector<int64_t> ts((size_t)nchunks + 1, 0);
                 for (int64_t c = 0; c < nchunks; ++c) ts[(size_t)c + 1] = ts[(size_t)c] + (fp.clen[(size_t)c] + tr - 1) / tr;
                 ntiles = ts[(size_t)nchunks];
@@ -2613,6 +2622,7 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
             }
             ba.nterms = 0;
             ba.out_len = d_len;
+            if (block_short) { ba.short_mode = 1; ba.short_shift = short_shift; }
             RDF_TRY(bfilter_scratch(ba));
             if (!kt) kt.reset(new KernelTimer());
             HIP_TRY(launch_bfilter(ba, es0, nulls, ctx.stream));
@@ -2620,7 +2630,7 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
         }
         if (kt) kt->stop();
     }
-    ctx.last_kernel = short_chunks ? "fcompact_dma_kernel (one pass)" : "bfilter_kernel";
+    ctx.last_kernel = short_chunks ? "fcompact_dma_kernel (one pass)" : block_short ? "bfilter_kernel (short batches)" : "bfilter_kernel";
     RDF_TRY(pinned_reserve(fp.pin_off + 8 * (nout + (size_t)nchunks) + 256));
     int64_t* pin = (int64_t*)(ctx.pinned + fp.pin_off);
     HIP_TRY(hipMemcpyAsync(pin, d_nullc, 8 * (nout + (size_t)nchunks), hipMemcpyDeviceToHost, ctx.stream));
@@ -2684,12 +2694,21 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
         for (int k = 0; k < ncols && roomy; ++k) roomy = dtype_size(cols[(int64_t)k * nchunks].dtype) == es0;
         // (outputs smaller than their chunk — a caller that sized them with rdf_filter_count — take the one pass as well: the kernel
         // knows every output's capacity, a chunk that keeps more than it holds is not written and the count it reports fails the call)
-        if (roomy && (rows_total + nchunks - 1) / nchunks >= (int64_t)ctx.opt_filter_block_rows) return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, false);
-        // ... and the readers' batches (no chunk longer than one wave tile of 1024 rows, most of them full): one pass as well
+        if (roomy && (rows_total + nchunks - 1) / nchunks >= (int64_t)ctx.opt_filter_block_rows) return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, 0);
+        // ... chunks no longer than a block tile (the readers' 1024-row batches, chunks of a few thousand rows): the block kernel with a
+        // chunk on 1 / 2 / 4 / 8 waves of a block, no prefix between blocks (round 6) — unless most slots would sit half empty
         int64_t max_len = 0;
         for (int64_t c = 0; c < nchunks; ++c) max_len = std::max<int64_t>(max_len, mask[c].length);
+        if (roomy && ctx.opt_filter_short && ctx.opt_filter_gen == 2) {
+            // (every column group of a call must fit: the groups of eight columns have the shortest tiles)
+            const int nc_min = ncols >= 2 ? 2 : 1;
+            const int sh = bfilter_short_shift(es0, nc_min, max_len);
+            if (sh >= 0 && rows_total * 2 >= nchunks * (((int64_t)bfilter_tile_rows(es0, nc_min) / 8) << sh))
+                return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, 2, max_len);
+        }
+        // ... and before that kernel had its short-batch mode: no chunk longer than one wave tile of 1024 rows, most of them full
         if (roomy && max_len <= kWDmaTile && rows_total >= nchunks * (int64_t)(kWDmaTile * 3 / 4) && ctx.opt_filter_gen == 2)
-            return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, true);
+            return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, 1);
     }
     RDF_TRY(filter_prepare(fp, cols, ncols, mask, nchunks, totals));
     for (int k = 0; k < ncols; ++k)
@@ -4482,6 +4501,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
     else if (strcmp(name, "filter_block") == 0) g_ctx.opt_filter_block = value == 3 ? 3 : value != 0;      // (3: tests — the scanner wave stays idle, every wait must time out)
     else if (strcmp(name, "interp_lean") == 0) g_ctx.opt_interp_lean = value == 2 ? 2 : value != 0;   // (2: the lean kernel with one tile per trip of its step loop — the A/B of its two-tile form)
+    else if (strcmp(name, "filter_short") == 0) g_ctx.opt_filter_short = value != 0;
     else if (strcmp(name, "filter_block_rows") == 0) g_ctx.opt_filter_block_rows = value < 1 ? 1 : (int)value;
     else if (strcmp(name, "filter_lookback") == 0) g_ctx.opt_filter_lookback = value == 1 ? 1 : value == 2 ? 2 : 3;
     else if (strcmp(name, "comm_max_bytes") == 0) g_ctx.opt_comm_max_bytes = value;

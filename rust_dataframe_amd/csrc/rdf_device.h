@@ -243,10 +243,12 @@ struct BFilterArgs {
     unsigned long long* tile_state;          // (pre-zeroed) [ntiles]: 0 -> count -> prefix
     unsigned int*       ticket;              // (pre-zeroed) 64 counters, 128 bytes apart
     int32_t             stall_test, pad;     // tests: 1 = the scanner does nothing (every wait must give up and the call must fail, not hang)
+    int32_t             short_mode, short_shift;   // short_mode 1: no batch is longer than a tile — a batch takes 1 << short_shift waves of one block, w.t.ntiles counts tiles of 8 >> short_shift BATCHES (chunk_tile_start / tile_inv / tile_state unused), block 0 works like the others
     unsigned int*       abort_flag;          // (pre-zeroed) set by a wait that saw no progress for kBfWaitSeconds: every waiter then leaves, the host reports a device error — a stuck prefix must cost a call, not the GPU
 };
 constexpr int kBfWaitSeconds = 4;
 int bfilter_tile_rows(int esize, int ncols);
+int bfilter_short_shift(int esize, int ncols, int64_t max_len);      // -1: some batch is longer than a tile
 hipError_t launch_bfilter(const BFilterArgs& a, int esize, bool nulls, hipStream_t s);
 hipError_t launch_fcount(const FilterWArgs& a, int tile_rows, int64_t* tile_counts, hipStream_t s);
 hipError_t launch_fcompact(const FilterWArgs& a, int tile_rows, hipStream_t s);

@@ -528,6 +528,71 @@ def test_filter_frame_block_tiles(gpu, ora, lens, off, nf, dts):
             lib.set_option("filter_block_rows", 8192)
 
 
+SHORT_LAYOUTS = [([1024] * 37 + [500], 0, 0.1), ([1024, 1000, 0, 1, 1023, 1024, 512, 777, 1024, 1024, 1024, 1024], 5, 0.1), ([4096] * 5 + [3000], 0, 0.0),
+                 ([4000, 3900, 4096, 2100], 3, 0.2), ([8192, 8000, 5000], 0, 0.1), ([3000], 0, 0.1), ([1024] * 300, 0, 0.0), ([2048] * 9 + [0, 2047], 2, 0.0)]
+
+
+def short_mode_expected(lens, ncols):
+    """The host's choice (filter_frame_fused / rdf_filter_columns): batches no longer than a block tile, slots at least half full."""
+    wr = (8192 if ncols == 1 else 4096) // 8
+    for sh in range(4):
+        if max(lens) <= wr << sh:
+            return sum(lens) * 2 >= len(lens) * (wr << sh) and -(-sum(lens) // len(lens)) < 8192 and sum(lens) >= len(lens) * 768
+    return False
+
+
+@pytest.mark.parametrize("lens,off,nf", SHORT_LAYOUTS)
+@pytest.mark.parametrize("dts", [[A.F64], [A.I64, A.F64, A.U64], [A.F32, A.I32, A.U32], [A.U32], [A.I64] * 8])
+def test_filter_frame_short_batches_block_kernel(gpu, ora, lens, off, nf, dts):
+    """Round 6: DataFrame::filter of batches no longer than a block tile — the readers' 1024-row RecordBatches, batches of a few
+    thousand rows — on the block kernel's short-batch mode (rdf_bfilter.hip, SHORT): a batch takes 1 / 2 / 4 / 8 waves of one block,
+    its kept rows start its own output, nothing is waited for.  Full, ragged, empty and one-row batches, a frame of ONE batch, tiles
+    whose last slots lie past the frame's end, slices that are not 16-byte aligned, validity bitmaps at odd bit offsets, 8- and 4-byte
+    columns, 1 / 3 / 8 columns, one- and two-term predicates.  Held to the oracle's eval_to_array + Column::filter per column AND to
+    the wave-tile kernel (`filter_short` 0), bit for bit."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(6300 + len(lens) + len(dts))
+    host = []
+    for k, dt in enumerate(dts):
+        kind = "unit" if dt in (A.F64, A.F32) else "extreme" if k % 2 == 0 else "plain"
+        host.append(make_chunks(rng, dt, lens, nf if k < 3 else 0.0, off, kind))
+    dev, keep = to_device(host)
+    e = A.Expr()
+    is_f = dts[0] in (A.F64, A.F32)
+    preds = {}
+    if is_f:
+        preds["gt"] = e.op("gt", e.col(0), e.scalar(0.25))
+        preds["keeps almost nothing"] = e.op("gt", e.col(0), e.scalar(0.999))
+        preds["keeps everything"] = e.op("le", e.col(0), e.scalar(float("inf")))
+    else:
+        preds["gt 0"] = e.op("gt", e.col(0), e.scalar(0, A.I64))
+        preds["ge fractional"] = e.op("ge", e.col(0), e.scalar(-0.5))
+        preds["ne"] = e.op("ne", e.col(0), e.scalar(float(np.iinfo(A.NP_OF[dts[0]]).min)))
+    if len(dts) > 1:
+        preds["and over two columns"] = e.op("and", preds[next(iter(preds))], e.op("lt", e.col(1), e.scalar(0.3)))
+        preds["or over two columns"] = e.op("or", e.op("gt", e.col(len(dts) - 1), e.scalar(0.9)), e.op("le", e.col(1), e.scalar(-0.7)))
+    expect_short = short_mode_expected(lens, len(dts))
+    with A.PinnedFrame(gpu, dev) as frame:
+        try:
+            for name, root in preds.items():
+                exp = ora.filter_columns(host, ora.predicate(e, root, host))
+                for short in (1, 0):
+                    lib.set_option("filter_short", short)
+                    out = gpu.filter_frame(frame, e, root)
+                    if short and expect_short:
+                        assert lib.last_kernel() == "bfilter_kernel (short batches)", (name, lib.last_kernel())
+                    else:
+                        assert lib.last_kernel() != "bfilter_kernel (short batches)", (name, lib.last_kernel())
+                    nc, nch, rows = out.info()
+                    assert (nc, nch) == (len(dts), len(lens)) and rows == sum(x.length for x in exp[0]), (name, short, rows)
+                    got = frame_columns(out)
+                    for k in range(len(dts)):
+                        match_unknown_nulls(got[k], exp[k], f"{name} short={short} lens={lens} column {k}")
+                    out.release()
+        finally:
+            lib.set_option("filter_short", 1)
+
+
 @pytest.mark.parametrize("lens,off,nf", BLOCK_LAYOUTS)
 @pytest.mark.parametrize("dts", [[A.F64], [A.I64, A.F64], [A.F32, A.I32, A.U32], [A.I64] * 11])
 def test_filter_columns_device_block_tiles(gpu, ora, lens, off, nf, dts):
@@ -612,12 +677,14 @@ def test_filter_columns_device_block_tiles(gpu, ora, lens, off, nf, dts):
             lib.set_option("filter_block_rows", 8192)
 
 
-@pytest.mark.parametrize("lens,off,nf", [([1024] * 40 + [500], 0, 0.1), ([1024, 0, 1024, 777, 1024], 3, 0.0), ([1000] * 9, 0, 0.2)])
-@pytest.mark.parametrize("dts", [[A.F64], [A.I64, A.F64, A.U64], [A.F32, A.I32]])
+@pytest.mark.parametrize("lens,off,nf", [([1024] * 40 + [500], 0, 0.1), ([1024, 0, 1024, 777, 1024], 3, 0.0), ([1000] * 9, 0, 0.2),
+                                         ([4096] * 5 + [3000], 0, 0.1), ([2048] * 9 + [0, 2047], 2, 0.0), ([8192, 8000, 5000], 0, 0.1), ([3000], 1, 0.1)])
+@pytest.mark.parametrize("dts", [[A.F64], [A.I64, A.F64, A.U64], [A.F32, A.I32], [A.I64] * 11])
 def test_filter_columns_device_one_pass_reader_batches(gpu, ora, lens, off, nf, dts):
-    """Column::filter over the readers' 1024-row batches, device-resident, outputs that can hold every row: a chunk is ONE wave tile
-    whose kept rows start its output, so the count and scan passes are skipped and the LDS-DMA kernel writes the lengths itself
-    (round 6).  Same oracle, same bytes as the counted path."""
+    """Column::filter over the readers' 1024-row batches and over chunks of a few thousand rows, device-resident, outputs that can
+    hold every row: no count pass, no scan — a chunk's kept rows start its output.  Round 6, first the wave-tile LDS-DMA kernel
+    (a chunk is ONE wave tile; `filter_short` 0), then the block kernel's short-batch mode (a chunk on 1 / 2 / 4 / 8 waves of a block,
+    chunks of up to a block tile; the default).  Same oracle, same bytes from both and from the counted path."""
     import torch
     from rust_dataframe_amd import lib
     rng = np.random.default_rng(6200 + len(lens) + len(dts))
@@ -639,22 +706,38 @@ def test_filter_columns_device_one_pass_reader_batches(gpu, ora, lens, off, nf, 
                 col.append(A.DeviceArray(vb.data_ptr(), bb.data_ptr() if bb is not None else None, 0, 0, dt, 0, keep=(vb, bb), capacity=n))
             outs.append(col)
         torch.cuda.synchronize()
-        gpu.filter_columns(dev, dmask[0], outs)
-        assert lib.last_kernel() == "fcompact_dma_kernel (one pass)", lib.last_kernel()
-        lib.synchronize()
-        i = 0
-        for k, dt in enumerate(dts):
-            es = np.dtype(A.NP_OF[dt]).itemsize
-            for c in range(len(lens)):
-                ee, o, (vb, bb) = exp[k][c], outs[k][c], bufs[i]
-                i += 1
-                assert o.length == ee.length and o.null_count == ee.null_count, (sel, k, c, o.length, ee.length, o.null_count, ee.null_count)
-                gv = vb.cpu().numpy()[:ee.length * es].view(A.NP_OF[dt])
-                m = ee.valid_mask()
-                if bb is not None:
-                    gm = np.unpackbits(bb.cpu().numpy()[:(ee.length + 7) // 8], bitorder="little")[:ee.length].astype(bool)
-                    assert np.array_equal(gm, m), (sel, k, c)
-                assert np.array_equal(gv[m].view(np.uint8), ee.to_numpy()[m].view(np.uint8)), (sel, k, c)
+        try:
+            for short in (1, 0):                          # the block kernel's short-batch mode (the default), the wave-tile LDS-DMA kernel
+                lib.set_option("filter_short", short)
+                for vb, bb in bufs:
+                    vb.fill_(0xAB)
+                    if bb is not None:
+                        bb.fill_(0xAB)
+                torch.cuda.synchronize()
+                gpu.filter_columns(dev, dmask[0], outs)
+                if short and short_mode_expected(lens, len(dts)):
+                    assert lib.last_kernel() == "bfilter_kernel (short batches)", lib.last_kernel()
+                elif max(lens) <= 1024 and sum(lens) >= len(lens) * 768:
+                    assert lib.last_kernel() == "fcompact_dma_kernel (one pass)", lib.last_kernel()
+                else:
+                    assert lib.last_kernel() != "bfilter_kernel (short batches)", lib.last_kernel()
+                lib.synchronize()
+                i = 0
+                for k, dt in enumerate(dts):
+                    es = np.dtype(A.NP_OF[dt]).itemsize
+                    for c in range(len(lens)):
+                        ee, o, (vb, bb) = exp[k][c], outs[k][c], bufs[i]
+                        i += 1
+                        assert o.length == ee.length and o.null_count == ee.null_count, (short, sel, k, c, o.length, ee.length, o.null_count, ee.null_count)
+                        gv = vb.cpu().numpy()[:ee.length * es].view(A.NP_OF[dt])
+                        m = ee.valid_mask()
+                        if bb is not None:
+                            gm = np.unpackbits(bb.cpu().numpy()[:(ee.length + 7) // 8], bitorder="little")[:ee.length].astype(bool)
+                            assert np.array_equal(gm, m), (short, sel, k, c)
+                        assert np.array_equal(gv[m].view(np.uint8), ee.to_numpy()[m].view(np.uint8)), (short, sel, k, c)
+                        assert (vb.cpu().numpy()[ee.length * es + 16:] == 0xAB).all(), ("written past the kept rows", short, sel, k, c)
+        finally:
+            lib.set_option("filter_short", 1)
 
 
 def test_filter_block_tiles_stuck_prefix_fails_the_call_not_the_gpu(gpu, ora):

@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--lookback", type=int, default=3, help="rdf_set_option(\"filter_lookback\"): 3 = a super-tile's first tile finds the rows in front of it from tile counts + older totals (default), 2 = from totals only, 1 = every tile walks the totals (round 4)")
     ap.add_argument("--block", type=int, default=1, help="rdf_set_option(\"filter_block\"): 1 = long batches on block tiles with a scanner wave (rdf_bfilter.hip, round 6, default), 0 = wave tiles + look-back (round 5)")
     ap.add_argument("--block-rows", type=int, default=0, help="rdf_set_option(\"filter_block_rows\"): the mean batch length from which the block kernel is taken (0: the library's default)")
+    ap.add_argument("--short", type=int, default=1, help="rdf_set_option(\"filter_short\"): 1 = batches no longer than a block tile on the block kernel's short-batch mode (round 6, default), 0 = the wave-tile kernel")
     args = ap.parse_args()
     n, cr = args.rows, args.chunk_rows
     only = set(filter(None, args.only.split(",")))
@@ -84,6 +85,7 @@ def main():
     api = lib.api()
     lib.set_option("filter_lookback", args.lookback)
     lib.set_option("filter_block", args.block)
+    lib.set_option("filter_short", args.short)
     if args.block_rows > 0:
         lib.set_option("filter_block_rows", args.block_rows)
 

@@ -184,7 +184,10 @@ def main():
     MF = A.PreparedCol([A.DeviceArray(m.values_ptr + i // 8, None, 0, min(1024, nfc - i), A.BOOL, 0, keep=m) for i in range(0, nfc, 1024)])
     ofb = torch.empty(nfc, dtype=torch.float64, device="cuda")
     OF = [A.DeviceArray(ofb.data_ptr() + i * 8, None, 0, min(1024, nfc - i), A.F64, 0, keep=ofb) for i in range(0, nfc, 1024)]
-    report("filter_1col_1024_row_chunks", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))     # round 6: one pass (a chunk is one wave tile), no count / scan
+    report("filter_1col_1024_row_chunks", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))     # round 6: one pass on the block kernel's short-batch mode (a chunk per wave), no count / scan
+    lib.set_option("filter_short", 0)
+    report("filter_1col_1024_row_chunks_wave_tiles", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))     # round 6, earlier: one pass on the wave-tile LDS-DMA kernel
+    lib.set_option("filter_short", 1)
     lib.set_option("filter_block", 0)
     for gen in (1, 2, 3):   # 3 = wave-granular without the next-tile look-ahead
         lib.set_option("filter_gen", gen)
@@ -206,6 +209,10 @@ def main():
         MF = A.PreparedCol([A.DeviceArray(m.values_ptr + i // 8, None, 0, min(cr, nfc - i), A.BOOL, 0, keep=m) for i in range(0, nfc, cr)])
         OF = [A.DeviceArray(ofb.data_ptr() + i * 8, None, 0, min(cr, nfc - i), A.F64, 0, keep=ofb) for i in range(0, nfc, cr)]
         report(f"filter_1col_{cr}_row_chunks", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))
+        if cr <= 8192:
+            lib.set_option("filter_short", 0)
+            report(f"filter_1col_{cr}_row_chunks_three_kernels", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))     # count, scan, compact (before the short-batch mode)
+            lib.set_option("filter_short", 1)
         del XF, MF, OF
     del ofb
     nidx = n // 4
