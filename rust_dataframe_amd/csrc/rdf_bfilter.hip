@@ -161,8 +161,12 @@ struct BfTile { int64_t tile, c, r0, clen, first, rw; bool valid; };      // rw:
 // batches, and a batch's kept rows start its own output: the waves of a batch add their counts up in LDS and that is the whole
 // prefix — no scanner block, no tile states, nothing to wait for.  Everything else (registers, staging at the ranks, aligned
 // 16-byte stores, the next tile counted under the current tile's stores) is the long-batch kernel's.
-template <typename T, int G, bool MULTI, bool NULLS, bool BYMASK, bool SHORT>
+// MODE 2 (OWNED): batches longer than a tile but many of them and none a large share of the frame (65 536-row batches of a 1e9-row
+// frame): a block draws whole BATCHES by ticket and walks a batch's tiles in order, so the rows in front of a tile are the block's
+// own running sum — again no scanner, no tile states, nothing to wait for (the long form pays two round trips per tile for them).
+template <typename T, int G, bool MULTI, bool NULLS, bool BYMASK, int MODE>
 __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs a) {
+    constexpr bool SHORT = MODE == 1, OWNED = MODE == 2;
     constexpr int E = 16 / (int)sizeof(T), WR = G * 64 * E, TR = kBfWaves * WR, NWW = G * E;
     static_assert(NWW <= 32, "one keep-word per lane, two words fetched per lane");
     using V = typename Vec16<T>::type;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
     __shared__ int64_t sh_base, sh_tile[2];
     const FilterWArgs& fa = a.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if constexpr (!SHORT) { if (blockIdx.x == 0) { if (wave == 0 && !a.stall_test) bf_scanner(a.tile_state, fa.t.ntiles, a.abort_flag); return; } }
+    if constexpr (MODE == 0) { if (blockIdx.x == 0) { if (wave == 0 && !a.stall_test) bf_scanner(a.tile_state, fa.t.ntiles, a.abort_flag); return; } }
     // the waves that share a batch: all eight of the block, or (SHORT) S of them — group wg, wave wj of its group
     const int sshift = SHORT ? a.short_shift : 3, S = 1 << sshift;
     const int wg = SHORT ? wave >> sshift : 0, wj = SHORT ? wave & (S - 1) : wave;
@@ -187,8 +191,21 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
 
     // tiles are handed out in order by `nclass` ticket counters (a single one would serialise every draw of the grid: 23 ns each);
     // block b draws from counter (b - 1) mod nclass, which numbers the tiles  nclass * k + its own index
-    const int nclass = a.nclass, ctr = (int)((blockIdx.x - (SHORT ? 0 : 1)) % (unsigned)nclass);
-    auto draw = [&]() __attribute__((always_inline)) -> int64_t { return (int64_t)atomicAdd(a.ticket + ctr * 32, 1u) * nclass + ctr; };
+    const int nclass = a.nclass, ctr = (int)((blockIdx.x - (MODE == 0 ? 1 : 0)) % (unsigned)nclass);
+    // (OWNED, thread 0 only: the tiles of the batch drawn last that have not been handed out yet)
+    int64_t own_next = 0, own_end = 0;
+    auto draw = [&]() __attribute__((always_inline)) -> int64_t {
+        if constexpr (OWNED) {
+            while (own_next >= own_end) {            // the next batch (empty ones have no tiles)
+                const int64_t c = (int64_t)atomicAdd(a.ticket + ctr * 32, 1u) * nclass + ctr;
+                if (c >= fa.t.nchunks) return ntiles;
+                own_next = __builtin_nontemporal_load(as_global<int64_t>(fa.t.chunk_tile_start) + c);
+                own_end = __builtin_nontemporal_load(as_global<int64_t>(fa.t.chunk_tile_start) + c + 1);
+            }
+            return own_next++;
+        }
+        return (int64_t)atomicAdd(a.ticket + ctr * 32, 1u) * nclass + ctr;
+    };
     auto locate = [&](int64_t tile) __attribute__((always_inline)) -> BfTile {
         BfTile t;
         t.tile = tile;
@@ -358,7 +375,7 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
         } else {
 #pragma unroll
             for (int w = 0; w < kBfWaves; ++w) { const int c = __builtin_amdgcn_readfirstlane(wcnt[par][w]); if (w < wave) wbase += c; bcnt += c; }
-            if (tid == 0) bf_st(a.tile_state + t.tile, kBfCount | (unsigned long long)bcnt);
+            if constexpr (MODE == 0) { if (tid == 0) bf_st(a.tile_state + t.tile, kBfCount | (unsigned long long)bcnt); }
         }
     };
 
@@ -376,6 +393,7 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
     if (Tn < ntiles) { tn = locate(Tn); prefetch(tn, PB); }
     count_publish(PA, tc, 0, km_c, wbase_c, bcnt_c);
 
+    int64_t own_rows = 0;          // (OWNED, thread 0) kept rows of the current batch up to and including the block's last tile
     auto flush_nulls = [&]() __attribute__((always_inline)) {      // (between two block barriers)
         if (NULLS && tid < ncols && nullacc[tid]) {
             atomicAdd((unsigned long long*)&fa.out_null_counts[(int64_t)tid * fa.t.nchunks + cur_chunk], (unsigned long long)nullacc[tid]);
@@ -395,7 +413,12 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
         // b. rows of the batch in front of the current tile
         if (tid == 0) {
             int64_t base = 0;               // a batch's first tile starts the batch's output
-            if (!SHORT && tc.first != Tc) {
+            if constexpr (OWNED) {
+                // the tile in front of this one, if the batch has one, was this block's previous tile
+                base = tc.first != Tc ? own_rows : 0;
+                own_rows = base + bcnt_c;
+            }
+            if (MODE == 0 && tc.first != Tc) {
                 unsigned long long w, t0 = 0;
                 int spins = 0;
                 auto wait_for = [&](const unsigned long long* p) __attribute__((always_inline)) {
@@ -568,11 +591,12 @@ int bfilter_tile_rows(int esize, int ncols) {
 hipError_t launch_bfilter(const BFilterArgs& a, int esize, bool nulls, hipStream_t s) {
     if (a.w.t.ntiles <= 0) return hipSuccess;
     const bool multi = a.w.ncols > 1, by_mask = a.nterms == 0;
-    const bool shrt = a.short_mode != 0;
-    const dim3 grid((unsigned)(a.nworkers + (shrt ? 0 : 1))), block(kBfBlock);
+    const int mode = a.short_mode;          // 0: long batches (block 0 scans), 1: short batches, 2: a block owns whole batches
+    const dim3 grid((unsigned)(a.nworkers + (mode == 0 ? 1 : 0))), block(kBfBlock);
 #define RDF_BF_LAUNCH3(T, G, MULTI, NULLS, BYMASK) \
-    do { if (shrt) hipLaunchKernelGGL((bfilter_kernel<T, G, MULTI, NULLS, BYMASK, true>), grid, block, 0, s, a); \
-         else hipLaunchKernelGGL((bfilter_kernel<T, G, MULTI, NULLS, BYMASK, false>), grid, block, 0, s, a); } while (0)
+    do { if (mode == 1) hipLaunchKernelGGL((bfilter_kernel<T, G, MULTI, NULLS, BYMASK, 1>), grid, block, 0, s, a); \
+         else if (mode == 2) hipLaunchKernelGGL((bfilter_kernel<T, G, MULTI, NULLS, BYMASK, 2>), grid, block, 0, s, a); \
+         else hipLaunchKernelGGL((bfilter_kernel<T, G, MULTI, NULLS, BYMASK, 0>), grid, block, 0, s, a); } while (0)
 #define RDF_BF_LAUNCH2(T, G, MULTI, NULLS) \
     do { if (by_mask) RDF_BF_LAUNCH3(T, G, MULTI, NULLS, true); else RDF_BF_LAUNCH3(T, G, MULTI, NULLS, false); } while (0)
 #define RDF_BF_LAUNCH(T, G, MULTI) \

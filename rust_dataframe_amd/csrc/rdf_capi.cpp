@@ -60,6 +60,7 @@ struct Ctx {
     int    opt_filter_gen = 2;      // compaction kernels: 2 = wave-granular tiles (rdf_filter.hip, default), 1 = first-generation block tiles (A/B)
     int    opt_filter_block = 1;    // one-pass compaction of LONG batches on block tiles held in registers, prefixes from a scanner wave (rdf_bfilter.hip, round 6; default); 0 = the wave-tile kernels only (A/B)
     int    opt_interp_lean = 1;             // interpreted aggregate programs whose every step has a lean handler run on eval_lean_kernel (rdf_eval_lean.hip); 0: always eval_kernel (the A/B)
+    int    opt_filter_owned = 1;    // long batches, many of them, none a large share of the frame: a block draws whole batches and adds up its own offsets (round 6; default); 0 = tiles by ticket, offsets from the scanner wave (A/B)
     int    opt_filter_short = 1;    // batches / chunks no longer than a block tile on the block kernel's short-batch mode (round 6; default); 0 = the wave-tile kernels (A/B)
     int    opt_filter_block_rows = 8192;    // ... for frames whose mean batch length is at least this many rows (one block tile of a single 8-byte column; measured ahead of the wave-tile kernel from 8192-row batches up: profiles/r06_filter_frame_batch_length_sweep.jsonl)
     int    opt_filter_fused = 1;    // rdf_filter_frame: `col CMP literal [AND|OR col CMP literal]` predicates evaluated inside the compaction kernel, one pass (1, default); 0 = predicate -> mask, count, compact (A/B)
@@ -2361,6 +2362,13 @@ rdf_status bfilter_scratch(BFilterArgs& ba) {
     ba.stall_test = ctx.opt_filter_block == 3 ? 1 : 0;
     return RDF_OK;
 }
+// Long batches, but many of them and none a large share of the frame (a 1e9-row frame in 65 536-row batches): a block draws whole
+// batches and keeps the running offset itself — no scanner wave, no tile states (BFilterArgs::short_mode 2).
+bool bfilter_owned_ok(int64_t nchunks, int64_t max_len, int64_t total_rows) {
+    const int64_t workers = (int64_t)(eval_grid_limit() / 8) * 2;
+    if (g_ctx.opt_filter_owned == 2) return g_ctx.opt_filter_block != 3;           // tests: every frame of long batches
+    return g_ctx.opt_filter_owned && g_ctx.opt_filter_block != 3 && nchunks >= 8 * workers && max_len <= total_rows / (workers * 16);       // (>= 16 batches per block: the blocks finish within a few per cent of each other; measured level with the scanner form at 65 536-row batches of 1e9 rows, 6 % ahead at 16 384, 9 % ahead with the mask given, behind at 200 000: profiles/r06_filter_owned_batches_ab.jsonl)
+}
 // after the kernel (stream already synchronised by the caller's result copy): did a wait give up?
 rdf_status bfilter_check(const BFilterArgs& ba) {
     Ctx& ctx = g_ctx;
@@ -2623,6 +2631,11 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
             ba.nterms = 0;
             ba.out_len = d_len;
             if (block_short) { ba.short_mode = 1; ba.short_shift = short_shift; }
+            else {
+                int64_t longest = 0, rows = 0;
+                for (int64_t c = 0; c < nchunks; ++c) { longest = std::max(longest, fp.clen[(size_t)c]); rows += fp.clen[(size_t)c]; }
+                if (bfilter_owned_ok(nchunks, longest, rows)) ba.short_mode = 2;
+            }
             RDF_TRY(bfilter_scratch(ba));
             if (!kt) kt.reset(new KernelTimer());
             HIP_TRY(launch_bfilter(ba, es0, nulls, ctx.stream));
@@ -2630,7 +2643,7 @@ rdf_status filter_columns_block(FilterPrep& fp, const rdf_array* cols, int ncols
         }
         if (kt) kt->stop();
     }
-    ctx.last_kernel = short_chunks ? "fcompact_dma_kernel (one pass)" : block_short ? "bfilter_kernel (short batches)" : "bfilter_kernel";
+    ctx.last_kernel = short_chunks ? "fcompact_dma_kernel (one pass)" : block_short ? "bfilter_kernel (short batches)" : !launched.empty() && launched[0].short_mode == 2 ? "bfilter_kernel (a block per batch)" : "bfilter_kernel";
     RDF_TRY(pinned_reserve(fp.pin_off + 8 * (nout + (size_t)nchunks) + 256));
     int64_t* pin = (int64_t*)(ctx.pinned + fp.pin_off);
     HIP_TRY(hipMemcpyAsync(pin, d_nullc, 8 * (nout + (size_t)nchunks), hipMemcpyDeviceToHost, ctx.stream));
@@ -4501,6 +4514,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
     else if (strcmp(name, "filter_block") == 0) g_ctx.opt_filter_block = value == 3 ? 3 : value != 0;      // (3: tests — the scanner wave stays idle, every wait must time out)
     else if (strcmp(name, "interp_lean") == 0) g_ctx.opt_interp_lean = value == 2 ? 2 : value != 0;   // (2: the lean kernel with one tile per trip of its step loop — the A/B of its two-tile form)
+    else if (strcmp(name, "filter_owned") == 0) g_ctx.opt_filter_owned = value == 2 ? 2 : value != 0;      // (2: tests — whatever the number and lengths of the batches)
     else if (strcmp(name, "filter_short") == 0) g_ctx.opt_filter_short = value != 0;
     else if (strcmp(name, "filter_block_rows") == 0) g_ctx.opt_filter_block_rows = value < 1 ? 1 : (int)value;
     else if (strcmp(name, "filter_lookback") == 0) g_ctx.opt_filter_lookback = value == 1 ? 1 : value == 2 ? 2 : 3;

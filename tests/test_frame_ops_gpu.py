@@ -516,16 +516,21 @@ def test_filter_frame_block_tiles(gpu, ora, lens, off, nf, dts):
             lib.set_option("filter_block_rows", 1)
             for name, root in preds.items():
                 exp = ora.filter_columns(host, ora.predicate(e, root, host))
-                out = gpu.filter_frame(frame, e, root)
-                assert lib.last_kernel() == "bfilter_kernel", (name, lib.last_kernel())
-                nc, nch, rows = out.info()
-                assert (nc, nch) == (len(dts), len(lens)) and rows == sum(x.length for x in exp[0]), (name, rows)
-                got = frame_columns(out)
-                for k in range(len(dts)):
-                    match_unknown_nulls(got[k], exp[k], f"{name} lens={lens} column {k}")
-                out.release()
+                # offsets from the scanner wave (few long batches), then a block per batch with its own running offset (many batches,
+                # none a large share of the frame; `filter_owned` 2 takes that form whatever the layout)
+                for owned, kern in ((0, "bfilter_kernel"), (2, "bfilter_kernel (a block per batch)")):
+                    lib.set_option("filter_owned", owned)
+                    out = gpu.filter_frame(frame, e, root)
+                    assert lib.last_kernel() == kern, (name, lib.last_kernel())
+                    nc, nch, rows = out.info()
+                    assert (nc, nch) == (len(dts), len(lens)) and rows == sum(x.length for x in exp[0]), (name, owned, rows)
+                    got = frame_columns(out)
+                    for k in range(len(dts)):
+                        match_unknown_nulls(got[k], exp[k], f"{name} owned={owned} lens={lens} column {k}")
+                    out.release()
         finally:
             lib.set_option("filter_block_rows", 8192)
+            lib.set_option("filter_owned", 1)
 
 
 SHORT_LAYOUTS = [([1024] * 37 + [500], 0, 0.1), ([1024, 1000, 0, 1, 1023, 1024, 512, 777, 1024, 1024, 1024, 1024], 5, 0.1), ([4096] * 5 + [3000], 0, 0.0),
@@ -647,6 +652,12 @@ def test_filter_columns_device_block_tiles(gpu, ora, lens, off, nf, dts):
 
         try:
             lib.set_option("filter_block_rows", 1)
+            lib.set_option("filter_owned", 2)               # a block per batch, its own running offset
+            bufs, outs = outputs(lens)
+            gpu.filter_columns(dev, dmask[0], outs)
+            assert lib.last_kernel() == "bfilter_kernel (a block per batch)", lib.last_kernel()
+            check(bufs, outs, f"one pass, a block per batch, sel={sel}")
+            lib.set_option("filter_owned", 0)               # tiles by ticket, offsets from the scanner wave
             bufs, outs = outputs(lens)
             gpu.filter_columns(dev, dmask[0], outs)
             assert lib.last_kernel() == "bfilter_kernel", lib.last_kernel()
@@ -675,6 +686,7 @@ def test_filter_columns_device_block_tiles(gpu, ora, lens, off, nf, dts):
                             assert (guard == 0xAB).all(), (k, c)
         finally:
             lib.set_option("filter_block_rows", 8192)
+            lib.set_option("filter_owned", 1)
 
 
 @pytest.mark.parametrize("lens,off,nf", [([1024] * 40 + [500], 0, 0.1), ([1024, 0, 1024, 777, 1024], 3, 0.0), ([1000] * 9, 0, 0.2),

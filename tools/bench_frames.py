@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--block", type=int, default=1, help="rdf_set_option(\"filter_block\"): 1 = long batches on block tiles with a scanner wave (rdf_bfilter.hip, round 6, default), 0 = wave tiles + look-back (round 5)")
     ap.add_argument("--block-rows", type=int, default=0, help="rdf_set_option(\"filter_block_rows\"): the mean batch length from which the block kernel is taken (0: the library's default)")
     ap.add_argument("--short", type=int, default=1, help="rdf_set_option(\"filter_short\"): 1 = batches no longer than a block tile on the block kernel's short-batch mode (round 6, default), 0 = the wave-tile kernel")
+    ap.add_argument("--owned", type=int, default=1, help="rdf_set_option(\"filter_owned\"): 1 = many long batches, none a large share of the frame: a block draws whole batches and adds up its own offsets (round 6, default), 0 = tiles by ticket, offsets from the scanner wave")
     args = ap.parse_args()
     n, cr = args.rows, args.chunk_rows
     only = set(filter(None, args.only.split(",")))
@@ -86,6 +87,7 @@ def main():
     lib.set_option("filter_lookback", args.lookback)
     lib.set_option("filter_block", args.block)
     lib.set_option("filter_short", args.short)
+    lib.set_option("filter_owned", args.owned)
     if args.block_rows > 0:
         lib.set_option("filter_block_rows", args.block_rows)
 

@@ -209,6 +209,10 @@ def main():
         MF = A.PreparedCol([A.DeviceArray(m.values_ptr + i // 8, None, 0, min(cr, nfc - i), A.BOOL, 0, keep=m) for i in range(0, nfc, cr)])
         OF = [A.DeviceArray(ofb.data_ptr() + i * 8, None, 0, min(cr, nfc - i), A.F64, 0, keep=ofb) for i in range(0, nfc, cr)]
         report(f"filter_1col_{cr}_row_chunks", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))
+        if cr > 8192:
+            lib.set_option("filter_owned", 0)
+            report(f"filter_1col_{cr}_row_chunks_scanner_wave", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))     # tiles by ticket, offsets from the scanner wave (before a block owned whole chunks)
+            lib.set_option("filter_owned", 1)
         if cr <= 8192:
             lib.set_option("filter_short", 0)
             report(f"filter_1col_{cr}_row_chunks_three_kernels", (8 + 8 * sel + 0.25) * nfc, lambda: api.filter(XF, MF, OF))     # count, scan, compact (before the short-batch mode)

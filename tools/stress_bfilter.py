@@ -30,16 +30,28 @@ def main():
     rng = np.random.default_rng(args.seed)
     rows_done = 0
     skipped = 0
+    forms = {}
     for it in range(args.iters):
         wide = rng.uniform() < 0.7
         pool = [A.F64, A.I64, A.U64] if wide else [A.F32, A.I32, A.U32]
         ncols = int(rng.integers(1, 5))
         dts = [pool[int(rng.integers(0, 3))] for _ in range(ncols)]
         nch = int(rng.integers(1, 12))
-        shape = rng.integers(0, 4)
+        shape = rng.integers(0, 7)
+        # form of the block kernel under test: 0 = tiles by ticket + scanner wave, 2 = a block per batch (its own running offset),
+        # 1 = short batches (a batch on 1 / 2 / 4 / 8 waves of a block; shapes 4-6: no batch longer than a block tile)
+        form = 1 if shape >= 4 else int(rng.choice([0, 2]))
+        if form == 1:
+            nch = int(rng.integers(1, 60))
         lens = []
         for _ in range(nch):
-            if shape == 0:
+            if shape == 4:
+                lens.append(int(rng.choice([1024, 1024, 1024, int(rng.integers(0, 1025))])))
+            elif shape == 5:
+                lens.append(int(rng.integers(1500, 4097)))
+            elif shape == 6:
+                lens.append(int(rng.integers(600, 2049)))
+            elif shape == 0:
                 lens.append(int(rng.integers(0, 40_000)))
             elif shape == 1:
                 lens.append(int(rng.integers(8000, 9000)))
@@ -66,12 +78,15 @@ def main():
             res = {}
             for block in (1, 0):
                 lib.set_option("filter_block", block)
-                lib.set_option("filter_block_rows", 1)
+                lib.set_option("filter_block_rows", 8192 if form == 1 else 1)
+                lib.set_option("filter_owned", form)
                 lib.set_option("filter_fused", 2)
                 out = gpu.filter_frame(frame, e, root)
                 res[block] = (out.info(), frame_columns(out), lib.last_kernel())
                 out.release()
-            if res[1][2] != "bfilter_kernel":        # (a frame of mostly tiny batches: both runs took the three passes — nothing to compare)
+            want = {0: "bfilter_kernel", 1: "bfilter_kernel (short batches)", 2: "bfilter_kernel (a block per batch)"}[form]
+            forms[form] = forms.get(form, 0) + (res[1][2] == want)
+            if res[1][2] != want:        # (a frame of mostly tiny batches: both runs took the three passes — nothing to compare; short form: slots mostly empty)
                 skipped += 1
                 continue
             assert res[0][2] == "ffilter_dma_kernel", (res[1][2], res[0][2])
@@ -86,7 +101,8 @@ def main():
         rows_done += sum(lens)
         if (it + 1) % 50 == 0:
             print(f"{it + 1} frames, {rows_done} rows: identical", flush=True)
-    lib.set_option("filter_block", 1); lib.set_option("filter_block_rows", 8192); lib.set_option("filter_fused", 1)
+    lib.set_option("filter_block", 1); lib.set_option("filter_block_rows", 8192); lib.set_option("filter_fused", 1); lib.set_option("filter_owned", 1)
+    print(f"forms compared (0 scanner wave, 1 short batches, 2 a block per batch): {forms}")
     print(f"stress_bfilter: {args.iters - skipped} random frames ({rows_done} rows; {skipped} more were not of the one-pass shape), block-tile kernel == wave-tile kernel on every column of every batch")
 
 
