@@ -69,6 +69,8 @@ struct Ctx {
     int    opt_gb_debug = 0;        // ablations of the partitioned GROUP BY (tools/bench_kernels.py): 1 = aggregate without LDS work, 2 = scatter without stores
     int    opt_sort_gen = 3;        // radix passes: 3 = one read + one write of the pairs per digit, decoupled look-back between 4096-pair tiles (rdf_sort.hip, default); 2 = count -> scan -> scatter over static tile ranges with the same wave-ranked tiles (A/B: slower, see rdf_sort.hip); 1 = first generation (rdf_kernels.hip)
     bool   sort_used_local = false; // the last sort finished at least one column with os_local_kernel
+    int    opt_sort_super = 1;      // the digit passes of rdf_sort.hip: 1 = a tile per ticket, decoupled look-back between tiles (os_scatter_kernel, default); K > 1 = a ticket is up to K consecutive tiles, counted together, ONE look-back, then ranked and written one by one (os_scatter4_kernel, round 6: built, correct, measured level at 1e9 i64 keys and 8-12 % SLOWER on 5e7 f64 / two-key sorts — profiles/r06_sort_super_tiles_ab.jsonl — kept as the A/B: the second read of the keys costs what the shorter wait saves)
+    int    opt_sort_super_force = 0;    // tests: this many tiles per ticket whatever the input's size (rdf_set_option("sort_super", 100 + K))
     int    opt_sort_pipe = 0;       // the digit passes of rdf_sort.hip: 0 = decoupled look-back between the tiles (os_scatter_kernel, default); 1 = a tile's digit counts are published one iteration before its offsets are asked for and scanner blocks turn counts into offsets (os_scatter3_kernel, round 6: built, correct, measured 4-16 % SLOWER — profiles/r06_sort_digit_pass_ab.jsonl — kept as the A/B)
     int    opt_sort_msd = 1;        // sort keys that vary in more than 32 bits: passes over the top bits, then every bucket sorted in LDS (1, default); 0 = one pass per byte (A/B)
     int    opt_sort_sample = 1;     // doubles: value buckets planned from a sample of the keys (range without outliers, bucket bits from the densest region); 0 = [min, max] and ~500 rows per bucket (round 3, A/B)
@@ -3351,6 +3353,7 @@ rdf_status os_column_passes(OsScratch& o, uint64_t* const keys[2], uint32_t* con
         pa.nullflags = np ? nullflags : nullptr;
         pa.state = o.state; pa.ticket = o.tickets + launched; pa.class_tickets = ctx.opt_sort_pipe ? o.ctick + (size_t)launched * 64 * 32 : nullptr; pa.bases = o.hist + hist_row * 256;
         pa.n = rows; pa.ntiles = (rows + os_tile_items() - 1) / os_tile_items(); pa.bias = bias; pa.shift = shift; pa.mask = mask; pa.seq = ++o.seq;
+        pa.super_tiles = ctx.opt_sort_pipe ? 1 : ctx.opt_sort_super_force ? ctx.opt_sort_super_force : os_super_tiles(pa.ntiles, ctx.opt_sort_super);
         if (!np) pa.fb = fb;
         static const bool dbg3 = getenv("RDF_DEBUG_SORT") != nullptr;
         if (dbg3) { pa.debug = o.tickets + 8; HIP_TRY(hipMemsetAsync(pa.debug, 0, 48, ctx.stream)); }
@@ -3542,6 +3545,7 @@ byte_passes:
         pa.nullflags = np ? nullflags : nullptr;
         pa.state = o.state; pa.ticket = o.tickets + launched; pa.class_tickets = ctx.opt_sort_pipe ? o.ctick + (size_t)launched * 64 * 32 : nullptr; pa.bases = o.hist + (np ? 8 : p) * 256;
         pa.n = n; pa.ntiles = o.ntiles; pa.bias = bias; pa.shift = 8 * p; pa.seq = ++o.seq;
+        pa.super_tiles = ctx.opt_sort_pipe ? 1 : ctx.opt_sort_super_force ? ctx.opt_sort_super_force : os_super_tiles(pa.ntiles, ctx.opt_sort_super);
         static const bool dbg = getenv("RDF_DEBUG_SORT") != nullptr;
         if (dbg) { pa.debug = o.tickets + 8; }
         HIP_TRY(launch_os_scatter(pa, ctx.stream));
@@ -4514,6 +4518,10 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
     else if (strcmp(name, "filter_fused") == 0) g_ctx.opt_filter_fused = (int)value;
     else if (strcmp(name, "filter_block") == 0) g_ctx.opt_filter_block = value == 3 ? 3 : value != 0;      // (3: tests — the scanner wave stays idle, every wait must time out)
     else if (strcmp(name, "interp_lean") == 0) g_ctx.opt_interp_lean = value == 2 ? 2 : value != 0;   // (2: the lean kernel with one tile per trip of its step loop — the A/B of its two-tile form)
+    else if (strcmp(name, "sort_super") == 0) {
+        if (value > 100) g_ctx.opt_sort_super_force = value > 164 ? 64 : (int)value - 100;      // (tests: K tiles per ticket on inputs of any size)
+        else { g_ctx.opt_sort_super_force = 0; g_ctx.opt_sort_super = value < 1 ? 1 : value > 64 ? 64 : (int)value; }
+    }
     else if (strcmp(name, "filter_owned") == 0) g_ctx.opt_filter_owned = value == 2 ? 2 : value != 0;      // (2: tests — whatever the number and lengths of the batches)
     else if (strcmp(name, "filter_short") == 0) g_ctx.opt_filter_short = value != 0;
     else if (strcmp(name, "filter_block_rows") == 0) g_ctx.opt_filter_block_rows = value < 1 ? 1 : (int)value;

@@ -313,7 +313,7 @@ struct OsPassArgs {
     OsBucket        fb;                              // ... or (value bucket >> shift) & mask
     unsigned long long* debug;                       // RDF_DEBUG: [6] cycle sums of the phases (ticket, load + rank, barrier, look-back, sort + write), tiles
     unsigned int*   class_tickets;                   // os_scatter3_kernel (round 6): 64 ticket counters of this pass, 128 bytes apart (zeroed); nullptr = os_scatter_kernel
-    int32_t         nclass, pad2;                    // counters in use (set by the launcher)
+    int32_t         nclass, super_tiles;             // nclass: counters in use (set by the launcher); super_tiles: K > 1 = os_scatter4_kernel (round 6): a ticket is K consecutive tiles, `state` holds one row of 256 words per super-tile
 };
 // Most-significant-digits-first finish (keys that vary in more than 32 bits): after stable passes over the TOP bits of the keys
 // the rows lie in buckets of <= kOsLocalMax rows that share those bits; every bucket is then sorted on the remaining `rbits`
@@ -336,6 +336,7 @@ hipError_t launch_os_sample(const uint64_t* keys, int64_t n, int nsamp, uint64_t
 hipError_t launch_os_hist(const OsHistArgs& a, hipStream_t s);
 hipError_t launch_os_scatter(const OsPassArgs& a, hipStream_t s);
 int os_tile_items();
+int os_super_tiles(int64_t ntiles, int max_k);
 int sr_grid(int64_t ntiles);
 hipError_t launch_sr_hist(const OsPassArgs& a, int64_t* hist, hipStream_t s);      // hist: [256 * sr_grid] digit-major per-block counts
 hipError_t launch_sr_scatter(const OsPassArgs& a, const int64_t* hist, hipStream_t s);   // hist: their exclusive scan

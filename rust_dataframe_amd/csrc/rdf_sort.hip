@@ -247,6 +247,172 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 6, second form (os_scatter4_kernel; rdf_set_option("sort_super", K) with K > 1 — NOT the default: measured level with the
+// kernel above on 1e9 i64 keys (51.8 - 59.2 against 57.7 - 58.0 ms, box noise) and 8 - 12 % slower on 5e7 f64 keys and two-key sorts,
+// profiles/r06_sort_super_tiles_ab.jsonl: the second read of the keys and the count sweep cost what the shorter wait saves, as the
+// static-range passes had shown — a pass is bound by the WORK a CU does per tile, 15 us that two resident blocks do not overlap, and
+// the waiting sits under the other block's work already).  A block draws a SUPER-TILE of K consecutive tiles.  It first counts the digits of all K tiles (one sweep over their keys: plain LDS adds, nothing
+// else), publishes those counts as ONE participant of the look-back, finds its offsets once — and then ranks, sorts and writes its K
+// tiles one after the other, thread d carrying digit d's running offset in a register.  What that buys (phase timers of the kernel
+// above, 1e9 pairs: 15 us of work and 12 us of waiting per 4096-pair tile, 2 blocks per CU):
+//   * the look-back's walk is as long as before — its length is the number of blocks in flight, not the tile size — but it is paid
+//     once per K tiles;
+//   * K times fewer state words and ticket draws (one ticket counter hands out 43 tiles per us at best: 5.6 ms per pass of 1e9 pairs);
+//   * the per-tile part loses its count-and-publish step (a tile's digit counts fall out of the per-wave counters the ranking fills).
+// The price is a second read of the keys, 8 of the pass's 24 bytes per pair; the K tiles of a block were read microseconds
+// earlier (K x 32 KB per block, 128 MB over the grid at K = 8: within the 256 MB of memory-side cache).
+// What the per-range variant of this idea cannot do: hand every range of tiles its own chain of offsets — a range's start inside
+// digit d's run is the count of d in ALL earlier ranges in the CURRENT order of the rows, which the one histogram taken before the
+// passes does not know (only the global counts survive a permutation).
+template <int ITEMS>
+__global__ __launch_bounds__(kBlock) void os_scatter4_kernel(const OsPassArgs a) {
+    constexpr int TILE = kBlock * ITEMS;
+    __shared__ uint64_t lkeys[TILE];
+    __shared__ uint32_t lidx[TILE];
+    __shared__ uint8_t ldig[TILE];
+    __shared__ unsigned int whist[kOsWaves][256];
+    __shared__ unsigned int dbase[256];
+    __shared__ int64_t gbase[256];
+    __shared__ unsigned int wsum[kOsWaves];
+    __shared__ unsigned int thist[256];                // the super-tile's digit counts
+    __shared__ int64_t tile_s;
+    __shared__ uint2 segs[kOsSegs];
+    os_load_segs(a.fb, segs);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t seq = (uint64_t)a.seq << 50;
+    const int K = a.super_tiles;
+    const int64_t nsuper = (a.ntiles + K - 1) / K;
+    auto digit_of = [&](uint64_t key, uint32_t row) __attribute__((always_inline)) -> int {
+        return a.nullflags ? (int)as_global<uint8_t>(a.nullflags)[row]
+                           : a.fb.bits ? (int)((os_value_bucket(key, a.fb, segs) >> a.shift) & (uint32_t)a.mask) : os_digit(key, a.bias, a.shift, a.mask);
+    };
+    for (;;) {
+        if (threadIdx.x == 0) tile_s = (int64_t)atomicAdd((unsigned long long*)a.ticket, 1ull);
+        thist[threadIdx.x] = 0;
+        __syncthreads();
+        const int64_t sup = tile_s;
+        if (sup >= nsuper) break;
+        const int64_t sbase = sup * K * TILE;
+        const int64_t send = (a.n - sbase) < (int64_t)K * TILE ? a.n : sbase + (int64_t)K * TILE;
+        // ---- the digit counts of all K tiles, published as one participant
+        if (a.nullflags) {
+            for (int64_t i = sbase + threadIdx.x; i < send; i += kBlock) {
+                const uint32_t row = a.idx_in ? __builtin_nontemporal_load(as_global<uint32_t>(a.idx_in) + i) : (uint32_t)i;
+                atomicAdd(&thist[as_global<uint8_t>(a.nullflags)[row]], 1u);
+            }
+        } else {
+            // (two keys per lane and load: TILE is even, so a super-tile starts on a 16-byte boundary of the key array)
+            const int64_t pairs_end = sbase + ((send - sbase) & ~(int64_t)1);
+            for (int64_t i = sbase + 2 * (int64_t)threadIdx.x; i < pairs_end; i += 2 * kBlock) {
+                typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+                const u64x2 kk = *(GlobalPtr<u64x2>)(as_global<uint64_t>(a.keys_in) + i);
+                atomicAdd(&thist[digit_of(kk[0], 0)], 1u);
+                atomicAdd(&thist[digit_of(kk[1], 0)], 1u);
+            }
+            if (threadIdx.x == 0 && pairs_end < send) atomicAdd(&thist[digit_of(as_global<uint64_t>(a.keys_in)[pairs_end], 0)], 1u);
+        }
+        __syncthreads();
+        const unsigned int total_d = thist[threadIdx.x];
+        unsigned long long* st = a.state + sup * 256 + threadIdx.x;
+        if (sup > 0) __hip_atomic_store(st, seq | kOsLocal | total_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- look back over the super-tiles before this one (thread d: digit d)
+        int64_t excl = 0;
+        for (int64_t t = sup - 1; t >= 0;) {
+            unsigned long long w[kOsLook];
+#pragma unroll
+            for (int u = 0; u < kOsLook; ++u)
+                w[u] = t - u >= 0 ? __hip_atomic_load(a.state + (t - u) * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (seq | kOsInclusive);
+            int used = 0;
+            bool done = false, stalled = false;
+#pragma unroll
+            for (int u = 0; u < kOsLook; ++u) {
+                if (done || stalled) continue;
+                if ((w[u] >> 50) != (unsigned long long)a.seq) { stalled = true; continue; }
+                excl += (int64_t)(w[u] & kOsValueMask);
+                ++used;
+                if (w[u] & kOsInclusive) done = true;
+            }
+            if (done) break;
+            t -= used;
+            if (stalled) __builtin_amdgcn_s_sleep(1);
+        }
+        __hip_atomic_store(st, seq | kOsInclusive | (unsigned long long)(excl + total_d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int64_t run_base = a.bases[threadIdx.x] + excl;         // where digit d's rows of the NEXT tile of this super-tile go
+        // ---- the K tiles
+        for (int k = 0; k < K; ++k) {
+            const int64_t base = sbase + (int64_t)k * TILE;
+            if (base >= a.n) break;
+            const int count = (int)((a.n - base) < (int64_t)TILE ? (a.n - base) : (int64_t)TILE);
+#pragma unroll
+            for (int w = 0; w < kOsWaves; ++w) whist[w][threadIdx.x] = 0;
+            uint64_t key[ITEMS];
+            uint32_t idx[ITEMS];
+            int digit[ITEMS], rank[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
+                const bool in = i < a.n;
+                key[j] = in ? as_global<uint64_t>(a.keys_in)[i] : 0;          // (read a few microseconds ago by the count sweep: not a streaming load)
+                idx[j] = in ? (a.idx_in ? __builtin_nontemporal_load(as_global<uint32_t>(a.idx_in) + i) : (uint32_t)i) : 0;
+            }
+            __syncthreads();               // whist is clear
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
+                const bool in = i < a.n;
+                const int d = in ? digit_of(key[j], idx[j]) : 0;
+                digit[j] = d;
+                uint64_t peers = __ballot(in);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const uint64_t m = __ballot((d >> b) & 1);
+                    peers &= ((d >> b) & 1) ? m : ~m;
+                }
+                const int leader = __builtin_ctzll(peers | (1ull << 63));
+                unsigned int before = 0;
+                if (in && lane == leader) { before = whist[wave][d]; whist[wave][d] = before + (unsigned)__popcll(peers); }
+                before = __shfl(before, leader);
+                rank[j] = (int)before + __popcll(peers & ((1ull << lane) - 1));
+            }
+            __syncthreads();
+            // thread d: the waves' counts of digit d -> their offsets inside the run; their sum is the tile's count of d
+            unsigned int tile_d = 0;
+#pragma unroll
+            for (int w = 0; w < kOsWaves; ++w) { const unsigned int c = whist[w][threadIdx.x]; whist[w][threadIdx.x] = tile_d; tile_d += c; }
+            unsigned int inc = tile_d;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { const unsigned int o = __shfl_up(inc, dd); if (lane >= dd) inc += o; }
+            if (lane == 63) wsum[wave] = inc;
+            gbase[threadIdx.x] = run_base;
+            run_base += tile_d;
+            __syncthreads();
+            unsigned int wb = 0;
+            for (int w = 0; w < wave; ++w) wb += wsum[w];
+            dbase[threadIdx.x] = wb + inc - tile_d;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int64_t i = base + (wave * ITEMS + j) * 64 + lane;
+                if (i < a.n) {
+                    const int pos = (int)(dbase[digit[j]] + whist[wave][digit[j]]) + rank[j];
+                    lkeys[pos] = key[j];
+                    lidx[pos] = idx[j];
+                    ldig[pos] = (uint8_t)digit[j];
+                }
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < count; t += kBlock) {
+                const int d = ldig[t];
+                const int64_t dst = gbase[d] + (t - (int)dbase[d]);
+                __builtin_nontemporal_store(lkeys[t], as_global_mut<uint64_t>(a.keys_out) + dst);
+                __builtin_nontemporal_store(lidx[t], as_global_mut<uint32_t>(a.idx_out) + dst);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Round 6: the same pass with the waiting taken out (os_scatter3_kernel; rdf_set_option("sort_pipe", 0) brings the kernel above
 // back for A/B).  By the phase timers a tile above spends 12 of its 27 us waiting in the look-back: its offsets need the counts of
 // EVERY tile ticketed before it, those tiles are being counted at the same moment, and a count is one memory round trip away
@@ -677,8 +843,21 @@ hipError_t launch_os_scatter(const OsPassArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((os_scatter3_kernel<kOsItems>), dim3((unsigned)(grid + kOsScanBlocks)), dim3(kBlock), 0, s, b);
         return hipGetLastError();
     }
+    if (b.super_tiles > 1) {    // round 6: K tiles per ticket — counted together, one look-back, then ranked and written one by one
+        const int64_t nsuper = (b.ntiles + b.super_tiles - 1) / b.super_tiles;
+        if (grid > nsuper) grid = nsuper;
+        hipLaunchKernelGGL((os_scatter4_kernel<kOsItems>), dim3((unsigned)grid), dim3(kBlock), 0, s, b);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((os_scatter_kernel<kOsItems>), dim3((unsigned)grid), dim3(kBlock), 0, s, b);
     return hipGetLastError();
+}
+// tiles per ticket for a pass over `ntiles` tiles: as many as `max_k` while every resident block still gets several super-tiles
+int os_super_tiles(int64_t ntiles, int max_k) {
+    const int64_t grid = (int64_t)(eval_grid_limit() / 8) * (kOsItems >= 16 ? 2 : 5);
+    int64_t k = ntiles / (grid * 4);
+    if (k > max_k) k = max_k;
+    return k < 2 ? 1 : (int)k;
 }
 
 // ------------------------------------------------------------------------------------------------

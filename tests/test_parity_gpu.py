@@ -715,6 +715,32 @@ def test_sort_digit_passes_with_scanner_blocks(gpu, ora, dtype):
         lib.set_option("sort_pipe", 0)
 
 
+@pytest.mark.parametrize("dtype", [A.I64, A.F64, A.I32, A.U8])
+def test_sort_digit_passes_on_super_tiles(gpu, ora, dtype):
+    """Round 6: a ticket of the digit passes is K consecutive tiles — counted together, ONE look-back, then ranked and written one
+    by one (os_scatter4_kernel; measured no faster than a tile per ticket and not the default — kept as its A/B partner, so it is
+    held to the same oracle).  `sort_super` 100 + K takes that form on inputs of any size: K = 2, 3, 8 over 104 and 611 tiles (a ragged last super-tile, a last tile of one row's worth), NULL keys (the NULLs-last
+    pass reads its digit through the row index), ties, descending, two key columns, value-bucket passes of doubles; and K = 1 by
+    option (the look-back kernel) gives the same indices."""
+    from rust_dataframe_amd import lib
+    rng = np.random.default_rng(1400 + dtype)
+    try:
+        for lens, nf in [([300_000, 1, 123_457], 0.05), ([2_500_000], 0.0)]:
+            kind = "special" if dtype == A.F64 else "extreme"
+            k1 = make_chunks(rng, dtype, lens, nf, 3, kind)
+            k2 = make_chunks(rng, A.I16, lens, 0.0, 0, "plain")
+            for ch in k2:
+                ch.values[:] = ch.values % 3
+            for cols, d in (([k1], [False]), ([k2, k1], [True, False])):
+                exp = ora.sort_to_indices(cols, d).to_numpy()
+                for k in (102, 103, 108, 1):
+                    lib.set_option("sort_super", k)
+                    got = gpu.sort_to_indices(cols, d).to_numpy()
+                    assert np.array_equal(got, exp), f"sort_super={k} dtype={dtype} lens={lens} desc={d}"
+    finally:
+        lib.set_option("sort_super", 1)
+
+
 @pytest.mark.parametrize("ngroups,n", [(20_000, 150_000), (300_000, 700_000), (1_300_000, 2_000_000)])
 def test_groupby_partitioned_high_cardinality(gpu, ora, ngroups, n):
     """More than 1024 groups: records are scattered once on 9 hash bits (default) — or radix-sorted in 1-2 passes (the

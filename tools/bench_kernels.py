@@ -74,11 +74,14 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--no-spec", action="store_true", help="force the general evaluator")
+    ap.add_argument("--sort-super", type=int, default=-1, help="rdf_set_option(\"sort_super\"): tiles per ticket of the sort's digit passes (default: the library's, 1 = a tile per ticket; K > 1 = os_scatter4_kernel)")
     args = ap.parse_args()
     n = args.rows
     only = set(filter(None, args.only.split(",")))
     lib.set_device(0)
     api = lib.api()
+    if args.sort_super >= 0:
+        lib.set_option("sort_super", args.sort_super)
     if args.no_spec:
         lib.set_option("spec", 0)
         lib.set_option("fast_filter", 0)
