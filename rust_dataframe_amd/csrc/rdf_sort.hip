@@ -251,7 +251,9 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
 // kernel above on 1e9 i64 keys (51.8 - 59.2 against 57.7 - 58.0 ms, box noise) and 8 - 12 % slower on 5e7 f64 keys and two-key sorts,
 // profiles/r06_sort_super_tiles_ab.jsonl: the second read of the keys and the count sweep cost what the shorter wait saves, as the
 // static-range passes had shown — a pass is bound by the WORK a CU does per tile, 15 us that two resident blocks do not overlap, and
-// the waiting sits under the other block's work already).  A block draws a SUPER-TILE of K consecutive tiles.  It first counts the digits of all K tiles (one sweep over their keys: plain LDS adds, nothing
+// the waiting sits under the other block's work already; with 16 loads of every lane in flight in the count sweep instead of one
+// the whole sort came out 25 - 40 % SLOWER still, r06_sort_super_tiles_unrolled_sweep_ab.jsonl: not the sweep's latency either).
+// A block draws a SUPER-TILE of K consecutive tiles.  It first counts the digits of all K tiles (one sweep over their keys: plain LDS adds, nothing
 // else), publishes those counts as ONE participant of the look-back, finds its offsets once — and then ranks, sorts and writes its K
 // tiles one after the other, thread d carrying digit d's running offset in a register.  What that buys (phase timers of the kernel
 // above, 1e9 pairs: 15 us of work and 12 us of waiting per 4096-pair tile, 2 blocks per CU):
