@@ -233,11 +233,28 @@ __global__ __launch_bounds__(kBlock) void os_scatter_kernel(const OsPassArgs a) 
         }
         __syncthreads();
         // ---- write-out: consecutive threads hold consecutive members of a digit run
-        for (int t = threadIdx.x; t < count; t += kBlock) {
-            const int d = ldig[t];
-            const int64_t dst = gbase[d] + (t - (int)dbase[d]);
-            __builtin_nontemporal_store(lkeys[t], as_global_mut<uint64_t>(a.keys_out) + dst);
-            __builtin_nontemporal_store(lidx[t], as_global_mut<uint32_t>(a.idx_out) + dst);
+        if (count == TILE) {
+            // a full tile: all ITEMS rounds at once — the digit reads, then the two base reads that depend on them, then the pair
+            // reads and the stores (one round at a time each store waited for a chain of three LDS round trips)
+            int dd[ITEMS];
+            int64_t dst[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) dd[j] = ldig[threadIdx.x + j * kBlock];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) dst[j] = gbase[dd[j]] + ((int)(threadIdx.x + j * kBlock) - (int)dbase[dd[j]]);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int t = threadIdx.x + j * kBlock;
+                __builtin_nontemporal_store(lkeys[t], as_global_mut<uint64_t>(a.keys_out) + dst[j]);
+                __builtin_nontemporal_store(lidx[t], as_global_mut<uint32_t>(a.idx_out) + dst[j]);
+            }
+        } else {
+            for (int t = threadIdx.x; t < count; t += kBlock) {
+                const int d = ldig[t];
+                const int64_t dst = gbase[d] + (t - (int)dbase[d]);
+                __builtin_nontemporal_store(lkeys[t], as_global_mut<uint64_t>(a.keys_out) + dst);
+                __builtin_nontemporal_store(lidx[t], as_global_mut<uint32_t>(a.idx_out) + dst);
+            }
         }
         __syncthreads();
         OS_TICK(c5);
