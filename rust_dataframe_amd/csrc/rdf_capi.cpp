@@ -3945,6 +3945,19 @@ rdf_status rdf_equijoin_indices_multi(const rdf_array* left_keys, int64_t left_n
         // have to write one slot after another (the placement fills the gaps in front of its keys itself)
         int64_t nd = nrv;
         if (bkmax >= bkmin && bkmax - bkmin < (uint64_t)nrv) nd = (int64_t)(bkmax - bkmin) + 1;
+        else if (nrv >= 65536) {
+            // ... and a few keys spread over a WIDE range (hashed identifiers, 37 of them over 3e6 rows): the sorted build side is
+            // read once more to COUNT its distinct keys (equal keys are neighbours; 8 B/row at the read rate, 0.1 ms per 1e8 rows,
+            // and a wait) — sized from the rows, the few lanes in front of such keys wrote millions of empty slots one by one
+            HIP_TRY(hipMemsetAsync(d_cnt + 3, 0, 8, ctx.stream));
+            HIP_TRY(launch_join_distinct(sb.keys[kcur], nrv, (unsigned long long*)(d_cnt + 3), ctx.stream));
+            unsigned long long distinct = 0;
+            HIP_TRY(hipMemcpyAsync(ctx.pinned + pin_off, d_cnt + 3, 8, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_TRY(hipStreamSynchronize(ctx.stream));
+            memcpy(&distinct, ctx.pinned + pin_off, 8);
+            HIP_TRY(hipMemsetAsync(d_cnt + 3, 0, 8, ctx.stream));          // (the placement's overflow flag lives in the same word)
+            if (distinct > 0 && (int64_t)distinct < nd) nd = (int64_t)distinct;
+        }
         while (((int64_t)1 << tbits) < 2 * nd) ++tbits;
         const int64_t cap = ((int64_t)1 << tbits) + (1 << 16);      // no wrap-around: the last home slot's cluster runs into the margin
         RDF_TRY(arena_alloc((size_t)cap * 16 + 64, &ptable));      // (not cleared: the placement writes every slot, the empty ones included)

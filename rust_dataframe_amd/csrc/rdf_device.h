@@ -765,6 +765,7 @@ hipError_t launch_join_buckets(const JoinBucketArgs& a, hipStream_t s);
 hipError_t launch_copy_small(const void* src_pinned, void* dst_dev, size_t bytes, hipStream_t s);   // src: page-locked, device-mapped host memory
 hipError_t launch_join_table(const JoinTableArgs& a, hipStream_t s);
 hipError_t launch_join_place(JoinPlaceArgs a, hipStream_t s);     // the three phases
+hipError_t launch_join_distinct(const uint64_t* sorted_keys, int64_t n, unsigned long long* out, hipStream_t s);     // distinct values of a sorted array, added to *out
 constexpr int kJoinPlaceTile = 2048;
 hipError_t launch_join_combine(const JoinCombineArgs& a, hipStream_t s);
 hipError_t launch_join_count(const JoinProbeArgs& a, hipStream_t s);

@@ -1924,6 +1924,29 @@ hipError_t launch_join_table(const JoinTableArgs& a, hipStream_t s) {
     if (a.nrv > 0) hipLaunchKernelGGL(join_table_kernel, dim3(rows_grid(a.nrv)), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
+// distinct values of a SORTED key array (equal keys are neighbours): rows whose key differs from the row in front of them
+__global__ __launch_bounds__(kBlock) void join_distinct_kernel(const uint64_t* keys, int64_t n, unsigned long long* out) {
+    __shared__ unsigned int part[kBlock / 64];
+    unsigned int mine = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t k = __builtin_nontemporal_load(as_global<uint64_t>(keys) + i);
+        const uint64_t p = i > 0 ? as_global<uint64_t>(keys)[i - 1] : ~k;
+        mine += k != p ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mine += (unsigned int)__shfl_xor((int)mine, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kBlock / 64; ++w) t += part[w];
+        if (t) atomicAdd(out, t);
+    }
+}
+hipError_t launch_join_distinct(const uint64_t* keys, int64_t n, unsigned long long* out, hipStream_t s) {     // *out zeroed by the caller
+    if (n > 0) hipLaunchKernelGGL(join_distinct_kernel, dim3(rows_grid(n)), dim3(kBlock), 0, s, keys, n, out);
+    return hipGetLastError();
+}
 hipError_t launch_join_place(JoinPlaceArgs a, hipStream_t s) {
     if (a.nrv <= 0) return hipSuccess;
     a.phase = 0;

@@ -1309,7 +1309,7 @@ def test_equijoin_bucket_index_edge_cases(gpu, ora, how):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["distinct", "duplicates", "few_keys", "crowded_slots"])
+@pytest.mark.parametrize("shape", ["distinct", "duplicates", "few_keys", "few_keys_wide_range", "crowded_slots"])
 def test_equijoin_table_placed_by_scan(gpu, shape):
     """Round 5: the table of distinct build keys is laid out without atomics — the build side sorted by key * golden ratio, slot(r) =
     r + prefix-max(home - r) over the distinct keys (three kernels: per-tile aggregates, one block scanning them, placement).  Sizes
@@ -1329,6 +1329,13 @@ def test_equijoin_table_placed_by_scan(gpu, shape):
         nb, npb = 3_000_000, 2_000
         bk = rng.integers(0, 37, nb).astype(np.int64)
         pk = rng.integers(0, 3700, npb).astype(np.int64)
+    elif shape == "few_keys_wide_range":
+        # ... and 37 keys spread over the whole 64-bit range (hashed identifiers): the range says nothing, so the sorted build side is
+        # read once more to count its distinct keys and the table is sized from that (round 6)
+        nb, npb = 3_000_000, 2_000
+        ids = rng.integers(-(1 << 62), 1 << 62, 37).astype(np.int64)
+        bk = ids[rng.integers(0, 37, nb)]
+        pk = np.concatenate([ids[rng.integers(0, 37, 20)], rng.integers(-(1 << 62), 1 << 62, npb - 20).astype(np.int64)])
     elif shape == "duplicates":
         nb, npb = 5_000_000, 500_000
         bk = rng.integers(0, 1_000_000, nb).astype(np.int64)          # ~5 build rows per key

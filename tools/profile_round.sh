@@ -25,6 +25,23 @@ if [ "$PART" = "new" ]; then
     find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*agent_info.csv" -delete
     exit 0
 fi
+if [ "$PART" = "r6f" ]; then
+    # round 6, after the block filter kernel got its short-batch and block-per-batch forms (and the sort's write-out its batched reads): the
+    # files those touch, on one box — the driver's line, the micro-benchmarks, the frame operators on 1024-row batches, DataFrame::filter by
+    # batch length (block kernel in all its forms against the wave-tile kernels), the HBM counters of filter_frame on 1024-row batches
+    python "$REPO/bench.py" > "$OUT/bench_1e9.json" 2> "$OUT/bench_1e9.err"
+    python "$REPO/tools/bench_kernels.py" --rows 1000000000 --steps 5 2> "$OUT/kernels.err" | grep kernel_ms > "$OUT/kernels_1e9_microbench.jsonl"
+    python "$REPO/tools/bench_frames.py" 2> "$OUT/frames.err" | grep kernel_ms > "$OUT/frames_1e9.jsonl"
+    rm -f "$OUT/filter_frame_long_batches.jsonl"
+    for cr in 1024 2048 4096 8192 16384 65536 1048576 16777216 1000000000; do for b in 1 0; do
+        python "$REPO/tools/bench_frames.py" --rows 1000000000 --chunk-rows $cr --steps 5 --block $b --only filter_frame_1col,filter_frame_2col,filter_frame_4col 2>> "$OUT/frames.err" | grep kernel_ms | sed "s/^{/{\"chunk_rows\": $cr, \"filter_block\": $b, /" >> "$OUT/filter_frame_long_batches.jsonl"
+    done; done
+    for e in filter_frame_1col filter_frame_4col; do
+        pmc frames_$e python "$REPO/tools/bench_frames.py" --steps 2 --only $e
+    done
+    find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*agent_info.csv" -delete
+    exit 0
+fi
 if [ "$PART" = "workloads" ]; then
     rm -f "$OUT/workloads.jsonl"
     for w in c3 c4 q1; do python "$REPO/bench.py" --workload $w --steps 10 --warmup 3 2>> "$OUT/workloads.err" | tail -1 >> "$OUT/workloads.jsonl"; done
