@@ -66,7 +66,8 @@ fi
 # 3b. HBM counters of compaction / take / small-group GROUP BY, one micro-benchmark entry per pass (the entries share kernels)
 for e in filter_1col filter_2col filter_1col_selectivity_1_16 take_random_u32 take_sequential_u32 groupby_sum_1000_groups \
          sort_to_indices_i64_full_range groupby_count_1000000_groups join_inner_1e8_x_1e7 \
-         groupby_sum_1000000_groups_zipf groupby_sum_1000000_groups_scattered_keys list_rows_of_1000_distinct; do
+         groupby_sum_1000000_groups_zipf groupby_sum_1000000_groups_scattered_keys list_rows_of_1000_distinct sort_to_indices_i64_full_range_1e9 \
+         filter_1col_1024_row_chunks filter_1col_4096_row_chunks; do
     pmc micro_$e python "$REPO/tools/bench_kernels.py" --rows 1000000000 --steps 3 --only $e
 done
 # 3c. round 3: frame-level operators on 976 563 batches of 1024 rows (wall against kernel time), ingestion, Int8 / UInt8 kernels,
@@ -125,7 +126,7 @@ fi
 #     the interpreter's two kernels (tools/lean_ab.py)
 if [ "$PART" = "all" ] || [ "$PART" = "r6" ]; then
 rm -f "$OUT/filter_frame_long_batches.jsonl"
-for cr in 8192 65536 1048576 16777216 1000000000; do for b in 1 0; do
+for cr in 1024 2048 4096 8192 16384 65536 1048576 16777216 1000000000; do for b in 1 0; do
     python "$REPO/tools/bench_frames.py" --rows 1000000000 --chunk-rows $cr --steps 5 --block $b --only filter_frame_1col,filter_frame_2col,filter_frame_4col 2>> "$OUT/frames.err" | grep kernel_ms | sed "s/^{/{\"chunk_rows\": $cr, \"filter_block\": $b, /" >> "$OUT/filter_frame_long_batches.jsonl"
 done; done
 pmc frames_long_filter_frame_1col python "$REPO/tools/bench_frames.py" --rows 1000000000 --chunk-rows 1000000000 --steps 2 --only filter_frame_1col
