@@ -255,22 +255,38 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
 #pragma unroll
                 for (int g = 0; g < G; ++g) x[g] = __builtin_nontemporal_load(p + g * 64);
             }
-        } else if (SHORT && (((uintptr_t)(const void*)src) & 15) == 0) {
-            // the ragged end of a batch (SHORT: every batch that is not a multiple of the wave's rows ends in one): whole vectors
-            // as far as they exist, the one across the end element by element
-            const GlobalPtr<V> p = (GlobalPtr<V>)src + lane;
+        } else if (SHORT && (((uintptr_t)(const void*)src) & 15) == 0 && t.clen - rw >= E) {
+            // the ragged end of a batch (a frame of 1000-row batches ends EVERY wave in one): whole vectors through a clamped vector
+            // index — lanes past the end re-read the last whole vector and are zeroed by a select —, the one vector across the end
+            // from E uniform element loads.  No per-lane branch: the loads go out back to back like the fast path's.  (Element-wise,
+            // two 8-byte loads per lane touch every line twice: 1000-row batches 3.3 ms per 1e9 rows against 2.6 this way, 2.1 for
+            // 1024-row ones.  SHORT only: in the long forms, where one wave per BATCH is ragged, the same code measured slower than the
+            // element path — 5000-row batches 3.12 against 2.66 ms, 7000 rows 2.63 against 2.22, same box, alternating.)
+            const int64_t avail = t.clen - rw;                    // rows of the batch from this wave's first row on (< WR)
+            const int nfull = (int)(avail / E), rem = (int)(avail - (int64_t)nfull * E);      // whole vectors (>= 1), rows in the one across the end
+            const GlobalPtr<V> p = (GlobalPtr<V>)src;
+            T sv[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) sv[e] = src[(int64_t)nfull * E + (e < rem ? e : 0) - (rem == 0 ? E : 0)];      // (uniform addresses inside the batch whatever rem is)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const int q0 = g * 64 * E + lane * E;
-                x[g] = zero;
-                if (rw + q0 + E <= t.clen) { if (!sparse || need[g]) x[g] = __builtin_nontemporal_load(p + g * 64); }
-                else {
+                const int vi = g * 64 + lane;
+                const int vc = vi < nfull ? vi : nfull - 1;
+                V v = zero;
+                if (!sparse || need[g]) v = __builtin_nontemporal_load(p + vc);
 #pragma unroll
-                    for (int e = 0; e < E; ++e) if (rw + q0 + e < t.clen) x[g][e] = src[q0 + e];
+                for (int e = 0; e < E; ++e) {
+                    T q = v[e];
+                    q = vi < nfull ? q : T(0);
+                    q = (vi == nfull && e < rem) ? sv[e] : q;
+                    x[g][e] = q;
                 }
             }
         } else {
-            // the ragged end of a batch, a slice that is not 16-byte aligned: element by element
+            // a slice that is not 16-byte aligned, a wave with fewer rows than one vector: element by element — sixteen independent guarded loads
+            // per lane, issued back to back.  (A form that kept whole vectors as far as they exist and went element-wise only across
+            // the end was tried for the short batches: a divergent if / else per vector, each waited for in turn — 5000-row batches
+            // 4.5 ms per 1e9 rows against 2.6 with this path.)
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll

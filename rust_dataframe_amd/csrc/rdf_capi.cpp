@@ -2714,12 +2714,21 @@ rdf_status rdf_filter_columns(const rdf_array* cols, int32_t ncols, const rdf_ar
         // chunk on 1 / 2 / 4 / 8 waves of a block, no prefix between blocks (round 6) — unless most slots would sit half empty
         int64_t max_len = 0;
         for (int64_t c = 0; c < nchunks; ++c) max_len = std::max<int64_t>(max_len, mask[c].length);
-        if (roomy && ctx.opt_filter_short && ctx.opt_filter_gen == 2) {
+        if (roomy && ctx.opt_filter_gen == 2) {
             // (every column group of a call must fit: the groups of eight columns have the shortest tiles)
+            // The same choice as rdf_filter_frame's (filter_frame_fused): slots filled to 0.9 -> the short form; chunks that average
+            // half a tile and fill their tiles to 0.5 (one column) / 0.65 -> the long forms; slots half full -> the short form.
             const int nc_min = ncols >= 2 ? 2 : 1;
-            const int sh = bfilter_short_shift(es0, nc_min, max_len);
-            if (sh >= 0 && rows_total * 2 >= nchunks * (((int64_t)bfilter_tile_rows(es0, nc_min) / 8) << sh))
-                return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, 2, max_len);
+            const int64_t tr = bfilter_tile_rows(es0, nc_min);
+            const int sh = ctx.opt_filter_short ? bfilter_short_shift(es0, nc_min, max_len) : -1;
+            const double short_fill = sh >= 0 ? (double)rows_total / ((double)nchunks * (double)((tr / 8) << sh)) : 0.0;
+            if (sh >= 0 && short_fill >= 0.9) return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, 2, max_len);
+            if ((rows_total + nchunks - 1) / nchunks * 2 >= tr) {
+                int64_t ntl = 0;
+                for (int64_t c = 0; c < nchunks; ++c) ntl += (mask[c].length + tr - 1) / tr;
+                if (ntl > 0 && (double)rows_total / ((double)ntl * (double)tr) >= (ncols == 1 ? 0.5 : 0.65)) return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, 0);
+            }
+            if (sh >= 0 && short_fill >= 0.5) return filter_columns_block(fp, cols, ncols, mask, nchunks, outs, es0, 2, max_len);
         }
         // ... and before that kernel had its short-batch mode: no chunk longer than one wave tile of 1024 rows, most of them full
         if (roomy && max_len <= kWDmaTile && rows_total >= nchunks * (int64_t)(kWDmaTile * 3 / 4) && ctx.opt_filter_gen == 2)

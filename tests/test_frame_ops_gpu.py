@@ -534,16 +534,36 @@ def test_filter_frame_block_tiles(gpu, ora, lens, off, nf, dts):
 
 
 SHORT_LAYOUTS = [([1024] * 37 + [500], 0, 0.1), ([1024, 1000, 0, 1, 1023, 1024, 512, 777, 1024, 1024, 1024, 1024], 5, 0.1), ([4096] * 5 + [3000], 0, 0.0),
-                 ([4000, 3900, 4096, 2100], 3, 0.2), ([8192, 8000, 5000], 0, 0.1), ([3000], 0, 0.1), ([1024] * 300, 0, 0.0), ([2048] * 9 + [0, 2047], 2, 0.0)]
+                 ([4000, 3900, 4096, 2100], 3, 0.2), ([8192, 8000, 5000], 0, 0.1), ([3000], 0, 0.1), ([1024] * 300, 0, 0.0), ([2048] * 9 + [0, 2047], 2, 0.0),
+                 ([1000] * 40, 0, 0.1), ([1500] * 21 + [7], 0, 0.0), ([5000] * 6, 0, 0.1), ([1001, 999, 1000, 3, 1000, 1000], 1, 0.0)]
 
 
-def short_mode_expected(lens, ncols):
-    """The host's choice (filter_frame_fused / rdf_filter_columns): batches no longer than a block tile, slots at least half full."""
-    wr = (8192 if ncols == 1 else 4096) // 8
+def block_form_expected(lens, ncols, frame=True):
+    """The host's choice (filter_frame_fused / rdf_filter_columns) -> "short" | "long" | None: slots filled to 0.9 take the short form,
+    batches that average half a tile and fill their tiles to 0.5 (one column) / 0.65 the long forms, half-full slots the short form."""
+    n, total = len(lens), sum(lens)
+    if total == 0 or (frame and total < n * 768):
+        return None
+    tr = 8192 if ncols == 1 else 4096
+    mean = -(-total // n)
+    if mean >= 8192:
+        return "long"
+    wr, fill = tr // 8, 0.0
     for sh in range(4):
         if max(lens) <= wr << sh:
-            return sum(lens) * 2 >= len(lens) * (wr << sh) and -(-sum(lens) // len(lens)) < 8192 and sum(lens) >= len(lens) * 768
-    return False
+            fill = total / (n * (wr << sh))
+            break
+    if fill >= 0.9:
+        return "short"
+    if mean * 2 >= tr:
+        ntl = sum(-(-x // tr) for x in lens)
+        if total / (ntl * tr) >= (0.5 if ncols == 1 else 0.65):
+            return "long"
+    return "short" if fill >= 0.5 else None
+
+
+def short_mode_expected(lens, ncols, frame=True):
+    return block_form_expected(lens, ncols, frame) == "short"
 
 
 @pytest.mark.parametrize("lens,off,nf", SHORT_LAYOUTS)
@@ -576,7 +596,8 @@ def test_filter_frame_short_batches_block_kernel(gpu, ora, lens, off, nf, dts):
     if len(dts) > 1:
         preds["and over two columns"] = e.op("and", preds[next(iter(preds))], e.op("lt", e.col(1), e.scalar(0.3)))
         preds["or over two columns"] = e.op("or", e.op("gt", e.col(len(dts) - 1), e.scalar(0.9)), e.op("le", e.col(1), e.scalar(-0.7)))
-    expect_short = short_mode_expected(lens, len(dts))
+    form = block_form_expected(lens, len(dts))
+    expect_short = form == "short"
     with A.PinnedFrame(gpu, dev) as frame:
         try:
             for name, root in preds.items():
@@ -586,6 +607,8 @@ def test_filter_frame_short_batches_block_kernel(gpu, ora, lens, off, nf, dts):
                     out = gpu.filter_frame(frame, e, root)
                     if short and expect_short:
                         assert lib.last_kernel() == "bfilter_kernel (short batches)", (name, lib.last_kernel())
+                    elif form == "long":
+                        assert lib.last_kernel().startswith("bfilter_kernel") and "short" not in lib.last_kernel(), (name, lib.last_kernel())
                     else:
                         assert lib.last_kernel() != "bfilter_kernel (short batches)", (name, lib.last_kernel())
                     nc, nch, rows = out.info()
@@ -727,8 +750,11 @@ def test_filter_columns_device_one_pass_reader_batches(gpu, ora, lens, off, nf, 
                         bb.fill_(0xAB)
                 torch.cuda.synchronize()
                 gpu.filter_columns(dev, dmask[0], outs)
-                if short and short_mode_expected(lens, len(dts)):
+                form = block_form_expected(lens, len(dts), frame=False)
+                if short and form == "short":
                     assert lib.last_kernel() == "bfilter_kernel (short batches)", lib.last_kernel()
+                elif form == "long":
+                    assert lib.last_kernel().startswith("bfilter_kernel") and "short" not in lib.last_kernel(), lib.last_kernel()
                 elif max(lens) <= 1024 and sum(lens) >= len(lens) * 768:
                     assert lib.last_kernel() == "fcompact_dma_kernel (one pass)", lib.last_kernel()
                 else:
