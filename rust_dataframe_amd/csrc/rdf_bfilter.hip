@@ -149,6 +149,20 @@ __device__ __forceinline__ void bf_term_fields(const BfTerm& tm, const typename 
     else bf_op_fields<T, G, float>(x, tm.op, tm.lit, kf);
 }
 
+// bit i of x -> bit 2 i (E = 2) / bit 4 i (E = 4): the keep bits of a lane's E consecutive rows are E ballots apart and E bits together
+__device__ __forceinline__ uint64_t bf_spread2(uint64_t x) {       // 32 bits in
+    x &= 0xFFFFFFFFull;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull; x = (x | (x << 8)) & 0x00FF00FF00FF00FFull; x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+__device__ __forceinline__ uint64_t bf_spread4(uint64_t x) {       // 16 bits in
+    x &= 0xFFFFull;
+    x = (x | (x << 24)) & 0x000000FF000000FFull; x = (x | (x << 12)) & 0x000F000F000F000Full; x = (x | (x << 6)) & 0x0303030303030303ull;
+    x = (x | (x << 3)) & 0x1111111111111111ull;
+    return x;
+}
+
 struct BfTile { int64_t tile, c, r0, clen, first, rw; bool valid; };      // rw: this wave's first row of the batch; valid: the batch exists (SHORT: a tile's last batches may lie past the frame's end)
 
 }  // namespace
@@ -369,14 +383,40 @@ __global__ __launch_bounds__(kBfBlock, 4) void bfilter_kernel(const BFilterArgs 
         }
         km = 0;
         int cnt = 0;
+        uint64_t roww = 0;          // (keep_out) lane r: the keep bits of the wave's rows [64 r, 64 r + 64) in ROW order
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+        for (int g = 0; g < G; ++g) {
+            uint64_t be[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const uint64_t w = __ballot((kf[g] >> e) & 1);
                 if (lane == g * E + e) km = w;
                 cnt += __popcll(w);
+                be[e] = w;
             }
+            if constexpr (!BYMASK) {
+                if (a.keep_out) {       // (block-uniform) frames of two column widths: the other width's launch reads the kept rows as a mask
+                    // rows 64 E g + 64 j + [0, 64) are lanes [64 j / E, 64 (j + 1) / E), E bits each: the ballots' pieces interleaved (scalar unit)
+#pragma unroll
+                    for (int j = 0; j < E; ++j) {
+                        uint64_t word = 0;
+#pragma unroll
+                        for (int e = 0; e < E; ++e)
+                            word |= (E == 2 ? bf_spread2(be[e] >> (32 * j)) : bf_spread4(be[e] >> (16 * j))) << e;
+                        if (lane == g * E + j) roww = word;
+                    }
+                }
+            }
+        }
+        if constexpr (!BYMASK) {
+            if (a.keep_out && lane < NWW) {
+                // into the frame's own mask: batch c's bits start at a multiple of 64 (fa.t.mask[c].values), this wave's at row rw, a
+                // multiple of 64 too; words past the batch's last row belong to the next batch
+                const int64_t rw = wave_row(t);
+                const DevChunkCol m = one ? fa.mask0 : const_col(fa.t.mask, t.c);
+                if (rw + 64 * (int64_t)lane < t.clen) ((GlobalMutPtr<uint64_t>)(void*)const_cast<void*>(m.values))[(rw >> 6) + lane] = roww;
+            }
+        }
         if (lane == 0) wcnt[par][wave] = cnt;
         __syncthreads();
         wbase = 0; bcnt = 0;
@@ -606,7 +646,7 @@ int bfilter_tile_rows(int esize, int ncols) {
 
 hipError_t launch_bfilter(const BFilterArgs& a, int esize, bool nulls, hipStream_t s) {
     if (a.w.t.ntiles <= 0) return hipSuccess;
-    const bool multi = a.w.ncols > 1, by_mask = a.nterms == 0;
+    const bool multi = a.w.ncols > 1 || a.force_multi, by_mask = a.nterms == 0;
     const int mode = a.short_mode;          // 0: long batches (block 0 scans), 1: short batches, 2: a block owns whole batches
     const dim3 grid((unsigned)(a.nworkers + (mode == 0 ? 1 : 0))), block(kBfBlock);
 #define RDF_BF_LAUNCH3(T, G, MULTI, NULLS, BYMASK) \

@@ -243,6 +243,7 @@ struct BFilterArgs {
     unsigned long long* tile_state;          // (pre-zeroed) [ntiles]: 0 -> count -> prefix
     unsigned int*       ticket;              // (pre-zeroed) 64 counters, 128 bytes apart
     int32_t             stall_test, pad;     // tests: 1 = the scanner does nothing (every wait must give up and the call must fail, not hang)
+    int32_t             keep_out, force_multi;   // keep_out 1 (predicate form): the kept rows are ALSO written, in row order, into the mask chunks w.t.mask / w.mask0 describe (bit offsets 0, 8-byte aligned: the frame's own mask) — a frame of two column widths is compacted by two launches, the second one by that mask; force_multi 1: the several-column instantiation (its tile geometry) whatever ncols
     int32_t             short_mode, short_shift;   // short_mode 1: no batch is longer than a tile — a batch takes 1 << short_shift waves of one block, w.t.ntiles counts tiles of 8 >> short_shift BATCHES (chunk_tile_start / tile_inv / tile_state unused), block 0 works like the others; 2: the long form's tiles and tables, but a block draws whole batches (ticket = batch) and adds up the rows in front of a tile itself (tile_state unused, no scanner block)
     unsigned int*       abort_flag;          // (pre-zeroed) set by a wait that saw no progress for kBfWaitSeconds: every waiter then leaves, the host reports a device error — a stuck prefix must cost a call, not the GPU
 };

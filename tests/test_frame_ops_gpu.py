@@ -400,18 +400,28 @@ def test_filter_frame_one_pass_predicates(gpu, ora, lens, off, nf):
         "or over two nullable columns": e.op("or", e.op("gt", e.col(2), e.scalar(0.9)), e.op("lt", e.col(1), e.scalar(-900, A.I64))),
         "eq keeps almost nothing": e.op("eq", e.col(4), e.scalar(7, A.I32)),
     }
+    seen_kernels = set()
     with A.PinnedFrame(gpu, dev) as frame:
         for name, root in preds.items():
             exp = ora.filter_columns(host, ora.predicate(e, root, host))
             try:
-                for fused in (2, 1, 0):               # 2: the one-pass kernel whatever the batch lengths; 1: the default choice; 0: three passes
+                # fused 2: the one-pass kernels whatever the batch lengths; 1: the default choice; 0: three passes.  mixed 1 (round 6): a frame
+                # of 8- and 4-byte columns takes the block kernel twice over the same tiles when the predicate's columns are of one width
+                # and the batches fill its slots / tiles — the second launch by the mask the first one wrote (2: wherever those forms
+                # apply; 1, the default: only where the wave-tile kernel's 1024-row tiles come out partial); 0: the wave-tile kernel
+                for fused, mixed in ((2, 2), (2, 0), (1, 2), (1, 1), (0, 2)):
                     lib.set_option("filter_fused", fused)
+                    lib.set_option("filter_mixed", mixed)
                     out = gpu.filter_frame(frame, e, root)
                     kern = lib.last_kernel()
-                    if fused != 1:
-                        assert (kern == "ffilter_dma_kernel") == bool(fused), (name, kern)
-                    elif max(lens) <= 65536:
+                    one_pass = kern == "ffilter_dma_kernel" or kern.startswith("bfilter_kernel x 2")
+                    if not mixed:
                         assert kern == "ffilter_dma_kernel", (name, kern)
+                    elif fused != 1:
+                        assert one_pass == bool(fused), (name, kern)
+                    elif max(lens) <= 65536:
+                        assert one_pass, (name, kern)
+                    seen_kernels.add(kern)
                     nc, nch, rows = out.info()
                     assert (nc, nch) == (len(dts), len(lens)) and rows == sum(x.length for x in exp[0]), (name, fused)
                     got = frame_columns(out)
@@ -427,6 +437,9 @@ def test_filter_frame_one_pass_predicates(gpu, ora, lens, off, nf):
                     out.release()
             finally:
                 lib.set_option("filter_fused", 1)
+                lib.set_option("filter_mixed", 1)
+    if sum(lens) >= len(lens) * 768:                 # (layouts the one-pass paths take at all) the two-launch form ran for some predicate
+        assert any(k.startswith("bfilter_kernel x 2") for k in seen_kernels), seen_kernels
 
 
 @pytest.mark.parametrize("lens,nf", [([3_000_000, 1024, 200_000], 0.0), ([1_500_000, 700_001], 0.1)])

@@ -136,6 +136,29 @@ def main():
             lib.set_option("filter_fused", 0)
             report(f"filter_frame_{m}col_three_pass", n, (8 + 8 * sel) * m * n, run, selectivity=sel, path="predicate -> mask, count, compact (round 3)")
             lib.set_option("filter_fused", 1)
+    # ---- the same over frames of TWO column widths (f64 predicate column + 4-byte columns beside it: a lineitem-shaped frame; round 6:
+    #      the block kernel twice over the same tiles, the second launch by the mask the first one wrote) against the wave-tile kernel
+    q = (k & 0x7FFFFFFF).to(torch.int32)
+    r32 = x.to(torch.float32)
+    lib.synchronize()
+    for name, colsm in (("mixed_f64_i32", [(x.data_ptr(), 8, A.F64), (q.data_ptr(), 4, A.I32)]),
+                        ("mixed_f64_i64_i32_f32", [(x.data_ptr(), 8, A.F64), (k.data_ptr(), 8, A.I64), (q.data_ptr(), 4, A.I32), (r32.data_ptr(), 4, A.F32)])):
+        if only and not any(f"filter_frame_{name}".startswith(o) for o in only):
+            continue
+        tab, nch = descriptors(colsm, n, cr)
+        row_bytes = sum(es for _, es, _ in colsm)
+        with RawFrame(api, tab, len(colsm), nch, (x, k, q, r32)) as fr:
+            def run():
+                out = api.filter_frame(fr, e, gt)
+                out.release()
+            lib.set_option("filter_fused", args.fused)
+            for mixed in (2, 0):
+                lib.set_option("filter_mixed", mixed)
+                report(f"filter_frame_{name}" + ("" if mixed else "_wave_tiles"), n, (1 + sel) * row_bytes * n + (0.25 * n if mixed else 0), run, selectivity=sel,
+                       path="block kernel x 2 (predicate's width, then the other width by the mask)" if mixed else "wave-tile kernel (any widths)")
+            lib.set_option("filter_mixed", 1)
+            lib.set_option("filter_fused", 1)
+    del q, r32
     # ---- DataFrame::take: random / sequential indices, every column in one gather pass
     nidx = n // 4
     ridx = torch.randint(0, n, (nidx,), dtype=torch.int64, device="cuda").to(torch.uint32)

@@ -31,11 +31,16 @@ def main():
     rows_done = 0
     skipped = 0
     forms = {}
+    two_widths = 0
     for it in range(args.iters):
         wide = rng.uniform() < 0.7
         pool = [A.F64, A.I64, A.U64] if wide else [A.F32, A.I32, A.U32]
-        ncols = int(rng.integers(1, 5))
-        dts = [pool[int(rng.integers(0, 3))] for _ in range(ncols)]
+        both = rng.uniform() < 0.3                      # a frame of 8- AND 4-byte columns: the block kernel twice, the second launch by the first one's mask
+        if both:
+            pool = [A.F64, A.I64, A.U64, A.F32, A.I32, A.U32]
+        ncols = int(rng.integers(2 if both else 1, 5))
+        dts = [pool[int(rng.integers(0, len(pool)))] for _ in range(ncols)]
+        widths = {np.dtype(A.NP_OF[d]).itemsize for d in dts}
         nch = int(rng.integers(1, 12))
         shape = rng.integers(0, 7)
         # form of the block kernel under test: 0 = tiles by ticket + scanner wave, 2 = a block per batch (its own running offset),
@@ -80,11 +85,15 @@ def main():
                 lib.set_option("filter_block", block)
                 lib.set_option("filter_block_rows", 8192 if form == 1 else 1)
                 lib.set_option("filter_owned", form)
+                lib.set_option("filter_mixed", 2)
                 lib.set_option("filter_fused", 2)
                 out = gpu.filter_frame(frame, e, root)
                 res[block] = (out.info(), frame_columns(out), lib.last_kernel())
                 out.release()
             want = {0: "bfilter_kernel", 1: "bfilter_kernel (short batches)", 2: "bfilter_kernel (a block per batch)"}[form]
+            if len(widths) == 2:
+                want = res[1][2] if res[1][2].startswith("bfilter_kernel x 2") else "bfilter_kernel x 2"
+                two_widths += res[1][2] == want
             forms[form] = forms.get(form, 0) + (res[1][2] == want)
             if res[1][2] != want:        # (a frame of mostly tiny batches: both runs took the three passes — nothing to compare; short form: slots mostly empty)
                 skipped += 1
@@ -101,8 +110,8 @@ def main():
         rows_done += sum(lens)
         if (it + 1) % 50 == 0:
             print(f"{it + 1} frames, {rows_done} rows: identical", flush=True)
-    lib.set_option("filter_block", 1); lib.set_option("filter_block_rows", 8192); lib.set_option("filter_fused", 1); lib.set_option("filter_owned", 1)
-    print(f"forms compared (0 scanner wave, 1 short batches, 2 a block per batch): {forms}")
+    lib.set_option("filter_block", 1); lib.set_option("filter_block_rows", 8192); lib.set_option("filter_fused", 1); lib.set_option("filter_owned", 1); lib.set_option("filter_mixed", 1)
+    print(f"forms compared (0 scanner wave, 1 short batches, 2 a block per batch): {forms}; frames of two column widths among them: {two_widths}")
     print(f"stress_bfilter: {args.iters - skipped} random frames ({rows_done} rows; {skipped} more were not of the one-pass shape), block-tile kernel == wave-tile kernel on every column of every batch")
 
 
