@@ -158,7 +158,24 @@ def main():
                        path="block kernel x 2 (predicate's width, then the other width by the mask)" if mixed else "wave-tile kernel (any widths)")
             lib.set_option("filter_mixed", 1)
             lib.set_option("filter_fused", 1)
-    del q, r32
+    # ---- frames of 4-byte columns only (f32 predicate column)
+    q2 = (q >> 3).contiguous()
+    r2 = (r32 * 0.5).contiguous()
+    gt32 = e.op("gt", e.col(0), e.scalar(0.0))
+    for m in (1, 2, 4):
+        name = f"filter_frame_narrow_{m}col"
+        if only and not any(name.startswith(o) for o in only):
+            continue
+        colsn = [(r32.data_ptr(), 4, A.F32), (q.data_ptr(), 4, A.I32), (r2.data_ptr(), 4, A.F32), (q2.data_ptr(), 4, A.I32)][:m]
+        tab, nch = descriptors(colsn, n, cr)
+        with RawFrame(api, tab, m, nch, (r32, q, r2, q2)) as fr:
+            def run():
+                out = api.filter_frame(fr, e, gt32)
+                out.release()
+            lib.set_option("filter_fused", args.fused)
+            report(name, n, (4 + 4 * sel) * m * n, run, selectivity=sel, path="one pass, 4-byte columns")
+            lib.set_option("filter_fused", 1)
+    del q, r32, q2, r2
     # ---- DataFrame::take: random / sequential indices, every column in one gather pass
     nidx = n // 4
     ridx = torch.randint(0, n, (nidx,), dtype=torch.int64, device="cuda").to(torch.uint32)
