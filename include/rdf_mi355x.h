@@ -650,8 +650,11 @@ rdf_status rdf_fill_validity(uint8_t* dev_ptr, int64_t nbits, uint64_t seed, uin
  * published one iteration before its offset is asked for, offsets from one scanner wave, default; 0 = the wave-tile kernels),
  * "filter_block_rows" (the mean batch length from which that kernel is taken, default 8192),
  * "filter_mixed" (rdf_filter_frame's one-pass form over frames of 8- AND 4-byte columns: the block kernel twice — the columns of the predicate's
- * width first, which also writes the kept rows into the frame's own mask, then the other width's columns by that mask: 1 = where the
- * wave-tile kernel's 1024-row tiles come out partial (batches of 1000 rows), default; 2 = wherever the block kernel's forms apply; 0 = never),
+ * width first, which also writes the kept rows into the frame's own mask, then the other width's columns by that mask; measured behind the
+ * wave-tile kernel, which takes any widths: 0 = never, default; 1 = where that kernel's 1024-row tiles come out partial; 2 = wherever the
+ * block kernel's forms apply),
+ * "filter_ends" (the wave-tile one-pass kernel on frames whose batch lengths are not multiples of its 1024-row tile: 1 = the tiles at the end
+ * of a batch take the LDS-DMA path too, default; 0 = they load row by row),
  * "filter_short" (the same operators on frames whose batches are no longer than one block tile — the readers' 1024-row RecordBatches,
  * chunks of a few thousand rows: 1 = the block kernel with a batch on 1 / 2 / 4 / 8 waves of one block and no prefix between blocks,
  * default; 0 = the wave-tile kernels; "filter_block" 0 switches both forms off),

@@ -61,7 +61,8 @@ struct Ctx {
     int    opt_filter_block = 1;    // one-pass compaction of LONG batches on block tiles held in registers, prefixes from a scanner wave (rdf_bfilter.hip, round 6; default); 0 = the wave-tile kernels only (A/B)
     int    opt_interp_lean = 1;             // interpreted aggregate programs whose every step has a lean handler run on eval_lean_kernel (rdf_eval_lean.hip); 0: always eval_kernel (the A/B)
     int    opt_filter_owned = 1;    // long batches, many of them, none a large share of the frame: a block draws whole batches and adds up its own offsets (round 6; default); 0 = tiles by ticket, offsets from the scanner wave (A/B)
-    int    opt_filter_mixed = 1;    // rdf_filter_frame over frames of 8- AND 4-byte columns: the block kernel twice (the predicate's width first, writing the kept rows into the frame's mask; the other width by that mask; round 6) — 1 = for short batches whose rows mostly lie in partial 1024-row tiles, where the wave-tile kernel is 1.2 - 1.65 x behind (default); 2 = wherever the block kernel's forms apply (tests, A/B: 5 - 20 % behind the wave-tile kernel on multiples of 1024 rows); 0 = never
+    int    opt_filter_ends = 1;     // the wave-tile one-pass kernel: tiles at the END of a batch take the LDS-DMA path too (clamped addresses; frames whose batch lengths are not multiples of 1024 rows; round 6, default); 0 = they load row by row (A/B)
+    int    opt_filter_mixed = 0;    // rdf_filter_frame over frames of 8- AND 4-byte columns: the block kernel twice (the predicate's width first, writing the kept rows into the frame's mask; the other width by that mask; round 6: built, parity-tested, measured 2 - 20 % BEHIND the wave-tile kernel on multiples of 1024 rows and — once that kernel's end-of-batch tiles took the DMA path, filter_ends — behind it on ragged lengths too: not the default) — 0 = never (default); 1 = for short batches whose rows mostly lie in partial 1024-row tiles; 2 = wherever the block kernel's forms apply (tests, A/B)
     int    opt_filter_short = 1;    // batches / chunks no longer than a block tile on the block kernel's short-batch mode (round 6; default); 0 = the wave-tile kernels (A/B)
     int    opt_filter_block_rows = 8192;    // ... for frames whose mean batch length is at least this many rows (one block tile of a single 8-byte column; measured ahead of the wave-tile kernel from 8192-row batches up: profiles/r06_filter_frame_batch_length_sweep.jsonl)
     int    opt_filter_fused = 1;    // rdf_filter_frame: `col CMP literal [AND|OR col CMP literal]` predicates evaluated inside the compaction kernel, one pass (1, default); 0 = predicate -> mask, count, compact (A/B)
@@ -4546,6 +4547,7 @@ rdf_status rdf_set_option(const char* name, int64_t value) {
         else { g_ctx.opt_sort_super_force = 0; g_ctx.opt_sort_super = value < 1 ? 1 : value > 64 ? 64 : (int)value; }
     }
     else if (strcmp(name, "filter_owned") == 0) g_ctx.opt_filter_owned = value == 2 ? 2 : value != 0;      // (2: tests — whatever the number and lengths of the batches)
+    else if (strcmp(name, "filter_ends") == 0) g_ctx.opt_filter_ends = value != 0;
     else if (strcmp(name, "filter_mixed") == 0) g_ctx.opt_filter_mixed = value == 2 ? 2 : value != 0;
     else if (strcmp(name, "filter_short") == 0) g_ctx.opt_filter_short = value != 0;
     else if (strcmp(name, "filter_block_rows") == 0) g_ctx.opt_filter_block_rows = value < 1 ? 1 : (int)value;

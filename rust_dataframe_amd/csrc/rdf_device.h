@@ -218,7 +218,7 @@ struct FusedFilterArgs {
     FilterWArgs         w;            // tile tables, column / output descriptors, null counters (mask / tile_scan unused)
     FusedTerm           term[2];
     int32_t             nterms, combine;     // combine: RDF_OP_AND / RDF_OP_OR of the two terms
-    int32_t             lookback, pad;       // some batch spans several tiles: tiles are taken by ticket, prefixes by look-back
+    int32_t             lookback, ends;      // lookback: some batch spans several tiles: tiles are taken by ticket, prefixes by look-back; ends: 1 = the instantiation whose tiles at the END of a batch take the LDS-DMA path too (batch lengths that are not multiples of the tile)
     int64_t*            out_len;             // [nchunks] kept rows per batch (pre-zeroed)
     unsigned long long* tile_state;          // (lookback; pre-zeroed) [ntiles] tile states, status << 62 | rows; 8 spare words; [ntiles] super-tile states
     unsigned int*       ticket;              // (lookback; pre-zeroed) 64 counters, 128 bytes apart
