@@ -2426,6 +2426,11 @@ rdf_status filter_tiles(FilterPrep& fp, int tile_rows, int64_t nchunks, std::vec
         memset(&fp.wa, 0, sizeof fp.wa);
         fp.wa.t = fp.mt;
         fp.wa.prefetch = ctx.opt_filter_gen != 3;   // (3: A/B without the look-ahead)
+        {   // chunk lengths that are not multiples of the DMA tile: the instantiation whose end-of-chunk tiles take the DMA path too
+            int64_t rows = 0;
+            for (int64_t c = 0; c < nchunks; ++c) rows += fp.clen[(size_t)c];
+            fp.wa.ends = ctx.opt_filter_ends && fp.tile_rows == kWDmaTile && (double)rows < 0.99 * (double)fp.ntiles * (double)kWDmaTile ? 1 : 0;
+        }
         if (nchunks == 1) { fp.wa.mask0 = fp.in.dev[0]; fp.wa.len0 = fp.clen[0]; }
         if (nchunks > 1 && fp.tile_start[(size_t)nchunks - 1] > 0 && nchunks - 1 < ((int64_t)1 << 31))
             fp.wa.tile_inv = (uint64_t)(((unsigned __int128)(uint64_t)(nchunks - 1) << 32) / (unsigned __int128)(uint64_t)fp.tile_start[(size_t)nchunks - 1]);

@@ -202,6 +202,7 @@ struct FilterWArgs {
     const int64_t*     tile_scan;        // [ntiles + 1] exclusive scan of the per-tile keep counts
     uint64_t           tile_inv;         // see find_chunk_tile_inv
     int32_t            ncols, prefetch;  // prefetch: look the next tile up under the current tile's loads (chunked frames)
+    int32_t            ends, pad_;       // ends (fcompact_dma_kernel): 1 = tiles at the END of a chunk take the LDS-DMA path too (chunk lengths that are not multiples of the tile)
     int32_t            esize[kMaxFilterCols];
     DevChunkCol        cols0[kMaxFilterCols];   // nchunks == 1
     DevOutChunk        outs0[kMaxFilterCols];

@@ -399,6 +399,8 @@ __device__ __forceinline__ void slow_compact(const DevChunkCol col, const DevOut
     __builtin_amdgcn_wave_barrier();
 }
 
+// (ENDS: as in ffilter_dma_kernel below — tiles at the end of their chunk through the DMA path too; FilterWArgs::ends)
+template <bool ENDS>
 __global__ __launch_bounds__(kBlock, 4) void fcompact_dma_kernel(const FilterWArgs a) {
     constexpr int WW = kWDmaTile / 64, kWaves = kBlock / 64;
     __shared__ __attribute__((aligned(16))) unsigned char stage[kWaves][WW * 64 * 8 + 32];
@@ -442,11 +444,17 @@ __global__ __launch_bounds__(kBlock, 4) void fcompact_dma_kernel(const FilterWAr
         // column 0's tile is requested before the mask words are waited for
         DevChunkCol col = meta.c0;
         int es = a.esize[0];
+        const int64_t avail = t.clen - t.r0;
         auto dma_ok = [&](const DevChunkCol& c, int e) {
-            return full && (e == 8 || e == 4) && (((uintptr_t)((const char*)c.values + (c.offset + t.r0) * e)) & 15) == 0;
+            return (full || (ENDS && avail * e >= 16)) && (e == 8 || e == 4) && (((uintptr_t)((const char*)c.values + (c.offset + t.r0) * e)) & 15) == 0;
+        };
+        auto dma_in = [&](const DevChunkCol& c, int e) __attribute__((always_inline)) {
+            if (!ENDS || full) { if (e == 8) dma_tile<uint64_t>(c, t.r0, stage[wave]); else dma_tile<uint32_t>(c, t.r0, stage[wave]); }
+            else if (e == 8) dma_tile_end<uint64_t>(c, t.r0, stage[wave], (int)(avail / 2));
+            else dma_tile_end<uint32_t>(c, t.r0, stage[wave], (int)(avail / 4));
         };
         bool dma = dma_ok(col, es);
-        if (dma) { if (es == 8) dma_tile<uint64_t>(col, t.r0, stage[wave]); else dma_tile<uint32_t>(col, t.r0, stage[wave]); }
+        if (dma) dma_in(col, es);
         const LaneWin<WW> q0 = lane_windows_issue<WW>((const uint8_t*)m.values, m.offset + t.r0, t.clen - t.r0);
         LaneWin<WW> q1 = q0;
         if (m.validity) q1 = lane_windows_issue<WW>(m.validity, m.offset + t.r0, t.clen - t.r0);
@@ -466,14 +474,14 @@ __global__ __launch_bounds__(kBlock, 4) void fcompact_dma_kernel(const FilterWAr
                 col = one ? a.cols0[k] : a.cols[(int64_t)k * a.t.nchunks + t.c];
                 es = a.esize[k];
                 dma = dma_ok(col, es);
-                if (dma) { if (es == 8) dma_tile<uint64_t>(col, t.r0, stage[wave]); else dma_tile<uint32_t>(col, t.r0, stage[wave]); }
+                if (dma) dma_in(col, es);
             }
             const DevOutChunk oc = one ? a.outs0[k] : a.outs[(int64_t)k * a.t.nchunks + t.c];
             const bool vec_out = (((uintptr_t)oc.values) & 15) == 0;
             uint32_t nn = 0;
             if (dma && vec_out) {
-                if (es == 8) dma_compact<uint64_t>(col, oc, t.r0, t.clen, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
-                else dma_compact<uint32_t>(col, oc, t.r0, t.clen, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
+                if (es == 8) dma_compact<uint64_t, ENDS>(col, oc, t.r0, t.clen, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
+                else dma_compact<uint32_t, ENDS>(col, oc, t.r0, t.clen, wave_out, kwv, cnt, stage[wave], vstage[wave], nn);
             } else {
                 if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 // chunk tails and slices that are not 16-byte aligned: one mask word at a time
@@ -810,7 +818,8 @@ hipError_t launch_ffilter(const FusedFilterArgs& a, hipStream_t s) {
 hipError_t launch_fcompact(const FilterWArgs& a, int tile_rows, hipStream_t s) {
     if (a.t.ntiles <= 0) return hipSuccess;
     if (tile_rows == kWDmaTile) {
-        hipLaunchKernelGGL(fcompact_dma_kernel, dim3(wgrid(a.t.ntiles, 4)), dim3(kBlock), 0, s, a);
+        if (a.ends) hipLaunchKernelGGL(fcompact_dma_kernel<true>, dim3(wgrid(a.t.ntiles, 4)), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL(fcompact_dma_kernel<false>, dim3(wgrid(a.t.ntiles, 4)), dim3(kBlock), 0, s, a);
         return hipGetLastError();
     }
     int es = a.esize[0];
